@@ -1,0 +1,285 @@
+"""oracle -- CPU checker for the d3d voxel / box hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package; nothing under d3d_amd/ does.  It wraps oracle/liboracle.so (plain C restatement
+of the reference algorithms, built by oracle/Makefile) with numpy in/out and mirrors the
+reference's Python operator layer:
+
+* reference d3d/voxel/__init__.py:12-104  -> VoxelGenerator
+* reference d3d/box/__init__.py:180-276   -> box2d_iou, box2d_nms
+* reference d3d/dgal_wrap.h:45-91 + d3d/tracking/matcher.pyx:57-80 -> iou3d
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+REDUCTION = {"NONE": 0, "MEAN": 1, "MAX": 2, "MIN": 3}            # voxelize.h:5
+MAX_POINTS_FILTER = {"NONE": 0, "TRIM": 1, "FARTHEST_SAMPLING": 2}  # voxelize.h:6
+MAX_VOXELS_FILTER = {"NONE": 0, "TRIM": 1, "DESCENDING": 2}        # voxelize.h:7
+IOU_TYPE = {"NA": 0, "BOX": 1, "RBOX": 2, "GBOX": 3, "GRBOX": 4, "DBOX": 5, "DRBOX": 6}  # box/common.h:5-9
+SUPRESSION = {"HARD": 0, "LINEAR": 1, "GAUSSIAN": 2}               # box/common.h:10
+
+
+def build():
+    """Compile oracle/liboracle.so with gcc (idempotent)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return os.path.join(_HERE, "liboracle.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        L.oracle_voxelize_3d_dense.restype = ctypes.c_int64
+        L.oracle_voxelize_3d_sparse.restype = ctypes.c_int64
+        L.oracle_voxelize_3d_filter.restype = ctypes.c_int32
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class Dict(dict):
+    """attribute-access dict (stands in for addict.Dict, voxel/__init__.py:1)"""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+# --------------------------------------------------------------------------- voxel
+def voxelize_3d_dense(points, shape, bound, max_points, max_voxels, reduction):
+    """voxelize.cpp:182-199.  reduction: int or name.  Returns Dict of numpy arrays."""
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    n, c = points.shape
+    shape = np.ascontiguousarray(shape, dtype=np.int32)
+    bound = np.ascontiguousarray(bound, dtype=np.float32)
+    red = REDUCTION[reduction.upper()] if isinstance(reduction, str) else int(reduction)
+    cap = int(max_voxels)
+    voxels = np.empty((cap, max_points, c), np.float32)
+    coords = np.empty((cap, 3), np.int64)
+    pmask = np.empty((cap, max_points), np.uint8)
+    npoints = np.empty((cap,), np.int32)
+    agg = np.empty((cap, c), np.float32) if red != 0 else None
+    nv = lib().oracle_voxelize_3d_dense(
+        _p(points), ctypes.c_int64(n), ctypes.c_int32(c), _p(shape), _p(bound),
+        ctypes.c_int32(max_points), ctypes.c_int32(max_voxels), ctypes.c_int32(red),
+        _p(voxels), _p(coords), _p(pmask), _p(npoints), _p(agg))
+    if nv < 0:
+        raise MemoryError("oracle_voxelize_3d_dense")
+    ret = Dict(voxels=voxels[:nv], coords=coords[:nv], voxel_pmask=pmask[:nv].astype(bool),
+               voxel_npoints=npoints[:nv])
+    if red != 0:
+        ret["aggregates"] = agg[:nv]
+    return ret
+
+
+def voxelize_3d_sparse(points, voxel_size, ndim=3):
+    """voxelize.cpp:288-335"""
+    assert ndim in (None, 3)
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    n, c = points.shape
+    voxel_size = np.ascontiguousarray(voxel_size, dtype=np.float32)
+    mapping = np.empty((n,), np.int64)
+    coords = np.empty((max(n, 1), 3), np.int64)
+    npoints = np.empty((max(n, 1),), np.int32)
+    nv = lib().oracle_voxelize_3d_sparse(_p(points), ctypes.c_int64(n), ctypes.c_int32(c), _p(voxel_size),
+                                         _p(mapping), _p(coords), _p(npoints))
+    if nv < 0:
+        raise MemoryError("oracle_voxelize_3d_sparse")
+    return Dict(points_mapping=mapping, coords=coords[:nv].copy(), voxel_npoints=npoints[:nv].copy())
+
+
+def voxelize_3d_filter(feats, points_mapping, coords, voxel_npoints, coords_bound,
+                       min_points, max_points, max_voxels, max_points_filter, max_voxels_filter):
+    """voxelize.cpp:337-484"""
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    n, c = feats.shape
+    points_mapping = np.ascontiguousarray(points_mapping, dtype=np.int64)
+    coords = np.ascontiguousarray(coords, dtype=np.int64)
+    voxel_npoints = np.ascontiguousarray(voxel_npoints, dtype=np.int32)
+    coords_bound = np.ascontiguousarray(coords_bound, dtype=np.int64).reshape(3, 2)
+    nvox = coords.shape[0]
+    pf = MAX_POINTS_FILTER[max_points_filter.upper()] if isinstance(max_points_filter, str) else int(max_points_filter or 0)
+    vf = MAX_VOXELS_FILTER[max_voxels_filter.upper()] if isinstance(max_voxels_filter, str) else int(max_voxels_filter or 0)
+    o_feats = np.empty((max(n, 1), c), np.float32)
+    o_mask = np.empty((max(n, 1),), np.int64)
+    o_map = np.empty((max(n, 1),), np.int64)
+    o_np = np.empty((max(nvox, 1),), np.int32)
+    o_coords = np.empty((max(nvox, 1), 3), np.int64)
+    counts = np.zeros((2,), np.int64)
+    rc = lib().oracle_voxelize_3d_filter(
+        _p(feats), ctypes.c_int64(n), ctypes.c_int32(c), _p(points_mapping), _p(coords), _p(voxel_npoints),
+        ctypes.c_int64(nvox), _p(coords_bound), ctypes.c_int32(min_points or 0), ctypes.c_int32(max_points),
+        ctypes.c_int32(max_voxels), ctypes.c_int32(pf), ctypes.c_int32(vf),
+        _p(o_feats), _p(o_mask), _p(o_map), _p(o_np), _p(o_coords), _p(counts))
+    if rc == -2:
+        raise ValueError("Farthest Sampling not implemented!")  # voxelize.cpp:470
+    if rc != 0:
+        raise RuntimeError("oracle_voxelize_3d_filter rc=%d" % rc)
+    k, v = int(counts[0]), int(counts[1])
+    return Dict(points=o_feats[:k].copy(), points_mask=o_mask[:k].copy(), points_mapping=o_map[:k].copy(),
+                voxel_npoints=o_np[:v].copy(), coords=o_coords[:v].copy())
+
+
+class VoxelGenerator:
+    """numpy restatement of reference d3d/voxel/__init__.py:12-104 (float32 arithmetic)."""
+
+    def __init__(self, bounds, shape, min_points=0, max_points=30, max_voxels=20000,
+                 max_points_filter=None, max_voxels_filter=None, reduction=None, dense=False):
+        self._bounds = np.asarray(bounds, dtype=np.float32)
+        self._shape = np.asarray(shape, dtype=np.int32)
+        self._min_points, self._max_points, self._max_voxels, self._dense = min_points, max_points, max_voxels, dense
+        b = self._bounds.reshape(3, 2)
+        self._size = ((b[:, 1] - b[:, 0]) / self._shape.astype(np.float32)).astype(np.float32)   # :41
+        dist = (b[:, 0] / self._size).astype(np.float32)                                           # :42
+        if np.any(np.abs(np.round(dist) - dist) > 1e-3):                                           # :43-44
+            raise ValueError("The voxelization grids is not aligned with the origin, which could lead to unexpected behavior!")
+        self._offset = np.round(dist).astype(np.int32)                                             # :45
+        self._vbounds = np.round(b / self._size.reshape(3, 1)).astype(np.int64)                    # :46
+        reduction = (reduction or "NONE").upper()
+        if reduction != "NONE" and not dense:
+            raise ValueError("Reduction is only for dense voxelization!")
+        if reduction not in REDUCTION:
+            raise ValueError("Unsupported reduction type in VoxelGenerator!")
+        self._reduction = REDUCTION[reduction]
+        pf = (max_points_filter or "NONE").upper()
+        if pf not in MAX_POINTS_FILTER:
+            raise ValueError("Unsupported maximum points filter in VoxelGenerator!")
+        self._pf = MAX_POINTS_FILTER[pf]
+        vf = (max_voxels_filter or "NONE").upper()
+        if vf not in MAX_VOXELS_FILTER:
+            raise ValueError("Unsupported maximum voxels filter in VoxelGenerator!")
+        self._vf = MAX_VOXELS_FILTER[vf]
+        if dense:
+            if min_points > 0:
+                raise NotImplementedError("Minimum points filtering is not implemented for dense")
+            if self._pf not in (0, 1):
+                raise NotImplementedError("Only trim is implemented for max points filtering")
+            if self._vf not in (0, 1):
+                raise NotImplementedError("Only trim is implemented for max voxels filtering")
+
+    def __call__(self, points):
+        if self._dense:
+            return voxelize_3d_dense(points, self._shape, self._bounds, self._max_points, self._max_voxels, self._reduction)
+        sp = voxelize_3d_sparse(points, self._size, 3)
+        ret = voxelize_3d_filter(points, sp.points_mapping, sp.coords, sp.voxel_npoints, self._vbounds,
+                                 self._min_points, self._max_points, self._max_voxels, self._pf, self._vf)
+        ret.coords = ret.coords - self._offset.astype(np.int64)   # :103
+        return ret
+
+
+# ----------------------------------------------------------------------------- box
+def _split_rows(n, nthreads):
+    nthreads = max(1, min(int(nthreads), int(n) if n > 0 else 1))
+    edges = np.linspace(0, n, nthreads + 1).astype(np.int64)
+    return [(int(edges[k]), int(edges[k + 1])) for k in range(nthreads)]
+
+
+def _run_rows(fn, n, nthreads):
+    parts = _split_rows(n, nthreads)
+    if len(parts) == 1:
+        fn(*parts[0])
+        return
+    import threading
+    ts = [threading.Thread(target=fn, args=p) for p in parts]   # ctypes releases the GIL
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+
+
+def iou2d_forward(b1, b2, method, nthreads=1):
+    """iou2d_forward / iou2dr_forward (iou.cpp:12-46, 95-141) in the dtype of b1 (f32 or f64)."""
+    m = IOU_TYPE[method.upper()] if isinstance(method, str) else int(method)
+    if m not in (1, 2):
+        raise ValueError("Unrecognized iou type!")
+    dt = np.float64 if b1.dtype == np.float64 else np.float32
+    b1 = np.ascontiguousarray(b1, dtype=dt)
+    b2 = np.ascontiguousarray(b2, dtype=dt)
+    n, k = b1.shape[0], b2.shape[0]
+    out = np.empty((n, k), dt)
+    f = lib().oracle_iou2d_f64 if dt == np.float64 else lib().oracle_iou2d_f32
+    f.restype = None
+
+    def run(r0, r1):
+        f(_p(b1), ctypes.c_int64(n), _p(b2), ctypes.c_int64(k), ctypes.c_int(m),
+          ctypes.c_int64(r0), ctypes.c_int64(r1), _p(out))
+    _run_rows(run, n, nthreads)
+    return out
+
+
+def box2d_iou(boxes1, boxes2, method="box", precise=True, nthreads=1):
+    """box/__init__.py:180-224 (numpy in, numpy out)"""
+    boxes1 = np.asarray(boxes1)
+    boxes2 = np.asarray(boxes2)
+    otype = boxes1.dtype
+    if precise:
+        boxes1 = boxes1.astype(np.float64)
+        boxes2 = boxes2.astype(np.float64)
+    if boxes1.ndim != 2 or boxes2.ndim != 2:
+        raise ValueError("Input of rbox_2d_iou should be Nx2 tensors!")
+    if boxes1.shape[1] != 5 or boxes2.shape[1] != 5:
+        raise ValueError("Input boxes should have 5 fields: x, y, w, h, r")
+    res = iou2d_forward(boxes1, boxes2, method, nthreads)
+    return res.astype(otype) if precise else res
+
+
+def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param):
+    """nms2d (nms.cpp:98-119): returns the SUPPRESSED mask."""
+    it = IOU_TYPE[iou_type.upper()] if isinstance(iou_type, str) else int(iou_type)
+    st = SUPRESSION[supression_type.upper()] if isinstance(supression_type, str) else int(supression_type)
+    if it not in (1, 2):
+        raise ValueError("Unsupported iou type!")          # common.h:25
+    dt = np.float64 if boxes.dtype == np.float64 else np.float32
+    boxes = np.ascontiguousarray(boxes, dtype=dt)
+    scores = np.ascontiguousarray(scores, dtype=dt)
+    n = boxes.shape[0]
+    order = np.argsort(-scores, kind="stable").astype(np.int64)   # nms.cpp:103 (stable tie-break = spec)
+    sup = np.zeros((n,), np.uint8)
+    f = lib().oracle_nms2d_f64 if dt == np.float64 else lib().oracle_nms2d_f32
+    f.restype = None
+    f(_p(boxes), _p(scores), ctypes.c_int64(n), _p(order), ctypes.c_int(it), ctypes.c_int(st),
+      ctypes.c_float(iou_threshold), ctypes.c_float(score_threshold), ctypes.c_float(supression_param), _p(sup))
+    return sup.astype(bool)
+
+
+def box2d_nms(boxes, scores, iou_method="box", supression_method="hard",
+              iou_threshold=0, score_threshold=0, supression_param=0, precise=True):
+    """box/__init__.py:226-276: returns the KEEP mask."""
+    boxes = np.asarray(boxes)
+    scores = np.asarray(scores)
+    if precise:
+        boxes = boxes.astype(np.float64)
+        scores = scores.astype(np.float64)
+    if len(boxes) != len(scores):
+        raise ValueError("Numbers of boxes and scores are inconsistent!")
+    if scores.ndim == 2:
+        scores = scores.max(axis=1)
+    if boxes.size == 0:
+        return np.zeros((0,), bool)
+    return ~nms2d(boxes, scores, iou_method, supression_method, iou_threshold, score_threshold, supression_param)
+
+
+def iou3d(boxes1, boxes2, method="rbox", nthreads=1):
+    """batched box3dr_iou ("rbox") / box3d_iou ("box") on [n,7] = (x,y,z,lx,ly,lz,rz), fp32
+    (dgal_wrap.h:45-91; pair loop matcher.pyx:57-80)."""
+    rot = {"RBOX": 1, "BOX": 0}[method.upper()]
+    b1 = np.ascontiguousarray(boxes1, dtype=np.float32)
+    b2 = np.ascontiguousarray(boxes2, dtype=np.float32)
+    n, m = b1.shape[0], b2.shape[0]
+    out = np.empty((n, m), np.float32)
+    f = lib().oracle_iou3d
+    f.restype = None
+
+    def run(r0, r1):
+        f(_p(b1), ctypes.c_int64(n), _p(b2), ctypes.c_int64(m), ctypes.c_int(rot),
+          ctypes.c_int64(r0), ctypes.c_int64(r1), _p(out))
+    _run_rows(run, n, nthreads)
+    return out

@@ -1,0 +1,192 @@
+/*
+ * oracle/box_oracle_impl.h -- TEST INFRASTRUCTURE (included twice by box_oracle.c
+ * with T = float and T = double; FN(name) appends _f32 / _f64).
+ *
+ * The geometry the reference gets from the un-vendored third-party header
+ * dgal/geometry.hpp (cmpute/dgal, submodule unpinned; reference .gitmodules:4-6)
+ * is restated here from its published behaviour: rectangle corners from
+ * (x,y,w,h,r), convex-polygon clipping (Sutherland-Hodgman), shoelace areas,
+ * IoU = A_int / (A1 + A2 - A_int).  Call sites followed: reference
+ * d3d/box/utils.h:15-34 (make_box), d3d/box/iou.cpp:12-46,95-141,
+ * d3d/box/nms.cpp:10-119, d3d/dgal_wrap.h:45-91.
+ */
+
+typedef struct { T x, y; } FN(pt);
+typedef struct { FN(pt) v[4]; } FN(quad);
+typedef struct { T xmin, xmax, ymin, ymax; } FN(aabox);
+
+/* dgal::poly2_from_xywhr (call site utils.h:19).  w spans the local x axis,
+ * h the local y axis, r = CCW angle of the local x axis; corners CCW starting
+ * at local (-w/2,-h/2)  (SURVEY.md App. D convention, pinned by test_box.py). */
+static FN(quad) FN(quad_from_xywhr)(T x, T y, T w, T h, T r)
+{
+    T s = SIN(r), c = COS(r);
+    T dxs = w * s / 2, dxc = w * c / 2;
+    T dys = h * s / 2, dyc = h * c / 2;
+    FN(quad) q;
+    q.v[0].x = x - dxc + dys; q.v[0].y = y - dxs - dyc;
+    q.v[1].x = x + dxc + dys; q.v[1].y = y + dxs - dyc;
+    q.v[2].x = x + dxc - dys; q.v[2].y = y + dxs + dyc;
+    q.v[3].x = x - dxc - dys; q.v[3].y = y - dxs + dyc;
+    return q;
+}
+
+/* dgal::aabox2_from_poly2 (call site utils.h:32) */
+static FN(aabox) FN(aabox_from_quad)(const FN(quad) *q)
+{
+    FN(aabox) a = { q->v[0].x, q->v[0].x, q->v[0].y, q->v[0].y };
+    for (int k = 1; k < 4; k++) {
+        if (q->v[k].x < a.xmin) a.xmin = q->v[k].x;
+        if (q->v[k].x > a.xmax) a.xmax = q->v[k].x;
+        if (q->v[k].y < a.ymin) a.ymin = q->v[k].y;
+        if (q->v[k].y > a.ymax) a.ymax = q->v[k].y;
+    }
+    return a;
+}
+
+/* dgal::iou(AABox2, AABox2) (call site iou.cpp:30) */
+static T FN(iou_aabox)(const FN(aabox) *a, const FN(aabox) *b)
+{
+    T ix = (a->xmax < b->xmax ? a->xmax : b->xmax) - (a->xmin > b->xmin ? a->xmin : b->xmin);
+    T iy = (a->ymax < b->ymax ? a->ymax : b->ymax) - (a->ymin > b->ymin ? a->ymin : b->ymin);
+    if (!(ix > 0) || !(iy > 0)) return 0;
+    T inter = ix * iy;
+    T a1 = (a->xmax - a->xmin) * (a->ymax - a->ymin);
+    T a2 = (b->xmax - b->xmin) * (b->ymax - b->ymin);
+    return inter / (a1 + a2 - inter);
+}
+
+static T FN(poly_area)(const FN(pt) *p, int n)
+{
+    if (n < 3) return 0;
+    T s = 0;
+    for (int k = 0; k < n; k++) {
+        const FN(pt) *a = &p[k], *b = &p[(k + 1) % n];
+        s += a->x * b->y - b->x * a->y;
+    }
+    return s / 2;
+}
+
+/* Sutherland-Hodgman: clip subject polygon (<=8 verts) by the CCW convex quad c.
+ * A vertex on the clip line counts as inside (identical boxes -> full overlap). */
+static int FN(clip_quad)(const FN(quad) *subj, const FN(quad) *c, FN(pt) *out)
+{
+    FN(pt) buf[2][16];
+    int n = 4, cur = 0;
+    for (int k = 0; k < 4; k++) buf[0][k] = subj->v[k];
+    for (int e = 0; e < 4 && n > 0; e++) {
+        FN(pt) a = c->v[e], b = c->v[(e + 1) & 3];
+        T ex = b.x - a.x, ey = b.y - a.y;
+        FN(pt) *in = buf[cur], *o = buf[cur ^ 1];
+        int m = 0;
+        for (int k = 0; k < n; k++) {
+            FN(pt) p = in[k], q = in[(k + 1) % n];
+            T dp = ex * (p.y - a.y) - ey * (p.x - a.x);
+            T dq = ex * (q.y - a.y) - ey * (q.x - a.x);
+            int pin = dp >= 0, qin = dq >= 0;
+            if (pin) o[m++] = p;
+            if (pin != qin) {
+                T t = dp / (dp - dq);
+                FN(pt) x = { p.x + t * (q.x - p.x), p.y + t * (q.y - p.y) };
+                o[m++] = x;
+            }
+        }
+        n = m; cur ^= 1;
+    }
+    for (int k = 0; k < n; k++) out[k] = buf[cur][k];
+    return n;
+}
+
+/* dgal::iou(Quad2, Quad2) (call sites iou.cpp:116, nms.cpp:51, dgal_wrap.h:50) */
+static T FN(iou_quad)(const FN(quad) *a, const FN(quad) *b)
+{
+    FN(pt) poly[16];
+    int n = FN(clip_quad)(a, b, poly);
+    T inter = FN(poly_area)(poly, n);
+    if (!(inter > 0)) return 0;
+    T a1 = FN(poly_area)(a->v, 4), a2 = FN(poly_area)(b->v, 4);
+    return inter / (a1 + a2 - inter);
+}
+
+/* one pair; method 1 = BOX (AABB of rotated rect), 2 = RBOX (box/common.h:5-9).
+ * make_box is evaluated per pair exactly like iou.cpp:27-28,113-114. */
+static T FN(pair_iou)(const T *bi, const T *bj, int method)
+{
+    FN(quad) qi = FN(quad_from_xywhr)(bi[0], bi[1], bi[2], bi[3], bi[4]);
+    FN(quad) qj = FN(quad_from_xywhr)(bj[0], bj[1], bj[2], bj[3], bj[4]);
+    if (method == 1) {
+        FN(aabox) ai = FN(aabox_from_quad)(&qi), aj = FN(aabox_from_quad)(&qj);
+        return FN(iou_aabox)(&ai, &aj);
+    }
+    return FN(iou_quad)(&qi, &qj);
+}
+
+/* iou2d_forward / iou2dr_forward (iou.cpp:12-46, 95-141): ious[N,M] row-major.
+ * Rows [row_begin,row_end) only, so callers can split across threads the way
+ * at::parallel_for does (iou.cpp:21,106). */
+void FN(oracle_iou2d)(const T *b1, int64_t n, const T *b2, int64_t m, int method,
+                      int64_t row_begin, int64_t row_end, T *ious)
+{
+    (void)n;
+    for (int64_t i = row_begin; i < row_end; i++)
+        for (int64_t j = 0; j < m; j++)
+            ious[i * m + j] = FN(pair_iou)(b1 + i * 5, b2 + j * 5, method);
+}
+
+/* nms2d + nms2d_templated (nms.cpp:10-119).  order must be the descending
+ * argsort of scores (nms.cpp:103; STABLE here).  scores is copied (nms.cpp:104).
+ * supp: 0 HARD, 1 LINEAR, 2 GAUSSIAN.  Thresholds are C floats compared against
+ * scalar_t (nms.h:9-10, nms.cpp:26,53). Writes suppressed[N] (u8). */
+void FN(oracle_nms2d)(const T *boxes, const T *scores_in, int64_t n_, const int64_t *order_in,
+                      int method, int supp, float iou_threshold, float score_threshold,
+                      float supp_param, uint8_t *suppressed)
+{
+    const int N = (int)n_;
+    T *scores = (T *)malloc(sizeof(T) * (size_t)(N > 0 ? N : 1));
+    int64_t *order = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
+    for (int i = 0; i < N; i++) { scores[i] = scores_in[i]; order[i] = order_in[i]; suppressed[i] = 0; }
+
+    /* nms.cpp:23-29  (never touches sorted position 0) */
+    for (int _i = N - 1; _i > 0; _i--) {
+        int i = (int)order[_i];
+        if (scores[i] > score_threshold) break;
+        suppressed[i] = 1;
+    }
+    /* nms.cpp:32-95 */
+    for (int _i = 0; _i < N; _i++) {
+        int i = (int)order[_i];
+        if (suppressed[i]) {
+            if (supp == 0) continue;
+            else break;
+        }
+        for (int _j = _i + 1; _j < N; _j++) {
+            int j = (int)order[_j];
+            if (supp == 0 && suppressed[j]) continue;
+            T iou = FN(pair_iou)(boxes + (size_t)i * 5, boxes + (size_t)j * 5, method);
+            if (iou > iou_threshold) {
+                switch (supp) {
+                case 0: suppressed[j] = 1; break;
+                case 1: scores[j] *= 1 - POW(iou, supp_param);
+                        suppressed[j] = scores[j] < score_threshold; break;
+                case 2: scores[j] *= EXP(-iou * iou / supp_param);
+                        suppressed[j] = scores[j] < score_threshold; break;
+                }
+            }
+        }
+        if (supp != 0) {
+            /* nms.cpp:74-94 re-sort the tail, suppressed entries sink */
+            int S = N - 1;
+            while (S > _i && !suppressed[order[S]]) S--;
+            for (int _j = S - 1; _j > _i; _j--) {
+                int j = (int)order[_j];
+                int _k = _j + 1;
+                while (_k < S && (suppressed[j] || scores[order[_k]] > scores[j])) {
+                    order[_k - 1] = order[_k];
+                    _k++;
+                }
+                order[_k - 1] = j;
+            }
+        }
+    }
+    free(scores); free(order);
+}
