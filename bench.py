@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the d3d voxel/box hot path on MI355X (contract: see README/DESIGN.md).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+  N = 1 : BASELINE.json config 2 -- 1 M LiDAR-like KITTI-range points, 0.1 m voxels, max 32 points/voxel,
+          dense contract + MEAN reduction through d3d_amd.voxel.VoxelGenerator (includes the one host read-back of
+          the voxel count that the operator's variable-size return contract needs).
+  N > 1 : the point-sharded voxelizer (one 1 M-point shard of config 2's shape per rank, weak scaling):
+          local hash voxelization -> RCCL all-gather of the per-rank voxel lists -> global numbering ->
+          RCCL all-reduce of the voxel feature grid (d3d_amd.voxel.sharded).
+Rank 0 prints ONE JSON line.  `value` is whole-job Mpoints/s.  The line also carries `roofline` (dominant kernel,
+timed with HIP events on its launch stream in a separate pass of the same K steps), `cpu_baseline` (the REAL
+reference voxelizer built from /root/reference into oracle/_ref, or the C port when that binary is absent) and
+`extra` (rotated IoU Mpairs/s, NMS boxes/s, iou3d Mpairs/s, sparse-contract voxelization).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def timed(fn, steps, warmup, barrier=None):
+    for _ in range(warmup):
+        fn()
+    if barrier:
+        barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    if barrier:
+        barrier()
+    sync()
+    return time.perf_counter() - t0
+
+
+def kernel_profile(fn, steps):
+    """per-kernel durations from HIP events recorded by the library on its launch stream"""
+    from d3d_amd import _lib
+    lib = _lib.load()
+    lib.d3d_profile_enable.argtypes = [ctypes.c_int]
+    lib.d3d_profile_report.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    sync()
+    lib.d3d_profile_enable(1)
+    for _ in range(steps):
+        fn()
+    sync()
+    lib.d3d_profile_enable(0)
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.d3d_profile_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().strip().splitlines():
+        name, calls, ms = line.rsplit(",", 2)
+        out[name] = dict(calls=int(calls), total_ms=float(ms), avg_us=1e3 * float(ms) / max(int(calls), 1))
+    return out
+
+
+def load_traffic(kernel, workload):
+    """HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/traffic.json), or None"""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        t = json.load(open(p))
+        return t.get(workload, {}).get(kernel)
+    except Exception:
+        return None
+
+
+def cpu_baseline_voxel(cloud, bounds, shape, max_points, max_voxels):
+    """reference voxelizer (oracle/_ref, built from /root/reference) on the host, 1 core (it is sequential)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    kind, fn = None, None
+    try:
+        from oracle.build_ref import load_ref
+        ref = load_ref()
+        if ref is not None:
+            pts = torch.from_numpy(cloud)
+            sh = torch.tensor(shape, dtype=torch.int32)
+            bd = torch.tensor(bounds, dtype=torch.float)
+            kind = "reference"
+            fn = lambda: ref.voxelize_3d_dense(pts, sh, bd, max_points, max_voxels, ref.ReductionType.MEAN)  # noqa: E731
+    except Exception as e:   # pragma: no cover
+        print("cpu_baseline: reference binary unavailable (%s), using the C port" % e, file=sys.stderr)
+    if fn is None:
+        import oracle
+        kind = "port"
+        fn = lambda: oracle.voxelize_3d_dense(cloud, shape, bounds, max_points, max_voxels, 1)  # noqa: E731
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    fn()
+    dt = time.perf_counter() - t0
+    runs = 1
+    while dt < 8.0 and runs < 3:       # bounded: about 10 s of CPU work
+        t1 = time.perf_counter()
+        fn()
+        dt += time.perf_counter() - t1
+        runs += 1
+    n = cloud.shape[0]
+    return dict(value=round(n * runs / dt / 1e6, 4), unit="Mpoints/s", cores=1, kind=kind,
+                sample="%d run(s) of the full %d-point cloud, dense+MEAN, max_points=%d" % (runs, n, max_points))
+
+
+def extras(args):
+    """secondary metrics of BASELINE.json (configs 2-sparse, 3, 4); short runs, GPU + bounded CPU samples"""
+    import oracle
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms, iou2dr_forward, iou3d
+    from d3d_amd.voxel import VoxelGenerator
+    ex = {}
+    ncpu = os.cpu_count() or 1
+    # config 2, sparse contract + trim
+    cloud = torch.from_numpy(synth.lidar_like(args.points, 0)).cuda()
+    gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, max_points=32, max_points_filter="trim")
+    dt = timed(lambda: gen(cloud), 10, 2)
+    ex["voxelize_sparse_trim_mpoints_per_s"] = round(args.points * 10 / dt / 1e6, 2)
+    del cloud
+    # config 3: 100k rotated boxes fp64, all 1e10 pairs, streamed in row blocks through one 20 GB buffer
+    n3 = args.boxes
+    b, s = synth.boxes2d_sparse(n3, 1)
+    bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+    rows = max(1, min(n3, int(20e9 // (8 * n3))))
+
+    def all_pairs():
+        for r0 in range(0, n3, rows):
+            iou2dr_forward(bt[r0:r0 + rows], bt)
+    dt = timed(all_pairs, 2, 1)
+    ex["iou2d_rbox_fp64_mpairs_per_s"] = round(n3 * n3 * 2 / dt / 1e6, 1)
+    ex["iou2d_rbox_fp64_GBps_written"] = round(n3 * n3 * 8 * 2 / dt / 1e9, 1)
+    torch.cuda.empty_cache()
+    bd, _ = synth.boxes2d_dense(5000, 1)      # the reference's own benchmark distribution (ALU-bound case)
+    bdt = torch.from_numpy(bd).cuda()
+    dt = timed(lambda: iou2dr_forward(bdt, bdt), 10, 2)
+    ex["iou2d_rbox_fp64_dense5k_mpairs_per_s"] = round(25e6 * 10 / dt / 1e6, 1)
+    dt = timed(lambda: box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5), 3, 1)
+    ex["nms_rbox_fp64_boxes_per_s"] = round(n3 * 3 / dt, 1)
+    del bt, st
+    torch.cuda.empty_cache()
+    # config 4: 20k x 5k iou3d fp32
+    p, g = synth.boxes3d_eval(5000, 4, 2)
+    pt, gt = torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda()
+    dt = timed(lambda: iou3d(pt, gt), 20, 3)
+    ex["iou3d_rbox_fp32_mpairs_per_s"] = round(1e8 * 20 / dt / 1e6, 1)
+    if not args.skip_cpu:
+        k = 3000
+        t0 = time.perf_counter(); oracle.iou2d_forward(b[:k], b[:k], "rbox", nthreads=ncpu); dt = time.perf_counter() - t0
+        ex["cpu_iou2d_rbox_fp64_mpairs_per_s"] = dict(value=round(k * k / dt / 1e6, 2), cores=ncpu, kind="port",
+                                                       sample="%dx%d pairs of config 3" % (k, k))
+        k = 20000
+        b2, s2 = synth.boxes2d_sparse(k, 1)
+        t0 = time.perf_counter(); oracle.box2d_nms(b2, s2, iou_method="rbox", iou_threshold=0.5); dt = time.perf_counter() - t0
+        ex["cpu_nms_rbox_fp64_boxes_per_s"] = dict(value=round(k / dt, 1), cores=1, kind="port",
+                                                    sample="%d boxes at config 3's density" % k)
+        t0 = time.perf_counter(); oracle.iou3d(p[:2000], g, "rbox", nthreads=1); dt = time.perf_counter() - t0
+        ex["cpu_iou3d_rbox_fp32_mpairs_per_s"] = dict(value=round(2000 * 5000 / dt / 1e6, 2), cores=1, kind="port",
+                                                       sample="2000x5000 pairs of config 4")
+    return ex
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=1000000, help="points per GPU")
+    ap.add_argument("--boxes", type=int, default=100000, help="boxes of config 3 (extra metrics)")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-extra", action="store_true")
+    ap.add_argument("--dist", choices=["lidar", "uniform"], default="lidar")
+    args = ap.parse_args()
+
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    barrier = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        barrier = dist.barrier
+
+    P, n = 32, args.points
+    mk = synth.lidar_like if args.dist == "lidar" else synth.uniform_cloud
+    cloud_h = mk(n, rank)                       # rank k owns shard k (seed = rank; rank 0 = config 2's cloud)
+    cloud = torch.from_numpy(cloud_h).cuda()
+    out = {}
+    if world == 1:
+        gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=P,
+                             max_voxels=n)
+        res = gen(cloud)
+        V = int(res.coords.shape[0])
+        kept = int(torch.clamp(res.voxel_npoints, max=P).sum())
+        del res
+        step = lambda: gen(cloud)  # noqa: E731
+        dt = timed(step, args.steps, args.warmup)
+        value = n * args.steps / dt / 1e6
+        workload = "config2: %d %s points, KITTI range, 0.1 m voxels (704x800x40), dense+MEAN, max 32 pts/voxel" % (
+            n, "LiDAR-like" if args.dist == "lidar" else "uniform")
+        prof = kernel_profile(step, args.steps)
+        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        # compulsory bytes of each kernel per launch (DESIGN.md "kernels"); C = 4
+        algo = {
+            "k_fill_c4": V * P * 16 + kept * (16 + 4),                       # voxels[V,P,4] written + kept rows gathered
+            "k_insert": n * 16 + n * 4 + n * 16,                              # points read, pslot written, one slot touched
+            "k_rank": n * 4 + n * 16 + kept * 4,
+            "k_init": None,
+        }
+        name = dom[0]
+        b_alg = algo.get(name) or (n * 16)
+        ach = b_alg / (dom[1]["avg_us"] * 1e-6) / 1e9
+        out["roofline"] = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(name, "config2"),
+                               avg_us=round(dom[1]["avg_us"], 2), algorithmic_bytes=b_alg,
+                               timing="HIP events on the launch stream, separate pass of the same %d steps" % args.steps)
+        out["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        out["op_algorithmic_GBps"] = round((n * 16 + V * (P * 16 + P + 24 + 4 + 16)) * args.steps / dt / 1e9, 1)
+        out["voxels"] = V
+        parallelism = "1 GPU"
+    else:
+        from d3d_amd.voxel.sharded import ShardedVoxelGenerator
+        gen = ShardedVoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, reduction="mean")
+        step = lambda: gen(cloud)  # noqa: E731
+        dt_local = timed(step, args.steps, args.warmup, barrier)
+        t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        value = n * world * args.steps / dt / 1e6
+        workload = ("config2-shaped shards: %d LiDAR-like points per rank (seed=rank), 0.1 m voxels, point-sharded "
+                    "voxelization + RCCL all-gather of voxel lists + all-reduce of the voxel feature grid" % n)
+        parallelism = "points sharded over %d GPUs" % world
+
+    if rank == 0:
+        line = {
+            "metric": "voxelize_mpoints_per_s", "value": round(value, 2), "unit": "Mpoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "points_per_gpu": n, "parallelism": parallelism},
+        }
+        line.update(out)
+        if world == 1 and not args.skip_cpu:
+            line["cpu_baseline"] = cpu_baseline_voxel(cloud_h, synth.KITTI_BOUNDS, synth.KITTI_SHAPE, P, n)
+        if world == 1 and not args.skip_extra:
+            del cloud
+            torch.cuda.empty_cache()
+            line["extra"] = extras(args)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+"""ctypes binding of libd3d_hip.so (C ABI: include/d3d_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible the
+operators raise -- they never silently compute somewhere else.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libd3d_hip.so")
+
+OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = 0, -1, -2, -3, -4
+COUNT_VOXELS, COUNT_POINTS, COUNT_STATUS, COUNT_AUX, NUM_COUNTS = 0, 1, 2, 3, 4
+STATUS_COORD_OVERFLOW, STATUS_TABLE_FULL = 1, 2
+F32, F64 = 0, 1
+
+_vp, _i64, _i32, _sz, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_size_t, ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol include/d3d_hip.h declares
+SIGNATURES = {
+    "d3d_abi_version": (ctypes.c_int, []),
+    "d3d_last_hip_error": (ctypes.c_int, []),
+    "d3d_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "d3d_voxelize_workspace_bytes": (_sz, [_i64, _i64]),
+    "d3d_voxelize_3d_dense": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3d_voxelize_3d_sparse": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3d_voxelize_3d_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
+                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3d_iou2d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "d3d_iou3d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "d3d_argsort_desc_workspace_bytes": (_sz, [_i64, _i32]),
+    "d3d_argsort_desc": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "d3d_nms2d_workspace_bytes": (_sz, [_i64]),
+    "d3d_nms2d": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "Cannot find compiled library! %s is missing: build it with "
+                "`make -C d3d_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("d3d_amd needs a HIP device (MI355X); there is no CPU fallback in the product path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def check(status, what):
+    """Map a d3d_status to the exception type the reference raises for the same condition."""
+    if status == OK:
+        return
+    lib = load()
+    msg = "%s: %s" % (what, lib.d3d_status_string(status).decode())
+    if status in (ERR_BAD_ARG, ERR_UNSUPPORTED):
+        raise ValueError(msg)                       # reference: py::value_error
+    if status == ERR_HIP:
+        msg += " (hipError %d)" % lib.d3d_last_hip_error()
+    raise RuntimeError(msg)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Reusable scratch arena per (device, stream); grows geometrically, never shrinks."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

@@ -1,0 +1,219 @@
+"""d3d_amd.box -- drop-in for the forward IoU / NMS path of d3d.box on MI355X.
+
+Mirrors reference d3d/box/__init__.py: `box2d_iou` (:180), `box2d_nms` (:226), the compiled
+entry points `iou2d_forward`, `iou2dr_forward`, `nms2d` (box/impl.cpp:8-54) and the enums
+`IouType`, `SupressionType` (box/common.h:5-10).  north_star's names `iou2d`, `iou3d`, `nms`
+are thin aliases (the reference reaches "iou3d" only through Cython: d3d/dgal_wrap.h:45-91,
+d3d/tracking/matcher.pyx:57-80).  All compute runs in HIP kernels behind include/d3d_hip.h.
+"""
+import enum
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class IouType(enum.IntEnum):            # box/common.h:5-9
+    NA = 0
+    BOX = 1
+    RBOX = 2
+    GBOX = 3
+    GRBOX = 4
+    DBOX = 5
+    DRBOX = 6
+
+
+class SupressionType(enum.IntEnum):     # box/common.h:10  (sic: the reference spells it this way)
+    HARD = 0
+    LINEAR = 1
+    GAUSSIAN = 2
+
+
+cuda_available = True   # box/impl.cpp:9-13: this build always has its device path
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float64:
+        return _lib.F64
+    if t.dtype == torch.float32:
+        return _lib.F32
+    raise RuntimeError("boxes must be float32 or float64")   # AT_DISPATCH_FLOATING_TYPES (iou.cpp:132)
+
+
+def _to_device(*ts):
+    dev = None
+    for t in ts:
+        if t.is_cuda:
+            dev = t.device
+            break
+    if dev is None:
+        dev = _lib.require_gpu()
+    return [t.to(dev).contiguous() for t in ts], dev
+
+
+def _iou_forward(boxes1, boxes2, iou_type):
+    lib = _lib.load()
+    odev = boxes1.device
+    if boxes1.dtype != boxes2.dtype:
+        raise RuntimeError("boxes1 and boxes2 must have the same dtype")
+    (b1, b2), dev = _to_device(boxes1, boxes2)
+    n, m = b1.shape[0], b2.shape[0]
+    with torch.cuda.device(dev):
+        ious = torch.empty((n, m), dtype=b1.dtype, device=dev)
+        rc = lib.d3d_iou2d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, int(iou_type), _dtype_code(b1), _lib.ptr(ious),
+                                   _lib.stream_ptr())
+    _lib.check(rc, "iou2d_forward")
+    return ious.to(odev) if odev != dev else ious
+
+
+def iou2d_forward(boxes1, boxes2):
+    """iou2d_forward / iou2d_forward_cuda (iou.h:7-13; iou.cpp:35-46): AABB-of-rotated-box IoU [N,M]."""
+    return _iou_forward(boxes1, boxes2, IouType.BOX)
+
+
+def iou2dr_forward(boxes1, boxes2):
+    """`ious` of iou2dr_forward / iou2dr_forward_cuda (iou.h:25-31; iou.cpp:125-141).  The
+    autograd side outputs (nx, xflags) belong to the backward path, which is a "next" row."""
+    return _iou_forward(boxes1, boxes2, IouType.RBOX)
+
+
+def box2d_iou(boxes1, boxes2, method="box", precise=True):
+    """IoU on axis-aligned ('box') or rotated ('rbox') 2D boxes -- reference box/__init__.py:180-224.
+
+    :param boxes1: N x 5 (x,y,w,h,r), torch tensor or numpy array
+    :param boxes2: M x 5
+    :param precise: compute in float64 and cast back to the input dtype
+    """
+    convert_numpy = False
+    if isinstance(boxes1, np.ndarray):
+        assert isinstance(boxes2, np.ndarray), "Input should be both numpy tensor or pytorch tensor!"
+        boxes1, boxes2 = torch.from_numpy(boxes1), torch.from_numpy(boxes2)
+        convert_numpy = True
+    otype = boxes1.dtype
+    if precise:
+        boxes1, boxes2 = boxes1.to(torch.float64), boxes2.to(torch.float64)
+    if len(boxes1.shape) != 2 or len(boxes2.shape) != 2:
+        raise ValueError("Input of rbox_2d_iou should be Nx2 tensors!")
+    if boxes1.shape[1] != 5 or boxes2.shape[1] != 5:
+        raise ValueError("Input boxes should have 5 fields: x, y, w, h, r")
+    iou_type = getattr(IouType, method.upper())     # AttributeError for unknown names, like the reference
+    if iou_type == IouType.BOX:
+        result = iou2d_forward(boxes1, boxes2)
+    elif iou_type == IouType.RBOX:
+        result = iou2dr_forward(boxes1, boxes2)
+    elif iou_type in (IouType.GRBOX, IouType.DRBOX):
+        raise NotImplementedError("GIoU / DIoU are not part of the forward hot path yet")
+    else:
+        raise ValueError("Unrecognized iou type!")
+    if precise:
+        result = result.to(otype)
+    return result.numpy() if convert_numpy else result
+
+
+def argsort_desc(scores):
+    """stable descending argsort on the device (nms.cpp:103 uses torch's unstable argsort)."""
+    lib = _lib.load()
+    n = scores.numel()
+    dev = scores.device
+    order = torch.empty((n,), dtype=torch.int64, device=dev)
+    code = _dtype_code(scores)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(lib.d3d_argsort_desc_workspace_bytes(n, code), dev)
+        rc = lib.d3d_argsort_desc(_lib.ptr(scores), n, code, _lib.ptr(order), _lib.ptr(ws), ws.numel(),
+                                  _lib.stream_ptr())
+    _lib.check(rc, "argsort_desc")
+    return order
+
+
+def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param):
+    """nms2d / nms2d_cuda (nms.h:6-18; nms.cpp:98-119): returns the SUPPRESSED mask (bool[N]).
+    Follows the CPU control flow of the reference (nms.cpp:23-59)."""
+    lib = _lib.load()
+    iou_type, supression_type = int(iou_type), int(supression_type)
+    if iou_type not in (IouType.BOX, IouType.RBOX):
+        raise ValueError("Unsupported iou type!")                   # common.h:25
+    if supression_type not in (0, 1, 2):
+        raise ValueError("Unsupported supression type!")            # common.h:40
+    if supression_type != SupressionType.HARD:
+        raise NotImplementedError("soft-NMS is sequential by construction and is not on the device path yet")
+    odev = boxes.device
+    if boxes.dtype != scores.dtype:
+        raise RuntimeError("boxes and scores must have the same dtype")
+    (b, s), dev = _to_device(boxes, scores)
+    n = b.shape[0]
+    code = _dtype_code(b)
+    with torch.cuda.device(dev):
+        order = argsort_desc(s)
+        sup = torch.empty((n,), dtype=torch.uint8, device=dev)
+        # both workspaces are carved from one arena; the sort finished with it (same stream)
+        ws = _lib.workspace(lib.d3d_nms2d_workspace_bytes(n), dev)
+        rc = lib.d3d_nms2d(_lib.ptr(b), _lib.ptr(s), _lib.ptr(order), n, iou_type, supression_type, code,
+                           float(iou_threshold), float(score_threshold), float(supression_param), _lib.ptr(sup),
+                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "nms2d")
+    sup = sup.view(torch.bool)
+    return sup.to(odev) if odev != dev else sup
+
+
+nms2d_cuda = nms2d
+
+
+def box2d_nms(boxes, scores, iou_method="box", supression_method="hard",
+              iou_threshold=0, score_threshold=0, supression_param=0, precise=True):
+    """NMS on axis-aligned or rotated 2D boxes; returns the KEEP mask -- reference box/__init__.py:226-276."""
+    convert_numpy = False
+    if isinstance(boxes, np.ndarray):
+        assert isinstance(scores, np.ndarray), "Input should be both numpy tensor or pytorch tensor!"
+        boxes, scores = torch.from_numpy(boxes), torch.from_numpy(scores)
+        convert_numpy = True
+    if precise:
+        boxes, scores = boxes.to(torch.float64), scores.to(torch.float64)
+    if len(boxes) != len(scores):
+        raise ValueError("Numbers of boxes and scores are inconsistent!")
+    if len(scores.shape) == 2:
+        scores = scores.max(axis=1).values
+    if boxes.numel() == 0:
+        return torch.tensor([], dtype=torch.bool)
+    iou_type = getattr(IouType, iou_method.upper())
+    supression_type = getattr(SupressionType, supression_method.upper())
+    suppressed = nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param)
+    mask = ~suppressed
+    return mask.numpy() if convert_numpy else mask
+
+
+def iou3d(boxes1, boxes2, method="rbox"):
+    """Pairwise "3D IoU" of [N,7] x [M,7] boxes (x,y,z,lx,ly,lz,rz) -> f32[N,M]: BEV IoU (rotated for
+    'rbox' = box3dr_iou, AABB for 'box' = box3d_iou) times the 1-D z-interval IoU, all in fp32
+    (reference d3d/dgal_wrap.h:45-91; the pair loop of BaseMatcher.prepare_boxes,
+    d3d/tracking/matcher.pyx:57-80, stores 1 - this value)."""
+    lib = _lib.load()
+    convert_numpy = False
+    if isinstance(boxes1, np.ndarray):
+        assert isinstance(boxes2, np.ndarray), "Input should be both numpy tensor or pytorch tensor!"
+        boxes1, boxes2 = torch.from_numpy(boxes1), torch.from_numpy(boxes2)
+        convert_numpy = True
+    key = method.upper()
+    if key not in ("RBOX", "BOX"):
+        raise ValueError("Unrecognized iou type!")
+    if len(boxes1.shape) != 2 or len(boxes2.shape) != 2 or boxes1.shape[1] != 7 or boxes2.shape[1] != 7:
+        raise ValueError("Input boxes should have 7 fields: x, y, z, lx, ly, lz, rz")
+    odev = boxes1.device
+    (b1, b2), dev = _to_device(boxes1.to(torch.float32), boxes2.to(torch.float32))
+    n, m = b1.shape[0], b2.shape[0]
+    with torch.cuda.device(dev):
+        out = torch.empty((n, m), dtype=torch.float32, device=dev)
+        rc = lib.d3d_iou3d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, 1 if key == "RBOX" else 0, _lib.ptr(out),
+                                   _lib.stream_ptr())
+    _lib.check(rc, "iou3d_forward")
+    if odev != dev:
+        out = out.to(odev)
+    return out.numpy() if convert_numpy else out
+
+
+# north_star operator names
+iou2d = box2d_iou
+nms = box2d_nms
+
+__all__ = ["box2d_iou", "box2d_nms", "iou2d", "iou3d", "nms", "iou2d_forward", "iou2dr_forward", "nms2d",
+           "nms2d_cuda", "argsort_desc", "IouType", "SupressionType", "cuda_available"]

@@ -1,0 +1,174 @@
+// common.hpp -- shared host/device helpers for libd3d_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "d3d_hip.h"
+
+extern int g_d3d_last_hip_error;
+
+#define D3D_HIP_CHECK(expr)                                        \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) {                                    \
+            g_d3d_last_hip_error = (int)e_;                        \
+            return D3D_ERR_HIP;                                    \
+        }                                                          \
+    } while (0)
+#define D3D_LAUNCH_CHECK() D3D_HIP_CHECK(hipGetLastError())
+
+// opt-in per-kernel timing (api.hip); NAME is a string literal shared by all launches of a kernel
+extern int g_d3d_prof_on;
+void d3d_prof_pre(const char *name, hipStream_t st);
+void d3d_prof_post(const char *name, hipStream_t st);
+#define D3D_LAUNCH(NAME, kernel, grid, block, lds, st, ...)                   \
+    do {                                                                      \
+        if (g_d3d_prof_on) d3d_prof_pre(NAME, st);                            \
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);        \
+        if (g_d3d_prof_on) d3d_prof_post(NAME, st);                           \
+        D3D_LAUNCH_CHECK();                                                   \
+    } while (0)
+
+static inline size_t d3d_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int64_t d3d_divup(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// bump allocator over the caller's workspace
+struct WsCarver {
+    char *base;
+    size_t off, cap;
+    WsCarver(void *p, size_t bytes) : base((char *)p), off(0), cap(bytes) {}
+    template <typename T> T *take(size_t count)
+    {
+        size_t b = d3d_align_up(count * sizeof(T));
+        T *r = (T *)(base ? base + off : nullptr);
+        off += b;
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+constexpr int kWave = 64;            // CDNA wavefront
+constexpr int kScanBlock = 256;      // threads per scan block (4 waves)
+constexpr int kScanItems = 4;        // consecutive items per thread
+constexpr int kScanTile = kScanBlock * kScanItems;
+
+// ---------------------------------------------------------------- wave / block scans (u64)
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        unsigned long long t = __shfl_up(v, d, kWave);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over the block; *total = block sum.  smem: BLOCK/64 u64 entries.
+template <int BLOCK>
+__device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long *total,
+                                                                  unsigned long long *smem)
+{
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    unsigned long long incl = wave_incl_scan_u64(v);
+    if (lane == kWave - 1) smem[w] = incl;
+    __syncthreads();
+    unsigned long long woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / kWave; k++) {
+        unsigned long long x = smem[k];
+        if (k < w) woff += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + incl - v;
+}
+
+// ---------------------------------------------------------------- generic 3-kernel scan
+// F provides:  u64 value(int64 i)   (count pass; may record side data)
+//              u64 value2(int64 i)  (apply pass; must return the same value)
+//              void apply(int64 i, u64 v, u64 excl)
+// Values are "packed pairs": two u32 sums in one u64 (hi, lo) -- both stay < 2^32.
+template <class F>
+__global__ __launch_bounds__(kScanBlock) void k_scan_count(F f, int64_t n, unsigned long long *bsum)
+{
+    __shared__ unsigned long long smem[kScanBlock / kWave];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        int64_t i = base + k;
+        if (i < n) s += f.value(i);
+    }
+    // block reduce via wave shuffles
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) s += __shfl_down(s, d, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) smem[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int k = 0; k < kScanBlock / kWave; k++) t += smem[k];
+        bsum[blockIdx.x] = t;
+    }
+}
+
+// single block: exclusive scan of bsum[nb] in place; writes clamped totals to counts.
+// counts[idx_hi] = min(total_hi, cap_hi) (if idx_hi >= 0); counts[idx_lo] = total_lo (if idx_lo >= 0)
+static __global__ __launch_bounds__(1024) void k_scan_bsum(unsigned long long *bsum, int64_t nb, int64_t *counts, int idx_hi,
+                                                     int idx_lo, unsigned long long cap_hi)
+{
+    __shared__ unsigned long long smem[1024 / kWave];
+    unsigned long long carry = 0;
+    for (int64_t c0 = 0; c0 < nb; c0 += 1024) {
+        int64_t i = c0 + threadIdx.x;
+        unsigned long long v = i < nb ? bsum[i] : 0ull, tot;
+        unsigned long long ex = block_excl_scan_u64<1024>(v, &tot, smem);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        unsigned long long hi = carry >> 32, lo = carry & 0xffffffffull;
+        if (idx_hi >= 0) counts[idx_hi] = (int64_t)(hi < cap_hi ? hi : cap_hi);
+        if (idx_lo >= 0) counts[idx_lo] = (int64_t)lo;
+    }
+}
+
+template <class F>
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(F f, int64_t n, const unsigned long long *bsum_excl)
+{
+    __shared__ unsigned long long smem[kScanBlock / kWave];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    unsigned long long v[kScanItems], s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        int64_t i = base + k;
+        v[k] = i < n ? f.value2(i) : 0ull;
+        s += v[k];
+    }
+    unsigned long long tot;
+    unsigned long long ex = block_excl_scan_u64<kScanBlock>(s, &tot, smem) + bsum_excl[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        int64_t i = base + k;
+        if (i < n) f.apply(i, v[k], ex);
+        ex += v[k];
+    }
+}
+
+// host driver for the trio.  bsum must hold ceil(n / kScanTile) u64.
+template <class F>
+static inline int d3d_run_scan(F f, int64_t n, unsigned long long *bsum, int64_t *counts, int idx_hi, int idx_lo,
+                               unsigned long long cap_hi, hipStream_t st)
+{
+    int64_t nb = d3d_divup(n, kScanTile);
+    if (nb > 0) {
+        D3D_LAUNCH(F::kName, k_scan_count<F>, dim3((unsigned)nb), dim3(kScanBlock), 0, st, f, n, bsum);
+    }
+    D3D_LAUNCH("k_scan_bsum", k_scan_bsum, dim3(1), dim3(1024), 0, st, bsum, nb, counts, idx_hi, idx_lo, cap_hi);
+    if (nb > 0) {
+        D3D_LAUNCH(F::kName2, k_scan_apply<F>, dim3((unsigned)nb), dim3(kScanBlock), 0, st, f, n, bsum);
+    }
+    return D3D_OK;
+}

@@ -1,0 +1,260 @@
+"""d3d_amd.voxel -- drop-in for d3d.voxel (reference d3d/voxel/__init__.py) on MI355X.
+
+Public names mirror the reference: `VoxelGenerator` (voxel/__init__.py:12) and the three
+functions + three enums of its compiled module `voxel_impl` (voxel/impl.cpp:3-21).  All
+compute happens in hand-written HIP kernels behind the C ABI of include/d3d_hip.h; torch is
+only used for device buffers and the current stream.  Tensors may live on the CPU (they are
+staged through the current HIP device and results come back on the CPU, like the reference's
+CPU-only operator) or on the GPU (results stay there).
+"""
+import ctypes
+import enum
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..utils import Dict
+
+
+class ReductionType(enum.IntEnum):          # voxelize.h:5
+    NONE = 0
+    MEAN = 1
+    MAX = 2
+    MIN = 3
+
+
+class MaxPointsFilterType(enum.IntEnum):    # voxelize.h:6
+    NONE = 0
+    TRIM = 1
+    FARTHEST_SAMPLING = 2
+
+
+class MaxVoxelsFilterType(enum.IntEnum):    # voxelize.h:7
+    NONE = 0
+    TRIM = 1
+    DESCENDING = 2
+
+
+def _as_tensor(x):
+    return torch.from_numpy(x) if isinstance(x, np.ndarray) else x
+
+
+def _host_array(t, ctype, count):
+    vals = [t[i].item() if isinstance(t, torch.Tensor) else t[i] for i in range(count)]
+    return (ctype * count)(*vals)
+
+
+def _stage(points, what="points"):
+    points = _as_tensor(points)
+    if not isinstance(points, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor or numpy array" % what)
+    if points.dim() != 2:
+        raise RuntimeError("%s must be a 2-D tensor" % what)       # reference: accessor<float,2> throws
+    if points.dtype != torch.float32:
+        raise RuntimeError("%s must be float32" % what)            # reference: accessor<float,2> throws
+    dev = _lib.require_gpu() if not points.is_cuda else points.device
+    return points.to(dev).contiguous(), points.device, dev
+
+
+def _counts_to_host(counts, what):
+    host = counts.cpu()     # the one host sync of a call: sizes of the variable-length outputs
+    status = int(host[_lib.COUNT_STATUS])
+    if status & _lib.STATUS_TABLE_FULL:
+        raise RuntimeError("%s: internal hash table overflow" % what)
+    if status & _lib.STATUS_COORD_OVERFLOW:
+        raise ValueError("%s: voxel coordinate out of the supported range [-2^20, 2^20) "
+                         "(non-finite point or voxel size too small)" % what)
+    return host
+
+
+def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type):
+    """voxelize_3d_dense of the reference (voxelize.h:9-12; voxelize.cpp:45-199).
+
+    Returns dict(voxels[V,P,C] f32, coords[V,3] i64, voxel_pmask[V,P] bool,
+    voxel_npoints[V] i32 [, aggregates[V,C] f32 when reduction != NONE]).
+    """
+    lib = _lib.load()
+    pts, odev, dev = _stage(points)
+    n, c = pts.shape
+    if c < 3:
+        raise RuntimeError("points need at least 3 columns (x, y, z)")
+    red = int(reduction_type)
+    max_points, max_voxels = int(max_points), int(max_voxels)
+    shape_h = _host_array(voxel_shape, ctypes.c_int32, 3)
+    bound_h = _host_array(voxel_bound, ctypes.c_float, 6)
+    cap = max(min(n, max_voxels), 0)
+    with torch.cuda.device(dev):
+        voxels = torch.empty((cap, max_points, c), dtype=torch.float32, device=dev)
+        coords = torch.empty((cap, 3), dtype=torch.int64, device=dev)
+        pmask = torch.empty((cap, max_points), dtype=torch.uint8, device=dev)
+        npts = torch.empty((cap,), dtype=torch.int32, device=dev)
+        agg = torch.empty((cap, c), dtype=torch.float32, device=dev) if red != 0 else None
+        counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+        wsb = lib.d3d_voxelize_workspace_bytes(n, 0)
+        ws = _lib.workspace(wsb, dev)
+        rc = lib.d3d_voxelize_3d_dense(
+            _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
+            max_points, max_voxels, red, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts),
+            _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        if rc == _lib.ERR_UNSUPPORTED:
+            raise ValueError("Unsupported reduction type in voxelization!")   # voxelize.cpp:196
+        _lib.check(rc, "voxelize_3d_dense")
+        nv = int(_counts_to_host(counts, "voxelize_3d_dense")[_lib.COUNT_VOXELS])
+    ret = dict(voxels=voxels[:nv], coords=coords[:nv], voxel_pmask=pmask[:nv].view(torch.bool),
+               voxel_npoints=npts[:nv])
+    if red != 0:
+        ret["aggregates"] = agg[:nv]
+    if odev != dev:
+        ret = {k: v.to(odev) for k, v in ret.items()}
+    return ret
+
+
+def voxelize_3d_sparse(points, voxel_size, ndim=3):
+    """voxelize_sparse of the reference, exported as voxelize_3d_sparse
+    (voxelize.h:14-17; voxelize.cpp:288-335; impl.cpp:5)."""
+    lib = _lib.load()
+    if ndim not in (None, 3):
+        raise ValueError("only ndim=3 is supported")   # the reference's map key is a 3-tuple (voxelize.cpp:16)
+    pts, odev, dev = _stage(points)
+    n, c = pts.shape
+    if c < 3:
+        raise RuntimeError("points need at least 3 columns (x, y, z)")
+    size_h = _host_array(voxel_size, ctypes.c_float, 3)
+    with torch.cuda.device(dev):
+        mapping = torch.empty((n,), dtype=torch.int64, device=dev)
+        coords = torch.empty((n, 3), dtype=torch.int64, device=dev)
+        npts = torch.empty((n,), dtype=torch.int32, device=dev)
+        counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+        ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
+        rc = lib.d3d_voxelize_3d_sparse(_lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), _lib.ptr(mapping),
+                                        _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
+                                        _lib.stream_ptr())
+        _lib.check(rc, "voxelize_3d_sparse")
+        nv = int(_counts_to_host(counts, "voxelize_3d_sparse")[_lib.COUNT_VOXELS])
+    ret = dict(points_mapping=mapping, coords=coords[:nv], voxel_npoints=npts[:nv])
+    if odev != dev:
+        ret = {k: v.to(odev) for k, v in ret.items()}
+    return ret
+
+
+def voxelize_3d_filter(feats, points_mapping, coords, voxel_npoints, coords_bound,
+                       min_points=None, max_points=None, max_voxels=None,
+                       max_points_filter=None, max_voxels_filter=None):
+    """voxelize_filter of the reference, exported as voxelize_3d_filter
+    (voxelize.h:19-25; voxelize.cpp:337-484).  `voxel_npoints` must be the per-voxel counts of
+    `points_mapping` (as produced by voxelize_3d_sparse).  `coords_bound` is required
+    (None crashes the reference, voxelize.cpp:348-349)."""
+    lib = _lib.load()
+    pf = int(max_points_filter) if max_points_filter is not None else 0
+    vf = int(max_voxels_filter) if max_voxels_filter is not None else 0
+    if vf != 0 and max_voxels is None:
+        raise ValueError("Must specify maximum voxel count to filter voxels!")            # voxelize.cpp:359
+    if pf != 0 and max_points is None:
+        raise ValueError("Must specify maximum points per voxel to filter points!")       # voxelize.cpp:362
+    if pf == MaxPointsFilterType.FARTHEST_SAMPLING:
+        raise ValueError("Farthest Sampling not implemented!")                            # voxelize.cpp:470
+    if coords_bound is None:
+        raise ValueError("coords_bound is required")
+    fts, odev, dev = _stage(feats, "feats")
+    n, c = fts.shape
+    mapping = _as_tensor(points_mapping).to(dev, torch.int64).contiguous()
+    crd = _as_tensor(coords).to(dev, torch.int64).contiguous()
+    cnt = _as_tensor(voxel_npoints).to(dev, torch.int32).contiguous()
+    if mapping.numel() != n:
+        raise RuntimeError("points_mapping must have one entry per point")
+    nvox = crd.shape[0]
+    if crd.dim() != 2 or crd.shape[1] != 3 or cnt.numel() != nvox:
+        raise RuntimeError("coords must be [V,3] and voxel_npoints [V]")
+    cb = _as_tensor(coords_bound).reshape(-1).tolist()
+    bound_h = (ctypes.c_int64 * 6)(*[int(x) for x in cb])
+    with torch.cuda.device(dev):
+        o_feats = torch.empty((n, c), dtype=torch.float32, device=dev)
+        o_mask = torch.empty((n,), dtype=torch.int64, device=dev)
+        o_map = torch.empty((n,), dtype=torch.int64, device=dev)
+        o_cnt = torch.empty((nvox,), dtype=torch.int32, device=dev)
+        o_crd = torch.empty((nvox, 3), dtype=torch.int64, device=dev)
+        counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+        ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, nvox), dev)
+        rc = lib.d3d_voxelize_3d_filter(
+            _lib.ptr(fts), n, c, _lib.ptr(mapping), _lib.ptr(crd), _lib.ptr(cnt), nvox,
+            ctypes.cast(bound_h, ctypes.c_void_p), int(min_points or 0), int(max_points or 0), int(max_voxels or 0),
+            pf, vf, _lib.ptr(o_feats), _lib.ptr(o_mask), _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd),
+            _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "voxelize_3d_filter")
+        host = _counts_to_host(counts, "voxelize_3d_filter")
+        k, v = int(host[_lib.COUNT_POINTS]), int(host[_lib.COUNT_VOXELS])
+    ret = dict(points=o_feats[:k], points_mask=o_mask[:k], points_mapping=o_map[:k],
+               voxel_npoints=o_cnt[:v], coords=o_crd[:v])
+    if odev != dev:
+        ret = {kk: vv.to(odev) for kk, vv in ret.items()}
+    return ret
+
+
+def _lookup(enum_cls, name, message):
+    key = (name or "NONE").upper()
+    if key not in enum_cls.__members__:
+        raise ValueError(message)
+    return enum_cls[key]
+
+
+class VoxelGenerator:
+    """Convert point cloud to voxels -- same constructor, call signature and results as the
+    reference's d3d.voxel.VoxelGenerator (voxel/__init__.py:12-104)."""
+
+    def __init__(self, bounds, shape, min_points=0, max_points=30, max_voxels=20000,
+                 max_points_filter=None, max_voxels_filter=None, reduction=None, dense=False):
+        # The derived grid quantities are tiny fp32 host tensors computed with the same torch
+        # ops as the reference so that `size` is bit-identical (it feeds the coordinate division).
+        self._bounds = torch.tensor(bounds, dtype=torch.float)
+        self._shape = torch.tensor(shape, dtype=torch.int32)
+        self._min_points, self._max_points, self._max_voxels, self._dense = min_points, max_points, max_voxels, dense
+
+        lohi = self._bounds.reshape(3, 2)
+        self._size = (lohi[:, 1] - lohi[:, 0]) / self._shape                                  # :41
+        origin_cells = lohi[:, 0] / self._size                                                # :42
+        if torch.any(torch.abs(torch.round(origin_cells) - origin_cells) > 1e-3):            # :43-44
+            raise ValueError("The voxelization grids is not aligned with the origin, "
+                             "which could lead to unexpected behavior!")
+        self._offset = torch.round(origin_cells).int()                                        # :45
+        self._vbounds = torch.round(lohi / self._size.reshape(3, 1)).long()                   # :46
+
+        red = (reduction or "NONE").upper()
+        if red != "NONE" and not dense:
+            raise ValueError("Reduction is only for dense voxelization!")                     # :50-51
+        self._reduction = _lookup(ReductionType, red, "Unsupported reduction type in VoxelGenerator!")
+        self._max_points_filter = _lookup(MaxPointsFilterType, max_points_filter,
+                                          "Unsupported maximum points filter in VoxelGenerator!")
+        self._max_voxels_filter = _lookup(MaxVoxelsFilterType, max_voxels_filter,
+                                          "Unsupported maximum voxels filter in VoxelGenerator!")
+        if dense:                                                                             # :71-77
+            if min_points > 0:
+                raise NotImplementedError("Minimum points filtering is not implemented for dense")
+            if self._max_points_filter not in (MaxPointsFilterType.NONE, MaxPointsFilterType.TRIM):
+                raise NotImplementedError("Only trim is implemented for max points filtering")
+            if self._max_voxels_filter not in (MaxVoxelsFilterType.NONE, MaxVoxelsFilterType.TRIM):
+                raise NotImplementedError("Only trim is implemented for max voxels filtering")
+
+    def __call__(self, points):
+        """Returns a Dict: dense -> voxels, coords, voxel_pmask, voxel_npoints[, aggregates];
+        sparse -> points, points_mask, points_mapping, voxel_npoints, coords (voxel/__init__.py:79-104)."""
+        points = _as_tensor(points)
+        odev = points.device
+        if not points.is_cuda:
+            points = points.to(_lib.require_gpu())    # stage once; results go back to the caller's device
+        if self._dense:
+            ret = Dict(voxelize_3d_dense(points, self._shape, self._bounds, self._max_points,
+                                         self._max_voxels, self._reduction))
+        else:
+            sparse = voxelize_3d_sparse(points, self._size, 3)
+            ret = Dict(voxelize_3d_filter(points, sparse["points_mapping"], sparse["coords"], sparse["voxel_npoints"],
+                                          self._vbounds, self._min_points, self._max_points, self._max_voxels,
+                                          self._max_points_filter, self._max_voxels_filter))
+            ret.coords = ret.coords - self._offset.to(ret.coords.device)                      # :103
+        if odev != points.device:
+            ret = Dict({k: v.to(odev) for k, v in ret.items()})
+        return ret
+
+
+__all__ = ["VoxelGenerator", "voxelize_3d_dense", "voxelize_3d_sparse", "voxelize_3d_filter",
+           "ReductionType", "MaxPointsFilterType", "MaxVoxelsFilterType"]

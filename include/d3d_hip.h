@@ -1,0 +1,140 @@
+/*
+ * d3d_hip.h -- C ABI of libd3d_hip.so: the MI355X (gfx950) implementation of the
+ * data-parallel hot path of cmpute/d3d (d3d/voxel + d3d/box).
+ *
+ * This is the drop-in boundary.  Every entry point replaces one function that the
+ * reference binds through pybind11 in d3d/voxel/impl.cpp:3-21 and d3d/box/impl.cpp:8-54
+ * (or, for iou3d, the C shims in d3d/dgal_wrap.h reached from Cython).  Conventions:
+ *
+ *  - plain pointers + sizes, no torch / pybind types;
+ *  - all tensor arguments are DEVICE pointers (HBM), contiguous row-major, unless
+ *    the parameter comment says "host";
+ *  - the caller owns every buffer, including the scratch `workspace` whose size is
+ *    returned by the matching *_workspace_bytes() query (256-byte aligned base);
+ *  - variable-size results are written into caller-provided upper-bound buffers; the
+ *    actual sizes go to a small device array `counts` (int64) that the caller copies
+ *    back when it needs them.  No entry point synchronises the stream, allocates,
+ *    or touches the legacy default stream (cf. reference nms_cuda.cu:186-214);
+ *  - every function returns a d3d_status (0 = ok, <0 = error) instead of throwing
+ *    py::value_error or exit()-ing (reference common.h:33-46);
+ *  - `stream` is a hipStream_t passed as void* (NULL = null stream).
+ */
+#ifndef D3D_HIP_H
+#define D3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    D3D_OK = 0,
+    D3D_ERR_BAD_ARG = -1,       /* null pointer / negative size / bad enum       -> ValueError   */
+    D3D_ERR_UNSUPPORTED = -2,   /* option the reference rejects too              -> ValueError   */
+    D3D_ERR_WORKSPACE = -3,     /* workspace smaller than *_workspace_bytes()    -> RuntimeError */
+    D3D_ERR_HIP = -4            /* a HIP call failed; see d3d_last_hip_error()   -> RuntimeError */
+} d3d_status;
+
+/* enum values are the reference's (d3d/voxel/voxelize.h:5-7, d3d/box/common.h:5-10) */
+enum { D3D_REDUCE_NONE = 0, D3D_REDUCE_MEAN = 1, D3D_REDUCE_MAX = 2, D3D_REDUCE_MIN = 3 };
+enum { D3D_MAXPTS_NONE = 0, D3D_MAXPTS_TRIM = 1, D3D_MAXPTS_FARTHEST_SAMPLING = 2 };
+enum { D3D_MAXVOX_NONE = 0, D3D_MAXVOX_TRIM = 1, D3D_MAXVOX_DESCENDING = 2 };
+enum { D3D_IOU_NA = 0, D3D_IOU_BOX = 1, D3D_IOU_RBOX = 2, D3D_IOU_GBOX = 3, D3D_IOU_GRBOX = 4,
+       D3D_IOU_DBOX = 5, D3D_IOU_DRBOX = 6 };
+enum { D3D_SUPPRESS_HARD = 0, D3D_SUPPRESS_LINEAR = 1, D3D_SUPPRESS_GAUSSIAN = 2 };
+enum { D3D_F32 = 0, D3D_F64 = 1 };
+
+/* status bits OR-ed into counts[D3D_COUNT_STATUS] by the voxel kernels */
+enum { D3D_VOXEL_STATUS_COORD_OVERFLOW = 1,   /* sparse: |floor(p/size)| >= 2^20 (or NaN)      */
+       D3D_VOXEL_STATUS_TABLE_FULL = 2 };     /* internal hash table overflow (cannot happen
+                                                 with the documented workspace size)           */
+enum { D3D_COUNT_VOXELS = 0, D3D_COUNT_POINTS = 1, D3D_COUNT_STATUS = 2, D3D_COUNT_AUX = 3, D3D_NUM_COUNTS = 4 };
+
+int         d3d_abi_version(void);
+int         d3d_last_hip_error(void);           /* hipError_t of the last D3D_ERR_HIP */
+const char *d3d_status_string(int status);
+
+/* ------------------------------------------------------------------ d3d/voxel */
+
+/* scratch for any of the three voxel entry points on n points / nvox voxels */
+size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels);
+
+/* replaces voxelize_3d_dense (reference d3d/voxel/voxelize.h:9-12, voxelize.cpp:45-199).
+ *   points[n,c] f32; shape[3] i32 (host); bound[6] f32 (host: xmin,xmax,ymin,ymax,zmin,zmax)
+ *   outputs sized for cap = min(n, max_voxels) voxels:
+ *   voxels[cap,max_points,c] f32, coords[cap,3] i64, pmask[cap,max_points] u8 (0/1),
+ *   npoints[cap] i32, aggregates[cap,c] f32 (NULL iff reduction == NONE).
+ *   Rows >= counts[D3D_COUNT_VOXELS] are left untouched (the caller slices them off,
+ *   cf. voxelize.cpp:167-179).  counts: device int64[D3D_NUM_COUNTS]. */
+int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c,
+                          const int32_t *shape, const float *bound,
+                          int32_t max_points, int32_t max_voxels, int32_t reduction,
+                          float *voxels, int64_t *coords, uint8_t *pmask, int32_t *npoints,
+                          float *aggregates, int64_t *counts,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* replaces voxelize_sparse, bound in Python as voxelize_3d_sparse
+ * (reference voxelize.h:14-17, voxelize.cpp:288-335, impl.cpp:5).
+ *   points[n,c] f32 (c >= 3); voxel_size[3] f32 (host)
+ *   points_mapping[n] i64, coords[n,3] i64 (first counts[0] rows valid), npoints[n] i32. */
+int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c, const float *voxel_size,
+                           int64_t *points_mapping, int64_t *coords, int32_t *npoints,
+                           int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+
+/* replaces voxelize_filter, bound as voxelize_3d_filter
+ * (reference voxelize.h:19-25, voxelize.cpp:337-484).
+ *   feats[n,c] f32, points_mapping[n] i64, coords[nvox,3] i64, voxel_npoints[nvox] i32,
+ *   coords_bound[6] i64 (host: row-major [3][2] = lo,hi per axis)
+ *   out_feats[n,c], out_mask[n] i64, out_mapping[n] i64, out_npoints[nvox] i32,
+ *   out_coords[nvox,3] i64;  counts[D3D_COUNT_POINTS] kept points, counts[D3D_COUNT_VOXELS]
+ *   kept voxels.  max_points_filter == FARTHEST_SAMPLING -> D3D_ERR_UNSUPPORTED
+ *   (reference throws at voxelize.cpp:469-471). */
+int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c,
+                           const int64_t *points_mapping, const int64_t *coords,
+                           const int32_t *voxel_npoints, int64_t nvox, const int64_t *coords_bound,
+                           int32_t min_points, int32_t max_points, int32_t max_voxels,
+                           int32_t max_points_filter, int32_t max_voxels_filter,
+                           float *out_feats, int64_t *out_mask, int64_t *out_mapping,
+                           int32_t *out_npoints, int64_t *out_coords,
+                           int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+
+/* -------------------------------------------------------------------- d3d/box */
+
+/* replaces iou2d_forward[_cuda] (method BOX) and the `ious` output of
+ * iou2dr_forward[_cuda] (method RBOX)  (reference d3d/box/iou.h:7-24, iou.cpp:12-46,95-141,
+ * iou_cuda.cu:10-48,100-151).  boxes1[n,5], boxes2[m,5] = (x,y,w,h,r) in `dtype`;
+ * ious[n,m] in `dtype`, row-major.  64-bit pair indexing (cf. iou_cuda.cu:36,137). */
+int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t m,
+                      int32_t iou_type, int32_t dtype, void *ious, void *stream);
+
+/* batched box3dr_iou (rotated=1) / box3d_iou (rotated=0)
+ * (reference d3d/dgal_wrap.h:45-91; pair loop d3d/tracking/matcher.pyx:57-80).
+ * boxes[.,7] f32 = (x,y,z,lx,ly,lz,rz); out[n,m] f32. */
+int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *boxes2, int64_t m,
+                      int32_t rotated, float *out, void *stream);
+
+/* stable descending argsort (the role torch::argsort plays inside the reference's nms2d,
+ * nms.cpp:103): keys[n] in `dtype` -> order[n] i64; ties keep ascending index. */
+size_t d3d_argsort_desc_workspace_bytes(int64_t n, int32_t dtype);
+int d3d_argsort_desc(const void *keys, int64_t n, int32_t dtype, int64_t *order,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+size_t d3d_nms2d_workspace_bytes(int64_t n);
+
+/* replaces nms2d / nms2d_cuda (reference d3d/box/nms.h:6-18, nms.cpp:10-119,
+ * nms_cuda.cu:17-244).  Follows the CPU control flow (nms.cpp:23-59).
+ *   boxes[n,5], scores[n] in `dtype`; order[n] i64 = descending argsort of scores
+ *   (nms.cpp:103) supplied by the caller; suppressed[n] u8 (0/1) output.
+ *   Only HARD suppression and BOX/RBOX are implemented on the device; everything
+ *   else returns D3D_ERR_UNSUPPORTED ("Unsupported iou type!", reference common.h:25). */
+int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n,
+              int32_t iou_type, int32_t suppression_type, int32_t dtype,
+              float iou_threshold, float score_threshold, float suppression_param,
+              uint8_t *suppressed, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3D_HIP_H */

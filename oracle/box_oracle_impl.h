@@ -101,10 +101,12 @@ static int FN(clip_quad)(const FN(quad) *subj, const FN(quad) *c, FN(pt) *out)
 static T FN(iou_quad)(const FN(quad) *a, const FN(quad) *b)
 {
     FN(pt) poly[16];
+    T a1 = FN(poly_area)(a->v, 4), a2 = FN(poly_area)(b->v, 4);
+    /* policy for degenerate (zero / negative size) boxes, SURVEY.md App. D: IoU 0, never NaN/inf */
+    if (!(a1 > 0) || !(a2 > 0)) return 0;
     int n = FN(clip_quad)(a, b, poly);
     T inter = FN(poly_area)(poly, n);
     if (!(inter > 0)) return 0;
-    T a1 = FN(poly_area)(a->v, 4), a2 = FN(poly_area)(b->v, 4);
     return inter / (a1 + a2 - inter);
 }
 

@@ -1,0 +1,190 @@
+"""GPU parity (through the C ABI): d3d_amd.box vs the reference's known answers and the CPU oracle.
+Tolerances (north_star): IoU 1e-6 in fp64, 1e-3 in fp32; NMS keep masks bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import box_cases as bc
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, cuda=True):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.cuda() if cuda else t
+
+
+@pytest.mark.parametrize("cuda", [True, False])
+def test_iou_aa_boxes(cuda):          # test_box.py:12-37
+    from d3d_amd.box import box2d_iou
+    exp = torch.from_numpy(bc.AA_EXPECTED)
+    ious = box2d_iou(T(bc.AA_B1, cuda), T(bc.AA_B2, cuda), method="box")
+    assert ious.is_cuda == cuda and ious.dtype == torch.float32
+    assert torch.allclose(ious.cpu(), exp, atol=bc.eps)
+    ious = box2d_iou(T(bc.AA_B1, cuda), T(bc.AA_B2, cuda), method="rbox")
+    assert torch.allclose(ious.cpu(), exp, atol=4 * bc.eps)
+
+
+def test_iou_rotated_boxes():         # test_box.py:39-72
+    from d3d_amd.box import box2d_iou, iou2d
+    for precise in [True, False]:
+        ious = box2d_iou(T(bc.ROT_B1), T(bc.ROT_B2), method="box", precise=precise)
+        assert torch.allclose(ious.cpu(), torch.from_numpy(bc.ROT_BOX_EXPECTED), atol=2 * bc.eps)
+        ious = iou2d(T(bc.ROT_B1), T(bc.ROT_B2), method="rbox", precise=precise)
+        assert torch.allclose(ious.cpu(), torch.from_numpy(bc.ROT_RBOX_EXPECTED), atol=4 * bc.eps)
+
+
+def test_iou_apart_boxes():           # test_box.py:74-100
+    from d3d_amd.box import box2d_iou
+    for precise in [True, False]:
+        ious = box2d_iou(T(bc.APART_BOX), T(bc.APART_BOX), method="box", precise=precise)
+        assert np.allclose(ious.cpu().numpy() - np.eye(4), 0, atol=1e-6)
+        ious = box2d_iou(T(bc.APART_RBOX), T(bc.APART_RBOX), method="rbox", precise=precise)
+        assert np.allclose(ious.cpu().numpy() - np.eye(5), 0, atol=1e-6)
+
+
+def test_numpy_ingress_and_errors():
+    from d3d_amd.box import box2d_iou, box2d_nms
+    r = box2d_iou(bc.AA_B1, bc.AA_B2, method="rbox")
+    assert isinstance(r, np.ndarray) and r.dtype == np.float32
+    with pytest.raises(ValueError):
+        box2d_iou(T(bc.AA_B1)[:, :4], T(bc.AA_B2), method="box")
+    with pytest.raises(ValueError):
+        box2d_iou(T(bc.AA_B1)[0], T(bc.AA_B2), method="box")
+    with pytest.raises(ValueError):
+        box2d_nms(T(bc.NMS_BOXES), T(bc.NMS_SCORES)[:3])
+    with pytest.raises(ValueError):
+        box2d_nms(T(bc.NMS_BOXES), T(bc.NMS_SCORES), iou_method="grbox")
+    assert box2d_nms(torch.zeros((0, 5)), torch.zeros((0,))).shape == (0,)
+    assert box2d_iou(torch.zeros((0, 5)).cuda(), T(bc.AA_B2), method="rbox").shape == (0, 3)
+
+
+def test_nms_known_answer():          # test_box.py:102-123
+    from d3d_amd.box import box2d_nms, nms
+    for m in ["box", "rbox"]:
+        for cuda in [True, False]:
+            mask = box2d_nms(T(bc.NMS_BOXES, cuda), T(bc.NMS_SCORES, cuda), iou_method=m)
+            assert mask.dtype == torch.bool and mask.is_cuda == cuda
+            assert np.array_equal(mask.cpu().numpy(), bc.NMS_EXPECTED)
+    assert np.array_equal(nms(bc.NMS_BOXES, bc.NMS_SCORES, iou_method="rbox"), bc.NMS_EXPECTED)
+    s2 = np.stack([bc.NMS_SCORES * 0.5, bc.NMS_SCORES], 1)      # [N,K] scores -> class max (box/__init__.py:253)
+    assert np.array_equal(box2d_nms(T(bc.NMS_BOXES), T(s2)).cpu().numpy(), bc.NMS_EXPECTED)
+
+
+def test_iou_large_array_and_nms_property():   # test_box.py:125-155
+    from d3d_amd.box import box2d_iou, box2d_nms
+    b, s = bc.random_boxes_like_reference(500, 0)
+    for m in ["box", "rbox"]:
+        r = box2d_iou(T(b), T(b), method=m)
+        assert torch.all(r >= -bc.eps) and torch.all(r <= 1 + bc.eps)
+        for thr in [0, 0.2, 0.5, 0.8, 0.99]:
+            keep = box2d_nms(T(b), T(s), iou_method=m, iou_threshold=0.3, score_threshold=thr).cpu().numpy()
+            assert np.all(keep[s <= thr] == False)  # noqa: E712
+            assert np.array_equal(keep, oracle.box2d_nms(b, s, iou_method=m, iou_threshold=0.3, score_threshold=thr))
+
+
+@pytest.mark.parametrize("method", ["box", "rbox"])
+@pytest.mark.parametrize("gen", ["sparse", "dense"])
+def test_iou_vs_oracle_fp64(method, gen):
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_iou
+    mk = synth.boxes2d_sparse if gen == "sparse" else synth.boxes2d_dense
+    b1, _ = mk(700, 21)
+    b2, _ = mk(333, 22)
+    got = box2d_iou(T(b1), T(b2), method=method).cpu().numpy()
+    exp = oracle.box2d_iou(b1, b2, method, nthreads=8)
+    assert got.dtype == np.float64 and got.shape == (700, 333)
+    assert np.max(np.abs(got - exp)) < 1e-6, np.max(np.abs(got - exp))   # north_star: 1e-6 in fp64
+    assert np.max(np.abs(got - exp)) < 1e-9                               # what we actually achieve
+
+
+@pytest.mark.parametrize("method", ["box", "rbox"])
+def test_iou_vs_oracle_fp32(method):
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_iou
+    b1, _ = synth.boxes2d_dense(500, 23, np.float32)
+    b2, _ = synth.boxes2d_dense(400, 24, np.float32)
+    got = box2d_iou(T(b1), T(b2), method=method, precise=False).cpu().numpy()
+    ref64 = oracle.box2d_iou(b1.astype(np.float64), b2.astype(np.float64), method, nthreads=8)
+    assert got.dtype == np.float32
+    assert np.max(np.abs(got - ref64)) < 1e-3                             # north_star: 1e-3 in fp32
+
+
+def test_degenerate_boxes():
+    from d3d_amd.box import box2d_iou
+    b = np.array([[0, 0, 2, 2, 0.3], [0, 0, 2, 2, 0.3],       # identical -> 1
+                  [0, 0, 0, 0, 0], [5, 5, 0, 3, 0.2],          # zero area -> 0, no NaN
+                  [2, 0, 2, 2, 0],                             # shares an edge with box 5
+                  [0, 0, 2, 2, 0], [0, 0, 1, 1, 0],            # contained: 1/4
+                  [0, 0, 2, 2, np.pi / 2]], np.float64)        # same square rotated 90 deg
+    got = box2d_iou(T(b), T(b), method="rbox").cpu().numpy()
+    exp = oracle.box2d_iou(b, b, "rbox")
+    assert np.all(np.isfinite(got))
+    assert abs(got[0, 1] - 1) < 1e-12 and abs(got[5, 6] - 0.25) < 1e-12 and abs(got[4, 5]) < 1e-12
+    assert abs(got[5, 7] - 1) < 1e-9
+    assert np.allclose(got, exp, atol=1e-9)
+
+
+@pytest.mark.parametrize("method", ["box", "rbox"])
+@pytest.mark.parametrize("gen,n,thr", [("sparse", 5000, 0.5), ("dense", 1500, 0.3), ("sparse", 5000, 0.0),
+                                        ("dense", 63, 0.1), ("dense", 64, 0.1), ("dense", 65, 0.1), ("dense", 1, 0.1)])
+def test_nms_vs_oracle_bit_exact(method, gen, n, thr):
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms
+    mk = synth.boxes2d_sparse if gen == "sparse" else synth.boxes2d_dense
+    b, s = mk(n, 31)
+    assert len(np.unique(s)) == n          # no score ties -> the order is unambiguous
+    for sthr in [0.0, 0.3]:
+        keep = box2d_nms(T(b), T(s), iou_method=method, iou_threshold=thr, score_threshold=sthr).cpu().numpy()
+        exp = oracle.box2d_nms(b, s, iou_method=method, iou_threshold=thr, score_threshold=sthr)
+        assert np.array_equal(keep, exp), (np.sum(keep != exp), n)
+
+
+def test_nms_score_ties_are_stable():
+    from d3d_amd.box import box2d_nms
+    b, _ = bc.random_boxes_like_reference(400, 8)
+    s = np.round(np.random.default_rng(9).random(400) * 10) / 10   # many ties
+    keep = box2d_nms(T(b.astype(np.float64)), T(s), iou_method="rbox", iou_threshold=0.2).cpu().numpy()
+    assert np.array_equal(keep, oracle.box2d_nms(b.astype(np.float64), s, iou_method="rbox", iou_threshold=0.2))
+
+
+def test_nms_top_box_below_score_threshold():
+    """CPU semantics (nms.cpp:23): sorted position 0 is never pre-suppressed by the score threshold."""
+    from d3d_amd.box import box2d_nms
+    b, s = bc.random_boxes_like_reference(50, 10)
+    keep = box2d_nms(T(b), T(s * 0.5), iou_method="box", score_threshold=0.9).cpu().numpy()
+    exp = oracle.box2d_nms(b, s * 0.5, iou_method="box", score_threshold=0.9)
+    assert np.array_equal(keep, exp) and keep.sum() == 1
+
+
+@pytest.mark.parametrize("method", ["rbox", "box"])
+def test_iou3d_vs_oracle(method):
+    from d3d_amd import synth
+    from d3d_amd.box import iou3d
+    pred, gt = synth.boxes3d_eval(300, 4, 2)
+    got = iou3d(T(pred), T(gt), method).cpu().numpy()
+    exp = oracle.iou3d(pred, gt, method, nthreads=8)
+    assert got.shape == (1200, 300) and got.dtype == np.float32
+    assert np.max(np.abs(got - exp)) < 1e-3
+    # evaluator vectors (test_benchmark.py:31-39, 45-71)
+    v = iou3d(T(bc.EVAL_DT), T(bc.EVAL_GT))[0, 0].item()
+    assert v > 0.1 and abs(v - bc.EVAL_IOU) < 1e-4
+    assert np.isclose(iou3d(T(bc.EVAL_DT), T(bc.EVAL_DT))[0, 0].item(), 1)
+
+
+def test_full_size_cfg4_properties():
+    """BASELINE config 4 at full size (20k x 5k): symmetry / range / matched-pair properties."""
+    from d3d_amd import synth
+    from d3d_amd.box import iou3d
+    pred, gt = synth.boxes3d_eval(5000, 4, 2)
+    m = iou3d(T(pred), T(gt))
+    assert m.shape == (20000, 5000)
+    assert float(m.min()) >= 0 and float(m.max()) <= 1 + 1e-3
+    mt = iou3d(T(gt), T(pred))
+    assert torch.allclose(m, mt.t(), atol=2e-3)            # IoU is symmetric
+    best = m.argmax(1).cpu().numpy()
+    assert np.mean(best == np.repeat(np.arange(5000), 4)) > 0.9   # each pred matches its own GT
+    rows = np.random.default_rng(0).choice(20000, 64, replace=False)
+    exp = oracle.iou3d(pred[rows], gt, "rbox", nthreads=8)
+    assert np.max(np.abs(m[torch.from_numpy(rows).cuda()].cpu().numpy() - exp)) < 1e-3

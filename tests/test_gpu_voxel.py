@@ -1,0 +1,177 @@
+"""GPU parity (through the C ABI): d3d_amd.voxel vs outputs of the real reference (golden) and vs the
+CPU oracle on seeded random clouds.  Bit-exact: coords, counts, voxels, pmask, mapping, MAX/MIN, and MEAN
+for voxels that do not overflow max_points; MEAN of overflow voxels within 1e-5 rel (atomic order)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_io import GOLDEN, derived_pmask, load_voxel_cases
+
+pytestmark = pytest.mark.gpu
+CASES = load_voxel_cases()
+
+
+def _np(d):
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+def check_dense(ret, exp, max_points):
+    assert np.array_equal(ret["coords"], exp["coords"]) and ret["coords"].dtype == np.int64
+    assert np.array_equal(ret["voxel_npoints"], exp["voxel_npoints"]) and ret["voxel_npoints"].dtype == np.int32
+    assert np.array_equal(ret["voxels"], exp["voxels"], equal_nan=True)
+    assert ret["voxel_pmask"].dtype == np.bool_
+    assert np.array_equal(ret["voxel_pmask"], derived_pmask(exp["voxel_npoints"], max_points))
+    assert ("aggregates" in ret) == ("aggregates" in exp)
+    if "aggregates" in exp:
+        fit = exp["voxel_npoints"] <= max_points
+        assert np.array_equal(ret["aggregates"][fit], exp["aggregates"][fit], equal_nan=True)
+        np.testing.assert_allclose(ret["aggregates"][~fit], exp["aggregates"][~fit], rtol=1e-5, atol=1e-6)
+
+
+def check_sparse(ret, exp):
+    for k in ["points", "points_mask", "points_mapping", "voxel_npoints", "coords"]:
+        assert np.array_equal(ret[k], exp[k]), k
+        assert ret[k].dtype == exp[k].dtype, k
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["meta"]["kind"] == "dense"])
+@pytest.mark.parametrize("on_gpu", [True, False])
+def test_dense_matches_reference(name, on_gpu):
+    from d3d_amd.voxel import VoxelGenerator
+    c = CASES[name]
+    kw = dict(c["meta"]["kw"])
+    gen = VoxelGenerator(c["meta"]["bounds"], c["meta"]["shape"], dense=True, **kw)
+    pts = torch.from_numpy(c["cloud"])
+    ret = gen(pts.cuda() if on_gpu else pts)
+    assert ret.voxels.is_cuda == on_gpu
+    check_dense(_np(ret), c["out"], kw.get("max_points", 30))
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["meta"]["kind"] == "sparse"])
+def test_sparse_matches_reference(name):
+    from d3d_amd.voxel import VoxelGenerator
+    c = CASES[name]
+    kw = dict(c["meta"]["kw"])
+    gen = VoxelGenerator(c["meta"]["bounds"], c["meta"]["shape"], **kw)
+    ret = _np(gen(torch.from_numpy(c["cloud"]).cuda()))
+    if kw.get("max_voxels_filter") == "descending":
+        # reference argsort is unstable (voxelize.cpp:406): our spec is the stable order -> compare with the oracle
+        exp = oracle.VoxelGenerator(c["meta"]["bounds"], c["meta"]["shape"], **kw)(c["cloud"])
+        check_sparse(ret, exp)
+        assert sorted(ret["voxel_npoints"].tolist()) == sorted(c["out"]["voxel_npoints"].tolist())
+    else:
+        check_sparse(ret, c["out"])
+
+
+def test_raw_sparse_function():
+    from d3d_amd.voxel import voxelize_3d_sparse
+    c = CASES["raw_sparse"]
+    r = _np(voxelize_3d_sparse(torch.from_numpy(c["cloud"]).cuda(), torch.from_numpy(c["size"]), 3))
+    for k in ["points_mapping", "coords", "voxel_npoints"]:
+        assert np.array_equal(r[k], c["out"][k]) and r[k].dtype == c["out"][k].dtype
+
+
+def test_reference_fixture_spconv():
+    """reference test/test_voxel.py:80-88"""
+    from d3d_amd.voxel import VoxelGenerator
+    data = np.load(GOLDEN + "/voxel_data_ref.npz")
+    gen = VoxelGenerator([0, 1, 0, 1, 0, 1], [10, 10, 10], max_points=5, max_points_filter="trim", dense=True)
+    ret = gen(torch.tensor(data["cloud"]))
+    assert np.allclose(ret.voxels.numpy(), data["voxels"]) and np.array_equal(ret.voxels.numpy(), data["voxels"])
+    assert np.array_equal(ret.coords.numpy(), data["coords"])
+
+
+@pytest.mark.parametrize("reduction", ["none", "mean", "max", "min"])
+@pytest.mark.parametrize("dist", ["lidar", "uniform"])
+def test_dense_vs_oracle_100k(reduction, dist):
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    cloud = synth.lidar_like(100000, 11) if dist == "lidar" else synth.uniform_cloud(100000, 12)
+    kw = dict(reduction=reduction, max_points=8, max_voxels=60000, dense=True)
+    exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(cloud)
+    ret = _np(VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(torch.from_numpy(cloud).cuda()))
+    check_dense(ret, exp, 8)
+
+
+def test_sparse_vs_oracle_100k():
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    cloud = synth.lidar_like(100000, 13)
+    for kw in [dict(max_points=4, max_points_filter="trim"),
+               dict(max_points=4, max_points_filter="trim", min_points=2, max_voxels=5000, max_voxels_filter="trim"),
+               dict(max_voxels=3000, max_voxels_filter="descending", max_points=3, max_points_filter="trim"),
+               dict()]:
+        exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(cloud)
+        ret = _np(VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(torch.from_numpy(cloud).cuda()))
+        check_sparse(ret, exp)
+
+
+def test_empty_and_tiny_inputs():
+    from d3d_amd.voxel import VoxelGenerator
+    unit = [0, 1, 0, 1, 0, 1]
+    e = torch.zeros((0, 4), dtype=torch.float32)
+    d = VoxelGenerator(unit, [10, 10, 10], dense=True, reduction="mean", max_points=5)(e.cuda())
+    assert d.voxels.shape == (0, 5, 4) and d.coords.shape == (0, 3) and d.aggregates.shape == (0, 4)
+    s = VoxelGenerator(unit, [10, 10, 10])(e.cuda())
+    assert s.points.shape == (0, 4) and s.coords.shape == (0, 3)
+    one = torch.tensor([[0.55, 0.15, 0.95, 7.0]])
+    d = VoxelGenerator(unit, [10, 10, 10], dense=True, reduction="max", max_points=2)(one.cuda())
+    assert d.coords.tolist() == [[5, 1, 9]] and d.voxel_npoints.tolist() == [1]
+    assert d.aggregates.cpu().tolist() == [[0.55, 0.15, 0.95, 7.0]] or np.allclose(d.aggregates.cpu(), one)
+    # all points out of range
+    far = torch.full((100, 4), 5.0)
+    d = VoxelGenerator(unit, [10, 10, 10], dense=True)(far.cuda())
+    assert d.voxels.shape[0] == 0
+
+
+def test_all_points_in_one_voxel_and_errors():
+    from d3d_amd.voxel import VoxelGenerator
+    unit = [0, 1, 0, 1, 0, 1]
+    rng = np.random.default_rng(5)
+    cloud = (0.5 + 0.01 * rng.random((50000, 4))).astype(np.float32)
+    exp = oracle.VoxelGenerator(unit, [10, 10, 10], dense=True, reduction="mean", max_points=16, max_voxels=10)(cloud)
+    ret = _np(VoxelGenerator(unit, [10, 10, 10], dense=True, reduction="mean", max_points=16, max_voxels=10)(
+        torch.from_numpy(cloud).cuda()))
+    check_dense(ret, exp, 16)
+    exp = oracle.VoxelGenerator(unit, [10, 10, 10], max_points=16, max_points_filter="trim")(cloud)
+    ret = _np(VoxelGenerator(unit, [10, 10, 10], max_points=16, max_points_filter="trim")(torch.from_numpy(cloud).cuda()))
+    check_sparse(ret, exp)
+    with pytest.raises(ValueError):
+        VoxelGenerator([0.05, 1, 0, 1, 0, 1], [10, 10, 10])
+    with pytest.raises(ValueError):
+        VoxelGenerator(unit, [10, 10, 10], reduction="mean")
+    with pytest.raises(ValueError):
+        VoxelGenerator(unit, [10, 10, 10], max_points_filter="bogus")
+    with pytest.raises(NotImplementedError):
+        VoxelGenerator(unit, [10, 10, 10], min_points=1, dense=True)
+    with pytest.raises(ValueError):   # NaN point in the unbounded sparse contract
+        VoxelGenerator(unit, [10, 10, 10])(torch.tensor([[float("nan"), 0, 0, 0]]).cuda())
+
+
+def test_full_size_cfg2_properties():
+    """BASELINE config 2 at full size: size-independent properties + oracle on indices."""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    cloud = synth.lidar_like(1000000, 0)
+    pts = torch.from_numpy(cloud).cuda()
+    gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=32,
+                         max_voxels=1000000)
+    d = gen(pts)
+    V = d.coords.shape[0]
+    assert int(d.voxel_npoints.sum()) == 1000000            # every generated point is in range
+    assert int(d.voxel_pmask.sum()) == int(torch.clamp(d.voxel_npoints, max=32).sum())
+    lin = (d.coords[:, 0] * 800 + d.coords[:, 1]) * 40 + d.coords[:, 2]
+    assert torch.unique(lin).numel() == V                    # voxels are unique
+    # stored points fall in their voxel (test_voxel.py:23-26 invariant)
+    first = d.voxels[:, 0, :3]
+    cc = ((first - torch.tensor([0, -40, -3.0], device="cuda")) / 0.1).long()
+    assert (torch.abs(cc - d.coords) <= 1).all()
+    # checksum of checksums: sum of all stored features == sum over points kept
+    # voxel mean * count == feature sum (fp64 reference)
+    tot = (d.aggregates.double() * d.voxel_npoints.double()[:, None]).sum(0)
+    assert torch.allclose(tot, pts.double().sum(0), rtol=1e-6)
+    exp = oracle.voxelize_3d_dense(cloud, synth.KITTI_SHAPE, synth.KITTI_BOUNDS, 1, 1000000, 0)   # max_points=1: cheap
+    assert np.array_equal(d.coords.cpu().numpy(), exp["coords"])
+    assert np.array_equal(d.voxel_npoints.cpu().numpy(), exp["voxel_npoints"])
+    assert np.array_equal(d.voxels[:, 0].cpu().numpy(), exp["voxels"][:, 0])
