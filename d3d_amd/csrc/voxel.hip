@@ -15,6 +15,7 @@
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off (IEEE div, no FMA contraction:
 // voxel coordinates must round exactly like the reference's CPU code).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -24,11 +25,24 @@ constexpr uint32_t kNoVoxel = 0xffffffffu;    // slot.first after numbering: vox
 constexpr uint32_t kNoSlot = 0x7fffffffu;     // pslot: point not in any voxel
 constexpr uint32_t kFirstBit = 0x80000000u;   // pslot: this point is the first of its voxel
 
+// 16-byte hash slot.  Two layouts (template parameter PK):
+//   plain  : key | first | cnt            voxel id overwrites `first` in the numbering pass
+//   packed : (key << 24 | cnt) | first | vid    -- claim + count in ONE 64-bit atomic (CAS for the
+//            first arrival, atomicAdd afterwards); usable when key < 2^40-1 and n < 2^24
 struct __attribute__((aligned(16))) Slot {
     unsigned long long key;
-    uint32_t first;   // min point index; overwritten by the voxel id in the numbering pass
-    uint32_t cnt;
+    uint32_t first;   // min point index
+    uint32_t cnt;     // plain: count; packed: voxel id
 };
+constexpr int kCntBits = 24;
+constexpr uint32_t kCntMask = (1u << kCntBits) - 1u;
+template <bool PK> __device__ __forceinline__ uint32_t slot_cnt(const uint4 &s) { return PK ? (s.x & kCntMask) : s.w; }
+template <bool PK> __device__ __forceinline__ uint32_t slot_vid(const uint4 &s) { return PK ? s.w : s.z; }
+template <bool PK> __device__ __forceinline__ unsigned long long slot_key(const uint4 &s)
+{
+    unsigned long long k = ((unsigned long long)s.y << 32) | s.x;
+    return PK ? (k >> kCntBits) : k;
+}
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long h)
 {
@@ -91,11 +105,11 @@ struct SparseKey {
 };
 
 // ------------------------------------------------------------------ kernels
-__global__ void k_init(Slot *table, int64_t cap, uint32_t *list, int64_t nlist, int64_t *counts)
+__global__ void k_init(Slot *table, int64_t cap, uint32_t *list, int64_t nlist, int64_t *counts, uint32_t aux_init)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint4 e = make_uint4(0xffffffffu, 0xffffffffu, kInf, 0u);
+    uint4 e = make_uint4(0xffffffffu, 0xffffffffu, kInf, aux_init);
     uint4 *tb = reinterpret_cast<uint4 *>(table);
     for (int64_t i = t0; i < cap; i += stride) tb[i] = e;
     uint4 f = make_uint4(kInf, kInf, kInf, kInf);
@@ -104,14 +118,14 @@ __global__ void k_init(Slot *table, int64_t cap, uint32_t *list, int64_t nlist, 
     if (t0 < D3D_NUM_COUNTS) counts[t0] = 0;
 }
 
-template <class Key, bool VEC4>
+template <class Key, bool VEC4, bool PK>
 __global__ __launch_bounds__(256) void k_insert(Key kf, const float *__restrict__ points, int64_t n, int c,
                                                 Slot *table, unsigned long long mask, uint32_t *pslot,
-                                                int64_t npad, int64_t *counts)
+                                                uint32_t *parr, int64_t npad, int64_t *counts)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npad) return;
-    uint32_t slot = kNoSlot, status = 0;
+    uint32_t slot = kNoSlot, status = 0, arrival = 0;
     if (i < n) {
         float p[3];
         if (VEC4) {
@@ -128,26 +142,45 @@ __global__ __launch_bounds__(256) void k_insert(Key kf, const float *__restrict_
             for (unsigned long long probe = 0; probe <= mask; probe++) {
                 Slot *s = &table[h];
                 unsigned long long k = __hip_atomic_load(&s->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (k == kEmptyKey) {
-                    unsigned long long old = atomicCAS(&s->key, kEmptyKey, key);
-                    k = (old == kEmptyKey) ? key : old;
+                if (PK) {
+                    if (k == kEmptyKey) {
+                        unsigned long long old = atomicCAS(&s->key, kEmptyKey, (key << kCntBits) | 1ull);
+                        if (old == kEmptyKey) { found = true; arrival = 0; break; }   // claimed and counted at once
+                        k = old;
+                    }
+                    if ((k >> kCntBits) == key) {
+                        arrival = (uint32_t)(atomicAdd(&s->key, 1ull) & kCntMask);
+                        found = true;
+                        break;
+                    }
+                } else {
+                    if (k == kEmptyKey) {
+                        unsigned long long old = atomicCAS(&s->key, kEmptyKey, key);
+                        k = (old == kEmptyKey) ? key : old;
+                    }
+                    if (k == key) {
+                        arrival = atomicAdd(&s->cnt, 1u);   // arrival position inside the voxel (any order)
+                        found = true;
+                        break;
+                    }
                 }
-                if (k == key) { found = true; break; }
                 h = (h + 1) & mask;
             }
             if (found) {
                 slot = (uint32_t)h;
-                atomicAdd(&table[h].cnt, 1u);
-                atomicMin(&table[h].first, (uint32_t)i);
+                // `first` only decreases, so a stale read can only cause a redundant atomicMin
+                if (__hip_atomic_load(&table[h].first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)i)
+                    atomicMin(&table[h].first, (uint32_t)i);
             } else status |= D3D_VOXEL_STATUS_TABLE_FULL;
         }
     }
     pslot[i] = slot;
+    if (parr) parr[i] = arrival;
     if (status) atomicOr(reinterpret_cast<unsigned long long *>(&counts[D3D_COUNT_STATUS]), (unsigned long long)status);
 }
 
 // scan functor: voxel numbering in first-seen order (+ list offsets)
-template <class Key>
+template <class Key, bool PK>
 struct NumberVoxels {
     static constexpr const char *kName = "k_scan_count<NumberVoxels>", *kName2 = "k_scan_apply<NumberVoxels>";
     Key kf;
@@ -156,8 +189,6 @@ struct NumberVoxels {
     uint32_t *voff;       // [cap_voxels] list offset per voxel
     int64_t *coords;      // [cap_voxels,3]
     int32_t *npoints;     // [cap_voxels]
-    float *agg;           // [cap_voxels,c] or null: initialised here for overflow voxels
-    int c, reduction;
     uint32_t max_points;  // 0 -> no lists (sparse contract)
     uint32_t max_voxels;
 
@@ -168,38 +199,35 @@ struct NumberVoxels {
         uint4 s = reinterpret_cast<const uint4 *>(table)[ps];
         if (s.z != (uint32_t)i) return 0;
         pslot[i] = ps | kFirstBit;
-        uint32_t w = s.w < max_points ? s.w : max_points;
+        uint32_t w = max_points ? slot_cnt<PK>(s) : 0u;     // list space: every point of the voxel gets a cell
         return (1ull << 32) | w;
     }
     __device__ __forceinline__ unsigned long long value2(int64_t i) const
     {
         uint32_t ps = pslot[i];
         if (!(ps & kFirstBit)) return 0;
-        uint32_t cnt = table[ps & ~kFirstBit].cnt;
-        uint32_t w = cnt < max_points ? cnt : max_points;
+        uint32_t w = max_points ? slot_cnt<PK>(reinterpret_cast<const uint4 *>(table)[ps & ~kFirstBit]) : 0u;
         return (1ull << 32) | w;
     }
     __device__ __forceinline__ void apply(int64_t i, unsigned long long v, unsigned long long excl) const
     {
         if (!v) return;
-        Slot *s = &table[pslot[i] & ~kFirstBit];
+        Slot *sp = &table[pslot[i] & ~kFirstBit];
+        const uint4 s = *reinterpret_cast<const uint4 *>(sp);
         uint32_t vid = (uint32_t)(excl >> 32);
-        if (vid >= max_voxels) { s->first = kNoVoxel; return; }   // voxelize.cpp:116-117
-        s->first = vid;
-        if (max_points) voff[vid] = (uint32_t)excl;
+        uint32_t *vid_field = PK ? &sp->cnt : &sp->first;
+        if (vid >= max_voxels) { *vid_field = kNoVoxel; return; }   // voxelize.cpp:116-117
+        *vid_field = vid;
+        if (max_points) {
+            voff[vid] = (uint32_t)excl;
+            if (PK) sp->first = (uint32_t)excl;   // `first` has done its job: reuse it for the list offset
+        }
         long long cc[3];
-        kf.decode(s->key, cc);
+        kf.decode(slot_key<PK>(s), cc);
         coords[(int64_t)vid * 3 + 0] = cc[0];
         coords[(int64_t)vid * 3 + 1] = cc[1];
         coords[(int64_t)vid * 3 + 2] = cc[2];
-        uint32_t cnt = s->cnt;
-        npoints[vid] = (int32_t)cnt;
-        if (agg && cnt > max_points) {
-            // overflow voxel: aggregated by atomics in k_rank; seed the accumulators
-            uint32_t init = reduction == D3D_REDUCE_MEAN ? 0u : (reduction == D3D_REDUCE_MAX ? 0x007fffffu /* enc(-inf) */
-                                                                                             : 0xff800000u /* enc(+inf) */);
-            for (int d = 0; d < c; d++) reinterpret_cast<uint32_t *>(agg)[(int64_t)vid * c + d] = init;
-        }
+        npoints[vid] = (int32_t)slot_cnt<PK>(s);
     }
 };
 
@@ -214,49 +242,56 @@ __device__ __forceinline__ float dec_f32(uint32_t e)
     return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
 }
 
-// per point: insert its index into the voxel's sorted list of the max_points smallest indices
-__global__ __launch_bounds__(256) void k_rank(const float *__restrict__ points, int64_t n, int c, const Slot *table,
-                                              const uint32_t *__restrict__ pslot, const uint32_t *__restrict__ voff,
-                                              uint32_t *list, uint32_t max_points, int reduction, float *agg)
+// Ranking without a sort and without dependent atomic chains:
+//   k_scatter  every point drops its index at unsorted[voff[v] + arrival]  (arrival = value returned by
+//              the count atomicAdd in k_insert; any order)
+//   k_select   every point counts the indices smaller than its own in its voxel's (contiguous, L2-hot)
+//              segment; that count IS its rank in point order.  It stops as soon as max_points smaller
+//              ones were seen (the point is then not among the first max_points, voxelize.cpp:128-134),
+//              so a voxel of c points costs O(c * max_points) loads when arrival order is roughly
+//              index order.  Ranks < max_points land in sorted[voff[v] + rank].
+template <bool PK>
+__global__ __launch_bounds__(256) void k_scatter(int64_t n, const Slot *table, uint32_t *__restrict__ pslot,
+                                                 uint32_t *__restrict__ parr, const uint32_t *__restrict__ voff,
+                                                 uint32_t *unsorted, uint32_t *sorted)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t ps = pslot[i] & ~kFirstBit;
-    if (ps == kNoSlot) return;
-    uint4 s = reinterpret_cast<const uint4 *>(table)[ps];
-    const uint32_t vid = s.z, cnt = s.w;
-    if (vid == kNoVoxel) return;
-    const uint32_t base = voff[vid];
-    if (cnt == 1) { list[base] = (uint32_t)i; return; }
-    const uint32_t L = cnt < max_points ? cnt : max_points;
-    bool insert = L > 0;
-    if (cnt > max_points) {
-        // overflow voxel: all of its points feed the aggregate (voxelize.cpp:137-157) ...
-        if (reduction != D3D_REDUCE_NONE) {
-            for (int d = 0; d < c; d++) {
-                float x = points[i * c + d];
-                float *a = &agg[(int64_t)vid * c + d];
-                if (reduction == D3D_REDUCE_MEAN) atomicAdd(a, x);
-                else if (x == x) {   // std::max/min never pick up a NaN operand
-                    if (reduction == D3D_REDUCE_MAX) atomicMax(reinterpret_cast<uint32_t *>(a), enc_f32(x));
-                    else atomicMin(reinterpret_cast<uint32_t *>(a), enc_f32(x));
-                }
-            }
-        }
-        // ... but only the max_points smallest indices are kept.  Cells only decrease, so a
-        // stale read of the last cell can only make us insert needlessly, never drop wrongly.
-        if (insert) {
-            uint32_t last = __hip_atomic_load(&list[base + L - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (last < (uint32_t)i) insert = false;
+    uint32_t todo = 0, base = 0;
+    if (ps != kNoSlot) {
+        uint4 s = reinterpret_cast<const uint4 *>(table)[ps];     // the one random access of this pass
+        const uint32_t vid = slot_vid<PK>(s), cnt = slot_cnt<PK>(s);
+        if (vid != kNoVoxel) {
+            base = PK ? s.z : voff[vid];     // packed slots carry the list offset in `first` after numbering
+            if (cnt == 1) sorted[base] = (uint32_t)i;
+            else { unsorted[base + parr[i]] = (uint32_t)i; todo = cnt; }
         }
     }
-    if (!insert) return;
-    uint32_t x = (uint32_t)i;
-    for (uint32_t k = 0; k < L; k++) {
-        uint32_t old = atomicMin(&list[base + k], x);
-        if (old == kInf) break;      // landed in an empty cell
-        if (old > x) x = old;        // displaced a larger index: carry it down the chain
+    // hand (segment length, segment base) to k_select through the per-point arrays: coalesced there
+    pslot[i] = todo;
+    parr[i] = base;
+}
+
+__global__ __launch_bounds__(256) void k_select(int64_t n, const uint32_t *__restrict__ pcnt,
+                                                const uint32_t *__restrict__ pbase,
+                                                const uint32_t *__restrict__ unsorted, uint32_t *sorted,
+                                                uint32_t max_points)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t cnt = pcnt[i];
+    if (cnt == 0) return;
+    const uint32_t base = pbase[i];
+    const uint32_t *seg = unsorted + base;
+    const uint32_t me = (uint32_t)i;
+    uint32_t rank = 0, k = 0;
+    for (; k + 4 <= cnt && rank < max_points; k += 4) {   // 4 independent loads per exit test
+        uint32_t a0 = seg[k], a1 = seg[k + 1], a2 = seg[k + 2], a3 = seg[k + 3];
+        rank += (a0 < me) + (a1 < me) + (a2 < me) + (a3 < me);
     }
+    for (; k < cnt && rank < max_points; k++) rank += seg[k] < me;
+    if (rank < max_points) sorted[base + rank] = me;
 }
 
 // voxels[V, P, 4]: one 16-byte row per lane, grid-stride, non-temporal stores
@@ -328,34 +363,66 @@ __global__ __launch_bounds__(256) void k_pmask(const int64_t *__restrict__ count
 
 // aggregates[V,C]: one (voxel, channel) per lane.  Voxels with cnt <= P are reduced
 // sequentially in point order from their sorted list -> bit-identical to the reference's
-// loop (voxelize.cpp:137-164).  Overflow voxels were accumulated by atomics in k_rank.
+// loop (voxelize.cpp:137-164).
 __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ points, int c,
                                                    const int64_t *__restrict__ counts,
                                                    const int32_t *__restrict__ npoints,
                                                    const uint32_t *__restrict__ voff, const uint32_t *__restrict__ list,
-                                                   uint32_t max_points, int reduction, float *agg)
+                                                   const uint32_t *__restrict__ unsorted, uint32_t max_points,
+                                                   int reduction, float *agg)
 {
     const int64_t total = counts[D3D_COUNT_VOXELS] * (int64_t)c;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const int64_t v = t / c;
+    const int lane = threadIdx.x & (kWave - 1);
+    // `wbase` is wave-uniform so that the whole wavefront stays in the loop for the cooperative part
+    for (int64_t wbase = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; wbase < total; wbase += stride) {
+        const int64_t t = wbase + lane;
+        const bool valid = t < total;
+        const int64_t v = valid ? t / c : 0;
         const int d = (int)(t - v * c);
-        const uint32_t cnt = (uint32_t)npoints[v];
-        float acc;
-        if (cnt <= max_points) {
+        const uint32_t cnt = valid ? (uint32_t)npoints[v] : 0u;
+        if (valid && cnt <= max_points) {
             const uint32_t base = voff[v];
-            acc = reduction == D3D_REDUCE_MEAN ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+            float acc = reduction == D3D_REDUCE_MEAN ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
             for (uint32_t k = 0; k < cnt; k++) {
                 float x = points[(int64_t)list[base + k] * c + d];
                 if (reduction == D3D_REDUCE_MEAN) acc += x;
                 else if (reduction == D3D_REDUCE_MAX) acc = acc < x ? x : acc;   // std::max(acc, x)
                 else acc = x < acc ? x : acc;                                      // std::min(acc, x)
             }
-        } else {
-            acc = reduction == D3D_REDUCE_MEAN ? agg[t] : dec_f32(reinterpret_cast<const uint32_t *>(agg)[t]);
+            if (reduction == D3D_REDUCE_MEAN) acc = acc / (float)(int32_t)cnt;   // voxelize.cpp:164 (float / int)
+            agg[t] = acc;
         }
-        if (reduction == D3D_REDUCE_MEAN) acc = acc / (float)(int32_t)cnt;   // voxelize.cpp:164 (float / int)
-        agg[t] = acc;
+        // Overflow voxels: every point counts (voxelize.cpp:137-157) but only max_points are ranked, so the
+        // wavefront walks the arrival-ordered segment together, 64 entries per step.  MEAN accumulates in fp64
+        // (insensitive to the arrival order to ~1e-16 => reproducible; differs from the reference's fp32
+        // running sum by rounding only).
+        unsigned long long big = __ballot(valid && cnt > max_points);
+        while (big) {
+            const int l = __builtin_ctzll(big);
+            big &= big - 1;
+            const int64_t vv = __shfl((long long)v, l, kWave);
+            const int dd = __shfl(d, l, kWave);
+            const uint32_t cc = __shfl(cnt, l, kWave);
+            const uint32_t *seg = unsorted + voff[vv];
+            double sum = 0.0;
+            float ext = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
+            for (uint32_t k = lane; k < cc; k += kWave) {
+                float x = points[(int64_t)seg[k] * c + dd];
+                if (reduction == D3D_REDUCE_MEAN) sum += (double)x;
+                else if (reduction == D3D_REDUCE_MAX) ext = ext < x ? x : ext;
+                else ext = x < ext ? x : ext;
+            }
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) {
+                double s2 = __shfl_xor(sum, o, kWave);
+                float e2 = __shfl_xor(ext, o, kWave);
+                sum += s2;
+                if (reduction == D3D_REDUCE_MAX) ext = ext < e2 ? e2 : ext;
+                else ext = e2 < ext ? e2 : ext;
+            }
+            if (lane == l) agg[t] = reduction == D3D_REDUCE_MEAN ? (float)sum / (float)(int32_t)cc : ext;
+        }
     }
 }
 
@@ -487,7 +554,9 @@ struct VoxelWs {
     Slot *table;
     unsigned long long cap;
     uint32_t *pslot;
-    uint32_t *list;
+    uint32_t *parr;      // arrival position of each point inside its voxel
+    uint32_t *list;      // per-voxel segments: point indices sorted ascending (first max_points valid)
+    uint32_t *unsorted;  // per-voxel segments in arrival order
     uint32_t *voff;
     unsigned long long *bsum;
     int32_t *newid;
@@ -511,7 +580,9 @@ static VoxelWs carve(void *ws, size_t ws_bytes, int64_t n, int64_t nvox)
     r.cap = table_capacity(n);
     r.table = w.take<Slot>(r.cap);
     r.pslot = w.take<uint32_t>(npad);
+    r.parr = w.take<uint32_t>(npad);
     r.list = w.take<uint32_t>(npad + 4);
+    r.unsorted = w.take<uint32_t>(npad + 4);
     r.voff = w.take<uint32_t>(npad + 4);
     r.bsum = w.take<unsigned long long>(d3d_divup(m > 0 ? m : 1, kScanTile) + 1);
     r.newid = w.take<int32_t>(nvox > 0 ? nvox : 1);
@@ -526,22 +597,40 @@ static inline unsigned grid_for(int64_t work, int block, int64_t maxblocks = 256
     return (unsigned)(g < maxblocks ? g : maxblocks);
 }
 
-template <class Key>
+template <class Key, bool PK>
 static int build_table(const Key &kf, const float *points, int64_t n, int c, const VoxelWs &w, int64_t *counts,
                        uint32_t max_points, hipStream_t st)
 {
     const int64_t npad = d3d_divup(n > 0 ? n : 1, kScanTile) * kScanTile;
-    const int64_t nlist = max_points ? npad + 4 - ((npad + 4) & 3) : 0;
     D3D_LAUNCH("k_init", k_init, dim3(grid_for((int64_t)w.cap, 256)), dim3(256), 0, st, w.table, (int64_t)w.cap, w.list,
-                       nlist, counts);
+               (int64_t)0, counts, PK ? kNoVoxel : 0u);
     const bool vec4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0);
     dim3 grid((unsigned)d3d_divup(npad, 256));
+    uint32_t *parr = max_points ? w.parr : nullptr;
     if (vec4)
-        D3D_LAUNCH("k_insert", (k_insert<Key, true>), grid, dim3(256), 0, st, kf, points, n, c, w.table, w.cap - 1, w.pslot,
-                           npad, counts);
+        D3D_LAUNCH("k_insert", (k_insert<Key, true, PK>), grid, dim3(256), 0, st, kf, points, n, c, w.table, w.cap - 1,
+                   w.pslot, parr, npad, counts);
     else
-        D3D_LAUNCH("k_insert", (k_insert<Key, false>), grid, dim3(256), 0, st, kf, points, n, c, w.table, w.cap - 1, w.pslot,
-                           npad, counts);
+        D3D_LAUNCH("k_insert", (k_insert<Key, false, PK>), grid, dim3(256), 0, st, kf, points, n, c, w.table, w.cap - 1,
+                   w.pslot, parr, npad, counts);
+    return D3D_OK;
+}
+
+// table + first-seen numbering + per-voxel sorted index lists for the dense contract
+template <bool PK>
+static int dense_index(const DenseKey &kf, const float *points, int64_t n, int c, const VoxelWs &w, int64_t *counts,
+                       int64_t *coords, int32_t *npoints, uint32_t max_points, uint32_t max_voxels, hipStream_t st)
+{
+    int rc = build_table<DenseKey, PK>(kf, points, n, c, w, counts, max_points, st);
+    if (rc) return rc;
+    NumberVoxels<DenseKey, PK> nv{kf, w.table, w.pslot, w.voff, coords, npoints, max_points, max_voxels};
+    rc = d3d_run_scan(nv, n, w.bsum, counts, D3D_COUNT_VOXELS, D3D_COUNT_AUX, (unsigned long long)max_voxels, st);
+    if (rc) return rc;
+    if (n == 0 || max_voxels == 0 || max_points == 0) return D3D_OK;
+    D3D_LAUNCH("k_scatter", k_scatter<PK>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, w.table, w.pslot,
+               w.parr, w.voff, w.unsorted, w.list);
+    D3D_LAUNCH("k_select", k_select, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, w.pslot, w.parr,
+               w.unsorted, w.list, max_points);
     return D3D_OK;
 }
 
@@ -580,19 +669,20 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
         volatile float sz = diff / (float)shape[d];
         kf.size[d] = sz;
     }
-    int rc = build_table(kf, points, n, c, w, counts, (uint32_t)max_points, st);
-    if (rc) return rc;
-
-    NumberVoxels<DenseKey> nv{kf, w.table, w.pslot, w.voff, coords, npoints,
-                              reduction != D3D_REDUCE_NONE ? aggregates : nullptr, c, reduction,
-                              (uint32_t)max_points, (uint32_t)max_voxels};
-    rc = d3d_run_scan(nv, n, w.bsum, counts, D3D_COUNT_VOXELS, D3D_COUNT_AUX, (unsigned long long)max_voxels, st);
+    // packed slots (claim + count in one 64-bit atomic) whenever key and count fit 40 + 24 bits
+    const double cells = (double)shape[0] * (double)shape[1] * (double)shape[2];
+    if (cells >= 9.0e18) return D3D_ERR_BAD_ARG;
+    // D3D_FORCE_PLAIN_SLOTS=1 selects the general layout (test hook for the n >= 2^24 path)
+    const char *force_plain = getenv("D3D_FORCE_PLAIN_SLOTS");
+    const bool packed = cells < 1.0e12 && n < (1ll << kCntBits) && !(force_plain && force_plain[0] == '1');
+    int rc = packed ? dense_index<true>(kf, points, n, c, w, counts, coords, npoints, (uint32_t)max_points,
+                                        (uint32_t)max_voxels, st)
+                    : dense_index<false>(kf, points, n, c, w, counts, coords, npoints, (uint32_t)max_points,
+                                         (uint32_t)max_voxels, st);
     if (rc) return rc;
     if (n == 0 || max_voxels == 0) return D3D_OK;
 
     if (max_points > 0) {
-        D3D_LAUNCH("k_rank", k_rank, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, points, n, c, w.table, w.pslot,
-                           w.voff, w.list, (uint32_t)max_points, reduction, aggregates);
         const int64_t cap = n < max_voxels ? n : (int64_t)max_voxels;
         const bool vec4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
                           ((reinterpret_cast<uintptr_t>(voxels) & 15) == 0);
@@ -610,7 +700,7 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
         const int64_t cap = n < max_voxels ? n : (int64_t)max_voxels;
         if (max_points == 0) return D3D_ERR_UNSUPPORTED;   // aggregates need the lists (documented)
         D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(cap * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
-                           w.voff, w.list, (uint32_t)max_points, reduction, aggregates);
+                           w.voff, w.list, w.unsorted, (uint32_t)max_points, reduction, aggregates);
     }
     return D3D_OK;
 }
@@ -627,9 +717,9 @@ extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c,
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     SparseKey kf;
     for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
-    int rc = build_table(kf, points, n, c, w, counts, 0u, st);
+    int rc = build_table<SparseKey, false>(kf, points, n, c, w, counts, 0u, st);
     if (rc) return rc;
-    NumberVoxels<SparseKey> nv{kf, w.table, w.pslot, w.voff, coords, npoints, nullptr, c, 0, 0u, 0xffffffffu};
+    NumberVoxels<SparseKey, false> nv{kf, w.table, w.pslot, w.voff, coords, npoints, 0u, 0xffffffffu};
     rc = d3d_run_scan(nv, n, w.bsum, counts, D3D_COUNT_VOXELS, -1, ~0ull, st);
     if (rc) return rc;
     if (n > 0) {

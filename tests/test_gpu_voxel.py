@@ -175,3 +175,15 @@ def test_full_size_cfg2_properties():
     assert np.array_equal(d.coords.cpu().numpy(), exp["coords"])
     assert np.array_equal(d.voxel_npoints.cpu().numpy(), exp["voxel_npoints"])
     assert np.array_equal(d.voxels[:, 0].cpu().numpy(), exp["voxels"][:, 0])
+
+
+def test_plain_slot_layout_matches(monkeypatch):
+    """the general (unpacked) hash-slot layout used for n >= 2^24 points gives the same results"""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    monkeypatch.setenv("D3D_FORCE_PLAIN_SLOTS", "1")
+    cloud = synth.lidar_like(60000, 17)
+    kw = dict(reduction="mean", max_points=6, max_voxels=30000, dense=True)
+    exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(cloud)
+    ret = _np(VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(torch.from_numpy(cloud).cuda()))
+    check_dense(ret, exp, 6)
