@@ -34,6 +34,7 @@ struct __attribute__((aligned(16))) Slot {
     uint32_t first;   // min point index
     uint32_t cnt;     // plain: count; packed: voxel id
 };
+constexpr int kReduceSum = 4;   // internal: MEAN without the division (per-rank partial of the sharded voxelizer)
 constexpr int kCntBits = 24;
 constexpr uint32_t kCntMask = (1u << kCntBits) - 1u;
 template <bool PK> __device__ __forceinline__ uint32_t slot_cnt(const uint4 &s) { return PK ? (s.x & kCntMask) : s.w; }
@@ -191,6 +192,8 @@ struct NumberVoxels {
     int32_t *npoints;     // [cap_voxels]
     uint32_t max_points;  // 0 -> no lists (sparse contract)
     uint32_t max_voxels;
+    int64_t *first_out;   // optional [cap_voxels]: global index of each voxel's first point
+    int64_t index_offset; // added to point indices in first_out (rank shard offset)
 
     __device__ __forceinline__ unsigned long long value(int64_t i) const
     {
@@ -228,6 +231,7 @@ struct NumberVoxels {
         coords[(int64_t)vid * 3 + 1] = cc[1];
         coords[(int64_t)vid * 3 + 2] = cc[2];
         npoints[vid] = (int32_t)slot_cnt<PK>(s);
+        if (first_out) first_out[vid] = index_offset + i;
     }
 };
 
@@ -374,6 +378,7 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
     const int64_t total = counts[D3D_COUNT_VOXELS] * (int64_t)c;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int lane = threadIdx.x & (kWave - 1);
+    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
     // `wbase` is wave-uniform so that the whole wavefront stays in the loop for the cooperative part
     for (int64_t wbase = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; wbase < total; wbase += stride) {
         const int64_t t = wbase + lane;
@@ -383,10 +388,10 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
         const uint32_t cnt = valid ? (uint32_t)npoints[v] : 0u;
         if (valid && cnt <= max_points) {
             const uint32_t base = voff[v];
-            float acc = reduction == D3D_REDUCE_MEAN ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+            float acc = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
             for (uint32_t k = 0; k < cnt; k++) {
                 float x = points[(int64_t)list[base + k] * c + d];
-                if (reduction == D3D_REDUCE_MEAN) acc += x;
+                if (is_sum) acc += x;
                 else if (reduction == D3D_REDUCE_MAX) acc = acc < x ? x : acc;   // std::max(acc, x)
                 else acc = x < acc ? x : acc;                                      // std::min(acc, x)
             }
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
             float ext = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
             for (uint32_t k = lane; k < cc; k += kWave) {
                 float x = points[(int64_t)seg[k] * c + dd];
-                if (reduction == D3D_REDUCE_MEAN) sum += (double)x;
+                if (is_sum) sum += (double)x;
                 else if (reduction == D3D_REDUCE_MAX) ext = ext < x ? x : ext;
                 else ext = x < ext ? x : ext;
             }
@@ -421,18 +426,25 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
                 if (reduction == D3D_REDUCE_MAX) ext = ext < e2 ? e2 : ext;
                 else ext = e2 < ext ? e2 : ext;
             }
-            if (lane == l) agg[t] = reduction == D3D_REDUCE_MEAN ? (float)sum / (float)(int32_t)cc : ext;
+            if (lane == l)
+                agg[t] = reduction == D3D_REDUCE_MEAN ? (float)sum / (float)(int32_t)cc : (is_sum ? (float)sum : ext);
         }
     }
 }
 
+template <bool PK>
 __global__ __launch_bounds__(256) void k_map(const Slot *table, const uint32_t *__restrict__ pslot, int64_t n,
                                              int64_t *mapping)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t ps = pslot[i] & ~kFirstBit;
-    mapping[i] = ps == kNoSlot ? -1ll : (long long)table[ps].first;
+    long long m = -1;
+    if (ps != kNoSlot) {
+        uint32_t vid = slot_vid<PK>(reinterpret_cast<const uint4 *>(table)[ps]);
+        if (vid != kNoVoxel) m = (long long)vid;
+    }
+    mapping[i] = m;
 }
 
 // ------------------------------------------------------------------ filter (direct-addressed by voxel id)
@@ -619,13 +631,17 @@ static int build_table(const Key &kf, const float *points, int64_t n, int c, con
 // table + first-seen numbering + per-voxel sorted index lists for the dense contract
 template <bool PK>
 static int dense_index(const DenseKey &kf, const float *points, int64_t n, int c, const VoxelWs &w, int64_t *counts,
-                       int64_t *coords, int32_t *npoints, uint32_t max_points, uint32_t max_voxels, hipStream_t st)
+                       int64_t *coords, int32_t *npoints, uint32_t max_points, uint32_t max_voxels, hipStream_t st,
+                       int64_t *first_out = nullptr, int64_t index_offset = 0, int64_t *mapping = nullptr)
 {
     int rc = build_table<DenseKey, PK>(kf, points, n, c, w, counts, max_points, st);
     if (rc) return rc;
-    NumberVoxels<DenseKey, PK> nv{kf, w.table, w.pslot, w.voff, coords, npoints, max_points, max_voxels};
+    NumberVoxels<DenseKey, PK> nv{kf, w.table, w.pslot, w.voff, coords, npoints, max_points, max_voxels,
+                                  first_out, index_offset};
     rc = d3d_run_scan(nv, n, w.bsum, counts, D3D_COUNT_VOXELS, D3D_COUNT_AUX, (unsigned long long)max_voxels, st);
     if (rc) return rc;
+    if (mapping && n > 0)   // before k_scatter recycles pslot
+        D3D_LAUNCH("k_map", k_map<PK>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, w.table, w.pslot, n, mapping);
     if (n == 0 || max_voxels == 0 || max_points == 0) return D3D_OK;
     D3D_LAUNCH("k_scatter", k_scatter<PK>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, w.table, w.pslot,
                w.parr, w.voff, w.unsorted, w.list);
@@ -705,6 +721,47 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
     return D3D_OK;
 }
 
+// The "voxel feature grid" without the dense [V,P,C] copy: first-seen voxel ids, counts, per-voxel
+// reduction of all in-range points, point -> voxel map and each voxel's first point index.  Same grid
+// semantics as d3d_voxelize_3d_dense (voxelize.cpp:100-101).  Used stand-alone ("dynamic voxelization")
+// and as the per-rank stage of the point-sharded voxelizer (d3d_amd/voxel/sharded.py).
+extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
+                                      int32_t reduction, int64_t index_offset, int64_t *coords, int32_t *npoints,
+                                      float *aggregates, int64_t *first, int64_t *mapping, int64_t *counts,
+                                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || c < 3 || !shape || !bound || !counts) return D3D_ERR_BAD_ARG;
+    if (n >= (1ll << 31) - kScanTile) return D3D_ERR_BAD_ARG;
+    if (reduction < D3D_REDUCE_MEAN || reduction > kReduceSum) return D3D_ERR_UNSUPPORTED;
+    if (shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0) return D3D_ERR_BAD_ARG;
+    if (n > 0 && (!points || !coords || !npoints || !aggregates)) return D3D_ERR_BAD_ARG;
+    VoxelWs w = carve(workspace, workspace_bytes, n, 0);
+    if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
+    DenseKey kf;
+    for (int d = 0; d < 3; d++) {
+        kf.lo[d] = bound[d << 1];
+        kf.shape[d] = shape[d];
+        volatile float diff = bound[(d << 1) | 1] - bound[d << 1];
+        volatile float sz = diff / (float)shape[d];
+        kf.size[d] = sz;
+    }
+    const double cells = (double)shape[0] * (double)shape[1] * (double)shape[2];
+    if (cells >= 9.0e18) return D3D_ERR_BAD_ARG;
+    const char *force_plain = getenv("D3D_FORCE_PLAIN_SLOTS");
+    const bool packed = cells < 1.0e12 && n < (1ll << kCntBits) && !(force_plain && force_plain[0] == '1');
+    const uint32_t P = 32;   // voxels up to 32 points are reduced sequentially in point order, larger ones cooperatively
+    int rc = packed ? dense_index<true>(kf, points, n, c, w, counts, coords, npoints, P, 0xffffffffu, st, first,
+                                        index_offset, mapping)
+                    : dense_index<false>(kf, points, n, c, w, counts, coords, npoints, P, 0xffffffffu, st, first,
+                                         index_offset, mapping);
+    if (rc) return rc;
+    if (n == 0) return D3D_OK;
+    D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(n * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
+               w.voff, w.list, w.unsorted, P, reduction, aggregates);
+    return D3D_OK;
+}
+
 extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c, const float *voxel_size,
                                       int64_t *points_mapping, int64_t *coords, int32_t *npoints, int64_t *counts,
                                       void *workspace, size_t workspace_bytes, void *stream)
@@ -719,11 +776,11 @@ extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c,
     for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
     int rc = build_table<SparseKey, false>(kf, points, n, c, w, counts, 0u, st);
     if (rc) return rc;
-    NumberVoxels<SparseKey, false> nv{kf, w.table, w.pslot, w.voff, coords, npoints, 0u, 0xffffffffu};
+    NumberVoxels<SparseKey, false> nv{kf, w.table, w.pslot, w.voff, coords, npoints, 0u, 0xffffffffu, nullptr, 0};
     rc = d3d_run_scan(nv, n, w.bsum, counts, D3D_COUNT_VOXELS, -1, ~0ull, st);
     if (rc) return rc;
     if (n > 0) {
-        D3D_LAUNCH("k_map", k_map, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, w.table, w.pslot, n,
+        D3D_LAUNCH("k_map", k_map<false>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, w.table, w.pslot, n,
                            points_mapping);
     }
     return D3D_OK;

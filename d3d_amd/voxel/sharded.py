@@ -1,0 +1,202 @@
+"""Point-sharded voxelization over the GPUs of one node (north_star; the reference has no distributed code).
+
+One process per GPU; rank r holds a contiguous slice of the frame's points (rank order = point order).
+The result is the voxel feature grid of the WHOLE frame, replicated on every rank, numbered exactly like the
+single-GPU dense contract (first-seen order over the global point index, voxelize.cpp:119), plus the
+point -> voxel map of the rank's own points:
+
+  1. local   d3d_voxelize_3d_reduce: hash the shard, per-voxel partial reduction (SUM / MAX / MIN), count,
+             global index of the voxel's first point                                    [HIP kernels]
+  2. gather  RCCL all-gather of the per-rank occupied-cell key lists (8 B per voxel)     [xGMI]
+  3. slots   every rank marks the gathered keys in a bitmap over the grid and popcount-scans it: identical
+             compact slot numbering on all ranks without exchanging a dictionary          [HIP kernels]
+             (RCCL has no bitwise-OR reduction, so the bitmap itself cannot be all-reduced)
+  4. reduce  RCCL all-reduce of the compact voxel table: SUM of features+counts (or MAX/MIN), MIN of first index
+  5. order   the same bitmap+scan over the first-point indices turns slots into first-seen voxel ids
+
+Exact: coords, counts, numbering, MAX/MIN.  MEAN: the cross-rank sum order differs from a sequential pass
+(as on one GPU for overflow voxels), so it matches within fp32 rounding (rtol 1e-5).
+Collective payloads (config 5, 8 x 1 M points, 5.9 M voxels): all-gather 8 B/voxel-occurrence (~47 MB),
+all-reduce (C+1) x 4 B + 8 B per voxel (~164 MB) -- sized for few large collectives over the 7 xGMI links.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from ..utils import Dict
+
+_REDUCTIONS = {"MEAN": 1, "MAX": 2, "MIN": 3}
+_SUM = 4
+_I64_MAX = (1 << 63) - 1
+
+
+class TorchComm:
+    """torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU) behind the three collectives used."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_gather_int(self, value, device):
+        t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+        out = torch.empty((self.world,), dtype=torch.int64, device=device)
+        self._dist.all_gather_into_tensor(out, t, group=self.group)
+        return [int(x) for x in out.tolist()]
+
+    def all_gather_var(self, t, sizes):
+        """concatenate 1-D tensors of different lengths in rank order (pad to the max, one collective)"""
+        cap = max(max(sizes), 1)
+        pad = torch.zeros((cap,), dtype=t.dtype, device=t.device)
+        pad[:t.numel()] = t
+        out = torch.empty((self.world * cap,), dtype=t.dtype, device=t.device)
+        self._dist.all_gather_into_tensor(out, pad, group=self.group)
+        return torch.cat([out[r * cap:r * cap + sizes[r]] for r in range(self.world)])
+
+    def all_reduce(self, t, op):
+        ops = {"sum": self._dist.ReduceOp.SUM, "max": self._dist.ReduceOp.MAX, "min": self._dist.ReduceOp.MIN}
+        self._dist.all_reduce(t, op=ops[op], group=self.group)
+        return t
+
+
+class HipOps:
+    """the compute steps, on the HIP kernels of libd3d_hip.so"""
+
+    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset):
+        lib = _lib.load()
+        pts = points.contiguous()
+        dev = pts.device
+        n, c = pts.shape
+        shape_h = (ctypes.c_int32 * 3)(*[int(x) for x in shape])
+        bound_h = (ctypes.c_float * 6)(*[float(x) for x in bounds])
+        with torch.cuda.device(dev):
+            coords = torch.empty((n, 3), dtype=torch.int64, device=dev)
+            cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+            agg = torch.empty((n, c), dtype=torch.float32, device=dev)
+            first = torch.empty((n,), dtype=torch.int64, device=dev)
+            mapping = torch.empty((n,), dtype=torch.int64, device=dev)
+            counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+            ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
+            rc = lib.d3d_voxelize_3d_reduce(
+                _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
+                int(reduction), int(index_offset), _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first),
+                _lib.ptr(mapping), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "voxelize_3d_reduce")
+            host = counts.cpu()
+            if int(host[_lib.COUNT_STATUS]) & _lib.STATUS_TABLE_FULL:
+                raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
+            v = int(host[_lib.COUNT_VOXELS])
+        return coords[:v], cnt[:v], agg[:v], first[:v], mapping
+
+    def compact_index(self, keys, ncells):
+        """-> (handle, number of distinct keys); handle feeds compact_lookup"""
+        lib = _lib.load()
+        dev = keys.device
+        keys = keys.contiguous()
+        with torch.cuda.device(dev):
+            ws = torch.empty((lib.d3d_grid_compact_workspace_bytes(ncells),), dtype=torch.uint8, device=dev)
+            counts = torch.zeros((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+            rc = lib.d3d_grid_compact_index(_lib.ptr(keys), keys.numel(), int(ncells), _lib.ptr(counts), _lib.ptr(ws),
+                                            ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "grid_compact_index")
+            total = int(counts.cpu()[0])
+        return (ws, int(ncells)), total
+
+    def compact_lookup(self, handle, keys):
+        lib = _lib.load()
+        ws, ncells = handle
+        dev = keys.device
+        keys = keys.contiguous()
+        with torch.cuda.device(dev):
+            slot = torch.empty((keys.numel(),), dtype=torch.int64, device=dev)
+            rc = lib.d3d_grid_compact_lookup(_lib.ptr(keys), keys.numel(), ncells, _lib.ptr(ws), ws.numel(),
+                                             _lib.ptr(slot), _lib.stream_ptr())
+            _lib.check(rc, "grid_compact_lookup")
+        return slot
+
+
+def voxelize_reduce(points, shape, bounds, reduction="mean"):
+    """single-GPU "dynamic voxelization": Dict(coords, voxel_npoints, aggregates, points_mapping, voxel_first)"""
+    red = _REDUCTIONS[reduction.upper()]
+    coords, cnt, agg, first, mapping = HipOps().voxelize_reduce(points, shape, bounds, red, 0)
+    return Dict(coords=coords, voxel_npoints=cnt, aggregates=agg, points_mapping=mapping, voxel_first=first)
+
+
+class ShardedVoxelGenerator:
+    """Voxel feature grid of a frame whose points are sharded over the ranks of `group` (contiguous slices in
+    rank order).  Grid arguments as d3d.voxel.VoxelGenerator (bounds, shape); reduction in {mean, max, min}."""
+
+    def __init__(self, bounds, shape, reduction="mean", group=None, comm=None, ops=None):
+        key = (reduction or "").upper()
+        if key not in _REDUCTIONS:
+            raise ValueError("Unsupported reduction type in VoxelGenerator!")
+        self._red = _REDUCTIONS[key]
+        self._bounds = [float(b) for b in bounds]
+        self._shape = [int(s) for s in shape]
+        if len(self._bounds) != 6 or len(self._shape) != 3 or min(self._shape) <= 0:
+            raise ValueError("bounds must have 6 entries and shape 3 positive entries")
+        self._ncells = self._shape[0] * self._shape[1] * self._shape[2]
+        self._comm = comm if comm is not None else TorchComm(group)
+        self._ops = ops if ops is not None else HipOps()
+
+    def __call__(self, points):
+        comm, ops = self._comm, self._ops
+        dev = points.device
+        c = points.shape[1]
+        sy, sz = self._shape[1], self._shape[2]
+        # 0. shard offsets in the global point order
+        sizes_n = comm.all_gather_int(points.shape[0], dev)
+        offset, n_total = sum(sizes_n[:comm.rank]), sum(sizes_n)
+        # 1. local hash + partial reduction
+        local_red = _SUM if self._red == 1 else self._red
+        coords_r, cnt_r, agg_r, first_r, map_r = ops.voxelize_reduce(points, self._shape, self._bounds, local_red, offset)
+        keys_r = (coords_r[:, 0] * sy + coords_r[:, 1]) * sz + coords_r[:, 2]
+        # 2. all-gather the occupied-cell keys
+        sizes_v = comm.all_gather_int(keys_r.numel(), dev)
+        keys_all = comm.all_gather_var(keys_r, sizes_v)
+        # 3. identical compact slots on every rank
+        handle, nvox = ops.compact_index(keys_all, self._ncells)
+        slot_r = ops.compact_lookup(handle, keys_r)
+        slot_all = ops.compact_lookup(handle, keys_all)
+        key_of_slot = torch.empty((nvox,), dtype=torch.int64, device=dev)
+        key_of_slot[slot_all] = keys_all                      # duplicates write the same value
+        # 4. all-reduce the compact voxel table
+        if self._red == 1:
+            table = torch.zeros((nvox, c + 1), dtype=torch.float32, device=dev)
+            table[slot_r, :c] = agg_r
+            table[slot_r, c] = cnt_r.to(torch.float32)        # counts < 2^24 are exact in fp32
+            comm.all_reduce(table, "sum")
+            cnt = table[:, c].round().to(torch.int32)
+            feats = table[:, :c] / table[:, c:c + 1]
+        else:
+            init = float("-inf") if self._red == 2 else float("inf")
+            feats = torch.full((nvox, c), init, dtype=torch.float32, device=dev)
+            feats[slot_r] = agg_r
+            comm.all_reduce(feats, "max" if self._red == 2 else "min")
+            cnt = torch.zeros((nvox,), dtype=torch.int32, device=dev)
+            cnt[slot_r] = cnt_r
+            comm.all_reduce(cnt, "sum")
+        first = torch.full((nvox,), _I64_MAX, dtype=torch.int64, device=dev)
+        first[slot_r] = first_r
+        comm.all_reduce(first, "min")
+        # 5. first-seen numbering: rank of each voxel's first point index among all first indices
+        handle2, nfirst = ops.compact_index(first, max(n_total, 1))
+        assert nfirst == nvox, "every voxel has a distinct first point"
+        vid_of_slot = ops.compact_lookup(handle2, first)
+        coords = torch.empty((nvox, 3), dtype=torch.int64, device=dev)
+        k = key_of_slot
+        coords[vid_of_slot] = torch.stack([k // (sy * sz), (k // sz) % sy, k % sz], 1)
+        out_cnt = torch.empty_like(cnt)
+        out_cnt[vid_of_slot] = cnt
+        out_feats = torch.empty_like(feats)
+        out_feats[vid_of_slot] = feats
+        gmap = torch.full_like(map_r, -1)
+        ok = map_r >= 0
+        gmap[ok] = vid_of_slot[slot_r[map_r[ok]]]
+        return Dict(coords=coords, voxel_npoints=out_cnt, aggregates=out_feats, points_mapping=gmap)
+
+
+__all__ = ["ShardedVoxelGenerator", "TorchComm", "HipOps", "voxelize_reduce"]

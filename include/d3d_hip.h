@@ -100,6 +100,32 @@ int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c,
                            int32_t *out_npoints, int64_t *out_coords,
                            int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- beyond the reference: the point-sharded voxelizer of north_star (d3d has no distributed code) ---- */
+
+/* Voxel feature grid without the dense [V,P,C] copy ("dynamic voxelization"): grid semantics of
+ * d3d_voxelize_3d_dense (voxelize.cpp:100-101), first-seen voxel ids (voxelize.cpp:119), reduction over
+ * ALL in-range points (voxelize.cpp:137-164).  reduction: MEAN/MAX/MIN or 4 = SUM (MEAN without the division).
+ *   coords[n,3] i64, npoints[n] i32, aggregates[n,c] f32, first[n] i64 (index_offset + index of the voxel's first
+ *   point; may be NULL), mapping[n] i64 (voxel id per point, -1 = out of range; may be NULL). */
+int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
+                           int32_t reduction, int64_t index_offset, int64_t *coords, int32_t *npoints,
+                           float *aggregates, int64_t *first, int64_t *mapping, int64_t *counts,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* Rank-independent compact numbering of occupied cells: mark keys[m] (linear cell index in [0,ncells)) in a
+ * bitmap, popcount-prefix it; counts[0] = distinct occupied cells.  lookup: slot[j] = index of keys[j] among the
+ * occupied cells in ascending key order (-1 when unmarked).  Both use the same workspace. */
+size_t d3d_grid_compact_workspace_bytes(int64_t ncells);
+int d3d_grid_compact_index(const int64_t *keys, int64_t m, int64_t ncells, int64_t *counts,
+                           void *workspace, size_t workspace_bytes, void *stream);
+int d3d_grid_compact_lookup(const int64_t *keys, int64_t m, int64_t ncells, const void *workspace,
+                            size_t workspace_bytes, int64_t *slot, void *stream);
+
+/* opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline leg);
+ * report: "kernel,calls,total_ms" lines. */
+int d3d_profile_enable(int on);
+int d3d_profile_report(char *buf, size_t buf_bytes);
+
 /* -------------------------------------------------------------------- d3d/box */
 
 /* replaces iou2d_forward[_cuda] (method BOX) and the `ious` output of
