@@ -1,0 +1,58 @@
+"""CPU: the C-ABI library loads and exports every symbol include/d3d_hip.h declares (no compute calls);
+the host-side layer validates arguments like the reference without touching a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "d3d_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(d3d_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from d3d_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libd3d_hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "d3d_amd/_lib.py does not bind %s" % n
+    assert set(_lib.SIGNATURES) <= set(names)
+    assert _lib.load().d3d_abi_version() == 1
+    assert _lib.load().d3d_status_string(-2) == b"unsupported option"
+
+
+def test_workspace_queries_are_pure():
+    from d3d_amd import _lib
+    lib = _lib.load()
+    assert lib.d3d_voxelize_workspace_bytes(1000000, 0) > 16 * 2 * 1000000
+    assert lib.d3d_nms2d_workspace_bytes(100000) > 100000 * (100000 // 64) * 8
+    assert lib.d3d_argsort_desc_workspace_bytes(1000, 1) > 0
+    assert lib.d3d_grid_compact_workspace_bytes(704 * 800 * 40) > 704 * 800 * 40 // 8
+
+
+def test_host_side_validation_without_gpu():
+    import torch
+    from d3d_amd.box import IouType, SupressionType, box2d_iou, box2d_nms
+    from d3d_amd.voxel import MaxPointsFilterType, ReductionType, VoxelGenerator
+    assert ReductionType.MIN == 3 and MaxPointsFilterType.TRIM == 1 and IouType.DRBOX == 6 and SupressionType.GAUSSIAN == 2
+    g = VoxelGenerator([0, 70.4, -40, 40, -3, 1], [704, 800, 40], max_points=32)
+    assert g._vbounds.tolist() == [[0, 704], [-400, 400], [-30, 10]] and g._offset.tolist() == [0, -400, -30]
+    with pytest.raises(ValueError):
+        VoxelGenerator([0.05, 1, 0, 1, 0, 1], [10, 10, 10])
+    with pytest.raises(ValueError):
+        VoxelGenerator([0, 1, 0, 1, 0, 1], [10, 10, 10], reduction="median", dense=True)
+    with pytest.raises(ValueError):
+        box2d_iou(torch.zeros(3, 4), torch.zeros(3, 5))
+    with pytest.raises(ValueError):
+        box2d_nms(torch.zeros(3, 5), torch.zeros(2))
+    assert box2d_nms(torch.zeros(0, 5), torch.zeros(0)).numel() == 0
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):          # no silent CPU fallback
+            g(torch.zeros(4, 4))
