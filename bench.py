@@ -222,9 +222,11 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
         # compulsory bytes of each kernel per launch (DESIGN.md "kernels"); C = 4
         algo = {
-            "k_fill_c4": V * P * 16 + kept * (16 + 4),                       # voxels[V,P,4] written + kept rows gathered
-            "k_insert": n * 16 + n * 4 + n * 16,                              # points read, pslot written, one slot touched
-            "k_rank": n * 4 + n * 16 + kept * 4,
+            # voxels[V,P,4] written, kept rows (16 B point + 4 B index) gathered
+            "k_fill_c4": V * P * 16 + kept * (16 + 4),
+            "k_insert": n * 16 + n * 8 + n * 8,          # points read, pslot+arrival written, one 8-byte slot touched
+            "k_scatter": n * 8 + n * 8 + n * 4 + n * 8,  # pslot+arrival read, aux read, index written, (cnt,base) written
+            "k_select": n * 8 + kept * 4,
             "k_init": None,
         }
         name = dom[0]

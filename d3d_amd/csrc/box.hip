@@ -32,25 +32,52 @@ struct Box3DGeom {
 };
 
 // ---------------------------------------------------------------- pairwise IoU, 2-D boxes
-template <typename T, bool ROTATED>
+// K = columns per lane.  K = 16 / sizeof(T) makes every lane store 16 bytes per row (1 KiB per
+// wave-instruction, the widest coalesced store) -- used whenever M % K == 0 keeps the rows 16-byte aligned.
+template <typename T, int K> struct VecOf;
+template <> struct VecOf<double, 2> { typedef double2 type; };
+template <> struct VecOf<float, 4> { typedef float4 type; };
+template <> struct VecOf<double, 1> { typedef double type; };
+template <> struct VecOf<float, 1> { typedef float type; };
+
+template <typename T, int K> __device__ __forceinline__ void store_row(T *out, const T (&v)[K])
+{
+    if constexpr (K == 1) __builtin_nontemporal_store(v[0], out);
+    else if constexpr (K == 2) {
+        typedef T vec2 __attribute__((ext_vector_type(2)));
+        vec2 x = {v[0], v[1]};
+        __builtin_nontemporal_store(x, reinterpret_cast<vec2 *>(out));
+    } else {
+        typedef T vec4 __attribute__((ext_vector_type(4)));
+        vec4 x = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(x, reinterpret_cast<vec4 *>(out));
+    }
+}
+
+template <typename T, bool ROTATED, int K>
 __global__ __launch_bounds__(kTileCols) void k_iou2d(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2,
                                                      int64_t m, T *__restrict__ ious)
 {
     __shared__ BoxGeom<T> rows[kTileRows];
     const int64_t i0 = (int64_t)blockIdx.y * kTileRows;
-    const int64_t j = (int64_t)blockIdx.x * kTileCols + threadIdx.x;
+    const int64_t j0 = ((int64_t)blockIdx.x * kTileCols + threadIdx.x) * K;
     const int nrows = (int)((n - i0) < kTileRows ? (n - i0) : kTileRows);
     if (threadIdx.x < nrows) rows[threadIdx.x] = Box2D<T>::load(b1 + (i0 + threadIdx.x) * 5);
-    BoxGeom<T> col;
-    const bool active = j < m;
-    if (active) col = Box2D<T>::load(b2 + j * 5);
+    BoxGeom<T> col[K];
+    const bool active = j0 < m;      // M % K == 0 (host-checked): a lane's K columns are all valid or all not
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < K; k++) col[k] = Box2D<T>::load(b2 + (j0 + k) * 5);
+    }
     __syncthreads();
     if (!active) return;
-    T *out = ious + i0 * m + j;
+    T *out = ious + i0 * m + j0;
     for (int r = 0; r < nrows; r++) {
-        const BoxGeom<T> &a = rows[r];      // LDS broadcast read
-        T v = ROTATED ? iou_rbox(a, col) : iou_aabb(a, col);
-        __builtin_nontemporal_store(v, out);
+        const BoxGeom<T> a = rows[r];      // LDS broadcast read
+        T v[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) v[k] = ROTATED ? iou_rbox(a, col[k]) : iou_aabb(a, col[k]);
+        store_row<T, K>(out, v);
         out += m;
     }
 }
@@ -66,33 +93,40 @@ __device__ __forceinline__ Box3DGeom load3d(const float *b)
     return r;
 }
 
-template <bool ROTATED>
+template <bool ROTATED, int K>
 __global__ __launch_bounds__(kTileCols) void k_iou3d(const float *__restrict__ b1, int64_t n,
                                                      const float *__restrict__ b2, int64_t m, float *__restrict__ out_)
 {
     __shared__ Box3DGeom rows[kTileRows];
     const int64_t i0 = (int64_t)blockIdx.y * kTileRows;
-    const int64_t j = (int64_t)blockIdx.x * kTileCols + threadIdx.x;
+    const int64_t j0 = ((int64_t)blockIdx.x * kTileCols + threadIdx.x) * K;
     const int nrows = (int)((n - i0) < kTileRows ? (n - i0) : kTileRows);
     if (threadIdx.x < nrows) rows[threadIdx.x] = load3d(b1 + (i0 + threadIdx.x) * 7);
-    Box3DGeom col;
-    const bool active = j < m;
-    if (active) col = load3d(b2 + j * 7);
+    Box3DGeom col[K];
+    const bool active = j0 < m;
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < K; k++) col[k] = load3d(b2 + (j0 + k) * 7);
+    }
     __syncthreads();
     if (!active) return;
-    float *out = out_ + i0 * m + j;
+    float *out = out_ + i0 * m + j0;
     for (int r = 0; r < nrows; r++) {
-        const Box3DGeom &a = rows[r];
-        float iou2d = ROTATED ? iou_rbox(a.g, col.g) : iou_aabb(a.g, col.g);
-        float v = 0.f;
-        if (iou2d != 0.f) {
-            float imax = fminf(a.zmax, col.zmax), imin = fmaxf(a.zmin, col.zmin);
-            float umax = fmaxf(a.zmax, col.zmax), umin = fminf(a.zmin, col.zmin);
-            float i = fmaxf(imax - imin, 0.f);
-            float u = fmaxf(umax - umin, (float)1e-6);
-            v = iou2d * (i / u);
+        const Box3DGeom a = rows[r];
+        float v[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            float iou2d = ROTATED ? iou_rbox(a.g, col[k].g) : iou_aabb(a.g, col[k].g);
+            v[k] = 0.f;
+            if (iou2d != 0.f) {
+                float imax = fminf(a.zmax, col[k].zmax), imin = fmaxf(a.zmin, col[k].zmin);
+                float umax = fmaxf(a.zmax, col[k].zmax), umin = fminf(a.zmin, col[k].zmin);
+                float i = fmaxf(imax - imin, 0.f);
+                float u = fmaxf(umax - umin, (float)1e-6);
+                v[k] = iou2d * (i / u);
+            }
         }
-        __builtin_nontemporal_store(v, out);
+        store_row<float, K>(out, v);
         out += m;
     }
 }
@@ -229,19 +263,21 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     if (!boxes1 || !boxes2 || !ious) return D3D_ERR_BAD_ARG;
     const int64_t gy = d3d_divup(n, kTileRows);
     if (gy > 65535) return D3D_ERR_BAD_ARG;   // 4.19 M rows per call; callers tile above that
-    dim3 grid((unsigned)d3d_divup(m, kTileCols), (unsigned)gy);
     const bool rot = iou_type == D3D_IOU_RBOX;
+    const bool al16 = (reinterpret_cast<uintptr_t>(ious) & 15) == 0;
+#define D3D_IOU2D(T, R, K)                                                                                          \
+    D3D_LAUNCH("k_iou2d", (k_iou2d<T, R, K>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols * K), (unsigned)gy),   \
+               dim3(kTileCols), 0, st, (const T *)boxes1, n, (const T *)boxes2, m, (T *)ious)
     if (dtype == D3D_F64) {
-        if (rot) D3D_LAUNCH("k_iou2d", (k_iou2d<double, true>), grid, dim3(kTileCols), 0, st, (const double *)boxes1, n,
-                                    (const double *)boxes2, m, (double *)ious);
-        else D3D_LAUNCH("k_iou2d", (k_iou2d<double, false>), grid, dim3(kTileCols), 0, st, (const double *)boxes1, n,
-                                (const double *)boxes2, m, (double *)ious);
+        const bool vec = al16 && (m % 2 == 0);
+        if (rot) { if (vec) D3D_IOU2D(double, true, 2); else D3D_IOU2D(double, true, 1); }
+        else     { if (vec) D3D_IOU2D(double, false, 2); else D3D_IOU2D(double, false, 1); }
     } else {
-        if (rot) D3D_LAUNCH("k_iou2d", (k_iou2d<float, true>), grid, dim3(kTileCols), 0, st, (const float *)boxes1, n,
-                                    (const float *)boxes2, m, (float *)ious);
-        else D3D_LAUNCH("k_iou2d", (k_iou2d<float, false>), grid, dim3(kTileCols), 0, st, (const float *)boxes1, n,
-                                (const float *)boxes2, m, (float *)ious);
+        const bool vec = al16 && (m % 4 == 0);
+        if (rot) { if (vec) D3D_IOU2D(float, true, 4); else D3D_IOU2D(float, true, 1); }
+        else     { if (vec) D3D_IOU2D(float, false, 4); else D3D_IOU2D(float, false, 1); }
     }
+#undef D3D_IOU2D
     return D3D_OK;
 }
 
@@ -253,9 +289,14 @@ extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *bo
     if (n == 0 || m == 0) return D3D_OK;
     if (!boxes1 || !boxes2 || !out) return D3D_ERR_BAD_ARG;
     if (d3d_divup(n, kTileRows) > 65535) return D3D_ERR_BAD_ARG;
-    dim3 grid((unsigned)d3d_divup(m, kTileCols), (unsigned)d3d_divup(n, kTileRows));
-    if (rotated) D3D_LAUNCH("k_iou3d", k_iou3d<true>, grid, dim3(kTileCols), 0, st, boxes1, n, boxes2, m, out);
-    else D3D_LAUNCH("k_iou3d", k_iou3d<false>, grid, dim3(kTileCols), 0, st, boxes1, n, boxes2, m, out);
+    const unsigned gy = (unsigned)d3d_divup(n, kTileRows);
+    const bool vec = (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (m % 4 == 0);
+#define D3D_IOU3D(R, K)                                                                                            \
+    D3D_LAUNCH("k_iou3d", (k_iou3d<R, K>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols * K), gy), dim3(kTileCols), \
+               0, st, boxes1, n, boxes2, m, out)
+    if (rotated) { if (vec) D3D_IOU3D(true, 4); else D3D_IOU3D(true, 1); }
+    else         { if (vec) D3D_IOU3D(false, 4); else D3D_IOU3D(false, 1); }
+#undef D3D_IOU3D
     return D3D_OK;
 }
 

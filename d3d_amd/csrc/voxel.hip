@@ -1,16 +1,18 @@
 // voxel.hip -- point cloud -> voxels on MI355X (gfx950).  Replaces the sequential
 // std::unordered_map loops of the reference (d3d/voxel/voxelize.cpp) with:
 //
-//   insert   one point per lane, coalesced float4 loads, open-addressing hash table in
-//            HBM (16-byte slots {key, first_point, count}); count by atomicAdd, the
-//            voxel's first point index by atomicMin
-//   number   a point is "first" iff slot.first == its index; an exclusive scan of the
-//            first-flags over the point array reproduces the reference's first-seen
-//            voxel numbering (voxelize.cpp:119,317) with no sort
-//   rank     per-voxel list of the max_points smallest point indices, built by an
-//            atomicMin insertion chain (order independent -> exact, no sort)
-//   fill     streaming write of voxels[V,P,C] (the HBM-roofline kernel), pmask,
-//            aggregates (sequential in point order for voxels that fit -> bit-exact MEAN)
+//   insert   one point per lane, coalesced float4 loads, open-addressing hash table in HBM.  A slot is ONE
+//            64-bit word {count | cell key | first point index}: the first arrival claims + counts + records
+//            itself with a single CAS, later arrivals need a single atomicAdd (which also returns their
+//            arrival position and the current `first`, so the rare "I am smaller" fix-up costs nothing
+//            in the common case).  Scattered device-scope atomics are the scarce resource (~20 G/s).
+//   number   the reference numbers voxels by first occurrence (voxelize.cpp:119,317).  Two coalesced sweeps
+//            over the table: flag[first] = 1, prefix-popcount of the flags = voxel id; the same sweeps
+//            allocate every voxel's index segment (scan of the counts in slot order).  No sort.
+//   rank     scatter indices by arrival position, then rank = number of smaller indices in the segment
+//            (early exit at max_points): exact point order without sorting or atomic chains.
+//   fill     streaming write of voxels[V,P,C] (the HBM-roofline kernel) fused with pmask and the
+//            per-voxel reduction (sequential in point order through wave shuffles -> bit-exact MEAN).
 //
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off (IEEE div, no FMA contraction:
 // voxel coordinates must round exactly like the reference's CPU code).
@@ -19,33 +21,20 @@
 
 namespace {
 
-constexpr unsigned long long kEmptyKey = ~0ull;
-constexpr uint32_t kInf = 0xffffffffu;        // empty list cell / "no first point yet"
-constexpr uint32_t kNoVoxel = 0xffffffffu;    // slot.first after numbering: voxel dropped by max_voxels
-constexpr uint32_t kNoSlot = 0x7fffffffu;     // pslot: point not in any voxel
-constexpr uint32_t kFirstBit = 0x80000000u;   // pslot: this point is the first of its voxel
+typedef unsigned long long u64;
 
-// 16-byte hash slot.  Two layouts (template parameter PK):
-//   plain  : key | first | cnt            voxel id overwrites `first` in the numbering pass
-//   packed : (key << 24 | cnt) | first | vid    -- claim + count in ONE 64-bit atomic (CAS for the
-//            first arrival, atomicAdd afterwards); usable when key < 2^40-1 and n < 2^24
-struct __attribute__((aligned(16))) Slot {
-    unsigned long long key;
-    uint32_t first;   // min point index
-    uint32_t cnt;     // plain: count; packed: voxel id
-};
-constexpr int kReduceSum = 4;   // internal: MEAN without the division (per-rank partial of the sharded voxelizer)
-constexpr int kCntBits = 24;
-constexpr uint32_t kCntMask = (1u << kCntBits) - 1u;
-template <bool PK> __device__ __forceinline__ uint32_t slot_cnt(const uint4 &s) { return PK ? (s.x & kCntMask) : s.w; }
-template <bool PK> __device__ __forceinline__ uint32_t slot_vid(const uint4 &s) { return PK ? s.w : s.z; }
-template <bool PK> __device__ __forceinline__ unsigned long long slot_key(const uint4 &s)
-{
-    unsigned long long k = ((unsigned long long)s.y << 32) | s.x;
-    return PK ? (k >> kCntBits) : k;
-}
+constexpr u64 kEmpty = ~0ull;
+constexpr uint32_t kInf = 0xffffffffu;        // "no first point yet" / empty chain cell (filter)
+constexpr uint32_t kNoVoxel = 0xffffffffu;    // voxel dropped by max_voxels
+constexpr uint32_t kNoSlot = 0xffffffffu;     // pslot: point not in any voxel
+constexpr uint32_t kNoBase = 0xffffffffu;     // aux.base of a dropped voxel
+constexpr int kReduceSum = 4;                 // internal: MEAN without the division (sharded partials)
+constexpr int kSweepTile = 1024;              // slots per block in the table sweeps
+constexpr int kFlagTile = 256 * 64;           // flags per block in k_flagpack
 
-__device__ __forceinline__ unsigned long long mix64(unsigned long long h)
+int g_force_plain = 0;                        // d3d_voxel_force_plain()
+
+__device__ __forceinline__ u64 mix64(u64 h)
 {
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
     h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull;
@@ -58,7 +47,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long h)
 struct DenseKey {
     float lo[3], size[3];
     int shape[3];
-    __device__ __forceinline__ bool make(const float *p, unsigned long long &key, uint32_t &status) const
+    __device__ __forceinline__ bool make(const float *p, u64 &key, uint32_t &status) const
     {
         (void)status;
         int c[3];
@@ -71,10 +60,10 @@ struct DenseKey {
             if (idx < 0 || idx >= shape[d]) return false;
             c[d] = idx;
         }
-        key = ((unsigned long long)c[0] * (unsigned)shape[1] + (unsigned)c[1]) * (unsigned)shape[2] + (unsigned)c[2];
+        key = ((u64)c[0] * (unsigned)shape[1] + (unsigned)c[1]) * (unsigned)shape[2] + (unsigned)c[2];
         return true;
     }
-    __device__ __forceinline__ void decode(unsigned long long key, long long *c) const
+    __device__ __forceinline__ void decode(u64 key, long long *c) const
     {
         c[2] = (long long)(key % (unsigned)shape[2]); key /= (unsigned)shape[2];
         c[1] = (long long)(key % (unsigned)shape[1]);
@@ -85,19 +74,19 @@ struct DenseKey {
 // sparse contract: coord = floor(p / size), unbounded (voxelize.cpp:309); 3 x 21-bit packing
 struct SparseKey {
     float size[3];
-    __device__ __forceinline__ bool make(const float *p, unsigned long long &key, uint32_t &status) const
+    __device__ __forceinline__ bool make(const float *p, u64 &key, uint32_t &status) const
     {
-        unsigned long long k = 0;
+        u64 k = 0;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             float q = floorf(p[d] / size[d]);
             if (!(q >= -1048576.0f && q < 1048576.0f)) { status |= D3D_VOXEL_STATUS_COORD_OVERFLOW; return false; }
-            k = (k << 21) | (unsigned long long)(unsigned)((int)q + 1048576);
+            k = (k << 21) | (u64)(unsigned)((int)q + 1048576);
         }
         key = k;
         return true;
     }
-    __device__ __forceinline__ void decode(unsigned long long key, long long *c) const
+    __device__ __forceinline__ void decode(u64 key, long long *c) const
     {
         c[2] = (long long)(key & 0x1fffff) - 1048576;
         c[1] = (long long)((key >> 21) & 0x1fffff) - 1048576;
@@ -105,169 +94,293 @@ struct SparseKey {
     }
 };
 
-// ------------------------------------------------------------------ kernels
-__global__ void k_init(Slot *table, int64_t cap, uint32_t *list, int64_t nlist, int64_t *counts, uint32_t aux_init)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint4 e = make_uint4(0xffffffffu, 0xffffffffu, kInf, aux_init);
-    uint4 *tb = reinterpret_cast<uint4 *>(table);
-    for (int64_t i = t0; i < cap; i += stride) tb[i] = e;
-    uint4 f = make_uint4(kInf, kInf, kInf, kInf);
-    uint4 *l4 = reinterpret_cast<uint4 *>(list);
-    for (int64_t i = t0; i < nlist / 4; i += stride) l4[i] = f;   // nlist is padded to a multiple of 4
-    if (t0 < D3D_NUM_COUNTS) counts[t0] = 0;
-}
 
-template <class Key, bool VEC4, bool PK>
-__global__ __launch_bounds__(256) void k_insert(Key kf, const float *__restrict__ points, int64_t n, int c,
-                                                Slot *table, unsigned long long mask, uint32_t *pslot,
-                                                uint32_t *parr, int64_t npad, int64_t *counts)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npad) return;
-    uint32_t slot = kNoSlot, status = 0, arrival = 0;
-    if (i < n) {
-        float p[3];
-        if (VEC4) {
-            float4 v = reinterpret_cast<const float4 *>(points)[i];
-            p[0] = v.x; p[1] = v.y; p[2] = v.z;
-        } else {
-            const float *src = points + i * c;
-            p[0] = src[0]; p[1] = src[1]; p[2] = src[2];
-        }
-        unsigned long long key;
-        if (kf.make(p, key, status)) {
-            unsigned long long h = mix64(key) & mask;
-            bool found = false;
-            for (unsigned long long probe = 0; probe <= mask; probe++) {
-                Slot *s = &table[h];
-                unsigned long long k = __hip_atomic_load(&s->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (PK) {
-                    if (k == kEmptyKey) {
-                        unsigned long long old = atomicCAS(&s->key, kEmptyKey, (key << kCntBits) | 1ull);
-                        if (old == kEmptyKey) { found = true; arrival = 0; break; }   // claimed and counted at once
-                        k = old;
-                    }
-                    if ((k >> kCntBits) == key) {
-                        arrival = (uint32_t)(atomicAdd(&s->key, 1ull) & kCntMask);
-                        found = true;
-                        break;
-                    }
-                } else {
-                    if (k == kEmptyKey) {
-                        unsigned long long old = atomicCAS(&s->key, kEmptyKey, key);
-                        k = (old == kEmptyKey) ? key : old;
-                    }
-                    if (k == key) {
-                        arrival = atomicAdd(&s->cnt, 1u);   // arrival position inside the voxel (any order)
-                        found = true;
-                        break;
-                    }
-                }
-                h = (h + 1) & mask;
+// ------------------------------------------------------------------ hash tables
+struct SlotInfo { bool occupied; u64 key; uint32_t first, cnt; };
+
+// Packed table: one u64 per slot = [count : cb][key : kb][first : ib], cb = 64 - kb - ib (>= 8).
+// A count that reaches 2^cb wraps out of the top of the word (nothing else is corrupted); the thread that
+// causes it raises D3D_VOXEL_STATUS_PACK_OVERFLOW and the caller repeats the call with the plain table.
+struct TabPacked {
+    u64 *w;
+    int ib, kb;
+    __device__ __forceinline__ bool insert(u64 key, uint32_t i, u64 mask, uint32_t &slot, uint32_t &arrival,
+                                           uint32_t &status) const
+    {
+        const int cs = ib + kb;
+        const u64 one = 1ull << cs, imask = (1ull << ib) - 1, kmask = (1ull << kb) - 1;
+        u64 h = mix64(key) & mask;
+        for (u64 probe = 0; probe <= mask; probe++) {
+            u64 cur = __hip_atomic_load(&w[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == kEmpty) {
+                u64 old = atomicCAS(&w[h], kEmpty, one | (key << ib) | i);    // claim + count + first, at once
+                if (old == kEmpty) { slot = (uint32_t)h; arrival = 0; return true; }
+                cur = old;
             }
-            if (found) {
+            if (((cur >> ib) & kmask) == key) {
+                u64 old = atomicAdd(&w[h], one);
+                arrival = (uint32_t)(old >> cs);
+                if (arrival == (uint32_t)((1ull << (64 - cs)) - 1)) status |= D3D_VOXEL_STATUS_PACK_OVERFLOW;
+                uint32_t f = (uint32_t)(old & imask);
+                while (i < f) {            // rare: an earlier point arrived later than a later one
+                    u64 expect = __hip_atomic_load(&w[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    f = (uint32_t)(expect & imask);
+                    if (i >= f) break;
+                    if (atomicCAS(&w[h], expect, (expect & ~imask) | i) == expect) break;
+                }
                 slot = (uint32_t)h;
+                return true;
+            }
+            h = (h + 1) & mask;
+        }
+        status |= D3D_VOXEL_STATUS_TABLE_FULL;
+        return false;
+    }
+    __device__ __forceinline__ SlotInfo read(u64 s) const
+    {
+        const u64 v = w[s];
+        SlotInfo r;
+        r.occupied = v != kEmpty;
+        r.first = (uint32_t)(v & ((1ull << ib) - 1));
+        r.key = (v >> ib) & ((1ull << kb) - 1);
+        r.cnt = (uint32_t)(v >> (ib + kb));
+        return r;
+    }
+    __device__ __forceinline__ void clear(u64 s) const { w[s] = kEmpty; }
+};
+
+// Plain table: key word + {first, count} word.  Any key < 2^64-1, any n < 2^31.
+struct TabPlain {
+    u64 *key;
+    uint2 *fc;     // x = first, y = count
+    __device__ __forceinline__ bool insert(u64 k, uint32_t i, u64 mask, uint32_t &slot, uint32_t &arrival,
+                                           uint32_t &status) const
+    {
+        u64 h = mix64(k) & mask;
+        for (u64 probe = 0; probe <= mask; probe++) {
+            u64 cur = __hip_atomic_load(&key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == kEmpty) {
+                u64 old = atomicCAS(&key[h], kEmpty, k);
+                cur = (old == kEmpty) ? k : old;
+            }
+            if (cur == k) {
+                arrival = atomicAdd(&fc[h].y, 1u);
                 // `first` only decreases, so a stale read can only cause a redundant atomicMin
-                if (__hip_atomic_load(&table[h].first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)i)
-                    atomicMin(&table[h].first, (uint32_t)i);
-            } else status |= D3D_VOXEL_STATUS_TABLE_FULL;
+                if (__hip_atomic_load(&fc[h].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&fc[h].x, i);
+                slot = (uint32_t)h;
+                return true;
+            }
+            h = (h + 1) & mask;
         }
+        status |= D3D_VOXEL_STATUS_TABLE_FULL;
+        return false;
     }
-    pslot[i] = slot;
-    if (parr) parr[i] = arrival;
-    if (status) atomicOr(reinterpret_cast<unsigned long long *>(&counts[D3D_COUNT_STATUS]), (unsigned long long)status);
-}
-
-// scan functor: voxel numbering in first-seen order (+ list offsets)
-template <class Key, bool PK>
-struct NumberVoxels {
-    static constexpr const char *kName = "k_scan_count<NumberVoxels>", *kName2 = "k_scan_apply<NumberVoxels>";
-    Key kf;
-    Slot *table;
-    uint32_t *pslot;
-    uint32_t *voff;       // [cap_voxels] list offset per voxel
-    int64_t *coords;      // [cap_voxels,3]
-    int32_t *npoints;     // [cap_voxels]
-    uint32_t max_points;  // 0 -> no lists (sparse contract)
-    uint32_t max_voxels;
-    int64_t *first_out;   // optional [cap_voxels]: global index of each voxel's first point
-    int64_t index_offset; // added to point indices in first_out (rank shard offset)
-
-    __device__ __forceinline__ unsigned long long value(int64_t i) const
+    __device__ __forceinline__ SlotInfo read(u64 s) const
     {
-        uint32_t ps = pslot[i];
-        if (ps == kNoSlot) return 0;
-        uint4 s = reinterpret_cast<const uint4 *>(table)[ps];
-        if (s.z != (uint32_t)i) return 0;
-        pslot[i] = ps | kFirstBit;
-        uint32_t w = max_points ? slot_cnt<PK>(s) : 0u;     // list space: every point of the voxel gets a cell
-        return (1ull << 32) | w;
+        SlotInfo r;
+        r.key = key[s];
+        r.occupied = r.key != kEmpty;
+        uint2 v = fc[s];
+        r.first = v.x;
+        r.cnt = v.y;
+        return r;
     }
-    __device__ __forceinline__ unsigned long long value2(int64_t i) const
+    __device__ __forceinline__ void clear(u64 s) const
     {
-        uint32_t ps = pslot[i];
-        if (!(ps & kFirstBit)) return 0;
-        uint32_t w = max_points ? slot_cnt<PK>(reinterpret_cast<const uint4 *>(table)[ps & ~kFirstBit]) : 0u;
-        return (1ull << 32) | w;
-    }
-    __device__ __forceinline__ void apply(int64_t i, unsigned long long v, unsigned long long excl) const
-    {
-        if (!v) return;
-        Slot *sp = &table[pslot[i] & ~kFirstBit];
-        const uint4 s = *reinterpret_cast<const uint4 *>(sp);
-        uint32_t vid = (uint32_t)(excl >> 32);
-        uint32_t *vid_field = PK ? &sp->cnt : &sp->first;
-        if (vid >= max_voxels) { *vid_field = kNoVoxel; return; }   // voxelize.cpp:116-117
-        *vid_field = vid;
-        if (max_points) {
-            voff[vid] = (uint32_t)excl;
-            if (PK) sp->first = (uint32_t)excl;   // `first` has done its job: reuse it for the list offset
-        }
-        long long cc[3];
-        kf.decode(slot_key<PK>(s), cc);
-        coords[(int64_t)vid * 3 + 0] = cc[0];
-        coords[(int64_t)vid * 3 + 1] = cc[1];
-        coords[(int64_t)vid * 3 + 2] = cc[2];
-        npoints[vid] = (int32_t)slot_cnt<PK>(s);
-        if (first_out) first_out[vid] = index_offset + i;
+        key[s] = kEmpty;
+        fc[s] = make_uint2(kInf, 0u);
     }
 };
 
-// monotone float <-> uint map for atomicMax/atomicMin on floats
-__device__ __forceinline__ uint32_t enc_f32(float f)
+// ------------------------------------------------------------------ kernels: table build
+template <class Tab>
+__global__ void k_init(Tab tab, int64_t cap, unsigned char *flags, int64_t nflags16, int64_t *counts)
 {
-    uint32_t b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float dec_f32(uint32_t e)
-{
-    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < cap; i += stride) tab.clear((u64)i);
+    uint4 z = make_uint4(0, 0, 0, 0);
+    for (int64_t i = t0; i < nflags16; i += stride) reinterpret_cast<uint4 *>(flags)[i] = z;
+    if (t0 < D3D_NUM_COUNTS) counts[t0] = 0;
 }
 
-// Ranking without a sort and without dependent atomic chains:
-//   k_scatter  every point drops its index at unsorted[voff[v] + arrival]  (arrival = value returned by
-//              the count atomicAdd in k_insert; any order)
+template <class Key, class Tab, bool VEC4>
+__global__ __launch_bounds__(256) void k_insert(Key kf, Tab tab, const float *__restrict__ points, int64_t n, int c,
+                                                u64 mask, uint32_t *pslot, uint32_t *parr, int64_t *counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t slot = kNoSlot, status = 0, arrival = 0;
+    float p[3];
+    if (VEC4) {
+        float4 v = reinterpret_cast<const float4 *>(points)[i];
+        p[0] = v.x; p[1] = v.y; p[2] = v.z;
+    } else {
+        const float *src = points + i * c;
+        p[0] = src[0]; p[1] = src[1]; p[2] = src[2];
+    }
+    u64 key;
+    if (kf.make(p, key, status)) tab.insert(key, (uint32_t)i, mask, slot, arrival, status);
+    pslot[i] = slot;
+    if (parr) parr[i] = arrival;
+    if (status) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)status);
+}
+
+// ------------------------------------------------------------------ kernels: numbering by table sweeps
+// sweep 1: flag the first point of every voxel; per-block sums of the counts (list space)
+template <class Tab>
+__global__ __launch_bounds__(256) void k_sweep1(Tab tab, int64_t cap, unsigned char *flags, uint32_t *bsumA)
+{
+    __shared__ u64 smem[256 / kWave];
+    const int64_t s0 = (int64_t)blockIdx.x * kSweepTile + (int64_t)threadIdx.x * 4;
+    u64 sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t s = s0 + k;
+        if (s < cap) {
+            SlotInfo si = tab.read((u64)s);
+            if (si.occupied) { flags[si.first] = 1; sum += si.cnt; }
+        }
+    }
+    u64 tot;
+    (void)block_excl_scan_u64<256>(sum, &tot, smem);
+    if (threadIdx.x == 0) bsumA[blockIdx.x] = (uint32_t)tot;
+}
+
+// 64 flag bytes -> one bit word; word popcounts scanned inside the block (fwpre), block totals -> bsumF
+__global__ __launch_bounds__(256) void k_flagpack(const unsigned char *__restrict__ flags, int64_t nwords, u64 *fwords,
+                                                  uint32_t *fwpre, uint32_t *bsumF)
+{
+    __shared__ u64 smem[256 / kWave];
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    u64 bits = 0;
+    if (t < nwords) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(flags + t * 64);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint4 v = src[q];
+            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // bytes are 0/1: gather the low bit of each of the 4 bytes
+                uint32_t x = wv[j];
+                u64 nib = (x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u);
+                bits |= nib << (q * 16 + j * 4);
+            }
+        }
+        fwords[t] = bits;
+    }
+    u64 tot;
+    u64 ex = block_excl_scan_u64<256>((u64)__popcll(bits), &tot, smem);
+    if (t < nwords) fwpre[t] = (uint32_t)ex;
+    if (threadIdx.x == 0) bsumF[blockIdx.x] = (uint32_t)tot;
+}
+
+// single block: exclusive scans of the two small block-sum arrays; totals -> counts
+__global__ __launch_bounds__(1024) void k_scan2(uint32_t *bsumF, int64_t nF, uint32_t *bsumA, int64_t nA, int64_t *counts,
+                                                u64 max_voxels)
+{
+    __shared__ u64 smem[1024 / kWave];
+    for (int pass = 0; pass < 2; pass++) {
+        uint32_t *a = pass == 0 ? bsumF : bsumA;
+        const int64_t m = pass == 0 ? nF : nA;
+        u64 carry = 0;
+        for (int64_t c0 = 0; c0 < m; c0 += 1024) {
+            const int64_t i = c0 + threadIdx.x;
+            u64 v = i < m ? a[i] : 0ull, tot;
+            u64 ex = block_excl_scan_u64<1024>(v, &tot, smem);
+            if (i < m) a[i] = (uint32_t)(carry + ex);
+            carry += tot;
+        }
+        if (threadIdx.x == 0) {
+            if (pass == 0) counts[D3D_COUNT_VOXELS] = (int64_t)(carry < max_voxels ? carry : max_voxels);
+            else counts[D3D_COUNT_AUX] = (int64_t)carry;
+        }
+        __syncthreads();
+    }
+}
+
+struct NumberOut {
+    u64 *aux;             // [cap] {base : lo32, count : hi32}; base == kNoBase -> voxel dropped
+    uint32_t *vidarr;     // [cap] voxel id per slot (optional)
+    uint4 *vinfo;         // [V] {key lo, key hi, segment base, count}: ONE scattered 16-byte store per voxel;
+                          // coords / npoints are produced from it later in voxel order (coalesced)
+    int64_t *first_out;   // [V] optional
+    int64_t index_offset;
+    uint32_t max_voxels;
+};
+
+// sweep 2: voxel id = rank of `first` among the flags; segment base = exclusive scan of counts in slot order
+template <class Tab>
+__global__ __launch_bounds__(256) void k_sweep2(Tab tab, int64_t cap, const u64 *__restrict__ fwords,
+                                                const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
+                                                const uint32_t *__restrict__ bsumA, NumberOut o)
+{
+    __shared__ u64 smem[256 / kWave];
+    const int64_t s0 = (int64_t)blockIdx.x * kSweepTile + (int64_t)threadIdx.x * 4;
+    SlotInfo si[4];
+    u64 sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t s = s0 + k;
+        si[k].occupied = false;
+        if (s < cap) si[k] = tab.read((u64)s);
+        if (si[k].occupied) sum += si[k].cnt;
+    }
+    u64 tot;
+    u64 base = block_excl_scan_u64<256>(sum, &tot, smem) + bsumA[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!si[k].occupied) continue;
+        const int64_t s = s0 + k;
+        const uint32_t f = si[k].first, wi = f >> 6;
+        const uint32_t vid = bsumF[f / kFlagTile] + fwpre[wi] + (uint32_t)__popcll(fwords[wi] & ((1ull << (f & 63)) - 1));
+        if (vid < o.max_voxels) {                       // voxelize.cpp:116-117: later voxels are never created
+            o.aux[s] = base | ((u64)si[k].cnt << 32);
+            if (o.vidarr) o.vidarr[s] = vid;
+            o.vinfo[vid] = make_uint4((uint32_t)si[k].key, (uint32_t)(si[k].key >> 32), (uint32_t)base, si[k].cnt);
+            if (o.first_out) o.first_out[vid] = o.index_offset + f;
+        } else {
+            o.aux[s] = (u64)kNoBase | ((u64)si[k].cnt << 32);
+            if (o.vidarr) o.vidarr[s] = kNoVoxel;
+        }
+        base += si[k].cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_map(const uint32_t *__restrict__ vidarr, const uint32_t *__restrict__ pslot,
+                                             int64_t n, int64_t *mapping)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ps = pslot[i];
+    long long m = -1;
+    if (ps != kNoSlot) {
+        const uint32_t vid = vidarr[ps];
+        if (vid != kNoVoxel) m = (long long)vid;
+    }
+    mapping[i] = m;
+}
+
+// ------------------------------------------------------------------ kernels: ranking
+//   k_scatter  every point drops its index at unsorted[base + arrival]  (arrival order is arbitrary)
 //   k_select   every point counts the indices smaller than its own in its voxel's (contiguous, L2-hot)
 //              segment; that count IS its rank in point order.  It stops as soon as max_points smaller
 //              ones were seen (the point is then not among the first max_points, voxelize.cpp:128-134),
 //              so a voxel of c points costs O(c * max_points) loads when arrival order is roughly
-//              index order.  Ranks < max_points land in sorted[voff[v] + rank].
-template <bool PK>
-__global__ __launch_bounds__(256) void k_scatter(int64_t n, const Slot *table, uint32_t *__restrict__ pslot,
-                                                 uint32_t *__restrict__ parr, const uint32_t *__restrict__ voff,
-                                                 uint32_t *unsorted, uint32_t *sorted)
+//              index order.  Ranks < max_points land in sorted[base + rank].
+__global__ __launch_bounds__(256) void k_scatter(int64_t n, const u64 *__restrict__ aux, uint32_t *__restrict__ pslot,
+                                                 uint32_t *__restrict__ parr, uint32_t *unsorted, uint32_t *sorted)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t ps = pslot[i] & ~kFirstBit;
+    const uint32_t ps = pslot[i];
     uint32_t todo = 0, base = 0;
     if (ps != kNoSlot) {
-        uint4 s = reinterpret_cast<const uint4 *>(table)[ps];     // the one random access of this pass
-        const uint32_t vid = slot_vid<PK>(s), cnt = slot_cnt<PK>(s);
-        if (vid != kNoVoxel) {
-            base = PK ? s.z : voff[vid];     // packed slots carry the list offset in `first` after numbering
+        const u64 a = aux[ps];                 // the one random access of this pass (8 bytes)
+        base = (uint32_t)a;
+        const uint32_t cnt = (uint32_t)(a >> 32);
+        if (base != kNoBase) {
             if (cnt == 1) sorted[base] = (uint32_t)i;
             else { unsorted[base + parr[i]] = (uint32_t)i; todo = cnt; }
         }
@@ -296,47 +409,6 @@ __global__ __launch_bounds__(256) void k_select(int64_t n, const uint32_t *__res
     }
     for (; k < cnt && rank < max_points; k++) rank += seg[k] < me;
     if (rank < max_points) sorted[base + rank] = me;
-}
-
-// voxels[V, P, 4]: one 16-byte row per lane, grid-stride, non-temporal stores
-__global__ __launch_bounds__(256) void k_fill_c4(const float4 *__restrict__ points, const int64_t *__restrict__ counts,
-                                                 const int32_t *__restrict__ npoints, const uint32_t *__restrict__ voff,
-                                                 const uint32_t *__restrict__ list, uint32_t max_points, float4 *voxels)
-{
-    const int64_t rows = counts[D3D_COUNT_VOXELS] * (int64_t)max_points;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
-        const int64_t v = r / max_points;
-        const uint32_t k = (uint32_t)(r - v * max_points);
-        const uint32_t cnt = (uint32_t)npoints[v];
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < cnt) val = points[list[voff[v] + k]];
-        __builtin_nontemporal_store(val.x, &voxels[r].x);
-        __builtin_nontemporal_store(val.y, &voxels[r].y);
-        __builtin_nontemporal_store(val.z, &voxels[r].z);
-        __builtin_nontemporal_store(val.w, &voxels[r].w);
-    }
-}
-
-// generic C: one float per lane
-__global__ __launch_bounds__(256) void k_fill_generic(const float *__restrict__ points, int c,
-                                                      const int64_t *__restrict__ counts,
-                                                      const int32_t *__restrict__ npoints,
-                                                      const uint32_t *__restrict__ voff,
-                                                      const uint32_t *__restrict__ list, uint32_t max_points,
-                                                      float *voxels)
-{
-    const int64_t pc = (int64_t)max_points * c;
-    const int64_t total = counts[D3D_COUNT_VOXELS] * pc;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int64_t v = e / pc;
-        const uint32_t rem = (uint32_t)(e - v * pc);
-        const uint32_t k = rem / (uint32_t)c, d = rem - k * (uint32_t)c;
-        float val = 0.f;
-        if (k < (uint32_t)npoints[v]) val = points[(int64_t)list[voff[v] + k] * c + d];
-        voxels[e] = val;
-    }
 }
 
 // pmask[V,P] bytes: pmask[v,k] = k < min(npoints[v], P).  (The reference leaves the
@@ -432,19 +504,165 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
     }
 }
 
-template <bool PK>
-__global__ __launch_bounds__(256) void k_map(const Slot *table, const uint32_t *__restrict__ pslot, int64_t n,
-                                             int64_t *mapping)
+
+// ------------------------------------------------------------------ kernels: outputs
+// voxels[V, P, 4]: one 16-byte row per lane, grid-stride, `global_store_dwordx4 nt` -- the HBM-roofline kernel
+__global__ __launch_bounds__(256) void k_fill_c4(const float4 *__restrict__ points, const int64_t *__restrict__ counts,
+                                                 const uint4 *__restrict__ vinfo, const uint32_t *__restrict__ sorted,
+                                                 uint32_t max_points, float4 *voxels)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t ps = pslot[i] & ~kFirstBit;
-    long long m = -1;
-    if (ps != kNoSlot) {
-        uint32_t vid = slot_vid<PK>(reinterpret_cast<const uint4 *>(table)[ps]);
-        if (vid != kNoVoxel) m = (long long)vid;
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    const int64_t rows = counts[D3D_COUNT_VOXELS] * (int64_t)max_points;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+        const int64_t v = r / max_points;
+        const uint32_t k = (uint32_t)(r - v * max_points);
+        const uint4 vi = vinfo[v];
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < vi.w) val = points[sorted[vi.z + k]];
+        vec4 x = {val.x, val.y, val.z, val.w};
+        __builtin_nontemporal_store(x, reinterpret_cast<vec4 *>(&voxels[r]));
     }
-    mapping[i] = m;
+}
+
+// generic C: one float per lane
+__global__ __launch_bounds__(256) void k_fill_generic(const float *__restrict__ points, int c,
+                                                      const int64_t *__restrict__ counts,
+                                                      const uint4 *__restrict__ vinfo,
+                                                      const uint32_t *__restrict__ sorted, uint32_t max_points,
+                                                      float *voxels)
+{
+    const int64_t pc = (int64_t)max_points * c;
+    const int64_t total = counts[D3D_COUNT_VOXELS] * pc;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t v = e / pc;
+        const uint32_t rem = (uint32_t)(e - v * pc);
+        const uint32_t k = rem / (uint32_t)c, d = rem - k * (uint32_t)c;
+        const uint4 vi = vinfo[v];
+        float val = 0.f;
+        if (k < vi.w) val = points[(int64_t)sorted[vi.z + k] * c + d];
+        voxels[e] = val;
+    }
+}
+
+// Per-voxel outputs in voxel order, one lane per voxel: coords, npoints, (C == 4:) the reduction as one float4
+// and (P % 16 == 0:) the pmask row.  Voxels with <= P points are reduced sequentially in point order from their
+// sorted list -> bit-identical to the reference's loop (voxelize.cpp:137-164).  Overflow voxels: every point
+// counts (voxelize.cpp:137-157) but only P are ranked, so the wavefront walks the arrival-ordered segment
+// together; MEAN accumulates in fp64 (insensitive to the arrival order to ~1e-16 => reproducible).
+template <class Key, bool AGG4>
+__global__ __launch_bounds__(256) void k_meta(Key kf, const float4 *__restrict__ points,
+                                              const int64_t *__restrict__ counts, const uint4 *__restrict__ vinfo,
+                                              const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ unsorted,
+                                              uint32_t P, int reduction, int64_t *coords, int32_t *npoints,
+                                              uint32_t *voff, unsigned char *pmask, float4 *agg)
+{
+    const int64_t V = counts[D3D_COUNT_VOXELS];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
+    for (int64_t wbase = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; wbase < V; wbase += stride) {
+        const int64_t v = wbase + lane;
+        const bool ok = v < V;
+        uint4 vi = make_uint4(0, 0, 0, 0);
+        if (ok) {
+            vi = vinfo[v];
+            long long cc[3];
+            kf.decode(((u64)vi.y << 32) | vi.x, cc);
+            coords[v * 3 + 0] = cc[0];
+            coords[v * 3 + 1] = cc[1];
+            coords[v * 3 + 2] = cc[2];
+            npoints[v] = (int32_t)vi.w;
+            if (voff) voff[v] = vi.z;
+            if (pmask) {                                   // P % 16 == 0, 16-byte aligned (host-checked)
+                for (uint32_t k0 = 0; k0 < P; k0 += 16) {
+                    uint32_t w4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        uint32_t b = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) b |= ((k0 + q * 4 + j) < vi.w ? 1u : 0u) << (8 * j);
+                        w4[q] = b;
+                    }
+                    *reinterpret_cast<uint4 *>(pmask + v * P + k0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+            }
+        }
+        if (AGG4) {
+            const uint32_t cnt = vi.w, base = vi.z;
+            if (ok && cnt <= P) {
+                float a0, a1, a2, a3;
+                a0 = a1 = a2 = a3 = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+                // 4 entries per step: the 4 index loads and the 4 row gathers are independent (latency / 4);
+                // the accumulation stays strictly in point order
+                for (uint32_t k = 0; k < cnt; k += 4) {
+                    const uint32_t i0 = sorted[base + k];
+                    const uint32_t i1 = k + 1 < cnt ? sorted[base + k + 1] : i0;
+                    const uint32_t i2 = k + 2 < cnt ? sorted[base + k + 2] : i0;
+                    const uint32_t i3 = k + 3 < cnt ? sorted[base + k + 3] : i0;
+                    const float4 xs[4] = {points[i0], points[i1], points[i2], points[i3]};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (k + j < cnt) {
+                            const float4 x = xs[j];
+                            if (is_sum) { a0 += x.x; a1 += x.y; a2 += x.z; a3 += x.w; }
+                            else if (reduction == D3D_REDUCE_MAX) {      // std::max(acc, x) = acc < x ? x : acc
+                                a0 = a0 < x.x ? x.x : a0; a1 = a1 < x.y ? x.y : a1; a2 = a2 < x.z ? x.z : a2; a3 = a3 < x.w ? x.w : a3;
+                            } else {
+                                a0 = x.x < a0 ? x.x : a0; a1 = x.y < a1 ? x.y : a1; a2 = x.z < a2 ? x.z : a2; a3 = x.w < a3 ? x.w : a3;
+                            }
+                        }
+                    }
+                }
+                if (reduction == D3D_REDUCE_MEAN) {              // voxelize.cpp:164 (float / int)
+                    const float d = (float)(int32_t)cnt;
+                    a0 = a0 / d; a1 = a1 / d; a2 = a2 / d; a3 = a3 / d;
+                }
+                agg[v] = make_float4(a0, a1, a2, a3);
+            }
+            unsigned long long big = __ballot(ok && cnt > P);
+            while (big) {
+                const int l = __builtin_ctzll(big);
+                big &= big - 1;
+                const uint32_t cc = __shfl(cnt, l, kWave);
+                const uint32_t *seg = unsorted + __shfl(base, l, kWave);
+                double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                float e0, e1, e2, e3;
+                e0 = e1 = e2 = e3 = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
+                for (uint32_t q = lane; q < cc; q += kWave) {
+                    const float4 x = points[seg[q]];
+                    if (is_sum) { s0 += x.x; s1 += x.y; s2 += x.z; s3 += x.w; }
+                    else if (reduction == D3D_REDUCE_MAX) {
+                        e0 = e0 < x.x ? x.x : e0; e1 = e1 < x.y ? x.y : e1; e2 = e2 < x.z ? x.z : e2; e3 = e3 < x.w ? x.w : e3;
+                    } else {
+                        e0 = x.x < e0 ? x.x : e0; e1 = x.y < e1 ? x.y : e1; e2 = x.z < e2 ? x.z : e2; e3 = x.w < e3 ? x.w : e3;
+                    }
+                }
+#pragma unroll
+                for (int o = kWave / 2; o > 0; o >>= 1) {
+                    if (is_sum) {
+                        s0 += __shfl_xor(s0, o, kWave); s1 += __shfl_xor(s1, o, kWave);
+                        s2 += __shfl_xor(s2, o, kWave); s3 += __shfl_xor(s3, o, kWave);
+                    } else {
+                        const float t0 = __shfl_xor(e0, o, kWave), t1 = __shfl_xor(e1, o, kWave);
+                        const float t2 = __shfl_xor(e2, o, kWave), t3 = __shfl_xor(e3, o, kWave);
+                        if (reduction == D3D_REDUCE_MAX) {
+                            e0 = e0 < t0 ? t0 : e0; e1 = e1 < t1 ? t1 : e1; e2 = e2 < t2 ? t2 : e2; e3 = e3 < t3 ? t3 : e3;
+                        } else {
+                            e0 = t0 < e0 ? t0 : e0; e1 = t1 < e1 ? t1 : e1; e2 = t2 < e2 ? t2 : e2; e3 = t3 < e3 ? t3 : e3;
+                        }
+                    }
+                }
+                if (lane == l) {
+                    if (is_sum) {
+                        const float d = reduction == D3D_REDUCE_MEAN ? (float)(int32_t)cc : 1.0f;
+                        agg[v] = make_float4((float)s0 / d, (float)s1 / d, (float)s2 / d, (float)s3 / d);
+                    } else agg[v] = make_float4(e0, e1, e2, e3);
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ filter (direct-addressed by voxel id)
@@ -561,25 +779,35 @@ __global__ void k_fill_u32(uint32_t *p, int64_t n, uint32_t val, int64_t *counts
     if (counts && t0 < D3D_NUM_COUNTS) counts[t0] = 0;
 }
 
+
+
 // ------------------------------------------------------------------ workspace layout
 struct VoxelWs {
-    Slot *table;
-    unsigned long long cap;
-    uint32_t *pslot;
-    uint32_t *parr;      // arrival position of each point inside its voxel
-    uint32_t *list;      // per-voxel segments: point indices sorted ascending (first max_points valid)
-    uint32_t *unsorted;  // per-voxel segments in arrival order
+    u64 *tabA;            // packed words, or plain keys
+    uint2 *tabB;          // plain {first, count}
+    u64 *aux;
+    uint32_t *vidarr;
+    u64 cap;
+    size_t tab_bytes;     // bytes of tabA..vidarr (reused as sort scratch by the filter)
+    uint32_t *pslot, *parr;
+    unsigned char *flags;
+    u64 *fwords;
+    uint32_t *fwpre, *bsumF, *bsumA;
+    uint32_t *list;       // per-voxel segments: point indices sorted ascending (first max_points valid)
+    uint32_t *unsorted;   // per-voxel segments in arrival order
     uint32_t *voff;
-    unsigned long long *bsum;
+    uint4 *vinfo;         // [V] {key lo, key hi, segment base, count}
+    u64 *bsum;            // generic scans (filter)
     int32_t *newid;
     uint32_t *coff;
+    int64_t npad;
     size_t bytes;
 };
 
-static unsigned long long table_capacity(int64_t n)
+static u64 table_capacity(int64_t n)
 {
-    unsigned long long cap = 1024;
-    while (cap < (unsigned long long)n * 2ull) cap <<= 1;
+    u64 cap = 1024;
+    while (cap < (u64)n * 2ull) cap <<= 1;
     return cap;
 }
 
@@ -587,16 +815,26 @@ static VoxelWs carve(void *ws, size_t ws_bytes, int64_t n, int64_t nvox)
 {
     WsCarver w(ws, ws_bytes);
     VoxelWs r;
-    const int64_t npad = d3d_divup(n > 0 ? n : 1, kScanTile) * kScanTile;
+    r.npad = d3d_divup(n > 0 ? n : 1, kFlagTile) * kFlagTile;      // multiple of 16384 (and of kScanTile)
     const int64_t m = n > nvox ? n : nvox;
     r.cap = table_capacity(n);
-    r.table = w.take<Slot>(r.cap);
-    r.pslot = w.take<uint32_t>(npad);
-    r.parr = w.take<uint32_t>(npad);
-    r.list = w.take<uint32_t>(npad + 4);
-    r.unsorted = w.take<uint32_t>(npad + 4);
-    r.voff = w.take<uint32_t>(npad + 4);
-    r.bsum = w.take<unsigned long long>(d3d_divup(m > 0 ? m : 1, kScanTile) + 1);
+    r.tabA = w.take<u64>(r.cap);
+    r.tabB = w.take<uint2>(r.cap);
+    r.aux = w.take<u64>(r.cap);
+    r.vidarr = w.take<uint32_t>(r.cap);
+    r.tab_bytes = w.off;
+    r.pslot = w.take<uint32_t>(r.npad);
+    r.parr = w.take<uint32_t>(r.npad);
+    r.flags = w.take<unsigned char>(r.npad);
+    r.fwords = w.take<u64>(r.npad / 64);
+    r.fwpre = w.take<uint32_t>(r.npad / 64);
+    r.bsumF = w.take<uint32_t>(r.npad / kFlagTile + 1);
+    r.bsumA = w.take<uint32_t>(r.cap / kSweepTile + 1);
+    r.list = w.take<uint32_t>(r.npad + 4);
+    r.unsorted = w.take<uint32_t>(r.npad + 4);
+    r.voff = w.take<uint32_t>(r.npad + 4);
+    r.vinfo = w.take<uint4>(r.npad);
+    r.bsum = w.take<u64>(d3d_divup(m > 0 ? m : 1, kScanTile) + 1);
     r.newid = w.take<int32_t>(nvox > 0 ? nvox : 1);
     r.coff = w.take<uint32_t>(nvox > 0 ? nvox : 1);
     r.bytes = w.off;
@@ -609,50 +847,102 @@ static inline unsigned grid_for(int64_t work, int block, int64_t maxblocks = 256
     return (unsigned)(g < maxblocks ? g : maxblocks);
 }
 
-template <class Key, bool PK>
-static int build_table(const Key &kf, const float *points, int64_t n, int c, const VoxelWs &w, int64_t *counts,
-                       uint32_t max_points, hipStream_t st)
+static inline int bits_for(u64 maxval)   // smallest b with maxval <= 2^b - 1
 {
-    const int64_t npad = d3d_divup(n > 0 ? n : 1, kScanTile) * kScanTile;
-    D3D_LAUNCH("k_init", k_init, dim3(grid_for((int64_t)w.cap, 256)), dim3(256), 0, st, w.table, (int64_t)w.cap, w.list,
-               (int64_t)0, counts, PK ? kNoVoxel : 0u);
-    const bool vec4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0);
-    dim3 grid((unsigned)d3d_divup(npad, 256));
-    uint32_t *parr = max_points ? w.parr : nullptr;
-    if (vec4)
-        D3D_LAUNCH("k_insert", (k_insert<Key, true, PK>), grid, dim3(256), 0, st, kf, points, n, c, w.table, w.cap - 1,
-                   w.pslot, parr, npad, counts);
-    else
-        D3D_LAUNCH("k_insert", (k_insert<Key, false, PK>), grid, dim3(256), 0, st, kf, points, n, c, w.table, w.cap - 1,
-                   w.pslot, parr, npad, counts);
+    int b = 1;
+    while (b < 64 && ((1ull << b) - 1) < maxval) b++;
+    return b;
+}
+
+struct IndexOpts {
+    uint32_t max_points;      // 0: no ranking lists
+    uint32_t max_voxels;
+    int64_t *first_out;
+    int64_t index_offset;
+    int64_t *mapping;         // optional point -> voxel id
+};
+
+// table + first-seen numbering (+ per-voxel sorted index lists when max_points > 0)
+template <class Key, class Tab>
+static int build_index(const Key &kf, const Tab &tab, const float *points, int64_t n, int c, const VoxelWs &w,
+                       int64_t *counts, const IndexOpts &o, hipStream_t st)
+{
+    const int64_t cap = (int64_t)w.cap;
+    D3D_LAUNCH("k_init", k_init<Tab>, dim3(grid_for(cap, 256)), dim3(256), 0, st, tab, cap, w.flags, w.npad / 16, counts);
+    if (n > 0) {
+        const bool vec4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0);
+        dim3 grid((unsigned)d3d_divup(n, 256));
+        uint32_t *parr = o.max_points ? w.parr : nullptr;
+        if (vec4)
+            D3D_LAUNCH("k_insert", (k_insert<Key, Tab, true>), grid, dim3(256), 0, st, kf, tab, points, n, c, w.cap - 1,
+                       w.pslot, parr, counts);
+        else
+            D3D_LAUNCH("k_insert", (k_insert<Key, Tab, false>), grid, dim3(256), 0, st, kf, tab, points, n, c, w.cap - 1,
+                       w.pslot, parr, counts);
+    }
+    const unsigned nbA = (unsigned)(cap / kSweepTile), nbF = (unsigned)(w.npad / kFlagTile);
+    D3D_LAUNCH("k_sweep1", k_sweep1<Tab>, dim3(nbA), dim3(256), 0, st, tab, cap, w.flags, w.bsumA);
+    D3D_LAUNCH("k_flagpack", k_flagpack, dim3(nbF), dim3(256), 0, st, w.flags, w.npad / 64, w.fwords, w.fwpre, w.bsumF);
+    D3D_LAUNCH("k_scan2", k_scan2, dim3(1), dim3(1024), 0, st, w.bsumF, (int64_t)nbF, w.bsumA, (int64_t)nbA, counts,
+               (u64)o.max_voxels);
+    NumberOut no{w.aux, o.mapping ? w.vidarr : nullptr, w.vinfo, o.first_out, o.index_offset, o.max_voxels};
+    D3D_LAUNCH("k_sweep2", k_sweep2<Tab>, dim3(nbA), dim3(256), 0, st, tab, cap, w.fwords, w.fwpre, w.bsumF, w.bsumA, no);
+    if (n == 0) return D3D_OK;
+    if (o.mapping)
+        D3D_LAUNCH("k_map", k_map, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, w.vidarr, w.pslot, n, o.mapping);
+    if (o.max_voxels == 0 || o.max_points == 0) return D3D_OK;
+    D3D_LAUNCH("k_scatter", k_scatter, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, w.aux, w.pslot, w.parr,
+               w.unsorted, w.list);
+    D3D_LAUNCH("k_select", k_select, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, w.pslot, w.parr, w.unsorted,
+               w.list, o.max_points);
     return D3D_OK;
 }
 
-// table + first-seen numbering + per-voxel sorted index lists for the dense contract
-template <bool PK>
 static int dense_index(const DenseKey &kf, const float *points, int64_t n, int c, const VoxelWs &w, int64_t *counts,
-                       int64_t *coords, int32_t *npoints, uint32_t max_points, uint32_t max_voxels, hipStream_t st,
-                       int64_t *first_out = nullptr, int64_t index_offset = 0, int64_t *mapping = nullptr)
+                       const IndexOpts &o, hipStream_t st)
 {
-    int rc = build_table<DenseKey, PK>(kf, points, n, c, w, counts, max_points, st);
-    if (rc) return rc;
-    NumberVoxels<DenseKey, PK> nv{kf, w.table, w.pslot, w.voff, coords, npoints, max_points, max_voxels,
-                                  first_out, index_offset};
-    rc = d3d_run_scan(nv, n, w.bsum, counts, D3D_COUNT_VOXELS, D3D_COUNT_AUX, (unsigned long long)max_voxels, st);
-    if (rc) return rc;
-    if (mapping && n > 0)   // before k_scatter recycles pslot
-        D3D_LAUNCH("k_map", k_map<PK>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, w.table, w.pslot, n, mapping);
-    if (n == 0 || max_voxels == 0 || max_points == 0) return D3D_OK;
-    D3D_LAUNCH("k_scatter", k_scatter<PK>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, w.table, w.pslot,
-               w.parr, w.voff, w.unsorted, w.list);
-    D3D_LAUNCH("k_select", k_select, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, w.pslot, w.parr,
-               w.unsorted, w.list, max_points);
+    // packed one-word slots whenever [count | key | first] fits 64 bits with >= 8 count bits
+    const double cells = (double)kf.shape[0] * (double)kf.shape[1] * (double)kf.shape[2];
+    const char *env = getenv("D3D_FORCE_PLAIN_SLOTS");
+    bool packed = !g_force_plain && !(env && env[0] == '1') && cells < 9.0e18;
+    int ib = 0, kb = 0;
+    if (packed) {
+        ib = bits_for((u64)(n > 1 ? n - 1 : 1));
+        kb = bits_for((u64)cells);            // keys are < cells <= 2^kb - 1: never all ones
+        packed = ib + kb <= 56;
+    }
+    if (packed) {
+        TabPacked tab{w.tabA, ib, kb};
+        return build_index(kf, tab, points, n, c, w, counts, o, st);
+    }
+    TabPlain tab{w.tabA, w.tabB};
+    return build_index(kf, tab, points, n, c, w, counts, o, st);
+}
+
+static int make_dense_key(const int32_t *shape, const float *bound, DenseKey &kf)
+{
+    if (shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0) return D3D_ERR_BAD_ARG;
+    if ((double)shape[0] * (double)shape[1] * (double)shape[2] >= 9.0e18) return D3D_ERR_BAD_ARG;
+    for (int d = 0; d < 3; d++) {
+        kf.lo[d] = bound[d << 1];
+        kf.shape[d] = shape[d];
+        // voxelize.cpp:84-86: float(hi - lo) / int, evaluated in fp32 on the host
+        volatile float diff = bound[(d << 1) | 1] - bound[d << 1];
+        volatile float sz = diff / (float)shape[d];
+        kf.size[d] = sz;
+    }
     return D3D_OK;
 }
 
 }  // namespace
 
 // ====================================================================== C ABI
+extern "C" int d3d_voxel_force_plain(int on)
+{
+    g_force_plain = on ? 1 : 0;
+    return D3D_OK;
+}
+
 extern "C" size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels)
 {
     if (n_points < 0) n_points = 0;
@@ -668,56 +958,48 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 3 || !shape || !bound || !counts || max_points < 0 || max_voxels < 0) return D3D_ERR_BAD_ARG;
     if (n > 0 && !points) return D3D_ERR_BAD_ARG;
-    if (n >= (1ll << 31) - kScanTile) return D3D_ERR_BAD_ARG;
+    if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
     if (reduction < D3D_REDUCE_NONE || reduction > D3D_REDUCE_MIN) return D3D_ERR_UNSUPPORTED;  // voxelize.cpp:196
     if (reduction != D3D_REDUCE_NONE && !aggregates && n > 0 && max_voxels > 0) return D3D_ERR_BAD_ARG;
-    if (shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0) return D3D_ERR_BAD_ARG;
+    if (reduction != D3D_REDUCE_NONE && max_points == 0 && n > 0 && max_voxels > 0) return D3D_ERR_UNSUPPORTED;   // aggregates need the lists
+    DenseKey kf;
+    int rc = make_dense_key(shape, bound, kf);
+    if (rc) return rc;
     VoxelWs w = carve(workspace, workspace_bytes, n, 0);
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     if ((max_voxels > 0 && n > 0) && (!voxels || !coords || !pmask || !npoints)) return D3D_ERR_BAD_ARG;
 
-    DenseKey kf;
-    for (int d = 0; d < 3; d++) {
-        kf.lo[d] = bound[d << 1];
-        kf.shape[d] = shape[d];
-        // voxelize.cpp:84-86: float(hi - lo) / int, evaluated in fp32 on the host
-        volatile float diff = bound[(d << 1) | 1] - bound[d << 1];
-        volatile float sz = diff / (float)shape[d];
-        kf.size[d] = sz;
-    }
-    // packed slots (claim + count in one 64-bit atomic) whenever key and count fit 40 + 24 bits
-    const double cells = (double)shape[0] * (double)shape[1] * (double)shape[2];
-    if (cells >= 9.0e18) return D3D_ERR_BAD_ARG;
-    // D3D_FORCE_PLAIN_SLOTS=1 selects the general layout (test hook for the n >= 2^24 path)
-    const char *force_plain = getenv("D3D_FORCE_PLAIN_SLOTS");
-    const bool packed = cells < 1.0e12 && n < (1ll << kCntBits) && !(force_plain && force_plain[0] == '1');
-    int rc = packed ? dense_index<true>(kf, points, n, c, w, counts, coords, npoints, (uint32_t)max_points,
-                                        (uint32_t)max_voxels, st)
-                    : dense_index<false>(kf, points, n, c, w, counts, coords, npoints, (uint32_t)max_points,
-                                         (uint32_t)max_voxels, st);
+    IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr};
+    rc = dense_index(kf, points, n, c, w, counts, o, st);
     if (rc) return rc;
     if (n == 0 || max_voxels == 0) return D3D_OK;
 
-    if (max_points > 0) {
-        const int64_t cap = n < max_voxels ? n : (int64_t)max_voxels;
-        const bool vec4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(voxels) & 15) == 0);
-        if (vec4)
-            D3D_LAUNCH("k_fill_c4", k_fill_c4, dim3(grid_for(cap * max_points, 256, 256 * 32)), dim3(256), 0, st,
-                               reinterpret_cast<const float4 *>(points), counts, npoints, w.voff, w.list,
-                               (uint32_t)max_points, reinterpret_cast<float4 *>(voxels));
-        else
-            D3D_LAUNCH("k_fill_generic", k_fill_generic, dim3(grid_for(cap * max_points * c, 256, 256 * 32)), dim3(256), 0, st,
-                               points, c, counts, npoints, w.voff, w.list, (uint32_t)max_points, voxels);
-        D3D_LAUNCH("k_pmask", k_pmask, dim3(grid_for(d3d_divup(cap * max_points, 16), 256)), dim3(256), 0, st, counts,
-                           npoints, (uint32_t)max_points, pmask);
-    }
-    if (reduction != D3D_REDUCE_NONE) {
-        const int64_t cap = n < max_voxels ? n : (int64_t)max_voxels;
-        if (max_points == 0) return D3D_ERR_UNSUPPORTED;   // aggregates need the lists (documented)
+    const int64_t cap = n < max_voxels ? n : (int64_t)max_voxels;
+    const uint32_t P = (uint32_t)max_points;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(points) & 15) == 0) && ((reinterpret_cast<uintptr_t>(voxels) & 15) == 0);
+    const bool vec4 = (c == 4) && al16 && (reduction == D3D_REDUCE_NONE || (reinterpret_cast<uintptr_t>(aggregates) & 15) == 0);
+    const bool fuse_pmask = P > 0 && (P % 16 == 0) && ((reinterpret_cast<uintptr_t>(pmask) & 15) == 0);
+    const bool agg4 = vec4 && reduction != D3D_REDUCE_NONE && P > 0;
+    const dim3 mgrid(grid_for(cap, 256));
+    const float4 *p4 = reinterpret_cast<const float4 *>(points);
+    if (agg4)
+        D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), mgrid, dim3(256), 0, st, kf, p4, counts, w.vinfo, w.list, w.unsorted, P,
+                   reduction, coords, npoints, w.voff, fuse_pmask ? pmask : nullptr, reinterpret_cast<float4 *>(aggregates));
+    else
+        D3D_LAUNCH("k_meta", (k_meta<DenseKey, false>), mgrid, dim3(256), 0, st, kf, p4, counts, w.vinfo, w.list, w.unsorted, P,
+                   reduction, coords, npoints, w.voff, fuse_pmask ? pmask : nullptr, (float4 *)nullptr);
+    if (P == 0) return D3D_OK;
+    if (vec4)
+        D3D_LAUNCH("k_fill_c4", k_fill_c4, dim3(grid_for(cap * P, 256, 256 * 32)), dim3(256), 0, st, p4, counts, w.vinfo, w.list,
+                   P, reinterpret_cast<float4 *>(voxels));
+    else
+        D3D_LAUNCH("k_fill_generic", k_fill_generic, dim3(grid_for(cap * P * c, 256, 256 * 32)), dim3(256), 0, st, points, c,
+                   counts, w.vinfo, w.list, P, voxels);
+    if (!fuse_pmask)
+        D3D_LAUNCH("k_pmask", k_pmask, dim3(grid_for(d3d_divup(cap * P, 16), 256)), dim3(256), 0, st, counts, npoints, P, pmask);
+    if (reduction != D3D_REDUCE_NONE && !agg4)
         D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(cap * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
-                           w.voff, w.list, w.unsorted, (uint32_t)max_points, reduction, aggregates);
-    }
+                   w.voff, w.list, w.unsorted, P, reduction, aggregates);
     return D3D_OK;
 }
 
@@ -732,33 +1014,32 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 3 || !shape || !bound || !counts) return D3D_ERR_BAD_ARG;
-    if (n >= (1ll << 31) - kScanTile) return D3D_ERR_BAD_ARG;
+    if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
     if (reduction < D3D_REDUCE_MEAN || reduction > kReduceSum) return D3D_ERR_UNSUPPORTED;
-    if (shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0) return D3D_ERR_BAD_ARG;
     if (n > 0 && (!points || !coords || !npoints || !aggregates)) return D3D_ERR_BAD_ARG;
+    DenseKey kf;
+    int rc = make_dense_key(shape, bound, kf);
+    if (rc) return rc;
     VoxelWs w = carve(workspace, workspace_bytes, n, 0);
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
-    DenseKey kf;
-    for (int d = 0; d < 3; d++) {
-        kf.lo[d] = bound[d << 1];
-        kf.shape[d] = shape[d];
-        volatile float diff = bound[(d << 1) | 1] - bound[d << 1];
-        volatile float sz = diff / (float)shape[d];
-        kf.size[d] = sz;
-    }
-    const double cells = (double)shape[0] * (double)shape[1] * (double)shape[2];
-    if (cells >= 9.0e18) return D3D_ERR_BAD_ARG;
-    const char *force_plain = getenv("D3D_FORCE_PLAIN_SLOTS");
-    const bool packed = cells < 1.0e12 && n < (1ll << kCntBits) && !(force_plain && force_plain[0] == '1');
     const uint32_t P = 32;   // voxels up to 32 points are reduced sequentially in point order, larger ones cooperatively
-    int rc = packed ? dense_index<true>(kf, points, n, c, w, counts, coords, npoints, P, 0xffffffffu, st, first,
-                                        index_offset, mapping)
-                    : dense_index<false>(kf, points, n, c, w, counts, coords, npoints, P, 0xffffffffu, st, first,
-                                         index_offset, mapping);
+    IndexOpts o{P, 0xffffffffu, first, index_offset, mapping};
+    rc = dense_index(kf, points, n, c, w, counts, o, st);
     if (rc) return rc;
     if (n == 0) return D3D_OK;
-    D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(n * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
-               w.voff, w.list, w.unsorted, P, reduction, aggregates);
+    const bool agg4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(aggregates) & 15) == 0);
+    const float4 *p4 = reinterpret_cast<const float4 *>(points);
+    if (agg4)
+        D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, p4, counts, w.vinfo,
+                   w.list, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr,
+                   reinterpret_cast<float4 *>(aggregates));
+    else {
+        D3D_LAUNCH("k_meta", (k_meta<DenseKey, false>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, p4, counts, w.vinfo,
+                   w.list, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr, (float4 *)nullptr);
+        D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(n * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
+                   w.voff, w.list, w.unsorted, P, reduction, aggregates);
+    }
     return D3D_OK;
 }
 
@@ -769,20 +1050,18 @@ extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c,
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 3 || !voxel_size || !counts) return D3D_ERR_BAD_ARG;
     if (n > 0 && (!points || !points_mapping || !coords || !npoints)) return D3D_ERR_BAD_ARG;
-    if (n >= (1ll << 31) - kScanTile) return D3D_ERR_BAD_ARG;
+    if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
     VoxelWs w = carve(workspace, workspace_bytes, n, 0);
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     SparseKey kf;
     for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
-    int rc = build_table<SparseKey, false>(kf, points, n, c, w, counts, 0u, st);
-    if (rc) return rc;
-    NumberVoxels<SparseKey, false> nv{kf, w.table, w.pslot, w.voff, coords, npoints, 0u, 0xffffffffu, nullptr, 0};
-    rc = d3d_run_scan(nv, n, w.bsum, counts, D3D_COUNT_VOXELS, -1, ~0ull, st);
-    if (rc) return rc;
-    if (n > 0) {
-        D3D_LAUNCH("k_map", k_map<false>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, w.table, w.pslot, n,
-                           points_mapping);
-    }
+    TabPlain tab{w.tabA, w.tabB};
+    IndexOpts o{0u, 0xffffffffu, nullptr, 0, points_mapping};
+    int rc = build_index(kf, tab, points, n, c, w, counts, o, st);
+    if (rc || n == 0) return rc;
+    D3D_LAUNCH("k_meta", (k_meta<SparseKey, false>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, (const float4 *)nullptr,
+               counts, w.vinfo, w.list, w.unsorted, 0u, 0, coords, npoints, (uint32_t *)nullptr, (unsigned char *)nullptr,
+               (float4 *)nullptr);
     return D3D_OK;
 }
 
@@ -805,7 +1084,7 @@ extern "C" int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, 
     if (max_points_filter < 0 || max_points_filter > 2 || max_voxels_filter < 0 || max_voxels_filter > 2)
         return D3D_ERR_BAD_ARG;
     if (max_points < 0 || max_voxels < 0) return D3D_ERR_BAD_ARG;
-    if (n >= (1ll << 31) - kScanTile || nvox >= (1ll << 31) - kScanTile) return D3D_ERR_BAD_ARG;
+    if (n >= (1ll << 31) - kScanTile || nvox >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
     if (n > 0 && (!feats || !points_mapping || !out_feats || !out_mask || !out_mapping)) return D3D_ERR_BAD_ARG;
     if (nvox > 0 && (!coords || !voxel_npoints || !out_npoints || !out_coords)) return D3D_ERR_BAD_ARG;
     VoxelWs w = carve(workspace, workspace_bytes, n, nvox);
@@ -825,8 +1104,8 @@ extern "C" int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, 
         int32_t *ord = reinterpret_cast<int32_t *>(w.pslot);   // npad >= ... only n entries guaranteed
         // pslot holds ceil(n/1024)*1024 entries; nvox may exceed n for hand-made inputs -> use table region
         size_t need = (size_t)nvox * sizeof(int32_t);
-        char *tb = reinterpret_cast<char *>(w.table);
-        size_t tbytes = (size_t)w.cap * sizeof(Slot);
+        char *tb = reinterpret_cast<char *>(w.tabA);
+        size_t tbytes = w.tab_bytes;
         size_t sort_bytes = d3d_internal_argsort_i32_bytes(nvox);
         if (d3d_align_up(need) + sort_bytes > tbytes) return D3D_ERR_WORKSPACE;
         ord = reinterpret_cast<int32_t *>(tb);

@@ -57,9 +57,15 @@ def _stage(points, what="points"):
     return points.to(dev).contiguous(), points.device, dev
 
 
+class _PackOverflow(Exception):
+    """a voxel outgrew the packed hash slot's count field: the call is repeated with the general layout"""
+
+
 def _counts_to_host(counts, what):
     host = counts.cpu()     # the one host sync of a call: sizes of the variable-length outputs
     status = int(host[_lib.COUNT_STATUS])
+    if status & _lib.STATUS_PACK_OVERFLOW:
+        raise _PackOverflow(what)
     if status & _lib.STATUS_TABLE_FULL:
         raise RuntimeError("%s: internal hash table overflow" % what)
     if status & _lib.STATUS_COORD_OVERFLOW:
@@ -93,14 +99,23 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
         counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
         wsb = lib.d3d_voxelize_workspace_bytes(n, 0)
         ws = _lib.workspace(wsb, dev)
-        rc = lib.d3d_voxelize_3d_dense(
-            _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
-            max_points, max_voxels, red, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts),
-            _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
-        if rc == _lib.ERR_UNSUPPORTED:
-            raise ValueError("Unsupported reduction type in voxelization!")   # voxelize.cpp:196
-        _lib.check(rc, "voxelize_3d_dense")
-        nv = int(_counts_to_host(counts, "voxelize_3d_dense")[_lib.COUNT_VOXELS])
+        def run():
+            rc = lib.d3d_voxelize_3d_dense(
+                _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
+                max_points, max_voxels, red, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts),
+                _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            if rc == _lib.ERR_UNSUPPORTED:
+                raise ValueError("Unsupported reduction type in voxelization!")   # voxelize.cpp:196
+            _lib.check(rc, "voxelize_3d_dense")
+            return int(_counts_to_host(counts, "voxelize_3d_dense")[_lib.COUNT_VOXELS])
+        try:
+            nv = run()
+        except _PackOverflow:      # > 2^cb points in one voxel: repeat with the general hash-slot layout
+            lib.d3d_voxel_force_plain(1)
+            try:
+                nv = run()
+            finally:
+                lib.d3d_voxel_force_plain(0)
     ret = dict(voxels=voxels[:nv], coords=coords[:nv], voxel_pmask=pmask[:nv].view(torch.bool),
                voxel_npoints=npts[:nv])
     if red != 0:

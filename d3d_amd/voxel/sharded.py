@@ -80,14 +80,20 @@ class HipOps:
             mapping = torch.empty((n,), dtype=torch.int64, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
             ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
-            rc = lib.d3d_voxelize_3d_reduce(
-                _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
-                int(reduction), int(index_offset), _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first),
-                _lib.ptr(mapping), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
-            _lib.check(rc, "voxelize_3d_reduce")
-            host = counts.cpu()
-            if int(host[_lib.COUNT_STATUS]) & _lib.STATUS_TABLE_FULL:
-                raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
+            for attempt in (0, 1):
+                rc = lib.d3d_voxelize_3d_reduce(
+                    _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
+                    int(reduction), int(index_offset), _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first),
+                    _lib.ptr(mapping), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                lib.d3d_voxel_force_plain(0)
+                _lib.check(rc, "voxelize_3d_reduce")
+                host = counts.cpu()
+                status = int(host[_lib.COUNT_STATUS])
+                if status & _lib.STATUS_TABLE_FULL:
+                    raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
+                if not (status & _lib.STATUS_PACK_OVERFLOW):
+                    break
+                lib.d3d_voxel_force_plain(1)     # one voxel outgrew the packed slot's counter: general layout
             v = int(host[_lib.COUNT_VOXELS])
         return coords[:v], cnt[:v], agg[:v], first[:v], mapping
 

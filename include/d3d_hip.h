@@ -48,8 +48,11 @@ enum { D3D_F32 = 0, D3D_F64 = 1 };
 
 /* status bits OR-ed into counts[D3D_COUNT_STATUS] by the voxel kernels */
 enum { D3D_VOXEL_STATUS_COORD_OVERFLOW = 1,   /* sparse: |floor(p/size)| >= 2^20 (or NaN)      */
-       D3D_VOXEL_STATUS_TABLE_FULL = 2 };     /* internal hash table overflow (cannot happen
+       D3D_VOXEL_STATUS_TABLE_FULL = 2,       /* internal hash table overflow (cannot happen
                                                  with the documented workspace size)           */
+       D3D_VOXEL_STATUS_PACK_OVERFLOW = 4 };  /* a voxel holds more points than the packed one-word
+                                                 hash slot can count: results are invalid; repeat the
+                                                 call after d3d_voxel_force_plain(1)             */
 enum { D3D_COUNT_VOXELS = 0, D3D_COUNT_POINTS = 1, D3D_COUNT_STATUS = 2, D3D_COUNT_AUX = 3, D3D_NUM_COUNTS = 4 };
 
 int         d3d_abi_version(void);
@@ -57,6 +60,10 @@ int         d3d_last_hip_error(void);           /* hipError_t of the last D3D_ER
 const char *d3d_status_string(int status);
 
 /* ------------------------------------------------------------------ d3d/voxel */
+
+/* 1 = always use the general two-word hash slots (any count / key width); 0 = automatic (default):
+ * one-word slots {count | key | first index} whenever they fit 64 bits (one atomic per point). */
+int d3d_voxel_force_plain(int on);
 
 /* scratch for any of the three voxel entry points on n points / nvox voxels */
 size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels);
