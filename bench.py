@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-extra", action="store_true")
     ap.add_argument("--dist", choices=["lidar", "uniform"], default="lidar")
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded (RCCL) path even with one rank")
     args = ap.parse_args()
 
     from d3d_amd import synth
@@ -196,9 +197,12 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     barrier = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         barrier = dist.barrier
 
     P, n = 32, args.points
@@ -206,7 +210,7 @@ def main():
     cloud_h = mk(n, rank)                       # rank k owns shard k (seed = rank; rank 0 = config 2's cloud)
     cloud = torch.from_numpy(cloud_h).cuda()
     out = {}
-    if world == 1:
+    if not sharded:
         gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=P,
                              max_voxels=n)
         res = gen(cloud)
@@ -262,14 +266,14 @@ def main():
             "config": {"workload": workload, "points_per_gpu": n, "parallelism": parallelism},
         }
         line.update(out)
-        if world == 1 and not args.skip_cpu:
+        if not sharded and not args.skip_cpu:
             line["cpu_baseline"] = cpu_baseline_voxel(cloud_h, synth.KITTI_BOUNDS, synth.KITTI_SHAPE, P, n)
-        if world == 1 and not args.skip_extra:
+        if not sharded and not args.skip_extra:
             del cloud
             torch.cuda.empty_cache()
             line["extra"] = extras(args)
         print(json.dumps(line))
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -194,7 +194,7 @@ struct TabPlain {
 
 // ------------------------------------------------------------------ kernels: table build
 template <class Tab>
-__global__ void k_init(Tab tab, int64_t cap, unsigned char *flags, int64_t nflags16, int64_t *counts)
+__global__ void k_init(Tab tab, int64_t cap, unsigned char *flags, int64_t nflags16, int64_t *counts, uint32_t *big_count)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,6 +202,7 @@ __global__ void k_init(Tab tab, int64_t cap, unsigned char *flags, int64_t nflag
     uint4 z = make_uint4(0, 0, 0, 0);
     for (int64_t i = t0; i < nflags16; i += stride) reinterpret_cast<uint4 *>(flags)[i] = z;
     if (t0 < D3D_NUM_COUNTS) counts[t0] = 0;
+    if (t0 == 0) *big_count = 0;
 }
 
 template <class Key, class Tab, bool VEC4>
@@ -370,7 +371,8 @@ __global__ __launch_bounds__(256) void k_map(const uint32_t *__restrict__ vidarr
 //              so a voxel of c points costs O(c * max_points) loads when arrival order is roughly
 //              index order.  Ranks < max_points land in sorted[base + rank].
 __global__ __launch_bounds__(256) void k_scatter(int64_t n, const u64 *__restrict__ aux, uint32_t *__restrict__ pslot,
-                                                 uint32_t *__restrict__ parr, uint32_t *unsorted, uint32_t *sorted)
+                                                 uint32_t *__restrict__ parr, uint32_t *unsorted, uint32_t *sorted,
+                                                 const float4 *__restrict__ points4, float4 *staged)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, const u64 *__restric
         base = (uint32_t)a;
         const uint32_t cnt = (uint32_t)(a >> 32);
         if (base != kNoBase) {
-            if (cnt == 1) sorted[base] = (uint32_t)i;
+            if (cnt == 1) { sorted[base] = (uint32_t)i; if (staged) staged[base] = points4[i]; }
             else { unsorted[base + parr[i]] = (uint32_t)i; todo = cnt; }
         }
     }
@@ -390,10 +392,13 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, const u64 *__restric
     parr[i] = base;
 }
 
+// When `staged` is given (C == 4) the point's row is copied next to its rank as well, so that the fill and
+// reduction kernels read contiguous rows instead of chasing sorted[] -> points[] (one coalesced read here
+// replaces two dependent random gathers there).
 __global__ __launch_bounds__(256) void k_select(int64_t n, const uint32_t *__restrict__ pcnt,
                                                 const uint32_t *__restrict__ pbase,
                                                 const uint32_t *__restrict__ unsorted, uint32_t *sorted,
-                                                uint32_t max_points)
+                                                uint32_t max_points, const float4 *__restrict__ points4, float4 *staged)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -408,7 +413,10 @@ __global__ __launch_bounds__(256) void k_select(int64_t n, const uint32_t *__res
         rank += (a0 < me) + (a1 < me) + (a2 < me) + (a3 < me);
     }
     for (; k < cnt && rank < max_points; k++) rank += seg[k] < me;
-    if (rank < max_points) sorted[base + rank] = me;
+    if (rank < max_points) {
+        sorted[base + rank] = me;
+        if (staged) staged[base + rank] = points4[i];
+    }
 }
 
 // pmask[V,P] bytes: pmask[v,k] = k < min(npoints[v], P).  (The reference leaves the
@@ -507,9 +515,8 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
 
 // ------------------------------------------------------------------ kernels: outputs
 // voxels[V, P, 4]: one 16-byte row per lane, grid-stride, `global_store_dwordx4 nt` -- the HBM-roofline kernel
-__global__ __launch_bounds__(256) void k_fill_c4(const float4 *__restrict__ points, const int64_t *__restrict__ counts,
-                                                 const uint4 *__restrict__ vinfo, const uint32_t *__restrict__ sorted,
-                                                 uint32_t max_points, float4 *voxels)
+__global__ __launch_bounds__(256) void k_fill_c4(const float4 *__restrict__ staged, const int64_t *__restrict__ counts,
+                                                 const uint4 *__restrict__ vinfo, uint32_t max_points, float4 *voxels)
 {
     typedef float vec4 __attribute__((ext_vector_type(4)));
     const int64_t rows = counts[D3D_COUNT_VOXELS] * (int64_t)max_points;
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(256) void k_fill_c4(const float4 *__restrict__ poin
         const uint32_t k = (uint32_t)(r - v * max_points);
         const uint4 vi = vinfo[v];
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < vi.w) val = points[sorted[vi.z + k]];
+        if (k < vi.w) val = staged[vi.z + k];
         vec4 x = {val.x, val.y, val.z, val.w};
         __builtin_nontemporal_store(x, reinterpret_cast<vec4 *>(&voxels[r]));
     }
@@ -554,17 +561,16 @@ __global__ __launch_bounds__(256) void k_fill_generic(const float *__restrict__ 
 template <class Key, bool AGG4>
 __global__ __launch_bounds__(256) void k_meta(Key kf, const float4 *__restrict__ points,
                                               const int64_t *__restrict__ counts, const uint4 *__restrict__ vinfo,
-                                              const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ unsorted,
+                                              const float4 *__restrict__ staged, const uint32_t *__restrict__ unsorted,
                                               uint32_t P, int reduction, int64_t *coords, int32_t *npoints,
-                                              uint32_t *voff, unsigned char *pmask, float4 *agg)
+                                              uint32_t *voff, unsigned char *pmask, float4 *agg, uint32_t *big_list,
+                                              uint32_t *big_count)
 {
     const int64_t V = counts[D3D_COUNT_VOXELS];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int lane = threadIdx.x & (kWave - 1);
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
-    for (int64_t wbase = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; wbase < V; wbase += stride) {
-        const int64_t v = wbase + lane;
-        const bool ok = v < V;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
+        const bool ok = true;
         uint4 vi = make_uint4(0, 0, 0, 0);
         if (ok) {
             vi = vinfo[v];
@@ -594,14 +600,12 @@ __global__ __launch_bounds__(256) void k_meta(Key kf, const float4 *__restrict__
             if (ok && cnt <= P) {
                 float a0, a1, a2, a3;
                 a0 = a1 = a2 = a3 = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
-                // 4 entries per step: the 4 index loads and the 4 row gathers are independent (latency / 4);
+                // 4 rows per step (independent loads);
                 // the accumulation stays strictly in point order
                 for (uint32_t k = 0; k < cnt; k += 4) {
-                    const uint32_t i0 = sorted[base + k];
-                    const uint32_t i1 = k + 1 < cnt ? sorted[base + k + 1] : i0;
-                    const uint32_t i2 = k + 2 < cnt ? sorted[base + k + 2] : i0;
-                    const uint32_t i3 = k + 3 < cnt ? sorted[base + k + 3] : i0;
-                    const float4 xs[4] = {points[i0], points[i1], points[i2], points[i3]};
+                    const float4 *row = staged + base + k;         // contiguous rows, loads independent
+                    const float4 xs[4] = {row[0], k + 1 < cnt ? row[1] : row[0], k + 2 < cnt ? row[2] : row[0],
+                                          k + 3 < cnt ? row[3] : row[0]};
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         if (k + j < cnt) {
@@ -621,46 +625,62 @@ __global__ __launch_bounds__(256) void k_meta(Key kf, const float4 *__restrict__
                 }
                 agg[v] = make_float4(a0, a1, a2, a3);
             }
-            unsigned long long big = __ballot(ok && cnt > P);
-            while (big) {
-                const int l = __builtin_ctzll(big);
-                big &= big - 1;
-                const uint32_t cc = __shfl(cnt, l, kWave);
-                const uint32_t *seg = unsorted + __shfl(base, l, kWave);
-                double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-                float e0, e1, e2, e3;
-                e0 = e1 = e2 = e3 = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
-                for (uint32_t q = lane; q < cc; q += kWave) {
-                    const float4 x = points[seg[q]];
-                    if (is_sum) { s0 += x.x; s1 += x.y; s2 += x.z; s3 += x.w; }
-                    else if (reduction == D3D_REDUCE_MAX) {
-                        e0 = e0 < x.x ? x.x : e0; e1 = e1 < x.y ? x.y : e1; e2 = e2 < x.z ? x.z : e2; e3 = e3 < x.w ? x.w : e3;
-                    } else {
-                        e0 = x.x < e0 ? x.x : e0; e1 = x.y < e1 ? x.y : e1; e2 = x.z < e2 ? x.z : e2; e3 = x.w < e3 ? x.w : e3;
-                    }
-                }
+            // overflow voxels (every point counts, voxelize.cpp:137-157, but only P are ranked) go to a work
+            // list and are reduced one-wavefront-per-voxel by k_overflow_reduce
+            if (ok && cnt > P) big_list[atomicAdd(big_count, 1u)] = (uint32_t)v;
+        }
+    }
+}
+
+// One wavefront per overflow voxel: walk its arrival-ordered segment 64 entries per step.  MEAN accumulates in
+// fp64 (insensitive to the arrival order to ~1e-16 => reproducible run to run; differs from the reference's fp32
+// running sum by rounding only).
+__global__ __launch_bounds__(256) void k_overflow_reduce(const float4 *__restrict__ points, const uint4 *__restrict__ vinfo,
+                                                         const uint32_t *__restrict__ unsorted,
+                                                         const uint32_t *__restrict__ big_list,
+                                                         const uint32_t *__restrict__ big_count, int reduction, float4 *agg)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
+    const uint32_t total = *big_count;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < total; t += nwaves) {
+        const uint32_t v = big_list[t];
+        const uint4 vi = vinfo[v];
+        const uint32_t cc = vi.w;
+        const uint32_t *seg = unsorted + vi.z;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        float e0, e1, e2, e3;
+        e0 = e1 = e2 = e3 = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
+        for (uint32_t q = lane; q < cc; q += kWave) {
+            const float4 x = points[seg[q]];
+            if (is_sum) { s0 += x.x; s1 += x.y; s2 += x.z; s3 += x.w; }
+            else if (reduction == D3D_REDUCE_MAX) {
+                e0 = e0 < x.x ? x.x : e0; e1 = e1 < x.y ? x.y : e1; e2 = e2 < x.z ? x.z : e2; e3 = e3 < x.w ? x.w : e3;
+            } else {
+                e0 = x.x < e0 ? x.x : e0; e1 = x.y < e1 ? x.y : e1; e2 = x.z < e2 ? x.z : e2; e3 = x.w < e3 ? x.w : e3;
+            }
+        }
 #pragma unroll
-                for (int o = kWave / 2; o > 0; o >>= 1) {
-                    if (is_sum) {
-                        s0 += __shfl_xor(s0, o, kWave); s1 += __shfl_xor(s1, o, kWave);
-                        s2 += __shfl_xor(s2, o, kWave); s3 += __shfl_xor(s3, o, kWave);
-                    } else {
-                        const float t0 = __shfl_xor(e0, o, kWave), t1 = __shfl_xor(e1, o, kWave);
-                        const float t2 = __shfl_xor(e2, o, kWave), t3 = __shfl_xor(e3, o, kWave);
-                        if (reduction == D3D_REDUCE_MAX) {
-                            e0 = e0 < t0 ? t0 : e0; e1 = e1 < t1 ? t1 : e1; e2 = e2 < t2 ? t2 : e2; e3 = e3 < t3 ? t3 : e3;
-                        } else {
-                            e0 = t0 < e0 ? t0 : e0; e1 = t1 < e1 ? t1 : e1; e2 = t2 < e2 ? t2 : e2; e3 = t3 < e3 ? t3 : e3;
-                        }
-                    }
-                }
-                if (lane == l) {
-                    if (is_sum) {
-                        const float d = reduction == D3D_REDUCE_MEAN ? (float)(int32_t)cc : 1.0f;
-                        agg[v] = make_float4((float)s0 / d, (float)s1 / d, (float)s2 / d, (float)s3 / d);
-                    } else agg[v] = make_float4(e0, e1, e2, e3);
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            if (is_sum) {
+                s0 += __shfl_xor(s0, o, kWave); s1 += __shfl_xor(s1, o, kWave);
+                s2 += __shfl_xor(s2, o, kWave); s3 += __shfl_xor(s3, o, kWave);
+            } else {
+                const float t0 = __shfl_xor(e0, o, kWave), t1 = __shfl_xor(e1, o, kWave);
+                const float t2 = __shfl_xor(e2, o, kWave), t3 = __shfl_xor(e3, o, kWave);
+                if (reduction == D3D_REDUCE_MAX) {
+                    e0 = e0 < t0 ? t0 : e0; e1 = e1 < t1 ? t1 : e1; e2 = e2 < t2 ? t2 : e2; e3 = e3 < t3 ? t3 : e3;
+                } else {
+                    e0 = t0 < e0 ? t0 : e0; e1 = t1 < e1 ? t1 : e1; e2 = t2 < e2 ? t2 : e2; e3 = t3 < e3 ? t3 : e3;
                 }
             }
+        }
+        if (lane == 0) {
+            if (is_sum) {
+                const float d = reduction == D3D_REDUCE_MEAN ? (float)(int32_t)cc : 1.0f;
+                agg[v] = make_float4((float)s0 / d, (float)s1 / d, (float)s2 / d, (float)s3 / d);
+            } else agg[v] = make_float4(e0, e1, e2, e3);
         }
     }
 }
@@ -797,6 +817,9 @@ struct VoxelWs {
     uint32_t *unsorted;   // per-voxel segments in arrival order
     uint32_t *voff;
     uint4 *vinfo;         // [V] {key lo, key hi, segment base, count}
+    float4 *staged;       // C == 4: point rows in per-voxel segments, point order (first max_points valid)
+    uint32_t *big_list;   // overflow voxels (count > max_points) awaiting k_overflow_reduce
+    uint32_t *big_count;
     u64 *bsum;            // generic scans (filter)
     int32_t *newid;
     uint32_t *coff;
@@ -834,6 +857,9 @@ static VoxelWs carve(void *ws, size_t ws_bytes, int64_t n, int64_t nvox)
     r.unsorted = w.take<uint32_t>(r.npad + 4);
     r.voff = w.take<uint32_t>(r.npad + 4);
     r.vinfo = w.take<uint4>(r.npad);
+    r.staged = w.take<float4>(r.npad + 4);
+    r.big_list = w.take<uint32_t>(r.npad);
+    r.big_count = w.take<uint32_t>(64);
     r.bsum = w.take<u64>(d3d_divup(m > 0 ? m : 1, kScanTile) + 1);
     r.newid = w.take<int32_t>(nvox > 0 ? nvox : 1);
     r.coff = w.take<uint32_t>(nvox > 0 ? nvox : 1);
@@ -860,6 +886,7 @@ struct IndexOpts {
     int64_t *first_out;
     int64_t index_offset;
     int64_t *mapping;         // optional point -> voxel id
+    bool stage4;              // C == 4 and 16-byte aligned points: stage rows for fill / reduction
 };
 
 // table + first-seen numbering (+ per-voxel sorted index lists when max_points > 0)
@@ -868,7 +895,8 @@ static int build_index(const Key &kf, const Tab &tab, const float *points, int64
                        int64_t *counts, const IndexOpts &o, hipStream_t st)
 {
     const int64_t cap = (int64_t)w.cap;
-    D3D_LAUNCH("k_init", k_init<Tab>, dim3(grid_for(cap, 256)), dim3(256), 0, st, tab, cap, w.flags, w.npad / 16, counts);
+    D3D_LAUNCH("k_init", k_init<Tab>, dim3(grid_for(cap, 256)), dim3(256), 0, st, tab, cap, w.flags, w.npad / 16, counts,
+               w.big_count);
     if (n > 0) {
         const bool vec4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0);
         dim3 grid((unsigned)d3d_divup(n, 256));
@@ -891,10 +919,12 @@ static int build_index(const Key &kf, const Tab &tab, const float *points, int64
     if (o.mapping)
         D3D_LAUNCH("k_map", k_map, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, w.vidarr, w.pslot, n, o.mapping);
     if (o.max_voxels == 0 || o.max_points == 0) return D3D_OK;
+    const float4 *p4 = reinterpret_cast<const float4 *>(points);
+    float4 *staged = o.stage4 ? w.staged : nullptr;
     D3D_LAUNCH("k_scatter", k_scatter, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, w.aux, w.pslot, w.parr,
-               w.unsorted, w.list);
+               w.unsorted, w.list, p4, staged);
     D3D_LAUNCH("k_select", k_select, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, w.pslot, w.parr, w.unsorted,
-               w.list, o.max_points);
+               w.list, o.max_points, p4, staged);
     return D3D_OK;
 }
 
@@ -969,28 +999,32 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     if ((max_voxels > 0 && n > 0) && (!voxels || !coords || !pmask || !npoints)) return D3D_ERR_BAD_ARG;
 
-    IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr};
+    const bool al16 = ((reinterpret_cast<uintptr_t>(points) & 15) == 0) && ((reinterpret_cast<uintptr_t>(voxels) & 15) == 0);
+    const bool vec4 = (c == 4) && al16 && (reduction == D3D_REDUCE_NONE || (reinterpret_cast<uintptr_t>(aggregates) & 15) == 0);
+    IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr, vec4};
     rc = dense_index(kf, points, n, c, w, counts, o, st);
     if (rc) return rc;
     if (n == 0 || max_voxels == 0) return D3D_OK;
 
     const int64_t cap = n < max_voxels ? n : (int64_t)max_voxels;
     const uint32_t P = (uint32_t)max_points;
-    const bool al16 = ((reinterpret_cast<uintptr_t>(points) & 15) == 0) && ((reinterpret_cast<uintptr_t>(voxels) & 15) == 0);
-    const bool vec4 = (c == 4) && al16 && (reduction == D3D_REDUCE_NONE || (reinterpret_cast<uintptr_t>(aggregates) & 15) == 0);
     const bool fuse_pmask = P > 0 && (P % 16 == 0) && ((reinterpret_cast<uintptr_t>(pmask) & 15) == 0);
     const bool agg4 = vec4 && reduction != D3D_REDUCE_NONE && P > 0;
     const dim3 mgrid(grid_for(cap, 256));
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
     if (agg4)
-        D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), mgrid, dim3(256), 0, st, kf, p4, counts, w.vinfo, w.list, w.unsorted, P,
-                   reduction, coords, npoints, w.voff, fuse_pmask ? pmask : nullptr, reinterpret_cast<float4 *>(aggregates));
+        D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), mgrid, dim3(256), 0, st, kf, p4, counts, w.vinfo, w.staged, w.unsorted, P,
+                   reduction, coords, npoints, w.voff, fuse_pmask ? pmask : nullptr, reinterpret_cast<float4 *>(aggregates),
+                   w.big_list, w.big_count);
     else
-        D3D_LAUNCH("k_meta", (k_meta<DenseKey, false>), mgrid, dim3(256), 0, st, kf, p4, counts, w.vinfo, w.list, w.unsorted, P,
-                   reduction, coords, npoints, w.voff, fuse_pmask ? pmask : nullptr, (float4 *)nullptr);
+        D3D_LAUNCH("k_meta", (k_meta<DenseKey, false>), mgrid, dim3(256), 0, st, kf, p4, counts, w.vinfo, w.staged, w.unsorted, P,
+                   reduction, coords, npoints, w.voff, fuse_pmask ? pmask : nullptr, (float4 *)nullptr, w.big_list, w.big_count);
+    if (agg4)
+        D3D_LAUNCH("k_overflow_reduce", k_overflow_reduce, dim3(512), dim3(256), 0, st, p4, w.vinfo, w.unsorted, w.big_list,
+                   w.big_count, reduction, reinterpret_cast<float4 *>(aggregates));
     if (P == 0) return D3D_OK;
     if (vec4)
-        D3D_LAUNCH("k_fill_c4", k_fill_c4, dim3(grid_for(cap * P, 256, 256 * 32)), dim3(256), 0, st, p4, counts, w.vinfo, w.list,
+        D3D_LAUNCH("k_fill_c4", k_fill_c4, dim3(grid_for(cap * P, 256, 256 * 32)), dim3(256), 0, st, w.staged, counts, w.vinfo,
                    P, reinterpret_cast<float4 *>(voxels));
     else
         D3D_LAUNCH("k_fill_generic", k_fill_generic, dim3(grid_for(cap * P * c, 256, 256 * 32)), dim3(256), 0, st, points, c,
@@ -1023,20 +1057,23 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     VoxelWs w = carve(workspace, workspace_bytes, n, 0);
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     const uint32_t P = 32;   // voxels up to 32 points are reduced sequentially in point order, larger ones cooperatively
-    IndexOpts o{P, 0xffffffffu, first, index_offset, mapping};
+    const bool agg4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(aggregates) & 15) == 0);
+    IndexOpts o{P, 0xffffffffu, first, index_offset, mapping, agg4};
     rc = dense_index(kf, points, n, c, w, counts, o, st);
     if (rc) return rc;
     if (n == 0) return D3D_OK;
-    const bool agg4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(aggregates) & 15) == 0);
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
-    if (agg4)
+    if (agg4) {
         D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, p4, counts, w.vinfo,
-                   w.list, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr,
-                   reinterpret_cast<float4 *>(aggregates));
-    else {
+                   w.staged, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr,
+                   reinterpret_cast<float4 *>(aggregates), w.big_list, w.big_count);
+        D3D_LAUNCH("k_overflow_reduce", k_overflow_reduce, dim3(512), dim3(256), 0, st, p4, w.vinfo, w.unsorted, w.big_list,
+                   w.big_count, reduction, reinterpret_cast<float4 *>(aggregates));
+    } else {
         D3D_LAUNCH("k_meta", (k_meta<DenseKey, false>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, p4, counts, w.vinfo,
-                   w.list, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr, (float4 *)nullptr);
+                   w.staged, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr, (float4 *)nullptr,
+                   w.big_list, w.big_count);
         D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(n * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
                    w.voff, w.list, w.unsorted, P, reduction, aggregates);
     }
@@ -1056,12 +1093,12 @@ extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c,
     SparseKey kf;
     for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
     TabPlain tab{w.tabA, w.tabB};
-    IndexOpts o{0u, 0xffffffffu, nullptr, 0, points_mapping};
+    IndexOpts o{0u, 0xffffffffu, nullptr, 0, points_mapping, false};
     int rc = build_index(kf, tab, points, n, c, w, counts, o, st);
     if (rc || n == 0) return rc;
     D3D_LAUNCH("k_meta", (k_meta<SparseKey, false>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, (const float4 *)nullptr,
-               counts, w.vinfo, w.list, w.unsorted, 0u, 0, coords, npoints, (uint32_t *)nullptr, (unsigned char *)nullptr,
-               (float4 *)nullptr);
+               counts, w.vinfo, w.staged, w.unsorted, 0u, 0, coords, npoints, (uint32_t *)nullptr, (unsigned char *)nullptr,
+               (float4 *)nullptr, w.big_list, w.big_count);
     return D3D_OK;
 }
 
