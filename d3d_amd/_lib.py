@@ -30,11 +30,13 @@ SIGNATURES = {
     "d3d_voxelize_3d_sparse": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_voxelize_3d_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "d3d_voxelize_3d_reduce": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+    "d3d_voxelize_3d_reduce": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                               _vp, _sz, _vp]),
+    "d3d_sharded_finalize": (ctypes.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "d3d_sharded_map": (ctypes.c_int, [_i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "d3d_grid_compact_workspace_bytes": (_sz, [_i64]),
     "d3d_grid_compact_index": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
-    "d3d_grid_compact_lookup": (ctypes.c_int, [_vp, _i64, _i64, _vp, _sz, _vp, _vp]),
+    "d3d_grid_compact_lookup": (ctypes.c_int, [_vp, _i64, _i64, _vp, _sz, _i64, _vp, _vp]),
     "d3d_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "d3d_profile_report": (ctypes.c_int, [ctypes.c_char_p, _sz]),
     "d3d_iou2d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void k_meta(Key kf, const float4 *__restrict__
                                               const float4 *__restrict__ staged, const uint32_t *__restrict__ unsorted,
                                               uint32_t P, int reduction, int64_t *coords, int32_t *npoints,
                                               uint32_t *voff, unsigned char *pmask, float4 *agg, uint32_t *big_list,
-                                              uint32_t *big_count)
+                                              uint32_t *big_count, int64_t *keys_out = nullptr)
 {
     const int64_t V = counts[D3D_COUNT_VOXELS];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -581,6 +581,7 @@ __global__ __launch_bounds__(256) void k_meta(Key kf, const float4 *__restrict__
             coords[v * 3 + 2] = cc[2];
             npoints[v] = (int32_t)vi.w;
             if (voff) voff[v] = vi.z;
+            if (keys_out) keys_out[v] = (int64_t)(((u64)vi.y << 32) | vi.x);
             if (pmask) {                                   // P % 16 == 0, 16-byte aligned (host-checked)
                 for (uint32_t k0 = 0; k0 < P; k0 += 16) {
                     uint32_t w4[4];
@@ -1043,10 +1044,11 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
 // and as the per-rank stage of the point-sharded voxelizer (d3d_amd/voxel/sharded.py).
 extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                       int32_t reduction, int64_t index_offset, int64_t *coords, int32_t *npoints,
-                                      float *aggregates, int64_t *first, int64_t *mapping, int64_t *counts,
-                                      void *workspace, size_t workspace_bytes, void *stream)
+                                      float *aggregates, int64_t *first, int64_t *mapping, int64_t *keys,
+                                      int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    if (keys && n > 0) D3D_HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)n * 8, st));   // -1 = no voxel in this row
     if (n < 0 || c < 3 || !shape || !bound || !counts) return D3D_ERR_BAD_ARG;
     if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
     if (reduction < D3D_REDUCE_MEAN || reduction > kReduceSum) return D3D_ERR_UNSUPPORTED;
@@ -1067,13 +1069,13 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     if (agg4) {
         D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, p4, counts, w.vinfo,
                    w.staged, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr,
-                   reinterpret_cast<float4 *>(aggregates), w.big_list, w.big_count);
+                   reinterpret_cast<float4 *>(aggregates), w.big_list, w.big_count, keys);
         D3D_LAUNCH("k_overflow_reduce", k_overflow_reduce, dim3(512), dim3(256), 0, st, p4, w.vinfo, w.unsorted, w.big_list,
                    w.big_count, reduction, reinterpret_cast<float4 *>(aggregates));
     } else {
         D3D_LAUNCH("k_meta", (k_meta<DenseKey, false>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, p4, counts, w.vinfo,
                    w.staged, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr, (float4 *)nullptr,
-                   w.big_list, w.big_count);
+                   w.big_list, w.big_count, keys);
         D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(n * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
                    w.voff, w.list, w.unsorted, P, reduction, aggregates);
     }

@@ -50,6 +50,10 @@ class TorchComm:
     def all_gather_var(self, t, sizes):
         """concatenate 1-D tensors of different lengths in rank order (pad to the max, one collective)"""
         cap = max(max(sizes), 1)
+        if min(sizes) == cap and t.numel() == cap:           # equal shards: no padding, no slicing
+            out = torch.empty((self.world * cap,), dtype=t.dtype, device=t.device)
+            self._dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+            return out
         pad = torch.zeros((cap,), dtype=t.dtype, device=t.device)
         pad[:t.numel()] = t
         out = torch.empty((self.world * cap,), dtype=t.dtype, device=t.device)
@@ -63,9 +67,12 @@ class TorchComm:
 
 
 class HipOps:
-    """the compute steps, on the HIP kernels of libd3d_hip.so"""
+    """the compute steps, on the HIP kernels of libd3d_hip.so (no host synchronisation except where noted)"""
 
-    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset):
+    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False):
+        """-> coords[n,3], cnt[n], agg[n,c], first[n], mapping[n], keys[n], counts[4] -- all on the device and all
+        sized for n voxels; only the first counts[0] rows are meaningful (keys is -1 beyond them).  counts[2]
+        carries the status bits."""
         lib = _lib.load()
         pts = points.contiguous()
         dev = pts.device
@@ -78,57 +85,94 @@ class HipOps:
             agg = torch.empty((n, c), dtype=torch.float32, device=dev)
             first = torch.empty((n,), dtype=torch.int64, device=dev)
             mapping = torch.empty((n,), dtype=torch.int64, device=dev)
+            keys = torch.empty((n,), dtype=torch.int64, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
             ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
-            for attempt in (0, 1):
+            lib.d3d_voxel_force_plain(1 if plain else 0)
+            try:
                 rc = lib.d3d_voxelize_3d_reduce(
                     _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
                     int(reduction), int(index_offset), _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first),
-                    _lib.ptr(mapping), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                    _lib.ptr(mapping), _lib.ptr(keys), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            finally:
                 lib.d3d_voxel_force_plain(0)
-                _lib.check(rc, "voxelize_3d_reduce")
-                host = counts.cpu()
-                status = int(host[_lib.COUNT_STATUS])
-                if status & _lib.STATUS_TABLE_FULL:
-                    raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
-                if not (status & _lib.STATUS_PACK_OVERFLOW):
-                    break
-                lib.d3d_voxel_force_plain(1)     # one voxel outgrew the packed slot's counter: general layout
-            v = int(host[_lib.COUNT_VOXELS])
-        return coords[:v], cnt[:v], agg[:v], first[:v], mapping
+            _lib.check(rc, "voxelize_3d_reduce")
+        return coords, cnt, agg, first, mapping, keys, counts
 
-    def compact_index(self, keys, ncells):
-        """-> (handle, number of distinct keys); handle feeds compact_lookup"""
+    def compact_index(self, keys, ncells, need_total=True):
+        """-> (handle, number of distinct keys or None); handle feeds compact_lookup.  Negative keys are ignored.
+        Reading the total is a host synchronisation."""
         lib = _lib.load()
         dev = keys.device
         keys = keys.contiguous()
         with torch.cuda.device(dev):
             ws = torch.empty((lib.d3d_grid_compact_workspace_bytes(ncells),), dtype=torch.uint8, device=dev)
-            counts = torch.zeros((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+            counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
             rc = lib.d3d_grid_compact_index(_lib.ptr(keys), keys.numel(), int(ncells), _lib.ptr(counts), _lib.ptr(ws),
                                             ws.numel(), _lib.stream_ptr())
             _lib.check(rc, "grid_compact_index")
-            total = int(counts.cpu()[0])
+            total = int(counts[0].item()) if need_total else None
         return (ws, int(ncells)), total
 
-    def compact_lookup(self, handle, keys):
+    def compact_lookup(self, handle, keys, missing=-1):
         lib = _lib.load()
         ws, ncells = handle
         dev = keys.device
         keys = keys.contiguous()
         with torch.cuda.device(dev):
             slot = torch.empty((keys.numel(),), dtype=torch.int64, device=dev)
-            rc = lib.d3d_grid_compact_lookup(_lib.ptr(keys), keys.numel(), ncells, _lib.ptr(ws), ws.numel(),
+            rc = lib.d3d_grid_compact_lookup(_lib.ptr(keys), keys.numel(), ncells, _lib.ptr(ws), ws.numel(), int(missing),
                                              _lib.ptr(slot), _lib.stream_ptr())
             _lib.check(rc, "grid_compact_lookup")
         return slot
+
+    def finalize(self, nvox, c, vid_of_slot, key_of_slot, table, mean, cnt_in, shape):
+        """slot-ordered reduced table -> voxel-id-ordered (coords, counts, features)"""
+        lib = _lib.load()
+        dev = table.device
+        shape_h = (ctypes.c_int32 * 3)(*[int(x) for x in shape])
+        with torch.cuda.device(dev):
+            coords = torch.empty((nvox, 3), dtype=torch.int64, device=dev)
+            cnt = torch.empty((nvox,), dtype=torch.int32, device=dev)
+            feats = torch.empty((nvox, c), dtype=torch.float32, device=dev)
+            rc = lib.d3d_sharded_finalize(nvox, c, _lib.ptr(vid_of_slot), _lib.ptr(key_of_slot), _lib.ptr(table),
+                                          table.shape[1], 1 if mean else 0, _lib.ptr(cnt_in),
+                                          ctypes.cast(shape_h, ctypes.c_void_p), _lib.ptr(coords), _lib.ptr(cnt),
+                                          _lib.ptr(feats), _lib.stream_ptr())
+            _lib.check(rc, "sharded_finalize")
+        return coords, cnt, feats
+
+    def compose_map(self, local_map, slot_of_local, nvox, vid_of_slot):
+        lib = _lib.load()
+        dev = local_map.device
+        with torch.cuda.device(dev):
+            gmap = torch.empty_like(local_map)
+            rc = lib.d3d_sharded_map(local_map.numel(), _lib.ptr(local_map), _lib.ptr(slot_of_local), nvox,
+                                     _lib.ptr(vid_of_slot), _lib.ptr(gmap), _lib.stream_ptr())
+            _lib.check(rc, "sharded_map")
+        return gmap
+
+
+def _status_retry(counts_host):
+    status = int(counts_host[_lib.COUNT_STATUS])
+    if status & _lib.STATUS_TABLE_FULL:
+        raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
+    return bool(status & _lib.STATUS_PACK_OVERFLOW)   # a voxel outgrew the packed slot counter: redo with plain slots
 
 
 def voxelize_reduce(points, shape, bounds, reduction="mean"):
     """single-GPU "dynamic voxelization": Dict(coords, voxel_npoints, aggregates, points_mapping, voxel_first)"""
     red = _REDUCTIONS[reduction.upper()]
-    coords, cnt, agg, first, mapping = HipOps().voxelize_reduce(points, shape, bounds, red, 0)
-    return Dict(coords=coords, voxel_npoints=cnt, aggregates=agg, points_mapping=mapping, voxel_first=first)
+    ops = HipOps()
+    out = ops.voxelize_reduce(points, shape, bounds, red, 0)
+    host = out[6].cpu()
+    if _status_retry(host):
+        out = ops.voxelize_reduce(points, shape, bounds, red, 0, plain=True)
+        host = out[6].cpu()
+    v = int(host[_lib.COUNT_VOXELS])
+    coords, cnt, agg, first, mapping, _, _ = out
+    return Dict(coords=coords[:v], voxel_npoints=cnt[:v], aggregates=agg[:v], points_mapping=mapping,
+                voxel_first=first[:v])
 
 
 class ShardedVoxelGenerator:
@@ -147,61 +191,71 @@ class ShardedVoxelGenerator:
         self._ncells = self._shape[0] * self._shape[1] * self._shape[2]
         self._comm = comm if comm is not None else TorchComm(group)
         self._ops = ops if ops is not None else HipOps()
+        self._layout_key, self._layout_val = None, None
+
+    def _layout(self, n, dev):
+        """shard sizes over the ranks; exchanged once per local shard size (one collective + host read)"""
+        if self._layout_key != n:
+            sizes = self._comm.all_gather_int(n, dev)
+            self._layout_key = n
+            self._layout_val = (sum(sizes[:self._comm.rank]), sum(sizes), max(max(sizes), 1))
+        return self._layout_val
 
     def __call__(self, points):
+        for plain in (False, True):
+            out = self._run(points, plain)
+            if out is not None:
+                return out
+        raise RuntimeError("sharded voxelization failed")
+
+    def _run(self, points, plain):
         comm, ops = self._comm, self._ops
         dev = points.device
-        c = points.shape[1]
-        sy, sz = self._shape[1], self._shape[2]
-        # 0. shard offsets in the global point order
-        sizes_n = comm.all_gather_int(points.shape[0], dev)
-        offset, n_total = sum(sizes_n[:comm.rank]), sum(sizes_n)
-        # 1. local hash + partial reduction
-        local_red = _SUM if self._red == 1 else self._red
-        coords_r, cnt_r, agg_r, first_r, map_r = ops.voxelize_reduce(points, self._shape, self._bounds, local_red, offset)
-        keys_r = (coords_r[:, 0] * sy + coords_r[:, 1]) * sz + coords_r[:, 2]
-        # 2. all-gather the occupied-cell keys
-        sizes_v = comm.all_gather_int(keys_r.numel(), dev)
-        keys_all = comm.all_gather_var(keys_r, sizes_v)
-        # 3. identical compact slots on every rank
+        n, c = points.shape
+        offset, n_total, cap = self._layout(n, dev)
+        mean = self._red == 1
+        # 1. local hash + partial reduction; nothing is read back: rows >= V_r carry key -1
+        kw = {"plain": True} if plain else {}
+        _, cnt_r, agg_r, first_r, map_r, keys_r, counts_r = ops.voxelize_reduce(
+            points, self._shape, self._bounds, _SUM if mean else self._red, offset, **kw)
+        # 2. all-gather the occupied-cell keys, padded to the largest shard
+        pad = keys_r if n == cap else torch.cat([keys_r, keys_r.new_full((cap - n,), -1)])
+        keys_all = comm.all_gather_var(pad, [cap] * comm.world)
+        # 3. identical compact slots on every rank (the one host read-back: the global voxel count)
         handle, nvox = ops.compact_index(keys_all, self._ncells)
-        slot_r = ops.compact_lookup(handle, keys_r)
-        slot_all = ops.compact_lookup(handle, keys_all)
-        key_of_slot = torch.empty((nvox,), dtype=torch.int64, device=dev)
-        key_of_slot[slot_all] = keys_all                      # duplicates write the same value
-        # 4. all-reduce the compact voxel table
-        if self._red == 1:
-            table = torch.zeros((nvox, c + 1), dtype=torch.float32, device=dev)
+        retry = 1.0 if _status_retry(counts_r.cpu()) else 0.0
+        slot_all = ops.compact_lookup(handle, keys_all, missing=nvox)       # row nvox swallows the padding
+        slot_r = slot_all[comm.rank * cap: comm.rank * cap + n]
+        key_of_slot = torch.empty((nvox + 1,), dtype=torch.int64, device=dev)
+        key_of_slot[slot_all] = keys_all                                    # duplicates write the same value
+        # 4. all-reduce the compact voxel table (a pack-overflow retry flag rides along in an extra row)
+        if mean:
+            table = torch.zeros((nvox + 2, c + 1), dtype=torch.float32, device=dev)
             table[slot_r, :c] = agg_r
-            table[slot_r, c] = cnt_r.to(torch.float32)        # counts < 2^24 are exact in fp32
+            table[slot_r, c] = cnt_r.to(torch.float32)       # counts < 2^24 are exact in fp32
+            table[nvox + 1, 0] = retry
             comm.all_reduce(table, "sum")
-            cnt = table[:, c].round().to(torch.int32)
-            feats = table[:, :c] / table[:, c:c + 1]
+            need_retry, cnt_t = table[nvox + 1, 0], None
         else:
-            init = float("-inf") if self._red == 2 else float("inf")
-            feats = torch.full((nvox, c), init, dtype=torch.float32, device=dev)
-            feats[slot_r] = agg_r
-            comm.all_reduce(feats, "max" if self._red == 2 else "min")
-            cnt = torch.zeros((nvox,), dtype=torch.int32, device=dev)
-            cnt[slot_r] = cnt_r
-            comm.all_reduce(cnt, "sum")
-        first = torch.full((nvox,), _I64_MAX, dtype=torch.int64, device=dev)
+            table = torch.full((nvox + 1, c), float("-inf") if self._red == 2 else float("inf"), dtype=torch.float32,
+                               device=dev)
+            table[slot_r] = agg_r
+            comm.all_reduce(table, "max" if self._red == 2 else "min")
+            cnt_t = torch.zeros((nvox + 2,), dtype=torch.int32, device=dev)
+            cnt_t[slot_r] = cnt_r
+            cnt_t[nvox + 1] = int(retry)
+            comm.all_reduce(cnt_t, "sum")
+            need_retry = cnt_t[nvox + 1]
+        first = torch.full((nvox + 1,), _I64_MAX, dtype=torch.int64, device=dev)
         first[slot_r] = first_r
         comm.all_reduce(first, "min")
         # 5. first-seen numbering: rank of each voxel's first point index among all first indices
-        handle2, nfirst = ops.compact_index(first, max(n_total, 1))
-        assert nfirst == nvox, "every voxel has a distinct first point"
-        vid_of_slot = ops.compact_lookup(handle2, first)
-        coords = torch.empty((nvox, 3), dtype=torch.int64, device=dev)
-        k = key_of_slot
-        coords[vid_of_slot] = torch.stack([k // (sy * sz), (k // sz) % sy, k % sz], 1)
-        out_cnt = torch.empty_like(cnt)
-        out_cnt[vid_of_slot] = cnt
-        out_feats = torch.empty_like(feats)
-        out_feats[vid_of_slot] = feats
-        gmap = torch.full_like(map_r, -1)
-        ok = map_r >= 0
-        gmap[ok] = vid_of_slot[slot_r[map_r[ok]]]
+        handle2, _ = ops.compact_index(first[:nvox], max(n_total, 1), need_total=False)
+        vid_of_slot = ops.compact_lookup(handle2, first[:nvox])
+        coords, out_cnt, out_feats = ops.finalize(nvox, c, vid_of_slot, key_of_slot, table, mean, cnt_t, self._shape)
+        gmap = ops.compose_map(map_r, slot_r, nvox, vid_of_slot)
+        if not plain and float(need_retry) > 0:       # some rank hit the packed-slot counter limit (rare): redo
+            return None
         return Dict(coords=coords, voxel_npoints=out_cnt, aggregates=out_feats, points_mapping=gmap)
 
 

@@ -113,20 +113,30 @@ int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c,
  * d3d_voxelize_3d_dense (voxelize.cpp:100-101), first-seen voxel ids (voxelize.cpp:119), reduction over
  * ALL in-range points (voxelize.cpp:137-164).  reduction: MEAN/MAX/MIN or 4 = SUM (MEAN without the division).
  *   coords[n,3] i64, npoints[n] i32, aggregates[n,c] f32, first[n] i64 (index_offset + index of the voxel's first
- *   point; may be NULL), mapping[n] i64 (voxel id per point, -1 = out of range; may be NULL). */
+ *   point; may be NULL), mapping[n] i64 (voxel id per point, -1 = out of range; may be NULL),
+ *   keys[n] i64 (linear cell index (x*sy+y)*sz+z per voxel, -1 in the rows >= counts[0]; may be NULL). */
 int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                            int32_t reduction, int64_t index_offset, int64_t *coords, int32_t *npoints,
-                           float *aggregates, int64_t *first, int64_t *mapping, int64_t *counts,
+                           float *aggregates, int64_t *first, int64_t *mapping, int64_t *keys, int64_t *counts,
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* Rank-independent compact numbering of occupied cells: mark keys[m] (linear cell index in [0,ncells)) in a
  * bitmap, popcount-prefix it; counts[0] = distinct occupied cells.  lookup: slot[j] = index of keys[j] among the
- * occupied cells in ascending key order (-1 when unmarked).  Both use the same workspace. */
+ * occupied cells in ascending key order (`missing` when unmarked).  Both use the same workspace. */
 size_t d3d_grid_compact_workspace_bytes(int64_t ncells);
 int d3d_grid_compact_index(const int64_t *keys, int64_t m, int64_t ncells, int64_t *counts,
                            void *workspace, size_t workspace_bytes, void *stream);
 int d3d_grid_compact_lookup(const int64_t *keys, int64_t m, int64_t ncells, const void *workspace,
-                            size_t workspace_bytes, int64_t *slot, void *stream);
+                            size_t workspace_bytes, int64_t missing, int64_t *slot, void *stream);
+
+/* last steps of the sharded voxelizer: (a) slot-ordered all-reduced table [nvox, table_stride] (mean: c sums + count;
+ * else c extrema, counts in cnt_in) -> voxel-id-ordered coords[nvox,3], cnt_out[nvox], feats[nvox,c];
+ * (b) global voxel id of every local point: gmap[i] = vid_of_slot[slot_of_local[local_map[i]]] (-1 stays -1). */
+int d3d_sharded_finalize(int64_t nvox, int32_t c, const int64_t *vid_of_slot, const int64_t *key_of_slot,
+                         const float *table, int32_t table_stride, int32_t mean, const int32_t *cnt_in,
+                         const int32_t *shape, int64_t *coords, int32_t *cnt_out, float *feats, void *stream);
+int d3d_sharded_map(int64_t n, const int64_t *local_map, const int64_t *slot_of_local, int64_t nvox,
+                    const int64_t *vid_of_slot, int64_t *gmap, void *stream);
 
 /* opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline leg);
  * report: "kernel,calls,total_ms" lines. */

@@ -11,7 +11,7 @@ import oracle
 class NumpyOps:
     """same interface as d3d_amd.voxel.sharded.HipOps, computed with the CPU oracle + numpy"""
 
-    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset):
+    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False):
         pts = points.cpu().numpy()
         n, c = pts.shape
         red = {1: 1, 2: 2, 3: 3, 4: 1}[int(reduction)]
@@ -33,18 +33,53 @@ class NumpyOps:
         for i in range(n - 1, -1, -1):
             if mapping[i] >= 0:
                 first[mapping[i]] = i + index_offset
-        T = torch.from_numpy
-        return T(coords), T(cnt), T(agg), T(first), T(mapping)
+        v = len(coords)
 
-    def compact_index(self, keys, ncells):
-        u = np.unique(keys.cpu().numpy())
+        def padded(a, fill):          # device contract: buffers sized for n voxels, rows >= V are garbage
+            out = np.full((n,) + a.shape[1:], fill, a.dtype)
+            out[:v] = a
+            return torch.from_numpy(out)
+        counts = torch.tensor([v, 0, 0, 0], dtype=torch.int64)
+        keys = (coords[:, 0] * shape[1] + coords[:, 1]) * shape[2] + coords[:, 2]
+        return (padded(coords, 7), padded(cnt, 99), padded(agg, 1e30), padded(first, 123), torch.from_numpy(mapping),
+                padded(keys.astype(np.int64), -1), counts)
+
+    def compact_index(self, keys, ncells, need_total=True):
+        k = keys.cpu().numpy()
+        u = np.unique(k[k >= 0])
         return u, len(u)
 
-    def compact_lookup(self, handle, keys):
+    def compact_lookup(self, handle, keys, missing=-1):
         k = keys.cpu().numpy()
+        if len(handle) == 0:
+            return torch.full((len(k),), missing, dtype=torch.int64)
         pos = np.searchsorted(handle, k)
-        pos = np.where((pos < len(handle)) & (handle[np.minimum(pos, len(handle) - 1)] == k), pos, -1)
+        pos = np.where((pos < len(handle)) & (handle[np.minimum(pos, len(handle) - 1)] == k), pos, missing)
         return torch.from_numpy(pos.astype(np.int64)).to(keys.device)
+
+    def finalize(self, nvox, c, vid_of_slot, key_of_slot, table, mean, cnt_in, shape):
+        vid = vid_of_slot.numpy()
+        k = key_of_slot.numpy()[:nvox]
+        t = table.numpy()[:nvox]
+        sy, sz = shape[1], shape[2]
+        coords = np.empty((nvox, 3), np.int64)
+        coords[vid] = np.stack([k // (sy * sz), (k // sz) % sy, k % sz], 1)
+        cnt = np.empty((nvox,), np.int32)
+        feats = np.empty((nvox, c), np.float32)
+        if mean:
+            cnt[vid] = np.round(t[:, c]).astype(np.int32)
+            feats[vid] = t[:, :c] / t[:, c:c + 1]
+        else:
+            cnt[vid] = cnt_in.numpy()[:nvox]
+            feats[vid] = t[:, :c]
+        return torch.from_numpy(coords), torch.from_numpy(cnt), torch.from_numpy(feats)
+
+    def compose_map(self, local_map, slot_of_local, nvox, vid_of_slot):
+        m = local_map.numpy()
+        out = np.full(m.shape, -1, np.int64)
+        ok = m >= 0
+        out[ok] = vid_of_slot.numpy()[slot_of_local.numpy()[m[ok]]]
+        return torch.from_numpy(out)
 
 
 class LockedOps:
