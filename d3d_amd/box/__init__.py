@@ -211,9 +211,52 @@ def iou3d(boxes1, boxes2, method="rbox"):
     return out.numpy() if convert_numpy else out
 
 
+def crop_2dr(points, boxes):
+    """crop_2dr of the reference (utils.cpp:38-47; box_impl.crop_2dr): bool[M,N] indicators, [i,j] = point j is
+    inside rotated box i.  points [N,2], boxes [M,5], same floating dtype."""
+    lib = _lib.load()
+    if len(points.shape) != 2 or points.shape[1] != 2 or len(boxes.shape) != 2 or boxes.shape[1] != 5:
+        raise ValueError("points should be Nx2 and boxes Mx5")
+    if points.dtype != boxes.dtype:
+        raise RuntimeError("points and boxes must have the same dtype")
+    odev = points.device
+    (p, b), dev = _to_device(points, boxes)
+    n, m = p.shape[0], b.shape[0]
+    with torch.cuda.device(dev):
+        out = torch.empty((m, n), dtype=torch.uint8, device=dev)
+        rc = lib.d3d_crop_2dr(_lib.ptr(p), n, _lib.ptr(b), m, _dtype_code(p), _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "crop_2dr")
+    out = out.view(torch.bool)
+    return out.to(odev) if odev != dev else out
+
+
+def box2dr_crop(points, boxes):
+    """Crop points by rotated boxes -- reference box/__init__.py:278-287 (returns the [M,N] indicator matrix,
+    as the reference's code does)."""
+    return crop_2dr(points, boxes)
+
+
+def box3dp_crop(points, boxes, project_axis=2):
+    """Crop points [N,3] by boxes [M,7] projected along `project_axis` -- reference box/__init__.py:289-315."""
+    if project_axis == 0:
+        points_2d, boxes_2d = points[:, [1, 2]], boxes[:, [1, 2, 4, 5, 6]]
+    elif project_axis == 1:
+        points_2d, boxes_2d = points[:, [0, 2]], boxes[:, [0, 2, 3, 5, 6]]
+    elif project_axis == 2:
+        points_2d, boxes_2d = points[:, [0, 1]], boxes[:, [0, 1, 3, 4, 6]]
+    else:
+        raise ValueError("The projection axis can only be 0-x, 1-y and 2-z!")
+    mask_2d = crop_2dr(points_2d, boxes_2d)
+    points_p = points[:, [project_axis]].t()
+    boxes_p = boxes[:, [project_axis]]
+    boxes_pd = boxes[:, [3 + project_axis]] / 2
+    mask_p = (points_p - boxes_pd < boxes_p) & (boxes_p < points_p + boxes_pd)
+    return mask_2d & mask_p
+
+
 # north_star operator names
 iou2d = box2d_iou
 nms = box2d_nms
 
-__all__ = ["box2d_iou", "box2d_nms", "iou2d", "iou3d", "nms", "iou2d_forward", "iou2dr_forward", "nms2d",
+__all__ = ["box2dr_crop", "box3dp_crop", "crop_2dr", "box2d_iou", "box2d_nms", "iou2d", "iou3d", "nms", "iou2d_forward", "iou2dr_forward", "nms2d",
            "nms2d_cuda", "argsort_desc", "IouType", "SupressionType", "cuda_available"]

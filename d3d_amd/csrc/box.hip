@@ -356,6 +356,52 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     return D3D_OK;
 }
 
+// ---------------------------------------------------------------- crop: points in rotated boxes
+// indicators[i, j] = point j inside box i (closed AABB test, then the four closed half-plane tests); replaces
+// crop_2dr (reference utils.cpp:9-47).  Lane = 4 consecutive points -> one 32-bit store per box row.
+template <typename T>
+__global__ __launch_bounds__(256) void k_crop2dr(const T *__restrict__ points, int64_t n, const T *__restrict__ boxes,
+                                                 int64_t m, uint8_t *__restrict__ out)
+{
+    __shared__ BoxGeom<T> rows[kTileRows];
+    const int64_t i0 = (int64_t)blockIdx.y * kTileRows;
+    const int nrows = (int)((m - i0) < kTileRows ? (m - i0) : kTileRows);
+    if (threadIdx.x < nrows) rows[threadIdx.x] = Box2D<T>::load(boxes + (i0 + threadIdx.x) * 5);
+    const int64_t j0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    T px[4], py[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool ok = j0 + k < n;
+        px[k] = ok ? points[(j0 + k) * 2] : (T)0;
+        py[k] = ok ? points[(j0 + k) * 2 + 1] : (T)0;
+    }
+    __syncthreads();
+    if (j0 >= n) return;
+    const bool vec = (n % 4 == 0);
+    for (int r = 0; r < nrows; r++) {
+        const BoxGeom<T> g = rows[r];
+        // corners relative to the centre: -u-v, u-v, u+v, -u+v
+        const T cx[4] = {-g.ux - g.vx, g.ux - g.vx, g.ux + g.vx, -g.ux + g.vx};
+        const T cy[4] = {-g.uy - g.vy, g.uy - g.vy, g.uy + g.vy, -g.uy + g.vy};
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            bool in = px[k] >= g.xmin && px[k] <= g.xmax && py[k] >= g.ymin && py[k] <= g.ymax;
+            const T dx = px[k] - g.cx, dy = py[k] - g.cy;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const T ex = cx[(e + 1) & 3] - cx[e], ey = cy[(e + 1) & 3] - cy[e];
+                in = in && (ex * (dy - cy[e]) - ey * (dx - cx[e]) >= 0);
+            }
+            word |= (in ? 1u : 0u) << (8 * k);
+        }
+        uint8_t *dst = out + (i0 + r) * n + j0;
+        if (vec) *reinterpret_cast<uint32_t *>(dst) = word;
+        else
+            for (int k = 0; k < 4 && j0 + k < n; k++) dst[k] = (uint8_t)((word >> (8 * k)) & 1u);
+    }
+}
+
 }  // namespace
 
 // ====================================================================== C ABI
@@ -436,4 +482,21 @@ extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *o
                                  score_threshold, suppressed, workspace, workspace_bytes, st);
     return nms_typed<float>((const float *)boxes, (const float *)scores, order, n, iou_type, iou_threshold,
                             score_threshold, suppressed, workspace, workspace_bytes, st);
+}
+
+extern "C" int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, int64_t m, int32_t dtype, uint8_t *out,
+                            void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || m < 0) return D3D_ERR_BAD_ARG;
+    if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
+    if (n == 0 || m == 0) return D3D_OK;
+    if (!points || !boxes || !out) return D3D_ERR_BAD_ARG;
+    if (d3d_divup(m, kTileRows) > 65535) return D3D_ERR_BAD_ARG;
+    dim3 grid((unsigned)d3d_divup(n, 256 * 4), (unsigned)d3d_divup(m, kTileRows));
+    if (dtype == D3D_F64)
+        D3D_LAUNCH("k_crop2dr", k_crop2dr<double>, grid, dim3(256), 0, st, (const double *)points, n, (const double *)boxes, m, out);
+    else
+        D3D_LAUNCH("k_crop2dr", k_crop2dr<float>, grid, dim3(256), 0, st, (const float *)points, n, (const float *)boxes, m, out);
+    return D3D_OK;
 }

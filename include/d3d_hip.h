@@ -158,6 +158,11 @@ int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t
 int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *boxes2, int64_t m,
                       int32_t rotated, float *out, void *stream);
 
+/* replaces crop_2dr (reference d3d/box/utils.cpp:9-47, bound at box/impl.cpp as crop_2dr; Python box2dr_crop /
+ * box3dp_crop, box/__init__.py:278-315): points[n,2], boxes[m,5] in `dtype`; out[m,n] u8 (0/1),
+ * out[i,j] = point j lies in rotated box i (boundary inclusive). */
+int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, int64_t m, int32_t dtype, uint8_t *out, void *stream);
+
 /* stable descending argsort (the role torch::argsort plays inside the reference's nms2d,
  * nms.cpp:103): keys[n] in `dtype` -> order[n] i64; ties keep ascending index. */
 size_t d3d_argsort_desc_workspace_bytes(int64_t n, int32_t dtype);

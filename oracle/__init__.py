@@ -283,3 +283,29 @@ def iou3d(boxes1, boxes2, method="rbox", nthreads=1):
           ctypes.c_int64(r0), ctypes.c_int64(r1), _p(out))
     _run_rows(run, n, nthreads)
     return out
+
+
+def crop_2dr(points, boxes):
+    """crop_2dr (utils.cpp:38-47): bool[M,N], entry [i,j] = point j lies in rotated box i"""
+    dt = np.float64 if points.dtype == np.float64 else np.float32
+    pts = np.ascontiguousarray(points, dtype=dt)
+    bx = np.ascontiguousarray(boxes, dtype=dt)
+    n, m = pts.shape[0], bx.shape[0]
+    out = np.zeros((m, n), np.uint8)
+    f = lib().oracle_crop_2dr_f64 if dt == np.float64 else lib().oracle_crop_2dr_f32
+    f.restype = None
+    f(_p(pts), ctypes.c_int64(n), _p(bx), ctypes.c_int64(m), _p(out))
+    return out.astype(bool)
+
+
+def box3dp_crop(points, boxes, project_axis=2):
+    """box/__init__.py:289-315 on numpy arrays"""
+    ax2 = {0: ([1, 2], [1, 2, 4, 5, 6]), 1: ([0, 2], [0, 2, 3, 5, 6]), 2: ([0, 1], [0, 1, 3, 4, 6])}
+    if project_axis not in ax2:
+        raise ValueError("The projection axis can only be 0-x, 1-y and 2-z!")
+    pi, bi = ax2[project_axis]
+    mask_2d = crop_2dr(np.ascontiguousarray(points[:, pi]), np.ascontiguousarray(boxes[:, bi]))
+    pp = points[:, [project_axis]].T
+    bp = boxes[:, [project_axis]]
+    bd = boxes[:, [3 + project_axis]] / 2
+    return mask_2d & ((pp - bd < bp) & (bp < pp + bd))

@@ -192,3 +192,25 @@ void FN(oracle_nms2d)(const T *boxes, const T *scores_in, int64_t n_, const int6
     }
     free(scores); free(order);
 }
+
+/* crop_2dr_templated (utils.cpp:9-36): indicators[i][j] = aabox.contains(p_j) && box_i.contains(p_j).
+ * dgal's contains() is restated as the closed point-in-convex-polygon test (cross(edge, p - v) >= 0 for the
+ * four CCW edges) behind the closed AABB test. */
+void FN(oracle_crop_2dr)(const T *points, int64_t n, const T *boxes, int64_t m, uint8_t *out)
+{
+    for (int64_t i = 0; i < m; i++) {
+        const T *b = boxes + i * 5;
+        FN(quad) q = FN(quad_from_xywhr)(b[0], b[1], b[2], b[3], b[4]);
+        FN(aabox) a = FN(aabox_from_quad)(&q);
+        for (int64_t j = 0; j < n; j++) {
+            T px = points[j * 2], py = points[j * 2 + 1];
+            int in = px >= a.xmin && px <= a.xmax && py >= a.ymin && py <= a.ymax;
+            for (int e = 0; e < 4 && in; e++) {
+                FN(pt) v = q.v[e], w = q.v[(e + 1) & 3];
+                T cr = (w.x - v.x) * (py - v.y) - (w.y - v.y) * (px - v.x);
+                if (!(cr >= 0)) in = 0;
+            }
+            out[i * n + j] = (uint8_t)in;
+        }
+    }
+}

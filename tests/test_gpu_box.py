@@ -188,3 +188,39 @@ def test_full_size_cfg4_properties():
     rows = np.random.default_rng(0).choice(20000, 64, replace=False)
     exp = oracle.iou3d(pred[rows], gt, "rbox", nthreads=8)
     assert np.max(np.abs(m[torch.from_numpy(rows).cuda()].cpu().numpy() - exp)) < 1e-3
+
+
+def test_box_crop_reference_case():
+    """reference test/test_box.py:191-205 (with the function's real name and return type)"""
+    from d3d_amd.box import box2dr_crop
+    rng = np.random.default_rng(40)
+    cloud = (rng.random((100, 2)) * 2 - 1).astype(np.float32)
+    boxes = np.array([[0, 0, 1, 1, 0], [0, 0, 1, 1, bc.d90]], np.float32)
+    res = box2dr_crop(T(cloud), T(boxes)).cpu().numpy()
+    a = np.abs(cloud)
+    assert res.shape == (2, 100) and res.dtype == np.bool_
+    assert np.array_equal(np.where(res[0])[0], np.where(np.all(a < 0.5, 1))[0])
+    assert np.array_equal(np.where(res[1])[0], np.where(np.abs(a[:, 0] + a[:, 1]) < bc.sq2 / 2)[0])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [1000, 1003])
+def test_crop_vs_oracle(dtype, n):
+    from d3d_amd.box import box2dr_crop, box3dp_crop
+    rng = np.random.default_rng(41)
+    pts = ((rng.random((n, 2)) - 0.5) * 12).astype(dtype)
+    boxes, _ = bc.random_boxes_like_reference(70, 42)
+    boxes = boxes.astype(dtype)
+    boxes[:, :2] = (rng.random((70, 2)) - 0.5) * 10
+    boxes[:, 2:4] *= 0.2
+    got = box2dr_crop(T(pts), T(boxes)).cpu().numpy()
+    exp = oracle.crop_2dr(pts, boxes)
+    assert got.shape == (70, n)
+    assert np.mean(got != exp) < (1e-4 if dtype == np.float32 else 1e-9)   # only rounding on the boundary may differ
+    assert exp.sum() > 100
+    p3 = np.concatenate([pts, ((rng.random((n, 1)) - 0.5) * 4).astype(dtype)], 1)
+    b3 = np.stack([boxes[:, 0], boxes[:, 1], np.zeros(70), boxes[:, 2], boxes[:, 3], np.full(70, 2.0), boxes[:, 4]], 1).astype(dtype)
+    for ax in [2]:
+        g3 = box3dp_crop(T(p3), T(b3), ax).cpu().numpy()
+        e3 = oracle.box3dp_crop(p3, b3, ax)
+        assert np.mean(g3 != e3) < 1e-4 and e3.sum() > 10

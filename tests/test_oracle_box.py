@@ -78,3 +78,13 @@ def test_threads_do_not_change_results():
     a = oracle.iou2d_forward(b.astype(np.float64), b.astype(np.float64), "rbox", nthreads=1)
     c = oracle.iou2d_forward(b.astype(np.float64), b.astype(np.float64), "rbox", nthreads=4)
     assert np.array_equal(a, c)
+
+
+def test_crop_reference_case():   # test_box.py:191-205
+    rng = np.random.default_rng(40)
+    cloud = (rng.random((100, 2)) * 2 - 1).astype(np.float32)
+    boxes = np.array([[0, 0, 1, 1, 0], [0, 0, 1, 1, bc.d90]], np.float32)
+    res = oracle.crop_2dr(cloud, boxes)
+    a = np.abs(cloud)
+    assert np.array_equal(np.where(res[0])[0], np.where(np.all(a < 0.5, 1))[0])
+    assert np.array_equal(np.where(res[1])[0], np.where(np.abs(a[:, 0] + a[:, 1]) < bc.sq2 / 2)[0])
