@@ -61,8 +61,10 @@ def _iou_forward(boxes1, boxes2, iou_type):
     n, m = b1.shape[0], b2.shape[0]
     with torch.cuda.device(dev):
         ious = torch.empty((n, m), dtype=b1.dtype, device=dev)
-        rc = lib.d3d_iou2d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, int(iou_type), _dtype_code(b1), _lib.ptr(ious),
-                                   _lib.stream_ptr())
+        code = _dtype_code(b1)
+        ws = _lib.workspace(lib.d3d_iou2d_workspace_bytes(n, m, code), dev) if int(iou_type) == IouType.RBOX else None
+        rc = lib.d3d_iou2d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, int(iou_type), code, _lib.ptr(ious),
+                                   _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr())
     _lib.check(rc, "iou2d_forward")
     return ious.to(odev) if odev != dev else ious
 
@@ -203,8 +205,9 @@ def iou3d(boxes1, boxes2, method="rbox"):
     n, m = b1.shape[0], b2.shape[0]
     with torch.cuda.device(dev):
         out = torch.empty((n, m), dtype=torch.float32, device=dev)
+        ws = _lib.workspace(lib.d3d_iou3d_workspace_bytes(n, m), dev)
         rc = lib.d3d_iou3d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, 1 if key == "RBOX" else 0, _lib.ptr(out),
-                                   _lib.stream_ptr())
+                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
     _lib.check(rc, "iou3d_forward")
     if odev != dev:
         out = out.to(odev)

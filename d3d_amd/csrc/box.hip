@@ -14,6 +14,7 @@
 //    (the reference runs this on a single thread: nms_cuda.cu:80-107 <<<1,1>>>).
 #include "common.hpp"
 #include "geom.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -56,8 +57,9 @@ template <typename T, int K> __device__ __forceinline__ void store_row(T *out, c
 
 template <typename T, bool ROTATED, int K>
 __global__ __launch_bounds__(kTileCols) void k_iou2d(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2,
-                                                     int64_t m, T *__restrict__ ious)
+                                                     int64_t m, T *__restrict__ ious, const unsigned int *only_if)
 {
+    if (only_if && !*only_if) return;     // fallback launch of the two-phase path: runs only after a list overflow
     __shared__ BoxGeom<T> rows[kTileRows];
     const int64_t i0 = (int64_t)blockIdx.y * kTileRows;
     const int64_t j0 = ((int64_t)blockIdx.x * kTileCols + threadIdx.x) * K;
@@ -82,6 +84,118 @@ __global__ __launch_bounds__(kTileCols) void k_iou2d(const T *__restrict__ b1, i
     }
 }
 
+// ---------------------------------------------------------------- rotated IoU, two-phase
+// The polygon clip needs ~180 VGPRs in fp64; inside the streaming kernel that caps occupancy at 2 waves/SIMD and
+// leaves most lanes idle whenever only a few pairs of a wavefront overlap.  So for `rbox` the matrix is produced
+// in two phases (MI355X: 288 GB make a 1 GB candidate list a non-issue):
+//   k_iou_pre   streams zeros at store bandwidth (few registers, full occupancy) and appends every pair whose
+//               AABBs overlap to a global candidate list (wave-aggregated atomic append)
+//   k_iou_clip  one candidate per lane -- dense wavefronts of clipping -- and scatters the non-zero IoUs
+// If the list overflows (more candidates than its capacity) the monolithic kernel recomputes everything.
+struct IouList { unsigned long long count; unsigned int overflow, pad; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_geom(const T *__restrict__ boxes, int64_t n, BoxGeom<T> *geom, IouList *hdr)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (hdr && i == 0) { hdr->count = 0; hdr->overflow = 0; }
+    if (i < n) geom[i] = Box2D<T>::load(boxes + i * 5);
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(kTileCols) void k_iou_pre(const BoxGeom<T> *__restrict__ ga, int64_t n,
+                                                       const BoxGeom<T> *__restrict__ gb, int64_t m, T *__restrict__ ious,
+                                                       IouList *hdr, unsigned long long *list, unsigned long long cap)
+{
+    constexpr int kGroup = 8;                                   // rows per candidate batch
+    __shared__ T rx0[kTileRows], rx1[kTileRows], ry0[kTileRows], ry1[kTileRows];
+    __shared__ unsigned char rok[kTileRows];
+    __shared__ unsigned int q[kGroup * kTileCols * K];          // (row << 16 | local column) of this batch
+    __shared__ unsigned int qn;
+    __shared__ unsigned long long qbase;
+    const int64_t i0 = (int64_t)blockIdx.y * kTileRows;
+    const int64_t jb = (int64_t)blockIdx.x * kTileCols * K;     // first column of the block
+    const int64_t j0 = jb + (int64_t)threadIdx.x * K;
+    const int nrows = (int)((n - i0) < kTileRows ? (n - i0) : kTileRows);
+    if (threadIdx.x < nrows) {
+        const BoxGeom<T> g = ga[i0 + threadIdx.x];
+        rx0[threadIdx.x] = g.xmin; rx1[threadIdx.x] = g.xmax; ry0[threadIdx.x] = g.ymin; ry1[threadIdx.x] = g.ymax;
+        rok[threadIdx.x] = g.area > 0;
+    }
+    T cx0[K], cx1[K], cy0[K], cy1[K];
+    bool cok[K];
+    const bool active = j0 < m;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        cok[k] = false;
+        if (active) {
+            const BoxGeom<T> g = gb[j0 + k];
+            cx0[k] = g.xmin; cx1[k] = g.xmax; cy0[k] = g.ymin; cy1[k] = g.ymax;
+            cok[k] = g.area > 0;
+        }
+    }
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    T *out = ious + i0 * m + j0;
+    T zero[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) zero[k] = 0;
+    for (int r0 = 0; r0 < nrows; r0 += kGroup) {
+        const int r1 = r0 + kGroup < nrows ? r0 + kGroup : nrows;
+        for (int r = r0; r < r1; r++) {
+            const T ax0 = rx0[r], ax1 = rx1[r], ay0 = ry0[r], ay1 = ry1[r];
+            const bool aok = rok[r];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const bool cand = aok && cok[k] && ax0 < cx1[k] && cx0[k] < ax1 && ay0 < cy1[k] && cy0[k] < ay1;
+                const unsigned long long mask = __ballot(cand);
+                if (mask) {                                   // wave-aggregated append to the LDS batch
+                    unsigned int base = 0;
+                    const int leader = __builtin_ctzll(mask);
+                    if (lane == leader) base = atomicAdd(&qn, (unsigned int)__popcll(mask));
+                    base = __shfl(base, leader, 64);
+                    if (cand) q[base + __popcll(mask & ((1ull << lane) - 1))] = ((unsigned)r << 16) | (unsigned)(threadIdx.x * K + k);
+                }
+            }
+            if (active) store_row<T, K>(out, zero);
+            out += m;
+        }
+        __syncthreads();
+        const unsigned int total = qn;
+        if (total) {                                          // block-uniform
+            if (threadIdx.x == 0) qbase = atomicAdd(&hdr->count, (unsigned long long)total);
+            __syncthreads();
+            const unsigned long long gbase = qbase;
+            for (unsigned int t = threadIdx.x; t < total; t += kTileCols) {
+                const unsigned int e = q[t];
+                const unsigned long long idx = gbase + t;
+                if (idx < cap) list[idx] = ((unsigned long long)(i0 + (e >> 16)) << 32) | (unsigned long long)(jb + (e & 0xffffu));
+                else hdr->overflow = 1;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) qn = 0;
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb,
+                                                  int64_t m, T *__restrict__ ious, const IouList *hdr,
+                                                  const unsigned long long *__restrict__ list, unsigned long long cap)
+{
+    if (hdr->overflow) return;
+    const unsigned long long total = hdr->count < cap ? hdr->count : cap;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const unsigned long long e = list[t];
+        const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
+        const T v = iou_rbox(ga[i], gb[j]);
+        if (v != 0) ious[i * m + j] = v;
+    }
+}
+
 // ---------------------------------------------------------------- pairwise "3D IoU" (BEV x z), fp32
 // box = (x, y, z, lx, ly, lz, rz); dgal_wrap.h:45-91
 __device__ __forceinline__ Box3DGeom load3d(const float *b)
@@ -95,8 +209,10 @@ __device__ __forceinline__ Box3DGeom load3d(const float *b)
 
 template <bool ROTATED, int K>
 __global__ __launch_bounds__(kTileCols) void k_iou3d(const float *__restrict__ b1, int64_t n,
-                                                     const float *__restrict__ b2, int64_t m, float *__restrict__ out_)
+                                                     const float *__restrict__ b2, int64_t m, float *__restrict__ out_,
+                                                     const unsigned int *only_if)
 {
+    if (only_if && !*only_if) return;
     __shared__ Box3DGeom rows[kTileRows];
     const int64_t i0 = (int64_t)blockIdx.y * kTileRows;
     const int64_t j0 = ((int64_t)blockIdx.x * kTileCols + threadIdx.x) * K;
@@ -128,6 +244,42 @@ __global__ __launch_bounds__(kTileCols) void k_iou3d(const float *__restrict__ b
         }
         store_row<float, K>(out, v);
         out += m;
+    }
+}
+
+// ---------------------------------------------------------------- "3D IoU", two-phase (same scheme as rbox)
+__global__ __launch_bounds__(256) void k_geom3d(const float *__restrict__ boxes, int64_t n, BoxGeom<float> *geom,
+                                                float2 *zr, IouList *hdr)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (hdr && i == 0) { hdr->count = 0; hdr->overflow = 0; }
+    if (i < n) {
+        const Box3DGeom g = load3d(boxes + i * 7);
+        geom[i] = g.g;
+        zr[i] = make_float2(g.zmin, g.zmax);
+    }
+}
+
+template <bool ROTATED>
+__global__ __launch_bounds__(256) void k_iou3d_clip(const BoxGeom<float> *__restrict__ ga, const float2 *__restrict__ za,
+                                                    const BoxGeom<float> *__restrict__ gb, const float2 *__restrict__ zb,
+                                                    int64_t m, float *__restrict__ out, const IouList *hdr,
+                                                    const unsigned long long *__restrict__ list, unsigned long long cap)
+{
+    if (hdr->overflow) return;
+    const unsigned long long total = hdr->count < cap ? hdr->count : cap;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const unsigned long long e = list[t];
+        const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
+        const float iou2d = ROTATED ? iou_rbox(ga[i], gb[j]) : iou_aabb(ga[i], gb[j]);
+        if (iou2d != 0.f) {
+            const float2 a = za[i], b = zb[j];
+            const float imax = fminf(a.y, b.y), imin = fmaxf(a.x, b.x);
+            const float umax = fmaxf(a.y, b.y), umin = fminf(a.x, b.x);
+            const float v = iou2d * (fmaxf(imax - imin, 0.f) / fmaxf(umax - umin, (float)1e-6));
+            if (v != 0.f) out[i * m + j] = v;
+        }
     }
 }
 
@@ -405,8 +557,54 @@ __global__ __launch_bounds__(256) void k_crop2dr(const T *__restrict__ points, i
 }  // namespace
 
 // ====================================================================== C ABI
+static unsigned long long iou_list_capacity(int64_t n, int64_t m)
+{
+    const unsigned long long pairs = (unsigned long long)n * (unsigned long long)m;
+    unsigned long long cap = pairs < (1ull << 27) ? pairs : (1ull << 27);
+    const char *env = getenv("D3D_IOU_LIST_CAP");      // test hook: force the overflow -> fallback path
+    if (env && env[0]) { unsigned long long v = strtoull(env, nullptr, 10); if (v > 0 && v < cap) cap = v; }
+    return cap;
+}
+
+extern "C" size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype)
+{
+    if (n < 1) n = 1;
+    if (m < 1) m = 1;
+    const size_t g = dtype == D3D_F64 ? sizeof(BoxGeom<double>) : sizeof(BoxGeom<float>);
+    return d3d_align_up(g * n) + d3d_align_up(g * m) + 256 + d3d_align_up(8 * iou_list_capacity(n, m)) + 256;
+}
+
+template <typename T>
+static int iou2d_rbox_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *ious, void *ws, size_t ws_bytes,
+                                hipStream_t st)
+{
+    WsCarver w(ws, ws_bytes);
+    BoxGeom<T> *ga = w.take<BoxGeom<T>>(n);
+    BoxGeom<T> *gb = w.take<BoxGeom<T>>(m);
+    IouList *hdr = w.take<IouList>(1);
+    const unsigned long long cap = iou_list_capacity(n, m);
+    unsigned long long *list = w.take<unsigned long long>(cap);
+    if (!w.ok()) return D3D_ERR_WORKSPACE;
+    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, hdr);
+    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, (IouList *)nullptr);
+    constexpr int KV = 16 / (int)sizeof(T);
+    const bool vec = ((reinterpret_cast<uintptr_t>(ious) & 15) == 0) && (m % KV == 0);
+    const unsigned gy = (unsigned)d3d_divup(n, kTileRows);
+    if (vec)
+        D3D_LAUNCH("k_iou_pre", (k_iou_pre<T, KV>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols * KV), gy), dim3(kTileCols), 0,
+                   st, ga, n, gb, m, ious, hdr, list, cap);
+    else
+        D3D_LAUNCH("k_iou_pre", (k_iou_pre<T, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols), 0, st,
+                   ga, n, gb, m, ious, hdr, list, cap);
+    D3D_LAUNCH("k_iou_clip", k_iou_clip<T>, dim3(256 * 16), dim3(256), 0, st, ga, gb, m, ious, hdr, list, cap);
+    // fallback (blocks exit at once unless the list overflowed)
+    D3D_LAUNCH("k_iou2d", (k_iou2d<T, true, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols), 0, st, b1,
+               n, b2, m, ious, &hdr->overflow);
+    return D3D_OK;
+}
+
 extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t m, int32_t iou_type,
-                                 int32_t dtype, void *ious, void *stream)
+                                 int32_t dtype, void *ious, void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || m < 0) return D3D_ERR_BAD_ARG;
@@ -415,12 +613,20 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     if (n == 0 || m == 0) return D3D_OK;
     if (!boxes1 || !boxes2 || !ious) return D3D_ERR_BAD_ARG;
     const int64_t gy = d3d_divup(n, kTileRows);
-    if (gy > 65535) return D3D_ERR_BAD_ARG;   // 4.19 M rows per call; callers tile above that
+    if (gy > 65535 || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;   // callers tile above that
     const bool rot = iou_type == D3D_IOU_RBOX;
+    if (rot && workspace && workspace_bytes >= d3d_iou2d_workspace_bytes(n, m, dtype)) {
+        if (dtype == D3D_F64)
+            return iou2d_rbox_two_phase<double>((const double *)boxes1, n, (const double *)boxes2, m, (double *)ious, workspace,
+                                                workspace_bytes, st);
+        return iou2d_rbox_two_phase<float>((const float *)boxes1, n, (const float *)boxes2, m, (float *)ious, workspace,
+                                           workspace_bytes, st);
+    }
+    // single-kernel path: method BOX, or RBOX without a workspace
     const bool al16 = (reinterpret_cast<uintptr_t>(ious) & 15) == 0;
 #define D3D_IOU2D(T, R, K)                                                                                          \
     D3D_LAUNCH("k_iou2d", (k_iou2d<T, R, K>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols * K), (unsigned)gy),   \
-               dim3(kTileCols), 0, st, (const T *)boxes1, n, (const T *)boxes2, m, (T *)ious)
+               dim3(kTileCols), 0, st, (const T *)boxes1, n, (const T *)boxes2, m, (T *)ious, (const unsigned int *)nullptr)
     if (dtype == D3D_F64) {
         const bool vec = al16 && (m % 2 == 0);
         if (rot) { if (vec) D3D_IOU2D(double, true, 2); else D3D_IOU2D(double, true, 1); }
@@ -434,22 +640,57 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     return D3D_OK;
 }
 
+extern "C" size_t d3d_iou3d_workspace_bytes(int64_t n, int64_t m)
+{
+    if (n < 1) n = 1;
+    if (m < 1) m = 1;
+    return d3d_align_up(sizeof(BoxGeom<float>) * n) + d3d_align_up(sizeof(BoxGeom<float>) * m) + d3d_align_up(8 * n) +
+           d3d_align_up(8 * m) + 256 + d3d_align_up(8 * iou_list_capacity(n, m)) + 256;
+}
+
 extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *boxes2, int64_t m, int32_t rotated,
-                                 float *out, void *stream)
+                                 float *out, void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || m < 0) return D3D_ERR_BAD_ARG;
     if (n == 0 || m == 0) return D3D_OK;
     if (!boxes1 || !boxes2 || !out) return D3D_ERR_BAD_ARG;
-    if (d3d_divup(n, kTileRows) > 65535) return D3D_ERR_BAD_ARG;
+    if (d3d_divup(n, kTileRows) > 65535 || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;
     const unsigned gy = (unsigned)d3d_divup(n, kTileRows);
     const bool vec = (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (m % 4 == 0);
-#define D3D_IOU3D(R, K)                                                                                            \
+#define D3D_IOU3D(R, K, FLAG)                                                                                      \
     D3D_LAUNCH("k_iou3d", (k_iou3d<R, K>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols * K), gy), dim3(kTileCols), \
-               0, st, boxes1, n, boxes2, m, out)
-    // rotated: one column per lane (the clip path is register-heavy; 4 columns/lane measured 20 % slower on config 4)
-    if (rotated) D3D_IOU3D(true, 1);
-    else         { if (vec) D3D_IOU3D(false, 4); else D3D_IOU3D(false, 1); }
+               0, st, boxes1, n, boxes2, m, out, FLAG)
+    if (workspace && workspace_bytes >= d3d_iou3d_workspace_bytes(n, m)) {
+        // zero-fill + candidate list + dense clipping (see "rotated IoU, two-phase")
+        WsCarver w(workspace, workspace_bytes);
+        BoxGeom<float> *ga = w.take<BoxGeom<float>>(n);
+        BoxGeom<float> *gb = w.take<BoxGeom<float>>(m);
+        float2 *za = w.take<float2>(n);
+        float2 *zb = w.take<float2>(m);
+        IouList *hdr = w.take<IouList>(1);
+        const unsigned long long cap = iou_list_capacity(n, m);
+        unsigned long long *list = w.take<unsigned long long>(cap);
+        if (!w.ok()) return D3D_ERR_WORKSPACE;
+        D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, boxes1, n, ga, za, hdr);
+        D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, boxes2, m, gb, zb, (IouList *)nullptr);
+        if (vec)
+            D3D_LAUNCH("k_iou_pre", (k_iou_pre<float, 4>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols * 4), gy),
+                       dim3(kTileCols), 0, st, ga, n, gb, m, out, hdr, list, cap);
+        else
+            D3D_LAUNCH("k_iou_pre", (k_iou_pre<float, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols),
+                       0, st, ga, n, gb, m, out, hdr, list, cap);
+        if (rotated) {
+            D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<true>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, m, out, hdr, list, cap);
+            D3D_IOU3D(true, 1, &hdr->overflow);
+        } else {
+            D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<false>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, m, out, hdr, list, cap);
+            D3D_IOU3D(false, 1, &hdr->overflow);
+        }
+        return D3D_OK;
+    }
+    if (rotated) D3D_IOU3D(true, 1, (const unsigned int *)nullptr);
+    else { if (vec) D3D_IOU3D(false, 4, (const unsigned int *)nullptr); else D3D_IOU3D(false, 1, (const unsigned int *)nullptr); }
 #undef D3D_IOU3D
     return D3D_OK;
 }

@@ -148,15 +148,19 @@ int d3d_profile_report(char *buf, size_t buf_bytes);
 /* replaces iou2d_forward[_cuda] (method BOX) and the `ious` output of
  * iou2dr_forward[_cuda] (method RBOX)  (reference d3d/box/iou.h:7-24, iou.cpp:12-46,95-141,
  * iou_cuda.cu:10-48,100-151).  boxes1[n,5], boxes2[m,5] = (x,y,w,h,r) in `dtype`;
- * ious[n,m] in `dtype`, row-major.  64-bit pair indexing (cf. iou_cuda.cu:36,137). */
+ * ious[n,m] in `dtype`, row-major.  64-bit pair indexing (cf. iou_cuda.cu:36,137).  The workspace is optional
+ * (NULL/0 selects the single-kernel path); with it RBOX runs as zero-fill + candidate list + dense clipping. */
+size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype);
 int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t m,
-                      int32_t iou_type, int32_t dtype, void *ious, void *stream);
+                      int32_t iou_type, int32_t dtype, void *ious,
+                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* batched box3dr_iou (rotated=1) / box3d_iou (rotated=0)
  * (reference d3d/dgal_wrap.h:45-91; pair loop d3d/tracking/matcher.pyx:57-80).
  * boxes[.,7] f32 = (x,y,z,lx,ly,lz,rz); out[n,m] f32. */
+size_t d3d_iou3d_workspace_bytes(int64_t n, int64_t m);
 int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *boxes2, int64_t m,
-                      int32_t rotated, float *out, void *stream);
+                      int32_t rotated, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* replaces crop_2dr (reference d3d/box/utils.cpp:9-47, bound at box/impl.cpp as crop_2dr; Python box2dr_crop /
  * box3dp_crop, box/__init__.py:278-315): points[n,2], boxes[m,5] in `dtype`; out[m,n] u8 (0/1),

@@ -224,3 +224,18 @@ def test_crop_vs_oracle(dtype, n):
         g3 = box3dp_crop(T(p3), T(b3), ax).cpu().numpy()
         e3 = oracle.box3dp_crop(p3, b3, ax)
         assert np.mean(g3 != e3) < 1e-4 and e3.sum() > 10
+
+
+def test_iou_candidate_list_overflow_falls_back(monkeypatch):
+    """two-phase rbox IoU: when the candidate list is too small the single-kernel path recomputes the matrix"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_iou
+    b1, _ = synth.boxes2d_dense(300, 51)
+    b2, _ = synth.boxes2d_dense(200, 52)
+    exp = oracle.box2d_iou(b1, b2, "rbox", nthreads=4)
+    monkeypatch.setenv("D3D_IOU_LIST_CAP", "64")
+    got = box2d_iou(T(b1), T(b2), method="rbox").cpu().numpy()
+    assert np.max(np.abs(got - exp)) < 1e-9
+    monkeypatch.delenv("D3D_IOU_LIST_CAP")
+    got = box2d_iou(T(b1), T(b2), method="rbox").cpu().numpy()
+    assert np.max(np.abs(got - exp)) < 1e-9
