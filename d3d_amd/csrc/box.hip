@@ -327,42 +327,66 @@ __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__
     if ((threadIdx.x & 63) == 0 && (p >> 6) < nb) remv[p >> 6] = word;
 }
 
-// block = 4 wavefronts = 4 row blocks against one column block
+// block = 4 wavefronts = 4 row blocks, swept against kColsPerBlock consecutive column blocks.  Only the
+// conservative fp32 AABBs are staged (16 B per column, LDS broadcast); the fp64 geometry of a pair is
+// fetched from global memory on the rare AABB hit.
+constexpr int kColsPerBlock = 8;
 template <typename T, bool ROTATED>
 __global__ __launch_bounds__(256) void k_nms_pairs(const BoxGeom<T> *__restrict__ geom, const float4 *__restrict__ fbox,
                                                    int64_t n, int64_t nb, T thr, unsigned long long *__restrict__ mask,
                                                    uint32_t *inc_cnt, uint32_t *inc, NmsFlags *flags)
 {
-    const int64_t cb = blockIdx.x;
+    const int64_t cb0 = (int64_t)blockIdx.x * kColsPerBlock;
     const int64_t rb = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (cb < (int64_t)blockIdx.y * 4) return;          // whole block below the diagonal
-    __shared__ BoxGeom<T> cols[64];
-    __shared__ float4 fcols[64];
+    if (cb0 + kColsPerBlock <= (int64_t)blockIdx.y * 4) return;          // whole block below the diagonal
     const int lane = threadIdx.x & 63;
-    const int64_t q0 = cb * 64;
-    const int ncols = (int)((n - q0) < 64 ? (n - q0) : 64);
-    if (threadIdx.x < ncols) { cols[threadIdx.x] = geom[q0 + threadIdx.x]; fcols[threadIdx.x] = fbox[q0 + threadIdx.x]; }
-    __syncthreads();
     const int64_t p = rb * 64 + lane;
-    if (rb > cb || rb >= nb || p >= n) return;
+    if (rb >= nb || p >= n) return;
     const float4 fa = fbox[p];
-    const BoxGeom<T> a = geom[p];
-    unsigned long long bits = 0;
-    const int cstart = (rb == cb) ? lane + 1 : 0;
-    for (int c = cstart; c < ncols; c++) {
-        const float4 fb = fcols[c];                    // LDS broadcast
-        if (!(fa.x < fb.z && fb.x < fa.z && fa.y < fb.w && fb.y < fa.w)) continue;   // conservative reject
-        const BoxGeom<T> &b = cols[c];
-        T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
-        if (v > thr) {                                 // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
-            bits |= 1ull << c;
-            const int64_t q = q0 + c;
-            const uint32_t e = atomicAdd(&inc_cnt[q], 1u);
-            if (e < (uint32_t)kIncCap) inc[q * kIncCap + e] = (uint32_t)p;
-            else flags->need_sweep = 1;
+    for (int cc = 0; cc < kColsPerBlock; cc++) {
+        const int64_t cb = cb0 + cc;
+        if (cb < rb || cb >= nb) continue;                                  // wave-uniform
+        const int64_t q0 = cb * 64;
+        const int ncols = (int)((n - q0) < 64 ? (n - q0) : 64);
+        // branch-free sweep of the 64 columns: the column AABBs are wave-uniform -> scalar loads (SGPRs), the
+        // four compares are combined with bitwise & (no short-circuit branches), hits land in a bit set; the
+        // exact test runs afterwards on the rare survivors.  (fbox is padded to nb * 64 entries.)
+        const float4 *__restrict__ fc = fbox + q0;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll 1
+        for (int c0 = 0; c0 < 64; c0 += 8) {          // 8 columns (32 SGPRs of AABBs) per trip: no SGPR spills
+            uint32_t byte = 0;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const float4 fb = fc[c0 + c];
+                // strict overlap in x and y as ONE compare: the smallest of the four gaps must be positive
+                // (branch-free; && would compile to exec-mask branches, four compares spill SGPR masks)
+                const float g = fminf(fminf(fb.z - fa.x, fa.z - fb.x), fminf(fb.w - fa.y, fa.w - fb.y));
+                byte |= (g > 0.f ? 1u : 0u) << c;
+            }
+            if (c0 < 32) lo |= byte << c0; else hi |= byte << (c0 - 32);
         }
+        unsigned long long cand = ((unsigned long long)hi << 32) | lo;
+        const int cstart = (rb == cb) ? lane + 1 : 0;
+        cand &= cstart >= 64 ? 0ull : (~0ull << cstart);
+        if (ncols < 64) cand &= (1ull << ncols) - 1ull;
+        unsigned long long bits = 0;
+        while (cand) {
+            const int c = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const int64_t q = q0 + c;
+            const BoxGeom<T> a = geom[p], b = geom[q];
+            T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
+            if (v > thr) {                                 // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
+                bits |= 1ull << c;
+                const uint32_t e = atomicAdd(&inc_cnt[q], 1u);
+                if (e < (uint32_t)kIncCap) inc[q * kIncCap + e] = (uint32_t)p;
+                else flags->need_sweep = 1;
+            }
+        }
+        if (bits) mask[p * nb + cb] = bits;      // the matrix is zero-filled up front (streaming memset): a lane-per-row
+                                                 // store here would be an uncoalesced 8-byte write per pair of blocks
     }
-    mask[p * nb + cb] = bits;
 }
 
 // one fixed-point round over all boxes; returns nothing -- states only move undecided -> decided
@@ -492,7 +516,8 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
     D3D_LAUNCH("k_nms_prepare", k_nms_prepare<T>, dim3((unsigned)nb), dim3(64), 0, st, boxes, scores, order, n, score_thr,
                geom, fbox, state, inc_cnt, remv, nb, flags);
-    dim3 grid((unsigned)nb, (unsigned)d3d_divup(nb, 4));
+    D3D_HIP_CHECK(hipMemsetAsync(mask, 0, (size_t)nb * 64 * nb * 8, st));
+    dim3 grid((unsigned)d3d_divup(nb, kColsPerBlock), (unsigned)d3d_divup(nb, 4));
     if (iou_type == D3D_IOU_RBOX)
         D3D_LAUNCH("k_nms_pairs", (k_nms_pairs<T, true>), grid, dim3(256), 0, st, geom, fbox, n, nb, (T)iou_thr, mask,
                    inc_cnt, inc, flags);
