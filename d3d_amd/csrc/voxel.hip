@@ -697,7 +697,7 @@ struct FilterVoxels {
     uint32_t max_points;      // P for TRIM, 0xffffffff for NONE
     unsigned long long max_voxels;
     int32_t *newid;           // [nvox]
-    uint32_t *coff;           // [nvox] chain cell offset of overflow voxels
+    uint32_t *coff;           // [nvox] offset of the index list of overflow voxels
     int64_t *out_coords;
     int32_t *out_npoints;
 
@@ -712,7 +712,7 @@ struct FilterVoxels {
             ok = ok && x >= lo[d] && x < hi[d];
         }
         if (!ok) return 0;
-        return (1ull << 32) | ((uint32_t)cnt > max_points ? max_points : 0u);
+        return (1ull << 32) | ((uint32_t)cnt > max_points ? (uint32_t)cnt : 0u);   // lo: list cells of overflow voxels
     }
     __device__ __forceinline__ unsigned long long value2(int64_t k) const { return value(k); }
     __device__ __forceinline__ void apply(int64_t k, unsigned long long val, unsigned long long excl) const
@@ -729,27 +729,23 @@ struct FilterVoxels {
     }
 };
 
-// TRIM: per kept overflow voxel keep the max_points smallest point indices (cells chain)
-__global__ __launch_bounds__(256) void k_filter_rank(const int64_t *__restrict__ mapping, int64_t n, int64_t nvox,
-                                                     const int32_t *__restrict__ npoints,
-                                                     const int32_t *__restrict__ newid, const uint32_t *__restrict__ coff,
-                                                     uint32_t max_points, uint32_t *cells, int64_t ncells)
+// TRIM: the points of every kept overflow voxel (count > max_points) are listed (arrival order); a point is
+// kept iff fewer than max_points indices of its voxel's list are smaller (voxelize.cpp:457-463) -- the same
+// rank-by-counting as the dense contract, early exit at max_points.
+__global__ __launch_bounds__(256) void k_filter_scatter(const int64_t *__restrict__ mapping, int64_t n, int64_t nvox,
+                                                        const int32_t *__restrict__ npoints,
+                                                        const int32_t *__restrict__ newid, const uint32_t *__restrict__ coff,
+                                                        uint32_t max_points, uint32_t *fcur, uint32_t *cells, int64_t ncells)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t v = mapping[i];
     if (v < 0 || v >= nvox || newid[v] < 0) return;
-    if ((uint32_t)npoints[v] <= max_points) return;
-    const uint32_t base = coff[v];
-    if ((int64_t)base + max_points > ncells) return;   // inconsistent voxel_npoints: cannot trim (see keep())
-    uint32_t last = __hip_atomic_load(&cells[base + max_points - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (last < (uint32_t)i) return;
-    uint32_t x = (uint32_t)i;
-    for (uint32_t k = 0; k < max_points; k++) {
-        uint32_t old = atomicMin(&cells[base + k], x);
-        if (old == kInf) break;
-        if (old > x) x = old;
-    }
+    const uint32_t cnt = (uint32_t)npoints[v];
+    if (cnt <= max_points) return;
+    const uint32_t a = atomicAdd(&fcur[v], 1u);
+    const int64_t pos = (int64_t)coff[v] + a;
+    if (a < cnt && pos < ncells) cells[pos] = (uint32_t)i;
 }
 
 struct FilterPoints {
@@ -764,6 +760,7 @@ struct FilterPoints {
     const uint32_t *cells;
     int64_t ncells;
     uint32_t max_points;      // 0xffffffff for NONE
+    int32_t *keepid;          // [n] new voxel id of a kept point, -1 otherwise (written by the count pass)
     float *out_feats;
     int64_t *out_mask, *out_mapping;
 
@@ -773,21 +770,33 @@ struct FilterPoints {
         if (v < 0 || v >= nvox) return -1;
         const int32_t id = newid[v];
         if (id < 0) return -1;
-        if ((uint32_t)npoints[v] > max_points) {
-            // voxelize.cpp:457-463: first max_points points of the voxel in point order
+        const uint32_t cnt = (uint32_t)npoints[v];
+        if (cnt > max_points) {
             if (max_points == 0) return -1;
-            const uint32_t base = coff[v];
-            if ((int64_t)base + max_points <= ncells && (uint32_t)i > cells[base + max_points - 1]) return -1;
+            const int64_t base = coff[v];
+            if (base + cnt > ncells) return id;          // inconsistent voxel_npoints: cannot trim
+            const uint32_t *seg = cells + base;
+            const uint32_t me = (uint32_t)i;
+            uint32_t rank = 0, k = 0;
+            for (; k + 4 <= cnt && rank < max_points; k += 4)
+                rank += (seg[k] < me) + (seg[k + 1] < me) + (seg[k + 2] < me) + (seg[k + 3] < me);
+            for (; k < cnt && rank < max_points; k++) rank += seg[k] < me;
+            if (rank >= max_points) return -1;
         }
         return id;
     }
-    __device__ __forceinline__ unsigned long long value(int64_t i) const { return keep(i) >= 0 ? 1ull : 0ull; }
-    __device__ __forceinline__ unsigned long long value2(int64_t i) const { return value(i); }
+    __device__ __forceinline__ unsigned long long value(int64_t i) const
+    {
+        const int32_t id = keep(i);
+        keepid[i] = id;
+        return id >= 0 ? 1ull : 0ull;
+    }
+    __device__ __forceinline__ unsigned long long value2(int64_t i) const { return keepid[i] >= 0 ? 1ull : 0ull; }
     __device__ __forceinline__ void apply(int64_t i, unsigned long long val, unsigned long long excl) const
     {
         if (!val) return;
         out_mask[excl] = i;
-        out_mapping[excl] = keep(i);
+        out_mapping[excl] = keepid[i];
         for (int d = 0; d < c; d++) out_feats[excl * c + d] = feats[i * c + d];
     }
 };
@@ -824,6 +833,7 @@ struct VoxelWs {
     u64 *bsum;            // generic scans (filter)
     int32_t *newid;
     uint32_t *coff;
+    uint32_t *fcur;       // filter: arrival cursor per voxel
     int64_t npad;
     size_t bytes;
 };
@@ -864,6 +874,7 @@ static VoxelWs carve(void *ws, size_t ws_bytes, int64_t n, int64_t nvox)
     r.bsum = w.take<u64>(d3d_divup(m > 0 ? m : 1, kScanTile) + 1);
     r.newid = w.take<int32_t>(nvox > 0 ? nvox : 1);
     r.coff = w.take<uint32_t>(nvox > 0 ? nvox : 1);
+    r.fcur = w.take<uint32_t>(nvox > 0 ? nvox : 1);
     r.bytes = w.off;
     return r;
 }
@@ -1131,10 +1142,9 @@ extern "C" int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, 
 
     const bool trim_pts = max_points_filter == D3D_MAXPTS_TRIM;
     const uint32_t P = trim_pts ? (uint32_t)max_points : 0xffffffffu;
-    // chain cells live in w.list: at most one group of P cells per overflow voxel, and an
-    // overflow voxel owns > P points, so sum <= n.
-    D3D_LAUNCH("k_fill_u32", k_fill_u32, dim3(grid_for(trim_pts ? n : 0, 256)), dim3(256), 0, st, w.list,
-                       trim_pts ? n : (int64_t)0, kInf, counts);
+    // index lists of the overflow voxels live in w.list (their counts sum to <= n); cursors start at zero
+    D3D_LAUNCH("k_fill_u32", k_fill_u32, dim3(grid_for(trim_pts ? nvox : 0, 256)), dim3(256), 0, st, w.fcur,
+               trim_pts ? nvox : (int64_t)0, 0u, counts);
 
     const int32_t *order = nullptr;
     if (max_voxels_filter == D3D_MAXVOX_DESCENDING && nvox > 0) {
@@ -1163,12 +1173,11 @@ extern "C" int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, 
     int rc = d3d_run_scan(fv, nvox, w.bsum, counts, D3D_COUNT_VOXELS, -1, fv.max_voxels, st);
     if (rc) return rc;
 
-    if (trim_pts && n > 0 && nvox > 0 && max_points > 0) {
-        D3D_LAUNCH("k_filter_rank", k_filter_rank, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, points_mapping, n, nvox,
-                           voxel_npoints, w.newid, w.coff, P, w.list, n);
-    }
+    if (trim_pts && n > 0 && nvox > 0 && max_points > 0)
+        D3D_LAUNCH("k_filter_scatter", k_filter_scatter, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, points_mapping,
+                   n, nvox, voxel_npoints, w.newid, w.coff, P, w.fcur, w.list, n);
     FilterPoints fp{feats, c, points_mapping, nvox, voxel_npoints, w.newid, w.coff, w.list, n, P,
-                    out_feats, out_mask, out_mapping};
+                    reinterpret_cast<int32_t *>(w.pslot), out_feats, out_mask, out_mapping};
     rc = d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st);
     return rc;
 }
