@@ -41,8 +41,25 @@ def _as_tensor(x):
 
 
 def _host_array(t, ctype, count):
-    vals = [t[i].item() if isinstance(t, torch.Tensor) else t[i] for i in range(count)]
-    return (ctype * count)(*vals)
+    if isinstance(t, ctypes.Array):          # already marshalled (VoxelGenerator caches its grid description)
+        return t
+    vals = t.tolist() if isinstance(t, torch.Tensor) else list(t)
+    return (ctype * count)(*vals[:count])
+
+
+class _device_ctx:
+    """torch.cuda.device(dev) only when dev is not already current (the context switch costs host time)"""
+
+    def __init__(self, dev):
+        self._ctx = None if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self._ctx is not None:
+            self._ctx.__exit__(*a)
 
 
 def _stage(points, what="points"):
@@ -74,6 +91,16 @@ def _counts_to_host(counts, what):
     return host
 
 
+_ws_bytes_cache = {}
+
+
+def _workspace_bytes(lib, n):
+    b = _ws_bytes_cache.get(n)
+    if b is None:
+        b = _ws_bytes_cache[n] = lib.d3d_voxelize_workspace_bytes(n, 0)
+    return b
+
+
 def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type):
     """voxelize_3d_dense of the reference (voxelize.h:9-12; voxelize.cpp:45-199).
 
@@ -90,15 +117,14 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
     shape_h = _host_array(voxel_shape, ctypes.c_int32, 3)
     bound_h = _host_array(voxel_bound, ctypes.c_float, 6)
     cap = max(min(n, max_voxels), 0)
-    with torch.cuda.device(dev):
+    with _device_ctx(dev):
         voxels = torch.empty((cap, max_points, c), dtype=torch.float32, device=dev)
         coords = torch.empty((cap, 3), dtype=torch.int64, device=dev)
         pmask = torch.empty((cap, max_points), dtype=torch.uint8, device=dev)
         npts = torch.empty((cap,), dtype=torch.int32, device=dev)
         agg = torch.empty((cap, c), dtype=torch.float32, device=dev) if red != 0 else None
         counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
-        wsb = lib.d3d_voxelize_workspace_bytes(n, 0)
-        ws = _lib.workspace(wsb, dev)
+        ws = _lib.workspace(_workspace_bytes(lib, n), dev)
         def run():
             rc = lib.d3d_voxelize_3d_dense(
                 _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
@@ -233,6 +259,9 @@ class VoxelGenerator:
                              "which could lead to unexpected behavior!")
         self._offset = torch.round(origin_cells).int()                                        # :45
         self._vbounds = torch.round(lohi / self._size.reshape(3, 1)).long()                   # :46
+        self._shape_h = _host_array(self._shape, ctypes.c_int32, 3)      # marshalled once for the C ABI
+        self._bounds_h = _host_array(self._bounds, ctypes.c_float, 6)
+        self._size_h = _host_array(self._size, ctypes.c_float, 3)
 
         red = (reduction or "NONE").upper()
         if red != "NONE" and not dense:
@@ -258,10 +287,10 @@ class VoxelGenerator:
         if not points.is_cuda:
             points = points.to(_lib.require_gpu())    # stage once; results go back to the caller's device
         if self._dense:
-            ret = Dict(voxelize_3d_dense(points, self._shape, self._bounds, self._max_points,
+            ret = Dict(voxelize_3d_dense(points, self._shape_h, self._bounds_h, self._max_points,
                                          self._max_voxels, self._reduction))
         else:
-            sparse = voxelize_3d_sparse(points, self._size, 3)
+            sparse = voxelize_3d_sparse(points, self._size_h, 3)
             ret = Dict(voxelize_3d_filter(points, sparse["points_mapping"], sparse["coords"], sparse["voxel_npoints"],
                                           self._vbounds, self._min_points, self._max_points, self._max_voxels,
                                           self._max_points_filter, self._max_voxels_filter))
