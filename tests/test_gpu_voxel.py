@@ -203,3 +203,35 @@ def test_packed_slot_count_overflow_falls_back():
     exp = oracle.VoxelGenerator(unit, [2000, 2000, 2000], **kw)(cloud)
     assert exp["voxel_npoints"].max() >= 4000
     check_dense(ret, exp, 2)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_configs_vs_oracle(seed):
+    """seeded sweep over C, max_points (incl. non powers of two and 0-ish sizes), max_voxels caps, reductions,
+    grid shapes and both contracts -- every output compared with the oracle"""
+    from d3d_amd.voxel import VoxelGenerator
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 30000))
+    c = int(rng.integers(3, 9))
+    shape = [int(rng.integers(1, 40)) for _ in range(3)]
+    size = [float(rng.choice([0.25, 0.5, 1.0, 2.0])) for _ in range(3)]
+    lo = [float(rng.integers(-5, 5)) * size[d] for d in range(3)]        # grid aligned with the origin
+    bounds = [lo[0], lo[0] + size[0] * shape[0], lo[1], lo[1] + size[1] * shape[1], lo[2], lo[2] + size[2] * shape[2]]
+    span = np.array([bounds[1] - bounds[0], bounds[3] - bounds[2], bounds[5] - bounds[4]])
+    cloud = rng.random((n, c)).astype(np.float32)
+    cloud[:, :3] = (np.array(lo) - 0.1 * span + cloud[:, :3] * 1.2 * span).astype(np.float32)   # 20 % outside
+    if seed % 3 == 0:
+        cloud[: n // 2, :3] = cloud[0, :3] + 0.01 * rng.random((n // 2, 3))                   # a heavy voxel
+    P = int(rng.choice([1, 2, 3, 5, 16, 30, 32, 40]))
+    mv = int(rng.choice([n + 5, max(1, n // 50), 7]))
+    red = str(rng.choice(["none", "mean", "max", "min"]))
+    pts = torch.from_numpy(cloud).cuda()
+    kw = dict(reduction=red, max_points=P, max_voxels=mv, dense=True)
+    exp = oracle.VoxelGenerator(bounds, shape, **kw)(cloud)
+    ret = _np(VoxelGenerator(bounds, shape, **kw)(pts))
+    check_dense(ret, exp, P)
+    kw = dict(max_points=P, max_points_filter=str(rng.choice(["trim", "none"])), min_points=int(rng.integers(0, 3)),
+              max_voxels=mv, max_voxels_filter=str(rng.choice(["trim", "none", "descending"])))
+    exp = oracle.VoxelGenerator(bounds, shape, **kw)(cloud)
+    ret = _np(VoxelGenerator(bounds, shape, **kw)(pts))
+    check_sparse(ret, exp)
