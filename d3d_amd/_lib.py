@@ -37,6 +37,8 @@ SIGNATURES = {
     "d3d_grid_compact_workspace_bytes": (_sz, [_i64]),
     "d3d_grid_compact_index": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "d3d_grid_compact_lookup": (ctypes.c_int, [_vp, _i64, _i64, _vp, _sz, _i64, _vp, _vp]),
+    "d3d_aligned_scatter_forward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _vp, _vp]),
+    "d3d_aligned_scatter_backward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _vp, _vp]),
     "d3d_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "d3d_profile_report": (ctypes.c_int, [ctypes.c_char_p, _sz]),
     "d3d_iou2d_workspace_bytes": (_sz, [_i64, _i64, _i32]),

@@ -138,6 +138,17 @@ int d3d_sharded_finalize(int64_t nvox, int32_t c, const int64_t *vid_of_slot, co
 int d3d_sharded_map(int64_t n, const int64_t *local_map, const int64_t *slot_of_local, int64_t nvox,
                     const int64_t *vid_of_slot, int64_t *gmap, void *stream);
 
+/* ------------------------------------------------------------------ d3d/point ("next" row) */
+
+/* replaces aligned_scatter_forward[_cuda] / aligned_scatter_backward[_cuda] (reference d3d/point/scatter.h:39-56,
+ * scatter.cpp:81-200, scatter_cuda.cu).  coord[n, dim+1] (batch index first), image[B, channels, dims[0..dim-1]],
+ * out / grad [n, channels], all in `dtype`; dims: host int64[dim]; align_type 1 = MEAN, 2 = LINEAR (others ->
+ * D3D_ERR_UNSUPPORTED like the reference's py::value_error).  backward ACCUMULATES into image_grad (atomics). */
+int d3d_aligned_scatter_forward(const void *coord, int64_t n, int32_t dim, const void *image, int64_t channels,
+                                const int64_t *dims, int32_t align_type, int32_t dtype, void *out, void *stream);
+int d3d_aligned_scatter_backward(const void *coord, int64_t n, int32_t dim, const void *grad, int64_t channels,
+                                 const int64_t *dims, int32_t align_type, int32_t dtype, void *image_grad, void *stream);
+
 /* opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline leg);
  * report: "kernel,calls,total_ms" lines. */
 int d3d_profile_enable(int on);

@@ -309,3 +309,48 @@ def box3dp_crop(points, boxes, project_axis=2):
     bp = boxes[:, [project_axis]]
     bd = boxes[:, [3 + project_axis]] / 2
     return mask_2d & ((pp - bd < bp) & (bp < pp + bd))
+
+
+# --------------------------------------------------------------------------- point (next row: d3d.point)
+ALIGN_TYPE = {"DROP": 0, "MEAN": 1, "LINEAR": 2, "MAX": 3, "NEAREST": 4}   # point/scatter.h:37
+
+
+def _scatter_args(coord, image):
+    dt = np.float64 if image.dtype == np.float64 else np.float32
+    coord = np.ascontiguousarray(coord, dtype=dt)
+    image = np.ascontiguousarray(image, dtype=dt)
+    dim = coord.shape[1] - 1
+    if dim not in (1, 2, 3) or image.ndim != dim + 2:
+        raise ValueError("Unsupported dimension size: %d" % dim)          # scatter.h:33
+    dims = np.ascontiguousarray(image.shape[2:], dtype=np.int64)
+    return coord, image, dim, dims, dt
+
+
+def aligned_scatter_forward(coord, image, atype):
+    """scatter.cpp:182-194"""
+    at = ALIGN_TYPE[atype.upper()] if isinstance(atype, str) else int(atype)
+    if at not in (1, 2):
+        raise ValueError("Unsupported align type!")                       # scatter.h:18
+    coord, image, dim, dims, dt = _scatter_args(coord, image)
+    n, C = coord.shape[0], image.shape[1]
+    out = np.empty((n, C), dt)
+    f = lib().oracle_aligned_scatter_forward_f64 if dt == np.float64 else lib().oracle_aligned_scatter_forward_f32
+    f.restype = None
+    f(_p(coord), ctypes.c_int64(n), ctypes.c_int(dim), _p(image), ctypes.c_int64(C), _p(dims), ctypes.c_int(at), _p(out))
+    return out
+
+
+def aligned_scatter_backward(coord, grad, atype, image_shape):
+    """scatter.cpp:196-200 into a zero image of `image_shape`; returns the image gradient"""
+    at = ALIGN_TYPE[atype.upper()] if isinstance(atype, str) else int(atype)
+    if at not in (1, 2):
+        raise ValueError("Unsupported align type!")
+    dt = np.float64 if grad.dtype == np.float64 else np.float32
+    img = np.zeros(image_shape, dt)
+    coord, img, dim, dims, dt = _scatter_args(coord, img)
+    grad = np.ascontiguousarray(grad, dtype=dt)
+    n, C = coord.shape[0], img.shape[1]
+    f = lib().oracle_aligned_scatter_backward_f64 if dt == np.float64 else lib().oracle_aligned_scatter_backward_f32
+    f.restype = None
+    f(_p(coord), ctypes.c_int64(n), ctypes.c_int(dim), _p(grad), ctypes.c_int64(C), _p(dims), ctypes.c_int(at), _p(img))
+    return img

@@ -16,41 +16,51 @@ REF = os.environ.get("D3D_REFERENCE", "/root/reference")
 OUT = os.path.join(HERE, "_ref")
 
 
-def ref_so_path():
-    return os.path.join(OUT, "voxel_impl.so")
+MODULES = {   # name -> reference sources (compiled where they lie)
+    "voxel_impl": ["d3d/voxel/impl.cpp", "d3d/voxel/voxelize.cpp"],
+    "point_impl": ["d3d/point/impl.cpp", "d3d/point/scatter.cpp"],     # "next" row: d3d.point.aligned_scatter
+}
 
 
-def build(verbose=False):
-    so = ref_so_path()
+def ref_so_path(name="voxel_impl"):
+    return os.path.join(OUT, name, name + ".so") if name != "voxel_impl" else os.path.join(OUT, "voxel_impl.so")
+
+
+def build(verbose=False, name="voxel_impl"):
+    so = ref_so_path(name)
     if os.path.exists(so):
         return so
-    srcs = [os.path.join(REF, "d3d/voxel/impl.cpp"), os.path.join(REF, "d3d/voxel/voxelize.cpp")]
+    srcs = [os.path.join(REF, s) for s in MODULES[name]]
     if not all(os.path.exists(s) for s in srcs):
         return None
-    os.makedirs(OUT, exist_ok=True)
+    outdir = os.path.dirname(so)
+    os.makedirs(outdir, exist_ok=True)
     os.environ.setdefault("CXX", "g++")
     os.environ.setdefault("MAX_JOBS", "2")
     from torch.utils.cpp_extension import load
-    load(name="voxel_impl", sources=srcs, extra_include_paths=[REF],
+    load(name=name, sources=srcs, extra_include_paths=[REF],
          extra_cflags=["-O2", "-Wno-deprecated-declarations"],
-         build_directory=OUT, verbose=verbose)
+         build_directory=outdir, verbose=verbose)
     return so if os.path.exists(so) else None
 
 
-def load_ref():
-    """Import the built reference module (or None if it is not available)."""
-    so = ref_so_path()
+def load_ref(name="voxel_impl"):
+    """Import a built reference module (or None if it is not available)."""
+    so = ref_so_path(name)
     if not os.path.exists(so):
         return None
     import importlib.util
     import torch  # noqa: F401  (the .so links against libtorch)
-    spec = importlib.util.spec_from_file_location("voxel_impl", so)
+    spec = importlib.util.spec_from_file_location(name, so)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
 
 
 if __name__ == "__main__":
-    p = build(verbose=True)
-    print("reference voxel_impl:", p)
-    sys.exit(0 if p else 1)
+    ok = True
+    for name in MODULES:
+        p = build(verbose=True, name=name)
+        print("reference %s:" % name, p)
+        ok = ok and bool(p)
+    sys.exit(0 if ok else 1)
