@@ -43,6 +43,7 @@ SIGNATURES = {
     "d3d_profile_report": (ctypes.c_int, [ctypes.c_char_p, _sz]),
     "d3d_iou2d_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "d3d_iou2d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "d3d_iou2d_backward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "d3d_iou3d_workspace_bytes": (_sz, [_i64, _i64]),
     "d3d_iou3d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "d3d_crop_2dr": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),

@@ -80,8 +80,63 @@ def iou2dr_forward(boxes1, boxes2):
     return _iou_forward(boxes1, boxes2, IouType.RBOX)
 
 
+def _iou_backward(boxes1, boxes2, grad, iou_type):
+    lib = _lib.load()
+    odev = boxes1.device
+    (b1, b2, g), dev = _to_device(boxes1.detach(), boxes2.detach(), grad.to(boxes1.dtype))
+    n, m = b1.shape[0], b2.shape[0]
+    code = _dtype_code(b1)
+    with torch.cuda.device(dev):
+        g1 = torch.empty((n, 5), dtype=b1.dtype, device=dev)
+        g2 = torch.empty((m, 5), dtype=b1.dtype, device=dev)
+        ws = _lib.workspace(lib.d3d_iou2d_workspace_bytes(n, m, code), dev)
+        rc = lib.d3d_iou2d_backward(_lib.ptr(b1), n, _lib.ptr(b2), m, _lib.ptr(g), int(iou_type), code, _lib.ptr(g1),
+                                    _lib.ptr(g2), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "iou2d_backward")
+    return (g1.to(odev), g2.to(odev)) if odev != dev else (g1, g2)
+
+
+def iou2d_backward(boxes1, boxes2, grad):
+    """iou2d_backward[_cuda] (iou.h:14-24; iou.cpp:75-93): (grad_boxes1[N,5], grad_boxes2[M,5])"""
+    return _iou_backward(boxes1, boxes2, grad, IouType.BOX)
+
+
+def iou2dr_backward(boxes1, boxes2, grad, nx=None, xflags=None):
+    """iou2dr_backward[_cuda] (iou.h:32-40; iou.cpp:191-211).  `nx` / `xflags` (the reference's saved clip flags)
+    are accepted for signature compatibility and ignored: the clip is recomputed."""
+    return _iou_backward(boxes1, boxes2, grad, IouType.RBOX)
+
+
+class Iou2D(torch.autograd.Function):
+    """Differentiable axis aligned IoU function for 2D boxes -- reference box/__init__.py:41-61"""
+
+    @staticmethod
+    def forward(ctx, boxes1, boxes2):
+        ctx.save_for_backward(boxes1, boxes2)
+        return iou2d_forward(boxes1, boxes2)
+
+    @staticmethod
+    def backward(ctx, grad):
+        boxes1, boxes2 = ctx.saved_tensors
+        return iou2d_backward(boxes1, boxes2, grad.contiguous())
+
+
+class Iou2DR(torch.autograd.Function):
+    """Differentiable rotated IoU function for 2D boxes -- reference box/__init__.py:63-84"""
+
+    @staticmethod
+    def forward(ctx, boxes1, boxes2):
+        ctx.save_for_backward(boxes1, boxes2)
+        return iou2dr_forward(boxes1, boxes2)
+
+    @staticmethod
+    def backward(ctx, grad):
+        boxes1, boxes2 = ctx.saved_tensors
+        return iou2dr_backward(boxes1, boxes2, grad.contiguous())
+
+
 def box2d_iou(boxes1, boxes2, method="box", precise=True):
-    """IoU on axis-aligned ('box') or rotated ('rbox') 2D boxes -- reference box/__init__.py:180-224.
+    """Differentiable IoU on axis-aligned ('box') or rotated ('rbox') 2D boxes -- reference box/__init__.py:180-224.
 
     :param boxes1: N x 5 (x,y,w,h,r), torch tensor or numpy array
     :param boxes2: M x 5
@@ -101,9 +156,9 @@ def box2d_iou(boxes1, boxes2, method="box", precise=True):
         raise ValueError("Input boxes should have 5 fields: x, y, w, h, r")
     iou_type = getattr(IouType, method.upper())     # AttributeError for unknown names, like the reference
     if iou_type == IouType.BOX:
-        result = iou2d_forward(boxes1, boxes2)
+        result = Iou2D.apply(boxes1, boxes2)
     elif iou_type == IouType.RBOX:
-        result = iou2dr_forward(boxes1, boxes2)
+        result = Iou2DR.apply(boxes1, boxes2)
     elif iou_type in (IouType.GRBOX, IouType.DRBOX):
         raise NotImplementedError("GIoU / DIoU are not part of the forward hot path yet")
     else:
@@ -261,5 +316,5 @@ def box3dp_crop(points, boxes, project_axis=2):
 iou2d = box2d_iou
 nms = box2d_nms
 
-__all__ = ["box2dr_crop", "box3dp_crop", "crop_2dr", "box2d_iou", "box2d_nms", "iou2d", "iou3d", "nms", "iou2d_forward", "iou2dr_forward", "nms2d",
+__all__ = ["Iou2D", "Iou2DR", "iou2d_backward", "iou2dr_backward", "box2dr_crop", "box3dp_crop", "crop_2dr", "box2d_iou", "box2d_nms", "iou2d", "iou3d", "nms", "iou2d_forward", "iou2dr_forward", "nms2d",
            "nms2d_cuda", "argsort_desc", "IouType", "SupressionType", "cuda_available"]

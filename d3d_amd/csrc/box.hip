@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const BoxGeom<T> *__restr
                     if (cand) q[base + __popcll(mask & ((1ull << lane) - 1))] = ((unsigned)r << 16) | (unsigned)(threadIdx.x * K + k);
                 }
             }
-            if (active) store_row<T, K>(out, zero);
+            if (active && ious) store_row<T, K>(out, zero);
             out += m;
         }
         __syncthreads();
@@ -244,6 +244,36 @@ __global__ __launch_bounds__(kTileCols) void k_iou3d(const float *__restrict__ b
         }
         store_row<float, K>(out, v);
         out += m;
+    }
+}
+
+// ---------------------------------------------------------------- IoU backward (loss path, "next" row 2)
+// grad_boxes1[i] = sum_j grad[i,j] * dIoU(i,j)/d box1_i, grad_boxes2[j] likewise (reference iou.cpp:48-93, 143-211).
+// One overlapping pair per lane from the candidate list, analytic gradients (geom.hpp), 10 float atomics per pair --
+// the reference's CUDA kernels accumulate with plain += from many threads (iou_cuda.cu:72-73,184-185: a data race).
+template <typename T, bool ROTATED>
+__global__ __launch_bounds__(256) void k_iou_grad(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb,
+                                                  const T *__restrict__ b1, const T *__restrict__ b2,
+                                                  const T *__restrict__ grad, int64_t m, const IouList *hdr,
+                                                  const unsigned long long *__restrict__ list, unsigned long long cap,
+                                                  T *g1, T *g2)
+{
+    const unsigned long long total = hdr->count < cap ? hdr->count : cap;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const unsigned long long e = list[t];
+        const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
+        const T g = grad[i * m + j];
+        if (g == 0) continue;
+        T da[5], db[5];
+        const T *pa = b1 + i * 5, *pb = b2 + j * 5;
+        if (ROTATED) iou_rbox_grad<T>(ga[i], gb[j], pa[2], pa[3], pb[2], pb[3], da, db);
+        else iou_aabb_grad<T>(ga[i], gb[j], pa, pb, da, db);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (da[k] != 0) atomicAdd(&g1[i * 5 + k], g * da[k]);
+            if (db[k] != 0) atomicAdd(&g2[j * 5 + k], g * db[k]);
+        }
     }
 }
 
@@ -765,4 +795,67 @@ extern "C" int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, in
     else
         D3D_LAUNCH("k_crop2dr", k_crop2dr<float>, grid, dim3(256), 0, st, (const float *)points, n, (const float *)boxes, m, out);
     return D3D_OK;
+}
+
+template <typename T>
+static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, const T *grad, bool rot, T *g1, T *g2, void *ws,
+                                size_t ws_bytes, hipStream_t st)
+{
+    WsCarver w(ws, ws_bytes);
+    BoxGeom<T> *ga = w.take<BoxGeom<T>>(n);
+    BoxGeom<T> *gb = w.take<BoxGeom<T>>(m);
+    IouList *hdr = w.take<IouList>(1);
+    // every AABB-overlapping pair must be listed (no fallback here): capacity = all pairs, processed in row chunks
+    const unsigned long long cap_all = iou_list_capacity(n, m);
+    unsigned long long *list = w.take<unsigned long long>(cap_all);
+    if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
+    D3D_HIP_CHECK(hipMemsetAsync(g1, 0, sizeof(T) * 5 * (size_t)n, st));
+    D3D_HIP_CHECK(hipMemsetAsync(g2, 0, sizeof(T) * 5 * (size_t)m, st));
+    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, (IouList *)nullptr);
+    // rows in chunks such that chunk_rows * m <= capacity: the list can then never overflow
+    int64_t rows_per = (int64_t)(cap_all / (unsigned long long)m);
+    if (rows_per < 1) return D3D_ERR_BAD_ARG;
+    rows_per = rows_per / kTileRows * kTileRows;
+    if (rows_per < kTileRows) rows_per = kTileRows < n ? kTileRows : n;
+    if ((unsigned long long)rows_per * (unsigned long long)m > cap_all && rows_per > n) rows_per = n;
+    for (int64_t r0 = 0; r0 < n; r0 += rows_per) {
+        const int64_t nr = (n - r0) < rows_per ? (n - r0) : rows_per;
+        if ((unsigned long long)nr * (unsigned long long)m > cap_all) return D3D_ERR_WORKSPACE;
+        D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(nr, 256)), dim3(256), 0, st, b1 + r0 * 5, nr, ga, hdr);
+        D3D_LAUNCH("k_iou_pre", (k_iou_pre<T, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), (unsigned)d3d_divup(nr, kTileRows)),
+                   dim3(kTileCols), 0, st, ga, nr, gb, m, (T *)nullptr, hdr, list, cap_all);
+        if (rot)
+            D3D_LAUNCH("k_iou_grad", (k_iou_grad<T, true>), dim3(256 * 8), dim3(256), 0, st, ga, gb, b1 + r0 * 5, b2, grad + r0 * m, m,
+                       hdr, list, cap_all, g1 + r0 * 5, g2);
+        else
+            D3D_LAUNCH("k_iou_grad", (k_iou_grad<T, false>), dim3(256 * 8), dim3(256), 0, st, ga, gb, b1 + r0 * 5, b2, grad + r0 * m, m,
+                       hdr, list, cap_all, g1 + r0 * 5, g2);
+    }
+    return D3D_OK;
+}
+
+extern "C" int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *boxes2, int64_t m, const void *grad,
+                                  int32_t iou_type, int32_t dtype, void *grad_boxes1, void *grad_boxes2, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || m < 0) return D3D_ERR_BAD_ARG;
+    if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
+    if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;
+    if (n > 0 && (!boxes1 || !grad_boxes1)) return D3D_ERR_BAD_ARG;
+    if (m > 0 && (!boxes2 || !grad_boxes2)) return D3D_ERR_BAD_ARG;
+    const size_t esz = dtype == D3D_F64 ? 8 : 4;
+    if (n == 0 || m == 0) {
+        if (n > 0) D3D_HIP_CHECK(hipMemsetAsync(grad_boxes1, 0, esz * 5 * (size_t)n, st));
+        if (m > 0) D3D_HIP_CHECK(hipMemsetAsync(grad_boxes2, 0, esz * 5 * (size_t)m, st));
+        return D3D_OK;
+    }
+    if (!grad || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;
+    if (workspace_bytes < d3d_iou2d_workspace_bytes(n, m, dtype)) return D3D_ERR_WORKSPACE;
+    const bool rot = iou_type == D3D_IOU_RBOX;
+    if (dtype == D3D_F64)
+        return iou2d_backward_typed<double>((const double *)boxes1, n, (const double *)boxes2, m, (const double *)grad, rot,
+                                            (double *)grad_boxes1, (double *)grad_boxes2, workspace, workspace_bytes, st);
+    return iou2d_backward_typed<float>((const float *)boxes1, n, (const float *)boxes2, m, (const float *)grad, rot,
+                                       (float *)grad_boxes1, (float *)grad_boxes2, workspace, workspace_bytes, st);
 }

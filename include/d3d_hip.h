@@ -166,6 +166,14 @@ int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t
                       int32_t iou_type, int32_t dtype, void *ious,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* replaces iou2d_backward[_cuda] (BOX) and iou2dr_backward[_cuda] (RBOX) ("next" row; reference iou.h:14-24,32-40,
+ * iou.cpp:48-93,143-211): grad[n,m] -> grad_boxes1[n,5], grad_boxes2[m,5] (overwritten), all in `dtype`.  The
+ * overlap flags the reference saves in forward (nx, xflags) are not needed: the clip is recomputed.
+ * Workspace: d3d_iou2d_workspace_bytes(n, m, dtype). */
+int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *boxes2, int64_t m, const void *grad,
+                       int32_t iou_type, int32_t dtype, void *grad_boxes1, void *grad_boxes2,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
 /* batched box3dr_iou (rotated=1) / box3d_iou (rotated=0)
  * (reference d3d/dgal_wrap.h:45-91; pair loop d3d/tracking/matcher.pyx:57-80).
  * boxes[.,7] f32 = (x,y,z,lx,ly,lz,rz); out[n,m] f32. */

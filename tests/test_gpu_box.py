@@ -239,3 +239,57 @@ def test_iou_candidate_list_overflow_falls_back(monkeypatch):
     monkeypatch.delenv("D3D_IOU_LIST_CAP")
     got = box2d_iou(T(b1), T(b2), method="rbox").cpu().numpy()
     assert np.max(np.abs(got - exp)) < 1e-9
+
+
+def _numeric_grads(b1, b2, g, method, h=1e-6):
+    """central differences of the fp64 oracle IoU: d sum(g * iou) / d boxes"""
+    def f(x1, x2):
+        return float(np.sum(g * oracle.iou2d_forward(x1, x2, method)))
+    g1, g2 = np.zeros_like(b1), np.zeros_like(b2)
+    for arr, out, first in ((b1, g1, True), (b2, g2, False)):
+        for i in range(arr.shape[0]):
+            for k in range(5):
+                p, q = arr.copy(), arr.copy()
+                p[i, k] += h
+                q[i, k] -= h
+                out[i, k] = (f(p, b2) - f(q, b2)) / (2 * h) if first else (f(b1, p) - f(b1, q)) / (2 * h)
+    return g1, g2
+
+
+@pytest.mark.parametrize("method", ["rbox", "box"])
+def test_iou_backward_vs_finite_differences(method):
+    """"next" row 2: analytic gradients of the HIP path against central differences of the fp64 oracle"""
+    from d3d_amd.box import box2d_iou
+    rng = np.random.default_rng(61)
+    n, m = 14, 11
+    mk = lambda k: np.stack([(rng.random(k) - .5) * 6, (rng.random(k) - .5) * 6, rng.random(k) * 3 + 1, rng.random(k) * 3 + 1,
+                             (rng.random(k) - .5) * 6], 1)   # noqa: E731
+    b1, b2 = mk(n), mk(m)
+    g = rng.random((n, m))
+    t1 = torch.from_numpy(b1).cuda().requires_grad_(True)
+    t2 = torch.from_numpy(b2).cuda().requires_grad_(True)
+    iou = box2d_iou(t1, t2, method=method)
+    assert (iou > 0).sum() > 20
+    (iou * torch.from_numpy(g).cuda()).sum().backward()
+    e1, e2 = _numeric_grads(b1, b2, g, method)
+    assert np.max(np.abs(t1.grad.cpu().numpy() - e1)) < 2e-6 * max(1.0, np.abs(e1).max())
+    assert np.max(np.abs(t2.grad.cpu().numpy() - e2)) < 2e-6 * max(1.0, np.abs(e2).max())
+    # disjoint boxes: zero gradient; identical boxes: finite
+    far = torch.tensor([[100., 100, 1, 1, 0]], dtype=torch.float64, device="cuda", requires_grad=True)
+    box2d_iou(far, t2.detach(), method=method).sum().backward()
+    assert torch.all(far.grad == 0)
+
+
+def test_iou_backward_fp32_and_large():
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_iou
+    b, _ = synth.boxes2d_dense(600, 71, np.float32)
+    t1 = torch.from_numpy(b).cuda().requires_grad_(True)
+    t2 = torch.from_numpy(b[::-1].copy()).cuda().requires_grad_(True)
+    box2d_iou(t1, t2, method="rbox", precise=False).sum().backward()
+    d1 = torch.from_numpy(b.astype(np.float64)).cuda().requires_grad_(True)
+    d2 = torch.from_numpy(b[::-1].astype(np.float64).copy()).cuda().requires_grad_(True)
+    box2d_iou(d1, d2, method="rbox").sum().backward()
+    assert torch.isfinite(t1.grad).all() and t1.grad.dtype == torch.float32
+    rel = (t1.grad.double() - d1.grad).abs().max() / d1.grad.abs().max()
+    assert rel < 5e-3        # fp32 clip vs fp64 clip of the same boxes
