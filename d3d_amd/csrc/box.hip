@@ -326,18 +326,33 @@ __global__ __launch_bounds__(256) void k_iou3d_clip(const BoxGeom<float> *__rest
 // ---------------------------------------------------------------- NMS
 // Greedy hard NMS in score order (nms.cpp:32-59) without the reference's serial collector:
 //   prepare  geometry in score order (N trig evaluations, not N^2), conservative fp32 AABBs, initial states
-//   pairs    64x64 tiles of the upper triangle: fp32 AABB reject, exact IoU for survivors; every hit
-//            (p suppresses q, p < q) is appended to q's incoming list AND set in the dense bit matrix
-//   rounds   the greedy result is the unique fixed point of: q is suppressed iff some KEPT earlier p hits it,
-//            kept iff all earlier hitters are suppressed.  Each round decides every box whose earlier hitters
-//            are decided; sparse overlap graphs (detection outputs) converge in a handful of rounds.
-//   sweep    only if a list overflowed or the chain is very long: one workgroup sweeps the dense bit
-//            matrix (diagonal block resolved by a wavefront with lane broadcasts, rows OR-ed into LDS).
+//   cand     broad phase: sweep-and-prune along x over the conservative AABBs -> candidate pair list
+//   hits     narrow phase: exact IoU per candidate; every hit (p suppresses q, p < q in score order) is appended
+//            to q's incoming list
+//   resolve  the greedy result is the unique fixed point of: q is suppressed iff some KEPT earlier p hits it,
+//            kept iff all earlier hitters are suppressed; one launch in which every box polls its hitters
+//   dense    only if a list overflowed or a dependency chain is very long: all-pairs bit matrix (the reference's
+//            nms_cuda.cu layout) + one workgroup sweeping it (diagonal block resolved by a wavefront with lane
+//            broadcasts, rows OR-ed into LDS)
+extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int32_t *order, void *ws, size_t ws_bytes,
+                                             hipStream_t st);      // sort.hip
+extern "C" size_t d3d_internal_argsort_i32_bytes(int64_t n);
+
 constexpr int kIncCap = 24;          // incoming-hit list capacity per box
-constexpr int kNmsRounds = 24;       // grid-wide rounds before the single-workgroup tail
 enum { kUndecided = 0, kKept = 1, kSuppressed = 2 };
 
 struct NmsFlags { unsigned int need_sweep, undecided; };
+struct NmsCand { unsigned long long count; };       // entries appended to the candidate list (may exceed its capacity)
+
+// candidate-list capacity: ~8.5 upper-triangle AABB candidates per box at detection densities;
+// 64 per box leaves head room, small dense sets get the full triangle.  D3D_NMS_CAND_CAP overrides (tests).
+static unsigned long long nms_cand_capacity(int64_t n)
+{
+    if (const char *e = getenv("D3D_NMS_CAND_CAP")) return (unsigned long long)std::max<long long>(atoll(e), 1);
+    const unsigned long long tri = (unsigned long long)n * (unsigned long long)(n > 0 ? n - 1 : 0) / 2 + 1;
+    return std::min<unsigned long long>(tri, std::max<unsigned long long>(64ull * (unsigned long long)n, 1ull << 22));
+}
+static unsigned int nms_force_dense() { const char *e = getenv("D3D_NMS_FORCE_DENSE"); return e && atoi(e) ? 1u : 0u; }
 
 __device__ __forceinline__ float round_down(double x) { float f = (float)x; return (double)f > x ? nextafterf(f, -INFINITY) : f; }
 __device__ __forceinline__ float round_up(double x) { float f = (float)x; return (double)f < x ? nextafterf(f, INFINITY) : f; }
@@ -348,16 +363,21 @@ template <typename T>
 __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__ scores,
                               const int64_t *__restrict__ order, int64_t n, float score_threshold,
                               BoxGeom<T> *geom, float4 *fbox, uint8_t *state, uint32_t *inc_cnt,
-                              unsigned long long *remv, int64_t nb, NmsFlags *flags)
+                              unsigned long long *remv, int64_t nb, NmsFlags *flags, NmsCand *cand_hdr,
+                              unsigned int force_dense, int32_t *xkey)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // sorted position
     bool pre = false;
-    if (p == 0) { flags->need_sweep = 0; flags->undecided = 0; }
+    if (p == 0) { flags->need_sweep = force_dense; flags->undecided = 0; cand_hdr->count = 0; }
     if (p < n) {
         const int64_t i = order[p];
         const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
         geom[p] = g;
-        fbox[p] = make_float4(round_down(g.xmin), round_down(g.ymin), round_up(g.xmax), round_up(g.ymax));
+        const float4 f = make_float4(round_down(g.xmin), round_down(g.ymin), round_up(g.xmax), round_up(g.ymax));
+        fbox[p] = f;
+        // key for the sweep-and-prune order: the descending sort of ~ordered(xmin) is ascending in xmin
+        const int32_t bits = __float_as_int(f.x);
+        xkey[p] = ~(bits ^ ((bits >> 31) & 0x7fffffff));
         // nms.cpp:23-29: the tail with score <= threshold is suppressed up front, never position 0
         pre = p > 0 && !(scores[i] > (T)score_threshold);
         state[p] = pre ? kSuppressed : kUndecided;
@@ -367,30 +387,148 @@ __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__
     if ((threadIdx.x & 63) == 0 && (p >> 6) < nb) remv[p >> 6] = word;
 }
 
-// block = 4 wavefronts = 4 row blocks, swept against kColsPerBlock consecutive column blocks.  Only the
-// conservative fp32 AABBs are staged (16 B per column, LDS broadcast); the fp64 geometry of a pair is
-// fetched from global memory on the rare AABB hit.
+// The pair phase is split so that the conservative AABB tests run in a kernel with a handful of registers and the
+// fp64 clipping runs with every lane busy -- and the AABB tests are pruned by a sweep along x:
+//   sort + k_nms_xgather   the boxes' AABBs in ascending-xmin order (radix sort of N keys), with their score ranks
+//   k_nms_cand   lane = box i of that order, walking the boxes j > i until one starts right of i's xmax (everything
+//                after it does too): consecutive lanes read consecutive AABBs, so the loads are coalesced and the
+//                N^2/2 tests shrink to N x (boxes within one box length in x).  Survivors (min rank, max rank) go
+//                to a per-wavefront LDS batch that is flushed to the global candidate list with one atomic
+//   k_nms_hits   one candidate (p, q) per lane: exact IoU, hit -> append p to q's incoming list
+// If the candidate list or an incoming list overflows, or the fixed point needs too many rounds, need_sweep is set
+// and the dense path runs instead (k_nms_pairs, k_nms_sweep -- gated on the flag, no host round trip).
 constexpr int kColsPerBlock = 8;
+constexpr int kCandLds = 256;        // LDS batch entries per wavefront (2 KiB)
+
+constexpr int kCandUnroll = 8;       // independent loads in flight per lane
+constexpr int kCandMaxSplit = 16;    // wavefronts sharing one block of 64 boxes
+constexpr int kCandPad = 64;         // sentinel AABBs behind the last block of boxes (a chunk touches 128 entries)
+
+__global__ __launch_bounds__(256) void k_nms_xgather(const float4 *__restrict__ fbox, const int32_t *__restrict__ perm,
+                                                     int64_t n, int64_t nb, float4 *__restrict__ fbx,
+                                                     uint32_t *__restrict__ rankx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb * 64 + kCandPad) return;
+    if (i < n) {
+        const int32_t r = perm[i];
+        fbx[i] = fbox[r];
+        rankx[i] = (uint32_t)r;
+    } else {                                      // sentinels: never a candidate, and they end every walk
+        fbx[i] = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+        if (i < nb * 64) rankx[i] = 0xffffffffu;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx, uint32_t nb, uint32_t nsplit,
+                                                  unsigned long long *__restrict__ list, unsigned long long cap,
+                                                  NmsCand *hdr, NmsFlags *flags)
+{
+    constexpr int U = kCandUnroll;
+    __shared__ unsigned long long batch[4][kCandLds];
+    __shared__ float4 window[4][128];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t wid = blockIdx.x * 4 + wave;
+    const uint32_t rb = wid / nsplit;
+    const uint32_t split = wid - rb * nsplit;
+    if (rb >= nb) return;
+    const uint32_t i = rb * 64 + lane;            // n < 2^28 (nb <= 65535)
+    const float4 fa = fbx[i];
+    unsigned long long *q = batch[wave];
+    float4 *win = window[wave];
+    unsigned int wn = 0;                                                  // wave-uniform fill of the batch
+    bool overflow = false;
+    auto flush = [&]() {
+        unsigned long long gb = 0;
+        if (lane == 0) gb = atomicAdd(&hdr->count, (unsigned long long)wn);
+        gb = __shfl(gb, 0, 64);
+        for (unsigned int t = lane; t < wn; t += 64)
+            if (gb + t < cap) list[gb + t] = q[t];
+        if (gb + wn > cap) { flags->need_sweep = 1; overflow = true; }    // the dense path takes over: stop early
+        wn = 0;
+    };
+    // lane i walks j = i + 1, i + 2, ... in chunks of 64 (the wavefronts sharing this block of boxes take every
+    // nsplit-th chunk): the 128 AABBs a chunk can touch are staged in LDS with two coalesced loads and each lane reads
+    // its own sliding window from there.  The walk ends with the first chunk whose last box starts right of every
+    // lane's xmax -- everything after it does too, and so do the sentinels behind the last box.
+    for (uint32_t c = split; rb + c < nb; c += nsplit) {
+        const uint32_t base = (rb + c) * 64;                              // chunk: j = base + lane + d, d = 1..64
+        win[lane] = fbx[base + lane];
+        win[64 + lane] = fbx[base + 64 + lane];                           // < nb * 64 + 64: boxes or sentinels
+#pragma unroll 1
+        for (int d0 = 1; d0 <= 64; d0 += U) {
+            float4 fb[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) fb[u] = win[lane + d0 + u];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                // strict overlap in x and y as ONE number: the smallest of the four gaps must be positive
+                const float g = fminf(fminf(fb[u].z - fa.x, fa.z - fb[u].x), fminf(fb[u].w - fa.y, fa.w - fb[u].y));
+                const bool cand = g > 0.f;                                // sentinels have g = -inf
+                const unsigned long long m = __ballot(cand);
+                if (m) {
+                    const unsigned int cnt = (unsigned int)__popcll(m);
+                    if (wn + cnt > (unsigned int)kCandLds) flush();
+                    if (cand)       // x-order indices; k_nms_hits turns them into score ranks
+                        q[wn + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] =
+                            ((unsigned long long)i << 32) | (unsigned long long)(base + lane + d0 + u);
+                    wn += cnt;
+                }
+            }
+        }
+        if (__ballot(win[lane + 64].x < fa.z) == 0 || overflow) break;
+    }
+    if (wn) flush();
+}
+
+template <typename T, bool ROTATED>
+__global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__ geom,
+                                                  const uint32_t *__restrict__ rankx,
+                                                  const unsigned long long *__restrict__ list, unsigned long long cap,
+                                                  const NmsCand *hdr, T thr, uint32_t *inc_cnt, uint32_t *inc,
+                                                  NmsFlags *flags)
+{
+    unsigned long long total = hdr->count;
+    if (total > cap) total = cap;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const unsigned long long e = list[t];
+        const uint32_t r1 = rankx[e >> 32], r2 = rankx[e & 0xffffffffull];      // x-order index -> score rank
+        const int64_t p = r1 < r2 ? r1 : r2, q = r1 < r2 ? r2 : r1;
+        const BoxGeom<T> a = geom[p], b = geom[q];
+        const T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
+        if (v > thr) {                                     // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
+            const uint32_t s = atomicAdd(&inc_cnt[q], 1u);
+            if (s < (uint32_t)kIncCap) inc[q * kIncCap + s] = (uint32_t)p;
+            else flags->need_sweep = 1;
+        }
+    }
+}
+
+// ---- dense path (runs only when need_sweep is set; every workgroup checks the flag first)
+// block = 4 wavefronts = 4 row blocks, swept against kColsPerBlock consecutive column blocks: the same conservative
+// AABB sweep, with the exact test inlined on the survivors and the hits written to the dense bit matrix
 template <typename T, bool ROTATED>
 __global__ __launch_bounds__(256) void k_nms_pairs(const BoxGeom<T> *__restrict__ geom, const float4 *__restrict__ fbox,
                                                    int64_t n, int64_t nb, T thr, unsigned long long *__restrict__ mask,
-                                                   uint32_t *inc_cnt, uint32_t *inc, NmsFlags *flags)
+                                                   const NmsFlags *flags)
 {
-    const int64_t cb0 = (int64_t)blockIdx.x * kColsPerBlock;
-    const int64_t rb = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (cb0 + kColsPerBlock <= (int64_t)blockIdx.y * 4) return;          // whole block below the diagonal
+    if (!flags->need_sweep) return;
+    const int64_t tx = (nb + kColsPerBlock - 1) / kColsPerBlock, ty = (nb + 3) / 4;
+    for (int64_t tile = blockIdx.x; tile < tx * ty; tile += gridDim.x) {
+    const int64_t by = tile / tx, bx = tile - by * tx;
+    const int64_t cb0 = bx * kColsPerBlock;
+    const int64_t rb = by * 4 + (threadIdx.x >> 6);
+    if (cb0 + kColsPerBlock <= by * 4) continue;                         // whole tile below the diagonal
     const int lane = threadIdx.x & 63;
     const int64_t p = rb * 64 + lane;
-    if (rb >= nb || p >= n) return;
+    if (rb >= nb || p >= n) continue;
     const float4 fa = fbox[p];
     for (int cc = 0; cc < kColsPerBlock; cc++) {
         const int64_t cb = cb0 + cc;
         if (cb < rb || cb >= nb) continue;                                  // wave-uniform
         const int64_t q0 = cb * 64;
         const int ncols = (int)((n - q0) < 64 ? (n - q0) : 64);
-        // branch-free sweep of the 64 columns: the column AABBs are wave-uniform -> scalar loads (SGPRs), the
-        // four compares are combined with bitwise & (no short-circuit branches), hits land in a bit set; the
-        // exact test runs afterwards on the rare survivors.  (fbox is padded to nb * 64 entries.)
         const float4 *__restrict__ fc = fbox + q0;
         uint32_t lo = 0, hi = 0;
 #pragma unroll 1
@@ -399,8 +537,6 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const BoxGeom<T> *__restrict_
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const float4 fb = fc[c0 + c];
-                // strict overlap in x and y as ONE compare: the smallest of the four gaps must be positive
-                // (branch-free; && would compile to exec-mask branches, four compares spill SGPR masks)
                 const float g = fminf(fminf(fb.z - fa.x, fa.z - fb.x), fminf(fb.w - fa.y, fa.w - fb.y));
                 byte |= (g > 0.f ? 1u : 0u) << c;
             }
@@ -414,71 +550,59 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const BoxGeom<T> *__restrict_
         while (cand) {
             const int c = __builtin_ctzll(cand);
             cand &= cand - 1;
-            const int64_t q = q0 + c;
-            const BoxGeom<T> a = geom[p], b = geom[q];
+            const BoxGeom<T> a = geom[p], b = geom[q0 + c];
             T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
-            if (v > thr) {                                 // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
-                bits |= 1ull << c;
-                const uint32_t e = atomicAdd(&inc_cnt[q], 1u);
-                if (e < (uint32_t)kIncCap) inc[q * kIncCap + e] = (uint32_t)p;
-                else flags->need_sweep = 1;
-            }
+            if (v > thr) bits |= 1ull << c;                // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
         }
-        if (bits) mask[p * nb + cb] = bits;      // the matrix is zero-filled up front (streaming memset): a lane-per-row
-                                                 // store here would be an uncoalesced 8-byte write per pair of blocks
+        mask[p * nb + cb] = bits;            // every word the sweep reads (upper triangle + diagonal) is written here
+    }
     }
 }
 
-// one fixed-point round over all boxes; returns nothing -- states only move undecided -> decided
-__device__ __forceinline__ bool nms_decide(int64_t q, uint8_t *state, const uint32_t *inc_cnt, const uint32_t *inc)
-{
-    if (state[q] != kUndecided) return false;
-    const uint32_t cnt = inc_cnt[q];
-    if (cnt > (uint32_t)kIncCap) return false;         // overflowed list: the dense sweep decides
-    bool pending = false, hit = false;
-    for (uint32_t e = 0; e < cnt; e++) {
-        const uint8_t sp = __hip_atomic_load(&state[inc[q * kIncCap + e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hit = hit || sp == kKept;
-        pending = pending || sp == kUndecided;
-    }
-    if (hit) { state[q] = kSuppressed; return true; }
-    if (!pending) { state[q] = kKept; return true; }
-    return false;
-}
-
-__global__ __launch_bounds__(256) void k_nms_round(int64_t n, uint8_t *state, const uint32_t *__restrict__ inc_cnt,
-                                                   const uint32_t *__restrict__ inc)
-{
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < n) nms_decide(q, state, inc_cnt, inc);
-}
-
-// single workgroup: keep iterating while something changes; leaves flags->undecided
-__global__ __launch_bounds__(1024) void k_nms_finish(int64_t n, uint8_t *state, const uint32_t *__restrict__ inc_cnt,
+// The greedy result as a fixed point, in ONE launch: lane = box q, polling the states of the earlier boxes that hit
+// it.  q is suppressed as soon as one of them is kept, kept once all of them are suppressed.  Hitters always rank
+// before q, so the lowest undecided box can always be decided and every resident wavefront makes progress; the
+// poll is bounded (kSpinPasses), and whatever is left -- dependency chains longer than that -- goes to the dense
+// sweep.  States cross XCDs, hence the agent-scope atomic loads/stores.
+constexpr int kSpinPasses = 4096;
+__global__ __launch_bounds__(256) void k_nms_resolve(int64_t n, uint8_t *state, const uint32_t *__restrict__ inc_cnt,
                                                      const uint32_t *__restrict__ inc, NmsFlags *flags)
 {
-    __shared__ int changed, left;
-    for (int it = 0; it < 4096; it++) {
-        if (threadIdx.x == 0) { changed = 0; left = 0; }
-        __syncthreads();
-        int c = 0, l = 0;
-        for (int64_t q = threadIdx.x; q < n; q += 1024) {
-            if (state[q] == kUndecided) {
-                if (nms_decide(q, state, inc_cnt, inc)) c = 1; else l = 1;
+    if (__hip_atomic_load(&flags->need_sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // a list overflowed
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool done = q >= n || state[q] != kUndecided;
+    uint32_t open = 0;                                   // bit e: hitter e of the list is still undecided
+    if (!done) {
+        const uint32_t cnt = inc_cnt[q];                 // <= kIncCap: otherwise need_sweep was set by k_nms_hits
+        open = cnt >= 32 ? 0xffffffffu : (1u << cnt) - 1u;
+    }
+    for (int pass = 0; pass < kSpinPasses; pass++) {
+        if (!done) {
+            bool hit = false;
+            for (uint32_t m = open; m; m &= m - 1) {
+                const int e = __builtin_ctz(m);
+                const uint8_t sp = __hip_atomic_load(&state[inc[q * kIncCap + e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hit = hit || sp == kKept;
+                if (sp != kUndecided) open &= ~(1u << e);
+            }
+            if (hit || !open) {
+                __hip_atomic_store(&state[q], (uint8_t)(hit ? kSuppressed : kKept), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                done = true;
             }
         }
-        if (c) changed = 1;
-        if (l) left = 1;
-        __threadfence_block();
-        __syncthreads();
-        const bool stop = !changed || !left;
-        __syncthreads();
-        if (stop) break;
+        if (__ballot(!done) == 0) return;
+        __builtin_amdgcn_s_sleep(2);
     }
-    if (threadIdx.x == 0) {
-        flags->undecided = left ? 1u : 0u;
-        if (left) flags->need_sweep = 1;
-    }
+    if (!done) flags->need_sweep = 1;
+}
+
+// the fixed point was reached: states are final
+__global__ __launch_bounds__(256) void k_nms_emit(int64_t n, const int64_t *__restrict__ order, const uint8_t *__restrict__ state,
+                                                  const NmsFlags *flags, uint8_t *__restrict__ suppressed)
+{
+    if (flags->need_sweep) return;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) suppressed[order[p]] = state[p] == kSuppressed;
 }
 
 // one workgroup; remv (nb words) lives in global scratch when it does not fit LDS
@@ -491,10 +615,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_nms_sweep(const unsigned long
                                                              const NmsFlags *flags, uint8_t *suppressed)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];
-    if (!flags->need_sweep) {            // the fixed point was reached: states are final
-        for (int64_t p = threadIdx.x; p < n; p += kSweepThreads) suppressed[order[p]] = state[p] == kSuppressed;
-        return;
-    }
+    if (!flags->need_sweep) return;      // the fixed point was reached: k_nms_emit wrote the result
     const bool in_lds = nb <= kSweepLdsWords;
     unsigned long long *remv = in_lds ? lds : remv_g;
     __shared__ unsigned long long keep_word;
@@ -552,21 +673,46 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     uint32_t *inc = w.take<uint32_t>((size_t)nb * 64 * kIncCap);
     NmsFlags *flags = w.take<NmsFlags>(1);
     unsigned long long *remv = w.take<unsigned long long>(nb);
+    NmsCand *cand_hdr = w.take<NmsCand>(1);
+    const unsigned long long cap = nms_cand_capacity(n);
+    unsigned long long *cand = w.take<unsigned long long>((size_t)cap);
+    int32_t *xkey = w.take<int32_t>(nb * 64);
+    int32_t *perm = w.take<int32_t>(nb * 64);
+    float4 *fbx = w.take<float4>(nb * 64 + kCandPad);
+    uint32_t *rankx = w.take<uint32_t>(nb * 64);
+    const size_t sort_bytes = d3d_internal_argsort_i32_bytes(n);
+    char *sort_ws = w.take<char>(sort_bytes);
     unsigned long long *mask = w.take<unsigned long long>((size_t)nb * 64 * nb);
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
+    const bool rot = iou_type == D3D_IOU_RBOX;
     D3D_LAUNCH("k_nms_prepare", k_nms_prepare<T>, dim3((unsigned)nb), dim3(64), 0, st, boxes, scores, order, n, score_thr,
-               geom, fbox, state, inc_cnt, remv, nb, flags);
-    D3D_HIP_CHECK(hipMemsetAsync(mask, 0, (size_t)nb * 64 * nb * 8, st));
-    dim3 grid((unsigned)d3d_divup(nb, kColsPerBlock), (unsigned)d3d_divup(nb, 4));
-    if (iou_type == D3D_IOU_RBOX)
-        D3D_LAUNCH("k_nms_pairs", (k_nms_pairs<T, true>), grid, dim3(256), 0, st, geom, fbox, n, nb, (T)iou_thr, mask,
-                   inc_cnt, inc, flags);
+               geom, fbox, state, inc_cnt, remv, nb, flags, cand_hdr, nms_force_dense(), xkey);
+    if (int rc = d3d_internal_argsort_desc_i32(xkey, n, perm, sort_ws, sort_bytes, st)) return rc;
+    D3D_LAUNCH("k_nms_xgather", k_nms_xgather, dim3((unsigned)d3d_divup(nb * 64 + kCandPad, 256)), dim3(256), 0, st, fbox,
+               perm, n, nb, fbx, rankx);
+    // enough wavefronts to fill the chip even when few row blocks exist: nsplit wavefronts share a row block
+    const uint32_t nsplit = (uint32_t)std::min<int64_t>(std::max<int64_t>(8192 / nb, 1), kCandMaxSplit);
+    D3D_LAUNCH("k_nms_cand", k_nms_cand, dim3((unsigned)d3d_divup(nb * nsplit, 4)), dim3(256), 0, st, (const float4 *)fbx,
+               (uint32_t)nb, nsplit, cand, cap, cand_hdr, flags);
+    const unsigned hits_blocks = (unsigned)std::min<unsigned long long>(d3d_divup((int64_t)cap, 256), 4096);
+    if (rot)
+        D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, true>), dim3(hits_blocks), dim3(256), 0, st, geom, rankx, cand, cap, cand_hdr,
+                   (T)iou_thr, inc_cnt, inc, flags);
     else
-        D3D_LAUNCH("k_nms_pairs", (k_nms_pairs<T, false>), grid, dim3(256), 0, st, geom, fbox, n, nb, (T)iou_thr, mask,
-                   inc_cnt, inc, flags);
-    for (int r = 0; r < kNmsRounds; r++)
-        D3D_LAUNCH("k_nms_round", k_nms_round, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state, inc_cnt, inc);
-    D3D_LAUNCH("k_nms_finish", k_nms_finish, dim3(1), dim3(1024), 0, st, n, state, inc_cnt, inc, flags);
+        D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, false>), dim3(hits_blocks), dim3(256), 0, st, geom, rankx, cand, cap, cand_hdr,
+                   (T)iou_thr, inc_cnt, inc, flags);
+    D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state, inc_cnt, inc,
+               flags);
+    D3D_LAUNCH("k_nms_emit", k_nms_emit, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, order, (const uint8_t *)state,
+               (const NmsFlags *)flags, suppressed);
+    // dense path, gated on need_sweep inside the kernels
+    const unsigned pair_blocks = (unsigned)std::min<int64_t>(d3d_divup(nb, kColsPerBlock) * d3d_divup(nb, 4), 8192);
+    if (rot)
+        D3D_LAUNCH("k_nms_pairs", (k_nms_pairs<T, true>), dim3(pair_blocks), dim3(256), 0, st, geom, fbox, n, nb, (T)iou_thr,
+                   mask, flags);
+    else
+        D3D_LAUNCH("k_nms_pairs", (k_nms_pairs<T, false>), dim3(pair_blocks), dim3(256), 0, st, geom, fbox, n, nb, (T)iou_thr,
+                   mask, flags);
     size_t lds = nb <= kSweepLdsWords ? (size_t)nb * 8 : 0;
     D3D_LAUNCH("k_nms_sweep", k_nms_sweep, dim3(1), dim3(kSweepThreads), lds, st, mask, n, nb, remv, order, state, flags,
                suppressed);
@@ -766,8 +912,9 @@ extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
     if (n < 1) n = 1;
     const size_t nb = (size_t)d3d_divup(n, 64);
     return d3d_align_up(nb * 64 * sizeof(BoxGeom<double>)) + d3d_align_up(nb * 64 * 16) + d3d_align_up(nb * 64) +
-           d3d_align_up(nb * 64 * 4) + d3d_align_up(nb * 64 * 4 * kIncCap) + 256 + d3d_align_up(nb * 8) +
-           d3d_align_up(nb * 64 * nb * 8) + 256;
+           d3d_align_up(nb * 64 * 4) + d3d_align_up(nb * 64 * 4 * kIncCap) + 256 + d3d_align_up(nb * 8) + 256 +
+           d3d_align_up((size_t)nms_cand_capacity(n) * 8) + 2 * d3d_align_up(nb * 64 * 4) + d3d_align_up((nb * 64 + kCandPad) * 16) +
+           d3d_align_up(nb * 64 * 4) + d3d_align_up(d3d_internal_argsort_i32_bytes(n)) + d3d_align_up(nb * 64 * nb * 8) + 256;
 }
 
 extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n, int32_t iou_type,

@@ -141,6 +141,59 @@ def test_nms_vs_oracle_bit_exact(method, gen, n, thr):
         assert np.array_equal(keep, exp), (np.sum(keep != exp), n)
 
 
+@pytest.mark.parametrize("hook,value", [("D3D_NMS_FORCE_DENSE", "1"), ("D3D_NMS_CAND_CAP", "100"), ("D3D_NMS_CAND_CAP", "3000")])
+@pytest.mark.parametrize("gen,n,thr", [("sparse", 5000, 0.3), ("dense", 1500, 0.3)])
+def test_nms_dense_path_hooks(monkeypatch, hook, value, gen, n, thr):
+    """the gated dense path (bit matrix + single-workgroup sweep) gives the same keep set as the list path: forced,
+    and reached through a candidate list that is too small (with and without the LDS batch spilling)"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms
+    mk = synth.boxes2d_sparse if gen == "sparse" else synth.boxes2d_dense
+    b, s = mk(n, 77)
+    exp = oracle.box2d_nms(b, s, iou_method="rbox", iou_threshold=thr, score_threshold=0.1)
+    monkeypatch.setenv(hook, value)
+    keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=thr, score_threshold=0.1).cpu().numpy()
+    assert np.array_equal(keep, exp)
+    monkeypatch.delenv(hook)
+    keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=thr, score_threshold=0.1).cpu().numpy()
+    assert np.array_equal(keep, exp)
+
+
+@pytest.mark.parametrize("n", [128, 3000])
+def test_nms_sweep_and_prune_edge_geometry(n):
+    """broad phase (sort by AABB xmin + walk): negative coordinates, many identical xmin, boxes spanning the whole scene,
+    zero-size boxes -- keep set bit-exact with the oracle"""
+    from d3d_amd.box import box2d_nms
+    rng = np.random.default_rng(n)
+    b = np.empty((n, 5))
+    b[:, 0] = rng.uniform(-300, 300, n)
+    b[:, 1] = rng.uniform(-300, 300, n)
+    b[:, 2] = rng.uniform(1, 40, n)
+    b[:, 3] = rng.uniform(1, 40, n)
+    b[:, 4] = rng.uniform(-3.2, 3.2, n)
+    b[: n // 8, 0] = np.round(b[: n // 8, 0] / 50) * 50          # columns of boxes sharing x
+    b[: n // 8, 2:4] = 20.0
+    b[: n // 8, 4] = 0.0                                         # ... and therefore the same AABB xmin
+    b[n // 8: n // 8 + 5, 2:4] = 2000.0                          # a few boxes covering everything
+    b[n // 4: n // 4 + 5, 2] = 0.0                               # degenerate
+    s = rng.permutation(n) / n + 0.001
+    for method in ["rbox", "box"]:
+        keep = box2d_nms(T(b), T(s), iou_method=method, iou_threshold=0.25).cpu().numpy()
+        exp = oracle.box2d_nms(b, s, iou_method=method, iou_threshold=0.25)
+        assert np.array_equal(keep, exp), (method, int(np.sum(keep != exp)))
+
+
+def test_nms_list_path_equals_dense_path_at_scale(monkeypatch):
+    """30k boxes at the cfg3 density: candidate-list path == all-pairs bit-matrix path (the reference's structure)"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms
+    b, s = synth.boxes2d_sparse(30000, 5)
+    keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3).cpu().numpy()
+    monkeypatch.setenv("D3D_NMS_FORCE_DENSE", "1")
+    dense = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3).cpu().numpy()
+    assert np.array_equal(keep, dense) and 0 < keep.sum() < len(keep)
+
+
 def test_nms_score_ties_are_stable():
     from d3d_amd.box import box2d_nms
     b, _ = bc.random_boxes_like_reference(400, 8)
