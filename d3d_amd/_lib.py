@@ -32,7 +32,10 @@ SIGNATURES = {
                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_voxelize_3d_reduce": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                               _vp, _sz, _vp]),
-    "d3d_sharded_finalize": (ctypes.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "d3d_sharded_scatter": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _sz, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
+                                           _vp, _vp, _vp, _vp, _vp]),
+    "d3d_sharded_finalize": (ctypes.c_int, [_i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
+                                            _vp, _vp, _vp]),
     "d3d_sharded_map": (ctypes.c_int, [_i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "d3d_grid_compact_workspace_bytes": (_sz, [_i64]),
     "d3d_grid_compact_index": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),

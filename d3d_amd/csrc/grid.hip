@@ -5,6 +5,7 @@
 // linear-key order".  RCCL has no bitwise-OR reduction, hence the keys are all-gathered and the
 // bitmap is built locally.
 #include "common.hpp"
+#include <cstdint>
 
 namespace {
 
@@ -47,16 +48,69 @@ __global__ __launch_bounds__(256) void k_grid_lookup(const int64_t *__restrict__
 }
 
 
-// sharded voxelizer, last step: slot-ordered reduced table -> voxel-id-ordered outputs
-__global__ __launch_bounds__(256) void k_sharded_finalize(int64_t nvox, int c, const int64_t *__restrict__ vid_of_slot,
+__device__ __forceinline__ long long compact_rank(long long k, int64_t ncells, const unsigned long long *__restrict__ bitmap,
+                                                  const uint32_t *__restrict__ prefix)
+{
+    if (k < 0 || k >= ncells) return -1;
+    const unsigned long long word = bitmap[k >> 6], bit = 1ull << (k & 63);
+    return (word & bit) ? (long long)prefix[k >> 6] + __popcll(word & (bit - 1)) : -1;
+}
+
+// sharded voxelizer, step 4a: identity rows for the all-reduce (sum: 0, max: -inf, min: +inf; first index: max)
+__global__ __launch_bounds__(256) void k_sharded_fill(int64_t nvox, int tstride, float identity, float *table,
+                                                      int32_t *cnt_table, int64_t *first)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nvox * tstride) table[i] = identity;
+    if (i < nvox) {
+        if (cnt_table) cnt_table[i] = 0;
+        first[i] = INT64_MAX;
+    }
+}
+
+// step 4b, one lane per gathered key: slot of the key; every rank writes key_of_slot (duplicates write the same value),
+// the lanes of this rank's own segment also place its partial rows into the table
+__global__ __launch_bounds__(256) void k_sharded_scatter(const int64_t *__restrict__ keys_all, int64_t m, int64_t begin,
+                                                         int64_t n_local, int64_t ncells,
+                                                         const unsigned long long *__restrict__ bitmap,
+                                                         const uint32_t *__restrict__ prefix, int c, int with_count,
+                                                         const float *__restrict__ agg, const int32_t *__restrict__ cnt,
+                                                         const int64_t *__restrict__ first_local, float *table, int tstride,
+                                                         int32_t *cnt_table, int64_t *first, int64_t *key_of_slot,
+                                                         int64_t *slot_of_local)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int64_t k = keys_all[j];
+    const long long s = compact_rank(k, ncells, bitmap, prefix);
+    const int64_t v = j - begin;                       // row of this rank's local result
+    const bool mine = v >= 0 && v < n_local;
+    if (mine) slot_of_local[v] = s;
+    if (s < 0) return;
+    key_of_slot[s] = k;
+    if (!mine) return;
+    for (int d = 0; d < c; d++) table[s * tstride + d] = agg[v * c + d];
+    if (with_count) table[s * tstride + c] = (float)cnt[v];      // counts < 2^24 are exact in fp32
+    else cnt_table[s] = cnt[v];
+    first[s] = first_local[v];
+}
+
+// sharded voxelizer, last step: slot-ordered reduced table -> voxel-id-ordered outputs.  The voxel id of a slot is
+// the rank of its first point index among all first indices (bitmap over the frame's points, popcount prefix).
+__global__ __launch_bounds__(256) void k_sharded_finalize(int64_t nvox, int c, const int64_t *__restrict__ first,
+                                                          int64_t n_total, const unsigned long long *__restrict__ bitmap,
+                                                          const uint32_t *__restrict__ prefix,
                                                           const int64_t *__restrict__ key_of_slot,
                                                           const float *__restrict__ table, int tstride, int mean,
                                                           const int32_t *__restrict__ cnt_in, int64_t sy, int64_t sz,
-                                                          int64_t *coords, int32_t *cnt_out, float *feats)
+                                                          int64_t *vid_of_slot, int64_t *coords, int32_t *cnt_out, float *feats)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nvox) return;
-    const int64_t v = vid_of_slot[s], k = key_of_slot[s];
+    const long long v = compact_rank(first[s], n_total, bitmap, prefix);
+    vid_of_slot[s] = v;
+    if (v < 0) return;                                 // cannot happen: every slot has a first point
+    const int64_t k = key_of_slot[s];
     coords[v * 3 + 0] = k / (sy * sz);
     coords[v * 3 + 1] = (k / sz) % sy;
     coords[v * 3 + 2] = k % sz;
@@ -133,17 +187,56 @@ extern "C" int d3d_grid_compact_lookup(const int64_t *keys, int64_t m, int64_t n
     return D3D_OK;
 }
 
-extern "C" int d3d_sharded_finalize(int64_t nvox, int32_t c, const int64_t *vid_of_slot, const int64_t *key_of_slot,
-                                    const float *table, int32_t table_stride, int32_t mean, const int32_t *cnt_in,
-                                    const int32_t *shape, int64_t *coords, int32_t *cnt_out, float *feats, void *stream)
+extern "C" int d3d_sharded_scatter(const int64_t *keys_all, int64_t m, int64_t begin, int64_t n_local, int64_t ncells,
+                                   const void *compact_ws, size_t compact_ws_bytes, int64_t nvox, int32_t c,
+                                   int32_t reduction, const float *agg, const int32_t *cnt, const int64_t *first_local,
+                                   float *table, int32_t table_stride, int32_t *cnt_table, int64_t *first,
+                                   int64_t *key_of_slot, int64_t *slot_of_local, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (nvox < 0 || c < 1 || !shape) return D3D_ERR_BAD_ARG;
+    if (m < 0 || n_local < 0 || nvox < 0 || ncells <= 0 || c < 1 || begin < 0) return D3D_ERR_BAD_ARG;
+    if (reduction != D3D_REDUCE_MEAN && reduction != D3D_REDUCE_MAX && reduction != D3D_REDUCE_MIN) return D3D_ERR_UNSUPPORTED;
+    const bool mean = reduction == D3D_REDUCE_MEAN;
+    if (table_stride < c + (mean ? 1 : 0)) return D3D_ERR_BAD_ARG;
+    if (nvox > 0 && (!table || !first || !key_of_slot || (!mean && !cnt_table))) return D3D_ERR_BAD_ARG;
+    if (m > 0 && !keys_all) return D3D_ERR_BAD_ARG;
+    if (n_local > 0 && (!agg || !cnt || !first_local || !slot_of_local)) return D3D_ERR_BAD_ARG;
+    const int64_t nw = d3d_divup(ncells, 64);
+    WsCarver w((void *)compact_ws, compact_ws_bytes);
+    unsigned long long *bitmap = w.take<unsigned long long>(nw);
+    uint32_t *prefix = w.take<uint32_t>(nw);
+    if (!compact_ws || !w.ok()) return D3D_ERR_WORKSPACE;
+    const float identity = mean ? 0.f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+    if (nvox > 0)
+        D3D_LAUNCH("k_sharded_fill", k_sharded_fill, dim3((unsigned)d3d_divup(nvox * table_stride, 256)), dim3(256), 0, st, nvox,
+                   table_stride, identity, table, mean ? nullptr : cnt_table, first);
+    if (m > 0)
+        D3D_LAUNCH("k_sharded_scatter", k_sharded_scatter, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, keys_all, m,
+                   begin, n_local, ncells, bitmap, prefix, c, mean ? 1 : 0, agg, cnt, first_local, table, table_stride,
+                   cnt_table, first, key_of_slot, slot_of_local);
+    return D3D_OK;
+}
+
+extern "C" int d3d_sharded_finalize(int64_t nvox, int32_t c, const int64_t *first, int64_t n_total, int64_t *counts,
+                                    void *compact_ws, size_t compact_ws_bytes, const int64_t *key_of_slot,
+                                    const float *table, int32_t table_stride, int32_t mean, const int32_t *cnt_in,
+                                    const int32_t *shape, int64_t *vid_of_slot, int64_t *coords, int32_t *cnt_out,
+                                    float *feats, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (nvox < 0 || c < 1 || !shape || n_total < 0) return D3D_ERR_BAD_ARG;
     if (nvox == 0) return D3D_OK;
-    if (!vid_of_slot || !key_of_slot || !table || !coords || !cnt_out || !feats || (!mean && !cnt_in)) return D3D_ERR_BAD_ARG;
-    D3D_LAUNCH("k_sharded_finalize", k_sharded_finalize, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox, c,
-               vid_of_slot, key_of_slot, table, table_stride, mean, cnt_in, (int64_t)shape[1], (int64_t)shape[2], coords,
-               cnt_out, feats);
+    if (!first || !key_of_slot || !table || !vid_of_slot || !coords || !cnt_out || !feats || (!mean && !cnt_in) || !counts)
+        return D3D_ERR_BAD_ARG;
+    int rc = d3d_grid_compact_index(first, nvox, n_total > 0 ? n_total : 1, counts, compact_ws, compact_ws_bytes, stream);
+    if (rc) return rc;
+    const int64_t nw = d3d_divup(n_total > 0 ? n_total : 1, 64);
+    WsCarver w(compact_ws, compact_ws_bytes);
+    unsigned long long *bitmap = w.take<unsigned long long>(nw);
+    uint32_t *prefix = w.take<uint32_t>(nw);
+    D3D_LAUNCH("k_sharded_finalize", k_sharded_finalize, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox, c, first,
+               n_total > 0 ? n_total : (int64_t)1, bitmap, prefix, key_of_slot, table, table_stride, mean, cnt_in,
+               (int64_t)shape[1], (int64_t)shape[2], vid_of_slot, coords, cnt_out, feats);
     return D3D_OK;
 }
 

@@ -564,9 +564,11 @@ __global__ __launch_bounds__(256) void k_meta(Key kf, const float4 *__restrict__
                                               const float4 *__restrict__ staged, const uint32_t *__restrict__ unsorted,
                                               uint32_t P, int reduction, int64_t *coords, int32_t *npoints,
                                               uint32_t *voff, unsigned char *pmask, float4 *agg, uint32_t *big_list,
-                                              uint32_t *big_count, int64_t *keys_out = nullptr)
+                                              uint32_t *big_count, int64_t *keys_out = nullptr, int64_t status_row = -1)
 {
     const int64_t V = counts[D3D_COUNT_VOXELS];
+    // sharded voxelizer: the status bits travel with the key list (row `status_row`, negative = not a cell)
+    if (keys_out && status_row >= 0 && blockIdx.x == 0 && threadIdx.x == 0) keys_out[status_row] = -1 - counts[D3D_COUNT_STATUS];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
@@ -1059,7 +1061,7 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
                                       int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (keys && n > 0) D3D_HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)n * 8, st));   // -1 = no voxel in this row
+    if (keys && n >= 0) D3D_HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)(n + 1) * 8, st));   // -1 = no voxel in this row
     if (n < 0 || c < 3 || !shape || !bound || !counts) return D3D_ERR_BAD_ARG;
     if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
     if (reduction < D3D_REDUCE_MEAN || reduction > kReduceSum) return D3D_ERR_UNSUPPORTED;
@@ -1080,13 +1082,13 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     if (agg4) {
         D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, p4, counts, w.vinfo,
                    w.staged, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr,
-                   reinterpret_cast<float4 *>(aggregates), w.big_list, w.big_count, keys);
+                   reinterpret_cast<float4 *>(aggregates), w.big_list, w.big_count, keys, n);
         D3D_LAUNCH("k_overflow_reduce", k_overflow_reduce, dim3(512), dim3(256), 0, st, p4, w.vinfo, w.unsorted, w.big_list,
                    w.big_count, reduction, reinterpret_cast<float4 *>(aggregates));
     } else {
         D3D_LAUNCH("k_meta", (k_meta<DenseKey, false>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, p4, counts, w.vinfo,
                    w.staged, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr, (float4 *)nullptr,
-                   w.big_list, w.big_count, keys);
+                   w.big_list, w.big_count, keys, n);
         D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(n * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
                    w.voff, w.list, w.unsorted, P, reduction, aggregates);
     }

@@ -10,9 +10,12 @@ point -> voxel map of the rank's own points:
   2. gather  RCCL all-gather of the per-rank occupied-cell key lists (8 B per voxel)     [xGMI]
   3. slots   every rank marks the gathered keys in a bitmap over the grid and popcount-scans it: identical
              compact slot numbering on all ranks without exchanging a dictionary          [HIP kernels]
-             (RCCL has no bitwise-OR reduction, so the bitmap itself cannot be all-reduced)
-  4. reduce  RCCL all-reduce of the compact voxel table: SUM of features+counts (or MAX/MIN), MIN of first index
-  5. order   the same bitmap+scan over the first-point indices turns slots into first-seen voxel ids
+             (RCCL has no bitwise-OR reduction, so the bitmap itself cannot be all-reduced).  The global voxel
+             count and every rank's status bits (they ride in the key lists) are the ONE host read-back of a call.
+  4. reduce  one kernel writes the reduction's identity and the rank's partial rows into the compact voxel table,
+             then RCCL all-reduce: SUM of features+counts (or MAX/MIN), MIN of first index
+  5. order   the same bitmap+scan over the first-point indices turns slots into first-seen voxel ids, fused
+             with the division / transposition into voxel-id order
 
 Exact: coords, counts, numbering, MAX/MIN.  MEAN: the cross-rank sum order differs from a sequential pass
 (as on one GPU for overflow voxels), so it matches within fp32 rounding (rtol 1e-5).
@@ -71,8 +74,8 @@ class HipOps:
 
     def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False):
         """-> coords[n,3], cnt[n], agg[n,c], first[n], mapping[n], keys[n], counts[4] -- all on the device and all
-        sized for n voxels; only the first counts[0] rows are meaningful (keys is -1 beyond them).  counts[2]
-        carries the status bits."""
+        sized for n voxels; only the first counts[0] rows are meaningful.  keys has n + 1 entries: -1 beyond the
+        voxels, and keys[n] = -1 - status bits (so the status reaches every rank with the key all-gather)."""
         lib = _lib.load()
         pts = points.contiguous()
         dev = pts.device
@@ -85,7 +88,7 @@ class HipOps:
             agg = torch.empty((n, c), dtype=torch.float32, device=dev)
             first = torch.empty((n,), dtype=torch.int64, device=dev)
             mapping = torch.empty((n,), dtype=torch.int64, device=dev)
-            keys = torch.empty((n,), dtype=torch.int64, device=dev)
+            keys = torch.empty((n + 1,), dtype=torch.int64, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
             ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
             lib.d3d_voxel_force_plain(1 if plain else 0)
@@ -99,9 +102,10 @@ class HipOps:
             _lib.check(rc, "voxelize_3d_reduce")
         return coords, cnt, agg, first, mapping, keys, counts
 
-    def compact_index(self, keys, ncells, need_total=True):
-        """-> (handle, number of distinct keys or None); handle feeds compact_lookup.  Negative keys are ignored.
-        Reading the total is a host synchronisation."""
+    def compact_index(self, keys, ncells, status_stride=None):
+        """-> (handle, number of distinct keys, status bits OR-ed over the ranks); handle feeds build_table.
+        Negative keys are ignored; with status_stride, every status_stride-th key (the last of each rank's block)
+        is a status row.  Reading the total is THE host synchronisation of a sharded call."""
         lib = _lib.load()
         dev = keys.device
         keys = keys.contiguous()
@@ -111,23 +115,37 @@ class HipOps:
             rc = lib.d3d_grid_compact_index(_lib.ptr(keys), keys.numel(), int(ncells), _lib.ptr(counts), _lib.ptr(ws),
                                             ws.numel(), _lib.stream_ptr())
             _lib.check(rc, "grid_compact_index")
-            total = int(counts[0].item()) if need_total else None
-        return (ws, int(ncells)), total
+            if status_stride:
+                host = torch.cat([counts[:1], keys[status_stride - 1::status_stride]]).tolist()
+            else:
+                host = counts[:1].tolist()
+        status = 0
+        for flag in host[1:]:
+            status |= -1 - int(flag)
+        return (ws, int(ncells)), int(host[0]), status
 
-    def compact_lookup(self, handle, keys, missing=-1):
+    def build_table(self, handle, keys_all, begin, n_local, nvox, c, reduction, agg, cnt, first_local):
+        """identity-filled all-reduce operands with this rank's partial rows in place:
+        -> table[nvox, c(+1)], cnt_table[nvox] (None for mean), first[nvox], key_of_slot[nvox], slot_of_local[n_local]"""
         lib = _lib.load()
         ws, ncells = handle
-        dev = keys.device
-        keys = keys.contiguous()
+        dev = keys_all.device
+        mean = int(reduction) == 1
         with torch.cuda.device(dev):
-            slot = torch.empty((keys.numel(),), dtype=torch.int64, device=dev)
-            rc = lib.d3d_grid_compact_lookup(_lib.ptr(keys), keys.numel(), ncells, _lib.ptr(ws), ws.numel(), int(missing),
-                                             _lib.ptr(slot), _lib.stream_ptr())
-            _lib.check(rc, "grid_compact_lookup")
-        return slot
+            table = torch.empty((nvox, c + 1 if mean else c), dtype=torch.float32, device=dev)
+            cnt_t = None if mean else torch.empty((nvox,), dtype=torch.int32, device=dev)
+            first = torch.empty((nvox,), dtype=torch.int64, device=dev)
+            key_of_slot = torch.empty((nvox,), dtype=torch.int64, device=dev)
+            slot = torch.empty((n_local,), dtype=torch.int64, device=dev)
+            rc = lib.d3d_sharded_scatter(_lib.ptr(keys_all), keys_all.numel(), int(begin), int(n_local), ncells, _lib.ptr(ws),
+                                         ws.numel(), int(nvox), int(c), int(reduction), _lib.ptr(agg), _lib.ptr(cnt),
+                                         _lib.ptr(first_local), _lib.ptr(table), table.shape[1], _lib.ptr(cnt_t),
+                                         _lib.ptr(first), _lib.ptr(key_of_slot), _lib.ptr(slot), _lib.stream_ptr())
+            _lib.check(rc, "sharded_scatter")
+        return table, cnt_t, first, key_of_slot, slot
 
-    def finalize(self, nvox, c, vid_of_slot, key_of_slot, table, mean, cnt_in, shape):
-        """slot-ordered reduced table -> voxel-id-ordered (coords, counts, features)"""
+    def finalize(self, nvox, c, first, n_total, key_of_slot, table, mean, cnt_in, shape):
+        """slot-ordered reduced table -> voxel-id-ordered (coords, counts, features) + vid_of_slot"""
         lib = _lib.load()
         dev = table.device
         shape_h = (ctypes.c_int32 * 3)(*[int(x) for x in shape])
@@ -135,12 +153,15 @@ class HipOps:
             coords = torch.empty((nvox, 3), dtype=torch.int64, device=dev)
             cnt = torch.empty((nvox,), dtype=torch.int32, device=dev)
             feats = torch.empty((nvox, c), dtype=torch.float32, device=dev)
-            rc = lib.d3d_sharded_finalize(nvox, c, _lib.ptr(vid_of_slot), _lib.ptr(key_of_slot), _lib.ptr(table),
-                                          table.shape[1], 1 if mean else 0, _lib.ptr(cnt_in),
-                                          ctypes.cast(shape_h, ctypes.c_void_p), _lib.ptr(coords), _lib.ptr(cnt),
-                                          _lib.ptr(feats), _lib.stream_ptr())
+            vid = torch.empty((nvox,), dtype=torch.int64, device=dev)
+            counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+            ws = torch.empty((lib.d3d_grid_compact_workspace_bytes(max(n_total, 1)),), dtype=torch.uint8, device=dev)
+            rc = lib.d3d_sharded_finalize(nvox, c, _lib.ptr(first), int(n_total), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
+                                          _lib.ptr(key_of_slot), _lib.ptr(table), table.shape[1], 1 if mean else 0,
+                                          _lib.ptr(cnt_in), ctypes.cast(shape_h, ctypes.c_void_p), _lib.ptr(vid),
+                                          _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(feats), _lib.stream_ptr())
             _lib.check(rc, "sharded_finalize")
-        return coords, cnt, feats
+        return coords, cnt, feats, vid
 
     def compose_map(self, local_map, slot_of_local, nvox, vid_of_slot):
         lib = _lib.load()
@@ -214,48 +235,31 @@ class ShardedVoxelGenerator:
         n, c = points.shape
         offset, n_total, cap = self._layout(n, dev)
         mean = self._red == 1
-        # 1. local hash + partial reduction; nothing is read back: rows >= V_r carry key -1
+        # 1. local hash + partial reduction; nothing is read back: rows >= V_r carry key -1, row n the status
         kw = {"plain": True} if plain else {}
-        _, cnt_r, agg_r, first_r, map_r, keys_r, counts_r = ops.voxelize_reduce(
+        _, cnt_r, agg_r, first_r, map_r, keys_r, _ = ops.voxelize_reduce(
             points, self._shape, self._bounds, _SUM if mean else self._red, offset, **kw)
-        # 2. all-gather the occupied-cell keys, padded to the largest shard
-        pad = keys_r if n == cap else torch.cat([keys_r, keys_r.new_full((cap - n,), -1)])
-        keys_all = comm.all_gather_var(pad, [cap] * comm.world)
-        # 3. identical compact slots on every rank (the one host read-back: the global voxel count)
-        handle, nvox = ops.compact_index(keys_all, self._ncells)
-        retry = 1.0 if _status_retry(counts_r.cpu()) else 0.0
-        slot_all = ops.compact_lookup(handle, keys_all, missing=nvox)       # row nvox swallows the padding
-        slot_r = slot_all[comm.rank * cap: comm.rank * cap + n]
-        key_of_slot = torch.empty((nvox + 1,), dtype=torch.int64, device=dev)
-        key_of_slot[slot_all] = keys_all                                    # duplicates write the same value
-        # 4. all-reduce the compact voxel table (a pack-overflow retry flag rides along in an extra row)
-        if mean:
-            table = torch.zeros((nvox + 2, c + 1), dtype=torch.float32, device=dev)
-            table[slot_r, :c] = agg_r
-            table[slot_r, c] = cnt_r.to(torch.float32)       # counts < 2^24 are exact in fp32
-            table[nvox + 1, 0] = retry
-            comm.all_reduce(table, "sum")
-            need_retry, cnt_t = table[nvox + 1, 0], None
-        else:
-            table = torch.full((nvox + 1, c), float("-inf") if self._red == 2 else float("inf"), dtype=torch.float32,
-                               device=dev)
-            table[slot_r] = agg_r
-            comm.all_reduce(table, "max" if self._red == 2 else "min")
-            cnt_t = torch.zeros((nvox + 2,), dtype=torch.int32, device=dev)
-            cnt_t[slot_r] = cnt_r
-            cnt_t[nvox + 1] = int(retry)
-            comm.all_reduce(cnt_t, "sum")
-            need_retry = cnt_t[nvox + 1]
-        first = torch.full((nvox + 1,), _I64_MAX, dtype=torch.int64, device=dev)
-        first[slot_r] = first_r
-        comm.all_reduce(first, "min")
+        # 2. all-gather the occupied-cell keys (+ status row), padded to the largest shard
+        pad = keys_r if n == cap else torch.cat([keys_r[:n], keys_r.new_full((cap - n,), -1), keys_r[n:]])
+        keys_all = comm.all_gather_var(pad, [cap + 1] * comm.world)
+        # 3. identical compact slots on every rank; the one host read-back: global voxel count + every rank's status
+        handle, nvox, status = ops.compact_index(keys_all, self._ncells, status_stride=cap + 1)
+        if status & _lib.STATUS_TABLE_FULL:
+            raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
+        if status & _lib.STATUS_PACK_OVERFLOW and not plain:
+            return None        # some rank hit the packed-slot counter limit (rare): all ranks redo with plain slots
+        # 4. all-reduce the compact voxel table
+        table, cnt_t, first, key_of_slot, slot_r = ops.build_table(
+            handle, keys_all, comm.rank * (cap + 1), n, nvox, c, self._red, agg_r, cnt_r, first_r)
+        if nvox > 0:
+            comm.all_reduce(table, "sum" if mean else ("max" if self._red == 2 else "min"))
+            if cnt_t is not None:
+                comm.all_reduce(cnt_t, "sum")
+            comm.all_reduce(first, "min")
         # 5. first-seen numbering: rank of each voxel's first point index among all first indices
-        handle2, _ = ops.compact_index(first[:nvox], max(n_total, 1), need_total=False)
-        vid_of_slot = ops.compact_lookup(handle2, first[:nvox])
-        coords, out_cnt, out_feats = ops.finalize(nvox, c, vid_of_slot, key_of_slot, table, mean, cnt_t, self._shape)
+        coords, out_cnt, out_feats, vid_of_slot = ops.finalize(nvox, c, first, n_total, key_of_slot, table, mean, cnt_t,
+                                                               self._shape)
         gmap = ops.compose_map(map_r, slot_r, nvox, vid_of_slot)
-        if not plain and float(need_retry) > 0:       # some rank hit the packed-slot counter limit (rare): redo
-            return None
         return Dict(coords=coords, voxel_npoints=out_cnt, aggregates=out_feats, points_mapping=gmap)
 
 

@@ -114,7 +114,8 @@ int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c,
  * ALL in-range points (voxelize.cpp:137-164).  reduction: MEAN/MAX/MIN or 4 = SUM (MEAN without the division).
  *   coords[n,3] i64, npoints[n] i32, aggregates[n,c] f32, first[n] i64 (index_offset + index of the voxel's first
  *   point; may be NULL), mapping[n] i64 (voxel id per point, -1 = out of range; may be NULL),
- *   keys[n] i64 (linear cell index (x*sy+y)*sz+z per voxel, -1 in the rows >= counts[0]; may be NULL). */
+ *   keys[n + 1] i64 (linear cell index (x*sy+y)*sz+z per voxel, -1 in the rows >= counts[0]; keys[n] = -1 - status
+ *   bits of counts[2], so that the status travels with the key list; may be NULL). */
 int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                            int32_t reduction, int64_t index_offset, int64_t *coords, int32_t *npoints,
                            float *aggregates, int64_t *first, int64_t *mapping, int64_t *keys, int64_t *counts,
@@ -129,12 +130,25 @@ int d3d_grid_compact_index(const int64_t *keys, int64_t m, int64_t ncells, int64
 int d3d_grid_compact_lookup(const int64_t *keys, int64_t m, int64_t ncells, const void *workspace,
                             size_t workspace_bytes, int64_t missing, int64_t *slot, void *stream);
 
-/* last steps of the sharded voxelizer: (a) slot-ordered all-reduced table [nvox, table_stride] (mean: c sums + count;
- * else c extrema, counts in cnt_in) -> voxel-id-ordered coords[nvox,3], cnt_out[nvox], feats[nvox,c];
- * (b) global voxel id of every local point: gmap[i] = vid_of_slot[slot_of_local[local_map[i]]] (-1 stays -1). */
-int d3d_sharded_finalize(int64_t nvox, int32_t c, const int64_t *vid_of_slot, const int64_t *key_of_slot,
-                         const float *table, int32_t table_stride, int32_t mean, const int32_t *cnt_in,
-                         const int32_t *shape, int64_t *coords, int32_t *cnt_out, float *feats, void *stream);
+/* Steps of the sharded voxelizer around the two all-reduces (no host synchronisation).
+ * scatter: keys_all[m] = all-gathered key lists (negative = padding / status rows), already indexed by
+ *   d3d_grid_compact_index into compact_ws; rows [begin, begin + n_local) are this rank's own.  Writes the identity
+ *   of the reduction into table[nvox, table_stride] (MEAN: c sums + count, else c extrema with the counts in
+ *   cnt_table[nvox]) and first[nvox] (INT64_MAX), then this rank's partial rows at their slots, key_of_slot[nvox]
+ *   for every gathered key, and slot_of_local[n_local] (-1 beyond the rank's voxels).
+ * finalize: voxel id of a slot = rank of first[slot] among all first indices (compact_ws sized for n_total cells is
+ *   overwritten); slot-ordered all-reduced table -> voxel-id-ordered coords[nvox,3], cnt_out[nvox], feats[nvox,c],
+ *   and vid_of_slot[nvox].
+ * map: global voxel id of every local point: gmap[i] = vid_of_slot[slot_of_local[local_map[i]]] (-1 stays -1). */
+int d3d_sharded_scatter(const int64_t *keys_all, int64_t m, int64_t begin, int64_t n_local, int64_t ncells,
+                        const void *compact_ws, size_t compact_ws_bytes, int64_t nvox, int32_t c, int32_t reduction,
+                        const float *agg, const int32_t *cnt, const int64_t *first_local, float *table,
+                        int32_t table_stride, int32_t *cnt_table, int64_t *first, int64_t *key_of_slot,
+                        int64_t *slot_of_local, void *stream);
+int d3d_sharded_finalize(int64_t nvox, int32_t c, const int64_t *first, int64_t n_total, int64_t *counts,
+                         void *compact_ws, size_t compact_ws_bytes, const int64_t *key_of_slot, const float *table,
+                         int32_t table_stride, int32_t mean, const int32_t *cnt_in, const int32_t *shape,
+                         int64_t *vid_of_slot, int64_t *coords, int32_t *cnt_out, float *feats, void *stream);
 int d3d_sharded_map(int64_t n, const int64_t *local_map, const int64_t *slot_of_local, int64_t nvox,
                     const int64_t *vid_of_slot, int64_t *gmap, void *stream);
 

@@ -35,30 +35,55 @@ class NumpyOps:
                 first[mapping[i]] = i + index_offset
         v = len(coords)
 
-        def padded(a, fill):          # device contract: buffers sized for n voxels, rows >= V are garbage
-            out = np.full((n,) + a.shape[1:], fill, a.dtype)
+        def padded(a, fill, extra=0):   # device contract: buffers sized for n voxels, rows >= V are garbage
+            out = np.full((n + extra,) + a.shape[1:], fill, a.dtype)
             out[:v] = a
             return torch.from_numpy(out)
         counts = torch.tensor([v, 0, 0, 0], dtype=torch.int64)
         keys = (coords[:, 0] * shape[1] + coords[:, 1]) * shape[2] + coords[:, 2]
         return (padded(coords, 7), padded(cnt, 99), padded(agg, 1e30), padded(first, 123), torch.from_numpy(mapping),
-                padded(keys.astype(np.int64), -1), counts)
+                padded(keys.astype(np.int64), -1, extra=1), counts)      # keys[n] = -1 - status (0)
 
-    def compact_index(self, keys, ncells, need_total=True):
+    def compact_index(self, keys, ncells, status_stride=None):
         k = keys.cpu().numpy()
+        status = 0
+        if status_stride:
+            for flag in k[status_stride - 1::status_stride]:
+                status |= -1 - int(flag)
         u = np.unique(k[k >= 0])
-        return u, len(u)
+        return u, len(u), status
 
-    def compact_lookup(self, handle, keys, missing=-1):
-        k = keys.cpu().numpy()
+    def _lookup(self, handle, k):
         if len(handle) == 0:
-            return torch.full((len(k),), missing, dtype=torch.int64)
+            return np.full((len(k),), -1, np.int64)
         pos = np.searchsorted(handle, k)
-        pos = np.where((pos < len(handle)) & (handle[np.minimum(pos, len(handle) - 1)] == k), pos, missing)
-        return torch.from_numpy(pos.astype(np.int64)).to(keys.device)
+        return np.where((pos < len(handle)) & (handle[np.minimum(pos, len(handle) - 1)] == k), pos, -1).astype(np.int64)
 
-    def finalize(self, nvox, c, vid_of_slot, key_of_slot, table, mean, cnt_in, shape):
-        vid = vid_of_slot.numpy()
+    def build_table(self, handle, keys_all, begin, n_local, nvox, c, reduction, agg, cnt, first_local):
+        k = keys_all.cpu().numpy()
+        slot_all = self._lookup(handle, k)
+        mean = int(reduction) == 1
+        ident = 0.0 if mean else (-np.inf if int(reduction) == 2 else np.inf)
+        table = np.full((nvox, c + 1 if mean else c), ident, np.float32)
+        cnt_t = None if mean else np.zeros((nvox,), np.int32)
+        first = np.full((nvox,), np.iinfo(np.int64).max, np.int64)
+        key_of_slot = np.empty((nvox,), np.int64)
+        ok = slot_all >= 0
+        key_of_slot[slot_all[ok]] = k[ok]
+        slot = slot_all[begin:begin + n_local].copy()
+        mine = slot >= 0
+        table[slot[mine], :c] = agg.numpy()[:n_local][mine]
+        if mean:
+            table[slot[mine], c] = cnt.numpy()[:n_local][mine].astype(np.float32)
+        else:
+            cnt_t[slot[mine]] = cnt.numpy()[:n_local][mine]
+        first[slot[mine]] = first_local.numpy()[:n_local][mine]
+        t = torch.from_numpy
+        return t(table), (None if mean else t(cnt_t)), t(first), t(key_of_slot), t(slot)
+
+    def finalize(self, nvox, c, first, n_total, key_of_slot, table, mean, cnt_in, shape):
+        f = first.numpy()[:nvox]
+        vid = np.argsort(np.argsort(f, kind="stable"), kind="stable").astype(np.int64)   # rank among the first indices
         k = key_of_slot.numpy()[:nvox]
         t = table.numpy()[:nvox]
         sy, sz = shape[1], shape[2]
@@ -72,7 +97,7 @@ class NumpyOps:
         else:
             cnt[vid] = cnt_in.numpy()[:nvox]
             feats[vid] = t[:, :c]
-        return torch.from_numpy(coords), torch.from_numpy(cnt), torch.from_numpy(feats)
+        return torch.from_numpy(coords), torch.from_numpy(cnt), torch.from_numpy(feats), torch.from_numpy(vid)
 
     def compose_map(self, local_map, slot_of_local, nvox, vid_of_slot):
         m = local_map.numpy()
