@@ -102,92 +102,153 @@ __global__ __launch_bounds__(kTileCols) void k_iou2d(const T *__restrict__ b1, i
 //               AABBs overlap to a global candidate list (wave-aggregated atomic append)
 //   k_iou_clip  one candidate per lane -- dense wavefronts of clipping -- and scatters the non-zero IoUs
 // If the list overflows (more candidates than its capacity) the monolithic kernel recomputes everything.
-struct IouList { unsigned long long count; unsigned int overflow, pad; };
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_geom(const T *__restrict__ boxes, int64_t n, BoxGeom<T> *geom, IouList *hdr)
+// The candidate list is split into nseg segments (1 or kListSegs) with a counter each, on separate cache lines:
+// atomics on ONE address are serialised (~7 ns each), which dominated short launches where every workgroup reserves
+// at about the same time.  A full segment counts as overflow (the single-kernel fallback recomputes everything).
+constexpr int kListSegs = 8;
+struct IouList { unsigned long long count[kListSegs * 16]; unsigned int overflow, nseg; };
+__device__ __forceinline__ void list_reset(IouList *hdr, unsigned int nseg)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (hdr && i == 0) { hdr->count = 0; hdr->overflow = 0; }
-    if (i < n) geom[i] = Box2D<T>::load(boxes + i * 5);
+    for (int s = 0; s < kListSegs; s++) hdr->count[s * 16] = 0;
+    hdr->overflow = 0;
+    hdr->nseg = nseg;
 }
 
-template <typename T, int K>
-__global__ __launch_bounds__(kTileCols) void k_iou_pre(const BoxGeom<T> *__restrict__ ga, int64_t n,
-                                                       const BoxGeom<T> *__restrict__ gb, int64_t m, T *__restrict__ ious,
+// conservative fp32 AABB of a box for the candidate test (outward rounding; a degenerate box gets an empty AABB and is
+// never a candidate: its IoU is 0 by the policy of geom.hpp).  Candidates are a superset of the exact AABB overlaps --
+// k_iou_clip computes the exact value, which is 0 for the extra ones -- so the result does not depend on the rounding.
+__device__ __forceinline__ float round_down(double x) { float f = (float)x; return (double)f > x ? nextafterf(f, -INFINITY) : f; }
+__device__ __forceinline__ float round_up(double x) { float f = (float)x; return (double)f < x ? nextafterf(f, INFINITY) : f; }
+__device__ __forceinline__ float round_down(float x) { return x; }
+__device__ __forceinline__ float round_up(float x) { return x; }
+template <typename T> __device__ __forceinline__ float4 cand_aabb(const BoxGeom<T> &g)
+{
+    if (!(g.area > 0)) return make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+    return make_float4(round_down(g.xmin), round_down(g.ymin), round_up(g.xmax), round_up(g.ymax));
+}
+// strict overlap in x and y as ONE number: the smallest of the four gaps must be positive
+__device__ __forceinline__ float aabb_gap(const float4 &a, const float4 &b)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));     // two packed subtractions (v_pk_add_f32) instead of four
+    const f2 d1 = f2{b.z, b.w} - f2{a.x, a.y}, d2 = f2{a.z, a.w} - f2{b.x, b.y};
+    return fminf(fminf(d1.x, d1.y), fminf(d2.x, d2.y));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_geom(const T *__restrict__ boxes, int64_t n, BoxGeom<T> *geom, float4 *aabb,
+                                              IouList *hdr, unsigned int nseg)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (hdr && i == 0) list_reset(hdr, nseg);
+    if (i < n) {
+        const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
+        geom[i] = g;
+        aabb[i] = cand_aabb(g);           // 16 B per box: what k_iou_pre reads (coalesced) instead of the geometry
+    }
+}
+
+// Tile = kTileRows rows x kPreCols columns.  Two independent jobs are interleaved row by row so that the stores of one
+// overlap the ALU work of the other:
+//   candidates  lane = 4 columns (AABBs in registers), rows broadcast from LDS; survivors go to a per-wavefront LDS
+//               batch (fill count is wave-uniform: no workgroup barrier inside the row loop) that is flushed to the
+//               global list with one atomic
+//   zero fill   the rows of a tile row are ONE contiguous slab of the matrix; its 4 KiB chunks are dealt to the
+//               workgroups of the tile row, so every wavefront store is 1 KiB and 1 KiB-aligned whatever m is
+//               (row-by-row stores are misaligned when m * sizeof(T) is not a multiple of the 128-byte line: 2x slower)
+constexpr int kPreK = 4;
+constexpr int kPreCols = kTileCols * kPreK;
+constexpr int kPreBatch = 1024;      // LDS batch entries per wavefront
+
+template <typename T>
+__global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict__ ra, int64_t n,
+                                                       const float4 *__restrict__ cb, int64_t m, T *__restrict__ ious,
                                                        IouList *hdr, unsigned long long *list, unsigned long long cap)
 {
-    constexpr int kGroup = 8;                                   // rows per candidate batch
-    __shared__ T rx0[kTileRows], rx1[kTileRows], ry0[kTileRows], ry1[kTileRows];
-    __shared__ unsigned char rok[kTileRows];
-    __shared__ unsigned int q[kGroup * kTileCols * K];          // (row << 16 | local column) of this batch
-    __shared__ unsigned int qn;
-    __shared__ unsigned long long qbase;
+    constexpr int K = kPreK;
+    typedef float vec16 __attribute__((ext_vector_type(4)));
+    __shared__ float4 rbox[kTileRows];
+    __shared__ unsigned int batch[kTileCols / 64][kPreBatch];   // (row << 16 | local column)
+    __shared__ unsigned int wcnt[kTileCols / 64];
+    __shared__ unsigned long long bbase;
     const int64_t i0 = (int64_t)blockIdx.y * kTileRows;
-    const int64_t jb = (int64_t)blockIdx.x * kTileCols * K;     // first column of the block
+    const int64_t jb = (int64_t)blockIdx.x * kPreCols;          // first column of the block
     const int64_t j0 = jb + (int64_t)threadIdx.x * K;
     const int nrows = (int)((n - i0) < kTileRows ? (n - i0) : kTileRows);
-    if (threadIdx.x < nrows) {
-        const BoxGeom<T> g = ga[i0 + threadIdx.x];
-        rx0[threadIdx.x] = g.xmin; rx1[threadIdx.x] = g.xmax; ry0[threadIdx.x] = g.ymin; ry1[threadIdx.x] = g.ymax;
-        rok[threadIdx.x] = g.area > 0;
-    }
-    T cx0[K], cx1[K], cy0[K], cy1[K];
-    bool cok[K];
-    const bool active = j0 < m;
+    if (threadIdx.x < nrows) rbox[threadIdx.x] = ra[i0 + threadIdx.x];
+    float4 cbox[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        cok[k] = false;
-        if (active) {
-            const BoxGeom<T> g = gb[j0 + k];
-            cx0[k] = g.xmin; cx1[k] = g.xmax; cy0[k] = g.ymin; cy1[k] = g.ymax;
-            cok[k] = g.area > 0;
-        }
-    }
-    if (threadIdx.x == 0) qn = 0;
+    for (int k = 0; k < K; k++)
+        cbox[k] = j0 + k < m ? cb[j0 + k] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    T *out = ious + i0 * m + j0;
-    T zero[K];
+    unsigned int *q = batch[threadIdx.x >> 6];
+    unsigned int wn = 0;                                          // wave-uniform fill of the batch
+    const unsigned int sg = (blockIdx.x + blockIdx.y) & (hdr->nseg - 1);     // nseg is a power of two
+    const unsigned long long segcap = cap / hdr->nseg;
+    unsigned long long *seg = list + sg * segcap, *counter = &hdr->count[sg * 16];
+    auto write_out = [&](unsigned long long base) {
+        for (unsigned int t = lane; t < wn; t += 64) {
+            const unsigned int e = q[t];
+            if (base + t < segcap) seg[base + t] = ((unsigned long long)(i0 + (e >> 16)) << 32) | (unsigned long long)(jb + (e & 0xffffu));
+            else hdr->overflow = 1;
+        }
+        wn = 0;
+    };
+    auto flush = [&]() {                                          // batch full (dense candidates): the wavefront reserves
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(counter, (unsigned long long)wn);
+        write_out(__shfl(base, 0, 64));
+    };
+    // zero fill: the slab [i0, i0 + nrows) x [0, m) as 16-byte vectors (16-byte aligned: i0 * m * sizeof(T) is a multiple
+    // of 256 and the host checks the base pointer), chunk c = vectors [256 c, 256 c + 256)
+    const size_t slab_bytes = (size_t)nrows * (size_t)m * sizeof(T);
+    const size_t nvec = slab_bytes / 16, nchunk = (nvec + kTileCols - 1) / kTileCols;
+    const size_t per_block = (nchunk + gridDim.x - 1) / gridDim.x;
+    const size_t c0 = (size_t)blockIdx.x * per_block, c1 = c0 + per_block < nchunk ? c0 + per_block : nchunk;
+    vec16 *slab = ious ? reinterpret_cast<vec16 *>(ious + i0 * m) : nullptr;
+    const vec16 z = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < kTileRows; r++) {
+        if (r < nrows) {
+            const float4 fa = rbox[r];                        // LDS broadcast
+            float g[K], best = -1.f;
 #pragma unroll
-    for (int k = 0; k < K; k++) zero[k] = 0;
-    for (int r0 = 0; r0 < nrows; r0 += kGroup) {
-        const int r1 = r0 + kGroup < nrows ? r0 + kGroup : nrows;
-        for (int r = r0; r < r1; r++) {
-            const T ax0 = rx0[r], ax1 = rx1[r], ay0 = ry0[r], ay1 = ry1[r];
-            const bool aok = rok[r];
+            for (int k = 0; k < K; k++) { g[k] = aabb_gap(fa, cbox[k]); best = fmaxf(best, g[k]); }
+            if (__ballot(best > 0.f)) {                       // some lane of the wavefront has a candidate in this row
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const bool cand = aok && cok[k] && ax0 < cx1[k] && cx0[k] < ax1 && ay0 < cy1[k] && cy0[k] < ay1;
-                const unsigned long long mask = __ballot(cand);
-                if (mask) {                                   // wave-aggregated append to the LDS batch
-                    unsigned int base = 0;
-                    const int leader = __builtin_ctzll(mask);
-                    if (lane == leader) base = atomicAdd(&qn, (unsigned int)__popcll(mask));
-                    base = __shfl(base, leader, 64);
-                    if (cand) q[base + __popcll(mask & ((1ull << lane) - 1))] = ((unsigned)r << 16) | (unsigned)(threadIdx.x * K + k);
+                for (int k = 0; k < K; k++) {
+                    const bool cand = g[k] > 0.f;
+                    const unsigned long long mask = __ballot(cand);
+                    if (mask) {
+                        const unsigned int cnt = (unsigned int)__popcll(mask);
+                        if (wn + cnt > (unsigned int)kPreBatch) flush();
+                        if (cand)
+                            q[wn + __popcll(mask & ((1ull << lane) - 1))] = ((unsigned)r << 16) | (unsigned)(threadIdx.x * K + k);
+                        wn += cnt;
+                    }
                 }
             }
-            if (active && ious) store_row<T, K>(out, zero);
-            out += m;
         }
-        __syncthreads();
-        const unsigned int total = qn;
-        if (total) {                                          // block-uniform
-            if (threadIdx.x == 0) qbase = atomicAdd(&hdr->count, (unsigned long long)total);
-            __syncthreads();
-            const unsigned long long gbase = qbase;
-            for (unsigned int t = threadIdx.x; t < total; t += kTileCols) {
-                const unsigned int e = q[t];
-                const unsigned long long idx = gbase + t;
-                if (idx < cap) list[idx] = ((unsigned long long)(i0 + (e >> 16)) << 32) | (unsigned long long)(jb + (e & 0xffffu));
-                else hdr->overflow = 1;
+        if (slab)
+            for (size_t c = c0 + r; c < c1; c += kTileRows) {
+                const size_t v = c * kTileCols + threadIdx.x;
+                if (v < nvec) __builtin_nontemporal_store(z, slab + v);
             }
-            __syncthreads();
-            if (threadIdx.x == 0) qn = 0;
-            __syncthreads();
-        }
     }
+    if (slab && blockIdx.x == 0 && threadIdx.x == 0)             // slab size not a multiple of 16 bytes (last tile row)
+        for (size_t e = nvec * (16 / sizeof(T)); e < (size_t)nrows * (size_t)m; e++) ious[i0 * m + e] = 0;
+    // what is left in the four batches is reserved with ONE atomic per workgroup: atomics on the list counter are
+    // serialised at ~7 ns each, and every workgroup of a short launch gets here at about the same time
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) wcnt[wave] = wn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        bbase = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = bbase;
+    for (int w = 0; w < wave; w++) base += wcnt[w];
+    write_out(base);
 }
 
 template <typename T>
@@ -196,13 +257,16 @@ __global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__
                                                   const unsigned long long *__restrict__ list, unsigned long long cap)
 {
     if (hdr->overflow) return;
-    const unsigned long long total = hdr->count < cap ? hdr->count : cap;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / hdr->nseg;
+    for (unsigned int sg = 0; sg < hdr->nseg; sg++) {
+    const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
+    const unsigned long long *seg = list + sg * segcap;
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const unsigned long long e = list[t];
+        const unsigned long long e = seg[t];
         const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
         const T v = iou_rbox(ga[i], gb[j]);
         if (v != 0) ious[i * m + j] = v;
+    }
     }
 }
 
@@ -268,10 +332,12 @@ __global__ __launch_bounds__(256) void k_iou_grad(const BoxGeom<T> *__restrict__
                                                   const unsigned long long *__restrict__ list, unsigned long long cap,
                                                   T *g1, T *g2)
 {
-    const unsigned long long total = hdr->count < cap ? hdr->count : cap;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / hdr->nseg;
+    for (unsigned int sg = 0; sg < hdr->nseg; sg++) {
+    const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
+    const unsigned long long *seg = list + sg * segcap;
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const unsigned long long e = list[t];
+        const unsigned long long e = seg[t];
         const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
         const T g = grad[i * m + j];
         if (g == 0) continue;
@@ -285,17 +351,19 @@ __global__ __launch_bounds__(256) void k_iou_grad(const BoxGeom<T> *__restrict__
             if (db[k] != 0) atomicAdd(&g2[j * 5 + k], g * db[k]);
         }
     }
+    }
 }
 
 // ---------------------------------------------------------------- "3D IoU", two-phase (same scheme as rbox)
 __global__ __launch_bounds__(256) void k_geom3d(const float *__restrict__ boxes, int64_t n, BoxGeom<float> *geom,
-                                                float2 *zr, IouList *hdr)
+                                                float4 *aabb, float2 *zr, IouList *hdr, unsigned int nseg)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (hdr && i == 0) { hdr->count = 0; hdr->overflow = 0; }
+    if (hdr && i == 0) list_reset(hdr, nseg);
     if (i < n) {
         const Box3DGeom g = load3d(boxes + i * 7);
         geom[i] = g.g;
+        aabb[i] = cand_aabb(g.g);
         zr[i] = make_float2(g.zmin, g.zmax);
     }
 }
@@ -307,10 +375,12 @@ __global__ __launch_bounds__(256) void k_iou3d_clip(const BoxGeom<float> *__rest
                                                     const unsigned long long *__restrict__ list, unsigned long long cap)
 {
     if (hdr->overflow) return;
-    const unsigned long long total = hdr->count < cap ? hdr->count : cap;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / hdr->nseg;
+    for (unsigned int sg = 0; sg < hdr->nseg; sg++) {
+    const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
+    const unsigned long long *seg = list + sg * segcap;
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const unsigned long long e = list[t];
+        const unsigned long long e = seg[t];
         const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
         const float iou2d = ROTATED ? iou_rbox(ga[i], gb[j]) : iou_aabb(ga[i], gb[j]);
         if (iou2d != 0.f) {
@@ -320,6 +390,7 @@ __global__ __launch_bounds__(256) void k_iou3d_clip(const BoxGeom<float> *__rest
             const float v = iou2d * (fmaxf(imax - imin, 0.f) / fmaxf(umax - umin, (float)1e-6));
             if (v != 0.f) out[i * m + j] = v;
         }
+    }
     }
 }
 
@@ -342,7 +413,8 @@ constexpr int kIncCap = 24;          // incoming-hit list capacity per box
 enum { kUndecided = 0, kKept = 1, kSuppressed = 2 };
 
 struct NmsFlags { unsigned int need_sweep, undecided; };
-struct NmsCand { unsigned long long count; };       // entries appended to the candidate list (may exceed its capacity)
+constexpr int kNmsListSegs = 1;     // see list_segments(): segmenting the list did not pay
+struct NmsCand { unsigned long long count[kNmsListSegs * 16]; };   // entries appended (may exceed the capacity)
 
 // candidate-list capacity: ~8.5 upper-triangle AABB candidates per box at detection densities;
 // 64 per box leaves head room, small dense sets get the full triangle.  D3D_NMS_CAND_CAP overrides (tests).
@@ -354,10 +426,6 @@ static unsigned long long nms_cand_capacity(int64_t n)
 }
 static unsigned int nms_force_dense() { const char *e = getenv("D3D_NMS_FORCE_DENSE"); return e && atoi(e) ? 1u : 0u; }
 
-__device__ __forceinline__ float round_down(double x) { float f = (float)x; return (double)f > x ? nextafterf(f, -INFINITY) : f; }
-__device__ __forceinline__ float round_up(double x) { float f = (float)x; return (double)f < x ? nextafterf(f, INFINITY) : f; }
-__device__ __forceinline__ float round_down(float x) { return x; }
-__device__ __forceinline__ float round_up(float x) { return x; }
 
 template <typename T>
 __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__ scores,
@@ -368,7 +436,8 @@ __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // sorted position
     bool pre = false;
-    if (p == 0) { flags->need_sweep = force_dense; flags->undecided = 0; cand_hdr->count = 0; }
+    if (p == 0) { flags->need_sweep = force_dense; flags->undecided = 0; }
+    if (p < kNmsListSegs) cand_hdr->count[p * 16] = 0;
     if (p < n) {
         const int64_t i = order[p];
         const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
@@ -427,25 +496,31 @@ __global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx
     constexpr int U = kCandUnroll;
     __shared__ unsigned long long batch[4][kCandLds];
     __shared__ float4 window[4][128];
+    __shared__ unsigned int wcnt[4];
+    __shared__ unsigned long long bbase;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t wid = blockIdx.x * 4 + wave;
     const uint32_t rb = wid / nsplit;
     const uint32_t split = wid - rb * nsplit;
-    if (rb >= nb) return;
     const uint32_t i = rb * 64 + lane;            // n < 2^28 (nb <= 65535)
-    const float4 fa = fbx[i];
+    const float4 fa = rb < nb ? fbx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned long long *q = batch[wave];
     float4 *win = window[wave];
     unsigned int wn = 0;                                                  // wave-uniform fill of the batch
     bool overflow = false;
-    auto flush = [&]() {
-        unsigned long long gb = 0;
-        if (lane == 0) gb = atomicAdd(&hdr->count, (unsigned long long)wn);
-        gb = __shfl(gb, 0, 64);
+    const unsigned long long segcap = cap / kNmsListSegs;                 // list segment of this workgroup
+    const unsigned int sgi = blockIdx.x % kNmsListSegs;
+    unsigned long long *seg = list + sgi * segcap, *counter = &hdr->count[sgi * 16];
+    auto write_out = [&](unsigned long long gb) {
         for (unsigned int t = lane; t < wn; t += 64)
-            if (gb + t < cap) list[gb + t] = q[t];
-        if (gb + wn > cap) { flags->need_sweep = 1; overflow = true; }    // the dense path takes over: stop early
+            if (gb + t < segcap) seg[gb + t] = q[t];
+        if (gb + wn > segcap) { flags->need_sweep = 1; overflow = true; } // the dense path takes over: stop early
         wn = 0;
+    };
+    auto flush = [&]() {                                                  // batch full: the wavefront reserves
+        unsigned long long gb = 0;
+        if (lane == 0) gb = atomicAdd(counter, (unsigned long long)wn);
+        write_out(__shfl(gb, 0, 64));
     };
     // lane i walks j = i + 1, i + 2, ... in chunks of 64 (the wavefronts sharing this block of boxes take every
     // nsplit-th chunk): the 128 AABBs a chunk can touch are staged in LDS with two coalesced loads and each lane reads
@@ -478,7 +553,17 @@ __global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx
         }
         if (__ballot(win[lane + 64].x < fa.z) == 0 || overflow) break;
     }
-    if (wn) flush();
+    // the rest is reserved with ONE atomic per workgroup (atomics on the list counter are serialised, ~7 ns each)
+    if (lane == 0) wcnt[wave] = wn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        bbase = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long gb = bbase;
+    for (uint32_t w = 0; w < wave; w++) gb += wcnt[w];
+    if (wn) write_out(gb);
 }
 
 template <typename T, bool ROTATED>
@@ -488,11 +573,12 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__
                                                   const NmsCand *hdr, T thr, uint32_t *inc_cnt, uint32_t *inc,
                                                   NmsFlags *flags)
 {
-    unsigned long long total = hdr->count;
-    if (total > cap) total = cap;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / kNmsListSegs;
+    for (int sg = 0; sg < kNmsListSegs; sg++) {
+    const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
+    const unsigned long long *seg = list + sg * segcap;
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const unsigned long long e = list[t];
+        const unsigned long long e = seg[t];
         const uint32_t r1 = rankx[e >> 32], r2 = rankx[e & 0xffffffffull];      // x-order index -> score rank
         const int64_t p = r1 < r2 ? r1 : r2, q = r1 < r2 ? r2 : r1;
         const BoxGeom<T> a = geom[p], b = geom[q];
@@ -502,6 +588,7 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__
             if (s < (uint32_t)kIncCap) inc[q * kIncCap + s] = (uint32_t)p;
             else flags->need_sweep = 1;
         }
+    }
     }
 }
 
@@ -768,6 +855,11 @@ __global__ __launch_bounds__(256) void k_crop2dr(const T *__restrict__ points, i
 }  // namespace
 
 // ====================================================================== C ABI
+// Segmented lists were measured on MI355X (8 segments): with one reservation per workgroup the counter is no longer
+// the bottleneck of the producer, while the consumers pay one dependent counter read per segment (k_iou_clip 12 -> 57 us),
+// so every list is kept in one piece.
+static unsigned int list_segments(unsigned long long) { return 1u; }
+
 static unsigned long long iou_list_capacity(int64_t n, int64_t m)
 {
     const unsigned long long pairs = (unsigned long long)n * (unsigned long long)m;
@@ -782,7 +874,8 @@ extern "C" size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype)
     if (n < 1) n = 1;
     if (m < 1) m = 1;
     const size_t g = dtype == D3D_F64 ? sizeof(BoxGeom<double>) : sizeof(BoxGeom<float>);
-    return d3d_align_up(g * n) + d3d_align_up(g * m) + 256 + d3d_align_up(8 * iou_list_capacity(n, m)) + 256;
+    return d3d_align_up(g * n) + d3d_align_up(g * m) + d3d_align_up(16 * n) + d3d_align_up(16 * m) + d3d_align_up(sizeof(IouList)) + d3d_align_up(8 * iou_list_capacity(n, m)) +
+           256;
 }
 
 template <typename T>
@@ -792,22 +885,23 @@ static int iou2d_rbox_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, 
     WsCarver w(ws, ws_bytes);
     BoxGeom<T> *ga = w.take<BoxGeom<T>>(n);
     BoxGeom<T> *gb = w.take<BoxGeom<T>>(m);
+    float4 *ra = w.take<float4>(n);
+    float4 *cb = w.take<float4>(m);
     IouList *hdr = w.take<IouList>(1);
     const unsigned long long cap = iou_list_capacity(n, m);
     unsigned long long *list = w.take<unsigned long long>(cap);
     if (!w.ok()) return D3D_ERR_WORKSPACE;
-    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, hdr);
-    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, (IouList *)nullptr);
-    constexpr int KV = 16 / (int)sizeof(T);      // one 16-byte store per lane and row (32 B per lane measured 2.2x
-                                                 // slower: each store instruction then writes every other 16-B chunk)
-    const bool vec = ((reinterpret_cast<uintptr_t>(ious) & 15) == 0) && (m % KV == 0);
+    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, ra, hdr,
+               list_segments(cap));
+    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u);
     const unsigned gy = (unsigned)d3d_divup(n, kTileRows);
-    if (vec)
-        D3D_LAUNCH("k_iou_pre", (k_iou_pre<T, KV>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols * KV), gy), dim3(kTileCols), 0,
-                   st, ga, n, gb, m, ious, hdr, list, cap);
-    else
-        D3D_LAUNCH("k_iou_pre", (k_iou_pre<T, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols), 0, st,
-                   ga, n, gb, m, ious, hdr, list, cap);
+    T *fill = ious;
+    if (reinterpret_cast<uintptr_t>(ious) & 15) {             // unaligned output: plain memset, candidates only
+        D3D_HIP_CHECK(hipMemsetAsync(ious, 0, (size_t)n * (size_t)m * sizeof(T), st));
+        fill = nullptr;
+    }
+    D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), gy), dim3(kTileCols), 0, st,
+               (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap);
     D3D_LAUNCH("k_iou_clip", k_iou_clip<T>, dim3(256 * 16), dim3(256), 0, st, ga, gb, m, ious, hdr, list, cap);
     // fallback (blocks exit at once unless the list overflowed)
     D3D_LAUNCH("k_iou2d", (k_iou2d<T, true, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols), 0, st, b1,
@@ -857,7 +951,7 @@ extern "C" size_t d3d_iou3d_workspace_bytes(int64_t n, int64_t m)
     if (n < 1) n = 1;
     if (m < 1) m = 1;
     return d3d_align_up(sizeof(BoxGeom<float>) * n) + d3d_align_up(sizeof(BoxGeom<float>) * m) + d3d_align_up(8 * n) +
-           d3d_align_up(8 * m) + 256 + d3d_align_up(8 * iou_list_capacity(n, m)) + 256;
+           d3d_align_up(8 * m) + d3d_align_up(16 * n) + d3d_align_up(16 * m) + d3d_align_up(sizeof(IouList)) + d3d_align_up(8 * iou_list_capacity(n, m)) + 256;
 }
 
 extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *boxes2, int64_t m, int32_t rotated,
@@ -880,18 +974,23 @@ extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *bo
         BoxGeom<float> *gb = w.take<BoxGeom<float>>(m);
         float2 *za = w.take<float2>(n);
         float2 *zb = w.take<float2>(m);
+        float4 *ra = w.take<float4>(n);
+        float4 *cb = w.take<float4>(m);
         IouList *hdr = w.take<IouList>(1);
         const unsigned long long cap = iou_list_capacity(n, m);
         unsigned long long *list = w.take<unsigned long long>(cap);
         if (!w.ok()) return D3D_ERR_WORKSPACE;
-        D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, boxes1, n, ga, za, hdr);
-        D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, boxes2, m, gb, zb, (IouList *)nullptr);
-        if (vec)
-            D3D_LAUNCH("k_iou_pre", (k_iou_pre<float, 4>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols * 4), gy),
-                       dim3(kTileCols), 0, st, ga, n, gb, m, out, hdr, list, cap);
-        else
-            D3D_LAUNCH("k_iou_pre", (k_iou_pre<float, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols),
-                       0, st, ga, n, gb, m, out, hdr, list, cap);
+        D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, boxes1, n, ga, ra, za, hdr,
+                   list_segments(cap));
+        D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, boxes2, m, gb, cb, zb, (IouList *)nullptr,
+                   1u);
+        float *fill = out;
+        if (reinterpret_cast<uintptr_t>(out) & 15) {
+            D3D_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n * (size_t)m * sizeof(float), st));
+            fill = nullptr;
+        }
+        D3D_LAUNCH("k_iou_pre", k_iou_pre<float>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), gy), dim3(kTileCols), 0, st,
+                   (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap);
         if (rotated) {
             D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<true>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, m, out, hdr, list, cap);
             D3D_IOU3D(true, 1, &hdr->overflow);
@@ -912,7 +1011,8 @@ extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
     if (n < 1) n = 1;
     const size_t nb = (size_t)d3d_divup(n, 64);
     return d3d_align_up(nb * 64 * sizeof(BoxGeom<double>)) + d3d_align_up(nb * 64 * 16) + d3d_align_up(nb * 64) +
-           d3d_align_up(nb * 64 * 4) + d3d_align_up(nb * 64 * 4 * kIncCap) + 256 + d3d_align_up(nb * 8) + 256 +
+           d3d_align_up(nb * 64 * 4) + d3d_align_up(nb * 64 * 4 * kIncCap) + 256 + d3d_align_up(nb * 8) +
+           d3d_align_up(sizeof(NmsCand)) +
            d3d_align_up((size_t)nms_cand_capacity(n) * 8) + 2 * d3d_align_up(nb * 64 * 4) + d3d_align_up((nb * 64 + kCandPad) * 16) +
            d3d_align_up(nb * 64 * 4) + d3d_align_up(d3d_internal_argsort_i32_bytes(n)) + d3d_align_up(nb * 64 * nb * 8) + 256;
 }
@@ -962,6 +1062,8 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     WsCarver w(ws, ws_bytes);
     BoxGeom<T> *ga = w.take<BoxGeom<T>>(n);
     BoxGeom<T> *gb = w.take<BoxGeom<T>>(m);
+    float4 *ra = w.take<float4>(n);
+    float4 *cb = w.take<float4>(m);
     IouList *hdr = w.take<IouList>(1);
     // every AABB-overlapping pair must be listed (no fallback here): capacity = all pairs, processed in row chunks
     const unsigned long long cap_all = iou_list_capacity(n, m);
@@ -969,7 +1071,7 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
     D3D_HIP_CHECK(hipMemsetAsync(g1, 0, sizeof(T) * 5 * (size_t)n, st));
     D3D_HIP_CHECK(hipMemsetAsync(g2, 0, sizeof(T) * 5 * (size_t)m, st));
-    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, (IouList *)nullptr);
+    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u);
     // rows in chunks such that chunk_rows * m <= capacity: the list can then never overflow
     int64_t rows_per = (int64_t)(cap_all / (unsigned long long)m);
     if (rows_per < 1) return D3D_ERR_BAD_ARG;
@@ -979,9 +1081,9 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     for (int64_t r0 = 0; r0 < n; r0 += rows_per) {
         const int64_t nr = (n - r0) < rows_per ? (n - r0) : rows_per;
         if ((unsigned long long)nr * (unsigned long long)m > cap_all) return D3D_ERR_WORKSPACE;
-        D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(nr, 256)), dim3(256), 0, st, b1 + r0 * 5, nr, ga, hdr);
-        D3D_LAUNCH("k_iou_pre", (k_iou_pre<T, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), (unsigned)d3d_divup(nr, kTileRows)),
-                   dim3(kTileCols), 0, st, ga, nr, gb, m, (T *)nullptr, hdr, list, cap_all);
+        D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(nr, 256)), dim3(256), 0, st, b1 + r0 * 5, nr, ga, ra, hdr, 1u);
+        D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), (unsigned)d3d_divup(nr, kTileRows)),
+                   dim3(kTileCols), 0, st, (const float4 *)ra, nr, (const float4 *)cb, m, (T *)nullptr, hdr, list, cap_all);
         if (rot)
             D3D_LAUNCH("k_iou_grad", (k_iou_grad<T, true>), dim3(256 * 8), dim3(256), 0, st, ga, gb, b1 + r0 * 5, b2, grad + r0 * m, m,
                        hdr, list, cap_all, g1 + r0 * 5, g2);
