@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+REQ_PEAK_GS = 26.3      # scattered 8-byte atomics/requests per ns, measured: tools/atomic_bench.hip
 
 
 def sync():
@@ -240,6 +241,20 @@ def main():
                                frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(name, "config2"),
                                avg_us=round(dom[1]["avg_us"], 2), algorithmic_bytes=b_alg,
                                timing="HIP events on the launch stream, separate pass of the same %d steps" % args.steps)
+        if name == "k_insert":
+            # the kernel's real limiter: scattered 8-byte requests (>= one coherent probe load + one atomic per point);
+            # ceiling measured with tools/atomic_bench.hip on MI355X (profiles/r01_d_atomic_bench.txt)
+            req = 2 * n
+            out["roofline"]["requests"] = dict(per_launch=req, achieved_G_per_s=round(req / dom[1]["avg_us"] / 1e3, 2),
+                                               measured_peak_G_per_s=REQ_PEAK_GS,
+                                               frac=round(req / dom[1]["avg_us"] / 1e3 / REQ_PEAK_GS, 3))
+        if "k_fill_c4" in prof:                     # the HBM-bound kernel of the op, priced the same way
+            f_us = prof["k_fill_c4"]["avg_us"]
+            f_ach = algo["k_fill_c4"] / (f_us * 1e-6) / 1e9
+            out["roofline_streaming"] = dict(bound="hbm", kernel="k_fill_c4", achieved=round(f_ach, 1), peak=HBM_PEAK_GBS,
+                                             unit="GB/s", frac=round(f_ach / HBM_PEAK_GBS, 4),
+                                             traffic=load_traffic("k_fill_c4", "config2"), avg_us=round(f_us, 2),
+                                             algorithmic_bytes=algo["k_fill_c4"])
         out["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         out["op_algorithmic_GBps"] = round((n * 16 + V * (P * 16 + P + 24 + 4 + 16)) * args.steps / dt / 1e9, 1)
         out["voxels"] = V
