@@ -94,11 +94,13 @@ template <class F>
 __global__ __launch_bounds__(kScanBlock) void k_scan_count(F f, int64_t n, unsigned long long *bsum)
 {
     __shared__ unsigned long long smem[kScanBlock / kWave];
-    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    // item layout of a tile: wavefront w owns [w * 64 * kScanItems, ...), row k of it = 64 consecutive items, one per
+    // lane -> every access of f is coalesced (consecutive items per THREAD would stride the lanes by kScanItems)
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)(threadIdx.x >> 6) * (kWave * kScanItems) + (threadIdx.x & (kWave - 1));
     unsigned long long s = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
-        int64_t i = base + k;
+        int64_t i = base + (int64_t)k * kWave;
         if (i < n) s += f.value(i);
     }
     // block reduce via wave shuffles
@@ -139,21 +141,27 @@ template <class F>
 __global__ __launch_bounds__(kScanBlock) void k_scan_apply(F f, int64_t n, const unsigned long long *bsum_excl)
 {
     __shared__ unsigned long long smem[kScanBlock / kWave];
-    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-    unsigned long long v[kScanItems], s = 0;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)w * (kWave * kScanItems) + lane;   // see k_scan_count
+    unsigned long long v[kScanItems], ex[kScanItems], carry = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
-        int64_t i = base + k;
+        int64_t i = base + (int64_t)k * kWave;
         v[k] = i < n ? f.value2(i) : 0ull;
-        s += v[k];
+        const unsigned long long incl = wave_incl_scan_u64(v[k]);
+        ex[k] = carry + incl - v[k];
+        carry += __shfl(incl, kWave - 1, kWave);        // row total
     }
-    unsigned long long tot;
-    unsigned long long ex = block_excl_scan_u64<kScanBlock>(s, &tot, smem) + bsum_excl[blockIdx.x];
+    if (lane == 0) smem[w] = carry;                      // wavefront total
+    __syncthreads();
+    unsigned long long woff = bsum_excl[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanBlock / kWave; k++)
+        if (k < w) woff += smem[k];
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
-        int64_t i = base + k;
-        if (i < n) f.apply(i, v[k], ex);
-        ex += v[k];
+        int64_t i = base + (int64_t)k * kWave;
+        if (i < n) f.apply(i, v[k], woff + ex[k]);
     }
 }
 

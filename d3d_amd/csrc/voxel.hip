@@ -737,7 +737,8 @@ struct FilterVoxels {
 __global__ __launch_bounds__(256) void k_filter_scatter(const int64_t *__restrict__ mapping, int64_t n, int64_t nvox,
                                                         const int32_t *__restrict__ npoints,
                                                         const int32_t *__restrict__ newid, const uint32_t *__restrict__ coff,
-                                                        uint32_t max_points, uint32_t *fcur, uint32_t *cells, int64_t ncells)
+                                                        uint32_t max_points, uint32_t *fcur, uint32_t *cells, uint32_t *cellvox,
+                                                        int64_t ncells)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -747,7 +748,30 @@ __global__ __launch_bounds__(256) void k_filter_scatter(const int64_t *__restric
     if (cnt <= max_points) return;
     const uint32_t a = atomicAdd(&fcur[v], 1u);
     const int64_t pos = (int64_t)coff[v] + a;
-    if (a < cnt && pos < ncells) cells[pos] = (uint32_t)i;
+    if (a < cnt && pos < ncells) { cells[pos] = (uint32_t)i; cellvox[pos] = (uint32_t)v; }
+}
+
+// one lane per list cell (dense wavefronts; the lanes of a wavefront mostly share a segment, so its reads are
+// broadcasts): trimmed[point] = at least max_points indices of the voxel's list are smaller.  Doing this per POINT
+// inside the compaction scan left 1-6 lanes of every wavefront walking 400-entry segments (80 us at config 2).
+__global__ __launch_bounds__(256) void k_filter_rank(const int64_t *__restrict__ counts, const uint32_t *__restrict__ cells,
+                                                     const uint32_t *__restrict__ cellvox, int64_t ncells,
+                                                     const int32_t *__restrict__ npoints, const uint32_t *__restrict__ coff,
+                                                     uint32_t max_points, unsigned char *trimmed)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncells || t >= counts[D3D_COUNT_AUX]) return;
+    const uint32_t v = cellvox[t];
+    if (v == 0xffffffffu) return;                      // cell of a voxel dropped by max_voxels, or never filled
+    const uint32_t cnt = (uint32_t)npoints[v], me = cells[t];
+    const int64_t base = coff[v];
+    if (base + cnt > ncells) return;                   // inconsistent voxel_npoints: cannot trim
+    const uint32_t *seg = cells + base;
+    uint32_t rank = 0, k = 0;
+    for (; k + 4 <= cnt && rank < max_points; k += 4)
+        rank += (seg[k] < me) + (seg[k + 1] < me) + (seg[k + 2] < me) + (seg[k + 3] < me);
+    for (; k < cnt && rank < max_points; k++) rank += seg[k] < me;
+    if (rank >= max_points) trimmed[me] = 1;
 }
 
 struct FilterPoints {
@@ -758,9 +782,7 @@ struct FilterPoints {
     int64_t nvox;
     const int32_t *npoints;
     const int32_t *newid;
-    const uint32_t *coff;
-    const uint32_t *cells;
-    int64_t ncells;
+    const unsigned char *trimmed;   // [n] set by k_filter_rank for the points beyond max_points of their voxel
     uint32_t max_points;      // 0xffffffff for NONE
     int32_t *keepid;          // [n] new voxel id of a kept point, -1 otherwise (written by the count pass)
     float *out_feats;
@@ -773,18 +795,7 @@ struct FilterPoints {
         const int32_t id = newid[v];
         if (id < 0) return -1;
         const uint32_t cnt = (uint32_t)npoints[v];
-        if (cnt > max_points) {
-            if (max_points == 0) return -1;
-            const int64_t base = coff[v];
-            if (base + cnt > ncells) return id;          // inconsistent voxel_npoints: cannot trim
-            const uint32_t *seg = cells + base;
-            const uint32_t me = (uint32_t)i;
-            uint32_t rank = 0, k = 0;
-            for (; k + 4 <= cnt && rank < max_points; k += 4)
-                rank += (seg[k] < me) + (seg[k + 1] < me) + (seg[k + 2] < me) + (seg[k + 3] < me);
-            for (; k < cnt && rank < max_points; k++) rank += seg[k] < me;
-            if (rank >= max_points) return -1;
-        }
+        if (cnt > max_points && (max_points == 0 || trimmed[i])) return -1;
         return id;
     }
     __device__ __forceinline__ unsigned long long value(int64_t i) const
@@ -1147,6 +1158,13 @@ extern "C" int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, 
     // index lists of the overflow voxels live in w.list (their counts sum to <= n); cursors start at zero
     D3D_LAUNCH("k_fill_u32", k_fill_u32, dim3(grid_for(trim_pts ? nvox : 0, 256)), dim3(256), 0, st, w.fcur,
                trim_pts ? nvox : (int64_t)0, 0u, counts);
+    const bool rank_pts = trim_pts && n > 0 && nvox > 0 && max_points > 0;
+    uint32_t *cellvox = w.parr;                                 // [n] voxel of each list cell
+    unsigned char *trimmed = w.flags;                           // [n]
+    if (rank_pts) {
+        D3D_HIP_CHECK(hipMemsetAsync(cellvox, 0xff, (size_t)n * 4, st));
+        D3D_HIP_CHECK(hipMemsetAsync(trimmed, 0, (size_t)n, st));
+    }
 
     const int32_t *order = nullptr;
     if (max_voxels_filter == D3D_MAXVOX_DESCENDING && nvox > 0) {
@@ -1172,13 +1190,16 @@ extern "C" int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, 
     fv.max_points = P;
     fv.max_voxels = max_voxels_filter == D3D_MAXVOX_NONE ? ~0ull : (unsigned long long)max_voxels;
     fv.newid = w.newid; fv.coff = w.coff; fv.out_coords = out_coords; fv.out_npoints = out_npoints;
-    int rc = d3d_run_scan(fv, nvox, w.bsum, counts, D3D_COUNT_VOXELS, -1, fv.max_voxels, st);
+    int rc = d3d_run_scan(fv, nvox, w.bsum, counts, D3D_COUNT_VOXELS, D3D_COUNT_AUX, fv.max_voxels, st);   // AUX = list cells
     if (rc) return rc;
 
-    if (trim_pts && n > 0 && nvox > 0 && max_points > 0)
+    if (rank_pts) {
         D3D_LAUNCH("k_filter_scatter", k_filter_scatter, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, points_mapping,
-                   n, nvox, voxel_npoints, w.newid, w.coff, P, w.fcur, w.list, n);
-    FilterPoints fp{feats, c, points_mapping, nvox, voxel_npoints, w.newid, w.coff, w.list, n, P,
+                   n, nvox, voxel_npoints, w.newid, w.coff, P, w.fcur, w.list, cellvox, n);
+        D3D_LAUNCH("k_filter_rank", k_filter_rank, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, (const int64_t *)counts,
+                   (const uint32_t *)w.list, (const uint32_t *)cellvox, n, voxel_npoints, (const uint32_t *)w.coff, P, trimmed);
+    }
+    FilterPoints fp{feats, c, points_mapping, nvox, voxel_npoints, w.newid, trimmed, P,
                     reinterpret_cast<int32_t *>(w.pslot), out_feats, out_mask, out_mapping};
     rc = d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st);
     return rc;
