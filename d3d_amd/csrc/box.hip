@@ -187,6 +187,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
     const unsigned long long segcap = cap / hdr->nseg;
     unsigned long long *seg = list + sg * segcap, *counter = &hdr->count[sg * 16];
     auto write_out = [&](unsigned long long base) {
+        __builtin_amdgcn_wave_barrier();          // LDS ops of one wavefront complete in order: no s_barrier needed
         for (unsigned int t = lane; t < wn; t += 64) {
             const unsigned int e = q[t];
             if (base + t < segcap) seg[base + t] = ((unsigned long long)(i0 + (e >> 16)) << 32) | (unsigned long long)(jb + (e & 0xffffu));
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx
     const unsigned int sgi = blockIdx.x % kNmsListSegs;
     unsigned long long *seg = list + sgi * segcap, *counter = &hdr->count[sgi * 16];
     auto write_out = [&](unsigned long long gb) {
+        __builtin_amdgcn_wave_barrier();
         for (unsigned int t = lane; t < wn; t += 64)
             if (gb + t < segcap) seg[gb + t] = q[t];
         if (gb + wn > segcap) { flags->need_sweep = 1; overflow = true; } // the dense path takes over: stop early
@@ -530,6 +532,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx
         const uint32_t base = (rb + c) * 64;                              // chunk: j = base + lane + d, d = 1..64
         win[lane] = fbx[base + lane];
         win[64 + lane] = fbx[base + 64 + lane];                           // < nb * 64 + 64: boxes or sentinels
+        __builtin_amdgcn_wave_barrier();          // LDS ops of one wavefront complete in order: no s_barrier needed
 #pragma unroll 1
         for (int d0 = 1; d0 <= 64; d0 += U) {
             float4 fb[U];

@@ -694,6 +694,7 @@ struct FilterVoxels {
     const int64_t *coords;
     const int32_t *npoints;
     const int32_t *order;     // null = id order; else voxel id per rank (descending count)
+    const int64_t *nvox_device;   // null, or the number of valid rows (the scan then runs over an upper bound)
     long long lo[3], hi[3];
     int32_t min_points;
     uint32_t max_points;      // P for TRIM, 0xffffffff for NONE
@@ -705,6 +706,7 @@ struct FilterVoxels {
 
     __device__ __forceinline__ unsigned long long value(int64_t k) const
     {
+        if (nvox_device && k >= *nvox_device) return 0;
         const int64_t v = order ? order[k] : k;
         const int32_t cnt = npoints[v];
         bool ok = cnt >= min_points;
@@ -1133,16 +1135,17 @@ extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int
                                              hipStream_t st);
 extern "C" size_t d3d_internal_argsort_i32_bytes(int64_t n);
 
-extern "C" int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, const int64_t *points_mapping,
-                                      const int64_t *coords, const int32_t *voxel_npoints, int64_t nvox,
-                                      const int64_t *coords_bound, int32_t min_points, int32_t max_points,
-                                      int32_t max_voxels, int32_t max_points_filter, int32_t max_voxels_filter,
-                                      float *out_feats, int64_t *out_mask, int64_t *out_mapping, int32_t *out_npoints,
-                                      int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
-                                      void *stream)
+// nvox_device != NULL: `nvox` is only an upper bound (buffer rows), the number of voxels is read on the device
+static int filter_impl(const float *feats, int64_t n, int32_t c, const int64_t *points_mapping, const int64_t *coords,
+                       const int32_t *voxel_npoints, int64_t nvox, const int64_t *nvox_device, const int64_t *coords_bound,
+                       int32_t min_points, int32_t max_points, int32_t max_voxels, int32_t max_points_filter,
+                       int32_t max_voxels_filter, float *out_feats, int64_t *out_mask, int64_t *out_mapping,
+                       int32_t *out_npoints, int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
+                       void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || nvox < 0 || c < 1 || !coords_bound || !counts) return D3D_ERR_BAD_ARG;
+    if (nvox_device && max_voxels_filter == D3D_MAXVOX_DESCENDING) return D3D_ERR_UNSUPPORTED;   // the sort needs the size
     if (max_points_filter == D3D_MAXPTS_FARTHEST_SAMPLING) return D3D_ERR_UNSUPPORTED;   // voxelize.cpp:469-471
     if (max_points_filter < 0 || max_points_filter > 2 || max_voxels_filter < 0 || max_voxels_filter > 2)
         return D3D_ERR_BAD_ARG;
@@ -1184,7 +1187,7 @@ extern "C" int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, 
     }
 
     FilterVoxels fv;
-    fv.coords = coords; fv.npoints = voxel_npoints; fv.order = order;
+    fv.coords = coords; fv.npoints = voxel_npoints; fv.order = order; fv.nvox_device = nvox_device;
     for (int d = 0; d < 3; d++) { fv.lo[d] = coords_bound[2 * d]; fv.hi[d] = coords_bound[2 * d + 1]; }
     fv.min_points = min_points;
     fv.max_points = P;
@@ -1203,4 +1206,32 @@ extern "C" int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, 
                     reinterpret_cast<int32_t *>(w.pslot), out_feats, out_mask, out_mapping};
     rc = d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st);
     return rc;
+}
+
+extern "C" int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, const int64_t *points_mapping,
+                                      const int64_t *coords, const int32_t *voxel_npoints, int64_t nvox,
+                                      const int64_t *coords_bound, int32_t min_points, int32_t max_points,
+                                      int32_t max_voxels, int32_t max_points_filter, int32_t max_voxels_filter,
+                                      float *out_feats, int64_t *out_mask, int64_t *out_mapping, int32_t *out_npoints,
+                                      int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
+                                      void *stream)
+{
+    return filter_impl(feats, n, c, points_mapping, coords, voxel_npoints, nvox, nullptr, coords_bound, min_points, max_points,
+                       max_voxels, max_points_filter, max_voxels_filter, out_feats, out_mask, out_mapping, out_npoints,
+                       out_coords, counts, workspace, workspace_bytes, stream);
+}
+
+extern "C" int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int32_t c, const int64_t *points_mapping,
+                                              const int64_t *coords, const int32_t *voxel_npoints, int64_t nvox_rows,
+                                              const int64_t *sparse_counts, const int64_t *coords_bound,
+                                              int32_t min_points, int32_t max_points, int32_t max_voxels,
+                                              int32_t max_points_filter, int32_t max_voxels_filter, float *out_feats,
+                                              int64_t *out_mask, int64_t *out_mapping, int32_t *out_npoints,
+                                              int64_t *out_coords, int64_t *counts, void *workspace,
+                                              size_t workspace_bytes, void *stream)
+{
+    if (!sparse_counts) return D3D_ERR_BAD_ARG;
+    return filter_impl(feats, n, c, points_mapping, coords, voxel_npoints, nvox_rows, sparse_counts + D3D_COUNT_VOXELS,
+                       coords_bound, min_points, max_points, max_voxels, max_points_filter, max_voxels_filter, out_feats,
+                       out_mask, out_mapping, out_npoints, out_coords, counts, workspace, workspace_bytes, stream);
 }

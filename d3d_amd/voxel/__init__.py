@@ -80,7 +80,11 @@ class _PackOverflow(Exception):
 
 def _counts_to_host(counts, what):
     host = counts.cpu()     # the one host sync of a call: sizes of the variable-length outputs
-    status = int(host[_lib.COUNT_STATUS])
+    _check_status(int(host[_lib.COUNT_STATUS]), what)
+    return host
+
+
+def _check_status(status, what):
     if status & _lib.STATUS_PACK_OVERFLOW:
         raise _PackOverflow(what)
     if status & _lib.STATUS_TABLE_FULL:
@@ -88,7 +92,6 @@ def _counts_to_host(counts, what):
     if status & _lib.STATUS_COORD_OVERFLOW:
         raise ValueError("%s: voxel coordinate out of the supported range [-2^20, 2^20) "
                          "(non-finite point or voxel size too small)" % what)
-    return host
 
 
 _ws_bytes_cache = {}
@@ -232,6 +235,52 @@ def voxelize_3d_filter(feats, points_mapping, coords, voxel_npoints, coords_boun
     return ret
 
 
+def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_voxels, pf, vf):
+    """voxelize_3d_sparse followed by voxelize_3d_filter as VoxelGenerator.__call__ chains them
+    (voxel/__init__.py:93-102), with ONE host read-back: the filter reads the voxel count on the device."""
+    lib = _lib.load()
+    if vf != 0 and max_voxels is None:
+        raise ValueError("Must specify maximum voxel count to filter voxels!")            # voxelize.cpp:359
+    if pf != 0 and max_points is None:
+        raise ValueError("Must specify maximum points per voxel to filter points!")       # voxelize.cpp:362
+    if pf == MaxPointsFilterType.FARTHEST_SAMPLING:
+        raise ValueError("Farthest Sampling not implemented!")                            # voxelize.cpp:470
+    pts, odev, dev = _stage(points)
+    n, c = pts.shape
+    if c < 3:
+        raise RuntimeError("points need at least 3 columns (x, y, z)")
+    bound_h = (ctypes.c_int64 * 6)(*[int(x) for x in _as_tensor(vbounds).reshape(-1).tolist()])
+    with torch.cuda.device(dev):
+        mapping = torch.empty((n,), dtype=torch.int64, device=dev)
+        coords = torch.empty((n, 3), dtype=torch.int64, device=dev)
+        npts = torch.empty((n,), dtype=torch.int32, device=dev)
+        counts = torch.empty((2, _lib.NUM_COUNTS), dtype=torch.int64, device=dev)
+        ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, n), dev)
+        rc = lib.d3d_voxelize_3d_sparse(_lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), _lib.ptr(mapping),
+                                        _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts[0]), _lib.ptr(ws), ws.numel(),
+                                        _lib.stream_ptr())
+        _lib.check(rc, "voxelize_3d_sparse")
+        o_feats = torch.empty((n, c), dtype=torch.float32, device=dev)
+        o_mask = torch.empty((n,), dtype=torch.int64, device=dev)
+        o_map = torch.empty((n,), dtype=torch.int64, device=dev)
+        o_cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+        o_crd = torch.empty((n, 3), dtype=torch.int64, device=dev)
+        rc = lib.d3d_voxelize_3d_filter_chained(
+            _lib.ptr(pts), n, c, _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), n, _lib.ptr(counts[0]),
+            ctypes.cast(bound_h, ctypes.c_void_p), int(min_points or 0), int(max_points or 0), int(max_voxels or 0),
+            pf, vf, _lib.ptr(o_feats), _lib.ptr(o_mask), _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd),
+            _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "voxelize_3d_filter")
+        host = counts.cpu()                                   # the one host sync of the pair
+        _check_status(int(host[0, _lib.COUNT_STATUS]), "voxelize_3d_sparse")
+        k, v = int(host[1, _lib.COUNT_POINTS]), int(host[1, _lib.COUNT_VOXELS])
+    ret = dict(points=o_feats[:k], points_mask=o_mask[:k], points_mapping=o_map[:k],
+               voxel_npoints=o_cnt[:v], coords=o_crd[:v])
+    if odev != dev:
+        ret = {kk: vv.to(odev) for kk, vv in ret.items()}
+    return ret
+
+
 def _lookup(enum_cls, name, message):
     key = (name or "NONE").upper()
     if key not in enum_cls.__members__:
@@ -260,6 +309,7 @@ class VoxelGenerator:
         self._offset = torch.round(origin_cells).int()                                        # :45
         self._vbounds = torch.round(lohi / self._size.reshape(3, 1)).long()                   # :46
         self._shape_h = _host_array(self._shape, ctypes.c_int32, 3)      # marshalled once for the C ABI
+        self._offset_dev = {}
         self._bounds_h = _host_array(self._bounds, ctypes.c_float, 6)
         self._size_h = _host_array(self._size, ctypes.c_float, 3)
 
@@ -290,11 +340,21 @@ class VoxelGenerator:
             ret = Dict(voxelize_3d_dense(points, self._shape_h, self._bounds_h, self._max_points,
                                          self._max_voxels, self._reduction))
         else:
-            sparse = voxelize_3d_sparse(points, self._size_h, 3)
-            ret = Dict(voxelize_3d_filter(points, sparse["points_mapping"], sparse["coords"], sparse["voxel_npoints"],
-                                          self._vbounds, self._min_points, self._max_points, self._max_voxels,
-                                          self._max_points_filter, self._max_voxels_filter))
-            ret.coords = ret.coords - self._offset.to(ret.coords.device)                      # :103
+            pf, vf = int(self._max_points_filter), int(self._max_voxels_filter)
+            if vf == MaxVoxelsFilterType.DESCENDING or points.shape[0] == 0:
+                # the count sort needs the number of voxels on the host: the two calls of the reference, two read-backs
+                sparse = voxelize_3d_sparse(points, self._size_h, 3)
+                ret = Dict(voxelize_3d_filter(points, sparse["points_mapping"], sparse["coords"],
+                                              sparse["voxel_npoints"], self._vbounds, self._min_points,
+                                              self._max_points, self._max_voxels, self._max_points_filter,
+                                              self._max_voxels_filter))
+            else:
+                ret = Dict(_sparse_filter_chained(points, self._size_h, self._vbounds, self._min_points,
+                                                  self._max_points, self._max_voxels, pf, vf))
+            off = self._offset_dev.get(ret.coords.device)
+            if off is None:
+                off = self._offset_dev[ret.coords.device] = self._offset.to(ret.coords.device)
+            ret.coords = ret.coords - off                                                     # :103
         if odev != points.device:
             ret = Dict({k: v.to(odev) for k, v in ret.items()})
         return ret

@@ -107,6 +107,19 @@ int d3d_voxelize_3d_filter(const float *feats, int64_t n, int32_t c,
                            int32_t *out_npoints, int64_t *out_coords,
                            int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
 
+/* d3d_voxelize_3d_filter directly behind d3d_voxelize_3d_sparse on the same stream, without reading the voxel count
+ * back in between (VoxelGenerator.__call__, voxel/__init__.py:93-102, does exactly this pair): coords / voxel_npoints
+ * are the sparse call's buffers with nvox_rows rows, sparse_counts its device `counts`; rows >= counts[0] are ignored.
+ * max_voxels_filter = DESCENDING is unsupported here (the sort needs the size on the host). */
+int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int32_t c, const int64_t *points_mapping,
+                                   const int64_t *coords, const int32_t *voxel_npoints, int64_t nvox_rows,
+                                   const int64_t *sparse_counts, const int64_t *coords_bound,
+                                   int32_t min_points, int32_t max_points, int32_t max_voxels,
+                                   int32_t max_points_filter, int32_t max_voxels_filter,
+                                   float *out_feats, int64_t *out_mask, int64_t *out_mapping,
+                                   int32_t *out_npoints, int64_t *out_coords,
+                                   int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- beyond the reference: the point-sharded voxelizer of north_star (d3d has no distributed code) ---- */
 
 /* Voxel feature grid without the dense [V,P,C] copy ("dynamic voxelization"): grid semantics of

@@ -235,3 +235,24 @@ def test_randomized_configs_vs_oracle(seed):
     exp = oracle.VoxelGenerator(bounds, shape, **kw)(cloud)
     ret = _np(VoxelGenerator(bounds, shape, **kw)(pts))
     check_sparse(ret, exp)
+
+
+@pytest.mark.parametrize("kw", [dict(max_points=4, max_points_filter="trim"),
+                                dict(max_points=3, max_points_filter="trim", min_points=2, max_voxels=700, max_voxels_filter="trim"),
+                                dict()])
+def test_chained_sparse_filter_equals_the_two_calls(kw):
+    """VoxelGenerator's sparse mode chains sparse -> filter with one read-back (d3d_voxelize_3d_filter_chained, the voxel
+    count stays on the device): same result as the reference's two separate calls (voxel/__init__.py:93-102)"""
+    from d3d_amd.voxel import VoxelGenerator, voxelize_3d_filter, voxelize_3d_sparse
+    rng = np.random.default_rng(5)
+    cloud = np.concatenate([rng.random((30000, 4)), rng.random((4000, 4)) * 0.1 + 0.45]).astype(np.float32)
+    pts = torch.from_numpy(cloud).cuda()
+    gen = VoxelGenerator([0, 1, 0, 1, 0, 1], [20, 20, 20], **kw)
+    one = _np(gen(pts))
+    sp = voxelize_3d_sparse(pts, gen._size_h, 3)
+    two = _np(voxelize_3d_filter(pts, sp["points_mapping"], sp["coords"], sp["voxel_npoints"], gen._vbounds, gen._min_points,
+                                 gen._max_points, gen._max_voxels, gen._max_points_filter, gen._max_voxels_filter))
+    two["coords"] = two["coords"] - gen._offset.numpy()
+    assert set(one) == set(two)
+    for k in one:
+        assert np.array_equal(one[k], two[k]), k
