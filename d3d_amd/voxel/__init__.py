@@ -94,6 +94,19 @@ def _check_status(status, what):
                          "(non-finite point or voxel size too small)" % what)
 
 
+def _with_plain_retry(lib, run):
+    """one-word hash slots first; when a field of the word overflowed (a voxel with > 2^cb points, or -- sparse contract --
+    a bounding box of voxel coordinates too large for the key field) repeat with the general two-word slots"""
+    try:
+        return run()
+    except _PackOverflow:
+        lib.d3d_voxel_force_plain(1)
+        try:
+            return run()
+        finally:
+            lib.d3d_voxel_force_plain(0)
+
+
 _ws_bytes_cache = {}
 
 
@@ -137,14 +150,7 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
                 raise ValueError("Unsupported reduction type in voxelization!")   # voxelize.cpp:196
             _lib.check(rc, "voxelize_3d_dense")
             return int(_counts_to_host(counts, "voxelize_3d_dense")[_lib.COUNT_VOXELS])
-        try:
-            nv = run()
-        except _PackOverflow:      # > 2^cb points in one voxel: repeat with the general hash-slot layout
-            lib.d3d_voxel_force_plain(1)
-            try:
-                nv = run()
-            finally:
-                lib.d3d_voxel_force_plain(0)
+        nv = _with_plain_retry(lib, run)
     ret = dict(voxels=voxels[:nv], coords=coords[:nv], voxel_pmask=pmask[:nv].view(torch.bool),
                voxel_npoints=npts[:nv])
     if red != 0:
@@ -171,11 +177,14 @@ def voxelize_3d_sparse(points, voxel_size, ndim=3):
         npts = torch.empty((n,), dtype=torch.int32, device=dev)
         counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
         ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
-        rc = lib.d3d_voxelize_3d_sparse(_lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), _lib.ptr(mapping),
-                                        _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
-                                        _lib.stream_ptr())
-        _lib.check(rc, "voxelize_3d_sparse")
-        nv = int(_counts_to_host(counts, "voxelize_3d_sparse")[_lib.COUNT_VOXELS])
+
+        def run():
+            rc = lib.d3d_voxelize_3d_sparse(_lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), _lib.ptr(mapping),
+                                            _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
+                                            _lib.stream_ptr())
+            _lib.check(rc, "voxelize_3d_sparse")
+            return int(_counts_to_host(counts, "voxelize_3d_sparse")[_lib.COUNT_VOXELS])
+        nv = _with_plain_retry(lib, run)
     ret = dict(points_mapping=mapping, coords=coords[:nv], voxel_npoints=npts[:nv])
     if odev != dev:
         ret = {k: v.to(odev) for k, v in ret.items()}
@@ -256,24 +265,27 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
         npts = torch.empty((n,), dtype=torch.int32, device=dev)
         counts = torch.empty((2, _lib.NUM_COUNTS), dtype=torch.int64, device=dev)
         ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, n), dev)
-        rc = lib.d3d_voxelize_3d_sparse(_lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), _lib.ptr(mapping),
-                                        _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts[0]), _lib.ptr(ws), ws.numel(),
-                                        _lib.stream_ptr())
-        _lib.check(rc, "voxelize_3d_sparse")
         o_feats = torch.empty((n, c), dtype=torch.float32, device=dev)
         o_mask = torch.empty((n,), dtype=torch.int64, device=dev)
         o_map = torch.empty((n,), dtype=torch.int64, device=dev)
         o_cnt = torch.empty((n,), dtype=torch.int32, device=dev)
         o_crd = torch.empty((n, 3), dtype=torch.int64, device=dev)
-        rc = lib.d3d_voxelize_3d_filter_chained(
-            _lib.ptr(pts), n, c, _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), n, _lib.ptr(counts[0]),
-            ctypes.cast(bound_h, ctypes.c_void_p), int(min_points or 0), int(max_points or 0), int(max_voxels or 0),
-            pf, vf, _lib.ptr(o_feats), _lib.ptr(o_mask), _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd),
-            _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
-        _lib.check(rc, "voxelize_3d_filter")
-        host = counts.cpu()                                   # the one host sync of the pair
-        _check_status(int(host[0, _lib.COUNT_STATUS]), "voxelize_3d_sparse")
-        k, v = int(host[1, _lib.COUNT_POINTS]), int(host[1, _lib.COUNT_VOXELS])
+
+        def run():
+            rc = lib.d3d_voxelize_3d_sparse(_lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), _lib.ptr(mapping),
+                                            _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts[0]), _lib.ptr(ws), ws.numel(),
+                                            _lib.stream_ptr())
+            _lib.check(rc, "voxelize_3d_sparse")
+            rc = lib.d3d_voxelize_3d_filter_chained(
+                _lib.ptr(pts), n, c, _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), n, _lib.ptr(counts[0]),
+                ctypes.cast(bound_h, ctypes.c_void_p), int(min_points or 0), int(max_points or 0), int(max_voxels or 0),
+                pf, vf, _lib.ptr(o_feats), _lib.ptr(o_mask), _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd),
+                _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "voxelize_3d_filter")
+            host = counts.cpu()                               # the one host sync of the pair
+            _check_status(int(host[0, _lib.COUNT_STATUS]), "voxelize_3d_sparse")
+            return int(host[1, _lib.COUNT_POINTS]), int(host[1, _lib.COUNT_VOXELS])
+        k, v = _with_plain_retry(lib, run)
     ret = dict(points=o_feats[:k], points_mask=o_mask[:k], points_mapping=o_map[:k],
                voxel_npoints=o_cnt[:v], coords=o_crd[:v])
     if odev != dev:

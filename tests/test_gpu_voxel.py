@@ -256,3 +256,22 @@ def test_chained_sparse_filter_equals_the_two_calls(kw):
     assert set(one) == set(two)
     for k in one:
         assert np.array_equal(one[k], two[k]), k
+
+
+def test_sparse_bounding_box_key_and_its_fallback():
+    """sparse contract: one-word hash slots keyed inside the frame's bounding box (k_bbox); a box too large for the key
+    field (far outliers on every axis) raises PACK_OVERFLOW and the call is repeated with plain slots -- same result"""
+    from d3d_amd.voxel import voxelize_3d_sparse
+    rng = np.random.default_rng(17)
+    cloud = (rng.random((20000, 4)) * [40, 40, 4, 1] - [20, 20, 2, 0]).astype(np.float32)
+    size = np.array([0.1, 0.1, 0.1], np.float32)
+    for outliers in (False, True):
+        pts = cloud.copy()
+        if outliers:
+            pts[:6, :3] = [[9e4, 0, 0], [-9e4, 0, 0], [0, 9e4, 0], [0, -9e4, 0], [0, 0, 9e4], [0, 0, -9e4]]
+        exp = oracle.voxelize_3d_sparse(pts, size)
+        got = _np(voxelize_3d_sparse(torch.from_numpy(pts).cuda(), torch.from_numpy(size), 3))
+        for k in ("points_mapping", "coords", "voxel_npoints"):
+            assert np.array_equal(got[k], exp[k]), (outliers, k)
+    one = _np(voxelize_3d_sparse(torch.from_numpy(cloud[:1]).cuda(), torch.from_numpy(size), 3))
+    assert one["coords"].shape == (1, 3) and one["voxel_npoints"].tolist() == [1]
