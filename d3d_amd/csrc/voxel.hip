@@ -255,7 +255,7 @@ struct TabPlain {
 // ------------------------------------------------------------------ kernels: table build
 template <class Tab>
 __global__ void k_init(Tab tab, int64_t cap, unsigned char *flags, int64_t nflags16, int64_t *counts, uint32_t *big_count,
-                       BoxParams *box = nullptr)
+                       BoxParams *box = nullptr, const float4 *warm = nullptr, int64_t nwarm = 0)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,6 +264,12 @@ __global__ void k_init(Tab tab, int64_t cap, unsigned char *flags, int64_t nflag
     for (int64_t i = t0; i < nflags16; i += stride) reinterpret_cast<uint4 *>(flags)[i] = z;
     if (t0 < D3D_NUM_COUNTS) counts[t0] = 0;
     if (t0 == 0) *big_count = 0;
+    // pull the point tensor into the Infinity Cache while the table is being cleared: k_insert is a chain of dependent
+    // requests per point (load -> probe -> atomic) and runs 20 % faster when its first link does not come from HBM
+    // (measured: 100 -> 80 us at 1 M points, for 2 us more here)
+    float acc = 0.f;
+    for (int64_t i = t0; i < nwarm; i += stride) { const float4 v = warm[i]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 1.2345e-30f) flags[0] = 1;               // never true; keeps the loads
     if (box && t0 == 0) {
         for (int d = 0; d < 3; d++) { box->mn[d] = INT_MAX; box->mx[d] = INT_MIN; }
         big_count[32] = 0;                              // k_bbox's ticket
@@ -1079,8 +1085,11 @@ static int build_index(const Key &kf, const Tab &tab, const float *points, int64
     const int64_t cap = (int64_t)w.cap;
     BoxParams *box = nullptr;
     if constexpr (Key::kBox) box = kf.prm;
+    // (the sparse contract's k_bbox reads the points anyway)
+    const bool warm = !Key::kBox && n > 0 && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
+                      (size_t)n * c * 4 <= ((size_t)64 << 20);          // must fit the cache next to the table
     D3D_LAUNCH("k_init", k_init<Tab>, dim3(grid_for(cap, 256)), dim3(256), 0, st, tab, cap, w.flags, w.npad / 16, counts,
-               w.big_count, box);
+               w.big_count, box, warm ? reinterpret_cast<const float4 *>(points) : nullptr, warm ? n * c / 4 : (int64_t)0);
     if (n > 0) {
         const bool vec4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0);
         if constexpr (Key::kBox) {
