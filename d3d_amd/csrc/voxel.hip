@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, const u64 *__restric
         base = (uint32_t)a;
         const uint32_t cnt = (uint32_t)(a >> 32);
         if (base != kNoBase) {
-            if (cnt == 1) { sorted[base] = (uint32_t)i; if (staged) staged[base] = points4[i]; }
+            if (cnt == 1) { if (staged) staged[base] = points4[i]; else sorted[base] = (uint32_t)i; }
             else { unsorted[base + parr[i]] = (uint32_t)i; todo = cnt; }
         }
     }
@@ -575,8 +575,9 @@ __global__ __launch_bounds__(256) void k_select(int64_t n, const uint32_t *__res
     }
     for (; k < cnt && rank < max_points; k++) rank += seg[k] < me;
     if (rank < max_points) {
-        sorted[base + rank] = me;
+        // the index list is only read when the rows are not staged (C != 4): one scattered request per point less
         if (staged) staged[base + rank] = points4[i];
+        else sorted[base + rank] = me;
     }
 }
 
