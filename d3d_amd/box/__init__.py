@@ -62,7 +62,7 @@ def _iou_forward(boxes1, boxes2, iou_type):
     with torch.cuda.device(dev):
         ious = torch.empty((n, m), dtype=b1.dtype, device=dev)
         code = _dtype_code(b1)
-        ws = _lib.workspace(lib.d3d_iou2d_workspace_bytes(n, m, code), dev) if int(iou_type) == IouType.RBOX else None
+        ws = _lib.workspace(lib.d3d_iou2d_workspace_bytes(n, m, code), dev)
         rc = lib.d3d_iou2d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, int(iou_type), code, _lib.ptr(ious),
                                    _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr())
     _lib.check(rc, "iou2d_forward")

@@ -121,9 +121,10 @@ __device__ __forceinline__ float round_down(double x) { float f = (float)x; retu
 __device__ __forceinline__ float round_up(double x) { float f = (float)x; return (double)f < x ? nextafterf(f, INFINITY) : f; }
 __device__ __forceinline__ float round_down(float x) { return x; }
 __device__ __forceinline__ float round_up(float x) { return x; }
-template <typename T> __device__ __forceinline__ float4 cand_aabb(const BoxGeom<T> &g)
+template <typename T> __device__ __forceinline__ float4 cand_aabb(const BoxGeom<T> &g, bool rotated = true)
 {
-    if (!(g.area > 0)) return make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+    // (method BOX measures the AABB itself, which has an area even when the rectangle has none)
+    if (rotated && !(g.area > 0)) return make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
     return make_float4(round_down(g.xmin), round_down(g.ymin), round_up(g.xmax), round_up(g.ymax));
 }
 // strict overlap in x and y as ONE number: the smallest of the four gaps must be positive
@@ -136,14 +137,14 @@ __device__ __forceinline__ float aabb_gap(const float4 &a, const float4 &b)
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_geom(const T *__restrict__ boxes, int64_t n, BoxGeom<T> *geom, float4 *aabb,
-                                              IouList *hdr, unsigned int nseg)
+                                              IouList *hdr, unsigned int nseg, bool rotated)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (hdr && i == 0) list_reset(hdr, nseg);
     if (i < n) {
         const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
         geom[i] = g;
-        aabb[i] = cand_aabb(g);           // 16 B per box: what k_iou_pre reads (coalesced) instead of the geometry
+        aabb[i] = cand_aabb(g, rotated);  // 16 B per box: what k_iou_pre reads (coalesced) instead of the geometry
     }
 }
 
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
     write_out(base);
 }
 
-template <typename T>
+template <typename T, bool ROTATED>
 __global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb,
                                                   int64_t m, T *__restrict__ ious, const IouList *hdr,
                                                   const unsigned long long *__restrict__ list, unsigned long long cap)
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const unsigned long long e = seg[t];
         const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
-        const T v = iou_rbox(ga[i], gb[j]);
+        const T v = ROTATED ? iou_rbox(ga[i], gb[j]) : iou_aabb(ga[i], gb[j]);
         if (v != 0) ious[i * m + j] = v;
     }
     }
@@ -357,14 +358,14 @@ __global__ __launch_bounds__(256) void k_iou_grad(const BoxGeom<T> *__restrict__
 
 // ---------------------------------------------------------------- "3D IoU", two-phase (same scheme as rbox)
 __global__ __launch_bounds__(256) void k_geom3d(const float *__restrict__ boxes, int64_t n, BoxGeom<float> *geom,
-                                                float4 *aabb, float2 *zr, IouList *hdr, unsigned int nseg)
+                                                float4 *aabb, float2 *zr, IouList *hdr, unsigned int nseg, bool rotated)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (hdr && i == 0) list_reset(hdr, nseg);
     if (i < n) {
         const Box3DGeom g = load3d(boxes + i * 7);
         geom[i] = g.g;
-        aabb[i] = cand_aabb(g.g);
+        aabb[i] = cand_aabb(g.g, rotated);
         zr[i] = make_float2(g.zmin, g.zmax);
     }
 }
@@ -881,9 +882,8 @@ extern "C" size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype)
            256;
 }
 
-template <typename T>
-static int iou2d_rbox_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *ious, void *ws, size_t ws_bytes,
-                                hipStream_t st)
+template <typename T, bool ROTATED>
+static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *ious, void *ws, size_t ws_bytes, hipStream_t st)
 {
     WsCarver w(ws, ws_bytes);
     BoxGeom<T> *ga = w.take<BoxGeom<T>>(n);
@@ -895,8 +895,9 @@ static int iou2d_rbox_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, 
     unsigned long long *list = w.take<unsigned long long>(cap);
     if (!w.ok()) return D3D_ERR_WORKSPACE;
     D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, ra, hdr,
-               list_segments(cap));
-    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u);
+               list_segments(cap), ROTATED);
+    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u,
+               ROTATED);
     const unsigned gy = (unsigned)d3d_divup(n, kTileRows);
     T *fill = ious;
     if (reinterpret_cast<uintptr_t>(ious) & 15) {             // unaligned output: plain memset, candidates only
@@ -905,9 +906,9 @@ static int iou2d_rbox_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, 
     }
     D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), gy), dim3(kTileCols), 0, st,
                (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap);
-    D3D_LAUNCH("k_iou_clip", k_iou_clip<T>, dim3(256 * 16), dim3(256), 0, st, ga, gb, m, ious, hdr, list, cap);
+    D3D_LAUNCH("k_iou_clip", (k_iou_clip<T, ROTATED>), dim3(256 * 16), dim3(256), 0, st, ga, gb, m, ious, hdr, list, cap);
     // fallback (blocks exit at once unless the list overflowed)
-    D3D_LAUNCH("k_iou2d", (k_iou2d<T, true, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols), 0, st, b1,
+    D3D_LAUNCH("k_iou2d", (k_iou2d<T, ROTATED, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols), 0, st, b1,
                n, b2, m, ious, &hdr->overflow);
     return D3D_OK;
 }
@@ -924,14 +925,14 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     const int64_t gy = d3d_divup(n, kTileRows);
     if (gy > 65535 || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;   // callers tile above that
     const bool rot = iou_type == D3D_IOU_RBOX;
-    if (rot && workspace && workspace_bytes >= d3d_iou2d_workspace_bytes(n, m, dtype)) {
-        if (dtype == D3D_F64)
-            return iou2d_rbox_two_phase<double>((const double *)boxes1, n, (const double *)boxes2, m, (double *)ious, workspace,
-                                                workspace_bytes, st);
-        return iou2d_rbox_two_phase<float>((const float *)boxes1, n, (const float *)boxes2, m, (float *)ious, workspace,
-                                           workspace_bytes, st);
+    if (workspace && workspace_bytes >= d3d_iou2d_workspace_bytes(n, m, dtype)) {
+        // zero fill + candidate list + one candidate per lane (BOX too: its IoU is non-zero only where the AABBs overlap)
+#define D3D_TWO_PHASE(T, R) iou2d_two_phase<T, R>((const T *)boxes1, n, (const T *)boxes2, m, (T *)ious, workspace, workspace_bytes, st)
+        if (dtype == D3D_F64) return rot ? D3D_TWO_PHASE(double, true) : D3D_TWO_PHASE(double, false);
+        return rot ? D3D_TWO_PHASE(float, true) : D3D_TWO_PHASE(float, false);
+#undef D3D_TWO_PHASE
     }
-    // single-kernel path: method BOX, or RBOX without a workspace
+    // single-kernel path: no workspace
     const bool al16 = (reinterpret_cast<uintptr_t>(ious) & 15) == 0;
 #define D3D_IOU2D(T, R, K)                                                                                          \
     D3D_LAUNCH("k_iou2d", (k_iou2d<T, R, K>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols * K), (unsigned)gy),   \
@@ -984,9 +985,9 @@ extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *bo
         unsigned long long *list = w.take<unsigned long long>(cap);
         if (!w.ok()) return D3D_ERR_WORKSPACE;
         D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, boxes1, n, ga, ra, za, hdr,
-                   list_segments(cap));
+                   list_segments(cap), rotated != 0);
         D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, boxes2, m, gb, cb, zb, (IouList *)nullptr,
-                   1u);
+                   1u, rotated != 0);
         float *fill = out;
         if (reinterpret_cast<uintptr_t>(out) & 15) {
             D3D_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n * (size_t)m * sizeof(float), st));
@@ -1074,7 +1075,8 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
     D3D_HIP_CHECK(hipMemsetAsync(g1, 0, sizeof(T) * 5 * (size_t)n, st));
     D3D_HIP_CHECK(hipMemsetAsync(g2, 0, sizeof(T) * 5 * (size_t)m, st));
-    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u);
+    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u,
+               rot);
     // rows in chunks such that chunk_rows * m <= capacity: the list can then never overflow
     int64_t rows_per = (int64_t)(cap_all / (unsigned long long)m);
     if (rows_per < 1) return D3D_ERR_BAD_ARG;
@@ -1084,7 +1086,8 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     for (int64_t r0 = 0; r0 < n; r0 += rows_per) {
         const int64_t nr = (n - r0) < rows_per ? (n - r0) : rows_per;
         if ((unsigned long long)nr * (unsigned long long)m > cap_all) return D3D_ERR_WORKSPACE;
-        D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(nr, 256)), dim3(256), 0, st, b1 + r0 * 5, nr, ga, ra, hdr, 1u);
+        D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(nr, 256)), dim3(256), 0, st, b1 + r0 * 5, nr, ga, ra, hdr, 1u,
+                   rot);
         D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), (unsigned)d3d_divup(nr, kTileRows)),
                    dim3(kTileCols), 0, st, (const float4 *)ra, nr, (const float4 *)cb, m, (T *)nullptr, hdr, list, cap_all);
         if (rot)

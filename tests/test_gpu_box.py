@@ -346,3 +346,23 @@ def test_iou_backward_fp32_and_large():
     assert torch.isfinite(t1.grad).all() and t1.grad.dtype == torch.float32
     rel = (t1.grad.double() - d1.grad).abs().max() / d1.grad.abs().max()
     assert rel < 5e-3        # fp32 clip vs fp64 clip of the same boxes
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_box_method_ragged_shapes_and_degenerate_rectangles(dtype):
+    """method "box" goes through the same zero-fill + candidate path as "rbox": odd matrix shapes, and rectangles
+    without area whose bounding box has one (w = 0, rotated) keep their AABB IoU"""
+    from d3d_amd.box import box2d_iou
+    rng = np.random.default_rng(3)
+    b1 = bc.random_boxes_like_reference(131, 21)[0].astype(dtype)
+    b2 = bc.random_boxes_like_reference(77, 22)[0].astype(dtype)
+    b1[:5, 2] = 0.0                       # zero width, rotated: AABB still has an area
+    b1[:5, 4] = 0.7
+    b2[:3, 3] = 0.0
+    b2[:3, 4] = -0.4
+    b2[10:15, :2] = b1[:5, :2]            # full boxes centred on the degenerate ones
+    got = box2d_iou(T(b1), T(b2), method="box", precise=False).cpu().numpy()
+    exp = oracle.box2d_iou(b1.astype(np.float64), b2.astype(np.float64), "box")
+    assert got.shape == (131, 77)
+    assert np.max(np.abs(got - exp)) < (1e-9 if dtype == np.float64 else 1e-3)
+    assert np.any(exp[:5] > 0)

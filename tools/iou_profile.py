@@ -30,3 +30,7 @@ show("iou2dr 20k x 20k fp32", lambda: iou2dr_forward(bf[:20000], bf[:20000]), 4e
 show("iou2dr 5k x 20k fp32", lambda: iou2dr_forward(bf[:5000], bf[:20000]), 1e8)
 show("iou2dr 20k x 5001 fp32", lambda: iou2dr_forward(bf[:20000], bf[:5001]), 1.0002e8)
 show("iou2dr 20001 x 4999 fp64", lambda: iou2dr_forward(bt[:20001], bt[:4999]), 1e8)
+from d3d_amd.box import iou2d_forward
+show("iou2d box 20k x 100k fp64", lambda: iou2d_forward(bt[:20000], bt), 2e9, 5)
+show("iou2d box 20k x 5001 fp32", lambda: iou2d_forward(bf[:20000], bf[:5001]), 1.0002e8)
+show("iou2d box 20k x 5000 fp32", lambda: iou2d_forward(bf[:20000], bf[:5000]), 1e8)
