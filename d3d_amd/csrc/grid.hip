@@ -19,6 +19,32 @@ __global__ __launch_bounds__(256) void k_grid_mark(const int64_t *__restrict__ k
     atomicOr(&bitmap[k >> 6], 1ull << (k & 63));
 }
 
+// ---- bitmap exchange (grids whose bitmap is smaller than the key lists): every rank marks its own cells, the bitmaps
+// are all-gathered and OR-ed here -- a streaming pass instead of one atomic per gathered key
+__global__ __launch_bounds__(256) void k_grid_or(const unsigned long long *__restrict__ parts, int64_t stride_words, int world,
+                                                 int64_t nw, unsigned long long *__restrict__ bitmap)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    unsigned long long x = 0;
+    for (int r = 0; r < world; r++) x |= parts[(int64_t)r * stride_words + w];
+    bitmap[w] = x;
+}
+
+// key_of_slot by enumerating the set bits: slot = prefix[word] + index of the bit within the word
+__global__ __launch_bounds__(256) void k_grid_keys(const unsigned long long *__restrict__ bitmap, const uint32_t *__restrict__ prefix,
+                                                   int64_t nw, int64_t *__restrict__ key_of_slot)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    unsigned long long x = bitmap[w];
+    int64_t s = prefix[w];
+    while (x) {
+        key_of_slot[s++] = w * 64 + __builtin_ctzll(x);
+        x &= x - 1;
+    }
+}
+
 struct PopcountWords {
     static constexpr const char *kName = "k_scan_count<PopcountWords>", *kName2 = "k_scan_apply<PopcountWords>";
     const unsigned long long *bitmap;
@@ -87,7 +113,7 @@ __global__ __launch_bounds__(256) void k_sharded_scatter(const int64_t *__restri
     const bool mine = v >= 0 && v < n_local;
     if (mine) slot_of_local[v] = s;
     if (s < 0) return;
-    key_of_slot[s] = k;
+    if (key_of_slot) key_of_slot[s] = k;
     if (!mine) return;
     for (int d = 0; d < c; d++) table[s * tstride + d] = agg[v * c + d];
     if (with_count) table[s * tstride + c] = (float)cnt[v];      // counts < 2^24 are exact in fp32
@@ -103,7 +129,8 @@ __global__ __launch_bounds__(256) void k_sharded_finalize(int64_t nvox, int c, c
                                                           const int64_t *__restrict__ key_of_slot,
                                                           const float *__restrict__ table, int tstride, int mean,
                                                           const int32_t *__restrict__ cnt_in, int64_t sy, int64_t sz,
-                                                          int64_t *vid_of_slot, int64_t *coords, int32_t *cnt_out, float *feats)
+                                                          int64_t *vid_of_slot, int64_t *coords, int32_t *cnt_out, float *feats,
+                                                          bool vec4)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nvox) return;
@@ -115,13 +142,14 @@ __global__ __launch_bounds__(256) void k_sharded_finalize(int64_t nvox, int c, c
     coords[v * 3 + 1] = (k / sz) % sy;
     coords[v * 3 + 2] = k % sz;
     const float *row = table + s * tstride;
-    if (mean) {
-        const float n = row[c];                       // counts < 2^24 are exact in fp32
-        cnt_out[v] = (int32_t)(n + 0.5f);
-        for (int d = 0; d < c; d++) feats[v * c + d] = row[d] / n;
+    const float n = mean ? row[c] : 1.f;              // counts < 2^24 are exact in fp32
+    cnt_out[v] = mean ? (int32_t)(n + 0.5f) : cnt_in[s];
+    if (c == 4 && vec4) {                             // one 16-byte scattered store instead of four 4-byte ones
+        float4 f = make_float4(row[0], row[1], row[2], row[3]);
+        if (mean) f = make_float4(f.x / n, f.y / n, f.z / n, f.w / n);
+        reinterpret_cast<float4 *>(feats)[v] = f;
     } else {
-        cnt_out[v] = cnt_in[s];
-        for (int d = 0; d < c; d++) feats[v * c + d] = row[d];
+        for (int d = 0; d < c; d++) feats[v * c + d] = mean ? row[d] / n : row[d];
     }
 }
 
@@ -170,6 +198,54 @@ extern "C" int d3d_grid_compact_index(const int64_t *keys, int64_t m, int64_t nc
     return d3d_run_scan(f, nw, bsum, counts, -1, 0, ~0ull, st);
 }
 
+// bitmap exchange, step 1: this rank's occupancy bitmap (ceil(ncells/64) words; negative keys are ignored)
+extern "C" int d3d_grid_bitmap_mark(const int64_t *keys, int64_t m, int64_t ncells, unsigned long long *bitmap, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (m < 0 || ncells <= 0 || !bitmap || (m > 0 && !keys)) return D3D_ERR_BAD_ARG;
+    const int64_t nw = d3d_divup(ncells, 64);
+    D3D_HIP_CHECK(hipMemsetAsync(bitmap, 0, (size_t)nw * 8, st));
+    if (m > 0) D3D_LAUNCH("k_grid_mark", k_grid_mark, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, keys, m, ncells, bitmap);
+    return D3D_OK;
+}
+
+// bitmap exchange, step 2: OR of the `world` all-gathered bitmaps (rank r at parts + r * stride_words) into the compact
+// index of `workspace` (as d3d_grid_compact_index does from key lists); counts[0] = distinct occupied cells; optionally
+// key_of_slot[counts[0]] (cells in ascending order).
+extern "C" int d3d_grid_compact_from_bitmaps(const unsigned long long *parts, int64_t stride_words, int32_t world, int64_t ncells,
+                                             int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (world < 1 || ncells <= 0 || !counts || !parts) return D3D_ERR_BAD_ARG;
+    if (ncells >= (1ll << 37)) return D3D_ERR_BAD_ARG;
+    const int64_t nw = d3d_divup(ncells, 64);
+    if (stride_words < nw) return D3D_ERR_BAD_ARG;
+    WsCarver w(workspace, workspace_bytes);
+    unsigned long long *bitmap = w.take<unsigned long long>(nw);
+    uint32_t *prefix = w.take<uint32_t>(nw);
+    unsigned long long *bsum = w.take<unsigned long long>(d3d_divup(nw, kScanTile) + 1);
+    if (!workspace || !w.ok()) return D3D_ERR_WORKSPACE;
+    D3D_LAUNCH("k_grid_or", k_grid_or, dim3((unsigned)d3d_divup(nw, 256)), dim3(256), 0, st, parts, stride_words, (int)world, nw,
+               bitmap);
+    PopcountWords f{bitmap, prefix};
+    return d3d_run_scan(f, nw, bsum, counts, -1, 0, ~0ull, st);
+}
+
+// key of every slot of a compact index (ascending cells): key_of_slot must hold counts[0] entries
+extern "C" int d3d_grid_compact_keys(int64_t ncells, const void *workspace, size_t workspace_bytes, int64_t *key_of_slot,
+                                     void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (ncells <= 0 || !key_of_slot) return D3D_ERR_BAD_ARG;
+    const int64_t nw = d3d_divup(ncells, 64);
+    WsCarver w((void *)workspace, workspace_bytes);
+    unsigned long long *bitmap = w.take<unsigned long long>(nw);
+    uint32_t *prefix = w.take<uint32_t>(nw);
+    if (!workspace || !w.ok()) return D3D_ERR_WORKSPACE;
+    D3D_LAUNCH("k_grid_keys", k_grid_keys, dim3((unsigned)d3d_divup(nw, 256)), dim3(256), 0, st, bitmap, prefix, nw, key_of_slot);
+    return D3D_OK;
+}
+
 // slot[j] = index of keys[j] among the occupied cells (ascending linear key), or `missing` if the cell is not marked
 extern "C" int d3d_grid_compact_lookup(const int64_t *keys, int64_t m, int64_t ncells, const void *workspace,
                                        size_t workspace_bytes, int64_t missing, int64_t *slot, void *stream)
@@ -198,7 +274,7 @@ extern "C" int d3d_sharded_scatter(const int64_t *keys_all, int64_t m, int64_t b
     if (reduction != D3D_REDUCE_MEAN && reduction != D3D_REDUCE_MAX && reduction != D3D_REDUCE_MIN) return D3D_ERR_UNSUPPORTED;
     const bool mean = reduction == D3D_REDUCE_MEAN;
     if (table_stride < c + (mean ? 1 : 0)) return D3D_ERR_BAD_ARG;
-    if (nvox > 0 && (!table || !first || !key_of_slot || (!mean && !cnt_table))) return D3D_ERR_BAD_ARG;
+    if (nvox > 0 && (!table || !first || (!mean && !cnt_table))) return D3D_ERR_BAD_ARG;
     if (m > 0 && !keys_all) return D3D_ERR_BAD_ARG;
     if (n_local > 0 && (!agg || !cnt || !first_local || !slot_of_local)) return D3D_ERR_BAD_ARG;
     const int64_t nw = d3d_divup(ncells, 64);
@@ -236,7 +312,8 @@ extern "C" int d3d_sharded_finalize(int64_t nvox, int32_t c, const int64_t *firs
     uint32_t *prefix = w.take<uint32_t>(nw);
     D3D_LAUNCH("k_sharded_finalize", k_sharded_finalize, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox, c, first,
                n_total > 0 ? n_total : (int64_t)1, bitmap, prefix, key_of_slot, table, table_stride, mean, cnt_in,
-               (int64_t)shape[1], (int64_t)shape[2], vid_of_slot, coords, cnt_out, feats);
+               (int64_t)shape[1], (int64_t)shape[2], vid_of_slot, coords, cnt_out, feats,
+               (reinterpret_cast<uintptr_t>(feats) & 15) == 0);
     return D3D_OK;
 }
 

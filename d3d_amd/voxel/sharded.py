@@ -124,7 +124,46 @@ class HipOps:
             status |= -1 - int(flag)
         return (ws, int(ncells)), int(host[0]), status
 
-    def build_table(self, handle, keys_all, begin, n_local, nvox, c, reduction, agg, cnt, first_local):
+    def bitmap_mark(self, keys, n, ncells):
+        """this rank's occupancy bitmap as int64 words + one trailing status word (keys[n] = -1 - status bits)"""
+        lib = _lib.load()
+        dev = keys.device
+        nw = (int(ncells) + 63) // 64
+        with torch.cuda.device(dev):
+            part = torch.empty((nw + 1,), dtype=torch.int64, device=dev)
+            rc = lib.d3d_grid_bitmap_mark(_lib.ptr(keys), int(n), int(ncells), _lib.ptr(part), _lib.stream_ptr())
+            _lib.check(rc, "grid_bitmap_mark")
+            part[nw:] = keys[n:n + 1]
+        return part
+
+    def compact_from_bitmaps(self, parts_all, world, ncells):
+        """-> (handle, number of occupied cells, status bits OR-ed over the ranks) from the all-gathered bitmaps;
+        the host read-back of a sharded call in bitmap mode"""
+        lib = _lib.load()
+        dev = parts_all.device
+        nw = (int(ncells) + 63) // 64
+        with torch.cuda.device(dev):
+            ws = torch.empty((lib.d3d_grid_compact_workspace_bytes(ncells),), dtype=torch.uint8, device=dev)
+            counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+            rc = lib.d3d_grid_compact_from_bitmaps(_lib.ptr(parts_all), nw + 1, int(world), int(ncells), _lib.ptr(counts),
+                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "grid_compact_from_bitmaps")
+            host = torch.cat([counts[:1], parts_all[nw::nw + 1]]).tolist()
+        status = 0
+        for flag in host[1:]:
+            status |= -1 - int(flag)
+        return (ws, int(ncells)), int(host[0]), status
+
+    def compact_keys(self, handle, nvox):
+        lib = _lib.load()
+        ws, ncells = handle
+        with torch.cuda.device(ws.device):
+            key_of_slot = torch.empty((nvox,), dtype=torch.int64, device=ws.device)
+            rc = lib.d3d_grid_compact_keys(ncells, _lib.ptr(ws), ws.numel(), _lib.ptr(key_of_slot), _lib.stream_ptr())
+            _lib.check(rc, "grid_compact_keys")
+        return key_of_slot
+
+    def build_table(self, handle, keys_all, begin, n_local, nvox, c, reduction, agg, cnt, first_local, want_keys=True):
         """identity-filled all-reduce operands with this rank's partial rows in place:
         -> table[nvox, c(+1)], cnt_table[nvox] (None for mean), first[nvox], key_of_slot[nvox], slot_of_local[n_local]"""
         lib = _lib.load()
@@ -135,7 +174,7 @@ class HipOps:
             table = torch.empty((nvox, c + 1 if mean else c), dtype=torch.float32, device=dev)
             cnt_t = None if mean else torch.empty((nvox,), dtype=torch.int32, device=dev)
             first = torch.empty((nvox,), dtype=torch.int64, device=dev)
-            key_of_slot = torch.empty((nvox,), dtype=torch.int64, device=dev)
+            key_of_slot = torch.empty((nvox,), dtype=torch.int64, device=dev) if want_keys else None
             slot = torch.empty((n_local,), dtype=torch.int64, device=dev)
             rc = lib.d3d_sharded_scatter(_lib.ptr(keys_all), keys_all.numel(), int(begin), int(n_local), ncells, _lib.ptr(ws),
                                          ws.numel(), int(nvox), int(c), int(reduction), _lib.ptr(agg), _lib.ptr(cnt),
@@ -200,7 +239,7 @@ class ShardedVoxelGenerator:
     """Voxel feature grid of a frame whose points are sharded over the ranks of `group` (contiguous slices in
     rank order).  Grid arguments as d3d.voxel.VoxelGenerator (bounds, shape); reduction in {mean, max, min}."""
 
-    def __init__(self, bounds, shape, reduction="mean", group=None, comm=None, ops=None):
+    def __init__(self, bounds, shape, reduction="mean", group=None, comm=None, ops=None, exchange="auto"):
         key = (reduction or "").upper()
         if key not in _REDUCTIONS:
             raise ValueError("Unsupported reduction type in VoxelGenerator!")
@@ -213,6 +252,9 @@ class ShardedVoxelGenerator:
         self._comm = comm if comm is not None else TorchComm(group)
         self._ops = ops if ops is not None else HipOps()
         self._layout_key, self._layout_val = None, None
+        if exchange not in ("auto", "keys", "bitmap"):
+            raise ValueError("exchange must be auto, keys or bitmap")
+        self._exchange = exchange        # what the ranks all-gather to agree on the occupied cells
 
     def _layout(self, n, dev):
         """shard sizes over the ranks; exchanged once per local shard size (one collective + host read)"""
@@ -239,18 +281,33 @@ class ShardedVoxelGenerator:
         kw = {"plain": True} if plain else {}
         _, cnt_r, agg_r, first_r, map_r, keys_r, _ = ops.voxelize_reduce(
             points, self._shape, self._bounds, _SUM if mean else self._red, offset, **kw)
-        # 2. all-gather the occupied-cell keys (+ status row), padded to the largest shard
-        pad = keys_r if n == cap else torch.cat([keys_r[:n], keys_r.new_full((cap - n,), -1), keys_r[n:]])
-        keys_all = comm.all_gather_var(pad, [cap + 1] * comm.world)
-        # 3. identical compact slots on every rank; the one host read-back: global voxel count + every rank's status
-        handle, nvox, status = ops.compact_index(keys_all, self._ncells, status_stride=cap + 1)
+        nw = (self._ncells + 63) // 64
+        # auto: bitmaps when the grid's bitmap is not larger than a key list (KITTI-size grids), else key lists
+        bitmap_mode = self._exchange == "bitmap" or (self._exchange == "auto" and nw <= cap + 1)
+        if bitmap_mode:
+            # 2b. all-gather the ranks' occupancy bitmaps (+ status word); 3b. OR them: a streaming pass instead of
+            #     one atomic per gathered key, and the keys of the slots fall out of the merged bitmap
+            part = ops.bitmap_mark(keys_r, n, self._ncells)
+            parts_all = comm.all_gather_var(part, [nw + 1] * comm.world)
+            handle, nvox, status = ops.compact_from_bitmaps(parts_all, comm.world, self._ncells)
+        else:
+            # 2. all-gather the occupied-cell keys (+ status row), padded to the largest shard
+            pad = keys_r if n == cap else torch.cat([keys_r[:n], keys_r.new_full((cap - n,), -1), keys_r[n:]])
+            keys_all = comm.all_gather_var(pad, [cap + 1] * comm.world)
+            # 3. identical compact slots on every rank; the one host read-back: global voxel count + every rank's status
+            handle, nvox, status = ops.compact_index(keys_all, self._ncells, status_stride=cap + 1)
         if status & _lib.STATUS_TABLE_FULL:
             raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
         if status & _lib.STATUS_PACK_OVERFLOW and not plain:
             return None        # some rank hit the packed-slot counter limit (rare): all ranks redo with plain slots
         # 4. all-reduce the compact voxel table
-        table, cnt_t, first, key_of_slot, slot_r = ops.build_table(
-            handle, keys_all, comm.rank * (cap + 1), n, nvox, c, self._red, agg_r, cnt_r, first_r)
+        if bitmap_mode:
+            key_of_slot = ops.compact_keys(handle, nvox)
+            table, cnt_t, first, _, slot_r = ops.build_table(handle, keys_r[:n], 0, n, nvox, c, self._red, agg_r, cnt_r,
+                                                             first_r, want_keys=False)
+        else:
+            table, cnt_t, first, key_of_slot, slot_r = ops.build_table(
+                handle, keys_all, comm.rank * (cap + 1), n, nvox, c, self._red, agg_r, cnt_r, first_r)
         if nvox > 0:
             comm.all_reduce(table, "sum" if mean else ("max" if self._red == 2 else "min"))
             if cnt_t is not None:

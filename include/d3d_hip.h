@@ -143,12 +143,22 @@ int d3d_grid_compact_index(const int64_t *keys, int64_t m, int64_t ncells, int64
 int d3d_grid_compact_lookup(const int64_t *keys, int64_t m, int64_t ncells, const void *workspace,
                             size_t workspace_bytes, int64_t missing, int64_t *slot, void *stream);
 
+/* The same index from all-gathered occupancy BITMAPS instead of key lists (for grids whose bitmap, ncells / 8 bytes, is
+ * smaller than the key lists: an OR pass replaces one atomic per gathered key): bitmap_mark = this rank's bitmap
+ * (ceil(ncells/64) words); compact_from_bitmaps = OR of `world` bitmaps (rank r at parts + r * stride_words) + prefix,
+ * counts[0] = distinct cells; compact_keys = the cell of every slot, ascending (key_of_slot[counts[0]]). */
+int d3d_grid_bitmap_mark(const int64_t *keys, int64_t m, int64_t ncells, unsigned long long *bitmap, void *stream);
+int d3d_grid_compact_from_bitmaps(const unsigned long long *parts, int64_t stride_words, int32_t world, int64_t ncells,
+                                  int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+int d3d_grid_compact_keys(int64_t ncells, const void *workspace, size_t workspace_bytes, int64_t *key_of_slot,
+                          void *stream);
+
 /* Steps of the sharded voxelizer around the two all-reduces (no host synchronisation).
  * scatter: keys_all[m] = all-gathered key lists (negative = padding / status rows), already indexed by
  *   d3d_grid_compact_index into compact_ws; rows [begin, begin + n_local) are this rank's own.  Writes the identity
  *   of the reduction into table[nvox, table_stride] (MEAN: c sums + count, else c extrema with the counts in
  *   cnt_table[nvox]) and first[nvox] (INT64_MAX), then this rank's partial rows at their slots, key_of_slot[nvox]
- *   for every gathered key, and slot_of_local[n_local] (-1 beyond the rank's voxels).
+ *   for every gathered key (skipped when NULL), and slot_of_local[n_local] (-1 beyond the rank's voxels).
  * finalize: voxel id of a slot = rank of first[slot] among all first indices (compact_ws sized for n_total cells is
  *   overwritten); slot-ordered all-reduced table -> voxel-id-ordered coords[nvox,3], cnt_out[nvox], feats[nvox,c],
  *   and vid_of_slot[nvox].

@@ -53,13 +53,35 @@ class NumpyOps:
         u = np.unique(k[k >= 0])
         return u, len(u), status
 
+    def bitmap_mark(self, keys, n, ncells):
+        k = keys.cpu().numpy()
+        nw = (int(ncells) + 63) // 64
+        bits = np.zeros((nw * 64,), np.uint8)
+        bits[k[:n][k[:n] >= 0]] = 1
+        words = np.packbits(bits.reshape(nw, 64), axis=1, bitorder="little").view("<u8").reshape(nw)
+        return torch.from_numpy(np.concatenate([words.view(np.int64), k[n:n + 1]]))
+
+    def compact_from_bitmaps(self, parts_all, world, ncells):
+        nw = (int(ncells) + 63) // 64
+        parts = parts_all.cpu().numpy().reshape(world, nw + 1)
+        status = 0
+        for flag in parts[:, nw]:
+            status |= -1 - int(flag)
+        merged = np.bitwise_or.reduce(parts[:, :nw].view(np.uint64), axis=0)
+        bits = np.unpackbits(merged.view(np.uint8).reshape(nw, 8), axis=1, bitorder="little").reshape(-1)
+        u = np.flatnonzero(bits[:ncells]).astype(np.int64)
+        return u, len(u), status
+
+    def compact_keys(self, handle, nvox):
+        return torch.from_numpy(handle[:nvox].copy())
+
     def _lookup(self, handle, k):
         if len(handle) == 0:
             return np.full((len(k),), -1, np.int64)
         pos = np.searchsorted(handle, k)
         return np.where((pos < len(handle)) & (handle[np.minimum(pos, len(handle) - 1)] == k), pos, -1).astype(np.int64)
 
-    def build_table(self, handle, keys_all, begin, n_local, nvox, c, reduction, agg, cnt, first_local):
+    def build_table(self, handle, keys_all, begin, n_local, nvox, c, reduction, agg, cnt, first_local, want_keys=True):
         k = keys_all.cpu().numpy()
         slot_all = self._lookup(handle, k)
         mean = int(reduction) == 1

@@ -56,7 +56,7 @@ def _free_port():
     return p
 
 
-def _gloo_worker(rank, world, port, reduction, q):
+def _gloo_worker(rank, world, port, reduction, exchange, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -65,7 +65,7 @@ def _gloo_worker(rank, world, port, reduction, q):
         cloud = _cloud(3000, 5)
         cuts = [0, 1100, 3000] if world == 2 else np.linspace(0, 3000, world + 1).astype(int).tolist()
         sl = slice(cuts[rank], cuts[rank + 1])
-        gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, ops=NumpyOps())
+        gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, ops=NumpyOps(), exchange=exchange)
         res = gen(torch.from_numpy(cloud[sl]))
         _check(res, cloud, sl, reduction)
         q.put((rank, "ok"))
@@ -76,12 +76,12 @@ def _gloo_worker(rank, world, port, reduction, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("reduction", ["mean", "max"])
-def test_sharded_orchestration_gloo_world2(reduction):
+@pytest.mark.parametrize("reduction,exchange", [("mean", "keys"), ("max", "bitmap"), ("mean", "bitmap")])
+def test_sharded_orchestration_gloo_world2(reduction, exchange):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, reduction, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, reduction, exchange, q)) for r in range(world)]
     [p.start() for p in procs]
     results = [q.get(timeout=180) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
@@ -89,8 +89,9 @@ def test_sharded_orchestration_gloo_world2(reduction):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,reduction", [(2, "mean"), (3, "min"), (4, "max"), (8, "mean")])
-def test_sharded_hip_kernels_virtual_ranks(world, reduction):
+@pytest.mark.parametrize("world,reduction,exchange", [(2, "mean", "keys"), (3, "min", "bitmap"), (4, "max", "keys"),
+                                                     (8, "mean", "bitmap"), (2, "mean", "auto")])
+def test_sharded_hip_kernels_virtual_ranks(world, reduction, exchange):
     from d3d_amd.voxel import VoxelGenerator
     from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
     cloud = _cloud(40000, 9)
@@ -102,7 +103,7 @@ def test_sharded_hip_kernels_virtual_ranks(world, reduction):
     def run(rank):
         try:
             torch.cuda.set_device(0)
-            gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, comm=tw.comm(rank),
+            gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, comm=tw.comm(rank), exchange=exchange,
                                         ops=LockedOps(HipOps(), lock))
             out[rank] = gen(torch.from_numpy(cloud[cuts[rank]:cuts[rank + 1]]).cuda())
         except Exception as e:  # pragma: no cover

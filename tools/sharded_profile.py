@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""per-kernel HIP-event timings of the sharded voxelizer's COMPUTE at world size W, emulated on one GPU with W virtual
+ranks (threads; collectives through shared memory) -- what every rank runs besides the RCCL collectives (development aid)"""
+import os, sys, threading
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from bench import kernel_profile
+from d3d_amd import synth
+from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
+from sharded_helpers import LockedOps, ThreadWorld
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+clouds = [torch.from_numpy(synth.lidar_like(n, r)).cuda() for r in range(W)]
+
+def step():
+    tw, lock = ThreadWorld(W), threading.Lock()
+    outs = [None] * W
+    def run(rank):
+        torch.cuda.set_device(0)
+        gen = ShardedVoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, reduction="mean", comm=tw.comm(rank),
+                                    ops=LockedOps(HipOps(), lock))
+        outs[rank] = gen(clouds[rank])
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    return outs
+
+outs = step()
+print("world", W, "points/rank", n, "global voxels", int(outs[0].coords.shape[0]))
+prof = kernel_profile(step, 3)
+tot = 0.0
+for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
+    per_rank = v["total_ms"] / 3 / W * 1e3
+    tot += per_rank
+    print("  %-36s %8.1f us per rank and step" % (k, per_rank))
+print("  total kernel time per rank and step: %.1f us (collectives not included)" % tot)
