@@ -42,7 +42,11 @@ SIGNATURES = {
     "d3d_grid_compact_workspace_bytes": (_sz, [_i64]),
     "d3d_grid_compact_index": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "d3d_grid_bitmap_mark": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
-    "d3d_grid_compact_from_bitmaps": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _sz, _vp]),
+    "d3d_grid_owner_workspace_bytes": (_sz, [_i64]),
+    "d3d_grid_compact_from_bitmaps": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _sz, _i32, _vp, _sz, _vp]),
+    "d3d_sharded_scatter_owned": (ctypes.c_int, [_vp, _i64, _i64, _vp, _sz, _vp, _sz, _i32, _i64, _i32, _i32, _vp, _vp, _vp,
+                                                 _i32, _vp, _vp, _vp, _sz, _vp]),
+    "d3d_sharded_finalize_owned": (ctypes.c_int, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "d3d_grid_compact_keys": (ctypes.c_int, [_i64, _vp, _sz, _vp, _vp]),
     "d3d_grid_compact_lookup": (ctypes.c_int, [_vp, _i64, _i64, _vp, _sz, _i64, _vp, _vp]),
     "d3d_aligned_scatter_forward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _vp, _vp]),

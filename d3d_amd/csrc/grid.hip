@@ -6,6 +6,7 @@
 // bitmap is built locally.
 #include "common.hpp"
 #include <cstdint>
+#include <algorithm>
 
 namespace {
 
@@ -21,14 +22,53 @@ __global__ __launch_bounds__(256) void k_grid_mark(const int64_t *__restrict__ k
 
 // ---- bitmap exchange (grids whose bitmap is smaller than the key lists): every rank marks its own cells, the bitmaps
 // are all-gathered and OR-ed here -- a streaming pass instead of one atomic per gathered key
+constexpr int kMaxOwnerWorld = 16;   // ranks for which the ownership bookkeeping below is kept in registers
+constexpr int kOwnerStride = 16;     // u64 words between the per-rank counters (own cache line each)
+
+// OR of the ranks' bitmaps.  A cell is OWNED by the lowest rank that has it -- that rank holds the voxel's first point,
+// because shards are contiguous point ranges in rank order.  With `lower` (this rank's view: cells some lower rank has)
+// and `newc` (cells owned per rank) the global first-seen numbering needs no exchange of first indices (see
+// OwnedRows below).  Grid-stride; one atomic per workgroup and rank, on separate cache lines.
 __global__ __launch_bounds__(256) void k_grid_or(const unsigned long long *__restrict__ parts, int64_t stride_words, int world,
-                                                 int64_t nw, unsigned long long *__restrict__ bitmap)
+                                                 int64_t nw, unsigned long long *__restrict__ bitmap, int rank,
+                                                 unsigned long long *__restrict__ lower, unsigned long long *newc)
 {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nw) return;
-    unsigned long long x = 0;
-    for (int r = 0; r < world; r++) x |= parts[(int64_t)r * stride_words + w];
-    bitmap[w] = x;
+    __shared__ unsigned int part[256 / kWave][kMaxOwnerWorld];
+    unsigned int mine[kMaxOwnerWorld];
+#pragma unroll
+    for (int q = 0; q < kMaxOwnerWorld; q++) mine[q] = 0;
+    const bool own = newc != nullptr;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long acc = 0;
+        if (own) {
+#pragma unroll
+            for (int q = 0; q < kMaxOwnerWorld; q++) {
+                if (q < world) {
+                    const unsigned long long x = parts[(int64_t)q * stride_words + w];
+                    if (q == rank) lower[w] = acc;
+                    mine[q] += (unsigned int)__popcll(x & ~acc);
+                    acc |= x;
+                }
+            }
+        } else {
+            for (int q = 0; q < world; q++) acc |= parts[(int64_t)q * stride_words + w];
+        }
+        bitmap[w] = acc;
+    }
+    if (!own) return;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < kMaxOwnerWorld; q++) {
+        unsigned int v = mine[q];
+        for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+        if (lane == 0) part[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)world && threadIdx.x < (unsigned)kMaxOwnerWorld) {
+        unsigned int t = 0;
+        for (int k = 0; k < 256 / kWave; k++) t += part[k][threadIdx.x];
+        if (t) atomicAdd(&newc[threadIdx.x * kOwnerStride], (unsigned long long)t);
+    }
 }
 
 // key_of_slot by enumerating the set bits: slot = prefix[word] + index of the bit within the word
@@ -153,6 +193,87 @@ __global__ __launch_bounds__(256) void k_sharded_finalize(int64_t nvox, int c, c
     }
 }
 
+// ---- numbering by ownership (bitmap exchange): the voxels a rank owns, in the rank's local first-seen order, are a
+// contiguous run of the global first-seen order; runs follow each other in rank order.  So
+//   voxel id = (cells owned by lower ranks) + (owned voxels before it in local order)
+// -- a scan over the rank's own voxels.  The owner writes the id into an extra column of the table, whose all-reduce
+// (sum: the others add 0; max / min: the others hold the identity) hands it to everybody: no exchange of first
+// indices, no bitmap over the frame's points.  Ids are exact in fp32 below 2^24 voxels (host-checked).
+struct OwnedRows {
+    static constexpr const char *kName = "k_scan_count<OwnedRows>", *kName2 = "k_scan_apply<OwnedRows>";
+    const int64_t *keys;              // [n_local] linear cell per local voxel, -1 beyond the rank's voxels
+    int64_t ncells;
+    const unsigned long long *bitmap; // merged occupancy + prefix: slot of a cell
+    const uint32_t *prefix;
+    const unsigned long long *lower;  // cells some lower rank has
+    const unsigned long long *newc;   // cells owned per rank (stride kOwnerStride)
+    int rank, c, with_count, tstride;
+    const float *agg;
+    const int32_t *cnt;
+    float *table;
+    int32_t *cnt_table;
+    int64_t *slot_of_local;
+    __device__ __forceinline__ unsigned long long value(int64_t v) const
+    {
+        const int64_t k = keys[v];
+        if (k < 0 || k >= ncells) return 0;
+        return (lower[k >> 6] >> (k & 63)) & 1ull ? 0ull : 1ull;
+    }
+    __device__ __forceinline__ unsigned long long value2(int64_t v) const { return value(v); }
+    __device__ __forceinline__ void apply(int64_t v, unsigned long long owned, unsigned long long excl) const
+    {
+        const int64_t k = keys[v];
+        const long long s = compact_rank(k, ncells, bitmap, prefix);
+        slot_of_local[v] = s;
+        if (s < 0) return;
+        float *row = table + s * tstride;
+        for (int d = 0; d < c; d++) row[d] = agg[v * c + d];
+        if (with_count) row[c] = (float)cnt[v];       // counts < 2^24 are exact in fp32
+        else cnt_table[s] = cnt[v];
+        if (owned) {
+            unsigned long long base = 0;
+            for (int q = 0; q < rank; q++) base += newc[q * kOwnerStride];
+            row[tstride - 1] = (float)(base + excl);
+        }
+    }
+};
+
+// table[nvox, tstride] <- identity (the id column too), cnt_table <- 0
+__global__ __launch_bounds__(256) void k_sharded_fill_owned(int64_t nvox, int tstride, float identity, float *table,
+                                                            int32_t *cnt_table)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nvox * tstride) table[i] = identity;
+    if (i < nvox && cnt_table) cnt_table[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_sharded_finalize_owned(int64_t nvox, int c, const int64_t *__restrict__ key_of_slot,
+                                                                const float *__restrict__ table, int tstride, int mean,
+                                                                const int32_t *__restrict__ cnt_in, int64_t sy, int64_t sz,
+                                                                int64_t *vid_of_slot, int64_t *coords, int32_t *cnt_out,
+                                                                float *feats, bool vec4)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nvox) return;
+    const float *row = table + s * tstride;
+    const int64_t v = (int64_t)(row[tstride - 1] + 0.5f);
+    vid_of_slot[s] = v;
+    if (v < 0 || v >= nvox) return;                     // cannot happen: every slot has exactly one owner
+    const int64_t k = key_of_slot[s];
+    coords[v * 3 + 0] = k / (sy * sz);
+    coords[v * 3 + 1] = (k / sz) % sy;
+    coords[v * 3 + 2] = k % sz;
+    const float n = mean ? row[c] : 1.f;
+    cnt_out[v] = mean ? (int32_t)(n + 0.5f) : cnt_in[s];
+    if (c == 4 && vec4) {
+        float4 f = make_float4(row[0], row[1], row[2], row[3]);
+        if (mean) f = make_float4(f.x / n, f.y / n, f.z / n, f.w / n);
+        reinterpret_cast<float4 *>(feats)[v] = f;
+    } else {
+        for (int d = 0; d < c; d++) feats[v * c + d] = mean ? row[d] / n : row[d];
+    }
+}
+
 // global voxel id of each local point: local voxel -> slot -> voxel id
 __global__ __launch_bounds__(256) void k_sharded_map(int64_t n, const int64_t *__restrict__ local_map,
                                                      const int64_t *__restrict__ slot_of_local, int64_t nvox,
@@ -212,8 +333,15 @@ extern "C" int d3d_grid_bitmap_mark(const int64_t *keys, int64_t m, int64_t ncel
 // bitmap exchange, step 2: OR of the `world` all-gathered bitmaps (rank r at parts + r * stride_words) into the compact
 // index of `workspace` (as d3d_grid_compact_index does from key lists); counts[0] = distinct occupied cells; optionally
 // key_of_slot[counts[0]] (cells in ascending order).
+extern "C" size_t d3d_grid_owner_workspace_bytes(int64_t ncells)
+{
+    if (ncells < 1) ncells = 1;
+    return d3d_align_up((size_t)d3d_divup(ncells, 64) * 8) + d3d_align_up((size_t)kMaxOwnerWorld * kOwnerStride * 8) + 256;
+}
+
 extern "C" int d3d_grid_compact_from_bitmaps(const unsigned long long *parts, int64_t stride_words, int32_t world, int64_t ncells,
-                                             int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
+                                             int64_t *counts, void *workspace, size_t workspace_bytes, int32_t rank,
+                                             void *owner_ws, size_t owner_ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (world < 1 || ncells <= 0 || !counts || !parts) return D3D_ERR_BAD_ARG;
@@ -225,8 +353,18 @@ extern "C" int d3d_grid_compact_from_bitmaps(const unsigned long long *parts, in
     uint32_t *prefix = w.take<uint32_t>(nw);
     unsigned long long *bsum = w.take<unsigned long long>(d3d_divup(nw, kScanTile) + 1);
     if (!workspace || !w.ok()) return D3D_ERR_WORKSPACE;
-    D3D_LAUNCH("k_grid_or", k_grid_or, dim3((unsigned)d3d_divup(nw, 256)), dim3(256), 0, st, parts, stride_words, (int)world, nw,
-               bitmap);
+    unsigned long long *lower = nullptr, *newc = nullptr;
+    if (owner_ws) {                                  // ownership bookkeeping for d3d_sharded_scatter_owned
+        if (world > kMaxOwnerWorld || rank < 0 || rank >= world) return D3D_ERR_UNSUPPORTED;
+        WsCarver ow(owner_ws, owner_ws_bytes);
+        lower = ow.take<unsigned long long>(nw);
+        newc = ow.take<unsigned long long>(kMaxOwnerWorld * kOwnerStride);
+        if (!ow.ok()) return D3D_ERR_WORKSPACE;
+        D3D_HIP_CHECK(hipMemsetAsync(newc, 0, (size_t)kMaxOwnerWorld * kOwnerStride * 8, st));
+    }
+    const unsigned nblk = (unsigned)std::min<int64_t>(d3d_divup(nw, 256), 1024);
+    D3D_LAUNCH("k_grid_or", k_grid_or, dim3(nblk), dim3(256), 0, st, parts, stride_words, (int)world, nw, bitmap, (int)rank, lower,
+               newc);
     PopcountWords f{bitmap, prefix};
     return d3d_run_scan(f, nw, bsum, counts, -1, 0, ~0ull, st);
 }
@@ -314,6 +452,55 @@ extern "C" int d3d_sharded_finalize(int64_t nvox, int32_t c, const int64_t *firs
                n_total > 0 ? n_total : (int64_t)1, bitmap, prefix, key_of_slot, table, table_stride, mean, cnt_in,
                (int64_t)shape[1], (int64_t)shape[2], vid_of_slot, coords, cnt_out, feats,
                (reinterpret_cast<uintptr_t>(feats) & 15) == 0);
+    return D3D_OK;
+}
+
+extern "C" int d3d_sharded_scatter_owned(const int64_t *keys_local, int64_t n_local, int64_t ncells, const void *compact_ws,
+                                         size_t compact_ws_bytes, const void *owner_ws, size_t owner_ws_bytes, int32_t rank,
+                                         int64_t nvox, int32_t c, int32_t reduction, const float *agg, const int32_t *cnt,
+                                         float *table, int32_t table_stride, int32_t *cnt_table, int64_t *slot_of_local,
+                                         void *scan_ws, size_t scan_ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n_local < 0 || nvox < 0 || ncells <= 0 || c < 1 || rank < 0 || rank >= kMaxOwnerWorld) return D3D_ERR_BAD_ARG;
+    if (reduction != D3D_REDUCE_MEAN && reduction != D3D_REDUCE_MAX && reduction != D3D_REDUCE_MIN) return D3D_ERR_UNSUPPORTED;
+    if (nvox >= (1ll << 24)) return D3D_ERR_UNSUPPORTED;              // ids travel in an fp32 column
+    const bool mean = reduction == D3D_REDUCE_MEAN;
+    if (table_stride < c + (mean ? 2 : 1)) return D3D_ERR_BAD_ARG;
+    if (nvox > 0 && (!table || (!mean && !cnt_table))) return D3D_ERR_BAD_ARG;
+    if (n_local > 0 && (!keys_local || !agg || !cnt || !slot_of_local)) return D3D_ERR_BAD_ARG;
+    const int64_t nw = d3d_divup(ncells, 64);
+    WsCarver w((void *)compact_ws, compact_ws_bytes);
+    unsigned long long *bitmap = w.take<unsigned long long>(nw);
+    uint32_t *prefix = w.take<uint32_t>(nw);
+    WsCarver ow((void *)owner_ws, owner_ws_bytes);
+    unsigned long long *lower = ow.take<unsigned long long>(nw);
+    unsigned long long *newc = ow.take<unsigned long long>(kMaxOwnerWorld * kOwnerStride);
+    WsCarver sw(scan_ws, scan_ws_bytes);
+    unsigned long long *bsum = sw.take<unsigned long long>(d3d_divup(n_local > 0 ? n_local : 1, kScanTile) + 1);
+    int64_t *scratch_counts = sw.take<int64_t>(D3D_NUM_COUNTS);
+    if (!compact_ws || !owner_ws || !scan_ws || !w.ok() || !ow.ok() || !sw.ok()) return D3D_ERR_WORKSPACE;
+    const float identity = mean ? 0.f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+    if (nvox > 0)
+        D3D_LAUNCH("k_sharded_fill_owned", k_sharded_fill_owned, dim3((unsigned)d3d_divup(nvox * table_stride, 256)), dim3(256), 0,
+                   st, nvox, table_stride, identity, table, mean ? nullptr : cnt_table);
+    if (n_local == 0) return D3D_OK;
+    OwnedRows f{keys_local, ncells, bitmap, prefix, lower, newc, (int)rank, (int)c, mean ? 1 : 0, (int)table_stride,
+                agg, cnt, table, cnt_table, slot_of_local};
+    return d3d_run_scan(f, n_local, bsum, scratch_counts, -1, 0, ~0ull, st);
+}
+
+extern "C" int d3d_sharded_finalize_owned(int64_t nvox, int32_t c, const int64_t *key_of_slot, const float *table,
+                                          int32_t table_stride, int32_t mean, const int32_t *cnt_in, const int32_t *shape,
+                                          int64_t *vid_of_slot, int64_t *coords, int32_t *cnt_out, float *feats, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (nvox < 0 || c < 1 || !shape) return D3D_ERR_BAD_ARG;
+    if (nvox == 0) return D3D_OK;
+    if (!key_of_slot || !table || !vid_of_slot || !coords || !cnt_out || !feats || (!mean && !cnt_in)) return D3D_ERR_BAD_ARG;
+    D3D_LAUNCH("k_sharded_finalize_owned", k_sharded_finalize_owned, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox, c,
+               key_of_slot, table, table_stride, mean, cnt_in, (int64_t)shape[1], (int64_t)shape[2], vid_of_slot, coords,
+               cnt_out, feats, (reinterpret_cast<uintptr_t>(feats) & 15) == 0);
     return D3D_OK;
 }
 

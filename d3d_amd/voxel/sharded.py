@@ -32,6 +32,7 @@ from ..utils import Dict
 _REDUCTIONS = {"MEAN": 1, "MAX": 2, "MIN": 3}
 _SUM = 4
 _I64_MAX = (1 << 63) - 1
+_MAX_OWNER_WORLD = 16      # kMaxOwnerWorld of grid.hip
 
 
 class TorchComm:
@@ -136,27 +137,68 @@ class HipOps:
             part[nw:] = keys[n:n + 1]
         return part
 
-    def compact_from_bitmaps(self, parts_all, world, ncells):
+    def compact_from_bitmaps(self, parts_all, world, ncells, rank=None):
         """-> (handle, number of occupied cells, status bits OR-ed over the ranks) from the all-gathered bitmaps;
-        the host read-back of a sharded call in bitmap mode"""
+        the host read-back of a sharded call in bitmap mode.  With `rank` the handle also carries the ownership
+        bookkeeping (cells a lower rank has, cells owned per rank) that build_table_owned needs."""
         lib = _lib.load()
         dev = parts_all.device
         nw = (int(ncells) + 63) // 64
         with torch.cuda.device(dev):
             ws = torch.empty((lib.d3d_grid_compact_workspace_bytes(ncells),), dtype=torch.uint8, device=dev)
+            ows = None
+            if rank is not None:
+                ows = torch.empty((lib.d3d_grid_owner_workspace_bytes(ncells),), dtype=torch.uint8, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
             rc = lib.d3d_grid_compact_from_bitmaps(_lib.ptr(parts_all), nw + 1, int(world), int(ncells), _lib.ptr(counts),
-                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                                                   _lib.ptr(ws), ws.numel(), int(rank or 0), _lib.ptr(ows),
+                                                   ows.numel() if ows is not None else 0, _lib.stream_ptr())
             _lib.check(rc, "grid_compact_from_bitmaps")
             host = torch.cat([counts[:1], parts_all[nw::nw + 1]]).tolist()
         status = 0
         for flag in host[1:]:
             status |= -1 - int(flag)
-        return (ws, int(ncells)), int(host[0]), status
+        return (ws, int(ncells), ows), int(host[0]), status
+
+    def build_table_owned(self, handle, keys_local, n_local, nvox, c, reduction, agg, cnt, rank):
+        """identity-filled all-reduce operand with this rank's partial rows in place and, for the voxels this rank owns,
+        the global voxel id in the last column: -> table[nvox, c + 2 | c + 1], cnt_table[nvox] | None, slot_of_local"""
+        lib = _lib.load()
+        ws, ncells, ows = handle
+        dev = keys_local.device
+        mean = int(reduction) == 1
+        with torch.cuda.device(dev):
+            table = torch.empty((nvox, c + 2 if mean else c + 1), dtype=torch.float32, device=dev)
+            cnt_t = None if mean else torch.empty((nvox,), dtype=torch.int32, device=dev)
+            slot = torch.empty((n_local,), dtype=torch.int64, device=dev)
+            sws = torch.empty(((n_local // 1024 + 2) * 8 + 1024,), dtype=torch.uint8, device=dev)
+            rc = lib.d3d_sharded_scatter_owned(_lib.ptr(keys_local), int(n_local), ncells, _lib.ptr(ws), ws.numel(),
+                                               _lib.ptr(ows), ows.numel(), int(rank), int(nvox), int(c), int(reduction),
+                                               _lib.ptr(agg), _lib.ptr(cnt), _lib.ptr(table), table.shape[1], _lib.ptr(cnt_t),
+                                               _lib.ptr(slot), _lib.ptr(sws), sws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "sharded_scatter_owned")
+        return table, cnt_t, slot
+
+    def finalize_owned(self, nvox, c, key_of_slot, table, mean, cnt_in, shape):
+        """slot-ordered reduced table (id in the last column) -> voxel-id-ordered (coords, counts, features) + vid_of_slot"""
+        lib = _lib.load()
+        dev = table.device
+        shape_h = (ctypes.c_int32 * 3)(*[int(x) for x in shape])
+        with torch.cuda.device(dev):
+            coords = torch.empty((nvox, 3), dtype=torch.int64, device=dev)
+            cnt = torch.empty((nvox,), dtype=torch.int32, device=dev)
+            feats = torch.empty((nvox, c), dtype=torch.float32, device=dev)
+            vid = torch.empty((nvox,), dtype=torch.int64, device=dev)
+            rc = lib.d3d_sharded_finalize_owned(nvox, c, _lib.ptr(key_of_slot), _lib.ptr(table), table.shape[1],
+                                                1 if mean else 0, _lib.ptr(cnt_in), ctypes.cast(shape_h, ctypes.c_void_p),
+                                                _lib.ptr(vid), _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(feats),
+                                                _lib.stream_ptr())
+            _lib.check(rc, "sharded_finalize_owned")
+        return coords, cnt, feats, vid
 
     def compact_keys(self, handle, nvox):
         lib = _lib.load()
-        ws, ncells = handle
+        ws, ncells = handle[0], handle[1]
         with torch.cuda.device(ws.device):
             key_of_slot = torch.empty((nvox,), dtype=torch.int64, device=ws.device)
             rc = lib.d3d_grid_compact_keys(ncells, _lib.ptr(ws), ws.numel(), _lib.ptr(key_of_slot), _lib.stream_ptr())
@@ -167,7 +209,7 @@ class HipOps:
         """identity-filled all-reduce operands with this rank's partial rows in place:
         -> table[nvox, c(+1)], cnt_table[nvox] (None for mean), first[nvox], key_of_slot[nvox], slot_of_local[n_local]"""
         lib = _lib.load()
-        ws, ncells = handle
+        ws, ncells = handle[0], handle[1]
         dev = keys_all.device
         mean = int(reduction) == 1
         with torch.cuda.device(dev):
@@ -289,7 +331,10 @@ class ShardedVoxelGenerator:
             #     one atomic per gathered key, and the keys of the slots fall out of the merged bitmap
             part = ops.bitmap_mark(keys_r, n, self._ncells)
             parts_all = comm.all_gather_var(part, [nw + 1] * comm.world)
-            handle, nvox, status = ops.compact_from_bitmaps(parts_all, comm.world, self._ncells)
+            owned = comm.world <= _MAX_OWNER_WORLD
+            handle, nvox, status = ops.compact_from_bitmaps(parts_all, comm.world, self._ncells,
+                                                            rank=comm.rank if owned else None)
+            owned = owned and nvox < (1 << 24)         # voxel ids travel in an fp32 column of the table
         else:
             # 2. all-gather the occupied-cell keys (+ status row), padded to the largest shard
             pad = keys_r if n == cap else torch.cat([keys_r[:n], keys_r.new_full((cap - n,), -1), keys_r[n:]])
@@ -301,6 +346,18 @@ class ShardedVoxelGenerator:
         if status & _lib.STATUS_PACK_OVERFLOW and not plain:
             return None        # some rank hit the packed-slot counter limit (rare): all ranks redo with plain slots
         # 4. all-reduce the compact voxel table
+        if bitmap_mode and owned:
+            # numbering by ownership: the lowest rank that has a cell holds its first point, so the voxel ids follow from
+            # the bitmaps and every rank's local order; they ride in an extra column of the table -- no first-index exchange
+            key_of_slot = ops.compact_keys(handle, nvox)
+            table, cnt_t, slot_r = ops.build_table_owned(handle, keys_r[:n], n, nvox, c, self._red, agg_r, cnt_r, comm.rank)
+            if nvox > 0:
+                comm.all_reduce(table, "sum" if mean else ("max" if self._red == 2 else "min"))
+                if cnt_t is not None:
+                    comm.all_reduce(cnt_t, "sum")
+            coords, out_cnt, out_feats, vid_of_slot = ops.finalize_owned(nvox, c, key_of_slot, table, mean, cnt_t, self._shape)
+            gmap = ops.compose_map(map_r, slot_r, nvox, vid_of_slot)
+            return Dict(coords=coords, voxel_npoints=out_cnt, aggregates=out_feats, points_mapping=gmap)
         if bitmap_mode:
             key_of_slot = ops.compact_keys(handle, nvox)
             table, cnt_t, first, _, slot_r = ops.build_table(handle, keys_r[:n], 0, n, nvox, c, self._red, agg_r, cnt_r,

@@ -146,12 +146,32 @@ int d3d_grid_compact_lookup(const int64_t *keys, int64_t m, int64_t ncells, cons
 /* The same index from all-gathered occupancy BITMAPS instead of key lists (for grids whose bitmap, ncells / 8 bytes, is
  * smaller than the key lists: an OR pass replaces one atomic per gathered key): bitmap_mark = this rank's bitmap
  * (ceil(ncells/64) words); compact_from_bitmaps = OR of `world` bitmaps (rank r at parts + r * stride_words) + prefix,
- * counts[0] = distinct cells; compact_keys = the cell of every slot, ascending (key_of_slot[counts[0]]). */
+ * counts[0] = distinct cells; compact_keys = the cell of every slot, ascending (key_of_slot[counts[0]]).
+ * With owner_ws (d3d_grid_owner_workspace_bytes; world <= 16) compact_from_bitmaps also records, for `rank`, which
+ * cells a lower rank has and how many cells every rank OWNS (a cell belongs to the lowest rank that has it -- the rank
+ * holding the voxel's first point, shards being contiguous point ranges in rank order). */
 int d3d_grid_bitmap_mark(const int64_t *keys, int64_t m, int64_t ncells, unsigned long long *bitmap, void *stream);
+size_t d3d_grid_owner_workspace_bytes(int64_t ncells);
 int d3d_grid_compact_from_bitmaps(const unsigned long long *parts, int64_t stride_words, int32_t world, int64_t ncells,
-                                  int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+                                  int64_t *counts, void *workspace, size_t workspace_bytes, int32_t rank,
+                                  void *owner_ws, size_t owner_ws_bytes, void *stream);
 int d3d_grid_compact_keys(int64_t ncells, const void *workspace, size_t workspace_bytes, int64_t *key_of_slot,
                           void *stream);
+
+/* Numbering by ownership (bitmap exchange, nvox < 2^24): the voxels a rank owns, in its local first-seen order, are a
+ * contiguous run of the global first-seen order, and the runs follow each other in rank order.  scatter_owned writes the
+ * reduction's identity into table[nvox, table_stride] (MEAN: c sums + count + id column; else c extrema + id column,
+ * counts in cnt_table), then this rank's partial rows at their slots and, for the voxels it owns, the global voxel id
+ * in the LAST column; slot_of_local[n_local].  scan_ws: (ceil(n_local/1024) + 2) * 8 + 1024 bytes.  After the all-reduce of
+ * the table (same op as the features) finalize_owned reads the id from that column: no exchange of first indices. */
+int d3d_sharded_scatter_owned(const int64_t *keys_local, int64_t n_local, int64_t ncells, const void *compact_ws,
+                              size_t compact_ws_bytes, const void *owner_ws, size_t owner_ws_bytes, int32_t rank,
+                              int64_t nvox, int32_t c, int32_t reduction, const float *agg, const int32_t *cnt,
+                              float *table, int32_t table_stride, int32_t *cnt_table, int64_t *slot_of_local,
+                              void *scan_ws, size_t scan_ws_bytes, void *stream);
+int d3d_sharded_finalize_owned(int64_t nvox, int32_t c, const int64_t *key_of_slot, const float *table,
+                               int32_t table_stride, int32_t mean, const int32_t *cnt_in, const int32_t *shape,
+                               int64_t *vid_of_slot, int64_t *coords, int32_t *cnt_out, float *feats, void *stream);
 
 /* Steps of the sharded voxelizer around the two all-reduces (no host synchronisation).
  * scatter: keys_all[m] = all-gathered key lists (negative = padding / status rows), already indexed by

@@ -61,19 +61,65 @@ class NumpyOps:
         words = np.packbits(bits.reshape(nw, 64), axis=1, bitorder="little").view("<u8").reshape(nw)
         return torch.from_numpy(np.concatenate([words.view(np.int64), k[n:n + 1]]))
 
-    def compact_from_bitmaps(self, parts_all, world, ncells):
+    def compact_from_bitmaps(self, parts_all, world, ncells, rank=None):
         nw = (int(ncells) + 63) // 64
         parts = parts_all.cpu().numpy().reshape(world, nw + 1)
         status = 0
         for flag in parts[:, nw]:
             status |= -1 - int(flag)
-        merged = np.bitwise_or.reduce(parts[:, :nw].view(np.uint64), axis=0)
-        bits = np.unpackbits(merged.view(np.uint8).reshape(nw, 8), axis=1, bitorder="little").reshape(-1)
-        u = np.flatnonzero(bits[:ncells]).astype(np.int64)
-        return u, len(u), status
+        words = np.ascontiguousarray(parts[:, :nw]).view(np.uint64)
+        bits = np.unpackbits(words.view(np.uint8).reshape(world, nw, 8), axis=2, bitorder="little").reshape(world, -1)[:, :ncells]
+        u = np.flatnonzero(bits.any(0)).astype(np.int64)
+        if rank is None:
+            return u, len(u), status
+        seen = np.zeros((ncells,), bool)
+        newc, lower = [], None
+        for q in range(world):
+            if q == rank:
+                lower = seen.copy()
+            newc.append(int(np.sum(bits[q].astype(bool) & ~seen)))
+            seen |= bits[q].astype(bool)
+        return dict(keys=u, lower=lower, newc=newc), len(u), status
 
     def compact_keys(self, handle, nvox):
-        return torch.from_numpy(handle[:nvox].copy())
+        keys = handle["keys"] if isinstance(handle, dict) else handle
+        return torch.from_numpy(keys[:nvox].copy())
+
+    def build_table_owned(self, handle, keys_local, n_local, nvox, c, reduction, agg, cnt, rank):
+        k = keys_local.cpu().numpy()[:n_local]
+        slot = self._lookup(handle["keys"], k)
+        mean = int(reduction) == 1
+        ident = 0.0 if mean else (-np.inf if int(reduction) == 2 else np.inf)
+        table = np.full((nvox, c + 2 if mean else c + 1), ident, np.float32)
+        cnt_t = None if mean else np.zeros((nvox,), np.int32)
+        mine = slot >= 0
+        owned = mine & ~handle["lower"][np.where(mine, k, 0)]
+        vid = sum(handle["newc"][:rank]) + np.cumsum(owned) - owned          # exclusive scan in local order
+        table[slot[mine], :c] = agg.numpy()[:n_local][mine]
+        if mean:
+            table[slot[mine], c] = cnt.numpy()[:n_local][mine].astype(np.float32)
+        else:
+            cnt_t[slot[mine]] = cnt.numpy()[:n_local][mine]
+        table[slot[owned], -1] = vid[owned].astype(np.float32)
+        t = torch.from_numpy
+        return t(table), (None if mean else t(cnt_t)), t(slot)
+
+    def finalize_owned(self, nvox, c, key_of_slot, table, mean, cnt_in, shape):
+        t = table.numpy()[:nvox]
+        vid = np.round(t[:, -1]).astype(np.int64)
+        k = key_of_slot.numpy()[:nvox]
+        sy, sz = shape[1], shape[2]
+        coords = np.empty((nvox, 3), np.int64)
+        coords[vid] = np.stack([k // (sy * sz), (k // sz) % sy, k % sz], 1)
+        cnt = np.empty((nvox,), np.int32)
+        feats = np.empty((nvox, c), np.float32)
+        if mean:
+            cnt[vid] = np.round(t[:, c]).astype(np.int32)
+            feats[vid] = t[:, :c] / t[:, c:c + 1]
+        else:
+            cnt[vid] = cnt_in.numpy()[:nvox]
+            feats[vid] = t[:, :c]
+        return torch.from_numpy(coords), torch.from_numpy(cnt), torch.from_numpy(feats), torch.from_numpy(vid)
 
     def _lookup(self, handle, k):
         if len(handle) == 0:
