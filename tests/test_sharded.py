@@ -90,13 +90,17 @@ def test_sharded_orchestration_gloo_world2(reduction, exchange):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,reduction,exchange", [(2, "mean", "keys"), (3, "min", "bitmap"), (4, "max", "keys"),
-                                                     (8, "mean", "bitmap"), (2, "mean", "auto")])
+                                                     (8, "mean", "bitmap"), (2, "mean", "auto"), (3, "mean", "bitmap-empty"),
+                                                     (3, "max", "keys-empty")])
 def test_sharded_hip_kernels_virtual_ranks(world, reduction, exchange):
     from d3d_amd.voxel import VoxelGenerator
     from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
     cloud = _cloud(40000, 9)
     cuts = np.linspace(0, len(cloud), world + 1).astype(int)
     cuts[1] = max(cuts[1] // 3, 1)                      # ragged shards
+    if exchange.endswith("-empty"):                     # ... and a rank without any point
+        exchange = exchange.split("-")[0]
+        cuts[2] = cuts[1]
     tw, lock = ThreadWorld(world), threading.Lock()
     out, errs = [None] * world, []
 
