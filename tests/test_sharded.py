@@ -45,7 +45,7 @@ def _check(res, cloud_all, my_slice, reduction):
     lo = np.array([0, -40, -3], np.float32)
     cc = ((pts[inside, :3] - lo) / np.array(size, np.float32)).astype(np.int64)
     assert np.array_equal(exp["coords"][m[inside]], cc)
-    assert inside.sum() > 0 and (~inside).sum() > 0      # the test cloud has in- and out-of-range points
+    assert len(m) == 0 or (inside.sum() > 0 and (~inside).sum() > 0)   # in- and out-of-range points (unless the shard is empty)
 
 
 def _free_port():
