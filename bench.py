@@ -109,7 +109,7 @@ def cpu_baseline_voxel(cloud, bounds, shape, max_points, max_voxels):
     fn()
     dt = time.perf_counter() - t0
     runs = 1
-    while dt < 8.0 and runs < 3:       # bounded: about 10 s of CPU work
+    while dt < 10.0 and runs < 64:     # bounded sample: about 10 s of CPU work on one core
         t1 = time.perf_counter()
         fn()
         dt += time.perf_counter() - t1
