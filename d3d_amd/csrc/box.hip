@@ -2,16 +2,16 @@
 // for MI355X (gfx950).  Replaces reference d3d/box/iou.cpp + iou_cuda.cu (forward),
 // d3d/box/nms.cpp + nms_cuda.cu, and the Cython pair loop over d3d/dgal_wrap.h.
 //
-//  * IoU matrix: 2-D tiling, the row boxes of a tile are expanded once into LDS (BoxGeom:
-//    trig, corners, AABB, area), every lane owns one column box in registers and walks the
-//    tile's rows, so stores to ious[i, j..j+63] are coalesced row-major (the reference's
-//    kernel strides lanes along i and stores with stride M, iou_cuda.cu:22-27) and pair
-//    indices are 64-bit (reference overflows int at N*M >= 2^31, iou_cuda.cu:36,137).
-//  * NMS: 64x64 tiles of the score-sorted "IoU > thr" bit matrix (one 64-bit word per lane =
-//    one wavefront-wide row segment), then ONE workgroup sweeps the sorted order: the
-//    64x64 diagonal block is resolved by a wavefront with lane broadcasts, and the rows of
-//    the kept boxes are OR-ed into an LDS-resident removal bitmap by all 16 wavefronts
-//    (the reference runs this on a single thread: nms_cuda.cu:80-107 <<<1,1>>>).
+//  * IoU matrix: every box is expanded once (BoxGeom: trig, corners, AABB, area; + a conservative fp32 AABB).
+//    k_iou_pre streams the zeros of the matrix at HBM write speed and, interleaved with that, lists the pairs whose
+//    AABBs overlap; k_iou_clip computes the exact IoU of one listed pair per lane.  Stores are row-major and
+//    coalesced (the reference's kernel strides lanes along i and stores with stride M, iou_cuda.cu:22-27), pair
+//    indices are 64-bit (reference overflows int at N*M >= 2^31, iou_cuda.cu:36,137).  k_iou2d is the single-kernel
+//    form (no workspace, or list overflow).
+//  * NMS: sweep-and-prune broad phase over the score-sorted boxes' AABBs -> candidate list -> exact IoU -> incoming
+//    hit lists -> the greedy result as a fixed point, resolved in one launch.  The reference's structure -- all-pairs
+//    "IoU > thr" bit matrix + a sweep of the sorted order (nms_cuda.cu:80-107 runs that on ONE thread) -- is kept as
+//    the dense path behind a device-side flag.
 #include "common.hpp"
 #include "geom.hpp"
 #include <stdlib.h>

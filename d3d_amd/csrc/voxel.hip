@@ -5,14 +5,20 @@
 //            64-bit word {count | cell key | first point index}: the first arrival claims + counts + records
 //            itself with a single CAS, later arrivals need a single atomicAdd (which also returns their
 //            arrival position and the current `first`, so the rare "I am smaller" fix-up costs nothing
-//            in the common case).  Scattered device-scope atomics are the scarce resource (~20 G/s).
+//            in the common case).  Scattered 8-byte requests are the scarce resource (~26 G/s, whatever the
+//            operation, scope or table size: tools/atomic_bench.hip).  Dense contract: key = linear cell of the
+//            grid; sparse contract: linear cell inside the frame's bounding box, which k_bbox finds on the device.
+//            Two-word slots (63-bit keys) when a field of the word overflows.
 //   number   the reference numbers voxels by first occurrence (voxelize.cpp:119,317).  Two coalesced sweeps
 //            over the table: flag[first] = 1, prefix-popcount of the flags = voxel id; the same sweeps
 //            allocate every voxel's index segment (scan of the counts in slot order).  No sort.
 //   rank     scatter indices by arrival position, then rank = number of smaller indices in the segment
-//            (early exit at max_points): exact point order without sorting or atomic chains.
-//   fill     streaming write of voxels[V,P,C] (the HBM-roofline kernel) fused with pmask and the
-//            per-voxel reduction (sequential in point order through wave shuffles -> bit-exact MEAN).
+//            (early exit at max_points): exact point order without sorting or atomic chains; the points
+//            themselves are staged next to their rank (C == 4).
+//   meta     one lane per voxel: coords, count, pmask row and the reduction over the staged rows,
+//            sequentially in point order -> bit-exact MEAN; overflow voxels through a work list.
+//   fill     streaming write of voxels[V,P,C] from the staged rows (the HBM-roofline kernel).
+//   filter   (sparse contract) scans over voxels and points; TRIM ranks the overflow voxels' points densely.
 //
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off (IEEE div, no FMA contraction:
 // voxel coordinates must round exactly like the reference's CPU code).
