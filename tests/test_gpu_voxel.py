@@ -275,3 +275,30 @@ def test_sparse_bounding_box_key_and_its_fallback():
             assert np.array_equal(got[k], exp[k]), (outliers, k)
     one = _np(voxelize_3d_sparse(torch.from_numpy(cloud[:1]).cuda(), torch.from_numpy(size), 3))
     assert one["coords"].shape == (1, 3) and one["voxel_npoints"].tolist() == [1]
+
+
+def test_results_are_reproducible_run_to_run():
+    """atomics decide arrival order, never results: five runs of the dense (MEAN, incl. overflow voxels summed in fp64),
+    sparse + trim and reduce paths are bit-identical"""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    from d3d_amd.voxel.sharded import voxelize_reduce
+    pts = torch.from_numpy(synth.lidar_like(300000, 21)).cuda()
+    dense = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=8, max_voxels=300000)
+    sparse = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, max_points=8, max_points_filter="trim")
+    first = None
+    for _ in range(5):
+        d, s = dense(pts), sparse(pts)
+        r = voxelize_reduce(pts, synth.KITTI_SHAPE, synth.KITTI_BOUNDS, "mean")
+        cur = [d.voxels, d.coords, d.voxel_npoints, d.aggregates, s.points, s.points_mask, s.points_mapping, s.coords,
+               r.coords, r.aggregates, r.points_mapping]
+        if first is None:
+            first = [t.clone() for t in cur]
+            assert int((d.voxel_npoints > 8).sum()) > 100          # overflow voxels are present
+        else:
+            for idx, (a, b) in enumerate(zip(first, cur)):
+                if idx in (3, 9):       # aggregates: overflow voxels are summed in fp64 in arrival order (1e-16 relative)
+                    fit = (d.voxel_npoints if idx == 3 else r.voxel_npoints) <= (8 if idx == 3 else 32)
+                    assert torch.equal(a[fit], b[fit]) and torch.allclose(a, b, rtol=1e-6, atol=0)
+                else:
+                    assert torch.equal(a, b)
