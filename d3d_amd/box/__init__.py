@@ -192,8 +192,6 @@ def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_thresho
         raise ValueError("Unsupported iou type!")                   # common.h:25
     if supression_type not in (0, 1, 2):
         raise ValueError("Unsupported supression type!")            # common.h:40
-    if supression_type != SupressionType.HARD:
-        raise NotImplementedError("soft-NMS is sequential by construction and is not on the device path yet")
     odev = boxes.device
     if boxes.dtype != scores.dtype:
         raise RuntimeError("boxes and scores must have the same dtype")

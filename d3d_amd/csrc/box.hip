@@ -810,6 +810,96 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     return D3D_OK;
 }
 
+// ---------------------------------------------------------------- soft-NMS (linear / gaussian), nms.cpp:32-95
+// Sequential by construction: every kept box rescales the scores of ALL later boxes it overlaps, and the order of the
+// remaining boxes is re-established after every box (an insertion pass that sinks the suppressed ones).  One workgroup
+// follows the reference's control flow literally: the inner loop over the later boxes (exact IoU, rescale, threshold)
+// runs on all lanes, the insertion pass on lane 0 -- skipped when the pass is the identity (nothing rescaled in this
+// round and the same suppressed suffix as in the round before: the block is a sub-block of one already in order).
+// Position-indexed state (order, working scores, suppressed) lives in LDS up to kSoftLds boxes, in global scratch above.
+constexpr int kSoftThreads = 1024;
+template <typename T> __device__ __forceinline__ T soft_decay(T iou, float param, int sup);
+template <> __device__ __forceinline__ float soft_decay<float>(float iou, float param, int sup)
+{
+    return sup == D3D_SUPPRESS_LINEAR ? 1 - powf(iou, param) : expf(-iou * iou / param);
+}
+template <> __device__ __forceinline__ double soft_decay<double>(double iou, float param, int sup)
+{
+    return sup == D3D_SUPPRESS_LINEAR ? 1 - pow(iou, (double)param) : exp(-iou * iou / (double)param);
+}
+
+template <typename T, bool ROTATED>
+__global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ boxes, const T *__restrict__ scores,
+                                                          const int64_t *__restrict__ order_in, int n, int sup,
+                                                          float iou_thr, float score_thr, float param,
+                                                          BoxGeom<T> *geom, int *g_ord, T *g_sc, uint8_t *g_sp, int in_lds,
+                                                          uint8_t *suppressed)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char soft_lds[];
+    __shared__ int s_S, s_mod, s_prevS;
+    T *sc = in_lds ? reinterpret_cast<T *>(soft_lds) : g_sc;                       // working score of the box at position p
+    int *ord = in_lds ? reinterpret_cast<int *>(soft_lds + (size_t)n * sizeof(T)) : g_ord;
+    uint8_t *sp = in_lds ? soft_lds + (size_t)n * (sizeof(T) + 4) : g_sp;          // suppressed, by position
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_S = 0; s_prevS = -1; }
+    for (int p = tid; p < n; p += kSoftThreads) {
+        const int i = (int)order_in[p];
+        ord[p] = p;                                          // initial rank of the box now at position p
+        sc[p] = scores[i];                                   // nms.cpp:104: the scores are copied
+        geom[p] = Box2D<T>::load(boxes + (size_t)i * 5);     // geometry by initial rank
+    }
+    __syncthreads();
+    // nms.cpp:23-29: walking up from the last position, everything is suppressed until a score above the threshold
+    // (position 0 is never touched) = the positions behind the LAST one whose score is above it
+    for (int p = 1 + tid; p < n; p += kSoftThreads)
+        if (sc[p] > (T)score_thr) atomicMax(&s_S, p);
+    __syncthreads();
+    const int last_above = s_S;
+    for (int p = tid; p < n; p += kSoftThreads) sp[p] = p > last_above ? 1 : 0;
+    __syncthreads();
+    for (int pi = 0; pi < n; pi++) {
+        if (sp[pi]) break;                                   // nms.cpp:38: the rest is suppressed (uniform)
+        const BoxGeom<T> gi = geom[ord[pi]];
+        if (tid == 0) { s_mod = 0; s_S = pi; }
+        __syncthreads();
+        int mod = 0, smax = pi;
+        for (int pj = pi + 1 + tid; pj < n; pj += kSoftThreads) {
+            const BoxGeom<T> gj = geom[ord[pj]];
+            const T iou = ROTATED ? iou_rbox(gi, gj) : iou_aabb(gi, gj);
+            if (iou > (T)iou_thr) {                          // nms.cpp:53
+                sc[pj] *= soft_decay<T>(iou, param, sup);
+                sp[pj] = sc[pj] < (T)score_thr ? 1 : 0;
+                mod = 1;
+            }
+            if (sp[pj]) smax = pj;                           // positions ascend: the last one seen is the largest
+        }
+        if (mod) s_mod = 1;
+        if (smax > pi) atomicMax(&s_S, smax);
+        __syncthreads();
+        // nms.cpp:74-94 on lane 0: S = last suppressed position; insertion pass over (pi, S)
+        if (tid == 0) {
+            const int S = s_S;
+            if (S > pi + 1 && (s_mod || S != s_prevS)) {
+                for (int pj = S - 1; pj > pi; pj--) {
+                    const int j = ord[pj];
+                    const T sj = sc[pj];
+                    const uint8_t pjs = sp[pj];
+                    int k = pj + 1;
+                    while (k < S && (pjs || sc[k] > sj)) {
+                        ord[k - 1] = ord[k]; sc[k - 1] = sc[k]; sp[k - 1] = sp[k];
+                        k++;
+                    }
+                    ord[k - 1] = j; sc[k - 1] = sj; sp[k - 1] = pjs;
+                }
+            }
+            s_prevS = S;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += kSoftThreads) suppressed[order_in[ord[p]]] = sp[p];
+}
+
 // ---------------------------------------------------------------- crop: points in rotated boxes
 // indicators[i, j] = point j inside box i (closed AABB test, then the four closed half-plane tests); replaces
 // crop_2dr (reference utils.cpp:9-47).  Lane = 4 consecutive points -> one 32-bit store per box row.
@@ -1010,6 +1100,28 @@ extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *bo
     return D3D_OK;
 }
 
+constexpr size_t kSoftLdsBytes = 128 * 1024;      // position-indexed state of the soft-NMS kernel stays in LDS below this
+template <typename T, bool ROTATED>
+static int softnms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, int sup, float iou_thr,
+                         float score_thr, float param, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    WsCarver w(ws, ws_bytes);
+    BoxGeom<T> *geom = w.take<BoxGeom<T>>(n);
+    int *ord = w.take<int>(n);
+    T *sc = w.take<T>(n);
+    uint8_t *sp = w.take<uint8_t>(n);
+    if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
+    const size_t lds = (size_t)n * (sizeof(T) + 4 + 1);
+    const char *no_lds = getenv("D3D_SOFTNMS_NO_LDS");             // test hook: the global-scratch variant
+    const bool in_lds = lds <= kSoftLdsBytes && !(no_lds && no_lds[0] == '1');
+    if (in_lds)
+        D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softnms<T, ROTATED>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSoftLdsBytes));
+    D3D_LAUNCH("k_softnms", (k_softnms<T, ROTATED>), dim3(1), dim3(kSoftThreads), in_lds ? lds : 0, st, boxes, scores, order, (int)n,
+               sup, iou_thr, score_thr, param, geom, ord, sc, sp, in_lds ? 1 : 0, suppressed);
+    return D3D_OK;
+}
+
 extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
 {
     if (n < 1) n = 1;
@@ -1026,14 +1138,32 @@ extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *o
                          float suppression_param, uint8_t *suppressed, void *workspace, size_t workspace_bytes,
                          void *stream)
 {
-    (void)suppression_param;
     hipStream_t st = (hipStream_t)stream;
     if (n < 0) return D3D_ERR_BAD_ARG;
     if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;   // common.h:25
-    if (suppression_type != D3D_SUPPRESS_HARD) return D3D_ERR_UNSUPPORTED;
+    if (suppression_type != D3D_SUPPRESS_HARD && suppression_type != D3D_SUPPRESS_LINEAR &&
+        suppression_type != D3D_SUPPRESS_GAUSSIAN)
+        return D3D_ERR_UNSUPPORTED;                                                          // common.h:40
     if (n == 0) return D3D_OK;
     if (!boxes || !scores || !order || !suppressed) return D3D_ERR_BAD_ARG;
+    if (suppression_type != D3D_SUPPRESS_HARD) {
+        if (n >= (1ll << 31)) return D3D_ERR_BAD_ARG;
+        const bool rot = iou_type == D3D_IOU_RBOX;
+        if (dtype == D3D_F64)
+            return rot ? softnms_typed<double, true>((const double *)boxes, (const double *)scores, order, n, suppression_type,
+                                                     iou_threshold, score_threshold, suppression_param, suppressed, workspace,
+                                                     workspace_bytes, st)
+                       : softnms_typed<double, false>((const double *)boxes, (const double *)scores, order, n, suppression_type,
+                                                      iou_threshold, score_threshold, suppression_param, suppressed, workspace,
+                                                      workspace_bytes, st);
+        return rot ? softnms_typed<float, true>((const float *)boxes, (const float *)scores, order, n, suppression_type,
+                                                iou_threshold, score_threshold, suppression_param, suppressed, workspace,
+                                                workspace_bytes, st)
+                   : softnms_typed<float, false>((const float *)boxes, (const float *)scores, order, n, suppression_type,
+                                                 iou_threshold, score_threshold, suppression_param, suppressed, workspace,
+                                                 workspace_bytes, st);
+    }
     if (d3d_divup(n, 64) > 65535) return D3D_ERR_BAD_ARG;
     if (dtype == D3D_F64)
         return nms_typed<double>((const double *)boxes, (const double *)scores, order, n, iou_type, iou_threshold,

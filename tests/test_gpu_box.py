@@ -366,3 +366,37 @@ def test_box_method_ragged_shapes_and_degenerate_rectangles(dtype):
     assert got.shape == (131, 77)
     assert np.max(np.abs(got - exp)) < (1e-9 if dtype == np.float64 else 1e-3)
     assert np.any(exp[:5] > 0)
+
+
+@pytest.mark.parametrize("sup,param", [("linear", 1.0), ("linear", 2.0), ("gaussian", 0.5), ("gaussian", 0.1)])
+@pytest.mark.parametrize("method", ["rbox", "box"])
+def test_softnms_vs_oracle(method, sup, param, monkeypatch):
+    """soft-NMS (nms.cpp:60-94) on the device: same keep mask as the literal restatement, incl. the insertion re-sort;
+    state in LDS and (hook) in global scratch"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms
+    for n, seed, gen in [(300, 41, synth.boxes2d_dense), (1200, 42, synth.boxes2d_sparse), (1, 43, synth.boxes2d_dense)]:
+        b, s = gen(n, seed)
+        for sthr in [0.0, 0.25]:
+            kw = dict(iou_method=method, supression_method=sup, iou_threshold=0.2, score_threshold=sthr, supression_param=param)
+            exp = oracle.box2d_nms(b, s, **kw)
+            keep = box2d_nms(T(b), T(s), **kw).cpu().numpy()
+            assert np.array_equal(keep, exp), (n, sthr, int(np.sum(keep != exp)))
+            if n == 300:
+                monkeypatch.setenv("D3D_SOFTNMS_NO_LDS", "1")
+                keep = box2d_nms(T(b), T(s), **kw).cpu().numpy()
+                monkeypatch.delenv("D3D_SOFTNMS_NO_LDS")
+                assert np.array_equal(keep, exp)
+
+
+def test_softnms_reference_case_and_fp32():
+    """test_box.py:157-179: nothing is suppressed at score_threshold 0; fp32 path (precise=False)"""
+    from d3d_amd.box import box2d_nms
+    for m in ["box", "rbox"]:
+        for sup in ["linear", "gaussian"]:
+            assert bool(box2d_nms(T(bc.SOFT_BOXES), T(bc.NMS_SCORES), iou_method=m, supression_method=sup).all())
+    b, s = bc.random_boxes_like_reference(500, 6)
+    kw = dict(iou_method="rbox", supression_method="gaussian", iou_threshold=0.1, score_threshold=0.3, supression_param=0.3)
+    keep = box2d_nms(T(b), T(s), precise=False, **kw).cpu().numpy()
+    exp = oracle.box2d_nms(b, s, precise=False, **kw)
+    assert np.mean(keep == exp) > 0.995          # fp32 powf / expf may differ from libm in the last ulp
