@@ -818,6 +818,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
 // round and the same suppressed suffix as in the round before: the block is a sub-block of one already in order).
 // Position-indexed state (order, working scores, suppressed) lives in LDS up to kSoftLds boxes, in global scratch above.
 constexpr int kSoftThreads = 1024;
+constexpr int kSoftList = 1024;      // rescaled positions remembered per round
 template <typename T> __device__ __forceinline__ T soft_decay(T iou, float param, int sup);
 template <> __device__ __forceinline__ float soft_decay<float>(float iou, float param, int sup)
 {
@@ -832,11 +833,12 @@ template <typename T, bool ROTATED>
 __global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ boxes, const T *__restrict__ scores,
                                                           const int64_t *__restrict__ order_in, int n, int sup,
                                                           float iou_thr, float score_thr, float param,
-                                                          BoxGeom<T> *geom, int *g_ord, T *g_sc, uint8_t *g_sp, int in_lds,
-                                                          uint8_t *suppressed)
+                                                          BoxGeom<T> *geom, float4 *aabb, int *g_ord, T *g_sc, uint8_t *g_sp,
+                                                          int in_lds, uint8_t *suppressed)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char soft_lds[];
-    __shared__ int s_S, s_mod, s_prevS;
+    __shared__ int s_S, s_mod, s_prevS, s_cnt;
+    __shared__ int s_list[kSoftList];
     T *sc = in_lds ? reinterpret_cast<T *>(soft_lds) : g_sc;                       // working score of the box at position p
     int *ord = in_lds ? reinterpret_cast<int *>(soft_lds + (size_t)n * sizeof(T)) : g_ord;
     uint8_t *sp = in_lds ? soft_lds + (size_t)n * (sizeof(T) + 4) : g_sp;          // suppressed, by position
@@ -846,7 +848,9 @@ __global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ 
         const int i = (int)order_in[p];
         ord[p] = p;                                          // initial rank of the box now at position p
         sc[p] = scores[i];                                   // nms.cpp:104: the scores are copied
-        geom[p] = Box2D<T>::load(boxes + (size_t)i * 5);     // geometry by initial rank
+        const BoxGeom<T> g = Box2D<T>::load(boxes + (size_t)i * 5);
+        geom[p] = g;                                         // geometry by initial rank
+        aabb[p] = cand_aabb(g, ROTATED);                     // 16 bytes: what the inner loop gathers first
     }
     __syncthreads();
     // nms.cpp:23-29: walking up from the last position, everything is suppressed until a score above the threshold
@@ -860,27 +864,38 @@ __global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ 
     for (int pi = 0; pi < n; pi++) {
         if (sp[pi]) break;                                   // nms.cpp:38: the rest is suppressed (uniform)
         const BoxGeom<T> gi = geom[ord[pi]];
-        if (tid == 0) { s_mod = 0; s_S = pi; }
+        const float4 fi = aabb[ord[pi]];
+        if (tid == 0) { s_mod = 0; s_S = pi; s_cnt = 0; }
         __syncthreads();
-        int mod = 0, smax = pi;
+        int smax = pi;
         for (int pj = pi + 1 + tid; pj < n; pj += kSoftThreads) {
-            const BoxGeom<T> gj = geom[ord[pj]];
-            const T iou = ROTATED ? iou_rbox(gi, gj) : iou_aabb(gi, gj);
+            const int rj = ord[pj];
+            T iou = 0;
+            if (aabb_gap(fi, aabb[rj]) > 0.f) {              // conservative: the exact IoU is 0 otherwise
+                const BoxGeom<T> gj = geom[rj];
+                iou = ROTATED ? iou_rbox(gi, gj) : iou_aabb(gi, gj);
+            }
             if (iou > (T)iou_thr) {                          // nms.cpp:53
-                sc[pj] *= soft_decay<T>(iou, param, sup);
+                const T before = sc[pj];
+                sc[pj] = before * soft_decay<T>(iou, param, sup);
                 sp[pj] = sc[pj] < (T)score_thr ? 1 : 0;
-                mod = 1;
+                if (sc[pj] > before) s_mod = 2;              // a score went UP (negative scores): no shortcut below
+                const int slot = atomicAdd(&s_cnt, 1);
+                if (slot < kSoftList) s_list[slot] = pj;
             }
             if (sp[pj]) smax = pj;                           // positions ascend: the last one seen is the largest
         }
-        if (mod) s_mod = 1;
         if (smax > pi) atomicMax(&s_S, smax);
         __syncthreads();
-        // nms.cpp:74-94 on lane 0: S = last suppressed position; insertion pass over (pi, S)
+        // nms.cpp:74-94 on lane 0: S = last suppressed position; insertion pass over (pi, S), walking down from S - 1.
+        // The pass moves only what is out of order.  When the block is a sub-block of the one ordered in the round before
+        // (same S) and scores only went down, the unchanged boxes are already in place (each is followed by boxes that
+        // did not score higher before and do not now), so visiting the rescaled positions, largest first, gives the
+        // same result as visiting every position.
         if (tid == 0) {
-            const int S = s_S;
-            if (S > pi + 1 && (s_mod || S != s_prevS)) {
-                for (int pj = S - 1; pj > pi; pj--) {
+            const int S = s_S, cnt = s_cnt;
+            if (S > pi + 1) {
+                auto insert = [&](int pj) {
                     const int j = ord[pj];
                     const T sj = sc[pj];
                     const uint8_t pjs = sp[pj];
@@ -890,6 +905,18 @@ __global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ 
                         k++;
                     }
                     ord[k - 1] = j; sc[k - 1] = sj; sp[k - 1] = pjs;
+                };
+                if (S != s_prevS || cnt > kSoftList || s_mod == 2) {
+                    for (int pj = S - 1; pj > pi; pj--) insert(pj);
+                } else if (cnt > 0) {
+                    for (int a = 1; a < cnt; a++) {          // the few rescaled positions, descending
+                        const int v = s_list[a];
+                        int b = a - 1;
+                        while (b >= 0 && s_list[b] < v) { s_list[b + 1] = s_list[b]; b--; }
+                        s_list[b + 1] = v;
+                    }
+                    for (int a = 0; a < cnt; a++)
+                        if (s_list[a] < S) insert(s_list[a]);
                 }
             }
             s_prevS = S;
@@ -1107,6 +1134,7 @@ static int softnms_typed(const T *boxes, const T *scores, const int64_t *order, 
 {
     WsCarver w(ws, ws_bytes);
     BoxGeom<T> *geom = w.take<BoxGeom<T>>(n);
+    float4 *aabb = w.take<float4>(n);
     int *ord = w.take<int>(n);
     T *sc = w.take<T>(n);
     uint8_t *sp = w.take<uint8_t>(n);
@@ -1118,7 +1146,7 @@ static int softnms_typed(const T *boxes, const T *scores, const int64_t *order, 
         D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softnms<T, ROTATED>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSoftLdsBytes));
     D3D_LAUNCH("k_softnms", (k_softnms<T, ROTATED>), dim3(1), dim3(kSoftThreads), in_lds ? lds : 0, st, boxes, scores, order, (int)n,
-               sup, iou_thr, score_thr, param, geom, ord, sc, sp, in_lds ? 1 : 0, suppressed);
+               sup, iou_thr, score_thr, param, geom, aabb, ord, sc, sp, in_lds ? 1 : 0, suppressed);
     return D3D_OK;
 }
 
