@@ -1176,7 +1176,7 @@ extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *o
     if (n == 0) return D3D_OK;
     if (!boxes || !scores || !order || !suppressed) return D3D_ERR_BAD_ARG;
     if (suppression_type != D3D_SUPPRESS_HARD) {
-        if (n >= (1ll << 31)) return D3D_ERR_BAD_ARG;
+        if (n > 65536) return D3D_ERR_UNSUPPORTED;         // one workgroup, n rounds: minutes beyond this size
         const bool rot = iou_type == D3D_IOU_RBOX;
         if (dtype == D3D_F64)
             return rot ? softnms_typed<double, true>((const double *)boxes, (const double *)scores, order, n, suppression_type,

@@ -257,7 +257,7 @@ size_t d3d_nms2d_workspace_bytes(int64_t n);
  *   (nms.cpp:103) supplied by the caller; suppressed[n] u8 (0/1) output.
  *   HARD: parallel (broad phase + exact IoU + fixed point, see box.hip).  LINEAR / GAUSSIAN (soft-NMS, nms.cpp:60-94)
  *   are sequential by construction -- every kept box rescales the later boxes it overlaps and the order is re-established
- *   after each -- and run in one workgroup that follows the reference's control flow (n < 2^31).
+ *   after each -- and run in one workgroup that follows the reference's control flow (n <= 65536, else UNSUPPORTED).
  *   Other IoU types return D3D_ERR_UNSUPPORTED ("Unsupported iou type!", reference common.h:25). */
 int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n,
               int32_t iou_type, int32_t suppression_type, int32_t dtype,
