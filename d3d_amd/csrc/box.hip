@@ -892,34 +892,50 @@ __global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ 
         // (same S) and scores only went down, the unchanged boxes are already in place (each is followed by boxes that
         // did not score higher before and do not now), so visiting the rescaled positions, largest first, gives the
         // same result as visiting every position.
-        if (tid == 0) {
+        if (tid < kWave) {                                   // wavefront 0; everything below is wave-uniform
             const int S = s_S, cnt = s_cnt;
             if (S > pi + 1) {
+                // one insertion of nms.cpp:84-92, 64 positions per step: the box at pj moves right past every box
+                // that outscores it (all the way to S - 1 when it is suppressed)
                 auto insert = [&](int pj) {
                     const int j = ord[pj];
                     const T sj = sc[pj];
                     const uint8_t pjs = sp[pj];
                     int k = pj + 1;
-                    while (k < S && (pjs || sc[k] > sj)) {
-                        ord[k - 1] = ord[k]; sc[k - 1] = sc[k]; sp[k - 1] = sp[k];
-                        k++;
+                    while (k < S) {
+                        const int idx = k + tid;
+                        const bool valid = idx < S;
+                        int o = 0; T v = 0; uint8_t u = 0;
+                        if (valid) { o = ord[idx]; v = sc[idx]; u = sp[idx]; }
+                        const unsigned long long pass = __ballot(valid && (pjs || v > sj));
+                        const int c = pass == ~0ull ? kWave : __builtin_ctzll(~pass);     // leading boxes that stay ahead
+                        if (!in_lds) __threadfence_block();
+                        if (tid < c) { ord[idx - 1] = o; sc[idx - 1] = v; sp[idx - 1] = u; }
+                        if (!in_lds) __threadfence_block();
+                        k += c;
+                        if (c < kWave) break;
                     }
-                    ord[k - 1] = j; sc[k - 1] = sj; sp[k - 1] = pjs;
+                    if (tid == 0) { ord[k - 1] = j; sc[k - 1] = sj; sp[k - 1] = pjs; }
+                    if (!in_lds) __threadfence_block();
                 };
                 if (S != s_prevS || cnt > kSoftList || s_mod == 2) {
                     for (int pj = S - 1; pj > pi; pj--) insert(pj);
                 } else if (cnt > 0) {
-                    for (int a = 1; a < cnt; a++) {          // the few rescaled positions, descending
-                        const int v = s_list[a];
-                        int b = a - 1;
-                        while (b >= 0 && s_list[b] < v) { s_list[b + 1] = s_list[b]; b--; }
-                        s_list[b + 1] = v;
+                    if (tid == 0)
+                        for (int a = 1; a < cnt; a++) {      // the few rescaled positions, descending
+                            const int v = s_list[a];
+                            int b = a - 1;
+                            while (b >= 0 && s_list[b] < v) { s_list[b + 1] = s_list[b]; b--; }
+                            s_list[b + 1] = v;
+                        }
+                    __builtin_amdgcn_wave_barrier();
+                    for (int a = 0; a < cnt; a++) {
+                        const int pj = s_list[a];
+                        if (pj < S) insert(pj);
                     }
-                    for (int a = 0; a < cnt; a++)
-                        if (s_list[a] < S) insert(s_list[a]);
                 }
             }
-            s_prevS = S;
+            if (tid == 0) s_prevS = S;
         }
         __syncthreads();
     }
