@@ -183,9 +183,10 @@ def argsort_desc(scores):
     return order
 
 
-def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param):
+def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param, sort_keys=None):
     """nms2d / nms2d_cuda (nms.h:6-18; nms.cpp:98-119): returns the SUPPRESSED mask (bool[N]).
-    Follows the CPU control flow of the reference (nms.cpp:23-59)."""
+    Follows the CPU control flow of the reference (nms.cpp:23-59).  sort_keys: optional fp32 tensor that orders like
+    `scores` (the scores before their promotion to fp64): half the radix passes of the argsort, same order."""
     lib = _lib.load()
     iou_type, supression_type = int(iou_type), int(supression_type)
     if iou_type not in (IouType.BOX, IouType.RBOX):
@@ -199,7 +200,10 @@ def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_thresho
     n = b.shape[0]
     code = _dtype_code(b)
     with torch.cuda.device(dev):
-        order = argsort_desc(s)
+        if sort_keys is not None and sort_keys.dtype == torch.float32 and sort_keys.numel() == n:
+            order = argsort_desc(sort_keys.to(dev).contiguous())
+        else:
+            order = argsort_desc(s)
         sup = torch.empty((n,), dtype=torch.uint8, device=dev)
         # both workspaces are carved from one arena; the sort finished with it (same stream)
         ws = _lib.workspace(lib.d3d_nms2d_workspace_bytes(n), dev)
@@ -222,17 +226,20 @@ def box2d_nms(boxes, scores, iou_method="box", supression_method="hard",
         assert isinstance(scores, np.ndarray), "Input should be both numpy tensor or pytorch tensor!"
         boxes, scores = torch.from_numpy(boxes), torch.from_numpy(scores)
         convert_numpy = True
+    narrow = scores if scores.dtype == torch.float32 else None      # fp32 -> fp64 is monotone and injective
     if precise:
         boxes, scores = boxes.to(torch.float64), scores.to(torch.float64)
     if len(boxes) != len(scores):
         raise ValueError("Numbers of boxes and scores are inconsistent!")
     if len(scores.shape) == 2:
         scores = scores.max(axis=1).values
+        narrow = narrow.max(axis=1).values if narrow is not None else None
     if boxes.numel() == 0:
         return torch.tensor([], dtype=torch.bool)
     iou_type = getattr(IouType, iou_method.upper())
     supression_type = getattr(SupressionType, supression_method.upper())
-    suppressed = nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param)
+    suppressed = nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param,
+                       sort_keys=narrow)
     mask = ~suppressed
     return mask.numpy() if convert_numpy else mask
 

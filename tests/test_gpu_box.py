@@ -400,3 +400,16 @@ def test_softnms_reference_case_and_fp32():
     keep = box2d_nms(T(b), T(s), precise=False, **kw).cpu().numpy()
     exp = oracle.box2d_nms(b, s, precise=False, **kw)
     assert np.mean(keep == exp) > 0.995          # fp32 powf / expf may differ from libm in the last ulp
+
+
+def test_nms_fp32_scores_sorted_narrow():
+    """fp32 scores (precise=True promotes them to fp64): the argsort runs on the fp32 keys -- same keep mask, ties included"""
+    from d3d_amd.box import box2d_nms
+    b, s = bc.random_boxes_like_reference(3000, 12)
+    s = (np.round(s * 50) / 50).astype(np.float32)                    # many ties
+    keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.2, score_threshold=0.1).cpu().numpy()
+    exp = oracle.box2d_nms(b, s, iou_method="rbox", iou_threshold=0.2, score_threshold=0.1)
+    assert np.array_equal(keep, exp)
+    s2 = np.stack([s, s * 0.5], 1)                                    # class scores: max over classes
+    keep2 = box2d_nms(T(b), T(s2), iou_method="rbox", iou_threshold=0.2, score_threshold=0.1).cpu().numpy()
+    assert np.array_equal(keep2, exp)
