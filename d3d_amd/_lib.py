@@ -49,8 +49,9 @@ SIGNATURES = {
     "d3d_sharded_finalize_owned": (ctypes.c_int, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "d3d_grid_compact_keys": (ctypes.c_int, [_i64, _vp, _sz, _vp, _vp]),
     "d3d_grid_compact_lookup": (ctypes.c_int, [_vp, _i64, _i64, _vp, _sz, _i64, _vp, _vp]),
-    "d3d_aligned_scatter_forward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _vp, _vp]),
-    "d3d_aligned_scatter_backward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _vp, _vp]),
+    "d3d_aligned_scatter_workspace_bytes": (_sz, [_i64, _i64, _vp, _i32, _i32]),
+    "d3d_aligned_scatter_forward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "d3d_aligned_scatter_backward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "d3d_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "d3d_profile_report": (ctypes.c_int, [ctypes.c_char_p, _sz]),
     "d3d_iou2d_workspace_bytes": (_sz, [_i64, _i64, _i32]),

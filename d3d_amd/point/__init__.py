@@ -24,8 +24,11 @@ def _call(fn_name, coord, a, atype, out, image_shape):
     dim = coord.shape[1] - 1
     dims_h = (ctypes.c_int64 * max(dim, 1))(*[int(x) for x in image_shape[2:]])
     code = _lib.F64 if a.dtype == torch.float64 else _lib.F32
-    rc = getattr(lib, fn_name)(_lib.ptr(coord), coord.shape[0], dim, _lib.ptr(a), int(image_shape[1]),
-                               ctypes.cast(dims_h, ctypes.c_void_p), int(atype), code, _lib.ptr(out), _lib.stream_ptr())
+    dims_p = ctypes.cast(dims_h, ctypes.c_void_p)
+    batch, channels = int(image_shape[0]), int(image_shape[1])
+    ws = _lib.workspace(lib.d3d_aligned_scatter_workspace_bytes(batch, channels, dims_p, dim, code), coord.device)
+    rc = getattr(lib, fn_name)(_lib.ptr(coord), coord.shape[0], dim, _lib.ptr(a), batch, channels, dims_p, int(atype), code,
+                               _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
     if rc == _lib.ERR_UNSUPPORTED:
         raise ValueError("Unsupported align type!" if dim in (1, 2, 3) else "Unsupported dimension size: %d" % dim)
     _lib.check(rc, fn_name)

@@ -198,13 +198,18 @@ int d3d_sharded_map(int64_t n, const int64_t *local_map, const int64_t *slot_of_
 /* ------------------------------------------------------------------ d3d/point ("next" row) */
 
 /* replaces aligned_scatter_forward[_cuda] / aligned_scatter_backward[_cuda] (reference d3d/point/scatter.h:39-56,
- * scatter.cpp:81-200, scatter_cuda.cu).  coord[n, dim+1] (batch index first), image[B, channels, dims[0..dim-1]],
+ * scatter.cpp:81-200, scatter_cuda.cu).  coord[n, dim+1] (batch index first), image[batch, channels, dims[0..dim-1]],
  * out / grad [n, channels], all in `dtype`; dims: host int64[dim]; align_type 1 = MEAN, 2 = LINEAR (others ->
- * D3D_ERR_UNSUPPORTED like the reference's py::value_error).  backward ACCUMULATES into image_grad (atomics). */
-int d3d_aligned_scatter_forward(const void *coord, int64_t n, int32_t dim, const void *image, int64_t channels,
-                                const int64_t *dims, int32_t align_type, int32_t dtype, void *out, void *stream);
-int d3d_aligned_scatter_backward(const void *coord, int64_t n, int32_t dim, const void *grad, int64_t channels,
-                                 const int64_t *dims, int32_t align_type, int32_t dtype, void *image_grad, void *stream);
+ * D3D_ERR_UNSUPPORTED like the reference's py::value_error).  backward ACCUMULATES into image_grad (atomics).
+ * workspace (d3d_aligned_scatter_workspace_bytes; may be NULL): a channels-last copy of the map / of the gradient
+ * accumulator, which turns the per-channel requests of a point's neighbours into coalesced ones (channels >= 8). */
+size_t d3d_aligned_scatter_workspace_bytes(int64_t batch, int64_t channels, const int64_t *dims, int32_t dim, int32_t dtype);
+int d3d_aligned_scatter_forward(const void *coord, int64_t n, int32_t dim, const void *image, int64_t batch,
+                                int64_t channels, const int64_t *dims, int32_t align_type, int32_t dtype, void *out,
+                                void *workspace, size_t workspace_bytes, void *stream);
+int d3d_aligned_scatter_backward(const void *coord, int64_t n, int32_t dim, const void *grad, int64_t batch,
+                                 int64_t channels, const int64_t *dims, int32_t align_type, int32_t dtype,
+                                 void *image_grad, void *workspace, size_t workspace_bytes, void *stream);
 
 /* opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline leg);
  * report: "kernel,calls,total_ms" lines. */
