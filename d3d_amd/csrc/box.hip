@@ -411,20 +411,20 @@ extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int
                                              hipStream_t st);      // sort.hip
 extern "C" size_t d3d_internal_argsort_i32_bytes(int64_t n);
 
-constexpr int kIncCap = 24;          // incoming-hit list capacity per box
 enum { kUndecided = 0, kKept = 1, kSuppressed = 2 };
 
 struct NmsFlags { unsigned int need_sweep, undecided; };
 constexpr int kNmsListSegs = 1;     // see list_segments(): segmenting the list did not pay
 struct NmsCand { unsigned long long count[kNmsListSegs * 16]; };   // entries appended (may exceed the capacity)
 
-// candidate-list capacity: ~8.5 upper-triangle AABB candidates per box at detection densities;
-// 64 per box leaves head room, small dense sets get the full triangle.  D3D_NMS_CAND_CAP overrides (tests).
+// candidate-list capacity: ~8.5 upper-triangle AABB candidates per box for scattered boxes, half the
+// cluster size for detector output (clusters of overlapping boxes around every object); 512 per box = 0.6 GB at 100 k
+// boxes, small sets get the full triangle.  D3D_NMS_CAND_CAP overrides (tests).
 static unsigned long long nms_cand_capacity(int64_t n)
 {
     if (const char *e = getenv("D3D_NMS_CAND_CAP")) return (unsigned long long)std::max<long long>(atoll(e), 1);
     const unsigned long long tri = (unsigned long long)n * (unsigned long long)(n > 0 ? n - 1 : 0) / 2 + 1;
-    return std::min<unsigned long long>(tri, std::max<unsigned long long>(64ull * (unsigned long long)n, 1ull << 22));
+    return std::min<unsigned long long>(tri, std::max<unsigned long long>(512ull * (unsigned long long)n, 1ull << 24));
 }
 static unsigned int nms_force_dense() { const char *e = getenv("D3D_NMS_FORCE_DENSE"); return e && atoi(e) ? 1u : 0u; }
 
@@ -432,7 +432,7 @@ static unsigned int nms_force_dense() { const char *e = getenv("D3D_NMS_FORCE_DE
 template <typename T>
 __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__ scores,
                               const int64_t *__restrict__ order, int64_t n, float score_threshold,
-                              BoxGeom<T> *geom, float4 *fbox, uint8_t *state, uint32_t *inc_cnt,
+                              BoxGeom<T> *geom, float4 *fbox, uint8_t *state, uint32_t *inc_cnt, uint32_t *cursor,
                               unsigned long long *remv, int64_t nb, NmsFlags *flags, NmsCand *cand_hdr,
                               unsigned int force_dense, int32_t *xkey)
 {
@@ -453,6 +453,7 @@ __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__
         pre = p > 0 && !(scores[i] > (T)score_threshold);
         state[p] = pre ? kSuppressed : kUndecided;
         inc_cnt[p] = 0;
+        cursor[p] = 0;
     }
     unsigned long long word = __ballot(pre);
     if ((threadIdx.x & 63) == 0 && (p >> 6) < nb) remv[p >> 6] = word;
@@ -570,12 +571,47 @@ __global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx
     if (wn) write_out(gb);
 }
 
+// narrow phase, pass A: exact IoU of one candidate per lane.  The entry is rewritten as (hit << 63 | p << 32 | q) in score
+// ranks (p suppresses q, p < q) and the hits of every box are counted; the scan of the counts (IncOffsets) and pass B
+// (k_nms_fill) then lay the hitters of every box out contiguously -- lists of any length, so clusters of hundreds of
+// overlapping detections stay on this path.
+constexpr unsigned long long kHitBit = 1ull << 63;
 template <typename T, bool ROTATED>
 __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__ geom,
                                                   const uint32_t *__restrict__ rankx,
-                                                  const unsigned long long *__restrict__ list, unsigned long long cap,
-                                                  const NmsCand *hdr, T thr, uint32_t *inc_cnt, uint32_t *inc,
-                                                  NmsFlags *flags)
+                                                  unsigned long long *__restrict__ list, unsigned long long cap,
+                                                  const NmsCand *hdr, T thr, uint32_t *inc_cnt)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / kNmsListSegs;
+    for (int sg = 0; sg < kNmsListSegs; sg++) {
+    const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
+    unsigned long long *seg = list + sg * segcap;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const unsigned long long e = seg[t];
+        const uint32_t r1 = rankx[e >> 32], r2 = rankx[e & 0xffffffffull];      // x-order index -> score rank
+        const uint32_t p = r1 < r2 ? r1 : r2, q = r1 < r2 ? r2 : r1;
+        const BoxGeom<T> a = geom[p], b = geom[q];
+        const T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
+        const bool hit = v > thr;                          // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
+        seg[t] = (hit ? kHitBit : 0ull) | ((unsigned long long)p << 32) | q;
+        if (hit) atomicAdd(&inc_cnt[q], 1u);
+    }
+    }
+}
+
+struct IncOffsets {                  // inc_off = exclusive scan of inc_cnt (d3d_run_scan)
+    static constexpr const char *kName = "k_scan_count<IncOffsets>", *kName2 = "k_scan_apply<IncOffsets>";
+    const uint32_t *inc_cnt;
+    uint32_t *inc_off;
+    __device__ __forceinline__ unsigned long long value(int64_t q) const { return inc_cnt[q]; }
+    __device__ __forceinline__ unsigned long long value2(int64_t q) const { return inc_cnt[q]; }
+    __device__ __forceinline__ void apply(int64_t q, unsigned long long, unsigned long long excl) const { inc_off[q] = (uint32_t)excl; }
+};
+
+// pass B: the hits into the boxes' segments
+__global__ __launch_bounds__(256) void k_nms_fill(const unsigned long long *__restrict__ list, unsigned long long cap,
+                                                  const NmsCand *hdr, const uint32_t *__restrict__ inc_off, uint32_t *cursor,
+                                                  uint32_t *__restrict__ inc)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / kNmsListSegs;
     for (int sg = 0; sg < kNmsListSegs; sg++) {
@@ -583,15 +619,9 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__
     const unsigned long long *seg = list + sg * segcap;
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const unsigned long long e = seg[t];
-        const uint32_t r1 = rankx[e >> 32], r2 = rankx[e & 0xffffffffull];      // x-order index -> score rank
-        const int64_t p = r1 < r2 ? r1 : r2, q = r1 < r2 ? r2 : r1;
-        const BoxGeom<T> a = geom[p], b = geom[q];
-        const T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
-        if (v > thr) {                                     // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
-            const uint32_t s = atomicAdd(&inc_cnt[q], 1u);
-            if (s < (uint32_t)kIncCap) inc[q * kIncCap + s] = (uint32_t)p;
-            else flags->need_sweep = 1;
-        }
+        if (!(e & kHitBit)) continue;
+        const uint32_t q = (uint32_t)e, p = (uint32_t)(e >> 32) & 0x7fffffffu;
+        inc[inc_off[q] + atomicAdd(&cursor[q], 1u)] = p;
     }
     }
 }
@@ -657,26 +687,26 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const BoxGeom<T> *__restrict_
 // sweep.  States cross XCDs, hence the agent-scope atomic loads/stores.
 constexpr int kSpinPasses = 4096;
 __global__ __launch_bounds__(256) void k_nms_resolve(int64_t n, uint8_t *state, const uint32_t *__restrict__ inc_cnt,
-                                                     const uint32_t *__restrict__ inc, NmsFlags *flags)
+                                                     const uint32_t *__restrict__ inc_off, uint32_t *inc, NmsFlags *flags)
 {
-    if (__hip_atomic_load(&flags->need_sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // a list overflowed
+    if (__hip_atomic_load(&flags->need_sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the list overflowed
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool done = q >= n || state[q] != kUndecided;
-    uint32_t open = 0;                                   // bit e: hitter e of the list is still undecided
-    if (!done) {
-        const uint32_t cnt = inc_cnt[q];                 // <= kIncCap: otherwise need_sweep was set by k_nms_hits
-        open = cnt >= 32 ? 0xffffffffu : (1u << cnt) - 1u;
-    }
+    // hitters [pos, cnt) are still undecided as far as this lane knows: every pass looks at all of them (ONE kept hitter
+    // decides, wherever it sits in the list) and moves the ones found suppressed in front of pos
+    uint32_t pos = 0, cnt = 0;
+    uint32_t *mine = nullptr;
+    if (!done) { cnt = inc_cnt[q]; mine = inc + inc_off[q]; }
     for (int pass = 0; pass < kSpinPasses; pass++) {
         if (!done) {
             bool hit = false;
-            for (uint32_t m = open; m; m &= m - 1) {
-                const int e = __builtin_ctz(m);
-                const uint8_t sp = __hip_atomic_load(&state[inc[q * kIncCap + e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hit = hit || sp == kKept;
-                if (sp != kUndecided) open &= ~(1u << e);
+            for (uint32_t e = pos; e < cnt; e++) {
+                const uint32_t h = mine[e];
+                const uint8_t sp = __hip_atomic_load(&state[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sp == kKept) { hit = true; break; }
+                if (sp == kSuppressed) { mine[e] = mine[pos]; mine[pos] = h; pos++; }
             }
-            if (hit || !open) {
+            if (hit || pos == cnt) {
                 __hip_atomic_store(&state[q], (uint8_t)(hit ? kSuppressed : kKept), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 done = true;
             }
@@ -761,12 +791,16 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     float4 *fbox = w.take<float4>(nb * 64);
     uint8_t *state = w.take<uint8_t>(nb * 64);
     uint32_t *inc_cnt = w.take<uint32_t>(nb * 64);
-    uint32_t *inc = w.take<uint32_t>((size_t)nb * 64 * kIncCap);
+    uint32_t *inc_off = w.take<uint32_t>(nb * 64);
+    uint32_t *cursor = w.take<uint32_t>(nb * 64);
+    unsigned long long *inc_bsum = w.take<unsigned long long>(d3d_divup(nb * 64, kScanTile) + 1);
+    int64_t *inc_total = w.take<int64_t>(D3D_NUM_COUNTS);
     NmsFlags *flags = w.take<NmsFlags>(1);
     unsigned long long *remv = w.take<unsigned long long>(nb);
     NmsCand *cand_hdr = w.take<NmsCand>(1);
     const unsigned long long cap = nms_cand_capacity(n);
     unsigned long long *cand = w.take<unsigned long long>((size_t)cap);
+    uint32_t *inc = w.take<uint32_t>((size_t)cap);                     // hits <= candidates
     int32_t *xkey = w.take<int32_t>(nb * 64);
     int32_t *perm = w.take<int32_t>(nb * 64);
     float4 *fbx = w.take<float4>(nb * 64 + kCandPad);
@@ -777,7 +811,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
     const bool rot = iou_type == D3D_IOU_RBOX;
     D3D_LAUNCH("k_nms_prepare", k_nms_prepare<T>, dim3((unsigned)nb), dim3(64), 0, st, boxes, scores, order, n, score_thr,
-               geom, fbox, state, inc_cnt, remv, nb, flags, cand_hdr, nms_force_dense(), xkey);
+               geom, fbox, state, inc_cnt, cursor, remv, nb, flags, cand_hdr, nms_force_dense(), xkey);
     if (int rc = d3d_internal_argsort_desc_i32(xkey, n, perm, sort_ws, sort_bytes, st)) return rc;
     D3D_LAUNCH("k_nms_xgather", k_nms_xgather, dim3((unsigned)d3d_divup(nb * 64 + kCandPad, 256)), dim3(256), 0, st, fbox,
                perm, n, nb, fbx, rankx);
@@ -788,12 +822,16 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     const unsigned hits_blocks = (unsigned)std::min<unsigned long long>(d3d_divup((int64_t)cap, 256), 4096);
     if (rot)
         D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, true>), dim3(hits_blocks), dim3(256), 0, st, geom, rankx, cand, cap, cand_hdr,
-                   (T)iou_thr, inc_cnt, inc, flags);
+                   (T)iou_thr, inc_cnt);
     else
         D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, false>), dim3(hits_blocks), dim3(256), 0, st, geom, rankx, cand, cap, cand_hdr,
-                   (T)iou_thr, inc_cnt, inc, flags);
-    D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state, inc_cnt, inc,
-               flags);
+                   (T)iou_thr, inc_cnt);
+    IncOffsets offs{inc_cnt, inc_off};
+    if (int rc = d3d_run_scan(offs, n, inc_bsum, inc_total, -1, 0, ~0ull, st)) return rc;
+    D3D_LAUNCH("k_nms_fill", k_nms_fill, dim3(hits_blocks), dim3(256), 0, st, (const unsigned long long *)cand, cap,
+               (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, cursor, inc);
+    D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,
+               (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, flags);
     D3D_LAUNCH("k_nms_emit", k_nms_emit, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, order, (const uint8_t *)state,
                (const NmsFlags *)flags, suppressed);
     // dense path, gated on need_sweep inside the kernels
@@ -1171,7 +1209,8 @@ extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
     if (n < 1) n = 1;
     const size_t nb = (size_t)d3d_divup(n, 64);
     return d3d_align_up(nb * 64 * sizeof(BoxGeom<double>)) + d3d_align_up(nb * 64 * 16) + d3d_align_up(nb * 64) +
-           d3d_align_up(nb * 64 * 4) + d3d_align_up(nb * 64 * 4 * kIncCap) + 256 + d3d_align_up(nb * 8) +
+           d3d_align_up(nb * 64 * 4) * 3 + d3d_align_up((nb * 64 / kScanTile + 2) * 8) + 256 + d3d_align_up((size_t)nms_cand_capacity(n) * 4) +
+           256 + d3d_align_up(nb * 8) +
            d3d_align_up(sizeof(NmsCand)) +
            d3d_align_up((size_t)nms_cand_capacity(n) * 8) + 2 * d3d_align_up(nb * 64 * 4) + d3d_align_up((nb * 64 + kCandPad) * 16) +
            d3d_align_up(nb * 64 * 4) + d3d_align_up(d3d_internal_argsort_i32_bytes(n)) + d3d_align_up(nb * 64 * nb * 8) + 256;

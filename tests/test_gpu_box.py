@@ -413,3 +413,20 @@ def test_nms_fp32_scores_sorted_narrow():
     s2 = np.stack([s, s * 0.5], 1)                                    # class scores: max over classes
     keep2 = box2d_nms(T(b), T(s2), iou_method="rbox", iou_threshold=0.2, score_threshold=0.1).cpu().numpy()
     assert np.array_equal(keep2, exp)
+
+
+@pytest.mark.parametrize("nobj,per", [(30, 100), (8, 400)])
+def test_nms_detector_like_clusters(nobj, per):
+    """clusters of heavily overlapping boxes around each object (hundreds of hitters per box): incoming lists of any
+    length keep this on the list path; keep mask bit-exact with the oracle"""
+    from d3d_amd.box import box2d_nms
+    rng = np.random.default_rng(nobj)
+    c = np.stack([rng.random(nobj) * 300, rng.random(nobj) * 300, rng.random(nobj) * 20 + 10, rng.random(nobj) * 20 + 10,
+                  rng.random(nobj) * 6.28], 1)
+    b = np.repeat(c, per, 0) + rng.normal(0, 1, (nobj * per, 5)) * [1.5, 1.5, 1.0, 1.0, 0.05]
+    s = rng.permutation(nobj * per) / (nobj * per)
+    for method, thr in [("rbox", 0.5), ("box", 0.3)]:
+        keep = box2d_nms(T(b), T(s), iou_method=method, iou_threshold=thr).cpu().numpy()
+        exp = oracle.box2d_nms(b, s, iou_method=method, iou_threshold=thr)
+        assert np.array_equal(keep, exp), (method, int(np.sum(keep != exp)))
+        assert keep.sum() < 20 * nobj

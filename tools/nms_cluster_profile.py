@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""box2d_nms on detector-like input: clusters of heavily overlapping boxes around each object (development aid)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bench import kernel_profile, timed
+from d3d_amd.box import box2d_nms
+
+def clustered(nobj, per, seed):
+    rng = np.random.default_rng(seed)
+    c = np.stack([rng.random(nobj) * 2000, rng.random(nobj) * 2000, rng.random(nobj) * 20 + 10, rng.random(nobj) * 20 + 10,
+                  rng.random(nobj) * 6.28], 1)
+    b = np.repeat(c, per, 0) + rng.normal(0, 1, (nobj * per, 5)) * [1.5, 1.5, 1.0, 1.0, 0.05]
+    return b, rng.random(nobj * per)
+
+for nobj, per in [(1000, 100), (5000, 20), (200, 500)]:
+    b, s = clustered(nobj, per, 1)
+    bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+    f = lambda: box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5)
+    dt = timed(f, 5, 1)
+    prof = kernel_profile(f, 3)
+    print("%d objects x %d boxes: %.2f ms, kept %d" % (nobj, per, dt / 5 * 1e3, int(f().sum())),
+          {k: round(v["total_ms"] / 3 * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:6]})
