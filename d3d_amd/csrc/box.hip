@@ -467,7 +467,7 @@ __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__
 //                N^2/2 tests shrink to N x (boxes within one box length in x).  Survivors (min rank, max rank) go
 //                to a per-wavefront LDS batch that is flushed to the global candidate list with one atomic
 //   k_nms_hits   one candidate (p, q) per lane: exact IoU, hit -> append p to q's incoming list
-// If the candidate list or an incoming list overflows, or the fixed point needs too many rounds, need_sweep is set
+// If the candidate list overflows or the fixed point needs too many rounds, need_sweep is set
 // and the dense path runs instead (k_nms_pairs, k_nms_sweep -- gated on the flag, no host round trip).
 constexpr int kColsPerBlock = 8;
 constexpr int kCandLds = 256;        // LDS batch entries per wavefront (2 KiB)

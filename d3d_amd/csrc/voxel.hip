@@ -161,6 +161,7 @@ struct SlotInfo { bool occupied; u64 key; uint32_t first, cnt; };
 struct TabPacked {
     u64 *w;
     int ib, kb;
+    uint32_t *fmin = nullptr;        // [cap] indices below the claimer's (kInf when none)
     const BoxParams *box = nullptr;  // BoxKey: the key width is found on the device (clamped so that shifts stay defined)
     __device__ __forceinline__ int key_bits() const
     {
@@ -186,13 +187,10 @@ struct TabPacked {
                 u64 old = atomicAdd(&w[h], one);
                 arrival = (uint32_t)(old >> cs);
                 if (arrival == (uint32_t)((1ull << (64 - cs)) - 1)) status |= D3D_VOXEL_STATUS_PACK_OVERFLOW;
-                uint32_t f = (uint32_t)(old & imask);
-                while (i < f) {            // rare: an earlier point arrived later than a later one
-                    u64 expect = __hip_atomic_load(&w[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    f = (uint32_t)(expect & imask);
-                    if (i >= f) break;
-                    if (atomicCAS(&w[h], expect, (expect & ~imask) | i) == expect) break;
-                }
+                // an earlier point arrived later than the one that claimed the slot: the word keeps the claimer's index,
+                // lower ones go to a side array with ONE atomicMin (it cannot fail; a CAS on the word is retried whenever
+                // another point of a busy voxel gets counted in between).  first = min of the two (read()).
+                if (i < (uint32_t)(old & imask)) atomicMin(&fmin[h], i);
                 slot = (uint32_t)h;
                 return true;
             }
@@ -207,12 +205,14 @@ struct TabPacked {
         const u64 v = w[s];
         SlotInfo r;
         r.occupied = v != kEmpty;
+        const uint32_t f2 = fmin[s];
         r.first = (uint32_t)(v & ((1ull << ib) - 1));
+        if (f2 < r.first) r.first = f2;
         r.key = (v >> ib) & ((1ull << kb) - 1);
         r.cnt = (uint32_t)(v >> (ib + kb));
         return r;
     }
-    __device__ __forceinline__ void clear(u64 s) const { w[s] = kEmpty; }
+    __device__ __forceinline__ void clear(u64 s) const { w[s] = kEmpty; fmin[s] = kInf; }
 };
 
 // Plain table: key word + {first, count} word.  Any key < 2^64-1, any n < 2^31.
@@ -1149,7 +1149,7 @@ static int dense_index(const DenseKey &kf, const float *points, int64_t n, int c
         packed = ib + kb <= 56;
     }
     if (packed) {
-        TabPacked tab{w.tabA, ib, kb};
+        TabPacked tab{w.tabA, ib, kb, reinterpret_cast<uint32_t *>(w.tabB)};     // the plain table's second array is free
         return build_index(kf, tab, points, n, c, w, counts, o, st);
     }
     TabPlain tab{w.tabA, w.tabB};
@@ -1308,7 +1308,7 @@ extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c,
         for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
         kf.prm = reinterpret_cast<BoxParams *>(w.big_count + 16);
         kf.kb_max = 56 - ib;
-        TabPacked tab{w.tabA, ib, 0, kf.prm};
+        TabPacked tab{w.tabA, ib, 0, reinterpret_cast<uint32_t *>(w.tabB), kf.prm};
         int rc = build_index(kf, tab, points, n, c, w, counts, o, st);
         if (rc || n == 0) return rc;
         D3D_LAUNCH("k_meta", (k_meta<BoxKey, false>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, (const float4 *)nullptr,
