@@ -30,7 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-REQ_PEAK_GS = 26.3      # scattered 8-byte atomics/requests per ns, measured: tools/atomic_bench.hip
+REQ_PEAK_GS = 44.0      # scattered 8-byte requests per ns for the hash probe's mix (one coherent load + one CAS per
+                        # thread), measured: tools/atomic_bench.hip (atomics alone: 23-26 per ns)
 
 
 def sync():
@@ -243,7 +244,8 @@ def main():
                                timing="HIP events on the launch stream, separate pass of the same %d steps" % args.steps)
         if name == "k_insert":
             # the kernel's real limiter: scattered 8-byte requests (>= one coherent probe load + one atomic per point);
-            # ceiling measured with tools/atomic_bench.hip on MI355X (profiles/r01_d_atomic_bench.txt)
+            # ceiling measured with tools/atomic_bench.hip on MI355X (profiles/r01_g_atomic_bench.txt); 2 per point is a lower
+            # bound (linear probing adds ~0.2 loads, dense voxels serialise on one slot)
             req = 2 * n
             out["roofline"]["requests"] = dict(per_launch=req, achieved_G_per_s=round(req / dom[1]["avg_us"] / 1e3, 2),
                                                measured_peak_G_per_s=REQ_PEAK_GS,

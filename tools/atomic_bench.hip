@@ -44,6 +44,15 @@ __global__ __launch_bounds__(256) void k_ops(u64 *tab, u64 slots, int per_thread
     }
     if (acc == 0x1234567) *sink = acc;
 }
+// the voxel hash's probe: one coherent 8-byte load, then one CAS on the same slot (2 requests per thread)
+__global__ __launch_bounds__(256) void k_probe(u64 *tab, u64 slots, u64 *sink)
+{
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 h = mix64(gid * 131) % slots;
+    const u64 cur = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 old = atomicCAS(&tab[h], cur, cur + 1);
+    if (old == 0x1234567) *sink = old;
+}
 __global__ void k_sum(const u64 *tab, u64 slots, u64 *out)
 {
     u64 s = 0;
@@ -101,6 +110,12 @@ int main()
             hipMemset(tab, 0, slots * 8);
             float ms = timeit([&] { k_ops<1><<<blocks1, 256>>>(tab, slots, per1, sink); });
             printf("%4llu MB cas 64, %d per thread, %d blocks      %7.2f G atomics/s\n", mb, per1, blocks1, (double)blocks1 * 256 * per1 / ms / 1e6);
+        }
+        {
+            const int blocks1 = 16384;
+            hipMemset(tab, 0, slots * 8);
+            float ms = timeit([&] { k_probe<<<blocks1, 256>>>(tab, slots, sink); });
+            printf("%4llu MB coherent load + cas per thread        %7.2f G requests/s\n", mb, 2.0 * blocks1 * 256 / ms / 1e6);
         }
         hipFree(tab);
     }
