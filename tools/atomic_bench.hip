@@ -53,6 +53,17 @@ __global__ __launch_bounds__(256) void k_probe(u64 *tab, u64 slots, u64 *sink)
     const u64 old = atomicCAS(&tab[h], cur, cur + 1);
     if (old == 0x1234567) *sink = old;
 }
+// scattered plain accesses: OP 0 = 4-byte store, 1 = 16-byte store, 2 = 16-byte load, 3 = 8-byte load
+template <int OP>
+__global__ __launch_bounds__(256) void k_scat(u64 *tab, u64 slots, u64 *sink)
+{
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 h = mix64(gid * 131) % slots;
+    if (OP == 0) reinterpret_cast<unsigned int *>(tab)[h * 2] = (unsigned int)gid;
+    if (OP == 1) reinterpret_cast<uint4 *>(tab)[h / 2] = make_uint4((unsigned)gid, 1, 2, 3);
+    if (OP == 2) { uint4 v = reinterpret_cast<const uint4 *>(tab)[h / 2]; if (v.x == 0x1234567u) *sink = v.y; }
+    if (OP == 3) { u64 v = tab[h]; if (v == 0x1234567ull) *sink = v; }
+}
 __global__ void k_sum(const u64 *tab, u64 slots, u64 *out)
 {
     u64 s = 0;
@@ -110,6 +121,16 @@ int main()
             hipMemset(tab, 0, slots * 8);
             float ms = timeit([&] { k_ops<1><<<blocks1, 256>>>(tab, slots, per1, sink); });
             printf("%4llu MB cas 64, %d per thread, %d blocks      %7.2f G atomics/s\n", mb, per1, blocks1, (double)blocks1 * 256 * per1 / ms / 1e6);
+        }
+        {
+            const int blocksS = 16384;
+            float m0 = timeit([&] { k_scat<0><<<blocksS, 256>>>(tab, slots, sink); });
+            float m1 = timeit([&] { k_scat<1><<<blocksS, 256>>>(tab, slots, sink); });
+            float m2 = timeit([&] { k_scat<2><<<blocksS, 256>>>(tab, slots, sink); });
+            float m3 = timeit([&] { k_scat<3><<<blocksS, 256>>>(tab, slots, sink); });
+            const double tot = (double)blocksS * 256 / 1e6;
+            printf("%4llu MB scattered: 4-B store %.1f, 16-B store %.1f, 16-B load %.1f, 8-B load %.1f G/s\n", mb, tot / m0, tot / m1,
+                   tot / m2, tot / m3);
         }
         {
             const int blocks1 = 16384;
