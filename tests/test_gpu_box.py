@@ -430,3 +430,30 @@ def test_nms_detector_like_clusters(nobj, per):
         exp = oracle.box2d_nms(b, s, iou_method=method, iou_threshold=thr)
         assert np.array_equal(keep, exp), (method, int(np.sum(keep != exp)))
         assert keep.sum() < 20 * nobj
+
+
+def test_c_abi_error_codes():
+    """the C ABI reports bad arguments / unsupported options with status codes (nothing throws, nothing exits:
+    reference common.h:25,33-46 exit()s on CUDA errors and throws py::value_error on unsupported enums)"""
+    import ctypes
+    from d3d_amd import _lib
+    lib = _lib.load()
+    z = ctypes.c_void_p(0)
+    b = torch.zeros((4, 5), dtype=torch.float64, device="cuda")
+    out = torch.zeros((4, 4), dtype=torch.float64, device="cuda")
+    sup = torch.zeros((4,), dtype=torch.uint8, device="cuda")
+    order = torch.arange(4, dtype=torch.int64, device="cuda")
+    ws = torch.zeros((1 << 20,), dtype=torch.uint8, device="cuda")
+    p = _lib.ptr
+    assert lib.d3d_iou2d_forward(z, 4, p(b), 4, 2, _lib.F64, p(out), z, 0, z) == _lib.ERR_BAD_ARG               # null boxes
+    assert lib.d3d_iou2d_forward(p(b), -1, p(b), 4, 2, _lib.F64, p(out), z, 0, z) == _lib.ERR_BAD_ARG          # negative size
+    assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 4, _lib.F64, p(out), z, 0, z) == _lib.ERR_UNSUPPORTED       # GRBOX
+    assert lib.d3d_iou2d_forward(p(b), 0, p(b), 4, 2, _lib.F64, z, z, 0, z) == 0                                # empty: ok
+    assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 3, 0, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), ws.numel(),
+                         z) == _lib.ERR_UNSUPPORTED                                                             # GBOX in NMS
+    assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 2, 7, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), ws.numel(),
+                         z) == _lib.ERR_UNSUPPORTED                                                             # suppression enum
+    assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 2, 0, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), 16,
+                         z) == _lib.ERR_WORKSPACE                                                               # workspace too small
+    assert lib.d3d_status_string(_lib.ERR_WORKSPACE) == b"workspace too small"
+    torch.cuda.synchronize()
