@@ -470,7 +470,7 @@ __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__
 // If the candidate list overflows or the fixed point needs too many rounds, need_sweep is set
 // and the dense path runs instead (k_nms_pairs, k_nms_sweep -- gated on the flag, no host round trip).
 constexpr int kColsPerBlock = 8;
-constexpr int kCandLds = 256;        // LDS batch entries per wavefront (2 KiB)
+constexpr int kCandLds = 512;        // LDS batch entries per wavefront (4 KiB): one list reservation per 512 candidates
 
 constexpr int kCandUnroll = 8;       // independent loads in flight per lane
 constexpr int kCandMaxSplit = 16;    // wavefronts sharing one block of 64 boxes
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx
                                                   NmsCand *hdr, NmsFlags *flags)
 {
     constexpr int U = kCandUnroll;
-    __shared__ unsigned long long batch[4][kCandLds];
+    __shared__ unsigned int batch[4][kCandLds];             // (j - first box of the wavefront's block) << 6 | lane
     __shared__ float4 window[4][128];
     __shared__ unsigned int wcnt[4];
     __shared__ unsigned long long bbase;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx
     const uint32_t split = wid - rb * nsplit;
     const uint32_t i = rb * 64 + lane;            // n < 2^28 (nb <= 65535)
     const float4 fa = rb < nb ? fbx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned long long *q = batch[wave];
+    unsigned int *q = batch[wave];
     float4 *win = window[wave];
     unsigned int wn = 0;                                                  // wave-uniform fill of the batch
     bool overflow = false;
@@ -517,7 +517,10 @@ __global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx
     auto write_out = [&](unsigned long long gb) {
         __builtin_amdgcn_wave_barrier();
         for (unsigned int t = lane; t < wn; t += 64)
-            if (gb + t < segcap) seg[gb + t] = q[t];
+            if (gb + t < segcap) {
+                const unsigned int e = q[t];
+                seg[gb + t] = ((unsigned long long)(rb * 64 + (e & 63u)) << 32) | (unsigned long long)(rb * 64 + (e >> 6));
+            }
         if (gb + wn > segcap) { flags->need_sweep = 1; overflow = true; } // the dense path takes over: stop early
         wn = 0;
     };
@@ -550,8 +553,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx
                     const unsigned int cnt = (unsigned int)__popcll(m);
                     if (wn + cnt > (unsigned int)kCandLds) flush();
                     if (cand)       // x-order indices; k_nms_hits turns them into score ranks
-                        q[wn + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] =
-                            ((unsigned long long)i << 32) | (unsigned long long)(base + lane + d0 + u);
+                        q[wn + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = ((base + lane + d0 + u - rb * 64) << 6) | lane;
                     wn += cnt;
                 }
             }
@@ -580,7 +582,7 @@ template <typename T, bool ROTATED>
 __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__ geom,
                                                   const uint32_t *__restrict__ rankx,
                                                   unsigned long long *__restrict__ list, unsigned long long cap,
-                                                  const NmsCand *hdr, T thr, uint32_t *inc_cnt)
+                                                  const NmsCand *hdr, T thr, uint32_t *inc_cnt, uint32_t *__restrict__ arrival)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / kNmsListSegs;
     for (int sg = 0; sg < kNmsListSegs; sg++) {
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__
         const T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
         const bool hit = v > thr;                          // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
         seg[t] = (hit ? kHitBit : 0ull) | ((unsigned long long)p << 32) | q;
-        if (hit) atomicAdd(&inc_cnt[q], 1u);
+        if (hit) arrival[sg * segcap + t] = atomicAdd(&inc_cnt[q], 1u);      // position inside q's segment
     }
     }
 }
@@ -610,8 +612,8 @@ struct IncOffsets {                  // inc_off = exclusive scan of inc_cnt (d3d
 
 // pass B: the hits into the boxes' segments
 __global__ __launch_bounds__(256) void k_nms_fill(const unsigned long long *__restrict__ list, unsigned long long cap,
-                                                  const NmsCand *hdr, const uint32_t *__restrict__ inc_off, uint32_t *cursor,
-                                                  uint32_t *__restrict__ inc)
+                                                  const NmsCand *hdr, const uint32_t *__restrict__ inc_off,
+                                                  const uint32_t *__restrict__ arrival, uint32_t *__restrict__ inc)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / kNmsListSegs;
     for (int sg = 0; sg < kNmsListSegs; sg++) {
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(256) void k_nms_fill(const unsigned long long *__re
         const unsigned long long e = seg[t];
         if (!(e & kHitBit)) continue;
         const uint32_t q = (uint32_t)e, p = (uint32_t)(e >> 32) & 0x7fffffffu;
-        inc[inc_off[q] + atomicAdd(&cursor[q], 1u)] = p;
+        inc[inc_off[q] + arrival[sg * segcap + t]] = p;     // plain scattered store: no second atomic per hit
     }
     }
 }
@@ -801,6 +803,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     const unsigned long long cap = nms_cand_capacity(n);
     unsigned long long *cand = w.take<unsigned long long>((size_t)cap);
     uint32_t *inc = w.take<uint32_t>((size_t)cap);                     // hits <= candidates
+    uint32_t *arrival = w.take<uint32_t>((size_t)cap);
     int32_t *xkey = w.take<int32_t>(nb * 64);
     int32_t *perm = w.take<int32_t>(nb * 64);
     float4 *fbx = w.take<float4>(nb * 64 + kCandPad);
@@ -822,14 +825,14 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     const unsigned hits_blocks = (unsigned)std::min<unsigned long long>(d3d_divup((int64_t)cap, 256), 4096);
     if (rot)
         D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, true>), dim3(hits_blocks), dim3(256), 0, st, geom, rankx, cand, cap, cand_hdr,
-                   (T)iou_thr, inc_cnt);
+                   (T)iou_thr, inc_cnt, arrival);
     else
         D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, false>), dim3(hits_blocks), dim3(256), 0, st, geom, rankx, cand, cap, cand_hdr,
-                   (T)iou_thr, inc_cnt);
+                   (T)iou_thr, inc_cnt, arrival);
     IncOffsets offs{inc_cnt, inc_off};
     if (int rc = d3d_run_scan(offs, n, inc_bsum, inc_total, -1, 0, ~0ull, st)) return rc;
     D3D_LAUNCH("k_nms_fill", k_nms_fill, dim3(hits_blocks), dim3(256), 0, st, (const unsigned long long *)cand, cap,
-               (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, cursor, inc);
+               (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, (const uint32_t *)arrival, inc);
     D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,
                (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, flags);
     D3D_LAUNCH("k_nms_emit", k_nms_emit, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, order, (const uint8_t *)state,
@@ -1209,7 +1212,7 @@ extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
     if (n < 1) n = 1;
     const size_t nb = (size_t)d3d_divup(n, 64);
     return d3d_align_up(nb * 64 * sizeof(BoxGeom<double>)) + d3d_align_up(nb * 64 * 16) + d3d_align_up(nb * 64) +
-           d3d_align_up(nb * 64 * 4) * 3 + d3d_align_up((nb * 64 / kScanTile + 2) * 8) + 256 + d3d_align_up((size_t)nms_cand_capacity(n) * 4) +
+           d3d_align_up(nb * 64 * 4) * 3 + d3d_align_up((nb * 64 / kScanTile + 2) * 8) + 256 + 2 * d3d_align_up((size_t)nms_cand_capacity(n) * 4) +
            256 + d3d_align_up(nb * 8) +
            d3d_align_up(sizeof(NmsCand)) +
            d3d_align_up((size_t)nms_cand_capacity(n) * 8) + 2 * d3d_align_up(nb * 64 * 4) + d3d_align_up((nb * 64 + kCandPad) * 16) +
