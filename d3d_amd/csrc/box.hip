@@ -593,8 +593,16 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__
         const uint32_t r1 = rankx[e >> 32], r2 = rankx[e & 0xffffffffull];      // x-order index -> score rank
         const uint32_t p = r1 < r2 ? r1 : r2, q = r1 < r2 ? r2 : r1;
         const BoxGeom<T> a = geom[p], b = geom[q];
-        const T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
-        const bool hit = v > thr;                          // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
+        bool hit = false;
+        // the intersection is at most the overlap of the AABBs and at most either area: when even that bound gives
+        // IoU <= thr (with a margin far above the rounding of either side) the clip is not needed
+        const T ix = fmin(a.xmax, b.xmax) - fmax(a.xmin, b.xmin), iy = fmin(a.ymax, b.ymax) - fmax(a.ymin, b.ymin);
+        const T iub = fmin(ix * iy, fmin(a.area, b.area));
+        const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-4;
+        if (!ROTATED || !(thr >= 0) || !(iub * (1 + thr) < thr * (a.area + b.area) * (1 - margin))) {
+            const T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
+            hit = v > thr;                                 // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
+        }
         seg[t] = (hit ? kHitBit : 0ull) | ((unsigned long long)p << 32) | q;
         if (hit) arrival[sg * segcap + t] = atomicAdd(&inc_cnt[q], 1u);      // position inside q's segment
     }
