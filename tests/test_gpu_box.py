@@ -457,3 +457,25 @@ def test_c_abi_error_codes():
                          z) == _lib.ERR_WORKSPACE                                                               # workspace too small
     assert lib.d3d_status_string(_lib.ERR_WORKSPACE) == b"workspace too small"
     torch.cuda.synchronize()
+
+
+def test_nms_is_graph_capturable():
+    """no host synchronisation, no allocation inside the library: box2d_nms records into a HIP graph and replays"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms
+    b, s = synth.boxes2d_sparse(20000, 3)
+    bt, st = T(b), T(s)
+    ref = box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.4)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up off the capture stream (workspace allocation)
+        box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.4)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.4)
+    st.copy_(torch.from_numpy(s[::-1].copy()).cuda())    # new scores, same buffers
+    g.replay()
+    torch.cuda.synchronize()
+    exp = oracle.box2d_nms(b, s[::-1].copy(), iou_method="rbox", iou_threshold=0.4)
+    assert np.array_equal(out.cpu().numpy(), exp) and not np.array_equal(exp, ref.cpu().numpy())
