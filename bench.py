@@ -9,8 +9,8 @@ A "step" is one pass of the hot path over one batch of synthetic input already r
           dense contract + MEAN reduction through d3d_amd.voxel.VoxelGenerator (includes the one host read-back of
           the voxel count that the operator's variable-size return contract needs).
   N > 1 : the point-sharded voxelizer (one 1 M-point shard of config 2's shape per rank, weak scaling):
-          local hash voxelization -> RCCL all-gather of the per-rank voxel lists -> global numbering ->
-          RCCL all-reduce of the voxel feature grid (d3d_amd.voxel.sharded).
+          local hash voxelization -> RCCL all-gather of the per-rank occupancy (bitmaps or key lists) -> global
+          numbering -> RCCL all-reduce of the voxel feature grid (d3d_amd.voxel.sharded).
 Rank 0 prints ONE JSON line.  `value` is whole-job Mpoints/s.  The line also carries `roofline` (dominant kernel,
 timed with HIP events on its launch stream in a separate pass of the same K steps), `cpu_baseline` (the REAL
 reference voxelizer built from /root/reference into oracle/_ref, or the C port when that binary is absent) and
@@ -265,13 +265,17 @@ def main():
         from d3d_amd.voxel.sharded import ShardedVoxelGenerator
         gen = ShardedVoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, reduction="mean")
         step = lambda: gen(cloud)  # noqa: E731
+        out["voxels_global"] = int(step().coords.shape[0])
+        ncells = synth.KITTI_SHAPE[0] * synth.KITTI_SHAPE[1] * synth.KITTI_SHAPE[2]
+        out["exchange"] = "bitmaps (%.1f MB per rank) + one all-reduce of the voxel table, voxel ids by ownership" % (
+            ncells / 8 / 1e6) if (ncells + 63) // 64 <= n + 1 else "key lists + all-reduces of table and first indices"
         dt_local = timed(step, args.steps, args.warmup, barrier)
         t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         value = n * world * args.steps / dt / 1e6
         workload = ("config2-shaped shards: %d LiDAR-like points per rank (seed=rank), 0.1 m voxels, point-sharded "
-                    "voxelization + RCCL all-gather of voxel lists + all-reduce of the voxel feature grid" % n)
+                    "voxelization + RCCL all-gather of the occupancy + all-reduce of the voxel feature grid" % n)
         parallelism = "points sharded over %d GPUs" % world
 
     if rank == 0:
