@@ -143,6 +143,18 @@ def main():
     # descending: make counts tie-free among the kept ones is impossible in general -> store, compare as sets
     sparse_case("sp_desc", c3, unit, [10, 10, 10], max_voxels=10, max_voxels_filter="descending")
 
+    # far outliers on every axis (sparse coordinates up to +-9e5): exercises the widest keys
+    c4 = c3.copy()
+    c4[:6] = [[9e4, 0, 0], [-9e4, 0, 0], [0, 9e4, 0], [0, -9e4, 0], [0, 0, 9e4], [0, 0, -9e4]]
+    sparse_case("sp_outliers", c4, [-1, 1, -1, 1, -1, 1], [20, 20, 20], max_points=4, max_points_filter="trim")
+    # C = 8 features, max_points not a multiple of 16, scan-ordered input (sorted by azimuth), a 600-point voxel
+    c8 = rng.random((6000, 8), dtype=np.float32)
+    c8[:600, :3] = 0.55 + 0.01 * rng.random((600, 3), dtype=np.float32)
+    c8 = c8[np.argsort(np.arctan2(c8[:, 1] - 0.5, c8[:, 0] - 0.5), kind="stable")]
+    dense_case("c8_ordered", np.ascontiguousarray(c8), unit, [12, 12, 12], reduction="mean", max_points=30, max_voxels=2000)
+    sparse_case("sp_c8_minpts", np.ascontiguousarray(c8), unit, [12, 12, 12], min_points=3, max_points=7,
+                max_points_filter="trim", max_voxels=400, max_voxels_filter="trim")
+
     # raw-function cases (boundary functions called directly, voxelize.h:9-25)
     sp = to_np(impl.voxelize_3d_sparse(torch.from_numpy(kc), torch.tensor([0.1, 0.1, 0.1]), 3))
     cases["raw_sparse"] = dict(kind="raw_sparse", cloud=kc, size=np.array([0.1, 0.1, 0.1], np.float32), out=sp)
