@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libd3d_hip.so")
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = 0, -1, -2, -3, -4
 COUNT_VOXELS, COUNT_POINTS, COUNT_STATUS, COUNT_AUX, NUM_COUNTS = 0, 1, 2, 3, 4
-STATUS_COORD_OVERFLOW, STATUS_TABLE_FULL, STATUS_PACK_OVERFLOW = 1, 2, 4
+STATUS_COORD_OVERFLOW, STATUS_TABLE_FULL, STATUS_PACK_OVERFLOW, STATUS_BIN_OVERFLOW = 1, 2, 4, 8
 F32, F64 = 0, 1
 
 _vp, _i64, _i32, _sz, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_size_t, ctypes.c_float
@@ -24,6 +24,7 @@ SIGNATURES = {
     "d3d_last_hip_error": (ctypes.c_int, []),
     "d3d_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "d3d_voxel_force_plain": (ctypes.c_int, [ctypes.c_int]),
+    "d3d_voxel_set_path": (ctypes.c_int, [ctypes.c_int]),
     "d3d_voxelize_workspace_bytes": (_sz, [_i64, _i64]),
     "d3d_voxelize_3d_dense": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -41,6 +41,7 @@ constexpr int kSweepTile = 1024;              // slots per block in the table sw
 constexpr int kFlagTile = 256 * 64;           // flags per block in k_flagpack
 
 int g_force_plain = 0;                        // d3d_voxel_force_plain()
+int g_voxel_path = 0;                         // d3d_voxel_set_path(): 0 auto, 1 hash table, 2 binned (where eligible)
 
 __device__ __forceinline__ u64 mix64(u64 h)
 {
@@ -727,6 +728,74 @@ __global__ __launch_bounds__(256) void k_fill_generic(const float *__restrict__ 
 // counts (voxelize.cpp:137-157) but only P are ranked, so the wavefront walks the arrival-ordered segment
 // together; MEAN accumulates in fp64 (insensitive to the arrival order to ~1e-16 => reproducible).
 template <class Key, bool AGG4>
+__device__ __forceinline__ void meta_voxel(const Key &kf, int64_t v, const uint4 vi, const float4 *__restrict__ staged,
+                                           uint32_t P, int reduction, int64_t *coords, int32_t *npoints, uint32_t *voff,
+                                           unsigned char *pmask, float4 *agg, uint32_t *big_list, uint32_t *big_count,
+                                           int64_t *keys_out)
+{
+    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
+    long long cc[3];
+    kf.decode(((u64)vi.y << 32) | vi.x, cc);
+    coords[v * 3 + 0] = cc[0];
+    coords[v * 3 + 1] = cc[1];
+    coords[v * 3 + 2] = cc[2];
+    npoints[v] = (int32_t)vi.w;
+    if (voff) voff[v] = vi.z;
+    if (keys_out) keys_out[v] = (int64_t)(((u64)vi.y << 32) | vi.x);
+    if (pmask) {                                   // P % 16 == 0, 16-byte aligned (host-checked)
+        for (uint32_t k0 = 0; k0 < P; k0 += 16) {
+            uint32_t w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t b = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) b |= ((k0 + q * 4 + j) < vi.w ? 1u : 0u) << (8 * j);
+                w4[q] = b;
+            }
+            *reinterpret_cast<uint4 *>(pmask + v * P + k0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+    }
+    if (AGG4) {
+        const uint32_t cnt = vi.w, base = vi.z;
+        if (cnt <= P) {
+            float a0, a1, a2, a3;
+            a0 = a1 = a2 = a3 = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+            // 4 rows per step (independent loads);
+            // the accumulation stays strictly in point order
+            for (uint32_t k = 0; k < cnt; k += 4) {
+                const float4 *row = staged + base + k;         // contiguous rows, loads independent
+                const float4 xs[4] = {row[0], k + 1 < cnt ? row[1] : row[0], k + 2 < cnt ? row[2] : row[0],
+                                      k + 3 < cnt ? row[3] : row[0]};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (k + j < cnt) {
+                        const float4 x = xs[j];
+                        if (is_sum) { a0 += x.x; a1 += x.y; a2 += x.z; a3 += x.w; }
+                        else if (reduction == D3D_REDUCE_MAX) {      // std::max(acc, x) = acc < x ? x : acc
+                            a0 = a0 < x.x ? x.x : a0; a1 = a1 < x.y ? x.y : a1; a2 = a2 < x.z ? x.z : a2; a3 = a3 < x.w ? x.w : a3;
+                        } else {
+                            a0 = x.x < a0 ? x.x : a0; a1 = x.y < a1 ? x.y : a1; a2 = x.z < a2 ? x.z : a2; a3 = x.w < a3 ? x.w : a3;
+                        }
+                    }
+                }
+            }
+            if (reduction == D3D_REDUCE_MEAN) {              // voxelize.cpp:164 (float / int)
+                const float d = (float)(int32_t)cnt;
+                a0 = a0 / d; a1 = a1 / d; a2 = a2 / d; a3 = a3 / d;
+            }
+            agg[v] = make_float4(a0, a1, a2, a3);
+        }
+        // overflow voxels (every point counts, voxelize.cpp:137-157, but only P are ranked): hash path -> work list,
+        // reduced one-wavefront-per-voxel by k_overflow_reduce; binned path -> k_bucket_index left the result in the
+        // unused row P of the voxel's segment
+        if (cnt > P) {
+            if (big_list) big_list[atomicAdd(big_count, 1u)] = (uint32_t)v;
+            else agg[v] = staged[base + P];
+        }
+    }
+}
+
+template <class Key, bool AGG4>
 __global__ __launch_bounds__(256) void k_meta(Key kf, const float4 *__restrict__ points,
                                               const int64_t *__restrict__ counts, const uint4 *__restrict__ vinfo,
                                               const float4 *__restrict__ staged, const uint32_t *__restrict__ unsorted,
@@ -734,73 +803,14 @@ __global__ __launch_bounds__(256) void k_meta(Key kf, const float4 *__restrict__
                                               uint32_t *voff, unsigned char *pmask, float4 *agg, uint32_t *big_list,
                                               uint32_t *big_count, int64_t *keys_out = nullptr, int64_t status_row = -1)
 {
+    (void)points; (void)unsorted;
     const int64_t V = counts[D3D_COUNT_VOXELS];
     // sharded voxelizer: the status bits travel with the key list (row `status_row`, negative = not a cell)
     if (keys_out && status_row >= 0 && blockIdx.x == 0 && threadIdx.x == 0) keys_out[status_row] = -1 - counts[D3D_COUNT_STATUS];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
-        const bool ok = true;
-        uint4 vi = make_uint4(0, 0, 0, 0);
-        if (ok) {
-            vi = vinfo[v];
-            long long cc[3];
-            kf.decode(((u64)vi.y << 32) | vi.x, cc);
-            coords[v * 3 + 0] = cc[0];
-            coords[v * 3 + 1] = cc[1];
-            coords[v * 3 + 2] = cc[2];
-            npoints[v] = (int32_t)vi.w;
-            if (voff) voff[v] = vi.z;
-            if (keys_out) keys_out[v] = (int64_t)(((u64)vi.y << 32) | vi.x);
-            if (pmask) {                                   // P % 16 == 0, 16-byte aligned (host-checked)
-                for (uint32_t k0 = 0; k0 < P; k0 += 16) {
-                    uint32_t w4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        uint32_t b = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) b |= ((k0 + q * 4 + j) < vi.w ? 1u : 0u) << (8 * j);
-                        w4[q] = b;
-                    }
-                    *reinterpret_cast<uint4 *>(pmask + v * P + k0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                }
-            }
-        }
-        if (AGG4) {
-            const uint32_t cnt = vi.w, base = vi.z;
-            if (ok && cnt <= P) {
-                float a0, a1, a2, a3;
-                a0 = a1 = a2 = a3 = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
-                // 4 rows per step (independent loads);
-                // the accumulation stays strictly in point order
-                for (uint32_t k = 0; k < cnt; k += 4) {
-                    const float4 *row = staged + base + k;         // contiguous rows, loads independent
-                    const float4 xs[4] = {row[0], k + 1 < cnt ? row[1] : row[0], k + 2 < cnt ? row[2] : row[0],
-                                          k + 3 < cnt ? row[3] : row[0]};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (k + j < cnt) {
-                            const float4 x = xs[j];
-                            if (is_sum) { a0 += x.x; a1 += x.y; a2 += x.z; a3 += x.w; }
-                            else if (reduction == D3D_REDUCE_MAX) {      // std::max(acc, x) = acc < x ? x : acc
-                                a0 = a0 < x.x ? x.x : a0; a1 = a1 < x.y ? x.y : a1; a2 = a2 < x.z ? x.z : a2; a3 = a3 < x.w ? x.w : a3;
-                            } else {
-                                a0 = x.x < a0 ? x.x : a0; a1 = x.y < a1 ? x.y : a1; a2 = x.z < a2 ? x.z : a2; a3 = x.w < a3 ? x.w : a3;
-                            }
-                        }
-                    }
-                }
-                if (reduction == D3D_REDUCE_MEAN) {              // voxelize.cpp:164 (float / int)
-                    const float d = (float)(int32_t)cnt;
-                    a0 = a0 / d; a1 = a1 / d; a2 = a2 / d; a3 = a3 / d;
-                }
-                agg[v] = make_float4(a0, a1, a2, a3);
-            }
-            // overflow voxels (every point counts, voxelize.cpp:137-157, but only P are ranked) go to a work
-            // list and are reduced one-wavefront-per-voxel by k_overflow_reduce
-            if (ok && cnt > P) big_list[atomicAdd(big_count, 1u)] = (uint32_t)v;
-        }
-    }
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride)
+        meta_voxel<Key, AGG4>(kf, v, vinfo[v], staged, P, reduction, coords, npoints, voff, pmask, agg, big_list, big_count,
+                              keys_out);
 }
 
 // One wavefront per overflow voxel: walk its arrival-ordered segment 64 entries per step.  MEAN accumulates in
@@ -854,6 +864,364 @@ __global__ __launch_bounds__(256) void k_overflow_reduce(const float4 *__restric
             } else agg[v] = make_float4(e0, e1, e2, e3);
         }
     }
+}
+
+// ------------------------------------------------------------------ binned index (dense contract, C == 4)
+// The hash path above pays ~4 scattered HBM requests per point (probe, atomic, arrival list, staged row) at 25-80 G/s.
+// Here the points are first PARTITIONED by hash(cell) into buckets of ~512 (tile histogram -> row scan -> scatter of the
+// 16-byte rows: the only scattered global traffic per point), then one workgroup per bucket does all the per-point
+// work -- voxel lookup, counting, first index, rank in point order -- in LDS and writes the rows next to their rank.
+// Numbering by first occurrence stays a prefix count over point indices; it is merged with the per-voxel outputs
+// (k_meta_first), whose stores are then coalesced by voxel id.
+constexpr int kBinTile = 4096;                // points per workgroup in k_bin_count / k_bin_scatter
+constexpr int kBinThreads = 1024;             // ... 4 per lane: 16 wavefronts per CU keep the loads in flight
+constexpr int kBinMax = 4096;                 // buckets (12 bits of the per-point word, 12 more for the rank in the tile)
+constexpr int kBucketCap = 2048;              // points one k_bucket_index workgroup holds in registers (8 per lane)
+constexpr int kBucketSlots = 2048;            // LDS table slots (>= distinct cells of a bucket, always)
+constexpr uint32_t kNoBin = 0xffffffffu;
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu;
+    h ^= h >> 13; h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// per tile: bucket histogram in LDS; every point remembers {bucket, arrival number inside the tile}
+__global__ __launch_bounds__(kBinThreads) void k_bin_count(DenseKey kf, const float4 *__restrict__ points, int64_t n, uint32_t nbins,
+                                                   uint32_t ntiles, uint32_t *__restrict__ pbin, uint32_t *__restrict__ tilecnt,
+                                                   uint32_t *__restrict__ firstmap, int64_t *counts, uint32_t *big_count,
+                                                   uint32_t *ticket)
+{
+    __shared__ uint32_t h[kBinMax];
+    for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) h[b] = 0;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
+        if (threadIdx.x == 0) { *big_count = 0; *ticket = 0; }
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kBinTile + threadIdx.x;
+    float4 v[kBinTile / kBinThreads];
+#pragma unroll
+    for (int r = 0; r < kBinTile / kBinThreads; r++) {
+        const int64_t i = base + r * kBinThreads;
+        if (i < n) v[r] = points[i];
+    }
+#pragma unroll
+    for (int r = 0; r < kBinTile / kBinThreads; r++) {
+        const int64_t i = base + r * kBinThreads;
+        uint32_t word = kNoBin, status = 0;
+        if (i < n) {
+            const float p[3] = {v[r].x, v[r].y, v[r].z};
+            u64 key;
+            if (kf.make(p, key, status)) {
+                const uint32_t b = mix32((uint32_t)key) & (nbins - 1);
+                word = b | (atomicAdd(&h[b], 1u) << 12);
+            }
+        }
+        pbin[i] = word;                 // arrays are padded to the tile
+        firstmap[i] = kInf;
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) tilecnt[(size_t)blockIdx.x * nbins + b] = h[b];     // [tile][bucket]
+}
+
+// tilecnt[tile][bucket] -> exclusive prefix over the tiles, per bucket; bucket totals.  A workgroup owns 64 consecutive
+// buckets (one per lane, coalesced rows), its 16 wavefronts split the tiles.
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t *tilecnt, uint32_t nbins, uint32_t ntiles, uint32_t *totals)
+{
+    __shared__ uint32_t wsum[16][kWave];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * kWave + lane;
+    const uint32_t per = (ntiles + 15) / 16, t0 = w * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    uint32_t sum = 0;
+    if (b < nbins)
+        for (uint32_t t = t0; t < t1; t++) sum += tilecnt[(size_t)t * nbins + b];
+    wsum[w][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t x = wsum[k][lane];
+        if (k < w) run += x;
+        all += x;
+    }
+    if (b >= nbins) return;
+    if (w == 0) totals[b] = all;
+    for (uint32_t t = t0; t < t1; t++) {
+        const uint32_t x = tilecnt[(size_t)t * nbins + b];
+        tilecnt[(size_t)t * nbins + b] = run;
+        run += x;
+    }
+}
+
+// exclusive scan of the bucket totals into LDS (every workgroup of k_bin_scatter repeats it: 4096 values at most)
+__device__ __forceinline__ void bucket_bases(const uint32_t *__restrict__ totals, uint32_t nbins, uint32_t *base /* LDS [nbins] */,
+                                             u64 *smem)
+{
+    constexpr int PER = kBinMax / kBinThreads;
+    const uint32_t b0 = threadIdx.x * PER;
+    uint32_t tot[PER];
+    u64 sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        tot[k] = b0 + k < nbins ? totals[b0 + k] : 0u;
+        sum += tot[k];
+    }
+    u64 all;
+    u64 ex = block_excl_scan_u64<kBinThreads>(sum, &all, smem);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        if (b0 + k < nbins) base[b0 + k] = (uint32_t)ex;
+        ex += tot[k];
+    }
+    __syncthreads();
+}
+
+// rows (and point indices) to their bucket: position = base of the bucket + offset of the tile + arrival in the tile
+__global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const float4 *__restrict__ points, int64_t n, uint32_t nbins, uint32_t ntiles,
+                                                     const uint32_t *__restrict__ pbin, const uint32_t *__restrict__ tileoff,
+                                                     const uint32_t *__restrict__ totals, uint32_t *__restrict__ bucket_base,
+                                                     float4 *__restrict__ brow, uint32_t *__restrict__ bidx)
+{
+    __shared__ uint32_t off[kBinMax];
+    __shared__ u64 smem[kBinThreads / kWave];
+    (void)ntiles;
+    bucket_bases(totals, nbins, off, smem);
+    if (blockIdx.x == 0)                                     // for k_bucket_index
+        for (uint32_t b = threadIdx.x; b <= nbins; b += kBinThreads) bucket_base[b] = b < nbins ? off[b] : off[nbins - 1] + totals[nbins - 1];
+    for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) off[b] += tileoff[(size_t)blockIdx.x * nbins + b];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kBinTile + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < kBinTile / kBinThreads; r++) {
+        const int64_t i = base + r * kBinThreads;
+        if (i >= n) break;
+        const uint32_t word = pbin[i];
+        if (word == kNoBin) continue;
+        const uint32_t pos = off[word & (kBinMax - 1)] + (word >> 12);
+        brow[pos] = points[i];
+        bidx[pos] = (uint32_t)i;
+    }
+}
+
+// One workgroup per bucket, everything per point in LDS: cell -> slot (open addressing), count, first index, segment of
+// the indices, rank = number of smaller indices in the segment (early exit at max_points).  Outputs: the rows next to
+// their rank (staged), one record per voxel {cell, first, segment base, count} and firstmap[first] = record position.
+__global__ __launch_bounds__(256) void k_bucket_index(DenseKey kf, const float4 *__restrict__ brow,
+                                                      const uint32_t *__restrict__ bidx, const uint32_t *__restrict__ bucket_base,
+                                                      int hshift, uint32_t P, int reduction /* NONE: no aggregates */,
+                                                      float4 *__restrict__ staged, uint4 *__restrict__ vrec,
+                                                      uint32_t *__restrict__ firstmap, int64_t *counts)
+{
+    constexpr int ITEMS = kBucketCap / 256, T = kBucketSlots;
+    __shared__ uint32_t tkey[T], tcnt[T], tfirst[T], tbase[T];
+    __shared__ uint32_t seg[kBucketCap];
+    __shared__ u64 smem[256 / kWave];
+    __shared__ uint16_t oslot[kBucketCap / 2];      // overflow voxels of the bucket (count > P >= 1)
+    __shared__ uint32_t nover;
+    const uint32_t bb = bucket_base[blockIdx.x], m = bucket_base[blockIdx.x + 1] - bb;
+    if (m == 0) return;
+    if (m > (uint32_t)kBucketCap) {                 // the caller repeats the call on the hash path
+        if (threadIdx.x == 0) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_BIN_OVERFLOW);
+        return;
+    }
+    for (int s = threadIdx.x; s < T; s += 256) { tkey[s] = kInf; tcnt[s] = 0; tfirst[s] = kInf; }
+    if (threadIdx.x == 0) nover = 0;
+    float4 row[ITEMS];
+    uint32_t idx[ITEMS], slot[ITEMS], arr[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t q = threadIdx.x + r * 256;
+        if (q < m) { row[r] = brow[bb + q]; idx[r] = bidx[bb + q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t q = threadIdx.x + r * 256;
+        if (q < m) {
+            const float p[3] = {row[r].x, row[r].y, row[r].z};
+            u64 key64;
+            uint32_t st = 0;
+            kf.make(p, key64, st);                  // valid by construction (k_bin_count dropped the others)
+            const uint32_t key = (uint32_t)key64;
+            uint32_t s = (mix32(key) >> hshift) & (T - 1);
+            for (;;) {                              // distinct cells <= m <= T: a free slot always exists
+                const uint32_t old = atomicCAS(&tkey[s], kInf, key);
+                if (old == kInf || old == key) break;
+                s = (s + 1) & (T - 1);
+            }
+            slot[r] = s;
+            arr[r] = atomicAdd(&tcnt[s], 1u);
+            atomicMin(&tfirst[s], idx[r]);
+        }
+    }
+    __syncthreads();
+    // segments in slot order; voxel records
+    {
+        constexpr int PER = T / 256;
+        const int s0 = threadIdx.x * PER;
+        uint32_t c[PER];
+        u64 mine = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { c[k] = tcnt[s0 + k]; mine += ((u64)c[k] << 32) | (c[k] ? 1u : 0u); }
+        u64 all;
+        u64 ex = block_excl_scan_u64<256>(mine, &all, smem);
+        uint32_t base = (uint32_t)(ex >> 32), j = (uint32_t)ex;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            tbase[s0 + k] = base;
+            if (c[k]) {
+                const uint32_t f = tfirst[s0 + k];
+                vrec[bb + j] = make_uint4(tkey[s0 + k], f, bb + base, c[k]);
+                firstmap[f] = bb + j;
+                j++;
+                if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
+            }
+            base += c[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t q = threadIdx.x + r * 256;
+        if (q < m) seg[tbase[slot[r]] + arr[r]] = idx[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t q = threadIdx.x + r * 256;
+        if (q >= m) continue;
+        const uint32_t s = slot[r], cnt = tcnt[s], base = tbase[s], me = idx[r];
+        uint32_t rank = 0, k = 0;
+        const uint32_t *sg = seg + base;
+        for (; k + 8 <= cnt && rank < P; k += 8)      // 8 independent LDS reads per exit test
+            rank += (sg[k] < me) + (sg[k + 1] < me) + (sg[k + 2] < me) + (sg[k + 3] < me) + (sg[k + 4] < me) + (sg[k + 5] < me) +
+                    (sg[k + 6] < me) + (sg[k + 7] < me);
+        for (; k < cnt && rank < P; k++) rank += sg[k] < me;
+        if (rank < P) staged[bb + base + rank] = row[r];
+    }
+    // Overflow voxels: every point counts (voxelize.cpp:137-157) but only P are ranked: one wavefront per voxel walks
+    // its segment (now holding bucket positions) 64 rows per step; the rows come from the bucket in L2.  MEAN
+    // accumulates in fp64 (insensitive to the order to ~1e-16 => the same float run to run; differs from the
+    // reference's fp32 running sum by rounding only).  The result waits in row P of the voxel's segment, which no
+    // ranked point uses.
+    const uint32_t no = reduction != D3D_REDUCE_NONE ? nover : 0u;
+    if (no == 0) return;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t q = threadIdx.x + r * 256;
+        if (q < m) seg[tbase[slot[r]] + arr[r]] = q;
+    }
+    __syncthreads();
+    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
+    const int lane = threadIdx.x & (kWave - 1);
+    for (uint32_t o = threadIdx.x >> 6; o < no; o += 256 / kWave) {
+        const uint32_t s = oslot[o], base = tbase[s], cnt = tcnt[s];
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        float e0, e1, e2, e3;
+        e0 = e1 = e2 = e3 = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
+        for (uint32_t k = lane; k < cnt; k += kWave) {
+            const float4 x = brow[bb + seg[base + k]];
+            if (is_sum) { s0 += x.x; s1 += x.y; s2 += x.z; s3 += x.w; }
+            else if (reduction == D3D_REDUCE_MAX) {
+                e0 = e0 < x.x ? x.x : e0; e1 = e1 < x.y ? x.y : e1; e2 = e2 < x.z ? x.z : e2; e3 = e3 < x.w ? x.w : e3;
+            } else {
+                e0 = x.x < e0 ? x.x : e0; e1 = x.y < e1 ? x.y : e1; e2 = x.z < e2 ? x.z : e2; e3 = x.w < e3 ? x.w : e3;
+            }
+        }
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            if (is_sum) {
+                s0 += __shfl_xor(s0, off, kWave); s1 += __shfl_xor(s1, off, kWave);
+                s2 += __shfl_xor(s2, off, kWave); s3 += __shfl_xor(s3, off, kWave);
+            } else {
+                const float t0 = __shfl_xor(e0, off, kWave), t1 = __shfl_xor(e1, off, kWave);
+                const float t2 = __shfl_xor(e2, off, kWave), t3 = __shfl_xor(e3, off, kWave);
+                if (reduction == D3D_REDUCE_MAX) {
+                    e0 = e0 < t0 ? t0 : e0; e1 = e1 < t1 ? t1 : e1; e2 = e2 < t2 ? t2 : e2; e3 = e3 < t3 ? t3 : e3;
+                } else {
+                    e0 = t0 < e0 ? t0 : e0; e1 = t1 < e1 ? t1 : e1; e2 = t2 < e2 ? t2 : e2; e3 = t3 < e3 ? t3 : e3;
+                }
+            }
+        }
+        if (lane == 0) {
+            float4 out;
+            if (is_sum) {
+                const float d = reduction == D3D_REDUCE_MEAN ? (float)(int32_t)cnt : 1.0f;
+                out = make_float4((float)s0 / d, (float)s1 / d, (float)s2 / d, (float)s3 / d);
+            } else out = make_float4(e0, e1, e2, e3);
+            staged[bb + base + P] = out;
+        }
+    }
+}
+
+// 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF; the last workgroup
+// to finish scans the (<= 256) block totals and publishes the voxel count
+__global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict__ firstmap, uint32_t *fwpre, uint32_t *bsumF,
+                                                      uint32_t *ticket, int64_t *counts, u64 max_voxels)
+{
+    __shared__ u64 smem[1024 / kWave];
+    __shared__ uint32_t wcnt[256];
+    __shared__ bool last;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    // wavefront w: words [16 w, 16 w + 16) of the tile's 256, all 16 loads in flight
+    const uint32_t *src = firstmap + ((size_t)blockIdx.x * 256 + w * 16) * 64 + lane;
+    uint32_t e[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) e[j] = src[(size_t)j * 64];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const unsigned long long bal = __ballot(e[j] != kInf);
+        if (lane == j) wcnt[w * 16 + j] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    u64 tot;
+    const u64 ex = block_excl_scan_u64<1024>(threadIdx.x < 256 ? (u64)wcnt[threadIdx.x] : 0ull, &tot, smem);
+    if (threadIdx.x < 256) fwpre[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint32_t)ex;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&bsumF[blockIdx.x], (uint32_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const uint32_t x = threadIdx.x < gridDim.x ? __hip_atomic_load(&bsumF[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    u64 all;
+    const u64 e2 = block_excl_scan_u64<1024>((u64)x, &all, smem);
+    if (threadIdx.x < gridDim.x) bsumF[threadIdx.x] = (uint32_t)e2;
+    if (threadIdx.x == 0) {
+        counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
+        counts[D3D_COUNT_AUX] = 0;
+    }
+}
+
+// one lane per point index: the lanes that are a voxel's first point number it (prefix count = the reference's
+// first-occurrence order, voxelize.cpp:119), fetch its record and write all per-voxel outputs -- coalesced, because
+// consecutive first points are consecutive voxel ids
+template <bool AGG4>
+__global__ __launch_bounds__(256) void k_meta_first(DenseKey kf, int64_t npad, const uint32_t *__restrict__ firstmap,
+                                                    const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
+                                                    const uint4 *__restrict__ vrec, uint32_t max_voxels, uint4 *__restrict__ vinfo,
+                                                    const float4 *__restrict__ staged, uint32_t P, int reduction, int64_t *coords,
+                                                    int32_t *npoints, unsigned char *pmask, float4 *agg)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npad) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t e = firstmap[i];
+    const unsigned long long bal = __ballot(e != kInf);
+    if (e == kInf) return;
+    const uint32_t vid = bsumF[i / kFlagTile] + fwpre[i >> 6] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (vid >= max_voxels) return;                          // voxelize.cpp:116-117: later voxels are never created
+    const uint4 rec = vrec[e];
+    const uint4 vi = make_uint4(rec.x, 0u, rec.z, rec.w);
+    vinfo[vid] = vi;
+    meta_voxel<DenseKey, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, nullptr, pmask, agg, nullptr, nullptr,
+                               nullptr);
 }
 
 // ------------------------------------------------------------------ filter (direct-addressed by voxel id)
@@ -1156,6 +1524,69 @@ static int dense_index(const DenseKey &kf, const float *points, int64_t n, int c
     return build_index(kf, tab, points, n, c, w, counts, o, st);
 }
 
+struct DenseOut {
+    uint32_t P, max_voxels;
+    int reduction;
+    bool agg4, fuse_pmask;
+    int64_t *coords;
+    int32_t *npoints;
+    unsigned char *pmask;
+    float *aggregates;
+};
+
+// n points -> which index path (dense contract, C == 4 rows)
+static bool binned_eligible(const DenseKey &kf, int64_t n, const VoxelWs &w, uint32_t *nbins_out, int *hshift_out)
+{
+    const char *env = getenv("D3D_VOXEL_PATH");
+    int mode = g_voxel_path;                            // an explicit d3d_voxel_set_path() wins over the environment
+    if (mode == 0 && env && env[0] == 'h') mode = 1;
+    if (mode == 0 && env && env[0] == 'b') mode = 2;
+    if (mode == 1 || n <= 0) return false;
+    if (mode == 0 && n < 32768) return false;           // a handful of workgroups: the launch count decides, not the requests
+    const double cells = (double)kf.shape[0] * (double)kf.shape[1] * (double)kf.shape[2];
+    if (cells >= 4294967295.0) return false;            // 32-bit cell keys in LDS
+    uint32_t nbins = 1;
+    int hshift = 0;
+    while (nbins < (uint32_t)kBinMax && (int64_t)nbins * 512 < n) { nbins <<= 1; hshift++; }
+    if ((int64_t)nbins * 1024 < n) return false;        // more than 4 M points: buckets would outgrow a workgroup
+    const uint64_t ntiles = (uint64_t)w.npad / kBinTile;
+    if ((uint64_t)nbins * ntiles * 4 > w.cap * 8 || 2 * (uint64_t)nbins + 2 > w.cap) return false;
+    *nbins_out = nbins;
+    *hshift_out = hshift;
+    return true;
+}
+
+static int binned_index(const DenseKey &kf, const float4 *p4, int64_t n, const VoxelWs &w, uint32_t nbins, int hshift,
+                        int64_t *counts, const DenseOut &o, hipStream_t st)
+{
+    const uint32_t ntiles = (uint32_t)(w.npad / kBinTile);
+    float4 *brow = reinterpret_cast<float4 *>(w.tabA);          // cap * 8 bytes >= 16 n
+    uint32_t *tilecnt = reinterpret_cast<uint32_t *>(w.tabB);
+    uint4 *vrec = reinterpret_cast<uint4 *>(w.aux);
+    uint32_t *bucket_base = w.vidarr, *ticket = w.vidarr + nbins + 1, *totals = w.vidarr + nbins + 2;
+    uint32_t *pbin = w.pslot, *bidx = w.parr, *firstmap = w.list;
+    D3D_LAUNCH("k_bin_count", k_bin_count, dim3(ntiles), dim3(kBinThreads), 0, st, kf, p4, n, nbins, ntiles, pbin, tilecnt, firstmap,
+               counts, w.big_count, ticket);
+    D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
+    D3D_LAUNCH("k_bin_scatter", k_bin_scatter, dim3(ntiles), dim3(kBinThreads), 0, st, p4, n, nbins, ntiles, pbin, tilecnt, totals,
+               bucket_base, brow, bidx);
+    D3D_LAUNCH("k_bucket_index", k_bucket_index, dim3(nbins), dim3(256), 0, st, kf, brow, bidx, bucket_base, hshift, o.P,
+               o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts);
+    const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 256 (n <= 4 M)
+    D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, ticket, counts,
+               (u64)o.max_voxels);
+    const dim3 grid((unsigned)(w.npad / 256));
+    if (o.agg4)
+        D3D_LAUNCH("k_meta_first", k_meta_first<true>, grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
+                   o.max_voxels, w.vinfo, w.staged, o.P, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr,
+                   reinterpret_cast<float4 *>(o.aggregates));
+    else
+        D3D_LAUNCH("k_meta_first", k_meta_first<false>, grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
+                   o.max_voxels, w.vinfo, w.staged, o.P, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr,
+                   (float4 *)nullptr);
+    return D3D_OK;
+}
+
 static int make_dense_key(const int32_t *shape, const float *bound, DenseKey &kf)
 {
     if (shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0) return D3D_ERR_BAD_ARG;
@@ -1177,6 +1608,13 @@ static int make_dense_key(const int32_t *shape, const float *bound, DenseKey &kf
 extern "C" int d3d_voxel_force_plain(int on)
 {
     g_force_plain = on ? 1 : 0;
+    return D3D_OK;
+}
+
+extern "C" int d3d_voxel_set_path(int path)
+{
+    if (path < 0 || path > 2) return D3D_ERR_BAD_ARG;
+    g_voxel_path = path;
     return D3D_OK;
 }
 
@@ -1208,27 +1646,35 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
 
     const bool al16 = ((reinterpret_cast<uintptr_t>(points) & 15) == 0) && ((reinterpret_cast<uintptr_t>(voxels) & 15) == 0);
     const bool vec4 = (c == 4) && al16 && (reduction == D3D_REDUCE_NONE || (reinterpret_cast<uintptr_t>(aggregates) & 15) == 0);
-    IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr, vec4};
-    rc = dense_index(kf, points, n, c, w, counts, o, st);
-    if (rc) return rc;
-    if (n == 0 || max_voxels == 0) return D3D_OK;
-
     const int64_t cap = n < max_voxels ? n : (int64_t)max_voxels;
     const uint32_t P = (uint32_t)max_points;
     const bool fuse_pmask = P > 0 && (P % 16 == 0) && ((reinterpret_cast<uintptr_t>(pmask) & 15) == 0);
     const bool agg4 = vec4 && reduction != D3D_REDUCE_NONE && P > 0;
-    const dim3 mgrid(grid_for(cap, 256));
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
-    if (agg4)
-        D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), mgrid, dim3(256), 0, st, kf, p4, counts, w.vinfo, w.staged, w.unsorted, P,
-                   reduction, coords, npoints, w.voff, fuse_pmask ? pmask : nullptr, reinterpret_cast<float4 *>(aggregates),
-                   w.big_list, w.big_count);
-    else
-        D3D_LAUNCH("k_meta", (k_meta<DenseKey, false>), mgrid, dim3(256), 0, st, kf, p4, counts, w.vinfo, w.staged, w.unsorted, P,
-                   reduction, coords, npoints, w.voff, fuse_pmask ? pmask : nullptr, (float4 *)nullptr, w.big_list, w.big_count);
-    if (agg4)
-        D3D_LAUNCH("k_overflow_reduce", k_overflow_reduce, dim3(512), dim3(256), 0, st, p4, w.vinfo, w.unsorted, w.big_list,
-                   w.big_count, reduction, reinterpret_cast<float4 *>(aggregates));
+    uint32_t nbins = 0;
+    int hshift = 0;
+    if (vec4 && max_voxels > 0 && binned_eligible(kf, n, w, &nbins, &hshift)) {
+        DenseOut d{P, (uint32_t)max_voxels, reduction, agg4, fuse_pmask, coords, npoints, pmask, aggregates};
+        rc = binned_index(kf, p4, n, w, nbins, hshift, counts, d, st);
+        if (rc) return rc;
+    } else {
+        IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr, vec4};
+        rc = dense_index(kf, points, n, c, w, counts, o, st);
+        if (rc) return rc;
+        if (n == 0 || max_voxels == 0) return D3D_OK;
+        const dim3 mgrid(grid_for(cap, 256));
+        if (agg4)
+            D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), mgrid, dim3(256), 0, st, kf, p4, counts, w.vinfo, w.staged, w.unsorted,
+                       P, reduction, coords, npoints, w.voff, fuse_pmask ? pmask : nullptr,
+                       reinterpret_cast<float4 *>(aggregates), w.big_list, w.big_count);
+        else
+            D3D_LAUNCH("k_meta", (k_meta<DenseKey, false>), mgrid, dim3(256), 0, st, kf, p4, counts, w.vinfo, w.staged, w.unsorted,
+                       P, reduction, coords, npoints, w.voff, fuse_pmask ? pmask : nullptr, (float4 *)nullptr, w.big_list,
+                       w.big_count);
+        if (agg4)
+            D3D_LAUNCH("k_overflow_reduce", k_overflow_reduce, dim3(512), dim3(256), 0, st, p4, w.vinfo, w.unsorted, w.big_list,
+                       w.big_count, reduction, reinterpret_cast<float4 *>(aggregates));
+    }
     if (P == 0) return D3D_OK;
     if (vec4)
         D3D_LAUNCH("k_fill_c4", k_fill_c4, dim3(grid_for(cap * P, 256, 256 * 32)), dim3(256), 0, st, w.staged, counts, w.vinfo,

@@ -78,6 +78,10 @@ class _PackOverflow(Exception):
     """a voxel outgrew the packed hash slot's count field: the call is repeated with the general layout"""
 
 
+class _BinOverflow(Exception):
+    """dense contract: a bucket of the binned index outgrew its workgroup: the call is repeated on the hash-table path"""
+
+
 def _counts_to_host(counts, what):
     host = counts.cpu()     # the one host sync of a call: sizes of the variable-length outputs
     _check_status(int(host[_lib.COUNT_STATUS]), what)
@@ -85,6 +89,8 @@ def _counts_to_host(counts, what):
 
 
 def _check_status(status, what):
+    if status & _lib.STATUS_BIN_OVERFLOW:
+        raise _BinOverflow(what)
     if status & _lib.STATUS_PACK_OVERFLOW:
         raise _PackOverflow(what)
     if status & _lib.STATUS_TABLE_FULL:
@@ -99,6 +105,12 @@ def _with_plain_retry(lib, run):
     a bounding box of voxel coordinates too large for the key field) repeat with the general two-word slots"""
     try:
         return run()
+    except _BinOverflow:
+        lib.d3d_voxel_set_path(1)
+        try:
+            return _with_plain_retry(lib, run)
+        finally:
+            lib.d3d_voxel_set_path(0)
     except _PackOverflow:
         lib.d3d_voxel_force_plain(1)
         try:

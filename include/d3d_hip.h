@@ -50,9 +50,13 @@ enum { D3D_F32 = 0, D3D_F64 = 1 };
 enum { D3D_VOXEL_STATUS_COORD_OVERFLOW = 1,   /* sparse: |floor(p/size)| >= 2^20 (or NaN)      */
        D3D_VOXEL_STATUS_TABLE_FULL = 2,       /* internal hash table overflow (cannot happen
                                                  with the documented workspace size)           */
-       D3D_VOXEL_STATUS_PACK_OVERFLOW = 4 };  /* a voxel holds more points than the packed one-word
+       D3D_VOXEL_STATUS_PACK_OVERFLOW = 4,    /* a voxel holds more points than the packed one-word
                                                  hash slot can count: results are invalid; repeat the
                                                  call after d3d_voxel_force_plain(1)             */
+       D3D_VOXEL_STATUS_BIN_OVERFLOW = 8 };   /* dense, binned index: a bucket of the partition got more
+                                                 points than one workgroup holds (a few cells with
+                                                 thousands of points each): results are invalid; repeat
+                                                 the call after d3d_voxel_set_path(1)            */
 enum { D3D_COUNT_VOXELS = 0, D3D_COUNT_POINTS = 1, D3D_COUNT_STATUS = 2, D3D_COUNT_AUX = 3, D3D_NUM_COUNTS = 4 };
 
 int         d3d_abi_version(void);
@@ -64,6 +68,11 @@ const char *d3d_status_string(int status);
 /* 1 = always use the general two-word hash slots (any count / key width); 0 = automatic (default):
  * one-word slots {count | key | first index} whenever they fit 64 bits (one atomic per point). */
 int d3d_voxel_force_plain(int on);
+
+/* index path of d3d_voxelize_3d_dense for C == 4 rows: 0 = automatic (default: binned from 32 k points up to 4 M),
+ * 1 = hash table in HBM (any input), 2 = binned (points partitioned into buckets, per-bucket index in LDS) whenever the
+ * grid has < 2^32 - 1 cells.  Both give identical outputs; see DESIGN.md section 4. */
+int d3d_voxel_set_path(int path);
 
 /* scratch for any of the three voxel entry points on n points / nvox voxels */
 size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels);

@@ -307,3 +307,80 @@ def test_results_are_reproducible_run_to_run():
                     assert torch.equal(a[fit], b[fit]) and torch.allclose(a, b, rtol=1e-6, atol=0)
                 else:
                     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------- dense contract: binned index path
+@pytest.fixture
+def voxel_path():
+    from d3d_amd import _lib
+    lib = _lib.load()
+    yield lib.d3d_voxel_set_path
+    lib.d3d_voxel_set_path(0)
+
+
+@pytest.mark.parametrize("n,P,mv,reduction", [(1, 4, 10, "mean"), (7, 1, 7, "max"), (300, 3, 100, "min"), (5000, 32, 5000, "mean"),
+                                              (40000, 5, 1500, "none"), (70000, 2, 70000, "mean")])
+def test_binned_index_vs_oracle(voxel_path, n, P, mv, reduction):
+    """forced onto the binned path at every size (automatic from 32 k points): same outputs as the reference's loop"""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    cloud = synth.lidar_like(n, 31 + n)
+    kw = dict(reduction=reduction, max_points=P, max_voxels=mv, dense=True)
+    exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(cloud)
+    voxel_path(2)
+    ret = _np(VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(torch.from_numpy(cloud).cuda()))
+    check_dense(ret, exp, P)
+
+
+@pytest.mark.parametrize("reduction", ["none", "mean", "max"])
+def test_binned_and_hash_index_paths_agree(voxel_path, reduction):
+    """250 k points with NaNs, out-of-range points and exact duplicates: every output tensor identical on both paths"""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand((250000, 4), generator=g) * torch.tensor([90.0, 100.0, 6.0, 1.0]) - torch.tensor([10.0, 50.0, 4.0, 0.0])
+    pts[::97, 0] = float("nan")
+    pts[1000:3000] = pts[0:2000].clone()
+    pts = pts.cuda()
+    out = []
+    for path in (1, 2):
+        voxel_path(path)
+        out.append(_np(VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, reduction=reduction, max_points=3, max_voxels=60000,
+                                      dense=True)(pts)))
+    assert out[0]["coords"].shape[0] == 60000
+    for k in out[0]:
+        if k == "aggregates":
+            assert np.allclose(out[0][k], out[1][k], rtol=1e-6, atol=1e-6, equal_nan=True), k
+        else:
+            assert np.array_equal(out[0][k], out[1][k], equal_nan=True), k
+
+
+def test_binned_bucket_overflow_repeats_on_the_hash_path(voxel_path):
+    """300 k points in 128 cells: buckets of the partition outgrow a workgroup, the C ABI reports BIN_OVERFLOW and the
+    operator repeats the call with the hash-table index"""
+    import ctypes
+    from d3d_amd import _lib, synth
+    from d3d_amd.voxel import voxelize_3d_dense
+    lib = _lib.load()
+    cloud = synth.lidar_like(300000, 41)
+    pts = torch.from_numpy(cloud).cuda()
+    n, P = pts.shape[0], 4
+    shape = (ctypes.c_int32 * 3)(8, 8, 2)
+    bound = (ctypes.c_float * 6)(*synth.KITTI_BOUNDS)
+    voxels = torch.empty((n, P, 4), device="cuda")
+    coords = torch.empty((n, 3), dtype=torch.int64, device="cuda")
+    pmask = torch.empty((n, P), dtype=torch.uint8, device="cuda")
+    npts = torch.empty((n,), dtype=torch.int32, device="cuda")
+    agg = torch.empty((n, 4), device="cuda")
+    counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device="cuda")
+    ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), pts.device)
+    voxel_path(2)
+    rc = lib.d3d_voxelize_3d_dense(_lib.ptr(pts), n, 4, ctypes.cast(shape, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p),
+                                   P, n, 1, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts), _lib.ptr(agg),
+                                   _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+    assert rc == 0
+    assert int(counts.cpu()[_lib.COUNT_STATUS]) & _lib.STATUS_BIN_OVERFLOW
+    ret = {k: v.cpu().numpy() for k, v in voxelize_3d_dense(pts, [8, 8, 2], synth.KITTI_BOUNDS, P, n, 1).items()}
+    exp = oracle.voxelize_3d_dense(cloud, [8, 8, 2], synth.KITTI_BOUNDS, P, n, 1)
+    assert ret["coords"].shape[0] == 128
+    check_dense(ret, exp, P)
