@@ -880,6 +880,15 @@ constexpr int kBucketCap = 2048;              // points one k_bucket_index workg
 constexpr int kBucketSlots = 2048;            // LDS table slots (>= distinct cells of a bucket, always)
 constexpr uint32_t kNoBin = 0xffffffffu;
 
+// reduce contract (d3d_voxelize_3d_reduce) on the binned path
+struct BinnedExtras {
+    int64_t *first_out;       // [V] index_offset + first point index
+    int64_t index_offset;
+    int64_t *keys_out;        // [V] cell key; row status_row = -1 - status bits
+    int64_t status_row;
+    uint32_t *vidof;          // [records] voxel id of a record (for the point -> voxel map)
+};
+
 __device__ __forceinline__ uint32_t mix32(uint32_t h)
 {
     h ^= h >> 16; h *= 0x85ebca6bu;
@@ -891,14 +900,12 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h)
 // per tile: bucket histogram in LDS; every point remembers {bucket, arrival number inside the tile}
 __global__ __launch_bounds__(kBinThreads) void k_bin_count(DenseKey kf, const float4 *__restrict__ points, int64_t n, uint32_t nbins,
                                                    uint32_t ntiles, uint32_t *__restrict__ pbin, uint32_t *__restrict__ tilecnt,
-                                                   uint32_t *__restrict__ firstmap, int64_t *counts, uint32_t *big_count,
-                                                   uint32_t *ticket)
+                                                   uint32_t *__restrict__ firstmap, int64_t *counts, int64_t *mapping)
 {
     __shared__ uint32_t h[kBinMax];
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) h[b] = 0;
     if (blockIdx.x == 0) {
         if (threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
-        if (threadIdx.x == 0) { *big_count = 0; *ticket = 0; }
     }
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kBinTile + threadIdx.x;
@@ -922,6 +929,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(DenseKey kf, const fl
         }
         pbin[i] = word;                 // arrays are padded to the tile
         firstmap[i] = kInf;
+        if (mapping && i < n) mapping[i] = -1;      // points outside the grid keep it
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) tilecnt[(size_t)blockIdx.x * nbins + b] = h[b];     // [tile][bucket]
@@ -1013,7 +1021,8 @@ __global__ __launch_bounds__(256) void k_bucket_index(DenseKey kf, const float4 
                                                       const uint32_t *__restrict__ bidx, const uint32_t *__restrict__ bucket_base,
                                                       int hshift, uint32_t P, int reduction /* NONE: no aggregates */,
                                                       float4 *__restrict__ staged, uint4 *__restrict__ vrec,
-                                                      uint32_t *__restrict__ firstmap, int64_t *counts)
+                                                      uint32_t *__restrict__ firstmap, int64_t *counts,
+                                                      uint32_t *__restrict__ precpos /* optional: record of every point */)
 {
     constexpr int ITEMS = kBucketCap / 256, T = kBucketSlots;
     __shared__ uint32_t tkey[T], tcnt[T], tfirst[T], tbase[T];
@@ -1076,6 +1085,7 @@ __global__ __launch_bounds__(256) void k_bucket_index(DenseKey kf, const float4 
                 const uint32_t f = tfirst[s0 + k];
                 vrec[bb + j] = make_uint4(tkey[s0 + k], f, bb + base, c[k]);
                 firstmap[f] = bb + j;
+                tfirst[s0 + k] = bb + j;            // from here on: the slot's record
                 j++;
                 if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
             }
@@ -1101,6 +1111,7 @@ __global__ __launch_bounds__(256) void k_bucket_index(DenseKey kf, const float4 
                     (sg[k + 6] < me) + (sg[k + 7] < me);
         for (; k < cnt && rank < P; k++) rank += sg[k] < me;
         if (rank < P) staged[bb + base + rank] = row[r];
+        if (precpos) precpos[bb + q] = tfirst[s];
     }
     // Overflow voxels: every point counts (voxelize.cpp:137-157) but only P are ranked: one wavefront per voxel walks
     // its segment (now holding bucket positions) 64 rows per step; the rows come from the bucket in L2.  MEAN
@@ -1158,14 +1169,12 @@ __global__ __launch_bounds__(256) void k_bucket_index(DenseKey kf, const float4 
     }
 }
 
-// 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF; the last workgroup
-// to finish scans the (<= 256) block totals and publishes the voxel count
-__global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict__ firstmap, uint32_t *fwpre, uint32_t *bsumF,
-                                                      uint32_t *ticket, int64_t *counts, u64 max_voxels)
+// 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF (<= 256 of them:
+// k_meta_first adds up the ones before its tile itself, which is cheaper than a scan launch or a last-block pass)
+__global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict__ firstmap, uint32_t *fwpre, uint32_t *bsumF)
 {
     __shared__ u64 smem[1024 / kWave];
     __shared__ uint32_t wcnt[256];
-    __shared__ bool last;
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     // wavefront w: words [16 w, 16 w + 16) of the tile's 256, all 16 loads in flight
     const uint32_t *src = firstmap + ((size_t)blockIdx.x * 256 + w * 16) * 64 + lane;
@@ -1181,22 +1190,7 @@ __global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict
     u64 tot;
     const u64 ex = block_excl_scan_u64<1024>(threadIdx.x < 256 ? (u64)wcnt[threadIdx.x] : 0ull, &tot, smem);
     if (threadIdx.x < 256) fwpre[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint32_t)ex;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&bsumF[blockIdx.x], (uint32_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    const uint32_t x = threadIdx.x < gridDim.x ? __hip_atomic_load(&bsumF[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    u64 all;
-    const u64 e2 = block_excl_scan_u64<1024>((u64)x, &all, smem);
-    if (threadIdx.x < gridDim.x) bsumF[threadIdx.x] = (uint32_t)e2;
-    if (threadIdx.x == 0) {
-        counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
-        counts[D3D_COUNT_AUX] = 0;
-    }
+    if (threadIdx.x == 0) bsumF[blockIdx.x] = (uint32_t)tot;
 }
 
 // one lane per point index: the lanes that are a voxel's first point number it (prefix count = the reference's
@@ -1207,21 +1201,55 @@ __global__ __launch_bounds__(256) void k_meta_first(DenseKey kf, int64_t npad, c
                                                     const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
                                                     const uint4 *__restrict__ vrec, uint32_t max_voxels, uint4 *__restrict__ vinfo,
                                                     const float4 *__restrict__ staged, uint32_t P, int reduction, int64_t *coords,
-                                                    int32_t *npoints, unsigned char *pmask, float4 *agg)
+                                                    int32_t *npoints, unsigned char *pmask, float4 *agg, int64_t *counts,
+                                                    BinnedExtras x)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npad) return;
     const int lane = threadIdx.x & (kWave - 1);
+    // voxels before this workgroup's tile of 16384 point indices (wave-uniform; <= 256 tile totals)
+    const uint32_t tile = (uint32_t)(i / kFlagTile), ntile = (uint32_t)(npad / kFlagTile);
+    uint32_t before = 0, all = 0;
+    for (uint32_t t = lane; t < ntile; t += kWave) {
+        const uint32_t x = bsumF[t];
+        all += x;
+        if (t < tile) before += x;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) { before += __shfl_xor(before, o, kWave); all += __shfl_xor(all, o, kWave); }
+    if (i == 0) {
+        counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
+        counts[D3D_COUNT_AUX] = 0;
+        // sharded voxelizer: the status bits travel with the key list (row `status_row`, negative = not a cell)
+        if (x.keys_out && x.status_row >= 0) x.keys_out[x.status_row] = -1 - counts[D3D_COUNT_STATUS];
+    }
     const uint32_t e = firstmap[i];
     const unsigned long long bal = __ballot(e != kInf);
     if (e == kInf) return;
-    const uint32_t vid = bsumF[i / kFlagTile] + fwpre[i >> 6] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-    if (vid >= max_voxels) return;                          // voxelize.cpp:116-117: later voxels are never created
+    const uint32_t vid = before + fwpre[i >> 6] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (vid >= max_voxels) {                                // voxelize.cpp:116-117: later voxels are never created
+        if (x.vidof) x.vidof[e] = kNoVoxel;
+        return;
+    }
+    if (x.vidof) x.vidof[e] = vid;
+    if (x.first_out) x.first_out[vid] = x.index_offset + i;
     const uint4 rec = vrec[e];
     const uint4 vi = make_uint4(rec.x, 0u, rec.z, rec.w);
     vinfo[vid] = vi;
     meta_voxel<DenseKey, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, nullptr, pmask, agg, nullptr, nullptr,
-                               nullptr);
+                               x.keys_out);
+}
+
+// point -> voxel id, from bucket order: the record of every point was left by k_bucket_index, the id of every record by
+// k_meta_first (a bucket's points refer to the bucket's own stretch of records: the gather stays local)
+__global__ __launch_bounds__(256) void k_map_binned(const uint32_t *__restrict__ bucket_base, uint32_t nbins,
+                                                    const uint32_t *__restrict__ precpos, const uint32_t *__restrict__ bidx,
+                                                    const uint32_t *__restrict__ vidof, int64_t *mapping)
+{
+    const uint32_t total = bucket_base[nbins];
+    for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+        const uint32_t vid = vidof[precpos[p]];
+        mapping[bidx[p]] = vid == kNoVoxel ? -1ll : (long long)vid;
+    }
 }
 
 // ------------------------------------------------------------------ filter (direct-addressed by voxel id)
@@ -1532,6 +1560,8 @@ struct DenseOut {
     int32_t *npoints;
     unsigned char *pmask;
     float *aggregates;
+    BinnedExtras x;           // all null for the dense contract
+    int64_t *mapping;
 };
 
 // n points -> which index path (dense contract, C == 4 rows)
@@ -1563,27 +1593,32 @@ static int binned_index(const DenseKey &kf, const float4 *p4, int64_t n, const V
     float4 *brow = reinterpret_cast<float4 *>(w.tabA);          // cap * 8 bytes >= 16 n
     uint32_t *tilecnt = reinterpret_cast<uint32_t *>(w.tabB);
     uint4 *vrec = reinterpret_cast<uint4 *>(w.aux);
-    uint32_t *bucket_base = w.vidarr, *ticket = w.vidarr + nbins + 1, *totals = w.vidarr + nbins + 2;
+    uint32_t *bucket_base = w.vidarr, *totals = w.vidarr + nbins + 2;
     uint32_t *pbin = w.pslot, *bidx = w.parr, *firstmap = w.list;
+    uint32_t *precpos = o.mapping ? w.unsorted : nullptr;       // the hash path's lists are not used here
+    BinnedExtras x = o.x;
+    x.vidof = o.mapping ? w.voff : nullptr;
     D3D_LAUNCH("k_bin_count", k_bin_count, dim3(ntiles), dim3(kBinThreads), 0, st, kf, p4, n, nbins, ntiles, pbin, tilecnt, firstmap,
-               counts, w.big_count, ticket);
+               counts, o.mapping);
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
     D3D_LAUNCH("k_bin_scatter", k_bin_scatter, dim3(ntiles), dim3(kBinThreads), 0, st, p4, n, nbins, ntiles, pbin, tilecnt, totals,
                bucket_base, brow, bidx);
     D3D_LAUNCH("k_bucket_index", k_bucket_index, dim3(nbins), dim3(256), 0, st, kf, brow, bidx, bucket_base, hshift, o.P,
-               o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts);
+               o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts, precpos);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 256 (n <= 4 M)
-    D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, ticket, counts,
-               (u64)o.max_voxels);
+    D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF);
     const dim3 grid((unsigned)(w.npad / 256));
     if (o.agg4)
         D3D_LAUNCH("k_meta_first", k_meta_first<true>, grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
                    o.max_voxels, w.vinfo, w.staged, o.P, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr,
-                   reinterpret_cast<float4 *>(o.aggregates));
+                   reinterpret_cast<float4 *>(o.aggregates), counts, x);
     else
         D3D_LAUNCH("k_meta_first", k_meta_first<false>, grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
                    o.max_voxels, w.vinfo, w.staged, o.P, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr,
-                   (float4 *)nullptr);
+                   (float4 *)nullptr, counts, x);
+    if (o.mapping)
+        D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos, bidx,
+                   x.vidof, o.mapping);
     return D3D_OK;
 }
 
@@ -1654,7 +1689,8 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
     uint32_t nbins = 0;
     int hshift = 0;
     if (vec4 && max_voxels > 0 && binned_eligible(kf, n, w, &nbins, &hshift)) {
-        DenseOut d{P, (uint32_t)max_voxels, reduction, agg4, fuse_pmask, coords, npoints, pmask, aggregates};
+        DenseOut d{P, (uint32_t)max_voxels, reduction, agg4, fuse_pmask, coords, npoints, pmask, aggregates,
+                   BinnedExtras{nullptr, 0, nullptr, -1, nullptr}, nullptr};
         rc = binned_index(kf, p4, n, w, nbins, hshift, counts, d, st);
         if (rc) return rc;
     } else {
@@ -1713,11 +1749,18 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     const uint32_t P = 32;   // voxels up to 32 points are reduced sequentially in point order, larger ones cooperatively
     const bool agg4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(aggregates) & 15) == 0);
+    const float4 *p4 = reinterpret_cast<const float4 *>(points);
+    uint32_t nbins = 0;
+    int hshift = 0;
+    if (agg4 && binned_eligible(kf, n, w, &nbins, &hshift)) {
+        DenseOut d{P, 0xffffffffu, reduction, true, false, coords, npoints, nullptr, aggregates,
+                   BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr}, mapping};
+        return binned_index(kf, p4, n, w, nbins, hshift, counts, d, st);
+    }
     IndexOpts o{P, 0xffffffffu, first, index_offset, mapping, agg4};
     rc = dense_index(kf, points, n, c, w, counts, o, st);
     if (rc) return rc;
     if (n == 0) return D3D_OK;
-    const float4 *p4 = reinterpret_cast<const float4 *>(points);
     if (agg4) {
         D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, p4, counts, w.vinfo,
                    w.staged, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr,

@@ -92,7 +92,8 @@ class HipOps:
             keys = torch.empty((n + 1,), dtype=torch.int64, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
             ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
-            lib.d3d_voxel_force_plain(1 if plain else 0)
+            lib.d3d_voxel_force_plain(1 if plain else 0)     # the retry after a status overflow: general slots ...
+            lib.d3d_voxel_set_path(1 if plain else 0)        # ... in the hash table (no bucket capacity to outgrow)
             try:
                 rc = lib.d3d_voxelize_3d_reduce(
                     _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
@@ -100,6 +101,7 @@ class HipOps:
                     _lib.ptr(mapping), _lib.ptr(keys), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
             finally:
                 lib.d3d_voxel_force_plain(0)
+                lib.d3d_voxel_set_path(0)
             _lib.check(rc, "voxelize_3d_reduce")
         return coords, cnt, agg, first, mapping, keys, counts
 
@@ -259,7 +261,8 @@ def _status_retry(counts_host):
     status = int(counts_host[_lib.COUNT_STATUS])
     if status & _lib.STATUS_TABLE_FULL:
         raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
-    return bool(status & _lib.STATUS_PACK_OVERFLOW)   # a voxel outgrew the packed slot counter: redo with plain slots
+    # a voxel outgrew the packed slot counter, or a bucket of the binned index its workgroup: redo on the general path
+    return bool(status & (_lib.STATUS_PACK_OVERFLOW | _lib.STATUS_BIN_OVERFLOW))
 
 
 def voxelize_reduce(points, shape, bounds, reduction="mean"):
@@ -343,8 +346,8 @@ class ShardedVoxelGenerator:
             handle, nvox, status = ops.compact_index(keys_all, self._ncells, status_stride=cap + 1)
         if status & _lib.STATUS_TABLE_FULL:
             raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
-        if status & _lib.STATUS_PACK_OVERFLOW and not plain:
-            return None        # some rank hit the packed-slot counter limit (rare): all ranks redo with plain slots
+        if status & (_lib.STATUS_PACK_OVERFLOW | _lib.STATUS_BIN_OVERFLOW) and not plain:
+            return None        # some rank hit a capacity limit of the fast index (rare): all ranks redo on the general path
         # 4. all-reduce the compact voxel table
         if bitmap_mode and owned:
             # numbering by ownership: the lowest rank that has a cell holds its first point, so the voxel ids follow from
