@@ -227,9 +227,16 @@ def main():
         prof = kernel_profile(step, args.steps)
         dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
         # compulsory bytes of each kernel per launch (DESIGN.md "kernels"); C = 4
+        npad = -(-n // 16384) * 16384
         algo = {
-            # voxels[V,P,4] written, kept rows (16 B point + 4 B index) gathered
-            "k_fill_c4": V * P * 16 + kept * (16 + 4),
+            # voxels[V,P,4] written; kept rows (16 B) gathered from the staged segments, one 16-byte record per voxel read
+            "k_fill_c4": V * P * 16 + kept * 16 + V * 16,
+            # binned index (n >= 32 k points): partition, per-bucket index in LDS, numbering + per-voxel outputs
+            "k_bin_count": n * 16 + npad * 8,                       # rows read; bucket word + firstmap reset written
+            "k_bin_scatter": n * (16 + 4) + n * (16 + 4),           # rows + bucket words read; rows + indices written
+            "k_bucket_index": n * (16 + 4) + kept * 16 + V * (16 + 4),   # bucket read; ranked rows, records, firstmap written
+            "k_meta_first": npad * 4 + V * 16 + kept * 16 + V * (16 + 24 + 4 + P + 16),
+            # hash-table index (other inputs)
             "k_insert": n * 16 + n * 8 + n * 8,          # points read, pslot+arrival written, one 8-byte slot touched
             "k_scatter": n * 8 + n * 8 + n * 4 + n * 8,  # pslot+arrival read, aux read, index written, (cnt,base) written
             "k_select": n * 8 + kept * 4,
@@ -242,6 +249,11 @@ def main():
                                frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(name, "config2"),
                                avg_us=round(dom[1]["avg_us"], 2), algorithmic_bytes=b_alg,
                                timing="HIP events on the launch stream, separate pass of the same %d steps" % args.steps)
+        if name in ("k_bin_scatter", "k_bucket_index"):
+            # limited by scattered 4..16-byte stores, not bytes: measured ceiling ~80 G/s (profiles/r01_g_atomic_bench.txt)
+            req = 2 * n if name == "k_bin_scatter" else kept + V
+            out["roofline"]["requests"] = dict(per_launch=req, achieved_G_per_s=round(req / dom[1]["avg_us"] / 1e3, 2),
+                                               measured_peak_G_per_s=80.0, frac=round(req / dom[1]["avg_us"] / 1e3 / 80.0, 3))
         if name == "k_insert":
             # the kernel's real limiter: scattered 8-byte requests (>= one coherent probe load + one atomic per point);
             # ceiling measured with tools/atomic_bench.hip on MI355X (profiles/r01_g_atomic_bench.txt); 2 per point is a lower

@@ -926,9 +926,12 @@ __global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ 
             }
             if (iou > (T)iou_thr) {                          // nms.cpp:53
                 const T before = sc[pj];
+                const uint8_t was = sp[pj];
                 sc[pj] = before * soft_decay<T>(iou, param, sup);
-                sp[pj] = sc[pj] < (T)score_thr ? 1 : 0;
-                if (sc[pj] > before) s_mod = 2;              // a score went UP (negative scores): no shortcut below
+                sp[pj] = sc[pj] < (T)score_thr ? 1 : 0;      // nms.cpp:58,62: assigned, so a box can come back
+                // a score went UP (negative scores) or a suppressed box came back (a trailing score == threshold,
+                // nms.cpp:23-29, that is not < threshold): the block is no longer ordered, no shortcut below
+                if (sc[pj] > before || (was && !sp[pj])) s_mod = 2;
                 const int slot = atomicAdd(&s_cnt, 1);
                 if (slot < kSoftList) s_list[slot] = pj;
             }

@@ -55,6 +55,15 @@ __device__ __forceinline__ u64 mix64(u64 h)
 // dense contract: idx = int((p - lo) / size), 0 <= idx < shape   (voxelize.cpp:100-101)
 struct DenseKey {
     static constexpr bool kBox = false;
+    typedef uint32_t bin_key_t;                         // binned index: cells < 2^32 - 1 (host-checked)
+    static __device__ __forceinline__ uint32_t bin_hash(u64 key)
+    {
+        uint32_t h = (uint32_t)key;                     // murmur3 finaliser
+        h ^= h >> 16; h *= 0x85ebca6bu;
+        h ^= h >> 13; h *= 0xc2b2ae35u;
+        h ^= h >> 16;
+        return h;
+    }
     float lo[3], size[3];
     int shape[3];
     __device__ __forceinline__ bool make(const float *p, u64 &key, uint32_t &status) const
@@ -84,6 +93,8 @@ struct DenseKey {
 // sparse contract: coord = floor(p / size), unbounded (voxelize.cpp:309); 3 x 21-bit packing
 struct SparseKey {
     static constexpr bool kBox = false;
+    typedef u64 bin_key_t;
+    static __device__ __forceinline__ uint32_t bin_hash(u64 key) { return (uint32_t)mix64(key); }
     float size[3];
     __device__ __forceinline__ bool make(const float *p, u64 &key, uint32_t &status) const
     {
@@ -889,43 +900,48 @@ struct BinnedExtras {
     uint32_t *vidof;          // [records] voxel id of a record (for the point -> voxel map)
 };
 
-__device__ __forceinline__ uint32_t mix32(uint32_t h)
-{
-    h ^= h >> 16; h *= 0x85ebca6bu;
-    h ^= h >> 13; h *= 0xc2b2ae35u;
-    h ^= h >> 16;
-    return h;
-}
-
-// per tile: bucket histogram in LDS; every point remembers {bucket, arrival number inside the tile}
-__global__ __launch_bounds__(kBinThreads) void k_bin_count(DenseKey kf, const float4 *__restrict__ points, int64_t n, uint32_t nbins,
-                                                   uint32_t ntiles, uint32_t *__restrict__ pbin, uint32_t *__restrict__ tilecnt,
-                                                   uint32_t *__restrict__ firstmap, int64_t *counts, int64_t *mapping)
+// per tile: bucket histogram in LDS; every point remembers {bucket, arrival number inside the tile}.  ROWS (dense contract,
+// C == 4): the 16-byte rows travel to the buckets and the cell is recomputed there; otherwise (sparse contract, any C) the
+// 64-bit cell key is kept per point and travels instead.
+constexpr uint32_t kBadBin = 0xfffffffeu;     // the point's coordinates overflowed: status raised by k_bin_scatter (this
+                                              // kernel resets the counters while it runs)
+template <class Key, bool VEC4, bool ROWS>
+__global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *__restrict__ points, int64_t n, int c, uint32_t nbins,
+                                                           uint32_t ntiles, uint32_t *__restrict__ pbin, u64 *__restrict__ pkey,
+                                                           uint32_t *__restrict__ tilecnt, uint32_t *__restrict__ firstmap,
+                                                           int64_t *counts, int64_t *mapping)
 {
     __shared__ uint32_t h[kBinMax];
+    (void)ntiles;
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) h[b] = 0;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kBinTile + threadIdx.x;
-    float4 v[kBinTile / kBinThreads];
+    float v[kBinTile / kBinThreads][3];
 #pragma unroll
     for (int r = 0; r < kBinTile / kBinThreads; r++) {
         const int64_t i = base + r * kBinThreads;
-        if (i < n) v[r] = points[i];
+        if (i < n) {
+            if (VEC4) {
+                const float4 q = reinterpret_cast<const float4 *>(points)[i];
+                v[r][0] = q.x; v[r][1] = q.y; v[r][2] = q.z;
+            } else {
+                const float *src = points + i * c;
+                v[r][0] = src[0]; v[r][1] = src[1]; v[r][2] = src[2];
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < kBinTile / kBinThreads; r++) {
         const int64_t i = base + r * kBinThreads;
         uint32_t word = kNoBin, status = 0;
         if (i < n) {
-            const float p[3] = {v[r].x, v[r].y, v[r].z};
             u64 key;
-            if (kf.make(p, key, status)) {
-                const uint32_t b = mix32((uint32_t)key) & (nbins - 1);
+            if (kf.make(v[r], key, status)) {
+                const uint32_t b = Key::bin_hash(key) & (nbins - 1);
                 word = b | (atomicAdd(&h[b], 1u) << 12);
-            }
+                if (!ROWS) pkey[i] = key;
+            } else if (status) word = kBadBin;
         }
         pbin[i] = word;                 // arrays are padded to the tile
         firstmap[i] = kInf;
@@ -987,37 +1003,43 @@ __device__ __forceinline__ void bucket_bases(const uint32_t *__restrict__ totals
     __syncthreads();
 }
 
-// rows (and point indices) to their bucket: position = base of the bucket + offset of the tile + arrival in the tile
-__global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const float4 *__restrict__ points, int64_t n, uint32_t nbins, uint32_t ntiles,
-                                                     const uint32_t *__restrict__ pbin, const uint32_t *__restrict__ tileoff,
-                                                     const uint32_t *__restrict__ totals, uint32_t *__restrict__ bucket_base,
-                                                     float4 *__restrict__ brow, uint32_t *__restrict__ bidx)
+// rows or keys (and point indices) to their bucket: position = base of the bucket + offset of the tile + arrival in the tile
+template <bool ROWS>
+__global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const float4 *__restrict__ points, const u64 *__restrict__ pkey, int64_t n,
+                                                             uint32_t nbins, const uint32_t *__restrict__ pbin,
+                                                             const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ totals,
+                                                             uint32_t *__restrict__ bucket_base, float4 *__restrict__ brow,
+                                                             u64 *__restrict__ bkey, uint32_t *__restrict__ bidx, int64_t *counts)
 {
     __shared__ uint32_t off[kBinMax];
     __shared__ u64 smem[kBinThreads / kWave];
-    (void)ntiles;
     bucket_bases(totals, nbins, off, smem);
     if (blockIdx.x == 0)                                     // for k_bucket_index
         for (uint32_t b = threadIdx.x; b <= nbins; b += kBinThreads) bucket_base[b] = b < nbins ? off[b] : off[nbins - 1] + totals[nbins - 1];
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) off[b] += tileoff[(size_t)blockIdx.x * nbins + b];
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kBinTile + threadIdx.x;
+    bool bad = false;
 #pragma unroll
     for (int r = 0; r < kBinTile / kBinThreads; r++) {
         const int64_t i = base + r * kBinThreads;
         if (i >= n) break;
         const uint32_t word = pbin[i];
-        if (word == kNoBin) continue;
+        if (word == kBadBin) bad = true;
+        if (word >= kBadBin) continue;
         const uint32_t pos = off[word & (kBinMax - 1)] + (word >> 12);
-        brow[pos] = points[i];
+        if (ROWS) brow[pos] = points[i];
+        else bkey[pos] = pkey[i];
         bidx[pos] = (uint32_t)i;
     }
+    if (bad) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_COORD_OVERFLOW);
 }
 
 // One workgroup per bucket, everything per point in LDS: cell -> slot (open addressing), count, first index, segment of
 // the indices, rank = number of smaller indices in the segment (early exit at max_points).  Outputs: the rows next to
 // their rank (staged), one record per voxel {cell, first, segment base, count} and firstmap[first] = record position.
-__global__ __launch_bounds__(256) void k_bucket_index(DenseKey kf, const float4 *__restrict__ brow,
+template <class Key, bool ROWS>
+__global__ __launch_bounds__(256) void k_bucket_index(Key kf, const float4 *__restrict__ brow, const u64 *__restrict__ bkey,
                                                       const uint32_t *__restrict__ bidx, const uint32_t *__restrict__ bucket_base,
                                                       int hshift, uint32_t P, int reduction /* NONE: no aggregates */,
                                                       float4 *__restrict__ staged, uint4 *__restrict__ vrec,
@@ -1025,40 +1047,52 @@ __global__ __launch_bounds__(256) void k_bucket_index(DenseKey kf, const float4 
                                                       uint32_t *__restrict__ precpos /* optional: record of every point */)
 {
     constexpr int ITEMS = kBucketCap / 256, T = kBucketSlots;
-    __shared__ uint32_t tkey[T], tcnt[T], tfirst[T], tbase[T];
+    typedef typename Key::bin_key_t KT;
+    constexpr KT kFree = (KT)~(KT)0;
+    __shared__ KT tkey[T];
+    __shared__ uint32_t tcnt[T], tfirst[T], tbase[T];
     __shared__ uint32_t seg[kBucketCap];
     __shared__ u64 smem[256 / kWave];
     __shared__ uint16_t oslot[kBucketCap / 2];      // overflow voxels of the bucket (count > P >= 1)
     __shared__ uint32_t nover;
     const uint32_t bb = bucket_base[blockIdx.x], m = bucket_base[blockIdx.x + 1] - bb;
     if (m == 0) return;
-    if (m > (uint32_t)kBucketCap) {                 // the caller repeats the call on the hash path
+    if (m > (uint32_t)kBucketCap) {                 // the caller repeats the call on the hash path; until then the outputs
+        if (precpos)                                // stay consistent (these points map to no voxel)
+            for (uint32_t q = threadIdx.x; q < m; q += 256) precpos[bb + q] = kInf;
         if (threadIdx.x == 0) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_BIN_OVERFLOW);
         return;
     }
-    for (int s = threadIdx.x; s < T; s += 256) { tkey[s] = kInf; tcnt[s] = 0; tfirst[s] = kInf; }
+    for (int s = threadIdx.x; s < T; s += 256) { tkey[s] = kFree; tcnt[s] = 0; tfirst[s] = kInf; }
     if (threadIdx.x == 0) nover = 0;
-    float4 row[ITEMS];
+    float4 row[ROWS ? ITEMS : 1];
+    u64 key_in[ROWS ? 1 : ITEMS];
     uint32_t idx[ITEMS], slot[ITEMS], arr[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t q = threadIdx.x + r * 256;
-        if (q < m) { row[r] = brow[bb + q]; idx[r] = bidx[bb + q]; }
+        if (q < m) {
+            if constexpr (ROWS) row[r] = brow[bb + q];
+            else key_in[r] = bkey[bb + q];
+            idx[r] = bidx[bb + q];
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t q = threadIdx.x + r * 256;
         if (q < m) {
-            const float p[3] = {row[r].x, row[r].y, row[r].z};
             u64 key64;
-            uint32_t st = 0;
-            kf.make(p, key64, st);                  // valid by construction (k_bin_count dropped the others)
-            const uint32_t key = (uint32_t)key64;
-            uint32_t s = (mix32(key) >> hshift) & (T - 1);
+            if constexpr (ROWS) {
+                const float p[3] = {row[r].x, row[r].y, row[r].z};
+                uint32_t st = 0;
+                kf.make(p, key64, st);              // valid by construction (k_bin_count dropped the others)
+            } else key64 = key_in[r];
+            const KT key = (KT)key64;
+            uint32_t s = (Key::bin_hash(key64) >> hshift) & (T - 1);
             for (;;) {                              // distinct cells <= m <= T: a free slot always exists
-                const uint32_t old = atomicCAS(&tkey[s], kInf, key);
-                if (old == kInf || old == key) break;
+                const KT old = atomicCAS(&tkey[s], kFree, key);
+                if (old == kFree || old == key) break;
                 s = (s + 1) & (T - 1);
             }
             slot[r] = s;
@@ -1083,7 +1117,8 @@ __global__ __launch_bounds__(256) void k_bucket_index(DenseKey kf, const float4 
             tbase[s0 + k] = base;
             if (c[k]) {
                 const uint32_t f = tfirst[s0 + k];
-                vrec[bb + j] = make_uint4(tkey[s0 + k], f, bb + base, c[k]);
+                const u64 kk = (u64)tkey[s0 + k];
+                vrec[bb + j] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), bb + base, c[k]);
                 firstmap[f] = bb + j;
                 tfirst[s0 + k] = bb + j;            // from here on: the slot's record
                 j++;
@@ -1110,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_bucket_index(DenseKey kf, const float4 
             rank += (sg[k] < me) + (sg[k + 1] < me) + (sg[k + 2] < me) + (sg[k + 3] < me) + (sg[k + 4] < me) + (sg[k + 5] < me) +
                     (sg[k + 6] < me) + (sg[k + 7] < me);
         for (; k < cnt && rank < P; k++) rank += sg[k] < me;
-        if (rank < P) staged[bb + base + rank] = row[r];
+        if constexpr (ROWS) { if (rank < P) staged[bb + base + rank] = row[r]; }
         if (precpos) precpos[bb + q] = tfirst[s];
     }
     // Overflow voxels: every point counts (voxelize.cpp:137-157) but only P are ranked: one wavefront per voxel walks
@@ -1118,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_bucket_index(DenseKey kf, const float4 
     // accumulates in fp64 (insensitive to the order to ~1e-16 => the same float run to run; differs from the
     // reference's fp32 running sum by rounding only).  The result waits in row P of the voxel's segment, which no
     // ranked point uses.
-    const uint32_t no = reduction != D3D_REDUCE_NONE ? nover : 0u;
+    const uint32_t no = ROWS && reduction != D3D_REDUCE_NONE ? nover : 0u;
     if (no == 0) return;
     __syncthreads();
 #pragma unroll
@@ -1196,8 +1231,8 @@ __global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict
 // one lane per point index: the lanes that are a voxel's first point number it (prefix count = the reference's
 // first-occurrence order, voxelize.cpp:119), fetch its record and write all per-voxel outputs -- coalesced, because
 // consecutive first points are consecutive voxel ids
-template <bool AGG4>
-__global__ __launch_bounds__(256) void k_meta_first(DenseKey kf, int64_t npad, const uint32_t *__restrict__ firstmap,
+template <class Key, bool AGG4>
+__global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
                                                     const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
                                                     const uint4 *__restrict__ vrec, uint32_t max_voxels, uint4 *__restrict__ vinfo,
                                                     const float4 *__restrict__ staged, uint32_t P, int reduction, int64_t *coords,
@@ -1233,9 +1268,9 @@ __global__ __launch_bounds__(256) void k_meta_first(DenseKey kf, int64_t npad, c
     if (x.vidof) x.vidof[e] = vid;
     if (x.first_out) x.first_out[vid] = x.index_offset + i;
     const uint4 rec = vrec[e];
-    const uint4 vi = make_uint4(rec.x, 0u, rec.z, rec.w);
-    vinfo[vid] = vi;
-    meta_voxel<DenseKey, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, nullptr, pmask, agg, nullptr, nullptr,
+    const uint4 vi = rec;                                   // {key lo, key hi, segment base, count}
+    if (vinfo) vinfo[vid] = vi;
+    meta_voxel<Key, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, nullptr, pmask, agg, nullptr, nullptr,
                                x.keys_out);
 }
 
@@ -1247,7 +1282,8 @@ __global__ __launch_bounds__(256) void k_map_binned(const uint32_t *__restrict__
 {
     const uint32_t total = bucket_base[nbins];
     for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
-        const uint32_t vid = vidof[precpos[p]];
+        const uint32_t e = precpos[p];
+        const uint32_t vid = e == kInf ? kNoVoxel : vidof[e];
         mapping[bidx[p]] = vid == kNoVoxel ? -1ll : (long long)vid;
     }
 }
@@ -1564,8 +1600,8 @@ struct DenseOut {
     int64_t *mapping;
 };
 
-// n points -> which index path (dense contract, C == 4 rows)
-static bool binned_eligible(const DenseKey &kf, int64_t n, const VoxelWs &w, uint32_t *nbins_out, int *hshift_out)
+// n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
+static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t *nbins_out, int *hshift_out)
 {
     const char *env = getenv("D3D_VOXEL_PATH");
     int mode = g_voxel_path;                            // an explicit d3d_voxel_set_path() wins over the environment
@@ -1573,8 +1609,6 @@ static bool binned_eligible(const DenseKey &kf, int64_t n, const VoxelWs &w, uin
     if (mode == 0 && env && env[0] == 'b') mode = 2;
     if (mode == 1 || n <= 0) return false;
     if (mode == 0 && n < 32768) return false;           // a handful of workgroups: the launch count decides, not the requests
-    const double cells = (double)kf.shape[0] * (double)kf.shape[1] * (double)kf.shape[2];
-    if (cells >= 4294967295.0) return false;            // 32-bit cell keys in LDS
     uint32_t nbins = 1;
     int hshift = 0;
     while (nbins < (uint32_t)kBinMax && (int64_t)nbins * 512 < n) { nbins <<= 1; hshift++; }
@@ -1586,11 +1620,20 @@ static bool binned_eligible(const DenseKey &kf, int64_t n, const VoxelWs &w, uin
     return true;
 }
 
-static int binned_index(const DenseKey &kf, const float4 *p4, int64_t n, const VoxelWs &w, uint32_t nbins, int hshift,
+static bool dense_cells_fit_u32(const DenseKey &kf)     // 32-bit cell keys in LDS
+{
+    return (double)kf.shape[0] * (double)kf.shape[1] * (double)kf.shape[2] < 4294967295.0;
+}
+
+// ROWS: dense contract on C == 4 rows (ranked rows staged, reductions); !ROWS: keys only (sparse contract, any C)
+template <class Key, bool ROWS>
+static int binned_index(const Key &kf, const float *points, int64_t n, int c, const VoxelWs &w, uint32_t nbins, int hshift,
                         int64_t *counts, const DenseOut &o, hipStream_t st)
 {
     const uint32_t ntiles = (uint32_t)(w.npad / kBinTile);
-    float4 *brow = reinterpret_cast<float4 *>(w.tabA);          // cap * 8 bytes >= 16 n
+    const float4 *p4 = reinterpret_cast<const float4 *>(points);
+    float4 *brow = reinterpret_cast<float4 *>(w.tabA);          // ROWS: cap * 8 bytes >= 16 n
+    u64 *bkey = w.tabA, *pkey = w.tabA + w.cap / 2;             // !ROWS: two u64[n] (cap >= 2 n)
     uint32_t *tilecnt = reinterpret_cast<uint32_t *>(w.tabB);
     uint4 *vrec = reinterpret_cast<uint4 *>(w.aux);
     uint32_t *bucket_base = w.vidarr, *totals = w.vidarr + nbins + 2;
@@ -1598,24 +1641,29 @@ static int binned_index(const DenseKey &kf, const float4 *p4, int64_t n, const V
     uint32_t *precpos = o.mapping ? w.unsorted : nullptr;       // the hash path's lists are not used here
     BinnedExtras x = o.x;
     x.vidof = o.mapping ? w.voff : nullptr;
-    D3D_LAUNCH("k_bin_count", k_bin_count, dim3(ntiles), dim3(kBinThreads), 0, st, kf, p4, n, nbins, ntiles, pbin, tilecnt, firstmap,
-               counts, o.mapping);
+    const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
+    if (vec4)
+        D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
+                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping);
+    else
+        D3D_LAUNCH("k_bin_count", (k_bin_count<Key, false, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
+                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping);
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
-    D3D_LAUNCH("k_bin_scatter", k_bin_scatter, dim3(ntiles), dim3(kBinThreads), 0, st, p4, n, nbins, ntiles, pbin, tilecnt, totals,
-               bucket_base, brow, bidx);
-    D3D_LAUNCH("k_bucket_index", k_bucket_index, dim3(nbins), dim3(256), 0, st, kf, brow, bidx, bucket_base, hshift, o.P,
-               o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts, precpos);
+    D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, p4, pkey, n, nbins, pbin, tilecnt, totals,
+               bucket_base, brow, bkey, bidx, counts);
+    D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS>), dim3(nbins), dim3(256), 0, st, kf, brow, bkey, bidx, bucket_base,
+               hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts, precpos);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 256 (n <= 4 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF);
     const dim3 grid((unsigned)(w.npad / 256));
     if (o.agg4)
-        D3D_LAUNCH("k_meta_first", k_meta_first<true>, grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
+        D3D_LAUNCH("k_meta_first", (k_meta_first<Key, true>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
                    o.max_voxels, w.vinfo, w.staged, o.P, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr,
                    reinterpret_cast<float4 *>(o.aggregates), counts, x);
     else
-        D3D_LAUNCH("k_meta_first", k_meta_first<false>, grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
-                   o.max_voxels, w.vinfo, w.staged, o.P, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr,
-                   (float4 *)nullptr, counts, x);
+        D3D_LAUNCH("k_meta_first", (k_meta_first<Key, false>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
+                   o.max_voxels, ROWS ? w.vinfo : (uint4 *)nullptr, w.staged, o.P, o.reduction, o.coords, o.npoints,
+                   o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, counts, x);
     if (o.mapping)
         D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos, bidx,
                    x.vidof, o.mapping);
@@ -1688,10 +1736,10 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
     uint32_t nbins = 0;
     int hshift = 0;
-    if (vec4 && max_voxels > 0 && binned_eligible(kf, n, w, &nbins, &hshift)) {
+    if (vec4 && max_voxels > 0 && dense_cells_fit_u32(kf) && binned_eligible(n, w, &nbins, &hshift)) {
         DenseOut d{P, (uint32_t)max_voxels, reduction, agg4, fuse_pmask, coords, npoints, pmask, aggregates,
                    BinnedExtras{nullptr, 0, nullptr, -1, nullptr}, nullptr};
-        rc = binned_index(kf, p4, n, w, nbins, hshift, counts, d, st);
+        rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
         if (rc) return rc;
     } else {
         IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr, vec4};
@@ -1752,10 +1800,10 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
     uint32_t nbins = 0;
     int hshift = 0;
-    if (agg4 && binned_eligible(kf, n, w, &nbins, &hshift)) {
+    if (agg4 && dense_cells_fit_u32(kf) && binned_eligible(n, w, &nbins, &hshift)) {
         DenseOut d{P, 0xffffffffu, reduction, true, false, coords, npoints, nullptr, aggregates,
                    BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr}, mapping};
-        return binned_index(kf, p4, n, w, nbins, hshift, counts, d, st);
+        return binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
     }
     IndexOpts o{P, 0xffffffffu, first, index_offset, mapping, agg4};
     rc = dense_index(kf, points, n, c, w, counts, o, st);
@@ -1787,6 +1835,17 @@ extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c,
     if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
     VoxelWs w = carve(workspace, workspace_bytes, n, 0);
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
+    uint32_t nbins = 0;
+    int hshift = 0;
+    if (binned_eligible(n, w, &nbins, &hshift)) {
+        // 32 k .. 4 M points: partition by hash(cell) and index every bucket in LDS -- the 63-bit cell key itself is the
+        // table key there, so no bounding box pass and no packed-slot limits
+        SparseKey kf;
+        for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
+        DenseOut d{0u, 0xffffffffu, D3D_REDUCE_NONE, false, false, coords, npoints, nullptr, nullptr,
+                   BinnedExtras{nullptr, 0, nullptr, -1, nullptr}, points_mapping};
+        return binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st);
+    }
     IndexOpts o{0u, 0xffffffffu, nullptr, 0, points_mapping, false};
     const char *env = getenv("D3D_FORCE_PLAIN_SLOTS");
     const int ib = bits_for((u64)(n > 1 ? n - 1 : 1));

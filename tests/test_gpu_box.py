@@ -479,3 +479,22 @@ def test_nms_is_graph_capturable():
     torch.cuda.synchronize()
     exp = oracle.box2d_nms(b, s[::-1].copy(), iou_method="rbox", iou_threshold=0.4)
     assert np.array_equal(out.cpu().numpy(), exp) and not np.array_equal(exp, ref.cpu().numpy())
+
+
+def test_soft_nms_trailing_zero_scores_come_back():
+    """score_threshold 0 with scores that are exactly 0: the reference first suppresses the trailing boxes whose score is not
+    ABOVE the threshold (nms.cpp:23-29) and later ASSIGNS suppressed = score < threshold to every box it rescales
+    (nms.cpp:58,62), which brings them back -- and reorders the tail (fuzz seed 3025)"""
+    from d3d_amd.box import box2d_nms
+    rng = np.random.default_rng(3025)
+    n = 1370
+    b = np.stack([rng.random(n) * 1000, rng.random(n) * 1000, rng.random(n) * 20 + 0.5, rng.random(n) * 20 + 0.5,
+                  (rng.random(n) - 0.5) * 8], 1)
+    b[: n // 3] = b[0] + rng.normal(0, 0.3, (n // 3, 5))
+    s = np.round(rng.random(n) * 20) / 20
+    assert (s == 0).sum() > 10
+    for sup in ("gaussian", "linear"):
+        for method in ("box", "rbox"):
+            kw = dict(iou_method=method, supression_method=sup, iou_threshold=0.1, score_threshold=0.0, supression_param=2.0)
+            keep = box2d_nms(torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), **kw).cpu().numpy()
+            assert np.array_equal(keep, oracle.box2d_nms(b, s, **kw)), (sup, method)

@@ -384,3 +384,18 @@ def test_binned_bucket_overflow_repeats_on_the_hash_path(voxel_path):
     exp = oracle.voxelize_3d_dense(cloud, [8, 8, 2], synth.KITTI_BOUNDS, P, n, 1)
     assert ret["coords"].shape[0] == 128
     check_dense(ret, exp, P)
+
+
+def test_sparse_contract_heavy_voxel_outgrows_a_bucket():
+    """100 k points, 30 k of them in one voxel: the binned index reports BIN_OVERFLOW before the chained filter has
+    consumed anything inconsistent, and the operator repeats the pair of calls with the hash-table index"""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    cloud = synth.lidar_like(100000, 43)
+    rng = np.random.default_rng(44)
+    cloud[20000:50000, :3] = cloud[7, :3] + 0.01 * rng.random((30000, 3), dtype=np.float32)
+    for kw in (dict(max_points=8, max_points_filter="trim", min_points=2), dict()):
+        exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(cloud)
+        ret = _np(VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(torch.from_numpy(cloud).cuda()))
+        assert exp["voxel_npoints"].max() >= 8 if kw else exp["voxel_npoints"].max() >= 30000
+        check_sparse(ret, exp)
