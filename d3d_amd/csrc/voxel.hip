@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <limits.h>
 #include <algorithm>
+#include <utility>
 
 namespace {
 
@@ -887,7 +888,8 @@ __global__ __launch_bounds__(256) void k_overflow_reduce(const float4 *__restric
 constexpr int kBinTile = 4096;                // points per workgroup in k_bin_count / k_bin_scatter
 constexpr int kBinThreads = 1024;             // ... 4 per lane: 16 wavefronts per CU keep the loads in flight
 constexpr int kBinMax = 4096;                 // buckets (12 bits of the per-point word, 12 more for the rank in the tile)
-constexpr int kBucketCap = 2048;              // points one k_bucket_index workgroup holds in registers (8 per lane)
+constexpr int kBucketCap = 2048;              // points one k_bucket_index workgroup holds in registers
+constexpr int kBucketThreads = 512;           // ... 4 per lane (256: 42 us, 512: 38 us, 1024: 44 us at config 2)
 constexpr int kBucketSlots = 2048;            // LDS table slots (>= distinct cells of a bucket, always)
 constexpr uint32_t kNoBin = 0xffffffffu;
 
@@ -900,14 +902,35 @@ struct BinnedExtras {
     uint32_t *vidof;          // [records] voxel id of a record (for the point -> voxel map)
 };
 
-// per tile: bucket histogram in LDS; every point remembers {bucket, arrival number inside the tile}.  ROWS (dense contract,
-// C == 4): the 16-byte rows travel to the buckets and the cell is recomputed there; otherwise (sparse contract, any C) the
-// 64-bit cell key is kept per point and travels instead.
+// per tile: bucket histogram in LDS; every point remembers its cell key and {bucket, arrival number inside the tile}.
+// ROWS = dense contract on C == 4 rows, otherwise sparse contract (any C).
+// What travels to the buckets: dense contract (C == 4 rows) {cell : 32 | point index : 32} in one 8-byte store -- the row
+// itself is gathered by k_bucket_index, late, behind its LDS phases; sparse contract {63-bit cell, point index} in one
+// 16-byte store.  One scattered request per point either way.
+template <bool ROWS> struct BinEntry;
+template <> struct BinEntry<true> {
+    typedef u64 type;
+    typedef uint32_t key_store_t;                   // per-point key between k_bin_count and k_bin_scatter
+    static __device__ __forceinline__ type pack(u64 key, uint32_t idx) { return key | ((u64)idx << 32); }
+    static __device__ __forceinline__ u64 key(type e) { return e & 0xffffffffull; }
+    static __device__ __forceinline__ uint32_t idx(type e) { return (uint32_t)(e >> 32); }
+    static constexpr int kIdxStride = 2, kIdxOff = 1;   // where the index sits, in 32-bit words
+};
+template <> struct BinEntry<false> {
+    typedef uint4 type;
+    typedef u64 key_store_t;
+    static __device__ __forceinline__ type pack(u64 key, uint32_t idx) { return make_uint4((uint32_t)key, (uint32_t)(key >> 32), idx, 0u); }
+    static __device__ __forceinline__ u64 key(type e) { return (u64)e.x | ((u64)e.y << 32); }
+    static __device__ __forceinline__ uint32_t idx(type e) { return e.z; }
+    static constexpr int kIdxStride = 4, kIdxOff = 2;
+};
+
 constexpr uint32_t kBadBin = 0xfffffffeu;     // the point's coordinates overflowed: status raised by k_bin_scatter (this
                                               // kernel resets the counters while it runs)
 template <class Key, bool VEC4, bool ROWS>
 __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *__restrict__ points, int64_t n, int c, uint32_t nbins,
-                                                           uint32_t ntiles, uint32_t *__restrict__ pbin, u64 *__restrict__ pkey,
+                                                           uint32_t ntiles, uint32_t *__restrict__ pbin,
+                                                           typename BinEntry<ROWS>::key_store_t *__restrict__ pkey,
                                                            uint32_t *__restrict__ tilecnt, uint32_t *__restrict__ firstmap,
                                                            int64_t *counts, int64_t *mapping)
 {
@@ -940,7 +963,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
             if (kf.make(v[r], key, status)) {
                 const uint32_t b = Key::bin_hash(key) & (nbins - 1);
                 word = b | (atomicAdd(&h[b], 1u) << 12);
-                if (!ROWS) pkey[i] = key;
+                pkey[i] = (typename BinEntry<ROWS>::key_store_t)key;
             } else if (status) word = kBadBin;
         }
         pbin[i] = word;                 // arrays are padded to the tile
@@ -1003,13 +1026,13 @@ __device__ __forceinline__ void bucket_bases(const uint32_t *__restrict__ totals
     __syncthreads();
 }
 
-// rows or keys (and point indices) to their bucket: position = base of the bucket + offset of the tile + arrival in the tile
+// {cell key, point index} to the bucket: position = base of the bucket + offset of the tile + arrival in the tile
 template <bool ROWS>
-__global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const float4 *__restrict__ points, const u64 *__restrict__ pkey, int64_t n,
+__global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinEntry<ROWS>::key_store_t *__restrict__ pkey, int64_t n,
                                                              uint32_t nbins, const uint32_t *__restrict__ pbin,
                                                              const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ totals,
-                                                             uint32_t *__restrict__ bucket_base, float4 *__restrict__ brow,
-                                                             u64 *__restrict__ bkey, uint32_t *__restrict__ bidx, int64_t *counts)
+                                                             uint32_t *__restrict__ bucket_base,
+                                                             typename BinEntry<ROWS>::type *__restrict__ bent, int64_t *counts)
 {
     __shared__ uint32_t off[kBinMax];
     __shared__ u64 smem[kBinThreads / kWave];
@@ -1027,10 +1050,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const float4 *__res
         const uint32_t word = pbin[i];
         if (word == kBadBin) bad = true;
         if (word >= kBadBin) continue;
-        const uint32_t pos = off[word & (kBinMax - 1)] + (word >> 12);
-        if (ROWS) brow[pos] = points[i];
-        else bkey[pos] = pkey[i];
-        bidx[pos] = (uint32_t)i;
+        bent[off[word & (kBinMax - 1)] + (word >> 12)] = BinEntry<ROWS>::pack((u64)pkey[i], (uint32_t)i);
     }
     if (bad) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_COORD_OVERFLOW);
 }
@@ -1038,58 +1058,101 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const float4 *__res
 // One workgroup per bucket, everything per point in LDS: cell -> slot (open addressing), count, first index, segment of
 // the indices, rank = number of smaller indices in the segment (early exit at max_points).  Outputs: the rows next to
 // their rank (staged), one record per voxel {cell, first, segment base, count} and firstmap[first] = record position.
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  Per-item register arrays indexed
+// through it are split into scalars up front; with `#pragma unroll` the compiler left k_bucket_index's rows in scratch.
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load
+// (s_waitcnt vmcnt(0)), which would expose the latency of k_bucket_index's row gather at the first barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int BLOCK>
+__device__ __forceinline__ u64 block_excl_scan_u64_lds(u64 v, u64 *total, u64 *smem)
+{
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const u64 incl = wave_incl_scan_u64(v);
+    if (lane == kWave - 1) smem[w] = incl;
+    lds_barrier();
+    u64 woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / kWave; k++) {
+        const u64 x = smem[k];
+        if (k < w) woff += x;
+        tot += x;
+    }
+    lds_barrier();
+    *total = tot;
+    return woff + incl - v;
+}
+
 template <class Key, bool ROWS>
-__global__ __launch_bounds__(256) void k_bucket_index(Key kf, const float4 *__restrict__ brow, const u64 *__restrict__ bkey,
-                                                      const uint32_t *__restrict__ bidx, const uint32_t *__restrict__ bucket_base,
+__global__ __launch_bounds__(kBucketThreads) void k_bucket_index(const typename BinEntry<ROWS>::type *__restrict__ bent,
+                                                      const float4 *__restrict__ points4 /* ROWS */,
+                                                      const uint32_t *__restrict__ bucket_base,
                                                       int hshift, uint32_t P, int reduction /* NONE: no aggregates */,
                                                       float4 *__restrict__ staged, uint4 *__restrict__ vrec,
                                                       uint32_t *__restrict__ firstmap, int64_t *counts,
                                                       uint32_t *__restrict__ precpos /* optional: record of every point */)
 {
-    constexpr int ITEMS = kBucketCap / 256, T = kBucketSlots;
+    constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
     typedef typename Key::bin_key_t KT;
+    typedef BinEntry<ROWS> E;
     constexpr KT kFree = (KT)~(KT)0;
     __shared__ KT tkey[T];
     __shared__ uint32_t tcnt[T], tfirst[T], tbase[T];
     __shared__ uint32_t seg[kBucketCap];
-    __shared__ u64 smem[256 / kWave];
+    __shared__ u64 smem[kBucketThreads / kWave];
     __shared__ uint16_t oslot[kBucketCap / 2];      // overflow voxels of the bucket (count > P >= 1)
     __shared__ uint32_t nover;
+    typedef float v4f __attribute__((ext_vector_type(4)));   // (an array of HIP float4 structs stayed in scratch)
     const uint32_t bb = bucket_base[blockIdx.x], m = bucket_base[blockIdx.x + 1] - bb;
     if (m == 0) return;
     if (m > (uint32_t)kBucketCap) {                 // the caller repeats the call on the hash path; until then the outputs
         if (precpos)                                // stay consistent (these points map to no voxel)
-            for (uint32_t q = threadIdx.x; q < m; q += 256) precpos[bb + q] = kInf;
+            for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) precpos[bb + q] = kInf;
         if (threadIdx.x == 0) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_BIN_OVERFLOW);
         return;
     }
-    for (int s = threadIdx.x; s < T; s += 256) { tkey[s] = kFree; tcnt[s] = 0; tfirst[s] = kInf; }
+    for (int s = threadIdx.x; s < T; s += kBucketThreads) { tkey[s] = kFree; tcnt[s] = 0; tfirst[s] = kInf; }
     if (threadIdx.x == 0) nover = 0;
-    float4 row[ROWS ? ITEMS : 1];
-    u64 key_in[ROWS ? 1 : ITEMS];
+    v4f row[ROWS ? ITEMS : 1];
+    u64 key_in[ITEMS];
     uint32_t idx[ITEMS], slot[ITEMS], arr[ITEMS];
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t q = threadIdx.x + r * 256;
-        if (q < m) {
-            if constexpr (ROWS) row[r] = brow[bb + q];
-            else key_in[r] = bkey[bb + q];
-            idx[r] = bidx[bb + q];
-        }
+    // branch-free loads (lanes past the end repeat the last entry): all ITEMS entry loads, then all row gathers, in flight
+    // together.  The rows are only needed when the ranks are known: their gather (one scattered 16-byte load per point
+    // from the cache-resident point tensor) runs behind the LDS phases (lds_barrier does not wait for it).
+    static_for<ITEMS>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        const uint32_t q = threadIdx.x + r * kBucketThreads;
+        const typename E::type e = bent[bb + (q < m ? q : m - 1)];
+        key_in[r] = E::key(e);
+        idx[r] = E::idx(e);
+    });
+    if constexpr (ROWS) {
+        static_for<ITEMS>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            row[r] = *reinterpret_cast<const v4f *>(&points4[idx[r]]);
+        });
     }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t q = threadIdx.x + r * 256;
+    lds_barrier();
+    static_for<ITEMS>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        const uint32_t q = threadIdx.x + r * kBucketThreads;
         if (q < m) {
-            u64 key64;
-            if constexpr (ROWS) {
-                const float p[3] = {row[r].x, row[r].y, row[r].z};
-                uint32_t st = 0;
-                kf.make(p, key64, st);              // valid by construction (k_bin_count dropped the others)
-            } else key64 = key_in[r];
-            const KT key = (KT)key64;
-            uint32_t s = (Key::bin_hash(key64) >> hshift) & (T - 1);
+            const KT key = (KT)key_in[r];
+            uint32_t s = (Key::bin_hash(key_in[r]) >> hshift) & (T - 1);
             for (;;) {                              // distinct cells <= m <= T: a free slot always exists
                 const KT old = atomicCAS(&tkey[s], kFree, key);
                 if (old == kFree || old == key) break;
@@ -1099,18 +1162,18 @@ __global__ __launch_bounds__(256) void k_bucket_index(Key kf, const float4 *__re
             arr[r] = atomicAdd(&tcnt[s], 1u);
             atomicMin(&tfirst[s], idx[r]);
         }
-    }
-    __syncthreads();
+    });
+    lds_barrier();
     // segments in slot order; voxel records
     {
-        constexpr int PER = T / 256;
+        constexpr int PER = T / kBucketThreads;
         const int s0 = threadIdx.x * PER;
         uint32_t c[PER];
         u64 mine = 0;
 #pragma unroll
         for (int k = 0; k < PER; k++) { c[k] = tcnt[s0 + k]; mine += ((u64)c[k] << 32) | (c[k] ? 1u : 0u); }
         u64 all;
-        u64 ex = block_excl_scan_u64<256>(mine, &all, smem);
+        u64 ex = block_excl_scan_u64_lds<kBucketThreads>(mine, &all, smem);
         uint32_t base = (uint32_t)(ex >> 32), j = (uint32_t)ex;
 #pragma unroll
         for (int k = 0; k < PER; k++) {
@@ -1127,50 +1190,44 @@ __global__ __launch_bounds__(256) void k_bucket_index(Key kf, const float4 *__re
             base += c[k];
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t q = threadIdx.x + r * 256;
+    lds_barrier();
+    static_for<ITEMS>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        const uint32_t q = threadIdx.x + r * kBucketThreads;
         if (q < m) seg[tbase[slot[r]] + arr[r]] = idx[r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t q = threadIdx.x + r * 256;
-        if (q >= m) continue;
-        const uint32_t s = slot[r], cnt = tcnt[s], base = tbase[s], me = idx[r];
-        uint32_t rank = 0, k = 0;
-        const uint32_t *sg = seg + base;
-        for (; k + 8 <= cnt && rank < P; k += 8)      // 8 independent LDS reads per exit test
-            rank += (sg[k] < me) + (sg[k + 1] < me) + (sg[k + 2] < me) + (sg[k + 3] < me) + (sg[k + 4] < me) + (sg[k + 5] < me) +
-                    (sg[k + 6] < me) + (sg[k + 7] < me);
-        for (; k < cnt && rank < P; k++) rank += sg[k] < me;
-        if constexpr (ROWS) { if (rank < P) staged[bb + base + rank] = row[r]; }
-        if (precpos) precpos[bb + q] = tfirst[s];
-    }
+    });
+    lds_barrier();
+    static_for<ITEMS>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        const uint32_t q = threadIdx.x + r * kBucketThreads;
+        if (q < m) {
+            const uint32_t s = slot[r], cnt = tcnt[s], base = tbase[s], me = idx[r];
+            uint32_t rank = 0, k = 0;
+            const uint32_t *sg = seg + base;
+            for (; k + 8 <= cnt && rank < P; k += 8)      // 8 independent LDS reads per exit test
+                rank += (sg[k] < me) + (sg[k + 1] < me) + (sg[k + 2] < me) + (sg[k + 3] < me) + (sg[k + 4] < me) + (sg[k + 5] < me) +
+                        (sg[k + 6] < me) + (sg[k + 7] < me);
+            for (; k < cnt && rank < P; k++) rank += sg[k] < me;
+            if constexpr (ROWS) { if (rank < P) *reinterpret_cast<v4f *>(&staged[bb + base + rank]) = row[r]; }
+            if (precpos) precpos[bb + q] = tfirst[s];
+        }
+    });
     // Overflow voxels: every point counts (voxelize.cpp:137-157) but only P are ranked: one wavefront per voxel walks
-    // its segment (now holding bucket positions) 64 rows per step; the rows come from the bucket in L2.  MEAN
+    // its segment of point indices 64 rows per step.  MEAN
     // accumulates in fp64 (insensitive to the order to ~1e-16 => the same float run to run; differs from the
     // reference's fp32 running sum by rounding only).  The result waits in row P of the voxel's segment, which no
     // ranked point uses.
     const uint32_t no = ROWS && reduction != D3D_REDUCE_NONE ? nover : 0u;
     if (no == 0) return;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t q = threadIdx.x + r * 256;
-        if (q < m) seg[tbase[slot[r]] + arr[r]] = q;
-    }
-    __syncthreads();
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
     const int lane = threadIdx.x & (kWave - 1);
-    for (uint32_t o = threadIdx.x >> 6; o < no; o += 256 / kWave) {
+    for (uint32_t o = threadIdx.x >> 6; o < no; o += kBucketThreads / kWave) {
         const uint32_t s = oslot[o], base = tbase[s], cnt = tcnt[s];
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         float e0, e1, e2, e3;
         e0 = e1 = e2 = e3 = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
         for (uint32_t k = lane; k < cnt; k += kWave) {
-            const float4 x = brow[bb + seg[base + k]];
+            const float4 x = points4[seg[base + k]];
             if (is_sum) { s0 += x.x; s1 += x.y; s2 += x.z; s3 += x.w; }
             else if (reduction == D3D_REDUCE_MAX) {
                 e0 = e0 < x.x ? x.x : e0; e1 = e1 < x.y ? x.y : e1; e2 = e2 < x.z ? x.z : e2; e3 = e3 < x.w ? x.w : e3;
@@ -1277,14 +1334,15 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
 // point -> voxel id, from bucket order: the record of every point was left by k_bucket_index, the id of every record by
 // k_meta_first (a bucket's points refer to the bucket's own stretch of records: the gather stays local)
 __global__ __launch_bounds__(256) void k_map_binned(const uint32_t *__restrict__ bucket_base, uint32_t nbins,
-                                                    const uint32_t *__restrict__ precpos, const uint32_t *__restrict__ bidx,
-                                                    const uint32_t *__restrict__ vidof, int64_t *mapping)
+                                                    const uint32_t *__restrict__ precpos, const uint32_t *__restrict__ ent32,
+                                                    int idx_stride, int idx_off, const uint32_t *__restrict__ vidof,
+                                                    int64_t *mapping)
 {
     const uint32_t total = bucket_base[nbins];
     for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
         const uint32_t e = precpos[p];
         const uint32_t vid = e == kInf ? kNoVoxel : vidof[e];
-        mapping[bidx[p]] = vid == kNoVoxel ? -1ll : (long long)vid;
+        mapping[ent32[(size_t)p * idx_stride + idx_off]] = vid == kNoVoxel ? -1ll : (long long)vid;
     }
 }
 
@@ -1632,12 +1690,15 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
 {
     const uint32_t ntiles = (uint32_t)(w.npad / kBinTile);
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
-    float4 *brow = reinterpret_cast<float4 *>(w.tabA);          // ROWS: cap * 8 bytes >= 16 n
-    u64 *bkey = w.tabA, *pkey = w.tabA + w.cap / 2;             // !ROWS: two u64[n] (cap >= 2 n)
+    typedef BinEntry<ROWS> E;
+    typename E::type *bent = reinterpret_cast<typename E::type *>(w.tabA);      // cap * 8 bytes >= 16 n
+    // per-point keys until the scatter: dense u32 (an index array of the hash path), sparse u64 (`staged` is not used there)
+    typename E::key_store_t *pkey = ROWS ? reinterpret_cast<typename E::key_store_t *>(w.big_list)
+                                         : reinterpret_cast<typename E::key_store_t *>(w.staged);
     uint32_t *tilecnt = reinterpret_cast<uint32_t *>(w.tabB);
     uint4 *vrec = reinterpret_cast<uint4 *>(w.aux);
     uint32_t *bucket_base = w.vidarr, *totals = w.vidarr + nbins + 2;
-    uint32_t *pbin = w.pslot, *bidx = w.parr, *firstmap = w.list;
+    uint32_t *pbin = w.pslot, *firstmap = w.list;
     uint32_t *precpos = o.mapping ? w.unsorted : nullptr;       // the hash path's lists are not used here
     BinnedExtras x = o.x;
     x.vidof = o.mapping ? w.voff : nullptr;
@@ -1649,9 +1710,9 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, false, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
                    ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping);
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
-    D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, p4, pkey, n, nbins, pbin, tilecnt, totals,
-               bucket_base, brow, bkey, bidx, counts);
-    D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS>), dim3(nbins), dim3(256), 0, st, kf, brow, bkey, bidx, bucket_base,
+    D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, pkey, n, nbins, pbin, tilecnt, totals,
+               bucket_base, bent, counts);
+    D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS>), dim3(nbins), dim3(kBucketThreads), 0, st, bent, p4, bucket_base,
                hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts, precpos);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 256 (n <= 4 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF);
@@ -1665,8 +1726,8 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
                    o.max_voxels, ROWS ? w.vinfo : (uint4 *)nullptr, w.staged, o.P, o.reduction, o.coords, o.npoints,
                    o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, counts, x);
     if (o.mapping)
-        D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos, bidx,
-                   x.vidof, o.mapping);
+        D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
+                   reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping);
     return D3D_OK;
 }
 
