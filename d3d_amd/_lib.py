@@ -4,6 +4,8 @@ There is no CPU fallback: if the HIP library is missing or no GPU is visible the
 operators raise -- they never silently compute somewhere else.
 """
 import ctypes
+import threading
+import time
 import os
 
 import torch
@@ -28,6 +30,8 @@ SIGNATURES = {
     "d3d_voxelize_workspace_bytes": (_sz, [_i64, _i64]),
     "d3d_voxelize_3d_dense": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3d_voxelize_3d_dense_notify": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "d3d_voxelize_3d_sparse": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_voxelize_3d_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -125,3 +129,33 @@ def workspace(nbytes, device):
         buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+class NotifyBuffer:
+    """host-mapped pinned int64[NUM_COUNTS + 1] that d3d_voxelize_3d_dense_notify fills as soon as the output sizes are
+    final (flag word last); one per thread.  wait() polls the flag -- the GPU keeps writing the outputs meanwhile."""
+    _local = threading.local()
+
+    def __init__(self):
+        self.tensor = torch.zeros((NUM_COUNTS + 1,), dtype=torch.int64).pin_memory()
+        self.arr = self.tensor.numpy()
+        self.ptr = ctypes.c_void_p(self.tensor.data_ptr())
+
+    @classmethod
+    def get(cls):
+        buf = getattr(cls._local, "buf", None)
+        if buf is None:
+            buf = cls._local.buf = cls()
+        return buf
+
+    def arm(self):
+        self.arr[NUM_COUNTS] = 0
+
+    def wait(self, counts, spin_s=0.05):
+        """-> list of the NUM_COUNTS values.  Falls back to a blocking read of the device counters (which also surfaces
+        HIP errors) if the flag has not appeared after spin_s."""
+        arr, t0 = self.arr, time.perf_counter()
+        while arr[NUM_COUNTS] == 0:
+            if time.perf_counter() - t0 > spin_s:
+                return counts.cpu().tolist()
+        return arr[:NUM_COUNTS].tolist()

@@ -900,7 +900,21 @@ struct BinnedExtras {
     int64_t *keys_out;        // [V] cell key; row status_row = -1 - status bits
     int64_t status_row;
     uint32_t *vidof;          // [records] voxel id of a record (for the point -> voxel map)
+    int64_t *host_counts;     // optional host-mapped copy of counts[] + ready flag (d3d_voxelize_3d_dense_notify)
 };
+
+// counts[] are final: publish them to host-mapped pinned memory, flag last (one lane)
+__device__ __forceinline__ void notify_host(const int64_t *counts, int64_t *host)
+{
+    for (int k = 0; k < D3D_NUM_COUNTS; k++) host[k] = counts[k];
+    __threadfence_system();
+    __hip_atomic_store(&host[D3D_NUM_COUNTS], (int64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_notify_host(const int64_t *counts, int64_t *host)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) notify_host(counts, host);
+}
 
 // per tile: bucket histogram in LDS; every point remembers its cell key and {bucket, arrival number inside the tile}.
 // ROWS = dense contract on C == 4 rows, otherwise sparse contract (any C).
@@ -1313,6 +1327,7 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
         counts[D3D_COUNT_AUX] = 0;
         // sharded voxelizer: the status bits travel with the key list (row `status_row`, negative = not a cell)
         if (x.keys_out && x.status_row >= 0) x.keys_out[x.status_row] = -1 - counts[D3D_COUNT_STATUS];
+        if (x.host_counts) notify_host(counts, x.host_counts);
     }
     const uint32_t e = firstmap[i];
     const unsigned long long bal = __ballot(e != kInf);
@@ -1769,10 +1784,10 @@ extern "C" size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxel
     return carve(nullptr, 0, n_points, n_voxels).bytes + 256;
 }
 
-extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
-                                     int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels,
-                                     int64_t *coords, uint8_t *pmask, int32_t *npoints, float *aggregates,
-                                     int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
+static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
+                               int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels, int64_t *coords,
+                               uint8_t *pmask, int32_t *npoints, float *aggregates, int64_t *counts, void *workspace,
+                               size_t workspace_bytes, void *stream, int64_t *host_counts)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 3 || !shape || !bound || !counts || max_points < 0 || max_voxels < 0) return D3D_ERR_BAD_ARG;
@@ -1799,13 +1814,14 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
     int hshift = 0;
     if (vec4 && max_voxels > 0 && dense_cells_fit_u32(kf) && binned_eligible(n, w, &nbins, &hshift)) {
         DenseOut d{P, (uint32_t)max_voxels, reduction, agg4, fuse_pmask, coords, npoints, pmask, aggregates,
-                   BinnedExtras{nullptr, 0, nullptr, -1, nullptr}, nullptr};
+                   BinnedExtras{nullptr, 0, nullptr, -1, nullptr, host_counts}, nullptr};
         rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
         if (rc) return rc;
     } else {
         IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr, vec4};
         rc = dense_index(kf, points, n, c, w, counts, o, st);
         if (rc) return rc;
+        if (host_counts) D3D_LAUNCH("k_notify_host", k_notify_host, dim3(1), dim3(64), 0, st, counts, host_counts);
         if (n == 0 || max_voxels == 0) return D3D_OK;
         const dim3 mgrid(grid_for(cap, 256));
         if (agg4)
@@ -1833,6 +1849,30 @@ extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, 
         D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(cap * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
                    w.voff, w.list, w.unsorted, P, reduction, aggregates);
     return D3D_OK;
+}
+
+extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
+                                     int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels,
+                                     int64_t *coords, uint8_t *pmask, int32_t *npoints, float *aggregates,
+                                     int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return voxelize_dense_impl(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
+                               aggregates, counts, workspace, workspace_bytes, stream, nullptr);
+}
+
+// Same, and as soon as counts[] are final -- before the HBM-bound fill of voxels[V,P,C] is launched -- they are also
+// written to host_counts[0 .. D3D_NUM_COUNTS) followed by host_counts[D3D_NUM_COUNTS] = 1.  host_counts must be
+// host-mapped, coherent pinned memory (hipHostMalloc) whose flag word the caller cleared: the host learns the output
+// sizes by polling it while the GPU is still writing the outputs, instead of draining the stream first.
+extern "C" int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
+                                            int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels,
+                                            int64_t *coords, uint8_t *pmask, int32_t *npoints, float *aggregates,
+                                            int64_t *counts, void *workspace, size_t workspace_bytes, void *stream,
+                                            int64_t *host_counts)
+{
+    if (!host_counts) return D3D_ERR_BAD_ARG;
+    return voxelize_dense_impl(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
+                               aggregates, counts, workspace, workspace_bytes, stream, host_counts);
 }
 
 // The "voxel feature grid" without the dense [V,P,C] copy: first-seen voxel ids, counts, per-voxel
@@ -1863,7 +1903,7 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     int hshift = 0;
     if (agg4 && dense_cells_fit_u32(kf) && binned_eligible(n, w, &nbins, &hshift)) {
         DenseOut d{P, 0xffffffffu, reduction, true, false, coords, npoints, nullptr, aggregates,
-                   BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr}, mapping};
+                   BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr, nullptr}, mapping};
         return binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
     }
     IndexOpts o{P, 0xffffffffu, first, index_offset, mapping, agg4};
@@ -1904,7 +1944,7 @@ extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c,
         SparseKey kf;
         for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
         DenseOut d{0u, 0xffffffffu, D3D_REDUCE_NONE, false, false, coords, npoints, nullptr, nullptr,
-                   BinnedExtras{nullptr, 0, nullptr, -1, nullptr}, points_mapping};
+                   BinnedExtras{nullptr, 0, nullptr, -1, nullptr, nullptr}, points_mapping};
         return binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st);
     }
     IndexOpts o{0u, 0xffffffffu, nullptr, 0, points_mapping, false};

@@ -153,15 +153,22 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
         agg = torch.empty((cap, c), dtype=torch.float32, device=dev) if red != 0 else None
         counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
         ws = _lib.workspace(_workspace_bytes(lib, n), dev)
+        note = _lib.NotifyBuffer.get()
+
         def run():
-            rc = lib.d3d_voxelize_3d_dense(
+            # the voxel count reaches the host through pinned memory as soon as it is final, while the GPU is still
+            # writing voxels[V,P,C]: the call returns views of outputs in flight on the current stream, like any torch op
+            note.arm()
+            rc = lib.d3d_voxelize_3d_dense_notify(
                 _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
                 max_points, max_voxels, red, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts),
-                _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr)
             if rc == _lib.ERR_UNSUPPORTED:
                 raise ValueError("Unsupported reduction type in voxelization!")   # voxelize.cpp:196
             _lib.check(rc, "voxelize_3d_dense")
-            return int(_counts_to_host(counts, "voxelize_3d_dense")[_lib.COUNT_VOXELS])
+            host = note.wait(counts)
+            _check_status(int(host[_lib.COUNT_STATUS]), "voxelize_3d_dense")
+            return int(host[_lib.COUNT_VOXELS])
         nv = _with_plain_retry(lib, run)
     ret = dict(voxels=voxels[:nv], coords=coords[:nv], voxel_pmask=pmask[:nv].view(torch.bool),
                voxel_npoints=npts[:nv])

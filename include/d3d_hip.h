@@ -91,6 +91,19 @@ int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c,
                           float *aggregates, int64_t *counts,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* d3d_voxelize_3d_dense that also publishes counts[] to the host as soon as they are final, i.e. BEFORE the
+ * HBM-bound fill of voxels[V,P,C] is launched: host_counts[0 .. D3D_NUM_COUNTS) = counts, then
+ * host_counts[D3D_NUM_COUNTS] = 1 (system-scope release).  host_counts = D3D_NUM_COUNTS + 1 int64 of host-mapped,
+ * coherent pinned memory (hipHostMalloc / torch pin_memory) with the flag word cleared by the caller, who polls it:
+ * the output sizes (the reference returns exactly-sized tensors, voxelize.cpp:166-180) reach the host while the GPU
+ * is still writing the outputs, and the next call can be queued behind them without draining the stream. */
+int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int32_t c,
+                          const int32_t *shape, const float *bound,
+                          int32_t max_points, int32_t max_voxels, int32_t reduction,
+                          float *voxels, int64_t *coords, uint8_t *pmask, int32_t *npoints,
+                          float *aggregates, int64_t *counts,
+                          void *workspace, size_t workspace_bytes, void *stream, int64_t *host_counts);
+
 /* replaces voxelize_sparse, bound in Python as voxelize_3d_sparse
  * (reference voxelize.h:14-17, voxelize.cpp:288-335, impl.cpp:5).
  *   points[n,c] f32 (c >= 3); voxel_size[3] f32 (host)
