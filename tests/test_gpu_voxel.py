@@ -399,3 +399,45 @@ def test_sparse_contract_heavy_voxel_outgrows_a_bucket():
         ret = _np(VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(torch.from_numpy(cloud).cuda()))
         assert exp["voxel_npoints"].max() >= 8 if kw else exp["voxel_npoints"].max() >= 30000
         check_sparse(ret, exp)
+
+
+@pytest.mark.parametrize("n,path", [(0, 0), (500, 1), (500, 2), (60000, 1), (60000, 2)])
+def test_dense_notify_publishes_the_counts_to_pinned_host_memory(voxel_path, n, path):
+    """d3d_voxelize_3d_dense_notify: host_counts[0..NUM_COUNTS) == counts[], flag word set, on both index paths and for the
+    empty input; outputs identical to the plain entry point"""
+    import ctypes
+    from d3d_amd import _lib, synth
+    lib = _lib.load()
+    cloud = synth.lidar_like(max(n, 1), 51)[:n]
+    pts = torch.from_numpy(cloud).cuda()
+    P, cap = 8, max(n, 1)
+    shape = (ctypes.c_int32 * 3)(352, 400, 20)
+    bound = (ctypes.c_float * 6)(*synth.KITTI_BOUNDS)
+    ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), torch.device("cuda", 0))
+    outs = []
+    for notify in (False, True):
+        voxels = torch.zeros((cap, P, 4), device="cuda")
+        coords = torch.zeros((cap, 3), dtype=torch.int64, device="cuda")
+        pmask = torch.zeros((cap, P), dtype=torch.uint8, device="cuda")
+        npts = torch.zeros((cap,), dtype=torch.int32, device="cuda")
+        agg = torch.zeros((cap, 4), device="cuda")
+        counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device="cuda")
+        args = [_lib.ptr(pts), n, 4, ctypes.cast(shape, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p), P, cap, 1,
+                _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts), _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws),
+                ws.numel(), _lib.stream_ptr()]
+        voxel_path(path)
+        if notify:
+            note = _lib.NotifyBuffer.get()
+            note.arm()
+            assert lib.d3d_voxelize_3d_dense_notify(*args, note.ptr) == 0
+            host = note.wait(counts, spin_s=5.0)
+            assert note.arr[_lib.NUM_COUNTS] == 1                       # the flag itself, not the fallback read
+            assert host == counts.cpu().tolist()
+            assert lib.d3d_voxelize_3d_dense_notify(*args, None) != 0   # the buffer is mandatory here
+        else:
+            assert lib.d3d_voxelize_3d_dense(*args) == 0
+        nv = int(counts.cpu()[_lib.COUNT_VOXELS])
+        outs.append((nv, voxels[:nv].cpu(), coords[:nv].cpu(), pmask[:nv].cpu(), npts[:nv].cpu(), agg[:nv].cpu()))
+    assert outs[0][0] == outs[1][0] and (n == 0) == (outs[0][0] == 0)
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(a, b)
