@@ -178,9 +178,12 @@ __global__ __launch_bounds__(256) void k_sharded_finalize(int64_t nvox, int c, c
     vid_of_slot[s] = v;
     if (v < 0) return;                                 // cannot happen: every slot has a first point
     const int64_t k = key_of_slot[s];
-    coords[v * 3 + 0] = k / (sy * sz);
-    coords[v * 3 + 1] = (k / sz) % sy;
-    coords[v * 3 + 2] = k % sz;
+    const long long c0 = k / (sy * sz), c1 = (k / sz) % sy, c2 = k % sz;
+    long long *cp = reinterpret_cast<long long *>(coords) + v * 3;
+    if (vec4) {                                          // 24 bytes as 16 + 8 (rows alternate their 16-byte alignment)
+        if ((v & 1) == 0) { *reinterpret_cast<longlong2 *>(cp) = make_longlong2(c0, c1); cp[2] = c2; }
+        else { cp[0] = c0; *reinterpret_cast<longlong2 *>(cp + 1) = make_longlong2(c1, c2); }
+    } else { cp[0] = c0; cp[1] = c1; cp[2] = c2; }
     const float *row = table + s * tstride;
     const float n = mean ? row[c] : 1.f;              // counts < 2^24 are exact in fp32
     cnt_out[v] = mean ? (int32_t)(n + 0.5f) : cnt_in[s];
@@ -213,6 +216,8 @@ struct OwnedRows {
     float *table;
     int32_t *cnt_table;
     int64_t *slot_of_local;
+    float identity;                   // what k_sharded_fill_owned wrote
+    bool row_pairs;                   // table and agg aligned for float2 / float4 access
     __device__ __forceinline__ unsigned long long value(int64_t v) const
     {
         const int64_t k = keys[v];
@@ -227,14 +232,26 @@ struct OwnedRows {
         slot_of_local[v] = s;
         if (s < 0) return;
         float *row = table + s * tstride;
-        for (int d = 0; d < c; d++) row[d] = agg[v * c + d];
-        if (with_count) row[c] = (float)cnt[v];       // counts < 2^24 are exact in fp32
-        else cnt_table[s] = cnt[v];
+        float id = 0.f;
         if (owned) {
             unsigned long long base = 0;
             for (int q = 0; q < rank; q++) base += newc[q * kOwnerStride];
-            row[tstride - 1] = (float)(base + excl);
+            id = (float)(base + excl);
         }
+        if (c == 4 && with_count && tstride == 6 && row_pairs) {
+            // the common shape (4 features + count + id = 24-byte rows): three 8-byte stores instead of six 4-byte ones --
+            // scattered requests are what this pass costs.  The id column of a row another rank owns keeps the identity.
+            const float4 a = reinterpret_cast<const float4 *>(agg)[v];
+            float2 *r2 = reinterpret_cast<float2 *>(row);
+            r2[0] = make_float2(a.x, a.y);
+            r2[1] = make_float2(a.z, a.w);
+            r2[2] = make_float2((float)cnt[v], owned ? id : identity);
+            return;
+        }
+        for (int d = 0; d < c; d++) row[d] = agg[v * c + d];
+        if (with_count) row[c] = (float)cnt[v];       // counts < 2^24 are exact in fp32
+        else cnt_table[s] = cnt[v];
+        if (owned) row[tstride - 1] = id;
     }
 };
 
@@ -260,9 +277,12 @@ __global__ __launch_bounds__(256) void k_sharded_finalize_owned(int64_t nvox, in
     vid_of_slot[s] = v;
     if (v < 0 || v >= nvox) return;                     // cannot happen: every slot has exactly one owner
     const int64_t k = key_of_slot[s];
-    coords[v * 3 + 0] = k / (sy * sz);
-    coords[v * 3 + 1] = (k / sz) % sy;
-    coords[v * 3 + 2] = k % sz;
+    const long long c0 = k / (sy * sz), c1 = (k / sz) % sy, c2 = k % sz;
+    long long *cp = reinterpret_cast<long long *>(coords) + v * 3;
+    if (vec4) {                                          // 24 bytes as 16 + 8 (rows alternate their 16-byte alignment)
+        if ((v & 1) == 0) { *reinterpret_cast<longlong2 *>(cp) = make_longlong2(c0, c1); cp[2] = c2; }
+        else { cp[0] = c0; *reinterpret_cast<longlong2 *>(cp + 1) = make_longlong2(c1, c2); }
+    } else { cp[0] = c0; cp[1] = c1; cp[2] = c2; }
     const float n = mean ? row[c] : 1.f;
     cnt_out[v] = mean ? (int32_t)(n + 0.5f) : cnt_in[s];
     if (c == 4 && vec4) {
@@ -486,7 +506,8 @@ extern "C" int d3d_sharded_scatter_owned(const int64_t *keys_local, int64_t n_lo
                    st, nvox, table_stride, identity, table, mean ? nullptr : cnt_table);
     if (n_local == 0) return D3D_OK;
     OwnedRows f{keys_local, ncells, bitmap, prefix, lower, newc, (int)rank, (int)c, mean ? 1 : 0, (int)table_stride,
-                agg, cnt, table, cnt_table, slot_of_local};
+                agg, cnt, table, cnt_table, slot_of_local, identity,
+                ((reinterpret_cast<uintptr_t>(table) & 7) == 0) && ((reinterpret_cast<uintptr_t>(agg) & 15) == 0)};
     return d3d_run_scan(f, n_local, bsum, scratch_counts, -1, 0, ~0ull, st);
 }
 
@@ -500,7 +521,7 @@ extern "C" int d3d_sharded_finalize_owned(int64_t nvox, int32_t c, const int64_t
     if (!key_of_slot || !table || !vid_of_slot || !coords || !cnt_out || !feats || (!mean && !cnt_in)) return D3D_ERR_BAD_ARG;
     D3D_LAUNCH("k_sharded_finalize_owned", k_sharded_finalize_owned, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox, c,
                key_of_slot, table, table_stride, mean, cnt_in, (int64_t)shape[1], (int64_t)shape[2], vid_of_slot, coords,
-               cnt_out, feats, (reinterpret_cast<uintptr_t>(feats) & 15) == 0);
+               cnt_out, feats, ((reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(coords)) & 15) == 0);
     return D3D_OK;
 }
 
