@@ -1118,7 +1118,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(const typename 
                                                       int hshift, uint32_t P, int reduction /* NONE: no aggregates */,
                                                       float4 *__restrict__ staged, uint4 *__restrict__ vrec,
                                                       uint32_t *__restrict__ firstmap, int64_t *counts,
-                                                      uint32_t *__restrict__ precpos /* optional: record of every point */)
+                                                      uint32_t *__restrict__ precpos /* optional: record of every point */,
+                                                      uint32_t *__restrict__ pinfo, uint32_t *__restrict__ gseg /* big buckets */)
 {
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
     typedef typename Key::bin_key_t KT;
@@ -1128,19 +1129,143 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(const typename 
     __shared__ uint32_t tcnt[T], tfirst[T], tbase[T];
     __shared__ uint32_t seg[kBucketCap];
     __shared__ u64 smem[kBucketThreads / kWave];
-    __shared__ uint16_t oslot[kBucketCap / 2];      // overflow voxels of the bucket (count > P >= 1)
-    __shared__ uint32_t nover;
+    __shared__ uint16_t oslot[T];                   // overflow voxels of the bucket (count > P)
+    __shared__ uint32_t nover, fail;
     typedef float v4f __attribute__((ext_vector_type(4)));   // (an array of HIP float4 structs stayed in scratch)
     const uint32_t bb = bucket_base[blockIdx.x], m = bucket_base[blockIdx.x + 1] - bb;
     if (m == 0) return;
-    if (m > (uint32_t)kBucketCap) {                 // the caller repeats the call on the hash path; until then the outputs
-        if (precpos)                                // stay consistent (these points map to no voxel)
-            for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) precpos[bb + q] = kInf;
-        if (threadIdx.x == 0) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_BIN_OVERFLOW);
+    for (int s = threadIdx.x; s < T; s += kBucketThreads) { tkey[s] = kFree; tcnt[s] = 0; tfirst[s] = kInf; }
+    if (threadIdx.x == 0) { nover = 0; fail = 0; }
+
+    // phase B of both modes: segments in slot order, one record per voxel, firstmap
+    auto records = [&]() {
+        constexpr int PER = T / kBucketThreads;
+        const int s0 = threadIdx.x * PER;
+        uint32_t c[PER];
+        u64 mine = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { c[k] = tcnt[s0 + k]; mine += ((u64)c[k] << 32) | (c[k] ? 1u : 0u); }
+        u64 all;
+        u64 ex = block_excl_scan_u64_lds<kBucketThreads>(mine, &all, smem);
+        uint32_t base = (uint32_t)(ex >> 32), j = (uint32_t)ex;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            tbase[s0 + k] = base;
+            if (c[k]) {
+                const uint32_t f = tfirst[s0 + k];
+                const u64 kk = (u64)tkey[s0 + k];
+                vrec[bb + j] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), bb + base, c[k]);
+                firstmap[f] = bb + j;
+                tfirst[s0 + k] = bb + j;            // from here on: the slot's record
+                j++;
+                if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
+            }
+            base += c[k];
+        }
+    };
+    // Overflow voxels: every point counts (voxelize.cpp:137-157) but only P are ranked: one wavefront per voxel walks
+    // its segment of point indices (sg: in LDS, or in global memory for a big bucket) 64 rows per step.  MEAN
+    // accumulates in fp64 (insensitive to the order to ~1e-16 => the same float run to run; differs from the
+    // reference's fp32 running sum by rounding only).  The result waits in row P of the voxel's segment, which no
+    // ranked point uses.
+    auto reduce_overflow = [&](const uint32_t *sg) {
+        const uint32_t no = ROWS && reduction != D3D_REDUCE_NONE ? nover : 0u;
+        if (no == 0) return;
+        const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
+        const int lane = threadIdx.x & (kWave - 1);
+        for (uint32_t o = threadIdx.x >> 6; o < no; o += kBucketThreads / kWave) {
+            const uint32_t s = oslot[o], base = tbase[s], cnt = tcnt[s];
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            float e0, e1, e2, e3;
+            e0 = e1 = e2 = e3 = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
+            for (uint32_t k = lane; k < cnt; k += kWave) {
+                const float4 x = points4[sg[base + k]];
+                if (is_sum) { s0 += x.x; s1 += x.y; s2 += x.z; s3 += x.w; }
+                else if (reduction == D3D_REDUCE_MAX) {
+                    e0 = e0 < x.x ? x.x : e0; e1 = e1 < x.y ? x.y : e1; e2 = e2 < x.z ? x.z : e2; e3 = e3 < x.w ? x.w : e3;
+                } else {
+                    e0 = x.x < e0 ? x.x : e0; e1 = x.y < e1 ? x.y : e1; e2 = x.z < e2 ? x.z : e2; e3 = x.w < e3 ? x.w : e3;
+                }
+            }
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) {
+                if (is_sum) {
+                    s0 += __shfl_xor(s0, off, kWave); s1 += __shfl_xor(s1, off, kWave);
+                    s2 += __shfl_xor(s2, off, kWave); s3 += __shfl_xor(s3, off, kWave);
+                } else {
+                    const float t0 = __shfl_xor(e0, off, kWave), t1 = __shfl_xor(e1, off, kWave);
+                    const float t2 = __shfl_xor(e2, off, kWave), t3 = __shfl_xor(e3, off, kWave);
+                    if (reduction == D3D_REDUCE_MAX) {
+                        e0 = e0 < t0 ? t0 : e0; e1 = e1 < t1 ? t1 : e1; e2 = e2 < t2 ? t2 : e2; e3 = e3 < t3 ? t3 : e3;
+                    } else {
+                        e0 = t0 < e0 ? t0 : e0; e1 = t1 < e1 ? t1 : e1; e2 = t2 < e2 ? t2 : e2; e3 = t3 < e3 ? t3 : e3;
+                    }
+                }
+            }
+            if (lane == 0) {
+                float4 out;
+                if (is_sum) {
+                    const float d = reduction == D3D_REDUCE_MEAN ? (float)(int32_t)cnt : 1.0f;
+                    out = make_float4((float)s0 / d, (float)s1 / d, (float)s2 / d, (float)s3 / d);
+                } else out = make_float4(e0, e1, e2, e3);
+                staged[bb + base + P] = out;
+            }
+        }
+    };
+
+    if (m > (uint32_t)kBucketCap) {
+        // BIG bucket (a few cells with thousands of points each -- returns piled up at the origin, a coarse grid): the same
+        // phases as below, but looping over the bucket with the per-point state {slot, arrival} and the index segments
+        // in global memory instead of registers / LDS.  Slower per point, no capacity limit on the points; only a bucket
+        // with more distinct cells than table slots (or 2 M points) is handed back to the hash-table path.
+        constexpr uint32_t kArrBits = 21, kArrMask = (1u << kArrBits) - 1;
+        __syncthreads();
+        if (m <= kArrMask) {
+            for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) {
+                const typename E::type e = bent[bb + q];
+                const u64 key64 = E::key(e);
+                const KT key = (KT)key64;
+                uint32_t s = (Key::bin_hash(key64) >> hshift) & (T - 1), probes = 0;
+                for (;;) {
+                    const KT old = atomicCAS(&tkey[s], kFree, key);
+                    if (old == kFree || old == key) break;
+                    s = (s + 1) & (T - 1);
+                    if (++probes >= (uint32_t)T) break;      // every slot holds another cell
+                }
+                if (probes >= (uint32_t)T) { fail = 1; continue; }
+                pinfo[bb + q] = (s << kArrBits) | atomicAdd(&tcnt[s], 1u);
+                atomicMin(&tfirst[s], E::idx(e));
+            }
+        } else if (threadIdx.x == 0) fail = 1;
+        __syncthreads();
+        if (fail) {                                 // the caller repeats the call on the hash path; until then the outputs
+            if (precpos)                            // stay consistent (these points map to no voxel)
+                for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) precpos[bb + q] = kInf;
+            if (threadIdx.x == 0) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_BIN_OVERFLOW);
+            return;
+        }
+        records();
+        __syncthreads();
+        uint32_t *sg = gseg + bb;
+        for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) {
+            const uint32_t w = pinfo[bb + q];
+            sg[tbase[w >> kArrBits] + (w & kArrMask)] = E::idx(bent[bb + q]);
+        }
+        __threadfence_block();
+        __syncthreads();                            // (waits for the stores: the segments are read back below)
+        for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) {
+            const uint32_t s = pinfo[bb + q] >> kArrBits, cnt = tcnt[s], base = tbase[s], me = E::idx(bent[bb + q]);
+            uint32_t rank = 0, k = 0;
+            const uint32_t *v = sg + base;
+            for (; k + 4 <= cnt && rank < P; k += 4) rank += (v[k] < me) + (v[k + 1] < me) + (v[k + 2] < me) + (v[k + 3] < me);
+            for (; k < cnt && rank < P; k++) rank += v[k] < me;
+            if constexpr (ROWS) { if (rank < P) staged[bb + base + rank] = points4[me]; }
+            if (precpos) precpos[bb + q] = tfirst[s];
+        }
+        reduce_overflow(sg);
         return;
     }
-    for (int s = threadIdx.x; s < T; s += kBucketThreads) { tkey[s] = kFree; tcnt[s] = 0; tfirst[s] = kInf; }
-    if (threadIdx.x == 0) nover = 0;
+
     v4f row[ROWS ? ITEMS : 1];
     u64 key_in[ITEMS];
     uint32_t idx[ITEMS], slot[ITEMS], arr[ITEMS];
@@ -1178,32 +1303,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(const typename 
         }
     });
     lds_barrier();
-    // segments in slot order; voxel records
-    {
-        constexpr int PER = T / kBucketThreads;
-        const int s0 = threadIdx.x * PER;
-        uint32_t c[PER];
-        u64 mine = 0;
-#pragma unroll
-        for (int k = 0; k < PER; k++) { c[k] = tcnt[s0 + k]; mine += ((u64)c[k] << 32) | (c[k] ? 1u : 0u); }
-        u64 all;
-        u64 ex = block_excl_scan_u64_lds<kBucketThreads>(mine, &all, smem);
-        uint32_t base = (uint32_t)(ex >> 32), j = (uint32_t)ex;
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            tbase[s0 + k] = base;
-            if (c[k]) {
-                const uint32_t f = tfirst[s0 + k];
-                const u64 kk = (u64)tkey[s0 + k];
-                vrec[bb + j] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), bb + base, c[k]);
-                firstmap[f] = bb + j;
-                tfirst[s0 + k] = bb + j;            // from here on: the slot's record
-                j++;
-                if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
-            }
-            base += c[k];
-        }
-    }
+    records();
     lds_barrier();
     static_for<ITEMS>([&](auto R) {
         constexpr int r = decltype(R)::value;
@@ -1226,53 +1326,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(const typename 
             if (precpos) precpos[bb + q] = tfirst[s];
         }
     });
-    // Overflow voxels: every point counts (voxelize.cpp:137-157) but only P are ranked: one wavefront per voxel walks
-    // its segment of point indices 64 rows per step.  MEAN
-    // accumulates in fp64 (insensitive to the order to ~1e-16 => the same float run to run; differs from the
-    // reference's fp32 running sum by rounding only).  The result waits in row P of the voxel's segment, which no
-    // ranked point uses.
-    const uint32_t no = ROWS && reduction != D3D_REDUCE_NONE ? nover : 0u;
-    if (no == 0) return;
-    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
-    const int lane = threadIdx.x & (kWave - 1);
-    for (uint32_t o = threadIdx.x >> 6; o < no; o += kBucketThreads / kWave) {
-        const uint32_t s = oslot[o], base = tbase[s], cnt = tcnt[s];
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        float e0, e1, e2, e3;
-        e0 = e1 = e2 = e3 = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
-        for (uint32_t k = lane; k < cnt; k += kWave) {
-            const float4 x = points4[seg[base + k]];
-            if (is_sum) { s0 += x.x; s1 += x.y; s2 += x.z; s3 += x.w; }
-            else if (reduction == D3D_REDUCE_MAX) {
-                e0 = e0 < x.x ? x.x : e0; e1 = e1 < x.y ? x.y : e1; e2 = e2 < x.z ? x.z : e2; e3 = e3 < x.w ? x.w : e3;
-            } else {
-                e0 = x.x < e0 ? x.x : e0; e1 = x.y < e1 ? x.y : e1; e2 = x.z < e2 ? x.z : e2; e3 = x.w < e3 ? x.w : e3;
-            }
-        }
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) {
-            if (is_sum) {
-                s0 += __shfl_xor(s0, off, kWave); s1 += __shfl_xor(s1, off, kWave);
-                s2 += __shfl_xor(s2, off, kWave); s3 += __shfl_xor(s3, off, kWave);
-            } else {
-                const float t0 = __shfl_xor(e0, off, kWave), t1 = __shfl_xor(e1, off, kWave);
-                const float t2 = __shfl_xor(e2, off, kWave), t3 = __shfl_xor(e3, off, kWave);
-                if (reduction == D3D_REDUCE_MAX) {
-                    e0 = e0 < t0 ? t0 : e0; e1 = e1 < t1 ? t1 : e1; e2 = e2 < t2 ? t2 : e2; e3 = e3 < t3 ? t3 : e3;
-                } else {
-                    e0 = t0 < e0 ? t0 : e0; e1 = t1 < e1 ? t1 : e1; e2 = t2 < e2 ? t2 : e2; e3 = t3 < e3 ? t3 : e3;
-                }
-            }
-        }
-        if (lane == 0) {
-            float4 out;
-            if (is_sum) {
-                const float d = reduction == D3D_REDUCE_MEAN ? (float)(int32_t)cnt : 1.0f;
-                out = make_float4((float)s0 / d, (float)s1 / d, (float)s2 / d, (float)s3 / d);
-            } else out = make_float4(e0, e1, e2, e3);
-            staged[bb + base + P] = out;
-        }
-    }
+    reduce_overflow(seg);
 }
 
 // 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF (<= 256 of them:
@@ -1728,7 +1782,8 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, pkey, n, nbins, pbin, tilecnt, totals,
                bucket_base, bent, counts);
     D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS>), dim3(nbins), dim3(kBucketThreads), 0, st, bent, p4, bucket_base,
-               hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts, precpos);
+               hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts, precpos, w.parr,
+               reinterpret_cast<uint32_t *>(w.vinfo));
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 256 (n <= 4 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF);
     const dim3 grid((unsigned)(w.npad / 256));

@@ -355,17 +355,12 @@ def test_binned_and_hash_index_paths_agree(voxel_path, reduction):
             assert np.array_equal(out[0][k], out[1][k], equal_nan=True), k
 
 
-def test_binned_bucket_overflow_repeats_on_the_hash_path(voxel_path):
-    """300 k points in 128 cells: buckets of the partition outgrow a workgroup, the C ABI reports BIN_OVERFLOW and the
-    operator repeats the call with the hash-table index"""
+def _dense_call(lib, pts, shape3, P, red, path_setter, path):
+    """raw C-ABI call -> (status bits, voxel count)"""
     import ctypes
     from d3d_amd import _lib, synth
-    from d3d_amd.voxel import voxelize_3d_dense
-    lib = _lib.load()
-    cloud = synth.lidar_like(300000, 41)
-    pts = torch.from_numpy(cloud).cuda()
-    n, P = pts.shape[0], 4
-    shape = (ctypes.c_int32 * 3)(8, 8, 2)
+    n = pts.shape[0]
+    shape = (ctypes.c_int32 * 3)(*shape3)
     bound = (ctypes.c_float * 6)(*synth.KITTI_BOUNDS)
     voxels = torch.empty((n, P, 4), device="cuda")
     coords = torch.empty((n, 3), dtype=torch.int64, device="cuda")
@@ -374,21 +369,59 @@ def test_binned_bucket_overflow_repeats_on_the_hash_path(voxel_path):
     agg = torch.empty((n, 4), device="cuda")
     counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device="cuda")
     ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), pts.device)
-    voxel_path(2)
+    path_setter(path)
     rc = lib.d3d_voxelize_3d_dense(_lib.ptr(pts), n, 4, ctypes.cast(shape, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p),
-                                   P, n, 1, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts), _lib.ptr(agg),
+                                   P, n, red, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts), _lib.ptr(agg),
                                    _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
     assert rc == 0
-    assert int(counts.cpu()[_lib.COUNT_STATUS]) & _lib.STATUS_BIN_OVERFLOW
-    ret = {k: v.cpu().numpy() for k, v in voxelize_3d_dense(pts, [8, 8, 2], synth.KITTI_BOUNDS, P, n, 1).items()}
-    exp = oracle.voxelize_3d_dense(cloud, [8, 8, 2], synth.KITTI_BOUNDS, P, n, 1)
-    assert ret["coords"].shape[0] == 128
-    check_dense(ret, exp, P)
+    host = counts.cpu()
+    return int(host[_lib.COUNT_STATUS]), int(host[_lib.COUNT_VOXELS])
 
 
-def test_sparse_contract_heavy_voxel_outgrows_a_bucket():
-    """100 k points, 30 k of them in one voxel: the binned index reports BIN_OVERFLOW before the chained filter has
-    consumed anything inconsistent, and the operator repeats the pair of calls with the hash-table index"""
+def test_binned_big_buckets_are_indexed_in_place(voxel_path):
+    """300 k points in 128 cells: every bucket of the partition holds thousands of points; the bucket kernel switches to
+    its looping mode (state in global memory) instead of giving up -- no status bit, same result as the reference"""
+    from d3d_amd import _lib, synth
+    from d3d_amd.voxel import voxelize_3d_dense
+    lib = _lib.load()
+    cloud = synth.lidar_like(300000, 41)
+    pts = torch.from_numpy(cloud).cuda()
+    status, nv = _dense_call(lib, pts, [8, 8, 2], 4, 1, voxel_path, 2)
+    assert status == 0 and nv == 128
+    for red in (1, 2, 0):
+        voxel_path(2)
+        ret = {k: v.cpu().numpy() for k, v in voxelize_3d_dense(pts, [8, 8, 2], synth.KITTI_BOUNDS, 4, 300000, red).items()}
+        exp = oracle.voxelize_3d_dense(cloud, [8, 8, 2], synth.KITTI_BOUNDS, 4, 300000, red)
+        check_dense(ret, exp, 4)
+
+
+def test_binned_bucket_with_too_many_cells_repeats_on_the_hash_path(voxel_path):
+    """3000 distinct cells chosen to fall into ONE bucket (same low bits of the cell hash): more cells than the bucket's
+    LDS table has slots -> the C ABI reports BIN_OVERFLOW and the operator repeats the call with the hash-table index"""
+    from d3d_amd import _lib, synth
+    from d3d_amd.voxel import voxelize_3d_dense
+    lib = _lib.load()
+    n, nbins = 40000, 128                                   # 40 k points -> 128 buckets (voxel.hip binned_eligible)
+    keys = np.arange(704 * 800 * 40, dtype=np.uint32)
+    h = keys.copy()
+    h ^= h >> 16; h *= np.uint32(0x85ebca6b); h ^= h >> 13; h *= np.uint32(0xc2b2ae35); h ^= h >> 16    # DenseKey::bin_hash
+    cells = keys[(h & (nbins - 1)) == 5][:3000].astype(np.int64)
+    cx, cy, cz = cells // (800 * 40), (cells // 40) % 800, cells % 40
+    cloud = synth.lidar_like(n, 47)
+    cloud[:3000, 0] = (cx + 0.5) * 0.1
+    cloud[:3000, 1] = (cy + 0.5) * 0.1 - 40.0
+    cloud[:3000, 2] = (cz + 0.5) * 0.1 - 3.0
+    pts = torch.from_numpy(cloud).cuda()
+    status, _ = _dense_call(lib, pts, synth.KITTI_SHAPE, 4, 1, voxel_path, 2)
+    assert status & _lib.STATUS_BIN_OVERFLOW
+    voxel_path(0)                                           # automatic: binned first, then the retry
+    ret = {k: v.cpu().numpy() for k, v in voxelize_3d_dense(pts, synth.KITTI_SHAPE, synth.KITTI_BOUNDS, 4, n, 1).items()}
+    exp = oracle.voxelize_3d_dense(cloud, synth.KITTI_SHAPE, synth.KITTI_BOUNDS, 4, n, 1)
+    check_dense(ret, exp, 4)
+
+
+def test_sparse_contract_heavy_voxel_in_a_big_bucket():
+    """100 k points, 30 k of them in one voxel: that bucket is indexed by the bucket kernel's looping mode"""
     from d3d_amd import synth
     from d3d_amd.voxel import VoxelGenerator
     cloud = synth.lidar_like(100000, 43)
