@@ -946,7 +946,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
                                                            uint32_t ntiles, uint32_t *__restrict__ pbin,
                                                            typename BinEntry<ROWS>::key_store_t *__restrict__ pkey,
                                                            uint32_t *__restrict__ tilecnt, uint32_t *__restrict__ firstmap,
-                                                           int64_t *counts, int64_t *mapping)
+                                                           int64_t *counts, int64_t *mapping, unsigned char *trimmed)
 {
     __shared__ uint32_t h[kBinMax];
     (void)ntiles;
@@ -983,6 +983,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
         pbin[i] = word;                 // arrays are padded to the tile
         firstmap[i] = kInf;
         if (mapping && i < n) mapping[i] = -1;      // points outside the grid keep it
+        if (trimmed && i < n) trimmed[i] = 0;
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) tilecnt[(size_t)blockIdx.x * nbins + b] = h[b];     // [tile][bucket]
@@ -1119,7 +1120,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(const typename 
                                                       float4 *__restrict__ staged, uint4 *__restrict__ vrec,
                                                       uint32_t *__restrict__ firstmap, int64_t *counts,
                                                       uint32_t *__restrict__ precpos /* optional: record of every point */,
-                                                      uint32_t *__restrict__ pinfo, uint32_t *__restrict__ gseg /* big buckets */)
+                                                      uint32_t *__restrict__ pinfo, uint32_t *__restrict__ gseg /* big buckets */,
+                                                      unsigned char *__restrict__ trimmed /* optional: [n] rank >= P */)
 {
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
     typedef typename Key::bin_key_t KT;
@@ -1260,6 +1262,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(const typename 
             for (; k + 4 <= cnt && rank < P; k += 4) rank += (v[k] < me) + (v[k + 1] < me) + (v[k + 2] < me) + (v[k + 3] < me);
             for (; k < cnt && rank < P; k++) rank += v[k] < me;
             if constexpr (ROWS) { if (rank < P) staged[bb + base + rank] = points4[me]; }
+            if (trimmed && rank >= P) trimmed[me] = 1;
             if (precpos) precpos[bb + q] = tfirst[s];
         }
         reduce_overflow(sg);
@@ -1323,6 +1326,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(const typename 
                         (sg[k + 6] < me) + (sg[k + 7] < me);
             for (; k < cnt && rank < P; k++) rank += sg[k] < me;
             if constexpr (ROWS) { if (rank < P) *reinterpret_cast<v4f *>(&staged[bb + base + rank]) = row[r]; }
+            if (trimmed && rank >= P) trimmed[me] = 1;     // sparse contract + TRIM filter (voxelize.cpp:457-463)
             if (precpos) precpos[bb + q] = tfirst[s];
         }
     });
@@ -1725,6 +1729,7 @@ struct DenseOut {
     float *aggregates;
     BinnedExtras x;           // all null for the dense contract
     int64_t *mapping;
+    unsigned char *trimmed = nullptr;   // sparse contract: flag the points beyond P of their voxel (for the TRIM filter)
 };
 
 // n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
@@ -1774,16 +1779,16 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     if (vec4)
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
-                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping);
+                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed);
     else
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, false, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
-                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping);
+                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed);
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
     D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, pkey, n, nbins, pbin, tilecnt, totals,
                bucket_base, bent, counts);
     D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS>), dim3(nbins), dim3(kBucketThreads), 0, st, bent, p4, bucket_base,
                hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts, precpos, w.parr,
-               reinterpret_cast<uint32_t *>(w.vinfo));
+               reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 256 (n <= 4 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF);
     const dim3 grid((unsigned)(w.npad / 256));
@@ -1981,15 +1986,18 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     return D3D_OK;
 }
 
-extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c, const float *voxel_size,
-                                      int64_t *points_mapping, int64_t *coords, int32_t *npoints, int64_t *counts,
-                                      void *workspace, size_t workspace_bytes, void *stream)
+// trim_points > 0: also flag (in the workspace's `flags`) the points that are not among the first trim_points of their
+// voxel, when the index path can do it on the way (*trim_done = 1) -- what the TRIM point filter would otherwise rank
+static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const float *voxel_size, int64_t *points_mapping,
+                                int64_t *coords, int32_t *npoints, int64_t *counts, void *workspace, size_t workspace_bytes,
+                                int64_t ws_nvox, void *stream, int32_t trim_points, int *trim_done)
 {
     hipStream_t st = (hipStream_t)stream;
+    if (trim_done) *trim_done = 0;
     if (n < 0 || c < 3 || !voxel_size || !counts) return D3D_ERR_BAD_ARG;
     if (n > 0 && (!points || !points_mapping || !coords || !npoints)) return D3D_ERR_BAD_ARG;
     if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
-    VoxelWs w = carve(workspace, workspace_bytes, n, 0);
+    VoxelWs w = carve(workspace, workspace_bytes, n, ws_nvox);   // (the arrays used here do not move with ws_nvox)
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     uint32_t nbins = 0;
     int hshift = 0;
@@ -2000,6 +2008,11 @@ extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c,
         for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
         DenseOut d{0u, 0xffffffffu, D3D_REDUCE_NONE, false, false, coords, npoints, nullptr, nullptr,
                    BinnedExtras{nullptr, 0, nullptr, -1, nullptr, nullptr}, points_mapping};
+        if (trim_points > 0 && trim_done) {
+            d.P = (uint32_t)trim_points;                // ranks are computed in LDS anyway when P > 0
+            d.trimmed = w.flags;
+            *trim_done = 1;
+        }
         return binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st);
     }
     IndexOpts o{0u, 0xffffffffu, nullptr, 0, points_mapping, false};
@@ -2032,6 +2045,14 @@ extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c,
 }
 
 // order (descending stable argsort of voxel_npoints) for MAXVOX_DESCENDING, implemented in sort.hip
+extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c, const float *voxel_size,
+                                      int64_t *points_mapping, int64_t *coords, int32_t *npoints, int64_t *counts,
+                                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    return voxelize_sparse_impl(points, n, c, voxel_size, points_mapping, coords, npoints, counts, workspace, workspace_bytes, 0,
+                                stream, 0, nullptr);
+}
+
 extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int32_t *order, void *ws, size_t ws_bytes,
                                              hipStream_t st);
 extern "C" size_t d3d_internal_argsort_i32_bytes(int64_t n);
@@ -2042,7 +2063,7 @@ static int filter_impl(const float *feats, int64_t n, int32_t c, const int64_t *
                        int32_t min_points, int32_t max_points, int32_t max_voxels, int32_t max_points_filter,
                        int32_t max_voxels_filter, float *out_feats, int64_t *out_mask, int64_t *out_mapping,
                        int32_t *out_npoints, int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
-                       void *stream)
+                       void *stream, bool pretrimmed = false /* w.flags already marks the points beyond max_points */)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || nvox < 0 || c < 1 || !coords_bound || !counts) return D3D_ERR_BAD_ARG;
@@ -2062,7 +2083,7 @@ static int filter_impl(const float *feats, int64_t n, int32_t c, const int64_t *
     // index lists of the overflow voxels live in w.list (their counts sum to <= n); cursors start at zero
     D3D_LAUNCH("k_fill_u32", k_fill_u32, dim3(grid_for(trim_pts ? nvox : 0, 256)), dim3(256), 0, st, w.fcur,
                trim_pts ? nvox : (int64_t)0, 0u, counts);
-    const bool rank_pts = trim_pts && n > 0 && nvox > 0 && max_points > 0;
+    const bool rank_pts = trim_pts && n > 0 && nvox > 0 && max_points > 0 && !pretrimmed;
     uint32_t *cellvox = w.parr;                                 // [n] voxel of each list cell
     unsigned char *trimmed = w.flags;                           // [n]
     if (rank_pts) {
@@ -2135,4 +2156,28 @@ extern "C" int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int
     return filter_impl(feats, n, c, points_mapping, coords, voxel_npoints, nvox_rows, sparse_counts + D3D_COUNT_VOXELS,
                        coords_bound, min_points, max_points, max_voxels, max_points_filter, max_voxels_filter, out_feats,
                        out_mask, out_mapping, out_npoints, out_coords, counts, workspace, workspace_bytes, stream);
+}
+
+// VoxelGenerator.__call__'s sparse branch in one call (voxel/__init__.py:93-102): voxelize_sparse followed by
+// voxelize_filter on its outputs, the voxel count staying on the device.  With the TRIM point filter the ranking "is this
+// point among the first max_points of its voxel" (voxelize.cpp:457-463) is taken from the binned index, which has every
+// voxel's indices in LDS anyway, instead of building and ranking index lists afterwards.
+extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int32_t c, const float *voxel_size,
+                                             const int64_t *coords_bound, int32_t min_points, int32_t max_points,
+                                             int32_t max_voxels, int32_t max_points_filter, int32_t max_voxels_filter,
+                                             int64_t *points_mapping, int64_t *coords, int32_t *npoints, int64_t *sparse_counts,
+                                             float *out_feats, int64_t *out_mask, int64_t *out_mapping, int32_t *out_npoints,
+                                             int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
+                                             void *stream)
+{
+    if (!sparse_counts || max_points < 0) return D3D_ERR_BAD_ARG;
+    if (max_voxels_filter == D3D_MAXVOX_DESCENDING) return D3D_ERR_UNSUPPORTED;       // needs the voxel count on the host
+    int trim_done = 0;
+    const int32_t trim = max_points_filter == D3D_MAXPTS_TRIM ? max_points : 0;
+    int rc = voxelize_sparse_impl(points, n, c, voxel_size, points_mapping, coords, npoints, sparse_counts, workspace,
+                                  workspace_bytes, n, stream, trim, &trim_done);
+    if (rc) return rc;
+    return filter_impl(points, n, c, points_mapping, coords, npoints, n, sparse_counts + D3D_COUNT_VOXELS, coords_bound,
+                       min_points, max_points, max_voxels, max_points_filter, max_voxels_filter, out_feats, out_mask,
+                       out_mapping, out_npoints, out_coords, counts, workspace, workspace_bytes, stream, trim_done != 0);
 }

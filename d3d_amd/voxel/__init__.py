@@ -291,16 +291,13 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
         o_crd = torch.empty((n, 3), dtype=torch.int64, device=dev)
 
         def run():
-            rc = lib.d3d_voxelize_3d_sparse(_lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), _lib.ptr(mapping),
-                                            _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts[0]), _lib.ptr(ws), ws.numel(),
-                                            _lib.stream_ptr())
-            _lib.check(rc, "voxelize_3d_sparse")
-            rc = lib.d3d_voxelize_3d_filter_chained(
-                _lib.ptr(pts), n, c, _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), n, _lib.ptr(counts[0]),
-                ctypes.cast(bound_h, ctypes.c_void_p), int(min_points or 0), int(max_points or 0), int(max_voxels or 0),
-                pf, vf, _lib.ptr(o_feats), _lib.ptr(o_mask), _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd),
+            rc = lib.d3d_voxelize_3d_sparse_filter(
+                _lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
+                int(min_points or 0), int(max_points or 0), int(max_voxels or 0), pf, vf,
+                _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts[0]),
+                _lib.ptr(o_feats), _lib.ptr(o_mask), _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd),
                 _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
-            _lib.check(rc, "voxelize_3d_filter")
+            _lib.check(rc, "voxelize_3d_sparse + voxelize_3d_filter")
             host = counts.cpu()                               # the one host sync of the pair
             _check_status(int(host[0, _lib.COUNT_STATUS]), "voxelize_3d_sparse")
             return int(host[1, _lib.COUNT_POINTS]), int(host[1, _lib.COUNT_VOXELS])
