@@ -36,7 +36,7 @@ SIGNATURES = {
     "d3d_voxelize_3d_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_voxelize_3d_sparse_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "d3d_voxelize_3d_filter_chained": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32,
                                                       _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_voxelize_3d_reduce": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -139,7 +139,7 @@ class NotifyBuffer:
     _local = threading.local()
 
     def __init__(self):
-        self.tensor = torch.zeros((NUM_COUNTS + 1,), dtype=torch.int64).pin_memory()
+        self.tensor = torch.zeros((2 * NUM_COUNTS + 1,), dtype=torch.int64).pin_memory()
         self.arr = self.tensor.numpy()
         self.ptr = ctypes.c_void_p(self.tensor.data_ptr())
 
@@ -154,10 +154,12 @@ class NotifyBuffer:
         self.arr[NUM_COUNTS] = 0
 
     def wait(self, counts, spin_s=0.05):
-        """-> list of the NUM_COUNTS values.  Falls back to a blocking read of the device counters (which also surfaces
-        HIP errors) if the flag has not appeared after spin_s."""
+        """-> list of the NUM_COUNTS values (counts[2, NUM_COUNTS]: the two rows, flattened).  Falls back to a blocking read
+        of the device counters (which also surfaces HIP errors) if the flag has not appeared after spin_s."""
         arr, t0 = self.arr, time.perf_counter()
         while arr[NUM_COUNTS] == 0:
             if time.perf_counter() - t0 > spin_s:
-                return counts.cpu().tolist()
+                return counts.cpu().reshape(-1).tolist()
+        if counts.dim() == 2:
+            return arr[:NUM_COUNTS].tolist() + arr[NUM_COUNTS + 1:].tolist()
         return arr[:NUM_COUNTS].tolist()

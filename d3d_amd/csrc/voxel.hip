@@ -2063,7 +2063,8 @@ static int filter_impl(const float *feats, int64_t n, int32_t c, const int64_t *
                        int32_t min_points, int32_t max_points, int32_t max_voxels, int32_t max_points_filter,
                        int32_t max_voxels_filter, float *out_feats, int64_t *out_mask, int64_t *out_mapping,
                        int32_t *out_npoints, int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
-                       void *stream, bool pretrimmed = false /* w.flags already marks the points beyond max_points */)
+                       void *stream, bool pretrimmed = false /* w.flags already marks the points beyond max_points */,
+                       int64_t *host_counts = nullptr, const int64_t *first_counts = nullptr)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || nvox < 0 || c < 1 || !coords_bound || !counts) return D3D_ERR_BAD_ARG;
@@ -2126,7 +2127,7 @@ static int filter_impl(const float *feats, int64_t n, int32_t c, const int64_t *
     }
     FilterPoints fp{feats, c, points_mapping, nvox, voxel_npoints, w.newid, trimmed, P,
                     reinterpret_cast<int32_t *>(w.pslot), out_feats, out_mask, out_mapping};
-    rc = d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st);
+    rc = d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st, host_counts, first_counts);
     return rc;
 }
 
@@ -2161,14 +2162,16 @@ extern "C" int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int
 // VoxelGenerator.__call__'s sparse branch in one call (voxel/__init__.py:93-102): voxelize_sparse followed by
 // voxelize_filter on its outputs, the voxel count staying on the device.  With the TRIM point filter the ranking "is this
 // point among the first max_points of its voxel" (voxelize.cpp:457-463) is taken from the binned index, which has every
-// voxel's indices in LDS anyway, instead of building and ranking index lists afterwards.
+// voxel's indices in LDS anyway, instead of building and ranking index lists afterwards.  host_counts (optional, 2 *
+// D3D_NUM_COUNTS + 1 int64 of host-mapped pinned memory, word [D3D_NUM_COUNTS] cleared by the caller): sparse_counts -> [0..4),
+// counts -> [5..9), then flag [4] = 1, written BEFORE the compaction of the kept points is launched.
 extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int32_t c, const float *voxel_size,
                                              const int64_t *coords_bound, int32_t min_points, int32_t max_points,
                                              int32_t max_voxels, int32_t max_points_filter, int32_t max_voxels_filter,
                                              int64_t *points_mapping, int64_t *coords, int32_t *npoints, int64_t *sparse_counts,
                                              float *out_feats, int64_t *out_mask, int64_t *out_mapping, int32_t *out_npoints,
                                              int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
-                                             void *stream)
+                                             void *stream, int64_t *host_counts)
 {
     if (!sparse_counts || max_points < 0) return D3D_ERR_BAD_ARG;
     if (max_voxels_filter == D3D_MAXVOX_DESCENDING) return D3D_ERR_UNSUPPORTED;       // needs the voxel count on the host
@@ -2179,5 +2182,6 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
     if (rc) return rc;
     return filter_impl(points, n, c, points_mapping, coords, npoints, n, sparse_counts + D3D_COUNT_VOXELS, coords_bound,
                        min_points, max_points, max_voxels, max_points_filter, max_voxels_filter, out_feats, out_mask,
-                       out_mapping, out_npoints, out_coords, counts, workspace, workspace_bytes, stream, trim_done != 0);
+                       out_mapping, out_npoints, out_coords, counts, workspace, workspace_bytes, stream, trim_done != 0, host_counts,
+                       sparse_counts);
 }

@@ -290,17 +290,20 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
         o_cnt = torch.empty((n,), dtype=torch.int32, device=dev)
         o_crd = torch.empty((n, 3), dtype=torch.int64, device=dev)
 
+        note = _lib.NotifyBuffer.get()
+
         def run():
+            note.arm()
             rc = lib.d3d_voxelize_3d_sparse_filter(
                 _lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
                 int(min_points or 0), int(max_points or 0), int(max_voxels or 0), pf, vf,
                 _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts[0]),
                 _lib.ptr(o_feats), _lib.ptr(o_mask), _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd),
-                _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr)
             _lib.check(rc, "voxelize_3d_sparse + voxelize_3d_filter")
-            host = counts.cpu()                               # the one host sync of the pair
-            _check_status(int(host[0, _lib.COUNT_STATUS]), "voxelize_3d_sparse")
-            return int(host[1, _lib.COUNT_POINTS]), int(host[1, _lib.COUNT_VOXELS])
+            host = note.wait(counts)      # the one host read of the pair, while the kept points are still being compacted
+            _check_status(int(host[_lib.COUNT_STATUS]), "voxelize_3d_sparse")
+            return int(host[_lib.NUM_COUNTS + _lib.COUNT_POINTS]), int(host[_lib.NUM_COUNTS + _lib.COUNT_VOXELS])
         k, v = _with_plain_retry(lib, run)
     ret = dict(points=o_feats[:k], points_mask=o_mask[:k], points_mapping=o_map[:k],
                voxel_npoints=o_cnt[:v], coords=o_crd[:v])
