@@ -1740,7 +1740,6 @@ static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t *nbins_out, in
     if (mode == 0 && env && env[0] == 'h') mode = 1;
     if (mode == 0 && env && env[0] == 'b') mode = 2;
     if (mode == 1 || n <= 0) return false;
-    if (mode == 0 && n < 32768) return false;           // a handful of workgroups: the launch count decides, not the requests
     uint32_t nbins = 1;
     int hshift = 0;
     while (nbins < (uint32_t)kBinMax && (int64_t)nbins * 512 < n) { nbins <<= 1; hshift++; }

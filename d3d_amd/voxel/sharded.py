@@ -92,16 +92,18 @@ class HipOps:
             keys = torch.empty((n + 1,), dtype=torch.int64, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
             ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
-            lib.d3d_voxel_force_plain(1 if plain else 0)     # the retry after a status overflow: general slots ...
-            lib.d3d_voxel_set_path(1 if plain else 0)        # ... in the hash table (no bucket capacity to outgrow)
+            if plain:                               # the retry after a status overflow: general slots ...
+                lib.d3d_voxel_force_plain(1)
+                lib.d3d_voxel_set_path(1)           # ... in the hash table (no bucket capacity to outgrow)
             try:
                 rc = lib.d3d_voxelize_3d_reduce(
                     _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
                     int(reduction), int(index_offset), _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first),
                     _lib.ptr(mapping), _lib.ptr(keys), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
             finally:
-                lib.d3d_voxel_force_plain(0)
-                lib.d3d_voxel_set_path(0)
+                if plain:
+                    lib.d3d_voxel_force_plain(0)
+                    lib.d3d_voxel_set_path(0)
             _lib.check(rc, "voxelize_3d_reduce")
         return coords, cnt, agg, first, mapping, keys, counts
 

@@ -69,7 +69,7 @@ const char *d3d_status_string(int status);
  * one-word slots {count | key | first index} whenever they fit 64 bits (one atomic per point). */
 int d3d_voxel_force_plain(int on);
 
-/* index path of d3d_voxelize_3d_dense for C == 4 rows: 0 = automatic (default: binned from 32 k points up to 4 M),
+/* index path of d3d_voxelize_3d_dense for C == 4 rows: 0 = automatic (default: binned up to 4 M points),
  * 1 = hash table in HBM (any input), 2 = binned (points partitioned into buckets, per-bucket index in LDS) whenever the
  * grid has < 2^32 - 1 cells.  Both give identical outputs; see DESIGN.md section 4. */
 int d3d_voxel_set_path(int path);

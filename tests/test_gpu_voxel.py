@@ -9,6 +9,17 @@ import oracle
 from golden_io import GOLDEN, derived_pmask, load_voxel_cases
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["auto", "hash"])
+def index_path(request):
+    """every test of this module runs on both index paths of the voxelizer: automatic (binned whenever eligible) and
+    the hash table (tests that pick a path themselves -- `voxel_path` -- override this)"""
+    from d3d_amd import _lib
+    lib = _lib.load()
+    lib.d3d_voxel_set_path(1 if request.param == "hash" else 0)
+    yield request.param
+    lib.d3d_voxel_set_path(0)
 CASES = load_voxel_cases()
 
 

@@ -88,11 +88,21 @@ def test_sharded_orchestration_gloo_world2(reduction, exchange):
     assert all(msg == "ok" for _, msg in results), results
 
 
+@pytest.fixture(params=["auto", "hash"])
+def index_path(request):
+    """both index paths of the per-rank voxelizer (automatic = binned whenever eligible, hash table)"""
+    from d3d_amd import _lib
+    lib = _lib.load()
+    lib.d3d_voxel_set_path(1 if request.param == "hash" else 0)
+    yield request.param
+    lib.d3d_voxel_set_path(0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,reduction,exchange", [(2, "mean", "keys"), (3, "min", "bitmap"), (4, "max", "keys"),
                                                      (8, "mean", "bitmap"), (2, "mean", "auto"), (3, "mean", "bitmap-empty"),
                                                      (3, "max", "keys-empty")])
-def test_sharded_hip_kernels_virtual_ranks(world, reduction, exchange):
+def test_sharded_hip_kernels_virtual_ranks(world, reduction, exchange, index_path):
     from d3d_amd.voxel import VoxelGenerator
     from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
     cloud = _cloud(40000, 9)
@@ -127,7 +137,7 @@ def test_sharded_hip_kernels_virtual_ranks(world, reduction, exchange):
 
 
 @pytest.mark.gpu
-def test_voxelize_reduce_single_gpu():
+def test_voxelize_reduce_single_gpu(index_path):
     from d3d_amd import synth
     from d3d_amd.voxel.sharded import voxelize_reduce
     cloud = synth.lidar_like(200000, 3)
