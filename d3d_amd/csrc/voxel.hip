@@ -1,6 +1,18 @@
 // voxel.hip -- point cloud -> voxels on MI355X (gfx950).  Replaces the sequential
-// std::unordered_map loops of the reference (d3d/voxel/voxelize.cpp) with:
+// std::unordered_map loops of the reference (d3d/voxel/voxelize.cpp).  Two index paths build the same intermediate
+// form (one record per voxel in first-seen order, the points' rows in per-voxel segments in point order):
 //
+// BINNED (default, up to 4 M points; "binned index" section below)
+//   partition  the points are partitioned by hash(cell) into buckets of ~512: tile histograms in LDS, a scan, ONE
+//              scattered 8-byte store per point {cell, index}
+//   bucket     one workgroup per bucket does everything per point in LDS: cell -> slot (CAS), count, first index,
+//              segment of indices, rank in point order (by counting, early exit at max_points); the rows are gathered
+//              behind those phases and written next to their rank; reduction of the overflow voxels
+//   number     the reference numbers voxels by first occurrence (voxelize.cpp:119,317): voxel id = number of "first
+//              points" before the voxel's own first point = a prefix count over point indices, merged with the
+//              per-voxel outputs, whose stores are then coalesced by voxel id
+//
+// HASH TABLE (any input: C != 4, more points, huge grids, the retry after a bucket overflow)
 //   insert   one point per lane, coalesced float4 loads, open-addressing hash table in HBM.  A slot is ONE
 //            64-bit word {count | cell key | first point index}: the first arrival claims + counts + records
 //            itself with a single CAS, later arrivals need a single atomicAdd (which also returns their
@@ -9,16 +21,18 @@
 //            operation, scope or table size: tools/atomic_bench.hip).  Dense contract: key = linear cell of the
 //            grid; sparse contract: linear cell inside the frame's bounding box, which k_bbox finds on the device.
 //            Two-word slots (63-bit keys) when a field of the word overflows.
-//   number   the reference numbers voxels by first occurrence (voxelize.cpp:119,317).  Two coalesced sweeps
-//            over the table: flag[first] = 1, prefix-popcount of the flags = voxel id; the same sweeps
-//            allocate every voxel's index segment (scan of the counts in slot order).  No sort.
+//   number   two coalesced sweeps over the table: flag[first] = 1, prefix-popcount of the flags = voxel id; the same
+//            sweeps allocate every voxel's index segment (scan of the counts in slot order).  No sort.
 //   rank     scatter indices by arrival position, then rank = number of smaller indices in the segment
 //            (early exit at max_points): exact point order without sorting or atomic chains; the points
 //            themselves are staged next to their rank (C == 4).
+//
+// SHARED
 //   meta     one lane per voxel: coords, count, pmask row and the reduction over the staged rows,
-//            sequentially in point order -> bit-exact MEAN; overflow voxels through a work list.
+//            sequentially in point order -> bit-exact MEAN; overflow voxels in fp64.
 //   fill     streaming write of voxels[V,P,C] from the staged rows (the HBM-roofline kernel).
-//   filter   (sparse contract) scans over voxels and points; TRIM ranks the overflow voxels' points densely.
+//   filter   (sparse contract) scans over voxels and points; TRIM ranks the overflow voxels' points densely (or takes
+//            the ranking from the binned index).
 //
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off (IEEE div, no FMA contraction:
 // voxel coordinates must round exactly like the reference's CPU code).
@@ -2001,7 +2015,7 @@ static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const
     uint32_t nbins = 0;
     int hshift = 0;
     if (binned_eligible(n, w, &nbins, &hshift)) {
-        // 32 k .. 4 M points: partition by hash(cell) and index every bucket in LDS -- the 63-bit cell key itself is the
+        // up to 4 M points: partition by hash(cell) and index every bucket in LDS -- the 63-bit cell key itself is the
         // table key there, so no bounding box pass and no packed-slot limits
         SparseKey kf;
         for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
