@@ -10,6 +10,22 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
+def pytest_generate_tests(metafunc):
+    # every NMS test runs with both broad phases: the uniform grid (default) and the sweep along x
+    if "nms" in metafunc.function.__name__ and "nms_broad" in metafunc.fixturenames:
+        metafunc.parametrize("nms_broad", ["grid", "sweep"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def nms_broad(request, monkeypatch):
+    mode = getattr(request, "param", "grid")
+    if mode == "sweep":
+        monkeypatch.setenv("D3D_NMS_BROAD", "sweep")
+    else:
+        monkeypatch.delenv("D3D_NMS_BROAD", raising=False)
+    yield mode
+
+
 def T(a, cuda=True):
     t = torch.from_numpy(np.ascontiguousarray(a))
     return t.cuda() if cuda else t
@@ -161,8 +177,9 @@ def test_nms_dense_path_hooks(monkeypatch, hook, value, gen, n, thr):
 
 @pytest.mark.parametrize("n", [128, 3000])
 def test_nms_sweep_and_prune_edge_geometry(n):
-    """broad phase (sort by AABB xmin + walk): negative coordinates, many identical xmin, boxes spanning the whole scene,
-    zero-size boxes -- keep set bit-exact with the oracle"""
+    """broad phases (uniform grid / sort by AABB xmin + walk): negative coordinates, many identical xmin, boxes spanning the
+    whole scene (more cells than one box may register in: the grid hands over to the dense path), zero-size boxes, a
+    non-finite box -- keep set bit-exact with the oracle"""
     from d3d_amd.box import box2d_nms
     rng = np.random.default_rng(n)
     b = np.empty((n, 5))
@@ -176,6 +193,9 @@ def test_nms_sweep_and_prune_edge_geometry(n):
     b[: n // 8, 4] = 0.0                                         # ... and therefore the same AABB xmin
     b[n // 8: n // 8 + 5, 2:4] = 2000.0                          # a few boxes covering everything
     b[n // 4: n // 4 + 5, 2] = 0.0                               # degenerate
+    b[n // 2, 0] = np.nan                                        # non-finite boxes: never overlap anything
+    b[n // 2 + 1, 2] = np.inf
+    b[n // 2 + 2, 1] = -np.inf
     s = rng.permutation(n) / n + 0.001
     for method in ["rbox", "box"]:
         keep = box2d_nms(T(b), T(s), iou_method=method, iou_threshold=0.25).cpu().numpy()
