@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_count(F f, int64_t n, unsig
 // host[4] = 1 -- the sizes of the compaction's outputs reach the host while k_scan_apply is still writing them.
 static __global__ __launch_bounds__(1024) void k_scan_bsum(unsigned long long *bsum, int64_t nb, int64_t *counts, int idx_hi,
                                                      int idx_lo, unsigned long long cap_hi, int64_t *host = nullptr,
-                                                     const int64_t *first_counts = nullptr)
+                                                     const int64_t *first_counts = nullptr, int adopt_voxels = 0)
 {
     __shared__ unsigned long long smem[1024 / kWave];
     unsigned long long carry = 0;
@@ -137,6 +137,11 @@ static __global__ __launch_bounds__(1024) void k_scan_bsum(unsigned long long *b
         unsigned long long hi = carry >> 32, lo = carry & 0xffffffffull;
         if (idx_hi >= 0) counts[idx_hi] = (int64_t)(hi < cap_hi ? hi : cap_hi);
         if (idx_lo >= 0) counts[idx_lo] = (int64_t)lo;
+        if (adopt_voxels) {          // fused sparse + filter: the voxel filter ran inside the index, its count lives there
+            counts[D3D_COUNT_VOXELS] = first_counts[D3D_COUNT_VOXELS];
+            counts[D3D_COUNT_STATUS] = 0;
+            counts[D3D_COUNT_AUX] = 0;
+        }
         if (host) {
             for (int k = 0; k < D3D_NUM_COUNTS; k++) {
                 host[k] = first_counts ? first_counts[k] : 0;
@@ -180,13 +185,14 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(F f, int64_t n, const
 template <class F>
 static inline int d3d_run_scan(F f, int64_t n, unsigned long long *bsum, int64_t *counts, int idx_hi, int idx_lo,
                                unsigned long long cap_hi, hipStream_t st, int64_t *host = nullptr,
-                               const int64_t *first_counts = nullptr)
+                               const int64_t *first_counts = nullptr, int adopt_voxels = 0)
 {
     int64_t nb = d3d_divup(n, kScanTile);
     if (nb > 0) {
         D3D_LAUNCH(F::kName, k_scan_count<F>, dim3((unsigned)nb), dim3(kScanBlock), 0, st, f, n, bsum);
     }
-    D3D_LAUNCH("k_scan_bsum", k_scan_bsum, dim3(1), dim3(1024), 0, st, bsum, nb, counts, idx_hi, idx_lo, cap_hi, host, first_counts);
+    D3D_LAUNCH("k_scan_bsum", k_scan_bsum, dim3(1), dim3(1024), 0, st, bsum, nb, counts, idx_hi, idx_lo, cap_hi, host, first_counts,
+               adopt_voxels);
     if (nb > 0) {
         D3D_LAUNCH(F::kName2, k_scan_apply<F>, dim3((unsigned)nb), dim3(kScanBlock), 0, st, f, n, bsum);
     }

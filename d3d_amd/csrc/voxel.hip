@@ -757,7 +757,7 @@ template <class Key, bool AGG4>
 __device__ __forceinline__ void meta_voxel(const Key &kf, int64_t v, const uint4 vi, const float4 *__restrict__ staged,
                                            uint32_t P, int reduction, int64_t *coords, int32_t *npoints, uint32_t *voff,
                                            unsigned char *pmask, float4 *agg, uint32_t *big_list, uint32_t *big_count,
-                                           int64_t *keys_out)
+                                           int64_t *keys_out, uint32_t npoints_clamp = 0xffffffffu)
 {
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
     long long cc[3];
@@ -765,7 +765,7 @@ __device__ __forceinline__ void meta_voxel(const Key &kf, int64_t v, const uint4
     coords[v * 3 + 0] = cc[0];
     coords[v * 3 + 1] = cc[1];
     coords[v * 3 + 2] = cc[2];
-    npoints[v] = (int32_t)vi.w;
+    npoints[v] = (int32_t)(vi.w < npoints_clamp ? vi.w : npoints_clamp);
     if (voff) voff[v] = vi.z;
     if (keys_out) keys_out[v] = (int64_t)(((u64)vi.y << 32) | vi.x);
     if (pmask) {                                   // P % 16 == 0, 16-byte aligned (host-checked)
@@ -915,6 +915,15 @@ struct BinnedExtras {
     int64_t status_row;
     uint32_t *vidof;          // [records] voxel id of a record (for the point -> voxel map)
     int64_t *host_counts;     // optional host-mapped copy of counts[] + ready flag (d3d_voxelize_3d_dense_notify)
+    uint32_t npoints_clamp = 0xffffffffu;
+};
+
+// sparse contract fused with the voxel filter (d3d_voxelize_3d_sparse_filter): only voxels that pass get a first-point
+// entry, so the first-seen numbering directly yields the filtered voxel ids (voxelize.cpp:374-403 in id order)
+struct VoxelPass {
+    bool on;
+    int32_t min_points;
+    long long lo[3], hi[3];
 };
 
 // counts[] are final: publish them to host-mapped pinned memory, flag last (one lane)
@@ -960,7 +969,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
                                                            uint32_t ntiles, uint32_t *__restrict__ pbin,
                                                            typename BinEntry<ROWS>::key_store_t *__restrict__ pkey,
                                                            uint32_t *__restrict__ tilecnt, uint32_t *__restrict__ firstmap,
-                                                           int64_t *counts, int64_t *mapping, unsigned char *trimmed)
+                                                           int64_t *counts, int64_t *mapping, unsigned char *trimmed,
+                                                           int32_t *keepid)
 {
     __shared__ uint32_t h[kBinMax];
     (void)ntiles;
@@ -998,6 +1008,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
         firstmap[i] = kInf;
         if (mapping && i < n) mapping[i] = -1;      // points outside the grid keep it
         if (trimmed && i < n) trimmed[i] = 0;
+        if (keepid && i < n) keepid[i] = -1;
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) tilecnt[(size_t)blockIdx.x * nbins + b] = h[b];     // [tile][bucket]
@@ -1127,7 +1138,8 @@ __device__ __forceinline__ u64 block_excl_scan_u64_lds(u64 v, u64 *total, u64 *s
 }
 
 template <class Key, bool ROWS>
-__global__ __launch_bounds__(kBucketThreads) void k_bucket_index(const typename BinEntry<ROWS>::type *__restrict__ bent,
+__global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPass vp, uint32_t *__restrict__ vidof,
+                                                      const typename BinEntry<ROWS>::type *__restrict__ bent,
                                                       const float4 *__restrict__ points4 /* ROWS */,
                                                       const uint32_t *__restrict__ bucket_base,
                                                       int hshift, uint32_t P, int reduction /* NONE: no aggregates */,
@@ -1171,7 +1183,15 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(const typename 
                 const uint32_t f = tfirst[s0 + k];
                 const u64 kk = (u64)tkey[s0 + k];
                 vrec[bb + j] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), bb + base, c[k]);
-                firstmap[f] = bb + j;
+                bool pass = true;
+                if (vp.on) {                        // voxelize.cpp:376-384: coordinate bounds and min_points
+                    long long cc[3];
+                    kf.decode(kk, cc);
+                    pass = (int32_t)c[k] >= vp.min_points && cc[0] >= vp.lo[0] && cc[0] < vp.hi[0] && cc[1] >= vp.lo[1] &&
+                           cc[1] < vp.hi[1] && cc[2] >= vp.lo[2] && cc[2] < vp.hi[2];
+                    vidof[bb + j] = kNoVoxel;       // k_meta_first overwrites it for the voxels that get an id
+                }
+                if (pass) firstmap[f] = bb + j;
                 tfirst[s0 + k] = bb + j;            // from here on: the slot's record
                 j++;
                 if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
@@ -1415,7 +1435,7 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
     const uint4 vi = rec;                                   // {key lo, key hi, segment base, count}
     if (vinfo) vinfo[vid] = vi;
     meta_voxel<Key, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, nullptr, pmask, agg, nullptr, nullptr,
-                               x.keys_out);
+                               x.keys_out, x.npoints_clamp);
 }
 
 // point -> voxel id, from bucket order: the record of every point was left by k_bucket_index, the id of every record by
@@ -1423,13 +1443,15 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
 __global__ __launch_bounds__(256) void k_map_binned(const uint32_t *__restrict__ bucket_base, uint32_t nbins,
                                                     const uint32_t *__restrict__ precpos, const uint32_t *__restrict__ ent32,
                                                     int idx_stride, int idx_off, const uint32_t *__restrict__ vidof,
-                                                    int64_t *mapping)
+                                                    int64_t *mapping, int32_t *keepid, const unsigned char *__restrict__ trimmed)
 {
     const uint32_t total = bucket_base[nbins];
     for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
         const uint32_t e = precpos[p];
         const uint32_t vid = e == kInf ? kNoVoxel : vidof[e];
-        mapping[ent32[(size_t)p * idx_stride + idx_off]] = vid == kNoVoxel ? -1ll : (long long)vid;
+        const uint32_t i = ent32[(size_t)p * idx_stride + idx_off];
+        if (keepid) keepid[i] = (vid == kNoVoxel || (trimmed && trimmed[i])) ? -1 : (int32_t)vid;   // fused filter: kept points
+        else mapping[i] = vid == kNoVoxel ? -1ll : (long long)vid;
     }
 }
 
@@ -1534,6 +1556,7 @@ struct FilterPoints {
     int32_t *keepid;          // [n] new voxel id of a kept point, -1 otherwise (written by the count pass)
     float *out_feats;
     int64_t *out_mask, *out_mapping;
+    bool precomputed = false; // keepid was filled by the fused sparse index (k_map_binned)
 
     __device__ __forceinline__ int32_t keep(int64_t i) const
     {
@@ -1547,6 +1570,7 @@ struct FilterPoints {
     }
     __device__ __forceinline__ unsigned long long value(int64_t i) const
     {
+        if (precomputed) return keepid[i] >= 0 ? 1ull : 0ull;
         const int32_t id = keep(i);
         keepid[i] = id;
         return id >= 0 ? 1ull : 0ull;
@@ -1744,6 +1768,9 @@ struct DenseOut {
     BinnedExtras x;           // all null for the dense contract
     int64_t *mapping;
     unsigned char *trimmed = nullptr;   // sparse contract: flag the points beyond P of their voxel (for the TRIM filter)
+    VoxelPass pass = {false, 0, {0, 0, 0}, {0, 0, 0}};   // sparse contract fused with the voxel filter
+    int32_t *keepid = nullptr;          // ... then: filtered voxel id of every point (-1: dropped) instead of `mapping`
+    uint32_t npoints_clamp = 0xffffffffu;   // ... and voxel_npoints = min(count, max_points) (voxelize.cpp:403)
 };
 
 // n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
@@ -1786,20 +1813,23 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     uint4 *vrec = reinterpret_cast<uint4 *>(w.aux);
     uint32_t *bucket_base = w.vidarr, *totals = w.vidarr + nbins + 2;
     uint32_t *pbin = w.pslot, *firstmap = w.list;
-    uint32_t *precpos = o.mapping ? w.unsorted : nullptr;       // the hash path's lists are not used here
+    const bool want_map = o.mapping || o.keepid;
+    uint32_t *precpos = want_map ? w.unsorted : nullptr;        // the hash path's lists are not used here
     BinnedExtras x = o.x;
-    x.vidof = o.mapping ? w.voff : nullptr;
+    x.vidof = want_map ? w.voff : nullptr;
+    x.npoints_clamp = o.npoints_clamp;
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     if (vec4)
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
-                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed);
+                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
     else
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, false, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
-                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed);
+                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
     D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, pkey, n, nbins, pbin, tilecnt, totals,
                bucket_base, bent, counts);
-    D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS>), dim3(nbins), dim3(kBucketThreads), 0, st, bent, p4, bucket_base,
+    D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass, x.vidof, bent, p4,
+               bucket_base,
                hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts, precpos, w.parr,
                reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 256 (n <= 4 M)
@@ -1813,9 +1843,10 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         D3D_LAUNCH("k_meta_first", (k_meta_first<Key, false>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
                    o.max_voxels, ROWS ? w.vinfo : (uint4 *)nullptr, w.staged, o.P, o.reduction, o.coords, o.npoints,
                    o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, counts, x);
-    if (o.mapping)
+    if (want_map)
         D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
-                   reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping);
+                   reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping, o.keepid,
+                   (const unsigned char *)o.trimmed);
     return D3D_OK;
 }
 
@@ -2188,6 +2219,43 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
 {
     if (!sparse_counts || max_points < 0) return D3D_ERR_BAD_ARG;
     if (max_voxels_filter == D3D_MAXVOX_DESCENDING) return D3D_ERR_UNSUPPORTED;       // needs the voxel count on the host
+    {
+        // Binned index + voxel filter in one numbering: a voxel that fails the filter (coordinate bounds, min_points) gets no
+        // first-point entry, so the first-seen numbering IS the filtered numbering (and its max_voxels cut the TRIM voxel
+        // filter); the per-voxel outputs are written once, filtered; k_map_binned leaves every point's filtered voxel id
+        // (or -1: no voxel / filtered voxel / trimmed point), which is all the point compaction needs.  The intermediate
+        // sparse outputs (points_mapping, coords, npoints) are not materialised on this path; sparse_counts holds the
+        // status bits (and the filtered voxel count).
+        hipStream_t st = (hipStream_t)stream;
+        const bool pf_ok = max_points_filter == D3D_MAXPTS_NONE || (max_points_filter == D3D_MAXPTS_TRIM && max_points > 0);
+        const bool vf_ok = max_voxels_filter == D3D_MAXVOX_NONE || max_voxels_filter == D3D_MAXVOX_TRIM;
+        if (pf_ok && vf_ok && n > 0 && c >= 3 && n < (1ll << 31) - kFlagTile && points && voxel_size && coords_bound && counts &&
+            out_feats && out_mask && out_mapping && out_npoints && out_coords && workspace && max_voxels >= 0) {
+            VoxelWs w = carve(workspace, workspace_bytes, n, n);
+            if (w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
+            uint32_t nbins = 0;
+            int hshift = 0;
+            if (binned_eligible(n, w, &nbins, &hshift)) {
+                SparseKey kf;
+                for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
+                const bool trim = max_points_filter == D3D_MAXPTS_TRIM;
+                const uint32_t vcap = max_voxels_filter == D3D_MAXVOX_NONE ? 0xffffffffu : (uint32_t)max_voxels;
+                DenseOut d{trim ? (uint32_t)max_points : 0u, vcap, D3D_REDUCE_NONE, false, false, out_coords, out_npoints, nullptr,
+                           nullptr, BinnedExtras{nullptr, 0, nullptr, -1, nullptr, nullptr}, nullptr};
+                d.trimmed = trim ? w.flags : nullptr;
+                d.pass.on = true;
+                d.pass.min_points = min_points;
+                for (int k = 0; k < 3; k++) { d.pass.lo[k] = coords_bound[2 * k]; d.pass.hi[k] = coords_bound[2 * k + 1]; }
+                d.keepid = reinterpret_cast<int32_t *>(w.big_list);
+                d.npoints_clamp = trim ? (uint32_t)max_points : 0xffffffffu;
+                int rc = binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, sparse_counts, d, st);
+                if (rc) return rc;
+                FilterPoints fp{points, c, nullptr, 0, nullptr, nullptr, nullptr, 0xffffffffu, d.keepid, out_feats, out_mask,
+                                out_mapping, true};
+                return d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st, host_counts, sparse_counts, 1);
+            }
+        }
+    }
     int trim_done = 0;
     const int32_t trim = max_points_filter == D3D_MAXPTS_TRIM ? max_points : 0;
     int rc = voxelize_sparse_impl(points, n, c, voxel_size, points_mapping, coords, npoints, sparse_counts, workspace,

@@ -145,7 +145,9 @@ int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int32_t c, con
 /* VoxelGenerator.__call__'s sparse branch (reference voxel/__init__.py:93-102) in one call: d3d_voxelize_3d_sparse
  * followed by d3d_voxelize_3d_filter on its outputs (same arguments, same outputs as the two calls; the voxel count
  * stays on the device, so max_voxels_filter DESCENDING is D3D_ERR_UNSUPPORTED here).  Besides saving the round trip it
- * lets the TRIM point filter reuse the per-voxel index ranking the sparse index already holds (voxelize.cpp:457-463).
+ * lets the TRIM point filter reuse the per-voxel index ranking the sparse index already holds (voxelize.cpp:457-463)
+ * and the voxel filter run inside the index (up to 4 M points, filters NONE / TRIM): points_mapping, coords and npoints
+ * are then scratch (not materialised), sparse_counts holds the status bits.
  * Workspace: d3d_voxelize_workspace_bytes(n, n).  host_counts: NULL, or 2 * D3D_NUM_COUNTS + 1 int64 of host-mapped
  * pinned memory with word [D3D_NUM_COUNTS] cleared: receives sparse_counts in [0, 4), counts in [5, 9) and then the flag
  * [4] = 1 before the last kernel (the compaction of the kept points) is launched -- see d3d_voxelize_3d_dense_notify. */
