@@ -902,6 +902,7 @@ __global__ __launch_bounds__(256) void k_overflow_reduce(const float4 *__restric
 constexpr int kBinTile = 4096;                // points per workgroup in k_bin_count / k_bin_scatter
 constexpr int kBinThreads = 1024;             // ... 4 per lane: 16 wavefronts per CU keep the loads in flight
 constexpr int kBinMax = 4096;                 // buckets (12 bits of the per-point word, 12 more for the rank in the tile)
+constexpr int kBucketTarget = 512;            // mean points per bucket the partition aims at
 constexpr int kBucketCap = 2048;              // points one k_bucket_index workgroup holds in registers
 constexpr int kBucketThreads = 512;           // ... 4 per lane (256: 42 us, 512: 38 us, 1024: 44 us at config 2)
 constexpr int kBucketSlots = 2048;            // LDS table slots (>= distinct cells of a bucket, always)
@@ -1783,7 +1784,7 @@ static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t *nbins_out, in
     if (mode == 1 || n <= 0) return false;
     uint32_t nbins = 1;
     int hshift = 0;
-    while (nbins < (uint32_t)kBinMax && (int64_t)nbins * 512 < n) { nbins <<= 1; hshift++; }
+    while (nbins < (uint32_t)kBinMax && (int64_t)nbins * kBucketTarget < n) { nbins <<= 1; hshift++; }
     if ((int64_t)nbins * 1024 < n) return false;        // more than 4 M points: buckets would outgrow a workgroup
     const uint64_t ntiles = (uint64_t)w.npad / kBinTile;
     if ((uint64_t)nbins * ntiles * 4 > w.cap * 8 || 2 * (uint64_t)nbins + 2 > w.cap) return false;
