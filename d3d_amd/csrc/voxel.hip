@@ -917,6 +917,7 @@ struct BinnedExtras {
     uint32_t *vidof;          // [records] voxel id of a record (for the point -> voxel map)
     int64_t *host_counts;     // optional host-mapped copy of counts[] + ready flag (d3d_voxelize_3d_dense_notify)
     uint32_t npoints_clamp = 0xffffffffu;
+    uint32_t *voff = nullptr; // [V] segment base (dense contract, C != 4: k_aggregate reads the index lists through it)
 };
 
 // sparse contract fused with the voxel filter (d3d_voxelize_3d_sparse_filter): only voxels that pass get a first-point
@@ -1138,7 +1139,7 @@ __device__ __forceinline__ u64 block_excl_scan_u64_lds(u64 v, u64 *total, u64 *s
     return woff + incl - v;
 }
 
-template <class Key, bool ROWS>
+template <class Key, bool ROWS, bool LISTS>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPass vp, uint32_t *__restrict__ vidof,
                                                       const typename BinEntry<ROWS>::type *__restrict__ bent,
                                                       const float4 *__restrict__ points4 /* ROWS */,
@@ -1148,7 +1149,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                       uint32_t *__restrict__ firstmap, int64_t *counts,
                                                       uint32_t *__restrict__ precpos /* optional: record of every point */,
                                                       uint32_t *__restrict__ pinfo, uint32_t *__restrict__ gseg /* big buckets */,
-                                                      unsigned char *__restrict__ trimmed /* optional: [n] rank >= P */)
+                                                      unsigned char *__restrict__ trimmed /* optional: [n] rank >= P */,
+                                                      uint32_t *__restrict__ sorted_out /* optional: ranked indices (C != 4) */,
+                                                      uint32_t *__restrict__ unsorted_out /* ... and all of an overflow voxel's */)
 {
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
     typedef typename Key::bin_key_t KT;
@@ -1192,7 +1195,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                            cc[1] < vp.hi[1] && cc[2] >= vp.lo[2] && cc[2] < vp.hi[2];
                     vidof[bb + j] = kNoVoxel;       // k_meta_first overwrites it for the voxels that get an id
                 }
-                if (pass) firstmap[f] = bb + j;
+                // (an atomic store on purpose: with two plain conditional stores next to each other -- vidof[bb + j] above and
+                // this one -- hipcc 7.2 emitted, in one code shape of this kernel, a merged store that wrote the value bb + j
+                // at firstmap[bb + j], i.e. the other store's index; found by the big-bucket tests)
+                if (pass) __hip_atomic_store(&firstmap[f], bb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 tfirst[s0 + k] = bb + j;            // from here on: the slot's record
                 j++;
                 if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
@@ -1297,6 +1303,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             for (; k + 4 <= cnt && rank < P; k += 4) rank += (v[k] < me) + (v[k + 1] < me) + (v[k + 2] < me) + (v[k + 3] < me);
             for (; k < cnt && rank < P; k++) rank += v[k] < me;
             if constexpr (ROWS) { if (rank < P) staged[bb + base + rank] = points4[me]; }
+            if constexpr (LISTS) {
+                if (rank < P) sorted_out[bb + base + rank] = me;
+                if (unsorted_out && cnt > P) unsorted_out[bb + base + (pinfo[bb + q] & kArrMask)] = me;
+            }
             if (trimmed && rank >= P) trimmed[me] = 1;
             if (precpos) precpos[bb + q] = tfirst[s];
         }
@@ -1361,6 +1371,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                         (sg[k + 6] < me) + (sg[k + 7] < me);
             for (; k < cnt && rank < P; k++) rank += sg[k] < me;
             if constexpr (ROWS) { if (rank < P) *reinterpret_cast<v4f *>(&staged[bb + base + rank]) = row[r]; }
+            if constexpr (LISTS) {                                 // dense contract, C != 4: index lists for
+                if (rank < P) sorted_out[bb + base + rank] = me;   // k_fill_generic / k_aggregate
+                if (unsorted_out && cnt > P) unsorted_out[bb + base + arr[r]] = me;
+            }
             if (trimmed && rank >= P) trimmed[me] = 1;     // sparse contract + TRIM filter (voxelize.cpp:457-463)
             if (precpos) precpos[bb + q] = tfirst[s];
         }
@@ -1435,7 +1449,7 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
     const uint4 rec = vrec[e];
     const uint4 vi = rec;                                   // {key lo, key hi, segment base, count}
     if (vinfo) vinfo[vid] = vi;
-    meta_voxel<Key, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, nullptr, pmask, agg, nullptr, nullptr,
+    meta_voxel<Key, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, x.voff, pmask, agg, nullptr, nullptr,
                                x.keys_out, x.npoints_clamp);
 }
 
@@ -1772,6 +1786,7 @@ struct DenseOut {
     VoxelPass pass = {false, 0, {0, 0, 0}, {0, 0, 0}};   // sparse contract fused with the voxel filter
     int32_t *keepid = nullptr;          // ... then: filtered voxel id of every point (-1: dropped) instead of `mapping`
     uint32_t npoints_clamp = 0xffffffffu;   // ... and voxel_npoints = min(count, max_points) (voxelize.cpp:403)
+    bool lists = false;                 // dense contract with C != 4: ranked index lists + voff instead of staged rows
 };
 
 // n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
@@ -1819,6 +1834,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     BinnedExtras x = o.x;
     x.vidof = want_map ? w.voff : nullptr;
     x.npoints_clamp = o.npoints_clamp;
+    x.voff = o.lists ? w.voff : nullptr;
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     if (vec4)
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
@@ -1829,10 +1845,15 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
     D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, pkey, n, nbins, pbin, tilecnt, totals,
                bucket_base, bent, counts);
-    D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass, x.vidof, bent, p4,
-               bucket_base,
-               hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts, precpos, w.parr,
-               reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed);
+    if (!ROWS && o.lists)
+        D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass, x.vidof,
+                   reinterpret_cast<const typename BinEntry<false>::type *>(bent), p4, bucket_base, hshift, o.P, (int)D3D_REDUCE_NONE,
+                   w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
+                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr);
+    else
+        D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass, x.vidof,
+                   bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
+                   precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 256 (n <= 4 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF);
     const dim3 grid((unsigned)(w.npad / 256));
@@ -1842,7 +1863,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
                    reinterpret_cast<float4 *>(o.aggregates), counts, x);
     else
         D3D_LAUNCH("k_meta_first", (k_meta_first<Key, false>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
-                   o.max_voxels, ROWS ? w.vinfo : (uint4 *)nullptr, w.staged, o.P, o.reduction, o.coords, o.npoints,
+                   o.max_voxels, ROWS || o.lists ? w.vinfo : (uint4 *)nullptr, w.staged, o.P, o.reduction, o.coords, o.npoints,
                    o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, counts, x);
     if (want_map)
         D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
@@ -1917,10 +1938,18 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
     uint32_t nbins = 0;
     int hshift = 0;
-    if (vec4 && max_voxels > 0 && dense_cells_fit_u32(kf) && binned_eligible(n, w, &nbins, &hshift)) {
+    bool lists_ready = false;           // C != 4 on the binned index: w.big_list / w.unsorted / w.voff hold the lists
+    if (max_voxels > 0 && dense_cells_fit_u32(kf) && binned_eligible(n, w, &nbins, &hshift)) {
         DenseOut d{P, (uint32_t)max_voxels, reduction, agg4, fuse_pmask, coords, npoints, pmask, aggregates,
                    BinnedExtras{nullptr, 0, nullptr, -1, nullptr, host_counts}, nullptr};
-        rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
+        if (vec4) rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
+        else {
+            // any C: the {cell, index} entries travel alone, the bucket kernel leaves per-voxel index lists in point order
+            // and the generic output kernels below gather through them
+            d.lists = true;
+            lists_ready = true;
+            rc = binned_index<DenseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st);
+        }
         if (rc) return rc;
     } else {
         IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr, vec4};
@@ -1947,12 +1976,12 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
                    P, reinterpret_cast<float4 *>(voxels));
     else
         D3D_LAUNCH("k_fill_generic", k_fill_generic, dim3(grid_for(cap * P * c, 256, 256 * 32)), dim3(256), 0, st, points, c,
-                   counts, w.vinfo, w.list, P, voxels);
+                   counts, w.vinfo, lists_ready ? w.big_list : w.list, P, voxels);
     if (!fuse_pmask)
         D3D_LAUNCH("k_pmask", k_pmask, dim3(grid_for(d3d_divup(cap * P, 16), 256)), dim3(256), 0, st, counts, npoints, P, pmask);
     if (reduction != D3D_REDUCE_NONE && !agg4)
         D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(cap * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
-                   w.voff, w.list, w.unsorted, P, reduction, aggregates);
+                   w.voff, lists_ready ? w.big_list : w.list, w.unsorted, P, reduction, aggregates);
     return D3D_OK;
 }
 
