@@ -766,9 +766,12 @@ __device__ __forceinline__ void meta_voxel(const Key &kf, int64_t v, const uint4
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
     long long cc[3];
     kf.decode(((u64)vi.y << 32) | vi.x, cc);
-    coords[v * 3 + 0] = cc[0];
-    coords[v * 3 + 1] = cc[1];
-    coords[v * 3 + 2] = cc[2];
+    // 24 bytes as 16 + 8 (rows alternate their 16-byte alignment): two store requests instead of three
+    long long *cp = reinterpret_cast<long long *>(coords) + v * 3;
+    if ((reinterpret_cast<uintptr_t>(coords) & 15) == 0) {
+        if ((v & 1) == 0) { *reinterpret_cast<longlong2 *>(cp) = make_longlong2(cc[0], cc[1]); cp[2] = cc[2]; }
+        else { cp[0] = cc[0]; *reinterpret_cast<longlong2 *>(cp + 1) = make_longlong2(cc[1], cc[2]); }
+    } else { cp[0] = cc[0]; cp[1] = cc[1]; cp[2] = cc[2]; }
     npoints[v] = (int32_t)(vi.w < npoints_clamp ? vi.w : npoints_clamp);
     if (voff) voff[v] = vi.z;
     if (keys_out) keys_out[v] = (int64_t)(((u64)vi.y << 32) | vi.x);
