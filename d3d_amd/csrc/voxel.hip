@@ -2112,14 +2112,11 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     return D3D_OK;
 }
 
-// trim_points > 0: also flag (in the workspace's `flags`) the points that are not among the first trim_points of their
-// voxel, when the index path can do it on the way (*trim_done = 1) -- what the TRIM point filter would otherwise rank
 static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const float *voxel_size, int64_t *points_mapping,
                                 int64_t *coords, int32_t *npoints, int64_t *counts, void *workspace, size_t workspace_bytes,
-                                int64_t ws_nvox, void *stream, int32_t trim_points, int *trim_done)
+                                int64_t ws_nvox, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (trim_done) *trim_done = 0;
     if (n < 0 || c < 3 || !voxel_size || !counts) return D3D_ERR_BAD_ARG;
     if (n > 0 && (!points || !points_mapping || !coords || !npoints)) return D3D_ERR_BAD_ARG;
     if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
@@ -2134,11 +2131,6 @@ static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const
         for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
         DenseOut d{0u, 0xffffffffu, D3D_REDUCE_NONE, false, false, coords, npoints, nullptr, nullptr,
                    BinnedExtras{nullptr, 0, nullptr, -1, nullptr, nullptr}, points_mapping};
-        if (trim_points > 0 && trim_done) {
-            d.P = (uint32_t)trim_points;                // ranks are computed in LDS anyway when P > 0
-            d.trimmed = w.flags;
-            *trim_done = 1;
-        }
         return binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st);
     }
     IndexOpts o{0u, 0xffffffffu, nullptr, 0, points_mapping, false};
@@ -2176,7 +2168,7 @@ extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c,
                                       void *workspace, size_t workspace_bytes, void *stream)
 {
     return voxelize_sparse_impl(points, n, c, voxel_size, points_mapping, coords, npoints, counts, workspace, workspace_bytes, 0,
-                                stream, 0, nullptr);
+                                stream);
 }
 
 extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int32_t *order, void *ws, size_t ws_bytes,
@@ -2189,8 +2181,7 @@ static int filter_impl(const float *feats, int64_t n, int32_t c, const int64_t *
                        int32_t min_points, int32_t max_points, int32_t max_voxels, int32_t max_points_filter,
                        int32_t max_voxels_filter, float *out_feats, int64_t *out_mask, int64_t *out_mapping,
                        int32_t *out_npoints, int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
-                       void *stream, bool pretrimmed = false /* w.flags already marks the points beyond max_points */,
-                       int64_t *host_counts = nullptr, const int64_t *first_counts = nullptr)
+                       void *stream, int64_t *host_counts = nullptr, const int64_t *first_counts = nullptr)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || nvox < 0 || c < 1 || !coords_bound || !counts) return D3D_ERR_BAD_ARG;
@@ -2210,7 +2201,7 @@ static int filter_impl(const float *feats, int64_t n, int32_t c, const int64_t *
     // index lists of the overflow voxels live in w.list (their counts sum to <= n); cursors start at zero
     D3D_LAUNCH("k_fill_u32", k_fill_u32, dim3(grid_for(trim_pts ? nvox : 0, 256)), dim3(256), 0, st, w.fcur,
                trim_pts ? nvox : (int64_t)0, 0u, counts);
-    const bool rank_pts = trim_pts && n > 0 && nvox > 0 && max_points > 0 && !pretrimmed;
+    const bool rank_pts = trim_pts && n > 0 && nvox > 0 && max_points > 0;
     uint32_t *cellvox = w.parr;                                 // [n] voxel of each list cell
     unsigned char *trimmed = w.flags;                           // [n]
     if (rank_pts) {
@@ -2338,13 +2329,12 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
             }
         }
     }
-    int trim_done = 0;
-    const int32_t trim = max_points_filter == D3D_MAXPTS_TRIM ? max_points : 0;
+    // other filter combinations / sizes: the two operators one after the other, the voxel count staying on the device
     int rc = voxelize_sparse_impl(points, n, c, voxel_size, points_mapping, coords, npoints, sparse_counts, workspace,
-                                  workspace_bytes, n, stream, trim, &trim_done);
+                                  workspace_bytes, n, stream);
     if (rc) return rc;
     return filter_impl(points, n, c, points_mapping, coords, npoints, n, sparse_counts + D3D_COUNT_VOXELS, coords_bound,
                        min_points, max_points, max_voxels, max_points_filter, max_voxels_filter, out_feats, out_mask,
-                       out_mapping, out_npoints, out_coords, counts, workspace, workspace_bytes, stream, trim_done != 0, host_counts,
+                       out_mapping, out_npoints, out_coords, counts, workspace, workspace_bytes, stream, host_counts,
                        sparse_counts);
 }
