@@ -153,6 +153,20 @@ def extras(args):
     ex["iou2d_rbox_fp64_dense5k_mpairs_per_s"] = round(25e6 * 10 / dt / 1e6, 1)
     dt = timed(lambda: box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5), 20, 2)
     ex["nms_rbox_fp64_boxes_per_s"] = round(n3 * 20 / dt, 1)
+    try:        # the same operator captured into a HIP graph by the caller and replayed (~28 launches without host work)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5)
+        dt = timed(graph.replay, 20, 2)
+        ex["nms_rbox_fp64_boxes_per_s_graph_replay"] = round(n3 * 20 / dt, 1)
+        del graph
+    except Exception as e:      # capture is a convenience of the caller's runtime, not of the library
+        ex["nms_rbox_fp64_boxes_per_s_graph_replay"] = "unavailable: %s" % type(e).__name__
     del bt, st
     torch.cuda.empty_cache()
     # config 4: 20k x 5k iou3d fp32
