@@ -927,11 +927,16 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const BoxGeom<T> *__restrict_
 // sweep.  States cross XCDs, hence the agent-scope atomic loads/stores.
 constexpr int kSpinPasses = 4096;
 __global__ __launch_bounds__(256) void k_nms_resolve(int64_t n, uint8_t *state, const uint32_t *__restrict__ inc_cnt,
-                                                     const uint32_t *__restrict__ inc_off, uint32_t *inc, NmsFlags *flags)
+                                                     const uint32_t *__restrict__ inc_off, uint32_t *inc, NmsFlags *flags,
+                                                     const int64_t *__restrict__ order, uint8_t *__restrict__ suppressed)
 {
     if (__hip_atomic_load(&flags->need_sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the list overflowed
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool done = q >= n || state[q] != kUndecided;
+    // every box reports its own result as soon as it is final (if the dense path takes over after all, its sweep rewrites
+    // every entry): no separate pass over the states
+    const int64_t mine_out = q < n ? order[q] : 0;
+    if (q < n && done) suppressed[mine_out] = state[q] == kSuppressed;
     // hitters [pos, cnt) are still undecided as far as this lane knows: every pass looks at all of them (ONE kept hitter
     // decides, wherever it sits in the list) and moves the ones found suppressed in front of pos
     uint32_t pos = 0, cnt = 0;
@@ -948,6 +953,7 @@ __global__ __launch_bounds__(256) void k_nms_resolve(int64_t n, uint8_t *state, 
             }
             if (hit || pos == cnt) {
                 __hip_atomic_store(&state[q], (uint8_t)(hit ? kSuppressed : kKept), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                suppressed[mine_out] = hit ? 1 : 0;
                 done = true;
             }
         }
@@ -955,15 +961,6 @@ __global__ __launch_bounds__(256) void k_nms_resolve(int64_t n, uint8_t *state, 
         __builtin_amdgcn_s_sleep(2);
     }
     if (!done) flags->need_sweep = 1;
-}
-
-// the fixed point was reached: states are final
-__global__ __launch_bounds__(256) void k_nms_emit(int64_t n, const int64_t *__restrict__ order, const uint8_t *__restrict__ state,
-                                                  const NmsFlags *flags, uint8_t *__restrict__ suppressed)
-{
-    if (flags->need_sweep) return;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) suppressed[order[p]] = state[p] == kSuppressed;
 }
 
 // one workgroup; remv (nb words) lives in global scratch when it does not fit LDS
@@ -976,7 +973,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_nms_sweep(const unsigned long
                                                              const NmsFlags *flags, uint8_t *suppressed)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];
-    if (!flags->need_sweep) return;      // the fixed point was reached: k_nms_emit wrote the result
+    if (!flags->need_sweep) return;      // the fixed point was reached: k_nms_resolve wrote the result
     const bool in_lds = nb <= kSweepLdsWords;
     unsigned long long *remv = in_lds ? lds : remv_g;
     __shared__ unsigned long long keep_word;
@@ -1097,9 +1094,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     D3D_LAUNCH("k_nms_fill", k_nms_fill, dim3(hits_blocks), dim3(256), 0, st, (const unsigned long long *)cand, cap,
                (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, (const uint32_t *)arrival, inc);
     D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,
-               (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, flags);
-    D3D_LAUNCH("k_nms_emit", k_nms_emit, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, order, (const uint8_t *)state,
-               (const NmsFlags *)flags, suppressed);
+               (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, flags, order, suppressed);
     // dense path, gated on need_sweep inside the kernels
     const unsigned pair_blocks = (unsigned)std::min<int64_t>(d3d_divup(nb, kColsPerBlock) * d3d_divup(nb, 4), 8192);
     if (rot)

@@ -6,11 +6,6 @@
 #include <rocprim/rocprim.hpp>
 
 namespace {
-__global__ void k_iota_i32(int32_t *p, int64_t n)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = (int32_t)i;
-}
 __global__ void k_widen(const int32_t *in, int64_t n, int64_t *out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -21,8 +16,8 @@ template <typename K>
 size_t sort_temp_bytes(int64_t n)
 {
     size_t tmp = 0;
-    (void)rocprim::radix_sort_pairs_desc<rocprim::default_config, const K *, K *, const int32_t *, int32_t *>(
-        nullptr, tmp, nullptr, nullptr, nullptr, nullptr, (size_t)n);
+    (void)rocprim::radix_sort_pairs_desc<rocprim::default_config, const K *, K *, rocprim::counting_iterator<int32_t>, int32_t *>(
+        nullptr, tmp, nullptr, nullptr, rocprim::counting_iterator<int32_t>(0), nullptr, (size_t)n);
     return tmp;
 }
 
@@ -44,9 +39,9 @@ int argsort_desc(const K *keys, int64_t n, int32_t *order32, void *ws, size_t ws
     size_t tmp = sort_temp_bytes<K>(n);
     char *temp = w.take<char>(tmp);
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
-    D3D_LAUNCH("k_iota_i32", k_iota_i32, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, iota, n);
-    D3D_HIP_CHECK((rocprim::radix_sort_pairs_desc(temp, tmp, keys, keys_out, (const int32_t *)iota, order32, (size_t)n, 0,
-                                                  sizeof(K) * 8, st)));
+    (void)iota;     // the values 0 .. n-1 come from a counting iterator: no kernel to materialise them
+    D3D_HIP_CHECK((rocprim::radix_sort_pairs_desc(temp, tmp, keys, keys_out, rocprim::counting_iterator<int32_t>(0), order32,
+                                                  (size_t)n, 0, sizeof(K) * 8, st)));
     return D3D_OK;
 }
 }  // namespace
