@@ -485,3 +485,38 @@ def test_dense_notify_publishes_the_counts_to_pinned_host_memory(voxel_path, n, 
     assert outs[0][0] == outs[1][0] and (n == 0) == (outs[0][0] == 0)
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n", [511, 512, 513, 65536, 65537])
+def test_binned_bucket_count_boundaries(voxel_path, n):
+    """point counts around the powers of two that change the number of buckets (n / 512 rounded up to a power of two)"""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    cloud = synth.uniform_cloud(n, 61 + n)
+    kw = dict(reduction="max", max_points=3, max_voxels=n, dense=True)
+    exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [88, 100, 8], **kw)(cloud)
+    voxel_path(2)
+    check_dense(_np(VoxelGenerator(synth.KITTI_BOUNDS, [88, 100, 8], **kw)(torch.from_numpy(cloud).cuda())), exp, 3)
+    kw = dict(max_points=2, max_points_filter="trim", max_voxels=max(n // 3, 1), max_voxels_filter="trim")
+    exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [88, 100, 8], **kw)(cloud)
+    check_sparse(_np(VoxelGenerator(synth.KITTI_BOUNDS, [88, 100, 8], **kw)(torch.from_numpy(cloud).cuda())), exp)
+
+
+def test_no_point_inside_the_grid_and_large_max_points(voxel_path):
+    """every point outside the bounds (dense contract: zero voxels; sparse + filter: zero kept points), and max_points larger
+    than any voxel / than the 64-lane wavefront"""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    cloud = synth.lidar_like(5000, 71)
+    far = cloud.copy()
+    far[:, 0] += 1000.0
+    for path in (1, 2):
+        voxel_path(path)
+        ret = VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], max_points=4, max_voxels=100, dense=True, reduction="mean")(
+            torch.from_numpy(far).cuda())
+        assert ret.coords.shape[0] == 0 and ret.voxels.shape == (0, 4, 4)
+        ret = VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], max_points=4, max_points_filter="trim")(torch.from_numpy(far).cuda())
+        assert ret.points.shape[0] == 0 and ret.coords.shape[0] == 0
+        kw = dict(reduction="mean", max_points=300, max_voxels=5000, dense=True)
+        exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [44, 50, 4], **kw)(cloud)
+        check_dense(_np(VoxelGenerator(synth.KITTI_BOUNDS, [44, 50, 4], **kw)(torch.from_numpy(cloud).cuda())), exp, 300)
