@@ -520,3 +520,18 @@ def test_no_point_inside_the_grid_and_large_max_points(voxel_path):
         kw = dict(reduction="mean", max_points=300, max_voxels=5000, dense=True)
         exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [44, 50, 4], **kw)(cloud)
         check_dense(_np(VoxelGenerator(synth.KITTI_BOUNDS, [44, 50, 4], **kw)(torch.from_numpy(cloud).cuda())), exp, 300)
+
+
+@pytest.mark.parametrize("n", [4194304, 4194305])
+def test_four_million_points_the_binned_limit(index_path, n):
+    """4 M points is the largest frame the binned index takes (4096 buckets of 1024 on average); one more goes to the hash
+    table -- both bit-exact with the oracle (config 5's single-GPU size class)"""
+    if index_path == "hash" and n == 4194305:
+        pytest.skip("same path as auto")
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    cloud = synth.lidar_like(n, 81, synth.WAYMO_BOUNDS)
+    kw = dict(reduction="mean", max_points=4, max_voxels=n, dense=True)
+    exp = oracle.VoxelGenerator(synth.WAYMO_BOUNDS, [752, 752, 30], **kw)(cloud)
+    ret = _np(VoxelGenerator(synth.WAYMO_BOUNDS, [752, 752, 30], **kw)(torch.from_numpy(cloud).cuda()))
+    check_dense(ret, exp, 4)
