@@ -2,7 +2,7 @@
 // std::unordered_map loops of the reference (d3d/voxel/voxelize.cpp).  Two index paths build the same intermediate
 // form (one record per voxel in first-seen order, the points' rows in per-voxel segments in point order):
 //
-// BINNED (default, up to 4 M points; "binned index" section below)
+// BINNED (default, up to 8 M points; "binned index" section below)
 //   partition  the points are partitioned by hash(cell) into buckets of ~512: tile histograms in LDS, a scan, ONE
 //              scattered 8-byte store per point {cell, index}
 //   bucket     one workgroup per bucket does everything per point in LDS: cell -> slot (CAS), count, first index,
@@ -950,7 +950,8 @@ __global__ __launch_bounds__(256) void k_overflow_reduce(const float4 *__restric
 // (k_meta_first), whose stores are then coalesced by voxel id.
 constexpr int kBinTile = 4096;                // points per workgroup in k_bin_count / k_bin_scatter
 constexpr int kBinThreads = 1024;             // ... 4 per lane: 16 wavefronts per CU keep the loads in flight
-constexpr int kBinMax = 4096;                 // buckets (12 bits of the per-point word, 12 more for the rank in the tile)
+constexpr int kBinBits = 13;
+constexpr int kBinMax = 1 << kBinBits;        // buckets (13 bits of the per-point word, 12 more for the rank in the tile)
 constexpr int kBucketTarget = 512;            // mean points per bucket the partition aims at
 constexpr int kBucketCap = 2048;              // points one k_bucket_index workgroup holds in registers
 constexpr int kBucketThreads = 512;           // ... 4 per lane (256: 42 us, 512: 38 us, 1024: 44 us at config 2)
@@ -1051,7 +1052,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
             u64 key;
             if (kf.make(v[r], key, status)) {
                 const uint32_t b = Key::bin_hash(key) & (nbins - 1);
-                word = b | (atomicAdd(&h[b], 1u) << 12);
+                word = b | (atomicAdd(&h[b], 1u) << kBinBits);
                 pkey[i] = (typename BinEntry<ROWS>::key_store_t)key;
             } else if (status) word = kBadBin;
         }
@@ -1141,7 +1142,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
         const uint32_t word = pbin[i];
         if (word == kBadBin) bad = true;
         if (word >= kBadBin) continue;
-        bent[off[word & (kBinMax - 1)] + (word >> 12)] = BinEntry<ROWS>::pack((u64)pkey[i], (uint32_t)i);
+        bent[off[word & (kBinMax - 1)] + (word >> kBinBits)] = BinEntry<ROWS>::pack((u64)pkey[i], (uint32_t)i);
     }
     if (bad) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_COORD_OVERFLOW);
 }
@@ -1849,7 +1850,7 @@ static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t *nbins_out, in
     uint32_t nbins = 1;
     int hshift = 0;
     while (nbins < (uint32_t)kBinMax && (int64_t)nbins * kBucketTarget < n) { nbins <<= 1; hshift++; }
-    if ((int64_t)nbins * 1024 < n) return false;        // more than 4 M points: buckets would outgrow a workgroup
+    if ((int64_t)nbins * 1024 < n) return false;        // more than 8 M points: buckets would outgrow a workgroup
     const uint64_t ntiles = (uint64_t)w.npad / kBinTile;
     if ((uint64_t)nbins * ntiles * 4 > w.cap * 8 || 2 * (uint64_t)nbins + 2 > w.cap) return false;
     *nbins_out = nbins;
@@ -1903,7 +1904,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass, x.vidof,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
                    precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr);
-    const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 256 (n <= 4 M)
+    const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 512 (n <= 8 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF);
     const dim3 grid((unsigned)(w.npad / 256));
     if (o.agg4)
@@ -2125,7 +2126,7 @@ static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const
     uint32_t nbins = 0;
     int hshift = 0;
     if (binned_eligible(n, w, &nbins, &hshift)) {
-        // up to 4 M points: partition by hash(cell) and index every bucket in LDS -- the 63-bit cell key itself is the
+        // up to 8 M points: partition by hash(cell) and index every bucket in LDS -- the 63-bit cell key itself is the
         // table key there, so no bounding box pass and no packed-slot limits
         SparseKey kf;
         for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];

@@ -69,7 +69,7 @@ const char *d3d_status_string(int status);
  * one-word slots {count | key | first index} whenever they fit 64 bits (one atomic per point). */
 int d3d_voxel_force_plain(int on);
 
-/* index path of d3d_voxelize_3d_dense for C == 4 rows: 0 = automatic (default: binned up to 4 M points),
+/* index path of d3d_voxelize_3d_dense for C == 4 rows: 0 = automatic (default: binned up to 8 M points),
  * 1 = hash table in HBM (any input), 2 = binned (points partitioned into buckets, per-bucket index in LDS) whenever the
  * grid has < 2^32 - 1 cells.  Both give identical outputs; see DESIGN.md section 4. */
 int d3d_voxel_set_path(int path);
@@ -146,7 +146,7 @@ int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int32_t c, con
  * followed by d3d_voxelize_3d_filter on its outputs (same arguments, same outputs as the two calls; the voxel count
  * stays on the device, so max_voxels_filter DESCENDING is D3D_ERR_UNSUPPORTED here).  Besides saving the round trip it
  * lets the TRIM point filter reuse the per-voxel index ranking the sparse index already holds (voxelize.cpp:457-463)
- * and the voxel filter run inside the index (up to 4 M points, filters NONE / TRIM): points_mapping, coords and npoints
+ * and the voxel filter run inside the index (up to 8 M points, filters NONE / TRIM): points_mapping, coords and npoints
  * are then scratch (not materialised), sparse_counts holds the status bits.
  * Workspace: d3d_voxelize_workspace_bytes(n, n).  host_counts: NULL, or 2 * D3D_NUM_COUNTS + 1 int64 of host-mapped
  * pinned memory with word [D3D_NUM_COUNTS] cleared: receives sparse_counts in [0, 4), counts in [5, 9) and then the flag

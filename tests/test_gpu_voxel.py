@@ -522,12 +522,12 @@ def test_no_point_inside_the_grid_and_large_max_points(voxel_path):
         check_dense(_np(VoxelGenerator(synth.KITTI_BOUNDS, [44, 50, 4], **kw)(torch.from_numpy(cloud).cuda())), exp, 300)
 
 
-@pytest.mark.parametrize("n", [4194304, 4194305])
-def test_four_million_points_the_binned_limit(index_path, n):
-    """4 M points is the largest frame the binned index takes (4096 buckets of 1024 on average); one more goes to the hash
-    table -- both bit-exact with the oracle (config 5's single-GPU size class)"""
-    if index_path == "hash" and n == 4194305:
-        pytest.skip("same path as auto")
+@pytest.mark.parametrize("n", [4194304, 8388608, 8388609])
+def test_millions_of_points_up_to_the_binned_limit(index_path, n):
+    """8 M points (config 5's frame on ONE GPU) is the largest frame the binned index takes (8192 buckets of 1024 on
+    average); one more goes to the hash table -- all bit-exact with the oracle"""
+    if index_path == "hash" and n != 4194304:
+        pytest.skip("one hash-table run of this size class is enough")
     from d3d_amd import synth
     from d3d_amd.voxel import VoxelGenerator
     cloud = synth.lidar_like(n, 81, synth.WAYMO_BOUNDS)
