@@ -1622,6 +1622,7 @@ struct FilterPoints {
     float *out_feats;
     int64_t *out_mask, *out_mapping;
     bool precomputed = false; // keepid was filled by the fused sparse index (k_map_binned)
+    bool vec4 = false;        // c == 4 and 16-byte aligned rows: one float4 copy per kept point
 
     __device__ __forceinline__ int32_t keep(int64_t i) const
     {
@@ -1646,7 +1647,9 @@ struct FilterPoints {
         if (!val) return;
         out_mask[excl] = i;
         out_mapping[excl] = keepid[i];
-        for (int d = 0; d < c; d++) out_feats[excl * c + d] = feats[i * c + d];
+        if (vec4) reinterpret_cast<float4 *>(out_feats)[excl] = reinterpret_cast<const float4 *>(feats)[i];   // c == 4, aligned
+        else
+            for (int d = 0; d < c; d++) out_feats[excl * c + d] = feats[i * c + d];
     }
 };
 
@@ -2244,7 +2247,8 @@ static int filter_impl(const float *feats, int64_t n, int32_t c, const int64_t *
                    (const uint32_t *)w.list, (const uint32_t *)cellvox, n, voxel_npoints, (const uint32_t *)w.coff, P, trimmed);
     }
     FilterPoints fp{feats, c, points_mapping, nvox, voxel_npoints, w.newid, trimmed, P,
-                    reinterpret_cast<int32_t *>(w.pslot), out_feats, out_mask, out_mapping};
+                    reinterpret_cast<int32_t *>(w.pslot), out_feats, out_mask, out_mapping, false,
+                    c == 4 && ((reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(out_feats)) & 15) == 0};
     rc = d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st, host_counts, first_counts);
     return rc;
 }
@@ -2325,7 +2329,8 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                 int rc = binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, sparse_counts, d, st);
                 if (rc) return rc;
                 FilterPoints fp{points, c, nullptr, 0, nullptr, nullptr, nullptr, 0xffffffffu, d.keepid, out_feats, out_mask,
-                                out_mapping, true};
+                                out_mapping, true,
+                                c == 4 && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out_feats)) & 15) == 0};
                 return d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st, host_counts, sparse_counts, 1);
             }
         }
