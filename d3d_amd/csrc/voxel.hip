@@ -716,8 +716,12 @@ __global__ __launch_bounds__(256) void k_fill_c4(const float4 *__restrict__ stag
     typedef float vec4 __attribute__((ext_vector_type(4)));
     const int64_t rows = counts[D3D_COUNT_VOXELS] * (int64_t)max_points;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // row -> (voxel, slot): a shift when max_points is a power of two, a 32-bit division while the row index fits, the
+    // 64-bit division (~100 instructions per row: a third of this kernel's issue slots at config 2) only beyond that
+    const int sh = (max_points & (max_points - 1)) == 0 ? __builtin_ctz(max_points) : -1;
+    const bool small = rows < (1ll << 32);
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
-        const int64_t v = r / max_points;
+        const int64_t v = sh >= 0 ? (r >> sh) : (small ? (int64_t)((uint32_t)r / max_points) : r / max_points);
         const uint32_t k = (uint32_t)(r - v * max_points);
         const uint4 vi = vinfo[v];
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
