@@ -264,6 +264,11 @@ __global__ __launch_bounds__(256) void k_sharded_fill_owned(int64_t nvox, int ts
     if (i < nvox && cnt_table) cnt_table[i] = 0;
 }
 
+// PACKED (C == 4, 16-byte aligned outputs): two scattered 16-byte stores per voxel instead of four -- the features (final)
+// and {cell key, count} parked in the 16-byte aligned half of the voxel's own 24-byte coordinate slot; k_sharded_unpack
+// then turns the slots into coordinates and counts in place, streaming.  Scattered store requests are what this pass costs
+// (4 per global voxel on every rank: 179 us at 2.55 M voxels).
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_sharded_finalize_owned(int64_t nvox, int c, const int64_t *__restrict__ key_of_slot,
                                                                 const float *__restrict__ table, int tstride, int mean,
                                                                 const int32_t *__restrict__ cnt_in, int64_t sy, int64_t sz,
@@ -277,14 +282,22 @@ __global__ __launch_bounds__(256) void k_sharded_finalize_owned(int64_t nvox, in
     vid_of_slot[s] = v;
     if (v < 0 || v >= nvox) return;                     // cannot happen: every slot has exactly one owner
     const int64_t k = key_of_slot[s];
-    const long long c0 = k / (sy * sz), c1 = (k / sz) % sy, c2 = k % sz;
+    const float n = mean ? row[c] : 1.f;
+    const int32_t cnt = mean ? (int32_t)(n + 0.5f) : cnt_in[s];
     long long *cp = reinterpret_cast<long long *>(coords) + v * 3;
+    if (PACKED) {
+        *reinterpret_cast<longlong2 *>(cp + (v & 1)) = make_longlong2(k, (long long)cnt);   // (3 v + (v & 1)) * 8 is a multiple of 16
+        float4 f = make_float4(row[0], row[1], row[2], row[3]);
+        if (mean) f = make_float4(f.x / n, f.y / n, f.z / n, f.w / n);
+        reinterpret_cast<float4 *>(feats)[v] = f;
+        return;
+    }
+    const long long c0 = k / (sy * sz), c1 = (k / sz) % sy, c2 = k % sz;
     if (vec4) {                                          // 24 bytes as 16 + 8 (rows alternate their 16-byte alignment)
         if ((v & 1) == 0) { *reinterpret_cast<longlong2 *>(cp) = make_longlong2(c0, c1); cp[2] = c2; }
         else { cp[0] = c0; *reinterpret_cast<longlong2 *>(cp + 1) = make_longlong2(c1, c2); }
     } else { cp[0] = c0; cp[1] = c1; cp[2] = c2; }
-    const float n = mean ? row[c] : 1.f;
-    cnt_out[v] = mean ? (int32_t)(n + 0.5f) : cnt_in[s];
+    cnt_out[v] = cnt;
     if (c == 4 && vec4) {
         float4 f = make_float4(row[0], row[1], row[2], row[3]);
         if (mean) f = make_float4(f.x / n, f.y / n, f.z / n, f.w / n);
@@ -292,6 +305,20 @@ __global__ __launch_bounds__(256) void k_sharded_finalize_owned(int64_t nvox, in
     } else {
         for (int d = 0; d < c; d++) feats[v * c + d] = mean ? row[d] / n : row[d];
     }
+}
+
+// in place, one lane per voxel id: {key, count} parked by the packed finalize -> coords[v, 0..3), cnt_out[v]
+__global__ __launch_bounds__(256) void k_sharded_unpack(int64_t nvox, int64_t sy, int64_t sz, int64_t *coords, int32_t *cnt_out)
+{
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvox) return;
+    long long *cp = reinterpret_cast<long long *>(coords) + v * 3;
+    const longlong2 kc = *reinterpret_cast<const longlong2 *>(cp + (v & 1));
+    const long long k = kc.x;
+    const long long c0 = k / (sy * sz), c1 = (k / sz) % sy, c2 = k % sz;
+    if ((v & 1) == 0) { *reinterpret_cast<longlong2 *>(cp) = make_longlong2(c0, c1); cp[2] = c2; }
+    else { cp[0] = c0; *reinterpret_cast<longlong2 *>(cp + 1) = make_longlong2(c1, c2); }
+    cnt_out[v] = (int32_t)kc.y;
 }
 
 // global voxel id of each local point: local voxel -> slot -> voxel id
@@ -519,9 +546,18 @@ extern "C" int d3d_sharded_finalize_owned(int64_t nvox, int32_t c, const int64_t
     if (nvox < 0 || c < 1 || !shape) return D3D_ERR_BAD_ARG;
     if (nvox == 0) return D3D_OK;
     if (!key_of_slot || !table || !vid_of_slot || !coords || !cnt_out || !feats || (!mean && !cnt_in)) return D3D_ERR_BAD_ARG;
-    D3D_LAUNCH("k_sharded_finalize_owned", k_sharded_finalize_owned, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox, c,
-               key_of_slot, table, table_stride, mean, cnt_in, (int64_t)shape[1], (int64_t)shape[2], vid_of_slot, coords,
-               cnt_out, feats, ((reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(coords)) & 15) == 0);
+    const bool al16 = ((reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(coords)) & 15) == 0;
+    if (c == 4 && al16) {
+        D3D_LAUNCH("k_sharded_finalize_owned", k_sharded_finalize_owned<true>, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st,
+                   nvox, c, key_of_slot, table, table_stride, mean, cnt_in, (int64_t)shape[1], (int64_t)shape[2], vid_of_slot,
+                   coords, cnt_out, feats, true);
+        D3D_LAUNCH("k_sharded_unpack", k_sharded_unpack, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox,
+                   (int64_t)shape[1], (int64_t)shape[2], coords, cnt_out);
+        return D3D_OK;
+    }
+    D3D_LAUNCH("k_sharded_finalize_owned", k_sharded_finalize_owned<false>, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st,
+               nvox, c, key_of_slot, table, table_stride, mean, cnt_in, (int64_t)shape[1], (int64_t)shape[2], vid_of_slot, coords,
+               cnt_out, feats, al16);
     return D3D_OK;
 }
 
