@@ -218,6 +218,7 @@ struct OwnedRows {
     int64_t *slot_of_local;
     float identity;                   // what k_sharded_fill_owned wrote
     bool row_pairs;                   // table and agg aligned for float2 / float4 access
+    bool row_quads;                   // ... and the table for float4 access
     __device__ __forceinline__ unsigned long long value(int64_t v) const
     {
         const int64_t k = keys[v];
@@ -242,10 +243,21 @@ struct OwnedRows {
             // the common shape (4 features + count + id = 24-byte rows): three 8-byte stores instead of six 4-byte ones --
             // scattered requests are what this pass costs.  The id column of a row another rank owns keeps the identity.
             const float4 a = reinterpret_cast<const float4 *>(agg)[v];
+            const float cf = (float)cnt[v], idf = owned ? id : identity;
+            if (row_quads) {                          // 24 bytes as 16 + 8: rows alternate their 16-byte alignment
+                if ((s & 1) == 0) {
+                    *reinterpret_cast<float4 *>(row) = a;
+                    *reinterpret_cast<float2 *>(row + 4) = make_float2(cf, idf);
+                } else {
+                    *reinterpret_cast<float2 *>(row) = make_float2(a.x, a.y);
+                    *reinterpret_cast<float4 *>(row + 2) = make_float4(a.z, a.w, cf, idf);
+                }
+                return;
+            }
             float2 *r2 = reinterpret_cast<float2 *>(row);
             r2[0] = make_float2(a.x, a.y);
             r2[1] = make_float2(a.z, a.w);
-            r2[2] = make_float2((float)cnt[v], owned ? id : identity);
+            r2[2] = make_float2(cf, idf);
             return;
         }
         for (int d = 0; d < c; d++) row[d] = agg[v * c + d];
@@ -534,7 +546,8 @@ extern "C" int d3d_sharded_scatter_owned(const int64_t *keys_local, int64_t n_lo
     if (n_local == 0) return D3D_OK;
     OwnedRows f{keys_local, ncells, bitmap, prefix, lower, newc, (int)rank, (int)c, mean ? 1 : 0, (int)table_stride,
                 agg, cnt, table, cnt_table, slot_of_local, identity,
-                ((reinterpret_cast<uintptr_t>(table) & 7) == 0) && ((reinterpret_cast<uintptr_t>(agg) & 15) == 0)};
+                ((reinterpret_cast<uintptr_t>(table) & 7) == 0) && ((reinterpret_cast<uintptr_t>(agg) & 15) == 0),
+                (reinterpret_cast<uintptr_t>(table) & 15) == 0};
     return d3d_run_scan(f, n_local, bsum, scratch_counts, -1, 0, ~0ull, st);
 }
 
