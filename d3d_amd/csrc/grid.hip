@@ -271,9 +271,17 @@ struct OwnedRows {
 __global__ __launch_bounds__(256) void k_sharded_fill_owned(int64_t nvox, int tstride, float identity, float *table,
                                                             int32_t *cnt_table)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nvox * tstride) table[i] = identity;
-    if (i < nvox && cnt_table) cnt_table[i] = 0;
+    // 16 bytes per lane where the table allows it (the table is all-reduced next: every rank writes all of it)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = nvox * tstride;
+    if ((reinterpret_cast<uintptr_t>(table) & 15) == 0) {
+        if (i * 4 + 4 <= total) reinterpret_cast<float4 *>(table)[i] = make_float4(identity, identity, identity, identity);
+        else
+            for (int64_t j = i * 4; j < total; j++) table[j] = identity;
+    } else {
+        for (int64_t j = i * 4; j < total && j < i * 4 + 4; j++) table[j] = identity;
+    }
+    if (cnt_table)
+        for (int64_t j = i * 4; j < nvox && j < i * 4 + 4; j++) cnt_table[j] = 0;
 }
 
 // PACKED (C == 4, 16-byte aligned outputs): two scattered 16-byte stores per voxel instead of four -- the features (final)
@@ -541,7 +549,7 @@ extern "C" int d3d_sharded_scatter_owned(const int64_t *keys_local, int64_t n_lo
     if (!compact_ws || !owner_ws || !scan_ws || !w.ok() || !ow.ok() || !sw.ok()) return D3D_ERR_WORKSPACE;
     const float identity = mean ? 0.f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
     if (nvox > 0)
-        D3D_LAUNCH("k_sharded_fill_owned", k_sharded_fill_owned, dim3((unsigned)d3d_divup(nvox * table_stride, 256)), dim3(256), 0,
+        D3D_LAUNCH("k_sharded_fill_owned", k_sharded_fill_owned, dim3((unsigned)d3d_divup(d3d_divup(nvox * table_stride, 4), 256)), dim3(256), 0,
                    st, nvox, table_stride, identity, table, mean ? nullptr : cnt_table);
     if (n_local == 0) return D3D_OK;
     OwnedRows f{keys_local, ncells, bitmap, prefix, lower, newc, (int)rank, (int)c, mean ? 1 : 0, (int)table_stride,
