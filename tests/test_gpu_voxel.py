@@ -535,3 +535,34 @@ def test_millions_of_points_up_to_the_binned_limit(index_path, n):
     exp = oracle.VoxelGenerator(synth.WAYMO_BOUNDS, [752, 752, 30], **kw)(cloud)
     ret = _np(VoxelGenerator(synth.WAYMO_BOUNDS, [752, 752, 30], **kw)(torch.from_numpy(cloud).cuda()))
     check_dense(ret, exp, 4)
+
+
+def test_fused_sparse_filter_entry_error_codes():
+    """d3d_voxelize_3d_sparse_filter: the DESCENDING voxel filter needs the voxel count on the host (unsupported in the fused
+    call, VoxelGenerator then issues the two calls), sparse_counts is mandatory, a short workspace is reported"""
+    import ctypes
+    from d3d_amd import _lib, synth
+    lib = _lib.load()
+    n = 5000
+    pts = torch.from_numpy(synth.lidar_like(n, 91)).cuda()
+    size = (ctypes.c_float * 3)(0.2, 0.2, 0.2)
+    bound = (ctypes.c_int64 * 6)(0, 352, -200, 200, -15, 5)
+    dev = pts.device
+    i64 = lambda *s: torch.empty(s, dtype=torch.int64, device=dev)   # noqa: E731
+    mapping, coords, o_mask, o_map, o_crd = i64(n), i64(n, 3), i64(n), i64(n), i64(n, 3)
+    npts, o_cnt = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+    o_feats = torch.empty((n, 4), device=dev)
+    counts = i64(2, _lib.NUM_COUNTS)
+    ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, n), dev)
+
+    def call(vf, sparse_counts, ws_bytes):
+        return lib.d3d_voxelize_3d_sparse_filter(
+            _lib.ptr(pts), n, 4, ctypes.cast(size, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p), 0, 8, 100, 1, vf,
+            _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), sparse_counts, _lib.ptr(o_feats), _lib.ptr(o_mask),
+            _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd), _lib.ptr(counts[1]), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(), None)
+    assert call(2, _lib.ptr(counts[0]), ws.numel()) == _lib.ERR_UNSUPPORTED          # DESCENDING
+    assert call(1, None, ws.numel()) == _lib.ERR_BAD_ARG
+    assert call(1, _lib.ptr(counts[0]), 1024) == _lib.ERR_WORKSPACE
+    assert call(1, _lib.ptr(counts[0]), ws.numel()) == 0
+    host = counts.cpu()
+    assert host[0, _lib.COUNT_STATUS] == 0 and 0 < host[1, _lib.COUNT_VOXELS] <= 100 and host[1, _lib.COUNT_POINTS] > 0
