@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the d3d voxel/box hot path on MI355X (contract: see README/DESIGN.md).
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher (WORLD_SIZE unset): bench.py starts `python -m torch.distributed.run --nproc-per-node N` on
+itself as a CHILD process before anything touches the GPU, relays rank 0's JSON line and exits with the child's code.
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
   N = 1 : BASELINE.json config 2 -- 1 M LiDAR-like KITTI-range points, 0.1 m voxels, max 32 points/voxel,
           dense contract + MEAN reduction through d3d_amd.voxel.VoxelGenerator (includes the one host read-back of
           the voxel count that the operator's variable-size return contract needs).
-  N > 1 : the point-sharded voxelizer (one 1 M-point shard of config 2's shape per rank, weak scaling):
-          local hash voxelization -> RCCL all-gather of the per-rank occupancy (bitmaps or key lists) -> global
-          numbering -> RCCL all-reduce of the voxel feature grid (d3d_amd.voxel.sharded).
-Rank 0 prints ONE JSON line.  `value` is whole-job Mpoints/s.  The line also carries `roofline` (dominant kernel,
-timed with HIP events on its launch stream in a separate pass of the same K steps), `cpu_baseline` (the REAL
-reference voxelizer built from /root/reference into oracle/_ref, or the C port when that binary is absent) and
-`extra` (rotated IoU Mpairs/s, NMS boxes/s, iou3d Mpairs/s, sparse-contract voxelization).
+  N > 1 : BASELINE.json config 5's shards -- rank k holds points [k M, (k+1) M) of the 8 M-point Waymo-scale frame
+          (0.05 m voxels, 3008 x 3008 x 120 grid); at N = 8 that is config 5 itself, at N = 2 / 4 the frame's first
+          2 M / 4 M points (weak scaling: 1 M points per rank): local binned voxelization -> RCCL all-gather of the
+          per-rank occupied-cell key lists -> global numbering -> RCCL all-reduce of the voxel feature grid
+          (d3d_amd.voxel.sharded).
+Rank 0 prints ONE JSON line.  `value` is whole-job Mpoints/s.  At N = 1 the line also carries `roofline` (dominant kernel,
+timed with HIP events on its launch stream in a separate pass of the same K steps), `roofline_large` (the same fill kernel
+on config 5's whole 8 M-point frame on one GPU: 3 GB of output, beyond the 256 MB Infinity Cache, next to the stream
+bandwidth measured on the same box), `cpu_baseline` (the REAL reference voxelizer built from /root/reference into
+oracle/_ref, or the C port when that binary is absent) and `extra` (uniform cloud, sparse contract, rotated IoU Mpairs/s,
+NMS boxes/s, iou3d Mpairs/s).
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -75,15 +82,70 @@ def kernel_profile(fn, steps):
 
 
 def load_traffic(kernel, workload):
-    """HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/traffic.json), or None"""
+    """HBM bytes per launch from the COMMITTED rocprofv3 --pmc passes (profiles/traffic.json, made by
+    tools/collect_profiles.sh + tools/summarize_pmc.py): PMC counters cannot be collected from inside this process, so
+    the figure is the one of the last profiled build, not of this run -> (bytes | None, source label)"""
     p = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(p):
-        return None
     try:
         t = json.load(open(p))
-        return t.get(workload, {}).get(kernel)
+        return t.get(workload, {}).get(kernel), "profiles/traffic.json (committed rocprofv3 --pmc passes, %s)" % t.get(
+            "_profile", "unlabelled")
     except Exception:
-        return None
+        return None, "unavailable"
+
+
+def stream_probe(nbytes, iters=5):
+    """achievable stream bandwidth of THIS box (GB/s): nontemporal stores, copy, read sweep over an nbytes buffer --
+    the access patterns of the HBM-bound kernels with the work stripped off (d3d_stream_probe, api.hip)"""
+    from d3d_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros((nbytes,), dtype=torch.uint8, device="cuda")
+    out = {}
+    for mode, name, moved in ((0, "store_nt", nbytes), (1, "copy", nbytes // 32 * 32), (2, "read", nbytes)):
+        run = lambda: _lib.check(lib.d3d_stream_probe(mode, _lib.ptr(buf), nbytes, _lib.stream_ptr()), "stream_probe")  # noqa: E731
+        run()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            run()
+        b.record()
+        b.synchronize()
+        out[name] = round(moved * iters / (a.elapsed_time(b) * 1e-3) / 1e9, 1)
+    del buf
+    torch.cuda.empty_cache()
+    return out
+
+
+def large_frame_leg(steps=5):
+    """config 5's whole 8 M-point frame through the dense operator on ONE GPU: 5.9 M voxels -> voxels[V,32,4] = 3 GB, far
+    beyond the 256 MB Infinity Cache, so k_fill_c4's rate here is an HBM rate (at config 2 the 300 MB output partly drains
+    through the cache).  Priced against the 8 TB/s spec AND the store / copy bandwidth measured on this box."""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    n, P = 8000000, 32
+    cloud = torch.from_numpy(synth.lidar_like(n, 3, synth.WAYMO_BOUNDS)).cuda()
+    gen = VoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, dense=True, reduction="mean", max_points=P, max_voxels=n)
+    res = gen(cloud)
+    V = int(res.coords.shape[0])
+    kept = int(torch.clamp(res.voxel_npoints, max=P).sum())
+    del res
+    step = lambda: gen(cloud)  # noqa: E731
+    dt = timed(step, steps, 2)
+    prof = kernel_profile(step, steps)
+    del cloud, gen
+    torch.cuda.empty_cache()
+    b_alg = V * P * 16 + kept * 16 + V * 16
+    us = prof["k_fill_c4"]["avg_us"]
+    ach = b_alg / (us * 1e-6) / 1e9
+    probe = stream_probe(3 << 30)
+    traffic, src = load_traffic("k_fill_c4", "config5_1gpu")
+    return dict(bound="hbm", kernel="k_fill_c4", workload="config 5 frame on one GPU: 8 M LiDAR-like points, 0.05 m voxels "
+                "(3008x3008x120), dense+MEAN, max 32 pts/voxel", voxels=V, achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+                unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), peak_measured=probe,
+                frac_of_measured_store=round(ach / probe["store_nt"], 4), avg_us=round(us, 2), algorithmic_bytes=b_alg,
+                traffic=traffic, traffic_source=src, op_ms=round(1e3 * dt / steps, 3),
+                op_mpoints_per_s=round(n * steps / dt / 1e6, 1),
+                kernels_us={k: round(v["avg_us"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])})
 
 
 def cpu_baseline_voxel(cloud, bounds, shape, max_points, max_voxels):
@@ -120,11 +182,29 @@ def cpu_baseline_voxel(cloud, bounds, shape, max_points, max_voxels):
                 sample="%d run(s) of the full %d-point cloud, dense+MEAN, max_points=%d" % (runs, n, max_points))
 
 
+def cpu_allcore_voxel(cloud, bounds, shape, max_points, max_voxels):
+    """the same sequential algorithm on every host core at once, one whole frame per thread (the reference has no
+    intra-frame parallelism, voxelize.cpp:94, so frame-parallel is the only all-core form): C port through ctypes
+    (releases the GIL); at most 32 threads (512 MB of output buffers each)."""
+    import threading
+    import oracle
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    oracle.lib()
+    run = lambda: oracle.voxelize_3d_dense(cloud, shape, bounds, max_points, max_voxels, 1)  # noqa: E731
+    ts = [threading.Thread(target=run) for _ in range(cores)]
+    t0 = time.perf_counter()
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    dt = time.perf_counter() - t0
+    return dict(value=round(cloud.shape[0] * cores / dt / 1e6, 4), unit="Mpoints/s", cores=cores, kind="port",
+                sample="one full %d-point frame per thread on %d threads at once (frame-parallel)" % (cloud.shape[0], cores))
+
+
 def extras(args):
     """secondary metrics of BASELINE.json (configs 2-sparse, 3, 4); short runs, GPU + bounded CPU samples"""
     import oracle
     from d3d_amd import synth
-    from d3d_amd.box import box2d_nms, iou2dr_forward, iou3d
+    from d3d_amd.box import box2d_iou, box2d_nms, iou3d
     from d3d_amd.voxel import VoxelGenerator
     ex = {}
     ncpu = os.cpu_count() or 1
@@ -134,6 +214,16 @@ def extras(args):
     dt = timed(lambda: gen(cloud), 10, 2)
     ex["voxelize_sparse_trim_mpoints_per_s"] = round(args.points * 10 / dt / 1e6, 2)
     del cloud
+    # config 2 on the UNIFORM cloud (SURVEY 8d's worst case: ~0.98 voxels per point, 500 MB of voxels[V,32,4])
+    cloud = torch.from_numpy(synth.uniform_cloud(args.points, 0)).cuda()
+    gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=32, max_voxels=args.points)
+    vu = int(gen(cloud).coords.shape[0])
+    dt = timed(lambda: gen(cloud), 10, 2)
+    ex["voxelize_dense_uniform_mpoints_per_s"] = round(args.points * 10 / dt / 1e6, 2)
+    ex["voxelize_dense_uniform_voxels"] = vu
+    ex["voxelize_dense_uniform_op_algorithmic_GBps"] = round((args.points * 16 + vu * (32 * 16 + 32 + 24 + 4 + 16)) * 10 / dt / 1e9, 1)
+    del cloud, gen
+    torch.cuda.empty_cache()
     # config 3: 100k rotated boxes fp64, all 1e10 pairs in ONE 80 GB result (288 GB of HBM; row blocks only beyond 100 GB)
     n3 = args.boxes
     b, s = synth.boxes2d_sparse(n3, 1)
@@ -142,14 +232,14 @@ def extras(args):
 
     def all_pairs():
         for r0 in range(0, n3, rows):
-            iou2dr_forward(bt[r0:r0 + rows], bt)
+            box2d_iou(bt[r0:r0 + rows], bt, method="rbox")       # the public operator (fp64 in, precise=True)
     dt = timed(all_pairs, 2, 1)
     ex["iou2d_rbox_fp64_mpairs_per_s"] = round(n3 * n3 * 2 / dt / 1e6, 1)
     ex["iou2d_rbox_fp64_GBps_written"] = round(n3 * n3 * 8 * 2 / dt / 1e9, 1)
     torch.cuda.empty_cache()
     bd, _ = synth.boxes2d_dense(5000, 1)      # the reference's own benchmark distribution (ALU-bound case)
     bdt = torch.from_numpy(bd).cuda()
-    dt = timed(lambda: iou2dr_forward(bdt, bdt), 10, 2)
+    dt = timed(lambda: box2d_iou(bdt, bdt, method="rbox"), 10, 2)
     ex["iou2d_rbox_fp64_dense5k_mpairs_per_s"] = round(25e6 * 10 / dt / 1e6, 1)
     dt = timed(lambda: box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5), 20, 2)
     ex["nms_rbox_fp64_boxes_per_s"] = round(n3 * 20 / dt, 1)
@@ -201,32 +291,42 @@ def main():
     ap.add_argument("--skip-extra", action="store_true")
     ap.add_argument("--dist", choices=["lidar", "uniform"], default="lidar")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (RCCL) path even with one rank")
+    ap.add_argument("--skip-large", action="store_true", help="skip the 8 M-point beyond-cache roofline leg")
+    ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port when bench.py launches the ranks itself")
     args = ap.parse_args()
-
-    from d3d_amd import synth
-    from d3d_amd.voxel import VoxelGenerator
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: one rank per GPU under torch.distributed.run, started as a CHILD process --
+        # nothing in this process has touched the GPU yet (importing torch does not), and this process never will
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+
     torch.cuda.set_device(local_rank)
     barrier = None
     sharded = world > 1 or args.force_sharded
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         barrier = dist.barrier
 
     P, n = 32, args.points
-    mk = synth.lidar_like if args.dist == "lidar" else synth.uniform_cloud
-    cloud_h = mk(n, rank)                       # rank k owns shard k (seed = rank; rank 0 = config 2's cloud)
-    cloud = torch.from_numpy(cloud_h).cuda()
     out = {}
     if not sharded:
+        mk = synth.lidar_like if args.dist == "lidar" else synth.uniform_cloud
+        cloud_h = mk(n, 0)                      # config 2's cloud
+        cloud = torch.from_numpy(cloud_h).cuda()
         gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=P,
                              max_voxels=n)
         res = gen(cloud)
@@ -260,8 +360,8 @@ def main():
         b_alg = algo.get(name) or (n * 16)
         ach = b_alg / (dom[1]["avg_us"] * 1e-6) / 1e9
         out["roofline"] = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                               frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(name, "config2"),
-                               avg_us=round(dom[1]["avg_us"], 2), algorithmic_bytes=b_alg,
+                               frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(name, "config2")[0],
+                               traffic_source=load_traffic(name, "config2")[1], avg_us=round(dom[1]["avg_us"], 2), algorithmic_bytes=b_alg,
                                timing="HIP events on the launch stream, separate pass of the same %d steps" % args.steps)
         if name in ("k_bin_scatter", "k_bucket_index"):
             # limited by scattered 4..16-byte stores, not bytes: measured ceiling ~80 G/s (profiles/r01_g_atomic_bench.txt)
@@ -281,27 +381,49 @@ def main():
             f_ach = algo["k_fill_c4"] / (f_us * 1e-6) / 1e9
             out["roofline_streaming"] = dict(bound="hbm", kernel="k_fill_c4", achieved=round(f_ach, 1), peak=HBM_PEAK_GBS,
                                              unit="GB/s", frac=round(f_ach / HBM_PEAK_GBS, 4),
-                                             traffic=load_traffic("k_fill_c4", "config2"), avg_us=round(f_us, 2),
+                                             traffic=load_traffic("k_fill_c4", "config2")[0], avg_us=round(f_us, 2),
                                              algorithmic_bytes=algo["k_fill_c4"])
         out["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         out["op_algorithmic_GBps"] = round((n * 16 + V * (P * 16 + P + 24 + 4 + 16)) * args.steps / dt / 1e9, 1)
         out["voxels"] = V
         parallelism = "1 GPU"
     else:
-        from d3d_amd.voxel.sharded import ShardedVoxelGenerator
-        gen = ShardedVoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, reduction="mean")
+        from d3d_amd.voxel.sharded import LocalComm, ShardedVoxelGenerator
+        # config 5: rank k holds points [k n, (k+1) n) of the frame (world = 8, n = 1 M: the 8 M-point frame itself)
+        frame = synth.lidar_like(world * n, 3, synth.WAYMO_BOUNDS)
+        cloud_h = np.ascontiguousarray(frame[rank * n:(rank + 1) * n])
+        del frame
+        cloud = torch.from_numpy(cloud_h).cuda()
+        # the same operator on this rank's shard alone (world of one, no collectives): the base of the weak-scaling curve
+        solo = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction="mean", comm=LocalComm())
+        dt_solo = timed(lambda: solo(cloud), max(args.steps // 2, 3), 2)
+        solo_ms = 1e3 * dt_solo / max(args.steps // 2, 3)
+        del solo
+        gen = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction="mean")
         step = lambda: gen(cloud)  # noqa: E731
         out["voxels_global"] = int(step().coords.shape[0])
-        ncells = synth.KITTI_SHAPE[0] * synth.KITTI_SHAPE[1] * synth.KITTI_SHAPE[2]
-        out["exchange"] = "bitmaps (%.1f MB per rank) + one all-reduce of the voxel table, voxel ids by ownership" % (
-            ncells / 8 / 1e6) if (ncells + 63) // 64 <= n + 1 else "key lists + all-reduces of table and first indices"
+        st = dict(gen.last_stats)
+        out["rccl_ranks"] = world
+        out["exchange"] = st["exchange"]
+        out["numbering"] = st["numbering"]
+        out["collectives_per_step"] = dict(
+            all_gather_bytes_per_rank=st["all_gather_bytes_per_rank"], all_gather_bytes_received=st["all_gather_bytes_per_rank"] * world,
+            all_reduce_bytes=st["all_reduce_bytes"], size_all_gather_bytes=8,
+            note="all-gather of the occupied-cell %s, all-reduce of the voxel table%s" % (
+                "key lists" if st["exchange"] == "keys" else "bitmaps",
+                " + MIN all-reduce of the first-point indices" if st["numbering"] == "first-index" else ""))
         dt_local = timed(step, args.steps, args.warmup, barrier)
-        t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt_local, solo_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
         value = n * world * args.steps / dt / 1e6
-        workload = ("config2-shaped shards: %d LiDAR-like points per rank (seed=rank), 0.1 m voxels, point-sharded "
-                    "voxelization + RCCL all-gather of the occupancy + all-reduce of the voxel feature grid" % n)
+        out["same_operator_one_rank"] = dict(ms_per_step=round(float(t[1].item()), 4),
+                                             mpoints_per_s=round(n / float(t[1].item()) / 1e3, 2),
+                                             note="sharded feature-grid operator on one rank's shard without collectives "
+                                                  "(max over ranks); bench.py --gpus 1 is a different operator: config 2 dense")
+        workload = ("config5 shards: rank k = points [k*%d, (k+1)*%d) of a %d-point LiDAR-like Waymo-range frame (seed 3), "
+                    "0.05 m voxels (3008x3008x120), MEAN feature grid: local voxelization + RCCL all-gather of the occupied "
+                    "cells + all-reduce of the voxel feature grid, result replicated" % (n, n, world * n))
         parallelism = "points sharded over %d GPUs" % world
 
     if rank == 0:
@@ -313,11 +435,15 @@ def main():
             "config": {"workload": workload, "points_per_gpu": n, "parallelism": parallelism},
         }
         line.update(out)
+        if not sharded:
+            del cloud, gen
+            torch.cuda.empty_cache()
+        if not sharded and not args.skip_large:
+            line["roofline_large"] = large_frame_leg()
         if not sharded and not args.skip_cpu:
             line["cpu_baseline"] = cpu_baseline_voxel(cloud_h, synth.KITTI_BOUNDS, synth.KITTI_SHAPE, P, n)
+            line["cpu_baseline_all_cores"] = cpu_allcore_voxel(cloud_h, synth.KITTI_BOUNDS, synth.KITTI_SHAPE, P, n)
         if not sharded and not args.skip_extra:
-            del cloud
-            torch.cuda.empty_cache()
             line["extra"] = extras(args)
         print(json.dumps(line))
     if sharded:

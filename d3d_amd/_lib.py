@@ -17,30 +17,40 @@ OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = 0, -1, -2, -3, -4
 COUNT_VOXELS, COUNT_POINTS, COUNT_STATUS, COUNT_AUX, NUM_COUNTS = 0, 1, 2, 3, 4
 STATUS_COORD_OVERFLOW, STATUS_TABLE_FULL, STATUS_PACK_OVERFLOW, STATUS_BIN_OVERFLOW = 1, 2, 4, 8
 F32, F64 = 0, 1
+# per-call option bits (include/d3d_hip.h)
+VOXEL_PATH_HASH, VOXEL_PLAIN_SLOTS = 1, 4
+NMS_BROAD_SWEEP, NMS_FORCE_DENSE, NMS_SOFT_NO_LDS = 1, 2, 4
 
-_vp, _i64, _i32, _sz, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_size_t, ctypes.c_float
+
+def nms_cand_cap(k):
+    return int(k) << 8
+
+
+def iou_list_cap(k):
+    return int(k) << 8
+
+
+_vp, _i64, _i32, _sz, _f32, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_size_t, ctypes.c_float, ctypes.c_uint32
 
 # name -> (restype, argtypes); must list every symbol include/d3d_hip.h declares
 SIGNATURES = {
     "d3d_abi_version": (ctypes.c_int, []),
     "d3d_last_hip_error": (ctypes.c_int, []),
     "d3d_status_string": (ctypes.c_char_p, [ctypes.c_int]),
-    "d3d_voxel_force_plain": (ctypes.c_int, [ctypes.c_int]),
-    "d3d_voxel_set_path": (ctypes.c_int, [ctypes.c_int]),
     "d3d_voxelize_workspace_bytes": (_sz, [_i64, _i64]),
     "d3d_voxelize_3d_dense": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
-                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32]),
     "d3d_voxelize_3d_dense_notify": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
-                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "d3d_voxelize_3d_sparse": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _u32]),
+    "d3d_voxelize_3d_sparse": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32]),
     "d3d_voxelize_3d_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_voxelize_3d_sparse_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+                                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _u32]),
     "d3d_voxelize_3d_filter_chained": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32,
                                                       _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_voxelize_3d_reduce": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                              _vp, _sz, _vp]),
+                                              _vp, _sz, _vp, _u32]),
     "d3d_sharded_scatter": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _sz, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                            _vp, _vp, _vp, _vp, _vp]),
     "d3d_sharded_finalize": (ctypes.c_int, [_i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
@@ -61,8 +71,9 @@ SIGNATURES = {
     "d3d_aligned_scatter_backward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "d3d_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "d3d_profile_report": (ctypes.c_int, [ctypes.c_char_p, _sz]),
+    "d3d_stream_probe": (ctypes.c_int, [ctypes.c_int, _vp, _sz, _vp]),
     "d3d_iou2d_workspace_bytes": (_sz, [_i64, _i64, _i32]),
-    "d3d_iou2d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "d3d_iou2d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp, _u32]),
     "d3d_iou2d_backward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "d3d_iou3d_workspace_bytes": (_sz, [_i64, _i64]),
     "d3d_iou3d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
@@ -70,7 +81,7 @@ SIGNATURES = {
     "d3d_argsort_desc_workspace_bytes": (_sz, [_i64, _i32]),
     "d3d_argsort_desc": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "d3d_nms2d_workspace_bytes": (_sz, [_i64]),
-    "d3d_nms2d": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp]),
+    "d3d_nms2d": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp, _u32]),
 }
 
 _lib = None
@@ -124,8 +135,10 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device):
-    """Reusable scratch arena per (device, stream); grows geometrically, never shrinks."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    """Reusable scratch arena per (device, stream, host thread); grows geometrically, never shrinks.  Per thread as well:
+    two threads that issue multi-kernel operators on the SAME stream interleave their launches, and each operator must
+    keep its scratch to itself for that to be harmless (the C ABI is re-entrant given distinct workspaces)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, threading.get_ident())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)

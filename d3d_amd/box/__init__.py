@@ -32,6 +32,11 @@ class SupressionType(enum.IntEnum):     # box/common.h:10  (sic: the reference s
 
 cuda_available = True   # box/impl.cpp:9-13: this build always has its device path
 
+# Options applied to the calls that do not pass their own (bits of _lib.NMS_* / _lib.nms_cand_cap, _lib.iou_list_cap):
+# diagnostic / test hooks that select between equivalent internal paths; they travel as per-call arguments of the C ABI.
+default_nms_flags = 0
+default_iou_flags = 0
+
 
 def _dtype_code(t):
     if t.dtype == torch.float64:
@@ -52,7 +57,7 @@ def _to_device(*ts):
     return [t.to(dev).contiguous() for t in ts], dev
 
 
-def _iou_forward(boxes1, boxes2, iou_type):
+def _iou_forward(boxes1, boxes2, iou_type, flags=None):
     lib = _lib.load()
     odev = boxes1.device
     if boxes1.dtype != boxes2.dtype:
@@ -64,7 +69,8 @@ def _iou_forward(boxes1, boxes2, iou_type):
         code = _dtype_code(b1)
         ws = _lib.workspace(lib.d3d_iou2d_workspace_bytes(n, m, code), dev)
         rc = lib.d3d_iou2d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, int(iou_type), code, _lib.ptr(ious),
-                                   _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr())
+                                   _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr(),
+                                   default_iou_flags if flags is None else int(flags))
     _lib.check(rc, "iou2d_forward")
     return ious.to(odev) if odev != dev else ious
 
@@ -183,7 +189,8 @@ def argsort_desc(scores):
     return order
 
 
-def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param, sort_keys=None):
+def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param, sort_keys=None,
+          flags=None):
     """nms2d / nms2d_cuda (nms.h:6-18; nms.cpp:98-119): returns the SUPPRESSED mask (bool[N]).
     Follows the CPU control flow of the reference (nms.cpp:23-59).  sort_keys: optional fp32 tensor that orders like
     `scores` (the scores before their promotion to fp64): half the radix passes of the argsort, same order."""
@@ -209,7 +216,7 @@ def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_thresho
         ws = _lib.workspace(lib.d3d_nms2d_workspace_bytes(n), dev)
         rc = lib.d3d_nms2d(_lib.ptr(b), _lib.ptr(s), _lib.ptr(order), n, iou_type, supression_type, code,
                            float(iou_threshold), float(score_threshold), float(supression_param), _lib.ptr(sup),
-                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), default_nms_flags if flags is None else int(flags))
     _lib.check(rc, "nms2d")
     sup = sup.view(torch.bool)
     return sup.to(odev) if odev != dev else sup

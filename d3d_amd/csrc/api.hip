@@ -27,7 +27,7 @@ void d3d_prof_post(const char *name, hipStream_t st)
     (void)hipEventRecord(g_recs.back().b, st);
 }
 
-extern "C" int d3d_abi_version(void) { return 4; }
+extern "C" int d3d_abi_version(void) { return 5; }
 extern "C" int d3d_last_hip_error(void) { return g_d3d_last_hip_error; }
 extern "C" const char *d3d_status_string(int status)
 {
@@ -72,5 +72,50 @@ extern "C" int d3d_profile_report(char *buf, size_t buf_bytes)
         if (k < 0 || off + (size_t)k >= buf_bytes) return D3D_ERR_WORKSPACE;
         off += (size_t)k;
     }
+    return D3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stream-bandwidth probes for bench.py's roofline legs ("fraction of the MEASURED copy bandwidth on the same box",
+// SURVEY 8d): the access patterns of the HBM-bound kernels with the work stripped off.  mode 0: nontemporal 16-byte
+// stores over `bytes` (the pattern of k_fill_c4 / the IoU zero fill); mode 1: copy of bytes/2 -> bytes/2
+// (16-byte loads + nontemporal stores); mode 2: read-only sweep (the sum lands in the first word, so the loads stay).
+namespace {
+typedef float bvec4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_probe_store(bvec4 *p, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const bvec4 v = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(v, &p[i]);
+}
+__global__ __launch_bounds__(256) void k_probe_copy(const bvec4 *__restrict__ src, bvec4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+}
+__global__ __launch_bounds__(256) void k_probe_read(const bvec4 *__restrict__ src, size_t n, float *sink)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    bvec4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += __builtin_nontemporal_load(&src[i]);
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) *sink = 1.f;      // never true for the zero-filled probe buffer
+}
+}  // namespace
+
+extern "C" int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!buf || bytes < 64 || (reinterpret_cast<uintptr_t>(buf) & 15)) return D3D_ERR_BAD_ARG;
+    const unsigned blocks = 256 * 32;
+    if (mode == 0) {
+        D3D_LAUNCH("k_probe_store", k_probe_store, dim3(blocks), dim3(256), 0, st, (bvec4 *)buf, bytes / 16);
+    } else if (mode == 1) {
+        const size_t half = bytes / 32 * 16;
+        D3D_LAUNCH("k_probe_copy", k_probe_copy, dim3(blocks), dim3(256), 0, st, (const bvec4 *)buf,
+                   (bvec4 *)((char *)buf + half), half / 16);
+    } else if (mode == 2) {
+        D3D_LAUNCH("k_probe_read", k_probe_read, dim3(blocks), dim3(256), 0, st, (const bvec4 *)buf, bytes / 16, (float *)buf);
+    } else return D3D_ERR_BAD_ARG;
     return D3D_OK;
 }

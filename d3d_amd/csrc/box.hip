@@ -422,11 +422,9 @@ struct NmsCand { unsigned long long count[kNmsListSegs * 16]; };   // entries ap
 // boxes, small sets get the full triangle.  D3D_NMS_CAND_CAP overrides (tests).
 static unsigned long long nms_cand_capacity(int64_t n)
 {
-    if (const char *e = getenv("D3D_NMS_CAND_CAP")) return (unsigned long long)std::max<long long>(atoll(e), 1);
     const unsigned long long tri = (unsigned long long)n * (unsigned long long)(n > 0 ? n - 1 : 0) / 2 + 1;
     return std::min<unsigned long long>(tri, std::max<unsigned long long>(512ull * (unsigned long long)n, 1ull << 24));
 }
-static unsigned int nms_force_dense() { const char *e = getenv("D3D_NMS_FORCE_DENSE"); return e && atoi(e) ? 1u : 0u; }
 
 
 template <typename T>
@@ -1020,7 +1018,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_nms_sweep(const unsigned long
 
 template <typename T>
 int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, int iou_type, float iou_thr,
-              float score_thr, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st)
+              float score_thr, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st, uint32_t opts)
 {
     const int64_t nb = d3d_divup(n, 64);
     WsCarver w(ws, ws_bytes);
@@ -1035,10 +1033,14 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     NmsFlags *flags = w.take<NmsFlags>(1);
     unsigned long long *remv = w.take<unsigned long long>(nb);
     NmsCand *cand_hdr = w.take<NmsCand>(1);
-    const unsigned long long cap = nms_cand_capacity(n);
-    unsigned long long *cand = w.take<unsigned long long>((size_t)cap);
-    uint32_t *inc = w.take<uint32_t>((size_t)cap);                     // hits <= candidates
-    uint32_t *arrival = w.take<uint32_t>((size_t)cap);
+    // the arrays are carved for the automatic capacity (what the workspace query counts); a per-call override
+    // (D3D_NMS_CAND_CAP, tests of the overflow -> dense path hand-over) can only shrink what is used of them
+    const unsigned long long cap_auto = nms_cand_capacity(n);
+    unsigned long long cap = cap_auto;
+    if ((opts >> 8) != 0 && (unsigned long long)(opts >> 8) < cap) cap = opts >> 8;
+    unsigned long long *cand = w.take<unsigned long long>((size_t)cap_auto);
+    uint32_t *inc = w.take<uint32_t>((size_t)cap_auto);                     // hits <= candidates
+    uint32_t *arrival = w.take<uint32_t>((size_t)cap_auto);
     int32_t *xkey = w.take<int32_t>(nb * 64);
     int32_t *perm = w.take<int32_t>(nb * 64);
     float4 *fbx = w.take<float4>(nb * 64 + kCandPad);
@@ -1057,10 +1059,9 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     float4 *fbc = w.take<float4>((size_t)cap_e);
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
     const bool rot = iou_type == D3D_IOU_RBOX;
-    const char *be = getenv("D3D_NMS_BROAD");
-    const bool use_grid = !(be && be[0] == 's');
+    const bool use_grid = !(opts & D3D_NMS_BROAD_SWEEP);
     D3D_LAUNCH("k_nms_prepare", k_nms_prepare<T>, dim3((unsigned)nb), dim3(64), 0, st, boxes, scores, order, n, score_thr,
-               geom, fbox, state, inc_cnt, cursor, remv, nb, flags, cand_hdr, nms_force_dense(), xkey, &grid->ticket);
+               geom, fbox, state, inc_cnt, cursor, remv, nb, flags, cand_hdr, (opts & D3D_NMS_FORCE_DENSE) ? 1u : 0u, xkey, &grid->ticket);
     if (use_grid) {
         const unsigned nbl = (unsigned)d3d_divup(n, 256);
         D3D_LAUNCH("k_nms_extent", k_nms_extent, dim3(kGridParts), dim3(256), 0, st, (const float4 *)fbox, n, gpartial, grid, cellcur);
@@ -1302,10 +1303,7 @@ static unsigned int list_segments(unsigned long long) { return 1u; }
 static unsigned long long iou_list_capacity(int64_t n, int64_t m)
 {
     const unsigned long long pairs = (unsigned long long)n * (unsigned long long)m;
-    unsigned long long cap = pairs < (1ull << 27) ? pairs : (1ull << 27);
-    const char *env = getenv("D3D_IOU_LIST_CAP");      // test hook: force the overflow -> fallback path
-    if (env && env[0]) { unsigned long long v = strtoull(env, nullptr, 10); if (v > 0 && v < cap) cap = v; }
-    return cap;
+    return pairs < (1ull << 27) ? pairs : (1ull << 27);
 }
 
 extern "C" size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype)
@@ -1318,7 +1316,8 @@ extern "C" size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype)
 }
 
 template <typename T, bool ROTATED>
-static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *ious, void *ws, size_t ws_bytes, hipStream_t st)
+static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *ious, void *ws, size_t ws_bytes, hipStream_t st,
+                           uint32_t opts)
 {
     WsCarver w(ws, ws_bytes);
     BoxGeom<T> *ga = w.take<BoxGeom<T>>(n);
@@ -1326,9 +1325,10 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *io
     float4 *ra = w.take<float4>(n);
     float4 *cb = w.take<float4>(m);
     IouList *hdr = w.take<IouList>(1);
-    const unsigned long long cap = iou_list_capacity(n, m);
+    unsigned long long cap = iou_list_capacity(n, m);
     unsigned long long *list = w.take<unsigned long long>(cap);
     if (!w.ok()) return D3D_ERR_WORKSPACE;
+    if ((opts >> 8) != 0 && (unsigned long long)(opts >> 8) < cap) cap = opts >> 8;     // D3D_IOU_LIST_CAP: use less of it
     D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, ra, hdr,
                list_segments(cap), ROTATED);
     D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u,
@@ -1349,10 +1349,10 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *io
 }
 
 extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t m, int32_t iou_type,
-                                 int32_t dtype, void *ious, void *workspace, size_t workspace_bytes, void *stream)
+                                 int32_t dtype, void *ious, void *workspace, size_t workspace_bytes, void *stream, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (n < 0 || m < 0) return D3D_ERR_BAD_ARG;
+    if (n < 0 || m < 0 || (flags & 0xffu)) return D3D_ERR_BAD_ARG;
     if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;
     if (n == 0 || m == 0) return D3D_OK;
@@ -1362,7 +1362,7 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     const bool rot = iou_type == D3D_IOU_RBOX;
     if (workspace && workspace_bytes >= d3d_iou2d_workspace_bytes(n, m, dtype)) {
         // zero fill + candidate list + one candidate per lane (BOX too: its IoU is non-zero only where the AABBs overlap)
-#define D3D_TWO_PHASE(T, R) iou2d_two_phase<T, R>((const T *)boxes1, n, (const T *)boxes2, m, (T *)ious, workspace, workspace_bytes, st)
+#define D3D_TWO_PHASE(T, R) iou2d_two_phase<T, R>((const T *)boxes1, n, (const T *)boxes2, m, (T *)ious, workspace, workspace_bytes, st, flags)
         if (dtype == D3D_F64) return rot ? D3D_TWO_PHASE(double, true) : D3D_TWO_PHASE(double, false);
         return rot ? D3D_TWO_PHASE(float, true) : D3D_TWO_PHASE(float, false);
 #undef D3D_TWO_PHASE
@@ -1448,7 +1448,7 @@ extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *bo
 constexpr size_t kSoftLdsBytes = 128 * 1024;      // position-indexed state of the soft-NMS kernel stays in LDS below this
 template <typename T, bool ROTATED>
 static int softnms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, int sup, float iou_thr,
-                         float score_thr, float param, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st)
+                         float score_thr, float param, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st, uint32_t opts)
 {
     WsCarver w(ws, ws_bytes);
     BoxGeom<T> *geom = w.take<BoxGeom<T>>(n);
@@ -1458,8 +1458,7 @@ static int softnms_typed(const T *boxes, const T *scores, const int64_t *order, 
     uint8_t *sp = w.take<uint8_t>(n);
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
     const size_t lds = (size_t)n * (sizeof(T) + 4 + 1);
-    const char *no_lds = getenv("D3D_SOFTNMS_NO_LDS");             // test hook: the global-scratch variant
-    const bool in_lds = lds <= kSoftLdsBytes && !(no_lds && no_lds[0] == '1');
+    const bool in_lds = lds <= kSoftLdsBytes && !(opts & D3D_NMS_SOFT_NO_LDS);    // (flag: the global-scratch variant)
     if (in_lds)
         D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softnms<T, ROTATED>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSoftLdsBytes));
@@ -1485,10 +1484,10 @@ extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
 extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n, int32_t iou_type,
                          int32_t suppression_type, int32_t dtype, float iou_threshold, float score_threshold,
                          float suppression_param, uint8_t *suppressed, void *workspace, size_t workspace_bytes,
-                         void *stream)
+                         void *stream, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (n < 0) return D3D_ERR_BAD_ARG;
+    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS))) return D3D_ERR_BAD_ARG;
     if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;   // common.h:25
     if (suppression_type != D3D_SUPPRESS_HARD && suppression_type != D3D_SUPPRESS_LINEAR &&
@@ -1502,23 +1501,23 @@ extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *o
         if (dtype == D3D_F64)
             return rot ? softnms_typed<double, true>((const double *)boxes, (const double *)scores, order, n, suppression_type,
                                                      iou_threshold, score_threshold, suppression_param, suppressed, workspace,
-                                                     workspace_bytes, st)
+                                                     workspace_bytes, st, flags)
                        : softnms_typed<double, false>((const double *)boxes, (const double *)scores, order, n, suppression_type,
                                                       iou_threshold, score_threshold, suppression_param, suppressed, workspace,
-                                                      workspace_bytes, st);
+                                                      workspace_bytes, st, flags);
         return rot ? softnms_typed<float, true>((const float *)boxes, (const float *)scores, order, n, suppression_type,
                                                 iou_threshold, score_threshold, suppression_param, suppressed, workspace,
-                                                workspace_bytes, st)
+                                                workspace_bytes, st, flags)
                    : softnms_typed<float, false>((const float *)boxes, (const float *)scores, order, n, suppression_type,
                                                  iou_threshold, score_threshold, suppression_param, suppressed, workspace,
-                                                 workspace_bytes, st);
+                                                 workspace_bytes, st, flags);
     }
     if (d3d_divup(n, 64) > 65535) return D3D_ERR_BAD_ARG;
     if (dtype == D3D_F64)
         return nms_typed<double>((const double *)boxes, (const double *)scores, order, n, iou_type, iou_threshold,
-                                 score_threshold, suppressed, workspace, workspace_bytes, st);
+                                 score_threshold, suppressed, workspace, workspace_bytes, st, flags);
     return nms_typed<float>((const float *)boxes, (const float *)scores, order, n, iou_type, iou_threshold,
-                            score_threshold, suppressed, workspace, workspace_bytes, st);
+                            score_threshold, suppressed, workspace, workspace_bytes, st, flags);
 }
 
 extern "C" int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, int64_t m, int32_t dtype, uint8_t *out,

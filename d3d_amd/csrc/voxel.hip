@@ -55,8 +55,6 @@ constexpr int kReduceSum = 4;                 // internal: MEAN without the divi
 constexpr int kSweepTile = 1024;              // slots per block in the table sweeps
 constexpr int kFlagTile = 256 * 64;           // flags per block in k_flagpack
 
-int g_force_plain = 0;                        // d3d_voxel_force_plain()
-int g_voxel_path = 0;                         // d3d_voxel_set_path(): 0 auto, 1 hash table, 2 binned (where eligible)
 
 __device__ __forceinline__ u64 mix64(u64 h)
 {
@@ -111,13 +109,17 @@ struct SparseKey {
     typedef u64 bin_key_t;
     static __device__ __forceinline__ uint32_t bin_hash(u64 key) { return (uint32_t)mix64(key); }
     float size[3];
+    // a point outside the key range (non-finite, or |floor(p/size)| >= 2^20): tolerant = it simply belongs to no voxel
+    // (the fused sparse + filter call, whose coordinate bounds lie inside the key range: the reference gives such a point
+    // a far-away voxel, voxelize.cpp:309, that its filter then drops, :376-384); otherwise COORD_OVERFLOW is raised
+    bool tolerant = false;
     __device__ __forceinline__ bool make(const float *p, u64 &key, uint32_t &status) const
     {
         u64 k = 0;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             float q = floorf(p[d] / size[d]);
-            if (!(q >= -1048576.0f && q < 1048576.0f)) { status |= D3D_VOXEL_STATUS_COORD_OVERFLOW; return false; }
+            if (!(q >= -1048576.0f && q < 1048576.0f)) { if (!tolerant) status |= D3D_VOXEL_STATUS_COORD_OVERFLOW; return false; }
             k = (k << 21) | (u64)(unsigned)((int)q + 1048576);
         }
         key = k;
@@ -151,12 +153,13 @@ struct BoxKey {
     float size[3];
     BoxParams *prm;
     int kb_max;               // widest key that still leaves 8 count bits
+    bool tolerant = false;    // see SparseKey
     __device__ __forceinline__ bool coord(const float *p, int *c, uint32_t &status) const
     {
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             float q = floorf(p[d] / size[d]);
-            if (!(q >= -1048576.0f && q < 1048576.0f)) { status |= D3D_VOXEL_STATUS_COORD_OVERFLOW; return false; }
+            if (!(q >= -1048576.0f && q < 1048576.0f)) { if (!tolerant) status |= D3D_VOXEL_STATUS_COORD_OVERFLOW; return false; }
             c[d] = (int)q;
         }
         return true;
@@ -1809,12 +1812,11 @@ static int build_index(const Key &kf, const Tab &tab, const float *points, int64
 }
 
 static int dense_index(const DenseKey &kf, const float *points, int64_t n, int c, const VoxelWs &w, int64_t *counts,
-                       const IndexOpts &o, hipStream_t st)
+                       const IndexOpts &o, uint32_t flags, hipStream_t st)
 {
     // packed one-word slots whenever [count | key | first] fits 64 bits with >= 8 count bits
     const double cells = (double)kf.shape[0] * (double)kf.shape[1] * (double)kf.shape[2];
-    const char *env = getenv("D3D_FORCE_PLAIN_SLOTS");
-    bool packed = !g_force_plain && !(env && env[0] == '1') && cells < 9.0e18;
+    bool packed = !(flags & D3D_VOXEL_PLAIN_SLOTS) && cells < 9.0e18;
     int ib = 0, kb = 0;
     if (packed) {
         ib = bits_for((u64)(n > 1 ? n - 1 : 1));
@@ -1847,13 +1849,9 @@ struct DenseOut {
 };
 
 // n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
-static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t *nbins_out, int *hshift_out)
+static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t flags, uint32_t *nbins_out, int *hshift_out)
 {
-    const char *env = getenv("D3D_VOXEL_PATH");
-    int mode = g_voxel_path;                            // an explicit d3d_voxel_set_path() wins over the environment
-    if (mode == 0 && env && env[0] == 'h') mode = 1;
-    if (mode == 0 && env && env[0] == 'b') mode = 2;
-    if (mode == 1 || n <= 0) return false;
+    if ((flags & D3D_VOXEL_PATH_HASH) || n <= 0) return false;
     uint32_t nbins = 1;
     int hshift = 0;
     while (nbins < (uint32_t)kBinMax && (int64_t)nbins * kBucketTarget < n) { nbins <<= 1; hshift++; }
@@ -1947,19 +1945,6 @@ static int make_dense_key(const int32_t *shape, const float *bound, DenseKey &kf
 }  // namespace
 
 // ====================================================================== C ABI
-extern "C" int d3d_voxel_force_plain(int on)
-{
-    g_force_plain = on ? 1 : 0;
-    return D3D_OK;
-}
-
-extern "C" int d3d_voxel_set_path(int path)
-{
-    if (path < 0 || path > 2) return D3D_ERR_BAD_ARG;
-    g_voxel_path = path;
-    return D3D_OK;
-}
-
 extern "C" size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels)
 {
     if (n_points < 0) n_points = 0;
@@ -1970,10 +1955,11 @@ extern "C" size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxel
 static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels, int64_t *coords,
                                uint8_t *pmask, int32_t *npoints, float *aggregates, int64_t *counts, void *workspace,
-                               size_t workspace_bytes, void *stream, int64_t *host_counts)
+                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 3 || !shape || !bound || !counts || max_points < 0 || max_voxels < 0) return D3D_ERR_BAD_ARG;
+    if (flags & ~(uint32_t)D3D_VOXEL_FLAGS_ALL) return D3D_ERR_BAD_ARG;
     if (n > 0 && !points) return D3D_ERR_BAD_ARG;
     if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
     if (reduction < D3D_REDUCE_NONE || reduction > D3D_REDUCE_MIN) return D3D_ERR_UNSUPPORTED;  // voxelize.cpp:196
@@ -1996,7 +1982,7 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
     uint32_t nbins = 0;
     int hshift = 0;
     bool lists_ready = false;           // C != 4 on the binned index: w.big_list / w.unsorted / w.voff hold the lists
-    if (max_voxels > 0 && dense_cells_fit_u32(kf) && binned_eligible(n, w, &nbins, &hshift)) {
+    if (max_voxels > 0 && dense_cells_fit_u32(kf) && binned_eligible(n, w, flags, &nbins, &hshift)) {
         DenseOut d{P, (uint32_t)max_voxels, reduction, agg4, fuse_pmask, coords, npoints, pmask, aggregates,
                    BinnedExtras{nullptr, 0, nullptr, -1, nullptr, host_counts}, nullptr};
         if (vec4) rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
@@ -2010,7 +1996,7 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
         if (rc) return rc;
     } else {
         IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr, vec4};
-        rc = dense_index(kf, points, n, c, w, counts, o, st);
+        rc = dense_index(kf, points, n, c, w, counts, o, flags, st);
         if (rc) return rc;
         if (host_counts) D3D_LAUNCH("k_notify_host", k_notify_host, dim3(1), dim3(64), 0, st, counts, host_counts);
         if (n == 0 || max_voxels == 0) return D3D_OK;
@@ -2048,10 +2034,10 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
 extern "C" int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                      int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels,
                                      int64_t *coords, uint8_t *pmask, int32_t *npoints, float *aggregates,
-                                     int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
+                                     int64_t *counts, void *workspace, size_t workspace_bytes, void *stream, uint32_t flags)
 {
     return voxelize_dense_impl(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
-                               aggregates, counts, workspace, workspace_bytes, stream, nullptr);
+                               aggregates, counts, workspace, workspace_bytes, stream, nullptr, flags);
 }
 
 // Same, and as soon as counts[] are final -- before the HBM-bound fill of voxels[V,P,C] is launched -- they are also
@@ -2062,11 +2048,11 @@ extern "C" int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int3
                                             int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels,
                                             int64_t *coords, uint8_t *pmask, int32_t *npoints, float *aggregates,
                                             int64_t *counts, void *workspace, size_t workspace_bytes, void *stream,
-                                            int64_t *host_counts)
+                                            int64_t *host_counts, uint32_t flags)
 {
     if (!host_counts) return D3D_ERR_BAD_ARG;
     return voxelize_dense_impl(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
-                               aggregates, counts, workspace, workspace_bytes, stream, host_counts);
+                               aggregates, counts, workspace, workspace_bytes, stream, host_counts, flags);
 }
 
 // The "voxel feature grid" without the dense [V,P,C] copy: first-seen voxel ids, counts, per-voxel
@@ -2076,9 +2062,10 @@ extern "C" int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int3
 extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                       int32_t reduction, int64_t index_offset, int64_t *coords, int32_t *npoints,
                                       float *aggregates, int64_t *first, int64_t *mapping, int64_t *keys,
-                                      int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
+                                      int64_t *counts, void *workspace, size_t workspace_bytes, void *stream, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
+    if (flags & ~(uint32_t)D3D_VOXEL_FLAGS_ALL) return D3D_ERR_BAD_ARG;
     if (keys && n >= 0) D3D_HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)(n + 1) * 8, st));   // -1 = no voxel in this row
     if (n < 0 || c < 3 || !shape || !bound || !counts) return D3D_ERR_BAD_ARG;
     if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
@@ -2095,13 +2082,13 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
     uint32_t nbins = 0;
     int hshift = 0;
-    if (agg4 && dense_cells_fit_u32(kf) && binned_eligible(n, w, &nbins, &hshift)) {
+    if (agg4 && dense_cells_fit_u32(kf) && binned_eligible(n, w, flags, &nbins, &hshift)) {
         DenseOut d{P, 0xffffffffu, reduction, true, false, coords, npoints, nullptr, aggregates,
                    BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr, nullptr}, mapping};
         return binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
     }
     IndexOpts o{P, 0xffffffffu, first, index_offset, mapping, agg4};
-    rc = dense_index(kf, points, n, c, w, counts, o, st);
+    rc = dense_index(kf, points, n, c, w, counts, o, flags, st);
     if (rc) return rc;
     if (n == 0) return D3D_OK;
     if (agg4) {
@@ -2122,33 +2109,35 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
 
 static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const float *voxel_size, int64_t *points_mapping,
                                 int64_t *coords, int32_t *npoints, int64_t *counts, void *workspace, size_t workspace_bytes,
-                                int64_t ws_nvox, void *stream)
+                                int64_t ws_nvox, void *stream, uint32_t flags, bool tolerant)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 3 || !voxel_size || !counts) return D3D_ERR_BAD_ARG;
+    if (flags & ~(uint32_t)D3D_VOXEL_FLAGS_ALL) return D3D_ERR_BAD_ARG;
     if (n > 0 && (!points || !points_mapping || !coords || !npoints)) return D3D_ERR_BAD_ARG;
     if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
     VoxelWs w = carve(workspace, workspace_bytes, n, ws_nvox);   // (the arrays used here do not move with ws_nvox)
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     uint32_t nbins = 0;
     int hshift = 0;
-    if (binned_eligible(n, w, &nbins, &hshift)) {
+    if (binned_eligible(n, w, flags, &nbins, &hshift)) {
         // up to 8 M points: partition by hash(cell) and index every bucket in LDS -- the 63-bit cell key itself is the
         // table key there, so no bounding box pass and no packed-slot limits
         SparseKey kf;
         for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
+        kf.tolerant = tolerant;
         DenseOut d{0u, 0xffffffffu, D3D_REDUCE_NONE, false, false, coords, npoints, nullptr, nullptr,
                    BinnedExtras{nullptr, 0, nullptr, -1, nullptr, nullptr}, points_mapping};
         return binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st);
     }
     IndexOpts o{0u, 0xffffffffu, nullptr, 0, points_mapping, false};
-    const char *env = getenv("D3D_FORCE_PLAIN_SLOTS");
     const int ib = bits_for((u64)(n > 1 ? n - 1 : 1));
-    if (!g_force_plain && !(env && env[0] == '1') && ib <= 40) {
+    if (!(flags & D3D_VOXEL_PLAIN_SLOTS) && ib <= 40) {
         // one-word slots keyed inside the frame's bounding box; PACK_OVERFLOW (box too large for the word, or a
         // voxel with more points than the count field holds) -> the caller repeats the call with plain slots
         BoxKey kf;
         for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
+        kf.tolerant = tolerant;
         kf.prm = reinterpret_cast<BoxParams *>(w.big_count + 16);
         kf.kb_max = 56 - ib;
         TabPacked tab{w.tabA, ib, 0, reinterpret_cast<uint32_t *>(w.tabB), kf.prm};
@@ -2161,6 +2150,7 @@ static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const
     }
     SparseKey kf;
     for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
+    kf.tolerant = tolerant;
     TabPlain tab{w.tabA, w.tabB};
     int rc = build_index(kf, tab, points, n, c, w, counts, o, st);
     if (rc || n == 0) return rc;
@@ -2173,10 +2163,10 @@ static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const
 // order (descending stable argsort of voxel_npoints) for MAXVOX_DESCENDING, implemented in sort.hip
 extern "C" int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c, const float *voxel_size,
                                       int64_t *points_mapping, int64_t *coords, int32_t *npoints, int64_t *counts,
-                                      void *workspace, size_t workspace_bytes, void *stream)
+                                      void *workspace, size_t workspace_bytes, void *stream, uint32_t flags)
 {
     return voxelize_sparse_impl(points, n, c, voxel_size, points_mapping, coords, npoints, counts, workspace, workspace_bytes, 0,
-                                stream);
+                                stream, flags, false);
 }
 
 extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int32_t *order, void *ws, size_t ws_bytes,
@@ -2297,10 +2287,17 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                                              int64_t *points_mapping, int64_t *coords, int32_t *npoints, int64_t *sparse_counts,
                                              float *out_feats, int64_t *out_mask, int64_t *out_mapping, int32_t *out_npoints,
                                              int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
-                                             void *stream, int64_t *host_counts)
+                                             void *stream, int64_t *host_counts, uint32_t flags)
 {
     if (!sparse_counts || max_points < 0) return D3D_ERR_BAD_ARG;
+    if (flags & ~(uint32_t)D3D_VOXEL_FLAGS_ALL) return D3D_ERR_BAD_ARG;
     if (max_voxels_filter == D3D_MAXVOX_DESCENDING) return D3D_ERR_UNSUPPORTED;       // needs the voxel count on the host
+    // points outside the 3 x 21-bit key range (NaN / inf, |floor(p/size)| >= 2^20): the reference gives them a far-away
+    // voxel (voxelize.cpp:309) that its coordinate-bound filter drops (:376-384).  With the bounds inside the key range the
+    // same points are simply dropped here; only bounds reaching beyond it keep the COORD_OVERFLOW error.
+    bool tolerant = coords_bound != nullptr;
+    for (int k = 0; tolerant && k < 3; k++)
+        tolerant = coords_bound[2 * k] >= -1048576 && coords_bound[2 * k + 1] <= 1048576;
     {
         // Binned index + voxel filter in one numbering: a voxel that fails the filter (coordinate bounds, min_points) gets no
         // first-point entry, so the first-seen numbering IS the filtered numbering (and its max_voxels cut the TRIM voxel
@@ -2317,9 +2314,10 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
             if (w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
             uint32_t nbins = 0;
             int hshift = 0;
-            if (binned_eligible(n, w, &nbins, &hshift)) {
+            if (binned_eligible(n, w, flags, &nbins, &hshift)) {
                 SparseKey kf;
                 for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
+                kf.tolerant = tolerant;
                 const bool trim = max_points_filter == D3D_MAXPTS_TRIM;
                 const uint32_t vcap = max_voxels_filter == D3D_MAXVOX_NONE ? 0xffffffffu : (uint32_t)max_voxels;
                 DenseOut d{trim ? (uint32_t)max_points : 0u, vcap, D3D_REDUCE_NONE, false, false, out_coords, out_npoints, nullptr,
@@ -2341,7 +2339,7 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
     }
     // other filter combinations / sizes: the two operators one after the other, the voxel count staying on the device
     int rc = voxelize_sparse_impl(points, n, c, voxel_size, points_mapping, coords, npoints, sparse_counts, workspace,
-                                  workspace_bytes, n, stream);
+                                  workspace_bytes, n, stream, flags, tolerant);
     if (rc) return rc;
     return filter_impl(points, n, c, points_mapping, coords, npoints, n, sparse_counts + D3D_COUNT_VOXELS, coords_bound,
                        min_points, max_points, max_voxels, max_points_filter, max_voxels_filter, out_feats, out_mask,

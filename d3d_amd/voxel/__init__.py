@@ -100,23 +100,27 @@ def _check_status(status, what):
                          "(non-finite point or voxel size too small)" % what)
 
 
-def _with_plain_retry(lib, run):
-    """one-word hash slots first; when a field of the word overflowed (a voxel with > 2^cb points, or -- sparse contract --
-    a bounding box of voxel coordinates too large for the key field) repeat with the general two-word slots"""
+# Index options applied to every call that does not pass its own (bits: _lib.VOXEL_PATH_HASH, _lib.VOXEL_PLAIN_SLOTS).
+# A diagnostic / test hook, read when a call starts; nothing in the package writes it -- the overflow retries below pass
+# their options as per-call arguments of the C ABI, so concurrent callers (threads, streams) never see each other's.
+default_flags = 0
+
+
+def _with_retry(run, flags=None):
+    """run(flags) on the fast index first.  A bucket of the binned index that outgrew its workgroup's table -> once more on
+    the hash table; a field of the packed one-word hash slot that overflowed (a voxel with > 2^cb points, or -- sparse
+    contract -- a bounding box of voxel coordinates too large for the key field) -> once more with two-word slots."""
+    flags = default_flags if flags is None else int(flags)
     try:
-        return run()
+        return run(flags)
     except _BinOverflow:
-        lib.d3d_voxel_set_path(1)
-        try:
-            return _with_plain_retry(lib, run)
-        finally:
-            lib.d3d_voxel_set_path(0)
+        flags |= _lib.VOXEL_PATH_HASH
     except _PackOverflow:
-        lib.d3d_voxel_force_plain(1)
-        try:
-            return run()
-        finally:
-            lib.d3d_voxel_force_plain(0)
+        return run(flags | _lib.VOXEL_PLAIN_SLOTS)
+    try:
+        return run(flags)
+    except _PackOverflow:
+        return run(flags | _lib.VOXEL_PLAIN_SLOTS)
 
 
 _ws_bytes_cache = {}
@@ -129,7 +133,7 @@ def _workspace_bytes(lib, n):
     return b
 
 
-def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type):
+def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type, flags=None):
     """voxelize_3d_dense of the reference (voxelize.h:9-12; voxelize.cpp:45-199).
 
     Returns dict(voxels[V,P,C] f32, coords[V,3] i64, voxel_pmask[V,P] bool,
@@ -155,21 +159,21 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
         ws = _lib.workspace(_workspace_bytes(lib, n), dev)
         note = _lib.NotifyBuffer.get()
 
-        def run():
+        def run(fl):
             # the voxel count reaches the host through pinned memory as soon as it is final, while the GPU is still
             # writing voxels[V,P,C]: the call returns views of outputs in flight on the current stream, like any torch op
             note.arm()
             rc = lib.d3d_voxelize_3d_dense_notify(
                 _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
                 max_points, max_voxels, red, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts),
-                _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr)
+                _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr, fl)
             if rc == _lib.ERR_UNSUPPORTED:
                 raise ValueError("Unsupported reduction type in voxelization!")   # voxelize.cpp:196
             _lib.check(rc, "voxelize_3d_dense")
             host = note.wait(counts)
             _check_status(int(host[_lib.COUNT_STATUS]), "voxelize_3d_dense")
             return int(host[_lib.COUNT_VOXELS])
-        nv = _with_plain_retry(lib, run)
+        nv = _with_retry(run, flags)
     ret = dict(voxels=voxels[:nv], coords=coords[:nv], voxel_pmask=pmask[:nv].view(torch.bool),
                voxel_npoints=npts[:nv])
     if red != 0:
@@ -179,7 +183,7 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
     return ret
 
 
-def voxelize_3d_sparse(points, voxel_size, ndim=3):
+def voxelize_3d_sparse(points, voxel_size, ndim=3, flags=None):
     """voxelize_sparse of the reference, exported as voxelize_3d_sparse
     (voxelize.h:14-17; voxelize.cpp:288-335; impl.cpp:5)."""
     lib = _lib.load()
@@ -197,13 +201,13 @@ def voxelize_3d_sparse(points, voxel_size, ndim=3):
         counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
         ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
 
-        def run():
+        def run(fl):
             rc = lib.d3d_voxelize_3d_sparse(_lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), _lib.ptr(mapping),
                                             _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
-                                            _lib.stream_ptr())
+                                            _lib.stream_ptr(), fl)
             _lib.check(rc, "voxelize_3d_sparse")
             return int(_counts_to_host(counts, "voxelize_3d_sparse")[_lib.COUNT_VOXELS])
-        nv = _with_plain_retry(lib, run)
+        nv = _with_retry(run, flags)
     ret = dict(points_mapping=mapping, coords=coords[:nv], voxel_npoints=npts[:nv])
     if odev != dev:
         ret = {k: v.to(odev) for k, v in ret.items()}
@@ -263,7 +267,7 @@ def voxelize_3d_filter(feats, points_mapping, coords, voxel_npoints, coords_boun
     return ret
 
 
-def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_voxels, pf, vf):
+def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_voxels, pf, vf, flags=None):
     """voxelize_3d_sparse followed by voxelize_3d_filter as VoxelGenerator.__call__ chains them
     (voxel/__init__.py:93-102), with ONE host read-back: the filter reads the voxel count on the device."""
     lib = _lib.load()
@@ -292,19 +296,19 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
 
         note = _lib.NotifyBuffer.get()
 
-        def run():
+        def run(fl):
             note.arm()
             rc = lib.d3d_voxelize_3d_sparse_filter(
                 _lib.ptr(pts), n, c, ctypes.cast(size_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
                 int(min_points or 0), int(max_points or 0), int(max_voxels or 0), pf, vf,
                 _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts[0]),
                 _lib.ptr(o_feats), _lib.ptr(o_mask), _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd),
-                _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr)
+                _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr, fl)
             _lib.check(rc, "voxelize_3d_sparse + voxelize_3d_filter")
             host = note.wait(counts)      # the one host read of the pair, while the kept points are still being compacted
             _check_status(int(host[_lib.COUNT_STATUS]), "voxelize_3d_sparse")
             return int(host[_lib.NUM_COUNTS + _lib.COUNT_POINTS]), int(host[_lib.NUM_COUNTS + _lib.COUNT_VOXELS])
-        k, v = _with_plain_retry(lib, run)
+        k, v = _with_retry(run, flags)
     ret = dict(points=o_feats[:k], points_mask=o_mask[:k], points_mapping=o_map[:k],
                voxel_npoints=o_cnt[:v], coords=o_crd[:v])
     if odev != dev:

@@ -70,6 +70,21 @@ class TorchComm:
         return t
 
 
+class LocalComm:
+    """world of one rank: the sharded operator without torch.distributed (single-GPU feature grid; bench.py's
+    same-operator base of the weak-scaling curve)"""
+    rank, world = 0, 1
+
+    def all_gather_int(self, value, device):
+        return [int(value)]
+
+    def all_gather_var(self, t, sizes):
+        return t
+
+    def all_reduce(self, t, op):
+        return t
+
+
 class HipOps:
     """the compute steps, on the HIP kernels of libd3d_hip.so (no host synchronisation except where noted)"""
 
@@ -92,18 +107,14 @@ class HipOps:
             keys = torch.empty((n + 1,), dtype=torch.int64, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
             ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
-            if plain:                               # the retry after a status overflow: general slots ...
-                lib.d3d_voxel_force_plain(1)
-                lib.d3d_voxel_set_path(1)           # ... in the hash table (no bucket capacity to outgrow)
-            try:
-                rc = lib.d3d_voxelize_3d_reduce(
-                    _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
-                    int(reduction), int(index_offset), _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first),
-                    _lib.ptr(mapping), _lib.ptr(keys), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
-            finally:
-                if plain:
-                    lib.d3d_voxel_force_plain(0)
-                    lib.d3d_voxel_set_path(0)
+            from . import default_flags
+            flags = default_flags
+            if plain:      # the retry after a status overflow: general slots in the hash table (no bucket capacity to outgrow)
+                flags |= _lib.VOXEL_PATH_HASH | _lib.VOXEL_PLAIN_SLOTS
+            rc = lib.d3d_voxelize_3d_reduce(
+                _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
+                int(reduction), int(index_offset), _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first),
+                _lib.ptr(mapping), _lib.ptr(keys), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), flags)
             _lib.check(rc, "voxelize_3d_reduce")
         return coords, cnt, agg, first, mapping, keys, counts
 
@@ -298,18 +309,17 @@ class ShardedVoxelGenerator:
         self._ncells = self._shape[0] * self._shape[1] * self._shape[2]
         self._comm = comm if comm is not None else TorchComm(group)
         self._ops = ops if ops is not None else HipOps()
-        self._layout_key, self._layout_val = None, None
         if exchange not in ("auto", "keys", "bitmap"):
             raise ValueError("exchange must be auto, keys or bitmap")
         self._exchange = exchange        # what the ranks all-gather to agree on the occupied cells
+        self.last_stats = None
 
     def _layout(self, n, dev):
-        """shard sizes over the ranks; exchanged once per local shard size (one collective + host read)"""
-        if self._layout_key != n:
-            sizes = self._comm.all_gather_int(n, dev)
-            self._layout_key = n
-            self._layout_val = (sum(sizes[:self._comm.rank]), sum(sizes), max(max(sizes), 1))
-        return self._layout_val
+        """shard sizes over the ranks -> (offset of this rank's first point, total points, largest shard).  Exchanged on
+        EVERY call (one 8-byte all-gather + host read): whether a rank's own size changed says nothing about the other
+        ranks', and a collective that only some ranks enter desynchronises the whole sequence."""
+        sizes = self._comm.all_gather_int(n, dev)
+        return sum(sizes[:self._comm.rank]), sum(sizes), max(max(sizes), 1)
 
     def __call__(self, points):
         for plain in (False, True):
@@ -331,6 +341,7 @@ class ShardedVoxelGenerator:
         nw = (self._ncells + 63) // 64
         # auto: bitmaps when the grid's bitmap is not larger than a key list (KITTI-size grids), else key lists
         bitmap_mode = self._exchange == "bitmap" or (self._exchange == "auto" and nw <= cap + 1)
+        owned = False
         if bitmap_mode:
             # 2b. all-gather the ranks' occupancy bitmaps (+ status word); 3b. OR them: a streaming pass instead of
             #     one atomic per gathered key, and the keys of the slots fall out of the merged bitmap
@@ -350,6 +361,13 @@ class ShardedVoxelGenerator:
             raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
         if status & (_lib.STATUS_PACK_OVERFLOW | _lib.STATUS_BIN_OVERFLOW) and not plain:
             return None        # some rank hit a capacity limit of the fast index (rare): all ranks redo on the general path
+        # what this call moves between the ranks (bytes each rank contributes / receives; bench.py reports them)
+        tcols = (c + 2 if bitmap_mode and owned else c + 1) if mean else (c + 1 if bitmap_mode and owned else c)
+        self.last_stats = dict(
+            exchange="bitmap" if bitmap_mode else "keys", numbering="ownership" if bitmap_mode and owned else "first-index",
+            voxels=nvox, ranks=comm.world,
+            all_gather_bytes_per_rank=8 * ((nw + 1) if bitmap_mode else (cap + 1)),
+            all_reduce_bytes=nvox * (4 * tcols + (0 if mean else 4) + (0 if bitmap_mode and owned else 8)))
         # 4. all-reduce the compact voxel table
         if bitmap_mode and owned:
             # numbering by ownership: the lowest rank that has a cell holds its first point, so the voxel ids follow from
@@ -382,4 +400,4 @@ class ShardedVoxelGenerator:
         return Dict(coords=coords, voxel_npoints=out_cnt, aggregates=out_feats, points_mapping=gmap)
 
 
-__all__ = ["ShardedVoxelGenerator", "TorchComm", "HipOps", "voxelize_reduce"]
+__all__ = ["ShardedVoxelGenerator", "TorchComm", "LocalComm", "HipOps", "voxelize_reduce"]

@@ -52,11 +52,10 @@ enum { D3D_VOXEL_STATUS_COORD_OVERFLOW = 1,   /* sparse: |floor(p/size)| >= 2^20
                                                  with the documented workspace size)           */
        D3D_VOXEL_STATUS_PACK_OVERFLOW = 4,    /* a voxel holds more points than the packed one-word
                                                  hash slot can count: results are invalid; repeat the
-                                                 call after d3d_voxel_force_plain(1)             */
-       D3D_VOXEL_STATUS_BIN_OVERFLOW = 8 };   /* dense, binned index: a bucket of the partition got more
-                                                 points than one workgroup holds (a few cells with
-                                                 thousands of points each): results are invalid; repeat
-                                                 the call after d3d_voxel_set_path(1)            */
+                                                 call with D3D_VOXEL_PLAIN_SLOTS                 */
+       D3D_VOXEL_STATUS_BIN_OVERFLOW = 8 };   /* binned index: a bucket of the partition holds more distinct
+                                                 cells than its LDS table (or > 2 M points): results are
+                                                 invalid; repeat the call with D3D_VOXEL_PATH_HASH */
 enum { D3D_COUNT_VOXELS = 0, D3D_COUNT_POINTS = 1, D3D_COUNT_STATUS = 2, D3D_COUNT_AUX = 3, D3D_NUM_COUNTS = 4 };
 
 int         d3d_abi_version(void);
@@ -65,14 +64,15 @@ const char *d3d_status_string(int status);
 
 /* ------------------------------------------------------------------ d3d/voxel */
 
-/* 1 = always use the general two-word hash slots (any count / key width); 0 = automatic (default):
- * one-word slots {count | key | first index} whenever they fit 64 bits (one atomic per point). */
-int d3d_voxel_force_plain(int on);
-
-/* index path of d3d_voxelize_3d_dense for C == 4 rows: 0 = automatic (default: binned up to 8 M points),
- * 1 = hash table in HBM (any input), 2 = binned (points partitioned into buckets, per-bucket index in LDS) whenever the
- * grid has < 2^32 - 1 cells.  Both give identical outputs; see DESIGN.md section 4. */
-int d3d_voxel_set_path(int path);
+/* Per-call options of the voxel entry points that build an index (`flags`, last argument; 0 = automatic).  They are
+ * arguments, not library state: two threads / streams may use different ones at the same time, and the retry a caller
+ * issues after a PACK_ / BIN_OVERFLOW status touches nothing shared.
+ *   D3D_VOXEL_PATH_HASH    hash table in HBM (any input) instead of the default binned index (points partitioned into
+ *                          buckets, per-bucket index in LDS; up to 8 M points, grids below 2^32 - 1 cells).  Both give
+ *                          identical outputs; see DESIGN.md section 4.
+ *   D3D_VOXEL_PLAIN_SLOTS  (hash table) general two-word slots, any count / key width, instead of the default one-word
+ *                          slots {count | key | first index} that are used whenever they fit 64 bits. */
+enum { D3D_VOXEL_PATH_HASH = 1, D3D_VOXEL_PLAIN_SLOTS = 4, D3D_VOXEL_FLAGS_ALL = 5 };
 
 /* scratch for any of the three voxel entry points on n points / nvox voxels */
 size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels);
@@ -89,7 +89,7 @@ int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c,
                           int32_t max_points, int32_t max_voxels, int32_t reduction,
                           float *voxels, int64_t *coords, uint8_t *pmask, int32_t *npoints,
                           float *aggregates, int64_t *counts,
-                          void *workspace, size_t workspace_bytes, void *stream);
+                          void *workspace, size_t workspace_bytes, void *stream, uint32_t flags);
 
 /* d3d_voxelize_3d_dense that also publishes counts[] to the host as soon as they are final, i.e. BEFORE the
  * HBM-bound fill of voxels[V,P,C] is launched: host_counts[0 .. D3D_NUM_COUNTS) = counts, then
@@ -102,7 +102,7 @@ int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int32_t c,
                           int32_t max_points, int32_t max_voxels, int32_t reduction,
                           float *voxels, int64_t *coords, uint8_t *pmask, int32_t *npoints,
                           float *aggregates, int64_t *counts,
-                          void *workspace, size_t workspace_bytes, void *stream, int64_t *host_counts);
+                          void *workspace, size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags);
 
 /* replaces voxelize_sparse, bound in Python as voxelize_3d_sparse
  * (reference voxelize.h:14-17, voxelize.cpp:288-335, impl.cpp:5).
@@ -110,7 +110,7 @@ int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int32_t c,
  *   points_mapping[n] i64, coords[n,3] i64 (first counts[0] rows valid), npoints[n] i32. */
 int d3d_voxelize_3d_sparse(const float *points, int64_t n, int32_t c, const float *voxel_size,
                            int64_t *points_mapping, int64_t *coords, int32_t *npoints,
-                           int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+                           int64_t *counts, void *workspace, size_t workspace_bytes, void *stream, uint32_t flags);
 
 /* replaces voxelize_filter, bound as voxelize_3d_filter
  * (reference voxelize.h:19-25, voxelize.cpp:337-484).
@@ -148,6 +148,9 @@ int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int32_t c, con
  * lets the TRIM point filter reuse the per-voxel index ranking the sparse index already holds (voxelize.cpp:457-463)
  * and the voxel filter run inside the index (up to 8 M points, filters NONE / TRIM): points_mapping, coords and npoints
  * are then scratch (not materialised), sparse_counts holds the status bits.
+ * Points outside the 3 x 21-bit key range (non-finite, |floor(p/size)| >= 2^20) are DROPPED here, as the reference's
+ * coordinate-bound filter drops the far-away voxel it gives them (voxelize.cpp:309, :376-384), as long as coords_bound
+ * lies inside [-2^20, 2^20]; d3d_voxelize_3d_sparse alone raises D3D_VOXEL_STATUS_COORD_OVERFLOW for them.
  * Workspace: d3d_voxelize_workspace_bytes(n, n).  host_counts: NULL, or 2 * D3D_NUM_COUNTS + 1 int64 of host-mapped
  * pinned memory with word [D3D_NUM_COUNTS] cleared: receives sparse_counts in [0, 4), counts in [5, 9) and then the flag
  * [4] = 1 before the last kernel (the compaction of the kept points) is launched -- see d3d_voxelize_3d_dense_notify. */
@@ -157,7 +160,7 @@ int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int32_t c, con
                                   int64_t *points_mapping, int64_t *coords, int32_t *npoints, int64_t *sparse_counts,
                                   float *out_feats, int64_t *out_mask, int64_t *out_mapping, int32_t *out_npoints,
                                   int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
-                                  void *stream, int64_t *host_counts);
+                                  void *stream, int64_t *host_counts, uint32_t flags);
 
 /* ---- beyond the reference: the point-sharded voxelizer of north_star (d3d has no distributed code) ---- */
 
@@ -171,7 +174,7 @@ int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int32_t c, con
 int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                            int32_t reduction, int64_t index_offset, int64_t *coords, int32_t *npoints,
                            float *aggregates, int64_t *first, int64_t *mapping, int64_t *keys, int64_t *counts,
-                           void *workspace, size_t workspace_bytes, void *stream);
+                           void *workspace, size_t workspace_bytes, void *stream, uint32_t flags);
 
 /* Rank-independent compact numbering of occupied cells: mark keys[m] (linear cell index in [0,ncells)) in a
  * bitmap, popcount-prefix it; counts[0] = distinct occupied cells.  lookup: slot[j] = index of keys[j] among the
@@ -255,6 +258,10 @@ int d3d_aligned_scatter_backward(const void *coord, int64_t n, int32_t dim, cons
 int d3d_profile_enable(int on);
 int d3d_profile_report(char *buf, size_t buf_bytes);
 
+/* stream-bandwidth probe on the caller's buffer (bench.py: "fraction of the measured copy bandwidth of the same box",
+ * SURVEY 8d).  mode 0 = nontemporal 16-byte stores over `bytes`, 1 = copy first half -> second half, 2 = read sweep. */
+int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream);
+
 /* -------------------------------------------------------------------- d3d/box */
 
 /* replaces iou2d_forward[_cuda] (method BOX) and the `ious` output of
@@ -265,7 +272,10 @@ int d3d_profile_report(char *buf, size_t buf_bytes);
 size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype);
 int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t m,
                       int32_t iou_type, int32_t dtype, void *ious,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      void *workspace, size_t workspace_bytes, void *stream, uint32_t flags);
+/* flags of d3d_iou2d_forward: 0, or D3D_IOU_LIST_CAP(k) = use only k entries of the candidate list (tests of the
+ * overflow -> single-kernel fallback) */
+#define D3D_IOU_LIST_CAP(k) ((uint32_t)(k) << 8)
 
 /* replaces iou2d_backward[_cuda] (BOX) and iou2dr_backward[_cuda] (RBOX) ("next" row; reference iou.h:14-24,32-40,
  * iou.cpp:48-93,143-211): grad[n,m] -> grad_boxes1[n,5], grad_boxes2[m,5] (overwritten), all in `dtype`.  The
@@ -302,11 +312,17 @@ size_t d3d_nms2d_workspace_bytes(int64_t n);
  *   HARD: parallel (broad phase + exact IoU + fixed point, see box.hip).  LINEAR / GAUSSIAN (soft-NMS, nms.cpp:60-94)
  *   are sequential by construction -- every kept box rescales the later boxes it overlaps and the order is re-established
  *   after each -- and run in one workgroup that follows the reference's control flow (n <= 65536, else UNSUPPORTED).
- *   Other IoU types return D3D_ERR_UNSUPPORTED ("Unsupported iou type!", reference common.h:25). */
+ *   Other IoU types return D3D_ERR_UNSUPPORTED ("Unsupported iou type!", reference common.h:25).
+ *   flags (per call, 0 = automatic): D3D_NMS_BROAD_SWEEP = sweep-and-prune broad phase instead of the uniform grid;
+ *   D3D_NMS_FORCE_DENSE = the reference's all-pairs bit matrix (nms_cuda.cu layout) instead of candidate lists;
+ *   D3D_NMS_SOFT_NO_LDS = soft-NMS state in global scratch; D3D_NMS_CAND_CAP(k) = use only k entries of the candidate
+ *   list (tests of the overflow -> dense hand-over).  All give the same mask. */
+enum { D3D_NMS_BROAD_SWEEP = 1, D3D_NMS_FORCE_DENSE = 2, D3D_NMS_SOFT_NO_LDS = 4 };
+#define D3D_NMS_CAND_CAP(k) ((uint32_t)(k) << 8)
 int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n,
               int32_t iou_type, int32_t suppression_type, int32_t dtype,
               float iou_threshold, float score_threshold, float suppression_param,
-              uint8_t *suppressed, void *workspace, size_t workspace_bytes, void *stream);
+              uint8_t *suppressed, void *workspace, size_t workspace_bytes, void *stream, uint32_t flags);
 
 #ifdef __cplusplus
 }

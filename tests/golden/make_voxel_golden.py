@@ -155,6 +155,13 @@ def main():
     sparse_case("sp_c8_minpts", np.ascontiguousarray(c8), unit, [12, 12, 12], min_points=3, max_points=7,
                 max_points_filter="trim", max_voxels=400, max_voxels_filter="trim")
 
+    # non-finite and far-out-of-range points in the default (sparse) mode: the reference's (int)floor(NaN) lands in an
+    # INT_MIN voxel (voxelize.cpp:309) that the coordinate-bound filter drops (:376-384) -- the frame still works
+    c5 = c3.copy()
+    c5[3, 0], c5[7, 1], c5[9, 2], c5[12, :3], c5[20, 1], c5[31, 0] = np.nan, np.inf, -np.inf, np.nan, -2.5e5, 3e6
+    sparse_case("sp_nonfinite", c5, [-1, 1, -1, 1, -1, 1], [20, 20, 20], max_points=4, max_points_filter="trim")
+    sparse_case("sp_nonfinite_none", c5, unit, [10, 10, 10], min_points=1)
+
     # raw-function cases (boundary functions called directly, voxelize.h:9-25)
     sp = to_np(impl.voxelize_3d_sparse(torch.from_numpy(kc), torch.tensor([0.1, 0.1, 0.1]), 3))
     cases["raw_sparse"] = dict(kind="raw_sparse", cloud=kc, size=np.array([0.1, 0.1, 0.1], np.float32), out=sp)

@@ -18,11 +18,9 @@ def pytest_generate_tests(metafunc):
 
 @pytest.fixture(autouse=True)
 def nms_broad(request, monkeypatch):
+    from d3d_amd import _lib, box
     mode = getattr(request, "param", "grid")
-    if mode == "sweep":
-        monkeypatch.setenv("D3D_NMS_BROAD", "sweep")
-    else:
-        monkeypatch.delenv("D3D_NMS_BROAD", raising=False)
+    monkeypatch.setattr(box, "default_nms_flags", _lib.NMS_BROAD_SWEEP if mode == "sweep" else 0)
     yield mode
 
 
@@ -157,7 +155,7 @@ def test_nms_vs_oracle_bit_exact(method, gen, n, thr):
         assert np.array_equal(keep, exp), (np.sum(keep != exp), n)
 
 
-@pytest.mark.parametrize("hook,value", [("D3D_NMS_FORCE_DENSE", "1"), ("D3D_NMS_CAND_CAP", "100"), ("D3D_NMS_CAND_CAP", "3000")])
+@pytest.mark.parametrize("hook,value", [("force_dense", 1), ("cand_cap", 100), ("cand_cap", 3000)])
 @pytest.mark.parametrize("gen,n,thr", [("sparse", 5000, 0.3), ("dense", 1500, 0.3)])
 def test_nms_dense_path_hooks(monkeypatch, hook, value, gen, n, thr):
     """the gated dense path (bit matrix + single-workgroup sweep) gives the same keep set as the list path: forced,
@@ -167,10 +165,12 @@ def test_nms_dense_path_hooks(monkeypatch, hook, value, gen, n, thr):
     mk = synth.boxes2d_sparse if gen == "sparse" else synth.boxes2d_dense
     b, s = mk(n, 77)
     exp = oracle.box2d_nms(b, s, iou_method="rbox", iou_threshold=thr, score_threshold=0.1)
-    monkeypatch.setenv(hook, value)
+    from d3d_amd import _lib, box
+    base = box.default_nms_flags
+    monkeypatch.setattr(box, "default_nms_flags", base | (_lib.NMS_FORCE_DENSE if hook == "force_dense" else _lib.nms_cand_cap(value)))
     keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=thr, score_threshold=0.1).cpu().numpy()
     assert np.array_equal(keep, exp)
-    monkeypatch.delenv(hook)
+    monkeypatch.setattr(box, "default_nms_flags", base)
     keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=thr, score_threshold=0.1).cpu().numpy()
     assert np.array_equal(keep, exp)
 
@@ -209,7 +209,8 @@ def test_nms_list_path_equals_dense_path_at_scale(monkeypatch):
     from d3d_amd.box import box2d_nms
     b, s = synth.boxes2d_sparse(30000, 5)
     keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3).cpu().numpy()
-    monkeypatch.setenv("D3D_NMS_FORCE_DENSE", "1")
+    from d3d_amd import _lib, box
+    monkeypatch.setattr(box, "default_nms_flags", box.default_nms_flags | _lib.NMS_FORCE_DENSE)
     dense = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3).cpu().numpy()
     assert np.array_equal(keep, dense) and 0 < keep.sum() < len(keep)
 
@@ -306,10 +307,11 @@ def test_iou_candidate_list_overflow_falls_back(monkeypatch):
     b1, _ = synth.boxes2d_dense(300, 51)
     b2, _ = synth.boxes2d_dense(200, 52)
     exp = oracle.box2d_iou(b1, b2, "rbox", nthreads=4)
-    monkeypatch.setenv("D3D_IOU_LIST_CAP", "64")
+    from d3d_amd import _lib, box
+    monkeypatch.setattr(box, "default_iou_flags", _lib.iou_list_cap(64))
     got = box2d_iou(T(b1), T(b2), method="rbox").cpu().numpy()
     assert np.max(np.abs(got - exp)) < 1e-9
-    monkeypatch.delenv("D3D_IOU_LIST_CAP")
+    monkeypatch.setattr(box, "default_iou_flags", 0)
     got = box2d_iou(T(b1), T(b2), method="rbox").cpu().numpy()
     assert np.max(np.abs(got - exp)) < 1e-9
 
@@ -403,9 +405,10 @@ def test_softnms_vs_oracle(method, sup, param, monkeypatch):
             keep = box2d_nms(T(b), T(s), **kw).cpu().numpy()
             assert np.array_equal(keep, exp), (n, sthr, int(np.sum(keep != exp)))
             if n == 300:
-                monkeypatch.setenv("D3D_SOFTNMS_NO_LDS", "1")
+                from d3d_amd import box
+                monkeypatch.setattr(box, "default_nms_flags", box.default_nms_flags | _lib.NMS_SOFT_NO_LDS)
                 keep = box2d_nms(T(b), T(s), **kw).cpu().numpy()
-                monkeypatch.delenv("D3D_SOFTNMS_NO_LDS")
+                monkeypatch.setattr(box, "default_nms_flags", box.default_nms_flags & ~_lib.NMS_SOFT_NO_LDS)
                 assert np.array_equal(keep, exp)
 
 
@@ -465,16 +468,18 @@ def test_c_abi_error_codes():
     order = torch.arange(4, dtype=torch.int64, device="cuda")
     ws = torch.zeros((1 << 20,), dtype=torch.uint8, device="cuda")
     p = _lib.ptr
-    assert lib.d3d_iou2d_forward(z, 4, p(b), 4, 2, _lib.F64, p(out), z, 0, z) == _lib.ERR_BAD_ARG               # null boxes
-    assert lib.d3d_iou2d_forward(p(b), -1, p(b), 4, 2, _lib.F64, p(out), z, 0, z) == _lib.ERR_BAD_ARG          # negative size
-    assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 4, _lib.F64, p(out), z, 0, z) == _lib.ERR_UNSUPPORTED       # GRBOX
-    assert lib.d3d_iou2d_forward(p(b), 0, p(b), 4, 2, _lib.F64, z, z, 0, z) == 0                                # empty: ok
+    assert lib.d3d_iou2d_forward(z, 4, p(b), 4, 2, _lib.F64, p(out), z, 0, z, 0) == _lib.ERR_BAD_ARG            # null boxes
+    assert lib.d3d_iou2d_forward(p(b), -1, p(b), 4, 2, _lib.F64, p(out), z, 0, z, 0) == _lib.ERR_BAD_ARG       # negative size
+    assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 4, _lib.F64, p(out), z, 0, z, 0) == _lib.ERR_UNSUPPORTED    # GRBOX
+    assert lib.d3d_iou2d_forward(p(b), 0, p(b), 4, 2, _lib.F64, z, z, 0, z, 0) == 0                             # empty: ok
     assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 3, 0, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), ws.numel(),
-                         z) == _lib.ERR_UNSUPPORTED                                                             # GBOX in NMS
+                         z, 0) == _lib.ERR_UNSUPPORTED                                                          # GBOX in NMS
     assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 2, 7, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), ws.numel(),
-                         z) == _lib.ERR_UNSUPPORTED                                                             # suppression enum
+                         z, 0) == _lib.ERR_UNSUPPORTED                                                          # suppression enum
     assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 2, 0, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), 16,
-                         z) == _lib.ERR_WORKSPACE                                                               # workspace too small
+                         z, 0) == _lib.ERR_WORKSPACE                                                            # workspace too small
+    assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 2, 0, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), ws.numel(),
+                         z, 0x80) == _lib.ERR_BAD_ARG                                                           # unknown option bit
     assert lib.d3d_status_string(_lib.ERR_WORKSPACE) == b"workspace too small"
     torch.cuda.synchronize()
 

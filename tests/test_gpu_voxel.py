@@ -15,11 +15,12 @@ pytestmark = pytest.mark.gpu
 def index_path(request):
     """every test of this module runs on both index paths of the voxelizer: automatic (binned whenever eligible) and
     the hash table (tests that pick a path themselves -- `voxel_path` -- override this)"""
-    from d3d_amd import _lib
-    lib = _lib.load()
-    lib.d3d_voxel_set_path(1 if request.param == "hash" else 0)
+    from d3d_amd import _lib, voxel
+    voxel.default_flags = _lib.VOXEL_PATH_HASH if request.param == "hash" else 0
     yield request.param
-    lib.d3d_voxel_set_path(0)
+    voxel.default_flags = 0
+
+
 CASES = load_voxel_cases()
 
 
@@ -161,8 +162,14 @@ def test_all_points_in_one_voxel_and_errors():
         VoxelGenerator(unit, [10, 10, 10], max_points_filter="bogus")
     with pytest.raises(NotImplementedError):
         VoxelGenerator(unit, [10, 10, 10], min_points=1, dense=True)
-    with pytest.raises(ValueError):   # NaN point in the unbounded sparse contract
-        VoxelGenerator(unit, [10, 10, 10])(torch.tensor([[float("nan"), 0, 0, 0]]).cuda())
+    # a non-finite point: the raw sparse function reports it (its key cannot be built), VoxelGenerator -- sparse + filter --
+    # drops it like the reference's coordinate-bound filter drops the INT_MIN voxel it lands in (goldens sp_nonfinite*)
+    from d3d_amd.voxel import voxelize_3d_sparse
+    bad = torch.tensor([[float("nan"), 0, 0, 0], [0.5, 0.5, 0.5, 1]]).cuda()
+    with pytest.raises(ValueError):
+        voxelize_3d_sparse(bad, [0.1, 0.1, 0.1])
+    ret = VoxelGenerator(unit, [10, 10, 10])(bad)
+    assert ret.points_mask.tolist() == [1] and ret.coords.tolist() == [[5, 5, 5]] and ret.points_mapping.tolist() == [0]
 
 
 def test_full_size_cfg2_properties():
@@ -195,9 +202,9 @@ def test_full_size_cfg2_properties():
 
 def test_plain_slot_layout_matches(monkeypatch):
     """the general (unpacked) hash-slot layout used for n >= 2^24 points gives the same results"""
-    from d3d_amd import synth
+    from d3d_amd import _lib, synth, voxel
     from d3d_amd.voxel import VoxelGenerator
-    monkeypatch.setenv("D3D_FORCE_PLAIN_SLOTS", "1")
+    monkeypatch.setattr(voxel, "default_flags", voxel.default_flags | _lib.VOXEL_PLAIN_SLOTS)
     cloud = synth.lidar_like(60000, 17)
     kw = dict(reduction="mean", max_points=6, max_voxels=30000, dense=True)
     exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(cloud)
@@ -323,10 +330,13 @@ def test_results_are_reproducible_run_to_run():
 # ---------------------------------------------------------------- dense contract: binned index path
 @pytest.fixture
 def voxel_path():
-    from d3d_amd import _lib
-    lib = _lib.load()
-    yield lib.d3d_voxel_set_path
-    lib.d3d_voxel_set_path(0)
+    """setter: 1 = hash table, 0 / 2 = binned index wherever eligible (the default)"""
+    from d3d_amd import _lib, voxel
+
+    def set_path(path):
+        voxel.default_flags = _lib.VOXEL_PATH_HASH if path == 1 else 0
+    yield set_path
+    voxel.default_flags = 0
 
 
 @pytest.mark.parametrize("n,P,mv,reduction", [(1, 4, 10, "mean"), (7, 1, 7, "max"), (300, 3, 100, "min"), (5000, 32, 5000, "mean"),
@@ -380,10 +390,10 @@ def _dense_call(lib, pts, shape3, P, red, path_setter, path):
     agg = torch.empty((n, 4), device="cuda")
     counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device="cuda")
     ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), pts.device)
-    path_setter(path)
     rc = lib.d3d_voxelize_3d_dense(_lib.ptr(pts), n, 4, ctypes.cast(shape, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p),
                                    P, n, red, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts), _lib.ptr(agg),
-                                   _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                                   _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(),
+                                   _lib.VOXEL_PATH_HASH if path == 1 else 0)
     assert rc == 0
     host = counts.cpu()
     return int(host[_lib.COUNT_STATUS]), int(host[_lib.COUNT_VOXELS])
@@ -469,17 +479,18 @@ def test_dense_notify_publishes_the_counts_to_pinned_host_memory(voxel_path, n, 
         args = [_lib.ptr(pts), n, 4, ctypes.cast(shape, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p), P, cap, 1,
                 _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts), _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws),
                 ws.numel(), _lib.stream_ptr()]
-        voxel_path(path)
+        fl = _lib.VOXEL_PATH_HASH if path == 1 else 0
         if notify:
             note = _lib.NotifyBuffer.get()
             note.arm()
-            assert lib.d3d_voxelize_3d_dense_notify(*args, note.ptr) == 0
+            assert lib.d3d_voxelize_3d_dense_notify(*args, note.ptr, fl) == 0
             host = note.wait(counts, spin_s=5.0)
             assert note.arr[_lib.NUM_COUNTS] == 1                       # the flag itself, not the fallback read
             assert host == counts.cpu().tolist()
-            assert lib.d3d_voxelize_3d_dense_notify(*args, None) != 0   # the buffer is mandatory here
+            assert lib.d3d_voxelize_3d_dense_notify(*args, None, fl) != 0   # the buffer is mandatory here
+            assert lib.d3d_voxelize_3d_dense_notify(*args, note.ptr, 0x100) == _lib.ERR_BAD_ARG   # unknown option bit
         else:
-            assert lib.d3d_voxelize_3d_dense(*args) == 0
+            assert lib.d3d_voxelize_3d_dense(*args, fl) == 0
         nv = int(counts.cpu()[_lib.COUNT_VOXELS])
         outs.append((nv, voxels[:nv].cpu(), coords[:nv].cpu(), pmask[:nv].cpu(), npts[:nv].cpu(), agg[:nv].cpu()))
     assert outs[0][0] == outs[1][0] and (n == 0) == (outs[0][0] == 0)
@@ -559,7 +570,7 @@ def test_fused_sparse_filter_entry_error_codes():
         return lib.d3d_voxelize_3d_sparse_filter(
             _lib.ptr(pts), n, 4, ctypes.cast(size, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p), 0, 8, 100, 1, vf,
             _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), sparse_counts, _lib.ptr(o_feats), _lib.ptr(o_mask),
-            _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd), _lib.ptr(counts[1]), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(), None)
+            _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd), _lib.ptr(counts[1]), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(), None, 0)
     assert call(2, _lib.ptr(counts[0]), ws.numel()) == _lib.ERR_UNSUPPORTED          # DESCENDING
     assert call(1, None, ws.numel()) == _lib.ERR_BAD_ARG
     assert call(1, _lib.ptr(counts[0]), 1024) == _lib.ERR_WORKSPACE

@@ -68,6 +68,13 @@ def _gloo_worker(rank, world, port, reduction, exchange, q):
         gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, ops=NumpyOps(), exchange=exchange)
         res = gen(torch.from_numpy(cloud[sl]))
         _check(res, cloud, sl, reduction)
+        # next frame through the SAME generator: only the last rank's shard size changes (rank 0 keeps its 1100 points).
+        # Every rank must still enter the same sequence of collectives and see the new offsets / totals.
+        cloud2 = _cloud(2600, 6)
+        cuts2 = [0, 1100, 2600] if world == 2 else cuts[:-1] + [2600]
+        sl2 = slice(cuts2[rank], cuts2[rank + 1])
+        res2 = gen(torch.from_numpy(cloud2[sl2]))
+        _check(res2, cloud2, sl2, reduction)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -91,11 +98,10 @@ def test_sharded_orchestration_gloo_world2(reduction, exchange):
 @pytest.fixture(params=["auto", "hash"])
 def index_path(request):
     """both index paths of the per-rank voxelizer (automatic = binned whenever eligible, hash table)"""
-    from d3d_amd import _lib
-    lib = _lib.load()
-    lib.d3d_voxel_set_path(1 if request.param == "hash" else 0)
+    from d3d_amd import _lib, voxel
+    voxel.default_flags = _lib.VOXEL_PATH_HASH if request.param == "hash" else 0
     yield request.param
-    lib.d3d_voxel_set_path(0)
+    voxel.default_flags = 0
 
 
 @pytest.mark.gpu

@@ -10,11 +10,7 @@ lib = _lib.load()
 
 
 def run(path, pts, shape, bound, P, mv, red):
-    lib.d3d_voxel_set_path(path)
-    try:
-        return voxelize_3d_dense(pts, shape, bound, P, mv, red)
-    finally:
-        lib.d3d_voxel_set_path(0)
+    return voxelize_3d_dense(pts, shape, bound, P, mv, red, flags=_lib.VOXEL_PATH_HASH if path == 1 else 0)
 
 
 def same(a, b, what):
@@ -57,15 +53,14 @@ ok &= same(a, b, "1 M points in 128 cells (overflow -> retry)")
 
 cloud = torch.from_numpy(synth.lidar_like(1000000, 0)).cuda()
 for path, name in ((1, "hash"), (2, "binned")):
-    lib.d3d_voxel_set_path(path)
+    fl = _lib.VOXEL_PATH_HASH if path == 1 else 0
     for _ in range(3):
-        voxelize_3d_dense(cloud, synth.KITTI_SHAPE, synth.KITTI_BOUNDS, 32, 1000000, 1)
+        voxelize_3d_dense(cloud, synth.KITTI_SHAPE, synth.KITTI_BOUNDS, 32, 1000000, 1, flags=fl)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(20):
-        voxelize_3d_dense(cloud, synth.KITTI_SHAPE, synth.KITTI_BOUNDS, 32, 1000000, 1)
+        voxelize_3d_dense(cloud, synth.KITTI_SHAPE, synth.KITTI_BOUNDS, 32, 1000000, 1, flags=fl)
     torch.cuda.synchronize()
     print("%s: %.1f us per call (operator level, incl. allocation + host sync)" % (name, (time.perf_counter() - t) / 20 * 1e6))
-lib.d3d_voxel_set_path(0)
 print("ALL OK" if ok else "FAILURES")
 sys.exit(0 if ok else 1)

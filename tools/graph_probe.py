@@ -21,7 +21,7 @@ ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), pts.device)
 def call():
     rc = lib.d3d_voxelize_3d_dense(_lib.ptr(pts), n, 4, ctypes.cast(shape, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p),
                                    P, n, 1, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts), _lib.ptr(agg),
-                                   _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                                   _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), 0)
     assert rc == 0
 
 
