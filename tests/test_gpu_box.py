@@ -405,7 +405,7 @@ def test_softnms_vs_oracle(method, sup, param, monkeypatch):
             keep = box2d_nms(T(b), T(s), **kw).cpu().numpy()
             assert np.array_equal(keep, exp), (n, sthr, int(np.sum(keep != exp)))
             if n == 300:
-                from d3d_amd import box
+                from d3d_amd import _lib, box
                 monkeypatch.setattr(box, "default_nms_flags", box.default_nms_flags | _lib.NMS_SOFT_NO_LDS)
                 keep = box2d_nms(T(b), T(s), **kw).cpu().numpy()
                 monkeypatch.setattr(box, "default_nms_flags", box.default_nms_flags & ~_lib.NMS_SOFT_NO_LDS)

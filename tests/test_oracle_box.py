@@ -88,3 +88,27 @@ def test_crop_reference_case():   # test_box.py:191-205
     a = np.abs(cloud)
     assert np.array_equal(np.where(res[0])[0], np.where(np.all(a < 0.5, 1))[0])
     assert np.array_equal(np.where(res[1])[0], np.where(np.abs(a[:, 0] + a[:, 1]) < bc.sq2 / 2)[0])
+
+
+def test_candidate_restricted_forms_equal_the_plain_loops():
+    """the two accelerated oracle forms the full-size GPU tests rely on: IoU over the pairs of an AABB sweep reproduces the
+    dense matrix (zero elsewhere), hard NMS over those pairs reproduces nms.cpp's greedy loop"""
+    from d3d_amd import synth
+    b, s = synth.boxes2d_sparse(4000, 11)
+    b2, _ = synth.boxes2d_dense(300, 12)
+    b2[:, :2] = b2[:, :2] * 30 + 300
+    b2[:, 2:4] *= 8
+    for x, y in ((b, None), (b[:700], b2)):
+        pi, pj = oracle.aabb_candidate_pairs(x, y)
+        yy = x if y is None else y
+        for method in ("rbox", "box"):
+            full = oracle.box2d_iou(x, yy, method, nthreads=4)
+            m = np.zeros_like(full)
+            m[pi, pj] = oracle.iou2d_pairs(x, yy, pi, pj, method)
+            assert np.array_equal(m, full) and (full > 0).sum() > 300
+    for method, thr, sthr in (("rbox", 0.5, 0.0), ("box", 0.0, 0.3), ("rbox", 0.25, 0.1)):
+        assert np.array_equal(oracle.box2d_nms(b, s, iou_method=method, iou_threshold=thr, score_threshold=sthr),
+                              oracle.box2d_nms_hard_candidates(b, s, method, thr, sthr))
+    d, ds = synth.boxes2d_dense(1500, 13)                     # the heavily overlapping distribution
+    assert np.array_equal(oracle.box2d_nms(d, ds, iou_method="rbox", iou_threshold=0.3),
+                          oracle.box2d_nms_hard_candidates(d, ds, "rbox", 0.3))
