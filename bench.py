@@ -101,7 +101,7 @@ def stream_probe(nbytes, iters=5):
     lib = _lib.load()
     buf = torch.zeros((nbytes,), dtype=torch.uint8, device="cuda")
     out = {}
-    for mode, name, moved in ((0, "store_nt", nbytes), (1, "copy", nbytes // 32 * 32), (2, "read", nbytes)):
+    for mode, name, moved in ((0, "store_nt", nbytes), (1, "copy", nbytes // 32 * 32), (2, "read", nbytes), (3, "memset", nbytes)):
         run = lambda: _lib.check(lib.d3d_stream_probe(mode, _lib.ptr(buf), nbytes, _lib.stream_ptr()), "stream_probe")  # noqa: E731
         run()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -712,9 +712,74 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
 
 
 // ------------------------------------------------------------------ kernels: outputs
-// voxels[V, P, 4]: one 16-byte row per lane, grid-stride, `global_store_dwordx4 nt` -- the HBM-roofline kernel
+// voxels[V, P, 4] -- the HBM-roofline kernel of the dense contract: 16 P bytes written per voxel, ~1.4 rows of 16 bytes
+// read.  One wavefront owns a GROUP of G consecutive voxels (G = 16 / 32 / 64, chosen by the host so that a launch has
+// >= 32 k wavefronts), i.e. G * P rows = one contiguous stretch of the output:
+//   1. lane l < G loads the record of voxel v0 + l (one coalesced request) and gathers that voxel's FIRST row -- G
+//      independent 16-byte gathers in ONE instruction.  ~80 % of a LiDAR frame's voxels hold a single point, so this one
+//      instruction covers most of what the kernel reads;
+//   2. the stretch is written 64 rows (1 KiB) per step with `global_store_dwordx4 nt`; the lane that holds row `slot` of
+//      voxel j takes count / base / first row from lane j by `ds_bpermute` (no memory), and only rows 1.. of the multi-point
+//      voxels are gathered inside the loop, four steps' worth in flight before their four stores.
+// For frames whose intermediate arrays have left the Infinity Cache by the time the fill starts (more than ~2 M points).
+// The row-per-lane form below (record load -> dependent row gather -> store, one chain per wavefront and KiB) then runs
+// at 3.5 TB/s on config 5's 3 GB output -- latency-bound: 8192 resident wavefronts x 1 KiB per ~2.5 us chain -- against
+// 6.5 TB/s for bare nt stores on the same box; this form reaches 5.5 TB/s there (tools/fill_bench.hip reproduces both with
+// the cache flushed between runs: 3.2-3.3 vs 4.7-5.1 TB/s; profiles/r02_fill_bench.txt).
+template <int G>
 __global__ __launch_bounds__(256) void k_fill_c4(const float4 *__restrict__ staged, const int64_t *__restrict__ counts,
-                                                 const uint4 *__restrict__ vinfo, uint32_t max_points, float4 *voxels)
+                                                 const uint4 *__restrict__ vinfo, uint32_t P, int pshift /* log2 P or -1 */,
+                                                 float4 *voxels)
+{
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    const int64_t V = counts[D3D_COUNT_VOXELS];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t group = (int64_t)blockIdx.x * (256 / kWave) + (threadIdx.x >> 6);
+    const int64_t v0 = group * G;
+    if (v0 >= V) return;
+    const uint32_t nv = V - v0 < G ? (uint32_t)(V - v0) : (uint32_t)G;        // voxels of this group
+    uint32_t base = 0, cnt = 0;
+    vec4 first = {0.f, 0.f, 0.f, 0.f};
+    if ((uint32_t)lane < nv) {
+        const uint4 vi = vinfo[v0 + lane];
+        base = vi.z;
+        cnt = vi.w;
+        if (cnt > 0) first = *reinterpret_cast<const vec4 *>(&staged[base]);
+    }
+    const uint32_t nrows = nv * P;                                             // <= 64 P
+    vec4 *out = reinterpret_cast<vec4 *>(voxels) + v0 * (int64_t)P;
+    for (uint32_t q0 = 0; q0 < nrows; q0 += 4 * kWave) {
+        vec4 val[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t q = q0 + u * kWave + lane;
+            // rows past the group's end compute with voxel 0's data and are not stored
+            const uint32_t qq = q < nrows ? q : 0u;
+            const uint32_t j = pshift >= 0 ? (qq >> pshift) : qq / P;
+            const uint32_t slot = qq - j * P;
+            const uint32_t c = (uint32_t)__shfl((int)cnt, (int)j, kWave);
+            const uint32_t b = (uint32_t)__shfl((int)base, (int)j, kWave);
+            vec4 f;
+            f.x = __shfl(first.x, (int)j, kWave); f.y = __shfl(first.y, (int)j, kWave);
+            f.z = __shfl(first.z, (int)j, kWave); f.w = __shfl(first.w, (int)j, kWave);
+            const vec4 zero = {0.f, 0.f, 0.f, 0.f};
+            val[u] = (slot == 0 && c > 0) ? f : zero;
+            if (slot > 0 && slot < c) val[u] = *reinterpret_cast<const vec4 *>(&staged[b + slot]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t q = q0 + u * kWave + lane;
+            if (q < nrows) __builtin_nontemporal_store(val[u], &out[q]);
+        }
+    }
+}
+
+// The same output, one 16-byte row per lane, grid-stride: the whole chip writes ONE compact moving window (the DRAM-friendliest
+// store order: 6.2-6.5 TB/s on a 300 MB output) -- the faster form while the frame's staged rows and records are still
+// cache-resident when the fill starts (config 2: 47-49 us for 324 MB; the group form 56 us, its 9 k-37 k short-lived
+// wavefronts leave a tail).
+__global__ __launch_bounds__(256) void k_fill_c4_rows(const float4 *__restrict__ staged, const int64_t *__restrict__ counts,
+                                                      const uint4 *__restrict__ vinfo, uint32_t max_points, float4 *voxels)
 {
     typedef float vec4 __attribute__((ext_vector_type(4)));
     const int64_t rows = counts[D3D_COUNT_VOXELS] * (int64_t)max_points;
@@ -763,6 +828,7 @@ __global__ __launch_bounds__(256) void k_fill_generic(const float *__restrict__ 
 // point, or zeros) and writes the 64 C floats out linearly, 16 bytes per lane -- coalesced nontemporal stores for any C
 // (the row-per-lane kernel above issues C strided 4-byte stores per row: 124 us at C = 5, this one 109 us).
 constexpr int kFillLdsMaxC = 16;
+constexpr int64_t kFillRowsMaxPoints = 2 << 20;     // frames up to this many points take k_fill_c4_rows (see there)
 __global__ __launch_bounds__(256) void k_fill_generic_lds(const float *__restrict__ points, int c,
                                                           const int64_t *__restrict__ counts,
                                                           const uint4 *__restrict__ vinfo,
@@ -2014,9 +2080,16 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
                        w.big_count, reduction, reinterpret_cast<float4 *>(aggregates));
     }
     if (P == 0) return D3D_OK;
-    if (vec4)
-        D3D_LAUNCH("k_fill_c4", k_fill_c4, dim3(grid_for(cap * P, 256, 256 * 32)), dim3(256), 0, st, w.staged, counts, w.vinfo,
+    if (vec4 && n <= kFillRowsMaxPoints) {
+        D3D_LAUNCH("k_fill_c4", k_fill_c4_rows, dim3(grid_for(cap * P, 256, 256 * 32)), dim3(256), 0, st, w.staged, counts, w.vinfo,
                    P, reinterpret_cast<float4 *>(voxels));
+    } else if (vec4) {
+        // large frames: 64 voxels per wavefront (the wavefronts past the actual voxel count exit at once)
+        const int pshift = (P & (P - 1)) == 0 ? __builtin_ctz(P) : -1;
+        const dim3 fgrid((unsigned)d3d_divup(d3d_divup(cap > 0 ? cap : 1, 64), 256 / kWave));
+        D3D_LAUNCH("k_fill_c4", k_fill_c4<64>, fgrid, dim3(256), 0, st, w.staged, counts, w.vinfo, P, pshift,
+                   reinterpret_cast<float4 *>(voxels));
+    }
     else if (c <= kFillLdsMaxC && (reinterpret_cast<uintptr_t>(voxels) & 15) == 0)
         D3D_LAUNCH("k_fill_generic_lds", k_fill_generic_lds, dim3(grid_for(cap * P, 256, 256 * 32)), dim3(256), 0, st, points, c,
                    counts, w.vinfo, lists_ready ? w.big_list : w.list, P, voxels);

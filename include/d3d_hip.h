@@ -259,7 +259,8 @@ int d3d_profile_enable(int on);
 int d3d_profile_report(char *buf, size_t buf_bytes);
 
 /* stream-bandwidth probe on the caller's buffer (bench.py: "fraction of the measured copy bandwidth of the same box",
- * SURVEY 8d).  mode 0 = nontemporal 16-byte stores over `bytes`, 1 = copy first half -> second half, 2 = read sweep. */
+ * SURVEY 8d).  mode 0 = nontemporal 16-byte stores over `bytes`, 1 = copy first half -> second half, 2 = read sweep,
+ * 3 = hipMemsetAsync (the runtime's fill, for reference). */
 int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream);
 
 /* -------------------------------------------------------------------- d3d/box */

@@ -542,10 +542,11 @@ def test_millions_of_points_up_to_the_binned_limit(index_path, n):
     from d3d_amd import synth
     from d3d_amd.voxel import VoxelGenerator
     cloud = synth.lidar_like(n, 81, synth.WAYMO_BOUNDS)
-    kw = dict(reduction="mean", max_points=4, max_voxels=n, dense=True)
+    P = 5 if n == 8388608 else 4          # (frames this large take the group-per-wavefront fill: both of its row -> voxel forms)
+    kw = dict(reduction="mean", max_points=P, max_voxels=n, dense=True)
     exp = oracle.VoxelGenerator(synth.WAYMO_BOUNDS, [752, 752, 30], **kw)(cloud)
     ret = _np(VoxelGenerator(synth.WAYMO_BOUNDS, [752, 752, 30], **kw)(torch.from_numpy(cloud).cuda()))
-    check_dense(ret, exp, 4)
+    check_dense(ret, exp, P)
 
 
 def test_fused_sparse_filter_entry_error_codes():
