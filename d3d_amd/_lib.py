@@ -75,8 +75,14 @@ SIGNATURES = {
     "d3d_iou2d_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "d3d_iou2d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp, _u32]),
     "d3d_iou2d_backward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "d3d_iou2dr_flags": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "d3d_pdist2dr_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "d3d_pdist2dr_backward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "d3d_iou3d_workspace_bytes": (_sz, [_i64, _i64]),
     "d3d_iou3d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "d3d_match_distance": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "d3d_score_match_workspace_bytes": (_sz, [_i64, _i64]),
+    "d3d_score_match": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_crop_2dr": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "d3d_argsort_desc_workspace_bytes": (_sz, [_i64, _i32]),
     "d3d_argsort_desc": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),

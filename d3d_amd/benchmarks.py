@@ -1,0 +1,97 @@
+"""d3d_amd.benchmarks -- DetectionEvaluator.calc_stats of the reference (d3d/benchmarks.pyx:60-300) on arrays.
+
+Boxes are [n,9] float32 rows (label, score, x, y, z, lx, ly, lz, yaw) -- Target3DArray.to_numpy's layout
+(d3d/abstraction.pyx:263-272); the container classes of d3d.abstraction and the dataset-specific class enums are outside
+this library's scope, classes are plain integers here.  The pairwise distance matrix (d3d_match_distance) and the
+score-ordered association (d3d_score_match) run on the GPU -- ONE association serves all score thresholds, see
+d3d_amd.tracking.matcher.score_match -- the per-threshold counts and means over the n + m matched indices are numpy.
+"""
+import numpy as np
+
+from .tracking.matcher import DistanceTypes, prepare_boxes, score_match
+from .utils import Dict
+
+
+class DetectionEvaluator:
+    """Benchmark for object detection; targets association is done by score sorting (benchmarks.pyx:84-149)."""
+
+    def __init__(self, classes, min_overlaps, pr_sample_count=40, min_score=0, pr_sample_scale="log10"):
+        classes = list(classes) if isinstance(classes, (list, tuple)) else [classes]
+        assert len(classes) > 0
+        self._classes = [int(getattr(c, "value", c)) for c in classes]
+        if isinstance(min_overlaps, (list, tuple)):
+            self._max_distance = {c: 1 - v for c, v in zip(self._classes, min_overlaps)}            # :114-115
+        elif isinstance(min_overlaps, (int, float)):
+            self._max_distance = {c: 1 - min_overlaps for c in self._classes}
+        else:
+            raise ValueError("min_overlaps should be a list or a single value")
+        self._pr_nsamples = int(pr_sample_count)
+        self._min_score = float(min_score)
+        if pr_sample_scale == "lin":                                                                 # :125-134
+            thresholds = np.linspace(min_score, 1, pr_sample_count, endpoint=False, dtype=np.float32)
+        elif pr_sample_scale.startswith("log"):
+            logstart, logend = 1, int(pr_sample_scale[3:] or "10")
+            thresholds = np.geomspace(logstart, logend, pr_sample_count + 1, dtype=np.float32)
+            thresholds = (thresholds - logstart) * (1 - min_score) / (logend - logstart)
+            thresholds = (1 - thresholds)[:0:-1]
+        else:
+            raise ValueError("Unrecognized PR sample type")
+        self._pr_thresholds = np.asarray(thresholds, dtype=np.float32)
+
+    @property
+    def score_thresholds(self):
+        return self._pr_thresholds
+
+    def calc_stats(self, gt_boxes, dt_boxes):
+        """-> Dict(ngt{c}, ndt{c}[T], tp, fp, fn, acc_iou{c}[T], acc_angular, acc_dist, acc_box, acc_var) as
+        DetectionEvalStats (benchmarks.pyx:60-82, 178-283); both box sets must be in the same frame"""
+        gt = np.ascontiguousarray(gt_boxes, dtype=np.float32).reshape(-1, 9)
+        dt = np.ascontiguousarray(dt_boxes, dtype=np.float32).reshape(-1, 9)
+        T, classes = self._pr_nsamples, self._classes
+        thr = self._pr_thresholds
+        gt_tag, dt_tag = gt[:, 0].astype(np.int64), dt[:, 0].astype(np.int64)
+        dt_score = dt[:, 1]
+        out = Dict(ngt={}, ndt={}, tp={}, fp={}, fn={}, acc_iou={}, acc_angular={}, acc_dist={}, acc_box={}, acc_var={})
+        if len(gt) and len(dt):
+            cache = prepare_boxes(dt, gt, DistanceTypes.RIoU)                                        # :188-189
+            sm, dm = score_match(cache, dt_score, dt_tag, gt_tag, self._max_distance)
+            dm = dm.cpu().numpy().astype(np.int64)
+            sm = sm.cpu().numpy().astype(np.int64)
+            matched = dm >= 0
+            iou = np.zeros((len(gt),), np.float32)
+            iou[matched] = (1 - cache[dm[matched], np.nonzero(matched)[0]]).cpu().numpy()            # :243
+        else:
+            sm, dm = np.full((len(dt),), -1, np.int64), np.full((len(gt),), -1, np.int64)
+            matched = dm >= 0
+            iou = np.zeros((len(gt),), np.float32)
+        partner = np.where(matched, dm, 0)
+        # a ground-truth box is a true positive at threshold t iff its detection is selected there (score >= t)  (:220-238)
+        gscore = np.where(matched, dt_score[partner] if len(dt) else 0.0, -np.inf)
+        live = gscore[:, None] >= thr[None, :]                                                        # [m, T]
+        dist = np.linalg.norm(gt[:, 2:5] - dt[partner, 2:5], axis=1) if len(dt) else np.zeros(len(gt))          # :244
+        box = np.linalg.norm(gt[:, 5:8] - dt[partner, 5:8], axis=1) if len(dt) else np.zeros(len(gt))           # :245
+        dyaw = (gt[:, 8] - dt[partner, 8]) if len(dt) else np.zeros(len(gt))
+        ang = np.abs((dyaw + np.pi) % (2 * np.pi) - np.pi) / np.pi                                     # quatdiff of two yaw rotations / pi (:247-248)
+        sel = dt_score[:, None] >= thr[None, :]                                                        # [n, T]  (:224-225: score < thres skipped)
+        dmatched = sm >= 0
+        for c in classes:
+            g, d = gt_tag == c, dt_tag == c
+            out.ngt[c] = int(g.sum())
+            out.ndt[c] = sel[d].sum(0).astype(np.int64).tolist()
+            tp = live[g].sum(0).astype(np.int64)
+            out.tp[c] = tp.tolist()
+            out.fn[c] = (out.ngt[c] - tp).tolist()
+            out.fp[c] = (sel[d] & ~dmatched[d][:, None]).sum(0).astype(np.int64).tolist()
+
+            def mean(values):
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    s = (live[g] * values[g][:, None].astype(np.float32)).sum(0, dtype=np.float32)
+                    return np.where(tp > 0, s / tp, np.nan).astype(np.float32).tolist()
+            out.acc_iou[c], out.acc_angular[c] = mean(iou), mean(ang)
+            out.acc_dist[c], out.acc_box[c] = mean(dist), mean(box)
+            # no variances travel in the [n,9] arrays: orientation_var = 0 -> -inf per match (:250-258), NaN without one
+            out.acc_var[c] = np.where(tp > 0, -np.inf, np.nan).astype(np.float32).tolist()
+        return out
+
+
+__all__ = ["DetectionEvaluator"]

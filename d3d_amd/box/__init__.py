@@ -1,9 +1,10 @@
-"""d3d_amd.box -- drop-in for the forward IoU / NMS path of d3d.box on MI355X.
+"""d3d_amd.box -- drop-in for d3d.box on MI355X.
 
-Mirrors reference d3d/box/__init__.py: `box2d_iou` (:180), `box2d_nms` (:226), the compiled
-entry points `iou2d_forward`, `iou2dr_forward`, `nms2d` (box/impl.cpp:8-54) and the enums
-`IouType`, `SupressionType` (box/common.h:5-10).  north_star's names `iou2d`, `iou3d`, `nms`
-are thin aliases (the reference reaches "iou3d" only through Cython: d3d/dgal_wrap.h:45-91,
+Mirrors reference d3d/box/__init__.py: `box2d_iou` (:180, methods box / rbox / grbox / drbox), `box2d_nms` (:226),
+`box2dr_crop` / `box3dp_crop` (:278-315), `box2dr_pdist` / `box3dr_pdist` (:333-381), the autograd functions `Iou2D`,
+`Iou2DR`, `GIou2DR`, `DIou2DR`, `PDist2DR` (:41-150) and the enums `IouType`, `SupressionType` (box/common.h:5-10).
+The compiled module's own names (box/impl.cpp:8-54) live in `d3d_amd.box.box_impl`.  north_star's names `iou2d`, `iou3d`,
+`nms` are thin aliases (the reference reaches "iou3d" only through Cython: d3d/dgal_wrap.h:45-91,
 d3d/tracking/matcher.pyx:57-80).  All compute runs in HIP kernels behind include/d3d_hip.h.
 """
 import enum
@@ -57,6 +58,9 @@ def _to_device(*ts):
     return [t.to(dev).contiguous() for t in ts], dev
 
 
+_MAX_ROWS = 65535 * 64      # rows of boxes1 per d3d_iou2d_forward launch (grid.y limit x 64-row tiles)
+
+
 def _iou_forward(boxes1, boxes2, iou_type, flags=None):
     lib = _lib.load()
     odev = boxes1.device
@@ -64,14 +68,17 @@ def _iou_forward(boxes1, boxes2, iou_type, flags=None):
         raise RuntimeError("boxes1 and boxes2 must have the same dtype")
     (b1, b2), dev = _to_device(boxes1, boxes2)
     n, m = b1.shape[0], b2.shape[0]
+    fl = default_iou_flags if flags is None else int(flags)
     with torch.cuda.device(dev):
         ious = torch.empty((n, m), dtype=b1.dtype, device=dev)
         code = _dtype_code(b1)
-        ws = _lib.workspace(lib.d3d_iou2d_workspace_bytes(n, m, code), dev)
-        rc = lib.d3d_iou2d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, int(iou_type), code, _lib.ptr(ious),
-                                   _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr(),
-                                   default_iou_flags if flags is None else int(flags))
-    _lib.check(rc, "iou2d_forward")
+        # one launch covers 65535 tiles of 64 rows; taller inputs go in row blocks into the same output
+        for r0 in range(0, max(n, 1), _MAX_ROWS):
+            r1 = min(n, r0 + _MAX_ROWS)
+            ws = _lib.workspace(lib.d3d_iou2d_workspace_bytes(r1 - r0, m, code), dev)
+            rc = lib.d3d_iou2d_forward(_lib.ptr(b1[r0:r1]), r1 - r0, _lib.ptr(b2), m, int(iou_type), code, _lib.ptr(ious[r0:r1]),
+                                       _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr(), fl)
+            _lib.check(rc, "iou2d_forward")
     return ious.to(odev) if odev != dev else ious
 
 
@@ -81,9 +88,38 @@ def iou2d_forward(boxes1, boxes2):
 
 
 def iou2dr_forward(boxes1, boxes2):
-    """`ious` of iou2dr_forward / iou2dr_forward_cuda (iou.h:25-31; iou.cpp:125-141).  The
-    autograd side outputs (nx, xflags) belong to the backward path, which is a "next" row."""
+    """`ious` of iou2dr_forward / iou2dr_forward_cuda (iou.h:25-31; iou.cpp:125-141).  The reference's 3-tuple form
+    (ious, nx, xflags) is `d3d_amd.box.box_impl.iou2dr_forward`; the flags alone: `iou2dr_flags`."""
     return _iou_forward(boxes1, boxes2, IouType.RBOX)
+
+
+def giou2dr_forward(boxes1, boxes2):
+    """`ious` of giou2dr_forward[_cuda] (iou.h:41-47; iou.cpp:243-258): GIoU = IoU - (hull - union) / hull"""
+    return _iou_forward(boxes1, boxes2, IouType.GRBOX)
+
+
+def diou2dr_forward(boxes1, boxes2):
+    """`ious` of diou2dr_forward[_cuda] (iou.h:56-62; iou.cpp:352-367): DIoU = IoU - centre distance^2 / hull diameter^2"""
+    return _iou_forward(boxes1, boxes2, IouType.DRBOX)
+
+
+def iou2dr_flags(boxes1, boxes2, which=("nx", "xflags")):
+    """the autograd bookkeeping of the rotated IoU family (include/d3d_hip.h: d3d_iou2dr_flags) -> dict of uint8 tensors:
+    nx[N,M], xflags[N,M,8] (iou.cpp:125-141), nm[N,M], mflags[N,M,8] (giou, iou.cpp:243-258), far[N,M,2] (diou, :352-367)"""
+    lib = _lib.load()
+    odev = boxes1.device
+    if boxes1.dtype != boxes2.dtype:
+        raise RuntimeError("boxes1 and boxes2 must have the same dtype")
+    (b1, b2), dev = _to_device(boxes1.detach(), boxes2.detach())
+    n, m = b1.shape[0], b2.shape[0]
+    shapes = dict(nx=(n, m), xflags=(n, m, 8), nm=(n, m), mflags=(n, m, 8), far=(n, m, 2))
+    with torch.cuda.device(dev):
+        out = {k: torch.empty(shapes[k], dtype=torch.uint8, device=dev) for k in which}
+        rc = lib.d3d_iou2dr_flags(_lib.ptr(b1), n, _lib.ptr(b2), m, _dtype_code(b1), _lib.ptr(out.get("nx")),
+                                  _lib.ptr(out.get("xflags")), _lib.ptr(out.get("nm")), _lib.ptr(out.get("mflags")),
+                                  _lib.ptr(out.get("far")), _lib.stream_ptr())
+    _lib.check(rc, "iou2dr_flags")
+    return {k: (v.to(odev) if odev != dev else v) for k, v in out.items()}
 
 
 def _iou_backward(boxes1, boxes2, grad, iou_type):
@@ -111,6 +147,16 @@ def iou2dr_backward(boxes1, boxes2, grad, nx=None, xflags=None):
     """iou2dr_backward[_cuda] (iou.h:32-40; iou.cpp:191-211).  `nx` / `xflags` (the reference's saved clip flags)
     are accepted for signature compatibility and ignored: the clip is recomputed."""
     return _iou_backward(boxes1, boxes2, grad, IouType.RBOX)
+
+
+def giou2dr_backward(boxes1, boxes2, grad, nxm=None, xmflags=None):
+    """giou2dr_backward[_cuda] (iou.h:48-55; iou.cpp:303-320); the saved flags are ignored (analytic gradients)"""
+    return _iou_backward(boxes1, boxes2, grad, IouType.GRBOX)
+
+
+def diou2dr_backward(boxes1, boxes2, grad, nxd=None, xflags=None):
+    """diou2dr_backward[_cuda] (iou.h:63-69; iou.cpp:402-419); the saved flags are ignored (analytic gradients)"""
+    return _iou_backward(boxes1, boxes2, grad, IouType.DRBOX)
 
 
 class Iou2D(torch.autograd.Function):
@@ -141,6 +187,34 @@ class Iou2DR(torch.autograd.Function):
         return iou2dr_backward(boxes1, boxes2, grad.contiguous())
 
 
+class GIou2DR(torch.autograd.Function):
+    """Differentiable rotated GIoU function for 2D boxes -- reference box/__init__.py:86-107"""
+
+    @staticmethod
+    def forward(ctx, boxes1, boxes2):
+        ctx.save_for_backward(boxes1, boxes2)
+        return giou2dr_forward(boxes1, boxes2)
+
+    @staticmethod
+    def backward(ctx, grad):
+        boxes1, boxes2 = ctx.saved_tensors
+        return giou2dr_backward(boxes1, boxes2, grad.contiguous())
+
+
+class DIou2DR(torch.autograd.Function):
+    """Differentiable rotated DIoU function for 2D boxes -- reference box/__init__.py:109-130"""
+
+    @staticmethod
+    def forward(ctx, boxes1, boxes2):
+        ctx.save_for_backward(boxes1, boxes2)
+        return diou2dr_forward(boxes1, boxes2)
+
+    @staticmethod
+    def backward(ctx, grad):
+        boxes1, boxes2 = ctx.saved_tensors
+        return diou2dr_backward(boxes1, boxes2, grad.contiguous())
+
+
 def box2d_iou(boxes1, boxes2, method="box", precise=True):
     """Differentiable IoU on axis-aligned ('box') or rotated ('rbox') 2D boxes -- reference box/__init__.py:180-224.
 
@@ -165,8 +239,10 @@ def box2d_iou(boxes1, boxes2, method="box", precise=True):
         result = Iou2D.apply(boxes1, boxes2)
     elif iou_type == IouType.RBOX:
         result = Iou2DR.apply(boxes1, boxes2)
-    elif iou_type in (IouType.GRBOX, IouType.DRBOX):
-        raise NotImplementedError("GIoU / DIoU are not part of the forward hot path yet")
+    elif iou_type == IouType.GRBOX:
+        result = GIou2DR.apply(boxes1, boxes2)
+    elif iou_type == IouType.DRBOX:
+        result = DIou2DR.apply(boxes1, boxes2)
     else:
         raise ValueError("Unrecognized iou type!")
     if precise:
@@ -324,9 +400,105 @@ def box3dp_crop(points, boxes, project_axis=2):
     return mask_2d & mask_p
 
 
+def pdist2dr_forward(points, boxes):
+    """pdist2dr_forward[_cuda] (dist.h:7-9; dist.cpp:36-52): (distance[M,N], iedge[M,N] uint8) for points[N,2], boxes[M,5];
+    signed distance to the box boundary, positive inside"""
+    lib = _lib.load()
+    if len(points.shape) != 2 or points.shape[1] != 2 or len(boxes.shape) != 2 or boxes.shape[1] != 5:
+        raise ValueError("points should be Nx2 and boxes Mx5")
+    if points.dtype != boxes.dtype:
+        raise RuntimeError("points and boxes must have the same dtype")
+    odev = points.device
+    (p, b), dev = _to_device(points.detach(), boxes.detach())
+    n, m = p.shape[0], b.shape[0]
+    with torch.cuda.device(dev):
+        dist = torch.empty((m, n), dtype=p.dtype, device=dev)
+        iedge = torch.empty((m, n), dtype=torch.uint8, device=dev)
+        rc = lib.d3d_pdist2dr_forward(_lib.ptr(p), n, _lib.ptr(b), m, _dtype_code(p), _lib.ptr(dist), _lib.ptr(iedge),
+                                      _lib.stream_ptr())
+    _lib.check(rc, "pdist2dr_forward")
+    return (dist.to(odev), iedge.to(odev)) if odev != dev else (dist, iedge)
+
+
+def pdist2dr_backward(points, boxes, grad, iedge=None):
+    """pdist2dr_backward[_cuda] (dist.h:10-13; dist.cpp:90-110): (grad_boxes[M,5], grad_points[N,2]); `iedge` is accepted
+    for signature compatibility and ignored (the nearest feature is recomputed)"""
+    lib = _lib.load()
+    odev = points.device
+    (p, b, g), dev = _to_device(points.detach(), boxes.detach(), grad.to(points.dtype))
+    n, m = p.shape[0], b.shape[0]
+    with torch.cuda.device(dev):
+        gb = torch.empty((m, 5), dtype=p.dtype, device=dev)
+        gp = torch.empty((n, 2), dtype=p.dtype, device=dev)
+        rc = lib.d3d_pdist2dr_backward(_lib.ptr(p), n, _lib.ptr(b), m, _lib.ptr(g), _dtype_code(p), _lib.ptr(gb), _lib.ptr(gp),
+                                       _lib.stream_ptr())
+    _lib.check(rc, "pdist2dr_backward")
+    return (gb.to(odev), gp.to(odev)) if odev != dev else (gb, gp)
+
+
+class PDist2DR(torch.autograd.Function):
+    """reference box/__init__.py:132-150 -- with its argument mix-up fixed: the compiled functions take (points, boxes)
+    (dist.h:7-13) while the reference passes (boxes, points) and returns the two gradients in the wrong order"""
+
+    @staticmethod
+    def forward(ctx, points, boxes):
+        dist, iedge = pdist2dr_forward(points, boxes)
+        ctx.save_for_backward(points, boxes)
+        return dist
+
+    @staticmethod
+    def backward(ctx, grad):
+        points, boxes = ctx.saved_tensors
+        grad_boxes, grad_points = pdist2dr_backward(points, boxes, grad.contiguous())
+        return grad_points, grad_boxes
+
+
+def seg1d_pdist(points, segs):
+    """distance from points [N,1] to 1-D segments [M,2] = (centre, width) -- reference box/__init__.py:317-331
+    (positive inside; broadcasts to the [N,M] / [M] shapes the reference's callers use)"""
+    assert torch.all(segs[:, 1] > 0)
+    dsegs = segs[:, 1] / 2
+    smax, smin = segs[:, 0] + dsegs, segs[:, 0] - dsegs
+    return torch.where(points > segs[:, 0], smax - points, points - smin)
+
+
+def box2dr_pdist(points, boxes, method="rbox"):
+    """Signed distance from points [N,2] to rotated 2D boxes [M,5] -> [M,N] -- reference box/__init__.py:333-349"""
+    if len(boxes.shape) != 2:
+        raise ValueError("Input boxes should be Nx2 tensors!")
+    if boxes.shape[1] != 5:
+        raise ValueError("Input boxes should have 5 fields: x, y, w, h, r")
+    if method != "rbox":
+        raise ValueError("Only supported rotated boxes by now!")
+    return PDist2DR.apply(points, boxes)
+
+
+def box3dr_pdist(points, boxes, project_axis=2):
+    """Signed distance from points [N,3] to 3D boxes [M,7] (surfaces) -> [M,N] -- reference box/__init__.py:351-381.
+    (The reference combines a [M,N] planar distance with a [N,M] axial one, which only broadcasts for N == M; here the
+    axial distance is laid out [M,N] as well.)"""
+    if project_axis == 0:
+        points_2d, boxes_2d = points[:, [1, 2]], boxes[:, [1, 2, 4, 5, 6]]
+    elif project_axis == 1:
+        points_2d, boxes_2d = points[:, [0, 2]], boxes[:, [0, 2, 3, 5, 6]]
+    elif project_axis == 2:
+        points_2d, boxes_2d = points[:, [0, 1]], boxes[:, [0, 1, 3, 4, 6]]
+    else:
+        raise ValueError("The projection axis can only be 0-x, 1-y and 2-z!")
+    dist_2d = box2dr_pdist(points_2d.contiguous(), boxes_2d.contiguous())
+    dist_p = seg1d_pdist(points[:, [project_axis]], boxes[:, [project_axis, 3 + project_axis]]).t()
+    return torch.where(
+        dist_p > 0,
+        torch.where(dist_2d > 0, torch.min(dist_p, dist_2d), dist_2d),
+        torch.where(dist_2d > 0, dist_p, -torch.sqrt(dist_2d.square() + dist_p.square())))
+
+
 # north_star operator names
 iou2d = box2d_iou
 nms = box2d_nms
 
-__all__ = ["Iou2D", "Iou2DR", "iou2d_backward", "iou2dr_backward", "box2dr_crop", "box3dp_crop", "crop_2dr", "box2d_iou", "box2d_nms", "iou2d", "iou3d", "nms", "iou2d_forward", "iou2dr_forward", "nms2d",
-           "nms2d_cuda", "argsort_desc", "IouType", "SupressionType", "cuda_available"]
+__all__ = ["Iou2D", "Iou2DR", "GIou2DR", "DIou2DR", "PDist2DR", "iou2d_backward", "iou2dr_backward", "giou2dr_forward",
+           "giou2dr_backward", "diou2dr_forward", "diou2dr_backward", "iou2dr_flags", "pdist2dr_forward", "pdist2dr_backward",
+           "box2dr_crop", "box3dp_crop", "box2dr_pdist", "box3dr_pdist", "seg1d_pdist", "crop_2dr", "box2d_iou", "box2d_nms",
+           "iou2d", "iou3d", "nms", "iou2d_forward", "iou2dr_forward", "nms2d", "nms2d_cuda", "argsort_desc", "IouType",
+           "SupressionType", "cuda_available"]

@@ -163,7 +163,8 @@ constexpr int kPreBatch = 1024;      // LDS batch entries per wavefront
 template <typename T>
 __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict__ ra, int64_t n,
                                                        const float4 *__restrict__ cb, int64_t m, T *__restrict__ ious,
-                                                       IouList *hdr, unsigned long long *list, unsigned long long cap)
+                                                       IouList *hdr, unsigned long long *list, unsigned long long cap,
+                                                       float fillv = 0.f /* T = float only: the matrix' background value */)
 {
     constexpr int K = kPreK;
     typedef float vec16 __attribute__((ext_vector_type(4)));
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
     const size_t per_block = (nchunk + gridDim.x - 1) / gridDim.x;
     const size_t c0 = (size_t)blockIdx.x * per_block, c1 = c0 + per_block < nchunk ? c0 + per_block : nchunk;
     vec16 *slab = ious ? reinterpret_cast<vec16 *>(ious + i0 * m) : nullptr;
-    const vec16 z = {0.f, 0.f, 0.f, 0.f};
+    const vec16 z = {fillv, fillv, fillv, fillv};
     for (int r = 0; r < kTileRows; r++) {
         if (r < nrows) {
             const float4 fa = rbox[r];                        // LDS broadcast
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
             }
     }
     if (slab && blockIdx.x == 0 && threadIdx.x == 0)             // slab size not a multiple of 16 bytes (last tile row)
-        for (size_t e = nvec * (16 / sizeof(T)); e < (size_t)nrows * (size_t)m; e++) ious[i0 * m + e] = 0;
+        for (size_t e = nvec * (16 / sizeof(T)); e < (size_t)nrows * (size_t)m; e++) ious[i0 * m + e] = (T)fillv;
     // what is left in the four batches is reserved with ONE atomic per workgroup: atomics on the list counter are
     // serialised at ~7 ns each, and every workgroup of a short launch gets here at about the same time
     const int wave = threadIdx.x >> 6;
@@ -274,31 +275,37 @@ __global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__
 
 // ---------------------------------------------------------------- pairwise "3D IoU" (BEV x z), fp32
 // box = (x, y, z, lx, ly, lz, rz); dgal_wrap.h:45-91
-__device__ __forceinline__ Box3DGeom load3d(const float *b)
+// clip_dims: the matcher's guard against "really weird boxes with unusual size" (matcher.pyx:49-51: np.clip(dims, -1e3, 1e3))
+__device__ __forceinline__ Box3DGeom load3d(const float *b, bool clip_dims = false)
 {
+    float lx = b[3], ly = b[4], lz = b[5];
+    if (clip_dims) {
+        lx = fminf(fmaxf(lx, -1e3f), 1e3f); ly = fminf(fmaxf(ly, -1e3f), 1e3f); lz = fminf(fmaxf(lz, -1e3f), 1e3f);
+    }
     Box3DGeom r;
-    r.g = make_geom<float>(b[0], b[1], b[3], b[4], b[6]);
-    r.zmax = b[2] + b[5] / 2;
-    r.zmin = b[2] - b[5] / 2;
+    r.g = make_geom<float>(b[0], b[1], lx, ly, b[6]);
+    r.zmax = b[2] + lz / 2;
+    r.zmin = b[2] - lz / 2;
     return r;
 }
 
+// stride: floats per row (7, or 9 for the matcher's [n,9] arrays entered at column 2); complement: store 1 - iou
 template <bool ROTATED, int K>
 __global__ __launch_bounds__(kTileCols) void k_iou3d(const float *__restrict__ b1, int64_t n,
                                                      const float *__restrict__ b2, int64_t m, float *__restrict__ out_,
-                                                     const unsigned int *only_if)
+                                                     const unsigned int *only_if, int stride = 7, bool complement = false)
 {
     if (only_if && !*only_if) return;
     __shared__ Box3DGeom rows[kTileRows];
     const int64_t i0 = (int64_t)blockIdx.y * kTileRows;
     const int64_t j0 = ((int64_t)blockIdx.x * kTileCols + threadIdx.x) * K;
     const int nrows = (int)((n - i0) < kTileRows ? (n - i0) : kTileRows);
-    if (threadIdx.x < nrows) rows[threadIdx.x] = load3d(b1 + (i0 + threadIdx.x) * 7);
+    if (threadIdx.x < nrows) rows[threadIdx.x] = load3d(b1 + (i0 + threadIdx.x) * stride, complement);
     Box3DGeom col[K];
     const bool active = j0 < m;
     if (active) {
 #pragma unroll
-        for (int k = 0; k < K; k++) col[k] = load3d(b2 + (j0 + k) * 7);
+        for (int k = 0; k < K; k++) col[k] = load3d(b2 + (j0 + k) * stride, complement);
     }
     __syncthreads();
     if (!active) return;
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou3d(const float *__restrict__ b
                 float u = fmaxf(umax - umin, (float)1e-6);
                 v[k] = iou2d * (i / u);
             }
+            if (complement) v[k] = 1 - v[k];
         }
         store_row<float, K>(out, v);
         out += m;
@@ -358,12 +366,13 @@ __global__ __launch_bounds__(256) void k_iou_grad(const BoxGeom<T> *__restrict__
 
 // ---------------------------------------------------------------- "3D IoU", two-phase (same scheme as rbox)
 __global__ __launch_bounds__(256) void k_geom3d(const float *__restrict__ boxes, int64_t n, BoxGeom<float> *geom,
-                                                float4 *aabb, float2 *zr, IouList *hdr, unsigned int nseg, bool rotated)
+                                                float4 *aabb, float2 *zr, IouList *hdr, unsigned int nseg, bool rotated,
+                                                int stride = 7, bool clip_dims = false)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (hdr && i == 0) list_reset(hdr, nseg);
     if (i < n) {
-        const Box3DGeom g = load3d(boxes + i * 7);
+        const Box3DGeom g = load3d(boxes + i * stride, clip_dims);
         geom[i] = g.g;
         aabb[i] = cand_aabb(g.g, rotated);
         zr[i] = make_float2(g.zmin, g.zmax);
@@ -374,7 +383,8 @@ template <bool ROTATED>
 __global__ __launch_bounds__(256) void k_iou3d_clip(const BoxGeom<float> *__restrict__ ga, const float2 *__restrict__ za,
                                                     const BoxGeom<float> *__restrict__ gb, const float2 *__restrict__ zb,
                                                     int64_t m, float *__restrict__ out, const IouList *hdr,
-                                                    const unsigned long long *__restrict__ list, unsigned long long cap)
+                                                    const unsigned long long *__restrict__ list, unsigned long long cap,
+                                                    bool complement = false)
 {
     if (hdr->overflow) return;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / hdr->nseg;
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(256) void k_iou3d_clip(const BoxGeom<float> *__rest
             const float imax = fminf(a.y, b.y), imin = fmaxf(a.x, b.x);
             const float umax = fmaxf(a.y, b.y), umin = fminf(a.x, b.x);
             const float v = iou2d * (fmaxf(imax - imin, 0.f) / fmaxf(umax - umin, (float)1e-6));
-            if (v != 0.f) out[i * m + j] = v;
+            if (v != 0.f) out[i * m + j] = complement ? 1 - v : v;
         }
     }
     }
@@ -1306,6 +1316,11 @@ static unsigned long long iou_list_capacity(int64_t n, int64_t m)
     return pairs < (1ull << 27) ? pairs : (1ull << 27);
 }
 
+// boxloss.hip
+int d3d_internal_loss_iou_forward(const void *b1, int64_t n, const void *b2, int64_t m, int kind, int dtype, void *out, hipStream_t st);
+int d3d_internal_loss_iou_backward(const void *b1, int64_t n, const void *b2, int64_t m, const void *grad, int kind, int dtype,
+                                   void *g1, void *g2, hipStream_t st);
+
 extern "C" size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype)
 {
     if (n < 1) n = 1;
@@ -1354,9 +1369,12 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || m < 0 || (flags & 0xffu)) return D3D_ERR_BAD_ARG;
     if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
-    if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;
+    const bool loss_kind = iou_type == D3D_IOU_GRBOX || iou_type == D3D_IOU_DRBOX;
+    if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX && !loss_kind) return D3D_ERR_UNSUPPORTED;
     if (n == 0 || m == 0) return D3D_OK;
     if (!boxes1 || !boxes2 || !ious) return D3D_ERR_BAD_ARG;
+    if (loss_kind)          // GIoU / DIoU: every pair has a value (boxloss.hip)
+        return d3d_internal_loss_iou_forward(boxes1, n, boxes2, m, iou_type == D3D_IOU_GRBOX ? 0 : 1, dtype, ious, st);
     const int64_t gy = d3d_divup(n, kTileRows);
     if (gy > 65535 || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;   // callers tile above that
     const bool rot = iou_type == D3D_IOU_RBOX;
@@ -1393,21 +1411,21 @@ extern "C" size_t d3d_iou3d_workspace_bytes(int64_t n, int64_t m)
            d3d_align_up(8 * m) + d3d_align_up(16 * n) + d3d_align_up(16 * m) + d3d_align_up(sizeof(IouList)) + d3d_align_up(8 * iou_list_capacity(n, m)) + 256;
 }
 
-extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *boxes2, int64_t m, int32_t rotated,
-                                 float *out, void *workspace, size_t workspace_bytes, void *stream)
+static int iou3d_impl(const float *boxes1, int64_t n, const float *boxes2, int64_t m, int32_t rotated, float *out,
+                      void *workspace, size_t workspace_bytes, hipStream_t st, int stride, bool complement)
 {
-    hipStream_t st = (hipStream_t)stream;
     if (n < 0 || m < 0) return D3D_ERR_BAD_ARG;
     if (n == 0 || m == 0) return D3D_OK;
     if (!boxes1 || !boxes2 || !out) return D3D_ERR_BAD_ARG;
     if (d3d_divup(n, kTileRows) > 65535 || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;
     const unsigned gy = (unsigned)d3d_divup(n, kTileRows);
-    const bool vec = (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (m % 4 == 0);
+    const bool al16 = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    const bool vec = al16 && (m % 4 == 0);
 #define D3D_IOU3D(R, K, FLAG)                                                                                      \
     D3D_LAUNCH("k_iou3d", (k_iou3d<R, K>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols * K), gy), dim3(kTileCols), \
-               0, st, boxes1, n, boxes2, m, out, FLAG)
-    if (workspace && workspace_bytes >= d3d_iou3d_workspace_bytes(n, m)) {
-        // zero-fill + candidate list + dense clipping (see "rotated IoU, two-phase")
+               0, st, boxes1, n, boxes2, m, out, FLAG, stride, complement)
+    if (workspace && workspace_bytes >= d3d_iou3d_workspace_bytes(n, m) && (al16 || !complement)) {
+        // background fill + candidate list + dense clipping (see "rotated IoU, two-phase")
         WsCarver w(workspace, workspace_bytes);
         BoxGeom<float> *ga = w.take<BoxGeom<float>>(n);
         BoxGeom<float> *gb = w.take<BoxGeom<float>>(m);
@@ -1420,21 +1438,21 @@ extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *bo
         unsigned long long *list = w.take<unsigned long long>(cap);
         if (!w.ok()) return D3D_ERR_WORKSPACE;
         D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, boxes1, n, ga, ra, za, hdr,
-                   list_segments(cap), rotated != 0);
+                   list_segments(cap), rotated != 0, stride, complement);
         D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, boxes2, m, gb, cb, zb, (IouList *)nullptr,
-                   1u, rotated != 0);
+                   1u, rotated != 0, stride, complement);
         float *fill = out;
-        if (reinterpret_cast<uintptr_t>(out) & 15) {
+        if (!al16) {
             D3D_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n * (size_t)m * sizeof(float), st));
             fill = nullptr;
         }
         D3D_LAUNCH("k_iou_pre", k_iou_pre<float>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), gy), dim3(kTileCols), 0, st,
-                   (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap);
+                   (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap, complement ? 1.f : 0.f);
         if (rotated) {
-            D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<true>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, m, out, hdr, list, cap);
+            D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<true>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, m, out, hdr, list, cap, complement);
             D3D_IOU3D(true, 1, &hdr->overflow);
         } else {
-            D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<false>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, m, out, hdr, list, cap);
+            D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<false>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, m, out, hdr, list, cap, complement);
             D3D_IOU3D(false, 1, &hdr->overflow);
         }
         return D3D_OK;
@@ -1443,6 +1461,23 @@ extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *bo
     else { if (vec) D3D_IOU3D(false, 4, (const unsigned int *)nullptr); else D3D_IOU3D(false, 1, (const unsigned int *)nullptr); }
 #undef D3D_IOU3D
     return D3D_OK;
+}
+
+extern "C" int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *boxes2, int64_t m, int32_t rotated,
+                                 float *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return iou3d_impl(boxes1, n, boxes2, m, rotated, out, workspace, workspace_bytes, (hipStream_t)stream, 7, false);
+}
+
+// BaseMatcher.prepare_boxes (reference d3d/tracking/matcher.pyx:46-80) for the IoU / RIoU metrics: src[n,9], dst[m,9] rows
+// (label, score, x, y, z, lx, ly, lz, yaw) as Target3DArray.to_numpy lays them out; dimensions clipped to +-1e3
+// (matcher.pyx:49-51); cache[i,j] = 1 - box3d_iou / box3dr_iou in fp32 (matcher.pyx:57-80).  One pass: the matrix is
+// filled with 1 at store bandwidth and the overlapping pairs get 1 - iou.
+extern "C" int d3d_match_distance(const float *src, int64_t n, const float *dst, int64_t m, int32_t rotated, float *cache,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    return iou3d_impl(src ? src + 2 : src, n, dst ? dst + 2 : dst, m, rotated, cache, workspace, workspace_bytes,
+                      (hipStream_t)stream, 9, true);
 }
 
 constexpr size_t kSoftLdsBytes = 128 * 1024;      // position-indexed state of the soft-NMS kernel stays in LDS below this
@@ -1585,7 +1620,8 @@ extern "C" int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *box
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || m < 0) return D3D_ERR_BAD_ARG;
     if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
-    if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;
+    const bool loss_kind = iou_type == D3D_IOU_GRBOX || iou_type == D3D_IOU_DRBOX;
+    if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX && !loss_kind) return D3D_ERR_UNSUPPORTED;
     if (n > 0 && (!boxes1 || !grad_boxes1)) return D3D_ERR_BAD_ARG;
     if (m > 0 && (!boxes2 || !grad_boxes2)) return D3D_ERR_BAD_ARG;
     const size_t esz = dtype == D3D_F64 ? 8 : 4;
@@ -1595,6 +1631,9 @@ extern "C" int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *box
         return D3D_OK;
     }
     if (!grad || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;
+    if (loss_kind)
+        return d3d_internal_loss_iou_backward(boxes1, n, boxes2, m, grad, iou_type == D3D_IOU_GRBOX ? 0 : 1, dtype, grad_boxes1,
+                                              grad_boxes2, st);
     if (workspace_bytes < d3d_iou2d_workspace_bytes(n, m, dtype)) return D3D_ERR_WORKSPACE;
     const bool rot = iou_type == D3D_IOU_RBOX;
     if (dtype == D3D_F64)

@@ -1,0 +1,360 @@
+// boxloss.hip -- the loss-path operators of d3d.box on MI355X (gfx950): GIoU / DIoU of rotated boxes forward + backward,
+// the autograd bookkeeping outputs of the rotated IoU family, and the signed point-to-box distance forward + backward.
+// Replaces reference d3d/box/iou.cpp:213-419 + iou_cuda.cu:216-440 (giou2dr_* / diou2dr_*), the nx / xflags outputs of
+// iou.cpp:95-141, and d3d/box/dist.cpp + dist_cuda.cu (pdist2dr_*).
+//
+// Unlike IoU, GIoU / DIoU are non-zero for EVERY pair (disjoint boxes get a negative value), so there is no candidate list:
+// one pair per lane over a 64-row x 256-column tile, row geometry broadcast from LDS, lanes along the columns (coalesced
+// row-major stores).  Gradients are analytic (geom.hpp) and accumulated race-free: a row's five partials are reduced across
+// the wavefront by shuffles (one atomic per wavefront and row), a column's stay in the lane's registers over the tile's rows
+// (one atomic per lane and tile) -- the reference's kernels add from many threads with plain += (iou_cuda.cu:72-73,184-185).
+#include "common.hpp"
+#include "geom.hpp"
+
+namespace {
+
+constexpr int kCols = 256, kRows = 64;
+
+template <typename T> struct RowBox { BoxGeom<T> g; T w, h; };
+
+template <typename T> __device__ __forceinline__ RowBox<T> load_row(const T *b)
+{
+    RowBox<T> r;
+    r.g = make_geom<T>(b[0], b[1], b[2], b[3], b[4]);
+    r.w = b[2]; r.h = b[3];
+    return r;
+}
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// ---------------------------------------------------------------- GIoU / DIoU forward
+template <typename T, int KIND>
+__global__ __launch_bounds__(kCols) void k_loss_iou(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
+                                                    T *__restrict__ out)
+{
+    __shared__ RowBox<T> rows[kRows];
+    const int64_t i0 = (int64_t)blockIdx.y * kRows, j = (int64_t)blockIdx.x * kCols + threadIdx.x;
+    const int nrows = (int)((n - i0) < kRows ? (n - i0) : kRows);
+    if (threadIdx.x < nrows) rows[threadIdx.x] = load_row<T>(b1 + (i0 + threadIdx.x) * 5);
+    __syncthreads();
+    if (j >= m) return;
+    const RowBox<T> c = load_row<T>(b2 + j * 5);
+    T *o = out + i0 * m + j;
+    T ga[5], gb[5];
+    for (int r = 0; r < nrows; r++) {
+        const RowBox<T> a = rows[r];
+        __builtin_nontemporal_store((loss_iou_rbox<T, KIND, false>(a.g, c.g, a.w, a.h, c.w, c.h, ga, gb)), o);
+        o += m;
+    }
+}
+
+// ---------------------------------------------------------------- GIoU / DIoU backward
+template <typename T, int KIND>
+__global__ __launch_bounds__(kCols) void k_loss_iou_grad(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
+                                                         const T *__restrict__ grad, T *g1, T *g2)
+{
+    __shared__ RowBox<T> rows[kRows];
+    const int64_t i0 = (int64_t)blockIdx.y * kRows, j = (int64_t)blockIdx.x * kCols + threadIdx.x;
+    const int nrows = (int)((n - i0) < kRows ? (n - i0) : kRows);
+    if (threadIdx.x < nrows) rows[threadIdx.x] = load_row<T>(b1 + (i0 + threadIdx.x) * 5);
+    __syncthreads();
+    const bool active = j < m;
+    RowBox<T> c = load_row<T>(b2 + (active ? j : 0) * 5);
+    T col[5] = {0, 0, 0, 0, 0};
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int r = 0; r < nrows; r++) {
+        const RowBox<T> a = rows[r];
+        T ga[5] = {0, 0, 0, 0, 0}, gb[5] = {0, 0, 0, 0, 0};
+        const T g = active ? grad[(i0 + r) * m + j] : (T)0;
+        if (g != 0) {
+            loss_iou_rbox<T, KIND, true>(a.g, c.g, a.w, a.h, c.w, c.h, ga, gb);
+#pragma unroll
+            for (int k = 0; k < 5; k++) { ga[k] *= g; col[k] += g * gb[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const T s = wave_sum<T>(ga[k]);
+            if (lane == 0 && s != 0) atomicAdd(&g1[(i0 + r) * 5 + k], s);
+        }
+    }
+    if (active)
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (col[k] != 0) atomicAdd(&g2[j * 5 + k], col[k]);
+}
+
+// ---------------------------------------------------------------- bookkeeping outputs (nx, xflags, nm, mflags, far)
+// Sutherland-Hodgman with the origin of every vertex, Andrew's monotone chain for the hull's vertex list.  These ARE
+// dynamically indexed vertex lists (scratch memory): they are what the reference's autograd saves between forward and
+// backward, nothing on a hot path -- this library's backward recomputes the clip analytically and ignores them.
+template <typename T> struct Pt { T x, y; };
+
+template <typename T>
+__device__ int clip_flags(const Pt<T> (&s)[4], const Pt<T> (&c)[4], uint8_t *flags)
+{
+    Pt<T> buf[2][16];
+    uint8_t vf[2][16], ef[2][16];
+    int n = 4, cur = 0;
+    for (int k = 0; k < 4; k++) { buf[0][k] = s[k]; vf[0][k] = (uint8_t)k; ef[0][k] = (uint8_t)k; }
+    for (int e = 0; e < 4 && n > 0; e++) {
+        const Pt<T> a = c[e], b = c[(e + 1) & 3];
+        const T ex = b.x - a.x, ey = b.y - a.y;
+        int mm = 0;
+        const int nxt = cur ^ 1;
+        for (int k = 0; k < n; k++) {
+            const Pt<T> p = buf[cur][k], q = buf[cur][(k + 1) % n];
+            const uint8_t o = ef[cur][k];
+            const T dp = ex * (p.y - a.y) - ey * (p.x - a.x), dq = ex * (q.y - a.y) - ey * (q.x - a.x);
+            const bool pin = dp >= 0, qin = dq >= 0;
+            if (pin) { buf[nxt][mm] = p; vf[nxt][mm] = vf[cur][k]; ef[nxt][mm] = o; mm++; }
+            if (pin != qin) {
+                const T t = dp / (dp - dq);
+                Pt<T> x = {p.x + t * (q.x - p.x), p.y + t * (q.y - p.y)};
+                uint8_t f;
+                if (o < 4) f = (uint8_t)(0x20 | (o << 2) | e);
+                else { const int e2 = o - 4; f = (uint8_t)(0x10 | (((e2 + 1) & 3) == e ? e : e2)); }
+                buf[nxt][mm] = x; vf[nxt][mm] = f; ef[nxt][mm] = pin ? (uint8_t)(4 + e) : o; mm++;
+            }
+        }
+        n = mm; cur = nxt;
+    }
+    if (n < 3) n = 0;                                  // no area: no polygon
+    if (n > 8) n = 8;
+    for (int k = 0; k < 8; k++) flags[k] = k < n ? vf[cur][k] : (uint8_t)0xff;
+    return n;
+}
+
+template <typename T>
+__device__ int hull_flags(const Pt<T> (&p)[8], uint8_t *hull)
+{
+    int idx[8];
+    for (int k = 0; k < 8; k++) idx[k] = k;
+    for (int a = 1; a < 8; a++) {
+        const int v = idx[a];
+        int b = a - 1;
+        while (b >= 0 && (p[idx[b]].x > p[v].x || (p[idx[b]].x == p[v].x && p[idx[b]].y > p[v].y))) { idx[b + 1] = idx[b]; b--; }
+        idx[b + 1] = v;
+    }
+    int st[17], mm = 0;
+    for (int k = 0; k < 8; k++) {
+        while (mm >= 2) {
+            const Pt<T> a = p[st[mm - 2]], b = p[st[mm - 1]], c = p[idx[k]];
+            if ((b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x) <= 0) mm--; else break;
+        }
+        st[mm++] = idx[k];
+    }
+    const int lower = mm + 1;
+    for (int k = 6; k >= 0; k--) {
+        while (mm >= lower) {
+            const Pt<T> a = p[st[mm - 2]], b = p[st[mm - 1]], c = p[idx[k]];
+            if ((b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x) <= 0) mm--; else break;
+        }
+        st[mm++] = idx[k];
+    }
+    mm--;
+    if (mm < 0) mm = 0;
+    if (mm > 8) mm = 8;
+    for (int k = 0; k < 8; k++) hull[k] = k < mm ? (uint8_t)st[k] : (uint8_t)0xff;
+    return mm;
+}
+
+// corners in the reference's formula order (utils.h:19 via dgal::poly2_from_xywhr; same expressions as the oracle)
+template <typename T> __device__ void quad_pts(const T *b, Pt<T> (&q)[4])
+{
+    T s, c;
+    d3d_sincos(b[4], &s, &c);
+    const T dxs = b[2] * s / 2, dxc = b[2] * c / 2, dys = b[3] * s / 2, dyc = b[3] * c / 2;
+    q[0] = {b[0] - dxc + dys, b[1] - dxs - dyc}; q[1] = {b[0] + dxc + dys, b[1] + dxs - dyc};
+    q[2] = {b[0] + dxc - dys, b[1] + dxs + dyc}; q[3] = {b[0] - dxc - dys, b[1] - dxs + dyc};
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pair_flags(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
+                                                    uint8_t *nx, uint8_t *xflags, uint8_t *nm, uint8_t *mflags, uint8_t *far)
+{
+    const int64_t total = n * m;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / m, j = e - i * m;
+        Pt<T> qa[4], qb[4], p8[8];
+        quad_pts<T>(b1 + i * 5, qa);
+        quad_pts<T>(b2 + j * 5, qb);
+        for (int k = 0; k < 4; k++) { p8[k] = qa[k]; p8[4 + k] = qb[k]; }
+        uint8_t fl[8];
+        if (nx || xflags) {
+            const int k = clip_flags<T>(qa, qb, fl);
+            if (nx) nx[e] = (uint8_t)k;
+            if (xflags) *reinterpret_cast<uint2 *>(xflags + e * 8) = *reinterpret_cast<const uint2 *>(fl);
+        }
+        if (nm || mflags) {
+            const int k = hull_flags<T>(p8, fl);
+            if (nm) nm[e] = (uint8_t)k;
+            if (mflags) *reinterpret_cast<uint2 *>(mflags + e * 8) = *reinterpret_cast<const uint2 *>(fl);
+        }
+        if (far) {
+            T best = -1;
+            int f1 = 0, f2 = 1;
+            for (int x = 0; x < 8; x++)
+                for (int y = x + 1; y < 8; y++) {
+                    const T dx = p8[x].x - p8[y].x, dy = p8[x].y - p8[y].y, d = dx * dx + dy * dy;
+                    if (d > best) { best = d; f1 = x; f2 = y; }
+                }
+            far[e * 2] = (uint8_t)f1; far[e * 2 + 1] = (uint8_t)f2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- point-to-box distance
+// dist[m, n] (box-major, like the reference: dist.cpp:39): tile = 64 boxes (LDS) x 256 points (lanes: coalesced rows)
+template <typename T>
+__global__ __launch_bounds__(kCols) void k_pdist(const T *__restrict__ points, int64_t n, const T *__restrict__ boxes, int64_t m,
+                                                 T *__restrict__ dist, uint8_t *__restrict__ iedge)
+{
+    __shared__ RowBox<T> rows[kRows];
+    const int64_t i0 = (int64_t)blockIdx.y * kRows, j = (int64_t)blockIdx.x * kCols + threadIdx.x;
+    const int nrows = (int)((m - i0) < kRows ? (m - i0) : kRows);
+    if (threadIdx.x < nrows) rows[threadIdx.x] = load_row<T>(boxes + (i0 + threadIdx.x) * 5);
+    __syncthreads();
+    if (j >= n) return;
+    const T px = points[j * 2], py = points[j * 2 + 1];
+    T gp[2], gb[5];
+    for (int r = 0; r < nrows; r++) {
+        const RowBox<T> b = rows[r];
+        int feat;
+        const T d = point_box_distance<T, false>(b.g, b.w, b.h, px, py, feat, gp, gb);
+        dist[(i0 + r) * n + j] = d;
+        if (iedge) iedge[(i0 + r) * n + j] = (uint8_t)feat;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kCols) void k_pdist_grad(const T *__restrict__ points, int64_t n, const T *__restrict__ boxes, int64_t m,
+                                                      const T *__restrict__ grad, T *gboxes, T *gpoints)
+{
+    __shared__ RowBox<T> rows[kRows];
+    const int64_t i0 = (int64_t)blockIdx.y * kRows, j = (int64_t)blockIdx.x * kCols + threadIdx.x;
+    const int nrows = (int)((m - i0) < kRows ? (m - i0) : kRows);
+    if (threadIdx.x < nrows) rows[threadIdx.x] = load_row<T>(boxes + (i0 + threadIdx.x) * 5);
+    __syncthreads();
+    const bool active = j < n;
+    const T px = active ? points[j * 2] : (T)0, py = active ? points[j * 2 + 1] : (T)0;
+    T accp[2] = {0, 0};
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int r = 0; r < nrows; r++) {
+        const RowBox<T> b = rows[r];
+        T gp[2] = {0, 0}, gb[5] = {0, 0, 0, 0, 0};
+        const T g = active ? grad[(i0 + r) * n + j] : (T)0;
+        if (g != 0) {
+            int feat;
+            point_box_distance<T, true>(b.g, b.w, b.h, px, py, feat, gp, gb);
+            accp[0] += g * gp[0]; accp[1] += g * gp[1];
+#pragma unroll
+            for (int k = 0; k < 5; k++) gb[k] *= g;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const T s = wave_sum<T>(gb[k]);
+            if (lane == 0 && s != 0) atomicAdd(&gboxes[(i0 + r) * 5 + k], s);
+        }
+    }
+    if (active) {
+        if (accp[0] != 0) atomicAdd(&gpoints[j * 2], accp[0]);
+        if (accp[1] != 0) atomicAdd(&gpoints[j * 2 + 1], accp[1]);
+    }
+}
+
+template <typename T>
+int loss_forward(const T *b1, int64_t n, const T *b2, int64_t m, int kind, T *out, hipStream_t st)
+{
+    const dim3 grid((unsigned)d3d_divup(m, kCols), (unsigned)d3d_divup(n, kRows));
+    if (kind == 0) D3D_LAUNCH("k_loss_iou<giou>", (k_loss_iou<T, 0>), grid, dim3(kCols), 0, st, b1, n, b2, m, out);
+    else D3D_LAUNCH("k_loss_iou<diou>", (k_loss_iou<T, 1>), grid, dim3(kCols), 0, st, b1, n, b2, m, out);
+    return D3D_OK;
+}
+
+template <typename T>
+int loss_backward(const T *b1, int64_t n, const T *b2, int64_t m, const T *grad, int kind, T *g1, T *g2, hipStream_t st)
+{
+    D3D_HIP_CHECK(hipMemsetAsync(g1, 0, (size_t)n * 5 * sizeof(T), st));
+    D3D_HIP_CHECK(hipMemsetAsync(g2, 0, (size_t)m * 5 * sizeof(T), st));
+    const dim3 grid((unsigned)d3d_divup(m, kCols), (unsigned)d3d_divup(n, kRows));
+    if (kind == 0) D3D_LAUNCH("k_loss_iou_grad<giou>", (k_loss_iou_grad<T, 0>), grid, dim3(kCols), 0, st, b1, n, b2, m, grad, g1, g2);
+    else D3D_LAUNCH("k_loss_iou_grad<diou>", (k_loss_iou_grad<T, 1>), grid, dim3(kCols), 0, st, b1, n, b2, m, grad, g1, g2);
+    return D3D_OK;
+}
+
+}  // namespace
+
+// called by d3d_iou2d_forward / d3d_iou2d_backward (box.hip) for iou_type GRBOX / DRBOX
+int d3d_internal_loss_iou_forward(const void *b1, int64_t n, const void *b2, int64_t m, int kind, int dtype, void *out, hipStream_t st)
+{
+    if (d3d_divup(n, kRows) > 65535) return D3D_ERR_BAD_ARG;
+    if (dtype == D3D_F64) return loss_forward<double>((const double *)b1, n, (const double *)b2, m, kind, (double *)out, st);
+    return loss_forward<float>((const float *)b1, n, (const float *)b2, m, kind, (float *)out, st);
+}
+
+int d3d_internal_loss_iou_backward(const void *b1, int64_t n, const void *b2, int64_t m, const void *grad, int kind, int dtype,
+                                   void *g1, void *g2, hipStream_t st)
+{
+    if (d3d_divup(n, kRows) > 65535) return D3D_ERR_BAD_ARG;
+    if (dtype == D3D_F64)
+        return loss_backward<double>((const double *)b1, n, (const double *)b2, m, (const double *)grad, kind, (double *)g1, (double *)g2, st);
+    return loss_backward<float>((const float *)b1, n, (const float *)b2, m, (const float *)grad, kind, (float *)g1, (float *)g2, st);
+}
+
+extern "C" int d3d_iou2dr_flags(const void *boxes1, int64_t n, const void *boxes2, int64_t m, int32_t dtype, uint8_t *nx,
+                                uint8_t *xflags, uint8_t *nm, uint8_t *mflags, uint8_t *far, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || m < 0 || (dtype != D3D_F32 && dtype != D3D_F64)) return D3D_ERR_BAD_ARG;
+    if (n == 0 || m == 0) return D3D_OK;
+    if (!boxes1 || !boxes2) return D3D_ERR_BAD_ARG;
+    if (((reinterpret_cast<uintptr_t>(xflags) | reinterpret_cast<uintptr_t>(mflags)) & 7)) return D3D_ERR_BAD_ARG;
+    const unsigned grid = (unsigned)(d3d_divup(n * m, 256) < 65536 ? d3d_divup(n * m, 256) : 65536);
+    if (dtype == D3D_F64)
+        D3D_LAUNCH("k_pair_flags", k_pair_flags<double>, dim3(grid), dim3(256), 0, st, (const double *)boxes1, n, (const double *)boxes2, m,
+                   nx, xflags, nm, mflags, far);
+    else
+        D3D_LAUNCH("k_pair_flags", k_pair_flags<float>, dim3(grid), dim3(256), 0, st, (const float *)boxes1, n, (const float *)boxes2, m,
+                   nx, xflags, nm, mflags, far);
+    return D3D_OK;
+}
+
+extern "C" int d3d_pdist2dr_forward(const void *points, int64_t n, const void *boxes, int64_t m, int32_t dtype, void *dist,
+                                    uint8_t *iedge, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || m < 0 || (dtype != D3D_F32 && dtype != D3D_F64)) return D3D_ERR_BAD_ARG;
+    if (n == 0 || m == 0) return D3D_OK;
+    if (!points || !boxes || !dist || d3d_divup(m, kRows) > 65535) return D3D_ERR_BAD_ARG;
+    const dim3 grid((unsigned)d3d_divup(n, kCols), (unsigned)d3d_divup(m, kRows));
+    if (dtype == D3D_F64)
+        D3D_LAUNCH("k_pdist", k_pdist<double>, grid, dim3(kCols), 0, st, (const double *)points, n, (const double *)boxes, m, (double *)dist, iedge);
+    else
+        D3D_LAUNCH("k_pdist", k_pdist<float>, grid, dim3(kCols), 0, st, (const float *)points, n, (const float *)boxes, m, (float *)dist, iedge);
+    return D3D_OK;
+}
+
+extern "C" int d3d_pdist2dr_backward(const void *points, int64_t n, const void *boxes, int64_t m, const void *grad, int32_t dtype,
+                                     void *grad_boxes, void *grad_points, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || m < 0 || (dtype != D3D_F32 && dtype != D3D_F64)) return D3D_ERR_BAD_ARG;
+    const size_t es = dtype == D3D_F64 ? 8 : 4;
+    if (m > 0) { if (!grad_boxes) return D3D_ERR_BAD_ARG; D3D_HIP_CHECK(hipMemsetAsync(grad_boxes, 0, (size_t)m * 5 * es, st)); }
+    if (n > 0) { if (!grad_points) return D3D_ERR_BAD_ARG; D3D_HIP_CHECK(hipMemsetAsync(grad_points, 0, (size_t)n * 2 * es, st)); }
+    if (n == 0 || m == 0) return D3D_OK;
+    if (!points || !boxes || !grad || d3d_divup(m, kRows) > 65535) return D3D_ERR_BAD_ARG;
+    const dim3 grid((unsigned)d3d_divup(n, kCols), (unsigned)d3d_divup(m, kRows));
+    if (dtype == D3D_F64)
+        D3D_LAUNCH("k_pdist_grad", k_pdist_grad<double>, grid, dim3(kCols), 0, st, (const double *)points, n, (const double *)boxes, m,
+                   (const double *)grad, (double *)grad_boxes, (double *)grad_points);
+    else
+        D3D_LAUNCH("k_pdist_grad", k_pdist_grad<float>, grid, dim3(kCols), 0, st, (const float *)points, n, (const float *)boxes, m,
+                   (const float *)grad, (float *)grad_boxes, (float *)grad_points);
+    return D3D_OK;
+}

@@ -248,3 +248,255 @@ __device__ __forceinline__ T iou_aabb_grad(const BoxGeom<T> &a, const BoxGeom<T>
     aabb_param_grad<T>(pb[2], pb[3], pb[4], b_x0, b_x1, b_y0, b_y1, 2 * by, 2 * bx, I, U, gb);
     return I / U;
 }
+
+// ---------------------------------------------------------------- GIoU / DIoU of rotated boxes (loss path)
+// GIoU = IoU - (H - U) / H,  H = area of the convex hull of the two rectangles, U = A1 + A2 - I
+// DIoU = IoU - d^2 / D^2,    d = distance of the centres, D = diameter of that hull (largest corner-to-corner distance)
+// (reference d3d/box/iou.cpp:213-419 calls dgal::giou / diou; dgal is not vendored -- these are the published definitions.)
+//
+// Hull area without a vertex list (a list would be dynamically indexed, i.e. live in scratch): the directed segment p -> q
+// between two of the eight corners is a hull edge (CCW) iff every other corner lies to its left.  Both quads are convex, so
+//   * an edge of A needs only B's four corners tested (A's own corners are on its left by convexity), and vice versa;
+//   * a bridge a_i -> b_j needs only the two neighbours of a_i and the two neighbours of b_j.
+// H = sum of cross(p, q) / 2 over the accepted segments: 160 cross products, fixed trip counts, registers only.
+// Ties: a corner exactly ON the line counts as "left" only if it lies within the closed segment (so of several collinear
+// candidates only the longest survives), and a segment whose end coincides with a lower-numbered corner (A's 0..3 before
+// B's 4..7) is dropped (coincident copies of one edge -- identical boxes -- are counted once).
+template <typename T> struct Corners8 { T x[8], y[8]; };    // 0..3 = A's corners, 4..7 = B's; relative to A's centre
+
+template <typename T>
+__device__ __forceinline__ Corners8<T> corners8(const BoxGeom<T> &a, const BoxGeom<T> &b)
+{
+    const T ox = b.cx - a.cx, oy = b.cy - a.cy;
+    Corners8<T> c;
+    c.x[0] = -a.ux - a.vx; c.y[0] = -a.uy - a.vy;  c.x[1] = a.ux - a.vx; c.y[1] = a.uy - a.vy;
+    c.x[2] = a.ux + a.vx;  c.y[2] = a.uy + a.vy;   c.x[3] = -a.ux + a.vx; c.y[3] = -a.uy + a.vy;
+    c.x[4] = ox - b.ux - b.vx; c.y[4] = oy - b.uy - b.vy;  c.x[5] = ox + b.ux - b.vx; c.y[5] = oy + b.uy - b.vy;
+    c.x[6] = ox + b.ux + b.vx; c.y[6] = oy + b.uy + b.vy;  c.x[7] = ox - b.ux + b.vx; c.y[7] = oy - b.uy + b.vy;
+    return c;
+}
+
+// is corner r acceptable for the candidate hull segment p -> q?  (ip, iq, ir: corner numbers, for the coincidence rule)
+template <typename T>
+__device__ __forceinline__ bool hull_side_ok(T px, T py, T qx, T qy, T rx, T ry, int ip, int iq, int ir)
+{
+    const T cr = (qx - px) * (ry - py) - (qy - py) * (rx - px);
+    if (cr > 0) return true;
+    if (cr < 0) return false;
+    // collinear: inside the closed segment?  (dot(r - p, q - r) >= 0)
+    if (!((rx - px) * (qx - rx) + (ry - py) * (qy - ry) >= 0)) return false;
+    // coincident with an end: the lower-numbered copy represents the point
+    if (rx == px && ry == py && ir < ip) return false;
+    if (rx == qx && ry == qy && ir < iq) return false;
+    return true;
+}
+
+// H2 = 2 * hull area; on request also d(H2)/d(corner k) as (gx[k], gy[k]) (each accepted segment p -> q adds
+// (q.y, -q.x) to p's and (-p.y, p.x) to q's)
+template <typename T, bool GRAD>
+__device__ __forceinline__ T hull_area2(const Corners8<T> &c, T (&gx)[8], T (&gy)[8])
+{
+    T h2 = 0;
+    if (GRAD) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { gx[k] = 0; gy[k] = 0; }
+    }
+    auto accept = [&](int p, int q) {
+        h2 += c.x[p] * c.y[q] - c.y[p] * c.x[q];
+        if (GRAD) { gx[p] += c.y[q]; gy[p] -= c.x[q]; gx[q] -= c.y[p]; gy[q] += c.x[p]; }
+    };
+    // edges of A (tested against B's corners) and of B (against A's)
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p = 4 * s + k, q = 4 * s + ((k + 1) & 3);
+            bool ok = true;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int r = 4 * (1 - s) + t;
+                ok = ok && hull_side_ok<T>(c.x[p], c.y[p], c.x[q], c.y[q], c.x[r], c.y[r], p, q, r);
+            }
+            if (ok) accept(p, q);
+        }
+    }
+    // bridges a_i -> b_j and b_j -> a_i
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int a = i, b = 4 + j;
+            const int an = (i + 1) & 3, ap = (i + 3) & 3, bn = 4 + ((j + 1) & 3), bp = 4 + ((j + 3) & 3);
+            if (c.x[a] == c.x[b] && c.y[a] == c.y[b]) continue;          // zero-length segment
+            bool ok = hull_side_ok<T>(c.x[a], c.y[a], c.x[b], c.y[b], c.x[an], c.y[an], a, b, an) &&
+                      hull_side_ok<T>(c.x[a], c.y[a], c.x[b], c.y[b], c.x[ap], c.y[ap], a, b, ap) &&
+                      hull_side_ok<T>(c.x[a], c.y[a], c.x[b], c.y[b], c.x[bn], c.y[bn], a, b, bn) &&
+                      hull_side_ok<T>(c.x[a], c.y[a], c.x[b], c.y[b], c.x[bp], c.y[bp], a, b, bp);
+            if (ok) accept(a, b);
+            ok = hull_side_ok<T>(c.x[b], c.y[b], c.x[a], c.y[a], c.x[an], c.y[an], b, a, an) &&
+                 hull_side_ok<T>(c.x[b], c.y[b], c.x[a], c.y[a], c.x[ap], c.y[ap], b, a, ap) &&
+                 hull_side_ok<T>(c.x[b], c.y[b], c.x[a], c.y[a], c.x[bn], c.y[bn], b, a, bn) &&
+                 hull_side_ok<T>(c.x[b], c.y[b], c.x[a], c.y[a], c.x[bp], c.y[bp], b, a, bp);
+            if (ok) accept(b, a);
+        }
+    }
+    return h2;
+}
+
+// largest squared corner-to-corner distance and the pair (i1 < i2, first in scan order) that reaches it
+template <typename T>
+__device__ __forceinline__ T diameter2(const Corners8<T> &c, int &i1, int &i2)
+{
+    T best = -1;
+    i1 = 0; i2 = 1;
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+#pragma unroll
+        for (int y = x + 1; y < 8; y++) {
+            const T dx = c.x[x] - c.x[y], dy = c.y[x] - c.y[y], d = dx * dx + dy * dy;
+            if (d > best) { best = d; i1 = x; i2 = y; }
+        }
+    }
+    return best;
+}
+
+// d(corner k of a box)/d(x, y, w, h, r): corner = centre + su * U + sv * V, U = (w/2)(cos, sin), V = (h/2)(-sin, cos),
+// (su, sv) = (-,-), (+,-), (+,+), (-,+) for k = 0..3.  Adds (gx, gy) . d(corner)/d(param) to g[5].
+template <typename T>
+__device__ __forceinline__ void corner_chain(const BoxGeom<T> &g, T w, T h, int k, T gx, T gy, T (&out)[5])
+{
+    const T su = (k == 1 || k == 2) ? (T)1 : (T)-1, sv = (k >= 2) ? (T)1 : (T)-1;
+    out[0] += gx;
+    out[1] += gy;
+    out[2] += su * (gx * g.ux + gy * g.uy) / w;           // dU/dw = U / w
+    out[3] += sv * (gx * g.vx + gy * g.vy) / h;
+    const T rx = su * g.ux + sv * g.vx, ry = su * g.uy + sv * g.vy;      // corner - centre; d/dr = perp
+    out[4] += -gx * ry + gy * rx;
+}
+
+// GIoU (KIND 0) / DIoU (KIND 1) of one pair, optionally with the 5 + 5 partial derivatives
+template <typename T, int KIND, bool GRAD>
+__device__ __forceinline__ T loss_iou_rbox(const BoxGeom<T> &a, const BoxGeom<T> &b, T w1, T h1, T w2, T h2, T (&ga)[5], T (&gb)[5])
+{
+    if (GRAD) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) { ga[k] = 0; gb[k] = 0; }
+    }
+    if (!(a.area > 0) || !(b.area > 0)) return 0;          // degenerate boxes: 0, never NaN (as for IoU)
+    // IoU part (value I / U and, on request, its gradient pieces)
+    T I = 0, dIa[5] = {0, 0, 0, 0, 0}, dIb[5] = {0, 0, 0, 0, 0};
+    if (!aabb_disjoint(a, b)) {
+        if (GRAD) {
+            T ta[5], tb[5];
+            const T iou = iou_rbox_grad<T>(a, b, w1, h1, w2, h2, ta, tb);
+            // iou_rbox_grad returns d(I/U); recover I and dI from it:  I = iou U', with U' = (A1 + A2) / (1 + iou)
+            I = iou * (a.area + b.area) / (1 + iou);
+            const T U = a.area + b.area - I;
+            const T dA1[5] = {0, 0, h1, w1, 0}, dA2[5] = {0, 0, h2, w2, 0};
+#pragma unroll
+            for (int k = 0; k < 5; k++) {      // d(I/U) = (dI (U + I) - I dA) / U^2  ->  dI
+                dIa[k] = (ta[k] * U * U + I * dA1[k]) / (U + I);
+                dIb[k] = (tb[k] * U * U + I * dA2[k]) / (U + I);
+            }
+        } else {
+            I = intersection_area(a, b);
+            if (!(I > 0)) I = 0;
+        }
+    }
+    const T U = a.area + b.area - I, iou = I / U;
+    const Corners8<T> c = corners8(a, b);
+    const T dA1[5] = {0, 0, h1, w1, 0}, dA2[5] = {0, 0, h2, w2, 0};
+    if (KIND == 0) {
+        T gx[8], gy[8];
+        const T H = hull_area2<T, GRAD>(c, gx, gy) / 2;
+        if (GRAD) {
+            T dHa[5] = {0, 0, 0, 0, 0}, dHb[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                corner_chain<T>(a, w1, h1, k, gx[k] / 2, gy[k] / 2, dHa);
+                corner_chain<T>(b, w2, h2, k, gx[4 + k] / 2, gy[4 + k] / 2, dHb);
+            }
+            // GIoU = I/U - 1 + U/H
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const T dUa = dA1[k] - dIa[k], dUb = dA2[k] - dIb[k];
+                ga[k] = (dIa[k] * U - I * dUa) / (U * U) + (dUa * H - U * dHa[k]) / (H * H);
+                gb[k] = (dIb[k] * U - I * dUb) / (U * U) + (dUb * H - U * dHb[k]) / (H * H);
+            }
+        }
+        return iou - (H - U) / H;
+    }
+    int i1, i2;
+    const T D2 = diameter2<T>(c, i1, i2);
+    const T ox = b.cx - a.cx, oy = b.cy - a.cy, d2 = ox * ox + oy * oy;
+    if (GRAD) {
+        // d(D2) = 2 (p - q) . (dp - dq)
+        const T ex = 2 * (c.x[i1] - c.x[i2]), ey = 2 * (c.y[i1] - c.y[i2]);
+        T dDa[5] = {0, 0, 0, 0, 0}, dDb[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const T s1 = (i1 == k ? (T)1 : (T)0) - (i2 == k ? (T)1 : (T)0);
+            const T s2 = (i1 == 4 + k ? (T)1 : (T)0) - (i2 == 4 + k ? (T)1 : (T)0);
+            if (s1 != 0) corner_chain<T>(a, w1, h1, k, s1 * ex, s1 * ey, dDa);
+            if (s2 != 0) corner_chain<T>(b, w2, h2, k, s2 * ex, s2 * ey, dDb);
+        }
+        const T dda[5] = {-2 * ox, -2 * oy, 0, 0, 0}, ddb[5] = {2 * ox, 2 * oy, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const T dUa = dA1[k] - dIa[k], dUb = dA2[k] - dIb[k];
+            ga[k] = (dIa[k] * U - I * dUa) / (U * U) - (dda[k] * D2 - d2 * dDa[k]) / (D2 * D2);
+            gb[k] = (dIb[k] * U - I * dUb) / (U * U) - (ddb[k] * D2 - d2 * dDb[k]) / (D2 * D2);
+        }
+    }
+    return iou - d2 / D2;
+}
+
+// ---------------------------------------------------------------- signed point-to-box distance (pdist2dr)
+// positive inside, negative outside (reference box/__init__.py:370-381 relies on that sign); feat = nearest edge k
+// (corner k -> k + 1) or 4 + k when the nearest boundary point is corner k.  On request the gradient w.r.t. the point
+// (gp) and the box parameters (gb).
+template <typename T, bool GRAD>
+__device__ __forceinline__ T point_box_distance(const BoxGeom<T> &b, T w, T h, T px, T py, int &feat, T (&gp)[2], T (&gb)[5])
+{
+    const T rx0 = px - b.cx, ry0 = py - b.cy;                     // relative to the centre
+    const T cx[4] = {-b.ux - b.vx, b.ux - b.vx, b.ux + b.vx, -b.ux + b.vx};
+    const T cy[4] = {-b.uy - b.vy, b.uy - b.vy, b.uy + b.vy, -b.uy + b.vy};
+    T best = -1, bdx = 0, bdy = 0;
+    bool inside = true;
+    feat = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const T ex = cx[(e + 1) & 3] - cx[e], ey = cy[(e + 1) & 3] - cy[e], rx = rx0 - cx[e], ry = ry0 - cy[e];
+        if (ex * ry - ey * rx < 0) inside = false;
+        const T len2 = ex * ex + ey * ey;
+        T t = len2 > 0 ? (rx * ex + ry * ey) / len2 : 0;
+        int f = e;
+        if (t <= 0) { t = 0; f = 4 + e; } else if (t >= 1) { t = 1; f = 4 + ((e + 1) & 3); }
+        const T dx = rx - t * ex, dy = ry - t * ey, d2 = dx * dx + dy * dy;
+        if (best < 0 || d2 < best) { best = d2; feat = f; bdx = dx; bdy = dy; }
+    }
+    const T d = sqrt(best);
+    if (GRAD) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) gb[k] = 0;
+        gp[0] = 0; gp[1] = 0;
+        if (feat >= 4) {
+            // nearest boundary point = corner k: dist = -|p - c_k| (a corner is never the nearest point of an interior point)
+            if (d > 0) {
+                const T nx = bdx / d, ny = bdy / d;               // (p - c_k) / |p - c_k|
+                gp[0] = -nx; gp[1] = -ny;
+                corner_chain<T>(b, w, h, feat - 4, nx, ny, gb);
+            }
+        } else {
+            // nearest point inside edge k: dist = n . (p - c_k) with n the inward unit normal (left of the edge direction)
+            const int k = feat;
+            const T ex = cx[(k + 1) & 3] - cx[k], ey = cy[(k + 1) & 3] - cy[k], len = sqrt(ex * ex + ey * ey);
+            const T nx = -ey / len, ny = ex / len;
+            gp[0] = nx; gp[1] = ny;
+            corner_chain<T>(b, w, h, k, -nx, -ny, gb);           // - n . d(c_k)
+            // the normal turns with the box: dn/dr = perp(n);  (dn/dr) . (p - c_k)
+            gb[4] += -ny * (rx0 - cx[k]) + nx * (ry0 - cy[k]);
+        }
+    }
+    return inside ? d : -d;
+}

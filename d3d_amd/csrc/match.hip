@@ -1,0 +1,175 @@
+// match.hip -- the association step of the detection evaluator on MI355X (gfx950).
+// Replaces ScoreMatcher.match + BaseMatcher.match_by_order (reference d3d/tracking/matcher.pyx:83-162) as
+// DetectionEvaluator.calc_stats drives them (d3d/benchmarks.pyx:218-238): boxes to match ("src", detections) are taken from
+// the best score down; each takes the nearest still-unassigned fixed box ("dst", ground truth) of its own category whose
+// distance is within that category's threshold.
+//
+// The reference re-sorts the whole n x m distance matrix for every score threshold (40 argsorts of 20 k x 5 k floats at
+// config 4).  Two observations make one pass enough:
+//   * a detection's choice depends only on the detections before it in score order, and every threshold's subset is a
+//     PREFIX of that order -- so the matching of the full set, cut at a score, IS the matching of that threshold;
+//   * only the pairs within the distance threshold can ever match -- a handful per row.
+// k_match_candidates lists those per row (one wavefront per row: coalesced sweep, ballot compaction, 64-key bitonic sort by
+// (distance, index) in registers); k_match_greedy walks the rows in score order in ONE wavefront: the 64 lanes test a row's
+// candidates against the assignment bitmap at once and the first free one (ballot + ffs) is taken.
+#include "common.hpp"
+#include <math.h>
+
+namespace {
+
+constexpr int kMaxCand = 64;            // candidates kept per row (one per lane); more -> overflow flag, caller falls back
+
+__device__ __forceinline__ bool pair_less(float d1, int j1, float d2, int j2) { return d1 < d2 || (d1 == d2 && j1 < j2); }
+
+// dist[n,m]; src_tag[n], dst_tag[m] categories (negative: not taking part); thr[m] = distance threshold of dst j's category
+__global__ __launch_bounds__(256) void k_match_candidates(const float *__restrict__ dist, int64_t n, int64_t m,
+                                                          const int32_t *__restrict__ src_tag, const int32_t *__restrict__ dst_tag,
+                                                          const float *__restrict__ thr, int32_t *cand_dst, float *cand_dist,
+                                                          int32_t *cand_cnt, int32_t *overflow)
+{
+    __shared__ float sd[256 / kWave][kMaxCand];
+    __shared__ int sj[256 / kWave][kMaxCand];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * (256 / kWave) + w;
+    if (row >= n) return;                       // (no workgroup barrier below: wavefronts are independent)
+    const int32_t tag = src_tag[row];
+    sd[w][lane] = INFINITY;
+    sj[w][lane] = 0x7fffffff;
+    int found = 0;
+    if (tag >= 0) {
+        const float *drow = dist + row * m;
+        for (int64_t j0 = 0; j0 < m; j0 += kWave) {
+            const int64_t j = j0 + lane;
+            float d = INFINITY;
+            bool ok = false;
+            if (j < m) {
+                d = drow[j];
+                ok = dst_tag[j] == tag && d <= thr[j];
+            }
+            const unsigned long long mask = __ballot(ok);
+            if (!mask) continue;
+            const int slot = found + __popcll(mask & ((1ull << lane) - 1));
+            if (ok && slot < kMaxCand) { sd[w][slot] = d; sj[w][slot] = (int)j; }
+            found += __popcll(mask);
+        }
+    }
+    if (found > kMaxCand && lane == 0) atomicOr(overflow, 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();            // LDS ops of one wavefront complete in order
+    float bd = sd[w][lane];
+    int bj = sj[w][lane];
+    // bitonic sort of the 64 (distance, index) pairs across the lanes, ascending; empty lanes hold (inf, max)
+#pragma unroll
+    for (int k = 2; k <= kWave; k <<= 1) {
+#pragma unroll
+        for (int s2 = k >> 1; s2 > 0; s2 >>= 1) {
+            const float od = __shfl_xor(bd, s2, kWave);
+            const int oj = __shfl_xor(bj, s2, kWave);
+            const bool up = (lane & k) == 0, lower = (lane & s2) == 0;
+            const bool other_less = pair_less(od, oj, bd, bj);
+            // ascending block: the lower lane keeps the smaller; descending block: the larger
+            const bool take = (up == lower) ? other_less : (!other_less && (od != bd || oj != bj));
+            if (take) { bd = od; bj = oj; }
+        }
+    }
+    cand_dst[row * kMaxCand + lane] = bj;
+    cand_dist[row * kMaxCand + lane] = bd;
+    if (lane == 0) cand_cnt[row] = found < kMaxCand ? found : kMaxCand;
+}
+
+// order[n]: src rows from the best score down; src_match[n], dst_match[m] <- partner or -1.  ONE wavefront: 64 rows'
+// candidate lists are staged in LDS at a time (64 independent loads in flight), then the rows are decided one after the other
+// from LDS: the 64 lanes test a row's candidates against the assignment bitmap at once, the first free one (ballot + ffs)
+// is taken.  The bitmap lives in LDS (dynamic, m <= 256 k) -- else in global memory, read and written with agent-scope atomics.
+template <bool LDS_MAP>
+__global__ __launch_bounds__(64) void k_match_greedy(const int64_t *__restrict__ order, int64_t n, int64_t m,
+                                                     const int32_t *__restrict__ cand_dst, const int32_t *__restrict__ cand_cnt,
+                                                     int32_t *src_match, int32_t *dst_match, unsigned int *taken_g /* zeroed */)
+{
+    extern __shared__ unsigned int taken_l[];
+    __shared__ int stage[kWave][kMaxCand];
+    const int lane = threadIdx.x;
+    const int64_t nwords = (m + 31) / 32;
+    if (LDS_MAP)
+        for (int64_t t = lane; t < nwords; t += kWave) taken_l[t] = 0;
+    for (int64_t j = lane; j < m; j += kWave) dst_match[j] = -1;
+    for (int64_t p0 = 0; p0 < n; p0 += kWave) {
+        const int rows = (int)(n - p0 < kWave ? n - p0 : kWave);
+        const int64_t myrow = lane < rows ? order[p0 + lane] : 0;
+        const int mycnt = lane < rows ? cand_cnt[myrow] : 0;
+        for (int r = 0; r < rows; r++) {
+            const int64_t row = __shfl(myrow, r, kWave);
+            stage[r][lane] = cand_dst[row * kMaxCand + lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int mypick = -1;
+        for (int r = 0; r < rows; r++) {
+            const int cnt = __shfl(mycnt, r, kWave);
+            const int64_t rowr = __shfl(myrow, r, kWave);
+            if (cnt == 0) continue;
+            const int dst = lane < cnt ? stage[r][lane] : -1;
+            bool free_ = false;
+            if (dst >= 0) {
+                const unsigned int word = LDS_MAP ? taken_l[dst >> 5]
+                                                  : __hip_atomic_load(&taken_g[dst >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                free_ = ((word >> (dst & 31)) & 1u) == 0;
+            }
+            const unsigned long long mask = __ballot(free_);
+            if (mask) {
+                const int l = __ffsll((long long)mask) - 1;                      // nearest free one
+                const int pick = __shfl(dst, l, kWave);
+                if (lane == l) {
+                    if (LDS_MAP) taken_l[dst >> 5] |= 1u << (dst & 31);
+                    else atomicOr(&taken_g[dst >> 5], 1u << (dst & 31));
+                    dst_match[dst] = (int32_t)rowr;
+                }
+                if (lane == r) mypick = pick;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane < rows) src_match[myrow] = mypick;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t d3d_score_match_workspace_bytes(int64_t n, int64_t m)
+{
+    if (n < 1) n = 1;
+    if (m < 1) m = 1;
+    return d3d_align_up((size_t)n * kMaxCand * 4) * 2 + d3d_align_up((size_t)n * 4) + d3d_align_up(((size_t)m + 31) / 32 * 4) + 512;
+}
+
+// status word (device, int32): bit 0 = some row had more than 64 candidates (results then cover its 64 nearest only)
+extern "C" int d3d_score_match(const float *dist, int64_t n, int64_t m, const int32_t *src_tag, const int32_t *dst_tag,
+                               const float *dst_threshold, const int64_t *order, int32_t *src_match, int32_t *dst_match,
+                               int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || m < 0 || !status) return D3D_ERR_BAD_ARG;
+    D3D_HIP_CHECK(hipMemsetAsync(status, 0, 4, st));
+    if (m > 0 && !dst_match) return D3D_ERR_BAD_ARG;
+    if (n == 0) { if (m > 0) D3D_HIP_CHECK(hipMemsetAsync(dst_match, 0xff, (size_t)m * 4, st)); return D3D_OK; }
+    if (!src_match || !src_tag || !order) return D3D_ERR_BAD_ARG;
+    if (m == 0) { D3D_HIP_CHECK(hipMemsetAsync(src_match, 0xff, (size_t)n * 4, st)); return D3D_OK; }
+    if (!dist || !dst_tag || !dst_threshold || m >= (1ll << 31) || n >= (1ll << 31)) return D3D_ERR_BAD_ARG;
+    WsCarver w(workspace, workspace_bytes);
+    int32_t *cand_dst = w.take<int32_t>((size_t)n * kMaxCand);
+    float *cand_dist = w.take<float>((size_t)n * kMaxCand);
+    int32_t *cand_cnt = w.take<int32_t>((size_t)n);
+    unsigned int *taken = w.take<unsigned int>(((size_t)m + 31) / 32);
+    if (!workspace || !w.ok()) return D3D_ERR_WORKSPACE;
+    D3D_HIP_CHECK(hipMemsetAsync(taken, 0, ((size_t)m + 31) / 32 * 4, st));
+    D3D_LAUNCH("k_match_candidates", k_match_candidates, dim3((unsigned)d3d_divup(n, 256 / kWave)), dim3(256), 0, st, dist, n, m,
+               src_tag, dst_tag, dst_threshold, cand_dst, cand_dist, cand_cnt, status);
+    const size_t map_bytes = ((size_t)m + 31) / 32 * 4;
+    if (map_bytes <= 32 * 1024)          // (+ 16 KB of staging: inside the 64 KB a workgroup gets without opting in)
+        D3D_LAUNCH("k_match_greedy", k_match_greedy<true>, dim3(1), dim3(64), map_bytes, st, order, n, m, (const int32_t *)cand_dst,
+                   (const int32_t *)cand_cnt, src_match, dst_match, taken);
+    else
+        D3D_LAUNCH("k_match_greedy", k_match_greedy<false>, dim3(1), dim3(64), 0, st, order, n, m, (const int32_t *)cand_dst,
+                   (const int32_t *)cand_cnt, src_match, dst_match, taken);
+    return D3D_OK;
+}

@@ -103,7 +103,10 @@ struct DenseKey {
     }
 };
 
-// sparse contract: coord = floor(p / size), unbounded (voxelize.cpp:309); 3 x 21-bit packing
+// sparse contract: coord = floor(p / size), unbounded (voxelize.cpp:309); 3 x 21-bit packing.  Field value 0 is the
+// reference's INT_MIN: what its (int)floor(..) yields on x86 (cvttss2si) for NaN, +-inf and |q| >= 2^31 -- real frames
+// carry NaN no-return points, and the reference files them under such a voxel (which any coordinate-bound filter then
+// drops).  Finite coordinates are held for (-2^20, 2^20); beyond that: COORD_OVERFLOW (or dropped, see `tolerant`).
 struct SparseKey {
     static constexpr bool kBox = false;
     typedef u64 bin_key_t;
@@ -119,17 +122,21 @@ struct SparseKey {
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             float q = floorf(p[d] / size[d]);
-            if (!(q >= -1048576.0f && q < 1048576.0f)) { if (!tolerant) status |= D3D_VOXEL_STATUS_COORD_OVERFLOW; return false; }
-            k = (k << 21) | (u64)(unsigned)((int)q + 1048576);
+            unsigned field;
+            if (!(q >= -2147483648.0f && q < 2147483648.0f)) field = 0u;          // NaN / inf / beyond int: INT_MIN
+            else if (!(q > -1048576.0f && q < 1048576.0f)) { if (!tolerant) status |= D3D_VOXEL_STATUS_COORD_OVERFLOW; return false; }
+            else field = (unsigned)((int)q + 1048576);
+            k = (k << 21) | (u64)field;
         }
         key = k;
         return true;
     }
+    static __device__ __forceinline__ long long field_coord(u64 f) { return f ? (long long)f - 1048576 : -2147483648ll; }
     __device__ __forceinline__ void decode(u64 key, long long *c) const
     {
-        c[2] = (long long)(key & 0x1fffff) - 1048576;
-        c[1] = (long long)((key >> 21) & 0x1fffff) - 1048576;
-        c[0] = (long long)((key >> 42) & 0x1fffff) - 1048576;
+        c[2] = field_coord(key & 0x1fffff);
+        c[1] = field_coord((key >> 21) & 0x1fffff);
+        c[0] = field_coord((key >> 42) & 0x1fffff);
     }
 };
 
@@ -159,7 +166,9 @@ struct BoxKey {
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             float q = floorf(p[d] / size[d]);
-            if (!(q >= -1048576.0f && q < 1048576.0f)) { if (!tolerant) status |= D3D_VOXEL_STATUS_COORD_OVERFLOW; return false; }
+            // non-finite / beyond int: the reference's INT_MIN voxel has no place in a bounding box -> general slots
+            if (!(q >= -2147483648.0f && q < 2147483648.0f)) { status |= D3D_VOXEL_STATUS_PACK_OVERFLOW; return false; }
+            if (!(q > -1048576.0f && q < 1048576.0f)) { if (!tolerant) status |= D3D_VOXEL_STATUS_COORD_OVERFLOW; return false; }
             c[d] = (int)q;
         }
         return true;

@@ -47,7 +47,8 @@ enum { D3D_SUPPRESS_HARD = 0, D3D_SUPPRESS_LINEAR = 1, D3D_SUPPRESS_GAUSSIAN = 2
 enum { D3D_F32 = 0, D3D_F64 = 1 };
 
 /* status bits OR-ed into counts[D3D_COUNT_STATUS] by the voxel kernels */
-enum { D3D_VOXEL_STATUS_COORD_OVERFLOW = 1,   /* sparse: |floor(p/size)| >= 2^20 (or NaN)      */
+enum { D3D_VOXEL_STATUS_COORD_OVERFLOW = 1,   /* sparse: 2^20 <= |floor(p/size)| < 2^31 (NaN, inf and
+                                                 larger values become the reference's INT_MIN coordinate) */
        D3D_VOXEL_STATUS_TABLE_FULL = 2,       /* internal hash table overflow (cannot happen
                                                  with the documented workspace size)           */
        D3D_VOXEL_STATUS_PACK_OVERFLOW = 4,    /* a voxel holds more points than the packed one-word
@@ -148,9 +149,10 @@ int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int32_t c, con
  * lets the TRIM point filter reuse the per-voxel index ranking the sparse index already holds (voxelize.cpp:457-463)
  * and the voxel filter run inside the index (up to 8 M points, filters NONE / TRIM): points_mapping, coords and npoints
  * are then scratch (not materialised), sparse_counts holds the status bits.
- * Points outside the 3 x 21-bit key range (non-finite, |floor(p/size)| >= 2^20) are DROPPED here, as the reference's
- * coordinate-bound filter drops the far-away voxel it gives them (voxelize.cpp:309, :376-384), as long as coords_bound
- * lies inside [-2^20, 2^20]; d3d_voxelize_3d_sparse alone raises D3D_VOXEL_STATUS_COORD_OVERFLOW for them.
+ * Non-finite points get the reference's INT_MIN coordinate on that axis (x86 (int)floor(NaN), voxelize.cpp:309) and are
+ * then removed by the coordinate-bound filter exactly as there (:376-384).  Finite points outside the 3 x 21-bit key range
+ * (2^20 <= |floor(p/size)| < 2^31) are DROPPED here as long as coords_bound lies inside [-2^20, 2^20] -- the same filter
+ * would remove their far-away voxel; d3d_voxelize_3d_sparse alone raises D3D_VOXEL_STATUS_COORD_OVERFLOW for them.
  * Workspace: d3d_voxelize_workspace_bytes(n, n).  host_counts: NULL, or 2 * D3D_NUM_COUNTS + 1 int64 of host-mapped
  * pinned memory with word [D3D_NUM_COUNTS] cleared: receives sparse_counts in [0, 4), counts in [5, 9) and then the flag
  * [4] = 1 before the last kernel (the compaction of the kept points) is launched -- see d3d_voxelize_3d_dense_notify. */
@@ -265,11 +267,15 @@ int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream);
 
 /* -------------------------------------------------------------------- d3d/box */
 
-/* replaces iou2d_forward[_cuda] (method BOX) and the `ious` output of
- * iou2dr_forward[_cuda] (method RBOX)  (reference d3d/box/iou.h:7-24, iou.cpp:12-46,95-141,
- * iou_cuda.cu:10-48,100-151).  boxes1[n,5], boxes2[m,5] = (x,y,w,h,r) in `dtype`;
+/* replaces iou2d_forward[_cuda] (iou_type BOX), the `ious` output of iou2dr_forward[_cuda] (RBOX), of giou2dr_forward[_cuda]
+ * (GRBOX) and of diou2dr_forward[_cuda] (DRBOX)  (reference d3d/box/iou.h:7-69, iou.cpp:12-46,95-141,213-258,322-367,
+ * iou_cuda.cu:10-48,100-151,216-440).  boxes1[n,5], boxes2[m,5] = (x,y,w,h,r) in `dtype`;
  * ious[n,m] in `dtype`, row-major.  64-bit pair indexing (cf. iou_cuda.cu:36,137).  The workspace is optional
- * (NULL/0 selects the single-kernel path); with it RBOX runs as zero-fill + candidate list + dense clipping. */
+ * (NULL/0 selects the single-kernel path); with it RBOX runs as zero-fill + candidate list + dense clipping.
+ * GIoU = IoU - (H - U) / H, H = area of the convex hull of the two rectangles, U = union area; DIoU = IoU - d^2 / D^2,
+ * d = distance of the centres, D = diameter of that hull (dgal's source is not vendored: the published definitions);
+ * a rectangle of non-positive area gives 0 for every type.  GBOX / DBOX are D3D_ERR_UNSUPPORTED (the reference's Python
+ * layer raises "Unrecognized iou type!" for them, box/__init__.py:216-217). */
 size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype);
 int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t m,
                       int32_t iou_type, int32_t dtype, void *ious,
@@ -278,13 +284,37 @@ int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t
  * overflow -> single-kernel fallback) */
 #define D3D_IOU_LIST_CAP(k) ((uint32_t)(k) << 8)
 
-/* replaces iou2d_backward[_cuda] (BOX) and iou2dr_backward[_cuda] (RBOX) ("next" row; reference iou.h:14-24,32-40,
- * iou.cpp:48-93,143-211): grad[n,m] -> grad_boxes1[n,5], grad_boxes2[m,5] (overwritten), all in `dtype`.  The
- * overlap flags the reference saves in forward (nx, xflags) are not needed: the clip is recomputed.
- * Workspace: d3d_iou2d_workspace_bytes(n, m, dtype). */
+/* replaces iou2d_backward[_cuda] (BOX), iou2dr_backward[_cuda] (RBOX), giou2dr_backward[_cuda] (GRBOX) and
+ * diou2dr_backward[_cuda] (DRBOX)  (reference iou.h:14-69, iou.cpp:48-93,143-211,260-320,369-419): grad[n,m] ->
+ * grad_boxes1[n,5], grad_boxes2[m,5] (overwritten), all in `dtype`.  The flags the reference saves in forward (nx,
+ * xflags, ...) are not needed: the geometry is recomputed analytically.
+ * Workspace: d3d_iou2d_workspace_bytes(n, m, dtype) (BOX / RBOX; unused for GRBOX / DRBOX). */
 int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *boxes2, int64_t m, const void *grad,
                        int32_t iou_type, int32_t dtype, void *grad_boxes1, void *grad_boxes2,
                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* the autograd bookkeeping outputs of iou2dr_forward (nx, xflags: iou.cpp:125-141), giou2dr_forward (nxm = {nx, nm},
+ * xmflags = {xflags, mflags}: iou.cpp:243-258) and diou2dr_forward (nxd = {nx, far[0], far[1]}, xflags: iou.cpp:352-367).
+ * Any output pointer may be NULL.  Per pair (i, j), row-major:
+ *   nx[n,m]        vertex count of the intersection polygon (0 when there is none)
+ *   xflags[n,m,8]  origin of its vertices, CCW: 0x00 | c = corner c of box 1 (inside box 2); 0x10 | c = corner c of box 2;
+ *                  0x20 | e1 << 2 | e2 = crossing of edge e1 of box 1 (corner e1 -> e1 + 1) with edge e2 of box 2; 0xff unused
+ *   nm[n,m], mflags[n,m,8]   vertex count of the convex hull of the two rectangles and the corner (0..3 box 1, 4..7 box 2)
+ *                  at every hull vertex, CCW from the lowest (x, y); 0xff unused
+ *   far[n,m,2]     the two corners (same numbering, far[0] < far[1]) farthest apart -- the hull's diameter
+ * (dgal's own flag encoding is not published; this library's backward ignores the arrays.)  xflags / mflags 8-byte aligned. */
+int d3d_iou2dr_flags(const void *boxes1, int64_t n, const void *boxes2, int64_t m, int32_t dtype, uint8_t *nx,
+                     uint8_t *xflags, uint8_t *nm, uint8_t *mflags, uint8_t *far, void *stream);
+
+/* replaces pdist2dr_forward[_cuda] / pdist2dr_backward[_cuda] (reference d3d/box/dist.h:7-20, dist.cpp:10-110,
+ * dist_cuda.cu:10-80; Python box2dr_pdist / box3dr_pdist, box/__init__.py:333-381): SIGNED distance from points[n,2] to the
+ * boundary of boxes[m,5], positive inside; dist[m,n] (box-major, as dist.cpp:39), iedge[m,n] (may be NULL) = nearest edge k
+ * (corner k -> k + 1) or 4 + k when the nearest boundary point is corner k.  backward: grad[m,n] -> grad_boxes[m,5],
+ * grad_points[n,2] (both overwritten; the reference's CUDA kernel accumulates them with a data race, dist_cuda.cu:78-79). */
+int d3d_pdist2dr_forward(const void *points, int64_t n, const void *boxes, int64_t m, int32_t dtype, void *dist,
+                         uint8_t *iedge, void *stream);
+int d3d_pdist2dr_backward(const void *points, int64_t n, const void *boxes, int64_t m, const void *grad, int32_t dtype,
+                          void *grad_boxes, void *grad_points, void *stream);
 
 /* batched box3dr_iou (rotated=1) / box3d_iou (rotated=0)
  * (reference d3d/dgal_wrap.h:45-91; pair loop d3d/tracking/matcher.pyx:57-80).
@@ -292,6 +322,26 @@ int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *boxes2, int64_
 size_t d3d_iou3d_workspace_bytes(int64_t n, int64_t m);
 int d3d_iou3d_forward(const float *boxes1, int64_t n, const float *boxes2, int64_t m,
                       int32_t rotated, float *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* replaces the pair loops of BaseMatcher.prepare_boxes (reference d3d/tracking/matcher.pyx:46-80) for the metrics IoU
+ * (rotated = 0: box3d_iou) and RIoU (rotated = 1: box3dr_iou): src[n,9], dst[m,9] f32 rows = (label, score, x, y, z, lx, ly,
+ * lz, yaw) as Target3DArray.to_numpy lays them out (abstraction.pyx:263-272); the dimensions are clipped to +-1e3
+ * (matcher.pyx:49-51); cache[n,m] f32 = 1 - iou.  Workspace: d3d_iou3d_workspace_bytes(n, m) (optional). */
+int d3d_match_distance(const float *src, int64_t n, const float *dst, int64_t m, int32_t rotated, float *cache,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* replaces ScoreMatcher.match + match_by_order (reference d3d/tracking/matcher.pyx:83-162) as the detection evaluator
+ * drives them once per score threshold (d3d/benchmarks.pyx:218-238).  dist[n,m] f32 (d3d_match_distance); src_tag[n],
+ * dst_tag[m] i32 categories (negative = takes no part); dst_threshold[m] f32 = distance threshold of dst j's category;
+ * order[n] i64 = src rows from the best score down.  Every src row, in that order, takes the nearest unassigned dst of its
+ * own category with dist <= threshold (ties: lower index).  src_match[n], dst_match[m] i32 = partner or -1.  Because a
+ * row's choice depends only on the rows before it, the matching restricted to the first k rows of `order` IS the matching of
+ * the score threshold that selects them: one call serves all thresholds.  status (device i32): bit 0 = a row had more than
+ * 64 dst within its threshold (only its 64 nearest were considered). */
+size_t d3d_score_match_workspace_bytes(int64_t n, int64_t m);
+int d3d_score_match(const float *dist, int64_t n, int64_t m, const int32_t *src_tag, const int32_t *dst_tag,
+                    const float *dst_threshold, const int64_t *order, int32_t *src_match, int32_t *dst_match,
+                    int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 
 /* replaces crop_2dr (reference d3d/box/utils.cpp:9-47, bound at box/impl.cpp as crop_2dr; Python box2dr_crop /
  * box3dp_crop, box/__init__.py:278-315): points[n,2], boxes[m,5] in `dtype`; out[m,n] u8 (0/1),

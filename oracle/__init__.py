@@ -261,6 +261,50 @@ def aabb_candidate_pairs(b1, b2=None):
     return np.concatenate(out_i).astype(np.int64), np.concatenate(out_j).astype(np.int64)
 
 
+def loss_iou2dr(b1, b2, kind, nthreads=1):
+    """giou2dr_forward (kind "grbox") / diou2dr_forward (kind "drbox") values (iou.cpp:213-258, 322-367), in the dtype of b1"""
+    k = {"GRBOX": 0, "DRBOX": 1}[kind.upper()]
+    dt = np.float64 if b1.dtype == np.float64 else np.float32
+    b1 = np.ascontiguousarray(b1, dtype=dt)
+    b2 = np.ascontiguousarray(b2, dtype=dt)
+    n, m = b1.shape[0], b2.shape[0]
+    out = np.empty((n, m), dt)
+    f = lib().oracle_loss_iou2dr_f64 if dt == np.float64 else lib().oracle_loss_iou2dr_f32
+    f.restype = None
+
+    def run(r0, r1):
+        f(_p(b1), ctypes.c_int64(n), _p(b2), ctypes.c_int64(m), ctypes.c_int(k), ctypes.c_int64(r0), ctypes.c_int64(r1), _p(out))
+    _run_rows(run, n, nthreads)
+    return out
+
+
+def iou2dr_flags(b1, b2):
+    """autograd bookkeeping of the rotated IoU family -> Dict(nx[n,m], xflags[n,m,8], nm[n,m], mflags[n,m,8], far[n,m,2])"""
+    dt = np.float64 if b1.dtype == np.float64 else np.float32
+    b1 = np.ascontiguousarray(b1, dtype=dt)
+    b2 = np.ascontiguousarray(b2, dtype=dt)
+    n, m = b1.shape[0], b2.shape[0]
+    r = Dict(nx=np.empty((n, m), np.uint8), xflags=np.empty((n, m, 8), np.uint8), nm=np.empty((n, m), np.uint8),
+             mflags=np.empty((n, m, 8), np.uint8), far=np.empty((n, m, 2), np.uint8))
+    f = lib().oracle_iou2dr_flags_f64 if dt == np.float64 else lib().oracle_iou2dr_flags_f32
+    f.restype = None
+    f(_p(b1), ctypes.c_int64(n), _p(b2), ctypes.c_int64(m), _p(r.nx), _p(r.xflags), _p(r.nm), _p(r.mflags), _p(r.far))
+    return r
+
+
+def pdist2dr(points, boxes):
+    """pdist2dr_forward (dist.cpp:36-52): (dist[m,n] signed, positive inside; iedge[m,n])"""
+    dt = np.float64 if points.dtype == np.float64 else np.float32
+    pts = np.ascontiguousarray(points, dtype=dt)
+    bx = np.ascontiguousarray(boxes, dtype=dt)
+    n, m = pts.shape[0], bx.shape[0]
+    dist, iedge = np.empty((m, n), dt), np.empty((m, n), np.uint8)
+    f = lib().oracle_pdist2dr_f64 if dt == np.float64 else lib().oracle_pdist2dr_f32
+    f.restype = None
+    f(_p(pts), ctypes.c_int64(n), _p(bx), ctypes.c_int64(m), _p(dist), _p(iedge))
+    return dist, iedge
+
+
 def box2d_iou(boxes1, boxes2, method="box", precise=True, nthreads=1):
     """box/__init__.py:180-224 (numpy in, numpy out)"""
     boxes1 = np.asarray(boxes1)
@@ -273,7 +317,10 @@ def box2d_iou(boxes1, boxes2, method="box", precise=True, nthreads=1):
         raise ValueError("Input of rbox_2d_iou should be Nx2 tensors!")
     if boxes1.shape[1] != 5 or boxes2.shape[1] != 5:
         raise ValueError("Input boxes should have 5 fields: x, y, w, h, r")
-    res = iou2d_forward(boxes1, boxes2, method, nthreads)
+    if method.upper() in ("GRBOX", "DRBOX"):
+        res = loss_iou2dr(boxes1, boxes2, method, nthreads)
+    else:
+        res = iou2d_forward(boxes1, boxes2, method, nthreads)
     return res.astype(otype) if precise else res
 
 
@@ -422,3 +469,107 @@ def aligned_scatter_backward(coord, grad, atype, image_shape):
     f.restype = None
     f(_p(coord), ctypes.c_int64(n), ctypes.c_int(dim), _p(grad), ctypes.c_int64(C), _p(dims), ctypes.c_int(at), _p(img))
     return img
+
+
+# --------------------------------------------------------------------------- matcher / evaluator (reference Cython, restated)
+def prepare_boxes(src_arr, dst_arr, rotated=True):
+    """BaseMatcher.prepare_boxes (matcher.pyx:46-80), metrics IoU / RIoU: f32[n,m] = 1 - box3d[r]_iou after the +-1e3 clip"""
+    src = np.array(src_arr, dtype=np.float32).reshape(-1, 9)
+    dst = np.array(dst_arr, dtype=np.float32).reshape(-1, 9)
+    src[:, 5:8] = np.clip(src[:, 5:8], -1e3, 1e3)
+    dst[:, 5:8] = np.clip(dst[:, 5:8], -1e3, 1e3)
+    if len(src) == 0 or len(dst) == 0:
+        return np.zeros((len(src), len(dst)), np.float32)
+    return (np.float32(1) - iou3d(src[:, 2:9], dst[:, 2:9], "rbox" if rotated else "box")).astype(np.float32)
+
+
+def score_match(cache, src_arr, dst_arr, src_subset, dst_subset, distance_threshold):
+    """ScoreMatcher.match + match_by_order (matcher.pyx:90-162), literally: -> (src_assignment, dst_assignment) dicts.
+    (ties: stable sorts, i.e. equal scores in index order, equal distances to the lower index -- the spec of this repo)"""
+    src_assign, dst_assign = {}, {}
+    src_subset, dst_subset = list(src_subset), list(dst_subset)
+    if not src_subset or not dst_subset:
+        return src_assign, dst_assign
+    scores = np.array([src_arr[i, 1] for i in src_subset])
+    src_order = np.argsort(-scores, kind="stable")
+    sub = cache[np.ix_(src_subset, dst_subset)]
+    dst_order = np.argsort(sub, axis=1, kind="stable")
+    for si in range(len(src_subset)):
+        s = src_subset[src_order[si]]
+        for di in range(len(dst_subset)):
+            d = dst_subset[dst_order[src_order[si], di]]
+            if s in src_assign:
+                continue
+            if d in dst_assign:
+                continue
+            if int(src_arr[s, 0]) != int(dst_arr[d, 0]):
+                continue
+            if cache[s, d] <= distance_threshold[int(dst_arr[d, 0])]:
+                src_assign[s] = d
+                dst_assign[d] = s
+    return src_assign, dst_assign
+
+
+def calc_stats(gt, dt, classes, max_distance, thresholds):
+    """DetectionEvaluator.calc_stats (benchmarks.pyx:178-283) on [n,9] arrays, one matching PER threshold like the reference"""
+    gt = np.asarray(gt, np.float32).reshape(-1, 9)
+    dt = np.asarray(dt, np.float32).reshape(-1, 9)
+    T = len(thresholds)
+    cache = prepare_boxes(dt, gt, True)
+    st = Dict(ngt={c: 0 for c in classes}, ndt={c: [0] * T for c in classes}, tp={c: [0] * T for c in classes},
+              fp={c: [0] * T for c in classes}, fn={c: [0] * T for c in classes})
+    acc = {k: [dict() for _ in range(T)] for k in ("iou", "angular", "dist", "box")}
+    gt_idx = []
+    for g in range(len(gt)):
+        if int(gt[g, 0]) in classes:
+            st.ngt[int(gt[g, 0])] += 1
+            gt_idx.append(g)
+    for t in range(T):
+        dt_idx = []
+        for d in range(len(dt)):
+            if int(dt[d, 0]) not in classes or dt[d, 1] < thresholds[t]:
+                continue
+            st.ndt[int(dt[d, 0])][t] += 1
+            dt_idx.append(d)
+        sa, da = score_match(cache, dt, gt, dt_idx, gt_idx, max_distance)
+        for g in gt_idx:
+            c = int(gt[g, 0])
+            if g not in da:
+                st.fn[c][t] += 1
+                continue
+            st.tp[c][t] += 1
+            d = da[g]
+            acc["iou"][t][g] = 1 - cache[d, g]
+            acc["dist"][t][g] = float(np.linalg.norm(gt[g, 2:5] - dt[d, 2:5]))
+            acc["box"][t][g] = float(np.linalg.norm(gt[g, 5:8] - dt[d, 5:8]))
+            dy = float(gt[g, 8] - dt[d, 8])
+            acc["angular"][t][g] = abs((dy + np.pi) % (2 * np.pi) - np.pi) / np.pi
+        for d in dt_idx:
+            if d not in sa:
+                st.fp[int(dt[d, 0])][t] += 1
+    for name in acc:
+        agg = {c: [float("nan")] * T for c in classes}
+        for t in range(T):
+            for c in classes:
+                vals = [v for g, v in acc[name][t].items() if int(gt[g, 0]) == c]
+                if vals:
+                    agg[c][t] = float(np.sum(np.asarray(vals, np.float32)) / len(vals))
+        st["acc_" + name] = agg
+    return st
+
+
+def score_match_rows(cache, src_arr, dst_arr, distance_threshold):
+    """the same association over ALL boxes, one numpy step per src row instead of match_by_order's n x m pair loop:
+    -> (src_match[n], dst_match[m]) index arrays, -1 = none (equality with score_match is tested on the CPU)"""
+    n, m = cache.shape
+    src_match, dst_match = np.full((n,), -1, np.int64), np.full((m,), -1, np.int64)
+    stag, dtag = src_arr[:, 0].astype(np.int64), dst_arr[:, 0].astype(np.int64)
+    thr = np.array([distance_threshold.get(int(t), -np.inf) for t in dtag], np.float32)
+    for s in np.argsort(-src_arr[:, 1], kind="stable"):
+        if int(stag[s]) not in distance_threshold:
+            continue
+        ok = np.nonzero((dtag == stag[s]) & (cache[s] <= thr) & (dst_match < 0))[0]
+        if len(ok):
+            d = ok[np.argmin(cache[s, ok])]            # first minimum = lowest index among equal distances
+            src_match[s], dst_match[d] = d, s
+    return src_match, dst_match

@@ -135,6 +135,193 @@ void FN(oracle_iou2d)(const T *b1, int64_t n, const T *b2, int64_t m, int method
             ious[i * m + j] = FN(pair_iou)(b1 + i * 5, b2 + j * 5, method);
 }
 
+/* ---- loss-path functions: GIoU / DIoU of rotated boxes and the autograd bookkeeping (reference iou.cpp:213-419, the
+ * dgal calls giou / diou / iou(.., nx, flags) at iou.cpp:116,225,334).  dgal's source is not available; the PUBLISHED
+ * definitions are restated:  GIoU = IoU - (H - U) / H with H = area of the convex hull of the two rectangles and
+ * U = A1 + A2 - I;  DIoU = IoU - d^2 / D^2 with d = distance of the centres and D = diameter of that hull (largest
+ * distance between two of the eight corners).  A rectangle of non-positive area gives 0 (never NaN), like IoU. */
+
+/* convex hull of 8 points: Andrew's monotone chain (collinear points dropped) -> vertex indices CCW, starting at the
+ * lowest (x, y) point; returns the vertex count */
+static int FN(hull8)(const FN(pt) *p, uint8_t *hull)
+{
+    int idx[8], n = 8;
+    for (int k = 0; k < n; k++) idx[k] = k;
+    for (int a = 1; a < n; a++) {                     /* insertion sort by (x, y, index) */
+        int v = idx[a], b = a - 1;
+        while (b >= 0 && (p[idx[b]].x > p[v].x || (p[idx[b]].x == p[v].x && p[idx[b]].y > p[v].y))) { idx[b + 1] = idx[b]; b--; }
+        idx[b + 1] = v;
+    }
+    int st[17], m = 0;
+    for (int k = 0; k < n; k++) {                     /* lower hull */
+        while (m >= 2) {
+            const FN(pt) *a = &p[st[m - 2]], *b = &p[st[m - 1]], *c = &p[idx[k]];
+            if ((b->x - a->x) * (c->y - a->y) - (b->y - a->y) * (c->x - a->x) <= 0) m--; else break;
+        }
+        st[m++] = idx[k];
+    }
+    const int lower = m + 1;
+    for (int k = n - 2; k >= 0; k--) {                /* upper hull */
+        while (m >= lower) {
+            const FN(pt) *a = &p[st[m - 2]], *b = &p[st[m - 1]], *c = &p[idx[k]];
+            if ((b->x - a->x) * (c->y - a->y) - (b->y - a->y) * (c->x - a->x) <= 0) m--; else break;
+        }
+        st[m++] = idx[k];
+    }
+    m--;                                              /* the start point is repeated at the end */
+    if (m < 0) m = 0;
+    for (int k = 0; k < m && k < 8; k++) hull[k] = (uint8_t)st[k];
+    return m < 8 ? m : 8;
+}
+
+static T FN(hull_area)(const FN(quad) *a, const FN(quad) *b, int *nm, uint8_t *mflags)
+{
+    FN(pt) p[8], h[8];
+    for (int k = 0; k < 4; k++) { p[k] = a->v[k]; p[4 + k] = b->v[k]; }
+    uint8_t hull[8];
+    int n = FN(hull8)(p, hull);
+    for (int k = 0; k < n; k++) h[k] = p[hull[k]];
+    if (nm) *nm = n;
+    if (mflags) for (int k = 0; k < 8; k++) mflags[k] = k < n ? hull[k] : 0xff;
+    return FN(poly_area)(h, n);
+}
+
+/* largest squared distance between two of the eight corners; i1 < i2 = the first pair that reaches it */
+static T FN(diameter2)(const FN(quad) *a, const FN(quad) *b, int *i1, int *i2)
+{
+    FN(pt) p[8];
+    for (int k = 0; k < 4; k++) { p[k] = a->v[k]; p[4 + k] = b->v[k]; }
+    T best = -1;
+    for (int x = 0; x < 8; x++)
+        for (int y = x + 1; y < 8; y++) {
+            T dx = p[x].x - p[y].x, dy = p[x].y - p[y].y, d = dx * dx + dy * dy;
+            if (d > best) { best = d; if (i1) *i1 = x; if (i2) *i2 = y; }
+        }
+    return best;
+}
+
+/* Sutherland-Hodgman with the origin of every vertex: subject = box 1, clipped by the edges of box 2 in order.
+ * flags[k] of vertex k (CCW): 0x00 | i = corner i of box 1;  0x10 | j = corner j of box 2;
+ * 0x20 | i << 2 | j = crossing of edge i of box 1 (corner i -> i + 1) with edge j of box 2.  Returns the vertex count. */
+static int FN(clip_quad_flags)(const FN(quad) *subj, const FN(quad) *c, FN(pt) *out, uint8_t *flags)
+{
+    FN(pt) buf[2][16];
+    uint8_t vf[2][16], ef[2][16];        /* vertex flag; origin of the edge that STARTS at the vertex: 0..3 box-1 edge, 4..7 box-2 edge */
+    int n = 4, cur = 0;
+    for (int k = 0; k < 4; k++) { buf[0][k] = subj->v[k]; vf[0][k] = (uint8_t)k; ef[0][k] = (uint8_t)k; }
+    for (int e = 0; e < 4 && n > 0; e++) {
+        FN(pt) a = c->v[e], b = c->v[(e + 1) & 3];
+        T ex = b.x - a.x, ey = b.y - a.y;
+        int m = 0, nxt = cur ^ 1;
+        for (int k = 0; k < n; k++) {
+            FN(pt) p = buf[cur][k], q = buf[cur][(k + 1) % n];
+            const uint8_t o = ef[cur][k];
+            T dp = ex * (p.y - a.y) - ey * (p.x - a.x);
+            T dq = ex * (q.y - a.y) - ey * (q.x - a.x);
+            int pin = dp >= 0, qin = dq >= 0;
+            if (pin) { buf[nxt][m] = p; vf[nxt][m] = vf[cur][k]; ef[nxt][m] = o; m++; }
+            if (pin != qin) {
+                T t = dp / (dp - dq);
+                FN(pt) x = { p.x + t * (q.x - p.x), p.y + t * (q.y - p.y) };
+                uint8_t f;
+                if (o < 4) f = (uint8_t)(0x20 | (o << 2) | e);
+                else {                                  /* two edges of box 2 meet in one of its corners */
+                    const int e2 = o - 4;
+                    f = (uint8_t)(0x10 | (((e2 + 1) & 3) == e ? e : e2));
+                }
+                buf[nxt][m] = x; vf[nxt][m] = f;
+                ef[nxt][m] = pin ? (uint8_t)(4 + e) : o;    /* leaving: continue along the clip edge; entering: along p -> q */
+                m++;
+            }
+        }
+        n = m; cur = nxt;
+    }
+    for (int k = 0; k < n && k < 8; k++) { out[k] = buf[cur][k]; flags[k] = vf[cur][k]; }
+    for (int k = n; k < 8; k++) flags[k] = 0xff;
+    return n < 8 ? n : 8;
+}
+
+/* one pair: kind 0 = GIoU (IouType GRBOX), 1 = DIoU (DRBOX) */
+static T FN(pair_loss_iou)(const T *bi, const T *bj, int kind)
+{
+    FN(quad) qi = FN(quad_from_xywhr)(bi[0], bi[1], bi[2], bi[3], bi[4]);
+    FN(quad) qj = FN(quad_from_xywhr)(bj[0], bj[1], bj[2], bj[3], bj[4]);
+    T a1 = FN(poly_area)(qi.v, 4), a2 = FN(poly_area)(qj.v, 4);
+    if (!(a1 > 0) || !(a2 > 0)) return 0;
+    FN(pt) poly[16];
+    int n = FN(clip_quad)(&qi, &qj, poly);
+    T inter = FN(poly_area)(poly, n);
+    if (!(inter > 0)) inter = 0;
+    T uni = a1 + a2 - inter, iou = inter / uni;
+    if (kind == 0) {
+        T hull = FN(hull_area)(&qi, &qj, 0, 0);
+        return iou - (hull - uni) / hull;
+    }
+    T dx = bi[0] - bj[0], dy = bi[1] - bj[1];
+    return iou - (dx * dx + dy * dy) / FN(diameter2)(&qi, &qj, 0, 0);
+}
+
+void FN(oracle_loss_iou2dr)(const T *b1, int64_t n, const T *b2, int64_t m, int kind, int64_t row_begin, int64_t row_end, T *out)
+{
+    (void)n;
+    for (int64_t i = row_begin; i < row_end; i++)
+        for (int64_t j = 0; j < m; j++) out[i * m + j] = FN(pair_loss_iou)(b1 + i * 5, b2 + j * 5, kind);
+}
+
+/* bookkeeping outputs of iou2dr_forward / giou2dr_forward / diou2dr_forward (iou.cpp:115-141, 224-258, 333-367):
+ * nx[n,m] intersection vertex count, xflags[n,m,8] (see clip_quad_flags), nm[n,m] hull vertex count, mflags[n,m,8]
+ * = corner index (0..3 box 1, 4..7 box 2) of every hull vertex, far[n,m,2] = the farthest corner pair.  Any may be NULL. */
+void FN(oracle_iou2dr_flags)(const T *b1, int64_t n, const T *b2, int64_t m, uint8_t *nx, uint8_t *xflags, uint8_t *nm,
+                             uint8_t *mflags, uint8_t *far)
+{
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < m; j++) {
+            const T *bi = b1 + i * 5, *bj = b2 + j * 5;
+            FN(quad) qi = FN(quad_from_xywhr)(bi[0], bi[1], bi[2], bi[3], bi[4]);
+            FN(quad) qj = FN(quad_from_xywhr)(bj[0], bj[1], bj[2], bj[3], bj[4]);
+            FN(pt) poly[16];
+            uint8_t fl[8], mf[8];
+            int k = FN(clip_quad_flags)(&qi, &qj, poly, fl), hm = 0, f1 = 0, f2 = 0;
+            if (k < 3) { k = 0; for (int t = 0; t < 8; t++) fl[t] = 0xff; }       /* no area: no polygon */
+            FN(hull_area)(&qi, &qj, &hm, mf);
+            FN(diameter2)(&qi, &qj, &f1, &f2);
+            const int64_t e = i * m + j;
+            if (nx) nx[e] = (uint8_t)k;
+            if (xflags) for (int t = 0; t < 8; t++) xflags[e * 8 + t] = fl[t];
+            if (nm) nm[e] = (uint8_t)hm;
+            if (mflags) for (int t = 0; t < 8; t++) mflags[e * 8 + t] = mf[t];
+            if (far) { far[e * 2] = (uint8_t)f1; far[e * 2 + 1] = (uint8_t)f2; }
+        }
+}
+
+/* pdist2dr_forward (dist.cpp:10-52; dgal::distance(Quad2, Point2, iedge)): SIGNED distance from a point to the boundary of
+ * a rotated box, positive inside (the convention box3dr_pdist relies on, box/__init__.py:370-381); iedge = the nearest
+ * edge k (corner k -> k + 1), or 4 + k when the nearest boundary point is corner k.  dist[m,n], iedge[m,n]: box-major. */
+void FN(oracle_pdist2dr)(const T *points, int64_t n, const T *boxes, int64_t m, T *dist, uint8_t *iedge)
+{
+    for (int64_t i = 0; i < m; i++) {
+        const T *b = boxes + i * 5;
+        FN(quad) q = FN(quad_from_xywhr)(b[0], b[1], b[2], b[3], b[4]);
+        for (int64_t j = 0; j < n; j++) {
+            T px = points[j * 2], py = points[j * 2 + 1], best = -1;
+            int inside = 1, feat = 0;
+            for (int e = 0; e < 4; e++) {
+                FN(pt) v = q.v[e], w = q.v[(e + 1) & 3];
+                T ex = w.x - v.x, ey = w.y - v.y, rx = px - v.x, ry = py - v.y;
+                if (ex * ry - ey * rx < 0) inside = 0;
+                T len2 = ex * ex + ey * ey, t = len2 > 0 ? (rx * ex + ry * ey) / len2 : 0;
+                int f = e;
+                if (t <= 0) { t = 0; f = 4 + e; } else if (t >= 1) { t = 1; f = 4 + ((e + 1) & 3); }
+                T dx = rx - t * ex, dy = ry - t * ey, d2 = dx * dx + dy * dy;
+                if (best < 0 || d2 < best) { best = d2; feat = f; }
+            }
+            T d = (T)sqrt((double)best);
+            dist[i * n + j] = inside ? d : -d;
+            if (iedge) iedge[i * n + j] = (uint8_t)feat;
+        }
+    }
+}
+
 /* the same per-pair arithmetic on a LIST of pairs (pi[k], pj[k]) -> out[k]: lets a test check a matrix far too large
  * to recompute densely on the CPU (config 3: 1e10 pairs) at every candidate pair of a CPU-side AABB sweep */
 void FN(oracle_iou2d_pairs)(const T *b1, const T *b2, const int64_t *pi, const int64_t *pj, int64_t k, int method, T *out)

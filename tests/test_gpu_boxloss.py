@@ -1,0 +1,258 @@
+"""GPU parity (through the C ABI) of the loss-path and evaluator rows of SURVEY 8(f): GIoU / DIoU forward + backward, the
+autograd bookkeeping tensors, point-to-box distance forward + backward, the matcher's distance cache and the
+score-ordered association behind DetectionEvaluator.calc_stats -- against the CPU oracle (values: 1e-9 fp64 / 1e-3 fp32;
+gradients: central differences of the fp64 oracle; indices, counts and matches: exact)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from test_oracle_box import _loss_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _rand_boxes(n, seed, spread=8.0):
+    rng = np.random.default_rng(seed)
+    return np.stack([(rng.random(n) - .5) * spread, (rng.random(n) - .5) * spread, rng.random(n) * 5 + .1, rng.random(n) * 5 + .1,
+                     (rng.random(n) - .5) * 10], 1)
+
+
+@pytest.mark.parametrize("method", ["grbox", "drbox"])
+def test_giou_diou_forward_vs_oracle(method):
+    from d3d_amd.box import box2d_iou
+    from d3d_amd import synth
+    b1, b2 = _loss_cases()                                     # random + identical / shared edge / corner contact / contained ...
+    got = box2d_iou(T(b1), T(b2), method=method).cpu().numpy()
+    assert np.max(np.abs(got - oracle.loss_iou2dr(b1, b2, method))) < 1e-9
+    a, _ = synth.boxes2d_dense(700, 3)
+    b, _ = synth.boxes2d_sparse(333, 4)                         # ragged sizes, mostly disjoint pairs (negative values)
+    b[:, :2] /= 40
+    got = box2d_iou(T(a), T(b), method=method).cpu().numpy()
+    exp = oracle.loss_iou2dr(a, b, method, nthreads=8)
+    assert got.shape == (700, 333) and np.max(np.abs(got - exp)) < 1e-9 and exp.min() < -0.5
+    got32 = box2d_iou(T(a.astype(np.float32)), T(b.astype(np.float32)), method=method, precise=False)
+    assert got32.dtype == torch.float32 and np.max(np.abs(got32.cpu().numpy() - exp)) < 1e-3
+    z = np.array([[0, 0, 0, 2, 0.3], [1, 1, -1, 2, 0]])         # no area: 0, never NaN
+    assert torch.count_nonzero(box2d_iou(T(z), T(b[:5]), method=method)) == 0
+    assert box2d_iou(T(a[:0]), T(b), method=method).shape == (0, 333)
+    assert np.array_equal(box2d_iou(a[:9], b[:7], method=method), got[:9, :7])      # numpy in, numpy out
+
+
+@pytest.mark.parametrize("method", ["grbox", "drbox"])
+def test_giou_diou_backward_vs_central_differences(method):
+    """analytic gradients through autograd (box2d_iou -> GIou2DR / DIou2DR.backward) against central differences of the
+    fp64 oracle, on overlapping, disjoint and contained pairs"""
+    from d3d_amd.box import box2d_iou
+    b1, b2 = _rand_boxes(40, 21, 6.0), _rand_boxes(25, 22, 6.0)
+    b1[0], b2[0] = [0, 0, 4, 3, 0.2], [0.3, 0.1, 1, 1, 0.9]                 # contained: the hull is box 1
+    w = np.random.default_rng(23).random((40, 25))
+    t1, t2 = T(b1).requires_grad_(True), T(b2).requires_grad_(True)
+    (box2d_iou(t1, t2, method=method) * T(w)).sum().backward()
+    g1, g2 = t1.grad.cpu().numpy(), t2.grad.cpu().numpy()
+    h = 1e-6
+
+    def loss(x1, x2):
+        return float((oracle.loss_iou2dr(x1, x2, method) * w).sum())
+    for arr, g, which in ((b1, g1, 0), (b2, g2, 1)):
+        for i in range(0, len(arr), 3):
+            for k in range(5):
+                p, m = arr.copy(), arr.copy()
+                p[i, k] += h
+                m[i, k] -= h
+                fd = (loss(p, b2) - loss(m, b2)) / (2 * h) if which == 0 else (loss(b1, p) - loss(b1, m)) / (2 * h)
+                assert abs(fd - g[i, k]) < 2e-5 * max(1.0, abs(fd)), (method, which, i, k, fd, g[i, k])
+    # fp32 gradients agree with the fp64 ones
+    t1, t2 = T(b1.astype(np.float32)).requires_grad_(True), T(b2.astype(np.float32)).requires_grad_(True)
+    (box2d_iou(t1, t2, method=method, precise=False) * T(w.astype(np.float32))).sum().backward()
+    assert np.max(np.abs(t1.grad.cpu().numpy() - g1)) < 2e-2 * max(1.0, np.abs(g1).max())
+
+
+def test_flags_vs_oracle_and_box_impl_tuples():
+    from d3d_amd.box import box_impl, iou2dr_flags
+    b1, b2 = _rand_boxes(90, 31, 6.0), _rand_boxes(70, 32, 6.0)
+    exp = oracle.iou2dr_flags(b1, b2)
+    got = iou2dr_flags(T(b1), T(b2), which=("nx", "xflags", "nm", "mflags", "far"))
+    for k in ("nx", "xflags", "nm", "mflags"):
+        assert np.array_equal(got[k].cpu().numpy(), exp[k]), k
+    # far: a rectangle's two diagonals are equally long, so the pair may differ by rounding -- the distance may not
+    from exact_clip import corners
+    far = got["far"].cpu().numpy()
+    pts = np.array([[corners(*b1[i]) + corners(*b2[j]) for j in range(70)] for i in range(90)])        # [90, 70, 8, 2]
+    ii, jj = np.meshgrid(np.arange(90), np.arange(70), indexing="ij")
+
+    def length(f):
+        return np.linalg.norm(pts[ii, jj, f[..., 0]] - pts[ii, jj, f[..., 1]], axis=-1)
+    assert np.allclose(length(far), length(exp.far), rtol=1e-12) and np.all(far[..., 0] < far[..., 1])
+    assert np.mean(np.all(far == exp.far, axis=-1)) > 0.9
+    assert exp.nx.max() == 8 or exp.nx.max() >= 6
+    # the compiled module's return shapes (iou.h:25-69)
+    ious, nx, xflags = box_impl.iou2dr_forward(T(b1), T(b2))
+    assert ious.shape == (90, 70) and nx.shape == (90, 70) and xflags.shape == (90, 70, 8) and nx.dtype == torch.uint8
+    assert np.max(np.abs(ious.cpu().numpy() - oracle.box2d_iou(b1, b2, "rbox"))) < 1e-9
+    assert torch.allclose(box_impl.iou2dr_backward(T(b1), T(b2), torch.ones_like(ious), nx, xflags)[0],
+                          box_impl.iou2dr_backward_cuda(T(b1), T(b2), torch.ones_like(ious))[0], rtol=1e-12, atol=1e-12)
+    ious, nxm, xmflags = box_impl.giou2dr_forward_cuda(T(b1), T(b2))
+    assert nxm.shape == (90, 70, 2) and xmflags.shape == (90, 70, 16)
+    assert np.array_equal(nxm[..., 1].cpu().numpy(), exp.nm) and np.array_equal(xmflags[..., 8:].cpu().numpy(), exp.mflags)
+    ious, nxd, xf = box_impl.diou2dr_forward(T(b1), T(b2))
+    assert nxd.shape == (90, 70, 3) and np.array_equal(nxd[..., 1:].cpu().numpy(), far) and xf.shape == (90, 70, 8)
+    g1, g2 = box_impl.diou2dr_backward(T(b1), T(b2), torch.ones_like(ious), nxd, xf)
+    assert g1.shape == (90, 5) and g2.shape == (70, 5)
+    old = box_impl.flags_max_pairs
+    try:                                    # beyond the limit the flag tensors come back empty, the values do not change
+        box_impl.flags_max_pairs = 100
+        i2, nx2, xf2 = box_impl.iou2dr_forward(T(b1), T(b2))
+        assert nx2.numel() == 0 and xf2.numel() == 0 and i2.shape == (90, 70)
+    finally:
+        box_impl.flags_max_pairs = old
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pdist_forward_backward(dtype):
+    from d3d_amd.box import box2dr_pdist, box3dr_pdist, box_impl, pdist2dr_forward
+    rng = np.random.default_rng(41)
+    pts = ((rng.random((700, 2)) - 0.5) * 12).astype(dtype)
+    boxes = _rand_boxes(90, 42, 8.0).astype(dtype)
+    d, e = pdist2dr_forward(T(pts), T(boxes))
+    dref, eref = oracle.pdist2dr(pts.astype(np.float64), boxes.astype(np.float64))
+    tol = 1e-9 if dtype == np.float64 else 1e-4
+    assert d.shape == (90, 700) and np.max(np.abs(d.cpu().numpy() - dref)) < tol
+    if dtype == np.float64:
+        assert np.array_equal(e.cpu().numpy(), eref)
+        assert np.array_equal((d > 0).cpu().numpy(), oracle.crop_2dr(pts, boxes) & (dref != 0))
+    # the reference's Python layer hands (boxes, points) to the (points, boxes) signature: the shim accepts both
+    d2, _ = box_impl.pdist2dr_forward_cuda(T(boxes), T(pts))
+    assert torch.equal(d, d2)
+    if dtype == np.float32:
+        return
+    w = rng.random((90, 700))
+    tp, tb = T(pts).requires_grad_(True), T(boxes).requires_grad_(True)
+    (box2dr_pdist(tp, tb) * T(w)).sum().backward()
+    gp, gb = tp.grad.cpu().numpy(), tb.grad.cpu().numpy()
+    h = 1e-6
+
+    def loss(p, b):
+        return float((oracle.pdist2dr(p, b)[0] * w).sum())
+    for i in range(0, 90, 7):
+        for k in range(5):
+            a, c = boxes.copy(), boxes.copy()
+            a[i, k] += h
+            c[i, k] -= h
+            fd = (loss(pts, a) - loss(pts, c)) / (2 * h)
+            assert abs(fd - gb[i, k]) < 1e-4 * max(1.0, abs(fd)), (i, k, fd, gb[i, k])
+    for j in range(0, 700, 53):
+        for k in range(2):
+            a, c = pts.copy(), pts.copy()
+            a[j, k] += h
+            c[j, k] -= h
+            fd = (loss(a, boxes) - loss(c, boxes)) / (2 * h)
+            assert abs(fd - gp[j, k]) < 1e-4 * max(1.0, abs(fd)), (j, k, fd, gp[j, k])
+    # 3-D: inside the box the distance is the smallest gap to the six faces
+    b3 = np.array([[0, 0, 0, 4, 2, 2, 0.0]])
+    p3 = np.array([[0.5, 0.2, 0.1], [1.9, 0, 0], [3.0, 0, 0], [0, 0, 2.0], [3, 0, 3]])
+    d3 = box3dr_pdist(T(p3), T(b3)).cpu().numpy()[0]
+    assert np.allclose(d3, [0.8, 0.1, -1.0, -1.0, -np.sqrt(1 + 4)], atol=1e-12)
+
+
+def _labelled(boxes7, seed, nclass=3, scores=True):
+    rng = np.random.default_rng(seed)
+    n = len(boxes7)
+    return np.concatenate([rng.integers(1, nclass + 1, (n, 1)), rng.random((n, 1)) if scores else np.zeros((n, 1)), boxes7],
+                          1).astype(np.float32)
+
+
+def test_matcher_distance_cache_config4():
+    """BaseMatcher.prepare_boxes (matcher.pyx:46-80) at config 4's size: 20 k x 5 k, [n,9] ingress, the +-1e3 dimension
+    clip, 1 - iou, IoU vs RIoU"""
+    from d3d_amd import synth
+    from d3d_amd.tracking import DistanceTypes, prepare_boxes
+    pred, gt = synth.boxes3d_eval(5000, 4, 2)
+    dt9, gt9 = _labelled(pred, 1), _labelled(gt, 2, scores=False)
+    dt9[5, 5:8] = [5e3, 2e3, -4e3]                              # "really weird boxes with unusual size"
+    # 2000 x 2000 x 2 over a 1000 x 1000 x 2 box: IoU 0.25 as they are, 1 once the clip has cut both to 1000 (matcher.pyx:49-51)
+    dt9[6, 2:5], dt9[6, 5:8], dt9[6, 8] = gt9[6, 2:5], [2e3, 2e3, 2], 0.0
+    gt9[6, 5:8], gt9[6, 8] = [1e3, 1e3, 2], 0.0
+    rows = np.r_[0:40, 5:7, 19990:20000]
+    for metric, rot in ((DistanceTypes.RIoU, True), (DistanceTypes.IoU, False)):
+        cache = prepare_boxes(T(dt9), T(gt9), metric)
+        assert cache.shape == (20000, 5000) and cache.dtype == torch.float32
+        exp = oracle.prepare_boxes(dt9[rows], gt9, rot)
+        assert np.max(np.abs(cache[T(rows)].cpu().numpy() - exp)) < 1e-3
+        assert float(cache.max()) == 1.0 and float(cache.min()) >= 0.0 and abs(float(cache[6, 6])) < 1e-6 and exp[41, 6] < 1e-6
+        # every pair without BEV overlap is exactly 1 (the background fill), every other one below
+        pi, pj = oracle.aabb_candidate_pairs(dt9[:, [2, 3, 5, 6, 8]].astype(np.float64), gt9[:, [2, 3, 5, 6, 8]].astype(np.float64))
+        keep = np.abs(dt9[pi, 5]) < 1e3
+        assert int((cache < 1).sum()) <= len(pi) and len(pi) > 20000 and keep.sum() > 20000
+    pos = prepare_boxes(dt9[:50], gt9[:60], DistanceTypes.Position).cpu().numpy()
+    assert np.allclose(pos, np.linalg.norm(dt9[:50, None, 2:5] - gt9[None, :60, 2:5], axis=2), atol=1e-4)
+
+
+def test_score_match_and_calc_stats_vs_oracle():
+    from d3d_amd import synth
+    from d3d_amd.benchmarks import DetectionEvaluator
+    from d3d_amd.tracking import DistanceTypes, ScoreMatcher, prepare_boxes, score_match
+    pred, gt = synth.boxes3d_eval(150, 4, 7)
+    dt9, gt9 = _labelled(pred, 3), _labelled(gt, 4, scores=False)
+    thr = {1: 0.7, 2: 0.5}                                       # class 3 is not evaluated
+    cache = prepare_boxes(dt9, gt9, DistanceTypes.RIoU)
+    sm, dm = score_match(cache, dt9[:, 1], dt9[:, 0], gt9[:, 0], thr)
+    esm, edm = oracle.score_match_rows(cache.cpu().numpy(), dt9, gt9, thr)
+    assert np.array_equal(sm.cpu().numpy(), esm) and np.array_equal(dm.cpu().numpy(), edm) and (esm >= 0).sum() > 50
+    # the matcher object on subsets (the call sequence of benchmarks.pyx:188-238)
+    mt = ScoreMatcher()
+    mt.prepare_boxes(dt9, gt9, DistanceTypes.RIoU)
+    src = [i for i in range(len(dt9)) if dt9[i, 1] >= 0.4 and int(dt9[i, 0]) in thr]
+    dst = [j for j in range(len(gt9)) if int(gt9[j, 0]) in thr]
+    mt.match(src, dst, thr)
+    sa, da = oracle.score_match(cache.cpu().numpy(), dt9, gt9, src, dst, thr)
+    assert {i: mt.query_src_match(i) for i in sa} == sa and mt.num_of_matches() == len(sa)
+    assert all(mt.query_dst_match(j) == da.get(j, -1) for j in range(len(gt9)))
+    # the evaluator: one association for all 40 thresholds == the reference's association per threshold
+    ev = DetectionEvaluator([1, 2], [0.3, 0.5], pr_sample_count=40)
+    got = ev.calc_stats(gt9, dt9)
+    exp = oracle.calc_stats(gt9, dt9, [1, 2], {1: 0.7, 2: 0.5}, ev.score_thresholds)
+    for c in (1, 2):
+        assert got.ngt[c] == exp.ngt[c]
+        for k in ("ndt", "tp", "fp", "fn"):
+            assert got[k][c] == exp[k][c], (k, c)
+        for k in ("acc_iou", "acc_angular", "acc_dist", "acc_box"):
+            assert np.allclose(got[k][c], exp[k][c], rtol=1e-4, atol=1e-5, equal_nan=True), (k, c)
+    assert max(exp.tp[1]) > 10 and exp.tp[1][0] > exp.tp[1][-1]
+    # test/test_benchmark.py:10-84
+    ev = DetectionEvaluator([1, 2], [0.1, 0.2])
+    dt = np.array([[1, 0.8, 0, 0, 0, 2, 2, 2, 0], [2, 0.7, 1, 1, 1, 2, 2, 2, 0], [3, 0.8, -1, -1, -1, 2, 2, 2, 0]], np.float32)
+    r = ev.calc_stats(dt, dt)
+    for c in (1, 2):
+        assert r.ngt[c] == 1 and r.ndt[c][0] == 1 and r.ndt[c][-1] == 0 and r.tp[c][0] == 1 and r.tp[c][-1] == 0
+        assert r.fp[c][0] == 0 and r.fn[c][0] == 0 and r.fn[c][-1] == 1 and np.isclose(r.acc_iou[c][0], 1) and np.isnan(r.acc_iou[c][-1])
+        assert np.isinf(r.acc_var[c][0]) and np.isnan(r.acc_var[c][-1])
+    gtb = np.array([[2, 0, 0, 0, 0, 2.1, 2.1, 2.1, 0.01], [1, 0, -1, 1, 0, 2.1, 2.1, 2.1, 0.01], [3, 0, 1, -1, 0, 2.1, 2.1, 2.1, 0.01]],
+                   np.float32)
+    r = ev.calc_stats(gtb, dt)
+    assert r.tp[1][0] == 1 and r.fp[1][0] == 0 and r.acc_iou[1][0] > 0.1 and r.acc_dist[1][0] > 1 and r.acc_angular[1][0] > 0
+    assert r.tp[2][0] == 0 and r.fp[2][0] == 1 and r.fn[2][0] == 1 and np.isnan(r.acc_iou[2][0])
+    r = ev.calc_stats(np.zeros((0, 9), np.float32), dt)
+    assert r.ngt[1] == 0 and r.fp[1][0] == 1 and r.tp[1][0] == 0
+
+
+def test_evaluator_association_config4_full_size():
+    """config 4 as the evaluator uses it: 20 k detections x 5 k ground truths, one association for all thresholds, against
+    the row-wise restatement of the reference's loop"""
+    from d3d_amd import synth
+    from d3d_amd.tracking import DistanceTypes, prepare_boxes, score_match
+    pred, gt = synth.boxes3d_eval(5000, 4, 2)
+    dt9, gt9 = _labelled(pred, 11, nclass=2), _labelled(gt, 12, nclass=2, scores=False)
+    dt9[:, 0] = np.repeat(gt9[:, 0], 4)                        # detections carry their ground truth's class, 10 % mislabelled
+    flip = np.random.default_rng(13).random(len(dt9)) < 0.1
+    dt9[flip, 0] = 3 - dt9[flip, 0]
+    thr = {1: 0.5, 2: 0.3}
+    cache = prepare_boxes(T(dt9), T(gt9), DistanceTypes.RIoU)
+    sm, dm = score_match(cache, dt9[:, 1], dt9[:, 0], gt9[:, 0], thr)
+    esm, edm = oracle.score_match_rows(cache.cpu().numpy(), dt9, gt9, thr)
+    assert np.array_equal(sm.cpu().numpy(), esm) and np.array_equal(dm.cpu().numpy(), edm)
+    assert 3000 < (edm >= 0).sum() <= 5000

@@ -162,14 +162,23 @@ def test_all_points_in_one_voxel_and_errors():
         VoxelGenerator(unit, [10, 10, 10], max_points_filter="bogus")
     with pytest.raises(NotImplementedError):
         VoxelGenerator(unit, [10, 10, 10], min_points=1, dense=True)
-    # a non-finite point: the raw sparse function reports it (its key cannot be built), VoxelGenerator -- sparse + filter --
-    # drops it like the reference's coordinate-bound filter drops the INT_MIN voxel it lands in (goldens sp_nonfinite*)
+    # non-finite points: the reference's (int)floor(NaN) = INT_MIN voxel (voxelize.cpp:309) is reproduced by the raw sparse
+    # function and dropped by the coordinate-bound filter (goldens sp_nonfinite*); a FINITE coordinate beyond the 21-bit key
+    # range is reported by the raw function and dropped by VoxelGenerator
     from d3d_amd.voxel import voxelize_3d_sparse
-    bad = torch.tensor([[float("nan"), 0, 0, 0], [0.5, 0.5, 0.5, 1]]).cuda()
-    with pytest.raises(ValueError):
-        voxelize_3d_sparse(bad, [0.1, 0.1, 0.1])
-    ret = VoxelGenerator(unit, [10, 10, 10])(bad)
+    bad = np.array([[np.nan, 0, 0, 0], [0.55, 0.55, 0.55, 1], [0.05, np.inf, -np.inf, 2], [np.nan, 0.01, 0.02, 3]], np.float32)
+    got = voxelize_3d_sparse(torch.from_numpy(bad).cuda(), [0.1, 0.1, 0.1])
+    exp = oracle.voxelize_3d_sparse(bad, np.array([0.1, 0.1, 0.1], np.float32))
+    for k in ("points_mapping", "coords", "voxel_npoints"):
+        assert np.array_equal(got[k].cpu().numpy(), exp[k]), k
+    assert exp["coords"].min() == -2147483648 and len(exp["coords"]) == 3
+    ret = VoxelGenerator(unit, [10, 10, 10])(torch.from_numpy(bad).cuda())
     assert ret.points_mask.tolist() == [1] and ret.coords.tolist() == [[5, 5, 5]] and ret.points_mapping.tolist() == [0]
+    far = torch.tensor([[2.0e5, 0, 0, 0], [0.5, 0.5, 0.5, 1]]).cuda()            # coordinate 2e6 > 2^20
+    with pytest.raises(ValueError):
+        voxelize_3d_sparse(far, [0.1, 0.1, 0.1])
+    ret = VoxelGenerator(unit, [10, 10, 10])(far)
+    assert ret.points_mask.tolist() == [1] and ret.coords.tolist() == [[5, 5, 5]]
 
 
 def test_full_size_cfg2_properties():

@@ -112,3 +112,134 @@ def test_candidate_restricted_forms_equal_the_plain_loops():
     d, ds = synth.boxes2d_dense(1500, 13)                     # the heavily overlapping distribution
     assert np.array_equal(oracle.box2d_nms(d, ds, iou_method="rbox", iou_threshold=0.3),
                           oracle.box2d_nms_hard_candidates(d, ds, "rbox", 0.3))
+
+
+def _loss_cases():
+    """pairs for GIoU / DIoU: random overlapping and disjoint ones plus the degenerate configurations of the hull logic"""
+    rng = np.random.default_rng(8)
+    n = 24
+    b1 = np.stack([(rng.random(n) - .5) * 8, (rng.random(n) - .5) * 8, rng.random(n) * 5 + .1, rng.random(n) * 5 + .1,
+                   (rng.random(n) - .5) * 10], 1)
+    b2 = np.stack([(rng.random(n) - .5) * 8, (rng.random(n) - .5) * 8, rng.random(n) * 5 + .1, rng.random(n) * 5 + .1,
+                   (rng.random(n) - .5) * 10], 1)
+    special1 = np.array([[0, 0, 2, 2, 0], [0, 0, 2, 2, 0], [0, 0, 2, 2, 0], [0, 0, 4, 4, 0], [0, 0, 2, 2, 0], [0, 0, 2, 2, 0],
+                         [0, 0, 2, 2, 0.5], [0, 0, 2, 1, 0], [1, 1, 2, 2, np.pi / 4]], np.float64)
+    special2 = np.array([[0, 0, 2, 2, 0],          # identical
+                         [2, 0, 2, 2, 0],          # sharing a whole edge
+                         [2, 2, 2, 2, 0],          # touching in one corner
+                         [0.5, 0.25, 1, 1, 0],     # contained
+                         [1, 0, 2, 2, 0],          # two collinear sides each, overlapping
+                         [5, 0, 2, 2, 0],          # apart, collinear sides
+                         [0, 0, 2, 2, 0.5],        # identical, rotated
+                         [0, 1.5, 2, 2, 0],        # collinear vertical sides, different sizes
+                         [1, 1, 2, 2, np.pi / 4 + np.pi / 2]], np.float64)     # the same square under another angle
+    return np.concatenate([b1, special1]), np.concatenate([b2, special2])
+
+
+def test_giou_diou_against_exact_rational():
+    from exact_clip import loss_iou_exact
+    b1, b2 = _loss_cases()
+    for kind in ("grbox", "drbox"):
+        got = oracle.loss_iou2dr(b1, b2, kind)
+        for i in range(len(b1)):
+            for j in list(range(0, len(b2), 5)) + [i]:
+                assert abs(got[i, j] - loss_iou_exact(b1[i], b2[j], kind)) < 1e-12, (kind, i, j)
+    g = oracle.loss_iou2dr(b1, b2, "grbox")
+    assert np.all(g <= 1 + 1e-12) and np.all(g > -1) and abs(g[len(b1) - 9, len(b2) - 9] - 1) < 1e-15     # identical boxes -> 1
+    assert np.all(oracle.loss_iou2dr(b1, b2, "drbox") <= 1 + 1e-12)
+    # the public wrapper routes the two methods (reference box/__init__.py:207-216)
+    assert np.array_equal(oracle.box2d_iou(b1, b2, "grbox"), g)
+    # a rectangle without area gives 0, never NaN
+    z = np.array([[0, 0, 0, 2, 0.3]])
+    assert oracle.loss_iou2dr(z, b2[:3], "grbox").tolist() == [[0, 0, 0]] and oracle.loss_iou2dr(b1[:2], z, "drbox").tolist() == [[0], [0]]
+
+
+def test_flags_describe_the_intersection_polygon():
+    """xflags name where every vertex of the intersection comes from: rebuilding the polygon from them gives the
+    intersection area of the IoU; hull flags list the hull's corners; far is the farthest corner pair"""
+    from exact_clip import corners
+    rng = np.random.default_rng(9)
+    n = 30
+    b1 = np.stack([(rng.random(n) - .5) * 6, (rng.random(n) - .5) * 6, rng.random(n) * 4 + .5, rng.random(n) * 4 + .5,
+                   (rng.random(n) - .5) * 6], 1)
+    f = oracle.iou2dr_flags(b1, b1[::-1].copy())
+    b2 = b1[::-1]
+    iou = oracle.box2d_iou(b1, b2, "rbox")
+
+    def line_x(p, q, r, s):
+        d = (q[0] - p[0]) * (s[1] - r[1]) - (q[1] - p[1]) * (s[0] - r[0])
+        t = ((r[0] - p[0]) * (s[1] - r[1]) - (r[1] - p[1]) * (s[0] - r[0])) / d
+        return (p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1]))
+    for i in range(n):
+        for j in range(n):
+            c1, c2 = corners(*b1[i]), corners(*b2[j])
+            k = int(f.nx[i, j])
+            assert (k == 0) == (iou[i, j] == 0) or k == 0
+            poly = []
+            for fl in f.xflags[i, j, :k]:
+                if fl < 0x10:
+                    poly.append(c1[fl])
+                elif fl < 0x20:
+                    poly.append(c2[fl & 3])
+                else:
+                    e1, e2 = (fl >> 2) & 3, fl & 3
+                    poly.append(line_x(c1[e1], c1[(e1 + 1) & 3], c2[e2], c2[(e2 + 1) & 3]))
+            assert np.all(f.xflags[i, j, k:] == 0xff)
+            a = 0.5 * sum(poly[t][0] * poly[(t + 1) % k][1] - poly[(t + 1) % k][0] * poly[t][1] for t in range(k)) if k else 0.0
+            a1, a2 = b1[i, 2] * b1[i, 3], b2[j, 2] * b2[j, 3]
+            inter = iou[i, j] * (a1 + a2) / (1 + iou[i, j])
+            assert abs(a - inter) < 1e-9, (i, j, k, a, inter)
+            pts = np.array(c1 + c2)
+            hull = f.mflags[i, j, :f.nm[i, j]]
+            assert 3 <= len(hull) <= 8 and len(set(hull.tolist())) == len(hull)
+            d = np.linalg.norm(pts[:, None] - pts[None], axis=2)
+            assert np.isclose(d[f.far[i, j, 0], f.far[i, j, 1]], d.max()) and f.far[i, j, 0] < f.far[i, j, 1]
+            hull_pts = {tuple(pts[h]) for h in hull}                     # (identical boxes: a hull vertex stands for both copies)
+            assert all(tuple(pts[v]) in hull_pts for v in f.far[i, j])   # the diameter is attained at hull vertices
+
+
+def test_pdist_sign_and_nearest_feature():
+    rng = np.random.default_rng(10)
+    pts = (rng.random((400, 2)) - 0.5) * 8
+    boxes = np.array([[0, 0, 2, 2, 0], [0.5, -0.3, 3, 1, 0.7], [-1, 1, 1, 4, -2.0]])
+    d, e = oracle.pdist2dr(pts, boxes)
+    inside = oracle.crop_2dr(pts, boxes)
+    assert np.array_equal(d > 0, inside & (d != 0))                       # positive exactly inside (box/__init__.py:370-381)
+    # axis-aligned square: closed form
+    ax, ay = np.abs(pts[:, 0]), np.abs(pts[:, 1])
+    inside0 = (ax <= 1) & (ay <= 1)
+    ref = np.where(inside0, np.minimum(1 - ax, 1 - ay), -np.hypot(np.maximum(ax - 1, 0), np.maximum(ay - 1, 0)))
+    assert np.allclose(d[0], ref, atol=1e-12)
+    assert np.all(e[0][inside0] < 4) and np.all(e[0][(ax > 1) & (ay > 1)] >= 4)      # corner regions name a corner
+
+
+def test_evaluator_restatement_reproduces_the_reference_test():
+    """test/test_benchmark.py:10-84 on arrays (classes Car = 1, Van = 2, Pedestrian = 3)"""
+    thr = np.array([0.05, 0.75, 0.9], np.float32)
+    dt = np.array([[1, 0.8, 0, 0, 0, 2, 2, 2, 0], [2, 0.7, 1, 1, 1, 2, 2, 2, 0], [3, 0.8, -1, -1, -1, 2, 2, 2, 0]], np.float32)
+    r = oracle.calc_stats(dt, dt, [1, 2], {1: 0.9, 2: 0.8}, thr)
+    for c in (1, 2):
+        assert r.ngt[c] == 1 and r.ndt[c][0] == 1 and r.ndt[c][-1] == 0 and r.tp[c][0] == 1 and r.tp[c][-1] == 0
+        assert r.fp[c][0] == 0 and r.fp[c][-1] == 0 and r.fn[c][0] == 0 and r.fn[c][-1] == 1
+        assert np.isclose(r.acc_iou[c][0], 1) and np.isnan(r.acc_iou[c][-1]) and np.isclose(r.acc_dist[c][0], 0)
+    gt = np.array([[2, 0, 0, 0, 0, 2.1, 2.1, 2.1, 0.01], [1, 0, -1, 1, 0, 2.1, 2.1, 2.1, 0.01],
+                   [3, 0, 1, -1, 0, 2.1, 2.1, 2.1, 0.01]], np.float32)
+    r = oracle.calc_stats(gt, dt, [1, 2], {1: 0.9, 2: 0.8}, thr)
+    assert r.tp[1][0] == 1 and r.fp[1][0] == 0 and r.fn[1][0] == 0 and r.acc_iou[1][0] > 0.1 and r.acc_dist[1][0] > 1
+    assert r.acc_angular[1][0] > 0 and r.acc_box[1][0] > 0 and abs(r.acc_iou[1][0] - bc.EVAL_IOU) < 1e-4
+    assert r.tp[2][0] == 0 and r.fp[2][0] == 1 and r.fn[2][0] == 1 and np.isnan(r.acc_iou[2][0])
+
+
+def test_row_wise_association_equals_the_pair_loop():
+    from d3d_amd import synth
+    pred, gt = synth.boxes3d_eval(60, 4, 5)
+    rng = np.random.default_rng(6)
+    dt = np.concatenate([rng.integers(1, 4, (len(pred), 1)), rng.random((len(pred), 1)), pred], 1).astype(np.float32)
+    g9 = np.concatenate([rng.integers(1, 4, (len(gt), 1)), np.zeros((len(gt), 1)), gt], 1).astype(np.float32)
+    cache = oracle.prepare_boxes(dt, g9)
+    thr = {1: 0.7, 2: 0.5}
+    sa, da = oracle.score_match(cache, dt, g9, [i for i in range(len(dt)) if int(dt[i, 0]) in thr],
+                                [j for j in range(len(g9)) if int(g9[j, 0]) in thr], thr)
+    sm, dm = oracle.score_match_rows(cache, dt, g9, thr)
+    assert {i: int(j) for i, j in enumerate(sm) if j >= 0} == sa and {j: int(i) for j, i in enumerate(dm) if i >= 0} == da
+    assert 10 < len(sa) < len(g9)
