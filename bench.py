@@ -292,6 +292,7 @@ def main():
     ap.add_argument("--dist", choices=["lidar", "uniform"], default="lidar")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (RCCL) path even with one rank")
     ap.add_argument("--skip-large", action="store_true", help="skip the 8 M-point beyond-cache roofline leg")
+    ap.add_argument("--large-only", action="store_true", help="run only that leg and print it (rocprofv3 --pmc passes)")
     ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port when bench.py launches the ranks itself")
     args = ap.parse_args()
 
@@ -312,6 +313,9 @@ def main():
     from d3d_amd.voxel import VoxelGenerator
 
     torch.cuda.set_device(local_rank)
+    if args.large_only:
+        print(json.dumps({"roofline_large": large_frame_leg()}))
+        return
     barrier = None
     sharded = world > 1 or args.force_sharded
     if sharded:

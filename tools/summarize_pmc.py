@@ -28,7 +28,7 @@ def short(name):
     if base.startswith("k_scan_"):
         f = re.search(r"(NumberVoxels|FilterVoxels|FilterPoints|PopcountWords)", targs)
         return "%s<%s>" % (base, f.group(1)) if f else base
-    return base
+    return "k_fill_c4" if base == "k_fill_c4_rows" else base       # (one kernel of the op, two forms: bench.py's name)
 
 
 def load(path, counter):
@@ -65,6 +65,7 @@ def main():
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     allt = json.load(open(tj)) if os.path.exists(tj) else {}
     allt[workload] = traffic
+    allt["_profile"] = tag
     json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
     print(open(out).read())
 
