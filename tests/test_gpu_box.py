@@ -470,7 +470,7 @@ def test_c_abi_error_codes():
     p = _lib.ptr
     assert lib.d3d_iou2d_forward(z, 4, p(b), 4, 2, _lib.F64, p(out), z, 0, z, 0) == _lib.ERR_BAD_ARG            # null boxes
     assert lib.d3d_iou2d_forward(p(b), -1, p(b), 4, 2, _lib.F64, p(out), z, 0, z, 0) == _lib.ERR_BAD_ARG       # negative size
-    assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 4, _lib.F64, p(out), z, 0, z, 0) == _lib.ERR_UNSUPPORTED    # GRBOX
+    assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 3, _lib.F64, p(out), z, 0, z, 0) == _lib.ERR_UNSUPPORTED    # GBOX
     assert lib.d3d_iou2d_forward(p(b), 0, p(b), 4, 2, _lib.F64, z, z, 0, z, 0) == 0                             # empty: ok
     assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 3, 0, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), ws.numel(),
                          z, 0) == _lib.ERR_UNSUPPORTED                                                          # GBOX in NMS
@@ -523,3 +523,21 @@ def test_soft_nms_trailing_zero_scores_come_back():
             kw = dict(iou_method=method, supression_method=sup, iou_threshold=0.1, score_threshold=0.0, supression_param=2.0)
             keep = box2d_nms(torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), **kw).cpu().numpy()
             assert np.array_equal(keep, oracle.box2d_nms(b, s, **kw)), (sup, method)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 4095, 4096, 4097, 100000, 131073])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_argsort_desc_stable_all_sizes(n, dtype):
+    """d3d_argsort_desc: descending, equal keys (+0 and -0 included) in index order, infinities at the ends"""
+    from d3d_amd.box import argsort_desc
+    rng = np.random.default_rng(n)
+    s = rng.random(n).astype(dtype)
+    if n > 10:
+        s[rng.integers(0, n, n // 5)] = s[rng.integers(0, n, n // 5)]          # ties
+        s[rng.integers(0, n, 3)] = 0.0
+        s[rng.integers(0, n, 3)] = -0.0
+        s[rng.integers(0, n, 2)] = -np.inf
+        s[rng.integers(0, n, 2)] = np.inf
+        s[::7] *= -1
+    got = argsort_desc(T(s)).cpu().numpy()
+    assert got.dtype == np.int64 and np.array_equal(got, np.argsort(-s, kind="stable"))
