@@ -35,7 +35,10 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "liboracle.so")
-        if not os.path.exists(path):
+        if os.environ.get("D3D_ORACLE_SANITIZED") == "1":       # tools/run_sanitized.sh: the ASan + UBSan build of the checker
+            path = os.path.join(_HERE, "liboracle_asan.so")
+            subprocess.check_call(["make", "-s", "-C", _HERE, "asan"])
+        elif not os.path.exists(path):
             build()
         L = ctypes.CDLL(path)
         L.oracle_voxelize_3d_dense.restype = ctypes.c_int64
