@@ -17,6 +17,8 @@ __global__ __launch_bounds__(256) void k_grid_mark(const int64_t *__restrict__ k
     if (j >= m) return;
     const int64_t k = keys[j];
     if (k < 0 || k >= ncells) return;
+    // (testing the word first -- the gathered lists name a cell 1.4 times on average at world 8 -- costs a coherent load
+    // per key and was slower: 733 vs 520 us for 8 M keys on config 5's 136 MB bitmap)
     atomicOr(&bitmap[k >> 6], 1ull << (k & 63));
 }
 
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(256) void k_sharded_scatter(const int64_t *__restri
 
 // sharded voxelizer, last step: slot-ordered reduced table -> voxel-id-ordered outputs.  The voxel id of a slot is
 // the rank of its first point index among all first indices (bitmap over the frame's points, popcount prefix).
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_sharded_finalize(int64_t nvox, int c, const int64_t *__restrict__ first,
                                                           int64_t n_total, const unsigned long long *__restrict__ bitmap,
                                                           const uint32_t *__restrict__ prefix,
@@ -178,8 +181,20 @@ __global__ __launch_bounds__(256) void k_sharded_finalize(int64_t nvox, int c, c
     vid_of_slot[s] = v;
     if (v < 0) return;                                 // cannot happen: every slot has a first point
     const int64_t k = key_of_slot[s];
-    const long long c0 = k / (sy * sz), c1 = (k / sz) % sy, c2 = k % sz;
     long long *cp = reinterpret_cast<long long *>(coords) + v * 3;
+    if (PACKED) {
+        // two scattered 16-byte stores per voxel instead of four requests: {key, count} parked in the 16-byte-aligned half
+        // of the voxel's coordinate row (k_sharded_unpack expands it in place, streaming) + the features
+        const float *row = table + s * tstride;
+        const float n = mean ? row[c] : 1.f;
+        const int32_t cnt = mean ? (int32_t)(n + 0.5f) : cnt_in[s];
+        *reinterpret_cast<longlong2 *>(cp + (v & 1)) = make_longlong2(k, (long long)cnt);
+        float4 f = make_float4(row[0], row[1], row[2], row[3]);
+        if (mean) f = make_float4(f.x / n, f.y / n, f.z / n, f.w / n);
+        reinterpret_cast<float4 *>(feats)[v] = f;
+        return;
+    }
+    const long long c0 = k / (sy * sz), c1 = (k / sz) % sy, c2 = k % sz;
     if (vec4) {                                          // 24 bytes as 16 + 8 (rows alternate their 16-byte alignment)
         if ((v & 1) == 0) { *reinterpret_cast<longlong2 *>(cp) = make_longlong2(c0, c1); cp[2] = c2; }
         else { cp[0] = c0; *reinterpret_cast<longlong2 *>(cp + 1) = make_longlong2(c1, c2); }
@@ -515,7 +530,16 @@ extern "C" int d3d_sharded_finalize(int64_t nvox, int32_t c, const int64_t *firs
     WsCarver w(compact_ws, compact_ws_bytes);
     unsigned long long *bitmap = w.take<unsigned long long>(nw);
     uint32_t *prefix = w.take<uint32_t>(nw);
-    D3D_LAUNCH("k_sharded_finalize", k_sharded_finalize, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox, c, first,
+    const bool al16 = ((reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(coords)) & 15) == 0;
+    if (c == 4 && al16) {
+        D3D_LAUNCH("k_sharded_finalize", k_sharded_finalize<true>, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox, c, first,
+                   n_total > 0 ? n_total : (int64_t)1, bitmap, prefix, key_of_slot, table, table_stride, mean, cnt_in,
+                   (int64_t)shape[1], (int64_t)shape[2], vid_of_slot, coords, cnt_out, feats, true);
+        D3D_LAUNCH("k_sharded_unpack", k_sharded_unpack, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox,
+                   (int64_t)shape[1], (int64_t)shape[2], coords, cnt_out);
+        return D3D_OK;
+    }
+    D3D_LAUNCH("k_sharded_finalize", k_sharded_finalize<false>, dim3((unsigned)d3d_divup(nvox, 256)), dim3(256), 0, st, nvox, c, first,
                n_total > 0 ? n_total : (int64_t)1, bitmap, prefix, key_of_slot, table, table_stride, mean, cnt_in,
                (int64_t)shape[1], (int64_t)shape[2], vid_of_slot, coords, cnt_out, feats,
                (reinterpret_cast<uintptr_t>(feats) & 15) == 0);

@@ -386,8 +386,11 @@ class ShardedVoxelGenerator:
             table, cnt_t, first, _, slot_r = ops.build_table(handle, keys_r[:n], 0, n, nvox, c, self._red, agg_r, cnt_r,
                                                              first_r, want_keys=False)
         else:
-            table, cnt_t, first, key_of_slot, slot_r = ops.build_table(
-                handle, keys_all, comm.rank * (cap + 1), n, nvox, c, self._red, agg_r, cnt_r, first_r)
+            # the cells of the slots come out of the marked bitmap in one streaming pass; only this rank's own voxels need
+            # the per-key lookup (looking all world x cap gathered keys up again cost 8 x the requests at world 8)
+            key_of_slot = ops.compact_keys(handle, nvox)
+            table, cnt_t, first, _, slot_r = ops.build_table(handle, keys_r[:n], 0, n, nvox, c, self._red, agg_r, cnt_r,
+                                                             first_r, want_keys=False)
         if nvox > 0:
             comm.all_reduce(table, "sum" if mean else ("max" if self._red == 2 else "min"))
             if cnt_t is not None:

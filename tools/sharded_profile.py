@@ -12,15 +12,20 @@ from sharded_helpers import LockedOps, ThreadWorld
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
-clouds = [torch.from_numpy(synth.lidar_like(n, r)).cuda() for r in range(W)]
+cfg5 = len(sys.argv) > 3 and sys.argv[3] == "config5"        # config 5: Waymo range, 0.05 m voxels, key exchange
+BOUNDS, SHAPE = (synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE) if cfg5 else (synth.KITTI_BOUNDS, synth.KITTI_SHAPE)
+if cfg5:
+    frame = synth.lidar_like(W * n, 3, BOUNDS)
+    clouds = [torch.from_numpy(frame[r * n:(r + 1) * n].copy()).cuda() for r in range(W)]
+else:
+    clouds = [torch.from_numpy(synth.lidar_like(n, r)).cuda() for r in range(W)]
 
 def step():
     tw, lock = ThreadWorld(W), threading.Lock()
     outs = [None] * W
     def run(rank):
         torch.cuda.set_device(0)
-        gen = ShardedVoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, reduction="mean", comm=tw.comm(rank),
-                                    ops=LockedOps(HipOps(), lock))
+        gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction="mean", comm=tw.comm(rank), ops=LockedOps(HipOps(), lock))
         outs[rank] = gen(clouds[rank])
     ts = [threading.Thread(target=run, args=(r,)) for r in range(W)]
     [t.start() for t in ts]; [t.join() for t in ts]
