@@ -917,24 +917,24 @@ __device__ __forceinline__ void meta_voxel(const Key &kf, int64_t v, const uint4
         if (cnt <= P) {
             float a0, a1, a2, a3;
             a0 = a1 = a2 = a3 = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
-            // 4 rows per step (independent loads);
-            // the accumulation stays strictly in point order
-            for (uint32_t k = 0; k < cnt; k += 4) {
+            // most voxels of a LiDAR frame hold ONE point: its row alone first (one gather), the rest 4 rows per step
+            // (independent loads); the accumulation stays strictly in point order
+            auto acc = [&](const float4 x) {
+                if (is_sum) { a0 += x.x; a1 += x.y; a2 += x.z; a3 += x.w; }
+                else if (reduction == D3D_REDUCE_MAX) {      // std::max(acc, x) = acc < x ? x : acc
+                    a0 = a0 < x.x ? x.x : a0; a1 = a1 < x.y ? x.y : a1; a2 = a2 < x.z ? x.z : a2; a3 = a3 < x.w ? x.w : a3;
+                } else {
+                    a0 = x.x < a0 ? x.x : a0; a1 = x.y < a1 ? x.y : a1; a2 = x.z < a2 ? x.z : a2; a3 = x.w < a3 ? x.w : a3;
+                }
+            };
+            if (cnt > 0) acc(staged[base]);
+            for (uint32_t k = 1; k < cnt; k += 4) {
                 const float4 *row = staged + base + k;         // contiguous rows, loads independent
                 const float4 xs[4] = {row[0], k + 1 < cnt ? row[1] : row[0], k + 2 < cnt ? row[2] : row[0],
                                       k + 3 < cnt ? row[3] : row[0]};
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (k + j < cnt) {
-                        const float4 x = xs[j];
-                        if (is_sum) { a0 += x.x; a1 += x.y; a2 += x.z; a3 += x.w; }
-                        else if (reduction == D3D_REDUCE_MAX) {      // std::max(acc, x) = acc < x ? x : acc
-                            a0 = a0 < x.x ? x.x : a0; a1 = a1 < x.y ? x.y : a1; a2 = a2 < x.z ? x.z : a2; a3 = a3 < x.w ? x.w : a3;
-                        } else {
-                            a0 = x.x < a0 ? x.x : a0; a1 = x.y < a1 ? x.y : a1; a2 = x.z < a2 ? x.z : a2; a3 = x.w < a3 ? x.w : a3;
-                        }
-                    }
-                }
+                for (int j = 0; j < 4; j++)
+                    if (k + j < cnt) acc(xs[j]);
             }
             if (reduction == D3D_REDUCE_MEAN) {              // voxelize.cpp:164 (float / int)
                 const float d = (float)(int32_t)cnt;
