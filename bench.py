@@ -264,6 +264,45 @@ def extras(args):
     pt, gt = torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda()
     dt = timed(lambda: iou3d(pt, gt), 20, 3)
     ex["iou3d_rbox_fp32_mpairs_per_s"] = round(1e8 * 20 / dt / 1e6, 1)
+    # config 4 as the evaluator uses it: [n,9] ingress + clip + 1 - riou, then ONE score-ordered association
+    # for all 40 score thresholds of DetectionEvaluator.calc_stats (the reference re-sorts the matrix per threshold)
+    from d3d_amd.benchmarks import DetectionEvaluator
+    from d3d_amd.tracking import DistanceTypes, prepare_boxes
+    rng = np.random.default_rng(5)
+    gt9 = np.concatenate([rng.integers(1, 3, (len(g), 1)), np.zeros((len(g), 1)), g], 1).astype(np.float32)
+    dt9 = np.concatenate([np.repeat(gt9[:, :1], 4, axis=0), rng.random((len(p), 1)), p], 1).astype(np.float32)
+    dt9t, gt9t = torch.from_numpy(dt9).cuda(), torch.from_numpy(gt9).cuda()
+    dt = timed(lambda: prepare_boxes(dt9t, gt9t, DistanceTypes.RIoU), 20, 3)
+    ex["match_distance_riou_fp32_mpairs_per_s"] = round(1e8 * 20 / dt / 1e6, 1)
+    ev = DetectionEvaluator([1, 2], [0.7, 0.5])
+    ev.calc_stats(gt9, dt9)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ev.calc_stats(gt9, dt9)
+    sync()
+    ex["evaluator_calc_stats_20kx5k_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 2)
+    del dt9t, gt9t
+    # loss path: GIoU / DIoU have a value for EVERY pair (no candidate list): 8 B/pair written + 160 cross
+    # products per pair for the hull; fp64, 10 k x 10 k of config 3's boxes; backward on the same matrix
+    nl = 10000
+    bl = torch.from_numpy(b[:nl]).cuda()
+    for method in ("grbox", "drbox"):
+        dt = timed(lambda: box2d_iou(bl, bl, method=method), 5, 1)
+        ex["iou2d_%s_fp64_mpairs_per_s" % method] = round(nl * nl * 5 / dt / 1e6, 1)
+    b1g, b2g = bl[:2000].clone().requires_grad_(True), bl[2000:4000].clone().requires_grad_(True)
+
+    def fwd_bwd():
+        b1g.grad = b2g.grad = None
+        box2d_iou(b1g, b2g, method="grbox").sum().backward()
+    dt = timed(fwd_bwd, 5, 1)
+    ex["iou2d_grbox_fp64_fwd_bwd_2kx2k_ms"] = round(dt / 5 * 1e3, 3)
+    from d3d_amd.box import pdist2dr_forward
+    pts2 = torch.rand((1000000, 2), dtype=torch.float32, device="cuda") * 3000
+    bx32 = bl[:2000].to(torch.float32)
+    dt = timed(lambda: pdist2dr_forward(pts2, bx32), 5, 1)          # 2000 boxes x 1 M points: 8 GB of distances + 2 GB of iedge
+    ex["pdist2dr_fp32_mpairs_per_s"] = round(2000 * 1e6 * 5 / dt / 1e6, 1)
+    del pts2, bx32, bl, b1g, b2g
+    torch.cuda.empty_cache()
     if not args.skip_cpu:
         k = 3000
         t0 = time.perf_counter(); oracle.iou2d_forward(b[:k], b[:k], "rbox", nthreads=ncpu); dt = time.perf_counter() - t0
@@ -277,6 +316,11 @@ def extras(args):
         t0 = time.perf_counter(); oracle.iou3d(p[:2000], g, "rbox", nthreads=1); dt = time.perf_counter() - t0
         ex["cpu_iou3d_rbox_fp32_mpairs_per_s"] = dict(value=round(2000 * 5000 / dt / 1e6, 2), cores=1, kind="port",
                                                        sample="2000x5000 pairs of config 4")
+        # the evaluator as the reference runs it (one association PER threshold, python restatement of the Cython loops)
+        sub_g, sub_d = gt9[:100], dt9[:400]
+        t0 = time.perf_counter(); oracle.calc_stats(sub_g, sub_d, [1, 2], {1: 0.3, 2: 0.5}, ev.score_thresholds); dt = time.perf_counter() - t0
+        ex["cpu_evaluator_calc_stats_ms"] = dict(value=round(dt * 1e3, 1), cores=1, kind="port",
+                                                  sample="400 detections x 100 ground truths, 40 thresholds (python loops)")
     return ex
 
 

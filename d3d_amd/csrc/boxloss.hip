@@ -209,25 +209,45 @@ __global__ __launch_bounds__(256) void k_pair_flags(const T *__restrict__ b1, in
 }
 
 // ---------------------------------------------------------------- point-to-box distance
-// dist[m, n] (box-major, like the reference: dist.cpp:39): tile = 64 boxes (LDS) x 256 points (lanes: coalesced rows)
-template <typename T>
+// dist[m, n] (box-major, like the reference: dist.cpp:39): tile = 64 boxes (LDS) x 256 * K points; a lane owns K consecutive
+// points, so a row of the tile leaves as K * sizeof(T)-byte and K-byte stores per lane (K = 4 where n % 4 == 0 keeps the rows
+// aligned: 16-byte / 4-byte stores for fp32 instead of 4-byte / 1-byte ones)
+template <typename T, int K>
 __global__ __launch_bounds__(kCols) void k_pdist(const T *__restrict__ points, int64_t n, const T *__restrict__ boxes, int64_t m,
                                                  T *__restrict__ dist, uint8_t *__restrict__ iedge)
 {
     __shared__ RowBox<T> rows[kRows];
-    const int64_t i0 = (int64_t)blockIdx.y * kRows, j = (int64_t)blockIdx.x * kCols + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * kRows, j0 = ((int64_t)blockIdx.x * kCols + threadIdx.x) * K;
     const int nrows = (int)((m - i0) < kRows ? (m - i0) : kRows);
     if (threadIdx.x < nrows) rows[threadIdx.x] = load_row<T>(boxes + (i0 + threadIdx.x) * 5);
     __syncthreads();
-    if (j >= n) return;
-    const T px = points[j * 2], py = points[j * 2 + 1];
+    if (j0 >= n) return;                   // n % K == 0 (host-checked): a lane's K points are all valid or all not
+    T px[K], py[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { px[k] = points[(j0 + k) * 2]; py[k] = points[(j0 + k) * 2 + 1]; }
     T gp[2], gb[5];
     for (int r = 0; r < nrows; r++) {
         const RowBox<T> b = rows[r];
-        int feat;
-        const T d = point_box_distance<T, false>(b.g, b.w, b.h, px, py, feat, gp, gb);
-        dist[(i0 + r) * n + j] = d;
-        if (iedge) iedge[(i0 + r) * n + j] = (uint8_t)feat;
+        T d[K];
+        uint8_t f[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            int feat;
+            d[k] = point_box_distance<T, false>(b.g, b.w, b.h, px[k], py[k], feat, gp, gb);
+            f[k] = (uint8_t)feat;
+        }
+        T *o = dist + (i0 + r) * n + j0;
+        if constexpr (K == 4) {
+            typedef T vecd __attribute__((ext_vector_type(4)));
+            const vecd x = {d[0], d[1], d[2], d[3]};
+            __builtin_nontemporal_store(x, reinterpret_cast<vecd *>(o));
+            if (iedge)
+                __builtin_nontemporal_store((unsigned int)f[0] | ((unsigned int)f[1] << 8) | ((unsigned int)f[2] << 16) | ((unsigned int)f[3] << 24),
+                                            reinterpret_cast<unsigned int *>(iedge + (i0 + r) * n + j0));
+        } else {
+            o[0] = d[0];
+            if (iedge) iedge[(i0 + r) * n + j0] = f[0];
+        }
     }
 }
 
@@ -331,11 +351,12 @@ extern "C" int d3d_pdist2dr_forward(const void *points, int64_t n, const void *b
     if (n < 0 || m < 0 || (dtype != D3D_F32 && dtype != D3D_F64)) return D3D_ERR_BAD_ARG;
     if (n == 0 || m == 0) return D3D_OK;
     if (!points || !boxes || !dist || d3d_divup(m, kRows) > 65535) return D3D_ERR_BAD_ARG;
-    const dim3 grid((unsigned)d3d_divup(n, kCols), (unsigned)d3d_divup(m, kRows));
-    if (dtype == D3D_F64)
-        D3D_LAUNCH("k_pdist", k_pdist<double>, grid, dim3(kCols), 0, st, (const double *)points, n, (const double *)boxes, m, (double *)dist, iedge);
-    else
-        D3D_LAUNCH("k_pdist", k_pdist<float>, grid, dim3(kCols), 0, st, (const float *)points, n, (const float *)boxes, m, (float *)dist, iedge);
+    const bool k4 = n % 4 == 0 && (reinterpret_cast<uintptr_t>(dist) & 31) == 0 && (reinterpret_cast<uintptr_t>(iedge) & 3) == 0;
+    const dim3 grid((unsigned)d3d_divup(n, (int64_t)kCols * (k4 ? 4 : 1)), (unsigned)d3d_divup(m, kRows));
+#define D3D_PDIST(T, K) D3D_LAUNCH("k_pdist", (k_pdist<T, K>), grid, dim3(kCols), 0, st, (const T *)points, n, (const T *)boxes, m, (T *)dist, iedge)
+    if (dtype == D3D_F64) { if (k4) D3D_PDIST(double, 4); else D3D_PDIST(double, 1); }
+    else { if (k4) D3D_PDIST(float, 4); else D3D_PDIST(float, 1); }
+#undef D3D_PDIST
     return D3D_OK;
 }
 

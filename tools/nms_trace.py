@@ -1,5 +1,8 @@
-#!/usr/bin/env python3
-"""box2d_nms on cfg3 under rocprofv3 --kernel-trace --stats (development aid; no per-launch events)"""
+"""box2d_nms on cfg3, for rocprofv3 (development aid; no per-launch events).  Run it with the interpreter named after `--`
+(a script with an env shebang would be an exec after the profiler has initialised the GPU, which this pool forbids):
+
+    cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d out -- python3 $GRAFT_REPO_ROOT/tools/nms_trace.py
+"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
