@@ -276,13 +276,30 @@ __device__ __forceinline__ Corners8<T> corners8(const BoxGeom<T> &a, const BoxGe
     return c;
 }
 
-// is corner r acceptable for the candidate hull segment p -> q?  (ip, iq, ir: corner numbers, for the coincidence rule)
+// orientation of the corner triple (ip, iq, ir): > 0 when r lies to the left of p -> q.  Evaluated in ONE canonical form per
+// triple (corners taken in ascending number, the sign following the permutation), so that the decisions about p -> q, q -> r
+// and p -> r that involve the same three corners can never contradict each other through rounding -- with the plain
+// cross(q - p, r - p) a nearly collinear triple could reject the long segment AND one of the two short ones (a missing
+// triangle: 1 % of the hull of two distant boxes in fp32, found by tools/fuzz.py), or accept all three.
 template <typename T>
-__device__ __forceinline__ bool hull_side_ok(T px, T py, T qx, T qy, T rx, T ry, int ip, int iq, int ir)
+__device__ __forceinline__ T orient3(const Corners8<T> &c, int ip, int iq, int ir)
 {
-    const T cr = (qx - px) * (ry - py) - (qy - py) * (rx - px);
+    int a = ip, b = iq, d = ir;
+    T sign = 1;
+    if (a > b) { const int t = a; a = b; b = t; sign = -sign; }
+    if (b > d) { const int t = b; b = d; d = t; sign = -sign; }
+    if (a > b) { const int t = a; a = b; b = t; sign = -sign; }
+    return sign * ((c.x[b] - c.x[a]) * (c.y[d] - c.y[a]) - (c.y[b] - c.y[a]) * (c.x[d] - c.x[a]));
+}
+
+// is corner r acceptable for the candidate hull segment p -> q?  (the corner numbers also decide coincidences)
+template <typename T>
+__device__ __forceinline__ bool hull_side_ok(const Corners8<T> &c, int ip, int iq, int ir)
+{
+    const T cr = orient3<T>(c, ip, iq, ir);
     if (cr > 0) return true;
     if (cr < 0) return false;
+    const T px = c.x[ip], py = c.y[ip], qx = c.x[iq], qy = c.y[iq], rx = c.x[ir], ry = c.y[ir];
     // collinear: inside the closed segment?  (dot(r - p, q - r) >= 0)
     if (!((rx - px) * (qx - rx) + (ry - py) * (qy - ry) >= 0)) return false;
     // coincident with an end: the lower-numbered copy represents the point
@@ -315,7 +332,7 @@ __device__ __forceinline__ T hull_area2(const Corners8<T> &c, T (&gx)[8], T (&gy
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int r = 4 * (1 - s) + t;
-                ok = ok && hull_side_ok<T>(c.x[p], c.y[p], c.x[q], c.y[q], c.x[r], c.y[r], p, q, r);
+                ok = ok && hull_side_ok<T>(c, p, q, r);
             }
             if (ok) accept(p, q);
         }
@@ -328,15 +345,11 @@ __device__ __forceinline__ T hull_area2(const Corners8<T> &c, T (&gx)[8], T (&gy
             const int a = i, b = 4 + j;
             const int an = (i + 1) & 3, ap = (i + 3) & 3, bn = 4 + ((j + 1) & 3), bp = 4 + ((j + 3) & 3);
             if (c.x[a] == c.x[b] && c.y[a] == c.y[b]) continue;          // zero-length segment
-            bool ok = hull_side_ok<T>(c.x[a], c.y[a], c.x[b], c.y[b], c.x[an], c.y[an], a, b, an) &&
-                      hull_side_ok<T>(c.x[a], c.y[a], c.x[b], c.y[b], c.x[ap], c.y[ap], a, b, ap) &&
-                      hull_side_ok<T>(c.x[a], c.y[a], c.x[b], c.y[b], c.x[bn], c.y[bn], a, b, bn) &&
-                      hull_side_ok<T>(c.x[a], c.y[a], c.x[b], c.y[b], c.x[bp], c.y[bp], a, b, bp);
+            bool ok = hull_side_ok<T>(c, a, b, an) && hull_side_ok<T>(c, a, b, ap) && hull_side_ok<T>(c, a, b, bn) &&
+                      hull_side_ok<T>(c, a, b, bp);
             if (ok) accept(a, b);
-            ok = hull_side_ok<T>(c.x[b], c.y[b], c.x[a], c.y[a], c.x[an], c.y[an], b, a, an) &&
-                 hull_side_ok<T>(c.x[b], c.y[b], c.x[a], c.y[a], c.x[ap], c.y[ap], b, a, ap) &&
-                 hull_side_ok<T>(c.x[b], c.y[b], c.x[a], c.y[a], c.x[bn], c.y[bn], b, a, bn) &&
-                 hull_side_ok<T>(c.x[b], c.y[b], c.x[a], c.y[a], c.x[bp], c.y[bp], b, a, bp);
+            ok = hull_side_ok<T>(c, b, a, an) && hull_side_ok<T>(c, b, a, ap) && hull_side_ok<T>(c, b, a, bn) &&
+                 hull_side_ok<T>(c, b, a, bp);
             if (ok) accept(b, a);
         }
     }

@@ -37,6 +37,12 @@ def test_giou_diou_forward_vs_oracle(method):
     assert got.shape == (700, 333) and np.max(np.abs(got - exp)) < 1e-9 and exp.min() < -0.5
     got32 = box2d_iou(T(a.astype(np.float32)), T(b.astype(np.float32)), method=method, precise=False)
     assert got32.dtype == torch.float32 and np.max(np.abs(got32.cpu().numpy() - exp)) < 1e-3
+    # fp32, two distant boxes with three nearly collinear corners: the hull's side tests must not contradict each other
+    # (a plain cross product per test dropped a triangle here: 1 % of the hull; found by tools/fuzz.py seed 1108)
+    p1 = np.array([[14.133374123782117, 95.78430107915649, 18.709020547809505, 17.869571663447932, -1.5023764635329853]], np.float32)
+    p2 = np.array([[99.75258369712863, 41.69109148023853, 13.649590629949753, 1.2516093306660403, -3.587157370156718]], np.float32)
+    v32 = float(box2d_iou(T(p1), T(p2), method=method, precise=False)[0, 0])
+    assert abs(v32 - float(oracle.loss_iou2dr(p1.astype(np.float64), p2.astype(np.float64), method)[0, 0])) < 1e-4
     z = np.array([[0, 0, 0, 2, 0.3], [1, 1, -1, 2, 0]])         # no area: 0, never NaN
     assert torch.count_nonzero(box2d_iou(T(z), T(b[:5]), method=method)) == 0
     assert box2d_iou(T(a[:0]), T(b), method=method).shape == (0, 333)

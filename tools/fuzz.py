@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import oracle
 import test_gpu_voxel as tv
-from d3d_amd.box import box2d_iou, box2d_nms
+from d3d_amd.box import box2d_iou, box2d_nms, iou2dr_flags, pdist2dr_forward
+from d3d_amd.tracking import DistanceTypes, prepare_boxes, score_match
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
@@ -42,4 +43,53 @@ for seed in range(first, first + count):
     err = float(np.max(np.abs(got - ref))) if got.size else 0.0
     if err > 1e-9:
         bad += 1; print("IOU seed", seed, method, n, m, "FAILED", err)
+    # ---- round-2 operators: GIoU / DIoU values, flag tensors, point-to-box distance, matcher association
+    m2 = min(m, 120)
+    bs, b2s = b[: min(n, 200)], b2[:m2]
+    if seed % 6 == 0:                                       # degenerate configurations of the hull logic
+        b2s = b2s.copy()
+        k = min(len(bs), len(b2s))
+        b2s[:k] = bs[:k]                                    # identical boxes
+        if k > 3:
+            b2s[1, 0] += bs[1, 2]; b2s[1, 4] = bs[1, 4]     # (roughly) sharing a side
+            b2s[2, 2:4] *= 0.25                             # contained
+    for meth in ("grbox", "drbox"):
+        got = box2d_iou(torch.from_numpy(bs).cuda(), torch.from_numpy(b2s).cuda(), method=meth).cpu().numpy()
+        err = float(np.max(np.abs(got - oracle.loss_iou2dr(bs, b2s, meth)))) if got.size else 0.0
+        if err > 1e-9:
+            bad += 1; print("LOSS-IOU seed", seed, meth, len(bs), len(b2s), "FAILED", err)
+        g32 = box2d_iou(torch.from_numpy(bs.astype(np.float32)).cuda(), torch.from_numpy(b2s.astype(np.float32)).cuda(), method=meth,
+                        precise=False).cpu().numpy()
+        if g32.size and float(np.max(np.abs(g32 - oracle.loss_iou2dr(bs, b2s, meth)))) > 2e-3:
+            bad += 1; print("LOSS-IOU fp32 seed", seed, meth, "FAILED")
+    fl = iou2dr_flags(torch.from_numpy(bs).cuda(), torch.from_numpy(b2s).cuda(), which=("nx", "xflags", "nm", "mflags"))
+    efl = oracle.iou2dr_flags(bs, b2s)
+    if seed % 6 != 0:                                       # (exactly degenerate pairs may round differently on the two sides)
+        for kk in ("nx", "xflags", "nm", "mflags"):
+            if not np.array_equal(fl[kk].cpu().numpy(), efl[kk]):
+                bad += 1; print("FLAGS seed", seed, kk, "FAILED", int(np.sum(fl[kk].cpu().numpy() != efl[kk])))
+    pts = np.stack([rng.random(300) * scale * 1.2 - 0.1 * scale, rng.random(300) * scale * 1.2 - 0.1 * scale], 1)
+    d, e = pdist2dr_forward(torch.from_numpy(pts).cuda(), torch.from_numpy(bs).cuda())
+    dr, er = oracle.pdist2dr(pts, bs)
+    if float(np.max(np.abs(d.cpu().numpy() - dr))) > 1e-9 * max(scale, 1):
+        bad += 1; print("PDIST seed", seed, "FAILED", float(np.max(np.abs(d.cpu().numpy() - dr))))
+    # matcher: [n,9] boxes with classes, scores (ties every 5th seed), thresholds per class
+    nd, ng = int(rng.integers(1, 400)), int(rng.integers(1, 150))
+    gt7 = np.stack([rng.random(ng) * 40, rng.random(ng) * 40, rng.random(ng) * 2 - 2, rng.random(ng) * 1.5 + 3.5, rng.random(ng) * .5 + 1.6,
+                    rng.random(ng) * .5 + 1.4, rng.random(ng) * 6.28 - 3.14], 1)
+    dt7 = gt7[rng.integers(0, ng, nd)] + rng.normal(0, 0.4, (nd, 7)) * np.array([1, 1, .3, .2, .2, .2, .2])
+    sc = rng.random(nd)
+    if seed % 5 == 0:
+        sc = np.round(sc * 10) / 10
+    dt9 = np.concatenate([rng.integers(1, 4, (nd, 1)), sc[:, None], dt7], 1).astype(np.float32)
+    gt9 = np.concatenate([rng.integers(1, 4, (ng, 1)), np.zeros((ng, 1)), gt7], 1).astype(np.float32)
+    thr_c = {1: float(rng.choice([0.3, 0.5, 0.9])), 2: float(rng.choice([0.5, 0.7]))}
+    cache = prepare_boxes(dt9, gt9, DistanceTypes.RIoU if seed % 2 else DistanceTypes.IoU)
+    ref_cache = oracle.prepare_boxes(dt9, gt9, bool(seed % 2))
+    if float(np.max(np.abs(cache.cpu().numpy() - ref_cache))) > 1e-3:
+        bad += 1; print("MATCH-DIST seed", seed, "FAILED")
+    sm, dm = score_match(cache, dt9[:, 1], dt9[:, 0], gt9[:, 0], thr_c)
+    esm, edm = oracle.score_match_rows(cache.cpu().numpy(), dt9, gt9, thr_c)       # on the GPU's own distances: exact
+    if not (np.array_equal(sm.cpu().numpy(), esm) and np.array_equal(dm.cpu().numpy(), edm)):
+        bad += 1; print("MATCH seed", seed, "FAILED", int(np.sum(sm.cpu().numpy() != esm)))
 print("fuzz: %d seeds, %d failures" % (count, bad))
