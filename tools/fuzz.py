@@ -92,4 +92,26 @@ for seed in range(first, first + count):
     esm, edm = oracle.score_match_rows(cache.cpu().numpy(), dt9, gt9, thr_c)       # on the GPU's own distances: exact
     if not (np.array_equal(sm.cpu().numpy(), esm) and np.array_equal(dm.cpu().numpy(), edm)):
         bad += 1; print("MATCH seed", seed, "FAILED", int(np.sum(sm.cpu().numpy() != esm)))
+    # gradients of the loss path against central differences of the fp64 oracle (small sets: 2 x (8 + 6) x 5 oracle passes)
+    g1n, g2n = bs[:8].copy(), b2s[:6].copy()
+    if len(g1n) and len(g2n) and seed % 6 != 0:        # (identical / touching boxes sit ON a kink: no two-sided derivative there)
+        wgt = rng.random((len(g1n), len(g2n)))
+        for meth in ("rbox", "grbox", "drbox"):
+            t1, t2 = torch.from_numpy(g1n).cuda().requires_grad_(True), torch.from_numpy(g2n).cuda().requires_grad_(True)
+            (box2d_iou(t1, t2, method=meth) * torch.from_numpy(wgt).cuda()).sum().backward()
+            ga, gb = t1.grad.cpu().numpy(), t2.grad.cpu().numpy()
+            ofn = (lambda x, y: oracle.box2d_iou(x, y, "rbox")) if meth == "rbox" else (lambda x, y: oracle.loss_iou2dr(x, y, meth))
+            h = 1e-6
+            worst = 0.0
+            for arr, g, first_arg in ((g1n, ga, True), (g2n, gb, False)):
+                for i in range(len(arr)):
+                    for k in range(5):
+                        pp, mm = arr.copy(), arr.copy()
+                        pp[i, k] += h
+                        mm[i, k] -= h
+                        f = ((ofn(pp, g2n) - ofn(mm, g2n)) * wgt).sum() if first_arg else ((ofn(g1n, pp) - ofn(g1n, mm)) * wgt).sum()
+                        fd = f / (2 * h)
+                        worst = max(worst, abs(fd - g[i, k]) / max(1.0, abs(fd)))
+            if worst > 1e-4:        # (a kink of the piecewise function within h of the sample would show up here too)
+                bad += 1; print("GRAD seed", seed, meth, "FAILED", worst)
 print("fuzz: %d seeds, %d failures" % (count, bad))
