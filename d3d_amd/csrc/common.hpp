@@ -126,11 +126,18 @@ static __global__ __launch_bounds__(1024) void k_scan_bsum(unsigned long long *b
 {
     __shared__ unsigned long long smem[1024 / kWave];
     unsigned long long carry = 0;
-    for (int64_t c0 = 0; c0 < nb; c0 += 1024) {
-        int64_t i = c0 + threadIdx.x;
-        unsigned long long v = i < nb ? bsum[i] : 0ull, tot;
-        unsigned long long ex = block_excl_scan_u64<1024>(v, &tot, smem);
-        if (i < nb) bsum[i] = carry + ex;
+    // 4 consecutive block sums per thread and step (a 136 MB bitmap has 16.6 k of them: 5 steps instead of 17)
+    for (int64_t c0 = 0; c0 < nb; c0 += 4096) {
+        const int64_t i = c0 + (int64_t)threadIdx.x * 4;
+        unsigned long long v[4], mine = 0, tot;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = i + k < nb ? bsum[i + k] : 0ull; mine += v[k]; }
+        unsigned long long ex = carry + block_excl_scan_u64<1024>(mine, &tot, smem);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i + k < nb) bsum[i + k] = ex;
+            ex += v[k];
+        }
         carry += tot;
     }
     if (threadIdx.x == 0) {

@@ -56,3 +56,31 @@ def test_host_side_validation_without_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):          # no silent CPU fallback
             g(torch.zeros(4, 4))
+
+
+def test_evaluator_and_matcher_host_logic_without_gpu():
+    """score thresholds as benchmarks.pyx:125-134 derives them, class / overlap parsing, array validation"""
+    import numpy as np
+    import torch
+    from d3d_amd.benchmarks import DetectionEvaluator
+    from d3d_amd.tracking import DistanceTypes, prepare_boxes
+    ev = DetectionEvaluator([3, 7], [0.7, 0.5])
+    assert abs(ev._max_distance[3] - 0.3) < 1e-12 and ev._max_distance[7] == 0.5 and len(ev.score_thresholds) == 40
+    t = ev.score_thresholds
+    assert np.all(np.diff(t) > 0) and t[0] == 0 and t[-1] < 1 and abs(t[-1] - (1 - (10 ** (1 / 40) - 1) / 9)) < 1e-6
+    lin = DetectionEvaluator(5, 0.5, pr_sample_count=4, min_score=0.2, pr_sample_scale="lin").score_thresholds
+    assert np.allclose(lin, [0.2, 0.4, 0.6, 0.8])
+    assert DetectionEvaluator([1], 0.5, pr_sample_scale="log100", pr_sample_count=8).score_thresholds.shape == (8,)
+    with pytest.raises(ValueError):
+        DetectionEvaluator([1], 0.5, pr_sample_scale="cubic")
+    with pytest.raises(ValueError):
+        DetectionEvaluator([1], "0.5")
+    assert DistanceTypes.IoU == 1 and DistanceTypes.RIoU == 2 and DistanceTypes.Position == 3
+    with pytest.raises(ValueError):
+        prepare_boxes(np.zeros((3, 7), np.float32), np.zeros((3, 9), np.float32), DistanceTypes.RIoU)
+    # no boxes on either side: the reference's early return (benchmarks.pyx / matcher.pyx:41-43), nothing touches a device
+    r = ev.calc_stats(np.zeros((0, 9), np.float32), np.zeros((0, 9), np.float32))
+    assert r.ngt == {3: 0, 7: 0} and r.tp[3] == [0] * 40 and np.all(np.isnan(r.acc_iou[7]))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="HIP device"):
+            prepare_boxes(np.zeros((3, 9), np.float32), np.zeros((3, 9), np.float32), DistanceTypes.IoU)
