@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256) void k_geom(const T *__restrict__ boxes, int64
 //   candidates  lane = 4 columns (AABBs in registers), rows broadcast from LDS; survivors go to a per-wavefront LDS
 //               batch (fill count is wave-uniform: no workgroup barrier inside the row loop) that is flushed to the
 //               global list with one atomic
-//   zero fill   the rows of a tile row are ONE contiguous slab of the matrix; its 4 KiB chunks are dealt to the
-//               workgroups of the tile row, so every wavefront store is 1 KiB and 1 KiB-aligned whatever m is
-//               (row-by-row stores are misaligned when m * sizeof(T) is not a multiple of the 128-byte line: 2x slower)
+//   zero fill   the matrix as one run of 4 KiB chunks dealt to the workgroups like a grid-stride loop (see below): every
+//               wavefront store is 1 KiB and 1 KiB-aligned whatever m is (row-by-row stores are misaligned when
+//               m * sizeof(T) is not a multiple of the 128-byte line: 2x slower), and the chip writes one moving window
 constexpr int kPreK = 4;
 constexpr int kPreCols = kTileCols * kPreK;
 constexpr int kPreBatch = 1024;      // LDS batch entries per wavefront
@@ -202,13 +202,16 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
         if (lane == 0) base = atomicAdd(counter, (unsigned long long)wn);
         write_out(__shfl(base, 0, 64));
     };
-    // zero fill: the slab [i0, i0 + nrows) x [0, m) as 16-byte vectors (16-byte aligned: i0 * m * sizeof(T) is a multiple
-    // of 256 and the host checks the base pointer), chunk c = vectors [256 c, 256 c + 256)
-    const size_t slab_bytes = (size_t)nrows * (size_t)m * sizeof(T);
-    const size_t nvec = slab_bytes / 16, nchunk = (nvec + kTileCols - 1) / kTileCols;
-    const size_t per_block = (nchunk + gridDim.x - 1) / gridDim.x;
-    const size_t c0 = (size_t)blockIdx.x * per_block, c1 = c0 + per_block < nchunk ? c0 + per_block : nchunk;
-    vec16 *slab = ious ? reinterpret_cast<vec16 *>(ious + i0 * m) : nullptr;
+    // background fill of the WHOLE matrix as 16-byte vectors (the host checks the base pointer's alignment), in 4 KiB chunks
+    // of 256 vectors dealt out like a grid-stride loop: workgroup L (in dispatch order) writes chunks L, L + G, L + 2 G, ...
+    // (G = workgroups of the launch), two or so per row of its tile.  The workgroups resident at any moment have consecutive
+    // L, so the chip writes ONE compact moving window of the matrix -- the DRAM-friendly order (bare nt stores: 6.5 TB/s
+    // against 4.8-5.6 TB/s when every workgroup streams through a region of its own, tools/fill_bench.hip).  Which workgroup
+    // zeroes which chunk is irrelevant to the result: the candidates are written by the next kernel.
+    const size_t total_bytes = (size_t)n * (size_t)m * sizeof(T);
+    const size_t nvec = total_bytes / 16, nchunk = (nvec + kTileCols - 1) / kTileCols;
+    const size_t G = (size_t)gridDim.x * gridDim.y, L = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    vec16 *slab = ious ? reinterpret_cast<vec16 *>(ious) : nullptr;
     const vec16 z = {fillv, fillv, fillv, fillv};
     for (int r = 0; r < kTileRows; r++) {
         if (r < nrows) {
@@ -232,13 +235,13 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
             }
         }
         if (slab)
-            for (size_t c = c0 + r; c < c1; c += kTileRows) {
+            for (size_t c = L + (size_t)r * G; c < nchunk; c += (size_t)kTileRows * G) {
                 const size_t v = c * kTileCols + threadIdx.x;
                 if (v < nvec) __builtin_nontemporal_store(z, slab + v);
             }
     }
-    if (slab && blockIdx.x == 0 && threadIdx.x == 0)             // slab size not a multiple of 16 bytes (last tile row)
-        for (size_t e = nvec * (16 / sizeof(T)); e < (size_t)nrows * (size_t)m; e++) ious[i0 * m + e] = (T)fillv;
+    if (slab && L == 0 && threadIdx.x == 0)                      // matrix size not a multiple of 16 bytes
+        for (size_t e = nvec * (16 / sizeof(T)); e < (size_t)n * (size_t)m; e++) ious[e] = (T)fillv;
     // what is left in the four batches is reserved with ONE atomic per workgroup: atomics on the list counter are
     // serialised at ~7 ns each, and every workgroup of a short launch gets here at about the same time
     const int wave = threadIdx.x >> 6;
