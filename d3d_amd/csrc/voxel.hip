@@ -1290,10 +1290,14 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
     typedef BinEntry<ROWS> E;
     constexpr KT kFree = (KT)~(KT)0;
     __shared__ KT tkey[T];
-    __shared__ uint32_t tcnt[T], tfirst[T], tbase[T];
+    // LDS budget: 4 workgroups per CU need <= 40 KiB each (and <= 64 VGPRs).  A register bucket has at most 2048 points, so a
+    // slot's count and segment base share one word after the records phase (tcnt = base << 16 | count); a big bucket keeps
+    // the bases in seg[] (its index segments live in global memory).
+    static_assert(kBucketCap <= 0xffff && kBucketCap == T, "packed count | base; tbase aliases seg");
+    __shared__ uint32_t tcnt[T], tfirst[T];
     __shared__ uint32_t seg[kBucketCap];
     __shared__ u64 smem[kBucketThreads / kWave];
-    __shared__ uint16_t oslot[T];                   // overflow voxels of the bucket (count > P)
+    __shared__ uint16_t oslot[ROWS ? T / 2 : 1];    // overflow voxels of the bucket (count > P >= 1: at most m / 2 of them)
     __shared__ uint32_t nover, fail;
     typedef float v4f __attribute__((ext_vector_type(4)));   // (an array of HIP float4 structs stayed in scratch)
     const uint32_t bb = bucket_base[blockIdx.x], m = bucket_base[blockIdx.x + 1] - bb;
@@ -1302,7 +1306,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
     if (threadIdx.x == 0) { nover = 0; fail = 0; }
 
     // phase B of both modes: segments in slot order, one record per voxel, firstmap
-    auto records = [&]() {
+    auto records = [&](auto BIG) {
         constexpr int PER = T / kBucketThreads;
         const int s0 = threadIdx.x * PER;
         uint32_t c[PER];
@@ -1314,7 +1318,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         uint32_t base = (uint32_t)(ex >> 32), j = (uint32_t)ex;
 #pragma unroll
         for (int k = 0; k < PER; k++) {
-            tbase[s0 + k] = base;
+            if constexpr (decltype(BIG)::value) seg[s0 + k] = base;
+            else tcnt[s0 + k] = c[k] | (base << 16);
             if (c[k]) {
                 const uint32_t f = tfirst[s0 + k];
                 const u64 kk = (u64)tkey[s0 + k];
@@ -1333,7 +1338,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                 if (pass) __hip_atomic_store(&firstmap[f], bb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 tfirst[s0 + k] = bb + j;            // from here on: the slot's record
                 j++;
-                if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
+                if constexpr (ROWS)
+                    if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
             }
             base += c[k];
         }
@@ -1343,13 +1349,14 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
     // accumulates in fp64 (insensitive to the order to ~1e-16 => the same float run to run; differs from the
     // reference's fp32 running sum by rounding only).  The result waits in row P of the voxel's segment, which no
     // ranked point uses.
-    auto reduce_overflow = [&](const uint32_t *sg) {
+    auto reduce_overflow = [&](const uint32_t *sg, auto BIG) {
         const uint32_t no = ROWS && reduction != D3D_REDUCE_NONE ? nover : 0u;
         if (no == 0) return;
         const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
         const int lane = threadIdx.x & (kWave - 1);
         for (uint32_t o = threadIdx.x >> 6; o < no; o += kBucketThreads / kWave) {
-            const uint32_t s = oslot[o], base = tbase[s], cnt = tcnt[s];
+            const uint32_t s = oslot[o], w = tcnt[s];
+            const uint32_t base = decltype(BIG)::value ? seg[s] : w >> 16, cnt = decltype(BIG)::value ? w : w & 0xffffu;
             double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
             float e0, e1, e2, e3;
             e0 = e1 = e2 = e3 = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
@@ -1419,7 +1426,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             if (threadIdx.x == 0) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_BIN_OVERFLOW);
             return;
         }
-        records();
+        const uint32_t *tbase = seg;
+        records(std::true_type{});
         __syncthreads();
         uint32_t *sg = gseg + bb;
         for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) {
@@ -1442,7 +1450,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             if (trimmed && rank >= P) trimmed[me] = 1;
             if (precpos) precpos[bb + q] = tfirst[s];
         }
-        reduce_overflow(sg);
+        reduce_overflow(sg, std::true_type{});
         return;
     }
 
@@ -1483,19 +1491,19 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         }
     });
     lds_barrier();
-    records();
+    records(std::false_type{});
     lds_barrier();
     static_for<ITEMS>([&](auto R) {
         constexpr int r = decltype(R)::value;
         const uint32_t q = threadIdx.x + r * kBucketThreads;
-        if (q < m) seg[tbase[slot[r]] + arr[r]] = idx[r];
+        if (q < m) seg[(tcnt[slot[r]] >> 16) + arr[r]] = idx[r];
     });
     lds_barrier();
     static_for<ITEMS>([&](auto R) {
         constexpr int r = decltype(R)::value;
         const uint32_t q = threadIdx.x + r * kBucketThreads;
         if (q < m) {
-            const uint32_t s = slot[r], cnt = tcnt[s], base = tbase[s], me = idx[r];
+            const uint32_t s = slot[r], cb = tcnt[s], cnt = cb & 0xffffu, base = cb >> 16, me = idx[r];
             uint32_t rank = 0, k = 0;
             const uint32_t *sg = seg + base;
             for (; k + 8 <= cnt && rank < P; k += 8)      // 8 independent LDS reads per exit test
@@ -1511,7 +1519,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             if (precpos) precpos[bb + q] = tfirst[s];
         }
     });
-    reduce_overflow(seg);
+    reduce_overflow(seg, std::false_type{});
 }
 
 // 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF (<= 256 of them:
