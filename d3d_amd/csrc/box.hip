@@ -425,6 +425,7 @@ extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int
 extern "C" size_t d3d_internal_argsort_i32_bytes(int64_t n);
 
 enum { kUndecided = 0, kKept = 1, kSuppressed = 2 };
+constexpr int kIncTile = 1024;      // boxes per workgroup of k_nms_incscan
 
 struct NmsFlags { unsigned int need_sweep, undecided; };
 constexpr int kNmsListSegs = 1;     // see list_segments(): segmenting the list did not pay
@@ -445,12 +446,13 @@ __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__
                               const int64_t *__restrict__ order, int64_t n, float score_threshold,
                               BoxGeom<T> *geom, float4 *fbox, uint8_t *state, uint32_t *inc_cnt, float *farea,
                               unsigned long long *remv, int64_t nb, NmsFlags *flags, NmsCand *cand_hdr,
-                              unsigned int force_dense, int32_t *xkey, unsigned int *grid_ticket)
+                              unsigned int force_dense, int32_t *xkey, unsigned int *grid_ticket, unsigned long long *tile_tot)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // sorted position
     bool pre = false;
     if (p == 0) { flags->need_sweep = force_dense; flags->undecided = 0; *grid_ticket = 0; }
     if (p < kNmsListSegs) cand_hdr->count[p * 16] = 0;
+    if (p * kIncTile < n) tile_tot[p] = 0;                   // k_nms_incscan's ready words
     if (p < n) {
         const int64_t i = order[p];
         const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(256) void k_nms_cand_grid(const float4 *__restrict_
 }
 
 // narrow phase, pass A: exact IoU of one candidate per lane.  The entry is rewritten as (hit << 63 | p << 32 | q) in score
-// ranks (p suppresses q, p < q) and the hits of every box are counted; the scan of the counts (IncOffsets) and pass B
+// ranks (p suppresses q, p < q) and the hits of every box are counted; the scan of the counts (k_nms_incscan) and pass B
 // (k_nms_fill) then lay the hitters of every box out contiguously -- lists of any length, so clusters of hundreds of
 // overlapping detections stay on this path.
 constexpr unsigned long long kHitBit = 1ull << 63;
@@ -869,14 +871,54 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__
     }
 }
 
-struct IncOffsets {                  // inc_off = exclusive scan of inc_cnt (d3d_run_scan)
-    static constexpr const char *kName = "k_scan_count<IncOffsets>", *kName2 = "k_scan_apply<IncOffsets>";
-    const uint32_t *inc_cnt;
-    uint32_t *inc_off;
-    __device__ __forceinline__ unsigned long long value(int64_t q) const { return inc_cnt[q]; }
-    __device__ __forceinline__ unsigned long long value2(int64_t q) const { return inc_cnt[q]; }
-    __device__ __forceinline__ void apply(int64_t q, unsigned long long, unsigned long long excl) const { inc_off[q] = (uint32_t)excl; }
-};
+// inc_off = exclusive scan of inc_cnt in ONE launch (the generic count / block-sum / apply trio is three, ~4 us each in a
+// stream): a local scan per 1024-box tile; every workgroup publishes its tile total with a ready bit (tile_tot[] is zeroed by
+// k_nms_prepare) and adds up the totals of the tiles before it, polling the ones not there yet.  A workgroup only waits for
+// LOWER-numbered workgroups, which the dispatcher started before it, and they publish before they wait: always progress.
+__global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict__ inc_cnt, int64_t n, uint32_t *__restrict__ inc_off,
+                                                     unsigned long long *tile_tot)
+{
+    __shared__ unsigned long long smem[4], sbase;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kIncTile + (int64_t)w * 256 + lane;       // wavefront w: 4 rows of 64 boxes
+    unsigned long long ex[4], carry = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t i = base + k * 64;
+        const unsigned long long v = i < n ? inc_cnt[i] : 0u;
+        const unsigned long long incl = wave_incl_scan_u64(v);
+        ex[k] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) smem[w] = carry;
+    __syncthreads();
+    unsigned long long woff = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (k < w) woff += smem[k]; total += smem[k]; }
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&tile_tot[blockIdx.x], (total << 1) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w == 0) {
+        unsigned long long acc = 0;
+        for (unsigned int j0 = 0; j0 < blockIdx.x; j0 += 64) {
+            const unsigned int j = j0 + lane;
+            if (j < blockIdx.x) {
+                unsigned long long t;
+                do { t = __hip_atomic_load(&tile_tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(t & 1ull));
+                acc += t >> 1;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) sbase = acc;
+    }
+    __syncthreads();
+    const unsigned long long off = sbase + woff;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t i = base + k * 64;
+        if (i < n) inc_off[i] = (uint32_t)(off + ex[k]);
+    }
+}
 
 // pass B: the hits into the boxes' segments
 __global__ __launch_bounds__(256) void k_nms_fill(const unsigned long long *__restrict__ list, unsigned long long cap,
@@ -1060,8 +1102,9 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     uint32_t *inc_cnt = w.take<uint32_t>(nb * 64);
     uint32_t *inc_off = w.take<uint32_t>(nb * 64);
     float *farea = w.take<float>(nb * 64);
-    unsigned long long *inc_bsum = w.take<unsigned long long>(d3d_divup(nb * 64, kScanTile) + 1);
-    int64_t *inc_total = w.take<int64_t>(D3D_NUM_COUNTS);
+    unsigned long long *tile_tot = w.take<unsigned long long>(d3d_divup(nb * 64, kScanTile) + 1);
+    (void)w.take<int64_t>(D3D_NUM_COUNTS);
+    static_assert(kIncTile == kScanTile, "workspace sized with kScanTile");
     NmsFlags *flags = w.take<NmsFlags>(1);
     unsigned long long *remv = w.take<unsigned long long>(nb);
     NmsCand *cand_hdr = w.take<NmsCand>(1);
@@ -1094,7 +1137,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     const bool rot = iou_type == D3D_IOU_RBOX;
     const bool use_grid = !(opts & D3D_NMS_BROAD_SWEEP);
     D3D_LAUNCH("k_nms_prepare", k_nms_prepare<T>, dim3((unsigned)nb), dim3(64), 0, st, boxes, scores, order, n, score_thr,
-               geom, fbox, state, inc_cnt, farea, remv, nb, flags, cand_hdr, (opts & D3D_NMS_FORCE_DENSE) ? 1u : 0u, xkey, &grid->ticket);
+               geom, fbox, state, inc_cnt, farea, remv, nb, flags, cand_hdr, (opts & D3D_NMS_FORCE_DENSE) ? 1u : 0u, xkey, &grid->ticket, tile_tot);
     if (use_grid) {
         const unsigned nbl = (unsigned)d3d_divup(n, 256);
         D3D_LAUNCH("k_nms_extent", k_nms_extent, dim3(kGridParts), dim3(256), 0, st, (const float4 *)fbox, n, gpartial, grid, cellcur);
@@ -1123,8 +1166,8 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     else
         D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, false>), dim3(hits_blocks), dim3(256), 0, st, geom, rankx, cand, cap, cand_hdr,
                    (T)iou_thr, inc_cnt, arrival);
-    IncOffsets offs{inc_cnt, inc_off};
-    if (int rc = d3d_run_scan(offs, n, inc_bsum, inc_total, -1, 0, ~0ull, st)) return rc;
+    D3D_LAUNCH("k_nms_incscan", k_nms_incscan, dim3((unsigned)d3d_divup(n, kIncTile)), dim3(256), 0, st, (const uint32_t *)inc_cnt, n,
+               inc_off, tile_tot);
     D3D_LAUNCH("k_nms_fill", k_nms_fill, dim3(hits_blocks), dim3(256), 0, st, (const unsigned long long *)cand, cap,
                (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, (const uint32_t *)arrival, inc);
     D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,

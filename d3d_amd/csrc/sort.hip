@@ -2,6 +2,7 @@
 // role torch::argsort plays inside the reference: nms.cpp:103, voxelize.cpp:406).
 #include <cstring>
 #include <cstdlib>
+#include <algorithm>
 #include "common.hpp"
 #include <rocprim/rocprim.hpp>
 
@@ -11,36 +12,329 @@ namespace {
 // (NMS of 100 k boxes 0.240 vs 0.231 ms), so the library default stays.
 typedef rocprim::default_config SortConfig;
 
+// ---------------------------------------------------------------- key order
+// The order both paths implement is torch's (nms.cpp:103 argsort(descending = true)): descending by VALUE, -0 == +0, every NaN
+// equal to every other and greater than any number, ties in ascending index (stable).  Keys are mapped to unsigned integers
+// whose ASCENDING order is that order, so the two paths cannot differ on special values.
+template <typename K> struct KeyBits;
+template <> struct KeyBits<float> {
+    typedef uint32_t U;
+    static __host__ __device__ __forceinline__ U desc(float x)
+    {
+        U b = __builtin_bit_cast(U, x);
+        if (x != x) return 0u;                               // NaN: first
+        if (b == 0x80000000u) b = 0u;                        // -0 -> +0
+        const U asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        return ~asc;
+    }
+};
+template <> struct KeyBits<double> {
+    typedef unsigned long long U;
+    static __host__ __device__ __forceinline__ U desc(double x)
+    {
+        U b = __builtin_bit_cast(U, x);
+        if (x != x) return 0ull;
+        if (b == 0x8000000000000000ull) b = 0ull;
+        const U asc = (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+        return ~asc;
+    }
+};
+template <> struct KeyBits<int32_t> {                        // (internal: the sweep broad phase's x keys)
+    typedef uint32_t U;
+    static __host__ __device__ __forceinline__ U desc(int32_t x) { return ~((uint32_t)x ^ 0x80000000u); }
+};
+template <typename K> struct DescKey {
+    typedef typename KeyBits<K>::U U;
+    __host__ __device__ __forceinline__ U operator()(const K &x) const { return KeyBits<K>::desc(x); }
+};
+
+// ---------------------------------------------------------------- library path (rocPRIM; any n)
 // V = type of the order entries (int32 inside the library, int64 at the C ABI: written directly, no widening pass)
 template <typename K, typename V>
 size_t sort_temp_bytes(int64_t n)
 {
+    typedef typename KeyBits<K>::U U;
     size_t tmp = 0;
-    (void)rocprim::radix_sort_pairs_desc<SortConfig, const K *, K *, rocprim::counting_iterator<V>, V *>(
-        nullptr, tmp, nullptr, nullptr, rocprim::counting_iterator<V>(0), nullptr, (size_t)n);
+    (void)rocprim::radix_sort_pairs<SortConfig, rocprim::transform_iterator<const K *, DescKey<K>, U>, U *, rocprim::counting_iterator<V>, V *>(
+        nullptr, tmp, rocprim::transform_iterator<const K *, DescKey<K>, U>(nullptr, DescKey<K>()), nullptr,
+        rocprim::counting_iterator<V>(0), nullptr, (size_t)n);
     return tmp;
+}
+
+template <typename K, typename V>
+size_t library_bytes(int64_t n)
+{
+    return d3d_align_up(sizeof(typename KeyBits<K>::U) * n) + d3d_align_up(sort_temp_bytes<K, V>(n)) + 256;
+}
+
+// order[n] <- stable descending argsort of keys; the values 0 .. n-1 come from a counting iterator
+template <typename K, typename V>
+int library_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    typedef typename KeyBits<K>::U U;
+    WsCarver w(ws, ws_bytes);
+    U *keys_out = w.take<U>(n);
+    size_t tmp = sort_temp_bytes<K, V>(n);
+    char *temp = w.take<char>(tmp);
+    if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
+    D3D_HIP_CHECK((rocprim::radix_sort_pairs<SortConfig>(temp, tmp, rocprim::transform_iterator<const K *, DescKey<K>, U>(keys, DescKey<K>()),
+                                                         keys_out, rocprim::counting_iterator<V>(0), order, (size_t)n, 0, sizeof(U) * 8, st)));
+    return D3D_OK;
+}
+
+// ---------------------------------------------------------------- bucket path (8 k .. 256 k keys: the NMS sizes)
+// The library sorts this range with a block sort + one merge launch per doubling (9 launches, 70 us at 100 k keys: launch
+// latency, not bandwidth).  Here: a sample sort in 4 launches --
+//   k_ss_splitters  one workgroup sorts 1024 stratified samples in LDS and keeps every (1024 / B)-th as a splitter
+//   k_ss_count      1024-key tiles: bucket of every key (binary search over the B - 1 splitters in LDS), LDS histogram whose
+//                   atomicAdd return value is the key's arrival number in (tile, bucket); one global atomicAdd per (tile,
+//                   bucket) reserves the tile's range inside the bucket (its return value = the tile's offset)
+//   k_ss_scatter    bucket bases = scan of the B totals (repeated per workgroup); (key, index) -> its bucket
+//   k_ss_bucket     one workgroup per bucket: sort in LDS, order[base + r] = index
+// Everything compares the composite (key, index): it is unique, so the splitters cut runs of equal keys (all-equal input
+// gives B equal buckets) and the result depends neither on the arrival order of the atomics nor on the sample.  Bucket
+// sizes only depend on the sample; a bucket that outgrows the LDS (> 5 x the mean at 4 samples per bucket: not seen) is
+// ranked from global memory by counting -- slow, still exact.
+// The LDS sort (samples, buckets): every wavefront sorts runs of 64 in registers (bitonic network over __shfl_xor, no
+// barrier), then log2(n / 64) merge passes in which every element finds its place in the merged run by a binary search
+// of the sibling run (unique composites: position = own position + number of smaller siblings) -- ~5 barriers instead of
+// the 55-66 of a workgroup-wide bitonic network, which took 22 us per bucket.
+constexpr int kSsSamples = 1024, kSsTile = 1024, kSsCountThreads = 256, kSsMaxBuckets = 256;
+constexpr int kSsSortThreads = 1024, kSsBucketCap = 2048;
+constexpr int64_t kSsMinN = 8192, kSsMaxN = (int64_t)kSsMaxBuckets * 1024;
+
+template <typename U> __device__ __forceinline__ bool comp_less(U da, uint32_t ia, U db, uint32_t ib)
+{
+    return da < db || (da == db && ia < ib);
+}
+__device__ __forceinline__ uint32_t shfl_xor_u(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, kWave); }
+__device__ __forceinline__ unsigned long long shfl_xor_u(unsigned long long v, int m)
+{
+    return ((unsigned long long)shfl_xor_u((uint32_t)(v >> 32), m) << 32) | shfl_xor_u((uint32_t)v, m);
+}
+
+// ascending sort of npad composites (power of two, 64 .. cap; entries are unique -- padding included) held in (d0, i0);
+// (d1, i1) is the second buffer.  Returns through *rd, *ri the buffer that holds the result.  Whole workgroup.
+template <typename U>
+__device__ __forceinline__ void sort_lds(U *d0, uint32_t *i0, U *d1, uint32_t *i1, int npad, U **rd, uint32_t **ri)
+{
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int c = wave; c < npad / kWave; c += nwaves) {                  // runs of 64 in registers
+        U d = d0[c * kWave + lane];
+        uint32_t i = i0[c * kWave + lane];
+#pragma unroll
+        for (int k = 2; k <= kWave; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const U od = shfl_xor_u(d, j);
+                const uint32_t oi = shfl_xor_u(i, j);
+                const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+                const bool other_less = comp_less(od, oi, d, i);
+                if (other_less == keep_min) { d = od; i = oi; }
+            }
+        d0[c * kWave + lane] = d;
+        i0[c * kWave + lane] = i;
+    }
+    __syncthreads();
+    U *sd = d0, *dd = d1;
+    uint32_t *si = i0, *di = i1;
+    for (int L = kWave; L < npad; L <<= 1) {
+        for (int e = threadIdx.x; e < npad; e += blockDim.x) {
+            const int run = e / L, pos = e - run * L;
+            const U *bd = sd + (run ^ 1) * L;
+            const uint32_t *bi = si + (run ^ 1) * L;
+            const U d = sd[e];
+            const uint32_t i = si[e];
+            int lo = 0;                                                  // number of sibling entries below (d, i)
+            for (int step = L >> 1; step > 0; step >>= 1)
+                if (comp_less(bd[lo + step - 1], bi[lo + step - 1], d, i)) lo += step;
+            if (comp_less(bd[lo], bi[lo], d, i)) lo++;                   // (lo <= L - 1 here)
+            const int dst = (run & ~1) * L + pos + lo;
+            dd[dst] = d;
+            di[dst] = i;
+        }
+        __syncthreads();
+        U *td = sd; sd = dd; dd = td;
+        uint32_t *ti = si; si = di; di = ti;
+    }
+    *rd = sd;
+    *ri = si;
+}
+
+__device__ __forceinline__ uint32_t ss_hash(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+template <typename K>
+__global__ __launch_bounds__(kSsSortThreads) void k_ss_splitters(const K *__restrict__ keys, uint32_t n, int B,
+                                                                 typename KeyBits<K>::U *spl_d, uint32_t *spl_i, uint32_t *bucket_cnt)
+{
+    typedef typename KeyBits<K>::U U;
+    __shared__ U d0[kSsSamples], d1[kSsSamples];
+    __shared__ uint32_t i0[kSsSamples], i1[kSsSamples];
+    const uint32_t len = n / kSsSamples;                     // n >= kSsMinN: >= 8
+    for (int j = threadIdx.x; j < kSsSamples; j += blockDim.x) {
+        const uint32_t pos = (uint32_t)j * len + ss_hash((uint32_t)j) % len;     // one sample per stratum, jittered
+        d0[j] = KeyBits<K>::desc(keys[pos]);
+        i0[j] = pos;
+    }
+    for (int b = threadIdx.x; b <= kSsMaxBuckets; b += blockDim.x) bucket_cnt[b] = 0;
+    __syncthreads();
+    U *d;
+    uint32_t *ii;
+    sort_lds(d0, i0, d1, i1, kSsSamples, &d, &ii);
+    for (int b = threadIdx.x + 1; b < B; b += blockDim.x) {
+        const int j = (int)((long long)b * kSsSamples / B);
+        spl_d[b - 1] = d[j];
+        spl_i[b - 1] = ii[j];
+    }
+}
+
+template <typename K>
+__global__ __launch_bounds__(kSsCountThreads) void k_ss_count(const K *__restrict__ keys, uint32_t n, int B,
+                                                              const typename KeyBits<K>::U *__restrict__ spl_d,
+                                                              const uint32_t *__restrict__ spl_i, uint32_t *__restrict__ pb,
+                                                              uint32_t *__restrict__ tileoff, uint32_t *bucket_cnt)
+{
+    typedef typename KeyBits<K>::U U;
+    __shared__ U sd[kSsMaxBuckets];
+    __shared__ uint32_t si[kSsMaxBuckets], hist[kSsMaxBuckets];
+    if ((int)threadIdx.x < B - 1) { sd[threadIdx.x] = spl_d[threadIdx.x]; si[threadIdx.x] = spl_i[threadIdx.x]; }
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSsTile / kSsCountThreads; k++) {
+        const uint32_t i = blockIdx.x * kSsTile + k * kSsCountThreads + threadIdx.x;
+        if (i < n) {
+            const U dk = KeyBits<K>::desc(keys[i]);
+            int lo = 0, hi = B - 1;                          // bucket = number of splitters <= (dk, i)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (comp_less(dk, i, sd[mid], si[mid])) hi = mid; else lo = mid + 1;
+            }
+            pb[i] = (uint32_t)lo | (atomicAdd(&hist[lo], 1u) << 8);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < B) {
+        const uint32_t c = hist[threadIdx.x];
+        tileoff[(size_t)blockIdx.x * kSsMaxBuckets + threadIdx.x] = c ? atomicAdd(&bucket_cnt[threadIdx.x], c) : 0u;
+    }
+}
+
+template <typename K>
+__global__ __launch_bounds__(kSsCountThreads) void k_ss_scatter(const K *__restrict__ keys, uint32_t n, int B,
+                                                                const uint32_t *__restrict__ pb, const uint32_t *__restrict__ tileoff,
+                                                                const uint32_t *__restrict__ bucket_cnt, uint32_t *bucket_base,
+                                                                typename KeyBits<K>::U *__restrict__ dk, uint32_t *__restrict__ di)
+{
+    __shared__ uint32_t off[kSsMaxBuckets];
+    __shared__ unsigned long long smem[kSsCountThreads / kWave];
+    unsigned long long total;
+    const uint32_t cnt = (int)threadIdx.x < B ? bucket_cnt[threadIdx.x] : 0u;
+    const uint32_t base = (uint32_t)block_excl_scan_u64<kSsCountThreads>(cnt, &total, smem);
+    off[threadIdx.x] = base + tileoff[(size_t)blockIdx.x * kSsMaxBuckets + threadIdx.x];
+    if (blockIdx.x == 0) {                                   // for k_ss_bucket
+        if ((int)threadIdx.x < B) bucket_base[threadIdx.x] = base;
+        if (threadIdx.x == 0) bucket_base[B] = (uint32_t)total;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSsTile / kSsCountThreads; k++) {
+        const uint32_t i = blockIdx.x * kSsTile + k * kSsCountThreads + threadIdx.x;
+        if (i < n) {
+            const uint32_t w = pb[i], pos = off[w & 255u] + (w >> 8);
+            dk[pos] = KeyBits<K>::desc(keys[i]);
+            di[pos] = i;
+        }
+    }
+}
+
+template <typename U, typename V>
+__global__ __launch_bounds__(kSsSortThreads) void k_ss_bucket(const U *__restrict__ dk, const uint32_t *__restrict__ di,
+                                                              const uint32_t *__restrict__ bucket_base, V *__restrict__ order)
+{
+    __shared__ U d0[kSsBucketCap], d1[kSsBucketCap];
+    __shared__ uint32_t i0[kSsBucketCap], i1[kSsBucketCap];
+    const uint32_t base = bucket_base[blockIdx.x], m = bucket_base[blockIdx.x + 1] - base;
+    if (m == 0) return;
+    if (m > (uint32_t)kSsBucketCap) {                        // rank by counting, from global memory
+        for (uint32_t e = threadIdx.x; e < m; e += blockDim.x) {
+            const U md = dk[base + e];
+            const uint32_t mi = di[base + e];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < m; j++) rank += comp_less(dk[base + j], di[base + j], md, mi) ? 1u : 0u;
+            order[base + rank] = (V)mi;
+        }
+        return;
+    }
+    int npad = kWave;
+    while ((uint32_t)npad < m) npad <<= 1;
+    for (int e = threadIdx.x; e < npad; e += blockDim.x) {
+        d0[e] = (uint32_t)e < m ? dk[base + e] : ~(U)0;      // padding sorts behind every real entry (indices are < 2^31)
+        i0[e] = (uint32_t)e < m ? di[base + e] : 0x80000000u + (uint32_t)e;      // ... and is unique too
+    }
+    __syncthreads();
+    U *d;
+    uint32_t *ii;
+    sort_lds(d0, i0, d1, i1, npad, &d, &ii);
+    for (uint32_t e = threadIdx.x; e < m; e += blockDim.x) order[base + e] = (V)ii[e];
+}
+
+static inline int ss_buckets(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(n / 384, 16), kSsMaxBuckets); }
+static inline bool ss_eligible(int64_t n) { return n >= kSsMinN && n <= kSsMaxN; }
+
+template <typename K>
+size_t bucket_bytes(int64_t n)
+{
+    typedef typename KeyBits<K>::U U;
+    const size_t ntiles = (size_t)d3d_divup(n, kSsTile);
+    return d3d_align_up(kSsMaxBuckets * sizeof(U)) + d3d_align_up(kSsMaxBuckets * 4) + d3d_align_up((size_t)n * 4) +
+           d3d_align_up(ntiles * kSsMaxBuckets * 4) + 2 * d3d_align_up((kSsMaxBuckets + 1) * 4) + d3d_align_up((size_t)n * sizeof(U)) +
+           d3d_align_up((size_t)n * 4) + 256;
+}
+
+template <typename K, typename V>
+int bucket_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    typedef typename KeyBits<K>::U U;
+    const int B = ss_buckets(n);
+    const unsigned ntiles = (unsigned)d3d_divup(n, kSsTile);
+    WsCarver w(ws, ws_bytes);
+    U *spl_d = w.take<U>(kSsMaxBuckets);
+    uint32_t *spl_i = w.take<uint32_t>(kSsMaxBuckets);
+    uint32_t *pb = w.take<uint32_t>(n);
+    uint32_t *tileoff = w.take<uint32_t>((size_t)ntiles * kSsMaxBuckets);
+    uint32_t *bucket_cnt = w.take<uint32_t>(kSsMaxBuckets + 1);
+    uint32_t *bucket_base = w.take<uint32_t>(kSsMaxBuckets + 1);
+    U *dk = w.take<U>(n);
+    uint32_t *di = w.take<uint32_t>(n);
+    if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
+    D3D_LAUNCH("k_ss_splitters", k_ss_splitters<K>, dim3(1), dim3(kSsSortThreads), 0, st, keys, (uint32_t)n, B, spl_d, spl_i, bucket_cnt);
+    D3D_LAUNCH("k_ss_count", k_ss_count<K>, dim3(ntiles), dim3(kSsCountThreads), 0, st, keys, (uint32_t)n, B, (const U *)spl_d,
+               (const uint32_t *)spl_i, pb, tileoff, bucket_cnt);
+    D3D_LAUNCH("k_ss_scatter", k_ss_scatter<K>, dim3(ntiles), dim3(kSsCountThreads), 0, st, keys, (uint32_t)n, B, (const uint32_t *)pb,
+               (const uint32_t *)tileoff, (const uint32_t *)bucket_cnt, bucket_base, dk, di);
+    D3D_LAUNCH("k_ss_bucket", (k_ss_bucket<U, V>), dim3((unsigned)B), dim3(kSsSortThreads), 0, st, (const U *)dk, (const uint32_t *)di,
+               (const uint32_t *)bucket_base, order);
+    return D3D_OK;
 }
 
 template <typename K, typename V>
 size_t argsort_bytes(int64_t n)
 {
     if (n < 1) n = 1;
-    return d3d_align_up(sizeof(K) * n) + d3d_align_up(sort_temp_bytes<K, V>(n)) + 256;
+    return std::max(library_bytes<K, V>(n), ss_eligible(n) ? bucket_bytes<K>(n) : (size_t)0);
 }
 
-// order[n] <- stable descending argsort of keys; the values 0 .. n-1 come from a counting iterator
 template <typename K, typename V>
-int argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st)
+int argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st, bool library_only = false)
 {
     if (n <= 0) return D3D_OK;
-    WsCarver w(ws, ws_bytes);
-    K *keys_out = w.take<K>(n);
-    size_t tmp = sort_temp_bytes<K, V>(n);
-    char *temp = w.take<char>(tmp);
-    if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
-    D3D_HIP_CHECK((rocprim::radix_sort_pairs_desc<SortConfig>(temp, tmp, keys, keys_out, rocprim::counting_iterator<V>(0), order,
-                                                              (size_t)n, 0, sizeof(K) * 8, st)));
-    return D3D_OK;
+    if (ss_eligible(n) && !library_only) return bucket_argsort_desc<K, V>(keys, n, order, ws, ws_bytes, st);
+    return library_argsort_desc<K, V>(keys, n, order, ws, ws_bytes, st);
 }
 }  // namespace
 
@@ -49,6 +343,15 @@ extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int
                                              hipStream_t st)
 {
     return argsort_desc<int32_t, int32_t>(keys, n, order, ws, ws_bytes, st);
+}
+
+// (tests: the library path at a size the bucket path would take)
+extern "C" int d3d_internal_argsort_desc_library(const void *keys, int64_t n, int32_t dtype, int64_t *order, void *ws, size_t ws_bytes,
+                                                 void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == D3D_F64 ? argsort_desc<double, int64_t>((const double *)keys, n, order, ws, ws_bytes, st, true)
+                            : argsort_desc<float, int64_t>((const float *)keys, n, order, ws, ws_bytes, st, true);
 }
 
 extern "C" size_t d3d_argsort_desc_workspace_bytes(int64_t n, int32_t dtype)

@@ -541,3 +541,50 @@ def test_argsort_desc_stable_all_sizes(n, dtype):
         s[::7] *= -1
     got = argsort_desc(T(s)).cpu().numpy()
     assert got.dtype == np.int64 and np.array_equal(got, np.argsort(-s, kind="stable"))
+
+
+def _expected_order(s):
+    """torch's descending order (nms.cpp:103): NaN first, -0 == +0, ties in index order"""
+    nan = np.isnan(s)
+    val = np.where(nan, 0, s)
+    return np.lexsort((np.arange(len(s)), -val, ~nan))
+
+
+@pytest.mark.parametrize("n", [8191, 8192, 8193, 50000, 262144, 262145, (1 << 20) + 3])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_argsort_desc_bucket_path(n, dtype):
+    """the 8 k .. 256 k range takes the bucket (sample) sort, the sizes around it the library: same order on random keys with
+    ties, on constant / sorted / few-valued inputs (the splitters cut runs of equal keys by index), and on NaN, +-0, +-inf;
+    the library path at the same size agrees entry by entry"""
+    import ctypes
+    from d3d_amd import _lib
+    from d3d_amd.box import argsort_desc
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    cases = {"random": rng.random(n), "constant": np.full(n, 0.25), "ascending": np.arange(n) / n, "descending": -np.arange(n) / n,
+             "few": rng.integers(0, 5, n) / 4.0, "normal": rng.normal(0, 1e3, n)}
+    special = rng.random(n)
+    special[rng.integers(0, n, n // 5)] = special[rng.integers(0, n, n // 5)]
+    special[rng.integers(0, n, 50)] = np.nan
+    special[rng.integers(0, n, 50)] = 0.0
+    special[rng.integers(0, n, 50)] = -0.0
+    special[rng.integers(0, n, 5)] = np.inf
+    special[rng.integers(0, n, 5)] = -np.inf
+    special[::5] *= -1
+    cases["special"] = special
+    lib.d3d_internal_argsort_desc_library.restype = ctypes.c_int
+    lib.d3d_internal_argsort_desc_library.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_size_t, ctypes.c_void_p]
+    for name, s in cases.items():
+        s = s.astype(dtype)
+        t = T(s)
+        got = argsort_desc(t).cpu().numpy()
+        exp = _expected_order(s)
+        assert np.array_equal(got, exp), (name, int(np.sum(got != exp)))
+        if name in ("special", "few"):
+            code = 1 if dtype == np.float64 else 0
+            order = torch.empty(n, dtype=torch.int64, device="cuda")
+            ws = torch.empty(lib.d3d_argsort_desc_workspace_bytes(n, code), dtype=torch.uint8, device="cuda")
+            rc = lib.d3d_internal_argsort_desc_library(t.data_ptr(), n, code, order.data_ptr(), ws.data_ptr(), ws.numel(), None)
+            torch.cuda.synchronize()
+            assert rc == 0 and np.array_equal(order.cpu().numpy(), exp), name

@@ -13,3 +13,7 @@ print("argsort f64 stream: %.1f us/call" % (dt / 50 * 1e6))
 s32 = st.float()
 dt = bench.timed(lambda: argsort_desc(s32), 50, 5)
 print("argsort f32 stream: %.1f us/call" % (dt / 50 * 1e6))
+prof = bench.kernel_profile(lambda: argsort_desc(st), 20)
+print({k: round(v["avg_us"], 1) for k, v in prof.items()})
+prof = bench.kernel_profile(lambda: argsort_desc(s32), 20)
+print({k: round(v["avg_us"], 1) for k, v in prof.items()})
