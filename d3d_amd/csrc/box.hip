@@ -441,24 +441,116 @@ static unsigned long long nms_cand_capacity(int64_t n)
 }
 
 
+// Scan across the workgroups of ONE launch: every workgroup publishes its total with a ready bit (tot[] zeroed by an earlier
+// kernel) and adds up the totals of the workgroups before it, polling the ones not there yet.  A workgroup only waits for
+// LOWER-numbered workgroups, which the dispatcher started before it, and they publish before they wait: always progress.
+// Returns (in every thread) the sum of the totals of workgroups 0 .. blockIdx.x - 1; contains workgroup barriers.
+__device__ __forceinline__ unsigned long long chained_prefix(unsigned long long *tot, unsigned long long total, unsigned long long *sbase)
+{
+    const unsigned int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&tot[blockIdx.x], (total << 1) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) {
+        unsigned long long acc = 0;
+        for (unsigned int j0 = 0; j0 < blockIdx.x; j0 += 64) {
+            const unsigned int j = j0 + lane;
+            if (j < blockIdx.x) {
+                unsigned long long t;
+                do { t = __hip_atomic_load(&tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(t & 1ull));
+                acc += t >> 1;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) *sbase = acc;
+    }
+    __syncthreads();
+    return *sbase;
+}
+
+constexpr int kGridMax = 256, kGridCells = kGridMax * kGridMax;
+constexpr int kGridReg = 8;            // registration capacity per box, on average
+constexpr int kGridBoxCells = 1024;    // most cells one box may touch
+constexpr float kGridCellScale = 2.f;  // cell size / mean AABB extent (4: scattered boxes 25 -> 37 us, clusters unchanged)
+constexpr int kGridPad = 16;           // one cell counter per 64-byte line: atomics on neighbouring words serialise like
+                                       // atomics on one word (gridreg 35 -> ? us with 5 k cells packed into 335 lines)
+struct NmsGrid { float ox, oy, inv_h; int gx, gy; unsigned int ticket, entries; };
+
+__device__ __forceinline__ int grid_cell(float x, float o, float inv_h, int g)
+{
+    const float t = fminf((x - o) * inv_h, (float)(g - 1));
+    return t > 0.f ? (int)t : 0;                     // NaN -> 0
+}
+__device__ __forceinline__ bool grid_valid(const float4 f)
+{
+    return f.x >= -3.0e38f && f.y >= -3.0e38f && f.z <= 3.0e38f && f.w <= 3.0e38f && f.z >= f.x && f.w >= f.y;   // finite, non-empty
+}
+
+
+// grid parameters from {min x, min y, max x, max y, sum of the mean extents, count} of the valid AABBs
+__device__ __forceinline__ NmsGrid make_nms_grid(const float (&v)[6])
+{
+    NmsGrid g;
+    g.ticket = 0; g.entries = 0;
+    if (!(v[5] > 0.f)) { g.ox = 0.f; g.oy = 0.f; g.inv_h = 0.f; g.gx = 1; g.gy = 1; }
+    else {
+        const float rx = v[2] - v[0], ry = v[3] - v[1];
+        float h = kGridCellScale * v[4] / v[5];
+        h = fmaxf(h, fmaxf(rx, ry) / (float)(kGridMax - 1));
+        if (!(h > 0.f)) h = 1.f;
+        g.ox = v[0]; g.oy = v[1]; g.inv_h = 1.f / h;
+        g.gx = (int)fminf(rx / h, (float)(kGridMax - 1)) + 1;
+        g.gy = (int)fminf(ry / h, (float)(kGridMax - 1)) + 1;
+    }
+    return g;
+}
+// {min, min, max, max, sum, sum} over the workgroup (256 threads); the result is valid in every thread
+__device__ __forceinline__ void block_reduce_extent(float (&v)[6], float (*sm)[6])
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        v[0] = fminf(v[0], __shfl_xor(v[0], o, 64)); v[1] = fminf(v[1], __shfl_xor(v[1], o, 64));
+        v[2] = fmaxf(v[2], __shfl_xor(v[2], o, 64)); v[3] = fmaxf(v[3], __shfl_xor(v[3], o, 64));
+        v[4] += __shfl_xor(v[4], o, 64); v[5] += __shfl_xor(v[5], o, 64);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) for (int k = 0; k < 6; k++) sm[w][k] = v[k];
+    __syncthreads();
+    for (int k = 0; k < 6; k++) v[k] = sm[0][k];
+    for (int q = 1; q < 4; q++) {
+        v[0] = fminf(v[0], sm[q][0]); v[1] = fminf(v[1], sm[q][1]); v[2] = fmaxf(v[2], sm[q][2]); v[3] = fmaxf(v[3], sm[q][3]);
+        v[4] += sm[q][4]; v[5] += sm[q][5];
+    }
+    __syncthreads();
+}
+constexpr int kGridScanWgs = (kGridCells + 1 + 1023) / 1024;      // workgroups of k_nms_gridscan
+constexpr int kGridFoldMax = 512;      // most k_nms_prepare partials that k_nms_gridreg folds itself (else: k_nms_extent)
+
 template <typename T>
-__global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__ scores,
+__global__ __launch_bounds__(256) void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__ scores,
                               const int64_t *__restrict__ order, int64_t n, float score_threshold,
                               BoxGeom<T> *geom, float4 *fbox, uint8_t *state, uint32_t *inc_cnt, float *farea,
                               unsigned long long *remv, int64_t nb, NmsFlags *flags, NmsCand *cand_hdr,
-                              unsigned int force_dense, int32_t *xkey, unsigned int *grid_ticket, unsigned long long *tile_tot)
+                              unsigned int force_dense, int32_t *xkey, unsigned int *grid_ticket, unsigned long long *tile_tot,
+                              float *gpartial, uint32_t *cellcnt, unsigned long long *chunk_tot)
 {
+    __shared__ float sm[4][6];
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // sorted position
     bool pre = false;
+    // for the uniform-grid broad phase: cleared cell counters, and this workgroup's share of the AABBs' bounding range and
+    // mean extent (folded by k_nms_gridreg<count>, or by k_nms_extent when there are more than kGridFoldMax workgroups)
+    for (int64_t i = p; i <= kGridCells; i += (int64_t)gridDim.x * blockDim.x) cellcnt[i * kGridPad] = 0;
+    float ext[6] = {INFINITY, INFINITY, -INFINITY, -INFINITY, 0.f, 0.f};
     if (p == 0) { flags->need_sweep = force_dense; flags->undecided = 0; *grid_ticket = 0; }
     if (p < kNmsListSegs) cand_hdr->count[p * 16] = 0;
     if (p * kIncTile < n) tile_tot[p] = 0;                   // k_nms_incscan's ready words
+    if (p < kGridScanWgs) chunk_tot[p] = 0;                  // ... and k_nms_gridscan's
     if (p < n) {
         const int64_t i = order[p];
         const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
         geom[p] = g;
         const float4 f = make_float4(round_down(g.xmin), round_down(g.ymin), round_up(g.xmax), round_up(g.ymax));
         fbox[p] = f;
+        if (grid_valid(f)) { ext[0] = f.x; ext[1] = f.y; ext[2] = f.z; ext[3] = f.w; ext[4] = 0.5f * ((f.z - f.x) + (f.w - f.y)); ext[5] = 1.f; }
         // key for the sweep-and-prune order: the descending sort of ~ordered(xmin) is ascending in xmin
         const int32_t bits = __float_as_int(f.x);
         xkey[p] = ~(bits ^ ((bits >> 31) & 0x7fffffff));
@@ -470,6 +562,9 @@ __global__ void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__
     }
     unsigned long long word = __ballot(pre);
     if ((threadIdx.x & 63) == 0 && (p >> 6) < nb) remv[p >> 6] = word;
+    block_reduce_extent(ext, sm);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; k++) gpartial[(size_t)blockIdx.x * 6 + k] = ext[k];
 }
 
 // The pair phase is split so that the conservative AABB tests run in a kernel with a handful of registers and the
@@ -595,100 +690,45 @@ __global__ __launch_bounds__(256) void k_nms_cand(const float4 *__restrict__ fbx
 // cell holding the lower-left corner of the two AABBs' intersection, so every overlapping pair appears exactly once --
 // the same candidate set as the sweep (same strict test on the same rounded AABBs).  Boxes of any size are handled
 // (a box touching more than 1024 cells, or more registrations than 8 per box on average, hands over to the dense path).
-constexpr int kGridMax = 256, kGridCells = kGridMax * kGridMax;
-constexpr int kGridReg = 8;            // registration capacity per box, on average
-constexpr int kGridBoxCells = 1024;    // most cells one box may touch
-constexpr int kGridParts = 64;         // workgroups of k_nms_extent
-constexpr float kGridCellScale = 2.f;  // cell size / mean AABB extent (4: scattered boxes 25 -> 37 us, clusters unchanged)
-constexpr int kGridPad = 16;           // one cell counter per 64-byte line: atomics on neighbouring words serialise like
-                                       // atomics on one word (gridreg 35 -> ? us with 5 k cells packed into 335 lines)
-struct NmsGrid { float ox, oy, inv_h; int gx, gy; unsigned int ticket, entries; };
-
-__device__ __forceinline__ int grid_cell(float x, float o, float inv_h, int g)
+// folds k_nms_prepare's partial extents into the grid parameters: inside k_nms_gridreg<count> for up to kGridFoldMax
+// partials (every workgroup repeats the fold -- 12 KB from L2 -- and workgroup 0 stores the result for the later kernels:
+// no launch, no ticket), by this one-workgroup kernel above that
+__device__ __forceinline__ NmsGrid fold_extents(const float *__restrict__ partial, unsigned int npart, float (*sm)[6])
 {
-    const float t = fminf((x - o) * inv_h, (float)(g - 1));
-    return t > 0.f ? (int)t : 0;                     // NaN -> 0
+    float v[6] = {INFINITY, INFINITY, -INFINITY, -INFINITY, 0.f, 0.f};
+    for (unsigned int j = threadIdx.x; j < npart; j += 256) {
+        const float *q = partial + (size_t)j * 6;
+        v[0] = fminf(v[0], q[0]); v[1] = fminf(v[1], q[1]); v[2] = fmaxf(v[2], q[2]); v[3] = fmaxf(v[3], q[3]);
+        v[4] += q[4]; v[5] += q[5];
+    }
+    block_reduce_extent(v, sm);
+    return make_nms_grid(v);
 }
-__device__ __forceinline__ bool grid_valid(const float4 f)
-{
-    return f.x >= -3.0e38f && f.y >= -3.0e38f && f.z <= 3.0e38f && f.w <= 3.0e38f && f.z >= f.x && f.w >= f.y;   // finite, non-empty
-}
-
-// bounding range and mean extent of the AABBs -> grid parameters (folded by the last workgroup to finish); also clears
-// the cell counters
-__global__ __launch_bounds__(256) void k_nms_extent(const float4 *__restrict__ fbox, int64_t n, float *partial, NmsGrid *grid,
-                                                    uint32_t *cellcnt)
+__global__ __launch_bounds__(256) void k_nms_extent(const float *__restrict__ partial, unsigned int npart, NmsGrid *grid)
 {
     __shared__ float sm[4][6];
-    __shared__ bool last;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (int64_t i = t0; i <= kGridCells; i += stride) cellcnt[i * kGridPad] = 0;
-    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY, sum = 0.f, cnt = 0.f;
-    for (int64_t i = t0; i < n; i += stride) {
-        const float4 f = fbox[i];
-        if (grid_valid(f)) {
-            mnx = fminf(mnx, f.x); mny = fminf(mny, f.y); mxx = fmaxf(mxx, f.z); mxy = fmaxf(mxy, f.w);
-            sum += 0.5f * ((f.z - f.x) + (f.w - f.y));
-            cnt += 1.f;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
-        mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
-        sum += __shfl_xor(sum, o, 64); cnt += __shfl_xor(cnt, o, 64);
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { sm[w][0] = mnx; sm[w][1] = mny; sm[w][2] = mxx; sm[w][3] = mxy; sm[w][4] = sum; sm[w][5] = cnt; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float v[6] = {sm[0][0], sm[0][1], sm[0][2], sm[0][3], sm[0][4], sm[0][5]};
-        for (int k = 1; k < 4; k++) {
-            v[0] = fminf(v[0], sm[k][0]); v[1] = fminf(v[1], sm[k][1]); v[2] = fmaxf(v[2], sm[k][2]); v[3] = fmaxf(v[3], sm[k][3]);
-            v[4] += sm[k][4]; v[5] += sm[k][5];
-        }
-        for (int k = 0; k < 6; k++) __hip_atomic_store(&partial[blockIdx.x * 6 + k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last = atomicAdd(&grid->ticket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last || threadIdx.x >= 64) return;
-    __threadfence();
-    float v[6] = {INFINITY, INFINITY, -INFINITY, -INFINITY, 0.f, 0.f};
-    if (threadIdx.x < gridDim.x)                     // kGridParts <= 64: one partial per lane
-        for (int j = 0; j < 6; j++) v[j] = __hip_atomic_load(&partial[threadIdx.x * 6 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int o = 32; o > 0; o >>= 1) {
-        v[0] = fminf(v[0], __shfl_xor(v[0], o, 64)); v[1] = fminf(v[1], __shfl_xor(v[1], o, 64));
-        v[2] = fmaxf(v[2], __shfl_xor(v[2], o, 64)); v[3] = fmaxf(v[3], __shfl_xor(v[3], o, 64));
-        v[4] += __shfl_xor(v[4], o, 64); v[5] += __shfl_xor(v[5], o, 64);
-    }
-    if (threadIdx.x != 0) return;
-    NmsGrid g;
-    g.ticket = 0; g.entries = 0;
-    if (!(v[5] > 0.f)) { g.ox = 0.f; g.oy = 0.f; g.inv_h = 0.f; g.gx = 1; g.gy = 1; }
-    else {
-        const float rx = v[2] - v[0], ry = v[3] - v[1];
-        float h = kGridCellScale * v[4] / v[5];
-        h = fmaxf(h, fmaxf(rx, ry) / (float)(kGridMax - 1));
-        if (!(h > 0.f)) h = 1.f;
-        g.ox = v[0]; g.oy = v[1]; g.inv_h = 1.f / h;
-        g.gx = (int)fminf(rx / h, (float)(kGridMax - 1)) + 1;
-        g.gy = (int)fminf(ry / h, (float)(kGridMax - 1)) + 1;
-    }
-    *grid = g;
+    const NmsGrid g = fold_extents(partial, npart, sm);
+    if (threadIdx.x == 0) *grid = g;
 }
 
 // pass 1 (SCATTER = false): count the registrations per cell; pass 2: place them (cursor = scanned counts)
 template <bool SCATTER>
-__global__ __launch_bounds__(256) void k_nms_gridreg(const float4 *__restrict__ fbox, int64_t n, const NmsGrid *grid, uint32_t *cellcur,
+__global__ __launch_bounds__(256) void k_nms_gridreg(const float4 *__restrict__ fbox, int64_t n, NmsGrid *grid, uint32_t *cellcur,
                                                      unsigned long long cap_e, uint32_t *__restrict__ cellbox,
                                                      uint32_t *__restrict__ cellof, float4 *__restrict__ fbc, NmsFlags *flags,
-                                                     const float *__restrict__ farea, float *__restrict__ carea)
+                                                     const float *__restrict__ farea, float *__restrict__ carea,
+                                                     const float *__restrict__ partial, unsigned int npart /* 0: *grid is ready */)
 {
+    __shared__ float sm[4][6];
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    NmsGrid g;
+    if (!SCATTER && npart) {
+        g = fold_extents(partial, npart, sm);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *grid = g;
+    } else g = *grid;
     if (p >= n) return;
     const float4 f = fbox[p];
     if (!grid_valid(f)) return;
-    const NmsGrid g = *grid;
     const int cx0 = grid_cell(f.x, g.ox, g.inv_h, g.gx), cx1 = grid_cell(f.z, g.ox, g.inv_h, g.gx);
     const int cy0 = grid_cell(f.y, g.oy, g.inv_h, g.gy), cy1 = grid_cell(f.w, g.oy, g.inv_h, g.gy);
     if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) > kGridBoxCells) { flags->need_sweep = 1; return; }   // a frame-sized box: dense path
@@ -700,37 +740,23 @@ __global__ __launch_bounds__(256) void k_nms_gridreg(const float4 *__restrict__ 
         }
 }
 
-// cellcnt[0 .. cells) -> exclusive offsets in cellstart[0 .. cells] and in the cursors (one workgroup; a wavefront owns a
-// contiguous range of 64-cell rows and scans them with shuffles, coalesced)
+// cellcnt[0 .. cells) -> exclusive offsets in cellstart[0 .. cells] and in the cursors: 1024 cells per workgroup (the padded
+// counters are 64 KB of strided reads per workgroup; ONE workgroup reading all 4 MB took 11 us) + chained_prefix across
+// the workgroups (chunk_tot[] zeroed by k_nms_prepare)
 __global__ __launch_bounds__(1024) void k_nms_gridscan(uint32_t *cellcur, uint32_t *cellstart, NmsGrid *grid, unsigned long long cap_e,
-                                                       NmsFlags *flags)
+                                                       NmsFlags *flags, unsigned long long *chunk_tot)
 {
-    __shared__ uint32_t wtot[16];
-    const int cells = grid->gx * grid->gy, rows = (cells + 1 + 63) / 64;          // entry `cells` = the total
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int per = (rows + 15) / 16, r0 = w * per, r1 = r0 + per < rows ? r0 + per : rows;
-    uint32_t run = 0;
-    for (int r = r0; r < r1; r++) {
-        const int c = r * 64 + lane;
-        run += c < cells ? cellcur[(size_t)c * kGridPad] : 0u;
-    }
-    for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o, 64);
-    if (lane == 0) wtot[w] = run;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-    for (int k = 0; k < 16; k++) { if (k < w) base += wtot[k]; tot += wtot[k]; }
-    for (int r = r0; r < r1; r++) {
-        const int c = r * 64 + lane;
-        const uint32_t x = c < cells ? cellcur[(size_t)c * kGridPad] : 0u;
-        uint32_t incl = x;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (c <= cells) { cellstart[c] = base + incl - x; cellcur[(size_t)c * kGridPad] = base + incl - x; }
-        base += __shfl(incl, 63, 64);
-    }
-    if (threadIdx.x == 0) {
+    __shared__ unsigned long long smem[1024 / kWave], sbase;
+    const int cells = grid->gx * grid->gy;                                      // entry `cells` = the total
+    if ((int)blockIdx.x * 1024 > cells) return;                                 // (nobody waits for a higher workgroup)
+    const int c = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t x = c < cells ? cellcur[(size_t)c * kGridPad] : 0u;
+    unsigned long long total;
+    const unsigned long long ex = block_excl_scan_u64<1024>(x, &total, smem);
+    const unsigned long long before = chained_prefix(chunk_tot, total, &sbase);
+    if (c <= cells) { cellstart[c] = (uint32_t)(before + ex); cellcur[(size_t)c * kGridPad] = (uint32_t)(before + ex); }
+    if (c == cells) {
+        const unsigned long long tot = before + ex;
         grid->entries = (unsigned int)(tot < cap_e ? tot : cap_e);
         if (tot > cap_e) flags->need_sweep = 1;
     }
@@ -872,9 +898,7 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__
 }
 
 // inc_off = exclusive scan of inc_cnt in ONE launch (the generic count / block-sum / apply trio is three, ~4 us each in a
-// stream): a local scan per 1024-box tile; every workgroup publishes its tile total with a ready bit (tile_tot[] is zeroed by
-// k_nms_prepare) and adds up the totals of the tiles before it, polling the ones not there yet.  A workgroup only waits for
-// LOWER-numbered workgroups, which the dispatcher started before it, and they publish before they wait: always progress.
+// stream): a local scan per 1024-box tile + chained_prefix over the tiles (tile_tot[] is zeroed by k_nms_prepare)
 __global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict__ inc_cnt, int64_t n, uint32_t *__restrict__ inc_off,
                                                      unsigned long long *tile_tot)
 {
@@ -895,24 +919,8 @@ __global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict_
     unsigned long long woff = 0, total = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { if (k < w) woff += smem[k]; total += smem[k]; }
-    if (threadIdx.x == 0)
-        __hip_atomic_store(&tile_tot[blockIdx.x], (total << 1) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (w == 0) {
-        unsigned long long acc = 0;
-        for (unsigned int j0 = 0; j0 < blockIdx.x; j0 += 64) {
-            const unsigned int j = j0 + lane;
-            if (j < blockIdx.x) {
-                unsigned long long t;
-                do { t = __hip_atomic_load(&tile_tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(t & 1ull));
-                acc += t >> 1;
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) sbase = acc;
-    }
-    __syncthreads();
-    const unsigned long long off = sbase + woff;
+    const unsigned long long before = chained_prefix(tile_tot, total, &sbase);
+    const unsigned long long off = before + woff;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int64_t i = base + k * 64;
@@ -1102,7 +1110,8 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     uint32_t *inc_cnt = w.take<uint32_t>(nb * 64);
     uint32_t *inc_off = w.take<uint32_t>(nb * 64);
     float *farea = w.take<float>(nb * 64);
-    unsigned long long *tile_tot = w.take<unsigned long long>(d3d_divup(nb * 64, kScanTile) + 1);
+    unsigned long long *tile_tot = w.take<unsigned long long>(d3d_divup(nb * 64, kScanTile) + 1 + kGridScanWgs);
+    unsigned long long *chunk_tot = tile_tot + d3d_divup(nb * 64, kScanTile) + 1;
     (void)w.take<int64_t>(D3D_NUM_COUNTS);
     static_assert(kIncTile == kScanTile, "workspace sized with kScanTile");
     NmsFlags *flags = w.take<NmsFlags>(1);
@@ -1127,7 +1136,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     const unsigned long long cap_e = (unsigned long long)kGridReg * (unsigned long long)(nb * 64);
     uint32_t *cellcur = w.take<uint32_t>((size_t)(kGridCells + 1) * kGridPad);
     uint32_t *cellstart = w.take<uint32_t>(kGridCells + 1);
-    float *gpartial = w.take<float>(kGridParts * 6);
+    float *gpartial = w.take<float>((size_t)d3d_divup(nb * 64, 256) * 6);
     NmsGrid *grid = w.take<NmsGrid>(1);
     uint32_t *cellbox = w.take<uint32_t>((size_t)cap_e);
     uint32_t *cellof = w.take<uint32_t>((size_t)cap_e);
@@ -1136,16 +1145,18 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
     const bool rot = iou_type == D3D_IOU_RBOX;
     const bool use_grid = !(opts & D3D_NMS_BROAD_SWEEP);
-    D3D_LAUNCH("k_nms_prepare", k_nms_prepare<T>, dim3((unsigned)nb), dim3(64), 0, st, boxes, scores, order, n, score_thr,
-               geom, fbox, state, inc_cnt, farea, remv, nb, flags, cand_hdr, (opts & D3D_NMS_FORCE_DENSE) ? 1u : 0u, xkey, &grid->ticket, tile_tot);
+    const unsigned nbl = (unsigned)d3d_divup(n, 256);
+    D3D_LAUNCH("k_nms_prepare", k_nms_prepare<T>, dim3(nbl), dim3(256), 0, st, boxes, scores, order, n, score_thr,
+               geom, fbox, state, inc_cnt, farea, remv, nb, flags, cand_hdr, (opts & D3D_NMS_FORCE_DENSE) ? 1u : 0u, xkey, &grid->ticket, tile_tot, gpartial, cellcur, chunk_tot);
     if (use_grid) {
-        const unsigned nbl = (unsigned)d3d_divup(n, 256);
-        D3D_LAUNCH("k_nms_extent", k_nms_extent, dim3(kGridParts), dim3(256), 0, st, (const float4 *)fbox, n, gpartial, grid, cellcur);
-        D3D_LAUNCH("k_nms_gridreg<count>", k_nms_gridreg<false>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, (const NmsGrid *)grid,
-                   cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea);
-        D3D_LAUNCH("k_nms_gridscan", k_nms_gridscan, dim3(1), dim3(1024), 0, st, cellcur, cellstart, grid, cap_e, flags);
-        D3D_LAUNCH("k_nms_gridreg<place>", k_nms_gridreg<true>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, (const NmsGrid *)grid,
-                   cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea);
+        const bool fold_inline = nbl <= (unsigned)kGridFoldMax;
+        if (!fold_inline) D3D_LAUNCH("k_nms_extent", k_nms_extent, dim3(1), dim3(256), 0, st, (const float *)gpartial, nbl, grid);
+        D3D_LAUNCH("k_nms_gridreg<count>", k_nms_gridreg<false>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
+                   cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, fold_inline ? nbl : 0u);
+        D3D_LAUNCH("k_nms_gridscan", k_nms_gridscan, dim3(kGridScanWgs), dim3(1024), 0, st, cellcur, cellstart, grid, cap_e, flags,
+                   chunk_tot);
+        D3D_LAUNCH("k_nms_gridreg<place>", k_nms_gridreg<true>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
+                   cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, 0u);
         D3D_LAUNCH("k_nms_cand_grid", k_nms_cand_grid, dim3((unsigned)d3d_divup((int64_t)cap_e, 256)), dim3(256), 0, st,
                    (const float4 *)fbc, (const uint32_t *)cellof, (const uint32_t *)cellstart, (const NmsGrid *)grid, cand, cap,
                    cand_hdr, flags, (const float *)carea, rot ? iou_thr : -1.f);
@@ -1573,12 +1584,12 @@ extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
     if (n < 1) n = 1;
     const size_t nb = (size_t)d3d_divup(n, 64);
     return d3d_align_up(nb * 64 * sizeof(BoxGeom<double>)) + d3d_align_up(nb * 64 * 16) + d3d_align_up(nb * 64) +
-           d3d_align_up(nb * 64 * 4) * 3 + d3d_align_up((nb * 64 / kScanTile + 2) * 8) + 256 + 2 * d3d_align_up((size_t)nms_cand_capacity(n) * 4) +
+           d3d_align_up(nb * 64 * 4) * 3 + d3d_align_up((nb * 64 / kScanTile + 2 + 80) * 8) + 256 + 2 * d3d_align_up((size_t)nms_cand_capacity(n) * 4) +
            256 + d3d_align_up(nb * 8) +
            d3d_align_up(sizeof(NmsCand)) +
            d3d_align_up((size_t)nms_cand_capacity(n) * 8) + 2 * d3d_align_up(nb * 64 * 4) + d3d_align_up((nb * 64 + kCandPad) * 16) +
            d3d_align_up(nb * 64 * 4) + d3d_align_up(d3d_internal_argsort_i32_bytes(n)) + d3d_align_up(nb * 64 * nb * 8) + 256 +
-           d3d_align_up((size_t)(kGridCells + 1) * kGridPad * 4) + d3d_align_up((kGridCells + 1) * 4) + d3d_align_up(kGridParts * 6 * 4) + d3d_align_up(sizeof(NmsGrid)) +
+           d3d_align_up((size_t)(kGridCells + 1) * kGridPad * 4) + d3d_align_up((kGridCells + 1) * 4) + d3d_align_up((nb * 64 / 256 + 1) * 6 * 4) + d3d_align_up(sizeof(NmsGrid)) +
            d3d_align_up(kGridReg * nb * 64 * 4) * 3 + d3d_align_up(kGridReg * nb * 64 * 16);
 }
 

@@ -35,6 +35,18 @@ def test_cfg3_nms_100k_boxes_vs_oracle():
     assert np.array_equal(keep, exp), int(np.sum(keep != exp))
 
 
+def test_nms_300k_boxes_beyond_the_inline_paths():
+    """300 k boxes: above the sizes that take the bucket argsort (256 k keys) and the in-kernel fold of the grid extents
+    (512 workgroups of k_nms_prepare) -- the library sort and the separate fold kernel; keep mask bit-exact"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms
+    b, s = synth.boxes2d_sparse(300000, 5)
+    s[::3] = np.round(s[::3] * 200) / 200                # ties
+    keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3, score_threshold=0.05).cpu().numpy()
+    exp = oracle.box2d_nms_hard_candidates(b, s, "rbox", 0.3, 0.05)
+    assert np.array_equal(keep, exp), int(np.sum(keep != exp))
+
+
 def test_cfg3_iou_50k_x_50k_fp64_vs_oracle():
     """config 3's boxes, 50 k x 50 k fp64 = 2.5e9 pairs (> 2^31: the index range the reference's CUDA kernel overflows,
     iou_cuda.cu:36,137) in ONE 20 GB matrix: every pair whose bounding boxes touch equals the oracle (1e-9), every other
