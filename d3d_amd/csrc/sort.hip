@@ -82,7 +82,7 @@ int library_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws
     return D3D_OK;
 }
 
-// ---------------------------------------------------------------- bucket path (8 k .. 256 k keys: the NMS sizes)
+// ---------------------------------------------------------------- bucket path (8 k .. 128 k keys: the NMS sizes)
 // The library sorts this range with a block sort + one merge launch per doubling (9 launches, 70 us at 100 k keys: launch
 // latency, not bandwidth).  Here: a sample sort in 4 launches --
 //   k_ss_splitters  one workgroup sorts 1024 stratified samples in LDS and keeps every (1024 / B)-th as a splitter
@@ -93,15 +93,18 @@ int library_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws
 //   k_ss_bucket     one workgroup per bucket: sort in LDS, order[base + r] = index
 // Everything compares the composite (key, index): it is unique, so the splitters cut runs of equal keys (all-equal input
 // gives B equal buckets) and the result depends neither on the arrival order of the atomics nor on the sample.  Bucket
-// sizes only depend on the sample; a bucket that outgrows the LDS (> 5 x the mean at 4 samples per bucket: not seen) is
-// ranked from global memory by counting -- slow, still exact.
+// sizes only depend on the sample: B = n / 192 buckets (<= 512, two samples per bucket), so a bucket's size is the mean
+// (<= 256) times Gamma(2) / 2 -- the largest of 512 is ~5 x the mean; the workgroup that gets it sets the kernel's duration,
+// which is why the buckets are small (256 buckets of mean 390: the largest, 1193, took 15 us).  One that outgrows the LDS
+// (2048 entries, >= 8 x the mean: p ~ 1e-3 per sort at 128 k keys, 1e-7 at 100 k) is ranked from global memory by counting
+// -- slow, still exact.
 // The LDS sort (samples, buckets): every wavefront sorts runs of 64 in registers (bitonic network over __shfl_xor, no
 // barrier), then log2(n / 64) merge passes in which every element finds its place in the merged run by a binary search
 // of the sibling run (unique composites: position = own position + number of smaller siblings) -- ~5 barriers instead of
 // the 55-66 of a workgroup-wide bitonic network, which took 22 us per bucket.
-constexpr int kSsSamples = 1024, kSsTile = 1024, kSsCountThreads = 256, kSsMaxBuckets = 256;
+constexpr int kSsSamples = 1024, kSsTile = 1024, kSsCountThreads = 512, kSsMaxBuckets = 512, kSsBucketBits = 9;
 constexpr int kSsSortThreads = 1024, kSsBucketCap = 2048;
-constexpr int64_t kSsMinN = 8192, kSsMaxN = (int64_t)kSsMaxBuckets * 1024;
+constexpr int64_t kSsMinN = 8192, kSsMaxN = (int64_t)kSsMaxBuckets * 256;
 
 template <typename U> __device__ __forceinline__ bool comp_less(U da, uint32_t ia, U db, uint32_t ib)
 {
@@ -114,44 +117,81 @@ __device__ __forceinline__ unsigned long long shfl_xor_u(unsigned long long v, i
 }
 
 // ascending sort of npad composites (power of two, 64 .. cap; entries are unique -- padding included) held in (d0, i0);
-// (d1, i1) is the second buffer.  Returns through *rd, *ri the buffer that holds the result.  Whole workgroup.
-template <typename U>
+// (d1, i1) is the second buffer.  Returns through *rd, *ri the buffer that holds the result.  Whole workgroup; EPT = entries
+// per thread (npad <= EPT * blockDim.x): with 2, a thread's two sorting networks / binary searches are interleaved, so the
+// second entry rides in the latency shadow of the first (2048 entries cost ~1.2x of 1024, not 2x).
+template <int EPT, typename U>
 __device__ __forceinline__ void sort_lds(U *d0, uint32_t *i0, U *d1, uint32_t *i1, int npad, U **rd, uint32_t **ri)
 {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int c = wave; c < npad / kWave; c += nwaves) {                  // runs of 64 in registers
-        U d = d0[c * kWave + lane];
-        uint32_t i = i0[c * kWave + lane];
+    {                                                                    // runs of 64 in registers
+        U d[EPT];
+        uint32_t i[EPT];
+        bool on[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            const int c = wave + u * nwaves;
+            on[u] = c < npad / kWave;                                    // (wave-uniform)
+            d[u] = on[u] ? d0[c * kWave + lane] : (U)0;
+            i[u] = on[u] ? i0[c * kWave + lane] : 0u;
+        }
 #pragma unroll
         for (int k = 2; k <= kWave; k <<= 1)
 #pragma unroll
             for (int j = k >> 1; j > 0; j >>= 1) {
-                const U od = shfl_xor_u(d, j);
-                const uint32_t oi = shfl_xor_u(i, j);
                 const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-                const bool other_less = comp_less(od, oi, d, i);
-                if (other_less == keep_min) { d = od; i = oi; }
+                U od[EPT];
+                uint32_t oi[EPT];
+#pragma unroll
+                for (int u = 0; u < EPT; u++) { od[u] = shfl_xor_u(d[u], j); oi[u] = shfl_xor_u(i[u], j); }
+#pragma unroll
+                for (int u = 0; u < EPT; u++)
+                    if (comp_less(od[u], oi[u], d[u], i[u]) == keep_min) { d[u] = od[u]; i[u] = oi[u]; }
             }
-        d0[c * kWave + lane] = d;
-        i0[c * kWave + lane] = i;
+#pragma unroll
+        for (int u = 0; u < EPT; u++)
+            if (on[u]) { const int c = wave + u * nwaves; d0[c * kWave + lane] = d[u]; i0[c * kWave + lane] = i[u]; }
     }
     __syncthreads();
     U *sd = d0, *dd = d1;
     uint32_t *si = i0, *di = i1;
     for (int L = kWave; L < npad; L <<= 1) {
-        for (int e = threadIdx.x; e < npad; e += blockDim.x) {
-            const int run = e / L, pos = e - run * L;
-            const U *bd = sd + (run ^ 1) * L;
-            const uint32_t *bi = si + (run ^ 1) * L;
-            const U d = sd[e];
-            const uint32_t i = si[e];
-            int lo = 0;                                                  // number of sibling entries below (d, i)
-            for (int step = L >> 1; step > 0; step >>= 1)
-                if (comp_less(bd[lo + step - 1], bi[lo + step - 1], d, i)) lo += step;
-            if (comp_less(bd[lo], bi[lo], d, i)) lo++;                   // (lo <= L - 1 here)
-            const int dst = (run & ~1) * L + pos + lo;
-            dd[dst] = d;
-            di[dst] = i;
+        U d[EPT];
+        uint32_t i[EPT];
+        int lo[EPT], e[EPT];
+        const U *bd[EPT];
+        const uint32_t *bi[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            e[u] = threadIdx.x + u * blockDim.x;
+            if (e[u] >= npad) e[u] = threadIdx.x;                        // (idle slot: repeats entry 0's work, writes nothing)
+            const int run = e[u] / L;
+            bd[u] = sd + (run ^ 1) * L;
+            bi[u] = si + (run ^ 1) * L;
+            d[u] = sd[e[u]];
+            i[u] = si[e[u]];
+            lo[u] = 0;                                                   // number of sibling entries below (d, i)
+        }
+        for (int step = L >> 1; step > 0; step >>= 1) {
+            // the searches are LDS-bandwidth bound (random 8-byte reads): the index is only fetched on equal keys
+            U xd[EPT];
+#pragma unroll
+            for (int u = 0; u < EPT; u++) xd[u] = bd[u][lo[u] + step - 1];
+#pragma unroll
+            for (int u = 0; u < EPT; u++) {
+                bool less = xd[u] < d[u];
+                if (xd[u] == d[u]) less = bi[u][lo[u] + step - 1] < i[u];
+                if (less) lo[u] += step;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            if (comp_less(bd[u][lo[u]], bi[u][lo[u]], d[u], i[u])) lo[u]++;      // (lo <= L - 1 here)
+            if ((int)(threadIdx.x + u * blockDim.x) < npad) {
+                const int run = e[u] / L, dst = (run & ~1) * L + (e[u] - run * L) + lo[u];
+                dd[dst] = d[u];
+                di[dst] = i[u];
+            }
         }
         __syncthreads();
         U *td = sd; sd = dd; dd = td;
@@ -184,7 +224,7 @@ __global__ __launch_bounds__(kSsSortThreads) void k_ss_splitters(const K *__rest
     __syncthreads();
     U *d;
     uint32_t *ii;
-    sort_lds(d0, i0, d1, i1, kSsSamples, &d, &ii);
+    sort_lds<1>(d0, i0, d1, i1, kSsSamples, &d, &ii);
     for (int b = threadIdx.x + 1; b < B; b += blockDim.x) {
         const int j = (int)((long long)b * kSsSamples / B);
         spl_d[b - 1] = d[j];
@@ -214,7 +254,7 @@ __global__ __launch_bounds__(kSsCountThreads) void k_ss_count(const K *__restric
                 const int mid = (lo + hi) >> 1;
                 if (comp_less(dk, i, sd[mid], si[mid])) hi = mid; else lo = mid + 1;
             }
-            pb[i] = (uint32_t)lo | (atomicAdd(&hist[lo], 1u) << 8);
+            pb[i] = (uint32_t)lo | (atomicAdd(&hist[lo], 1u) << kSsBucketBits);
         }
     }
     __syncthreads();
@@ -245,7 +285,7 @@ __global__ __launch_bounds__(kSsCountThreads) void k_ss_scatter(const K *__restr
     for (int k = 0; k < kSsTile / kSsCountThreads; k++) {
         const uint32_t i = blockIdx.x * kSsTile + k * kSsCountThreads + threadIdx.x;
         if (i < n) {
-            const uint32_t w = pb[i], pos = off[w & 255u] + (w >> 8);
+            const uint32_t w = pb[i], pos = off[w & (kSsMaxBuckets - 1)] + (w >> kSsBucketBits);
             dk[pos] = KeyBits<K>::desc(keys[i]);
             di[pos] = i;
         }
@@ -279,11 +319,12 @@ __global__ __launch_bounds__(kSsSortThreads) void k_ss_bucket(const U *__restric
     __syncthreads();
     U *d;
     uint32_t *ii;
-    sort_lds(d0, i0, d1, i1, npad, &d, &ii);
+    if (npad <= kSsSortThreads) sort_lds<1>(d0, i0, d1, i1, npad, &d, &ii);
+    else sort_lds<2>(d0, i0, d1, i1, npad, &d, &ii);
     for (uint32_t e = threadIdx.x; e < m; e += blockDim.x) order[base + e] = (V)ii[e];
 }
 
-static inline int ss_buckets(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(n / 384, 16), kSsMaxBuckets); }
+static inline int ss_buckets(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(n / 192, 16), kSsMaxBuckets); }
 static inline bool ss_eligible(int64_t n) { return n >= kSsMinN && n <= kSsMaxN; }
 
 template <typename K>

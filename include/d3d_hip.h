@@ -350,7 +350,7 @@ int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, int64_t m, in
 
 /* stable descending argsort (the role torch::argsort plays inside the reference's nms2d,
  * nms.cpp:103): keys[n] in `dtype` -> order[n] i64; ties keep ascending index.  The order is torch's:
- * by value (-0 == +0), NaN before every number.  8 k .. 256 k keys: a 4-launch sample sort; other sizes: rocPRIM. */
+ * by value (-0 == +0), NaN before every number.  8 k .. 128 k keys: a 4-launch sample sort; other sizes: rocPRIM. */
 size_t d3d_argsort_desc_workspace_bytes(int64_t n, int32_t dtype);
 int d3d_argsort_desc(const void *keys, int64_t n, int32_t dtype, int64_t *order,
                      void *workspace, size_t workspace_bytes, void *stream);

@@ -36,7 +36,7 @@ def test_cfg3_nms_100k_boxes_vs_oracle():
 
 
 def test_nms_300k_boxes_beyond_the_inline_paths():
-    """300 k boxes: above the sizes that take the bucket argsort (256 k keys) and the in-kernel fold of the grid extents
+    """300 k boxes: above the sizes that take the bucket argsort (128 k keys) and the in-kernel fold of the grid extents
     (512 workgroups of k_nms_prepare) -- the library sort and the separate fold kernel; keep mask bit-exact"""
     from d3d_amd import synth
     from d3d_amd.box import box2d_nms
