@@ -442,19 +442,28 @@ static unsigned long long nms_cand_capacity(int64_t n)
 
 
 // Scan across the workgroups of ONE launch: every workgroup publishes its total with a ready bit (tot[] zeroed by an earlier
-// kernel) and adds up the totals of the workgroups before it, polling the ones not there yet.  A workgroup only waits for
-// LOWER-numbered workgroups, which the dispatcher started before it, and they publish before they wait: always progress.
-// Returns (in every thread) the sum of the totals of workgroups 0 .. blockIdx.x - 1; contains workgroup barriers.
-__device__ __forceinline__ unsigned long long chained_prefix(unsigned long long *tot, unsigned long long total, unsigned long long *sbase)
+// kernel) and adds up the totals of the workgroups before it, polling the ones not there yet.  "Before" is the order of
+// scan_ticket(), not blockIdx.x -- the dispatch order of workgroups is undefined: a workgroup holding ticket t only waits for
+// tickets < t, whose holders are running (they took theirs first) and publish before they wait: always progress, wherever
+// and in whatever order the workgroups are placed.  Value and ready bit travel in one agent-scope 64-bit word.
+// Returns (in every thread) the sum of the totals of tickets 0 .. id - 1; both contain workgroup barriers.
+__device__ __forceinline__ unsigned int scan_ticket(unsigned int *ticket, unsigned int *sid)
+{
+    if (threadIdx.x == 0) *sid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    return *sid;
+}
+__device__ __forceinline__ unsigned long long chained_prefix(unsigned long long *tot, unsigned int id, unsigned long long total,
+                                                             unsigned long long *sbase)
 {
     const unsigned int lane = threadIdx.x & 63;
     if (threadIdx.x == 0)
-        __hip_atomic_store(&tot[blockIdx.x], (total << 1) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&tot[id], (total << 1) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < 64) {
         unsigned long long acc = 0;
-        for (unsigned int j0 = 0; j0 < blockIdx.x; j0 += 64) {
+        for (unsigned int j0 = 0; j0 < id; j0 += 64) {
             const unsigned int j = j0 + lane;
-            if (j < blockIdx.x) {
+            if (j < id) {
                 unsigned long long t;
                 do { t = __hip_atomic_load(&tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(t & 1ull));
                 acc += t >> 1;
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(256) void k_nms_prepare(const T *__restrict__ boxes
     if (p == 0) { flags->need_sweep = force_dense; flags->undecided = 0; *grid_ticket = 0; }
     if (p < kNmsListSegs) cand_hdr->count[p * 16] = 0;
     if (p * kIncTile < n) tile_tot[p] = 0;                   // k_nms_incscan's ready words
-    if (p < kGridScanWgs) chunk_tot[p] = 0;                  // ... and k_nms_gridscan's
+    if (p < kGridScanWgs + 1) chunk_tot[p] = 0;              // ... and k_nms_gridscan's; behind them the two tickets
     if (p < n) {
         const int64_t i = order[p];
         const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
@@ -744,16 +753,18 @@ __global__ __launch_bounds__(256) void k_nms_gridreg(const float4 *__restrict__ 
 // counters are 64 KB of strided reads per workgroup; ONE workgroup reading all 4 MB took 11 us) + chained_prefix across
 // the workgroups (chunk_tot[] zeroed by k_nms_prepare)
 __global__ __launch_bounds__(1024) void k_nms_gridscan(uint32_t *cellcur, uint32_t *cellstart, NmsGrid *grid, unsigned long long cap_e,
-                                                       NmsFlags *flags, unsigned long long *chunk_tot)
+                                                       NmsFlags *flags, unsigned long long *chunk_tot, unsigned int *ticket)
 {
     __shared__ unsigned long long smem[1024 / kWave], sbase;
+    __shared__ unsigned int sid;
+    const int chunk = (int)scan_ticket(ticket, &sid);
     const int cells = grid->gx * grid->gy;                                      // entry `cells` = the total
-    if ((int)blockIdx.x * 1024 > cells) return;                                 // (nobody waits for a higher workgroup)
-    const int c = blockIdx.x * 1024 + threadIdx.x;
+    if (chunk * 1024 > cells) return;                                           // (nobody waits for a higher chunk)
+    const int c = chunk * 1024 + threadIdx.x;
     const uint32_t x = c < cells ? cellcur[(size_t)c * kGridPad] : 0u;
     unsigned long long total;
     const unsigned long long ex = block_excl_scan_u64<1024>(x, &total, smem);
-    const unsigned long long before = chained_prefix(chunk_tot, total, &sbase);
+    const unsigned long long before = chained_prefix(chunk_tot, (unsigned int)chunk, total, &sbase);
     if (c <= cells) { cellstart[c] = (uint32_t)(before + ex); cellcur[(size_t)c * kGridPad] = (uint32_t)(before + ex); }
     if (c == cells) {
         const unsigned long long tot = before + ex;
@@ -900,11 +911,13 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__
 // inc_off = exclusive scan of inc_cnt in ONE launch (the generic count / block-sum / apply trio is three, ~4 us each in a
 // stream): a local scan per 1024-box tile + chained_prefix over the tiles (tile_tot[] is zeroed by k_nms_prepare)
 __global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict__ inc_cnt, int64_t n, uint32_t *__restrict__ inc_off,
-                                                     unsigned long long *tile_tot)
+                                                     unsigned long long *tile_tot, unsigned int *ticket)
 {
     __shared__ unsigned long long smem[4], sbase;
+    __shared__ unsigned int sid;
+    const unsigned int tile = scan_ticket(ticket, &sid);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t base = (int64_t)blockIdx.x * kIncTile + (int64_t)w * 256 + lane;       // wavefront w: 4 rows of 64 boxes
+    const int64_t base = (int64_t)tile * kIncTile + (int64_t)w * 256 + lane;             // wavefront w: 4 rows of 64 boxes
     unsigned long long ex[4], carry = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict_
     unsigned long long woff = 0, total = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { if (k < w) woff += smem[k]; total += smem[k]; }
-    const unsigned long long before = chained_prefix(tile_tot, total, &sbase);
+    const unsigned long long before = chained_prefix(tile_tot, tile, total, &sbase);
     const unsigned long long off = before + woff;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1110,8 +1123,9 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     uint32_t *inc_cnt = w.take<uint32_t>(nb * 64);
     uint32_t *inc_off = w.take<uint32_t>(nb * 64);
     float *farea = w.take<float>(nb * 64);
-    unsigned long long *tile_tot = w.take<unsigned long long>(d3d_divup(nb * 64, kScanTile) + 1 + kGridScanWgs);
+    unsigned long long *tile_tot = w.take<unsigned long long>(d3d_divup(nb * 64, kScanTile) + 1 + kGridScanWgs + 1);
     unsigned long long *chunk_tot = tile_tot + d3d_divup(nb * 64, kScanTile) + 1;
+    unsigned int *tickets = reinterpret_cast<unsigned int *>(chunk_tot + kGridScanWgs);     // [0] k_nms_incscan, [1] k_nms_gridscan
     (void)w.take<int64_t>(D3D_NUM_COUNTS);
     static_assert(kIncTile == kScanTile, "workspace sized with kScanTile");
     NmsFlags *flags = w.take<NmsFlags>(1);
@@ -1154,7 +1168,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
         D3D_LAUNCH("k_nms_gridreg<count>", k_nms_gridreg<false>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
                    cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, fold_inline ? nbl : 0u);
         D3D_LAUNCH("k_nms_gridscan", k_nms_gridscan, dim3(kGridScanWgs), dim3(1024), 0, st, cellcur, cellstart, grid, cap_e, flags,
-                   chunk_tot);
+                   chunk_tot, tickets + 1);
         D3D_LAUNCH("k_nms_gridreg<place>", k_nms_gridreg<true>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
                    cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, 0u);
         D3D_LAUNCH("k_nms_cand_grid", k_nms_cand_grid, dim3((unsigned)d3d_divup((int64_t)cap_e, 256)), dim3(256), 0, st,
@@ -1178,7 +1192,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
         D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, false>), dim3(hits_blocks), dim3(256), 0, st, geom, rankx, cand, cap, cand_hdr,
                    (T)iou_thr, inc_cnt, arrival);
     D3D_LAUNCH("k_nms_incscan", k_nms_incscan, dim3((unsigned)d3d_divup(n, kIncTile)), dim3(256), 0, st, (const uint32_t *)inc_cnt, n,
-               inc_off, tile_tot);
+               inc_off, tile_tot, tickets);
     D3D_LAUNCH("k_nms_fill", k_nms_fill, dim3(hits_blocks), dim3(256), 0, st, (const unsigned long long *)cand, cap,
                (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, (const uint32_t *)arrival, inc);
     D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,
