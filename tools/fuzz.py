@@ -36,6 +36,20 @@ for seed in range(first, first + count):
     exp = oracle.box2d_nms(b, s, **kw)
     if not np.array_equal(keep, exp):
         bad += 1; print("NMS seed", seed, kw, n, "FAILED", int(np.sum(keep != exp)))
+    if seed % 10 == 0:        # a large set now and then: the bucket argsort (>= 8 k keys), long incoming lists, the grid's cell scan
+        nl = int(rng.integers(9000, 60000))
+        side = float(rng.choice([300.0, 1500.0, 6000.0]))
+        bl = np.stack([rng.random(nl) * side, rng.random(nl) * side, rng.random(nl) * 20 + 5, rng.random(nl) * 20 + 5,
+                       (rng.random(nl) - 0.5) * 6.3], 1)
+        sl = rng.random(nl)
+        if seed % 20 == 0:
+            sl = np.round(sl * 1000) / 1000                                  # many ties
+        thr_l, sthr_l = float(rng.choice([0.1, 0.3, 0.5])), float(rng.choice([0.0, 0.3]))
+        keep = box2d_nms(torch.from_numpy(bl).cuda(), torch.from_numpy(sl).cuda(), iou_method=method, iou_threshold=thr_l,
+                         score_threshold=sthr_l).cpu().numpy()
+        exp = oracle.box2d_nms_hard_candidates(bl, sl, method, thr_l, sthr_l)
+        if not np.array_equal(keep, exp):
+            bad += 1; print("NMS-LARGE seed", seed, method, nl, side, thr_l, "FAILED", int(np.sum(keep != exp)))
     m = int(rng.integers(1, 400))
     b2 = b[rng.integers(0, n, m)] + rng.normal(0, 1.0, (m, 5))
     got = box2d_iou(torch.from_numpy(b).cuda(), torch.from_numpy(b2).cuda(), method=method).cpu().numpy()
