@@ -283,14 +283,14 @@ def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_thresho
     n = b.shape[0]
     code = _dtype_code(b)
     with torch.cuda.device(dev):
-        if sort_keys is not None and sort_keys.dtype == torch.float32 and sort_keys.numel() == n:
+        # order = None: the library sorts the scores itself (inside the first kernel for up to 4096 boxes)
+        order = None
+        if sort_keys is not None and sort_keys.dtype == torch.float32 and sort_keys.numel() == n and s.dtype != torch.float32 and n > 4096:
             order = argsort_desc(sort_keys.to(dev).contiguous())
-        else:
-            order = argsort_desc(s)
         sup = torch.empty((n,), dtype=torch.uint8, device=dev)
         # both workspaces are carved from one arena; the sort finished with it (same stream)
         ws = _lib.workspace(lib.d3d_nms2d_workspace_bytes(n), dev)
-        rc = lib.d3d_nms2d(_lib.ptr(b), _lib.ptr(s), _lib.ptr(order), n, iou_type, supression_type, code,
+        rc = lib.d3d_nms2d(_lib.ptr(b), _lib.ptr(s), _lib.ptr(order) if order is not None else None, n, iou_type, supression_type, code,
                            float(iou_threshold), float(score_threshold), float(supression_param), _lib.ptr(sup),
                            _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), default_nms_flags if flags is None else int(flags))
     _lib.check(rc, "nms2d")

@@ -14,6 +14,7 @@
 //    the dense path behind a device-side flag.
 #include "common.hpp"
 #include "geom.hpp"
+#include "lds_sort.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -889,7 +890,8 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__
     unsigned long long *seg = list + sg * segcap;
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const unsigned long long e = seg[t];
-        const uint32_t r1 = rankx[e >> 32], r2 = rankx[e & 0xffffffffull];      // x-order index -> score rank
+        // list entry -> score ranks (through the broad phase's own numbering; the small-set path lists ranks directly)
+        const uint32_t r1 = rankx ? rankx[e >> 32] : (uint32_t)(e >> 32), r2 = rankx ? rankx[e & 0xffffffffull] : (uint32_t)e;
         const uint32_t p = r1 < r2 ? r1 : r2, q = r1 < r2 ? r2 : r1;
         const BoxGeom<T> a = geom[p], b = geom[q];
         bool hit = false;
@@ -1032,19 +1034,45 @@ __global__ __launch_bounds__(256) void k_nms_resolve(int64_t n, uint8_t *state, 
     if (q < n && done) suppressed[mine_out] = state[q] == kSuppressed;
     // hitters [pos, cnt) are still undecided as far as this lane knows: every pass looks at all of them (ONE kept hitter
     // decides, wherever it sits in the list) and moves the ones found suppressed in front of pos
-    uint32_t pos = 0, cnt = 0;
+    // Before the list, the box's lowest-ranked hitter alone (one load per pass): in a cluster of detections it is the cluster's
+    // best box for almost every member, kept early; while it is undecided the box waits, the list is only walked once it
+    // turns out suppressed (see k_nms_resolve_small).
+    uint32_t cnt = 0, first = 0;
     uint32_t *mine = nullptr;
-    if (!done) { cnt = inc_cnt[q]; mine = inc + inc_off[q]; }
+    if (!done) {
+        cnt = inc_cnt[q]; mine = inc + inc_off[q];
+        first = 0xffffffffu;            // (found here, by independent loads: a second atomic per hit on the box's counters
+        for (uint32_t e = 0; e < cnt; e++) first = mine[e] < first ? mine[e] : first;   //  doubled k_nms_hits on clusters)
+    }
     for (int pass = 0; pass < kSpinPasses; pass++) {
         if (!done) {
-            bool hit = false;
-            for (uint32_t e = pos; e < cnt; e++) {
-                const uint32_t h = mine[e];
-                const uint8_t sp = __hip_atomic_load(&state[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sp == kKept) { hit = true; break; }
-                if (sp == kSuppressed) { mine[e] = mine[pos]; mine[pos] = h; pos++; }
+            bool hit = false, wait = false;
+            if (cnt > 0) {
+                const uint8_t s0 = __hip_atomic_load(&state[first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hit = s0 == kKept;
+                wait = s0 == kUndecided;
             }
-            if (hit || pos == cnt) {
+            if (!hit && !wait) {
+                // four entries per step (independent loads); the undecided ones are written back compacted -- the write cursor
+                // never passes the read position -- so the list shrinks to what is still open
+                uint32_t wr = 0;
+                for (uint32_t e = 0; e < cnt && !hit; e += 4) {
+                    uint32_t h[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) h[k] = e + k < cnt ? mine[e + k] : 0u;
+                    uint8_t sp[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) sp[k] = __hip_atomic_load(&state[h[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (e + k < cnt) {
+                            if (sp[k] == kKept) hit = true;
+                            else if (sp[k] == kUndecided) mine[wr++] = h[k];
+                        }
+                }
+                if (!hit) cnt = wr;
+            }
+            if (hit || (!wait && cnt == 0)) {
                 __hip_atomic_store(&state[q], (uint8_t)(hit ? kSuppressed : kKept), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 suppressed[mine_out] = hit ? 1 : 0;
                 done = true;
@@ -1111,9 +1139,250 @@ __global__ __launch_bounds__(kSweepThreads) void k_nms_sweep(const unsigned long
         suppressed[order[p]] = (uint8_t)((remv[p >> 6] >> (p & 63)) & 1ull);
 }
 
+// ---------------------------------------------------------------- small sets (n <= kNmsSmallMax): five launches
+// A detector's top-k (1 k - 4 k boxes) is all launch latency on the general path: sort + 13 dependent launches, ~5 us each
+// on the stream.  Here:
+//   k_nms_small_front    ONE workgroup: the scores are sorted in LDS (lds_sort.hpp; skipped when the caller brings the
+//                        order), then everything k_nms_prepare does, in rank order
+//   k_nms_cand_all       all pairs p < q of the set against each other (64 rows from LDS x one column per lane): AABB
+//                        overlap + the IoU upper bound -> candidate list, in ranks
+//   k_nms_hits           (as above) exact IoU per candidate, hit counts
+//   k_nms_fill_small     the offsets of the incoming lists = scan of <= 4096 counts, repeated in LDS by every workgroup;
+//                        the hits into the lists
+//   k_nms_resolve_small  ONE workgroup, the states in LDS: passes over the undecided boxes until none is left (the lowest
+//                        undecided box can always be decided, so at most n passes; no spin limit, no dense fallback).
+// The candidate list holds the full triangle at these sizes, so it cannot overflow.
+constexpr int kNmsSmallMax = 4096;
+constexpr int kNmsSmallResolveMax = 1024;     // one box per lane of k_nms_resolve_small; above: k_nms_resolve (state in global
+                                              // memory, all CUs: 4 boxes per lane of one workgroup took 106 us at 4 k clustered boxes)
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_nms_small_front(const T *__restrict__ boxes, const T *__restrict__ scores,
+                                                          const int64_t *__restrict__ order_in, uint32_t n, float score_threshold,
+                                                          int64_t *order_out, BoxGeom<T> *geom, float4 *fbox, float *farea,
+                                                          uint8_t *state, uint32_t *inc_cnt, NmsFlags *flags, NmsCand *cand_hdr,
+                                                          unsigned long long *remv)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char small_lds[];
+    typedef typename KeyBits<T>::U U;
+    uint32_t npad = kWave;
+    while (npad < n) npad <<= 1;
+    U *d0 = reinterpret_cast<U *>(small_lds), *d1 = d0 + npad;
+    uint32_t *i0 = reinterpret_cast<uint32_t *>(d1 + npad), *i1 = i0 + npad;
+    uint32_t *ii = i0;
+    if (!order_in) {
+        for (uint32_t e = threadIdx.x; e < npad; e += blockDim.x) {
+            d0[e] = e < n ? KeyBits<T>::desc(scores[e]) : ~(U)0;         // padding sorts behind every real entry and is unique
+            i0[e] = e < n ? e : 0x80000000u + e;
+        }
+        __syncthreads();
+        U *d;
+        if (npad <= 1024) sort_lds<1>(d0, i0, d1, i1, (int)npad, &d, &ii);          // entries per thread: no idle slots
+        else if (npad <= 2048) sort_lds<2>(d0, i0, d1, i1, (int)npad, &d, &ii);
+        else sort_lds<kNmsSmallMax / 1024>(d0, i0, d1, i1, (int)npad, &d, &ii);
+    }
+    if (threadIdx.x == 0) { flags->need_sweep = 0; flags->undecided = 0; cand_hdr->count[0] = 0; }
+    for (uint32_t p0 = 0; p0 < n; p0 += blockDim.x) {                // (wave-uniform bound: the ballot below)
+        const uint32_t p = p0 + threadIdx.x;
+        bool pre = false;
+        if (p < n) {
+            const int64_t i = order_in ? order_in[p] : (int64_t)ii[p];
+            if (!order_in) order_out[p] = i;
+            const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
+            geom[p] = g;
+            fbox[p] = make_float4(round_down(g.xmin), round_down(g.ymin), round_up(g.xmax), round_up(g.ymax));
+            farea[p] = round_down(g.area);
+            // nms.cpp:23-29: the tail with score <= threshold is suppressed up front, never position 0
+            pre = p > 0 && !(scores[i] > (T)score_threshold);
+            state[p] = pre ? kSuppressed : kUndecided;
+            inc_cnt[p] = 0;
+        }
+        const unsigned long long word = __ballot(pre);               // (for the dense fallback's sweep)
+        if ((threadIdx.x & 63) == 0 && p < n) remv[p >> 6] = word;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nms_cand_all(const float4 *__restrict__ fbox, const float *__restrict__ farea, uint32_t n,
+                                                      float thr, unsigned long long *__restrict__ list, unsigned long long cap,
+                                                      NmsCand *hdr, NmsFlags *flags)
+{
+    __shared__ unsigned long long batch[4][kCandLds];
+    __shared__ float4 rows[kWave];
+    __shared__ float rarea[kWave];
+    __shared__ unsigned int wcnt[4];
+    __shared__ unsigned long long bbase;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t p0 = blockIdx.y * kWave, q = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 + 255 <= p0) return;                       // every column of the tile is at or before its first row
+    if (threadIdx.x < kWave) {
+        const uint32_t p = p0 + threadIdx.x;
+        rows[threadIdx.x] = p < n ? fbox[p] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+        rarea[threadIdx.x] = p < n ? farea[p] : 0.f;
+    }
+    __syncthreads();
+    const bool live = q < n;
+    const float4 fb = live ? fbox[q] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+    const float ab = live ? farea[q] : 0.f;
+    const bool bound_on = thr >= 0.f;                               // (see k_nms_cand_grid)
+    const float thr_lhs = 1.f + thr, thr_rhs = thr * (1.f - 1e-4f);
+    unsigned long long *qb = batch[wave];
+    unsigned int wn = 0;
+    unsigned long long *counter = &hdr->count[0];
+    auto write_out = [&](unsigned long long gb) {
+        __builtin_amdgcn_wave_barrier();
+        for (unsigned int t = lane; t < wn; t += 64)
+            if (gb + t < cap) list[gb + t] = qb[t];
+        if (gb + wn > cap) flags->need_sweep = 1;                   // (cannot happen: the list holds the full triangle)
+        wn = 0;
+    };
+    for (uint32_t r = 0; r < kWave; r++) {
+        const uint32_t p = p0 + r;
+        const float4 fa = rows[r];
+        const float gap = fminf(fminf(fb.z - fa.x, fa.z - fb.x), fminf(fb.w - fa.y, fa.w - fb.y));
+        bool cand = live && p < q && gap > 0.f;                     // (rows past n have empty AABBs)
+        if (cand && bound_on) {
+            const float aa = rarea[r];
+            const float ix = fminf(fa.z, fb.z) - fmaxf(fa.x, fb.x), iy = fminf(fa.w, fb.w) - fmaxf(fa.y, fb.y);
+            const float iub = fminf(ix * iy, fminf(aa, ab));
+            cand = !(iub * thr_lhs < thr_rhs * (aa + ab));
+        }
+        const unsigned long long m = __ballot(cand);
+        if (m) {
+            const unsigned int cnt = (unsigned int)__popcll(m);
+            if (wn + cnt > (unsigned int)kCandLds) {
+                unsigned long long gb = 0;
+                if (lane == 0) gb = atomicAdd(counter, (unsigned long long)wn);
+                write_out(__shfl(gb, 0, 64));
+            }
+            if (cand) qb[wn + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)p << 32) | (unsigned long long)q;
+            wn += cnt;
+        }
+    }
+    if (lane == 0) wcnt[wave] = wn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        bbase = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long gb = bbase;
+    for (uint32_t w = 0; w < wave; w++) gb += wcnt[w];
+    if (wn) write_out(gb);
+}
+
+__global__ __launch_bounds__(1024) void k_nms_fill_small(const unsigned long long *__restrict__ list, unsigned long long cap,
+                                                         const NmsCand *hdr, const uint32_t *__restrict__ inc_cnt, uint32_t n,
+                                                         uint32_t *__restrict__ inc_off, const uint32_t *__restrict__ arrival,
+                                                         uint32_t *__restrict__ inc)
+{
+    __shared__ uint32_t off[kNmsSmallMax];
+    __shared__ unsigned long long smem[1024 / kWave];
+    uint32_t c[4];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t i = threadIdx.x * 4 + k; c[k] = i < n ? inc_cnt[i] : 0u; mine += c[k]; }
+    unsigned long long total;
+    unsigned long long ex = block_excl_scan_u64<1024>(mine, &total, smem);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = threadIdx.x * 4 + k;
+        off[i] = (uint32_t)ex;
+        if (blockIdx.x == 0 && i < n) inc_off[i] = (uint32_t)ex;     // for k_nms_resolve_small
+        ex += c[k];
+    }
+    __syncthreads();
+    const unsigned long long cnt = hdr->count[0], tot = cnt < cap ? cnt : cap;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long e = list[t];
+        if (!(e & kHitBit)) continue;
+        const uint32_t q = (uint32_t)e, p = (uint32_t)(e >> 32) & 0x7fffffffu;
+        inc[off[q] + arrival[t]] = p;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_nms_resolve_small(uint32_t n, const uint8_t *__restrict__ state0,
+                                                            const uint32_t *__restrict__ inc_cnt, const uint32_t *__restrict__ inc_off,
+                                                            uint32_t *inc, const int64_t *__restrict__ order,
+                                                            uint8_t *__restrict__ suppressed)
+{
+    __shared__ uint8_t st_lds[kNmsSmallResolveMax];
+    volatile uint8_t *st = st_lds;
+    constexpr int PER = kNmsSmallResolveMax / 1024;
+    uint32_t cnt[PER];
+    uint32_t *mine[PER], first[PER];
+    bool done[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const uint32_t q = threadIdx.x + u * 1024;
+        done[u] = true; cnt[u] = 0; mine[u] = nullptr; first[u] = 0;
+        if (q < n) {
+            const uint8_t s0 = state0[q];
+            st[q] = s0;
+            if (s0 == kUndecided) {
+                done[u] = false; cnt[u] = inc_cnt[q]; mine[u] = inc + inc_off[q];
+                first[u] = 0xffffffffu;
+                for (uint32_t e = 0; e < cnt[u]; e++) first[u] = mine[u][e] < first[u] ? mine[u][e] : first[u];
+            }
+        }
+    }
+    __syncthreads();
+    // Per pass and undecided box: FIRST its lowest-ranked hitter (one LDS read).  In a cluster of detections around an object
+    // that is the cluster's best box for almost every member: kept in the first pass, so the members are suppressed in the
+    // second without their lists being touched.  While it is undecided the box just waits (it is the hitter decided earliest);
+    // only when it turns out suppressed is the list walked: ONE kept hitter decides, wherever it sits; the undecided entries
+    // are written back compacted, so the list shrinks to what is still open.  A decision only uses final states, so reading a
+    // neighbour's
+    // state a pass late delays it and nothing else; the lowest undecided box can always be decided: at most n passes.
+    for (;;) {
+        int any = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            if (done[u]) continue;
+            const uint32_t q = threadIdx.x + u * 1024;
+            bool hit = false, wait = false;
+            if (cnt[u] > 0) {
+                const uint8_t s0 = st[first[u]];
+                hit = s0 == kKept;
+                wait = s0 == kUndecided;
+            }
+            if (!hit && !wait) {
+                uint32_t wr = 0;                                     // four entries per step, the undecided ones compacted
+                for (uint32_t e = 0; e < cnt[u] && !hit; e += 4) {
+                    uint32_t h[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) h[k] = e + k < cnt[u] ? mine[u][e + k] : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (e + k < cnt[u]) {
+                            const uint8_t sp = st[h[k]];
+                            if (sp == kKept) hit = true;
+                            else if (sp == kUndecided) mine[u][wr++] = h[k];
+                        }
+                }
+                if (!hit) cnt[u] = wr;
+            }
+            if (hit || (!wait && cnt[u] == 0)) { st[q] = hit ? kSuppressed : kKept; done[u] = true; }
+            else any = 1;
+        }
+        if (!__syncthreads_or(any)) break;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const uint32_t q = threadIdx.x + u * 1024;
+        if (q < n) suppressed[order[q]] = st[q] == kSuppressed;
+    }
+}
+
+
+// the small-set path takes hard NMS of up to kNmsSmallMax boxes unless a flag asks for a specific general path (tests)
+static inline bool nms_small_eligible(int64_t n, uint32_t opts)
+{
+    return n <= kNmsSmallMax && !(opts & (D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_GENERAL)) && (opts >> 8) == 0;
+}
+
 template <typename T>
 int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, int iou_type, float iou_thr,
-              float score_thr, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st, uint32_t opts)
+              float score_thr, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st, uint32_t opts, int64_t *order_ws)
 {
     const int64_t nb = d3d_divup(n, 64);
     WsCarver w(ws, ws_bytes);
@@ -1158,6 +1427,45 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     float *carea = w.take<float>((size_t)cap_e);
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
     const bool rot = iou_type == D3D_IOU_RBOX;
+    if (nms_small_eligible(n, opts)) {
+        typedef typename KeyBits<T>::U U;
+        uint32_t npad = kWave;
+        while ((int64_t)npad < n) npad <<= 1;
+        const size_t lds = order ? 0 : (size_t)npad * (2 * sizeof(U) + 8);
+        if (lds > 65536)
+            D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nms_small_front<T>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int64_t *ord = order ? order : order_ws;
+        D3D_LAUNCH("k_nms_small_front", k_nms_small_front<T>, dim3(1), dim3(1024), lds, st, boxes, scores, order, (uint32_t)n, score_thr,
+                   order_ws, geom, fbox, farea, state, inc_cnt, flags, cand_hdr, remv);
+        D3D_LAUNCH("k_nms_cand_all", k_nms_cand_all, dim3((unsigned)d3d_divup(n, 256), (unsigned)nb), dim3(256), 0, st,
+                   (const float4 *)fbox, (const float *)farea, (uint32_t)n, rot ? iou_thr : -1.f, cand, cap, cand_hdr, flags);
+        const unsigned hb = (unsigned)std::min<unsigned long long>(d3d_divup((int64_t)cap, 256), 4096);
+        if (rot)
+            D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, true>), dim3(hb), dim3(256), 0, st, geom, (const uint32_t *)nullptr, cand, cap, cand_hdr,
+                       (T)iou_thr, inc_cnt, arrival);
+        else
+            D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, false>), dim3(hb), dim3(256), 0, st, geom, (const uint32_t *)nullptr, cand, cap, cand_hdr,
+                       (T)iou_thr, inc_cnt, arrival);
+        D3D_LAUNCH("k_nms_fill_small", k_nms_fill_small, dim3(64), dim3(1024), 0, st, (const unsigned long long *)cand, cap,
+                   (const NmsCand *)cand_hdr, (const uint32_t *)inc_cnt, (uint32_t)n, inc_off, (const uint32_t *)arrival, inc);
+        if (n <= kNmsSmallResolveMax) {
+            D3D_LAUNCH("k_nms_resolve_small", k_nms_resolve_small, dim3(1), dim3(1024), 0, st, (uint32_t)n, (const uint8_t *)state,
+                       (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, ord, suppressed);
+            return D3D_OK;
+        }
+        // 1 k - 4 k boxes: the general fixed point (+ its dense fallback for dependency chains beyond the poll limit)
+        D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,
+                   (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, flags, ord, suppressed);
+        const unsigned pb = (unsigned)std::min<int64_t>(d3d_divup(nb, kColsPerBlock) * d3d_divup(nb, 4), 8192);
+        if (rot)
+            D3D_LAUNCH("k_nms_pairs", (k_nms_pairs<T, true>), dim3(pb), dim3(256), 0, st, geom, fbox, n, nb, (T)iou_thr, mask, flags);
+        else
+            D3D_LAUNCH("k_nms_pairs", (k_nms_pairs<T, false>), dim3(pb), dim3(256), 0, st, geom, fbox, n, nb, (T)iou_thr, mask, flags);
+        D3D_LAUNCH("k_nms_sweep", k_nms_sweep, dim3(1), dim3(kSweepThreads), (size_t)nb * 8, st, mask, n, nb, remv, ord, state, flags,
+                   suppressed);
+        return D3D_OK;
+    }
     const bool use_grid = !(opts & D3D_NMS_BROAD_SWEEP);
     const unsigned nbl = (unsigned)d3d_divup(n, 256);
     D3D_LAUNCH("k_nms_prepare", k_nms_prepare<T>, dim3(nbl), dim3(256), 0, st, boxes, scores, order, n, score_thr,
@@ -1593,7 +1901,7 @@ static int softnms_typed(const T *boxes, const T *scores, const int64_t *order, 
     return D3D_OK;
 }
 
-extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
+static size_t nms_core_workspace_bytes(int64_t n)
 {
     if (n < 1) n = 1;
     const size_t nb = (size_t)d3d_divup(n, 64);
@@ -1607,20 +1915,39 @@ extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
            d3d_align_up(kGridReg * nb * 64 * 4) * 3 + d3d_align_up(kGridReg * nb * 64 * 16);
 }
 
+extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
+{
+    if (n < 1) n = 1;
+    // [NMS arrays][order, when the caller passes none][workspace of d3d_argsort_desc]
+    return nms_core_workspace_bytes(n) + d3d_align_up((size_t)n * 8) + d3d_align_up(d3d_argsort_desc_workspace_bytes(n, D3D_F64)) + 256;
+}
+
 extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n, int32_t iou_type,
                          int32_t suppression_type, int32_t dtype, float iou_threshold, float score_threshold,
                          float suppression_param, uint8_t *suppressed, void *workspace, size_t workspace_bytes,
                          void *stream, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS))) return D3D_ERR_BAD_ARG;
+    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL))) return D3D_ERR_BAD_ARG;
     if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;   // common.h:25
     if (suppression_type != D3D_SUPPRESS_HARD && suppression_type != D3D_SUPPRESS_LINEAR &&
         suppression_type != D3D_SUPPRESS_GAUSSIAN)
         return D3D_ERR_UNSUPPORTED;                                                          // common.h:40
     if (n == 0) return D3D_OK;
-    if (!boxes || !scores || !order || !suppressed) return D3D_ERR_BAD_ARG;
+    if (!boxes || !scores || !suppressed) return D3D_ERR_BAD_ARG;
+    // order == NULL: the descending argsort of the scores happens here (nms.cpp:103 does it inside nms2d too) -- inside the
+    // first kernel of the small-set path, by d3d_argsort_desc otherwise; both live behind the NMS part of the workspace
+    const size_t nms_bytes = nms_core_workspace_bytes(n);
+    if (!workspace || workspace_bytes < d3d_nms2d_workspace_bytes(n)) return D3D_ERR_WORKSPACE;
+    int64_t *order_ws = reinterpret_cast<int64_t *>(static_cast<char *>(workspace) + nms_bytes);
+    const bool small = suppression_type == D3D_SUPPRESS_HARD && nms_small_eligible(n, flags);
+    if (!order && !small) {
+        char *sort_ws = reinterpret_cast<char *>(order_ws) + d3d_align_up((size_t)n * 8);
+        const int rc = d3d_argsort_desc(scores, n, dtype, order_ws, sort_ws, d3d_argsort_desc_workspace_bytes(n, dtype), stream);
+        if (rc) return rc;
+        order = order_ws;
+    }
     if (suppression_type != D3D_SUPPRESS_HARD) {
         if (n > 65536) return D3D_ERR_UNSUPPORTED;         // one workgroup, n rounds: minutes beyond this size
         const bool rot = iou_type == D3D_IOU_RBOX;
@@ -1641,9 +1968,9 @@ extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *o
     if (d3d_divup(n, 64) > 65535) return D3D_ERR_BAD_ARG;
     if (dtype == D3D_F64)
         return nms_typed<double>((const double *)boxes, (const double *)scores, order, n, iou_type, iou_threshold,
-                                 score_threshold, suppressed, workspace, workspace_bytes, st, flags);
+                                 score_threshold, suppressed, workspace, nms_bytes, st, flags, order_ws);
     return nms_typed<float>((const float *)boxes, (const float *)scores, order, n, iou_type, iou_threshold,
-                            score_threshold, suppressed, workspace, workspace_bytes, st, flags);
+                            score_threshold, suppressed, workspace, nms_bytes, st, flags, order_ws);
 }
 
 extern "C" int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, int64_t m, int32_t dtype, uint8_t *out,

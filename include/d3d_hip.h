@@ -359,17 +359,20 @@ size_t d3d_nms2d_workspace_bytes(int64_t n);
 
 /* replaces nms2d / nms2d_cuda (reference d3d/box/nms.h:6-18, nms.cpp:10-119,
  * nms_cuda.cu:17-244).  Follows the CPU control flow (nms.cpp:23-59).
- *   boxes[n,5], scores[n] in `dtype`; order[n] i64 = descending argsort of scores
- *   (nms.cpp:103) supplied by the caller; suppressed[n] u8 (0/1) output.
- *   HARD: parallel (broad phase + exact IoU + fixed point, see box.hip).  LINEAR / GAUSSIAN (soft-NMS, nms.cpp:60-94)
+ *   boxes[n,5], scores[n] in `dtype`; order[n] i64 = descending argsort of scores (nms.cpp:103), or NULL: the library
+ *   sorts the scores itself, as nms2d does (d3d_argsort_desc's order; inside the first kernel for up to 4096 boxes);
+ *   suppressed[n] u8 (0/1) output.
+ *   HARD: parallel (broad phase + exact IoU + fixed point, see box.hip); sets of up to 4096 boxes (a detector's top-k) take
+ *   a five-launch path of their own unless a flag below names a general one.  LINEAR / GAUSSIAN (soft-NMS, nms.cpp:60-94)
  *   are sequential by construction -- every kept box rescales the later boxes it overlaps and the order is re-established
  *   after each -- and run in one workgroup that follows the reference's control flow (n <= 65536, else UNSUPPORTED).
  *   Other IoU types return D3D_ERR_UNSUPPORTED ("Unsupported iou type!", reference common.h:25).
  *   flags (per call, 0 = automatic): D3D_NMS_BROAD_SWEEP = sweep-and-prune broad phase instead of the uniform grid;
  *   D3D_NMS_FORCE_DENSE = the reference's all-pairs bit matrix (nms_cuda.cu layout) instead of candidate lists;
  *   D3D_NMS_SOFT_NO_LDS = soft-NMS state in global scratch; D3D_NMS_CAND_CAP(k) = use only k entries of the candidate
- *   list (tests of the overflow -> dense hand-over).  All give the same mask. */
-enum { D3D_NMS_BROAD_SWEEP = 1, D3D_NMS_FORCE_DENSE = 2, D3D_NMS_SOFT_NO_LDS = 4 };
+ *   list (tests of the overflow -> dense hand-over); D3D_NMS_GENERAL = the general path (uniform grid) also for sets of up to
+ *   4096 boxes.  All give the same mask. */
+enum { D3D_NMS_BROAD_SWEEP = 1, D3D_NMS_FORCE_DENSE = 2, D3D_NMS_SOFT_NO_LDS = 4, D3D_NMS_GENERAL = 8 };
 #define D3D_NMS_CAND_CAP(k) ((uint32_t)(k) << 8)
 int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n,
               int32_t iou_type, int32_t suppression_type, int32_t dtype,

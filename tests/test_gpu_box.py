@@ -11,16 +11,17 @@ pytestmark = pytest.mark.gpu
 
 
 def pytest_generate_tests(metafunc):
-    # every NMS test runs with both broad phases: the uniform grid (default) and the sweep along x
+    # every NMS test runs three ways: as the operator picks (sets of up to 4096 boxes take the small-set path), and on the
+    # general path with either broad phase: the uniform grid and the sweep along x
     if "nms" in metafunc.function.__name__ and "nms_broad" in metafunc.fixturenames:
-        metafunc.parametrize("nms_broad", ["grid", "sweep"], indirect=True)
+        metafunc.parametrize("nms_broad", ["auto", "grid", "sweep"], indirect=True)
 
 
 @pytest.fixture(autouse=True)
 def nms_broad(request, monkeypatch):
     from d3d_amd import _lib, box
-    mode = getattr(request, "param", "grid")
-    monkeypatch.setattr(box, "default_nms_flags", _lib.NMS_BROAD_SWEEP if mode == "sweep" else 0)
+    mode = getattr(request, "param", "auto")
+    monkeypatch.setattr(box, "default_nms_flags", {"auto": 0, "grid": _lib.NMS_GENERAL, "sweep": _lib.NMS_BROAD_SWEEP}[mode])
     yield mode
 
 
@@ -588,3 +589,67 @@ def test_argsort_desc_bucket_path(n, dtype):
             rc = lib.d3d_internal_argsort_desc_library(t.data_ptr(), n, code, order.data_ptr(), ws.data_ptr(), ws.numel(), None)
             torch.cuda.synchronize()
             assert rc == 0 and np.array_equal(order.cpu().numpy(), exp), name
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097])
+def test_nms_small_set_path_sizes(n):
+    """the small-set path (<= 4096 boxes: scores sorted inside the first kernel, all-pairs candidates, one-workgroup fixed point
+    up to 1024 boxes) at its size boundaries, fp64 and fp32 scores with ties, clustered and scattered boxes: bit-exact with the
+    oracle and with the general path"""
+    from d3d_amd import _lib
+    from d3d_amd.box import box2d_nms, nms2d, IouType
+    rng = np.random.default_rng(n)
+    nobj = max(n // 40, 1)
+    c = np.stack([rng.random(nobj) * 300, rng.random(nobj) * 300, rng.random(nobj) * 20 + 10, rng.random(nobj) * 20 + 10,
+                  rng.random(nobj) * 6.28], 1)
+    b = c[rng.integers(0, nobj, n)] + rng.normal(0, 1, (n, 5)) * [2.0, 2.0, 1.5, 1.5, 0.08]
+    s = np.round(rng.random(n) * 200) / 200                       # ties
+    for method, thr, sthr in (("rbox", 0.5, 0.0), ("rbox", 0.2, 0.3), ("box", 0.4, 0.1)):
+        exp = oracle.box2d_nms(b, s, iou_method=method, iou_threshold=thr, score_threshold=sthr)
+        keep = box2d_nms(T(b), T(s), iou_method=method, iou_threshold=thr, score_threshold=sthr).cpu().numpy()
+        assert np.array_equal(keep, exp), (method, thr, int(np.sum(keep != exp)))
+        sup = nms2d(T(b), T(s), IouType[method.upper()], 0, thr, sthr, 0.0, flags=_lib.NMS_GENERAL).cpu().numpy()
+        assert np.array_equal(~sup, exp), ("general", method)
+    b32, s32 = b.astype(np.float32), s.astype(np.float32)
+    k32 = box2d_nms(T(b32), T(s32), iou_method="rbox", iou_threshold=0.5, precise=False).cpu().numpy()
+    g32 = nms2d(T(b32), T(s32), IouType.RBOX, 0, 0.5, 0.0, 0.0, flags=_lib.NMS_GENERAL).cpu().numpy()
+    assert np.array_equal(k32, ~g32)                              # same fp32 arithmetic on both paths
+
+
+def test_nms_c_abi_order_optional():
+    """d3d_nms2d with order = NULL sorts the scores itself (any size, hard and soft); with the caller's order it follows it --
+    a different valid order of tied scores gives the mask of THAT order (nms.cpp:103 leaves ties to the sort)"""
+    import ctypes
+    from d3d_amd import _lib
+    lib = _lib.load()
+    for n in (700, 6000):
+        b, s = bc.random_boxes_like_reference(n, n)
+        b, s = b.astype(np.float64), np.round(s.astype(np.float64) * 20) / 20
+        bt, st = T(b), T(s)
+        ws = torch.empty(lib.d3d_nms2d_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+        for sup_type, param in ((0, 0.0), (1, 0.5)):
+            out = {}
+            for name, order in (("internal", None), ("given", T(np.argsort(-s, kind="stable").astype(np.int64)))):
+                sup = torch.empty(n, dtype=torch.uint8, device="cuda")
+                rc = lib.d3d_nms2d(bt.data_ptr(), st.data_ptr(), order.data_ptr() if order is not None else None, n, 2, sup_type, 1,
+                                   0.3, 0.1, float(param), sup.data_ptr(), ws.data_ptr(),
+                                   ws.numel(), None, 0)
+                torch.cuda.synchronize()
+                assert rc == 0
+                out[name] = sup.cpu().numpy()
+            assert np.array_equal(out["internal"], out["given"])
+        rev = np.lexsort((-np.arange(n), -s)).astype(np.int64)           # ties in DESCENDING index order: also a valid order
+        sup = torch.empty(n, dtype=torch.uint8, device="cuda")
+        rc = lib.d3d_nms2d(bt.data_ptr(), st.data_ptr(), T(rev).data_ptr(), n, 2, 0, 1, 0.3, 0.1,
+                           0.0, sup.data_ptr(), ws.data_ptr(), ws.numel(), None, 0)
+        torch.cuda.synchronize()
+        assert rc == 0
+        if n <= 1000:                                                      # the greedy loop of nms.cpp:23-59 over THAT order
+            iou = oracle.box2d_iou(b, b, "rbox")
+            supp = np.zeros(n, bool)
+            supp[rev[1:]] = ~(s[rev[1:]] > np.float32(0.1))
+            for a, i in enumerate(rev):
+                if not supp[i]:
+                    later = rev[a + 1:]
+                    supp[later[iou[i, later] > np.float32(0.3)]] = True
+            assert np.array_equal(sup.cpu().numpy().astype(bool), supp)

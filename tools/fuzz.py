@@ -36,6 +36,13 @@ for seed in range(first, first + count):
     exp = oracle.box2d_nms(b, s, **kw)
     if not np.array_equal(keep, exp):
         bad += 1; print("NMS seed", seed, kw, n, "FAILED", int(np.sum(keep != exp)))
+    if sup == "hard":        # sets this small take the small-set path above; the general one (uniform grid) on the same input
+        from d3d_amd import _lib
+        from d3d_amd.box import nms2d, IouType
+        gsup = nms2d(torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), IouType[method.upper()], 0, thr, sthr, 0.0,
+                     flags=_lib.NMS_GENERAL).cpu().numpy()
+        if not np.array_equal(~gsup, exp):
+            bad += 1; print("NMS-GENERAL seed", seed, kw, n, "FAILED", int(np.sum(~gsup != exp)))
     if seed % 10 == 0:        # a large set now and then: the bucket argsort (>= 8 k keys), long incoming lists, the grid's cell scan
         nl = int(rng.integers(9000, 60000))
         side = float(rng.choice([300.0, 1500.0, 6000.0]))
