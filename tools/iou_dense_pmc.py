@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """the clip-bound IoU case (the reference's benchmark boxes: 28 % of the pairs overlap, 5 k x 5 k, fp64) a few times, for a
 rocprofv3 --pmc pass over k_iou_clip (VALU activity; development aid):
   rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d out -- python3 tools/iou_dense_pmc.py"""
