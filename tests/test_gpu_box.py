@@ -485,11 +485,14 @@ def test_c_abi_error_codes():
     torch.cuda.synchronize()
 
 
-def test_nms_is_graph_capturable():
-    """no host synchronisation, no allocation inside the library: box2d_nms records into a HIP graph and replays"""
+@pytest.mark.parametrize("n", [20000, 3000, 800])
+def test_nms_is_graph_capturable(n):
+    """no host synchronisation, no allocation inside the library: box2d_nms records into a HIP graph and replays -- the general
+    path and the small-set path (3000 fp64 boxes: more than 64 KB of LDS for the sort inside its first kernel)"""
     from d3d_amd import synth
     from d3d_amd.box import box2d_nms
-    b, s = synth.boxes2d_sparse(20000, 3)
+    b, s = synth.boxes2d_sparse(n, 3)
+    b[:, :2] *= (n / 100000.0) ** 0.5                     # same density at every size
     bt, st = T(b), T(s)
     ref = box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.4)
     side = torch.cuda.Stream()
