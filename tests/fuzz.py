@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """seeded fuzzing of the HIP path against the CPU oracle beyond the seeds of the test-suite (development aid):
-python tools/fuzz.py [first_seed] [count]"""
+python tests/fuzz.py [first_seed] [count]   (it checks against oracle/, so it lives with the tests)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
