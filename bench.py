@@ -238,6 +238,13 @@ def extras(args):
     dt = timed(all_pairs, 2, 1)
     ex["iou2d_rbox_fp64_mpairs_per_s"] = round(n3 * n3 * 2 / dt / 1e6, 1)
     ex["iou2d_rbox_fp64_GBps_written"] = round(n3 * n3 * 8 * 2 / dt / 1e9, 1)
+    if rows >= n3:      # roofline of ITS dominant kernel (8 B per pair, write-bound), HIP events on the launch stream
+        kp = kernel_profile(all_pairs, 2).get("k_iou_pre")
+        if kp:
+            ach = n3 * n3 * 8 / (kp["avg_us"] * 1e-6) / 1e9
+            ex["iou2d_rbox_fp64_roofline"] = dict(bound="hbm", kernel="k_iou_pre", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                                  frac=round(ach / HBM_PEAK_GBS, 4), avg_us=round(kp["avg_us"], 1),
+                                                  algorithmic_bytes=n3 * n3 * 8)
     torch.cuda.empty_cache()
     bd, _ = synth.boxes2d_dense(5000, 1)      # the reference's own benchmark distribution (ALU-bound case)
     bdt = torch.from_numpy(bd).cuda()
