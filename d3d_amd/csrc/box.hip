@@ -277,6 +277,24 @@ __global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__
     }
 }
 
+// Small matrices (a frame's detections against its ground truth: up to kIouSmallPairs pairs): ONE launch, one pair per lane,
+// the geometry of both boxes rebuilt per pair (two sincos: nothing at these sizes) instead of geometry x 2 + fill + clip +
+// fallback = five launches of ~5 us each.  Same candidate test (conservative fp32 AABBs, empty for degenerate boxes) and the
+// same per-pair function as the two-phase path: identical values.
+constexpr unsigned long long kIouSmallPairs = 1ull << 16;
+template <typename T, bool ROTATED>
+__global__ __launch_bounds__(256) void k_iou_small(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
+                                                   T *__restrict__ ious)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * m) return;
+    const int64_t i = idx / m, j = idx - i * m;
+    const BoxGeom<T> a = Box2D<T>::load(b1 + i * 5), b = Box2D<T>::load(b2 + j * 5);
+    T v = 0;
+    if (aabb_gap(cand_aabb(a, ROTATED), cand_aabb(b, ROTATED)) > 0.f) v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
+    ious[idx] = v;
+}
+
 // ---------------------------------------------------------------- pairwise "3D IoU" (BEV x z), fp32
 // box = (x, y, z, lx, ly, lz, rz); dgal_wrap.h:45-91
 // clip_dims: the matcher's guard against "really weird boxes with unusual size" (matcher.pyx:49-51: np.clip(dims, -1e3, 1e3))
@@ -333,6 +351,27 @@ __global__ __launch_bounds__(kTileCols) void k_iou3d(const float *__restrict__ b
         store_row<float, K>(out, v);
         out += m;
     }
+}
+
+// the same for the pairwise 3D IoU / the matcher's distance (see k_iou_small)
+template <bool ROTATED>
+__global__ __launch_bounds__(256) void k_iou3d_small(const float *__restrict__ b1, int64_t n, const float *__restrict__ b2, int64_t m,
+                                                     float *__restrict__ out, int stride, bool complement)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * m) return;
+    const int64_t i = idx / m, j = idx - i * m;
+    const Box3DGeom a = load3d(b1 + i * stride, complement), b = load3d(b2 + j * stride, complement);
+    float v = 0.f;
+    if (aabb_gap(cand_aabb(a.g, ROTATED), cand_aabb(b.g, ROTATED)) > 0.f) {
+        const float iou2d = ROTATED ? iou_rbox(a.g, b.g) : iou_aabb(a.g, b.g);
+        if (iou2d != 0.f) {
+            const float imax = fminf(a.zmax, b.zmax), imin = fmaxf(a.zmin, b.zmin);
+            const float umax = fmaxf(a.zmax, b.zmax), umin = fminf(a.zmin, b.zmin);
+            v = iou2d * (fmaxf(imax - imin, 0.f) / fmaxf(umax - umin, (float)1e-6));
+        }
+    }
+    out[idx] = complement ? 1 - v : v;
 }
 
 // ---------------------------------------------------------------- IoU backward (loss path, "next" row 2)
@@ -1777,6 +1816,17 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     const int64_t gy = d3d_divup(n, kTileRows);
     if (gy > 65535 || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;   // callers tile above that
     const bool rot = iou_type == D3D_IOU_RBOX;
+    if ((unsigned long long)n * (unsigned long long)m <= kIouSmallPairs && (flags >> 8) == 0) {      // (a list-cap flag asks for the list path)
+        const dim3 sgrid((unsigned)d3d_divup(n * m, 256));
+        if (dtype == D3D_F64) {
+            if (rot) D3D_LAUNCH("k_iou_small", (k_iou_small<double, true>), sgrid, dim3(256), 0, st, (const double *)boxes1, n, (const double *)boxes2, m, (double *)ious);
+            else D3D_LAUNCH("k_iou_small", (k_iou_small<double, false>), sgrid, dim3(256), 0, st, (const double *)boxes1, n, (const double *)boxes2, m, (double *)ious);
+        } else {
+            if (rot) D3D_LAUNCH("k_iou_small", (k_iou_small<float, true>), sgrid, dim3(256), 0, st, (const float *)boxes1, n, (const float *)boxes2, m, (float *)ious);
+            else D3D_LAUNCH("k_iou_small", (k_iou_small<float, false>), sgrid, dim3(256), 0, st, (const float *)boxes1, n, (const float *)boxes2, m, (float *)ious);
+        }
+        return D3D_OK;
+    }
     if (workspace && workspace_bytes >= d3d_iou2d_workspace_bytes(n, m, dtype)) {
         // zero fill + candidate list + one candidate per lane (BOX too: its IoU is non-zero only where the AABBs overlap)
 #define D3D_TWO_PHASE(T, R) iou2d_two_phase<T, R>((const T *)boxes1, n, (const T *)boxes2, m, (T *)ious, workspace, workspace_bytes, st, flags)
@@ -1817,6 +1867,12 @@ static int iou3d_impl(const float *boxes1, int64_t n, const float *boxes2, int64
     if (n == 0 || m == 0) return D3D_OK;
     if (!boxes1 || !boxes2 || !out) return D3D_ERR_BAD_ARG;
     if (d3d_divup(n, kTileRows) > 65535 || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;
+    if ((unsigned long long)n * (unsigned long long)m <= kIouSmallPairs) {
+        const dim3 sgrid((unsigned)d3d_divup(n * m, 256));
+        if (rotated) D3D_LAUNCH("k_iou3d_small", k_iou3d_small<true>, sgrid, dim3(256), 0, st, boxes1, n, boxes2, m, out, stride, complement);
+        else D3D_LAUNCH("k_iou3d_small", k_iou3d_small<false>, sgrid, dim3(256), 0, st, boxes1, n, boxes2, m, out, stride, complement);
+        return D3D_OK;
+    }
     const unsigned gy = (unsigned)d3d_divup(n, kTileRows);
     const bool al16 = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     const bool vec = al16 && (m % 4 == 0);

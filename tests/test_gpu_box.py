@@ -656,3 +656,34 @@ def test_nms_c_abi_order_optional():
                     later = rev[a + 1:]
                     supp[later[iou[i, later] > np.float32(0.3)]] = True
             assert np.array_equal(sup.cpu().numpy().astype(bool), supp)
+
+
+def test_small_matrix_kernels_equal_the_two_phase_path():
+    """matrices of up to 65536 pairs take a one-launch kernel (one pair per lane); larger ones geometry + fill + candidate list
+    + clip.  Same candidates, same per-pair function: a 100 x 300 block computed on its own equals the first 100 rows of the
+    300 x 300 matrix bit for bit -- IoU (rbox / box, fp64 / fp32), iou3d (rbox / box) and the matcher's distance; degenerate
+    boxes and identical boxes included"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_iou, iou3d
+    from d3d_amd.tracking import DistanceTypes, prepare_boxes
+    b, _ = synth.boxes2d_dense(300, 9)
+    b[5, 2] = 0.0                                        # degenerate
+    b[7] = b[6]                                          # identical
+    for method in ("rbox", "box"):
+        for dt in (np.float64, np.float32):
+            x = T(b.astype(dt))
+            big = box2d_iou(x, x, method=method, precise=dt == np.float64).cpu().numpy()
+            small = box2d_iou(x[:100], x, method=method, precise=dt == np.float64).cpu().numpy()
+            assert np.array_equal(big[:100], small), (method, dt)
+            assert np.max(np.abs(big - oracle.box2d_iou(b.astype(dt).astype(np.float64), b.astype(dt).astype(np.float64), method))) < (1e-9 if dt == np.float64 else 2e-3)
+    p, g = synth.boxes3d_eval(75, 4, 5)                  # 300 predictions around 75 ground truths
+    p[3, 3] = 0.0
+    for method in ("rbox", "box"):
+        big = iou3d(T(p), T(p), method=method).cpu().numpy()
+        small = iou3d(T(p[:100]), T(p), method=method).cpu().numpy()
+        assert np.array_equal(big[:100], small), method
+    d9 = np.concatenate([np.ones((300, 1)), np.linspace(1, 0, 300)[:, None], p], 1).astype(np.float32)
+    for metric in (DistanceTypes.RIoU, DistanceTypes.IoU):
+        big = prepare_boxes(d9, d9, metric).cpu().numpy()
+        small = prepare_boxes(d9[:100], d9, metric).cpu().numpy()
+        assert np.array_equal(big[:100], small), metric
