@@ -272,6 +272,7 @@ int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream);
  * iou_cuda.cu:10-48,100-151,216-440).  boxes1[n,5], boxes2[m,5] = (x,y,w,h,r) in `dtype`;
  * ious[n,m] in `dtype`, row-major.  64-bit pair indexing (cf. iou_cuda.cu:36,137).  The workspace is optional
  * (NULL/0 selects the single-kernel path); with it RBOX runs as zero-fill + candidate list + dense clipping.
+ * Matrices of up to 65536 pairs (BOX / RBOX) take one launch with one pair per lane, with or without a workspace.
  * GIoU = IoU - (H - U) / H, H = area of the convex hull of the two rectangles, U = union area; DIoU = IoU - d^2 / D^2,
  * d = distance of the centres, D = diameter of that hull (dgal's source is not vendored: the published definitions);
  * a rectangle of non-positive area gives 0 for every type.  GBOX / DBOX are D3D_ERR_UNSUPPORTED (the reference's Python
