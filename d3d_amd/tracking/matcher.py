@@ -56,20 +56,27 @@ def score_match(distance, src_scores, src_tags, dst_tags, distance_threshold):
     lib = _lib.load()
     dev = distance.device
     n, m = distance.shape
-    st = torch.as_tensor(np.asarray(src_tags), dtype=torch.int32).clone()
-    dt = torch.as_tensor(np.asarray(dst_tags), dtype=torch.int32).clone()
-    thr = torch.full((m,), float("nan"), dtype=torch.float32)
-    known = torch.zeros((max(int(st.max()) if n else 0, int(dt.max()) if m else 0, 0) + 2,), dtype=torch.bool)
+    def host(a):                       # tags / scores: numpy arrays, lists, or tensors on any device
+        return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    # host-side preparation in numpy (a frame has a few hundred boxes: tensor ops would each cost more than the arithmetic),
+    # shipped to the device as ONE buffer: [order i64 | src tags i32 | dst tags i32 | dst thresholds f32]
+    st = host(src_tags).astype(np.int32, copy=True).reshape(-1)
+    dt = host(dst_tags).astype(np.int32, copy=True).reshape(-1)
+    thr = np.full((m,), np.nan, np.float32)
+    known = np.zeros((max(int(st.max()) if n else 0, int(dt.max()) if m else 0, 0) + 2,), bool)
     for tag, v in distance_threshold.items():
-        if 0 <= int(tag) < known.numel():
+        if 0 <= int(tag) < known.size:
             known[int(tag)] = True
         thr[dt == int(tag)] = float(v)
-    st[(st < 0) | ~known[st.clamp(min=0).long()]] = -1
-    dt[(dt < 0) | ~known[dt.clamp(min=0).long()]] = -1
-    scores = torch.as_tensor(np.asarray(src_scores), dtype=torch.float32)
-    order = torch.argsort(scores, descending=True, stable=True)
+    st[(st < 0) | ~known[np.clip(st, 0, None)]] = -1
+    dt[(dt < 0) | ~known[np.clip(dt, 0, None)]] = -1
+    order = np.argsort(-host(src_scores).astype(np.float32).reshape(-1), kind="stable").astype(np.int64)
+    packed = torch.from_numpy(np.concatenate([order.view(np.uint8), st.view(np.uint8), dt.view(np.uint8), thr.view(np.uint8)]))
     with torch.cuda.device(dev):
-        st, dt, thr, order = st.to(dev), dt.to(dev), thr.to(dev), order.to(dev)
+        packed = packed.to(dev)
+        order = packed[:8 * n].view(torch.int64)
+        st, dt = packed[8 * n:12 * n].view(torch.int32), packed[12 * n:12 * n + 4 * m].view(torch.int32)
+        thr = packed[12 * n + 4 * m:].view(torch.float32)
         src_match = torch.empty((n,), dtype=torch.int32, device=dev)
         dst_match = torch.empty((m,), dtype=torch.int32, device=dev)
         status = torch.zeros((1,), dtype=torch.int32, device=dev)

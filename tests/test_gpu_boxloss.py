@@ -209,6 +209,9 @@ def test_score_match_and_calc_stats_vs_oracle():
     sm, dm = score_match(cache, dt9[:, 1], dt9[:, 0], gt9[:, 0], thr)
     esm, edm = oracle.score_match_rows(cache.cpu().numpy(), dt9, gt9, thr)
     assert np.array_equal(sm.cpu().numpy(), esm) and np.array_equal(dm.cpu().numpy(), edm) and (esm >= 0).sum() > 50
+    d9 = torch.from_numpy(dt9).cuda()                            # tags / scores as device tensors: the same association
+    sm2, dm2 = score_match(cache, d9[:, 1], d9[:, 0], torch.from_numpy(gt9[:, 0]), thr)
+    assert torch.equal(sm2, sm) and torch.equal(dm2, dm)
     # the matcher object on subsets (the call sequence of benchmarks.pyx:188-238)
     mt = ScoreMatcher()
     mt.prepare_boxes(dt9, gt9, DistanceTypes.RIoU)
