@@ -453,6 +453,18 @@ class PDist2DR(torch.autograd.Function):
         return grad_points, grad_boxes
 
 
+def seg1d_iou(seg1, seg2):
+    """IoU of 1-D segments, row by row: seg1, seg2 [N,2] = (centre, width) -> [N] -- reference box/__init__.py:152-178 (plain
+    tensor arithmetic there too; its half-width of seg2 is taken from seg1, :164, a slip: seg2's own width is used here)"""
+    assert torch.all(seg1[:, 1] > 0)
+    assert torch.all(seg2[:, 1] > 0)
+    d1, d2 = seg1[:, 1] / 2, seg2[:, 1] / 2
+    s1max, s1min, s2max, s2min = seg1[:, 0] + d1, seg1[:, 0] - d1, seg2[:, 0] + d2, seg2[:, 0] - d2
+    i = torch.clamp_min(torch.minimum(s1max, s2max) - torch.maximum(s1min, s2min), 0)
+    u = torch.clamp_min(torch.maximum(s1max, s2max) - torch.minimum(s1min, s2min), 1e-6)
+    return i / u
+
+
 def seg1d_pdist(points, segs):
     """distance from points [N,1] to 1-D segments [M,2] = (centre, width) -- reference box/__init__.py:317-331
     (positive inside; broadcasts to the [N,M] / [M] shapes the reference's callers use)"""
@@ -499,6 +511,6 @@ nms = box2d_nms
 
 __all__ = ["Iou2D", "Iou2DR", "GIou2DR", "DIou2DR", "PDist2DR", "iou2d_backward", "iou2dr_backward", "giou2dr_forward",
            "giou2dr_backward", "diou2dr_forward", "diou2dr_backward", "iou2dr_flags", "pdist2dr_forward", "pdist2dr_backward",
-           "box2dr_crop", "box3dp_crop", "box2dr_pdist", "box3dr_pdist", "seg1d_pdist", "crop_2dr", "box2d_iou", "box2d_nms",
+           "box2dr_crop", "box3dp_crop", "box2dr_pdist", "box3dr_pdist", "seg1d_pdist", "seg1d_iou", "crop_2dr", "box2d_iou", "box2d_nms",
            "iou2d", "iou3d", "nms", "iou2d_forward", "iou2dr_forward", "nms2d", "nms2d_cuda", "argsort_desc", "IouType",
            "SupressionType", "cuda_available"]

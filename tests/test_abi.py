@@ -84,3 +84,14 @@ def test_evaluator_and_matcher_host_logic_without_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="HIP device"):
             prepare_boxes(np.zeros((3, 9), np.float32), np.zeros((3, 9), np.float32), DistanceTypes.IoU)
+
+
+def test_segment_helpers_are_plain_tensor_arithmetic():
+    """seg1d_iou / seg1d_pdist (reference box/__init__.py:152-178, 317-331): no kernel behind them, they run on CPU tensors"""
+    import torch
+    from d3d_amd.box import seg1d_iou, seg1d_pdist
+    a = torch.tensor([[0.0, 2.0], [0.0, 2.0], [5.0, 1.0], [0.0, 4.0]])
+    b = torch.tensor([[1.0, 2.0], [3.0, 2.0], [5.0, 1.0], [0.0, 2.0]])
+    assert torch.allclose(seg1d_iou(a, b), torch.tensor([1.0 / 3.0, 0.0, 1.0, 0.5]))
+    d = seg1d_pdist(torch.tensor([[0.5], [3.0]]), torch.tensor([[0.0, 2.0]]))
+    assert torch.allclose(d, torch.tensor([[0.5], [-2.0]]))
