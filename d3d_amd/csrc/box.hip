@@ -577,7 +577,7 @@ constexpr int kGridFoldMax = 512;      // most k_nms_prepare partials that k_nms
 template <typename T>
 __global__ __launch_bounds__(256) void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__ scores,
                               const int64_t *__restrict__ order, int64_t n, float score_threshold,
-                              BoxGeom<T> *geom, float4 *fbox, uint8_t *state, uint32_t *inc_cnt, float *farea,
+                              BoxCore<T> *geom, float4 *fbox, uint8_t *state, uint32_t *inc_cnt, float *farea,
                               unsigned long long *remv, int64_t nb, NmsFlags *flags, NmsCand *cand_hdr,
                               unsigned int force_dense, int32_t *xkey, unsigned int *grid_ticket, unsigned long long *tile_tot,
                               float *gpartial, uint32_t *cellcnt, unsigned long long *chunk_tot)
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void k_nms_prepare(const T *__restrict__ boxes
     if (p < n) {
         const int64_t i = order[p];
         const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
-        geom[p] = g;
+        geom[p] = core_of(g);
         const float4 f = make_float4(round_down(g.xmin), round_down(g.ymin), round_up(g.xmax), round_up(g.ymax));
         fbox[p] = f;
         if (grid_valid(f)) { ext[0] = f.x; ext[1] = f.y; ext[2] = f.z; ext[3] = f.w; ext[4] = 0.5f * ((f.z - f.x) + (f.w - f.y)); ext[5] = 1.f; }
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256) void k_nms_cand_grid(const float4 *__restrict_
 // overlapping detections stay on this path.
 constexpr unsigned long long kHitBit = 1ull << 63;
 template <typename T, bool ROTATED>
-__global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__ geom,
+__global__ __launch_bounds__(256) void k_nms_hits(const BoxCore<T> *__restrict__ geom,
                                                   const uint32_t *__restrict__ rankx,
                                                   unsigned long long *__restrict__ list, unsigned long long cap,
                                                   const NmsCand *hdr, T thr, uint32_t *inc_cnt, uint32_t *__restrict__ arrival)
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxGeom<T> *__restrict__
         // list entry -> score ranks (through the broad phase's own numbering; the small-set path lists ranks directly)
         const uint32_t r1 = rankx ? rankx[e >> 32] : (uint32_t)(e >> 32), r2 = rankx ? rankx[e & 0xffffffffull] : (uint32_t)e;
         const uint32_t p = r1 < r2 ? r1 : r2, q = r1 < r2 ? r2 : r1;
-        const BoxGeom<T> a = geom[p], b = geom[q];
+        const BoxGeom<T> a = expand(geom[p]), b = expand(geom[q]);       // one sector per box
         bool hit = false;
         // the intersection is at most the overlap of the AABBs and at most either area: when even that bound gives
         // IoU <= thr (with a margin far above the rounding of either side) the clip is not needed
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_nms_fill(const unsigned long long *__re
 // block = 4 wavefronts = 4 row blocks, swept against kColsPerBlock consecutive column blocks: the same conservative
 // AABB sweep, with the exact test inlined on the survivors and the hits written to the dense bit matrix
 template <typename T, bool ROTATED>
-__global__ __launch_bounds__(256) void k_nms_pairs(const BoxGeom<T> *__restrict__ geom, const float4 *__restrict__ fbox,
+__global__ __launch_bounds__(256) void k_nms_pairs(const BoxCore<T> *__restrict__ geom, const float4 *__restrict__ fbox,
                                                    int64_t n, int64_t nb, T thr, unsigned long long *__restrict__ mask,
                                                    const NmsFlags *flags)
 {
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const BoxGeom<T> *__restrict_
         while (cand) {
             const int c = __builtin_ctzll(cand);
             cand &= cand - 1;
-            const BoxGeom<T> a = geom[p], b = geom[q0 + c];
+            const BoxGeom<T> a = expand(geom[p]), b = expand(geom[q0 + c]);
             T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
             if (v > thr) bits |= 1ull << c;                // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
         }
@@ -1198,7 +1198,7 @@ constexpr int kNmsSmallResolveMax = 1024;     // one box per lane of k_nms_resol
 template <typename T>
 __global__ __launch_bounds__(1024) void k_nms_small_front(const T *__restrict__ boxes, const T *__restrict__ scores,
                                                           const int64_t *__restrict__ order_in, uint32_t n, float score_threshold,
-                                                          int64_t *order_out, BoxGeom<T> *geom, float4 *fbox, float *farea,
+                                                          int64_t *order_out, BoxCore<T> *geom, float4 *fbox, float *farea,
                                                           uint8_t *state, uint32_t *inc_cnt, NmsFlags *flags, NmsCand *cand_hdr,
                                                           unsigned long long *remv)
 {
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(1024) void k_nms_small_front(const T *__restrict__ 
             const int64_t i = order_in ? order_in[p] : (int64_t)ii[p];
             if (!order_in) order_out[p] = i;
             const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
-            geom[p] = g;
+            geom[p] = core_of(g);
             fbox[p] = make_float4(round_down(g.xmin), round_down(g.ymin), round_up(g.xmax), round_up(g.ymax));
             farea[p] = round_down(g.area);
             // nms.cpp:23-29: the tail with score <= threshold is suppressed up front, never position 0
@@ -1425,7 +1425,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
 {
     const int64_t nb = d3d_divup(n, 64);
     WsCarver w(ws, ws_bytes);
-    BoxGeom<T> *geom = w.take<BoxGeom<T>>(nb * 64);
+    BoxCore<T> *geom = w.take<BoxCore<T>>(nb * 64);
     float4 *fbox = w.take<float4>(nb * 64);
     uint8_t *state = w.take<uint8_t>(nb * 64);
     uint32_t *inc_cnt = w.take<uint32_t>(nb * 64);

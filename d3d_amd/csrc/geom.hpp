@@ -48,6 +48,27 @@ __device__ __forceinline__ BoxGeom<T> make_geom(T x, T y, T w, T h, T r)
     return g;
 }
 
+// The six numbers everything else of a BoxGeom follows from, padded to one 64-byte (fp64) / 32-byte (fp32) sector: what the
+// NMS narrow phase gathers per box (an 88-byte BoxGeom<double> straddles two sectors).  expand() repeats make_geom's own
+// arithmetic on the stored centre / half-extent vectors, so the result is bit-identical to the BoxGeom they came from.
+template <typename T> struct __attribute__((aligned(8 * sizeof(T)))) BoxCore { T cx, cy, ux, uy, vx, vy, pad0, pad1; };
+template <typename T> __device__ __forceinline__ BoxCore<T> core_of(const BoxGeom<T> &g)
+{
+    return BoxCore<T>{g.cx, g.cy, g.ux, g.uy, g.vx, g.vy, (T)0, (T)0};
+}
+template <typename T> __device__ __forceinline__ BoxGeom<T> expand(const BoxCore<T> &c)
+{
+    BoxGeom<T> g;
+    g.cx = c.cx; g.cy = c.cy; g.ux = c.ux; g.uy = c.uy; g.vx = c.vx; g.vy = c.vy;
+    const T x = c.cx, y = c.cy;
+    const T x0 = x - g.ux - g.vx, x1 = x + g.ux - g.vx, x2 = x + g.ux + g.vx, x3 = x - g.ux + g.vx;
+    const T y0 = y - g.uy - g.vy, y1 = y + g.uy - g.vy, y2 = y + g.uy + g.vy, y3 = y - g.uy + g.vy;
+    g.xmin = fmin(fmin(x0, x1), fmin(x2, x3)); g.xmax = fmax(fmax(x0, x1), fmax(x2, x3));
+    g.ymin = fmin(fmin(y0, y1), fmin(y2, y3)); g.ymax = fmax(fmax(y0, y1), fmax(y2, y3));
+    g.area = 4 * (g.ux * g.vy - g.uy * g.vx);
+    return g;
+}
+
 // IoU of the axis-aligned bounding boxes (method "box": dgal::iou(AABox2, AABox2))
 template <typename T>
 __device__ __forceinline__ T iou_aabb(const BoxGeom<T> &a, const BoxGeom<T> &b)
