@@ -132,7 +132,19 @@ for seed in range(first, first + count):
                         mm[i, k] -= h
                         f = ((ofn(pp, g2n) - ofn(mm, g2n)) * wgt).sum() if first_arg else ((ofn(g1n, pp) - ofn(g1n, mm)) * wgt).sum()
                         fd = f / (2 * h)
-                        worst = max(worst, abs(fd - g[i, k]) / max(1.0, abs(fd)))
-            if worst > 1e-4:        # (a kink of the piecewise function within h of the sample would show up here too)
+                        err = abs(fd - g[i, k]) / max(1.0, abs(fd))
+                        if err > 1e-4:
+                            # a kink of the piecewise function (a corner entering the hull, an edge crossing a corner) within h of
+                            # the sample: the one-sided derivatives differ there and the analytic value is one of them (about
+                            # one such sample per 1000 seeds: seed 50051, the angle of a box disjoint from its partner)
+                            base = (ofn(g1n, g2n) * wgt).sum()
+                            fp = ((ofn(pp, g2n) if first_arg else ofn(g1n, pp)) * wgt).sum()
+                            fm = ((ofn(mm, g2n) if first_arg else ofn(g1n, mm)) * wgt).sum()
+                            one_sided = min(abs((fp - base) / h - g[i, k]), abs((base - fm) / h - g[i, k])) / max(1.0, abs(fd))
+                            if one_sided < 1e-4:
+                                print("GRAD seed", seed, meth, "kink at the sample (one-sided derivative matches)", (i, k))
+                                err = 0.0
+                        worst = max(worst, err)
+            if worst > 1e-4:
                 bad += 1; print("GRAD seed", seed, meth, "FAILED", worst)
 print("fuzz: %d seeds, %d failures" % (count, bad))
