@@ -95,3 +95,30 @@ def test_segment_helpers_are_plain_tensor_arithmetic():
     assert torch.allclose(seg1d_iou(a, b), torch.tensor([1.0 / 3.0, 0.0, 1.0, 0.5]))
     d = seg1d_pdist(torch.tensor([[0.5], [3.0]]), torch.tensor([[0.0, 2.0]]))
     assert torch.allclose(d, torch.tensor([[0.5], [-2.0]]))
+
+
+def test_bucket_kernel_keeps_its_first_point_store_separate(tmp_path):
+    """with two plain conditional stores next to each other in k_bucket_index's record phase hipcc 7.2 once emitted
+    a MERGED store that wrote the record position at firstmap[record position] -- the other store's index.  The firstmap
+    store is an agent-scope atomic store since.  This pins the shape: in the gfx950 assembly every instantiation of the
+    kernel carries one `global_store_dword ... sc1` per record slot of a lane (kBucketSlots / kBucketThreads = 4) in each of
+    the two copies of the record phase (register buckets, big buckets) -- if a compiler bump folds them into something else,
+    look at the record phase again before trusting the big-bucket tests alone."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "d3d_amd", "csrc", "voxel.hip")
+    asm = str(tmp_path / "voxel.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           "-S", "--cuda-device-only", src, "-o", asm], stderr=subprocess.DEVNULL)
+    scoped, cur = {}, None
+    for line in open(asm):
+        m = re.match(r"^(_Z\S+):", line)
+        if m:
+            cur = m.group(1)
+        elif cur and "k_bucket_index" in cur and re.search(r"global_store_dword\b.*\bsc1\b", line):
+            scoped[cur] = scoped.get(cur, 0) + 1
+    assert len(scoped) == 5 and set(scoped.values()) == {8}, scoped
