@@ -487,14 +487,18 @@ static unsigned long long nms_cand_capacity(int64_t n)
 // tickets < t, whose holders are running (they took theirs first) and publish before they wait: always progress, wherever
 // and in whatever order the workgroups are placed.  Value and ready bit travel in one agent-scope 64-bit word.
 // Returns (in every thread) the sum of the totals of tickets 0 .. id - 1; both contain workgroup barriers.
+// The poll is bounded all the same (kChainSpins reads of one word, seconds): a predecessor that never publishes -- only a
+// defect elsewhere could cause that -- raises *gave_up (the callers pass NmsFlags::need_sweep: the dense path then recomputes
+// everything from the geometry) instead of hanging the GPU.
 __device__ __forceinline__ unsigned int scan_ticket(unsigned int *ticket, unsigned int *sid)
 {
     if (threadIdx.x == 0) *sid = atomicAdd(ticket, 1u);
     __syncthreads();
     return *sid;
 }
+constexpr unsigned int kChainSpins = 1u << 22;
 __device__ __forceinline__ unsigned long long chained_prefix(unsigned long long *tot, unsigned int id, unsigned long long total,
-                                                             unsigned long long *sbase)
+                                                             unsigned long long *sbase, unsigned int *gave_up)
 {
     const unsigned int lane = threadIdx.x & 63;
     if (threadIdx.x == 0)
@@ -505,7 +509,9 @@ __device__ __forceinline__ unsigned long long chained_prefix(unsigned long long 
             const unsigned int j = j0 + lane;
             if (j < id) {
                 unsigned long long t;
-                do { t = __hip_atomic_load(&tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(t & 1ull));
+                unsigned int spins = 0;
+                do { t = __hip_atomic_load(&tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(t & 1ull) && ++spins < kChainSpins);
+                if (!(t & 1ull)) { t = 0; *gave_up = 1; }
                 acc += t >> 1;
             }
         }
@@ -804,7 +810,7 @@ __global__ __launch_bounds__(1024) void k_nms_gridscan(uint32_t *cellcur, uint32
     const uint32_t x = c < cells ? cellcur[(size_t)c * kGridPad] : 0u;
     unsigned long long total;
     const unsigned long long ex = block_excl_scan_u64<1024>(x, &total, smem);
-    const unsigned long long before = chained_prefix(chunk_tot, (unsigned int)chunk, total, &sbase);
+    const unsigned long long before = chained_prefix(chunk_tot, (unsigned int)chunk, total, &sbase, &flags->need_sweep);
     if (c <= cells) { cellstart[c] = (uint32_t)(before + ex); cellcur[(size_t)c * kGridPad] = (uint32_t)(before + ex); }
     if (c == cells) {
         const unsigned long long tot = before + ex;
@@ -952,7 +958,7 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxCore<T> *__restrict__
 // inc_off = exclusive scan of inc_cnt in ONE launch (the generic count / block-sum / apply trio is three, ~4 us each in a
 // stream): a local scan per 1024-box tile + chained_prefix over the tiles (tile_tot[] is zeroed by k_nms_prepare)
 __global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict__ inc_cnt, int64_t n, uint32_t *__restrict__ inc_off,
-                                                     unsigned long long *tile_tot, unsigned int *ticket)
+                                                     unsigned long long *tile_tot, unsigned int *ticket, NmsFlags *flags)
 {
     __shared__ unsigned long long smem[4], sbase;
     __shared__ unsigned int sid;
@@ -973,7 +979,7 @@ __global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict_
     unsigned long long woff = 0, total = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { if (k < w) woff += smem[k]; total += smem[k]; }
-    const unsigned long long before = chained_prefix(tile_tot, tile, total, &sbase);
+    const unsigned long long before = chained_prefix(tile_tot, tile, total, &sbase, &flags->need_sweep);
     const unsigned long long off = before + woff;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1539,7 +1545,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
         D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, false>), dim3(hits_blocks), dim3(256), 0, st, geom, rankx, cand, cap, cand_hdr,
                    (T)iou_thr, inc_cnt, arrival);
     D3D_LAUNCH("k_nms_incscan", k_nms_incscan, dim3((unsigned)d3d_divup(n, kIncTile)), dim3(256), 0, st, (const uint32_t *)inc_cnt, n,
-               inc_off, tile_tot, tickets);
+               inc_off, tile_tot, tickets, flags);
     D3D_LAUNCH("k_nms_fill", k_nms_fill, dim3(hits_blocks), dim3(256), 0, st, (const unsigned long long *)cand, cap,
                (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, (const uint32_t *)arrival, inc);
     D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,
