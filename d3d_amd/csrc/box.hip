@@ -1378,7 +1378,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_small(uint32_t n, const ui
     // are written back compacted, so the list shrinks to what is still open.  A decision only uses final states, so reading a
     // neighbour's
     // state a pass late delays it and nothing else; the lowest undecided box can always be decided: at most n passes.
-    for (;;) {
+    for (uint32_t pass = 0; pass <= n; pass++) {               // (n passes always suffice; the bound only rules out a hang)
         int any = 0;
 #pragma unroll
         for (int u = 0; u < PER; u++) {
