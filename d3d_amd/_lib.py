@@ -19,7 +19,6 @@ STATUS_COORD_OVERFLOW, STATUS_TABLE_FULL, STATUS_PACK_OVERFLOW, STATUS_BIN_OVERF
 F32, F64 = 0, 1
 # per-call option bits (include/d3d_hip.h)
 VOXEL_PATH_HASH, VOXEL_PLAIN_SLOTS, VOXEL_SPLIT_FILL = 1, 4, 8
-VOXEL_STATE_WORDS = 4
 NMS_BROAD_SWEEP, NMS_FORCE_DENSE, NMS_SOFT_NO_LDS, NMS_GENERAL = 1, 2, 4, 8
 
 
@@ -43,8 +42,6 @@ SIGNATURES = {
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32]),
     "d3d_voxelize_3d_dense_notify": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _u32]),
-    "d3d_voxelize_3d_dense_stream": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
-                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _u32]),
     "d3d_voxelize_3d_sparse": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32]),
     "d3d_voxelize_3d_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1040,47 +1040,6 @@ constexpr int kBucketThreads = 512;           // ... 4 per lane (256: 42 us, 512
 constexpr int kBucketSlots = 2048;            // LDS table slots (>= distinct cells of a bucket, always)
 constexpr uint32_t kNoBin = 0xffffffffu;
 
-
-// ---- speculative pre-zeroing of voxels[V,P,4] (d3d_voxelize_3d_dense_stream) -------------------------------------------
-// 95 % of the dense output is zero rows, and the index kernels (partition, per-bucket LDS index, numbering: ~75 us at
-// config 2) are latency- / request-bound with the HBM write path mostly idle.  A caller that processes a STREAM of frames
-// hands a small device state from call to call; state[0] = the previous frame's voxel count.  This call zeroes the rows of
-// the first Vz = min(cap, state[0] * (1 + 1/32) + 64) voxels from extra ("filler") wavefronts inside the index launches --
-// they only issue nontemporal stores -- and the output kernel (k_emit) then writes just the occupied rows of the voxels
-// below Vz and whole voxels from Vz on.  The result never depends on the speculation: a wrong Vz costs time, not rows.
-struct PreZero {
-    int64_t *state;           // null: off.  [0] voxels of the previous call, [1] Vz of this call (set by k_bin_count)
-    float4 *voxels;
-    int64_t cap;              // voxels the output buffer holds
-    uint32_t P;
-    uint32_t a, b;            // this launch's share of the 1 KiB granules: [G a / 256, G b / 256)
-};
-
-__device__ __forceinline__ int64_t prezero_voxels(const int64_t *state, int64_t cap)
-{
-    int64_t v = state[0];
-    if (v <= 0) return 0;
-    v += (v >> 5) + 64;
-    return v < cap ? v : cap;
-}
-
-// filler wavefront `unit` of `units`: granules unit, unit + units, ... of this launch's share (all fillers of a launch
-// together write one compact moving window, the DRAM-friendly store order)
-__device__ __forceinline__ void prezero_run(const PreZero &z, uint32_t unit, uint32_t units)
-{
-    typedef float vec4 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t rows = prezero_voxels(z.state, z.cap) * (int64_t)z.P;
-    const int64_t G = (rows + kWave - 1) / kWave;
-    const int64_t g0 = (G * z.a) >> 8, g1 = (G * z.b) >> 8;
-    const vec4 zero = {0.f, 0.f, 0.f, 0.f};
-    vec4 *out = reinterpret_cast<vec4 *>(z.voxels);
-    for (int64_t g = g0 + unit; g < g1; g += units) {
-        const int64_t r = g * kWave + lane;
-        if (r < rows) __builtin_nontemporal_store(zero, &out[r]);
-    }
-}
-
 // reduce contract (d3d_voxelize_3d_reduce) on the binned path
 struct BinnedExtras {
     int64_t *first_out;       // [V] index_offset + first point index
@@ -1145,16 +1104,12 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
                                                            typename BinEntry<ROWS>::key_store_t *__restrict__ pkey,
                                                            uint32_t *__restrict__ tilecnt, uint32_t *__restrict__ firstmap,
                                                            int64_t *counts, int64_t *mapping, unsigned char *trimmed,
-                                                           int32_t *keepid, PreZero z)
+                                                           int32_t *keepid)
 {
     __shared__ uint32_t h[kBinMax];
-    if (blockIdx.x >= ntiles) {                 // filler workgroups (launched only with a pre-zero state)
-        prezero_run(z, (blockIdx.x - ntiles) * (kBinThreads / kWave) + (threadIdx.x >> 6), (gridDim.x - ntiles) * (kBinThreads / kWave));
-        return;
-    }
+    (void)ntiles;
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) h[b] = 0;
     if (blockIdx.x == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
-    if (z.state && blockIdx.x == 0 && threadIdx.x == 0) z.state[1] = prezero_voxels(z.state, z.cap);    // for k_emit
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kBinTile + threadIdx.x;
     float v[kBinTile / kBinThreads][3];
@@ -1195,15 +1150,10 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
 
 // tilecnt[tile][bucket] -> exclusive prefix over the tiles, per bucket; bucket totals.  A workgroup owns 64 consecutive
 // buckets (one per lane, coalesced rows), its 16 wavefronts split the tiles.
-__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t *tilecnt, uint32_t nbins, uint32_t ntiles, uint32_t *totals, PreZero z)
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t *tilecnt, uint32_t nbins, uint32_t ntiles, uint32_t *totals)
 {
     __shared__ uint32_t wsum[16][kWave];
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
-    const uint32_t nreal = (nbins + kWave - 1) / kWave;
-    if (blockIdx.x >= nreal) {                  // filler workgroups
-        prezero_run(z, (blockIdx.x - nreal) * 16 + w, (gridDim.x - nreal) * 16);
-        return;
-    }
     const uint32_t b = blockIdx.x * kWave + lane;
     const uint32_t per = (ntiles + 15) / 16, t0 = w * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
     uint32_t sum = 0;
@@ -1256,15 +1206,10 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
                                                              uint32_t nbins, const uint32_t *__restrict__ pbin,
                                                              const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ totals,
                                                              uint32_t *__restrict__ bucket_base,
-                                                             typename BinEntry<ROWS>::type *__restrict__ bent, int64_t *counts,
-                                                             uint32_t ntiles, PreZero z)
+                                                             typename BinEntry<ROWS>::type *__restrict__ bent, int64_t *counts)
 {
     __shared__ uint32_t off[kBinMax];
     __shared__ u64 smem[kBinThreads / kWave];
-    if (blockIdx.x >= ntiles) {                 // filler workgroups
-        prezero_run(z, (blockIdx.x - ntiles) * (kBinThreads / kWave) + (threadIdx.x >> 6), (gridDim.x - ntiles) * (kBinThreads / kWave));
-        return;
-    }
     bucket_bases(totals, nbins, off, smem);
     if (blockIdx.x == 0)                                     // for k_bucket_index
         for (uint32_t b = threadIdx.x; b <= nbins; b += kBinThreads) bucket_base[b] = b < nbins ? off[b] : off[nbins - 1] + totals[nbins - 1];
@@ -1326,8 +1271,11 @@ __device__ __forceinline__ u64 block_excl_scan_u64_lds(u64 v, u64 *total, u64 *s
     return woff + incl - v;
 }
 
-template <class Key, bool ROWS, bool LISTS>
-__global__ __launch_bounds__(kBucketThreads + kWave) void k_bucket_index(Key kf, VoxelPass vp, uint32_t *__restrict__ vidof,
+// STAGE (dense contract on C == 4 rows): the ranked rows themselves are gathered and staged next to their rank, for the
+// two-launch output stage.  ROWS && LISTS && !STAGE is the index for k_emit: no row moves here at all -- a voxel's first
+// row is points[first point], which k_emit reads coalesced, and ranks 1 .. P-1 leave their point INDEX in sorted_out.
+template <class Key, bool ROWS, bool LISTS, bool STAGE = ROWS>
+__global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPass vp, uint32_t *__restrict__ vidof,
                                                       const typename BinEntry<ROWS>::type *__restrict__ bent,
                                                       const float4 *__restrict__ points4 /* ROWS */,
                                                       const uint32_t *__restrict__ bucket_base,
@@ -1338,12 +1286,8 @@ __global__ __launch_bounds__(kBucketThreads + kWave) void k_bucket_index(Key kf,
                                                       uint32_t *__restrict__ pinfo, uint32_t *__restrict__ gseg /* big buckets */,
                                                       unsigned char *__restrict__ trimmed /* optional: [n] rank >= P */,
                                                       uint32_t *__restrict__ sorted_out /* optional: ranked indices (C != 4) */,
-                                                      uint32_t *__restrict__ unsorted_out /* ... and all of an overflow voxel's */,
-                                                      PreZero z)
+                                                      uint32_t *__restrict__ unsorted_out /* ... and all of an overflow voxel's */)
 {
-    // a ninth wavefront (launched only with a pre-zero state) does nothing but its share of the zero stores and ends: a
-    // terminated wavefront no longer takes part in the workgroup's barriers
-    if (threadIdx.x >= kBucketThreads) { prezero_run(z, blockIdx.x, gridDim.x); return; }
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
     typedef typename Key::bin_key_t KT;
     typedef BinEntry<ROWS> E;
@@ -1356,7 +1300,8 @@ __global__ __launch_bounds__(kBucketThreads + kWave) void k_bucket_index(Key kf,
     __shared__ uint32_t tcnt[T], tfirst[T];
     __shared__ uint32_t seg[kBucketCap];
     __shared__ u64 smem[kBucketThreads / kWave];
-    __shared__ uint16_t oslot[ROWS ? T / 2 : 1];    // overflow voxels of the bucket (count > P >= 1: at most m / 2 of them)
+    __shared__ uint16_t oslot[ROWS ? T : 1];        // overflow voxels of the bucket (one per slot at most: a big bucket can hold
+                                                    // T distinct cells with more than P points each)
     __shared__ uint32_t nover, fail;
     typedef float v4f __attribute__((ext_vector_type(4)));   // (an array of HIP float4 structs stayed in scratch)
     const uint32_t bb = bucket_base[blockIdx.x], m = bucket_base[blockIdx.x + 1] - bb;
@@ -1501,9 +1446,9 @@ __global__ __launch_bounds__(kBucketThreads + kWave) void k_bucket_index(Key kf,
             const uint32_t *v = sg + base;
             for (; k + 4 <= cnt && rank < P; k += 4) rank += (v[k] < me) + (v[k + 1] < me) + (v[k + 2] < me) + (v[k + 3] < me);
             for (; k < cnt && rank < P; k++) rank += v[k] < me;
-            if constexpr (ROWS) { if (rank < P) staged[bb + base + rank] = points4[me]; }
+            if constexpr (STAGE) { if (rank < P) staged[bb + base + rank] = points4[me]; }
             if constexpr (LISTS) {
-                if (rank < P) sorted_out[bb + base + rank] = me;
+                if (rank < P && (rank > 0 || !ROWS)) sorted_out[bb + base + rank] = me;
                 if (unsorted_out && cnt > P) unsorted_out[bb + base + (pinfo[bb + q] & kArrMask)] = me;
             }
             if (trimmed && rank >= P) trimmed[me] = 1;
@@ -1513,7 +1458,7 @@ __global__ __launch_bounds__(kBucketThreads + kWave) void k_bucket_index(Key kf,
         return;
     }
 
-    v4f row[ROWS ? ITEMS : 1];
+    v4f row[STAGE ? ITEMS : 1];
     u64 key_in[ITEMS];
     uint32_t idx[ITEMS], slot[ITEMS], arr[ITEMS];
     // branch-free loads (lanes past the end repeat the last entry): all ITEMS entry loads, then all row gathers, in flight
@@ -1526,7 +1471,7 @@ __global__ __launch_bounds__(kBucketThreads + kWave) void k_bucket_index(Key kf,
         key_in[r] = E::key(e);
         idx[r] = E::idx(e);
     });
-    if constexpr (ROWS) {
+    if constexpr (STAGE) {
         static_for<ITEMS>([&](auto R) {
             constexpr int r = decltype(R)::value;
             row[r] = *reinterpret_cast<const v4f *>(&points4[idx[r]]);
@@ -1569,9 +1514,9 @@ __global__ __launch_bounds__(kBucketThreads + kWave) void k_bucket_index(Key kf,
                 rank += (sg[k] < me) + (sg[k + 1] < me) + (sg[k + 2] < me) + (sg[k + 3] < me) + (sg[k + 4] < me) + (sg[k + 5] < me) +
                         (sg[k + 6] < me) + (sg[k + 7] < me);
             for (; k < cnt && rank < P; k++) rank += sg[k] < me;
-            if constexpr (ROWS) { if (rank < P) *reinterpret_cast<v4f *>(&staged[bb + base + rank]) = row[r]; }
-            if constexpr (LISTS) {                                 // dense contract, C != 4: index lists for
-                if (rank < P) sorted_out[bb + base + rank] = me;   // k_fill_generic / k_aggregate
+            if constexpr (STAGE) { if (rank < P) *reinterpret_cast<v4f *>(&staged[bb + base + rank]) = row[r]; }
+            if constexpr (LISTS) {                                 // dense contract, C != 4: index lists for k_fill_generic /
+                if (rank < P && (rank > 0 || !ROWS)) sorted_out[bb + base + rank] = me;   // k_aggregate; C == 4: for k_emit
                 if (unsorted_out && cnt > P) unsorted_out[bb + base + arr[r]] = me;
             }
             if (trimmed && rank >= P) trimmed[me] = 1;     // sparse contract + TRIM filter (voxelize.cpp:457-463)
@@ -1583,16 +1528,11 @@ __global__ __launch_bounds__(kBucketThreads + kWave) void k_bucket_index(Key kf,
 
 // 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF (<= 256 of them:
 // k_meta_first adds up the ones before its tile itself, which is cheaper than a scan launch or a last-block pass)
-__global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict__ firstmap, uint32_t *fwpre, uint32_t *bsumF,
-                                                      uint32_t nreal, PreZero z)
+__global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict__ firstmap, uint32_t *fwpre, uint32_t *bsumF)
 {
     __shared__ u64 smem[1024 / kWave];
     __shared__ uint32_t wcnt[256];
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
-    if (blockIdx.x >= nreal) {                  // filler workgroups
-        prezero_run(z, (blockIdx.x - nreal) * 16 + w, (gridDim.x - nreal) * 16);
-        return;
-    }
     // wavefront w: words [16 w, 16 w + 16) of the tile's 256, all 16 loads in flight
     const uint32_t *src = firstmap + ((size_t)blockIdx.x * 256 + w * 16) * 64 + lane;
     uint32_t e[16];
@@ -1657,23 +1597,29 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
                                x.keys_out, x.npoints_clamp);
 }
 
-// Dense contract, C == 4: numbering, per-voxel outputs AND the voxel's rows of voxels[V,P,4] in one launch (k_meta_first +
-// k_fill_c4 read every voxel's record and first row twice, through two random 16-byte gathers each, and passed a 16-byte
-// vinfo record per voxel between them).  A wavefront owns 64 consecutive point indices; the nv of them that are a voxel's
-// first point are nv CONSECUTIVE voxel ids vid0 .. vid0 + nv - 1 (first-seen numbering, voxelize.cpp:119), i.e. one
-// contiguous stretch of every output.  The records' positions are compacted across the lanes (ds_permute), lane l < nv
-// gathers voxel vid0 + l's record and first row and writes its per-voxel outputs (coalesced over l); then
-//   * vid0 + nv <= Vz (rows pre-zeroed by the fillers of the index launches, see PreZero): only the occupied rows are written;
-//   * otherwise the stretch of nv * P rows is written whole, 64 rows = 1 KiB per store instruction, count / base / first row
-//     travelling between the lanes by ds_bpermute and rows 1.. of multi-point voxels gathered four steps deep -- the loop
-//     of k_fill_c4<G> with G = nv.
+// Dense contract, C == 4: numbering, per-voxel outputs AND the voxel's rows of voxels[V,P,4] in one launch.  (The two-launch
+// stage -- k_meta_first, then k_fill_c4 -- reads every voxel's record and first row twice, through two random 16-byte gathers
+// each, passes a 16-byte vinfo record per voxel between them, and needs every row staged by k_bucket_index first.)
+// A wavefront owns 64 consecutive point indices; the nv of them that are a voxel's first point are nv CONSECUTIVE voxel ids
+// vid0 .. vid0 + nv - 1 (first-seen numbering, voxelize.cpp:119), i.e. one contiguous stretch of every output:
+//   1. the record positions and the point indices of those first points are compacted across the lanes (ds_permute); lane
+//      l < nv gathers voxel vid0 + l's record (the one random access per voxel) and reads the voxel's FIRST ROW as
+//      points[first point] -- ascending indices inside one 1 KiB window, no gather: nothing was staged for it;
+//   2. the stretch of nv * P rows is written 64 rows = 1 KiB per store instruction: first rows (from the owning lane by
+//      ds_bpermute) and zeros -- no loads in this loop, so the stores of a wavefront stream back to back;
+//   3. rows 1 .. min(count, P) - 1 of the multi-point voxels (a fifth of a LiDAR frame's voxels): the wavefront takes them
+//      one voxel at a time, lane k fetching index k of the voxel's ranked list and gathering that point; the reduction over a
+//      voxel with <= P points runs over those lanes IN POINT ORDER (sequential fp32, bit-identical to voxelize.cpp:137-164);
+//      overflow voxels take the fp64 result k_bucket_index left in row P of their segment;
+//   4. coords / npoints / pmask / aggregates: one lane per voxel, coalesced over the stretch.
 template <class Key, bool AGG4>
 __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
                                               const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
                                               const uint4 *__restrict__ vrec, uint32_t max_voxels,
+                                              const float4 *__restrict__ points4, const uint32_t *__restrict__ ranked,
                                               const float4 *__restrict__ staged, uint32_t P, int pshift /* log2 P or -1 */,
                                               int reduction, int64_t *coords, int32_t *npoints, unsigned char *pmask, float4 *agg,
-                                              float4 *voxels, int64_t *counts, int64_t *host_counts, int64_t *state)
+                                              float4 *voxels, int64_t *counts, int64_t *host_counts)
 {
     typedef float vec4 __attribute__((ext_vector_type(4)));
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1687,66 +1633,102 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     }
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) { before += __shfl_xor(before, o, kWave); all += __shfl_xor(all, o, kWave); }
-    const int64_t vz = state ? state[1] : 0;                // voxels whose rows are already zero
     if (i == 0) {
-        const int64_t V = (int64_t)(all < max_voxels ? all : max_voxels);
-        counts[D3D_COUNT_VOXELS] = V;
+        counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
         counts[D3D_COUNT_AUX] = 0;
-        if (state) state[0] = V;                            // the next frame's speculation
         if (host_counts) notify_host(counts, host_counts);
     }
     const uint32_t e = firstmap[i];
     const unsigned long long bal = __ballot(e != kInf);
-    uint32_t nv = (uint32_t)__popcll(bal);
+    const uint32_t nfirst = (uint32_t)__popcll(bal);
+    uint32_t nv = nfirst;
     const uint32_t vid0 = before + fwpre[i >> 6];
     if (nv == 0 || vid0 >= max_voxels) return;             // wave-uniform
     if (nv > max_voxels - vid0) nv = max_voxels - vid0;     // voxelize.cpp:116-117: later voxels are never created
-    // compaction as a full permutation: the r-th first point sends its record position to lane r, the others fill up behind
+    // compaction as a full permutation: the r-th first point sends {record position, own index} to lane r, the rest fill up
     const uint32_t r = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-    const uint32_t dst = e != kInf ? r : (uint32_t)__popcll(bal) + ((uint32_t)lane - r);
-    const uint32_t el = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)e);
-    uint32_t base = 0, cnt = 0;
+    const uint32_t dst = (e != kInf ? r : nfirst + ((uint32_t)lane - r)) << 2;
+    const uint32_t el = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)e);
+    const uint32_t il = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)(uint32_t)i);
+    const bool mine = (uint32_t)lane < nv;
+    uint32_t base = 0, cnt = 0, klo = 0, khi = 0;
     vec4 first = {0.f, 0.f, 0.f, 0.f};
-    const int64_t v = (int64_t)vid0 + lane;
-    if ((uint32_t)lane < nv) {
+    if (mine) {
         const uint4 rec = vrec[el];
-        base = rec.z;
-        cnt = rec.w;
-        first = *reinterpret_cast<const vec4 *>(&staged[base]);
-        meta_voxel<Key, AGG4>(kf, v, rec, staged, P, reduction, coords, npoints, nullptr, pmask, agg, nullptr, nullptr, nullptr);
+        klo = rec.x; khi = rec.y; base = rec.z; cnt = rec.w;
+        first = *reinterpret_cast<const vec4 *>(&points4[il]);
     }
+    const uint32_t kept = cnt < P ? cnt : P;
     vec4 *out = reinterpret_cast<vec4 *>(voxels) + (int64_t)vid0 * P;
-    if ((int64_t)vid0 + nv <= vz) {
-        if ((uint32_t)lane < nv) {
-            vec4 *o = out + (size_t)lane * P;
-            const uint32_t kept = cnt < P ? cnt : P;
-            if (kept > 0) __builtin_nontemporal_store(first, &o[0]);
-            for (uint32_t k = 1; k < kept; k++) __builtin_nontemporal_store(*reinterpret_cast<const vec4 *>(&staged[base + k]), &o[k]);
-        }
-        return;
-    }
-    const uint32_t nrows = nv * P;                          // <= 64 P
-    for (uint32_t q0 = 0; q0 < nrows; q0 += 4 * kWave) {
-        vec4 val[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t q = q0 + u * kWave + lane;
+    // 2. the stretch: first rows and zeros; rows that step 3 writes are left out (no write-after-write between the two)
+    {
+        const uint32_t nrows = nv * P;                      // <= 64 P
+        const vec4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t q0 = 0; q0 < nrows; q0 += kWave) {     // wave-uniform trips: every lane takes part in the shuffles
+            const uint32_t q = q0 + lane;
             const uint32_t qq = q < nrows ? q : 0u;         // rows past the end compute with voxel 0's data and are not stored
             const uint32_t j = pshift >= 0 ? (qq >> pshift) : qq / P;
             const uint32_t slot = qq - j * P;
-            const uint32_t c = (uint32_t)__shfl((int)cnt, (int)j, kWave);
-            const uint32_t b = (uint32_t)__shfl((int)base, (int)j, kWave);
+            const uint32_t kj = (uint32_t)__shfl((int)kept, (int)j, kWave);
             vec4 f;
             f.x = __shfl(first.x, (int)j, kWave); f.y = __shfl(first.y, (int)j, kWave);
             f.z = __shfl(first.z, (int)j, kWave); f.w = __shfl(first.w, (int)j, kWave);
-            const vec4 zero = {0.f, 0.f, 0.f, 0.f};
-            val[u] = (slot == 0 && c > 0) ? f : zero;
-            if (slot > 0 && slot < c) val[u] = *reinterpret_cast<const vec4 *>(&staged[b + slot]);
+            const vec4 val = (slot == 0 && kj > 0) ? f : zero;
+            if (q < nrows && (slot == 0 || slot >= kj)) __builtin_nontemporal_store(val, &out[q]);
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t q = q0 + u * kWave + lane;
-            if (q < nrows) __builtin_nontemporal_store(val[u], &out[q]);
+    }
+    // 3. further rows of the multi-point voxels + the reduction in point order
+    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
+    float a0, a1, a2, a3;
+    a0 = a1 = a2 = a3 = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+    auto acc = [&](float &b0, float &b1, float &b2, float &b3, const vec4 x) {
+        if (is_sum) { b0 += x.x; b1 += x.y; b2 += x.z; b3 += x.w; }
+        else if (reduction == D3D_REDUCE_MAX) {              // std::max(acc, x) = acc < x ? x : acc
+            b0 = b0 < x.x ? x.x : b0; b1 = b1 < x.y ? x.y : b1; b2 = b2 < x.z ? x.z : b2; b3 = b3 < x.w ? x.w : b3;
+        } else {
+            b0 = x.x < b0 ? x.x : b0; b1 = x.y < b1 ? x.y : b1; b2 = x.z < b2 ? x.z : b2; b3 = x.w < b3 ? x.w : b3;
+        }
+    };
+    if (AGG4 && mine && cnt > 0) acc(a0, a1, a2, a3, first);
+    unsigned long long multi = __ballot(mine && kept > 1);
+    while (multi) {
+        const int j = __ffsll((long long)multi) - 1;
+        multi &= multi - 1;
+        const uint32_t cj = (uint32_t)__shfl((int)cnt, j, kWave), bj = (uint32_t)__shfl((int)base, j, kWave);
+        const uint32_t kj = cj < P ? cj : P;                // 2 .. P rows; this loop covers 64 of them per pass
+        for (uint32_t k0 = 0; k0 < kj; k0 += kWave) {
+            const uint32_t k = k0 + lane;
+            vec4 row = {0.f, 0.f, 0.f, 0.f};
+            if (k >= 1 && k < kj) {
+                row = *reinterpret_cast<const vec4 *>(&points4[ranked[bj + k]]);
+                __builtin_nontemporal_store(row, &out[(size_t)j * P + k]);
+            }
+            if (AGG4 && cj <= P) {                          // sequential, point order
+                float b0 = __shfl(a0, j, kWave), b1 = __shfl(a1, j, kWave), b2 = __shfl(a2, j, kWave), b3 = __shfl(a3, j, kWave);
+                const uint32_t kend = kj - k0 < (uint32_t)kWave ? kj - k0 : (uint32_t)kWave;
+                for (uint32_t t = (k0 == 0 ? 1u : 0u); t < kend; t++) {
+                    vec4 x;
+                    x.x = __shfl(row.x, (int)t, kWave); x.y = __shfl(row.y, (int)t, kWave);
+                    x.z = __shfl(row.z, (int)t, kWave); x.w = __shfl(row.w, (int)t, kWave);
+                    acc(b0, b1, b2, b3, x);
+                }
+                if (lane == j) { a0 = b0; a1 = b1; a2 = b2; a3 = b3; }
+            }
+        }
+    }
+    // 4. per-voxel outputs
+    if (!mine) return;
+    const int64_t v = (int64_t)vid0 + lane;
+    meta_voxel<Key, false>(kf, v, make_uint4(klo, khi, base, cnt), nullptr, P, reduction, coords, npoints, nullptr, pmask, nullptr,
+                           nullptr, nullptr, nullptr);
+    if (AGG4) {
+        if (cnt > P) agg[v] = staged[base + P];             // fp64 reduction of k_bucket_index (voxelize.cpp:137-157: all points)
+        else {
+            if (reduction == D3D_REDUCE_MEAN) {              // voxelize.cpp:164 (float / int)
+                const float d = (float)(int32_t)cnt;
+                a0 = a0 / d; a1 = a1 / d; a2 = a2 / d; a3 = a3 / d;
+            }
+            agg[v] = make_float4(a0, a1, a2, a3);
         }
     }
 }
@@ -2087,18 +2069,8 @@ struct DenseOut {
     int32_t *keepid = nullptr;          // ... then: filtered voxel id of every point (-1: dropped) instead of `mapping`
     uint32_t npoints_clamp = 0xffffffffu;   // ... and voxel_npoints = min(count, max_points) (voxelize.cpp:403)
     bool lists = false;                 // dense contract with C != 4: ranked index lists + voff instead of staged rows
-    float4 *emit_voxels = nullptr;      // dense contract on C == 4 rows: k_emit writes voxels[V,P,4] too (no separate fill)
-    PreZero pz = {nullptr, nullptr, 0, 0, 0, 0};
+    float4 *emit_voxels = nullptr;      // dense contract on C == 4 rows: k_emit writes voxels[V,P,4] too (no staging, no fill)
 };
-
-// shares of the pre-zero granules per index launch, in 1/256 (cumulative): count | scan | scatter | bucket | first_count
-static uint32_t g_prezero_cut[4] = {20, 44, 90, 236};
-extern "C" int d3d_internal_set_prezero_shares(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
-{
-    if (!(a <= b && b <= c && c <= d && d <= 256)) return D3D_ERR_BAD_ARG;
-    g_prezero_cut[0] = a; g_prezero_cut[1] = b; g_prezero_cut[2] = c; g_prezero_cut[3] = d;
-    return D3D_OK;
-}
 
 // n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
 static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t flags, uint32_t *nbins_out, int *hshift_out)
@@ -2143,44 +2115,43 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     x.npoints_clamp = o.npoints_clamp;
     x.voff = o.lists ? w.voff : nullptr;
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
-    // pre-zero fillers (PreZero): extra workgroups behind the real ones, a ninth wavefront per bucket workgroup
-    const bool pzon = o.pz.state != nullptr;
-    auto share = [&](int k) { PreZero z = o.pz; z.a = k ? g_prezero_cut[k - 1] : 0u; z.b = k < 4 ? g_prezero_cut[k] : 256u; return z; };
-    const unsigned fillA = pzon ? 256u : 0u, fillB = pzon ? 480u : 0u;
     if (vec4)
-        D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles + fillA), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
-                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid, share(0));
+        D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
+                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
     else
-        D3D_LAUNCH("k_bin_count", (k_bin_count<Key, false, ROWS>), dim3(ntiles + fillA), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
-                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid, share(0));
-    D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave + fillB), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals,
-               share(1));
-    D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles + fillA), dim3(kBinThreads), 0, st, pkey, n, nbins, pbin, tilecnt, totals,
-               bucket_base, bent, counts, ntiles, share(2));
+        D3D_LAUNCH("k_bin_count", (k_bin_count<Key, false, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
+                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
+    D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
+    D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, pkey, n, nbins, pbin, tilecnt, totals,
+               bucket_base, bent, counts);
     if (!ROWS && o.lists)
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass, x.vidof,
                    reinterpret_cast<const typename BinEntry<false>::type *>(bent), p4, bucket_base, hshift, o.P, (int)D3D_REDUCE_NONE,
                    w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
-                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr, share(3));
+                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr);
+    else if (ROWS && o.emit_voxels)
+        D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, true, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
+                   x.vidof, bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
+                   counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.unsorted, (uint32_t *)nullptr);
     else
-        D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads + (pzon ? kWave : 0)), 0, st,
-                   kf, o.pass, x.vidof,
+        D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass, x.vidof,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
-                   precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr, share(3));
+                   precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 512 (n <= 8 M)
-    D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF + fillB), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, nbF, share(4));
+    D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF);
     const dim3 grid((unsigned)(w.npad / 256));
     if constexpr (ROWS) {
         if (o.emit_voxels) {
             const int pshift = (o.P & (o.P - 1)) == 0 ? __builtin_ctz(o.P) : -1;
             if (o.agg4)
                 D3D_LAUNCH("k_emit", (k_emit<Key, true>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
-                           o.max_voxels, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr,
-                           reinterpret_cast<float4 *>(o.aggregates), o.emit_voxels, counts, x.host_counts, o.pz.state);
+                           o.max_voxels, p4, w.unsorted, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
+                           o.fuse_pmask ? o.pmask : nullptr, reinterpret_cast<float4 *>(o.aggregates), o.emit_voxels, counts,
+                           x.host_counts);
             else
                 D3D_LAUNCH("k_emit", (k_emit<Key, false>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
-                           o.max_voxels, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr,
-                           (float4 *)nullptr, o.emit_voxels, counts, x.host_counts, o.pz.state);
+                           o.max_voxels, p4, w.unsorted, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
+                           o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, o.emit_voxels, counts, x.host_counts);
             return D3D_OK;
         }
     }
@@ -2227,8 +2198,7 @@ extern "C" size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxel
 static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels, int64_t *coords,
                                uint8_t *pmask, int32_t *npoints, float *aggregates, int64_t *counts, void *workspace,
-                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags,
-                               int64_t *state = nullptr)
+                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 3 || !shape || !bound || !counts || max_points < 0 || max_voxels < 0) return D3D_ERR_BAD_ARG;
@@ -2261,7 +2231,6 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
                    BinnedExtras{nullptr, 0, nullptr, -1, nullptr, host_counts}, nullptr};
         if (vec4 && P > 0 && !(flags & D3D_VOXEL_SPLIT_FILL)) {
             d.emit_voxels = reinterpret_cast<float4 *>(voxels);
-            d.pz = PreZero{state, reinterpret_cast<float4 *>(voxels), cap, P, 0u, 0u};
             emitted = true;
         }
         if (vec4) rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
@@ -2344,20 +2313,6 @@ extern "C" int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int3
     if (!host_counts) return D3D_ERR_BAD_ARG;
     return voxelize_dense_impl(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
                                aggregates, counts, workspace, workspace_bytes, stream, host_counts, flags);
-}
-
-// d3d_voxelize_3d_dense_notify for a STREAM of frames: `state` (device int64[D3D_VOXEL_STATE_WORDS], zeroed once by the
-// caller, then handed unchanged from call to call) carries the previous frame's voxel count, on which this call speculates
-// to zero most of voxels[V,P,C] from inside the index launches (see PreZero).  state == NULL or a state of zeros: no
-// speculation.  host_counts may be NULL.
-extern "C" int d3d_voxelize_3d_dense_stream(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
-                                            int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels,
-                                            int64_t *coords, uint8_t *pmask, int32_t *npoints, float *aggregates,
-                                            int64_t *counts, void *workspace, size_t workspace_bytes, void *stream,
-                                            int64_t *host_counts, int64_t *state, uint32_t flags)
-{
-    return voxelize_dense_impl(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
-                               aggregates, counts, workspace, workspace_bytes, stream, host_counts, flags, state);
 }
 
 // The "voxel feature grid" without the dense [V,P,C] copy: first-seen voxel ids, counts, per-voxel

@@ -136,16 +136,12 @@ def _workspace_bytes(lib, n):
     return b
 
 
-def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type, flags=None, state=None):
+def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type, flags=None):
     """voxelize_3d_dense of the reference (voxelize.h:9-12; voxelize.cpp:45-199).
 
     Returns dict(voxels[V,P,C] f32, coords[V,3] i64, voxel_pmask[V,P] bool,
     voxel_npoints[V] i32 [, aggregates[V,C] f32 when reduction != NONE]).
 
-    `state` (beyond the reference): a device int64[VOXEL_STATE_WORDS] tensor of zeros that a caller processing a stream
-    of frames passes to every call (VoxelGenerator keeps one per device): it carries the previous frame's voxel count, on
-    which the call speculates to zero most of `voxels` from inside its index kernels (d3d_voxelize_3d_dense_stream).  The
-    result does not depend on it.
     """
     lib = _lib.load()
     pts, odev, dev = _stage(points)
@@ -175,11 +171,10 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
             # the voxel count reaches the host through pinned memory as soon as it is final, while the GPU is still
             # writing voxels[V,P,C]: the call returns views of outputs in flight on the current stream, like any torch op
             note.arm()
-            rc = lib.d3d_voxelize_3d_dense_stream(
+            rc = lib.d3d_voxelize_3d_dense_notify(
                 _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
                 max_points, max_voxels, red, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts),
-                _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr,
-                _lib.ptr(state) if state is not None else None, fl)
+                _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr, fl)
             if rc == _lib.ERR_UNSUPPORTED:
                 raise ValueError("Unsupported reduction type in voxelization!")   # voxelize.cpp:196
             _lib.check(rc, "voxelize_3d_dense")
@@ -358,8 +353,6 @@ class VoxelGenerator:
         self._vbounds = torch.round(lohi / self._size.reshape(3, 1)).long()                   # :46
         self._shape_h = _host_array(self._shape, ctypes.c_int32, 3)      # marshalled once for the C ABI
         self._offset_dev = {}
-        self._speculate = True      # dense contract: pre-zero `voxels` for about the previous frame's voxel count
-        self._stream_state = {}     # device -> int64[VOXEL_STATE_WORDS]: the previous frame's voxel count (dense contract)
         self._bounds_h = _host_array(self._bounds, ctypes.c_float, 6)
         self._size_h = _host_array(self._size, ctypes.c_float, 3)
 
@@ -387,14 +380,8 @@ class VoxelGenerator:
         if not points.is_cuda:
             points = points.to(_lib.require_gpu())    # stage once; results go back to the caller's device
         if self._dense:
-            state = self._stream_state.get(points.device) if self._speculate else False
-            if state is False:
-                state = None
-            elif state is None:
-                state = self._stream_state[points.device] = torch.zeros((_lib.VOXEL_STATE_WORDS,), dtype=torch.int64,
-                                                                        device=points.device)
             ret = Dict(voxelize_3d_dense(points, self._shape_h, self._bounds_h, self._max_points,
-                                         self._max_voxels, self._reduction, state=state))
+                                         self._max_voxels, self._reduction))
         else:
             pf, vf = int(self._max_points_filter), int(self._max_voxels_filter)
             if vf == MaxVoxelsFilterType.DESCENDING or points.shape[0] == 0:

@@ -73,10 +73,10 @@ const char *d3d_status_string(int status);
  *                          identical outputs; see DESIGN.md section 4.
  *   D3D_VOXEL_PLAIN_SLOTS  (hash table) general two-word slots, any count / key width, instead of the default one-word
  *                          slots {count | key | first index} that are used whenever they fit 64 bits.
- *   D3D_VOXEL_SPLIT_FILL   (dense contract, binned index, C == 4) per-voxel outputs and voxels[V,P,C] from two launches
- *                          (k_meta_first + k_fill_c4) instead of the fused k_emit.  Identical outputs. */
+ *   D3D_VOXEL_SPLIT_FILL   (dense contract, binned index, C == 4) the ranked rows staged by the index, then per-voxel outputs
+ *                          and voxels[V,P,C] from two launches (k_meta_first + k_fill_c4) instead of the fused k_emit, which
+ *                          reads first rows straight from `points`.  Identical outputs. */
 enum { D3D_VOXEL_PATH_HASH = 1, D3D_VOXEL_PLAIN_SLOTS = 4, D3D_VOXEL_SPLIT_FILL = 8, D3D_VOXEL_FLAGS_ALL = 13 };
-enum { D3D_VOXEL_STATE_WORDS = 4 };
 
 /* scratch for any of the three voxel entry points on n points / nvox voxels */
 size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels);
@@ -107,21 +107,6 @@ int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int32_t c,
                           float *voxels, int64_t *coords, uint8_t *pmask, int32_t *npoints,
                           float *aggregates, int64_t *counts,
                           void *workspace, size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags);
-
-/* d3d_voxelize_3d_dense_notify for a stream of frames (a LiDAR sequence through one VoxelGenerator).  `state`: device
- * int64[D3D_VOXEL_STATE_WORDS], zeroed once by the caller and then passed unchanged to every call; it carries the previous
- * frame's voxel count.  95 % of voxels[V,P,C] are zero rows (voxelize.cpp:56 zero-fills, :129-134 writes the points): this
- * call zeroes the rows of about that many voxels from spare wavefronts of its index launches, whose HBM write path is
- * otherwise idle, and afterwards writes only the occupied rows there (whole voxels beyond).  Results are identical to
- * d3d_voxelize_3d_dense whatever the state holds.  Rows of voxels[] past counts[D3D_COUNT_VOXELS] may be overwritten with
- * zeros.  state == NULL: no speculation.  host_counts may be NULL. */
-int d3d_voxelize_3d_dense_stream(const float *points, int64_t n, int32_t c,
-                          const int32_t *shape, const float *bound,
-                          int32_t max_points, int32_t max_voxels, int32_t reduction,
-                          float *voxels, int64_t *coords, uint8_t *pmask, int32_t *npoints,
-                          float *aggregates, int64_t *counts,
-                          void *workspace, size_t workspace_bytes, void *stream, int64_t *host_counts, int64_t *state,
-                          uint32_t flags);
 
 /* replaces voxelize_sparse, bound in Python as voxelize_3d_sparse
  * (reference voxelize.h:14-17, voxelize.cpp:288-335, impl.cpp:5).
