@@ -121,4 +121,4 @@ def test_bucket_kernel_keeps_its_first_point_store_separate(tmp_path):
             cur = m.group(1)
         elif cur and "k_bucket_index" in cur and re.search(r"global_store_dword\b.*\bsc1\b", line):
             scoped[cur] = scoped.get(cur, 0) + 1
-    assert len(scoped) == 5 and set(scoped.values()) == {8}, scoped
+    assert len(scoped) == 6 and set(scoped.values()) == {8}, scoped
