@@ -1603,15 +1603,25 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
 // A wavefront owns 64 consecutive point indices; the nv of them that are a voxel's first point are nv CONSECUTIVE voxel ids
 // vid0 .. vid0 + nv - 1 (first-seen numbering, voxelize.cpp:119), i.e. one contiguous stretch of every output:
 //   1. the record positions and the point indices of those first points are compacted across the lanes (ds_permute); lane
-//      l < nv gathers voxel vid0 + l's record (the one random access per voxel) and reads the voxel's FIRST ROW as
-//      points[first point] -- ascending indices inside one 1 KiB window, no gather: nothing was staged for it;
-//   2. the stretch of nv * P rows is written 64 rows = 1 KiB per store instruction: first rows (from the owning lane by
-//      ds_bpermute) and zeros -- no loads in this loop, so the stores of a wavefront stream back to back;
-//   3. rows 1 .. min(count, P) - 1 of the multi-point voxels (a fifth of a LiDAR frame's voxels): the wavefront takes them
-//      one voxel at a time, lane k fetching index k of the voxel's ranked list and gathering that point; the reduction over a
-//      voxel with <= P points runs over those lanes IN POINT ORDER (sequential fp32, bit-identical to voxelize.cpp:137-164);
-//      overflow voxels take the fp64 result k_bucket_index left in row P of their segment;
-//   4. coords / npoints / pmask / aggregates: one lane per voxel, coalesced over the stretch.
+//      l < nv gathers voxel vid0 + l's record -- the one random access per voxel;
+//   2. ALL kept rows of the wavefront's voxels (sum of min(count, P): ~63 for a LiDAR frame) are fetched in one flat,
+//      lane-parallel pass into a row buffer in LDS: row t belongs to voxel j (binary search over the voxels' row offsets) at
+//      rank k; its point index is the voxel's first point (k = 0: ascending indices inside one 1 KiB window of the point
+//      tensor, nothing was staged for it) or entry k of the voxel's ranked list.  Two dependent loads for the whole
+//      wavefront, however many multi-point voxels it holds;
+//   3. reductions: lane j walks ITS voxel's rows in the buffer in point order (sequential fp32, bit-identical to
+//      voxelize.cpp:137-164); overflow voxels take the fp64 result k_bucket_index left in row P of their segment;
+//   4. the stretch of nv * P rows is written 64 rows = 1 KiB per store instruction, rows from the buffer, zeros elsewhere: no
+//      global load in this loop, the stores of a wavefront stream back to back;
+//   5. coords / npoints / pmask / aggregates: one lane per voxel, coalesced over the stretch.
+// A wavefront whose rows exceed the buffer (kEmitCap) takes its voxels in batches of consecutive ids.
+constexpr int kEmitCap = 256;                     // rows per wavefront in LDS (4 KiB); max_points <= kEmitCap on this path
+
+__device__ __forceinline__ void wave_lds_fence()  // LDS traffic of THIS wavefront is ordered (the pipe is in-order per wave);
+{                                                 // keep the compiler from moving accesses across, and let writes land
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <class Key, bool AGG4>
 __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
                                               const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
@@ -1622,8 +1632,14 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
                                               float4 *voxels, int64_t *counts, int64_t *host_counts)
 {
     typedef float vec4 __attribute__((ext_vector_type(4)));
+    __shared__ vec4 rowbuf_all[256 / kWave][kEmitCap];
+    __shared__ uint32_t off_all[256 / kWave][kWave], base_all[256 / kWave][kWave], first_all[256 / kWave][kWave];
+    __shared__ uint16_t kept_all[256 / kWave][kWave];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & (kWave - 1);
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    vec4 *rowbuf = rowbuf_all[w];
+    uint32_t *sh_off = off_all[w], *sh_base = base_all[w], *sh_first = first_all[w];
+    uint16_t *sh_kept = kept_all[w];
     const uint32_t tile = (uint32_t)(i / kFlagTile), ntile = (uint32_t)(npad / kFlagTile);
     uint32_t before = 0, all = 0;
     for (uint32_t t = lane; t < ntile; t += kWave) {
@@ -1645,82 +1661,87 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     const uint32_t vid0 = before + fwpre[i >> 6];
     if (nv == 0 || vid0 >= max_voxels) return;             // wave-uniform
     if (nv > max_voxels - vid0) nv = max_voxels - vid0;     // voxelize.cpp:116-117: later voxels are never created
-    // compaction as a full permutation: the r-th first point sends {record position, own index} to lane r, the rest fill up
+    // 1. compaction as a full permutation: the r-th first point sends {record position, own index} to lane r, the rest fill up
     const uint32_t r = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
     const uint32_t dst = (e != kInf ? r : nfirst + ((uint32_t)lane - r)) << 2;
     const uint32_t el = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)e);
     const uint32_t il = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)(uint32_t)i);
     const bool mine = (uint32_t)lane < nv;
-    uint32_t base = 0, cnt = 0, klo = 0, khi = 0;
-    vec4 first = {0.f, 0.f, 0.f, 0.f};
-    if (mine) {
-        const uint4 rec = vrec[el];
-        klo = rec.x; khi = rec.y; base = rec.z; cnt = rec.w;
-        first = *reinterpret_cast<const vec4 *>(&points4[il]);
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (mine) rec = vrec[el];
+    const uint32_t base = rec.z, cnt = rec.w;
+    const uint32_t kept = cnt < P ? cnt : P;                // 0 for the lanes past nv
+    uint32_t incl = kept;                                   // rows before this voxel in the wavefront's flat row list
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, kWave);
+        if (lane >= d) incl += t;
     }
-    const uint32_t kept = cnt < P ? cnt : P;
-    vec4 *out = reinterpret_cast<vec4 *>(voxels) + (int64_t)vid0 * P;
-    // 2. the stretch: first rows and zeros; rows that step 3 writes are left out (no write-after-write between the two)
-    {
-        const uint32_t nrows = nv * P;                      // <= 64 P
-        const vec4 zero = {0.f, 0.f, 0.f, 0.f};
-        for (uint32_t q0 = 0; q0 < nrows; q0 += kWave) {     // wave-uniform trips: every lane takes part in the shuffles
-            const uint32_t q = q0 + lane;
-            const uint32_t qq = q < nrows ? q : 0u;         // rows past the end compute with voxel 0's data and are not stored
-            const uint32_t j = pshift >= 0 ? (qq >> pshift) : qq / P;
-            const uint32_t slot = qq - j * P;
-            const uint32_t kj = (uint32_t)__shfl((int)kept, (int)j, kWave);
-            vec4 f;
-            f.x = __shfl(first.x, (int)j, kWave); f.y = __shfl(first.y, (int)j, kWave);
-            f.z = __shfl(first.z, (int)j, kWave); f.w = __shfl(first.w, (int)j, kWave);
-            const vec4 val = (slot == 0 && kj > 0) ? f : zero;
-            if (q < nrows && (slot == 0 || slot >= kj)) __builtin_nontemporal_store(val, &out[q]);
-        }
-    }
-    // 3. further rows of the multi-point voxels + the reduction in point order
+    const uint32_t off = incl - kept;
+    sh_off[lane] = off; sh_base[lane] = base; sh_first[lane] = il; sh_kept[lane] = (uint16_t)kept;
+    wave_lds_fence();
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
     float a0, a1, a2, a3;
     a0 = a1 = a2 = a3 = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
-    auto acc = [&](float &b0, float &b1, float &b2, float &b3, const vec4 x) {
-        if (is_sum) { b0 += x.x; b1 += x.y; b2 += x.z; b3 += x.w; }
-        else if (reduction == D3D_REDUCE_MAX) {              // std::max(acc, x) = acc < x ? x : acc
-            b0 = b0 < x.x ? x.x : b0; b1 = b1 < x.y ? x.y : b1; b2 = b2 < x.z ? x.z : b2; b3 = b3 < x.w ? x.w : b3;
-        } else {
-            b0 = x.x < b0 ? x.x : b0; b1 = x.y < b1 ? x.y : b1; b2 = x.z < b2 ? x.z : b2; b3 = x.w < b3 ? x.w : b3;
-        }
-    };
-    if (AGG4 && mine && cnt > 0) acc(a0, a1, a2, a3, first);
-    unsigned long long multi = __ballot(mine && kept > 1);
-    while (multi) {
-        const int j = __ffsll((long long)multi) - 1;
-        multi &= multi - 1;
-        const uint32_t cj = (uint32_t)__shfl((int)cnt, j, kWave), bj = (uint32_t)__shfl((int)base, j, kWave);
-        const uint32_t kj = cj < P ? cj : P;                // 2 .. P rows; this loop covers 64 of them per pass
-        for (uint32_t k0 = 0; k0 < kj; k0 += kWave) {
-            const uint32_t k = k0 + lane;
-            vec4 row = {0.f, 0.f, 0.f, 0.f};
-            if (k >= 1 && k < kj) {
-                row = *reinterpret_cast<const vec4 *>(&points4[ranked[bj + k]]);
-                __builtin_nontemporal_store(row, &out[(size_t)j * P + k]);
-            }
-            if (AGG4 && cj <= P) {                          // sequential, point order
-                float b0 = __shfl(a0, j, kWave), b1 = __shfl(a1, j, kWave), b2 = __shfl(a2, j, kWave), b3 = __shfl(a3, j, kWave);
-                const uint32_t kend = kj - k0 < (uint32_t)kWave ? kj - k0 : (uint32_t)kWave;
-                for (uint32_t t = (k0 == 0 ? 1u : 0u); t < kend; t++) {
-                    vec4 x;
-                    x.x = __shfl(row.x, (int)t, kWave); x.y = __shfl(row.y, (int)t, kWave);
-                    x.z = __shfl(row.z, (int)t, kWave); x.w = __shfl(row.w, (int)t, kWave);
-                    acc(b0, b1, b2, b3, x);
+    vec4 *out = reinterpret_cast<vec4 *>(voxels) + (int64_t)vid0 * P;
+    const vec4 zero = {0.f, 0.f, 0.f, 0.f};
+    uint32_t ja = 0;
+    while (ja < nv) {                                       // wave-uniform: one batch unless the rows exceed the buffer
+        const uint32_t oa = (uint32_t)__shfl((int)off, (int)ja, kWave);
+        const bool fits = (uint32_t)lane >= ja && mine && incl - oa <= (uint32_t)kEmitCap;
+        const unsigned long long nf = ~(__ballot(fits) >> ja);
+        const uint32_t jb = ja + (nf ? (uint32_t)__ffsll((long long)nf) - 1u : (uint32_t)kWave - ja);     // >= ja + 1: kept <= P <= kEmitCap
+        const uint32_t rows = (uint32_t)__shfl((int)incl, (int)jb - 1, kWave) - oa;
+        // 2. the batch's rows, flat and lane-parallel
+        for (uint32_t t0 = 0; t0 < rows; t0 += kWave) {
+            const uint32_t t = t0 + lane;
+            if (t < rows) {
+                uint32_t lo = ja, hi = jb;                  // largest j in [ja, jb) with off[j] - oa <= t
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sh_off[mid] - oa <= t) lo = mid; else hi = mid;
                 }
-                if (lane == j) { a0 = b0; a1 = b1; a2 = b2; a3 = b3; }
+                const uint32_t k = t - (sh_off[lo] - oa);
+                const uint32_t idx = k == 0 ? sh_first[lo] : ranked[sh_base[lo] + k];
+                rowbuf[t] = *reinterpret_cast<const vec4 *>(&points4[idx]);
             }
         }
+        wave_lds_fence();
+        // 3. reductions in point order, one lane per voxel
+        if (AGG4 && (uint32_t)lane >= ja && (uint32_t)lane < jb && cnt <= P) {
+            const vec4 *rw = rowbuf + (off - oa);
+            for (uint32_t k = 0; k < kept; k++) {
+                const vec4 x = rw[k];
+                if (is_sum) { a0 += x.x; a1 += x.y; a2 += x.z; a3 += x.w; }
+                else if (reduction == D3D_REDUCE_MAX) {      // std::max(acc, x) = acc < x ? x : acc
+                    a0 = a0 < x.x ? x.x : a0; a1 = a1 < x.y ? x.y : a1; a2 = a2 < x.z ? x.z : a2; a3 = a3 < x.w ? x.w : a3;
+                } else {
+                    a0 = x.x < a0 ? x.x : a0; a1 = x.y < a1 ? x.y : a1; a2 = x.z < a2 ? x.z : a2; a3 = x.w < a3 ? x.w : a3;
+                }
+            }
+        }
+        // 4. the stretch of the batch's voxels
+        const uint32_t q1 = jb * P;
+        for (uint32_t q0 = ja * P; q0 < q1; q0 += 4 * kWave) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t q = q0 + u * kWave + lane;
+                if (q < q1) {
+                    const uint32_t j = pshift >= 0 ? (q >> pshift) : q / P;
+                    const uint32_t slot = q - j * P;
+                    vec4 val = zero;
+                    if (slot < sh_kept[j]) val = rowbuf[sh_off[j] - oa + slot];
+                    __builtin_nontemporal_store(val, &out[q]);
+                }
+            }
+        }
+        wave_lds_fence();                                   // the next batch overwrites the buffer
+        ja = jb;
     }
-    // 4. per-voxel outputs
+    // 5. per-voxel outputs
     if (!mine) return;
     const int64_t v = (int64_t)vid0 + lane;
-    meta_voxel<Key, false>(kf, v, make_uint4(klo, khi, base, cnt), nullptr, P, reduction, coords, npoints, nullptr, pmask, nullptr,
-                           nullptr, nullptr, nullptr);
+    meta_voxel<Key, false>(kf, v, rec, nullptr, P, reduction, coords, npoints, nullptr, pmask, nullptr, nullptr, nullptr, nullptr);
     if (AGG4) {
         if (cnt > P) agg[v] = staged[base + P];             // fp64 reduction of k_bucket_index (voxelize.cpp:137-157: all points)
         else {
@@ -2229,7 +2250,7 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
     if (max_voxels > 0 && dense_cells_fit_u32(kf) && binned_eligible(n, w, flags, &nbins, &hshift)) {
         DenseOut d{P, (uint32_t)max_voxels, reduction, agg4, fuse_pmask, coords, npoints, pmask, aggregates,
                    BinnedExtras{nullptr, 0, nullptr, -1, nullptr, host_counts}, nullptr};
-        if (vec4 && P > 0 && !(flags & D3D_VOXEL_SPLIT_FILL)) {
+        if (vec4 && P > 0 && P <= (uint32_t)kEmitCap && !(flags & D3D_VOXEL_SPLIT_FILL)) {
             d.emit_voxels = reinterpret_cast<float4 *>(voxels);
             emitted = true;
         }
