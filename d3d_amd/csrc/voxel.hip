@@ -1738,19 +1738,50 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
         wave_lds_fence();                                   // the next batch overwrites the buffer
         ja = jb;
     }
-    // 5. per-voxel outputs
-    if (!mine) return;
+    // 5. per-voxel outputs, each as contiguous full-width stores over the wavefront's stretch (streamed past the caches like
+    //    the rows: partially written lines left in the L2 are written back during the next launches)
     const int64_t v = (int64_t)vid0 + lane;
-    meta_voxel<Key, false>(kf, v, rec, nullptr, P, reduction, coords, npoints, nullptr, pmask, nullptr, nullptr, nullptr, nullptr);
-    if (AGG4) {
-        if (cnt > P) agg[v] = staged[base + P];             // fp64 reduction of k_bucket_index (voxelize.cpp:137-157: all points)
+    {
+        // coords[nv][3] i64: through LDS (the row buffer is free now), then 8-byte words 64 at a time
+        long long *cbuf = reinterpret_cast<long long *>(rowbuf);       // 64 * 3 * 8 B = 1.5 KiB
+        if (mine) {
+            long long cc[3];
+            kf.decode(((u64)rec.y << 32) | rec.x, cc);
+            cbuf[lane * 3 + 0] = cc[0]; cbuf[lane * 3 + 1] = cc[1]; cbuf[lane * 3 + 2] = cc[2];
+            __builtin_nontemporal_store((int32_t)cnt, &npoints[v]);
+        }
+        wave_lds_fence();
+        long long *cdst = reinterpret_cast<long long *>(coords) + (int64_t)vid0 * 3;
+        for (uint32_t t = lane; t < nv * 3; t += kWave) __builtin_nontemporal_store(cbuf[t], &cdst[t]);
+        if (pmask) {                                         // P % 16 == 0, 16-byte aligned (host-checked): 16-byte pieces
+            const uint32_t per = P >> 4, total = nv * per;
+            typedef uint32_t uvec4 __attribute__((ext_vector_type(4)));
+            uvec4 *pdst = reinterpret_cast<uvec4 *>(pmask + (int64_t)vid0 * P);
+            for (uint32_t t = lane; t < total; t += kWave) {
+                const uint32_t j = t / per, k0 = (t - j * per) << 4, kj = sh_kept[j];
+                uvec4 w4;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t b = 0;
+#pragma unroll
+                    for (int x = 0; x < 4; x++) b |= ((k0 + q * 4 + x) < kj ? 1u : 0u) << (8 * x);
+                    w4[q] = b;
+                }
+                __builtin_nontemporal_store(w4, &pdst[t]);
+            }
+        }
+    }
+    if (AGG4 && mine) {
+        vec4 res;
+        if (cnt > P) res = *reinterpret_cast<const vec4 *>(&staged[base + P]);   // fp64 reduction of k_bucket_index (voxelize.cpp:137-157)
         else {
             if (reduction == D3D_REDUCE_MEAN) {              // voxelize.cpp:164 (float / int)
                 const float d = (float)(int32_t)cnt;
                 a0 = a0 / d; a1 = a1 / d; a2 = a2 / d; a3 = a3 / d;
             }
-            agg[v] = make_float4(a0, a1, a2, a3);
+            res.x = a0; res.y = a1; res.z = a2; res.w = a3;
         }
+        __builtin_nontemporal_store(res, reinterpret_cast<vec4 *>(&agg[v]));
     }
 }
 

@@ -30,7 +30,12 @@ def run(tag, flags, steps=20):
           {k: round(v["avg_us"], 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, flush=True)
 
 
+lib = _lib.load()
 run("split (k_meta_first + k_fill_c4)", _lib.VOXEL_SPLIT_FILL)
 run("emit", 0)
-run("split again", _lib.VOXEL_SPLIT_FILL)
+if hasattr(lib, "d3d_internal_emit_dbg"):
+    for m, what in ((4, "no per-voxel outputs"), (32, "per-voxel outputs by meta_voxel (plain stores)"), (14, "zeros stretch only")):
+        lib.d3d_internal_emit_dbg(m)
+        run("emit dbg %d: %s" % (m, what), 0)
+    lib.d3d_internal_emit_dbg(0)
 run("emit again", 0)
