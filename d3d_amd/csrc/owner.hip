@@ -1,0 +1,495 @@
+// owner.hip -- point-sharded voxelizer, owner-computes exchange (the reference has no distributed code).
+//
+// Every cell of the grid has ONE owner rank, owner(cell) = hash(cell) * W >> 64.  A rank voxelizes its own shard
+// (d3d_voxelize_3d_reduce), sends each local voxel's partial record {cell, first global point index, count, partial
+// features} to the cell's owner (one all-to-all), and the owner merges the <= W records of each of its cells: the
+// "all-reduce of the voxel feature grid" of north_star, done sparsely -- a reduce-scatter whose scatter is the hash.  All
+// per-voxel work after the local pass (merge, numbering, division, output order) touches 1/W of the frame's voxels per
+// rank; nothing is sized by the grid (no bitmap over cells) and nothing by the frame except one bit per POINT:
+//   numbering   the owners' voxels are disjoint and every voxel has one first point, so the owners' "first point" bit
+//               sets over the frame's point indices are disjoint -> their integer SUM (an all-reduce RCCL has) is their
+//               OR; its popcount prefix is the reference's first-seen voxel id (voxelize.cpp:119).  1 bit per point.
+//   merge       deterministic: a slot keeps one record index per source rank and the sums run in rank order -- the
+//               result does not depend on the arrival order of the records or on the atomics that place them.
+#include "common.hpp"
+#include <cstdint>
+#include <algorithm>
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr int kMaxWorld = 64;
+constexpr u64 kFree = ~0ull;
+constexpr int kPackTile = 1024;      // records per workgroup in the partition by owner
+
+__device__ __forceinline__ u64 mix64(u64 h)
+{
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
+    return h;
+}
+__device__ __forceinline__ uint32_t owner_of(int64_t key, uint32_t world)
+{
+    return (uint32_t)(((mix64((u64)key) >> 32) * (u64)world) >> 32);
+}
+
+// record = RS 32-bit words: key (2), first global point index (2), count (1), c partial features, padding to even
+__host__ __device__ inline int rec_stride(int c) { return (5 + c + 1) & ~1; }
+
+// ---------------------------------------------------------------- partition of the local voxels by owner (3 launches)
+// per tile of kPackTile voxels: how many go to each rank
+__global__ __launch_bounds__(256) void k_owner_count(const int64_t *__restrict__ keys, const int64_t *__restrict__ counts,
+                                                     uint32_t world, uint32_t *__restrict__ tilecnt)
+{
+    __shared__ uint32_t h[kMaxWorld];
+    const int64_t V = counts[D3D_COUNT_VOXELS];
+    if (threadIdx.x < kMaxWorld) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = 0; k < kPackTile / 256; k++) {
+        const int64_t i = (int64_t)blockIdx.x * kPackTile + k * 256 + threadIdx.x;
+        if (i < V) atomicAdd(&h[owner_of(keys[i], world)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < world) tilecnt[(size_t)blockIdx.x * world + threadIdx.x] = h[threadIdx.x];
+}
+
+// one wavefront per destination: exclusive prefix of its column of tilecnt over the tiles; then the destinations' bases.
+// send_counts[0 .. world) = records per destination, [world] = the shard's status bits (keys[n] = -1 - status)
+__global__ __launch_bounds__(1024) void k_owner_offsets(uint32_t *tilecnt, uint32_t ntiles, uint32_t world, int64_t *send_counts,
+                                                        uint32_t *dest_base, const int64_t *status_key)
+{
+    __shared__ uint32_t tot[kMaxWorld];
+    const int lane = threadIdx.x & (kWave - 1);
+    for (uint32_t d = threadIdx.x >> 6; d < world; d += 1024 / kWave) {
+        uint32_t carry = 0;
+        for (uint32_t t0 = 0; t0 < ntiles; t0 += kWave) {
+            const uint32_t t = t0 + lane;
+            const uint32_t x = t < ntiles ? tilecnt[(size_t)t * world + d] : 0u;
+            uint32_t incl = x;
+#pragma unroll
+            for (int s = 1; s < kWave; s <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)incl, s, kWave);
+                if (lane >= s) incl += y;
+            }
+            if (t < ntiles) tilecnt[(size_t)t * world + d] = carry + incl - x;
+            carry += (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+        }
+        if (lane == 0) tot[d] = carry;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t d = 0; d < world; d++) {
+            dest_base[d] = run;
+            send_counts[d] = tot[d];
+            run += tot[d];
+        }
+        dest_base[world] = run;
+        send_counts[world] = status_key ? -1 - *status_key : 0;
+    }
+}
+
+// records to their place in the send buffer (grouped by destination, tile order inside a destination, the order inside a
+// tile from the wavefronts' ballots: the same on every run)
+__global__ __launch_bounds__(256) void k_owner_scatter(const int64_t *__restrict__ keys, const int32_t *__restrict__ cnt,
+                                                       const float *__restrict__ agg, const int64_t *__restrict__ first,
+                                                       const int64_t *__restrict__ counts, int c, uint32_t world,
+                                                       const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ dest_base,
+                                                       int32_t *__restrict__ send, int32_t *__restrict__ perm)
+{
+    __shared__ uint32_t run[kMaxWorld];          // records of this tile already placed, per destination
+    __shared__ uint32_t wcnt[256 / kWave][kMaxWorld];
+    const int64_t V = counts[D3D_COUNT_VOXELS];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int RS = rec_stride(c);
+    if (threadIdx.x < kMaxWorld) run[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = 0; k < kPackTile / 256; k++) {
+        const int64_t i = (int64_t)blockIdx.x * kPackTile + k * 256 + threadIdx.x;
+        const bool ok = i < V;
+        const int64_t key = ok ? keys[i] : 0;
+        const uint32_t d = ok ? owner_of(key, world) : 0xffffffffu;
+        uint32_t myrank = 0;
+        for (uint32_t q = 0; q < world; q++) {               // wave-uniform
+            const u64 b = __ballot(d == q);
+            if (d == q) myrank = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[w][q] = (uint32_t)__popcll(b);
+        }
+        __syncthreads();
+        if (ok) {
+            uint32_t before = run[d];
+            for (int ww = 0; ww < w; ww++) before += wcnt[ww][d];
+            const uint32_t pos = dest_base[d] + tileoff[(size_t)blockIdx.x * world + d] + before + myrank;
+            int32_t *r = send + (size_t)pos * RS;
+            *reinterpret_cast<int64_t *>(r) = key;
+            *reinterpret_cast<int64_t *>(r + 2) = first[i];
+            r[4] = cnt[i];
+            for (int f = 0; f < c; f++) r[5 + f] = __float_as_int(agg[i * c + f]);
+            perm[pos] = (int32_t)i;
+        }
+        __syncthreads();
+        if (threadIdx.x < world) {
+            uint32_t add = 0;
+            for (int ww = 0; ww < 256 / kWave; ww++) add += wcnt[ww][threadIdx.x];
+            run[threadIdx.x] += add;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- merge on the owner
+struct MergeWs {
+    u64 *tkey;            // [cap]
+    uint32_t *contrib;    // [cap * world] record index + 1 per source rank, 0 = none
+    uint32_t *rec_slot;   // [R]
+    uint32_t *slot_owned; // [cap]
+    u64 *bsum;            // scan scratch
+    u64 cap;
+    size_t bytes;
+};
+
+static u64 merge_cap(int64_t R)
+{
+    u64 cap = 1024;
+    while (cap < (u64)R * 2ull) cap <<= 1;
+    return cap;
+}
+
+static MergeWs carve_merge(void *ws, size_t bytes, int64_t R, int world)
+{
+    WsCarver w(ws, bytes);
+    MergeWs m;
+    m.cap = merge_cap(R);
+    m.tkey = w.take<u64>(m.cap);
+    m.contrib = w.take<uint32_t>(m.cap * (size_t)world);
+    m.rec_slot = w.take<uint32_t>(R > 0 ? R : 1);
+    m.slot_owned = w.take<uint32_t>(m.cap);
+    m.bsum = w.take<u64>(d3d_divup((int64_t)m.cap, kScanTile) + 1);
+    m.bytes = w.off;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_merge_init(u64 *tkey, uint32_t *contrib, u64 cap, int world)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) tkey[i] = kFree;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap * (u64)world; i += stride) contrib[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_merge_insert(const int32_t *__restrict__ recv, int64_t R, int RS,
+                                                      const int64_t *__restrict__ src_off, int world, u64 *tkey, u64 mask,
+                                                      uint32_t *contrib, uint32_t *rec_slot)
+{
+    __shared__ int64_t so[kMaxWorld + 1];
+    if (threadIdx.x <= (unsigned)world) so[threadIdx.x] = src_off[threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    int lo = 0, hi = world;                       // source rank: the last s with so[s] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (so[mid] <= i) lo = mid; else hi = mid;
+    }
+    const u64 key = (u64)*reinterpret_cast<const int64_t *>(recv + (size_t)i * RS);
+    u64 h = mix64(key * 0x9e3779b97f4a7c15ull) & mask;        // (a second mix: the owner hash already split on mix64's top bits)
+    for (;;) {
+        const u64 cur = __hip_atomic_load(&tkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) break;
+        if (cur == kFree) {
+            const u64 old = atomicCAS(&tkey[h], kFree, key);
+            if (old == kFree || old == key) break;
+        }
+        h = (h + 1) & mask;                       // cap >= 2 R: a free slot always exists
+    }
+    contrib[h * (u64)world + lo] = (uint32_t)i + 1u;
+    rec_slot[i] = (uint32_t)h;
+}
+
+// scan over the table's slots: occupied slots are numbered (= the owner's voxels, in slot order) and merged on the spot
+struct MergeSlots {
+    static constexpr const char *kName = "k_scan_count<MergeSlots>", *kName2 = "k_scan_apply<MergeSlots>";
+    const u64 *tkey;
+    const uint32_t *contrib;
+    const int32_t *recv;
+    int RS, c, world, reduction;
+    uint32_t *slot_owned;
+    int64_t *keys_o, *first_o;
+    int32_t *cnt_o;
+    float *agg_o;
+    __device__ u64 value(int64_t s) const { return tkey[s] != kFree ? 1ull : 0ull; }
+    __device__ u64 value2(int64_t s) const { return value(s); }
+    __device__ void apply(int64_t s, u64 v, u64 excl) const
+    {
+        if (!v) return;
+        const uint32_t o = (uint32_t)excl;
+        slot_owned[s] = o;
+        int64_t first = INT64_MAX;
+        int32_t cnt = 0;
+        float acc[16];
+        const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
+        const float ident = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+        for (int f = 0; f < c && f < 16; f++) acc[f] = ident;
+        for (int q = 0; q < world; q++) {         // rank order: the same sums whatever the arrival order
+            const uint32_t ri = contrib[(u64)s * world + q];
+            if (!ri) continue;
+            const int32_t *r = recv + (size_t)(ri - 1) * RS;
+            const int64_t f0 = *reinterpret_cast<const int64_t *>(r + 2);
+            first = f0 < first ? f0 : first;
+            cnt += r[4];
+            for (int f = 0; f < c && f < 16; f++) {
+                const float x = __int_as_float(r[5 + f]);
+                if (is_sum) acc[f] += x;
+                else if (reduction == D3D_REDUCE_MAX) acc[f] = acc[f] < x ? x : acc[f];
+                else acc[f] = x < acc[f] ? x : acc[f];
+            }
+        }
+        keys_o[o] = (int64_t)tkey[s];
+        first_o[o] = first;
+        cnt_o[o] = cnt;
+        for (int f = 0; f < c && f < 16; f++) agg_o[(size_t)o * c + f] = acc[f];
+    }
+};
+
+__global__ __launch_bounds__(256) void k_merge_recmap(int64_t R, const uint32_t *__restrict__ rec_slot,
+                                                      const uint32_t *__restrict__ slot_owned, int32_t *rec_owned)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) rec_owned[i] = (int32_t)slot_owned[rec_slot[i]];
+}
+
+// ---------------------------------------------------------------- numbering
+__global__ __launch_bounds__(256) void k_first_mark(const int64_t *__restrict__ first_o, const int64_t *__restrict__ counts,
+                                                    int64_t n_total, u64 *bitmap)
+{
+    const int64_t Vo = counts[D3D_COUNT_VOXELS];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Vo) return;
+    const int64_t f = first_o[i];
+    if (f >= 0 && f < n_total) atomicOr(&bitmap[f >> 6], 1ull << (f & 63));
+}
+
+// popcount prefix of two bitmaps at once: hi = all owners' first points (the all-reduced bitmap), lo = this owner's
+struct FirstWords {
+    static constexpr const char *kName = "k_scan_count<FirstWords>", *kName2 = "k_scan_apply<FirstWords>";
+    const u64 *global, *local;
+    u64 *pre;
+    __device__ u64 value(int64_t w) const { return ((u64)__popcll(global[w]) << 32) | (u64)__popcll(local[w]); }
+    __device__ u64 value2(int64_t w) const { return value(w); }
+    __device__ void apply(int64_t w, u64, u64 excl) const { pre[w] = excl; }
+};
+
+// owned voxel -> global voxel id (first-seen order over the whole frame) and its place among this owner's voxels in
+// that order; then its finished row goes there
+__global__ __launch_bounds__(256) void k_owner_finalize(const int64_t *__restrict__ counts_o, const u64 *__restrict__ gbits,
+                                                        const u64 *__restrict__ lbits, const u64 *__restrict__ pre,
+                                                        const int64_t *__restrict__ keys_o, const int64_t *__restrict__ first_o,
+                                                        const int32_t *__restrict__ cnt_o, const float *__restrict__ agg_o, int c,
+                                                        int mean, int64_t sy, int64_t sz, int64_t *vid_of_owned,
+                                                        int32_t *pos_of_owned, int64_t *vids, int64_t *coords, int32_t *npoints,
+                                                        float *feats)
+{
+    const int64_t Vo = counts_o[D3D_COUNT_VOXELS];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Vo) return;
+    const int64_t f = first_o[i];
+    const u64 below = (1ull << (f & 63)) - 1ull, p = pre[f >> 6];
+    const int64_t vid = (int64_t)(p >> 32) + __popcll(gbits[f >> 6] & below);
+    const int64_t pos = (int64_t)(p & 0xffffffffull) + __popcll(lbits[f >> 6] & below);
+    vid_of_owned[i] = vid;
+    pos_of_owned[i] = (int32_t)pos;
+    vids[pos] = vid;
+    const int64_t k = keys_o[i];
+    coords[pos * 3 + 0] = k / (sy * sz);
+    coords[pos * 3 + 1] = (k / sz) % sy;
+    coords[pos * 3 + 2] = k % sz;
+    const int32_t n = cnt_o[i];
+    npoints[pos] = n;
+    const float d = mean ? (float)n : 1.0f;
+    for (int q = 0; q < c; q++) feats[pos * c + q] = mean ? agg_o[i * c + q] / d : agg_o[i * c + q];
+}
+
+__global__ __launch_bounds__(256) void k_owner_reply(int64_t R, const int32_t *__restrict__ rec_owned,
+                                                     const int64_t *__restrict__ vid_of_owned, int64_t *reply)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) reply[i] = vid_of_owned[rec_owned[i]];
+}
+
+// the ids that came back, in send order -> id of every local voxel -> id of every local point
+__global__ __launch_bounds__(256) void k_owner_unperm(int64_t Rs, const int32_t *__restrict__ perm, const int64_t *__restrict__ back,
+                                                      int64_t *vid_of_local)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < Rs) vid_of_local[perm[j]] = back[j];
+}
+__global__ __launch_bounds__(256) void k_owner_map(int64_t n, const int64_t *__restrict__ local_map,
+                                                   const int64_t *__restrict__ vid_of_local, int64_t *gmap)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t v = local_map[i];
+    gmap[i] = v < 0 ? -1 : vid_of_local[v];
+}
+
+// replicate: rows of all owners (any order) -> voxel-id order
+__global__ __launch_bounds__(256) void k_owner_replicate(int64_t V, const int64_t *__restrict__ vids,
+                                                         const int64_t *__restrict__ coords_in, const int32_t *__restrict__ cnt_in,
+                                                         const float *__restrict__ feats_in, int c, int64_t *coords, int32_t *cnt,
+                                                         float *feats)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const int64_t v = vids[i];
+    coords[v * 3] = coords_in[i * 3]; coords[v * 3 + 1] = coords_in[i * 3 + 1]; coords[v * 3 + 2] = coords_in[i * 3 + 2];
+    cnt[v] = cnt_in[i];
+    for (int q = 0; q < c; q++) feats[v * c + q] = feats_in[i * c + q];
+}
+
+inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)std::max<int64_t>(1, d3d_divup(n, per)); }
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" int d3d_owner_record_words(int32_t c) { return rec_stride(c); }
+
+extern "C" size_t d3d_owner_pack_workspace_bytes(int64_t n, int32_t world)
+{
+    const int64_t ntiles = d3d_divup(n > 0 ? n : 1, kPackTile);
+    return d3d_align_up((size_t)ntiles * world * 4) + d3d_align_up((size_t)(world + 1) * 4) + 256;
+}
+
+// local voxels (outputs of d3d_voxelize_3d_reduce: keys[n + 1], cnt[n], agg[n, c], first[n], counts) -> records grouped by
+// owner rank: send[n, d3d_owner_record_words(c)] (int32 words), perm[n] (send position -> local voxel),
+// send_counts[world + 1] (device; records per destination, then the shard's status bits)
+extern "C" int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const float *agg, const int64_t *first,
+                              const int64_t *counts, int64_t n, int32_t c, int32_t world, int32_t *send, int32_t *perm,
+                              int64_t *send_counts, void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !send_counts) return D3D_ERR_BAD_ARG;
+    if (n > 0 && (!keys || !cnt || !agg || !first || !send || !perm)) return D3D_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < d3d_owner_pack_workspace_bytes(n, world)) return D3D_ERR_WORKSPACE;
+    const uint32_t ntiles = (uint32_t)d3d_divup(n > 0 ? n : 1, kPackTile);
+    WsCarver w(workspace, workspace_bytes);
+    uint32_t *tilecnt = w.take<uint32_t>((size_t)ntiles * world);
+    uint32_t *dest_base = w.take<uint32_t>(world + 1);
+    if (n > 0) D3D_LAUNCH("k_owner_count", k_owner_count, dim3(ntiles), dim3(256), 0, st, keys, counts, (uint32_t)world, tilecnt);
+    else D3D_HIP_CHECK(hipMemsetAsync(tilecnt, 0, (size_t)ntiles * world * 4, st));
+    D3D_LAUNCH("k_owner_offsets", k_owner_offsets, dim3(1), dim3(1024), 0, st, tilecnt, ntiles, (uint32_t)world, send_counts,
+               dest_base, keys ? keys + n : (const int64_t *)nullptr);
+    if (n > 0)
+        D3D_LAUNCH("k_owner_scatter", k_owner_scatter, dim3(ntiles), dim3(256), 0, st, keys, cnt, agg, first, counts, (int)c,
+                   (uint32_t)world, tilecnt, dest_base, send, perm);
+    return D3D_OK;
+}
+
+extern "C" size_t d3d_owner_merge_workspace_bytes(int64_t R, int32_t world)
+{
+    return carve_merge(nullptr, 0, R > 0 ? R : 0, world).bytes + 256;
+}
+
+// received records recv[R, words] (grouped by source rank: src_off[world + 1], device) -> this owner's voxels, in table
+// order: keys_o / first_o / cnt_o / agg_o [R rows, counts[0] valid], rec_owned[R] = the owned voxel of every record.
+// reduction: MEAN or 4 (sums), MAX, MIN.
+extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *src_off, int32_t world, int32_t c, int32_t reduction,
+                               int64_t *keys_o, int64_t *first_o, int32_t *cnt_o, float *agg_o, int32_t *rec_owned,
+                               int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (R < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !src_off) return D3D_ERR_BAD_ARG;
+    if (R >= (1ll << 31)) return D3D_ERR_BAD_ARG;
+    if (R > 0 && (!recv || !keys_o || !first_o || !cnt_o || !agg_o || !rec_owned)) return D3D_ERR_BAD_ARG;
+    MergeWs m = carve_merge(workspace, workspace_bytes, R, world);
+    if (!workspace || m.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
+    D3D_HIP_CHECK(hipMemsetAsync(counts, 0, D3D_NUM_COUNTS * sizeof(int64_t), st));
+    D3D_LAUNCH("k_merge_init", k_merge_init, dim3(blocks_for((int64_t)m.cap * world, 256 * 8)), dim3(256), 0, st, m.tkey, m.contrib,
+               m.cap, (int)world);
+    if (R > 0)
+        D3D_LAUNCH("k_merge_insert", k_merge_insert, dim3(blocks_for(R)), dim3(256), 0, st, recv, R, rec_stride(c), src_off, (int)world,
+                   m.tkey, m.cap - 1, m.contrib, m.rec_slot);
+    MergeSlots f{m.tkey, m.contrib, recv, rec_stride(c), (int)c, (int)world, (int)reduction, m.slot_owned, keys_o, first_o, cnt_o, agg_o};
+    int rc = d3d_run_scan(f, (int64_t)m.cap, m.bsum, counts, -1, D3D_COUNT_VOXELS, ~0ull, st);
+    if (rc) return rc;
+    if (R > 0) D3D_LAUNCH("k_merge_recmap", k_merge_recmap, dim3(blocks_for(R)), dim3(256), 0, st, R, m.rec_slot, m.slot_owned, rec_owned);
+    return D3D_OK;
+}
+
+// bit f of bitmap[(n_total + 63) / 64] set for every owned voxel's first point f (the words are cleared here)
+extern "C" int d3d_owner_mark_first(const int64_t *first_o, const int64_t *counts_o, int64_t cap_o, int64_t n_total,
+                                    uint64_t *bitmap, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (cap_o < 0 || n_total < 0 || !bitmap || !counts_o) return D3D_ERR_BAD_ARG;
+    D3D_HIP_CHECK(hipMemsetAsync(bitmap, 0, (size_t)d3d_divup(n_total > 0 ? n_total : 1, 64) * 8, st));
+    if (cap_o > 0)
+        D3D_LAUNCH("k_first_mark", k_first_mark, dim3(blocks_for(cap_o)), dim3(256), 0, st, first_o, counts_o, n_total, (u64 *)bitmap);
+    return D3D_OK;
+}
+
+extern "C" size_t d3d_owner_finalize_workspace_bytes(int64_t n_total)
+{
+    const int64_t nw = d3d_divup(n_total > 0 ? n_total : 1, 64);
+    return d3d_align_up((size_t)nw * 8) + d3d_align_up((size_t)(d3d_divup(nw, kScanTile) + 1) * 8) + 256;
+}
+
+// global_bits = the SUM all-reduce of every owner's d3d_owner_mark_first bitmap (disjoint bits: their OR), local_bits = this
+// owner's.  Numbers the owned voxels (first-seen order over the whole frame, voxelize.cpp:119) and writes their finished rows
+// in that order: vids / coords / npoints / feats [cap_o rows, counts_o[0] valid]; vid_of_owned / pos_of_owned in table order.
+// counts_out[D3D_COUNT_VOXELS] = voxels of the whole frame, counts_out[D3D_COUNT_POINTS] = owned voxels.
+extern "C" int d3d_owner_finalize(const uint64_t *global_bits, const uint64_t *local_bits, int64_t n_total, const int64_t *keys_o,
+                                  const int64_t *first_o, const int32_t *cnt_o, const float *agg_o, const int64_t *counts_o,
+                                  int64_t cap_o, int32_t c, int32_t mean, const int32_t *shape, int64_t *vid_of_owned,
+                                  int32_t *pos_of_owned, int64_t *vids, int64_t *coords, int32_t *npoints, float *feats,
+                                  int64_t *counts_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n_total < 0 || cap_o < 0 || c < 1 || !shape || !counts_o || !counts_out || !global_bits || !local_bits) return D3D_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < d3d_owner_finalize_workspace_bytes(n_total)) return D3D_ERR_WORKSPACE;
+    const int64_t nw = d3d_divup(n_total > 0 ? n_total : 1, 64);
+    WsCarver w(workspace, workspace_bytes);
+    u64 *pre = w.take<u64>(nw);
+    u64 *bsum = w.take<u64>(d3d_divup(nw, kScanTile) + 1);
+    D3D_HIP_CHECK(hipMemsetAsync(counts_out, 0, D3D_NUM_COUNTS * sizeof(int64_t), st));
+    FirstWords f{(const u64 *)global_bits, (const u64 *)local_bits, pre};
+    int rc = d3d_run_scan(f, nw, bsum, counts_out, D3D_COUNT_VOXELS, D3D_COUNT_POINTS, ~0ull, st);
+    if (rc) return rc;
+    if (cap_o > 0)
+        D3D_LAUNCH("k_owner_finalize", k_owner_finalize, dim3(blocks_for(cap_o)), dim3(256), 0, st, counts_o, (const u64 *)global_bits,
+                   (const u64 *)local_bits, pre, keys_o, first_o, cnt_o, agg_o, (int)c, (int)mean, (int64_t)shape[1], (int64_t)shape[2],
+                   vid_of_owned, pos_of_owned, vids, coords, npoints, feats);
+    return D3D_OK;
+}
+
+// reply[i] = global voxel id of received record i (sent back to the record's source rank)
+extern "C" int d3d_owner_reply(int64_t R, const int32_t *rec_owned, const int64_t *vid_of_owned, int64_t *reply, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (R < 0) return D3D_ERR_BAD_ARG;
+    if (R > 0) D3D_LAUNCH("k_owner_reply", k_owner_reply, dim3(blocks_for(R)), dim3(256), 0, st, R, rec_owned, vid_of_owned, reply);
+    return D3D_OK;
+}
+
+// back[Rs] = the ids returned for this rank's records, in send order; perm as left by d3d_owner_pack; local_map[n] =
+// point -> local voxel (d3d_voxelize_3d_reduce).  -> gmap[n] global voxel id per point; vid_of_local[Rs] scratch.
+extern "C" int d3d_owner_map(int64_t n, const int64_t *local_map, int64_t Rs, const int32_t *perm, const int64_t *back,
+                             int64_t *vid_of_local, int64_t *gmap, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || Rs < 0) return D3D_ERR_BAD_ARG;
+    if (Rs > 0) D3D_LAUNCH("k_owner_unperm", k_owner_unperm, dim3(blocks_for(Rs)), dim3(256), 0, st, Rs, perm, back, vid_of_local);
+    if (n > 0) D3D_LAUNCH("k_owner_map", k_owner_map, dim3(blocks_for(n)), dim3(256), 0, st, n, local_map, vid_of_local, gmap);
+    return D3D_OK;
+}
+
+// all owners' finished rows (concatenated in any order) -> the replicated feature grid in voxel-id order
+extern "C" int d3d_owner_replicate(int64_t V, const int64_t *vids, const int64_t *coords_in, const int32_t *cnt_in,
+                                   const float *feats_in, int32_t c, int64_t *coords, int32_t *cnt, float *feats, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (V < 0 || c < 1) return D3D_ERR_BAD_ARG;
+    if (V > 0)
+        D3D_LAUNCH("k_owner_replicate", k_owner_replicate, dim3(blocks_for(V)), dim3(256), 0, st, V, vids, coords_in, cnt_in, feats_in,
+                   (int)c, coords, cnt, feats);
+    return D3D_OK;
+}

@@ -69,6 +69,19 @@ class TorchComm:
         self._dist.all_reduce(t, op=ops[op], group=self.group)
         return t
 
+    def exchange_counts(self, counts):
+        """counts: int64[k] on the device, one row per rank -> the world x k matrix on the host (a host synchronisation)"""
+        out = torch.empty((self.world, counts.numel()), dtype=torch.int64, device=counts.device)
+        self._dist.all_gather_into_tensor(out, counts.contiguous(), group=self.group)
+        return out.tolist()
+
+    def all_to_all(self, send, send_counts, recv_counts):
+        """rows of `send` grouped by destination (send_counts rows each) -> rows grouped by source (recv_counts)"""
+        out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        self._dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts),
+                                     input_split_sizes=list(send_counts), group=self.group)
+        return out
+
 
 class LocalComm:
     """world of one rank: the sharded operator without torch.distributed (single-GPU feature grid; bench.py's
@@ -83,6 +96,12 @@ class LocalComm:
 
     def all_reduce(self, t, op):
         return t
+
+    def exchange_counts(self, counts):
+        return [counts.tolist()]
+
+    def all_to_all(self, send, send_counts, recv_counts):
+        return send
 
 
 class HipOps:
@@ -259,6 +278,112 @@ class HipOps:
             _lib.check(rc, "sharded_finalize")
         return coords, cnt, feats, vid
 
+    # ---- owner-computes exchange (owner.hip) ----
+    def owner_pack(self, keys, cnt, agg, first, counts, n, c, world):
+        """local voxels -> records grouped by owner rank: send[n, words] int32, perm[n], send_counts[world + 1] (device)"""
+        lib = _lib.load()
+        dev = keys.device
+        words = lib.d3d_owner_record_words(c)
+        with torch.cuda.device(dev):
+            send = torch.empty((n, words), dtype=torch.int32, device=dev)
+            perm = torch.empty((n,), dtype=torch.int32, device=dev)
+            sc = torch.empty((world + 1,), dtype=torch.int64, device=dev)
+            ws = torch.empty((lib.d3d_owner_pack_workspace_bytes(n, world),), dtype=torch.uint8, device=dev)
+            rc = lib.d3d_owner_pack(_lib.ptr(keys), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first), _lib.ptr(counts), n, c, world,
+                                    _lib.ptr(send), _lib.ptr(perm), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "owner_pack")
+        return send, perm, sc
+
+    def owner_merge(self, recv, recv_counts, world, c, reduction):
+        """records grouped by source rank -> this owner's voxels (table order): keys, first, cnt, agg, rec_owned, counts"""
+        lib = _lib.load()
+        dev = recv.device
+        R = int(recv.shape[0])
+        off = [0]
+        for k in recv_counts:
+            off.append(off[-1] + int(k))
+        with torch.cuda.device(dev):
+            src_off = torch.tensor(off, dtype=torch.int64, device=dev)
+            keys_o = torch.empty((R,), dtype=torch.int64, device=dev)
+            first_o = torch.empty((R,), dtype=torch.int64, device=dev)
+            cnt_o = torch.empty((R,), dtype=torch.int32, device=dev)
+            agg_o = torch.empty((R, c), dtype=torch.float32, device=dev)
+            rec_owned = torch.empty((R,), dtype=torch.int32, device=dev)
+            counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+            ws = torch.empty((lib.d3d_owner_merge_workspace_bytes(R, world),), dtype=torch.uint8, device=dev)
+            rc = lib.d3d_owner_merge(_lib.ptr(recv), R, _lib.ptr(src_off), world, c, int(reduction), _lib.ptr(keys_o),
+                                     _lib.ptr(first_o), _lib.ptr(cnt_o), _lib.ptr(agg_o), _lib.ptr(rec_owned), _lib.ptr(counts),
+                                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "owner_merge")
+        return keys_o, first_o, cnt_o, agg_o, rec_owned, counts
+
+    def owner_mark_first(self, first_o, counts_o, n_total):
+        """-> int64 words of the bitmap over the frame's point indices with this owner's first points set"""
+        lib = _lib.load()
+        dev = first_o.device
+        with torch.cuda.device(dev):
+            bits = torch.empty(((max(n_total, 1) + 63) // 64,), dtype=torch.int64, device=dev)
+            rc = lib.d3d_owner_mark_first(_lib.ptr(first_o), _lib.ptr(counts_o), first_o.numel(), n_total, _lib.ptr(bits),
+                                          _lib.stream_ptr())
+            _lib.check(rc, "owner_mark_first")
+        return bits
+
+    def owner_finalize(self, gbits, lbits, n_total, keys_o, first_o, cnt_o, agg_o, counts_o, c, mean, shape):
+        """-> vid_of_owned, vids, coords, npoints, feats (owned rows in id order; R rows allocated), counts_out (device)"""
+        lib = _lib.load()
+        dev = keys_o.device
+        R = int(keys_o.numel())
+        shape_h = (ctypes.c_int32 * 3)(*[int(x) for x in shape])
+        with torch.cuda.device(dev):
+            vid_of = torch.empty((R,), dtype=torch.int64, device=dev)
+            pos_of = torch.empty((R,), dtype=torch.int32, device=dev)
+            vids = torch.empty((R,), dtype=torch.int64, device=dev)
+            coords = torch.empty((R, 3), dtype=torch.int64, device=dev)
+            npoints = torch.empty((R,), dtype=torch.int32, device=dev)
+            feats = torch.empty((R, c), dtype=torch.float32, device=dev)
+            counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+            ws = torch.empty((lib.d3d_owner_finalize_workspace_bytes(n_total),), dtype=torch.uint8, device=dev)
+            rc = lib.d3d_owner_finalize(_lib.ptr(gbits), _lib.ptr(lbits), n_total, _lib.ptr(keys_o), _lib.ptr(first_o),
+                                        _lib.ptr(cnt_o), _lib.ptr(agg_o), _lib.ptr(counts_o), R, c, 1 if mean else 0,
+                                        ctypes.cast(shape_h, ctypes.c_void_p), _lib.ptr(vid_of), _lib.ptr(pos_of), _lib.ptr(vids),
+                                        _lib.ptr(coords), _lib.ptr(npoints), _lib.ptr(feats), _lib.ptr(counts), _lib.ptr(ws),
+                                        ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "owner_finalize")
+        return vid_of, pos_of, vids, coords, npoints, feats, counts
+
+    def owner_reply(self, rec_owned, vid_of_owned):
+        lib = _lib.load()
+        R = int(rec_owned.numel())
+        with torch.cuda.device(rec_owned.device):
+            reply = torch.empty((R,), dtype=torch.int64, device=rec_owned.device)
+            _lib.check(lib.d3d_owner_reply(R, _lib.ptr(rec_owned), _lib.ptr(vid_of_owned), _lib.ptr(reply), _lib.stream_ptr()),
+                       "owner_reply")
+        return reply
+
+    def owner_map(self, local_map, perm, back):
+        lib = _lib.load()
+        dev = local_map.device
+        n, rs = int(local_map.numel()), int(back.numel())
+        with torch.cuda.device(dev):
+            gmap = torch.empty((n,), dtype=torch.int64, device=dev)
+            scratch = torch.empty((max(rs, 1),), dtype=torch.int64, device=dev)
+            _lib.check(lib.d3d_owner_map(n, _lib.ptr(local_map), rs, _lib.ptr(perm), _lib.ptr(back), _lib.ptr(scratch),
+                                         _lib.ptr(gmap), _lib.stream_ptr()), "owner_map")
+        return gmap
+
+    def owner_replicate(self, nvox, vids, coords_in, cnt_in, feats_in):
+        lib = _lib.load()
+        dev = vids.device
+        c = int(feats_in.shape[1])
+        with torch.cuda.device(dev):
+            coords = torch.empty((nvox, 3), dtype=torch.int64, device=dev)
+            cnt = torch.empty((nvox,), dtype=torch.int32, device=dev)
+            feats = torch.empty((nvox, c), dtype=torch.float32, device=dev)
+            _lib.check(lib.d3d_owner_replicate(nvox, _lib.ptr(vids), _lib.ptr(coords_in), _lib.ptr(cnt_in), _lib.ptr(feats_in), c,
+                                               _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(feats), _lib.stream_ptr()),
+                       "owner_replicate")
+        return coords, cnt, feats
+
     def compose_map(self, local_map, slot_of_local, nvox, vid_of_slot):
         lib = _lib.load()
         dev = local_map.device
@@ -297,7 +422,7 @@ class ShardedVoxelGenerator:
     """Voxel feature grid of a frame whose points are sharded over the ranks of `group` (contiguous slices in
     rank order).  Grid arguments as d3d.voxel.VoxelGenerator (bounds, shape); reduction in {mean, max, min}."""
 
-    def __init__(self, bounds, shape, reduction="mean", group=None, comm=None, ops=None, exchange="auto"):
+    def __init__(self, bounds, shape, reduction="mean", group=None, comm=None, ops=None, exchange="owner", replicate=True):
         key = (reduction or "").upper()
         if key not in _REDUCTIONS:
             raise ValueError("Unsupported reduction type in VoxelGenerator!")
@@ -309,9 +434,17 @@ class ShardedVoxelGenerator:
         self._ncells = self._shape[0] * self._shape[1] * self._shape[2]
         self._comm = comm if comm is not None else TorchComm(group)
         self._ops = ops if ops is not None else HipOps()
-        if exchange not in ("auto", "keys", "bitmap"):
-            raise ValueError("exchange must be auto, keys or bitmap")
-        self._exchange = exchange        # what the ranks all-gather to agree on the occupied cells
+        if exchange not in ("owner", "auto", "keys", "bitmap"):
+            raise ValueError("exchange must be owner, auto, keys or bitmap")
+        # "owner" (default): owner-computes -- partial voxel records go to the cell's owner rank (all-to-all), which merges,
+        # numbers and finishes 1/world of the frame's voxels; per-rank work scales with the shard.  replicate=False then
+        # returns each rank's OWNED voxels (in global id order, with their ids) instead of all-gathering the grid.
+        # "keys" / "bitmap" / "auto": the replicated-grid exchanges (all-gather of the occupied cells + all-reduce of a
+        # compact table every rank finalises in full).
+        self._exchange = exchange
+        self._replicate = bool(replicate)
+        if not self._replicate and exchange != "owner":
+            raise ValueError("replicate=False needs exchange='owner'")
         self.last_stats = None
 
     def _layout(self, n, dev):
@@ -322,11 +455,63 @@ class ShardedVoxelGenerator:
         return sum(sizes[:self._comm.rank]), sum(sizes), max(max(sizes), 1)
 
     def __call__(self, points):
+        run = self._run_owner if self._exchange == "owner" else self._run
         for plain in (False, True):
-            out = self._run(points, plain)
+            out = run(points, plain)
             if out is not None:
                 return out
         raise RuntimeError("sharded voxelization failed")
+
+    def _run_owner(self, points, plain):
+        """owner-computes exchange (module docstring of owner.hip).  Host synchronisations: the 8-byte size all-gather, the
+        world x (world + 1) record-count matrix, and the voxel counts at the end."""
+        comm, ops = self._comm, self._ops
+        dev = points.device
+        n, c = points.shape
+        W = comm.world
+        offset, n_total, _ = self._layout(n, dev)
+        mean = self._red == 1
+        kw = {"plain": True} if plain else {}
+        _, cnt_r, agg_r, first_r, map_r, keys_r, counts_r = ops.voxelize_reduce(
+            points, self._shape, self._bounds, _SUM if mean else self._red, offset, **kw)
+        send, perm, sc_dev = ops.owner_pack(keys_r, cnt_r, agg_r, first_r, counts_r, n, c, W)
+        mat = comm.exchange_counts(sc_dev)                      # [src][dst] records, [src][W] status bits
+        status = 0
+        for row in mat:
+            status |= int(row[W])
+        if status & _lib.STATUS_TABLE_FULL:
+            raise RuntimeError("voxelize_3d_reduce: internal hash table overflow")
+        if status & (_lib.STATUS_PACK_OVERFLOW | _lib.STATUS_BIN_OVERFLOW) and not plain:
+            return None        # some rank hit a capacity limit of the fast index (rare): all ranks redo on the general path
+        sc = [int(x) for x in mat[comm.rank][:W]]
+        rc = [int(mat[s][comm.rank]) for s in range(W)]
+        recv = comm.all_to_all(send[:sum(sc)], sc, rc)
+        keys_o, first_o, cnt_o, agg_o, rec_owned, counts_o = ops.owner_merge(recv, rc, W, c, _SUM if mean else self._red)
+        lbits = ops.owner_mark_first(first_o, counts_o, n_total)
+        gbits = comm.all_reduce(lbits.clone(), "sum")           # disjoint bit sets: their sum is their OR
+        vid_of, _, vids, coords, npoints, feats, counts_out = ops.owner_finalize(
+            gbits, lbits, n_total, keys_o, first_o, cnt_o, agg_o, counts_o, c, mean, self._shape)
+        back = comm.all_to_all(ops.owner_reply(rec_owned, vid_of), rc, sc)
+        gmap = ops.owner_map(map_r, perm, back)
+        host = counts_out.tolist()
+        nvox, nown = int(host[_lib.COUNT_VOXELS]), int(host[_lib.COUNT_POINTS])
+        words = int(send.shape[1])
+        self.last_stats = dict(
+            exchange="owner", numbering="first-point bitmap", voxels=nvox, owned_voxels=nown, ranks=W,
+            all_to_all_bytes_sent=(sum(sc) - sc[comm.rank]) * 4 * words, all_to_all_bytes_received=(sum(rc) - rc[comm.rank]) * 4 * words,
+            reply_bytes_sent=(sum(rc) - rc[comm.rank]) * 8, all_reduce_bytes=int(lbits.numel()) * 8,
+            all_gather_bytes_per_rank=nown * (8 + 24 + 4 + 4 * c) if self._replicate else 0)
+        vids, coords, npoints, feats = vids[:nown], coords[:nown], npoints[:nown], feats[:nown]
+        if not self._replicate:
+            return Dict(coords=coords, voxel_npoints=npoints, aggregates=feats, voxel_ids=vids, points_mapping=gmap,
+                        num_voxels=nvox)
+        sizes = comm.all_gather_int(nown, dev)
+        packed = torch.cat([vids.view(-1, 1), coords, npoints.to(torch.int64).view(-1, 1)], 1)      # one int64 gather
+        packed = comm.all_gather_var(packed.reshape(-1), [5 * k for k in sizes]).view(-1, 5)
+        feats_all = comm.all_gather_var(feats.reshape(-1), [c * k for k in sizes]).view(-1, c)
+        coords_f, cnt_f, feats_f = ops.owner_replicate(nvox, packed[:, 0].contiguous(), packed[:, 1:4].contiguous(),
+                                                        packed[:, 4].to(torch.int32).contiguous(), feats_all)
+        return Dict(coords=coords_f, voxel_npoints=cnt_f, aggregates=feats_f, points_mapping=gmap)
 
     def _run(self, points, plain):
         comm, ops = self._comm, self._ops

@@ -242,6 +242,48 @@ int d3d_sharded_finalize(int64_t nvox, int32_t c, const int64_t *first, int64_t 
 int d3d_sharded_map(int64_t n, const int64_t *local_map, const int64_t *slot_of_local, int64_t nvox,
                     const int64_t *vid_of_slot, int64_t *gmap, void *stream);
 
+/* ---- point-sharded voxelizer, owner-computes exchange (owner.hip; d3d_amd/voxel/sharded.py drives it) ----
+ * Every grid cell has one owner rank (a hash of the cell).  A rank sends the partial record of each of its local voxels to
+ * the cell's owner (all-to-all), the owner merges the <= world records of a cell in rank order, numbers its voxels in the
+ * frame's first-seen order (voxelize.cpp:119) from a one-bit-per-point bitmap whose SUM all-reduce is the OR of the owners'
+ * disjoint bit sets, and finishes 1/world of the frame's voxels.  A record is d3d_owner_record_words(c) int32 words:
+ * cell key (2), first global point index (2), count (1), c partial features (float bits), padding to an even count. */
+int    d3d_owner_record_words(int32_t c);
+size_t d3d_owner_pack_workspace_bytes(int64_t n, int32_t world);
+/* outputs of d3d_voxelize_3d_reduce (keys[n + 1], cnt[n], agg[n, c], first[n], its counts) -> send[n, words] grouped by owner
+ * rank, perm[n] (send position -> local voxel), send_counts[world + 1] (device: records per destination, then the shard's
+ * status bits). */
+int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const float *agg, const int64_t *first, const int64_t *counts,
+                   int64_t n, int32_t c, int32_t world, int32_t *send, int32_t *perm, int64_t *send_counts,
+                   void *workspace, size_t workspace_bytes, void *stream);
+size_t d3d_owner_merge_workspace_bytes(int64_t n_records, int32_t world);
+/* recv[R, words] grouped by source rank (src_off[world + 1], device) -> this owner's voxels in table order: keys_o / first_o /
+ * cnt_o / agg_o (R rows, counts[D3D_COUNT_VOXELS] valid) and rec_owned[R] = owned voxel of every record.  reduction: MEAN
+ * or 4 (sums, in rank order), MAX, MIN. */
+int d3d_owner_merge(const int32_t *recv, int64_t n_records, const int64_t *src_off, int32_t world, int32_t c, int32_t reduction,
+                    int64_t *keys_o, int64_t *first_o, int32_t *cnt_o, float *agg_o, int32_t *rec_owned, int64_t *counts,
+                    void *workspace, size_t workspace_bytes, void *stream);
+/* bitmap[(n_total + 63) / 64] <- bit f for every owned voxel's first point f */
+int d3d_owner_mark_first(const int64_t *first_o, const int64_t *counts_o, int64_t cap_o, int64_t n_total, uint64_t *bitmap,
+                         void *stream);
+size_t d3d_owner_finalize_workspace_bytes(int64_t n_total);
+/* global_bits = SUM all-reduce of all owners' bitmaps, local_bits = this owner's.  Owned voxels -> their global ids and
+ * their finished rows in id order: vids / coords / npoints / feats (cap_o rows); vid_of_owned / pos_of_owned in table order;
+ * counts_out[D3D_COUNT_VOXELS] = voxels of the frame, counts_out[D3D_COUNT_POINTS] = owned voxels. */
+int d3d_owner_finalize(const uint64_t *global_bits, const uint64_t *local_bits, int64_t n_total, const int64_t *keys_o,
+                       const int64_t *first_o, const int32_t *cnt_o, const float *agg_o, const int64_t *counts_o, int64_t cap_o,
+                       int32_t c, int32_t mean, const int32_t *shape, int64_t *vid_of_owned, int32_t *pos_of_owned,
+                       int64_t *vids, int64_t *coords, int32_t *npoints, float *feats, int64_t *counts_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* reply[i] = global voxel id of received record i (returned to the record's source rank by the reverse all-to-all) */
+int d3d_owner_reply(int64_t n_records, const int32_t *rec_owned, const int64_t *vid_of_owned, int64_t *reply, void *stream);
+/* back[n_sent] (ids returned, in send order), perm (d3d_owner_pack), local_map[n] (point -> local voxel) -> gmap[n] */
+int d3d_owner_map(int64_t n, const int64_t *local_map, int64_t n_sent, const int32_t *perm, const int64_t *back,
+                  int64_t *vid_of_local, int64_t *gmap, void *stream);
+/* all owners' finished rows, concatenated in any order -> the replicated feature grid in voxel-id order */
+int d3d_owner_replicate(int64_t nvox, const int64_t *vids, const int64_t *coords_in, const int32_t *cnt_in,
+                        const float *feats_in, int32_t c, int64_t *coords, int32_t *cnt, float *feats, void *stream);
+
 /* ------------------------------------------------------------------ d3d/point ("next" row) */
 
 /* replaces aligned_scatter_forward[_cuda] / aligned_scatter_backward[_cuda] (reference d3d/point/scatter.h:39-56,
