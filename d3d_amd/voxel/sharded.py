@@ -71,9 +71,9 @@ class TorchComm:
 
     def exchange_counts(self, counts):
         """counts: int64[k] on the device, one row per rank -> the world x k matrix on the host (a host synchronisation)"""
-        out = torch.empty((self.world, counts.numel()), dtype=torch.int64, device=counts.device)
+        out = torch.empty((self.world * counts.numel(),), dtype=torch.int64, device=counts.device)
         self._dist.all_gather_into_tensor(out, counts.contiguous(), group=self.group)
-        return out.tolist()
+        return out.view(self.world, -1).tolist()
 
     def all_to_all(self, send, send_counts, recv_counts):
         """rows of `send` grouped by destination (send_counts rows each) -> rows grouped by source (recv_counts)"""

@@ -167,6 +167,115 @@ class NumpyOps:
             feats[vid] = t[:, :c]
         return torch.from_numpy(coords), torch.from_numpy(cnt), torch.from_numpy(feats), torch.from_numpy(vid)
 
+    # ---- owner-computes exchange: numpy twins of owner.hip (same record layout, any deterministic owner function) ----
+    @staticmethod
+    def _owner(keys, world):
+        h = keys.astype(np.uint64)
+        with np.errstate(over="ignore"):
+            h ^= h >> np.uint64(33); h *= np.uint64(0xff51afd7ed558ccd)
+            h ^= h >> np.uint64(33); h *= np.uint64(0xc4ceb9fe1a85ec53)
+            h ^= h >> np.uint64(33)
+        return (((h >> np.uint64(32)) * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
+
+    def owner_pack(self, keys, cnt, agg, first, counts, n, c, world):
+        v = int(counts[0])
+        k = keys.numpy()[:v]
+        words = (5 + c + 1) & ~1
+        own = self._owner(k, world)
+        perm = np.argsort(own, kind="stable").astype(np.int32)
+        send = np.zeros((n, words), np.int32)
+        rec = send[:v]
+        rec[:, 0:2] = k[perm].astype(np.int64).reshape(-1, 1).view(np.int32)
+        rec[:, 2:4] = first.numpy()[:v][perm].reshape(-1, 1).view(np.int32)
+        rec[:, 4] = cnt.numpy()[:v][perm]
+        rec[:, 5:5 + c] = agg.numpy()[:v][perm].view(np.int32)
+        sc = np.zeros((world + 1,), np.int64)
+        sc[:world] = np.bincount(own, minlength=world)
+        sc[world] = -1 - int(keys.numpy()[n])
+        full_perm = np.zeros((n,), np.int32)
+        full_perm[:v] = perm
+        return torch.from_numpy(send), torch.from_numpy(full_perm), torch.from_numpy(sc)
+
+    def owner_merge(self, recv, recv_counts, world, c, reduction):
+        r = recv.numpy()
+        R = len(r)
+        keys = np.ascontiguousarray(r[:, 0:2]).view(np.int64).reshape(-1)
+        first = np.ascontiguousarray(r[:, 2:4]).view(np.int64).reshape(-1)
+        cnt = r[:, 4].copy()
+        agg = np.ascontiguousarray(r[:, 5:5 + c]).view(np.float32)
+        uniq, inv = np.unique(keys, return_inverse=True)          # records arrive grouped by source rank, in rank order
+        vo = len(uniq)
+        red = int(reduction)
+        ident = 0.0 if red in (1, 4) else (-np.inf if red == 2 else np.inf)
+        agg_o = np.full((R, c), ident, np.float32)
+        cnt_o = np.zeros((R,), np.int32)
+        first_o = np.full((R,), np.iinfo(np.int64).max, np.int64)
+        for i in range(R):                                        # sequential = rank order
+            o = inv[i]
+            if red in (1, 4):
+                agg_o[o] = agg_o[o] + agg[i]
+            elif red == 2:
+                agg_o[o] = np.maximum(agg_o[o], agg[i])
+            else:
+                agg_o[o] = np.minimum(agg_o[o], agg[i])
+            cnt_o[o] += cnt[i]
+            first_o[o] = min(first_o[o], first[i])
+        keys_o = np.zeros((R,), np.int64)
+        keys_o[:vo] = uniq
+        t = torch.from_numpy
+        return (t(keys_o), t(first_o), t(cnt_o), t(agg_o), t(inv.astype(np.int32)),
+                torch.tensor([vo, 0, 0, 0], dtype=torch.int64))
+
+    def owner_mark_first(self, first_o, counts_o, n_total):
+        nw = (max(n_total, 1) + 63) // 64
+        bits = np.zeros((nw * 64,), np.uint8)
+        bits[first_o.numpy()[:int(counts_o[0])]] = 1
+        return torch.from_numpy(np.packbits(bits.reshape(nw, 64), axis=1, bitorder="little").view("<u8").reshape(nw).view(np.int64).copy())
+
+    def owner_finalize(self, gbits, lbits, n_total, keys_o, first_o, cnt_o, agg_o, counts_o, c, mean, shape):
+        def unpack(b):
+            w = b.numpy().view(np.uint64)
+            return np.unpackbits(w.view(np.uint8).reshape(-1, 8), axis=1, bitorder="little").reshape(-1).astype(np.int64)
+        g, l = unpack(gbits), unpack(lbits)
+        gpre, lpre = np.cumsum(g) - g, np.cumsum(l) - l
+        vo = int(counts_o[0])
+        R = len(keys_o)
+        f = first_o.numpy()[:vo]
+        vid, pos = gpre[f], lpre[f]
+        k = keys_o.numpy()[:vo]
+        sy, sz = shape[1], shape[2]
+        vids = np.zeros((R,), np.int64); coords = np.zeros((R, 3), np.int64)
+        npoints = np.zeros((R,), np.int32); feats = np.zeros((R, c), np.float32)
+        vids[pos] = vid
+        coords[pos] = np.stack([k // (sy * sz), (k // sz) % sy, k % sz], 1)
+        npoints[pos] = cnt_o.numpy()[:vo]
+        a = agg_o.numpy()[:vo]
+        feats[pos] = a / cnt_o.numpy()[:vo, None].astype(np.float32) if mean else a
+        vid_of = np.zeros((R,), np.int64); vid_of[:vo] = vid
+        pos_of = np.zeros((R,), np.int32); pos_of[:vo] = pos
+        t = torch.from_numpy
+        return (t(vid_of), t(pos_of), t(vids), t(coords), t(npoints), t(feats),
+                torch.tensor([int(g.sum()), int(l.sum()), 0, 0], dtype=torch.int64))
+
+    def owner_reply(self, rec_owned, vid_of_owned):
+        return vid_of_owned[rec_owned.long()]
+
+    def owner_map(self, local_map, perm, back):
+        m = local_map.numpy()
+        vid_of_local = np.zeros((max(len(back), 1),), np.int64)
+        vid_of_local[perm.numpy()[:len(back)]] = back.numpy()
+        out = np.full(m.shape, -1, np.int64)
+        ok = m >= 0
+        out[ok] = vid_of_local[m[ok]]
+        return torch.from_numpy(out)
+
+    def owner_replicate(self, nvox, vids, coords_in, cnt_in, feats_in):
+        v = vids.numpy()
+        coords = np.zeros((nvox, 3), np.int64); cnt = np.zeros((nvox,), np.int32)
+        feats = np.zeros((nvox, feats_in.shape[1]), np.float32)
+        coords[v] = coords_in.numpy(); cnt[v] = cnt_in.numpy(); feats[v] = feats_in.numpy()
+        return torch.from_numpy(coords), torch.from_numpy(cnt), torch.from_numpy(feats)
+
     def compose_map(self, local_map, slot_of_local, nvox, vid_of_slot):
         m = local_map.numpy()
         out = np.full(m.shape, -1, np.int64)
@@ -227,3 +336,15 @@ class _ThreadComm:
         r = st.sum(0) if op == "sum" else (st.max(0).values if op == "max" else st.min(0).values)
         t.copy_(r.to(t.dtype))
         return t
+
+    def exchange_counts(self, counts):
+        return [v.tolist() for v in self._exchange(counts.clone())]
+
+    def all_to_all(self, send, send_counts, recv_counts):
+        off = [0]
+        for k in send_counts:
+            off.append(off[-1] + int(k))
+        parts = self._exchange([send[off[d]:off[d + 1]].clone() for d in range(self.world)])
+        out = torch.cat([parts[s][self.rank] for s in range(self.world)])
+        assert [int(parts[s][self.rank].shape[0]) for s in range(self.world)] == [int(k) for k in recv_counts]
+        return out

@@ -83,32 +83,53 @@ def cfg5():
     """config 5's frame and the oracle's voxel grid for it (8 M points, 3008 x 3008 x 120 cells of 0.05 m)"""
     from d3d_amd import synth
     cloud = synth.lidar_like(8000000, 3, synth.WAYMO_BOUNDS)
-    exp = oracle.voxelize_3d_dense(cloud, synth.WAYMO_SHAPE, synth.WAYMO_BOUNDS, 4, len(cloud), "mean")
+    # at the STATED max_points = 32 (BASELINE.json config 5): the oracle's voxels[V,32,4] is 3 GB of host memory
+    exp = oracle.voxelize_3d_dense(cloud, synth.WAYMO_SHAPE, synth.WAYMO_BOUNDS, 32, len(cloud), "mean")
     return cloud, exp
 
 
-def test_cfg5_single_gpu_dense_contract(cfg5):
-    """config 5's frame on ONE GPU through the dense contract: 1.086 G cells (30-bit linear keys), ~5.9 M voxels"""
-    from d3d_amd import synth
+def _rows_equal(dev_tensor, host_array, chunk=400000):
+    """a multi-GB device tensor against the oracle's array, in row chunks"""
+    assert tuple(dev_tensor.shape) == host_array.shape
+    for a in range(0, len(host_array), chunk):
+        if not np.array_equal(dev_tensor[a:a + chunk].cpu().numpy(), host_array[a:a + chunk], equal_nan=True):
+            return False
+    return True
+
+
+@pytest.mark.parametrize("path", ["auto", "split"])
+def test_cfg5_single_gpu_dense_contract(cfg5, path):
+    """config 5's frame on ONE GPU through the dense contract at max_points = 32: 1.086 G cells (30-bit linear keys), ~5.9 M
+    voxels, 3 GB of voxels[V,32,4] compared in row chunks; output buffers poisoned first.  Both output stages: the fused
+    k_emit and (split) k_meta_first + k_fill_c4<64>."""
+    from d3d_amd import _lib, synth, voxel
     from d3d_amd.voxel import VoxelGenerator
     cloud, exp = cfg5
-    ret = VoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, dense=True, reduction="mean", max_points=4,
-                         max_voxels=len(cloud))(T(cloud))
+    voxel.poison_outputs = True
+    voxel.default_flags = _lib.VOXEL_SPLIT_FILL if path == "split" else 0
+    try:
+        ret = VoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, dense=True, reduction="mean", max_points=32,
+                             max_voxels=len(cloud))(T(cloud))
+    finally:
+        voxel.poison_outputs = False
+        voxel.default_flags = 0
     assert 5000000 < len(exp["coords"]) < 7000000
     assert np.array_equal(ret.coords.cpu().numpy(), exp["coords"])
     assert np.array_equal(ret.voxel_npoints.cpu().numpy(), exp["voxel_npoints"])
-    assert np.array_equal(ret.voxels.cpu().numpy(), exp["voxels"])
-    fit = exp["voxel_npoints"] <= 4
+    assert _rows_equal(ret.voxels, exp["voxels"])
+    pm = ret.voxel_pmask.cpu().numpy()
+    assert np.array_equal(pm, np.arange(32)[None, :] < np.minimum(exp["voxel_npoints"], 32)[:, None])
+    fit = exp["voxel_npoints"] <= 32
     agg = ret.aggregates.cpu().numpy()
     assert np.array_equal(agg[fit], exp["aggregates"][fit])
     np.testing.assert_allclose(agg[~fit], exp["aggregates"][~fit], rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("reduction", ["mean", "max"])
-def test_cfg5_point_sharded_over_8_ranks(cfg5, reduction):
-    """config 5 as stated: rank k holds points [k M, (k+1) M) of the frame; 8 virtual ranks (threads of this process, real
-    kernels, collectives through host-side exchange), exchange="auto" -- which must choose the key exchange on this grid
-    (136 MB bitmap vs 8 MB key lists).  Every rank's replicated result = the oracle's grid of the whole frame."""
+def test_cfg5_point_sharded_owner_computes(cfg5, reduction):
+    """config 5 as stated, owner-computes exchange without the final all-gather (replicate=False): rank k holds points
+    [k M, (k+1) M); 8 virtual ranks (threads, real kernels, host-side collectives).  The ranks' owned voxels partition the
+    oracle's grid of the whole frame: every owned row (coords, count, reduction) equals the oracle's row of that voxel id."""
     from d3d_amd import synth
     from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
     cloud, exp = cfg5
@@ -122,7 +143,61 @@ def test_cfg5_point_sharded_over_8_ranks(cfg5, reduction):
         try:
             torch.cuda.set_device(0)
             gen = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction=reduction, comm=tw.comm(rank),
-                                        exchange="auto", ops=HipOps())
+                                        exchange="owner", replicate=False, ops=HipOps())
+            res = gen(T(cloud[rank * n:(rank + 1) * n]))
+            stats[rank] = gen.last_stats
+            out[rank] = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in res.items()}
+        except Exception:  # pragma: no cover
+            import traceback
+            errs.append(traceback.format_exc())
+            tw.barrier.abort()
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[0]
+    V = len(exp["coords"])
+    assert all(s["exchange"] == "owner" and s["voxels"] == V and s["ranks"] == 8 for s in stats)
+    ids = np.concatenate([out[r]["voxel_ids"] for r in range(world)])
+    assert len(ids) == V and np.array_equal(np.sort(ids), np.arange(V))          # a partition of the frame's voxels
+    assert max(len(out[r]["voxel_ids"]) for r in range(world)) < 1.05 * V / world   # ... in equal shares (the owner hash)
+    for r in range(world):
+        o, k = out[r], out[r]["voxel_ids"]
+        assert np.all(np.diff(k) > 0)
+        assert np.array_equal(o["coords"], exp["coords"][k])
+        assert np.array_equal(o["voxel_npoints"], exp["voxel_npoints"][k])
+        if reduction == "mean":
+            np.testing.assert_allclose(o["aggregates"], exp["aggregates"][k], rtol=1e-5, atol=1e-6)
+        else:
+            assert np.array_equal(o["aggregates"], exp["aggregates"][k])
+    lo = np.array(synth.WAYMO_BOUNDS[0::2], np.float32)
+    size = ((np.array(synth.WAYMO_BOUNDS[1::2], np.float32) - lo) / np.array(synth.WAYMO_SHAPE, np.float32)).astype(np.float32)
+    for r in range(world):
+        m = out[r]["points_mapping"]
+        assert m.min() >= 0
+        cells = ((cloud[r * n:(r + 1) * n, :3] - lo) / size).astype(np.int64)
+        assert np.array_equal(exp["coords"][m], cells)
+
+
+@pytest.mark.parametrize("reduction,exchange", [("mean", "owner"), ("mean", "auto"), ("max", "auto")])
+def test_cfg5_point_sharded_over_8_ranks(cfg5, reduction, exchange):
+    """config 5 as stated: rank k holds points [k M, (k+1) M) of the frame; 8 virtual ranks (threads of this process, real
+    kernels, collectives through host-side exchange).  exchange="owner" with the final all-gather, and the replicated-grid
+    exchange ("auto" must choose the key exchange on this grid: 136 MB bitmap vs 8 MB key lists).  Every rank's replicated
+    result = the oracle's grid of the whole frame."""
+    from d3d_amd import synth
+    from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
+    cloud, exp = cfg5
+    if reduction == "max":
+        exp = oracle.voxelize_3d_dense(cloud, synth.WAYMO_SHAPE, synth.WAYMO_BOUNDS, 1, len(cloud), "max")
+    world, n = 8, 1000000
+    tw = ThreadWorld(world)
+    out, stats, errs = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            gen = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction=reduction, comm=tw.comm(rank),
+                                        exchange=exchange, ops=HipOps())
             res = gen(T(cloud[rank * n:(rank + 1) * n]))
             stats[rank] = gen.last_stats
             # keep only what is compared (8 replicas of the grid are 8 x 0.3 GB)
@@ -140,9 +215,12 @@ def test_cfg5_point_sharded_over_8_ranks(cfg5, reduction):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs[0]
-    assert all(s["exchange"] == "keys" and s["numbering"] == "first-index" and s["ranks"] == 8 for s in stats)
     V = len(exp["coords"])
-    assert stats[0]["voxels"] == V and stats[0]["all_gather_bytes_per_rank"] == 8 * (n + 1)
+    if exchange == "auto":
+        assert all(s["exchange"] == "keys" and s["numbering"] == "first-index" and s["ranks"] == 8 for s in stats)
+        assert stats[0]["voxels"] == V and stats[0]["all_gather_bytes_per_rank"] == 8 * (n + 1)
+    else:
+        assert all(s["exchange"] == "owner" and s["voxels"] == V for s in stats)
     for r in (0, world - 1):
         assert np.array_equal(out[r]["coords"], exp["coords"])
         assert np.array_equal(out[r]["voxel_npoints"], exp["voxel_npoints"])

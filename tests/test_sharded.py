@@ -56,6 +56,27 @@ def _free_port():
     return p
 
 
+def _check_owned(res, cloud_all, my_slice, reduction):
+    """replicate=False: this rank's OWNED voxels, in global id order, equal those rows of the whole frame's grid"""
+    exp = _expected(cloud_all, reduction)
+    ids = res.voxel_ids.cpu().numpy()
+    assert res.num_voxels == len(exp["coords"])
+    assert np.all(np.diff(ids) > 0) if len(ids) > 1 else True
+    assert np.array_equal(res.coords.cpu().numpy(), exp["coords"][ids])
+    assert np.array_equal(res.voxel_npoints.cpu().numpy(), exp["voxel_npoints"][ids])
+    if reduction == "mean":
+        np.testing.assert_allclose(res.aggregates.cpu().numpy(), exp["aggregates"][ids], rtol=1e-5, atol=1e-6)
+    else:
+        assert np.array_equal(res.aggregates.cpu().numpy(), exp["aggregates"][ids])
+    m = res.points_mapping.cpu().numpy()
+    pts = cloud_all[my_slice]
+    inside = m >= 0
+    lo = np.array([0, -40, -3], np.float32)
+    cc = ((pts[inside, :3] - lo) / np.array([0.8, 0.8, 1.0], np.float32)).astype(np.int64)
+    assert np.array_equal(exp["coords"][m[inside]], cc)
+    return ids
+
+
 def _gloo_worker(rank, world, port, reduction, exchange, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -68,6 +89,12 @@ def _gloo_worker(rank, world, port, reduction, exchange, q):
         gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, ops=NumpyOps(), exchange=exchange)
         res = gen(torch.from_numpy(cloud[sl]))
         _check(res, cloud, sl, reduction)
+        if exchange == "owner":     # ... and without the final all-gather: the owned voxels of the ranks partition the grid
+            own = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, ops=NumpyOps(), exchange="owner", replicate=False)
+            ids = _check_owned(own(torch.from_numpy(cloud[sl])), cloud, sl, reduction)
+            allids = [None] * world
+            dist.all_gather_object(allids, ids.tolist())
+            assert sorted(sum(allids, [])) == list(range(len(_expected(cloud, reduction)["coords"])))
         # next frame through the SAME generator: only the last rank's shard size changes (rank 0 keeps its 1100 points).
         # Every rank must still enter the same sequence of collectives and see the new offsets / totals.
         cloud2 = _cloud(2600, 6)
@@ -83,7 +110,7 @@ def _gloo_worker(rank, world, port, reduction, exchange, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("reduction,exchange", [("mean", "keys"), ("max", "bitmap"), ("mean", "bitmap")])
+@pytest.mark.parametrize("reduction,exchange", [("mean", "owner"), ("min", "owner"), ("mean", "keys"), ("max", "bitmap"), ("mean", "bitmap")])
 def test_sharded_orchestration_gloo_world2(reduction, exchange):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -105,7 +132,9 @@ def index_path(request):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,reduction,exchange", [(2, "mean", "keys"), (3, "min", "bitmap"), (4, "max", "keys"),
+@pytest.mark.parametrize("world,reduction,exchange", [(2, "mean", "owner"), (3, "min", "owner"), (4, "max", "owner"),
+                                                     (8, "mean", "owner"), (3, "mean", "owner-empty"), (1, "mean", "owner"),
+                                                     (2, "mean", "keys"), (3, "min", "bitmap"), (4, "max", "keys"),
                                                      (8, "mean", "bitmap"), (2, "mean", "auto"), (3, "mean", "bitmap-empty"),
                                                      (3, "max", "keys-empty")])
 def test_sharded_hip_kernels_virtual_ranks(world, reduction, exchange, index_path):
@@ -140,6 +169,45 @@ def test_sharded_hip_kernels_virtual_ranks(world, reduction, exchange, index_pat
     single = VoxelGenerator(BOUNDS, SHAPE, dense=True, reduction=reduction, max_points=4, max_voxels=len(cloud))(
         torch.from_numpy(cloud).cuda())
     assert torch.equal(single.coords, out[0].coords) and torch.equal(single.voxel_npoints, out[0].voxel_npoints)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,reduction,empty", [(2, "mean", False), (3, "max", True), (8, "min", False), (5, "mean", True)])
+def test_owner_computes_without_replication_virtual_ranks(world, reduction, empty):
+    """replicate=False on the real kernels: every rank returns its owned voxels in global id order; together they are the
+    single-GPU grid.  Ragged shards, optionally a rank without points; repeated calls give identical bits (the merge runs in
+    rank order whatever the arrival order of the records)."""
+    from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
+    cloud = _cloud(50000, 19)
+    cuts = np.linspace(0, len(cloud), world + 1).astype(int)
+    cuts[1] = max(cuts[1] // 3, 1)
+    if empty:
+        cuts[2] = cuts[1]
+    tw, lock = ThreadWorld(world), threading.Lock()
+    out, errs = [[None] * world, [None] * world], []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, comm=tw.comm(rank), exchange="owner", replicate=False,
+                                        ops=LockedOps(HipOps(), lock))
+            for it in range(2):
+                out[it][rank] = gen(torch.from_numpy(cloud[cuts[rank]:cuts[rank + 1]]).cuda())
+        except Exception:  # pragma: no cover
+            import traceback
+            errs.append(traceback.format_exc())
+            tw.barrier.abort()
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[0]
+    ids = []
+    for r in range(world):
+        ids.append(_check_owned(out[0][r], cloud, slice(cuts[r], cuts[r + 1]), reduction))
+        for k in ("coords", "voxel_npoints", "aggregates", "voxel_ids", "points_mapping"):
+            assert torch.equal(out[0][r][k], out[1][r][k]), k
+    allids = np.concatenate(ids)
+    assert np.array_equal(np.sort(allids), np.arange(out[0][0].num_voxels))
 
 
 @pytest.mark.gpu
