@@ -133,7 +133,7 @@ def index_path(request):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,reduction,exchange", [(2, "mean", "owner"), (3, "min", "owner"), (4, "max", "owner"),
-                                                     (8, "mean", "owner"), (3, "mean", "owner-empty"), (1, "mean", "owner"),
+                                                     (8, "mean", "owner"), (3, "mean", "owner-empty"),
                                                      (2, "mean", "keys"), (3, "min", "bitmap"), (4, "max", "keys"),
                                                      (8, "mean", "bitmap"), (2, "mean", "auto"), (3, "mean", "bitmap-empty"),
                                                      (3, "max", "keys-empty")])
