@@ -12,7 +12,9 @@ from sharded_helpers import LockedOps, ThreadWorld
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
-cfg5 = len(sys.argv) > 3 and sys.argv[3] == "config5"        # config 5: Waymo range, 0.05 m voxels, key exchange
+cfg5 = len(sys.argv) > 3 and sys.argv[3] == "config5"        # config 5: Waymo range, 0.05 m voxels
+exchange = sys.argv[4] if len(sys.argv) > 4 else "owner"      # owner | auto | keys | bitmap
+replicate = not (len(sys.argv) > 5 and sys.argv[5] == "noreplicate")
 BOUNDS, SHAPE = (synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE) if cfg5 else (synth.KITTI_BOUNDS, synth.KITTI_SHAPE)
 if cfg5:
     frame = synth.lidar_like(W * n, 3, BOUNDS)
@@ -23,16 +25,21 @@ else:
 def step():
     tw, lock = ThreadWorld(W), threading.Lock()
     outs = [None] * W
+    global stats
+    stats = [None] * W
     def run(rank):
         torch.cuda.set_device(0)
-        gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction="mean", comm=tw.comm(rank), ops=LockedOps(HipOps(), lock))
+        gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction="mean", comm=tw.comm(rank), ops=LockedOps(HipOps(), lock),
+                                    exchange=exchange, replicate=replicate)
         outs[rank] = gen(clouds[rank])
+        stats[rank] = gen.last_stats
     ts = [threading.Thread(target=run, args=(r,)) for r in range(W)]
     [t.start() for t in ts]; [t.join() for t in ts]
     return outs
 
 outs = step()
-print("world", W, "points/rank", n, "global voxels", int(outs[0].coords.shape[0]))
+print("world", W, "points/rank", n, "exchange", exchange, "replicate", replicate, "global voxels", stats[0]["voxels"])
+print("  collective bytes of rank 0:", {k: v for k, v in stats[0].items() if "bytes" in k})
 prof = kernel_profile(step, 3)
 tot = 0.0
 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
