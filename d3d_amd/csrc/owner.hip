@@ -206,48 +206,85 @@ __global__ __launch_bounds__(256) void k_merge_insert(const int32_t *__restrict_
     rec_slot[i] = (uint32_t)h;
 }
 
-// scan over the table's slots: occupied slots are numbered (= the owner's voxels, in slot order) and merged on the spot
-struct MergeSlots {
-    static constexpr const char *kName = "k_scan_count<MergeSlots>", *kName2 = "k_scan_apply<MergeSlots>";
-    const u64 *tkey;
-    const uint32_t *contrib;
+// The shards are contiguous point ranges in rank order, so a cell's first point lies in the LOWEST rank that has the cell,
+// and inside one source's batch the records follow the shard's first-seen order: the "leader" records (lowest source of
+// their cell), taken in receive order, are this owner's voxels in ascending order of first point = ascending global voxel
+// id.  A scan over the RECORDS numbers the leaders; each leader merges its cell's records in rank order and writes the
+// voxel's finished row at its number -- consecutive leaders write consecutive rows (coalesced), and no pass over the table.
+__device__ __forceinline__ int record_source(const int64_t *__restrict__ src_off, int world, int64_t i)
+{
+    int lo = 0, hi = world;                       // the last s with src_off[s] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (src_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+struct MergeRecords {
+    static constexpr const char *kName = "k_scan_count<MergeRecords>", *kName2 = "k_scan_apply<MergeRecords>";
+    const uint32_t *contrib, *rec_slot;
+    const int64_t *src_off;
     const int32_t *recv;
-    int RS, c, world, reduction;
+    int RS, c, world, reduction;         // reduction: MEAN (divide), 4 = sums, MAX, MIN
+    int64_t sy, sz;
     uint32_t *slot_owned;
-    int64_t *keys_o, *first_o;
-    int32_t *cnt_o;
-    float *agg_o;
-    __device__ u64 value(int64_t s) const { return tkey[s] != kFree ? 1ull : 0ull; }
-    __device__ u64 value2(int64_t s) const { return value(s); }
-    __device__ void apply(int64_t s, u64 v, u64 excl) const
+    int64_t *first_o, *coords;
+    int32_t *npoints;
+    float *feats;
+    __device__ u64 value(int64_t i) const
+    {
+        const int s = record_source(src_off, world, i);
+        const uint32_t *cb = contrib + (u64)rec_slot[i] * world;
+        for (int q = 0; q < s; q++)
+            if (cb[q]) return 0ull;
+        return 1ull;
+    }
+    __device__ u64 value2(int64_t i) const { return value(i); }
+    __device__ void apply(int64_t i, u64 v, u64 excl) const
     {
         if (!v) return;
-        const uint32_t o = (uint32_t)excl;
-        slot_owned[s] = o;
-        int64_t first = INT64_MAX;
-        int32_t cnt = 0;
-        float acc[16];
+        const int64_t o = (int64_t)excl;
+        const uint32_t slot = rec_slot[i];
+        slot_owned[slot] = (uint32_t)o;
+        const uint32_t *cb = contrib + (u64)slot * world;
         const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
         const float ident = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
-        for (int f = 0; f < c && f < 16; f++) acc[f] = ident;
-        for (int q = 0; q < world; q++) {         // rank order: the same sums whatever the arrival order
-            const uint32_t ri = contrib[(u64)s * world + q];
+        float a0 = ident, a1 = ident, a2 = ident, a3 = ident;      // c == 4 in registers; other widths through feats[]
+        if (c != 4)
+            for (int f = 0; f < c; f++) feats[o * c + f] = ident;
+        int64_t first = INT64_MAX;
+        int32_t cnt = 0;
+        int64_t key = 0;
+        for (int q = record_source(src_off, world, i); q < world; q++) {      // rank order: the same sums on every run
+            const uint32_t ri = cb[q];
             if (!ri) continue;
             const int32_t *r = recv + (size_t)(ri - 1) * RS;
+            key = *reinterpret_cast<const int64_t *>(r);
             const int64_t f0 = *reinterpret_cast<const int64_t *>(r + 2);
             first = f0 < first ? f0 : first;
             cnt += r[4];
-            for (int f = 0; f < c && f < 16; f++) {
-                const float x = __int_as_float(r[5 + f]);
-                if (is_sum) acc[f] += x;
-                else if (reduction == D3D_REDUCE_MAX) acc[f] = acc[f] < x ? x : acc[f];
-                else acc[f] = x < acc[f] ? x : acc[f];
+            if (c == 4) {
+                const float x0 = __int_as_float(r[5]), x1 = __int_as_float(r[6]), x2 = __int_as_float(r[7]), x3 = __int_as_float(r[8]);
+                if (is_sum) { a0 += x0; a1 += x1; a2 += x2; a3 += x3; }
+                else if (reduction == D3D_REDUCE_MAX) { a0 = a0 < x0 ? x0 : a0; a1 = a1 < x1 ? x1 : a1; a2 = a2 < x2 ? x2 : a2; a3 = a3 < x3 ? x3 : a3; }
+                else { a0 = x0 < a0 ? x0 : a0; a1 = x1 < a1 ? x1 : a1; a2 = x2 < a2 ? x2 : a2; a3 = x3 < a3 ? x3 : a3; }
+            } else {
+                for (int f = 0; f < c; f++) {
+                    const float x = __int_as_float(r[5 + f]), y = feats[o * c + f];
+                    feats[o * c + f] = is_sum ? y + x : (reduction == D3D_REDUCE_MAX ? (y < x ? x : y) : (x < y ? x : y));
+                }
             }
         }
-        keys_o[o] = (int64_t)tkey[s];
         first_o[o] = first;
-        cnt_o[o] = cnt;
-        for (int f = 0; f < c && f < 16; f++) agg_o[(size_t)o * c + f] = acc[f];
+        npoints[o] = cnt;
+        coords[o * 3 + 0] = key / (sy * sz);
+        coords[o * 3 + 1] = (key / sz) % sy;
+        coords[o * 3 + 2] = key % sz;
+        const float d = reduction == D3D_REDUCE_MEAN ? (float)cnt : 1.0f;
+        if (c == 4) *reinterpret_cast<float4 *>(feats + o * 4) = make_float4(a0 / d, a1 / d, a2 / d, a3 / d);
+        else if (reduction == D3D_REDUCE_MEAN)
+            for (int f = 0; f < c; f++) feats[o * c + f] = feats[o * c + f] / d;
     }
 };
 
@@ -259,61 +296,56 @@ __global__ __launch_bounds__(256) void k_merge_recmap(int64_t R, const uint32_t 
 }
 
 // ---------------------------------------------------------------- numbering
+// first_o ascends with the owned voxel index, so a wavefront's 64 bits fall into a handful of words: the lanes that share a
+// word OR their bits together (the lowest of them issues the atomic)
 __global__ __launch_bounds__(256) void k_first_mark(const int64_t *__restrict__ first_o, const int64_t *__restrict__ counts,
                                                     int64_t n_total, u64 *bitmap)
 {
     const int64_t Vo = counts[D3D_COUNT_VOXELS];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Vo) return;
-    const int64_t f = first_o[i];
-    if (f >= 0 && f < n_total) atomicOr(&bitmap[f >> 6], 1ull << (f & 63));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t f = i < Vo ? first_o[i] : -1;
+    const bool ok = f >= 0 && f < n_total;
+    const int64_t word = ok ? (f >> 6) : -1 - lane;          // lanes without a bit: a word of their own, never written
+    u64 bits = ok ? 1ull << (f & 63) : 0ull;
+    // segmented OR over runs of equal words (ascending input: equal words are adjacent)
+    bool head = lane == 0 || __shfl_up(word, 1, kWave) != word;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const u64 other = __shfl_down(bits, d, kWave);
+        const int64_t ow = __shfl_down(word, d, kWave);
+        if (lane + d < kWave && ow == word) bits |= other;
+    }
+    if (ok && head) atomicOr(&bitmap[word], bits);
 }
 
-// popcount prefix of two bitmaps at once: hi = all owners' first points (the all-reduced bitmap), lo = this owner's
+// popcount prefix of the all-reduced bitmap (every owner's first points)
 struct FirstWords {
     static constexpr const char *kName = "k_scan_count<FirstWords>", *kName2 = "k_scan_apply<FirstWords>";
-    const u64 *global, *local;
-    u64 *pre;
-    __device__ u64 value(int64_t w) const { return ((u64)__popcll(global[w]) << 32) | (u64)__popcll(local[w]); }
+    const u64 *global;
+    uint32_t *pre;
+    __device__ u64 value(int64_t w) const { return (u64)__popcll(global[w]); }
     __device__ u64 value2(int64_t w) const { return value(w); }
-    __device__ void apply(int64_t w, u64, u64 excl) const { pre[w] = excl; }
+    __device__ void apply(int64_t w, u64, u64 excl) const { pre[w] = (uint32_t)excl; }
 };
 
-// owned voxel -> global voxel id (first-seen order over the whole frame) and its place among this owner's voxels in
-// that order; then its finished row goes there
-__global__ __launch_bounds__(256) void k_owner_finalize(const int64_t *__restrict__ counts_o, const u64 *__restrict__ gbits,
-                                                        const u64 *__restrict__ lbits, const u64 *__restrict__ pre,
-                                                        const int64_t *__restrict__ keys_o, const int64_t *__restrict__ first_o,
-                                                        const int32_t *__restrict__ cnt_o, const float *__restrict__ agg_o, int c,
-                                                        int mean, int64_t sy, int64_t sz, int64_t *vid_of_owned,
-                                                        int32_t *pos_of_owned, int64_t *vids, int64_t *coords, int32_t *npoints,
-                                                        float *feats)
+// owned voxel (already in id order) -> its global voxel id = number of first points before its own in the whole frame
+__global__ __launch_bounds__(256) void k_owner_number(const int64_t *__restrict__ counts_o, const u64 *__restrict__ gbits,
+                                                      const uint32_t *__restrict__ pre, const int64_t *__restrict__ first_o,
+                                                      int64_t *vids)
 {
     const int64_t Vo = counts_o[D3D_COUNT_VOXELS];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Vo) return;
     const int64_t f = first_o[i];
-    const u64 below = (1ull << (f & 63)) - 1ull, p = pre[f >> 6];
-    const int64_t vid = (int64_t)(p >> 32) + __popcll(gbits[f >> 6] & below);
-    const int64_t pos = (int64_t)(p & 0xffffffffull) + __popcll(lbits[f >> 6] & below);
-    vid_of_owned[i] = vid;
-    pos_of_owned[i] = (int32_t)pos;
-    vids[pos] = vid;
-    const int64_t k = keys_o[i];
-    coords[pos * 3 + 0] = k / (sy * sz);
-    coords[pos * 3 + 1] = (k / sz) % sy;
-    coords[pos * 3 + 2] = k % sz;
-    const int32_t n = cnt_o[i];
-    npoints[pos] = n;
-    const float d = mean ? (float)n : 1.0f;
-    for (int q = 0; q < c; q++) feats[pos * c + q] = mean ? agg_o[i * c + q] / d : agg_o[i * c + q];
+    vids[i] = (int64_t)pre[f >> 6] + __popcll(gbits[f >> 6] & ((1ull << (f & 63)) - 1ull));
 }
 
 __global__ __launch_bounds__(256) void k_owner_reply(int64_t R, const int32_t *__restrict__ rec_owned,
-                                                     const int64_t *__restrict__ vid_of_owned, int64_t *reply)
+                                                     const int64_t *__restrict__ vids, int64_t *reply)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < R) reply[i] = vid_of_owned[rec_owned[i]];
+    if (i < R) reply[i] = vids[rec_owned[i]];
 }
 
 // the ids that came back, in send order -> id of every local voxel -> id of every local point
@@ -389,17 +421,18 @@ extern "C" size_t d3d_owner_merge_workspace_bytes(int64_t R, int32_t world)
     return carve_merge(nullptr, 0, R > 0 ? R : 0, world).bytes + 256;
 }
 
-// received records recv[R, words] (grouped by source rank: src_off[world + 1], device) -> this owner's voxels, in table
-// order: keys_o / first_o / cnt_o / agg_o [R rows, counts[0] valid], rec_owned[R] = the owned voxel of every record.
-// reduction: MEAN or 4 (sums), MAX, MIN.
+// received records recv[R, words] (grouped by source rank: src_off[world + 1], device) -> this owner's voxels IN GLOBAL ID
+// ORDER, finished: first_o / coords / npoints / feats [R rows, counts[D3D_COUNT_VOXELS] valid], rec_owned[R] = the owned voxel
+// of every record.  reduction: MEAN (sums in rank order, then the division of voxelize.cpp:164), MAX, MIN.
 extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *src_off, int32_t world, int32_t c, int32_t reduction,
-                               int64_t *keys_o, int64_t *first_o, int32_t *cnt_o, float *agg_o, int32_t *rec_owned,
-                               int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
+                               const int32_t *shape, int64_t *first_o, int64_t *coords, int32_t *npoints, float *feats,
+                               int32_t *rec_owned, int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (R < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !src_off) return D3D_ERR_BAD_ARG;
+    if (R < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !src_off || !shape) return D3D_ERR_BAD_ARG;
+    if (reduction < D3D_REDUCE_MEAN || reduction > D3D_REDUCE_MIN) return D3D_ERR_UNSUPPORTED;
     if (R >= (1ll << 31)) return D3D_ERR_BAD_ARG;
-    if (R > 0 && (!recv || !keys_o || !first_o || !cnt_o || !agg_o || !rec_owned)) return D3D_ERR_BAD_ARG;
+    if (R > 0 && (!recv || !first_o || !coords || !npoints || !feats || !rec_owned)) return D3D_ERR_BAD_ARG;
     MergeWs m = carve_merge(workspace, workspace_bytes, R, world);
     if (!workspace || m.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     D3D_HIP_CHECK(hipMemsetAsync(counts, 0, D3D_NUM_COUNTS * sizeof(int64_t), st));
@@ -408,8 +441,9 @@ extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *sr
     if (R > 0)
         D3D_LAUNCH("k_merge_insert", k_merge_insert, dim3(blocks_for(R)), dim3(256), 0, st, recv, R, rec_stride(c), src_off, (int)world,
                    m.tkey, m.cap - 1, m.contrib, m.rec_slot);
-    MergeSlots f{m.tkey, m.contrib, recv, rec_stride(c), (int)c, (int)world, (int)reduction, m.slot_owned, keys_o, first_o, cnt_o, agg_o};
-    int rc = d3d_run_scan(f, (int64_t)m.cap, m.bsum, counts, -1, D3D_COUNT_VOXELS, ~0ull, st);
+    MergeRecords f{m.contrib, m.rec_slot, src_off, recv, rec_stride(c), (int)c, (int)world, (int)reduction, (int64_t)shape[1],
+                   (int64_t)shape[2], m.slot_owned, first_o, coords, npoints, feats};
+    int rc = d3d_run_scan(f, R, m.bsum, counts, -1, D3D_COUNT_VOXELS, ~0ull, st);
     if (rc) return rc;
     if (R > 0) D3D_LAUNCH("k_merge_recmap", k_merge_recmap, dim3(blocks_for(R)), dim3(256), 0, st, R, m.rec_slot, m.slot_owned, rec_owned);
     return D3D_OK;
@@ -427,46 +461,43 @@ extern "C" int d3d_owner_mark_first(const int64_t *first_o, const int64_t *count
     return D3D_OK;
 }
 
-extern "C" size_t d3d_owner_finalize_workspace_bytes(int64_t n_total)
+extern "C" size_t d3d_owner_number_workspace_bytes(int64_t n_total)
 {
     const int64_t nw = d3d_divup(n_total > 0 ? n_total : 1, 64);
-    return d3d_align_up((size_t)nw * 8) + d3d_align_up((size_t)(d3d_divup(nw, kScanTile) + 1) * 8) + 256;
+    return d3d_align_up((size_t)nw * 4) + d3d_align_up((size_t)(d3d_divup(nw, kScanTile) + 1) * 8) + 256;
 }
 
-// global_bits = the SUM all-reduce of every owner's d3d_owner_mark_first bitmap (disjoint bits: their OR), local_bits = this
-// owner's.  Numbers the owned voxels (first-seen order over the whole frame, voxelize.cpp:119) and writes their finished rows
-// in that order: vids / coords / npoints / feats [cap_o rows, counts_o[0] valid]; vid_of_owned / pos_of_owned in table order.
-// counts_out[D3D_COUNT_VOXELS] = voxels of the whole frame, counts_out[D3D_COUNT_POINTS] = owned voxels.
-extern "C" int d3d_owner_finalize(const uint64_t *global_bits, const uint64_t *local_bits, int64_t n_total, const int64_t *keys_o,
-                                  const int64_t *first_o, const int32_t *cnt_o, const float *agg_o, const int64_t *counts_o,
-                                  int64_t cap_o, int32_t c, int32_t mean, const int32_t *shape, int64_t *vid_of_owned,
-                                  int32_t *pos_of_owned, int64_t *vids, int64_t *coords, int32_t *npoints, float *feats,
-                                  int64_t *counts_out, void *workspace, size_t workspace_bytes, void *stream)
+// global_bits = the SUM all-reduce of every owner's d3d_owner_mark_first bitmap (disjoint bit sets: their OR).  vids[i] =
+// global voxel id (first-seen order over the whole frame, voxelize.cpp:119) of owned voxel i; counts_out[D3D_COUNT_VOXELS] =
+// voxels of the whole frame.
+extern "C" int d3d_owner_number(const uint64_t *global_bits, int64_t n_total, const int64_t *first_o, const int64_t *counts_o,
+                                int64_t cap_o, int64_t *vids, int64_t *counts_out, void *workspace, size_t workspace_bytes,
+                                void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (n_total < 0 || cap_o < 0 || c < 1 || !shape || !counts_o || !counts_out || !global_bits || !local_bits) return D3D_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < d3d_owner_finalize_workspace_bytes(n_total)) return D3D_ERR_WORKSPACE;
+    if (n_total < 0 || cap_o < 0 || !counts_o || !counts_out || !global_bits) return D3D_ERR_BAD_ARG;
+    if (n_total >= (1ll << 32)) return D3D_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < d3d_owner_number_workspace_bytes(n_total)) return D3D_ERR_WORKSPACE;
     const int64_t nw = d3d_divup(n_total > 0 ? n_total : 1, 64);
     WsCarver w(workspace, workspace_bytes);
-    u64 *pre = w.take<u64>(nw);
+    uint32_t *pre = w.take<uint32_t>(nw);
     u64 *bsum = w.take<u64>(d3d_divup(nw, kScanTile) + 1);
     D3D_HIP_CHECK(hipMemsetAsync(counts_out, 0, D3D_NUM_COUNTS * sizeof(int64_t), st));
-    FirstWords f{(const u64 *)global_bits, (const u64 *)local_bits, pre};
-    int rc = d3d_run_scan(f, nw, bsum, counts_out, D3D_COUNT_VOXELS, D3D_COUNT_POINTS, ~0ull, st);
+    FirstWords f{(const u64 *)global_bits, pre};
+    int rc = d3d_run_scan(f, nw, bsum, counts_out, -1, D3D_COUNT_VOXELS, ~0ull, st);
     if (rc) return rc;
     if (cap_o > 0)
-        D3D_LAUNCH("k_owner_finalize", k_owner_finalize, dim3(blocks_for(cap_o)), dim3(256), 0, st, counts_o, (const u64 *)global_bits,
-                   (const u64 *)local_bits, pre, keys_o, first_o, cnt_o, agg_o, (int)c, (int)mean, (int64_t)shape[1], (int64_t)shape[2],
-                   vid_of_owned, pos_of_owned, vids, coords, npoints, feats);
+        D3D_LAUNCH("k_owner_number", k_owner_number, dim3(blocks_for(cap_o)), dim3(256), 0, st, counts_o, (const u64 *)global_bits, pre,
+                   first_o, vids);
     return D3D_OK;
 }
 
 // reply[i] = global voxel id of received record i (sent back to the record's source rank)
-extern "C" int d3d_owner_reply(int64_t R, const int32_t *rec_owned, const int64_t *vid_of_owned, int64_t *reply, void *stream)
+extern "C" int d3d_owner_reply(int64_t R, const int32_t *rec_owned, const int64_t *vids, int64_t *reply, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (R < 0) return D3D_ERR_BAD_ARG;
-    if (R > 0) D3D_LAUNCH("k_owner_reply", k_owner_reply, dim3(blocks_for(R)), dim3(256), 0, st, R, rec_owned, vid_of_owned, reply);
+    if (R > 0) D3D_LAUNCH("k_owner_reply", k_owner_reply, dim3(blocks_for(R)), dim3(256), 0, st, R, rec_owned, vids, reply);
     return D3D_OK;
 }
 

@@ -888,14 +888,16 @@ __device__ __forceinline__ void meta_voxel(const Key &kf, int64_t v, const uint4
                                            int64_t *keys_out, uint32_t npoints_clamp = 0xffffffffu)
 {
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
-    long long cc[3];
-    kf.decode(((u64)vi.y << 32) | vi.x, cc);
-    // 24 bytes as 16 + 8 (rows alternate their 16-byte alignment): two store requests instead of three
-    long long *cp = reinterpret_cast<long long *>(coords) + v * 3;
-    if ((reinterpret_cast<uintptr_t>(coords) & 15) == 0) {
-        if ((v & 1) == 0) { *reinterpret_cast<longlong2 *>(cp) = make_longlong2(cc[0], cc[1]); cp[2] = cc[2]; }
-        else { cp[0] = cc[0]; *reinterpret_cast<longlong2 *>(cp + 1) = make_longlong2(cc[1], cc[2]); }
-    } else { cp[0] = cc[0]; cp[1] = cc[1]; cp[2] = cc[2]; }
+    if (coords) {                                  // (the sharded voxelizer's local pass only needs the cell keys)
+        long long cc[3];
+        kf.decode(((u64)vi.y << 32) | vi.x, cc);
+        // 24 bytes as 16 + 8 (rows alternate their 16-byte alignment): two store requests instead of three
+        long long *cp = reinterpret_cast<long long *>(coords) + v * 3;
+        if ((reinterpret_cast<uintptr_t>(coords) & 15) == 0) {
+            if ((v & 1) == 0) { *reinterpret_cast<longlong2 *>(cp) = make_longlong2(cc[0], cc[1]); cp[2] = cc[2]; }
+            else { cp[0] = cc[0]; *reinterpret_cast<longlong2 *>(cp + 1) = make_longlong2(cc[1], cc[2]); }
+        } else { cp[0] = cc[0]; cp[1] = cc[1]; cp[2] = cc[2]; }
+    }
     npoints[v] = (int32_t)(vi.w < npoints_clamp ? vi.w : npoints_clamp);
     if (voff) voff[v] = vi.z;
     if (keys_out) keys_out[v] = (int64_t)(((u64)vi.y << 32) | vi.x);
@@ -2382,7 +2384,7 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     if (n < 0 || c < 3 || !shape || !bound || !counts) return D3D_ERR_BAD_ARG;
     if (n >= (1ll << 31) - kFlagTile) return D3D_ERR_BAD_ARG;
     if (reduction < D3D_REDUCE_MEAN || reduction > kReduceSum) return D3D_ERR_UNSUPPORTED;
-    if (n > 0 && (!points || !coords || !npoints || !aggregates)) return D3D_ERR_BAD_ARG;
+    if (n > 0 && (!points || !npoints || !aggregates || (!coords && !keys))) return D3D_ERR_BAD_ARG;
     DenseKey kf;
     int rc = make_dense_key(shape, bound, kf);
     if (rc) return rc;

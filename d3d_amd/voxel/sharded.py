@@ -107,7 +107,7 @@ class LocalComm:
 class HipOps:
     """the compute steps, on the HIP kernels of libd3d_hip.so (no host synchronisation except where noted)"""
 
-    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False):
+    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False, want_coords=True):
         """-> coords[n,3], cnt[n], agg[n,c], first[n], mapping[n], keys[n], counts[4] -- all on the device and all
         sized for n voxels; only the first counts[0] rows are meaningful.  keys has n + 1 entries: -1 beyond the
         voxels, and keys[n] = -1 - status bits (so the status reaches every rank with the key all-gather)."""
@@ -118,7 +118,7 @@ class HipOps:
         shape_h = (ctypes.c_int32 * 3)(*[int(x) for x in shape])
         bound_h = (ctypes.c_float * 6)(*[float(x) for x in bounds])
         with torch.cuda.device(dev):
-            coords = torch.empty((n, 3), dtype=torch.int64, device=dev)
+            coords = torch.empty((n, 3), dtype=torch.int64, device=dev) if want_coords else None
             cnt = torch.empty((n,), dtype=torch.int32, device=dev)
             agg = torch.empty((n, c), dtype=torch.float32, device=dev)
             first = torch.empty((n,), dtype=torch.int64, device=dev)
@@ -294,28 +294,31 @@ class HipOps:
             _lib.check(rc, "owner_pack")
         return send, perm, sc
 
-    def owner_merge(self, recv, recv_counts, world, c, reduction):
-        """records grouped by source rank -> this owner's voxels (table order): keys, first, cnt, agg, rec_owned, counts"""
+    def owner_merge(self, recv, recv_counts, world, c, reduction, shape):
+        """records grouped by source rank -> this owner's voxels in global id order, finished:
+        first_o, coords, npoints, feats (R rows allocated), rec_owned[R], counts (device; [0] = owned voxels)"""
         lib = _lib.load()
         dev = recv.device
         R = int(recv.shape[0])
         off = [0]
         for k in recv_counts:
             off.append(off[-1] + int(k))
+        shape_h = (ctypes.c_int32 * 3)(*[int(x) for x in shape])
         with torch.cuda.device(dev):
             src_off = torch.tensor(off, dtype=torch.int64, device=dev)
-            keys_o = torch.empty((R,), dtype=torch.int64, device=dev)
             first_o = torch.empty((R,), dtype=torch.int64, device=dev)
-            cnt_o = torch.empty((R,), dtype=torch.int32, device=dev)
-            agg_o = torch.empty((R, c), dtype=torch.float32, device=dev)
+            coords = torch.empty((R, 3), dtype=torch.int64, device=dev)
+            npoints = torch.empty((R,), dtype=torch.int32, device=dev)
+            feats = torch.empty((R, c), dtype=torch.float32, device=dev)
             rec_owned = torch.empty((R,), dtype=torch.int32, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
-            ws = torch.empty((lib.d3d_owner_merge_workspace_bytes(R, world),), dtype=torch.uint8, device=dev)
-            rc = lib.d3d_owner_merge(_lib.ptr(recv), R, _lib.ptr(src_off), world, c, int(reduction), _lib.ptr(keys_o),
-                                     _lib.ptr(first_o), _lib.ptr(cnt_o), _lib.ptr(agg_o), _lib.ptr(rec_owned), _lib.ptr(counts),
-                                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            ws = _lib.workspace(lib.d3d_owner_merge_workspace_bytes(R, world), dev)
+            rc = lib.d3d_owner_merge(_lib.ptr(recv), R, _lib.ptr(src_off), world, c, int(reduction),
+                                     ctypes.cast(shape_h, ctypes.c_void_p), _lib.ptr(first_o), _lib.ptr(coords), _lib.ptr(npoints),
+                                     _lib.ptr(feats), _lib.ptr(rec_owned), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
+                                     _lib.stream_ptr())
             _lib.check(rc, "owner_merge")
-        return keys_o, first_o, cnt_o, agg_o, rec_owned, counts
+        return first_o, coords, npoints, feats, rec_owned, counts
 
     def owner_mark_first(self, first_o, counts_o, n_total):
         """-> int64 words of the bitmap over the frame's point indices with this owner's first points set"""
@@ -328,35 +331,26 @@ class HipOps:
             _lib.check(rc, "owner_mark_first")
         return bits
 
-    def owner_finalize(self, gbits, lbits, n_total, keys_o, first_o, cnt_o, agg_o, counts_o, c, mean, shape):
-        """-> vid_of_owned, vids, coords, npoints, feats (owned rows in id order; R rows allocated), counts_out (device)"""
+    def owner_number(self, gbits, n_total, first_o, counts_o):
+        """-> vids[R] (global id of every owned voxel), counts_out (device; [0] = voxels of the whole frame)"""
         lib = _lib.load()
-        dev = keys_o.device
-        R = int(keys_o.numel())
-        shape_h = (ctypes.c_int32 * 3)(*[int(x) for x in shape])
+        dev = first_o.device
+        R = int(first_o.numel())
         with torch.cuda.device(dev):
-            vid_of = torch.empty((R,), dtype=torch.int64, device=dev)
-            pos_of = torch.empty((R,), dtype=torch.int32, device=dev)
             vids = torch.empty((R,), dtype=torch.int64, device=dev)
-            coords = torch.empty((R, 3), dtype=torch.int64, device=dev)
-            npoints = torch.empty((R,), dtype=torch.int32, device=dev)
-            feats = torch.empty((R, c), dtype=torch.float32, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
-            ws = torch.empty((lib.d3d_owner_finalize_workspace_bytes(n_total),), dtype=torch.uint8, device=dev)
-            rc = lib.d3d_owner_finalize(_lib.ptr(gbits), _lib.ptr(lbits), n_total, _lib.ptr(keys_o), _lib.ptr(first_o),
-                                        _lib.ptr(cnt_o), _lib.ptr(agg_o), _lib.ptr(counts_o), R, c, 1 if mean else 0,
-                                        ctypes.cast(shape_h, ctypes.c_void_p), _lib.ptr(vid_of), _lib.ptr(pos_of), _lib.ptr(vids),
-                                        _lib.ptr(coords), _lib.ptr(npoints), _lib.ptr(feats), _lib.ptr(counts), _lib.ptr(ws),
-                                        ws.numel(), _lib.stream_ptr())
-            _lib.check(rc, "owner_finalize")
-        return vid_of, pos_of, vids, coords, npoints, feats, counts
+            ws = _lib.workspace(lib.d3d_owner_number_workspace_bytes(n_total), dev)
+            rc = lib.d3d_owner_number(_lib.ptr(gbits), n_total, _lib.ptr(first_o), _lib.ptr(counts_o), R, _lib.ptr(vids),
+                                      _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "owner_number")
+        return vids, counts
 
-    def owner_reply(self, rec_owned, vid_of_owned):
+    def owner_reply(self, rec_owned, vids):
         lib = _lib.load()
         R = int(rec_owned.numel())
         with torch.cuda.device(rec_owned.device):
             reply = torch.empty((R,), dtype=torch.int64, device=rec_owned.device)
-            _lib.check(lib.d3d_owner_reply(R, _lib.ptr(rec_owned), _lib.ptr(vid_of_owned), _lib.ptr(reply), _lib.stream_ptr()),
+            _lib.check(lib.d3d_owner_reply(R, _lib.ptr(rec_owned), _lib.ptr(vids), _lib.ptr(reply), _lib.stream_ptr()),
                        "owner_reply")
         return reply
 
@@ -473,7 +467,7 @@ class ShardedVoxelGenerator:
         mean = self._red == 1
         kw = {"plain": True} if plain else {}
         _, cnt_r, agg_r, first_r, map_r, keys_r, counts_r = ops.voxelize_reduce(
-            points, self._shape, self._bounds, _SUM if mean else self._red, offset, **kw)
+            points, self._shape, self._bounds, _SUM if mean else self._red, offset, want_coords=False, **kw)
         send, perm, sc_dev = ops.owner_pack(keys_r, cnt_r, agg_r, first_r, counts_r, n, c, W)
         mat = comm.exchange_counts(sc_dev)                      # [src][dst] records, [src][W] status bits
         status = 0
@@ -486,20 +480,19 @@ class ShardedVoxelGenerator:
         sc = [int(x) for x in mat[comm.rank][:W]]
         rc = [int(mat[s][comm.rank]) for s in range(W)]
         recv = comm.all_to_all(send[:sum(sc)], sc, rc)
-        keys_o, first_o, cnt_o, agg_o, rec_owned, counts_o = ops.owner_merge(recv, rc, W, c, _SUM if mean else self._red)
+        first_o, coords, npoints, feats, rec_owned, counts_o = ops.owner_merge(recv, rc, W, c, self._red, self._shape)
         lbits = ops.owner_mark_first(first_o, counts_o, n_total)
-        gbits = comm.all_reduce(lbits.clone(), "sum")           # disjoint bit sets: their sum is their OR
-        vid_of, _, vids, coords, npoints, feats, counts_out = ops.owner_finalize(
-            gbits, lbits, n_total, keys_o, first_o, cnt_o, agg_o, counts_o, c, mean, self._shape)
-        back = comm.all_to_all(ops.owner_reply(rec_owned, vid_of), rc, sc)
+        gbits = comm.all_reduce(lbits, "sum")                   # disjoint bit sets: their sum is their OR
+        vids, counts_out = ops.owner_number(gbits, n_total, first_o, counts_o)
+        back = comm.all_to_all(ops.owner_reply(rec_owned, vids), rc, sc)
         gmap = ops.owner_map(map_r, perm, back)
-        host = counts_out.tolist()
-        nvox, nown = int(host[_lib.COUNT_VOXELS]), int(host[_lib.COUNT_POINTS])
+        host = torch.stack([counts_out, counts_o]).tolist()     # the host read-back of the output sizes
+        nvox, nown = int(host[0][_lib.COUNT_VOXELS]), int(host[1][_lib.COUNT_VOXELS])
         words = int(send.shape[1])
         self.last_stats = dict(
             exchange="owner", numbering="first-point bitmap", voxels=nvox, owned_voxels=nown, ranks=W,
             all_to_all_bytes_sent=(sum(sc) - sc[comm.rank]) * 4 * words, all_to_all_bytes_received=(sum(rc) - rc[comm.rank]) * 4 * words,
-            reply_bytes_sent=(sum(rc) - rc[comm.rank]) * 8, all_reduce_bytes=int(lbits.numel()) * 8,
+            reply_bytes_sent=(sum(rc) - rc[comm.rank]) * 8, all_reduce_bytes=int(gbits.numel()) * 8,
             all_gather_bytes_per_rank=nown * (8 + 24 + 4 + 4 * c) if self._replicate else 0)
         vids, coords, npoints, feats = vids[:nown], coords[:nown], npoints[:nown], feats[:nown]
         if not self._replicate:

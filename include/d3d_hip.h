@@ -172,7 +172,7 @@ int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int32_t c, con
 /* Voxel feature grid without the dense [V,P,C] copy ("dynamic voxelization"): grid semantics of
  * d3d_voxelize_3d_dense (voxelize.cpp:100-101), first-seen voxel ids (voxelize.cpp:119), reduction over
  * ALL in-range points (voxelize.cpp:137-164).  reduction: MEAN/MAX/MIN or 4 = SUM (MEAN without the division).
- *   coords[n,3] i64, npoints[n] i32, aggregates[n,c] f32, first[n] i64 (index_offset + index of the voxel's first
+ *   coords[n,3] i64 (may be NULL when keys is given), npoints[n] i32, aggregates[n,c] f32, first[n] i64 (index_offset + index of the voxel's first
  *   point; may be NULL), mapping[n] i64 (voxel id per point, -1 = out of range; may be NULL),
  *   keys[n + 1] i64 (linear cell index (x*sy+y)*sz+z per voxel, -1 in the rows >= counts[0]; keys[n] = -1 - status
  *   bits of counts[2], so that the status travels with the key list; may be NULL). */
@@ -257,26 +257,23 @@ int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const float *agg, co
                    int64_t n, int32_t c, int32_t world, int32_t *send, int32_t *perm, int64_t *send_counts,
                    void *workspace, size_t workspace_bytes, void *stream);
 size_t d3d_owner_merge_workspace_bytes(int64_t n_records, int32_t world);
-/* recv[R, words] grouped by source rank (src_off[world + 1], device) -> this owner's voxels in table order: keys_o / first_o /
- * cnt_o / agg_o (R rows, counts[D3D_COUNT_VOXELS] valid) and rec_owned[R] = owned voxel of every record.  reduction: MEAN
- * or 4 (sums, in rank order), MAX, MIN. */
+/* recv[R, words] grouped by source rank (src_off[world + 1], device) -> this owner's voxels in GLOBAL ID ORDER, finished
+ * (the lowest source rank of a cell holds its first point; the records of one source follow the shard's first-seen order):
+ * first_o / coords / npoints / feats (R rows allocated, counts[D3D_COUNT_VOXELS] valid) and rec_owned[R] = owned voxel of
+ * every record.  reduction: MEAN (sums in rank order, then voxelize.cpp:164's division), MAX, MIN. */
 int d3d_owner_merge(const int32_t *recv, int64_t n_records, const int64_t *src_off, int32_t world, int32_t c, int32_t reduction,
-                    int64_t *keys_o, int64_t *first_o, int32_t *cnt_o, float *agg_o, int32_t *rec_owned, int64_t *counts,
-                    void *workspace, size_t workspace_bytes, void *stream);
+                    const int32_t *shape, int64_t *first_o, int64_t *coords, int32_t *npoints, float *feats,
+                    int32_t *rec_owned, int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
 /* bitmap[(n_total + 63) / 64] <- bit f for every owned voxel's first point f */
 int d3d_owner_mark_first(const int64_t *first_o, const int64_t *counts_o, int64_t cap_o, int64_t n_total, uint64_t *bitmap,
                          void *stream);
-size_t d3d_owner_finalize_workspace_bytes(int64_t n_total);
-/* global_bits = SUM all-reduce of all owners' bitmaps, local_bits = this owner's.  Owned voxels -> their global ids and
- * their finished rows in id order: vids / coords / npoints / feats (cap_o rows); vid_of_owned / pos_of_owned in table order;
- * counts_out[D3D_COUNT_VOXELS] = voxels of the frame, counts_out[D3D_COUNT_POINTS] = owned voxels. */
-int d3d_owner_finalize(const uint64_t *global_bits, const uint64_t *local_bits, int64_t n_total, const int64_t *keys_o,
-                       const int64_t *first_o, const int32_t *cnt_o, const float *agg_o, const int64_t *counts_o, int64_t cap_o,
-                       int32_t c, int32_t mean, const int32_t *shape, int64_t *vid_of_owned, int32_t *pos_of_owned,
-                       int64_t *vids, int64_t *coords, int32_t *npoints, float *feats, int64_t *counts_out,
-                       void *workspace, size_t workspace_bytes, void *stream);
+size_t d3d_owner_number_workspace_bytes(int64_t n_total);
+/* global_bits = SUM all-reduce of all owners' bitmaps.  vids[i] = global voxel id of owned voxel i;
+ * counts_out[D3D_COUNT_VOXELS] = voxels of the whole frame. */
+int d3d_owner_number(const uint64_t *global_bits, int64_t n_total, const int64_t *first_o, const int64_t *counts_o, int64_t cap_o,
+                     int64_t *vids, int64_t *counts_out, void *workspace, size_t workspace_bytes, void *stream);
 /* reply[i] = global voxel id of received record i (returned to the record's source rank by the reverse all-to-all) */
-int d3d_owner_reply(int64_t n_records, const int32_t *rec_owned, const int64_t *vid_of_owned, int64_t *reply, void *stream);
+int d3d_owner_reply(int64_t n_records, const int32_t *rec_owned, const int64_t *vids, int64_t *reply, void *stream);
 /* back[n_sent] (ids returned, in send order), perm (d3d_owner_pack), local_map[n] (point -> local voxel) -> gmap[n] */
 int d3d_owner_map(int64_t n, const int64_t *local_map, int64_t n_sent, const int32_t *perm, const int64_t *back,
                   int64_t *vid_of_local, int64_t *gmap, void *stream);

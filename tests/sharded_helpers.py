@@ -11,7 +11,7 @@ import oracle
 class NumpyOps:
     """same interface as d3d_amd.voxel.sharded.HipOps, computed with the CPU oracle + numpy"""
 
-    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False):
+    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False, want_coords=True):
         pts = points.cpu().numpy()
         n, c = pts.shape
         red = {1: 1, 2: 2, 3: 3, 4: 1}[int(reduction)]
@@ -196,23 +196,30 @@ class NumpyOps:
         full_perm[:v] = perm
         return torch.from_numpy(send), torch.from_numpy(full_perm), torch.from_numpy(sc)
 
-    def owner_merge(self, recv, recv_counts, world, c, reduction):
+    def owner_merge(self, recv, recv_counts, world, c, reduction, shape):
         r = recv.numpy()
         R = len(r)
         keys = np.ascontiguousarray(r[:, 0:2]).view(np.int64).reshape(-1)
         first = np.ascontiguousarray(r[:, 2:4]).view(np.int64).reshape(-1)
         cnt = r[:, 4].copy()
         agg = np.ascontiguousarray(r[:, 5:5 + c]).view(np.float32)
-        uniq, inv = np.unique(keys, return_inverse=True)          # records arrive grouped by source rank, in rank order
-        vo = len(uniq)
         red = int(reduction)
-        ident = 0.0 if red in (1, 4) else (-np.inf if red == 2 else np.inf)
+        ident = 0.0 if red == 1 else (-np.inf if red == 2 else np.inf)
+        owned, order = {}, []                                     # voxels in order of their first record (= lowest source rank)
+        rec_owned = np.zeros((R,), np.int32)
+        for i in range(R):                                        # records arrive grouped by source rank, in rank order
+            k = int(keys[i])
+            if k not in owned:
+                owned[k] = len(order)
+                order.append(k)
+            rec_owned[i] = owned[k]
+        vo = len(order)
         agg_o = np.full((R, c), ident, np.float32)
         cnt_o = np.zeros((R,), np.int32)
         first_o = np.full((R,), np.iinfo(np.int64).max, np.int64)
-        for i in range(R):                                        # sequential = rank order
-            o = inv[i]
-            if red in (1, 4):
+        for i in range(R):
+            o = rec_owned[i]
+            if red == 1:
                 agg_o[o] = agg_o[o] + agg[i]
             elif red == 2:
                 agg_o[o] = np.maximum(agg_o[o], agg[i])
@@ -220,11 +227,14 @@ class NumpyOps:
                 agg_o[o] = np.minimum(agg_o[o], agg[i])
             cnt_o[o] += cnt[i]
             first_o[o] = min(first_o[o], first[i])
-        keys_o = np.zeros((R,), np.int64)
-        keys_o[:vo] = uniq
+        if red == 1:
+            agg_o[:vo] = agg_o[:vo] / cnt_o[:vo, None].astype(np.float32)
+        k = np.asarray(order, np.int64)
+        sy, sz = shape[1], shape[2]
+        coords = np.zeros((R, 3), np.int64)
+        coords[:vo] = np.stack([k // (sy * sz), (k // sz) % sy, k % sz], 1) if vo else np.zeros((0, 3), np.int64)
         t = torch.from_numpy
-        return (t(keys_o), t(first_o), t(cnt_o), t(agg_o), t(inv.astype(np.int32)),
-                torch.tensor([vo, 0, 0, 0], dtype=torch.int64))
+        return t(first_o), t(coords), t(cnt_o), t(agg_o), t(rec_owned), torch.tensor([vo, 0, 0, 0], dtype=torch.int64)
 
     def owner_mark_first(self, first_o, counts_o, n_total):
         nw = (max(n_total, 1) + 63) // 64
@@ -232,33 +242,17 @@ class NumpyOps:
         bits[first_o.numpy()[:int(counts_o[0])]] = 1
         return torch.from_numpy(np.packbits(bits.reshape(nw, 64), axis=1, bitorder="little").view("<u8").reshape(nw).view(np.int64).copy())
 
-    def owner_finalize(self, gbits, lbits, n_total, keys_o, first_o, cnt_o, agg_o, counts_o, c, mean, shape):
-        def unpack(b):
-            w = b.numpy().view(np.uint64)
-            return np.unpackbits(w.view(np.uint8).reshape(-1, 8), axis=1, bitorder="little").reshape(-1).astype(np.int64)
-        g, l = unpack(gbits), unpack(lbits)
-        gpre, lpre = np.cumsum(g) - g, np.cumsum(l) - l
+    def owner_number(self, gbits, n_total, first_o, counts_o):
+        w = gbits.numpy().view(np.uint64)
+        g = np.unpackbits(w.view(np.uint8).reshape(-1, 8), axis=1, bitorder="little").reshape(-1).astype(np.int64)
+        gpre = np.cumsum(g) - g
         vo = int(counts_o[0])
-        R = len(keys_o)
-        f = first_o.numpy()[:vo]
-        vid, pos = gpre[f], lpre[f]
-        k = keys_o.numpy()[:vo]
-        sy, sz = shape[1], shape[2]
-        vids = np.zeros((R,), np.int64); coords = np.zeros((R, 3), np.int64)
-        npoints = np.zeros((R,), np.int32); feats = np.zeros((R, c), np.float32)
-        vids[pos] = vid
-        coords[pos] = np.stack([k // (sy * sz), (k // sz) % sy, k % sz], 1)
-        npoints[pos] = cnt_o.numpy()[:vo]
-        a = agg_o.numpy()[:vo]
-        feats[pos] = a / cnt_o.numpy()[:vo, None].astype(np.float32) if mean else a
-        vid_of = np.zeros((R,), np.int64); vid_of[:vo] = vid
-        pos_of = np.zeros((R,), np.int32); pos_of[:vo] = pos
-        t = torch.from_numpy
-        return (t(vid_of), t(pos_of), t(vids), t(coords), t(npoints), t(feats),
-                torch.tensor([int(g.sum()), int(l.sum()), 0, 0], dtype=torch.int64))
+        vids = np.zeros((len(first_o),), np.int64)
+        vids[:vo] = gpre[first_o.numpy()[:vo]]
+        return torch.from_numpy(vids), torch.tensor([int(g.sum()), 0, 0, 0], dtype=torch.int64)
 
-    def owner_reply(self, rec_owned, vid_of_owned):
-        return vid_of_owned[rec_owned.long()]
+    def owner_reply(self, rec_owned, vids):
+        return vids[rec_owned.long()]
 
     def owner_map(self, local_map, perm, back):
         m = local_map.numpy()
