@@ -20,7 +20,7 @@ namespace {
 typedef unsigned long long u64;
 constexpr int kMaxWorld = 64;
 constexpr u64 kFree = ~0ull;
-constexpr int kPackTile = 1024;      // records per workgroup in the partition by owner
+constexpr int kPackTile = 4096;      // records per workgroup in the partition by owner
 
 __device__ __forceinline__ u64 mix64(u64 h)
 {
@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void k_owner_scatter(const int64_t *__restrict
                                                        const float *__restrict__ agg, const int64_t *__restrict__ first,
                                                        const int64_t *__restrict__ counts, int c, uint32_t world,
                                                        const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ dest_base,
-                                                       int32_t *__restrict__ send, int32_t *__restrict__ perm)
+                                                       int32_t *__restrict__ send, int32_t *__restrict__ perm,
+                                                       int32_t *__restrict__ pos_of_local)
 {
     __shared__ uint32_t run[kMaxWorld];          // records of this tile already placed, per destination
     __shared__ uint32_t wcnt[256 / kWave][kMaxWorld];
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void k_owner_scatter(const int64_t *__restrict
             r[4] = cnt[i];
             for (int f = 0; f < c; f++) r[5 + f] = __float_as_int(agg[i * c + f]);
             perm[pos] = (int32_t)i;
+            pos_of_local[i] = (int32_t)pos;
         }
         __syncthreads();
         if (threadIdx.x < world) {
@@ -144,16 +146,15 @@ struct MergeWs {
     uint32_t *contrib;    // [cap * world] record index + 1 per source rank, 0 = none
     uint32_t *rec_slot;   // [R]
     uint32_t *slot_owned; // [cap]
+    unsigned char *flag;  // [R]
     u64 *bsum;            // scan scratch
     u64 cap;
     size_t bytes;
 };
 
-static u64 merge_cap(int64_t R)
+static u64 merge_cap(int64_t R)        // load factor <= 2/3; slots are found by multiply-shift, so no power of two is needed
 {
-    u64 cap = 1024;
-    while (cap < (u64)R * 2ull) cap <<= 1;
-    return cap;
+    return (u64)d3d_divup((R > 0 ? R : 1) * 3, 2 * 1024) * 1024 + 1024;
 }
 
 static MergeWs carve_merge(void *ws, size_t bytes, int64_t R, int world)
@@ -165,6 +166,7 @@ static MergeWs carve_merge(void *ws, size_t bytes, int64_t R, int world)
     m.contrib = w.take<uint32_t>(m.cap * (size_t)world);
     m.rec_slot = w.take<uint32_t>(R > 0 ? R : 1);
     m.slot_owned = w.take<uint32_t>(m.cap);
+    m.flag = w.take<unsigned char>(R > 0 ? R : 1);
     m.bsum = w.take<u64>(d3d_divup((int64_t)m.cap, kScanTile) + 1);
     m.bytes = w.off;
     return m;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void k_merge_init(u64 *tkey, uint32_t *contrib
 }
 
 __global__ __launch_bounds__(256) void k_merge_insert(const int32_t *__restrict__ recv, int64_t R, int RS,
-                                                      const int64_t *__restrict__ src_off, int world, u64 *tkey, u64 mask,
+                                                      const int64_t *__restrict__ src_off, int world, u64 *tkey, u64 cap,
                                                       uint32_t *contrib, uint32_t *rec_slot)
 {
     __shared__ int64_t so[kMaxWorld + 1];
@@ -192,15 +194,12 @@ __global__ __launch_bounds__(256) void k_merge_insert(const int32_t *__restrict_
         if (so[mid] <= i) lo = mid; else hi = mid;
     }
     const u64 key = (u64)*reinterpret_cast<const int64_t *>(recv + (size_t)i * RS);
-    u64 h = mix64(key * 0x9e3779b97f4a7c15ull) & mask;        // (a second mix: the owner hash already split on mix64's top bits)
+    // (a second mix: the owner hash already split on mix64's top bits)
+    u64 h = __umul64hi(mix64(key * 0x9e3779b97f4a7c15ull), cap);
     for (;;) {
-        const u64 cur = __hip_atomic_load(&tkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == key) break;
-        if (cur == kFree) {
-            const u64 old = atomicCAS(&tkey[h], kFree, key);
-            if (old == kFree || old == key) break;
-        }
-        h = (h + 1) & mask;                       // cap >= 2 R: a free slot always exists
+        const u64 old = atomicCAS(&tkey[h], kFree, key);      // most records are the first of their cell: claim at once
+        if (old == kFree || old == key) break;
+        h = h + 1 < cap ? h + 1 : 0;              // cap >= 1.5 R: a free slot always exists
     }
     contrib[h * (u64)world + lo] = (uint32_t)i + 1u;
     rec_slot[i] = (uint32_t)h;
@@ -224,6 +223,8 @@ __device__ __forceinline__ int record_source(const int64_t *__restrict__ src_off
 struct MergeRecords {
     static constexpr const char *kName = "k_scan_count<MergeRecords>", *kName2 = "k_scan_apply<MergeRecords>";
     const uint32_t *contrib, *rec_slot;
+    unsigned char *flag;                 // per record, left by the count pass: 0 = not a leader, 1 = leader of a cell with
+                                         // further records, 3 = leader and the cell's only record
     const int64_t *src_off;
     const int32_t *recv;
     int RS, c, world, reduction;         // reduction: MEAN (divide), 4 = sums, MAX, MIN
@@ -236,17 +237,39 @@ struct MergeRecords {
     {
         const int s = record_source(src_off, world, i);
         const uint32_t *cb = contrib + (u64)rec_slot[i] * world;
-        for (int q = 0; q < s; q++)
-            if (cb[q]) return 0ull;
-        return 1ull;
+        unsigned char f = 3;
+        for (int q = 0; q < world; q++)
+            if (cb[q] && q != s) f = q < s ? 0 : (f & 1);
+        flag[i] = f;
+        return f ? 1ull : 0ull;
     }
-    __device__ u64 value2(int64_t i) const { return value(i); }
+    __device__ u64 value2(int64_t i) const { return flag[i] ? 1ull : 0ull; }
     __device__ void apply(int64_t i, u64 v, u64 excl) const
     {
         if (!v) return;
         const int64_t o = (int64_t)excl;
         const uint32_t slot = rec_slot[i];
         slot_owned[slot] = (uint32_t)o;
+        if (flag[i] == 3 && c == 4) {             // the cell's only record (4 of 5 at config 5): everything is in record i
+            const int32_t *r = recv + (size_t)i * RS;
+            const int64_t key = *reinterpret_cast<const int64_t *>(r);
+            const int32_t cnt = r[4];
+            const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
+            const float ident = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+            float a[4];
+            for (int f = 0; f < 4; f++) {         // identity (op) x, exactly as the general loop below
+                const float x = __int_as_float(r[5 + f]);
+                a[f] = is_sum ? ident + x : (reduction == D3D_REDUCE_MAX ? (ident < x ? x : ident) : (x < ident ? x : ident));
+            }
+            first_o[o] = *reinterpret_cast<const int64_t *>(r + 2);
+            npoints[o] = cnt;
+            coords[o * 3 + 0] = key / (sy * sz);
+            coords[o * 3 + 1] = (key / sz) % sy;
+            coords[o * 3 + 2] = key % sz;
+            const float d = reduction == D3D_REDUCE_MEAN ? (float)cnt : 1.0f;
+            *reinterpret_cast<float4 *>(feats + o * 4) = make_float4(a[0] / d, a[1] / d, a[2] / d, a[3] / d);
+            return;
+        }
         const uint32_t *cb = contrib + (u64)slot * world;
         const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
         const float ident = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
@@ -348,20 +371,15 @@ __global__ __launch_bounds__(256) void k_owner_reply(int64_t R, const int32_t *_
     if (i < R) reply[i] = vids[rec_owned[i]];
 }
 
-// the ids that came back, in send order -> id of every local voxel -> id of every local point
-__global__ __launch_bounds__(256) void k_owner_unperm(int64_t Rs, const int32_t *__restrict__ perm, const int64_t *__restrict__ back,
-                                                      int64_t *vid_of_local)
-{
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < Rs) vid_of_local[perm[j]] = back[j];
-}
+// the ids that came back (send order) -> id of every local point: point -> local voxel -> its place in the send buffer
 __global__ __launch_bounds__(256) void k_owner_map(int64_t n, const int64_t *__restrict__ local_map,
-                                                   const int64_t *__restrict__ vid_of_local, int64_t *gmap)
+                                                   const int32_t *__restrict__ pos_of_local, const int64_t *__restrict__ back,
+                                                   int64_t *gmap)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t v = local_map[i];
-    gmap[i] = v < 0 ? -1 : vid_of_local[v];
+    gmap[i] = v < 0 ? -1 : back[pos_of_local[v]];
 }
 
 // replicate: rows of all owners (any order) -> voxel-id order
@@ -396,11 +414,11 @@ extern "C" size_t d3d_owner_pack_workspace_bytes(int64_t n, int32_t world)
 // send_counts[world + 1] (device; records per destination, then the shard's status bits)
 extern "C" int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const float *agg, const int64_t *first,
                               const int64_t *counts, int64_t n, int32_t c, int32_t world, int32_t *send, int32_t *perm,
-                              int64_t *send_counts, void *workspace, size_t workspace_bytes, void *stream)
+                              int32_t *pos_of_local, int64_t *send_counts, void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !send_counts) return D3D_ERR_BAD_ARG;
-    if (n > 0 && (!keys || !cnt || !agg || !first || !send || !perm)) return D3D_ERR_BAD_ARG;
+    if (n > 0 && (!keys || !cnt || !agg || !first || !send || !perm || !pos_of_local)) return D3D_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < d3d_owner_pack_workspace_bytes(n, world)) return D3D_ERR_WORKSPACE;
     const uint32_t ntiles = (uint32_t)d3d_divup(n > 0 ? n : 1, kPackTile);
     WsCarver w(workspace, workspace_bytes);
@@ -412,7 +430,7 @@ extern "C" int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const flo
                dest_base, keys ? keys + n : (const int64_t *)nullptr);
     if (n > 0)
         D3D_LAUNCH("k_owner_scatter", k_owner_scatter, dim3(ntiles), dim3(256), 0, st, keys, cnt, agg, first, counts, (int)c,
-                   (uint32_t)world, tilecnt, dest_base, send, perm);
+                   (uint32_t)world, tilecnt, dest_base, send, perm, pos_of_local);
     return D3D_OK;
 }
 
@@ -440,8 +458,8 @@ extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *sr
                m.cap, (int)world);
     if (R > 0)
         D3D_LAUNCH("k_merge_insert", k_merge_insert, dim3(blocks_for(R)), dim3(256), 0, st, recv, R, rec_stride(c), src_off, (int)world,
-                   m.tkey, m.cap - 1, m.contrib, m.rec_slot);
-    MergeRecords f{m.contrib, m.rec_slot, src_off, recv, rec_stride(c), (int)c, (int)world, (int)reduction, (int64_t)shape[1],
+                   m.tkey, m.cap, m.contrib, m.rec_slot);
+    MergeRecords f{m.contrib, m.rec_slot, m.flag, src_off, recv, rec_stride(c), (int)c, (int)world, (int)reduction, (int64_t)shape[1],
                    (int64_t)shape[2], m.slot_owned, first_o, coords, npoints, feats};
     int rc = d3d_run_scan(f, R, m.bsum, counts, -1, D3D_COUNT_VOXELS, ~0ull, st);
     if (rc) return rc;
@@ -501,15 +519,14 @@ extern "C" int d3d_owner_reply(int64_t R, const int32_t *rec_owned, const int64_
     return D3D_OK;
 }
 
-// back[Rs] = the ids returned for this rank's records, in send order; perm as left by d3d_owner_pack; local_map[n] =
-// point -> local voxel (d3d_voxelize_3d_reduce).  -> gmap[n] global voxel id per point; vid_of_local[Rs] scratch.
-extern "C" int d3d_owner_map(int64_t n, const int64_t *local_map, int64_t Rs, const int32_t *perm, const int64_t *back,
-                             int64_t *vid_of_local, int64_t *gmap, void *stream)
+// back[] = the ids returned for this rank's records, in send order; pos_of_local as left by d3d_owner_pack; local_map[n] =
+// point -> local voxel (d3d_voxelize_3d_reduce).  -> gmap[n] global voxel id per point.
+extern "C" int d3d_owner_map(int64_t n, const int64_t *local_map, const int32_t *pos_of_local, const int64_t *back,
+                             int64_t *gmap, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (n < 0 || Rs < 0) return D3D_ERR_BAD_ARG;
-    if (Rs > 0) D3D_LAUNCH("k_owner_unperm", k_owner_unperm, dim3(blocks_for(Rs)), dim3(256), 0, st, Rs, perm, back, vid_of_local);
-    if (n > 0) D3D_LAUNCH("k_owner_map", k_owner_map, dim3(blocks_for(n)), dim3(256), 0, st, n, local_map, vid_of_local, gmap);
+    if (n < 0) return D3D_ERR_BAD_ARG;
+    if (n > 0) D3D_LAUNCH("k_owner_map", k_owner_map, dim3(blocks_for(n)), dim3(256), 0, st, n, local_map, pos_of_local, back, gmap);
     return D3D_OK;
 }
 

@@ -280,19 +280,22 @@ class HipOps:
 
     # ---- owner-computes exchange (owner.hip) ----
     def owner_pack(self, keys, cnt, agg, first, counts, n, c, world):
-        """local voxels -> records grouped by owner rank: send[n, words] int32, perm[n], send_counts[world + 1] (device)"""
+        """local voxels -> records grouped by owner rank: send[n, words] int32, perm[n] (send position -> local voxel),
+        pos_of_local[n] (its inverse), send_counts[world + 1] (device)"""
         lib = _lib.load()
         dev = keys.device
         words = lib.d3d_owner_record_words(c)
         with torch.cuda.device(dev):
             send = torch.empty((n, words), dtype=torch.int32, device=dev)
             perm = torch.empty((n,), dtype=torch.int32, device=dev)
+            pos = torch.empty((n,), dtype=torch.int32, device=dev)
             sc = torch.empty((world + 1,), dtype=torch.int64, device=dev)
             ws = torch.empty((lib.d3d_owner_pack_workspace_bytes(n, world),), dtype=torch.uint8, device=dev)
             rc = lib.d3d_owner_pack(_lib.ptr(keys), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first), _lib.ptr(counts), n, c, world,
-                                    _lib.ptr(send), _lib.ptr(perm), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                                    _lib.ptr(send), _lib.ptr(perm), _lib.ptr(pos), _lib.ptr(sc), _lib.ptr(ws), ws.numel(),
+                                    _lib.stream_ptr())
             _lib.check(rc, "owner_pack")
-        return send, perm, sc
+        return send, perm, pos, sc
 
     def owner_merge(self, recv, recv_counts, world, c, reduction, shape):
         """records grouped by source rank -> this owner's voxels in global id order, finished:
@@ -354,15 +357,14 @@ class HipOps:
                        "owner_reply")
         return reply
 
-    def owner_map(self, local_map, perm, back):
+    def owner_map(self, local_map, pos_of_local, back):
         lib = _lib.load()
         dev = local_map.device
-        n, rs = int(local_map.numel()), int(back.numel())
+        n = int(local_map.numel())
         with torch.cuda.device(dev):
             gmap = torch.empty((n,), dtype=torch.int64, device=dev)
-            scratch = torch.empty((max(rs, 1),), dtype=torch.int64, device=dev)
-            _lib.check(lib.d3d_owner_map(n, _lib.ptr(local_map), rs, _lib.ptr(perm), _lib.ptr(back), _lib.ptr(scratch),
-                                         _lib.ptr(gmap), _lib.stream_ptr()), "owner_map")
+            _lib.check(lib.d3d_owner_map(n, _lib.ptr(local_map), _lib.ptr(pos_of_local), _lib.ptr(back), _lib.ptr(gmap),
+                                         _lib.stream_ptr()), "owner_map")
         return gmap
 
     def owner_replicate(self, nvox, vids, coords_in, cnt_in, feats_in):
@@ -468,7 +470,7 @@ class ShardedVoxelGenerator:
         kw = {"plain": True} if plain else {}
         _, cnt_r, agg_r, first_r, map_r, keys_r, counts_r = ops.voxelize_reduce(
             points, self._shape, self._bounds, _SUM if mean else self._red, offset, want_coords=False, **kw)
-        send, perm, sc_dev = ops.owner_pack(keys_r, cnt_r, agg_r, first_r, counts_r, n, c, W)
+        send, perm, pos_r, sc_dev = ops.owner_pack(keys_r, cnt_r, agg_r, first_r, counts_r, n, c, W)
         mat = comm.exchange_counts(sc_dev)                      # [src][dst] records, [src][W] status bits
         status = 0
         for row in mat:
@@ -485,7 +487,7 @@ class ShardedVoxelGenerator:
         gbits = comm.all_reduce(lbits, "sum")                   # disjoint bit sets: their sum is their OR
         vids, counts_out = ops.owner_number(gbits, n_total, first_o, counts_o)
         back = comm.all_to_all(ops.owner_reply(rec_owned, vids), rc, sc)
-        gmap = ops.owner_map(map_r, perm, back)
+        gmap = ops.owner_map(map_r, pos_r, back)
         host = torch.stack([counts_out, counts_o]).tolist()     # the host read-back of the output sizes
         nvox, nown = int(host[0][_lib.COUNT_VOXELS]), int(host[1][_lib.COUNT_VOXELS])
         words = int(send.shape[1])

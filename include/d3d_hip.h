@@ -251,11 +251,11 @@ int d3d_sharded_map(int64_t n, const int64_t *local_map, const int64_t *slot_of_
 int    d3d_owner_record_words(int32_t c);
 size_t d3d_owner_pack_workspace_bytes(int64_t n, int32_t world);
 /* outputs of d3d_voxelize_3d_reduce (keys[n + 1], cnt[n], agg[n, c], first[n], its counts) -> send[n, words] grouped by owner
- * rank, perm[n] (send position -> local voxel), send_counts[world + 1] (device: records per destination, then the shard's
- * status bits). */
+ * rank, perm[n] (send position -> local voxel), pos_of_local[n] (its inverse), send_counts[world + 1] (device: records per
+ * destination, then the shard's status bits). */
 int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const float *agg, const int64_t *first, const int64_t *counts,
-                   int64_t n, int32_t c, int32_t world, int32_t *send, int32_t *perm, int64_t *send_counts,
-                   void *workspace, size_t workspace_bytes, void *stream);
+                   int64_t n, int32_t c, int32_t world, int32_t *send, int32_t *perm, int32_t *pos_of_local,
+                   int64_t *send_counts, void *workspace, size_t workspace_bytes, void *stream);
 size_t d3d_owner_merge_workspace_bytes(int64_t n_records, int32_t world);
 /* recv[R, words] grouped by source rank (src_off[world + 1], device) -> this owner's voxels in GLOBAL ID ORDER, finished
  * (the lowest source rank of a cell holds its first point; the records of one source follow the shard's first-seen order):
@@ -274,9 +274,9 @@ int d3d_owner_number(const uint64_t *global_bits, int64_t n_total, const int64_t
                      int64_t *vids, int64_t *counts_out, void *workspace, size_t workspace_bytes, void *stream);
 /* reply[i] = global voxel id of received record i (returned to the record's source rank by the reverse all-to-all) */
 int d3d_owner_reply(int64_t n_records, const int32_t *rec_owned, const int64_t *vids, int64_t *reply, void *stream);
-/* back[n_sent] (ids returned, in send order), perm (d3d_owner_pack), local_map[n] (point -> local voxel) -> gmap[n] */
-int d3d_owner_map(int64_t n, const int64_t *local_map, int64_t n_sent, const int32_t *perm, const int64_t *back,
-                  int64_t *vid_of_local, int64_t *gmap, void *stream);
+/* back[] (ids returned, in send order), pos_of_local (d3d_owner_pack), local_map[n] (point -> local voxel) -> gmap[n] */
+int d3d_owner_map(int64_t n, const int64_t *local_map, const int32_t *pos_of_local, const int64_t *back, int64_t *gmap,
+                  void *stream);
 /* all owners' finished rows, concatenated in any order -> the replicated feature grid in voxel-id order */
 int d3d_owner_replicate(int64_t nvox, const int64_t *vids, const int64_t *coords_in, const int32_t *cnt_in,
                         const float *feats_in, int32_t c, int64_t *coords, int32_t *cnt, float *feats, void *stream);

@@ -194,7 +194,9 @@ class NumpyOps:
         sc[world] = -1 - int(keys.numpy()[n])
         full_perm = np.zeros((n,), np.int32)
         full_perm[:v] = perm
-        return torch.from_numpy(send), torch.from_numpy(full_perm), torch.from_numpy(sc)
+        pos = np.zeros((n,), np.int32)
+        pos[perm] = np.arange(v, dtype=np.int32)
+        return torch.from_numpy(send), torch.from_numpy(full_perm), torch.from_numpy(pos), torch.from_numpy(sc)
 
     def owner_merge(self, recv, recv_counts, world, c, reduction, shape):
         r = recv.numpy()
@@ -254,13 +256,11 @@ class NumpyOps:
     def owner_reply(self, rec_owned, vids):
         return vids[rec_owned.long()]
 
-    def owner_map(self, local_map, perm, back):
+    def owner_map(self, local_map, pos_of_local, back):
         m = local_map.numpy()
-        vid_of_local = np.zeros((max(len(back), 1),), np.int64)
-        vid_of_local[perm.numpy()[:len(back)]] = back.numpy()
         out = np.full(m.shape, -1, np.int64)
         ok = m >= 0
-        out[ok] = vid_of_local[m[ok]]
+        out[ok] = back.numpy()[pos_of_local.numpy()[m[ok]]]
         return torch.from_numpy(out)
 
     def owner_replicate(self, nvox, vids, coords_in, cnt_in, feats_in):
