@@ -39,15 +39,15 @@ __host__ __device__ inline int rec_stride(int c) { return (5 + c + 1) & ~1; }
 
 // ---------------------------------------------------------------- partition of the local voxels by owner (3 launches)
 // per tile of kPackTile voxels: how many go to each rank
-__global__ __launch_bounds__(256) void k_owner_count(const int64_t *__restrict__ keys, const int64_t *__restrict__ counts,
+__global__ __launch_bounds__(1024) void k_owner_count(const int64_t *__restrict__ keys, const int64_t *__restrict__ counts,
                                                      uint32_t world, uint32_t *__restrict__ tilecnt)
 {
     __shared__ uint32_t h[kMaxWorld];
     const int64_t V = counts[D3D_COUNT_VOXELS];
     if (threadIdx.x < kMaxWorld) h[threadIdx.x] = 0;
     __syncthreads();
-    for (int k = 0; k < kPackTile / 256; k++) {
-        const int64_t i = (int64_t)blockIdx.x * kPackTile + k * 256 + threadIdx.x;
+    for (int k = 0; k < kPackTile / 1024; k++) {
+        const int64_t i = (int64_t)blockIdx.x * kPackTile + k * 1024 + threadIdx.x;
         if (i < V) atomicAdd(&h[owner_of(keys[i], world)], 1u);
     }
     __syncthreads();
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(1024) void k_owner_offsets(uint32_t *tilecnt, uint3
 
 // records to their place in the send buffer (grouped by destination, tile order inside a destination, the order inside a
 // tile from the wavefronts' ballots: the same on every run)
-__global__ __launch_bounds__(256) void k_owner_scatter(const int64_t *__restrict__ keys, const int32_t *__restrict__ cnt,
+__global__ __launch_bounds__(1024) void k_owner_scatter(const int64_t *__restrict__ keys, const int32_t *__restrict__ cnt,
                                                        const float *__restrict__ agg, const int64_t *__restrict__ first,
                                                        const int64_t *__restrict__ counts, int c, uint32_t world,
                                                        const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ dest_base,
@@ -100,14 +100,14 @@ __global__ __launch_bounds__(256) void k_owner_scatter(const int64_t *__restrict
                                                        int32_t *__restrict__ pos_of_local)
 {
     __shared__ uint32_t run[kMaxWorld];          // records of this tile already placed, per destination
-    __shared__ uint32_t wcnt[256 / kWave][kMaxWorld];
+    __shared__ uint32_t wcnt[1024 / kWave][kMaxWorld];
     const int64_t V = counts[D3D_COUNT_VOXELS];
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     const int RS = rec_stride(c);
     if (threadIdx.x < kMaxWorld) run[threadIdx.x] = 0;
     __syncthreads();
-    for (int k = 0; k < kPackTile / 256; k++) {
-        const int64_t i = (int64_t)blockIdx.x * kPackTile + k * 256 + threadIdx.x;
+    for (int k = 0; k < kPackTile / 1024; k++) {
+        const int64_t i = (int64_t)blockIdx.x * kPackTile + k * 1024 + threadIdx.x;
         const bool ok = i < V;
         const int64_t key = ok ? keys[i] : 0;
         const uint32_t d = ok ? owner_of(key, world) : 0xffffffffu;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_owner_scatter(const int64_t *__restrict
         __syncthreads();
         if (threadIdx.x < world) {
             uint32_t add = 0;
-            for (int ww = 0; ww < 256 / kWave; ww++) add += wcnt[ww][threadIdx.x];
+            for (int ww = 0; ww < 1024 / kWave; ww++) add += wcnt[ww][threadIdx.x];
             run[threadIdx.x] += add;
         }
         __syncthreads();
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_owner_scatter(const int64_t *__restrict
 // ---------------------------------------------------------------- merge on the owner
 struct MergeWs {
     u64 *tkey;            // [cap]
-    uint32_t *contrib;    // [cap * world] record index + 1 per source rank, 0 = none
+    uint32_t *contrib;    // [cap * ws] record index + 1 per source rank, 0 = none; ws = world rounded up to 4 (16-byte reads)
     uint32_t *rec_slot;   // [R]
     uint32_t *slot_owned; // [cap]
     unsigned char *flag;  // [R]
@@ -163,7 +163,7 @@ static MergeWs carve_merge(void *ws, size_t bytes, int64_t R, int world)
     MergeWs m;
     m.cap = merge_cap(R);
     m.tkey = w.take<u64>(m.cap);
-    m.contrib = w.take<uint32_t>(m.cap * (size_t)world);
+    m.contrib = w.take<uint32_t>(m.cap * (size_t)((world + 3) & ~3));
     m.rec_slot = w.take<uint32_t>(R > 0 ? R : 1);
     m.slot_owned = w.take<uint32_t>(m.cap);
     m.flag = w.take<unsigned char>(R > 0 ? R : 1);
@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void k_merge_init(u64 *tkey, uint32_t *contrib
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) tkey[i] = kFree;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap * (u64)world; i += stride) contrib[i] = 0;
+    uint4 *c4 = reinterpret_cast<uint4 *>(contrib);
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap * (u64)((world + 3) >> 2); i += stride) c4[i] = make_uint4(0, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(256) void k_merge_insert(const int32_t *__restrict__ recv, int64_t R, int RS,
@@ -197,11 +198,15 @@ __global__ __launch_bounds__(256) void k_merge_insert(const int32_t *__restrict_
     // (a second mix: the owner hash already split on mix64's top bits)
     u64 h = __umul64hi(mix64(key * 0x9e3779b97f4a7c15ull), cap);
     for (;;) {
-        const u64 old = atomicCAS(&tkey[h], kFree, key);      // most records are the first of their cell: claim at once
-        if (old == kFree || old == key) break;
+        const u64 cur = __hip_atomic_load(&tkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) break;
+        if (cur == kFree) {
+            const u64 old = atomicCAS(&tkey[h], kFree, key);
+            if (old == kFree || old == key) break;
+        }
         h = h + 1 < cap ? h + 1 : 0;              // cap >= 1.5 R: a free slot always exists
     }
-    contrib[h * (u64)world + lo] = (uint32_t)i + 1u;
+    contrib[h * (u64)((world + 3) & ~3) + lo] = (uint32_t)i + 1u;
     rec_slot[i] = (uint32_t)h;
 }
 
@@ -236,10 +241,16 @@ struct MergeRecords {
     __device__ u64 value(int64_t i) const
     {
         const int s = record_source(src_off, world, i);
-        const uint32_t *cb = contrib + (u64)rec_slot[i] * world;
+        const int ws = (world + 3) & ~3;
+        const uint4 *cb = reinterpret_cast<const uint4 *>(contrib + (u64)rec_slot[i] * ws);
         unsigned char f = 3;
-        for (int q = 0; q < world; q++)
-            if (cb[q] && q != s) f = q < s ? 0 : (f & 1);
+        for (int q4 = 0; q4 < ws; q4 += 4) {        // one 16-byte read per four source ranks
+            const uint4 x = cb[q4 >> 2];
+            const uint32_t e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (e[k] && q4 + k != s) f = q4 + k < s ? 0 : (f & 1);
+        }
         flag[i] = f;
         return f ? 1ull : 0ull;
     }
@@ -270,7 +281,7 @@ struct MergeRecords {
             *reinterpret_cast<float4 *>(feats + o * 4) = make_float4(a[0] / d, a[1] / d, a[2] / d, a[3] / d);
             return;
         }
-        const uint32_t *cb = contrib + (u64)slot * world;
+        const uint32_t *cb = contrib + (u64)slot * ((world + 3) & ~3);
         const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
         const float ident = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
         float a0 = ident, a1 = ident, a2 = ident, a3 = ident;      // c == 4 in registers; other widths through feats[]
@@ -424,12 +435,12 @@ extern "C" int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const flo
     WsCarver w(workspace, workspace_bytes);
     uint32_t *tilecnt = w.take<uint32_t>((size_t)ntiles * world);
     uint32_t *dest_base = w.take<uint32_t>(world + 1);
-    if (n > 0) D3D_LAUNCH("k_owner_count", k_owner_count, dim3(ntiles), dim3(256), 0, st, keys, counts, (uint32_t)world, tilecnt);
+    if (n > 0) D3D_LAUNCH("k_owner_count", k_owner_count, dim3(ntiles), dim3(1024), 0, st, keys, counts, (uint32_t)world, tilecnt);
     else D3D_HIP_CHECK(hipMemsetAsync(tilecnt, 0, (size_t)ntiles * world * 4, st));
     D3D_LAUNCH("k_owner_offsets", k_owner_offsets, dim3(1), dim3(1024), 0, st, tilecnt, ntiles, (uint32_t)world, send_counts,
                dest_base, keys ? keys + n : (const int64_t *)nullptr);
     if (n > 0)
-        D3D_LAUNCH("k_owner_scatter", k_owner_scatter, dim3(ntiles), dim3(256), 0, st, keys, cnt, agg, first, counts, (int)c,
+        D3D_LAUNCH("k_owner_scatter", k_owner_scatter, dim3(ntiles), dim3(1024), 0, st, keys, cnt, agg, first, counts, (int)c,
                    (uint32_t)world, tilecnt, dest_base, send, perm, pos_of_local);
     return D3D_OK;
 }
@@ -454,7 +465,7 @@ extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *sr
     MergeWs m = carve_merge(workspace, workspace_bytes, R, world);
     if (!workspace || m.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     D3D_HIP_CHECK(hipMemsetAsync(counts, 0, D3D_NUM_COUNTS * sizeof(int64_t), st));
-    D3D_LAUNCH("k_merge_init", k_merge_init, dim3(blocks_for((int64_t)m.cap * world, 256 * 8)), dim3(256), 0, st, m.tkey, m.contrib,
+    D3D_LAUNCH("k_merge_init", k_merge_init, dim3(blocks_for((int64_t)m.cap * ((world + 3) >> 2), 256 * 4)), dim3(256), 0, st, m.tkey, m.contrib,
                m.cap, (int)world);
     if (R > 0)
         D3D_LAUNCH("k_merge_insert", k_merge_insert, dim3(blocks_for(R)), dim3(256), 0, st, recv, R, rec_stride(c), src_off, (int)world,
