@@ -49,8 +49,9 @@ SIGNATURES = {
                                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _u32]),
     "d3d_voxelize_3d_filter_chained": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32,
                                                       _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "d3d_voxelize_3d_reduce": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                              _vp, _sz, _vp, _u32]),
+    "d3d_voxelize_reduce_rows": (_sz, [_i64]),
+    "d3d_voxelize_3d_reduce": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                              _i32, _vp, _vp, _vp, _vp, _sz, _vp, _u32]),
     "d3d_sharded_scatter": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _sz, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                            _vp, _vp, _vp, _vp, _vp]),
     "d3d_sharded_finalize": (ctypes.c_int, [_i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
@@ -68,9 +69,11 @@ SIGNATURES = {
     "d3d_grid_compact_lookup": (ctypes.c_int, [_vp, _i64, _i64, _vp, _sz, _i64, _vp, _vp]),
     "d3d_owner_record_words": (ctypes.c_int, [_i32]),
     "d3d_owner_pack_workspace_bytes": (_sz, [_i64, _i32]),
-    "d3d_owner_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3d_owner_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _sz, _vp]),
     "d3d_owner_merge_workspace_bytes": (_sz, [_i64, _i32]),
-    "d3d_owner_merge": (ctypes.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3d_owner_merge": (ctypes.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3d_owner_dense": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp, _vp]),
     "d3d_owner_mark_first": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "d3d_owner_number_workspace_bytes": (_sz, [_i64]),
     "d3d_owner_number": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),

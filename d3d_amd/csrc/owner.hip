@@ -38,103 +38,162 @@ __device__ __forceinline__ uint32_t owner_of(int64_t key, uint32_t world)
 __host__ __device__ inline int rec_stride(int c) { return (5 + c + 1) & ~1; }
 
 // ---------------------------------------------------------------- partition of the local voxels by owner (3 launches)
-// per tile of kPackTile voxels: how many go to each rank
-__global__ __launch_bounds__(1024) void k_owner_count(const int64_t *__restrict__ keys, const int64_t *__restrict__ counts,
-                                                     uint32_t world, uint32_t *__restrict__ tilecnt)
+// DENSE: the voxels' ranked rows (the first min(count, P) points of every local voxel, d3d_voxelize_3d_reduce's `rows`) travel
+// too, in a second buffer with the same grouping; a record then carries, in its last word, the offset of its rows inside
+// its (source, destination) batch.
+struct PackDense {
+    uint32_t P;
+    const uint32_t *seg_base;     // [n] first row of every local voxel in rows_local
+    const float4 *rows_local;
+    float4 *send_rows;
+    uint32_t *tilerows;           // [ntiles][world] rows per tile and destination -> exclusive prefix over the tiles
+    uint32_t *dest_rowbase;       // [world + 1]
+};
+
+// per tile of kPackTile voxels: how many go to each rank (DENSE: and how many rows)
+template <bool DENSE>
+__global__ __launch_bounds__(1024) void k_owner_count(const int64_t *__restrict__ keys, const int32_t *__restrict__ cnt,
+                                                      const int64_t *__restrict__ counts, uint32_t world,
+                                                      uint32_t *__restrict__ tilecnt, PackDense pd)
 {
-    __shared__ uint32_t h[kMaxWorld];
+    __shared__ uint32_t h[kMaxWorld], hr[kMaxWorld];
     const int64_t V = counts[D3D_COUNT_VOXELS];
-    if (threadIdx.x < kMaxWorld) h[threadIdx.x] = 0;
+    if (threadIdx.x < kMaxWorld) { h[threadIdx.x] = 0; hr[threadIdx.x] = 0; }
     __syncthreads();
     for (int k = 0; k < kPackTile / 1024; k++) {
         const int64_t i = (int64_t)blockIdx.x * kPackTile + k * 1024 + threadIdx.x;
-        if (i < V) atomicAdd(&h[owner_of(keys[i], world)], 1u);
+        if (i < V) {
+            const uint32_t d = owner_of(keys[i], world);
+            atomicAdd(&h[d], 1u);
+            if (DENSE) { const uint32_t c = (uint32_t)cnt[i]; atomicAdd(&hr[d], c < pd.P ? c : pd.P); }
+        }
     }
     __syncthreads();
-    if (threadIdx.x < world) tilecnt[(size_t)blockIdx.x * world + threadIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < world) {
+        tilecnt[(size_t)blockIdx.x * world + threadIdx.x] = h[threadIdx.x];
+        if (DENSE) pd.tilerows[(size_t)blockIdx.x * world + threadIdx.x] = hr[threadIdx.x];
+    }
 }
 
-// one wavefront per destination: exclusive prefix of its column of tilecnt over the tiles; then the destinations' bases.
-// send_counts[0 .. world) = records per destination, [world] = the shard's status bits (keys[n] = -1 - status)
-__global__ __launch_bounds__(1024) void k_owner_offsets(uint32_t *tilecnt, uint32_t ntiles, uint32_t world, int64_t *send_counts,
-                                                        uint32_t *dest_base, const int64_t *status_key)
+// one wavefront per destination (and matrix): exclusive prefix of its column over the tiles; then the destinations' bases.
+// send_counts[0 .. world) = records per destination, [world] = the shard's status bits (keys[n] = -1 - status),
+// [world + 1 .. 2 world + 1) = rows per destination (DENSE, else 0)
+__global__ __launch_bounds__(1024) void k_owner_offsets(uint32_t *tilecnt, uint32_t *tilerows, uint32_t ntiles, uint32_t world,
+                                                        int64_t *send_counts, uint32_t *dest_base, uint32_t *dest_rowbase,
+                                                        const int64_t *status_key)
 {
-    __shared__ uint32_t tot[kMaxWorld];
+    __shared__ uint32_t tot[2][kMaxWorld];
     const int lane = threadIdx.x & (kWave - 1);
-    for (uint32_t d = threadIdx.x >> 6; d < world; d += 1024 / kWave) {
+    const uint32_t jobs = tilerows ? 2 * world : world;
+    for (uint32_t job = threadIdx.x >> 6; job < jobs; job += 1024 / kWave) {
+        const uint32_t d = job % world, which = job / world;
+        uint32_t *mat = which ? tilerows : tilecnt;
         uint32_t carry = 0;
         for (uint32_t t0 = 0; t0 < ntiles; t0 += kWave) {
             const uint32_t t = t0 + lane;
-            const uint32_t x = t < ntiles ? tilecnt[(size_t)t * world + d] : 0u;
+            const uint32_t x = t < ntiles ? mat[(size_t)t * world + d] : 0u;
             uint32_t incl = x;
 #pragma unroll
             for (int s = 1; s < kWave; s <<= 1) {
                 const uint32_t y = (uint32_t)__shfl_up((int)incl, s, kWave);
                 if (lane >= s) incl += y;
             }
-            if (t < ntiles) tilecnt[(size_t)t * world + d] = carry + incl - x;
+            if (t < ntiles) mat[(size_t)t * world + d] = carry + incl - x;
             carry += (uint32_t)__shfl((int)incl, kWave - 1, kWave);
         }
-        if (lane == 0) tot[d] = carry;
+        if (lane == 0) tot[which][d] = carry;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t run = 0;
+        uint32_t run = 0, rrun = 0;
         for (uint32_t d = 0; d < world; d++) {
             dest_base[d] = run;
-            send_counts[d] = tot[d];
-            run += tot[d];
+            send_counts[d] = tot[0][d];
+            run += tot[0][d];
+            const uint32_t r = tilerows ? tot[1][d] : 0u;
+            if (tilerows) dest_rowbase[d] = rrun;
+            send_counts[world + 1 + d] = r;
+            rrun += r;
         }
         dest_base[world] = run;
+        if (tilerows) dest_rowbase[world] = rrun;
         send_counts[world] = status_key ? -1 - *status_key : 0;
     }
 }
 
 // records to their place in the send buffer (grouped by destination, tile order inside a destination, the order inside a
 // tile from the wavefronts' ballots: the same on every run)
+template <bool DENSE>
 __global__ __launch_bounds__(1024) void k_owner_scatter(const int64_t *__restrict__ keys, const int32_t *__restrict__ cnt,
-                                                       const float *__restrict__ agg, const int64_t *__restrict__ first,
-                                                       const int64_t *__restrict__ counts, int c, uint32_t world,
-                                                       const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ dest_base,
-                                                       int32_t *__restrict__ send, int32_t *__restrict__ perm,
-                                                       int32_t *__restrict__ pos_of_local)
+                                                        const float *__restrict__ agg, const int64_t *__restrict__ first,
+                                                        const int64_t *__restrict__ counts, int c, uint32_t world,
+                                                        const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ dest_base,
+                                                        int32_t *__restrict__ send, int32_t *__restrict__ perm,
+                                                        int32_t *__restrict__ pos_of_local, PackDense pd)
 {
-    __shared__ uint32_t run[kMaxWorld];          // records of this tile already placed, per destination
-    __shared__ uint32_t wcnt[1024 / kWave][kMaxWorld];
+    __shared__ uint32_t run[kMaxWorld], runr[kMaxWorld];   // records / rows of this tile already placed, per destination
+    __shared__ uint32_t wcnt[1024 / kWave][kMaxWorld], wrow[DENSE ? 1024 / kWave : 1][kMaxWorld];
     const int64_t V = counts[D3D_COUNT_VOXELS];
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     const int RS = rec_stride(c);
-    if (threadIdx.x < kMaxWorld) run[threadIdx.x] = 0;
+    if (threadIdx.x < kMaxWorld) { run[threadIdx.x] = 0; runr[threadIdx.x] = 0; }
     __syncthreads();
     for (int k = 0; k < kPackTile / 1024; k++) {
         const int64_t i = (int64_t)blockIdx.x * kPackTile + k * 1024 + threadIdx.x;
         const bool ok = i < V;
         const int64_t key = ok ? keys[i] : 0;
         const uint32_t d = ok ? owner_of(key, world) : 0xffffffffu;
-        uint32_t myrank = 0;
+        const uint32_t nc = ok ? (uint32_t)cnt[i] : 0u;
+        const uint32_t kept = DENSE ? (nc < pd.P ? nc : pd.P) : 0u;
+        uint32_t myrank = 0, myrows = 0;
         for (uint32_t q = 0; q < world; q++) {               // wave-uniform
             const u64 b = __ballot(d == q);
             if (d == q) myrank = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
             if (lane == 0) wcnt[w][q] = (uint32_t)__popcll(b);
+            if (DENSE) {                                      // rows of the same-destination records before mine in the wave
+                uint32_t incl = d == q ? kept : 0u;
+#pragma unroll
+                for (int sft = 1; sft < kWave; sft <<= 1) {
+                    const uint32_t y = (uint32_t)__shfl_up((int)incl, sft, kWave);
+                    if (lane >= sft) incl += y;
+                }
+                if (d == q) myrows = incl - kept;
+                if (lane == kWave - 1) wrow[w][q] = incl;
+            }
         }
         __syncthreads();
         if (ok) {
-            uint32_t before = run[d];
-            for (int ww = 0; ww < w; ww++) before += wcnt[ww][d];
-            const uint32_t pos = dest_base[d] + tileoff[(size_t)blockIdx.x * world + d] + before + myrank;
+            uint32_t before = run[d], rbefore = DENSE ? runr[d] : 0u;
+            for (int ww = 0; ww < w; ww++) {
+                before += wcnt[ww][d];
+                if (DENSE) rbefore += wrow[ww][d];
+            }
+            const size_t tidx = (size_t)blockIdx.x * world + d;
+            const uint32_t pos = dest_base[d] + tileoff[tidx] + before + myrank;
             int32_t *r = send + (size_t)pos * RS;
             *reinterpret_cast<int64_t *>(r) = key;
             *reinterpret_cast<int64_t *>(r + 2) = first[i];
-            r[4] = cnt[i];
+            r[4] = (int32_t)nc;
             for (int f = 0; f < c; f++) r[5 + f] = __float_as_int(agg[i * c + f]);
             perm[pos] = (int32_t)i;
             pos_of_local[i] = (int32_t)pos;
+            if (DENSE) {
+                const uint32_t inbatch = pd.tilerows[tidx] + rbefore + myrows;      // offset inside the (me -> d) row batch
+                r[RS - 1] = (int32_t)inbatch;
+                const float4 *src = pd.rows_local + pd.seg_base[i];
+                float4 *dst = pd.send_rows + pd.dest_rowbase[d] + inbatch;
+                for (uint32_t t = 0; t < kept; t++) dst[t] = src[t];
+            }
         }
         __syncthreads();
         if (threadIdx.x < world) {
-            uint32_t add = 0;
-            for (int ww = 0; ww < 1024 / kWave; ww++) add += wcnt[ww][threadIdx.x];
+            uint32_t add = 0, addr = 0;
+            for (int ww = 0; ww < 1024 / kWave; ww++) {
+                add += wcnt[ww][threadIdx.x];
+                if (DENSE) addr += wrow[ww][threadIdx.x];
+            }
             run[threadIdx.x] += add;
+            runr[threadIdx.x] += addr;
         }
         __syncthreads();
     }
@@ -152,9 +211,9 @@ struct MergeWs {
     size_t bytes;
 };
 
-static u64 merge_cap(int64_t R)        // load factor <= 2/3; slots are found by multiply-shift, so no power of two is needed
+static u64 merge_cap(int64_t R)        // load factor <= 1/2; slots are found by multiply-shift, so no power of two is needed
 {
-    return (u64)d3d_divup((R > 0 ? R : 1) * 3, 2 * 1024) * 1024 + 1024;
+    return (u64)d3d_divup((R > 0 ? R : 1) * 2, 1024) * 1024 + 1024;
 }
 
 static MergeWs carve_merge(void *ws, size_t bytes, int64_t R, int world)
@@ -204,7 +263,7 @@ __global__ __launch_bounds__(256) void k_merge_insert(const int32_t *__restrict_
             const u64 old = atomicCAS(&tkey[h], kFree, key);
             if (old == kFree || old == key) break;
         }
-        h = h + 1 < cap ? h + 1 : 0;              // cap >= 1.5 R: a free slot always exists
+        h = h + 1 < cap ? h + 1 : 0;              // cap >= 2 R: a free slot always exists
     }
     contrib[h * (u64)((world + 3) & ~3) + lo] = (uint32_t)i + 1u;
     rec_slot[i] = (uint32_t)h;
@@ -238,6 +297,7 @@ struct MergeRecords {
     int64_t *first_o, *coords;
     int32_t *npoints;
     float *feats;
+    int32_t *lead_rec;                   // [owned voxel] its leader record
     __device__ u64 value(int64_t i) const
     {
         const int s = record_source(src_off, world, i);
@@ -261,6 +321,7 @@ struct MergeRecords {
         const int64_t o = (int64_t)excl;
         const uint32_t slot = rec_slot[i];
         slot_owned[slot] = (uint32_t)o;
+        lead_rec[o] = (int32_t)i;
         if (flag[i] == 3 && c == 4) {             // the cell's only record (4 of 5 at config 5): everything is in record i
             const int32_t *r = recv + (size_t)i * RS;
             const int64_t key = *reinterpret_cast<const int64_t *>(r);
@@ -393,6 +454,103 @@ __global__ __launch_bounds__(256) void k_owner_map(int64_t n, const int64_t *__r
     gmap[i] = v < 0 ? -1 : back[pos_of_local[v]];
 }
 
+// ---------------------------------------------------------------- dense contract on the owner: voxels[Vo, P, 4] + pmask
+// The first P points of a voxel by GLOBAL index (voxelize.cpp:128-134): the ranks' candidate rows (each the first
+// min(count, P) points of the voxel inside that shard, in point order) taken in rank order until P are filled -- shards are
+// contiguous point ranges in rank order, so a lower rank's points all come first.  The shape of k_emit (voxel.hip): a
+// wavefront owns 64 consecutive owned voxels = one contiguous stretch of the outputs; lane j walks voxel j's records in rank
+// order and copies its rows into a row buffer in LDS; the stretch is then written 1 KiB per store instruction from LDS.
+constexpr int kDenseCap = 256;                    // rows per wavefront in LDS; max_points <= kDenseCap
+
+__global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__ counts_o, const int32_t *__restrict__ lead_rec,
+                                                     const int32_t *__restrict__ npoints, const uint32_t *__restrict__ rec_slot,
+                                                     const uint32_t *__restrict__ contrib, int world,
+                                                     const int32_t *__restrict__ recv, int RS, const float4 *__restrict__ recv_rows,
+                                                     const int64_t *__restrict__ rows_src_off, uint32_t P, int pshift,
+                                                     float4 *voxels, unsigned char *pmask)
+{
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    __shared__ vec4 rowbuf_all[256 / kWave][kDenseCap];
+    __shared__ uint32_t off_all[256 / kWave][kWave];
+    __shared__ uint16_t kept_all[256 / kWave][kWave];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    vec4 *rowbuf = rowbuf_all[w];
+    uint32_t *sh_off = off_all[w];
+    uint16_t *sh_kept = kept_all[w];
+    const int64_t Vo = counts_o[D3D_COUNT_VOXELS];
+    const int64_t v0 = ((int64_t)blockIdx.x * (256 / kWave) + w) * kWave;
+    if (v0 >= Vo) return;                                   // wave-uniform
+    const uint32_t nv = Vo - v0 < kWave ? (uint32_t)(Vo - v0) : (uint32_t)kWave;
+    const bool mine = (uint32_t)lane < nv;
+    const int ws = (world + 3) & ~3;
+    uint32_t slot = 0, kept = 0;
+    if (mine) {
+        slot = rec_slot[lead_rec[v0 + lane]];
+        const uint32_t n = (uint32_t)npoints[v0 + lane];
+        kept = n < P ? n : P;
+    }
+    uint32_t incl = kept;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, kWave);
+        if (lane >= d) incl += t;
+    }
+    const uint32_t off = incl - kept;
+    sh_off[lane] = off; sh_kept[lane] = (uint16_t)kept;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    vec4 *out = reinterpret_cast<vec4 *>(voxels) + v0 * (int64_t)P;
+    const vec4 zero = {0.f, 0.f, 0.f, 0.f};
+    uint32_t ja = 0;
+    while (ja < nv) {                                       // wave-uniform: one batch unless the rows exceed the buffer
+        const uint32_t oa = (uint32_t)__shfl((int)off, (int)ja, kWave);
+        const bool fits = (uint32_t)lane >= ja && mine && incl - oa <= (uint32_t)kDenseCap;
+        const unsigned long long nf = ~(__ballot(fits) >> ja);
+        const uint32_t jb = ja + (nf ? (uint32_t)__ffsll((long long)nf) - 1u : (uint32_t)kWave - ja);
+        if ((uint32_t)lane >= ja && (uint32_t)lane < jb) {  // my voxel's rows, in rank order of the contributing records
+            const uint4 *cb = reinterpret_cast<const uint4 *>(contrib + (u64)slot * ws);
+            vec4 *dst = rowbuf + (off - oa);
+            uint32_t have = 0;
+            for (int q4 = 0; q4 < ws && have < kept; q4 += 4) {
+                const uint4 x = cb[q4 >> 2];
+                const uint32_t e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (!e[k] || have >= kept) continue;
+                    const int32_t *r = recv + (size_t)(e[k] - 1) * RS;
+                    const uint32_t nr = (uint32_t)r[4] < P ? (uint32_t)r[4] : P;
+                    const uint32_t take = nr < kept - have ? nr : kept - have;
+                    const vec4 *src = reinterpret_cast<const vec4 *>(recv_rows) + rows_src_off[q4 + k] + (uint32_t)r[RS - 1];
+                    for (uint32_t t = 0; t < take; t++) dst[have + t] = src[t];
+                    have += take;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t q1 = jb * P;
+        for (uint32_t q0 = ja * P; q0 < q1; q0 += 4 * kWave) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t q = q0 + u * kWave + lane;
+                if (q < q1) {
+                    const uint32_t j = pshift >= 0 ? (q >> pshift) : q / P;
+                    const uint32_t sl = q - j * P;
+                    vec4 val = zero;
+                    if (sl < sh_kept[j]) val = rowbuf[sh_off[j] - oa + sl];
+                    __builtin_nontemporal_store(val, &out[q]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ja = jb;
+    }
+    // pmask[nv][P] bytes, contiguous over the stretch
+    unsigned char *pdst = pmask + v0 * (int64_t)P;
+    for (uint32_t t = lane; t < nv * P; t += kWave) {
+        const uint32_t j = pshift >= 0 ? (t >> pshift) : t / P;
+        pdst[t] = (t - j * P) < sh_kept[j] ? 1 : 0;
+    }
+}
+
 // replicate: rows of all owners (any order) -> voxel-id order
 __global__ __launch_bounds__(256) void k_owner_replicate(int64_t V, const int64_t *__restrict__ vids,
                                                          const int64_t *__restrict__ coords_in, const int32_t *__restrict__ cnt_in,
@@ -417,31 +575,52 @@ extern "C" int d3d_owner_record_words(int32_t c) { return rec_stride(c); }
 extern "C" size_t d3d_owner_pack_workspace_bytes(int64_t n, int32_t world)
 {
     const int64_t ntiles = d3d_divup(n > 0 ? n : 1, kPackTile);
-    return d3d_align_up((size_t)ntiles * world * 4) + d3d_align_up((size_t)(world + 1) * 4) + 256;
+    return 2 * (d3d_align_up((size_t)ntiles * world * 4) + d3d_align_up((size_t)(world + 1) * 4)) + 256;
 }
 
 // local voxels (outputs of d3d_voxelize_3d_reduce: keys[n + 1], cnt[n], agg[n, c], first[n], counts) -> records grouped by
-// owner rank: send[n, d3d_owner_record_words(c)] (int32 words), perm[n] (send position -> local voxel),
-// send_counts[world + 1] (device; records per destination, then the shard's status bits)
+// owner rank: send[n, d3d_owner_record_words(c)] (int32 words), perm[n] (send position -> local voxel), pos_of_local[n] (its inverse),
+// send_counts[2 world + 1] (device): records per destination, the shard's status bits, rows per destination.
+// Dense contract (max_points > 0; c == 4): seg_base / rows_local as left by d3d_voxelize_3d_reduce(max_points, ...) ->
+// send_rows[kept rows, 4] with the same grouping; a record's last word = offset of its rows inside its batch.
 extern "C" int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const float *agg, const int64_t *first,
-                              const int64_t *counts, int64_t n, int32_t c, int32_t world, int32_t *send, int32_t *perm,
-                              int32_t *pos_of_local, int64_t *send_counts, void *workspace, size_t workspace_bytes, void *stream)
+                              const int64_t *counts, int64_t n, int32_t c, int32_t world, int32_t max_points,
+                              const uint32_t *seg_base, const float *rows_local, int32_t *send, int32_t *perm,
+                              int32_t *pos_of_local, float *send_rows, int64_t *send_counts, void *workspace,
+                              size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (n < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !send_counts) return D3D_ERR_BAD_ARG;
+    if (n < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !send_counts || max_points < 0) return D3D_ERR_BAD_ARG;
     if (n > 0 && (!keys || !cnt || !agg || !first || !send || !perm || !pos_of_local)) return D3D_ERR_BAD_ARG;
+    const bool dense = max_points > 0;
+    if (dense && (c != 4 || (n > 0 && (!seg_base || !rows_local || !send_rows)))) return D3D_ERR_BAD_ARG;
+    if (dense && ((reinterpret_cast<uintptr_t>(rows_local) | reinterpret_cast<uintptr_t>(send_rows)) & 15)) return D3D_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < d3d_owner_pack_workspace_bytes(n, world)) return D3D_ERR_WORKSPACE;
     const uint32_t ntiles = (uint32_t)d3d_divup(n > 0 ? n : 1, kPackTile);
     WsCarver w(workspace, workspace_bytes);
     uint32_t *tilecnt = w.take<uint32_t>((size_t)ntiles * world);
     uint32_t *dest_base = w.take<uint32_t>(world + 1);
-    if (n > 0) D3D_LAUNCH("k_owner_count", k_owner_count, dim3(ntiles), dim3(1024), 0, st, keys, counts, (uint32_t)world, tilecnt);
-    else D3D_HIP_CHECK(hipMemsetAsync(tilecnt, 0, (size_t)ntiles * world * 4, st));
-    D3D_LAUNCH("k_owner_offsets", k_owner_offsets, dim3(1), dim3(1024), 0, st, tilecnt, ntiles, (uint32_t)world, send_counts,
-               dest_base, keys ? keys + n : (const int64_t *)nullptr);
-    if (n > 0)
-        D3D_LAUNCH("k_owner_scatter", k_owner_scatter, dim3(ntiles), dim3(1024), 0, st, keys, cnt, agg, first, counts, (int)c,
-                   (uint32_t)world, tilecnt, dest_base, send, perm, pos_of_local);
+    uint32_t *tilerows = w.take<uint32_t>((size_t)ntiles * world);
+    uint32_t *dest_rowbase = w.take<uint32_t>(world + 1);
+    PackDense pd{(uint32_t)max_points, seg_base, reinterpret_cast<const float4 *>(rows_local), reinterpret_cast<float4 *>(send_rows),
+                 tilerows, dest_rowbase};
+    if (n > 0) {
+        if (dense) D3D_LAUNCH("k_owner_count", k_owner_count<true>, dim3(ntiles), dim3(1024), 0, st, keys, cnt, counts, (uint32_t)world, tilecnt, pd);
+        else D3D_LAUNCH("k_owner_count", k_owner_count<false>, dim3(ntiles), dim3(1024), 0, st, keys, cnt, counts, (uint32_t)world, tilecnt, pd);
+    } else {
+        D3D_HIP_CHECK(hipMemsetAsync(tilecnt, 0, (size_t)ntiles * world * 4, st));
+        D3D_HIP_CHECK(hipMemsetAsync(tilerows, 0, (size_t)ntiles * world * 4, st));
+    }
+    D3D_LAUNCH("k_owner_offsets", k_owner_offsets, dim3(1), dim3(1024), 0, st, tilecnt, dense ? tilerows : (uint32_t *)nullptr, ntiles,
+               (uint32_t)world, send_counts, dest_base, dest_rowbase, keys ? keys + n : (const int64_t *)nullptr);
+    if (n > 0) {
+        if (dense)
+            D3D_LAUNCH("k_owner_scatter", k_owner_scatter<true>, dim3(ntiles), dim3(1024), 0, st, keys, cnt, agg, first, counts, (int)c,
+                       (uint32_t)world, tilecnt, dest_base, send, perm, pos_of_local, pd);
+        else
+            D3D_LAUNCH("k_owner_scatter", k_owner_scatter<false>, dim3(ntiles), dim3(1024), 0, st, keys, cnt, agg, first, counts, (int)c,
+                       (uint32_t)world, tilecnt, dest_base, send, perm, pos_of_local, pd);
+    }
     return D3D_OK;
 }
 
@@ -452,16 +631,18 @@ extern "C" size_t d3d_owner_merge_workspace_bytes(int64_t R, int32_t world)
 
 // received records recv[R, words] (grouped by source rank: src_off[world + 1], device) -> this owner's voxels IN GLOBAL ID
 // ORDER, finished: first_o / coords / npoints / feats [R rows, counts[D3D_COUNT_VOXELS] valid], rec_owned[R] = the owned voxel
-// of every record.  reduction: MEAN (sums in rank order, then the division of voxelize.cpp:164), MAX, MIN.
+// of every record, lead_rec[R] = the leader record of every owned voxel.  reduction: MEAN (sums in rank order, then the division
+// of voxelize.cpp:164), MAX, MIN.  The workspace keeps the table (for d3d_owner_dense) until it is reused.
 extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *src_off, int32_t world, int32_t c, int32_t reduction,
                                const int32_t *shape, int64_t *first_o, int64_t *coords, int32_t *npoints, float *feats,
-                               int32_t *rec_owned, int64_t *counts, void *workspace, size_t workspace_bytes, void *stream)
+                               int32_t *rec_owned, int32_t *lead_rec, int64_t *counts, void *workspace, size_t workspace_bytes,
+                               void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (R < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !src_off || !shape) return D3D_ERR_BAD_ARG;
     if (reduction < D3D_REDUCE_MEAN || reduction > D3D_REDUCE_MIN) return D3D_ERR_UNSUPPORTED;
     if (R >= (1ll << 31)) return D3D_ERR_BAD_ARG;
-    if (R > 0 && (!recv || !first_o || !coords || !npoints || !feats || !rec_owned)) return D3D_ERR_BAD_ARG;
+    if (R > 0 && (!recv || !first_o || !coords || !npoints || !feats || !rec_owned || !lead_rec)) return D3D_ERR_BAD_ARG;
     MergeWs m = carve_merge(workspace, workspace_bytes, R, world);
     if (!workspace || m.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     D3D_HIP_CHECK(hipMemsetAsync(counts, 0, D3D_NUM_COUNTS * sizeof(int64_t), st));
@@ -471,7 +652,7 @@ extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *sr
         D3D_LAUNCH("k_merge_insert", k_merge_insert, dim3(blocks_for(R)), dim3(256), 0, st, recv, R, rec_stride(c), src_off, (int)world,
                    m.tkey, m.cap, m.contrib, m.rec_slot);
     MergeRecords f{m.contrib, m.rec_slot, m.flag, src_off, recv, rec_stride(c), (int)c, (int)world, (int)reduction, (int64_t)shape[1],
-                   (int64_t)shape[2], m.slot_owned, first_o, coords, npoints, feats};
+                   (int64_t)shape[2], m.slot_owned, first_o, coords, npoints, feats, lead_rec};
     int rc = d3d_run_scan(f, R, m.bsum, counts, -1, D3D_COUNT_VOXELS, ~0ull, st);
     if (rc) return rc;
     if (R > 0) D3D_LAUNCH("k_merge_recmap", k_merge_recmap, dim3(blocks_for(R)), dim3(256), 0, st, R, m.rec_slot, m.slot_owned, rec_owned);
@@ -518,6 +699,29 @@ extern "C" int d3d_owner_number(const uint64_t *global_bits, int64_t n_total, co
     if (cap_o > 0)
         D3D_LAUNCH("k_owner_number", k_owner_number, dim3(blocks_for(cap_o)), dim3(256), 0, st, counts_o, (const u64 *)global_bits, pre,
                    first_o, vids);
+    return D3D_OK;
+}
+
+// dense contract on the owner, after d3d_owner_merge (whose workspace, untouched since, holds the table):
+// recv_rows[*, 4] = the candidate rows received (grouped by source rank; rows_src_off[world + 1], device), a record's last word =
+// offset of its rows inside its batch.  -> voxels[cap_o, max_points, 4] and pmask[cap_o, max_points] of the owned voxels in id order.
+extern "C" int d3d_owner_dense(const int32_t *recv, int64_t R, const float *recv_rows, const int64_t *rows_src_off, int32_t world,
+                               int32_t max_points, const int32_t *lead_rec, const int32_t *npoints, const int64_t *counts_o,
+                               int64_t cap_o, const void *merge_workspace, size_t merge_workspace_bytes, float *voxels,
+                               uint8_t *pmask, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (R < 0 || cap_o < 0 || world < 1 || world > kMaxWorld || max_points < 1 || max_points > kDenseCap || !counts_o) return D3D_ERR_BAD_ARG;
+    if (cap_o == 0) return D3D_OK;
+    if (!recv || !recv_rows || !rows_src_off || !lead_rec || !npoints || !voxels || !pmask) return D3D_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(recv_rows) | reinterpret_cast<uintptr_t>(voxels)) & 15) return D3D_ERR_BAD_ARG;
+    MergeWs m = carve_merge(const_cast<void *>(merge_workspace), merge_workspace_bytes, R, world);
+    if (!merge_workspace || m.bytes > merge_workspace_bytes) return D3D_ERR_WORKSPACE;
+    const uint32_t P = (uint32_t)max_points;
+    const int pshift = (P & (P - 1)) == 0 ? __builtin_ctz(P) : -1;
+    D3D_LAUNCH("k_owner_dense", k_owner_dense, dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec, npoints, m.rec_slot,
+               m.contrib, (int)world, recv, rec_stride(4), reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift,
+               reinterpret_cast<float4 *>(voxels), pmask);
     return D3D_OK;
 }
 

@@ -2123,6 +2123,7 @@ struct DenseOut {
     int32_t *keepid = nullptr;          // ... then: filtered voxel id of every point (-1: dropped) instead of `mapping`
     uint32_t npoints_clamp = 0xffffffffu;   // ... and voxel_npoints = min(count, max_points) (voxelize.cpp:403)
     bool lists = false;                 // dense contract with C != 4: ranked index lists + voff instead of staged rows
+    uint32_t *seg_out = nullptr;        // reduce contract: segment base of every voxel's staged rows (for the caller)
     float4 *emit_voxels = nullptr;      // dense contract on C == 4 rows: k_emit writes voxels[V,P,4] too (no staging, no fill)
 };
 
@@ -2167,7 +2168,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     BinnedExtras x = o.x;
     x.vidof = want_map ? w.voff : nullptr;
     x.npoints_clamp = o.npoints_clamp;
-    x.voff = o.lists ? w.voff : nullptr;
+    x.voff = o.seg_out ? o.seg_out : (o.lists ? w.voff : nullptr);
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     if (vec4)
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
@@ -2373,9 +2374,12 @@ extern "C" int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int3
 // reduction of all in-range points, point -> voxel map and each voxel's first point index.  Same grid
 // semantics as d3d_voxelize_3d_dense (voxelize.cpp:100-101).  Used stand-alone ("dynamic voxelization")
 // and as the per-rank stage of the point-sharded voxelizer (d3d_amd/voxel/sharded.py).
+extern "C" size_t d3d_voxelize_reduce_rows(int64_t n) { return (size_t)carve(nullptr, 0, n > 0 ? n : 0, 0).npad + 4; }
+
 extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                       int32_t reduction, int64_t index_offset, int64_t *coords, int32_t *npoints,
                                       float *aggregates, int64_t *first, int64_t *mapping, int64_t *keys,
+                                      int32_t max_points, uint32_t *seg_base, float *rows,
                                       int64_t *counts, void *workspace, size_t workspace_bytes, void *stream, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -2390,15 +2394,23 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     if (rc) return rc;
     VoxelWs w = carve(workspace, workspace_bytes, n, 0);
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
-    const uint32_t P = 32;   // voxels up to 32 points are reduced sequentially in point order, larger ones cooperatively
+    if (max_points < 0 || ((seg_base != nullptr) != (rows != nullptr))) return D3D_ERR_BAD_ARG;
+    // voxels up to P points are reduced sequentially in point order, larger ones cooperatively; with `rows` the first
+    // min(count, P) rows of every voxel, in point order, are left in the caller's buffer at seg_base[voxel]
+    const uint32_t P = max_points > 0 ? (uint32_t)max_points : 32u;
     const bool agg4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(aggregates) & 15) == 0);
+    if (rows) {
+        if (!agg4 || (reinterpret_cast<uintptr_t>(rows) & 15)) return D3D_ERR_UNSUPPORTED;    // staged rows are float4
+        w.staged = reinterpret_cast<float4 *>(rows);
+    }
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
     uint32_t nbins = 0;
     int hshift = 0;
     if (agg4 && dense_cells_fit_u32(kf) && binned_eligible(n, w, flags, &nbins, &hshift)) {
         DenseOut d{P, 0xffffffffu, reduction, true, false, coords, npoints, nullptr, aggregates,
                    BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr, nullptr}, mapping};
+        d.seg_out = seg_base;
         return binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
     }
     IndexOpts o{P, 0xffffffffu, first, index_offset, mapping, agg4};
@@ -2407,7 +2419,7 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     if (n == 0) return D3D_OK;
     if (agg4) {
         D3D_LAUNCH("k_meta", (k_meta<DenseKey, true>), dim3(grid_for(n, 256)), dim3(256), 0, st, kf, p4, counts, w.vinfo,
-                   w.staged, w.unsorted, P, reduction, coords, npoints, w.voff, (unsigned char *)nullptr,
+                   w.staged, w.unsorted, P, reduction, coords, npoints, seg_base ? seg_base : w.voff, (unsigned char *)nullptr,
                    reinterpret_cast<float4 *>(aggregates), w.big_list, w.big_count, keys, n);
         D3D_LAUNCH("k_overflow_reduce", k_overflow_reduce, dim3(512), dim3(256), 0, st, p4, w.vinfo, w.unsorted, w.big_list,
                    w.big_count, reduction, reinterpret_cast<float4 *>(aggregates));

@@ -107,7 +107,7 @@ class LocalComm:
 class HipOps:
     """the compute steps, on the HIP kernels of libd3d_hip.so (no host synchronisation except where noted)"""
 
-    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False, want_coords=True):
+    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False, want_coords=True, max_points=0):
         """-> coords[n,3], cnt[n], agg[n,c], first[n], mapping[n], keys[n], counts[4] -- all on the device and all
         sized for n voxels; only the first counts[0] rows are meaningful.  keys has n + 1 entries: -1 beyond the
         voxels, and keys[n] = -1 - status bits (so the status reaches every rank with the key all-gather)."""
@@ -125,6 +125,10 @@ class HipOps:
             mapping = torch.empty((n,), dtype=torch.int64, device=dev)
             keys = torch.empty((n + 1,), dtype=torch.int64, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+            seg = rows = None
+            if max_points:     # dense contract: every voxel's first min(count, max_points) rows, in point order
+                seg = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+                rows = torch.empty((lib.d3d_voxelize_reduce_rows(n), 4), dtype=torch.float32, device=dev)
             ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
             from . import default_flags
             flags = default_flags
@@ -133,8 +137,13 @@ class HipOps:
             rc = lib.d3d_voxelize_3d_reduce(
                 _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
                 int(reduction), int(index_offset), _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first),
-                _lib.ptr(mapping), _lib.ptr(keys), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), flags)
+                _lib.ptr(mapping), _lib.ptr(keys), int(max_points), _lib.ptr(seg), _lib.ptr(rows), _lib.ptr(counts), _lib.ptr(ws),
+                ws.numel(), _lib.stream_ptr(), flags)
+            if rc == _lib.ERR_UNSUPPORTED and max_points:
+                raise ValueError("the sharded dense contract needs points[n, 4] float32, 16-byte aligned")
             _lib.check(rc, "voxelize_3d_reduce")
+        if max_points:
+            return coords, cnt, agg, first, mapping, keys, counts, seg, rows
         return coords, cnt, agg, first, mapping, keys, counts
 
     def compact_index(self, keys, ncells, status_stride=None):
@@ -279,9 +288,10 @@ class HipOps:
         return coords, cnt, feats, vid
 
     # ---- owner-computes exchange (owner.hip) ----
-    def owner_pack(self, keys, cnt, agg, first, counts, n, c, world):
+    def owner_pack(self, keys, cnt, agg, first, counts, n, c, world, max_points=0, seg=None, rows=None):
         """local voxels -> records grouped by owner rank: send[n, words] int32, perm[n] (send position -> local voxel),
-        pos_of_local[n] (its inverse), send_counts[world + 1] (device)"""
+        pos_of_local[n] (its inverse), send_rows[n, 4] | None (dense contract: the voxels' ranked rows, same grouping),
+        send_counts[2 world + 1] (device: records per destination, status bits, rows per destination)"""
         lib = _lib.load()
         dev = keys.device
         words = lib.d3d_owner_record_words(c)
@@ -289,17 +299,19 @@ class HipOps:
             send = torch.empty((n, words), dtype=torch.int32, device=dev)
             perm = torch.empty((n,), dtype=torch.int32, device=dev)
             pos = torch.empty((n,), dtype=torch.int32, device=dev)
-            sc = torch.empty((world + 1,), dtype=torch.int64, device=dev)
+            send_rows = torch.empty((max(n, 1), 4), dtype=torch.float32, device=dev) if max_points else None
+            sc = torch.empty((2 * world + 1,), dtype=torch.int64, device=dev)
             ws = torch.empty((lib.d3d_owner_pack_workspace_bytes(n, world),), dtype=torch.uint8, device=dev)
             rc = lib.d3d_owner_pack(_lib.ptr(keys), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first), _lib.ptr(counts), n, c, world,
-                                    _lib.ptr(send), _lib.ptr(perm), _lib.ptr(pos), _lib.ptr(sc), _lib.ptr(ws), ws.numel(),
-                                    _lib.stream_ptr())
+                                    int(max_points), _lib.ptr(seg), _lib.ptr(rows), _lib.ptr(send), _lib.ptr(perm), _lib.ptr(pos),
+                                    _lib.ptr(send_rows), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
             _lib.check(rc, "owner_pack")
-        return send, perm, pos, sc
+        return send, perm, pos, send_rows, sc
 
     def owner_merge(self, recv, recv_counts, world, c, reduction, shape):
         """records grouped by source rank -> this owner's voxels in global id order, finished:
-        first_o, coords, npoints, feats (R rows allocated), rec_owned[R], counts (device; [0] = owned voxels)"""
+        first_o, coords, npoints, feats (R rows allocated), rec_owned[R], counts (device; [0] = owned voxels), and a handle
+        (leader records + the table) for owner_dense"""
         lib = _lib.load()
         dev = recv.device
         R = int(recv.shape[0])
@@ -314,14 +326,34 @@ class HipOps:
             npoints = torch.empty((R,), dtype=torch.int32, device=dev)
             feats = torch.empty((R, c), dtype=torch.float32, device=dev)
             rec_owned = torch.empty((R,), dtype=torch.int32, device=dev)
+            lead = torch.empty((R,), dtype=torch.int32, device=dev)
             counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
-            ws = _lib.workspace(lib.d3d_owner_merge_workspace_bytes(R, world), dev)
+            ws = torch.empty((lib.d3d_owner_merge_workspace_bytes(R, world),), dtype=torch.uint8, device=dev)   # kept for owner_dense
             rc = lib.d3d_owner_merge(_lib.ptr(recv), R, _lib.ptr(src_off), world, c, int(reduction),
                                      ctypes.cast(shape_h, ctypes.c_void_p), _lib.ptr(first_o), _lib.ptr(coords), _lib.ptr(npoints),
-                                     _lib.ptr(feats), _lib.ptr(rec_owned), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
+                                     _lib.ptr(feats), _lib.ptr(rec_owned), _lib.ptr(lead), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
                                      _lib.stream_ptr())
             _lib.check(rc, "owner_merge")
-        return first_o, coords, npoints, feats, rec_owned, counts
+        return first_o, coords, npoints, feats, rec_owned, counts, (recv, lead, npoints, counts, ws, world)
+
+    def owner_dense(self, handle, recv_rows, recv_row_counts, max_points):
+        """the dense contract of the owned voxels (id order): voxels[R, max_points, 4], pmask[R, max_points] uint8"""
+        lib = _lib.load()
+        recv, lead, npoints, counts, ws, world = handle
+        dev = recv.device
+        R = int(recv.shape[0])
+        off = [0]
+        for k in recv_row_counts:
+            off.append(off[-1] + int(k))
+        with torch.cuda.device(dev):
+            roff = torch.tensor(off, dtype=torch.int64, device=dev)
+            voxels = torch.empty((R, max_points, 4), dtype=torch.float32, device=dev)
+            pmask = torch.empty((R, max_points), dtype=torch.uint8, device=dev)
+            rc = lib.d3d_owner_dense(_lib.ptr(recv), R, _lib.ptr(recv_rows), _lib.ptr(roff), world, int(max_points), _lib.ptr(lead),
+                                     _lib.ptr(npoints), _lib.ptr(counts), R, _lib.ptr(ws), ws.numel(), _lib.ptr(voxels),
+                                     _lib.ptr(pmask), _lib.stream_ptr())
+            _lib.check(rc, "owner_dense")
+        return voxels, pmask
 
     def owner_mark_first(self, first_o, counts_o, n_total):
         """-> int64 words of the bitmap over the frame's point indices with this owner's first points set"""
@@ -418,7 +450,8 @@ class ShardedVoxelGenerator:
     """Voxel feature grid of a frame whose points are sharded over the ranks of `group` (contiguous slices in
     rank order).  Grid arguments as d3d.voxel.VoxelGenerator (bounds, shape); reduction in {mean, max, min}."""
 
-    def __init__(self, bounds, shape, reduction="mean", group=None, comm=None, ops=None, exchange="owner", replicate=True):
+    def __init__(self, bounds, shape, reduction="mean", group=None, comm=None, ops=None, exchange="owner", replicate=True,
+                 max_points=None):
         key = (reduction or "").upper()
         if key not in _REDUCTIONS:
             raise ValueError("Unsupported reduction type in VoxelGenerator!")
@@ -441,6 +474,13 @@ class ShardedVoxelGenerator:
         self._replicate = bool(replicate)
         if not self._replicate and exchange != "owner":
             raise ValueError("replicate=False needs exchange='owner'")
+        # max_points: also the dense contract's voxels[V, max_points, 4] + voxel_pmask (voxelize.cpp:128-134: the first
+        # max_points points of every voxel by global index), assembled by the voxel's owner from the ranks' candidate rows
+        self._max_points = int(max_points) if max_points else 0
+        if self._max_points and exchange != "owner":
+            raise ValueError("max_points (the dense contract) needs exchange='owner'")
+        if self._max_points > 256:
+            raise ValueError("max_points <= 256 on the sharded path")
         self.last_stats = None
 
     def _layout(self, n, dev):
@@ -468,10 +508,15 @@ class ShardedVoxelGenerator:
         offset, n_total, _ = self._layout(n, dev)
         mean = self._red == 1
         kw = {"plain": True} if plain else {}
-        _, cnt_r, agg_r, first_r, map_r, keys_r, counts_r = ops.voxelize_reduce(
-            points, self._shape, self._bounds, _SUM if mean else self._red, offset, want_coords=False, **kw)
-        send, perm, pos_r, sc_dev = ops.owner_pack(keys_r, cnt_r, agg_r, first_r, counts_r, n, c, W)
-        mat = comm.exchange_counts(sc_dev)                      # [src][dst] records, [src][W] status bits
+        P = self._max_points
+        if P and c != 4:
+            raise ValueError("the sharded dense contract needs points[n, 4]")
+        out = ops.voxelize_reduce(points, self._shape, self._bounds, _SUM if mean else self._red, offset, want_coords=False,
+                                  max_points=P, **kw)
+        _, cnt_r, agg_r, first_r, map_r, keys_r, counts_r = out[:7]
+        seg_r, rows_r = out[7:] if P else (None, None)
+        send, perm, pos_r, send_rows, sc_dev = ops.owner_pack(keys_r, cnt_r, agg_r, first_r, counts_r, n, c, W, P, seg_r, rows_r)
+        mat = comm.exchange_counts(sc_dev)                      # [src][dst] records, [src][W] status bits, [src][W+1+dst] rows
         status = 0
         for row in mat:
             status |= int(row[W])
@@ -482,7 +527,13 @@ class ShardedVoxelGenerator:
         sc = [int(x) for x in mat[comm.rank][:W]]
         rc = [int(mat[s][comm.rank]) for s in range(W)]
         recv = comm.all_to_all(send[:sum(sc)], sc, rc)
-        first_o, coords, npoints, feats, rec_owned, counts_o = ops.owner_merge(recv, rc, W, c, self._red, self._shape)
+        first_o, coords, npoints, feats, rec_owned, counts_o, handle = ops.owner_merge(recv, rc, W, c, self._red, self._shape)
+        voxels = pmask = None
+        if P:
+            rsc = [int(x) for x in mat[comm.rank][W + 1:2 * W + 1]]
+            rrc = [int(mat[s][W + 1 + comm.rank]) for s in range(W)]
+            recv_rows = comm.all_to_all(send_rows[:sum(rsc)], rsc, rrc)
+            voxels, pmask = ops.owner_dense(handle, recv_rows, rrc, P)
         lbits = ops.owner_mark_first(first_o, counts_o, n_total)
         gbits = comm.all_reduce(lbits, "sum")                   # disjoint bit sets: their sum is their OR
         vids, counts_out = ops.owner_number(gbits, n_total, first_o, counts_o)
@@ -497,16 +548,31 @@ class ShardedVoxelGenerator:
             reply_bytes_sent=(sum(rc) - rc[comm.rank]) * 8, all_reduce_bytes=int(gbits.numel()) * 8,
             all_gather_bytes_per_rank=nown * (8 + 24 + 4 + 4 * c) if self._replicate else 0)
         vids, coords, npoints, feats = vids[:nown], coords[:nown], npoints[:nown], feats[:nown]
+        if P:
+            voxels, pmask = voxels[:nown], pmask[:nown].view(torch.bool)
+            self.last_stats["rows_all_to_all_bytes_sent"] = (sum(rsc) - rsc[comm.rank]) * 16
         if not self._replicate:
-            return Dict(coords=coords, voxel_npoints=npoints, aggregates=feats, voxel_ids=vids, points_mapping=gmap,
-                        num_voxels=nvox)
+            ret = Dict(coords=coords, voxel_npoints=npoints, aggregates=feats, voxel_ids=vids, points_mapping=gmap,
+                       num_voxels=nvox)
+            if P:
+                ret.voxels, ret.voxel_pmask = voxels, pmask
+            return ret
         sizes = comm.all_gather_int(nown, dev)
         packed = torch.cat([vids.view(-1, 1), coords, npoints.to(torch.int64).view(-1, 1)], 1)      # one int64 gather
         packed = comm.all_gather_var(packed.reshape(-1), [5 * k for k in sizes]).view(-1, 5)
         feats_all = comm.all_gather_var(feats.reshape(-1), [c * k for k in sizes]).view(-1, c)
         coords_f, cnt_f, feats_f = ops.owner_replicate(nvox, packed[:, 0].contiguous(), packed[:, 1:4].contiguous(),
                                                         packed[:, 4].to(torch.int32).contiguous(), feats_all)
-        return Dict(coords=coords_f, voxel_npoints=cnt_f, aggregates=feats_f, points_mapping=gmap)
+        ret = Dict(coords=coords_f, voxel_npoints=cnt_f, aggregates=feats_f, points_mapping=gmap)
+        if P:
+            # the replicated dense tensor (V x max_points x 16 bytes on EVERY rank: a convenience for parity tests, sized by
+            # the frame; production callers keep replicate=False): gather the owners' blocks, then place them by voxel id
+            blocks = comm.all_gather_var(voxels.reshape(-1), [4 * P * k for k in sizes]).view(-1, P, 4)
+            masks = comm.all_gather_var(pmask.view(torch.uint8).reshape(-1), [P * k for k in sizes]).view(-1, P)
+            order = packed[:, 0]
+            ret.voxels = torch.empty_like(blocks).index_copy_(0, order, blocks)
+            ret.voxel_pmask = torch.empty_like(masks).index_copy_(0, order, masks).view(torch.bool)
+        return ret
 
     def _run(self, points, plain):
         comm, ops = self._comm, self._ops

@@ -175,10 +175,15 @@ int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int32_t c, con
  *   coords[n,3] i64 (may be NULL when keys is given), npoints[n] i32, aggregates[n,c] f32, first[n] i64 (index_offset + index of the voxel's first
  *   point; may be NULL), mapping[n] i64 (voxel id per point, -1 = out of range; may be NULL),
  *   keys[n + 1] i64 (linear cell index (x*sy+y)*sz+z per voxel, -1 in the rows >= counts[0]; keys[n] = -1 - status
- *   bits of counts[2], so that the status travels with the key list; may be NULL). */
+ *   bits of counts[2], so that the status travels with the key list; may be NULL).
+ *   Optionally (C == 4, 16-byte aligned points / aggregates / rows) the ranked rows themselves: rows[d3d_voxelize_reduce_rows(n), 4]
+ *   f32 receives, per voxel, its first min(count, max_points) points in point order at row seg_base[voxel] (seg_base[n] u32);
+ *   max_points = 0 and seg_base = rows = NULL otherwise.  The sharded dense contract sends them to the voxel's owner. */
+size_t d3d_voxelize_reduce_rows(int64_t n);
 int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                            int32_t reduction, int64_t index_offset, int64_t *coords, int32_t *npoints,
-                           float *aggregates, int64_t *first, int64_t *mapping, int64_t *keys, int64_t *counts,
+                           float *aggregates, int64_t *first, int64_t *mapping, int64_t *keys,
+                           int32_t max_points, uint32_t *seg_base, float *rows, int64_t *counts,
                            void *workspace, size_t workspace_bytes, void *stream, uint32_t flags);
 
 /* Rank-independent compact numbering of occupied cells: mark keys[m] (linear cell index in [0,ncells)) in a
@@ -251,19 +256,30 @@ int d3d_sharded_map(int64_t n, const int64_t *local_map, const int64_t *slot_of_
 int    d3d_owner_record_words(int32_t c);
 size_t d3d_owner_pack_workspace_bytes(int64_t n, int32_t world);
 /* outputs of d3d_voxelize_3d_reduce (keys[n + 1], cnt[n], agg[n, c], first[n], its counts) -> send[n, words] grouped by owner
- * rank, perm[n] (send position -> local voxel), pos_of_local[n] (its inverse), send_counts[world + 1] (device: records per
- * destination, then the shard's status bits). */
+ * rank, perm[n] (send position -> local voxel), pos_of_local[n] (its inverse), send_counts[2 world + 1] (device: records per
+ * destination, the shard's status bits, rows per destination).  Dense contract (max_points > 0, c == 4): seg_base / rows_local
+ * as left by d3d_voxelize_3d_reduce(max_points, ...) -> send_rows[kept rows, 4] with the same grouping, and a record's last word
+ * = offset of its rows inside its (source, destination) batch; otherwise max_points = 0 and the three pointers NULL. */
 int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const float *agg, const int64_t *first, const int64_t *counts,
-                   int64_t n, int32_t c, int32_t world, int32_t *send, int32_t *perm, int32_t *pos_of_local,
-                   int64_t *send_counts, void *workspace, size_t workspace_bytes, void *stream);
+                   int64_t n, int32_t c, int32_t world, int32_t max_points, const uint32_t *seg_base, const float *rows_local,
+                   int32_t *send, int32_t *perm, int32_t *pos_of_local, float *send_rows, int64_t *send_counts,
+                   void *workspace, size_t workspace_bytes, void *stream);
 size_t d3d_owner_merge_workspace_bytes(int64_t n_records, int32_t world);
 /* recv[R, words] grouped by source rank (src_off[world + 1], device) -> this owner's voxels in GLOBAL ID ORDER, finished
  * (the lowest source rank of a cell holds its first point; the records of one source follow the shard's first-seen order):
  * first_o / coords / npoints / feats (R rows allocated, counts[D3D_COUNT_VOXELS] valid) and rec_owned[R] = owned voxel of
- * every record.  reduction: MEAN (sums in rank order, then voxelize.cpp:164's division), MAX, MIN. */
+ * every record, lead_rec[R] = leader record of every owned voxel.  reduction: MEAN (sums in rank order, then
+ * voxelize.cpp:164's division), MAX, MIN. */
 int d3d_owner_merge(const int32_t *recv, int64_t n_records, const int64_t *src_off, int32_t world, int32_t c, int32_t reduction,
                     const int32_t *shape, int64_t *first_o, int64_t *coords, int32_t *npoints, float *feats,
-                    int32_t *rec_owned, int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+                    int32_t *rec_owned, int32_t *lead_rec, int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+/* dense contract on the owner (voxelize.cpp:128-134: the first max_points points of a voxel by global index = the ranks'
+ * candidate rows in rank order): after d3d_owner_merge, with ITS workspace untouched since; recv_rows[*, 4] grouped by source
+ * rank (rows_src_off[world + 1], device); lead_rec / npoints / counts_o from d3d_owner_merge.
+ * -> voxels[cap_o, max_points, 4], pmask[cap_o, max_points] of the owned voxels in id order (max_points <= 256, c == 4). */
+int d3d_owner_dense(const int32_t *recv, int64_t n_records, const float *recv_rows, const int64_t *rows_src_off, int32_t world,
+                    int32_t max_points, const int32_t *lead_rec, const int32_t *npoints, const int64_t *counts_o, int64_t cap_o,
+                    const void *merge_workspace, size_t merge_workspace_bytes, float *voxels, uint8_t *pmask, void *stream);
 /* bitmap[(n_total + 63) / 64] <- bit f for every owned voxel's first point f */
 int d3d_owner_mark_first(const int64_t *first_o, const int64_t *counts_o, int64_t cap_o, int64_t n_total, uint64_t *bitmap,
                          void *stream);

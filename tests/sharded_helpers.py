@@ -11,11 +11,11 @@ import oracle
 class NumpyOps:
     """same interface as d3d_amd.voxel.sharded.HipOps, computed with the CPU oracle + numpy"""
 
-    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False, want_coords=True):
+    def voxelize_reduce(self, points, shape, bounds, reduction, index_offset, plain=False, want_coords=True, max_points=0):
         pts = points.cpu().numpy()
         n, c = pts.shape
         red = {1: 1, 2: 2, 3: 3, 4: 1}[int(reduction)]
-        r = oracle.voxelize_3d_dense(pts, shape, bounds, 1, max(n, 1), red)
+        r = oracle.voxelize_3d_dense(pts, shape, bounds, max(int(max_points), 1), max(n, 1), red)
         coords, cnt = r["coords"], r["voxel_npoints"]
         agg = r["aggregates"].astype(np.float32)
         if int(reduction) == 4:
@@ -41,8 +41,17 @@ class NumpyOps:
             return torch.from_numpy(out)
         counts = torch.tensor([v, 0, 0, 0], dtype=torch.int64)
         keys = (coords[:, 0] * shape[1] + coords[:, 1]) * shape[2] + coords[:, 2]
-        return (padded(coords, 7), padded(cnt, 99), padded(agg, 1e30), padded(first, 123), torch.from_numpy(mapping),
-                padded(keys.astype(np.int64), -1, extra=1), counts)      # keys[n] = -1 - status (0)
+        ret = (padded(coords, 7), padded(cnt, 99), padded(agg, 1e30), padded(first, 123), torch.from_numpy(mapping),
+               padded(keys.astype(np.int64), -1, extra=1), counts)      # keys[n] = -1 - status (0)
+        if max_points:       # every voxel's first min(count, max_points) rows at seg[voxel] (segments of `count` rows, like the kernels)
+            seg = np.zeros((max(n, 1),), np.int32)
+            seg[:v] = np.cumsum(cnt) - cnt
+            rows = np.full((n + 8, 4), np.nan, np.float32)
+            for q in range(v):
+                k = min(int(cnt[q]), int(max_points))
+                rows[seg[q]:seg[q] + k] = r["voxels"][q, :k]
+            ret = ret + (torch.from_numpy(seg), torch.from_numpy(rows))
+        return ret
 
     def compact_index(self, keys, ncells, status_stride=None):
         k = keys.cpu().numpy()
@@ -177,7 +186,7 @@ class NumpyOps:
             h ^= h >> np.uint64(33)
         return (((h >> np.uint64(32)) * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
 
-    def owner_pack(self, keys, cnt, agg, first, counts, n, c, world):
+    def owner_pack(self, keys, cnt, agg, first, counts, n, c, world, max_points=0, seg=None, rows=None):
         v = int(counts[0])
         k = keys.numpy()[:v]
         words = (5 + c + 1) & ~1
@@ -189,14 +198,31 @@ class NumpyOps:
         rec[:, 2:4] = first.numpy()[:v][perm].reshape(-1, 1).view(np.int32)
         rec[:, 4] = cnt.numpy()[:v][perm]
         rec[:, 5:5 + c] = agg.numpy()[:v][perm].view(np.int32)
-        sc = np.zeros((world + 1,), np.int64)
+        sc = np.zeros((2 * world + 1,), np.int64)
         sc[:world] = np.bincount(own, minlength=world)
         sc[world] = -1 - int(keys.numpy()[n])
         full_perm = np.zeros((n,), np.int32)
         full_perm[:v] = perm
         pos = np.zeros((n,), np.int32)
         pos[perm] = np.arange(v, dtype=np.int32)
-        return torch.from_numpy(send), torch.from_numpy(full_perm), torch.from_numpy(pos), torch.from_numpy(sc)
+        send_rows = None
+        if max_points:
+            kept = np.minimum(cnt.numpy()[:v][perm], max_points)
+            dest = own[perm]
+            send_rows = np.zeros((max(n, 1), 4), np.float32)
+            at = 0
+            for d in range(world):
+                inbatch = 0
+                for j in np.flatnonzero(dest == d):
+                    k = int(kept[j])
+                    rec[j, words - 1] = inbatch
+                    b = int(seg.numpy()[perm[j]])
+                    send_rows[at + inbatch:at + inbatch + k] = rows.numpy()[b:b + k]
+                    inbatch += k
+                sc[world + 1 + d] = inbatch
+                at += inbatch
+            send_rows = torch.from_numpy(send_rows)
+        return torch.from_numpy(send), torch.from_numpy(full_perm), torch.from_numpy(pos), send_rows, torch.from_numpy(sc)
 
     def owner_merge(self, recv, recv_counts, world, c, reduction, shape):
         r = recv.numpy()
@@ -236,7 +262,27 @@ class NumpyOps:
         coords = np.zeros((R, 3), np.int64)
         coords[:vo] = np.stack([k // (sy * sz), (k // sz) % sy, k % sz], 1) if vo else np.zeros((0, 3), np.int64)
         t = torch.from_numpy
-        return t(first_o), t(coords), t(cnt_o), t(agg_o), t(rec_owned), torch.tensor([vo, 0, 0, 0], dtype=torch.int64)
+        handle = dict(recv=r, rec_owned=rec_owned, cnt=cnt, vo=vo, counts=recv_counts, total=cnt_o)
+        return t(first_o), t(coords), t(cnt_o), t(agg_o), t(rec_owned), torch.tensor([vo, 0, 0, 0], dtype=torch.int64), handle
+
+    def owner_dense(self, handle, recv_rows, recv_row_counts, max_points):
+        r, R, P = handle["recv"], len(handle["recv"]), int(max_points)
+        rows = recv_rows.numpy()
+        voxels = np.zeros((R, P, 4), np.float32)
+        pmask = np.zeros((R, P), np.uint8)
+        have = np.zeros((R,), np.int64)
+        src_of = np.repeat(np.arange(len(handle["counts"])), handle["counts"])
+        rbase = np.concatenate([[0], np.cumsum(recv_row_counts)])
+        for i in range(R):                                        # receive order = rank order
+            o = handle["rec_owned"][i]
+            k = min(int(handle["cnt"][i]), P)
+            take = min(k, P - int(have[o]))
+            b = int(rbase[src_of[i]]) + int(r[i, -1])
+            voxels[o, have[o]:have[o] + take] = rows[b:b + take]
+            have[o] += take
+        for o in range(handle["vo"]):
+            pmask[o, :min(int(handle["total"][o]), P)] = 1
+        return torch.from_numpy(voxels), torch.from_numpy(pmask)
 
     def owner_mark_first(self, first_o, counts_o, n_total):
         nw = (max(n_total, 1) + 63) // 64

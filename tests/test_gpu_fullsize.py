@@ -129,10 +129,12 @@ def test_cfg5_single_gpu_dense_contract(cfg5, path):
 def test_cfg5_point_sharded_owner_computes(cfg5, reduction):
     """config 5 as stated, owner-computes exchange without the final all-gather (replicate=False): rank k holds points
     [k M, (k+1) M); 8 virtual ranks (threads, real kernels, host-side collectives).  The ranks' owned voxels partition the
-    oracle's grid of the whole frame: every owned row (coords, count, reduction) equals the oracle's row of that voxel id."""
+    oracle's grid of the whole frame: every owned row (coords, count, reduction) equals the oracle's row of that voxel id, and
+    (mean) so does the dense contract voxels[V,32,4] / voxel_pmask the owners assemble from the ranks' candidate rows."""
     from d3d_amd import synth
     from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
     cloud, exp = cfg5
+    P = 32 if reduction == "mean" else 0       # mean: with the dense contract at the stated max_points = 32
     if reduction == "max":
         exp = oracle.voxelize_3d_dense(cloud, synth.WAYMO_SHAPE, synth.WAYMO_BOUNDS, 1, len(cloud), "max")
     world, n = 8, 1000000
@@ -143,7 +145,7 @@ def test_cfg5_point_sharded_owner_computes(cfg5, reduction):
         try:
             torch.cuda.set_device(0)
             gen = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction=reduction, comm=tw.comm(rank),
-                                        exchange="owner", replicate=False, ops=HipOps())
+                                        exchange="owner", replicate=False, ops=HipOps(), max_points=P or None)
             res = gen(T(cloud[rank * n:(rank + 1) * n]))
             stats[rank] = gen.last_stats
             out[rank] = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in res.items()}
@@ -169,6 +171,9 @@ def test_cfg5_point_sharded_owner_computes(cfg5, reduction):
             np.testing.assert_allclose(o["aggregates"], exp["aggregates"][k], rtol=1e-5, atol=1e-6)
         else:
             assert np.array_equal(o["aggregates"], exp["aggregates"][k])
+        if P:       # voxels[V_owned, 32, 4] of every owner, bit-exact against the oracle's dense contract of the whole frame
+            assert np.array_equal(o["voxels"], exp["voxels"][k])
+            assert np.array_equal(o["voxel_pmask"], np.arange(P)[None, :] < np.minimum(exp["voxel_npoints"][k], P)[:, None])
     lo = np.array(synth.WAYMO_BOUNDS[0::2], np.float32)
     size = ((np.array(synth.WAYMO_BOUNDS[1::2], np.float32) - lo) / np.array(synth.WAYMO_SHAPE, np.float32)).astype(np.float32)
     for r in range(world):

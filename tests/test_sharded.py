@@ -56,10 +56,15 @@ def _free_port():
     return p
 
 
-def _check_owned(res, cloud_all, my_slice, reduction):
+def _check_owned(res, cloud_all, my_slice, reduction, max_points=0):
     """replicate=False: this rank's OWNED voxels, in global id order, equal those rows of the whole frame's grid"""
     exp = _expected(cloud_all, reduction)
     ids = res.voxel_ids.cpu().numpy()
+    if max_points:      # the dense contract of the owned voxels, bit for bit
+        dense = oracle.voxelize_3d_dense(cloud_all, SHAPE, BOUNDS, max_points, len(cloud_all), reduction)
+        assert np.array_equal(res.voxels.cpu().numpy(), dense["voxels"][ids])
+        pm = np.arange(max_points)[None, :] < np.minimum(dense["voxel_npoints"][ids], max_points)[:, None]
+        assert np.array_equal(res.voxel_pmask.cpu().numpy(), pm)
     assert res.num_voxels == len(exp["coords"])
     assert np.all(np.diff(ids) > 0) if len(ids) > 1 else True
     assert np.array_equal(res.coords.cpu().numpy(), exp["coords"][ids])
@@ -95,6 +100,17 @@ def _gloo_worker(rank, world, port, reduction, exchange, q):
             allids = [None] * world
             dist.all_gather_object(allids, ids.tolist())
             assert sorted(sum(allids, [])) == list(range(len(_expected(cloud, reduction)["coords"])))
+            # the dense contract through the same exchange: owned blocks, and the replicated tensor
+            for rep in (False, True):
+                dg = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, ops=NumpyOps(), exchange="owner", replicate=rep,
+                                           max_points=3)
+                dres = dg(torch.from_numpy(cloud[sl]))
+                if not rep:
+                    _check_owned(dres, cloud, sl, reduction, max_points=3)
+                else:
+                    _check(dres, cloud, sl, reduction)
+                    dense = oracle.voxelize_3d_dense(cloud, SHAPE, BOUNDS, 3, len(cloud), reduction)
+                    assert np.array_equal(dres.voxels.numpy(), dense["voxels"])
         # next frame through the SAME generator: only the last rank's shard size changes (rank 0 keeps its 1100 points).
         # Every rank must still enter the same sequence of collectives and see the new offsets / totals.
         cloud2 = _cloud(2600, 6)
@@ -172,13 +188,17 @@ def test_sharded_hip_kernels_virtual_ranks(world, reduction, exchange, index_pat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,reduction,empty", [(2, "mean", False), (3, "max", True), (8, "min", False), (5, "mean", True)])
-def test_owner_computes_without_replication_virtual_ranks(world, reduction, empty):
+@pytest.mark.parametrize("world,reduction,empty,P", [(2, "mean", False, 0), (3, "max", True, 4), (8, "min", False, 32),
+                                                      (5, "mean", True, 5), (4, "mean", False, 70)])
+def test_owner_computes_without_replication_virtual_ranks(world, reduction, empty, P):
     """replicate=False on the real kernels: every rank returns its owned voxels in global id order; together they are the
     single-GPU grid.  Ragged shards, optionally a rank without points; repeated calls give identical bits (the merge runs in
-    rank order whatever the arrival order of the records)."""
+    rank order whatever the arrival order of the records).  P > 0: with the dense contract (voxels / voxel_pmask of the owned
+    voxels, bit-exact against the oracle's dense contract of the whole frame; a dense blob so that candidate rows of several
+    ranks compete for a voxel's P slots)."""
     from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
     cloud = _cloud(50000, 19)
+    cloud[::7, :3] = cloud[::7, :3] * 0.02 + np.array([30, 0, -1], np.float32)      # ~7000 points in a handful of cells
     cuts = np.linspace(0, len(cloud), world + 1).astype(int)
     cuts[1] = max(cuts[1] // 3, 1)
     if empty:
@@ -190,7 +210,7 @@ def test_owner_computes_without_replication_virtual_ranks(world, reduction, empt
         try:
             torch.cuda.set_device(0)
             gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, comm=tw.comm(rank), exchange="owner", replicate=False,
-                                        ops=LockedOps(HipOps(), lock))
+                                        ops=LockedOps(HipOps(), lock), max_points=P or None)
             for it in range(2):
                 out[it][rank] = gen(torch.from_numpy(cloud[cuts[rank]:cuts[rank + 1]]).cuda())
         except Exception:  # pragma: no cover
@@ -203,8 +223,8 @@ def test_owner_computes_without_replication_virtual_ranks(world, reduction, empt
     assert not errs, errs[0]
     ids = []
     for r in range(world):
-        ids.append(_check_owned(out[0][r], cloud, slice(cuts[r], cuts[r + 1]), reduction))
-        for k in ("coords", "voxel_npoints", "aggregates", "voxel_ids", "points_mapping"):
+        ids.append(_check_owned(out[0][r], cloud, slice(cuts[r], cuts[r + 1]), reduction, max_points=P))
+        for k in ("coords", "voxel_npoints", "aggregates", "voxel_ids", "points_mapping") + (("voxels", "voxel_pmask") if P else ()):
             assert torch.equal(out[0][r][k], out[1][r][k]), k
     allids = np.concatenate(ids)
     assert np.array_equal(np.sort(allids), np.arange(out[0][0].num_voxels))
