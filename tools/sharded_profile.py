@@ -15,6 +15,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 cfg5 = len(sys.argv) > 3 and sys.argv[3] == "config5"        # config 5: Waymo range, 0.05 m voxels
 exchange = sys.argv[4] if len(sys.argv) > 4 else "owner"      # owner | auto | keys | bitmap
 replicate = not (len(sys.argv) > 5 and sys.argv[5] == "noreplicate")
+max_points = int(sys.argv[6]) if len(sys.argv) > 6 else None   # with the dense contract (owner exchange)
 BOUNDS, SHAPE = (synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE) if cfg5 else (synth.KITTI_BOUNDS, synth.KITTI_SHAPE)
 if cfg5:
     frame = synth.lidar_like(W * n, 3, BOUNDS)
@@ -30,7 +31,7 @@ def step():
     def run(rank):
         torch.cuda.set_device(0)
         gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction="mean", comm=tw.comm(rank), ops=LockedOps(HipOps(), lock),
-                                    exchange=exchange, replicate=replicate)
+                                    exchange=exchange, replicate=replicate, max_points=max_points)
         outs[rank] = gen(clouds[rank])
         stats[rank] = gen.last_stats
     ts = [threading.Thread(target=run, args=(r,)) for r in range(W)]
@@ -38,7 +39,7 @@ def step():
     return outs
 
 outs = step()
-print("world", W, "points/rank", n, "exchange", exchange, "replicate", replicate, "global voxels", stats[0]["voxels"])
+print("world", W, "points/rank", n, "exchange", exchange, "replicate", replicate, "max_points", max_points, "global voxels", stats[0]["voxels"])
 print("  collective bytes of rank 0:", {k: v for k, v in stats[0].items() if "bytes" in k})
 prof = kernel_profile(step, 3)
 tot = 0.0
