@@ -480,39 +480,62 @@ def main():
         # config 5: rank k holds points [k n, (k+1) n) of the frame (world = 8, n = 1 M: the 8 M-point frame itself)
         frame = synth.lidar_like(world * n, 3, synth.WAYMO_BOUNDS)
         cloud_h = np.ascontiguousarray(frame[rank * n:(rank + 1) * n])
-        del frame
         cloud = torch.from_numpy(cloud_h).cuda()
-        # the same operator on this rank's shard alone (world of one, no collectives): the base of the weak-scaling curve
-        solo = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction="mean", comm=LocalComm())
+        # strong-scaling base: the SAME operator on the WHOLE world x n frame on one GPU (a world of one: no collectives)
+        whole = None
+        if rank == 0:
+            solo = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction="mean", comm=LocalComm(), replicate=False)
+            fr = torch.from_numpy(frame).cuda()
+            k = max(args.steps // 4, 3)
+            whole = 1e3 * timed(lambda: solo(fr), k, 2) / k
+            del solo, fr
+            torch.cuda.empty_cache()
+        del frame
+        # ... and on this rank's shard alone (the base of the weak-scaling curve)
+        solo = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction="mean", comm=LocalComm(), replicate=False)
         dt_solo = timed(lambda: solo(cloud), max(args.steps // 2, 3), 2)
         solo_ms = 1e3 * dt_solo / max(args.steps // 2, 3)
         del solo
-        gen = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction="mean")
+        # the scalable form: owner-computes exchange, every rank keeps its owned 1/world of the voxels (replicate=False)
+        gen = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction="mean", replicate=False)
         step = lambda: gen(cloud)  # noqa: E731
-        out["voxels_global"] = int(step().coords.shape[0])
+        out["voxels_global"] = int(step().num_voxels)
         st = dict(gen.last_stats)
         out["rccl_ranks"] = world
         out["exchange"] = st["exchange"]
         out["numbering"] = st["numbering"]
         out["collectives_per_step"] = dict(
-            all_gather_bytes_per_rank=st["all_gather_bytes_per_rank"], all_gather_bytes_received=st["all_gather_bytes_per_rank"] * world,
-            all_reduce_bytes=st["all_reduce_bytes"], size_all_gather_bytes=8,
-            note="all-gather of the occupied-cell %s, all-reduce of the voxel table%s" % (
-                "key lists" if st["exchange"] == "keys" else "bitmaps",
-                " + MIN all-reduce of the first-point indices" if st["numbering"] == "first-index" else ""))
+            {k: v for k, v in st.items() if "bytes" in k}, size_all_gather_bytes=8, count_matrix_all_gather_bytes=8 * (2 * world + 1),
+            note="per rank: all-to-all of the partial voxel records to the cells' owner ranks (a sparse reduce-scatter of the "
+                 "feature grid), SUM all-reduce of the one-bit-per-point first-point bitmap (= OR of disjoint sets), all-to-all "
+                 "of the voxel ids back; no all-gather of the grid (every rank keeps its owned 1/world of the voxels)")
         dt_local = timed(step, args.steps, args.warmup, barrier)
-        t = torch.tensor([dt_local, solo_ms], dtype=torch.float64, device="cuda")
+        # the same with the final all-gather of the finished grid (replicated result, the frame-sized part)
+        gen_rep = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction="mean", replicate=True)
+        k = max(args.steps // 4, 3)
+        dt_rep = timed(lambda: gen_rep(cloud), k, 2, barrier) / k
+        del gen_rep
+        t = torch.tensor([dt_local, solo_ms, dt_rep], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
         value = n * world * args.steps / dt / 1e6
         out["same_operator_one_rank"] = dict(ms_per_step=round(float(t[1].item()), 4),
                                              mpoints_per_s=round(n / float(t[1].item()) / 1e3, 2),
-                                             note="sharded feature-grid operator on one rank's shard without collectives "
-                                                  "(max over ranks); bench.py --gpus 1 is a different operator: config 2 dense")
+                                             note="the same operator on one rank's shard without collectives (max over ranks)")
+        if whole is not None:
+            out["single_gpu_whole_frame"] = dict(
+                ms_per_step=round(whole, 4), mpoints_per_s=round(n * world / whole / 1e3, 2),
+                note="the same operator (sharded feature-grid voxelizer, world of one) on the WHOLE %d-point frame on one GPU: "
+                     "speed-up of this run = single_gpu_whole_frame.ms_per_step / ms_per_step" % (n * world))
+            out["speedup_vs_single_gpu_whole_frame"] = round(whole / (1e3 * dt / args.steps), 3)
+        out["replicated_result"] = dict(ms_per_step=round(1e3 * float(t[2].item()), 4),
+                                        note="with replicate=True: + all-gather of the owners' finished rows and the scatter into "
+                                             "voxel-id order on every rank (sized by the frame, not the shard)")
         workload = ("config5 shards: rank k = points [k*%d, (k+1)*%d) of a %d-point LiDAR-like Waymo-range frame (seed 3), "
-                    "0.05 m voxels (3008x3008x120), MEAN feature grid: local voxelization + RCCL all-gather of the occupied "
-                    "cells + all-reduce of the voxel feature grid, result replicated" % (n, n, world * n))
-        parallelism = "points sharded over %d GPUs" % world
+                    "0.05 m voxels (3008x3008x120), MEAN feature grid: local voxelization + RCCL all-to-all of the partial voxel "
+                    "records to the cells' owners + bitmap all-reduce for the first-seen numbering; every rank returns its owned "
+                    "voxels with their global ids and the global voxel id of each of its points" % (n, n, world * n))
+        parallelism = "points sharded over %d GPUs, voxels owned by hash(cell) %% %d" % (world, world)
 
     if rank == 0:
         line = {
