@@ -37,6 +37,9 @@ cuda_available = True   # box/impl.cpp:9-13: this build always has its device pa
 # diagnostic / test hooks that select between equivalent internal paths; they travel as per-call arguments of the C ABI.
 default_nms_flags = 0
 default_iou_flags = 0
+# Test hook: fill the IoU / iou3d result buffer with NaN before the kernels run, so that a chunk of the matrix the zero fill
+# skips cannot hide behind fresh (zeroed) memory.  Read when a call starts.
+poison_outputs = False
 
 
 def _dtype_code(t):
@@ -71,6 +74,8 @@ def _iou_forward(boxes1, boxes2, iou_type, flags=None):
     fl = default_iou_flags if flags is None else int(flags)
     with torch.cuda.device(dev):
         ious = torch.empty((n, m), dtype=b1.dtype, device=dev)
+        if poison_outputs:
+            ious.fill_(float("nan"))
         code = _dtype_code(b1)
         # one launch covers 65535 tiles of 64 rows; taller inputs go in row blocks into the same output
         for r0 in range(0, max(n, 1), _MAX_ROWS):
@@ -348,6 +353,8 @@ def iou3d(boxes1, boxes2, method="rbox"):
     n, m = b1.shape[0], b2.shape[0]
     with torch.cuda.device(dev):
         out = torch.empty((n, m), dtype=torch.float32, device=dev)
+        if poison_outputs:
+            out.fill_(float("nan"))
         ws = _lib.workspace(lib.d3d_iou3d_workspace_bytes(n, m), dev)
         rc = lib.d3d_iou3d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, 1 if key == "RBOX" else 0, _lib.ptr(out),
                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr())

@@ -22,6 +22,7 @@ def nms_broad(request, monkeypatch):
     from d3d_amd import _lib, box
     mode = getattr(request, "param", "auto")
     monkeypatch.setattr(box, "default_nms_flags", {"auto": 0, "grid": _lib.NMS_GENERAL, "sweep": _lib.NMS_BROAD_SWEEP}[mode])
+    monkeypatch.setattr(box, "poison_outputs", True)    # every IoU / iou3d result buffer of this module starts as NaN
     yield mode
 
 

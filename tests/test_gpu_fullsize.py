@@ -47,7 +47,47 @@ def test_nms_300k_boxes_beyond_the_inline_paths():
     assert np.array_equal(keep, exp), int(np.sum(keep != exp))
 
 
-def test_cfg3_iou_50k_x_50k_fp64_vs_oracle():
+@pytest.fixture
+def poisoned_iou():
+    """the IoU operators' result buffers are filled with NaN before the kernels run"""
+    from d3d_amd import box
+    box.poison_outputs = True
+    yield
+    box.poison_outputs = False
+
+
+def test_cfg3_iou_100k_x_100k_fp64_full_launch(poisoned_iou):
+    """config 3 AS STATED: 100 k x 100 k rotated boxes fp64 = 1e10 pairs in ONE 80 GB matrix, the launch bench.py times.  The
+    result buffer is pre-poisoned with NaN: a 4 KiB chunk the zero fill skipped would show.  No NaN anywhere; the number of
+    non-zeros equals the oracle's over the pairs whose bounding boxes touch; 256 sampled rows complete at 1e-9; last row,
+    last column and the corner explicitly."""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_iou
+    n = 100000
+    b, _ = synth.boxes2d_sparse(n, 1)
+    bt = T(b)
+    got = box2d_iou(bt, bt, method="rbox")
+    assert got.shape == (n, n) and got.dtype == torch.float64
+    for r0 in range(0, n, 10000):                         # (a 10 GB mask at a time)
+        assert not bool(torch.isnan(got[r0:r0 + 10000]).any()), r0
+    pi, pj = oracle.aabb_candidate_pairs(b, b)
+    exp = oracle.iou2d_pairs(b, b, pi, pj, "rbox")
+    nz = sum(int(torch.count_nonzero(got[r0:r0 + 10000])) for r0 in range(0, n, 10000))
+    assert nz == int(np.count_nonzero(exp))
+    vals = got[T(pi), T(pj)].cpu().numpy()
+    assert np.max(np.abs(vals - exp)) < 1e-9
+    rows = np.random.default_rng(9).choice(n, 256, replace=False)
+    ref = oracle.box2d_iou(b[rows], b, "rbox", nthreads=8)
+    assert np.max(np.abs(got[T(rows)].cpu().numpy() - ref)) < 1e-9
+    assert abs(float(got[n - 1, n - 1]) - 1.0) < 1e-12
+    row_ref = oracle.box2d_iou(b[n - 1:], b, "rbox", nthreads=8)[0]
+    assert np.max(np.abs(got[n - 1].cpu().numpy() - row_ref)) < 1e-9
+    assert np.max(np.abs(got[:, n - 1].cpu().numpy() - row_ref)) < 1e-9           # symmetric input: the last column too
+    del got
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_iou_50k_x_50k_fp64_vs_oracle(poisoned_iou):
     """config 3's boxes, 50 k x 50 k fp64 = 2.5e9 pairs (> 2^31: the index range the reference's CUDA kernel overflows,
     iou_cuda.cu:36,137) in ONE 20 GB matrix: every pair whose bounding boxes touch equals the oracle (1e-9), every other
     entry is zero (count of non-zeros), last row / column / corner looked at explicitly"""
