@@ -297,6 +297,18 @@ int d3d_owner_map(int64_t n, const int64_t *local_map, const int32_t *pos_of_loc
 int d3d_owner_replicate(int64_t nvox, const int64_t *vids, const int64_t *coords_in, const int32_t *cnt_in,
                         const float *feats_in, int32_t c, int64_t *coords, int32_t *cnt, float *feats, void *stream);
 
+/* ---- points in 3D boxes: Target3DArray.crop_points / paint_label (reference d3d/abstraction.pyx:308-324,
+ * 654-687), per pair box3dr_contains (d3d/dgal_wrap.h:6-19): closed z interval in fp32, the rotated rectangle's bounding
+ * box, the rectangle.  points[n, point_stride >= 3] f32 (x, y, z first); box row i = (x, y, z, lx, ly, lz, rz) at
+ * boxes + i * box_stride + box_offset ([M,7]: 7, 0; the [n,9] rows of Target3DArray.to_numpy: 9, 2). */
+int d3d_crop_3dr(const float *points, int64_t n, int32_t point_stride, const float *boxes, int64_t m, int32_t box_stride,
+                 int32_t box_offset, uint8_t *out /* [m, n] 0/1 */, void *stream);
+/* idarr[n] u16 = 1 + the lowest index of a box that contains the point and whose class labels[i] (u8) equals semantics[j]
+ * (u8), 0 where there is none -- what the reference's descending paint loop leaves (abstraction.pyx:662-673) -- without the
+ * bool[m, n] mask. */
+int d3d_paint_label(const float *points, int64_t n, int32_t point_stride, const uint8_t *semantics, const float *boxes,
+                    int64_t m, int32_t box_stride, int32_t box_offset, const uint8_t *labels, uint16_t *idarr, void *stream);
+
 /* ------------------------------------------------------------------ d3d/point ("next" row) */
 
 /* replaces aligned_scatter_forward[_cuda] / aligned_scatter_backward[_cuda] (reference d3d/point/scatter.h:39-56,

@@ -429,6 +429,45 @@ def box3dp_crop(points, boxes, project_axis=2):
     return mask_2d & ((pp - bd < bp) & (bp < pp + bd))
 
 
+def _box_rows(boxes):
+    """[M,7] (x,y,z,lx,ly,lz,rz) or the [n,9] rows of Target3DArray.to_numpy (label, score, then the 7) -> (array, stride, offset)"""
+    bx = np.ascontiguousarray(boxes, dtype=np.float32)
+    if bx.ndim != 2 or bx.shape[1] not in (7, 9):
+        raise ValueError("boxes should be [M,7] or [M,9]")
+    return bx, bx.shape[1], 0 if bx.shape[1] == 7 else 2
+
+
+def crop_points(boxes, cloud):
+    """Target3DArray.crop_points (abstraction.pyx:684-687; per pair box3dr_contains, dgal_wrap.h:6-19): bool[M,N]"""
+    bx, bs, bo = _box_rows(boxes)
+    pts = np.ascontiguousarray(cloud, dtype=np.float32)
+    n, m = pts.shape[0], bx.shape[0]
+    out = np.zeros((m, n), np.uint8)
+    f = lib().oracle_crop_3dr
+    f.restype = None
+    f(_p(pts), ctypes.c_int64(n), ctypes.c_int(pts.shape[1]), _p(bx), ctypes.c_int64(m), ctypes.c_int(bs), ctypes.c_int(bo), _p(out))
+    return out.astype(bool)
+
+
+def paint_label(boxes, cloud, semantics, labels=None):
+    """Target3DArray.paint_label (abstraction.pyx:662-682): uint16[N]; labels default to column 0 of [n,9] rows"""
+    bx, bs, bo = _box_rows(boxes)
+    if labels is None:
+        if bs != 9:
+            raise ValueError("labels are needed with [M,7] boxes")
+        labels = bx[:, 0]
+    lab = np.ascontiguousarray(labels).astype(np.uint8)
+    pts = np.ascontiguousarray(cloud, dtype=np.float32)
+    sem = np.ascontiguousarray(semantics, dtype=np.uint8)
+    n, m = pts.shape[0], bx.shape[0]
+    out = np.zeros((n,), np.uint16)
+    f = lib().oracle_paint_label
+    f.restype = None
+    f(_p(pts), ctypes.c_int64(n), ctypes.c_int(pts.shape[1]), _p(sem), _p(bx), ctypes.c_int64(m), ctypes.c_int(bs), ctypes.c_int(bo),
+      _p(lab), _p(out))
+    return out
+
+
 # --------------------------------------------------------------------------- point (next row: d3d.point)
 ALIGN_TYPE = {"DROP": 0, "MEAN": 1, "LINEAR": 2, "MAX": 3, "NEAREST": 4}   # point/scatter.h:37
 
