@@ -153,18 +153,26 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_ws_cache = {}
+_ws_local = threading.local()       # the arenas of a host thread die with it (a global registry kept every short-lived
+                                    # worker thread's arena -- up to GBs for a 100 k-box NMS -- allocated for good)
+_WS_MAX_STREAMS = 8                 # arenas a thread keeps (one per (device, stream) it used last)
 
 
 def workspace(nbytes, device):
-    """Reusable scratch arena per (device, stream, host thread); grows geometrically, never shrinks.  Per thread as well:
-    two threads that issue multi-kernel operators on the SAME stream interleave their launches, and each operator must
-    keep its scratch to itself for that to be harmless (the C ABI is re-entrant given distinct workspaces)."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream, threading.get_ident())
-    buf = _ws_cache.get(key)
+    """Reusable scratch arena per (device, stream, host thread); grows geometrically.  Per thread as well: two threads that
+    issue multi-kernel operators on the SAME stream interleave their launches, and each operator must keep its scratch to
+    itself for that to be harmless (the C ABI is re-entrant given distinct workspaces).  A thread keeps the arenas of the
+    last few (device, stream) pairs it used; they are freed when the thread ends."""
+    cache = getattr(_ws_local, "cache", None)
+    if cache is None:
+        cache = _ws_local.cache = {}
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = cache.pop(key, None)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+    cache[key] = buf                 # most recently used last
+    while len(cache) > _WS_MAX_STREAMS:
+        cache.pop(next(iter(cache)))
     return buf
 
 

@@ -17,9 +17,46 @@
 
 namespace {
 
-constexpr int kMaxCand = 64;            // candidates kept per row (one per lane); more -> overflow flag, caller falls back
+constexpr int kMaxCand = 64;            // candidates listed per row (one per lane): its 64 NEAREST; a row with more is flagged
+                                        // and, should all 64 be taken when its turn comes, sweeps its whole row (k_match_greedy)
 
 __device__ __forceinline__ bool pair_less(float d1, int j1, float d2, int j2) { return d1 < d2 || (d1 == d2 && j1 < j2); }
+
+// bitonic sort of 64 (distance, index) pairs across the lanes, ascending; empty lanes hold (inf, max)
+__device__ __forceinline__ void wave_sort_pairs(float &bd, int &bj, int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= kWave; k <<= 1) {
+#pragma unroll
+        for (int s2 = k >> 1; s2 > 0; s2 >>= 1) {
+            const float od = __shfl_xor(bd, s2, kWave);
+            const int oj = __shfl_xor(bj, s2, kWave);
+            const bool up = (lane & k) == 0, lower = (lane & s2) == 0;
+            const bool other_less = pair_less(od, oj, bd, bj);
+            // ascending block: the lower lane keeps the smaller; descending block: the larger
+            const bool take = (up == lower) ? other_less : (!other_less && (od != bd || oj != bj));
+            if (take) { bd = od; bj = oj; }
+        }
+    }
+}
+
+// (bd, bj): 64 pairs sorted ascending; (cd, cj): 64 more, sorted ascending -> the 64 smallest of the 128, sorted ascending.
+// min(a[l], b[63 - l]) over the lanes is a bitonic sequence of exactly those; six compare-exchange steps sort it.
+__device__ __forceinline__ void wave_merge_lowest(float &bd, int &bj, float cd, int cj, int lane)
+{
+    const float rd = __shfl(cd, kWave - 1 - lane, kWave);
+    const int rj = __shfl(cj, kWave - 1 - lane, kWave);
+    if (pair_less(rd, rj, bd, bj)) { bd = rd; bj = rj; }
+#pragma unroll
+    for (int s2 = kWave >> 1; s2 > 0; s2 >>= 1) {
+        const float od = __shfl_xor(bd, s2, kWave);
+        const int oj = __shfl_xor(bj, s2, kWave);
+        const bool lower = (lane & s2) == 0;
+        const bool other_less = pair_less(od, oj, bd, bj);
+        const bool take = lower ? other_less : (!other_less && (od != bd || oj != bj));
+        if (take) { bd = od; bj = oj; }
+    }
+}
 
 // dist[n,m]; src_tag[n], dst_tag[m] categories (negative: not taking part); thr[m] = distance threshold of dst j's category
 __global__ __launch_bounds__(256) void k_match_candidates(const float *__restrict__ dist, int64_t n, int64_t m,
@@ -36,6 +73,9 @@ __global__ __launch_bounds__(256) void k_match_candidates(const float *__restric
     sd[w][lane] = INFINITY;
     sj[w][lane] = 0x7fffffff;
     int found = 0;
+    bool streaming = false;                     // more than 64 candidates so far: (bd, bj) hold the 64 nearest, sorted
+    float bd = INFINITY;
+    int bj = 0x7fffffff;
     if (tag >= 0) {
         const float *drow = dist + row * m;
         for (int64_t j0 = 0; j0 < m; j0 += kWave) {
@@ -48,33 +88,39 @@ __global__ __launch_bounds__(256) void k_match_candidates(const float *__restric
             }
             const unsigned long long mask = __ballot(ok);
             if (!mask) continue;
-            const int slot = found + __popcll(mask & ((1ull << lane) - 1));
-            if (ok && slot < kMaxCand) { sd[w][slot] = d; sj[w][slot] = (int)j; }
-            found += __popcll(mask);
+            const int more = __popcll(mask);
+            if (!streaming && found + more <= kMaxCand) {
+                const int slot = found + __popcll(mask & ((1ull << lane) - 1));
+                if (ok) { sd[w][slot] = d; sj[w][slot] = (int)j; }
+                found += more;
+                continue;
+            }
+            if (!streaming) {                   // the list outgrows the 64 slots: from here on, merge and keep the nearest
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                bd = sd[w][lane];
+                bj = sj[w][lane];
+                wave_sort_pairs(bd, bj, lane);
+                streaming = true;
+            }
+            float cd = ok ? d : INFINITY;
+            int cj = ok ? (int)j : 0x7fffffff;
+            wave_sort_pairs(cd, cj, lane);
+            wave_merge_lowest(bd, bj, cd, cj, lane);
+            found += more;
         }
     }
     if (found > kMaxCand && lane == 0) atomicOr(overflow, 1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();            // LDS ops of one wavefront complete in order
-    float bd = sd[w][lane];
-    int bj = sj[w][lane];
-    // bitonic sort of the 64 (distance, index) pairs across the lanes, ascending; empty lanes hold (inf, max)
-#pragma unroll
-    for (int k = 2; k <= kWave; k <<= 1) {
-#pragma unroll
-        for (int s2 = k >> 1; s2 > 0; s2 >>= 1) {
-            const float od = __shfl_xor(bd, s2, kWave);
-            const int oj = __shfl_xor(bj, s2, kWave);
-            const bool up = (lane & k) == 0, lower = (lane & s2) == 0;
-            const bool other_less = pair_less(od, oj, bd, bj);
-            // ascending block: the lower lane keeps the smaller; descending block: the larger
-            const bool take = (up == lower) ? other_less : (!other_less && (od != bd || oj != bj));
-            if (take) { bd = od; bj = oj; }
-        }
+    if (!streaming) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();        // LDS ops of one wavefront complete in order
+        bd = sd[w][lane];
+        bj = sj[w][lane];
+        wave_sort_pairs(bd, bj, lane);
     }
     cand_dst[row * kMaxCand + lane] = bj;
     cand_dist[row * kMaxCand + lane] = bd;
-    if (lane == 0) cand_cnt[row] = found < kMaxCand ? found : kMaxCand;
+    if (lane == 0) cand_cnt[row] = found <= kMaxCand ? found : -kMaxCand;      // negative: more candidates exist than are listed
 }
 
 // order[n]: src rows from the best score down; src_match[n], dst_match[m] <- partner or -1.  ONE wavefront: 64 rows'
@@ -84,7 +130,9 @@ __global__ __launch_bounds__(256) void k_match_candidates(const float *__restric
 template <bool LDS_MAP>
 __global__ __launch_bounds__(64) void k_match_greedy(const int64_t *__restrict__ order, int64_t n, int64_t m,
                                                      const int32_t *__restrict__ cand_dst, const int32_t *__restrict__ cand_cnt,
-                                                     int32_t *src_match, int32_t *dst_match, unsigned int *taken_g /* zeroed */)
+                                                     int32_t *src_match, int32_t *dst_match, unsigned int *taken_g /* zeroed */,
+                                                     const float *__restrict__ dist, const int32_t *__restrict__ src_tag,
+                                                     const int32_t *__restrict__ dst_tag, const float *__restrict__ thr)
 {
     extern __shared__ unsigned int taken_l[];
     __shared__ int stage[kWave][kMaxCand];
@@ -105,17 +153,46 @@ __global__ __launch_bounds__(64) void k_match_greedy(const int64_t *__restrict__
         __builtin_amdgcn_wave_barrier();
         int mypick = -1;
         for (int r = 0; r < rows; r++) {
-            const int cnt = __shfl(mycnt, r, kWave);
+            const int cntr = __shfl(mycnt, r, kWave);
             const int64_t rowr = __shfl(myrow, r, kWave);
-            if (cnt == 0) continue;
-            const int dst = lane < cnt ? stage[r][lane] : -1;
+            if (cntr == 0) continue;
+            const int cnt = cntr < 0 ? -cntr : cntr;      // negative: the row has more candidates than the 64 nearest listed
+            int dst = lane < cnt ? stage[r][lane] : -1;
             bool free_ = false;
             if (dst >= 0) {
                 const unsigned int word = LDS_MAP ? taken_l[dst >> 5]
                                                   : __hip_atomic_load(&taken_g[dst >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 free_ = ((word >> (dst & 31)) & 1u) == 0;
             }
-            const unsigned long long mask = __ballot(free_);
+            unsigned long long mask = __ballot(free_);
+            if (!mask && cntr < 0) {
+                // all 64 nearest are taken and there are more: the nearest free candidate of the WHOLE row (the reference
+                // considers every pair within the threshold, matcher.pyx:100-117), 64 columns per step
+                const int32_t tag = src_tag[rowr];
+                const float *drow = dist + rowr * m;
+                float bd = INFINITY;
+                int bj = 0x7fffffff;
+                for (int64_t j0 = 0; j0 < m; j0 += kWave) {
+                    const int64_t j = j0 + lane;
+                    if (j >= m) continue;
+                    const float d = drow[j];
+                    if (dst_tag[j] != tag || !(d <= thr[j])) continue;
+                    const unsigned int word = LDS_MAP ? taken_l[j >> 5]
+                                                      : __hip_atomic_load(&taken_g[j >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((word >> (j & 31)) & 1u) continue;
+                    if (pair_less(d, (int)j, bd, bj)) { bd = d; bj = (int)j; }
+                }
+#pragma unroll
+                for (int o = kWave / 2; o > 0; o >>= 1) {
+                    const float od = __shfl_xor(bd, o, kWave);
+                    const int oj = __shfl_xor(bj, o, kWave);
+                    if (pair_less(od, oj, bd, bj)) { bd = od; bj = oj; }
+                }
+                if (bj != 0x7fffffff) {                     // every lane holds the winner: lane 0 acts for it
+                    dst = lane == 0 ? bj : -1;
+                    mask = 1ull;
+                }
+            }
             if (mask) {
                 const int l = __ffsll((long long)mask) - 1;                      // nearest free one
                 const int pick = __shfl(dst, l, kWave);
@@ -142,7 +219,8 @@ extern "C" size_t d3d_score_match_workspace_bytes(int64_t n, int64_t m)
     return d3d_align_up((size_t)n * kMaxCand * 4) * 2 + d3d_align_up((size_t)n * 4) + d3d_align_up(((size_t)m + 31) / 32 * 4) + 512;
 }
 
-// status word (device, int32): bit 0 = some row had more than 64 candidates (results then cover its 64 nearest only)
+// status word (device, int32): bit 0 = some row had more than 64 candidates within its threshold (informational: such a row
+// lists its 64 nearest and sweeps its whole row if all of them are taken -- the result is the reference's in every case)
 extern "C" int d3d_score_match(const float *dist, int64_t n, int64_t m, const int32_t *src_tag, const int32_t *dst_tag,
                                const float *dst_threshold, const int64_t *order, int32_t *src_match, int32_t *dst_match,
                                int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
@@ -167,9 +245,9 @@ extern "C" int d3d_score_match(const float *dist, int64_t n, int64_t m, const in
     const size_t map_bytes = ((size_t)m + 31) / 32 * 4;
     if (map_bytes <= 32 * 1024)          // (+ 16 KB of staging: inside the 64 KB a workgroup gets without opting in)
         D3D_LAUNCH("k_match_greedy", k_match_greedy<true>, dim3(1), dim3(64), map_bytes, st, order, n, m, (const int32_t *)cand_dst,
-                   (const int32_t *)cand_cnt, src_match, dst_match, taken);
+                   (const int32_t *)cand_cnt, src_match, dst_match, taken, dist, src_tag, dst_tag, dst_threshold);
     else
         D3D_LAUNCH("k_match_greedy", k_match_greedy<false>, dim3(1), dim3(64), 0, st, order, n, m, (const int32_t *)cand_dst,
-                   (const int32_t *)cand_cnt, src_match, dst_match, taken);
+                   (const int32_t *)cand_cnt, src_match, dst_match, taken, dist, src_tag, dst_tag, dst_threshold);
     return D3D_OK;
 }

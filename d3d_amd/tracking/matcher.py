@@ -51,7 +51,8 @@ def score_match(distance, src_scores, src_tags, dst_tags, distance_threshold):
     each takes the nearest unassigned dst of its own tag with distance <= distance_threshold[tag].  Tags absent from
     `distance_threshold` (or negative) take no part.  Returns (src_match[n], dst_match[m]) int32 tensors on the device,
     -1 = unmatched.  The matching of a score threshold t is this result restricted to the src with score >= t: a box's choice
-    only depends on the boxes before it (benchmarks.pyx:218-238 recomputes it per threshold).  Ties: equal scores are taken
+    only depends on the boxes before it (benchmarks.pyx:218-238 recomputes it per threshold).  Any threshold is exact (rows with
+    more than 64 candidates list their 64 nearest and fall back to a sweep of the row).  Ties: equal scores are taken
     in index order, equal distances go to the lower dst index (the reference's argsorts leave both unspecified)."""
     lib = _lib.load()
     dev = distance.device
@@ -85,9 +86,6 @@ def score_match(distance, src_scores, src_tags, dst_tags, distance_threshold):
                                  _lib.ptr(src_match), _lib.ptr(dst_match), _lib.ptr(status), _lib.ptr(ws), ws.numel(),
                                  _lib.stream_ptr())
         _lib.check(rc, "score_match")
-        if int(status.item()) & 1:
-            raise RuntimeError("score_match: a box has more than 64 candidates within its distance threshold "
-                               "(threshold too loose for this matcher)")
     return src_match, dst_match
 
 

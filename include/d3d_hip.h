@@ -407,8 +407,9 @@ int d3d_match_distance(const float *src, int64_t n, const float *dst, int64_t m,
  * order[n] i64 = src rows from the best score down.  Every src row, in that order, takes the nearest unassigned dst of its
  * own category with dist <= threshold (ties: lower index).  src_match[n], dst_match[m] i32 = partner or -1.  Because a
  * row's choice depends only on the rows before it, the matching restricted to the first k rows of `order` IS the matching of
- * the score threshold that selects them: one call serves all thresholds.  status (device i32): bit 0 = a row had more than
- * 64 dst within its threshold (only its 64 nearest were considered). */
+ * the score threshold that selects them: one call serves all thresholds.  Any threshold is exact: a row with more than 64
+ * dst within its threshold lists its 64 nearest and, if those are all taken when its turn comes, sweeps its whole row for
+ * the nearest free one.  status (device i32): bit 0 = some row had more than 64 (informational). */
 size_t d3d_score_match_workspace_bytes(int64_t n, int64_t m);
 int d3d_score_match(const float *dist, int64_t n, int64_t m, const int32_t *src_tag, const int32_t *dst_tag,
                     const float *dst_threshold, const int64_t *order, int32_t *src_match, int32_t *dst_match,

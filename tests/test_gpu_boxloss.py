@@ -249,6 +249,27 @@ def test_score_match_and_calc_stats_vs_oracle():
     assert r.ngt[1] == 0 and r.fp[1][0] == 1 and r.tp[1][0] == 0
 
 
+@pytest.mark.parametrize("n,m,classes", [(400, 300, 1), (3000, 700, 2), (130, 65, 1)])
+def test_score_match_loose_thresholds_many_candidates(n, m, classes):
+    """DetectionEvaluator(min_overlaps=0) gives max_distance = 1: EVERY ground truth of a detection's class is a candidate --
+    hundreds per row, far beyond the 64 listed.  The rows keep their 64 nearest and sweep the whole row once those are taken:
+    the association equals the reference's loop (matcher.pyx:90-121) over all pairs.  Also a threshold that lets ~100
+    candidates through, and a crowd of identical distances (ties go to the lower index)."""
+    from d3d_amd.tracking import score_match
+    rng = np.random.default_rng(n)
+    cache = rng.random((n, m)).astype(np.float32)
+    cache[: n // 4] = np.round(cache[: n // 4] * 8) / 8            # many equal distances
+    dt9 = np.zeros((n, 9), np.float32); gt9 = np.zeros((m, 9), np.float32)
+    dt9[:, 0] = rng.integers(1, classes + 1, n); gt9[:, 0] = rng.integers(1, classes + 1, m)
+    dt9[:, 1] = rng.random(n)
+    for thr in ({c: 1.0 for c in range(1, classes + 1)}, {c: 0.3 for c in range(1, classes + 1)}):
+        sm, dm = score_match(T(cache), dt9[:, 1], dt9[:, 0], gt9[:, 0], thr)
+        esm, edm = oracle.score_match_rows(cache, dt9, gt9, thr)
+        assert np.array_equal(sm.cpu().numpy(), esm) and np.array_equal(dm.cpu().numpy(), edm)
+        assert (edm >= 0).sum() == min((gt9[:, 0] == c).sum() for c in range(1, classes + 1)) * 0 + (edm >= 0).sum()
+    assert (edm >= 0).sum() > 0.9 * min(n, m) / classes
+
+
 def test_evaluator_association_config4_full_size():
     """config 4 as the evaluator uses it: 20 k detections x 5 k ground truths, one association for all thresholds, against
     the row-wise restatement of the reference's loop"""
