@@ -1052,6 +1052,7 @@ struct BinnedExtras {
     int64_t *host_counts;     // optional host-mapped copy of counts[] + ready flag (d3d_voxelize_3d_dense_notify)
     uint32_t npoints_clamp = 0xffffffffu;
     uint32_t *voff = nullptr; // [V] segment base (dense contract, C != 4: k_aggregate reads the index lists through it)
+    uint32_t *kept_part = nullptr;   // fused sparse + filter: [workgroups of k_meta_first] points kept in the workgroup's voxels
 };
 
 // sparse contract fused with the voxel filter (d3d_voxelize_3d_sparse_filter): only voxels that pass get a first-point
@@ -1584,19 +1585,58 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
     }
     const uint32_t e = firstmap[i];
     const unsigned long long bal = __ballot(e != kInf);
-    if (e == kInf) return;
-    const uint32_t vid = before + fwpre[i >> 6] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-    if (vid >= max_voxels) {                                // voxelize.cpp:116-117: later voxels are never created
-        if (x.vidof) x.vidof[e] = kNoVoxel;
-        return;
+    uint32_t kept = 0;                                      // points this lane's voxel keeps (fused sparse + filter)
+    if (e != kInf) {
+        const uint32_t vid = before + fwpre[i >> 6] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (vid >= max_voxels) {                            // voxelize.cpp:116-117: later voxels are never created
+            if (x.vidof) x.vidof[e] = kNoVoxel;
+        } else {
+            if (x.vidof) x.vidof[e] = vid;
+            if (x.first_out) x.first_out[vid] = x.index_offset + i;
+            const uint4 rec = vrec[e];
+            const uint4 vi = rec;                           // {key lo, key hi, segment base, count}
+            if (vinfo) vinfo[vid] = vi;
+            kept = vi.w < x.npoints_clamp ? vi.w : x.npoints_clamp;
+            meta_voxel<Key, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, x.voff, pmask, agg, nullptr, nullptr,
+                                  x.keys_out, x.npoints_clamp);
+        }
     }
-    if (x.vidof) x.vidof[e] = vid;
-    if (x.first_out) x.first_out[vid] = x.index_offset + i;
-    const uint4 rec = vrec[e];
-    const uint4 vi = rec;                                   // {key lo, key hi, segment base, count}
-    if (vinfo) vinfo[vid] = vi;
-    meta_voxel<Key, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, x.voff, pmask, agg, nullptr, nullptr,
-                               x.keys_out, x.npoints_clamp);
+    if (x.kept_part) {                                      // sum over the workgroup -> k_publish_kept adds the workgroups up
+        __shared__ uint32_t wsum[256 / kWave];
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) kept += __shfl_xor(kept, o, kWave);
+        if (lane == 0) wsum[threadIdx.x >> 6] = kept;
+        __syncthreads();
+        if (threadIdx.x == 0) x.kept_part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+
+// fused sparse + filter: the sizes of BOTH filtered outputs are known once k_meta_first has run -- the voxels it numbered and
+// the points they keep (count, or min(count, max_points) with the TRIM point filter; voxelize.cpp:403, 457-463).  One
+// workgroup adds the partial sums up and publishes them to the host, BEFORE the point map and the three launches of the
+// compaction scan: the host's per-call work (returning the result, allocating the next call's buffers) hides behind them.
+__global__ __launch_bounds__(1024) void k_publish_kept(const uint32_t *__restrict__ part, uint32_t nparts,
+                                                       const int64_t *__restrict__ first_counts, int64_t *host)
+{
+    __shared__ unsigned long long smem[1024 / kWave];
+    unsigned long long s = 0;
+    for (uint32_t t = threadIdx.x; t < nparts; t += 1024) s += part[t];
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) smem[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < 1024 / kWave; k++) tot += smem[k];
+        for (int k = 0; k < D3D_NUM_COUNTS; k++) {
+            host[k] = first_counts[k];
+            host[D3D_NUM_COUNTS + 1 + k] = 0;
+        }
+        host[D3D_NUM_COUNTS + 1 + D3D_COUNT_VOXELS] = first_counts[D3D_COUNT_VOXELS];
+        host[D3D_NUM_COUNTS + 1 + D3D_COUNT_POINTS] = (int64_t)tot;
+        __threadfence_system();
+        __hip_atomic_store(&host[D3D_NUM_COUNTS], (int64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Dense contract, C == 4: numbering, per-voxel outputs AND the voxel's rows of voxels[V,P,4] in one launch.  (The two-launch
@@ -1907,6 +1947,12 @@ struct FilterPoints {
     int64_t *out_mask, *out_mapping;
     bool precomputed = false; // keepid was filled by the fused sparse index (k_map_binned)
     bool vec4 = false;        // c == 4 and 16-byte aligned rows: one float4 copy per kept point
+    // fused sparse + filter on the binned index: the count pass finds every point's filtered voxel id ITSELF, in point order --
+    // the point's place in its bucket is base of the bucket + offset of the tile + arrival number (as k_bin_scatter computed
+    // it), there the record of its voxel, there the voxel's id (k_meta_first) -- instead of a pass over the buckets that
+    // scatters the ids to the points (k_map_binned)
+    const uint32_t *pbin = nullptr, *bucket_base = nullptr, *tileoff = nullptr, *precpos = nullptr, *vidof = nullptr;
+    uint32_t nbins = 0;
 
     __device__ __forceinline__ int32_t keep(int64_t i) const
     {
@@ -1920,6 +1966,19 @@ struct FilterPoints {
     }
     __device__ __forceinline__ unsigned long long value(int64_t i) const
     {
+        if (pbin) {
+            const uint32_t word = pbin[i];
+            int32_t id = -1;
+            if (word < kBadBin) {                  // kBadBin / kNoBin: the point lies in no voxel
+                const uint32_t b = word & (kBinMax - 1), arr = word >> kBinBits;
+                const uint32_t p = bucket_base[b] + tileoff[(size_t)(i / kBinTile) * nbins + b] + arr;
+                const uint32_t e = precpos[p];
+                const uint32_t vid = e == kInf ? kNoVoxel : vidof[e];
+                if (vid != kNoVoxel && !(trimmed && trimmed[i])) id = (int32_t)vid;
+            }
+            keepid[i] = id;
+            return id >= 0 ? 1ull : 0ull;
+        }
         if (precomputed) return keepid[i] >= 0 ? 1ull : 0ull;
         const int32_t id = keep(i);
         keepid[i] = id;
@@ -2121,6 +2180,9 @@ struct DenseOut {
     unsigned char *trimmed = nullptr;   // sparse contract: flag the points beyond P of their voxel (for the TRIM filter)
     VoxelPass pass = {false, 0, {0, 0, 0}, {0, 0, 0}};   // sparse contract fused with the voxel filter
     int32_t *keepid = nullptr;          // ... then: filtered voxel id of every point (-1: dropped) instead of `mapping`
+    bool map_later = false;             // ... computed by the caller's point scan (FilterPoints), not by k_map_binned here
+    int64_t *early_counts = nullptr;    // ... whose output sizes k_meta_first then publishes: counts of the filter call
+    int64_t *early_host = nullptr;      //     + the host-mapped notify buffer (d3d_voxelize_3d_sparse_filter)
     uint32_t npoints_clamp = 0xffffffffu;   // ... and voxel_npoints = min(count, max_points) (voxelize.cpp:403)
     bool lists = false;                 // dense contract with C != 4: ranked index lists + voff instead of staged rows
     uint32_t *seg_out = nullptr;        // reduce contract: segment base of every voxel's staged rows (for the caller)
@@ -2168,6 +2230,8 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     BinnedExtras x = o.x;
     x.vidof = want_map ? w.voff : nullptr;
     x.npoints_clamp = o.npoints_clamp;
+    uint32_t *kept_part = reinterpret_cast<uint32_t *>(w.fwords);      // npad / 64 u64 of the hash path, free here; npad / 256 used
+    x.kept_part = o.early_host ? kept_part : nullptr;
     x.voff = o.seg_out ? o.seg_out : (o.lists ? w.voff : nullptr);
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     if (vec4)
@@ -2218,7 +2282,9 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         D3D_LAUNCH("k_meta_first", (k_meta_first<Key, false>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
                    o.max_voxels, ROWS || o.lists ? w.vinfo : (uint4 *)nullptr, w.staged, o.P, o.reduction, o.coords, o.npoints,
                    o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, counts, x);
-    if (want_map)
+    if (o.early_host)
+        D3D_LAUNCH("k_publish_kept", k_publish_kept, dim3(1), dim3(1024), 0, st, kept_part, (uint32_t)(w.npad / 256), counts, o.early_host);
+    if (want_map && !o.map_later)
         D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
                    reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping, o.keepid,
                    (const unsigned char *)o.trimmed);
@@ -2654,12 +2720,16 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                 for (int k = 0; k < 3; k++) { d.pass.lo[k] = coords_bound[2 * k]; d.pass.hi[k] = coords_bound[2 * k + 1]; }
                 d.keepid = reinterpret_cast<int32_t *>(w.big_list);
                 d.npoints_clamp = trim ? (uint32_t)max_points : 0xffffffffu;
+                d.map_later = true;                     // the compaction's count pass maps the points itself, in point order
+                d.early_host = host_counts;             // output sizes to the host right after the numbering
                 int rc = binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, sparse_counts, d, st);
                 if (rc) return rc;
-                FilterPoints fp{points, c, nullptr, 0, nullptr, nullptr, nullptr, 0xffffffffu, d.keepid, out_feats, out_mask,
+                FilterPoints fp{points, c, nullptr, 0, nullptr, nullptr, d.trimmed, 0xffffffffu, d.keepid, out_feats, out_mask,
                                 out_mapping, true,
                                 c == 4 && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out_feats)) & 15) == 0};
-                return d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st, host_counts, sparse_counts, 1);
+                fp.pbin = w.pslot; fp.bucket_base = w.vidarr; fp.tileoff = reinterpret_cast<const uint32_t *>(w.tabB);
+                fp.precpos = w.unsorted; fp.vidof = w.voff; fp.nbins = nbins;
+                return d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st, (int64_t *)nullptr, sparse_counts, 1);
             }
         }
     }

@@ -136,6 +136,16 @@ def _workspace_bytes(lib, n):
     return b
 
 
+_ws_bytes_cache2 = {}
+
+
+def _workspace_bytes2(lib, n):
+    b = _ws_bytes_cache2.get(n)
+    if b is None:
+        b = _ws_bytes_cache2[n] = lib.d3d_voxelize_workspace_bytes(n, n)
+    return b
+
+
 def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type, flags=None):
     """voxelize_3d_dense of the reference (voxelize.h:9-12; voxelize.cpp:45-199).
 
@@ -290,12 +300,16 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
     if c < 3:
         raise RuntimeError("points need at least 3 columns (x, y, z)")
     bound_h = (ctypes.c_int64 * 6)(*[int(x) for x in _as_tensor(vbounds).reshape(-1).tolist()])
-    with torch.cuda.device(dev):
-        mapping = torch.empty((n,), dtype=torch.int64, device=dev)
-        coords = torch.empty((n, 3), dtype=torch.int64, device=dev)
-        npts = torch.empty((n,), dtype=torch.int32, device=dev)
-        counts = torch.empty((2, _lib.NUM_COUNTS), dtype=torch.int64, device=dev)
-        ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, n), dev)
+    with _device_ctx(dev):
+        # the intermediate sparse outputs (only materialised when the call falls back to the two-operator form) and the two
+        # count rows: slices of ONE scratch tensor -- every torch.empty costs the host a few microseconds per call
+        scratch = torch.empty((n * 9 + 2 * _lib.NUM_COUNTS + 4,), dtype=torch.int32, device=dev)
+        counts = scratch[:4 * _lib.NUM_COUNTS].view(torch.int64).view(2, _lib.NUM_COUNTS)
+        base = 4 * _lib.NUM_COUNTS
+        mapping = scratch[base:base + 2 * n].view(torch.int64)
+        coords = scratch[base + 2 * n:base + 8 * n].view(torch.int64).view(n, 3)
+        npts = scratch[base + 8 * n:base + 9 * n]
+        ws = _lib.workspace(_workspace_bytes2(lib, n), dev)
         o_feats = torch.empty((n, c), dtype=torch.float32, device=dev)
         o_mask = torch.empty((n,), dtype=torch.int64, device=dev)
         o_map = torch.empty((n,), dtype=torch.int64, device=dev)
