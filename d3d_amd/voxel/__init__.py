@@ -303,7 +303,7 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
     with _device_ctx(dev):
         # the intermediate sparse outputs (only materialised when the call falls back to the two-operator form) and the two
         # count rows: slices of ONE scratch tensor -- every torch.empty costs the host a few microseconds per call
-        scratch = torch.empty((n * 9 + 2 * _lib.NUM_COUNTS + 4,), dtype=torch.int32, device=dev)
+        scratch = torch.empty((n * 9 + 4 * _lib.NUM_COUNTS + 8,), dtype=torch.int32, device=dev)
         counts = scratch[:4 * _lib.NUM_COUNTS].view(torch.int64).view(2, _lib.NUM_COUNTS)
         base = 4 * _lib.NUM_COUNTS
         mapping = scratch[base:base + 2 * n].view(torch.int64)
