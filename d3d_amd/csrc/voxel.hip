@@ -1447,8 +1447,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             const uint32_t s = pinfo[bb + q] >> kArrBits, cnt = tcnt[s], base = tbase[s], me = E::idx(bent[bb + q]);
             uint32_t rank = 0, k = 0;
             const uint32_t *v = sg + base;
-            for (; k + 4 <= cnt && rank < P; k += 4) rank += (v[k] < me) + (v[k + 1] < me) + (v[k + 2] < me) + (v[k + 3] < me);
-            for (; k < cnt && rank < P; k++) rank += v[k] < me;
+            // (the rank of a voxel's only point is 0; with nothing to stage or list, only voxels above P need ranks at all)
+            const bool need = (STAGE || LISTS) ? cnt > 1 : cnt > P;
+            for (; need && k + 4 <= cnt && rank < P; k += 4) rank += (v[k] < me) + (v[k + 1] < me) + (v[k + 2] < me) + (v[k + 3] < me);
+            for (; need && k < cnt && rank < P; k++) rank += v[k] < me;
             if constexpr (STAGE) { if (rank < P) staged[bb + base + rank] = points4[me]; }
             if constexpr (LISTS) {
                 if (rank < P && (rank > 0 || !ROWS)) sorted_out[bb + base + rank] = me;
@@ -1513,10 +1515,13 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             const uint32_t s = slot[r], cb = tcnt[s], cnt = cb & 0xffffu, base = cb >> 16, me = idx[r];
             uint32_t rank = 0, k = 0;
             const uint32_t *sg = seg + base;
-            for (; k + 8 <= cnt && rank < P; k += 8)      // 8 independent LDS reads per exit test
+            // (the rank of a voxel's only point is 0; with nothing to stage or list -- the sparse contract's TRIM filter -- only
+            // the points of voxels above P need ranks at all)
+            const bool need = (STAGE || LISTS) ? cnt > 1 : cnt > P;
+            for (; need && k + 8 <= cnt && rank < P; k += 8)      // 8 independent LDS reads per exit test
                 rank += (sg[k] < me) + (sg[k + 1] < me) + (sg[k + 2] < me) + (sg[k + 3] < me) + (sg[k + 4] < me) + (sg[k + 5] < me) +
                         (sg[k + 6] < me) + (sg[k + 7] < me);
-            for (; k < cnt && rank < P; k++) rank += sg[k] < me;
+            for (; need && k < cnt && rank < P; k++) rank += sg[k] < me;
             if constexpr (STAGE) { if (rank < P) *reinterpret_cast<v4f *>(&staged[bb + base + rank]) = row[r]; }
             if constexpr (LISTS) {                                 // dense contract, C != 4: index lists for k_fill_generic /
                 if (rank < P && (rank > 0 || !ROWS)) sorted_out[bb + base + rank] = me;   // k_aggregate; C == 4: for k_emit
@@ -1608,34 +1613,6 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
         if (lane == 0) wsum[threadIdx.x >> 6] = kept;
         __syncthreads();
         if (threadIdx.x == 0) x.kept_part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    }
-}
-
-// fused sparse + filter: the sizes of BOTH filtered outputs are known once k_meta_first has run -- the voxels it numbered and
-// the points they keep (count, or min(count, max_points) with the TRIM point filter; voxelize.cpp:403, 457-463).  One
-// workgroup adds the partial sums up and publishes them to the host, BEFORE the point map and the three launches of the
-// compaction scan: the host's per-call work (returning the result, allocating the next call's buffers) hides behind them.
-__global__ __launch_bounds__(1024) void k_publish_kept(const uint32_t *__restrict__ part, uint32_t nparts,
-                                                       const int64_t *__restrict__ first_counts, int64_t *host)
-{
-    __shared__ unsigned long long smem[1024 / kWave];
-    unsigned long long s = 0;
-    for (uint32_t t = threadIdx.x; t < nparts; t += 1024) s += part[t];
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0) smem[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long tot = 0;
-        for (int k = 0; k < 1024 / kWave; k++) tot += smem[k];
-        for (int k = 0; k < D3D_NUM_COUNTS; k++) {
-            host[k] = first_counts[k];
-            host[D3D_NUM_COUNTS + 1 + k] = 0;
-        }
-        host[D3D_NUM_COUNTS + 1 + D3D_COUNT_VOXELS] = first_counts[D3D_COUNT_VOXELS];
-        host[D3D_NUM_COUNTS + 1 + D3D_COUNT_POINTS] = (int64_t)tot;
-        __threadfence_system();
-        __hip_atomic_store(&host[D3D_NUM_COUNTS], (int64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1953,6 +1930,38 @@ struct FilterPoints {
     // scatters the ids to the points (k_map_binned)
     const uint32_t *pbin = nullptr, *bucket_base = nullptr, *tileoff = nullptr, *precpos = nullptr, *vidof = nullptr;
     uint32_t nbins = 0;
+    // ... and its first workgroup publishes the sizes of both filtered outputs to the host before anything else: the voxels
+    // k_meta_first numbered and the points they keep (count, or min(count, max_points) with the TRIM point filter;
+    // voxelize.cpp:403, 457-463), summed from k_meta_first's per-workgroup partials.  The host's per-call work (returning the
+    // result, allocating the next call's buffers) then hides behind the three launches of this scan.
+    const uint32_t *kept_part = nullptr;
+    uint32_t nparts = 0;
+    const int64_t *first_counts = nullptr;
+    int64_t *host = nullptr;
+    __device__ __forceinline__ void begin() const
+    {
+        if (!host || blockIdx.x != 0) return;              // workgroup-uniform
+        __shared__ unsigned long long psum[kScanBlock / kWave];
+        unsigned long long t = 0;
+        for (uint32_t k = threadIdx.x; k < nparts; k += kScanBlock) t += kept_part[k];
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) t += __shfl_xor(t, o, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0) psum[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < kScanBlock / kWave; k++) tot += psum[k];
+            for (int k = 0; k < D3D_NUM_COUNTS; k++) {
+                host[k] = first_counts[k];
+                host[D3D_NUM_COUNTS + 1 + k] = 0;
+            }
+            host[D3D_NUM_COUNTS + 1 + D3D_COUNT_VOXELS] = first_counts[D3D_COUNT_VOXELS];
+            host[D3D_NUM_COUNTS + 1 + D3D_COUNT_POINTS] = (int64_t)tot;
+            __threadfence_system();
+            __hip_atomic_store(&host[D3D_NUM_COUNTS], (int64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+    }
 
     __device__ __forceinline__ int32_t keep(int64_t i) const
     {
@@ -2282,8 +2291,6 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         D3D_LAUNCH("k_meta_first", (k_meta_first<Key, false>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
                    o.max_voxels, ROWS || o.lists ? w.vinfo : (uint4 *)nullptr, w.staged, o.P, o.reduction, o.coords, o.npoints,
                    o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, counts, x);
-    if (o.early_host)
-        D3D_LAUNCH("k_publish_kept", k_publish_kept, dim3(1), dim3(1024), 0, st, kept_part, (uint32_t)(w.npad / 256), counts, o.early_host);
     if (want_map && !o.map_later)
         D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
                    reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping, o.keepid,
@@ -2729,6 +2736,8 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                                 c == 4 && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out_feats)) & 15) == 0};
                 fp.pbin = w.pslot; fp.bucket_base = w.vidarr; fp.tileoff = reinterpret_cast<const uint32_t *>(w.tabB);
                 fp.precpos = w.unsorted; fp.vidof = w.voff; fp.nbins = nbins;
+                fp.kept_part = reinterpret_cast<const uint32_t *>(w.fwords); fp.nparts = (uint32_t)(w.npad / 256);
+                fp.first_counts = sparse_counts; fp.host = host_counts;
                 return d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st, (int64_t *)nullptr, sparse_counts, 1);
             }
         }
