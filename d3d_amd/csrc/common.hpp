@@ -90,16 +90,10 @@ __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long 
 //              u64 value2(int64 i)  (apply pass; must return the same value)
 //              void apply(int64 i, u64 v, u64 excl)
 // Values are "packed pairs": two u32 sums in one u64 (hi, lo) -- both stay < 2^32.
-// optional F::begin(): run by every workgroup of the count pass before its items (e.g. workgroup 0 publishing sizes that the
-// launches before the scan have settled, so that no launch of its own is needed for it)
-template <class F> __device__ __forceinline__ auto scan_begin(const F &f, int) -> decltype(f.begin(), void()) { f.begin(); }
-template <class F> __device__ __forceinline__ void scan_begin(const F &, long) {}
-
 template <class F>
 __global__ __launch_bounds__(kScanBlock) void k_scan_count(F f, int64_t n, unsigned long long *bsum)
 {
     __shared__ unsigned long long smem[kScanBlock / kWave];
-    scan_begin(f, 0);
     // item layout of a tile: wavefront w owns [w * 64 * kScanItems, ...), row k of it = 64 consecutive items, one per
     // lane -> every access of f is coalesced (consecutive items per THREAD would stride the lanes by kScanItems)
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)(threadIdx.x >> 6) * (kWave * kScanItems) + (threadIdx.x & (kWave - 1));
