@@ -2722,7 +2722,9 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                 for (int k = 0; k < 3; k++) { d.pass.lo[k] = coords_bound[2 * k]; d.pass.hi[k] = coords_bound[2 * k + 1]; }
                 d.keepid = reinterpret_cast<int32_t *>(w.big_list);
                 d.npoints_clamp = trim ? (uint32_t)max_points : 0xffffffffu;
-                d.map_later = true;                     // the compaction's count pass maps the points itself, in point order
+                // the compaction's count pass maps the points itself, in point order (k_map_binned as a launch of its own: 21 us
+                // of kernel against +8 us in the count pass, and 173 vs 158 us per call)
+                d.map_later = true;
                 d.early_host = host_counts;             // output sizes to the host right after the numbering
                 int rc = binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, sparse_counts, d, st);
                 if (rc) return rc;
