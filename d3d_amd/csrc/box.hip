@@ -165,11 +165,14 @@ template <typename T>
 __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict__ ra, int64_t n,
                                                        const float4 *__restrict__ cb, int64_t m, T *__restrict__ ious,
                                                        IouList *hdr, unsigned long long *list, unsigned long long cap,
-                                                       float fillv = 0.f /* T = float only: the matrix' background value */)
+                                                       float fillv = 0.f /* T = float only: the matrix' background value */,
+                                                       const BoxGeom<T> *__restrict__ ga = nullptr /* rotated IoU: the */,
+                                                       const BoxGeom<T> *__restrict__ gb = nullptr /* separating-axis test */)
 {
     constexpr int K = kPreK;
     typedef float vec16 __attribute__((ext_vector_type(4)));
     __shared__ float4 rbox[kTileRows];
+    __shared__ BoxGeom<T> rgeo[kTileRows];          // (only read when ga is given)
     __shared__ unsigned int batch[kTileCols / 64][kPreBatch];   // (row << 16 | local column)
     __shared__ unsigned int wcnt[kTileCols / 64];
     __shared__ unsigned long long bbase;
@@ -177,7 +180,10 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
     const int64_t jb = (int64_t)blockIdx.x * kPreCols;          // first column of the block
     const int64_t j0 = jb + (int64_t)threadIdx.x * K;
     const int nrows = (int)((n - i0) < kTileRows ? (n - i0) : kTileRows);
-    if (threadIdx.x < nrows) rbox[threadIdx.x] = ra[i0 + threadIdx.x];
+    if (threadIdx.x < nrows) {
+        rbox[threadIdx.x] = ra[i0 + threadIdx.x];
+        if (ga) rgeo[threadIdx.x] = ga[i0 + threadIdx.x];
+    }
     float4 cbox[K];
 #pragma unroll
     for (int k = 0; k < K; k++)
@@ -223,7 +229,11 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
             if (__ballot(best > 0.f)) {                       // some lane of the wavefront has a candidate in this row
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    const bool cand = g[k] > 0.f;
+                    bool cand = g[k] > 0.f;
+                    // rotated boxes whose bounding boxes overlap are often disjoint all the same: a separating-axis test on
+                    // the few lanes that got this far keeps them out of the list, so that the clip kernel's wavefronts are
+                    // spent on pairs that do intersect (the column's geometry is gathered only here)
+                    if (ga && cand) cand = !sat_separated(rgeo[r], gb[j0 + k]);
                     const unsigned long long mask = __ballot(cand);
                     if (mask) {
                         const unsigned int cnt = (unsigned int)__popcll(mask);
@@ -1799,7 +1809,8 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *io
         fill = nullptr;
     }
     D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), gy), dim3(kTileCols), 0, st,
-               (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap);
+               (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap, 0.f,
+               ROTATED ? (const BoxGeom<T> *)ga : (const BoxGeom<T> *)nullptr, ROTATED ? (const BoxGeom<T> *)gb : (const BoxGeom<T> *)nullptr);
     D3D_LAUNCH("k_iou_clip", (k_iou_clip<T, ROTATED>), dim3(256 * 16), dim3(256), 0, st, ga, gb, m, ious, hdr, list, cap);
     // fallback (blocks exit at once unless the list overflowed)
     D3D_LAUNCH("k_iou2d", (k_iou2d<T, ROTATED, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols), 0, st, b1,

@@ -204,6 +204,29 @@ __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeo
     return acc / 2;
 }
 
+// Separating-axis test for two rectangles: true only when some edge normal of A or B separates them by a clear margin
+// (1e-9 of the extents: a pair it rejects has intersection area 0 or below that scale; a pair it lets through is simply
+// clipped).  ~60 operations against the ~500 of the clip; for boxes of random orientation a third of the pairs whose
+// bounding boxes overlap are in fact disjoint.
+template <typename T>
+__device__ __forceinline__ bool sat_separated(const BoxGeom<T> &a, const BoxGeom<T> &b)
+{
+    const T dx = b.cx - a.cx, dy = b.cy - a.cy;
+    const T uu = a.ux * b.ux + a.uy * b.uy, uv = a.ux * b.vx + a.uy * b.vy;     // dot(ua, ub), dot(ua, vb)
+    const T vu = a.vx * b.ux + a.vy * b.uy, vv = a.vx * b.vx + a.vy * b.vy;     // dot(va, ub), dot(va, vb)
+    const T tol = (T)1 + (T)1e-9;
+    T r;
+    r = a.ux * a.ux + a.uy * a.uy + fabs(uu) + fabs(uv);                        // axis ua (not normalised: both sides scale)
+    if (fabs(dx * a.ux + dy * a.uy) > r * tol) return true;
+    r = a.vx * a.vx + a.vy * a.vy + fabs(vu) + fabs(vv);                        // axis va
+    if (fabs(dx * a.vx + dy * a.vy) > r * tol) return true;
+    r = b.ux * b.ux + b.uy * b.uy + fabs(uu) + fabs(vu);                        // axis ub
+    if (fabs(dx * b.ux + dy * b.uy) > r * tol) return true;
+    r = b.vx * b.vx + b.vy * b.vy + fabs(uv) + fabs(vv);                        // axis vb
+    if (fabs(dx * b.vx + dy * b.vy) > r * tol) return true;
+    return false;
+}
+
 // rotated IoU (method "rbox": dgal::iou(Quad2, Quad2))
 template <typename T>
 __device__ __forceinline__ T iou_rbox(const BoxGeom<T> &a, const BoxGeom<T> &b)
