@@ -165,14 +165,11 @@ template <typename T>
 __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict__ ra, int64_t n,
                                                        const float4 *__restrict__ cb, int64_t m, T *__restrict__ ious,
                                                        IouList *hdr, unsigned long long *list, unsigned long long cap,
-                                                       float fillv = 0.f /* T = float only: the matrix' background value */,
-                                                       const BoxGeom<T> *__restrict__ ga = nullptr /* rotated IoU: the */,
-                                                       const BoxGeom<T> *__restrict__ gb = nullptr /* separating-axis test */)
+                                                       float fillv = 0.f /* T = float only: the matrix' background value */)
 {
     constexpr int K = kPreK;
     typedef float vec16 __attribute__((ext_vector_type(4)));
     __shared__ float4 rbox[kTileRows];
-    __shared__ BoxGeom<T> rgeo[kTileRows];          // (only read when ga is given)
     __shared__ unsigned int batch[kTileCols / 64][kPreBatch];   // (row << 16 | local column)
     __shared__ unsigned int wcnt[kTileCols / 64];
     __shared__ unsigned long long bbase;
@@ -180,10 +177,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
     const int64_t jb = (int64_t)blockIdx.x * kPreCols;          // first column of the block
     const int64_t j0 = jb + (int64_t)threadIdx.x * K;
     const int nrows = (int)((n - i0) < kTileRows ? (n - i0) : kTileRows);
-    if (threadIdx.x < nrows) {
-        rbox[threadIdx.x] = ra[i0 + threadIdx.x];
-        if (ga) rgeo[threadIdx.x] = ga[i0 + threadIdx.x];
-    }
+    if (threadIdx.x < nrows) rbox[threadIdx.x] = ra[i0 + threadIdx.x];
     float4 cbox[K];
 #pragma unroll
     for (int k = 0; k < K; k++)
@@ -229,11 +223,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
             if (__ballot(best > 0.f)) {                       // some lane of the wavefront has a candidate in this row
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    bool cand = g[k] > 0.f;
-                    // rotated boxes whose bounding boxes overlap are often disjoint all the same: a separating-axis test on
-                    // the few lanes that got this far keeps them out of the list, so that the clip kernel's wavefronts are
-                    // spent on pairs that do intersect (the column's geometry is gathered only here)
-                    if (ga && cand) cand = !sat_separated(rgeo[r], gb[j0 + k]);
+                    const bool cand = g[k] > 0.f;
                     const unsigned long long mask = __ballot(cand);
                     if (mask) {
                         const unsigned int cnt = (unsigned int)__popcll(mask);
@@ -268,21 +258,52 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
     write_out(base);
 }
 
+// One candidate per lane.  ROTATED: rectangles whose bounding boxes overlap are often disjoint all the same (a third of the
+// candidates for boxes of random orientation), and the clip costs ~10x a separating-axis test -- so a workgroup takes 1024
+// candidates at a time, tests them (4 per lane), compacts the survivors through LDS and clips THOSE on dense wavefronts.
+constexpr int kClipChunk = 1024;
 template <typename T, bool ROTATED>
 __global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb,
                                                   int64_t m, T *__restrict__ ious, const IouList *hdr,
                                                   const unsigned long long *__restrict__ list, unsigned long long cap)
 {
     if (hdr->overflow) return;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / hdr->nseg;
+    const unsigned long long segcap = cap / hdr->nseg;
     for (unsigned int sg = 0; sg < hdr->nseg; sg++) {
     const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
     const unsigned long long *seg = list + sg * segcap;
-    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const unsigned long long e = seg[t];
-        const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
-        const T v = ROTATED ? iou_rbox(ga[i], gb[j]) : iou_aabb(ga[i], gb[j]);
-        if (v != 0) ious[i * m + j] = v;
+    if (ROTATED) {
+        __shared__ unsigned long long surv[kClipChunk];
+        __shared__ unsigned int ns;
+        for (unsigned long long c0 = (unsigned long long)blockIdx.x * kClipChunk; c0 < total; c0 += (unsigned long long)gridDim.x * kClipChunk) {
+            if (threadIdx.x == 0) ns = 0;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kClipChunk / 256; u++) {
+                const unsigned long long t = c0 + (unsigned)u * 256u + threadIdx.x;
+                if (t < total) {
+                    const unsigned long long e = seg[t];
+                    if (!sat_separated(ga[e >> 32], gb[e & 0xffffffffull])) surv[atomicAdd(&ns, 1u)] = e;
+                }
+            }
+            __syncthreads();
+            const unsigned int n_s = ns;
+            for (unsigned int q = threadIdx.x; q < n_s; q += 256) {
+                const unsigned long long e = surv[q];
+                const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
+                const T v = iou_rbox(ga[i], gb[j]);
+                if (v != 0) ious[i * m + j] = v;
+            }
+            __syncthreads();
+        }
+    } else {
+        const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+        for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+            const unsigned long long e = seg[t];
+            const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
+            const T v = iou_aabb(ga[i], gb[j]);
+            if (v != 0) ious[i * m + j] = v;
+        }
     }
     }
 }
@@ -1809,8 +1830,7 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *io
         fill = nullptr;
     }
     D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), gy), dim3(kTileCols), 0, st,
-               (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap, 0.f,
-               ROTATED ? (const BoxGeom<T> *)ga : (const BoxGeom<T> *)nullptr, ROTATED ? (const BoxGeom<T> *)gb : (const BoxGeom<T> *)nullptr);
+               (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap);
     D3D_LAUNCH("k_iou_clip", (k_iou_clip<T, ROTATED>), dim3(256 * 16), dim3(256), 0, st, ga, gb, m, ious, hdr, list, cap);
     // fallback (blocks exit at once unless the list overflowed)
     D3D_LAUNCH("k_iou2d", (k_iou2d<T, ROTATED, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols), 0, st, b1,

@@ -169,6 +169,7 @@ __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeo
         for (int e = 0; e < 2; e++)
             rc[k][e] = 1 / fmax(fmax(fabs(nd[k][e]), fabs(nd[k + 2][e])), fmax(fabs(nd[k][e + 2]), fabs(nd[k + 2][e + 2])));
     T acc = 0;
+    const T kBig = (T)3.0e38;                     // "no bound from this half-plane" (finite: no NaN from inf - inf anywhere)
     // A's edges inside B.  CLOSED: an edge lying exactly on an edge of B that runs in the same direction counts as inside (a
     // shared boundary is integrated exactly once; collinear edges in opposite directions -- boxes touching from outside --
     // are dropped from both)
@@ -180,9 +181,10 @@ __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeo
         for (int e = 0; e < 4; e++) {
             const T n0 = ebx[e] * (ay[k] - by[e]) - eby[e] * (ax[k] - bx[e]);   // cross(Eb_e, Pa_k - Qb_e): >= 0 inside
             const T d = nd[k][e], t = n0 * rc[k & 1][e & 1];                    // n0 / |nd|:  -n0 / nd = -t (nd > 0), t (nd < 0)
-            if (d > 0) t0 = fmax(t0, -t);
-            else if (d < 0) t1 = fmin(t1, t);
-            else alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
+            // (selects, not branches: 32 three-way branches cost more scalar bookkeeping than the arithmetic they guard)
+            t0 = fmax(t0, d > 0 ? -t : -kBig);
+            t1 = fmin(t1, d < 0 ? t : kBig);
+            if (d == 0) alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
         }
         if (alive && t0 < t1) acc += (t1 - t0) * (ax[k] * eay[k] - ay[k] * eax[k]);
     }
@@ -195,9 +197,9 @@ __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeo
         for (int k = 0; k < 4; k++) {
             const T n0 = eax[k] * (by[e] - ay[k]) - eay[k] * (bx[e] - ax[k]);   // cross(Ea_k, Pb_e - Qa_k)
             const T d = -nd[k][e], t = n0 * rc[k & 1][e & 1];
-            if (d > 0) t0 = fmax(t0, -t);
-            else if (d < 0) t1 = fmin(t1, t);
-            else alive = alive && n0 > 0;
+            t0 = fmax(t0, d > 0 ? -t : -kBig);
+            t1 = fmin(t1, d < 0 ? t : kBig);
+            alive = alive && (d != 0 || n0 > 0);
         }
         if (alive && t0 < t1) acc += (t1 - t0) * (bx[e] * eby[e] - by[e] * ebx[e]);
     }
