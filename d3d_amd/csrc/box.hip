@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__
             for (unsigned int q = threadIdx.x; q < n_s; q += 256) {
                 const unsigned long long e = surv[q];
                 const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
-                const T v = iou_rbox(ga[i], gb[j]);
+                const T v = iou_rbox<T, true>(ga[i], gb[j]);
                 if (v != 0) ious[i * m + j] = v;
             }
             __syncthreads();

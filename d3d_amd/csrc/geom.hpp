@@ -140,7 +140,11 @@ __device__ __forceinline__ T clip_edge_cross(T px, T py, T dx, T dy, const T (&q
 // wavefront of pairs in profiles/r02_e_iou_clip_valu_pmc.txt).  Every SIGN decision (entering / leaving / parallel, inside /
 // outside when parallel) still uses the individual nd and n0, exactly as before: identical boxes, shared edges and corner
 // contact keep their exact-tie results.
-template <typename T>
+// SELECTS: the per-half-plane updates as selects instead of three-way branches (same arithmetic, same results): the 32
+// branches cost more scalar bookkeeping than the arithmetic they guard -- for the kernel whose only job is the clip
+// (k_iou_clip).  Kernels that inline the clip next to other work and are short of registers (k_softnms: 1024 threads, 128
+// VGPRs) keep the branched form, which needs fewer live masks.
+template <typename T, bool SELECTS = false>
 __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeom<T> &b)
 {
     // corners relative to A's centre
@@ -181,10 +185,15 @@ __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeo
         for (int e = 0; e < 4; e++) {
             const T n0 = ebx[e] * (ay[k] - by[e]) - eby[e] * (ax[k] - bx[e]);   // cross(Eb_e, Pa_k - Qb_e): >= 0 inside
             const T d = nd[k][e], t = n0 * rc[k & 1][e & 1];                    // n0 / |nd|:  -n0 / nd = -t (nd > 0), t (nd < 0)
-            // (selects, not branches: 32 three-way branches cost more scalar bookkeeping than the arithmetic they guard)
-            t0 = fmax(t0, d > 0 ? -t : -kBig);
-            t1 = fmin(t1, d < 0 ? t : kBig);
-            if (d == 0) alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
+            if (SELECTS) {
+                t0 = fmax(t0, d > 0 ? -t : -kBig);
+                t1 = fmin(t1, d < 0 ? t : kBig);
+                if (d == 0) alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
+            } else {
+                if (d > 0) t0 = fmax(t0, -t);
+                else if (d < 0) t1 = fmin(t1, t);
+                else alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
+            }
         }
         if (alive && t0 < t1) acc += (t1 - t0) * (ax[k] * eay[k] - ay[k] * eax[k]);
     }
@@ -197,9 +206,15 @@ __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeo
         for (int k = 0; k < 4; k++) {
             const T n0 = eax[k] * (by[e] - ay[k]) - eay[k] * (bx[e] - ax[k]);   // cross(Ea_k, Pb_e - Qa_k)
             const T d = -nd[k][e], t = n0 * rc[k & 1][e & 1];
-            t0 = fmax(t0, d > 0 ? -t : -kBig);
-            t1 = fmin(t1, d < 0 ? t : kBig);
-            alive = alive && (d != 0 || n0 > 0);
+            if (SELECTS) {
+                t0 = fmax(t0, d > 0 ? -t : -kBig);
+                t1 = fmin(t1, d < 0 ? t : kBig);
+                alive = alive && (d != 0 || n0 > 0);
+            } else {
+                if (d > 0) t0 = fmax(t0, -t);
+                else if (d < 0) t1 = fmin(t1, t);
+                else alive = alive && n0 > 0;
+            }
         }
         if (alive && t0 < t1) acc += (t1 - t0) * (bx[e] * eby[e] - by[e] * ebx[e]);
     }
@@ -230,12 +245,12 @@ __device__ __forceinline__ bool sat_separated(const BoxGeom<T> &a, const BoxGeom
 }
 
 // rotated IoU (method "rbox": dgal::iou(Quad2, Quad2))
-template <typename T>
+template <typename T, bool SELECTS = false>
 __device__ __forceinline__ T iou_rbox(const BoxGeom<T> &a, const BoxGeom<T> &b)
 {
     if (!(a.area > 0) || !(b.area > 0)) return 0;   // degenerate (zero / negative size) boxes: IoU 0, never NaN
     if (aabb_disjoint(a, b)) return 0;
-    T inter = intersection_area(a, b);
+    T inter = intersection_area<T, SELECTS>(a, b);
     if (!(inter > 0)) return 0;
     return inter / (a.area + b.area - inter);
 }
