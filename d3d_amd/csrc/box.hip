@@ -136,7 +136,9 @@ __device__ __forceinline__ float aabb_gap(const float4 &a, const float4 &b)
     return fminf(fminf(d1.x, d1.y), fminf(d2.x, d2.y));
 }
 
-template <typename T>
+// CORE: the six numbers of a box (centre, half-extent vectors) in one 64-byte (fp64) / 32-byte (fp32) aligned record instead of
+// the 88 / 44-byte BoxGeom: what the rotated clip gathers per candidate -- one sector per box instead of two
+template <typename T, bool CORE = false>
 __global__ __launch_bounds__(256) void k_geom(const T *__restrict__ boxes, int64_t n, BoxGeom<T> *geom, float4 *aabb,
                                               IouList *hdr, unsigned int nseg, bool rotated)
 {
@@ -144,7 +146,8 @@ __global__ __launch_bounds__(256) void k_geom(const T *__restrict__ boxes, int64
     if (hdr && i == 0) list_reset(hdr, nseg);
     if (i < n) {
         const BoxGeom<T> g = Box2D<T>::load(boxes + i * 5);
-        geom[i] = g;
+        if (CORE) reinterpret_cast<BoxCore<T> *>(geom)[i] = core_of(g);
+        else geom[i] = g;
         aabb[i] = cand_aabb(g, rotated);  // 16 B per box: what k_iou_pre reads (coalesced) instead of the geometry
     }
 }
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__
     const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
     const unsigned long long *seg = list + sg * segcap;
     if (ROTATED) {
+        const BoxCore<T> *ca = reinterpret_cast<const BoxCore<T> *>(ga), *cb = reinterpret_cast<const BoxCore<T> *>(gb);   // k_geom<T, true>
         __shared__ unsigned long long surv[kClipChunk];
         __shared__ unsigned int ns;
         for (unsigned long long c0 = (unsigned long long)blockIdx.x * kClipChunk; c0 < total; c0 += (unsigned long long)gridDim.x * kClipChunk) {
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__
                 const unsigned long long t = c0 + (unsigned)u * 256u + threadIdx.x;
                 if (t < total) {
                     const unsigned long long e = seg[t];
-                    if (!sat_separated(ga[e >> 32], gb[e & 0xffffffffull])) surv[atomicAdd(&ns, 1u)] = e;
+                    if (!sat_separated(ca[e >> 32], cb[e & 0xffffffffull])) surv[atomicAdd(&ns, 1u)] = e;
                 }
             }
             __syncthreads();
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__
             for (unsigned int q = threadIdx.x; q < n_s; q += 256) {
                 const unsigned long long e = surv[q];
                 const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
-                const T v = iou_rbox<T, true>(ga[i], gb[j]);
+                const T v = iou_rbox_core<T, true>(ca[i], cb[j]);
                 if (v != 0) ious[i * m + j] = v;
             }
             __syncthreads();
@@ -1819,9 +1823,9 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *io
     unsigned long long *list = w.take<unsigned long long>(cap);
     if (!w.ok()) return D3D_ERR_WORKSPACE;
     if ((opts >> 8) != 0 && (unsigned long long)(opts >> 8) < cap) cap = opts >> 8;     // D3D_IOU_LIST_CAP: use less of it
-    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, ra, hdr,
+    D3D_LAUNCH("k_geom", (k_geom<T, ROTATED>), dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, ra, hdr,
                list_segments(cap), ROTATED);
-    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u,
+    D3D_LAUNCH("k_geom", (k_geom<T, ROTATED>), dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u,
                ROTATED);
     const unsigned gy = (unsigned)d3d_divup(n, kTileRows);
     T *fill = ious;

@@ -225,8 +225,8 @@ __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeo
 // (1e-9 of the extents: a pair it rejects has intersection area 0 or below that scale; a pair it lets through is simply
 // clipped).  ~60 operations against the ~500 of the clip; for boxes of random orientation a third of the pairs whose
 // bounding boxes overlap are in fact disjoint.
-template <typename T>
-__device__ __forceinline__ bool sat_separated(const BoxGeom<T> &a, const BoxGeom<T> &b)
+template <typename T, class G>
+__device__ __forceinline__ bool sat_separated_t(const G &a, const G &b)
 {
     const T dx = b.cx - a.cx, dy = b.cy - a.cy;
     const T uu = a.ux * b.ux + a.uy * b.uy, uv = a.ux * b.vx + a.uy * b.vy;     // dot(ua, ub), dot(ua, vb)
@@ -244,6 +244,9 @@ __device__ __forceinline__ bool sat_separated(const BoxGeom<T> &a, const BoxGeom
     return false;
 }
 
+template <typename T> __device__ __forceinline__ bool sat_separated(const BoxGeom<T> &a, const BoxGeom<T> &b) { return sat_separated_t<T>(a, b); }
+template <typename T> __device__ __forceinline__ bool sat_separated(const BoxCore<T> &a, const BoxCore<T> &b) { return sat_separated_t<T>(a, b); }
+
 // rotated IoU (method "rbox": dgal::iou(Quad2, Quad2))
 template <typename T, bool SELECTS = false>
 __device__ __forceinline__ T iou_rbox(const BoxGeom<T> &a, const BoxGeom<T> &b)
@@ -251,6 +254,20 @@ __device__ __forceinline__ T iou_rbox(const BoxGeom<T> &a, const BoxGeom<T> &b)
     if (!(a.area > 0) || !(b.area > 0)) return 0;   // degenerate (zero / negative size) boxes: IoU 0, never NaN
     if (aabb_disjoint(a, b)) return 0;
     T inter = intersection_area<T, SELECTS>(a, b);
+    if (!(inter > 0)) return 0;
+    return inter / (a.area + b.area - inter);
+}
+
+// the same from the boxes' cores (candidates of the rotated clip: their bounding boxes are known to overlap)
+template <typename T, bool SELECTS = false>
+__device__ __forceinline__ T iou_rbox_core(const BoxCore<T> &ca, const BoxCore<T> &cb)
+{
+    BoxGeom<T> a, b;                              // only the centre, the half-extent vectors and the area are read below
+    a.cx = ca.cx; a.cy = ca.cy; a.ux = ca.ux; a.uy = ca.uy; a.vx = ca.vx; a.vy = ca.vy; a.area = 4 * (ca.ux * ca.vy - ca.uy * ca.vx);
+    b.cx = cb.cx; b.cy = cb.cy; b.ux = cb.ux; b.uy = cb.uy; b.vx = cb.vx; b.vy = cb.vy; b.area = 4 * (cb.ux * cb.vy - cb.uy * cb.vx);
+    a.xmin = a.xmax = a.ymin = a.ymax = b.xmin = b.xmax = b.ymin = b.ymax = 0;
+    if (!(a.area > 0) || !(b.area > 0)) return 0;
+    const T inter = intersection_area<T, SELECTS>(a, b);
     if (!(inter > 0)) return 0;
     return inter / (a.area + b.area - inter);
 }
