@@ -129,17 +129,18 @@ __device__ __forceinline__ T clip_edge_cross(T px, T py, T dx, T dy, const T (&q
     return sx * ey - sy * ex;
 }
 
-// area of A ∩ B for two CCW quads.
+// area of A ∩ B for two rectangles (CCW quads given by centre and half-extent vectors).
 // Green's theorem over the boundary of the intersection: every edge P + t D of either quad contributes cross(S, E) / 2 for
 // the piece [S, E] = [P + t0 D, P + t1 D] that survives the four half-planes of the other quad (Cyrus-Beck) -- and
-// cross(P + t0 D, P + t1 D) = (t1 - t0) cross(P, D), so only the LENGTH of the parameter interval is needed.  The 32
-// (edge, half-plane) combinations share their denominators: nd(k, e) = cross(Eb_e, Ea_k) serves A's edge k against B's
-// half-plane e, and -nd(k, e) -- bit for bit: products commute and a - b = -(b - a) -- B's edge e against A's half-plane k;
-// a rectangle's opposite edges are antiparallel, so up to sign and rounding there are only four distinct denominators and
-// FOUR divisions per pair (the plain form spends 32 fp64 divisions of ~15 instructions each: 9.0 k VALU instructions per
-// wavefront of pairs in profiles/r02_e_iou_clip_valu_pmc.txt).  Every SIGN decision (entering / leaving / parallel, inside /
-// outside when parallel) still uses the individual nd and n0, exactly as before: identical boxes, shared edges and corner
-// contact keep their exact-tie results.
+// cross(P + t0 D, P + t1 D) = (t1 - t0) cross(P, D), so only the LENGTH of the parameter interval is needed.
+// A rectangle's edge vectors are exactly +2u, +2v, -2u, -2v (doubling and negation are exact), so the denominators of the 32
+// (edge, half-plane) combinations, nd(k, e) = cross(Eb_e, Ea_k), are +-4 times FOUR cross products -- cross(ub, ua),
+// cross(vb, ua), cross(ub, va), cross(vb, va) -- with a sign known at compile time; the same four serve B's edges against A's
+// half-planes (cross(Ea_k, Eb_e) = -nd(k, e), bit for bit).  Four divisions per pair and eight comparisons decide
+// entering / leaving / parallel for all 32 combinations (the plain form: 32 fp64 divisions of ~15 instructions each and 64
+// comparisons; 9.0 k VALU instructions per wavefront of pairs in profiles/r02_e_iou_clip_valu_pmc.txt).  Ties stay exact:
+// for identical boxes all parallel combinations have nd == 0 exactly, and the inside / outside decision of a parallel edge
+// uses cross(E, P - Q) of the actual corners, which is exactly 0 for coincident edges.
 // SELECTS: the per-half-plane updates as selects instead of three-way branches (same arithmetic, same results): the 32
 // branches cost more scalar bookkeeping than the arithmetic they guard -- for the kernel whose only job is the clip
 // (k_iou_clip).  Kernels that inline the clip next to other work and are short of registers (k_softnms: 1024 threads, 128
@@ -153,25 +154,21 @@ __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeo
     const T ox = b.cx - a.cx, oy = b.cy - a.cy;
     const T bx[4] = {ox - b.ux - b.vx, ox + b.ux - b.vx, ox + b.ux + b.vx, ox - b.ux + b.vx};
     const T by[4] = {oy - b.uy - b.vy, oy + b.uy - b.vy, oy + b.uy + b.vy, oy - b.uy + b.vy};
-    T eax[4], eay[4], ebx[4], eby[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        eax[k] = ax[(k + 1) & 3] - ax[k]; eay[k] = ay[(k + 1) & 3] - ay[k];
-        ebx[k] = bx[(k + 1) & 3] - bx[k]; eby[k] = by[(k + 1) & 3] - by[k];
-    }
-    T nd[4][4];                                   // nd[k][e] = cross(Eb_e, Ea_k)
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) nd[k][e] = ebx[e] * eay[k] - eby[e] * eax[k];
-    // one reciprocal per group of (anti)parallel combinations {k, k + 2} x {e, e + 2}, of the member largest in magnitude
-    // (so that it is finite whenever any member is non-zero); the sign is always taken from the individual nd
-    T rc[2][2];
+    // edge k runs from corner k to corner k + 1: +2u, +2v, -2u, -2v
+    const T eax[4] = {2 * a.ux, 2 * a.vx, -2 * a.ux, -2 * a.vx}, eay[4] = {2 * a.uy, 2 * a.vy, -2 * a.uy, -2 * a.vy};
+    const T ebx[4] = {2 * b.ux, 2 * b.vx, -2 * b.ux, -2 * b.vx}, eby[4] = {2 * b.uy, 2 * b.vy, -2 * b.uy, -2 * b.vy};
+    // base[kk][ee] = cross(Eb_ee, Ea_kk) for kk, ee in {0, 1};  nd(k, e) = sgn(k) sgn(e) base[k & 1][e & 1],  sgn = + + - -
+    T base[2][2], rc[2][2];
+    bool pos[2][2], neg[2][2];
 #pragma unroll
     for (int k = 0; k < 2; k++)
 #pragma unroll
-        for (int e = 0; e < 2; e++)
-            rc[k][e] = 1 / fmax(fmax(fabs(nd[k][e]), fabs(nd[k + 2][e])), fmax(fabs(nd[k][e + 2]), fabs(nd[k + 2][e + 2])));
+        for (int e = 0; e < 2; e++) {
+            base[k][e] = ebx[e] * eay[k] - eby[e] * eax[k];
+            pos[k][e] = base[k][e] > 0;
+            neg[k][e] = base[k][e] < 0;
+            rc[k][e] = 1 / fabs(base[k][e]);          // inf when parallel: never used then
+        }
     T acc = 0;
     const T kBig = (T)3.0e38;                     // "no bound from this half-plane" (finite: no NaN from inf - inf anywhere)
     // A's edges inside B.  CLOSED: an edge lying exactly on an edge of B that runs in the same direction counts as inside (a
@@ -183,36 +180,40 @@ __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeo
         bool alive = true;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
+            const bool flip = ((k >> 1) ^ (e >> 1)) != 0;                       // compile-time: nd(k, e) = -base
+            const bool dpos = flip ? neg[k & 1][e & 1] : pos[k & 1][e & 1], dneg = flip ? pos[k & 1][e & 1] : neg[k & 1][e & 1];
             const T n0 = ebx[e] * (ay[k] - by[e]) - eby[e] * (ax[k] - bx[e]);   // cross(Eb_e, Pa_k - Qb_e): >= 0 inside
-            const T d = nd[k][e], t = n0 * rc[k & 1][e & 1];                    // n0 / |nd|:  -n0 / nd = -t (nd > 0), t (nd < 0)
+            const T t = n0 * rc[k & 1][e & 1];                                  // n0 / |nd|:  -n0 / nd = -t (nd > 0), t (nd < 0)
             if (SELECTS) {
-                t0 = fmax(t0, d > 0 ? -t : -kBig);
-                t1 = fmin(t1, d < 0 ? t : kBig);
-                if (d == 0) alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
+                t0 = fmax(t0, dpos ? -t : -kBig);
+                t1 = fmin(t1, dneg ? t : kBig);
+                if (!dpos && !dneg) alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
             } else {
-                if (d > 0) t0 = fmax(t0, -t);
-                else if (d < 0) t1 = fmin(t1, t);
+                if (dpos) t0 = fmax(t0, -t);
+                else if (dneg) t1 = fmin(t1, t);
                 else alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
             }
         }
         if (alive && t0 < t1) acc += (t1 - t0) * (ax[k] * eay[k] - ay[k] * eax[k]);
     }
-    // B's edges inside A (open)
+    // B's edges inside A (open): cross(Ea_k, Eb_e) = -nd(k, e)
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         T t0 = 0, t1 = 1;
         bool alive = true;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+            const bool flip = ((k >> 1) ^ (e >> 1)) == 0;                       // the sign of -nd(k, e)
+            const bool dpos = flip ? neg[k & 1][e & 1] : pos[k & 1][e & 1], dneg = flip ? pos[k & 1][e & 1] : neg[k & 1][e & 1];
             const T n0 = eax[k] * (by[e] - ay[k]) - eay[k] * (bx[e] - ax[k]);   // cross(Ea_k, Pb_e - Qa_k)
-            const T d = -nd[k][e], t = n0 * rc[k & 1][e & 1];
+            const T t = n0 * rc[k & 1][e & 1];
             if (SELECTS) {
-                t0 = fmax(t0, d > 0 ? -t : -kBig);
-                t1 = fmin(t1, d < 0 ? t : kBig);
-                alive = alive && (d != 0 || n0 > 0);
+                t0 = fmax(t0, dpos ? -t : -kBig);
+                t1 = fmin(t1, dneg ? t : kBig);
+                alive = alive && (dpos || dneg || n0 > 0);
             } else {
-                if (d > 0) t0 = fmax(t0, -t);
-                else if (d < 0) t1 = fmin(t1, t);
+                if (dpos) t0 = fmax(t0, -t);
+                else if (dneg) t1 = fmin(t1, t);
                 else alive = alive && n0 > 0;
             }
         }
