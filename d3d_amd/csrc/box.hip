@@ -138,6 +138,24 @@ __device__ __forceinline__ float aabb_gap(const float4 &a, const float4 &b)
 
 // CORE: the six numbers of a box (centre, half-extent vectors) in one 64-byte (fp64) / 32-byte (fp32) aligned record instead of
 // the 88 / 44-byte BoxGeom: what the rotated clip gathers per candidate -- one sector per box instead of two
+// both operands of a pairwise call in ONE launch (a launch per operand costs ~6 us each at a few thousand boxes)
+template <typename T, bool CORE>
+__global__ __launch_bounds__(256) void k_geom2(const T *__restrict__ b1, int64_t n, BoxGeom<T> *g1, float4 *a1,
+                                               const T *__restrict__ b2, int64_t m, BoxGeom<T> *g2, float4 *a2,
+                                               IouList *hdr, unsigned int nseg, bool rotated)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (hdr && i == 0) list_reset(hdr, nseg);
+    if (i >= n + m) return;
+    const bool second = i >= n;
+    if (second) i -= n;
+    const BoxGeom<T> g = Box2D<T>::load((second ? b2 : b1) + i * 5);
+    BoxGeom<T> *gd = second ? g2 : g1;
+    if (CORE) reinterpret_cast<BoxCore<T> *>(gd)[i] = core_of(g);
+    else gd[i] = g;
+    (second ? a2 : a1)[i] = cand_aabb(g, rotated);
+}
+
 template <typename T, bool CORE = false>
 __global__ __launch_bounds__(256) void k_geom(const T *__restrict__ boxes, int64_t n, BoxGeom<T> *geom, float4 *aabb,
                                               IouList *hdr, unsigned int nseg, bool rotated)
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
 // candidates at a time, tests them (4 per lane), compacts the survivors through LDS and clips THOSE on dense wavefronts.
 constexpr int kClipChunk = 1024;
 template <typename T, bool ROTATED>
-__global__ __launch_bounds__(256) void k_iou_clip(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_iou_clip(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb,
                                                   int64_t m, T *__restrict__ ious, const IouList *hdr,
                                                   const unsigned long long *__restrict__ list, unsigned long long cap)
 {
@@ -1823,10 +1841,8 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *io
     unsigned long long *list = w.take<unsigned long long>(cap);
     if (!w.ok()) return D3D_ERR_WORKSPACE;
     if ((opts >> 8) != 0 && (unsigned long long)(opts >> 8) < cap) cap = opts >> 8;     // D3D_IOU_LIST_CAP: use less of it
-    D3D_LAUNCH("k_geom", (k_geom<T, ROTATED>), dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, ra, hdr,
-               list_segments(cap), ROTATED);
-    D3D_LAUNCH("k_geom", (k_geom<T, ROTATED>), dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u,
-               ROTATED);
+    D3D_LAUNCH("k_geom", (k_geom2<T, ROTATED>), dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, ga, ra, b2, m, gb, cb,
+               hdr, list_segments(cap), ROTATED);
     const unsigned gy = (unsigned)d3d_divup(n, kTileRows);
     T *fill = ious;
     if (reinterpret_cast<uintptr_t>(ious) & 15) {             // unaligned output: plain memset, candidates only
