@@ -347,6 +347,27 @@ def extras(args):
         box2d_iou(b1g, b2g, method="grbox").sum().backward()
     dt = timed(fwd_bwd, 5, 1)
     ex["iou2d_grbox_fp64_fwd_bwd_2kx2k_ms"] = round(dt / 5 * 1e3, 3)
+    # the reference's OWN IoU benchmark protocol (test/compare/benchmark_riou.py:53-118): n x n rotated IoU of fp32 boxes
+    # through box2d_iou (precise=True: fp64 inside), forward, then .sum().backward() into boxes2, for n = 1 ... 5000; boxes as
+    # there (centres in +-5, sizes in [0, 5), angles in +-5 rad: 28 % of the pairs overlap).  Times with a device
+    # synchronisation on both sides (the reference's script stops its clock without one).
+    proto = {}
+    rngp = np.random.default_rng(11)
+    for n_p, rep in ((1, 50), (1, 200), (2, 200), (5, 100), (10, 100), (20, 50), (50, 20), (100, 10), (200, 10), (500, 5), (1000, 5),
+                     (2000, 5), (5000, 5)):
+        tf = tb = 0.0
+        for _ in range(rep):
+            mk = lambda: np.stack([(rngp.random(n_p) - 0.5) * 10, (rngp.random(n_p) - 0.5) * 10, rngp.random(n_p) * 5,  # noqa: E731
+                                   rngp.random(n_p) * 5, (rngp.random(n_p) - 0.5) * 10], 1).astype(np.float32)
+            p1, p2 = torch.from_numpy(mk()).cuda(), torch.from_numpy(mk()).cuda().requires_grad_(True)
+            sync(); t0 = time.perf_counter()
+            r = box2d_iou(p1, p2, method="rbox")
+            sync(); t1 = time.perf_counter()
+            r.sum().backward()
+            sync(); t2 = time.perf_counter()
+            tf += t1 - t0; tb += t2 - t1
+        proto[str(n_p)] = dict(forward_ms=round(1e3 * tf / rep, 4), backward_ms=round(1e3 * tb / rep, 4))   # the first n = 1 round
+    ex["reference_riou_protocol_ms"] = proto                                                               # is the warm-up
     from d3d_amd.box import pdist2dr_forward
     pts2 = torch.rand((1000000, 2), dtype=torch.float32, device="cuda") * 3000
     bx32 = bl[:2000].to(torch.float32)
