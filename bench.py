@@ -106,9 +106,10 @@ def stream_probe(nbytes, iters=5):
     the access patterns of the HBM-bound kernels with the work stripped off (d3d_stream_probe, api.hip)"""
     from d3d_amd import _lib
     lib = _lib.load()
-    buf = torch.zeros((nbytes,), dtype=torch.uint8, device="cuda")
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
     out = {}
-    for mode, name, moved in ((0, "store_nt", nbytes), (1, "copy", nbytes // 32 * 32), (2, "read", nbytes), (3, "memset", nbytes)):
+    for mode, name, moved in ((0, "store_nt", nbytes), (4, "store_nt_chunked", nbytes), (1, "copy", nbytes // 32 * 32), (2, "read", nbytes),
+                              (3, "memset", nbytes)):
         run = lambda: _lib.check(lib.d3d_stream_probe(mode, _lib.ptr(buf), nbytes, _lib.stream_ptr()), "stream_probe")  # noqa: E731
         run()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -158,6 +159,8 @@ def large_frame_leg(steps=5):
                 "(3008x3008x120), dense+MEAN, max 32 pts/voxel", voxels=V, achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), peak_measured=probe,
                 frac_of_measured_store=round(ach / probe["store_nt"], 4),
+                # k_emit's own store pattern (every wavefront through a stretch of its own) without any of its loads
+                frac_of_measured_chunked_store=round(ach / probe["store_nt_chunked"], 4),
                 # the fill moves reads as well as writes: against the best streaming rate of either kind measured on this box
                 frac_of_measured_best=round(ach / max(probe.values()), 4), avg_us=round(us, 2), algorithmic_bytes=b_alg,
                 traffic=traffic, traffic_source=src, op_ms=round(1e3 * dt / steps, 3),
@@ -275,6 +278,11 @@ def extras(args):
             ex["iou2d_rbox_fp64_roofline"] = dict(bound="hbm", kernel="k_iou_pre", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                                   frac=round(ach / HBM_PEAK_GBS, 4), avg_us=round(kp["avg_us"], 1),
                                                   algorithmic_bytes=n3 * n3 * 8)
+            # the stream probes at THIS kernel's footprint (an 80 GB buffer: the 3 GB probes of roofline_large undersell a
+            # fill that runs for 13 ms over every channel of the 288 GB) -- no fraction of a measured rate may exceed 1
+            torch.cuda.empty_cache()
+            pr = stream_probe(n3 * n3 * 8, iters=2)
+            ex["iou2d_rbox_fp64_roofline"].update(peak_measured=pr, frac_of_measured_best=round(ach / max(pr.values()), 4))
     torch.cuda.empty_cache()
     bd, _ = synth.boxes2d_dense(5000, 1)      # the reference's own benchmark distribution (ALU-bound case)
     bdt = torch.from_numpy(bd).cuda()

@@ -79,7 +79,8 @@ extern "C" int d3d_profile_report(char *buf, size_t buf_bytes)
 // Stream-bandwidth probes for bench.py's roofline legs ("fraction of the MEASURED copy bandwidth on the same box",
 // SURVEY 8d): the access patterns of the HBM-bound kernels with the work stripped off.  mode 0: nontemporal 16-byte
 // stores over `bytes` (the pattern of k_fill_c4 / the IoU zero fill); mode 1: copy of bytes/2 -> bytes/2
-// (16-byte loads + nontemporal stores); mode 2: read-only sweep (the sum lands in the first word, so the loads stay).
+// (16-byte loads + nontemporal stores); mode 2: read-only sweep (the sum lands in the first word, so the loads stay); mode 3:
+// hipMemsetAsync; mode 4: nontemporal stores, every wavefront through a 32 KiB stretch of its own (the pattern of k_emit).
 namespace {
 typedef float bvec4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_probe_store(bvec4 *p, size_t n)
@@ -87,6 +88,16 @@ __global__ __launch_bounds__(256) void k_probe_store(bvec4 *p, size_t n)
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const bvec4 v = {0.f, 0.f, 0.f, 0.f};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(v, &p[i]);
+}
+// the store pattern of the fused output kernels (k_emit, k_owner_dense): every wavefront streams through a stretch of its
+// own (32 KiB here), 1 KiB per store instruction -- "chunked", against the single moving window of the grid-stride form
+__global__ __launch_bounds__(256) void k_probe_store_chunked(bvec4 *p, size_t n)
+{
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const size_t per = 2048;                                   // 16-byte vectors per stretch
+    const bvec4 v = {0.f, 0.f, 0.f, 0.f};
+    for (size_t s0 = wave * per; s0 < n; s0 += (size_t)gridDim.x * (blockDim.x >> 6) * per)
+        for (size_t k = lane; k < per && s0 + k < n; k += 64) __builtin_nontemporal_store(v, &p[s0 + k]);
 }
 __global__ __launch_bounds__(256) void k_probe_copy(const bvec4 *__restrict__ src, bvec4 *__restrict__ dst, size_t n)
 {
@@ -120,6 +131,10 @@ extern "C" int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream)
         D3D_LAUNCH("k_probe_read", k_probe_read, dim3(blocks), dim3(256), 0, st, (const bvec4 *)buf, bytes / 16, (float *)buf);
     } else if (mode == 3) {
         D3D_HIP_CHECK(hipMemsetAsync(buf, 0, bytes, st));          // the runtime's own fill kernel, for reference
+    } else if (mode == 4) {
+        const size_t nvec = bytes / 16, stretches = (nvec + 2047) / 2048;
+        const unsigned b = (unsigned)(stretches / 4 < 65536 ? (stretches + 3) / 4 : 65536);
+        D3D_LAUNCH("k_probe_store_chunked", k_probe_store_chunked, dim3(b ? b : 1), dim3(256), 0, st, (bvec4 *)buf, nvec);
     } else return D3D_ERR_BAD_ARG;
     return D3D_OK;
 }
