@@ -2062,7 +2062,11 @@ extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *o
         order = order_ws;
     }
     if (suppression_type != D3D_SUPPRESS_HARD) {
-        if (n > 65536) return D3D_ERR_UNSUPPORTED;         // one workgroup, n rounds: minutes beyond this size
+        // one workgroup, one round per box that is still alive when its turn comes, each round a sweep over the boxes behind
+        // it (16-byte AABB reads; position-indexed state in global scratch above kSoftLds boxes): ~n rounds of ~n / 50 us --
+        // 100 k boxes with most of them alive take seconds (the reference's loop, nms.cpp:60-94: n^2 / 2 clips and an
+        // insertion pass that is itself quadratic per round).  No size limit of its own (nms.cpp has none)
+        if (n >= (1ll << 31) - 64) return D3D_ERR_BAD_ARG;
         const bool rot = iou_type == D3D_IOU_RBOX;
         if (dtype == D3D_F64)
             return rot ? softnms_typed<double, true>((const double *)boxes, (const double *)scores, order, n, suppression_type,

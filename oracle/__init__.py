@@ -368,6 +368,30 @@ def box2d_nms_hard_candidates(boxes, scores, iou_method="rbox", iou_threshold=0.
     return ~sup.astype(bool)
 
 
+def box2d_nms_soft_candidates(boxes, scores, iou_method="rbox", supression_method="linear", iou_threshold=0.0,
+                              score_threshold=0.0, supression_param=1.0):
+    """box2d_nms(..., supression_method="linear" | "gaussian") with the rescaling loop of nms.cpp:41-72 visiting only the pairs
+    whose bounding boxes touch: the same KEEP mask (tested against the literal loop), affordable beyond 65 k boxes"""
+    assert iou_threshold >= 0
+    boxes = np.ascontiguousarray(boxes, dtype=np.float64)
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    n = len(boxes)
+    it, st = IOU_TYPE[iou_method.upper()], SUPRESSION[supression_method.upper()]
+    assert st in (1, 2)
+    a, b = aabb_candidate_pairs(boxes)            # ordered pairs, both directions (positions change during the run)
+    o = np.argsort(a, kind="stable")
+    a, b = a[o], np.ascontiguousarray(b[o])
+    off = np.zeros((n + 1,), np.int64)
+    np.cumsum(np.bincount(a, minlength=n), out=off[1:])
+    order = np.argsort(-scores, kind="stable").astype(np.int64)
+    sup = np.zeros((n,), np.uint8)
+    f = lib().oracle_nms2d_soft_candidates_f64
+    f.restype = None
+    f(_p(boxes), _p(scores), ctypes.c_int64(n), _p(order), _p(off), _p(b), ctypes.c_int(it), ctypes.c_int(st),
+      ctypes.c_float(iou_threshold), ctypes.c_float(score_threshold), ctypes.c_float(supression_param), _p(sup))
+    return ~sup.astype(bool)
+
+
 def box2d_nms(boxes, scores, iou_method="box", supression_method="hard",
               iou_threshold=0, score_threshold=0, supression_param=0, precise=True):
     """box/__init__.py:226-276: returns the KEEP mask."""

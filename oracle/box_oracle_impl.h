@@ -387,6 +387,56 @@ void FN(oracle_nms2d)(const T *boxes, const T *scores_in, int64_t n_, const int6
     free(scores); free(order);
 }
 
+/* Soft NMS of oracle_nms2d (nms.cpp:60-94) with the inner loop restricted to candidate pairs: a pair whose bounding boxes do
+ * not even touch has IoU 0, which never exceeds a threshold >= 0, so rescaling only the neighbours of i that stand at a later
+ * position gives the SAME scores, order and suppressed mask -- the updates of different j are independent of each other.
+ * The insertion pass is the literal one (O(n) per round: plain integer work, seconds at 100 k boxes); pos[] follows the
+ * boxes through it.  Equality with oracle_nms2d is itself tested (tests/test_oracle_box.py). */
+void FN(oracle_nms2d_soft_candidates)(const T *boxes, const T *scores_in, int64_t n_, const int64_t *order_in,
+                                      const int64_t *nbr_off, const int64_t *nbr, int method, int supp, float iou_threshold,
+                                      float score_threshold, float supp_param, uint8_t *suppressed)
+{
+    const int N = (int)n_;
+    T *scores = (T *)malloc(sizeof(T) * (size_t)(N > 0 ? N : 1));
+    int64_t *order = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
+    int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
+    for (int i = 0; i < N; i++) { scores[i] = scores_in[i]; order[i] = order_in[i]; suppressed[i] = 0; }
+    for (int p = 0; p < N; p++) pos[order[p]] = p;
+    for (int _i = N - 1; _i > 0; _i--) {                     /* nms.cpp:23-29 */
+        int i = (int)order[_i];
+        if (scores[i] > score_threshold) break;
+        suppressed[i] = 1;
+    }
+    for (int _i = 0; _i < N; _i++) {
+        int i = (int)order[_i];
+        if (suppressed[i]) break;                            /* nms.cpp:38 (soft) */
+        for (int64_t t = nbr_off[i]; t < nbr_off[i + 1]; t++) {
+            int j = (int)nbr[t];
+            if (pos[j] <= _i) continue;                      /* only the boxes at later positions (nms.cpp:41) */
+            T iou = FN(pair_iou)(boxes + (size_t)i * 5, boxes + (size_t)j * 5, method);
+            if (iou > iou_threshold) {
+                if (supp == 1) scores[j] *= 1 - POW(iou, supp_param);
+                else scores[j] *= EXP(-iou * iou / supp_param);
+                suppressed[j] = scores[j] < score_threshold;
+            }
+        }
+        int S = N - 1;                                       /* nms.cpp:74-94 */
+        while (S > _i && !suppressed[order[S]]) S--;
+        for (int _j = S - 1; _j > _i; _j--) {
+            int j = (int)order[_j];
+            int _k = _j + 1;
+            while (_k < S && (suppressed[j] || scores[order[_k]] > scores[j])) {
+                order[_k - 1] = order[_k];
+                pos[order[_k - 1]] = _k - 1;
+                _k++;
+            }
+            order[_k - 1] = j;
+            pos[j] = _k - 1;
+        }
+    }
+    free(scores); free(order); free(pos);
+}
+
 /* Hard NMS of oracle_nms2d restricted to candidate pairs: the inner loop of nms.cpp:41-58 visits every later box j, but a
  * pair whose bounding boxes do not even touch has IoU 0, which never exceeds a threshold >= 0 -- so visiting only the
  * neighbours of i (CSR adjacency nbr_off / nbr from a CPU AABB sweep, any order) gives the SAME suppressed mask.  Lets a

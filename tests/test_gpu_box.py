@@ -427,6 +427,31 @@ def test_softnms_reference_case_and_fp32():
     assert np.mean(keep == exp) > 0.995          # fp32 powf / expf may differ from libm in the last ulp
 
 
+def test_softnms_beyond_65536_boxes():
+    """soft-NMS has no size limit (nms.cpp:60-94 has none): 70 000 boxes, position-indexed state in global scratch.  5000 boxes
+    score above the threshold, 65 000 below it -- those are suppressed before the loop starts (nms.cpp:23-29), are never
+    processed (a suppressed box ends the loop, :38) and only sink; so the keep mask of the 5000 must be that of the 5000 on
+    their own plus ONE low box (which gives the insertion pass the same extent, :75), from the literal loop restricted to
+    touching pairs (equal to the literal loop: tests/test_oracle_box.py)."""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms
+    rng = np.random.default_rng(77)
+    b, _ = synth.boxes2d_sparse(70000, 31)
+    s = np.concatenate([0.5 + 0.5 * rng.random(5000), 0.3 * rng.random(65000)])
+    perm = rng.permutation(70000)
+    b, s = np.ascontiguousarray(b[perm]), np.ascontiguousarray(s[perm])
+    top = np.flatnonzero(s >= 0.5)
+    low = int(np.flatnonzero(s < 0.5)[np.argmax(s[s < 0.5])])                 # the best of the low boxes: first behind the 5000
+    sub = np.concatenate([top, [low]])
+    for method, sup, param in (("rbox", "linear", 1.0), ("box", "gaussian", 0.5)):
+        keep = box2d_nms(T(b), T(s), iou_method=method, supression_method=sup, iou_threshold=0.05, score_threshold=0.4,
+                         supression_param=param).cpu().numpy()
+        exp = oracle.box2d_nms_soft_candidates(b[sub], s[sub], method, sup, 0.05, 0.4, param)
+        assert not keep[s < 0.5].any()
+        assert np.array_equal(keep[top], exp[:-1]) and not exp[-1]
+        assert 1000 < keep.sum() < 5000
+
+
 def test_nms_fp32_scores_sorted_narrow():
     """fp32 scores (precise=True promotes them to fp64): the argsort runs on the fp32 keys -- same keep mask, ties included"""
     from d3d_amd.box import box2d_nms

@@ -243,3 +243,17 @@ def test_row_wise_association_equals_the_pair_loop():
     sm, dm = oracle.score_match_rows(cache, dt, g9, thr)
     assert {i: int(j) for i, j in enumerate(sm) if j >= 0} == sa and {j: int(i) for j, i in enumerate(dm) if i >= 0} == da
     assert 10 < len(sa) < len(g9)
+
+
+@pytest.mark.parametrize("sup,thr,sthr,param", [("linear", 0.1, 0.3, 1.0), ("gaussian", 0.0, 0.2, 0.5), ("linear", 0.3, 0.0, 2.0)])
+def test_soft_nms_over_candidate_pairs_equals_the_literal_loop(sup, thr, sthr, param):
+    """oracle.box2d_nms_soft_candidates (rescaling only the neighbours whose bounding boxes touch) == the literal restatement
+    of nms.cpp:60-94: what lets a GPU test check soft-NMS beyond 65 536 boxes"""
+    from d3d_amd import synth
+    for n, gen in ((300, synth.boxes2d_dense), (1200, synth.boxes2d_sparse)):
+        b, s = gen(n, 3)
+        for method in ("rbox", "box"):
+            a = oracle.box2d_nms(b, s, iou_method=method, supression_method=sup, iou_threshold=thr, score_threshold=sthr,
+                                 supression_param=param)
+            c = oracle.box2d_nms_soft_candidates(b, s, method, sup, thr, sthr, param)
+            assert np.array_equal(a, c)
