@@ -417,6 +417,7 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (RCCL) path even with one rank")
     ap.add_argument("--skip-large", action="store_true", help="skip the 8 M-point beyond-cache roofline leg")
     ap.add_argument("--large-only", action="store_true", help="run only that leg and print it (rocprofv3 --pmc passes)")
+    ap.add_argument("--sparse-only", action="store_true", help="run only config 2's sparse + trim operator (rocprofv3 --pmc passes)")
     ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port when bench.py launches the ranks itself")
     args = ap.parse_args()
 
@@ -439,6 +440,12 @@ def main():
     torch.cuda.set_device(local_rank)
     if args.large_only:
         print(json.dumps({"roofline_large": large_frame_leg()}))
+        return
+    if args.sparse_only:
+        cloud = torch.from_numpy(synth.lidar_like(args.points, 0)).cuda()
+        gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, max_points=32, max_points_filter="trim")
+        dt = timed(lambda: gen(cloud), args.steps, args.warmup)
+        print(json.dumps({"sparse_trim_ms_per_step": round(1e3 * dt / args.steps, 4)}))
         return
     barrier = None
     sharded = world > 1 or args.force_sharded

@@ -12,6 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --skip-cpu --skip-large > $out/bench_prof.json 2> $out/prof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_large -o large -- python3 $GRAFT_REPO_ROOT/bench.py --large-only > $out/large_prof.json 2> $out/prof_large.err
 for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${c}_sparse -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --sparse-only --steps 5 --warmup 2 > /dev/null 2> $out/pmc_${c}_sparse.err
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${c}_cfg2 -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --skip-cpu --skip-extra --skip-large --steps 5 --warmup 2 > /dev/null 2> $out/pmc_${c}_cfg2.err
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${c}_large -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --large-only > /dev/null 2> $out/pmc_${c}_large.err
 done

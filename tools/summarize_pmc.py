@@ -26,7 +26,7 @@ def short(name):
         return name[:60]
     base, targs = m.group(1), m.group(2) or ""
     if base.startswith("k_scan_"):
-        f = re.search(r"(NumberVoxels|FilterVoxels|FilterPoints|PopcountWords)", targs)
+        f = re.search(r"(NumberVoxels|FilterVoxels|FilterPoints|PopcountWords|MergeRecords|FirstWords)", targs)
         return "%s<%s>" % (base, f.group(1)) if f else base
     return "k_fill_c4" if base == "k_fill_c4_rows" else base       # (one kernel of the op, two forms: bench.py's name)
 
@@ -62,6 +62,8 @@ def main():
         f.write("kernel,launches,FETCH_SIZE_KiB_raw_avg,WRITE_SIZE_KiB_avg,fetch_bytes_corrected_x2,write_bytes,hbm_bytes_per_launch\n")
         for r in sorted(rows, key=lambda r: -r[6]):
             f.write("%s,%d,%.1f,%.1f,%.0f,%.0f,%.0f\n" % r)
+    if workload.endswith("_sparse"):       # every kernel of the operator runs once per step: the operator's traffic per step
+        traffic["sparse_op_total"] = int(sum(v for k, v in traffic.items()))
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     allt = json.load(open(tj)) if os.path.exists(tj) else {}
     allt[workload] = traffic
