@@ -549,28 +549,40 @@ __device__ __forceinline__ unsigned int scan_ticket(unsigned int *ticket, unsign
     __syncthreads();
     return *sid;
 }
-constexpr unsigned int kChainSpins = 1u << 22;
+// A predecessor holds a lower ticket, i.e. it is running and publishes within microseconds; kChainSpins polls (~0.1 s) without
+// its word turning up means something is wrong (a lost store, a preempted queue): the scan GIVES UP -- *gave_up is raised (the
+// caller's device flag: the dense path then recomputes everything) and the returned prefix is void: *sbase = ~0, callers must
+// not store anything that depends on it.  After the first give-up the wavefront stops polling altogether (the remaining words
+// would each cost another kChainSpins).  withhold (test hook, D3D_NMS_TEST_WITHHOLD): ticket 0 does not publish.
+constexpr unsigned int kChainSpins = 1u << 18;
+constexpr unsigned long long kChainVoid = ~0ull;
 __device__ __forceinline__ unsigned long long chained_prefix(unsigned long long *tot, unsigned int id, unsigned long long total,
-                                                             unsigned long long *sbase, unsigned int *gave_up)
+                                                             unsigned long long *sbase, unsigned int *gave_up, bool withhold = false)
 {
     const unsigned int lane = threadIdx.x & 63;
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0 && !(withhold && id == 0))
         __hip_atomic_store(&tot[id], (total << 1) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < 64) {
         unsigned long long acc = 0;
-        for (unsigned int j0 = 0; j0 < id; j0 += 64) {
+        bool dead = false;
+        for (unsigned int j0 = 0; j0 < id && !dead; j0 += 64) {
             const unsigned int j = j0 + lane;
+            bool mine_dead = false;
             if (j < id) {
                 unsigned long long t;
                 unsigned int spins = 0;
                 do { t = __hip_atomic_load(&tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(t & 1ull) && ++spins < kChainSpins);
-                if (!(t & 1ull)) { t = 0; *gave_up = 1; }
+                if (!(t & 1ull)) { t = 0; mine_dead = true; }
                 acc += t >> 1;
             }
+            dead = __any(mine_dead);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) *sbase = acc;
+        if (lane == 0) {
+            *sbase = dead ? kChainVoid : acc;
+            if (dead) *gave_up = 1;
+        }
     }
     __syncthreads();
     return *sbase;
@@ -852,7 +864,8 @@ __global__ __launch_bounds__(256) void k_nms_gridreg(const float4 *__restrict__ 
 // counters are 64 KB of strided reads per workgroup; ONE workgroup reading all 4 MB took 11 us) + chained_prefix across
 // the workgroups (chunk_tot[] zeroed by k_nms_prepare)
 __global__ __launch_bounds__(1024) void k_nms_gridscan(uint32_t *cellcur, uint32_t *cellstart, NmsGrid *grid, unsigned long long cap_e,
-                                                       NmsFlags *flags, unsigned long long *chunk_tot, unsigned int *ticket)
+                                                       NmsFlags *flags, unsigned long long *chunk_tot, unsigned int *ticket,
+                                                       bool withhold)
 {
     __shared__ unsigned long long smem[1024 / kWave], sbase;
     __shared__ unsigned int sid;
@@ -863,7 +876,12 @@ __global__ __launch_bounds__(1024) void k_nms_gridscan(uint32_t *cellcur, uint32
     const uint32_t x = c < cells ? cellcur[(size_t)c * kGridPad] : 0u;
     unsigned long long total;
     const unsigned long long ex = block_excl_scan_u64<1024>(x, &total, smem);
-    const unsigned long long before = chained_prefix(chunk_tot, (unsigned int)chunk, total, &sbase, &flags->need_sweep);
+    const unsigned long long before = chained_prefix(chunk_tot, (unsigned int)chunk, total, &sbase, &flags->need_sweep, withhold);
+    if (before == kChainVoid) {                             // gave up: the dense path takes over; leave an EMPTY grid behind so that
+        if (c <= cells) { cellstart[c] = 0; cellcur[(size_t)c * kGridPad] = 0; }      // the launches in between find nothing to do
+        if (c == cells) grid->entries = 0;
+        return;
+    }
     if (c <= cells) { cellstart[c] = (uint32_t)(before + ex); cellcur[(size_t)c * kGridPad] = (uint32_t)(before + ex); }
     if (c == cells) {
         const unsigned long long tot = before + ex;
@@ -1011,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxCore<T> *__restrict__
 // inc_off = exclusive scan of inc_cnt in ONE launch (the generic count / block-sum / apply trio is three, ~4 us each in a
 // stream): a local scan per 1024-box tile + chained_prefix over the tiles (tile_tot[] is zeroed by k_nms_prepare)
 __global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict__ inc_cnt, int64_t n, uint32_t *__restrict__ inc_off,
-                                                     unsigned long long *tile_tot, unsigned int *ticket, NmsFlags *flags)
+                                                     unsigned long long *tile_tot, unsigned int *ticket, NmsFlags *flags, bool withhold)
 {
     __shared__ unsigned long long smem[4], sbase;
     __shared__ unsigned int sid;
@@ -1032,7 +1050,8 @@ __global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict_
     unsigned long long woff = 0, total = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { if (k < w) woff += smem[k]; total += smem[k]; }
-    const unsigned long long before = chained_prefix(tile_tot, tile, total, &sbase, &flags->need_sweep);
+    const unsigned long long before = chained_prefix(tile_tot, tile, total, &sbase, &flags->need_sweep, withhold);
+    if (before == kChainVoid) return;                       // gave up: nothing that depends on the prefix is stored
     const unsigned long long off = before + woff;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1574,7 +1593,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
         D3D_LAUNCH("k_nms_gridreg<count>", k_nms_gridreg<false>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
                    cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, fold_inline ? nbl : 0u);
         D3D_LAUNCH("k_nms_gridscan", k_nms_gridscan, dim3(kGridScanWgs), dim3(1024), 0, st, cellcur, cellstart, grid, cap_e, flags,
-                   chunk_tot, tickets + 1);
+                   chunk_tot, tickets + 1, (opts & D3D_NMS_TEST_WITHHOLD) != 0 && (opts & D3D_NMS_BROAD_SWEEP) == 0);
         D3D_LAUNCH("k_nms_gridreg<place>", k_nms_gridreg<true>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
                    cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, 0u);
         D3D_LAUNCH("k_nms_cand_grid", k_nms_cand_grid, dim3((unsigned)d3d_divup((int64_t)cap_e, 256)), dim3(256), 0, st,
@@ -1598,7 +1617,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
         D3D_LAUNCH("k_nms_hits", (k_nms_hits<T, false>), dim3(hits_blocks), dim3(256), 0, st, geom, rankx, cand, cap, cand_hdr,
                    (T)iou_thr, inc_cnt, arrival);
     D3D_LAUNCH("k_nms_incscan", k_nms_incscan, dim3((unsigned)d3d_divup(n, kIncTile)), dim3(256), 0, st, (const uint32_t *)inc_cnt, n,
-               inc_off, tile_tot, tickets, flags);
+               inc_off, tile_tot, tickets, flags, (opts & D3D_NMS_TEST_WITHHOLD) != 0 && (opts & D3D_NMS_BROAD_SWEEP) != 0);
     D3D_LAUNCH("k_nms_fill", k_nms_fill, dim3(hits_blocks), dim3(256), 0, st, (const unsigned long long *)cand, cap,
                (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, (const uint32_t *)arrival, inc);
     D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,
@@ -2041,7 +2060,7 @@ extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *o
                          void *stream, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL))) return D3D_ERR_BAD_ARG;
+    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL | D3D_NMS_TEST_WITHHOLD))) return D3D_ERR_BAD_ARG;
     if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;   // common.h:25
     if (suppression_type != D3D_SUPPRESS_HARD && suppression_type != D3D_SUPPRESS_LINEAR &&

@@ -437,14 +437,17 @@ size_t d3d_nms2d_workspace_bytes(int64_t n);
  *   HARD: parallel (broad phase + exact IoU + fixed point, see box.hip); sets of up to 4096 boxes (a detector's top-k) take
  *   a five-launch path of their own unless a flag below names a general one.  LINEAR / GAUSSIAN (soft-NMS, nms.cpp:60-94)
  *   are sequential by construction -- every kept box rescales the later boxes it overlaps and the order is re-established
- *   after each -- and run in one workgroup that follows the reference's control flow (n <= 65536, else UNSUPPORTED).
+ *   after each -- and run in one workgroup that follows the reference's control flow.
  *   Other IoU types return D3D_ERR_UNSUPPORTED ("Unsupported iou type!", reference common.h:25).
  *   flags (per call, 0 = automatic): D3D_NMS_BROAD_SWEEP = sweep-and-prune broad phase instead of the uniform grid;
  *   D3D_NMS_FORCE_DENSE = the reference's all-pairs bit matrix (nms_cuda.cu layout) instead of candidate lists;
  *   D3D_NMS_SOFT_NO_LDS = soft-NMS state in global scratch; D3D_NMS_CAND_CAP(k) = use only k entries of the candidate
  *   list (tests of the overflow -> dense hand-over); D3D_NMS_GENERAL = the general path (uniform grid) also for sets of up to
- *   4096 boxes.  All give the same mask. */
-enum { D3D_NMS_BROAD_SWEEP = 1, D3D_NMS_FORCE_DENSE = 2, D3D_NMS_SOFT_NO_LDS = 4, D3D_NMS_GENERAL = 8 };
+ *   4096 boxes; D3D_NMS_TEST_WITHHOLD = test hook: the first workgroup of a one-launch scan (the grid's cell scan; with
+ *   D3D_NMS_BROAD_SWEEP the scan of the incoming-list sizes) withholds its total, so the scan gives up after ~0.1 s and hands
+ *   the call to the dense path.  All give the same mask.
+ *   soft-NMS has no size limit of its own (100 k boxes with most of them alive: seconds). */
+enum { D3D_NMS_BROAD_SWEEP = 1, D3D_NMS_FORCE_DENSE = 2, D3D_NMS_SOFT_NO_LDS = 4, D3D_NMS_GENERAL = 8, D3D_NMS_TEST_WITHHOLD = 16 };
 #define D3D_NMS_CAND_CAP(k) ((uint32_t)(k) << 8)
 int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n,
               int32_t iou_type, int32_t suppression_type, int32_t dtype,

@@ -177,6 +177,25 @@ def test_nms_dense_path_hooks(monkeypatch, hook, value, gen, n, thr):
     assert np.array_equal(keep, exp)
 
 
+@pytest.mark.parametrize("scan", ["grid cells", "incoming lists"])
+def test_nms_chained_scan_gives_up_and_hands_over(monkeypatch, scan):
+    """the one-launch scans poll their predecessors' totals; a predecessor that never publishes (test hook: ticket 0
+    withholds) makes every later workgroup give up after ~0.1 s, nothing that depends on the void prefix is stored, and the
+    dense path recomputes the call: same keep mask.  Both scans: the grid's cell scan, the scan of the incoming-list sizes."""
+    from d3d_amd import _lib, box, synth
+    from d3d_amd.box import box2d_nms
+    b, s = synth.boxes2d_sparse(6000, 81)
+    exp = oracle.box2d_nms_hard_candidates(b, s, "rbox", 0.3, 0.1)
+    hook = _lib.NMS_TEST_WITHHOLD | (_lib.NMS_GENERAL if scan == "grid cells" else _lib.NMS_BROAD_SWEEP)
+    monkeypatch.setattr(box, "default_nms_flags", hook)
+    for _ in range(2):
+        keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3, score_threshold=0.1).cpu().numpy()
+        assert np.array_equal(keep, exp)
+    monkeypatch.setattr(box, "default_nms_flags", hook & ~_lib.NMS_TEST_WITHHOLD)         # and the next call is healthy again
+    keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3, score_threshold=0.1).cpu().numpy()
+    assert np.array_equal(keep, exp)
+
+
 @pytest.mark.parametrize("n", [128, 3000])
 def test_nms_sweep_and_prune_edge_geometry(n):
     """broad phases (uniform grid / sort by AABB xmin + walk): negative coordinates, many identical xmin, boxes spanning the
