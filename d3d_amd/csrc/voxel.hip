@@ -1048,7 +1048,7 @@ struct BinnedExtras {
     int64_t index_offset;
     int64_t *keys_out;        // [V] cell key; row status_row = -1 - status bits
     int64_t status_row;
-    uint32_t *vidof;          // [records] voxel id of a record (for the point -> voxel map)
+    uint32_t *vidof;          // [npad] voxel id of the voxel whose first point is i, kNoVoxel elsewhere (for the point -> voxel map)
     int64_t *host_counts;     // optional host-mapped copy of counts[] + ready flag (d3d_voxelize_3d_dense_notify)
     uint32_t npoints_clamp = 0xffffffffu;
     uint32_t *voff = nullptr; // [V] segment base (dense contract, C != 4: k_aggregate reads the index lists through it)
@@ -1206,10 +1206,11 @@ __device__ __forceinline__ void bucket_bases(const uint32_t *__restrict__ totals
 // {cell key, point index} to the bucket: position = base of the bucket + offset of the tile + arrival in the tile
 template <bool ROWS>
 __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinEntry<ROWS>::key_store_t *__restrict__ pkey, int64_t n,
-                                                             uint32_t nbins, const uint32_t *__restrict__ pbin,
+                                                             uint32_t nbins, uint32_t *pbin,
                                                              const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ totals,
                                                              uint32_t *__restrict__ bucket_base,
-                                                             typename BinEntry<ROWS>::type *__restrict__ bent, int64_t *counts)
+                                                             typename BinEntry<ROWS>::type *__restrict__ bent, int64_t *counts,
+                                                             bool keep_pos /* pbin[i] := the point's place in the buckets (kInf: none) */)
 {
     __shared__ uint32_t off[kBinMax];
     __shared__ u64 smem[kBinThreads / kWave];
@@ -1226,8 +1227,13 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
         if (i >= n) break;
         const uint32_t word = pbin[i];
         if (word == kBadBin) bad = true;
-        if (word >= kBadBin) continue;
-        bent[off[word & (kBinMax - 1)] + (word >> kBinBits)] = BinEntry<ROWS>::pack((u64)pkey[i], (uint32_t)i);
+        if (word >= kBadBin) {
+            if (keep_pos) pbin[i] = kInf;
+            continue;
+        }
+        const uint32_t pos = off[word & (kBinMax - 1)] + (word >> kBinBits);
+        bent[pos] = BinEntry<ROWS>::pack((u64)pkey[i], (uint32_t)i);
+        if (keep_pos) pbin[i] = pos;            // (same lane read it: in place)
     }
     if (bad) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_COORD_OVERFLOW);
 }
@@ -1278,14 +1284,14 @@ __device__ __forceinline__ u64 block_excl_scan_u64_lds(u64 v, u64 *total, u64 *s
 // two-launch output stage.  ROWS && LISTS && !STAGE is the index for k_emit: no row moves here at all -- a voxel's first
 // row is points[first point], which k_emit reads coalesced, and ranks 1 .. P-1 leave their point INDEX in sorted_out.
 template <class Key, bool ROWS, bool LISTS, bool STAGE = ROWS>
-__global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPass vp, uint32_t *__restrict__ vidof,
+__global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPass vp,
                                                       const typename BinEntry<ROWS>::type *__restrict__ bent,
                                                       const float4 *__restrict__ points4 /* ROWS */,
                                                       const uint32_t *__restrict__ bucket_base,
                                                       int hshift, uint32_t P, int reduction /* NONE: no aggregates */,
                                                       float4 *__restrict__ staged, uint4 *__restrict__ vrec,
                                                       uint32_t *__restrict__ firstmap, int64_t *counts,
-                                                      uint32_t *__restrict__ precpos /* optional: record of every point */,
+                                                      uint32_t *__restrict__ precpos /* optional: per bucket entry, the FIRST point of its voxel */,
                                                       uint32_t *__restrict__ pinfo, uint32_t *__restrict__ gseg /* big buckets */,
                                                       unsigned char *__restrict__ trimmed /* optional: [n] rank >= P */,
                                                       uint32_t *__restrict__ sorted_out /* optional: ranked indices (C != 4) */,
@@ -1337,13 +1343,12 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                     kf.decode(kk, cc);
                     pass = (int32_t)c[k] >= vp.min_points && cc[0] >= vp.lo[0] && cc[0] < vp.hi[0] && cc[1] >= vp.lo[1] &&
                            cc[1] < vp.hi[1] && cc[2] >= vp.lo[2] && cc[2] < vp.hi[2];
-                    vidof[bb + j] = kNoVoxel;       // k_meta_first overwrites it for the voxels that get an id
                 }
-                // (an atomic store on purpose: with two plain conditional stores next to each other -- vidof[bb + j] above and
-                // this one -- hipcc 7.2 emitted, in one code shape of this kernel, a merged store that wrote the value bb + j
-                // at firstmap[bb + j], i.e. the other store's index; found by the big-bucket tests)
+                // (an atomic store on purpose: with two plain conditional stores next to each other -- a second one at index
+                // bb + j used to sit above this one -- hipcc 7.2 emitted, in one code shape of this kernel, a merged store that
+                // wrote the value bb + j at firstmap[bb + j], i.e. the other store's index; found by the big-bucket tests, see
+                // DESIGN.md 4a)
                 if (pass) __hip_atomic_store(&firstmap[f], bb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tfirst[s0 + k] = bb + j;            // from here on: the slot's record
                 j++;
                 if constexpr (ROWS)
                     if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
@@ -1591,12 +1596,11 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
     const uint32_t e = firstmap[i];
     const unsigned long long bal = __ballot(e != kInf);
     uint32_t kept = 0;                                      // points this lane's voxel keeps (fused sparse + filter)
+    uint32_t myvid = kNoVoxel;
     if (e != kInf) {
         const uint32_t vid = before + fwpre[i >> 6] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (vid >= max_voxels) {                            // voxelize.cpp:116-117: later voxels are never created
-            if (x.vidof) x.vidof[e] = kNoVoxel;
-        } else {
-            if (x.vidof) x.vidof[e] = vid;
+        if (vid < max_voxels) {                             // voxelize.cpp:116-117: later voxels are never created
+            myvid = vid;
             if (x.first_out) x.first_out[vid] = x.index_offset + i;
             const uint4 rec = vrec[e];
             const uint4 vi = rec;                           // {key lo, key hi, segment base, count}
@@ -1606,6 +1610,7 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
                                   x.keys_out, x.npoints_clamp);
         }
     }
+    if (x.vidof) x.vidof[i] = myvid;                        // every lane: one coalesced store (the map looks it up by first point)
     if (x.kept_part) {                                      // sum over the workgroup -> k_publish_kept adds the workgroups up
         __shared__ uint32_t wsum[256 / kWave];
 #pragma unroll
@@ -1832,8 +1837,8 @@ __global__ __launch_bounds__(1024) void k_publish_kept(const uint32_t *__restric
     }
 }
 
-// point -> voxel id, from bucket order: the record of every point was left by k_bucket_index, the id of every record by
-// k_meta_first (a bucket's points refer to the bucket's own stretch of records: the gather stays local)
+// point -> voxel id, from bucket order: k_bucket_index left the first point of every entry's voxel, k_meta_first the id of the
+// voxel that starts at a point index
 __global__ __launch_bounds__(256) void k_map_binned(const uint32_t *__restrict__ bucket_base, uint32_t nbins,
                                                     const uint32_t *__restrict__ precpos, const uint32_t *__restrict__ ent32,
                                                     int idx_stride, int idx_off, const uint32_t *__restrict__ vidof,
@@ -1953,11 +1958,10 @@ struct FilterPoints {
     bool precomputed = false; // keepid was filled by the fused sparse index (k_map_binned)
     bool vec4 = false;        // c == 4 and 16-byte aligned rows: one float4 copy per kept point
     // fused sparse + filter on the binned index: the count pass finds every point's filtered voxel id ITSELF, in point order --
-    // the point's place in its bucket is base of the bucket + offset of the tile + arrival number (as k_bin_scatter computed
-    // it), there the record of its voxel, there the voxel's id (k_meta_first) -- instead of a pass over the buckets that
-    // scatters the ids to the points (k_map_binned)
-    const uint32_t *pbin = nullptr, *bucket_base = nullptr, *tileoff = nullptr, *precpos = nullptr, *vidof = nullptr;
-    uint32_t nbins = 0;
+    // the point's place in the buckets (k_bin_scatter left it in pbin: one coalesced load), there the record of its voxel,
+    // there the voxel's id (k_meta_first) -- instead of a pass over the buckets that scatters the ids to the points
+    // (k_map_binned)
+    const uint32_t *pbin = nullptr, *precpos = nullptr, *vidof = nullptr;
     __device__ __forceinline__ int32_t keep(int64_t i) const
     {
         const int64_t v = mapping[i];
@@ -1971,11 +1975,9 @@ struct FilterPoints {
     __device__ __forceinline__ unsigned long long value(int64_t i) const
     {
         if (pbin) {
-            const uint32_t word = pbin[i];
+            const uint32_t p = pbin[i];
             int32_t id = -1;
-            if (word < kBadBin) {                  // kBadBin / kNoBin: the point lies in no voxel
-                const uint32_t b = word & (kBinMax - 1), arr = word >> kBinBits;
-                const uint32_t p = bucket_base[b] + tileoff[(size_t)(i / kBinTile) * nbins + b] + arr;
+            if (p != kInf) {                       // kInf: the point lies in no voxel
                 const uint32_t e = precpos[p];
                 const uint32_t vid = e == kInf ? kNoVoxel : vidof[e];
                 if (vid != kNoVoxel && !(trimmed && trimmed[i])) id = (int32_t)vid;
@@ -2246,18 +2248,18 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
                    ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
     D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, pkey, n, nbins, pbin, tilecnt, totals,
-               bucket_base, bent, counts);
+               bucket_base, bent, counts, o.map_later);
     if (!ROWS && o.lists)
-        D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass, x.vidof,
+        D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    reinterpret_cast<const typename BinEntry<false>::type *>(bent), p4, bucket_base, hshift, o.P, (int)D3D_REDUCE_NONE,
                    w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
                    o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr);
     else if (ROWS && o.emit_voxels)
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, true, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
-                   x.vidof, bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
+                   bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
                    counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.unsorted, (uint32_t *)nullptr);
     else
-        D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass, x.vidof,
+        D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
                    precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 512 (n <= 8 M)
@@ -2731,8 +2733,7 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                 FilterPoints fp{points, c, nullptr, 0, nullptr, nullptr, d.trimmed, 0xffffffffu, d.keepid, out_feats, out_mask,
                                 out_mapping, true,
                                 c == 4 && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out_feats)) & 15) == 0};
-                fp.pbin = w.pslot; fp.bucket_base = w.vidarr; fp.tileoff = reinterpret_cast<const uint32_t *>(w.tabB);
-                fp.precpos = w.unsorted; fp.vidof = w.voff; fp.nbins = nbins;
+                fp.pbin = w.pslot; fp.precpos = w.unsorted; fp.vidof = w.voff;
                 // the sizes of both filtered outputs reach the host NOW, before the three launches of the compaction (a launch of
                 // its own: folded into the count pass's first workgroup the flag reached the host ~15 us later, 168 vs 153 us per call)
                 if (host_counts)
