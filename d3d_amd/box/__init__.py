@@ -460,12 +460,13 @@ class PDist2DR(torch.autograd.Function):
         return grad_points, grad_boxes
 
 
-def seg1d_iou(seg1, seg2):
+def seg1d_iou(seg1, seg2, reference_compat=False):
     """IoU of 1-D segments, row by row: seg1, seg2 [N,2] = (centre, width) -> [N] -- reference box/__init__.py:152-178 (plain
-    tensor arithmetic there too; its half-width of seg2 is taken from seg1, :164, a slip: seg2's own width is used here)"""
+    tensor arithmetic there too; its half-width of seg2 is taken from seg1, :164, a slip: seg2's own width is used here.
+    `reference_compat=True` reproduces the reference's values bit for bit -- INTEGRATION.md section 5)"""
     assert torch.all(seg1[:, 1] > 0)
     assert torch.all(seg2[:, 1] > 0)
-    d1, d2 = seg1[:, 1] / 2, seg2[:, 1] / 2
+    d1, d2 = seg1[:, 1] / 2, (seg1 if reference_compat else seg2)[:, 1] / 2
     s1max, s1min, s2max, s2min = seg1[:, 0] + d1, seg1[:, 0] - d1, seg2[:, 0] + d2, seg2[:, 0] - d2
     i = torch.clamp_min(torch.minimum(s1max, s2max) - torch.maximum(s1min, s2min), 0)
     u = torch.clamp_min(torch.maximum(s1max, s2max) - torch.minimum(s1min, s2min), 1e-6)

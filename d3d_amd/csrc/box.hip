@@ -181,12 +181,22 @@ __global__ __launch_bounds__(256) void k_geom(const T *__restrict__ boxes, int64
 constexpr int kPreK = 4;
 constexpr int kPreCols = kTileCols * kPreK;
 constexpr int kPreBatch = 1024;      // LDS batch entries per wavefront
+// rows per workgroup: kTileRows, fewer for matrices that would otherwise launch too few workgroups to fill 256 CUs
+// (5 k x 5 k at 64 rows: 395 workgroups = 1.5 wavefronts per SIMD, 81 us for 25 M tests + 200 MB)
+static inline int pre_tile_rows(int64_t n, int64_t m)
+{
+    int rows = kTileRows;
+    int64_t wgs = d3d_divup(m, (int64_t)kPreCols) * d3d_divup(n, (int64_t)rows);
+    while (rows > 8 && wgs < 2048) { rows >>= 1; wgs = d3d_divup(m, (int64_t)kPreCols) * d3d_divup(n, (int64_t)rows); }
+    return rows;
+}
 
 template <typename T>
 __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict__ ra, int64_t n,
                                                        const float4 *__restrict__ cb, int64_t m, T *__restrict__ ious,
                                                        IouList *hdr, unsigned long long *list, unsigned long long cap,
-                                                       float fillv = 0.f /* T = float only: the matrix' background value */)
+                                                       float fillv = 0.f /* T = float only: the matrix' background value */,
+                                                       int tile_rows = kTileRows /* rows per workgroup, <= kTileRows */)
 {
     constexpr int K = kPreK;
     typedef float vec16 __attribute__((ext_vector_type(4)));
@@ -194,10 +204,10 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
     __shared__ unsigned int batch[kTileCols / 64][kPreBatch];   // (row << 16 | local column)
     __shared__ unsigned int wcnt[kTileCols / 64];
     __shared__ unsigned long long bbase;
-    const int64_t i0 = (int64_t)blockIdx.y * kTileRows;
+    const int64_t i0 = (int64_t)blockIdx.y * tile_rows;
     const int64_t jb = (int64_t)blockIdx.x * kPreCols;          // first column of the block
     const int64_t j0 = jb + (int64_t)threadIdx.x * K;
-    const int nrows = (int)((n - i0) < kTileRows ? (n - i0) : kTileRows);
+    const int nrows = (int)((n - i0) < tile_rows ? (n - i0) : tile_rows);
     if (threadIdx.x < nrows) rbox[threadIdx.x] = ra[i0 + threadIdx.x];
     float4 cbox[K];
 #pragma unroll
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
     const size_t G = (size_t)gridDim.x * gridDim.y, L = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     vec16 *slab = ious ? reinterpret_cast<vec16 *>(ious) : nullptr;
     const vec16 z = {fillv, fillv, fillv, fillv};
-    for (int r = 0; r < kTileRows; r++) {
+    for (int r = 0; r < tile_rows; r++) {
         if (r < nrows) {
             const float4 fa = rbox[r];                        // LDS broadcast
             float g[K], best = -1.f;
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
             }
         }
         if (slab)
-            for (size_t c = L + (size_t)r * G; c < nchunk; c += (size_t)kTileRows * G) {
+            for (size_t c = L + (size_t)r * G; c < nchunk; c += (size_t)tile_rows * G) {
                 const size_t v = c * kTileCols + threadIdx.x;
                 if (v < nvec) __builtin_nontemporal_store(z, slab + v);
             }
@@ -523,6 +533,8 @@ constexpr int kIncTile = 1024;      // boxes per workgroup of k_nms_incscan
 struct NmsFlags { unsigned int need_sweep, undecided; };
 constexpr int kNmsListSegs = 1;     // see list_segments(): segmenting the list did not pay
 struct NmsCand { unsigned long long count[kNmsListSegs * 16]; };   // entries appended (may exceed the capacity)
+constexpr int kHdrKill = 8;          // count[kHdrKill + level - 1]: entries of that level's kill list (k_nms_level_roots)
+constexpr int kHdrDensity = 12;      // count[kHdrDensity]: sum over the grid's cells of (registrations in the cell)^2
 
 // candidate-list capacity: ~8.5 upper-triangle AABB candidates per box for scattered boxes, half the
 // cluster size for detector output (clusters of overlapping boxes around every object); 512 per box = 0.6 GB at 100 k
@@ -595,6 +607,14 @@ constexpr float kGridCellScale = 2.f;  // cell size / mean AABB extent (4: scatt
 constexpr int kGridPad = 16;           // one cell counter per 64-byte line: atomics on neighbouring words serialise like
                                        // atomics on one word (gridreg 35 -> ? us with 5 k cells packed into 335 lines)
 struct NmsGrid { float ox, oy, inv_h; int gx, gy; unsigned int ticket, entries; };
+// the levels of the greedy result (k_nms_level_*, below) run when the grid is dense
+constexpr int kNmsLevels = 2;             // default number of levels (D3D_NMS_LEVELS(k) overrides per call)
+constexpr unsigned long long kNmsLevelDensity = 128;
+constexpr int kNmsLevelChunks = 3;      // k_nms_level_block: chunks of 64 partners a wavefront tests before it gives up
+__device__ __forceinline__ bool nms_levels_on(const NmsGrid &g, const NmsCand *hdr)
+{
+    return hdr->count[kHdrDensity] > kNmsLevelDensity * (unsigned long long)g.entries;
+}
 
 __device__ __forceinline__ int grid_cell(float x, float o, float inv_h, int g)
 {
@@ -651,7 +671,8 @@ __global__ __launch_bounds__(256) void k_nms_prepare(const T *__restrict__ boxes
                               BoxCore<T> *geom, float4 *fbox, uint8_t *state, uint32_t *inc_cnt, float *farea,
                               unsigned long long *remv, int64_t nb, NmsFlags *flags, NmsCand *cand_hdr,
                               unsigned int force_dense, int32_t *xkey, unsigned int *grid_ticket, unsigned long long *tile_tot,
-                              float *gpartial, uint32_t *cellcnt, unsigned long long *chunk_tot)
+                              float *gpartial, uint32_t *cellcnt, unsigned long long *chunk_tot, uint8_t *blocked,
+                              unsigned int force_levels)
 {
     __shared__ float sm[4][6];
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // sorted position
@@ -661,7 +682,8 @@ __global__ __launch_bounds__(256) void k_nms_prepare(const T *__restrict__ boxes
     for (int64_t i = p; i <= kGridCells; i += (int64_t)gridDim.x * blockDim.x) cellcnt[i * kGridPad] = 0;
     float ext[6] = {INFINITY, INFINITY, -INFINITY, -INFINITY, 0.f, 0.f};
     if (p == 0) { flags->need_sweep = force_dense; flags->undecided = 0; *grid_ticket = 0; }
-    if (p < kNmsListSegs) cand_hdr->count[p * 16] = 0;
+    // list counter(s), kill-list counters, density sum (kHdr*; D3D_NMS_FORCE_LEVELS: a density no grid reaches)
+    if (p < kNmsListSegs * 16) cand_hdr->count[p] = (p == kHdrDensity && force_levels) ? (1ull << 62) : 0ull;
     if (p * kIncTile < n) tile_tot[p] = 0;                   // k_nms_incscan's ready words
     if (p < kGridScanWgs + 1) chunk_tot[p] = 0;              // ... and k_nms_gridscan's; behind them the two tickets
     if (p < n) {
@@ -678,6 +700,7 @@ __global__ __launch_bounds__(256) void k_nms_prepare(const T *__restrict__ boxes
         pre = p > 0 && !(scores[i] > (T)score_threshold);
         state[p] = pre ? kSuppressed : kUndecided;
         inc_cnt[p] = 0;
+        blocked[p] = 0;                     // set by the broad phase for every box that has a better-ranked candidate partner
         farea[p] = round_down(g.area);      // (lower bound: for the IoU upper bound of the broad phase)
     }
     unsigned long long word = __ballot(pre);
@@ -832,15 +855,23 @@ __global__ __launch_bounds__(256) void k_nms_extent(const float *__restrict__ pa
 }
 
 // pass 1 (SCATTER = false): count the registrations per cell; pass 2: place them (cursor = scanned counts)
+constexpr int kEliteShift = 4;
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_nms_gridreg(const float4 *__restrict__ fbox, int64_t n, NmsGrid *grid, uint32_t *cellcur,
                                                      unsigned long long cap_e, uint32_t *__restrict__ cellbox,
                                                      uint32_t *__restrict__ cellof, float4 *__restrict__ fbc, NmsFlags *flags,
                                                      const float *__restrict__ farea, float *__restrict__ carea,
-                                                     const float *__restrict__ partial, unsigned int npart /* 0: *grid is ready */)
+                                                     const float *__restrict__ partial, unsigned int npart /* 0: *grid is ready */,
+                                                     const uint32_t *__restrict__ cellstart, const uint8_t *__restrict__ state,
+                                                     uint8_t *__restrict__ regopen, const NmsCand *hdr = nullptr,
+                                                     const uint8_t *__restrict__ blocked = nullptr, unsigned int levels = 0)
 {
     __shared__ float sm[4][6];
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // second registration (hdr != NULL), after the levels: only the boxes they left open, so that k_nms_cand_grid walks short
+    // lists; nothing happens unless the levels ran
+    if (hdr && !nms_levels_on(*grid, hdr)) return;
+    if (hdr && p < n && !(state[p] == kUndecided && blocked[p] == levels)) return;
     NmsGrid g;
     if (!SCATTER && npart) {
         g = fold_extents(partial, npart, sm);
@@ -855,8 +886,16 @@ __global__ __launch_bounds__(256) void k_nms_gridreg(const float4 *__restrict__ 
     for (int cy = cy0; cy <= cy1; cy++)
         for (int cx = cx0; cx <= cx1; cx++) {
             const uint32_t c = (uint32_t)(cy * g.gx + cx);
-            const uint32_t pos = atomicAdd(&cellcur[(size_t)c * kGridPad], 1u);
-            if (SCATTER && pos < cap_e) { cellbox[pos] = (uint32_t)p; cellof[pos] = c; fbc[pos] = f; carea[pos] = farea[p]; }
+            // placement: the best-ranked sixteenth of the boxes (kEliteShift) fills a cell's list from the front, everybody
+            // else from the back (a second cursor in the counter's padding).  A box then finds its better-ranked partners
+            // early in the list, and one of the front section finds ALL of them there (k_nms_level_block)
+            uint32_t pos;
+            if (!SCATTER || p < (n >> kEliteShift)) pos = atomicAdd(&cellcur[(size_t)c * kGridPad], 1u);
+            else pos = cellstart[c + 1] - 1u - atomicAdd(&cellcur[(size_t)c * kGridPad + 1], 1u);
+            if (SCATTER && pos < cap_e) {
+                cellbox[pos] = (uint32_t)p; cellof[pos] = c; fbc[pos] = f; carea[pos] = farea[p];
+                regopen[pos] = state[p] == kUndecided;      // (the score threshold's verdict: for level 1 of k_nms_level_block)
+            }
         }
 }
 
@@ -865,10 +904,13 @@ __global__ __launch_bounds__(256) void k_nms_gridreg(const float4 *__restrict__ 
 // the workgroups (chunk_tot[] zeroed by k_nms_prepare)
 __global__ __launch_bounds__(1024) void k_nms_gridscan(uint32_t *cellcur, uint32_t *cellstart, NmsGrid *grid, unsigned long long cap_e,
                                                        NmsFlags *flags, unsigned long long *chunk_tot, unsigned int *ticket,
-                                                       bool withhold)
+                                                       bool withhold, unsigned long long *density, const NmsCand *gate = nullptr)
 {
     __shared__ unsigned long long smem[1024 / kWave], sbase;
     __shared__ unsigned int sid;
+    // (second registration: runs only when the levels did.  Workgroups of this launch raise the density and lower the entries
+    // while others still test them -- both move the test further towards "on")
+    if (gate && !nms_levels_on(*grid, gate)) return;
     const int chunk = (int)scan_ticket(ticket, &sid);
     const int cells = grid->gx * grid->gy;                                      // entry `cells` = the total
     if (chunk * 1024 > cells) return;                                           // (nobody waits for a higher chunk)
@@ -876,13 +918,23 @@ __global__ __launch_bounds__(1024) void k_nms_gridscan(uint32_t *cellcur, uint32
     const uint32_t x = c < cells ? cellcur[(size_t)c * kGridPad] : 0u;
     unsigned long long total;
     const unsigned long long ex = block_excl_scan_u64<1024>(x, &total, smem);
+    {   // sum of squared list lengths: registrations x partners, what a walk over all pairs of the cells costs
+        unsigned long long sq = (unsigned long long)x * x;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0 && sq) atomicAdd(density, sq);
+    }
     const unsigned long long before = chained_prefix(chunk_tot, (unsigned int)chunk, total, &sbase, &flags->need_sweep, withhold);
     if (before == kChainVoid) {                             // gave up: the dense path takes over; leave an EMPTY grid behind so that
         if (c <= cells) { cellstart[c] = 0; cellcur[(size_t)c * kGridPad] = 0; }      // the launches in between find nothing to do
         if (c == cells) grid->entries = 0;
         return;
     }
-    if (c <= cells) { cellstart[c] = (uint32_t)(before + ex); cellcur[(size_t)c * kGridPad] = (uint32_t)(before + ex); }
+    if (c <= cells) {
+        cellstart[c] = (uint32_t)(before + ex);
+        cellcur[(size_t)c * kGridPad] = (uint32_t)(before + ex);
+        cellcur[(size_t)c * kGridPad + 1] = 0;              // the cell's back cursor (k_nms_gridreg<place>)
+    }
     if (c == cells) {
         const unsigned long long tot = before + ex;
         grid->entries = (unsigned int)(tot < cap_e ? tot : cap_e);
@@ -894,7 +946,10 @@ __global__ __launch_bounds__(1024) void k_nms_gridscan(uint32_t *cellcur, uint32
 __global__ __launch_bounds__(256) void k_nms_cand_grid(const float4 *__restrict__ fbc, const uint32_t *__restrict__ cellof,
                                                        const uint32_t *__restrict__ cellstart, const NmsGrid *grid,
                                                        unsigned long long *__restrict__ list, unsigned long long cap, NmsCand *hdr,
-                                                       NmsFlags *flags, const float *__restrict__ carea, float thr)
+                                                       NmsFlags *flags, const float *__restrict__ carea, float thr,
+                                                       const uint32_t *__restrict__ cellbox, const uint8_t *__restrict__ blocked,
+                                                       const uint8_t *__restrict__ state, unsigned int levels /* that were launched */,
+                                                       int *dense_hint /* host-mapped, optional */)
 {
     __shared__ unsigned long long batch[4][kCandLds];
     __shared__ float4 window[4][128 + 4];
@@ -904,7 +959,17 @@ __global__ __launch_bounds__(256) void k_nms_cand_grid(const float4 *__restrict_
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const NmsGrid g = *grid;
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    const bool live = e < g.entries;
+    // only the boxes the levels left open (undecided and blocked at the last level; level 0 = everybody when they did not
+    // run) take part, on either side
+    const unsigned int level = nms_levels_on(g, hdr) ? levels : 0u;
+    if (dense_hint && e == 0)                 // for the host's NEXT call: was this grid dense? (nms_dense_hint)
+        __hip_atomic_store(dense_hint, nms_levels_on(g, hdr) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    auto open = [&](uint32_t reg) {
+        const uint32_t r = cellbox[reg];
+        return state[r] == kUndecided && blocked[r] == level;
+    };
+    const bool live = e < g.entries && open(e);
+    if (__syncthreads_or(live) == 0) return;
     const float4 fa = live ? fbc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t c = live ? cellof[e] : 0u;
     const uint32_t end = live ? cellstart[c + 1] : 0u;
@@ -941,10 +1006,11 @@ __global__ __launch_bounds__(256) void k_nms_cand_grid(const float4 *__restrict_
     for (uint32_t ch = 0; !overflow; ch++) {
         const uint32_t base = e0 + ch * 64;                               // partner t = base + lane + d, d = 1..64
         if (__ballot(live && base + lane + 1 < end) == 0) break;
-        win[lane] = base + lane < nent ? fbc[base + lane] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
-        win[64 + lane] = base + 64 + lane < nent ? fbc[base + 64 + lane] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
-        awin[lane] = base + lane < nent ? carea[base + lane] : 0.f;
-        awin[64 + lane] = base + 64 + lane < nent ? carea[base + 64 + lane] : 0.f;
+        const bool in0 = base + lane < nent && open(base + lane), in1 = base + 64 + lane < nent && open(base + 64 + lane);
+        win[lane] = in0 ? fbc[base + lane] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+        win[64 + lane] = in1 ? fbc[base + 64 + lane] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+        awin[lane] = in0 ? carea[base + lane] : 0.f;
+        awin[64 + lane] = in1 ? carea[base + 64 + lane] : 0.f;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
         for (int d0 = 1; d0 <= 64; d0 += 4) {
@@ -994,6 +1060,283 @@ __global__ __launch_bounds__(256) void k_nms_cand_grid(const float4 *__restrict_
 // (k_nms_fill) then lay the hitters of every box out contiguously -- lists of any length, so clusters of hundreds of
 // overlapping detections stay on this path.
 constexpr unsigned long long kHitBit = 1ull << 63;
+
+// exact test of one candidate pair (score ranks p < q)
+template <typename T, bool ROTATED>
+__device__ __forceinline__ bool nms_pair_hits(const BoxCore<T> *__restrict__ geom, uint32_t p, uint32_t q, T thr)
+{
+    const BoxGeom<T> a = expand(geom[p]), b = expand(geom[q]);           // one sector per box
+    // the intersection is at most the overlap of the AABBs and at most either area: when even that bound gives
+    // IoU <= thr (with a margin far above the rounding of either side) the clip is not needed
+    const T ix = fmin(a.xmax, b.xmax) - fmax(a.xmin, b.xmin), iy = fmin(a.ymax, b.ymax) - fmax(a.ymin, b.ymin);
+    const T iub = fmin(ix * iy, fmin(a.area, b.area));
+    const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-4;
+    if (ROTATED && thr >= 0 && iub * (1 + thr) < thr * (a.area + b.area) * (1 - margin)) return false;
+    const T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
+    return v > thr;                                         // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
+}
+
+// between the levels and the second registration: the cell counters and the cell scan's ready words / ticket start over
+__global__ __launch_bounds__(256) void k_nms_regrid_reset(uint32_t *cellcnt, const NmsGrid *grid, const NmsCand *hdr,
+                                                          unsigned long long *chunk_tot, unsigned int *ticket)
+{
+    if (!nms_levels_on(*grid, hdr)) return;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = p; i <= kGridCells; i += (int64_t)gridDim.x * blockDim.x) cellcnt[i * kGridPad] = 0;
+    if (p < kGridScanWgs + 1) chunk_tot[p] = 0;
+    if (p == 0) *ticket = 0;
+}
+
+// ---- levels of the greedy result on the grid, BEFORE any pair is listed
+// A detector's raw output is clusters of hundreds of boxes around every object: listing all overlapping pairs of a cluster
+// (200 objects x 500 boxes: 25 M pairs = 200 MB of list, one list reservation per 512 of them, one returning atomic per
+// hit) costs milliseconds, although the greedy result is decided by a handful of boxes per cluster.  Level i, three launches
+// over the cell-sorted registrations:
+//   k_nms_level_block   a box that is still open (undecided, blocked at level i - 1) looks for ANY open better-ranked partner
+//                       in its cells whose conservative test (AABB overlap + IoU upper bound) passes; if there is one -- or
+//                       the search is cut short -- the
+//                       box is "blocked" at level i (blocked[rank] = i).  An open box that is NOT blocked has only decided
+//                       partners before it: the suppressed ones do not matter, the kept ones were roots of an earlier level
+//                       and did not hit it (next kernels) -- it is KEPT: a root of level i.
+//   k_nms_level_roots   every root of level i walks its cells' lists, 64 partners per step across the lanes, and lists the
+//                       blocked boxes it may hit: (root, victim) pairs, about one per box of a cluster;
+//   k_nms_level_kill    one listed pair per lane: exact IoU, a hit suppresses the victim for good (nms.cpp:36-43: a kept box
+//                       suppresses what it overlaps, a suppressed box nobody).
+// A root stays `undecided` with blocked != last level: it gets no list entries and k_nms_resolve keeps it.  After kNmsLevels
+// levels only the boxes blocked at the last level are still open; k_nms_cand_grid lists the pairs among THOSE.
+// The levels pay on clusters and cost on scattered boxes (where nearly every box is a root with a list of its own to walk):
+// they run when the grid is dense -- sum of squared list lengths > kNmsLevelDensity x registrations, i.e. a registration has
+// that many partners on average -- decided on the device (k_nms_gridscan adds the squares up), every kernel checks it first.
+// k_nms_level_block's walk: a wavefront owns 64 consecutive registrations (sorted by cell) and walks the union of their
+// cells' lists in chunks of 64 staged in LDS; the partner of a step is wave-uniform (LDS broadcast), only the open partners
+// of a chunk (ballot) are visited, four per trip, and the wavefront stops as soon as none of its lanes needs more.  The
+// lists hold the best-ranked sixteenth of all boxes first (k_nms_gridreg<place>): in a cluster nearly every box finds a
+// blocker among the first entries, and a box OF that sixteenth only walks the front section (whoever ranks before it is there).
+
+__global__ __launch_bounds__(256) void k_nms_level_block(const float4 *__restrict__ fbc, const uint32_t *__restrict__ cellof,
+                                                         const uint32_t *__restrict__ cellstart, const uint32_t *__restrict__ cellcur,
+                                                         const NmsGrid *grid, const NmsCand *hdr, const float *__restrict__ carea,
+                                                         float thr, const uint32_t *__restrict__ cellbox, uint8_t *blocked,
+                                                         const uint8_t *__restrict__ state, unsigned int level, uint32_t elite,
+                                                         const uint8_t *__restrict__ regopen /* level 1: open flag per registration */)
+{
+    __shared__ float4 window[4][64];
+    __shared__ uint32_t rwindow[4][64];
+    __shared__ float awindow[4][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const NmsGrid g = *grid;
+    if (!nms_levels_on(g, hdr)) return;
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    const bool live = e < g.entries;
+    if (__ballot(live) == 0) return;
+    const float4 fa = live ? fbc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t c = live ? cellof[e] : 0u, ra = live ? cellbox[e] : 0xffffffffu;
+    const float aa = live ? carea[e] : 0.f;
+    const bool bound_on = thr >= 0.f;
+    const float thr_lhs = 1.f + thr, thr_rhs = thr * (1.f - 1e-4f);
+    // open boxes of this level: blocked at the level before.  Level 1: everybody the score threshold left (k_nms_gridreg<place>
+    // noted it per registration: no gather by rank in this kernel's dependent chain); later levels look the rank up -- lanes of
+    // this launch may already have raised an entry to `level`
+    auto is_open = [&](uint32_t reg, uint32_t rank) {
+        if (regopen) return regopen[reg] != 0;
+        const uint8_t bb = __hip_atomic_load(&blocked[rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return state[rank] == kUndecided && bb + 1u >= level;
+    };
+    const bool mine = live && is_open(e, ra);
+    if (__ballot(mine) == 0) return;
+    const uint32_t mystart = mine ? cellstart[c] : 0xffffffffu;
+    // a box of the front section: everything that ranks before it sits in the front section too
+    const uint32_t myend = mine ? (ra < elite ? cellcur[(size_t)c * kGridPad] : cellstart[c + 1]) : 0u;
+    // union of the lanes' cell lists (registrations are sorted by cell: the lists of consecutive lanes follow each other)
+    uint32_t lo = mystart, hi = myend;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const uint32_t l2 = __shfl_xor(lo, o, kWave), h2 = __shfl_xor(hi, o, kWave);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    float4 *win = window[wave];
+    uint32_t *rwin = rwindow[wave];
+    float *awin = awindow[wave];
+    bool settled = !mine;                       // blocked: nothing more to learn for this lane
+    // one chunk ahead: the loads of chunk k + 1 are in flight while chunk k is tested
+    float4 nfb = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t nrb = 0xffffffffu;
+    float nab = 0.f;
+    bool nopen = false;
+    auto fetch = [&](uint32_t cb) {
+        const uint32_t t = cb + lane;
+        nopen = false;
+        if (t < hi) {
+            nrb = cellbox[t];
+            nfb = fbc[t];
+            nab = carea[t];
+            nopen = is_open(t, nrb);
+        }
+    };
+    fetch(lo);
+    int walked = 0;
+    for (uint32_t cb = lo; cb < hi;) {
+        if (__ballot(!settled && cb < myend) == 0) break;                   // (lists are walked in ascending order)
+        if (__ballot(!settled && cb + 64 > mystart && cb < myend) == 0) {   // nobody needs this chunk: on to the next list
+            uint32_t nx = (!settled && mystart > cb) ? mystart : 0xffffffffu;   // that a lane still looking walks
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) { const uint32_t x2 = __shfl_xor(nx, o, kWave); nx = x2 < nx ? x2 : nx; }
+            cb = nx;
+            if (cb >= hi) break;
+            fetch(cb);
+            continue;
+        }
+        const float4 cfb = nfb;
+        const uint32_t crb = nrb;
+        const float cab = nab;
+        const bool partner = nopen;
+        // A lane still looking after kNmsLevelChunks chunks OF ITS OWN LISTS gives up and counts as blocked -- always safe: it
+        // stays open and its pairs are listed.  The kernel is bound by its vector ALUs (every lane of a wavefront pays for every
+        // partner the slowest lane tests: six chunks cost 90 us per launch on 100 k boxes whatever the input, two cost 35), and
+        // two chunks are what the roots that matter need: the best box of a cluster sits in the front section (a sixteenth of a
+        // list of up to 2048 entries).  What gives up are roots of long lists outside the front section, and the many roots of
+        // lists of boxes that merely touch (20 k boxes all over each other: every wavefront holds a few).
+        if (!settled && cb + 64 > mystart && cb < myend && walked++ >= kNmsLevelChunks) settled = true;
+        if (cb + 64 < hi) fetch(cb + 64);
+        if (partner) { win[lane] = cfb; rwin[lane] = crb; awin[lane] = cab; }
+        unsigned long long pm = __ballot(partner);
+        __builtin_amdgcn_wave_barrier();
+        while (pm) {
+            int j[4], nj = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                j[u] = pm ? __builtin_ctzll(pm) : j[0];
+                if (pm) { pm &= pm - 1; nj = u + 1; }
+            }
+            float4 fb[4];
+            uint32_t rbj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { fb[u] = win[j[u]]; rbj[u] = rwin[j[u]]; }
+            bool near[4];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t tj = cb + (uint32_t)j[u];
+                const float gap = fminf(fminf(fb[u].z - fa.x, fa.z - fb[u].x), fminf(fb[u].w - fa.y, fa.w - fb[u].y));
+                near[u] = !settled && u < nj && tj >= mystart && tj < myend && rbj[u] < ra && gap > 0.f;
+                any = any || near[u];
+            }
+            if (!bound_on) settled = settled || any;
+            else if (__ballot(any)) {            // the IoU bound only where some lane has an overlapping better-ranked partner
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float ab = awin[j[u]];
+                    const float ix = fminf(fa.z, fb[u].z) - fmaxf(fa.x, fb[u].x), iy = fminf(fa.w, fb[u].w) - fmaxf(fa.y, fb[u].y);
+                    const float iub = fminf(ix * iy, fminf(aa, ab));
+                    settled = settled || (near[u] && !(iub * thr_lhs < thr_rhs * (aa + ab)));
+                }
+            }
+            if (__ballot(!settled) == 0) break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        cb += 64;
+    }
+    if (mine && settled) __hip_atomic_store(&blocked[ra], (uint8_t)level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// roots of the level -> (root rank, victim rank) pairs.  A wavefront takes 64 registrations; for each root among them (wave-
+// uniform loop) all 64 lanes walk that root's cell list, one partner each per step.  A pair sharing several cells is listed
+// in the cell of the lower-left corner of the AABBs' intersection only (as k_nms_cand_grid does).
+__global__ __launch_bounds__(256) void k_nms_level_roots(const float4 *__restrict__ fbc, const uint32_t *__restrict__ cellof,
+                                                         const uint32_t *__restrict__ cellstart, const NmsGrid *grid, NmsCand *hdr,
+                                                         const float *__restrict__ carea, float thr,
+                                                         const uint32_t *__restrict__ cellbox, const uint8_t *__restrict__ blocked,
+                                                         const uint8_t *__restrict__ state, unsigned int level,
+                                                         unsigned long long *__restrict__ list, unsigned long long cap, NmsFlags *flags)
+{
+    __shared__ unsigned long long batch[4][kCandLds];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const NmsGrid g = *grid;
+    if (!nms_levels_on(g, hdr)) return;
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    const bool live = e < g.entries;
+    const uint32_t ra = live ? cellbox[e] : 0xffffffffu;
+    const bool root = live && state[ra] == kUndecided && blocked[ra] + 1u == level;    // open at this level and not blocked in it
+    unsigned long long rm = __ballot(root);
+    if (rm == 0) return;
+    const float4 fa = live ? fbc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t c = live ? cellof[e] : 0u;
+    const uint32_t mystart = live ? cellstart[c] : 0u, myend = live ? cellstart[c + 1] : 0u;
+    const float aa = live ? carea[e] : 0.f;
+    const bool bound_on = thr >= 0.f;
+    const float thr_lhs = 1.f + thr, thr_rhs = thr * (1.f - 1e-4f);
+    unsigned long long *q = batch[wave], *counter = &hdr->count[kHdrKill + level - 1];
+    unsigned int wn = 0;
+    bool overflow = false;
+    auto flush = [&]() {
+        unsigned long long gb = 0;
+        if (lane == 0) gb = atomicAdd(counter, (unsigned long long)wn);
+        gb = __shfl(gb, 0, kWave);
+        __builtin_amdgcn_wave_barrier();
+        for (unsigned int t = lane; t < wn; t += 64)
+            if (gb + t < cap) list[gb + t] = q[t];
+        if (gb + wn > cap) { flags->need_sweep = 1; overflow = true; }     // the dense path takes over
+        wn = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    while (rm && !overflow) {
+        const int j = __builtin_ctzll(rm);
+        rm &= rm - 1;
+        const float4 fr = make_float4(__shfl(fa.x, j, kWave), __shfl(fa.y, j, kWave), __shfl(fa.z, j, kWave), __shfl(fa.w, j, kWave));
+        const float ar = __shfl(aa, j, kWave);
+        const uint32_t rr = __shfl(ra, j, kWave), cr = __shfl(c, j, kWave), s0 = __shfl(mystart, j, kWave), s1 = __shfl(myend, j, kWave);
+        const int ccx = (int)(cr % (uint32_t)g.gx), ccy = (int)(cr / (uint32_t)g.gx);
+        float4 nfb = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t nrb = 0;
+        if (s0 + lane < s1) { nfb = fbc[s0 + lane]; nrb = cellbox[s0 + lane]; }
+        for (uint32_t t0 = s0; t0 < s1; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            bool cand = false;
+            const float4 fb = nfb;
+            const uint32_t rb = nrb;
+            if (t + 64 < s1) { nfb = fbc[t + 64]; nrb = cellbox[t + 64]; }       // the next step's entries, in flight meanwhile
+            if (t < s1) {
+                const float gap = fminf(fminf(fb.z - fr.x, fr.z - fb.x), fminf(fb.w - fr.y, fr.w - fb.y));
+                cand = rb > rr && gap > 0.f && grid_cell(fmaxf(fr.x, fb.x), g.ox, g.inv_h, g.gx) == ccx &&
+                       grid_cell(fmaxf(fr.y, fb.y), g.oy, g.inv_h, g.gy) == ccy;
+                if (cand && bound_on) {
+                    const float ab = carea[t];
+                    const float ix = fminf(fr.z, fb.z) - fmaxf(fr.x, fb.x), iy = fminf(fr.w, fb.w) - fmaxf(fr.y, fb.y);
+                    const float iub = fminf(ix * iy, fminf(ar, ab));
+                    cand = !(iub * thr_lhs < thr_rhs * (ar + ab));
+                }
+                if (cand) cand = state[rb] == kUndecided && blocked[rb] == level;      // an open box: blocked at this level
+            }
+            const unsigned long long m = __ballot(cand);
+            if (m) {
+                const unsigned int cnt = (unsigned int)__popcll(m);
+                if (wn + cnt > (unsigned int)kCandLds) flush();
+                if (cand) q[wn + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)rr << 32) | rb;
+                wn += cnt;
+            }
+        }
+    }
+    if (wn) flush();
+}
+
+template <typename T, bool ROTATED>
+__global__ __launch_bounds__(256) void k_nms_level_kill(const BoxCore<T> *__restrict__ geom, const unsigned long long *__restrict__ list,
+                                                        unsigned long long cap, const NmsGrid *grid, const NmsCand *hdr,
+                                                        unsigned int level, T thr, uint8_t *state)
+{
+    if (!nms_levels_on(*grid, hdr)) return;
+    const unsigned long long cnt = hdr->count[kHdrKill + level - 1], total = cnt < cap ? cnt : cap;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const unsigned long long e = list[t];
+        const uint32_t p = (uint32_t)(e >> 32), q = (uint32_t)e;
+        if (__hip_atomic_load(&state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kUndecided) continue;   // another root got it
+        if (nms_pair_hits<T, ROTATED>(geom, p, q, thr))
+            __hip_atomic_store(&state[q], (uint8_t)kSuppressed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <typename T, bool ROTATED>
 __global__ __launch_bounds__(256) void k_nms_hits(const BoxCore<T> *__restrict__ geom,
                                                   const uint32_t *__restrict__ rankx,
@@ -1009,17 +1352,7 @@ __global__ __launch_bounds__(256) void k_nms_hits(const BoxCore<T> *__restrict__
         // list entry -> score ranks (through the broad phase's own numbering; the small-set path lists ranks directly)
         const uint32_t r1 = rankx ? rankx[e >> 32] : (uint32_t)(e >> 32), r2 = rankx ? rankx[e & 0xffffffffull] : (uint32_t)e;
         const uint32_t p = r1 < r2 ? r1 : r2, q = r1 < r2 ? r2 : r1;
-        const BoxGeom<T> a = expand(geom[p]), b = expand(geom[q]);       // one sector per box
-        bool hit = false;
-        // the intersection is at most the overlap of the AABBs and at most either area: when even that bound gives
-        // IoU <= thr (with a margin far above the rounding of either side) the clip is not needed
-        const T ix = fmin(a.xmax, b.xmax) - fmax(a.xmin, b.xmin), iy = fmin(a.ymax, b.ymax) - fmax(a.ymin, b.ymin);
-        const T iub = fmin(ix * iy, fmin(a.area, b.area));
-        const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-4;
-        if (!ROTATED || !(thr >= 0) || !(iub * (1 + thr) < thr * (a.area + b.area) * (1 - margin))) {
-            const T v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
-            hit = v > thr;                                 // nms.cpp:53  iou > (scalar_t)(float)iou_threshold
-        }
+        const bool hit = nms_pair_hits<T, ROTATED>(geom, p, q, thr);
         seg[t] = (hit ? kHitBit : 0ull) | ((unsigned long long)p << 32) | q;
         if (hit) arrival[sg * segcap + t] = atomicAdd(&inc_cnt[q], 1u);      // position inside q's segment
     }
@@ -1491,10 +1824,34 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_small(uint32_t n, const ui
 }
 
 
+// Whether the level kernels are worth LAUNCHING is a guess from the previous call: they decide on the device whether to run
+// (density of the grid), but on scattered boxes even their six empty launches cost ~15 % of a 100 k-box call.  The grid's
+// density of every call is left in one host-mapped word; the next call -- a detector's stream of frames looks like the frame
+// before -- skips the launches when it says "sparse".  Only speed depends on the guess: without the launches every pair is
+// listed as before.  (One word per process, unsynchronised on purpose; never allocated during a stream capture.)
+static int *g_nms_hint_host = nullptr, *g_nms_hint_dev = nullptr;
+static void nms_dense_hint(hipStream_t st, int **dev, bool *launch_levels)
+{
+    *dev = nullptr;
+    *launch_levels = true;
+    if (!g_nms_hint_host) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+        int *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&h), 64, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(reinterpret_cast<void **>(&d), h, 0) != hipSuccess) { (void)hipGetLastError(); return; }
+        *h = 1;
+        g_nms_hint_dev = d;
+        g_nms_hint_host = h;
+    }
+    *dev = g_nms_hint_dev;
+    *launch_levels = *reinterpret_cast<volatile int *>(g_nms_hint_host) != 0;
+}
+
 // the small-set path takes hard NMS of up to kNmsSmallMax boxes unless a flag asks for a specific general path (tests)
 static inline bool nms_small_eligible(int64_t n, uint32_t opts)
 {
-    return n <= kNmsSmallMax && !(opts & (D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_GENERAL)) && (opts >> 8) == 0;
+    return n <= kNmsSmallMax && !(opts & (D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_GENERAL | D3D_NMS_FORCE_LEVELS)) && (opts >> 8) == 0;
 }
 
 template <typename T>
@@ -1506,6 +1863,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     BoxCore<T> *geom = w.take<BoxCore<T>>(nb * 64);
     float4 *fbox = w.take<float4>(nb * 64);
     uint8_t *state = w.take<uint8_t>(nb * 64);
+    uint8_t *blocked = w.take<uint8_t>(nb * 64);
     uint32_t *inc_cnt = w.take<uint32_t>(nb * 64);
     uint32_t *inc_off = w.take<uint32_t>(nb * 64);
     float *farea = w.take<float>(nb * 64);
@@ -1542,6 +1900,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     uint32_t *cellof = w.take<uint32_t>((size_t)cap_e);
     float4 *fbc = w.take<float4>((size_t)cap_e);
     float *carea = w.take<float>((size_t)cap_e);
+    uint8_t *regopen = w.take<uint8_t>((size_t)cap_e);
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
     const bool rot = iou_type == D3D_IOU_RBOX;
     if (nms_small_eligible(n, opts)) {
@@ -1586,19 +1945,62 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     const bool use_grid = !(opts & D3D_NMS_BROAD_SWEEP);
     const unsigned nbl = (unsigned)d3d_divup(n, 256);
     D3D_LAUNCH("k_nms_prepare", k_nms_prepare<T>, dim3(nbl), dim3(256), 0, st, boxes, scores, order, n, score_thr,
-               geom, fbox, state, inc_cnt, farea, remv, nb, flags, cand_hdr, (opts & D3D_NMS_FORCE_DENSE) ? 1u : 0u, xkey, &grid->ticket, tile_tot, gpartial, cellcur, chunk_tot);
+               geom, fbox, state, inc_cnt, farea, remv, nb, flags, cand_hdr, (opts & D3D_NMS_FORCE_DENSE) ? 1u : 0u, xkey, &grid->ticket, tile_tot, gpartial, cellcur, chunk_tot, blocked,
+               (opts & D3D_NMS_FORCE_LEVELS) ? 1u : 0u);
     if (use_grid) {
         const bool fold_inline = nbl <= (unsigned)kGridFoldMax;
         if (!fold_inline) D3D_LAUNCH("k_nms_extent", k_nms_extent, dim3(1), dim3(256), 0, st, (const float *)gpartial, nbl, grid);
         D3D_LAUNCH("k_nms_gridreg<count>", k_nms_gridreg<false>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
-                   cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, fold_inline ? nbl : 0u);
+                   cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, fold_inline ? nbl : 0u,
+                   (const uint32_t *)cellstart, (const uint8_t *)state, regopen);
         D3D_LAUNCH("k_nms_gridscan", k_nms_gridscan, dim3(kGridScanWgs), dim3(1024), 0, st, cellcur, cellstart, grid, cap_e, flags,
-                   chunk_tot, tickets + 1, (opts & D3D_NMS_TEST_WITHHOLD) != 0 && (opts & D3D_NMS_BROAD_SWEEP) == 0);
+                   chunk_tot, tickets + 1, (opts & D3D_NMS_TEST_WITHHOLD) != 0 && (opts & D3D_NMS_BROAD_SWEEP) == 0,
+                   &cand_hdr->count[kHdrDensity]);
         D3D_LAUNCH("k_nms_gridreg<place>", k_nms_gridreg<true>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
-                   cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, 0u);
+                   cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, 0u,
+                   (const uint32_t *)cellstart, (const uint8_t *)state, regopen);
+        unsigned int levels = ((opts >> 6) & 3u) ? ((opts >> 6) & 3u) : (unsigned int)kNmsLevels;
+        int *hint_dev = nullptr;
+        bool launch_levels = true;
+        nms_dense_hint(st, &hint_dev, &launch_levels);
+        if (!launch_levels && !(opts & D3D_NMS_FORCE_LEVELS)) levels = 0;
+        for (unsigned int level = 1; level <= levels; level++) {
+            const dim3 lg((unsigned)d3d_divup((int64_t)cap_e, 256));
+            const float bthr = rot ? iou_thr : -1.f;
+            D3D_LAUNCH("k_nms_level_block", k_nms_level_block, lg, dim3(256), 0, st, (const float4 *)fbc, (const uint32_t *)cellof,
+                       (const uint32_t *)cellstart, (const uint32_t *)cellcur, (const NmsGrid *)grid, (const NmsCand *)cand_hdr,
+                       (const float *)carea, bthr, (const uint32_t *)cellbox, blocked, (const uint8_t *)state, level,
+                       (uint32_t)(n >> kEliteShift), level == 1 ? (const uint8_t *)regopen : (const uint8_t *)nullptr);
+            D3D_LAUNCH("k_nms_level_roots", k_nms_level_roots, lg, dim3(256), 0, st, (const float4 *)fbc, (const uint32_t *)cellof,
+                       (const uint32_t *)cellstart, (const NmsGrid *)grid, cand_hdr, (const float *)carea, bthr,
+                       (const uint32_t *)cellbox, (const uint8_t *)blocked, (const uint8_t *)state, level, cand, cap, flags);
+            const unsigned kb = (unsigned)std::min<int64_t>(d3d_divup(n, 256) * 2, 4096);
+            if (rot)
+                D3D_LAUNCH("k_nms_level_kill", (k_nms_level_kill<T, true>), dim3(kb), dim3(256), 0, st, (const BoxCore<T> *)geom,
+                           (const unsigned long long *)cand, cap, (const NmsGrid *)grid, (const NmsCand *)cand_hdr, level, (T)iou_thr, state);
+            else
+                D3D_LAUNCH("k_nms_level_kill", (k_nms_level_kill<T, false>), dim3(kb), dim3(256), 0, st, (const BoxCore<T> *)geom,
+                           (const unsigned long long *)cand, cap, (const NmsGrid *)grid, (const NmsCand *)cand_hdr, level, (T)iou_thr, state);
+        }
+        if (levels > 0) {
+            // the boxes the levels left open are registered again, alone: the candidate walk is quadratic in the list lengths
+            D3D_LAUNCH("k_nms_regrid_reset", k_nms_regrid_reset, dim3(64), dim3(256), 0, st, cellcur, (const NmsGrid *)grid,
+                       (const NmsCand *)cand_hdr, chunk_tot, tickets + 1);
+            D3D_LAUNCH("k_nms_gridreg<count>", k_nms_gridreg<false>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
+                       cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, 0u,
+                       (const uint32_t *)cellstart, (const uint8_t *)state, regopen, (const NmsCand *)cand_hdr, (const uint8_t *)blocked,
+                       levels);
+            D3D_LAUNCH("k_nms_gridscan", k_nms_gridscan, dim3(kGridScanWgs), dim3(1024), 0, st, cellcur, cellstart, grid, cap_e, flags,
+                       chunk_tot, tickets + 1, false, &cand_hdr->count[kHdrDensity], (const NmsCand *)cand_hdr);
+            D3D_LAUNCH("k_nms_gridreg<place>", k_nms_gridreg<true>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
+                       cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, 0u,
+                       (const uint32_t *)cellstart, (const uint8_t *)state, regopen, (const NmsCand *)cand_hdr, (const uint8_t *)blocked,
+                       levels);
+        }
         D3D_LAUNCH("k_nms_cand_grid", k_nms_cand_grid, dim3((unsigned)d3d_divup((int64_t)cap_e, 256)), dim3(256), 0, st,
                    (const float4 *)fbc, (const uint32_t *)cellof, (const uint32_t *)cellstart, (const NmsGrid *)grid, cand, cap,
-                   cand_hdr, flags, (const float *)carea, rot ? iou_thr : -1.f);
+                   cand_hdr, flags, (const float *)carea, rot ? iou_thr : -1.f, (const uint32_t *)cellbox, (const uint8_t *)blocked,
+                   (const uint8_t *)state, levels, hint_dev);
         rankx = cellbox;                                   // registration -> score rank, for k_nms_hits
     } else {
         if (int rc = d3d_internal_argsort_desc_i32(xkey, n, perm, sort_ws, sort_bytes, st)) return rc;
@@ -1868,8 +2270,9 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *io
         D3D_HIP_CHECK(hipMemsetAsync(ious, 0, (size_t)n * (size_t)m * sizeof(T), st));
         fill = nullptr;
     }
-    D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), gy), dim3(kTileCols), 0, st,
-               (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap);
+    const int prows = pre_tile_rows(n, m);
+    D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), (unsigned)d3d_divup(n, (int64_t)prows)),
+               dim3(kTileCols), 0, st, (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap, 0.f, prows);
     D3D_LAUNCH("k_iou_clip", (k_iou_clip<T, ROTATED>), dim3(256 * 16), dim3(256), 0, st, ga, gb, m, ious, hdr, list, cap);
     // fallback (blocks exit at once unless the list overflowed)
     D3D_LAUNCH("k_iou2d", (k_iou2d<T, ROTATED, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols), 0, st, b1,
@@ -1977,8 +2380,10 @@ static int iou3d_impl(const float *boxes1, int64_t n, const float *boxes2, int64
             D3D_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n * (size_t)m * sizeof(float), st));
             fill = nullptr;
         }
-        D3D_LAUNCH("k_iou_pre", k_iou_pre<float>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), gy), dim3(kTileCols), 0, st,
-                   (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap, complement ? 1.f : 0.f);
+        const int prows = pre_tile_rows(n, m);
+        D3D_LAUNCH("k_iou_pre", k_iou_pre<float>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), (unsigned)d3d_divup(n, (int64_t)prows)),
+                   dim3(kTileCols), 0, st, (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap, complement ? 1.f : 0.f,
+                   prows);
         if (rotated) {
             D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<true>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, m, out, hdr, list, cap, complement);
             D3D_IOU3D(true, 1, &hdr->overflow);
@@ -2037,14 +2442,14 @@ static size_t nms_core_workspace_bytes(int64_t n)
 {
     if (n < 1) n = 1;
     const size_t nb = (size_t)d3d_divup(n, 64);
-    return d3d_align_up(nb * 64 * sizeof(BoxGeom<double>)) + d3d_align_up(nb * 64 * 16) + d3d_align_up(nb * 64) +
+    return d3d_align_up(nb * 64 * sizeof(BoxGeom<double>)) + d3d_align_up(nb * 64 * 16) + 2 * d3d_align_up(nb * 64) +
            d3d_align_up(nb * 64 * 4) * 3 + d3d_align_up((nb * 64 / kScanTile + 2 + 80) * 8) + 256 + 2 * d3d_align_up((size_t)nms_cand_capacity(n) * 4) +
            256 + d3d_align_up(nb * 8) +
            d3d_align_up(sizeof(NmsCand)) +
            d3d_align_up((size_t)nms_cand_capacity(n) * 8) + 2 * d3d_align_up(nb * 64 * 4) + d3d_align_up((nb * 64 + kCandPad) * 16) +
            d3d_align_up(nb * 64 * 4) + d3d_align_up(d3d_internal_argsort_i32_bytes(n)) + d3d_align_up(nb * 64 * nb * 8) + 256 +
            d3d_align_up((size_t)(kGridCells + 1) * kGridPad * 4) + d3d_align_up((kGridCells + 1) * 4) + d3d_align_up((nb * 64 / 256 + 1) * 6 * 4) + d3d_align_up(sizeof(NmsGrid)) +
-           d3d_align_up(kGridReg * nb * 64 * 4) * 3 + d3d_align_up(kGridReg * nb * 64 * 16);
+           d3d_align_up(kGridReg * nb * 64 * 4) * 3 + d3d_align_up(kGridReg * nb * 64 * 16) + d3d_align_up(kGridReg * nb * 64);
 }
 
 extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
@@ -2060,7 +2465,7 @@ extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *o
                          void *stream, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL | D3D_NMS_TEST_WITHHOLD))) return D3D_ERR_BAD_ARG;
+    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL | D3D_NMS_TEST_WITHHOLD | D3D_NMS_FORCE_LEVELS | D3D_NMS_LEVELS(3)))) return D3D_ERR_BAD_ARG;
     if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;   // common.h:25
     if (suppression_type != D3D_SUPPRESS_HARD && suppression_type != D3D_SUPPRESS_LINEAR &&

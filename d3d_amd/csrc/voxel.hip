@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
                                                    const int32_t *__restrict__ npoints,
                                                    const uint32_t *__restrict__ voff, const uint32_t *__restrict__ list,
                                                    const uint32_t *__restrict__ unsorted, uint32_t max_points,
-                                                   int reduction, float *agg)
+                                                   int reduction, float *agg, int only_overflow = 0 /* the rest is done (k_emit_c) */)
 {
     const int64_t total = counts[D3D_COUNT_VOXELS] * (int64_t)c;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
         const int64_t v = valid ? t / c : 0;
         const int d = (int)(t - v * c);
         const uint32_t cnt = valid ? (uint32_t)npoints[v] : 0u;
-        if (valid && cnt <= max_points) {
+        if (valid && cnt <= max_points && !only_overflow) {
             const uint32_t base = voff[v];
             float acc = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
             for (uint32_t k = 0; k < cnt; k++) {
@@ -1809,6 +1809,175 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     }
 }
 
+// The same for rows of C != 4 floats (C = 3, 5 .. 8: x, y, z + up to five features): the row buffer holds C floats per row,
+// the stretch of a wavefront's voxels is still ONE contiguous run of nv * P * C floats, written 16 bytes per lane -- a piece
+// may straddle two rows, so its four floats are looked up one by one (P * C is a multiple of 4: every voxel, hence every
+// batch, starts on a 16-byte boundary).  The index came from k_bucket_index<LISTS>: ranked point indices per voxel, all ranks.
+// Overflow voxels (more than P points) get their reduction from k_aggregate afterwards (one wavefront per (voxel, channel)
+// over the arrival-ordered list, fp64), which needs the segment base of every voxel: voff.
+// Replaces k_meta_first + k_fill_generic_lds + k_aggregate (config 2 with a fifth column: 34 + 109 + 60 us).
+template <class Key, int C>
+__global__ __launch_bounds__(256) void k_emit_c(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
+                                                const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
+                                                const uint4 *__restrict__ vrec, uint32_t max_voxels,
+                                                const float *__restrict__ points, const uint32_t *__restrict__ ranked,
+                                                uint32_t P, int pshift /* log2 P or -1 */, int reduction, int64_t *coords,
+                                                int32_t *npoints, unsigned char *pmask, float *agg, uint32_t *voff, float *voxels,
+                                                int64_t *counts, int64_t *host_counts)
+{
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float rowbuf_all[256 / kWave][kEmitCap * C];
+    __shared__ uint32_t off_all[256 / kWave][kWave], base_all[256 / kWave][kWave], first_all[256 / kWave][kWave];
+    __shared__ uint16_t kept_all[256 / kWave][kWave];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    float *rowbuf = rowbuf_all[w];
+    uint32_t *sh_off = off_all[w], *sh_base = base_all[w], *sh_first = first_all[w];
+    uint16_t *sh_kept = kept_all[w];
+    const uint32_t tile = (uint32_t)(i / kFlagTile), ntile = (uint32_t)(npad / kFlagTile);
+    uint32_t before = 0, all = 0;
+    for (uint32_t t = lane; t < ntile; t += kWave) {
+        const uint32_t x = bsumF[t];
+        all += x;
+        if (t < tile) before += x;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) { before += __shfl_xor(before, o, kWave); all += __shfl_xor(all, o, kWave); }
+    if (i == 0) {
+        counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
+        counts[D3D_COUNT_AUX] = 0;
+        if (host_counts) notify_host(counts, host_counts);
+    }
+    const uint32_t e = firstmap[i];
+    const unsigned long long bal = __ballot(e != kInf);
+    const uint32_t nfirst = (uint32_t)__popcll(bal);
+    uint32_t nv = nfirst;
+    const uint32_t vid0 = before + fwpre[i >> 6];
+    if (nv == 0 || vid0 >= max_voxels) return;             // wave-uniform
+    if (nv > max_voxels - vid0) nv = max_voxels - vid0;     // voxelize.cpp:116-117: later voxels are never created
+    const uint32_t r = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    const uint32_t dst = (e != kInf ? r : nfirst + ((uint32_t)lane - r)) << 2;
+    const uint32_t el = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)e);
+    const uint32_t il = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)(uint32_t)i);
+    const bool mine = (uint32_t)lane < nv;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (mine) rec = vrec[el];
+    const uint32_t base = rec.z, cnt = rec.w;
+    const uint32_t kept = cnt < P ? cnt : P;                // 0 for the lanes past nv
+    uint32_t incl = kept;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, kWave);
+        if (lane >= d) incl += t;
+    }
+    const uint32_t off = incl - kept;
+    sh_off[lane] = off; sh_base[lane] = base; sh_first[lane] = il; sh_kept[lane] = (uint16_t)kept;
+    wave_lds_fence();
+    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
+    float acc[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) acc[ch] = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+    vec4 *out = reinterpret_cast<vec4 *>(voxels + (int64_t)vid0 * P * C);      // 16-byte aligned: P * C % 4 == 0 (host-checked)
+    const uint32_t PC = P * (uint32_t)C;
+    uint32_t ja = 0;
+    while (ja < nv) {                                       // wave-uniform: one batch unless the rows exceed the buffer
+        const uint32_t oa = (uint32_t)__shfl((int)off, (int)ja, kWave);
+        const bool fits = (uint32_t)lane >= ja && mine && incl - oa <= (uint32_t)kEmitCap;
+        const unsigned long long nf = ~(__ballot(fits) >> ja);
+        const uint32_t jb = ja + (nf ? (uint32_t)__ffsll((long long)nf) - 1u : (uint32_t)kWave - ja);
+        const uint32_t rows = (uint32_t)__shfl((int)incl, (int)jb - 1, kWave) - oa;
+        for (uint32_t t0 = 0; t0 < rows; t0 += kWave) {
+            const uint32_t t = t0 + lane;
+            if (t < rows) {
+                uint32_t lo = ja, hi = jb;                  // largest j in [ja, jb) with off[j] - oa <= t
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sh_off[mid] - oa <= t) lo = mid; else hi = mid;
+                }
+                const uint32_t k = t - (sh_off[lo] - oa);
+                const uint32_t idx = k == 0 ? sh_first[lo] : ranked[sh_base[lo] + k];
+                const float *src = points + (size_t)idx * C;
+                float x[C];
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) x[ch] = src[ch];
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) rowbuf[t * C + ch] = x[ch];
+            }
+        }
+        wave_lds_fence();
+        if (reduction != D3D_REDUCE_NONE && (uint32_t)lane >= ja && (uint32_t)lane < jb && cnt <= P) {
+            const float *rw = rowbuf + (size_t)(off - oa) * C;
+            for (uint32_t k = 0; k < kept; k++) {
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) {
+                    const float x = rw[k * C + ch];
+                    if (is_sum) acc[ch] += x;
+                    else if (reduction == D3D_REDUCE_MAX) acc[ch] = acc[ch] < x ? x : acc[ch];     // std::max(acc, x)
+                    else acc[ch] = x < acc[ch] ? x : acc[ch];
+                }
+            }
+        }
+        // the stretch of the batch's voxels, in 16-byte pieces
+        const uint32_t q1 = jb * PC / 4;
+        for (uint32_t q0 = ja * PC / 4; q0 < q1; q0 += 4 * kWave) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t q = q0 + u * kWave + lane;
+                if (q < q1) {
+                    uint32_t row = (q * 4u) / (uint32_t)C, ch = q * 4u - row * (uint32_t)C;     // row = voxel * P + slot
+                    vec4 val;
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const uint32_t j = pshift >= 0 ? (row >> pshift) : row / P;
+                        const uint32_t slot = row - j * P;
+                        val[x] = slot < sh_kept[j] ? rowbuf[(size_t)(sh_off[j] - oa + slot) * C + ch] : 0.f;
+                        if (++ch == (uint32_t)C) { ch = 0; row++; }
+                    }
+                    __builtin_nontemporal_store(val, &out[q]);
+                }
+            }
+        }
+        wave_lds_fence();                                   // the next batch overwrites the buffer
+        ja = jb;
+    }
+    const int64_t v = (int64_t)vid0 + lane;
+    {
+        long long *cbuf = reinterpret_cast<long long *>(rowbuf);       // 64 * 3 * 8 B = 1.5 KiB (kEmitCap * C * 4 >= 3 KiB)
+        if (mine) {
+            long long cc[3];
+            kf.decode(((u64)rec.y << 32) | rec.x, cc);
+            cbuf[lane * 3 + 0] = cc[0]; cbuf[lane * 3 + 1] = cc[1]; cbuf[lane * 3 + 2] = cc[2];
+            __builtin_nontemporal_store((int32_t)cnt, &npoints[v]);
+            if (voff) voff[v] = base;
+        }
+        wave_lds_fence();
+        long long *cdst = reinterpret_cast<long long *>(coords) + (int64_t)vid0 * 3;
+        for (uint32_t t = lane; t < nv * 3; t += kWave) __builtin_nontemporal_store(cbuf[t], &cdst[t]);
+        if (pmask) {                                         // P % 16 == 0, 16-byte aligned (host-checked): 16-byte pieces
+            const uint32_t per = P >> 4, total = nv * per;
+            typedef uint32_t uvec4 __attribute__((ext_vector_type(4)));
+            uvec4 *pdst = reinterpret_cast<uvec4 *>(pmask + (int64_t)vid0 * P);
+            for (uint32_t t = lane; t < total; t += kWave) {
+                const uint32_t j = t / per, k0 = (t - j * per) << 4, kj = sh_kept[j];
+                uvec4 w4;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t b = 0;
+#pragma unroll
+                    for (int x = 0; x < 4; x++) b |= ((k0 + q * 4 + x) < kj ? 1u : 0u) << (8 * x);
+                    w4[q] = b;
+                }
+                __builtin_nontemporal_store(w4, &pdst[t]);
+            }
+        }
+    }
+    if (reduction != D3D_REDUCE_NONE && mine && cnt <= P) {
+        const float d = reduction == D3D_REDUCE_MEAN ? (float)(int32_t)cnt : 1.0f;      // voxelize.cpp:164 (float / int)
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) agg[v * C + ch] = reduction == D3D_REDUCE_MEAN ? acc[ch] / d : acc[ch];
+    }
+}
+
 // fused sparse + filter: the sizes of BOTH filtered outputs are known once k_meta_first has run -- the voxels it numbered and
 // the points they keep (count, or min(count, max_points) with the TRIM point filter; voxelize.cpp:403, 457-463).  One
 // workgroup adds the per-workgroup partial sums up and publishes them to the host, BEFORE the three launches of the
@@ -2193,6 +2362,7 @@ struct DenseOut {
     bool lists = false;                 // dense contract with C != 4: ranked index lists + voff instead of staged rows
     uint32_t *seg_out = nullptr;        // reduce contract: segment base of every voxel's staged rows (for the caller)
     float4 *emit_voxels = nullptr;      // dense contract on C == 4 rows: k_emit writes voxels[V,P,4] too (no staging, no fill)
+    float *emit_generic = nullptr;      // dense contract, C = 3, 5 .. 8: k_emit_c writes voxels[V,P,C] and the per-voxel outputs
 };
 
 // n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
@@ -2265,6 +2435,24 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 512 (n <= 8 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF);
     const dim3 grid((unsigned)(w.npad / 256));
+    if constexpr (!ROWS && std::is_same<Key, DenseKey>::value) {
+        if (o.emit_generic) {
+            const int pshift = (o.P & (o.P - 1)) == 0 ? __builtin_ctz(o.P) : -1;
+#define D3D_EMIT_C(CC)                                                                                                          \
+    D3D_LAUNCH("k_emit_c", (k_emit_c<Key, CC>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec, o.max_voxels,  \
+               points, w.big_list, o.P, pshift, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr, o.aggregates,   \
+               w.voff, o.emit_generic, counts, x.host_counts)
+            switch (c) {
+            case 3: D3D_EMIT_C(3); break;
+            case 5: D3D_EMIT_C(5); break;
+            case 6: D3D_EMIT_C(6); break;
+            case 7: D3D_EMIT_C(7); break;
+            default: D3D_EMIT_C(8); break;
+            }
+#undef D3D_EMIT_C
+            return D3D_OK;
+        }
+    }
     if constexpr (ROWS) {
         if (o.emit_voxels) {
             const int pshift = (o.P & (o.P - 1)) == 0 ? __builtin_ctz(o.P) : -1;
@@ -2351,6 +2539,7 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
     int hshift = 0;
     bool lists_ready = false;           // C != 4 on the binned index: w.big_list / w.unsorted / w.voff hold the lists
     bool emitted = false;               // k_emit wrote voxels[V,P,4] as well
+    bool emitted_generic = false;       // k_emit_c wrote voxels[V,P,C], the per-voxel outputs and the aggregates of voxels within P
     if (max_voxels > 0 && dense_cells_fit_u32(kf) && binned_eligible(n, w, flags, &nbins, &hshift)) {
         DenseOut d{P, (uint32_t)max_voxels, reduction, agg4, fuse_pmask, coords, npoints, pmask, aggregates,
                    BinnedExtras{nullptr, 0, nullptr, -1, nullptr, host_counts}, nullptr};
@@ -2364,6 +2553,11 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
             // and the generic output kernels below gather through them
             d.lists = true;
             lists_ready = true;
+            if ((c == 3 || (c >= 5 && c <= 8)) && P > 0 && P <= (uint32_t)kEmitCap && (P * (uint32_t)c) % 4 == 0 &&
+                (reinterpret_cast<uintptr_t>(voxels) & 15) == 0 && !(flags & D3D_VOXEL_SPLIT_FILL)) {
+                d.emit_generic = voxels;
+                emitted_generic = true;
+            }
             rc = binned_index<DenseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st);
         }
         if (rc) return rc;
@@ -2387,9 +2581,12 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
                        w.big_count, reduction, reinterpret_cast<float4 *>(aggregates));
     }
     if (P == 0) return D3D_OK;
-    if (emitted) {
+    if (emitted || emitted_generic) {
         if (!fuse_pmask)
             D3D_LAUNCH("k_pmask", k_pmask, dim3(grid_for(d3d_divup(cap * P, 16), 256)), dim3(256), 0, st, counts, npoints, P, pmask);
+        if (emitted_generic && reduction != D3D_REDUCE_NONE)          // voxels with more than P points: all their points count
+            D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(cap * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
+                       w.voff, w.big_list, w.unsorted, P, reduction, aggregates, 1);
         return D3D_OK;
     }
     if (vec4 && n <= kFillRowsMaxPoints) {

@@ -43,6 +43,10 @@ for seed in range(first, first + count):
                      flags=_lib.NMS_GENERAL).cpu().numpy()
         if not np.array_equal(~gsup, exp):
             bad += 1; print("NMS-GENERAL seed", seed, kw, n, "FAILED", int(np.sum(~gsup != exp)))
+        lsup = nms2d(torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), IouType[method.upper()], 0, thr, sthr, 0.0,
+                     flags=_lib.NMS_FORCE_LEVELS).cpu().numpy()           # ... and with the grid's level kernels forced on
+        if not np.array_equal(~lsup, exp):
+            bad += 1; print("NMS-LEVELS seed", seed, kw, n, "FAILED", int(np.sum(~lsup != exp)))
     if seed % 10 == 0:        # a large set now and then: the bucket argsort (>= 8 k keys), long incoming lists, the grid's cell scan
         nl = int(rng.integers(9000, 60000))
         side = float(rng.choice([300.0, 1500.0, 6000.0]))
@@ -57,6 +61,12 @@ for seed in range(first, first + count):
         exp = oracle.box2d_nms_hard_candidates(bl, sl, method, thr_l, sthr_l)
         if not np.array_equal(keep, exp):
             bad += 1; print("NMS-LARGE seed", seed, method, nl, side, thr_l, "FAILED", int(np.sum(keep != exp)))
+        from d3d_amd import _lib
+        from d3d_amd.box import nms2d, IouType
+        lsup = nms2d(torch.from_numpy(bl).cuda(), torch.from_numpy(sl).cuda(), IouType[method.upper()], 0, thr_l, sthr_l, 0.0,
+                     flags=_lib.NMS_FORCE_LEVELS).cpu().numpy()
+        if not np.array_equal(~lsup, exp):
+            bad += 1; print("NMS-LARGE-LEVELS seed", seed, method, nl, side, thr_l, "FAILED", int(np.sum(~lsup != exp)))
     m = int(rng.integers(1, 400))
     b2 = b[rng.integers(0, n, m)] + rng.normal(0, 1.0, (m, 5))
     got = box2d_iou(torch.from_numpy(b).cuda(), torch.from_numpy(b2).cuda(), method=method).cpu().numpy()

@@ -83,3 +83,55 @@ def test_reference_voxel_layer_imports_against_voxel_impl(ref_pkg):
             gen(torch.zeros(4, 4))
         with pytest.raises(RuntimeError, match="HIP device"):
             mod.VoxelGenerator([0, 1, 0, 1, 0, 1], [10, 10, 10], max_points=5, max_points_filter="trim")(torch.zeros(4, 4))
+
+
+def test_intentional_deviations_are_pinned(ref_pkg):
+    """where this library deliberately differs from the reference's Python layer, pinned against the
+    reference's own code: (1) seg1d_iou -- the reference halves seg1's width for BOTH segments (box/__init__.py:163-164);
+    `reference_compat=True` reproduces its values bit for bit, the default uses seg2's own width and agrees wherever the widths
+    agree; (2) PDist2DR -- the reference hands (boxes, points) to compiled functions declared (points, boxes) and returns the
+    backward's (grad_boxes, grad_points) for the inputs (points, boxes); this library's PDist2DR passes (points, boxes) and
+    returns the gradients in input order."""
+    from d3d_amd import box as ours
+    from d3d_amd.box import box_impl
+    mod = ref_pkg("box", "box_impl", box_impl)
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(200, 2, generator=g) + 0.1
+    b = torch.rand(200, 2, generator=g) + 0.1
+    ref = mod.seg1d_iou(a, b)
+    assert torch.equal(ours.seg1d_iou(a, b, reference_compat=True), ref)
+    fixed = ours.seg1d_iou(a, b)
+    assert not torch.allclose(fixed, ref)                      # the widths differ: so do the results
+    lo = torch.maximum(a[:, 0] - a[:, 1] / 2, b[:, 0] - b[:, 1] / 2)
+    hi = torch.minimum(a[:, 0] + a[:, 1] / 2, b[:, 0] + b[:, 1] / 2)
+    inter = torch.clamp_min(hi - lo, 0)
+    assert torch.allclose(fixed, inter / (a[:, 1] + b[:, 1] - inter), atol=1e-6)
+    b2 = torch.stack([b[:, 0], a[:, 1]], 1)                    # equal widths: no deviation
+    assert torch.equal(ours.seg1d_iou(a, b2), mod.seg1d_iou(a, b2))
+
+    calls = []
+
+    def fwd(x, y):
+        calls.append(("fwd", tuple(x.shape), tuple(y.shape)))
+        return torch.zeros(y.shape[0] if x.shape[1] == 2 else x.shape[0], 1), torch.zeros(1, dtype=torch.uint8)
+
+    def bwd(x, y, grad, *rest):
+        calls.append(("bwd", tuple(x.shape), tuple(y.shape)))
+        return torch.zeros_like(x), torch.zeros_like(y)
+    pts, boxes = torch.zeros(7, 2, requires_grad=True), torch.zeros(3, 5, requires_grad=True)
+    mod.pdist2dr_forward, mod.pdist2dr_backward = fwd, bwd      # the reference's PDist2DR: (boxes, points) reach the functions
+    with pytest.raises(RuntimeError, match="invalid gradient"):    # ... and their gradients come back in THAT order, for the
+        mod.PDist2DR.apply(pts, boxes).sum().backward()            # inputs (points, boxes): autograd rejects it when N != M
+    assert calls == [("fwd", (3, 5), (7, 2)), ("bwd", (3, 5), (7, 2))]
+    calls.clear()
+    saved = ours.pdist2dr_forward, ours.pdist2dr_backward
+    try:
+        ours.pdist2dr_forward = lambda p, b: (calls.append(("fwd", tuple(p.shape), tuple(b.shape))) or torch.zeros(3, 7), None)
+        ours.pdist2dr_backward = lambda p, b, g: (calls.append(("bwd", tuple(p.shape), tuple(b.shape))) or torch.zeros_like(b),
+                                                  torch.zeros_like(p))
+        p2, b2_ = torch.zeros(7, 2, requires_grad=True), torch.zeros(3, 5, requires_grad=True)
+        ours.PDist2DR.apply(p2, b2_).sum().backward()
+    finally:
+        ours.pdist2dr_forward, ours.pdist2dr_backward = saved
+    assert calls == [("fwd", (7, 2), (3, 5)), ("bwd", (7, 2), (3, 5))]   # ours: (points, boxes), as dist.h:7-13 declares
+    assert p2.grad.shape == (7, 2) and b2_.grad.shape == (3, 5)

@@ -11,17 +11,19 @@ pytestmark = pytest.mark.gpu
 
 
 def pytest_generate_tests(metafunc):
-    # every NMS test runs three ways: as the operator picks (sets of up to 4096 boxes take the small-set path), and on the
-    # general path with either broad phase: the uniform grid and the sweep along x
+    # every NMS test runs four ways: as the operator picks (sets of up to 4096 boxes take the small-set path), on the general
+    # path with either broad phase (the uniform grid, the sweep along x), and on the grid with its level kernels forced (they
+    # run by themselves only on dense grids: clusters of detections)
     if "nms" in metafunc.function.__name__ and "nms_broad" in metafunc.fixturenames:
-        metafunc.parametrize("nms_broad", ["auto", "grid", "sweep"], indirect=True)
+        metafunc.parametrize("nms_broad", ["auto", "grid", "sweep", "levels"], indirect=True)
 
 
 @pytest.fixture(autouse=True)
 def nms_broad(request, monkeypatch):
     from d3d_amd import _lib, box
     mode = getattr(request, "param", "auto")
-    monkeypatch.setattr(box, "default_nms_flags", {"auto": 0, "grid": _lib.NMS_GENERAL, "sweep": _lib.NMS_BROAD_SWEEP}[mode])
+    monkeypatch.setattr(box, "default_nms_flags", {"auto": 0, "grid": _lib.NMS_GENERAL, "sweep": _lib.NMS_BROAD_SWEEP,
+                                                   "levels": _lib.NMS_FORCE_LEVELS}[mode])
     monkeypatch.setattr(box, "poison_outputs", True)    # every IoU / iou3d result buffer of this module starts as NaN
     yield mode
 
@@ -484,10 +486,11 @@ def test_nms_fp32_scores_sorted_narrow():
     assert np.array_equal(keep2, exp)
 
 
-@pytest.mark.parametrize("nobj,per", [(30, 100), (8, 400)])
+@pytest.mark.parametrize("nobj,per", [(30, 100), (8, 400), (60, 300), (3, 3000)])
 def test_nms_detector_like_clusters(nobj, per):
-    """clusters of heavily overlapping boxes around each object (hundreds of hitters per box): incoming lists of any
-    length keep this on the list path; keep mask bit-exact with the oracle"""
+    """clusters of heavily overlapping boxes around each object (hundreds of hitters per box; cell lists spanning many
+    wavefronts of the level kernels): the levels decide most of a cluster before any pair is listed, incoming lists of any
+    length keep the rest on the list path; keep mask bit-exact with the oracle"""
     from d3d_amd.box import box2d_nms
     rng = np.random.default_rng(nobj)
     c = np.stack([rng.random(nobj) * 300, rng.random(nobj) * 300, rng.random(nobj) * 20 + 10, rng.random(nobj) * 20 + 10,

@@ -115,6 +115,25 @@ def test_dense_vs_oracle_100k(reduction, dist):
     check_dense(ret, exp, 8)
 
 
+@pytest.mark.parametrize("c", [3, 5, 6, 7, 8])
+@pytest.mark.parametrize("P,reduction", [(32, "mean"), (8, "max"), (12, "min"), (32, "none"), (5, "mean")])
+def test_dense_rows_of_other_widths_vs_oracle(c, P, reduction):
+    """C = 3, 5 .. 8 columns take the one-launch output kernel for C-float rows (when P * C is a multiple of 4; P = 5 with an odd C
+    takes the generic kernels): voxels, pmask, coords bit-exact, aggregates bit-exact within max_points, overflow voxels (the
+    400-point voxels next to the sensor and a planted one of 3000 points) to the fp32 bound"""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    base = synth.lidar_like(150000, 21)
+    rng = np.random.default_rng(c)
+    cloud = np.concatenate([base[:, :3], rng.random((len(base), c - 3), dtype=np.float32) * 10 - 5], 1).astype(np.float32)
+    cloud[1000:4000, :3] = cloud[999, :3] + rng.random((3000, 3), dtype=np.float32) * 0.01       # one heavy voxel
+    kw = dict(reduction=reduction, max_points=P, max_voxels=90000, dense=True)
+    exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(cloud)
+    ret = _np(VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(torch.from_numpy(cloud).cuda()))
+    check_dense(ret, exp, P)
+    assert exp["voxel_npoints"].max() > 2000 and len(exp["coords"]) > 30000
+
+
 def test_sparse_vs_oracle_100k():
     from d3d_amd import synth
     from d3d_amd.voxel import VoxelGenerator

@@ -26,6 +26,15 @@ show("iou2dr_backward dense 3k x 3k fp64", lambda: iou2dr_backward(bdt, bdt, gd)
 pts = torch.rand(1000000, 2, device="cuda") * 100
 boxes = torch.rand(2000, 5, device="cuda") * torch.tensor([100, 100, 5, 5, 3.14], device="cuda")
 show("crop_2dr 2000 boxes x 1M points fp32", lambda: crop_2dr(pts, boxes), 2e9)
+from d3d_amd.abstraction import crop_points, paint_label
+cloud = torch.cat([torch.rand(1000000, 2, device="cuda") * 100, torch.rand(1000000, 1, device="cuda") * 4 - 2,
+                   torch.rand(1000000, 1, device="cuda")], 1)
+b3 = torch.cat([torch.rand(2000, 2, device="cuda") * 100, torch.rand(2000, 1, device="cuda") * 2 - 1,
+                torch.rand(2000, 3, device="cuda") * 4 + 1, torch.rand(2000, 1, device="cuda") * 6.28], 1)
+show("crop_points 2000 boxes x 1M points (bool[M,N])", lambda: crop_points(b3, cloud), 2e9)
+sem = torch.randint(0, 4, (1000000,), device="cuda", dtype=torch.uint8)
+lab = torch.randint(0, 4, (2000,), device="cuda", dtype=torch.uint8)
+show("paint_label 2000 boxes x 1M points (uint16[N])", lambda: paint_label(b3, cloud, sem, lab), 2e9)
 img = torch.rand(2, 64, 200, 176, device="cuda")
 coord = torch.cat([torch.randint(0, 2, (500000, 1), device="cuda").float(), torch.rand(500000, 1, device="cuda") * 199,
                    torch.rand(500000, 1, device="cuda") * 175], 1)

@@ -13,11 +13,16 @@ def clustered(nobj, per, seed):
     b = np.repeat(c, per, 0) + rng.normal(0, 1, (nobj * per, 5)) * [1.5, 1.5, 1.0, 1.0, 0.05]
     return b, rng.random(nobj * per)
 
-for nobj, per in [(1000, 100), (5000, 20), (200, 500)]:
+from d3d_amd import _lib, box
+modes = {"default": 0, "1 level": _lib.nms_levels(1), "3 levels": _lib.nms_levels(3)}
+for nobj, per in [(1000, 100), (5000, 20), (200, 500), (20000, 5)]:
     b, s = clustered(nobj, per, 1)
     bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
-    f = lambda: box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5)
-    dt = timed(f, 5, 1)
-    prof = kernel_profile(f, 3)
-    print("%d objects x %d boxes: %.2f ms, kept %d" % (nobj, per, dt / 5 * 1e3, int(f().sum())),
-          {k: round(v["total_ms"] / 3 * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:6]})
+    for tag, fl in modes.items():
+        box.default_nms_flags = fl
+        f = lambda: box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5)
+        dt = timed(f, 5, 1)
+        prof = kernel_profile(f, 3)
+        print("%d objects x %d boxes [%s]: %.2f ms, kept %d" % (nobj, per, tag, dt / 5 * 1e3, int(f().sum())),
+              {k: round(v["total_ms"] / 3 * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:7]})
+    box.default_nms_flags = 0
