@@ -313,6 +313,17 @@ def extras(args):
     sk = torch.from_numpy(rng.random(2000)).cuda()
     dt = timed(lambda: box2d_nms(bk, sk, iou_method="rbox", iou_threshold=0.5), 50, 5)
     ex["nms_rbox_fp64_topk2000_clustered_us_per_call"] = round(dt / 50 * 1e6, 1)
+    # a detector's RAW output: 100 k boxes in clusters around the objects (tools/nms_cluster_profile.py; the general path with
+    # its level kernels -- whether they are launched is a guess from the previous call, so the warm-up calls matter here)
+    for nobj, per in ((200, 500), (1000, 100)):
+        rc = np.random.default_rng(1)
+        cc = np.stack([rc.random(nobj) * 2000, rc.random(nobj) * 2000, rc.random(nobj) * 20 + 10, rc.random(nobj) * 20 + 10,
+                       rc.random(nobj) * 6.28], 1)
+        bc = torch.from_numpy(np.repeat(cc, per, 0) + rc.normal(0, 1, (nobj * per, 5)) * [1.5, 1.5, 1.0, 1.0, 0.05]).cuda()
+        sc = torch.from_numpy(rc.random(nobj * per)).cuda()
+        dt = timed(lambda: box2d_nms(bc, sc, iou_method="rbox", iou_threshold=0.5), 10, 3)
+        ex["nms_rbox_fp64_clusters_%dx%d_ms" % (nobj, per)] = round(dt / 10 * 1e3, 3)
+        del bc, sc
     from d3d_amd.box import argsort_desc
     s100 = torch.from_numpy(np.random.default_rng(1).random(n3)).cuda()
     dt = timed(lambda: argsort_desc(s100), 50, 5)

@@ -19,11 +19,7 @@ STATUS_COORD_OVERFLOW, STATUS_TABLE_FULL, STATUS_PACK_OVERFLOW, STATUS_BIN_OVERF
 F32, F64 = 0, 1
 # per-call option bits (include/d3d_hip.h)
 VOXEL_PATH_HASH, VOXEL_PLAIN_SLOTS, VOXEL_SPLIT_FILL = 1, 4, 8
-NMS_BROAD_SWEEP, NMS_FORCE_DENSE, NMS_SOFT_NO_LDS, NMS_GENERAL, NMS_TEST_WITHHOLD, NMS_FORCE_LEVELS = 1, 2, 4, 8, 16, 32
-
-
-def nms_levels(k):
-    return (int(k) & 3) << 6
+NMS_BROAD_SWEEP, NMS_FORCE_DENSE, NMS_SOFT_NO_LDS, NMS_GENERAL, NMS_TEST_WITHHOLD, NMS_FORCE_LEVELS, NMS_ONE_LEVEL = 1, 2, 4, 8, 16, 32, 64
 
 
 def nms_cand_cap(k):

@@ -608,7 +608,7 @@ constexpr int kGridPad = 16;           // one cell counter per 64-byte line: ato
                                        // atomics on one word (gridreg 35 -> ? us with 5 k cells packed into 335 lines)
 struct NmsGrid { float ox, oy, inv_h; int gx, gy; unsigned int ticket, entries; };
 // the levels of the greedy result (k_nms_level_*, below) run when the grid is dense
-constexpr int kNmsLevels = 2;             // default number of levels (D3D_NMS_LEVELS(k) overrides per call)
+constexpr int kNmsLevels = 2;             // number of levels (D3D_NMS_ONE_LEVEL: one)
 constexpr unsigned long long kNmsLevelDensity = 128;
 constexpr int kNmsLevelChunks = 3;      // k_nms_level_block: chunks of 64 partners a wavefront tests before it gives up
 __device__ __forceinline__ bool nms_levels_on(const NmsGrid &g, const NmsCand *hdr)
@@ -1959,7 +1959,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
         D3D_LAUNCH("k_nms_gridreg<place>", k_nms_gridreg<true>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
                    cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, 0u,
                    (const uint32_t *)cellstart, (const uint8_t *)state, regopen);
-        unsigned int levels = ((opts >> 6) & 3u) ? ((opts >> 6) & 3u) : (unsigned int)kNmsLevels;
+        unsigned int levels = (opts & D3D_NMS_ONE_LEVEL) ? 1u : (unsigned int)kNmsLevels;
         int *hint_dev = nullptr;
         bool launch_levels = true;
         nms_dense_hint(st, &hint_dev, &launch_levels);
@@ -2465,7 +2465,7 @@ extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *o
                          void *stream, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL | D3D_NMS_TEST_WITHHOLD | D3D_NMS_FORCE_LEVELS | D3D_NMS_LEVELS(3)))) return D3D_ERR_BAD_ARG;
+    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL | D3D_NMS_TEST_WITHHOLD | D3D_NMS_FORCE_LEVELS | D3D_NMS_ONE_LEVEL))) return D3D_ERR_BAD_ARG;
     if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;   // common.h:25
     if (suppression_type != D3D_SUPPRESS_HARD && suppression_type != D3D_SUPPRESS_LINEAR &&

@@ -25,6 +25,14 @@ __device__ __forceinline__ Box3 load_box3(const float *__restrict__ b)
     return r;
 }
 
+// the cheap part of the test: z interval and the rectangle's bounding box (a point that fails it is outside)
+__device__ __forceinline__ bool near3(const Box3 &b, float x, float y, float z)
+{
+    if (z > b.zhi || z < b.zlo) return false;                                   // dgal_wrap.h:12-13 (NaN z: inside, as there)
+    const BoxGeom<float> &g = b.g;
+    return x >= g.xmin && x <= g.xmax && y >= g.ymin && y <= g.ymax;             // :14-15
+}
+
 __device__ __forceinline__ bool contains3(const Box3 &b, float x, float y, float z)
 {
     if (z > b.zhi || z < b.zlo) return false;                                   // dgal_wrap.h:12-13 (NaN z: inside, as there)
@@ -65,8 +73,13 @@ __global__ __launch_bounds__(256) void k_crop3dr(const float *__restrict__ point
     for (int r = 0; r < nrows; r++) {
         const Box3 b = rows[r];
         uint32_t word = 0;
+        bool near = false;                       // z interval + bounding box first: most (wavefront, box) pairs end here
 #pragma unroll
-        for (int k = 0; k < 4; k++) word |= (contains3(b, px[k], py[k], pz[k]) ? 1u : 0u) << (8 * k);
+        for (int k = 0; k < 4; k++) near = near || near3(b, px[k], py[k], pz[k]);
+        if (__ballot(near)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) word |= (contains3(b, px[k], py[k], pz[k]) ? 1u : 0u) << (8 * k);
+        }
         uint8_t *dst = out + (i0 + r) * n + j0;
         if (vec) *reinterpret_cast<uint32_t *>(dst) = word;
         else
@@ -78,6 +91,7 @@ __global__ __launch_bounds__(256) void k_crop3dr(const float *__restrict__ point
 // class equals the point's semantic label (the reference paints boxes M-1 .. 0, so the lowest index -- the best score of a
 // sorted array -- is written last), 0 if none.  One lane per point walks the boxes in ascending order and stops at its first
 // hit; the bool[M,N] mask of the reference never exists.  uint16 like there: ib + 1 wraps beyond 65535 boxes.
+constexpr int kPaintPts = 4;        // points per lane: a box's record is read from LDS once for four tests
 __global__ __launch_bounds__(256) void k_paint_label(const float *__restrict__ points, int64_t n, int pstride,
                                                      const uint8_t *__restrict__ semantics, const float *__restrict__ boxes,
                                                      int64_t m, int bstride, int boff, const uint8_t *__restrict__ labels,
@@ -85,12 +99,23 @@ __global__ __launch_bounds__(256) void k_paint_label(const float *__restrict__ p
 {
     __shared__ Box3 rows[kBoxTile];
     __shared__ uint8_t cls[kBoxTile];
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = j < n;
-    const float x = ok ? points[j * pstride] : 0.f, y = ok ? points[j * pstride + 1] : 0.f, z = ok ? points[j * pstride + 2] : 0.f;
-    const uint8_t sem = ok ? semantics[j] : 0;
-    bool found = !ok;
-    uint16_t id = 0;
+    // lane = points j0 + k * 256 (k < kPaintPts): consecutive lanes read consecutive points
+    const int64_t j0 = (int64_t)blockIdx.x * (256 * kPaintPts) + threadIdx.x;
+    float x[kPaintPts], y[kPaintPts], z[kPaintPts];
+    uint8_t sem[kPaintPts];
+    uint16_t id[kPaintPts];
+    bool found[kPaintPts];
+#pragma unroll
+    for (int k = 0; k < kPaintPts; k++) {
+        const int64_t j = j0 + (int64_t)k * 256;
+        const bool ok = j < n;
+        x[k] = ok ? points[j * pstride] : 0.f;
+        y[k] = ok ? points[j * pstride + 1] : 0.f;
+        z[k] = ok ? points[j * pstride + 2] : 0.f;
+        sem[k] = ok ? semantics[j] : 0;
+        id[k] = 0;
+        found[k] = !ok;
+    }
     for (int64_t i0 = 0; i0 < m; i0 += kBoxTile) {
         const int nrows = (int)((m - i0) < kBoxTile ? (m - i0) : kBoxTile);
         __syncthreads();
@@ -98,16 +123,34 @@ __global__ __launch_bounds__(256) void k_paint_label(const float *__restrict__ p
             rows[threadIdx.x] = load_box3(boxes + (i0 + threadIdx.x) * bstride + boff);
             cls[threadIdx.x] = labels[i0 + threadIdx.x];
         }
-        __syncthreads();
-        if (__syncthreads_and(found)) break;                   // every point of the workgroup is painted
-        for (int r = 0; r < nrows && !found; r++) {
-            if (cls[r] == sem && contains3(rows[r], x, y, z)) {
-                id = (uint16_t)(i0 + r + 1);
-                found = true;
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < kPaintPts; k++) all = all && found[k];
+        if (__syncthreads_and(all)) break;                     // every point of the workgroup is painted (also the tile barrier)
+        // the class, the z interval and the bounding box first; the four half-planes only for the boxes that SOME lane of the
+        // wavefront comes near (a wavefront's points lie anywhere in the scene: a few % of the (wavefront, box) pairs)
+        for (int r = 0; r < nrows; r++) {
+            const uint8_t c = cls[r];
+            bool near[kPaintPts], any = false;
+#pragma unroll
+            for (int k = 0; k < kPaintPts; k++) {
+                near[k] = !found[k] && c == sem[k] && near3(rows[r], x[k], y[k], z[k]);
+                any = any || near[k];
             }
+            if (__ballot(any) == 0) continue;
+#pragma unroll
+            for (int k = 0; k < kPaintPts; k++)
+                if (near[k] && contains3(rows[r], x[k], y[k], z[k])) {
+                    id[k] = (uint16_t)(i0 + r + 1);
+                    found[k] = true;
+                }
         }
     }
-    if (ok) idarr[j] = id;
+#pragma unroll
+    for (int k = 0; k < kPaintPts; k++) {
+        const int64_t j = j0 + (int64_t)k * 256;
+        if (j < n) idarr[j] = id[k];
+    }
 }
 
 }  // namespace
@@ -137,7 +180,7 @@ extern "C" int d3d_paint_label(const float *points, int64_t n, int32_t point_str
     if (n < 0 || m < 0 || point_stride < 3 || box_offset < 0 || box_stride < box_offset + 7) return D3D_ERR_BAD_ARG;
     if (n == 0) return D3D_OK;
     if (!points || !semantics || !idarr || (m > 0 && (!boxes || !labels))) return D3D_ERR_BAD_ARG;
-    D3D_LAUNCH("k_paint_label", k_paint_label, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, points, n, (int)point_stride,
+    D3D_LAUNCH("k_paint_label", k_paint_label, dim3((unsigned)d3d_divup(n, 256 * kPaintPts)), dim3(256), 0, st, points, n, (int)point_stride,
                semantics, boxes, m, (int)box_stride, (int)box_offset, labels, idarr);
     return D3D_OK;
 }

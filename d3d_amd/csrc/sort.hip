@@ -47,7 +47,7 @@ int library_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws
     return D3D_OK;
 }
 
-// ---------------------------------------------------------------- bucket path (8 k .. 128 k keys: the NMS sizes)
+// ---------------------------------------------------------------- bucket path (2 k .. 128 k keys: the NMS sizes)
 // The library sorts this range with a block sort + one merge launch per doubling (9 launches, 70 us at 100 k keys: launch
 // latency, not bandwidth).  Here: a sample sort in 4 launches --
 //   k_ss_splitters  one workgroup sorts 1024 stratified samples in LDS and keeps every (1024 / B)-th as a splitter
@@ -69,7 +69,7 @@ int library_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws
 // the 55-66 of a workgroup-wide bitonic network, which took 22 us per bucket.
 constexpr int kSsSamples = 1024, kSsTile = 1024, kSsCountThreads = 512, kSsMaxBuckets = 512, kSsBucketBits = 9;
 constexpr int kSsSortThreads = 1024, kSsBucketCap = 2048;
-constexpr int64_t kSsMinN = 8192, kSsMaxN = (int64_t)kSsMaxBuckets * 256;
+constexpr int64_t kSsMinN = 2049, kSsMaxN = (int64_t)kSsMaxBuckets * 256;      // (below: k_sort_small, one launch)
 
 __device__ __forceinline__ uint32_t ss_hash(uint32_t x)
 {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kSsSortThreads) void k_ss_splitters(const K *__rest
     typedef typename KeyBits<K>::U U;
     __shared__ U d0[kSsSamples], d1[kSsSamples];
     __shared__ uint32_t i0[kSsSamples], i1[kSsSamples];
-    const uint32_t len = n / kSsSamples;                     // n >= kSsMinN: >= 8
+    const uint32_t len = n / kSsSamples;                     // n >= kSsMinN: >= 2
     for (int j = threadIdx.x; j < kSsSamples; j += blockDim.x) {
         const uint32_t pos = (uint32_t)j * len + ss_hash((uint32_t)j) % len;     // one sample per stratum, jittered
         d0[j] = KeyBits<K>::desc(keys[pos]);
@@ -194,6 +194,28 @@ __global__ __launch_bounds__(kSsSortThreads) void k_ss_bucket(const U *__restric
     for (uint32_t e = threadIdx.x; e < m; e += blockDim.x) order[base + e] = (V)ii[e];
 }
 
+// ---------------------------------------------------------------- up to kSsBucketCap keys: ONE launch, one workgroup, in LDS
+// (the library: block sort + merge launches, 25-40 us of launch latency for a few hundred keys)
+template <typename K, typename V>
+__global__ __launch_bounds__(kSsSortThreads) void k_sort_small(const K *__restrict__ keys, uint32_t n, V *__restrict__ order)
+{
+    typedef typename KeyBits<K>::U U;
+    __shared__ U d0[kSsBucketCap], d1[kSsBucketCap];
+    __shared__ uint32_t i0[kSsBucketCap], i1[kSsBucketCap];
+    int npad = kWave;
+    while ((uint32_t)npad < n) npad <<= 1;
+    for (int e = threadIdx.x; e < npad; e += blockDim.x) {
+        d0[e] = (uint32_t)e < n ? KeyBits<K>::desc(keys[e]) : ~(U)0;     // padding sorts behind every real entry
+        i0[e] = (uint32_t)e < n ? (uint32_t)e : 0x80000000u + (uint32_t)e;
+    }
+    __syncthreads();
+    U *d;
+    uint32_t *ii;
+    if (npad <= kSsSortThreads) sort_lds<1>(d0, i0, d1, i1, npad, &d, &ii);
+    else sort_lds<2>(d0, i0, d1, i1, npad, &d, &ii);
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) order[e] = (V)ii[e];
+}
+
 static inline int ss_buckets(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(n / 192, 16), kSsMaxBuckets); }
 static inline bool ss_eligible(int64_t n) { return n >= kSsMinN && n <= kSsMaxN; }
 
@@ -244,6 +266,10 @@ template <typename K, typename V>
 int argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st, bool library_only = false)
 {
     if (n <= 0) return D3D_OK;
+    if (n <= kSsBucketCap && !library_only) {
+        D3D_LAUNCH("k_sort_small", (k_sort_small<K, V>), dim3(1), dim3(kSsSortThreads), 0, st, keys, (uint32_t)n, order);
+        return D3D_OK;
+    }
     if (ss_eligible(n) && !library_only) return bucket_argsort_desc<K, V>(keys, n, order, ws, ws_bytes, st);
     return library_argsort_desc<K, V>(keys, n, order, ws, ws_bytes, st);
 }

@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
                                                    const int32_t *__restrict__ npoints,
                                                    const uint32_t *__restrict__ voff, const uint32_t *__restrict__ list,
                                                    const uint32_t *__restrict__ unsorted, uint32_t max_points,
-                                                   int reduction, float *agg, int only_overflow = 0 /* the rest is done (k_emit_c) */)
+                                                   int reduction, float *agg)
 {
     const int64_t total = counts[D3D_COUNT_VOXELS] * (int64_t)c;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ poi
         const int64_t v = valid ? t / c : 0;
         const int d = (int)(t - v * c);
         const uint32_t cnt = valid ? (uint32_t)npoints[v] : 0u;
-        if (valid && cnt <= max_points && !only_overflow) {
+        if (valid && cnt <= max_points) {
             const uint32_t base = voff[v];
             float acc = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
             for (uint32_t k = 0; k < cnt; k++) {
@@ -1541,8 +1541,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
 
 // 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF (<= 256 of them:
 // k_meta_first adds up the ones before its tile itself, which is cheaper than a scan launch or a last-block pass)
-__global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict__ firstmap, uint32_t *fwpre, uint32_t *bsumF)
+__global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict__ firstmap, uint32_t *fwpre, uint32_t *bsumF,
+                                                      uint32_t *clear_word = nullptr /* k_emit_c's overflow-voxel counter */)
 {
+    if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0;
     __shared__ u64 smem[1024 / kWave];
     __shared__ uint32_t wcnt[256];
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
@@ -1809,6 +1811,60 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     }
 }
 
+// aggregates of the voxels with MORE than max_points points, all channels of a voxel at once (k_emit_c did the others and
+// listed these): one wavefront per listed voxel walks its arrival-ordered index list, 64 rows per step, every row read once.
+// Sums in fp64 (see k_aggregate).
+__global__ __launch_bounds__(256) void k_aggregate_overflow(const float *__restrict__ points, int c,
+                                                            const uint32_t *__restrict__ ov_list, const uint32_t *__restrict__ ov_count,
+                                                            const int32_t *__restrict__ npoints, const uint32_t *__restrict__ voff,
+                                                            const uint32_t *__restrict__ unsorted, int reduction, float *agg)
+{
+    constexpr int kMaxC = 8;
+    const uint32_t total = *ov_count;
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
+    const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
+    for (uint32_t e = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6); e < total; e += nwaves) {
+        const int64_t vv = ov_list[e];
+        const uint32_t cc = (uint32_t)npoints[vv];
+        const uint32_t *seg = unsorted + voff[vv];
+        double sum[kMaxC];
+        float ext[kMaxC];
+#pragma unroll
+        for (int d = 0; d < kMaxC; d++) { sum[d] = 0.0; ext[d] = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY; }
+        for (uint32_t k = lane; k < cc; k += kWave) {
+            const float *row = points + (int64_t)seg[k] * c;
+#pragma unroll
+            for (int d = 0; d < kMaxC; d++)
+                if (d < c) {
+                    const float x = row[d];
+                    if (is_sum) sum[d] += (double)x;
+                    else if (reduction == D3D_REDUCE_MAX) ext[d] = ext[d] < x ? x : ext[d];
+                    else ext[d] = x < ext[d] ? x : ext[d];
+                }
+        }
+#pragma unroll
+        for (int d = 0; d < kMaxC; d++) {
+            if (d >= c) break;
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) {
+                const double s2 = __shfl_xor(sum[d], o, kWave);
+                const float e2 = __shfl_xor(ext[d], o, kWave);
+                sum[d] += s2;
+                if (reduction == D3D_REDUCE_MAX) ext[d] = ext[d] < e2 ? e2 : ext[d];
+                else ext[d] = e2 < ext[d] ? e2 : ext[d];
+            }
+            if (lane == 0) {
+                float r;
+                if (reduction == D3D_REDUCE_MEAN) r = (float)sum[d] / (float)(int32_t)cc;      // (as k_aggregate)
+                else if (is_sum) r = (float)sum[d];
+                else r = ext[d];
+                agg[vv * c + d] = r;
+            }
+        }
+    }
+}
+
 // The same for rows of C != 4 floats (C = 3, 5 .. 8: x, y, z + up to five features): the row buffer holds C floats per row,
 // the stretch of a wavefront's voxels is still ONE contiguous run of nv * P * C floats, written 16 bytes per lane -- a piece
 // may straddle two rows, so its four floats are looked up one by one (P * C is a multiple of 4: every voxel, hence every
@@ -1823,7 +1879,7 @@ __global__ __launch_bounds__(256) void k_emit_c(Key kf, int64_t npad, const uint
                                                 const float *__restrict__ points, const uint32_t *__restrict__ ranked,
                                                 uint32_t P, int pshift /* log2 P or -1 */, int reduction, int64_t *coords,
                                                 int32_t *npoints, unsigned char *pmask, float *agg, uint32_t *voff, float *voxels,
-                                                int64_t *counts, int64_t *host_counts)
+                                                int64_t *counts, int64_t *host_counts, uint32_t *ov_list, uint32_t *ov_count)
 {
     typedef float vec4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float rowbuf_all[256 / kWave][kEmitCap * C];
@@ -1949,6 +2005,9 @@ __global__ __launch_bounds__(256) void k_emit_c(Key kf, int64_t npad, const uint
             cbuf[lane * 3 + 0] = cc[0]; cbuf[lane * 3 + 1] = cc[1]; cbuf[lane * 3 + 2] = cc[2];
             __builtin_nontemporal_store((int32_t)cnt, &npoints[v]);
             if (voff) voff[v] = base;
+            // voxels with more than P points: listed for k_aggregate_overflow (they sit next to the sensor = among the first
+            // voxel ids: found by a scan over the voxels, a handful of wavefronts would get them all)
+            if (reduction != D3D_REDUCE_NONE && cnt > P) ov_list[atomicAdd(ov_count, 1u)] = (uint32_t)v;
         }
         wave_lds_fence();
         long long *cdst = reinterpret_cast<long long *>(coords) + (int64_t)vid0 * 3;
@@ -2433,7 +2492,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
                    precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 512 (n <= 8 M)
-    D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF);
+    D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, w.big_count);
     const dim3 grid((unsigned)(w.npad / 256));
     if constexpr (!ROWS && std::is_same<Key, DenseKey>::value) {
         if (o.emit_generic) {
@@ -2441,7 +2500,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
 #define D3D_EMIT_C(CC)                                                                                                          \
     D3D_LAUNCH("k_emit_c", (k_emit_c<Key, CC>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec, o.max_voxels,  \
                points, w.big_list, o.P, pshift, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr, o.aggregates,   \
-               w.voff, o.emit_generic, counts, x.host_counts)
+               w.voff, o.emit_generic, counts, x.host_counts, reinterpret_cast<uint32_t *>(w.vinfo), w.big_count)
             switch (c) {
             case 3: D3D_EMIT_C(3); break;
             case 5: D3D_EMIT_C(5); break;
@@ -2585,8 +2644,9 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
         if (!fuse_pmask)
             D3D_LAUNCH("k_pmask", k_pmask, dim3(grid_for(d3d_divup(cap * P, 16), 256)), dim3(256), 0, st, counts, npoints, P, pmask);
         if (emitted_generic && reduction != D3D_REDUCE_NONE)          // voxels with more than P points: all their points count
-            D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(cap * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
-                       w.voff, w.big_list, w.unsorted, P, reduction, aggregates, 1);
+            D3D_LAUNCH("k_aggregate_overflow", k_aggregate_overflow, dim3(1024), dim3(256), 0, st, points, c,
+                       (const uint32_t *)reinterpret_cast<uint32_t *>(w.vinfo), (const uint32_t *)w.big_count, (const int32_t *)npoints,
+                       (const uint32_t *)w.voff, (const uint32_t *)w.unsorted, reduction, aggregates);
         return D3D_OK;
     }
     if (vec4 && n <= kFillRowsMaxPoints) {

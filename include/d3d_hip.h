@@ -446,13 +446,13 @@ size_t d3d_nms2d_workspace_bytes(int64_t n);
  *   4096 boxes; D3D_NMS_TEST_WITHHOLD = test hook: the first workgroup of a one-launch scan (the grid's cell scan; with
  *   D3D_NMS_BROAD_SWEEP the scan of the incoming-list sizes) withholds its total, so the scan gives up after ~0.1 s and hands
  *   the call to the dense path; D3D_NMS_FORCE_LEVELS = the uniform grid's level kernels (roots of the greedy result decided
- *   before any pair is listed; automatic on dense grids: clusters of detections) on any input, implies the general path.
+ *   before any pair is listed; automatic on dense grids: clusters of detections) on any input, implies the general path;
+ *   D3D_NMS_ONE_LEVEL = one level of them instead of two (clusters of a few boxes).
  *   All give the same mask.
  *   soft-NMS has no size limit of its own (100 k boxes with most of them alive: seconds). */
 enum { D3D_NMS_BROAD_SWEEP = 1, D3D_NMS_FORCE_DENSE = 2, D3D_NMS_SOFT_NO_LDS = 4, D3D_NMS_GENERAL = 8, D3D_NMS_TEST_WITHHOLD = 16,
-       D3D_NMS_FORCE_LEVELS = 32 };
+       D3D_NMS_FORCE_LEVELS = 32, D3D_NMS_ONE_LEVEL = 64 };
 #define D3D_NMS_CAND_CAP(k) ((uint32_t)(k) << 8)
-#define D3D_NMS_LEVELS(k) (((uint32_t)(k) & 3u) << 6)      /* 1..3 levels of the grid's level kernels instead of the default 2 */
 int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n,
               int32_t iou_type, int32_t suppression_type, int32_t dtype,
               float iou_threshold, float score_threshold, float suppression_param,

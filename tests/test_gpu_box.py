@@ -497,10 +497,14 @@ def test_nms_detector_like_clusters(nobj, per):
                   rng.random(nobj) * 6.28], 1)
     b = np.repeat(c, per, 0) + rng.normal(0, 1, (nobj * per, 5)) * [1.5, 1.5, 1.0, 1.0, 0.05]
     s = rng.permutation(nobj * per) / (nobj * per)
+    from d3d_amd import _lib, box
+    base = box.default_nms_flags
     for method, thr in [("rbox", 0.5), ("box", 0.3)]:
-        keep = box2d_nms(T(b), T(s), iou_method=method, iou_threshold=thr).cpu().numpy()
         exp = oracle.box2d_nms(b, s, iou_method=method, iou_threshold=thr)
-        assert np.array_equal(keep, exp), (method, int(np.sum(keep != exp)))
+        for extra in (0, _lib.NMS_ONE_LEVEL):             # (two levels of the level kernels, or one)
+            box.default_nms_flags = base | extra          # (the fixture's monkeypatch restores it)
+            keep = box2d_nms(T(b), T(s), iou_method=method, iou_threshold=thr).cpu().numpy()
+            assert np.array_equal(keep, exp), (method, extra, int(np.sum(keep != exp)))
         assert keep.sum() < 20 * nobj
 
 

@@ -14,7 +14,7 @@ def clustered(nobj, per, seed):
     return b, rng.random(nobj * per)
 
 from d3d_amd import _lib, box
-modes = {"default": 0, "1 level": _lib.nms_levels(1), "3 levels": _lib.nms_levels(3)}
+modes = {"default": 0, "1 level": _lib.NMS_ONE_LEVEL}
 for nobj, per in [(1000, 100), (5000, 20), (200, 500), (20000, 5)]:
     b, s = clustered(nobj, per, 1)
     bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
