@@ -1032,7 +1032,11 @@ __global__ __launch_bounds__(256) void k_overflow_reduce(const float4 *__restric
 // work -- voxel lookup, counting, first index, rank in point order -- in LDS and writes the rows next to their rank.
 // Numbering by first occurrence stays a prefix count over point indices; it is merged with the per-voxel outputs
 // (k_meta_first), whose stores are then coalesced by voxel id.
-constexpr int kBinTile = 4096;                // points per workgroup in k_bin_count / k_bin_scatter
+constexpr int kBinTile = 4096;                // points per pass of a workgroup of k_bin_count / k_bin_scatter
+// passes per workgroup: a workgroup's tile is kBinTile * bin_passes(n) points.  Frames above 2 M points take 4 -- the tile x
+// bucket matrix (written by k_bin_count, scanned by k_bin_scan, read by k_bin_scatter) shrinks by that factor: 64 -> 16 MB
+// at 8 M points, where scanning it cost 89 us
+static inline int bin_passes(int64_t n) { return n > (2 << 20) ? 4 : 1; }
 constexpr int kBinThreads = 1024;             // ... 4 per lane: 16 wavefronts per CU keep the loads in flight
 constexpr int kBinBits = 13;
 constexpr int kBinMax = 1 << kBinBits;        // buckets (13 bits of the per-point word, 12 more for the rank in the tile)
@@ -1103,18 +1107,18 @@ constexpr uint32_t kBadBin = 0xfffffffeu;     // the point's coordinates overflo
                                               // kernel resets the counters while it runs)
 template <class Key, bool VEC4, bool ROWS>
 __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *__restrict__ points, int64_t n, int c, uint32_t nbins,
-                                                           uint32_t ntiles, uint32_t *__restrict__ pbin,
+                                                           uint32_t passes, uint32_t *__restrict__ pbin,
                                                            typename BinEntry<ROWS>::key_store_t *__restrict__ pkey,
                                                            uint32_t *__restrict__ tilecnt, uint32_t *__restrict__ firstmap,
                                                            int64_t *counts, int64_t *mapping, unsigned char *trimmed,
                                                            int32_t *keepid)
 {
     __shared__ uint32_t h[kBinMax];
-    (void)ntiles;
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) h[b] = 0;
     if (blockIdx.x == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kBinTile + threadIdx.x;
+    for (uint32_t pass = 0; pass < passes; pass++) {
+    const int64_t base = ((int64_t)blockIdx.x * passes + pass) * kBinTile + threadIdx.x;
     float v[kBinTile / kBinThreads][3];
 #pragma unroll
     for (int r = 0; r < kBinTile / kBinThreads; r++) {
@@ -1146,6 +1150,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
         if (mapping && i < n) mapping[i] = -1;      // points outside the grid keep it
         if (trimmed && i < n) trimmed[i] = 0;
         if (keepid && i < n) keepid[i] = -1;
+    }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) tilecnt[(size_t)blockIdx.x * nbins + b] = h[b];     // [tile][bucket]
@@ -1210,7 +1215,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
                                                              const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ totals,
                                                              uint32_t *__restrict__ bucket_base,
                                                              typename BinEntry<ROWS>::type *__restrict__ bent, int64_t *counts,
-                                                             bool keep_pos /* pbin[i] := the point's place in the buckets (kInf: none) */)
+                                                             bool keep_pos /* pbin[i] := the point's place in the buckets (kInf: none) */,
+                                                             uint32_t passes)
 {
     __shared__ uint32_t off[kBinMax];
     __shared__ u64 smem[kBinThreads / kWave];
@@ -1219,8 +1225,9 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
         for (uint32_t b = threadIdx.x; b <= nbins; b += kBinThreads) bucket_base[b] = b < nbins ? off[b] : off[nbins - 1] + totals[nbins - 1];
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) off[b] += tileoff[(size_t)blockIdx.x * nbins + b];
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kBinTile + threadIdx.x;
     bool bad = false;
+    for (uint32_t pass = 0; pass < passes; pass++) {
+    const int64_t base = ((int64_t)blockIdx.x * passes + pass) * kBinTile + threadIdx.x;
 #pragma unroll
     for (int r = 0; r < kBinTile / kBinThreads; r++) {
         const int64_t i = base + r * kBinThreads;
@@ -1234,6 +1241,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
         const uint32_t pos = off[word & (kBinMax - 1)] + (word >> kBinBits);
         bent[pos] = BinEntry<ROWS>::pack((u64)pkey[i], (uint32_t)i);
         if (keep_pos) pbin[i] = pos;            // (same lane read it: in place)
+    }
     }
     if (bad) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_COORD_OVERFLOW);
 }
@@ -1655,7 +1663,8 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
                                               const float4 *__restrict__ points4, const uint32_t *__restrict__ ranked,
                                               const float4 *__restrict__ staged, uint32_t P, int pshift /* log2 P or -1 */,
                                               int reduction, int64_t *coords, int32_t *npoints, unsigned char *pmask, float4 *agg,
-                                              float4 *voxels, int64_t *counts, int64_t *host_counts)
+                                              float4 *voxels /* NULL: no rows (reduce contract) */, int64_t *counts,
+                                              int64_t *host_counts, BinnedExtras x)
 {
     typedef float vec4 __attribute__((ext_vector_type(4)));
     __shared__ vec4 rowbuf_all[256 / kWave][kEmitCap];
@@ -1678,6 +1687,8 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     if (i == 0) {
         counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
         counts[D3D_COUNT_AUX] = 0;
+        // sharded voxelizer: the status bits travel with the key list (row `status_row`, negative = not a cell)
+        if (x.keys_out && x.status_row >= 0) x.keys_out[x.status_row] = -1 - counts[D3D_COUNT_STATUS];
         if (host_counts) notify_host(counts, host_counts);
     }
     const uint32_t e = firstmap[i];
@@ -1685,10 +1696,12 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     const uint32_t nfirst = (uint32_t)__popcll(bal);
     uint32_t nv = nfirst;
     const uint32_t vid0 = before + fwpre[i >> 6];
+    const uint32_t r = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (x.vidof)                                            // every lane: the voxel that STARTS at this point index, for the map
+        x.vidof[i] = (e != kInf && vid0 < max_voxels && r < max_voxels - vid0) ? vid0 + r : kNoVoxel;
     if (nv == 0 || vid0 >= max_voxels) return;             // wave-uniform
     if (nv > max_voxels - vid0) nv = max_voxels - vid0;     // voxelize.cpp:116-117: later voxels are never created
     // 1. compaction as a full permutation: the r-th first point sends {record position, own index} to lane r, the rest fill up
-    const uint32_t r = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
     const uint32_t dst = (e != kInf ? r : nfirst + ((uint32_t)lane - r)) << 2;
     const uint32_t el = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)e);
     const uint32_t il = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)(uint32_t)i);
@@ -1747,7 +1760,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
             }
         }
         // 4. the stretch of the batch's voxels
-        const uint32_t q1 = jb * P;
+        const uint32_t q1 = voxels ? jb * P : 0u;
         for (uint32_t q0 = ja * P; q0 < q1; q0 += 4 * kWave) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -1775,10 +1788,16 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
             kf.decode(((u64)rec.y << 32) | rec.x, cc);
             cbuf[lane * 3 + 0] = cc[0]; cbuf[lane * 3 + 1] = cc[1]; cbuf[lane * 3 + 2] = cc[2];
             __builtin_nontemporal_store((int32_t)cnt, &npoints[v]);
+            // reduce contract (sharded voxelizer): linear cell key, global index of the first point, segment base
+            if (x.keys_out) x.keys_out[v] = (int64_t)(((u64)rec.y << 32) | rec.x);
+            if (x.first_out) x.first_out[v] = x.index_offset + (int64_t)il;
+            if (x.voff) x.voff[v] = base;
         }
         wave_lds_fence();
-        long long *cdst = reinterpret_cast<long long *>(coords) + (int64_t)vid0 * 3;
-        for (uint32_t t = lane; t < nv * 3; t += kWave) __builtin_nontemporal_store(cbuf[t], &cdst[t]);
+        if (coords) {
+            long long *cdst = reinterpret_cast<long long *>(coords) + (int64_t)vid0 * 3;
+            for (uint32_t t = lane; t < nv * 3; t += kWave) __builtin_nontemporal_store(cbuf[t], &cdst[t]);
+        }
         if (pmask) {                                         // P % 16 == 0, 16-byte aligned (host-checked): 16-byte pieces
             const uint32_t per = P >> 4, total = nv * per;
             typedef uint32_t uvec4 __attribute__((ext_vector_type(4)));
@@ -2422,6 +2441,7 @@ struct DenseOut {
     uint32_t *seg_out = nullptr;        // reduce contract: segment base of every voxel's staged rows (for the caller)
     float4 *emit_voxels = nullptr;      // dense contract on C == 4 rows: k_emit writes voxels[V,P,4] too (no staging, no fill)
     float *emit_generic = nullptr;      // dense contract, C = 3, 5 .. 8: k_emit_c writes voxels[V,P,C] and the per-voxel outputs
+    bool emit_reduce = false;           // reduce contract without rows: k_emit without the stretch (nothing staged by the index)
 };
 
 // n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
@@ -2432,7 +2452,7 @@ static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t flags, uint32_
     int hshift = 0;
     while (nbins < (uint32_t)kBinMax && (int64_t)nbins * kBucketTarget < n) { nbins <<= 1; hshift++; }
     if ((int64_t)nbins * 1024 < n) return false;        // more than 8 M points: buckets would outgrow a workgroup
-    const uint64_t ntiles = (uint64_t)w.npad / kBinTile;
+    const uint64_t ntiles = d3d_divup((int64_t)(w.npad / kBinTile), (int64_t)bin_passes(n));
     if ((uint64_t)nbins * ntiles * 4 > w.cap * 8 || 2 * (uint64_t)nbins + 2 > w.cap) return false;
     *nbins_out = nbins;
     *hshift_out = hshift;
@@ -2449,7 +2469,7 @@ template <class Key, bool ROWS>
 static int binned_index(const Key &kf, const float *points, int64_t n, int c, const VoxelWs &w, uint32_t nbins, int hshift,
                         int64_t *counts, const DenseOut &o, hipStream_t st)
 {
-    const uint32_t ntiles = (uint32_t)(w.npad / kBinTile);
+    const uint32_t passes = (uint32_t)bin_passes(n), ntiles = (uint32_t)d3d_divup((int64_t)(w.npad / kBinTile), (int64_t)passes);
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
     typedef BinEntry<ROWS> E;
     typename E::type *bent = reinterpret_cast<typename E::type *>(w.tabA);      // cap * 8 bytes >= 16 n
@@ -2471,22 +2491,23 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     if (vec4)
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
-                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
+                   passes, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
     else
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, false, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
-                   ntiles, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
+                   passes, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
     D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, pkey, n, nbins, pbin, tilecnt, totals,
-               bucket_base, bent, counts, o.map_later);
+               bucket_base, bent, counts, o.map_later, passes);
     if (!ROWS && o.lists)
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    reinterpret_cast<const typename BinEntry<false>::type *>(bent), p4, bucket_base, hshift, o.P, (int)D3D_REDUCE_NONE,
                    w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
                    o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr);
-    else if (ROWS && o.emit_voxels)
+    else if (ROWS && (o.emit_voxels || o.emit_reduce))
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, true, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
-                   counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.unsorted, (uint32_t *)nullptr);
+                   counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list /* the per-point keys are
+                   done with it; w.unsorted may be precpos */, (uint32_t *)nullptr);
     else
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
@@ -2513,17 +2534,21 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         }
     }
     if constexpr (ROWS) {
-        if (o.emit_voxels) {
+        if (o.emit_voxels || o.emit_reduce) {
             const int pshift = (o.P & (o.P - 1)) == 0 ? __builtin_ctz(o.P) : -1;
             if (o.agg4)
                 D3D_LAUNCH("k_emit", (k_emit<Key, true>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
-                           o.max_voxels, p4, w.unsorted, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
+                           o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
                            o.fuse_pmask ? o.pmask : nullptr, reinterpret_cast<float4 *>(o.aggregates), o.emit_voxels, counts,
-                           x.host_counts);
+                           x.host_counts, x);
             else
                 D3D_LAUNCH("k_emit", (k_emit<Key, false>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
-                           o.max_voxels, p4, w.unsorted, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
-                           o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, o.emit_voxels, counts, x.host_counts);
+                           o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
+                           o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, o.emit_voxels, counts, x.host_counts, x);
+            if (want_map && !o.map_later)
+                D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
+                           reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping, o.keepid,
+                           (const unsigned char *)o.trimmed);
             return D3D_OK;
         }
     }
@@ -2738,6 +2763,7 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
         DenseOut d{P, 0xffffffffu, reduction, true, false, coords, npoints, nullptr, aggregates,
                    BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr, nullptr}, mapping};
         d.seg_out = seg_base;
+        d.emit_reduce = !rows && P <= (uint32_t)kEmitCap && !(flags & D3D_VOXEL_SPLIT_FILL);     // (rows: the index stages them)
         return binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
     }
     IndexOpts o{P, 0xffffffffu, first, index_offset, mapping, agg4};
