@@ -1038,8 +1038,9 @@ constexpr int kBinTile = 4096;                // points per pass of a workgroup 
 // at 8 M points, where scanning it cost 89 us
 static inline int bin_passes(int64_t n) { return n > (2 << 20) ? 4 : 1; }
 constexpr int kBinThreads = 1024;             // ... 4 per lane: 16 wavefronts per CU keep the loads in flight
-constexpr int kBinBits = 13;
-constexpr int kBinMax = 1 << kBinBits;        // buckets (13 bits of the per-point word, 12 more for the rank in the tile)
+constexpr int kBinBits = 14;
+constexpr int kBinMax = 1 << kBinBits;        // buckets (14 bits of the per-point word, 14 more for the rank in the tile): frames
+                                              // of up to 16 M points (round 3; 13 bits = 8 M before)
 constexpr int kBucketTarget = 512;            // mean points per bucket the partition aims at
 constexpr int kBucketCap = 2048;              // points one k_bucket_index workgroup holds in registers
 constexpr int kBucketThreads = 512;           // ... 4 per lane (256: 42 us, 512: 38 us, 1024: 44 us at config 2)
@@ -1113,7 +1114,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
                                                            int64_t *counts, int64_t *mapping, unsigned char *trimmed,
                                                            int32_t *keepid)
 {
-    __shared__ uint32_t h[kBinMax];
+    extern __shared__ uint32_t h[];                       // [nbins]: 2 KB (1 M points) .. 64 KB (16 M points), sized by the launch
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) h[b] = 0;
     if (blockIdx.x == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
     __syncthreads();
@@ -1218,7 +1219,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
                                                              bool keep_pos /* pbin[i] := the point's place in the buckets (kInf: none) */,
                                                              uint32_t passes)
 {
-    __shared__ uint32_t off[kBinMax];
+    extern __shared__ uint32_t off[];                     // [nbins], sized by the launch
     __shared__ u64 smem[kBinThreads / kWave];
     bucket_bases(totals, nbins, off, smem);
     if (blockIdx.x == 0)                                     // for k_bucket_index
@@ -2450,8 +2451,11 @@ static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t flags, uint32_
     if ((flags & D3D_VOXEL_PATH_HASH) || n <= 0) return false;
     uint32_t nbins = 1;
     int hshift = 0;
-    while (nbins < (uint32_t)kBinMax && (int64_t)nbins * kBucketTarget < n) { nbins <<= 1; hshift++; }
-    if ((int64_t)nbins * 1024 < n) return false;        // more than 8 M points: buckets would outgrow a workgroup
+    // buckets of ~512 points up to 8192 buckets, then of up to 1024 (8 M points with 16384 buckets of 512: scatter and bucket
+    // kernel 10 % slower than with 8192 of 1024), the last doubling only for frames that need it
+    while (nbins < 8192u && (int64_t)nbins * kBucketTarget < n) { nbins <<= 1; hshift++; }
+    while (nbins < (uint32_t)kBinMax && (int64_t)nbins * 1024 < n) { nbins <<= 1; hshift++; }
+    if ((int64_t)nbins * 1024 < n) return false;        // more than 16 M points: buckets would outgrow a workgroup
     const uint64_t ntiles = d3d_divup((int64_t)(w.npad / kBinTile), (int64_t)bin_passes(n));
     if ((uint64_t)nbins * ntiles * 4 > w.cap * 8 || 2 * (uint64_t)nbins + 2 > w.cap) return false;
     *nbins_out = nbins;
@@ -2489,14 +2493,19 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     x.kept_part = o.early_host ? kept_part : nullptr;
     x.voff = o.seg_out ? o.seg_out : (o.lists ? w.voff : nullptr);
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
+    const size_t bin_lds = (size_t)nbins * 4;                 // (at 16384 buckets the scatter's 64 KB + 128 B exceed the default limit)
+    if (bin_lds + 256 > 65536) {
+        D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_scatter<ROWS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
+    }
     if (vec4)
-        D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
+        D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles), dim3(kBinThreads), bin_lds, st, kf, points, n, c, nbins,
                    passes, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
     else
-        D3D_LAUNCH("k_bin_count", (k_bin_count<Key, false, ROWS>), dim3(ntiles), dim3(kBinThreads), 0, st, kf, points, n, c, nbins,
+        D3D_LAUNCH("k_bin_count", (k_bin_count<Key, false, ROWS>), dim3(ntiles), dim3(kBinThreads), bin_lds, st, kf, points, n, c, nbins,
                    passes, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
-    D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), 0, st, pkey, n, nbins, pbin, tilecnt, totals,
+    D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), bin_lds, st, pkey, n, nbins, pbin, tilecnt, totals,
                bucket_base, bent, counts, o.map_later, passes);
     if (!ROWS && o.lists)
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,

@@ -586,16 +586,16 @@ def test_no_point_inside_the_grid_and_large_max_points(voxel_path):
         check_dense(_np(VoxelGenerator(synth.KITTI_BOUNDS, [44, 50, 4], **kw)(torch.from_numpy(cloud).cuda())), exp, 300)
 
 
-@pytest.mark.parametrize("n", [4194304, 8388608, 8388609])
+@pytest.mark.parametrize("n", [4194304, 8388608, 8388609, 16777216, 16777217])
 def test_millions_of_points_up_to_the_binned_limit(index_path, n):
-    """8 M points (config 5's frame on ONE GPU) is the largest frame the binned index takes (8192 buckets of 1024 on
-    average); one more goes to the hash table -- all bit-exact with the oracle"""
+    """16 M points is the largest frame the binned index takes (16384 buckets of 1024 on average; 8 M = config 5's frame on
+    ONE GPU was the limit until round 3); one more goes to the hash table -- all bit-exact with the oracle"""
     if index_path == "hash" and n != 4194304:
         pytest.skip("one hash-table run of this size class is enough")
     from d3d_amd import synth
     from d3d_amd.voxel import VoxelGenerator
     cloud = synth.lidar_like(n, 81, synth.WAYMO_BOUNDS)
-    P = 5 if n == 8388608 else 4          # (frames this large take the group-per-wavefront fill: both of its row -> voxel forms)
+    P = 5 if n in (8388608, 16777216) else 4          # (frames this large take the group-per-wavefront fill: both of its row -> voxel forms)
     kw = dict(reduction="mean", max_points=P, max_voxels=n, dense=True)
     exp = oracle.VoxelGenerator(synth.WAYMO_BOUNDS, [752, 752, 30], **kw)(cloud)
     ret = _np(VoxelGenerator(synth.WAYMO_BOUNDS, [752, 752, 30], **kw)(torch.from_numpy(cloud).cuda()))
