@@ -2,7 +2,7 @@
 // std::unordered_map loops of the reference (d3d/voxel/voxelize.cpp).  Two index paths build the same intermediate
 // form (one record per voxel in first-seen order, the points' rows in per-voxel segments in point order):
 //
-// BINNED (default, up to 8 M points; "binned index" section below)
+// BINNED (default, up to 16 M points; "binned index" section below)
 //   partition  the points are partitioned by hash(cell) into buckets of ~512: tile histograms in LDS, a scan, ONE
 //              scattered 8-byte store per point {cell, index}
 //   bucket     one workgroup per bucket does everything per point in LDS: cell -> slot (CAS), count, first index,
@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
     reduce_overflow(seg, std::false_type{});
 }
 
-// 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF (<= 256 of them:
+// 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF (<= 1024 of them:
 // k_meta_first adds up the ones before its tile itself, which is cheaper than a scan launch or a last-block pass)
 __global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict__ firstmap, uint32_t *fwpre, uint32_t *bsumF,
                                                       uint32_t *clear_word = nullptr /* k_emit_c's overflow-voxel counter */)
@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
-    // voxels before this workgroup's tile of 16384 point indices (wave-uniform; <= 256 tile totals)
+    // voxels before this workgroup's tile of 16384 point indices (wave-uniform; <= 1024 tile totals)
     const uint32_t tile = (uint32_t)(i / kFlagTile), ntile = (uint32_t)(npad / kFlagTile);
     uint32_t before = 0, all = 0;
     for (uint32_t t = lane; t < ntile; t += kWave) {
@@ -2521,7 +2521,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
                    precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr);
-    const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 512 (n <= 8 M)
+    const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 1024 (n <= 16 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, w.big_count);
     const dim3 grid((unsigned)(w.npad / 256));
     if constexpr (!ROWS && std::is_same<Key, DenseKey>::value) {
@@ -2809,7 +2809,7 @@ static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const
     uint32_t nbins = 0;
     int hshift = 0;
     if (binned_eligible(n, w, flags, &nbins, &hshift)) {
-        // up to 8 M points: partition by hash(cell) and index every bucket in LDS -- the 63-bit cell key itself is the
+        // up to 16 M points: partition by hash(cell) and index every bucket in LDS -- the 63-bit cell key itself is the
         // table key there, so no bounding box pass and no packed-slot limits
         SparseKey kf;
         for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];

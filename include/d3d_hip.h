@@ -69,7 +69,7 @@ const char *d3d_status_string(int status);
  * arguments, not library state: two threads / streams may use different ones at the same time, and the retry a caller
  * issues after a PACK_ / BIN_OVERFLOW status touches nothing shared.
  *   D3D_VOXEL_PATH_HASH    hash table in HBM (any input) instead of the default binned index (points partitioned into
- *                          buckets, per-bucket index in LDS; up to 8 M points, grids below 2^32 - 1 cells).  Both give
+ *                          buckets, per-bucket index in LDS; up to 16 M points, grids below 2^32 - 1 cells).  Both give
  *                          identical outputs; see DESIGN.md section 4.
  *   D3D_VOXEL_PLAIN_SLOTS  (hash table) general two-word slots, any count / key width, instead of the default one-word
  *                          slots {count | key | first index} that are used whenever they fit 64 bits.
@@ -150,7 +150,7 @@ int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int32_t c, con
  * followed by d3d_voxelize_3d_filter on its outputs (same arguments, same outputs as the two calls; the voxel count
  * stays on the device, so max_voxels_filter DESCENDING is D3D_ERR_UNSUPPORTED here).  Besides saving the round trip it
  * lets the TRIM point filter reuse the per-voxel index ranking the sparse index already holds (voxelize.cpp:457-463)
- * and the voxel filter run inside the index (up to 8 M points, filters NONE / TRIM): points_mapping, coords and npoints
+ * and the voxel filter run inside the index (up to 16 M points, filters NONE / TRIM): points_mapping, coords and npoints
  * are then scratch (not materialised), sparse_counts holds the status bits.
  * Non-finite points get the reference's INT_MIN coordinate on that axis (x86 (int)floor(NaN), voxelize.cpp:309) and are
  * then removed by the coordinate-bound filter exactly as there (:376-384).  Finite points outside the 3 x 21-bit key range
