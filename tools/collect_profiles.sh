@@ -4,7 +4,7 @@
 # as MI355X_MICROARCH.md prescribes) for config 2 and for config 5's frame on one GPU
 # -> gpurun_out/<tag>/ ; tools/summarize_pmc.py turns the PMC passes into profiles/<tag>_pmc_*.csv + profiles/traffic.json
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 python3 bench.py > $out/bench.json 2> $out/bench.err
