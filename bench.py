@@ -323,6 +323,14 @@ def extras(args):
         sc = torch.from_numpy(rc.random(nobj * per)).cuda()
         dt = timed(lambda: box2d_nms(bc, sc, iou_method="rbox", iou_threshold=0.5), 10, 3)
         ex["nms_rbox_fp64_clusters_%dx%d_ms" % (nobj, per)] = round(dt / 10 * 1e3, 3)
+        if per == 500:      # the guess gone wrong: ONE call on clusters right after a call on scattered boxes (no level kernels launched)
+            bs_, ss_ = synth.boxes2d_sparse(20000, 9)
+            bst, sst = torch.from_numpy(bs_).cuda(), torch.from_numpy(ss_).cuda()
+            box2d_nms(bst, sst, iou_method="rbox", iou_threshold=0.5)
+            torch.cuda.synchronize()
+            dt1 = timed(lambda: box2d_nms(bc, sc, iou_method="rbox", iou_threshold=0.5), 1, 0)
+            ex["nms_rbox_fp64_clusters_200x500_first_call_after_sparse_ms"] = round(dt1 * 1e3, 3)
+            del bst, sst
         del bc, sc
     from d3d_amd.box import argsort_desc
     s100 = torch.from_numpy(np.random.default_rng(1).random(n3)).cuda()
