@@ -508,6 +508,24 @@ def test_nms_detector_like_clusters(nobj, per):
         assert keep.sum() < 20 * nobj
 
 
+def test_nms_launch_guess_alternating_inputs():
+    """whether the grid's level kernels are LAUNCHED is a guess from the previous call's grid density (one host-mapped word):
+    scattered boxes after clusters launch them for nothing (they test the density on the device and return), clusters after
+    scattered boxes run without them (every pair is listed, the round-2 route) -- the keep mask never depends on it"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms
+    rng = np.random.default_rng(3)
+    c = np.stack([rng.random(30) * 300, rng.random(30) * 300, rng.random(30) * 20 + 10, rng.random(30) * 20 + 10, rng.random(30) * 6.28], 1)
+    bc = np.repeat(c, 300, 0) + rng.normal(0, 1, (9000, 5)) * [1.5, 1.5, 1.0, 1.0, 0.05]
+    sc = rng.permutation(9000) / 9000
+    bs, ss = synth.boxes2d_sparse(6000, 17)
+    exp_c = oracle.box2d_nms(bc, sc, iou_method="rbox", iou_threshold=0.5)
+    exp_s = oracle.box2d_nms(bs, ss, iou_method="rbox", iou_threshold=0.5)
+    for b, s, exp in [(bs, ss, exp_s), (bc, sc, exp_c), (bc, sc, exp_c), (bs, ss, exp_s), (bs, ss, exp_s), (bc, sc, exp_c)]:
+        keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.5).cpu().numpy()
+        assert np.array_equal(keep, exp)
+
+
 def test_c_abi_error_codes():
     """the C ABI reports bad arguments / unsupported options with status codes (nothing throws, nothing exits:
     reference common.h:25,33-46 exit()s on CUDA errors and throws py::value_error on unsupported enums)"""
