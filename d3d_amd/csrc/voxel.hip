@@ -48,6 +48,7 @@ typedef unsigned long long u64;
 
 constexpr u64 kEmpty = ~0ull;
 constexpr uint32_t kInf = 0xffffffffu;        // "no first point yet" / empty chain cell (filter)
+constexpr uint32_t kSingleVoxel = 0xfffffffeu; // firstmap: first (and only) point of a voxel without a record (k_bucket_index -> k_emit)
 constexpr uint32_t kNoVoxel = 0xffffffffu;    // voxel dropped by max_voxels
 constexpr uint32_t kNoSlot = 0xffffffffu;     // pslot: point not in any voxel
 constexpr uint32_t kNoBase = 0xffffffffu;     // aux.base of a dropped voxel
@@ -1333,8 +1334,11 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         const int s0 = threadIdx.x * PER;
         uint32_t c[PER];
         u64 mine = 0;
+        // (the index for k_emit keeps no record for a voxel of ONE point in a register bucket -- 80 % of a LiDAR frame's voxels:
+        // k_emit rebuilds it from the point itself, firstmap says so)
+        constexpr bool kSkipSingles = ROWS && LISTS && !STAGE && !decltype(BIG)::value;
 #pragma unroll
-        for (int k = 0; k < PER; k++) { c[k] = tcnt[s0 + k]; mine += ((u64)c[k] << 32) | (c[k] ? 1u : 0u); }
+        for (int k = 0; k < PER; k++) { c[k] = tcnt[s0 + k]; mine += ((u64)c[k] << 32) | ((kSkipSingles ? c[k] > 1 : c[k] > 0) ? 1u : 0u); }
         u64 all;
         u64 ex = block_excl_scan_u64_lds<kBucketThreads>(mine, &all, smem);
         uint32_t base = (uint32_t)(ex >> 32), j = (uint32_t)ex;
@@ -1345,7 +1349,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             if (c[k]) {
                 const uint32_t f = tfirst[s0 + k];
                 const u64 kk = (u64)tkey[s0 + k];
-                vrec[bb + j] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), bb + base, c[k]);
+                const bool single = kSkipSingles && c[k] == 1;
+                if (!single) vrec[bb + j] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), bb + base, c[k]);
                 bool pass = true;
                 if (vp.on) {                        // voxelize.cpp:376-384: coordinate bounds and min_points
                     long long cc[3];
@@ -1357,8 +1362,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                 // bb + j used to sit above this one -- hipcc 7.2 emitted, in one code shape of this kernel, a merged store that
                 // wrote the value bb + j at firstmap[bb + j], i.e. the other store's index; found by the big-bucket tests, see
                 // DESIGN.md 4a)
-                if (pass) __hip_atomic_store(&firstmap[f], bb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                j++;
+                if (pass) __hip_atomic_store(&firstmap[f], single ? kSingleVoxel : bb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!single) j++;
                 if constexpr (ROWS)
                     if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
             }
@@ -1708,7 +1713,17 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     const uint32_t il = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)(uint32_t)i);
     const bool mine = (uint32_t)lane < nv;
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-    if (mine) rec = vrec[el];
+    if (mine) {
+        if (el != kSingleVoxel) rec = vrec[el];             // the one random access per multi-point voxel
+        else {                                              // a voxel of one point has no record: its cell from the point itself
+            const float4 p0 = points4[il];                  // (ascending indices inside the wavefront's 1 KiB window)
+            const float v3[3] = {p0.x, p0.y, p0.z};
+            u64 key = 0;
+            uint32_t st = 0;
+            (void)kf.make(v3, key, st);                     // the same arithmetic on the same floats as k_bin_count: the same cell
+            rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), 0u, 1u);
+        }
+    }
     const uint32_t base = rec.z, cnt = rec.w;
     const uint32_t kept = cnt < P ? cnt : P;                // 0 for the lanes past nv
     uint32_t incl = kept;                                   // rows before this voxel in the wavefront's flat row list
