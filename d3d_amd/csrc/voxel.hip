@@ -1334,9 +1334,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         const int s0 = threadIdx.x * PER;
         uint32_t c[PER];
         u64 mine = 0;
-        // (the index for k_emit keeps no record for a voxel of ONE point in a register bucket -- 80 % of a LiDAR frame's voxels:
-        // k_emit rebuilds it from the point itself, firstmap says so)
-        constexpr bool kSkipSingles = ROWS && LISTS && !STAGE && !decltype(BIG)::value;
+        // (the index for k_emit and the sparse contract's keep no record for a voxel of ONE point in a register bucket -- 80 % of a
+        // LiDAR frame's voxels: k_emit / k_meta_first rebuild it from the point itself, firstmap says so)
+        constexpr bool kSkipSingles = ((ROWS && LISTS && !STAGE) || std::is_same<Key, SparseKey>::value) && !decltype(BIG)::value;
 #pragma unroll
         for (int k = 0; k < PER; k++) { c[k] = tcnt[s0 + k]; mine += ((u64)c[k] << 32) | ((kSkipSingles ? c[k] > 1 : c[k] > 0) ? 1u : 0u); }
         u64 all;
@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
                                                     const uint4 *__restrict__ vrec, uint32_t max_voxels, uint4 *__restrict__ vinfo,
                                                     const float4 *__restrict__ staged, uint32_t P, int reduction, int64_t *coords,
                                                     int32_t *npoints, unsigned char *pmask, float4 *agg, int64_t *counts,
-                                                    BinnedExtras x)
+                                                    BinnedExtras x, const float *__restrict__ points, int c)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
@@ -1618,7 +1618,16 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
         if (vid < max_voxels) {                             // voxelize.cpp:116-117: later voxels are never created
             myvid = vid;
             if (x.first_out) x.first_out[vid] = x.index_offset + i;
-            const uint4 rec = vrec[e];
+            uint4 rec;
+            if (e != kSingleVoxel) rec = vrec[e];
+            else {              // (sparse contract) a voxel of one point has no record: its cell from the point -- this lane's own index
+                const float *src = points + i * c;
+                const float v3[3] = {src[0], src[1], src[2]};
+                u64 key = 0;
+                uint32_t st = 0;
+                (void)kf.make(v3, key, st);                 // the same arithmetic on the same floats as k_bin_count
+                rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), 0u, 1u);
+            }
             const uint4 vi = rec;                           // {key lo, key hi, segment base, count}
             if (vinfo) vinfo[vid] = vi;
             kept = vi.w < x.npoints_clamp ? vi.w : x.npoints_clamp;
@@ -2579,11 +2588,11 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     if (o.agg4)
         D3D_LAUNCH("k_meta_first", (k_meta_first<Key, true>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
                    o.max_voxels, w.vinfo, w.staged, o.P, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr,
-                   reinterpret_cast<float4 *>(o.aggregates), counts, x);
+                   reinterpret_cast<float4 *>(o.aggregates), counts, x, points, c);
     else
         D3D_LAUNCH("k_meta_first", (k_meta_first<Key, false>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
                    o.max_voxels, ROWS || o.lists ? w.vinfo : (uint4 *)nullptr, w.staged, o.P, o.reduction, o.coords, o.npoints,
-                   o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, counts, x);
+                   o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, counts, x, points, c);
     if (want_map && !o.map_later)
         D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
                    reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping, o.keepid,
