@@ -610,7 +610,7 @@ struct NmsGrid { float ox, oy, inv_h; int gx, gy; unsigned int ticket, entries; 
 // the levels of the greedy result (k_nms_level_*, below) run when the grid is dense
 constexpr int kNmsLevels = 2;             // number of levels (D3D_NMS_ONE_LEVEL: one)
 constexpr unsigned long long kNmsLevelDensity = 128;
-constexpr int kNmsLevelChunks = 3;      // k_nms_level_block: chunks of 64 partners a wavefront tests before it gives up
+constexpr int kNmsLevelChunks = 2;      // k_nms_level_block: chunks of 64 partners a wavefront tests before it gives up
 __device__ __forceinline__ bool nms_levels_on(const NmsGrid &g, const NmsCand *hdr)
 {
     return hdr->count[kHdrDensity] > kNmsLevelDensity * (unsigned long long)g.entries;
