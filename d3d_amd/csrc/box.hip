@@ -1251,6 +1251,12 @@ __global__ __launch_bounds__(256) void k_nms_level_roots(const float4 *__restric
                                                          unsigned long long *__restrict__ list, unsigned long long cap, NmsFlags *flags)
 {
     __shared__ unsigned long long batch[4][kCandLds];
+    // the roots with LONG lists among the workgroup's 256 registrations (big clusters: a handful): ALL four wavefronts walk such a
+    // list together, 256 partners per step -- a wavefront alone walked a 1500-entry list in 24 dependent steps.  Short lists
+    // (many roots per workgroup: clusters of a few boxes) stay with the wavefront that holds the root
+    __shared__ float4 rt_f[256];
+    __shared__ float rt_a[256];
+    __shared__ uint32_t rt_r[256], rt_c[256], rt_s0[256], rt_s1[256], nroots;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const NmsGrid g = *grid;
     if (!nms_levels_on(g, hdr)) return;
@@ -1258,12 +1264,20 @@ __global__ __launch_bounds__(256) void k_nms_level_roots(const float4 *__restric
     const bool live = e < g.entries;
     const uint32_t ra = live ? cellbox[e] : 0xffffffffu;
     const bool root = live && state[ra] == kUndecided && blocked[ra] + 1u == level;    // open at this level and not blocked in it
-    unsigned long long rm = __ballot(root);
-    if (rm == 0) return;
-    const float4 fa = live ? fbc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint32_t c = live ? cellof[e] : 0u;
-    const uint32_t mystart = live ? cellstart[c] : 0u, myend = live ? cellstart[c + 1] : 0u;
-    const float aa = live ? carea[e] : 0.f;
+    if (threadIdx.x == 0) nroots = 0;
+    __syncthreads();
+    const float4 fa = root ? fbc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t c = root ? cellof[e] : 0u;
+    const uint32_t mystart = root ? cellstart[c] : 0u, myend = root ? cellstart[c + 1] : 0u;
+    const float aa = root ? carea[e] : 0.f;
+    const bool longlist = root && myend - mystart > 192u;
+    if (longlist) {
+        const uint32_t slot = atomicAdd(&nroots, 1u);
+        rt_f[slot] = fa; rt_a[slot] = aa; rt_r[slot] = ra; rt_c[slot] = c; rt_s0[slot] = mystart; rt_s1[slot] = myend;
+    }
+    __syncthreads();
+    const uint32_t nr = nroots;
+    if (nr == 0 && __ballot(root) == 0) return;
     const bool bound_on = thr >= 0.f;
     const float thr_lhs = 1.f + thr, thr_rhs = thr * (1.f - 1e-4f);
     unsigned long long *q = batch[wave], *counter = &hdr->count[kHdrKill + level - 1];
@@ -1280,22 +1294,20 @@ __global__ __launch_bounds__(256) void k_nms_level_roots(const float4 *__restric
         wn = 0;
         __builtin_amdgcn_wave_barrier();
     };
-    while (rm && !overflow) {
-        const int j = __builtin_ctzll(rm);
-        rm &= rm - 1;
-        const float4 fr = make_float4(__shfl(fa.x, j, kWave), __shfl(fa.y, j, kWave), __shfl(fa.z, j, kWave), __shfl(fa.w, j, kWave));
-        const float ar = __shfl(aa, j, kWave);
-        const uint32_t rr = __shfl(ra, j, kWave), cr = __shfl(c, j, kWave), s0 = __shfl(mystart, j, kWave), s1 = __shfl(myend, j, kWave);
+    // one root's list: `first` = the caller's first partner index, `stride` = partners all its callers take per step
+    auto walk = [&](const float4 fr, const float ar, const uint32_t rr, const uint32_t cr, const uint32_t s0, const uint32_t s1,
+                    const uint32_t first, const uint32_t stride) {
+        (void)s0;
         const int ccx = (int)(cr % (uint32_t)g.gx), ccy = (int)(cr / (uint32_t)g.gx);
         float4 nfb = make_float4(0.f, 0.f, 0.f, 0.f);
         uint32_t nrb = 0;
-        if (s0 + lane < s1) { nfb = fbc[s0 + lane]; nrb = cellbox[s0 + lane]; }
-        for (uint32_t t0 = s0; t0 < s1; t0 += 64) {
+        if (first + lane < s1) { nfb = fbc[first + lane]; nrb = cellbox[first + lane]; }
+        for (uint32_t t0 = first; t0 < s1 && !overflow; t0 += stride) {
             const uint32_t t = t0 + lane;
             bool cand = false;
             const float4 fb = nfb;
             const uint32_t rb = nrb;
-            if (t + 64 < s1) { nfb = fbc[t + 64]; nrb = cellbox[t + 64]; }       // the next step's entries, in flight meanwhile
+            if (t + stride < s1) { nfb = fbc[t + stride]; nrb = cellbox[t + stride]; }     // the next step's entries, in flight meanwhile
             if (t < s1) {
                 const float gap = fminf(fminf(fb.z - fr.x, fr.z - fb.x), fminf(fb.w - fr.y, fr.w - fb.y));
                 cand = rb > rr && gap > 0.f && grid_cell(fmaxf(fr.x, fb.x), g.ox, g.inv_h, g.gx) == ccx &&
@@ -1316,7 +1328,19 @@ __global__ __launch_bounds__(256) void k_nms_level_roots(const float4 *__restric
                 wn += cnt;
             }
         }
+    };
+    // short lists: every wavefront takes the roots among its own 64 registrations (wave-uniform loop, data by shuffles)
+    unsigned long long rm = __ballot(root && !longlist);
+    while (rm && !overflow) {
+        const int j = __builtin_ctzll(rm);
+        rm &= rm - 1;
+        const float4 fr = make_float4(__shfl(fa.x, j, kWave), __shfl(fa.y, j, kWave), __shfl(fa.z, j, kWave), __shfl(fa.w, j, kWave));
+        const uint32_t s0 = __shfl(mystart, j, kWave);
+        walk(fr, __shfl(aa, j, kWave), __shfl(ra, j, kWave), __shfl(c, j, kWave), s0, __shfl(myend, j, kWave), s0, 64u);
     }
+    // long lists: all four wavefronts walk one together, 256 partners per step
+    for (uint32_t ri = 0; ri < nr; ri++)
+        walk(rt_f[ri], rt_a[ri], rt_r[ri], rt_c[ri], rt_s0[ri], rt_s1[ri], rt_s0[ri] + wave * 64, 256u);
     if (wn) flush();
 }
 
