@@ -1229,8 +1229,14 @@ __global__ __launch_bounds__(256) void k_nms_level_block(const float4 *__restric
         // lists of boxes that merely touch (20 k boxes all over each other: every wavefront holds a few).
         if (!settled && cb + 64 > mystart && cb < myend && walked++ >= kNmsLevelChunks) settled = true;
         if (cb + 64 < hi) fetch(cb + 64);
-        if (partner) { win[lane] = cfb; rwin[lane] = crb; awin[lane] = cab; }
-        unsigned long long pm = __ballot(partner);
+        // only partners that rank before SOME lane still looking can block anybody: from the second chunk on most lanes are
+        // settled and the ones left are the well-ranked ones
+        uint32_t wmax = settled ? 0u : ra;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) { const uint32_t x2 = __shfl_xor(wmax, o, kWave); wmax = x2 > wmax ? x2 : wmax; }
+        const bool useful = partner && crb < wmax;
+        if (useful) { win[lane] = cfb; rwin[lane] = crb; awin[lane] = cab; }
+        unsigned long long pm = __ballot(useful);
         __builtin_amdgcn_wave_barrier();
         while (pm) {
             int j[4], nj = 0;
