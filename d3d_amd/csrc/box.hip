@@ -1886,10 +1886,15 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_small(uint32_t n, const ui
 
 // Whether the level kernels are worth LAUNCHING is a guess from the previous call: they decide on the device whether to run
 // (density of the grid), but on scattered boxes even their six empty launches cost ~15 % of a 100 k-box call.  The grid's
-// density of every call is left in one host-mapped word; the next call -- a detector's stream of frames looks like the frame
-// before -- skips the launches when it says "sparse".  Only speed depends on the guess: without the launches every pair is
-// listed as before.  (One word per process, unsynchronised on purpose; never allocated during a stream capture.)
+// density of every call is left in one host-mapped word; the launches are skipped once kNmsSparseStreak calls IN A ROW have
+// found it "sparse" -- a detector's stream of frames looks like the frame before.  The two ways to be wrong are not alike:
+// launching for nothing costs ~20 us, NOT launching on clusters costs the round-2 route (200 x 500: 2.9 ms instead of 0.4),
+// hence the streak: a caller that alternates between raw detections and scattered boxes never builds one and always launches.
+// Only speed depends on the guess: without the launches every pair is listed as before.  (One word + one counter per process,
+// unsynchronised on purpose; never allocated during a stream capture.)
+constexpr int kNmsSparseStreak = 4;
 static int *g_nms_hint_host = nullptr, *g_nms_hint_dev = nullptr;
+static int g_nms_sparse_streak = 0;
 static void nms_dense_hint(hipStream_t st, int **dev, bool *launch_levels)
 {
     *dev = nullptr;
@@ -1905,7 +1910,9 @@ static void nms_dense_hint(hipStream_t st, int **dev, bool *launch_levels)
         g_nms_hint_host = h;
     }
     *dev = g_nms_hint_dev;
-    *launch_levels = *reinterpret_cast<volatile int *>(g_nms_hint_host) != 0;
+    if (*reinterpret_cast<volatile int *>(g_nms_hint_host) != 0) g_nms_sparse_streak = 0;
+    else if (g_nms_sparse_streak < kNmsSparseStreak) g_nms_sparse_streak++;
+    *launch_levels = g_nms_sparse_streak < kNmsSparseStreak;
 }
 
 // the small-set path takes hard NMS of up to kNmsSmallMax boxes unless a flag asks for a specific general path (tests)

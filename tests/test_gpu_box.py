@@ -509,9 +509,10 @@ def test_nms_detector_like_clusters(nobj, per):
 
 
 def test_nms_launch_guess_alternating_inputs():
-    """whether the grid's level kernels are LAUNCHED is a guess from the previous call's grid density (one host-mapped word):
-    scattered boxes after clusters launch them for nothing (they test the density on the device and return), clusters after
-    scattered boxes run without them (every pair is listed, the round-2 route) -- the keep mask never depends on it"""
+    """whether the grid's level kernels are LAUNCHED is a guess from the grid density of the calls before (one host-mapped word
+    + a streak counter): scattered boxes after clusters launch them for nothing (they test the density on the device and
+    return), clusters after a STREAK of calls on scattered boxes run without them (every pair is listed, the round-2 route),
+    alternating inputs always launch -- the keep mask never depends on it"""
     from d3d_amd import synth
     from d3d_amd.box import box2d_nms
     rng = np.random.default_rng(3)
@@ -521,7 +522,8 @@ def test_nms_launch_guess_alternating_inputs():
     bs, ss = synth.boxes2d_sparse(6000, 17)
     exp_c = oracle.box2d_nms(bc, sc, iou_method="rbox", iou_threshold=0.5)
     exp_s = oracle.box2d_nms(bs, ss, iou_method="rbox", iou_threshold=0.5)
-    for b, s, exp in [(bs, ss, exp_s), (bc, sc, exp_c), (bc, sc, exp_c), (bs, ss, exp_s), (bs, ss, exp_s), (bc, sc, exp_c)]:
+    seq = [(bs, ss, exp_s)] * 6 + [(bc, sc, exp_c)] * 2 + [(bs, ss, exp_s), (bc, sc, exp_c)] * 2 + [(bs, ss, exp_s)] * 5 + [(bc, sc, exp_c)]
+    for b, s, exp in seq:
         keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.5).cpu().numpy()
         assert np.array_equal(keep, exp)
 
