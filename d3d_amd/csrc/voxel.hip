@@ -2025,13 +2025,17 @@ __global__ __launch_bounds__(256) void k_emit_c(Key kf, int64_t npad, const uint
                 const uint32_t q = q0 + u * kWave + lane;
                 if (q < q1) {
                     uint32_t row = (q * 4u) / (uint32_t)C, ch = q * 4u - row * (uint32_t)C;     // row = voxel * P + slot
-                    vec4 val;
+                    // (a piece never straddles two voxels: every voxel starts on a multiple of 4 floats)
+                    const uint32_t j = pshift >= 0 ? (row >> pshift) : row / P;
+                    const uint32_t kj = sh_kept[j], rb0 = sh_off[j] - oa;
+                    uint32_t slot = row - j * P;
+                    vec4 val = {0.f, 0.f, 0.f, 0.f};
+                    if (slot < kj) {                         // (97 % of a LiDAR frame's pieces lie behind the kept rows: zeros)
 #pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        const uint32_t j = pshift >= 0 ? (row >> pshift) : row / P;
-                        const uint32_t slot = row - j * P;
-                        val[x] = slot < sh_kept[j] ? rowbuf[(size_t)(sh_off[j] - oa + slot) * C + ch] : 0.f;
-                        if (++ch == (uint32_t)C) { ch = 0; row++; }
+                        for (int x = 0; x < 4; x++) {
+                            val[x] = slot < kj ? rowbuf[(size_t)(rb0 + slot) * C + ch] : 0.f;
+                            if (++ch == (uint32_t)C) { ch = 0; slot++; }
+                        }
                     }
                     __builtin_nontemporal_store(val, &out[q]);
                 }
