@@ -300,6 +300,34 @@ def test_box_crop_reference_case():
     assert np.array_equal(np.where(res[1])[0], np.where(np.abs(a[:, 0] + a[:, 1]) < bc.sq2 / 2)[0])
 
 
+@pytest.mark.parametrize("method", ["rbox", "box"])
+def test_iou_backward_row_reduction_is_additive(method):
+    """k_iou_grad sums the row gradients of a wavefront's candidates across the lanes (a segmented scan over runs of equal row)
+    before its atomics.  The gradient is additive over any split of the columns, and a split changes every run: rows with
+    hundreds of candidates (runs longer than a wavefront), rows that come back in later batches, weighted upstream gradients
+    with zeros in them -- full == left + right in fp64"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_iou
+    b, _ = synth.boxes2d_dense(900, 5)
+    b1, b2 = b[:400], b[400:]
+    rng = np.random.default_rng(0)
+    w = rng.random((400, 500))
+    w[rng.random((400, 500)) < 0.3] = 0.0
+    wt = torch.from_numpy(w).cuda()
+
+    def grads(cols):
+        t1 = torch.from_numpy(b1).cuda().requires_grad_(True)
+        t2 = torch.from_numpy(np.ascontiguousarray(b2[cols])).cuda().requires_grad_(True)
+        (box2d_iou(t1, t2, method=method) * wt[:, cols]).sum().backward()
+        return t1.grad.cpu().numpy(), t2.grad.cpu().numpy()
+    full1, full2 = grads(slice(0, 500))
+    l1, l2 = grads(slice(0, 137))
+    r1, r2 = grads(slice(137, 500))
+    assert np.abs(full1 - (l1 + r1)).max() < 1e-9 * max(np.abs(full1).max(), 1.0)
+    assert np.abs(full2 - np.concatenate([l2, r2])).max() < 1e-9 * max(np.abs(full2).max(), 1.0)
+    assert np.abs(full1).max() > 0 and np.abs(full2).max() > 0
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n", [1000, 1003])
 def test_crop_vs_oracle(dtype, n):
