@@ -2265,19 +2265,10 @@ __global__ __launch_bounds__(256) void k_crop2dr(const T *__restrict__ points, i
     const bool vec = (n % 4 == 0);
     for (int r = 0; r < nrows; r++) {
         const BoxGeom<T> g = rows[r];
-        // corners relative to the centre: -u-v, u-v, u+v, -u+v
-        const T cx[4] = {-g.ux - g.vx, g.ux - g.vx, g.ux + g.vx, -g.ux + g.vx};
-        const T cy[4] = {-g.uy - g.vy, g.uy - g.vy, g.uy + g.vy, -g.uy + g.vy};
         uint32_t word = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            bool in = px[k] >= g.xmin && px[k] <= g.xmax && py[k] >= g.ymin && py[k] <= g.ymax;
-            const T dx = px[k] - g.cx, dy = py[k] - g.cy;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const T ex = cx[(e + 1) & 3] - cx[e], ey = cy[(e + 1) & 3] - cy[e];
-                in = in && (ex * (dy - cy[e]) - ey * (dx - cx[e]) >= 0);
-            }
+            const bool in = quad_contains<T>(g, px[k], py[k]);
             word |= (in ? 1u : 0u) << (8 * k);
         }
         uint8_t *dst = out + (i0 + r) * n + j0;

@@ -36,17 +36,7 @@ __device__ __forceinline__ bool near3(const Box3 &b, float x, float y, float z)
 __device__ __forceinline__ bool contains3(const Box3 &b, float x, float y, float z)
 {
     if (z > b.zhi || z < b.zlo) return false;                                   // dgal_wrap.h:12-13 (NaN z: inside, as there)
-    const BoxGeom<float> &g = b.g;
-    bool in = x >= g.xmin && x <= g.xmax && y >= g.ymin && y <= g.ymax;          // :14-15
-    const float cx[4] = {-g.ux - g.vx, g.ux - g.vx, g.ux + g.vx, -g.ux + g.vx};
-    const float cy[4] = {-g.uy - g.vy, g.uy - g.vy, g.uy + g.vy, -g.uy + g.vy};
-    const float dx = x - g.cx, dy = y - g.cy;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {                                                // :16-17, the four closed half-planes
-        const float ex = cx[(e + 1) & 3] - cx[e], ey = cy[(e + 1) & 3] - cy[e];
-        in = in && (ex * (dy - cy[e]) - ey * (dx - cx[e]) >= 0);
-    }
-    return in;
+    return quad_contains<float>(b.g, x, y);                                     // :14-17
 }
 
 // indicators[i, j] = box i contains point j.  Lane = 4 consecutive points -> one 32-bit store per box row.

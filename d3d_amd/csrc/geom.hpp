@@ -69,6 +69,25 @@ template <typename T> __device__ __forceinline__ BoxGeom<T> expand(const BoxCore
     return g;
 }
 
+// point in rotated rectangle (dgal's aabox.contains + box.contains at utils.cpp:22-29, dgal_wrap.h:14-17): the closed
+// bounding-box test, then the four closed half-planes on the ABSOLUTE corners -- cross(v[e+1] - v[e], p - v[e]) >= 0 with
+// the corners and the products formed in the same order as the checker's (oracle_crop_2dr, box3dr_contains_f32), so the
+// two sides can only differ through the last bit of sin / cos
+template <typename T>
+__device__ __forceinline__ bool quad_contains(const BoxGeom<T> &g, T px, T py)
+{
+    bool in = px >= g.xmin && px <= g.xmax && py >= g.ymin && py <= g.ymax;
+    const T x = g.cx, y = g.cy;
+    const T qx[4] = {x - g.ux - g.vx, x + g.ux - g.vx, x + g.ux + g.vx, x - g.ux + g.vx};
+    const T qy[4] = {y - g.uy - g.vy, y + g.uy - g.vy, y + g.uy + g.vy, y - g.uy + g.vy};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const T cr = (qx[(e + 1) & 3] - qx[e]) * (py - qy[e]) - (qy[(e + 1) & 3] - qy[e]) * (px - qx[e]);
+        in = in && (cr >= 0);
+    }
+    return in;
+}
+
 // IoU of the axis-aligned bounding boxes (method "box": dgal::iou(AABox2, AABox2))
 template <typename T>
 __device__ __forceinline__ T iou_aabb(const BoxGeom<T> &a, const BoxGeom<T> &b)

@@ -1248,6 +1248,122 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
     if (bad) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_COORD_OVERFLOW);
 }
 
+// ------------------------------------------------------------------ one-launch partition (round 4)
+// k_bin_count + k_bin_scan + k_bin_scatter are three launch + drain floors (36-38 us at 1 M points for 24 MB of compulsory
+// traffic) and 1 M scattered 8-byte stores.  Here a workgroup SORTS its tile of 8192 points by bucket in LDS (histogram with
+// arrival numbers, scan over the buckets, entries placed, all on chip) and writes the tile back as ONE coalesced run in bucket
+// order, plus one word per (bucket, tile) {offset of the bucket inside the tile : 16 | entries : 16} into a bucket-major
+// table.  No tile waits for another one: the bucket workgroup of k_bucket_index reads its row of the table (coalesced),
+// whose offsets add up to the number of entries in lower buckets -- its base in every per-bucket array, no scan over the
+// buckets anywhere -- and gathers its entries as <= ntiles short runs (tile sort: mean run = 8192 / buckets = 4 entries at
+// config 2, i.e. a quarter of the requests of one scattered store per point; frames above 4 M points keep the three-pass
+// partition, where runs would shrink to single entries and the table would outgrow the entries).
+constexpr int kSortThreads = 1024;
+constexpr int kSortItems = 8;                              // points per lane
+constexpr int kSortTileShift = 13;
+constexpr int kSortTile = kSortThreads * kSortItems;       // 8192 points per tile: offsets and run lengths fit 16 bits
+static_assert(kSortTile == (1 << kSortTileShift) && kFlagTile % kSortTile == 0, "arrays are padded to kFlagTile");
+constexpr int64_t kTileSortMaxPoints = 4ll << 20;          // <= 512 tiles; k_bucket_index keeps the run table in LDS (<= 1024)
+constexpr int kRunCap = 1024;
+
+template <class Key, bool VEC4, bool ROWS>
+__global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float *__restrict__ points, int64_t n, int c, uint32_t nbins,
+                                                            uint32_t ntiles, typename BinEntry<ROWS>::type *__restrict__ tsort,
+                                                            uint32_t *__restrict__ table /* [nbins][ntiles] */,
+                                                            uint32_t *__restrict__ tileinfo /* [ntiles] entries | bad << 31 */,
+                                                            uint32_t *__restrict__ ppos /* optional: [n] the point's place in tsort */,
+                                                            uint32_t *__restrict__ firstmap, int64_t *counts, int64_t *mapping,
+                                                            unsigned char *trimmed, int32_t *keepid)
+{
+    typedef typename Key::bin_key_t KT;
+    typedef BinEntry<ROWS> E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
+    KT *keys = reinterpret_cast<KT *>(tile_lds);                           // [kSortTile] in bucket order
+    uint32_t *h = reinterpret_cast<uint32_t *>(keys + kSortTile);           // [nbins] histogram, then the buckets' offsets
+    uint16_t *lidx = reinterpret_cast<uint16_t *>(h + nbins);               // [kSortTile] point index inside the tile
+    __shared__ u64 smem[kSortThreads / kWave];
+    __shared__ uint32_t sbad;
+    for (uint32_t b = threadIdx.x; b < nbins; b += kSortThreads) h[b] = 0;
+    if (threadIdx.x == 0) sbad = 0;
+    if (blockIdx.x == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile + threadIdx.x;
+    float v[kSortItems][3];
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const int64_t i = base + r * kSortThreads;
+        if (i < n) {
+            if (VEC4) {
+                const float4 q = reinterpret_cast<const float4 *>(points)[i];
+                v[r][0] = q.x; v[r][1] = q.y; v[r][2] = q.z;
+            } else {
+                const float *src = points + i * c;
+                v[r][0] = src[0]; v[r][1] = src[1]; v[r][2] = src[2];
+            }
+        }
+    }
+    KT key[kSortItems];
+    uint32_t word[kSortItems];
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const int64_t i = base + r * kSortThreads;
+        word[r] = kNoBin;
+        key[r] = 0;
+        if (i < n) {
+            u64 k64;
+            uint32_t status = 0;
+            if (kf.make(v[r], k64, status)) {
+                const uint32_t b = Key::bin_hash(k64) & (nbins - 1);
+                word[r] = b | (atomicAdd(&h[b], 1u) << kBinBits);
+                key[r] = (KT)k64;
+            } else if (status) bad = true;
+        }
+        firstmap[i] = kInf;                         // arrays are padded to the tile
+        if (mapping && i < n) mapping[i] = -1;      // points outside the grid keep it
+        if (trimmed && i < n) trimmed[i] = 0;
+        if (keepid && i < n) keepid[i] = -1;
+    }
+    if (bad) sbad = 1;
+    __syncthreads();
+    // buckets' offsets inside the tile: exclusive scan of the histogram (consecutive buckets per thread)
+    constexpr int kPerMax = 8;                                  // nbins <= 8192 on this path (host-checked)
+    const uint32_t per = nbins > (uint32_t)kSortThreads ? nbins / kSortThreads : 1u, b0 = threadIdx.x * per;
+    uint32_t cnt[kPerMax];
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPerMax; k++) {
+        cnt[k] = ((uint32_t)k < per && b0 + k < nbins) ? h[b0 + k] : 0u;
+        mine += cnt[k];
+    }
+    u64 all;
+    u64 ex = block_excl_scan_u64<kSortThreads>(mine, &all, smem);
+#pragma unroll
+    for (int k = 0; k < kPerMax; k++) {
+        if ((uint32_t)k < per && b0 + k < nbins) {
+            h[b0 + k] = (uint32_t)ex;
+            table[(size_t)(b0 + k) * ntiles + blockIdx.x] = (uint32_t)ex | (cnt[k] << 16);
+            ex += cnt[k];
+        }
+    }
+    if (threadIdx.x == 0) tileinfo[blockIdx.x] = (uint32_t)all | (sbad << 31);
+    __syncthreads();
+    const uint32_t tbase = (uint32_t)blockIdx.x << kSortTileShift;
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const int64_t i = base + r * kSortThreads;
+        if (word[r] != kNoBin) {
+            const uint32_t p = h[word[r] & (kBinMax - 1)] + (word[r] >> kBinBits);
+            keys[p] = key[r];
+            lidx[p] = (uint16_t)(r * kSortThreads + threadIdx.x);
+            if (ppos) ppos[i] = tbase + p;
+        } else if (ppos && i < n) ppos[i] = kInf;
+    }
+    __syncthreads();
+    const uint32_t total = (uint32_t)all;
+    for (uint32_t p = threadIdx.x; p < total; p += kSortThreads) tsort[tbase + p] = E::pack((u64)keys[p], tbase + lidx[p]);
+}
+
 // One workgroup per bucket, everything per point in LDS: cell -> slot (open addressing), count, first index, segment of
 // the indices, rank = number of smaller indices in the segment (early exit at max_points).  Outputs: the rows next to
 // their rank (staged), one record per voxel {cell, first, segment base, count} and firstmap[first] = record position.
@@ -1305,7 +1421,11 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                       uint32_t *__restrict__ pinfo, uint32_t *__restrict__ gseg /* big buckets */,
                                                       unsigned char *__restrict__ trimmed /* optional: [n] rank >= P */,
                                                       uint32_t *__restrict__ sorted_out /* optional: ranked indices (C != 4) */,
-                                                      uint32_t *__restrict__ unsorted_out /* ... and all of an overflow voxel's */)
+                                                      uint32_t *__restrict__ unsorted_out /* ... and all of an overflow voxel's */,
+                                                      // tile-sorted input (k_tile_sort): row blockIdx.x of the bucket-major table
+                                                      // holds this bucket's run in every tile; NULL = `bent` is partitioned
+                                                      const uint32_t *__restrict__ table, uint32_t ntiles,
+                                                      const uint32_t *__restrict__ tileinfo, uint32_t *__restrict__ gpos /* big buckets */)
 {
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
     typedef typename Key::bin_key_t KT;
@@ -1323,10 +1443,56 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                     // T distinct cells with more than P points each)
     __shared__ uint32_t nover, fail;
     typedef float v4f __attribute__((ext_vector_type(4)));   // (an array of HIP float4 structs stayed in scratch)
-    const uint32_t bb = bucket_base[blockIdx.x], m = bucket_base[blockIdx.x + 1] - bb;
+    uint32_t bb, m;
+    if (table) {
+        // this bucket's runs: {offset in the tile, entries} per tile.  The offsets add up to the entries of all lower
+        // buckets = the bucket's base in the per-bucket arrays; the run starts (scan of the lengths) and the runs' places in
+        // `bent` wait in seg[] (free until the segments phase) for the lanes to look their entries up
+        static_assert(2 * kRunCap <= kBucketCap && kRunCap <= 2 * kBucketThreads, "run table lives in seg[]");
+        const uint32_t *row = table + (size_t)blockIdx.x * ntiles;
+        const uint32_t per = ntiles > (uint32_t)kBucketThreads ? 2u : 1u, t0 = threadIdx.x * per;
+        uint32_t wv[2];
+        u64 mine = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            wv[k] = ((uint32_t)k < per && t0 + k < ntiles) ? row[t0 + k] : 0u;
+            mine += (u64)(wv[k] >> 16) | ((u64)(wv[k] & 0xffffu) << 32);
+        }
+        if (blockIdx.x == 0) {                      // a tile met a coordinate beyond the key range (k_tile_sort reset the word)
+            bool bad = false;
+            for (uint32_t t = threadIdx.x; t < ntiles; t += kBucketThreads) bad = bad || (tileinfo[t] >> 31);
+            if (bad) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_COORD_OVERFLOW);
+        }
+        u64 all;
+        const u64 ex = block_excl_scan_u64_lds<kBucketThreads>(mine, &all, smem);
+        m = (uint32_t)all;
+        bb = (uint32_t)(all >> 32);
+        uint32_t run = (uint32_t)ex;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if ((uint32_t)k < per && t0 + k < ntiles) {
+                seg[t0 + k] = run;
+                seg[kRunCap + t0 + k] = ((t0 + k) << kSortTileShift) + (wv[k] & 0xffffu);
+                run += wv[k] >> 16;
+            }
+        }
+    } else {
+        bb = bucket_base[blockIdx.x];
+        m = bucket_base[blockIdx.x + 1] - bb;
+    }
     if (m == 0) return;
     for (int s = threadIdx.x; s < T; s += kBucketThreads) { tkey[s] = kFree; tcnt[s] = 0; tfirst[s] = kInf; }
     if (threadIdx.x == 0) { nover = 0; fail = 0; }
+    // entry q of the bucket -> its place in `bent`
+    auto locate = [&](uint32_t q) -> uint32_t {
+        if (!table) return bb + q;
+        uint32_t lo = 0, hi = ntiles;               // the last tile whose run starts at or before q (empty runs share a start)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (seg[mid] <= q) lo = mid; else hi = mid;
+        }
+        return seg[kRunCap + lo] + (q - seg[lo]);
+    };
 
     // phase B of both modes: segments in slot order, one record per voxel, firstmap
     auto records = [&](auto BIG) {
@@ -1430,7 +1596,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         __syncthreads();
         if (m <= kArrMask) {
             for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) {
-                const typename E::type e = bent[bb + q];
+                const uint32_t pos = locate(q);
+                gpos[bb + q] = pos;
+                const typename E::type e = bent[pos];
                 const u64 key64 = E::key(e);
                 const KT key = (KT)key64;
                 uint32_t s = (Key::bin_hash(key64) >> hshift) & (T - 1), probes = 0;
@@ -1448,7 +1616,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         __syncthreads();
         if (fail) {                                 // the caller repeats the call on the hash path; until then the outputs
             if (precpos)                            // stay consistent (these points map to no voxel)
-                for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) precpos[bb + q] = kInf;
+                for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) precpos[m <= kArrMask ? gpos[bb + q] : locate(q)] = kInf;
             if (threadIdx.x == 0) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_BIN_OVERFLOW);
             return;
         }
@@ -1458,12 +1626,13 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         uint32_t *sg = gseg + bb;
         for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) {
             const uint32_t w = pinfo[bb + q];
-            sg[tbase[w >> kArrBits] + (w & kArrMask)] = E::idx(bent[bb + q]);
+            sg[tbase[w >> kArrBits] + (w & kArrMask)] = E::idx(bent[gpos[bb + q]]);
         }
         __threadfence_block();
         __syncthreads();                            // (waits for the stores: the segments are read back below)
         for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) {
-            const uint32_t s = pinfo[bb + q] >> kArrBits, cnt = tcnt[s], base = tbase[s], me = E::idx(bent[bb + q]);
+            const uint32_t pos = gpos[bb + q];
+            const uint32_t s = pinfo[bb + q] >> kArrBits, cnt = tcnt[s], base = tbase[s], me = E::idx(bent[pos]);
             uint32_t rank = 0, k = 0;
             const uint32_t *v = sg + base;
             // (the rank of a voxel's only point is 0; with nothing to stage or list, only voxels above P need ranks at all)
@@ -1476,7 +1645,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                 if (unsorted_out && cnt > P) unsorted_out[bb + base + (pinfo[bb + q] & kArrMask)] = me;
             }
             if (trimmed && rank >= P) trimmed[me] = 1;
-            if (precpos) precpos[bb + q] = tfirst[s];
+            if (precpos) precpos[pos] = tfirst[s];
         }
         reduce_overflow(sg, std::true_type{});
         return;
@@ -1484,14 +1653,16 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
 
     v4f row[STAGE ? ITEMS : 1];
     u64 key_in[ITEMS];
-    uint32_t idx[ITEMS], slot[ITEMS], arr[ITEMS];
+    uint32_t idx[ITEMS], slot[ITEMS], arr[ITEMS], pos[ITEMS];
+    if (table) lds_barrier();                       // the run table is complete
     // branch-free loads (lanes past the end repeat the last entry): all ITEMS entry loads, then all row gathers, in flight
     // together.  The rows are only needed when the ranks are known: their gather (one scattered 16-byte load per point
     // from the cache-resident point tensor) runs behind the LDS phases (lds_barrier does not wait for it).
     static_for<ITEMS>([&](auto R) {
         constexpr int r = decltype(R)::value;
         const uint32_t q = threadIdx.x + r * kBucketThreads;
-        const typename E::type e = bent[bb + (q < m ? q : m - 1)];
+        pos[r] = locate(q < m ? q : m - 1);
+        const typename E::type e = bent[pos[r]];
         key_in[r] = E::key(e);
         idx[r] = E::idx(e);
     });
@@ -1547,7 +1718,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                 if (unsorted_out && cnt > P) unsorted_out[bb + base + arr[r]] = me;
             }
             if (trimmed && rank >= P) trimmed[me] = 1;     // sparse contract + TRIM filter (voxelize.cpp:457-463)
-            if (precpos) precpos[bb + q] = tfirst[s];
+            if (precpos) precpos[pos[r]] = tfirst[s];
         }
     });
     reduce_overflow(seg, std::false_type{});
@@ -2118,10 +2289,13 @@ __global__ __launch_bounds__(1024) void k_publish_kept(const uint32_t *__restric
 __global__ __launch_bounds__(256) void k_map_binned(const uint32_t *__restrict__ bucket_base, uint32_t nbins,
                                                     const uint32_t *__restrict__ precpos, const uint32_t *__restrict__ ent32,
                                                     int idx_stride, int idx_off, const uint32_t *__restrict__ vidof,
-                                                    int64_t *mapping, int32_t *keepid, const unsigned char *__restrict__ trimmed)
+                                                    int64_t *mapping, int32_t *keepid, const unsigned char *__restrict__ trimmed,
+                                                    const uint32_t *__restrict__ tileinfo /* tile-sorted entries: */, uint32_t ntiles)
 {
-    const uint32_t total = bucket_base[nbins];
+    // entries partitioned by bucket: positions [0, total); tile-sorted: the first tileinfo[t] positions of every tile
+    const uint32_t total = tileinfo ? ntiles << kSortTileShift : bucket_base[nbins];
     for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+        if (tileinfo && (p & (kSortTile - 1)) >= (tileinfo[p >> kSortTileShift] & 0x7fffffffu)) continue;
         const uint32_t e = precpos[p];
         const uint32_t vid = e == kInf ? kNoVoxel : vidof[e];
         const uint32_t i = ent32[(size_t)p * idx_stride + idx_off];
@@ -2499,7 +2673,7 @@ static bool dense_cells_fit_u32(const DenseKey &kf)     // 32-bit cell keys in L
 // ROWS: dense contract on C == 4 rows (ranked rows staged, reductions); !ROWS: keys only (sparse contract, any C)
 template <class Key, bool ROWS>
 static int binned_index(const Key &kf, const float *points, int64_t n, int c, const VoxelWs &w, uint32_t nbins, int hshift,
-                        int64_t *counts, const DenseOut &o, hipStream_t st)
+                        int64_t *counts, const DenseOut &o, hipStream_t st, bool tile_sort)
 {
     const uint32_t passes = (uint32_t)bin_passes(n), ntiles = (uint32_t)d3d_divup((int64_t)(w.npad / kBinTile), (int64_t)passes);
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
@@ -2522,6 +2696,31 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     x.voff = o.seg_out ? o.seg_out : (o.lists ? w.voff : nullptr);
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     const size_t bin_lds = (size_t)nbins * 4;                 // (at 16384 buckets the scatter's 64 KB + 128 B exceed the default limit)
+    // one-launch partition (k_tile_sort) whenever the frame and the table fit; else, or on request, the three-pass one
+    const uint32_t stiles = (uint32_t)(w.npad >> kSortTileShift);
+    uint32_t *table = nullptr, *tileinfo = nullptr, *gpos = reinterpret_cast<uint32_t *>(w.vinfo) + w.npad;
+    if (tile_sort && n <= kTileSortMaxPoints && nbins <= 8192u && stiles <= (uint32_t)kRunCap &&
+        ((uint64_t)nbins + 1) * stiles * 4 <= w.cap * 8) {
+        table = tilecnt;
+        tileinfo = tilecnt + (size_t)nbins * stiles;
+    }
+    if (table) {
+        const size_t lds = (size_t)kSortTile * (sizeof(typename Key::bin_key_t) + 2) + bin_lds;
+        uint32_t *ppos = o.map_later ? pbin : nullptr;
+        if (vec4) {
+            if (lds + 1024 > 65536)
+                D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort<Key, true, ROWS>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            D3D_LAUNCH("k_tile_sort", (k_tile_sort<Key, true, ROWS>), dim3(stiles), dim3(kSortThreads), lds, st, kf, points, n, c, nbins,
+                       stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid);
+        } else {
+            if (lds + 1024 > 65536)
+                D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort<Key, false, ROWS>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            D3D_LAUNCH("k_tile_sort", (k_tile_sort<Key, false, ROWS>), dim3(stiles), dim3(kSortThreads), lds, st, kf, points, n, c, nbins,
+                       stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid);
+        }
+    } else {
     if (bin_lds + 256 > 65536) {
         D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_scatter<ROWS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
@@ -2535,20 +2734,22 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
     D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), bin_lds, st, pkey, n, nbins, pbin, tilecnt, totals,
                bucket_base, bent, counts, o.map_later, passes);
+    }
     if (!ROWS && o.lists)
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    reinterpret_cast<const typename BinEntry<false>::type *>(bent), p4, bucket_base, hshift, o.P, (int)D3D_REDUCE_NONE,
                    w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
-                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr);
+                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr, table, stiles, tileinfo, gpos);
     else if (ROWS && (o.emit_voxels || o.emit_reduce))
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, true, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
                    counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list /* the per-point keys are
-                   done with it; w.unsorted may be precpos */, (uint32_t *)nullptr);
+                   done with it; w.unsorted may be precpos */, (uint32_t *)nullptr, table, stiles, tileinfo, gpos);
     else
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
-                   precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                   precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                   table, stiles, tileinfo, gpos);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 1024 (n <= 16 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, w.big_count);
     const dim3 grid((unsigned)(w.npad / 256));
@@ -2585,7 +2786,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
             if (want_map && !o.map_later)
                 D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
                            reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping, o.keepid,
-                           (const unsigned char *)o.trimmed);
+                           (const unsigned char *)o.trimmed, (const uint32_t *)tileinfo, stiles);
             return D3D_OK;
         }
     }
@@ -2600,7 +2801,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     if (want_map && !o.map_later)
         D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
                    reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping, o.keepid,
-                   (const unsigned char *)o.trimmed);
+                   (const unsigned char *)o.trimmed, (const uint32_t *)tileinfo, stiles);
     return D3D_OK;
 }
 
@@ -2668,7 +2869,7 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
             d.emit_voxels = reinterpret_cast<float4 *>(voxels);
             emitted = true;
         }
-        if (vec4) rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
+        if (vec4) rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
         else {
             // any C: the {cell, index} entries travel alone, the bucket kernel leaves per-voxel index lists in point order
             // and the generic output kernels below gather through them
@@ -2679,7 +2880,7 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
                 d.emit_generic = voxels;
                 emitted_generic = true;
             }
-            rc = binned_index<DenseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st);
+            rc = binned_index<DenseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
         }
         if (rc) return rc;
     } else {
@@ -2801,7 +3002,7 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
                    BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr, nullptr}, mapping};
         d.seg_out = seg_base;
         d.emit_reduce = !rows && P <= (uint32_t)kEmitCap && !(flags & D3D_VOXEL_SPLIT_FILL);     // (rows: the index stages them)
-        return binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st);
+        return binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
     }
     IndexOpts o{P, 0xffffffffu, first, index_offset, mapping, agg4};
     rc = dense_index(kf, points, n, c, w, counts, o, flags, st);
@@ -2844,7 +3045,7 @@ static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const
         kf.tolerant = tolerant;
         DenseOut d{0u, 0xffffffffu, D3D_REDUCE_NONE, false, false, coords, npoints, nullptr, nullptr,
                    BinnedExtras{nullptr, 0, nullptr, -1, nullptr, nullptr}, points_mapping};
-        return binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st);
+        return binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
     }
     IndexOpts o{0u, 0xffffffffu, nullptr, 0, points_mapping, false};
     const int ib = bits_for((u64)(n > 1 ? n - 1 : 1));
@@ -3048,7 +3249,7 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                 // of kernel against +8 us in the count pass, and 173 vs 158 us per call)
                 d.map_later = true;
                 d.early_host = host_counts;             // output sizes to the host right after the numbering
-                int rc = binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, sparse_counts, d, st);
+                int rc = binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, sparse_counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
                 if (rc) return rc;
                 FilterPoints fp{points, c, nullptr, 0, nullptr, nullptr, d.trimmed, 0xffffffffu, d.keepid, out_feats, out_mask,
                                 out_mapping, true,

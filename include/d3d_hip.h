@@ -75,8 +75,14 @@ const char *d3d_status_string(int status);
  *                          slots {count | key | first index} that are used whenever they fit 64 bits.
  *   D3D_VOXEL_SPLIT_FILL   (dense contract, binned index, C == 4) the ranked rows staged by the index, then per-voxel outputs
  *                          and voxels[V,P,C] from two launches (k_meta_first + k_fill_c4) instead of the fused k_emit, which
- *                          reads first rows straight from `points`.  Identical outputs. */
-enum { D3D_VOXEL_PATH_HASH = 1, D3D_VOXEL_PLAIN_SLOTS = 4, D3D_VOXEL_SPLIT_FILL = 8, D3D_VOXEL_FLAGS_ALL = 13 };
+ *                          reads first rows straight from `points`.  Identical outputs.
+ *   D3D_VOXEL_PARTITION_3PASS  (binned index) the partition of rounds 1-3 -- tile histograms, a scan over the tile x bucket
+ *                          matrix, one scattered store per point: three launches -- instead of the one-launch tile sort
+ *                          (round 4: every tile of 8192 points is sorted by bucket in LDS and written as one coalesced
+ *                          run; the bucket workgroups gather their runs).  Identical outputs; frames above 4 M points
+ *                          always take the three-pass partition. */
+enum { D3D_VOXEL_PATH_HASH = 1, D3D_VOXEL_PARTITION_3PASS = 2, D3D_VOXEL_PLAIN_SLOTS = 4, D3D_VOXEL_SPLIT_FILL = 8,
+       D3D_VOXEL_FLAGS_ALL = 15 };
 
 /* scratch for any of the three voxel entry points on n points / nvox voxels */
 size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels);

@@ -341,14 +341,41 @@ def test_crop_vs_oracle(dtype, n):
     got = box2dr_crop(T(pts), T(boxes)).cpu().numpy()
     exp = oracle.crop_2dr(pts, boxes)
     assert got.shape == (70, n)
-    assert np.mean(got != exp) < (1e-4 if dtype == np.float32 else 1e-9)   # only rounding on the boundary may differ
+    assert np.array_equal(got, exp)     # bit for bit: quad_contains forms corners and products in the oracle's order
     assert exp.sum() > 100
     p3 = np.concatenate([pts, ((rng.random((n, 1)) - 0.5) * 4).astype(dtype)], 1)
     b3 = np.stack([boxes[:, 0], boxes[:, 1], np.zeros(70), boxes[:, 2], boxes[:, 3], np.full(70, 2.0), boxes[:, 4]], 1).astype(dtype)
     for ax in [2]:
         g3 = box3dp_crop(T(p3), T(b3), ax).cpu().numpy()
         e3 = oracle.box3dp_crop(p3, b3, ax)
-        assert np.mean(g3 != e3) < 1e-4 and e3.sum() > 10
+        assert np.array_equal(g3, e3) and e3.sum() > 10
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_crop_2dr_2k_boxes_x_1m_points_bit_exact(dtype):
+    """box2dr_crop at the size of a GT-sampling pass, the WHOLE 2 GB mask against the oracle (250 box rows at a time), and
+    box3dp_crop (box/__init__.py:289-315) on the same scene: array_equal, no mismatch budget"""
+    from d3d_amd.box import box2dr_crop, box3dp_crop
+    m, n = 2000, 1000000
+    rng = np.random.default_rng(43)
+    pts = ((rng.random((n, 3)) - 0.5) * np.array([140.0, 140.0, 4.0])).astype(dtype)
+    b3 = np.stack([(rng.random(m) - 0.5) * 130, (rng.random(m) - 0.5) * 130, (rng.random(m) - 0.5) * 2,
+                   3.5 + 1.5 * rng.random(m), 1.6 + 0.5 * rng.random(m), 1.4 + 0.5 * rng.random(m),
+                   (rng.random(m) - 0.5) * 2 * np.pi], 1).astype(dtype)
+    b2 = np.ascontiguousarray(b3[:, [0, 1, 3, 4, 6]])
+    p2 = np.ascontiguousarray(pts[:, :2])
+    got2 = box2dr_crop(T(p2), T(b2))
+    got3 = box3dp_crop(T(pts), T(b3), 2)
+    assert got2.shape == (m, n) and got2.dtype == torch.bool and got3.shape == (m, n)
+    total = 0
+    for i0 in range(0, m, 250):
+        e2 = oracle.crop_2dr(p2, b2[i0:i0 + 250])
+        assert torch.equal(got2[i0:i0 + 250], torch.from_numpy(e2).cuda()), i0
+        if i0 < 500:                    # (numpy temporaries of 250 x 1 M per comparison: two row blocks are enough)
+            e3 = oracle.box3dp_crop(pts, b3[i0:i0 + 250], 2)
+            assert torch.equal(got3[i0:i0 + 250], torch.from_numpy(e3).cuda()), i0
+        total += int(e2.sum())
+    assert total > 100000
 
 
 def test_iou_candidate_list_overflow_falls_back(monkeypatch):

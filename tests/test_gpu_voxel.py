@@ -11,14 +11,15 @@ from golden_io import GOLDEN, derived_pmask, load_voxel_cases
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "hash", "split"])
+@pytest.fixture(autouse=True, params=["auto", "hash", "split", "3pass"])
 def index_path(request):
     """every test of this module runs on both index paths of the voxelizer: automatic (binned whenever eligible; dense
     contract: the fused output kernel k_emit) and the hash table (tests that pick a path themselves -- `voxel_path` --
     override this); "split" = binned index with the two-launch output stage (k_meta_first + k_fill_c4).  The dense
     operator's output buffers are poisoned before every call."""
     from d3d_amd import _lib, voxel
-    voxel.default_flags = {"hash": _lib.VOXEL_PATH_HASH, "split": _lib.VOXEL_SPLIT_FILL}.get(request.param, 0)
+    voxel.default_flags = {"hash": _lib.VOXEL_PATH_HASH, "split": _lib.VOXEL_SPLIT_FILL,
+                           "3pass": _lib.VOXEL_PARTITION_3PASS}.get(request.param, 0)
     voxel.poison_outputs = True
     yield request.param
     voxel.default_flags = 0
