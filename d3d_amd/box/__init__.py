@@ -12,7 +12,7 @@ import enum
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, options
 
 
 class IouType(enum.IntEnum):            # box/common.h:5-9
@@ -33,13 +33,7 @@ class SupressionType(enum.IntEnum):     # box/common.h:10  (sic: the reference s
 
 cuda_available = True   # box/impl.cpp:9-13: this build always has its device path
 
-# Options applied to the calls that do not pass their own (bits of _lib.NMS_* / _lib.nms_cand_cap, _lib.iou_list_cap):
-# diagnostic / test hooks that select between equivalent internal paths; they travel as per-call arguments of the C ABI.
-default_nms_flags = 0
-default_iou_flags = 0
-# Test hook: fill the IoU / iou3d result buffer with NaN before the kernels run, so that a chunk of the matrix the zero fill
-# skips cannot hide behind fresh (zeroed) memory.  Read when a call starts.
-poison_outputs = False
+# (per-call options -- flags=, poison= -- or the calling context's: d3d_amd.options)
 
 
 def _dtype_code(t):
@@ -71,10 +65,10 @@ def _iou_forward(boxes1, boxes2, iou_type, flags=None):
         raise RuntimeError("boxes1 and boxes2 must have the same dtype")
     (b1, b2), dev = _to_device(boxes1, boxes2)
     n, m = b1.shape[0], b2.shape[0]
-    fl = default_iou_flags if flags is None else int(flags)
+    fl = options.current().iou_flags if flags is None else int(flags)
     with torch.cuda.device(dev):
         ious = torch.empty((n, m), dtype=b1.dtype, device=dev)
-        if poison_outputs:
+        if options.current().poison:
             ious.fill_(float("nan"))
         code = _dtype_code(b1)
         # one launch covers 65535 tiles of 64 rows; taller inputs go in row blocks into the same output
@@ -297,7 +291,7 @@ def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_thresho
         ws = _lib.workspace(lib.d3d_nms2d_workspace_bytes(n), dev)
         rc = lib.d3d_nms2d(_lib.ptr(b), _lib.ptr(s), _lib.ptr(order) if order is not None else None, n, iou_type, supression_type, code,
                            float(iou_threshold), float(score_threshold), float(supression_param), _lib.ptr(sup),
-                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), default_nms_flags if flags is None else int(flags))
+                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), options.current().nms_flags if flags is None else int(flags))
     _lib.check(rc, "nms2d")
     sup = sup.view(torch.bool)
     return sup.to(odev) if odev != dev else sup
@@ -353,7 +347,7 @@ def iou3d(boxes1, boxes2, method="rbox"):
     n, m = b1.shape[0], b2.shape[0]
     with torch.cuda.device(dev):
         out = torch.empty((n, m), dtype=torch.float32, device=dev)
-        if poison_outputs:
+        if options.current().poison:
             out.fill_(float("nan"))
         ws = _lib.workspace(lib.d3d_iou3d_workspace_bytes(n, m), dev)
         rc = lib.d3d_iou3d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, 1 if key == "RBOX" else 0, _lib.ptr(out),

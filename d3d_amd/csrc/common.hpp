@@ -53,14 +53,88 @@ constexpr int kScanItems = 4;        // consecutive items per thread
 constexpr int kScanTile = kScanBlock * kScanItems;
 
 // ---------------------------------------------------------------- wave / block scans (u64)
+// Inclusive scan over the wavefront on the DPP path of the vector ALUs: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes,
+// then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 -- six steps of two moves and a 64-bit add, no LDS
+// traffic.  (__shfl_up is a ds_bpermute per 32-bit half and step: twelve dependent round trips through the LDS pipe, which the
+// scans of k_bucket_index -- three per workgroup, on the pipe its hash table saturates -- paid in full.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long d3d_dpp_u64(unsigned long long v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, true);
+    return ((unsigned long long)hi << 32) | lo;           // lanes without a source (row start, masked rows) read 0
+}
 __device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v)
 {
-    const int lane = threadIdx.x & (kWave - 1);
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        unsigned long long t = __shfl_up(v, d, kWave);
-        if (lane >= d) v += t;
+    v += d3d_dpp_u64<0x111, 0xf>(v);                      // row_shr:1
+    v += d3d_dpp_u64<0x112, 0xf>(v);                      // row_shr:2
+    v += d3d_dpp_u64<0x114, 0xf>(v);                      // row_shr:4
+    v += d3d_dpp_u64<0x118, 0xf>(v);                      // row_shr:8
+    v += d3d_dpp_u64<0x142, 0xa>(v);                      // row_bcast:15 -> rows 1, 3
+    v += d3d_dpp_u64<0x143, 0xc>(v);                      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t d3d_dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += d3d_dpp_u32<0x111, 0xf>(v);
+    v += d3d_dpp_u32<0x112, 0xf>(v);
+    v += d3d_dpp_u32<0x114, 0xf>(v);
+    v += d3d_dpp_u32<0x118, 0xf>(v);
+    v += d3d_dpp_u32<0x142, 0xa>(v);
+    v += d3d_dpp_u32<0x143, 0xc>(v);
+    return v;
+}
+// sum over the wavefront, the same in every lane (wave-uniform: lane 63 of the scan)
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    const unsigned long long incl = wave_incl_scan_u64(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)incl, kWave - 1);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(incl >> 32), kWave - 1);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Reductions over the wavefront on the same DPP steps; the result is valid in LANE 63 only.  A lane without a source adds
+// nothing: 0.0 for the sum, its own value for max / min.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double d3d_dpp_f64(double v)
+{
+    const unsigned long long b = d3d_dpp_u64<CTRL, ROW_MASK>((unsigned long long)__double_as_longlong(v));
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ double wave_sum_f64_lane63(double v)
+{
+    v += d3d_dpp_f64<0x111, 0xf>(v);
+    v += d3d_dpp_f64<0x112, 0xf>(v);
+    v += d3d_dpp_f64<0x114, 0xf>(v);
+    v += d3d_dpp_f64<0x118, 0xf>(v);
+    v += d3d_dpp_f64<0x142, 0xa>(v);
+    v += d3d_dpp_f64<0x143, 0xc>(v);
+    return v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float d3d_dpp_f32_self(float v)
+{
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xf, false));
+}
+// IS_MAX: std::max(acc, x) = acc < x ? x : acc; else std::min(acc, x) = x < acc ? x : acc  (voxelize.cpp:146, 150)
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_extreme_f32_lane63(float v)
+{
+#define D3D_EXT_STEP(CTRL, MASK)                                             \
+    {                                                                        \
+        const float t = d3d_dpp_f32_self<CTRL, MASK>(v);                     \
+        v = IS_MAX ? (v < t ? t : v) : (t < v ? t : v);                      \
     }
+    D3D_EXT_STEP(0x111, 0xf) D3D_EXT_STEP(0x112, 0xf) D3D_EXT_STEP(0x114, 0xf) D3D_EXT_STEP(0x118, 0xf)
+    D3D_EXT_STEP(0x142, 0xa) D3D_EXT_STEP(0x143, 0xc)
+#undef D3D_EXT_STEP
     return v;
 }
 

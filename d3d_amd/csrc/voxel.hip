@@ -1033,6 +1033,22 @@ __global__ __launch_bounds__(256) void k_overflow_reduce(const float4 *__restric
 // work -- voxel lookup, counting, first index, rank in point order -- in LDS and writes the rows next to their rank.
 // Numbering by first occurrence stays a prefix count over point indices; it is merged with the per-voxel outputs
 // (k_meta_first), whose stores are then coalesced by voxel id.
+// Diagnostic build only (make PHASE_CLOCKS=1; tools/phase_clocks.py): wavefront 0 of every workgroup adds the cycles between
+// its phase marks to g_phase[kernel][phase]; the product build compiles none of it.
+#ifdef D3D_PHASE_CLOCKS
+__device__ unsigned long long g_phase[4][16];
+#define D3D_PHASE_DECL unsigned long long ph_t_ = __builtin_readcyclecounter()
+#define D3D_PHASE(K, P)                                                                                  \
+    do {                                                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                    \
+        if (threadIdx.x == 0) atomicAdd(&g_phase[K][P], now_ - ph_t_);                                   \
+        ph_t_ = now_;                                                                                    \
+    } while (0)
+#else
+#define D3D_PHASE_DECL do { } while (0)
+#define D3D_PHASE(K, P) do { } while (0)
+#endif
+
 constexpr int kBinTile = 4096;                // points per pass of a workgroup of k_bin_count / k_bin_scatter
 // passes per workgroup: a workgroup's tile is kBinTile * bin_passes(n) points.  Frames above 2 M points take 4 -- the tile x
 // bucket matrix (written by k_bin_count, scanned by k_bin_scan, read by k_bin_scatter) shrinks by that factor: 64 -> 16 MB
@@ -1259,14 +1275,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
 // config 2, i.e. a quarter of the requests of one scattered store per point; frames above 4 M points keep the three-pass
 // partition, where runs would shrink to single entries and the table would outgrow the entries).
 constexpr int kSortThreads = 1024;
-constexpr int kSortItems = 8;                              // points per lane
-constexpr int kSortTileShift = 13;
-constexpr int kSortTile = kSortThreads * kSortItems;       // 8192 points per tile: offsets and run lengths fit 16 bits
-static_assert(kSortTile == (1 << kSortTileShift) && kFlagTile % kSortTile == 0, "arrays are padded to kFlagTile");
-constexpr int64_t kTileSortMaxPoints = 4ll << 20;          // <= 512 tiles; k_bucket_index keeps the run table in LDS (<= 1024)
-constexpr int kRunCap = 1024;
+constexpr int64_t kTileSortMaxPoints = 2ll << 20;          // beyond: runs shrink to single entries (4 M points: no gain measured)
+constexpr int kRunCap = 1024;                              // tiles: k_bucket_index keeps the run table in LDS
 
-template <class Key, bool VEC4, bool ROWS>
+// kSortItems points per lane: tiles of 1024 * kSortItems points (offsets and run lengths fit 16 bits)
+template <class Key, bool VEC4, bool ROWS, int kSortItems>
 __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float *__restrict__ points, int64_t n, int c, uint32_t nbins,
                                                             uint32_t ntiles, typename BinEntry<ROWS>::type *__restrict__ tsort,
                                                             uint32_t *__restrict__ table /* [nbins][ntiles] */,
@@ -1277,20 +1290,19 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
 {
     typedef typename Key::bin_key_t KT;
     typedef BinEntry<ROWS> E;
+    constexpr int kSortTile = kSortThreads * kSortItems;
+    constexpr int kSortTileShift = kSortItems == 8 ? 13 : 12;
+    static_assert(kSortTile == (1 << kSortTileShift) && kFlagTile % kSortTile == 0, "arrays are padded to kFlagTile");
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
     KT *keys = reinterpret_cast<KT *>(tile_lds);                           // [kSortTile] in bucket order
     uint32_t *h = reinterpret_cast<uint32_t *>(keys + kSortTile);           // [nbins] histogram, then the buckets' offsets
     uint16_t *lidx = reinterpret_cast<uint16_t *>(h + nbins);               // [kSortTile] point index inside the tile
     __shared__ u64 smem[kSortThreads / kWave];
     __shared__ uint32_t sbad;
-    for (uint32_t b = threadIdx.x; b < nbins; b += kSortThreads) h[b] = 0;
-    if (threadIdx.x == 0) sbad = 0;
-    if (blockIdx.x == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
-    __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kSortTile + threadIdx.x;
     float v[kSortItems][3];
 #pragma unroll
-    for (int r = 0; r < kSortItems; r++) {
+    for (int r = 0; r < kSortItems; r++) {                  // (the loads fly while the histogram is cleared)
         const int64_t i = base + r * kSortThreads;
         if (i < n) {
             if (VEC4) {
@@ -1302,6 +1314,12 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
             }
         }
     }
+    D3D_PHASE_DECL;
+    for (uint32_t b = threadIdx.x; b < nbins; b += kSortThreads) h[b] = 0;
+    if (threadIdx.x == 0) sbad = 0;
+    if (blockIdx.x == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
+    __syncthreads();
+    D3D_PHASE(1, 0);                                        // points arrived, histogram cleared
     KT key[kSortItems];
     uint32_t word[kSortItems];
     bool bad = false;
@@ -1326,6 +1344,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
     }
     if (bad) sbad = 1;
     __syncthreads();
+    D3D_PHASE(1, 1);                                        // keys, histogram
     // buckets' offsets inside the tile: exclusive scan of the histogram (consecutive buckets per thread)
     constexpr int kPerMax = 8;                                  // nbins <= 8192 on this path (host-checked)
     const uint32_t per = nbins > (uint32_t)kSortThreads ? nbins / kSortThreads : 1u, b0 = threadIdx.x * per;
@@ -1348,6 +1367,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
     }
     if (threadIdx.x == 0) tileinfo[blockIdx.x] = (uint32_t)all | (sbad << 31);
     __syncthreads();
+    D3D_PHASE(1, 2);                                        // scan, table row stored
     const uint32_t tbase = (uint32_t)blockIdx.x << kSortTileShift;
 #pragma unroll
     for (int r = 0; r < kSortItems; r++) {
@@ -1360,8 +1380,10 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
         } else if (ppos && i < n) ppos[i] = kInf;
     }
     __syncthreads();
+    D3D_PHASE(1, 3);                                        // entries placed in LDS
     const uint32_t total = (uint32_t)all;
     for (uint32_t p = threadIdx.x; p < total; p += kSortThreads) tsort[tbase + p] = E::pack((u64)keys[p], tbase + lidx[p]);
+    D3D_PHASE(1, 4);                                        // run written (stores issued)
 }
 
 // One workgroup per bucket, everything per point in LDS: cell -> slot (open addressing), count, first index, segment of
@@ -1424,7 +1446,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                       uint32_t *__restrict__ unsorted_out /* ... and all of an overflow voxel's */,
                                                       // tile-sorted input (k_tile_sort): row blockIdx.x of the bucket-major table
                                                       // holds this bucket's run in every tile; NULL = `bent` is partitioned
-                                                      const uint32_t *__restrict__ table, uint32_t ntiles,
+                                                      const uint32_t *__restrict__ table, uint32_t ntiles, int tshift /* log2 tile */,
                                                       const uint32_t *__restrict__ tileinfo, uint32_t *__restrict__ gpos /* big buckets */)
 {
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
@@ -1443,6 +1465,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                     // T distinct cells with more than P points each)
     __shared__ uint32_t nover, fail;
     typedef float v4f __attribute__((ext_vector_type(4)));   // (an array of HIP float4 structs stayed in scratch)
+    D3D_PHASE_DECL;
     uint32_t bb, m;
     if (table) {
         // this bucket's runs: {offset in the tile, entries} per tile.  The offsets add up to the entries of all lower
@@ -1452,12 +1475,14 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         const uint32_t *row = table + (size_t)blockIdx.x * ntiles;
         const uint32_t per = ntiles > (uint32_t)kBucketThreads ? 2u : 1u, t0 = threadIdx.x * per;
         uint32_t wv[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) wv[k] = ((uint32_t)k < per && t0 + k < ntiles) ? row[t0 + k] : 0u;
+        // (the tables are cleared while the row is on its way)
+        for (int s = threadIdx.x; s < T; s += kBucketThreads) { tkey[s] = kFree; tcnt[s] = 0; tfirst[s] = kInf; }
+        if (threadIdx.x == 0) { nover = 0; fail = 0; }
         u64 mine = 0;
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            wv[k] = ((uint32_t)k < per && t0 + k < ntiles) ? row[t0 + k] : 0u;
-            mine += (u64)(wv[k] >> 16) | ((u64)(wv[k] & 0xffffu) << 32);
-        }
+        for (int k = 0; k < 2; k++) mine += (u64)(wv[k] >> 16) | ((u64)(wv[k] & 0xffffu) << 32);
         if (blockIdx.x == 0) {                      // a tile met a coordinate beyond the key range (k_tile_sort reset the word)
             bool bad = false;
             for (uint32_t t = threadIdx.x; t < ntiles; t += kBucketThreads) bad = bad || (tileinfo[t] >> 31);
@@ -1472,7 +1497,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         for (int k = 0; k < 2; k++) {
             if ((uint32_t)k < per && t0 + k < ntiles) {
                 seg[t0 + k] = run;
-                seg[kRunCap + t0 + k] = ((t0 + k) << kSortTileShift) + (wv[k] & 0xffffu);
+                seg[kRunCap + t0 + k] = ((t0 + k) << tshift) + (wv[k] & 0xffffu);
                 run += wv[k] >> 16;
             }
         }
@@ -1480,16 +1505,23 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         bb = bucket_base[blockIdx.x];
         m = bucket_base[blockIdx.x + 1] - bb;
     }
+    D3D_PHASE(0, 0);                                // row / bases loaded, run table
     if (m == 0) return;
-    for (int s = threadIdx.x; s < T; s += kBucketThreads) { tkey[s] = kFree; tcnt[s] = 0; tfirst[s] = kInf; }
-    if (threadIdx.x == 0) { nover = 0; fail = 0; }
+    if (!table) {
+        for (int s = threadIdx.x; s < T; s += kBucketThreads) { tkey[s] = kFree; tcnt[s] = 0; tfirst[s] = kInf; }
+        if (threadIdx.x == 0) { nover = 0; fail = 0; }
+    }
     // entry q of the bucket -> its place in `bent`
+    // (the last tile whose run starts at or before q -- empty runs share a start; a fixed number of halvings, no branches)
+    const int lsteps = table ? 32 - __builtin_clz(ntiles > 1 ? ntiles - 1 : 1u) : 0;
     auto locate = [&](uint32_t q) -> uint32_t {
         if (!table) return bb + q;
-        uint32_t lo = 0, hi = ntiles;               // the last tile whose run starts at or before q (empty runs share a start)
-        while (hi - lo > 1) {
+        uint32_t lo = 0, hi = ntiles;
+        for (int it = 0; it < lsteps; it++) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (seg[mid] <= q) lo = mid; else hi = mid;
+            const bool le = hi - lo > 1 && seg[mid] <= q;
+            lo = le ? mid : lo;
+            hi = (le || hi - lo <= 1) ? hi : mid;
         }
         return seg[kRunCap + lo] + (q - seg[lo]);
     };
@@ -1507,6 +1539,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         for (int k = 0; k < PER; k++) { c[k] = tcnt[s0 + k]; mine += ((u64)c[k] << 32) | ((kSkipSingles ? c[k] > 1 : c[k] > 0) ? 1u : 0u); }
         u64 all;
         u64 ex = block_excl_scan_u64_lds<kBucketThreads>(mine, &all, smem);
+        D3D_PHASE(0, 7);                            // (records: the scan)
         uint32_t base = (uint32_t)(ex >> 32), j = (uint32_t)ex;
 #pragma unroll
         for (int k = 0; k < PER; k++) {
@@ -1541,7 +1574,15 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
     // accumulates in fp64 (insensitive to the order to ~1e-16 => the same float run to run; differs from the
     // reference's fp32 running sum by rounding only).  The result waits in row P of the voxel's segment, which no
     // ranked point uses.
-    auto reduce_overflow = [&](const uint32_t *sg, auto BIG) {
+    // (register buckets: the first 64 rows of the wavefront's first overflow voxel are requested BEFORE the rank phase --
+    // overflow_first -- so that this gather's latency passes behind it)
+    auto overflow_first = [&](const uint32_t *sg, v4f &pre) {
+        const uint32_t no = ROWS && reduction != D3D_REDUCE_NONE ? nover : 0u, o = threadIdx.x >> 6;
+        if (o >= no) return;
+        const uint32_t w = tcnt[oslot[o]], lane = threadIdx.x & (kWave - 1);
+        if (lane < (w & 0xffffu)) pre = *reinterpret_cast<const v4f *>(&points4[sg[(w >> 16) + lane]]);
+    };
+    auto reduce_overflow = [&](const uint32_t *sg, auto BIG, const v4f *pre) {
         const uint32_t no = ROWS && reduction != D3D_REDUCE_NONE ? nover : 0u;
         if (no == 0) return;
         const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
@@ -1553,7 +1594,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             float e0, e1, e2, e3;
             e0 = e1 = e2 = e3 = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
             for (uint32_t k = lane; k < cnt; k += kWave) {
-                const float4 x = points4[sg[base + k]];
+                const v4f x = (pre && o == (threadIdx.x >> 6) && k == (uint32_t)lane)
+                                  ? *pre : *reinterpret_cast<const v4f *>(&points4[sg[base + k]]);
                 if (is_sum) { s0 += x.x; s1 += x.y; s2 += x.z; s3 += x.w; }
                 else if (reduction == D3D_REDUCE_MAX) {
                     e0 = e0 < x.x ? x.x : e0; e1 = e1 < x.y ? x.y : e1; e2 = e2 < x.z ? x.z : e2; e3 = e3 < x.w ? x.w : e3;
@@ -1561,22 +1603,18 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                     e0 = x.x < e0 ? x.x : e0; e1 = x.y < e1 ? x.y : e1; e2 = x.z < e2 ? x.z : e2; e3 = x.w < e3 ? x.w : e3;
                 }
             }
-#pragma unroll
-            for (int off = kWave / 2; off > 0; off >>= 1) {
-                if (is_sum) {
-                    s0 += __shfl_xor(s0, off, kWave); s1 += __shfl_xor(s1, off, kWave);
-                    s2 += __shfl_xor(s2, off, kWave); s3 += __shfl_xor(s3, off, kWave);
-                } else {
-                    const float t0 = __shfl_xor(e0, off, kWave), t1 = __shfl_xor(e1, off, kWave);
-                    const float t2 = __shfl_xor(e2, off, kWave), t3 = __shfl_xor(e3, off, kWave);
-                    if (reduction == D3D_REDUCE_MAX) {
-                        e0 = e0 < t0 ? t0 : e0; e1 = e1 < t1 ? t1 : e1; e2 = e2 < t2 ? t2 : e2; e3 = e3 < t3 ? t3 : e3;
-                    } else {
-                        e0 = t0 < e0 ? t0 : e0; e1 = t1 < e1 ? t1 : e1; e2 = t2 < e2 ? t2 : e2; e3 = t3 < e3 ? t3 : e3;
-                    }
-                }
+            // over the wavefront on the DPP path (valid in lane 63)
+            if (is_sum) {
+                s0 = wave_sum_f64_lane63(s0); s1 = wave_sum_f64_lane63(s1);
+                s2 = wave_sum_f64_lane63(s2); s3 = wave_sum_f64_lane63(s3);
+            } else if (reduction == D3D_REDUCE_MAX) {
+                e0 = wave_extreme_f32_lane63<true>(e0); e1 = wave_extreme_f32_lane63<true>(e1);
+                e2 = wave_extreme_f32_lane63<true>(e2); e3 = wave_extreme_f32_lane63<true>(e3);
+            } else {
+                e0 = wave_extreme_f32_lane63<false>(e0); e1 = wave_extreme_f32_lane63<false>(e1);
+                e2 = wave_extreme_f32_lane63<false>(e2); e3 = wave_extreme_f32_lane63<false>(e3);
             }
-            if (lane == 0) {
+            if (lane == kWave - 1) {
                 float4 out;
                 if (is_sum) {
                     const float d = reduction == D3D_REDUCE_MEAN ? (float)(int32_t)cnt : 1.0f;
@@ -1647,7 +1685,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             if (trimmed && rank >= P) trimmed[me] = 1;
             if (precpos) precpos[pos] = tfirst[s];
         }
-        reduce_overflow(sg, std::true_type{});
+        reduce_overflow(sg, std::true_type{}, (const v4f *)nullptr);
         return;
     }
 
@@ -1661,10 +1699,13 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
     static_for<ITEMS>([&](auto R) {
         constexpr int r = decltype(R)::value;
         const uint32_t q = threadIdx.x + r * kBucketThreads;
-        pos[r] = locate(q < m ? q : m - 1);
-        const typename E::type e = bent[pos[r]];
-        key_in[r] = E::key(e);
-        idx[r] = E::idx(e);
+        pos[r] = 0; key_in[r] = 0; idx[r] = 0;
+        if (q < m) {                                // (items past the bucket's end are never looked at again)
+            pos[r] = locate(q);
+            const typename E::type e = bent[pos[r]];
+            key_in[r] = E::key(e);
+            idx[r] = E::idx(e);
+        }
     });
     if constexpr (STAGE) {
         static_for<ITEMS>([&](auto R) {
@@ -1673,6 +1714,11 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         });
     }
     lds_barrier();
+    D3D_PHASE(0, 1);                                // tables cleared, entries located, loads issued
+#ifdef D3D_PHASE_CLOCKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    D3D_PHASE(0, 8);                                // (insert: the entries arrived)
+#endif
     static_for<ITEMS>([&](auto R) {
         constexpr int r = decltype(R)::value;
         const uint32_t q = threadIdx.x + r * kBucketThreads;
@@ -1690,14 +1736,19 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         }
     });
     lds_barrier();
+    D3D_PHASE(0, 2);                                // entries arrived, inserted
     records(std::false_type{});
     lds_barrier();
+    D3D_PHASE(0, 3);                                // records
     static_for<ITEMS>([&](auto R) {
         constexpr int r = decltype(R)::value;
         const uint32_t q = threadIdx.x + r * kBucketThreads;
         if (q < m) seg[(tcnt[slot[r]] >> 16) + arr[r]] = idx[r];
     });
     lds_barrier();
+    D3D_PHASE(0, 4);                                // segments
+    v4f over_pre = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (ROWS) overflow_first(seg, over_pre);
     static_for<ITEMS>([&](auto R) {
         constexpr int r = decltype(R)::value;
         const uint32_t q = threadIdx.x + r * kBucketThreads;
@@ -1721,7 +1772,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             if (precpos) precpos[pos[r]] = tfirst[s];
         }
     });
-    reduce_overflow(seg, std::false_type{});
+    D3D_PHASE(0, 5);                                // ranks, list stores issued
+    reduce_overflow(seg, std::false_type{}, ROWS ? &over_pre : (const v4f *)nullptr);
+    D3D_PHASE(0, 6);                                // overflow voxels reduced
 }
 
 // 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF (<= 1024 of them:
@@ -1771,8 +1824,11 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
         all += x;
         if (t < tile) before += x;
     }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) { before += __shfl_xor(before, o, kWave); all += __shfl_xor(all, o, kWave); }
+    {
+        const u64 both = wave_sum_u64(((u64)all << 32) | before);       // (each below 2^32: the halves do not carry)
+        before = (uint32_t)both;
+        all = (uint32_t)(both >> 32);
+    }
     if (i == 0) {
         counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
         counts[D3D_COUNT_AUX] = 0;
@@ -1868,8 +1924,11 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
         all += x;
         if (t < tile) before += x;
     }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) { before += __shfl_xor(before, o, kWave); all += __shfl_xor(all, o, kWave); }
+    {
+        const u64 both = wave_sum_u64(((u64)all << 32) | before);       // (each below 2^32: the halves do not carry)
+        before = (uint32_t)both;
+        all = (uint32_t)(both >> 32);
+    }
     if (i == 0) {
         counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
         counts[D3D_COUNT_AUX] = 0;
@@ -1906,12 +1965,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     }
     const uint32_t base = rec.z, cnt = rec.w;
     const uint32_t kept = cnt < P ? cnt : P;                // 0 for the lanes past nv
-    uint32_t incl = kept;                                   // rows before this voxel in the wavefront's flat row list
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, kWave);
-        if (lane >= d) incl += t;
-    }
+    const uint32_t incl = wave_incl_scan_u32(kept);         // rows before this voxel in the wavefront's flat row list
     const uint32_t off = incl - kept;
     sh_off[lane] = off; sh_base[lane] = base; sh_first[lane] = il; sh_kept[lane] = (uint16_t)kept;
     wave_lds_fence();
@@ -2112,8 +2166,11 @@ __global__ __launch_bounds__(256) void k_emit_c(Key kf, int64_t npad, const uint
         all += x;
         if (t < tile) before += x;
     }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) { before += __shfl_xor(before, o, kWave); all += __shfl_xor(all, o, kWave); }
+    {
+        const u64 both = wave_sum_u64(((u64)all << 32) | before);       // (each below 2^32: the halves do not carry)
+        before = (uint32_t)both;
+        all = (uint32_t)(both >> 32);
+    }
     if (i == 0) {
         counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
         counts[D3D_COUNT_AUX] = 0;
@@ -2135,12 +2192,7 @@ __global__ __launch_bounds__(256) void k_emit_c(Key kf, int64_t npad, const uint
     if (mine) rec = vrec[el];
     const uint32_t base = rec.z, cnt = rec.w;
     const uint32_t kept = cnt < P ? cnt : P;                // 0 for the lanes past nv
-    uint32_t incl = kept;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, kWave);
-        if (lane >= d) incl += t;
-    }
+    const uint32_t incl = wave_incl_scan_u32(kept);
     const uint32_t off = incl - kept;
     sh_off[lane] = off; sh_base[lane] = base; sh_first[lane] = il; sh_kept[lane] = (uint16_t)kept;
     wave_lds_fence();
@@ -2290,12 +2342,13 @@ __global__ __launch_bounds__(256) void k_map_binned(const uint32_t *__restrict__
                                                     const uint32_t *__restrict__ precpos, const uint32_t *__restrict__ ent32,
                                                     int idx_stride, int idx_off, const uint32_t *__restrict__ vidof,
                                                     int64_t *mapping, int32_t *keepid, const unsigned char *__restrict__ trimmed,
-                                                    const uint32_t *__restrict__ tileinfo /* tile-sorted entries: */, uint32_t ntiles)
+                                                    const uint32_t *__restrict__ tileinfo /* tile-sorted entries: */, uint32_t ntiles,
+                                                    int tshift)
 {
     // entries partitioned by bucket: positions [0, total); tile-sorted: the first tileinfo[t] positions of every tile
-    const uint32_t total = tileinfo ? ntiles << kSortTileShift : bucket_base[nbins];
+    const uint32_t total = tileinfo ? ntiles << tshift : bucket_base[nbins];
     for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
-        if (tileinfo && (p & (kSortTile - 1)) >= (tileinfo[p >> kSortTileShift] & 0x7fffffffu)) continue;
+        if (tileinfo && (p & ((1u << tshift) - 1)) >= (tileinfo[p >> tshift] & 0x7fffffffu)) continue;
         const uint32_t e = precpos[p];
         const uint32_t vid = e == kInf ? kNoVoxel : vidof[e];
         const uint32_t i = ent32[(size_t)p * idx_stride + idx_off];
@@ -2655,7 +2708,8 @@ static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t flags, uint32_
     int hshift = 0;
     // buckets of ~512 points up to 8192 buckets, then of up to 1024 (8 M points with 16384 buckets of 512: scatter and bucket
     // kernel 10 % slower than with 8192 of 1024), the last doubling only for frames that need it
-    while (nbins < 8192u && (int64_t)nbins * kBucketTarget < n) { nbins <<= 1; hshift++; }
+    static const int tune_target = getenv("D3D_TUNE_BUCKET") ? atoi(getenv("D3D_TUNE_BUCKET")) : kBucketTarget;   // (tuning, temporary)
+    while (nbins < 8192u && (int64_t)nbins * tune_target < n) { nbins <<= 1; hshift++; }
     while (nbins < (uint32_t)kBinMax && (int64_t)nbins * 1024 < n) { nbins <<= 1; hshift++; }
     if ((int64_t)nbins * 1024 < n) return false;        // more than 16 M points: buckets would outgrow a workgroup
     const uint64_t ntiles = d3d_divup((int64_t)(w.npad / kBinTile), (int64_t)bin_passes(n));
@@ -2697,7 +2751,9 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     const size_t bin_lds = (size_t)nbins * 4;                 // (at 16384 buckets the scatter's 64 KB + 128 B exceed the default limit)
     // one-launch partition (k_tile_sort) whenever the frame and the table fit; else, or on request, the three-pass one
-    const uint32_t stiles = (uint32_t)(w.npad >> kSortTileShift);
+    static const int tune_items = getenv("D3D_TUNE_SORT_ITEMS") ? atoi(getenv("D3D_TUNE_SORT_ITEMS")) : 8;   // (tuning, temporary)
+    const int tshift = tune_items == 4 ? 12 : 13;
+    const uint32_t stiles = (uint32_t)(w.npad >> tshift);
     uint32_t *table = nullptr, *tileinfo = nullptr, *gpos = reinterpret_cast<uint32_t *>(w.vinfo) + w.npad;
     if (tile_sort && n <= kTileSortMaxPoints && nbins <= 8192u && stiles <= (uint32_t)kRunCap &&
         ((uint64_t)nbins + 1) * stiles * 4 <= w.cap * 8) {
@@ -2705,21 +2761,19 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         tileinfo = tilecnt + (size_t)nbins * stiles;
     }
     if (table) {
-        const size_t lds = (size_t)kSortTile * (sizeof(typename Key::bin_key_t) + 2) + bin_lds;
+        const size_t lds = ((size_t)1 << tshift) * (sizeof(typename Key::bin_key_t) + 2) + bin_lds;
         uint32_t *ppos = o.map_later ? pbin : nullptr;
-        if (vec4) {
-            if (lds + 1024 > 65536)
-                D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort<Key, true, ROWS>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            D3D_LAUNCH("k_tile_sort", (k_tile_sort<Key, true, ROWS>), dim3(stiles), dim3(kSortThreads), lds, st, kf, points, n, c, nbins,
-                       stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid);
-        } else {
-            if (lds + 1024 > 65536)
-                D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort<Key, false, ROWS>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            D3D_LAUNCH("k_tile_sort", (k_tile_sort<Key, false, ROWS>), dim3(stiles), dim3(kSortThreads), lds, st, kf, points, n, c, nbins,
-                       stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid);
-        }
+#define D3D_TILE_SORT(V4, IT)                                                                                                   \
+    do {                                                                                                                        \
+        if (lds + 1024 > 65536)                                                                                                 \
+            D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort<Key, V4, ROWS, IT>),                  \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+        D3D_LAUNCH("k_tile_sort", (k_tile_sort<Key, V4, ROWS, IT>), dim3(stiles), dim3(kSortThreads), lds, st, kf, points, n, c, \
+                   nbins, stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid);               \
+    } while (0)
+        if (vec4) { if (tshift == 13) D3D_TILE_SORT(true, 8); else D3D_TILE_SORT(true, 4); }
+        else { if (tshift == 13) D3D_TILE_SORT(false, 8); else D3D_TILE_SORT(false, 4); }
+#undef D3D_TILE_SORT
     } else {
     if (bin_lds + 256 > 65536) {
         D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_scatter<ROWS>),
@@ -2739,17 +2793,17 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    reinterpret_cast<const typename BinEntry<false>::type *>(bent), p4, bucket_base, hshift, o.P, (int)D3D_REDUCE_NONE,
                    w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
-                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr, table, stiles, tileinfo, gpos);
+                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos);
     else if (ROWS && (o.emit_voxels || o.emit_reduce))
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, true, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
                    counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list /* the per-point keys are
-                   done with it; w.unsorted may be precpos */, (uint32_t *)nullptr, table, stiles, tileinfo, gpos);
+                   done with it; w.unsorted may be precpos */, (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos);
     else
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
                    precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                   table, stiles, tileinfo, gpos);
+                   table, stiles, tshift, tileinfo, gpos);
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 1024 (n <= 16 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, w.big_count);
     const dim3 grid((unsigned)(w.npad / 256));
@@ -2786,7 +2840,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
             if (want_map && !o.map_later)
                 D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
                            reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping, o.keepid,
-                           (const unsigned char *)o.trimmed, (const uint32_t *)tileinfo, stiles);
+                           (const unsigned char *)o.trimmed, (const uint32_t *)tileinfo, stiles, tshift);
             return D3D_OK;
         }
     }
@@ -2801,7 +2855,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     if (want_map && !o.map_later)
         D3D_LAUNCH("k_map_binned", k_map_binned, dim3(grid_for(n, 256)), dim3(256), 0, st, bucket_base, nbins, precpos,
                    reinterpret_cast<const uint32_t *>(bent), E::kIdxStride, E::kIdxOff, x.vidof, o.mapping, o.keepid,
-                   (const unsigned char *)o.trimmed, (const uint32_t *)tileinfo, stiles);
+                   (const unsigned char *)o.trimmed, (const uint32_t *)tileinfo, stiles, tshift);
     return D3D_OK;
 }
 
@@ -3273,3 +3327,15 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                        out_mapping, out_npoints, out_coords, counts, workspace, workspace_bytes, stream, host_counts,
                        sparse_counts);
 }
+
+#ifdef D3D_PHASE_CLOCKS
+// diagnostic build: read (and clear) the phase clocks -- out[4][16] u64 host array
+extern "C" int d3d_debug_phase_clocks(unsigned long long *out)
+{
+    D3D_HIP_CHECK(hipDeviceSynchronize());
+    D3D_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64));
+    unsigned long long zero[64] = {0};
+    D3D_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof(zero)));
+    return D3D_OK;
+}
+#endif

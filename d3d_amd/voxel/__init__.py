@@ -13,7 +13,7 @@ import enum
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, options
 from ..utils import Dict
 
 
@@ -100,20 +100,11 @@ def _check_status(status, what):
                          "(non-finite point or voxel size too small)" % what)
 
 
-# Index options applied to every call that does not pass its own (bits: _lib.VOXEL_PATH_HASH, _lib.VOXEL_PLAIN_SLOTS).
-# A diagnostic / test hook, read when a call starts; nothing in the package writes it -- the overflow retries below pass
-# their options as per-call arguments of the C ABI, so concurrent callers (threads, streams) never see each other's.
-default_flags = 0
-# Test hook: fill every output buffer of the dense operator with NaN / 0xff patterns before the call, so that a row the
-# kernels fail to write cannot hide behind fresh (zeroed) memory.  Read when a call starts.
-poison_outputs = False
-
-
 def _with_retry(run, flags=None):
     """run(flags) on the fast index first.  A bucket of the binned index that outgrew its workgroup's table -> once more on
     the hash table; a field of the packed one-word hash slot that overflowed (a voxel with > 2^cb points, or -- sparse
     contract -- a bounding box of voxel coordinates too large for the key field) -> once more with two-word slots."""
-    flags = default_flags if flags is None else int(flags)
+    flags = options.current().voxel_flags if flags is None else int(flags)     # per call, or the calling context's
     try:
         return run(flags)
     except _BinOverflow:
@@ -146,12 +137,15 @@ def _workspace_bytes2(lib, n):
     return b
 
 
-def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type, flags=None):
+def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type, flags=None, poison=None):
     """voxelize_3d_dense of the reference (voxelize.h:9-12; voxelize.cpp:45-199).
 
     Returns dict(voxels[V,P,C] f32, coords[V,3] i64, voxel_pmask[V,P] bool,
     voxel_npoints[V] i32 [, aggregates[V,C] f32 when reduction != NONE]).
 
+    flags: per-call index options (_lib.VOXEL_*; None = the calling context's, d3d_amd.options).  poison (test hook): fill
+    every output buffer with NaN / 0xff patterns first, so that a row the kernels fail to write cannot hide behind fresh
+    (zeroed) memory.
     """
     lib = _lib.load()
     pts, odev, dev = _stage(points)
@@ -172,7 +166,7 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
         counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
         ws = _lib.workspace(_workspace_bytes(lib, n), dev)
         note = _lib.NotifyBuffer.get()
-        if poison_outputs:
+        if options.current().poison if poison is None else poison:
             voxels.fill_(float("nan")); coords.fill_(-(1 << 62)); pmask.fill_(0xff); npts.fill_(-7)
             if agg is not None:
                 agg.fill_(float("nan"))
@@ -386,28 +380,29 @@ class VoxelGenerator:
             if self._max_voxels_filter not in (MaxVoxelsFilterType.NONE, MaxVoxelsFilterType.TRIM):
                 raise NotImplementedError("Only trim is implemented for max voxels filtering")
 
-    def __call__(self, points):
+    def __call__(self, points, flags=None, poison=None):
         """Returns a Dict: dense -> voxels, coords, voxel_pmask, voxel_npoints[, aggregates];
-        sparse -> points, points_mask, points_mapping, voxel_npoints, coords (voxel/__init__.py:79-104)."""
+        sparse -> points, points_mask, points_mapping, voxel_npoints, coords (voxel/__init__.py:79-104).
+        flags / poison: per-call options beyond the reference's signature (see voxelize_3d_dense)."""
         points = _as_tensor(points)
         odev = points.device
         if not points.is_cuda:
             points = points.to(_lib.require_gpu())    # stage once; results go back to the caller's device
         if self._dense:
             ret = Dict(voxelize_3d_dense(points, self._shape_h, self._bounds_h, self._max_points,
-                                         self._max_voxels, self._reduction))
+                                         self._max_voxels, self._reduction, flags=flags, poison=poison))
         else:
             pf, vf = int(self._max_points_filter), int(self._max_voxels_filter)
             if vf == MaxVoxelsFilterType.DESCENDING or points.shape[0] == 0:
                 # the count sort needs the number of voxels on the host: the two calls of the reference, two read-backs
-                sparse = voxelize_3d_sparse(points, self._size_h, 3)
+                sparse = voxelize_3d_sparse(points, self._size_h, 3, flags=flags)
                 ret = Dict(voxelize_3d_filter(points, sparse["points_mapping"], sparse["coords"],
                                               sparse["voxel_npoints"], self._vbounds, self._min_points,
                                               self._max_points, self._max_voxels, self._max_points_filter,
                                               self._max_voxels_filter))
             else:
                 ret = Dict(_sparse_filter_chained(points, self._size_h, self._vbounds, self._min_points,
-                                                  self._max_points, self._max_voxels, pf, vf))
+                                                  self._max_points, self._max_voxels, pf, vf, flags=flags))
             off = self._offset_dev.get(ret.coords.device)
             if off is None:
                 off = self._offset_dev[ret.coords.device] = self._offset.to(ret.coords.device)

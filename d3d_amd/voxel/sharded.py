@@ -130,8 +130,8 @@ class HipOps:
                 seg = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
                 rows = torch.empty((lib.d3d_voxelize_reduce_rows(n), 4), dtype=torch.float32, device=dev)
             ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), dev)
-            from . import default_flags
-            flags = default_flags
+            from .. import options
+            flags = options.current().voxel_flags
             if plain:      # the retry after a status overflow: general slots in the hash table (no bucket capacity to outgrow)
                 flags |= _lib.VOXEL_PATH_HASH | _lib.VOXEL_PLAIN_SLOTS
             rc = lib.d3d_voxelize_3d_reduce(

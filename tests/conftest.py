@@ -25,3 +25,12 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+
+@pytest.fixture(autouse=True)
+def _unwind_call_options():
+    """whatever options a test (or its fixtures) bound with call_opts.set_opts() end with the test"""
+    yield
+    import call_opts
+    call_opts.unwind()

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 import box_cases as bc
+from call_opts import cur_opts, set_opts
 import oracle
 
 pytestmark = pytest.mark.gpu
@@ -22,9 +23,8 @@ def pytest_generate_tests(metafunc):
 def nms_broad(request, monkeypatch):
     from d3d_amd import _lib, box
     mode = getattr(request, "param", "auto")
-    monkeypatch.setattr(box, "default_nms_flags", {"auto": 0, "grid": _lib.NMS_GENERAL, "sweep": _lib.NMS_BROAD_SWEEP,
-                                                   "levels": _lib.NMS_FORCE_LEVELS}[mode])
-    monkeypatch.setattr(box, "poison_outputs", True)    # every IoU / iou3d result buffer of this module starts as NaN
+    set_opts(nms_flags={"auto": 0, "grid": _lib.NMS_GENERAL, "sweep": _lib.NMS_BROAD_SWEEP, "levels": _lib.NMS_FORCE_LEVELS}[mode],
+             poison=True)                               # every IoU / iou3d result buffer of this module starts as NaN
     yield mode
 
 
@@ -170,11 +170,11 @@ def test_nms_dense_path_hooks(monkeypatch, hook, value, gen, n, thr):
     b, s = mk(n, 77)
     exp = oracle.box2d_nms(b, s, iou_method="rbox", iou_threshold=thr, score_threshold=0.1)
     from d3d_amd import _lib, box
-    base = box.default_nms_flags
-    monkeypatch.setattr(box, "default_nms_flags", base | (_lib.NMS_FORCE_DENSE if hook == "force_dense" else _lib.nms_cand_cap(value)))
+    base = cur_opts().nms_flags
+    set_opts(nms_flags=base | (_lib.NMS_FORCE_DENSE if hook == "force_dense" else _lib.nms_cand_cap(value)))
     keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=thr, score_threshold=0.1).cpu().numpy()
     assert np.array_equal(keep, exp)
-    monkeypatch.setattr(box, "default_nms_flags", base)
+    set_opts(nms_flags=base)
     keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=thr, score_threshold=0.1).cpu().numpy()
     assert np.array_equal(keep, exp)
 
@@ -189,11 +189,11 @@ def test_nms_chained_scan_gives_up_and_hands_over(monkeypatch, scan):
     b, s = synth.boxes2d_sparse(6000, 81)
     exp = oracle.box2d_nms_hard_candidates(b, s, "rbox", 0.3, 0.1)
     hook = _lib.NMS_TEST_WITHHOLD | (_lib.NMS_GENERAL if scan == "grid cells" else _lib.NMS_BROAD_SWEEP)
-    monkeypatch.setattr(box, "default_nms_flags", hook)
+    set_opts(nms_flags=hook)
     for _ in range(2):
         keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3, score_threshold=0.1).cpu().numpy()
         assert np.array_equal(keep, exp)
-    monkeypatch.setattr(box, "default_nms_flags", hook & ~_lib.NMS_TEST_WITHHOLD)         # and the next call is healthy again
+    set_opts(nms_flags=hook & ~_lib.NMS_TEST_WITHHOLD)         # and the next call is healthy again
     keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3, score_threshold=0.1).cpu().numpy()
     assert np.array_equal(keep, exp)
 
@@ -233,7 +233,7 @@ def test_nms_list_path_equals_dense_path_at_scale(monkeypatch):
     b, s = synth.boxes2d_sparse(30000, 5)
     keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3).cpu().numpy()
     from d3d_amd import _lib, box
-    monkeypatch.setattr(box, "default_nms_flags", box.default_nms_flags | _lib.NMS_FORCE_DENSE)
+    set_opts(nms_flags=cur_opts().nms_flags | _lib.NMS_FORCE_DENSE)
     dense = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3).cpu().numpy()
     assert np.array_equal(keep, dense) and 0 < keep.sum() < len(keep)
 
@@ -282,9 +282,16 @@ def test_full_size_cfg4_properties():
     assert torch.allclose(m, mt.t(), atol=2e-3)            # IoU is symmetric
     best = m.argmax(1).cpu().numpy()
     assert np.mean(best == np.repeat(np.arange(5000), 4)) > 0.9   # each pred matches its own GT
-    rows = np.random.default_rng(0).choice(20000, 64, replace=False)
-    exp = oracle.iou3d(pred[rows], gt, "rbox", nthreads=8)
-    assert np.max(np.abs(m[torch.from_numpy(rows).cuda()].cpu().numpy() - exp)) < 1e-3
+    # EVERY pair of the 20 k x 5 k matrix against the oracle (1e8 pairs, NaN-poisoned result buffer), both methods; the
+    # non-zero pattern too: a pair is non-zero here iff it is in the oracle, up to pairs whose overlap is rounding noise
+    for method, mat in (("rbox", m), ("box", iou3d(T(pred), T(gt), "box"))):
+        got = mat.cpu().numpy()
+        exp = oracle.iou3d(pred, gt, method, nthreads=8)
+        assert not np.isnan(got).any()
+        assert np.max(np.abs(got - exp)) < 1e-3
+        differ = (got != 0) != (exp != 0)
+        assert np.count_nonzero(exp) > 150000 and np.max(np.maximum(got, exp)[differ], initial=0.0) < 1e-5
+        assert int(differ.sum()) <= 4, int(differ.sum())
 
 
 def test_box_crop_reference_case():
@@ -386,10 +393,10 @@ def test_iou_candidate_list_overflow_falls_back(monkeypatch):
     b2, _ = synth.boxes2d_dense(200, 52)
     exp = oracle.box2d_iou(b1, b2, "rbox", nthreads=4)
     from d3d_amd import _lib, box
-    monkeypatch.setattr(box, "default_iou_flags", _lib.iou_list_cap(64))
+    set_opts(iou_flags=_lib.iou_list_cap(64))
     got = box2d_iou(T(b1), T(b2), method="rbox").cpu().numpy()
     assert np.max(np.abs(got - exp)) < 1e-9
-    monkeypatch.setattr(box, "default_iou_flags", 0)
+    set_opts(iou_flags=0)
     got = box2d_iou(T(b1), T(b2), method="rbox").cpu().numpy()
     assert np.max(np.abs(got - exp)) < 1e-9
 
@@ -484,9 +491,9 @@ def test_softnms_vs_oracle(method, sup, param, monkeypatch):
             assert np.array_equal(keep, exp), (n, sthr, int(np.sum(keep != exp)))
             if n == 300:
                 from d3d_amd import _lib, box
-                monkeypatch.setattr(box, "default_nms_flags", box.default_nms_flags | _lib.NMS_SOFT_NO_LDS)
+                set_opts(nms_flags=cur_opts().nms_flags | _lib.NMS_SOFT_NO_LDS)
                 keep = box2d_nms(T(b), T(s), **kw).cpu().numpy()
-                monkeypatch.setattr(box, "default_nms_flags", box.default_nms_flags & ~_lib.NMS_SOFT_NO_LDS)
+                set_opts(nms_flags=cur_opts().nms_flags & ~_lib.NMS_SOFT_NO_LDS)
                 assert np.array_equal(keep, exp)
 
 
@@ -553,11 +560,11 @@ def test_nms_detector_like_clusters(nobj, per):
     b = np.repeat(c, per, 0) + rng.normal(0, 1, (nobj * per, 5)) * [1.5, 1.5, 1.0, 1.0, 0.05]
     s = rng.permutation(nobj * per) / (nobj * per)
     from d3d_amd import _lib, box
-    base = box.default_nms_flags
+    base = cur_opts().nms_flags
     for method, thr in [("rbox", 0.5), ("box", 0.3)]:
         exp = oracle.box2d_nms(b, s, iou_method=method, iou_threshold=thr)
         for extra in (0, _lib.NMS_ONE_LEVEL):             # (two levels of the level kernels, or one)
-            box.default_nms_flags = base | extra          # (the fixture's monkeypatch restores it)
+            set_opts(nms_flags=base | extra)              # (unwound by conftest)
             keep = box2d_nms(T(b), T(s), iou_method=method, iou_threshold=thr).cpu().numpy()
             assert np.array_equal(keep, exp), (method, extra, int(np.sum(keep != exp)))
         assert keep.sum() < 20 * nobj

@@ -187,6 +187,9 @@ def test_matcher_distance_cache_config4():
     for metric, rot in ((DistanceTypes.RIoU, True), (DistanceTypes.IoU, False)):
         cache = prepare_boxes(T(dt9), T(gt9), metric)
         assert cache.shape == (20000, 5000) and cache.dtype == torch.float32
+        full = oracle.iou3d(np.clip(dt9[:, 2:9], [-np.inf] * 3 + [-1e3] * 3 + [-np.inf], [np.inf] * 3 + [1e3] * 3 + [np.inf]),
+                            gt9[:, 2:9], "rbox" if rot else "box", nthreads=8)          # all 1e8 pairs (matcher.pyx:50-51 clip)
+        assert np.max(np.abs(cache.cpu().numpy() - (np.float32(1) - full))) < 1e-3
         exp = oracle.prepare_boxes(dt9[rows], gt9, rot)
         assert np.max(np.abs(cache[T(rows)].cpu().numpy() - exp)) < 1e-3
         assert float(cache.max()) == 1.0 and float(cache.min()) >= 0.0 and abs(float(cache[6, 6])) < 1e-6 and exp[41, 6] < 1e-6

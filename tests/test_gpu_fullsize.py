@@ -50,10 +50,9 @@ def test_nms_300k_boxes_beyond_the_inline_paths():
 @pytest.fixture
 def poisoned_iou():
     """the IoU operators' result buffers are filled with NaN before the kernels run"""
-    from d3d_amd import box
-    box.poison_outputs = True
+    from call_opts import set_opts
+    set_opts(poison=True)
     yield
-    box.poison_outputs = False
 
 
 def test_cfg3_iou_100k_x_100k_fp64_full_launch(poisoned_iou):
@@ -142,17 +141,11 @@ def test_cfg5_single_gpu_dense_contract(cfg5, path):
     """config 5's frame on ONE GPU through the dense contract at max_points = 32: 1.086 G cells (30-bit linear keys), ~5.9 M
     voxels, 3 GB of voxels[V,32,4] compared in row chunks; output buffers poisoned first.  Both output stages: the fused
     k_emit and (split) k_meta_first + k_fill_c4<64>."""
-    from d3d_amd import _lib, synth, voxel
+    from d3d_amd import _lib, synth
     from d3d_amd.voxel import VoxelGenerator
     cloud, exp = cfg5
-    voxel.poison_outputs = True
-    voxel.default_flags = _lib.VOXEL_SPLIT_FILL if path == "split" else 0
-    try:
-        ret = VoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, dense=True, reduction="mean", max_points=32,
-                             max_voxels=len(cloud))(T(cloud))
-    finally:
-        voxel.poison_outputs = False
-        voxel.default_flags = 0
+    ret = VoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, dense=True, reduction="mean", max_points=32,
+                         max_voxels=len(cloud))(T(cloud), flags=_lib.VOXEL_SPLIT_FILL if path == "split" else 0, poison=True)
     assert 5000000 < len(exp["coords"]) < 7000000
     assert np.array_equal(ret.coords.cpu().numpy(), exp["coords"])
     assert np.array_equal(ret.voxel_npoints.cpu().numpy(), exp["voxel_npoints"])

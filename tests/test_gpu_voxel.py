@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import oracle
+from call_opts import cur_opts, set_opts
 from golden_io import GOLDEN, derived_pmask, load_voxel_cases
 
 pytestmark = pytest.mark.gpu
@@ -17,13 +18,10 @@ def index_path(request):
     contract: the fused output kernel k_emit) and the hash table (tests that pick a path themselves -- `voxel_path` --
     override this); "split" = binned index with the two-launch output stage (k_meta_first + k_fill_c4).  The dense
     operator's output buffers are poisoned before every call."""
-    from d3d_amd import _lib, voxel
-    voxel.default_flags = {"hash": _lib.VOXEL_PATH_HASH, "split": _lib.VOXEL_SPLIT_FILL,
-                           "3pass": _lib.VOXEL_PARTITION_3PASS}.get(request.param, 0)
-    voxel.poison_outputs = True
+    from d3d_amd import _lib
+    set_opts(voxel_flags={"hash": _lib.VOXEL_PATH_HASH, "split": _lib.VOXEL_SPLIT_FILL,
+                          "3pass": _lib.VOXEL_PARTITION_3PASS}.get(request.param, 0), poison=True)
     yield request.param
-    voxel.default_flags = 0
-    voxel.poison_outputs = False
 
 
 CASES = load_voxel_cases()
@@ -258,7 +256,7 @@ def test_plain_slot_layout_matches(monkeypatch):
     """the general (unpacked) hash-slot layout used for n >= 2^24 points gives the same results"""
     from d3d_amd import _lib, synth, voxel
     from d3d_amd.voxel import VoxelGenerator
-    monkeypatch.setattr(voxel, "default_flags", voxel.default_flags | _lib.VOXEL_PLAIN_SLOTS)
+    set_opts(voxel_flags=cur_opts().voxel_flags | _lib.VOXEL_PLAIN_SLOTS)
     cloud = synth.lidar_like(60000, 17)
     kw = dict(reduction="mean", max_points=6, max_voxels=30000, dense=True)
     exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, [352, 400, 20], **kw)(cloud)
@@ -388,9 +386,8 @@ def voxel_path():
     from d3d_amd import _lib, voxel
 
     def set_path(path):
-        voxel.default_flags = _lib.VOXEL_PATH_HASH if path == 1 else 0
+        set_opts(voxel_flags=_lib.VOXEL_PATH_HASH if path == 1 else 0)
     yield set_path
-    voxel.default_flags = 0
 
 
 @pytest.mark.parametrize("n,P,mv,reduction", [(1, 4, 10, "mean"), (7, 1, 7, "max"), (300, 3, 100, "min"), (5000, 32, 5000, "mean"),

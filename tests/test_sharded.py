@@ -141,10 +141,10 @@ def test_sharded_orchestration_gloo_world2(reduction, exchange):
 @pytest.fixture(params=["auto", "hash"])
 def index_path(request):
     """both index paths of the per-rank voxelizer (automatic = binned whenever eligible, hash table)"""
-    from d3d_amd import _lib, voxel
-    voxel.default_flags = _lib.VOXEL_PATH_HASH if request.param == "hash" else 0
+    from d3d_amd import _lib
+    from call_opts import set_opts
+    set_opts(voxel_flags=_lib.VOXEL_PATH_HASH if request.param == "hash" else 0)
     yield request.param
-    voxel.default_flags = 0
 
 
 @pytest.mark.gpu

@@ -6,7 +6,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import kernel_profile, timed
-from d3d_amd import _lib, synth, voxel
+from d3d_amd import _lib, synth
 from d3d_amd.voxel import VoxelGenerator
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
@@ -17,13 +17,12 @@ B = torch.from_numpy(synth.lidar_like(n, 4 if big else 1, bounds)).cuda()
 
 
 def run(tag, flags, steps=20):
-    voxel.default_flags = flags
     gen = VoxelGenerator(bounds, shape, dense=True, max_voxels=n, reduction="mean", max_points=32)
     k = [0]
 
     def step():
         k[0] += 1
-        return gen(A if k[0] & 1 else B)
+        return gen(A if k[0] & 1 else B, flags=flags)
     dt = timed(step, steps, 4)
     prof = kernel_profile(step, steps)
     print("%-34s %7.1f us/step  sum %.1f " % (tag, dt / steps * 1e6, sum(v["avg_us"] for v in prof.values())),

@@ -13,16 +13,15 @@ def clustered(nobj, per, seed):
     b = np.repeat(c, per, 0) + rng.normal(0, 1, (nobj * per, 5)) * [1.5, 1.5, 1.0, 1.0, 0.05]
     return b, rng.random(nobj * per)
 
-from d3d_amd import _lib, box
+from d3d_amd import _lib
+from d3d_amd.box import nms2d, IouType, SupressionType
 modes = {"default": 0, "1 level": _lib.NMS_ONE_LEVEL}
 for nobj, per in [(1000, 100), (5000, 20), (200, 500), (20000, 5)]:
     b, s = clustered(nobj, per, 1)
     bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
     for tag, fl in modes.items():
-        box.default_nms_flags = fl
-        f = lambda: box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5)
+        f = lambda fl=fl: ~nms2d(bt, st, IouType.RBOX, SupressionType.HARD, 0.5, 0.0, 0.0, flags=fl)     # = box2d_nms, per-call flags
         dt = timed(f, 5, 1)
         prof = kernel_profile(f, 3)
         print("%d objects x %d boxes [%s]: %.2f ms, kept %d" % (nobj, per, tag, dt / 5 * 1e3, int(f().sum())),
               {k: round(v["total_ms"] / 3 * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:7]})
-    box.default_nms_flags = 0

@@ -5,7 +5,7 @@ import sys
 import torch
 sys.path.insert(0, ".")
 import bench
-from d3d_amd import _lib, synth, voxel
+from d3d_amd import _lib, synth
 from d3d_amd.voxel import VoxelGenerator
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
@@ -19,12 +19,10 @@ for n in sizes:
     for mode, gen in gens.items():
         for rep in range(2):
             for name, fl in (("tile-sort", 0), ("3-pass", _lib.VOXEL_PARTITION_3PASS)):
-                voxel.default_flags = fl
-                dt = bench.timed(lambda: gen(cloud), steps, 3)
-                prof = bench.kernel_profile(lambda: gen(cloud), steps)
+                dt = bench.timed(lambda: gen(cloud, flags=fl), steps, 3)
+                prof = bench.kernel_profile(lambda: gen(cloud, flags=fl), steps)
                 ks = sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])
                 print("n=%d %-11s %-9s %7.1f us/call | " % (n, mode, name, 1e6 * dt / steps) +
                       " ".join("%s %.1f" % (k.replace("k_", ""), p["avg_us"]) for k, p in ks[:9]), flush=True)
-    voxel.default_flags = 0
     del cloud, gens
     torch.cuda.empty_cache()
