@@ -52,20 +52,29 @@ def paint_label(boxes, cloud, semantics, labels=None):
     box; defaults to column 0 of [n,9] rows (tag.labels[0], abstraction.pyx:667)."""
     lib = _lib.load()
     bx, pts, dev, odev, convert = _ingress(boxes, cloud)
+    def as_u8(t, what):
+        # class ids travel as uint8 (abstraction.pyx:662-682 compares uint8 label arrays): a value outside [0, 255] would
+        # wrap silently in the cast -- refuse it
+        t = torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t
+        if t.numel() and t.dtype != torch.uint8:
+            lo, hi = float(t.min()), float(t.max())
+            if lo < 0 or hi > 255 or (t.is_floating_point() and bool((t != t.round()).any())):
+                raise ValueError("%s must be integers in [0, 255]" % what)
+        return t.to(dev, torch.uint8).contiguous()
     if labels is None:
         if bx.shape[1] != 9:
             raise ValueError("labels are needed with [M,7] boxes")
-        lab = bx[:, 0].to(torch.uint8)
+        lab = as_u8(bx[:, 0], "labels")
     else:
-        lab = (torch.from_numpy(np.ascontiguousarray(labels)) if isinstance(labels, np.ndarray) else labels).to(dev, torch.uint8)
-    sem = (torch.from_numpy(semantics) if isinstance(semantics, np.ndarray) else semantics).to(dev, torch.uint8).contiguous()
+        lab = as_u8(labels, "labels")
+    sem = as_u8(semantics, "semantics")
     m, n = bx.shape[0], pts.shape[0]
     if sem.numel() != n or lab.numel() != m:
         raise ValueError("semantics needs one entry per point, labels one per box")
     with torch.cuda.device(dev):
         idarr = torch.empty((n,), dtype=torch.int16, device=dev)      # uint16 bits (torch has no uint16 arithmetic type)
         rc = lib.d3d_paint_label(_lib.ptr(pts), n, pts.shape[1], _lib.ptr(sem), _lib.ptr(bx), m, bx.shape[1],
-                                 0 if bx.shape[1] == 7 else 2, _lib.ptr(lab.contiguous()), _lib.ptr(idarr), _lib.stream_ptr())
+                                 0 if bx.shape[1] == 7 else 2, _lib.ptr(lab), _lib.ptr(idarr), _lib.stream_ptr())
     _lib.check(rc, "paint_label")
     if convert or odev != dev:
         out = idarr.cpu().numpy().view(np.uint16)

@@ -138,6 +138,50 @@ __device__ __forceinline__ float wave_extreme_f32_lane63(float v)
     return v;
 }
 
+// ---------------------------------------------------------------- decoupled look-back (single-pass scans across workgroups)
+// One status word per tile: {state : 2 | value : 62}; state 0 = nothing yet, 1 = the tile's own total, 2 = the inclusive
+// prefix up to and including the tile (status[] zeroed by an earlier kernel).  A tile publishes its total at once, then walks
+// back 64 predecessors per step, adding totals until it meets an inclusive prefix -- in the steady state one or two steps,
+// whatever the number of tiles (summing ALL predecessors, as chained_prefix in box.hip does for its <= 1024 chunks, grows
+// with the tile number).  Tiles are numbered by a TICKET taken when the workgroup starts (lookback_ticket), not by
+// blockIdx: every predecessor of a waiting tile took its ticket earlier, so it is running and publishes before it waits --
+// progress wherever and in whatever order the workgroups are dispatched.  The value travels inside the word, so relaxed
+// agent-scope accesses suffice.  Values are sums of up to two packed fields below 2^31 / 2^30 (no carry between them).
+constexpr unsigned long long kLbAgg = 1ull << 62, kLbIncl = 2ull << 62, kLbMask = (1ull << 62) - 1;
+
+__device__ __forceinline__ unsigned int lookback_ticket(unsigned int *ticket, unsigned int *sid /* LDS */)
+{
+    if (threadIdx.x == 0) *sid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    return *sid;
+}
+
+// all 64 lanes of ONE wavefront call it; returns (in every lane) the sum of the totals of tiles 0 .. tile - 1
+__device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long *status, unsigned int tile, unsigned long long total)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    if (tile == 0) {
+        if (lane == 0) __hip_atomic_store(&status[0], kLbIncl | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&status[tile], kLbAgg | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long excl = 0;
+    long long base = (long long)tile - 1;
+    for (;;) {
+        const long long j = base - lane;
+        const unsigned long long s = j >= 0 ? __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kLbIncl;
+        const unsigned long long incl = __ballot((s >> 62) == 2ull), empty = __ballot((s >> 62) == 0ull);
+        const int p = incl ? __ffsll((long long)incl) - 1 : kWave - 1;         // the window: lanes 0 .. p
+        const unsigned long long window = p == kWave - 1 ? ~0ull : ((2ull << p) - 1ull);
+        if (empty & window) { __builtin_amdgcn_s_sleep(1); continue; }         // a predecessor has not published yet
+        excl += wave_sum_u64(lane <= p ? (s & kLbMask) : 0ull);
+        if (incl) break;
+        base -= kWave;
+    }
+    if (lane == 0) __hip_atomic_store(&status[tile], kLbIncl | ((total + excl) & kLbMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
 // exclusive scan over the block; *total = block sum.  smem: BLOCK/64 u64 entries.
 template <int BLOCK>
 __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long *total,

@@ -242,8 +242,7 @@ __device__ __forceinline__ T intersection_area(const BoxGeom<T> &a, const BoxGeo
 }
 
 // Separating-axis test for two rectangles: true only when some edge normal of A or B separates them by a clear margin
-// (1e-9 of the extents: a pair it rejects has intersection area 0 or below that scale; a pair it lets through is simply
-// clipped).  ~60 operations against the ~500 of the clip; for boxes of random orientation a third of the pairs whose
+// (1e-9 of the extents in fp64, 1e-5 in fp32: a pair it rejects is disjoint; a pair it lets through is simply clipped).  ~60 operations against the ~500 of the clip; for boxes of random orientation a third of the pairs whose
 // bounding boxes overlap are in fact disjoint.
 template <typename T, class G>
 __device__ __forceinline__ bool sat_separated_t(const G &a, const G &b)
@@ -251,7 +250,9 @@ __device__ __forceinline__ bool sat_separated_t(const G &a, const G &b)
     const T dx = b.cx - a.cx, dy = b.cy - a.cy;
     const T uu = a.ux * b.ux + a.uy * b.uy, uv = a.ux * b.vx + a.uy * b.vy;     // dot(ua, ub), dot(ua, vb)
     const T vu = a.vx * b.ux + a.vy * b.uy, vv = a.vx * b.vx + a.vy * b.vy;     // dot(va, ub), dot(va, vb)
-    const T tol = (T)1 + (T)1e-9;
+    // the margin must exist in T: 1 + 1e-9 rounds to exactly 1.0f -- fp32 rounding of the projections (~1e-6 of
+    // the extents with distant centres) could then reject a barely overlapping pair that the clip gives a tiny positive area
+    const T tol = sizeof(T) == 4 ? (T)1 + (T)1e-5 : (T)1 + (T)1e-9;
     T r;
     r = a.ux * a.ux + a.uy * a.uy + fabs(uu) + fabs(uv);                        // axis ua (not normalised: both sides scale)
     if (fabs(dx * a.ux + dy * a.uy) > r * tol) return true;

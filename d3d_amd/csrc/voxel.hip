@@ -1058,7 +1058,8 @@ constexpr int kBinThreads = 1024;             // ... 4 per lane: 16 wavefronts p
 constexpr int kBinBits = 14;
 constexpr int kBinMax = 1 << kBinBits;        // buckets (14 bits of the per-point word, 14 more for the rank in the tile): frames
                                               // of up to 16 M points (round 3; 13 bits = 8 M before)
-constexpr int kBucketTarget = 512;            // mean points per bucket the partition aims at
+constexpr int kBucketTarget = 1024;           // mean points per bucket the partition aims at (round 4: 512 before -- two points per lane
+                                              // in flight hide the phases' latencies: config 2 134 -> 123 us per call, profiles/r04_bucket_target.txt)
 constexpr int kBucketCap = 2048;              // points one k_bucket_index workgroup holds in registers
 constexpr int kBucketThreads = 512;           // ... 4 per lane (256: 42 us, 512: 38 us, 1024: 44 us at config 2)
 constexpr int kBucketSlots = 2048;            // LDS table slots (>= distinct cells of a bucket, always)
@@ -1461,8 +1462,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
     __shared__ uint32_t tcnt[T], tfirst[T];
     __shared__ uint32_t seg[kBucketCap];
     __shared__ u64 smem[kBucketThreads / kWave];
-    __shared__ uint16_t oslot[ROWS ? T : 1];        // overflow voxels of the bucket (one per slot at most: a big bucket can hold
-                                                    // T distinct cells with more than P points each)
+    __shared__ uint16_t oslot[T];                   // overflow voxels of the bucket (one per slot at most: a big bucket can hold
+                                                    // T distinct cells with more than P points each); before the records
+                                                    // phase: the tile of every entry of a register bucket (tile-sorted input)
+    uint16_t *const tileof = oslot;
     __shared__ uint32_t nover, fail;
     typedef float v4f __attribute__((ext_vector_type(4)));   // (an array of HIP float4 structs stayed in scratch)
     D3D_PHASE_DECL;
@@ -1498,6 +1501,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             if ((uint32_t)k < per && t0 + k < ntiles) {
                 seg[t0 + k] = run;
                 seg[kRunCap + t0 + k] = ((t0 + k) << tshift) + (wv[k] & 0xffffu);
+                // a register bucket: the run's lane names the tile of each of its entries (a handful of stores; the lanes
+                // then find their entry with three reads instead of a binary search over the run starts)
+                if (m <= (uint32_t)kBucketCap)
+                    for (uint32_t j = 0; j < (wv[k] >> 16); j++) tileof[run + j] = (uint16_t)(t0 + k);
                 run += wv[k] >> 16;
             }
         }
@@ -1701,7 +1708,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         const uint32_t q = threadIdx.x + r * kBucketThreads;
         pos[r] = 0; key_in[r] = 0; idx[r] = 0;
         if (q < m) {                                // (items past the bucket's end are never looked at again)
-            pos[r] = locate(q);
+            if (table) {
+                const uint32_t t = tileof[q];
+                pos[r] = seg[kRunCap + t] + (q - seg[t]);
+            } else pos[r] = bb + q;
             const typename E::type e = bent[pos[r]];
             key_in[r] = E::key(e);
             idx[r] = E::idx(e);
@@ -1917,6 +1927,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     vec4 *rowbuf = rowbuf_all[w];
     uint32_t *sh_off = off_all[w], *sh_base = base_all[w], *sh_first = first_all[w];
     uint16_t *sh_kept = kept_all[w];
+    D3D_PHASE_DECL;
     const uint32_t tile = (uint32_t)(i / kFlagTile), ntile = (uint32_t)(npad / kFlagTile);
     uint32_t before = 0, all = 0;
     for (uint32_t t = lane; t < ntile; t += kWave) {
@@ -1938,6 +1949,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     }
     const uint32_t e = firstmap[i];
     const unsigned long long bal = __ballot(e != kInf);
+    D3D_PHASE(2, 0);                                        // tile prefix, firstmap
     const uint32_t nfirst = (uint32_t)__popcll(bal);
     uint32_t nv = nfirst;
     const uint32_t vid0 = before + fwpre[i >> 6];
@@ -1963,6 +1975,10 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
             rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), 0u, 1u);
         }
     }
+#ifdef D3D_PHASE_CLOCKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    D3D_PHASE(2, 1);                                        // records / single points arrived
     const uint32_t base = rec.z, cnt = rec.w;
     const uint32_t kept = cnt < P ? cnt : P;                // 0 for the lanes past nv
     const uint32_t incl = wave_incl_scan_u32(kept);         // rows before this voxel in the wavefront's flat row list
@@ -1995,6 +2011,10 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
                 rowbuf[t] = *reinterpret_cast<const vec4 *>(&points4[idx]);
             }
         }
+#ifdef D3D_PHASE_CLOCKS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        D3D_PHASE(2, 2);                                    // rows gathered
         wave_lds_fence();
         // 3. reductions in point order, one lane per voxel
         if (AGG4 && (uint32_t)lane >= ja && (uint32_t)lane < jb && cnt <= P) {
@@ -2009,6 +2029,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
                 }
             }
         }
+        D3D_PHASE(2, 3);                                    // reductions
         // 4. the stretch of the batch's voxels
         const uint32_t q1 = voxels ? jb * P : 0u;
         for (uint32_t q0 = ja * P; q0 < q1; q0 += 4 * kWave) {
@@ -2024,6 +2045,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
                 }
             }
         }
+        D3D_PHASE(2, 4);                                    // stretch stores issued
         wave_lds_fence();                                   // the next batch overwrites the buffer
         ja = jb;
     }
@@ -2078,6 +2100,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
         }
         __builtin_nontemporal_store(res, reinterpret_cast<vec4 *>(&agg[v]));
     }
+    D3D_PHASE(2, 5);                                        // per-voxel outputs issued
 }
 
 // aggregates of the voxels with MORE than max_points points, all channels of a voxel at once (k_emit_c did the others and

@@ -451,7 +451,7 @@ class ShardedVoxelGenerator:
     rank order).  Grid arguments as d3d.voxel.VoxelGenerator (bounds, shape); reduction in {mean, max, min}."""
 
     def __init__(self, bounds, shape, reduction="mean", group=None, comm=None, ops=None, exchange="owner", replicate=True,
-                 max_points=None):
+                 max_points=None, debug_checks=False):
         key = (reduction or "").upper()
         if key not in _REDUCTIONS:
             raise ValueError("Unsupported reduction type in VoxelGenerator!")
@@ -470,8 +470,22 @@ class ShardedVoxelGenerator:
         # returns each rank's OWNED voxels (in global id order, with their ids) instead of all-gathering the grid.
         # "keys" / "bitmap" / "auto": the replicated-grid exchanges (all-gather of the occupied cells + all-reduce of a
         # compact table every rank finalises in full).
+        # A caller-supplied `comm` written for the replicated-grid protocol of rounds 1-2 (all_gather_int, all_gather_var,
+        # all_reduce) lacks the two collectives the owner-computes exchange adds (exchange_counts, all_to_all -- protocol in
+        # INTEGRATION.md section 6): the default then stays what that comm can run; asking for what it cannot is an error
+        # here, not an AttributeError in the middle of a collective sequence.
+        if exchange == "owner" and not (hasattr(self._comm, "exchange_counts") and hasattr(self._comm, "all_to_all")):
+            if replicate and not max_points:
+                exchange = "auto"
+            else:
+                raise TypeError("comm lacks exchange_counts / all_to_all: replicate=False and max_points need the "
+                                "owner-computes exchange (INTEGRATION.md section 6)")
         self._exchange = exchange
         self._replicate = bool(replicate)
+        # debug_checks: assert the two invariants the global numbering rests on (costs a device reduction per call): the
+        # owned voxels arrive ordered by their first point, i.e. local voxel ids follow first-seen order, and shards are
+        # contiguous point ranges in rank order
+        self._debug_checks = bool(debug_checks)
         if not self._replicate and exchange != "owner":
             raise ValueError("replicate=False needs exchange='owner'")
         # max_points: also the dense contract's voxels[V, max_points, 4] + voxel_pmask (voxelize.cpp:128-134: the first
@@ -548,6 +562,11 @@ class ShardedVoxelGenerator:
             reply_bytes_sent=(sum(rc) - rc[comm.rank]) * 8, all_reduce_bytes=int(gbits.numel()) * 8,
             all_gather_bytes_per_rank=nown * (8 + 24 + 4 + 4 * c) if self._replicate else 0)
         vids, coords, npoints, feats = vids[:nown], coords[:nown], npoints[:nown], feats[:nown]
+        if self._debug_checks and nown > 1:
+            fo = first_o[:nown]
+            assert bool((fo[1:] > fo[:-1]).all()), "owned voxels are not ordered by their first point"
+            assert bool((vids[1:] > vids[:-1]).all()), "global voxel ids of the owned voxels are not ascending"
+            assert 0 <= int(fo[0]) and int(fo[-1]) < n_total, "first-point index outside the frame"
         if P:
             voxels, pmask = voxels[:nown], pmask[:nown].view(torch.bool)
             self.last_stats["rows_all_to_all_bytes_sent"] = (sum(rsc) - rsc[comm.rank]) * 16

@@ -105,3 +105,20 @@ def test_crop_points_2k_boxes_x_1m_points():
         first = torch.where((first == 0) & any_hit, idx, first)
     assert torch.equal(first, ids.int())
     assert int(mask.sum()) > 300000
+
+
+@pytest.mark.gpu
+def test_paint_label_refuses_class_ids_beyond_uint8():
+    """class ids travel as uint8; a value that would wrap in the cast is an error, not a silent mismatch"""
+    from d3d_amd.abstraction import paint_label
+    boxes, rows9, pts, labels, sem = _scene(5, 100, 3)
+    bad = labels.astype(np.int64).copy()
+    bad[2] = 300
+    with pytest.raises(ValueError):
+        paint_label(boxes, pts, sem, labels=bad)
+    neg = sem.astype(np.int32)
+    neg[0] = -1
+    with pytest.raises(ValueError):
+        paint_label(boxes, pts, neg, labels=labels)
+    ok = paint_label(boxes, pts, sem.astype(np.int64), labels=labels.astype(np.int64))      # in range: any integer dtype
+    assert np.array_equal(ok, oracle.paint_label(rows9, pts, sem))

@@ -95,7 +95,8 @@ def _gloo_worker(rank, world, port, reduction, exchange, q):
         res = gen(torch.from_numpy(cloud[sl]))
         _check(res, cloud, sl, reduction)
         if exchange == "owner":     # ... and without the final all-gather: the owned voxels of the ranks partition the grid
-            own = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, ops=NumpyOps(), exchange="owner", replicate=False)
+            own = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, ops=NumpyOps(), exchange="owner", replicate=False,
+                                        debug_checks=True)
             ids = _check_owned(own(torch.from_numpy(cloud[sl])), cloud, sl, reduction)
             allids = [None] * world
             dist.all_gather_object(allids, ids.tolist())
@@ -103,7 +104,7 @@ def _gloo_worker(rank, world, port, reduction, exchange, q):
             # the dense contract through the same exchange: owned blocks, and the replicated tensor
             for rep in (False, True):
                 dg = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, ops=NumpyOps(), exchange="owner", replicate=rep,
-                                           max_points=3)
+                                           max_points=3, debug_checks=True)
                 dres = dg(torch.from_numpy(cloud[sl]))
                 if not rep:
                     _check_owned(dres, cloud, sl, reduction, max_points=3)
@@ -136,6 +137,32 @@ def test_sharded_orchestration_gloo_world2(reduction, exchange):
     results = [q.get(timeout=180) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
     assert all(msg == "ok" for _, msg in results), results
+
+
+def test_comm_of_the_replicated_grid_protocol_keeps_working():
+    """a caller's comm that implements only the round 1-2 protocol (all_gather_int / all_gather_var / all_reduce)
+    still constructs with the default arguments -- the generator then stays on the replicated-grid exchange -- and asking
+    for what needs the owner-computes collectives is a TypeError at construction"""
+    from d3d_amd.voxel.sharded import ShardedVoxelGenerator
+
+    class OldComm:
+        rank, world = 0, 1
+
+        def all_gather_int(self, v, dev):
+            return [int(v)]
+
+        def all_gather_var(self, t, sizes):
+            return t
+
+        def all_reduce(self, t, op):
+            return t
+    gen = ShardedVoxelGenerator(BOUNDS, SHAPE, comm=OldComm(), ops=NumpyOps())
+    assert gen._exchange == "auto"
+    cloud = _cloud(500, 9)
+    _check(gen(torch.from_numpy(cloud)), cloud, slice(0, 500), "mean")
+    for kw in (dict(replicate=False), dict(max_points=4)):
+        with pytest.raises(TypeError):
+            ShardedVoxelGenerator(BOUNDS, SHAPE, comm=OldComm(), ops=NumpyOps(), **kw)
 
 
 @pytest.fixture(params=["auto", "hash"])

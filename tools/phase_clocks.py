@@ -15,7 +15,8 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 64)()
 names = {0: ("k_bucket_index", ["prologue", "clear+locate+issue", "insert", "records-loop", "segments", "rank+stores", "overflow", "records-scan", "entries-wait"]),
-         1: ("k_tile_sort", ["load+clear", "keys+hist", "scan+table", "place", "copy-out"])}
+         1: ("k_tile_sort", ["load+clear", "keys+hist", "scan+table", "place", "copy-out"]),
+         2: ("k_emit (wave 0 of each WG)", ["prefix+firstmap", "records", "rows", "reduce", "stretch", "per-voxel"])}
 n = 1000000
 target = int(os.environ.get("D3D_TUNE_BUCKET", "512"))
 nb = 1
@@ -31,7 +32,7 @@ for mode, gen in (("dense", VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE
             gen(cloud, flags=fl)
         lib.d3d_debug_phase_clocks(buf)
         for k, (kname, phases) in names.items():
-            wgs = {0: nb, 1: (n + 8191) // 8192}[k] * steps
+            wgs = {0: nb, 1: (n + 8191) // 8192, 2: (n + 16383) // 16384 * 64}[k] * steps
             vals = [buf[k * 16 + p] / wgs for p in range(len(phases))]
             if sum(vals) == 0:
                 continue
