@@ -46,7 +46,7 @@ SIGNATURES = {
     "d3d_voxelize_3d_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_voxelize_3d_sparse_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _u32]),
+                                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _u32, _vp]),
     "d3d_voxelize_3d_filter_chained": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32,
                                                       _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_voxelize_reduce_rows": (_sz, [_i64]),

@@ -886,12 +886,14 @@ template <class Key, bool AGG4>
 __device__ __forceinline__ void meta_voxel(const Key &kf, int64_t v, const uint4 vi, const float4 *__restrict__ staged,
                                            uint32_t P, int reduction, int64_t *coords, int32_t *npoints, uint32_t *voff,
                                            unsigned char *pmask, float4 *agg, uint32_t *big_list, uint32_t *big_count,
-                                           int64_t *keys_out, uint32_t npoints_clamp = 0xffffffffu)
+                                           int64_t *keys_out, uint32_t npoints_clamp = 0xffffffffu,
+                                           const long long *coord_sub = nullptr /* VoxelGenerator's offset (voxel/__init__.py:103) */)
 {
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
     if (coords) {                                  // (the sharded voxelizer's local pass only needs the cell keys)
         long long cc[3];
         kf.decode(((u64)vi.y << 32) | vi.x, cc);
+        if (coord_sub) { cc[0] -= coord_sub[0]; cc[1] -= coord_sub[1]; cc[2] -= coord_sub[2]; }
         // 24 bytes as 16 + 8 (rows alternate their 16-byte alignment): two store requests instead of three
         long long *cp = reinterpret_cast<long long *>(coords) + v * 3;
         if ((reinterpret_cast<uintptr_t>(coords) & 15) == 0) {
@@ -1075,7 +1077,8 @@ struct BinnedExtras {
     int64_t *host_counts;     // optional host-mapped copy of counts[] + ready flag (d3d_voxelize_3d_dense_notify)
     uint32_t npoints_clamp = 0xffffffffu;
     uint32_t *voff = nullptr; // [V] segment base (dense contract, C != 4: k_aggregate reads the index lists through it)
-    uint32_t *kept_part = nullptr;   // fused sparse + filter: [workgroups of k_meta_first] points kept in the workgroup's voxels
+    bool has_coord_sub = false;      // fused sparse + filter: coords - offset (VoxelGenerator.__call__, voxel/__init__.py:103)
+    long long coord_sub[3] = {0, 0, 0};
 };
 
 // sparse contract fused with the voxel filter (d3d_voxelize_3d_sparse_filter): only voxels that pass get a first-point
@@ -1130,11 +1133,16 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(Key kf, const float *
                                                            typename BinEntry<ROWS>::key_store_t *__restrict__ pkey,
                                                            uint32_t *__restrict__ tilecnt, uint32_t *__restrict__ firstmap,
                                                            int64_t *counts, int64_t *mapping, unsigned char *trimmed,
-                                                           int32_t *keepid)
+                                                           int32_t *keepid, u64 *zero_words /* look-back words of a later launch */,
+                                                           uint32_t nzero, unsigned int *zero_ticket)
 {
     extern __shared__ uint32_t h[];                       // [nbins]: 2 KB (1 M points) .. 64 KB (16 M points), sized by the launch
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads) h[b] = 0;
     if (blockIdx.x == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
+    if (zero_words && blockIdx.x == 0) {
+        for (uint32_t t = threadIdx.x; t < nzero; t += kBinThreads) zero_words[t] = 0ull;
+        if (threadIdx.x == 0) *zero_ticket = 0u;
+    }
     __syncthreads();
     for (uint32_t pass = 0; pass < passes; pass++) {
     const int64_t base = ((int64_t)blockIdx.x * passes + pass) * kBinTile + threadIdx.x;
@@ -1234,7 +1242,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
                                                              const uint32_t *__restrict__ tileoff, const uint32_t *__restrict__ totals,
                                                              uint32_t *__restrict__ bucket_base,
                                                              typename BinEntry<ROWS>::type *__restrict__ bent, int64_t *counts,
-                                                             bool keep_pos /* pbin[i] := the point's place in the buckets (kInf: none) */,
+                                                             bool keep_pos /* pbin[i] := kInf for the points in no bucket (it becomes pfirst) */,
                                                              uint32_t passes)
 {
     extern __shared__ uint32_t off[];                     // [nbins], sized by the launch
@@ -1258,8 +1266,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
             continue;
         }
         const uint32_t pos = off[word & (kBinMax - 1)] + (word >> kBinBits);
-        bent[pos] = BinEntry<ROWS>::pack((u64)pkey[i], (uint32_t)i);
-        if (keep_pos) pbin[i] = pos;            // (same lane read it: in place)
+        bent[pos] = BinEntry<ROWS>::pack((u64)pkey[i], (uint32_t)i);       // (keep_pos: k_bucket_index overwrites pbin[i])
     }
     }
     if (bad) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_COORD_OVERFLOW);
@@ -1285,9 +1292,12 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
                                                             uint32_t ntiles, typename BinEntry<ROWS>::type *__restrict__ tsort,
                                                             uint32_t *__restrict__ table /* [nbins][ntiles] */,
                                                             uint32_t *__restrict__ tileinfo /* [ntiles] entries | bad << 31 */,
-                                                            uint32_t *__restrict__ ppos /* optional: [n] the point's place in tsort */,
+                                                            uint32_t *__restrict__ pfirst /* optional: [n] kInf for the points in no bucket
+                                                                                             (k_bucket_index fills in the others) */,
                                                             uint32_t *__restrict__ firstmap, int64_t *counts, int64_t *mapping,
-                                                            unsigned char *trimmed, int32_t *keepid)
+                                                            unsigned char *trimmed, int32_t *keepid,
+                                                            u64 *zero_words /* look-back words of a later launch */, uint32_t nzero,
+                                                            unsigned int *zero_ticket)
 {
     typedef typename Key::bin_key_t KT;
     typedef BinEntry<ROWS> E;
@@ -1319,6 +1329,10 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
     for (uint32_t b = threadIdx.x; b < nbins; b += kSortThreads) h[b] = 0;
     if (threadIdx.x == 0) sbad = 0;
     if (blockIdx.x == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
+    if (zero_words && blockIdx.x == 0) {
+        for (uint32_t t = threadIdx.x; t < nzero; t += kSortThreads) zero_words[t] = 0ull;
+        if (threadIdx.x == 0) *zero_ticket = 0u;
+    }
     __syncthreads();
     D3D_PHASE(1, 0);                                        // points arrived, histogram cleared
     KT key[kSortItems];
@@ -1377,8 +1391,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
             const uint32_t p = h[word[r] & (kBinMax - 1)] + (word[r] >> kBinBits);
             keys[p] = key[r];
             lidx[p] = (uint16_t)(r * kSortThreads + threadIdx.x);
-            if (ppos) ppos[i] = tbase + p;
-        } else if (ppos && i < n) ppos[i] = kInf;
+        } else if (pfirst && i < n) pfirst[i] = kInf;
     }
     __syncthreads();
     D3D_PHASE(1, 3);                                        // entries placed in LDS
@@ -1429,6 +1442,27 @@ __device__ __forceinline__ u64 block_excl_scan_u64_lds(u64 v, u64 *total, u64 *s
     return woff + incl - v;
 }
 
+// two scans behind ONE pair of barriers (smem: 2 x BLOCK / 64 words)
+template <int BLOCK>
+__device__ __forceinline__ void block_excl_scan_2u64_lds(u64 a, u64 b, u64 *ex_a, u64 *ex_b, u64 *tot_a, u64 *tot_b, u64 *smem)
+{
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const u64 ia = wave_incl_scan_u64(a), ib = wave_incl_scan_u64(b);
+    if (lane == kWave - 1) { smem[w] = ia; smem[BLOCK / kWave + w] = ib; }
+    lds_barrier();
+    u64 wa = 0, wb = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / kWave; k++) {
+        const u64 x = smem[k], y = smem[BLOCK / kWave + k];
+        if (k < w) { wa += x; wb += y; }
+        ta += x; tb += y;
+    }
+    lds_barrier();
+    *tot_a = ta; *tot_b = tb;
+    *ex_a = wa + ia - a;
+    *ex_b = wb + ib - b;
+}
+
 // STAGE (dense contract on C == 4 rows): the ranked rows themselves are gathered and staged next to their rank, for the
 // two-launch output stage.  ROWS && LISTS && !STAGE is the index for k_emit: no row moves here at all -- a voxel's first
 // row is points[first point], which k_emit reads coalesced, and ranks 1 .. P-1 leave their point INDEX in sorted_out.
@@ -1448,7 +1482,12 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                       // tile-sorted input (k_tile_sort): row blockIdx.x of the bucket-major table
                                                       // holds this bucket's run in every tile; NULL = `bent` is partitioned
                                                       const uint32_t *__restrict__ table, uint32_t ntiles, int tshift /* log2 tile */,
-                                                      const uint32_t *__restrict__ tileinfo, uint32_t *__restrict__ gpos /* big buckets */)
+                                                      const uint32_t *__restrict__ tileinfo, uint32_t *__restrict__ gpos /* big buckets */,
+                                                      // fused sparse + filter: by POINT index, the first point of the point's voxel if
+                                                      // the point is kept (its voxel passes the filter, its rank is below P when
+                                                      // P > 0), else kInf -- all the compaction needs (one scattered store per point
+                                                      // here instead of two dependent random reads per point there)
+                                                      uint32_t *__restrict__ pfirst_out)
 {
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
     typedef typename Key::bin_key_t KT;
@@ -1461,7 +1500,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
     static_assert(kBucketCap <= 0xffff && kBucketCap == T, "packed count | base; tbase aliases seg");
     __shared__ uint32_t tcnt[T], tfirst[T];
     __shared__ uint32_t seg[kBucketCap];
-    __shared__ u64 smem[kBucketThreads / kWave];
+    __shared__ u64 smem[2 * kBucketThreads / kWave];
     __shared__ uint16_t oslot[T];                   // overflow voxels of the bucket (one per slot at most: a big bucket can hold
                                                     // T distinct cells with more than P points each); before the records
                                                     // phase: the tile of every entry of a register bucket (tile-sorted input)
@@ -1536,44 +1575,74 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
     // phase B of both modes: segments in slot order, one record per voxel, firstmap
     auto records = [&](auto BIG) {
         constexpr int PER = T / kBucketThreads;
-        const int s0 = threadIdx.x * PER;
-        uint32_t c[PER];
-        u64 mine = 0;
         // (the index for k_emit and the sparse contract's keep no record for a voxel of ONE point in a register bucket -- 80 % of a
         // LiDAR frame's voxels: k_emit / k_meta_first rebuild it from the point itself, firstmap says so)
         constexpr bool kSkipSingles = ((ROWS && LISTS && !STAGE) || std::is_same<Key, SparseKey>::value) && !decltype(BIG)::value;
-#pragma unroll
-        for (int k = 0; k < PER; k++) { c[k] = tcnt[s0 + k]; mine += ((u64)c[k] << 32) | ((kSkipSingles ? c[k] > 1 : c[k] > 0) ? 1u : 0u); }
-        u64 all;
-        u64 ex = block_excl_scan_u64_lds<kBucketThreads>(mine, &all, smem);
-        D3D_PHASE(0, 7);                            // (records: the scan)
-        uint32_t base = (uint32_t)(ex >> 32), j = (uint32_t)ex;
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            if constexpr (decltype(BIG)::value) seg[s0 + k] = base;
-            else tcnt[s0 + k] = c[k] | (base << 16);
-            if (c[k]) {
-                const uint32_t f = tfirst[s0 + k];
-                const u64 kk = (u64)tkey[s0 + k];
-                const bool single = kSkipSingles && c[k] == 1;
-                if (!single) vrec[bb + j] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), bb + base, c[k]);
-                bool pass = true;
-                if (vp.on) {                        // voxelize.cpp:376-384: coordinate bounds and min_points
-                    long long cc[3];
-                    kf.decode(kk, cc);
-                    pass = (int32_t)c[k] >= vp.min_points && cc[0] >= vp.lo[0] && cc[0] < vp.hi[0] && cc[1] >= vp.lo[1] &&
-                           cc[1] < vp.hi[1] && cc[2] >= vp.lo[2] && cc[2] < vp.hi[2];
-                }
-                // (an atomic store on purpose: with two plain conditional stores next to each other -- a second one at index
-                // bb + j used to sit above this one -- hipcc 7.2 emitted, in one code shape of this kernel, a merged store that
-                // wrote the value bb + j at firstmap[bb + j], i.e. the other store's index; found by the big-bucket tests, see
-                // DESIGN.md 4a)
-                if (pass) __hip_atomic_store(&firstmap[f], single ? kSingleVoxel : bb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!single) j++;
-                if constexpr (ROWS)
-                    if (reduction != D3D_REDUCE_NONE && c[k] > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)(s0 + k);
+        // one slot of the table -> its voxel's record, first-point entry, overflow listing
+        auto slot_out = [&](uint32_t sl, uint32_t cnt, uint32_t base, uint32_t &j) {
+            const uint32_t f = tfirst[sl];
+            const u64 kk = (u64)tkey[sl];
+            const bool single = kSkipSingles && cnt == 1;
+            if (!single) vrec[bb + j] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), bb + base, cnt);
+            bool pass = true;
+            if (vp.on) {                        // voxelize.cpp:376-384: coordinate bounds and min_points
+                long long cc[3];
+                kf.decode(kk, cc);
+                pass = (int32_t)cnt >= vp.min_points && cc[0] >= vp.lo[0] && cc[0] < vp.hi[0] && cc[1] >= vp.lo[1] &&
+                       cc[1] < vp.hi[1] && cc[2] >= vp.lo[2] && cc[2] < vp.hi[2];
             }
-            base += c[k];
+            // (an atomic store on purpose: with two plain conditional stores next to each other -- a second one at index
+            // bb + j used to sit above this one -- hipcc 7.2 emitted, in one code shape of this kernel, a merged store that
+            // wrote the value bb + j at firstmap[bb + j], i.e. the other store's index; found by the big-bucket tests, see
+            // DESIGN.md 4a)
+            if (pass) __hip_atomic_store(&firstmap[f], single ? kSingleVoxel : bb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else tfirst[sl] = kInf;             // (its points belong to no kept voxel: what precpos / pfirst_out hand on)
+            if (!single) j++;
+            if constexpr (ROWS)
+                if (reduction != D3D_REDUCE_NONE && cnt > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)sl;
+        };
+        if constexpr (!decltype(BIG)::value) {
+            // register bucket: lane t owns slots t, t + 512, .. -- every LDS access of this phase is a conflict-free row (four
+            // CONSECUTIVE slots per lane put eight lanes on each bank) -- and the four rows' prefix sums travel as 16-bit
+            // fields of one word (a row holds at most 2048 points): segments and records still follow slot order
+            static_assert(PER == 4 && kBucketCap < 65536, "four 16-bit fields");
+            uint32_t c[PER];
+            u64 cs = 0, rs = 0;
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                c[k] = tcnt[threadIdx.x + k * kBucketThreads];
+                cs |= (u64)c[k] << (16 * k);
+                rs |= (u64)((kSkipSingles ? c[k] > 1 : c[k] > 0) ? 1u : 0u) << (16 * k);
+            }
+            u64 ex_c, ex_r, tot_c, tot_r;
+            block_excl_scan_2u64_lds<kBucketThreads>(cs, rs, &ex_c, &ex_r, &tot_c, &tot_r, smem);
+            D3D_PHASE(0, 7);                        // (records: the scan)
+            uint32_t row_c = 0, row_r = 0;
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const uint32_t sl = threadIdx.x + k * kBucketThreads;
+                const uint32_t base = row_c + (uint32_t)((ex_c >> (16 * k)) & 0xffffu);
+                uint32_t j = row_r + (uint32_t)((ex_r >> (16 * k)) & 0xffffu);
+                tcnt[sl] = c[k] | (base << 16);
+                if (c[k]) slot_out(sl, c[k], base, j);
+                row_c += (uint32_t)((tot_c >> (16 * k)) & 0xffffu);
+                row_r += (uint32_t)((tot_r >> (16 * k)) & 0xffffu);
+            }
+        } else {
+            const int s0 = threadIdx.x * PER;
+            uint32_t c[PER];
+            u64 mine = 0;
+#pragma unroll
+            for (int k = 0; k < PER; k++) { c[k] = tcnt[s0 + k]; mine += ((u64)c[k] << 32) | (c[k] > 0 ? 1u : 0u); }
+            u64 all;
+            u64 ex = block_excl_scan_u64_lds<kBucketThreads>(mine, &all, smem);
+            uint32_t base = (uint32_t)(ex >> 32), j = (uint32_t)ex;
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                seg[s0 + k] = base;
+                if (c[k]) slot_out((uint32_t)(s0 + k), c[k], base, j);
+                base += c[k];
+            }
         }
     };
     // Overflow voxels: every point counts (voxelize.cpp:137-157) but only P are ranked: one wavefront per voxel walks
@@ -1662,6 +1731,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         if (fail) {                                 // the caller repeats the call on the hash path; until then the outputs
             if (precpos)                            // stay consistent (these points map to no voxel)
                 for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) precpos[m <= kArrMask ? gpos[bb + q] : locate(q)] = kInf;
+            if (pfirst_out)
+                for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads)
+                    pfirst_out[E::idx(bent[m <= kArrMask ? gpos[bb + q] : locate(q)])] = kInf;
             if (threadIdx.x == 0) atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_BIN_OVERFLOW);
             return;
         }
@@ -1691,6 +1763,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             }
             if (trimmed && rank >= P) trimmed[me] = 1;
             if (precpos) precpos[pos] = tfirst[s];
+            if (pfirst_out) pfirst_out[me] = (P > 0 && rank >= P) ? kInf : tfirst[s];
         }
         reduce_overflow(sg, std::true_type{}, (const v4f *)nullptr);
         return;
@@ -1780,6 +1853,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             }
             if (trimmed && rank >= P) trimmed[me] = 1;     // sparse contract + TRIM filter (voxelize.cpp:457-463)
             if (precpos) precpos[pos[r]] = tfirst[s];
+            if (pfirst_out) pfirst_out[me] = (P > 0 && rank >= P) ? kInf : tfirst[s];
         }
     });
     D3D_PHASE(0, 5);                                // ranks, list stores issued
@@ -1816,6 +1890,38 @@ __global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict
 // one lane per point index: the lanes that are a voxel's first point number it (prefix count = the reference's
 // first-occurrence order, voxelize.cpp:119), fetch its record and write all per-voxel outputs -- coalesced, because
 // consecutive first points are consecutive voxel ids
+// the lane whose point index i is a voxel's first point (e = its firstmap entry) and that voxel's id: record, per-voxel outputs.
+// Returns the points the voxel keeps (fused sparse + filter); every lane leaves the id of the voxel that starts at i.
+template <class Key, bool AGG4>
+__device__ __forceinline__ uint32_t meta_first_lane(const Key &kf, int64_t i, uint32_t e, uint32_t vid, const uint4 *__restrict__ vrec,
+                                                    uint32_t max_voxels, uint4 *__restrict__ vinfo, const float4 *__restrict__ staged,
+                                                    uint32_t P, int reduction, int64_t *coords, int32_t *npoints, unsigned char *pmask,
+                                                    float4 *agg, const BinnedExtras &x, const float *__restrict__ points, int c)
+{
+    uint32_t kept = 0, myvid = kNoVoxel;
+    if (e != kInf && vid < max_voxels) {                    // voxelize.cpp:116-117: later voxels are never created
+        myvid = vid;
+        if (x.first_out) x.first_out[vid] = x.index_offset + i;
+        uint4 rec;
+        if (e != kSingleVoxel) rec = vrec[e];
+        else {              // (sparse contract) a voxel of one point has no record: its cell from the point -- this lane's own index
+            const float *src = points + i * c;
+            const float v3[3] = {src[0], src[1], src[2]};
+            u64 key = 0;
+            uint32_t st = 0;
+            (void)kf.make(v3, key, st);                     // the same arithmetic on the same floats as k_bin_count
+            rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), 0u, 1u);
+        }
+        const uint4 vi = rec;                               // {key lo, key hi, segment base, count}
+        if (vinfo) vinfo[vid] = vi;
+        kept = vi.w < x.npoints_clamp ? vi.w : x.npoints_clamp;
+        meta_voxel<Key, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, x.voff, pmask, agg, nullptr, nullptr,
+                              x.keys_out, x.npoints_clamp, x.has_coord_sub ? x.coord_sub : (const long long *)nullptr);
+    }
+    if (x.vidof) x.vidof[i] = myvid;                        // every lane: one coalesced store (the map looks it up by first point)
+    return kept;
+}
+
 template <class Key, bool AGG4>
 __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
                                                     const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
@@ -1848,38 +1954,110 @@ __global__ __launch_bounds__(256) void k_meta_first(Key kf, int64_t npad, const 
     }
     const uint32_t e = firstmap[i];
     const unsigned long long bal = __ballot(e != kInf);
-    uint32_t kept = 0;                                      // points this lane's voxel keeps (fused sparse + filter)
-    uint32_t myvid = kNoVoxel;
-    if (e != kInf) {
-        const uint32_t vid = before + fwpre[i >> 6] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (vid < max_voxels) {                             // voxelize.cpp:116-117: later voxels are never created
-            myvid = vid;
-            if (x.first_out) x.first_out[vid] = x.index_offset + i;
-            uint4 rec;
-            if (e != kSingleVoxel) rec = vrec[e];
-            else {              // (sparse contract) a voxel of one point has no record: its cell from the point -- this lane's own index
-                const float *src = points + i * c;
-                const float v3[3] = {src[0], src[1], src[2]};
-                u64 key = 0;
-                uint32_t st = 0;
-                (void)kf.make(v3, key, st);                 // the same arithmetic on the same floats as k_bin_count
-                rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), 0u, 1u);
-            }
-            const uint4 vi = rec;                           // {key lo, key hi, segment base, count}
-            if (vinfo) vinfo[vid] = vi;
-            kept = vi.w < x.npoints_clamp ? vi.w : x.npoints_clamp;
-            meta_voxel<Key, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, x.voff, pmask, agg, nullptr, nullptr,
-                                  x.keys_out, x.npoints_clamp);
+    const uint32_t vid = before + fwpre[i >> 6] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    (void)meta_first_lane<Key, AGG4>(kf, i, e, vid, vrec, max_voxels, vinfo, staged, P, reduction, coords, npoints, pmask, agg, x, points, c);
+}
+
+// Fused sparse + filter (round 4): numbering, per-voxel outputs AND both output sizes in ONE launch -- no k_first_count before
+// it, no k_publish_kept behind it.  Tiles of 4096 point indices (a few hundred workgroups: the ticket word of the look-back
+// serves them in a microsecond or two; k_emit's 4000 waited 14 us for it, see binned_index): the voxels before a tile by
+// decoupled look-back (common.hpp), the points its voxels keep published next to it; the LAST tile -- it has waited for
+// every predecessor's voxel count anyway -- adds the kept points of all tiles up and tells the host.  Also clears the
+// look-back words of the launch behind it (k_compact_kept).
+constexpr int kMetaLbThreads = 1024, kMetaLbItems = 4, kMetaLbTile = kMetaLbThreads * kMetaLbItems;
+struct MetaLb {
+    u64 *stat;              // [tiles] voxel look-back words, [tiles .. 2 tiles) kept points | ready bit; cleared by k_tile_sort /
+    unsigned int *ticket;   //   k_bin_count with the ticket
+    u64 *next_stat;         // k_compact_kept's words + ticket, cleared here
+    uint32_t next_n;
+    unsigned int *next_ticket;
+    int64_t *host;          // 2 * D3D_NUM_COUNTS + 1 words (d3d_voxelize_3d_sparse_filter)
+};
+template <class Key>
+__global__ __launch_bounds__(kMetaLbThreads) void k_meta_first_lb(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
+                                                                  const uint4 *__restrict__ vrec, uint32_t max_voxels, int64_t *coords,
+                                                                  int32_t *npoints, int64_t *counts, BinnedExtras x, MetaLb lb,
+                                                                  const float *__restrict__ points, int c)
+{
+    __shared__ unsigned int sid;
+    __shared__ uint32_t wtot[kMetaLbThreads / kWave];
+    __shared__ u64 sprefix;
+    const unsigned int tile = lookback_ticket(lb.ticket, &sid);
+    const unsigned int ntiles = gridDim.x;
+    if (tile == 0) {
+        for (uint32_t t = threadIdx.x; t < lb.next_n; t += kMetaLbThreads) lb.next_stat[t] = 0ull;
+        if (threadIdx.x == 0) *lb.next_ticket = 0u;
+    }
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)tile * kMetaLbTile + (int64_t)w * (kWave * kMetaLbItems) + lane;     // (w, row, lane) = index order
+    uint32_t e[kMetaLbItems], ex[kMetaLbItems], carry = 0;
+#pragma unroll
+    for (int k = 0; k < kMetaLbItems; k++) e[k] = firstmap[base + (int64_t)k * kWave];                // (padded to the tile)
+#pragma unroll
+    for (int k = 0; k < kMetaLbItems; k++) {
+        const unsigned long long bal = __ballot(e[k] != kInf);
+        ex[k] = carry + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        carry += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) wtot[w] = carry;
+    __syncthreads();
+    uint32_t total = 0, woff = 0;
+#pragma unroll
+    for (int k = 0; k < kMetaLbThreads / kWave; k++) {
+        const uint32_t t = wtot[k];
+        total += t;
+        if (k < w) woff += t;
+    }
+    if (w == 0) {
+        const u64 before = lookback_exclusive(lb.stat, tile, (u64)total);
+        if (lane == 0) sprefix = before;
+    }
+    __syncthreads();
+    const uint32_t pre = (uint32_t)sprefix + woff;
+    uint32_t kept = 0;
+#pragma unroll
+    for (int k = 0; k < kMetaLbItems; k++)
+        kept += meta_first_lane<Key, false>(kf, base + (int64_t)k * kWave, e[k], pre + ex[k], vrec, max_voxels, (uint4 *)nullptr,
+                                            (const float4 *)nullptr, 0u, (int)D3D_REDUCE_NONE, coords, npoints, (unsigned char *)nullptr,
+                                            (float4 *)nullptr, x, points, c);
+    // the tile's kept points next to its voxel word; the last tile adds all of them up
+    kept = (uint32_t)wave_sum_u64((u64)kept);
+    __syncthreads();                                        // (wtot is read above by every thread)
+    if (lane == 0) wtot[w] = kept;
+    __syncthreads();
+    if (w != 0) return;
+    u64 mine = 0;
+    for (int k = lane; k < kMetaLbThreads / kWave; k += kWave) mine += wtot[k];
+    mine = wave_sum_u64(mine);
+    if (tile + 1 != ntiles) {
+        if (lane == 0) __hip_atomic_store(&lb.stat[ntiles + tile], (mine << 1) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    u64 acc = 0;
+    for (unsigned int j0 = 0; j0 + 1 < ntiles; j0 += kWave) {
+        const unsigned int j = j0 + lane;
+        if (j + 1 < ntiles) {
+            u64 t;
+            do { t = __hip_atomic_load(&lb.stat[ntiles + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(t & 1ull));
+            acc += t >> 1;
         }
     }
-    if (x.vidof) x.vidof[i] = myvid;                        // every lane: one coalesced store (the map looks it up by first point)
-    if (x.kept_part) {                                      // sum over the workgroup -> k_publish_kept adds the workgroups up
-        __shared__ uint32_t wsum[256 / kWave];
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) kept += __shfl_xor(kept, o, kWave);
-        if (lane == 0) wsum[threadIdx.x >> 6] = kept;
-        __syncthreads();
-        if (threadIdx.x == 0) x.kept_part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    acc = wave_sum_u64(acc) + mine;
+    if (lane == 0) {
+        const u64 all = sprefix + total;                    // voxels of the frame (this is the last tile)
+        const int64_t nvox = (int64_t)(all < max_voxels ? all : max_voxels);
+        counts[D3D_COUNT_VOXELS] = nvox;
+        counts[D3D_COUNT_AUX] = 0;
+        if (lb.host) {
+            for (int k = 0; k < D3D_NUM_COUNTS; k++) {
+                lb.host[k] = counts[k];
+                lb.host[D3D_NUM_COUNTS + 1 + k] = 0;
+            }
+            lb.host[D3D_NUM_COUNTS + 1 + D3D_COUNT_VOXELS] = nvox;
+            lb.host[D3D_NUM_COUNTS + 1 + D3D_COUNT_POINTS] = (int64_t)acc;
+            __threadfence_system();
+            __hip_atomic_store(&lb.host[D3D_NUM_COUNTS], (int64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -2331,34 +2509,6 @@ __global__ __launch_bounds__(256) void k_emit_c(Key kf, int64_t npad, const uint
     }
 }
 
-// fused sparse + filter: the sizes of BOTH filtered outputs are known once k_meta_first has run -- the voxels it numbered and
-// the points they keep (count, or min(count, max_points) with the TRIM point filter; voxelize.cpp:403, 457-463).  One
-// workgroup adds the per-workgroup partial sums up and publishes them to the host, BEFORE the three launches of the
-// compaction scan: the host's per-call work (returning the result, allocating the next call's buffers) hides behind them.
-__global__ __launch_bounds__(1024) void k_publish_kept(const uint32_t *__restrict__ part, uint32_t nparts,
-                                                       const int64_t *__restrict__ first_counts, int64_t *host)
-{
-    __shared__ unsigned long long smem[1024 / kWave];
-    unsigned long long s = 0;
-    for (uint32_t t = threadIdx.x; t < nparts; t += 1024) s += part[t];
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0) smem[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long tot = 0;
-        for (int k = 0; k < 1024 / kWave; k++) tot += smem[k];
-        for (int k = 0; k < D3D_NUM_COUNTS; k++) {
-            host[k] = first_counts[k];
-            host[D3D_NUM_COUNTS + 1 + k] = 0;
-        }
-        host[D3D_NUM_COUNTS + 1 + D3D_COUNT_VOXELS] = first_counts[D3D_COUNT_VOXELS];
-        host[D3D_NUM_COUNTS + 1 + D3D_COUNT_POINTS] = (int64_t)tot;
-        __threadfence_system();
-        __hip_atomic_store(&host[D3D_NUM_COUNTS], (int64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 // point -> voxel id, from bucket order: k_bucket_index left the first point of every entry's voxel, k_meta_first the id of the
 // voxel that starts at a point index
 __global__ __launch_bounds__(256) void k_map_binned(const uint32_t *__restrict__ bucket_base, uint32_t nbins,
@@ -2483,11 +2633,6 @@ struct FilterPoints {
     int64_t *out_mask, *out_mapping;
     bool precomputed = false; // keepid was filled by the fused sparse index (k_map_binned)
     bool vec4 = false;        // c == 4 and 16-byte aligned rows: one float4 copy per kept point
-    // fused sparse + filter on the binned index: the count pass finds every point's filtered voxel id ITSELF, in point order --
-    // the point's place in the buckets (k_bin_scatter left it in pbin: one coalesced load), there the record of its voxel,
-    // there the voxel's id (k_meta_first) -- instead of a pass over the buckets that scatters the ids to the points
-    // (k_map_binned)
-    const uint32_t *pbin = nullptr, *precpos = nullptr, *vidof = nullptr;
     __device__ __forceinline__ int32_t keep(int64_t i) const
     {
         const int64_t v = mapping[i];
@@ -2500,17 +2645,6 @@ struct FilterPoints {
     }
     __device__ __forceinline__ unsigned long long value(int64_t i) const
     {
-        if (pbin) {
-            const uint32_t p = pbin[i];
-            int32_t id = -1;
-            if (p != kInf) {                       // kInf: the point lies in no voxel
-                const uint32_t e = precpos[p];
-                const uint32_t vid = e == kInf ? kNoVoxel : vidof[e];
-                if (vid != kNoVoxel && !(trimmed && trimmed[i])) id = (int32_t)vid;
-            }
-            keepid[i] = id;
-            return id >= 0 ? 1ull : 0ull;
-        }
         if (precomputed) return keepid[i] >= 0 ? 1ull : 0ull;
         const int32_t id = keep(i);
         keepid[i] = id;
@@ -2537,6 +2671,89 @@ __global__ void k_fill_u32(uint32_t *p, int64_t n, uint32_t val, int64_t *counts
 }
 
 
+
+// out_coords[v, :] -= offset for the counts[VOXELS] valid rows (the two-operator form of d3d_voxelize_3d_sparse_filter)
+__global__ __launch_bounds__(256) void k_sub_offset(int64_t *coords, const int64_t *__restrict__ counts, int64_t rows, long long o0,
+                                                    long long o1, long long o2)
+{
+    const int64_t valid = counts[D3D_COUNT_VOXELS] < rows ? counts[D3D_COUNT_VOXELS] : rows;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < valid * 3; t += (int64_t)gridDim.x * 256) {
+        const int d = (int)(t % 3);
+        coords[t] -= d == 0 ? o0 : (d == 1 ? o1 : o2);
+    }
+}
+
+// Fused sparse + filter, the compaction of the kept points in ONE launch (round 4; before: count pass, block-sum pass, apply
+// pass = three launches that each re-derived the point's voxel through two dependent random reads).  pfirst[i] (left by
+// k_bucket_index) names the first point of point i's voxel when the point is kept, vidof[] (k_meta_first) that voxel's
+// filtered id: one coalesced and one random read per point.  Tiles of 4096 points; the tile's place in the output comes from
+// decoupled look-back over the ~n / 4096 tiles of this launch (common.hpp; few enough for the ticket word), the last tile
+// leaves the sizes in counts[].  Output order = point order (voxelize.cpp:441-468).
+constexpr int kCompactThreads = 1024, kCompactItems = 4, kCompactTile = kCompactThreads * kCompactItems;
+template <bool VEC4>
+__global__ __launch_bounds__(kCompactThreads) void k_compact_kept(const float *__restrict__ feats, int c, int64_t n, int64_t npad,
+                                                                  const uint32_t *__restrict__ pfirst, const uint32_t *__restrict__ vidof,
+                                                                  float *__restrict__ out_feats, int64_t *__restrict__ out_mask,
+                                                                  int64_t *__restrict__ out_mapping, u64 *lbstat, unsigned int *ticket,
+                                                                  int64_t *counts, const int64_t *__restrict__ first_counts)
+{
+    __shared__ unsigned int sid;
+    __shared__ uint32_t wtot[kCompactThreads / kWave];
+    __shared__ u64 sprefix;
+    const unsigned int tile = lookback_ticket(ticket, &sid);
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    // wavefront w owns 256 consecutive points, row k of it = 64 consecutive points: coalesced, and (w, k, lane) is point order
+    const int64_t base = (int64_t)tile * kCompactTile + (int64_t)w * (kWave * kCompactItems) + lane;
+    uint32_t f[kCompactItems];
+#pragma unroll
+    for (int k = 0; k < kCompactItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        f[k] = i < n ? pfirst[i] : kInf;
+    }
+    uint32_t id[kCompactItems];
+#pragma unroll
+    for (int k = 0; k < kCompactItems; k++) id[k] = (int64_t)f[k] < npad ? vidof[f[k]] : kNoVoxel;     // (kInf, or a stale word after a
+                                                                                                       //  BIN_OVERFLOW: in bounds)
+    uint32_t ex[kCompactItems], carry = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactItems; k++) {
+        const unsigned long long bal = __ballot(id[k] != kNoVoxel);
+        ex[k] = carry + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        carry += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) wtot[w] = carry;
+    __syncthreads();
+    uint32_t total = 0, woff = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactThreads / kWave; k++) {
+        const uint32_t x = wtot[k];
+        total += x;
+        if (k < w) woff += x;
+    }
+    if (w == 0) {
+        const u64 before = lookback_exclusive(lbstat, tile, (u64)total);
+        if (lane == 0) sprefix = before;
+    }
+    __syncthreads();
+    const u64 pre = sprefix + woff;
+#pragma unroll
+    for (int k = 0; k < kCompactItems; k++) {
+        if (id[k] == kNoVoxel) continue;
+        const int64_t i = base + (int64_t)k * kWave;
+        const u64 e = pre + ex[k];
+        out_mask[e] = i;
+        out_mapping[e] = (int64_t)id[k];
+        if (VEC4) reinterpret_cast<float4 *>(out_feats)[e] = reinterpret_cast<const float4 *>(feats)[i];
+        else
+            for (int d = 0; d < c; d++) out_feats[e * c + d] = feats[i * c + d];
+    }
+    if (tile == gridDim.x - 1 && threadIdx.x == 0) {        // the sizes, as the filter operator leaves them (voxels: the index's)
+        counts[D3D_COUNT_POINTS] = (int64_t)(sprefix + total);
+        counts[D3D_COUNT_VOXELS] = first_counts[D3D_COUNT_VOXELS];
+        counts[D3D_COUNT_STATUS] = 0;
+        counts[D3D_COUNT_AUX] = 0;
+    }
+}
 
 // ------------------------------------------------------------------ workspace layout
 struct VoxelWs {
@@ -2715,6 +2932,9 @@ struct DenseOut {
     bool map_later = false;             // ... computed by the caller's point scan (FilterPoints), not by k_map_binned here
     int64_t *early_counts = nullptr;    // ... whose output sizes k_meta_first then publishes: counts of the filter call
     int64_t *early_host = nullptr;      //     + the host-mapped notify buffer (d3d_voxelize_3d_sparse_filter)
+    const int64_t *coord_offset = nullptr;   // ... subtracted from the output coords (host, 3 values)
+    u64 *compact_stat = nullptr;        // ... look-back words of k_compact_kept (cleared by k_meta_first)
+    uint32_t compact_tiles = 0;
     uint32_t npoints_clamp = 0xffffffffu;   // ... and voxel_npoints = min(count, max_points) (voxelize.cpp:403)
     bool lists = false;                 // dense contract with C != 4: ranked index lists + voff instead of staged rows
     uint32_t *seg_out = nullptr;        // reduce contract: segment base of every voxel's staged rows (for the caller)
@@ -2763,13 +2983,23 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     uint4 *vrec = reinterpret_cast<uint4 *>(w.aux);
     uint32_t *bucket_base = w.vidarr, *totals = w.vidarr + nbins + 2;
     uint32_t *pbin = w.pslot, *firstmap = w.list;
-    const bool want_map = o.mapping || o.keepid;
-    uint32_t *precpos = want_map ? w.unsorted : nullptr;        // the hash path's lists are not used here
+    const bool want_map = o.mapping || o.keepid || o.map_later;
+    uint32_t *precpos = want_map && !o.map_later ? w.unsorted : nullptr;        // the hash path's lists are not used here
     BinnedExtras x = o.x;
     x.vidof = want_map ? w.voff : nullptr;
     x.npoints_clamp = o.npoints_clamp;
-    uint32_t *kept_part = reinterpret_cast<uint32_t *>(w.fwords);      // npad / 64 u64 of the hash path, free here; npad / 256 used
-    x.kept_part = o.early_host ? kept_part : nullptr;
+    if (o.coord_offset) {
+        x.has_coord_sub = true;
+        for (int k = 0; k < 3; k++) x.coord_sub[k] = (long long)o.coord_offset[k];
+    }
+    // fused sparse + filter: numbering + per-voxel outputs + output sizes in one launch (k_meta_first_lb)
+    const bool meta_lb = o.map_later;
+    const uint32_t mtiles = (uint32_t)(w.npad / kMetaLbTile);
+    MetaLb mlb{w.fwords /* npad / 64 words of the hash path, 2 * npad / 4096 used */, w.big_count + 40, o.compact_stat, o.compact_tiles,
+               w.big_count + 41, o.early_host};
+    u64 *zero_words = meta_lb ? mlb.stat : nullptr;
+    const uint32_t nzero = 2 * mtiles;
+    unsigned int *zero_ticket = meta_lb ? mlb.ticket : nullptr;
     x.voff = o.seg_out ? o.seg_out : (o.lists ? w.voff : nullptr);
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     const size_t bin_lds = (size_t)nbins * 4;                 // (at 16384 buckets the scatter's 64 KB + 128 B exceed the default limit)
@@ -2785,14 +3015,15 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     }
     if (table) {
         const size_t lds = ((size_t)1 << tshift) * (sizeof(typename Key::bin_key_t) + 2) + bin_lds;
-        uint32_t *ppos = o.map_later ? pbin : nullptr;
+        uint32_t *ppos = o.map_later ? pbin : nullptr;      // (pfirst: by point, the first point of its voxel when it is kept)
 #define D3D_TILE_SORT(V4, IT)                                                                                                   \
     do {                                                                                                                        \
         if (lds + 1024 > 65536)                                                                                                 \
             D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort<Key, V4, ROWS, IT>),                  \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
         D3D_LAUNCH("k_tile_sort", (k_tile_sort<Key, V4, ROWS, IT>), dim3(stiles), dim3(kSortThreads), lds, st, kf, points, n, c, \
-                   nbins, stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid);               \
+                   nbins, stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid, zero_words,    \
+                   nzero, zero_ticket);                                                                                         \
     } while (0)
         if (vec4) { if (tshift == 13) D3D_TILE_SORT(true, 8); else D3D_TILE_SORT(true, 4); }
         else { if (tshift == 13) D3D_TILE_SORT(false, 8); else D3D_TILE_SORT(false, 4); }
@@ -2804,10 +3035,10 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     }
     if (vec4)
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, true, ROWS>), dim3(ntiles), dim3(kBinThreads), bin_lds, st, kf, points, n, c, nbins,
-                   passes, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
+                   passes, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid, zero_words, nzero, zero_ticket);
     else
         D3D_LAUNCH("k_bin_count", (k_bin_count<Key, false, ROWS>), dim3(ntiles), dim3(kBinThreads), bin_lds, st, kf, points, n, c, nbins,
-                   passes, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid);
+                   passes, pbin, pkey, tilecnt, firstmap, counts, o.mapping, o.trimmed, o.keepid, zero_words, nzero, zero_ticket);
     D3D_LAUNCH("k_bin_scan", k_bin_scan, dim3((nbins + kWave - 1) / kWave), dim3(1024), 0, st, tilecnt, nbins, ntiles, totals);
     D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), bin_lds, st, pkey, n, nbins, pbin, tilecnt, totals,
                bucket_base, bent, counts, o.map_later, passes);
@@ -2816,17 +3047,24 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    reinterpret_cast<const typename BinEntry<false>::type *>(bent), p4, bucket_base, hshift, o.P, (int)D3D_REDUCE_NONE,
                    w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
-                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos);
+                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr);
     else if (ROWS && (o.emit_voxels || o.emit_reduce))
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, true, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
                    counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list /* the per-point keys are
-                   done with it; w.unsorted may be precpos */, (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos);
+                   done with it; w.unsorted may be precpos */, (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr);
     else
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
                    precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                   table, stiles, tshift, tileinfo, gpos);
+                   table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr);
+    if constexpr (!ROWS) {
+        if (meta_lb) {
+            D3D_LAUNCH("k_meta_first_lb", k_meta_first_lb<Key>, dim3(mtiles), dim3(kMetaLbThreads), 0, st, kf, w.npad, firstmap, vrec,
+                       o.max_voxels, o.coords, o.npoints, counts, x, mlb, points, c);
+            return D3D_OK;
+        }
+    }
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 1024 (n <= 16 M)
     D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, w.big_count);
     const dim3 grid((unsigned)(w.npad / 256));
@@ -3281,7 +3519,7 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                                              int64_t *points_mapping, int64_t *coords, int32_t *npoints, int64_t *sparse_counts,
                                              float *out_feats, int64_t *out_mask, int64_t *out_mapping, int32_t *out_npoints,
                                              int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
-                                             void *stream, int64_t *host_counts, uint32_t flags)
+                                             void *stream, int64_t *host_counts, uint32_t flags, const int64_t *coord_offset)
 {
     if (!sparse_counts || max_points < 0) return D3D_ERR_BAD_ARG;
     if (flags & ~(uint32_t)D3D_VOXEL_FLAGS_ALL) return D3D_ERR_BAD_ARG;
@@ -3316,28 +3554,32 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                 const uint32_t vcap = max_voxels_filter == D3D_MAXVOX_NONE ? 0xffffffffu : (uint32_t)max_voxels;
                 DenseOut d{trim ? (uint32_t)max_points : 0u, vcap, D3D_REDUCE_NONE, false, false, out_coords, out_npoints, nullptr,
                            nullptr, BinnedExtras{nullptr, 0, nullptr, -1, nullptr, nullptr}, nullptr};
-                d.trimmed = trim ? w.flags : nullptr;
                 d.pass.on = true;
                 d.pass.min_points = min_points;
                 for (int k = 0; k < 3; k++) { d.pass.lo[k] = coords_bound[2 * k]; d.pass.hi[k] = coords_bound[2 * k + 1]; }
-                d.keepid = reinterpret_cast<int32_t *>(w.big_list);
                 d.npoints_clamp = trim ? (uint32_t)max_points : 0xffffffffu;
-                // the compaction's count pass maps the points itself, in point order (k_map_binned as a launch of its own: 21 us
-                // of kernel against +8 us in the count pass, and 173 vs 158 us per call)
+                // the compaction maps the points itself, in point order: k_bucket_index leaves every kept point's voxel (its
+                // first point) by point index, trimmed points and filtered voxels already taken out (k_map_binned as a launch of
+                // its own: 21 us of kernel, 173 vs 158 us per call)
                 d.map_later = true;
                 d.early_host = host_counts;             // output sizes to the host right after the numbering
+                d.coord_offset = coord_offset;
+                d.compact_stat = w.bsum;                // look-back words of k_compact_kept: k_meta_first clears them
+                d.compact_tiles = (uint32_t)d3d_divup(n, kCompactTile);
                 int rc = binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, sparse_counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
                 if (rc) return rc;
-                FilterPoints fp{points, c, nullptr, 0, nullptr, nullptr, d.trimmed, 0xffffffffu, d.keepid, out_feats, out_mask,
-                                out_mapping, true,
-                                c == 4 && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out_feats)) & 15) == 0};
-                fp.pbin = w.pslot; fp.precpos = w.unsorted; fp.vidof = w.voff;
-                // the sizes of both filtered outputs reach the host NOW, before the three launches of the compaction (a launch of
-                // its own: folded into the count pass's first workgroup the flag reached the host ~15 us later, 168 vs 153 us per call)
-                if (host_counts)
-                    D3D_LAUNCH("k_publish_kept", k_publish_kept, dim3(1), dim3(1024), 0, st, reinterpret_cast<const uint32_t *>(w.fwords),
-                               (uint32_t)(w.npad / 256), sparse_counts, host_counts);
-                return d3d_run_scan(fp, n, w.bsum, counts, -1, D3D_COUNT_POINTS, ~0ull, st, (int64_t *)nullptr, sparse_counts, 1);
+                // (both output sizes went to the host from k_meta_first_lb's last tile, before this launch)
+                const bool v4 = c == 4 && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out_feats)) & 15) == 0;
+                unsigned int *cticket = w.big_count + 41;
+                if (v4)
+                    D3D_LAUNCH("k_compact_kept", k_compact_kept<true>, dim3(d.compact_tiles), dim3(kCompactThreads), 0, st, points, (int)c, n,
+                               w.npad, (const uint32_t *)w.pslot, (const uint32_t *)w.voff, out_feats, out_mask, out_mapping, w.bsum, cticket,
+                               counts, (const int64_t *)sparse_counts);
+                else
+                    D3D_LAUNCH("k_compact_kept", k_compact_kept<false>, dim3(d.compact_tiles), dim3(kCompactThreads), 0, st, points, (int)c, n,
+                               w.npad, (const uint32_t *)w.pslot, (const uint32_t *)w.voff, out_feats, out_mask, out_mapping, w.bsum, cticket,
+                               counts, (const int64_t *)sparse_counts);
+                return D3D_OK;
             }
         }
     }
@@ -3345,10 +3587,14 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
     int rc = voxelize_sparse_impl(points, n, c, voxel_size, points_mapping, coords, npoints, sparse_counts, workspace,
                                   workspace_bytes, n, stream, flags, tolerant);
     if (rc) return rc;
-    return filter_impl(points, n, c, points_mapping, coords, npoints, n, sparse_counts + D3D_COUNT_VOXELS, coords_bound,
-                       min_points, max_points, max_voxels, max_points_filter, max_voxels_filter, out_feats, out_mask,
-                       out_mapping, out_npoints, out_coords, counts, workspace, workspace_bytes, stream, host_counts,
-                       sparse_counts);
+    rc = filter_impl(points, n, c, points_mapping, coords, npoints, n, sparse_counts + D3D_COUNT_VOXELS, coords_bound,
+                     min_points, max_points, max_voxels, max_points_filter, max_voxels_filter, out_feats, out_mask,
+                     out_mapping, out_npoints, out_coords, counts, workspace, workspace_bytes, stream, host_counts,
+                     sparse_counts);
+    if (rc == D3D_OK && coord_offset && n > 0)
+        D3D_LAUNCH("k_sub_offset", k_sub_offset, dim3(grid_for(n * 3, 256)), dim3(256), 0, (hipStream_t)stream, out_coords,
+                   (const int64_t *)counts, n, (long long)coord_offset[0], (long long)coord_offset[1], (long long)coord_offset[2]);
+    return rc;
 }
 
 #ifdef D3D_PHASE_CLOCKS

@@ -9,6 +9,7 @@ CPU-only operator) or on the GPU (results stay there).
 """
 import ctypes
 import enum
+import threading
 
 import numpy as np
 import torch
@@ -279,9 +280,34 @@ def voxelize_3d_filter(feats, points_mapping, coords, voxel_npoints, coords_boun
     return ret
 
 
-def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_voxels, pf, vf, flags=None):
+# Output buffers of the NEXT sparse + filter call, allocated while the current one waits for its output sizes: the GPU-side
+# work behind the size notification (the compaction, ~20 us) is shorter than the host's per-call work (six allocations, the
+# launches), so the next frame's first kernel used to wait for the host.  One set per thread, only for a repeat of the same
+# shape, handed over to the caller whole (the cache keeps no reference to buffers it has given out).
+_spare = threading.local()
+
+
+def _spare_take(key, make):
+    got = getattr(_spare, "set", None)
+    _spare.set = None
+    if got is not None and got[0] == key:
+        return got[1]
+    return make()
+
+
+def _spare_put(key, make):
+    _spare.set = (key, make())
+
+
+def release_cached_buffers():
+    """drop the spare output set this thread holds for its next sparse VoxelGenerator call (~100 bytes per point)"""
+    _spare.set = None
+
+
+def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_voxels, pf, vf, flags=None, offset_h=None):
     """voxelize_3d_sparse followed by voxelize_3d_filter as VoxelGenerator.__call__ chains them
-    (voxel/__init__.py:93-102), with ONE host read-back: the filter reads the voxel count on the device."""
+    (voxel/__init__.py:93-102), with ONE host read-back: the filter reads the voxel count on the device.  offset_h: the
+    generator's grid offset (int64[3]), subtracted from the returned coords (voxel/__init__.py:103) where they are written."""
     lib = _lib.load()
     if vf != 0 and max_voxels is None:
         raise ValueError("Must specify maximum voxel count to filter voxels!")            # voxelize.cpp:359
@@ -297,18 +323,19 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
     with _device_ctx(dev):
         # the intermediate sparse outputs (only materialised when the call falls back to the two-operator form) and the two
         # count rows: slices of ONE scratch tensor -- every torch.empty costs the host a few microseconds per call
-        scratch = torch.empty((n * 9 + 4 * _lib.NUM_COUNTS + 8,), dtype=torch.int32, device=dev)
+        def make():
+            return (torch.empty((n * 9 + 4 * _lib.NUM_COUNTS + 8,), dtype=torch.int32, device=dev),
+                    torch.empty((n, c), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.int64, device=dev),
+                    torch.empty((n,), dtype=torch.int64, device=dev), torch.empty((n,), dtype=torch.int32, device=dev),
+                    torch.empty((n, 3), dtype=torch.int64, device=dev))
+        key = (dev, n, c, torch.cuda.current_stream().cuda_stream)
+        scratch, o_feats, o_mask, o_map, o_cnt, o_crd = _spare_take(key, make)
         counts = scratch[:4 * _lib.NUM_COUNTS].view(torch.int64).view(2, _lib.NUM_COUNTS)
         base = 4 * _lib.NUM_COUNTS
         mapping = scratch[base:base + 2 * n].view(torch.int64)
         coords = scratch[base + 2 * n:base + 8 * n].view(torch.int64).view(n, 3)
         npts = scratch[base + 8 * n:base + 9 * n]
         ws = _lib.workspace(_workspace_bytes2(lib, n), dev)
-        o_feats = torch.empty((n, c), dtype=torch.float32, device=dev)
-        o_mask = torch.empty((n,), dtype=torch.int64, device=dev)
-        o_map = torch.empty((n,), dtype=torch.int64, device=dev)
-        o_cnt = torch.empty((n,), dtype=torch.int32, device=dev)
-        o_crd = torch.empty((n, 3), dtype=torch.int64, device=dev)
 
         note = _lib.NotifyBuffer.get()
 
@@ -319,8 +346,10 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
                 int(min_points or 0), int(max_points or 0), int(max_voxels or 0), pf, vf,
                 _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), _lib.ptr(counts[0]),
                 _lib.ptr(o_feats), _lib.ptr(o_mask), _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd),
-                _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr, fl)
+                _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr, fl,
+                ctypes.cast(offset_h, ctypes.c_void_p) if offset_h is not None else None)
             _lib.check(rc, "voxelize_3d_sparse + voxelize_3d_filter")
+            _spare_put(key, make)         # the next call's buffers, while this one's sizes are on their way
             host = note.wait(counts)      # the one host read of the pair, while the kept points are still being compacted
             _check_status(int(host[_lib.COUNT_STATUS]), "voxelize_3d_sparse")
             return int(host[_lib.NUM_COUNTS + _lib.COUNT_POINTS]), int(host[_lib.NUM_COUNTS + _lib.COUNT_VOXELS])
@@ -363,6 +392,7 @@ class VoxelGenerator:
         self._offset_dev = {}
         self._bounds_h = _host_array(self._bounds, ctypes.c_float, 6)
         self._size_h = _host_array(self._size, ctypes.c_float, 3)
+        self._offset_h = (ctypes.c_int64 * 3)(*[int(v) for v in self._offset.tolist()])
 
         red = (reduction or "NONE").upper()
         if red != "NONE" and not dense:
@@ -400,17 +430,17 @@ class VoxelGenerator:
                                               sparse["voxel_npoints"], self._vbounds, self._min_points,
                                               self._max_points, self._max_voxels, self._max_points_filter,
                                               self._max_voxels_filter))
-            else:
+                off = self._offset_dev.get(ret.coords.device)
+                if off is None:
+                    off = self._offset_dev[ret.coords.device] = self._offset.to(ret.coords.device)
+                ret.coords = ret.coords - off                                                 # :103
+            else:       # (the offset of :103 is subtracted inside the call, where the coords are written)
                 ret = Dict(_sparse_filter_chained(points, self._size_h, self._vbounds, self._min_points,
-                                                  self._max_points, self._max_voxels, pf, vf, flags=flags))
-            off = self._offset_dev.get(ret.coords.device)
-            if off is None:
-                off = self._offset_dev[ret.coords.device] = self._offset.to(ret.coords.device)
-            ret.coords = ret.coords - off                                                     # :103
+                                                  self._max_points, self._max_voxels, pf, vf, flags=flags, offset_h=self._offset_h))
         if odev != points.device:
             ret = Dict({k: v.to(odev) for k, v in ret.items()})
         return ret
 
 
-__all__ = ["VoxelGenerator", "voxelize_3d_dense", "voxelize_3d_sparse", "voxelize_3d_filter",
+__all__ = ["VoxelGenerator", "voxelize_3d_dense", "voxelize_3d_sparse", "voxelize_3d_filter", "release_cached_buffers",
            "ReductionType", "MaxPointsFilterType", "MaxVoxelsFilterType"]

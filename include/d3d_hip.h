@@ -164,14 +164,16 @@ int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int32_t c, con
  * would remove their far-away voxel; d3d_voxelize_3d_sparse alone raises D3D_VOXEL_STATUS_COORD_OVERFLOW for them.
  * Workspace: d3d_voxelize_workspace_bytes(n, n).  host_counts: NULL, or 2 * D3D_NUM_COUNTS + 1 int64 of host-mapped
  * pinned memory with word [D3D_NUM_COUNTS] cleared: receives sparse_counts in [0, 4), counts in [5, 9) and then the flag
- * [4] = 1 before the last kernel (the compaction of the kept points) is launched -- see d3d_voxelize_3d_dense_notify. */
+ * [4] = 1 before the last kernel (the compaction of the kept points) is launched -- see d3d_voxelize_3d_dense_notify.
+ * coord_offset: NULL, or 3 host values subtracted from every row of out_coords -- the `ret.coords - self._offset` that ends
+ * VoxelGenerator.__call__ (voxel/__init__.py:103), done where the rows are written instead of by one more launch. */
 int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int32_t c, const float *voxel_size,
                                   const int64_t *coords_bound, int32_t min_points, int32_t max_points,
                                   int32_t max_voxels, int32_t max_points_filter, int32_t max_voxels_filter,
                                   int64_t *points_mapping, int64_t *coords, int32_t *npoints, int64_t *sparse_counts,
                                   float *out_feats, int64_t *out_mask, int64_t *out_mapping, int32_t *out_npoints,
                                   int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
-                                  void *stream, int64_t *host_counts, uint32_t flags);
+                                  void *stream, int64_t *host_counts, uint32_t flags, const int64_t *coord_offset);
 
 /* ---- beyond the reference: the point-sharded voxelizer of north_star (d3d has no distributed code) ---- */
 

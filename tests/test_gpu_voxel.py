@@ -622,7 +622,7 @@ def test_fused_sparse_filter_entry_error_codes():
         return lib.d3d_voxelize_3d_sparse_filter(
             _lib.ptr(pts), n, 4, ctypes.cast(size, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p), 0, 8, 100, 1, vf,
             _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), sparse_counts, _lib.ptr(o_feats), _lib.ptr(o_mask),
-            _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd), _lib.ptr(counts[1]), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(), None, 0)
+            _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd), _lib.ptr(counts[1]), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(), None, 0, None)
     assert call(2, _lib.ptr(counts[0]), ws.numel()) == _lib.ERR_UNSUPPORTED          # DESCENDING
     assert call(1, None, ws.numel()) == _lib.ERR_BAD_ARG
     assert call(1, _lib.ptr(counts[0]), 1024) == _lib.ERR_WORKSPACE
