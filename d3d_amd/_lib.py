@@ -104,6 +104,7 @@ SIGNATURES = {
     "d3d_argsort_desc": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "d3d_nms2d_workspace_bytes": (_sz, [_i64]),
     "d3d_nms2d": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp, _u32]),
+    "d3d_nms2d_notify": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp, _u32, _vp]),
 }
 
 _lib = None
@@ -174,6 +175,22 @@ def workspace(nbytes, device):
     while len(cache) > _WS_MAX_STREAMS:
         cache.pop(next(iter(cache)))
     return buf
+
+
+class HostWord:
+    """host-mapped pinned int32 word, one per thread: d3d_nms2d_notify's density verdict lands here"""
+    _local = threading.local()
+
+    def __init__(self):
+        self.tensor = torch.zeros((16,), dtype=torch.int32).pin_memory()
+        self.ptr = ctypes.c_void_p(self.tensor.data_ptr())
+
+    @classmethod
+    def get(cls):
+        buf = getattr(cls._local, "buf", None)
+        if buf is None:
+            buf = cls._local.buf = cls()
+        return buf
 
 
 class NotifyBuffer:

@@ -289,9 +289,11 @@ def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_thresho
         sup = torch.empty((n,), dtype=torch.uint8, device=dev)
         # both workspaces are carved from one arena; the sort finished with it (same stream)
         ws = _lib.workspace(lib.d3d_nms2d_workspace_bytes(n), dev)
-        rc = lib.d3d_nms2d(_lib.ptr(b), _lib.ptr(s), _lib.ptr(order) if order is not None else None, n, iou_type, supression_type, code,
-                           float(iou_threshold), float(score_threshold), float(supression_param), _lib.ptr(sup),
-                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), options.current().nms_flags if flags is None else int(flags))
+        # (the per-thread host word: the call decides from ITS OWN grid whether the level kernels are worth launching)
+        rc = lib.d3d_nms2d_notify(_lib.ptr(b), _lib.ptr(s), _lib.ptr(order) if order is not None else None, n, iou_type, supression_type,
+                                  code, float(iou_threshold), float(score_threshold), float(supression_param), _lib.ptr(sup),
+                                  _lib.ptr(ws), ws.numel(), _lib.stream_ptr(),
+                                  options.current().nms_flags if flags is None else int(flags), _lib.HostWord.get().ptr)
     _lib.check(rc, "nms2d")
     sup = sup.view(torch.bool)
     return sup.to(odev) if odev != dev else sup

@@ -894,10 +894,15 @@ __global__ __launch_bounds__(256) void k_nms_gridreg(const float4 *__restrict__ 
                                                      const float *__restrict__ partial, unsigned int npart /* 0: *grid is ready */,
                                                      const uint32_t *__restrict__ cellstart, const uint8_t *__restrict__ state,
                                                      uint8_t *__restrict__ regopen, const NmsCand *hdr = nullptr,
-                                                     const uint8_t *__restrict__ blocked = nullptr, unsigned int levels = 0)
+                                                     const uint8_t *__restrict__ blocked = nullptr, unsigned int levels = 0,
+                                                     const NmsCand *density_hdr = nullptr, int *host_dense = nullptr)
 {
     __shared__ float sm[4][6];
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // first placement: the grid's density is final (k_nms_gridscan summed it up) -- tell the host NOW, which is waiting to
+    // decide whether the level kernels are worth launching (nms_typed): 2 = dense, 1 = sparse
+    if (host_dense && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(host_dense, nms_levels_on(*grid, density_hdr) ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // second registration (hdr != NULL), after the levels: only the boxes they left open, so that k_nms_cand_grid walks short
     // lists; nothing happens unless the levels ran
     if (hdr && !nms_levels_on(*grid, hdr)) return;
@@ -978,8 +983,7 @@ __global__ __launch_bounds__(256) void k_nms_cand_grid(const float4 *__restrict_
                                                        unsigned long long *__restrict__ list, unsigned long long cap, NmsCand *hdr,
                                                        NmsFlags *flags, const float *__restrict__ carea, float thr,
                                                        const uint32_t *__restrict__ cellbox, const uint8_t *__restrict__ blocked,
-                                                       const uint8_t *__restrict__ state, unsigned int levels /* that were launched */,
-                                                       int *dense_hint /* host-mapped, optional */)
+                                                       const uint8_t *__restrict__ state, unsigned int levels /* that were launched */)
 {
     __shared__ unsigned long long batch[4][kCandLds];
     __shared__ float4 window[4][128 + 4];
@@ -992,8 +996,6 @@ __global__ __launch_bounds__(256) void k_nms_cand_grid(const float4 *__restrict_
     // only the boxes the levels left open (undecided and blocked at the last level; level 0 = everybody when they did not
     // run) take part, on either side
     const unsigned int level = nms_levels_on(g, hdr) ? levels : 0u;
-    if (dense_hint && e == 0)                 // for the host's NEXT call: was this grid dense? (nms_dense_hint)
-        __hip_atomic_store(dense_hint, nms_levels_on(g, hdr) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     auto open = [&](uint32_t reg) {
         const uint32_t r = cellbox[reg];
         return state[r] == kUndecided && blocked[r] == level;
@@ -1884,35 +1886,22 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_small(uint32_t n, const ui
 }
 
 
-// Whether the level kernels are worth LAUNCHING is a guess from the previous call: they decide on the device whether to run
-// (density of the grid), but on scattered boxes even their six empty launches cost ~15 % of a 100 k-box call.  The grid's
-// density of every call is left in one host-mapped word; the launches are skipped once kNmsSparseStreak calls IN A ROW have
-// found it "sparse" -- a detector's stream of frames looks like the frame before.  The two ways to be wrong are not alike:
-// launching for nothing costs ~20 us, NOT launching on clusters costs the round-2 route (200 x 500: 2.9 ms instead of 0.4),
-// hence the streak: a caller that alternates between raw detections and scattered boxes never builds one and always launches.
-// Only speed depends on the guess: without the launches every pair is listed as before.  (One word + one counter per process,
-// unsynchronised on purpose; never allocated during a stream capture.)
-constexpr int kNmsSparseStreak = 4;
-static int *g_nms_hint_host = nullptr, *g_nms_hint_dev = nullptr;
-static int g_nms_sparse_streak = 0;
-static void nms_dense_hint(hipStream_t st, int **dev, bool *launch_levels)
+// Whether the level kernels are worth LAUNCHING (they decide on the device whether to run, but on scattered boxes their ten
+// empty launches cost ~15 % of a 100 k-box call) is decided from THIS call's grid, not from a guess: the density is final when
+// k_nms_gridscan ends; the first thread of the next launch (the placement, 18 us of work) stores the verdict in a host-mapped
+// word of the CALLER's, and the host -- about six launches ahead of the GPU at that point -- waits for it before it enqueues
+// the rest.  The queue never runs dry (the placement covers the host's reaction), sparse calls launch nothing for the levels,
+// clustered calls always get them: no history, no first-call cliff, nothing shared between callers.  (Rounds 2-3 kept a
+// process-wide streak counter + one mapped word for all devices, streams and threads; gone.)  Without the word -- plain
+// d3d_nms2d, or a stream under capture -- the levels are always launched.
+static bool nms_wait_dense(volatile int *host_word, hipStream_t st)
 {
-    *dev = nullptr;
-    *launch_levels = true;
-    if (!g_nms_hint_host) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
-        int *h = nullptr, *d = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void **>(&h), 64, hipHostMallocMapped) != hipSuccess ||
-            hipHostGetDevicePointer(reinterpret_cast<void **>(&d), h, 0) != hipSuccess) { (void)hipGetLastError(); return; }
-        *h = 1;
-        g_nms_hint_dev = d;
-        g_nms_hint_host = h;
-    }
-    *dev = g_nms_hint_dev;
-    if (*reinterpret_cast<volatile int *>(g_nms_hint_host) != 0) g_nms_sparse_streak = 0;
-    else if (g_nms_sparse_streak < kNmsSparseStreak) g_nms_sparse_streak++;
-    *launch_levels = g_nms_sparse_streak < kNmsSparseStreak;
+    for (long spins = 0; *host_word == 0; spins++)
+        if (spins > (1l << 26)) {                           // (~ a second: something is wrong -- drain the stream, which also
+            if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();     //  surfaces the error to the caller's next check)
+            break;
+        }
+    return *host_word != 1;                                 // 2 = dense; unknown counts as dense
 }
 
 // the small-set path takes hard NMS of up to kNmsSmallMax boxes unless a flag asks for a specific general path (tests)
@@ -1923,7 +1912,8 @@ static inline bool nms_small_eligible(int64_t n, uint32_t opts)
 
 template <typename T>
 int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, int iou_type, float iou_thr,
-              float score_thr, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st, uint32_t opts, int64_t *order_ws)
+              float score_thr, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st, uint32_t opts, int64_t *order_ws,
+              int32_t *host_word)
 {
     const int64_t nb = d3d_divup(n, 64);
     WsCarver w(ws, ws_bytes);
@@ -2023,14 +2013,23 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
         D3D_LAUNCH("k_nms_gridscan", k_nms_gridscan, dim3(kGridScanWgs), dim3(1024), 0, st, cellcur, cellstart, grid, cap_e, flags,
                    chunk_tot, tickets + 1, (opts & D3D_NMS_TEST_WITHHOLD) != 0 && (opts & D3D_NMS_BROAD_SWEEP) == 0,
                    &cand_hdr->count[kHdrDensity]);
+        int *host_dense = nullptr;
+        if (host_word && !(opts & D3D_NMS_FORCE_LEVELS)) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+            else if (cs == hipStreamCaptureStatusNone) {
+                void *dptr = nullptr;
+                if (hipHostGetDevicePointer(&dptr, host_word, 0) == hipSuccess) host_dense = static_cast<int *>(dptr);
+                else (void)hipGetLastError();
+            }
+        }
+        if (host_dense) *reinterpret_cast<volatile int32_t *>(host_word) = 0;
         D3D_LAUNCH("k_nms_gridreg<place>", k_nms_gridreg<true>, dim3(nbl), dim3(256), 0, st, (const float4 *)fbox, n, grid,
                    cellcur, cap_e, cellbox, cellof, fbc, flags, (const float *)farea, carea, (const float *)gpartial, 0u,
-                   (const uint32_t *)cellstart, (const uint8_t *)state, regopen);
+                   (const uint32_t *)cellstart, (const uint8_t *)state, regopen, (const NmsCand *)nullptr, (const uint8_t *)nullptr, 0u,
+                   (const NmsCand *)cand_hdr, host_dense);
         unsigned int levels = (opts & D3D_NMS_ONE_LEVEL) ? 1u : (unsigned int)kNmsLevels;
-        int *hint_dev = nullptr;
-        bool launch_levels = true;
-        nms_dense_hint(st, &hint_dev, &launch_levels);
-        if (!launch_levels && !(opts & D3D_NMS_FORCE_LEVELS)) levels = 0;
+        if (host_dense && !nms_wait_dense(host_word, st)) levels = 0;
         for (unsigned int level = 1; level <= levels; level++) {
             const dim3 lg((unsigned)d3d_divup((int64_t)cap_e, 256));
             const float bthr = rot ? iou_thr : -1.f;
@@ -2067,7 +2066,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
         D3D_LAUNCH("k_nms_cand_grid", k_nms_cand_grid, dim3((unsigned)d3d_divup((int64_t)cap_e, 256)), dim3(256), 0, st,
                    (const float4 *)fbc, (const uint32_t *)cellof, (const uint32_t *)cellstart, (const NmsGrid *)grid, cand, cap,
                    cand_hdr, flags, (const float *)carea, rot ? iou_thr : -1.f, (const uint32_t *)cellbox, (const uint8_t *)blocked,
-                   (const uint8_t *)state, levels, hint_dev);
+                   (const uint8_t *)state, levels);
         rankx = cellbox;                                   // registration -> score rank, for k_nms_hits
     } else {
         if (int rc = d3d_internal_argsort_desc_i32(xkey, n, perm, sort_ws, sort_bytes, st)) return rc;
@@ -2517,10 +2516,10 @@ extern "C" size_t d3d_nms2d_workspace_bytes(int64_t n)
     return nms_core_workspace_bytes(n) + d3d_align_up((size_t)n * 8) + d3d_align_up(d3d_argsort_desc_workspace_bytes(n, D3D_F64)) + 256;
 }
 
-extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n, int32_t iou_type,
-                         int32_t suppression_type, int32_t dtype, float iou_threshold, float score_threshold,
-                         float suppression_param, uint8_t *suppressed, void *workspace, size_t workspace_bytes,
-                         void *stream, uint32_t flags)
+static int nms2d_impl(const void *boxes, const void *scores, const int64_t *order, int64_t n, int32_t iou_type,
+                      int32_t suppression_type, int32_t dtype, float iou_threshold, float score_threshold,
+                      float suppression_param, uint8_t *suppressed, void *workspace, size_t workspace_bytes,
+                      void *stream, uint32_t flags, int32_t *host_word)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL | D3D_NMS_TEST_WITHHOLD | D3D_NMS_FORCE_LEVELS | D3D_NMS_ONE_LEVEL))) return D3D_ERR_BAD_ARG;
@@ -2567,9 +2566,27 @@ extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *o
     if (d3d_divup(n, 64) > 65535) return D3D_ERR_BAD_ARG;
     if (dtype == D3D_F64)
         return nms_typed<double>((const double *)boxes, (const double *)scores, order, n, iou_type, iou_threshold,
-                                 score_threshold, suppressed, workspace, nms_bytes, st, flags, order_ws);
+                                 score_threshold, suppressed, workspace, nms_bytes, st, flags, order_ws, host_word);
     return nms_typed<float>((const float *)boxes, (const float *)scores, order, n, iou_type, iou_threshold,
-                            score_threshold, suppressed, workspace, nms_bytes, st, flags, order_ws);
+                            score_threshold, suppressed, workspace, nms_bytes, st, flags, order_ws, host_word);
+}
+
+extern "C" int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n, int32_t iou_type,
+                         int32_t suppression_type, int32_t dtype, float iou_threshold, float score_threshold,
+                         float suppression_param, uint8_t *suppressed, void *workspace, size_t workspace_bytes,
+                         void *stream, uint32_t flags)
+{
+    return nms2d_impl(boxes, scores, order, n, iou_type, suppression_type, dtype, iou_threshold, score_threshold, suppression_param,
+                      suppressed, workspace, workspace_bytes, stream, flags, nullptr);
+}
+
+extern "C" int d3d_nms2d_notify(const void *boxes, const void *scores, const int64_t *order, int64_t n, int32_t iou_type,
+                                int32_t suppression_type, int32_t dtype, float iou_threshold, float score_threshold,
+                                float suppression_param, uint8_t *suppressed, void *workspace, size_t workspace_bytes,
+                                void *stream, uint32_t flags, int32_t *host_word)
+{
+    return nms2d_impl(boxes, scores, order, n, iou_type, suppression_type, dtype, iou_threshold, score_threshold, suppression_param,
+                      suppressed, workspace, workspace_bytes, stream, flags, host_word);
 }
 
 extern "C" int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, int64_t m, int32_t dtype, uint8_t *out,

@@ -1,49 +1,249 @@
-// sort.hip -- stable descending argsort (rocPRIM radix sort; a plain library sort, the same
-// role torch::argsort plays inside the reference: nms.cpp:103, voxelize.cpp:406).
+// sort.hip -- stable descending argsort (the role torch::argsort plays inside the reference: nms.cpp:103,
+// voxelize.cpp:406): one workgroup in LDS up to 2 k keys, a four-launch sample sort up to 128 k, an LSD radix sort above.
+// No library sort (round 4: rocprim::radix_sort_pairs is gone).
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
 #include "common.hpp"
 #include "lds_sort.hpp"
-#include <rocprim/rocprim.hpp>
 
 namespace {
-// rocPRIM sorts inputs below 1 M items with a merge sort: block sort (1024 items per workgroup) + one launch per doubling,
-// 7 at 100 k.  A larger block sort (merge_sort_config<512, 1024, 4>: 4096 items, 5 merge launches) was slower end to end
-// (NMS of 100 k boxes 0.240 vs 0.231 ms), so the library default stays.
-typedef rocprim::default_config SortConfig;
+// ---------------------------------------------------------------- radix path (any n; what runs above 128 k keys)
+// Own LSD radix sort (round 4; rocprim::radix_sort_pairs before): 8-bit digits, stable, the (key, index) pair travels.
+//   k_rs_hist     one sweep over the keys: the digit histograms of ALL passes (64 workgroups, LDS histograms, one global
+//                 atomic per non-empty bin)
+//   k_rs_plan     one workgroup: a pass whose digit is the same in every key is SKIPPED (promoted fp32 scores have three
+//                 zero mantissa bytes, voxel counts two zero high bytes): which buffer every remaining pass reads and
+//                 writes, which pass is the last (it writes `order`), the bins' bases
+//   per pass      k_rs_tile_hist: digit counts of every 4096-key tile (tile-major rows of 1 KiB);  k_rs_scatter: ranks by
+//                 wavefront ballots (eight per row of 64 keys: the lanes with my digit), the tile's offsets = the column sums
+//                 of the rows before it (read by the workgroup itself: no scan launch, nobody waits for anybody), the tile
+//                 reordered in LDS so that the global stores run along the digits' runs.  Both exit at once on a skipped pass.
+// A one-launch pass with look-back was measured in round 2 (tools/radix_bench.hip): with every tile resident at once nobody
+// has an inclusive prefix to offer and each tile walks all its predecessors -- 990 us for 1 M pairs.
+constexpr int kRsThreads = 256, kRsItems = 16, kRsTile = kRsThreads * kRsItems, kRsBins = 256, kRsWaves = kRsThreads / kWave;
+constexpr int kRsHistBlocks = 64, kRsHistThreads = 1024;
 
-// ---------------------------------------------------------------- library path (rocPRIM; any n)
-// V = type of the order entries (int32 inside the library, int64 at the C ABI: written directly, no widening pass)
-template <typename K, typename V>
-size_t sort_temp_bytes(int64_t n)
+struct RsPlan {             // per pass
+    int32_t skip, src, dst;  // src: -1 = the caller's keys (index = position), 0 / 1 = ping-pong buffer; dst: 0 / 1, 2 = `order`
+};
+
+template <typename K>
+__global__ __launch_bounds__(kRsHistThreads) void k_rs_hist(const K *__restrict__ keys, uint32_t n, uint32_t *ghist)
 {
     typedef typename KeyBits<K>::U U;
-    size_t tmp = 0;
-    (void)rocprim::radix_sort_pairs<SortConfig, rocprim::transform_iterator<const K *, DescKey<K>, U>, U *, rocprim::counting_iterator<V>, V *>(
-        nullptr, tmp, rocprim::transform_iterator<const K *, DescKey<K>, U>(nullptr, DescKey<K>()), nullptr,
-        rocprim::counting_iterator<V>(0), nullptr, (size_t)n);
-    return tmp;
+    constexpr int PASSES = sizeof(U);
+    __shared__ uint32_t h[PASSES][kRsBins];
+    for (int i = threadIdx.x; i < PASSES * kRsBins; i += kRsHistThreads) (&h[0][0])[i] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * kRsHistThreads + threadIdx.x; i < n; i += gridDim.x * kRsHistThreads) {
+        const U k = KeyBits<K>::desc(keys[i]);
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) {
+            // a digit that is the same in the whole wavefront (the zero mantissa bytes of promoted fp32 scores, a sign / exponent
+            // byte) is counted by one lane: 64 atomics on one LDS word serialise (k_rs_hist 71 us on such keys)
+            const uint32_t d = (uint32_t)(k >> (8 * p)) & 255u;
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+            const unsigned long long act = __ballot(true);
+            if (__ballot(d == d0) == act) {
+                if ((threadIdx.x & (kWave - 1)) == (uint32_t)__builtin_ctzll(act)) atomicAdd(&h[p][d0], (uint32_t)__popcll(act));
+            } else atomicAdd(&h[p][d], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PASSES * kRsBins; i += kRsHistThreads)
+        if ((&h[0][0])[i]) atomicAdd(&ghist[i], (&h[0][0])[i]);
+}
+
+template <int PASSES>
+__global__ __launch_bounds__(kRsBins) void k_rs_plan(uint32_t *ghist /* -> exclusive bases */, uint32_t n, RsPlan *plan)
+{
+    __shared__ unsigned long long smem[kRsBins / kWave];
+    __shared__ int skip[PASSES];
+    for (int p = 0; p < PASSES; p++) {
+        const uint32_t c = ghist[p * kRsBins + threadIdx.x];
+        const int full = __syncthreads_or(c == n);                    // one bin holds every key: nothing to do in this pass
+        unsigned long long tot;
+        const unsigned long long ex = block_excl_scan_u64<kRsBins>(c, &tot, smem);
+        ghist[p * kRsBins + threadIdx.x] = (uint32_t)ex;
+        if (threadIdx.x == 0) skip[p] = full;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int last = -1;
+        for (int p = 0; p < PASSES; p++)
+            if (!skip[p]) last = p;
+        int cur = -1;                                                  // where the pairs are: -1 = the caller's keys
+        for (int p = 0; p < PASSES; p++) {
+            plan[p].skip = skip[p];
+            plan[p].src = cur;
+            plan[p].dst = p == last ? 2 : (cur == 0 ? 1 : 0);
+            if (!skip[p]) cur = plan[p].dst;
+        }
+        plan[PASSES].skip = last < 0;                                  // every key equal: the order is the identity
+    }
+}
+
+// the pass's key of item i and its index, from wherever the plan says the pairs are
+template <typename K>
+__device__ __forceinline__ typename KeyBits<K>::U rs_load(const K *__restrict__ keys, const typename KeyBits<K>::U *__restrict__ kin,
+                                                          const uint32_t *__restrict__ vin, int src, uint32_t i, uint32_t &val)
+{
+    if (src < 0) { val = i; return KeyBits<K>::desc(keys[i]); }
+    val = vin[i];
+    return kin[i];
+}
+
+template <typename K>
+__global__ __launch_bounds__(kRsThreads) void k_rs_tile_hist(const K *__restrict__ keys, typename KeyBits<K>::U *kb0,
+                                                             typename KeyBits<K>::U *kb1, uint32_t n, int pass,
+                                                             const RsPlan *__restrict__ plan, uint32_t *__restrict__ tilehist)
+{
+    typedef typename KeyBits<K>::U U;
+    const RsPlan pl = plan[pass];
+    if (pl.skip) return;
+    __shared__ uint32_t h[kRsBins];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const U *kin = pl.src == 0 ? kb0 : kb1;
+    const uint32_t base = blockIdx.x * kRsTile + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < kRsItems; r++) {
+        const uint32_t i = base + r * kRsThreads;
+        if (i < n) {
+            const U k = pl.src < 0 ? KeyBits<K>::desc(keys[i]) : kin[i];
+            atomicAdd(&h[(uint32_t)(k >> (8 * pass)) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    tilehist[(size_t)blockIdx.x * kRsBins + threadIdx.x] = h[threadIdx.x];
 }
 
 template <typename K, typename V>
-size_t library_bytes(int64_t n)
-{
-    return d3d_align_up(sizeof(typename KeyBits<K>::U) * n) + d3d_align_up(sort_temp_bytes<K, V>(n)) + 256;
-}
-
-// order[n] <- stable descending argsort of keys; the values 0 .. n-1 come from a counting iterator
-template <typename K, typename V>
-int library_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st)
+__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const K *__restrict__ keys, typename KeyBits<K>::U *kb0,
+                                                           typename KeyBits<K>::U *kb1, uint32_t *vb0, uint32_t *vb1, uint32_t n,
+                                                           int pass, const RsPlan *__restrict__ plan,
+                                                           const uint32_t *__restrict__ tilehist, const uint32_t *__restrict__ gbase,
+                                                           V *__restrict__ order)
 {
     typedef typename KeyBits<K>::U U;
+    const RsPlan pl = plan[pass];
+    if (pl.skip) {
+        // (every key equal: pass 0 writes the identity)
+        if (pass == 0 && plan[sizeof(U)].skip)
+            for (uint32_t i = blockIdx.x * kRsTile + threadIdx.x; i < n && i < (blockIdx.x + 1) * (uint32_t)kRsTile; i += kRsThreads)
+                order[i] = (V)i;
+        return;
+    }
+    __shared__ uint32_t cnt[kRsWaves][kRsBins];     // per-wavefront digit counts -> the wavefront's offset inside the digit's run
+    __shared__ uint32_t dstart[kRsBins];            // the digit's run inside the tile (exclusive scan of the tile's counts)
+    __shared__ uint32_t gpos[kRsBins];              // where that run goes: bin base + the same digit in all earlier tiles
+    __shared__ U skey[kRsTile];
+    __shared__ uint32_t sval[kRsTile];
+    __shared__ unsigned long long smem[kRsThreads / kWave];
+    for (int i = threadIdx.x; i < kRsWaves * kRsBins; i += kRsThreads) (&cnt[0][0])[i] = 0;
+    // column sums of the earlier tiles' rows (thread = digit; coalesced rows, independent loads)
+    uint32_t before = 0;
+#pragma unroll 8
+    for (uint32_t t = 0; t < blockIdx.x; t++) before += tilehist[(size_t)t * kRsBins + threadIdx.x];
+    __syncthreads();
+    const U *kin = pl.src == 0 ? kb0 : kb1;
+    const uint32_t *vin = pl.src == 0 ? vb0 : vb1;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * kRsTile + w * (kWave * kRsItems) + lane;     // wavefront-striped: row r at base + 64 r
+    U key[kRsItems];
+    uint32_t val[kRsItems], rank[kRsItems];
+#pragma unroll
+    for (int r = 0; r < kRsItems; r++) {
+        const uint32_t i = base + r * kWave;
+        key[r] = ~(U)0;
+        val[r] = 0;
+        if (i < n) key[r] = rs_load<K>(keys, kin, vin, pl.src, i, val[r]);
+    }
+    // rank of every pair among the pairs of its wavefront with the same digit, in input order
+#pragma unroll
+    for (int r = 0; r < kRsItems; r++) {
+        const uint32_t i = base + r * kWave;
+        const bool valid = i < n;
+        const uint32_t d = (uint32_t)(key[r] >> (8 * pass)) & 255u;
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const int leader = __builtin_ctzll(same | (valid ? 0ull : 1ull << lane));
+        uint32_t old = 0;
+        if (valid && lane == leader) { old = cnt[w][d]; cnt[w][d] = old + (uint32_t)__popcll(same); }
+        __builtin_amdgcn_wave_barrier();
+        old = __shfl(old, leader, kWave);
+        rank[r] = old + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    {   // thread = digit: the wavefronts' offsets inside the digit's run, the runs inside the tile, their place in the output
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < kRsWaves; ww++) { const uint32_t c = cnt[ww][threadIdx.x]; cnt[ww][threadIdx.x] = run; run += c; }
+        unsigned long long tot;
+        const uint32_t ex = (uint32_t)block_excl_scan_u64<kRsThreads>(run, &tot, smem);
+        dstart[threadIdx.x] = ex;
+        gpos[threadIdx.x] = gbase[pass * kRsBins + threadIdx.x] + before - ex;        // + position inside the tile = output place
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRsItems; r++) {
+        const uint32_t i = base + r * kWave;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(key[r] >> (8 * pass)) & 255u;
+            const uint32_t p = dstart[d] + cnt[w][d] + rank[r];
+            skey[p] = key[r];
+            sval[p] = val[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t m = n - blockIdx.x * kRsTile < (uint32_t)kRsTile ? n - blockIdx.x * kRsTile : (uint32_t)kRsTile;
+    U *kout = pl.dst == 0 ? kb0 : kb1;
+    uint32_t *vout = pl.dst == 0 ? vb0 : vb1;
+    for (uint32_t p = threadIdx.x; p < m; p += kRsThreads) {            // consecutive lanes: consecutive places of a digit's run
+        const U k = skey[p];
+        const uint32_t pos = gpos[(uint32_t)(k >> (8 * pass)) & 255u] + p;
+        if (pl.dst == 2) order[pos] = (V)sval[p];
+        else { kout[pos] = k; vout[pos] = sval[p]; }
+    }
+}
+
+template <typename K>
+size_t radix_bytes(int64_t n)
+{
+    typedef typename KeyBits<K>::U U;
+    const size_t ntiles = (size_t)d3d_divup(n, kRsTile);
+    return 2 * d3d_align_up(sizeof(U) * (size_t)n) + 2 * d3d_align_up(4 * (size_t)n) + d3d_align_up(sizeof(U) * kRsBins * 4) +
+           d3d_align_up(ntiles * kRsBins * 4) + d3d_align_up((sizeof(U) + 1) * sizeof(RsPlan)) + 256;
+}
+
+// order[n] <- stable descending argsort of keys
+template <typename K, typename V>
+int radix_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    typedef typename KeyBits<K>::U U;
+    constexpr int PASSES = sizeof(U);
+    const unsigned ntiles = (unsigned)d3d_divup(n, kRsTile);
     WsCarver w(ws, ws_bytes);
-    U *keys_out = w.take<U>(n);
-    size_t tmp = sort_temp_bytes<K, V>(n);
-    char *temp = w.take<char>(tmp);
+    U *kb0 = w.take<U>(n), *kb1 = w.take<U>(n);
+    uint32_t *vb0 = w.take<uint32_t>(n), *vb1 = w.take<uint32_t>(n);
+    uint32_t *ghist = w.take<uint32_t>((size_t)PASSES * kRsBins);
+    uint32_t *tilehist = w.take<uint32_t>((size_t)ntiles * kRsBins);
+    RsPlan *plan = w.take<RsPlan>(PASSES + 1);
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
-    D3D_HIP_CHECK((rocprim::radix_sort_pairs<SortConfig>(temp, tmp, rocprim::transform_iterator<const K *, DescKey<K>, U>(keys, DescKey<K>()),
-                                                         keys_out, rocprim::counting_iterator<V>(0), order, (size_t)n, 0, sizeof(U) * 8, st)));
+    D3D_HIP_CHECK(hipMemsetAsync(ghist, 0, (size_t)PASSES * kRsBins * 4, st));
+    D3D_LAUNCH("k_rs_hist", k_rs_hist<K>, dim3(kRsHistBlocks), dim3(kRsHistThreads), 0, st, keys, (uint32_t)n, ghist);
+    D3D_LAUNCH("k_rs_plan", k_rs_plan<PASSES>, dim3(1), dim3(kRsBins), 0, st, ghist, (uint32_t)n, plan);
+    for (int p = 0; p < PASSES; p++) {
+        D3D_LAUNCH("k_rs_tile_hist", k_rs_tile_hist<K>, dim3(ntiles), dim3(kRsThreads), 0, st, keys, kb0, kb1, (uint32_t)n, p,
+                   (const RsPlan *)plan, tilehist);
+        D3D_LAUNCH("k_rs_scatter", (k_rs_scatter<K, V>), dim3(ntiles), dim3(kRsThreads), 0, st, keys, kb0, kb1, vb0, vb1, (uint32_t)n, p,
+                   (const RsPlan *)plan, (const uint32_t *)tilehist, (const uint32_t *)ghist, order);
+    }
     return D3D_OK;
 }
 
@@ -259,19 +459,19 @@ template <typename K, typename V>
 size_t argsort_bytes(int64_t n)
 {
     if (n < 1) n = 1;
-    return std::max(library_bytes<K, V>(n), ss_eligible(n) ? bucket_bytes<K>(n) : (size_t)0);
+    return std::max(radix_bytes<K>(n), ss_eligible(n) ? bucket_bytes<K>(n) : (size_t)0);
 }
 
 template <typename K, typename V>
-int argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st, bool library_only = false)
+int argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st, bool radix_only = false)
 {
     if (n <= 0) return D3D_OK;
-    if (n <= kSsBucketCap && !library_only) {
+    if (n <= kSsBucketCap && !radix_only) {
         D3D_LAUNCH("k_sort_small", (k_sort_small<K, V>), dim3(1), dim3(kSsSortThreads), 0, st, keys, (uint32_t)n, order);
         return D3D_OK;
     }
-    if (ss_eligible(n) && !library_only) return bucket_argsort_desc<K, V>(keys, n, order, ws, ws_bytes, st);
-    return library_argsort_desc<K, V>(keys, n, order, ws, ws_bytes, st);
+    if (ss_eligible(n) && !radix_only) return bucket_argsort_desc<K, V>(keys, n, order, ws, ws_bytes, st);
+    return radix_argsort_desc<K, V>(keys, n, order, ws, ws_bytes, st);
 }
 }  // namespace
 
@@ -282,8 +482,8 @@ extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int
     return argsort_desc<int32_t, int32_t>(keys, n, order, ws, ws_bytes, st);
 }
 
-// (tests: the library path at a size the bucket path would take)
-extern "C" int d3d_internal_argsort_desc_library(const void *keys, int64_t n, int32_t dtype, int64_t *order, void *ws, size_t ws_bytes,
+// (tests: the radix path at a size the bucket path would take)
+extern "C" int d3d_internal_argsort_desc_radix(const void *keys, int64_t n, int32_t dtype, int64_t *order, void *ws, size_t ws_bytes,
                                                  void *stream)
 {
     hipStream_t st = (hipStream_t)stream;

@@ -466,6 +466,18 @@ int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64
               float iou_threshold, float score_threshold, float suppression_param,
               uint8_t *suppressed, void *workspace, size_t workspace_bytes, void *stream, uint32_t flags);
 
+/* d3d_nms2d with a host-mapped word of the CALLER's (hipHostMalloc / pinned, int32, one per thread of callers): hard NMS on
+ * the general path learns from it, half-way through ITS OWN launches, whether this call's boxes form clusters (a dense
+ * broad-phase grid) -- only then are the ten launches of the level kernels enqueued; a scattered set skips them.  The call
+ * waits for that word (the GPU keeps working: the launch that writes it has 18 us of work of its own), so it returns with
+ * the second half of its kernels still in flight, like d3d_nms2d.  Same mask either way.  NULL, a stream under capture, or
+ * D3D_NMS_FORCE_LEVELS: as d3d_nms2d, which always enqueues the level kernels.  Nothing is remembered between calls. */
+int d3d_nms2d_notify(const void *boxes, const void *scores, const int64_t *order, int64_t n,
+                     int32_t iou_type, int32_t suppression_type, int32_t dtype,
+                     float iou_threshold, float score_threshold, float suppression_param,
+                     uint8_t *suppressed, void *workspace, size_t workspace_bytes, void *stream, uint32_t flags,
+                     int32_t *host_word);
+
 #ifdef __cplusplus
 }
 #endif
