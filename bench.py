@@ -249,6 +249,30 @@ def extras(args):
         kernels_sum_us=round(sum(v["total_ms"] for v in sp.values()) * 1e3 / 20, 1),
         traffic=load_traffic("sparse_op_total", "config2_sparse")[0], traffic_source=load_traffic("sparse_op_total", "config2_sparse")[1])
     del cloud
+    # SURVEY 8d "batched variant": a stream of config-2 frames through VoxelGenerator.stream -- frame k + 1's index launches on a
+    # side stream under frame k's output launch (two frames in flight).  An EXTRA: the headline stays the sequential operator.
+    ca = torch.from_numpy(synth.lidar_like(args.points, 0)).cuda()
+    cb = torch.from_numpy(synth.lidar_like(args.points, 1)).cuda()
+    gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=32, max_voxels=args.points)
+    nfr = 60
+
+    def run_stream():
+        nv = 0
+        for r in gen.stream(((ca if k & 1 else cb) for k in range(nfr)), pipelined=True):
+            nv += r.coords.shape[0]
+        return nv
+    run_stream()
+    sync()
+    t0 = time.perf_counter()
+    run_stream()
+    sync()
+    dtp = time.perf_counter() - t0
+    ex["voxelize_dense_pipelined_mpoints_per_s"] = round(args.points * nfr / dtp / 1e6, 2)
+    ex["voxelize_dense_pipelined_us_per_frame"] = round(dtp / nfr * 1e6, 1)
+    ex["voxelize_dense_pipelined_note"] = ("two frames in flight on two streams: no gain on this stack -- one hardware queue serialises "
+                                           "them, two queues pay 50-60 us per cross-queue event wait (DESIGN.md 4d); off by default")
+    del ca, cb, gen
+    torch.cuda.empty_cache()
     # config 2 on the UNIFORM cloud (SURVEY 8d's worst case: ~0.98 voxels per point, 500 MB of voxels[V,32,4])
     cloud = torch.from_numpy(synth.uniform_cloud(args.points, 0)).cuda()
     gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=32, max_voxels=args.points)
@@ -503,6 +527,7 @@ def main():
             # voxels[V,P,4] written; kept rows (16 B) gathered from the staged segments, one 16-byte record per voxel read
             "k_fill_c4": V * P * 16 + kept * 16 + V * 16,
             # binned index (n >= 32 k points): partition, per-bucket index in LDS, numbering + per-voxel outputs
+            "k_tile_sort": n * 16 + n * 8 + npad * 4,               # rows read; {cell, index} entries + firstmap reset written
             "k_bin_count": n * 16 + npad * 8,                       # rows read; bucket word + firstmap reset written
             "k_bin_scatter": n * (16 + 4) + n * (16 + 4),           # rows + bucket words read; rows + indices written
             "k_bucket_index": n * (16 + 4) + kept * 16 + V * (16 + 4),   # bucket read; ranked rows, records, firstmap written

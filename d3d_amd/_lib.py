@@ -18,7 +18,7 @@ COUNT_VOXELS, COUNT_POINTS, COUNT_STATUS, COUNT_AUX, NUM_COUNTS = 0, 1, 2, 3, 4
 STATUS_COORD_OVERFLOW, STATUS_TABLE_FULL, STATUS_PACK_OVERFLOW, STATUS_BIN_OVERFLOW = 1, 2, 4, 8
 F32, F64 = 0, 1
 # per-call option bits (include/d3d_hip.h)
-VOXEL_PATH_HASH, VOXEL_PARTITION_3PASS, VOXEL_PLAIN_SLOTS, VOXEL_SPLIT_FILL = 1, 2, 4, 8
+VOXEL_PATH_HASH, VOXEL_PARTITION_3PASS, VOXEL_PLAIN_SLOTS, VOXEL_SPLIT_FILL, VOXEL_EXACT_MEAN = 1, 2, 4, 8, 16
 NMS_BROAD_SWEEP, NMS_FORCE_DENSE, NMS_SOFT_NO_LDS, NMS_GENERAL, NMS_TEST_WITHHOLD, NMS_FORCE_LEVELS, NMS_ONE_LEVEL = 1, 2, 4, 8, 16, 32, 64
 
 
@@ -42,6 +42,8 @@ SIGNATURES = {
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32]),
     "d3d_voxelize_3d_dense_notify": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _u32]),
+    "d3d_voxelize_3d_dense_staged": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _u32, _i32]),
     "d3d_voxelize_3d_sparse": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32]),
     "d3d_voxelize_3d_filter": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256) void k_nms_gridreg(const float4 *__restrict__ 
     // first placement: the grid's density is final (k_nms_gridscan summed it up) -- tell the host NOW, which is waiting to
     // decide whether the level kernels are worth launching (nms_typed): 2 = dense, 1 = sparse
     if (host_dense && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(host_dense, nms_levels_on(*grid, density_hdr) ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_dense, nms_levels_on(*grid, density_hdr) ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the word IS the message: nothing to release)
     // second registration (hdr != NULL), after the levels: only the boxes they left open, so that k_nms_cand_grid walks short
     // lists; nothing happens unless the levels ran
     if (hdr && !nms_levels_on(*grid, hdr)) return;

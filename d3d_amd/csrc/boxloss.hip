@@ -15,13 +15,14 @@ namespace {
 
 constexpr int kCols = 256, kRows = 64;
 
-template <typename T> struct RowBox { BoxGeom<T> g; T w, h; };
+template <typename T> struct RowBox { BoxGeom<T> g; T w, h, c, s; };
 
 template <typename T> __device__ __forceinline__ RowBox<T> load_row(const T *b)
 {
     RowBox<T> r;
     r.g = make_geom<T>(b[0], b[1], b[2], b[3], b[4]);
     r.w = b[2]; r.h = b[3];
+    d3d_sincos(b[4], &r.s, &r.c);
     return r;
 }
 
@@ -230,10 +231,12 @@ __global__ __launch_bounds__(kCols) void k_pdist(const T *__restrict__ points, i
         const RowBox<T> b = rows[r];
         T d[K];
         uint8_t f[K];
+        const bool regular = b.w > 0 && b.h > 0;           // (wave-uniform: every lane works on box r)
 #pragma unroll
         for (int k = 0; k < K; k++) {
             int feat;
-            d[k] = point_box_distance<T, false>(b.g, b.w, b.h, px[k], py[k], feat, gp, gb);
+            if (regular) d[k] = point_box_distance_local<T>(b.g.cx, b.g.cy, b.c, b.s, b.w / 2, b.h / 2, px[k], py[k], feat);
+            else d[k] = point_box_distance<T, false>(b.g, b.w, b.h, px[k], py[k], feat, gp, gb);
             f[k] = (uint8_t)feat;
         }
         T *o = dist + (i0 + r) * n + j0;

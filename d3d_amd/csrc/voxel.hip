@@ -2755,6 +2755,148 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact_kept(const float *_
     }
 }
 
+// ------------------------------------------------------------------ D3D_VOXEL_EXACT_MEAN: the reference's fp32 running sum
+// voxelize.cpp:142 adds every in-range point of a voxel to its aggregate in point order, in fp32; :164 divides by the count.
+// Voxels within max_points are reduced that way by the output kernels already.  For the others this post-pass repeats it
+// literally, from the operator's own outputs (so it serves every index path): a table {cell -> voxel id} of the overflow
+// voxels, every point looked up and the hits compacted IN POINT ORDER (look-back over 4096-point tiles), a stable sort of the
+// hits by voxel id (sort.hip), then one wavefront per voxel: 64 rows gathered at a time, added one after the other.
+constexpr int kExactThreads = 1024, kExactItems = 4, kExactTile = kExactThreads * kExactItems;
+
+__global__ __launch_bounds__(256) void k_exact_clear(u64 *tkeys, int64_t cap, int32_t *sortkey, int64_t n, u64 *lbstat, uint32_t nlb,
+                                                     unsigned int *ticket)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int64_t t = t0; t < cap; t += stride) tkeys[t] = kEmpty;
+    for (int64_t t = t0; t < n; t += stride) sortkey[t] = INT_MIN;             // sorts behind every hit (descending sort of -id)
+    for (int64_t t = t0; t < nlb; t += stride) lbstat[t] = 0ull;
+    if (t0 == 0) *ticket = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_exact_table(DenseKey kf, const int64_t *__restrict__ coords, const int32_t *__restrict__ npoints,
+                                                     const int64_t *__restrict__ counts, uint32_t P, u64 *tkeys, uint32_t *tvals, u64 mask)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= counts[D3D_COUNT_VOXELS] || (uint32_t)npoints[v] <= P) return;
+    const u64 key = ((u64)coords[v * 3] * (unsigned)kf.shape[1] + (u64)coords[v * 3 + 1]) * (unsigned)kf.shape[2] + (u64)coords[v * 3 + 2];
+    u64 h = mix64(key) & mask;
+    for (;;) {                                              // (capacity >= 2 x the overflow voxels: a free slot exists)
+        const u64 old = atomicCAS(&tkeys[h], kEmpty, key);
+        if (old == kEmpty || old == key) break;
+        h = (h + 1) & mask;
+    }
+    tvals[h] = (uint32_t)v;
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(kExactThreads) void k_exact_collect(DenseKey kf, const float *__restrict__ points, int64_t n, int c,
+                                                                 const u64 *__restrict__ tkeys, const uint32_t *__restrict__ tvals, u64 mask,
+                                                                 int32_t *__restrict__ sortkey, uint32_t *__restrict__ oidx, u64 *lbstat,
+                                                                 unsigned int *ticket)
+{
+    __shared__ unsigned int sid;
+    __shared__ uint32_t wtot[kExactThreads / kWave];
+    __shared__ u64 sprefix;
+    const unsigned int tile = lookback_ticket(ticket, &sid);
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)tile * kExactTile + (int64_t)w * (kWave * kExactItems) + lane;       // (w, row, lane) = point order
+    uint32_t vid[kExactItems], ex[kExactItems], carry = 0;
+#pragma unroll
+    for (int k = 0; k < kExactItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        vid[k] = kNoVoxel;
+        if (i < n) {
+            float v3[3];
+            if (VEC4) { const float4 q = reinterpret_cast<const float4 *>(points)[i]; v3[0] = q.x; v3[1] = q.y; v3[2] = q.z; }
+            else { const float *src = points + i * c; v3[0] = src[0]; v3[1] = src[1]; v3[2] = src[2]; }
+            u64 key;
+            uint32_t st = 0;
+            if (kf.make(v3, key, st)) {
+                u64 h = mix64(key) & mask;
+                for (;;) {
+                    const u64 cur = tkeys[h];
+                    if (cur == key) { vid[k] = tvals[h]; break; }
+                    if (cur == kEmpty) break;
+                    h = (h + 1) & mask;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kExactItems; k++) {
+        const unsigned long long bal = __ballot(vid[k] != kNoVoxel);
+        ex[k] = carry + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        carry += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) wtot[w] = carry;
+    __syncthreads();
+    uint32_t total = 0, woff = 0;
+#pragma unroll
+    for (int k = 0; k < kExactThreads / kWave; k++) {
+        const uint32_t t = wtot[k];
+        total += t;
+        if (k < w) woff += t;
+    }
+    if (w == 0) {
+        const u64 before = lookback_exclusive(lbstat, tile, (u64)total);
+        if (lane == 0) sprefix = before;
+    }
+    __syncthreads();
+    const u64 pre = sprefix + woff;
+#pragma unroll
+    for (int k = 0; k < kExactItems; k++)
+        if (vid[k] != kNoVoxel) {
+            const u64 e = pre + ex[k];
+            sortkey[e] = -(int32_t)vid[k];                  // descending stable sort of these = ascending voxel id, point order kept
+            oidx[e] = (uint32_t)(base + (int64_t)k * kWave);
+        }
+}
+
+// one wavefront per 64 sorted hits: it owns the voxels whose first hit lies among them
+__global__ __launch_bounds__(256) void k_exact_sum(const float *__restrict__ points, int c, const int32_t *__restrict__ sortkey,
+                                                   const int32_t *__restrict__ order, const uint32_t *__restrict__ oidx, int64_t n,
+                                                   const int32_t *__restrict__ npoints, float *__restrict__ agg)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t p0 = ((int64_t)blockIdx.x * (256 / kWave) + (threadIdx.x >> 6)) * kWave, p = p0 + lane;
+    const int32_t key = p < n ? sortkey[order[p]] : INT_MIN;
+    const int32_t prev = p > 0 && p - 1 < n ? sortkey[order[p - 1]] : INT_MIN;
+    unsigned long long heads = __ballot(key != INT_MIN && (p == 0 || prev != key));
+    while (heads) {
+        const int hl = __builtin_ctzll(heads);
+        heads &= heads - 1;
+        const int64_t h = p0 + hl;
+        const uint32_t v = (uint32_t)(-__shfl(key, hl, kWave));
+        const uint32_t cnt = (uint32_t)npoints[v];
+        for (int d0 = 0; d0 < c; d0 += 4) {                 // four channels at a time, each a running fp32 sum in point order
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (uint32_t k0 = 0; k0 < cnt; k0 += kWave) {
+                const uint32_t k = k0 + lane;
+                float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+                if (k < cnt) {
+                    const float *row = points + (size_t)oidx[order[h + k]] * c + d0;
+                    x0 = row[0];
+                    if (d0 + 1 < c) x1 = row[1];
+                    if (d0 + 2 < c) x2 = row[2];
+                    if (d0 + 3 < c) x3 = row[3];
+                }
+                const int m = (int)(cnt - k0 < (uint32_t)kWave ? cnt - k0 : (uint32_t)kWave);
+                for (int j = 0; j < m; j++) {               // (wave-uniform: every lane keeps the same sums)
+                    s0 += __shfl(x0, j, kWave); s1 += __shfl(x1, j, kWave); s2 += __shfl(x2, j, kWave); s3 += __shfl(x3, j, kWave);
+                }
+            }
+            if (lane == 0) {
+                const float dv = (float)(int32_t)cnt;       // voxelize.cpp:164 (float / int)
+                float *out = agg + (size_t)v * c + d0;
+                out[0] = s0 / dv;
+                if (d0 + 1 < c) out[1] = s1 / dv;
+                if (d0 + 2 < c) out[2] = s2 / dv;
+                if (d0 + 3 < c) out[3] = s3 / dv;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ workspace layout
 struct VoxelWs {
     u64 *tabA;            // packed words, or plain keys
@@ -2941,6 +3083,7 @@ struct DenseOut {
     float4 *emit_voxels = nullptr;      // dense contract on C == 4 rows: k_emit writes voxels[V,P,4] too (no staging, no fill)
     float *emit_generic = nullptr;      // dense contract, C = 3, 5 .. 8: k_emit_c writes voxels[V,P,C] and the per-voxel outputs
     bool emit_reduce = false;           // reduce contract without rows: k_emit without the stretch (nothing staged by the index)
+    int stage = 0;                      // d3d_voxelize_3d_dense_staged: 1 = index launches only, 2 = the output launch only
 };
 
 // n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
@@ -3013,7 +3156,8 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         table = tilecnt;
         tileinfo = tilecnt + (size_t)nbins * stiles;
     }
-    if (table) {
+    const bool do_index = o.stage != 2;                        // (stage 2: this frame's index was launched by an earlier call)
+    if (do_index && table) {
         const size_t lds = ((size_t)1 << tshift) * (sizeof(typename Key::bin_key_t) + 2) + bin_lds;
         uint32_t *ppos = o.map_later ? pbin : nullptr;      // (pfirst: by point, the first point of its voxel when it is kept)
 #define D3D_TILE_SORT(V4, IT)                                                                                                   \
@@ -3028,7 +3172,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         if (vec4) { if (tshift == 13) D3D_TILE_SORT(true, 8); else D3D_TILE_SORT(true, 4); }
         else { if (tshift == 13) D3D_TILE_SORT(false, 8); else D3D_TILE_SORT(false, 4); }
 #undef D3D_TILE_SORT
-    } else {
+    } else if (do_index) {
     if (bin_lds + 256 > 65536) {
         D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_scatter<ROWS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
@@ -3043,7 +3187,8 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     D3D_LAUNCH("k_bin_scatter", k_bin_scatter<ROWS>, dim3(ntiles), dim3(kBinThreads), bin_lds, st, pkey, n, nbins, pbin, tilecnt, totals,
                bucket_base, bent, counts, o.map_later, passes);
     }
-    if (!ROWS && o.lists)
+    if (!do_index) { }
+    else if (!ROWS && o.lists)
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    reinterpret_cast<const typename BinEntry<false>::type *>(bent), p4, bucket_base, hshift, o.P, (int)D3D_REDUCE_NONE,
                    w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
@@ -3066,7 +3211,8 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         }
     }
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 1024 (n <= 16 M)
-    D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, w.big_count);
+    if (do_index) D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, w.big_count);
+    if (o.stage == 1) return D3D_OK;
     const dim3 grid((unsigned)(w.npad / 256));
     if constexpr (!ROWS && std::is_same<Key, DenseKey>::value) {
         if (o.emit_generic) {
@@ -3145,10 +3291,70 @@ extern "C" size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxel
     return carve(nullptr, 0, n_points, n_voxels).bytes + 256;
 }
 
+extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int32_t *order, void *ws, size_t ws_bytes,
+                                             hipStream_t st);
+extern "C" size_t d3d_internal_argsort_i32_bytes(int64_t n);
+
+// D3D_VOXEL_EXACT_MEAN (kernels above): everything it needs is in the operator's outputs; scratch = the index's, which is done
+static int exact_mean_pass(const DenseKey &kf, const float *points, int64_t n, int32_t c, uint32_t P, const int64_t *coords,
+                           const int32_t *npoints, float *aggregates, const int64_t *counts, const VoxelWs &w, hipStream_t st)
+{
+    u64 cap2 = 1024;                                        // >= 2 x the voxels that can hold more than P points
+    while (cap2 < 2ull * ((u64)n / (P + 1) + 1)) cap2 <<= 1;
+    if (cap2 > w.cap) return D3D_ERR_WORKSPACE;             // (w.cap >= 2 n)
+    u64 *tkeys = w.aux;
+    uint32_t *tvals = w.vidarr;
+    int32_t *sortkey = reinterpret_cast<int32_t *>(w.unsorted), *order = reinterpret_cast<int32_t *>(w.list);
+    uint32_t *oidx = w.parr;
+    unsigned int *ticket = w.big_count + 42;
+    const uint32_t tiles = (uint32_t)d3d_divup(n, kExactTile);
+    D3D_LAUNCH("k_exact_clear", k_exact_clear, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, tkeys, (int64_t)cap2, sortkey, n, w.bsum,
+               tiles, ticket);
+    D3D_LAUNCH("k_exact_table", k_exact_table, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, kf, coords, npoints, counts, P, tkeys,
+               tvals, cap2 - 1);
+    const bool v4 = c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0;
+    if (v4)
+        D3D_LAUNCH("k_exact_collect", k_exact_collect<true>, dim3(tiles), dim3(kExactThreads), 0, st, kf, points, n, (int)c, (const u64 *)tkeys,
+                   (const uint32_t *)tvals, cap2 - 1, sortkey, oidx, w.bsum, ticket);
+    else
+        D3D_LAUNCH("k_exact_collect", k_exact_collect<false>, dim3(tiles), dim3(kExactThreads), 0, st, kf, points, n, (int)c, (const u64 *)tkeys,
+                   (const uint32_t *)tvals, cap2 - 1, sortkey, oidx, w.bsum, ticket);
+    // stable sort of the hits by voxel (the table is done with: its region is the sort's scratch)
+    const size_t sort_bytes = d3d_internal_argsort_i32_bytes(n);
+    if (sort_bytes > w.tab_bytes) return D3D_ERR_WORKSPACE;
+    if (int rc = d3d_internal_argsort_desc_i32(sortkey, n, order, w.tabA, w.tab_bytes, st)) return rc;
+    D3D_LAUNCH("k_exact_sum", k_exact_sum, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, points, (int)c, (const int32_t *)sortkey,
+               (const int32_t *)order, (const uint32_t *)oidx, n, npoints, aggregates);
+    return D3D_OK;
+}
+
+static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
+                               int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels, int64_t *coords,
+                               uint8_t *pmask, int32_t *npoints, float *aggregates, int64_t *counts, void *workspace,
+                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags, int stage);
+
 static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels, int64_t *coords,
                                uint8_t *pmask, int32_t *npoints, float *aggregates, int64_t *counts, void *workspace,
-                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags)
+                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags, int stage = 0)
+{
+    int rc = voxelize_dense_core(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
+                                 aggregates, counts, workspace, workspace_bytes, stream, host_counts, flags, stage);
+    if (rc == D3D_OK && (flags & D3D_VOXEL_EXACT_MEAN) && reduction == D3D_REDUCE_MEAN && max_points > 0 && max_voxels > 0 && n > 0 &&
+        stage != 1) {
+        DenseKey kf;
+        rc = make_dense_key(shape, bound, kf);
+        if (rc) return rc;
+        const VoxelWs w = carve(workspace, workspace_bytes, n, 0);
+        rc = exact_mean_pass(kf, points, n, c, (uint32_t)max_points, coords, npoints, aggregates, counts, w, (hipStream_t)stream);
+    }
+    return rc;
+}
+
+static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
+                               int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels, int64_t *coords,
+                               uint8_t *pmask, int32_t *npoints, float *aggregates, int64_t *counts, void *workspace,
+                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags, int stage)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 3 || !shape || !bound || !counts || max_points < 0 || max_voxels < 0) return D3D_ERR_BAD_ARG;
@@ -3184,6 +3390,9 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
             d.emit_voxels = reinterpret_cast<float4 *>(voxels);
             emitted = true;
         }
+        // staged calls (d3d_voxelize_3d_dense_staged): only the path whose output is ONE launch
+        if (stage != 0 && !(emitted && fuse_pmask)) return D3D_ERR_UNSUPPORTED;
+        d.stage = stage;
         if (vec4) rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
         else {
             // any C: the {cell, index} entries travel alone, the bucket kernel leaves per-voxel index lists in point order
@@ -3199,6 +3408,7 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
         }
         if (rc) return rc;
     } else {
+        if (stage != 0) return D3D_ERR_UNSUPPORTED;
         IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr, vec4};
         rc = dense_index(kf, points, n, c, w, counts, o, flags, st);
         if (rc) return rc;
@@ -3273,6 +3483,24 @@ extern "C" int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int3
     if (!host_counts) return D3D_ERR_BAD_ARG;
     return voxelize_dense_impl(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
                                aggregates, counts, workspace, workspace_bytes, stream, host_counts, flags);
+}
+
+// d3d_voxelize_3d_dense_notify in two calls, for callers that pipeline a stream of frames (round 4): stage 1 enqueues the
+// index launches (partition, bucket index, first-point counts: latency-bound, little traffic), stage 2 the output launch
+// (k_emit: bandwidth-bound) -- on a DIFFERENT stream if the caller likes, behind an event recorded after stage 1, so that frame
+// k + 1's index runs under frame k's output.  Same arguments in both calls (the workspace carries the index from one to the
+// other: one workspace per frame in flight).  Available where the output is one launch (C == 4 rows, 16-byte aligned buffers,
+// max_points a multiple of 16 up to 256, a frame the binned index takes); D3D_ERR_UNSUPPORTED otherwise -- run stage 0.
+extern "C" int d3d_voxelize_3d_dense_staged(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
+                                            int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels,
+                                            int64_t *coords, uint8_t *pmask, int32_t *npoints, float *aggregates,
+                                            int64_t *counts, void *workspace, size_t workspace_bytes, void *stream,
+                                            int64_t *host_counts, uint32_t flags, int32_t stage)
+{
+    if (stage < 0 || stage > 2) return D3D_ERR_BAD_ARG;
+    if (n <= 0 && stage != 0) return D3D_ERR_UNSUPPORTED;
+    return voxelize_dense_impl(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
+                               aggregates, counts, workspace, workspace_bytes, stream, host_counts, flags, stage);
 }
 
 // The "voxel feature grid" without the dense [V,P,C] copy: first-seen voxel ids, counts, per-voxel

@@ -80,9 +80,15 @@ const char *d3d_status_string(int status);
  *                          matrix, one scattered store per point: three launches -- instead of the one-launch tile sort
  *                          (round 4: every tile of 8192 points is sorted by bucket in LDS and written as one coalesced
  *                          run; the bucket workgroups gather their runs).  Identical outputs; frames above 4 M points
- *                          always take the three-pass partition. */
+ *                          always take the three-pass partition.
+ *   D3D_VOXEL_EXACT_MEAN   (dense contract, reduction MEAN) the aggregates of voxels with MORE than max_points points are summed
+ *                          sequentially in fp32 in point order, bit for bit like voxelize.cpp:142,164 -- a post-pass (table of
+ *                          those voxels, their points compacted in point order, a stable sort by voxel, one wavefront per
+ *                          voxel adding in order; ~2x the call).  Default: those voxels are summed in fp64 in arrival order,
+ *                          which differs from the reference by ITS rounding error (count * 2^-24 relative) only; voxels within
+ *                          max_points, MAX and MIN are bit-exact either way. */
 enum { D3D_VOXEL_PATH_HASH = 1, D3D_VOXEL_PARTITION_3PASS = 2, D3D_VOXEL_PLAIN_SLOTS = 4, D3D_VOXEL_SPLIT_FILL = 8,
-       D3D_VOXEL_FLAGS_ALL = 15 };
+       D3D_VOXEL_EXACT_MEAN = 16, D3D_VOXEL_FLAGS_ALL = 31 };
 
 /* scratch for any of the three voxel entry points on n points / nvox voxels */
 size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels);
@@ -113,6 +119,20 @@ int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int32_t c,
                           float *voxels, int64_t *coords, uint8_t *pmask, int32_t *npoints,
                           float *aggregates, int64_t *counts,
                           void *workspace, size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags);
+
+/* d3d_voxelize_3d_dense_notify split for a caller that pipelines a stream of frames (the reference is a per-frame loop,
+ * voxelize.cpp:94; its callers feed it frame after frame): stage 1 = the index launches, stage 2 = the output launch, stage 0 =
+ * both.  The two stages may go to two streams (event between them), so that frame k + 1's index -- latency-bound, a few tens of
+ * MB -- runs under frame k's output -- bandwidth-bound.  Same arguments in both calls; the workspace carries the index (one
+ * workspace per frame in flight).  host_counts may be NULL.  D3D_ERR_UNSUPPORTED for stage != 0 where the output is not one
+ * launch (C != 4, unaligned buffers, max_points not a multiple of 16 or above 256, a frame the binned index does not take). */
+int d3d_voxelize_3d_dense_staged(const float *points, int64_t n, int32_t c,
+                          const int32_t *shape, const float *bound,
+                          int32_t max_points, int32_t max_voxels, int32_t reduction,
+                          float *voxels, int64_t *coords, uint8_t *pmask, int32_t *npoints,
+                          float *aggregates, int64_t *counts,
+                          void *workspace, size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags,
+                          int32_t stage);
 
 /* replaces voxelize_sparse, bound in Python as voxelize_3d_sparse
  * (reference voxelize.h:14-17, voxelize.cpp:288-335, impl.cpp:5).

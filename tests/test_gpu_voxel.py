@@ -629,3 +629,58 @@ def test_fused_sparse_filter_entry_error_codes():
     assert call(1, _lib.ptr(counts[0]), ws.numel()) == 0
     host = counts.cpu()
     assert host[0, _lib.COUNT_STATUS] == 0 and 0 < host[1, _lib.COUNT_VOXELS] <= 100 and host[1, _lib.COUNT_POINTS] > 0
+
+
+def test_pipelined_stream_of_frames_bit_exact():
+    """VoxelGenerator.stream (round 4): six different frames of different sizes through the pipelined mode -- frame k + 1's
+    index on a side stream under frame k's output, two frames in flight -- with poisoned outputs: every output of every frame
+    equals the oracle's; then the same generator on a frame the staged path refuses (five columns) falls back to the plain call"""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    sizes = [60000, 200000, 1000, 350000, 200000, 77777]
+    clouds = [synth.lidar_like(n, 40 + k) for k, n in enumerate(sizes)]
+    kw = dict(dense=True, reduction="mean", max_points=16, max_voxels=300000)
+    gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, **kw)
+    ora = oracle.VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, **kw)
+    frames = [torch.from_numpy(c).cuda() for c in clouds]
+    got = list(gen.stream(iter(frames), poison=True, pipelined=True))
+    plain = list(gen.stream(iter(frames[:2]), poison=True))                  # (default: the plain loop)
+    assert torch.equal(plain[1].voxels, got[1].voxels)
+    assert len(got) == len(clouds)
+    for cloud, ret in zip(clouds, got):
+        check_dense(_np(ret), ora(cloud), 16)
+    # interleaved use: results consumed while later frames are in flight, on a stream of the caller's
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        sums = [float(r.voxels.sum()) for r in gen.stream(frames[:4], poison=True, pipelined=True)]
+    for cloud, sm in zip(clouds[:4], sums):
+        assert abs(sm - float(ora(cloud)["voxels"].astype(np.float64).sum())) <= 1e-3 * max(abs(sm), 1.0)
+    wide = np.concatenate([clouds[0], np.ones((len(clouds[0]), 1), np.float32)], 1)
+    (one,) = list(gen.stream([torch.from_numpy(wide).cuda()], poison=True, pipelined=True))
+    check_dense(_np(one), ora(wide), 16)
+
+
+@pytest.mark.parametrize("n,c,P", [(1000000, 4, 32), (150000, 4, 4), (120000, 5, 8), (3000, 3, 1)])
+def test_exact_mean_flag_is_bit_exact_on_overflow_voxels(n, c, P):
+    """D3D_VOXEL_EXACT_MEAN: MEAN of the voxels with more than max_points points summed sequentially in
+    fp32 in point order, bit for bit like voxelize.cpp:142,164 -- config 2 itself (1 M points, max_points 32: ~3 k overflow
+    voxels of up to 407 points), a setting where most voxels overflow, rows of 5 and 3 columns; on every index path of the
+    module's fixture.  Without the flag those voxels differ from the reference by rounding (checked: the flag matters)."""
+    from d3d_amd import _lib, synth
+    from d3d_amd.voxel import VoxelGenerator
+    base = synth.lidar_like(n, 7)
+    rng = np.random.default_rng(n)
+    cloud = base[:, :c] if c <= 4 else np.concatenate([base, rng.random((n, c - 4), dtype=np.float32)], 1)
+    cloud = np.ascontiguousarray(cloud)
+    kw = dict(dense=True, reduction="mean", max_points=P, max_voxels=n)
+    exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, **kw)(cloud)
+    gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, **kw)
+    got = _np(gen(torch.from_numpy(cloud).cuda(), flags=cur_opts().voxel_flags | _lib.VOXEL_EXACT_MEAN))
+    over = exp["voxel_npoints"] > P
+    assert over.sum() > 10
+    assert np.array_equal(got["coords"], exp["coords"]) and np.array_equal(got["voxels"], exp["voxels"])
+    assert np.array_equal(got["aggregates"], exp["aggregates"]), int((got["aggregates"] != exp["aggregates"]).any(1).sum())
+    plain = _np(gen(torch.from_numpy(cloud).cuda()))["aggregates"]
+    assert np.array_equal(plain[~over], exp["aggregates"][~over])
+    if n >= 100000:
+        assert not np.array_equal(plain[over], exp["aggregates"][over])       # (fp64 sums: within rounding, not bit-equal)

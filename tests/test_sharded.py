@@ -274,3 +274,21 @@ def test_voxelize_reduce_single_gpu(index_path):
     assert m.min() >= 0 and np.array_equal(np.bincount(m, minlength=len(exp["coords"])), exp["voxel_npoints"])
     f = r.voxel_first.cpu().numpy()
     assert np.array_equal(m[f], np.arange(len(f))) and np.all(np.diff(f) > 0)
+
+
+@pytest.mark.gpu
+def test_rccl_world1_child_process():
+    """the sharded voxelizer through TorchComm on backend `nccl` (RCCL) with world_size 1, in a fresh child
+    process started before that child touches the GPU (tests/nccl_world1_child.py): every exchange, every collective
+    signature, results against the oracle"""
+    import subprocess
+    import sys
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_world1_child.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, child, str(port)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CHILD_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
