@@ -80,7 +80,8 @@ extern "C" int d3d_profile_report(char *buf, size_t buf_bytes)
 // SURVEY 8d): the access patterns of the HBM-bound kernels with the work stripped off.  mode 0: nontemporal 16-byte
 // stores over `bytes` (the pattern of k_fill_c4 / the IoU zero fill); mode 1: copy of bytes/2 -> bytes/2
 // (16-byte loads + nontemporal stores); mode 2: read-only sweep (the sum lands in the first word, so the loads stay); mode 3:
-// hipMemsetAsync; mode 4: nontemporal stores, every wavefront through a 32 KiB stretch of its own (the pattern of k_emit).
+// hipMemsetAsync; mode 4: nontemporal stores, every wavefront through a 32 KiB stretch of its own (the pattern of k_emit);
+// mode 5: nontemporal stores in the launch shape of k_iou_pre's fill (short-lived workgroups, 4 KiB chunks dealt round-robin).
 namespace {
 typedef float bvec4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_probe_store(bvec4 *p, size_t n)
@@ -98,6 +99,15 @@ __global__ __launch_bounds__(256) void k_probe_store_chunked(bvec4 *p, size_t n)
     const bvec4 v = {0.f, 0.f, 0.f, 0.f};
     for (size_t s0 = wave * per; s0 < n; s0 += (size_t)gridDim.x * (blockDim.x >> 6) * per)
         for (size_t k = lane; k < per && s0 + k < n; k += 64) __builtin_nontemporal_store(v, &p[s0 + k]);
+}
+__global__ __launch_bounds__(256) void k_probe_store_dealt(bvec4 *p, size_t nvec)
+{
+    const size_t nchunk = (nvec + 255) / 256, G = gridDim.x, L = blockIdx.x;
+    const bvec4 v = {0.f, 0.f, 0.f, 0.f};
+    for (size_t c = L; c < nchunk; c += G) {
+        const size_t i = c * 256 + threadIdx.x;
+        if (i < nvec) __builtin_nontemporal_store(v, &p[i]);
+    }
 }
 __global__ __launch_bounds__(256) void k_probe_copy(const bvec4 *__restrict__ src, bvec4 *__restrict__ dst, size_t n)
 {
@@ -131,6 +141,14 @@ extern "C" int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream)
         D3D_LAUNCH("k_probe_read", k_probe_read, dim3(blocks), dim3(256), 0, st, (const bvec4 *)buf, bytes / 16, (float *)buf);
     } else if (mode == 3) {
         D3D_HIP_CHECK(hipMemsetAsync(buf, 0, bytes, st));          // the runtime's own fill kernel, for reference
+    } else if (mode == 5) {
+        // the launch shape of k_iou_pre's fill (box.hip): one short-lived workgroup per 64 x 1024 tile of an n x n fp64 matrix,
+        // each writing ~64 of the 4 KiB chunks, dealt L, L + G, ... -- the store part of that kernel with everything else removed
+        const size_t nvec = bytes / 16, nchunk = (nvec + 255) / 256;
+        size_t g = (nchunk + 63) / 64;
+        if (g < 1) g = 1;
+        D3D_LAUNCH("k_probe_store_dealt", k_probe_store_dealt, dim3((unsigned)(g < 2147483647u ? g : 2147483647u)), dim3(256), 0, st,
+                   (bvec4 *)buf, nvec);
     } else if (mode == 4) {
         const size_t nvec = bytes / 16, stretches = (nvec + 2047) / 2048;
         const unsigned b = (unsigned)(stretches / 4 < 65536 ? (stretches + 3) / 4 : 65536);

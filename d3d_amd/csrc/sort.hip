@@ -29,8 +29,10 @@ struct RsPlan {             // per pass
 };
 
 template <typename K>
-__global__ __launch_bounds__(kRsHistThreads) void k_rs_hist(const K *__restrict__ keys, uint32_t n, uint32_t *ghist)
+__global__ __launch_bounds__(kRsHistThreads) void k_rs_hist(const K *__restrict__ keys, uint32_t n, uint32_t *ghist,
+                                                            const int64_t *__restrict__ n_dev)
 {
+    if (n_dev && (uint64_t)*n_dev < n) n = (uint32_t)*n_dev;     // (the caller only knows an upper bound on the host)
     typedef typename KeyBits<K>::U U;
     constexpr int PASSES = sizeof(U);
     __shared__ uint32_t h[PASSES][kRsBins];
@@ -56,8 +58,10 @@ __global__ __launch_bounds__(kRsHistThreads) void k_rs_hist(const K *__restrict_
 }
 
 template <int PASSES>
-__global__ __launch_bounds__(kRsBins) void k_rs_plan(uint32_t *ghist /* -> exclusive bases */, uint32_t n, RsPlan *plan)
+__global__ __launch_bounds__(kRsBins) void k_rs_plan(uint32_t *ghist /* -> exclusive bases */, uint32_t n, RsPlan *plan,
+                                                      const int64_t *__restrict__ n_dev, int first_pass)
 {
+    if (n_dev && (uint64_t)*n_dev < n) n = (uint32_t)*n_dev;
     __shared__ unsigned long long smem[kRsBins / kWave];
     __shared__ int skip[PASSES];
     for (int p = 0; p < PASSES; p++) {
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(kRsBins) void k_rs_plan(uint32_t *ghist /* -> exclu
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        for (int p = 0; p < first_pass; p++) skip[p] = 1;          // (never launched: see radix_argsort_desc)
         int last = -1;
         for (int p = 0; p < PASSES; p++)
             if (!skip[p]) last = p;
@@ -97,11 +102,17 @@ __device__ __forceinline__ typename KeyBits<K>::U rs_load(const K *__restrict__ 
 template <typename K>
 __global__ __launch_bounds__(kRsThreads) void k_rs_tile_hist(const K *__restrict__ keys, typename KeyBits<K>::U *kb0,
                                                              typename KeyBits<K>::U *kb1, uint32_t n, int pass,
-                                                             const RsPlan *__restrict__ plan, uint32_t *__restrict__ tilehist)
+                                                             const RsPlan *__restrict__ plan, uint32_t *__restrict__ tilehist,
+                                                             const int64_t *__restrict__ n_dev)
 {
     typedef typename KeyBits<K>::U U;
     const RsPlan pl = plan[pass];
     if (pl.skip) return;
+    if (n_dev && (uint64_t)*n_dev < n) n = (uint32_t)*n_dev;
+    if ((uint64_t)blockIdx.x * kRsTile >= n) {                      // a tile beyond the device-side size: an empty row
+        tilehist[(size_t)blockIdx.x * kRsBins + threadIdx.x] = 0;
+        return;
+    }
     __shared__ uint32_t h[kRsBins];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -124,13 +135,15 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const K *__restrict__
                                                            typename KeyBits<K>::U *kb1, uint32_t *vb0, uint32_t *vb1, uint32_t n,
                                                            int pass, const RsPlan *__restrict__ plan,
                                                            const uint32_t *__restrict__ tilehist, const uint32_t *__restrict__ gbase,
-                                                           V *__restrict__ order)
+                                                           V *__restrict__ order, const int64_t *__restrict__ n_dev, int first_pass)
 {
     typedef typename KeyBits<K>::U U;
+    if (n_dev && (uint64_t)*n_dev < n) n = (uint32_t)*n_dev;
+    if ((uint64_t)blockIdx.x * kRsTile >= n) return;
     const RsPlan pl = plan[pass];
     if (pl.skip) {
         // (every key equal: pass 0 writes the identity)
-        if (pass == 0 && plan[sizeof(U)].skip)
+        if (pass == first_pass && plan[sizeof(U)].skip)
             for (uint32_t i = blockIdx.x * kRsTile + threadIdx.x; i < n && i < (blockIdx.x + 1) * (uint32_t)kRsTile; i += kRsThreads)
                 order[i] = (V)i;
         return;
@@ -221,9 +234,12 @@ size_t radix_bytes(int64_t n)
            d3d_align_up(ntiles * kRsBins * 4) + d3d_align_up((sizeof(U) + 1) * sizeof(RsPlan)) + 256;
 }
 
-// order[n] <- stable descending argsort of keys
+// order[n] <- stable descending argsort of keys.  n_dev (optional): the number of keys on the device, <= n (the host only has
+// the bound).  key_bits (optional): the keys' desc() images agree above that many low bits (the caller knows the range of
+// its keys): the higher passes are not even launched -- (skipped passes cost a launch each otherwise).
 template <typename K, typename V>
-int radix_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st)
+int radix_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_bytes, hipStream_t st, const int64_t *n_dev = nullptr,
+                       int key_bits = 0)
 {
     typedef typename KeyBits<K>::U U;
     constexpr int PASSES = sizeof(U);
@@ -235,14 +251,15 @@ int radix_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_b
     uint32_t *tilehist = w.take<uint32_t>((size_t)ntiles * kRsBins);
     RsPlan *plan = w.take<RsPlan>(PASSES + 1);
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
+    const int npass = key_bits > 0 && key_bits < PASSES * 8 ? (key_bits + 7) / 8 : PASSES;
     D3D_HIP_CHECK(hipMemsetAsync(ghist, 0, (size_t)PASSES * kRsBins * 4, st));
-    D3D_LAUNCH("k_rs_hist", k_rs_hist<K>, dim3(kRsHistBlocks), dim3(kRsHistThreads), 0, st, keys, (uint32_t)n, ghist);
-    D3D_LAUNCH("k_rs_plan", k_rs_plan<PASSES>, dim3(1), dim3(kRsBins), 0, st, ghist, (uint32_t)n, plan);
-    for (int p = 0; p < PASSES; p++) {
+    D3D_LAUNCH("k_rs_hist", k_rs_hist<K>, dim3(kRsHistBlocks), dim3(kRsHistThreads), 0, st, keys, (uint32_t)n, ghist, n_dev);
+    D3D_LAUNCH("k_rs_plan", k_rs_plan<PASSES>, dim3(1), dim3(kRsBins), 0, st, ghist, (uint32_t)n, plan, n_dev, 0);
+    for (int p = 0; p < npass; p++) {
         D3D_LAUNCH("k_rs_tile_hist", k_rs_tile_hist<K>, dim3(ntiles), dim3(kRsThreads), 0, st, keys, kb0, kb1, (uint32_t)n, p,
-                   (const RsPlan *)plan, tilehist);
+                   (const RsPlan *)plan, tilehist, n_dev);
         D3D_LAUNCH("k_rs_scatter", (k_rs_scatter<K, V>), dim3(ntiles), dim3(kRsThreads), 0, st, keys, kb0, kb1, vb0, vb1, (uint32_t)n, p,
-                   (const RsPlan *)plan, (const uint32_t *)tilehist, (const uint32_t *)ghist, order);
+                   (const RsPlan *)plan, (const uint32_t *)tilehist, (const uint32_t *)ghist, order, n_dev, 0);
     }
     return D3D_OK;
 }
@@ -480,6 +497,14 @@ extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int
                                              hipStream_t st)
 {
     return argsort_desc<int32_t, int32_t>(keys, n, order, ws, ws_bytes, st);
+}
+
+// the radix path on a device-side count: non-negative keys below 2^key_bits (voxel counts), n_dev <= n of them
+extern "C" int d3d_internal_argsort_desc_i32_dev(const int32_t *keys, int64_t n, const int64_t *n_dev, int key_bits, int32_t *order,
+                                                 void *ws, size_t ws_bytes, hipStream_t st)
+{
+    if (n <= 0) return D3D_OK;
+    return radix_argsort_desc<int32_t, int32_t>(keys, n, order, ws, ws_bytes, st, n_dev, key_bits);
 }
 
 // (tests: the radix path at a size the bucket path would take)

@@ -1077,6 +1077,7 @@ struct BinnedExtras {
     int64_t *host_counts;     // optional host-mapped copy of counts[] + ready flag (d3d_voxelize_3d_dense_notify)
     uint32_t npoints_clamp = 0xffffffffu;
     uint32_t *voff = nullptr; // [V] segment base (dense contract, C != 4: k_aggregate reads the index lists through it)
+    int32_t *count_out = nullptr;    // fused sparse + filter, DESCENDING: [V] the voxel's point count, unclamped (the sort key)
     bool has_coord_sub = false;      // fused sparse + filter: coords - offset (VoxelGenerator.__call__, voxel/__init__.py:103)
     long long coord_sub[3] = {0, 0, 0};
 };
@@ -1914,6 +1915,7 @@ __device__ __forceinline__ uint32_t meta_first_lane(const Key &kf, int64_t i, ui
         }
         const uint4 vi = rec;                               // {key lo, key hi, segment base, count}
         if (vinfo) vinfo[vid] = vi;
+        if (x.count_out) x.count_out[vid] = (int32_t)vi.w;
         kept = vi.w < x.npoints_clamp ? vi.w : x.npoints_clamp;
         meta_voxel<Key, AGG4>(kf, (int64_t)vid, vi, staged, P, reduction, coords, npoints, x.voff, pmask, agg, nullptr, nullptr,
                               x.keys_out, x.npoints_clamp, x.has_coord_sub ? x.coord_sub : (const long long *)nullptr);
@@ -2695,7 +2697,9 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact_kept(const float *_
                                                                   const uint32_t *__restrict__ pfirst, const uint32_t *__restrict__ vidof,
                                                                   float *__restrict__ out_feats, int64_t *__restrict__ out_mask,
                                                                   int64_t *__restrict__ out_mapping, u64 *lbstat, unsigned int *ticket,
-                                                                  int64_t *counts, const int64_t *__restrict__ first_counts)
+                                                                  int64_t *counts, const int64_t *__restrict__ first_counts,
+                                                                  int64_t *host /* optional: both count rows + flag, by the last tile */,
+                                                                  int voxels_index /* of first_counts: where the voxel count is */)
 {
     __shared__ unsigned int sid;
     __shared__ uint32_t wtot[kCompactThreads / kWave];
@@ -2749,10 +2753,42 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact_kept(const float *_
     }
     if (tile == gridDim.x - 1 && threadIdx.x == 0) {        // the sizes, as the filter operator leaves them (voxels: the index's)
         counts[D3D_COUNT_POINTS] = (int64_t)(sprefix + total);
-        counts[D3D_COUNT_VOXELS] = first_counts[D3D_COUNT_VOXELS];
+        counts[D3D_COUNT_VOXELS] = first_counts[voxels_index];
         counts[D3D_COUNT_STATUS] = 0;
         counts[D3D_COUNT_AUX] = 0;
+        if (host) {
+            for (int k = 0; k < D3D_NUM_COUNTS; k++) {
+                host[k] = first_counts[k];
+                host[D3D_NUM_COUNTS + 1 + k] = counts[k];
+            }
+            __threadfence_system();
+            __hip_atomic_store(&host[D3D_NUM_COUNTS], (int64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
+}
+
+// DESCENDING voxel filter, fused (voxelize.cpp:404-420): the voxels that pass the filter, numbered v in first-seen order by
+// k_meta_first_lb, are ranked r by a stable descending sort of their counts; the first max_voxels ranks are the result.
+// Thread = rank: the voxel's per-voxel outputs move to row r, and the entry of its FIRST POINT in vidof[] -- what every
+// point of the voxel looks up in k_compact_kept -- becomes r (or "no voxel" behind the cut).
+__global__ __launch_bounds__(256) void k_desc_finish(const int32_t *__restrict__ order, int64_t *counts /* [VOXELS]: in V', out the cut */,
+                                                     uint32_t max_voxels, const int64_t *__restrict__ tmp_coords,
+                                                     const int32_t *__restrict__ tmp_npoints, const int64_t *__restrict__ first_of,
+                                                     int64_t *__restrict__ out_coords, int32_t *__restrict__ out_npoints,
+                                                     uint32_t *__restrict__ vidof, int64_t *cut_out)
+{
+    const int64_t nv = counts[D3D_COUNT_VOXELS], r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t cut = nv < (int64_t)max_voxels ? nv : (int64_t)max_voxels;
+    if (r == 0) *cut_out = cut;                             // (counts[VOXELS] itself is rewritten by the launch behind this one)
+    if (r >= nv) return;
+    const int32_t v = order[r];
+    const int64_t f = first_of[v];
+    if (r < cut) {
+        out_coords[r * 3] = tmp_coords[(int64_t)v * 3]; out_coords[r * 3 + 1] = tmp_coords[(int64_t)v * 3 + 1];
+        out_coords[r * 3 + 2] = tmp_coords[(int64_t)v * 3 + 2];
+        out_npoints[r] = tmp_npoints[v];
+        vidof[f] = (uint32_t)r;
+    } else vidof[f] = kNoVoxel;
 }
 
 // ------------------------------------------------------------------ D3D_VOXEL_EXACT_MEAN: the reference's fp32 running sum
@@ -3075,6 +3111,8 @@ struct DenseOut {
     int64_t *early_counts = nullptr;    // ... whose output sizes k_meta_first then publishes: counts of the filter call
     int64_t *early_host = nullptr;      //     + the host-mapped notify buffer (d3d_voxelize_3d_sparse_filter)
     const int64_t *coord_offset = nullptr;   // ... subtracted from the output coords (host, 3 values)
+    int32_t *count_out = nullptr;       // ... DESCENDING voxel filter: unclamped counts per first-seen voxel
+    int64_t *first_out = nullptr;       // ...                          and every voxel's first point
     u64 *compact_stat = nullptr;        // ... look-back words of k_compact_kept (cleared by k_meta_first)
     uint32_t compact_tiles = 0;
     uint32_t npoints_clamp = 0xffffffffu;   // ... and voxel_npoints = min(count, max_points) (voxelize.cpp:403)
@@ -3131,6 +3169,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     BinnedExtras x = o.x;
     x.vidof = want_map ? w.voff : nullptr;
     x.npoints_clamp = o.npoints_clamp;
+    if (o.count_out) { x.count_out = o.count_out; x.first_out = o.first_out; x.index_offset = 0; }
     if (o.coord_offset) {
         x.has_coord_sub = true;
         for (int k = 0; k < 3; k++) x.coord_sub[k] = (long long)o.coord_offset[k];
@@ -3294,6 +3333,8 @@ extern "C" size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxel
 extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int32_t *order, void *ws, size_t ws_bytes,
                                              hipStream_t st);
 extern "C" size_t d3d_internal_argsort_i32_bytes(int64_t n);
+extern "C" int d3d_internal_argsort_desc_i32_dev(const int32_t *keys, int64_t n, const int64_t *n_dev, int key_bits, int32_t *order,
+                                                 void *ws, size_t ws_bytes, hipStream_t st);
 
 // D3D_VOXEL_EXACT_MEAN (kernels above): everything it needs is in the operator's outputs; scratch = the index's, which is done
 static int exact_mean_pass(const DenseKey &kf, const float *points, int64_t n, int32_t c, uint32_t P, const int64_t *coords,
@@ -3751,7 +3792,7 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
 {
     if (!sparse_counts || max_points < 0) return D3D_ERR_BAD_ARG;
     if (flags & ~(uint32_t)D3D_VOXEL_FLAGS_ALL) return D3D_ERR_BAD_ARG;
-    if (max_voxels_filter == D3D_MAXVOX_DESCENDING) return D3D_ERR_UNSUPPORTED;       // needs the voxel count on the host
+    const bool desc = max_voxels_filter == D3D_MAXVOX_DESCENDING;     // fused below; the two-operator form needs the count on the host
     // points outside the 3 x 21-bit key range (NaN / inf, |floor(p/size)| >= 2^20): the reference gives them a far-away
     // voxel (voxelize.cpp:309) that its coordinate-bound filter drops (:376-384).  With the bounds inside the key range the
     // same points are simply dropped here; only bounds reaching beyond it keep the COORD_OVERFLOW error.
@@ -3767,7 +3808,8 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
         // status bits (and the filtered voxel count).
         hipStream_t st = (hipStream_t)stream;
         const bool pf_ok = max_points_filter == D3D_MAXPTS_NONE || (max_points_filter == D3D_MAXPTS_TRIM && max_points > 0);
-        const bool vf_ok = max_voxels_filter == D3D_MAXVOX_NONE || max_voxels_filter == D3D_MAXVOX_TRIM;
+        const bool vf_ok = max_voxels_filter == D3D_MAXVOX_NONE || max_voxels_filter == D3D_MAXVOX_TRIM ||
+                           (desc && points_mapping && coords && npoints);
         if (pf_ok && vf_ok && n > 0 && c >= 3 && n < (1ll << 31) - kFlagTile && points && voxel_size && coords_bound && counts &&
             out_feats && out_mask && out_mapping && out_npoints && out_coords && workspace && max_voxels >= 0) {
             VoxelWs w = carve(workspace, workspace_bytes, n, n);
@@ -3779,9 +3821,13 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                 for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
                 kf.tolerant = tolerant;
                 const bool trim = max_points_filter == D3D_MAXPTS_TRIM;
-                const uint32_t vcap = max_voxels_filter == D3D_MAXVOX_NONE ? 0xffffffffu : (uint32_t)max_voxels;
-                DenseOut d{trim ? (uint32_t)max_points : 0u, vcap, D3D_REDUCE_NONE, false, false, out_coords, out_npoints, nullptr,
-                           nullptr, BinnedExtras{nullptr, 0, nullptr, -1, nullptr, nullptr}, nullptr};
+                // DESCENDING (voxelize.cpp:404-420): first-seen numbering of ALL passing voxels into scratch rows, then a stable
+                // sort of their counts decides the ranks, the first max_voxels of which are the result (k_desc_finish)
+                const uint32_t vcap = (max_voxels_filter == D3D_MAXVOX_NONE || desc) ? 0xffffffffu : (uint32_t)max_voxels;
+                DenseOut d{trim ? (uint32_t)max_points : 0u, vcap, D3D_REDUCE_NONE, false, false, desc ? coords : out_coords,
+                           desc ? npoints : out_npoints, nullptr, nullptr, BinnedExtras{nullptr, 0, nullptr, -1, nullptr, nullptr}, nullptr};
+                int32_t *desc_keys = reinterpret_cast<int32_t *>(w.big_list), *desc_order = reinterpret_cast<int32_t *>(w.parr);
+                if (desc) { d.count_out = desc_keys; d.first_out = points_mapping; }
                 d.pass.on = true;
                 d.pass.min_points = min_points;
                 for (int k = 0; k < 3; k++) { d.pass.lo[k] = coords_bound[2 * k]; d.pass.hi[k] = coords_bound[2 * k + 1]; }
@@ -3790,27 +3836,43 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                 // first point) by point index, trimmed points and filtered voxels already taken out (k_map_binned as a launch of
                 // its own: 21 us of kernel, 173 vs 158 us per call)
                 d.map_later = true;
-                d.early_host = host_counts;             // output sizes to the host right after the numbering
+                d.early_host = desc ? nullptr : host_counts;     // output sizes to the host right after the numbering (DESCENDING:
+                                                                 // they are known after the sort; k_compact_kept's last tile tells)
                 d.coord_offset = coord_offset;
                 d.compact_stat = w.bsum;                // look-back words of k_compact_kept: k_meta_first clears them
                 d.compact_tiles = (uint32_t)d3d_divup(n, kCompactTile);
                 int rc = binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, sparse_counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
                 if (rc) return rc;
-                // (both output sizes went to the host from k_meta_first_lb's last tile, before this launch)
+                if (desc) {
+                    int bits = 1;
+                    while (bits < 31 && (1ll << bits) <= n) bits++;             // counts <= n
+                    const size_t sort_bytes = d3d_internal_argsort_i32_bytes(n);
+                    if (sort_bytes > w.tab_bytes) return D3D_ERR_WORKSPACE;
+                    rc = d3d_internal_argsort_desc_i32_dev(desc_keys, n, sparse_counts + D3D_COUNT_VOXELS, bits, desc_order, w.tabA,
+                                                           w.tab_bytes, st);
+                    if (rc) return rc;
+                    D3D_LAUNCH("k_desc_finish", k_desc_finish, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, (const int32_t *)desc_order,
+                               sparse_counts, (uint32_t)max_voxels, (const int64_t *)coords, (const int32_t *)npoints,
+                               (const int64_t *)points_mapping, out_coords, out_npoints, w.voff, sparse_counts + D3D_COUNT_AUX);
+                }
+                // (both output sizes went to the host from k_meta_first_lb's last tile, before this launch; DESCENDING: from this one's)
+                const int vix = desc ? D3D_COUNT_AUX : D3D_COUNT_VOXELS;
+                int64_t *late_host = desc ? host_counts : nullptr;
                 const bool v4 = c == 4 && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out_feats)) & 15) == 0;
                 unsigned int *cticket = w.big_count + 41;
                 if (v4)
                     D3D_LAUNCH("k_compact_kept", k_compact_kept<true>, dim3(d.compact_tiles), dim3(kCompactThreads), 0, st, points, (int)c, n,
                                w.npad, (const uint32_t *)w.pslot, (const uint32_t *)w.voff, out_feats, out_mask, out_mapping, w.bsum, cticket,
-                               counts, (const int64_t *)sparse_counts);
+                               counts, (const int64_t *)sparse_counts, late_host, vix);
                 else
                     D3D_LAUNCH("k_compact_kept", k_compact_kept<false>, dim3(d.compact_tiles), dim3(kCompactThreads), 0, st, points, (int)c, n,
                                w.npad, (const uint32_t *)w.pslot, (const uint32_t *)w.voff, out_feats, out_mask, out_mapping, w.bsum, cticket,
-                               counts, (const int64_t *)sparse_counts);
+                               counts, (const int64_t *)sparse_counts, late_host, vix);
                 return D3D_OK;
             }
         }
     }
+    if (desc) return D3D_ERR_UNSUPPORTED;      // (the two-operator form sorts on a host-side count: the caller runs the two calls)
     // other filter combinations / sizes: the two operators one after the other, the voxel count staying on the device
     int rc = voxelize_sparse_impl(points, n, c, voxel_size, points_mapping, coords, npoints, sparse_counts, workspace,
                                   workspace_bytes, n, stream, flags, tolerant);

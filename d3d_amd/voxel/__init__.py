@@ -79,6 +79,10 @@ class _PackOverflow(Exception):
     """a voxel outgrew the packed hash slot's count field: the call is repeated with the general layout"""
 
 
+class _NotFused(Exception):
+    """the one-call sparse + filter entry does not take this combination here (DESCENDING off the binned index): two calls"""
+
+
 class _BinOverflow(Exception):
     """dense contract: a bucket of the binned index outgrew its workgroup: the call is repeated on the hash-table path"""
 
@@ -348,6 +352,8 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
                 _lib.ptr(o_feats), _lib.ptr(o_mask), _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd),
                 _lib.ptr(counts[1]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr, fl,
                 ctypes.cast(offset_h, ctypes.c_void_p) if offset_h is not None else None)
+            if rc == _lib.ERR_UNSUPPORTED and vf == MaxVoxelsFilterType.DESCENDING:
+                raise _NotFused()
             _lib.check(rc, "voxelize_3d_sparse + voxelize_3d_filter")
             _spare_put(key, make)         # the next call's buffers, while this one's sizes are on their way
             host = note.wait(counts)      # the one host read of the pair, while the kept points are still being compacted
@@ -437,8 +443,16 @@ class VoxelGenerator:
                                          self._max_voxels, self._reduction, flags=flags, poison=poison))
         else:
             pf, vf = int(self._max_points_filter), int(self._max_voxels_filter)
-            if vf == MaxVoxelsFilterType.DESCENDING or points.shape[0] == 0:
-                # the count sort needs the number of voxels on the host: the two calls of the reference, two read-backs
+            ret = None
+            if points.shape[0] > 0:
+                try:    # (the offset of :103 is subtracted inside the call, where the coords are written)
+                    ret = Dict(_sparse_filter_chained(points, self._size_h, self._vbounds, self._min_points, self._max_points,
+                                                      self._max_voxels, pf, vf, flags=flags, offset_h=self._offset_h))
+                except _NotFused:
+                    pass
+            if ret is None:
+                # (an empty cloud; DESCENDING off the binned index: its sort needs the voxel count on the host) the two calls
+                # of the reference, two read-backs
                 sparse = voxelize_3d_sparse(points, self._size_h, 3, flags=flags)
                 ret = Dict(voxelize_3d_filter(points, sparse["points_mapping"], sparse["coords"],
                                               sparse["voxel_npoints"], self._vbounds, self._min_points,
@@ -448,9 +462,6 @@ class VoxelGenerator:
                 if off is None:
                     off = self._offset_dev[ret.coords.device] = self._offset.to(ret.coords.device)
                 ret.coords = ret.coords - off                                                 # :103
-            else:       # (the offset of :103 is subtracted inside the call, where the coords are written)
-                ret = Dict(_sparse_filter_chained(points, self._size_h, self._vbounds, self._min_points,
-                                                  self._max_points, self._max_voxels, pf, vf, flags=flags, offset_h=self._offset_h))
         if odev != points.device:
             ret = Dict({k: v.to(odev) for k, v in ret.items()})
         return ret

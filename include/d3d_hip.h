@@ -174,7 +174,9 @@ int d3d_voxelize_3d_filter_chained(const float *feats, int64_t n, int32_t c, con
 
 /* VoxelGenerator.__call__'s sparse branch (reference voxel/__init__.py:93-102) in one call: d3d_voxelize_3d_sparse
  * followed by d3d_voxelize_3d_filter on its outputs (same arguments, same outputs as the two calls; the voxel count
- * stays on the device, so max_voxels_filter DESCENDING is D3D_ERR_UNSUPPORTED here).  Besides saving the round trip it
+ * stays on the device.  max_voxels_filter DESCENDING, round 4: fused as well wherever the binned index runs -- a stable sort
+ * of the passing voxels' counts on the device decides the ranks, the output sizes reach host_counts from the LAST launch;
+ * D3D_ERR_UNSUPPORTED for it elsewhere: issue the two calls).  Besides saving the round trip it
  * lets the TRIM point filter reuse the per-voxel index ranking the sparse index already holds (voxelize.cpp:457-463)
  * and the voxel filter run inside the index (up to 16 M points, filters NONE / TRIM): points_mapping, coords and npoints
  * are then scratch (not materialised), sparse_counts holds the status bits.

@@ -314,6 +314,8 @@ def test_randomized_configs_vs_oracle(seed):
 
 @pytest.mark.parametrize("kw", [dict(max_points=4, max_points_filter="trim"),
                                 dict(max_points=3, max_points_filter="trim", min_points=2, max_voxels=700, max_voxels_filter="trim"),
+                                dict(max_points=4, max_points_filter="trim", min_points=2, max_voxels=900, max_voxels_filter="descending"),
+                                dict(max_voxels=100000, max_voxels_filter="descending"),
                                 dict()])
 def test_chained_sparse_filter_equals_the_two_calls(kw):
     """VoxelGenerator's sparse mode chains sparse -> filter with one read-back (d3d_voxelize_3d_filter_chained, the voxel
@@ -601,7 +603,7 @@ def test_millions_of_points_up_to_the_binned_limit(index_path, n):
 
 
 def test_fused_sparse_filter_entry_error_codes():
-    """d3d_voxelize_3d_sparse_filter: the DESCENDING voxel filter needs the voxel count on the host (unsupported in the fused
+    """d3d_voxelize_3d_sparse_filter: the DESCENDING voxel filter off the binned index needs the voxel count on the host (unsupported in the fused
     call, VoxelGenerator then issues the two calls), sparse_counts is mandatory, a short workspace is reported"""
     import ctypes
     from d3d_amd import _lib, synth
@@ -618,12 +620,14 @@ def test_fused_sparse_filter_entry_error_codes():
     counts = i64(2, _lib.NUM_COUNTS)
     ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, n), dev)
 
-    def call(vf, sparse_counts, ws_bytes):
+    def call(vf, sparse_counts, ws_bytes, fl=0):
         return lib.d3d_voxelize_3d_sparse_filter(
             _lib.ptr(pts), n, 4, ctypes.cast(size, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p), 0, 8, 100, 1, vf,
             _lib.ptr(mapping), _lib.ptr(coords), _lib.ptr(npts), sparse_counts, _lib.ptr(o_feats), _lib.ptr(o_mask),
-            _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd), _lib.ptr(counts[1]), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(), None, 0, None)
-    assert call(2, _lib.ptr(counts[0]), ws.numel()) == _lib.ERR_UNSUPPORTED          # DESCENDING
+            _lib.ptr(o_map), _lib.ptr(o_cnt), _lib.ptr(o_crd), _lib.ptr(counts[1]), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(), None, fl, None)
+    assert call(2, _lib.ptr(counts[0]), ws.numel(), _lib.VOXEL_PATH_HASH) == _lib.ERR_UNSUPPORTED   # DESCENDING off the binned index
+    assert call(2, _lib.ptr(counts[0]), ws.numel()) == 0                             # ... fused on it (round 4)
+    torch.cuda.synchronize()
     assert call(1, None, ws.numel()) == _lib.ERR_BAD_ARG
     assert call(1, _lib.ptr(counts[0]), 1024) == _lib.ERR_WORKSPACE
     assert call(1, _lib.ptr(counts[0]), ws.numel()) == 0
