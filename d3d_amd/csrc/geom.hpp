@@ -48,6 +48,23 @@ __device__ __forceinline__ BoxGeom<T> make_geom(T x, T y, T w, T h, T r)
     return g;
 }
 
+// make_geom with the angle's sine and cosine handed in (the caller evaluated d3d_sincos(r) once and keeps them): the same
+// expressions on the same values, bit-identical to make_geom(x, y, w, h, r)
+template <typename T>
+__device__ __forceinline__ BoxGeom<T> make_geom_cs(T x, T y, T w, T h, T c, T s)
+{
+    BoxGeom<T> g;
+    g.cx = x; g.cy = y;
+    g.ux = w * c / 2; g.uy = w * s / 2;
+    g.vx = -(h * s / 2); g.vy = h * c / 2;
+    T x0 = x - g.ux - g.vx, x1 = x + g.ux - g.vx, x2 = x + g.ux + g.vx, x3 = x - g.ux + g.vx;
+    T y0 = y - g.uy - g.vy, y1 = y + g.uy - g.vy, y2 = y + g.uy + g.vy, y3 = y - g.uy + g.vy;
+    g.xmin = fmin(fmin(x0, x1), fmin(x2, x3)); g.xmax = fmax(fmax(x0, x1), fmax(x2, x3));
+    g.ymin = fmin(fmin(y0, y1), fmin(y2, y3)); g.ymax = fmax(fmax(y0, y1), fmax(y2, y3));
+    g.area = 4 * (g.ux * g.vy - g.uy * g.vx);
+    return g;
+}
+
 // The six numbers everything else of a BoxGeom follows from, padded to one 64-byte (fp64) / 32-byte (fp32) sector: what the
 // NMS narrow phase gathers per box (an 88-byte BoxGeom<double> straddles two sectors).  expand() repeats make_geom's own
 // arithmetic on the stored centre / half-extent vectors, so the result is bit-identical to the BoxGeom they came from.

@@ -35,6 +35,10 @@ show("crop_points 2000 boxes x 1M points (bool[M,N])", lambda: crop_points(b3, c
 sem = torch.randint(0, 4, (1000000,), device="cuda", dtype=torch.uint8)
 lab = torch.randint(0, 4, (2000,), device="cuda", dtype=torch.uint8)
 show("paint_label 2000 boxes x 1M points (uint16[N])", lambda: paint_label(b3, cloud, sem, lab), 2e9)
+from d3d_amd.box import pdist2dr_forward, box2d_iou
+show("pdist2dr_forward 2000 boxes x 1M points fp32 (10 GB out)", lambda: pdist2dr_forward(pts, boxes), 2e9, 5)
+bg = bt[:10000].contiguous()
+show("giou (grbox) forward 10k x 10k fp64", lambda: box2d_iou(bg, bg, method="grbox"), 1e8, 3)
 img = torch.rand(2, 64, 200, 176, device="cuda")
 coord = torch.cat([torch.randint(0, 2, (500000, 1), device="cuda").float(), torch.rand(500000, 1, device="cuda") * 199,
                    torch.rand(500000, 1, device="cuda") * 175], 1)
