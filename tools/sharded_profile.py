@@ -48,3 +48,30 @@ for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
     tot += per_rank
     print("  %-36s %8.1f us per rank and step" % (k, per_rank))
 print("  total kernel time per rank and step: %.1f us (collectives not included)" % tot)
+
+# ---- modelled step time on 8 MI355X over xGMI: what one GPU cannot measure, priced with public figures --
+# every rank has 7 links of ~153 GB/s to its 7 peers, a direct all-to-all keeps all of them busy; a collective costs a launch +
+# rendezvous latency on top (RCCL on MI300-class nodes: ~25 us for small messages); every host read-back a stream drain (~20 us)
+LINK_GBS, LINKS, COLL_LAT_US, HOST_SYNC_US = 153.0, 7, 25.0, 20.0
+st0 = stats[0]
+a2a = max(st0.get("all_to_all_bytes_sent", 0), st0.get("all_to_all_bytes_received", 0)) + st0.get("reply_bytes_sent", 0) + \
+    st0.get("rows_all_to_all_bytes_sent", 0)
+ncoll = 2 + 1 + 1 + 1 + 1 + (1 if max_points else 0) + (2 if replicate else 0)     # sizes, counts, records, bitmap, reply [, rows] [, gather x2]
+t_wire = a2a / (LINKS * LINK_GBS * 1e3) + 2 * (W - 1) / W * st0.get("all_reduce_bytes", 0) / (LINK_GBS * 1e3) + \
+    (W - 1) * st0.get("all_gather_bytes_per_rank", 0) / (LINKS * LINK_GBS * 1e3)
+model = tot + t_wire + ncoll * COLL_LAT_US + 3 * HOST_SYNC_US
+print("  modelled step at world %d: %.0f us = kernels %.0f + wire %.0f + %d collectives x %.0f + 3 host syncs x %.0f"
+      % (W, model, tot, t_wire, ncoll, COLL_LAT_US, HOST_SYNC_US))
+try:
+    from d3d_amd.voxel import VoxelGenerator
+    import bench
+    whole = torch.cat(clouds)
+    if max_points:
+        g1 = VoxelGenerator(BOUNDS, SHAPE, dense=True, reduction="mean", max_points=max_points, max_voxels=len(whole))
+    else:
+        from d3d_amd.voxel.sharded import LocalComm
+        g1 = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction="mean", comm=LocalComm(), replicate=False)
+    t1 = bench.timed(lambda: g1(whole), 5, 2) / 5 * 1e6
+    print("  single GPU, whole %d-point frame, same contract: %.0f us  ->  predicted speed-up at world %d: %.2fx" % (len(whole), t1, W, t1 / model))
+except Exception as e:      # pragma: no cover
+    print("  (single-GPU base not measured: %r)" % (e,))
