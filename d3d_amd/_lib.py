@@ -107,6 +107,7 @@ SIGNATURES = {
     "d3d_nms2d_workspace_bytes": (_sz, [_i64]),
     "d3d_nms2d": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp, _u32]),
     "d3d_nms2d_notify": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp, _u32, _vp]),
+    "d3d_nms2d_status": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
 }
 
 _lib = None

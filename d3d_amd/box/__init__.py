@@ -7,6 +7,7 @@ The compiled module's own names (box/impl.cpp:8-54) live in `d3d_amd.box.box_imp
 `nms` are thin aliases (the reference reaches "iou3d" only through Cython: d3d/dgal_wrap.h:45-91,
 d3d/tracking/matcher.pyx:57-80).  All compute runs in HIP kernels behind include/d3d_hip.h.
 """
+import ctypes
 import enum
 
 import numpy as np
@@ -264,11 +265,15 @@ def argsort_desc(scores):
     return order
 
 
+NMS_STATUS_DENSE_PATH, NMS_STATUS_SCAN_GAVE_UP = 1, 2
+
+
 def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param, sort_keys=None,
-          flags=None):
+          flags=None, return_status=False):
     """nms2d / nms2d_cuda (nms.h:6-18; nms.cpp:98-119): returns the SUPPRESSED mask (bool[N]).
     Follows the CPU control flow of the reference (nms.cpp:23-59).  sort_keys: optional fp32 tensor that orders like
-    `scores` (the scores before their promotion to fp64): half the radix passes of the argsort, same order."""
+    `scores` (the scores before their promotion to fp64): half the radix passes of the argsort, same order.
+    return_status: (mask, status) with d3d_nms2d_status's bits -- which route decided the mask (waits for the stream)."""
     lib = _lib.load()
     iou_type, supression_type = int(iou_type), int(supression_type)
     if iou_type not in (IouType.BOX, IouType.RBOX):
@@ -294,9 +299,13 @@ def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_thresho
                                   code, float(iou_threshold), float(score_threshold), float(supression_param), _lib.ptr(sup),
                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr(),
                                   options.current().nms_flags if flags is None else int(flags), _lib.HostWord.get().ptr)
-    _lib.check(rc, "nms2d")
+        _lib.check(rc, "nms2d")
+        status = ctypes.c_uint32(0)
+        if return_status and n > 0:
+            _lib.check(lib.d3d_nms2d_status(_lib.ptr(ws), supression_type, _lib.stream_ptr(), ctypes.byref(status)), "nms2d_status")
     sup = sup.view(torch.bool)
-    return sup.to(odev) if odev != dev else sup
+    sup = sup.to(odev) if odev != dev else sup
+    return (sup, int(status.value)) if return_status else sup
 
 
 nms2d_cuda = nms2d

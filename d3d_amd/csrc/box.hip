@@ -560,7 +560,7 @@ extern "C" size_t d3d_internal_argsort_i32_bytes(int64_t n);
 enum { kUndecided = 0, kKept = 1, kSuppressed = 2 };
 constexpr int kIncTile = 1024;      // boxes per workgroup of k_nms_incscan
 
-struct NmsFlags { unsigned int need_sweep, undecided; };
+struct NmsFlags { unsigned int need_sweep, undecided, scan_gave_up, pad; };     // FIRST thing in the workspace (d3d_nms2d_status)
 constexpr int kNmsListSegs = 1;     // see list_segments(): segmenting the list did not pay
 struct NmsCand { unsigned long long count[kNmsListSegs * 16]; };   // entries appended (may exceed the capacity)
 constexpr int kHdrKill = 8;          // count[kHdrKill + level - 1]: entries of that level's kill list (k_nms_level_roots)
@@ -583,8 +583,8 @@ static unsigned long long nms_cand_capacity(int64_t n)
 // and in whatever order the workgroups are placed.  Value and ready bit travel in one agent-scope 64-bit word.
 // Returns (in every thread) the sum of the totals of tickets 0 .. id - 1; both contain workgroup barriers.
 // The poll is bounded all the same (kChainSpins reads of one word, seconds): a predecessor that never publishes -- only a
-// defect elsewhere could cause that -- raises *gave_up (the callers pass NmsFlags::need_sweep: the dense path then recomputes
-// everything from the geometry) instead of hanging the GPU.
+// defect elsewhere could cause that -- raises flags->need_sweep (the dense path then recomputes everything from the geometry)
+// instead of hanging the GPU.
 __device__ __forceinline__ unsigned int scan_ticket(unsigned int *ticket, unsigned int *sid)
 {
     if (threadIdx.x == 0) *sid = atomicAdd(ticket, 1u);
@@ -592,14 +592,15 @@ __device__ __forceinline__ unsigned int scan_ticket(unsigned int *ticket, unsign
     return *sid;
 }
 // A predecessor holds a lower ticket, i.e. it is running and publishes within microseconds; kChainSpins polls (~0.1 s) without
-// its word turning up means something is wrong (a lost store, a preempted queue): the scan GIVES UP -- *gave_up is raised (the
-// caller's device flag: the dense path then recomputes everything) and the returned prefix is void: *sbase = ~0, callers must
-// not store anything that depends on it.  After the first give-up the wavefront stops polling altogether (the remaining words
+// its word turning up means something is wrong (a lost store, a preempted queue): the scan GIVES UP -- flags->need_sweep is
+// raised (the dense path then recomputes everything), flags->scan_gave_up counts it (d3d_nms2d_status reports both: a caller
+// on a shared or profiled GPU can see that a call took seconds for THIS reason and retry) and the returned prefix is void:
+// *sbase = ~0, callers must not store anything that depends on it.  After the first give-up the wavefront stops polling altogether (the remaining words
 // would each cost another kChainSpins).  withhold (test hook, D3D_NMS_TEST_WITHHOLD): ticket 0 does not publish.
 constexpr unsigned int kChainSpins = 1u << 18;
 constexpr unsigned long long kChainVoid = ~0ull;
 __device__ __forceinline__ unsigned long long chained_prefix(unsigned long long *tot, unsigned int id, unsigned long long total,
-                                                             unsigned long long *sbase, unsigned int *gave_up, bool withhold = false)
+                                                             unsigned long long *sbase, NmsFlags *flags, bool withhold = false)
 {
     const unsigned int lane = threadIdx.x & 63;
     if (threadIdx.x == 0 && !(withhold && id == 0))
@@ -623,7 +624,7 @@ __device__ __forceinline__ unsigned long long chained_prefix(unsigned long long 
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (lane == 0) {
             *sbase = dead ? kChainVoid : acc;
-            if (dead) *gave_up = 1;
+            if (dead) { flags->need_sweep = 1; atomicAdd(&flags->scan_gave_up, 1u); }
         }
     }
     __syncthreads();
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(256) void k_nms_prepare(const T *__restrict__ boxes
     // mean extent (folded by k_nms_gridreg<count>, or by k_nms_extent when there are more than kGridFoldMax workgroups)
     for (int64_t i = p; i <= kGridCells; i += (int64_t)gridDim.x * blockDim.x) cellcnt[i * kGridPad] = 0;
     float ext[6] = {INFINITY, INFINITY, -INFINITY, -INFINITY, 0.f, 0.f};
-    if (p == 0) { flags->need_sweep = force_dense; flags->undecided = 0; *grid_ticket = 0; }
+    if (p == 0) { flags->need_sweep = force_dense; flags->undecided = 0; flags->scan_gave_up = 0; *grid_ticket = 0; }
     // list counter(s), kill-list counters, density sum (kHdr*; D3D_NMS_FORCE_LEVELS: a density no grid reaches)
     if (p < kNmsListSegs * 16) cand_hdr->count[p] = (p == kHdrDensity && force_levels) ? (1ull << 62) : 0ull;
     if (p * kIncTile < n) tile_tot[p] = 0;                   // k_nms_incscan's ready words
@@ -959,7 +960,7 @@ __global__ __launch_bounds__(1024) void k_nms_gridscan(uint32_t *cellcur, uint32
         for (int o = kWave / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, kWave);
         if ((threadIdx.x & (kWave - 1)) == 0 && sq) atomicAdd(density, sq);
     }
-    const unsigned long long before = chained_prefix(chunk_tot, (unsigned int)chunk, total, &sbase, &flags->need_sweep, withhold);
+    const unsigned long long before = chained_prefix(chunk_tot, (unsigned int)chunk, total, &sbase, flags, withhold);
     if (before == kChainVoid) {                             // gave up: the dense path takes over; leave an EMPTY grid behind so that
         if (c <= cells) { cellstart[c] = 0; cellcur[(size_t)c * kGridPad] = 0; }      // the launches in between find nothing to do
         if (c == cells) grid->entries = 0;
@@ -1445,7 +1446,7 @@ __global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict_
     unsigned long long woff = 0, total = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { if (k < w) woff += smem[k]; total += smem[k]; }
-    const unsigned long long before = chained_prefix(tile_tot, tile, total, &sbase, &flags->need_sweep, withhold);
+    const unsigned long long before = chained_prefix(tile_tot, tile, total, &sbase, flags, withhold);
     if (before == kChainVoid) return;                       // gave up: nothing that depends on the prefix is stored
     const unsigned long long off = before + woff;
 #pragma unroll
@@ -1693,7 +1694,7 @@ __global__ __launch_bounds__(1024) void k_nms_small_front(const T *__restrict__ 
         else if (npad <= 2048) sort_lds<2>(d0, i0, d1, i1, (int)npad, &d, &ii);
         else sort_lds<kNmsSmallMax / 1024>(d0, i0, d1, i1, (int)npad, &d, &ii);
     }
-    if (threadIdx.x == 0) { flags->need_sweep = 0; flags->undecided = 0; cand_hdr->count[0] = 0; }
+    if (threadIdx.x == 0) { flags->need_sweep = 0; flags->undecided = 0; flags->scan_gave_up = 0; cand_hdr->count[0] = 0; }
     for (uint32_t p0 = 0; p0 < n; p0 += blockDim.x) {                // (wave-uniform bound: the ballot below)
         const uint32_t p = p0 + threadIdx.x;
         bool pre = false;
@@ -1917,6 +1918,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
 {
     const int64_t nb = d3d_divup(n, 64);
     WsCarver w(ws, ws_bytes);
+    NmsFlags *flags = w.take<NmsFlags>(1);                 // at offset 0: d3d_nms2d_status reads it there
     BoxCore<T> *geom = w.take<BoxCore<T>>(nb * 64);
     float4 *fbox = w.take<float4>(nb * 64);
     uint8_t *state = w.take<uint8_t>(nb * 64);
@@ -1929,7 +1931,6 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     unsigned int *tickets = reinterpret_cast<unsigned int *>(chunk_tot + kGridScanWgs);     // [0] k_nms_incscan, [1] k_nms_gridscan
     (void)w.take<int64_t>(D3D_NUM_COUNTS);
     static_assert(kIncTile == kScanTile, "workspace sized with kScanTile");
-    NmsFlags *flags = w.take<NmsFlags>(1);
     unsigned long long *remv = w.take<unsigned long long>(nb);
     NmsCand *cand_hdr = w.take<NmsCand>(1);
     // the arrays are carved for the automatic capacity (what the workspace query counts); a per-call override
@@ -2587,6 +2588,20 @@ extern "C" int d3d_nms2d_notify(const void *boxes, const void *scores, const int
 {
     return nms2d_impl(boxes, scores, order, n, iou_type, suppression_type, dtype, iou_threshold, score_threshold, suppression_param,
                       suppressed, workspace, workspace_bytes, stream, flags, host_word);
+}
+
+// which route the last hard-NMS call on this workspace took (a chained scan that gives up used to be silent)
+extern "C" int d3d_nms2d_status(const void *workspace, int32_t suppression_type, void *stream, uint32_t *status)
+{
+    if (!status) return D3D_ERR_BAD_ARG;
+    *status = 0;
+    if (suppression_type != D3D_SUPPRESS_HARD) return D3D_OK;         // (soft-NMS has one route)
+    if (!workspace) return D3D_ERR_BAD_ARG;
+    NmsFlags h{};
+    D3D_HIP_CHECK(hipMemcpyAsync(&h, workspace, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    D3D_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    *status = (h.need_sweep ? D3D_NMS_STATUS_DENSE_PATH : 0u) | (h.scan_gave_up ? D3D_NMS_STATUS_SCAN_GAVE_UP : 0u);
+    return D3D_OK;
 }
 
 extern "C" int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, int64_t m, int32_t dtype, uint8_t *out,

@@ -199,17 +199,38 @@ __global__ __launch_bounds__(1024) void k_owner_scatter(const int64_t *__restric
     }
 }
 
-// ---------------------------------------------------------------- merge on the owner
+// ---------------------------------------------------------------- merge on the owner (3 launches)
+// The shards are contiguous point ranges in rank order, so a cell's first point lies in the LOWEST rank that has the cell,
+// and inside one source's batch the records follow the shard's first-seen order: the "leader" records (lowest record index
+// = lowest source of their cell), taken in receive order, are this owner's voxels in ascending order of first point =
+// ascending global voxel id.
+//   k_merge_init    table cleared: 16-byte slots {cell, head of the cell's record chain} at load <= 1/2
+//   k_merge_insert  a record finds / claims its cell's slot (one CAS when the slot is free) and pushes itself on the slot's
+//                   chain (one exchange on the same line).  The chain's ORDER is the arrival order -- nobody reads it as
+//                   an order: every consumer visits a chain by ascending record index (chain_in_order), i.e. in rank
+//                   order, so sums and row order are the same on every run.
+//   k_merge_finish  one launch, tiles of records numbered by ticket: a record is a leader iff it is the lowest index of its
+//                   chain; a decoupled look-back over the tiles' leader counts numbers the leaders; each leader merges its
+//                   cell's records and writes the voxel's finished row at its number (consecutive leaders -> consecutive
+//                   rows); the other records then pick up their leader's number (the leader sits in the same or an earlier
+//                   tile: it is running or done, a short poll).
+// Round 3 kept one record index per (slot, source rank) -- 40 bytes per slot to clear and to gather from -- and needed
+// seven launches (init, insert, a three-launch scan over a leader flag, the map of the records): 191 us per rank at config 5
+// against ... now (profiles/r04_sharded_*).
+struct MergeSlot { u64 key; uint32_t head, pad; };          // head: record index + 1 of the last record pushed, 0 = none
+
 struct MergeWs {
-    u64 *tkey;            // [cap]
-    uint32_t *contrib;    // [cap * ws] record index + 1 per source rank, 0 = none; ws = world rounded up to 4 (16-byte reads)
+    MergeSlot *slot;      // [cap]
+    uint32_t *next;       // [R] record index + 1 of the record pushed before this one on the same chain, 0 = end
     uint32_t *rec_slot;   // [R]
-    uint32_t *slot_owned; // [cap]
-    unsigned char *flag;  // [R]
-    u64 *bsum;            // scan scratch
+    u64 *status;          // look-back words of k_merge_finish, [ntiles] + one word holding the ticket
+    int64_t *src_off;     // [world + 1] copy of the caller's (d3d_owner_dense finds a record's source rank with it)
     u64 cap;
+    uint32_t ntiles;
     size_t bytes;
 };
+
+constexpr int kFinishThreads = 256, kFinishItems = 4, kFinishTile = kFinishThreads * kFinishItems;
 
 static u64 merge_cap(int64_t R)        // load factor <= 1/2; slots are found by multiply-shift, so no power of two is needed
 {
@@ -221,59 +242,48 @@ static MergeWs carve_merge(void *ws, size_t bytes, int64_t R, int world)
     WsCarver w(ws, bytes);
     MergeWs m;
     m.cap = merge_cap(R);
-    m.tkey = w.take<u64>(m.cap);
-    m.contrib = w.take<uint32_t>(m.cap * (size_t)((world + 3) & ~3));
+    m.ntiles = (uint32_t)d3d_divup(R > 0 ? R : 1, kFinishTile);
+    m.slot = w.take<MergeSlot>(m.cap);
+    m.next = w.take<uint32_t>(R > 0 ? R : 1);
     m.rec_slot = w.take<uint32_t>(R > 0 ? R : 1);
-    m.slot_owned = w.take<uint32_t>(m.cap);
-    m.flag = w.take<unsigned char>(R > 0 ? R : 1);
-    m.bsum = w.take<u64>(d3d_divup((int64_t)m.cap, kScanTile) + 1);
+    m.status = w.take<u64>((size_t)m.ntiles + 1);
+    m.src_off = w.take<int64_t>((size_t)world + 1);
     m.bytes = w.off;
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_merge_init(u64 *tkey, uint32_t *contrib, u64 cap, int world)
+__global__ __launch_bounds__(256) void k_merge_init(MergeSlot *slot, u64 cap, u64 *status, uint32_t nstatus, int64_t *counts,
+                                                    const int64_t *__restrict__ src_off, int world, int64_t *src_off_copy)
 {
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) tkey[i] = kFree;
-    uint4 *c4 = reinterpret_cast<uint4 *>(contrib);
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap * (u64)((world + 3) >> 2); i += stride) c4[i] = make_uint4(0, 0, 0, 0);
+    typedef uint32_t uvec4 __attribute__((ext_vector_type(4)));
+    const u64 stride = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const uvec4 empty = {0xffffffffu, 0xffffffffu, 0u, 0u};
+    uvec4 *s4 = reinterpret_cast<uvec4 *>(slot);
+    for (u64 i = t; i < cap; i += stride) s4[i] = empty;
+    for (u64 i = t; i < nstatus; i += stride) status[i] = 0ull;
+    if (t < D3D_NUM_COUNTS) counts[t] = 0;
+    if (t <= (u64)world) src_off_copy[t] = src_off[t];
 }
 
-__global__ __launch_bounds__(256) void k_merge_insert(const int32_t *__restrict__ recv, int64_t R, int RS,
-                                                      const int64_t *__restrict__ src_off, int world, u64 *tkey, u64 cap,
-                                                      uint32_t *contrib, uint32_t *rec_slot)
+__global__ __launch_bounds__(256) void k_merge_insert(const int32_t *__restrict__ recv, int64_t R, int RS, MergeSlot *slot, u64 cap,
+                                                      uint32_t *__restrict__ next, uint32_t *__restrict__ rec_slot,
+                                                      int32_t *__restrict__ rec_owned)
 {
-    __shared__ int64_t so[kMaxWorld + 1];
-    if (threadIdx.x <= (unsigned)world) so[threadIdx.x] = src_off[threadIdx.x];
-    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
-    int lo = 0, hi = world;                       // source rank: the last s with so[s] <= i
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (so[mid] <= i) lo = mid; else hi = mid;
-    }
     const u64 key = (u64)*reinterpret_cast<const int64_t *>(recv + (size_t)i * RS);
     // (a second mix: the owner hash already split on mix64's top bits)
     u64 h = __umul64hi(mix64(key * 0x9e3779b97f4a7c15ull), cap);
     for (;;) {
-        const u64 cur = __hip_atomic_load(&tkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == key) break;
-        if (cur == kFree) {
-            const u64 old = atomicCAS(&tkey[h], kFree, key);
-            if (old == kFree || old == key) break;
-        }
+        const u64 old = atomicCAS(&slot[h].key, kFree, key);      // a free slot is the common case: one round trip
+        if (old == kFree || old == key) break;
         h = h + 1 < cap ? h + 1 : 0;              // cap >= 2 R: a free slot always exists
     }
-    contrib[h * (u64)((world + 3) & ~3) + lo] = (uint32_t)i + 1u;
+    next[i] = atomicExch(&slot[h].head, (uint32_t)i + 1u);
     rec_slot[i] = (uint32_t)h;
+    rec_owned[i] = -1;                            // "my leader has no number yet" (k_merge_finish polls it)
 }
 
-// The shards are contiguous point ranges in rank order, so a cell's first point lies in the LOWEST rank that has the cell,
-// and inside one source's batch the records follow the shard's first-seen order: the "leader" records (lowest source of
-// their cell), taken in receive order, are this owner's voxels in ascending order of first point = ascending global voxel
-// id.  A scan over the RECORDS numbers the leaders; each leader merges its cell's records in rank order and writes the
-// voxel's finished row at its number -- consecutive leaders write consecutive rows (coalesced), and no pass over the table.
 __device__ __forceinline__ int record_source(const int64_t *__restrict__ src_off, int world, int64_t i)
 {
     int lo = 0, hi = world;                       // the last s with src_off[s] <= i
@@ -284,110 +294,154 @@ __device__ __forceinline__ int record_source(const int64_t *__restrict__ src_off
     return lo;
 }
 
-struct MergeRecords {
-    static constexpr const char *kName = "k_scan_count<MergeRecords>", *kName2 = "k_scan_apply<MergeRecords>";
-    const uint32_t *contrib, *rec_slot;
-    unsigned char *flag;                 // per record, left by the count pass: 0 = not a leader, 1 = leader of a cell with
-                                         // further records, 3 = leader and the cell's only record
-    const int64_t *src_off;
-    const int32_t *recv;
-    int RS, c, world, reduction;         // reduction: MEAN (divide), 4 = sums, MAX, MIN
+// the records of a chain by ascending record index (= source rank order); chains hold at most `world` records, nearly all one
+// or two, so selection by repeated walks beats gathering them into a (dynamically indexed, i.e. scratch) list
+template <class F>
+__device__ __forceinline__ void chain_in_order(const uint32_t *__restrict__ next, uint32_t head, F &&visit)
+{
+    uint32_t prev = 0;
+    for (;;) {
+        uint32_t best = ~0u;
+        for (uint32_t e = head; e; e = next[e - 1])
+            if (e > prev && e < best) best = e;
+        if (best == ~0u) return;
+        visit(best - 1u);
+        prev = best;
+    }
+}
+
+struct MergeOut {
+    int RS, c, reduction;                // reduction: MEAN (divide), 4 = sums, MAX, MIN
     int64_t sy, sz;
-    uint32_t *slot_owned;
     int64_t *first_o, *coords;
     int32_t *npoints;
     float *feats;
     int32_t *lead_rec;                   // [owned voxel] its leader record
-    __device__ u64 value(int64_t i) const
-    {
-        const int s = record_source(src_off, world, i);
-        const int ws = (world + 3) & ~3;
-        const uint4 *cb = reinterpret_cast<const uint4 *>(contrib + (u64)rec_slot[i] * ws);
-        unsigned char f = 3;
-        for (int q4 = 0; q4 < ws; q4 += 4) {        // one 16-byte read per four source ranks
-            const uint4 x = cb[q4 >> 2];
-            const uint32_t e[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (e[k] && q4 + k != s) f = q4 + k < s ? 0 : (f & 1);
-        }
-        flag[i] = f;
-        return f ? 1ull : 0ull;
-    }
-    __device__ u64 value2(int64_t i) const { return flag[i] ? 1ull : 0ull; }
-    __device__ void apply(int64_t i, u64 v, u64 excl) const
-    {
-        if (!v) return;
-        const int64_t o = (int64_t)excl;
-        const uint32_t slot = rec_slot[i];
-        slot_owned[slot] = (uint32_t)o;
-        lead_rec[o] = (int32_t)i;
-        if (flag[i] == 3 && c == 4) {             // the cell's only record (4 of 5 at config 5): everything is in record i
-            const int32_t *r = recv + (size_t)i * RS;
-            const int64_t key = *reinterpret_cast<const int64_t *>(r);
-            const int32_t cnt = r[4];
-            const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
-            const float ident = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
-            float a[4];
-            for (int f = 0; f < 4; f++) {         // identity (op) x, exactly as the general loop below
-                const float x = __int_as_float(r[5 + f]);
-                a[f] = is_sum ? ident + x : (reduction == D3D_REDUCE_MAX ? (ident < x ? x : ident) : (x < ident ? x : ident));
-            }
-            first_o[o] = *reinterpret_cast<const int64_t *>(r + 2);
-            npoints[o] = cnt;
-            coords[o * 3 + 0] = key / (sy * sz);
-            coords[o * 3 + 1] = (key / sz) % sy;
-            coords[o * 3 + 2] = key % sz;
-            const float d = reduction == D3D_REDUCE_MEAN ? (float)cnt : 1.0f;
-            *reinterpret_cast<float4 *>(feats + o * 4) = make_float4(a[0] / d, a[1] / d, a[2] / d, a[3] / d);
-            return;
-        }
-        const uint32_t *cb = contrib + (u64)slot * ((world + 3) & ~3);
-        const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
-        const float ident = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
-        float a0 = ident, a1 = ident, a2 = ident, a3 = ident;      // c == 4 in registers; other widths through feats[]
-        if (c != 4)
-            for (int f = 0; f < c; f++) feats[o * c + f] = ident;
-        int64_t first = INT64_MAX;
-        int32_t cnt = 0;
-        int64_t key = 0;
-        for (int q = record_source(src_off, world, i); q < world; q++) {      // rank order: the same sums on every run
-            const uint32_t ri = cb[q];
-            if (!ri) continue;
-            const int32_t *r = recv + (size_t)(ri - 1) * RS;
-            key = *reinterpret_cast<const int64_t *>(r);
-            const int64_t f0 = *reinterpret_cast<const int64_t *>(r + 2);
-            first = f0 < first ? f0 : first;
-            cnt += r[4];
-            if (c == 4) {
-                const float x0 = __int_as_float(r[5]), x1 = __int_as_float(r[6]), x2 = __int_as_float(r[7]), x3 = __int_as_float(r[8]);
-                if (is_sum) { a0 += x0; a1 += x1; a2 += x2; a3 += x3; }
-                else if (reduction == D3D_REDUCE_MAX) { a0 = a0 < x0 ? x0 : a0; a1 = a1 < x1 ? x1 : a1; a2 = a2 < x2 ? x2 : a2; a3 = a3 < x3 ? x3 : a3; }
-                else { a0 = x0 < a0 ? x0 : a0; a1 = x1 < a1 ? x1 : a1; a2 = x2 < a2 ? x2 : a2; a3 = x3 < a3 ? x3 : a3; }
-            } else {
-                for (int f = 0; f < c; f++) {
-                    const float x = __int_as_float(r[5 + f]), y = feats[o * c + f];
-                    feats[o * c + f] = is_sum ? y + x : (reduction == D3D_REDUCE_MAX ? (y < x ? x : y) : (x < y ? x : y));
-                }
-            }
-        }
-        first_o[o] = first;
-        npoints[o] = cnt;
-        coords[o * 3 + 0] = key / (sy * sz);
-        coords[o * 3 + 1] = (key / sz) % sy;
-        coords[o * 3 + 2] = key % sz;
-        const float d = reduction == D3D_REDUCE_MEAN ? (float)cnt : 1.0f;
-        if (c == 4) *reinterpret_cast<float4 *>(feats + o * 4) = make_float4(a0 / d, a1 / d, a2 / d, a3 / d);
-        else if (reduction == D3D_REDUCE_MEAN)
-            for (int f = 0; f < c; f++) feats[o * c + f] = feats[o * c + f] / d;
-    }
 };
 
-__global__ __launch_bounds__(256) void k_merge_recmap(int64_t R, const uint32_t *__restrict__ rec_slot,
-                                                      const uint32_t *__restrict__ slot_owned, int32_t *rec_owned)
+// leader record i -> owned voxel o: the cell's records merged in rank order, the voxel's finished row written
+__device__ __forceinline__ void merge_leader(const MergeOut &f, const int32_t *__restrict__ recv, const uint32_t *__restrict__ next,
+                                             uint32_t head, int64_t i, int64_t o, bool sole)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < R) rec_owned[i] = (int32_t)slot_owned[rec_slot[i]];
+    const int c = f.c, RS = f.RS, reduction = f.reduction;
+    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
+    const float ident = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+    f.lead_rec[o] = (int32_t)i;
+    if (sole && c == 4) {                         // the cell's only record (most cells): everything is in record i
+        const int32_t *r = recv + (size_t)i * RS;
+        const int64_t key = *reinterpret_cast<const int64_t *>(r);
+        const int32_t cnt = r[4];
+        float a[4];
+        for (int q = 0; q < 4; q++) {             // identity (op) x, exactly as the general loop below
+            const float x = __int_as_float(r[5 + q]);
+            a[q] = is_sum ? ident + x : (reduction == D3D_REDUCE_MAX ? (ident < x ? x : ident) : (x < ident ? x : ident));
+        }
+        f.first_o[o] = *reinterpret_cast<const int64_t *>(r + 2);
+        f.npoints[o] = cnt;
+        f.coords[o * 3 + 0] = key / (f.sy * f.sz);
+        f.coords[o * 3 + 1] = (key / f.sz) % f.sy;
+        f.coords[o * 3 + 2] = key % f.sz;
+        const float d = reduction == D3D_REDUCE_MEAN ? (float)cnt : 1.0f;
+        *reinterpret_cast<float4 *>(f.feats + o * 4) = make_float4(a[0] / d, a[1] / d, a[2] / d, a[3] / d);
+        return;
+    }
+    float a0 = ident, a1 = ident, a2 = ident, a3 = ident;      // c == 4 in registers; other widths through feats[]
+    if (c != 4)
+        for (int q = 0; q < c; q++) f.feats[o * c + q] = ident;
+    int64_t first = INT64_MAX;
+    int32_t cnt = 0;
+    int64_t key = 0;
+    chain_in_order(next, head, [&](uint32_t ri) {              // rank order: the same sums on every run
+        const int32_t *r = recv + (size_t)ri * RS;
+        key = *reinterpret_cast<const int64_t *>(r);
+        const int64_t f0 = *reinterpret_cast<const int64_t *>(r + 2);
+        first = f0 < first ? f0 : first;
+        cnt += r[4];
+        if (c == 4) {
+            const float x0 = __int_as_float(r[5]), x1 = __int_as_float(r[6]), x2 = __int_as_float(r[7]), x3 = __int_as_float(r[8]);
+            if (is_sum) { a0 += x0; a1 += x1; a2 += x2; a3 += x3; }
+            else if (reduction == D3D_REDUCE_MAX) { a0 = a0 < x0 ? x0 : a0; a1 = a1 < x1 ? x1 : a1; a2 = a2 < x2 ? x2 : a2; a3 = a3 < x3 ? x3 : a3; }
+            else { a0 = x0 < a0 ? x0 : a0; a1 = x1 < a1 ? x1 : a1; a2 = x2 < a2 ? x2 : a2; a3 = x3 < a3 ? x3 : a3; }
+        } else {
+            for (int q = 0; q < c; q++) {
+                const float x = __int_as_float(r[5 + q]), y = f.feats[o * c + q];
+                f.feats[o * c + q] = is_sum ? y + x : (reduction == D3D_REDUCE_MAX ? (y < x ? x : y) : (x < y ? x : y));
+            }
+        }
+    });
+    f.first_o[o] = first;
+    f.npoints[o] = cnt;
+    f.coords[o * 3 + 0] = key / (f.sy * f.sz);
+    f.coords[o * 3 + 1] = (key / f.sz) % f.sy;
+    f.coords[o * 3 + 2] = key % f.sz;
+    const float d = reduction == D3D_REDUCE_MEAN ? (float)cnt : 1.0f;
+    if (c == 4) *reinterpret_cast<float4 *>(f.feats + o * 4) = make_float4(a0 / d, a1 / d, a2 / d, a3 / d);
+    else if (reduction == D3D_REDUCE_MEAN)
+        for (int q = 0; q < c; q++) f.feats[o * c + q] = f.feats[o * c + q] / d;
+}
+
+__global__ __launch_bounds__(kFinishThreads) void k_merge_finish(const int32_t *__restrict__ recv, int64_t R,
+                                                                 const MergeSlot *__restrict__ slot,
+                                                                 const uint32_t *__restrict__ next,
+                                                                 const uint32_t *__restrict__ rec_slot, u64 *status,
+                                                                 uint32_t ntiles, MergeOut f, int32_t *rec_owned, int64_t *counts)
+{
+    __shared__ unsigned int sid;
+    __shared__ u64 smem[kFinishThreads / kWave];
+    __shared__ u64 sexcl;
+    const unsigned int tile = lookback_ticket(reinterpret_cast<unsigned int *>(status + ntiles), &sid);
+    // consecutive records per lane: the leaders' numbers then ascend with the record index across the tile
+    const int64_t i0 = (int64_t)tile * kFinishTile + (int64_t)threadIdx.x * kFinishItems;
+    uint32_t head[kFinishItems], lead[kFinishItems];          // lead: index + 1 of the chain's lowest record
+    bool sole[kFinishItems];
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kFinishItems; k++) {
+        const int64_t i = i0 + k;
+        head[k] = 0; lead[k] = 0; sole[k] = false;
+        if (i < R) {
+            head[k] = slot[rec_slot[i]].head;
+            const uint32_t nx = next[i];
+            sole[k] = head[k] == (uint32_t)i + 1u && nx == 0u;
+            uint32_t m = (uint32_t)i + 1u;
+            if (!sole[k])
+                for (uint32_t e = head[k]; e; e = next[e - 1]) m = e < m ? e : m;
+            lead[k] = m;
+            if (m == (uint32_t)i + 1u) mine++;
+        }
+    }
+    u64 total;
+    u64 ex = block_excl_scan_u64<kFinishThreads>(mine, &total, smem);
+    if (threadIdx.x < kWave) {
+        const u64 e = lookback_exclusive(status, tile, total);
+        if (threadIdx.x == 0) {
+            sexcl = e;
+            if (tile == ntiles - 1) counts[D3D_COUNT_VOXELS] = (int64_t)(e + total);
+        }
+    }
+    __syncthreads();
+    ex += sexcl;
+#pragma unroll
+    for (int k = 0; k < kFinishItems; k++) {
+        const int64_t i = i0 + k;
+        if (i < R && lead[k] == (uint32_t)i + 1u) {
+            merge_leader(f, recv, next, head[k], i, (int64_t)ex, sole[k]);
+            __hip_atomic_store(&rec_owned[i], (int32_t)ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ex++;
+        }
+    }
+    // the other records: their leader has a lower index -- this lane (done above), this workgroup (no barrier between its
+    // store and here), or a tile with a lower ticket (running: it needs nothing from this one)
+#pragma unroll
+    for (int k = 0; k < kFinishItems; k++) {
+        const int64_t i = i0 + k;
+        if (i < R && lead[k] != (uint32_t)i + 1u) {
+            int32_t o;
+            while ((o = __hip_atomic_load(&rec_owned[lead[k] - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0)
+                __builtin_amdgcn_s_sleep(1);
+            rec_owned[i] = o;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- numbering
@@ -414,15 +468,52 @@ __global__ __launch_bounds__(256) void k_first_mark(const int64_t *__restrict__ 
     if (ok && head) atomicOr(&bitmap[word], bits);
 }
 
-// popcount prefix of the all-reduced bitmap (every owner's first points)
-struct FirstWords {
-    static constexpr const char *kName = "k_scan_count<FirstWords>", *kName2 = "k_scan_apply<FirstWords>";
-    const u64 *global;
-    uint32_t *pre;
-    __device__ u64 value(int64_t w) const { return (u64)__popcll(global[w]); }
-    __device__ u64 value2(int64_t w) const { return value(w); }
-    __device__ void apply(int64_t w, u64, u64 excl) const { pre[w] = (uint32_t)excl; }
-};
+// popcount prefix of the all-reduced bitmap (every owner's first points): one launch, tiles of 4096 words by ticket, decoupled
+// look-back over the tiles' popcounts (a frame of 8 M points: 31 tiles); the last tile writes the frame's voxel count.
+// status[ntiles] + the ticket word are zeroed by the caller.  (Round 3: the three-launch generic scan, 23 us for 1 MB.)
+constexpr int kPrefixThreads = 1024, kPrefixItems = 4, kPrefixTile = kPrefixThreads * kPrefixItems;
+__global__ __launch_bounds__(kPrefixThreads) void k_first_prefix(const u64 *__restrict__ global, int64_t nw, uint32_t *__restrict__ pre,
+                                                                 u64 *status, uint32_t ntiles, int64_t *counts_out)
+{
+    __shared__ unsigned int sid;
+    __shared__ u64 smem[kPrefixThreads / kWave];
+    __shared__ u64 sexcl;
+    const unsigned int tile = lookback_ticket(reinterpret_cast<unsigned int *>(status + ntiles), &sid);
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    // row k of a wavefront = 64 consecutive words, one per lane (coalesced)
+    const int64_t base = (int64_t)tile * kPrefixTile + (int64_t)w * (kWave * kPrefixItems) + lane;
+    u64 v[kPrefixItems], ex[kPrefixItems], carry = 0;
+#pragma unroll
+    for (int k = 0; k < kPrefixItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        v[k] = i < nw ? (u64)__popcll(global[i]) : 0ull;
+        const u64 incl = wave_incl_scan_u64(v[k]);
+        ex[k] = carry + incl - v[k];
+        carry += __shfl(incl, kWave - 1, kWave);
+    }
+    if (lane == 0) smem[w] = carry;
+    __syncthreads();
+    u64 woff = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kPrefixThreads / kWave; k++) { if (k < w) woff += smem[k]; total += smem[k]; }
+    if (threadIdx.x < kWave) {
+        const u64 e = lookback_exclusive(status, tile, total);
+        if (threadIdx.x == 0) {
+            sexcl = e;
+            if (tile == ntiles - 1) {
+                counts_out[D3D_COUNT_VOXELS] = (int64_t)(e + total);
+                counts_out[D3D_COUNT_POINTS] = 0; counts_out[D3D_COUNT_STATUS] = 0; counts_out[D3D_COUNT_AUX] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    woff += sexcl;
+#pragma unroll
+    for (int k = 0; k < kPrefixItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        if (i < nw) pre[i] = (uint32_t)(woff + ex[k]);
+    }
+}
 
 // owned voxel (already in id order) -> its global voxel id = number of first points before its own in the whole frame
 __global__ __launch_bounds__(256) void k_owner_number(const int64_t *__restrict__ counts_o, const u64 *__restrict__ gbits,
@@ -464,7 +555,8 @@ constexpr int kDenseCap = 256;                    // rows per wavefront in LDS; 
 
 __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__ counts_o, const int32_t *__restrict__ lead_rec,
                                                      const int32_t *__restrict__ npoints, const uint32_t *__restrict__ rec_slot,
-                                                     const uint32_t *__restrict__ contrib, int world,
+                                                     const MergeSlot *__restrict__ mslot, const uint32_t *__restrict__ next,
+                                                     const int64_t *__restrict__ src_off, int world,
                                                      const int32_t *__restrict__ recv, int RS, const float4 *__restrict__ recv_rows,
                                                      const int64_t *__restrict__ rows_src_off, uint32_t P, int pshift,
                                                      float4 *voxels, unsigned char *pmask)
@@ -482,10 +574,9 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
     if (v0 >= Vo) return;                                   // wave-uniform
     const uint32_t nv = Vo - v0 < kWave ? (uint32_t)(Vo - v0) : (uint32_t)kWave;
     const bool mine = (uint32_t)lane < nv;
-    const int ws = (world + 3) & ~3;
-    uint32_t slot = 0, kept = 0;
+    uint32_t head = 0, kept = 0;
     if (mine) {
-        slot = rec_slot[lead_rec[v0 + lane]];
+        head = mslot[rec_slot[lead_rec[v0 + lane]]].head;
         const uint32_t n = (uint32_t)npoints[v0 + lane];
         kept = n < P ? n : P;
     }
@@ -507,23 +598,17 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
         const unsigned long long nf = ~(__ballot(fits) >> ja);
         const uint32_t jb = ja + (nf ? (uint32_t)__ffsll((long long)nf) - 1u : (uint32_t)kWave - ja);
         if ((uint32_t)lane >= ja && (uint32_t)lane < jb) {  // my voxel's rows, in rank order of the contributing records
-            const uint4 *cb = reinterpret_cast<const uint4 *>(contrib + (u64)slot * ws);
             vec4 *dst = rowbuf + (off - oa);
             uint32_t have = 0;
-            for (int q4 = 0; q4 < ws && have < kept; q4 += 4) {
-                const uint4 x = cb[q4 >> 2];
-                const uint32_t e[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (!e[k] || have >= kept) continue;
-                    const int32_t *r = recv + (size_t)(e[k] - 1) * RS;
-                    const uint32_t nr = (uint32_t)r[4] < P ? (uint32_t)r[4] : P;
-                    const uint32_t take = nr < kept - have ? nr : kept - have;
-                    const vec4 *src = reinterpret_cast<const vec4 *>(recv_rows) + rows_src_off[q4 + k] + (uint32_t)r[RS - 1];
-                    for (uint32_t t = 0; t < take; t++) dst[have + t] = src[t];
-                    have += take;
-                }
-            }
+            chain_in_order(next, head, [&](uint32_t ri) {
+                if (have >= kept) return;
+                const int32_t *r = recv + (size_t)ri * RS;
+                const uint32_t nr = (uint32_t)r[4] < P ? (uint32_t)r[4] : P;
+                const uint32_t take = nr < kept - have ? nr : kept - have;
+                const vec4 *src = reinterpret_cast<const vec4 *>(recv_rows) + rows_src_off[record_source(src_off, world, ri)] + (uint32_t)r[RS - 1];
+                for (uint32_t t = 0; t < take; t++) dst[have + t] = src[t];
+                have += take;
+            });
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint32_t q1 = jb * P;
@@ -664,17 +749,15 @@ extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *sr
     if (R > 0 && (!recv || !first_o || !coords || !npoints || !feats || !rec_owned || !lead_rec)) return D3D_ERR_BAD_ARG;
     MergeWs m = carve_merge(workspace, workspace_bytes, R, world);
     if (!workspace || m.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
-    D3D_HIP_CHECK(hipMemsetAsync(counts, 0, D3D_NUM_COUNTS * sizeof(int64_t), st));
-    D3D_LAUNCH("k_merge_init", k_merge_init, dim3(blocks_for((int64_t)m.cap * ((world + 3) >> 2), 256 * 4)), dim3(256), 0, st, m.tkey, m.contrib,
-               m.cap, (int)world);
-    if (R > 0)
-        D3D_LAUNCH("k_merge_insert", k_merge_insert, dim3(blocks_for(R)), dim3(256), 0, st, recv, R, rec_stride(c), src_off, (int)world,
-                   m.tkey, m.cap, m.contrib, m.rec_slot);
-    MergeRecords f{m.contrib, m.rec_slot, m.flag, src_off, recv, rec_stride(c), (int)c, (int)world, (int)reduction, (int64_t)shape[1],
-                   (int64_t)shape[2], m.slot_owned, first_o, coords, npoints, feats, lead_rec};
-    int rc = d3d_run_scan(f, R, m.bsum, counts, -1, D3D_COUNT_VOXELS, ~0ull, st);
-    if (rc) return rc;
-    if (R > 0) D3D_LAUNCH("k_merge_recmap", k_merge_recmap, dim3(blocks_for(R)), dim3(256), 0, st, R, m.rec_slot, m.slot_owned, rec_owned);
+    D3D_LAUNCH("k_merge_init", k_merge_init, dim3(blocks_for((int64_t)m.cap, 256 * 4)), dim3(256), 0, st, m.slot, m.cap, m.status,
+               m.ntiles + 1, counts, src_off, (int)world, m.src_off);
+    if (R > 0) {
+        D3D_LAUNCH("k_merge_insert", k_merge_insert, dim3(blocks_for(R)), dim3(256), 0, st, recv, R, rec_stride(c), m.slot, m.cap, m.next,
+                   m.rec_slot, rec_owned);
+        MergeOut f{rec_stride(c), (int)c, (int)reduction, (int64_t)shape[1], (int64_t)shape[2], first_o, coords, npoints, feats, lead_rec};
+        D3D_LAUNCH("k_merge_finish", k_merge_finish, dim3(m.ntiles), dim3(kFinishThreads), 0, st, recv, R, (const MergeSlot *)m.slot,
+                   (const uint32_t *)m.next, (const uint32_t *)m.rec_slot, m.status, m.ntiles, f, rec_owned, counts);
+    }
     return D3D_OK;
 }
 
@@ -693,7 +776,7 @@ extern "C" int d3d_owner_mark_first(const int64_t *first_o, const int64_t *count
 extern "C" size_t d3d_owner_number_workspace_bytes(int64_t n_total)
 {
     const int64_t nw = d3d_divup(n_total > 0 ? n_total : 1, 64);
-    return d3d_align_up((size_t)nw * 4) + d3d_align_up((size_t)(d3d_divup(nw, kScanTile) + 1) * 8) + 256;
+    return d3d_align_up((size_t)nw * 4) + d3d_align_up((size_t)(d3d_divup(nw, kPrefixTile) + 1) * 8) + 256;
 }
 
 // global_bits = the SUM all-reduce of every owner's d3d_owner_mark_first bitmap (disjoint bit sets: their OR).  vids[i] =
@@ -710,11 +793,11 @@ extern "C" int d3d_owner_number(const uint64_t *global_bits, int64_t n_total, co
     const int64_t nw = d3d_divup(n_total > 0 ? n_total : 1, 64);
     WsCarver w(workspace, workspace_bytes);
     uint32_t *pre = w.take<uint32_t>(nw);
-    u64 *bsum = w.take<u64>(d3d_divup(nw, kScanTile) + 1);
-    D3D_HIP_CHECK(hipMemsetAsync(counts_out, 0, D3D_NUM_COUNTS * sizeof(int64_t), st));
-    FirstWords f{(const u64 *)global_bits, pre};
-    int rc = d3d_run_scan(f, nw, bsum, counts_out, -1, D3D_COUNT_VOXELS, ~0ull, st);
-    if (rc) return rc;
+    const uint32_t ntiles = (uint32_t)d3d_divup(nw, kPrefixTile);
+    u64 *status = w.take<u64>((size_t)ntiles + 1);
+    D3D_HIP_CHECK(hipMemsetAsync(status, 0, ((size_t)ntiles + 1) * 8, st));
+    D3D_LAUNCH("k_first_prefix", k_first_prefix, dim3(ntiles), dim3(kPrefixThreads), 0, st, (const u64 *)global_bits, nw, pre, status, ntiles,
+               counts_out);
     if (cap_o > 0)
         D3D_LAUNCH("k_owner_number", k_owner_number, dim3(blocks_for(cap_o)), dim3(256), 0, st, counts_o, (const u64 *)global_bits, pre,
                    first_o, vids);
@@ -739,7 +822,7 @@ extern "C" int d3d_owner_dense(const int32_t *recv, int64_t R, const float *recv
     const uint32_t P = (uint32_t)max_points;
     const int pshift = (P & (P - 1)) == 0 ? __builtin_ctz(P) : -1;
     D3D_LAUNCH("k_owner_dense", k_owner_dense, dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec, npoints, m.rec_slot,
-               m.contrib, (int)world, recv, rec_stride(4), reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift,
+               (const MergeSlot *)m.slot, (const uint32_t *)m.next, (const int64_t *)m.src_off, (int)world, recv, rec_stride(4), reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift,
                reinterpret_cast<float4 *>(voxels), pmask);
     return D3D_OK;
 }

@@ -3130,10 +3130,9 @@ static bool binned_eligible(int64_t n, const VoxelWs &w, uint32_t flags, uint32_
     if ((flags & D3D_VOXEL_PATH_HASH) || n <= 0) return false;
     uint32_t nbins = 1;
     int hshift = 0;
-    // buckets of ~512 points up to 8192 buckets, then of up to 1024 (8 M points with 16384 buckets of 512: scatter and bucket
-    // kernel 10 % slower than with 8192 of 1024), the last doubling only for frames that need it
-    static const int tune_target = getenv("D3D_TUNE_BUCKET") ? atoi(getenv("D3D_TUNE_BUCKET")) : kBucketTarget;   // (tuning, temporary)
-    while (nbins < 8192u && (int64_t)nbins * tune_target < n) { nbins <<= 1; hshift++; }
+    // buckets of ~kBucketTarget points up to 8192 buckets (8 M points with 16384 buckets of 512: scatter and bucket kernel
+    // 10 % slower than with 8192 of 1024), the last doubling only for frames that need it
+    while (nbins < 8192u && (int64_t)nbins * kBucketTarget < n) { nbins <<= 1; hshift++; }
     while (nbins < (uint32_t)kBinMax && (int64_t)nbins * 1024 < n) { nbins <<= 1; hshift++; }
     if ((int64_t)nbins * 1024 < n) return false;        // more than 16 M points: buckets would outgrow a workgroup
     const uint64_t ntiles = d3d_divup((int64_t)(w.npad / kBinTile), (int64_t)bin_passes(n));
@@ -3186,8 +3185,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     const size_t bin_lds = (size_t)nbins * 4;                 // (at 16384 buckets the scatter's 64 KB + 128 B exceed the default limit)
     // one-launch partition (k_tile_sort) whenever the frame and the table fit; else, or on request, the three-pass one
-    static const int tune_items = getenv("D3D_TUNE_SORT_ITEMS") ? atoi(getenv("D3D_TUNE_SORT_ITEMS")) : 8;   // (tuning, temporary)
-    const int tshift = tune_items == 4 ? 12 : 13;
+    const int tshift = 13;                                     // tiles of 8192 points (4096: profiles/r04_bucket_target.txt)
     const uint32_t stiles = (uint32_t)(w.npad >> tshift);
     uint32_t *table = nullptr, *tileinfo = nullptr, *gpos = reinterpret_cast<uint32_t *>(w.vinfo) + w.npad;
     if (tile_sort && n <= kTileSortMaxPoints && nbins <= 8192u && stiles <= (uint32_t)kRunCap &&
@@ -3208,8 +3206,8 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
                    nbins, stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid, zero_words,    \
                    nzero, zero_ticket);                                                                                         \
     } while (0)
-        if (vec4) { if (tshift == 13) D3D_TILE_SORT(true, 8); else D3D_TILE_SORT(true, 4); }
-        else { if (tshift == 13) D3D_TILE_SORT(false, 8); else D3D_TILE_SORT(false, 4); }
+        if (vec4) D3D_TILE_SORT(true, 8);
+        else D3D_TILE_SORT(false, 8);
 #undef D3D_TILE_SORT
     } else if (do_index) {
     if (bin_lds + 256 > 65536) {

@@ -500,6 +500,18 @@ int d3d_nms2d_notify(const void *boxes, const void *scores, const int64_t *order
                      uint8_t *suppressed, void *workspace, size_t workspace_bytes, void *stream, uint32_t flags,
                      int32_t *host_word);
 
+/* Which route the LAST hard-NMS call that used `workspace` took (waits for `stream`).  Bits of *status:
+ *   D3D_NMS_STATUS_DENSE_PATH    the n x n mask + sequential sweep decided the result (candidate list overflowed, a box covered
+ *                                more than 1024 grid cells, the fixed point did not settle, D3D_NMS_FORCE_DENSE, or a scan gave up):
+ *                                same mask, but seconds instead of microseconds at 100 k boxes;
+ *   D3D_NMS_STATUS_SCAN_GAVE_UP  a one-launch scan stopped waiting for an earlier workgroup's total (~0.1 s of polling: a
+ *                                preempted queue, a profiler holding workgroups back) and handed over to the dense path -- the
+ *                                result is still exact; a caller that sees this on a shared GPU may simply call again.
+ * The flags sit in the first bytes of the workspace: ask before anything else uses it.
+ * suppression_type != HARD: *status = 0 (soft-NMS has a single route).  The reference has no counterpart (nms.cpp is one loop). */
+enum { D3D_NMS_STATUS_DENSE_PATH = 1, D3D_NMS_STATUS_SCAN_GAVE_UP = 2 };
+int d3d_nms2d_status(const void *workspace, int32_t suppression_type, void *stream, uint32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,9 +193,14 @@ def test_nms_chained_scan_gives_up_and_hands_over(monkeypatch, scan):
     for _ in range(2):
         keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3, score_threshold=0.1).cpu().numpy()
         assert np.array_equal(keep, exp)
+    # the give-up is reported, not silent (d3d_nms2d_status)
+    sup, status = box.nms2d(T(b), T(s), box.IouType.RBOX, 0, 0.3, 0.1, 0.0, return_status=True)
+    assert status == (box.NMS_STATUS_DENSE_PATH | box.NMS_STATUS_SCAN_GAVE_UP)
     set_opts(nms_flags=hook & ~_lib.NMS_TEST_WITHHOLD)         # and the next call is healthy again
     keep = box2d_nms(T(b), T(s), iou_method="rbox", iou_threshold=0.3, score_threshold=0.1).cpu().numpy()
     assert np.array_equal(keep, exp)
+    sup2, status = box.nms2d(T(b), T(s), box.IouType.RBOX, 0, 0.3, 0.1, 0.0, return_status=True)
+    assert status == 0 and torch.equal(sup, sup2)
 
 
 @pytest.mark.parametrize("n", [128, 3000])
