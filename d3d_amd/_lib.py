@@ -19,6 +19,7 @@ STATUS_COORD_OVERFLOW, STATUS_TABLE_FULL, STATUS_PACK_OVERFLOW, STATUS_BIN_OVERF
 F32, F64 = 0, 1
 # per-call option bits (include/d3d_hip.h)
 VOXEL_PATH_HASH, VOXEL_PARTITION_3PASS, VOXEL_PLAIN_SLOTS, VOXEL_SPLIT_FILL, VOXEL_EXACT_MEAN = 1, 2, 4, 8, 16
+OWNER_MERGE_CHAINS, OWNER_MERGE_TEST_TINY = 1, 2
 NMS_BROAD_SWEEP, NMS_FORCE_DENSE, NMS_SOFT_NO_LDS, NMS_GENERAL, NMS_TEST_WITHHOLD, NMS_FORCE_LEVELS, NMS_ONE_LEVEL = 1, 2, 4, 8, 16, 32, 64
 
 
@@ -74,8 +75,8 @@ SIGNATURES = {
     "d3d_owner_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _sz, _vp]),
     "d3d_owner_merge_workspace_bytes": (_sz, [_i64, _i32]),
-    "d3d_owner_merge": (ctypes.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "d3d_owner_dense": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp, _vp]),
+    "d3d_owner_merge": (ctypes.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32]),
+    "d3d_owner_dense": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp, _vp, _u32]),
     "d3d_owner_mark_first": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "d3d_owner_number_workspace_bytes": (_sz, [_i64]),
     "d3d_owner_number": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1024) void k_owner_scatter(const int64_t *__restric
         const uint32_t d = ok ? owner_of(key, world) : 0xffffffffu;
         const uint32_t nc = ok ? (uint32_t)cnt[i] : 0u;
         const uint32_t kept = DENSE ? (nc < pd.P ? nc : pd.P) : 0u;
-        uint32_t myrank = 0, myrows = 0;
+        uint32_t myrank = 0, myrows = 0, rsrc = 0, rdst = 0;
         for (uint32_t q = 0; q < world; q++) {               // wave-uniform
             const u64 b = __ballot(d == q);
             if (d == q) myrank = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
@@ -180,9 +180,37 @@ __global__ __launch_bounds__(1024) void k_owner_scatter(const int64_t *__restric
             if (DENSE) {
                 const uint32_t inbatch = pd.tilerows[tidx] + rbefore + myrows;      // offset inside the (me -> d) row batch
                 r[RS - 1] = (int32_t)inbatch;
-                const float4 *src = pd.rows_local + pd.seg_base[i];
-                float4 *dst = pd.send_rows + pd.dest_rowbase[d] + inbatch;
-                for (uint32_t t = 0; t < kept; t++) dst[t] = src[t];
+                rsrc = pd.seg_base[i];
+                rdst = pd.dest_rowbase[d] + inbatch;
+            }
+        }
+        if (DENSE) {
+            // the rows of the wavefront's 64 voxels, copied by all lanes together: row j of the wavefront belongs to the voxel
+            // whose running row count first exceeds j (a lane copying its own voxel's rows one after the other made the
+            // whole wavefront wait for its fullest voxel: up to max_points trips of one 16-byte copy per lane)
+            uint32_t incl = kept;
+#pragma unroll
+            for (int sft = 1; sft < kWave; sft <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)incl, sft, kWave);
+                if (lane >= sft) incl += y;
+            }
+            const uint32_t wtotal = (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+            for (uint32_t j0 = 0; j0 < wtotal; j0 += kWave) {
+                const uint32_t j = j0 + lane;
+                // owner of row j: the number of lanes whose inclusive count is <= j (ballot per probe: binary search over lanes)
+                int lo = 0, hi = kWave - 1;
+#pragma unroll
+                for (int step = 0; step < 6; step++) {
+                    const int mid = (lo + hi) >> 1;
+                    const uint32_t v = (uint32_t)__shfl((int)incl, mid, kWave);
+                    if (v <= j) lo = mid + 1; else hi = mid;
+                }
+                const uint32_t own_incl = (uint32_t)__shfl((int)incl, lo, kWave), own_kept = (uint32_t)__shfl((int)kept, lo, kWave);
+                const uint32_t s0 = (uint32_t)__shfl((int)rsrc, lo, kWave), d0 = (uint32_t)__shfl((int)rdst, lo, kWave);
+                if (j < wtotal) {
+                    const uint32_t t = j - (own_incl - own_kept);
+                    pd.send_rows[d0 + t] = pd.rows_local[s0 + t];
+                }
             }
         }
         __syncthreads();
@@ -320,8 +348,9 @@ struct MergeOut {
 };
 
 // leader record i -> owned voxel o: the cell's records merged in rank order, the voxel's finished row written
-__device__ __forceinline__ void merge_leader(const MergeOut &f, const int32_t *__restrict__ recv, const uint32_t *__restrict__ next,
-                                             uint32_t head, int64_t i, int64_t o, bool sole)
+template <class Each>
+__device__ __forceinline__ void merge_leader(const MergeOut &f, const int32_t *__restrict__ recv, int64_t i, int64_t o, bool sole,
+                                             Each &&each_record /* each_record(visit): visit(record) in rank order */)
 {
     const int c = f.c, RS = f.RS, reduction = f.reduction;
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
@@ -351,7 +380,7 @@ __device__ __forceinline__ void merge_leader(const MergeOut &f, const int32_t *_
     int64_t first = INT64_MAX;
     int32_t cnt = 0;
     int64_t key = 0;
-    chain_in_order(next, head, [&](uint32_t ri) {              // rank order: the same sums on every run
+    each_record([&](uint32_t ri) {                             // rank order: the same sums on every run
         const int32_t *r = recv + (size_t)ri * RS;
         key = *reinterpret_cast<const int64_t *>(r);
         const int64_t f0 = *reinterpret_cast<const int64_t *>(r + 2);
@@ -425,7 +454,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_merge_finish(const int32_t *
     for (int k = 0; k < kFinishItems; k++) {
         const int64_t i = i0 + k;
         if (i < R && lead[k] == (uint32_t)i + 1u) {
-            merge_leader(f, recv, next, head[k], i, (int64_t)ex, sole[k]);
+            merge_leader(f, recv, i, (int64_t)ex, sole[k], [&](auto &&visit) { chain_in_order(next, head[k], visit); });
             __hip_atomic_store(&rec_owned[i], (int32_t)ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ex++;
         }
@@ -444,14 +473,449 @@ __global__ __launch_bounds__(kFinishThreads) void k_merge_finish(const int32_t *
     }
 }
 
+// c == 4 records in registers: {cell, first point, count, four partial features}
+struct Rec4 { int64_t key, first; int32_t cnt; float x0, x1, x2, x3; };
+__device__ __forceinline__ Rec4 load_rec4(const int32_t *__restrict__ recv, int RS, uint32_t ri)
+{
+    const int32_t *r = recv + (size_t)ri * RS;
+    Rec4 v;
+    v.key = *reinterpret_cast<const int64_t *>(r);
+    v.first = *reinterpret_cast<const int64_t *>(r + 2);
+    v.cnt = r[4];
+    v.x0 = __int_as_float(r[5]); v.x1 = __int_as_float(r[6]); v.x2 = __int_as_float(r[7]); v.x3 = __int_as_float(r[8]);
+    return v;
+}
+struct Acc4 {
+    float a0, a1, a2, a3;
+    int64_t first;
+    int32_t cnt;
+    __device__ __forceinline__ void init(int reduction)
+    {
+        const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
+        a0 = a1 = a2 = a3 = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+        first = INT64_MAX; cnt = 0;
+    }
+    __device__ __forceinline__ void add(const Rec4 &v, int reduction)      // identity (op) x for the first record: as merge_leader
+    {
+        const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == 4;
+        if (is_sum) { a0 += v.x0; a1 += v.x1; a2 += v.x2; a3 += v.x3; }
+        else if (reduction == D3D_REDUCE_MAX) { a0 = a0 < v.x0 ? v.x0 : a0; a1 = a1 < v.x1 ? v.x1 : a1; a2 = a2 < v.x2 ? v.x2 : a2; a3 = a3 < v.x3 ? v.x3 : a3; }
+        else { a0 = v.x0 < a0 ? v.x0 : a0; a1 = v.x1 < a1 ? v.x1 : a1; a2 = v.x2 < a2 ? v.x2 : a2; a3 = v.x3 < a3 ? v.x3 : a3; }
+        first = v.first < first ? v.first : first;
+        cnt += v.cnt;
+    }
+    __device__ __forceinline__ void store(const MergeOut &f, int64_t key, int64_t o, int64_t i) const
+    {
+        f.lead_rec[o] = (int32_t)i;
+        f.first_o[o] = first;
+        f.npoints[o] = cnt;
+        f.coords[o * 3 + 0] = key / (f.sy * f.sz);
+        f.coords[o * 3 + 1] = (key / f.sz) % f.sy;
+        f.coords[o * 3 + 2] = key % f.sz;
+        const float d = f.reduction == D3D_REDUCE_MEAN ? (float)cnt : 1.0f;
+        *reinterpret_cast<float4 *>(f.feats + o * 4) = make_float4(a0 / d, a1 / d, a2 / d, a3 / d);
+    }
+};
+
+// ---------------------------------------------------------------- merge on the owner, LDS buckets (3 launches, no global atomics)
+// The chain path above pays two RETURNING global atomics per record -- 1.6 M of them at config 5, at the 17 G/s scattered
+// returning atomics run at (k_nms_hits) that is its 92 us.  Up to 2 M records the merge is done the way the voxel
+// index is built (voxel.hip k_tile_sort / k_bucket_index), with the hash tables in LDS:
+//   k_rec_tile_sort  tile of 2048 records -> sorted by hash bucket in LDS, written as {cell, record} entries; a bucket-major
+//                    table [bucket][tile] of the runs {offset : 16 | length : 16}
+//   k_rec_bucket     one workgroup per bucket (<= 1024 records on average): its runs gathered, cells grouped by an LDS hash
+//                    table; per cell the lowest record index (the leader) and the list of its records (fixed segment of
+//                    kRecSeg entries per bucket in `cellrecs`); per record one word `rinfo`: a leader's list {base, length},
+//                    or the index of its leader.  A bucket with more than kRecBucketCap entries raises BIN_OVERFLOW in
+//                    counts[STATUS] (hashed cells: 8 sigma above the largest mean) -- the caller then uses the chain path.
+//   k_rec_finish     as k_merge_finish: look-back over the leader flags, each leader merges its list in rank order and writes
+//                    its voxel's row; the other records pick up their leader's number.
+constexpr int kRecTileThreads = 512, kRecTileItems = 4, kRecTile = kRecTileThreads * kRecTileItems;
+constexpr int kRecBucketThreads = 512, kRecSlots = 2048, kRecSeg = 2048, kRecBucketCap = 1280, kRecBucketMean = 1024;
+constexpr int kRecMaxBuckets = 2048, kRecMaxTiles = 1024;
+constexpr int kRecMulti = kRecBucketCap / 2;       // cells of several records a bucket can hold
+constexpr int64_t kRecMaxRecords = (int64_t)kRecMaxTiles * kRecTile;
+constexpr uint32_t kRecLeader = 1u << 31;
+
+__device__ __forceinline__ u64 rec_hash(u64 key) { return mix64(key * 0x9e3779b97f4a7c15ull); }   // (owner_of took mix64(key))
+
+static uint32_t rec_buckets(int64_t R)
+{
+    uint32_t nb = 1;
+    while ((int64_t)nb * kRecBucketMean < R) nb <<= 1;
+    return nb;
+}
+
+struct RecWs {
+    u64 *ekey;            // [ntiles * kRecTile] tile-sorted entries: cell ...
+    uint32_t *eidx;       //                       ... and record index
+    uint32_t *table;      // [nb][ntiles]
+    uint32_t *cellrecs;   // [nb * kRecSeg]
+    uint32_t *rinfo;      // [R]
+    uint32_t *minfo;      // [R] by leader record, cells of several records: where the merged record is (index into mrec)
+    int32_t *mrec;        // [nb * kRecMulti][RS of c == 4] merged records, laid out like a received record
+    u64 *status;          // look-back words of k_rec_finish, [ftiles] + ticket word
+    int64_t *src_off;     // [world + 1]
+    uint32_t *overflow;   // one word
+    uint32_t nb, ntiles, ftiles;
+    size_t bytes;
+};
+
+static RecWs carve_rec(void *ws, size_t bytes, int64_t R, int world)
+{
+    WsCarver w(ws, bytes);
+    RecWs m;
+    const int64_t r1 = R > 0 ? R : 1;
+    m.nb = rec_buckets(r1);
+    m.ntiles = (uint32_t)d3d_divup(r1, kRecTile);
+    m.ftiles = (uint32_t)d3d_divup(r1, kFinishTile);
+    m.ekey = w.take<u64>((size_t)m.ntiles * kRecTile);
+    m.eidx = w.take<uint32_t>((size_t)m.ntiles * kRecTile);
+    m.table = w.take<uint32_t>((size_t)m.nb * m.ntiles);
+    m.cellrecs = w.take<uint32_t>((size_t)m.nb * kRecSeg);
+    m.rinfo = w.take<uint32_t>(r1);
+    m.minfo = w.take<uint32_t>(r1);
+    m.mrec = w.take<int32_t>((size_t)m.nb * kRecMulti * rec_stride(4));
+    m.status = w.take<u64>((size_t)m.ftiles + 1);
+    m.src_off = w.take<int64_t>((size_t)world + 1);
+    m.overflow = w.take<uint32_t>(1);
+    m.bytes = w.off;
+    return m;
+}
+
+__global__ __launch_bounds__(kRecTileThreads) void k_rec_tile_sort(const int32_t *__restrict__ recv, int64_t R, int RS, uint32_t nb,
+                                                                   uint32_t ntiles, u64 *__restrict__ ekey, uint32_t *__restrict__ eidx,
+                                                                   uint32_t *__restrict__ table, int32_t *__restrict__ rec_owned,
+                                                                   u64 *status, uint32_t nstatus, uint32_t *overflow, int64_t *counts,
+                                                                   const int64_t *__restrict__ src_off, int world, int64_t *src_off_copy)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rec_lds[];
+    u64 *keys = reinterpret_cast<u64 *>(rec_lds);                         // [kRecTile] in bucket order
+    uint32_t *h = reinterpret_cast<uint32_t *>(keys + kRecTile);           // [nb] histogram, then the buckets' offsets
+    uint16_t *lidx = reinterpret_cast<uint16_t *>(h + nb);                 // [kRecTile] record index inside the tile
+    __shared__ u64 smem[kRecTileThreads / kWave];
+    const int64_t base = (int64_t)blockIdx.x * kRecTile + threadIdx.x;
+    u64 key[kRecTileItems];
+#pragma unroll
+    for (int r = 0; r < kRecTileItems; r++) {
+        const int64_t i = base + r * kRecTileThreads;
+        key[r] = i < R ? (u64)*reinterpret_cast<const int64_t *>(recv + (size_t)i * RS) : 0ull;
+    }
+    for (uint32_t b = threadIdx.x; b < nb; b += kRecTileThreads) h[b] = 0;
+    if (blockIdx.x == 0) {                                                 // housekeeping for the launches behind this one
+        for (uint32_t t = threadIdx.x; t < nstatus; t += kRecTileThreads) status[t] = 0ull;
+        if (threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
+        if (threadIdx.x <= (unsigned)world) src_off_copy[threadIdx.x] = src_off[threadIdx.x];
+        if (threadIdx.x == 0) *overflow = 0;
+    }
+    __syncthreads();
+    uint32_t word[kRecTileItems];                  // bucket : 12 | arrival inside the bucket << 12
+#pragma unroll
+    for (int r = 0; r < kRecTileItems; r++) {
+        const int64_t i = base + r * kRecTileThreads;
+        word[r] = ~0u;
+        if (i < R) {
+            const uint32_t b = (uint32_t)rec_hash(key[r]) & (nb - 1);
+            word[r] = b | (atomicAdd(&h[b], 1u) << 12);
+            rec_owned[i] = -1;                     // "my leader has no number yet" (k_rec_finish polls it)
+        }
+    }
+    __syncthreads();
+    constexpr int kPerMax = kRecMaxBuckets / kRecTileThreads;
+    const uint32_t per = nb > (uint32_t)kRecTileThreads ? nb / kRecTileThreads : 1u, b0 = threadIdx.x * per;
+    uint32_t cnt[kPerMax];
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPerMax; k++) {
+        cnt[k] = ((uint32_t)k < per && b0 + k < nb) ? h[b0 + k] : 0u;
+        mine += cnt[k];
+    }
+    u64 all;
+    u64 ex = block_excl_scan_u64<kRecTileThreads>(mine, &all, smem);
+#pragma unroll
+    for (int k = 0; k < kPerMax; k++) {
+        if ((uint32_t)k < per && b0 + k < nb) {
+            h[b0 + k] = (uint32_t)ex;
+            table[(size_t)(b0 + k) * ntiles + blockIdx.x] = (uint32_t)ex | (cnt[k] << 16);
+            ex += cnt[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRecTileItems; r++) {
+        if (word[r] != ~0u) {
+            const uint32_t p = h[word[r] & 0xfffu] + (word[r] >> 12);
+            keys[p] = key[r];
+            lidx[p] = (uint16_t)(r * kRecTileThreads + threadIdx.x);
+        }
+    }
+    __syncthreads();
+    const size_t tbase = (size_t)blockIdx.x * kRecTile;
+    for (uint32_t p = threadIdx.x; p < (uint32_t)all; p += kRecTileThreads) {
+        ekey[tbase + p] = keys[p];
+        eidx[tbase + p] = (uint32_t)tbase + lidx[p];
+    }
+}
+
+__global__ __launch_bounds__(kRecBucketThreads) void k_rec_bucket(const u64 *__restrict__ ekey, const uint32_t *__restrict__ eidx,
+                                                                  const uint32_t *__restrict__ table, uint32_t ntiles,
+                                                                  uint32_t *__restrict__ cellrecs, uint32_t *__restrict__ rinfo,
+                                                                  uint32_t *overflow, int64_t *counts, uint32_t cap,
+                                                                  const int32_t *__restrict__ recv /* c == 4: merge here */,
+                                                                  int reduction, uint32_t *__restrict__ minfo, int32_t *__restrict__ mrec)
+{
+    __shared__ uint16_t mq[kRecMulti];                                   // slots of the cells of several records
+    __shared__ uint32_t nmulti;
+    __shared__ u64 hkey[kRecSlots];
+    __shared__ uint32_t hmin[kRecSlots], hcnt[kRecSlots];                 // hcnt: records of the cell, then {count : 8 | offset << 8}
+    __shared__ uint32_t srcpos[kRecBucketCap];                           // where the bucket's entries are; then (llist) the
+    uint32_t *llist = srcpos;                                            // cells' record lists as in cellrecs (160 KB / 4 workgroups)
+    __shared__ u64 smem[kRecBucketThreads / kWave];
+    const uint32_t b = blockIdx.x;
+    // this bucket's runs: one per tile
+    constexpr int kRuns = kRecMaxTiles / kRecBucketThreads;
+    uint32_t roff[kRuns], rlen[kRuns];
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kRuns; k++) {
+        const uint32_t t = threadIdx.x * kRuns + k;
+        const uint32_t w = t < ntiles ? table[(size_t)b * ntiles + t] : 0u;
+        roff[k] = w & 0xffffu; rlen[k] = w >> 16;
+        mine += rlen[k];
+    }
+    for (uint32_t s = threadIdx.x; s < (uint32_t)kRecSlots; s += kRecBucketThreads) { hkey[s] = kFree; hmin[s] = ~0u; hcnt[s] = 0; }
+    if (threadIdx.x == 0) nmulti = 0;
+    u64 total;
+    u64 ex = block_excl_scan_u64<kRecBucketThreads>(mine, &total, smem);
+    const uint32_t m = (uint32_t)total;
+    if (m > cap) {                                                          // (wave-uniform: every thread sees the same total)
+        if (threadIdx.x == 0) {
+            *overflow = 1;
+            atomicOr(reinterpret_cast<u64 *>(&counts[D3D_COUNT_STATUS]), (u64)D3D_VOXEL_STATUS_BIN_OVERFLOW);
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < kRuns; k++) {
+        const uint32_t t = threadIdx.x * kRuns + k;
+        for (uint32_t q = 0; q < rlen[k]; q++) srcpos[(uint32_t)ex + q] = t * kRecTile + roff[k] + q;
+        ex += rlen[k];
+    }
+    __syncthreads();
+    constexpr int kEnt = (kRecBucketCap + kRecBucketThreads - 1) / kRecBucketThreads;
+    u64 key[kEnt];
+    uint32_t idx[kEnt], slot[kEnt], pos[kEnt];
+#pragma unroll
+    for (int k = 0; k < kEnt; k++) {
+        const uint32_t j = threadIdx.x + k * kRecBucketThreads;
+        if (j < m) { const uint32_t sp = srcpos[j]; key[k] = ekey[sp]; idx[k] = eidx[sp]; }
+    }
+#pragma unroll
+    for (int k = 0; k < kEnt; k++) {
+        const uint32_t j = threadIdx.x + k * kRecBucketThreads;
+        if (j < m) {
+            uint32_t s = (uint32_t)(rec_hash(key[k]) >> 32) & (kRecSlots - 1);
+            for (;;) {
+                const u64 old = atomicCAS(&hkey[s], kFree, key[k]);
+                if (old == kFree || old == key[k]) break;
+                s = (s + 1) & (kRecSlots - 1);                              // m <= kRecBucketCap < kRecSlots: a free slot exists
+            }
+            slot[k] = s;
+            atomicMin(&hmin[s], idx[k]);
+            pos[k] = atomicAdd(&hcnt[s], 1u);
+        }
+    }
+    __syncthreads();
+    {   // the cells' list offsets inside the bucket's segment: exclusive scan of the counts over the slots
+        constexpr int kPer = kRecSlots / kRecBucketThreads;
+        uint32_t c[kPer];
+        u64 sum = 0, tot;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) { c[k] = hcnt[threadIdx.x * kPer + k]; sum += c[k]; }
+        u64 e = block_excl_scan_u64<kRecBucketThreads>(sum, &tot, smem);
+#pragma unroll
+        for (int k = 0; k < kPer; k++) { hcnt[threadIdx.x * kPer + k] = c[k] | ((uint32_t)e << 8); e += c[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kEnt; k++) {
+        const uint32_t j = threadIdx.x + k * kRecBucketThreads;
+        if (j < m) {
+            const uint32_t w = hcnt[slot[k]], L = w & 0xffu, off = w >> 8, lead = hmin[slot[k]];
+            const uint32_t lbase = b * kRecSeg + off;
+            cellrecs[lbase + pos[k]] = idx[k];
+            llist[off + pos[k]] = idx[k];
+            rinfo[idx[k]] = lead == idx[k] ? (kRecLeader | ((L - 1u) << 22) | lbase) : lead;
+            if (recv && lead == idx[k] && L > 1u) mq[atomicAdd(&nmulti, 1u)] = (uint16_t)slot[k];
+        }
+    }
+    if (!recv) return;
+    __syncthreads();
+    // cells of several records, 4 features: merged HERE, in rank order, into a record of the same layout -- k_rec_finish then
+    // reads one record per leader whatever the cell (walking the lists there made every wavefront wait for its longest
+    // cell, row after row: 60 of its 103 us at config 5, 30 with the lists sorted in registers).  One such cell per thread
+    // (queued above: a few dozen per bucket), so the bucket pays one chain of loads, not one per entry of a thread.
+    const int RS = rec_stride(4);
+    for (uint32_t jm = threadIdx.x; jm < nmulti; jm += kRecBucketThreads) {
+        const uint32_t sl = mq[jm], w = hcnt[sl], L = w & 0xffu, off = w >> 8;
+        Acc4 acc;
+        acc.init(reduction);
+        uint32_t prev = 0;                                               // index + 1 of the record added last
+        for (uint32_t n0 = 0; n0 < L; n0 += 4) {                         // the next four in index order, loaded together
+            uint32_t e[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t best = ~0u;
+                for (uint32_t t = 0; t < L; t++) {
+                    const uint32_t x = llist[off + t] + 1u;
+                    if (x > prev && x < best) best = x;
+                }
+                e[q] = best;
+                if (best != ~0u) prev = best;
+            }
+            Rec4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (e[q] != ~0u) v[q] = load_rec4(recv, RS, e[q] - 1u);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (e[q] != ~0u) acc.add(v[q], reduction);
+        }
+        const uint32_t at = b * kRecMulti + jm;
+        int32_t *r = mrec + (size_t)at * RS;
+        *reinterpret_cast<int64_t *>(r) = (int64_t)hkey[sl];
+        *reinterpret_cast<int64_t *>(r + 2) = acc.first;
+        r[4] = acc.cnt;
+        r[5] = __float_as_int(acc.a0); r[6] = __float_as_int(acc.a1); r[7] = __float_as_int(acc.a2); r[8] = __float_as_int(acc.a3);
+        minfo[hmin[sl]] = at;
+    }
+}
+
+// a leader's records by ascending record index (selection over its short list: the arrival order in the list is arbitrary)
+template <class F>
+__device__ __forceinline__ void list_in_order(const uint32_t *__restrict__ list, uint32_t L, F &&visit)
+{
+    uint32_t prev = 0;                            // index + 1 of the record visited last
+    for (uint32_t n = 0; n < L; n++) {
+        uint32_t best = ~0u;
+        for (uint32_t q = 0; q < L; q++) {
+            const uint32_t e = list[q] + 1u;
+            if (e > prev && e < best) best = e;
+        }
+        visit(best - 1u);
+        prev = best;
+    }
+}
+
+// any width (c != 4: the lists are walked here)
+__device__ __noinline__ void merge_listed(const MergeOut &f, const int32_t *__restrict__ recv, const uint32_t *__restrict__ list,
+                                          uint32_t L, int64_t i, int64_t o)
+{
+    merge_leader(f, recv, i, o, L == 1u, [&](auto &&visit) { list_in_order(list, L, visit); });
+}
+
+__global__ __launch_bounds__(kFinishThreads) void k_rec_finish(const int32_t *__restrict__ recv, int64_t R,
+                                                               const uint32_t *__restrict__ rinfo,
+                                                               const uint32_t *__restrict__ cellrecs, const uint32_t *__restrict__ minfo,
+                                                               const int32_t *__restrict__ mrec, u64 *status, uint32_t ntiles,
+                                                               const uint32_t *__restrict__ overflow, MergeOut f, int32_t *rec_owned,
+                                                               int64_t *counts)
+{
+    __shared__ unsigned int sid;
+    __shared__ u64 smem[kFinishThreads / kWave];
+    __shared__ u64 sexcl;
+    if (*overflow) return;                        // a bucket did not fit: rinfo is incomplete, the caller repeats on the chain path
+    const unsigned int tile = lookback_ticket(reinterpret_cast<unsigned int *>(status + ntiles), &sid);
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    // row k of a wavefront = 64 consecutive records, one per lane: coalesced reads, and consecutive leaders write consecutive rows
+    const int64_t base = (int64_t)tile * kFinishTile + (int64_t)w * (kWave * kFinishItems) + lane;
+    uint32_t info[kFinishItems];
+    u64 ex[kFinishItems], carry = 0;
+#pragma unroll
+    for (int k = 0; k < kFinishItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        info[k] = i < R ? rinfo[i] : 0u;
+        const u64 v = (i < R && (info[k] & kRecLeader)) ? 1ull : 0ull;
+        const u64 incl = wave_incl_scan_u64(v);
+        ex[k] = carry + incl - v;
+        carry += __shfl(incl, kWave - 1, kWave);
+    }
+    if (lane == 0) smem[w] = carry;
+    __syncthreads();
+    u64 woff = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kFinishThreads / kWave; k++) { if (k < w) woff += smem[k]; total += smem[k]; }
+    if (threadIdx.x < kWave) {
+        const u64 e = lookback_exclusive(status, tile, total);
+        if (threadIdx.x == 0) {
+            sexcl = e;
+            if (tile == ntiles - 1) counts[D3D_COUNT_VOXELS] = (int64_t)(e + total);
+        }
+    }
+    __syncthreads();
+    woff += sexcl;
+    // c == 4: one record per leader -- its own, or the merged record k_rec_bucket left for a cell of several; the records of
+    // all rows are loaded before the first is used
+    const bool fast4 = f.c == 4;
+    uint32_t mi[kFinishItems];
+#pragma unroll
+    for (int k = 0; k < kFinishItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        mi[k] = ~0u;
+        if (fast4 && i < R && (info[k] & kRecLeader) && ((info[k] >> 22) & 0xffu) != 0u) mi[k] = minfo[i];
+    }
+    Rec4 one[kFinishItems];
+#pragma unroll
+    for (int k = 0; k < kFinishItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        if (fast4 && i < R && (info[k] & kRecLeader)) one[k] = mi[k] == ~0u ? load_rec4(recv, f.RS, (uint32_t)i) : load_rec4(mrec, f.RS, mi[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kFinishItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        if (fast4 && i < R && (info[k] & kRecLeader)) {
+            const int64_t o = (int64_t)(woff + ex[k]);
+            Acc4 acc;
+            acc.init(f.reduction);
+            acc.add(one[k], f.reduction);
+            acc.store(f, one[k].key, o, i);
+            __hip_atomic_store(&rec_owned[i], (int32_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!fast4) {
+#pragma unroll
+        for (int k = 0; k < kFinishItems; k++) {
+            const int64_t i = base + (int64_t)k * kWave;
+            if (i < R && (info[k] & kRecLeader)) {
+                const int64_t o = (int64_t)(woff + ex[k]);
+                merge_listed(f, recv, cellrecs + (info[k] & 0x3fffffu), ((info[k] >> 22) & 0xffu) + 1u, i, o);
+                __hip_atomic_store(&rec_owned[i], (int32_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // the other records: their leader has a lower index -- this wavefront (done above), this workgroup (no barrier between its
+    // store and here), or a tile with a lower ticket (running: it needs nothing from this one)
+#pragma unroll
+    for (int k = 0; k < kFinishItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        if (i < R && !(info[k] & kRecLeader)) {
+            int32_t o;
+            while ((o = __hip_atomic_load(&rec_owned[info[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0)
+                __builtin_amdgcn_s_sleep(1);
+            rec_owned[i] = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- numbering
 // first_o ascends with the owned voxel index, so a wavefront's 64 bits fall into a handful of words: the lanes that share a
 // word OR their bits together (the lowest of them issues the atomic)
 __global__ __launch_bounds__(256) void k_first_mark(const int64_t *__restrict__ first_o, const int64_t *__restrict__ counts,
-                                                    int64_t n_total, u64 *bitmap)
+                                                    int64_t n_total, u64 *bitmap, int64_t nw)
 {
     const int64_t Vo = counts[D3D_COUNT_VOXELS];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && (counts[D3D_COUNT_STATUS] & D3D_VOXEL_STATUS_BIN_OVERFLOW)) bitmap[nw] = 1ull;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t f = i < Vo ? first_o[i] : -1;
     const bool ok = f >= 0 && f < n_total;
@@ -502,7 +966,8 @@ __global__ __launch_bounds__(kPrefixThreads) void k_first_prefix(const u64 *__re
             sexcl = e;
             if (tile == ntiles - 1) {
                 counts_out[D3D_COUNT_VOXELS] = (int64_t)(e + total);
-                counts_out[D3D_COUNT_POINTS] = 0; counts_out[D3D_COUNT_STATUS] = 0; counts_out[D3D_COUNT_AUX] = 0;
+                counts_out[D3D_COUNT_STATUS] = global[nw] ? D3D_VOXEL_STATUS_BIN_OVERFLOW : 0;   // some owner's merge (see k_first_mark)
+                counts_out[D3D_COUNT_POINTS] = 0; counts_out[D3D_COUNT_AUX] = 0;
             }
         }
     }
@@ -531,7 +996,10 @@ __global__ __launch_bounds__(256) void k_owner_reply(int64_t R, const int32_t *_
                                                      const int64_t *__restrict__ vids, int64_t *reply)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < R) reply[i] = vids[rec_owned[i]];
+    if (i < R) {
+        const int32_t o = rec_owned[i];
+        reply[i] = o >= 0 ? vids[o] : -1;         // (-1: the merge asked to be repeated, d3d_owner_merge)
+    }
 }
 
 // the ids that came back (send order) -> id of every local point: point -> local voxel -> its place in the send buffer
@@ -553,9 +1021,12 @@ __global__ __launch_bounds__(256) void k_owner_map(int64_t n, const int64_t *__r
 // order and copies its rows into a row buffer in LDS; the stretch is then written 1 KiB per store instruction from LDS.
 constexpr int kDenseCap = 256;                    // rows per wavefront in LDS; max_points <= kDenseCap
 
+// BUCKETS: a voxel's records are the list its leader's rinfo word names; else the chain of its slot
+template <bool BUCKETS>
 __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__ counts_o, const int32_t *__restrict__ lead_rec,
                                                      const int32_t *__restrict__ npoints, const uint32_t *__restrict__ rec_slot,
                                                      const MergeSlot *__restrict__ mslot, const uint32_t *__restrict__ next,
+                                                     const uint32_t *__restrict__ rinfo, const uint32_t *__restrict__ cellrecs,
                                                      const int64_t *__restrict__ src_off, int world,
                                                      const int32_t *__restrict__ recv, int RS, const float4 *__restrict__ recv_rows,
                                                      const int64_t *__restrict__ rows_src_off, uint32_t P, int pshift,
@@ -576,7 +1047,7 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
     const bool mine = (uint32_t)lane < nv;
     uint32_t head = 0, kept = 0;
     if (mine) {
-        head = mslot[rec_slot[lead_rec[v0 + lane]]].head;
+        head = BUCKETS ? rinfo[lead_rec[v0 + lane]] : mslot[rec_slot[lead_rec[v0 + lane]]].head;
         const uint32_t n = (uint32_t)npoints[v0 + lane];
         kept = n < P ? n : P;
     }
@@ -600,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
         if ((uint32_t)lane >= ja && (uint32_t)lane < jb) {  // my voxel's rows, in rank order of the contributing records
             vec4 *dst = rowbuf + (off - oa);
             uint32_t have = 0;
-            chain_in_order(next, head, [&](uint32_t ri) {
+            auto take_rows = [&](uint32_t ri) {
                 if (have >= kept) return;
                 const int32_t *r = recv + (size_t)ri * RS;
                 const uint32_t nr = (uint32_t)r[4] < P ? (uint32_t)r[4] : P;
@@ -608,7 +1079,9 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
                 const vec4 *src = reinterpret_cast<const vec4 *>(recv_rows) + rows_src_off[record_source(src_off, world, ri)] + (uint32_t)r[RS - 1];
                 for (uint32_t t = 0; t < take; t++) dst[have + t] = src[t];
                 have += take;
-            });
+            };
+            if (BUCKETS) list_in_order(cellrecs + (head & 0x3fffffu), ((head >> 22) & 0xffu) + 1u, take_rows);
+            else chain_in_order(next, head, take_rows);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint32_t q1 = jb * P;
@@ -728,48 +1201,78 @@ extern "C" int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const flo
     return D3D_OK;
 }
 
+static bool merge_on_chains(int64_t R, uint32_t flags) { return (flags & D3D_OWNER_MERGE_CHAINS) || R > kRecMaxRecords; }
+
 extern "C" size_t d3d_owner_merge_workspace_bytes(int64_t R, int32_t world)
 {
-    return carve_merge(nullptr, 0, R > 0 ? R : 0, world).bytes + 256;
+    const int64_t r = R > 0 ? R : 0;
+    const size_t chains = carve_merge(nullptr, 0, r, world).bytes;
+    const size_t buckets = r <= kRecMaxRecords ? carve_rec(nullptr, 0, r, world).bytes : 0;
+    return std::max(chains, buckets) + 256;
 }
 
 // received records recv[R, words] (grouped by source rank: src_off[world + 1], device) -> this owner's voxels IN GLOBAL ID
 // ORDER, finished: first_o / coords / npoints / feats [R rows, counts[D3D_COUNT_VOXELS] valid], rec_owned[R] = the owned voxel
 // of every record, lead_rec[R] = the leader record of every owned voxel.  reduction: MEAN (sums in rank order, then the division
-// of voxelize.cpp:164), MAX, MIN.  The workspace keeps the table (for d3d_owner_dense) until it is reused.
+// of voxelize.cpp:164), MAX, MIN.  The workspace keeps the cells' record lists (for d3d_owner_dense, same flags) until it is
+// reused.  flags: D3D_OWNER_MERGE_CHAINS = the general path (global hash table; taken by itself above 2 M records);
+// otherwise counts[D3D_COUNT_STATUS] may come back with D3D_VOXEL_STATUS_BIN_OVERFLOW (nothing else is valid then): repeat
+// with the flag.  D3D_OWNER_MERGE_TEST_TINY = test hook, buckets overflow at 4 records.
 extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *src_off, int32_t world, int32_t c, int32_t reduction,
                                const int32_t *shape, int64_t *first_o, int64_t *coords, int32_t *npoints, float *feats,
                                int32_t *rec_owned, int32_t *lead_rec, int64_t *counts, void *workspace, size_t workspace_bytes,
-                               void *stream)
+                               void *stream, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
     if (R < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !src_off || !shape) return D3D_ERR_BAD_ARG;
+    if (flags & ~(uint32_t)(D3D_OWNER_MERGE_CHAINS | D3D_OWNER_MERGE_TEST_TINY)) return D3D_ERR_BAD_ARG;
     if (reduction < D3D_REDUCE_MEAN || reduction > D3D_REDUCE_MIN) return D3D_ERR_UNSUPPORTED;
     if (R >= (1ll << 31)) return D3D_ERR_BAD_ARG;
     if (R > 0 && (!recv || !first_o || !coords || !npoints || !feats || !rec_owned || !lead_rec)) return D3D_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < d3d_owner_merge_workspace_bytes(R, world)) return D3D_ERR_WORKSPACE;
+    MergeOut f{rec_stride(c), (int)c, (int)reduction, (int64_t)shape[1], (int64_t)shape[2], first_o, coords, npoints, feats, lead_rec};
+    if (!merge_on_chains(R, flags)) {
+        RecWs m = carve_rec(workspace, workspace_bytes, R, world);
+        if (R == 0) {
+            D3D_HIP_CHECK(hipMemsetAsync(counts, 0, D3D_NUM_COUNTS * sizeof(int64_t), st));
+            return D3D_OK;
+        }
+        const size_t lds = (size_t)kRecTile * 10 + (size_t)m.nb * 4;
+        D3D_LAUNCH("k_rec_tile_sort", k_rec_tile_sort, dim3(m.ntiles), dim3(kRecTileThreads), lds, st, recv, R, rec_stride(c), m.nb, m.ntiles,
+                   m.ekey, m.eidx, m.table, rec_owned, m.status, m.ftiles + 1, m.overflow, counts, src_off, (int)world, m.src_off);
+        D3D_LAUNCH("k_rec_bucket", k_rec_bucket, dim3(m.nb), dim3(kRecBucketThreads), 0, st, (const u64 *)m.ekey, (const uint32_t *)m.eidx,
+                   (const uint32_t *)m.table, m.ntiles, m.cellrecs, m.rinfo, m.overflow, counts,
+                   (flags & D3D_OWNER_MERGE_TEST_TINY) ? 4u : (uint32_t)kRecBucketCap, c == 4 ? recv : (const int32_t *)nullptr,
+                   (int)reduction, m.minfo, m.mrec);
+        D3D_LAUNCH("k_rec_finish", k_rec_finish, dim3(m.ftiles), dim3(kFinishThreads), 0, st, recv, R, (const uint32_t *)m.rinfo,
+                   (const uint32_t *)m.cellrecs, (const uint32_t *)m.minfo, (const int32_t *)m.mrec, m.status, m.ftiles,
+                   (const uint32_t *)m.overflow, f, rec_owned, counts);
+        return D3D_OK;
+    }
     MergeWs m = carve_merge(workspace, workspace_bytes, R, world);
-    if (!workspace || m.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     D3D_LAUNCH("k_merge_init", k_merge_init, dim3(blocks_for((int64_t)m.cap, 256 * 4)), dim3(256), 0, st, m.slot, m.cap, m.status,
                m.ntiles + 1, counts, src_off, (int)world, m.src_off);
     if (R > 0) {
         D3D_LAUNCH("k_merge_insert", k_merge_insert, dim3(blocks_for(R)), dim3(256), 0, st, recv, R, rec_stride(c), m.slot, m.cap, m.next,
                    m.rec_slot, rec_owned);
-        MergeOut f{rec_stride(c), (int)c, (int)reduction, (int64_t)shape[1], (int64_t)shape[2], first_o, coords, npoints, feats, lead_rec};
         D3D_LAUNCH("k_merge_finish", k_merge_finish, dim3(m.ntiles), dim3(kFinishThreads), 0, st, recv, R, (const MergeSlot *)m.slot,
                    (const uint32_t *)m.next, (const uint32_t *)m.rec_slot, m.status, m.ntiles, f, rec_owned, counts);
     }
     return D3D_OK;
 }
 
-// bit f of bitmap[(n_total + 63) / 64] set for every owned voxel's first point f (the words are cleared here)
+// bit f of bitmap[(n_total + 63) / 64] set for every owned voxel's first point f (the words are cleared here); one word MORE
+// behind them carries this owner's merge status (1 = a bucket overflowed): the SUM all-reduce of the bitmaps then tells every
+// rank whether ANY owner has to repeat (d3d_owner_number raises BIN_OVERFLOW in counts_out[STATUS] on all of them alike)
 extern "C" int d3d_owner_mark_first(const int64_t *first_o, const int64_t *counts_o, int64_t cap_o, int64_t n_total,
                                     uint64_t *bitmap, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (cap_o < 0 || n_total < 0 || !bitmap || !counts_o) return D3D_ERR_BAD_ARG;
-    D3D_HIP_CHECK(hipMemsetAsync(bitmap, 0, (size_t)d3d_divup(n_total > 0 ? n_total : 1, 64) * 8, st));
-    if (cap_o > 0)
-        D3D_LAUNCH("k_first_mark", k_first_mark, dim3(blocks_for(cap_o)), dim3(256), 0, st, first_o, counts_o, n_total, (u64 *)bitmap);
+    const int64_t nw = d3d_divup(n_total > 0 ? n_total : 1, 64);
+    D3D_HIP_CHECK(hipMemsetAsync(bitmap, 0, (size_t)(nw + 1) * 8, st));
+    D3D_LAUNCH("k_first_mark", k_first_mark, dim3(blocks_for(cap_o > 0 ? cap_o : 1)), dim3(256), 0, st, first_o, counts_o, n_total,
+               (u64 *)bitmap, nw);
     return D3D_OK;
 }
 
@@ -779,7 +1282,7 @@ extern "C" size_t d3d_owner_number_workspace_bytes(int64_t n_total)
     return d3d_align_up((size_t)nw * 4) + d3d_align_up((size_t)(d3d_divup(nw, kPrefixTile) + 1) * 8) + 256;
 }
 
-// global_bits = the SUM all-reduce of every owner's d3d_owner_mark_first bitmap (disjoint bit sets: their OR).  vids[i] =
+// global_bits = the SUM all-reduce of every owner's d3d_owner_mark_first bitmap (disjoint bit sets: their OR; + the status word).  vids[i] =
 // global voxel id (first-seen order over the whole frame, voxelize.cpp:119) of owned voxel i; counts_out[D3D_COUNT_VOXELS] =
 // voxels of the whole frame.
 extern "C" int d3d_owner_number(const uint64_t *global_bits, int64_t n_total, const int64_t *first_o, const int64_t *counts_o,
@@ -804,26 +1307,35 @@ extern "C" int d3d_owner_number(const uint64_t *global_bits, int64_t n_total, co
     return D3D_OK;
 }
 
-// dense contract on the owner, after d3d_owner_merge (whose workspace, untouched since, holds the table):
+// dense contract on the owner, after d3d_owner_merge (whose workspace, untouched since, holds the cells' record lists; same flags):
 // recv_rows[*, 4] = the candidate rows received (grouped by source rank; rows_src_off[world + 1], device), a record's last word =
 // offset of its rows inside its batch.  -> voxels[cap_o, max_points, 4] and pmask[cap_o, max_points] of the owned voxels in id order.
 extern "C" int d3d_owner_dense(const int32_t *recv, int64_t R, const float *recv_rows, const int64_t *rows_src_off, int32_t world,
                                int32_t max_points, const int32_t *lead_rec, const int32_t *npoints, const int64_t *counts_o,
                                int64_t cap_o, const void *merge_workspace, size_t merge_workspace_bytes, float *voxels,
-                               uint8_t *pmask, void *stream)
+                               uint8_t *pmask, void *stream, uint32_t flags)
 {
     hipStream_t st = (hipStream_t)stream;
     if (R < 0 || cap_o < 0 || world < 1 || world > kMaxWorld || max_points < 1 || max_points > kDenseCap || !counts_o) return D3D_ERR_BAD_ARG;
     if (cap_o == 0) return D3D_OK;
     if (!recv || !recv_rows || !rows_src_off || !lead_rec || !npoints || !voxels || !pmask) return D3D_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(recv_rows) | reinterpret_cast<uintptr_t>(voxels)) & 15) return D3D_ERR_BAD_ARG;
-    MergeWs m = carve_merge(const_cast<void *>(merge_workspace), merge_workspace_bytes, R, world);
-    if (!merge_workspace || m.bytes > merge_workspace_bytes) return D3D_ERR_WORKSPACE;
+    if (!merge_workspace || merge_workspace_bytes < d3d_owner_merge_workspace_bytes(R, world)) return D3D_ERR_WORKSPACE;
     const uint32_t P = (uint32_t)max_points;
     const int pshift = (P & (P - 1)) == 0 ? __builtin_ctz(P) : -1;
-    D3D_LAUNCH("k_owner_dense", k_owner_dense, dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec, npoints, m.rec_slot,
-               (const MergeSlot *)m.slot, (const uint32_t *)m.next, (const int64_t *)m.src_off, (int)world, recv, rec_stride(4), reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift,
-               reinterpret_cast<float4 *>(voxels), pmask);
+    if (!merge_on_chains(R, flags)) {
+        RecWs m = carve_rec(const_cast<void *>(merge_workspace), merge_workspace_bytes, R, world);
+        D3D_LAUNCH("k_owner_dense", k_owner_dense<true>, dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec, npoints,
+                   (const uint32_t *)nullptr, (const MergeSlot *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)m.rinfo,
+                   (const uint32_t *)m.cellrecs, (const int64_t *)m.src_off, (int)world, recv, rec_stride(4),
+                   reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift, reinterpret_cast<float4 *>(voxels), pmask);
+        return D3D_OK;
+    }
+    MergeWs m = carve_merge(const_cast<void *>(merge_workspace), merge_workspace_bytes, R, world);
+    D3D_LAUNCH("k_owner_dense", k_owner_dense<false>, dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec, npoints,
+               (const uint32_t *)m.rec_slot, (const MergeSlot *)m.slot, (const uint32_t *)m.next, (const uint32_t *)nullptr,
+               (const uint32_t *)nullptr, (const int64_t *)m.src_off, (int)world, recv, rec_stride(4),
+               reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift, reinterpret_cast<float4 *>(voxels), pmask);
     return D3D_OK;
 }
 

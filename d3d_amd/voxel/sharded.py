@@ -308,10 +308,11 @@ class HipOps:
             _lib.check(rc, "owner_pack")
         return send, perm, pos, send_rows, sc
 
-    def owner_merge(self, recv, recv_counts, world, c, reduction, shape):
+    def owner_merge(self, recv, recv_counts, world, c, reduction, shape, flags=0):
         """records grouped by source rank -> this owner's voxels in global id order, finished:
-        first_o, coords, npoints, feats (R rows allocated), rec_owned[R], counts (device; [0] = owned voxels), and a handle
-        (leader records + the table) for owner_dense"""
+        first_o, coords, npoints, feats (R rows allocated), rec_owned[R], counts (device; [0] = owned voxels, [2] = status:
+        BIN_OVERFLOW asks for flags=OWNER_MERGE_CHAINS), and a handle (leader records + the cells' record lists) for
+        owner_dense"""
         lib = _lib.load()
         dev = recv.device
         R = int(recv.shape[0])
@@ -332,14 +333,14 @@ class HipOps:
             rc = lib.d3d_owner_merge(_lib.ptr(recv), R, _lib.ptr(src_off), world, c, int(reduction),
                                      ctypes.cast(shape_h, ctypes.c_void_p), _lib.ptr(first_o), _lib.ptr(coords), _lib.ptr(npoints),
                                      _lib.ptr(feats), _lib.ptr(rec_owned), _lib.ptr(lead), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
-                                     _lib.stream_ptr())
+                                     _lib.stream_ptr(), int(flags))
             _lib.check(rc, "owner_merge")
-        return first_o, coords, npoints, feats, rec_owned, counts, (recv, lead, npoints, counts, ws, world)
+        return first_o, coords, npoints, feats, rec_owned, counts, (recv, lead, npoints, counts, ws, world, int(flags))
 
     def owner_dense(self, handle, recv_rows, recv_row_counts, max_points):
         """the dense contract of the owned voxels (id order): voxels[R, max_points, 4], pmask[R, max_points] uint8"""
         lib = _lib.load()
-        recv, lead, npoints, counts, ws, world = handle
+        recv, lead, npoints, counts, ws, world, flags = handle
         dev = recv.device
         R = int(recv.shape[0])
         off = [0]
@@ -351,16 +352,17 @@ class HipOps:
             pmask = torch.empty((R, max_points), dtype=torch.uint8, device=dev)
             rc = lib.d3d_owner_dense(_lib.ptr(recv), R, _lib.ptr(recv_rows), _lib.ptr(roff), world, int(max_points), _lib.ptr(lead),
                                      _lib.ptr(npoints), _lib.ptr(counts), R, _lib.ptr(ws), ws.numel(), _lib.ptr(voxels),
-                                     _lib.ptr(pmask), _lib.stream_ptr())
+                                     _lib.ptr(pmask), _lib.stream_ptr(), flags)
             _lib.check(rc, "owner_dense")
         return voxels, pmask
 
     def owner_mark_first(self, first_o, counts_o, n_total):
-        """-> int64 words of the bitmap over the frame's point indices with this owner's first points set"""
+        """-> int64 words of the bitmap over the frame's point indices with this owner's first points set, + one word: this
+        owner's merge has to be repeated (summed over the ranks by the same all-reduce)"""
         lib = _lib.load()
         dev = first_o.device
         with torch.cuda.device(dev):
-            bits = torch.empty(((max(n_total, 1) + 63) // 64,), dtype=torch.int64, device=dev)
+            bits = torch.empty(((max(n_total, 1) + 63) // 64 + 1,), dtype=torch.int64, device=dev)
             rc = lib.d3d_owner_mark_first(_lib.ptr(first_o), _lib.ptr(counts_o), first_o.numel(), n_total, _lib.ptr(bits),
                                           _lib.stream_ptr())
             _lib.check(rc, "owner_mark_first")
@@ -451,7 +453,7 @@ class ShardedVoxelGenerator:
     rank order).  Grid arguments as d3d.voxel.VoxelGenerator (bounds, shape); reduction in {mean, max, min}."""
 
     def __init__(self, bounds, shape, reduction="mean", group=None, comm=None, ops=None, exchange="owner", replicate=True,
-                 max_points=None, debug_checks=False):
+                 max_points=None, debug_checks=False, merge_flags=0):
         key = (reduction or "").upper()
         if key not in _REDUCTIONS:
             raise ValueError("Unsupported reduction type in VoxelGenerator!")
@@ -486,6 +488,7 @@ class ShardedVoxelGenerator:
         # owned voxels arrive ordered by their first point, i.e. local voxel ids follow first-seen order, and shards are
         # contiguous point ranges in rank order
         self._debug_checks = bool(debug_checks)
+        self._merge_flags = int(merge_flags)        # d3d_owner_merge's flags (tests: OWNER_MERGE_CHAINS, OWNER_MERGE_TEST_TINY)
         if not self._replicate and exchange != "owner":
             raise ValueError("replicate=False needs exchange='owner'")
         # max_points: also the dense contract's voxels[V, max_points, 4] + voxel_pmask (voxelize.cpp:128-134: the first
@@ -541,7 +544,8 @@ class ShardedVoxelGenerator:
         sc = [int(x) for x in mat[comm.rank][:W]]
         rc = [int(mat[s][comm.rank]) for s in range(W)]
         recv = comm.all_to_all(send[:sum(sc)], sc, rc)
-        first_o, coords, npoints, feats, rec_owned, counts_o, handle = ops.owner_merge(recv, rc, W, c, self._red, self._shape)
+        first_o, coords, npoints, feats, rec_owned, counts_o, handle = ops.owner_merge(
+            recv, rc, W, c, self._red, self._shape, flags=self._merge_flags | (_lib.OWNER_MERGE_CHAINS if plain else 0))
         voxels = pmask = None
         if P:
             rsc = [int(x) for x in mat[comm.rank][W + 1:2 * W + 1]]
@@ -554,6 +558,8 @@ class ShardedVoxelGenerator:
         back = comm.all_to_all(ops.owner_reply(rec_owned, vids), rc, sc)
         gmap = ops.owner_map(map_r, pos_r, back)
         host = torch.stack([counts_out, counts_o]).tolist()     # the host read-back of the output sizes
+        if int(host[0][_lib.COUNT_STATUS]) & _lib.STATUS_BIN_OVERFLOW and not plain:
+            return None        # some owner's merge outgrew a bucket (every rank reads the same word): all redo on the general path
         nvox, nown = int(host[0][_lib.COUNT_VOXELS]), int(host[1][_lib.COUNT_VOXELS])
         words = int(send.shape[1])
         self.last_stats = dict(

@@ -299,23 +299,32 @@ size_t d3d_owner_merge_workspace_bytes(int64_t n_records, int32_t world);
  * (the lowest source rank of a cell holds its first point; the records of one source follow the shard's first-seen order):
  * first_o / coords / npoints / feats (R rows allocated, counts[D3D_COUNT_VOXELS] valid) and rec_owned[R] = owned voxel of
  * every record, lead_rec[R] = leader record of every owned voxel.  reduction: MEAN (sums in rank order, then
- * voxelize.cpp:164's division), MAX, MIN. */
+ * voxelize.cpp:164's division), MAX, MIN.
+ * flags: 0 = up to 2 M records the cells are grouped in LDS, bucket by bucket (three launches, no global atomics); should a
+ * bucket not fit (hashed cells: it does) counts[D3D_COUNT_STATUS] carries D3D_VOXEL_STATUS_BIN_OVERFLOW, nothing else is valid
+ * and the call is to be repeated with D3D_OWNER_MERGE_CHAINS = the general path (a global hash table with a record chain per
+ * cell; taken by itself above 2 M records).  D3D_OWNER_MERGE_TEST_TINY: test hook, buckets overflow at 4 records. */
+enum { D3D_OWNER_MERGE_CHAINS = 1, D3D_OWNER_MERGE_TEST_TINY = 2 };
 int d3d_owner_merge(const int32_t *recv, int64_t n_records, const int64_t *src_off, int32_t world, int32_t c, int32_t reduction,
                     const int32_t *shape, int64_t *first_o, int64_t *coords, int32_t *npoints, float *feats,
-                    int32_t *rec_owned, int32_t *lead_rec, int64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+                    int32_t *rec_owned, int32_t *lead_rec, int64_t *counts, void *workspace, size_t workspace_bytes, void *stream,
+                    uint32_t flags);
 /* dense contract on the owner (voxelize.cpp:128-134: the first max_points points of a voxel by global index = the ranks'
- * candidate rows in rank order): after d3d_owner_merge, with ITS workspace untouched since; recv_rows[*, 4] grouped by source
+ * candidate rows in rank order): after d3d_owner_merge, with ITS workspace untouched since and ITS flags; recv_rows[*, 4] grouped by source
  * rank (rows_src_off[world + 1], device); lead_rec / npoints / counts_o from d3d_owner_merge.
  * -> voxels[cap_o, max_points, 4], pmask[cap_o, max_points] of the owned voxels in id order (max_points <= 256, c == 4). */
 int d3d_owner_dense(const int32_t *recv, int64_t n_records, const float *recv_rows, const int64_t *rows_src_off, int32_t world,
                     int32_t max_points, const int32_t *lead_rec, const int32_t *npoints, const int64_t *counts_o, int64_t cap_o,
-                    const void *merge_workspace, size_t merge_workspace_bytes, float *voxels, uint8_t *pmask, void *stream);
-/* bitmap[(n_total + 63) / 64] <- bit f for every owned voxel's first point f */
+                    const void *merge_workspace, size_t merge_workspace_bytes, float *voxels, uint8_t *pmask, void *stream,
+                    uint32_t flags);
+/* bitmap[(n_total + 63) / 64 + 1] <- bit f for every owned voxel's first point f; the last word = 1 when counts_o carries
+ * BIN_OVERFLOW (d3d_owner_merge), else 0 */
 int d3d_owner_mark_first(const int64_t *first_o, const int64_t *counts_o, int64_t cap_o, int64_t n_total, uint64_t *bitmap,
                          void *stream);
 size_t d3d_owner_number_workspace_bytes(int64_t n_total);
-/* global_bits = SUM all-reduce of all owners' bitmaps.  vids[i] = global voxel id of owned voxel i;
- * counts_out[D3D_COUNT_VOXELS] = voxels of the whole frame. */
+/* global_bits = SUM all-reduce of all owners' bitmaps (with their last word).  vids[i] = global voxel id of owned voxel i;
+ * counts_out[D3D_COUNT_VOXELS] = voxels of the whole frame; counts_out[D3D_COUNT_STATUS] = BIN_OVERFLOW when ANY owner's merge
+ * has to be repeated (every rank sees the same word: they repeat together). */
 int d3d_owner_number(const uint64_t *global_bits, int64_t n_total, const int64_t *first_o, const int64_t *counts_o, int64_t cap_o,
                      int64_t *vids, int64_t *counts_out, void *workspace, size_t workspace_bytes, void *stream);
 /* reply[i] = global voxel id of received record i (returned to the record's source rank by the reverse all-to-all) */

@@ -224,7 +224,7 @@ class NumpyOps:
             send_rows = torch.from_numpy(send_rows)
         return torch.from_numpy(send), torch.from_numpy(full_perm), torch.from_numpy(pos), send_rows, torch.from_numpy(sc)
 
-    def owner_merge(self, recv, recv_counts, world, c, reduction, shape):
+    def owner_merge(self, recv, recv_counts, world, c, reduction, shape, flags=0):
         r = recv.numpy()
         R = len(r)
         keys = np.ascontiguousarray(r[:, 0:2]).view(np.int64).reshape(-1)

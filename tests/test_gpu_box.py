@@ -186,7 +186,8 @@ def test_nms_chained_scan_gives_up_and_hands_over(monkeypatch, scan):
     dense path recomputes the call: same keep mask.  Both scans: the grid's cell scan, the scan of the incoming-list sizes."""
     from d3d_amd import _lib, box, synth
     from d3d_amd.box import box2d_nms
-    b, s = synth.boxes2d_sparse(6000, 81)
+    # (the grid's cell scan only has a second workgroup to wait above 1024 cells: 20 k boxes)
+    b, s = synth.boxes2d_sparse(20000 if scan == "grid cells" else 6000, 81)
     exp = oracle.box2d_nms_hard_candidates(b, s, "rbox", 0.3, 0.1)
     hook = _lib.NMS_TEST_WITHHOLD | (_lib.NMS_GENERAL if scan == "grid cells" else _lib.NMS_BROAD_SWEEP)
     set_opts(nms_flags=hook)

@@ -215,15 +215,20 @@ def test_sharded_hip_kernels_virtual_ranks(world, reduction, exchange, index_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("merge", ["buckets", "chains", "tiny buckets"])
 @pytest.mark.parametrize("world,reduction,empty,P", [(2, "mean", False, 0), (3, "max", True, 4), (8, "min", False, 32),
                                                       (5, "mean", True, 5), (4, "mean", False, 70)])
-def test_owner_computes_without_replication_virtual_ranks(world, reduction, empty, P):
+def test_owner_computes_without_replication_virtual_ranks(world, reduction, empty, P, merge):
     """replicate=False on the real kernels: every rank returns its owned voxels in global id order; together they are the
     single-GPU grid.  Ragged shards, optionally a rank without points; repeated calls give identical bits (the merge runs in
     rank order whatever the arrival order of the records).  P > 0: with the dense contract (voxels / voxel_pmask of the owned
     voxels, bit-exact against the oracle's dense contract of the whole frame; a dense blob so that candidate rows of several
-    ranks compete for a voxel's P slots)."""
+    ranks compete for a voxel's P slots).  merge: the owner's merge on LDS buckets (default), on the global hash table with
+    record chains (the general path), and with buckets that overflow at 4 records (test hook): every rank learns of the
+    overflow from the all-reduced status word and they all repeat on the general path."""
+    from d3d_amd import _lib
     from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
+    mflags = {"buckets": 0, "chains": _lib.OWNER_MERGE_CHAINS, "tiny buckets": _lib.OWNER_MERGE_TEST_TINY}[merge]
     cloud = _cloud(50000, 19)
     cloud[::7, :3] = cloud[::7, :3] * 0.02 + np.array([30, 0, -1], np.float32)      # ~7000 points in a handful of cells
     cuts = np.linspace(0, len(cloud), world + 1).astype(int)
@@ -237,7 +242,7 @@ def test_owner_computes_without_replication_virtual_ranks(world, reduction, empt
         try:
             torch.cuda.set_device(0)
             gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction=reduction, comm=tw.comm(rank), exchange="owner", replicate=False,
-                                        ops=LockedOps(HipOps(), lock), max_points=P or None)
+                                        ops=LockedOps(HipOps(), lock), max_points=P or None, merge_flags=mflags)
             for it in range(2):
                 out[it][rank] = gen(torch.from_numpy(cloud[cuts[rank]:cuts[rank + 1]]).cuda())
         except Exception:  # pragma: no cover
