@@ -1036,7 +1036,10 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
     __shared__ vec4 rowbuf_all[256 / kWave][kDenseCap];
     __shared__ uint32_t off_all[256 / kWave][kWave];
     __shared__ uint16_t kept_all[256 / kWave][kWave];
+    __shared__ int64_t so[kMaxWorld + 1], rso[kMaxWorld + 1];          // records / rows per source rank, exclusive prefixes
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    if (threadIdx.x <= (unsigned)world) { so[threadIdx.x] = src_off[threadIdx.x]; rso[threadIdx.x] = rows_src_off[threadIdx.x]; }
+    __syncthreads();
     vec4 *rowbuf = rowbuf_all[w];
     uint32_t *sh_off = off_all[w];
     uint16_t *sh_kept = kept_all[w];
@@ -1045,9 +1048,10 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
     if (v0 >= Vo) return;                                   // wave-uniform
     const uint32_t nv = Vo - v0 < kWave ? (uint32_t)(Vo - v0) : (uint32_t)kWave;
     const bool mine = (uint32_t)lane < nv;
-    uint32_t head = 0, kept = 0;
+    uint32_t head = 0, kept = 0, lead = 0;
     if (mine) {
-        head = BUCKETS ? rinfo[lead_rec[v0 + lane]] : mslot[rec_slot[lead_rec[v0 + lane]]].head;
+        lead = (uint32_t)lead_rec[v0 + lane];
+        head = BUCKETS ? rinfo[lead] : mslot[rec_slot[lead]].head;
         const uint32_t n = (uint32_t)npoints[v0 + lane];
         kept = n < P ? n : P;
     }
@@ -1076,12 +1080,15 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
                 const int32_t *r = recv + (size_t)ri * RS;
                 const uint32_t nr = (uint32_t)r[4] < P ? (uint32_t)r[4] : P;
                 const uint32_t take = nr < kept - have ? nr : kept - have;
-                const vec4 *src = reinterpret_cast<const vec4 *>(recv_rows) + rows_src_off[record_source(src_off, world, ri)] + (uint32_t)r[RS - 1];
+                const vec4 *src = reinterpret_cast<const vec4 *>(recv_rows) + rso[record_source(so, world, ri)] + (uint32_t)r[RS - 1];
                 for (uint32_t t = 0; t < take; t++) dst[have + t] = src[t];
                 have += take;
             };
-            if (BUCKETS) list_in_order(cellrecs + (head & 0x3fffffu), ((head >> 22) & 0xffu) + 1u, take_rows);
-            else chain_in_order(next, head, take_rows);
+            if (BUCKETS) {
+                const uint32_t L = ((head >> 22) & 0xffu) + 1u;
+                if (L == 1u) take_rows(lead);                           // (the cell's only record is its leader: no list to read)
+                else list_in_order(cellrecs + (head & 0x3fffffu), L, take_rows);
+            } else chain_in_order(next, head, take_rows);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint32_t q1 = jb * P;
