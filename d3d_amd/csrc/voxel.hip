@@ -1284,7 +1284,10 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
 // config 2, i.e. a quarter of the requests of one scattered store per point; frames above 4 M points keep the three-pass
 // partition, where runs would shrink to single entries and the table would outgrow the entries).
 constexpr int kSortThreads = 1024;
-constexpr int64_t kTileSortMaxPoints = 2ll << 20;          // beyond: runs shrink to single entries (4 M points: no gain measured)
+// the one-launch partition up to here; beyond, a bucket's run in a tile shrinks to a single entry and k_bucket_index gathers
+// them one by one (profiles/r04_tile_sort_large.txt: dense 4 M / 8 M points 4 % faster than the three passes, sparse + trim
+// 4 M 11 % faster, 8 M 7 % slower -- its 12-byte entries)
+constexpr int64_t kTileSortMaxPoints = 8ll << 20, kTileSortMaxPointsSparse = 4ll << 20;
 constexpr int kRunCap = 1024;                              // tiles: k_bucket_index keeps the run table in LDS
 
 // kSortItems points per lane: tiles of 1024 * kSortItems points (offsets and run lengths fit 16 bits)
@@ -3188,7 +3191,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     const int tshift = 13;                                     // tiles of 8192 points (4096: profiles/r04_bucket_target.txt)
     const uint32_t stiles = (uint32_t)(w.npad >> tshift);
     uint32_t *table = nullptr, *tileinfo = nullptr, *gpos = reinterpret_cast<uint32_t *>(w.vinfo) + w.npad;
-    if (tile_sort && n <= kTileSortMaxPoints && nbins <= 8192u && stiles <= (uint32_t)kRunCap &&
+    if (tile_sort && n <= (ROWS ? kTileSortMaxPoints : kTileSortMaxPointsSparse) && nbins <= 8192u && stiles <= (uint32_t)kRunCap &&
         ((uint64_t)nbins + 1) * stiles * 4 <= w.cap * 8) {
         table = tilecnt;
         tileinfo = tilecnt + (size_t)nbins * stiles;
