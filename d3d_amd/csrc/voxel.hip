@@ -1491,7 +1491,11 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                       // the point is kept (its voxel passes the filter, its rank is below P when
                                                       // P > 0), else kInf -- all the compaction needs (one scattered store per point
                                                       // here instead of two dependent random reads per point there)
-                                                      uint32_t *__restrict__ pfirst_out)
+                                                      uint32_t *__restrict__ pfirst_out,
+                                                      // ... and the output sizes ahead of the numbering: 64 pairs {voxels that pass
+                                                      // the filter, points they keep (count clamped to early_clamp)}, added up
+                                                      // by the wavefronts (k_meta_first_lb's first tile tells the host)
+                                                      u64 *__restrict__ early_tot = nullptr, uint32_t early_clamp = 0)
 {
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
     typedef typename Key::bin_key_t KT;
@@ -1576,6 +1580,16 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         return seg[kRunCap + lo] + (q - seg[lo]);
     };
 
+    uint32_t early_v = 0, early_p = 0;
+    auto early_publish = [&]() {                            // (workgroup-uniform call sites: all lanes take part in the sum)
+        if (!early_tot) return;
+        const u64 both = wave_sum_u64(((u64)early_v << 32) | early_p);
+        if ((threadIdx.x & (kWave - 1)) == 0 && both) {
+            u64 *dst = early_tot + 2 * (((blockIdx.x << 3) + (threadIdx.x >> 6)) & 63u);
+            (void)__hip_atomic_fetch_add(&dst[0], both >> 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(&dst[1], both & 0xffffffffull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     // phase B of both modes: segments in slot order, one record per voxel, firstmap
     auto records = [&](auto BIG) {
         constexpr int PER = T / kBucketThreads;
@@ -1599,8 +1613,11 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             // bb + j used to sit above this one -- hipcc 7.2 emitted, in one code shape of this kernel, a merged store that
             // wrote the value bb + j at firstmap[bb + j], i.e. the other store's index; found by the big-bucket tests, see
             // DESIGN.md 4a)
-            if (pass) __hip_atomic_store(&firstmap[f], single ? kSingleVoxel : bb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else tfirst[sl] = kInf;             // (its points belong to no kept voxel: what precpos / pfirst_out hand on)
+            if (pass) {
+                __hip_atomic_store(&firstmap[f], single ? kSingleVoxel : bb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                early_v++;
+                early_p += cnt < early_clamp ? cnt : early_clamp;
+            } else tfirst[sl] = kInf;             // (its points belong to no kept voxel: what precpos / pfirst_out hand on)
             if (!single) j++;
             if constexpr (ROWS)
                 if (reduction != D3D_REDUCE_NONE && cnt > P) oslot[atomicAdd(&nover, 1u)] = (uint16_t)sl;
@@ -1743,6 +1760,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         }
         const uint32_t *tbase = seg;
         records(std::true_type{});
+        early_publish();
         __syncthreads();
         uint32_t *sg = gseg + bb;
         for (uint32_t q = threadIdx.x; q < m; q += kBucketThreads) {
@@ -1825,6 +1843,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
     lds_barrier();
     D3D_PHASE(0, 2);                                // entries arrived, inserted
     records(std::false_type{});
+    early_publish();
     lds_barrier();
     D3D_PHASE(0, 3);                                // records
     static_for<ITEMS>([&](auto R) {
@@ -1977,6 +1996,8 @@ struct MetaLb {
     uint32_t next_n;
     unsigned int *next_ticket;
     int64_t *host;          // 2 * D3D_NUM_COUNTS + 1 words (d3d_voxelize_3d_sparse_filter)
+    const u64 *early;       // k_bucket_index's 64 pairs {passing voxels, kept points}: complete when this launch starts
+    uint32_t early_on;
 };
 template <class Key>
 __global__ __launch_bounds__(kMetaLbThreads) void k_meta_first_lb(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
@@ -1990,6 +2011,25 @@ __global__ __launch_bounds__(kMetaLbThreads) void k_meta_first_lb(Key kf, int64_
     const unsigned int tile = lookback_ticket(lb.ticket, &sid);
     const unsigned int ntiles = gridDim.x;
     if (tile == 0) {
+        // the output sizes are known before any voxel has its number -- unless max_voxels cuts the frame short (which voxels
+        // then exist is a matter of the numbering: the last tile reports, as it did for every frame before) -- and the host,
+        // waiting for them to size the outputs, gets them a launch earlier: it returns and enqueues the NEXT frame while this
+        // launch and k_compact_kept (38 us at config 2) run, instead of k_compact_kept (18 us) alone
+        if (lb.host && lb.early_on && threadIdx.x < kWave) {
+            const u64 tv = wave_sum_u64(lb.early[2 * threadIdx.x]), tp = wave_sum_u64(lb.early[2 * threadIdx.x + 1]);
+            if (threadIdx.x == 0 && tv <= (u64)max_voxels) {
+                for (int k = 0; k < D3D_NUM_COUNTS; k++) {
+                    lb.host[k] = counts[k];
+                    lb.host[D3D_NUM_COUNTS + 1 + k] = 0;
+                }
+                lb.host[D3D_COUNT_VOXELS] = (int64_t)tv;
+                lb.host[D3D_COUNT_AUX] = 0;
+                lb.host[D3D_NUM_COUNTS + 1 + D3D_COUNT_VOXELS] = (int64_t)tv;
+                lb.host[D3D_NUM_COUNTS + 1 + D3D_COUNT_POINTS] = (int64_t)tp;
+                __threadfence_system();
+                __hip_atomic_store(&lb.host[D3D_NUM_COUNTS], (int64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         for (uint32_t t = threadIdx.x; t < lb.next_n; t += kMetaLbThreads) lb.next_stat[t] = 0ull;
         if (threadIdx.x == 0) *lb.next_ticket = 0u;
     }
@@ -2053,7 +2093,7 @@ __global__ __launch_bounds__(kMetaLbThreads) void k_meta_first_lb(Key kf, int64_
         const int64_t nvox = (int64_t)(all < max_voxels ? all : max_voxels);
         counts[D3D_COUNT_VOXELS] = nvox;
         counts[D3D_COUNT_AUX] = 0;
-        if (lb.host) {
+        if (lb.host && !(lb.early_on && all <= (u64)max_voxels)) {          // (else the first tile has told the host)
             for (int k = 0; k < D3D_NUM_COUNTS; k++) {
                 lb.host[k] = counts[k];
                 lb.host[D3D_NUM_COUNTS + 1 + k] = 0;
@@ -3179,10 +3219,11 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     // fused sparse + filter: numbering + per-voxel outputs + output sizes in one launch (k_meta_first_lb)
     const bool meta_lb = o.map_later;
     const uint32_t mtiles = (uint32_t)(w.npad / kMetaLbTile);
-    MetaLb mlb{w.fwords /* npad / 64 words of the hash path, 2 * npad / 4096 used */, w.big_count + 40, o.compact_stat, o.compact_tiles,
-               w.big_count + 41, o.early_host};
+    MetaLb mlb{w.fwords /* npad / 64 words of the hash path, 2 * npad / 4096 + 128 used */, w.big_count + 40, o.compact_stat, o.compact_tiles,
+               w.big_count + 41, o.early_host, w.fwords + 2 * mtiles, o.early_host ? 1u : 0u};
     u64 *zero_words = meta_lb ? mlb.stat : nullptr;
-    const uint32_t nzero = 2 * mtiles;
+    const uint32_t nzero = 2 * mtiles + 128;
+    u64 *early_tot = meta_lb && o.early_host ? w.fwords + 2 * mtiles : nullptr;
     unsigned int *zero_ticket = meta_lb ? mlb.ticket : nullptr;
     x.voff = o.seg_out ? o.seg_out : (o.lists ? w.voff : nullptr);
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
@@ -3232,17 +3273,19 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    reinterpret_cast<const typename BinEntry<false>::type *>(bent), p4, bucket_base, hshift, o.P, (int)D3D_REDUCE_NONE,
                    w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
-                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr);
+                   o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr,
+                   early_tot, x.npoints_clamp);
     else if (ROWS && (o.emit_voxels || o.emit_reduce))
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, true, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
                    counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list /* the per-point keys are
-                   done with it; w.unsorted may be precpos */, (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr);
+                   done with it; w.unsorted may be precpos */, (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr,
+                   early_tot, x.npoints_clamp);
     else
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
                    precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                   table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr);
+                   table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr, early_tot, x.npoints_clamp);
     if constexpr (!ROWS) {
         if (meta_lb) {
             D3D_LAUNCH("k_meta_first_lb", k_meta_first_lb<Key>, dim3(mtiles), dim3(kMetaLbThreads), 0, st, kf, w.npad, firstmap, vrec,
