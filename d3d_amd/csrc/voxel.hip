@@ -1495,7 +1495,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                       // ... and the output sizes ahead of the numbering: 64 pairs {voxels that pass
                                                       // the filter, points they keep (count clamped to early_clamp)}, added up
                                                       // by the wavefronts (k_meta_first_lb's first tile tells the host)
-                                                      u64 *__restrict__ early_tot = nullptr, uint32_t early_clamp = 0)
+                                                      u64 *__restrict__ early_tot = nullptr, uint32_t early_clamp = 0,
+                                                      uint32_t early_mask = 0 /* pairs - 1; one pair per 128-byte line */)
 {
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
     typedef typename Key::bin_key_t KT;
@@ -1585,7 +1586,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         if (!early_tot) return;
         const u64 both = wave_sum_u64(((u64)early_v << 32) | early_p);
         if ((threadIdx.x & (kWave - 1)) == 0 && both) {
-            u64 *dst = early_tot + 2 * (((blockIdx.x << 3) + (threadIdx.x >> 6)) & 63u);
+            // (a pair per 128-byte line: atomics on one line serialise in its L2 channel -- 64 pairs packed into 16 lines made
+            // this kernel 8 us slower at config 2)
+            u64 *dst = early_tot + 16 * (((blockIdx.x << 3) + (threadIdx.x >> 6)) & early_mask);
             (void)__hip_atomic_fetch_add(&dst[0], both >> 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             (void)__hip_atomic_fetch_add(&dst[1], both & 0xffffffffull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1996,8 +1999,8 @@ struct MetaLb {
     uint32_t next_n;
     unsigned int *next_ticket;
     int64_t *host;          // 2 * D3D_NUM_COUNTS + 1 words (d3d_voxelize_3d_sparse_filter)
-    const u64 *early;       // k_bucket_index's 64 pairs {passing voxels, kept points}: complete when this launch starts
-    uint32_t early_on;
+    const u64 *early;       // k_bucket_index's pairs {passing voxels, kept points}, one per 16 words: complete when this launch starts
+    uint32_t early_pairs;   // 0 = off
 };
 template <class Key>
 __global__ __launch_bounds__(kMetaLbThreads) void k_meta_first_lb(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
@@ -2015,8 +2018,9 @@ __global__ __launch_bounds__(kMetaLbThreads) void k_meta_first_lb(Key kf, int64_
         // then exist is a matter of the numbering: the last tile reports, as it did for every frame before) -- and the host,
         // waiting for them to size the outputs, gets them a launch earlier: it returns and enqueues the NEXT frame while this
         // launch and k_compact_kept (38 us at config 2) run, instead of k_compact_kept (18 us) alone
-        if (lb.host && lb.early_on && threadIdx.x < kWave) {
-            const u64 tv = wave_sum_u64(lb.early[2 * threadIdx.x]), tp = wave_sum_u64(lb.early[2 * threadIdx.x + 1]);
+        if (lb.host && lb.early_pairs && threadIdx.x < kWave) {
+            const bool have = threadIdx.x < lb.early_pairs;
+            const u64 tv = wave_sum_u64(have ? lb.early[16 * threadIdx.x] : 0ull), tp = wave_sum_u64(have ? lb.early[16 * threadIdx.x + 1] : 0ull);
             if (threadIdx.x == 0 && tv <= (u64)max_voxels) {
                 for (int k = 0; k < D3D_NUM_COUNTS; k++) {
                     lb.host[k] = counts[k];
@@ -2093,7 +2097,7 @@ __global__ __launch_bounds__(kMetaLbThreads) void k_meta_first_lb(Key kf, int64_
         const int64_t nvox = (int64_t)(all < max_voxels ? all : max_voxels);
         counts[D3D_COUNT_VOXELS] = nvox;
         counts[D3D_COUNT_AUX] = 0;
-        if (lb.host && !(lb.early_on && all <= (u64)max_voxels)) {          // (else the first tile has told the host)
+        if (lb.host && !(lb.early_pairs && all <= (u64)max_voxels)) {          // (else the first tile has told the host)
             for (int k = 0; k < D3D_NUM_COUNTS; k++) {
                 lb.host[k] = counts[k];
                 lb.host[D3D_NUM_COUNTS + 1 + k] = 0;
@@ -3219,11 +3223,16 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     // fused sparse + filter: numbering + per-voxel outputs + output sizes in one launch (k_meta_first_lb)
     const bool meta_lb = o.map_later;
     const uint32_t mtiles = (uint32_t)(w.npad / kMetaLbTile);
-    MetaLb mlb{w.fwords /* npad / 64 words of the hash path, 2 * npad / 4096 + 128 used */, w.big_count + 40, o.compact_stat, o.compact_tiles,
-               w.big_count + 41, o.early_host, w.fwords + 2 * mtiles, o.early_host ? 1u : 0u};
+    // (w.fwords: npad / 64 words of the hash path; here 2 * npad / 4096 look-back words, then, from the next multiple of 16
+    // words on, up to 64 pairs of early totals at 16 words each -- as many as fit, a power of two)
+    const uint32_t early_at = (2 * mtiles + 15u) & ~15u;
+    uint32_t early_pairs = 0;
+    if (meta_lb && o.early_host)
+        for (early_pairs = 64; early_pairs > 1 && (uint64_t)early_at + 16ull * early_pairs > (uint64_t)(w.npad / 64); early_pairs >>= 1) { }
+    MetaLb mlb{w.fwords, w.big_count + 40, o.compact_stat, o.compact_tiles, w.big_count + 41, o.early_host, w.fwords + early_at, early_pairs};
     u64 *zero_words = meta_lb ? mlb.stat : nullptr;
-    const uint32_t nzero = 2 * mtiles + 128;
-    u64 *early_tot = meta_lb && o.early_host ? w.fwords + 2 * mtiles : nullptr;
+    const uint32_t nzero = early_at + 16u * early_pairs;
+    u64 *early_tot = early_pairs ? w.fwords + early_at : nullptr;
     unsigned int *zero_ticket = meta_lb ? mlb.ticket : nullptr;
     x.voff = o.seg_out ? o.seg_out : (o.lists ? w.voff : nullptr);
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
@@ -3274,18 +3283,18 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
                    reinterpret_cast<const typename BinEntry<false>::type *>(bent), p4, bucket_base, hshift, o.P, (int)D3D_REDUCE_NONE,
                    w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
                    o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr,
-                   early_tot, x.npoints_clamp);
+                   early_tot, x.npoints_clamp, early_pairs ? early_pairs - 1u : 0u);
     else if (ROWS && (o.emit_voxels || o.emit_reduce))
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, true, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
                    counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list /* the per-point keys are
                    done with it; w.unsorted may be precpos */, (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr,
-                   early_tot, x.npoints_clamp);
+                   early_tot, x.npoints_clamp, early_pairs ? early_pairs - 1u : 0u);
     else
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap, counts,
                    precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                   table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr, early_tot, x.npoints_clamp);
+                   table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr, early_tot, x.npoints_clamp, early_pairs ? early_pairs - 1u : 0u);
     if constexpr (!ROWS) {
         if (meta_lb) {
             D3D_LAUNCH("k_meta_first_lb", k_meta_first_lb<Key>, dim3(mtiles), dim3(kMetaLbThreads), 0, st, kf, w.npad, firstmap, vrec,
