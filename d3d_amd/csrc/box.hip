@@ -1459,8 +1459,13 @@ __global__ __launch_bounds__(256) void k_nms_incscan(const uint32_t *__restrict_
 // pass B: the hits into the boxes' segments
 __global__ __launch_bounds__(256) void k_nms_fill(const unsigned long long *__restrict__ list, unsigned long long cap,
                                                   const NmsCand *hdr, const uint32_t *__restrict__ inc_off,
-                                                  const uint32_t *__restrict__ arrival, uint32_t *__restrict__ inc)
+                                                  const uint32_t *__restrict__ arrival, uint32_t *__restrict__ inc,
+                                                  const NmsFlags *flags)
 {
+    // (the dense path has taken over -- possibly because k_nms_incscan GAVE UP, and then inc_off holds whatever an earlier call
+    // left in the workspace: storing through it wrote out of bounds.  Found in round 4 when the give-up test first ran behind a
+    // call of another size; rounds 2-3 were lucky with their workspace history)
+    if (flags->need_sweep) return;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / kNmsListSegs;
     for (int sg = 0; sg < kNmsListSegs; sg++) {
     const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
@@ -2088,7 +2093,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     D3D_LAUNCH("k_nms_incscan", k_nms_incscan, dim3((unsigned)d3d_divup(n, kIncTile)), dim3(256), 0, st, (const uint32_t *)inc_cnt, n,
                inc_off, tile_tot, tickets, flags, (opts & D3D_NMS_TEST_WITHHOLD) != 0 && (opts & D3D_NMS_BROAD_SWEEP) != 0);
     D3D_LAUNCH("k_nms_fill", k_nms_fill, dim3(hits_blocks), dim3(256), 0, st, (const unsigned long long *)cand, cap,
-               (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, (const uint32_t *)arrival, inc);
+               (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, (const uint32_t *)arrival, inc, (const NmsFlags *)flags);
     D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,
                (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, flags, order, suppressed);
     // dense path, gated on need_sweep inside the kernels
