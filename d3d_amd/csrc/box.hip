@@ -556,6 +556,8 @@ __global__ __launch_bounds__(256) void k_iou3d_clip(const BoxGeom<float> *__rest
 extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int32_t *order, void *ws, size_t ws_bytes,
                                              hipStream_t st);      // sort.hip
 extern "C" size_t d3d_internal_argsort_i32_bytes(int64_t n);
+extern "C" int d3d_internal_crop2dr_grid_f32(const float *points, int64_t n, const float *boxes, int64_t m, uint8_t *out,
+                                             hipStream_t st);      // crop.hip
 
 enum { kUndecided = 0, kKept = 1, kSuppressed = 2 };
 constexpr int kIncTile = 1024;      // boxes per workgroup of k_nms_incscan
@@ -2618,6 +2620,10 @@ extern "C" int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, in
     if (n == 0 || m == 0) return D3D_OK;
     if (!points || !boxes || !out) return D3D_ERR_BAD_ARG;
     if (d3d_divup(m, kTileRows) > 65535) return D3D_ERR_BAD_ARG;
+    if (dtype == D3D_F32) {          // fp32, up to 4096 boxes: a box grid per workgroup, only the hits are stored (crop.hip)
+        const int rc = d3d_internal_crop2dr_grid_f32((const float *)points, n, (const float *)boxes, m, out, st);
+        if (rc != D3D_ERR_UNSUPPORTED) return rc;
+    }
     dim3 grid((unsigned)d3d_divup(n, 256 * 4), (unsigned)d3d_divup(m, kTileRows));
     if (dtype == D3D_F64)
         D3D_LAUNCH("k_crop2dr", k_crop2dr<double>, grid, dim3(256), 0, st, (const double *)points, n, (const double *)boxes, m, out);

@@ -177,8 +177,13 @@ __device__ __forceinline__ int grid_axis(float x, float o, float inv, int n)
     return t > 0.f ? (int)t : 0;                // (NaN -> 0)
 }
 
+// where (x, y) = columns 0, 1 of a box row keep their extents and their angle: 3-D rows (x, y, z, lx, ly, lz, rz), 2-D rows
+// (x, y, w, h, r) of crop_2dr
+struct BoxCols { int w, h, r; };
+constexpr BoxCols kCols3{3, 4, 6}, kCols2{2, 3, 4};
+
 // whole workgroup; m <= kGridMaxBoxes
-__device__ void build_box_grid(BoxGrid &G, const float *__restrict__ boxes, int64_t m, int bstride, int boff)
+__device__ void build_box_grid(BoxGrid &G, const float *__restrict__ boxes, int64_t m, int bstride, int boff, BoxCols cols = kCols3)
 {
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     float lo_x = INFINITY, lo_y = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY;
@@ -186,9 +191,9 @@ __device__ void build_box_grid(BoxGrid &G, const float *__restrict__ boxes, int6
     for (int i = threadIdx.x; i < (int)m; i += kGridThreads) {
         const float *b = boxes + (size_t)i * bstride + boff;
         float sn, cn;
-        d3d_sincos(b[6], &sn, &cn);
+        d3d_sincos(b[cols.r], &sn, &cn);
         G.cs[i] = make_float2(cn, sn);
-        const BoxGeom<float> g = make_geom_cs<float>(b[0], b[1], b[3], b[4], cn, sn);
+        const BoxGeom<float> g = make_geom_cs<float>(b[0], b[1], b[cols.w], b[cols.h], cn, sn);
         if (!(g.xmin >= -3.0e38f && g.ymin >= -3.0e38f && g.xmax <= 3.0e38f && g.ymax <= 3.0e38f)) { bad = true; continue; }
         lo_x = fminf(lo_x, g.xmin); lo_y = fminf(lo_y, g.ymin); hi_x = fmaxf(hi_x, g.xmax); hi_y = fmaxf(hi_y, g.ymax);
     }
@@ -225,7 +230,7 @@ __device__ void build_box_grid(BoxGrid &G, const float *__restrict__ boxes, int6
         bool over = false;
         for (int i = threadIdx.x; i < (int)m; i += kGridThreads) {
             const float *b = boxes + (size_t)i * bstride + boff;
-            const BoxGeom<float> g = make_geom_cs<float>(b[0], b[1], b[3], b[4], G.cs[i].x, G.cs[i].y);
+            const BoxGeom<float> g = make_geom_cs<float>(b[0], b[1], b[cols.w], b[cols.h], G.cs[i].x, G.cs[i].y);
             const int x0 = grid_axis(g.xmin, G.ox, G.ix, gn), x1 = grid_axis(g.xmax, G.ox, G.ix, gn);
             const int y0 = grid_axis(g.ymin, G.oy, G.iy, gn), y1 = grid_axis(g.ymax, G.oy, G.iy, gn);
             if ((x1 - x0 + 1) * (y1 - y0 + 1) > kGridBoxCells) { over = true; continue; }
@@ -254,7 +259,7 @@ __device__ void build_box_grid(BoxGrid &G, const float *__restrict__ boxes, int6
     __syncthreads();
     for (int i = threadIdx.x; i < (int)m; i += kGridThreads) {
         const float *b = boxes + (size_t)i * bstride + boff;
-        const BoxGeom<float> g = make_geom_cs<float>(b[0], b[1], b[3], b[4], G.cs[i].x, G.cs[i].y);
+        const BoxGeom<float> g = make_geom_cs<float>(b[0], b[1], b[cols.w], b[cols.h], G.cs[i].x, G.cs[i].y);
         const int x0 = grid_axis(g.xmin, G.ox, G.ix, G.n), x1 = grid_axis(g.xmax, G.ox, G.ix, G.n);
         const int y0 = grid_axis(g.ymin, G.oy, G.iy, G.n), y1 = grid_axis(g.ymax, G.oy, G.iy, G.n);
         for (int cy = y0; cy <= y1; cy++)
@@ -318,7 +323,37 @@ __global__ __launch_bounds__(kGridThreads) void k_crop3dr_grid(const float *__re
     }
 }
 
+// crop_2dr on fp32 inputs through the same grid: points[n, 2], boxes[m, 5] = (x, y, w, h, r); the geometry of a candidate is
+// make_geom_cs on the cached cos / sin = the numbers Box2D<float>::load gives k_crop2dr (same expressions), the test is the
+// same quad_contains: same bits
+__global__ __launch_bounds__(kGridThreads) void k_crop2dr_grid(const float *__restrict__ points, int64_t n,
+                                                               const float *__restrict__ boxes, int64_t m, uint8_t *__restrict__ out)
+{
+    __shared__ BoxGrid G;
+    build_box_grid(G, boxes, m, 5, 0, kCols2);
+    const int64_t j0 = (int64_t)blockIdx.x * (kGridThreads * kGridPts) + threadIdx.x;
+    for (int k = 0; k < kGridPts; k++) {
+        const int64_t j = j0 + (int64_t)k * kGridThreads;
+        if (j >= n) break;
+        const float x = points[j * 2], y = points[j * 2 + 1];
+        for_candidates(G, m, x, y, [&](int i) {
+            const float *b = boxes + (size_t)i * 5;
+            if (quad_contains<float>(make_geom_cs<float>(b[0], b[1], b[2], b[3], G.cs[i].x, G.cs[i].y), x, y)) out[(size_t)i * n + j] = 1;
+        });
+    }
+}
+
 }  // namespace
+
+// d3d_crop_2dr's fp32 path for up to kGridMaxBoxes boxes (box.hip): zeros at the memset's rate, then the hits
+extern "C" int d3d_internal_crop2dr_grid_f32(const float *points, int64_t n, const float *boxes, int64_t m, uint8_t *out, hipStream_t st)
+{
+    if (m > kGridMaxBoxes || n < 4096) return D3D_ERR_UNSUPPORTED;
+    D3D_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)m * (size_t)n, st));
+    D3D_LAUNCH("k_crop2dr_grid", k_crop2dr_grid, dim3((unsigned)d3d_divup(n, kGridThreads * kGridPts)), dim3(kGridThreads), 0, st, points, n,
+               boxes, m, out);
+    return D3D_OK;
+}
 
 // bool[M,N] indicators of box3dr_contains (dgal_wrap.h:6-19) over boxes x points (Target3DArray.crop_points,
 // abstraction.pyx:654-660, 684-687).  points[n, point_stride >= 3] f32 (x, y, z first), box row i = 7 floats
