@@ -1114,19 +1114,51 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
         if ((uint32_t)lane >= ja && (uint32_t)lane < jb) {  // my voxel's rows, in rank order of the contributing records
             vec4 *dst = rowbuf + (off - oa);
             uint32_t have = 0;
-            auto take_rows = [&](uint32_t ri) {
+            auto take_known = [&](uint32_t ri, uint32_t rcnt, uint32_t roff) {      // record ri holds rcnt points, its rows start at roff
                 if (have >= kept) return;
-                const int32_t *r = recv + (size_t)ri * RS;
-                const uint32_t nr = (uint32_t)r[4] < P ? (uint32_t)r[4] : P;
+                const uint32_t nr = rcnt < P ? rcnt : P;
                 const uint32_t take = nr < kept - have ? nr : kept - have;
-                const vec4 *src = reinterpret_cast<const vec4 *>(recv_rows) + rso[record_source(so, world, ri)] + (uint32_t)r[RS - 1];
+                const vec4 *src = reinterpret_cast<const vec4 *>(recv_rows) + rso[record_source(so, world, ri)] + roff;
                 for (uint32_t t = 0; t < take; t++) dst[have + t] = src[t];
                 have += take;
             };
+            auto take_rows = [&](uint32_t ri) {
+                const int32_t *r = recv + (size_t)ri * RS;
+                take_known(ri, (uint32_t)r[4], (uint32_t)r[RS - 1]);
+            };
             if (BUCKETS) {
                 const uint32_t L = ((head >> 22) & 0xffu) + 1u;
+                const uint32_t *list = cellrecs + (head & 0x3fffffu);
                 if (L == 1u) take_rows(lead);                           // (the cell's only record is its leader: no list to read)
-                else list_in_order(cellrecs + (head & 0x3fffffu), L, take_rows);
+                else if (L <= 8u) {
+                    // the list sorted in registers, the records' counts and row offsets loaded TOGETHER, then taken in rank order:
+                    // two round trips whatever the length (walking the list by repeated selection, a load per step, was 52 of
+                    // this kernel's 147 us at config 5: every wavefront waits for its longest cell)
+                    uint32_t e[8], rc[4], ro[4];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) e[q] = (uint32_t)q < L ? list[q] : ~0u;
+#define D3D_CE(a, b) { const uint32_t lo_ = e[a] < e[b] ? e[a] : e[b], hi_ = e[a] < e[b] ? e[b] : e[a]; e[a] = lo_; e[b] = hi_; }
+                    D3D_CE(0, 1) D3D_CE(2, 3) D3D_CE(4, 5) D3D_CE(6, 7)
+                    D3D_CE(0, 2) D3D_CE(1, 3) D3D_CE(4, 6) D3D_CE(5, 7)
+                    D3D_CE(1, 2) D3D_CE(5, 6)
+                    D3D_CE(0, 4) D3D_CE(1, 5) D3D_CE(2, 6) D3D_CE(3, 7)
+                    D3D_CE(2, 4) D3D_CE(3, 5)
+                    D3D_CE(1, 2) D3D_CE(3, 4) D3D_CE(5, 6)
+#undef D3D_CE
+#pragma unroll
+                    for (int h = 0; h < 8; h += 4) {        // four records' fields in flight at a time (eight: 102 VGPRs, half the occupancy)
+                        if (h == 4 && e[4] == ~0u) break;
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (e[h + q] != ~0u) {
+                                const int32_t *r = recv + (size_t)e[h + q] * RS;
+                                rc[q] = (uint32_t)r[4]; ro[q] = (uint32_t)r[RS - 1];
+                            }
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (e[h + q] != ~0u) take_known(e[h + q], rc[q], ro[q]);
+                    }
+                } else list_in_order(list, L, take_rows);
             } else chain_in_order(next, head, take_rows);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
