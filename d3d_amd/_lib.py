@@ -73,7 +73,7 @@ SIGNATURES = {
     "d3d_owner_record_words": (ctypes.c_int, [_i32]),
     "d3d_owner_pack_workspace_bytes": (_sz, [_i64, _i32]),
     "d3d_owner_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                      _vp, _sz, _vp]),
+                                      _vp, _sz, _vp, _vp, _i64]),
     "d3d_owner_merge_workspace_bytes": (_sz, [_i64, _i32]),
     "d3d_owner_merge": (ctypes.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32]),
     "d3d_owner_dense": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp, _vp, _u32]),

@@ -45,7 +45,11 @@ __host__ __device__ inline int rec_stride(int c) { return (5 + c + 1) & ~1; }
 struct PackDense {
     uint32_t P;
     const uint32_t *seg_base;     // [n] first row of every local voxel in rows_local
-    const float4 *rows_local;
+    const float4 *rows_local;     // the staged rows -- or, when counts[D3D_COUNT_AUX] == 1 (d3d_voxelize_3d_reduce on the binned
+                                  // index), uint32 ranked point indices: row k >= 1 of voxel i = points4[ranked[seg_base[i] + k]],
+                                  // row 0 = its first point points4[first[i] - index_offset]
+    const float4 *points4;        // the shard's points (ranked mode)
+    int64_t index_offset;
     float4 *send_rows;
     uint32_t *tilerows;           // [ntiles][world] rows per tile and destination -> exclusive prefix over the tiles
     uint32_t *dest_rowbase;       // [world + 1]
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(1024) void k_owner_scatter(const int64_t *__restric
     __shared__ uint32_t f_before[kMaxWorld], f_total[kMaxWorld], f_rbefore[kMaxWorld], f_rtotal[kMaxWorld], f_base[kMaxWorld + 1],
         f_rbase[kMaxWorld + 1];
     const int64_t V = counts[D3D_COUNT_VOXELS];
+    const bool ranked = DENSE && pd.points4 && counts[D3D_COUNT_AUX] == 1;
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     const int RS = rec_stride(c);
     if (threadIdx.x < kMaxWorld) {
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(1024) void k_owner_scatter(const int64_t *__restric
         const uint32_t d = ok ? owner_of(key, world) : 0xffffffffu;
         const uint32_t nc = ok ? (uint32_t)cnt[i] : 0u;
         const uint32_t kept = DENSE ? (nc < pd.P ? nc : pd.P) : 0u;
-        uint32_t myrank = 0, myrows = 0, rsrc = 0, rdst = 0;
+        uint32_t myrank = 0, myrows = 0, rsrc = 0, rdst = 0, rfirst = 0;
         for (uint32_t q = 0; q < world; q++) {               // wave-uniform
             const u64 b = __ballot(d == q);
             if (d == q) myrank = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(1024) void k_owner_scatter(const int64_t *__restric
                 const uint32_t inbatch = (fused_tiles ? f_rbefore[d] : pd.tilerows[tidx]) + rbefore + myrows;   // offset inside the (me -> d) row batch
                 r[RS - 1] = (int32_t)inbatch;
                 rsrc = pd.seg_base[i];
+                rfirst = (uint32_t)(first[i] - pd.index_offset);
                 rdst = (fused_tiles ? f_rbase[d] : pd.dest_rowbase[d]) + inbatch;
             }
         }
@@ -246,9 +252,13 @@ __global__ __launch_bounds__(1024) void k_owner_scatter(const int64_t *__restric
                 }
                 const uint32_t own_incl = (uint32_t)__shfl((int)incl, lo, kWave), own_kept = (uint32_t)__shfl((int)kept, lo, kWave);
                 const uint32_t s0 = (uint32_t)__shfl((int)rsrc, lo, kWave), d0 = (uint32_t)__shfl((int)rdst, lo, kWave);
+                const uint32_t f0 = (uint32_t)__shfl((int)rfirst, lo, kWave);
                 if (j < wtotal) {
                     const uint32_t t = j - (own_incl - own_kept);
-                    pd.send_rows[d0 + t] = pd.rows_local[s0 + t];
+                    if (ranked) {
+                        const uint32_t idx = t == 0 ? f0 : reinterpret_cast<const uint32_t *>(pd.rows_local)[s0 + t];
+                        pd.send_rows[d0 + t] = pd.points4[idx];
+                    } else pd.send_rows[d0 + t] = pd.rows_local[s0 + t];
                 }
             }
         }
@@ -1237,12 +1247,14 @@ extern "C" size_t d3d_owner_pack_workspace_bytes(int64_t n, int32_t world)
 // owner rank: send[n, d3d_owner_record_words(c)] (int32 words), perm[n] (send position -> local voxel), pos_of_local[n] (its inverse),
 // send_counts[2 world + 1] (device): records per destination, the shard's status bits, rows per destination.
 // Dense contract (max_points > 0; c == 4): seg_base / rows_local as left by d3d_voxelize_3d_reduce(max_points, ...) ->
-// send_rows[kept rows, 4] with the same grouping; a record's last word = offset of its rows inside its batch.
+// send_rows[kept rows, 4] with the same grouping; a record's last word = offset of its rows inside its batch.  `points` /
+// `index_offset` = the shard d3d_voxelize_3d_reduce saw: when that call left ranked point indices instead of rows (its counts say
+// so) the rows are gathered from the points here; NULL: rows_local must hold rows.
 extern "C" int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const float *agg, const int64_t *first,
                               const int64_t *counts, int64_t n, int32_t c, int32_t world, int32_t max_points,
                               const uint32_t *seg_base, const float *rows_local, int32_t *send, int32_t *perm,
                               int32_t *pos_of_local, float *send_rows, int64_t *send_counts, void *workspace,
-                              size_t workspace_bytes, void *stream)
+                              size_t workspace_bytes, void *stream, const float *points, int64_t index_offset)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !send_counts || max_points < 0) return D3D_ERR_BAD_ARG;
@@ -1257,8 +1269,9 @@ extern "C" int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const flo
     uint32_t *dest_base = w.take<uint32_t>(world + 1);
     uint32_t *tilerows = w.take<uint32_t>((size_t)ntiles * world);
     uint32_t *dest_rowbase = w.take<uint32_t>(world + 1);
-    PackDense pd{(uint32_t)max_points, seg_base, reinterpret_cast<const float4 *>(rows_local), reinterpret_cast<float4 *>(send_rows),
-                 tilerows, dest_rowbase};
+    if (points && (reinterpret_cast<uintptr_t>(points) & 15)) return D3D_ERR_BAD_ARG;
+    PackDense pd{(uint32_t)max_points, seg_base, reinterpret_cast<const float4 *>(rows_local), reinterpret_cast<const float4 *>(points),
+                 index_offset, reinterpret_cast<float4 *>(send_rows), tilerows, dest_rowbase};
     if (n > 0) {
         if (dense) D3D_LAUNCH("k_owner_count", k_owner_count<true>, dim3(ntiles), dim3(1024), 0, st, keys, cnt, counts, (uint32_t)world, tilecnt, pd);
         else D3D_LAUNCH("k_owner_count", k_owner_count<false>, dim3(ntiles), dim3(1024), 0, st, keys, cnt, counts, (uint32_t)world, tilecnt, pd);

@@ -1080,6 +1080,7 @@ struct BinnedExtras {
     int32_t *count_out = nullptr;    // fused sparse + filter, DESCENDING: [V] the voxel's point count, unclamped (the sort key)
     bool has_coord_sub = false;      // fused sparse + filter: coords - offset (VoxelGenerator.__call__, voxel/__init__.py:103)
     long long coord_sub[3] = {0, 0, 0};
+    int64_t aux_value = 0;           // what k_emit leaves in counts[D3D_COUNT_AUX] (d3d_voxelize_3d_reduce: 1 = ranked index lists)
 };
 
 // sparse contract fused with the voxel filter (d3d_voxelize_3d_sparse_filter): only voxels that pass get a first-point
@@ -2169,7 +2170,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     }
     if (i == 0) {
         counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
-        counts[D3D_COUNT_AUX] = 0;
+        counts[D3D_COUNT_AUX] = x.aux_value;
         // sharded voxelizer: the status bits travel with the key list (row `status_row`, negative = not a cell)
         if (x.keys_out && x.status_row >= 0) x.keys_out[x.status_row] = -1 - counts[D3D_COUNT_STATUS];
         if (host_counts) notify_host(counts, host_counts);
@@ -3643,10 +3644,7 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
     const uint32_t P = max_points > 0 ? (uint32_t)max_points : 32u;
     const bool agg4 = (c == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(aggregates) & 15) == 0);
-    if (rows) {
-        if (!agg4 || (reinterpret_cast<uintptr_t>(rows) & 15)) return D3D_ERR_UNSUPPORTED;    // staged rows are float4
-        w.staged = reinterpret_cast<float4 *>(rows);
-    }
+    if (rows && (!agg4 || (reinterpret_cast<uintptr_t>(rows) & 15))) return D3D_ERR_UNSUPPORTED;    // staged rows are float4
     const float4 *p4 = reinterpret_cast<const float4 *>(points);
     uint32_t nbins = 0;
     int hshift = 0;
@@ -3654,9 +3652,18 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
         DenseOut d{P, 0xffffffffu, reduction, true, false, coords, npoints, nullptr, aggregates,
                    BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr, nullptr}, mapping};
         d.seg_out = seg_base;
-        d.emit_reduce = !rows && P <= (uint32_t)kEmitCap && !(flags & D3D_VOXEL_SPLIT_FILL);     // (rows: the index stages them)
+        d.emit_reduce = P <= (uint32_t)kEmitCap && !(flags & D3D_VOXEL_SPLIT_FILL);
+        // With `rows` on this path NO row is moved: the caller's buffer receives the voxels' ranked point INDICES (uint32; entry
+        // seg_base[v] + k = the voxel's point of rank k >= 1, rank 0 = its first point) and counts[D3D_COUNT_AUX] = 1 says so --
+        // d3d_owner_pack gathers the rows it sends from the points through them.  (Round 3 staged every row here: the bucket
+        // kernel 45 instead of 31 us and k_meta_first 43 instead of k_emit's 22 us at config 5's shards.)
+        if (rows && d.emit_reduce) {
+            w.big_list = reinterpret_cast<uint32_t *>(rows);
+            d.x.aux_value = 1;
+        } else if (rows) w.staged = reinterpret_cast<float4 *>(rows);
         return binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
     }
+    if (rows) w.staged = reinterpret_cast<float4 *>(rows);
     IndexOpts o{P, 0xffffffffu, first, index_offset, mapping, agg4};
     rc = dense_index(kf, points, n, c, w, counts, o, flags, st);
     if (rc) return rc;
@@ -3674,6 +3681,8 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
         D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(n * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
                    w.voff, w.list, w.unsorted, P, reduction, aggregates);
     }
+    // (rows were STAGED on this path: counts[D3D_COUNT_AUX] -- the hash path's list-cell count until here -- must not read 1)
+    if (rows) D3D_HIP_CHECK(hipMemsetAsync(counts + D3D_COUNT_AUX, 0, sizeof(int64_t), st));
     return D3D_OK;
 }
 

@@ -104,6 +104,15 @@ class LocalComm:
         return send
 
 
+class _RowSource:
+    """what HipOps.voxelize_reduce(max_points) hands to HipOps.owner_pack: the `rows` buffer of d3d_voxelize_3d_reduce (staged
+    rows, or ranked point indices into `points`) together with the shard it came from"""
+    __slots__ = ("buf", "points", "index_offset")
+
+    def __init__(self, buf, points, index_offset):
+        self.buf, self.points, self.index_offset = buf, points, index_offset
+
+
 class HipOps:
     """the compute steps, on the HIP kernels of libd3d_hip.so (no host synchronisation except where noted)"""
 
@@ -143,7 +152,9 @@ class HipOps:
                 raise ValueError("the sharded dense contract needs points[n, 4] float32, 16-byte aligned")
             _lib.check(rc, "voxelize_3d_reduce")
         if max_points:
-            return coords, cnt, agg, first, mapping, keys, counts, seg, rows
+            # (on the binned index `rows` holds ranked point indices, not rows -- counts[3] says which -- and owner_pack gathers
+            # the rows from the points: they travel with the buffer)
+            return coords, cnt, agg, first, mapping, keys, counts, seg, _RowSource(rows, pts, int(index_offset))
         return coords, cnt, agg, first, mapping, keys, counts
 
     def compact_index(self, keys, ncells, status_stride=None):
@@ -302,9 +313,11 @@ class HipOps:
             send_rows = torch.empty((max(n, 1), 4), dtype=torch.float32, device=dev) if max_points else None
             sc = torch.empty((2 * world + 1,), dtype=torch.int64, device=dev)
             ws = torch.empty((lib.d3d_owner_pack_workspace_bytes(n, world),), dtype=torch.uint8, device=dev)
+            src = rows if isinstance(rows, _RowSource) else _RowSource(rows, None, 0)
             rc = lib.d3d_owner_pack(_lib.ptr(keys), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first), _lib.ptr(counts), n, c, world,
-                                    int(max_points), _lib.ptr(seg), _lib.ptr(rows), _lib.ptr(send), _lib.ptr(perm), _lib.ptr(pos),
-                                    _lib.ptr(send_rows), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                                    int(max_points), _lib.ptr(seg), _lib.ptr(src.buf), _lib.ptr(send), _lib.ptr(perm), _lib.ptr(pos),
+                                    _lib.ptr(send_rows), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(),
+                                    _lib.ptr(src.points), int(src.index_offset))
             _lib.check(rc, "owner_pack")
         return send, perm, pos, send_rows, sc
 

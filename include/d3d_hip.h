@@ -289,11 +289,13 @@ size_t d3d_owner_pack_workspace_bytes(int64_t n, int32_t world);
  * rank, perm[n] (send position -> local voxel), pos_of_local[n] (its inverse), send_counts[2 world + 1] (device: records per
  * destination, the shard's status bits, rows per destination).  Dense contract (max_points > 0, c == 4): seg_base / rows_local
  * as left by d3d_voxelize_3d_reduce(max_points, ...) -> send_rows[kept rows, 4] with the same grouping, and a record's last word
- * = offset of its rows inside its (source, destination) batch; otherwise max_points = 0 and the three pointers NULL. */
+ * = offset of its rows inside its (source, destination) batch; otherwise max_points = 0 and the three pointers NULL.
+ * points / index_offset: the shard that call voxelized -- on the binned index it leaves, instead of rows, the voxels' ranked
+ * point INDICES in `rows` (counts[D3D_COUNT_AUX] = 1) and the rows are gathered here; NULL = rows_local holds rows. */
 int d3d_owner_pack(const int64_t *keys, const int32_t *cnt, const float *agg, const int64_t *first, const int64_t *counts,
                    int64_t n, int32_t c, int32_t world, int32_t max_points, const uint32_t *seg_base, const float *rows_local,
                    int32_t *send, int32_t *perm, int32_t *pos_of_local, float *send_rows, int64_t *send_counts,
-                   void *workspace, size_t workspace_bytes, void *stream);
+                   void *workspace, size_t workspace_bytes, void *stream, const float *points, int64_t index_offset);
 size_t d3d_owner_merge_workspace_bytes(int64_t n_records, int32_t world);
 /* recv[R, words] grouped by source rank (src_off[world + 1], device) -> this owner's voxels in GLOBAL ID ORDER, finished
  * (the lowest source rank of a cell holds its first point; the records of one source follow the shard's first-seen order):
