@@ -588,10 +588,14 @@ constexpr uint32_t kRecLeader = 1u << 31;
 
 __device__ __forceinline__ u64 rec_hash(u64 key) { return mix64(key * 0x9e3779b97f4a7c15ull); }   // (owner_of took mix64(key))
 
-static uint32_t rec_buckets(int64_t R)
+// (a bucket's size varies by whole CELLS: with W ranks sharing most cells its spread is W times that of single records -- above
+// eight ranks the buckets are made half as large, which keeps 1280 four and more sigma away even at W = 64; a bucket that
+// outgrows it all the same hands the call over, tests/owner_merge_fuzz.py)
+static uint32_t rec_buckets(int64_t R, int world)
 {
+    const int64_t mean = world > 8 ? kRecBucketMean / 2 : kRecBucketMean;
     uint32_t nb = 1;
-    while ((int64_t)nb * kRecBucketMean < R) nb <<= 1;
+    while ((int64_t)nb * mean < R && nb < (uint32_t)kRecMaxBuckets) nb <<= 1;
     return nb;
 }
 
@@ -615,7 +619,7 @@ static RecWs carve_rec(void *ws, size_t bytes, int64_t R, int world)
     WsCarver w(ws, bytes);
     RecWs m;
     const int64_t r1 = R > 0 ? R : 1;
-    m.nb = rec_buckets(r1);
+    m.nb = rec_buckets(r1, world);
     m.ntiles = (uint32_t)d3d_divup(r1, kRecTile);
     m.ftiles = (uint32_t)d3d_divup(r1, kFinishTile);
     m.ekey = w.take<u64>((size_t)m.ntiles * kRecTile);
