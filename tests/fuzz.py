@@ -104,6 +104,31 @@ for seed in range(first, first + count):
     dr, er = oracle.pdist2dr(pts, bs)
     if float(np.max(np.abs(d.cpu().numpy() - dr))) > 1e-9 * max(scale, 1):
         bad += 1; print("PDIST seed", seed, "FAILED", float(np.max(np.abs(d.cpu().numpy() - dr))))
+    # points in boxes on the grid paths (>= 4096 points, <= 4096 boxes) and on the all-pairs kernels: crop_2dr (fp32 grid / fp64
+    # all pairs), crop_points, paint_label -- box sizes from a few cells to most of the scene, boundary points planted on edges
+    from d3d_amd.box import crop_2dr
+    from d3d_amd.abstraction import crop_points, paint_label
+    npt, nbx = int(rng.choice([300, 5000, 20000])), int(rng.choice([1, 7, 200, 1500]))
+    ext = float(rng.choice([1.0, 8.0, 60.0]))
+    b7 = np.stack([rng.random(nbx) * scale, rng.random(nbx) * scale, rng.random(nbx) * 4 - 2, rng.random(nbx) * ext + 0.3,
+                   rng.random(nbx) * ext + 0.3, rng.random(nbx) * 3 + 0.5, (rng.random(nbx) - 0.5) * 7], 1).astype(np.float32)
+    if seed % 3 == 0:
+        b7[:, 6] = np.round(b7[:, 6] / (np.pi / 2)) * (np.pi / 2)          # axis-aligned: points ON edges are likely below
+    p4 = np.stack([rng.random(npt) * scale * 1.1 - 0.05 * scale, rng.random(npt) * scale * 1.1 - 0.05 * scale, rng.random(npt) * 6 - 3,
+                   rng.random(npt)], 1).astype(np.float32)
+    k = min(npt, nbx)
+    p4[:k, 0] = b7[:k, 0] + b7[:k, 3] / 2; p4[:k, 1] = b7[:k, 1]           # on the +x face of box i (when it is axis-aligned)
+    for dt in (np.float32, np.float64):
+        got = crop_2dr(torch.from_numpy(p4[:, :2].astype(dt)).cuda(), torch.from_numpy(b7[:, [0, 1, 3, 4, 6]].astype(dt)).cuda()).cpu().numpy()
+        if not np.array_equal(got, oracle.crop_2dr(p4[:, :2].astype(dt), b7[:, [0, 1, 3, 4, 6]].astype(dt))):
+            bad += 1; print("CROP2D seed", seed, dt.__name__, npt, nbx, "FAILED")
+    if not np.array_equal(crop_points(torch.from_numpy(b7).cuda(), torch.from_numpy(p4).cuda()).cpu().numpy(), oracle.crop_points(b7, p4)):
+        bad += 1; print("CROP3D seed", seed, npt, nbx, "FAILED")
+    sem, lab = rng.integers(0, 4, npt).astype(np.uint8), rng.integers(0, 4, nbx).astype(np.uint8)
+    gp = paint_label(torch.from_numpy(b7).cuda(), torch.from_numpy(p4).cuda(), torch.from_numpy(sem).cuda(), torch.from_numpy(lab).cuda())
+    gp = gp.cpu().numpy() if hasattr(gp, "cpu") else np.asarray(gp)
+    if not np.array_equal(gp.astype(np.int64), oracle.paint_label(b7, p4, sem, lab).astype(np.int64)):
+        bad += 1; print("PAINT seed", seed, npt, nbx, "FAILED")
     # matcher: [n,9] boxes with classes, scores (ties every 5th seed), thresholds per class
     nd, ng = int(rng.integers(1, 400)), int(rng.integers(1, 150))
     gt7 = np.stack([rng.random(ng) * 40, rng.random(ng) * 40, rng.random(ng) * 2 - 2, rng.random(ng) * 1.5 + 3.5, rng.random(ng) * .5 + 1.6,
