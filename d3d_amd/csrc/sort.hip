@@ -22,7 +22,7 @@ namespace {
 // A one-launch pass with look-back was measured in round 2 (tools/radix_bench.hip): with every tile resident at once nobody
 // has an inclusive prefix to offer and each tile walks all its predecessors -- 990 us for 1 M pairs.
 constexpr int kRsThreads = 256, kRsItems = 16, kRsTile = kRsThreads * kRsItems, kRsBins = 256, kRsWaves = kRsThreads / kWave;
-constexpr int kRsHistBlocks = 64, kRsHistThreads = 1024;
+constexpr int kRsHistBlocks = 256, kRsHistThreads = 1024;    // (64 blocks: a quarter of the CUs, 49 us for 4 M keys)
 
 struct RsPlan {             // per pass
     int32_t skip, src, dst;  // src: -1 = the caller's keys (index = position), 0 / 1 = ping-pong buffer; dst: 0 / 1, 2 = `order`
