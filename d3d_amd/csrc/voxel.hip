@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const typename BinE
 constexpr int kSortThreads = 1024;
 // the one-launch partition up to here; beyond, a bucket's run in a tile shrinks to a single entry and k_bucket_index gathers
 // them one by one (profiles/r04_tile_sort_large.txt: dense 4 M / 8 M points 4 % faster than the three passes, sparse + trim
-// 4 M 11 % faster, 8 M 7 % slower -- its 12-byte entries)
+// 4 M 11 % faster, 8 M 7 % slower -- its 16-byte entries)
 constexpr int64_t kTileSortMaxPoints = 8ll << 20, kTileSortMaxPointsSparse = 4ll << 20;
 constexpr int kRunCap = 1024;                              // tiles: k_bucket_index keeps the run table in LDS
 
