@@ -23,7 +23,16 @@ template <typename T> struct BoxGeom {
     T area;
 };
 
-__device__ __forceinline__ void d3d_sincos(float r, float *s, float *c) { sincosf(r, s, c); }
+// fp32 angles: evaluated in double and rounded once -- the correctly rounded float, which is what glibc's sinf / cosf return
+// (the reference's host code and the oracle).  The device's sincosf is 1 ulp off for about one angle in a few hundred, and a
+// 1-ulp sine moves a 50-unit edge by 6e-5 * its length: tests/fuzz.py found a point ON such an edge inside for the oracle and
+// outside here (crop_2dr, seed 20267).  One evaluation per box, never per pair.
+__device__ __forceinline__ void d3d_sincos(float r, float *s, float *c)
+{
+    double sd, cd;
+    sincos((double)r, &sd, &cd);
+    *s = (float)sd; *c = (float)cd;
+}
 __device__ __forceinline__ void d3d_sincos(double r, double *s, double *c) { sincos(r, s, c); }
 
 // corners (CCW, starting at local (-w/2,-h/2)) = c - u - v, c + u - v, c + u + v, c - u + v
@@ -572,8 +581,15 @@ __device__ __forceinline__ T hull_area2(const Corners8<T> &c, T (&gx)[8], T (&gy
         for (int j = 0; j < 4; j++) {
             // an = oA[i][j], ap = oA[i-1][j], bn = oB[j][i], bp = oB[j-1][i]
             const uint32_t an = 1u << (4 * i + j), ap = 1u << (4 * ((i + 3) & 3) + j), bn = 1u << (4 * j + i), bp = 1u << (4 * ((j + 3) & 3) + i);
-            if ((na & an) && (pa & ap) && (pb & bn) && (nb & bp)) accept(i, 4 + j);
-            if ((pa & an) && (na & ap) && (nb & bn) && (pb & bp)) accept(4 + j, i);
+            const bool ab = (na & an) && (pa & ap) && (pb & bn) && (nb & bp), ba = (pa & an) && (na & ap) && (nb & bn) && (pb & bp);
+            if (GRAD) {
+                if (ab) accept(i, 4 + j);
+                if (ba) accept(4 + j, i);
+            } else {                               // cross(b, a) = -cross(a, b) exactly (products commute, the difference flips)
+                const T x = c.x[i] * c.y[4 + j] - c.y[i] * c.x[4 + j];
+                if (ab) h2 += x;
+                if (ba) h2 -= x;
+            }
         }
     }
     return h2;

@@ -120,8 +120,15 @@ for seed in range(first, first + count):
     p4[:k, 0] = b7[:k, 0] + b7[:k, 3] / 2; p4[:k, 1] = b7[:k, 1]           # on the +x face of box i (when it is axis-aligned)
     for dt in (np.float32, np.float64):
         got = crop_2dr(torch.from_numpy(p4[:, :2].astype(dt)).cuda(), torch.from_numpy(b7[:, [0, 1, 3, 4, 6]].astype(dt)).cuda()).cpu().numpy()
-        if not np.array_equal(got, oracle.crop_2dr(p4[:, :2].astype(dt), b7[:, [0, 1, 3, 4, 6]].astype(dt))):
+        exp2 = oracle.crop_2dr(p4[:, :2].astype(dt), b7[:, [0, 1, 3, 4, 6]].astype(dt))
+        if not np.array_equal(got, exp2):
             bad += 1; print("CROP2D seed", seed, dt.__name__, npt, nbx, "FAILED")
+            for bi, pj in list(zip(*np.nonzero(got != exp2)))[:4]:
+                print("   box", bi, b7[bi, [0, 1, 3, 4, 6]].tolist(), "point", pj, p4[pj, :2].tolist(), "got", bool(got[bi, pj]), "exp", bool(exp2[bi, pj]),
+                      "scene", float(b7[:, 0].min()), float(b7[:, 0].max()), float(b7[:, 1].min()), float(b7[:, 1].max()),
+                      "all-pairs kernel:", bool(crop_2dr(torch.from_numpy(p4[pj:pj + 1, :2].astype(dt)).cuda(),
+                                                         torch.from_numpy(b7[:, [0, 1, 3, 4, 6]].astype(dt)).cuda()).cpu().numpy()[bi, 0]),
+                      "ext", float(b7[:, 3].max()), float(b7[:, 4].max()))
     if not np.array_equal(crop_points(torch.from_numpy(b7).cuda(), torch.from_numpy(p4).cuda()).cpu().numpy(), oracle.crop_points(b7, p4)):
         bad += 1; print("CROP3D seed", seed, npt, nbx, "FAILED")
     sem, lab = rng.integers(0, 4, npt).astype(np.uint8), rng.integers(0, 4, nbx).astype(np.uint8)
