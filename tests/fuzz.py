@@ -136,6 +136,31 @@ for seed in range(first, first + count):
     gp = gp.cpu().numpy() if hasattr(gp, "cpu") else np.asarray(gp)
     if not np.array_equal(gp.astype(np.int64), oracle.paint_label(b7, p4, sem, lab).astype(np.int64)):
         bad += 1; print("PAINT seed", seed, npt, nbx, "FAILED")
+    # aligned_scatter (d3d.point): 2-D / 3-D maps, all align types, coordinates partly outside the map; forward bit-exact
+    # (same accumulation order), backward against the oracle's adjoint within the atomics' reordering
+    from d3d_amd.point import AlignType, aligned_scatter_backward, aligned_scatter_forward
+    nd_ = int(rng.choice([2, 3]))
+    dims = [int(rng.integers(2, 24)) for _ in range(nd_)]
+    bsz, ch, npts_ = int(rng.integers(1, 4)), int(rng.choice([1, 3, 16, 64])), int(rng.choice([1, 37, 3000]))
+    dtp = np.float32 if seed % 2 else np.float64
+    img_ = rng.standard_normal([bsz, ch] + dims).astype(dtp)
+    crd = np.concatenate([rng.integers(0, bsz, (npts_, 1)), rng.random((npts_, nd_)) * (np.array(dims) + 2.0) - 1.0], 1).astype(dtp)
+    for at in ("drop", "mean", "linear"):
+        try:
+            want = oracle.aligned_scatter_forward(crd, img_, at)
+        except ValueError:
+            continue
+        atype = AlignType[at.upper()]
+        gotf = aligned_scatter_forward(torch.from_numpy(crd).cuda(), torch.from_numpy(img_).cuda(), atype).cpu().numpy()
+        if not np.array_equal(gotf, want, equal_nan=True):
+            bad += 1; print("SCATTER-FWD seed", seed, at, dims, ch, npts_, "FAILED", float(np.nanmax(np.abs(gotf - want))))
+        gr = rng.standard_normal(want.shape).astype(dtp)
+        ig = torch.zeros(img_.shape, dtype=torch.from_numpy(img_).dtype, device="cuda")
+        aligned_scatter_backward(torch.from_numpy(crd).cuda(), torch.from_numpy(gr).cuda(), atype, ig)
+        wb = oracle.aligned_scatter_backward(crd, gr, at, img_.shape)
+        tolb = 1e-4 if dtp == np.float32 else 1e-11
+        if not np.allclose(ig.cpu().numpy(), wb, rtol=tolb, atol=tolb * max(1.0, float(np.abs(wb).max()))):
+            bad += 1; print("SCATTER-BWD seed", seed, at, dims, ch, npts_, "FAILED", float(np.abs(ig.cpu().numpy() - wb).max()))
     # matcher: [n,9] boxes with classes, scores (ties every 5th seed), thresholds per class
     nd, ng = int(rng.integers(1, 400)), int(rng.integers(1, 150))
     gt7 = np.stack([rng.random(ng) * 40, rng.random(ng) * 40, rng.random(ng) * 2 - 2, rng.random(ng) * 1.5 + 3.5, rng.random(ng) * .5 + 1.6,
