@@ -865,3 +865,20 @@ def test_nms_two_threads_two_streams_mixed_inputs():
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors
+
+
+@pytest.mark.gpu
+def test_crop_2dr_fp32_point_on_a_long_edge_follows_the_hosts_sine():
+    """found by tests/fuzz.py (seed 20267): for this angle the device's sincosf is one ulp off glibc's sinf -- the correctly
+    rounded float, which the reference's host code and the oracle use -- and with it the point, exactly ON the 54-unit edge,
+    fell outside.  fp32 angles are evaluated in double and rounded once (geom.hpp: d3d_sincos).  Both kernels: all pairs
+    (few points) and the box grid (>= 4096 points)."""
+    from d3d_amd.box import crop_2dr
+    box = np.array([[16.303468704223633, 5.941005706787109, 54.238182067871094, 3.4432148933410645, -2.555604934692383]], np.float32)
+    pt = np.array([[7.366237163543701, 2.075172185897827]], np.float32)
+    assert oracle.crop_2dr(pt, box)[0, 0]
+    assert bool(crop_2dr(T(pt), T(box)).cpu().numpy()[0, 0])
+    rng = np.random.default_rng(3)
+    many = np.concatenate([pt, (rng.random((5000, 2)) * 40 - 10).astype(np.float32)])
+    got = crop_2dr(T(many), T(box)).cpu().numpy()
+    assert got[0, 0] and np.array_equal(got, oracle.crop_2dr(many, box))
