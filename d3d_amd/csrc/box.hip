@@ -2124,7 +2124,9 @@ constexpr int kSoftList = 1024;      // rescaled positions remembered per round
 template <typename T> __device__ __forceinline__ T soft_decay(T iou, float param, int sup);
 template <> __device__ __forceinline__ float soft_decay<float>(float iou, float param, int sup)
 {
-    return sup == D3D_SUPPRESS_LINEAR ? 1 - powf(iou, param) : expf(-iou * iou / param);
+    // (the float ARGUMENTS as the host forms them, the functions in double and rounded once: glibc's powf / expf are the
+    // correctly rounded floats in all but the rarest cases, the device's are 1 ulp off now and then -- see d3d_sincos)
+    return sup == D3D_SUPPRESS_LINEAR ? 1 - (float)pow((double)iou, (double)param) : (float)exp((double)(-iou * iou / param));
 }
 template <> __device__ __forceinline__ double soft_decay<double>(double iou, float param, int sup)
 {
