@@ -1396,6 +1396,9 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
             const uint32_t p = h[word[r] & (kBinMax - 1)] + (word[r] >> kBinBits);
             keys[p] = key[r];
             lidx[p] = (uint16_t)(r * kSortThreads + threadIdx.x);
+            // (preset "the first point of my voxel is myself": true for the 80 % of a LiDAR frame's points that are alone in their
+            // voxel -- k_bucket_index then only writes the others, one scattered store per point less for most of them)
+            if (pfirst) pfirst[i] = (uint32_t)i;
         } else if (pfirst && i < n) pfirst[i] = kInf;
     }
     __syncthreads();
@@ -1789,7 +1792,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             }
             if (trimmed && rank >= P) trimmed[me] = 1;
             if (precpos) precpos[pos] = tfirst[s];
-            if (pfirst_out) pfirst_out[me] = (P > 0 && rank >= P) ? kInf : tfirst[s];
+            if (pfirst_out) {
+                const uint32_t pf = (P > 0 && rank >= P) ? kInf : tfirst[s];
+                if (!table || pf != me) pfirst_out[me] = pf;        // (tile-sorted input: k_tile_sort preset pfirst[me] = me)
+            }
         }
         reduce_overflow(sg, std::true_type{}, (const v4f *)nullptr);
         return;
@@ -1880,7 +1886,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             }
             if (trimmed && rank >= P) trimmed[me] = 1;     // sparse contract + TRIM filter (voxelize.cpp:457-463)
             if (precpos) precpos[pos[r]] = tfirst[s];
-            if (pfirst_out) pfirst_out[me] = (P > 0 && rank >= P) ? kInf : tfirst[s];
+            if (pfirst_out) {
+                const uint32_t pf = (P > 0 && rank >= P) ? kInf : tfirst[s];
+                if (!table || pf != me) pfirst_out[me] = pf;        // (tile-sorted input: k_tile_sort preset pfirst[me] = me)
+            }
         }
     });
     D3D_PHASE(0, 5);                                // ranks, list stores issued
