@@ -82,7 +82,7 @@ SIGNATURES = {
     "d3d_owner_number": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "d3d_owner_reply": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "d3d_owner_map": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
-    "d3d_owner_replicate": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "d3d_owner_replicate": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz]),
     "d3d_aligned_scatter_workspace_bytes": (_sz, [_i64, _i64, _vp, _i32, _i32]),
     "d3d_aligned_scatter_forward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "d3d_aligned_scatter_backward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),

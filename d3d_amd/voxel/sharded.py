@@ -414,16 +414,27 @@ class HipOps:
                                          _lib.stream_ptr()), "owner_map")
         return gmap
 
-    def owner_replicate(self, nvox, vids, coords_in, cnt_in, feats_in):
+    def owner_replicate(self, nvox, vids, coords_in, cnt_in, feats_in, sizes=None):
+        """rows of all owners -> voxel-id order.  sizes: rows per rank when the rows are the ranks' blocks in rank order, each
+        ascending in id (the all-gather's layout): merged with coalesced accesses instead of scattered row by row"""
         lib = _lib.load()
         dev = vids.device
         c = int(feats_in.shape[1])
         with torch.cuda.device(dev):
+            src_off = ws = None
+            if sizes is not None:
+                off = [0]
+                for k in sizes:
+                    off.append(off[-1] + int(k))
+                src_off = torch.tensor(off, dtype=torch.int64, device=dev)
+                ws = torch.empty(((nvox // 1024 + 2) * len(sizes),), dtype=torch.int64, device=dev)
             coords = torch.empty((nvox, 3), dtype=torch.int64, device=dev)
             cnt = torch.empty((nvox,), dtype=torch.int32, device=dev)
             feats = torch.empty((nvox, c), dtype=torch.float32, device=dev)
             _lib.check(lib.d3d_owner_replicate(nvox, _lib.ptr(vids), _lib.ptr(coords_in), _lib.ptr(cnt_in), _lib.ptr(feats_in), c,
-                                               _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(feats), _lib.stream_ptr()),
+                                               _lib.ptr(coords), _lib.ptr(cnt), _lib.ptr(feats), _lib.stream_ptr(),
+                                               _lib.ptr(src_off), len(sizes) if sizes is not None else 0,
+                                               _lib.ptr(ws), ws.numel() * 8 if ws is not None else 0),
                        "owner_replicate")
         return coords, cnt, feats
 
@@ -600,7 +611,7 @@ class ShardedVoxelGenerator:
         packed = comm.all_gather_var(packed.reshape(-1), [5 * k for k in sizes]).view(-1, 5)
         feats_all = comm.all_gather_var(feats.reshape(-1), [c * k for k in sizes]).view(-1, c)
         coords_f, cnt_f, feats_f = ops.owner_replicate(nvox, packed[:, 0].contiguous(), packed[:, 1:4].contiguous(),
-                                                        packed[:, 4].to(torch.int32).contiguous(), feats_all)
+                                                        packed[:, 4].to(torch.int32).contiguous(), feats_all, sizes=sizes)
         ret = Dict(coords=coords_f, voxel_npoints=cnt_f, aggregates=feats_f, points_mapping=gmap)
         if P:
             # the replicated dense tensor (V x max_points x 16 bytes on EVERY rank: a convenience for parity tests, sized by

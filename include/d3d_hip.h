@@ -334,9 +334,13 @@ int d3d_owner_reply(int64_t n_records, const int32_t *rec_owned, const int64_t *
 /* back[] (ids returned, in send order), pos_of_local (d3d_owner_pack), local_map[n] (point -> local voxel) -> gmap[n] */
 int d3d_owner_map(int64_t n, const int64_t *local_map, const int32_t *pos_of_local, const int64_t *back, int64_t *gmap,
                   void *stream);
-/* all owners' finished rows, concatenated in any order -> the replicated feature grid in voxel-id order */
+/* all owners' finished rows -> the replicated feature grid in voxel-id order.  src_off[world + 1] (device; may be NULL): the rows
+ * are the ranks' blocks one after the other, block s = rows [src_off[s], src_off[s + 1]), each in ascending id order (what an
+ * all-gather of the owners' results delivers) -- merged with coalesced reads and writes (workspace: (nvox / 1024 + 2) * world * 8
+ * bytes); NULL: any order, one scattered row each. */
 int d3d_owner_replicate(int64_t nvox, const int64_t *vids, const int64_t *coords_in, const int32_t *cnt_in,
-                        const float *feats_in, int32_t c, int64_t *coords, int32_t *cnt, float *feats, void *stream);
+                        const float *feats_in, int32_t c, int64_t *coords, int32_t *cnt, float *feats, void *stream,
+                        const int64_t *src_off, int32_t world, void *workspace, size_t workspace_bytes);
 
 /* ---- points in 3D boxes: Target3DArray.crop_points / paint_label (reference d3d/abstraction.pyx:308-324,
  * 654-687), per pair box3dr_contains (d3d/dgal_wrap.h:6-19): closed z interval in fp32, the rotated rectangle's bounding

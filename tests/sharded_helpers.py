@@ -309,7 +309,7 @@ class NumpyOps:
         out[ok] = back.numpy()[pos_of_local.numpy()[m[ok]]]
         return torch.from_numpy(out)
 
-    def owner_replicate(self, nvox, vids, coords_in, cnt_in, feats_in):
+    def owner_replicate(self, nvox, vids, coords_in, cnt_in, feats_in, sizes=None):
         v = vids.numpy()
         coords = np.zeros((nvox, 3), np.int64); cnt = np.zeros((nvox,), np.int32)
         feats = np.zeros((nvox, feats_in.shape[1]), np.float32)
