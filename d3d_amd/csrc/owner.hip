@@ -1260,6 +1260,7 @@ __global__ __launch_bounds__(256) void k_owner_replicate_bounds(int64_t V, const
     bounds[g] = l;
 }
 
+template <int MAXC>
 __global__ __launch_bounds__(256) void k_owner_replicate_merge(int64_t V, const int64_t *__restrict__ vids,
                                                                const int64_t *__restrict__ coords_in, const int32_t *__restrict__ cnt_in,
                                                                const float *__restrict__ feats_in, int c, int64_t *coords, int32_t *cnt,
@@ -1269,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_owner_replicate_merge(int64_t V, const 
     __shared__ uint32_t pre[kMaxWorld + 1];
     __shared__ int64_t cbuf[kRepTile * 3];
     __shared__ int32_t nbuf[kRepTile];
-    __shared__ float fbuf[kRepTile * kRepMaxC];
+    __shared__ __attribute__((aligned(16))) float fbuf[kRepTile * MAXC];   // (44 KB per workgroup at four features: three per CU)
     const int64_t v0 = (int64_t)blockIdx.x * kRepTile, v1 = v0 + kRepTile < V ? v0 + kRepTile : V;
     if ((int)threadIdx.x < world) {
         const int64_t l0 = bounds[(int64_t)blockIdx.x * world + threadIdx.x];
@@ -1290,7 +1291,10 @@ __global__ __launch_bounds__(256) void k_owner_replicate_merge(int64_t V, const 
         const uint32_t slot = (uint32_t)(vids[i] - v0);
         cbuf[slot * 3] = coords_in[i * 3]; cbuf[slot * 3 + 1] = coords_in[i * 3 + 1]; cbuf[slot * 3 + 2] = coords_in[i * 3 + 2];
         nbuf[slot] = cnt_in[i];
-        for (int q = 0; q < c; q++) fbuf[slot * c + q] = feats_in[i * c + q];
+        if (c == 4 && (reinterpret_cast<uintptr_t>(feats_in) & 15) == 0)
+            *reinterpret_cast<float4 *>(&fbuf[slot * 4]) = reinterpret_cast<const float4 *>(feats_in)[i];
+        else
+            for (int q = 0; q < c; q++) fbuf[slot * c + q] = feats_in[i * c + q];
     }
     __syncthreads();
     const uint32_t nrows = (uint32_t)(v1 - v0);
@@ -1537,8 +1541,12 @@ extern "C" int d3d_owner_replicate(int64_t V, const int64_t *vids, const int64_t
         int64_t *bounds = static_cast<int64_t *>(workspace);
         D3D_LAUNCH("k_owner_replicate_bounds", k_owner_replicate_bounds, dim3(blocks_for((ntiles + 1) * world)), dim3(256), 0, st, V, vids,
                    src_off, (int)world, ntiles, bounds);
-        D3D_LAUNCH("k_owner_replicate_merge", k_owner_replicate_merge, dim3((unsigned)ntiles), dim3(256), 0, st, V, vids, coords_in,
-                   cnt_in, feats_in, (int)c, coords, cnt, feats, (const int64_t *)bounds, (int)world);
+        if (c <= 4)
+            D3D_LAUNCH("k_owner_replicate_merge", k_owner_replicate_merge<4>, dim3((unsigned)ntiles), dim3(256), 0, st, V, vids, coords_in,
+                       cnt_in, feats_in, (int)c, coords, cnt, feats, (const int64_t *)bounds, (int)world);
+        else
+            D3D_LAUNCH("k_owner_replicate_merge", k_owner_replicate_merge<kRepMaxC>, dim3((unsigned)ntiles), dim3(256), 0, st, V, vids,
+                       coords_in, cnt_in, feats_in, (int)c, coords, cnt, feats, (const int64_t *)bounds, (int)world);
     } else
         D3D_LAUNCH("k_owner_replicate", k_owner_replicate, dim3(blocks_for(V)), dim3(256), 0, st, V, vids, coords_in, cnt_in, feats_in,
                    (int)c, coords, cnt, feats);
