@@ -395,3 +395,17 @@ extern "C" int d3d_paint_label(const float *points, int64_t n, int32_t point_str
                semantics, boxes, m, (int)box_stride, (int)box_offset, labels, idarr);
     return D3D_OK;
 }
+
+// The host build of geom.hpp's HostSinCos, for tests/test_host_sincos.py: the restatement is checked against the libm it claims
+// to reproduce on whatever machine runs the tests (no GPU involved).  Returns how many angles took the restated path.
+extern "C" int64_t d3d_internal_host_sincosf(const float *angles, int64_t n, float *sines, float *cosines)
+{
+    int64_t covered = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        float s = 0.f, c = 0.f;
+        if (HostSinCos::eval(angles[i], &s, &c)) ++covered;
+        else { s = sinf(angles[i]); c = cosf(angles[i]); }
+        sines[i] = s; cosines[i] = c;
+    }
+    return covered;
+}

@@ -23,12 +23,56 @@ template <typename T> struct BoxGeom {
     T area;
 };
 
-// fp32 angles: evaluated in double and rounded once -- the correctly rounded float, which is what glibc's sinf / cosf return
-// for 98.5 % of the angles (the reference's host code and the oracle call them); the device's sincosf agrees with glibc for
-// about 80 % only.  A 1-ulp sine moves a 50-unit edge by 6e-5 * its length: tests/fuzz.py found a point ON such an edge inside for the oracle and
-// outside here (crop_2dr, seed 20267).  One evaluation per box, never per pair.
+// fp32 angles: the HOST's sinf / cosf, operation for operation.  The reference's host code and the oracle call glibc's, whose
+// result is the correctly rounded float for only 98.5 % of the angles (and the device's own sincosf agrees with it for about
+// 80 %); a 1-ulp sine moves a 50-unit edge by 6e-5 * its length, and tests/fuzz.py found points lying ON such an edge inside for
+// the oracle and outside here (crop_2dr, seeds 20267, 61633).  glibc (2.28 and later) evaluates both in double with the
+// polynomials of the ARM optimized routines -- restated below from the published algorithm (sincosf.h: reduce_fast, sinf_poly;
+// the constants are the minimax coefficients it tabulates), with the fused multiply-adds its x86-64 FMA build contracts to.
+// Checked on the host against libm's sinf / cosf over 4 x 10^7 random angles in +-8 and +-100: identical (without the fused
+// operations: 15 differences), tests/test_host_sincos.py.  |angle| >= 120 (glibc switches to a table-driven reduction there):
+// the double routine rounded once.  One evaluation per box, never per pair.
+struct HostSinCos {
+    // c0 .. c4: cosine polynomial in x^2, s1 .. s3: sine polynomial; NEG = the table that yields -cos / keeps sin
+    template <bool NEG> static __host__ __device__ __forceinline__ float poly(double x, double x2, int n)
+    {
+        constexpr double c0 = NEG ? -0x1p0 : 0x1p0, c1 = NEG ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2,
+                         c2 = NEG ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5, c3 = NEG ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10,
+                         c4 = NEG ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+        constexpr double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+        if ((n & 1) == 0) {
+            const double x3 = x * x2, t1 = fma(x2, s3, s2), x7 = x3 * x2, t = fma(x3, s1, x);
+            return (float)fma(x7, t1, t);
+        }
+        const double x4 = x2 * x2, u2 = fma(x2, c4, c3), u1 = fma(x2, c1, c0), x6 = x4 * x2, u = fma(x4, c2, u1);
+        return (float)fma(x6, u2, u);
+    }
+    static __host__ __device__ __forceinline__ bool eval(float y, float *sn, float *cs)
+    {
+        const uint32_t bits = __builtin_bit_cast(uint32_t, y);
+        const uint32_t top = (bits >> 20) & 0x7ffu;                  // exponent and the top mantissa bits of |y|
+        double x = (double)y;
+        if (top < 0x3f4u) {                                           // |y| < pi / 4 (top bits of 0x1.921FB6p-1f)
+            if (top < 0x398u) { *sn = y; *cs = 1.0f; return true; }   // |y| < 2^-12
+            const double x2 = x * x;
+            *sn = poly<false>(x, x2, 0);
+            *cs = poly<false>(x, x2, 1);
+            return true;
+        }
+        if (top >= 0x42fu) return false;                              // |y| >= 120, inf, NaN
+        const double r = x * 0x1.45F306DC9C883p+23;                   // 2 / pi * 2^24
+        const int n = ((int32_t)r + 0x800000) >> 24;
+        x = fma(-(double)n, 0x1.921FB54442D18p0, x);
+        const double sg = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        const double xs = x * sg, x2 = x * x;
+        if (n & 2) { *sn = poly<true>(xs, x2, n); *cs = poly<true>(xs, x2, n ^ 1); }
+        else { *sn = poly<false>(xs, x2, n); *cs = poly<false>(xs, x2, n ^ 1); }
+        return true;
+    }
+};
 __device__ __forceinline__ void d3d_sincos(float r, float *s, float *c)
 {
+    if (HostSinCos::eval(r, s, c)) return;
     double sd, cd;
     sincos((double)r, &sd, &cd);
     *s = (float)sd; *c = (float)cd;

@@ -121,21 +121,8 @@ for seed in range(first, first + count):
     for dt in (np.float32, np.float64):
         got = crop_2dr(torch.from_numpy(p4[:, :2].astype(dt)).cuda(), torch.from_numpy(b7[:, [0, 1, 3, 4, 6]].astype(dt)).cuda()).cpu().numpy()
         exp2 = oracle.crop_2dr(p4[:, :2].astype(dt), b7[:, [0, 1, 3, 4, 6]].astype(dt))
-        if not np.array_equal(got, exp2) and dt == np.float32:
-            # the library evaluates fp32 angles in double and rounds once (the correctly rounded float); the oracle calls the
-            # host's sinf / cosf, which glibc 2.35 gets 1 ulp off for ~1.5 % of the angles: a point exactly ON an edge of such a
-            # box can fall on either side.  Those boxes are not counted (seed 61633 is one).
-            import ctypes
-            libm = ctypes.CDLL("libm.so.6")
-            libm.sinf.restype = libm.cosf.restype = ctypes.c_float
-            libm.sinf.argtypes = libm.cosf.argtypes = [ctypes.c_float]
-            rows = np.unique(np.nonzero(got != exp2)[0])
-            ang = b7[rows, 6].astype(np.float32)
-            host_off = np.array([np.float32(libm.sinf(float(a))) != np.float32(np.sin(np.float64(a))) or
-                                 np.float32(libm.cosf(float(a))) != np.float32(np.cos(np.float64(a))) for a in ang])
-            if host_off.all():
-                print("   (crop_2dr seed %d: %d box(es) whose host sinf / cosf is not the correctly rounded float -- skipped)" % (seed, len(rows)))
-                got = exp2
+        # fp32: the library evaluates the host's sinf / cosf operation for operation (geom.hpp HostSinCos), so points planted ON an
+        # edge must fall on the oracle's side of it too (seeds 20267 and 61633 did not, before)
         if not np.array_equal(got, exp2):
             bad += 1; print("CROP2D seed", seed, dt.__name__, npt, nbx, "FAILED")
             for bi, pj in list(zip(*np.nonzero(got != exp2)))[:4]:

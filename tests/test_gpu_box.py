@@ -871,8 +871,8 @@ def test_nms_two_threads_two_streams_mixed_inputs():
 def test_crop_2dr_fp32_point_on_a_long_edge_follows_the_hosts_sine():
     """found by tests/fuzz.py (seed 20267): for this angle the device's sincosf is one ulp off glibc's sinf -- the correctly
     rounded float, which the reference's host code and the oracle use -- and with it the point, exactly ON the 54-unit edge,
-    fell outside.  fp32 angles are evaluated in double and rounded once (geom.hpp: d3d_sincos).  Both kernels: all pairs
-    (few points) and the box grid (>= 4096 points)."""
+    fell outside.  fp32 angles now take the host's own sinf / cosf operation for operation (geom.hpp: HostSinCos, checked
+    against libm in tests/test_host_sincos.py).  Both kernels: all pairs (few points) and the box grid (>= 4096 points)."""
     from d3d_amd.box import crop_2dr
     box = np.array([[16.303468704223633, 5.941005706787109, 54.238182067871094, 3.4432148933410645, -2.555604934692383]], np.float32)
     pt = np.array([[7.366237163543701, 2.075172185897827]], np.float32)
@@ -882,3 +882,27 @@ def test_crop_2dr_fp32_point_on_a_long_edge_follows_the_hosts_sine():
     many = np.concatenate([pt, (rng.random((5000, 2)) * 40 - 10).astype(np.float32)])
     got = crop_2dr(T(many), T(box)).cpu().numpy()
     assert got[0, 0] and np.array_equal(got, oracle.crop_2dr(many, box))
+
+
+@pytest.mark.parametrize("npts", [1500, 6000])
+def test_crop_2dr_fp32_points_within_an_ulp_of_an_edge(npts):
+    """every point is planted on an edge of its own rotated box (computed in double, rounded to fp32): which side it falls on is
+    decided by the last bit of the box's sine and cosine, so the mask equals the oracle's only if the device's fp32 angles are the
+    host's bit for bit -- seed 61633 of tests/fuzz.py was a box whose glibc sinf is not even the correctly rounded float."""
+    from d3d_amd.box import crop_2dr
+    rng = np.random.default_rng(npts)
+    m = min(npts, 3000)                               # 6000 points on 3000 boxes take the box grid, 1500 on 1500 all pairs
+    box = np.stack([rng.random(m) * 80 - 40, rng.random(m) * 80 - 40, rng.random(m) * 50 + 5, rng.random(m) * 4 + 1,
+                    (rng.random(m) - 0.5) * 12], 1).astype(np.float32)
+    which = np.arange(npts) % m
+    b = box.astype(np.float64)[which]
+    t = rng.random(npts) * 2 - 1
+    side = rng.integers(0, 4, npts)
+    lx = np.where(side < 2, t * b[:, 2] / 2, np.where(side == 2, b[:, 2] / 2, -b[:, 2] / 2))
+    ly = np.where(side == 0, b[:, 3] / 2, np.where(side == 1, -b[:, 3] / 2, t * b[:, 3] / 2))
+    cs, sn = np.cos(b[:, 4]), np.sin(b[:, 4])
+    pts = np.stack([b[:, 0] + lx * cs - ly * sn, b[:, 1] + lx * sn + ly * cs], 1).astype(np.float32)
+    exp = oracle.crop_2dr(pts, box)
+    own = exp[which, np.arange(npts)]
+    assert 0.2 < own.mean() < 0.8                     # the planted points really straddle their edges
+    assert np.array_equal(crop_2dr(T(pts), T(box)).cpu().numpy(), exp)
