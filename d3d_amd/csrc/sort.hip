@@ -264,6 +264,163 @@ int radix_argsort_desc(const K *keys, int64_t n, V *order, void *ws, size_t ws_b
     return D3D_OK;
 }
 
+// ---------------------------------------------------------------- voxel counts (the fused DESCENDING filter, voxelize.cpp:406)
+// Keys are the point counts of voxels: nearly all below 255, a handful above (the cells next to the sensor).  The general path
+// spends a histogram sweep, a plan, two live 8-bit passes and a skipped one on them (82 us for 585 k voxels).  Here ONE pass on
+// the digit 255 - min(count, 255): descending, stable, written straight into `order` -- except the class "255 or more", which
+// comes first and leaves in index order into a side list; those few (at most points / 255) are then ranked among themselves
+// by (count descending, position ascending), all pairs, one thread each.  Three launches, no plan: every workgroup scans the
+// tiles' digit rows itself (bases = exclusive scan of the column totals + the column sums of the tiles before it).
+__device__ __forceinline__ uint32_t cs_digit(int32_t c) { return 255u - ((uint32_t)c < 255u ? (uint32_t)c : 255u); }      // counts >= 0
+
+__global__ __launch_bounds__(kRsThreads) void k_cs_tile_hist(const int32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ tilehist,
+                                                             const int64_t *__restrict__ n_dev)
+{
+    if (n_dev && (uint64_t)*n_dev < n) n = (uint32_t)*n_dev;
+    if ((uint64_t)blockIdx.x * kRsTile >= n) return;                 // (rows beyond the device-side size are never read)
+    __shared__ uint32_t h[kRsBins];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kRsTile + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < kRsItems; r++) {
+        const uint32_t i = base + r * kRsThreads;
+        if (i < n) atomicAdd(&h[cs_digit(keys[i])], 1u);
+    }
+    __syncthreads();
+    tilehist[(size_t)blockIdx.x * kRsBins + threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kRsThreads) void k_cs_scatter(const int32_t *__restrict__ keys, uint32_t n, const uint32_t *__restrict__ tilehist,
+                                                           int32_t *__restrict__ order, uint32_t *__restrict__ bigidx, uint32_t bigcap,
+                                                           uint32_t *__restrict__ kbig, const int64_t *__restrict__ n_dev)
+{
+    if (n_dev && (uint64_t)*n_dev < n) n = (uint32_t)*n_dev;
+    if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) *kbig = 0;
+    if ((uint64_t)blockIdx.x * kRsTile >= n) return;
+    __shared__ uint32_t cnt[kRsWaves][kRsBins];
+    __shared__ uint32_t dstart[kRsBins];
+    __shared__ uint32_t gpos[kRsBins];
+    __shared__ uint32_t sdig[kRsTile];               // (one byte would do; a word keeps the LDS reads conflict-free)
+    __shared__ uint32_t sval[kRsTile];
+    __shared__ unsigned long long smem[kRsThreads / kWave];
+    for (int i = threadIdx.x; i < kRsWaves * kRsBins; i += kRsThreads) (&cnt[0][0])[i] = 0;
+    const uint32_t ntiles = (n + kRsTile - 1) / kRsTile;
+    uint32_t before = 0, total = 0;                   // thread = digit: its count in the tiles before mine, and in all
+#pragma unroll 8
+    for (uint32_t t = 0; t < blockIdx.x; t++) before += tilehist[(size_t)t * kRsBins + threadIdx.x];
+    total = before;
+#pragma unroll 8
+    for (uint32_t t = blockIdx.x; t < ntiles; t++) total += tilehist[(size_t)t * kRsBins + threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * kRsTile + w * (kWave * kRsItems) + lane;
+    uint32_t dig[kRsItems], rank[kRsItems];
+#pragma unroll
+    for (int r = 0; r < kRsItems; r++) {
+        const uint32_t i = base + r * kWave;
+        dig[r] = i < n ? cs_digit(keys[i]) : 255u;
+    }
+#pragma unroll
+    for (int r = 0; r < kRsItems; r++) {
+        const uint32_t i = base + r * kWave;
+        const bool valid = i < n;
+        const uint32_t d = dig[r];
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const int leader = __builtin_ctzll(same | (valid ? 0ull : 1ull << lane));
+        uint32_t old = 0;
+        if (valid && lane == leader) { old = cnt[w][d]; cnt[w][d] = old + (uint32_t)__popcll(same); }
+        __builtin_amdgcn_wave_barrier();
+        old = __shfl(old, leader, kWave);
+        rank[r] = old + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < kRsWaves; ww++) { const uint32_t c = cnt[ww][threadIdx.x]; cnt[ww][threadIdx.x] = run; run += c; }
+        unsigned long long tot;
+        const uint32_t ex = (uint32_t)block_excl_scan_u64<kRsThreads>(run, &tot, smem);
+        dstart[threadIdx.x] = ex;
+        __syncthreads();                               // (smem is reused by the second scan)
+        const uint32_t gbase = (uint32_t)block_excl_scan_u64<kRsThreads>(total, &tot, smem);
+        gpos[threadIdx.x] = gbase + before - ex;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *kbig = total < bigcap ? total : bigcap;      // digit 0: the class "255 or more"
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRsItems; r++) {
+        const uint32_t i = base + r * kWave;
+        if (i < n) {
+            const uint32_t d = dig[r];
+            const uint32_t p = dstart[d] + cnt[w][d] + rank[r];
+            sdig[p] = d;
+            sval[p] = i;
+        }
+    }
+    __syncthreads();
+    const uint32_t m = n - blockIdx.x * kRsTile < (uint32_t)kRsTile ? n - blockIdx.x * kRsTile : (uint32_t)kRsTile;
+    for (uint32_t p = threadIdx.x; p < m; p += kRsThreads) {
+        const uint32_t d = sdig[p];
+        const uint32_t pos = gpos[d] + p;
+        if (d == 0) { if (pos < bigcap) bigidx[pos] = sval[p]; }
+        else order[pos] = (int32_t)sval[p];
+    }
+}
+
+// the class "255 or more", in index order in bigidx[0 .. *kbig): rank by (count descending, position ascending)
+__global__ __launch_bounds__(256) void k_cs_rank_big(const int32_t *__restrict__ keys, const uint32_t *__restrict__ bigidx,
+                                                     const uint32_t *__restrict__ kbig, int32_t *__restrict__ order)
+{
+    const uint32_t kb = *kbig;
+    if (blockIdx.x * 256u >= kb) return;
+    __shared__ int32_t sk[256];
+    const uint32_t me = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t myidx = me < kb ? bigidx[me] : 0u;
+    const int32_t mykey = me < kb ? keys[myidx] : 0;
+    uint32_t rank = 0;
+    for (uint32_t c0 = 0; c0 < kb; c0 += 256) {
+        const uint32_t j = c0 + threadIdx.x;
+        __syncthreads();
+        sk[threadIdx.x] = j < kb ? keys[bigidx[j]] : -1;            // (-1: behind every count)
+        __syncthreads();
+        const uint32_t lim = kb - c0 < 256u ? kb - c0 : 256u;
+        for (uint32_t t = 0; t < lim; t++) {
+            const int32_t k = sk[t];
+            rank += (k > mykey || (k == mykey && c0 + t < me)) ? 1u : 0u;
+        }
+    }
+    if (me < kb) order[rank] = (int32_t)myidx;
+}
+
+size_t counts_argsort_bytes(int64_t n)
+{
+    return d3d_align_up((size_t)d3d_divup(n, kRsTile) * kRsBins * 4) + d3d_align_up(((size_t)n / 255 + 1) * 4) + 256;
+}
+
+int counts_argsort_desc(const int32_t *keys, int64_t n, const int64_t *n_dev, int64_t max_key_sum, int32_t *order, void *ws, size_t ws_bytes,
+                        hipStream_t st)
+{
+    const unsigned ntiles = (unsigned)d3d_divup(n, kRsTile);
+    const uint32_t bigcap = (uint32_t)(max_key_sum / 255 + 1);
+    WsCarver w(ws, ws_bytes);
+    uint32_t *tilehist = w.take<uint32_t>((size_t)ntiles * kRsBins);
+    uint32_t *bigidx = w.take<uint32_t>(bigcap);
+    uint32_t *kbig = w.take<uint32_t>(1);
+    if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
+    D3D_LAUNCH("k_cs_tile_hist", k_cs_tile_hist, dim3(ntiles), dim3(kRsThreads), 0, st, keys, (uint32_t)n, tilehist, n_dev);
+    D3D_LAUNCH("k_cs_scatter", k_cs_scatter, dim3(ntiles), dim3(kRsThreads), 0, st, keys, (uint32_t)n, (const uint32_t *)tilehist, order, bigidx,
+               bigcap, kbig, n_dev);
+    D3D_LAUNCH("k_cs_rank_big", k_cs_rank_big, dim3((unsigned)d3d_divup((int64_t)bigcap, 256)), dim3(256), 0, st, keys, (const uint32_t *)bigidx,
+               (const uint32_t *)kbig, order);
+    return D3D_OK;
+}
+
 // ---------------------------------------------------------------- bucket path (2 k .. 128 k keys: the NMS sizes)
 // The library sorts this range with a block sort + one merge launch per doubling (9 launches, 70 us at 100 k keys: launch
 // latency, not bandwidth).  Here: a sample sort in 4 launches --
@@ -499,12 +656,14 @@ extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int
     return argsort_desc<int32_t, int32_t>(keys, n, order, ws, ws_bytes, st);
 }
 
-// the radix path on a device-side count: non-negative keys below 2^key_bits (voxel counts), n_dev <= n of them
-extern "C" int d3d_internal_argsort_desc_i32_dev(const int32_t *keys, int64_t n, const int64_t *n_dev, int key_bits, int32_t *order,
-                                                 void *ws, size_t ws_bytes, hipStream_t st)
+// voxel counts on a device-side count: keys >= 0 whose SUM is at most max_key_sum (the points), n_dev <= n of them
+extern "C" size_t d3d_internal_argsort_counts_bytes(int64_t n) { return counts_argsort_bytes(n); }
+extern "C" int d3d_internal_argsort_desc_counts_dev(const int32_t *keys, int64_t n, const int64_t *n_dev, int64_t max_key_sum, int32_t *order,
+                                                    void *ws, size_t ws_bytes, hipStream_t st)
 {
     if (n <= 0) return D3D_OK;
-    return radix_argsort_desc<int32_t, int32_t>(keys, n, order, ws, ws_bytes, st, n_dev, key_bits);
+    if (max_key_sum > n) max_key_sum = n;          // (the workspace was sized for n / 255 + 1 entries)
+    return counts_argsort_desc(keys, n, n_dev, max_key_sum, order, ws, ws_bytes, st);
 }
 
 // (tests: the radix path at a size the bucket path would take)

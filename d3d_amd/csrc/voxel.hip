@@ -3424,8 +3424,9 @@ extern "C" size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxel
 extern "C" int d3d_internal_argsort_desc_i32(const int32_t *keys, int64_t n, int32_t *order, void *ws, size_t ws_bytes,
                                              hipStream_t st);
 extern "C" size_t d3d_internal_argsort_i32_bytes(int64_t n);
-extern "C" int d3d_internal_argsort_desc_i32_dev(const int32_t *keys, int64_t n, const int64_t *n_dev, int key_bits, int32_t *order,
-                                                 void *ws, size_t ws_bytes, hipStream_t st);
+extern "C" size_t d3d_internal_argsort_counts_bytes(int64_t n);
+extern "C" int d3d_internal_argsort_desc_counts_dev(const int32_t *keys, int64_t n, const int64_t *n_dev, int64_t max_key_sum, int32_t *order,
+                                                    void *ws, size_t ws_bytes, hipStream_t st);
 
 // D3D_VOXEL_EXACT_MEAN (kernels above): everything it needs is in the operator's outputs; scratch = the index's, which is done
 static int exact_mean_pass(const DenseKey &kf, const float *points, int64_t n, int32_t c, uint32_t P, const int64_t *coords,
@@ -3943,12 +3944,11 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                 int rc = binned_index<SparseKey, false>(kf, points, n, c, w, nbins, hshift, sparse_counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
                 if (rc) return rc;
                 if (desc) {
-                    int bits = 1;
-                    while (bits < 31 && (1ll << bits) <= n) bits++;             // counts <= n
-                    const size_t sort_bytes = d3d_internal_argsort_i32_bytes(n);
+                    // (one counting pass on min(count, 255) + the few larger ones ranked among themselves: sort.hip)
+                    const size_t sort_bytes = d3d_internal_argsort_counts_bytes(n);
                     if (sort_bytes > w.tab_bytes) return D3D_ERR_WORKSPACE;
-                    rc = d3d_internal_argsort_desc_i32_dev(desc_keys, n, sparse_counts + D3D_COUNT_VOXELS, bits, desc_order, w.tabA,
-                                                           w.tab_bytes, st);
+                    rc = d3d_internal_argsort_desc_counts_dev(desc_keys, n, sparse_counts + D3D_COUNT_VOXELS, n, desc_order, w.tabA,
+                                                              w.tab_bytes, st);
                     if (rc) return rc;
                     D3D_LAUNCH("k_desc_finish", k_desc_finish, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, (const int32_t *)desc_order,
                                sparse_counts, (uint32_t)max_voxels, (const int64_t *)coords, (const int32_t *)npoints,

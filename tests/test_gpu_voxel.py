@@ -335,6 +335,32 @@ def test_chained_sparse_filter_equals_the_two_calls(kw):
         assert np.array_equal(one[k], two[k]), k
 
 
+@pytest.mark.parametrize("max_voxels", [7, 300, 5000, 10 ** 6])
+@pytest.mark.parametrize("max_points_filter", ["trim", "none"])
+def test_descending_filter_with_many_crowded_voxels(max_voxels, max_points_filter):
+    """the fused DESCENDING filter sorts the voxels' counts in one counting pass on min(count, 255) and ranks the voxels of 255
+    points or more among themselves (sort.hip: k_cs_scatter, k_cs_rank_big): 700 crowded voxels with counts around the class
+    boundary (253 .. 257) and far above it, most of them tied (voxelize.cpp:406 keeps ties in first-seen order), 60 k ordinary
+    ones; the cut falls inside the crowded class, behind it, nowhere."""
+    from d3d_amd.voxel import VoxelGenerator
+    rng = np.random.default_rng(max_voxels % 97)
+    shape, bounds = [64, 64, 16], [0, 64, 0, 64, 0, 16]
+    cells = rng.choice(64 * 64 * 16, 700, replace=False)
+    counts = rng.choice([253, 254, 255, 256, 257, 300, 300, 300, 511, 512, 1200], 700)
+    rows = []
+    for cell, k in zip(cells, counts):
+        corner = np.array([cell // (64 * 16), (cell // 16) % 64, cell % 16], np.float32)
+        rows.append(np.concatenate([corner + 0.05 + 0.9 * rng.random((k, 3)), rng.random((k, 1))], 1))
+    rows.append(rng.random((120000, 4)) * np.array([64, 64, 16, 1]))
+    cloud = np.concatenate(rows).astype(np.float32)
+    cloud = cloud[rng.permutation(len(cloud))]
+    kw = dict(max_points=5, max_points_filter=max_points_filter, min_points=1, max_voxels=max_voxels, max_voxels_filter="descending")
+    exp = oracle.VoxelGenerator(bounds, shape, **kw)(cloud)
+    ret = _np(VoxelGenerator(bounds, shape, **kw)(torch.from_numpy(cloud).cuda()))
+    check_sparse(ret, exp)
+    assert (exp["voxel_npoints"] >= 255).sum() >= min(max_voxels, 400) or max_points_filter == "trim"
+
+
 def test_sparse_bounding_box_key_and_its_fallback():
     """sparse contract: one-word hash slots keyed inside the frame's bounding box (k_bbox); a box too large for the key
     field (far outliers on every axis) raises PACK_OVERFLOW and the call is repeated with plain slots -- same result"""
