@@ -1081,6 +1081,7 @@ struct BinnedExtras {
     bool has_coord_sub = false;      // fused sparse + filter: coords - offset (VoxelGenerator.__call__, voxel/__init__.py:103)
     long long coord_sub[3] = {0, 0, 0};
     int64_t aux_value = 0;           // what k_emit leaves in counts[D3D_COUNT_AUX] (d3d_voxelize_3d_reduce: 1 = ranked index lists)
+    uint16_t *row_state = nullptr;   // d3d_voxelize_3d_dense_resident: [capacity] rows of voxels[v] that may be non-zero (k_emit<.., true>)
 };
 
 // sparse contract fused with the voxel filter (d3d_voxelize_3d_sparse_filter): only voxels that pass get a first-point
@@ -2157,7 +2158,12 @@ __device__ __forceinline__ void wave_lds_fence()  // LDS traffic of THIS wavefro
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <class Key, bool AGG4>
+// RESIDENT (d3d_voxelize_3d_dense_resident): voxels[capacity, P, 4] is a buffer the caller keeps from frame to frame, with
+// row_state[v] = the number of leading rows of voxels[v] that may be non-zero (both zero-filled once, by the caller).  95 % of
+// the dense tensor is padding (1.6 points per voxel at config 2, P = 32) and is ALREADY zero there: the stretch then stores
+// only the rows below max(kept now, row_state[v]) -- the new rows, and zeros over what the previous occupant of id v left --
+// and row_state[v] <- kept.  Ids past this frame's voxel count keep their state until a later frame reaches them.
+template <class Key, bool AGG4, bool RESIDENT = false>
 __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
                                               const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
                                               const uint4 *__restrict__ vrec, uint32_t max_voxels,
@@ -2171,11 +2177,13 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     __shared__ vec4 rowbuf_all[256 / kWave][kEmitCap];
     __shared__ uint32_t off_all[256 / kWave][kWave], base_all[256 / kWave][kWave], first_all[256 / kWave][kWave];
     __shared__ uint16_t kept_all[256 / kWave][kWave];
+    __shared__ uint16_t lim_all[RESIDENT ? 256 / kWave : 1][kWave];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     vec4 *rowbuf = rowbuf_all[w];
     uint32_t *sh_off = off_all[w], *sh_base = base_all[w], *sh_first = first_all[w];
     uint16_t *sh_kept = kept_all[w];
+    uint16_t *sh_lim = lim_all[RESIDENT ? w : 0];
     D3D_PHASE_DECL;
     const uint32_t tile = (uint32_t)(i / kFlagTile), ntile = (uint32_t)(npad / kFlagTile);
     uint32_t before = 0, all = 0;
@@ -2233,6 +2241,16 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     const uint32_t incl = wave_incl_scan_u32(kept);         // rows before this voxel in the wavefront's flat row list
     const uint32_t off = incl - kept;
     sh_off[lane] = off; sh_base[lane] = base; sh_first[lane] = il; sh_kept[lane] = (uint16_t)kept;
+    if (RESIDENT) {                                         // rows to store: the new ones, and zeros over the previous occupant's
+        uint32_t lim = 0;
+        if (mine) {
+            const uint32_t prev = x.row_state[(int64_t)vid0 + lane];
+            lim = prev > kept ? prev : kept;
+            if (lim > P) lim = P;
+            if (prev != kept) x.row_state[(int64_t)vid0 + lane] = (uint16_t)kept;
+        }
+        sh_lim[lane] = (uint16_t)lim;
+    }
     wave_lds_fence();
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
     float a0, a1, a2, a3;
@@ -2290,7 +2308,8 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
                     const uint32_t slot = q - j * P;
                     vec4 val = zero;
                     if (slot < sh_kept[j]) val = rowbuf[sh_off[j] - oa + slot];
-                    __builtin_nontemporal_store(val, &out[q]);
+                    if (RESIDENT) { if (slot < sh_lim[j]) out[q] = val; }
+                    else __builtin_nontemporal_store(val, &out[q]);
                 }
             }
         }
@@ -3365,7 +3384,17 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     if constexpr (ROWS) {
         if (o.emit_voxels || o.emit_reduce) {
             const int pshift = (o.P & (o.P - 1)) == 0 ? __builtin_ctz(o.P) : -1;
-            if (o.agg4)
+            if (x.row_state && o.emit_voxels) {
+                if (o.agg4)
+                    D3D_LAUNCH("k_emit_resident", (k_emit<Key, true, true>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
+                               o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
+                               o.fuse_pmask ? o.pmask : nullptr, reinterpret_cast<float4 *>(o.aggregates), o.emit_voxels, counts,
+                               x.host_counts, x);
+                else
+                    D3D_LAUNCH("k_emit_resident", (k_emit<Key, false, true>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
+                               o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
+                               o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, o.emit_voxels, counts, x.host_counts, x);
+            } else if (o.agg4)
                 D3D_LAUNCH("k_emit", (k_emit<Key, true>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
                            o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
                            o.fuse_pmask ? o.pmask : nullptr, reinterpret_cast<float4 *>(o.aggregates), o.emit_voxels, counts,
@@ -3464,15 +3493,16 @@ static int exact_mean_pass(const DenseKey &kf, const float *points, int64_t n, i
 static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels, int64_t *coords,
                                uint8_t *pmask, int32_t *npoints, float *aggregates, int64_t *counts, void *workspace,
-                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags, int stage);
+                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags, int stage, uint16_t *row_state);
 
 static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels, int64_t *coords,
                                uint8_t *pmask, int32_t *npoints, float *aggregates, int64_t *counts, void *workspace,
-                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags, int stage = 0)
+                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags, int stage = 0,
+                               uint16_t *row_state = nullptr)
 {
     int rc = voxelize_dense_core(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
-                                 aggregates, counts, workspace, workspace_bytes, stream, host_counts, flags, stage);
+                                 aggregates, counts, workspace, workspace_bytes, stream, host_counts, flags, stage, row_state);
     if (rc == D3D_OK && (flags & D3D_VOXEL_EXACT_MEAN) && reduction == D3D_REDUCE_MEAN && max_points > 0 && max_voxels > 0 && n > 0 &&
         stage != 1) {
         DenseKey kf;
@@ -3487,7 +3517,7 @@ static int voxelize_dense_impl(const float *points, int64_t n, int32_t c, const 
 static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels, int64_t *coords,
                                uint8_t *pmask, int32_t *npoints, float *aggregates, int64_t *counts, void *workspace,
-                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags, int stage)
+                               size_t workspace_bytes, void *stream, int64_t *host_counts, uint32_t flags, int stage, uint16_t *row_state)
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || c < 3 || !shape || !bound || !counts || max_points < 0 || max_voxels < 0) return D3D_ERR_BAD_ARG;
@@ -3525,6 +3555,8 @@ static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const 
         }
         // staged calls (d3d_voxelize_3d_dense_staged): only the path whose output is ONE launch
         if (stage != 0 && !(emitted && fuse_pmask)) return D3D_ERR_UNSUPPORTED;
+        if (row_state && !emitted) return D3D_ERR_UNSUPPORTED;       // (resident rows: k_emit's stretch, C == 4)
+        d.x.row_state = row_state;
         d.stage = stage;
         if (vec4) rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
         else {
@@ -3541,7 +3573,7 @@ static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const 
         }
         if (rc) return rc;
     } else {
-        if (stage != 0) return D3D_ERR_UNSUPPORTED;
+        if (stage != 0 || row_state) return D3D_ERR_UNSUPPORTED;
         IndexOpts o{(uint32_t)max_points, (uint32_t)max_voxels, nullptr, 0, nullptr, vec4};
         rc = dense_index(kf, points, n, c, w, counts, o, flags, st);
         if (rc) return rc;
@@ -3616,6 +3648,28 @@ extern "C" int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int3
     if (!host_counts) return D3D_ERR_BAD_ARG;
     return voxelize_dense_impl(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
                                aggregates, counts, workspace, workspace_bytes, stream, host_counts, flags);
+}
+
+// The dense contract into a RESIDENT output (round 4): `voxels` is a buffer [capacity >= min(n, max_voxels) of any call, max_points,
+// 4] that the caller keeps from frame to frame and never writes, `row_state` [capacity] uint16 beside it; both zero-filled by the
+// caller ONCE (hipMemset).  A frame's voxels[0 .. V) then equal what d3d_voxelize_3d_dense writes, bit for bit, but only the rows
+// that hold points -- and zeros over the rows the previous frame's voxel of the same id held -- are stored: the padding, 95 % of
+// the tensor on a LiDAR frame, is already there.  The result aliases the buffer: valid until the next call on it.  Everything
+// else (coords, masks, counts, aggregates, host_counts -- optional here) as in d3d_voxelize_3d_dense_notify.  C == 4 rows on
+// 16-byte aligned buffers, max_points <= 256, the binned index (frames up to 8 M points): else D3D_ERR_UNSUPPORTED and nothing is
+// touched.  max_points is part of the buffer's layout: the same value in every call on it.
+extern "C" int d3d_voxelize_3d_dense_resident(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
+                                              int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels,
+                                              uint16_t *row_state, int64_t *coords, uint8_t *pmask, int32_t *npoints, float *aggregates,
+                                              int64_t *counts, void *workspace, size_t workspace_bytes, void *stream,
+                                              int64_t *host_counts, uint32_t flags)
+{
+    if (!row_state) return D3D_ERR_BAD_ARG;
+    if (max_voxels <= 0 || max_points <= 0) return D3D_ERR_UNSUPPORTED;
+    if (n == 0) row_state = nullptr;               // an empty frame: no voxel, no row, the state stays
+    if (flags & (D3D_VOXEL_PATH_HASH | D3D_VOXEL_SPLIT_FILL)) return D3D_ERR_UNSUPPORTED;
+    return voxelize_dense_impl(points, n, c, shape, bound, max_points, max_voxels, reduction, voxels, coords, pmask, npoints,
+                               aggregates, counts, workspace, workspace_bytes, stream, host_counts, flags, 0, row_state);
 }
 
 // d3d_voxelize_3d_dense_notify in two calls, for callers that pipeline a stream of frames (round 4): stage 1 enqueues the

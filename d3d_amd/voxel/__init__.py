@@ -142,7 +142,21 @@ def _workspace_bytes2(lib, n):
     return b
 
 
-def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type, flags=None, poison=None):
+class DenseOutputBuffer:
+    """A resident output for the dense contract (d3d_voxelize_3d_dense_resident; beyond the reference, which allocates per
+    frame): voxels[capacity, max_points, 4] kept on the device from frame to frame together with, per voxel id, the number of
+    rows that may be non-zero.  A call then stores only the rows that hold points and zeros over what the previous frame's
+    voxel of the same id held; the padding -- 95 % of the tensor on a LiDAR frame -- stays as it is.  The `voxels` a call
+    returns is a view of this buffer: valid until the next call with it, and not to be written."""
+
+    def __init__(self, capacity, max_points, device):
+        self.capacity, self.max_points, self.device = int(capacity), int(max_points), torch.device(device)
+        self.voxels = torch.zeros((self.capacity, self.max_points, 4), dtype=torch.float32, device=self.device)
+        self.row_state = torch.zeros((self.capacity,), dtype=torch.int16, device=self.device)       # (uint16 bits)
+
+
+def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, reduction_type, flags=None, poison=None,
+                      resident=None):
     """voxelize_3d_dense of the reference (voxelize.h:9-12; voxelize.cpp:45-199).
 
     Returns dict(voxels[V,P,C] f32, coords[V,3] i64, voxel_pmask[V,P] bool,
@@ -150,7 +164,8 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
 
     flags: per-call index options (_lib.VOXEL_*; None = the calling context's, d3d_amd.options).  poison (test hook): fill
     every output buffer with NaN / 0xff patterns first, so that a row the kernels fail to write cannot hide behind fresh
-    (zeroed) memory.
+    (zeroed) memory.  resident: a DenseOutputBuffer -- `voxels` comes back as a view of it (same values, see there; a frame the binned index does
+    not take gets a fresh tensor instead); ValueError for rows of other than 4 floats or a buffer that does not fit.
     """
     lib = _lib.load()
     pts, odev, dev = _stage(points)
@@ -162,8 +177,11 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
     shape_h = _host_array(voxel_shape, ctypes.c_int32, 3)
     bound_h = _host_array(voxel_bound, ctypes.c_float, 6)
     cap = max(min(n, max_voxels), 0)
+    if resident is not None and (c != 4 or resident.max_points != max_points or resident.capacity < cap or resident.device != dev
+                                 or max_points <= 0 or max_voxels <= 0):
+        raise ValueError("resident output: needs [N,4] points, the buffer's max_points and device, capacity >= min(N, max_voxels)")
     with _device_ctx(dev):
-        voxels = torch.empty((cap, max_points, c), dtype=torch.float32, device=dev)
+        voxels = resident.voxels if resident is not None else torch.empty((cap, max_points, c), dtype=torch.float32, device=dev)
         coords = torch.empty((cap, 3), dtype=torch.int64, device=dev)
         pmask = torch.empty((cap, max_points), dtype=torch.uint8, device=dev)
         npts = torch.empty((cap,), dtype=torch.int32, device=dev)
@@ -172,11 +190,36 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
         ws = _lib.workspace(_workspace_bytes(lib, n), dev)
         note = _lib.NotifyBuffer.get()
         if options.current().poison if poison is None else poison:
-            voxels.fill_(float("nan")); coords.fill_(-(1 << 62)); pmask.fill_(0xff); npts.fill_(-7)
+            if resident is None:
+                voxels.fill_(float("nan"))
+            coords.fill_(-(1 << 62)); pmask.fill_(0xff); npts.fill_(-7)
             if agg is not None:
                 agg.fill_(float("nan"))
 
+        def run_resident(fl):
+            note.arm()
+            rc = lib.d3d_voxelize_3d_dense_resident(
+                _lib.ptr(pts), n, c, ctypes.cast(shape_h, ctypes.c_void_p), ctypes.cast(bound_h, ctypes.c_void_p),
+                max_points, max_voxels, red, _lib.ptr(voxels), _lib.ptr(resident.row_state), _lib.ptr(coords), _lib.ptr(pmask),
+                _lib.ptr(npts), _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), note.ptr, fl)
+            if rc == _lib.ERR_UNSUPPORTED:
+                return None                 # nothing was touched: the plain call decides (and reports a bad reduction type)
+            _lib.check(rc, "voxelize_3d_dense_resident")
+            host = note.wait(counts)
+            _check_status(int(host[_lib.COUNT_STATUS]), "voxelize_3d_dense_resident")
+            return int(host[_lib.COUNT_VOXELS])
+
         def run(fl):
+            nonlocal voxels
+            if resident is not None:
+                if not (fl & _lib.VOXEL_PATH_HASH):
+                    nv_res = run_resident(fl)
+                    if nv_res is not None:
+                        return nv_res
+                # (a frame the binned index does not take -- above 8 M points, or a bucket overflowed and the call is repeated
+                # on the hash path: those paths write whole tensors, a fresh one for this frame; the buffer's invariant is
+                # untouched and the next frame uses it again)
+                voxels = torch.empty((cap, max_points, c), dtype=torch.float32, device=dev)
             # the voxel count reaches the host through pinned memory as soon as it is final, while the GPU is still
             # writing voxels[V,P,C]: the call returns views of outputs in flight on the current stream, like any torch op
             note.arm()
@@ -379,12 +422,17 @@ class VoxelGenerator:
     reference's d3d.voxel.VoxelGenerator (voxel/__init__.py:12-104)."""
 
     def __init__(self, bounds, shape, min_points=0, max_points=30, max_voxels=20000,
-                 max_points_filter=None, max_voxels_filter=None, reduction=None, dense=False):
+                 max_points_filter=None, max_voxels_filter=None, reduction=None, dense=False, resident=False):
+        # resident (beyond the reference; dense only): `voxels` is returned as a view of a buffer the generator keeps on the
+        # device (DenseOutputBuffer) -- same values, valid until the generator's next call.
         # The derived grid quantities are tiny fp32 host tensors computed with the same torch
         # ops as the reference so that `size` is bit-identical (it feeds the coordinate division).
         self._bounds = torch.tensor(bounds, dtype=torch.float)
         self._shape = torch.tensor(shape, dtype=torch.int32)
         self._min_points, self._max_points, self._max_voxels, self._dense = min_points, max_points, max_voxels, dense
+        if resident and not dense:
+            raise ValueError("resident output is for dense voxelization")
+        self._resident, self._resident_buf = bool(resident), None
 
         lohi = self._bounds.reshape(3, 2)
         self._size = (lohi[:, 1] - lohi[:, 0]) / self._shape                                  # :41
@@ -439,8 +487,15 @@ class VoxelGenerator:
         if not points.is_cuda:
             points = points.to(_lib.require_gpu())    # stage once; results go back to the caller's device
         if self._dense:
+            buf = None
+            if self._resident and points.shape[0] > 0:
+                need = min(int(points.shape[0]), int(self._max_voxels))
+                buf = self._resident_buf
+                if buf is None or buf.capacity < need or buf.device != points.device:
+                    grow = need if buf is None else max(need, buf.capacity + buf.capacity // 4)
+                    buf = self._resident_buf = DenseOutputBuffer(min(grow, int(self._max_voxels)), self._max_points, points.device)
             ret = Dict(voxelize_3d_dense(points, self._shape_h, self._bounds_h, self._max_points,
-                                         self._max_voxels, self._reduction, flags=flags, poison=poison))
+                                         self._max_voxels, self._reduction, flags=flags, poison=poison, resident=buf))
         else:
             pf, vf = int(self._max_points_filter), int(self._max_voxels_filter)
             ret = None

@@ -361,6 +361,93 @@ def test_descending_filter_with_many_crowded_voxels(max_voxels, max_points_filte
     assert (exp["voxel_npoints"] >= 255).sum() >= min(max_voxels, 400) or max_points_filter == "trim"
 
 
+@pytest.mark.parametrize("red", ["none", "mean", "max"])
+@pytest.mark.parametrize("P", [4, 32])
+def test_resident_dense_output_over_a_sequence_of_frames(red, P, index_path):
+    """VoxelGenerator(dense=True, resident=True) (d3d_voxelize_3d_dense_resident): `voxels` is a view of a buffer kept on the
+    device, of which a call stores only the rows with points and zeros over what the previous frame left under the same voxel
+    id.  Ten frames of very different shape -- dense, sparse, one crowded voxel, a single point, empty, growing past the
+    buffer's capacity, max_voxels cutting -- each equal to the oracle (= the reference's fresh, zero-padded tensor) bit for
+    bit on EVERY output, and the buffer's invariant (rows at and beyond a voxel's count are zero, everywhere) after each."""
+    from d3d_amd.voxel import VoxelGenerator
+    rng = np.random.default_rng(P)
+    bounds, shape = [0, 8, 0, 8, 0, 2], [40, 40, 8]
+    gen = VoxelGenerator(bounds, shape, max_points=P, max_voxels=9000, reduction=red, dense=True, resident=True)
+    ref = oracle.VoxelGenerator(bounds, shape, max_points=P, max_voxels=9000, reduction=red, dense=True)
+    span = np.array([8, 8, 2, 1], np.float32)
+
+    def cloud(n, clump=0.0, where=0.5):
+        c = rng.random((n, 4)).astype(np.float32) * span
+        k = int(n * clump)
+        c[:k, :3] = (np.array([8, 8, 2]) * where + 0.15 * rng.random((k, 3))).astype(np.float32)
+        return c[rng.permutation(n)]
+
+    frames = [cloud(6000), cloud(60000, 0.3), cloud(900), cloud(1), cloud(20000, 0.9, 0.2), np.zeros((0, 4), np.float32),
+              cloud(5000, 0.5, 0.8), cloud(200000), cloud(7000, 0.2), cloud(40000, 0.1, 0.3)]
+    for k, f in enumerate(frames):
+        exp = ref(f)
+        got = gen(torch.from_numpy(f).cuda())
+        check_dense(_np(got), exp, P)
+        buf = gen._resident_buf
+        if buf is not None and len(f):
+            # (the hash path and the two-launch output stage write whole tensors: a fresh one then, the buffer is left alone)
+            aliased = got["voxels"].untyped_storage().data_ptr() == buf.voxels.untyped_storage().data_ptr()
+            assert aliased == (index_path in ("auto", "3pass")), k
+            state = buf.row_state.cpu().numpy().astype(np.int64) & 0xffff
+            nz = (buf.voxels != 0).any(dim=2).cpu().numpy()                     # [capacity, P]: rows that hold anything
+            assert not (nz & (np.arange(P)[None, :] >= state[:, None])).any(), k
+    assert gen._resident_buf.capacity == 9000                                   # (grew from 6000 when the 60000-point frame came)
+
+
+def test_resident_dense_c_abi_contract():
+    """d3d_voxelize_3d_dense_resident through ctypes: rows of 5 floats, the hash path and SPLIT_FILL are D3D_ERR_UNSUPPORTED
+    and touch nothing; a missing row_state is a bad argument; two frames through ONE buffer equal the plain entry point."""
+    import ctypes
+    from d3d_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    shape = (ctypes.c_int32 * 3)(32, 32, 4)
+    bound = (ctypes.c_float * 6)(0, 1, 0, 1, 0, 1)
+    P, MV = 16, 5000
+    vox = torch.zeros((MV, P, 4), device="cuda")
+    state = torch.zeros((MV,), dtype=torch.int16, device="cuda")
+
+    def outs(c=4):
+        return (torch.full((MV, 3), -5, dtype=torch.int64, device="cuda"), torch.full((MV, P), 7, dtype=torch.uint8, device="cuda"),
+                torch.full((MV,), -5, dtype=torch.int32, device="cuda"), torch.full((MV, c), -5.0, device="cuda"),
+                torch.zeros((_lib.NUM_COUNTS,), dtype=torch.int64, device="cuda"))
+
+    def call(pts, c, flags=0, row_state=state, resident=True, voxels=vox):
+        coords, pmask, npts, agg, counts = outs(c)
+        n = pts.shape[0]
+        ws = _lib.workspace(lib.d3d_voxelize_workspace_bytes(n, 0), pts.device)
+        a = [_lib.ptr(pts), n, c, ctypes.cast(shape, ctypes.c_void_p), ctypes.cast(bound, ctypes.c_void_p), P, MV, 1, _lib.ptr(voxels)]
+        b = [_lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts), _lib.ptr(agg), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()]
+        if resident:
+            rc = lib.d3d_voxelize_3d_dense_resident(*a, _lib.ptr(row_state) if row_state is not None else None, *b, None, flags)
+        else:
+            rc = lib.d3d_voxelize_3d_dense(*a, *b, flags)
+        torch.cuda.synchronize()
+        return rc, coords, pmask, npts, agg, counts
+
+    p5 = torch.from_numpy(rng.random((3000, 5)).astype(np.float32)).cuda()
+    p4 = torch.from_numpy(rng.random((3000, 4)).astype(np.float32)).cuda()
+    for rc, *o in (call(p5, 5), call(p4, 4, _lib.VOXEL_PATH_HASH), call(p4, 4, _lib.VOXEL_SPLIT_FILL)):
+        assert rc == _lib.ERR_UNSUPPORTED
+        assert int(vox.count_nonzero()) == 0 and int(state.count_nonzero()) == 0 and int((o[2] != -5).sum()) == 0
+    assert call(p4, 4, row_state=None)[0] == _lib.ERR_BAD_ARG
+    for n in (3000, 700):
+        pts = torch.from_numpy(rng.random((n, 4)).astype(np.float32)).cuda()
+        rc, coords, pmask, npts, agg, counts = call(pts, 4)
+        assert rc == _lib.OK
+        fresh = torch.full((MV, P, 4), float("nan"), device="cuda")
+        rc2, coords2, pmask2, npts2, agg2, counts2 = call(pts, 4, resident=False, voxels=fresh)
+        nv = int(counts[_lib.COUNT_VOXELS])
+        assert rc2 == _lib.OK and nv == int(counts2[_lib.COUNT_VOXELS]) and nv > 0
+        assert torch.equal(vox[:nv], fresh[:nv]) and torch.equal(coords[:nv], coords2[:nv]) and torch.equal(npts[:nv], npts2[:nv])
+        assert torch.equal(pmask[:nv], pmask2[:nv]) and torch.equal(agg[:nv], agg2[:nv])
+
+
 def test_sparse_bounding_box_key_and_its_fallback():
     """sparse contract: one-word hash slots keyed inside the frame's bounding box (k_bbox); a box too large for the key
     field (far outliers on every axis) raises PACK_OVERFLOW and the call is repeated with plain slots -- same result"""
