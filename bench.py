@@ -271,6 +271,25 @@ def extras(args):
     ex["voxelize_dense_pipelined_us_per_frame"] = round(dtp / nfr * 1e6, 1)
     ex["voxelize_dense_pipelined_note"] = ("two frames in flight on two streams: no gain on this stack -- one hardware queue serialises "
                                            "them, two queues pay 50-60 us per cross-queue event wait (DESIGN.md 4d); off by default")
+    del gen
+    # the dense contract into a RESIDENT output (d3d_voxelize_3d_dense_resident): voxels[V,P,4] comes back as a view
+    # of a buffer the generator keeps on the device, of which a frame stores only the rows that hold points and zeros over the
+    # previous frame's -- same values as the headline's fresh tensor, bit for bit, without re-writing 95 % zero padding.  An EXTRA
+    # (a different output contract: the result is valid until the next call); alternating frames, so that every voxel id changes hands.
+    gen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=32, max_voxels=args.points,
+                         resident=True)
+    kfr = [0]
+
+    def resident_step():
+        kfr[0] += 1
+        return gen(ca if kfr[0] & 1 else cb)
+    dtr = timed(resident_step, 40, 4)
+    rp = kernel_profile(resident_step, 20)
+    ex["voxelize_dense_resident_mpoints_per_s"] = round(args.points * 40 / dtr / 1e6, 2)
+    ex["voxelize_dense_resident_us_per_frame"] = round(dtr / 40 * 1e6, 1)
+    ex["voxelize_dense_resident_kernels_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(rp.items(), key=lambda kv: -kv[1]["total_ms"])}
+    ex["voxelize_dense_resident_note"] = ("output buffer resident on the device: rows with points + stale rows stored, zero padding kept "
+                                          "(same values as the headline's tensor; valid until the next call); not the headline contract")
     del ca, cb, gen
     torch.cuda.empty_cache()
     # config 2 on the UNIFORM cloud (SURVEY 8d's worst case: ~0.98 voxels per point, 500 MB of voxels[V,32,4])

@@ -2178,12 +2178,14 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     __shared__ uint32_t off_all[256 / kWave][kWave], base_all[256 / kWave][kWave], first_all[256 / kWave][kWave];
     __shared__ uint16_t kept_all[256 / kWave][kWave];
     __shared__ uint16_t lim_all[RESIDENT ? 256 / kWave : 1][kWave];
+    __shared__ uint32_t loff_all[RESIDENT ? 256 / kWave : 1][kWave + 1];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     vec4 *rowbuf = rowbuf_all[w];
     uint32_t *sh_off = off_all[w], *sh_base = base_all[w], *sh_first = first_all[w];
     uint16_t *sh_kept = kept_all[w];
     uint16_t *sh_lim = lim_all[RESIDENT ? w : 0];
+    uint32_t *sh_loff = loff_all[RESIDENT ? w : 0];
     D3D_PHASE_DECL;
     const uint32_t tile = (uint32_t)(i / kFlagTile), ntile = (uint32_t)(npad / kFlagTile);
     uint32_t before = 0, all = 0;
@@ -2241,6 +2243,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     const uint32_t incl = wave_incl_scan_u32(kept);         // rows before this voxel in the wavefront's flat row list
     const uint32_t off = incl - kept;
     sh_off[lane] = off; sh_base[lane] = base; sh_first[lane] = il; sh_kept[lane] = (uint16_t)kept;
+    uint32_t loff = 0;
     if (RESIDENT) {                                         // rows to store: the new ones, and zeros over the previous occupant's
         uint32_t lim = 0;
         if (mine) {
@@ -2250,6 +2253,8 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
             if (prev != kept) x.row_state[(int64_t)vid0 + lane] = (uint16_t)kept;
         }
         sh_lim[lane] = (uint16_t)lim;
+        loff = wave_incl_scan_u32(lim) - lim;               // rows to store before this voxel, over the wavefront
+        sh_loff[lane] = loff;
     }
     wave_lds_fence();
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
@@ -2298,7 +2303,27 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
         }
         D3D_PHASE(2, 3);                                    // reductions
         // 4. the stretch of the batch's voxels
-        const uint32_t q1 = voxels ? jb * P : 0u;
+        if (RESIDENT) {
+            // the rows to store, flat over the batch's voxels (a few dozen per wavefront, not nv * P slots)
+            const uint32_t l0 = (uint32_t)__shfl((int)loff, (int)ja, kWave);
+            const uint32_t l1 = jb < (uint32_t)kWave ? (uint32_t)__shfl((int)loff, (int)jb, kWave)
+                                                    : (uint32_t)__shfl((int)(loff + sh_lim[lane]), kWave - 1, kWave);
+            for (uint32_t t0 = l0; t0 < l1; t0 += kWave) {
+                const uint32_t t = t0 + lane;
+                if (t < l1) {
+                    uint32_t lo = ja, hi = jb;              // largest j in [ja, jb) with loff[j] <= t
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (sh_loff[mid] <= t) lo = mid; else hi = mid;
+                    }
+                    const uint32_t slot = t - sh_loff[lo];
+                    vec4 val = zero;
+                    if (slot < sh_kept[lo]) val = rowbuf[sh_off[lo] - oa + slot];
+                    out[lo * P + slot] = val;
+                }
+            }
+        }
+        const uint32_t q1 = voxels && !RESIDENT ? jb * P : 0u;
         for (uint32_t q0 = ja * P; q0 < q1; q0 += 4 * kWave) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -2308,8 +2333,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
                     const uint32_t slot = q - j * P;
                     vec4 val = zero;
                     if (slot < sh_kept[j]) val = rowbuf[sh_off[j] - oa + slot];
-                    if (RESIDENT) { if (slot < sh_lim[j]) out[q] = val; }
-                    else __builtin_nontemporal_store(val, &out[q]);
+                    __builtin_nontemporal_store(val, &out[q]);
                 }
             }
         }
