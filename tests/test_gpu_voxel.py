@@ -305,6 +305,10 @@ def test_randomized_configs_vs_oracle(seed):
     exp = oracle.VoxelGenerator(bounds, shape, **kw)(cloud)
     ret = _np(VoxelGenerator(bounds, shape, **kw)(pts))
     check_dense(ret, exp, P)
+    if c == 4:          # the resident output (d3d_voxelize_3d_dense_resident): four frames through ONE buffer, each vs the oracle
+        rgen, ogen = VoxelGenerator(bounds, shape, resident=True, **kw), oracle.VoxelGenerator(bounds, shape, **kw)
+        for frame in (cloud, cloud[::3].copy(), cloud[::-1].copy(), cloud[: max(1, n // 7)].copy(), cloud):
+            check_dense(_np(rgen(torch.from_numpy(frame).cuda())), ogen(frame), P)
     kw = dict(max_points=P, max_points_filter=str(rng.choice(["trim", "none"])), min_points=int(rng.integers(0, 3)),
               max_voxels=mv, max_voxels_filter=str(rng.choice(["trim", "none", "descending"])))
     exp = oracle.VoxelGenerator(bounds, shape, **kw)(cloud)
