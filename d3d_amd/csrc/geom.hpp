@@ -589,22 +589,81 @@ __device__ __noinline__ T hull_area2_general(const Corners8<T> &c, T (&gx)[8], T
 // with oA[k][t] = orient(a_k, a_k+1, b_t), oB[k][t] = orient(b_k, b_k+1, a_t).  A wavefront in which ANY lane meets an exact
 // zero (collinear or coincident corners: identical boxes, shared edges, the axis-aligned test cases) takes the general
 // routine with its tie rules; random boxes never do.  Same decisions, same accepted segments, same sums.
+// The 32 signs are first read off in the boxes' OWN frames (late round 4): oA[k][t] is the distance of corner b_t from edge k of
+// A times that edge's length, and in A's frame (p, q) = ((b_t - centre) . U, (b_t - centre) . V) the four edges are the lines
+// q = -|V|^2, p = |U|^2, q = |V|^2, p = -|U|^2.  With b_t = D +- Ub +- Vb the sixteen (p, q) of both frames come from eight dot
+// products of the half-extent vectors and the centre offset: ~60 fp64 operations instead of 32 orientations of 7.  A value
+// within 256 ulp of the operands' scale of zero proves nothing about the orientation's sign; a wavefront with such a lane (boxes
+// sharing an edge, axis-aligned test cases; never a random pair) evaluates the orientations themselves, as before.  Where every
+// value is clear of zero by that margin the orientation's computed sign is the true one too, so the decisions -- and with them
+// the accepted segments and their sums -- are the same as before, bit for bit.
+template <typename T>
+__device__ __forceinline__ void hull_signs_own_frames(const BoxGeom<T> &a, const BoxGeom<T> &b, uint32_t &pa, uint32_t &na,
+                                                      uint32_t &pb, uint32_t &nb)
+{
+    const T dx = b.cx - a.cx, dy = b.cy - a.cy;
+    const T uu = a.ux * b.ux + a.uy * b.uy, uv = a.ux * b.vx + a.uy * b.vy;      // Ua . Ub, Ua . Vb
+    const T vu = a.vx * b.ux + a.vy * b.uy, vv = a.vx * b.vx + a.vy * b.vy;      // Va . Ub, Va . Vb
+    const T ra = fabs(a.ux) + fabs(a.uy) + fabs(a.vx) + fabs(a.vy), rb = fabs(b.ux) + fabs(b.uy) + fabs(b.vx) + fabs(b.vy);
+    const T ext = (fabs(dx) + fabs(dy) + ra + rb) * ((T)256 * (sizeof(T) == 8 ? (T)2.220446049250313e-16 : (T)1.1920929e-7f));
+    {
+        const T p0 = dx * a.ux + dy * a.uy, q0 = dx * a.vx + dy * a.vy;
+        const T hu = a.ux * a.ux + a.uy * a.uy, hv = a.vx * a.vx + a.vy * a.vy, tol = ext * ra;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const T p = p0 + ((t == 1 || t == 2) ? uu : -uu) + (t >= 2 ? uv : -uv);
+            const T q = q0 + ((t == 1 || t == 2) ? vu : -vu) + (t >= 2 ? vv : -vv);
+            const T e0 = q + hv, e1 = hu - p, e2 = hv - q, e3 = p + hu;
+            pa |= ((e0 > tol ? 1u : 0u) | (e1 > tol ? 16u : 0u) | (e2 > tol ? 256u : 0u) | (e3 > tol ? 4096u : 0u)) << t;
+            na |= ((e0 < -tol ? 1u : 0u) | (e1 < -tol ? 16u : 0u) | (e2 < -tol ? 256u : 0u) | (e3 < -tol ? 4096u : 0u)) << t;
+        }
+    }
+    {
+        const T p0 = -(dx * b.ux + dy * b.uy), q0 = -(dx * b.vx + dy * b.vy);
+        const T hu = b.ux * b.ux + b.uy * b.uy, hv = b.vx * b.vx + b.vy * b.vy, tol = ext * rb;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const T p = p0 + ((t == 1 || t == 2) ? uu : -uu) + (t >= 2 ? vu : -vu);
+            const T q = q0 + ((t == 1 || t == 2) ? uv : -uv) + (t >= 2 ? vv : -vv);
+            const T e0 = q + hv, e1 = hu - p, e2 = hv - q, e3 = p + hu;
+            pb |= ((e0 > tol ? 1u : 0u) | (e1 > tol ? 16u : 0u) | (e2 > tol ? 256u : 0u) | (e3 > tol ? 4096u : 0u)) << t;
+            nb |= ((e0 < -tol ? 1u : 0u) | (e1 < -tol ? 16u : 0u) | (e2 < -tol ? 256u : 0u) | (e3 < -tol ? 4096u : 0u)) << t;
+        }
+    }
+}
+
 template <typename T, bool GRAD>
-__device__ __forceinline__ T hull_area2(const Corners8<T> &c, T (&gx)[8], T (&gy)[8])
+__device__ __forceinline__ T hull_area2(const Corners8<T> &c, const BoxGeom<T> &ga, const BoxGeom<T> &gb, T (&gx)[8], T (&gy)[8])
 {
     // only the SIGNS are kept: bit 4 k + t of pa / na = oA[k][t] > 0 / < 0 (pb / nb likewise) -- 32 fp64 values held until the
     // bridges are through cost 64 VGPRs and an occupancy step
     uint32_t pa = 0, na = 0, pb = 0, nb = 0;
+    hull_signs_own_frames<T>(ga, gb, pa, na, pb, nb);
+    if (__any(((pa | na) & (pb | nb)) != 0xffffu)) {        // a value too close to zero somewhere: the orientations themselves
+        pa = na = pb = nb = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 4; k++) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const T a = orient3<T>(c, k, (k + 1) & 3, 4 + t), b = orient3<T>(c, 4 + k, 4 + ((k + 1) & 3), t);
-            pa |= (a > 0 ? 1u : 0u) << (4 * k + t); na |= (a < 0 ? 1u : 0u) << (4 * k + t);
-            pb |= (b > 0 ? 1u : 0u) << (4 * k + t); nb |= (b < 0 ? 1u : 0u) << (4 * k + t);
+            for (int t = 0; t < 4; t++) {
+                const T a = orient3<T>(c, k, (k + 1) & 3, 4 + t), b = orient3<T>(c, 4 + k, 4 + ((k + 1) & 3), t);
+                pa |= (a > 0 ? 1u : 0u) << (4 * k + t); na |= (a < 0 ? 1u : 0u) << (4 * k + t);
+                pb |= (b > 0 ? 1u : 0u) << (4 * k + t); nb |= (b < 0 ? 1u : 0u) << (4 * k + t);
+            }
         }
+        if (__any(((pa | na) & (pb | nb)) != 0xffffu)) return hull_area2_general<T, GRAD>(c, gx, gy);    // an exact zero somewhere
     }
-    if (__any(((pa | na) & (pb | nb)) != 0xffffu)) return hull_area2_general<T, GRAD>(c, gx, gy);    // an exact zero somewhere
+    // All 32 bridge decisions at once, on the 16-bit masks (bit 4 i + j = bridge between a_i and b_j): a_i -> b_j is a hull
+    // segment when oA[i][j] < 0, oA[i-1][j] > 0, oB[j][i] > 0 and oB[j-1][i] < 0 -- the second mask is the first's rows moved up
+    // by one (a 4-bit rotation of the 16), the B masks are indexed [j][i]: transposed, rows moved up = columns after it.
+    // (~45 integer operations for the 32 decisions; spelled out per bridge they were eight mask tests each.)
+    auto rot4 = [](uint32_t x) { return ((x << 4) | (x >> 12)) & 0xffffu; };
+    auto transpose4 = [](uint32_t x) {
+        return (x & 0x8421u) | ((x & 0x0842u) << 3) | ((x & 0x0084u) << 6) | ((x & 0x0008u) << 9) | ((x >> 3) & 0x0842u) |
+               ((x >> 6) & 0x0084u) | ((x >> 9) & 0x0008u);
+    };
+    auto colrot = [](uint32_t t) { return ((t << 1) & 0xeeeeu) | ((t >> 3) & 0x1111u); };       // transpose4(rot4(x)) from transpose4(x)
+    const uint32_t tpb = transpose4(pb), tnb = transpose4(nb);
+    const uint32_t m_ab = na & rot4(pa) & tpb & colrot(tnb), m_ba = pa & rot4(na) & tnb & colrot(tpb);
     T h2 = 0;
     if (GRAD) {
 #pragma unroll
@@ -616,23 +675,28 @@ __device__ __forceinline__ T hull_area2(const Corners8<T> &c, T (&gx)[8], T (&gy
     };
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        if (((pa >> (4 * k)) & 15u) == 15u) accept(k, (k + 1) & 3);
-        if (((pb >> (4 * k)) & 15u) == 15u) accept(4 + k, 4 + ((k + 1) & 3));
+        if (GRAD) {
+            if (((pa >> (4 * k)) & 15u) == 15u) accept(k, (k + 1) & 3);
+            if (((pb >> (4 * k)) & 15u) == 15u) accept(4 + k, 4 + ((k + 1) & 3));
+        } else {                                   // selects, no branches (the order of the sums is the same)
+            const int k1 = (k + 1) & 3;
+            const T ea = c.x[k] * c.y[k1] - c.y[k] * c.x[k1], eb = c.x[4 + k] * c.y[4 + k1] - c.y[4 + k] * c.x[4 + k1];
+            h2 += ((pa >> (4 * k)) & 15u) == 15u ? ea : (T)0;
+            h2 += ((pb >> (4 * k)) & 15u) == 15u ? eb : (T)0;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            // an = oA[i][j], ap = oA[i-1][j], bn = oB[j][i], bp = oB[j-1][i]
-            const uint32_t an = 1u << (4 * i + j), ap = 1u << (4 * ((i + 3) & 3) + j), bn = 1u << (4 * j + i), bp = 1u << (4 * ((j + 3) & 3) + i);
-            const bool ab = (na & an) && (pa & ap) && (pb & bn) && (nb & bp), ba = (pa & an) && (na & ap) && (nb & bn) && (pb & bp);
+            const bool ab = (m_ab >> (4 * i + j)) & 1u, ba = (m_ba >> (4 * i + j)) & 1u;
             if (GRAD) {
                 if (ab) accept(i, 4 + j);
                 if (ba) accept(4 + j, i);
             } else {                               // cross(b, a) = -cross(a, b) exactly (products commute, the difference flips)
                 const T x = c.x[i] * c.y[4 + j] - c.y[i] * c.x[4 + j];
-                if (ab) h2 += x;
-                if (ba) h2 -= x;
+                h2 += ab ? x : (T)0;
+                h2 -= ba ? x : (T)0;
             }
         }
     }
@@ -704,7 +768,7 @@ __device__ __forceinline__ T loss_iou_rbox(const BoxGeom<T> &a, const BoxGeom<T>
     const T dA1[5] = {0, 0, h1, w1, 0}, dA2[5] = {0, 0, h2, w2, 0};
     if (KIND == 0) {
         T gx[8], gy[8];
-        const T H = hull_area2<T, GRAD>(c, gx, gy) / 2;
+        const T H = hull_area2<T, GRAD>(c, a, b, gx, gy) / 2;
         if (GRAD) {
             T dHa[5] = {0, 0, 0, 0, 0}, dHb[5] = {0, 0, 0, 0, 0};
 #pragma unroll
