@@ -1075,7 +1075,9 @@ __global__ __launch_bounds__(256) void k_owner_map(int64_t n, const int64_t *__r
 constexpr int kDenseCap = 256;                    // rows per wavefront in LDS; max_points <= kDenseCap
 
 // BUCKETS: a voxel's records are the list its leader's rinfo word names; else the chain of its slot
-template <bool BUCKETS>
+// RESIDENT: voxels / row_state are kept by the caller from frame to frame (see k_emit<.., RESIDENT> in voxel.hip and
+// d3d_voxelize_3d_dense_resident): only rows below max(kept, row_state[v]) are stored, row_state[v] <- kept.
+template <bool BUCKETS, bool RESIDENT = false>
 __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__ counts_o, const int32_t *__restrict__ lead_rec,
                                                      const int32_t *__restrict__ npoints, const uint32_t *__restrict__ rec_slot,
                                                      const MergeSlot *__restrict__ mslot, const uint32_t *__restrict__ next,
@@ -1083,12 +1085,14 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
                                                      const int64_t *__restrict__ src_off, int world,
                                                      const int32_t *__restrict__ recv, int RS, const float4 *__restrict__ recv_rows,
                                                      const int64_t *__restrict__ rows_src_off, uint32_t P, int pshift,
-                                                     float4 *voxels, unsigned char *pmask)
+                                                     float4 *voxels, unsigned char *pmask, uint16_t *row_state)
 {
     typedef float vec4 __attribute__((ext_vector_type(4)));
     __shared__ vec4 rowbuf_all[256 / kWave][kDenseCap];
     __shared__ uint32_t off_all[256 / kWave][kWave];
     __shared__ uint16_t kept_all[256 / kWave][kWave];
+    __shared__ uint16_t lim_all[RESIDENT ? 256 / kWave : 1][kWave];
+    __shared__ uint32_t loff_all[RESIDENT ? 256 / kWave : 1][kWave];
     __shared__ int64_t so[kMaxWorld + 1], rso[kMaxWorld + 1];          // records / rows per source rank, exclusive prefixes
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     if (threadIdx.x <= (unsigned)world) { so[threadIdx.x] = src_off[threadIdx.x]; rso[threadIdx.x] = rows_src_off[threadIdx.x]; }
@@ -1116,6 +1120,25 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
     }
     const uint32_t off = incl - kept;
     sh_off[lane] = off; sh_kept[lane] = (uint16_t)kept;
+    uint16_t *sh_lim = lim_all[RESIDENT ? w : 0];
+    uint32_t *sh_loff = loff_all[RESIDENT ? w : 0];
+    uint32_t loff = 0, lim = 0;
+    if (RESIDENT) {
+        if (mine) {
+            const uint32_t prev = row_state[v0 + lane];
+            lim = prev > kept ? prev : kept;
+            if (lim > P) lim = P;
+            if (prev != kept) row_state[v0 + lane] = (uint16_t)kept;
+        }
+        uint32_t li = lim;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)li, d, kWave);
+            if (lane >= d) li += t;
+        }
+        loff = li - lim;
+        sh_lim[lane] = (uint16_t)lim; sh_loff[lane] = loff;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     vec4 *out = reinterpret_cast<vec4 *>(voxels) + v0 * (int64_t)P;
     const vec4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -1176,7 +1199,26 @@ __global__ __launch_bounds__(256) void k_owner_dense(const int64_t *__restrict__
             } else chain_in_order(next, head, take_rows);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const uint32_t q1 = jb * P;
+        if (RESIDENT) {                                     // the rows to store, flat over the batch's voxels
+            const uint32_t l0 = (uint32_t)__shfl((int)loff, (int)ja, kWave);
+            const uint32_t l1 = jb < (uint32_t)kWave ? (uint32_t)__shfl((int)loff, (int)jb, kWave)
+                                                    : (uint32_t)__shfl((int)(loff + lim), kWave - 1, kWave);
+            for (uint32_t t0 = l0; t0 < l1; t0 += kWave) {
+                const uint32_t t = t0 + lane;
+                if (t < l1) {
+                    uint32_t lo = ja, hi = jb;              // largest j in [ja, jb) with loff[j] <= t
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (sh_loff[mid] <= t) lo = mid; else hi = mid;
+                    }
+                    const uint32_t sl = t - sh_loff[lo];
+                    vec4 val = zero;
+                    if (sl < sh_kept[lo]) val = rowbuf[sh_off[lo] - oa + sl];
+                    out[lo * P + sl] = val;
+                }
+            }
+        }
+        const uint32_t q1 = RESIDENT ? 0u : jb * P;
         for (uint32_t q0 = ja * P; q0 < q1; q0 += 4 * kWave) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -1478,10 +1520,12 @@ extern "C" int d3d_owner_number(const uint64_t *global_bits, int64_t n_total, co
 // dense contract on the owner, after d3d_owner_merge (whose workspace, untouched since, holds the cells' record lists; same flags):
 // recv_rows[*, 4] = the candidate rows received (grouped by source rank; rows_src_off[world + 1], device), a record's last word =
 // offset of its rows inside its batch.  -> voxels[cap_o, max_points, 4] and pmask[cap_o, max_points] of the owned voxels in id order.
+// row_state (NULL: every row of voxels[0 .. Vo) is written): the resident form of d3d_voxelize_3d_dense_resident -- voxels and
+// row_state[capacity] kept by the caller from frame to frame, zero-filled once; only rows with points and stale rows are stored.
 extern "C" int d3d_owner_dense(const int32_t *recv, int64_t R, const float *recv_rows, const int64_t *rows_src_off, int32_t world,
                                int32_t max_points, const int32_t *lead_rec, const int32_t *npoints, const int64_t *counts_o,
                                int64_t cap_o, const void *merge_workspace, size_t merge_workspace_bytes, float *voxels,
-                               uint8_t *pmask, void *stream, uint32_t flags)
+                               uint8_t *pmask, void *stream, uint32_t flags, uint16_t *row_state)
 {
     hipStream_t st = (hipStream_t)stream;
     if (R < 0 || cap_o < 0 || world < 1 || world > kMaxWorld || max_points < 1 || max_points > kDenseCap || !counts_o) return D3D_ERR_BAD_ARG;
@@ -1493,17 +1537,32 @@ extern "C" int d3d_owner_dense(const int32_t *recv, int64_t R, const float *recv
     const int pshift = (P & (P - 1)) == 0 ? __builtin_ctz(P) : -1;
     if (!merge_on_chains(R, flags)) {
         RecWs m = carve_rec(const_cast<void *>(merge_workspace), merge_workspace_bytes, R, world);
-        D3D_LAUNCH("k_owner_dense", k_owner_dense<true>, dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec, npoints,
-                   (const uint32_t *)nullptr, (const MergeSlot *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)m.rinfo,
-                   (const uint32_t *)m.cellrecs, (const int64_t *)m.src_off, (int)world, recv, rec_stride(4),
-                   reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift, reinterpret_cast<float4 *>(voxels), pmask);
+        if (row_state)
+            D3D_LAUNCH("k_owner_dense_resident", (k_owner_dense<true, true>), dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec,
+                       npoints, (const uint32_t *)nullptr, (const MergeSlot *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)m.rinfo,
+                       (const uint32_t *)m.cellrecs, (const int64_t *)m.src_off, (int)world, recv, rec_stride(4),
+                       reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift, reinterpret_cast<float4 *>(voxels), pmask,
+                       row_state);
+        else
+            D3D_LAUNCH("k_owner_dense", k_owner_dense<true>, dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec, npoints,
+                       (const uint32_t *)nullptr, (const MergeSlot *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)m.rinfo,
+                       (const uint32_t *)m.cellrecs, (const int64_t *)m.src_off, (int)world, recv, rec_stride(4),
+                       reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift, reinterpret_cast<float4 *>(voxels), pmask,
+                       (uint16_t *)nullptr);
         return D3D_OK;
     }
     MergeWs m = carve_merge(const_cast<void *>(merge_workspace), merge_workspace_bytes, R, world);
-    D3D_LAUNCH("k_owner_dense", k_owner_dense<false>, dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec, npoints,
-               (const uint32_t *)m.rec_slot, (const MergeSlot *)m.slot, (const uint32_t *)m.next, (const uint32_t *)nullptr,
-               (const uint32_t *)nullptr, (const int64_t *)m.src_off, (int)world, recv, rec_stride(4),
-               reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift, reinterpret_cast<float4 *>(voxels), pmask);
+    if (row_state)
+        D3D_LAUNCH("k_owner_dense_resident", (k_owner_dense<false, true>), dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec,
+                   npoints, (const uint32_t *)m.rec_slot, (const MergeSlot *)m.slot, (const uint32_t *)m.next, (const uint32_t *)nullptr,
+                   (const uint32_t *)nullptr, (const int64_t *)m.src_off, (int)world, recv, rec_stride(4),
+                   reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift, reinterpret_cast<float4 *>(voxels), pmask, row_state);
+    else
+        D3D_LAUNCH("k_owner_dense", k_owner_dense<false>, dim3(blocks_for(cap_o, 256)), dim3(256), 0, st, counts_o, lead_rec, npoints,
+                   (const uint32_t *)m.rec_slot, (const MergeSlot *)m.slot, (const uint32_t *)m.next, (const uint32_t *)nullptr,
+                   (const uint32_t *)nullptr, (const int64_t *)m.src_off, (int)world, recv, rec_stride(4),
+                   reinterpret_cast<const float4 *>(recv_rows), rows_src_off, P, pshift, reinterpret_cast<float4 *>(voxels), pmask,
+                   (uint16_t *)nullptr);
     return D3D_OK;
 }
 

@@ -350,8 +350,9 @@ class HipOps:
             _lib.check(rc, "owner_merge")
         return first_o, coords, npoints, feats, rec_owned, counts, (recv, lead, npoints, counts, ws, world, int(flags))
 
-    def owner_dense(self, handle, recv_rows, recv_row_counts, max_points):
-        """the dense contract of the owned voxels (id order): voxels[R, max_points, 4], pmask[R, max_points] uint8"""
+    def owner_dense(self, handle, recv_rows, recv_row_counts, max_points, resident=None):
+        """the dense contract of the owned voxels (id order): voxels[R, max_points, 4], pmask[R, max_points] uint8.
+        resident: a d3d_amd.voxel.DenseOutputBuffer of at least R voxels -- `voxels` is then that buffer"""
         lib = _lib.load()
         recv, lead, npoints, counts, ws, world, flags = handle
         dev = recv.device
@@ -361,11 +362,14 @@ class HipOps:
             off.append(off[-1] + int(k))
         with torch.cuda.device(dev):
             roff = torch.tensor(off, dtype=torch.int64, device=dev)
-            voxels = torch.empty((R, max_points, 4), dtype=torch.float32, device=dev)
+            if resident is not None and (resident.capacity < R or resident.max_points != int(max_points) or resident.device != dev):
+                raise ValueError("resident output: capacity, max_points or device do not fit")
+            voxels = resident.voxels if resident is not None else torch.empty((R, max_points, 4), dtype=torch.float32, device=dev)
             pmask = torch.empty((R, max_points), dtype=torch.uint8, device=dev)
             rc = lib.d3d_owner_dense(_lib.ptr(recv), R, _lib.ptr(recv_rows), _lib.ptr(roff), world, int(max_points), _lib.ptr(lead),
                                      _lib.ptr(npoints), _lib.ptr(counts), R, _lib.ptr(ws), ws.numel(), _lib.ptr(voxels),
-                                     _lib.ptr(pmask), _lib.stream_ptr(), flags)
+                                     _lib.ptr(pmask), _lib.stream_ptr(), flags,
+                                     _lib.ptr(resident.row_state) if resident is not None else None)
             _lib.check(rc, "owner_dense")
         return voxels, pmask
 
@@ -477,7 +481,7 @@ class ShardedVoxelGenerator:
     rank order).  Grid arguments as d3d.voxel.VoxelGenerator (bounds, shape); reduction in {mean, max, min}."""
 
     def __init__(self, bounds, shape, reduction="mean", group=None, comm=None, ops=None, exchange="owner", replicate=True,
-                 max_points=None, debug_checks=False, merge_flags=0):
+                 max_points=None, debug_checks=False, merge_flags=0, resident=False):
         key = (reduction or "").upper()
         if key not in _REDUCTIONS:
             raise ValueError("Unsupported reduction type in VoxelGenerator!")
@@ -518,6 +522,12 @@ class ShardedVoxelGenerator:
         # max_points: also the dense contract's voxels[V, max_points, 4] + voxel_pmask (voxelize.cpp:128-134: the first
         # max_points points of every voxel by global index), assembled by the voxel's owner from the ranks' candidate rows
         self._max_points = int(max_points) if max_points else 0
+        # resident (dense contract, replicate=False): the owned voxels' voxels[Vo, max_points, 4] comes back as a view of a
+        # buffer this generator keeps on the device -- only rows with points and stale rows are stored per frame, the zero
+        # padding stays (d3d_amd.voxel.DenseOutputBuffer, d3d_owner_dense's row_state); valid until the next call
+        self._resident, self._resident_buf = bool(resident), None
+        if self._resident and (self._replicate or not self._max_points):
+            raise ValueError("resident needs the dense contract (max_points) with replicate=False")
         if self._max_points and exchange != "owner":
             raise ValueError("max_points (the dense contract) needs exchange='owner'")
         if self._max_points > 256:
@@ -575,7 +585,15 @@ class ShardedVoxelGenerator:
             rsc = [int(x) for x in mat[comm.rank][W + 1:2 * W + 1]]
             rrc = [int(mat[s][W + 1 + comm.rank]) for s in range(W)]
             recv_rows = comm.all_to_all(send_rows[:sum(rsc)], rsc, rrc)
-            voxels, pmask = ops.owner_dense(handle, recv_rows, rrc, P)
+            if self._resident:
+                from . import DenseOutputBuffer
+                buf, need = self._resident_buf, int(recv.shape[0])        # (rows are indexed by owned voxel id < records received)
+                if buf is None or buf.capacity < need or buf.device != recv.device:
+                    grow = need if buf is None else max(need, buf.capacity + buf.capacity // 4)
+                    buf = self._resident_buf = DenseOutputBuffer(grow, P, recv.device)
+                voxels, pmask = ops.owner_dense(handle, recv_rows, rrc, P, resident=buf)
+            else:
+                voxels, pmask = ops.owner_dense(handle, recv_rows, rrc, P)
         lbits = ops.owner_mark_first(first_o, counts_o, n_total)
         gbits = comm.all_reduce(lbits, "sum")                   # disjoint bit sets: their sum is their OR
         vids, counts_out = ops.owner_number(gbits, n_total, first_o, counts_o)

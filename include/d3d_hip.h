@@ -332,11 +332,14 @@ int d3d_owner_merge(const int32_t *recv, int64_t n_records, const int64_t *src_o
 /* dense contract on the owner (voxelize.cpp:128-134: the first max_points points of a voxel by global index = the ranks'
  * candidate rows in rank order): after d3d_owner_merge, with ITS workspace untouched since and ITS flags; recv_rows[*, 4] grouped by source
  * rank (rows_src_off[world + 1], device); lead_rec / npoints / counts_o from d3d_owner_merge.
- * -> voxels[cap_o, max_points, 4], pmask[cap_o, max_points] of the owned voxels in id order (max_points <= 256, c == 4). */
+ * -> voxels[cap_o, max_points, 4], pmask[cap_o, max_points] of the owned voxels in id order (max_points <= 256, c == 4).
+ * row_state: NULL, or the resident form of d3d_voxelize_3d_dense_resident -- voxels[capacity >= cap_o, max_points, 4] and
+ * row_state[capacity] kept by the caller from frame to frame (zero-filled once): only the rows that hold points and the rows the
+ * previous frame left under the same owned id are stored, the zero padding stays; same values in voxels[0 .. Vo). */
 int d3d_owner_dense(const int32_t *recv, int64_t n_records, const float *recv_rows, const int64_t *rows_src_off, int32_t world,
                     int32_t max_points, const int32_t *lead_rec, const int32_t *npoints, const int64_t *counts_o, int64_t cap_o,
                     const void *merge_workspace, size_t merge_workspace_bytes, float *voxels, uint8_t *pmask, void *stream,
-                    uint32_t flags);
+                    uint32_t flags, uint16_t *row_state);
 /* bitmap[(n_total + 63) / 64 + 1] <- bit f for every owned voxel's first point f; the last word = 1 when counts_o carries
  * BIN_OVERFLOW (d3d_owner_merge), else 0 */
 int d3d_owner_mark_first(const int64_t *first_o, const int64_t *counts_o, int64_t cap_o, int64_t n_total, uint64_t *bitmap,

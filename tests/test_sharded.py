@@ -263,6 +263,53 @@ def test_owner_computes_without_replication_virtual_ranks(world, reduction, empt
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,P,merge", [(3, 4, "buckets"), (8, 32, "buckets"), (4, 16, "chains")])
+def test_owner_dense_resident_over_a_sequence_of_frames(world, P, merge):
+    """ShardedVoxelGenerator(..., replicate=False, max_points=P, resident=True): every rank's voxels[Vo, P, 4] is a view of a
+    buffer the generator keeps (d3d_owner_dense with row_state: rows with points + stale rows stored, padding kept).  Five
+    frames of different size and shape through the same generators -- the owned voxels change completely from frame to
+    frame -- each equal to the oracle's dense contract of the whole frame, bit for bit; the buffers' invariant afterwards."""
+    from d3d_amd import _lib
+    from d3d_amd.voxel.sharded import HipOps, ShardedVoxelGenerator
+    mflags = {"buckets": 0, "chains": _lib.OWNER_MERGE_CHAINS}[merge]
+    frames = []
+    for k, (n, blob) in enumerate([(50000, (30, 0, -1)), (9000, (5, 10, 0)), (80000, (50, -20, -2)), (300, (30, 0, -1)), (40000, (10, 5, 0))]):
+        cl = _cloud(n, 100 + k)
+        cl[::5, :3] = cl[::5, :3] * 0.03 + np.array(blob, np.float32)
+        frames.append(cl)
+    tw, lock = ThreadWorld(world), threading.Lock()
+    out, errs, gens = [[None] * world for _ in frames], [], [None] * world
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            gen = gens[rank] = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction="mean", comm=tw.comm(rank), exchange="owner", replicate=False,
+                                                     ops=LockedOps(HipOps(), lock), max_points=P, merge_flags=mflags, resident=True)
+            for f, cl in enumerate(frames):
+                cuts = np.linspace(0, len(cl), world + 1).astype(int)
+                res = gen(torch.from_numpy(cl[cuts[rank]:cuts[rank + 1]]).cuda())
+                assert res.voxels.untyped_storage().data_ptr() == gen._resident_buf.voxels.untyped_storage().data_ptr()
+                out[f][rank] = type(res)({k: (v.cpu() if hasattr(v, "cpu") else v) for k, v in res.items()})   # before the next frame
+        except Exception:  # pragma: no cover
+            import traceback
+            errs.append(traceback.format_exc())
+            tw.barrier.abort()
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[0]
+    for f, cl in enumerate(frames):
+        cuts = np.linspace(0, len(cl), world + 1).astype(int)
+        ids = [_check_owned(out[f][r], cl, slice(cuts[r], cuts[r + 1]), "mean", max_points=P) for r in range(world)]
+        assert np.array_equal(np.sort(np.concatenate(ids)), np.arange(out[f][0].num_voxels))
+    for g in gens:
+        buf = g._resident_buf
+        state = buf.row_state.cpu().numpy().astype(np.int64) & 0xffff
+        nz = (buf.voxels != 0).any(dim=2).cpu().numpy()
+        assert not (nz & (np.arange(P)[None, :] >= state[:, None])).any()
+
+
+@pytest.mark.gpu
 def test_voxelize_reduce_single_gpu(index_path):
     from d3d_amd import synth
     from d3d_amd.voxel.sharded import voxelize_reduce

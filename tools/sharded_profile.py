@@ -23,15 +23,18 @@ if cfg5:
 else:
     clouds = [torch.from_numpy(synth.lidar_like(n, r)).cuda() for r in range(W)]
 
+resident = len(sys.argv) > 7 and sys.argv[7] == "resident"    # dense contract into buffers the generators keep (replicate off)
+tw, lock = ThreadWorld(W), threading.Lock()
+gens = [ShardedVoxelGenerator(BOUNDS, SHAPE, reduction="mean", comm=tw.comm(r), ops=LockedOps(HipOps(), lock), exchange=exchange,
+                              replicate=replicate, max_points=max_points, resident=resident) for r in range(W)]
+
 def step():
-    tw, lock = ThreadWorld(W), threading.Lock()
     outs = [None] * W
     global stats
     stats = [None] * W
     def run(rank):
         torch.cuda.set_device(0)
-        gen = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction="mean", comm=tw.comm(rank), ops=LockedOps(HipOps(), lock),
-                                    exchange=exchange, replicate=replicate, max_points=max_points)
+        gen = gens[rank]
         outs[rank] = gen(clouds[rank])
         stats[rank] = gen.last_stats
     ts = [threading.Thread(target=run, args=(r,)) for r in range(W)]
@@ -67,7 +70,7 @@ try:
     import bench
     whole = torch.cat(clouds)
     if max_points:
-        g1 = VoxelGenerator(BOUNDS, SHAPE, dense=True, reduction="mean", max_points=max_points, max_voxels=len(whole))
+        g1 = VoxelGenerator(BOUNDS, SHAPE, dense=True, reduction="mean", max_points=max_points, max_voxels=len(whole), resident=resident)
     else:
         from d3d_amd.voxel.sharded import LocalComm
         g1 = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction="mean", comm=LocalComm(), replicate=False)
