@@ -474,7 +474,7 @@ class VoxelGenerator:
         MEASURED on MI355X / ROCm 7.2 (profiles/r04_pipelined_*): no gain -- the runtime maps both streams to one
         hardware queue (144 vs 137 us per frame for the plain loop), and on two queues every cross-queue event wait costs
         50-60 us (247 us per frame).  Hence off by default: the plain loop."""
-        if not (pipelined and self._dense):
+        if not (pipelined and self._dense) or self._resident:       # (a resident output is ONE buffer: one frame in flight)
             return (self(f, flags=flags, poison=poison) for f in frames)
         return _stream_frames(self, frames, flags, poison)
 
