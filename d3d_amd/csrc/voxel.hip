@@ -1316,7 +1316,16 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
     uint16_t *lidx = reinterpret_cast<uint16_t *>(h + nbins);               // [kSortTile] point index inside the tile
     __shared__ u64 smem[kSortThreads / kWave];
     __shared__ uint32_t sbad;
-    const int64_t base = (int64_t)blockIdx.x * kSortTile + threadIdx.x;
+    // XCD-aware tile numbering: workgroup ids go round the eight XCDs, so the workgroups of ONE XCD take a contiguous range of
+    // tiles -- a bucket's row of the table (one 4-byte word per tile) is then written as adjacent words into the same L2
+    // instead of one word per line from eight different ones (the 8 M-point frame wrote 400 MB for a 33 MB table).  Tiles
+    // are independent (no look-back between them), so any numbering is valid.
+    // (A/B on one box: k_tile_sort 118 -> 96 us at 8 M points, 44.5 -> 42.5 at 4 M; at 1 M -- 123 tiles, a 0.5 MB table -- nothing
+    // to gain, so small frames keep the identity.)
+    const uint32_t per_xcd = (ntiles + 7u) >> 3;
+    const uint32_t tile = ntiles >= 256u ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= ntiles) return;                             // (the grid is rounded up to a multiple of 8)
+    const int64_t base = (int64_t)tile * kSortTile + threadIdx.x;
     float v[kSortItems][3];
 #pragma unroll
     for (int r = 0; r < kSortItems; r++) {                  // (the loads fly while the histogram is cleared)
@@ -1334,8 +1343,8 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
     D3D_PHASE_DECL;
     for (uint32_t b = threadIdx.x; b < nbins; b += kSortThreads) h[b] = 0;
     if (threadIdx.x == 0) sbad = 0;
-    if (blockIdx.x == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
-    if (zero_words && blockIdx.x == 0) {
+    if (tile == 0 && threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
+    if (zero_words && tile == 0) {
         for (uint32_t t = threadIdx.x; t < nzero; t += kSortThreads) zero_words[t] = 0ull;
         if (threadIdx.x == 0) *zero_ticket = 0u;
     }
@@ -1382,14 +1391,14 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
     for (int k = 0; k < kPerMax; k++) {
         if ((uint32_t)k < per && b0 + k < nbins) {
             h[b0 + k] = (uint32_t)ex;
-            table[(size_t)(b0 + k) * ntiles + blockIdx.x] = (uint32_t)ex | (cnt[k] << 16);
+            table[(size_t)(b0 + k) * ntiles + tile] = (uint32_t)ex | (cnt[k] << 16);
             ex += cnt[k];
         }
     }
-    if (threadIdx.x == 0) tileinfo[blockIdx.x] = (uint32_t)all | (sbad << 31);
+    if (threadIdx.x == 0) tileinfo[tile] = (uint32_t)all | (sbad << 31);
     __syncthreads();
     D3D_PHASE(1, 2);                                        // scan, table row stored
-    const uint32_t tbase = (uint32_t)blockIdx.x << kSortTileShift;
+    const uint32_t tbase = tile << kSortTileShift;
 #pragma unroll
     for (int r = 0; r < kSortItems; r++) {
         const int64_t i = base + r * kSortThreads;
@@ -3336,7 +3345,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         if (lds + 1024 > 65536)                                                                                                 \
             D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort<Key, V4, ROWS, IT>),                  \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-        D3D_LAUNCH("k_tile_sort", (k_tile_sort<Key, V4, ROWS, IT>), dim3(stiles), dim3(kSortThreads), lds, st, kf, points, n, c, \
+        D3D_LAUNCH("k_tile_sort", (k_tile_sort<Key, V4, ROWS, IT>), dim3(((stiles + 7u) >> 3) << 3), dim3(kSortThreads), lds, st, kf, points, n, c, \
                    nbins, stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid, zero_words,    \
                    nzero, zero_ticket);                                                                                         \
     } while (0)
