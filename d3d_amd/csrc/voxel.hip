@@ -1066,6 +1066,7 @@ constexpr int kBucketCap = 2048;              // points one k_bucket_index workg
 constexpr int kBucketThreads = 512;           // ... 4 per lane (256: 42 us, 512: 38 us, 1024: 44 us at config 2)
 constexpr int kBucketSlots = 2048;            // LDS table slots (>= distinct cells of a bucket, always)
 constexpr uint32_t kNoBin = 0xffffffffu;
+constexpr uint32_t kXcdBucketsMin = 2048;     // k_bucket_index: XCD-aware bucket numbering from this many buckets (a power of two) on
 
 // reduce contract (d3d_voxelize_3d_reduce) on the binned path
 struct BinnedExtras {
@@ -1537,7 +1538,12 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         // buckets = the bucket's base in the per-bucket arrays; the run starts (scan of the lengths) and the runs' places in
         // `bent` wait in seg[] (free until the segments phase) for the lanes to look their entries up
         static_assert(2 * kRunCap <= kBucketCap && kRunCap <= 2 * kBucketThreads, "run table lives in seg[]");
-        const uint32_t *row = table + (size_t)blockIdx.x * ntiles;
+        // XCD-aware bucket numbering (large frames): inside a tile the runs of buckets b, b + 1, ... lie side by side -- at 8 M
+        // points a run is one 8-byte entry, sixteen buckets to a 128-byte line -- and workgroup ids go round the eight XCDs: with
+        // bucket = id every line was fetched by all eight L2s.  Buckets are independent (their bases come from the table), so
+        // the workgroups of one XCD take a contiguous range of them.
+        const uint32_t bucket = gridDim.x >= kXcdBucketsMin ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+        const uint32_t *row = table + (size_t)bucket * ntiles;
         const uint32_t per = ntiles > (uint32_t)kBucketThreads ? 2u : 1u, t0 = threadIdx.x * per;
         uint32_t wv[2];
 #pragma unroll
