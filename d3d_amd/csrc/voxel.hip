@@ -2494,12 +2494,14 @@ __global__ __launch_bounds__(256) void k_emit_c(Key kf, int64_t npad, const uint
                                                 const float *__restrict__ points, const uint32_t *__restrict__ ranked,
                                                 uint32_t P, int pshift /* log2 P or -1 */, int reduction, int64_t *coords,
                                                 int32_t *npoints, unsigned char *pmask, float *agg, uint32_t *voff, float *voxels,
-                                                int64_t *counts, int64_t *host_counts, uint32_t *ov_list, uint32_t *ov_count)
+                                                int64_t *counts, int64_t *host_counts, uint32_t *ov_list, uint32_t *ov_count,
+                                                uint16_t *row_state /* resident output (see k_emit<.., RESIDENT>) or NULL */)
 {
     typedef float vec4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float rowbuf_all[256 / kWave][kEmitCap * C];
     __shared__ uint32_t off_all[256 / kWave][kWave], base_all[256 / kWave][kWave], first_all[256 / kWave][kWave];
-    __shared__ uint16_t kept_all[256 / kWave][kWave];
+    __shared__ uint16_t kept_all[256 / kWave][kWave], lim_all[256 / kWave][kWave];
+    __shared__ uint32_t loff_all[256 / kWave][kWave];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     float *rowbuf = rowbuf_all[w];
@@ -2541,6 +2543,22 @@ __global__ __launch_bounds__(256) void k_emit_c(Key kf, int64_t npad, const uint
     const uint32_t incl = wave_incl_scan_u32(kept);
     const uint32_t off = incl - kept;
     sh_off[lane] = off; sh_base[lane] = base; sh_first[lane] = il; sh_kept[lane] = (uint16_t)kept;
+    uint16_t *sh_lim = lim_all[w];
+    uint32_t loff = 0, lpieces = 0;
+    if (row_state) {                                        // rows to store: the new ones, and zeros over the previous occupant's
+        uint32_t lim = 0;
+        if (mine) {
+            const uint32_t prev = row_state[(int64_t)vid0 + lane];
+            lim = prev > kept ? prev : kept;
+            if (lim > P) lim = P;
+            if (prev != kept) row_state[(int64_t)vid0 + lane] = (uint16_t)kept;
+        }
+        sh_lim[lane] = (uint16_t)lim;
+        const uint32_t pieces = (lim * (uint32_t)C + 3u) >> 2;         // 16-byte pieces of the voxel that reach into rows in use
+        loff = wave_incl_scan_u32(pieces) - pieces;
+        loff_all[w][lane] = loff;
+        lpieces = pieces;
+    }
     wave_lds_fence();
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
     float acc[C];
@@ -2586,8 +2604,35 @@ __global__ __launch_bounds__(256) void k_emit_c(Key kf, int64_t npad, const uint
                 }
             }
         }
+        if (row_state) {
+            // resident: only the pieces that reach into rows in use, flat over the batch's voxels
+            const uint32_t *sh_loff = loff_all[w];
+            const uint32_t l0 = (uint32_t)__shfl((int)loff, (int)ja, kWave);
+            const uint32_t l1 = jb < (uint32_t)kWave ? (uint32_t)__shfl((int)loff, (int)jb, kWave)
+                                                    : (uint32_t)__shfl((int)(loff + lpieces), kWave - 1, kWave);
+            for (uint32_t t0 = l0; t0 < l1; t0 += kWave) {
+                const uint32_t t = t0 + lane;
+                if (t < l1) {
+                    uint32_t lo = ja, hi = jb;              // largest j in [ja, jb) with loff[j] <= t
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (sh_loff[mid] <= t) lo = mid; else hi = mid;
+                    }
+                    const uint32_t j = lo, f0 = (t - sh_loff[j]) * 4u;          // first float of the piece inside the voxel
+                    uint32_t slot = f0 / (uint32_t)C, ch = f0 - slot * (uint32_t)C;
+                    const uint32_t kj = sh_kept[j], rb0 = sh_off[j] - oa;
+                    vec4 val = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        val[x] = slot < kj ? rowbuf[(size_t)(rb0 + slot) * C + ch] : 0.f;
+                        if (++ch == (uint32_t)C) { ch = 0; slot++; }
+                    }
+                    out[j * (PC / 4) + (t - sh_loff[j])] = val;
+                }
+            }
+        }
         // the stretch of the batch's voxels, in 16-byte pieces
-        const uint32_t q1 = jb * PC / 4;
+        const uint32_t q1 = row_state ? 0u : jb * PC / 4;
         for (uint32_t q0 = ja * PC / 4; q0 < q1; q0 += 4 * kWave) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -3408,7 +3453,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
 #define D3D_EMIT_C(CC)                                                                                                          \
     D3D_LAUNCH("k_emit_c", (k_emit_c<Key, CC>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec, o.max_voxels,  \
                points, w.big_list, o.P, pshift, o.reduction, o.coords, o.npoints, o.fuse_pmask ? o.pmask : nullptr, o.aggregates,   \
-               w.voff, o.emit_generic, counts, x.host_counts, reinterpret_cast<uint32_t *>(w.vinfo), w.big_count)
+               w.voff, o.emit_generic, counts, x.host_counts, reinterpret_cast<uint32_t *>(w.vinfo), w.big_count, x.row_state)
             switch (c) {
             case 3: D3D_EMIT_C(3); break;
             case 5: D3D_EMIT_C(5); break;
@@ -3594,11 +3639,12 @@ static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const 
         }
         // staged calls (d3d_voxelize_3d_dense_staged): only the path whose output is ONE launch
         if (stage != 0 && !(emitted && fuse_pmask)) return D3D_ERR_UNSUPPORTED;
-        if (row_state && !emitted) return D3D_ERR_UNSUPPORTED;       // (resident rows: k_emit's stretch, C == 4)
         d.x.row_state = row_state;
         d.stage = stage;
-        if (vec4) rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
-        else {
+        if (vec4) {
+            if (row_state && !emitted) return D3D_ERR_UNSUPPORTED;       // (resident rows: the one-launch output kernels only)
+            rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
+        } else {
             // any C: the {cell, index} entries travel alone, the bucket kernel leaves per-voxel index lists in point order
             // and the generic output kernels below gather through them
             d.lists = true;
@@ -3608,6 +3654,7 @@ static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const 
                 d.emit_generic = voxels;
                 emitted_generic = true;
             }
+            if (row_state && !emitted_generic) return D3D_ERR_UNSUPPORTED;
             rc = binned_index<DenseKey, false>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
         }
         if (rc) return rc;
@@ -3694,9 +3741,9 @@ extern "C" int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int3
 // caller ONCE (hipMemset).  A frame's voxels[0 .. V) then equal what d3d_voxelize_3d_dense writes, bit for bit, but only the rows
 // that hold points -- and zeros over the rows the previous frame's voxel of the same id held -- are stored: the padding, 95 % of
 // the tensor on a LiDAR frame, is already there.  The result aliases the buffer: valid until the next call on it.  Everything
-// else (coords, masks, counts, aggregates, host_counts -- optional here) as in d3d_voxelize_3d_dense_notify.  C == 4 rows on
-// 16-byte aligned buffers, max_points <= 256, the binned index (frames up to 8 M points): else D3D_ERR_UNSUPPORTED and nothing is
-// touched.  max_points is part of the buffer's layout: the same value in every call on it.
+// else (coords, masks, counts, aggregates, host_counts -- optional here) as in d3d_voxelize_3d_dense_notify.  Rows of 3 .. 8
+// floats on 16-byte aligned buffers, max_points <= 256 (c != 4: max_points * c a multiple of 4), the binned index (frames up to
+// 8 M points): else D3D_ERR_UNSUPPORTED and nothing is touched.  max_points and c are the buffer's layout: the same in every call.
 extern "C" int d3d_voxelize_3d_dense_resident(const float *points, int64_t n, int32_t c, const int32_t *shape, const float *bound,
                                               int32_t max_points, int32_t max_voxels, int32_t reduction, float *voxels,
                                               uint16_t *row_state, int64_t *coords, uint8_t *pmask, int32_t *npoints, float *aggregates,

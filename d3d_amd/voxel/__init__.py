@@ -144,14 +144,14 @@ def _workspace_bytes2(lib, n):
 
 class DenseOutputBuffer:
     """A resident output for the dense contract (d3d_voxelize_3d_dense_resident; beyond the reference, which allocates per
-    frame): voxels[capacity, max_points, 4] kept on the device from frame to frame together with, per voxel id, the number of
+    frame): voxels[capacity, max_points, C] kept on the device from frame to frame together with, per voxel id, the number of
     rows that may be non-zero.  A call then stores only the rows that hold points and zeros over what the previous frame's
     voxel of the same id held; the padding -- 95 % of the tensor on a LiDAR frame -- stays as it is.  The `voxels` a call
     returns is a view of this buffer: valid until the next call with it, and not to be written."""
 
-    def __init__(self, capacity, max_points, device):
-        self.capacity, self.max_points, self.device = int(capacity), int(max_points), torch.device(device)
-        self.voxels = torch.zeros((self.capacity, self.max_points, 4), dtype=torch.float32, device=self.device)
+    def __init__(self, capacity, max_points, device, columns=4):
+        self.capacity, self.max_points, self.device, self.columns = int(capacity), int(max_points), torch.device(device), int(columns)
+        self.voxels = torch.zeros((self.capacity, self.max_points, self.columns), dtype=torch.float32, device=self.device)
         self.row_state = torch.zeros((self.capacity,), dtype=torch.int16, device=self.device)       # (uint16 bits)
 
 
@@ -165,7 +165,7 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
     flags: per-call index options (_lib.VOXEL_*; None = the calling context's, d3d_amd.options).  poison (test hook): fill
     every output buffer with NaN / 0xff patterns first, so that a row the kernels fail to write cannot hide behind fresh
     (zeroed) memory.  resident: a DenseOutputBuffer -- `voxels` comes back as a view of it (same values, see there; a frame the binned index does
-    not take gets a fresh tensor instead); ValueError for rows of other than 4 floats or a buffer that does not fit.
+    not take gets a fresh tensor instead); ValueError for a buffer that does not fit the call.
     """
     lib = _lib.load()
     pts, odev, dev = _stage(points)
@@ -177,9 +177,9 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
     shape_h = _host_array(voxel_shape, ctypes.c_int32, 3)
     bound_h = _host_array(voxel_bound, ctypes.c_float, 6)
     cap = max(min(n, max_voxels), 0)
-    if resident is not None and (c != 4 or resident.max_points != max_points or resident.capacity < cap or resident.device != dev
-                                 or max_points <= 0 or max_voxels <= 0):
-        raise ValueError("resident output: needs [N,4] points, the buffer's max_points and device, capacity >= min(N, max_voxels)")
+    if resident is not None and (c != resident.columns or resident.max_points != max_points or resident.capacity < cap or
+                                 resident.device != dev or max_points <= 0 or max_voxels <= 0):
+        raise ValueError("resident output: needs the buffer's columns, max_points and device, capacity >= min(N, max_voxels)")
     with _device_ctx(dev):
         voxels = resident.voxels if resident is not None else torch.empty((cap, max_points, c), dtype=torch.float32, device=dev)
         coords = torch.empty((cap, 3), dtype=torch.int64, device=dev)
@@ -491,9 +491,10 @@ class VoxelGenerator:
             if self._resident and points.shape[0] > 0:
                 need = min(int(points.shape[0]), int(self._max_voxels))
                 buf = self._resident_buf
-                if buf is None or buf.capacity < need or buf.device != points.device:
+                if buf is None or buf.capacity < need or buf.device != points.device or buf.columns != int(points.shape[1]):
                     grow = need if buf is None else max(need, buf.capacity + buf.capacity // 4)
-                    buf = self._resident_buf = DenseOutputBuffer(min(grow, int(self._max_voxels)), self._max_points, points.device)
+                    buf = self._resident_buf = DenseOutputBuffer(min(grow, int(self._max_voxels)), self._max_points, points.device,
+                                                                 columns=int(points.shape[1]))
             ret = Dict(voxelize_3d_dense(points, self._shape_h, self._bounds_h, self._max_points,
                                          self._max_voxels, self._reduction, flags=flags, poison=poison, resident=buf))
         else:

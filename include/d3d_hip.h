@@ -122,15 +122,16 @@ int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int32_t c,
 
 /* The dense contract into a RESIDENT output buffer (beyond the reference, which returns fresh tensors per frame,
  * voxelize.cpp:166-180; for callers that consume voxels[V,P,C] on the device before the next frame arrives).
- *   voxels[capacity, max_points, 4] f32 and row_state[capacity] u16: caller-owned, kept from frame to frame, zero-filled by
+ *   voxels[capacity, max_points, c] f32 and row_state[capacity] u16: caller-owned, kept from frame to frame, zero-filled by
  *   the caller ONCE and never written by it; capacity >= min(n, max_voxels) of every call; the same max_points in every call.
  * Invariant kept by the call: row r of voxels[v] is zero for r >= row_state[v].  After the call voxels[0 .. V) hold exactly
  * what d3d_voxelize_3d_dense writes (bit for bit, padding included) -- but only the rows that hold points, and zeros over the
  * rows the previous occupant of the same voxel id held, are stored: the zero padding (95 % of the tensor on a LiDAR frame:
  * 1.6 points per voxel at max_points 32) is already there.  The result aliases the buffer: it is valid until the next call
  * on it.  coords / pmask / npoints / aggregates / counts / host_counts (may be NULL) as in d3d_voxelize_3d_dense_notify.
- * D3D_ERR_UNSUPPORTED, with nothing touched: c != 4, buffers not 16-byte aligned, max_points > 256, a frame the binned index
- * does not take (D3D_VOXEL_PATH_HASH, more than 8 M points), D3D_VOXEL_SPLIT_FILL. */
+ * D3D_ERR_UNSUPPORTED, with nothing touched: rows of more than 8 floats, buffers not 16-byte aligned, max_points > 256 (c != 4:
+ * also max_points * c not a multiple of 4), a frame the binned index does not take (D3D_VOXEL_PATH_HASH, more than 8 M points),
+ * D3D_VOXEL_SPLIT_FILL. */
 int d3d_voxelize_3d_dense_resident(const float *points, int64_t n, int32_t c,
                           const int32_t *shape, const float *bound,
                           int32_t max_points, int32_t max_voxels, int32_t reduction,

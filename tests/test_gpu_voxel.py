@@ -305,7 +305,7 @@ def test_randomized_configs_vs_oracle(seed):
     exp = oracle.VoxelGenerator(bounds, shape, **kw)(cloud)
     ret = _np(VoxelGenerator(bounds, shape, **kw)(pts))
     check_dense(ret, exp, P)
-    if c == 4:          # the resident output (d3d_voxelize_3d_dense_resident): four frames through ONE buffer, each vs the oracle
+    if True:            # the resident output (d3d_voxelize_3d_dense_resident), rows of 3 .. 8 floats: five frames through ONE buffer, each vs the oracle
         rgen, ogen = VoxelGenerator(bounds, shape, resident=True, **kw), oracle.VoxelGenerator(bounds, shape, **kw)
         for frame in (cloud, cloud[::3].copy(), cloud[::-1].copy(), cloud[: max(1, n // 7)].copy(), cloud):
             check_dense(_np(rgen(torch.from_numpy(frame).cuda())), ogen(frame), P)
@@ -366,8 +366,8 @@ def test_descending_filter_with_many_crowded_voxels(max_voxels, max_points_filte
 
 
 @pytest.mark.parametrize("red", ["none", "mean", "max"])
-@pytest.mark.parametrize("P", [4, 32])
-def test_resident_dense_output_over_a_sequence_of_frames(red, P, index_path):
+@pytest.mark.parametrize("P,C", [(4, 4), (32, 4), (32, 5), (8, 3), (12, 7)])
+def test_resident_dense_output_over_a_sequence_of_frames(red, P, C, index_path):
     """VoxelGenerator(dense=True, resident=True) (d3d_voxelize_3d_dense_resident): `voxels` is a view of a buffer kept on the
     device, of which a call stores only the rows with points and zeros over what the previous frame left under the same voxel
     id.  Ten frames of very different shape -- dense, sparse, one crowded voxel, a single point, empty, growing past the
@@ -378,15 +378,15 @@ def test_resident_dense_output_over_a_sequence_of_frames(red, P, index_path):
     bounds, shape = [0, 8, 0, 8, 0, 2], [40, 40, 8]
     gen = VoxelGenerator(bounds, shape, max_points=P, max_voxels=9000, reduction=red, dense=True, resident=True)
     ref = oracle.VoxelGenerator(bounds, shape, max_points=P, max_voxels=9000, reduction=red, dense=True)
-    span = np.array([8, 8, 2, 1], np.float32)
+    span = np.array([8, 8, 2] + [1] * (C - 3), np.float32)
 
     def cloud(n, clump=0.0, where=0.5):
-        c = rng.random((n, 4)).astype(np.float32) * span
+        c = rng.random((n, C)).astype(np.float32) * span
         k = int(n * clump)
         c[:k, :3] = (np.array([8, 8, 2]) * where + 0.15 * rng.random((k, 3))).astype(np.float32)
         return c[rng.permutation(n)]
 
-    frames = [cloud(6000), cloud(60000, 0.3), cloud(900), cloud(1), cloud(20000, 0.9, 0.2), np.zeros((0, 4), np.float32),
+    frames = [cloud(6000), cloud(60000, 0.3), cloud(900), cloud(1), cloud(20000, 0.9, 0.2), np.zeros((0, C), np.float32),
               cloud(5000, 0.5, 0.8), cloud(200000), cloud(7000, 0.2), cloud(40000, 0.1, 0.3)]
     for k, f in enumerate(frames):
         exp = ref(f)
@@ -404,7 +404,7 @@ def test_resident_dense_output_over_a_sequence_of_frames(red, P, index_path):
 
 
 def test_resident_dense_c_abi_contract():
-    """d3d_voxelize_3d_dense_resident through ctypes: rows of 5 floats, the hash path and SPLIT_FILL are D3D_ERR_UNSUPPORTED
+    """d3d_voxelize_3d_dense_resident through ctypes: rows of 9 floats, the hash path and SPLIT_FILL are D3D_ERR_UNSUPPORTED
     and touch nothing; a missing row_state is a bad argument; two frames through ONE buffer equal the plain entry point."""
     import ctypes
     from d3d_amd import _lib
@@ -434,9 +434,9 @@ def test_resident_dense_c_abi_contract():
         torch.cuda.synchronize()
         return rc, coords, pmask, npts, agg, counts
 
-    p5 = torch.from_numpy(rng.random((3000, 5)).astype(np.float32)).cuda()
+    p9 = torch.from_numpy(rng.random((3000, 9)).astype(np.float32)).cuda()
     p4 = torch.from_numpy(rng.random((3000, 4)).astype(np.float32)).cuda()
-    for rc, *o in (call(p5, 5), call(p4, 4, _lib.VOXEL_PATH_HASH), call(p4, 4, _lib.VOXEL_SPLIT_FILL)):
+    for rc, *o in (call(p9, 9), call(p4, 4, _lib.VOXEL_PATH_HASH), call(p4, 4, _lib.VOXEL_SPLIT_FILL)):
         assert rc == _lib.ERR_UNSUPPORTED
         assert int(vox.count_nonzero()) == 0 and int(state.count_nonzero()) == 0 and int((o[2] != -5).sum()) == 0
     assert call(p4, 4, row_state=None)[0] == _lib.ERR_BAD_ARG
