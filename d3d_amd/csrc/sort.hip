@@ -1,5 +1,6 @@
 // sort.hip -- stable descending argsort (the role torch::argsort plays inside the reference: nms.cpp:103,
-// voxelize.cpp:406): one workgroup in LDS up to 2 k keys, a four-launch sample sort up to 128 k, an LSD radix sort above.
+// voxelize.cpp:406): one workgroup in LDS up to 2 k keys, a four-launch sample sort up to 128 k, an LSD radix sort above;
+// voxel counts (the fused DESCENDING filter) have a counting sort of their own (k_cs_*).
 // No library sort (round 4: rocprim::radix_sort_pairs is gone).
 #include <cstring>
 #include <cstdlib>

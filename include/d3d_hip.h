@@ -123,7 +123,7 @@ int d3d_voxelize_3d_dense_notify(const float *points, int64_t n, int32_t c,
 /* The dense contract into a RESIDENT output buffer (beyond the reference, which returns fresh tensors per frame,
  * voxelize.cpp:166-180; for callers that consume voxels[V,P,C] on the device before the next frame arrives).
  *   voxels[capacity, max_points, c] f32 and row_state[capacity] u16: caller-owned, kept from frame to frame, zero-filled by
- *   the caller ONCE and never written by it; capacity >= min(n, max_voxels) of every call; the same max_points in every call.
+ *   the caller ONCE and never written by it; capacity >= min(n, max_voxels) of every call; the same max_points and c in every call.
  * Invariant kept by the call: row r of voxels[v] is zero for r >= row_state[v].  After the call voxels[0 .. V) hold exactly
  * what d3d_voxelize_3d_dense writes (bit for bit, padding included) -- but only the rows that hold points, and zeros over the
  * rows the previous occupant of the same voxel id held, are stored: the zero padding (95 % of the tensor on a LiDAR frame:
