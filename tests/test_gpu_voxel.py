@@ -805,3 +805,9 @@ def test_exact_mean_flag_is_bit_exact_on_overflow_voxels(n, c, P):
     assert np.array_equal(plain[~over], exp["aggregates"][~over])
     if n >= 100000:
         assert not np.array_equal(plain[over], exp["aggregates"][over])       # (fp64 sums: within rounding, not bit-equal)
+    # ... and with the resident output (the exact-mean pass only rewrites aggregates): a different frame first, then this one
+    rgen = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, resident=True, **kw)
+    rgen(torch.from_numpy(np.ascontiguousarray(cloud[::-2])).cuda(), flags=cur_opts().voxel_flags | _lib.VOXEL_EXACT_MEAN)
+    res = _np(rgen(torch.from_numpy(cloud).cuda(), flags=cur_opts().voxel_flags | _lib.VOXEL_EXACT_MEAN))
+    assert np.array_equal(res["voxels"], exp["voxels"]) and np.array_equal(res["aggregates"], exp["aggregates"])
+    assert np.array_equal(res["coords"], exp["coords"]) and np.array_equal(res["voxel_npoints"], exp["voxel_npoints"])
