@@ -1291,6 +1291,7 @@ constexpr int kSortThreads = 1024;
 // them one by one (profiles/r04_tile_sort_large.txt: dense 4 M / 8 M points 4 % faster than the three passes, sparse + trim
 // 4 M 11 % faster, 8 M 7 % slower -- its 16-byte entries)
 constexpr int64_t kTileSortMaxPoints = 8ll << 20, kTileSortMaxPointsSparse = 4ll << 20;
+constexpr int64_t kBigTileMinPoints = 6 << 20;              // k_tile_sort: tiles of 16384 points from here on (dense contract; A/B: 8 M points -15 us, 4 M +3)
 constexpr int kRunCap = 1024;                              // tiles: k_bucket_index keeps the run table in LDS
 
 // kSortItems points per lane: tiles of 1024 * kSortItems points (offsets and run lengths fit 16 bits)
@@ -1309,7 +1310,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
     typedef typename Key::bin_key_t KT;
     typedef BinEntry<ROWS> E;
     constexpr int kSortTile = kSortThreads * kSortItems;
-    constexpr int kSortTileShift = kSortItems == 8 ? 13 : 12;
+    constexpr int kSortTileShift = kSortItems == 16 ? 14 : kSortItems == 8 ? 13 : 12;
     static_assert(kSortTile == (1 << kSortTileShift) && kFlagTile % kSortTile == 0, "arrays are padded to kFlagTile");
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
     KT *keys = reinterpret_cast<KT *>(tile_lds);                           // [kSortTile] in bucket order
@@ -3379,7 +3380,10 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     const bool vec4 = ROWS || (c == 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0);
     const size_t bin_lds = (size_t)nbins * 4;                 // (at 16384 buckets the scatter's 64 KB + 128 B exceed the default limit)
     // one-launch partition (k_tile_sort) whenever the frame and the table fit; else, or on request, the three-pass one
-    const int tshift = 13;                                     // tiles of 8192 points (4096: profiles/r04_bucket_target.txt)
+    // tiles of 8192 points (4096: profiles/r04_bucket_target.txt); large frames of the dense contract on C == 4 rows: 16384 -- half
+    // the tiles, so half the table, and k_bucket_index finds a bucket's entries in half as many runs of twice the length
+    const bool big_tiles = ROWS && vec4 && sizeof(typename Key::bin_key_t) == 4 && n >= kBigTileMinPoints;
+    const int tshift = big_tiles ? 14 : 13;
     const uint32_t stiles = (uint32_t)(w.npad >> tshift);
     uint32_t *table = nullptr, *tileinfo = nullptr, *gpos = reinterpret_cast<uint32_t *>(w.vinfo) + w.npad;
     if (tile_sort && n <= (ROWS ? kTileSortMaxPoints : kTileSortMaxPointsSparse) && nbins <= 8192u && stiles <= (uint32_t)kRunCap &&
@@ -3400,7 +3404,8 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
                    nbins, stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid, zero_words,    \
                    nzero, zero_ticket);                                                                                         \
     } while (0)
-        if (vec4) D3D_TILE_SORT(true, 8);
+        if (big_tiles) D3D_TILE_SORT(true, 16);
+        else if (vec4) D3D_TILE_SORT(true, 8);
         else D3D_TILE_SORT(false, 8);
 #undef D3D_TILE_SORT
     } else if (do_index) {
