@@ -48,6 +48,15 @@ def test_host_side_validation_without_gpu():
         VoxelGenerator([0.05, 1, 0, 1, 0, 1], [10, 10, 10])
     with pytest.raises(ValueError):
         VoxelGenerator([0, 1, 0, 1, 0, 1], [10, 10, 10], reduction="median", dense=True)
+    with pytest.raises(ValueError):              # the resident output is an option of the dense contract ...
+        VoxelGenerator([0, 1, 0, 1, 0, 1], [10, 10, 10], resident=True)
+    from d3d_amd.voxel.sharded import ShardedVoxelGenerator
+    from sharded_helpers import NumpyOps
+    from d3d_amd.voxel.sharded import LocalComm
+    with pytest.raises(ValueError):              # ... and, sharded, of the owners' own voxels (no replication)
+        ShardedVoxelGenerator([0, 1, 0, 1, 0, 1], [10, 10, 10], comm=LocalComm(), ops=NumpyOps(), max_points=4, replicate=True, resident=True)
+    with pytest.raises(ValueError):
+        ShardedVoxelGenerator([0, 1, 0, 1, 0, 1], [10, 10, 10], comm=LocalComm(), ops=NumpyOps(), replicate=False, resident=True)
     with pytest.raises(ValueError):
         box2d_iou(torch.zeros(3, 4), torch.zeros(3, 5))
     with pytest.raises(ValueError):
