@@ -452,6 +452,24 @@ def test_resident_dense_c_abi_contract():
         assert torch.equal(pmask[:nv], pmask2[:nv]) and torch.equal(agg[:nv], agg2[:nv])
 
 
+def test_descending_filter_when_every_voxel_is_crowded():
+    """the adversarial frame for the counting sort of the DESCENDING filter: 15 000 voxels of 255 .. 269 points each (3.9 M
+    points) -- ALL of them in the class the counting pass hands to the all-pairs ranking (k_cs_rank_big), whose side list is
+    sized by points / 255; ties everywhere, the cut in the middle"""
+    from d3d_amd.voxel import VoxelGenerator
+    rng = np.random.default_rng(1)
+    shape, bounds = [64, 64, 16], [0, 64, 0, 64, 0, 16]
+    cells = rng.choice(64 * 64 * 16, 15000, replace=False)
+    rows = []
+    for cell, k in zip(cells, rng.integers(255, 270, 15000)):
+        corner = np.array([cell // (64 * 16), (cell // 16) % 64, cell % 16], np.float32)
+        rows.append(np.concatenate([corner + 0.05 + 0.9 * rng.random((k, 3)), rng.random((k, 1))], 1))
+    cloud = np.concatenate(rows).astype(np.float32)
+    cloud = cloud[rng.permutation(len(cloud))]
+    kw = dict(max_points=5, max_points_filter="trim", min_points=1, max_voxels=7000, max_voxels_filter="descending")
+    check_sparse(_np(VoxelGenerator(bounds, shape, **kw)(torch.from_numpy(cloud).cuda())), oracle.VoxelGenerator(bounds, shape, **kw)(cloud))
+
+
 def test_sparse_bounding_box_key_and_its_fallback():
     """sparse contract: one-word hash slots keyed inside the frame's bounding box (k_bbox); a box too large for the key
     field (far outliers on every axis) raises PACK_OVERFLOW and the call is repeated with plain slots -- same result"""
