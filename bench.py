@@ -288,6 +288,7 @@ def extras(args):
     ex["voxelize_dense_resident_mpoints_per_s"] = round(args.points * 40 / dtr / 1e6, 2)
     ex["voxelize_dense_resident_us_per_frame"] = round(dtr / 40 * 1e6, 1)
     ex["voxelize_dense_resident_kernels_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(rp.items(), key=lambda kv: -kv[1]["total_ms"])}
+    ex["voxelize_dense_resident_traffic"] = load_traffic("k_emit_resident", "config2_resident")[0]
     ex["voxelize_dense_resident_note"] = ("output buffer resident on the device: rows with points + stale rows stored, zero padding kept "
                                           "(same values as the headline's tensor; valid until the next call); not the headline contract")
     del ca, cb, gen
