@@ -647,7 +647,11 @@ __global__ __launch_bounds__(kRecTileThreads) void k_rec_tile_sort(const int32_t
     uint32_t *h = reinterpret_cast<uint32_t *>(keys + kRecTile);           // [nb] histogram, then the buckets' offsets
     uint16_t *lidx = reinterpret_cast<uint16_t *>(h + nb);                 // [kRecTile] record index inside the tile
     __shared__ u64 smem[kRecTileThreads / kWave];
-    const int64_t base = (int64_t)blockIdx.x * kRecTile + threadIdx.x;
+    // (XCD-aware tile numbering as in k_tile_sort of voxel.hip: a bucket's table row is written as adjacent words into one L2)
+    const uint32_t per_xcd = (ntiles + 7u) >> 3;
+    const uint32_t tile = ntiles >= 64u ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= ntiles) return;
+    const int64_t base = (int64_t)tile * kRecTile + threadIdx.x;
     u64 key[kRecTileItems];
 #pragma unroll
     for (int r = 0; r < kRecTileItems; r++) {
@@ -655,7 +659,7 @@ __global__ __launch_bounds__(kRecTileThreads) void k_rec_tile_sort(const int32_t
         key[r] = i < R ? (u64)*reinterpret_cast<const int64_t *>(recv + (size_t)i * RS) : 0ull;
     }
     for (uint32_t b = threadIdx.x; b < nb; b += kRecTileThreads) h[b] = 0;
-    if (blockIdx.x == 0) {                                                 // housekeeping for the launches behind this one
+    if (tile == 0) {                                                 // housekeeping for the launches behind this one
         for (uint32_t t = threadIdx.x; t < nstatus; t += kRecTileThreads) status[t] = 0ull;
         if (threadIdx.x < D3D_NUM_COUNTS) counts[threadIdx.x] = 0;
         if (threadIdx.x <= (unsigned)world) src_off_copy[threadIdx.x] = src_off[threadIdx.x];
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(kRecTileThreads) void k_rec_tile_sort(const int32_t
     for (int k = 0; k < kPerMax; k++) {
         if ((uint32_t)k < per && b0 + k < nb) {
             h[b0 + k] = (uint32_t)ex;
-            table[(size_t)(b0 + k) * ntiles + blockIdx.x] = (uint32_t)ex | (cnt[k] << 16);
+            table[(size_t)(b0 + k) * ntiles + tile] = (uint32_t)ex | (cnt[k] << 16);
             ex += cnt[k];
         }
     }
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(kRecTileThreads) void k_rec_tile_sort(const int32_t
         }
     }
     __syncthreads();
-    const size_t tbase = (size_t)blockIdx.x * kRecTile;
+    const size_t tbase = (size_t)tile * kRecTile;
     for (uint32_t p = threadIdx.x; p < (uint32_t)all; p += kRecTileThreads) {
         ekey[tbase + p] = keys[p];
         eidx[tbase + p] = (uint32_t)tbase + lidx[p];
@@ -724,7 +728,8 @@ __global__ __launch_bounds__(kRecBucketThreads) void k_rec_bucket(const u64 *__r
     __shared__ uint32_t srcpos[kRecBucketCap];                           // where the bucket's entries are; then (llist) the
     uint32_t *llist = srcpos;                                            // cells' record lists as in cellrecs (160 KB / 4 workgroups)
     __shared__ u64 smem[kRecBucketThreads / kWave];
-    const uint32_t b = blockIdx.x;
+    // (XCD-aware numbering as in k_bucket_index of voxel.hip: the runs of neighbouring buckets share lines inside a tile)
+    const uint32_t b = gridDim.x >= 64u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     // this bucket's runs: one per tile
     constexpr int kRuns = kRecMaxTiles / kRecBucketThreads;
     uint32_t roff[kRuns], rlen[kRuns];
@@ -1448,7 +1453,7 @@ extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *sr
             return D3D_OK;
         }
         const size_t lds = (size_t)kRecTile * 10 + (size_t)m.nb * 4;
-        D3D_LAUNCH("k_rec_tile_sort", k_rec_tile_sort, dim3(m.ntiles), dim3(kRecTileThreads), lds, st, recv, R, rec_stride(c), m.nb, m.ntiles,
+        D3D_LAUNCH("k_rec_tile_sort", k_rec_tile_sort, dim3((m.ntiles + 7u) & ~7u), dim3(kRecTileThreads), lds, st, recv, R, rec_stride(c), m.nb, m.ntiles,
                    m.ekey, m.eidx, m.table, rec_owned, m.status, m.ftiles + 1, m.overflow, counts, src_off, (int)world, m.src_off);
         D3D_LAUNCH("k_rec_bucket", k_rec_bucket, dim3(m.nb), dim3(kRecBucketThreads), 0, st, (const u64 *)m.ekey, (const uint32_t *)m.eidx,
                    (const uint32_t *)m.table, m.ntiles, m.cellrecs, m.rinfo, m.overflow, counts,
