@@ -1067,6 +1067,16 @@ constexpr int kBucketThreads = 512;           // ... 4 per lane (256: 42 us, 512
 constexpr int kBucketSlots = 2048;            // LDS table slots (>= distinct cells of a bucket, always)
 constexpr uint32_t kNoBin = 0xffffffffu;
 constexpr uint32_t kXcdBucketsMin = 2048;     // k_bucket_index: XCD-aware bucket numbering from this many buckets (a power of two) on
+// Round 5 (k_bucket_index<.., V2> -> k_emit): the first-point entry of a voxel carries the voxel itself --
+//   firstmap[first] = {count : 8 | base : 24}   count 1 .. 254 points, base = the voxel's segment in the ranked index lists (its
+//                                                cell is rebuilt from the first point's row, which k_emit reads anyway: no record),
+//                     {255 | record position}    255 points or more (or a big bucket): the 16-byte record as before,
+//                     kInf                        not a first point.
+// One dependent random gather less per multi-point voxel in k_emit, no record stores in the index, and the points kept
+// (min(count, max_points)) are known to k_emit as soon as its first load returns.  Positions stay below 2^24 - 1 (host-checked).
+constexpr uint32_t kFmShift = 24, kFmMask = 0xffffffu, kFmRecord = 255u;
+constexpr int64_t kFmMaxPoints = (1 << 24) - 2;
+constexpr uint32_t kDenseMin = 64;            // V2: cells with more points are ranked by ONE wavefront (select + all-pairs on the kept ones)
 
 // reduce contract (d3d_voxelize_3d_reduce) on the binned path
 struct BinnedExtras {
@@ -1083,6 +1093,7 @@ struct BinnedExtras {
     long long coord_sub[3] = {0, 0, 0};
     int64_t aux_value = 0;           // what k_emit leaves in counts[D3D_COUNT_AUX] (d3d_voxelize_3d_reduce: 1 = ranked index lists)
     uint16_t *row_state = nullptr;   // d3d_voxelize_3d_dense_resident: [capacity] rows of voxels[v] that may be non-zero (k_emit<.., true>)
+    bool fm_packed = false;          // firstmap entries are {count : 8 | segment : 24} words (k_bucket_index<.., V2>), see kFmShift
 };
 
 // sparse contract fused with the voxel filter (d3d_voxelize_3d_sparse_filter): only voxels that pass get a first-point
@@ -1443,6 +1454,11 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+__device__ __forceinline__ void wave_lds_fence()  // LDS traffic of THIS wavefront is ordered (the pipe is in-order per wave);
+{                                                 // keep the compiler from moving accesses across, and let writes land
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <int BLOCK>
 __device__ __forceinline__ u64 block_excl_scan_u64_lds(u64 v, u64 *total, u64 *smem)
 {
@@ -1486,7 +1502,7 @@ __device__ __forceinline__ void block_excl_scan_2u64_lds(u64 a, u64 b, u64 *ex_a
 // STAGE (dense contract on C == 4 rows): the ranked rows themselves are gathered and staged next to their rank, for the
 // two-launch output stage.  ROWS && LISTS && !STAGE is the index for k_emit: no row moves here at all -- a voxel's first
 // row is points[first point], which k_emit reads coalesced, and ranks 1 .. P-1 leave their point INDEX in sorted_out.
-template <class Key, bool ROWS, bool LISTS, bool STAGE = ROWS>
+template <class Key, bool ROWS, bool LISTS, bool STAGE = ROWS, bool V2 = false>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPass vp,
                                                       const typename BinEntry<ROWS>::type *__restrict__ bent,
                                                       const float4 *__restrict__ points4 /* ROWS */,
@@ -1512,8 +1528,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                       // the filter, points they keep (count clamped to early_clamp)}, added up
                                                       // by the wavefronts (k_meta_first_lb's first tile tells the host)
                                                       u64 *__restrict__ early_tot = nullptr, uint32_t early_clamp = 0,
-                                                      uint32_t early_mask = 0 /* pairs - 1; one pair per 128-byte line */)
+                                                      uint32_t early_mask = 0 /* pairs - 1; one pair per 128-byte line */,
+                                                      int idx_bits = 24 /* V2: point indices < 2^idx_bits */)
 {
+    static_assert(!V2 || (ROWS && LISTS && !STAGE), "V2: the index for k_emit (dense contract on C == 4 rows)");
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
     typedef typename Key::bin_key_t KT;
     typedef BinEntry<ROWS> E;
@@ -1531,6 +1549,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                     // phase: the tile of every entry of a register bucket (tile-sorted input)
     uint16_t *const tileof = oslot;
     __shared__ uint32_t nover, fail;
+    __shared__ uint32_t whist[V2 ? kBucketThreads / kWave : 1][kWave];      // V2: one 64-bin histogram per wavefront (dense cells)
     typedef float v4f __attribute__((ext_vector_type(4)));   // (an array of HIP float4 structs stayed in scratch)
     D3D_PHASE_DECL;
     uint32_t bb, m;
@@ -1638,7 +1657,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             // wrote the value bb + j at firstmap[bb + j], i.e. the other store's index; found by the big-bucket tests, see
             // DESIGN.md 4a)
             if (pass) {
-                __hip_atomic_store(&firstmap[f], single ? kSingleVoxel : bb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&firstmap[f], V2 ? ((kFmRecord << kFmShift) | (bb + j)) : (single ? kSingleVoxel : bb + j),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 early_v++;
                 early_p += cnt < early_clamp ? cnt : early_clamp;
             } else tfirst[sl] = kInf;             // (its points belong to no kept voxel: what precpos / pfirst_out hand on)
@@ -1711,6 +1731,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         for (uint32_t o = threadIdx.x >> 6; o < no; o += kBucketThreads / kWave) {
             const uint32_t s = oslot[o], w = tcnt[s];
             const uint32_t base = decltype(BIG)::value ? seg[s] : w >> 16, cnt = decltype(BIG)::value ? w : w & 0xffffu;
+            if (V2 && cnt <= P) continue;           // (V2 also lists the cells above kDenseMin points, for their ranking)
             double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
             float e0, e1, e2, e3;
             e0 = e1 = e2 = e3 = reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY;
@@ -1827,6 +1848,198 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             }
         }
         reduce_overflow(sg, std::true_type{}, (const v4f *)nullptr);
+        return;
+    }
+
+    if constexpr (V2) {
+        // ---- round 5, register bucket of the index for k_emit.  Against the path below: no first-index table (the point of
+        // rank 0 IS the first point and stores the voxel's entry itself: one LDS atomic per point less, no scattered stores
+        // in the slot-ordered records phase, which shrinks to the scan of the counts), the four CAS of a lane in flight
+        // together, no record for a voxel below 255 points (the entry carries count and segment), and the cells with more
+        // than kDenseMin points -- whose per-point counting loops kept whole wavefronts waiting for one lane -- ranked by ONE
+        // wavefront each: radix-64 select of the max_points smallest indices, all-pairs ranks among those.
+        KT key[ITEMS];
+        uint32_t idx[ITEMS], slot[ITEMS], arr[ITEMS];
+        if (table) lds_barrier();                   // the run table is complete
+        static_for<ITEMS>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            const uint32_t q = threadIdx.x + r * kBucketThreads;
+            key[r] = 0; idx[r] = 0;
+            if (q < m) {
+                uint32_t p;
+                if (table) {
+                    const uint32_t t = tileof[q];
+                    p = seg[kRunCap + t] + (q - seg[t]);
+                } else p = bb + q;
+                const typename E::type e = bent[p];
+                key[r] = (KT)E::key(e);
+                idx[r] = E::idx(e);
+            }
+        });
+        lds_barrier();
+        D3D_PHASE(0, 1);
+#ifdef D3D_PHASE_CLOCKS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        D3D_PHASE(0, 8);
+#endif
+        KT old[ITEMS];
+        static_for<ITEMS>([&](auto R) {             // first probe of all items: the atomics' round trips overlap
+            constexpr int r = decltype(R)::value;
+            const uint32_t q = threadIdx.x + r * kBucketThreads;
+            slot[r] = (Key::bin_hash((u64)key[r]) >> hshift) & (T - 1);
+            old[r] = kFree;
+            if (q < m) old[r] = atomicCAS(&tkey[slot[r]], kFree, key[r]);
+        });
+        static_for<ITEMS>([&](auto R) {             // (distinct cells <= m <= T: a free slot always exists)
+            constexpr int r = decltype(R)::value;
+            const uint32_t q = threadIdx.x + r * kBucketThreads;
+            if (q < m) {
+                uint32_t s = slot[r];
+                KT o = old[r];
+                while (o != kFree && o != key[r]) {
+                    s = (s + 1) & (T - 1);
+                    o = atomicCAS(&tkey[s], kFree, key[r]);
+                }
+                slot[r] = s;
+            }
+        });
+        static_for<ITEMS>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            const uint32_t q = threadIdx.x + r * kBucketThreads;
+            arr[r] = 0;
+            if (q < m) arr[r] = atomicAdd(&tcnt[slot[r]], 1u);
+        });
+        lds_barrier();
+        D3D_PHASE(0, 2);
+        {
+            // segments in slot order: lane t owns slots t, t + 512, .. (conflict-free rows); the four rows' prefix sums travel
+            // as 16-bit fields of one word.  Cells for a wavefront of their own -- more than kDenseMin points (ranking) or more
+            // than P with a reduction (every point counts, voxelize.cpp:137-157) -- are listed.
+            constexpr int PER = T / kBucketThreads;
+            static_assert(PER == 4 && kBucketCap < 65536, "four 16-bit fields");
+            uint32_t c[PER];
+            u64 cs = 0;
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                c[k] = tcnt[threadIdx.x + k * kBucketThreads];
+                cs |= (u64)c[k] << (16 * k);
+            }
+            u64 tot_c;
+            const u64 ex_c = block_excl_scan_u64_lds<kBucketThreads>(cs, &tot_c, smem);
+            D3D_PHASE(0, 7);
+            uint32_t row_c = 0;
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const uint32_t sl = threadIdx.x + k * kBucketThreads;
+                const uint32_t base = row_c + (uint32_t)((ex_c >> (16 * k)) & 0xffffu);
+                tcnt[sl] = c[k] | (base << 16);
+                if (c[k] > kDenseMin || (reduction != D3D_REDUCE_NONE && c[k] > P)) oslot[atomicAdd(&nover, 1u)] = (uint16_t)sl;
+                row_c += (uint32_t)((tot_c >> (16 * k)) & 0xffffu);
+            }
+        }
+        lds_barrier();
+        D3D_PHASE(0, 3);
+        static_for<ITEMS>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            const uint32_t q = threadIdx.x + r * kBucketThreads;
+            if (q < m) seg[(tcnt[slot[r]] >> 16) + arr[r]] = idx[r];
+        });
+        lds_barrier();
+        D3D_PHASE(0, 4);
+        // the voxel's entry, by its first point (a relaxed atomic store: see the note at the other firstmap store)
+        auto first_entry = [&](uint32_t f, uint32_t cnt, uint32_t base, uint32_t s) {
+            uint32_t w = (cnt << kFmShift) | (bb + base);
+            if (cnt >= kFmRecord) {
+                const u64 kk = (u64)tkey[s];
+                vrec[bb + base] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), bb + base, cnt);
+                w = (kFmRecord << kFmShift) | (bb + base);
+            }
+            __hip_atomic_store(&firstmap[f], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        v4f over_pre = {0.f, 0.f, 0.f, 0.f};
+        overflow_first(seg, over_pre);
+        static_for<ITEMS>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            const uint32_t q = threadIdx.x + r * kBucketThreads;
+            if (q < m) {
+                const uint32_t s = slot[r], cb = tcnt[s], cnt = cb & 0xffffu, base = cb >> 16, me = idx[r];
+                if (cnt <= kDenseMin) {
+                    uint32_t rank = 0, k = 0;
+                    const uint32_t *sg = seg + base;
+                    for (; k + 8 <= cnt && rank < P; k += 8)          // 8 independent LDS reads per exit test
+                        rank += (sg[k] < me) + (sg[k + 1] < me) + (sg[k + 2] < me) + (sg[k + 3] < me) + (sg[k + 4] < me) + (sg[k + 5] < me) +
+                                (sg[k + 6] < me) + (sg[k + 7] < me);
+                    for (; k < cnt && rank < P; k++) rank += sg[k] < me;
+                    if (rank == 0) first_entry(me, cnt, base, s);
+                    else if (rank < P) sorted_out[bb + base + rank] = me;
+                }
+            }
+        });
+        D3D_PHASE(0, 5);
+        // listed cells, one wavefront each: the reduction over ALL points first (it reads the whole segment), then the ranking,
+        // which compacts the segment in place
+        {
+            const uint32_t no = nover, lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+            const bool reduce = reduction != D3D_REDUCE_NONE;
+            if (reduce) reduce_overflow(seg, std::false_type{}, &over_pre);
+            uint32_t *hist = whist[V2 ? wv : 0];
+            for (uint32_t o = wv; o < no; o += kBucketThreads / kWave) {
+                const uint32_t s = oslot[o], cb = tcnt[s], cnt = cb & 0xffffu, base = cb >> 16;
+                if (cnt <= kDenseMin) continue;                     // (listed for its reduction only)
+                uint32_t *sg = seg + base;
+                const uint32_t want = cnt < P ? cnt : P, K = (cnt + kWave - 1) / kWave;
+                // the `want` smallest indices: radix-64 select, six bits a round -- bins [lo + b << shift, lo + (b + 1) << shift)
+                uint32_t lo = 0, below = 0, tau = 0xffffffffu;
+                int shift = idx_bits > 6 ? idx_bits - 6 : 0;
+                if (cnt > want) {
+                    for (;;) {
+                        hist[lane] = 0;
+                        wave_lds_fence();
+                        for (uint32_t k = 0; k < K; k++) {
+                            const uint32_t t = k * kWave + lane;
+                            if (t < cnt) {
+                                const uint32_t e = sg[t], d = (e - lo) >> shift;
+                                if (e >= lo && d < (uint32_t)kWave) atomicAdd(&hist[d], 1u);
+                            }
+                        }
+                        wave_lds_fence();
+                        const uint32_t c = hist[lane], incl = wave_incl_scan_u32(c);
+                        const unsigned long long hit = __ballot(below + incl >= want);     // never empty: the range holds >= want - below
+                        const int b = __ffsll((long long)hit) - 1;
+                        const uint32_t ex_b = (uint32_t)__builtin_amdgcn_readlane((int)(incl - c), b);
+                        const uint32_t c_b = (uint32_t)__builtin_amdgcn_readlane((int)c, b);
+                        if (below + ex_b + c_b == want || shift == 0) { tau = lo + (((uint32_t)b + 1u) << shift); break; }
+                        below += ex_b;
+                        lo += (uint32_t)b << shift;
+                        shift = shift > 6 ? shift - 6 : 0;
+                    }
+                }
+                // kept = below tau, compacted to the front of the segment (forward, in place: position <= index read)
+                uint32_t run = 0;
+                for (uint32_t k = 0; k < K; k++) {
+                    const uint32_t t = k * kWave + lane;
+                    const uint32_t e = t < cnt ? sg[t] : 0xffffffffu;
+                    const bool keep = t < cnt && e < tau;
+                    const unsigned long long kb = __ballot(keep);
+                    wave_lds_fence();
+                    if (keep) sg[run + (uint32_t)__popcll(kb & ((1ull << lane) - 1ull))] = e;
+                    run += (uint32_t)__popcll(kb);
+                    wave_lds_fence();
+                }
+                // ranks among the kept (run == want of them): every kept index against all of them, broadcast reads
+                for (uint32_t j0 = 0; j0 < want; j0 += kWave) {
+                    const uint32_t t = j0 + lane;
+                    const uint32_t me = t < want ? sg[t] : 0u;
+                    uint32_t rank = 0;
+                    for (uint32_t u = 0; u < want; u++) rank += sg[u] < me;
+                    if (t < want) {
+                        if (rank == 0) first_entry(me, cnt, base, s);
+                        else sorted_out[bb + base + rank] = me;
+                    }
+                }
+            }
+        }
+        D3D_PHASE(0, 6);
         return;
     }
 
@@ -2169,10 +2382,6 @@ __global__ __launch_bounds__(kMetaLbThreads) void k_meta_first_lb(Key kf, int64_
 // A wavefront whose rows exceed the buffer (kEmitCap) takes its voxels in batches of consecutive ids.
 constexpr int kEmitCap = 256;                     // rows per wavefront in LDS (4 KiB); max_points <= kEmitCap on this path
 
-__device__ __forceinline__ void wave_lds_fence()  // LDS traffic of THIS wavefront is ordered (the pipe is in-order per wave);
-{                                                 // keep the compiler from moving accesses across, and let writes land
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
 
 // RESIDENT (d3d_voxelize_3d_dense_resident): voxels[capacity, P, 4] is a buffer the caller keeps from frame to frame, with
 // row_state[v] = the number of leading rows of voxels[v] that may be non-zero (both zero-filled once, by the caller).  95 % of
@@ -2240,14 +2449,16 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     const bool mine = (uint32_t)lane < nv;
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     if (mine) {
-        if (el != kSingleVoxel) rec = vrec[el];             // the one random access per multi-point voxel
-        else {                                              // a voxel of one point has no record: its cell from the point itself
+        // packed entries (round 5): count and segment travel in the entry, the record only for 255 points and more
+        const bool has_rec = x.fm_packed ? (el >> kFmShift) == kFmRecord : el != kSingleVoxel;
+        if (has_rec) rec = vrec[x.fm_packed ? (el & kFmMask) : el];   // the one random access per such voxel
+        else {                                              // no record: the voxel's cell from its first point itself
             const float4 p0 = points4[il];                  // (ascending indices inside the wavefront's 1 KiB window)
             const float v3[3] = {p0.x, p0.y, p0.z};
             u64 key = 0;
             uint32_t st = 0;
             (void)kf.make(v3, key, st);                     // the same arithmetic on the same floats as k_bin_count: the same cell
-            rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), 0u, 1u);
+            rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), x.fm_packed ? (el & kFmMask) : 0u, x.fm_packed ? (el >> kFmShift) : 1u);
         }
     }
 #ifdef D3D_PHASE_CLOCKS
@@ -3311,6 +3522,7 @@ struct DenseOut {
     float *emit_generic = nullptr;      // dense contract, C = 3, 5 .. 8: k_emit_c writes voxels[V,P,C] and the per-voxel outputs
     bool emit_reduce = false;           // reduce contract without rows: k_emit without the stretch (nothing staged by the index)
     int stage = 0;                      // d3d_voxelize_3d_dense_staged: 1 = index launches only, 2 = the output launch only
+    bool index_v1 = false;              // D3D_VOXEL_INDEX_V1: round 4's bucket kernel and record entries (A/B, tests)
 };
 
 // n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
@@ -3391,6 +3603,11 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         table = tilecnt;
         tileinfo = tilecnt + (size_t)nbins * stiles;
     }
+    // round 5: the lean bucket kernel + packed first-point entries, whenever k_emit is the consumer and nothing needs the
+    // cells' first indices per point (the point -> voxel map, the sparse contract's filters)
+    const bool fm_packed = ROWS && (o.emit_voxels || o.emit_reduce) && !o.index_v1 && !precpos && !o.map_later && !o.trimmed &&
+                           !o.pass.on && n <= kFmMaxPoints;
+    x.fm_packed = fm_packed;
     const bool do_index = o.stage != 2;                        // (stage 2: this frame's index was launched by an earlier call)
     if (do_index && table) {
         const size_t lds = ((size_t)1 << tshift) * (sizeof(typename Key::bin_key_t) + 2) + bin_lds;
@@ -3430,7 +3647,14 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
                    w.staged, vrec, firstmap, counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list,
                    o.reduction != D3D_REDUCE_NONE ? w.unsorted : (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, o.map_later ? pbin : (uint32_t *)nullptr,
                    early_tot, x.npoints_clamp, early_pairs ? early_pairs - 1u : 0u);
-    else if (ROWS && (o.emit_voxels || o.emit_reduce))
+    else if (fm_packed) {
+        if constexpr (ROWS)
+            D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, true, true, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
+                       bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
+                       counts, (uint32_t *)nullptr, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), (unsigned char *)nullptr, w.big_list,
+                       (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, (uint32_t *)nullptr, (u64 *)nullptr, 0u, 0u,
+                       bits_for((u64)(n > 1 ? n - 1 : 1)));
+    } else if (ROWS && (o.emit_voxels || o.emit_reduce))
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, true, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
                    counts, precpos, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), o.trimmed, w.big_list /* the per-point keys are
@@ -3646,6 +3870,7 @@ static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const 
         if (stage != 0 && !(emitted && fuse_pmask)) return D3D_ERR_UNSUPPORTED;
         d.x.row_state = row_state;
         d.stage = stage;
+        d.index_v1 = (flags & D3D_VOXEL_INDEX_V1) != 0;
         if (vec4) {
             if (row_state && !emitted) return D3D_ERR_UNSUPPORTED;       // (resident rows: the one-launch output kernels only)
             rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
@@ -3819,6 +4044,7 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
         DenseOut d{P, 0xffffffffu, reduction, true, false, coords, npoints, nullptr, aggregates,
                    BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr, nullptr}, mapping};
         d.seg_out = seg_base;
+        d.index_v1 = (flags & D3D_VOXEL_INDEX_V1) != 0;
         d.emit_reduce = P <= (uint32_t)kEmitCap && !(flags & D3D_VOXEL_SPLIT_FILL);
         // With `rows` on this path NO row is moved: the caller's buffer receives the voxels' ranked point INDICES (uint32; entry
         // seg_base[v] + k = the voxel's point of rank k >= 1, rank 0 = its first point) and counts[D3D_COUNT_AUX] = 1 says so --

@@ -89,14 +89,59 @@ def score_match(distance, src_scores, src_tags, dst_tags, distance_threshold):
     return src_match, dst_match
 
 
+def score_match_reference_compat(distance, src_scores, src_tags, dst_tags, distance_threshold, src_subset, dst_subset):
+    """ScoreMatcher.match exactly as matcher.pyx:142-162 pairs the two orders -- INCLUDING its row mix-up: the k-th best source
+    (`src_subset[src_order[k]]`, :157) walks the destinations in the distance order of the k-th row OF THE SUBSET
+    (`dst_order[src_idx, ...]` with src_idx the loop counter, :158), i.e. of another box whenever the subset is not already
+    sorted by score, and takes the first one that is free, of its tag and within the threshold (match_by_order :96-115 skips a
+    failing pair and goes on).  `score_match` (the default) walks the source's OWN row -- nearest first -- which is what the
+    docstring of the reference's class describes; this function exists so that the difference can be measured
+    (tests/test_gpu_boxloss.py: a detection within the threshold of two ground truths).  A sequential loop of small tensor
+    operations on the device of `distance` (one source per step): a parity mode, not a fast path.
+    Returns (src_match[n], dst_match[m]) int32 tensors, -1 = unmatched."""
+    dev = distance.device
+    n, m = distance.shape
+    src_subset = torch.as_tensor(list(src_subset), dtype=torch.int64, device=dev)
+    dst_subset = torch.as_tensor(list(dst_subset), dtype=torch.int64, device=dev)
+    src_match = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    dst_match = torch.full((m,), -1, dtype=torch.int32, device=dev)
+    if src_subset.numel() == 0 or dst_subset.numel() == 0:
+        return src_match, dst_match
+    scores = torch.as_tensor(np.asarray(src_scores.detach().cpu() if isinstance(src_scores, torch.Tensor) else src_scores, np.float32)).to(dev)
+    stags = torch.as_tensor(np.asarray(src_tags.detach().cpu() if isinstance(src_tags, torch.Tensor) else src_tags, np.int64)).to(dev)
+    dtags = torch.as_tensor(np.asarray(dst_tags.detach().cpu() if isinstance(dst_tags, torch.Tensor) else dst_tags, np.int64)).to(dev)
+    thr = torch.full((m,), float("nan"), dtype=torch.float32, device=dev)
+    for tag, v in distance_threshold.items():
+        thr[dtags == int(tag)] = float(v)
+    # np.flip(np.argsort(scores)) (:146); ties: the stable descending order of this library's other sorts
+    src_order = torch.argsort(-scores[src_subset], stable=True)
+    sub = distance[src_subset][:, dst_subset]
+    dst_order = torch.argsort(sub, dim=1, stable=True)                       # (:148) row k = subset row k
+    free = torch.ones((m,), dtype=torch.bool, device=dev)
+    for k in range(src_subset.numel()):
+        s = src_subset[src_order[k]]
+        cand = dst_subset[dst_order[k]]                                      # (:158) the LOOP COUNTER's row, not the source's
+        ok = free[cand] & (dtags[cand] == stags[s]) & (distance[s, cand] <= thr[cand])
+        first = torch.argmax(ok.to(torch.int8))
+        hit = ok[first]
+        d = cand[first]
+        src_match[s] = torch.where(hit, d.to(torch.int32), src_match[s])
+        dst_match[d] = torch.where(hit, s.to(torch.int32), dst_match[d])
+        free[d] = free[d] & ~hit
+    return src_match, dst_match
+
+
 class ScoreMatcher:
     """array-level ScoreMatcher (matcher.pyx:138-162): prepare_boxes, match on subsets, query_* -- same call sequence as the
-    reference's evaluator uses (benchmarks.pyx:188-238)"""
+    reference's evaluator uses (benchmarks.pyx:188-238).  `reference_compat=True` reproduces the reference's pairing of the
+    k-th best source with the k-th subset row's distance order (matcher.pyx:155-158); the default pairs
+    every source with its own nearest destinations."""
 
-    def __init__(self):
+    def __init__(self, reference_compat=False):
         self._cache = None
         self._src = self._dst = None
         self._src_assignment, self._dst_assignment = {}, {}
+        self.reference_compat = bool(reference_compat)
 
     def clear_match(self):
         self._src_assignment, self._dst_assignment = {}, {}
@@ -123,7 +168,11 @@ class ScoreMatcher:
         dtags = np.full((m,), -1, np.int64)
         stags[src_subset] = self._src[src_subset, 0].cpu().numpy().astype(np.int64)
         dtags[dst_subset] = self._dst[dst_subset, 0].cpu().numpy().astype(np.int64)
-        sm, dm = score_match(self._cache, self._src[:, 1].cpu().numpy(), stags, dtags, distance_threshold)
+        if self.reference_compat:
+            sm, dm = score_match_reference_compat(self._cache, self._src[:, 1].cpu().numpy(), stags, dtags, distance_threshold,
+                                                  src_subset, dst_subset)
+        else:
+            sm, dm = score_match(self._cache, self._src[:, 1].cpu().numpy(), stags, dtags, distance_threshold)
         sm, dm = sm.cpu().numpy(), dm.cpu().numpy()
         self._src_assignment = {int(i): int(j) for i, j in enumerate(sm) if j >= 0}
         self._dst_assignment = {int(j): int(i) for j, i in enumerate(dm) if i >= 0}

@@ -549,8 +549,10 @@ def _stream_frames(gen, frames, flags, poison):
     def finish(item):
         slot, out, pts = item
         voxels, coords, pmask, npts, agg, counts = out
+        # the outputs (and `counts`) are written on the side stream: the caller's stream waits for them BEFORE anything reads
+        # them there -- note.wait() polls host memory, but its fallback after 50 ms is a device read of `counts` on this stream
+        torch.cuda.current_stream().wait_event(slot.out_done)
         host = slot.note.wait(counts)
-        torch.cuda.current_stream().wait_event(slot.out_done)      # the outputs are written on the side stream
         slot.busy = False
         if int(host[_lib.COUNT_STATUS]) != 0:                       # a capacity limit of the fast index: this frame again, alone
             torch.cuda.current_stream().synchronize()
@@ -562,76 +564,80 @@ def _stream_frames(gen, frames, flags, poison):
         return ret
 
     k = 0
-    for frame in frames:
-        pts = _as_tensor(frame)
-        ok = (staged and isinstance(pts, torch.Tensor) and pts.is_cuda and pts.dtype == torch.float32 and pts.dim() == 2 and
-              pts.shape[1] == 4 and pts.shape[0] > 0 and pts.is_contiguous() and P > 0)
-        if not ok:
-            if pending is not None:
-                yield finish(pending)
-                pending = None
-            yield gen(frame, flags=flags, poison=poison)
-            continue
-        dev = pts.device
-        n = pts.shape[0]
-        cap = max(min(n, mv), 0)
-        with _device_ctx(dev):
-            if s_idx is None:
-                s_idx, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-            slot = slots[k & 1]
-            k += 1
-            if slot.busy:                                            # (cannot happen: a slot's frame is finished two frames on)
-                raise RuntimeError("frame slot still in flight")
-            cur = torch.cuda.current_stream()
-            voxels = torch.empty((cap, P, 4), dtype=torch.float32, device=dev)
-            coords = torch.empty((cap, 3), dtype=torch.int64, device=dev)
-            pmask = torch.empty((cap, P), dtype=torch.uint8, device=dev)
-            npts = torch.empty((cap,), dtype=torch.int32, device=dev)
-            agg = torch.empty((cap, 4), dtype=torch.float32, device=dev) if red != 0 else None
-            counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
-            if poison:
-                voxels.fill_(float("nan")); coords.fill_(-(1 << 62)); pmask.fill_(0xff); npts.fill_(-7)
-                if agg is not None:
-                    agg.fill_(float("nan"))
-            need = _workspace_bytes(lib, n)
-            if slot.ws is None or slot.ws.numel() < need:
-                slot.ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
-            args = (_lib.ptr(pts), n, 4, ctypes.cast(gen._shape_h, ctypes.c_void_p), ctypes.cast(gen._bounds_h, ctypes.c_void_p),
-                    P, mv, red, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts), _lib.ptr(agg),
-                    _lib.ptr(counts), _lib.ptr(slot.ws), slot.ws.numel())
-            s_idx.wait_stream(cur)                                   # the frame (and the poison fills) are ready
-            if slot.used:
-                s_idx.wait_event(slot.out_done)                      # this slot's scratch: its last frame's output has read it
-            slot.used = True
-            rc = lib.d3d_voxelize_3d_dense_staged(*args, ctypes.c_void_p(s_idx.cuda_stream), None, fl, 1)
-            if rc == _lib.OK:
-                slot.idx_done.record(s_idx)
-            if rc == _lib.ERR_UNSUPPORTED:                           # this frame (and the rest) the ordinary way
-                staged = False
+    try:
+        for frame in frames:
+            pts = _as_tensor(frame)
+            ok = (staged and isinstance(pts, torch.Tensor) and pts.is_cuda and pts.dtype == torch.float32 and pts.dim() == 2 and
+                  pts.shape[1] == 4 and pts.shape[0] > 0 and pts.is_contiguous() and P > 0)
+            if not ok:
                 if pending is not None:
                     yield finish(pending)
                     pending = None
                 yield gen(frame, flags=flags, poison=poison)
                 continue
-            _lib.check(rc, "voxelize_3d_dense (index stage)")
-            slot.note.arm()
-            s_out.wait_event(slot.idx_done)
-            rc = lib.d3d_voxelize_3d_dense_staged(*args, ctypes.c_void_p(s_out.cuda_stream), slot.note.ptr, fl, 2)
-            slot.out_done.record(s_out)
-            _lib.check(rc, "voxelize_3d_dense (output stage)")
-            slot.busy = True
-            # (the buffers belong to the caller's stream for the allocator: by the time a result is handed out that stream has
-            # waited for the side streams, so whatever it frees or reuses later is ordered behind their work -- no
-            # record_stream, which would keep every freed block out of the cache until an event has been polled: a hipMalloc
-            # per frame, 314 us per frame measured)
+            dev = pts.device
+            n = pts.shape[0]
+            cap = max(min(n, mv), 0)
+            with _device_ctx(dev):
+                if s_idx is None:
+                    s_idx, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+                slot = slots[k & 1]
+                k += 1
+                if slot.busy:                                            # (cannot happen: a slot's frame is finished two frames on)
+                    raise RuntimeError("frame slot still in flight")
+                cur = torch.cuda.current_stream()
+                voxels = torch.empty((cap, P, 4), dtype=torch.float32, device=dev)
+                coords = torch.empty((cap, 3), dtype=torch.int64, device=dev)
+                pmask = torch.empty((cap, P), dtype=torch.uint8, device=dev)
+                npts = torch.empty((cap,), dtype=torch.int32, device=dev)
+                agg = torch.empty((cap, 4), dtype=torch.float32, device=dev) if red != 0 else None
+                counts = torch.empty((_lib.NUM_COUNTS,), dtype=torch.int64, device=dev)
+                if poison:
+                    voxels.fill_(float("nan")); coords.fill_(-(1 << 62)); pmask.fill_(0xff); npts.fill_(-7)
+                    if agg is not None:
+                        agg.fill_(float("nan"))
+                need = _workspace_bytes(lib, n)
+                if slot.ws is None or slot.ws.numel() < need:
+                    slot.ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
+                args = (_lib.ptr(pts), n, 4, ctypes.cast(gen._shape_h, ctypes.c_void_p), ctypes.cast(gen._bounds_h, ctypes.c_void_p),
+                        P, mv, red, _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(pmask), _lib.ptr(npts), _lib.ptr(agg),
+                        _lib.ptr(counts), _lib.ptr(slot.ws), slot.ws.numel())
+                s_idx.wait_stream(cur)                                   # the frame (and the poison fills) are ready
+                if slot.used:
+                    s_idx.wait_event(slot.out_done)                      # this slot's scratch: its last frame's output has read it
+                slot.used = True
+                rc = lib.d3d_voxelize_3d_dense_staged(*args, ctypes.c_void_p(s_idx.cuda_stream), None, fl, 1)
+                if rc == _lib.OK:
+                    slot.idx_done.record(s_idx)
+                if rc == _lib.ERR_UNSUPPORTED:                           # this frame (and the rest) the ordinary way
+                    staged = False
+                    if pending is not None:
+                        yield finish(pending)
+                        pending = None
+                    yield gen(frame, flags=flags, poison=poison)
+                    continue
+                _lib.check(rc, "voxelize_3d_dense (index stage)")
+                slot.note.arm()
+                s_out.wait_event(slot.idx_done)
+                rc = lib.d3d_voxelize_3d_dense_staged(*args, ctypes.c_void_p(s_out.cuda_stream), slot.note.ptr, fl, 2)
+                slot.out_done.record(s_out)
+                _lib.check(rc, "voxelize_3d_dense (output stage)")
+                slot.busy = True
+                # (the buffers belong to the caller's stream for the allocator: by the time a result is handed out that stream has
+                # waited for the side streams, so whatever it frees or reuses later is ordered behind their work -- no
+                # record_stream, which would keep every freed block out of the cache until an event has been polled: a hipMalloc
+                # per frame, 314 us per frame measured)
+            if pending is not None:
+                yield finish(pending)
+            pending = (slot, (voxels, coords, pmask, npts, agg, counts), pts)
         if pending is not None:
             yield finish(pending)
-        pending = (slot, (voxels, coords, pmask, npts, agg, counts), pts)
-    if pending is not None:
-        yield finish(pending)
-    if s_out is not None:
-        torch.cuda.current_stream().wait_stream(s_out)
-        torch.cuda.current_stream().wait_stream(s_idx)
+    finally:
+        # also when the consumer stops early or a frame raises: the side streams may still be writing the pending frame's
+        # outputs and the slots' scratch, which go back to the CALLER's stream's allocator pool once they are dropped
+        if s_out is not None:
+            torch.cuda.current_stream().wait_stream(s_out)
+            torch.cuda.current_stream().wait_stream(s_idx)
 
 
 __all__ = ["VoxelGenerator", "voxelize_3d_dense", "voxelize_3d_sparse", "voxelize_3d_filter", "release_cached_buffers",

@@ -549,8 +549,15 @@ def prepare_boxes(src_arr, dst_arr, rotated=True):
     return (np.float32(1) - iou3d(src[:, 2:9], dst[:, 2:9], "rbox" if rotated else "box")).astype(np.float32)
 
 
-def score_match(cache, src_arr, dst_arr, src_subset, dst_subset, distance_threshold):
-    """ScoreMatcher.match + match_by_order (matcher.pyx:90-162), literally: -> (src_assignment, dst_assignment) dicts.
+def score_match(cache, src_arr, dst_arr, src_subset, dst_subset, distance_threshold, literal=False):
+    """ScoreMatcher.match + match_by_order (matcher.pyx:90-162) -> (src_assignment, dst_assignment) dicts.
+    literal=False (what the product's default implements): every source walks ITS OWN row of the distance matrix, nearest
+    destination first -- the behaviour the reference's class docstring describes.
+    literal=True: the reference's loop as written -- the k-th best source is paired with the distance order of the k-th ROW OF
+    THE SUBSET (`dst_order[src_idx, dst_idx]` next to `src_order[src_idx]`, matcher.pyx:155-158: the loop counter indexes the
+    unsorted row), so a source may take a destination that is merely the first acceptable one in ANOTHER box's order.  The two
+    agree whenever no source has more than one acceptable destination (the reference's own test_calc_stats) or the subset
+    happens to be sorted by score.
     (ties: stable sorts, i.e. equal scores in index order, equal distances to the lower index -- the spec of this repo)"""
     src_assign, dst_assign = {}, {}
     src_subset, dst_subset = list(src_subset), list(dst_subset)
@@ -563,7 +570,7 @@ def score_match(cache, src_arr, dst_arr, src_subset, dst_subset, distance_thresh
     for si in range(len(src_subset)):
         s = src_subset[src_order[si]]
         for di in range(len(dst_subset)):
-            d = dst_subset[dst_order[src_order[si], di]]
+            d = dst_subset[dst_order[si if literal else src_order[si], di]]
             if s in src_assign:
                 continue
             if d in dst_assign:

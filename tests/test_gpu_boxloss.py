@@ -252,6 +252,55 @@ def test_score_match_and_calc_stats_vs_oracle():
     assert r.ngt[1] == 0 and r.fp[1][0] == 1 and r.tp[1][0] == 0
 
 
+def _crowded_scene():
+    """two ground truths next to each other, two detections: A (best score) overlaps BOTH ground truths within the threshold
+    and is nearest to g1; B overlaps g0 only.  Listed with B first, so that the subset is NOT in score order"""
+    gt9 = np.array([[1, 0, 0.0, 0.0, 0, 4, 2, 2, 0], [1, 0, 1.2, 0.0, 0, 4, 2, 2, 0]], np.float32)
+    dt9 = np.array([[1, 0.6, -0.4, 0.0, 0, 4, 2, 2, 0],         # B: near g0 (its own nearest), far from g1
+                    [1, 0.9, 0.9, 0.0, 0, 4, 2, 2, 0]], np.float32)  # A: nearest g1, also within the threshold of g0
+    return gt9, dt9
+
+
+def test_score_match_reference_compat_reproduces_the_row_mixup():
+    """matcher.pyx:155-158 pairs the k-th BEST source with the distance order of the k-th subset ROW.  On a crowded scene the
+    literal loop hands the best detection the ground truth that is nearest to ANOTHER detection; the default association gives
+    every detection its own nearest.  compat == the literal restatement, default == nearest-first, and the two differ here"""
+    from d3d_amd.tracking import DistanceTypes, ScoreMatcher, prepare_boxes, score_match, score_match_reference_compat
+    gt9, dt9 = _crowded_scene()
+    thr = {1: 0.8}
+    cache = prepare_boxes(dt9, gt9, DistanceTypes.RIoU)
+    c = cache.cpu().numpy()
+    assert c[1, 1] < c[1, 0] <= thr[1] and c[0, 0] < c[0, 1] and c[0, 0] <= thr[1]      # A: g1 nearest, g0 acceptable; B: g0
+    src, dst = [0, 1], [0, 1]
+    lit_s, lit_d = oracle.score_match(c, dt9, gt9, src, dst, thr, literal=True)
+    own_s, own_d = oracle.score_match(c, dt9, gt9, src, dst, thr, literal=False)
+    assert own_s == {1: 1, 0: 0}                      # nearest-first: A -> g1, B -> g0
+    assert lit_s[1] == 0 and lit_s != own_s           # literal: A walks ROW 0 (B's order: g0 first) and takes g0
+    sm, dm = score_match(cache, dt9[:, 1], dt9[:, 0], gt9[:, 0], thr)
+    assert {i: int(j) for i, j in enumerate(sm.cpu().numpy()) if j >= 0} == own_s
+    cs, cd = score_match_reference_compat(cache, dt9[:, 1], dt9[:, 0], gt9[:, 0], thr, src, dst)
+    assert {i: int(j) for i, j in enumerate(cs.cpu().numpy()) if j >= 0} == lit_s
+    assert {j: int(i) for j, i in enumerate(cd.cpu().numpy()) if i >= 0} == lit_d
+    for compat, exp in ((True, lit_s), (False, own_s)):
+        mt = ScoreMatcher(reference_compat=compat)
+        mt.prepare_boxes(dt9, gt9, DistanceTypes.RIoU)
+        mt.match(src, dst, thr)
+        assert {i: mt.query_src_match(i) for i in src if mt.query_src_match(i) >= 0} == exp
+    # random crowded frames: compat == literal on every one (subsets in index order, as the evaluator passes them)
+    from d3d_amd import synth
+    for seed in range(4):
+        pred, gt = synth.boxes3d_eval(40, 4, 100 + seed)
+        d9, g9 = _labelled(pred, 2), _labelled(gt, 2, scores=False)
+        thr2 = {1: 0.95, 2: 0.9}                                # loose: several acceptable ground truths per detection
+        cc = prepare_boxes(d9, g9, DistanceTypes.RIoU)
+        src = [i for i in range(len(d9)) if d9[i, 1] >= 0.2]
+        dst = list(range(len(g9)))
+        ls, ld = oracle.score_match(cc.cpu().numpy(), d9, g9, src, dst, thr2, literal=True)
+        cs, cd = score_match_reference_compat(cc, d9[:, 1], d9[:, 0], g9[:, 0], thr2, src, dst)
+        assert {i: int(j) for i, j in enumerate(cs.cpu().numpy()) if j >= 0} == ls
+        assert {j: int(i) for j, i in enumerate(cd.cpu().numpy()) if i >= 0} == ld
+
+
 @pytest.mark.parametrize("n,m,classes", [(400, 300, 1), (3000, 700, 2), (130, 65, 1)])
 def test_score_match_loose_thresholds_many_candidates(n, m, classes):
     """DetectionEvaluator(min_overlaps=0) gives max_distance = 1: EVERY ground truth of a detection's class is a candidate --

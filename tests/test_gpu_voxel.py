@@ -12,15 +12,16 @@ from golden_io import GOLDEN, derived_pmask, load_voxel_cases
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "hash", "split", "3pass"])
+@pytest.fixture(autouse=True, params=["auto", "hash", "split", "3pass", "v1"])
 def index_path(request):
     """every test of this module runs on both index paths of the voxelizer: automatic (binned whenever eligible; dense
     contract: the fused output kernel k_emit) and the hash table (tests that pick a path themselves -- `voxel_path` --
-    override this); "split" = binned index with the two-launch output stage (k_meta_first + k_fill_c4).  The dense
-    operator's output buffers are poisoned before every call."""
+    override this); "split" = binned index with the two-launch output stage (k_meta_first + k_fill_c4); "v1" = round 4's
+    bucket kernel with one record per voxel (D3D_VOXEL_INDEX_V1) where round 5's packed first-point entries are the default.
+    The dense operator's output buffers are poisoned before every call."""
     from d3d_amd import _lib
     set_opts(voxel_flags={"hash": _lib.VOXEL_PATH_HASH, "split": _lib.VOXEL_SPLIT_FILL,
-                          "3pass": _lib.VOXEL_PARTITION_3PASS}.get(request.param, 0), poison=True)
+                          "3pass": _lib.VOXEL_PARTITION_3PASS, "v1": _lib.VOXEL_INDEX_V1}.get(request.param, 0), poison=True)
     yield request.param
 
 
@@ -396,7 +397,7 @@ def test_resident_dense_output_over_a_sequence_of_frames(red, P, C, index_path):
         if buf is not None and len(f):
             # (the hash path and the two-launch output stage write whole tensors: a fresh one then, the buffer is left alone)
             aliased = got["voxels"].untyped_storage().data_ptr() == buf.voxels.untyped_storage().data_ptr()
-            assert aliased == (index_path in ("auto", "3pass")), k
+            assert aliased == (index_path in ("auto", "3pass", "v1")), k
             state = buf.row_state.cpu().numpy().astype(np.int64) & 0xffff
             nz = (buf.voxels != 0).any(dim=2).cpu().numpy()                     # [capacity, P]: rows that hold anything
             assert not (nz & (np.arange(P)[None, :] >= state[:, None])).any(), k
@@ -627,6 +628,40 @@ def test_binned_bucket_with_too_many_cells_repeats_on_the_hash_path(voxel_path):
     ret = {k: v.cpu().numpy() for k, v in voxelize_3d_dense(pts, synth.KITTI_SHAPE, synth.KITTI_BOUNDS, 4, n, 1).items()}
     exp = oracle.voxelize_3d_dense(cloud, synth.KITTI_SHAPE, synth.KITTI_BOUNDS, 4, n, 1)
     check_dense(ret, exp, 4)
+
+
+@pytest.mark.parametrize("P,reduction", [(32, "mean"), (1, "max"), (5, "none"), (64, "min"), (100, "mean"), (256, "max"), (72, "none")])
+@pytest.mark.parametrize("layout", ["shuffled", "front", "back", "runs"])
+def test_crowded_cells_ranked_by_one_wavefront(P, reduction, layout):
+    """cells of 65 .. 2048 points in a register bucket: round 5's bucket kernel ranks each of them with ONE wavefront (radix-64
+    select of the max_points smallest point indices, all-pairs ranks among those) and leaves a record only from 255 points
+    on.  Crowded cells of every size class (64 / 65, 254 / 255 / 256, a full bucket), their points spread over the frame, at
+    its front, at its end or in runs of consecutive indices (the select's bins then hold everything or nothing), for max_points
+    below, at and above the cells' sizes -- all outputs against the oracle"""
+    from d3d_amd import synth
+    from d3d_amd.voxel import VoxelGenerator
+    n = 120000
+    cloud = synth.lidar_like(n, 77)
+    rng = np.random.default_rng(78)
+    sizes = [64, 65, 66, 100, 128, 129, 254, 255, 256, 257, 400, 1000, 1500, 1900]
+    homes = rng.choice(n, len(sizes), replace=False)
+    at = 0
+    order = rng.permutation(n) if layout == "shuffled" else np.arange(n) if layout in ("front", "runs") else np.arange(n)[::-1]
+    for sz, h in zip(sizes, homes):
+        lo3 = np.array(synth.KITTI_BOUNDS[0::2])
+        centre = ((np.floor((cloud[h, :3] - lo3) / 0.1) + 0.3) * 0.1 + lo3).astype(np.float32)      # inside one 0.1 m cell
+        if layout == "runs":
+            start = int(rng.integers(0, n - sz))
+            idx = np.arange(start, start + sz)
+        else:
+            idx = order[at:at + sz]
+        at += sz
+        cloud[idx, :3] = centre + 0.03 * rng.random((sz, 3), dtype=np.float32)
+    kw = dict(reduction=reduction, max_points=P, max_voxels=n, dense=True)
+    exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, **kw)(cloud)
+    assert exp["voxel_npoints"].max() >= 1900
+    ret = _np(VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, **kw)(torch.from_numpy(cloud).cuda()))
+    check_dense(ret, exp, P)
 
 
 def test_sparse_contract_heavy_voxel_in_a_big_bucket():

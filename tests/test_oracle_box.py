@@ -230,6 +230,29 @@ def test_evaluator_restatement_reproduces_the_reference_test():
     assert r.tp[2][0] == 0 and r.fp[2][0] == 1 and r.fn[2][0] == 1 and np.isnan(r.acc_iou[2][0])
 
 
+def test_literal_association_order_of_the_reference_and_where_it_matters():
+    """matcher.pyx:155-158 walks, for the k-th best source, the distance order of the k-th ROW of the subset.  oracle.score_match
+    restates both: literal=True (that loop as written) and the default (every source its own row).  They agree on the
+    reference's own test scene (test/test_benchmark.py: one acceptable ground truth per detection) and differ on a crowded
+    one, where the literal loop gives the best detection the ground truth nearest to ANOTHER detection"""
+    dt = np.array([[1, 0.8, 0, 0, 0, 2, 2, 2, 0], [2, 0.7, 1, 1, 1, 2, 2, 2, 0], [3, 0.8, -1, -1, -1, 2, 2, 2, 0]], np.float32)
+    gt = np.array([[2, 0, 0, 0, 0, 2.1, 2.1, 2.1, 0.01], [1, 0, -1, 1, 0, 2.1, 2.1, 2.1, 0.01],
+                   [3, 0, 1, -1, 0, 2.1, 2.1, 2.1, 0.01]], np.float32)
+    cache = oracle.prepare_boxes(dt, gt)
+    for thr in ({1: 0.9, 2: 0.8}, {1: 0.9, 2: 0.8, 3: 0.9}):
+        src = [i for i in range(3) if int(dt[i, 0]) in thr]
+        dst = [j for j in range(3) if int(gt[j, 0]) in thr]
+        assert oracle.score_match(cache, dt, gt, src, dst, thr, literal=True) == oracle.score_match(cache, dt, gt, src, dst, thr)
+    g9 = np.array([[1, 0, 0.0, 0.0, 0, 4, 2, 2, 0], [1, 0, 1.2, 0.0, 0, 4, 2, 2, 0]], np.float32)
+    d9 = np.array([[1, 0.6, -0.4, 0.0, 0, 4, 2, 2, 0], [1, 0.9, 0.9, 0.0, 0, 4, 2, 2, 0]], np.float32)
+    c = oracle.prepare_boxes(d9, g9)
+    lit, _ = oracle.score_match(c, d9, g9, [0, 1], [0, 1], {1: 0.8}, literal=True)
+    own, _ = oracle.score_match(c, d9, g9, [0, 1], [0, 1], {1: 0.8})
+    assert own == {1: 1, 0: 0} and lit == {1: 0, 0: 1}
+    # a subset that IS in score order: the loop counter then names the source's own row, both forms agree
+    assert oracle.score_match(c, d9, g9, [1, 0], [0, 1], {1: 0.8}, literal=True)[0] == own
+
+
 def test_row_wise_association_equals_the_pair_loop():
     from d3d_amd import synth
     pred, gt = synth.boxes3d_eval(60, 4, 5)

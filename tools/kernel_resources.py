@@ -1,32 +1,28 @@
-"""VGPRs / LDS / scratch / occupancy of the kernels of one .hip file, from hipcc's resource remarks.
-usage: python tools/kernel_resources.py d3d_amd/csrc/voxel.hip [name-substring ...]"""
+"""Kernel resource table (VGPRs, SGPRs, occupancy, LDS, scratch) from hipcc's -Rpass-analysis=kernel-resource-usage remarks.
+usage: hipcc ... -Rpass-analysis=kernel-resource-usage 2> remarks.txt ; python tools/kernel_resources.py remarks.txt [name filter ...]"""
 import re
 import subprocess
 import sys
 
-src = sys.argv[1]
-want = sys.argv[2:]
-cmd = ["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Iinclude", "-I../../include",
-       "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
-err = subprocess.run(cmd, capture_output=True, text=True).stderr
+txt = open(sys.argv[1]).read()
+filt = sys.argv[2:]
 cur = None
 rows = {}
-for line in err.splitlines():
-    m = re.search(r"remark: (?:\s*)(.*?) \[-Rpass", line)
+for line in txt.splitlines():
+    m = re.search(r'remark:\s+(.*?) \[-Rpass', line)
     if not m:
         continue
-    t = m.group(1).strip()
-    if t.startswith("Function Name:"):
-        name = t.split(":", 1)[1].strip()
-        dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-        dem = dem.replace("(anonymous namespace)::", "")
-        cur = dem.split("(")[0].replace("void ", "")
+    s = m.group(1).strip()
+    if s.startswith('Function Name:'):
+        cur = s.split(': ')[1]
         rows[cur] = {}
-    elif cur and ":" in t:
-        k, v = t.split(":", 1)
+    elif cur and ':' in s:
+        k, v = s.split(':', 1)
         rows[cur][k.strip()] = v.strip()
-for k, r in rows.items():
-    if want and not any(w in k for w in want):
-        continue
-    print("%-70s vgpr %4s agpr %3s sgpr %4s scratch %5s lds %6s occ %s" % (k[:70], r.get("VGPRs"), r.get("AGPRs"), r.get("SGPRs"),
-          r.get("ScratchSize [bytes/lane]"), r.get("LDS Size [bytes/block]"), r.get("Occupancy [waves/SIMD]")))
+for k, v in rows.items():
+    d = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip()
+    d = re.sub(r'\(anonymous namespace\)::', '', d)
+    d = d.split('(')[0]
+    if not filt or any(x in d for x in filt):
+        print(d[:100].ljust(100), 'VGPR', v.get('VGPRs'), 'SGPR', v.get('TotalSGPRs'), 'occ', v.get('Occupancy [waves/SIMD]'),
+              'lds', v.get('LDS Size [bytes/block]'), 'scratch', v.get('ScratchSize [bytes/lane]'))
