@@ -77,7 +77,7 @@ SIGNATURES = {
     "d3d_owner_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _sz, _vp, _vp, _i64]),
     "d3d_owner_merge_workspace_bytes": (_sz, [_i64, _i32]),
-    "d3d_owner_merge": (ctypes.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32]),
+    "d3d_owner_merge": (ctypes.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32, _vp]),
     "d3d_owner_dense": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp, _vp, _u32, _vp]),
     "d3d_owner_mark_first": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "d3d_owner_number_workspace_bytes": (_sz, [_i64]),

@@ -371,6 +371,11 @@ __device__ __forceinline__ int record_source(const int64_t *__restrict__ src_off
     return lo;
 }
 
+// global first point of the voxel whose leader is record i.  Shards are contiguous point ranges in rank order and the leader
+// is the cell's record from the LOWEST source rank, so the leader's first index is the voxel's (with global indices it equals
+// the minimum over the cell's records, which is what rounds 3-4 took)
+__device__ __forceinline__ int64_t leader_first(const struct MergeOut &f, int64_t i);
+
 // the records of a chain by ascending record index (= source rank order); chains hold at most `world` records, nearly all one
 // or two, so selection by repeated walks beats gathering them into a (dynamically indexed, i.e. scratch) list
 template <class F>
@@ -394,7 +399,20 @@ struct MergeOut {
     int32_t *npoints;
     float *feats;
     int32_t *lead_rec;                   // [owned voxel] its leader record
+    // round 5: records may carry indices LOCAL to their source rank's shard (d3d_voxelize_3d_reduce with index_offset 0, so that
+    // the local pass needs nobody's shard size); point_off[s] = global index of source s's first point then turns the leader's
+    // index into the voxel's global first point.  NULL: the records carry global indices already.
+    const int32_t *recv = nullptr;
+    const int64_t *src_off = nullptr;    // [world + 1] records of source s = [src_off[s], src_off[s + 1])  (the workspace's copy)
+    const int64_t *point_off = nullptr;  // [world]
+    int world = 0;
 };
+
+__device__ __forceinline__ int64_t leader_first(const MergeOut &f, int64_t i)
+{
+    const int64_t local = *reinterpret_cast<const int64_t *>(f.recv + (size_t)i * f.RS + 2);
+    return f.point_off ? local + f.point_off[record_source(f.src_off, f.world, i)] : local;
+}
 
 // leader record i -> owned voxel o: the cell's records merged in rank order, the voxel's finished row written
 template <class Each>
@@ -414,7 +432,7 @@ __device__ __forceinline__ void merge_leader(const MergeOut &f, const int32_t *_
             const float x = __int_as_float(r[5 + q]);
             a[q] = is_sum ? ident + x : (reduction == D3D_REDUCE_MAX ? (ident < x ? x : ident) : (x < ident ? x : ident));
         }
-        f.first_o[o] = *reinterpret_cast<const int64_t *>(r + 2);
+        f.first_o[o] = leader_first(f, i);
         f.npoints[o] = cnt;
         f.coords[o * 3 + 0] = key / (f.sy * f.sz);
         f.coords[o * 3 + 1] = (key / f.sz) % f.sy;
@@ -426,14 +444,11 @@ __device__ __forceinline__ void merge_leader(const MergeOut &f, const int32_t *_
     float a0 = ident, a1 = ident, a2 = ident, a3 = ident;      // c == 4 in registers; other widths through feats[]
     if (c != 4)
         for (int q = 0; q < c; q++) f.feats[o * c + q] = ident;
-    int64_t first = INT64_MAX;
     int32_t cnt = 0;
     int64_t key = 0;
     each_record([&](uint32_t ri) {                             // rank order: the same sums on every run
         const int32_t *r = recv + (size_t)ri * RS;
         key = *reinterpret_cast<const int64_t *>(r);
-        const int64_t f0 = *reinterpret_cast<const int64_t *>(r + 2);
-        first = f0 < first ? f0 : first;
         cnt += r[4];
         if (c == 4) {
             const float x0 = __int_as_float(r[5]), x1 = __int_as_float(r[6]), x2 = __int_as_float(r[7]), x3 = __int_as_float(r[8]);
@@ -447,7 +462,7 @@ __device__ __forceinline__ void merge_leader(const MergeOut &f, const int32_t *_
             }
         }
     });
-    f.first_o[o] = first;
+    f.first_o[o] = leader_first(f, i);
     f.npoints[o] = cnt;
     f.coords[o * 3 + 0] = key / (f.sy * f.sz);
     f.coords[o * 3 + 1] = (key / f.sz) % f.sy;
@@ -556,7 +571,7 @@ struct Acc4 {
     __device__ __forceinline__ void store(const MergeOut &f, int64_t key, int64_t o, int64_t i) const
     {
         f.lead_rec[o] = (int32_t)i;
-        f.first_o[o] = first;
+        f.first_o[o] = leader_first(f, i);
         f.npoints[o] = cnt;
         f.coords[o * 3 + 0] = key / (f.sy * f.sz);
         f.coords[o * 3 + 1] = (key / f.sz) % f.sy;
@@ -1436,7 +1451,7 @@ extern "C" size_t d3d_owner_merge_workspace_bytes(int64_t R, int32_t world)
 extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *src_off, int32_t world, int32_t c, int32_t reduction,
                                const int32_t *shape, int64_t *first_o, int64_t *coords, int32_t *npoints, float *feats,
                                int32_t *rec_owned, int32_t *lead_rec, int64_t *counts, void *workspace, size_t workspace_bytes,
-                               void *stream, uint32_t flags)
+                               void *stream, uint32_t flags, const int64_t *point_off)
 {
     hipStream_t st = (hipStream_t)stream;
     if (R < 0 || c < 1 || c > 16 || world < 1 || world > kMaxWorld || !counts || !src_off || !shape) return D3D_ERR_BAD_ARG;
@@ -1446,8 +1461,12 @@ extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *sr
     if (R > 0 && (!recv || !first_o || !coords || !npoints || !feats || !rec_owned || !lead_rec)) return D3D_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < d3d_owner_merge_workspace_bytes(R, world)) return D3D_ERR_WORKSPACE;
     MergeOut f{rec_stride(c), (int)c, (int)reduction, (int64_t)shape[1], (int64_t)shape[2], first_o, coords, npoints, feats, lead_rec};
+    f.recv = recv;
+    f.point_off = point_off;
+    f.world = (int)world;
     if (!merge_on_chains(R, flags)) {
         RecWs m = carve_rec(workspace, workspace_bytes, R, world);
+        f.src_off = m.src_off;
         if (R == 0) {
             D3D_HIP_CHECK(hipMemsetAsync(counts, 0, D3D_NUM_COUNTS * sizeof(int64_t), st));
             return D3D_OK;
@@ -1465,6 +1484,7 @@ extern "C" int d3d_owner_merge(const int32_t *recv, int64_t R, const int64_t *sr
         return D3D_OK;
     }
     MergeWs m = carve_merge(workspace, workspace_bytes, R, world);
+    f.src_off = m.src_off;
     D3D_LAUNCH("k_merge_init", k_merge_init, dim3(blocks_for((int64_t)m.cap, 256 * 4)), dim3(256), 0, st, m.slot, m.cap, m.status,
                m.ntiles + 1, counts, src_off, (int)world, m.src_off);
     if (R > 0) {

@@ -1074,9 +1074,17 @@ constexpr uint32_t kXcdBucketsMin = 2048;     // k_bucket_index: XCD-aware bucke
 //                     kInf                        not a first point.
 // One dependent random gather less per multi-point voxel in k_emit, no record stores in the index, and the points kept
 // (min(count, max_points)) are known to k_emit as soon as its first load returns.  Positions stay below 2^24 - 1 (host-checked).
+// experiment knobs of the diagnostic build (make TUNE=1 -> libd3d_hip_tune.so; tools/tune_ab.py): the product build compiles the defaults in
+#ifdef D3D_TUNE
+int g_d3d_tune[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+#define D3D_TUNE_VAL(K, DEF) (g_d3d_tune[K] >= 0 ? g_d3d_tune[K] : (DEF))
+#else
+#define D3D_TUNE_VAL(K, DEF) (DEF)
+#endif
 constexpr uint32_t kFmShift = 24, kFmMask = 0xffffffu, kFmRecord = 255u;
 constexpr int64_t kFmMaxPoints = (1 << 24) - 2;
-constexpr uint32_t kDenseMin = 64;            // V2: cells with more points are ranked by ONE wavefront (select + all-pairs on the kept ones)
+constexpr uint32_t kDenseMin = 32;            // V2: cells with more points are ranked by ONE wavefront (select + all-pairs on the kept ones);
+                                              // 16 .. 48: the same within noise, 64: +2.5 us, 128: +4 us at config 2 (profiles/r05_b_tune.txt)
 
 // reduce contract (d3d_voxelize_3d_reduce) on the binned path
 struct BinnedExtras {
@@ -1094,6 +1102,7 @@ struct BinnedExtras {
     int64_t aux_value = 0;           // what k_emit leaves in counts[D3D_COUNT_AUX] (d3d_voxelize_3d_reduce: 1 = ranked index lists)
     uint16_t *row_state = nullptr;   // d3d_voxelize_3d_dense_resident: [capacity] rows of voxels[v] that may be non-zero (k_emit<.., true>)
     bool fm_packed = false;          // firstmap entries are {count : 8 | segment : 24} words (k_bucket_index<.., V2>), see kFmShift
+    bool early_zero = false;         // k_emit: the all-zero lines of the stretch are stored as soon as the entries are known
 };
 
 // sparse contract fused with the voxel filter (d3d_voxelize_3d_sparse_filter): only voxels that pass get a first-point
@@ -1321,7 +1330,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
     typedef typename Key::bin_key_t KT;
     typedef BinEntry<ROWS> E;
     constexpr int kSortTile = kSortThreads * kSortItems;
-    constexpr int kSortTileShift = kSortItems == 16 ? 14 : kSortItems == 8 ? 13 : 12;
+    constexpr int kSortTileShift = kSortItems == 16 ? 14 : kSortItems == 8 ? 13 : kSortItems == 4 ? 12 : 11;
     static_assert(kSortTile == (1 << kSortTileShift) && kFlagTile % kSortTile == 0, "arrays are padded to kFlagTile");
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
     KT *keys = reinterpret_cast<KT *>(tile_lds);                           // [kSortTile] in bucket order
@@ -1529,7 +1538,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                       // by the wavefronts (k_meta_first_lb's first tile tells the host)
                                                       u64 *__restrict__ early_tot = nullptr, uint32_t early_clamp = 0,
                                                       uint32_t early_mask = 0 /* pairs - 1; one pair per 128-byte line */,
-                                                      int idx_bits = 24 /* V2: point indices < 2^idx_bits */)
+                                                      int idx_bits = 24 /* V2: point indices < 2^idx_bits */,
+                                                      uint32_t dense_min = kDenseMin)
 {
     static_assert(!V2 || (ROWS && LISTS && !STAGE), "V2: the index for k_emit (dense contract on C == 4 rows)");
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
@@ -1933,7 +1943,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                 const uint32_t sl = threadIdx.x + k * kBucketThreads;
                 const uint32_t base = row_c + (uint32_t)((ex_c >> (16 * k)) & 0xffffu);
                 tcnt[sl] = c[k] | (base << 16);
-                if (c[k] > kDenseMin || (reduction != D3D_REDUCE_NONE && c[k] > P)) oslot[atomicAdd(&nover, 1u)] = (uint16_t)sl;
+                if (c[k] > dense_min || (reduction != D3D_REDUCE_NONE && c[k] > P)) oslot[atomicAdd(&nover, 1u)] = (uint16_t)sl;
                 row_c += (uint32_t)((tot_c >> (16 * k)) & 0xffffu);
             }
         }
@@ -1954,6 +1964,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                 vrec[bb + base] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), bb + base, cnt);
                 w = (kFmRecord << kFmShift) | (bb + base);
             }
+            // (a plain store -- inline assembly, so nothing can be merged -- left the kernel unchanged at 1 M points and made
+            // it 5 % faster at 8 M, but k_emit behind it 5 % SLOWER at 4 M points: profiles/r05_b_tune.txt.  Not taken.)
             __hip_atomic_store(&firstmap[f], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         v4f over_pre = {0.f, 0.f, 0.f, 0.f};
@@ -1963,7 +1975,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             const uint32_t q = threadIdx.x + r * kBucketThreads;
             if (q < m) {
                 const uint32_t s = slot[r], cb = tcnt[s], cnt = cb & 0xffffu, base = cb >> 16, me = idx[r];
-                if (cnt <= kDenseMin) {
+                if (cnt <= dense_min) {
                     uint32_t rank = 0, k = 0;
                     const uint32_t *sg = seg + base;
                     for (; k + 8 <= cnt && rank < P; k += 8)          // 8 independent LDS reads per exit test
@@ -1985,7 +1997,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             uint32_t *hist = whist[V2 ? wv : 0];
             for (uint32_t o = wv; o < no; o += kBucketThreads / kWave) {
                 const uint32_t s = oslot[o], cb = tcnt[s], cnt = cb & 0xffffu, base = cb >> 16;
-                if (cnt <= kDenseMin) continue;                     // (listed for its reduction only)
+                if (cnt <= dense_min) continue;                     // (listed for its reduction only)
                 uint32_t *sg = seg + base;
                 const uint32_t want = cnt < P ? cnt : P, K = (cnt + kWave - 1) / kWave;
                 // the `want` smallest indices: radix-64 select, six bits a round -- bins [lo + b << shift, lo + (b + 1) << shift)
@@ -2402,14 +2414,14 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     __shared__ vec4 rowbuf_all[256 / kWave][kEmitCap];
     __shared__ uint32_t off_all[256 / kWave][kWave], base_all[256 / kWave][kWave], first_all[256 / kWave][kWave];
     __shared__ uint16_t kept_all[256 / kWave][kWave];
-    __shared__ uint16_t lim_all[RESIDENT ? 256 / kWave : 1][kWave];
+    __shared__ uint16_t lim_all[256 / kWave][kWave];
     __shared__ uint32_t loff_all[RESIDENT ? 256 / kWave : 1][kWave + 1];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     vec4 *rowbuf = rowbuf_all[w];
     uint32_t *sh_off = off_all[w], *sh_base = base_all[w], *sh_first = first_all[w];
     uint16_t *sh_kept = kept_all[w];
-    uint16_t *sh_lim = lim_all[RESIDENT ? w : 0];
+    uint16_t *sh_lim = lim_all[w];
     uint32_t *sh_loff = loff_all[RESIDENT ? w : 0];
     D3D_PHASE_DECL;
     const uint32_t tile = (uint32_t)(i / kFlagTile), ntile = (uint32_t)(npad / kFlagTile);
@@ -2461,6 +2473,36 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
             rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), x.fm_packed ? (el & kFmMask) : 0u, x.fm_packed ? (el >> kFmShift) : 1u);
         }
     }
+    // (round 5) With packed entries the rows a voxel keeps are known NOW, before its record / first row / ranked rows have
+    // arrived: the 128-byte lines of the stretch that hold no row at all -- three of four at config 2 -- are stored while
+    // those loads are in flight; the lines with rows follow below.  Whole lines only (P * 16 and the tensor 128-byte
+    // aligned), every line stored exactly once.
+    bool early = false;
+    vec4 *out = reinterpret_cast<vec4 *>(voxels) + (int64_t)vid0 * P;
+    const vec4 zero = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!RESIDENT) {
+        if (x.early_zero && voxels && (P & 7u) == 0 && (reinterpret_cast<uintptr_t>(voxels) & 127) == 0) {
+            const uint32_t c8 = el >> kFmShift;
+            const bool unsure = mine && c8 == kFmRecord && P >= kFmRecord;      // (the count itself is in the record)
+            if (!__ballot(unsure)) {
+                early = true;
+                const uint32_t kept_e = mine ? (c8 < P ? c8 : P) : 0u;
+                sh_lim[lane] = (uint16_t)((kept_e + 7u) & ~7u);
+                wave_lds_fence();
+                const uint32_t qa = nv * P;
+                for (uint32_t q0 = 0; q0 < qa; q0 += 4 * kWave) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t q = q0 + u * kWave + lane;
+                        if (q < qa) {
+                            const uint32_t j = pshift >= 0 ? (q >> pshift) : q / P;
+                            if (q - j * P >= sh_lim[j]) __builtin_nontemporal_store(zero, &out[q]);
+                        }
+                    }
+                }
+            }
+        }
+    }
 #ifdef D3D_PHASE_CLOCKS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -2487,8 +2529,6 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
     const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
     float a0, a1, a2, a3;
     a0 = a1 = a2 = a3 = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
-    vec4 *out = reinterpret_cast<vec4 *>(voxels) + (int64_t)vid0 * P;
-    const vec4 zero = {0.f, 0.f, 0.f, 0.f};
     uint32_t ja = 0;
     while (ja < nv) {                                       // wave-uniform: one batch unless the rows exceed the buffer
         const uint32_t oa = (uint32_t)__shfl((int)off, (int)ja, kWave);
@@ -2560,7 +2600,7 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
                     const uint32_t slot = q - j * P;
                     vec4 val = zero;
                     if (slot < sh_kept[j]) val = rowbuf[sh_off[j] - oa + slot];
-                    __builtin_nontemporal_store(val, &out[q]);
+                    if (!early || slot < sh_lim[j]) __builtin_nontemporal_store(val, &out[q]);
                 }
             }
         }
@@ -3595,7 +3635,12 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     // tiles of 8192 points (4096: profiles/r04_bucket_target.txt); large frames of the dense contract on C == 4 rows: 16384 -- half
     // the tiles, so half the table, and k_bucket_index finds a bucket's entries in half as many runs of twice the length
     const bool big_tiles = ROWS && vec4 && sizeof(typename Key::bin_key_t) == 4 && n >= kBigTileMinPoints;
-    const int tshift = big_tiles ? 14 : 13;
+    // tiles of 4096 points while tiles of 8192 would leave a third of the CUs without a workgroup (one workgroup per tile):
+    // 1 M points 16.2 -> 13.7 us with the bucket kernel unchanged; at 2 M points (245 tiles of 8192) +4 us, at 4 M +6; tiles of
+    // 2048 points: +2 us in the bucket kernel (runs of two entries) -- profiles/r05_b_tune.txt
+    const int tune_tile = !big_tiles && vec4 && ROWS ? D3D_TUNE_VAL(2, (w.npad >> 13) <= 160 ? 12 : 0) : 0;
+    const bool small_tiles = tune_tile == 12, tiny_tiles = tune_tile == 11;
+    const int tshift = big_tiles ? 14 : small_tiles ? 12 : tiny_tiles ? 11 : 13;
     const uint32_t stiles = (uint32_t)(w.npad >> tshift);
     uint32_t *table = nullptr, *tileinfo = nullptr, *gpos = reinterpret_cast<uint32_t *>(w.vinfo) + w.npad;
     if (tile_sort && n <= (ROWS ? kTileSortMaxPoints : kTileSortMaxPointsSparse) && nbins <= 8192u && stiles <= (uint32_t)kRunCap &&
@@ -3608,6 +3653,8 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     const bool fm_packed = ROWS && (o.emit_voxels || o.emit_reduce) && !o.index_v1 && !precpos && !o.map_later && !o.trimmed &&
                            !o.pass.on && n <= kFmMaxPoints;
     x.fm_packed = fm_packed;
+    // (early zero lines: -6 us at 1 M points, -7 at 2 M, -3 at 4 M, nothing at 8 M, where the launch is in its steady state)
+    x.early_zero = fm_packed && D3D_TUNE_VAL(4, n < kBigTileMinPoints ? 1 : 0) != 0;
     const bool do_index = o.stage != 2;                        // (stage 2: this frame's index was launched by an earlier call)
     if (do_index && table) {
         const size_t lds = ((size_t)1 << tshift) * (sizeof(typename Key::bin_key_t) + 2) + bin_lds;
@@ -3622,6 +3669,8 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
                    nzero, zero_ticket);                                                                                         \
     } while (0)
         if (big_tiles) D3D_TILE_SORT(true, 16);
+        else if (small_tiles) D3D_TILE_SORT(true, 4);
+        else if (tiny_tiles) D3D_TILE_SORT(true, 2);
         else if (vec4) D3D_TILE_SORT(true, 8);
         else D3D_TILE_SORT(false, 8);
 #undef D3D_TILE_SORT
@@ -3653,7 +3702,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
                        bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
                        counts, (uint32_t *)nullptr, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), (unsigned char *)nullptr, w.big_list,
                        (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, (uint32_t *)nullptr, (u64 *)nullptr, 0u, 0u,
-                       bits_for((u64)(n > 1 ? n - 1 : 1)));
+                       bits_for((u64)(n > 1 ? n - 1 : 1)), (uint32_t)D3D_TUNE_VAL(0, (int)kDenseMin));
     } else if (ROWS && (o.emit_voxels || o.emit_reduce))
         D3D_LAUNCH("k_bucket_index", (k_bucket_index<Key, ROWS, true, false>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, o.pass,
                    bent, p4, bucket_base, hshift, o.P, o.agg4 ? o.reduction : (int)D3D_REDUCE_NONE, w.staged, vrec, firstmap,
@@ -4357,6 +4406,9 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
     return rc;
 }
 
+#ifdef D3D_TUNE
+extern "C" void d3d_debug_set_tune(int k, int v) { if (k >= 0 && k < 16) g_d3d_tune[k] = v; }
+#endif
 #ifdef D3D_PHASE_CLOCKS
 // diagnostic build: read (and clear) the phase clocks -- out[4][16] u64 host array
 extern "C" int d3d_debug_phase_clocks(unsigned long long *out)

@@ -299,10 +299,10 @@ class HipOps:
         return coords, cnt, feats, vid
 
     # ---- owner-computes exchange (owner.hip) ----
-    def owner_pack(self, keys, cnt, agg, first, counts, n, c, world, max_points=0, seg=None, rows=None):
+    def owner_pack(self, keys, cnt, agg, first, counts, n, c, world, max_points=0, seg=None, rows=None, points_in_shard=None):
         """local voxels -> records grouped by owner rank: send[n, words] int32, perm[n] (send position -> local voxel),
         pos_of_local[n] (its inverse), send_rows[n, 4] | None (dense contract: the voxels' ranked rows, same grouping),
-        send_counts[2 world + 1] (device: records per destination, status bits, rows per destination)"""
+        send_counts[2 world + 2] (device: records per destination, status bits, rows per destination, points_in_shard)"""
         lib = _lib.load()
         dev = keys.device
         words = lib.d3d_owner_record_words(c)
@@ -311,7 +311,10 @@ class HipOps:
             perm = torch.empty((n,), dtype=torch.int32, device=dev)
             pos = torch.empty((n,), dtype=torch.int32, device=dev)
             send_rows = torch.empty((max(n, 1), 4), dtype=torch.float32, device=dev) if max_points else None
-            sc = torch.empty((2 * world + 1,), dtype=torch.int64, device=dev)
+            # (one word more than the C entry point fills: the shard's point count, which travels with the record counts so
+            # that no separate size exchange is needed -- ShardedVoxelGenerator._run_owner)
+            sc = torch.empty((2 * world + 2,), dtype=torch.int64, device=dev)
+            sc[2 * world + 1:].fill_(int(points_in_shard) if points_in_shard is not None else -1)
             ws = torch.empty((lib.d3d_owner_pack_workspace_bytes(n, world),), dtype=torch.uint8, device=dev)
             src = rows if isinstance(rows, _RowSource) else _RowSource(rows, None, 0)
             rc = lib.d3d_owner_pack(_lib.ptr(keys), _lib.ptr(cnt), _lib.ptr(agg), _lib.ptr(first), _lib.ptr(counts), n, c, world,
@@ -321,11 +324,12 @@ class HipOps:
             _lib.check(rc, "owner_pack")
         return send, perm, pos, send_rows, sc
 
-    def owner_merge(self, recv, recv_counts, world, c, reduction, shape, flags=0):
+    def owner_merge(self, recv, recv_counts, world, c, reduction, shape, flags=0, point_off=None):
         """records grouped by source rank -> this owner's voxels in global id order, finished:
         first_o, coords, npoints, feats (R rows allocated), rec_owned[R], counts (device; [0] = owned voxels, [2] = status:
         BIN_OVERFLOW asks for flags=OWNER_MERGE_CHAINS), and a handle (leader records + the cells' record lists) for
-        owner_dense"""
+        owner_dense.  point_off (list of world ints, or None): the records carry point indices LOCAL to their source rank's shard;
+        point_off[s] = global index of rank s's first point (added to the leader's index: first_o is global either way)"""
         lib = _lib.load()
         dev = recv.device
         R = int(recv.shape[0])
@@ -334,7 +338,10 @@ class HipOps:
             off.append(off[-1] + int(k))
         shape_h = (ctypes.c_int32 * 3)(*[int(x) for x in shape])
         with torch.cuda.device(dev):
-            src_off = torch.tensor(off, dtype=torch.int64, device=dev)
+            # record offsets and (optionally) point offsets of the sources: ONE small host -> device copy
+            both = torch.tensor(off + ([int(x) for x in point_off] if point_off is not None else []), dtype=torch.int64, device=dev)
+            src_off = both[:world + 1]
+            poff = both[world + 1:] if point_off is not None else None
             first_o = torch.empty((R,), dtype=torch.int64, device=dev)
             coords = torch.empty((R, 3), dtype=torch.int64, device=dev)
             npoints = torch.empty((R,), dtype=torch.int32, device=dev)
@@ -346,7 +353,7 @@ class HipOps:
             rc = lib.d3d_owner_merge(_lib.ptr(recv), R, _lib.ptr(src_off), world, c, int(reduction),
                                      ctypes.cast(shape_h, ctypes.c_void_p), _lib.ptr(first_o), _lib.ptr(coords), _lib.ptr(npoints),
                                      _lib.ptr(feats), _lib.ptr(rec_owned), _lib.ptr(lead), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
-                                     _lib.stream_ptr(), int(flags))
+                                     _lib.stream_ptr(), int(flags), _lib.ptr(poff))
             _lib.check(rc, "owner_merge")
         return first_o, coords, npoints, feats, rec_owned, counts, (recv, lead, npoints, counts, ws, world, int(flags))
 
@@ -550,24 +557,33 @@ class ShardedVoxelGenerator:
         raise RuntimeError("sharded voxelization failed")
 
     def _run_owner(self, points, plain):
-        """owner-computes exchange (module docstring of owner.hip).  Host synchronisations: the 8-byte size all-gather, the
-        world x (world + 1) record-count matrix, and the voxel counts at the end."""
+        """owner-computes exchange (module docstring).  FOUR collectives (five with the dense contract's rows) and TWO host
+        synchronisations per call: the count matrix -- which since round 5 also carries every shard's point count, so the local
+        pass runs on shard-local point indices and nobody waits for a size exchange first -- and the output sizes at the end."""
         comm, ops = self._comm, self._ops
         dev = points.device
         n, c = points.shape
         W = comm.world
-        offset, n_total, _ = self._layout(n, dev)
         mean = self._red == 1
         kw = {"plain": True} if plain else {}
         P = self._max_points
         if P and c != 4:
             raise ValueError("the sharded dense contract needs points[n, 4]")
-        out = ops.voxelize_reduce(points, self._shape, self._bounds, _SUM if mean else self._red, offset, want_coords=False,
-                                  max_points=P, **kw)
+        out = ops.voxelize_reduce(points, self._shape, self._bounds, _SUM if mean else self._red, 0, want_coords=False,
+                                  max_points=P, **kw)                  # (first points as indices into THIS shard)
         _, cnt_r, agg_r, first_r, map_r, keys_r, counts_r = out[:7]
         seg_r, rows_r = out[7:] if P else (None, None)
-        send, perm, pos_r, send_rows, sc_dev = ops.owner_pack(keys_r, cnt_r, agg_r, first_r, counts_r, n, c, W, P, seg_r, rows_r)
-        mat = comm.exchange_counts(sc_dev)                      # [src][dst] records, [src][W] status bits, [src][W+1+dst] rows
+        send, perm, pos_r, send_rows, sc_dev = ops.owner_pack(keys_r, cnt_r, agg_r, first_r, counts_r, n, c, W, P, seg_r, rows_r,
+                                                              points_in_shard=n)
+        # [src][dst] records, [src][W] status bits, [src][W+1+dst] rows, [src][2W+1] points of the shard -- host sync 1 of 2
+        mat = comm.exchange_counts(sc_dev)
+        shard = [int(row[2 * W + 1]) for row in mat]
+        if min(shard) < 0:
+            raise RuntimeError("owner_pack of some rank did not report its shard size (an `ops` of the round-4 protocol?)")
+        point_off = [0] * W
+        for r in range(1, W):
+            point_off[r] = point_off[r - 1] + shard[r - 1]
+        n_total = point_off[-1] + shard[-1]
         status = 0
         for row in mat:
             status |= int(row[W])
@@ -579,7 +595,8 @@ class ShardedVoxelGenerator:
         rc = [int(mat[s][comm.rank]) for s in range(W)]
         recv = comm.all_to_all(send[:sum(sc)], sc, rc)
         first_o, coords, npoints, feats, rec_owned, counts_o, handle = ops.owner_merge(
-            recv, rc, W, c, self._red, self._shape, flags=self._merge_flags | (_lib.OWNER_MERGE_CHAINS if plain else 0))
+            recv, rc, W, c, self._red, self._shape, flags=self._merge_flags | (_lib.OWNER_MERGE_CHAINS if plain else 0),
+            point_off=point_off)
         voxels = pmask = None
         if P:
             rsc = [int(x) for x in mat[comm.rank][W + 1:2 * W + 1]]
@@ -599,7 +616,7 @@ class ShardedVoxelGenerator:
         vids, counts_out = ops.owner_number(gbits, n_total, first_o, counts_o)
         back = comm.all_to_all(ops.owner_reply(rec_owned, vids), rc, sc)
         gmap = ops.owner_map(map_r, pos_r, back)
-        host = torch.stack([counts_out, counts_o]).tolist()     # the host read-back of the output sizes
+        host = torch.stack([counts_out, counts_o]).tolist()     # the output sizes -- host sync 2 of 2
         if int(host[0][_lib.COUNT_STATUS]) & _lib.STATUS_BIN_OVERFLOW and not plain:
             return None        # some owner's merge outgrew a bucket (every rank reads the same word): all redo on the general path
         nvox, nown = int(host[0][_lib.COUNT_VOXELS]), int(host[1][_lib.COUNT_VOXELS])
@@ -610,6 +627,11 @@ class ShardedVoxelGenerator:
             reply_bytes_sent=(sum(rc) - rc[comm.rank]) * 8, all_reduce_bytes=int(gbits.numel()) * 8,
             all_gather_bytes_per_rank=nown * (8 + 24 + 4 + 4 * c) if self._replicate else 0)
         vids, coords, npoints, feats = vids[:nown], coords[:nown], npoints[:nown], feats[:nown]
+        if self._debug_checks:
+            # the status word behind the bitmap is a SUM over the ranks of 0 / 1 flags: anything else means the comm's
+            # all_reduce is not an int64 SUM (the lock-step redo rests on every rank reading the same word)
+            if int(gbits.numel()) == (max(n_total, 1) + 63) // 64 + 1:       # (HipOps: one status word behind the bitmap)
+                assert 0 <= int(gbits[-1]) <= W, "all_reduce('sum') of the first-point bitmap did not add the ranks' status words"
         if self._debug_checks and nown > 1:
             fo = first_o[:nown]
             assert bool((fo[1:] > fo[:-1]).all()), "owned voxels are not ordered by their first point"

@@ -332,7 +332,10 @@ enum { D3D_OWNER_MERGE_CHAINS = 1, D3D_OWNER_MERGE_TEST_TINY = 2 };
 int d3d_owner_merge(const int32_t *recv, int64_t n_records, const int64_t *src_off, int32_t world, int32_t c, int32_t reduction,
                     const int32_t *shape, int64_t *first_o, int64_t *coords, int32_t *npoints, float *feats,
                     int32_t *rec_owned, int32_t *lead_rec, int64_t *counts, void *workspace, size_t workspace_bytes, void *stream,
-                    uint32_t flags);
+                    uint32_t flags, const int64_t *point_off);
+/* point_off (device, [world]; may be NULL): when the ranks ran d3d_voxelize_3d_reduce with index_offset 0 -- no rank needs the
+ * others' shard sizes before its local pass -- the records carry indices local to their source's shard, and point_off[s] =
+ * global index of rank s's first point turns the leader's into the voxel's global first point (first_o).  NULL: global already. */
 /* dense contract on the owner (voxelize.cpp:128-134: the first max_points points of a voxel by global index = the ranks'
  * candidate rows in rank order): after d3d_owner_merge, with ITS workspace untouched since and ITS flags; recv_rows[*, 4] grouped by source
  * rank (rows_src_off[world + 1], device); lead_rec / npoints / counts_o from d3d_owner_merge.

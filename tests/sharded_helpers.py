@@ -186,7 +186,7 @@ class NumpyOps:
             h ^= h >> np.uint64(33)
         return (((h >> np.uint64(32)) * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
 
-    def owner_pack(self, keys, cnt, agg, first, counts, n, c, world, max_points=0, seg=None, rows=None):
+    def owner_pack(self, keys, cnt, agg, first, counts, n, c, world, max_points=0, seg=None, rows=None, points_in_shard=None):
         v = int(counts[0])
         k = keys.numpy()[:v]
         words = (5 + c + 1) & ~1
@@ -198,7 +198,8 @@ class NumpyOps:
         rec[:, 2:4] = first.numpy()[:v][perm].reshape(-1, 1).view(np.int32)
         rec[:, 4] = cnt.numpy()[:v][perm]
         rec[:, 5:5 + c] = agg.numpy()[:v][perm].view(np.int32)
-        sc = np.zeros((2 * world + 1,), np.int64)
+        sc = np.zeros((2 * world + 2,), np.int64)
+        sc[2 * world + 1] = -1 if points_in_shard is None else int(points_in_shard)
         sc[:world] = np.bincount(own, minlength=world)
         sc[world] = -1 - int(keys.numpy()[n])
         full_perm = np.zeros((n,), np.int32)
@@ -224,11 +225,13 @@ class NumpyOps:
             send_rows = torch.from_numpy(send_rows)
         return torch.from_numpy(send), torch.from_numpy(full_perm), torch.from_numpy(pos), send_rows, torch.from_numpy(sc)
 
-    def owner_merge(self, recv, recv_counts, world, c, reduction, shape, flags=0):
+    def owner_merge(self, recv, recv_counts, world, c, reduction, shape, flags=0, point_off=None):
         r = recv.numpy()
         R = len(r)
         keys = np.ascontiguousarray(r[:, 0:2]).view(np.int64).reshape(-1)
         first = np.ascontiguousarray(r[:, 2:4]).view(np.int64).reshape(-1)
+        if point_off is not None:                                 # local indices + the source rank's first point = global
+            first = first + np.repeat(np.asarray(point_off, np.int64), [int(k) for k in recv_counts])
         cnt = r[:, 4].copy()
         agg = np.ascontiguousarray(r[:, 5:5 + c]).view(np.float32)
         red = int(reduction)

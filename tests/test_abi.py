@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, n), "libd3d_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "d3d_amd/_lib.py does not bind %s" % n
     assert set(_lib.SIGNATURES) <= set(names)
-    assert _lib.load().d3d_abi_version() == 10
+    assert _lib.load().d3d_abi_version() == 11
     assert _lib.load().d3d_status_string(-2) == b"unsupported option"
 
 
@@ -130,4 +130,9 @@ def test_bucket_kernel_keeps_its_first_point_store_separate(tmp_path):
             cur = m.group(1)
         elif cur and "k_bucket_index" in cur and re.search(r"global_store_dword\b.*\bsc1\b", line):
             scoped[cur] = scoped.get(cur, 0) + 1
-    assert len(scoped) == 6 and set(scoped.values()) == {8}, scoped
+    # round 5's instantiation (V2, the last template argument): its register path stores a voxel's entry from the point of rank 0
+    # -- one store per item of a lane (4) + one in the crowded cells' wavefront loop -- next to the big-bucket copy (4)
+    v2 = {k: v for k, v in scoped.items() if "Lb1EEE" in k.split("vT_")[0]}
+    v1 = {k: v for k, v in scoped.items() if k not in v2}
+    assert len(v1) == 6 and set(v1.values()) == {8}, scoped
+    assert len(v2) == 1 and set(v2.values()) == {9}, scoped

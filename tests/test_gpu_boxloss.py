@@ -293,8 +293,8 @@ def test_score_match_reference_compat_reproduces_the_row_mixup():
         d9, g9 = _labelled(pred, 2), _labelled(gt, 2, scores=False)
         thr2 = {1: 0.95, 2: 0.9}                                # loose: several acceptable ground truths per detection
         cc = prepare_boxes(d9, g9, DistanceTypes.RIoU)
-        src = [i for i in range(len(d9)) if d9[i, 1] >= 0.2]
-        dst = list(range(len(g9)))
+        src = [i for i in range(len(d9)) if d9[i, 1] >= 0.2 and int(d9[i, 0]) in thr2]      # (the evaluator's subsets: known classes)
+        dst = [j for j in range(len(g9)) if int(g9[j, 0]) in thr2]
         ls, ld = oracle.score_match(cc.cpu().numpy(), d9, g9, src, dst, thr2, literal=True)
         cs, cd = score_match_reference_compat(cc, d9[:, 1], d9[:, 0], g9[:, 0], thr2, src, dst)
         assert {i: int(j) for i, j in enumerate(cs.cpu().numpy()) if j >= 0} == ls
