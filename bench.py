@@ -124,10 +124,17 @@ def stream_probe(nbytes, iters=5):
     return out
 
 
-def emit_bytes(npad, V, P, kept):
-    """compulsory bytes of one k_emit launch: firstmap read, one record per voxel, the kept rows from the point
-    tensor, and EVERY output of the dense contract written: voxels[V,P,4], coords, npoints, pmask, aggregates"""
-    return npad * 4 + V * 16 + kept * 16 + V * (P * 16 + 24 + 4 + P + 16)
+def emit_bytes(n, V, P):
+    """ALGORITHMIC bytes of the dense contract per SURVEY 8(d) -- compulsory operator I/O only, no scratch: the point tensor
+    read once (n x 16 B) and every output written (voxels[V,P,4], voxel_pmask, coords, voxel_npoints, aggregates).  k_emit is
+    the launch that moves them (it reads the rows it stores straight from the point tensor)."""
+    return n * 16 + V * (P * 16 + P + 24 + 4 + 16)
+
+
+def emit_scratch_bytes(npad, V, kept, multi_rows):
+    """what k_emit reads on top of that from the index's scratch: one 4-byte first-point entry per point index (numbering +
+    count + segment of the voxel, round 5) and one 4-byte ranked index per kept row that is not a voxel's first point"""
+    return npad * 4 + multi_rows * 4
 
 
 def large_frame_leg(steps=5):
@@ -150,7 +157,7 @@ def large_frame_leg(steps=5):
     torch.cuda.empty_cache()
     npad = -(-n // 16384) * 16384
     kern = "k_emit" if "k_emit" in prof else "k_fill_c4"
-    b_alg = emit_bytes(npad, V, P, kept) if kern == "k_emit" else V * P * 16 + kept * 16 + V * 16
+    b_alg = emit_bytes(n, V, P) if kern == "k_emit" else V * P * 16 + kept * 16 + V * 16
     us = prof[kern]["avg_us"]
     ach = b_alg / (us * 1e-6) / 1e9
     probe = stream_probe(3 << 30)
@@ -163,6 +170,7 @@ def large_frame_leg(steps=5):
                 frac_of_measured_chunked_store=round(ach / probe["store_nt_chunked"], 4),
                 # the fill moves reads as well as writes: against the best streaming rate of either kind measured on this box
                 frac_of_measured_best=round(ach / max(probe.values()), 4), avg_us=round(us, 2), algorithmic_bytes=b_alg,
+                scratch_bytes=emit_scratch_bytes(npad, V, kept, kept - V) if kern == "k_emit" else None,
                 traffic=traffic, traffic_source=src, op_ms=round(1e3 * dt / steps, 3),
                 op_mpoints_per_s=round(n * steps / dt / 1e6, 1),
                 kernels_us={k: round(v["avg_us"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])})
@@ -556,7 +564,7 @@ def main():
             "k_bin_scatter": n * (16 + 4) + n * (16 + 4),           # rows + bucket words read; rows + indices written
             "k_bucket_index": n * (16 + 4) + kept * 16 + V * (16 + 4),   # bucket read; ranked rows, records, firstmap written
             "k_meta_first": npad * 4 + V * 16 + kept * 16 + V * (16 + 24 + 4 + P + 16),
-            "k_emit": emit_bytes(npad, V, P, kept),
+            "k_emit": emit_bytes(n, V, P),                          # 16 B/point in + every output (no scratch)
             # hash-table index (other inputs)
             "k_insert": n * 16 + n * 8 + n * 8,          # points read, pslot+arrival written, one 8-byte slot touched
             "k_scatter": n * 8 + n * 8 + n * 4 + n * 8,  # pslot+arrival read, aux read, index written, (cnt,base) written
@@ -571,7 +579,20 @@ def main():
                                traffic_source=load_traffic(name, "config2")[1], avg_us=round(dom[1]["avg_us"], 2), algorithmic_bytes=b_alg,
                                timing="HIP events on the launch stream, separate pass of the same %d steps" % args.steps,
                                cache_note="config 2's 345 MB of outputs partly drain through the 256 MB Infinity Cache: this fraction "
-                                          "is cache-assisted; the HBM claim is roofline_large.frac (same kernel, 3.3 GB of outputs)")
+                                          "is cache-assisted; the HBM claim is roofline_large.frac (same kernel, 3.3 GB of outputs)",
+                               bytes_note="algorithmic_bytes = SURVEY 8(d): 16 B/point read + every output of the dense contract "
+                                          "written; scratch_bytes (index entries the launch also reads) are not part of it")
+        if name == "k_emit":
+            # what the launch reads from the index's scratch on top of the 8(d) bytes, and the stream probes at THIS launch's
+            # footprint (the outputs' 345 MB, partly absorbed by the 256 MB Infinity Cache exactly as the kernel's are): the
+            # store forms with the work stripped off, on the same box in the same process
+            out["roofline"]["scratch_bytes"] = emit_scratch_bytes(npad, V, kept, kept - V)
+            pr = stream_probe(V * (P * 16 + P + 24 + 4 + 16))
+            out["roofline"].update(peak_measured=pr, frac_of_measured_store=round(ach / pr["store_nt"], 4),
+                                   frac_of_measured_chunked_store=round(ach / pr["store_nt_chunked"], 4),
+                                   frac_of_measured_best=round(ach / max(pr.values()), 4),
+                                   probe_note="probes on a buffer of the outputs' size (V x 588 B): floors of what the box stores in "
+                                              "that form, not ceilings")
         if name in ("k_bin_scatter", "k_bucket_index"):
             # limited by scattered 4..16-byte stores, not bytes: measured ceiling ~80 G/s (profiles/r01_g_atomic_bench.txt)
             req = 2 * n if name == "k_bin_scatter" else kept + V
@@ -602,12 +623,16 @@ def main():
         frame = synth.lidar_like(world * n, 3, synth.WAYMO_BOUNDS)
         cloud_h = np.ascontiguousarray(frame[rank * n:(rank + 1) * n])
         cloud = torch.from_numpy(cloud_h).cuda()
-        # strong-scaling base: the SAME operator on the WHOLE world x n frame on one GPU (a world of one: no collectives)
-        whole = None
+        # strong-scaling bases on ONE GPU, whole world x n frame: (a) the same CONTRACT without an exchange -- what one would
+        # actually run on one GPU: sharded.voxelize_reduce (local index + feature grid, nothing packed / merged / replied) --
+        # and (b) the same OPERATOR with a world of one (the full pack / merge / number / reply machinery on one rank)
+        whole = best = None
         if rank == 0:
-            solo = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction="mean", comm=LocalComm(), replicate=False)
+            from d3d_amd.voxel.sharded import voxelize_reduce
             fr = torch.from_numpy(frame).cuda()
             k = max(args.steps // 4, 3)
+            best = 1e3 * timed(lambda: voxelize_reduce(fr, synth.WAYMO_SHAPE, synth.WAYMO_BOUNDS, "mean"), k, 2) / k
+            solo = ShardedVoxelGenerator(synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, reduction="mean", comm=LocalComm(), replicate=False)
             whole = 1e3 * timed(lambda: solo(fr), k, 2) / k
             del solo, fr
             torch.cuda.empty_cache()
@@ -622,7 +647,14 @@ def main():
         step = lambda: gen(cloud)  # noqa: E731
         out["voxels_global"] = int(step().num_voxels)
         st = dict(gen.last_stats)
-        out["rccl_ranks"] = world
+        # what RCCL itself saw: an all-reduce of ones over the group, and the distinct devices behind the ranks
+        ones = torch.ones((1,), dtype=torch.int64, device="cuda")
+        dist.all_reduce(ones)
+        ids = [None] * world
+        props = torch.cuda.get_device_properties(local_rank)
+        dist.all_gather_object(ids, str(getattr(props, "uuid", "")) or "%s#%d" % (props.name, local_rank))
+        out["rccl_ranks"] = int(ones.item())
+        out["rccl_distinct_devices"] = len(set(ids))
         out["exchange"] = st["exchange"]
         out["numbering"] = st["numbering"]
         out["collectives_per_step"] = dict(
@@ -644,10 +676,15 @@ def main():
                                              mpoints_per_s=round(n / float(t[1].item()) / 1e3, 2),
                                              note="the same operator on one rank's shard without collectives (max over ranks)")
         if whole is not None:
+            out["single_gpu_best"] = dict(
+                ms_per_step=round(best, 4), mpoints_per_s=round(n * world / best / 1e3, 2),
+                note="sharded.voxelize_reduce on the WHOLE %d-point frame on one GPU: the same contract (feature grid + point -> "
+                     "voxel map) with no exchange at all -- the honest single-GPU base of the speed-up" % (n * world))
+            out["speedup_vs_single_gpu_best"] = round(best / (1e3 * dt / args.steps), 3)
             out["single_gpu_whole_frame"] = dict(
                 ms_per_step=round(whole, 4), mpoints_per_s=round(n * world / whole / 1e3, 2),
-                note="the same operator (sharded feature-grid voxelizer, world of one) on the WHOLE %d-point frame on one GPU: "
-                     "speed-up of this run = single_gpu_whole_frame.ms_per_step / ms_per_step" % (n * world))
+                note="the same OPERATOR (pack / merge / number / reply, world of one) on the whole frame on one GPU: an upper "
+                     "bound of what one GPU needs, not what one would run there")
             out["speedup_vs_single_gpu_whole_frame"] = round(whole / (1e3 * dt / args.steps), 3)
         out["replicated_result"] = dict(ms_per_step=round(1e3 * float(t[2].item()), 4),
                                         note="with replicate=True: + all-gather of the owners' finished rows and the scatter into "

@@ -142,6 +142,42 @@ struct SparseKey {
 };
 
 
+// sparse contract FUSED with the voxel filter (d3d_voxelize_3d_sparse_filter, round 5): the filter's coordinate bounds
+// (voxelize.cpp:369-379: lo <= floor(p / size) < hi on every axis) are known before the first point is read, a voxel
+// outside them is dropped whatever else holds, and a point can only belong to the voxel of its own cell -- so a point outside
+// the bounds belongs to no kept voxel and need not be indexed at all.  Inside, the cell linearised over the bounds box is a
+// 32-bit key (host-checked: fewer than 2^32 - 1 cells): the entries, LDS tables and kernels of the DENSE contract's index
+// apply (8-byte entries instead of 16, four workgroups per CU instead of two).  NaN / inf / beyond-int coordinates -- the
+// reference's INT_MIN -- are outside every such box (the host requires lo > INT_MIN).
+struct BoundKey {
+    typedef uint32_t bin_key_t;
+    static __device__ __forceinline__ uint32_t bin_hash(u64 key) { return DenseKey::bin_hash(key); }
+    float size[3];
+    long long lo[3];
+    unsigned ext[3];                                    // hi - lo
+    __device__ __forceinline__ bool make(const float *p, u64 &key, uint32_t &status) const
+    {
+        (void)status;
+        unsigned c[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float q = floorf(p[d] / size[d]);     // voxelize.cpp:309
+            if (!(q >= -2147483648.0f && q < 2147483648.0f)) return false;
+            const long long rel = (long long)(int)q - lo[d];
+            if (rel < 0 || rel >= (long long)ext[d]) return false;
+            c[d] = (unsigned)rel;
+        }
+        key = ((u64)c[0] * ext[1] + c[1]) * ext[2] + c[2];
+        return true;
+    }
+    __device__ __forceinline__ void decode(u64 key, long long *c) const
+    {
+        c[2] = (long long)(key % ext[2]) + lo[2]; key /= ext[2];
+        c[1] = (long long)(key % ext[1]) + lo[1];
+        c[0] = (long long)(key / ext[1]) + lo[0];
+    }
+};
+
 // sparse contract, one-word slots: the same coordinates, linearised inside the bounding box of the frame's voxels
 // (found on the device by k_bbox, so there is no host round trip): key = ((x-x0) * Ry + (y-y0)) * Rz + (z-z0) needs
 // log2(Rx Ry Rz) bits -- 25 for a KITTI frame at 0.1 m -- instead of 63, which leaves room for count and first index
@@ -1325,7 +1361,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
                                                             uint32_t *__restrict__ firstmap, int64_t *counts, int64_t *mapping,
                                                             unsigned char *trimmed, int32_t *keepid,
                                                             u64 *zero_words /* look-back words of a later launch */, uint32_t nzero,
-                                                            unsigned int *zero_ticket)
+                                                            unsigned int *zero_ticket, bool pfirst_self = true /* false: pfirst <- kInf */)
 {
     typedef typename Key::bin_key_t KT;
     typedef BinEntry<ROWS> E;
@@ -1430,7 +1466,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
             lidx[p] = (uint16_t)(r * kSortThreads + threadIdx.x);
             // (preset "the first point of my voxel is myself": true for the 80 % of a LiDAR frame's points that are alone in their
             // voxel -- k_bucket_index then only writes the others, one scattered store per point less for most of them)
-            if (pfirst) pfirst[i] = (uint32_t)i;
+            if (pfirst) pfirst[i] = pfirst_self ? (uint32_t)i : kInf;
         } else if (pfirst && i < n) pfirst[i] = kInf;
     }
     __syncthreads();
@@ -1541,8 +1577,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                                       int idx_bits = 24 /* V2: point indices < 2^idx_bits */,
                                                       uint32_t dense_min = kDenseMin)
 {
-    static_assert(!V2 || (ROWS && LISTS && !STAGE), "V2: the index for k_emit (dense contract on C == 4 rows)");
+    static_assert(!V2 || (ROWS && LISTS && !STAGE), "V2: the index for k_emit (dense contract on C == 4 rows) / k_sparse_finish (8-byte entries)");
     constexpr int ITEMS = kBucketCap / kBucketThreads, T = kBucketSlots;
+    constexpr bool SPV2 = V2 && std::is_same<Key, BoundKey>::value;      // the fused sparse + filter call on packed entries (see V2 below)
     typedef typename Key::bin_key_t KT;
     typedef BinEntry<ROWS> E;
     constexpr KT kFree = (KT)~(KT)0;
@@ -1671,6 +1708,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 early_v++;
                 early_p += cnt < early_clamp ? cnt : early_clamp;
+                if (SPV2) tfirst[sl] = bb + j;    // (big bucket: the points' handle of their voxel is its record)
             } else tfirst[sl] = kInf;             // (its points belong to no kept voxel: what precpos / pfirst_out hand on)
             if (!single) j++;
             if constexpr (ROWS)
@@ -1854,7 +1892,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             if (precpos) precpos[pos] = tfirst[s];
             if (pfirst_out) {
                 const uint32_t pf = (P > 0 && rank >= P) ? kInf : tfirst[s];
-                if (!table || pf != me) pfirst_out[me] = pf;        // (tile-sorted input: k_tile_sort preset pfirst[me] = me)
+                if (SPV2 || !table || pf != me) pfirst_out[me] = pf;        // (tile-sorted input: k_tile_sort preset pfirst[me] = me)
             }
         }
         reduce_overflow(sg, std::true_type{}, (const v4f *)nullptr);
@@ -1868,6 +1906,11 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         // together, no record for a voxel below 255 points (the entry carries count and segment), and the cells with more
         // than kDenseMin points -- whose per-point counting loops kept whole wavefronts waiting for one lane -- ranked by ONE
         // wavefront each: radix-64 select of the max_points smallest indices, all-pairs ranks among those.
+        // SP: the sparse contract fused with its voxel filter on the SAME kernel (BoundKey): no rows, no reductions; every kept
+        // point needs a handle of its voxel (the segment, as in the entry) for the compaction, a voxel below min_points gets no
+        // entry, only cells above max_points need ranks at all (TRIM, voxelize.cpp:457-463) -- so the first index of a cell is
+        // found by an atomicMin again instead of by the rank-0 point.
+        constexpr bool SP = std::is_same<Key, BoundKey>::value;
         KT key[ITEMS];
         uint32_t idx[ITEMS], slot[ITEMS], arr[ITEMS];
         if (table) lds_barrier();                   // the run table is complete
@@ -1917,7 +1960,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             constexpr int r = decltype(R)::value;
             const uint32_t q = threadIdx.x + r * kBucketThreads;
             arr[r] = 0;
-            if (q < m) arr[r] = atomicAdd(&tcnt[slot[r]], 1u);
+            if (q < m) {
+                arr[r] = atomicAdd(&tcnt[slot[r]], 1u);
+                if constexpr (SP) atomicMin(&tfirst[slot[r]], idx[r]);
+            }
         });
         lds_barrier();
         D3D_PHASE(0, 2);
@@ -1943,7 +1989,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                 const uint32_t sl = threadIdx.x + k * kBucketThreads;
                 const uint32_t base = row_c + (uint32_t)((ex_c >> (16 * k)) & 0xffffu);
                 tcnt[sl] = c[k] | (base << 16);
-                if (c[k] > dense_min || (reduction != D3D_REDUCE_NONE && c[k] > P)) oslot[atomicAdd(&nover, 1u)] = (uint16_t)sl;
+                const bool listed = SP ? (P > 0 && c[k] > P && c[k] > dense_min) : (c[k] > dense_min || (reduction != D3D_REDUCE_NONE && c[k] > P));
+                if (listed) oslot[atomicAdd(&nover, 1u)] = (uint16_t)sl;
                 row_c += (uint32_t)((tot_c >> (16 * k)) & 0xffffu);
             }
         }
@@ -1952,7 +1999,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         static_for<ITEMS>([&](auto R) {
             constexpr int r = decltype(R)::value;
             const uint32_t q = threadIdx.x + r * kBucketThreads;
-            if (q < m) seg[(tcnt[slot[r]] >> 16) + arr[r]] = idx[r];
+            if (q < m) {
+                const uint32_t cb = tcnt[slot[r]];
+                if (!SP || (P > 0 && (cb & 0xffffu) > P)) seg[(cb >> 16) + arr[r]] = idx[r];
+            }
         });
         lds_barrier();
         D3D_PHASE(0, 4);
@@ -1968,6 +2018,89 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             // it 5 % faster at 8 M, but k_emit behind it 5 % SLOWER at 4 M points: profiles/r05_b_tune.txt.  Not taken.)
             __hip_atomic_store(&firstmap[f], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
+        // the `want` smallest point indices of a crowded cell's segment: radix-64 select, six bits a round -- bins
+        // [lo + (b << shift), lo + ((b + 1) << shift)); returns tau: the wanted indices are exactly those below it
+        auto select_tau = [&](const uint32_t *sg, uint32_t cnt, uint32_t want, uint32_t *hist) -> uint32_t {
+            const uint32_t lane = threadIdx.x & (kWave - 1), K = (cnt + kWave - 1) / kWave;
+            uint32_t lo = 0, below = 0;
+            int shift = idx_bits > 6 ? idx_bits - 6 : 0;
+            if (cnt <= want) return 0xffffffffu;
+            for (;;) {
+                hist[lane] = 0;
+                wave_lds_fence();
+                for (uint32_t k = 0; k < K; k++) {
+                    const uint32_t t = k * kWave + lane;
+                    if (t < cnt) {
+                        const uint32_t e = sg[t], d = (e - lo) >> shift;
+                        if (e >= lo && d < (uint32_t)kWave) atomicAdd(&hist[d], 1u);
+                    }
+                }
+                wave_lds_fence();
+                const uint32_t c = hist[lane], incl = wave_incl_scan_u32(c);
+                const unsigned long long hit = __ballot(below + incl >= want);     // never empty: the range holds >= want - below
+                const int b = __ffsll((long long)hit) - 1;
+                const uint32_t ex_b = (uint32_t)__builtin_amdgcn_readlane((int)(incl - c), b);
+                const uint32_t c_b = (uint32_t)__builtin_amdgcn_readlane((int)c, b);
+                if (below + ex_b + c_b == want || shift == 0) return lo + (((uint32_t)b + 1u) << shift);
+                below += ex_b;
+                lo += (uint32_t)b << shift;
+                shift = shift > 6 ? shift - 6 : 0;
+            }
+        };
+        if constexpr (SP) {
+            // every kept point leaves the handle of its voxel (the segment, as in the first point's entry) for the compaction;
+            // the first point leaves the entry instead -- if the voxel passes min_points (its coordinates are inside the bounds
+            // by construction of the key)
+            static_for<ITEMS>([&](auto R) {
+                constexpr int r = decltype(R)::value;
+                const uint32_t q = threadIdx.x + r * kBucketThreads;
+                if (q < m) {
+                    const uint32_t s = slot[r], cb = tcnt[s], cnt = cb & 0xffffu, base = cb >> 16, me = idx[r];
+                    const bool pass = !vp.on || (int32_t)cnt >= vp.min_points;
+                    bool kept = pass, later = false;
+                    if (pass && P > 0 && cnt > P) {                      // TRIM: the first P points by index stay (voxelize.cpp:457-463)
+                        if (cnt > dense_min) later = true;               // (the cell's wavefront decides, below)
+                        else {
+                            uint32_t rank = 0, k = 0;
+                            const uint32_t *sg = seg + base;
+                            for (; k + 8 <= cnt && rank < P; k += 8)
+                                rank += (sg[k] < me) + (sg[k + 1] < me) + (sg[k + 2] < me) + (sg[k + 3] < me) + (sg[k + 4] < me) +
+                                        (sg[k + 5] < me) + (sg[k + 6] < me) + (sg[k + 7] < me);
+                            for (; k < cnt && rank < P; k++) rank += sg[k] < me;
+                            kept = rank < P;
+                        }
+                    }
+                    if (!later && kept) {
+                        if (tfirst[s] == me) {
+                            first_entry(me, cnt, base, s);
+                            early_v++;
+                            early_p += cnt < early_clamp ? cnt : early_clamp;
+                        } else pfirst_out[me] = bb + base;
+                    }
+                }
+            });
+            D3D_PHASE(0, 5);
+            const uint32_t no = nover, lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+            uint32_t *hist = whist[V2 ? wv : 0];
+            for (uint32_t o = wv; o < no; o += kBucketThreads / kWave) {
+                const uint32_t s = oslot[o], cb = tcnt[s], cnt = cb & 0xffffu, base = cb >> 16;
+                if (vp.on && (int32_t)cnt < vp.min_points) continue;
+                const uint32_t *sg = seg + base;
+                const uint32_t tau = select_tau(sg, cnt, P, hist), f = tfirst[s];
+                for (uint32_t t = lane; t < cnt; t += kWave) {
+                    const uint32_t e = sg[t];
+                    if (e >= tau) continue;
+                    if (e == f) {
+                        first_entry(e, cnt, base, s);
+                        early_v++;
+                        early_p += cnt < early_clamp ? cnt : early_clamp;
+                    } else pfirst_out[e] = bb + base;
+                }
+            }
+            early_publish();
+            D3D_PHASE(0, 6);
+            return;
+        }
         v4f over_pre = {0.f, 0.f, 0.f, 0.f};
         overflow_first(seg, over_pre);
         static_for<ITEMS>([&](auto R) {
@@ -2000,32 +2133,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                 if (cnt <= dense_min) continue;                     // (listed for its reduction only)
                 uint32_t *sg = seg + base;
                 const uint32_t want = cnt < P ? cnt : P, K = (cnt + kWave - 1) / kWave;
-                // the `want` smallest indices: radix-64 select, six bits a round -- bins [lo + b << shift, lo + (b + 1) << shift)
-                uint32_t lo = 0, below = 0, tau = 0xffffffffu;
-                int shift = idx_bits > 6 ? idx_bits - 6 : 0;
-                if (cnt > want) {
-                    for (;;) {
-                        hist[lane] = 0;
-                        wave_lds_fence();
-                        for (uint32_t k = 0; k < K; k++) {
-                            const uint32_t t = k * kWave + lane;
-                            if (t < cnt) {
-                                const uint32_t e = sg[t], d = (e - lo) >> shift;
-                                if (e >= lo && d < (uint32_t)kWave) atomicAdd(&hist[d], 1u);
-                            }
-                        }
-                        wave_lds_fence();
-                        const uint32_t c = hist[lane], incl = wave_incl_scan_u32(c);
-                        const unsigned long long hit = __ballot(below + incl >= want);     // never empty: the range holds >= want - below
-                        const int b = __ffsll((long long)hit) - 1;
-                        const uint32_t ex_b = (uint32_t)__builtin_amdgcn_readlane((int)(incl - c), b);
-                        const uint32_t c_b = (uint32_t)__builtin_amdgcn_readlane((int)c, b);
-                        if (below + ex_b + c_b == want || shift == 0) { tau = lo + (((uint32_t)b + 1u) << shift); break; }
-                        below += ex_b;
-                        lo += (uint32_t)b << shift;
-                        shift = shift > 6 ? shift - 6 : 0;
-                    }
-                }
+                const uint32_t tau = select_tau(sg, cnt, want, hist);
                 // kept = below tau, compacted to the front of the segment (forward, in place: position <= index read)
                 uint32_t run = 0;
                 for (uint32_t k = 0; k < K; k++) {
@@ -3207,6 +3315,187 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact_kept(const float *_
     }
 }
 
+// Round 5: numbering, per-voxel outputs AND the compaction of the kept points of the fused sparse + filter call in ONE launch
+// (k_meta_first_lb + k_compact_kept before), behind k_bucket_index<BoundKey, .., V2>.  Tiles of 4096 point indices in ticket
+// order, two decoupled look-backs:
+//   A  first points -> filtered voxel ids (the first-seen numbering of the voxels that pass, voxelize.cpp:380-403); a first point
+//      writes its voxel's coords / voxel_npoints -- the cell from its own row, the count from its entry -- and, for a voxel of
+//      several points, publishes the id under the voxel's HANDLE (its segment, as in the entry): vidseg[handle] = id;
+//   B  kept points -> places in the compacted outputs.  A first point knows its id; any other kept point carries the handle of
+//      its voxel (k_bucket_index) and reads the id there.  The voxel's first point has a lower index, i.e. sits in this tile or
+//      in one with an earlier ticket: that workgroup is running and publishes without waiting for anything but tiles before
+//      ITS OWN -- so a reader that finds the word still unset (k_tile_sort preset it) polls, and cannot wait for ever.
+// Against the two launches: one read of the entries and the handles instead of firstmap / vidof / pfirst twice, no vidof array.
+constexpr int kFinThreads = 1024, kFinItems = 4, kFinTile = kFinThreads * kFinItems;
+constexpr uint32_t kVoxelCut = 0xfffffffeu;       // vidseg: the voxel exists but lies behind the max_voxels cut
+struct SparseFin {
+    u64 *stat_a, *stat_b;       // [tiles] each, cleared by k_tile_sort together with the ticket
+    unsigned int *ticket;
+    int64_t *host;              // 2 * D3D_NUM_COUNTS + 1 words (d3d_voxelize_3d_sparse_filter), or NULL
+    const u64 *early;           // k_bucket_index's pairs {passing voxels, kept points}: complete when this launch starts
+    uint32_t early_pairs;
+    long long coord_sub[3];     // VoxelGenerator's coords - offset (voxel/__init__.py:103), applied in the store
+};
+template <bool VEC4>
+__global__ __launch_bounds__(kFinThreads) void k_sparse_finish(BoundKey kf, int64_t n, const uint32_t *__restrict__ firstmap,
+                                                               const uint32_t *__restrict__ phandle, const uint4 *__restrict__ vrec,
+                                                               uint32_t *vidseg, const float *__restrict__ points, int c,
+                                                               uint32_t max_voxels, uint32_t npoints_clamp, int64_t *__restrict__ out_coords,
+                                                               int32_t *__restrict__ out_npoints, float *__restrict__ out_feats,
+                                                               int64_t *__restrict__ out_mask, int64_t *__restrict__ out_mapping,
+                                                               int64_t *sparse_counts, int64_t *counts, SparseFin lb)
+{
+    __shared__ unsigned int sid;
+    __shared__ uint32_t wtot[kFinThreads / kWave];
+    __shared__ u64 sprefix;
+    const unsigned int tile = lookback_ticket(lb.ticket, &sid);
+    const unsigned int ntiles = gridDim.x;
+    if (tile == 0 && lb.host && lb.early_pairs && threadIdx.x < kWave) {
+        // both output sizes are known before any voxel has its number -- unless max_voxels cuts the frame short -- and the host,
+        // which waits for them to size what it returns, gets them now (as k_meta_first_lb's first tile did)
+        const bool have = threadIdx.x < lb.early_pairs;
+        const u64 tv = wave_sum_u64(have ? lb.early[16 * threadIdx.x] : 0ull), tp = wave_sum_u64(have ? lb.early[16 * threadIdx.x + 1] : 0ull);
+        if (threadIdx.x == 0 && tv <= (u64)max_voxels) {
+            for (int k = 0; k < D3D_NUM_COUNTS; k++) {
+                lb.host[k] = sparse_counts[k];
+                lb.host[D3D_NUM_COUNTS + 1 + k] = 0;
+            }
+            lb.host[D3D_COUNT_VOXELS] = (int64_t)tv;
+            lb.host[D3D_COUNT_AUX] = 0;
+            lb.host[D3D_NUM_COUNTS + 1 + D3D_COUNT_VOXELS] = (int64_t)tv;
+            lb.host[D3D_NUM_COUNTS + 1 + D3D_COUNT_POINTS] = (int64_t)tp;
+            __threadfence_system();
+            __hip_atomic_store(&lb.host[D3D_NUM_COUNTS], (int64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)tile * kFinTile + (int64_t)w * (kWave * kFinItems) + lane;          // (w, row, lane) = index order
+    uint32_t e[kFinItems], h[kFinItems], ex[kFinItems], carry = 0;
+#pragma unroll
+    for (int k = 0; k < kFinItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        e[k] = firstmap[i];                                 // (padded to the tile, preset by k_tile_sort)
+        h[k] = i < n ? phandle[i] : kInf;
+    }
+    // the first points' rows (for their cells) are on their way while the numbering is resolved
+    float px[kFinItems][3];
+#pragma unroll
+    for (int k = 0; k < kFinItems; k++) {
+        const int64_t i = base + (int64_t)k * kWave;
+        px[k][0] = px[k][1] = px[k][2] = 0.f;
+        if (e[k] != kInf) {
+            if (VEC4) { const float4 q = reinterpret_cast<const float4 *>(points)[i]; px[k][0] = q.x; px[k][1] = q.y; px[k][2] = q.z; }
+            else { const float *src = points + i * c; px[k][0] = src[0]; px[k][1] = src[1]; px[k][2] = src[2]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kFinItems; k++) {
+        const unsigned long long bal = __ballot(e[k] != kInf);
+        ex[k] = carry + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        carry += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) wtot[w] = carry;
+    __syncthreads();
+    uint32_t total = 0, woff = 0;
+#pragma unroll
+    for (int k = 0; k < kFinThreads / kWave; k++) {
+        const uint32_t t = wtot[k];
+        total += t;
+        if (k < w) woff += t;
+    }
+    if (w == 0) {
+        const u64 before = lookback_exclusive(lb.stat_a, tile, (u64)total);
+        if (lane == 0) sprefix = before;
+    }
+    __syncthreads();
+    const u64 voxels_before = sprefix;
+    uint32_t id[kFinItems];
+#pragma unroll
+    for (int k = 0; k < kFinItems; k++) {
+        id[k] = kNoVoxel;
+        if (e[k] == kInf) continue;
+        const u64 vid64 = voxels_before + woff + ex[k];
+        const uint32_t c8 = e[k] >> kFmShift, handle = e[k] & kFmMask;
+        const bool cut = vid64 >= (u64)max_voxels;                  // voxelize.cpp:396-397: later voxels are not taken
+        uint32_t cnt = c8;
+        if (c8 == kFmRecord && !cut) cnt = vrec[handle].w;
+        if (c8 != 1u) __hip_atomic_store(&vidseg[handle], cut ? kVoxelCut : (uint32_t)vid64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cut) continue;
+        const uint32_t vid = (uint32_t)vid64;
+        id[k] = vid;
+        u64 key = 0;
+        uint32_t st = 0;
+        (void)kf.make(px[k], key, st);                      // the same arithmetic on the same floats as k_tile_sort: the same cell
+        long long cc[3];
+        kf.decode(key, cc);
+        out_coords[(int64_t)vid * 3 + 0] = cc[0] - lb.coord_sub[0];
+        out_coords[(int64_t)vid * 3 + 1] = cc[1] - lb.coord_sub[1];
+        out_coords[(int64_t)vid * 3 + 2] = cc[2] - lb.coord_sub[2];
+        out_npoints[vid] = (int32_t)(cnt < npoints_clamp ? cnt : npoints_clamp);
+    }
+    __syncthreads();                                        // (this workgroup's own ids are published: s_waitcnt vmcnt(0) + barrier)
+    // B: the other kept points read their voxel's id under its handle
+#pragma unroll
+    for (int k = 0; k < kFinItems; k++) {
+        if (e[k] != kInf || h[k] == kInf) continue;
+        uint32_t v;
+        while ((v = __hip_atomic_load(&vidseg[h[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kInf) __builtin_amdgcn_s_sleep(1);
+        id[k] = v == kVoxelCut ? kNoVoxel : v;
+    }
+    uint32_t px2[kFinItems];
+    carry = 0;
+#pragma unroll
+    for (int k = 0; k < kFinItems; k++) {
+        const unsigned long long bal = __ballot(id[k] != kNoVoxel);
+        px2[k] = carry + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        carry += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) wtot[w] = carry;
+    __syncthreads();
+    uint32_t ktotal = 0, kwoff = 0;
+#pragma unroll
+    for (int k = 0; k < kFinThreads / kWave; k++) {
+        const uint32_t t = wtot[k];
+        ktotal += t;
+        if (k < w) kwoff += t;
+    }
+    if (w == 0) {
+        const u64 before = lookback_exclusive(lb.stat_b, tile, (u64)ktotal);
+        if (lane == 0) sprefix = before;
+    }
+    __syncthreads();
+    const u64 pre = sprefix + kwoff;
+#pragma unroll
+    for (int k = 0; k < kFinItems; k++) {
+        if (id[k] == kNoVoxel) continue;
+        const int64_t i = base + (int64_t)k * kWave;
+        const u64 o = pre + px2[k];
+        out_mask[o] = i;
+        out_mapping[o] = (int64_t)id[k];
+        if (VEC4) reinterpret_cast<float4 *>(out_feats)[o] = reinterpret_cast<const float4 *>(points)[i];
+        else
+            for (int d = 0; d < c; d++) out_feats[o * c + d] = points[i * c + d];
+    }
+    if (tile == ntiles - 1 && threadIdx.x == 0) {           // the sizes, as the two operators leave them
+        const u64 all = voxels_before + total;
+        const int64_t nvox = (int64_t)(all < (u64)max_voxels ? all : (u64)max_voxels), kept = (int64_t)(sprefix + ktotal);
+        sparse_counts[D3D_COUNT_VOXELS] = nvox;
+        sparse_counts[D3D_COUNT_AUX] = 0;
+        counts[D3D_COUNT_POINTS] = kept;
+        counts[D3D_COUNT_VOXELS] = nvox;
+        counts[D3D_COUNT_STATUS] = 0;
+        counts[D3D_COUNT_AUX] = 0;
+        if (lb.host && !(lb.early_pairs && all <= (u64)max_voxels)) {          // (else the first tile has told the host)
+            for (int k = 0; k < D3D_NUM_COUNTS; k++) {
+                lb.host[k] = sparse_counts[k];
+                lb.host[D3D_NUM_COUNTS + 1 + k] = counts[k];
+            }
+            __threadfence_system();
+            __hip_atomic_store(&lb.host[D3D_NUM_COUNTS], (int64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // DESCENDING voxel filter, fused (voxelize.cpp:404-420): the voxels that pass the filter, numbered v in first-seen order by
 // k_meta_first_lb, are ranked r by a stable descending sort of their counts; the first max_voxels ranks are the result.
 // Thread = rank: the voxel's per-voxel outputs move to row r, and the entry of its FIRST POINT in vidof[] -- what every
@@ -3787,6 +4076,70 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     return D3D_OK;
 }
 
+// Round 5: the fused sparse + filter call in THREE launches on the dense contract's index machinery (BoundKey: the cell inside
+// the filter's coordinate bounds is a 32-bit key): k_tile_sort -> k_bucket_index<.., V2> (the voxel filter and the TRIM point
+// filter inside; a handle of its voxel per kept point) -> k_sparse_finish (numbering, per-voxel outputs, compaction).
+// Returns D3D_ERR_UNSUPPORTED when the frame does not take this path (the caller then runs round 4's four launches).
+static int sparse_fused_index(const BoundKey &kf, const float *points, int64_t n, int c, const VoxelWs &w, uint32_t nbins, int hshift,
+                              const VoxelPass &pass, uint32_t P /* 0: no point filter */, uint32_t max_voxels, uint32_t npoints_clamp,
+                              const int64_t *coord_offset, float *out_feats, int64_t *out_mask, int64_t *out_mapping,
+                              int32_t *out_npoints, int64_t *out_coords, int64_t *sparse_counts, int64_t *counts, int64_t *host,
+                              hipStream_t st)
+{
+    typedef BinEntry<true> E;
+    if (n > kFmMaxPoints || nbins > 8192u) return D3D_ERR_UNSUPPORTED;
+    const bool vec4 = c == 4 && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out_feats)) & 15) == 0;
+    const bool big_tiles = vec4 && n >= kBigTileMinPoints;
+    const int tune_tile = !big_tiles && vec4 ? D3D_TUNE_VAL(2, (w.npad >> 13) <= 160 ? 12 : 0) : 0;
+    const int tshift = big_tiles ? 14 : tune_tile == 12 ? 12 : 13;
+    const uint32_t stiles = (uint32_t)(w.npad >> tshift);
+    if (n > kTileSortMaxPoints || stiles > (uint32_t)kRunCap || ((uint64_t)nbins + 1) * stiles * 4 > w.cap * 8) return D3D_ERR_UNSUPPORTED;
+    E::type *bent = reinterpret_cast<E::type *>(w.tabA);
+    uint32_t *table = reinterpret_cast<uint32_t *>(w.tabB), *tileinfo = table + (size_t)nbins * stiles;
+    uint4 *vrec = reinterpret_cast<uint4 *>(w.aux);
+    uint32_t *firstmap = w.list, *phandle = w.pslot, *vidseg = w.voff;
+    uint32_t *gpos = reinterpret_cast<uint32_t *>(w.vinfo) + w.npad;
+    // look-back words of k_sparse_finish (two per tile of 4096 points) and, behind them, up to 64 pairs of early totals
+    const uint32_t ftiles = (uint32_t)(w.npad / kFinTile);
+    const uint32_t early_at = (2 * ftiles + 15u) & ~15u;
+    uint32_t early_pairs = 0;
+    if (host)
+        for (early_pairs = 64; early_pairs > 1 && (uint64_t)early_at + 16ull * early_pairs > (uint64_t)(w.npad / 64); early_pairs >>= 1) { }
+    if (host && (uint64_t)early_at + 16ull * early_pairs > (uint64_t)(w.npad / 64)) early_pairs = 0;
+    u64 *early_tot = early_pairs ? w.fwords + early_at : nullptr;
+    unsigned int *ticket = w.big_count + 40;
+    const size_t lds = ((size_t)1 << tshift) * (sizeof(uint32_t) + 2) + (size_t)nbins * 4;
+#define D3D_TILE_SORT_B(V4, IT)                                                                                                  \
+    do {                                                                                                                        \
+        if (lds + 1024 > 65536)                                                                                                 \
+            D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort<BoundKey, V4, true, IT>),             \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+        D3D_LAUNCH("k_tile_sort", (k_tile_sort<BoundKey, V4, true, IT>), dim3(((stiles + 7u) >> 3) << 3), dim3(kSortThreads), lds, st, kf, points, \
+                   n, c, nbins, stiles, bent, table, tileinfo, phandle, firstmap, sparse_counts, (int64_t *)nullptr,           \
+                   (unsigned char *)nullptr, reinterpret_cast<int32_t *>(vidseg), w.fwords, early_at + 16u * early_pairs, ticket, false); \
+    } while (0)
+    if (big_tiles) D3D_TILE_SORT_B(true, 16);
+    else if (tshift == 12) D3D_TILE_SORT_B(true, 4);
+    else if (vec4) D3D_TILE_SORT_B(true, 8);
+    else D3D_TILE_SORT_B(false, 8);
+#undef D3D_TILE_SORT_B
+    D3D_LAUNCH("k_bucket_index", (k_bucket_index<BoundKey, true, true, false, true>), dim3(nbins), dim3(kBucketThreads), 0, st, kf, pass, bent,
+               (const float4 *)nullptr, (const uint32_t *)nullptr, hshift, P, (int)D3D_REDUCE_NONE, (float4 *)nullptr, vrec, firstmap,
+               sparse_counts, (uint32_t *)nullptr, w.parr, reinterpret_cast<uint32_t *>(w.vinfo), (unsigned char *)nullptr, w.big_list,
+               (uint32_t *)nullptr, table, stiles, tshift, tileinfo, gpos, phandle, early_tot, npoints_clamp,
+               early_pairs ? early_pairs - 1u : 0u, bits_for((u64)(n > 1 ? n - 1 : 1)), (uint32_t)D3D_TUNE_VAL(0, (int)kDenseMin));
+    SparseFin lb{w.fwords, w.fwords + ftiles, ticket, host, early_tot, early_pairs, {0, 0, 0}};
+    if (coord_offset)
+        for (int k = 0; k < 3; k++) lb.coord_sub[k] = (long long)coord_offset[k];
+    if (vec4)
+        D3D_LAUNCH("k_sparse_finish", k_sparse_finish<true>, dim3(ftiles), dim3(kFinThreads), 0, st, kf, n, firstmap, phandle, vrec, vidseg,
+                   points, c, max_voxels, npoints_clamp, out_coords, out_npoints, out_feats, out_mask, out_mapping, sparse_counts, counts, lb);
+    else
+        D3D_LAUNCH("k_sparse_finish", k_sparse_finish<false>, dim3(ftiles), dim3(kFinThreads), 0, st, kf, n, firstmap, phandle, vrec, vidseg,
+                   points, c, max_voxels, npoints_clamp, out_coords, out_npoints, out_feats, out_mask, out_mapping, sparse_counts, counts, lb);
+    return D3D_OK;
+}
+
 static int make_dense_key(const int32_t *shape, const float *bound, DenseKey &kf)
 {
     if (shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0) return D3D_ERR_BAD_ARG;
@@ -4337,10 +4690,35 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
             uint32_t nbins = 0;
             int hshift = 0;
             if (binned_eligible(n, w, flags, &nbins, &hshift)) {
+                const bool trim = max_points_filter == D3D_MAXPTS_TRIM;
+                // round 5: three launches on 32-bit cells inside the coordinate bounds (not DESCENDING, whose sort sits between
+                // the numbering and the compaction; not on request of round 4's kernels; boxes of 2^32 - 1 cells and more, or
+                // reaching INT_MIN -- where the reference files its NaN points -- keep the 63-bit keys)
+                if (!desc && !(flags & (D3D_VOXEL_INDEX_V1 | D3D_VOXEL_PARTITION_3PASS))) {
+                    BoundKey bk;
+                    double cells = 1.0;
+                    bool ok = true;
+                    for (int d = 0; d < 3; d++) {
+                        const int64_t lo = coords_bound[2 * d], hi = coords_bound[2 * d + 1];
+                        ok = ok && lo > (int64_t)INT_MIN && hi <= (int64_t)INT_MAX + 1 && hi > lo && hi - lo < (1ll << 32);
+                        bk.size[d] = voxel_size[d];
+                        bk.lo[d] = (long long)lo;
+                        bk.ext[d] = ok ? (unsigned)(hi - lo) : 1u;
+                        cells *= (double)(hi - lo);
+                    }
+                    if (ok && cells < 4294967295.0) {
+                        VoxelPass vp{true, min_points, {0, 0, 0}, {0, 0, 0}};
+                        for (int k = 0; k < 3; k++) { vp.lo[k] = coords_bound[2 * k]; vp.hi[k] = coords_bound[2 * k + 1]; }
+                        const uint32_t vcap2 = max_voxels_filter == D3D_MAXVOX_NONE ? 0xffffffffu : (uint32_t)max_voxels;
+                        int rc = sparse_fused_index(bk, points, n, c, w, nbins, hshift, vp, trim ? (uint32_t)max_points : 0u, vcap2,
+                                                    trim ? (uint32_t)max_points : 0xffffffffu, coord_offset, out_feats, out_mask, out_mapping,
+                                                    out_npoints, out_coords, sparse_counts, counts, host_counts, st);
+                        if (rc != D3D_ERR_UNSUPPORTED) return rc;
+                    }
+                }
                 SparseKey kf;
                 for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
                 kf.tolerant = tolerant;
-                const bool trim = max_points_filter == D3D_MAXPTS_TRIM;
                 // DESCENDING (voxelize.cpp:404-420): first-seen numbering of ALL passing voxels into scratch rows, then a stable
                 // sort of their counts decides the ranks, the first max_voxels of which are the result (k_desc_finish)
                 const uint32_t vcap = (max_voxels_filter == D3D_MAXVOX_NONE || desc) ? 0xffffffffu : (uint32_t)max_voxels;

@@ -1,26 +1,41 @@
 """Point-sharded voxelization over the GPUs of one node (north_star; the reference has no distributed code).
 
-One process per GPU; rank r holds a contiguous slice of the frame's points (rank order = point order).
-The result is the voxel feature grid of the WHOLE frame, replicated on every rank, numbered exactly like the
-single-GPU dense contract (first-seen order over the global point index, voxelize.cpp:119), plus the
-point -> voxel map of the rank's own points:
+One process per GPU; rank r holds a contiguous slice of the frame's points (rank order = point order).  The result is the
+voxel feature grid of the WHOLE frame -- numbered exactly like the single-GPU contract (first-seen order over the global point
+index, voxelize.cpp:119) -- plus the global voxel id of each of the rank's own points.
 
-  1. local   d3d_voxelize_3d_reduce: hash the shard, per-voxel partial reduction (SUM / MAX / MIN), count,
-             global index of the voxel's first point                                    [HIP kernels]
-  2. gather  RCCL all-gather of the per-rank occupied-cell key lists (8 B per voxel)     [xGMI]
-  3. slots   every rank marks the gathered keys in a bitmap over the grid and popcount-scans it: identical
-             compact slot numbering on all ranks without exchanging a dictionary          [HIP kernels]
-             (RCCL has no bitwise-OR reduction, so the bitmap itself cannot be all-reduced).  The global voxel
-             count and every rank's status bits (they ride in the key lists) are the ONE host read-back of a call.
-  4. reduce  one kernel writes the reduction's identity and the rank's partial rows into the compact voxel table,
-             then RCCL all-reduce: SUM of features+counts (or MAX/MIN), MIN of first index
-  5. order   the same bitmap+scan over the first-point indices turns slots into first-seen voxel ids, fused
-             with the division / transposition into voxel-id order
+DEFAULT: owner-computes (`exchange="owner"`, rounds 3-5; kernels in csrc/owner.hip).  A cell has an owner rank,
+owner(cell) = mix64(cell) * W >> 64, and per-rank work scales with the SHARD, not with the frame:
 
-Exact: coords, counts, numbering, MAX/MIN.  MEAN: the cross-rank sum order differs from a sequential pass
-(as on one GPU for overflow voxels), so it matches within fp32 rounding (rtol 1e-5).
-Collective payloads (config 5, 8 x 1 M points, 5.9 M voxels): all-gather 8 B/voxel-occurrence (~47 MB),
-all-reduce (C+1) x 4 B + 8 B per voxel (~164 MB) -- sized for few large collectives over the 7 xGMI links.
+  1. local    d3d_voxelize_3d_reduce on the shard alone, point indices local to it (no rank needs another's size first):
+              per-voxel partial SUM / MAX / MIN, count, first point, cell key, point -> local voxel map          [HIP]
+  2. pack     one partial RECORD per local voxel {cell, first point, count, C partial features}, grouped by owner   [HIP]
+  3. counts   ONE small all-gather: records / rows per destination, status bits and the shard's point count of every rank
+              (the sizes of the all-to-alls and every rank's global point offset) -- host synchronisation 1 of 2  [RCCL]
+  4. records  all_to_all_single of the records: a sparse reduce-scatter of the feature grid                       [RCCL, xGMI]
+  5. merge    the owner groups the records of a cell (LDS buckets, d3d_owner_merge), folds the partials in source-rank order
+              and turns the leader's local first point into a global index (point_off)                           [HIP]
+  6. number   every owner sets bit `first point` of a one-bit-per-point bitmap over the frame; the bitmaps are SUM-all-reduced
+              (disjoint sets: SUM = OR; RCCL has no OR) and a popcount scan gives every owned voxel its global id  [RCCL + HIP]
+  7. reply    all_to_all_single of the ids back along the records' path; every point's local voxel -> global id   [RCCL + HIP]
+  8. sizes    the owned / global voxel counts -- host synchronisation 2 of 2
+
+Four collectives and two host synchronisations per call (five collectives with the dense contract, `max_points=P`, whose
+candidate rows travel in a second all-to-all).  `replicate=False` ends here: each rank returns ITS voxels (coords, counts,
+features, global ids) -- the scalable form.  `replicate=True` adds an all-gather of the finished rows and a merge into
+voxel-id order on every rank (work sized by the frame again; for callers that want the replicated grid).
+
+Exact: coords, counts, numbering, MAX / MIN, the dense contract's rows.  MEAN: partial sums are folded in source-rank order
+(the same on every run) and match a sequential pass within fp32 rounding (rtol 1e-5).
+Collective payloads (config 5, 8 x 1 M points, 5.9 M voxels, per rank): records 31 MB, ids 6 MB, bitmap 1 MB (+ rows 14 MB).
+
+LEGACY: the replicated-grid exchanges of rounds 1-2 (`exchange="keys" | "bitmap" | "auto"`, still tested): all-gather of the
+occupied cells (key lists or occupancy bitmaps), identical compact slots on every rank, all-reduce of the compact voxel table,
+every rank finalises the WHOLE grid (`_run`).  Kept for communicators that only implement the round 1-2 protocol.
+
+Never run on more than one GPU in any round (no multi-GPU box was available): world-2 gloo tests on CPU, 8 virtual ranks on
+one GPU at config 5's full size, and RCCL (backend "nccl") with one rank.  `tools/sharded_profile.py` prints a MODELLED step
+(assumed link and latency constants) next to both single-GPU bases.
 """
 import ctypes
 

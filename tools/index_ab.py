@@ -15,7 +15,9 @@ for n in sizes:
     bounds, shape, seed = (synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, 3) if big else (synth.KITTI_BOUNDS, synth.KITTI_SHAPE, 0)
     cloud = torch.from_numpy(synth.lidar_like(n, seed, bounds)).cuda()
     gens = {"dense": VoxelGenerator(bounds, shape, dense=True, reduction="mean", max_points=32, max_voxels=n),
-            "dense-none": VoxelGenerator(bounds, shape, dense=True, max_points=32, max_voxels=n)}
+            "dense-none": VoxelGenerator(bounds, shape, dense=True, max_points=32, max_voxels=n),
+            "sparse+trim": VoxelGenerator(bounds, shape, max_points=32, max_voxels=n, max_points_filter="trim"),
+            "sparse": VoxelGenerator(bounds, shape, max_voxels=n)}
     for mode, gen in gens.items():
         for rep in range(3):
             for name, fl in (("r5", 0), ("v1", _lib.VOXEL_INDEX_V1)):

@@ -59,12 +59,15 @@ LINK_GBS, LINKS, COLL_LAT_US, HOST_SYNC_US = 153.0, 7, 25.0, 20.0
 st0 = stats[0]
 a2a = max(st0.get("all_to_all_bytes_sent", 0), st0.get("all_to_all_bytes_received", 0)) + st0.get("reply_bytes_sent", 0) + \
     st0.get("rows_all_to_all_bytes_sent", 0)
-ncoll = 2 + 1 + 1 + 1 + 1 + (1 if max_points else 0) + (2 if replicate else 0)     # sizes, counts, records, bitmap, reply [, rows] [, gather x2]
+# round 5: the shard sizes ride in the count matrix -- counts, records, bitmap, reply [, rows] [, sizes + gather x2]; two host
+# synchronisations (the count matrix, the output sizes) [+ one for the replicated result's sizes]
+ncoll = 1 + 1 + 1 + 1 + (1 if max_points else 0) + (3 if replicate else 0)
+nsync = 2 + (1 if replicate else 0)
 t_wire = a2a / (LINKS * LINK_GBS * 1e3) + 2 * (W - 1) / W * st0.get("all_reduce_bytes", 0) / (LINK_GBS * 1e3) + \
     (W - 1) * st0.get("all_gather_bytes_per_rank", 0) / (LINKS * LINK_GBS * 1e3)
-model = tot + t_wire + ncoll * COLL_LAT_US + 3 * HOST_SYNC_US
-print("  modelled step at world %d: %.0f us = kernels %.0f + wire %.0f + %d collectives x %.0f + 3 host syncs x %.0f"
-      % (W, model, tot, t_wire, ncoll, COLL_LAT_US, HOST_SYNC_US))
+model = tot + t_wire + ncoll * COLL_LAT_US + nsync * HOST_SYNC_US
+print("  modelled step at world %d: %.0f us = kernels %.0f + wire %.0f + %d collectives x %.0f + %d host syncs x %.0f  (constants are "
+      "ASSUMPTIONS: no multi-GPU box was available to any round)" % (W, model, tot, t_wire, ncoll, COLL_LAT_US, nsync, HOST_SYNC_US))
 try:
     from d3d_amd.voxel import VoxelGenerator
     import bench
@@ -75,6 +78,14 @@ try:
         from d3d_amd.voxel.sharded import LocalComm
         g1 = ShardedVoxelGenerator(BOUNDS, SHAPE, reduction="mean", comm=LocalComm(), replicate=False)
     t1 = bench.timed(lambda: g1(whole), 5, 2) / 5 * 1e6
-    print("  single GPU, whole %d-point frame, same contract: %.0f us  ->  predicted speed-up at world %d: %.2fx" % (len(whole), t1, W, t1 / model))
+    if max_points:
+        print("  single GPU, whole %d-point frame, same contract (VoxelGenerator, dense): %.0f us  ->  predicted speed-up at world %d: %.2fx"
+              % (len(whole), t1, W, t1 / model))
+    else:
+        from d3d_amd.voxel.sharded import voxelize_reduce
+        tb = bench.timed(lambda: voxelize_reduce(whole, SHAPE, BOUNDS, "mean"), 5, 2) / 5 * 1e6
+        print("  single GPU, whole %d-point frame: best (voxelize_reduce: the contract with NO exchange) %.0f us -> predicted speed-up at "
+              "world %d: %.2fx;  the sharded operator at world 1 (pack / merge / number / reply on one rank) %.0f us -> %.2fx"
+              % (len(whole), tb, W, tb / model, t1, t1 / model))
 except Exception as e:      # pragma: no cover
     print("  (single-GPU base not measured: %r)" % (e,))
