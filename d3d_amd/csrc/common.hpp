@@ -167,13 +167,21 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
     if (lane == 0) __hip_atomic_store(&status[tile], kLbAgg | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long excl = 0;
     long long base = (long long)tile - 1;
+    unsigned int polls = 0;
     for (;;) {
         const long long j = base - lane;
         const unsigned long long s = j >= 0 ? __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kLbIncl;
         const unsigned long long incl = __ballot((s >> 62) == 2ull), empty = __ballot((s >> 62) == 0ull);
         const int p = incl ? __ffsll((long long)incl) - 1 : kWave - 1;         // the window: lanes 0 .. p
         const unsigned long long window = p == kWave - 1 ? ~0ull : ((2ull << p) - 1ull);
-        if (empty & window) { __builtin_amdgcn_s_sleep(1); continue; }         // a predecessor has not published yet
+        if (empty & window) {                                                   // a predecessor has not published yet
+            // (every predecessor holds an earlier ticket, i.e. is running: the wait is short.  A status word that was never
+            // cleared, or a workspace shared by two calls, would make it endless: after ~2^24 polls -- a second or more -- the
+            // wavefront traps, which surfaces as a HIP error on the stream instead of a hung GPU)
+            if (++polls > (1u << 24)) __builtin_trap();
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
         excl += wave_sum_u64(lane <= p ? (s & kLbMask) : 0ull);
         if (incl) break;
         base -= kWave;

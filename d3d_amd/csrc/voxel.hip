@@ -335,6 +335,87 @@ struct TabPlain {
 };
 
 // ------------------------------------------------------------------ kernels: table build
+// Sparse contract, ANY int32 coordinates (D3D_VOXEL_WIDE_KEYS; round 5): the reference keys a voxel by the three ints
+// (int)floor(p / size) (voxelize.cpp:309-313), whatever their size -- 1 mm voxels a kilometre from the origin are beyond the
+// 3 x 21 bits of SparseKey.  Here the table compares all 96 bits: slot = {w1 = 1 | x : 32 | y >> 1 : 31, w2 = 1 | y & 1 | z : 32,
+// {first, count}}.  A point claims with one CAS on w1 and then publishes w2; a point that finds ITS w1 reads w2 (waiting, when
+// the claimer -- another wavefront, or a lane of this one that has already issued the store -- has not published yet) and
+// moves on to the next slot when the third coordinate differs.  The voxels' coordinates are not decoded from a key afterwards
+// but recomputed from their first points (k_wide_coords).  A fallback for frames SparseKey refuses: not a fast path.
+struct WideKey {
+    static constexpr bool kBox = false;
+    float size[3];
+    static __device__ __forceinline__ int coord(float p, float sz)
+    {
+        const float q = floorf(p / sz);
+        return (q >= -2147483648.0f && q < 2147483648.0f) ? (int)q : INT_MIN;       // x86 cvttss2si of the reference build
+    }
+    __device__ __forceinline__ bool make(const float *p, u64 &key, uint32_t &status) const
+    {
+        (void)status;
+        const u64 a = (u64)(uint32_t)coord(p[0], size[0]), b = (u64)(uint32_t)coord(p[1], size[1]), c = (u64)(uint32_t)coord(p[2], size[2]);
+        key = mix64((a << 32 | b) ^ mix64(c + 0x9e3779b97f4a7c15ull));      // where the probe starts; the table compares the coordinates
+        return true;
+    }
+    __device__ __forceinline__ void decode(u64, long long *c) const { c[0] = c[1] = c[2] = 0; }     // (never used: k_wide_coords)
+};
+struct TabWide {
+    u64 *w1, *w2;
+    uint2 *fc;        // x = first, y = count
+    const float *points;
+    int c;
+    float size[3];
+    __device__ __forceinline__ bool insert(u64 k, uint32_t i, u64 mask, uint32_t &slot, uint32_t &arrival, uint32_t &status) const
+    {
+        const float *p = points + (size_t)i * c;
+        const uint32_t x = (uint32_t)WideKey::coord(p[0], size[0]), y = (uint32_t)WideKey::coord(p[1], size[1]),
+                       z = (uint32_t)WideKey::coord(p[2], size[2]);
+        const u64 v1 = (1ull << 63) | ((u64)x << 31) | (u64)(y >> 1), v2 = (1ull << 63) | ((u64)(y & 1u) << 32) | (u64)z;
+        u64 h = k & mask;
+        for (u64 probe = 0; probe <= mask; probe++) {
+            u64 cur = __hip_atomic_load(&w1[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == 0ull) {
+                const u64 old = atomicCAS(&w1[h], 0ull, v1);
+                if (old == 0ull) __hip_atomic_store(&w2[h], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cur = old == 0ull ? v1 : old;
+            }
+            if (cur == v1) {                            // same x and y: the slot's z decides
+                u64 b;
+                uint32_t polls = 0;
+                while ((b = __hip_atomic_load(&w2[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+                    if (++polls > (1u << 24)) __builtin_trap();
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (b == v2) {
+                    arrival = atomicAdd(&fc[h].y, 1u);
+                    if (__hip_atomic_load(&fc[h].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&fc[h].x, i);
+                    slot = (uint32_t)h;
+                    return true;
+                }
+            }
+            h = (h + 1) & mask;
+        }
+        status |= D3D_VOXEL_STATUS_TABLE_FULL;
+        return false;
+    }
+    __device__ __forceinline__ SlotInfo read(u64 s) const
+    {
+        SlotInfo r;
+        r.key = w1[s];
+        r.occupied = r.key != 0ull;
+        const uint2 v = fc[s];
+        r.first = v.x;
+        r.cnt = v.y;
+        return r;
+    }
+    __device__ __forceinline__ void clear(u64 s) const
+    {
+        w1[s] = 0ull;
+        w2[s] = 0ull;
+        fc[s] = make_uint2(kInf, 0u);
+    }
+};
+
 template <class Tab>
 __global__ void k_init(Tab tab, int64_t cap, unsigned char *flags, int64_t nflags16, int64_t *counts, uint32_t *big_count,
                        BoxParams *box = nullptr, const float4 *warm = nullptr, int64_t nwarm = 0)
@@ -1708,7 +1789,6 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 early_v++;
                 early_p += cnt < early_clamp ? cnt : early_clamp;
-                if (SPV2) tfirst[sl] = bb + j;    // (big bucket: the points' handle of their voxel is its record)
             } else tfirst[sl] = kInf;             // (its points belong to no kept voxel: what precpos / pfirst_out hand on)
             if (!single) j++;
             if constexpr (ROWS)
@@ -1907,7 +1987,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
         // than kDenseMin points -- whose per-point counting loops kept whole wavefronts waiting for one lane -- ranked by ONE
         // wavefront each: radix-64 select of the max_points smallest indices, all-pairs ranks among those.
         // SP: the sparse contract fused with its voxel filter on the SAME kernel (BoundKey): no rows, no reductions; every kept
-        // point needs a handle of its voxel (the segment, as in the entry) for the compaction, a voxel below min_points gets no
+        // point needs a handle of its voxel (its first point's index) for the compaction, a voxel below min_points gets no
         // entry, only cells above max_points need ranks at all (TRIM, voxelize.cpp:457-463) -- so the first index of a cell is
         // found by an atomicMin again instead of by the rank-0 point.
         constexpr bool SP = std::is_same<Key, BoundKey>::value;
@@ -2048,9 +2128,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
             }
         };
         if constexpr (SP) {
-            // every kept point leaves the handle of its voxel (the segment, as in the first point's entry) for the compaction;
-            // the first point leaves the entry instead -- if the voxel passes min_points (its coordinates are inside the bounds
-            // by construction of the key)
+            // every kept point leaves the handle of its voxel -- the index of the voxel's first point, under which
+            // k_sparse_finish publishes the voxel's id -- for the compaction; the first point leaves the voxel's entry instead,
+            // if the voxel passes min_points (its coordinates are inside the bounds by construction of the key)
             static_for<ITEMS>([&](auto R) {
                 constexpr int r = decltype(R)::value;
                 const uint32_t q = threadIdx.x + r * kBucketThreads;
@@ -2071,11 +2151,12 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                         }
                     }
                     if (!later && kept) {
-                        if (tfirst[s] == me) {
+                        const uint32_t f = tfirst[s];
+                        if (f == me) {
                             first_entry(me, cnt, base, s);
                             early_v++;
                             early_p += cnt < early_clamp ? cnt : early_clamp;
-                        } else pfirst_out[me] = bb + base;
+                        } else pfirst_out[me] = f;
                     }
                 }
             });
@@ -2094,7 +2175,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
                         first_entry(e, cnt, base, s);
                         early_v++;
                         early_p += cnt < early_clamp ? cnt : early_clamp;
-                    } else pfirst_out[e] = bb + base;
+                    } else pfirst_out[e] = f;
                 }
             }
             early_publish();
@@ -3223,6 +3304,18 @@ __global__ void k_fill_u32(uint32_t *p, int64_t n, uint32_t val, int64_t *counts
 
 
 // out_coords[v, :] -= offset for the counts[VOXELS] valid rows (the two-operator form of d3d_voxelize_3d_sparse_filter)
+// wide keys: a voxel's coordinates from its first point (the table compared them, nothing decodes them)
+__global__ __launch_bounds__(256) void k_wide_coords(WideKey kf, const float *__restrict__ points, int c, const int64_t *__restrict__ counts,
+                                                     const int64_t *__restrict__ first, const uint4 *__restrict__ vinfo,
+                                                     int64_t *__restrict__ coords, int32_t *__restrict__ npoints)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= counts[D3D_COUNT_VOXELS]) return;
+    const float *p = points + (size_t)first[v] * c;
+    for (int d = 0; d < 3; d++) coords[v * 3 + d] = (int64_t)WideKey::coord(p[d], kf.size[d]);
+    npoints[v] = (int32_t)vinfo[v].w;
+}
+
 __global__ __launch_bounds__(256) void k_sub_offset(int64_t *coords, const int64_t *__restrict__ counts, int64_t rows, long long o0,
                                                     long long o1, long long o2)
 {
@@ -3317,17 +3410,20 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact_kept(const float *_
 
 // Round 5: numbering, per-voxel outputs AND the compaction of the kept points of the fused sparse + filter call in ONE launch
 // (k_meta_first_lb + k_compact_kept before), behind k_bucket_index<BoundKey, .., V2>.  Tiles of 4096 point indices in ticket
-// order, two decoupled look-backs:
+// order, decoupled look-back:
 //   A  first points -> filtered voxel ids (the first-seen numbering of the voxels that pass, voxelize.cpp:380-403); a first point
-//      writes its voxel's coords / voxel_npoints -- the cell from its own row, the count from its entry -- and, for a voxel of
-//      several points, publishes the id under the voxel's HANDLE (its segment, as in the entry): vidseg[handle] = id;
-//   B  kept points -> places in the compacted outputs.  A first point knows its id; any other kept point carries the handle of
-//      its voxel (k_bucket_index) and reads the id there.  The voxel's first point has a lower index, i.e. sits in this tile or
-//      in one with an earlier ticket: that workgroup is running and publishes without waiting for anything but tiles before
-//      ITS OWN -- so a reader that finds the word still unset (k_tile_sort preset it) polls, and cannot wait for ever.
+//      writes its voxel's coords / voxel_npoints -- the cell from its own row, the count from its entry -- and then REPLACES its
+//      entry by the id: firstmap[first point] = {0 : 8 | id : 24} (an entry's count field is never 0): a coalesced store;
+//   B  kept points -> places in the compacted outputs.  A first point knows its id; any other kept point carries the index of
+//      its voxel's first point (k_bucket_index) and reads the id there.  That point has a lower index, i.e. sits in this tile or
+//      in one with an earlier ticket: its workgroup is running and publishes without waiting for anything but tiles before
+//      ITS OWN -- so a reader that still finds the entry polls, and cannot wait for ever.
+//   When max_voxels cannot cut the frame (the index has added up the passing voxels) every point with an entry or a handle is
+//   kept whatever its voxel's id: ONE look-back carries both prefixes; otherwise a second one follows the ids.
 // Against the two launches: one read of the entries and the handles instead of firstmap / vidof / pfirst twice, no vidof array.
-constexpr int kFinThreads = 1024, kFinItems = 4, kFinTile = kFinThreads * kFinItems;
-constexpr uint32_t kVoxelCut = 0xfffffffeu;       // vidseg: the voxel exists but lies behind the max_voxels cut
+constexpr int kFinThreads = 1024, kFinItems = 4, kFinTile = kFinThreads * kFinItems;   // (tiles of 2048 points on 512 lanes, three
+                                                  // workgroups per CU: 30 -> 39 us at config 2 -- twice the tiles in the look-back)
+constexpr uint32_t kVoxelCut = 0x00ffffffu;       // published id: the voxel exists but lies behind the max_voxels cut
 struct SparseFin {
     u64 *stat_a, *stat_b;       // [tiles] each, cleared by k_tile_sort together with the ticket
     unsigned int *ticket;
@@ -3337,16 +3433,17 @@ struct SparseFin {
     long long coord_sub[3];     // VoxelGenerator's coords - offset (voxel/__init__.py:103), applied in the store
 };
 template <bool VEC4>
-__global__ __launch_bounds__(kFinThreads) void k_sparse_finish(BoundKey kf, int64_t n, const uint32_t *__restrict__ firstmap,
+__global__ __launch_bounds__(kFinThreads) void k_sparse_finish(BoundKey kf, int64_t n, uint32_t *firstmap,
                                                                const uint32_t *__restrict__ phandle, const uint4 *__restrict__ vrec,
-                                                               uint32_t *vidseg, const float *__restrict__ points, int c,
+                                                               const float *__restrict__ points, int c,
                                                                uint32_t max_voxels, uint32_t npoints_clamp, int64_t *__restrict__ out_coords,
                                                                int32_t *__restrict__ out_npoints, float *__restrict__ out_feats,
                                                                int64_t *__restrict__ out_mask, int64_t *__restrict__ out_mapping,
                                                                int64_t *sparse_counts, int64_t *counts, SparseFin lb)
 {
+    typedef float vec4 __attribute__((ext_vector_type(4)));
     __shared__ unsigned int sid;
-    __shared__ uint32_t wtot[kFinThreads / kWave];
+    __shared__ uint32_t wtot[kFinThreads / kWave], wtot2[kFinThreads / kWave];
     __shared__ u64 sprefix;
     const unsigned int tile = lookback_ticket(lb.ticket, &sid);
     const unsigned int ntiles = gridDim.x;
@@ -3377,15 +3474,23 @@ __global__ __launch_bounds__(kFinThreads) void k_sparse_finish(BoundKey kf, int6
         e[k] = firstmap[i];                                 // (padded to the tile, preset by k_tile_sort)
         h[k] = i < n ? phandle[i] : kInf;
     }
-    // the first points' rows (for their cells) are on their way while the numbering is resolved
+    // the rows of every point that may be kept -- a first point (its cell comes from its row too) or the holder of a handle --
+    // are on their way while the numbering is resolved: nothing but stores is left behind the second look-back
+    vec4 row[VEC4 ? kFinItems : 1];
     float px[kFinItems][3];
 #pragma unroll
     for (int k = 0; k < kFinItems; k++) {
         const int64_t i = base + (int64_t)k * kWave;
         px[k][0] = px[k][1] = px[k][2] = 0.f;
-        if (e[k] != kInf) {
-            if (VEC4) { const float4 q = reinterpret_cast<const float4 *>(points)[i]; px[k][0] = q.x; px[k][1] = q.y; px[k][2] = q.z; }
-            else { const float *src = points + i * c; px[k][0] = src[0]; px[k][1] = src[1]; px[k][2] = src[2]; }
+        if (VEC4) {
+            row[VEC4 ? k : 0] = vec4{0.f, 0.f, 0.f, 0.f};
+            if (e[k] != kInf || h[k] != kInf) {
+                row[VEC4 ? k : 0] = reinterpret_cast<const vec4 *>(points)[i];
+                px[k][0] = row[VEC4 ? k : 0].x; px[k][1] = row[VEC4 ? k : 0].y; px[k][2] = row[VEC4 ? k : 0].z;
+            }
+        } else if (e[k] != kInf) {
+            const float *src = points + i * c;
+            px[k][0] = src[0]; px[k][1] = src[1]; px[k][2] = src[2];
         }
     }
 #pragma unroll
@@ -3403,26 +3508,69 @@ __global__ __launch_bounds__(kFinThreads) void k_sparse_finish(BoundKey kf, int6
         total += t;
         if (k < w) woff += t;
     }
+    // When max_voxels cannot cut the frame -- the index added up the passing voxels: lb.early -- every point with an entry or a
+    // handle is kept whatever its voxel's id turns out to be, so ONE look-back carries both prefixes {voxels : 32 | kept : 31}
+    // and the handles are only read for the ids' values, not for the positions.
+    bool nocut = false;
+    if (lb.early_pairs) {
+        u64 tv = 0;
+        for (uint32_t t = lane; t < lb.early_pairs; t += kWave) tv += lb.early[16 * t];
+        nocut = wave_sum_u64(tv) <= (u64)max_voxels;                    // (the same in every wavefront)
+    }
+    uint32_t kex[kFinItems], ktot_w = 0;
+    if (nocut) {
+#pragma unroll
+        for (int k = 0; k < kFinItems; k++) {
+            const unsigned long long bal = __ballot(e[k] != kInf || h[k] != kInf);
+            kex[k] = ktot_w + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            ktot_w += (uint32_t)__popcll(bal);
+        }
+        if (lane == 0) wtot2[w] = ktot_w;
+        __syncthreads();
+    }
+    uint32_t ktotal1 = 0, kwoff1 = 0;
+    if (nocut) {
+#pragma unroll
+        for (int k = 0; k < kFinThreads / kWave; k++) {
+            const uint32_t t = wtot2[k];
+            ktotal1 += t;
+            if (k < w) kwoff1 += t;
+        }
+    }
     if (w == 0) {
-        const u64 before = lookback_exclusive(lb.stat_a, tile, (u64)total);
+        const u64 before = lookback_exclusive(lb.stat_a, tile, nocut ? (((u64)total << 31) | (u64)ktotal1) : (u64)total);
         if (lane == 0) sprefix = before;
     }
     __syncthreads();
-    const u64 voxels_before = sprefix;
+    const u64 voxels_before = nocut ? sprefix >> 31 : sprefix;
+    const u64 kept_before1 = sprefix & 0x7fffffffull;
+    // A: the first points' ids, published under the voxel's handle for its other points
     uint32_t id[kFinItems];
+    bool cutk[kFinItems];
 #pragma unroll
     for (int k = 0; k < kFinItems; k++) {
         id[k] = kNoVoxel;
+        cutk[k] = false;
         if (e[k] == kInf) continue;
         const u64 vid64 = voxels_before + woff + ex[k];
-        const uint32_t c8 = e[k] >> kFmShift, handle = e[k] & kFmMask;
-        const bool cut = vid64 >= (u64)max_voxels;                  // voxelize.cpp:396-397: later voxels are not taken
-        uint32_t cnt = c8;
-        if (c8 == kFmRecord && !cut) cnt = vrec[handle].w;
-        if (c8 != 1u) __hip_atomic_store(&vidseg[handle], cut ? kVoxelCut : (uint32_t)vid64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cut) continue;
-        const uint32_t vid = (uint32_t)vid64;
-        id[k] = vid;
+        cutk[k] = vid64 >= (u64)max_voxels;                         // voxelize.cpp:396-397: later voxels are not taken
+        __hip_atomic_store(&firstmap[base + (int64_t)k * kWave], cutk[k] ? kVoxelCut : (uint32_t)vid64, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);               // (ids < 2^24: the count field reads 0 = "an id")
+        if (!cutk[k]) id[k] = (uint32_t)vid64;
+    }
+    __syncthreads();                                        // (this workgroup's own ids are out: s_waitcnt vmcnt(0) + barrier)
+    // B: the other kept points read their voxel's id under its handle -- first attempt now, the per-voxel outputs meanwhile
+    uint32_t got[kFinItems];
+#pragma unroll
+    for (int k = 0; k < kFinItems; k++) {
+        got[k] = kInf;
+        if (e[k] == kInf && h[k] != kInf) got[k] = __hip_atomic_load(&firstmap[h[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < kFinItems; k++) {
+        if (id[k] == kNoVoxel) continue;                    // (not a first point, or behind the cut)
+        const uint32_t vid = id[k], c8 = e[k] >> kFmShift;
+        const uint32_t cnt = c8 == kFmRecord ? vrec[e[k] & kFmMask].w : c8;
         u64 key = 0;
         uint32_t st = 0;
         (void)kf.make(px[k], key, st);                      // the same arithmetic on the same floats as k_tile_sort: the same cell
@@ -3433,38 +3581,51 @@ __global__ __launch_bounds__(kFinThreads) void k_sparse_finish(BoundKey kf, int6
         out_coords[(int64_t)vid * 3 + 2] = cc[2] - lb.coord_sub[2];
         out_npoints[vid] = (int32_t)(cnt < npoints_clamp ? cnt : npoints_clamp);
     }
-    __syncthreads();                                        // (this workgroup's own ids are published: s_waitcnt vmcnt(0) + barrier)
-    // B: the other kept points read their voxel's id under its handle
 #pragma unroll
     for (int k = 0; k < kFinItems; k++) {
         if (e[k] != kInf || h[k] == kInf) continue;
-        uint32_t v;
-        while ((v = __hip_atomic_load(&vidseg[h[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kInf) __builtin_amdgcn_s_sleep(1);
+        uint32_t v = got[k], polls = 0;
+        // the voxel's first point sits in this tile or in one with an earlier ticket, whose workgroup is running and publishes
+        // without waiting for this one (bounded like the look-back's poll: a trap instead of a hung GPU)
+        while ((v >> kFmShift) != 0u) {                     // (still the voxel's entry)
+            if (++polls > (1u << 24)) __builtin_trap();
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(&firstmap[h[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         id[k] = v == kVoxelCut ? kNoVoxel : v;
     }
     uint32_t px2[kFinItems];
-    carry = 0;
-#pragma unroll
-    for (int k = 0; k < kFinItems; k++) {
-        const unsigned long long bal = __ballot(id[k] != kNoVoxel);
-        px2[k] = carry + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        carry += (uint32_t)__popcll(bal);
-    }
-    if (lane == 0) wtot[w] = carry;
-    __syncthreads();
     uint32_t ktotal = 0, kwoff = 0;
+    u64 kept_before = kept_before1;
+    if (nocut) {                                            // (positions from the one look-back above)
 #pragma unroll
-    for (int k = 0; k < kFinThreads / kWave; k++) {
-        const uint32_t t = wtot[k];
-        ktotal += t;
-        if (k < w) kwoff += t;
+        for (int k = 0; k < kFinItems; k++) px2[k] = kex[k];
+        ktotal = ktotal1;
+        kwoff = kwoff1;
+    } else {
+        carry = 0;
+#pragma unroll
+        for (int k = 0; k < kFinItems; k++) {
+            const unsigned long long bal = __ballot(id[k] != kNoVoxel);
+            px2[k] = carry + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            carry += (uint32_t)__popcll(bal);
+        }
+        if (lane == 0) wtot[w] = carry;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kFinThreads / kWave; k++) {
+            const uint32_t t = wtot[k];
+            ktotal += t;
+            if (k < w) kwoff += t;
+        }
+        if (w == 0) {
+            const u64 before = lookback_exclusive(lb.stat_b, tile, (u64)ktotal);
+            if (lane == 0) sprefix = before;
+        }
+        __syncthreads();
+        kept_before = sprefix;
     }
-    if (w == 0) {
-        const u64 before = lookback_exclusive(lb.stat_b, tile, (u64)ktotal);
-        if (lane == 0) sprefix = before;
-    }
-    __syncthreads();
-    const u64 pre = sprefix + kwoff;
+    const u64 pre = kept_before + kwoff;
 #pragma unroll
     for (int k = 0; k < kFinItems; k++) {
         if (id[k] == kNoVoxel) continue;
@@ -3472,13 +3633,13 @@ __global__ __launch_bounds__(kFinThreads) void k_sparse_finish(BoundKey kf, int6
         const u64 o = pre + px2[k];
         out_mask[o] = i;
         out_mapping[o] = (int64_t)id[k];
-        if (VEC4) reinterpret_cast<float4 *>(out_feats)[o] = reinterpret_cast<const float4 *>(points)[i];
+        if (VEC4) reinterpret_cast<vec4 *>(out_feats)[o] = row[VEC4 ? k : 0];
         else
             for (int d = 0; d < c; d++) out_feats[o * c + d] = points[i * c + d];
     }
     if (tile == ntiles - 1 && threadIdx.x == 0) {           // the sizes, as the two operators leave them
         const u64 all = voxels_before + total;
-        const int64_t nvox = (int64_t)(all < (u64)max_voxels ? all : (u64)max_voxels), kept = (int64_t)(sprefix + ktotal);
+        const int64_t nvox = (int64_t)(all < (u64)max_voxels ? all : (u64)max_voxels), kept = (int64_t)(kept_before + ktotal);
         sparse_counts[D3D_COUNT_VOXELS] = nvox;
         sparse_counts[D3D_COUNT_AUX] = 0;
         counts[D3D_COUNT_POINTS] = kept;
@@ -4097,15 +4258,14 @@ static int sparse_fused_index(const BoundKey &kf, const float *points, int64_t n
     E::type *bent = reinterpret_cast<E::type *>(w.tabA);
     uint32_t *table = reinterpret_cast<uint32_t *>(w.tabB), *tileinfo = table + (size_t)nbins * stiles;
     uint4 *vrec = reinterpret_cast<uint4 *>(w.aux);
-    uint32_t *firstmap = w.list, *phandle = w.pslot, *vidseg = w.voff;
+    uint32_t *firstmap = w.list, *phandle = w.pslot;
     uint32_t *gpos = reinterpret_cast<uint32_t *>(w.vinfo) + w.npad;
     // look-back words of k_sparse_finish (two per tile of 4096 points) and, behind them, up to 64 pairs of early totals
     const uint32_t ftiles = (uint32_t)(w.npad / kFinTile);
     const uint32_t early_at = (2 * ftiles + 15u) & ~15u;
-    uint32_t early_pairs = 0;
-    if (host)
-        for (early_pairs = 64; early_pairs > 1 && (uint64_t)early_at + 16ull * early_pairs > (uint64_t)(w.npad / 64); early_pairs >>= 1) { }
-    if (host && (uint64_t)early_at + 16ull * early_pairs > (uint64_t)(w.npad / 64)) early_pairs = 0;
+    uint32_t early_pairs = 64;       // (also without a host buffer: k_sparse_finish learns from them that max_voxels cannot cut)
+    for (; early_pairs > 1 && (uint64_t)early_at + 16ull * early_pairs > (uint64_t)(w.npad / 64); early_pairs >>= 1) { }
+    if ((uint64_t)early_at + 16ull * early_pairs > (uint64_t)(w.npad / 64)) early_pairs = 0;
     u64 *early_tot = early_pairs ? w.fwords + early_at : nullptr;
     unsigned int *ticket = w.big_count + 40;
     const size_t lds = ((size_t)1 << tshift) * (sizeof(uint32_t) + 2) + (size_t)nbins * 4;
@@ -4116,7 +4276,7 @@ static int sparse_fused_index(const BoundKey &kf, const float *points, int64_t n
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
         D3D_LAUNCH("k_tile_sort", (k_tile_sort<BoundKey, V4, true, IT>), dim3(((stiles + 7u) >> 3) << 3), dim3(kSortThreads), lds, st, kf, points, \
                    n, c, nbins, stiles, bent, table, tileinfo, phandle, firstmap, sparse_counts, (int64_t *)nullptr,           \
-                   (unsigned char *)nullptr, reinterpret_cast<int32_t *>(vidseg), w.fwords, early_at + 16u * early_pairs, ticket, false); \
+                   (unsigned char *)nullptr, (int32_t *)nullptr, w.fwords, early_at + 16u * early_pairs, ticket, false); \
     } while (0)
     if (big_tiles) D3D_TILE_SORT_B(true, 16);
     else if (tshift == 12) D3D_TILE_SORT_B(true, 4);
@@ -4132,10 +4292,10 @@ static int sparse_fused_index(const BoundKey &kf, const float *points, int64_t n
     if (coord_offset)
         for (int k = 0; k < 3; k++) lb.coord_sub[k] = (long long)coord_offset[k];
     if (vec4)
-        D3D_LAUNCH("k_sparse_finish", k_sparse_finish<true>, dim3(ftiles), dim3(kFinThreads), 0, st, kf, n, firstmap, phandle, vrec, vidseg,
+        D3D_LAUNCH("k_sparse_finish", k_sparse_finish<true>, dim3(ftiles), dim3(kFinThreads), 0, st, kf, n, firstmap, phandle, vrec,
                    points, c, max_voxels, npoints_clamp, out_coords, out_npoints, out_feats, out_mask, out_mapping, sparse_counts, counts, lb);
     else
-        D3D_LAUNCH("k_sparse_finish", k_sparse_finish<false>, dim3(ftiles), dim3(kFinThreads), 0, st, kf, n, firstmap, phandle, vrec, vidseg,
+        D3D_LAUNCH("k_sparse_finish", k_sparse_finish<false>, dim3(ftiles), dim3(kFinThreads), 0, st, kf, n, firstmap, phandle, vrec,
                    points, c, max_voxels, npoints_clamp, out_coords, out_npoints, out_feats, out_mask, out_mapping, sparse_counts, counts, lb);
     return D3D_OK;
 }
@@ -4494,6 +4654,19 @@ static int voxelize_sparse_impl(const float *points, int64_t n, int32_t c, const
     if (!workspace || w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;
     uint32_t nbins = 0;
     int hshift = 0;
+    if (flags & D3D_VOXEL_WIDE_KEYS) {
+        // any int32 coordinates (the caller repeats a call that came back with COORD_OVERFLOW): 96-bit compare in the table
+        WideKey kf;
+        for (int d = 0; d < 3; d++) kf.size[d] = voxel_size[d];
+        TabWide tab{w.tabA, w.aux, w.tabB, points, (int)c, {voxel_size[0], voxel_size[1], voxel_size[2]}};
+        int64_t *first = reinterpret_cast<int64_t *>(w.staged);          // [n] (free on the sparse contract)
+        IndexOpts ow{0u, 0xffffffffu, first, 0, points_mapping, false};
+        int rc = build_index(kf, tab, points, n, c, w, counts, ow, st);
+        if (rc || n == 0) return rc;
+        D3D_LAUNCH("k_wide_coords", k_wide_coords, dim3(grid_for(n, 256, (int64_t)1 << 30)), dim3(256), 0, st, kf, points, (int)c,
+                   (const int64_t *)counts, (const int64_t *)first, (const uint4 *)w.vinfo, coords, npoints);
+        return D3D_OK;
+    }
     if (binned_eligible(n, w, flags, &nbins, &hshift)) {
         // up to 16 M points: partition by hash(cell) and index every bucket in LDS -- the 63-bit cell key itself is the
         // table key there, so no bounding box pass and no packed-slot limits
@@ -4683,7 +4856,7 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
         const bool pf_ok = max_points_filter == D3D_MAXPTS_NONE || (max_points_filter == D3D_MAXPTS_TRIM && max_points > 0);
         const bool vf_ok = max_voxels_filter == D3D_MAXVOX_NONE || max_voxels_filter == D3D_MAXVOX_TRIM ||
                            (desc && points_mapping && coords && npoints);
-        if (pf_ok && vf_ok && n > 0 && c >= 3 && n < (1ll << 31) - kFlagTile && points && voxel_size && coords_bound && counts &&
+        if (!(flags & D3D_VOXEL_WIDE_KEYS) && pf_ok && vf_ok && n > 0 && c >= 3 && n < (1ll << 31) - kFlagTile && points && voxel_size && coords_bound && counts &&
             out_feats && out_mask && out_mapping && out_npoints && out_coords && workspace && max_voxels >= 0) {
             VoxelWs w = carve(workspace, workspace_bytes, n, n);
             if (w.bytes > workspace_bytes) return D3D_ERR_WORKSPACE;

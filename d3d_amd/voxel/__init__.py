@@ -83,6 +83,10 @@ class _NotFused(Exception):
     """the one-call sparse + filter entry does not take this combination here (DESCENDING off the binned index): two calls"""
 
 
+class _CoordOverflow(Exception):
+    """sparse contract: a finite voxel coordinate beyond the 3 x 21-bit key: the call is repeated with the 96-bit table"""
+
+
 class _BinOverflow(Exception):
     """dense contract: a bucket of the binned index outgrew its workgroup: the call is repeated on the hash-table path"""
 
@@ -101,8 +105,7 @@ def _check_status(status, what):
     if status & _lib.STATUS_TABLE_FULL:
         raise RuntimeError("%s: internal hash table overflow" % what)
     if status & _lib.STATUS_COORD_OVERFLOW:
-        raise ValueError("%s: voxel coordinate out of the supported range [-2^20, 2^20) "
-                         "(non-finite point or voxel size too small)" % what)
+        raise _CoordOverflow(what)
 
 
 def _with_retry(run, flags=None):
@@ -110,16 +113,23 @@ def _with_retry(run, flags=None):
     the hash table; a field of the packed one-word hash slot that overflowed (a voxel with > 2^cb points, or -- sparse
     contract -- a bounding box of voxel coordinates too large for the key field) -> once more with two-word slots."""
     flags = options.current().voxel_flags if flags is None else int(flags)     # per call, or the calling context's
-    try:
-        return run(flags)
-    except _BinOverflow:
-        flags |= _lib.VOXEL_PATH_HASH
-    except _PackOverflow:
-        return run(flags | _lib.VOXEL_PLAIN_SLOTS)
-    try:
-        return run(flags)
-    except _PackOverflow:
-        return run(flags | _lib.VOXEL_PLAIN_SLOTS)
+    # every status names the option that lifts its limit; a call may meet several in a row (a frame with NaN points AND far
+    # voxels on the hash path: packed slots -> plain slots -> wide keys), each at most once
+    for _ in range(4):
+        try:
+            return run(flags)
+        except _BinOverflow as e:
+            add, err = _lib.VOXEL_PATH_HASH, e
+        except _PackOverflow as e:
+            add, err = _lib.VOXEL_PLAIN_SLOTS, e
+        except _CoordOverflow as e:
+            # a voxel coordinate beyond (-2^20, 2^20): the reference takes any int (voxelize.cpp:309) -- once more on the table
+            # that compares all three 32-bit coordinates (D3D_VOXEL_WIDE_KEYS)
+            add, err = _lib.VOXEL_WIDE_KEYS, e
+        if flags & add:
+            raise RuntimeError("%s: the index reported a limit that its own option should have lifted" % err)
+        flags |= add
+    raise RuntimeError("voxel index: no path took this frame")
 
 
 _ws_bytes_cache = {}

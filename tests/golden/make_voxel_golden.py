@@ -166,6 +166,21 @@ def main():
     sp = to_np(impl.voxelize_3d_sparse(torch.from_numpy(kc), torch.tensor([0.1, 0.1, 0.1]), 3))
     cases["raw_sparse"] = dict(kind="raw_sparse", cloud=kc, size=np.array([0.1, 0.1, 0.1], np.float32), out=sp)
 
+    # round 5 -- voxel coordinates of ANY size (voxelize.cpp:309 keys a voxel by three ints, whatever they are): +-3e6 cells on
+    # every axis at once (far beyond 3 x 21 bits; together beyond 64), several points per far voxel, far voxels that differ in ONE
+    # coordinate only (in z; in y by one), non-finite points (INT_MIN) next to them
+    cw = c3.copy()
+    far = np.array([[3e5, 3e5, 3e5], [-3e5, -3e5, -3e5], [3e5, -3e5, 2.5e5], [3e5, -3e5, -2.5e5], [2.9e5, 1.0, 3e5], [2.9e5, 1.1, 3e5],
+                    [2.9e5, 1.0, -3e5], [-1.5e5, 2e5, 0.05], [1.2e5, 0.05, 0.05], [0.05, -1.2e5, 0.05]], np.float32)
+    for k in range(60):
+        cw[5 * k, :3] = far[k % len(far)] + (0.01 if k >= 30 else 0.0)        # (0.01 stays inside the far cell at 0.1 m)
+    cw[7, 0], cw[13, 1], cw[19, :3] = np.nan, np.inf, np.nan
+    spw = to_np(impl.voxelize_3d_sparse(torch.from_numpy(cw), torch.tensor([0.1, 0.1, 0.1]), 3))
+    cases["raw_sparse_wide"] = dict(kind="raw_sparse", cloud=cw, size=np.array([0.1, 0.1, 0.1], np.float32), out=spw)
+    # ... and through the generator, its coordinate bounds reaching that far (so the far voxels are KEPT by the filter)
+    sparse_case("sp_wide", cw, [-3.2e5, 3.2e5, -3.2e5, 3.2e5, -3.2e5, 3.2e5], [6400000, 6400000, 6400000], max_points=3,
+                max_points_filter="trim", min_points=1)
+
     flat = {}
     import json
     meta = {}

@@ -85,9 +85,13 @@ def test_sparse_matches_reference(name):
         check_sparse(ret, c["out"])
 
 
-def test_raw_sparse_function():
+@pytest.mark.parametrize("name", ["raw_sparse", "raw_sparse_wide"])
+def test_raw_sparse_function(name):
+    """raw_sparse_wide (round 5): voxel coordinates of +-3e6 cells on every axis -- beyond the 3 x 21-bit key: the call comes
+    back with COORD_OVERFLOW and is repeated on the table that compares all 96 bits (D3D_VOXEL_WIDE_KEYS); same voxels, ids and
+    counts as the compiled reference, INT_MIN voxels of the non-finite points included"""
     from d3d_amd.voxel import voxelize_3d_sparse
-    c = CASES["raw_sparse"]
+    c = CASES[name]
     r = _np(voxelize_3d_sparse(torch.from_numpy(c["cloud"]).cuda(), torch.from_numpy(c["size"]), 3))
     for k in ["points_mapping", "coords", "voxel_npoints"]:
         assert np.array_equal(r[k], c["out"][k]) and r[k].dtype == c["out"][k].dtype
@@ -197,9 +201,9 @@ def test_all_points_in_one_voxel_and_errors():
     assert exp["coords"].min() == -2147483648 and len(exp["coords"]) == 3
     ret = VoxelGenerator(unit, [10, 10, 10])(torch.from_numpy(bad).cuda())
     assert ret.points_mask.tolist() == [1] and ret.coords.tolist() == [[5, 5, 5]] and ret.points_mapping.tolist() == [0]
-    far = torch.tensor([[2.0e5, 0, 0, 0], [0.5, 0.5, 0.5, 1]]).cuda()            # coordinate 2e6 > 2^20
-    with pytest.raises(ValueError):
-        voxelize_3d_sparse(far, [0.1, 0.1, 0.1])
+    far = torch.tensor([[2.0e5, 0, 0, 0], [0.5, 0.5, 0.5, 1]]).cuda()            # coordinate 2e6 > 2^20: any int is a voxel
+    got = voxelize_3d_sparse(far, [0.1, 0.1, 0.1])                               # (voxelize.cpp:309; ValueError until round 5)
+    assert got["coords"].tolist() == [[2000000, 0, 0], [5, 5, 5]] and got["points_mapping"].tolist() == [0, 1]
     ret = VoxelGenerator(unit, [10, 10, 10])(far)
     assert ret.points_mask.tolist() == [1] and ret.coords.tolist() == [[5, 5, 5]]
 

@@ -56,8 +56,10 @@ def test_oracle_sparse_matches_reference(name):
     check_sparse(gen(c["cloud"]), c["out"], descending=kw.get("max_voxels_filter") == "descending")
 
 
-def test_oracle_raw_sparse():
-    c = CASES["raw_sparse"]
+@pytest.mark.parametrize("name", ["raw_sparse", "raw_sparse_wide"])
+def test_oracle_raw_sparse(name):
+    """(raw_sparse_wide: voxel coordinates of +-3e6 cells on every axis, voxels that differ in one coordinate only, INT_MIN)"""
+    c = CASES[name]
     r = oracle.voxelize_3d_sparse(c["cloud"], c["size"], 3)
     for k in ["points_mapping", "coords", "voxel_npoints"]:
         assert np.array_equal(r[k], c["out"][k]) and r[k].dtype == c["out"][k].dtype

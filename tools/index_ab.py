@@ -1,6 +1,7 @@
 """A/B of the binned index's bucket kernel on ONE box in ONE call: round 5's (packed first-point entries, dense cells ranked by one
 wavefront) against round 4's (D3D_VOXEL_INDEX_V1), alternating, per-kernel HIP-event times.
 usage (GPU box): python tools/index_ab.py [steps] [n ...]"""
+import os
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -18,7 +19,10 @@ for n in sizes:
             "dense-none": VoxelGenerator(bounds, shape, dense=True, max_points=32, max_voxels=n),
             "sparse+trim": VoxelGenerator(bounds, shape, max_points=32, max_voxels=n, max_points_filter="trim"),
             "sparse": VoxelGenerator(bounds, shape, max_voxels=n)}
+    only = os.environ.get("AB_MODES")
     for mode, gen in gens.items():
+        if only and mode not in only.split(","):
+            continue
         for rep in range(3):
             for name, fl in (("r5", 0), ("v1", _lib.VOXEL_INDEX_V1)):
                 dt = bench.timed(lambda: gen(cloud, flags=fl), steps, 3)
