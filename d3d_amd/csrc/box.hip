@@ -13,6 +13,7 @@
 //    "IoU > thr" bit matrix + a sweep of the sorted order (nms_cuda.cu:80-107 runs that on ONE thread) -- is kept as
 //    the dense path behind a device-side flag.
 #include "common.hpp"
+#include <chrono>
 #include "geom.hpp"
 #include "lds_sort.hpp"
 #include <stdlib.h>
@@ -1902,13 +1903,20 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_small(uint32_t n, const ui
 // clustered calls always get them: no history, no first-call cliff, nothing shared between callers.  (Rounds 2-3 kept a
 // process-wide streak counter + one mapped word for all devices, streams and threads; gone.)  Without the word -- plain
 // d3d_nms2d, or a stream under capture -- the levels are always launched.
+// The wait is bounded by WALL-CLOCK time (an iteration count depends on the host's speed, and with a backlog on the
+// stream -- a model's forward pass in front of the NMS -- the host would burn a core for all of it): after kNmsWaitUs the verdict
+// counts as "dense" and the ten level launches are enqueued unasked (~20 us of empty launches when the grid turns out sparse;
+// every level kernel tests the density on the device, so the keep mask does not depend on what the host saw).  A verdict that
+// arrives late lands in the caller's word, which the next call re-arms before it launches anything.
+constexpr long kNmsWaitUs = 400;
 static bool nms_wait_dense(volatile int *host_word, hipStream_t st)
 {
-    for (long spins = 0; *host_word == 0; spins++)
-        if (spins > (1l << 26)) {                           // (~ a second: something is wrong -- drain the stream, which also
-            if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();     //  surfaces the error to the caller's next check)
-            break;
-        }
+    (void)st;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 1; *host_word == 0; spins++)
+        if ((spins & 255) == 0 &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kNmsWaitUs)
+            return true;
     return *host_word != 1;                                 // 2 = dense; unknown counts as dense
 }
 

@@ -339,21 +339,31 @@ def voxelize_3d_filter(feats, points_mapping, coords, voxel_npoints, coords_boun
 
 # Output buffers of the NEXT sparse + filter call, allocated while the current one waits for its output sizes: the GPU-side
 # work behind the size notification (the compaction, ~20 us) is shorter than the host's per-call work (six allocations, the
-# launches), so the next frame's first kernel used to wait for the host.  One set per thread, only for a repeat of the same
-# shape, handed over to the caller whole (the cache keeps no reference to buffers it has given out).
+# launches), so the next frame's first kernel used to wait for the host.  One set per thread, handed over to the caller whole
+# (the cache keeps no reference to buffers it has given out) and at most ONE call old: a set the next call does not take is
+# dropped there.  Keyed by CAPACITY: real frames differ in size from call to call, so the set is sized for the
+# frame's point count rounded up to 64 k and serves any frame of that size class (the outputs are views of its first n rows).
 _spare = threading.local()
+_SPARE_ROUND = 1 << 16
 
 
-def _spare_take(key, make):
+def _spare_cap(n):
+    return -(-max(int(n), 1) // _SPARE_ROUND) * _SPARE_ROUND
+
+
+def _spare_take(key, n, make):
+    """-> (capacity, buffers) for n points"""
     got = getattr(_spare, "set", None)
     _spare.set = None
-    if got is not None and got[0] == key:
-        return got[1]
-    return make()
+    cap = _spare_cap(n)
+    if got is not None and got[0] == key and n <= got[1] <= 2 * cap:
+        return got[1], got[2]
+    return cap, make(cap)
 
 
-def _spare_put(key, make):
-    _spare.set = (key, make())
+def _spare_put(key, n, make):
+    cap = _spare_cap(n)
+    _spare.set = (key, cap, make(cap))
 
 
 def release_cached_buffers():
@@ -376,17 +386,18 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
     n, c = pts.shape
     if c < 3:
         raise RuntimeError("points need at least 3 columns (x, y, z)")
-    bound_h = (ctypes.c_int64 * 6)(*[int(x) for x in _as_tensor(vbounds).reshape(-1).tolist()])
+    bound_h = vbounds if isinstance(vbounds, ctypes.Array) else \
+        (ctypes.c_int64 * 6)(*[int(x) for x in _as_tensor(vbounds).reshape(-1).tolist()])
     with _device_ctx(dev):
         # the intermediate sparse outputs (only materialised when the call falls back to the two-operator form) and the two
         # count rows: slices of ONE scratch tensor -- every torch.empty costs the host a few microseconds per call
-        def make():
-            return (torch.empty((n * 9 + 4 * _lib.NUM_COUNTS + 8,), dtype=torch.int32, device=dev),
-                    torch.empty((n, c), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.int64, device=dev),
-                    torch.empty((n,), dtype=torch.int64, device=dev), torch.empty((n,), dtype=torch.int32, device=dev),
-                    torch.empty((n, 3), dtype=torch.int64, device=dev))
-        key = (dev, n, c, torch.cuda.current_stream().cuda_stream)
-        scratch, o_feats, o_mask, o_map, o_cnt, o_crd = _spare_take(key, make)
+        def make(m):
+            return (torch.empty((m * 9 + 4 * _lib.NUM_COUNTS + 8,), dtype=torch.int32, device=dev),
+                    torch.empty((m, c), dtype=torch.float32, device=dev), torch.empty((m,), dtype=torch.int64, device=dev),
+                    torch.empty((m,), dtype=torch.int64, device=dev), torch.empty((m,), dtype=torch.int32, device=dev),
+                    torch.empty((m, 3), dtype=torch.int64, device=dev))
+        key = (dev, c, _lib.stream_raw())
+        _, (scratch, o_feats, o_mask, o_map, o_cnt, o_crd) = _spare_take(key, n, make)
         counts = scratch[:4 * _lib.NUM_COUNTS].view(torch.int64).view(2, _lib.NUM_COUNTS)
         base = 4 * _lib.NUM_COUNTS
         mapping = scratch[base:base + 2 * n].view(torch.int64)
@@ -408,7 +419,7 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
             if rc == _lib.ERR_UNSUPPORTED and vf == MaxVoxelsFilterType.DESCENDING:
                 raise _NotFused()
             _lib.check(rc, "voxelize_3d_sparse + voxelize_3d_filter")
-            _spare_put(key, make)         # the next call's buffers, while this one's sizes are on their way
+            _spare_put(key, n, make)      # the next call's buffers, while this one's sizes are on their way
             host = note.wait(counts)      # the one host read of the pair, while the kept points are still being compacted
             _check_status(int(host[_lib.COUNT_STATUS]), "voxelize_3d_sparse")
             return int(host[_lib.NUM_COUNTS + _lib.COUNT_POINTS]), int(host[_lib.NUM_COUNTS + _lib.COUNT_VOXELS])
@@ -457,6 +468,7 @@ class VoxelGenerator:
         self._bounds_h = _host_array(self._bounds, ctypes.c_float, 6)
         self._size_h = _host_array(self._size, ctypes.c_float, 3)
         self._offset_h = (ctypes.c_int64 * 3)(*[int(v) for v in self._offset.tolist()])
+        self._vbounds_h = (ctypes.c_int64 * 6)(*[int(v) for v in self._vbounds.reshape(-1).tolist()])
 
         red = (reduction or "NONE").upper()
         if red != "NONE" and not dense:
@@ -512,7 +524,7 @@ class VoxelGenerator:
             ret = None
             if points.shape[0] > 0:
                 try:    # (the offset of :103 is subtracted inside the call, where the coords are written)
-                    ret = Dict(_sparse_filter_chained(points, self._size_h, self._vbounds, self._min_points, self._max_points,
+                    ret = Dict(_sparse_filter_chained(points, self._size_h, self._vbounds_h, self._min_points, self._max_points,
                                                       self._max_voxels, pf, vf, flags=flags, offset_h=self._offset_h))
                 except _NotFused:
                     pass

@@ -135,4 +135,4 @@ def test_bucket_kernel_keeps_its_first_point_store_separate(tmp_path):
     v2 = {k: v for k, v in scoped.items() if "Lb1EEE" in k.split("vT_")[0]}
     v1 = {k: v for k, v in scoped.items() if k not in v2}
     assert len(v1) == 6 and set(v1.values()) == {8}, scoped
-    assert len(v2) == 1 and set(v2.values()) == {9}, scoped
+    assert len(v2) == 2 and set(v2.values()) == {9}, scoped            # (DenseKey: the index for k_emit; BoundKey: for k_sparse_finish)
