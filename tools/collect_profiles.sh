@@ -1,19 +1,48 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/collect_profiles.sh <tag>
-# bench line, rocprofv3 kernel stats and the PMC passes (FETCH_SIZE / WRITE_SIZE in SEPARATE runs with --kernel-trace only,
-# as MI355X_MICROARCH.md prescribes) for config 2 and for config 5's frame on one GPU
-# -> gpurun_out/<tag>/ ; tools/summarize_pmc.py turns the PMC passes into profiles/<tag>_pmc_*.csv + profiles/traffic.json
+# usage (on the GPU box, from the repo root): bash tools/collect_profiles.sh <tag> [commit]
+# One collection = the bench line + rocprofv3 kernel stats of EXACTLY the three workloads the line's legs run -- config 2 alone
+# (bench.py --skip-cpu --skip-extra --skip-large), the large frame (--large-only), the sparse operator (--sparse-only) -- + the PMC
+# passes of each (FETCH_SIZE / WRITE_SIZE in SEPARATE runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes) + the SQ
+# counters of k_bucket_index (LDS bank conflicts) -> gpurun_out/<tag>/ ;
+# tools/summarize_pmc.py then writes profiles/<tag>_*_pmc_summary.csv + profiles/traffic.json (with the commit).
 set -u
-tag=${1:-r03}
+tag=${1:-r05}
+commit=${2:-unknown}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
+echo "$commit" > $out/commit.txt
 python3 bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --skip-cpu --skip-large > $out/bench_prof.json 2> $out/prof.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_large -o large -- python3 $GRAFT_REPO_ROOT/bench.py --large-only > $out/large_prof.json 2> $out/prof_large.err
+B=$GRAFT_REPO_ROOT/bench.py
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg2 -o cfg2 -- python3 $B --skip-cpu --skip-extra --skip-large > $out/cfg2_prof.json 2> $out/prof_cfg2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_large -o large -- python3 $B --large-only > $out/large_prof.json 2> $out/prof_large.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_sparse -o sparse -- python3 $B --sparse-only --steps 50 --warmup 5 > $out/sparse_prof.json 2> $out/prof_sparse.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${c}_sparse -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --sparse-only --steps 5 --warmup 2 > /dev/null 2> $out/pmc_${c}_sparse.err
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${c}_cfg2 -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --skip-cpu --skip-extra --skip-large --steps 5 --warmup 2 > /dev/null 2> $out/pmc_${c}_cfg2.err
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${c}_large -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --large-only > /dev/null 2> $out/pmc_${c}_large.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${c}_sparse -o pmc -- python3 $B --sparse-only --steps 5 --warmup 2 > /dev/null 2> $out/pmc_${c}_sparse.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${c}_cfg2 -o pmc -- python3 $B --skip-cpu --skip-extra --skip-large --steps 5 --warmup 2 > /dev/null 2> $out/pmc_${c}_cfg2.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${c}_large -o pmc -- python3 $B --large-only > /dev/null 2> $out/pmc_${c}_large.err
 done
-find $out -name "*.csv" | head -40
+for c in SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/sq_$c -o pmc -- python3 $B --skip-cpu --skip-extra --skip-large --steps 5 --warmup 2 > /dev/null 2> $out/sq_$c.err
+done
+python3 - $out <<'PY' > $out/sq_bucket_index.txt
+import csv, glob, os, sys
+out = sys.argv[1]
+vals = {}
+for c in ("SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
+    for kern in ("k_bucket_index", "k_tile_sort", "k_emit"):
+        tot, n = 0.0, 0
+        for f in glob.glob(os.path.join(out, "sq_" + c, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kern + "<" in row["Kernel_Name"] or kern + "(" in row["Kernel_Name"]:
+                    if row["Counter_Name"] == c:
+                        tot += float(row["Counter_Value"]); n += 1
+        vals[(kern, c)] = tot / max(n, 1)
+        print("%-16s %-24s launches %4d  mean per launch %.0f" % (kern, c, n, tot / max(n, 1)))
+for kern in ("k_bucket_index", "k_tile_sort", "k_emit"):
+    a = vals.get((kern, "SQ_ACTIVE_INST_LDS"), 0)
+    if a:
+        print("%-16s SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = %.3f" % (kern, vals[(kern, "SQ_LDS_BANK_CONFLICT")] / a))
+PY
+cat $out/sq_bucket_index.txt
+find $out -name "*stats*.csv" | head -20

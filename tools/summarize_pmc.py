@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected in SEPARATE runs, as
 MI355X_MICROARCH.md prescribes) into per-kernel HBM bytes per launch.
 
-    python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag> [workload]
+    python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag> [workload] [commit]
 
 Corrections applied (MI355X_MICROARCH.md, HBM section): the counters are in KiB; on gfx950 FETCH_SIZE reports half of
 the bytes of a wide coalesced read stream, so fetch is doubled (an upper bound for narrow/random accesses, which the
@@ -46,6 +46,7 @@ def load(path, counter):
 def main():
     fetch_csv, write_csv, tag = sys.argv[1:4]
     workload = sys.argv[4] if len(sys.argv) > 4 else "config2"
+    commit = sys.argv[5] if len(sys.argv) > 5 else None
     fe, wr = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     rows, traffic = [], {}
     for k in sorted(set(fe) | set(wr)):
@@ -67,7 +68,7 @@ def main():
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     allt = json.load(open(tj)) if os.path.exists(tj) else {}
     allt[workload] = traffic
-    allt["_profile"] = tag
+    allt["_profile"] = tag if not commit else "%s @ commit %s" % (tag, commit)
     json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
     print(open(out).read())
 
