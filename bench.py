@@ -453,6 +453,17 @@ def extras(args):
             tf += t1 - t0; tb += t2 - t1
         proto[str(n_p)] = dict(forward_ms=round(1e3 * tf / rep, 4), backward_ms=round(1e3 * tb / rep, 4))   # the first n = 1 round
     ex["reference_riou_protocol_ms"] = proto                                                               # is the warm-up
+    # ALU rooflines of the clip-bound kernels: VALU counters cannot be read from inside this process, so the
+    # figures are those of the committed rocprofv3 --pmc collection (tools/alu_roofline.sh -> profiles/alu_roofline.json)
+    try:
+        alu = json.load(open(os.path.join(ROOT, "profiles", "alu_roofline.json")))
+        ex["roofline_alu"] = {
+            k: dict(bound="valu_fp64", achieved=v["achieved_Tlaneops"], peak_fp64=v["peak_fp64_Tlaneops"], unit="T lane-operations/s",
+                    frac=v["frac"], valu_busy=v["valu_busy"], valu_insts_per_wave=v["valu_insts_per_wave"], avg_us=v["duration_us"],
+                    source="profiles/alu_roofline.json (%s)" % alu.get("_profile", "unlabelled"))
+            for k, v in alu.items() if isinstance(v, dict) and "frac" in v}
+    except Exception:
+        ex["roofline_alu"] = None
     from d3d_amd.box import pdist2dr_forward
     pts2 = torch.rand((1000000, 2), dtype=torch.float32, device="cuda") * 3000
     bx32 = bl[:2000].to(torch.float32)
