@@ -2310,7 +2310,8 @@ static unsigned long long iou_list_capacity(int64_t n, int64_t m)
 }
 
 // boxloss.hip
-int d3d_internal_loss_iou_forward(const void *b1, int64_t n, const void *b2, int64_t m, int kind, int dtype, void *out, hipStream_t st);
+int d3d_internal_loss_iou_forward(const void *b1, int64_t n, const void *b2, int64_t m, int kind, int dtype, void *out, void *ws,
+                                  size_t ws_bytes, unsigned long long list_cap, hipStream_t st);
 int d3d_internal_loss_iou_backward(const void *b1, int64_t n, const void *b2, int64_t m, const void *grad, int kind, int dtype,
                                    void *g1, void *g2, hipStream_t st);
 
@@ -2319,7 +2320,8 @@ extern "C" size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype)
     if (n < 1) n = 1;
     if (m < 1) m = 1;
     const size_t g = dtype == D3D_F64 ? sizeof(BoxGeom<double>) : sizeof(BoxGeom<float>);
-    return d3d_align_up(g * n) + d3d_align_up(g * m) + d3d_align_up(16 * n) + d3d_align_up(16 * m) + d3d_align_up(sizeof(IouList)) + d3d_align_up(8 * iou_list_capacity(n, m)) +
+    // 64 bytes per box instead of the 16 of the candidate boxes: GRBOX keeps its per-box hull terms there (boxloss.hip, HullPre)
+    return d3d_align_up(g * n) + d3d_align_up(g * m) + d3d_align_up(64 * n) + d3d_align_up(64 * m) + d3d_align_up(sizeof(IouList)) + d3d_align_up(8 * iou_list_capacity(n, m)) +
            256;
 }
 
@@ -2365,8 +2367,13 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX && !loss_kind) return D3D_ERR_UNSUPPORTED;
     if (n == 0 || m == 0) return D3D_OK;
     if (!boxes1 || !boxes2 || !ious) return D3D_ERR_BAD_ARG;
-    if (loss_kind)          // GIoU / DIoU: every pair has a value (boxloss.hip)
-        return d3d_internal_loss_iou_forward(boxes1, n, boxes2, m, iou_type == D3D_IOU_GRBOX ? 0 : 1, dtype, ious, st);
+    if (loss_kind) {        // GIoU / DIoU: every pair has a value (boxloss.hip); GIoU lists the pairs that need the clip
+        const bool use_ws = workspace && workspace_bytes >= d3d_iou2d_workspace_bytes(n, m, dtype) && n < (1ll << 32) && m < (1ll << 32);
+        unsigned long long cap = iou_list_capacity(n, m);
+        if ((flags >> 8) != 0 && (unsigned long long)(flags >> 8) < cap) cap = flags >> 8;        // D3D_IOU_LIST_CAP
+        return d3d_internal_loss_iou_forward(boxes1, n, boxes2, m, iou_type == D3D_IOU_GRBOX ? 0 : 1, dtype, ious,
+                                             use_ws ? workspace : nullptr, use_ws ? workspace_bytes : 0, cap, st);
+    }
     const int64_t gy = d3d_divup(n, kTileRows);
     if (gy > 65535 || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;   // callers tile above that
     const bool rot = iou_type == D3D_IOU_RBOX;

@@ -33,24 +33,152 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
+// GIoU of one pair by the complete routine (clip + hull with the tie rules), out of line: what the forward-only hull defers
+template <typename T> __device__ __noinline__ T giou_complete(const BoxGeom<T> &a, const BoxGeom<T> &b)
+{
+    T da[5], db[5];
+    return loss_iou_rbox<T, 0, false>(a, b, (T)0, (T)0, (T)0, (T)0, da, db);       // forward: the sizes are not read
+}
+
 // ---------------------------------------------------------------- GIoU / DIoU forward
 template <typename T, int KIND>
 __global__ __launch_bounds__(kCols) void k_loss_iou(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
-                                                    T *__restrict__ out)
+                                                    T *__restrict__ out, const unsigned int *only_if = nullptr)
 {
+    if (only_if && !*only_if) return;                  // the redo after a list overflow of k_giou_main: nothing to do otherwise
     __shared__ RowBox<T> rows[kRows];
+    __shared__ HullPre<T> hulls[KIND == 0 ? kRows : 1];
     const int64_t i0 = (int64_t)blockIdx.y * kRows, j = (int64_t)blockIdx.x * kCols + threadIdx.x;
     const int nrows = (int)((n - i0) < kRows ? (n - i0) : kRows);
-    if (threadIdx.x < nrows) rows[threadIdx.x] = load_row<T>(b1 + (i0 + threadIdx.x) * 5);
+    if (threadIdx.x < nrows) {
+        const RowBox<T> r = load_row<T>(b1 + (i0 + threadIdx.x) * 5);
+        rows[threadIdx.x] = r;
+        if (KIND == 0) hulls[threadIdx.x] = hull_pre<T>(r.g);
+    }
     __syncthreads();
     if (j >= m) return;
     const RowBox<T> c = load_row<T>(b2 + j * 5);
     T *o = out + i0 * m + j;
+    if (KIND == 0) {                                   // GIoU: the forward-only hull where it applies (geom.hpp, giou_rbox_apart)
+        const HullPre<T> hc = hull_pre<T>(c.g);
+        for (int r = 0; r < nrows; r++) {
+            bool defer;
+            T v = giou_rbox_apart<T>(rows[r].g, hulls[r], c.g, hc, defer);
+            if (__any(defer)) {                        // a pair that needs the clip or the tie rules: the complete routine
+                const T full = giou_complete<T>(rows[r].g, c.g);
+                v = defer ? full : v;
+            }
+            __builtin_nontemporal_store(v, o);
+            o += m;
+        }
+        return;
+    }
     T ga[5], gb[5];
     for (int r = 0; r < nrows; r++) {
         const RowBox<T> a = rows[r];
         __builtin_nontemporal_store((loss_iou_rbox<T, KIND, false>(a.g, c.g, a.w, a.h, c.w, c.h, ga, gb)), o);
         o += m;
+    }
+}
+
+// ---------------------------------------------------------------- GIoU forward in two kernels (round 5)
+// Almost every pair of a large matrix is two boxes apart from each other: its value needs the hull only, and the hull in the
+// forward-only form of geom.hpp (hull_area2_clear) is ~280 vector + ~190 scalar instructions on 97 VGPRs.  The clip for the
+// pairs whose bounding boxes overlap and the tie rules for the pairs with a corner on an edge line cost 160+ VGPRs and a
+// call -- kept in the same kernel they took the occupancy of ALL pairs from 4-5 wavefronts per SIMD to 1.1 (scratch for the call;
+// MeanOccupancyPerCU 4.6 -> 13.6 without them).  So k_giou_main computes the pairs that need neither and LISTS the others,
+// k_giou_fix computes the listed pairs, one per lane, with the complete routine (loss_iou_rbox: same code as the single-kernel
+// path and as before this round).  A list that overflows raises a flag and the single-kernel path redoes the matrix.
+struct FixList { unsigned long long count; unsigned int overflow, pad; };
+constexpr int kFixBatch = 256;
+
+// geometry of both box sets, once per box (the sine / cosine routines stay out of the pair kernel), and the list header reset
+template <typename T>
+__global__ __launch_bounds__(256) void k_giou_geom(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
+                                                   BoxGeom<T> *__restrict__ ga, HullPre<T> *__restrict__ ha, BoxGeom<T> *__restrict__ gb,
+                                                   HullPre<T> *__restrict__ hb, FixList *hdr)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) { hdr->count = 0; hdr->overflow = 0; }
+    if (t >= n + m) return;
+    const T *b = t < n ? b1 + t * 5 : b2 + (t - n) * 5;
+    const BoxGeom<T> g = make_geom<T>(b[0], b[1], b[2], b[3], b[4]);
+    if (t < n) { ga[t] = g; ha[t] = hull_pre<T>(g); }
+    else { gb[t - n] = g; hb[t - n] = hull_pre<T>(g); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kCols) void k_giou_main(const BoxGeom<T> *__restrict__ ga, const HullPre<T> *__restrict__ ha, int64_t n,
+                                                     const BoxGeom<T> *__restrict__ gb, const HullPre<T> *__restrict__ hb, int64_t m,
+                                                     T *__restrict__ out, FixList *hdr, unsigned long long *__restrict__ list,
+                                                     unsigned long long cap)
+{
+    __shared__ BoxGeom<T> rows[kRows];
+    __shared__ HullPre<T> hulls[kRows];
+    __shared__ unsigned int batch[kCols / 64][kFixBatch];       // (row << 16 | local column)
+    __shared__ unsigned int wcnt[kCols / 64];
+    __shared__ unsigned long long bbase;
+    const int64_t i0 = (int64_t)blockIdx.y * kRows, jb = (int64_t)blockIdx.x * kCols, j = jb + threadIdx.x;
+    const int nrows = (int)((n - i0) < kRows ? (n - i0) : kRows);
+    if (threadIdx.x < nrows) { rows[threadIdx.x] = ga[i0 + threadIdx.x]; hulls[threadIdx.x] = ha[i0 + threadIdx.x]; }
+    const bool valid = j < m;
+    const BoxGeom<T> c = gb[valid ? j : m - 1];
+    const HullPre<T> hc = hb[valid ? j : m - 1];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int *q = batch[wave];
+    unsigned int wn = 0;                                          // wave-uniform fill of the batch
+    auto write_out = [&](unsigned long long base) {
+        __builtin_amdgcn_wave_barrier();          // LDS ops of one wavefront complete in order: no s_barrier needed
+        for (unsigned int t = lane; t < wn; t += 64) {
+            const unsigned int e = q[t];
+            if (base + t < cap) list[base + t] = ((unsigned long long)(i0 + (e >> 16)) << 32) | (unsigned long long)(jb + (e & 0xffffu));
+            else hdr->overflow = 1;
+        }
+        wn = 0;
+    };
+    T *o = out + i0 * m + j;
+    for (int r = 0; r < nrows; r++) {
+        bool defer;
+        const T v = giou_rbox_apart<T>(rows[r], hulls[r], c, hc, defer);
+        if (valid) __builtin_nontemporal_store(v, o);
+        o += m;
+        const unsigned long long mask = __ballot(defer && valid);
+        if (mask) {
+            const unsigned int cnt = (unsigned int)__popcll(mask);
+            if (wn + cnt > (unsigned int)kFixBatch) {             // batch full: the wavefront reserves
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&hdr->count, (unsigned long long)wn);
+                write_out(__shfl(base, 0, 64));
+            }
+            if (defer && valid) q[wn + __popcll(mask & ((1ull << lane) - 1))] = ((unsigned)r << 16) | (unsigned)threadIdx.x;
+            wn += cnt;
+        }
+    }
+    // what is left in the four batches: ONE atomic per workgroup (same-address atomics are serialised, box.hip k_iou_pre)
+    if (lane == 0) wcnt[wave] = wn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        bbase = total ? atomicAdd(&hdr->count, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = bbase;
+    for (int w = 0; w < wave; w++) base += wcnt[w];
+    write_out(base);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_giou_fix(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb, int64_t m,
+                                                  T *__restrict__ out, const FixList *hdr, const unsigned long long *__restrict__ list,
+                                                  unsigned long long cap)
+{
+    const unsigned long long cnt = hdr->count, total = cnt < cap ? cnt : cap;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long e = list[k];
+        const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
+        const BoxGeom<T> a = ga[i], b = gb[j];
+        out[i * m + j] = giou_complete<T>(a, b);
     }
 }
 
@@ -291,11 +419,30 @@ __global__ __launch_bounds__(kCols) void k_pdist_grad(const T *__restrict__ poin
 }
 
 template <typename T>
-int loss_forward(const T *b1, int64_t n, const T *b2, int64_t m, int kind, T *out, hipStream_t st)
+int loss_forward(const T *b1, int64_t n, const T *b2, int64_t m, int kind, T *out, void *ws, size_t ws_bytes, unsigned long long list_cap,
+                 hipStream_t st)
 {
     const dim3 grid((unsigned)d3d_divup(m, kCols), (unsigned)d3d_divup(n, kRows));
-    if (kind == 0) D3D_LAUNCH("k_loss_iou<giou>", (k_loss_iou<T, 0>), grid, dim3(kCols), 0, st, b1, n, b2, m, out);
-    else D3D_LAUNCH("k_loss_iou<diou>", (k_loss_iou<T, 1>), grid, dim3(kCols), 0, st, b1, n, b2, m, out);
+    const unsigned int *no_gate = nullptr;
+    if (kind == 0 && ws && (int64_t)n * m > 65536) {              // GIoU of a matrix: two kernels (above)
+        WsCarver w(ws, ws_bytes);
+        BoxGeom<T> *ga = w.take<BoxGeom<T>>(n);
+        BoxGeom<T> *gb = w.take<BoxGeom<T>>(m);
+        HullPre<T> *ha = w.take<HullPre<T>>(n);
+        HullPre<T> *hb = w.take<HullPre<T>>(m);
+        FixList *hdr = w.take<FixList>(1);
+        unsigned long long *list = w.take<unsigned long long>(list_cap);
+        if (w.ok() && list_cap > 0) {
+            D3D_LAUNCH("k_giou_geom", k_giou_geom<T>, dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, b2, m, ga, ha, gb, hb, hdr);
+            D3D_LAUNCH("k_giou_main", k_giou_main<T>, grid, dim3(kCols), 0, st, (const BoxGeom<T> *)ga, (const HullPre<T> *)ha, n,
+                       (const BoxGeom<T> *)gb, (const HullPre<T> *)hb, m, out, hdr, list, list_cap);
+            D3D_LAUNCH("k_giou_fix", k_giou_fix<T>, dim3(256 * 8), dim3(256), 0, st, ga, gb, m, out, hdr, list, list_cap);
+            D3D_LAUNCH("k_loss_iou<giou>", (k_loss_iou<T, 0>), grid, dim3(kCols), 0, st, b1, n, b2, m, out, (const unsigned int *)&hdr->overflow);
+            return D3D_OK;
+        }
+    }
+    if (kind == 0) D3D_LAUNCH("k_loss_iou<giou>", (k_loss_iou<T, 0>), grid, dim3(kCols), 0, st, b1, n, b2, m, out, no_gate);
+    else D3D_LAUNCH("k_loss_iou<diou>", (k_loss_iou<T, 1>), grid, dim3(kCols), 0, st, b1, n, b2, m, out, no_gate);
     return D3D_OK;
 }
 
@@ -313,11 +460,15 @@ int loss_backward(const T *b1, int64_t n, const T *b2, int64_t m, const T *grad,
 }  // namespace
 
 // called by d3d_iou2d_forward / d3d_iou2d_backward (box.hip) for iou_type GRBOX / DRBOX
-int d3d_internal_loss_iou_forward(const void *b1, int64_t n, const void *b2, int64_t m, int kind, int dtype, void *out, hipStream_t st)
+// workspace (optional; GIoU only): geometry of both box sets, the list header, `list_cap` 8-byte entries -- a prefix of what
+// d3d_iou2d_workspace_bytes(n, m, dtype) sizes for the candidate list of RBOX (box.hip)
+int d3d_internal_loss_iou_forward(const void *b1, int64_t n, const void *b2, int64_t m, int kind, int dtype, void *out, void *ws,
+                                  size_t ws_bytes, unsigned long long list_cap, hipStream_t st)
 {
     if (d3d_divup(n, kRows) > 65535) return D3D_ERR_BAD_ARG;
-    if (dtype == D3D_F64) return loss_forward<double>((const double *)b1, n, (const double *)b2, m, kind, (double *)out, st);
-    return loss_forward<float>((const float *)b1, n, (const float *)b2, m, kind, (float *)out, st);
+    if (dtype == D3D_F64)
+        return loss_forward<double>((const double *)b1, n, (const double *)b2, m, kind, (double *)out, ws, ws_bytes, list_cap, st);
+    return loss_forward<float>((const float *)b1, n, (const float *)b2, m, kind, (float *)out, ws, ws_bytes, list_cap, st);
 }
 
 int d3d_internal_loss_iou_backward(const void *b1, int64_t n, const void *b2, int64_t m, const void *grad, int kind, int dtype,
