@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_giou_geom(const T *__restrict__ b1, int
 }
 
 template <typename T>
-__global__ __launch_bounds__(kCols) void k_giou_main(const BoxGeom<T> *__restrict__ ga, const HullPre<T> *__restrict__ ha, int64_t n,
+__global__ __launch_bounds__(kCols) __attribute__((amdgpu_waves_per_eu(4))) void k_giou_main(const BoxGeom<T> *__restrict__ ga, const HullPre<T> *__restrict__ ha, int64_t n,
                                                      const BoxGeom<T> *__restrict__ gb, const HullPre<T> *__restrict__ hb, int64_t m,
                                                      T *__restrict__ out, FixList *hdr, unsigned long long *__restrict__ list,
                                                      unsigned long long cap)
@@ -137,11 +137,13 @@ __global__ __launch_bounds__(kCols) void k_giou_main(const BoxGeom<T> *__restric
         }
         wn = 0;
     };
-    T *o = out + i0 * m + j;
+    // lanes past the last column work on the last column once more and store the same value there: a store under `valid` would
+    // take the whole computation under that branch with it, behind ALL the side tests (whose results then all wait in SGPRs)
+    T *o = out + i0 * m + (valid ? j : m - 1);
     for (int r = 0; r < nrows; r++) {
         bool defer;
         const T v = giou_rbox_apart<T>(rows[r], hulls[r], c, hc, defer);
-        if (valid) __builtin_nontemporal_store(v, o);
+        __builtin_nontemporal_store(v, o);
         o += m;
         const unsigned long long mask = __ballot(defer && valid);
         if (mask) {

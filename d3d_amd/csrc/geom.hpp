@@ -751,7 +751,11 @@ __device__ __forceinline__ float unit_pm(bool plus, bool minus, float) { return 
 
 typedef unsigned long long lanes;                 // one predicate of the whole wavefront: a compare's result as it leaves the VALU
 
-// 2 * hull area of the lanes whose bit in `ok` is set (every side value clear of zero); the others' value means nothing
+// 2 * hull area of the lanes whose bit in `ok` is set (every side value clear of zero); the others' value means nothing.
+// Order of work = order of the predicates' lives: A's sixteen stay (both their rows are needed by every bridge), B's are
+// produced four at a time -- corner a_t against B's edges -- and go straight into the four bridges that leave or reach a_t
+// and into the running "edge k of B has every corner of A on its left"; with all 32 held to the end the scalar registers ran
+// out and 92 of 353 vector instructions per pair were spills of them (v_writelane / v_readlane).
 template <typename T>
 __device__ __forceinline__ T hull_area2_clear(const BoxGeom<T> &a, const HullPre<T> &ha, const BoxGeom<T> &b, const HullPre<T> &hb, lanes &ok)
 {
@@ -759,57 +763,66 @@ __device__ __forceinline__ T hull_area2_clear(const BoxGeom<T> &a, const HullPre
     const T uu = fma(a.ux, b.ux, a.uy * b.uy), uv = fma(a.ux, b.vx, a.uy * b.vy);      // Ua . Ub, Ua . Vb
     const T vu = fma(a.vx, b.ux, a.vy * b.uy), vv = fma(a.vx, b.vx, a.vy * b.vy);      // Va . Ub, Va . Vb
     const T ext = (fabs(dx) + fabs(dy) + ha.r + hb.r) * ((T)256 * (sizeof(T) == 8 ? (T)2.220446049250313e-16 : (T)1.1920929e-7f));
-    lanes PA[4][4], PB[4][4];                     // P?[k][t]: corner t of the other box strictly left of edge k
+    auto on = [](lanes m) { return (bool)__builtin_amdgcn_inverse_ballot_w64(m); };
     ok = ~0ull;
-    auto side = [&](T p, T q, T hu, T hv, T tol, lanes (&P)[4][4], int t) {
+    // corner (p, q) in the other box's frame against its four edges: P[k] = strictly left of edge k
+    auto side = [&](T p, T q, T hu, T hv, T tol, lanes (&P)[4]) {
         const T dp = fabs(p) - hu, dq = fabs(q) - hv;
         ok &= __builtin_amdgcn_ballot_w64(fabs(dp) > tol) & __builtin_amdgcn_ballot_w64(fabs(dq) > tol);
         const lanes inp = __builtin_amdgcn_ballot_w64(dp < 0), inq = __builtin_amdgcn_ballot_w64(dq < 0);
         const lanes pp = __builtin_amdgcn_ballot_w64(p > 0), pq = __builtin_amdgcn_ballot_w64(q > 0);
-        P[0][t] = inq | pq; P[2][t] = inq | ~pq; P[1][t] = inp | ~pp; P[3][t] = inp | pp;
+        P[0] = inq | pq; P[2] = inq | ~pq; P[1] = inp | ~pp; P[3] = inp | pp;
     };
+    lanes PA[4][4];                                // PA[t][k]: corner t of B strictly left of edge k of A
     {
         const T p0 = fma(dx, a.ux, dy * a.uy), q0 = fma(dx, a.vx, dy * a.vy), tol = ext * ha.r;
         const T ps = uu + uv, pd = uu - uv, qs = vu + vv, qd = vu - vv;
-        side(p0 - ps, q0 - qs, ha.hu, ha.hv, tol, PA, 0); side(p0 + pd, q0 + qd, ha.hu, ha.hv, tol, PA, 1);
-        side(p0 + ps, q0 + qs, ha.hu, ha.hv, tol, PA, 2); side(p0 - pd, q0 - qd, ha.hu, ha.hv, tol, PA, 3);
+        side(p0 - ps, q0 - qs, ha.hu, ha.hv, tol, PA[0]); side(p0 + pd, q0 + qd, ha.hu, ha.hv, tol, PA[1]);
+        side(p0 + ps, q0 + qs, ha.hu, ha.hv, tol, PA[2]); side(p0 - pd, q0 - qd, ha.hu, ha.hv, tol, PA[3]);
     }
-    {
-        const T p0 = -fma(dx, b.ux, dy * b.uy), q0 = -fma(dx, b.vx, dy * b.vy), tol = ext * hb.r;
-        const T ps = uu + vu, pd = uu - vu, qs = uv + vv, qd = uv - vv;
-        side(p0 - ps, q0 - qs, hb.hu, hb.hv, tol, PB, 0); side(p0 + pd, q0 + qd, hb.hu, hb.hv, tol, PB, 1);
-        side(p0 + ps, q0 + qs, hb.hu, hb.hv, tol, PB, 2); side(p0 - pd, q0 - qd, hb.hu, hb.hv, tol, PB, 3);
-    }
-    auto on = [](lanes m) { return (bool)__builtin_amdgcn_inverse_ballot_w64(m); };
-    // A's edges: area / 2 each; B's: area / 2 +- 2 cross(D, Ub | Vb)
+    // A's edges: area / 2 each
     T h2 = 0;
-    const T ea = a.area / 2, eb = b.area / 2;
-    const T cdu = 2 * fma(dx, b.uy, -(dy * b.ux)), cdv = 2 * fma(dx, b.vy, -(dy * b.vx));
-    const T ebk[4] = {eb + cdu, eb + cdv, eb - cdu, eb - cdv};
+    const T ea = a.area / 2;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        h2 = fma(unit_pm(on(PA[k][0] & PA[k][1] & PA[k][2] & PA[k][3]), false, (T)0), ea, h2);
-        h2 = fma(unit_pm(on(PB[k][0] & PB[k][1] & PB[k][2] & PB[k][3]), false, (T)0), ebk[k], h2);
-    }
-    // bridges: a_i = -P, Q, P, -Q;  b_j = D + (-W1, W2, W1, -W2)
-    const T w1x = hb.px, w1y = hb.py, w2x = hb.qx, w2y = hb.qy;
+    for (int k = 0; k < 4; k++) h2 = fma(unit_pm(on(PA[0][k] & PA[1][k] & PA[2][k] & PA[3][k]), false, (T)0), ea, h2);
+    // bridges: a_i = -P, Q, P, -Q;  b_j = D + (-W1, W2, W1, -W2);  cross(a_i, b_j) = cross(a_i, D) + cross(a_i, w_j)
     const T cpd = fma(ha.px, dy, -(ha.py * dx)), cqd = fma(ha.qx, dy, -(ha.qy * dx));
-    const T cpw1 = fma(ha.px, w1y, -(ha.py * w1x)), cpw2 = fma(ha.px, w2y, -(ha.py * w2x));
-    const T cqw1 = fma(ha.qx, w1y, -(ha.qy * w1x)), cqw2 = fma(ha.qx, w2y, -(ha.qy * w2x));
+    const T cpw1 = fma(ha.px, hb.py, -(ha.py * hb.px)), cpw2 = fma(ha.px, hb.qy, -(ha.py * hb.qx));
+    const T cqw1 = fma(ha.qx, hb.py, -(ha.qy * hb.px)), cqw2 = fma(ha.qx, hb.qy, -(ha.qy * hb.qx));
+    const T p0 = -fma(dx, b.ux, dy * b.uy), q0 = -fma(dx, b.vx, dy * b.vy), tol = ext * hb.r;
+    const T ps = uu + vu, pd = uu - vu, qs = uv + vv, qd = uv - vv;
+    lanes EB[4] = {~0ull, ~0ull, ~0ull, ~0ull};   // edge k of B: every corner of A so far on its left
+    asm volatile("" : "+v"(h2));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
+        lanes PB[4];                               // corner a_i against the edges of B
+        side(i == 0 ? p0 - ps : i == 1 ? p0 + pd : i == 2 ? p0 + ps : p0 - pd, i == 0 ? q0 - qs : i == 1 ? q0 + qd : i == 2 ? q0 + qs : q0 - qd,
+             hb.hu, hb.hv, tol, PB);
         const T sa = (i == 1 || i == 2) ? (T)1 : (T)-1;
         const T cad = sa * ((i & 1) ? cqd : cpd);
+        const int ip = (i + 3) & 3;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+            EB[j] &= PB[j];
             const T sw = (j == 1 || j == 2) ? (T)1 : (T)-1;
             const T caw = (i & 1) ? ((j & 1) ? cqw2 : cqw1) : ((j & 1) ? cpw2 : cpw1);
             const T x = cad + (sa * sw) * caw;
-            const int ip = (i + 3) & 3, jp = (j + 3) & 3;
-            const lanes ab = ~PA[i][j] & PA[ip][j] & PB[j][i] & ~PB[jp][i], ba = PA[i][j] & ~PA[ip][j] & ~PB[j][i] & PB[jp][i];
+            const int jp = (j + 3) & 3;
+            // a_i -> b_j: b_j right of A's edge i, left of edge i - 1; a_i left of B's edge j, right of edge j - 1 (b_j -> a_i: all flipped)
+            const lanes ab = ~PA[j][i] & PA[j][ip] & PB[j] & ~PB[jp], ba = PA[j][i] & ~PA[j][ip] & ~PB[j] & PB[jp];
             h2 = fma(unit_pm(on(ab), on(ba), (T)0), x, h2);
         }
+        asm volatile("" : "+v"(h2));               // the four bridges are added HERE (not after all sixteen side values:
+        __builtin_amdgcn_sched_barrier(0);         //  their decisions would all wait in scalar registers)
     }
+    // B's edges: area / 2 +- 2 cross(D, Ub | Vb)
+    const T eb = b.area / 2;
+    const T cdu = 2 * fma(dx, b.uy, -(dy * b.ux)), cdv = 2 * fma(dx, b.vy, -(dy * b.vx));
+    h2 = fma(unit_pm(on(EB[0]), false, (T)0), eb + cdu, h2);
+    h2 = fma(unit_pm(on(EB[1]), false, (T)0), eb + cdv, h2);
+    h2 = fma(unit_pm(on(EB[2]), false, (T)0), eb - cdu, h2);
+    h2 = fma(unit_pm(on(EB[3]), false, (T)0), eb - cdv, h2);
     return h2;
 }
 
@@ -822,10 +835,10 @@ __device__ __forceinline__ T giou_rbox_apart(const BoxGeom<T> &a, const HullPre<
 {
     lanes ok;
     const T H = hull_area2_clear<T>(a, ha, b, hb, ok) / 2, U = a.area + b.area;
-    const bool good = (a.area > 0) & (b.area > 0);
+    const bool good = (a.area > 0) & (b.area > 0);          // (a box without area: the complete routine's 0, deferred like the rest)
     const bool touch = (a.xmin < b.xmax) & (b.xmin < a.xmax) & (a.ymin < b.ymax) & (b.ymin < a.ymax);     // !aabb_disjoint
-    defer = good & (touch | !(bool)__builtin_amdgcn_inverse_ballot_w64(ok));
-    return good ? (T)0 - (H - U) / H : (T)0;
+    defer = !good | touch | !(bool)__builtin_amdgcn_inverse_ballot_w64(ok);
+    return (T)0 - (H - U) / H;
 }
 
 // largest squared corner-to-corner distance and the pair (i1 < i2, first in scan order) that reaches it
