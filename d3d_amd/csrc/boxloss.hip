@@ -33,11 +33,11 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
-// GIoU of one pair by the complete routine (clip + hull with the tie rules), out of line: what the forward-only hull defers
-template <typename T> __device__ __noinline__ T giou_complete(const BoxGeom<T> &a, const BoxGeom<T> &b)
+// GIoU / DIoU of one pair by the complete routine (clip + hull with the tie rules / diameter), out of line: what the forward-only forms defer
+template <typename T, int KIND> __device__ __noinline__ T loss_complete(const BoxGeom<T> &a, const BoxGeom<T> &b)
 {
     T da[5], db[5];
-    return loss_iou_rbox<T, 0, false>(a, b, (T)0, (T)0, (T)0, (T)0, da, db);       // forward: the sizes are not read
+    return loss_iou_rbox<T, KIND, false>(a, b, (T)0, (T)0, (T)0, (T)0, da, db);       // forward: the sizes are not read
 }
 
 // ---------------------------------------------------------------- GIoU / DIoU forward
@@ -47,36 +47,28 @@ __global__ __launch_bounds__(kCols) void k_loss_iou(const T *__restrict__ b1, in
 {
     if (only_if && !*only_if) return;                  // the redo after a list overflow of k_giou_main: nothing to do otherwise
     __shared__ RowBox<T> rows[kRows];
-    __shared__ HullPre<T> hulls[KIND == 0 ? kRows : 1];
+    __shared__ HullPre<T> hulls[kRows];
     const int64_t i0 = (int64_t)blockIdx.y * kRows, j = (int64_t)blockIdx.x * kCols + threadIdx.x;
     const int nrows = (int)((n - i0) < kRows ? (n - i0) : kRows);
     if (threadIdx.x < nrows) {
         const RowBox<T> r = load_row<T>(b1 + (i0 + threadIdx.x) * 5);
         rows[threadIdx.x] = r;
-        if (KIND == 0) hulls[threadIdx.x] = hull_pre<T>(r.g);
+        hulls[threadIdx.x] = hull_pre<T>(r.g);
     }
     __syncthreads();
     if (j >= m) return;
     const RowBox<T> c = load_row<T>(b2 + j * 5);
     T *o = out + i0 * m + j;
-    if (KIND == 0) {                                   // GIoU: the forward-only hull where it applies (geom.hpp, giou_rbox_apart)
-        const HullPre<T> hc = hull_pre<T>(c.g);
-        for (int r = 0; r < nrows; r++) {
-            bool defer;
-            T v = giou_rbox_apart<T>(rows[r].g, hulls[r], c.g, hc, defer);
-            if (__any(defer)) {                        // a pair that needs the clip or the tie rules: the complete routine
-                const T full = giou_complete<T>(rows[r].g, c.g);
-                v = defer ? full : v;
-            }
-            __builtin_nontemporal_store(v, o);
-            o += m;
-        }
-        return;
-    }
-    T ga[5], gb[5];
+    // the forward-only forms where they apply (geom.hpp, giou_rbox_apart / diou_rbox_apart), the complete routine for the rest
+    const HullPre<T> hc = hull_pre<T>(c.g);
     for (int r = 0; r < nrows; r++) {
-        const RowBox<T> a = rows[r];
-        __builtin_nontemporal_store((loss_iou_rbox<T, KIND, false>(a.g, c.g, a.w, a.h, c.w, c.h, ga, gb)), o);
+        bool defer;
+        T v = loss_rbox_apart<T, KIND>(rows[r].g, hulls[r], c.g, hc, defer);
+        if (__any(defer)) {
+            const T full = loss_complete<T, KIND>(rows[r].g, c.g);
+            v = defer ? full : v;
+        }
+        __builtin_nontemporal_store(v, o);
         o += m;
     }
 }
@@ -107,7 +99,7 @@ __global__ __launch_bounds__(256) void k_giou_geom(const T *__restrict__ b1, int
     else { gb[t - n] = g; hb[t - n] = hull_pre<T>(g); }
 }
 
-template <typename T>
+template <typename T, int KIND>
 __global__ __launch_bounds__(kCols) __attribute__((amdgpu_waves_per_eu(4))) void k_giou_main(const BoxGeom<T> *__restrict__ ga, const HullPre<T> *__restrict__ ha, int64_t n,
                                                      const BoxGeom<T> *__restrict__ gb, const HullPre<T> *__restrict__ hb, int64_t m,
                                                      T *__restrict__ out, FixList *hdr, unsigned long long *__restrict__ list,
@@ -142,7 +134,7 @@ __global__ __launch_bounds__(kCols) __attribute__((amdgpu_waves_per_eu(4))) void
     T *o = out + i0 * m + (valid ? j : m - 1);
     for (int r = 0; r < nrows; r++) {
         bool defer;
-        const T v = giou_rbox_apart<T>(rows[r], hulls[r], c, hc, defer);
+        const T v = loss_rbox_apart<T, KIND>(rows[r], hulls[r], c, hc, defer);
         __builtin_nontemporal_store(v, o);
         o += m;
         const unsigned long long mask = __ballot(defer && valid);
@@ -170,7 +162,7 @@ __global__ __launch_bounds__(kCols) __attribute__((amdgpu_waves_per_eu(4))) void
     write_out(base);
 }
 
-template <typename T>
+template <typename T, int KIND>
 __global__ __launch_bounds__(256) void k_giou_fix(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb, int64_t m,
                                                   T *__restrict__ out, const FixList *hdr, const unsigned long long *__restrict__ list,
                                                   unsigned long long cap)
@@ -180,7 +172,7 @@ __global__ __launch_bounds__(256) void k_giou_fix(const BoxGeom<T> *__restrict__
         const unsigned long long e = list[k];
         const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
         const BoxGeom<T> a = ga[i], b = gb[j];
-        out[i * m + j] = giou_complete<T>(a, b);
+        out[i * m + j] = loss_complete<T, KIND>(a, b);
     }
 }
 
@@ -426,7 +418,7 @@ int loss_forward(const T *b1, int64_t n, const T *b2, int64_t m, int kind, T *ou
 {
     const dim3 grid((unsigned)d3d_divup(m, kCols), (unsigned)d3d_divup(n, kRows));
     const unsigned int *no_gate = nullptr;
-    if (kind == 0 && ws && (int64_t)n * m > 65536) {              // GIoU of a matrix: two kernels (above)
+    if (ws && (int64_t)n * m > 65536) {                           // a matrix: two kernels (above)
         WsCarver w(ws, ws_bytes);
         BoxGeom<T> *ga = w.take<BoxGeom<T>>(n);
         BoxGeom<T> *gb = w.take<BoxGeom<T>>(m);
@@ -435,11 +427,15 @@ int loss_forward(const T *b1, int64_t n, const T *b2, int64_t m, int kind, T *ou
         FixList *hdr = w.take<FixList>(1);
         unsigned long long *list = w.take<unsigned long long>(list_cap);
         if (w.ok() && list_cap > 0) {
+            const unsigned int *redo = &hdr->overflow;
             D3D_LAUNCH("k_giou_geom", k_giou_geom<T>, dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, b2, m, ga, ha, gb, hb, hdr);
-            D3D_LAUNCH("k_giou_main", k_giou_main<T>, grid, dim3(kCols), 0, st, (const BoxGeom<T> *)ga, (const HullPre<T> *)ha, n,
-                       (const BoxGeom<T> *)gb, (const HullPre<T> *)hb, m, out, hdr, list, list_cap);
-            D3D_LAUNCH("k_giou_fix", k_giou_fix<T>, dim3(256 * 8), dim3(256), 0, st, ga, gb, m, out, hdr, list, list_cap);
-            D3D_LAUNCH("k_loss_iou<giou>", (k_loss_iou<T, 0>), grid, dim3(kCols), 0, st, b1, n, b2, m, out, (const unsigned int *)&hdr->overflow);
+#define D3D_LOSS_TWO(K, NAME)                                                                                                            \
+    D3D_LAUNCH(NAME "_main", (k_giou_main<T, K>), grid, dim3(kCols), 0, st, (const BoxGeom<T> *)ga, (const HullPre<T> *)ha, n,             \
+               (const BoxGeom<T> *)gb, (const HullPre<T> *)hb, m, out, hdr, list, list_cap);                                              \
+    D3D_LAUNCH(NAME "_fix", (k_giou_fix<T, K>), dim3(256 * 8), dim3(256), 0, st, ga, gb, m, out, hdr, list, list_cap);                      \
+    D3D_LAUNCH("k_loss_iou<redo>", (k_loss_iou<T, K>), grid, dim3(kCols), 0, st, b1, n, b2, m, out, redo)
+            if (kind == 0) { D3D_LOSS_TWO(0, "k_giou"); } else { D3D_LOSS_TWO(1, "k_diou"); }
+#undef D3D_LOSS_TWO
             return D3D_OK;
         }
     }

@@ -841,6 +841,34 @@ __device__ __forceinline__ T giou_rbox_apart(const BoxGeom<T> &a, const HullPre<
     return (T)0 - (H - U) / H;
 }
 
+// DIoU forward of the pairs whose bounding boxes are apart: 0 - d^2 / D^2 with D^2 the largest of the sixteen distances between
+// a corner of A and one of B and of the two boxes' own diagonals (a rectangle's sides are shorter than its diagonal).  Same rule
+// as for GIoU: `defer` = this pair's value is loss_iou_rbox's (boxes that may intersect, boxes without area).
+template <typename T>
+__device__ __forceinline__ T diou_rbox_apart(const BoxGeom<T> &a, const HullPre<T> &ha, const BoxGeom<T> &b, const HullPre<T> &hb, bool &defer)
+{
+    const T dx = b.cx - a.cx, dy = b.cy - a.cy;
+    const T ex[4] = {dx - hb.px, dx + hb.qx, dx + hb.px, dx - hb.qx}, ey[4] = {dy - hb.py, dy + hb.qy, dy + hb.py, dy - hb.qy};
+    T best = 4 * fmax(ha.hu + ha.hv, hb.hu + hb.hv);          // |2 (U +- V)|^2 = 4 (|U|^2 + |V|^2)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const T f0x = ex[j] + ha.px, f0y = ey[j] + ha.py, f1x = ex[j] - ha.qx, f1y = ey[j] - ha.qy;      // a_0 = -P, a_1 = Q
+        const T f2x = ex[j] - ha.px, f2y = ey[j] - ha.py, f3x = ex[j] + ha.qx, f3y = ey[j] + ha.qy;      // a_2 = P, a_3 = -Q
+        best = fmax(fmax(best, fma(f0x, f0x, f0y * f0y)), fmax(fma(f1x, f1x, f1y * f1y), fmax(fma(f2x, f2x, f2y * f2y), fma(f3x, f3x, f3y * f3y))));
+    }
+    const bool good = (a.area > 0) & (b.area > 0);
+    const bool touch = (a.xmin < b.xmax) & (b.xmin < a.xmax) & (a.ymin < b.ymax) & (b.ymin < a.ymax);     // !aabb_disjoint
+    defer = !good | touch;
+    return (T)0 - fma(dx, dx, dy * dy) / best;
+}
+
+template <typename T, int KIND>
+__device__ __forceinline__ T loss_rbox_apart(const BoxGeom<T> &a, const HullPre<T> &ha, const BoxGeom<T> &b, const HullPre<T> &hb, bool &defer)
+{
+    if (KIND == 0) return giou_rbox_apart<T>(a, ha, b, hb, defer);
+    return diou_rbox_apart<T>(a, ha, b, hb, defer);
+}
+
 // largest squared corner-to-corner distance and the pair (i1 < i2, first in scan order) that reaches it
 template <typename T>
 __device__ __forceinline__ T diameter2(const Corners8<T> &c, int &i1, int &i2)

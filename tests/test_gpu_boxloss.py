@@ -49,9 +49,10 @@ def test_giou_diou_forward_vs_oracle(method):
     assert np.array_equal(box2d_iou(a[:9], b[:7], method=method), got[:9, :7])      # numpy in, numpy out
 
 
+@pytest.mark.parametrize("method", ["grbox", "drbox"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_giou_forward_two_kernels_same_value_for_a_pair_on_every_path(dtype):
-    """GIoU forward of a matrix: hull-only kernel + list of the pairs that need the clip or the tie rules + one listed pair
+def test_giou_forward_two_kernels_same_value_for_a_pair_on_every_path(dtype, method):
+    """GIoU / DIoU forward of a matrix: hull-only (diameter-only) kernel + list of the pairs that need the clip or the tie rules + one listed pair
     per lane (boxloss.hip k_giou_main / k_giou_fix).  A pair's value must not depend on the path: the matrix in one call ==
     the same pairs in small calls (single kernel) == the call with a list too small (the redo) -- bit for bit; and all of it
     against the oracle.  Dense scene (a third of the pairs overlap), sparse scene, exact ties (identical boxes on the
@@ -67,15 +68,15 @@ def test_giou_forward_two_kernels_same_value_for_a_pair_on_every_path(dtype):
     for b1, b2 in ((dense, dense[100:500]), (sparse, sparse), (np.concatenate([ties, dense[:300]]), np.concatenate([ties, sparse[:260]]))):
         b1, b2 = b1.astype(dtype), b2.astype(dtype)
         assert len(b1) * len(b2) > 65536                         # the two-kernel path
-        exp = oracle.loss_iou2dr(b1.astype(np.float64), b2.astype(np.float64), "grbox", nthreads=8)
-        got = box2d_iou(T(b1), T(b2), method="grbox", precise=(dtype == np.float64))
+        exp = oracle.loss_iou2dr(b1.astype(np.float64), b2.astype(np.float64), method, nthreads=8)
+        got = box2d_iou(T(b1), T(b2), method=method, precise=(dtype == np.float64))
         assert float(np.max(np.abs(got.cpu().numpy().astype(np.float64) - exp))) < tol
         for r0, c0 in ((0, 0), (37, 101), (len(b1) - 60, len(b2) - 90)):           # 60 x 90 pairs: one launch, in-place routine
-            small = box2d_iou(T(b1[r0:r0 + 60]), T(b2[c0:c0 + 90]), method="grbox", precise=(dtype == np.float64))
+            small = box2d_iou(T(b1[r0:r0 + 60]), T(b2[c0:c0 + 90]), method=method, precise=(dtype == np.float64))
             assert torch.equal(small, got[r0:r0 + 60, c0:c0 + 90]), (r0, c0)
         set_opts(iou_flags=_lib.iou_list_cap(100))               # the list overflows: the single-kernel path redoes the matrix
         try:
-            redo = box2d_iou(T(b1), T(b2), method="grbox", precise=(dtype == np.float64))
+            redo = box2d_iou(T(b1), T(b2), method=method, precise=(dtype == np.float64))
         finally:
             set_opts(iou_flags=0)
         assert torch.equal(redo, got)
