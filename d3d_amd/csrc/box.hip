@@ -2313,7 +2313,7 @@ static unsigned long long iou_list_capacity(int64_t n, int64_t m)
 int d3d_internal_loss_iou_forward(const void *b1, int64_t n, const void *b2, int64_t m, int kind, int dtype, void *out, void *ws,
                                   size_t ws_bytes, unsigned long long list_cap, hipStream_t st);
 int d3d_internal_loss_iou_backward(const void *b1, int64_t n, const void *b2, int64_t m, const void *grad, int kind, int dtype,
-                                   void *g1, void *g2, hipStream_t st);
+                                   void *g1, void *g2, void *ws, size_t ws_bytes, hipStream_t st);
 
 extern "C" size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype)
 {
@@ -2710,7 +2710,7 @@ extern "C" int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *box
     if (!grad || n >= (1ll << 32) || m >= (1ll << 32)) return D3D_ERR_BAD_ARG;
     if (loss_kind)
         return d3d_internal_loss_iou_backward(boxes1, n, boxes2, m, grad, iou_type == D3D_IOU_GRBOX ? 0 : 1, dtype, grad_boxes1,
-                                              grad_boxes2, st);
+                                              grad_boxes2, workspace, workspace ? workspace_bytes : 0, st);
     if (workspace_bytes < d3d_iou2d_workspace_bytes(n, m, dtype)) return D3D_ERR_WORKSPACE;
     const bool rot = iou_type == D3D_IOU_RBOX;
     if (dtype == D3D_F64)

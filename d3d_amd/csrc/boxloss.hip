@@ -177,23 +177,43 @@ __global__ __launch_bounds__(256) void k_giou_fix(const BoxGeom<T> *__restrict__
 }
 
 // ---------------------------------------------------------------- GIoU / DIoU backward
+// Round 5: as in forward, the pairs that are apart take a kernel of their own (k_giou_grad_main: geom.hpp giou_rbox_apart_grad)
+// and leave one bit per pair for the others; this kernel, given that bitmap (`only`, `wpr` words per row), computes exactly
+// those -- a wavefront whose word is zero skips the row.  Without a bitmap it computes every pair (small matrices, DIoU).
 template <typename T, int KIND>
 __global__ __launch_bounds__(kCols) void k_loss_iou_grad(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
-                                                         const T *__restrict__ grad, T *g1, T *g2)
+                                                         const T *__restrict__ grad, T *g1, T *g2,
+                                                         const unsigned long long *__restrict__ only = nullptr, int64_t wpr = 0,
+                                                         int tile_rows = kRows)
 {
     __shared__ RowBox<T> rows[kRows];
-    const int64_t i0 = (int64_t)blockIdx.y * kRows, j = (int64_t)blockIdx.x * kCols + threadIdx.x;
-    const int nrows = (int)((n - i0) < kRows ? (n - i0) : kRows);
+    const int64_t i0 = (int64_t)blockIdx.y * tile_rows, j = (int64_t)blockIdx.x * kCols + threadIdx.x;
+    const int nrows = (int)((n - i0) < tile_rows ? (n - i0) : tile_rows);
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool active = j < m, wave_in = (j & ~(int64_t)63) < m;
+    // the tile's words of the bitmap, one row per lane, before anything else waits (a load per row in the loop is a round trip per row)
+    unsigned long long words = ~0ull;
+    if (only) words = (lane < nrows && wave_in) ? only[(i0 + lane) * wpr + (j >> 6)] : 0ull;
+    if (only && !__any(words != 0)) {                  // nothing left for this wavefront: it still has to load its rows for the others
+        if (threadIdx.x < nrows) rows[threadIdx.x] = load_row<T>(b1 + (i0 + threadIdx.x) * 5);
+        __syncthreads();
+        return;
+    }
     if (threadIdx.x < nrows) rows[threadIdx.x] = load_row<T>(b1 + (i0 + threadIdx.x) * 5);
     __syncthreads();
-    const bool active = j < m;
+    if (!wave_in) return;                              // a wavefront past the last column
     RowBox<T> c = load_row<T>(b2 + (active ? j : 0) * 5);
     T col[5] = {0, 0, 0, 0, 0};
-    const int lane = threadIdx.x & (kWave - 1);
     for (int r = 0; r < nrows; r++) {
+        bool mine = true;
+        if (only) {
+            const unsigned long long word = __shfl(words, r, kWave);
+            if (word == 0) continue;
+            mine = (word >> lane) & 1ull;
+        }
         const RowBox<T> a = rows[r];
         T ga[5] = {0, 0, 0, 0, 0}, gb[5] = {0, 0, 0, 0, 0};
-        const T g = active ? grad[(i0 + r) * m + j] : (T)0;
+        const T g = (active && mine) ? grad[(i0 + r) * m + j] : (T)0;
         if (g != 0) {
             loss_iou_rbox<T, KIND, true>(a.g, c.g, a.w, a.h, c.w, c.h, ga, gb);
 #pragma unroll
@@ -206,6 +226,63 @@ __global__ __launch_bounds__(kCols) void k_loss_iou_grad(const T *__restrict__ b
         }
     }
     if (active)
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (col[k] != 0) atomicAdd(&g2[j * 5 + k], col[k]);
+}
+
+// the pairs that are apart (GIoU): gradient by giou_rbox_apart_grad, one bit per pair left for k_loss_iou_grad
+template <typename T> struct GradRow { BoxGeom<T> g; HullPre<T> h; T w, hgt, iw, ih; };
+
+template <typename T>
+__global__ __launch_bounds__(kCols) __attribute__((amdgpu_waves_per_eu(3))) void k_giou_grad_main(
+    const BoxGeom<T> *__restrict__ ga, const HullPre<T> *__restrict__ ha, const T *__restrict__ b1, int64_t n,
+    const BoxGeom<T> *__restrict__ gb, const HullPre<T> *__restrict__ hb, const T *__restrict__ b2, int64_t m, const T *__restrict__ grad, T *g1,
+    T *g2, unsigned long long *__restrict__ bitmap, int64_t wpr, int tile_rows)
+{
+    __shared__ GradRow<T> rows[kRows];
+    const int64_t i0 = (int64_t)blockIdx.y * tile_rows, j = (int64_t)blockIdx.x * kCols + threadIdx.x;
+    const int nrows = (int)((n - i0) < tile_rows ? (n - i0) : tile_rows);
+    if (threadIdx.x < nrows) {
+        GradRow<T> &r = rows[threadIdx.x];             // (field by field: a local copy of the struct went through scratch)
+        r.g = ga[i0 + threadIdx.x]; r.h = ha[i0 + threadIdx.x];
+        const T w = b1[(i0 + threadIdx.x) * 5 + 2], hgt = b1[(i0 + threadIdx.x) * 5 + 3];
+        r.w = w; r.hgt = hgt; r.iw = (T)1 / w; r.ih = (T)1 / hgt;
+    }
+    __syncthreads();
+    if ((j & ~(int64_t)63) >= m) return;               // a wavefront past the last column
+    const bool valid = j < m;
+    const int64_t jc = valid ? j : m - 1;
+    const BoxGeom<T> c = gb[jc];
+    const HullPre<T> hc = hb[jc];
+    const T cw = b2[jc * 5 + 2], chgt = b2[jc * 5 + 3], ciw = (T)1 / cw, cih = (T)1 / chgt;
+    T col[5] = {0, 0, 0, 0, 0};
+    const int lane = threadIdx.x & (kWave - 1);
+    const T *gp = grad + i0 * m + jc;
+    unsigned long long *bw = bitmap + i0 * wpr + (j >> 6);
+    T gnext = valid ? *gp : (T)0;
+    for (int r = 0; r < nrows; r++, bw += wpr) {
+        const T g = gnext;
+        gp += m;
+        if (r + 1 < nrows) gnext = valid ? *gp : (T)0;          // the next row's weight is on its way while this row computes
+        if (!__any(g != 0)) {                          // nothing arrives for this stretch of the row (a loss on selected pairs)
+            if (lane == 0) *bw = 0;
+            continue;
+        }
+        T da[5], db[5];
+        bool defer;
+        giou_rbox_apart_grad<T>(rows[r].g, rows[r].h, rows[r].w, rows[r].hgt, rows[r].iw, rows[r].ih, c, hc, cw, chgt, ciw, cih, da, db, defer);
+        const bool take = (g != 0) & !defer;
+        const unsigned long long left = __ballot((g != 0) & defer);
+        if (lane == 0) *bw = left;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            col[k] += take ? g * db[k] : (T)0;
+            const T s = wave_sum<T>(take ? g * da[k] : (T)0);
+            if (lane == 0 && s != 0) atomicAdd(&g1[(i0 + r) * 5 + k], s);
+        }
+    }
+    if (valid)
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (col[k] != 0) atomicAdd(&g2[j * 5 + k], col[k]);
@@ -445,13 +522,37 @@ int loss_forward(const T *b1, int64_t n, const T *b2, int64_t m, int kind, T *ou
 }
 
 template <typename T>
-int loss_backward(const T *b1, int64_t n, const T *b2, int64_t m, const T *grad, int kind, T *g1, T *g2, hipStream_t st)
+int loss_backward(const T *b1, int64_t n, const T *b2, int64_t m, const T *grad, int kind, T *g1, T *g2, void *ws, size_t ws_bytes, hipStream_t st)
 {
     D3D_HIP_CHECK(hipMemsetAsync(g1, 0, (size_t)n * 5 * sizeof(T), st));
     D3D_HIP_CHECK(hipMemsetAsync(g2, 0, (size_t)m * 5 * sizeof(T), st));
     const dim3 grid((unsigned)d3d_divup(m, kCols), (unsigned)d3d_divup(n, kRows));
-    if (kind == 0) D3D_LAUNCH("k_loss_iou_grad<giou>", (k_loss_iou_grad<T, 0>), grid, dim3(kCols), 0, st, b1, n, b2, m, grad, g1, g2);
-    else D3D_LAUNCH("k_loss_iou_grad<diou>", (k_loss_iou_grad<T, 1>), grid, dim3(kCols), 0, st, b1, n, b2, m, grad, g1, g2);
+    const unsigned long long *all = nullptr;
+    if (kind == 0 && ws && (int64_t)n * m > 65536) {              // GIoU of a matrix: the pairs apart first, the others by their bitmap
+        const int64_t wpr = d3d_divup(m, 64);
+        // rows per workgroup: 64, or fewer while the launch would not give every SIMD of the chip two wavefronts (2 k x 2 k boxes at
+        // 64 rows: 256 workgroups = one wavefront per SIMD, each walking its rows' round trips alone)
+        int tr = kRows;
+        while (tr > 8 && d3d_divup(m, kCols) * d3d_divup(n, tr) < 2048) tr >>= 1;
+        const dim3 tgrid((unsigned)d3d_divup(m, kCols), (unsigned)d3d_divup(n, tr));
+        WsCarver w(ws, ws_bytes);
+        BoxGeom<T> *ga = w.take<BoxGeom<T>>(n);
+        BoxGeom<T> *gb = w.take<BoxGeom<T>>(m);
+        HullPre<T> *ha = w.take<HullPre<T>>(n);
+        HullPre<T> *hb = w.take<HullPre<T>>(m);
+        FixList *hdr = w.take<FixList>(1);
+        unsigned long long *bitmap = w.take<unsigned long long>((size_t)n * (size_t)wpr);
+        if (w.ok()) {
+            D3D_LAUNCH("k_giou_geom", k_giou_geom<T>, dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, b2, m, ga, ha, gb, hb, hdr);
+            D3D_LAUNCH("k_giou_grad_main", k_giou_grad_main<T>, tgrid, dim3(kCols), 0, st, (const BoxGeom<T> *)ga, (const HullPre<T> *)ha, b1, n,
+                       (const BoxGeom<T> *)gb, (const HullPre<T> *)hb, b2, m, grad, g1, g2, bitmap, wpr, tr);
+            D3D_LAUNCH("k_loss_iou_grad<giou>", (k_loss_iou_grad<T, 0>), tgrid, dim3(kCols), 0, st, b1, n, b2, m, grad, g1, g2,
+                       (const unsigned long long *)bitmap, wpr, tr);
+            return D3D_OK;
+        }
+    }
+    if (kind == 0) D3D_LAUNCH("k_loss_iou_grad<giou>", (k_loss_iou_grad<T, 0>), grid, dim3(kCols), 0, st, b1, n, b2, m, grad, g1, g2, all, (int64_t)0, (int)kRows);
+    else D3D_LAUNCH("k_loss_iou_grad<diou>", (k_loss_iou_grad<T, 1>), grid, dim3(kCols), 0, st, b1, n, b2, m, grad, g1, g2, all, (int64_t)0, (int)kRows);
     return D3D_OK;
 }
 
@@ -470,12 +571,13 @@ int d3d_internal_loss_iou_forward(const void *b1, int64_t n, const void *b2, int
 }
 
 int d3d_internal_loss_iou_backward(const void *b1, int64_t n, const void *b2, int64_t m, const void *grad, int kind, int dtype,
-                                   void *g1, void *g2, hipStream_t st)
+                                   void *g1, void *g2, void *ws, size_t ws_bytes, hipStream_t st)
 {
     if (d3d_divup(n, kRows) > 65535) return D3D_ERR_BAD_ARG;
     if (dtype == D3D_F64)
-        return loss_backward<double>((const double *)b1, n, (const double *)b2, m, (const double *)grad, kind, (double *)g1, (double *)g2, st);
-    return loss_backward<float>((const float *)b1, n, (const float *)b2, m, (const float *)grad, kind, (float *)g1, (float *)g2, st);
+        return loss_backward<double>((const double *)b1, n, (const double *)b2, m, (const double *)grad, kind, (double *)g1, (double *)g2, ws,
+                                     ws_bytes, st);
+    return loss_backward<float>((const float *)b1, n, (const float *)b2, m, (const float *)grad, kind, (float *)g1, (float *)g2, ws, ws_bytes, st);
 }
 
 extern "C" int d3d_iou2dr_flags(const void *boxes1, int64_t n, const void *boxes2, int64_t m, int32_t dtype, uint8_t *nx,

@@ -111,6 +111,56 @@ def test_giou_diou_backward_vs_central_differences(method):
     assert np.max(np.abs(t1.grad.cpu().numpy() - g1)) < 2e-2 * max(1.0, np.abs(g1).max())
 
 
+@pytest.mark.parametrize("method", ["grbox", "drbox"])
+def test_loss_backward_of_a_matrix_two_kernels(method):
+    """backward of a matrix (> 65536 pairs): GIoU's pairs that are apart take a kernel of their own, the others the complete
+    routine by their bitmap (boxloss.hip k_giou_grad_main + k_loss_iou_grad).  Against (a) the same gradients gathered from row
+    blocks small enough for the one-kernel path, (b) central differences of the fp64 oracle on sampled parameters; dense weights,
+    weights on selected pairs only (most wavefronts skip), a sparse and a crowded scene, ties, boxes without area."""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_iou
+    dense, _ = synth.boxes2d_dense(700, 71)
+    sparse, _ = synth.boxes2d_sparse(100000, 72)
+    ties = np.array([[10. + 3 * k, 5., 2., 1., 0.] for k in range(30)] + [[4., 4., 0., 2., 0.1]])
+    rng = np.random.default_rng(73)
+    for b1, b2, pick in ((sparse[:400], sparse[300:700], False), (dense[:330], dense[200:530], False), (sparse[:500], sparse[100:600], True),
+                         (np.concatenate([ties, sparse[:300]]), np.concatenate([ties, dense[:270]]), False)):
+        n, m = len(b1), len(b2)
+        assert n * m > 65536
+        w = rng.random((n, m)) - 0.3
+        if pick:                                                 # a loss on matched pairs: one weight per row
+            sel = np.zeros((n, m))
+            sel[np.arange(n), rng.integers(0, m, n)] = 1.0
+            w = w * sel
+        t1, t2 = T(b1).requires_grad_(True), T(b2).requires_grad_(True)
+        (box2d_iou(t1, t2, method=method) * T(w)).sum().backward()
+        g1, g2 = t1.grad.cpu().numpy(), t2.grad.cpu().numpy()
+        assert np.isfinite(g1).all() and np.isfinite(g2).all()
+        r1, r2 = np.zeros_like(g1), np.zeros_like(g2)
+        step = 65536 // m
+        for r0 in range(0, n, step):
+            s1, s2 = T(b1[r0:r0 + step]).requires_grad_(True), T(b2).requires_grad_(True)
+            (box2d_iou(s1, s2, method=method) * T(w[r0:r0 + step])).sum().backward()
+            r1[r0:r0 + step] = s1.grad.cpu().numpy()
+            r2 += s2.grad.cpu().numpy()
+        scale = max(1.0, np.abs(r1).max(), np.abs(r2).max())
+        assert np.max(np.abs(g1 - r1)) < 1e-9 * scale and np.max(np.abs(g2 - r2)) < 1e-9 * scale
+        h = 1e-6
+        for _ in range(6):
+            which, k = int(rng.integers(0, 2)), int(rng.integers(0, 5))
+            i = int(rng.integers(0, n if which == 0 else m))
+            arr = (b1 if which == 0 else b2)
+            p, q = arr.copy(), arr.copy()
+            p[i, k] += h
+            q[i, k] -= h
+            if which == 0:
+                fd = float(((oracle.loss_iou2dr(p[i:i + 1], b2, method) - oracle.loss_iou2dr(q[i:i + 1], b2, method)) * w[i:i + 1]).sum()) / (2 * h)
+                assert abs(fd - g1[i, k]) < 5e-5 * max(1.0, abs(fd)), (method, which, i, k, fd, g1[i, k])
+            else:
+                fd = float(((oracle.loss_iou2dr(b1, p[i:i + 1], method) - oracle.loss_iou2dr(b1, q[i:i + 1], method)) * w[:, i:i + 1]).sum()) / (2 * h)
+                assert abs(fd - g2[i, k]) < 5e-5 * max(1.0, abs(fd)), (method, which, i, k, fd, g2[i, k])
+
+
 def test_flags_vs_oracle_and_box_impl_tuples():
     from d3d_amd.box import box_impl, iou2dr_flags
     b1, b2 = _rand_boxes(90, 31, 6.0), _rand_boxes(70, 32, 6.0)

@@ -1,12 +1,12 @@
 #!/bin/bash
 # VALU counters + durations of the clip-bound IoU kernels: k_iou_clip<double> on the reference's benchmark
-# boxes (5 k x 5 k, 28 % of the pairs overlap) and k_loss_iou<double, 0> (GIoU, 10 k x 10 k).  One rocprofv3 pass per counter
+# boxes (5 k x 5 k, 28 % of the pairs overlap) and k_giou_main<double, 0> (GIoU's pair kernel, 10 k x 10 k; round 5: was k_loss_iou).  One rocprofv3 pass per counter
 # (--kernel-trace + --pmc only).  usage (GPU box): bash tools/alu_roofline.sh <tag>  ->  gpurun_out/<tag>/alu_*.txt
 tag=${1:-r05_alu}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for job in "k_iou_clip iou_dense_pmc.py" "k_loss_iou iou_loss_pmc.py"; do
+for job in "k_iou_clip iou_dense_pmc.py" "k_giou_main iou_loss_pmc.py"; do
   set -- $job
   pat=$1; script=$2
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$pat -o t -- python3 $GRAFT_REPO_ROOT/tools/$script > /dev/null 2> $out/trace_$pat.err

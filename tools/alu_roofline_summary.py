@@ -13,7 +13,7 @@ import sys
 out = sys.argv[1]
 PEAK = 256 * 4 * 16 * 2.4e9
 res = {}
-for pat in ("k_iou_clip", "k_loss_iou"):
+for pat in ("k_iou_clip", "k_giou_main"):
     dur = []
     for f in glob.glob(os.path.join(out, "trace_" + pat, "**", "*kernel_trace.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
