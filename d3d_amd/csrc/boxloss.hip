@@ -33,6 +33,26 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
+// The five sums of a row's gradient over the wavefront in NINE exchanges instead of thirty (round 5: the thirty, two
+// ds_bpermute each in fp64, and five atomics one after the other were most of k_diou_grad_main's 767 us on 6 k x 6 k):
+// at every level a lane sends the value its partner keeps, so the number of values halves with the distance --
+// (v0, v1), (v2, v3), v4 across xor 1; then two, one, and three plain levels.  Returns to lane L the total of value
+// min(L & 7, 4): lanes 0 .. 4 hold the five sums (and add them to memory side by side).
+template <typename T> __device__ __forceinline__ T wave_sum5(const T (&v)[5], int lane)
+{
+    const bool o1 = lane & 1, o2 = lane & 2, o4 = lane & 4;
+    const T a0 = (o1 ? v[1] : v[0]) + __shfl_xor(o1 ? v[0] : v[1], 1, kWave);
+    const T a1 = (o1 ? v[3] : v[2]) + __shfl_xor(o1 ? v[2] : v[3], 1, kWave);
+    const T a2 = v[4] + __shfl_xor(v[4], 1, kWave);
+    const T b0 = (o2 ? a1 : a0) + __shfl_xor(o2 ? a0 : a1, 2, kWave);
+    const T b1 = a2 + __shfl_xor(a2, 2, kWave);
+    T c = (o4 ? b1 : b0) + __shfl_xor(o4 ? b0 : b1, 4, kWave);
+    c += __shfl_xor(c, 8, kWave);
+    c += __shfl_xor(c, 16, kWave);
+    c += __shfl_xor(c, 32, kWave);
+    return c;
+}
+
 // GIoU / DIoU of one pair by the complete routine (clip + hull with the tie rules / diameter), out of line: what the forward-only forms defer
 template <typename T, int KIND> __device__ __noinline__ T loss_complete(const BoxGeom<T> &a, const BoxGeom<T> &b)
 {
@@ -219,11 +239,8 @@ __global__ __launch_bounds__(kCols) void k_loss_iou_grad(const T *__restrict__ b
 #pragma unroll
             for (int k = 0; k < 5; k++) { ga[k] *= g; col[k] += g * gb[k]; }
         }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const T s = wave_sum<T>(ga[k]);
-            if (lane == 0 && s != 0) atomicAdd(&g1[(i0 + r) * 5 + k], s);
-        }
+        const T s = wave_sum5<T>(ga, lane);
+        if (lane < 5 && s != 0) atomicAdd(&g1[(i0 + r) * 5 + lane], s);
     }
     if (active)
 #pragma unroll
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(kCols) void k_loss_iou_grad(const T *__restrict__ b
 // the pairs that are apart (GIoU): gradient by giou_rbox_apart_grad, one bit per pair left for k_loss_iou_grad
 template <typename T> struct GradRow { BoxGeom<T> g; HullPre<T> h; T w, hgt, iw, ih; };
 
-template <typename T>
+template <typename T, int KIND>
 __global__ __launch_bounds__(kCols) __attribute__((amdgpu_waves_per_eu(3))) void k_giou_grad_main(
     const BoxGeom<T> *__restrict__ ga, const HullPre<T> *__restrict__ ha, const T *__restrict__ b1, int64_t n,
     const BoxGeom<T> *__restrict__ gb, const HullPre<T> *__restrict__ hb, const T *__restrict__ b2, int64_t m, const T *__restrict__ grad, T *g1,
@@ -260,27 +277,34 @@ __global__ __launch_bounds__(kCols) __attribute__((amdgpu_waves_per_eu(3))) void
     const int lane = threadIdx.x & (kWave - 1);
     const T *gp = grad + i0 * m + jc;
     unsigned long long *bw = bitmap + i0 * wpr + (j >> 6);
-    T gnext = valid ? *gp : (T)0;
-    for (int r = 0; r < nrows; r++, bw += wpr) {
-        const T g = gnext;
-        gp += m;
-        if (r + 1 < nrows) gnext = valid ? *gp : (T)0;          // the next row's weight is on its way while this row computes
+    // the rows' weights arrive four rows ahead of their use (one row ahead, the round trip still showed: 2.2 TB/s on weights that
+    // are zero almost everywhere)
+    T ring[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) ring[q] = (valid && q < nrows) ? gp[(int64_t)q * m] : (T)0;
+    gp += 4 * m;
+    for (int r = 0; r < nrows; r++, bw += wpr, gp += m) {
+        const T g = ring[0];
+        ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
+        ring[3] = (valid && r + 4 < nrows) ? *gp : (T)0;
         if (!__any(g != 0)) {                          // nothing arrives for this stretch of the row (a loss on selected pairs)
             if (lane == 0) *bw = 0;
             continue;
         }
         T da[5], db[5];
         bool defer;
-        giou_rbox_apart_grad<T>(rows[r].g, rows[r].h, rows[r].w, rows[r].hgt, rows[r].iw, rows[r].ih, c, hc, cw, chgt, ciw, cih, da, db, defer);
+        loss_rbox_apart_grad<T, KIND>(rows[r].g, rows[r].h, rows[r].w, rows[r].hgt, rows[r].iw, rows[r].ih, c, hc, cw, chgt, ciw, cih, da, db, defer);
         const bool take = (g != 0) & !defer;
         const unsigned long long left = __ballot((g != 0) & defer);
         if (lane == 0) *bw = left;
+        T wa[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             col[k] += take ? g * db[k] : (T)0;
-            const T s = wave_sum<T>(take ? g * da[k] : (T)0);
-            if (lane == 0 && s != 0) atomicAdd(&g1[(i0 + r) * 5 + k], s);
+            wa[k] = take ? g * da[k] : (T)0;
         }
+        const T s = wave_sum5<T>(wa, lane);
+        if (lane < 5 && s != 0) atomicAdd(&g1[(i0 + r) * 5 + lane], s);
     }
     if (valid)
 #pragma unroll
@@ -477,11 +501,8 @@ __global__ __launch_bounds__(kCols) void k_pdist_grad(const T *__restrict__ poin
 #pragma unroll
             for (int k = 0; k < 5; k++) gb[k] *= g;
         }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const T s = wave_sum<T>(gb[k]);
-            if (lane == 0 && s != 0) atomicAdd(&gboxes[(i0 + r) * 5 + k], s);
-        }
+        const T s = wave_sum5<T>(gb, lane);
+        if (lane < 5 && s != 0) atomicAdd(&gboxes[(i0 + r) * 5 + lane], s);
     }
     if (active) {
         if (accp[0] != 0) atomicAdd(&gpoints[j * 2], accp[0]);
@@ -528,7 +549,7 @@ int loss_backward(const T *b1, int64_t n, const T *b2, int64_t m, const T *grad,
     D3D_HIP_CHECK(hipMemsetAsync(g2, 0, (size_t)m * 5 * sizeof(T), st));
     const dim3 grid((unsigned)d3d_divup(m, kCols), (unsigned)d3d_divup(n, kRows));
     const unsigned long long *all = nullptr;
-    if (kind == 0 && ws && (int64_t)n * m > 65536) {              // GIoU of a matrix: the pairs apart first, the others by their bitmap
+    if (ws && (int64_t)n * m > 65536) {                           // a matrix: the pairs apart first, the others by their bitmap
         const int64_t wpr = d3d_divup(m, 64);
         // rows per workgroup: 64, or fewer while the launch would not give every SIMD of the chip two wavefronts (2 k x 2 k boxes at
         // 64 rows: 256 workgroups = one wavefront per SIMD, each walking its rows' round trips alone)
@@ -544,10 +565,13 @@ int loss_backward(const T *b1, int64_t n, const T *b2, int64_t m, const T *grad,
         unsigned long long *bitmap = w.take<unsigned long long>((size_t)n * (size_t)wpr);
         if (w.ok()) {
             D3D_LAUNCH("k_giou_geom", k_giou_geom<T>, dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, b2, m, ga, ha, gb, hb, hdr);
-            D3D_LAUNCH("k_giou_grad_main", k_giou_grad_main<T>, tgrid, dim3(kCols), 0, st, (const BoxGeom<T> *)ga, (const HullPre<T> *)ha, b1, n,
-                       (const BoxGeom<T> *)gb, (const HullPre<T> *)hb, b2, m, grad, g1, g2, bitmap, wpr, tr);
-            D3D_LAUNCH("k_loss_iou_grad<giou>", (k_loss_iou_grad<T, 0>), tgrid, dim3(kCols), 0, st, b1, n, b2, m, grad, g1, g2,
-                       (const unsigned long long *)bitmap, wpr, tr);
+#define D3D_GRAD_TWO(K, NAME)                                                                                                            \
+    D3D_LAUNCH(NAME "_grad_main", (k_giou_grad_main<T, K>), tgrid, dim3(kCols), 0, st, (const BoxGeom<T> *)ga, (const HullPre<T> *)ha, b1, n, \
+               (const BoxGeom<T> *)gb, (const HullPre<T> *)hb, b2, m, grad, g1, g2, bitmap, wpr, tr);                                     \
+    D3D_LAUNCH("k_loss_iou_grad<rest>", (k_loss_iou_grad<T, K>), tgrid, dim3(kCols), 0, st, b1, n, b2, m, grad, g1, g2,                   \
+               (const unsigned long long *)bitmap, wpr, tr)
+            if (kind == 0) { D3D_GRAD_TWO(0, "k_giou"); } else { D3D_GRAD_TWO(1, "k_diou"); }
+#undef D3D_GRAD_TWO
             return D3D_OK;
         }
     }

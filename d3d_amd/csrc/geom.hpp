@@ -972,6 +972,61 @@ __device__ __forceinline__ void giou_rbox_apart_grad(const BoxGeom<T> &a, const 
     defer = !good | touch | !on(ok);
 }
 
+// Gradient of DIoU for the pairs whose bounding boxes are apart: value -d^2 / D^2, so d value = -d(d^2) / D^2 + d^2 d(D^2) / D^4.
+// D^2 is one of the sixteen corner-to-corner distances |F|^2, F = b_j - a_i (d D^2 = 2 F . (d b_j - d a_i)) or a box's own
+// diagonal w^2 + h^2.  Candidates in the scan order of diameter2 (A's diagonal, the cross pairs by i then j, B's diagonal; a later
+// one must be strictly larger), so that symmetric scenes -- equal distances -- pick the same pair as the complete routine does.
+template <typename T>
+__device__ __forceinline__ void diou_rbox_apart_grad(const BoxGeom<T> &a, const HullPre<T> &ha, T w1, T h1, T iw1, T ih1, const BoxGeom<T> &b,
+                                                     const HullPre<T> &hb, T w2, T hgt2, T iw2, T ih2, T (&ga)[5], T (&gb)[5], bool &defer)
+{
+    const T dx = b.cx - a.cx, dy = b.cy - a.cy;
+    const T ex[4] = {dx - hb.px, dx + hb.qx, dx + hb.px, dx - hb.qx}, ey[4] = {dy - hb.py, dy + hb.qy, dy + hb.py, dy - hb.qy};
+    T best = 4 * (ha.hu + ha.hv), fx = 0, fy = 0;
+    int idx = -1;                                              // -1: A's own diagonal; 4 i + j: corners a_i, b_j; 16: B's diagonal
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const T sa = (i == 1 || i == 2) ? (T)1 : (T)-1;
+        const T aix = sa * ((i & 1) ? ha.qx : ha.px), aiy = sa * ((i & 1) ? ha.qy : ha.py);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const T gx = ex[j] - aix, gy = ey[j] - aiy, d = fma(gx, gx, gy * gy);
+            const bool better = d > best;
+            best = better ? d : best; fx = better ? gx : fx; fy = better ? gy : fy; idx = better ? 4 * i + j : idx;
+        }
+    }
+    const T bd = 4 * (hb.hu + hb.hv);
+    if (bd > best) { best = bd; idx = 16; }
+    const T d2 = fma(dx, dx, dy * dy), inv = (T)1 / best, c1 = -inv, c2 = d2 * inv * inv;
+    const bool cross = (idx >= 0) & (idx < 16);
+    const int i = (idx >> 2) & 3, j = idx & 3;
+    const T sui = (i == 1 || i == 2) ? (T)1 : (T)-1, svi = (i >= 2) ? (T)1 : (T)-1;
+    const T suj = (j == 1 || j == 2) ? (T)1 : (T)-1, svj = (j >= 2) ? (T)1 : (T)-1;
+    const T aix = sui * a.ux + svi * a.vx, aiy = sui * a.uy + svi * a.vy, wjx = suj * b.ux + svj * b.vx, wjy = suj * b.uy + svj * b.vy;
+    const T k2 = cross ? 2 * c2 : (T)0;                        // (a diagonal: no F)
+    ga[0] = c1 * (-2 * dx) - k2 * fx; ga[1] = c1 * (-2 * dy) - k2 * fy;
+    ga[2] = -k2 * sui * (fx * a.ux + fy * a.uy) * iw1; ga[3] = -k2 * svi * (fx * a.vx + fy * a.vy) * ih1;
+    ga[4] = -k2 * (fy * aix - fx * aiy);
+    gb[0] = c1 * (2 * dx) + k2 * fx; gb[1] = c1 * (2 * dy) + k2 * fy;
+    gb[2] = k2 * suj * (fx * b.ux + fy * b.uy) * iw2; gb[3] = k2 * svj * (fx * b.vx + fy * b.vy) * ih2;
+    gb[4] = k2 * (fy * wjx - fx * wjy);
+    if (idx < 0) { ga[2] = c2 * 2 * w1; ga[3] = c2 * 2 * h1; }                  // D^2 = w1^2 + h1^2
+    if (idx == 16) { gb[2] = c2 * 2 * w2; gb[3] = c2 * 2 * hgt2; }
+    const bool good = (a.area > 0) & (b.area > 0);
+    const T mrg = (T)16 * (sizeof(T) == 8 ? (T)2.220446049250313e-16 : (T)1.1920929e-7f);
+    const T wx = (fabs(a.ux) + fabs(a.vx)) + (fabs(b.ux) + fabs(b.vx)), wy = (fabs(a.uy) + fabs(a.vy)) + (fabs(b.uy) + fabs(b.vy));
+    const bool touch = (int)(fabs(dx) <= wx + (fabs(a.cx) + fabs(b.cx) + wx) * mrg) & (int)(fabs(dy) <= wy + (fabs(a.cy) + fabs(b.cy) + wy) * mrg);
+    defer = !good | touch;
+}
+
+template <typename T, int KIND>
+__device__ __forceinline__ void loss_rbox_apart_grad(const BoxGeom<T> &a, const HullPre<T> &ha, T w1, T h1, T iw1, T ih1, const BoxGeom<T> &b,
+                                                     const HullPre<T> &hb, T w2, T hgt2, T iw2, T ih2, T (&ga)[5], T (&gb)[5], bool &defer)
+{
+    if (KIND == 0) giou_rbox_apart_grad<T>(a, ha, w1, h1, iw1, ih1, b, hb, w2, hgt2, iw2, ih2, ga, gb, defer);
+    else diou_rbox_apart_grad<T>(a, ha, w1, h1, iw1, ih1, b, hb, w2, hgt2, iw2, ih2, ga, gb, defer);
+}
+
 // DIoU forward of the pairs whose bounding boxes are apart: 0 - d^2 / D^2 with D^2 the largest of the sixteen distances between
 // a corner of A and one of B and of the two boxes' own diagonals (a rectangle's sides are shorter than its diagonal).  Same rule
 // as for GIoU: `defer` = this pair's value is loss_iou_rbox's (boxes that may intersect, boxes without area).
