@@ -418,8 +418,9 @@ def extras(args):
     sync()
     ex["evaluator_calc_stats_20kx5k_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 2)
     del dt9t, gt9t
-    # loss path: GIoU / DIoU have a value for EVERY pair (no candidate list): 8 B/pair written + 160 cross
-    # products per pair for the hull; fp64, 10 k x 10 k of config 3's boxes; backward on the same matrix
+    # loss path: GIoU / DIoU have a value for EVERY pair: 8 B/pair written + the hull (diameter) of the two
+    # rectangles per pair -- round 5: a pair kernel for the boxes that are apart, the pairs that need the clip listed and done one
+    # per lane; fp64, 10 k x 10 k of config 3's boxes; forward + backward on 2 k x 2 k
     nl = 10000
     bl = torch.from_numpy(b[:nl]).cuda()
     for method in ("grbox", "drbox"):
@@ -432,6 +433,12 @@ def extras(args):
         box2d_iou(b1g, b2g, method="grbox").sum().backward()
     dt = timed(fwd_bwd, 5, 1)
     ex["iou2d_grbox_fp64_fwd_bwd_2kx2k_ms"] = round(dt / 5 * 1e3, 3)
+
+    def fwd_bwd_d():
+        b1g.grad = b2g.grad = None
+        box2d_iou(b1g, b2g, method="drbox").sum().backward()
+    dt = timed(fwd_bwd_d, 5, 1)
+    ex["iou2d_drbox_fp64_fwd_bwd_2kx2k_ms"] = round(dt / 5 * 1e3, 3)
     # the reference's OWN IoU benchmark protocol (test/compare/benchmark_riou.py:53-118): n x n rotated IoU of fp32 boxes
     # through box2d_iou (precise=True: fp64 inside), forward, then .sum().backward() into boxes2, for n = 1 ... 5000; boxes as
     # there (centres in +-5, sizes in [0, 5), angles in +-5 rad: 28 % of the pairs overlap).  Times with a device

@@ -418,7 +418,9 @@ int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream);
  * (GRBOX) and of diou2dr_forward[_cuda] (DRBOX)  (reference d3d/box/iou.h:7-69, iou.cpp:12-46,95-141,213-258,322-367,
  * iou_cuda.cu:10-48,100-151,216-440).  boxes1[n,5], boxes2[m,5] = (x,y,w,h,r) in `dtype`;
  * ious[n,m] in `dtype`, row-major.  64-bit pair indexing (cf. iou_cuda.cu:36,137).  The workspace is optional
- * (NULL/0 selects the single-kernel path); with it RBOX runs as zero-fill + candidate list + dense clipping.
+ * (NULL/0 selects the single-kernel path); with it RBOX runs as zero-fill + candidate list + dense clipping, and GRBOX /
+ * DRBOX of more than 65536 pairs as a pair kernel for the boxes that are apart (hull / diameter only) + a list of the pairs
+ * that need the clip or the tie rules + one listed pair per lane.  A pair's value is the same on every path.
  * Matrices of up to 65536 pairs (BOX / RBOX) take one launch with one pair per lane, with or without a workspace.
  * GIoU = IoU - (H - U) / H, H = area of the convex hull of the two rectangles, U = union area; DIoU = IoU - d^2 / D^2,
  * d = distance of the centres, D = diameter of that hull (dgal's source is not vendored: the published definitions);
@@ -436,7 +438,8 @@ int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t
  * diou2dr_backward[_cuda] (DRBOX)  (reference iou.h:14-69, iou.cpp:48-93,143-211,260-320,369-419): grad[n,m] ->
  * grad_boxes1[n,5], grad_boxes2[m,5] (overwritten), all in `dtype`.  The flags the reference saves in forward (nx,
  * xflags, ...) are not needed: the geometry is recomputed analytically.
- * Workspace: d3d_iou2d_workspace_bytes(n, m, dtype) (BOX / RBOX; unused for GRBOX / DRBOX). */
+ * Workspace: d3d_iou2d_workspace_bytes(n, m, dtype); required for BOX / RBOX, optional for GRBOX / DRBOX (with it, matrices
+ * of more than 65536 pairs take a gradient kernel for the pairs that are apart and the complete routine for the rest). */
 int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *boxes2, int64_t m, const void *grad,
                        int32_t iou_type, int32_t dtype, void *grad_boxes1, void *grad_boxes2,
                        void *workspace, size_t workspace_bytes, void *stream);
