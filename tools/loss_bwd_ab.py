@@ -41,3 +41,29 @@ for n in (2000, 6000):
             lib.d3d_profile_report(buf, len(buf))
             ks = " ".join("%s %.0f" % (ln.rsplit(",", 2)[0], 1e3 * float(ln.rsplit(",", 2)[2])) for ln in buf.value.decode().strip().splitlines())
             print(f"{method} {n}x{n} backward, {name} weights: {best * 1e3:8.3f} ms  ({n * n / best / 1e9:6.2f} G pairs/s) | us: {ks}", flush=True)
+
+# a crowded scene (a third of the pairs overlap: most pairs take the complete routine) -- the two-kernel path against the
+# one-kernel path (no workspace), which is what ran before round 5
+from d3d_amd import _lib as _L  # noqa: E402
+dense_boxes, _ = synth.boxes2d_dense(2000, 5)
+for method in ("grbox", "drbox"):
+    for label, patched in (("two kernels", False), ("one kernel", True)):
+        keep = _L.workspace
+        if patched:
+            _L.workspace = lambda nbytes, dev: torch.empty((0,), dtype=torch.uint8, device=dev)
+        try:
+            b1 = torch.from_numpy(dense_boxes[:2000]).cuda().requires_grad_(True)
+            b2 = torch.from_numpy(dense_boxes[:2000].copy()).cuda().requires_grad_(True)
+            w = torch.ones((2000, 2000), dtype=torch.float64, device="cuda")
+            out = box2d_iou(b1, b2, method=method)
+            best = 1e9
+            for _ in range(5):
+                b1.grad = b2.grad = None
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out.backward(w, retain_graph=True)
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            print(f"{method} crowded 2000x2000 backward, {label}: {best * 1e3:8.3f} ms", flush=True)
+        finally:
+            _L.workspace = keep
