@@ -93,6 +93,43 @@ for seed in range(first, first + count):
                         precise=False).cpu().numpy()
         if g32.size and float(np.max(np.abs(g32 - oracle.loss_iou2dr(bs, b2s, meth)))) > 2e-3:
             bad += 1; print("LOSS-IOU fp32 seed", seed, meth, "FAILED")
+    if seed % 4 == 0:        # a MATRIX (> 65536 pairs): the two-kernel paths of round 5 -- forward against the oracle and, bit for bit, against
+        # the same pairs in small calls; backward against the same gradients gathered from row blocks on the one-kernel path
+        nl, ml = int(rng.integers(260, 420)), int(rng.integers(260, 420))
+        side = float(rng.choice([40.0, 200.0, 1500.0]))
+        mk = lambda k: np.stack([rng.random(k) * side, rng.random(k) * side, rng.random(k) * 20 + 1, rng.random(k) * 20 + 1,  # noqa: E731
+                                 (rng.random(k) - 0.5) * 6.3], 1)
+        bl1, bl2 = mk(nl), mk(ml)
+        if seed % 8 == 0:
+            bl2[:50] = bl1[:50]                                  # identical boxes; axis-aligned ones on common edge lines
+            bl1[50:80, 4] = 0.0; bl2[50:80, 4] = 0.0; bl1[50:80, 1] = bl2[50:80, 1] = 7.0; bl1[50:80, 3] = bl2[50:80, 3] = 2.0
+        for meth in ("grbox", "drbox"):
+            t1, t2 = torch.from_numpy(bl1).cuda().requires_grad_(True), torch.from_numpy(bl2).cuda().requires_grad_(True)
+            big = box2d_iou(t1, t2, method=meth)
+            if float(np.max(np.abs(big.detach().cpu().numpy() - oracle.loss_iou2dr(bl1, bl2, meth, nthreads=8)))) > 1e-9:
+                bad += 1; print("LOSS-MATRIX seed", seed, meth, nl, ml, "FAILED against the oracle")
+            r0, c0 = int(rng.integers(0, nl - 100)), int(rng.integers(0, ml - 100))
+            small = box2d_iou(torch.from_numpy(bl1[r0:r0 + 100]).cuda(), torch.from_numpy(bl2[c0:c0 + 100]).cuda(), method=meth)
+            if not torch.equal(small, big.detach()[r0:r0 + 100, c0:c0 + 100]):
+                bad += 1; print("LOSS-MATRIX seed", seed, meth, nl, ml, "a pair's value depends on the path")
+            wl = rng.random((nl, ml)) - 0.3
+            if seed % 12 == 0:
+                wl *= (rng.random((nl, ml)) < 0.01)              # a loss on a few selected pairs
+            (big * torch.from_numpy(wl).cuda()).sum().backward()
+            g1l, g2l = t1.grad.cpu().numpy(), t2.grad.cpu().numpy()
+            r1l, r2l, step = np.zeros_like(g1l), np.zeros_like(g2l), 65536 // ml
+            for q0 in range(0, nl, step):
+                s1, s2 = torch.from_numpy(bl1[q0:q0 + step]).cuda().requires_grad_(True), torch.from_numpy(bl2).cuda().requires_grad_(True)
+                (box2d_iou(s1, s2, method=meth) * torch.from_numpy(wl[q0:q0 + step]).cuda()).sum().backward()
+                r1l[q0:q0 + step] = s1.grad.cpu().numpy()
+                r2l += s2.grad.cpu().numpy()
+            # identical / edge-sharing pairs sit on a kink: both routines return A one-sided derivative there, not always the same one
+            if seed % 8 != 0:
+                sc = max(1.0, float(np.abs(r1l).max()), float(np.abs(r2l).max()))
+                if not (np.isfinite(g1l).all() and np.max(np.abs(g1l - r1l)) < 1e-8 * sc and np.max(np.abs(g2l - r2l)) < 1e-8 * sc):
+                    bad += 1; print("LOSS-MATRIX-GRAD seed", seed, meth, nl, ml, "FAILED", float(np.max(np.abs(g1l - r1l))), float(np.max(np.abs(g2l - r2l))))
+            elif not (np.isfinite(g1l).all() and np.isfinite(g2l).all()):
+                bad += 1; print("LOSS-MATRIX-GRAD seed", seed, meth, "not finite")
     fl = iou2dr_flags(torch.from_numpy(bs).cuda(), torch.from_numpy(b2s).cuda(), which=("nx", "xflags", "nm", "mflags"))
     efl = oracle.iou2dr_flags(bs, b2s)
     if seed % 6 != 0:                                       # (exactly degenerate pairs may round differently on the two sides)
