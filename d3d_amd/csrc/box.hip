@@ -542,6 +542,7 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *
     for (int k = 0; k < 5; k++) { racc[wave][lane][k] = 0; cacc[threadIdx.x][k] = 0; }
     __syncthreads();
     if ((j & ~(int64_t)63) >= m) return;               // a wavefront past the last column (no barrier below)
+    const BoxGeom<T> cmine = cgeo[active ? threadIdx.x : wave * 64];
     unsigned short *q = queue[wave];
     T *qw = qg[wave];
     unsigned int wn = 0;
@@ -571,7 +572,10 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *
         const T g = ring[0];
         ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
         ring[3] = (active && r + 4 < nrows) ? *gp : (T)0;
-        const bool mark = (g != 0) & (aabb_gap(rbox[r], cbox) > 0.f);
+        bool mark = (g != 0) & (aabb_gap(rbox[r], cbox) > 0.f);
+        // a third of the rectangles whose bounding boxes overlap are apart all the same: a separating axis (clear margin) means no
+        // intersection, hence no gradient -- ~60 instructions here against ~2000 in the queue
+        if (mark) mark = !sat_separated(rgeo[r], cmine);
         const unsigned long long word = __ballot(mark);
         if (word == 0) continue;
         const unsigned int cnt = (unsigned int)__popcll(word);
