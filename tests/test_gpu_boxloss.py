@@ -161,6 +161,38 @@ def test_loss_backward_of_a_matrix_two_kernels(method):
                 assert abs(fd - g2[i, k]) < 5e-5 * max(1.0, abs(fd)), (method, which, i, k, fd, g2[i, k])
 
 
+@pytest.mark.parametrize("shape", [(1, 70000), (70000, 1), (257, 257), (1100, 63), (513, 129)])
+def test_matrix_paths_ragged_shapes(shape):
+    """one row, one column, sizes that are no multiple of the 64 x 256 tile or of a wavefront: values against the oracle, gradients
+    against the same gradients gathered from blocks small enough for the one-kernel paths (rbox: its tile kernel in other blocks)"""
+    from d3d_amd.box import box2d_iou
+    n, m = shape
+    rng = np.random.default_rng(n * 7 + m)
+    mk = lambda k: np.stack([rng.random(k) * 300, rng.random(k) * 300, rng.random(k) * 20 + 1, rng.random(k) * 20 + 1,  # noqa: E731
+                             (rng.random(k) - 0.5) * 6.3], 1)
+    b1, b2 = mk(n), mk(m)
+    w = rng.random((n, m)) - 0.3
+    for meth in ("grbox", "drbox", "rbox"):
+        t1, t2 = T(b1).requires_grad_(True), T(b2).requires_grad_(True)
+        out = box2d_iou(t1, t2, method=meth)
+        exp = oracle.loss_iou2dr(b1, b2, meth, nthreads=8) if meth != "rbox" else oracle.box2d_iou(b1, b2, "rbox", nthreads=8)
+        assert float(np.max(np.abs(out.detach().cpu().numpy() - exp))) < 1e-9, meth
+        (out * T(w)).sum().backward()
+        g1, g2 = t1.grad.cpu().numpy(), t2.grad.cpu().numpy()
+        r1, r2 = np.zeros_like(g1), np.zeros_like(g2)
+        cs = min(m, 60000)
+        rs = max(1, min(n, 60000 // cs))
+        for q0 in range(0, n, rs):
+            for c0 in range(0, m, cs):
+                s1, s2 = T(b1[q0:q0 + rs]).requires_grad_(True), T(b2[c0:c0 + cs]).requires_grad_(True)
+                (box2d_iou(s1, s2, method=meth) * T(w[q0:q0 + rs, c0:c0 + cs])).sum().backward()
+                r1[q0:q0 + rs] += s1.grad.cpu().numpy()
+                r2[c0:c0 + cs] += s2.grad.cpu().numpy()
+        sc = max(1.0, float(np.abs(r1).max()), float(np.abs(r2).max()))
+        assert np.isfinite(g1).all() and np.isfinite(g2).all(), meth
+        assert max(float(np.max(np.abs(g1 - r1))), float(np.max(np.abs(g2 - r2)))) < 1e-8 * sc, meth
+
+
 def test_flags_vs_oracle_and_box_impl_tuples():
     from d3d_amd.box import box_impl, iou2dr_flags
     b1, b2 = _rand_boxes(90, 31, 6.0), _rand_boxes(70, 32, 6.0)
