@@ -371,8 +371,10 @@ __device__ __forceinline__ T iou_rbox_core(const BoxCore<T> &ca, const BoxCore<T
 // along its axes), so the midpoint rule is exact.  IoU = I / U, U = A1 + A2 - I:
 //   dIoU = (dI (U + I) - I dA) / U^2,   dA1/dw1 = h1, dA1/dh1 = w1.
 // ga / gb receive the 5 partials (zero when the boxes do not overlap).  Returns the IoU.
+// (iw, ih = 1 / w, 1 / h: round 5 -- the routine made 35 fp64 divisions per pair, ~13 instructions each: two per piece here, eight for
+// the unit axes and ten for the final quotients below; six are left: the four reciprocals, 1 / U^2 and I / U)
 template <typename T>
-__device__ __forceinline__ void piece_grad(T sx, T sy, T ex, T ey, T ox, T oy, T ux, T uy, T vx, T vy, T w, T h, T (&g)[5])
+__device__ __forceinline__ void piece_grad(T sx, T sy, T ex, T ey, T ox, T oy, T ux, T uy, T vx, T vy, T iw, T ih, T (&g)[5])
 {
     // midpoint relative to the owning box's centre (ox, oy), piece vector d
     const T mx = (sx + ex) / 2 - ox, my = (sy + ey) / 2 - oy, dx = ex - sx, dy = ey - sy;
@@ -380,8 +382,8 @@ __device__ __forceinline__ void piece_grad(T sx, T sy, T ex, T ey, T ox, T oy, T
     g[1] += -dx;                                  // v = (0, 1)
     g[4] += -my * dy - mx * dx;                   // v = (-my, mx)
     const T uc = mx * ux + my * uy, vc = mx * vx + my * vy;      // local coordinates along the unit axes
-    g[2] += (uc / w) * (ux * dy - uy * dx);       // v = (uc / w) * u_hat
-    g[3] += (vc / h) * (vx * dy - vy * dx);       // v = (vc / h) * v_hat
+    g[2] += (uc * iw) * (ux * dy - uy * dx);      // v = (uc / w) * u_hat
+    g[3] += (vc * ih) * (vx * dy - vy * dx);      // v = (vc / h) * v_hat
 }
 
 template <typename T>
@@ -397,15 +399,16 @@ __device__ __forceinline__ T iou_rbox_grad(const BoxGeom<T> &a, const BoxGeom<T>
     const T bx[4] = {ox - b.ux - b.vx, ox + b.ux - b.vx, ox + b.ux + b.vx, ox - b.ux + b.vx};
     const T by[4] = {oy - b.uy - b.vy, oy + b.uy - b.vy, oy + b.uy + b.vy, oy - b.uy + b.vy};
     // unit axes of both boxes
-    const T aux = 2 * a.ux / w1, auy = 2 * a.uy / w1, avx = 2 * a.vx / h1, avy = 2 * a.vy / h1;
-    const T bux = 2 * b.ux / w2, buy = 2 * b.uy / w2, bvx = 2 * b.vx / h2, bvy = 2 * b.vy / h2;
+    const T iw1 = (T)1 / w1, ih1 = (T)1 / h1, iw2 = (T)1 / w2, ih2 = (T)1 / h2;
+    const T aux = 2 * a.ux * iw1, auy = 2 * a.uy * iw1, avx = 2 * a.vx * ih1, avy = 2 * a.vy * ih1;
+    const T bux = 2 * b.ux * iw2, buy = 2 * b.uy * iw2, bvx = 2 * b.vx * ih2, bvy = 2 * b.vy * ih2;
     T acc = 0, da[5] = {0, 0, 0, 0, 0}, db[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         T sx, sy, ex, ey;
         if (clip_edge_piece<T, true>(ax[k], ay[k], ax[(k + 1) & 3] - ax[k], ay[(k + 1) & 3] - ay[k], bx, by, sx, sy, ex, ey)) {
             acc += sx * ey - sy * ex;
-            piece_grad<T>(sx, sy, ex, ey, (T)0, (T)0, aux, auy, avx, avy, w1, h1, da);
+            piece_grad<T>(sx, sy, ex, ey, (T)0, (T)0, aux, auy, avx, avy, iw1, ih1, da);
         }
     }
 #pragma unroll
@@ -413,17 +416,17 @@ __device__ __forceinline__ T iou_rbox_grad(const BoxGeom<T> &a, const BoxGeom<T>
         T sx, sy, ex, ey;
         if (clip_edge_piece<T, false>(bx[k], by[k], bx[(k + 1) & 3] - bx[k], by[(k + 1) & 3] - by[k], ax, ay, sx, sy, ex, ey)) {
             acc += sx * ey - sy * ex;
-            piece_grad<T>(sx, sy, ex, ey, ox, oy, bux, buy, bvx, bvy, w2, h2, db);
+            piece_grad<T>(sx, sy, ex, ey, ox, oy, bux, buy, bvx, bvy, iw2, ih2, db);
         }
     }
     const T I = acc / 2;
     if (!(I > 0)) return 0;
-    const T U = a.area + b.area - I, U2 = U * U;
+    const T U = a.area + b.area - I, iU2 = (T)1 / (U * U);
     const T dA1[5] = {0, 0, h1, w1, 0}, dA2[5] = {0, 0, h2, w2, 0};
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        ga[k] = (da[k] * (U + I) - I * dA1[k]) / U2;
-        gb[k] = (db[k] * (U + I) - I * dA2[k]) / U2;
+        ga[k] = (da[k] * (U + I) - I * dA1[k]) * iU2;
+        gb[k] = (db[k] * (U + I) - I * dA2[k]) * iU2;
     }
     return I / U;
 }
@@ -1075,13 +1078,13 @@ __device__ __forceinline__ T diameter2(const Corners8<T> &c, int &i1, int &i2)
 // d(corner k of a box)/d(x, y, w, h, r): corner = centre + su * U + sv * V, U = (w/2)(cos, sin), V = (h/2)(-sin, cos),
 // (su, sv) = (-,-), (+,-), (+,+), (-,+) for k = 0..3.  Adds (gx, gy) . d(corner)/d(param) to g[5].
 template <typename T>
-__device__ __forceinline__ void corner_chain(const BoxGeom<T> &g, T w, T h, int k, T gx, T gy, T (&out)[5])
+__device__ __forceinline__ void corner_chain(const BoxGeom<T> &g, T iw, T ih, int k, T gx, T gy, T (&out)[5])
 {
     const T su = (k == 1 || k == 2) ? (T)1 : (T)-1, sv = (k >= 2) ? (T)1 : (T)-1;
     out[0] += gx;
     out[1] += gy;
-    out[2] += su * (gx * g.ux + gy * g.uy) / w;           // dU/dw = U / w
-    out[3] += sv * (gx * g.vx + gy * g.vy) / h;
+    out[2] += su * (gx * g.ux + gy * g.uy) * iw;          // dU/dw = U / w  (iw = 1 / w: one division per box, not one per corner)
+    out[3] += sv * (gx * g.vx + gy * g.vy) * ih;
     const T rx = su * g.ux + sv * g.vx, ry = su * g.uy + sv * g.vy;      // corner - centre; d/dr = perp
     out[4] += -gx * ry + gy * rx;
 }
@@ -1105,10 +1108,11 @@ __device__ __forceinline__ T loss_iou_rbox(const BoxGeom<T> &a, const BoxGeom<T>
             I = iou * (a.area + b.area) / (1 + iou);
             const T U = a.area + b.area - I;
             const T dA1[5] = {0, 0, h1, w1, 0}, dA2[5] = {0, 0, h2, w2, 0};
+            const T iUI = (T)1 / (U + I);
 #pragma unroll
             for (int k = 0; k < 5; k++) {      // d(I/U) = (dI (U + I) - I dA) / U^2  ->  dI
-                dIa[k] = (ta[k] * U * U + I * dA1[k]) / (U + I);
-                dIb[k] = (tb[k] * U * U + I * dA2[k]) / (U + I);
+                dIa[k] = (ta[k] * U * U + I * dA1[k]) * iUI;
+                dIb[k] = (tb[k] * U * U + I * dA2[k]) * iUI;
             }
         } else {
             I = intersection_area(a, b);
@@ -1123,17 +1127,19 @@ __device__ __forceinline__ T loss_iou_rbox(const BoxGeom<T> &a, const BoxGeom<T>
         const T H = hull_area2<T, GRAD>(c, a, b, gx, gy) / 2;
         if (GRAD) {
             T dHa[5] = {0, 0, 0, 0, 0}, dHb[5] = {0, 0, 0, 0, 0};
+            const T iw1 = (T)1 / w1, ih1 = (T)1 / h1, iw2 = (T)1 / w2, ih2 = (T)1 / h2;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                corner_chain<T>(a, w1, h1, k, gx[k] / 2, gy[k] / 2, dHa);
-                corner_chain<T>(b, w2, h2, k, gx[4 + k] / 2, gy[4 + k] / 2, dHb);
+                corner_chain<T>(a, iw1, ih1, k, gx[k] / 2, gy[k] / 2, dHa);
+                corner_chain<T>(b, iw2, ih2, k, gx[4 + k] / 2, gy[4 + k] / 2, dHb);
             }
             // GIoU = I/U - 1 + U/H
+            const T iU2 = (T)1 / (U * U), iH2 = (T)1 / (H * H);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 const T dUa = dA1[k] - dIa[k], dUb = dA2[k] - dIb[k];
-                ga[k] = (dIa[k] * U - I * dUa) / (U * U) + (dUa * H - U * dHa[k]) / (H * H);
-                gb[k] = (dIb[k] * U - I * dUb) / (U * U) + (dUb * H - U * dHb[k]) / (H * H);
+                ga[k] = (dIa[k] * U - I * dUa) * iU2 + (dUa * H - U * dHa[k]) * iH2;
+                gb[k] = (dIb[k] * U - I * dUb) * iU2 + (dUb * H - U * dHb[k]) * iH2;
             }
         }
         return iou - (H - U) / H;
@@ -1145,19 +1151,21 @@ __device__ __forceinline__ T loss_iou_rbox(const BoxGeom<T> &a, const BoxGeom<T>
         // d(D2) = 2 (p - q) . (dp - dq)
         const T ex = 2 * (c.x[i1] - c.x[i2]), ey = 2 * (c.y[i1] - c.y[i2]);
         T dDa[5] = {0, 0, 0, 0, 0}, dDb[5] = {0, 0, 0, 0, 0};
+        const T iw1 = (T)1 / w1, ih1 = (T)1 / h1, iw2 = (T)1 / w2, ih2 = (T)1 / h2;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const T s1 = (i1 == k ? (T)1 : (T)0) - (i2 == k ? (T)1 : (T)0);
             const T s2 = (i1 == 4 + k ? (T)1 : (T)0) - (i2 == 4 + k ? (T)1 : (T)0);
-            if (s1 != 0) corner_chain<T>(a, w1, h1, k, s1 * ex, s1 * ey, dDa);
-            if (s2 != 0) corner_chain<T>(b, w2, h2, k, s2 * ex, s2 * ey, dDb);
+            if (s1 != 0) corner_chain<T>(a, iw1, ih1, k, s1 * ex, s1 * ey, dDa);
+            if (s2 != 0) corner_chain<T>(b, iw2, ih2, k, s2 * ex, s2 * ey, dDb);
         }
         const T dda[5] = {-2 * ox, -2 * oy, 0, 0, 0}, ddb[5] = {2 * ox, 2 * oy, 0, 0, 0};
+        const T iU2 = (T)1 / (U * U), iD4 = (T)1 / (D2 * D2);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const T dUa = dA1[k] - dIa[k], dUb = dA2[k] - dIb[k];
-            ga[k] = (dIa[k] * U - I * dUa) / (U * U) - (dda[k] * D2 - d2 * dDa[k]) / (D2 * D2);
-            gb[k] = (dIb[k] * U - I * dUb) / (U * U) - (ddb[k] * D2 - d2 * dDb[k]) / (D2 * D2);
+            ga[k] = (dIa[k] * U - I * dUa) * iU2 - (dda[k] * D2 - d2 * dDa[k]) * iD4;
+            gb[k] = (dIb[k] * U - I * dUb) * iU2 - (ddb[k] * D2 - d2 * dDb[k]) * iD4;
         }
     }
     return iou - d2 / D2;
@@ -1229,7 +1237,7 @@ __device__ __forceinline__ T point_box_distance(const BoxGeom<T> &b, T w, T h, T
             if (d > 0) {
                 const T nx = bdx / d, ny = bdy / d;               // (p - c_k) / |p - c_k|
                 gp[0] = -nx; gp[1] = -ny;
-                corner_chain<T>(b, w, h, feat - 4, nx, ny, gb);
+                corner_chain<T>(b, (T)1 / w, (T)1 / h, feat - 4, nx, ny, gb);
             }
         } else {
             // nearest point inside edge k: dist = n . (p - c_k) with n the inward unit normal (left of the edge direction)
@@ -1237,7 +1245,7 @@ __device__ __forceinline__ T point_box_distance(const BoxGeom<T> &b, T w, T h, T
             const T ex = cx[(k + 1) & 3] - cx[k], ey = cy[(k + 1) & 3] - cy[k], len = sqrt(ex * ex + ey * ey);
             const T nx = -ey / len, ny = ex / len;
             gp[0] = nx; gp[1] = ny;
-            corner_chain<T>(b, w, h, k, -nx, -ny, gb);           // - n . d(c_k)
+            corner_chain<T>(b, (T)1 / w, (T)1 / h, k, -nx, -ny, gb);           // - n . d(c_k)
             // the normal turns with the box: dn/dr = perp(n);  (dn/dr) . (p - c_k)
             gb[4] += -ny * (rx0 - cx[k]) + nx * (ry0 - cy[k]);
         }
