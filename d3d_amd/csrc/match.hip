@@ -247,8 +247,7 @@ __global__ __launch_bounds__(kStableThreads) void k_match_stable(const int64_t *
         for (unsigned int k = tid; k < count; k += kStableThreads) {
             const int32_t sidx = first ? (int32_t)k : __hip_atomic_load(&qin[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int32_t c = cand_cnt[sidx], cabs = c < 0 ? -c : c;
-            const int32_t r = first ? (int32_t)__hip_atomic_load(&rank[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                    : __hip_atomic_load(&rank[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int32_t r = __hip_atomic_load(&rank[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int32_t p = first ? 0 : __hip_atomic_load(&ptr[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             const int32_t *list = cand_dst + (int64_t)sidx * kMaxCand;
             while (p < cabs) {
