@@ -219,9 +219,11 @@ __global__ __launch_bounds__(64) void k_match_greedy(const int64_t *__restrict__
 // at once whether it now holds the destination (and whom it displaced: that source goes to the next round's queue and goes
 // on from its next candidate) or was refused (next candidate, same round).  20 k sources against 5 k destinations: a few dozen
 // rounds of a shrinking queue in one workgroup instead of 20 000 dependent steps of one wavefront (k_match_greedy: 8.7 of
-// calc_stats' 13.5 ms).  A source whose list was cut at 64 and runs out of it raises `need_walk`: k_match_greedy then redoes
-// the matching (it sweeps such a row); it exits at once otherwise.
+// calc_stats' 13.5 ms).  A source whose list was cut at 64 and runs out of it raises `need_walk`, and so does a queue that is
+// not empty after kStableRounds rounds: k_match_greedy then redoes the matching (it sweeps such a row); it exits at once otherwise.
 constexpr int kStableThreads = 1024;
+constexpr int kStableRounds = 512;      // a displacement chain longer than this (detections in a row, each preferring its left
+                                        // neighbour's ground truth): one displacement per round -- the walk is the faster routine then
 __global__ __launch_bounds__(kStableThreads) void k_match_stable(const int64_t *__restrict__ order, int64_t n, int64_t m,
                                                                  const int32_t *__restrict__ cand_dst, const int32_t *__restrict__ cand_cnt,
                                                                  int32_t *src_match, int32_t *dst_match, int32_t *rank, int32_t *ptr,
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(kStableThreads) void k_match_stable(const int64_t *
     if (tid == 0) { qn[0] = 0; qn[1] = 0; *need_walk = 0; }
     __threadfence();
     __syncthreads();
-    int cur = 0;
+    int cur = 0, rounds = 0;
     unsigned int count = (unsigned int)n;
     bool first = true;                              // round 0: every source, from the top of its list
     for (;;) {
@@ -273,6 +275,10 @@ __global__ __launch_bounds__(kStableThreads) void k_match_stable(const int64_t *
         cur ^= 1;
         first = false;
         if (count == 0) break;
+        if (++rounds > kStableRounds) {             // (wave-uniform: every thread counts the same rounds)
+            if (tid == 0) *need_walk = 1;
+            break;
+        }
         __syncthreads();
     }
     for (int64_t d = tid; d < m; d += kStableThreads) {

@@ -367,6 +367,29 @@ def test_score_match_and_calc_stats_vs_oracle():
     assert r.ngt[1] == 0 and r.fp[1][0] == 1 and r.tp[1][0] == 0
 
 
+@pytest.mark.parametrize("length", [40, 300, 3000])
+def test_score_match_displacement_chains(length):
+    """detections in a row, each nearest to its LEFT neighbour's ground truth and second nearest to its own, best score first: the
+    sequential rule gives detection i ground truth i; deferred acceptance (k_match_stable) gets there by a chain of displacements,
+    one per round -- short chains inside the kernel, the 3000-long one past its round limit through the walk.  Plus a random
+    background of other pairs."""
+    from d3d_amd.tracking import score_match
+    rng = np.random.default_rng(length)
+    n = m = length + 500
+    dist = np.full((n, m), 9.0, np.float32)
+    idx = np.arange(length)
+    dist[idx, idx] = 0.2
+    dist[idx[1:], idx[:-1]] = 0.1
+    bg = rng.random((500, 500)).astype(np.float32) * 30                     # the rest: an unstructured block of its own (~17 candidates per row)
+    dist[length:, length:] = bg
+    scores = np.concatenate([np.linspace(1.0, 0.5, length), rng.random(500) * 0.4]).astype(np.float32)
+    tags = np.ones((n,), np.int64)
+    sm, dm = score_match(T(dist), scores, tags, tags, {1: 1.0})
+    esm, edm = oracle.score_match_rows(dist, np.stack([tags, scores], 1), np.stack([tags, tags], 1), {1: 1.0})
+    assert np.array_equal(sm.cpu().numpy(), esm) and np.array_equal(dm.cpu().numpy(), edm)
+    assert np.array_equal(sm.cpu().numpy()[:length], idx)
+
+
 def _crowded_scene():
     """two ground truths next to each other, two detections: A (best score) overlaps BOTH ground truths within the threshold
     and is nearest to g1; B overlaps g0 only.  Listed with B first, so that the subset is NOT in score order"""
