@@ -22,6 +22,14 @@ for n in (1000, 2000, 5000):
                            (rng.random(n) - 0.5) * 10], 1).astype(np.float32)
     p1, p2 = torch.from_numpy(mk()).cuda().requires_grad_(True), torch.from_numpy(mk()).cuda().requires_grad_(True)
     out = box2d_iou(p1, p2, method="rbox")
+    torch.cuda.synchronize()
+    lib.d3d_profile_enable(1)
+    box2d_iou(p1, p2, method="rbox")
+    torch.cuda.synchronize()
+    lib.d3d_profile_enable(0)
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.d3d_profile_report(buf, len(buf))
+    print(f"rbox {n}x{n} forward kernels | us: " + " ".join("%s %.0f" % (ln.rsplit(",", 2)[0], 1e3 * float(ln.rsplit(",", 2)[2])) for ln in buf.value.decode().strip().splitlines()), flush=True)
     w = torch.ones_like(out)
     best = 1e9
     for _ in range(6):
