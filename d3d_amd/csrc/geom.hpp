@@ -1036,15 +1036,19 @@ __device__ __forceinline__ void loss_rbox_apart_grad(const BoxGeom<T> &a, const 
 template <typename T>
 __device__ __forceinline__ T diou_rbox_apart(const BoxGeom<T> &a, const HullPre<T> &ha, const BoxGeom<T> &b, const HullPre<T> &hb, bool &defer)
 {
+    // |b_j - a_i|^2 = |E_j|^2 + |a_i|^2 - 2 E_j . a_i with E_j = b_j - centre of A; A's corners are +-P, +-Q of ONE length
+    // (|P|^2 = |Q|^2 = |U|^2 + |V|^2), so the farthest of them from b_j is the one with the largest |E_j . P| or |E_j . Q|:
+    // nine operations per corner of B instead of twenty
     const T dx = b.cx - a.cx, dy = b.cy - a.cy;
     const T ex[4] = {dx - hb.px, dx + hb.qx, dx + hb.px, dx - hb.qx}, ey[4] = {dy - hb.py, dy + hb.qy, dy + hb.py, dy - hb.qy};
-    T best = 4 * fmax(ha.hu + ha.hv, hb.hu + hb.hv);          // |2 (U +- V)|^2 = 4 (|U|^2 + |V|^2)
+    const T ra2 = ha.hu + ha.hv;
+    T far = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const T f0x = ex[j] + ha.px, f0y = ey[j] + ha.py, f1x = ex[j] - ha.qx, f1y = ey[j] - ha.qy;      // a_0 = -P, a_1 = Q
-        const T f2x = ex[j] - ha.px, f2y = ey[j] - ha.py, f3x = ex[j] + ha.qx, f3y = ey[j] + ha.qy;      // a_2 = P, a_3 = -Q
-        best = fmax(fmax(best, fma(f0x, f0x, f0y * f0y)), fmax(fma(f1x, f1x, f1y * f1y), fmax(fma(f2x, f2x, f2y * f2y), fma(f3x, f3x, f3y * f3y))));
+        const T ep = fma(ex[j], ha.px, ey[j] * ha.py), eq = fma(ex[j], ha.qx, ey[j] * ha.qy);
+        far = fmax(far, fma((T)2, fmax(fabs(ep), fabs(eq)), fma(ex[j], ex[j], ey[j] * ey[j])));
     }
+    const T best = fmax(far + ra2, 4 * fmax(ra2, hb.hu + hb.hv));      // ... or a box's own diagonal |2 (U +- V)|^2
     const bool good = (a.area > 0) & (b.area > 0);
     const bool touch = (a.xmin < b.xmax) & (b.xmin < a.xmax) & (a.ymin < b.ymax) & (b.ymin < a.ymax);     // !aabb_disjoint
     defer = !good | touch;
