@@ -67,28 +67,35 @@ class DetectionEvaluator:
         partner = np.where(matched, dm, 0)
         # a ground-truth box is a true positive at threshold t iff its detection is selected there (score >= t)  (:220-238)
         gscore = np.where(matched, dt_score[partner] if len(dt) else 0.0, -np.inf)
-        live = gscore[:, None] >= thr[None, :]                                                        # [m, T]
         dist = np.linalg.norm(gt[:, 2:5] - dt[partner, 2:5], axis=1) if len(dt) else np.zeros(len(gt))          # :244
         box = np.linalg.norm(gt[:, 5:8] - dt[partner, 5:8], axis=1) if len(dt) else np.zeros(len(gt))           # :245
         dyaw = (gt[:, 8] - dt[partner, 8]) if len(dt) else np.zeros(len(gt))
         ang = np.abs((dyaw + np.pi) % (2 * np.pi) - np.pi) / np.pi                                     # quatdiff of two yaw rotations / pi (:247-248)
-        sel = dt_score[:, None] >= thr[None, :]                                                        # [n, T]  (:224-225: score < thres skipped)
         dmatched = sm >= 0
+        vals = np.stack([iou, ang, dist, box]).astype(np.float64)                                      # [4, m]
+
+        def at_least(scores):
+            """#(scores >= t) for every threshold t: one sort instead of a [len, T] comparison (:224-225: score < thres skipped)"""
+            srt = np.sort(scores)
+            return (len(srt) - np.searchsorted(srt, thr, side="left")).astype(np.int64)
         for c in classes:
             g, d = gt_tag == c, dt_tag == c
             out.ngt[c] = int(g.sum())
-            out.ndt[c] = sel[d].sum(0).astype(np.int64).tolist()
-            tp = live[g].sum(0).astype(np.int64)
+            out.ndt[c] = at_least(dt_score[d]).tolist()
+            out.fp[c] = at_least(dt_score[d & ~dmatched]).tolist()
+            # the true positives of threshold t are the matched boxes with gscore >= t: sorted by that score, every threshold is
+            # a prefix -- counts by searchsorted, the sums of the accuracy terms by one cumulative sum (float64, rounded once)
+            gs = gscore[g]
+            o = np.argsort(-gs, kind="stable")
+            gs_sorted = gs[o]
+            tp = np.searchsorted(-gs_sorted, -thr, side="right").astype(np.int64)                      # #(gscore >= t)
             out.tp[c] = tp.tolist()
             out.fn[c] = (out.ngt[c] - tp).tolist()
-            out.fp[c] = (sel[d] & ~dmatched[d][:, None]).sum(0).astype(np.int64).tolist()
-
-            def mean(values):
-                with np.errstate(invalid="ignore", divide="ignore"):
-                    s = (live[g] * values[g][:, None].astype(np.float32)).sum(0, dtype=np.float32)
-                    return np.where(tp > 0, s / tp, np.nan).astype(np.float32).tolist()
-            out.acc_iou[c], out.acc_angular[c] = mean(iou), mean(ang)
-            out.acc_dist[c], out.acc_box[c] = mean(dist), mean(box)
+            csum = np.concatenate([np.zeros((4, 1)), np.cumsum(vals[:, g][:, o], axis=1)], axis=1)      # [4, mc + 1]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                means = np.where(tp[None, :] > 0, csum[:, tp] / tp[None, :], np.nan).astype(np.float32)
+            out.acc_iou[c], out.acc_angular[c] = means[0].tolist(), means[1].tolist()
+            out.acc_dist[c], out.acc_box[c] = means[2].tolist(), means[3].tolist()
             # no variances travel in the [n,9] arrays: orientation_var = 0 -> -inf per match (:250-258), NaN without one
             out.acc_var[c] = np.where(tp > 0, -np.inf, np.nan).astype(np.float32).tolist()
         return out
