@@ -60,7 +60,7 @@ def score_match(distance, src_scores, src_tags, dst_tags, distance_threshold):
     def host(a):                       # tags / scores: numpy arrays, lists, or tensors on any device
         return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     # host-side preparation in numpy (a frame has a few hundred boxes: tensor ops would each cost more than the arithmetic),
-    # shipped to the device as ONE buffer: [order i64 | src tags i32 | dst tags i32 | dst thresholds f32]
+    # shipped to the device as ONE buffer: [src scores f32 | src tags i32 | dst tags i32 | dst thresholds f32]
     st = host(src_tags).astype(np.int32, copy=True).reshape(-1)
     dt = host(dst_tags).astype(np.int32, copy=True).reshape(-1)
     thr = np.full((m,), np.nan, np.float32)
@@ -71,13 +71,15 @@ def score_match(distance, src_scores, src_tags, dst_tags, distance_threshold):
         thr[dt == int(tag)] = float(v)
     st[(st < 0) | ~known[np.clip(st, 0, None)]] = -1
     dt[(dt < 0) | ~known[np.clip(dt, 0, None)]] = -1
-    order = np.argsort(-host(src_scores).astype(np.float32).reshape(-1), kind="stable").astype(np.int64)
-    packed = torch.from_numpy(np.concatenate([order.view(np.uint8), st.view(np.uint8), dt.view(np.uint8), thr.view(np.uint8)]))
+    # the score order: a stable descending sort ON THE DEVICE (equal scores in index order, as numpy's stable argsort of the
+    # negated scores gives them; 20 k scores: 1 ms of numpy on the host against ~50 us) -- the scores ride in the one buffer
+    sc = host(src_scores).astype(np.float32).reshape(-1)
+    packed = torch.from_numpy(np.concatenate([sc.view(np.uint8), st.view(np.uint8), dt.view(np.uint8), thr.view(np.uint8)]))
     with torch.cuda.device(dev):
         packed = packed.to(dev)
-        order = packed[:8 * n].view(torch.int64)
-        st, dt = packed[8 * n:12 * n].view(torch.int32), packed[12 * n:12 * n + 4 * m].view(torch.int32)
-        thr = packed[12 * n + 4 * m:].view(torch.float32)
+        order = torch.sort(packed[:4 * n].view(torch.float32), descending=True, stable=True).indices
+        st, dt = packed[4 * n:8 * n].view(torch.int32), packed[8 * n:8 * n + 4 * m].view(torch.int32)
+        thr = packed[8 * n + 4 * m:].view(torch.float32)
         src_match = torch.empty((n,), dtype=torch.int32, device=dev)
         dst_match = torch.empty((m,), dtype=torch.int32, device=dev)
         status = torch.zeros((1,), dtype=torch.int32, device=dev)
