@@ -78,14 +78,21 @@ __global__ __launch_bounds__(256) void k_match_candidates(const float *__restric
     int bj = 0x7fffffff;
     if (tag >= 0) {
         const float *drow = dist + row * m;
-        for (int64_t j0 = 0; j0 < m; j0 += kWave) {
-            const int64_t j = j0 + lane;
-            float d = INFINITY;
-            bool ok = false;
-            if (j < m) {
-                d = drow[j];
-                ok = dst_tag[j] == tag && d <= thr[j];
-            }
+        // four stretches of 64 columns in flight per step (the sweep is a chain of round trips otherwise: 78 for 5 k columns)
+        for (int64_t jq = 0; jq < m; jq += 4 * kWave) {
+          float dq[4];
+          bool okq[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+              const int64_t j = jq + u * kWave + lane, jc = j < m ? j : m - 1;      // (no branch: the four loads leave together)
+              dq[u] = drow[jc];
+              okq[u] = (j < m) & (dst_tag[jc] == tag) & (dq[u] <= thr[jc]);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int64_t j = jq + u * kWave + lane;
+            const float d = dq[u];
+            const bool ok = okq[u];
             const unsigned long long mask = __ballot(ok);
             if (!mask) continue;
             const int more = __popcll(mask);
@@ -108,6 +115,7 @@ __global__ __launch_bounds__(256) void k_match_candidates(const float *__restric
             wave_sort_pairs(cd, cj, lane);
             wave_merge_lowest(bd, bj, cd, cj, lane);
             found += more;
+          }
         }
     }
     if (found > kMaxCand && lane == 0) atomicOr(overflow, 1);
