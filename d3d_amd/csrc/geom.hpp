@@ -845,14 +845,17 @@ __device__ __forceinline__ T giou_rbox_apart(const BoxGeom<T> &a, const HullPre<
 }
 
 // Gradient of GIoU for the same pairs (apart, every side value clear): GIoU = U / H - 1 with U = A1 + A2, so
-// d GIoU = (dU H - U dH) / H^2, dU = (0, 0, h, w, 0) per box, and dH = 1/2 sum over the hull's corners v of (S_v.y, -S_v.x) . dv
-// with S_v = successor - predecessor of v on the hull.  The side tests run as in hull_area2_clear (A's sixteen predicates held,
-// B's streamed corner by corner); an accepted segment p -> q adds q to S_p and subtracts p from S_q, a bridge both ways at once
-// with its weight +1 / 0 / -1.  A's S_i are complete when corner a_i is through and are folded into seven sums at once (the
-// chain rule of corner = centre + su U + sv V: d/dw = su U / w, d/dh = sv V / h, d/dr = perp(corner - centre)); B's four wait
-// for the loop's end (its edges' decisions are the AND over A's corners).  ~400 vector instructions on ~130 VGPRs; the complete
-// routine (loss_iou_rbox<.., true>) needs 256 + scratch and ran ~1 wavefront per SIMD.
-// inv = (1 / w1, 1 / h1, 1 / w2, 1 / h2).
+// d GIoU = (dU H - U dH) / H^2, dU = (0, 0, h, w, 0) per box.  In the centred form of hull_area2_clear, 2 H is a sum of TEN
+// quantities with piecewise-constant integer coefficients -- the decisions:
+//   2 H = E ea + F eb + G cdu + Hc cdv + A cpd + B cqd + C00 cpw1 + C01 cpw2 + C10 cqw1 + C11 cqw2
+//   ea, eb = area / 2;  cdu, cdv = 2 cross(D, Ub | Vb);  cpd, cqd = cross(P | Q, D);  cXwY = cross(P | Q, W1 | W2)
+// (E, F: accepted edges of A / B; G, Hc: B's edges 0 - 2 / 1 - 3; A, B: +- the bridge weights of corners -P, P / Q, -Q; Cxy: the
+// bridge weights with the signs of both corners).  So the side tests only have to COUNT (two additions per bridge), and the
+// gradient is the coefficients times the derivatives of ten bilinear forms of (P, Q, W1, W2, D):
+//   d/d centre: D moves;  d/dw: U -> U + U dw / w (P and Q both);  d/dh: V likewise (P and -Q);  d/dr: cross(perp X, Y) = -X . Y.
+// First version of this round: successor - predecessor sums per hull corner, five fused multiply-adds per bridge and a chain
+// rule per corner -- ~600 vector instructions per pair against ~380 here, same values to rounding.
+// iw*, ih* = 1 / w, 1 / h.
 template <typename T>
 __device__ __forceinline__ void giou_rbox_apart_grad(const BoxGeom<T> &a, const HullPre<T> &ha, T w1, T h1, T iw1, T ih1, const BoxGeom<T> &b,
                                                      const HullPre<T> &hb, T w2, T hgt2, T iw2, T ih2, T (&ga)[5], T (&gb)[5], bool &defer)
@@ -871,101 +874,78 @@ __device__ __forceinline__ void giou_rbox_apart_grad(const BoxGeom<T> &a, const 
         P[0] = inq | pq; P[2] = inq | ~pq; P[1] = inp | ~pp; P[3] = inp | pp;
     };
     lanes PA[4][4];                                // PA[t][k]: corner t of B strictly left of edge k of A
+    const T du = fma(dx, a.ux, dy * a.uy), dv = fma(dx, a.vx, dy * a.vy);               // D . Ua, D . Va
     {
-        const T p0 = fma(dx, a.ux, dy * a.uy), q0 = fma(dx, a.vx, dy * a.vy), tol = ext * ha.r;
+        const T tol = ext * ha.r;
         const T ps = uu + uv, pd = uu - uv, qs = vu + vv, qd = vu - vv;
-        side(p0 - ps, q0 - qs, ha.hu, ha.hv, tol, PA[0]); side(p0 + pd, q0 + qd, ha.hu, ha.hv, tol, PA[1]);
-        side(p0 + ps, q0 + qs, ha.hu, ha.hv, tol, PA[2]); side(p0 - pd, q0 - qd, ha.hu, ha.hv, tol, PA[3]);
+        side(du - ps, dv - qs, ha.hu, ha.hv, tol, PA[0]); side(du + pd, dv + qd, ha.hu, ha.hv, tol, PA[1]);
+        side(du + ps, dv + qs, ha.hu, ha.hv, tol, PA[2]); side(du - pd, dv - qd, ha.hu, ha.hv, tol, PA[3]);
     }
-    lanes EA[4];
-    T h2 = 0;
-    const T ea = a.area / 2;
+    T cE = 0;                                      // accepted edges of A
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        EA[k] = PA[0][k] & PA[1][k] & PA[2][k] & PA[3][k];
-        h2 = fma(unit_pm(on(EA[k]), false, (T)0), ea, h2);
-    }
-    // corners relative to A's centre: a_i = -P, Q, P, -Q;  b_j = D + w_j, w_j = -W1, W2, W1, -W2
-    const T cpd = fma(ha.px, dy, -(ha.py * dx)), cqd = fma(ha.qx, dy, -(ha.qy * dx));
-    const T cpw1 = fma(ha.px, hb.py, -(ha.py * hb.px)), cpw2 = fma(ha.px, hb.qy, -(ha.py * hb.qx));
-    const T cqw1 = fma(ha.qx, hb.py, -(ha.qy * hb.px)), cqw2 = fma(ha.qx, hb.qy, -(ha.qy * hb.qx));
-    const T p0 = -fma(dx, b.ux, dy * b.uy), q0 = -fma(dx, b.vx, dy * b.vy), tol = ext * hb.r;
+    for (int k = 0; k < 4; k++) cE += unit_pm(on(PA[0][k] & PA[1][k] & PA[2][k] & PA[3][k]), false, (T)0);
+    const T dub = fma(dx, b.ux, dy * b.uy), dvb = fma(dx, b.vx, dy * b.vy);             // D . Ub, D . Vb
+    const T p0 = -dub, q0 = -dvb, tol = ext * hb.r;
     const T ps = uu + vu, pd = uu - vu, qs = uv + vv, qd = uv - vv;
     lanes EB[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-    T sbx[4] = {0, 0, 0, 0}, sby[4] = {0, 0, 0, 0};              // S of B's corners
-    T asx = 0, asy = 0, ausx = 0, ausy = 0, avsx = 0, avsy = 0, adot = 0;       // A: sum S, sum su S, sum sv S, sum S . (corner - centre)
-    asm volatile("" : "+v"(h2));
+    T cA = 0, cB = 0, c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+    asm volatile("" : "+v"(cE));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         lanes PB[4];
         side(i == 0 ? p0 - ps : i == 1 ? p0 + pd : i == 2 ? p0 + ps : p0 - pd, i == 0 ? q0 - qs : i == 1 ? q0 + qd : i == 2 ? q0 + qs : q0 - qd,
              hb.hu, hb.hv, tol, PB);
-        const T sa = (i == 1 || i == 2) ? (T)1 : (T)-1;
-        const T aix = sa * ((i & 1) ? ha.qx : ha.px), aiy = sa * ((i & 1) ? ha.qy : ha.py);          // a_i
-        const T cad = sa * ((i & 1) ? cqd : cpd);
-        const int ip = (i + 3) & 3, in = (i + 1) & 3;
-        // A's own edges at a_i: edge i leaves it (towards a_i+1), edge i - 1 reaches it (from a_i-1); a_i+1 = -a_i-1
-        const T sn = (in == 1 || in == 2) ? (T)1 : (T)-1;
-        const T anx = sn * ((in & 1) ? ha.qx : ha.px), any_ = sn * ((in & 1) ? ha.qy : ha.py);       // a_i+1 (a_i-1 = its negative)
-        const T wo = unit_pm(on(EA[i]), false, (T)0) + unit_pm(on(EA[ip]), false, (T)0);            // S_i += a_i+1 - a_i-1 = (. + .) a_i+1
-        T six = wo * anx, siy = wo * any_, wsum = 0;             // b_j = D + w_j: the D part of S_i is (sum of the weights) D
+        const bool sa_pos = (i == 1 || i == 2);
+        const int ip = (i + 3) & 3;
+        T rs = 0;                                  // the sum of corner a_i's bridge weights
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             EB[j] &= PB[j];
-            const T sw = (j == 1 || j == 2) ? (T)1 : (T)-1;
-            const T caw = (i & 1) ? ((j & 1) ? cqw2 : cqw1) : ((j & 1) ? cpw2 : cpw1);
-            const T x = cad + (sa * sw) * caw;
+            const bool sw_pos = (j == 1 || j == 2);
             const int jp = (j + 3) & 3;
             const lanes ab = ~PA[j][i] & PA[j][ip] & PB[j] & ~PB[jp], ba = PA[j][i] & ~PA[j][ip] & ~PB[j] & PB[jp];
             const T w = unit_pm(on(ab), on(ba), (T)0);
-            h2 = fma(w, x, h2);
-            wsum += w;
-            six = fma(sw * w, (j & 1) ? hb.qx : hb.px, six); siy = fma(sw * w, (j & 1) ? hb.qy : hb.py, siy);
-            sbx[j] = fma(-w, aix, sbx[j]); sby[j] = fma(-w, aiy, sby[j]);
+            rs += w;
+            const T ws = (sa_pos == sw_pos) ? w : -w;                    // sa sw w
+            if (i & 1) { if (j & 1) c11 += ws; else c10 += ws; }
+            else       { if (j & 1) c01 += ws; else c00 += ws; }
         }
-        six = fma(wsum, dx, six); siy = fma(wsum, dy, siy);
-        const bool su = (i == 1 || i == 2), sv = (i >= 2);
-        asx += six; asy += siy;
-        ausx += su ? six : -six; ausy += su ? siy : -siy;
-        avsx += sv ? six : -six; avsy += sv ? siy : -siy;
-        adot = fma(six, aix, fma(siy, aiy, adot));
-        asm volatile("" : "+v"(h2), "+v"(adot));
+        if (i & 1) cB += sa_pos ? rs : -rs;
+        else       cA += sa_pos ? rs : -rs;
+        asm volatile("" : "+v"(cA), "+v"(cB));
         __builtin_amdgcn_sched_barrier(0);
     }
-    // B's edges: k leaves b_k towards b_k+1
-    const T eb = b.area / 2;
+    const T web0 = unit_pm(on(EB[0]), false, (T)0), web1 = unit_pm(on(EB[1]), false, (T)0);
+    const T web2 = unit_pm(on(EB[2]), false, (T)0), web3 = unit_pm(on(EB[3]), false, (T)0);
+    const T cF = (web0 + web1) + (web2 + web3), cG = web0 - web2, cH = web1 - web3;
+    // the ten forms
+    const T ea = a.area / 2, eb = b.area / 2;
     const T cdu = 2 * fma(dx, b.uy, -(dy * b.ux)), cdv = 2 * fma(dx, b.vy, -(dy * b.vx));
-    const T ebk[4] = {eb + cdu, eb + cdv, eb - cdu, eb - cdv};
-    T bsx = 0, bsy = 0, busx = 0, busy = 0, bvsx = 0, bvsy = 0, bdot = 0;
-    T web[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { web[k] = unit_pm(on(EB[k]), false, (T)0); h2 = fma(web[k], ebk[k], h2); }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int jn = (j + 1) & 3, jp = (j + 3) & 3;
-        const bool su = (j == 1 || j == 2), sv = (j >= 2);
-        const T sw = su ? (T)1 : (T)-1;
-        const T wjx = sw * ((j & 1) ? hb.qx : hb.px), wjy = sw * ((j & 1) ? hb.qy : hb.py);        // b_j - centre of B = w_j
-        // b_j+1 = D + w_j+1 = D + perp-neighbour of w_j; b_j-1 = D - w_j+1 ... spelled out: w_j+1 and w_j-1 = -w_j+1
-        const T sn = (jn == 1 || jn == 2) ? (T)1 : (T)-1;
-        const T wnx = sn * ((jn & 1) ? hb.qx : hb.px), wny = sn * ((jn & 1) ? hb.qy : hb.py);      // w_j+1 (w_j-1 = its negative)
-        const T wd = web[j] - web[jp], ws = web[j] + web[jp];
-        const T sjx = fma(wd, dx, fma(ws, wnx, sbx[j])), sjy = fma(wd, dy, fma(ws, wny, sby[j]));
-        bsx += sjx; bsy += sjy;
-        busx += su ? sjx : -sjx; busy += su ? sjy : -sjy;
-        bvsx += sv ? sjx : -sjx; bvsy += sv ? sjy : -sjy;
-        bdot = fma(sjx, wjx, fma(sjy, wjy, bdot));
-    }
+    const T cpd = fma(ha.px, dy, -(ha.py * dx)), cqd = fma(ha.qx, dy, -(ha.qy * dx));
+    const T cpw1 = fma(ha.px, hb.py, -(ha.py * hb.px)), cpw2 = fma(ha.px, hb.qy, -(ha.py * hb.qx));
+    const T cqw1 = fma(ha.qx, hb.py, -(ha.qy * hb.px)), cqw2 = fma(ha.qx, hb.qy, -(ha.qy * hb.qx));
+    const T h2 = fma(cE, ea, fma(cF, eb, fma(cG, cdu, fma(cH, cdv, fma(cA, cpd, fma(cB, cqd, fma(c00, cpw1, fma(c01, cpw2, fma(c10, cqw1, c11 * cqw2)))))))));
+    // d (2 H): centres (D = centre of B - centre of A)
+    const T gx = fma(cA, ha.py, fma(cB, ha.qy, -2 * fma(cG, b.uy, cH * b.vy)));          // d / d a.cx;  d / d b.cx = -gx
+    const T gy = -fma(cA, ha.px, fma(cB, ha.qx, -2 * fma(cG, b.ux, cH * b.vx)));         // d / d a.cy
+    // sizes of A: dP = dQ = Ua dw / w;  dP = -dQ = Va dh / h  (cross(Ua, X) = (cross(P, X) + cross(Q, X)) / 2, Va: the difference)
+    const T gwa = (fma(cA + cB, cpd + cqd, fma(c00 + c10, cpw1 + cqw1, (c01 + c11) * (cpw2 + cqw2))) / 2 + cE * ea) * iw1;
+    const T gha = (fma(cA - cB, cpd - cqd, fma(c00 - c10, cpw1 - cqw1, (c01 - c11) * (cpw2 - cqw2))) / 2 + cE * ea) * ih1;
+    // sizes of B: dW1 = dW2 = Ub dw / w;  dW1 = -dW2 = Vb dh / h
+    const T gwb = (fma(c00 + c01, cpw1 + cpw2, (c10 + c11) * (cqw1 + cqw2)) / 2 + fma(cF, eb, cG * cdu)) * iw2;
+    const T ghb = (fma(c00 - c01, cpw1 - cpw2, (c10 - c11) * (cqw1 - cqw2)) / 2 + fma(cF, eb, cH * cdv)) * ih2;
+    // angles: cross(perp X, Y) = -X . Y,  cross(X, perp Y) = X . Y
+    const T dpd = fma(ha.px, dx, ha.py * dy), dqd = fma(ha.qx, dx, ha.qy * dy);
+    const T dpw1 = fma(ha.px, hb.px, ha.py * hb.py), dpw2 = fma(ha.px, hb.qx, ha.py * hb.qy);
+    const T dqw1 = fma(ha.qx, hb.px, ha.qy * hb.py), dqw2 = fma(ha.qx, hb.qx, ha.qy * hb.qy);
+    const T cw = fma(c00, dpw1, fma(c01, dpw2, fma(c10, dqw1, c11 * dqw2)));
+    const T gra = -(fma(cA, dpd, cB * dqd) + cw);
+    const T grb = cw + 2 * fma(cG, dub, cH * dvb);
     const T H = h2 / 2, U = a.area + b.area;
-    const T c1 = (T)1 / H, c2 = U * c1 * c1 / 2;              // dU / H  and  U / H^2 * (the 1/2 of dH)
-    // dH = 1/2 (S.y, -S.x) . d(corner):  d/dcx = sum S.y, d/dcy = -sum S.x, d/dw = (ux sum su S.y - uy sum su S.x) / w, d/dr = -sum S . (corner - centre)
-    ga[0] = -c2 * asy; ga[1] = c2 * asx;
-    ga[2] = h1 * c1 - c2 * (a.ux * ausy - a.uy * ausx) * iw1; ga[3] = w1 * c1 - c2 * (a.vx * avsy - a.vy * avsx) * ih1;
-    ga[4] = c2 * adot;
-    gb[0] = -c2 * bsy; gb[1] = c2 * bsx;
-    gb[2] = hgt2 * c1 - c2 * (b.ux * busy - b.uy * busx) * iw2; gb[3] = w2 * c1 - c2 * (b.vx * bvsy - b.vy * bvsx) * ih2;
-    gb[4] = c2 * bdot;
+    const T c1 = (T)1 / H, c2 = U * c1 * c1 / 2;              // dU / H  and  U / H^2 * (the 1/2 of d H = d (2 H) / 2)
+    ga[0] = -c2 * gx; ga[1] = -c2 * gy; ga[2] = h1 * c1 - c2 * gwa; ga[3] = w1 * c1 - c2 * gha; ga[4] = -c2 * gra;
+    gb[0] = c2 * gx; gb[1] = c2 * gy; gb[2] = hgt2 * c1 - c2 * gwb; gb[3] = w2 * c1 - c2 * ghb; gb[4] = -c2 * grb;
     // the bounding boxes from the half-extent vectors, with a margin for the rounding of the stored ones: a superset of the exact
     // test (aabb_disjoint), which is all the rule needs -- a deferred pair gets the complete routine, and that applies the exact one
     const bool good = (a.area > 0) & (b.area > 0);
