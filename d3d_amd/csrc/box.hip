@@ -439,69 +439,11 @@ __global__ __launch_bounds__(256) void k_iou3d_small(const float *__restrict__ b
 }
 
 // ---------------------------------------------------------------- IoU backward (loss path, "next" row 2)
-// grad_boxes1[i] = sum_j grad[i,j] * dIoU(i,j)/d box1_i, grad_boxes2[j] likewise (reference iou.cpp:48-93, 143-211).
-// One overlapping pair per lane from the candidate list, analytic gradients (geom.hpp), 10 float atomics per pair --
-// the reference's CUDA kernels accumulate with plain += from many threads (iou_cuda.cu:72-73,184-185: a data race).
-template <typename T, bool ROTATED>
-__global__ __launch_bounds__(256) void k_iou_grad(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb,
-                                                  const T *__restrict__ b1, const T *__restrict__ b2,
-                                                  const T *__restrict__ grad, int64_t m, const IouList *hdr,
-                                                  const unsigned long long *__restrict__ list, unsigned long long cap,
-                                                  T *g1, T *g2)
-{
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / hdr->nseg;
-    for (unsigned int sg = 0; sg < hdr->nseg; sg++) {
-    const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
-    const unsigned long long *seg = list + sg * segcap;
-    // wave-uniform trip count: the row gradients of a wavefront's candidates are summed across the lanes first.  The list holds a
-    // row's candidates next to each other (k_iou_pre appends them row by row), so the 64 entries of a wavefront share a few rows:
-    // a segmented scan over runs of equal i (head flags: correct for any sequence, a row that comes back later is a run of its
-    // own) leaves one atomicAdd per run and component instead of one per pair -- the kernel ran at the rate of its ten scattered
-    // fp64 atomics per overlapping pair (3 k x 3 k at 28 % overlap: 25 M atomics on 30 k addresses, 853 us)
-    const int lane = threadIdx.x & (kWave - 1);
-    for (unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x - lane; t0 < total; t0 += stride) {
-        const unsigned long long t = t0 + lane;
-        const bool in = t < total;
-        const unsigned long long e = in ? seg[t] : 0ull;
-        const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
-        const T g = in ? grad[i * m + j] : (T)0;
-        T da[5] = {0, 0, 0, 0, 0}, db[5] = {0, 0, 0, 0, 0};
-        if (g != 0) {
-            const T *pa = b1 + i * 5, *pb = b2 + j * 5;
-            if (ROTATED) iou_rbox_grad<T>(ga[i], gb[j], pa[2], pa[3], pb[2], pb[3], da, db);
-            else iou_aabb_grad<T>(ga[i], gb[j], pa, pb, da, db);
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                da[k] *= g;
-                if (db[k] != 0) atomicAdd(&g2[j * 5 + k], g * db[k]);
-            }
-        }
-        const long long key = in ? (long long)i : -1ll - lane;
-        const long long prev = __shfl_up(key, 1, kWave);
-        bool head = lane == 0 || prev != key;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            T v2[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) v2[k] = __shfl_up(da[k], off, kWave);
-            const bool h2 = __shfl_up((int)head, off, kWave) != 0;
-            if (lane >= off && !head) {
-#pragma unroll
-                for (int k = 0; k < 5; k++) da[k] += v2[k];
-                head = h2;
-            }
-        }
-        const long long next = __shfl_down(key, 1, kWave);
-        if (in && (lane == kWave - 1 || next != key)) {          // the last lane of a run holds the run's sums
-#pragma unroll
-            for (int k = 0; k < 5; k++)
-                if (da[k] != 0) atomicAdd(&g1[i * 5 + k], da[k]);
-        }
-    }
-    }
-}
-
-// Rotated IoU backward over TILES (round 5).  The list form above paid five scattered fp64 atomics per overlapping pair for the
+// grad_boxes1[i] = sum_j grad[i,j] * dIoU(i,j)/d box1_i, grad_boxes2[j] likewise (reference iou.cpp:48-93, 143-211); analytic
+// gradients (geom.hpp).  The reference's CUDA kernels accumulate with plain += from many threads (iou_cuda.cu:72-73,184-185: a
+// data race).  Rounds 2-4 ran one listed pair per lane (k_iou_pre's candidate list), the row sums by a segmented scan across the
+// wavefront and FIVE scattered fp64 atomics per pair for the columns; round 5 replaced that by tiles:
+// IoU backward over TILES (round 5).  The list form paid five scattered fp64 atomics per overlapping pair for the
 // column gradients: 720 of k_iou_grad's 1434 us on the reference's benchmark boxes at 5 k x 5 k (5.15 M overlapping pairs; without
 // those atomics 714 us, without the segmented scan either 645 us) -- plus 109 us of k_iou_pre for the list.  Here a workgroup owns
 // a tile of `tile_rows` x 256 pairs: every wavefront walks its 64 columns row by row, marks the pairs with a weight whose
@@ -509,7 +451,7 @@ __global__ __launch_bounds__(256) void k_iou_grad(const BoxGeom<T> *__restrict__
 // are together; then every lane takes one pair through iou_rbox_grad and adds the ten products to LDS accumulators (ds_add_f64:
 // per row of the tile and wavefront, per column).  The accumulators go to memory once per tile, side by side.  No list.
 constexpr int kGradCols = 256;
-template <typename T>
+template <typename T, bool ROTATED>
 __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *__restrict__ ga, const float4 *__restrict__ ra,
                                                               const T *__restrict__ b1, int64_t n, const BoxGeom<T> *__restrict__ gb,
                                                               const float4 *__restrict__ cb, const T *__restrict__ b2, int64_t m,
@@ -552,7 +494,8 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *
             const unsigned int e = q[lane], r = e >> 8, c = e & 63u;
             const T g = qw[lane];
             T da[5], db[5];
-            iou_rbox_grad<T>(rgeo[r], cgeo[wave * 64 + c], rwh[r][0], rwh[r][1], cwh[wave * 64 + c][0], cwh[wave * 64 + c][1], da, db);
+            if (ROTATED) iou_rbox_grad<T>(rgeo[r], cgeo[wave * 64 + c], rwh[r][0], rwh[r][1], cwh[wave * 64 + c][0], cwh[wave * 64 + c][1], da, db);
+            else iou_aabb_grad<T>(rgeo[r], cgeo[wave * 64 + c], b1 + (i0 + r) * 5, b2 + (jb + wave * 64 + c) * 5, da, db);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 if (da[k] != 0) atomicAdd(&racc[wave][r][k], g * da[k]);
@@ -575,7 +518,7 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *
         bool mark = (g != 0) & (aabb_gap(rbox[r], cbox) > 0.f);
         // a third of the rectangles whose bounding boxes overlap are apart all the same: a separating axis (clear margin) means no
         // intersection, hence no gradient -- ~60 instructions here against ~2000 in the queue
-        if (mark) mark = !sat_separated(rgeo[r], cmine);
+        if (ROTATED && mark) mark = !sat_separated(rgeo[r], cmine);
         const unsigned long long word = __ballot(mark);
         if (word == 0) continue;
         const unsigned int cnt = (unsigned int)__popcll(word);
@@ -2753,47 +2696,25 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     BoxGeom<T> *gb = w.take<BoxGeom<T>>(m);
     float4 *ra = w.take<float4>(n);
     float4 *cb = w.take<float4>(m);
-    IouList *hdr = w.take<IouList>(1);
-    // every AABB-overlapping pair must be listed (no fallback here): capacity = all pairs, processed in row chunks
-    const unsigned long long cap_all = iou_list_capacity(n, m);
-    unsigned long long *list = w.take<unsigned long long>(cap_all);
-    if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;
+    if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;      // (geometry and candidate boxes of both sets: the front of the forward's workspace)
     D3D_HIP_CHECK(hipMemsetAsync(g1, 0, sizeof(T) * 5 * (size_t)n, st));
     D3D_HIP_CHECK(hipMemsetAsync(g2, 0, sizeof(T) * 5 * (size_t)m, st));
     D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u,
                rot);
-    if (rot) {                                         // rotated boxes: tiles with LDS accumulators, no list (k_iou_grad_tiles)
+    {                                                  // tiles with LDS accumulators, no list (k_iou_grad_tiles)
         D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, ra, (IouList *)nullptr, 1u, rot);
         int tr = kTileRows;                            // fewer rows per workgroup while the launch is short of 2048 workgroups
         while (tr > 8 && d3d_divup(m, kGradCols) * d3d_divup(n, tr) < 2048) tr >>= 1;
         const int64_t rows_max = (int64_t)65535 * tr;
         for (int64_t r0 = 0; r0 < n; r0 += rows_max) {
             const int64_t nr = (n - r0) < rows_max ? (n - r0) : rows_max;
-            D3D_LAUNCH("k_iou_grad_tiles", k_iou_grad_tiles<T>, dim3((unsigned)d3d_divup(m, kGradCols), (unsigned)d3d_divup(nr, tr)),
-                       dim3(kGradCols), 0, st, (const BoxGeom<T> *)ga + r0, (const float4 *)ra + r0, b1 + r0 * 5, nr, (const BoxGeom<T> *)gb,
-                       (const float4 *)cb, b2, m, grad + r0 * m, g1 + r0 * 5, g2, tr);
+#define D3D_GRAD_TILES(R)                                                                                                                   \
+    D3D_LAUNCH("k_iou_grad_tiles", (k_iou_grad_tiles<T, R>), dim3((unsigned)d3d_divup(m, kGradCols), (unsigned)d3d_divup(nr, tr)),               \
+               dim3(kGradCols), 0, st, (const BoxGeom<T> *)ga + r0, (const float4 *)ra + r0, b1 + r0 * 5, nr, (const BoxGeom<T> *)gb,        \
+               (const float4 *)cb, b2, m, grad + r0 * m, g1 + r0 * 5, g2, tr)
+            if (rot) D3D_GRAD_TILES(true); else D3D_GRAD_TILES(false);
+#undef D3D_GRAD_TILES
         }
-        return D3D_OK;
-    }
-    // rows in chunks such that chunk_rows * m <= capacity: the list can then never overflow
-    int64_t rows_per = (int64_t)(cap_all / (unsigned long long)m);
-    if (rows_per < 1) return D3D_ERR_BAD_ARG;
-    rows_per = rows_per / kTileRows * kTileRows;
-    if (rows_per < kTileRows) rows_per = kTileRows < n ? kTileRows : n;
-    if ((unsigned long long)rows_per * (unsigned long long)m > cap_all && rows_per > n) rows_per = n;
-    for (int64_t r0 = 0; r0 < n; r0 += rows_per) {
-        const int64_t nr = (n - r0) < rows_per ? (n - r0) : rows_per;
-        if ((unsigned long long)nr * (unsigned long long)m > cap_all) return D3D_ERR_WORKSPACE;
-        D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(nr, 256)), dim3(256), 0, st, b1 + r0 * 5, nr, ga, ra, hdr, 1u,
-                   rot);
-        D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), (unsigned)d3d_divup(nr, kTileRows)),
-                   dim3(kTileCols), 0, st, (const float4 *)ra, nr, (const float4 *)cb, m, (T *)nullptr, hdr, list, cap_all);
-        if (rot)
-            D3D_LAUNCH("k_iou_grad", (k_iou_grad<T, true>), dim3(256 * 8), dim3(256), 0, st, ga, gb, b1 + r0 * 5, b2, grad + r0 * m, m,
-                       hdr, list, cap_all, g1 + r0 * 5, g2);
-        else
-            D3D_LAUNCH("k_iou_grad", (k_iou_grad<T, false>), dim3(256 * 8), dim3(256), 0, st, ga, gb, b1 + r0 * 5, b2, grad + r0 * m, m,
-                       hdr, list, cap_all, g1 + r0 * 5, g2);
     }
     return D3D_OK;
 }
