@@ -172,10 +172,10 @@ def test_matrix_paths_ragged_shapes(shape):
                              (rng.random(k) - 0.5) * 6.3], 1)
     b1, b2 = mk(n), mk(m)
     w = rng.random((n, m)) - 0.3
-    for meth in ("grbox", "drbox", "rbox"):
+    for meth in ("grbox", "drbox", "rbox", "box"):
         t1, t2 = T(b1).requires_grad_(True), T(b2).requires_grad_(True)
         out = box2d_iou(t1, t2, method=meth)
-        exp = oracle.loss_iou2dr(b1, b2, meth, nthreads=8) if meth != "rbox" else oracle.box2d_iou(b1, b2, "rbox", nthreads=8)
+        exp = oracle.loss_iou2dr(b1, b2, meth, nthreads=8) if meth in ("grbox", "drbox") else oracle.box2d_iou(b1, b2, meth, nthreads=8)
         assert float(np.max(np.abs(out.detach().cpu().numpy() - exp))) < 1e-9, meth
         (out * T(w)).sum().backward()
         g1, g2 = t1.grad.cpu().numpy(), t2.grad.cpu().numpy()
