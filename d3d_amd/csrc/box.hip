@@ -451,12 +451,158 @@ __global__ __launch_bounds__(256) void k_iou3d_small(const float *__restrict__ b
 // are together; then every lane takes one pair through iou_rbox_grad and adds the ten products to LDS accumulators (ds_add_f64:
 // per row of the tile and wavefront, per column).  The accumulators go to memory once per tile, side by side.  No list.
 constexpr int kGradCols = 256;
+constexpr int kMarkStripes = 64;             // counters of the marks
+
+// The marking as a kernel of its own (a few dozen VGPRs, full occupancy): one bit per pair that has a weight, overlapping
+// conservative bounding boxes and (rotated) no separating axis, one 64-bit word per row and wavefront of columns.  Inside the
+// gradient kernel -- 246 VGPRs, two wavefronts per SIMD -- the same loop ran the 400 M pairs of 20 k x 20 k boxes at config 3's
+// density in 0.62 ms; the list form of rounds 2-4 took 0.22 ms for that call.  Lane = 2 columns (two words per wavefront and row).
+template <typename T, bool ROTATED>
+__global__ __launch_bounds__(kGradCols) void k_iou_grad_mark(const BoxGeom<T> *__restrict__ ga, const float4 *__restrict__ ra, int64_t n,
+                                                             const BoxGeom<T> *__restrict__ gb, const float4 *__restrict__ cb, int64_t m,
+                                                             const T *__restrict__ grad, unsigned long long *__restrict__ bitmap,
+                                                             int64_t wpr, int tile_rows, unsigned long long *nmarks)
+{
+    __shared__ BoxCore<T> rcore[kTileRows];
+    __shared__ float4 rbox[kTileRows];
+    unsigned int mymarks = 0;                          // (lane 0 of every wavefront: the bits it wrote)
+    const int64_t i0 = (int64_t)blockIdx.y * tile_rows, jb = (int64_t)blockIdx.x * (2 * kGradCols);
+    const int nrows = (int)((n - i0) < tile_rows ? (n - i0) : tile_rows);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    if (threadIdx.x < nrows) { rcore[threadIdx.x] = core_of(ga[i0 + threadIdx.x]); rbox[threadIdx.x] = ra[i0 + threadIdx.x]; }
+    __syncthreads();
+    // the wavefront's 128 columns: lane l holds columns l and 64 + l of them (word 2 * wave and 2 * wave + 1 of the workgroup)
+    const int64_t j0 = jb + wave * 128 + lane, j1 = j0 + 64;
+    if (jb + wave * 128 >= m) return;
+    const bool a0 = j0 < m, a1 = j1 < m;
+    const float4 c0 = a0 ? cb[j0] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+    const float4 c1 = a1 ? cb[j1] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+    BoxCore<T> k0, k1;
+    if (ROTATED) { k0 = core_of(gb[a0 ? j0 : m - 1]); k1 = core_of(gb[a1 ? j1 : m - 1]); }
+    const int64_t w0 = (jb + wave * 128) >> 6;
+    const bool two = jb + wave * 128 + 64 < m;
+    for (int r0 = 0; r0 < nrows; r0 += 4) {
+        bool x0[4], x1[4];
+        bool some = false;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float4 rb = rbox[r0 + u < nrows ? r0 + u : r0];
+            x0[u] = (r0 + u < nrows) & (aabb_gap(rb, c0) > 0.f);
+            x1[u] = (r0 + u < nrows) & (aabb_gap(rb, c1) > 0.f);
+            some |= x0[u] | x1[u];
+        }
+        if (!__any(some)) {                            // nothing near in these four rows (the usual case of a sparse scene): eight zero words
+            const int u = lane >> 1;
+            if (lane < 8 && r0 + u < nrows && ((lane & 1) == 0 || two)) bitmap[(i0 + r0 + u) * wpr + w0 + (lane & 1)] = 0ull;
+            continue;
+        }
+        {
+            T g0[4], g1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {                          // the weights of the candidate pairs only, all loads in flight together
+                g0[u] = x0[u] ? grad[(i0 + r0 + u) * m + j0] : (T)0;
+                g1[u] = x1[u] ? grad[(i0 + r0 + u) * m + j1] : (T)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                x0[u] = x0[u] & (g0[u] != 0);
+                x1[u] = x1[u] & (g1[u] != 0);
+                if (ROTATED) {
+                    if (x0[u]) x0[u] = !sat_separated(rcore[r0 + u], k0);
+                    if (x1[u]) x1[u] = !sat_separated(rcore[r0 + u], k1);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (r0 + u >= nrows) break;
+            const unsigned long long b0 = __ballot(x0[u]), b1 = __ballot(x1[u]);
+            if (lane == 0) {
+                unsigned long long *dst = bitmap + (i0 + r0 + u) * wpr + w0;
+                dst[0] = b0;
+                if (two) dst[1] = b1;
+                mymarks += (unsigned int)__popcll(b0) + (unsigned int)__popcll(b1);
+            }
+        }
+    }
+    // (64 counters: one address would take the whole grid's atomics one after the other -- the marking went from 208 to 395 us)
+    if (lane == 0 && mymarks) atomicAdd(&nmarks[(blockIdx.x + 7u * blockIdx.y + 13u * (unsigned)wave) & (kMarkStripes - 1)], (unsigned long long)mymarks);
+}
+
+// dense or sparse?  The tiles below pay one pass through the gradient routine per wavefront and 64 marked pairs of its 64 x 64
+// part -- right when the marks are many; when they are few (config 3's density: 5 per tile of 16 k pairs) almost every
+// wavefront would run the routine for one or two lanes.  Below one mark per 128 pairs the marks are compacted GLOBALLY instead
+// (k_iou_grad_sparse: 64 consecutive marks of the bitmap per wavefront, gradients by atomics -- few pairs, few atomics).  Both
+// kernels are launched; the one whose case it is not exits at once.
+__global__ __launch_bounds__(kMarkStripes) void k_iou_grad_decide(unsigned long long *nmarks, int64_t n, int64_t m)
+{
+    unsigned long long tot = nmarks[threadIdx.x];
+#pragma unroll
+    for (int o = kMarkStripes / 2; o > 0; o >>= 1) tot += __shfl_xor(tot, o, kWave);
+    if (threadIdx.x == 0) nmarks[kMarkStripes] = tot * 128ull >= (unsigned long long)n * (unsigned long long)m ? 1ull : 0ull;
+}
+__device__ __forceinline__ bool grad_marks_dense(const unsigned long long *nmarks, int64_t, int64_t) { return nmarks[kMarkStripes] != 0; }
+
+constexpr int kSparseWords = 2048;                 // bitmap words per workgroup (131 k pairs)
+template <typename T, bool ROTATED>
+__global__ __launch_bounds__(256) void k_iou_grad_sparse(const BoxGeom<T> *__restrict__ ga, const T *__restrict__ b1, int64_t n,
+                                                         const BoxGeom<T> *__restrict__ gb, const T *__restrict__ b2, int64_t m,
+                                                         const T *__restrict__ grad, T *g1, T *g2,
+                                                         const unsigned long long *__restrict__ bitmap, int64_t wpr,
+                                                         const unsigned long long *nmarks)
+{
+    if (grad_marks_dense(nmarks, n, m)) return;
+    __shared__ unsigned long long smem[256 / kWave];
+    __shared__ unsigned int pre[kSparseWords];         // marks before word k of the chunk
+    __shared__ unsigned long long wv[kSparseWords];
+    const int64_t nwords = n * wpr, base = (int64_t)blockIdx.x * kSparseWords;
+    constexpr int PER = kSparseWords / 256;
+    unsigned int cnt[PER];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {                    // thread t: words PER t .. PER t + PER - 1 of the chunk
+        const int64_t w = base + (int64_t)threadIdx.x * PER + k;
+        const unsigned long long x = w < nwords ? bitmap[w] : 0ull;
+        wv[threadIdx.x * PER + k] = x;
+        cnt[k] = (unsigned int)__popcll(x);
+        mine += cnt[k];
+    }
+    unsigned long long total;
+    unsigned long long ex = block_excl_scan_u64<256>(mine, &total, smem);
+#pragma unroll
+    for (int k = 0; k < PER; k++) { pre[threadIdx.x * PER + k] = (unsigned int)ex; ex += cnt[k]; }
+    __syncthreads();
+    for (unsigned int t = threadIdx.x; t < (unsigned int)total; t += 256) {
+        int lo = 0, hi = kSparseWords;                 // the last word with pre[word] <= t
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= t) lo = mid; else hi = mid;
+        }
+        unsigned long long x = wv[lo];
+        for (unsigned int skip = t - pre[lo]; skip; skip--) x &= x - 1;       // drop the marks before this one
+        const int bit = __ffsll((long long)x) - 1;
+        const int64_t w = base + lo, i = w / wpr, j = (w - i * wpr) * 64 + bit;
+        const T g = grad[i * m + j];
+        T da[5], db[5];
+        if (ROTATED) iou_rbox_grad<T>(ga[i], gb[j], b1[i * 5 + 2], b1[i * 5 + 3], b2[j * 5 + 2], b2[j * 5 + 3], da, db);
+        else iou_aabb_grad<T>(ga[i], gb[j], b1 + i * 5, b2 + j * 5, da, db);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (da[k] != 0) atomicAdd(&g1[i * 5 + k], g * da[k]);
+            if (db[k] != 0) atomicAdd(&g2[j * 5 + k], g * db[k]);
+        }
+    }
+}
+
 template <typename T, bool ROTATED>
 __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *__restrict__ ga, const float4 *__restrict__ ra,
                                                               const T *__restrict__ b1, int64_t n, const BoxGeom<T> *__restrict__ gb,
                                                               const float4 *__restrict__ cb, const T *__restrict__ b2, int64_t m,
-                                                              const T *__restrict__ grad, T *g1, T *g2, int tile_rows)
+                                                              const T *__restrict__ grad, T *g1, T *g2, int tile_rows,
+                                                              const unsigned long long *__restrict__ bitmap, int64_t wpr,
+                                                              const unsigned long long *nmarks)
 {
+    if (!grad_marks_dense(nmarks, n, m)) return;       // few marks: k_iou_grad_sparse's case
     __shared__ BoxGeom<T> rgeo[kTileRows];
     __shared__ float4 rbox[kTileRows];
     __shared__ T rwh[kTileRows][2];
@@ -484,7 +630,6 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *
     for (int k = 0; k < 5; k++) { racc[wave][lane][k] = 0; cacc[threadIdx.x][k] = 0; }
     __syncthreads();
     if ((j & ~(int64_t)63) >= m) return;               // a wavefront past the last column (no barrier below)
-    const BoxGeom<T> cmine = cgeo[active ? threadIdx.x : wave * 64];
     unsigned short *q = queue[wave];
     T *qw = qg[wave];
     unsigned int wn = 0;
@@ -505,30 +650,24 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *
         wn = 0;
         __builtin_amdgcn_wave_barrier();
     };
-    // the rows' weights arrive four rows ahead of their use
-    const T *gp = grad + i0 * m + (active ? j : m - 1);
-    T ring[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) ring[t] = (active && t < nrows) ? gp[(int64_t)t * m] : (T)0;
-    gp += 4 * m;
-    for (int r = 0; r < nrows; r++, gp += m) {
-        const T g = ring[0];
-        ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
-        ring[3] = (active && r + 4 < nrows) ? *gp : (T)0;
-        bool mark = (g != 0) & (aabb_gap(rbox[r], cbox) > 0.f);
-        // a third of the rectangles whose bounding boxes overlap are apart all the same: a separating axis (clear margin) means no
-        // intersection, hence no gradient -- ~60 instructions here against ~2000 in the queue
-        if (ROTATED && mark) mark = !sat_separated(rgeo[r], cmine);
-        const unsigned long long word = __ballot(mark);
-        if (word == 0) continue;
-        const unsigned int cnt = (unsigned int)__popcll(word);
-        if (wn + cnt > 64u) process();
-        if (mark) {
-            const unsigned int at = wn + (unsigned int)__popcll(word & ((1ull << lane) - 1));
-            q[at] = (unsigned short)((r << 8) | lane);
-            qw[at] = g;
+    // the tile's words of the bitmap (k_iou_grad_mark), one row per lane; a marked pair's weight is fetched when it is queued
+    const unsigned long long words = lane < nrows ? bitmap[(i0 + lane) * wpr + (j >> 6)] : 0ull;
+    if (__any(words != 0)) {
+        const T *gp = grad + i0 * m + (active ? j : m - 1);
+        for (int r = 0; r < nrows; r++) {
+            const unsigned long long word = __shfl(words, r, kWave);
+            if (word == 0) continue;
+            const bool mark = (word >> lane) & 1ull;
+            const T g = mark ? gp[(int64_t)r * m] : (T)0;
+            const unsigned int cnt = (unsigned int)__popcll(word);
+            if (wn + cnt > 64u) process();
+            if (mark) {
+                const unsigned int at = wn + (unsigned int)__popcll(word & ((1ull << lane) - 1));
+                q[at] = (unsigned short)((r << 8) | lane);
+                qw[at] = g;
+            }
+            wn += cnt;
         }
-        wn += cnt;
     }
     if (wn) process();
 #pragma unroll
@@ -2696,12 +2835,16 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     BoxGeom<T> *gb = w.take<BoxGeom<T>>(m);
     float4 *ra = w.take<float4>(n);
     float4 *cb = w.take<float4>(m);
-    if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;      // (geometry and candidate boxes of both sets: the front of the forward's workspace)
+    const int64_t wpr = d3d_divup(m, 64);
+    const int64_t rows_bm = n < (int64_t)65535 * kTileRows ? n : (int64_t)65535 * kTileRows;       // (a row chunk's marks at a time)
+    unsigned long long *bitmap = w.take<unsigned long long>((size_t)rows_bm * (size_t)wpr);
+    unsigned long long *nmarks = w.take<unsigned long long>(kMarkStripes + 1);        // 64 counters + the decision
+    if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;      // (geometry and candidate boxes of both sets + one bit per pair: inside the forward's workspace)
     D3D_HIP_CHECK(hipMemsetAsync(g1, 0, sizeof(T) * 5 * (size_t)n, st));
     D3D_HIP_CHECK(hipMemsetAsync(g2, 0, sizeof(T) * 5 * (size_t)m, st));
     D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u,
                rot);
-    {                                                  // tiles with LDS accumulators, no list (k_iou_grad_tiles)
+    {                                                  // marks, then tiles with LDS accumulators (k_iou_grad_mark, k_iou_grad_tiles)
         D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, ra, (IouList *)nullptr, 1u, rot);
         int tr = kTileRows;                            // fewer rows per workgroup while the launch is short of 2048 workgroups
         while (tr > 8 && d3d_divup(m, kGradCols) * d3d_divup(n, tr) < 2048) tr >>= 1;
@@ -2709,10 +2852,19 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
         for (int64_t r0 = 0; r0 < n; r0 += rows_max) {
             const int64_t nr = (n - r0) < rows_max ? (n - r0) : rows_max;
 #define D3D_GRAD_TILES(R)                                                                                                                   \
+    D3D_HIP_CHECK(hipMemsetAsync(nmarks, 0, 8 * kMarkStripes, st));                                                                                         \
+    D3D_LAUNCH("k_iou_grad_mark", (k_iou_grad_mark<T, R>), dim3((unsigned)d3d_divup(m, 2 * kGradCols), (unsigned)d3d_divup(nr, tr)),            \
+               dim3(kGradCols), 0, st, (const BoxGeom<T> *)ga + r0, (const float4 *)ra + r0, nr, (const BoxGeom<T> *)gb, (const float4 *)cb, \
+               m, grad + r0 * m, bitmap, wpr, tr, nmarks);                                                                                  \
+    D3D_LAUNCH("k_iou_grad_decide", k_iou_grad_decide, dim3(1), dim3(kMarkStripes), 0, st, nmarks, nr, m);                                    \
     D3D_LAUNCH("k_iou_grad_tiles", (k_iou_grad_tiles<T, R>), dim3((unsigned)d3d_divup(m, kGradCols), (unsigned)d3d_divup(nr, tr)),               \
                dim3(kGradCols), 0, st, (const BoxGeom<T> *)ga + r0, (const float4 *)ra + r0, b1 + r0 * 5, nr, (const BoxGeom<T> *)gb,        \
-               (const float4 *)cb, b2, m, grad + r0 * m, g1 + r0 * 5, g2, tr)
-            if (rot) D3D_GRAD_TILES(true); else D3D_GRAD_TILES(false);
+               (const float4 *)cb, b2, m, grad + r0 * m, g1 + r0 * 5, g2, tr, (const unsigned long long *)bitmap, wpr,                      \
+               (const unsigned long long *)nmarks);                                                                                         \
+    D3D_LAUNCH("k_iou_grad_sparse", (k_iou_grad_sparse<T, R>), dim3((unsigned)d3d_divup(nr * wpr, (int64_t)kSparseWords)), dim3(256), 0, st,   \
+               (const BoxGeom<T> *)ga + r0, b1 + r0 * 5, nr, (const BoxGeom<T> *)gb, b2, m, grad + r0 * m, g1 + r0 * 5, g2,                  \
+               (const unsigned long long *)bitmap, wpr, (const unsigned long long *)nmarks)
+            if (rot) { D3D_GRAD_TILES(true); } else { D3D_GRAD_TILES(false); }
 #undef D3D_GRAD_TILES
         }
     }

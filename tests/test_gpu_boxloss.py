@@ -193,6 +193,38 @@ def test_matrix_paths_ragged_shapes(shape):
         assert max(float(np.max(np.abs(g1 - r1))), float(np.max(np.abs(g2 - r2)))) < 1e-8 * sc, meth
 
 
+@pytest.mark.parametrize("side", [40.0, 3000.0])
+@pytest.mark.parametrize("method", ["rbox", "box"])
+def test_iou_backward_dense_and_sparse_routes(method, side):
+    """IoU backward marks the pairs that matter, counts them and takes the tiles (many marks: side 40, a third of the pairs
+    overlap) or the global compaction (few: side 3000, one pair in thousands) -- box.hip k_iou_grad_mark / _tiles / _sparse.
+    Both against central differences of the fp64 oracle on sampled parameters, weights with zeros among them."""
+    from d3d_amd.box import box2d_iou
+    rng = np.random.default_rng(int(side))
+    mk = lambda k: np.stack([rng.random(k) * side, rng.random(k) * side, rng.random(k) * 20 + 1, rng.random(k) * 20 + 1,  # noqa: E731
+                             (rng.random(k) - 0.5) * 6.3], 1)
+    b1, b2 = mk(700), mk(650)
+    w = (rng.random((700, 650)) - 0.3) * (rng.random((700, 650)) < 0.8)
+    t1, t2 = T(b1).requires_grad_(True), T(b2).requires_grad_(True)
+    out = box2d_iou(t1, t2, method=method)
+    frac = float((out > 0).double().mean())
+    assert (frac > 0.05) if side < 100 else (0 < frac < 0.002)
+    (out * T(w)).sum().backward()
+    g1, g2 = t1.grad.cpu().numpy(), t2.grad.cpu().numpy()
+    assert np.isfinite(g1).all() and np.isfinite(g2).all() and np.abs(g1).sum() > 0
+    h, bad, tried = 1e-6, 0, 0
+    rows = np.nonzero(np.abs(g1).sum(1) > 0)[0] if side > 100 else np.arange(700)
+    for i in rng.choice(rows, size=min(12, len(rows)), replace=False):
+        k = int(rng.integers(0, 5))
+        p, q = b1.copy(), b1.copy()
+        p[i, k] += h
+        q[i, k] -= h
+        fd = float(((oracle.box2d_iou(p[i:i + 1], b2, method) - oracle.box2d_iou(q[i:i + 1], b2, method)) * w[i:i + 1]).sum()) / (2 * h)
+        tried += 1
+        bad += abs(fd - g1[i, k]) > 1e-4 * max(1.0, abs(fd))
+    assert bad <= 1, (bad, tried)                  # (a sample may sit on a kink of the piecewise function: an edge through a corner)
+
+
 def test_flags_vs_oracle_and_box_impl_tuples():
     from d3d_amd.box import box_impl, iou2dr_flags
     b1, b2 = _rand_boxes(90, 31, 6.0), _rand_boxes(70, 32, 6.0)
