@@ -543,6 +543,29 @@ __global__ __launch_bounds__(kMarkStripes) void k_iou_grad_decide(unsigned long 
 }
 __device__ __forceinline__ bool grad_marks_dense(const unsigned long long *nmarks, int64_t, int64_t) { return nmarks[kMarkStripes] != 0; }
 
+// a frame's worth of pairs (<= kIouSmallPairs): ONE launch, one pair per lane, geometry rebuilt per pair, atomics per pair --
+// the marks / decision / tiles / compaction above are five launches of ~5 us each, more than the arithmetic at this size
+template <typename T, bool ROTATED>
+__global__ __launch_bounds__(256) void k_iou_grad_small(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
+                                                        const T *__restrict__ grad, T *g1, T *g2)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * m) return;
+    const T g = grad[idx];
+    if (g == 0) return;
+    const int64_t i = idx / m, j = idx - i * m;
+    const BoxGeom<T> a = Box2D<T>::load(b1 + i * 5), b = Box2D<T>::load(b2 + j * 5);
+    if (!(aabb_gap(cand_aabb(a, ROTATED), cand_aabb(b, ROTATED)) > 0.f)) return;
+    T da[5], db[5];
+    if (ROTATED) iou_rbox_grad<T>(a, b, b1[i * 5 + 2], b1[i * 5 + 3], b2[j * 5 + 2], b2[j * 5 + 3], da, db);
+    else iou_aabb_grad<T>(a, b, b1 + i * 5, b2 + j * 5, da, db);
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (da[k] != 0) atomicAdd(&g1[i * 5 + k], g * da[k]);
+        if (db[k] != 0) atomicAdd(&g2[j * 5 + k], g * db[k]);
+    }
+}
+
 constexpr int kSparseWords = 2048;                 // bitmap words per workgroup (131 k pairs)
 template <typename T, bool ROTATED>
 __global__ __launch_bounds__(256) void k_iou_grad_sparse(const BoxGeom<T> *__restrict__ ga, const T *__restrict__ b1, int64_t n,
@@ -2842,6 +2865,11 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;      // (geometry and candidate boxes of both sets + one bit per pair: inside the forward's workspace)
     D3D_HIP_CHECK(hipMemsetAsync(g1, 0, sizeof(T) * 5 * (size_t)n, st));
     D3D_HIP_CHECK(hipMemsetAsync(g2, 0, sizeof(T) * 5 * (size_t)m, st));
+    if ((unsigned long long)n * (unsigned long long)m <= kIouSmallPairs) {
+        if (rot) D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, true>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
+        else D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, false>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
+        return D3D_OK;
+    }
     D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u,
                rot);
     {                                                  // marks, then tiles with LDS accumulators (k_iou_grad_mark, k_iou_grad_tiles)
