@@ -439,6 +439,15 @@ def extras(args):
         box2d_iou(b1g, b2g, method="drbox").sum().backward()
     dt = timed(fwd_bwd_d, 5, 1)
     ex["iou2d_drbox_fp64_fwd_bwd_2kx2k_ms"] = round(dt / 5 * 1e3, 3)
+    # rotated IoU backward where almost no pair overlaps (config 3's density, 20 k x 20 k, a weight on every pair): marks, then the
+    # marked pairs compacted globally (the dense regime is the reference's protocol below)
+    from d3d_amd.box import iou2dr_backward
+    if len(b) >= 40000:
+        gsp = torch.ones((20000, 20000), dtype=torch.float64, device="cuda")
+        sp1, sp2 = torch.from_numpy(b[:20000]).cuda(), torch.from_numpy(b[20000:40000]).cuda()
+        dt = timed(lambda: iou2dr_backward(sp1, sp2, gsp), 5, 1)
+        ex["iou2dr_backward_fp64_20kx20k_sparse_ms"] = round(dt / 5 * 1e3, 3)
+        del gsp, sp1, sp2
     # the reference's OWN IoU benchmark protocol (test/compare/benchmark_riou.py:53-118): n x n rotated IoU of fp32 boxes
     # through box2d_iou (precise=True: fp64 inside), forward, then .sum().backward() into boxes2, for n = 1 ... 5000; boxes as
     # there (centres in +-5, sizes in [0, 5), angles in +-5 rad: 28 % of the pairs overlap).  Times with a device
