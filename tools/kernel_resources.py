@@ -13,6 +13,7 @@ for line in txt.splitlines():
     if not m:
         continue
     s = m.group(1).strip()
+    s = re.sub(r'^\S+:\d+:\d+:\s*', '', s)          # (remarks carry "file:line:col:" in front when the source path is absolute)
     if s.startswith('Function Name:'):
         cur = s.split(': ')[1]
         rows[cur] = {}
