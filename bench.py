@@ -131,6 +131,28 @@ def emit_bytes(n, V, P):
     return n * 16 + V * (P * 16 + P + 24 + 4 + 16)
 
 
+def dense_last_plan():
+    """what the last dense call launched: (split, voxels whose zero padding was stored under the index launches, bytes of zeros
+    stored by k_tile_sort's fillers, by k_first_count's)"""
+    from d3d_amd import _lib
+    out = (ctypes.c_int64 * 4)()
+    _lib.load().d3d_voxelize_dense_last_plan(out)
+    return tuple(int(x) for x in out)
+
+
+def emit_split_bytes(n, P, npoints, plan):
+    """ALGORITHMIC bytes of k_emit_split: the dense contract's 8(d) bytes (emit_bytes) minus the zero padding that the filler
+    workgroups of the index launches stored and this launch therefore does not: for a voxel id below plan[1], every row from
+    min(P, 8 * ceil(min(count, P) / 8)) on (a voxel of 255 points and more: none) -- computed from the call's own voxel_npoints"""
+    V = int(npoints.shape[0])
+    pre = min(plan[1], V)
+    cnt = npoints[:pre].to(torch.int64)
+    lim = torch.clamp(((torch.clamp(cnt, max=P) + 7) // 8) * 8, max=P)
+    lim = torch.where(cnt >= 255, torch.full_like(lim, P), lim)
+    skipped = int(((P - lim) * 16).sum())
+    return emit_bytes(n, V, P) - skipped, skipped
+
+
 def emit_scratch_bytes(npad, V, kept, multi_rows):
     """what k_emit reads on top of that from the index's scratch: one 4-byte first-point entry per point index (numbering +
     count + segment of the voxel, round 5) and one 4-byte ranked index per kept row that is not a voxel's first point"""
@@ -149,6 +171,8 @@ def large_frame_leg(steps=5):
     res = gen(cloud)
     V = int(res.coords.shape[0])
     kept = int(torch.clamp(res.voxel_npoints, max=P).sum())
+    plan = dense_last_plan()
+    b_split = emit_split_bytes(n, P, res.voxel_npoints, plan)[0]
     del res
     step = lambda: gen(cloud)  # noqa: E731
     dt = timed(step, steps, 2)
@@ -156,8 +180,8 @@ def large_frame_leg(steps=5):
     del cloud, gen
     torch.cuda.empty_cache()
     npad = -(-n // 16384) * 16384
-    kern = "k_emit" if "k_emit" in prof else "k_fill_c4"
-    b_alg = emit_bytes(n, V, P) if kern == "k_emit" else V * P * 16 + kept * 16 + V * 16
+    kern = "k_emit_split" if "k_emit_split" in prof else "k_emit" if "k_emit" in prof else "k_fill_c4"
+    b_alg = b_split if kern == "k_emit_split" else emit_bytes(n, V, P) if kern == "k_emit" else V * P * 16 + kept * 16 + V * 16
     us = prof[kern]["avg_us"]
     ach = b_alg / (us * 1e-6) / 1e9
     probe = stream_probe(3 << 30)
@@ -170,7 +194,7 @@ def large_frame_leg(steps=5):
                 frac_of_measured_chunked_store=round(ach / probe["store_nt_chunked"], 4),
                 # the fill moves reads as well as writes: against the best streaming rate of either kind measured on this box
                 frac_of_measured_best=round(ach / max(probe.values()), 4), avg_us=round(us, 2), algorithmic_bytes=b_alg,
-                scratch_bytes=emit_scratch_bytes(npad, V, kept, kept - V) if kern == "k_emit" else None,
+                scratch_bytes=emit_scratch_bytes(npad, V, kept, kept - V) if kern in ("k_emit", "k_emit_split") else None,
                 traffic=traffic, traffic_source=src, op_ms=round(1e3 * dt / steps, 3),
                 op_mpoints_per_s=round(n * steps / dt / 1e6, 1),
                 kernels_us={k: round(v["avg_us"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])})
@@ -571,6 +595,8 @@ def main():
         res = gen(cloud)
         V = int(res.coords.shape[0])
         kept = int(torch.clamp(res.voxel_npoints, max=P).sum())
+        plan = dense_last_plan()
+        split_bytes, split_skipped = emit_split_bytes(n, P, res.voxel_npoints, plan)
         del res
         step = lambda: gen(cloud)  # noqa: E731
         dt = timed(step, args.steps, args.warmup)
@@ -592,6 +618,8 @@ def main():
             "k_bucket_index": n * (16 + 4) + kept * 16 + V * (16 + 4),   # bucket read; ranked rows, records, firstmap written
             "k_meta_first": npad * 4 + V * 16 + kept * 16 + V * (16 + 24 + 4 + P + 16),
             "k_emit": emit_bytes(n, V, P),                          # 16 B/point in + every output (no scratch)
+            # round 6: the same minus the zero padding stored under the index launches (k_tile_sort's / k_first_count's fillers)
+            "k_emit_split": split_bytes,
             # hash-table index (other inputs)
             "k_insert": n * 16 + n * 8 + n * 8,          # points read, pslot+arrival written, one 8-byte slot touched
             "k_scatter": n * 8 + n * 8 + n * 4 + n * 8,  # pslot+arrival read, aux read, index written, (cnt,base) written
@@ -609,7 +637,15 @@ def main():
                                           "is cache-assisted; the HBM claim is roofline_large.frac (same kernel, 3.3 GB of outputs)",
                                bytes_note="algorithmic_bytes = SURVEY 8(d): 16 B/point read + every output of the dense contract "
                                           "written; scratch_bytes (index entries the launch also reads) are not part of it")
-        if name == "k_emit":
+        if name == "k_emit_split":
+            out["roofline"].update(
+                algorithmic_bytes_operator=emit_bytes(n, V, P), zero_padding_stored_under_index_launches=split_skipped,
+                filler_bytes=dict(k_tile_sort=plan[2], k_first_count=plan[3]), prefilled_voxels=plan[1],
+                split_note="k_emit_split moves the dense contract's 8(d) bytes EXCEPT the zero padding of voxel ids below prefilled_voxels: "
+                           "filler workgroups on the CUs k_tile_sort / k_first_count leave idle store those (plus the rows' lines of the same "
+                           "voxels, which this launch overwrites: filler_bytes > zero_padding_stored).  The operator-level figure on ALL 8(d) "
+                           "bytes is roofline_operator")
+        if name in ("k_emit", "k_emit_split"):
             # what the launch reads from the index's scratch on top of the 8(d) bytes, and the stream probes at THIS launch's
             # footprint (the outputs' 345 MB, partly absorbed by the 256 MB Infinity Cache exactly as the kernel's are): the
             # store forms with the work stripped off, on the same box in the same process
@@ -642,6 +678,10 @@ def main():
                                              algorithmic_bytes=algo["k_fill_c4"])
         out["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         out["op_algorithmic_GBps"] = round((n * 16 + V * (P * 16 + P + 24 + 4 + 16)) * args.steps / dt / 1e9, 1)
+        # the whole operator (every launch of a step) on the 8(d) bytes: what a caller sees
+        out["roofline_operator"] = dict(bound="hbm", achieved=out["op_algorithmic_GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+                                        frac=round(out["op_algorithmic_GBps"] / HBM_PEAK_GBS, 4), algorithmic_bytes=emit_bytes(n, V, P),
+                                        us_per_step=round(1e6 * dt / args.steps, 2))
         out["voxels"] = V
         parallelism = "1 GPU"
     else:

@@ -90,6 +90,7 @@ SIGNATURES = {
     "d3d_aligned_scatter_backward": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "d3d_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "d3d_profile_report": (ctypes.c_int, [ctypes.c_char_p, _sz]),
+    "d3d_voxelize_dense_last_plan": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64)]),
     "d3d_stream_probe": (ctypes.c_int, [ctypes.c_int, _vp, _sz, _vp]),
     "d3d_iou2d_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "d3d_iou2d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp, _u32]),

@@ -1183,6 +1183,9 @@ constexpr int kBucketCap = 2048;              // points one k_bucket_index workg
 constexpr int kBucketThreads = 512;           // ... 4 per lane (256: 42 us, 512: 38 us, 1024: 44 us at config 2)
 constexpr int kBucketSlots = 2048;            // LDS table slots (>= distinct cells of a bucket, always)
 constexpr uint32_t kNoBin = 0xffffffffu;
+thread_local int64_t g_last_plan[4] = {0, 0, 0, 0};       // d3d_voxelize_dense_last_plan
+constexpr int64_t kFillSortMax16 = 76ll << 16;   // ZeroFill: 16-byte zeros under k_tile_sort (76 MB)
+constexpr int kNumCUs = 256;                  // MI355X (the library is built for gfx950 only): the fillers of ZeroFill take the CUs a launch leaves idle
 constexpr uint32_t kXcdBucketsMin = 2048;     // k_bucket_index: XCD-aware bucket numbering from this many buckets (a power of two) on
 // Round 5 (k_bucket_index<.., V2> -> k_emit): the first-point entry of a voxel carries the voxel itself --
 //   firstmap[first] = {count : 8 | base : 24}   count 1 .. 254 points, base = the voxel's segment in the ranked index lists (its
@@ -1202,6 +1205,32 @@ constexpr uint32_t kFmShift = 24, kFmMask = 0xffffffu, kFmRecord = 255u;
 constexpr int64_t kFmMaxPoints = (1 << 24) - 2;
 constexpr uint32_t kDenseMin = 32;            // V2: cells with more points are ranked by ONE wavefront (select + all-pairs on the kept ones);
                                               // 16 .. 48: the same within noise, 64: +2.5 us, 128: +4 us at config 2 (profiles/r05_b_tune.txt)
+
+// Round 6: part of the zero padding of voxels[V,P,4] leaves UNDER the index launches.  Workgroups `first` ..
+// `first + nblk - 1` of a launch's grid take no tile, they stream 16-byte zeros over [0, n16) of `dst`, one 16 KiB piece per
+// workgroup per step, the pieces of one step side by side (the grid-stride pattern of the store probes).  Only where CUs would
+// otherwise stand idle for the whole launch: k_tile_sort on tiles of 8192 points (124 workgroups at config 2, one per CU: 132
+// fillers write 76 MB for +2 us) and k_first_count (62 workgroups).  Everything else that was tried costs the index what it saves
+// k_emit_split, or more -- zeros stored by the tiles' / buckets' own workgroups behind their first loads, filler workgroups
+// behind the buckets (the CUs are full: they only run in the launch's tail): profiles/r06_ab_prefill.txt.  The range is fixed by
+// the host before the first launch, from the frame's size alone (no state from earlier calls): rows past the final V are never
+// returned (the tensor has min(n, max_voxels) rows), so an overshoot only wastes stores.
+struct ZeroFill {
+    float4 *dst = nullptr;
+    int64_t n16 = 0;
+    uint32_t first = 0xffffffffu, nblk = 0;
+};
+__device__ __forceinline__ bool zero_fill_role(const ZeroFill &z)
+{
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    if (blockIdx.x < z.first) return false;
+    vec4 *out = reinterpret_cast<vec4 *>(z.dst);
+    const vec4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int64_t step = (int64_t)z.nblk * blockDim.x;
+    for (int64_t i = (int64_t)(blockIdx.x - z.first) * blockDim.x + threadIdx.x; i < z.n16; i += step)
+        __builtin_nontemporal_store(zero, &out[i]);
+    return true;
+}
 
 // reduce contract (d3d_voxelize_3d_reduce) on the binned path
 struct BinnedExtras {
@@ -1442,11 +1471,13 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(Key kf, const float 
                                                             uint32_t *__restrict__ firstmap, int64_t *counts, int64_t *mapping,
                                                             unsigned char *trimmed, int32_t *keepid,
                                                             u64 *zero_words /* look-back words of a later launch */, uint32_t nzero,
-                                                            unsigned int *zero_ticket, bool pfirst_self = true /* false: pfirst <- kInf */)
+                                                            unsigned int *zero_ticket, bool pfirst_self = true /* false: pfirst <- kInf */,
+                                                            ZeroFill zf = ZeroFill())
 {
     typedef typename Key::bin_key_t KT;
     typedef BinEntry<ROWS> E;
     constexpr int kSortTile = kSortThreads * kSortItems;
+    if (zero_fill_role(zf)) return;
     constexpr int kSortTileShift = kSortItems == 16 ? 14 : kSortItems == 8 ? 13 : kSortItems == 4 ? 12 : 11;
     static_assert(kSortTile == (1 << kSortTileShift) && kFlagTile % kSortTile == 0, "arrays are padded to kFlagTile");
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
@@ -2343,8 +2374,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_index(Key kf, VoxelPa
 // 64 firstmap entries -> one count; counts scanned inside the block (fwpre), block totals -> bsumF (<= 1024 of them:
 // k_meta_first adds up the ones before its tile itself, which is cheaper than a scan launch or a last-block pass)
 __global__ __launch_bounds__(1024) void k_first_count(const uint32_t *__restrict__ firstmap, uint32_t *fwpre, uint32_t *bsumF,
-                                                      uint32_t *clear_word = nullptr /* k_emit_c's overflow-voxel counter */)
+                                                      uint32_t *clear_word = nullptr /* k_emit_c's overflow-voxel counter */,
+                                                      ZeroFill zf = ZeroFill())
 {
+    if (zero_fill_role(zf)) return;
     if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0;
     __shared__ u64 smem[1024 / kWave];
     __shared__ uint32_t wcnt[256];
@@ -2849,6 +2882,229 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
         __builtin_nontemporal_store(res, reinterpret_cast<vec4 *>(&agg[v]));
     }
     D3D_PHASE(2, 5);                                        // per-voxel outputs issued
+}
+
+// Round 6 -- the dense contract's output launch in TWO ROLES (packed entries, rows of 4 floats).  k_emit is a
+// latency chain (entries -> first rows -> ranked indices -> rows) AND a 345 MB store stream in every wavefront, and the two did not
+// overlap: with the stretch stores switched off it takes 32 us, the stores by themselves 49-54 us, together 81-86 us
+// (profiles/r06_emit_parts.txt) -- the wavefronts of a launch walk their chains at the same time, then store at the same time.
+// Here two workgroups take each 256 points.  The EVEN one is the chain: rows gathered into LDS, reductions, the voxels' leading
+// 128-byte lines (rows kept rounded up to 8) and the aggregates -- no cell arithmetic, its first dependent load is already a row or
+// a ranked index.  The ODD one needs nothing but the entries to know which lines of the stretch hold no row -- three of four at
+// config 2 -- and streams them; its one gather (the voxels' first points, for the cells) is in flight under those stores and
+// feeds coords / voxel_npoints / voxel_pmask.  Voxels of 255 points and more (count and cell in a record) belong to the even role
+// entirely.  Both roles derive a voxel's split point `lim` from its entry alone; every byte has exactly one writer.
+// voxels[0 .. prefilled) x P rows were zero-filled under the index launches (ZeroFill): the odd role skips those.
+template <class Key, bool AGG4>
+__global__ __launch_bounds__(256) void k_emit_split(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
+                                                    const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
+                                                    const uint4 *__restrict__ vrec, uint32_t max_voxels,
+                                                    const float4 *__restrict__ points4, const uint32_t *__restrict__ ranked,
+                                                    const float4 *__restrict__ staged, uint32_t P, int pshift /* log2 P or -1 */,
+                                                    int reduction, int64_t *coords, int32_t *npoints, unsigned char *pmask /* or NULL */,
+                                                    float4 *agg, float4 *voxels, int64_t *counts, int64_t *host_counts,
+                                                    uint32_t prefilled, int64_t aux_value)
+{
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t uvec4 __attribute__((ext_vector_type(4)));
+    __shared__ vec4 rowbuf_all[256 / kWave][kEmitCap];
+    __shared__ uint32_t off_all[256 / kWave][kWave], base_all[256 / kWave][kWave], first_all[256 / kWave][kWave];
+    __shared__ uint32_t loff_all[256 / kWave][kWave];
+    __shared__ uint16_t kept_all[256 / kWave][kWave], lim_all[256 / kWave][kWave];
+    const bool zrole = (blockIdx.x & 1u) != 0;
+    const int64_t i = (int64_t)(blockIdx.x >> 1) * 256 + threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    vec4 *rowbuf = rowbuf_all[w];
+    uint32_t *sh_off = off_all[w], *sh_base = base_all[w], *sh_first = first_all[w], *sh_loff = loff_all[w];
+    uint16_t *sh_kept = kept_all[w], *sh_lim = lim_all[w];
+    const uint32_t tile = (uint32_t)(i / kFlagTile), ntile = (uint32_t)(npad / kFlagTile);
+    uint32_t before = 0, all = 0;
+    for (uint32_t t = lane; t < ntile; t += kWave) {
+        const uint32_t x = bsumF[t];
+        all += x;
+        if (t < tile) before += x;
+    }
+    {
+        const u64 both = wave_sum_u64(((u64)all << 32) | before);
+        before = (uint32_t)both;
+        all = (uint32_t)(both >> 32);
+    }
+    if (i == 0 && !zrole) {
+        counts[D3D_COUNT_VOXELS] = (int64_t)(all < max_voxels ? all : max_voxels);
+        counts[D3D_COUNT_AUX] = aux_value;
+        if (host_counts) notify_host(counts, host_counts);
+    }
+    const uint32_t e = firstmap[i];
+    const unsigned long long bal = __ballot(e != kInf);
+    const uint32_t nfirst = (uint32_t)__popcll(bal);
+    uint32_t nv = nfirst;
+    const uint32_t vid0 = before + fwpre[i >> 6];
+    const uint32_t r = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (nv == 0 || vid0 >= max_voxels) return;             // wave-uniform
+    if (nv > max_voxels - vid0) nv = max_voxels - vid0;     // voxelize.cpp:116-117: later voxels are never created
+    const uint32_t dst = (e != kInf ? r : nfirst + ((uint32_t)lane - r)) << 2;
+    const uint32_t el = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)e);
+    const uint32_t il = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)(uint32_t)i);
+    const bool mine = (uint32_t)lane < nv;
+    const uint32_t c8 = el >> kFmShift, seg = el & kFmMask;
+    const bool isrec = c8 == kFmRecord;
+    const unsigned long long recmask = __ballot(mine && isrec);
+    const int64_t v = (int64_t)vid0 + lane;
+    vec4 *out = reinterpret_cast<vec4 *>(voxels) + (int64_t)vid0 * P;
+    const vec4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (zrole) {
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mine && !isrec) p0 = points4[il];               // (ascending indices inside the wavefront's 1 KiB window)
+        {
+            const uint32_t kept_e = c8 < P ? c8 : P, l8 = (kept_e + 7u) & ~7u;
+            sh_lim[lane] = (uint16_t)(!mine ? 0u : (isrec || l8 > P) ? P : l8);
+            sh_kept[lane] = (uint16_t)(mine ? kept_e : 0u);
+        }
+        // the per-voxel outputs that need no row, FIRST: the wavefront then ends on its zero lines without ever waiting for a
+        // store (behind the store loop the compiler can only wait for everything in flight; zeros first: 62 -> 56 us with the
+        // filled range below, profiles/r06_ab_split.txt).  Cell: the same arithmetic on the same floats as k_tile_sort.
+        long long *cbuf = reinterpret_cast<long long *>(rowbuf);       // 64 * 3 * 8 B = 1.5 KiB
+        if (mine && !isrec) {
+            const float v3[3] = {p0.x, p0.y, p0.z};
+            u64 key = 0;
+            uint32_t st = 0;
+            (void)kf.make(v3, key, st);
+            long long cc[3];
+            kf.decode(key, cc);
+            cbuf[lane * 3 + 0] = cc[0]; cbuf[lane * 3 + 1] = cc[1]; cbuf[lane * 3 + 2] = cc[2];
+            __builtin_nontemporal_store((int32_t)c8, &npoints[v]);
+        }
+        wave_lds_fence();
+        long long *cdst = reinterpret_cast<long long *>(coords) + (int64_t)vid0 * 3;
+        for (uint32_t t = lane; t < nv * 3; t += kWave)
+            if (!((recmask >> (t / 3u)) & 1ull)) __builtin_nontemporal_store(cbuf[t], &cdst[t]);
+        if (pmask) {                                         // P % 16 == 0, 16-byte aligned (host-checked): 16-byte pieces
+            const uint32_t per = P >> 4, total = nv * per;
+            uvec4 *pdst = reinterpret_cast<uvec4 *>(pmask + (int64_t)vid0 * P);
+            for (uint32_t t = lane; t < total; t += kWave) {
+                const uint32_t j = t / per, k0 = (t - j * per) << 4, kj = sh_kept[j];
+                if ((recmask >> j) & 1ull) continue;
+                uvec4 w4;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t b = 0;
+#pragma unroll
+                    for (int x = 0; x < 4; x++) b |= ((k0 + q * 4 + x) < kj ? 1u : 0u) << (8 * x);
+                    w4[q] = b;
+                }
+                __builtin_nontemporal_store(w4, &pdst[t]);
+            }
+        }
+        // rows [lim, P) of the voxels past the range filled under the index launches
+        const uint32_t npre = prefilled <= vid0 ? 0u : (prefilled - vid0 < nv ? prefilled - vid0 : nv);
+        const uint32_t qa = nv * P;
+        for (uint32_t q0 = npre * P; q0 < qa; q0 += 4 * kWave) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t q = q0 + u * kWave + lane;
+                if (q < qa) {
+                    const uint32_t j = pshift >= 0 ? (q >> pshift) : q / P;
+                    if (q - j * P >= sh_lim[j]) __builtin_nontemporal_store(zero, &out[q]);
+                }
+            }
+        }
+        return;
+    }
+    // the chain
+    uint32_t cnt = mine ? c8 : 0u, base = seg;
+    u64 key = 0;
+    if (mine && isrec) {                                    // 255 points and more: count, segment and cell in the record
+        const uint4 rec = vrec[seg];
+        key = ((u64)rec.y << 32) | rec.x;
+        base = rec.z;
+        cnt = rec.w;
+    }
+    const uint32_t kept = cnt < P ? cnt : P;                // 0 for the lanes past nv
+    const uint32_t incl = wave_incl_scan_u32(kept);
+    const uint32_t off = incl - kept;
+    uint32_t lim = (kept + 7u) & ~7u;
+    if (lim > P || (mine && isrec)) lim = P;
+    const uint32_t lincl = wave_incl_scan_u32(lim);
+    const uint32_t loff = lincl - lim;                      // rows to store before this voxel, over the wavefront
+    sh_off[lane] = off; sh_base[lane] = base; sh_first[lane] = il; sh_kept[lane] = (uint16_t)kept;
+    sh_lim[lane] = (uint16_t)lim; sh_loff[lane] = loff;
+    wave_lds_fence();
+    const bool is_sum = reduction == D3D_REDUCE_MEAN || reduction == kReduceSum;
+    float a0, a1, a2, a3;
+    a0 = a1 = a2 = a3 = is_sum ? 0.0f : (reduction == D3D_REDUCE_MAX ? -INFINITY : INFINITY);
+    uint32_t ja = 0;
+    while (ja < nv) {                                       // wave-uniform: one batch unless the rows exceed the buffer
+        const uint32_t oa = (uint32_t)__shfl((int)off, (int)ja, kWave);
+        const bool fits = (uint32_t)lane >= ja && mine && incl - oa <= (uint32_t)kEmitCap;
+        const unsigned long long nf = ~(__ballot(fits) >> ja);
+        const uint32_t jb = ja + (nf ? (uint32_t)__ffsll((long long)nf) - 1u : (uint32_t)kWave - ja);     // >= ja + 1: kept <= P <= kEmitCap
+        const uint32_t rows = (uint32_t)__shfl((int)incl, (int)jb - 1, kWave) - oa;
+        for (uint32_t t0 = 0; t0 < rows; t0 += kWave) {     // the batch's rows, flat and lane-parallel
+            const uint32_t t = t0 + lane;
+            if (t < rows) {
+                uint32_t lo = ja, hi = jb;                  // largest j in [ja, jb) with off[j] - oa <= t
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sh_off[mid] - oa <= t) lo = mid; else hi = mid;
+                }
+                const uint32_t k = t - (sh_off[lo] - oa);
+                const uint32_t idx = k == 0 ? sh_first[lo] : ranked[sh_base[lo] + k];
+                rowbuf[t] = *reinterpret_cast<const vec4 *>(&points4[idx]);
+            }
+        }
+        wave_lds_fence();
+        if (AGG4 && (uint32_t)lane >= ja && (uint32_t)lane < jb && cnt <= P) {     // reductions in point order, one lane per voxel
+            const vec4 *rw = rowbuf + (off - oa);
+            for (uint32_t k = 0; k < kept; k++) {
+                const vec4 x = rw[k];
+                if (is_sum) { a0 += x.x; a1 += x.y; a2 += x.z; a3 += x.w; }
+                else if (reduction == D3D_REDUCE_MAX) {      // std::max(acc, x) = acc < x ? x : acc
+                    a0 = a0 < x.x ? x.x : a0; a1 = a1 < x.y ? x.y : a1; a2 = a2 < x.z ? x.z : a2; a3 = a3 < x.w ? x.w : a3;
+                } else {
+                    a0 = x.x < a0 ? x.x : a0; a1 = x.y < a1 ? x.y : a1; a2 = x.z < a2 ? x.z : a2; a3 = x.w < a3 ? x.w : a3;
+                }
+            }
+        }
+        // rows [0, lim) of the batch's voxels, flat: eight lanes per 128-byte line
+        const uint32_t l0 = (uint32_t)__shfl((int)loff, (int)ja, kWave);
+        const uint32_t l1 = (uint32_t)__shfl((int)lincl, (int)jb - 1, kWave);
+        for (uint32_t t0 = l0; t0 < l1; t0 += kWave) {
+            const uint32_t t = t0 + lane;
+            if (t < l1) {
+                uint32_t lo = ja, hi = jb;                  // largest j in [ja, jb) with loff[j] <= t
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sh_loff[mid] <= t) lo = mid; else hi = mid;
+                }
+                const uint32_t slot = t - sh_loff[lo];
+                vec4 val = zero;
+                if (slot < sh_kept[lo]) val = rowbuf[sh_off[lo] - oa + slot];
+                __builtin_nontemporal_store(val, &out[lo * P + slot]);
+            }
+        }
+        wave_lds_fence();                                   // the next batch overwrites the buffer
+        ja = jb;
+    }
+    if (AGG4 && mine) {
+        vec4 res;
+        if (cnt > P) res = *reinterpret_cast<const vec4 *>(&staged[base + P]);   // fp64 reduction of k_bucket_index (voxelize.cpp:137-157)
+        else {
+            if (reduction == D3D_REDUCE_MEAN) {              // voxelize.cpp:164 (float / int)
+                const float d = (float)(int32_t)cnt;
+                a0 = a0 / d; a1 = a1 / d; a2 = a2 / d; a3 = a3 / d;
+            }
+            res.x = a0; res.y = a1; res.z = a2; res.w = a3;
+        }
+        __builtin_nontemporal_store(res, reinterpret_cast<vec4 *>(&agg[v]));
+    }
+    if (mine && isrec) {                                    // the record voxels' own per-voxel outputs (a handful per frame)
+        long long cc[3];
+        kf.decode(key, cc);
+        coords[v * 3 + 0] = cc[0]; coords[v * 3 + 1] = cc[1]; coords[v * 3 + 2] = cc[2];
+        npoints[v] = (int32_t)cnt;
+        if (pmask)
+            for (uint32_t k = 0; k < P; k++) pmask[v * (int64_t)P + k] = k < kept ? 1 : 0;
+    }
 }
 
 // aggregates of the voxels with MORE than max_points points, all channels of a voxel at once (k_emit_c did the others and
@@ -4085,10 +4341,24 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     // tiles of 8192 points (4096: profiles/r04_bucket_target.txt); large frames of the dense contract on C == 4 rows: 16384 -- half
     // the tiles, so half the table, and k_bucket_index finds a bucket's entries in half as many runs of twice the length
     const bool big_tiles = ROWS && vec4 && sizeof(typename Key::bin_key_t) == 4 && n >= kBigTileMinPoints;
+    // round 5: the lean bucket kernel + packed first-point entries, whenever k_emit is the consumer and nothing needs the
+    // cells' first indices per point (the point -> voxel map, the sparse contract's filters)
+    const bool fm_packed = ROWS && (o.emit_voxels || o.emit_reduce) && !o.index_v1 && !precpos && !o.map_later && !o.trimmed &&
+                           !o.pass.on && n <= kFmMaxPoints;
+    x.fm_packed = fm_packed;
+    // round 6: the dense contract itself (nothing for the sharded operator, no resident rows, no staged call) leaves through
+    // k_emit_split, and part of its zero padding under the index launches (ZeroFill)
+    const bool split = fm_packed && o.emit_voxels && !x.row_state && o.stage == 0 && !x.keys_out && !x.first_out && !x.voff && !want_map &&
+                       D3D_TUNE_VAL(3, 1) != 0;
+    const int fill_sort_k = split ? D3D_TUNE_VAL(6, 36) : 0, fill_count_k = split ? D3D_TUNE_VAL(11, 12) : 0;    // 1024 x 16 B per filler
+    // (frames of 0.72 .. 1.3 M points: below, k_emit_split is not store-bound and the fillers only lengthen the partition -- 0.5 M
+    // points 71 -> 78 us, 0.1 M 57 -> 64 --, above, every CU has a tile: profiles/r06_ab_sizes.txt)
+    const bool fill_tiles = fill_sort_k > 0 && !big_tiles && vec4 && tile_sort && (w.npad >> 13) >= 88 && (w.npad >> 13) <= 160;
     // tiles of 4096 points while tiles of 8192 would leave a third of the CUs without a workgroup (one workgroup per tile):
     // 1 M points 16.2 -> 13.7 us with the bucket kernel unchanged; at 2 M points (245 tiles of 8192) +4 us, at 4 M +6; tiles of
-    // 2048 points: +2 us in the bucket kernel (runs of two entries) -- profiles/r05_b_tune.txt
-    const int tune_tile = !big_tiles && vec4 && ROWS ? D3D_TUNE_VAL(2, (w.npad >> 13) <= 160 ? 12 : 0) : 0;
+    // 2048 points: +2 us in the bucket kernel (runs of two entries) -- profiles/r05_b_tune.txt.  Round 6: where fillers take the
+    // CUs without a tile, tiles of 8192 it is (those CUs then write 76 MB of zeros in the 16 us).
+    const int tune_tile = !big_tiles && vec4 && ROWS ? D3D_TUNE_VAL(2, (w.npad >> 13) <= 160 && !fill_tiles ? 12 : 0) : 0;
     const bool small_tiles = tune_tile == 12, tiny_tiles = tune_tile == 11;
     const int tshift = big_tiles ? 14 : small_tiles ? 12 : tiny_tiles ? 11 : 13;
     const uint32_t stiles = (uint32_t)(w.npad >> tshift);
@@ -4098,14 +4368,43 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         table = tilecnt;
         tileinfo = tilecnt + (size_t)nbins * stiles;
     }
-    // round 5: the lean bucket kernel + packed first-point entries, whenever k_emit is the consumer and nothing needs the
-    // cells' first indices per point (the point -> voxel map, the sparse contract's filters)
-    const bool fm_packed = ROWS && (o.emit_voxels || o.emit_reduce) && !o.index_v1 && !precpos && !o.map_later && !o.trimmed &&
-                           !o.pass.on && n <= kFmMaxPoints;
-    x.fm_packed = fm_packed;
     // (early zero lines: -6 us at 1 M points, -7 at 2 M, -3 at 4 M, nothing at 8 M, where the launch is in its steady state)
     x.early_zero = fm_packed && D3D_TUNE_VAL(4, n < kBigTileMinPoints ? 1 : 0) != 0;
     const bool do_index = o.stage != 2;                        // (stage 2: this frame's index was launched by an earlier call)
+    // voxels[0 .. prefilled): as much as the idle CUs of the two launches write in passing, at most the voxels a LiDAR frame of
+    // this size has (9 n / 16; config 2: 0.585 n) and never more than the tensor's rows
+    ZeroFill zf_sort, zf_count;
+    uint32_t prefilled = 0;
+    if (split && table && do_index) {
+        const int64_t capv = n < (int64_t)o.max_voxels ? n : (int64_t)o.max_voxels;
+        const int64_t all16 = (n * 9 / 16 < capv ? n * 9 / 16 : capv) * (int64_t)o.P;
+        const uint32_t sort_wgs = ((stiles + 7u) >> 3) << 3, count_wgs = (uint32_t)(w.npad / kFlagTile);
+        int64_t at = 0;
+        if (fill_tiles && tshift == 13 && sort_wgs + 64u <= (uint32_t)kNumCUs) {
+            zf_sort.nblk = (uint32_t)kNumCUs - sort_wgs;
+            zf_sort.first = sort_wgs;
+            zf_sort.dst = o.emit_voxels;
+            zf_sort.n16 = (int64_t)zf_sort.nblk * fill_sort_k * 1024;
+            if (zf_sort.n16 > kFillSortMax16) zf_sort.n16 = kFillSortMax16;      // (what leaves in the launch's 16 us, however many fillers)
+            if (zf_sort.n16 > all16) zf_sort.n16 = all16;
+            at = zf_sort.n16;
+        }
+        if (fill_count_k > 0 && fill_tiles && count_wgs + 64u <= (uint32_t)kNumCUs && at < all16) {
+            zf_count.nblk = (uint32_t)kNumCUs - count_wgs;
+            zf_count.first = count_wgs;
+            zf_count.dst = o.emit_voxels + at;
+            zf_count.n16 = (int64_t)zf_count.nblk * fill_count_k * 1024;
+            if (zf_count.n16 > all16 - at) zf_count.n16 = all16 - at;
+            at += zf_count.n16;
+        }
+        prefilled = (uint32_t)(at / (int64_t)o.P);
+    }
+    if (o.emit_voxels && o.stage == 0) {
+        g_last_plan[0] = split ? 1 : 0;
+        g_last_plan[1] = prefilled;
+        g_last_plan[2] = zf_sort.n16 * 16;
+        g_last_plan[3] = zf_count.n16 * 16;
+    }
     if (do_index && table) {
         const size_t lds = ((size_t)1 << tshift) * (sizeof(typename Key::bin_key_t) + 2) + bin_lds;
         uint32_t *ppos = o.map_later ? pbin : nullptr;      // (pfirst: by point, the first point of its voxel when it is kept)
@@ -4114,9 +4413,9 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         if (lds + 1024 > 65536)                                                                                                 \
             D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort<Key, V4, ROWS, IT>),                  \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-        D3D_LAUNCH("k_tile_sort", (k_tile_sort<Key, V4, ROWS, IT>), dim3(((stiles + 7u) >> 3) << 3), dim3(kSortThreads), lds, st, kf, points, n, c, \
+        D3D_LAUNCH("k_tile_sort", (k_tile_sort<Key, V4, ROWS, IT>), dim3((((stiles + 7u) >> 3) << 3) + zf_sort.nblk), dim3(kSortThreads), lds, st, kf, points, n, c, \
                    nbins, stiles, bent, table, tileinfo, ppos, firstmap, counts, o.mapping, o.trimmed, o.keepid, zero_words,    \
-                   nzero, zero_ticket);                                                                                         \
+                   nzero, zero_ticket, true, zf_sort);                                                                          \
     } while (0)
         if (big_tiles) D3D_TILE_SORT(true, 16);
         else if (small_tiles) D3D_TILE_SORT(true, 4);
@@ -4172,7 +4471,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
         }
     }
     const unsigned nbF = (unsigned)(w.npad / kFlagTile);            // <= 1024 (n <= 16 M)
-    if (do_index) D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, w.big_count);
+    if (do_index) D3D_LAUNCH("k_first_count", k_first_count, dim3(nbF + zf_count.nblk), dim3(1024), 0, st, firstmap, w.fwpre, w.bsumF, w.big_count, zf_count);
     if (o.stage == 1) return D3D_OK;
     const dim3 grid((unsigned)(w.npad / 256));
     if constexpr (!ROWS && std::is_same<Key, DenseKey>::value) {
@@ -4196,6 +4495,18 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     if constexpr (ROWS) {
         if (o.emit_voxels || o.emit_reduce) {
             const int pshift = (o.P & (o.P - 1)) == 0 ? __builtin_ctz(o.P) : -1;
+            if (split) {
+                if (o.agg4)
+                    D3D_LAUNCH("k_emit_split", (k_emit_split<Key, true>), dim3(2u * grid.x), dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre,
+                               w.bsumF, vrec, o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
+                               o.fuse_pmask ? o.pmask : nullptr, reinterpret_cast<float4 *>(o.aggregates), o.emit_voxels, counts,
+                               x.host_counts, prefilled, x.aux_value);
+                else
+                    D3D_LAUNCH("k_emit_split", (k_emit_split<Key, false>), dim3(2u * grid.x), dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre,
+                               w.bsumF, vrec, o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
+                               o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, o.emit_voxels, counts, x.host_counts, prefilled,
+                               x.aux_value);
+            } else
             if (x.row_state && o.emit_voxels) {
                 if (o.agg4)
                     D3D_LAUNCH("k_emit_resident", (k_emit<Key, true, true>), grid, dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre, w.bsumF, vrec,
@@ -4501,6 +4812,16 @@ static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const 
     if (reduction != D3D_REDUCE_NONE && !agg4)
         D3D_LAUNCH("k_aggregate", k_aggregate, dim3(grid_for(cap * c, 256)), dim3(256), 0, st, points, c, counts, npoints,
                    w.voff, lists_ready ? w.big_list : w.list, w.unsorted, P, reduction, aggregates);
+    return D3D_OK;
+}
+
+// What the calling thread's last d3d_voxelize_3d_dense[_notify] launched (bench.py prices k_emit_split on the bytes IT moves):
+// out[0] = 1 when the output left through k_emit_split, out[1] = voxels whose zero padding was written under the index launches,
+// out[2] / out[3] = the bytes of zeros k_tile_sort's / k_first_count's filler workgroups stored.
+extern "C" int d3d_voxelize_dense_last_plan(int64_t *out4)
+{
+    if (!out4) return D3D_ERR_BAD_ARG;
+    for (int k = 0; k < 4; k++) out4[k] = g_last_plan[k];
     return D3D_OK;
 }
 

@@ -407,6 +407,12 @@ int d3d_aligned_scatter_backward(const void *coord, int64_t n, int32_t dim, cons
 int d3d_profile_enable(int on);
 int d3d_profile_report(char *buf, size_t buf_bytes);
 
+/* what the calling thread's last d3d_voxelize_3d_dense[_notify] launched (measurement only, bench.py): out4[0] = 1 when the
+ * output left through the two-role launch (k_emit_split), out4[1] = voxel ids whose zero padding was stored under the index
+ * launches, out4[2] / out4[3] = bytes of zeros the filler workgroups of k_tile_sort / k_first_count stored.  No reference
+ * counterpart (voxelize.cpp:56-59 zero-fills with torch::zeros). */
+int d3d_voxelize_dense_last_plan(int64_t *out4);
+
 /* stream-bandwidth probe on the caller's buffer (bench.py: "fraction of the measured copy bandwidth of the same box",
  * SURVEY 8d).  mode 0 = nontemporal 16-byte stores over `bytes`, 1 = copy first half -> second half, 2 = read sweep,
  * 3 = hipMemsetAsync (the runtime's fill, for reference). */

@@ -7,12 +7,15 @@ import sys
 import torch
 sys.path.insert(0, ".")
 from d3d_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libd3d_hip_phase.so")
+KV = os.environ.get("D3D_TUNE_KV", "")              # "k=v,k=v": experiment knobs (make PHASE_TUNE=1 -> libd3d_hip_phase_tune.so)
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libd3d_hip_phase_tune.so" if KV else "libd3d_hip_phase.so")
 from d3d_amd import synth
 from d3d_amd.voxel import VoxelGenerator
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 lib = _lib.load()
+for kv in filter(None, KV.split(",")):
+    lib.d3d_debug_set_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
 buf = (ctypes.c_ulonglong * 64)()
 names = {0: ("k_bucket_index", ["prologue", "clear+locate+issue", "insert", "records-loop", "segments", "rank+stores", "overflow", "records-scan", "entries-wait"]),
          1: ("k_tile_sort", ["load+clear", "keys+hist", "scan+table", "place", "copy-out"]),

@@ -28,7 +28,8 @@ def apply(kv):
 
 big = n > 2000000
 bounds, shape, seed = (synth.WAYMO_BOUNDS, synth.WAYMO_SHAPE, 3) if big else (synth.KITTI_BOUNDS, synth.KITTI_SHAPE, 0)
-cloud = torch.from_numpy(synth.lidar_like(n, seed, bounds)).cuda()
+make_cloud = synth.uniform_cloud if os.environ.get("TUNE_DIST", "lidar") == "uniform" else synth.lidar_like
+cloud = torch.from_numpy(make_cloud(n, seed, bounds)).cuda()
 mode = os.environ.get("TUNE_MODE", "dense")
 if mode == "dense":
     gen = VoxelGenerator(bounds, shape, dense=True, reduction="mean", max_points=32, max_voxels=n)
@@ -39,7 +40,7 @@ ref = {k: v.clone() for k, v in gen(cloud).items()}
 for rep in range(3):
     for name, kv in variants:
         apply(kv)
-        got = gen(cloud)
+        got = gen(cloud, poison=True) if mode == 'dense' else gen(cloud)
         same = all(torch.equal(got[k], ref[k]) for k in ref)
         dt = bench.timed(lambda: gen(cloud), steps, 3)
         prof = bench.kernel_profile(lambda: gen(cloud), steps)
