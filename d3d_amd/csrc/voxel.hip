@@ -2895,27 +2895,30 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
 // feeds coords / voxel_npoints / voxel_pmask.  Voxels of 255 points and more (count and cell in a record) belong to the even role
 // entirely.  Both roles derive a voxel's split point `lim` from its entry alone; every byte has exactly one writer.
 // voxels[0 .. prefilled) x P rows were zero-filled under the index launches (ZeroFill): the odd role skips those.
-template <class Key, bool AGG4>
-__global__ __launch_bounds__(256) void k_emit_split(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
+template <class Key, bool AGG4, int WG = 256>
+__global__ __launch_bounds__(WG) void k_emit_split(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
                                                     const uint32_t *__restrict__ fwpre, const uint32_t *__restrict__ bsumF,
                                                     const uint4 *__restrict__ vrec, uint32_t max_voxels,
                                                     const float4 *__restrict__ points4, const uint32_t *__restrict__ ranked,
                                                     const float4 *__restrict__ staged, uint32_t P, int pshift /* log2 P or -1 */,
                                                     int reduction, int64_t *coords, int32_t *npoints, unsigned char *pmask /* or NULL */,
                                                     float4 *agg, float4 *voxels, int64_t *counts, int64_t *host_counts,
-                                                    uint32_t prefilled, int64_t aux_value)
+                                                    uint32_t prefilled, int64_t aux_value,
+                                                    uint32_t dbg /* TUNE build: timing experiments with WRONG outputs; else 0 */)
 {
     typedef float vec4 __attribute__((ext_vector_type(4)));
     typedef uint32_t uvec4 __attribute__((ext_vector_type(4)));
     __shared__ vec4 rowbuf_all[256 / kWave][kEmitCap];
     __shared__ uint32_t off_all[256 / kWave][kWave], base_all[256 / kWave][kWave], first_all[256 / kWave][kWave];
     __shared__ uint32_t loff_all[256 / kWave][kWave];
-    __shared__ uint16_t kept_all[256 / kWave][kWave], lim_all[256 / kWave][kWave];
-    const bool zrole = (blockIdx.x & 1u) != 0;
-    const int64_t i = (int64_t)(blockIdx.x >> 1) * 256 + threadIdx.x;
+    __shared__ uint16_t kept_all[WG / kWave][kWave], lim_all[WG / kWave][kWave];
+    __shared__ long long zbuf_all[WG == 512 ? 4 : 1][WG == 512 ? 3 * kWave : 1];
+    // WG == 256: two workgroups per 256 points, the role by the workgroup's parity; 512: one workgroup, wavefronts 4 .. 7 the second role
+    const bool zrole = WG == 512 ? threadIdx.x >= 256u : (blockIdx.x & 1u) != 0;
+    const int64_t i = (int64_t)(WG == 512 ? blockIdx.x : blockIdx.x >> 1) * 256 + (threadIdx.x & 255u);
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
-    vec4 *rowbuf = rowbuf_all[w];
-    uint32_t *sh_off = off_all[w], *sh_base = base_all[w], *sh_first = first_all[w], *sh_loff = loff_all[w];
+    vec4 *rowbuf = rowbuf_all[w & 3];
+    uint32_t *sh_off = off_all[w & 3], *sh_base = base_all[w & 3], *sh_first = first_all[w & 3], *sh_loff = loff_all[w & 3];
     uint16_t *sh_kept = kept_all[w], *sh_lim = lim_all[w];
     const uint32_t tile = (uint32_t)(i / kFlagTile), ntile = (uint32_t)(npad / kFlagTile);
     uint32_t before = 0, all = 0;
@@ -2953,8 +2956,9 @@ __global__ __launch_bounds__(256) void k_emit_split(Key kf, int64_t npad, const 
     vec4 *out = reinterpret_cast<vec4 *>(voxels) + (int64_t)vid0 * P;
     const vec4 zero = {0.f, 0.f, 0.f, 0.f};
     if (zrole) {
+        if (dbg & 8u) return;                               // no second role at all
         float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mine && !isrec) p0 = points4[il];               // (ascending indices inside the wavefront's 1 KiB window)
+        if (mine && !isrec && !(dbg & 2u)) p0 = points4[il];               // (ascending indices inside the wavefront's 1 KiB window)
         {
             const uint32_t kept_e = c8 < P ? c8 : P, l8 = (kept_e + 7u) & ~7u;
             sh_lim[lane] = (uint16_t)(!mine ? 0u : (isrec || l8 > P) ? P : l8);
@@ -2963,8 +2967,8 @@ __global__ __launch_bounds__(256) void k_emit_split(Key kf, int64_t npad, const 
         // the per-voxel outputs that need no row, FIRST: the wavefront then ends on its zero lines without ever waiting for a
         // store (behind the store loop the compiler can only wait for everything in flight; zeros first: 62 -> 56 us with the
         // filled range below, profiles/r06_ab_split.txt).  Cell: the same arithmetic on the same floats as k_tile_sort.
-        long long *cbuf = reinterpret_cast<long long *>(rowbuf);       // 64 * 3 * 8 B = 1.5 KiB
-        if (mine && !isrec) {
+        long long *cbuf = WG == 512 ? zbuf_all[w & 3] : reinterpret_cast<long long *>(rowbuf);       // 64 * 3 * 8 B = 1.5 KiB
+        if (mine && !isrec && !(dbg & 2u)) {
             const float v3[3] = {p0.x, p0.y, p0.z};
             u64 key = 0;
             uint32_t st = 0;
@@ -2976,9 +2980,9 @@ __global__ __launch_bounds__(256) void k_emit_split(Key kf, int64_t npad, const 
         }
         wave_lds_fence();
         long long *cdst = reinterpret_cast<long long *>(coords) + (int64_t)vid0 * 3;
-        for (uint32_t t = lane; t < nv * 3; t += kWave)
+        for (uint32_t t = lane; t < ((dbg & 2u) ? 0u : nv * 3); t += kWave)
             if (!((recmask >> (t / 3u)) & 1ull)) __builtin_nontemporal_store(cbuf[t], &cdst[t]);
-        if (pmask) {                                         // P % 16 == 0, 16-byte aligned (host-checked): 16-byte pieces
+        if (pmask && !(dbg & 2u)) {                                         // P % 16 == 0, 16-byte aligned (host-checked): 16-byte pieces
             const uint32_t per = P >> 4, total = nv * per;
             uvec4 *pdst = reinterpret_cast<uvec4 *>(pmask + (int64_t)vid0 * P);
             for (uint32_t t = lane; t < total; t += kWave) {
@@ -2997,7 +3001,7 @@ __global__ __launch_bounds__(256) void k_emit_split(Key kf, int64_t npad, const 
         }
         // rows [lim, P) of the voxels past the range filled under the index launches
         const uint32_t npre = prefilled <= vid0 ? 0u : (prefilled - vid0 < nv ? prefilled - vid0 : nv);
-        const uint32_t qa = nv * P;
+        const uint32_t qa = (dbg & 1u) ? 0u : nv * P;
         for (uint32_t q0 = npre * P; q0 < qa; q0 += 4 * kWave) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -3010,6 +3014,7 @@ __global__ __launch_bounds__(256) void k_emit_split(Key kf, int64_t npad, const 
         }
         return;
     }
+    if (dbg & 4u) return;                                   // no chain role at all
     // the chain
     uint32_t cnt = mine ? c8 : 0u, base = seg;
     u64 key = 0;
@@ -3048,12 +3053,13 @@ __global__ __launch_bounds__(256) void k_emit_split(Key kf, int64_t npad, const 
                     if (sh_off[mid] - oa <= t) lo = mid; else hi = mid;
                 }
                 const uint32_t k = t - (sh_off[lo] - oa);
+                if (dbg & 16u) continue;                    // no row gather
                 const uint32_t idx = k == 0 ? sh_first[lo] : ranked[sh_base[lo] + k];
                 rowbuf[t] = *reinterpret_cast<const vec4 *>(&points4[idx]);
             }
         }
         wave_lds_fence();
-        if (AGG4 && (uint32_t)lane >= ja && (uint32_t)lane < jb && cnt <= P) {     // reductions in point order, one lane per voxel
+        if (AGG4 && !(dbg & 32u) && (uint32_t)lane >= ja && (uint32_t)lane < jb && cnt <= P) {     // reductions in point order, one lane per voxel
             const vec4 *rw = rowbuf + (off - oa);
             for (uint32_t k = 0; k < kept; k++) {
                 const vec4 x = rw[k];
@@ -3068,7 +3074,7 @@ __global__ __launch_bounds__(256) void k_emit_split(Key kf, int64_t npad, const 
         // rows [0, lim) of the batch's voxels, flat: eight lanes per 128-byte line
         const uint32_t l0 = (uint32_t)__shfl((int)loff, (int)ja, kWave);
         const uint32_t l1 = (uint32_t)__shfl((int)lincl, (int)jb - 1, kWave);
-        for (uint32_t t0 = l0; t0 < l1; t0 += kWave) {
+        for (uint32_t t0 = l0; t0 < ((dbg & 64u) ? l0 : l1); t0 += kWave) {     // (64: no row lines)
             const uint32_t t = t0 + lane;
             if (t < l1) {
                 uint32_t lo = ja, hi = jb;                  // largest j in [ja, jb) with loff[j] <= t
@@ -3085,7 +3091,7 @@ __global__ __launch_bounds__(256) void k_emit_split(Key kf, int64_t npad, const 
         wave_lds_fence();                                   // the next batch overwrites the buffer
         ja = jb;
     }
-    if (AGG4 && mine) {
+    if (AGG4 && mine && !(dbg & 128u)) {
         vec4 res;
         if (cnt > P) res = *reinterpret_cast<const vec4 *>(&staged[base + P]);   // fp64 reduction of k_bucket_index (voxelize.cpp:137-157)
         else {
@@ -4495,17 +4501,31 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     if constexpr (ROWS) {
         if (o.emit_voxels || o.emit_reduce) {
             const int pshift = (o.P & (o.P - 1)) == 0 ? __builtin_ctz(o.P) : -1;
-            if (split) {
+            // both roles in ONE workgroup of 512 lanes from 3 M points on (less LDS per wavefront, 32 instead of 28 per CU): 4 M
+            // points 384 -> 358 us, 8 M 704 -> 664, a uniform cloud of 1 M 99 -> 93; 2 M and below: the same or worse (config 2
+            // with its fillers 61 -> 65) -- profiles/r06_ab_sizes.txt
+            if (split && D3D_TUNE_VAL(1, n >= (3ll << 20) ? 1 : 0) == 1) {
+                if (o.agg4)
+                    D3D_LAUNCH("k_emit_split", (k_emit_split<Key, true, 512>), dim3(grid.x), dim3(512), 0, st, kf, w.npad, firstmap, w.fwpre,
+                               w.bsumF, vrec, o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
+                               o.fuse_pmask ? o.pmask : nullptr, reinterpret_cast<float4 *>(o.aggregates), o.emit_voxels, counts,
+                               x.host_counts, prefilled, x.aux_value, (uint32_t)D3D_TUNE_VAL(15, 0));
+                else
+                    D3D_LAUNCH("k_emit_split", (k_emit_split<Key, false, 512>), dim3(grid.x), dim3(512), 0, st, kf, w.npad, firstmap, w.fwpre,
+                               w.bsumF, vrec, o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
+                               o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, o.emit_voxels, counts, x.host_counts, prefilled,
+                               x.aux_value, (uint32_t)D3D_TUNE_VAL(15, 0));
+            } else if (split) {
                 if (o.agg4)
                     D3D_LAUNCH("k_emit_split", (k_emit_split<Key, true>), dim3(2u * grid.x), dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre,
                                w.bsumF, vrec, o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
                                o.fuse_pmask ? o.pmask : nullptr, reinterpret_cast<float4 *>(o.aggregates), o.emit_voxels, counts,
-                               x.host_counts, prefilled, x.aux_value);
+                               x.host_counts, prefilled, x.aux_value, (uint32_t)D3D_TUNE_VAL(15, 0));
                 else
                     D3D_LAUNCH("k_emit_split", (k_emit_split<Key, false>), dim3(2u * grid.x), dim3(256), 0, st, kf, w.npad, firstmap, w.fwpre,
                                w.bsumF, vrec, o.max_voxels, p4, w.big_list, w.staged, o.P, pshift, o.reduction, o.coords, o.npoints,
                                o.fuse_pmask ? o.pmask : nullptr, (float4 *)nullptr, o.emit_voxels, counts, x.host_counts, prefilled,
-                               x.aux_value);
+                               x.aux_value, (uint32_t)D3D_TUNE_VAL(15, 0));
             } else
             if (x.row_state && o.emit_voxels) {
                 if (o.agg4)

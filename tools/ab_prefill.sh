@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06
-python bench.py > gpurun_out/r06/bench_a.json 2> gpurun_out/r06/bench_a.err; tail -3 gpurun_out/r06/bench_a.err; head -c 2500 gpurun_out/r06/bench_a.json; echo
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+for n in 2000000 8000000 500000 200000; do python tools/tune_ab.py 50 $n "wg512:1=1" 2>&1 | grep -v amdgpu.ids; done > gpurun_out/r06/ab13_wg512_sizes.txt
+cat gpurun_out/r06/ab13_wg512_sizes.txt
