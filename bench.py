@@ -88,15 +88,39 @@ def kernel_profile(fn, steps):
     return out
 
 
+TRAFFIC_SOURCES = {      # the kernel sources a workload's traffic figures depend on (tools/summarize_pmc.py hashes the same files)
+    "voxel": ("voxel.hip", "common.hpp", "lds_sort.hpp"),
+    "box": ("box.hip", "geom.hpp", "sort.hip", "common.hpp", "lds_sort.hpp"),
+}
+
+
+def source_hashes():
+    import hashlib
+    d = os.path.join(ROOT, "d3d_amd", "csrc")
+    return {f: hashlib.sha1(open(os.path.join(d, f), "rb").read()).hexdigest()[:16]
+            for fs in TRAFFIC_SOURCES.values() for f in fs if os.path.exists(os.path.join(d, f))}
+
+
 def load_traffic(kernel, workload):
     """HBM bytes per launch from the COMMITTED rocprofv3 --pmc passes (profiles/traffic.json, made by
     tools/collect_profiles.sh + tools/summarize_pmc.py): PMC counters cannot be collected from inside this process, so
-    the figure is the one of the last profiled build, not of this run -> (bytes | None, source label)"""
+    the figure is the one of the last profiled build, not of this run -> (bytes | None, source label).  The file carries the
+    hashes of the kernel sources it was collected on: when one of the files behind `workload` has changed since, the figure is
+    withheld (None, "stale ...") instead of being passed off as this build's."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(p))
-        return t.get(workload, {}).get(kernel), "profiles/traffic.json (committed rocprofv3 --pmc passes, %s)" % t.get(
-            "_profile", "unlabelled")
+        group = "box" if workload.startswith(("config3", "config4")) else "voxel"
+        then, now = t.get("_sources", {}).get(workload, {}), source_hashes()
+        changed = [f for f in TRAFFIC_SOURCES[group] if then.get(f) != now.get(f)]
+        if changed:
+            return None, "stale: %s changed since profiles/traffic.json's %s collection (%s)" % (
+                ", ".join(changed), workload, t.get("_profile", {}).get(workload, "unlabelled") if isinstance(t.get("_profile"), dict)
+                else t.get("_profile", "unlabelled"))
+        prof = t.get("_profile", "unlabelled")
+        if isinstance(prof, dict):
+            prof = prof.get(workload, "unlabelled")
+        return t.get(workload, {}).get(kernel), "profiles/traffic.json (committed rocprofv3 --pmc passes, %s)" % prof
     except Exception:
         return None, "unavailable"
 
@@ -252,6 +276,107 @@ def cpu_allcore_voxel(cloud, bounds, shape, max_points, max_voxels):
                 sample="one full %d-point frame per thread on %d threads at once (frame-parallel)" % (cloud.shape[0], cores))
 
 
+def iou_leg(n3, steps=2, warmup=1):
+    """config 3: n3 rotated boxes fp64, all n3^2 pairs in ONE result (80 GB at 100 k boxes; 288 GB of HBM; row blocks only
+    beyond 100 GB) through the public operator, and the roofline of its dominant kernel (8 B per pair, write-bound)"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_iou
+    ex = {}
+    b, _ = synth.boxes2d_sparse(n3, 1)
+    bt = torch.from_numpy(b).cuda()
+    rows = max(1, min(n3, int(100e9 // (8 * n3))))
+
+    def all_pairs():
+        for r0 in range(0, n3, rows):
+            box2d_iou(bt[r0:r0 + rows], bt, method="rbox")       # the public operator (fp64 in, precise=True)
+    dt = timed(all_pairs, steps, warmup)
+    ex["iou2d_rbox_fp64_mpairs_per_s"] = round(n3 * n3 * steps / dt / 1e6, 1)
+    ex["iou2d_rbox_fp64_GBps_written"] = round(n3 * n3 * 8 * steps / dt / 1e9, 1)
+    if rows >= n3:      # HIP events on the launch stream
+        prof = kernel_profile(all_pairs, steps)
+        kp = prof.get("k_iou_pre")
+        if kp:
+            b_alg = n3 * n3 * 8 + 2 * n3 * 5 * 8
+            ach = b_alg / (kp["avg_us"] * 1e-6) / 1e9
+            tr, src = load_traffic("k_iou_pre", "config3_iou")
+            ex["iou2d_rbox_fp64_roofline"] = dict(bound="hbm", kernel="k_iou_pre", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                                  frac=round(ach / HBM_PEAK_GBS, 4), avg_us=round(kp["avg_us"], 1),
+                                                  algorithmic_bytes=b_alg, traffic=tr, traffic_source=src,
+                                                  op_frac=round(n3 * n3 * 8 * steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+                                                  kernels_us={k: round(v["avg_us"], 2) for k, v in prof.items()})
+            # the stream probes at THIS kernel's footprint (an 80 GB buffer: the 3 GB probes of roofline_large undersell a
+            # fill that runs for 13 ms over every channel of the 288 GB) -- no fraction of a measured rate may exceed 1
+            del bt
+            torch.cuda.empty_cache()
+            pr = stream_probe(n3 * n3 * 8, iters=2)
+            fb = ach / max(pr.values())
+            ex["iou2d_rbox_fp64_roofline"].update(peak_measured=pr, frac_of_measured_best=round(fb, 4))
+            if fb > 1:      # the probes are FLOORS of what the box can store (their loops are not this kernel's): say so
+                ex["iou2d_rbox_fp64_roofline"]["probe_note"] = ("the kernel's fill ran faster than every store probe on this box: the "
+                                                               "probes bound the achievable rate from below, not from above; "
+                                                               "traffic (WRITE_SIZE pass of the same launch) is the evidence")
+    torch.cuda.empty_cache()
+    return ex
+
+
+def nms_leg(n3, steps=20, warmup=1):
+    """config 3: box2d_nms (rbox, fp64, threshold 0.5) on n3 boxes.  SURVEY 8(d): compulsory I/O is tiny (boxes + scores in, one
+    byte per box out); the reference design's figure is the N x ceil(N / 64) x 8 B suppression matrix written and read by the
+    sweep (nms_cuda.cu:17-110) -- this build does not materialise it (grid broad phase -> candidate lists -> resolve), so the
+    roofline object prices the launch sequence on the bytes it DOES move (PMC passes) and says what bounds it instead."""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms
+    b, s = synth.boxes2d_sparse(n3, 1)
+    bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+    step = lambda: box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5)  # noqa: E731
+    dt = timed(step, steps, warmup)
+    ex = {"nms_rbox_fp64_boxes_per_s": round(n3 * steps / dt, 1)}
+    prof = kernel_profile(step, steps)
+    ksum = sum(v["total_ms"] for v in prof.values()) / steps * 1e3
+    launches = sum(v["calls"] for v in prof.values()) / steps
+    tr, src = load_traffic("nms_op_total", "config3_nms")
+    compulsory = n3 * (5 + 1) * 8 + n3
+    us = 1e6 * dt / steps
+    ex["nms_rbox_fp64_roofline"] = dict(
+        bound="hbm", kernel="d3d_nms2d (all launches of a call)", achieved=round((tr or compulsory) / (us * 1e-6) / 1e9, 2), peak=HBM_PEAK_GBS,
+        unit="GB/s", frac=round((tr or compulsory) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), us_per_call=round(us, 1),
+        kernel_sum_us=round(ksum, 1), launches_per_call=round(launches, 1), algorithmic_bytes=compulsory, traffic=tr, traffic_source=src,
+        reference_mask_bytes=n3 * ((n3 + 63) // 64) * 8,
+        note="achieved = PMC traffic of one call (or, without it, the compulsory bytes) / the call's duration: the operator is bound by "
+             "its chain of ~%d dependent launches over a few MB, not by bandwidth; reference_mask_bytes is what nms_cuda.cu's dense "
+             "bit matrix would write (and the sweep read) -- not moved here" % round(launches),
+        kernels_us={k: round(v["avg_us"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]})
+    del bt, st
+    torch.cuda.empty_cache()
+    return ex
+
+
+def iou3d_leg(steps=20, warmup=3):
+    """config 4: 20 k predictions x 5 k ground truths, rbox iou3d fp32 (4 B per pair written + 7 floats per box read)"""
+    from d3d_amd import synth
+    from d3d_amd.box import iou3d
+    p, g = synth.boxes3d_eval(5000, 4, 2)
+    pt, gt = torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda()
+    step = lambda: iou3d(pt, gt)  # noqa: E731
+    dt = timed(step, steps, warmup)
+    npairs = len(p) * len(g)
+    ex = {"iou3d_rbox_fp32_mpairs_per_s": round(npairs * steps / dt / 1e6, 1)}
+    prof = kernel_profile(step, steps)
+    b_alg = npairs * 4 + (len(p) + len(g)) * 7 * 4
+    us = 1e6 * dt / steps
+    dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+    tr, src = load_traffic("iou3d_op_total", "config4_iou3d")
+    ex["iou3d_rbox_fp32_roofline"] = dict(
+        bound="hbm", kernel="d3d_iou3d_forward (all launches of a call)", achieved=round(b_alg / (us * 1e-6) / 1e9, 1), peak=HBM_PEAK_GBS,
+        unit="GB/s", frac=round(b_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), us_per_call=round(us, 2), algorithmic_bytes=b_alg,
+        traffic=tr, traffic_source=src, dominant_kernel=dom[0],
+        dominant_kernel_frac=round(b_alg / (dom[1]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+        kernels_us={k: round(v["avg_us"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])})
+    del pt, gt
+    torch.cuda.empty_cache()
+    return ex
+
+
 def extras(args):
     """secondary metrics of BASELINE.json (configs 2-sparse, 3, 4); short runs, GPU + bounded CPU samples"""
     import oracle
@@ -335,42 +460,17 @@ def extras(args):
     ex["voxelize_dense_uniform_op_algorithmic_GBps"] = round((args.points * 16 + vu * (32 * 16 + 32 + 24 + 4 + 16)) * 10 / dt / 1e9, 1)
     del cloud, gen
     torch.cuda.empty_cache()
-    # config 3: 100k rotated boxes fp64, all 1e10 pairs in ONE 80 GB result (288 GB of HBM; row blocks only beyond 100 GB)
     n3 = args.boxes
+    ex.update(iou_leg(n3))
     b, s = synth.boxes2d_sparse(n3, 1)
     bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
-    rows = max(1, min(n3, int(100e9 // (8 * n3))))
-
-    def all_pairs():
-        for r0 in range(0, n3, rows):
-            box2d_iou(bt[r0:r0 + rows], bt, method="rbox")       # the public operator (fp64 in, precise=True)
-    dt = timed(all_pairs, 2, 1)
-    ex["iou2d_rbox_fp64_mpairs_per_s"] = round(n3 * n3 * 2 / dt / 1e6, 1)
-    ex["iou2d_rbox_fp64_GBps_written"] = round(n3 * n3 * 8 * 2 / dt / 1e9, 1)
-    if rows >= n3:      # roofline of ITS dominant kernel (8 B per pair, write-bound), HIP events on the launch stream
-        kp = kernel_profile(all_pairs, 2).get("k_iou_pre")
-        if kp:
-            ach = n3 * n3 * 8 / (kp["avg_us"] * 1e-6) / 1e9
-            ex["iou2d_rbox_fp64_roofline"] = dict(bound="hbm", kernel="k_iou_pre", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                                                  frac=round(ach / HBM_PEAK_GBS, 4), avg_us=round(kp["avg_us"], 1),
-                                                  algorithmic_bytes=n3 * n3 * 8)
-            # the stream probes at THIS kernel's footprint (an 80 GB buffer: the 3 GB probes of roofline_large undersell a
-            # fill that runs for 13 ms over every channel of the 288 GB) -- no fraction of a measured rate may exceed 1
-            torch.cuda.empty_cache()
-            pr = stream_probe(n3 * n3 * 8, iters=2)
-            fb = ach / max(pr.values())
-            ex["iou2d_rbox_fp64_roofline"].update(peak_measured=pr, frac_of_measured_best=round(fb, 4))
-            if fb > 1:      # the probes are FLOORS of what the box can store (their loops are not this kernel's): say so
-                ex["iou2d_rbox_fp64_roofline"]["probe_note"] = ("the kernel's fill ran faster than every store probe on this box: the "
-                                                               "probes bound the achievable rate from below, not from above")
     torch.cuda.empty_cache()
     bd, _ = synth.boxes2d_dense(5000, 1)      # the reference's own benchmark distribution (ALU-bound case)
     bdt = torch.from_numpy(bd).cuda()
     dt = timed(lambda: box2d_iou(bdt, bdt, method="rbox"), 10, 2)
     ex["iou2d_rbox_fp64_dense5k_mpairs_per_s"] = round(25e6 * 10 / dt / 1e6, 1)
     # (no warm-up streak: since round 4 every call decides from ITS OWN grid whether the level kernels are launched)
-    dt = timed(lambda: box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.5), 20, 1)
-    ex["nms_rbox_fp64_boxes_per_s"] = round(n3 * 20 / dt, 1)
+    ex.update(nms_leg(n3, 20, 1))
     try:        # the same operator captured into a HIP graph by the caller and replayed (~28 launches without host work)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -422,8 +522,7 @@ def extras(args):
     # config 4: 20k x 5k iou3d fp32
     p, g = synth.boxes3d_eval(5000, 4, 2)
     pt, gt = torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda()
-    dt = timed(lambda: iou3d(pt, gt), 20, 3)
-    ex["iou3d_rbox_fp32_mpairs_per_s"] = round(1e8 * 20 / dt / 1e6, 1)
+    ex.update(iou3d_leg(20, 3))
     # config 4 as the evaluator uses it: [n,9] ingress + clip + 1 - riou, then ONE score-ordered association
     # for all 40 score thresholds of DetectionEvaluator.calc_stats (the reference re-sorts the matrix per threshold)
     from d3d_amd.benchmarks import DetectionEvaluator
@@ -546,6 +645,9 @@ def main():
     ap.add_argument("--skip-large", action="store_true", help="skip the 8 M-point beyond-cache roofline leg")
     ap.add_argument("--large-only", action="store_true", help="run only that leg and print it (rocprofv3 --pmc passes)")
     ap.add_argument("--sparse-only", action="store_true", help="run only config 2's sparse + trim operator (rocprofv3 --pmc passes)")
+    ap.add_argument("--iou-only", action="store_true", help="run only config 3's box2d_iou (one n x n rbox fp64 launch) and print its leg")
+    ap.add_argument("--nms-only", action="store_true", help="run only config 3's box2d_nms and print its leg")
+    ap.add_argument("--iou3d-only", action="store_true", help="run only config 4's iou3d (20 k x 5 k fp32) and print its leg")
     ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port when bench.py launches the ranks itself")
     args = ap.parse_args()
 
@@ -566,6 +668,11 @@ def main():
     from d3d_amd.voxel import VoxelGenerator
 
     torch.cuda.set_device(local_rank)
+    if args.iou_only or args.nms_only or args.iou3d_only:
+        leg = iou_leg(args.boxes, max(1, min(args.steps, 2)), 1) if args.iou_only else \
+            nms_leg(args.boxes, args.steps, args.warmup) if args.nms_only else iou3d_leg(args.steps, args.warmup)
+        print(json.dumps(leg))
+        return
     if args.large_only:
         print(json.dumps({"roofline_large": large_frame_leg()}))
         return

@@ -2,12 +2,16 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected in SEPARATE runs, as
 MI355X_MICROARCH.md prescribes) into per-kernel HBM bytes per launch.
 
-    python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag> [workload] [commit]
+    python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag> [workload] [commit] [calls]
+
+`calls` (operators made of many launches: config3_nms, config4_iou3d): the operator calls the profiled process made; the
+workload then also gets "<op>_op_total" = all its kernels' bytes / calls.
 
 Corrections applied (MI355X_MICROARCH.md, HBM section): the counters are in KiB; on gfx950 FETCH_SIZE reports half of
 the bytes of a wide coalesced read stream, so fetch is doubled (an upper bound for narrow/random accesses, which the
 guide calls uncalibrated); WRITE_SIZE is taken as is.  Writes profiles/<tag>_pmc_summary.csv and merges
-{workload: {kernel: bytes_per_launch}} into profiles/traffic.json (read by bench.py).
+{workload: {kernel: bytes_per_launch}} into profiles/traffic.json (read by bench.py), together with the hashes of the kernel
+sources the figures were collected on ("_sources": bench.py withholds a workload's figures once one of its files has changed).
 """
 import csv
 import json
@@ -65,10 +69,22 @@ def main():
             f.write("%s,%d,%.1f,%.1f,%.0f,%.0f,%.0f\n" % r)
     if workload.endswith("_sparse"):       # every kernel of the operator runs once per step: the operator's traffic per step
         traffic["sparse_op_total"] = int(sum(v for k, v in traffic.items()))
+    calls = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    if calls > 0:                          # an operator of many launches: all bytes of the process / its calls
+        tot = sum(2.0 * 1024.0 * fe.get(k, [0, 0.0])[1] + 1024.0 * wr.get(k, [0, 0.0])[1] for k in set(fe) | set(wr)
+                  if k.startswith("k_") and not k.startswith("k_probe"))
+        traffic[workload.split("_", 1)[1] + "_op_total"] = int(tot / calls)
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     allt = json.load(open(tj)) if os.path.exists(tj) else {}
     allt[workload] = traffic
-    allt["_profile"] = tag if not commit else "%s @ commit %s" % (tag, commit)
+    prof = allt.get("_profile")
+    if not isinstance(prof, dict):
+        prof = {}
+    prof[workload] = tag if not commit else "%s @ commit %s" % (tag, commit)
+    allt["_profile"] = prof
+    sys.path.insert(0, ROOT)
+    import bench
+    allt.setdefault("_sources", {})[workload] = bench.source_hashes()
     json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
     print(open(out).read())
 
