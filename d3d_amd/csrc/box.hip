@@ -702,44 +702,67 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *
 }
 
 // ---------------------------------------------------------------- "3D IoU", two-phase (same scheme as rbox)
-__global__ __launch_bounds__(256) void k_geom3d(const float *__restrict__ boxes, int64_t n, BoxGeom<float> *geom,
-                                                float4 *aabb, float2 *zr, IouList *hdr, unsigned int nseg, bool rotated,
-                                                int stride = 7, bool clip_dims = false)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (hdr && i == 0) list_reset(hdr, nseg);
-    if (i < n) {
-        const Box3DGeom g = load3d(boxes + i * stride, clip_dims);
-        geom[i] = g.g;
-        aabb[i] = cand_aabb(g.g, rotated);
-        zr[i] = make_float2(g.zmin, g.zmax);
-    }
-}
-
 template <bool ROTATED>
 __global__ __launch_bounds__(256) void k_iou3d_clip(const BoxGeom<float> *__restrict__ ga, const float2 *__restrict__ za,
                                                     const BoxGeom<float> *__restrict__ gb, const float2 *__restrict__ zb,
-                                                    int64_t m, float *__restrict__ out, const IouList *hdr,
+                                                    int64_t n, int64_t m, float *__restrict__ out, const IouList *hdr,
                                                     const unsigned long long *__restrict__ list, unsigned long long cap,
                                                     bool complement = false)
 {
-    if (hdr->overflow) return;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, segcap = cap / hdr->nseg;
+    auto pair = [&](int64_t i, int64_t j) -> float {
+        const float iou2d = ROTATED ? iou_rbox(ga[i], gb[j]) : iou_aabb(ga[i], gb[j]);
+        if (iou2d == 0.f) return 0.f;
+        const float2 a = za[i], b = zb[j];
+        const float imax = fminf(a.y, b.y), imin = fmaxf(a.x, b.x);
+        const float umax = fmaxf(a.y, b.y), umin = fminf(a.x, b.x);
+        return iou2d * (fmaxf(imax - imin, 0.f) / fmaxf(umax - umin, (float)1e-6));
+    };
+    if (hdr->overflow) {
+        // the candidate list overflowed (more than the workspace's capacity of overlapping pairs): EVERY pair, one per lane --
+        // slow, correct, and no launch of its own in the calls that never need it
+        const unsigned long long total = (unsigned long long)n * (unsigned long long)m;
+        for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+            const float v = pair((int64_t)(t / (unsigned long long)m), (int64_t)(t % (unsigned long long)m));
+            out[t] = complement ? 1 - v : v;
+        }
+        return;
+    }
     for (unsigned int sg = 0; sg < hdr->nseg; sg++) {
     const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
     const unsigned long long *seg = list + sg * segcap;
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const unsigned long long e = seg[t];
         const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
-        const float iou2d = ROTATED ? iou_rbox(ga[i], gb[j]) : iou_aabb(ga[i], gb[j]);
-        if (iou2d != 0.f) {
-            const float2 a = za[i], b = zb[j];
-            const float imax = fminf(a.y, b.y), imin = fmaxf(a.x, b.x);
-            const float umax = fmaxf(a.y, b.y), umin = fminf(a.x, b.x);
-            const float v = iou2d * (fmaxf(imax - imin, 0.f) / fmaxf(umax - umin, (float)1e-6));
-            if (v != 0.f) out[i * m + j] = complement ? 1 - v : v;
-        }
+        const float v = pair(i, j);
+        if (v != 0.f) out[i * m + j] = complement ? 1 - v : v;
     }
+    }
+}
+
+// Round 6 (config 4 at 0.48 of HBM).  Five launches were three too many for a 100 us operator: both operands'
+// geometry in ONE launch (k_geom3d2, which also resets the list), and the all-pairs fallback for an overflowed list inside
+// k_iou3d_clip instead of a launch of its own that returns at once (6 us each on this stack): 105 -> 92 us per call.
+// Built, measured and NOT kept (profiles/r06_iou3d_fused_ab.txt, bit-identical outputs): ONE launch that fills, tests and clips --
+// every workgroup stores the background over the non-candidates of its own elements and clips its candidates itself, from its
+// wavefronts' LDS batches, so that fill and values have disjoint writers and need no order -- (a) over tiles of its own (32 rows x
+// 1024 columns): 141 us at config 4, 2.9 TB/s; (b) over dealt chunks whose columns repeat (G x 1024 a multiple of m): 143 us.  The
+// clip is the reason, not the store pattern: at config 4's density a wavefront ends up with a handful of candidates, and clipping 5
+// takes as long as clipping 64 -- every workgroup holds its wave slots for that latency with nothing to store.  (Small matrices,
+// where the three launches' fixed costs dominate, did gain: 8 k x 2 k 50 -> 27 us.)
+__global__ __launch_bounds__(256) void k_geom3d2(const float *__restrict__ b1, int64_t n, BoxGeom<float> *g1, float4 *a1, float2 *z1,
+                                                 const float *__restrict__ b2, int64_t m, BoxGeom<float> *g2, float4 *a2, float2 *z2,
+                                                 IouList *hdr, unsigned int nseg, bool rotated, int stride, bool clip_dims)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) list_reset(hdr, nseg);
+    if (i < n) {
+        const Box3DGeom g = load3d(b1 + i * stride, clip_dims);
+        g1[i] = g.g; a1[i] = cand_aabb(g.g, rotated); z1[i] = make_float2(g.zmin, g.zmax);
+    } else if (i - n < m) {
+        const int64_t j = i - n;
+        const Box3DGeom g = load3d(b2 + j * stride, clip_dims);
+        g2[j] = g.g; a2[j] = cand_aabb(g.g, rotated); z2[j] = make_float2(g.zmin, g.zmax);
     }
 }
 
@@ -2653,10 +2676,8 @@ static int iou3d_impl(const float *boxes1, int64_t n, const float *boxes2, int64
         const unsigned long long cap = iou_list_capacity(n, m);
         unsigned long long *list = w.take<unsigned long long>(cap);
         if (!w.ok()) return D3D_ERR_WORKSPACE;
-        D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, boxes1, n, ga, ra, za, hdr,
-                   list_segments(cap), rotated != 0, stride, complement);
-        D3D_LAUNCH("k_geom3d", k_geom3d, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, boxes2, m, gb, cb, zb, (IouList *)nullptr,
-                   1u, rotated != 0, stride, complement);
+        D3D_LAUNCH("k_geom3d2", k_geom3d2, dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, boxes1, n, ga, ra, za, boxes2, m,
+                   gb, cb, zb, hdr, list_segments(cap), rotated != 0, stride, complement);
         float *fill = out;
         if (!al16) {
             D3D_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n * (size_t)m * sizeof(float), st));
@@ -2666,13 +2687,10 @@ static int iou3d_impl(const float *boxes1, int64_t n, const float *boxes2, int64
         D3D_LAUNCH("k_iou_pre", k_iou_pre<float>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), (unsigned)d3d_divup(n, (int64_t)prows)),
                    dim3(kTileCols), 0, st, (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap, complement ? 1.f : 0.f,
                    prows);
-        if (rotated) {
-            D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<true>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, m, out, hdr, list, cap, complement);
-            D3D_IOU3D(true, 1, &hdr->overflow);
-        } else {
-            D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<false>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, m, out, hdr, list, cap, complement);
-            D3D_IOU3D(false, 1, &hdr->overflow);
-        }
+        if (rotated)
+            D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<true>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, n, m, out, hdr, list, cap, complement);
+        else
+            D3D_LAUNCH("k_iou3d_clip", k_iou3d_clip<false>, dim3(256 * 16), dim3(256), 0, st, ga, za, gb, zb, n, m, out, hdr, list, cap, complement);
         return D3D_OK;
     }
     if (rotated) D3D_IOU3D(true, 1, (const unsigned int *)nullptr);

@@ -394,6 +394,29 @@ def test_crop_2dr_2k_boxes_x_1m_points_bit_exact(dtype):
     assert total > 100000
 
 
+@pytest.mark.parametrize("method", ["rbox", "box"])
+def test_iou3d_candidate_list_overflow_takes_every_pair(method):
+    """pairwise 3D IoU: more overlapping pairs than the candidate list holds (2^27) -- 11 700 x 11 700 boxes crowded into a few
+    metres -- and k_iou3d_clip computes every pair itself (round 6: no fallback launch); row / column samples against the oracle"""
+    from d3d_amd.box import iou3d
+    rng = np.random.default_rng(77)
+    k = 11700
+
+    def mk():
+        return np.concatenate([rng.normal(0, 0.7, (k, 2)), rng.uniform(-1.5, -0.5, (k, 1)), rng.uniform(3.5, 5, (k, 1)),
+                               rng.uniform(3.4, 4.2, (k, 1)), rng.uniform(1.4, 1.9, (k, 1)), rng.uniform(-3.14, 3.14, (k, 1))], 1).astype(np.float32)
+    a, b = mk(), mk()
+    got = iou3d(T(a), T(b), method=method)
+    assert got.shape == (k, k)
+    assert int((got > 0).sum()) > (1 << 27)                       # the list did overflow
+    ri, ci = rng.choice(k, 40, replace=False), rng.choice(k, 300, replace=False)
+    exp = oracle.iou3d(a[ri], b[ci], method)
+    sub = got[torch.from_numpy(ri).cuda()][:, torch.from_numpy(ci).cuda()].cpu().numpy()
+    assert np.max(np.abs(sub - exp)) < 1e-3                       # fp32 tolerance of BASELINE.json
+    exp = oracle.iou3d(a[:3], b, method)
+    assert np.max(np.abs(got[:3].cpu().numpy() - exp)) < 1e-3
+
+
 def test_iou_candidate_list_overflow_falls_back(monkeypatch):
     """two-phase rbox IoU: when the candidate list is too small the single-kernel path recomputes the matrix"""
     from d3d_amd import synth
