@@ -12,8 +12,11 @@ from d3d_amd.tracking import DistanceTypes, prepare_boxes
 import numpy as np
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+if len(sys.argv) > 2:      # another build of the library (e.g. libd3d_hip_tune.so left from before a change): same-box comparison
+    import os
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), sys.argv[2])
 lib = _lib.load()
-for n_gt, rep in ((5000, 4), (2000, 4), (20000, 1), (1000, 2), (5001, 4), (40000, 1)):
+for n_gt, rep in ((5000, 4), (20000, 1), (40000, 1)):
     p, g = synth.boxes3d_eval(n_gt, rep, 2)
     pt, gt = torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda()
     res = {}
