@@ -3,19 +3,26 @@
 Boxes are [n,9] float32 rows (label, score, x, y, z, lx, ly, lz, yaw) -- Target3DArray.to_numpy's layout
 (d3d/abstraction.pyx:263-272); the container classes of d3d.abstraction and the dataset-specific class enums are outside
 this library's scope, classes are plain integers here.  The pairwise distance matrix (d3d_match_distance) and the
-score-ordered association (d3d_score_match) run on the GPU -- ONE association serves all score thresholds, see
-d3d_amd.tracking.matcher.score_match -- the per-threshold counts and means over the n + m matched indices are numpy.
+score-ordered association (d3d_score_match) run on the GPU; the per-threshold counts and means over the n + m matched indices
+are numpy.  Two associations:
+* the default, `reference_compat=True`: the reference's own, result for result -- one association PER score threshold
+  (benchmarks.pyx:218-238) with ScoreMatcher.match's literal pairing of the two orders (matcher.pyx:142-162,
+  d3d_amd.tracking.matcher.score_match_reference_compat);
+* `reference_compat=False`: every detection walks its own nearest ground truths -- then ONE association serves all thresholds
+  (a box's choice only depends on the boxes of higher score), 40 times less work.  Equal to the first wherever no detection
+  has two acceptable ground truths.
 """
 import numpy as np
 
-from .tracking.matcher import DistanceTypes, prepare_boxes, score_match
+from .tracking.matcher import DistanceTypes, prepare_boxes, score_match, score_match_reference_compat
 from .utils import Dict
 
 
 class DetectionEvaluator:
     """Benchmark for object detection; targets association is done by score sorting (benchmarks.pyx:84-149)."""
 
-    def __init__(self, classes, min_overlaps, pr_sample_count=40, min_score=0, pr_sample_scale="log10"):
+    def __init__(self, classes, min_overlaps, pr_sample_count=40, min_score=0, pr_sample_scale="log10", reference_compat=True):
+        self.reference_compat = bool(reference_compat)
         classes = list(classes) if isinstance(classes, (list, tuple)) else [classes]
         assert len(classes) > 0
         self._classes = [int(getattr(c, "value", c)) for c in classes]
@@ -52,6 +59,8 @@ class DetectionEvaluator:
         gt_tag, dt_tag = gt[:, 0].astype(np.int64), dt[:, 0].astype(np.int64)
         dt_score = dt[:, 1]
         out = Dict(ngt={}, ndt={}, tp={}, fp={}, fn={}, acc_iou={}, acc_angular={}, acc_dist={}, acc_box={}, acc_var={})
+        if self.reference_compat:
+            return self._calc_stats_per_threshold(gt, dt, out)
         if len(gt) and len(dt):
             cache = prepare_boxes(dt, gt, DistanceTypes.RIoU)                                        # :188-189
             sm, dm = score_match(cache, dt_score, dt_tag, gt_tag, self._max_distance)
@@ -75,9 +84,11 @@ class DetectionEvaluator:
         vals = np.stack([iou, ang, dist, box]).astype(np.float64)                                      # [4, m]
 
         def at_least(scores):
-            """#(scores >= t) for every threshold t: one sort instead of a [len, T] comparison (:224-225: score < thres skipped)"""
-            srt = np.sort(scores)
-            return (len(srt) - np.searchsorted(srt, thr, side="left")).astype(np.int64)
+            """#(scores >= t) for every threshold t: one sort instead of a [len, T] comparison (:224-225: `score < thres` is
+            skipped, so a NaN score is selected at EVERY threshold there -- counted apart, np.sort files NaNs last)"""
+            nan = int(np.isnan(scores).sum())
+            srt = np.sort(scores[~np.isnan(scores)])
+            return (len(srt) - np.searchsorted(srt, thr, side="left") + nan).astype(np.int64)
         for c in classes:
             g, d = gt_tag == c, dt_tag == c
             out.ngt[c] = int(g.sum())
@@ -98,6 +109,50 @@ class DetectionEvaluator:
             out.acc_dist[c], out.acc_box[c] = means[2].tolist(), means[3].tolist()
             # no variances travel in the [n,9] arrays: orientation_var = 0 -> -inf per match (:250-258), NaN without one
             out.acc_var[c] = np.where(tp > 0, -np.inf, np.nan).astype(np.float32).tolist()
+        return out
+
+
+    def _calc_stats_per_threshold(self, gt, dt, out):
+        """benchmarks.pyx:188-283 as written: select the detections of a threshold, associate (the literal pairing), count"""
+        T, classes, thr = self._pr_nsamples, self._classes, self._pr_thresholds
+        gt_tag, dt_tag = gt[:, 0].astype(np.int64), dt[:, 0].astype(np.int64)
+        dt_score = dt[:, 1]
+        gt_idx = np.nonzero(np.isin(gt_tag, classes))[0]                                              # :205-212
+        dt_in = np.isin(dt_tag, classes)
+        for c in classes:
+            out.ngt[c] = int((gt_tag == c).sum())
+            for k in ("ndt", "tp", "fp", "fn"):
+                out[k][c] = [0] * T
+            for k in ("acc_iou", "acc_angular", "acc_dist", "acc_box", "acc_var"):
+                out[k][c] = [float("nan")] * T
+        cache = prepare_boxes(dt, gt, DistanceTypes.RIoU) if len(gt) and len(dt) else None             # :188-189
+        for t in range(T):
+            dt_idx = np.nonzero(dt_in & ~(dt_score < thr[t]))[0]                                        # :219-228 (`score < thres`: skip)
+            for c in classes:
+                out.ndt[c][t] = int((dt_tag[dt_idx] == c).sum())
+            if cache is not None and len(dt_idx) and len(gt_idx):
+                sm, dm = score_match_reference_compat(cache, dt_score, dt_tag, gt_tag, self._max_distance, dt_idx, gt_idx)   # :231-232
+                sm, dm = sm.cpu().numpy().astype(np.int64), dm.cpu().numpy().astype(np.int64)
+            else:
+                sm, dm = np.full((len(dt),), -1, np.int64), np.full((len(gt),), -1, np.int64)
+            g_hit = gt_idx[dm[gt_idx] >= 0]
+            d_of = dm[g_hit]
+            if len(g_hit):
+                iou = (1 - cache[d_of, g_hit]).cpu().numpy().astype(np.float32)                         # :243
+                dist = np.linalg.norm(gt[g_hit, 2:5] - dt[d_of, 2:5], axis=1)                           # :244
+                box = np.linalg.norm(gt[g_hit, 5:8] - dt[d_of, 5:8], axis=1)                            # :245
+                dyaw = gt[g_hit, 8] - dt[d_of, 8]
+                ang = np.abs((dyaw + np.pi) % (2 * np.pi) - np.pi) / np.pi                               # :247-248
+            for c in classes:
+                gc = gt_tag[g_hit] == c
+                tp = int(gc.sum())
+                out.tp[c][t] = tp
+                out.fn[c][t] = out.ngt[c] - tp                                                           # :236-240
+                out.fp[c][t] = int(((dt_tag[dt_idx] == c) & (sm[dt_idx] < 0)).sum())                     # :262-265
+                if tp:                                                                                   # :150-174 (sum / count, fp32)
+                    for name, v in (("acc_iou", iou), ("acc_angular", ang), ("acc_dist", dist), ("acc_box", box)):
+                        out[name][c][t] = float(np.float32(np.sum(v[gc].astype(np.float64)) / tp))
+                    out.acc_var[c][t] = float("-inf")       # no variances travel in the [n,9] arrays: orientation_var = 0 (:250-258)
         return out
 
 

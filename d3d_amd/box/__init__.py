@@ -465,10 +465,10 @@ class PDist2DR(torch.autograd.Function):
         return grad_points, grad_boxes
 
 
-def seg1d_iou(seg1, seg2, reference_compat=False):
+def seg1d_iou(seg1, seg2, reference_compat=True):
     """IoU of 1-D segments, row by row: seg1, seg2 [N,2] = (centre, width) -> [N] -- reference box/__init__.py:152-178 (plain
-    tensor arithmetic there too; its half-width of seg2 is taken from seg1, :164, a slip: seg2's own width is used here.
-    `reference_compat=True` reproduces the reference's values bit for bit -- INTEGRATION.md section 5)"""
+    tensor arithmetic there too).  The default reproduces the reference's values bit for bit, INCLUDING its slip: the half-width
+    of seg2 is taken from seg1 (:164).  `reference_compat=False` uses seg2's own width -- INTEGRATION.md section 5"""
     assert torch.all(seg1[:, 1] > 0)
     assert torch.all(seg2[:, 1] > 0)
     d1, d2 = seg1[:, 1] / 2, (seg1 if reference_compat else seg2)[:, 1] / 2

@@ -5,9 +5,11 @@ shapes (iou.h, nms.h, dist.h, utils.h): dropping this file in as d3d/box/box_imp
 run unchanged on the HIP kernels.  The `_cuda` twins are the same functions (tensors live where they live: HIP tensors are
 `is_cuda` on PyTorch-ROCm, CPU tensors are staged through the GPU and come back on the CPU).
 
-The flag tensors the reference's autograd saves between forward and backward (nx, xflags, ...) are produced for inputs up to
-`flags_max_pairs` pairs -- they cost 9-18 bytes per pair and a Sutherland-Hodgman pass over every pair, while this library's
-backward recomputes the geometry analytically and never reads them; beyond that size they are returned empty.
+The flag tensors the reference's autograd saves between forward and backward (nx, xflags, ...) are produced at ANY size, in the
+declared shapes (iou.cpp:125-141: nx[N,M], xflags[N,M,8], ...; 9-18 bytes per pair -- torch raises its out-of-memory error where
+they do not fit, as the reference's allocation would).  This library's backward recomputes the geometry analytically and never
+reads them: a caller that owns both ends of the call and wants to skip the Sutherland-Hodgman pass over every pair sets
+`box_impl.compute_flags = False` and gets EMPTY tensors in their place -- an explicit opt-out, never a size-dependent default.
 """
 import torch
 
@@ -16,12 +18,11 @@ from . import (IouType, SupressionType, crop_2dr, cuda_available, diou2dr_backwa
                iou2dr_backward as _riou_bwd, iou2dr_flags, iou2dr_forward as _riou_fwd, nms2d as _nms2d,
                pdist2dr_backward as _pdist_bwd, pdist2dr_forward as _pdist_fwd)
 
-flags_max_pairs = 1 << 24
+compute_flags = True
 
 
 def _flags(boxes1, boxes2, which):
-    n, m = boxes1.shape[0], boxes2.shape[0]
-    if n * m > flags_max_pairs:
+    if not compute_flags:
         return {k: torch.empty((0,), dtype=torch.uint8, device=boxes1.device) for k in which}
     return iou2dr_flags(boxes1, boxes2, which)
 

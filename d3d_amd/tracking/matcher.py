@@ -96,50 +96,59 @@ def score_match_reference_compat(distance, src_scores, src_tags, dst_tags, dista
     (`src_subset[src_order[k]]`, :157) walks the destinations in the distance order of the k-th row OF THE SUBSET
     (`dst_order[src_idx, ...]` with src_idx the loop counter, :158), i.e. of another box whenever the subset is not already
     sorted by score, and takes the first one that is free, of its tag and within the threshold (match_by_order :96-115 skips a
-    failing pair and goes on).  `score_match` (the default) walks the source's OWN row -- nearest first -- which is what the
-    docstring of the reference's class describes; this function exists so that the difference can be measured
-    (tests/test_gpu_boxloss.py: a detection within the threshold of two ground truths).  A sequential loop of small tensor
-    operations on the device of `distance` (one source per step): a parity mode, not a fast path.
+    failing pair and goes on).  `score_match` walks the source's OWN row -- nearest first -- which is what the docstring of the
+    reference's class describes.
+    On the device (round 6; a sequential loop of tensor operations before): slot k's acceptable destinations are those of the
+    k-th best source (its tag, ITS distance within the threshold, :103-112), their order is that of row k of the subset -- so the
+    matrix P[k, j] = distance[subset row k, j] where (k-th best source, j) is acceptable, +inf elsewhere, handed to
+    d3d_score_match with the slots in order, reproduces the loop: every slot takes its smallest free entry.
+    The score order is the reference's own call on the same values, np.flip(np.argsort(scores)) on the host (so equal scores
+    come out as they do there); equal DISTANCES go to the destination earlier in `dst_subset` (np.argsort's unstable default
+    leaves that open in the reference); a destination tag missing from `distance_threshold` gets the threshold 0.0, as
+    unordered_map::operator[] hands out (:112).
     Returns (src_match[n], dst_match[m]) int32 tensors, -1 = unmatched."""
     dev = distance.device
     n, m = distance.shape
-    src_subset = torch.as_tensor(list(src_subset), dtype=torch.int64, device=dev)
-    dst_subset = torch.as_tensor(list(dst_subset), dtype=torch.int64, device=dev)
     src_match = torch.full((n,), -1, dtype=torch.int32, device=dev)
     dst_match = torch.full((m,), -1, dtype=torch.int32, device=dev)
-    if src_subset.numel() == 0 or dst_subset.numel() == 0:
+    ssub = np.asarray(list(src_subset), dtype=np.int64).reshape(-1)
+    dsub = np.asarray(list(dst_subset), dtype=np.int64).reshape(-1)
+    if ssub.size == 0 or dsub.size == 0:
         return src_match, dst_match
-    scores = torch.as_tensor(np.asarray(src_scores.detach().cpu() if isinstance(src_scores, torch.Tensor) else src_scores, np.float32)).to(dev)
-    stags = torch.as_tensor(np.asarray(src_tags.detach().cpu() if isinstance(src_tags, torch.Tensor) else src_tags, np.int64)).to(dev)
-    dtags = torch.as_tensor(np.asarray(dst_tags.detach().cpu() if isinstance(dst_tags, torch.Tensor) else dst_tags, np.int64)).to(dev)
-    thr = torch.full((m,), float("nan"), dtype=torch.float32, device=dev)
-    for tag, v in distance_threshold.items():
-        thr[dtags == int(tag)] = float(v)
-    # np.flip(np.argsort(scores)) (:146); ties: the stable descending order of this library's other sorts
-    src_order = torch.argsort(-scores[src_subset], stable=True)
-    sub = distance[src_subset][:, dst_subset]
-    dst_order = torch.argsort(sub, dim=1, stable=True)                       # (:148) row k = subset row k
-    free = torch.ones((m,), dtype=torch.bool, device=dev)
-    for k in range(src_subset.numel()):
-        s = src_subset[src_order[k]]
-        cand = dst_subset[dst_order[k]]                                      # (:158) the LOOP COUNTER's row, not the source's
-        ok = free[cand] & (dtags[cand] == stags[s]) & (distance[s, cand] <= thr[cand])
-        first = torch.argmax(ok.to(torch.int8))
-        hit = ok[first]
-        d = cand[first]
-        src_match[s] = torch.where(hit, d.to(torch.int32), src_match[s])
-        dst_match[d] = torch.where(hit, s.to(torch.int32), dst_match[d])
-        free[d] = free[d] & ~hit
+
+    def host(a):
+        return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    scores = host(src_scores).astype(np.float32).reshape(-1)
+    stags, dtags = host(src_tags).astype(np.int64).reshape(-1), host(dst_tags).astype(np.int64).reshape(-1)
+    src_order = np.flip(np.argsort([float(scores[i]) for i in ssub]))                  # matcher.pyx:145-146, literally
+    best = ssub[src_order]                                                                # slot k's source
+    thr = np.array([float(distance_threshold.get(int(t), 0.0)) for t in dtags[dsub]], np.float32)
+    with torch.cuda.device(dev):
+        ssub_t, dsub_t, best_t = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (ssub, dsub, best))
+        own = distance.index_select(0, best_t).index_select(1, dsub_t)                    # the source's own distances: the test of :112
+        ok = (own <= torch.from_numpy(thr).to(dev)[None, :]) & \
+             (torch.from_numpy(stags[best]).to(dev)[:, None] == torch.from_numpy(dtags[dsub]).to(dev)[None, :])
+        del own
+        pref = distance.index_select(0, ssub_t).index_select(1, dsub_t)                   # row k of the subset: the order walked (:148, :158)
+        pref = torch.where(ok, pref, torch.full((), float("inf"), dtype=pref.dtype, device=dev))
+        del ok
+        k = len(ssub)
+        sm, dm = score_match(pref, -np.arange(k, dtype=np.float32), np.zeros((k,), np.int32), np.zeros((len(dsub),), np.int32),
+                             {0: 3.0e38})
+        hit = sm >= 0
+        src_match[best_t[hit]] = dsub_t[sm[hit].long()].to(torch.int32)
+        taken = dm >= 0
+        dst_match[dsub_t[taken]] = best_t[dm[taken].long()].to(torch.int32)
     return src_match, dst_match
 
 
 class ScoreMatcher:
     """array-level ScoreMatcher (matcher.pyx:138-162): prepare_boxes, match on subsets, query_* -- same call sequence as the
-    reference's evaluator uses (benchmarks.pyx:188-238).  `reference_compat=True` reproduces the reference's pairing of the
-    k-th best source with the k-th subset row's distance order (matcher.pyx:155-158); the default pairs
-    every source with its own nearest destinations."""
+    reference's evaluator uses (benchmarks.pyx:188-238).  The default reproduces the reference's results: its pairing of the
+    k-th best source with the k-th subset row's distance order (matcher.pyx:155-158; INTEGRATION.md 5);
+    `reference_compat=False` pairs every source with its own nearest destinations (what the class docstring describes)."""
 
-    def __init__(self, reference_compat=False):
+    def __init__(self, reference_compat=True):
         self._cache = None
         self._src = self._dst = None
         self._src_assignment, self._dst_assignment = {}, {}
@@ -173,7 +182,7 @@ class ScoreMatcher:
         if self.reference_compat:
             sm, dm = score_match_reference_compat(self._cache, self._src[:, 1].cpu().numpy(), stags, dtags, distance_threshold,
                                                   src_subset, dst_subset)
-        else:
+        else:      # (boxes outside the subsets carry the tag -1 and take no part)
             sm, dm = score_match(self._cache, self._src[:, 1].cpu().numpy(), stags, dtags, distance_threshold)
         sm, dm = sm.cpu().numpy(), dm.cpu().numpy()
         self._src_assignment = {int(i): int(j) for i, j in enumerate(sm) if j >= 0}

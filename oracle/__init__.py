@@ -558,13 +558,16 @@ def score_match(cache, src_arr, dst_arr, src_subset, dst_subset, distance_thresh
     unsorted row), so a source may take a destination that is merely the first acceptable one in ANOTHER box's order.  The two
     agree whenever no source has more than one acceptable destination (the reference's own test_calc_stats) or the subset
     happens to be sorted by score.
-    (ties: stable sorts, i.e. equal scores in index order, equal distances to the lower index -- the spec of this repo)"""
+    literal=True makes the reference's own call for the score order -- np.flip(np.argsort(scores)), so equal scores come out as they
+    do there -- and hands a destination tag missing from `distance_threshold` the 0.0 that unordered_map::operator[] inserts (:112).
+    (otherwise: stable sorts, i.e. equal scores in index order; equal distances go to the lower index in both modes -- the reference's
+    unstable np.argsort leaves that open)"""
     src_assign, dst_assign = {}, {}
     src_subset, dst_subset = list(src_subset), list(dst_subset)
     if not src_subset or not dst_subset:
         return src_assign, dst_assign
     scores = np.array([src_arr[i, 1] for i in src_subset])
-    src_order = np.argsort(-scores, kind="stable")
+    src_order = np.flip(np.argsort([float(x) for x in scores])) if literal else np.argsort(-scores, kind="stable")
     sub = cache[np.ix_(src_subset, dst_subset)]
     dst_order = np.argsort(sub, axis=1, kind="stable")
     for si in range(len(src_subset)):
@@ -577,14 +580,15 @@ def score_match(cache, src_arr, dst_arr, src_subset, dst_subset, distance_thresh
                 continue
             if int(src_arr[s, 0]) != int(dst_arr[d, 0]):
                 continue
-            if cache[s, d] <= distance_threshold[int(dst_arr[d, 0])]:
+            if cache[s, d] <= (distance_threshold.get(int(dst_arr[d, 0]), 0.0) if literal else distance_threshold[int(dst_arr[d, 0])]):
                 src_assign[s] = d
                 dst_assign[d] = s
     return src_assign, dst_assign
 
 
-def calc_stats(gt, dt, classes, max_distance, thresholds):
-    """DetectionEvaluator.calc_stats (benchmarks.pyx:178-283) on [n,9] arrays, one matching PER threshold like the reference"""
+def calc_stats(gt, dt, classes, max_distance, thresholds, literal=False):
+    """DetectionEvaluator.calc_stats (benchmarks.pyx:178-283) on [n,9] arrays, one matching PER threshold like the reference;
+    literal: with ScoreMatcher.match's pairing as written (score_match(literal=True)) -- the reference's own numbers"""
     gt = np.asarray(gt, np.float32).reshape(-1, 9)
     dt = np.asarray(dt, np.float32).reshape(-1, 9)
     T = len(thresholds)
@@ -604,7 +608,7 @@ def calc_stats(gt, dt, classes, max_distance, thresholds):
                 continue
             st.ndt[int(dt[d, 0])][t] += 1
             dt_idx.append(d)
-        sa, da = score_match(cache, dt, gt, dt_idx, gt_idx, max_distance)
+        sa, da = score_match(cache, dt, gt, dt_idx, gt_idx, max_distance, literal=literal)
         for g in gt_idx:
             c = int(gt[g, 0])
             if g not in da:

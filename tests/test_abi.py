@@ -101,7 +101,8 @@ def test_segment_helpers_are_plain_tensor_arithmetic():
     from d3d_amd.box import seg1d_iou, seg1d_pdist
     a = torch.tensor([[0.0, 2.0], [0.0, 2.0], [5.0, 1.0], [0.0, 4.0]])
     b = torch.tensor([[1.0, 2.0], [3.0, 2.0], [5.0, 1.0], [0.0, 2.0]])
-    assert torch.allclose(seg1d_iou(a, b), torch.tensor([1.0 / 3.0, 0.0, 1.0, 0.5]))
+    assert torch.allclose(seg1d_iou(a, b, reference_compat=False), torch.tensor([1.0 / 3.0, 0.0, 1.0, 0.5]))
+    assert torch.allclose(seg1d_iou(a, b), torch.tensor([1.0 / 3.0, 0.0, 1.0, 1.0]))      # the reference's (seg1's width twice, :164)
     d = seg1d_pdist(torch.tensor([[0.5], [3.0]]), torch.tensor([[0.0, 2.0]]))
     assert torch.allclose(d, torch.tensor([[0.5], [-2.0]]))
 

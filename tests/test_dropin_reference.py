@@ -88,7 +88,7 @@ def test_reference_voxel_layer_imports_against_voxel_impl(ref_pkg):
 def test_intentional_deviations_are_pinned(ref_pkg):
     """where this library deliberately differs from the reference's Python layer, pinned against the
     reference's own code: (1) seg1d_iou -- the reference halves seg1's width for BOTH segments (box/__init__.py:163-164);
-    `reference_compat=True` reproduces its values bit for bit, the default uses seg2's own width and agrees wherever the widths
+    the default reproduces its values bit for bit, `reference_compat=False` uses seg2's own width and agrees wherever the widths
     agree; (2) PDist2DR -- the reference hands (boxes, points) to compiled functions declared (points, boxes) and returns the
     backward's (grad_boxes, grad_points) for the inputs (points, boxes); this library's PDist2DR passes (points, boxes) and
     returns the gradients in input order."""
@@ -99,8 +99,8 @@ def test_intentional_deviations_are_pinned(ref_pkg):
     a = torch.rand(200, 2, generator=g) + 0.1
     b = torch.rand(200, 2, generator=g) + 0.1
     ref = mod.seg1d_iou(a, b)
-    assert torch.equal(ours.seg1d_iou(a, b, reference_compat=True), ref)
-    fixed = ours.seg1d_iou(a, b)
+    assert torch.equal(ours.seg1d_iou(a, b), ref) and torch.equal(ours.seg1d_iou(a, b, reference_compat=True), ref)
+    fixed = ours.seg1d_iou(a, b, reference_compat=False)
     assert not torch.allclose(fixed, ref)                      # the widths differ: so do the results
     lo = torch.maximum(a[:, 0] - a[:, 1] / 2, b[:, 0] - b[:, 1] / 2)
     hi = torch.minimum(a[:, 0] + a[:, 1] / 2, b[:, 0] + b[:, 1] / 2)
