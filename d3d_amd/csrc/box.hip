@@ -2879,7 +2879,14 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     float4 *ra = w.take<float4>(n);
     float4 *cb = w.take<float4>(m);
     const int64_t wpr = d3d_divup(m, 64);
-    const int64_t rows_bm = n < (int64_t)65535 * kTileRows ? n : (int64_t)65535 * kTileRows;       // (a row chunk's marks at a time)
+    // a row chunk's marks at a time, one bit per pair, inside what the forward's workspace holds for its candidate list (8 bytes x
+    // iou_list_capacity): matrices beyond 8.6e9 pairs take several chunks (they came back with D3D_ERR_WORKSPACE)
+    int64_t rows_bm = n < (int64_t)65535 * kTileRows ? n : (int64_t)65535 * kTileRows;
+    {
+        const int64_t rows_fit = (int64_t)(iou_list_capacity(n, m) / (unsigned long long)wpr);
+        if (rows_fit < 8) return D3D_ERR_WORKSPACE;
+        if (rows_bm > rows_fit) rows_bm = rows_fit & ~(int64_t)7;
+    }
     unsigned long long *bitmap = w.take<unsigned long long>((size_t)rows_bm * (size_t)wpr);
     unsigned long long *nmarks = w.take<unsigned long long>(kMarkStripes + 1);        // 64 counters + the decision
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;      // (geometry and candidate boxes of both sets + one bit per pair: inside the forward's workspace)
@@ -2896,7 +2903,8 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
         D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, ra, (IouList *)nullptr, 1u, rot);
         int tr = kTileRows;                            // fewer rows per workgroup while the launch is short of 2048 workgroups
         while (tr > 8 && d3d_divup(m, kGradCols) * d3d_divup(n, tr) < 2048) tr >>= 1;
-        const int64_t rows_max = (int64_t)65535 * tr;
+        while (tr > 8 && tr > rows_bm) tr >>= 1;
+        const int64_t rows_max = (int64_t)65535 * tr < rows_bm ? (int64_t)65535 * tr : rows_bm / tr * tr;
         for (int64_t r0 = 0; r0 < n; r0 += rows_max) {
             const int64_t nr = (n - r0) < rows_max ? (n - r0) : rows_max;
 #define D3D_GRAD_TILES(R)                                                                                                                   \

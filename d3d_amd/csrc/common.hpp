@@ -156,6 +156,21 @@ __device__ __forceinline__ unsigned int lookback_ticket(unsigned int *ticket, un
     return *sid;
 }
 
+// Bound of every cross-workgroup poll of this library (look-back predecessors, entries another wavefront publishes): TIME, not a
+// poll count -- wall_clock64() ticks at 100 MHz whatever the shader clock does, and a predecessor that is merely slow (several
+// processes sharing the GPU, as the 8 virtual ranks of the sharded tests do) must not be mistaken for one that never comes.  What
+// never comes: a status word that was never cleared, a workspace shared by two calls in flight.  After kPollSeconds the wavefront
+// traps: on ROCm that raises an HSA exception and the runtime ABORTS THE PROCESS (it does not come back as a HIP error on the
+// stream) -- the alternative is a GPU hung for good, which takes every other process on it down as well.
+constexpr unsigned long long kPollTicks = 8ull * 100000000ull;      // 8 s
+__device__ __forceinline__ void poll_or_trap(unsigned long long &t0)
+{
+    const unsigned long long now = wall_clock64();
+    if (t0 == 0) t0 = now;
+    else if (now - t0 > kPollTicks) __builtin_trap();
+    __builtin_amdgcn_s_sleep(1);
+}
+
 // all 64 lanes of ONE wavefront call it; returns (in every lane) the sum of the totals of tiles 0 .. tile - 1
 __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long *status, unsigned int tile, unsigned long long total)
 {
@@ -167,7 +182,7 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
     if (lane == 0) __hip_atomic_store(&status[tile], kLbAgg | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long excl = 0;
     long long base = (long long)tile - 1;
-    unsigned int polls = 0;
+    unsigned long long waited = 0;
     for (;;) {
         const long long j = base - lane;
         const unsigned long long s = j >= 0 ? __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kLbIncl;
@@ -175,11 +190,8 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
         const int p = incl ? __ffsll((long long)incl) - 1 : kWave - 1;         // the window: lanes 0 .. p
         const unsigned long long window = p == kWave - 1 ? ~0ull : ((2ull << p) - 1ull);
         if (empty & window) {                                                   // a predecessor has not published yet
-            // (every predecessor holds an earlier ticket, i.e. is running: the wait is short.  A status word that was never
-            // cleared, or a workspace shared by two calls, would make it endless: after ~2^24 polls -- a second or more -- the
-            // wavefront traps, which surfaces as a HIP error on the stream instead of a hung GPU)
-            if (++polls > (1u << 24)) __builtin_trap();
-            __builtin_amdgcn_s_sleep(1);
+            // (every predecessor holds an earlier ticket, i.e. is running: the wait is short; bounded by time, see poll_or_trap)
+            poll_or_trap(waited);
             continue;
         }
         excl += wave_sum_u64(lane <= p ? (s & kLbMask) : 0ull);

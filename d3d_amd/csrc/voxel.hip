@@ -381,11 +381,8 @@ struct TabWide {
             }
             if (cur == v1) {                            // same x and y: the slot's z decides
                 u64 b;
-                uint32_t polls = 0;
-                while ((b = __hip_atomic_load(&w2[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
-                    if (++polls > (1u << 24)) __builtin_trap();
-                    __builtin_amdgcn_s_sleep(1);
-                }
+                unsigned long long waited = 0;
+                while ((b = __hip_atomic_load(&w2[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) poll_or_trap(waited);
                 if (b == v2) {
                     arrival = atomicAdd(&fc[h].y, 1u);
                     if (__hip_atomic_load(&fc[h].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&fc[h].x, i);
@@ -3846,12 +3843,12 @@ __global__ __launch_bounds__(kFinThreads) void k_sparse_finish(BoundKey kf, int6
 #pragma unroll
     for (int k = 0; k < kFinItems; k++) {
         if (e[k] != kInf || h[k] == kInf) continue;
-        uint32_t v = got[k], polls = 0;
+        uint32_t v = got[k];
+        unsigned long long waited = 0;
         // the voxel's first point sits in this tile or in one with an earlier ticket, whose workgroup is running and publishes
-        // without waiting for this one (bounded like the look-back's poll: a trap instead of a hung GPU)
+        // without waiting for this one (bounded by time like the look-back's poll: common.hpp, poll_or_trap)
         while ((v >> kFmShift) != 0u) {                     // (still the voxel's entry)
-            if (++polls > (1u << 24)) __builtin_trap();
-            __builtin_amdgcn_s_sleep(1);
+            poll_or_trap(waited);
             v = __hip_atomic_load(&firstmap[h[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         id[k] = v == kVoxelCut ? kNoVoxel : v;

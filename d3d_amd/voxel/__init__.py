@@ -342,13 +342,17 @@ def voxelize_3d_filter(feats, points_mapping, coords, voxel_npoints, coords_boun
 # launches), so the next frame's first kernel used to wait for the host.  One set per thread, handed over to the caller whole
 # (the cache keeps no reference to buffers it has given out) and at most ONE call old: a set the next call does not take is
 # dropped there.  Keyed by CAPACITY: real frames differ in size from call to call, so the set is sized for the
-# frame's point count rounded up to 64 k and serves any frame of that size class (the outputs are views of its first n rows).
+# frame's point count rounded up by at most 12.5 % and serves any frame of that size class (the outputs are views of its first n rows).
 _spare = threading.local()
-_SPARE_ROUND = 1 << 16
+_SPARE_FLOOR = 1 << 12
 
 
 def _spare_cap(n):
-    return -(-max(int(n), 1) // _SPARE_ROUND) * _SPARE_ROUND
+    """n rounded up in steps of 1/8 of its power of two (at least 4 k rows): the views handed out pin at most 12.5 % more than the
+    frame needs -- a fixed 64 k step pinned 30 x the memory of a 2 k-point crop for as long as the caller kept one output"""
+    n = max(int(n), 1)
+    step = max(_SPARE_FLOOR, 1 << max(n.bit_length() - 4, 0))
+    return -(-n // step) * step
 
 
 def _spare_take(key, n, make):
@@ -407,6 +411,8 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
 
         note = _lib.NotifyBuffer.get()
 
+        put = []
+
         def run(fl):
             note.arm()
             rc = lib.d3d_voxelize_3d_sparse_filter(
@@ -419,7 +425,9 @@ def _sparse_filter_chained(points, size_h, vbounds, min_points, max_points, max_
             if rc == _lib.ERR_UNSUPPORTED and vf == MaxVoxelsFilterType.DESCENDING:
                 raise _NotFused()
             _lib.check(rc, "voxelize_3d_sparse + voxelize_3d_filter")
-            _spare_put(key, n, make)      # the next call's buffers, while this one's sizes are on their way
+            if not put:                   # the next call's buffers, while this one's sizes are on their way (once: not per retry)
+                _spare_put(key, n, make)
+                put.append(True)
             host = note.wait(counts)      # the one host read of the pair, while the kept points are still being compacted
             _check_status(int(host[_lib.COUNT_STATUS]), "voxelize_3d_sparse")
             return int(host[_lib.NUM_COUNTS + _lib.COUNT_POINTS]), int(host[_lib.NUM_COUNTS + _lib.COUNT_VOXELS])
