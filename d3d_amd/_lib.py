@@ -91,6 +91,9 @@ SIGNATURES = {
     "d3d_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "d3d_profile_report": (ctypes.c_int, [ctypes.c_char_p, _sz]),
     "d3d_voxelize_dense_last_plan": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64)]),
+    "d3d_voxelize_3d_sparse_filter_call_layout": (_sz, [_i64, ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]),
+    "d3d_voxelize_3d_sparse_filter_call_workspace_bytes": (_sz, [_i64]),
+    "d3d_voxelize_3d_sparse_filter_call": (ctypes.c_int, [ctypes.c_void_p]),
     "d3d_stream_probe": (ctypes.c_int, [ctypes.c_int, _vp, _sz, _vp]),
     "d3d_iou2d_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "d3d_iou2d_forward": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp, _u32]),

@@ -5295,6 +5295,52 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
     return rc;
 }
 
+// d3d_voxelize_3d_sparse_filter through one prepared argument block (include/d3d_hip.h, D3DSparseFilterCall)
+static size_t call_front_bytes(int64_t n)
+{
+    const size_t rows = (size_t)(n > 0 ? n : 1);
+    return d3d_align_up(2 * D3D_NUM_COUNTS * 8) + d3d_align_up(rows * 8) + d3d_align_up(rows * 24) + d3d_align_up(rows * 4);
+}
+
+extern "C" size_t d3d_voxelize_3d_sparse_filter_call_layout(int64_t n, int32_t c, size_t *offsets5)
+{
+    const size_t rows = (size_t)(n > 0 ? n : 1), cc = (size_t)(c > 0 ? c : 1);
+    const size_t sizes[5] = {rows * cc * 4, rows * 8, rows * 8, rows * 4, rows * 24};
+    size_t at = 0;
+    for (int k = 0; k < 5; k++) {
+        if (offsets5) offsets5[k] = at;
+        at += d3d_align_up(sizes[k]);
+    }
+    return at;
+}
+
+extern "C" size_t d3d_voxelize_3d_sparse_filter_call_workspace_bytes(int64_t n)
+{
+    return call_front_bytes(n) + d3d_voxelize_workspace_bytes(n, n);
+}
+
+extern "C" int d3d_voxelize_3d_sparse_filter_call(const D3DSparseFilterCall *a)
+{
+    if (!a || a->n < 0) return D3D_ERR_BAD_ARG;
+    size_t off[5];
+    const size_t need = d3d_voxelize_3d_sparse_filter_call_layout(a->n, a->c, off), front = call_front_bytes(a->n);
+    if (!a->outputs || a->outputs_bytes < need) return D3D_ERR_BAD_ARG;
+    if (!a->workspace || a->workspace_bytes < front + d3d_voxelize_workspace_bytes(a->n, a->n)) return D3D_ERR_WORKSPACE;
+    char *w = static_cast<char *>(a->workspace), *o = static_cast<char *>(a->outputs);
+    const size_t rows = (size_t)(a->n > 0 ? a->n : 1);
+    int64_t *counts2 = reinterpret_cast<int64_t *>(w);
+    int64_t *mapping = reinterpret_cast<int64_t *>(w + d3d_align_up(2 * D3D_NUM_COUNTS * 8));
+    int64_t *coords = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(mapping) + d3d_align_up(rows * 8));
+    int32_t *npoints = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(coords) + d3d_align_up(rows * 24));
+    return d3d_voxelize_3d_sparse_filter(a->points, a->n, a->c, a->voxel_size, a->coords_bound, a->min_points, a->max_points, a->max_voxels,
+                                         a->max_points_filter, a->max_voxels_filter, mapping, coords, npoints, counts2,
+                                         reinterpret_cast<float *>(o + off[0]), reinterpret_cast<int64_t *>(o + off[1]),
+                                         reinterpret_cast<int64_t *>(o + off[2]), reinterpret_cast<int32_t *>(o + off[3]),
+                                         reinterpret_cast<int64_t *>(o + off[4]), counts2 + D3D_NUM_COUNTS, w + front,
+                                         a->workspace_bytes - front, a->stream, a->host_counts, a->flags,
+                                         a->has_coord_offset ? a->coord_offset : nullptr);
+}
+
 #ifdef D3D_TUNE
 extern "C" void d3d_debug_set_tune(int k, int v) { if (k >= 0 && k < 16) g_d3d_tune[k] = v; }
 #endif

@@ -223,6 +223,36 @@ int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int32_t c, con
                                   int64_t *out_coords, int64_t *counts, void *workspace, size_t workspace_bytes,
                                   void *stream, int64_t *host_counts, uint32_t flags, const int64_t *coord_offset);
 
+/* The same call through ONE prepared argument block (round 6): a caller that voxelizes frame after frame fills the block once
+ * per generator (sizes, bounds, filters -- what VoxelGenerator.__init__ derives, voxel/__init__.py:16-77) and per frame sets
+ * `points`, `n` and `outputs`.  Binding the 26-argument form costs a ctypes / cgo caller more host time per call than the three
+ * launches it makes; the intermediates (points_mapping, coords, npoints, both count rows) live at the front of the workspace
+ * instead of in caller tensors, the five outputs are carved from ONE caller allocation:
+ *   d3d_voxelize_3d_sparse_filter_call_layout(n, c, offsets) -> bytes of `outputs`; offsets[0..4] = byte offsets of
+ *     points f32[n,c], points_mask i64[n], points_mapping i64[n], voxel_npoints i32[n], coords i64[n,3] (rows [0, kept) valid);
+ *   d3d_voxelize_3d_sparse_filter_call_workspace_bytes(n) -> workspace bytes (the device count rows: its first
+ *     2 * D3D_NUM_COUNTS int64 -- sparse_counts, then counts);
+ *   d3d_voxelize_3d_sparse_filter_call(call) = d3d_voxelize_3d_sparse_filter on those buffers, same status codes. */
+typedef struct D3DSparseFilterCall {
+    const float *points;
+    int64_t n;
+    int32_t c, min_points, max_points, max_voxels, max_points_filter, max_voxels_filter;
+    float voxel_size[3];
+    uint32_t flags;
+    int64_t coords_bound[6];
+    int64_t coord_offset[3];
+    int32_t has_coord_offset, reserved;
+    void *outputs;
+    size_t outputs_bytes;
+    void *workspace;
+    size_t workspace_bytes;
+    void *stream;
+    int64_t *host_counts;
+} D3DSparseFilterCall;
+size_t d3d_voxelize_3d_sparse_filter_call_layout(int64_t n, int32_t c, size_t *offsets5);
+size_t d3d_voxelize_3d_sparse_filter_call_workspace_bytes(int64_t n);
+int d3d_voxelize_3d_sparse_filter_call(const D3DSparseFilterCall *call);
+
 /* ---- beyond the reference: the point-sharded voxelizer of north_star (d3d has no distributed code) ---- */
 
 /* Voxel feature grid without the dense [V,P,C] copy ("dynamic voxelization"): grid semantics of
