@@ -344,3 +344,35 @@ def test_rccl_world1_child_process():
                MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, child, str(port)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "CHILD_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_rccl_every_visible_gpu():
+    """lights up by itself on a multi-GPU box -- one FRESH child process per visible GPU (started before
+    anything in it touches the GPU), backend `nccl`: config-5 geometry sharded over the ranks against the oracle, replicated and
+    owner-only, the dense contract, the lock-step repeat after a bucket overflow, and the rank count RCCL reports
+    (tests/nccl_worldN_child.py).  One GPU (every box of this pool so far): skipped -- test_rccl_world1_child_process covers the
+    collective signatures there."""
+    import subprocess
+    import sys
+    import socket
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs (this box shows %d)" % world)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_worldN_child.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, child, str(r), str(world), str(port)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=900))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("CHILD_OK %d" % r) in so, (r, p.returncode, so[-2000:], se[-4000:])
