@@ -18,7 +18,7 @@ COUNT_VOXELS, COUNT_POINTS, COUNT_STATUS, COUNT_AUX, NUM_COUNTS = 0, 1, 2, 3, 4
 STATUS_COORD_OVERFLOW, STATUS_TABLE_FULL, STATUS_PACK_OVERFLOW, STATUS_BIN_OVERFLOW = 1, 2, 4, 8
 F32, F64 = 0, 1
 # per-call option bits (include/d3d_hip.h)
-VOXEL_PATH_HASH, VOXEL_PARTITION_3PASS, VOXEL_PLAIN_SLOTS, VOXEL_SPLIT_FILL, VOXEL_EXACT_MEAN, VOXEL_INDEX_V1, VOXEL_WIDE_KEYS = 1, 2, 4, 8, 16, 32, 64
+VOXEL_PATH_HASH, VOXEL_PARTITION_3PASS, VOXEL_PLAIN_SLOTS, VOXEL_SPLIT_FILL, VOXEL_EXACT_MEAN, VOXEL_WIDE_KEYS = 1, 2, 4, 8, 16, 64
 OWNER_MERGE_CHAINS, OWNER_MERGE_TEST_TINY = 1, 2
 NMS_BROAD_SWEEP, NMS_FORCE_DENSE, NMS_SOFT_NO_LDS, NMS_GENERAL, NMS_TEST_WITHHOLD, NMS_FORCE_LEVELS, NMS_ONE_LEVEL = 1, 2, 4, 8, 16, 32, 64
 

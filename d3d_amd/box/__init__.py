@@ -215,39 +215,43 @@ class DIou2DR(torch.autograd.Function):
         return diou2dr_backward(boxes1, boxes2, grad.contiguous())
 
 
+_IOU_FUNCTIONS = {IouType.BOX: Iou2D, IouType.RBOX: Iou2DR, IouType.GRBOX: GIou2DR, IouType.DRBOX: DIou2DR}
+
+
+def _ingress(first, *rest):
+    """numpy arrays in, numpy arrays out: -> (tensors, was_numpy).  A mix of the two is refused with the reference's message
+    (box/__init__.py:191-192, 237-238)."""
+    if not isinstance(first, np.ndarray):
+        return (first,) + rest, False
+    assert all(isinstance(a, np.ndarray) for a in rest), "Input should be both numpy tensor or pytorch tensor!"
+    return tuple(torch.from_numpy(a) for a in (first,) + rest), True
+
+
+def _egress(t, was_numpy):
+    return t.numpy() if was_numpy else t
+
+
 def box2d_iou(boxes1, boxes2, method="box", precise=True):
-    """Differentiable IoU on axis-aligned ('box') or rotated ('rbox') 2D boxes -- reference box/__init__.py:180-224.
+    """Differentiable IoU on axis-aligned ('box') or rotated ('rbox') 2D boxes, and the loss variants 'grbox' / 'drbox' --
+    signature, validation order, messages and dtype handling of reference box/__init__.py:180-224.
 
     :param boxes1: N x 5 (x,y,w,h,r), torch tensor or numpy array
     :param boxes2: M x 5
     :param precise: compute in float64 and cast back to the input dtype
     """
-    convert_numpy = False
-    if isinstance(boxes1, np.ndarray):
-        assert isinstance(boxes2, np.ndarray), "Input should be both numpy tensor or pytorch tensor!"
-        boxes1, boxes2 = torch.from_numpy(boxes1), torch.from_numpy(boxes2)
-        convert_numpy = True
-    otype = boxes1.dtype
+    (boxes1, boxes2), was_numpy = _ingress(boxes1, boxes2)
+    dtype_in = boxes1.dtype
     if precise:
-        boxes1, boxes2 = boxes1.to(torch.float64), boxes2.to(torch.float64)
-    if len(boxes1.shape) != 2 or len(boxes2.shape) != 2:
+        boxes1, boxes2 = boxes1.double(), boxes2.double()
+    if boxes1.dim() != 2 or boxes2.dim() != 2:
         raise ValueError("Input of rbox_2d_iou should be Nx2 tensors!")
     if boxes1.shape[1] != 5 or boxes2.shape[1] != 5:
         raise ValueError("Input boxes should have 5 fields: x, y, w, h, r")
-    iou_type = getattr(IouType, method.upper())     # AttributeError for unknown names, like the reference
-    if iou_type == IouType.BOX:
-        result = Iou2D.apply(boxes1, boxes2)
-    elif iou_type == IouType.RBOX:
-        result = Iou2DR.apply(boxes1, boxes2)
-    elif iou_type == IouType.GRBOX:
-        result = GIou2DR.apply(boxes1, boxes2)
-    elif iou_type == IouType.DRBOX:
-        result = DIou2DR.apply(boxes1, boxes2)
-    else:
+    fn = _IOU_FUNCTIONS.get(getattr(IouType, method.upper()))     # AttributeError for unknown names, like the reference
+    if fn is None:
         raise ValueError("Unrecognized iou type!")
-    if precise:
-        result = result.to(otype)
-    return result.numpy() if convert_numpy else result
+    ious = fn.apply(boxes1, boxes2)
+    return _egress(ious.to(dtype_in) if precise else ious, was_numpy)
 
 
 def argsort_desc(scores):
@@ -313,28 +317,23 @@ nms2d_cuda = nms2d
 
 def box2d_nms(boxes, scores, iou_method="box", supression_method="hard",
               iou_threshold=0, score_threshold=0, supression_param=0, precise=True):
-    """NMS on axis-aligned or rotated 2D boxes; returns the KEEP mask -- reference box/__init__.py:226-276."""
-    convert_numpy = False
-    if isinstance(boxes, np.ndarray):
-        assert isinstance(scores, np.ndarray), "Input should be both numpy tensor or pytorch tensor!"
-        boxes, scores = torch.from_numpy(boxes), torch.from_numpy(scores)
-        convert_numpy = True
-    narrow = scores if scores.dtype == torch.float32 else None      # fp32 -> fp64 is monotone and injective
+    """NMS on axis-aligned or rotated 2D boxes; returns the KEEP mask -- signature, validation order and messages of reference
+    box/__init__.py:226-276 (fp64 promotion of boxes AND scores, class-max of [N,K] scores, the empty case's CPU tensor)."""
+    (boxes, scores), was_numpy = _ingress(boxes, scores)
+    # (the order of fp32 scores survives the promotion -- fp32 -> fp64 is monotone and injective -- so the sort may use the narrow keys)
+    keys = scores if scores.dtype == torch.float32 else None
     if precise:
-        boxes, scores = boxes.to(torch.float64), scores.to(torch.float64)
+        boxes, scores = boxes.double(), scores.double()
     if len(boxes) != len(scores):
         raise ValueError("Numbers of boxes and scores are inconsistent!")
-    if len(scores.shape) == 2:
+    if scores.dim() == 2:
         scores = scores.max(axis=1).values
-        narrow = narrow.max(axis=1).values if narrow is not None else None
+        keys = None if keys is None else keys.max(axis=1).values
     if boxes.numel() == 0:
         return torch.tensor([], dtype=torch.bool)
-    iou_type = getattr(IouType, iou_method.upper())
-    supression_type = getattr(SupressionType, supression_method.upper())
-    suppressed = nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param,
-                       sort_keys=narrow)
-    mask = ~suppressed
-    return mask.numpy() if convert_numpy else mask
+    suppressed = nms2d(boxes, scores, getattr(IouType, iou_method.upper()), getattr(SupressionType, supression_method.upper()),
+                       iou_threshold, score_threshold, supression_param, sort_keys=keys)
+    return _egress(~suppressed, was_numpy)
 
 
 def iou3d(boxes1, boxes2, method="rbox"):

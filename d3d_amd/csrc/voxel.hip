@@ -4271,7 +4271,6 @@ struct DenseOut {
     float *emit_generic = nullptr;      // dense contract, C = 3, 5 .. 8: k_emit_c writes voxels[V,P,C] and the per-voxel outputs
     bool emit_reduce = false;           // reduce contract without rows: k_emit without the stretch (nothing staged by the index)
     int stage = 0;                      // d3d_voxelize_3d_dense_staged: 1 = index launches only, 2 = the output launch only
-    bool index_v1 = false;              // D3D_VOXEL_INDEX_V1: round 4's bucket kernel and record entries (A/B, tests)
 };
 
 // n points -> which index path: bucket count / hash shift of the binned index, or false for the hash table
@@ -4346,7 +4345,7 @@ static int binned_index(const Key &kf, const float *points, int64_t n, int c, co
     const bool big_tiles = ROWS && vec4 && sizeof(typename Key::bin_key_t) == 4 && n >= kBigTileMinPoints;
     // round 5: the lean bucket kernel + packed first-point entries, whenever k_emit is the consumer and nothing needs the
     // cells' first indices per point (the point -> voxel map, the sparse contract's filters)
-    const bool fm_packed = ROWS && (o.emit_voxels || o.emit_reduce) && !o.index_v1 && !precpos && !o.map_later && !o.trimmed &&
+    const bool fm_packed = ROWS && (o.emit_voxels || o.emit_reduce) && !precpos && !o.map_later && !o.trimmed &&
                            !o.pass.on && n <= kFmMaxPoints;
     x.fm_packed = fm_packed;
     // round 6: the dense contract itself (nothing for the sharded operator, no resident rows, no staged call) leaves through
@@ -4760,7 +4759,6 @@ static int voxelize_dense_core(const float *points, int64_t n, int32_t c, const 
         if (stage != 0 && !(emitted && fuse_pmask)) return D3D_ERR_UNSUPPORTED;
         d.x.row_state = row_state;
         d.stage = stage;
-        d.index_v1 = (flags & D3D_VOXEL_INDEX_V1) != 0;
         if (vec4) {
             if (row_state && !emitted) return D3D_ERR_UNSUPPORTED;       // (resident rows: the one-launch output kernels only)
             rc = binned_index<DenseKey, true>(kf, points, n, c, w, nbins, hshift, counts, d, st, !(flags & D3D_VOXEL_PARTITION_3PASS));
@@ -4944,7 +4942,6 @@ extern "C" int d3d_voxelize_3d_reduce(const float *points, int64_t n, int32_t c,
         DenseOut d{P, 0xffffffffu, reduction, true, false, coords, npoints, nullptr, aggregates,
                    BinnedExtras{first, index_offset, keys, keys ? n : (int64_t)-1, nullptr, nullptr}, mapping};
         d.seg_out = seg_base;
-        d.index_v1 = (flags & D3D_VOXEL_INDEX_V1) != 0;
         d.emit_reduce = P <= (uint32_t)kEmitCap && !(flags & D3D_VOXEL_SPLIT_FILL);
         // With `rows` on this path NO row is moved: the caller's buffer receives the voxels' ranked point INDICES (uint32; entry
         // seg_base[v] + k = the voxel's point of rank k >= 1, rank 0 = its first point) and counts[D3D_COUNT_AUX] = 1 says so --
@@ -5205,7 +5202,7 @@ extern "C" int d3d_voxelize_3d_sparse_filter(const float *points, int64_t n, int
                 // round 5: three launches on 32-bit cells inside the coordinate bounds (not DESCENDING, whose sort sits between
                 // the numbering and the compaction; not on request of round 4's kernels; boxes of 2^32 - 1 cells and more, or
                 // reaching INT_MIN -- where the reference files its NaN points -- keep the 63-bit keys)
-                if (!desc && !(flags & (D3D_VOXEL_INDEX_V1 | D3D_VOXEL_PARTITION_3PASS))) {
+                if (!desc && !(flags & D3D_VOXEL_PARTITION_3PASS)) {
                     BoundKey bk;
                     double cells = 1.0;
                     bool ok = true;

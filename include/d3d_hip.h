@@ -87,15 +87,12 @@ const char *d3d_status_string(int status);
  *                          voxel adding in order; ~2x the call).  Default: those voxels are summed in fp64 in arrival order,
  *                          which differs from the reference by ITS rounding error (count * 2^-24 relative) only; voxels within
  *                          max_points, MAX and MIN are bit-exact either way. */
-/*   D3D_VOXEL_INDEX_V1    (binned index) round 4's bucket kernel (first-index table in LDS, one 16-byte record per multi-point
- *                          voxel) instead of round 5's (first-point entries that carry count and segment, dense cells ranked by
- *                          one wavefront).  Identical outputs; kept for A/B runs and as a tested second implementation. */
 /*   D3D_VOXEL_WIDE_KEYS   (sparse contract) ANY int32 voxel coordinate: the hash table compares all 96 bits of (x, y, z) instead of
  *                          the default 3 x 21-bit key (finite coordinates in (-2^20, 2^20) per axis; beyond it the call comes back
  *                          with D3D_VOXEL_STATUS_COORD_OVERFLOW and is to be repeated with this flag).  Every input
  *                          voxelize.cpp:309 accepts then gives the reference's voxels.  A general path, slower than the default. */
 enum { D3D_VOXEL_PATH_HASH = 1, D3D_VOXEL_PARTITION_3PASS = 2, D3D_VOXEL_PLAIN_SLOTS = 4, D3D_VOXEL_SPLIT_FILL = 8,
-       D3D_VOXEL_EXACT_MEAN = 16, D3D_VOXEL_INDEX_V1 = 32, D3D_VOXEL_WIDE_KEYS = 64, D3D_VOXEL_FLAGS_ALL = 127 };
+       D3D_VOXEL_EXACT_MEAN = 16, /* 32: retired */ D3D_VOXEL_WIDE_KEYS = 64, D3D_VOXEL_FLAGS_ALL = 95 };
 
 /* scratch for any of the three voxel entry points on n points / nvox voxels */
 size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels);

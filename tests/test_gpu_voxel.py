@@ -12,16 +12,17 @@ from golden_io import GOLDEN, derived_pmask, load_voxel_cases
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "hash", "split", "3pass", "v1"])
+@pytest.fixture(autouse=True, params=["auto", "hash", "split", "3pass"])
 def index_path(request):
     """every test of this module runs on both index paths of the voxelizer: automatic (binned whenever eligible; dense
     contract: the fused output kernel k_emit) and the hash table (tests that pick a path themselves -- `voxel_path` --
-    override this); "split" = binned index with the two-launch output stage (k_meta_first + k_fill_c4); "v1" = round 4's
-    bucket kernel with one record per voxel (D3D_VOXEL_INDEX_V1) where round 5's packed first-point entries are the default.
-    The dense operator's output buffers are poisoned before every call."""
+    override this); "split" = binned index with the two-launch output stage (k_meta_first + k_fill_c4: what max_points above 256
+    takes by itself); "3pass" = the partition of frames above 8 M points.  (Round 5's fifth run on D3D_VOXEL_INDEX_V1 went with the
+    flag: the bucket kernel's record form stays under test through the contracts that use it -- rows of 3 / 5 .. 8 floats, the
+    reduce contract with a point map, DESCENDING.)  The dense operator's output buffers are poisoned before every call."""
     from d3d_amd import _lib
     set_opts(voxel_flags={"hash": _lib.VOXEL_PATH_HASH, "split": _lib.VOXEL_SPLIT_FILL,
-                          "3pass": _lib.VOXEL_PARTITION_3PASS, "v1": _lib.VOXEL_INDEX_V1}.get(request.param, 0), poison=True)
+                          "3pass": _lib.VOXEL_PARTITION_3PASS}.get(request.param, 0), poison=True)
     yield request.param
 
 
