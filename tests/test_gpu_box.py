@@ -15,7 +15,9 @@ def pytest_generate_tests(metafunc):
     # every NMS test runs four ways: as the operator picks (sets of up to 4096 boxes take the small-set path), on the general
     # path with either broad phase (the uniform grid, the sweep along x), and on the grid with its level kernels forced (they
     # run by themselves only on dense grids: clusters of detections)
-    if "nms" in metafunc.function.__name__ and "nms_broad" in metafunc.fixturenames:
+    # (soft-NMS is one kernel of its own -- k_softnms -- and takes none of the broad phases: once is enough, 4 x 33 s saved)
+    name = metafunc.function.__name__
+    if "nms" in name and "soft" not in name and "nms_broad" in metafunc.fixturenames:
         metafunc.parametrize("nms_broad", ["auto", "grid", "sweep", "levels"], indirect=True)
 
 

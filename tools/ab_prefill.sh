@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python tests/nccl_worldN_child.py 0 1 29577 100000 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu" | tail -8
+mkdir -p gpurun_out/r06
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tail -22 > gpurun_out/r06/suite_durations.txt; cat gpurun_out/r06/suite_durations.txt
