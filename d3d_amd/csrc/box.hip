@@ -2884,8 +2884,10 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     int64_t rows_bm = n < (int64_t)65535 * kTileRows ? n : (int64_t)65535 * kTileRows;
     {
         const int64_t rows_fit = (int64_t)(iou_list_capacity(n, m) / (unsigned long long)wpr);
-        if (rows_fit < 8) return D3D_ERR_WORKSPACE;
-        if (rows_bm > rows_fit) rows_bm = rows_fit & ~(int64_t)7;
+        if (rows_bm > rows_fit) {                      // (never below 2^27 pairs: n x ceil(m / 64) words <= n x m)
+            if (rows_fit < 8) return D3D_ERR_WORKSPACE;
+            rows_bm = rows_fit & ~(int64_t)7;
+        }
     }
     unsigned long long *bitmap = w.take<unsigned long long>((size_t)rows_bm * (size_t)wpr);
     unsigned long long *nmarks = w.take<unsigned long long>(kMarkStripes + 1);        // 64 counters + the decision

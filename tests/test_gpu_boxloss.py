@@ -161,7 +161,7 @@ def test_loss_backward_of_a_matrix_two_kernels(method):
                 assert abs(fd - g2[i, k]) < 5e-5 * max(1.0, abs(fd)), (method, which, i, k, fd, g2[i, k])
 
 
-@pytest.mark.parametrize("shape", [(1, 70000), (70000, 1), (257, 257), (1100, 63), (513, 129)])
+@pytest.mark.parametrize("shape", [(1, 70000), (70000, 1), (257, 257), (1100, 63), (513, 129), (1, 1), (5, 20000)])
 def test_matrix_paths_ragged_shapes(shape):
     """one row, one column, sizes that are no multiple of the 64 x 256 tile or of a wavefront: values against the oracle, gradients
     against the same gradients gathered from blocks small enough for the one-kernel paths (rbox: its tile kernel in other blocks)"""

@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r06
-timeout 1500 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tail -22 > gpurun_out/r06/suite_durations.txt; cat gpurun_out/r06/suite_durations.txt
+mkdir -p gpurun_out/r06_p1
+python bench.py > gpurun_out/r06_p1/bench.json 2> gpurun_out/r06_p1/bench.err; tail -3 gpurun_out/r06_p1/bench.err; head -c 600 gpurun_out/r06_p1/bench.json
+timeout 600 python -m pytest tests/test_gpu_boxloss.py -x -q 2>&1 | tail -2
