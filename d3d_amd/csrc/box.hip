@@ -184,8 +184,14 @@ constexpr int kPreCols = kTileCols * kPreK;
 constexpr int kPreBatch = 1024;      // LDS batch entries per wavefront
 // rows per workgroup: kTileRows, fewer for matrices that would otherwise launch too few workgroups to fill 256 CUs
 // (5 k x 5 k at 64 rows: 395 workgroups = 1.5 wavefronts per SIMD, 81 us for 25 M tests + 200 MB)
+// (round 6, profiles/r06_pre_rows_ab.txt: the rule below is the dense regime's -- the reference's benchmark boxes, 5 k x 5 k, want 8
+// rows = 3125 workgroups: 57 us against 99 at 32 rows -- and costs the sparse regime on SMALL matrices: 8 k x 2 k iou3d 45 us at the
+// 8 rows it picks, 31 at 32; config 4 and everything larger are at their best, or within 3 % of it.  The density is not known here.)
+int g_pre_rows_override = 0;           // tools/pre_rows_ab.py
+extern "C" void d3d_debug_set_pre_rows(int rows) { g_pre_rows_override = rows; }
 static inline int pre_tile_rows(int64_t n, int64_t m)
 {
+    if (g_pre_rows_override) return g_pre_rows_override;
     int rows = kTileRows;
     int64_t wgs = d3d_divup(m, (int64_t)kPreCols) * d3d_divup(n, (int64_t)rows);
     while (rows > 8 && wgs < 2048) { rows >>= 1; wgs = d3d_divup(m, (int64_t)kPreCols) * d3d_divup(n, (int64_t)rows); }

@@ -16,12 +16,13 @@ if len(sys.argv) > 2:      # another build of the library (e.g. libd3d_hip_tune.
     import os
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), sys.argv[2])
 lib = _lib.load()
-for n_gt, rep in ((5000, 4), (20000, 1), (40000, 1)):
+for n_gt, rep in ((5000, 4), (20000, 1), (2000, 4), (10000, 2)):
     p, g = synth.boxes3d_eval(n_gt, rep, 2)
     pt, gt = torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda()
     res = {}
     for r in range(3):
-        for name, on in (("library", 0),):
+        for name, on in (("default", 0), ("rows8", 8), ("rows16", 16), ("rows32", 32), ("rows64", 64)):
+            lib.d3d_debug_set_pre_rows(on)
             for method in ("rbox", "box"):
                 out = iou3d(pt, gt, method=method)
                 res.setdefault((name, method), out.clone())
