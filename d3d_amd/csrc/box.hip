@@ -304,10 +304,25 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
 constexpr int kClipChunk = 1024;
 template <typename T, bool ROTATED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_iou_clip(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb,
-                                                  int64_t m, T *__restrict__ ious, const IouList *hdr,
+                                                  int64_t n, int64_t m, T *__restrict__ ious, const IouList *hdr,
                                                   const unsigned long long *__restrict__ list, unsigned long long cap)
 {
-    if (hdr->overflow) return;
+    if (hdr->overflow) {
+        // the candidate list overflowed (more overlapping pairs than the workspace's list holds): EVERY pair, one per lane, from the
+        // same geometry records -- slow, correct, and (round 6) no launch of its own in the calls that never need it (k_iou2d's
+        // workgroups used to be launched behind every call to look at this flag and leave: 6 us of a 100 us operator)
+        const unsigned long long total = (unsigned long long)n * (unsigned long long)m, stride = (unsigned long long)gridDim.x * blockDim.x;
+        for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+            const int64_t i = (int64_t)(t / (unsigned long long)m), j = (int64_t)(t % (unsigned long long)m);
+            T v;
+            if (ROTATED) {
+                const BoxCore<T> *ca = reinterpret_cast<const BoxCore<T> *>(ga), *cb = reinterpret_cast<const BoxCore<T> *>(gb);
+                v = sat_separated(ca[i], cb[j]) ? (T)0 : iou_rbox_core<T, true>(ca[i], cb[j]);
+            } else v = iou_aabb(ga[i], gb[j]);
+            if (v != 0) ious[t] = v;
+        }
+        return;
+    }
     const unsigned long long segcap = cap / hdr->nseg;
     for (unsigned int sg = 0; sg < hdr->nseg; sg++) {
     const unsigned long long cnt = hdr->count[sg * 16], total = cnt < segcap ? cnt : segcap;
@@ -2572,7 +2587,6 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *io
     if ((opts >> 8) != 0 && (unsigned long long)(opts >> 8) < cap) cap = opts >> 8;     // D3D_IOU_LIST_CAP: use less of it
     D3D_LAUNCH("k_geom", (k_geom2<T, ROTATED>), dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, ga, ra, b2, m, gb, cb,
                hdr, list_segments(cap), ROTATED);
-    const unsigned gy = (unsigned)d3d_divup(n, kTileRows);
     T *fill = ious;
     if (reinterpret_cast<uintptr_t>(ious) & 15) {             // unaligned output: plain memset, candidates only
         D3D_HIP_CHECK(hipMemsetAsync(ious, 0, (size_t)n * (size_t)m * sizeof(T), st));
@@ -2581,10 +2595,7 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *io
     const int prows = pre_tile_rows(n, m);
     D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), (unsigned)d3d_divup(n, (int64_t)prows)),
                dim3(kTileCols), 0, st, (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap, 0.f, prows);
-    D3D_LAUNCH("k_iou_clip", (k_iou_clip<T, ROTATED>), dim3(256 * 16), dim3(256), 0, st, ga, gb, m, ious, hdr, list, cap);
-    // fallback (blocks exit at once unless the list overflowed)
-    D3D_LAUNCH("k_iou2d", (k_iou2d<T, ROTATED, 1>), dim3((unsigned)d3d_divup(m, (int64_t)kTileCols), gy), dim3(kTileCols), 0, st, b1,
-               n, b2, m, ious, &hdr->overflow);
+    D3D_LAUNCH("k_iou_clip", (k_iou_clip<T, ROTATED>), dim3(256 * 16), dim3(256), 0, st, ga, gb, n, m, ious, hdr, list, cap);
     return D3D_OK;
 }
 

@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python tools/tune_ab.py 200 1000000 "unfused:12=0" 2>&1 | grep -v amdgpu.ids | tail -6
-for n in 750000 1300000 2000000 100000; do python tools/tune_ab.py 50 $n "unfused:12=0" 2>&1 | grep -v amdgpu.ids | tail -4; done
-TUNE_DIST=uniform python tools/tune_ab.py 100 1000000 "unfused:12=0" 2>&1 | grep -v amdgpu.ids | tail -4
-timeout 900 python -m pytest tests/test_gpu_voxel.py -x -q 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_box.py tests/test_gpu_boxloss.py tests/test_gpu_fullsize.py -x -q -k "iou or overflow or cfg3 or cfg4" 2>&1 | tail -3
+python bench.py --iou-only 2>&1 | grep -v amdgpu | cut -c1-330
