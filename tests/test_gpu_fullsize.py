@@ -341,3 +341,41 @@ def test_concurrent_calls_with_overflow_retries_on_two_streams():
     [t.join() for t in ts]
     assert not errs, errs[0]
     assert len(results) == 16 and all(results.values()), results
+
+
+@pytest.mark.parametrize("n,P,reduction,max_voxels", [(730000, 32, "mean", None), (1310000, 32, "max", None), (1000000, 8, "mean", None),
+                                                      (1000000, 40, None, None), (1000000, 20, "min", None), (900000, 32, "mean", 100000),
+                                                      (1000000, 256, "mean", None)])
+def test_dense_output_roles_and_fillers(n, P, reduction, max_voxels):
+    """round 6: the frame sizes at which filler workgroups zero part of `voxels` under the index launches (0.72 .. 1.3 M points) and
+    the two-role output launch (k_emit_split) writes the rest -- every output against the oracle, poisoned buffers.  Shapes that
+    move the roles' split point: 8 rows per voxel (one line: no zero line at all), 40 (five lines), 20 (no whole number of
+    lines), 256 (count bytes saturate: voxels with a record), `max_voxels` cutting far inside the filled range; a crowded cell of
+    400 points (a record voxel) and a uniform half (one point per voxel) in every frame."""
+    from d3d_amd import _lib, synth
+    from d3d_amd.voxel import VoxelGenerator
+    a, b = synth.lidar_like(n // 2, 21), synth.uniform_cloud(n - n // 2, 22)
+    cloud = np.concatenate([a, b]).astype(np.float32)
+    np.random.default_rng(23).shuffle(cloud)
+    cloud[1000:1400, :3] = np.array([35.21, 3.33, -0.96], np.float32) + np.random.default_rng(24).random((400, 3)).astype(np.float32) * 0.05
+    mv = n if max_voxels is None else max_voxels
+    kw = dict(dense=True, reduction=reduction, max_points=P, max_voxels=mv)
+    got = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, **kw)(T(cloud), poison=True)
+    import ctypes
+    out = (ctypes.c_int64 * 4)()
+    _lib.load().d3d_voxelize_dense_last_plan(out)
+    assert out[0] == 1                                          # the two-role launch took it
+    if P <= 40 and max_voxels is None:
+        assert out[1] > 0 and out[2] > 0                        # ... and fillers zeroed part of the tensor
+    exp = oracle.VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, **kw)(cloud)
+    assert np.array_equal(got.coords.cpu().numpy(), exp.coords)
+    assert np.array_equal(got.voxel_npoints.cpu().numpy(), exp.voxel_npoints)
+    assert np.array_equal(got.voxels.cpu().numpy(), exp.voxels)
+    pm = np.arange(P)[None, :] < np.minimum(exp.voxel_npoints, P)[:, None]
+    assert np.array_equal(got.voxel_pmask.cpu().numpy(), pm)
+    if reduction:
+        fit = exp.voxel_npoints <= P
+        ga, ea = got.aggregates.cpu().numpy(), exp.aggregates
+        assert np.array_equal(ga[fit], ea[fit])
+        np.testing.assert_allclose(ga[~fit], ea[~fit], rtol=1e-4, atol=1e-6)
+    assert exp.voxel_npoints.max() >= 400
