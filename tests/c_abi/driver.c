@@ -90,6 +90,73 @@ static int voxel_case(void)
     return bad;
 }
 
+/* the reference's default mode (sparse + filter) through the prepared argument block: voxel/__init__.py:93-103 in one call */
+int64_t oracle_voxelize_3d_sparse(const float *points, int64_t n, int32_t c, const float *voxel_size, int64_t *points_mapping,
+                                  int64_t *coords, int32_t *npoints);
+int32_t oracle_voxelize_3d_filter(const float *feats, int64_t n, int32_t c, const int64_t *points_mapping, const int64_t *coords,
+                                  const int32_t *voxel_npoints, int64_t nvox, const int64_t *coords_bound, int32_t min_points,
+                                  int32_t max_points, int32_t max_voxels, int32_t max_points_filter, int32_t max_voxels_filter,
+                                  float *out_feats, int64_t *out_mask, int64_t *out_mapping, int32_t *out_npoints, int64_t *out_coords,
+                                  int64_t *counts);
+
+static int sparse_call_case(void)
+{
+    const int64_t n = 60000;
+    const int32_t c = 4;
+    float *pts = (float *)malloc(sizeof(float) * n * c);
+    for (int64_t i = 0; i < n; i++) {
+        pts[i * 4 + 0] = frand() * 74.f - 2.f;            /* some points outside the coordinate bounds */
+        pts[i * 4 + 1] = frand() * 84.f - 42.f;
+        pts[i * 4 + 2] = frand() * 4.4f - 3.2f;
+        pts[i * 4 + 3] = frand();
+    }
+    D3DSparseFilterCall call;
+    memset(&call, 0, sizeof(call));
+    call.n = n; call.c = c;
+    call.min_points = 2; call.max_points = 3; call.max_voxels = 20000;
+    call.max_points_filter = 1 /* TRIM */; call.max_voxels_filter = 1 /* TRIM */;
+    call.voxel_size[0] = 0.4f; call.voxel_size[1] = 0.4f; call.voxel_size[2] = 0.4f;
+    const int64_t cb[6] = {0, 176, -100, 100, -7, 2};       /* voxel coordinates [lo, hi) per axis */
+    memcpy(call.coords_bound, cb, sizeof(cb));
+    call.coord_offset[0] = 0; call.coord_offset[1] = -100; call.coord_offset[2] = -7; call.has_coord_offset = 1;
+    size_t off[5];
+    call.outputs_bytes = d3d_voxelize_3d_sparse_filter_call_layout(n, c, off);
+    call.workspace_bytes = d3d_voxelize_3d_sparse_filter_call_workspace_bytes(n);
+    float *d_pts;
+    CHECK_HIP(hipMalloc((void **)&d_pts, sizeof(float) * n * c));
+    CHECK_HIP(hipMalloc(&call.outputs, call.outputs_bytes));
+    CHECK_HIP(hipMalloc(&call.workspace, call.workspace_bytes));
+    CHECK_HIP(hipMemcpy(d_pts, pts, sizeof(float) * n * c, hipMemcpyHostToDevice));
+    call.points = d_pts;
+    CHECK_D3D(d3d_voxelize_3d_sparse_filter_call(&call));
+    int64_t counts[2 * D3D_NUM_COUNTS];                     /* the device count rows: the front of the workspace */
+    CHECK_HIP(hipMemcpy(counts, call.workspace, sizeof(counts), hipMemcpyDeviceToHost));
+    const int64_t k = counts[D3D_NUM_COUNTS + D3D_COUNT_POINTS], v = counts[D3D_NUM_COUNTS + D3D_COUNT_VOXELS];
+    /* oracle: the two reference calls, then coords - offset */
+    int64_t *m0 = (int64_t *)malloc(8 * n), *c0 = (int64_t *)malloc(24 * n), *e_mask = (int64_t *)malloc(8 * n), *e_map = (int64_t *)malloc(8 * n),
+            *e_crd = (int64_t *)malloc(24 * n), ecnt[D3D_NUM_COUNTS];
+    int32_t *n0 = (int32_t *)malloc(4 * n), *e_np = (int32_t *)malloc(4 * n);
+    float *e_feats = (float *)malloc(sizeof(float) * n * c);
+    const int64_t nv0 = oracle_voxelize_3d_sparse(pts, n, c, call.voxel_size, m0, c0, n0);
+    const int32_t rc = oracle_voxelize_3d_filter(pts, n, c, m0, c0, n0, nv0, cb, call.min_points, call.max_points, call.max_voxels, 1, 1,
+                                                 e_feats, e_mask, e_map, e_np, e_crd, ecnt);
+    const int64_t ek = ecnt[0], ev = ecnt[1];                /* (the oracle's own order: kept points, kept voxels) */
+    for (int64_t q = 0; q < ev; q++) { e_crd[q * 3 + 1] += 100; e_crd[q * 3 + 2] += 7; }
+    int ok = rc == 0 && k == ek && v == ev && counts[D3D_COUNT_STATUS] == 0 && k > 1000 && v > 500;
+    if (ok) {
+        char *host = (char *)malloc(call.outputs_bytes);
+        CHECK_HIP(hipMemcpy(host, call.outputs, call.outputs_bytes, hipMemcpyDeviceToHost));
+        ok = !memcmp(host + off[0], e_feats, sizeof(float) * k * c) && !memcmp(host + off[1], e_mask, 8 * k) &&
+             !memcmp(host + off[2], e_map, 8 * k) && !memcmp(host + off[3], e_np, 4 * v) && !memcmp(host + off[4], e_crd, 24 * v);
+        free(host);
+    }
+    printf("voxelize_3d_sparse_filter_call: %lld points in %lld voxels kept (oracle %lld / %lld) %s\n", (long long)k, (long long)v,
+           (long long)ek, (long long)ev, ok ? "bit-exact" : "MISMATCH");
+    hipFree(d_pts); hipFree(call.outputs); hipFree(call.workspace);
+    free(pts); free(m0); free(c0); free(e_mask); free(e_map); free(e_crd); free(n0); free(e_np); free(e_feats);
+    return !ok;
+}
+
 static const double *sort_scores;
 static int by_score_desc(const void *pa, const void *pb)           /* ties in ascending index: the order of d3d_argsort_desc */
 {
@@ -151,7 +218,7 @@ static int box_case(void)
 int main(void)
 {
     printf("libd3d_hip ABI version %d\n", d3d_abi_version());
-    const int bad = voxel_case() + box_case();
+    const int bad = voxel_case() + sparse_call_case() + box_case();
     printf(bad ? "FAILED\n" : "all comparisons passed\n");
     return bad ? 1 : 0;
 }
