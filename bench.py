@@ -125,6 +125,20 @@ def load_traffic(kernel, workload):
         return None, "unavailable"
 
 
+def event_overhead_us(iters=50):
+    """HIP-event duration of an EMPTY launch (d3d_stream_probe mode 6) behind a busy stream: what the event pair of d3d_profile_*
+    adds to every kernel's figure on top of the dispatch's own begin-to-end time that rocprofv3 reports"""
+    from d3d_amd import _lib
+    lib = _lib.load()
+    buf = torch.empty((1 << 20,), dtype=torch.uint8, device="cuda")
+
+    def run():
+        _lib.check(lib.d3d_stream_probe(0, _lib.ptr(buf), buf.numel(), _lib.stream_ptr()), "stream_probe")      # (a launch before it,
+        _lib.check(lib.d3d_stream_probe(6, _lib.ptr(buf), buf.numel(), _lib.stream_ptr()), "stream_probe")      #  as inside an operator)
+    prof = kernel_profile(run, iters)
+    return round(prof["k_probe_empty"]["avg_us"], 2)
+
+
 def stream_probe(nbytes, iters=5):
     """achievable stream bandwidth of THIS box (GB/s): nontemporal stores, copy, read sweep over an nbytes buffer --
     the access patterns of the HBM-bound kernels with the work stripped off (d3d_stream_probe, api.hip)"""
@@ -755,6 +769,13 @@ def main():
                            "filler workgroups on the CUs k_tile_sort / k_first_count leave idle store those (plus the rows' lines of the same "
                            "voxels, which this launch overwrites: filler_bytes > zero_padding_stored).  The operator-level figure on ALL 8(d) "
                            "bytes is roofline_operator")
+        ov = event_overhead_us()
+        out["roofline"].update(
+            event_overhead_us=ov, avg_us_net=round(dom[1]["avg_us"] - ov, 2),
+            frac_net=round(b_alg / ((dom[1]["avg_us"] - ov) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            event_note="avg_us = HIP events recorded around the launch on its stream; an EMPTY launch measures event_overhead_us that way "
+                       "(the first event waits for the previous launch, the dispatch follows).  rocprofv3's per-dispatch durations (profiles/"
+                       "*_kernel_stats_config2_only.csv) are begin-to-end of the dispatch and compare with avg_us_net; `frac` stays on avg_us")
         if name in ("k_emit", "k_emit_split"):
             # what the launch reads from the index's scratch on top of the 8(d) bytes, and the stream probes at THIS launch's
             # footprint (the outputs' 345 MB, partly absorbed by the 256 MB Infinity Cache exactly as the kernel's are): the

@@ -149,6 +149,11 @@ extern "C" int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream)
         if (g < 1) g = 1;
         D3D_LAUNCH("k_probe_store_dealt", k_probe_store_dealt, dim3((unsigned)(g < 2147483647u ? g : 2147483647u)), dim3(256), 0, st,
                    (bvec4 *)buf, nvec);
+    } else if (mode == 6) {
+        // an EMPTY launch: what the event pair around a launch measures by itself -- the record of the first event waits for the
+        // launch before it, the kernel is dispatched behind it: d3d_profile_* durations exceed rocprofv3's dispatch timestamps by
+        // about this much (bench.py: roofline.event_overhead_us)
+        D3D_LAUNCH("k_probe_empty", k_probe_store, dim3(1), dim3(64), 0, st, (bvec4 *)buf, (size_t)0);
     } else if (mode == 4) {
         const size_t nvec = bytes / 16, stretches = (nvec + 2047) / 2048;
         const unsigned b = (unsigned)(stretches / 4 < 65536 ? (stretches + 3) / 4 : 65536);

@@ -442,7 +442,8 @@ int d3d_voxelize_dense_last_plan(int64_t *out4);
 
 /* stream-bandwidth probe on the caller's buffer (bench.py: "fraction of the measured copy bandwidth of the same box",
  * SURVEY 8d).  mode 0 = nontemporal 16-byte stores over `bytes`, 1 = copy first half -> second half, 2 = read sweep,
- * 3 = hipMemsetAsync (the runtime's fill, for reference). */
+ * 3 = hipMemsetAsync (the runtime's fill, for reference), 4 / 5 = nontemporal stores in the launch shapes of the output kernel /
+ * of the IoU fill, 6 = an empty launch (the overhead of the event pair that d3d_profile_* puts around every launch). */
 int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream);
 
 /* -------------------------------------------------------------------- d3d/box */
