@@ -102,8 +102,11 @@ size_t d3d_voxelize_workspace_bytes(int64_t n_points, int64_t n_voxels);
  *   outputs sized for cap = min(n, max_voxels) voxels:
  *   voxels[cap,max_points,c] f32, coords[cap,3] i64, pmask[cap,max_points] u8 (0/1),
  *   npoints[cap] i32, aggregates[cap,c] f32 (NULL iff reduction == NONE).
- *   Rows >= counts[D3D_COUNT_VOXELS] are left untouched (the caller slices them off,
- *   cf. voxelize.cpp:167-179).  counts: device int64[D3D_NUM_COUNTS]. */
+ *   Rows >= counts[D3D_COUNT_VOXELS] are not part of the result (the caller slices them off, cf. voxelize.cpp:167-179):
+ *   coords / pmask / npoints / aggregates leave them untouched; `voxels` may hold ZEROS there, anywhere inside its cap rows
+ *   (round 6: part of the tensor's zero padding is stored under the index launches, over a range fixed before the voxel
+ *   count exists -- the buffers MUST have the cap rows stated above, not just the rows a caller expects to come back).
+ *   counts: device int64[D3D_NUM_COUNTS]. */
 int d3d_voxelize_3d_dense(const float *points, int64_t n, int32_t c,
                           const int32_t *shape, const float *bound,
                           int32_t max_points, int32_t max_voxels, int32_t reduction,
