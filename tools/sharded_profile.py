@@ -51,6 +51,17 @@ for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
     tot += per_rank
     print("  %-36s %8.1f us per rank and step" % (k, per_rank))
 print("  total kernel time per rank and step: %.1f us (collectives not included)" % tot)
+# (round 6) every figure above is an EVENT PAIR around a launch, which also measures the wait for the launch before it and the
+# dispatch: an empty launch comes out at ~6 us that way (bench.event_overhead_us, measured here the same way), and a step is 15 or
+# more launches per rank -- while the single-GPU bases below are wall-clock.  Net of that, the kernels of a rank:
+import bench as _bench
+launches = sum(v["calls"] for v in prof.values()) / 3 / W
+ov = _bench.event_overhead_us()
+tot_events = tot
+GAP_US = 2.0          # what stays between two dependent launches on one stream (an ASSUMPTION like the link constants below)
+tot = tot - launches * ov + launches * GAP_US
+print("  %.1f launches per rank and step x %.2f us of event-pair overhead each, %.1f us of gap put back per launch -> %.1f us per rank "
+      "(the modelled step below uses this; the event sum was %.1f)" % (launches, ov, GAP_US, tot, tot_events))
 
 # ---- modelled step time on 8 MI355X over xGMI: what one GPU cannot measure, priced with public figures --
 # every rank has 7 links of ~153 GB/s to its 7 peers, a direct all-to-all keeps all of them busy; a collective costs a launch +
