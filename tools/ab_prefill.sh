@@ -1,3 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06
-( python tools/sharded_profile.py 8 1000000 config5 owner noreplicate; python tools/sharded_profile.py 8 1000000 config5 owner noreplicate 32; python tools/sharded_profile.py 8 1000000 config5 owner ) 2>&1 | grep -v amdgpu > gpurun_out/r06/sharded_w8.txt; cat gpurun_out/r06/sharded_w8.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py --skip-cpu --skip-extra --skip-large 2>&1 | grep -v amdgpu | python -c "
+import json,sys
+b=json.loads(sys.stdin.read()); r=b['roofline']
+print(b['value'], b['ms_per_step'], r['frac'], r['frac_net'], r['traffic'], r['traffic_source'][:90])"
