@@ -94,10 +94,18 @@ TRAFFIC_SOURCES = {      # the kernel sources a workload's traffic figures depen
 }
 
 
-def source_hashes():
+def source_hash(text):
+    """hash of a kernel source's CODE: comments and white space do not count (a reworded comment must not retire the PMC passes)"""
     import hashlib
+    import re
+    code = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    code = re.sub(r"//[^\n]*", " ", code)
+    return hashlib.sha1(" ".join(code.split()).encode()).hexdigest()[:16]
+
+
+def source_hashes():
     d = os.path.join(ROOT, "d3d_amd", "csrc")
-    return {f: hashlib.sha1(open(os.path.join(d, f), "rb").read()).hexdigest()[:16]
+    return {f: source_hash(open(os.path.join(d, f), errors="replace").read())
             for fs in TRAFFIC_SOURCES.values() for f in fs if os.path.exists(os.path.join(d, f))}
 
 

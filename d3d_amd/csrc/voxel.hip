@@ -2888,9 +2888,8 @@ __global__ __launch_bounds__(256) void k_emit(Key kf, int64_t npad, const uint32
 // Here two workgroups take each 256 points.  The EVEN one is the chain: rows gathered into LDS, reductions, the voxels' leading
 // 128-byte lines (rows kept rounded up to 8) and the aggregates -- no cell arithmetic, its first dependent load is already a row or
 // a ranked index.  The ODD one needs nothing but the entries to know which lines of the stretch hold no row -- three of four at
-// config 2 -- and streams them; its one gather (the voxels' first points, for the cells) is in flight under those stores and
-// feeds coords / voxel_npoints / voxel_pmask.  Voxels of 255 points and more (count and cell in a record) belong to the even role
-// entirely.  Both roles derive a voxel's split point `lim` from its entry alone; every byte has exactly one writer.
+// config 2 -- and streams them, after it has written coords / voxel_npoints / voxel_pmask (one gather: the voxels' first points,
+// for the cells).  Voxels of 255 points and more (count and cell in a record) belong to the even role entirely.  Both roles derive a voxel's split point `lim` from its entry alone; every byte has exactly one writer.
 // voxels[0 .. prefilled) x P rows were zero-filled under the index launches (ZeroFill): the odd role skips those.
 template <class Key, bool AGG4, int WG = 256>
 __global__ __launch_bounds__(WG) void k_emit_split(Key kf, int64_t npad, const uint32_t *__restrict__ firstmap,
