@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python tools/lib_ab.py libd3d_hip.so libd3d_hip_tune.so 1000000 8000000 2000000 750000 2>&1 | grep -v amdgpu
+mkdir -p gpurun_out/r06
+python tools/iou3d_ab.py 50 2>&1 | grep -v amdgpu.ids | grep rbox > gpurun_out/r06/iou3d_roles.txt; cat gpurun_out/r06/iou3d_roles.txt
