@@ -142,16 +142,6 @@ def _workspace_bytes(lib, n):
     return b
 
 
-_ws_bytes_cache2 = {}
-
-
-def _workspace_bytes2(lib, n):
-    b = _ws_bytes_cache2.get(n)
-    if b is None:
-        b = _ws_bytes_cache2[n] = lib.d3d_voxelize_workspace_bytes(n, n)
-    return b
-
-
 class DenseOutputBuffer:
     """A resident output for the dense contract (d3d_voxelize_3d_dense_resident; beyond the reference, which allocates per
     frame): voxels[capacity, max_points, C] kept on the device from frame to frame together with, per voxel id, the number of
