@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r06
-python tools/iou3d_ab.py 50 2>&1 | grep -v amdgpu.ids | grep rbox > gpurun_out/r06/iou3d_roles.txt; cat gpurun_out/r06/iou3d_roles.txt
+for red in mean max ""; do echo "== reduction '$red'"; TUNE_RED=$red python tools/tune_ab.py 200 1000000 2>&1 | grep -v amdgpu.ids | tail -2; done

@@ -32,7 +32,7 @@ make_cloud = synth.uniform_cloud if os.environ.get("TUNE_DIST", "lidar") == "uni
 cloud = torch.from_numpy(make_cloud(n, seed, bounds)).cuda()
 mode = os.environ.get("TUNE_MODE", "dense")
 if mode == "dense":
-    gen = VoxelGenerator(bounds, shape, dense=True, reduction="mean", max_points=32, max_voxels=n)
+    gen = VoxelGenerator(bounds, shape, dense=True, reduction=os.environ.get("TUNE_RED", "mean") or None, max_points=32, max_voxels=n)
 else:
     gen = VoxelGenerator(bounds, shape, max_points=32, max_voxels=n, max_points_filter="trim")
 apply({})
