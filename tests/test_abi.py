@@ -137,3 +137,30 @@ def test_bucket_kernel_keeps_its_first_point_store_separate(tmp_path):
     v1 = {k: v for k, v in scoped.items() if k not in v2}
     assert len(v1) == 6 and set(v1.values()) == {8}, scoped
     assert len(v2) == 2 and set(v2.values()) == {9}, scoped            # (DenseKey: the index for k_emit; BoundKey: for k_sparse_finish)
+
+
+def test_sparse_call_block_layout_matches_the_header(tmp_path):
+    """D3DSparseFilterCall: the ctypes Structure the Python layer fills (d3d_amd.voxel._SparseFilterCall) against the struct of
+    include/d3d_hip.h as gcc lays it out -- size and the offset of every field; and the layout query: aligned, ordered pieces that
+    hold their rows (a pure function: no GPU)"""
+    import subprocess
+    from d3d_amd import _lib
+    from d3d_amd.voxel import _SparseFilterCall
+    fields = [f[0] for f in _SparseFilterCall._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "d3d_hip.h"\nint main(void) {\n'
+                   '    printf("%zu\\n", sizeof(D3DSparseFilterCall));\n' +
+                   "".join('    printf("%%zu\\n", offsetof(D3DSparseFilterCall, %s));\n' % f for f in fields) + "    return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", str(src), "-I" + os.path.join(ROOT, "include"), "-o", str(exe)])
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(_SparseFilterCall)
+    assert got[1:] == [getattr(_SparseFilterCall, f).offset for f in fields]
+    lib = _lib.load()
+    off = (ctypes.c_size_t * 5)()
+    for n, c in ((1, 3), (1000, 4), (1000003, 7)):
+        total = lib.d3d_voxelize_3d_sparse_filter_call_layout(n, c, off)
+        sizes = [n * c * 4, n * 8, n * 8, n * 4, n * 24]
+        assert list(off)[0] == 0 and all(o % 256 == 0 for o in off)
+        assert all(off[k] + sizes[k] <= (off[k + 1] if k < 4 else total) for k in range(5))
+        assert lib.d3d_voxelize_3d_sparse_filter_call_workspace_bytes(n) > lib.d3d_voxelize_workspace_bytes(n, n)
