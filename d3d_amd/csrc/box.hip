@@ -640,8 +640,11 @@ __global__ __launch_bounds__(256) void k_iou_grad_sparse(const BoxGeom<T> *__res
     }
 }
 
+// (round 6: three wavefronts per SIMD for the fp64 rotated form -- 226 -> 168 VGPRs with 80 bytes of scratch, possible since its LDS
+// went from 57 to 44 KB: 603 -> 539 us on the reference's 5 k x 5 k benchmark boxes, profiles/r06_pre_rows_ab.txt; the other three
+// forms need fewer registers than that anyway)
 template <typename T, bool ROTATED>
-__global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *__restrict__ ga, const float4 *__restrict__ ra,
+__global__ __launch_bounds__(kGradCols) __attribute__((amdgpu_waves_per_eu(3))) void k_iou_grad_tiles(const BoxGeom<T> *__restrict__ ga, const float4 *__restrict__ ra,
                                                               const T *__restrict__ b1, int64_t n, const BoxGeom<T> *__restrict__ gb,
                                                               const float4 *__restrict__ cb, const T *__restrict__ b2, int64_t m,
                                                               const T *__restrict__ grad, T *g1, T *g2, int tile_rows,
@@ -649,10 +652,14 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *
                                                               const unsigned long long *nmarks)
 {
     if (!grad_marks_dense(nmarks, n, m)) return;       // few marks: k_iou_grad_sparse's case
-    __shared__ BoxGeom<T> rgeo[kTileRows];
+    // (round 6) rotated boxes: centre + half-extent vectors (48 of BoxGeom's 88 bytes in fp64) are all the gradient routine reads of a
+    // MARKED pair -- 57 -> 44 KB of LDS, three workgroups per CU instead of two
+    struct Core6 { T cx, cy, ux, uy, vx, vy; };
+    typedef typename std::conditional<ROTATED, Core6, BoxGeom<T>>::type Geo;
+    __shared__ Geo rgeo[kTileRows];
     __shared__ float4 rbox[kTileRows];
     __shared__ T rwh[kTileRows][2];
-    __shared__ BoxGeom<T> cgeo[kGradCols];
+    __shared__ Geo cgeo[kGradCols];
     __shared__ T cwh[kGradCols][2];
     __shared__ T racc[kGradCols / 64][kTileRows][5];
     __shared__ T cacc[kGradCols][5];
@@ -664,12 +671,16 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *
     const bool active = j < m;
     if (threadIdx.x < nrows) {
         const int64_t i = i0 + threadIdx.x;
-        rgeo[threadIdx.x] = ga[i]; rbox[threadIdx.x] = ra[i];
+        if constexpr (ROTATED) { const BoxGeom<T> g = ga[i]; rgeo[threadIdx.x] = Core6{g.cx, g.cy, g.ux, g.uy, g.vx, g.vy}; }
+        else rgeo[threadIdx.x] = ga[i];
+        rbox[threadIdx.x] = ra[i];
         rwh[threadIdx.x][0] = b1[i * 5 + 2]; rwh[threadIdx.x][1] = b1[i * 5 + 3];
     }
     float4 cbox = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
     if (active) {
-        cgeo[threadIdx.x] = gb[j]; cbox = cb[j];
+        if constexpr (ROTATED) { const BoxGeom<T> g = gb[j]; cgeo[threadIdx.x] = Core6{g.cx, g.cy, g.ux, g.uy, g.vx, g.vy}; }
+        else cgeo[threadIdx.x] = gb[j];
+        cbox = cb[j];
         cwh[threadIdx.x][0] = b2[j * 5 + 2]; cwh[threadIdx.x][1] = b2[j * 5 + 3];
     }
 #pragma unroll
@@ -685,8 +696,13 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_tiles(const BoxGeom<T> *
             const unsigned int e = q[lane], r = e >> 8, c = e & 63u;
             const T g = qw[lane];
             T da[5], db[5];
-            if (ROTATED) iou_rbox_grad<T>(rgeo[r], cgeo[wave * 64 + c], rwh[r][0], rwh[r][1], cwh[wave * 64 + c][0], cwh[wave * 64 + c][1], da, db);
-            else iou_aabb_grad<T>(rgeo[r], cgeo[wave * 64 + c], b1 + (i0 + r) * 5, b2 + (jb + wave * 64 + c) * 5, da, db);
+            if constexpr (ROTATED) {
+                const Core6 ca = rgeo[r], cc = cgeo[wave * 64 + c];
+                BoxGeom<T> a, b;                            // (the fields the routine reads without its bounding-box test)
+                a.cx = ca.cx; a.cy = ca.cy; a.ux = ca.ux; a.uy = ca.uy; a.vx = ca.vx; a.vy = ca.vy; a.area = 4 * (ca.ux * ca.vy - ca.uy * ca.vx);
+                b.cx = cc.cx; b.cy = cc.cy; b.ux = cc.ux; b.uy = cc.uy; b.vx = cc.vx; b.vy = cc.vy; b.area = 4 * (cc.ux * cc.vy - cc.uy * cc.vx);
+                iou_rbox_grad<T, false>(a, b, rwh[r][0], rwh[r][1], cwh[wave * 64 + c][0], cwh[wave * 64 + c][1], da, db);
+            } else iou_aabb_grad<T>(rgeo[r], cgeo[wave * 64 + c], b1 + (i0 + r) * 5, b2 + (jb + wave * 64 + c) * 5, da, db);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 if (da[k] != 0) atomicAdd(&racc[wave][r][k], g * da[k]);

@@ -386,13 +386,15 @@ __device__ __forceinline__ void piece_grad(T sx, T sy, T ex, T ey, T ox, T oy, T
     g[3] += (vc * ih) * (vx * dy - vy * dx);      // v = (vc / h) * v_hat
 }
 
-template <typename T>
+// CHECK_AABB = false: the caller has tested the bounding boxes already (a marked pair); only centre, half-extent vectors and area are read
+template <typename T, bool CHECK_AABB = true>
 __device__ __forceinline__ T iou_rbox_grad(const BoxGeom<T> &a, const BoxGeom<T> &b, T w1, T h1, T w2, T h2, T (&ga)[5],
                                            T (&gb)[5])
 {
 #pragma unroll
     for (int k = 0; k < 5; k++) { ga[k] = 0; gb[k] = 0; }
-    if (!(a.area > 0) || !(b.area > 0) || aabb_disjoint(a, b)) return 0;
+    if (!(a.area > 0) || !(b.area > 0)) return 0;
+    if (CHECK_AABB && aabb_disjoint(a, b)) return 0;
     const T ax[4] = {-a.ux - a.vx, a.ux - a.vx, a.ux + a.vx, -a.ux + a.vx};
     const T ay[4] = {-a.uy - a.vy, a.uy - a.vy, a.uy + a.vy, -a.uy + a.vy};
     const T ox = b.cx - a.cx, oy = b.cy - a.cy;
