@@ -2932,10 +2932,9 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
         else D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, false>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
         return D3D_OK;
     }
-    D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(m, 256)), dim3(256), 0, st, b2, m, gb, cb, (IouList *)nullptr, 1u,
-               rot);
+    D3D_LAUNCH("k_geom", (k_geom2<T, false>), dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, ga, ra, b2, m, gb, cb,
+               (IouList *)nullptr, 1u, rot);           // (both operands in one launch, as the forward does)
     {                                                  // marks, then tiles with LDS accumulators (k_iou_grad_mark, k_iou_grad_tiles)
-        D3D_LAUNCH("k_geom", k_geom<T>, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, b1, n, ga, ra, (IouList *)nullptr, 1u, rot);
         int tr = kTileRows;                            // fewer rows per workgroup while the launch is short of 2048 workgroups
         while (tr > 8 && d3d_divup(m, kGradCols) * d3d_divup(n, tr) < 2048) tr >>= 1;
         while (tr > 8 && tr > rows_bm) tr >>= 1;
