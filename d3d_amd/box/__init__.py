@@ -59,7 +59,8 @@ def _to_device(*ts):
 _MAX_ROWS = 65535 * 64      # rows of boxes1 per d3d_iou2d_forward launch (grid.y limit x 64-row tiles)
 
 
-def _iou_forward(boxes1, boxes2, iou_type, flags=None):
+def _iou_forward(boxes1, boxes2, iou_type, flags=None, matrix32=False):
+    """matrix32 (fp64 boxes, BOX / RBOX): the arithmetic in fp64, `ious` stored as fp32 (D3D_F64_M32)"""
     lib = _lib.load()
     odev = boxes1.device
     if boxes1.dtype != boxes2.dtype:
@@ -68,10 +69,14 @@ def _iou_forward(boxes1, boxes2, iou_type, flags=None):
     n, m = b1.shape[0], b2.shape[0]
     fl = options.current().iou_flags if flags is None else int(flags)
     with torch.cuda.device(dev):
-        ious = torch.empty((n, m), dtype=b1.dtype, device=dev)
+        ious = torch.empty((n, m), dtype=torch.float32 if matrix32 else b1.dtype, device=dev)
         if options.current().poison:
             ious.fill_(float("nan"))
         code = _dtype_code(b1)
+        if matrix32:
+            if code != _lib.F64 or int(iou_type) not in (IouType.BOX, IouType.RBOX):
+                raise ValueError("matrix32 takes fp64 boxes and the box / rbox methods")
+            code = _lib.F64_M32
         # one launch covers 65535 tiles of 64 rows; taller inputs go in row blocks into the same output
         for r0 in range(0, max(n, 1), _MAX_ROWS):
             r1 = min(n, r0 + _MAX_ROWS)
@@ -122,12 +127,17 @@ def iou2dr_flags(boxes1, boxes2, which=("nx", "xflags")):
     return {k: (v.to(odev) if odev != dev else v) for k, v in out.items()}
 
 
-def _iou_backward(boxes1, boxes2, grad, iou_type):
+def _iou_backward(boxes1, boxes2, grad, iou_type, matrix32=False):
+    """matrix32 (fp64 boxes, BOX / RBOX): `grad` is read as fp32 and widened in the kernels (D3D_F64_M32)"""
     lib = _lib.load()
     odev = boxes1.device
-    (b1, b2, g), dev = _to_device(boxes1.detach(), boxes2.detach(), grad.to(boxes1.dtype))
+    (b1, b2, g), dev = _to_device(boxes1.detach(), boxes2.detach(), grad.to(torch.float32 if matrix32 else boxes1.dtype))
     n, m = b1.shape[0], b2.shape[0]
     code = _dtype_code(b1)
+    if matrix32:
+        if code != _lib.F64 or int(iou_type) not in (IouType.BOX, IouType.RBOX):
+            raise ValueError("matrix32 takes fp64 boxes and the box / rbox methods")
+        code = _lib.F64_M32
     with torch.cuda.device(dev):
         g1 = torch.empty((n, 5), dtype=b1.dtype, device=dev)
         g2 = torch.empty((m, 5), dtype=b1.dtype, device=dev)
@@ -215,6 +225,25 @@ class DIou2DR(torch.autograd.Function):
         return diou2dr_backward(boxes1, boxes2, grad.contiguous())
 
 
+class _IouPrecise32(torch.autograd.Function):
+    """box2d_iou(precise=True) on fp32 boxes, 'box' / 'rbox': the reference widens the boxes, computes in fp64 and casts the matrix
+    back (box/__init__.py:204-205, 224).  Same numbers -- fp64 arithmetic on the widened boxes, every value rounded once -- with
+    the rounding where the matrix is stored, and in backward the widening where the incoming gradient is read: no fp64 copy of an
+    [N,M] matrix in either direction."""
+
+    @staticmethod
+    def forward(ctx, boxes1, boxes2, iou_type):
+        ctx.save_for_backward(boxes1, boxes2)
+        ctx.iou_type = iou_type
+        return _iou_forward(boxes1.double(), boxes2.double(), iou_type, matrix32=True)
+
+    @staticmethod
+    def backward(ctx, grad):
+        boxes1, boxes2 = ctx.saved_tensors
+        g1, g2 = _iou_backward(boxes1.double(), boxes2.double(), grad.contiguous(), ctx.iou_type, matrix32=True)
+        return g1.to(boxes1.dtype), g2.to(boxes2.dtype), None
+
+
 _IOU_FUNCTIONS = {IouType.BOX: Iou2D, IouType.RBOX: Iou2DR, IouType.GRBOX: GIou2DR, IouType.DRBOX: DIou2DR}
 
 
@@ -241,15 +270,22 @@ def box2d_iou(boxes1, boxes2, method="box", precise=True):
     """
     (boxes1, boxes2), was_numpy = _ingress(boxes1, boxes2)
     dtype_in = boxes1.dtype
-    if precise:
+    # fp32 boxes, precise: the fp64 arithmetic with an fp32 matrix (_IouPrecise32) instead of .double() ... .to(float32) around it
+    fused32 = precise and dtype_in == torch.float32 and boxes2.dtype == torch.float32
+    if precise and not fused32:
         boxes1, boxes2 = boxes1.double(), boxes2.double()
     if boxes1.dim() != 2 or boxes2.dim() != 2:
         raise ValueError("Input of rbox_2d_iou should be Nx2 tensors!")
     if boxes1.shape[1] != 5 or boxes2.shape[1] != 5:
         raise ValueError("Input boxes should have 5 fields: x, y, w, h, r")
-    fn = _IOU_FUNCTIONS.get(getattr(IouType, method.upper()))     # AttributeError for unknown names, like the reference
+    iou_type = getattr(IouType, method.upper())                   # AttributeError for unknown names, like the reference
+    fn = _IOU_FUNCTIONS.get(iou_type)
     if fn is None:
         raise ValueError("Unrecognized iou type!")
+    if fused32 and iou_type in (IouType.BOX, IouType.RBOX):
+        return _egress(_IouPrecise32.apply(boxes1, boxes2, iou_type), was_numpy)
+    if fused32:
+        boxes1, boxes2 = boxes1.double(), boxes2.double()
     ious = fn.apply(boxes1, boxes2)
     return _egress(ious.to(dtype_in) if precise else ious, was_numpy)
 
@@ -273,11 +309,12 @@ NMS_STATUS_DENSE_PATH, NMS_STATUS_SCAN_GAVE_UP = 1, 2
 
 
 def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param, sort_keys=None,
-          flags=None, return_status=False):
+          flags=None, return_status=False, keep_mask=False):
     """nms2d / nms2d_cuda (nms.h:6-18; nms.cpp:98-119): returns the SUPPRESSED mask (bool[N]).
     Follows the CPU control flow of the reference (nms.cpp:23-59).  sort_keys: optional fp32 tensor that orders like
     `scores` (the scores before their promotion to fp64): half the radix passes of the argsort, same order.
-    return_status: (mask, status) with d3d_nms2d_status's bits -- which route decided the mask (waits for the stream)."""
+    return_status: (mask, status) with d3d_nms2d_status's bits -- which route decided the mask (waits for the stream).
+    keep_mask: the kernels write the KEEP mask instead (D3D_NMS_KEEP_MASK): box2d_nms's `~suppressed` without the extra pass."""
     lib = _lib.load()
     iou_type, supression_type = int(iou_type), int(supression_type)
     if iou_type not in (IouType.BOX, IouType.RBOX):
@@ -302,7 +339,8 @@ def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_thresho
         rc = lib.d3d_nms2d_notify(_lib.ptr(b), _lib.ptr(s), _lib.ptr(order) if order is not None else None, n, iou_type, supression_type,
                                   code, float(iou_threshold), float(score_threshold), float(supression_param), _lib.ptr(sup),
                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr(),
-                                  options.current().nms_flags if flags is None else int(flags), _lib.HostWord.get().ptr)
+                                  (options.current().nms_flags if flags is None else int(flags)) | (_lib.NMS_KEEP_MASK if keep_mask else 0),
+                                  _lib.HostWord.get().ptr)
         _lib.check(rc, "nms2d")
         status = ctypes.c_uint32(0)
         if return_status and n > 0:
@@ -331,9 +369,10 @@ def box2d_nms(boxes, scores, iou_method="box", supression_method="hard",
         keys = None if keys is None else keys.max(axis=1).values
     if boxes.numel() == 0:
         return torch.tensor([], dtype=torch.bool)
-    suppressed = nms2d(boxes, scores, getattr(IouType, iou_method.upper()), getattr(SupressionType, supression_method.upper()),
-                       iou_threshold, score_threshold, supression_param, sort_keys=keys)
-    return _egress(~suppressed, was_numpy)
+    # (the reference returns ~suppressed, box/__init__.py:272: here the kernels that decide the mask write it inverted)
+    keep = nms2d(boxes, scores, getattr(IouType, iou_method.upper()), getattr(SupressionType, supression_method.upper()),
+                 iou_threshold, score_threshold, supression_param, sort_keys=keys, keep_mask=True)
+    return _egress(keep, was_numpy)
 
 
 def iou3d(boxes1, boxes2, method="rbox"):

@@ -302,9 +302,11 @@ __global__ __launch_bounds__(kTileCols) void k_iou_pre(const float4 *__restrict_
 // candidates for boxes of random orientation), and the clip costs ~10x a separating-axis test -- so a workgroup takes 1024
 // candidates at a time, tests them (4 per lane), compacts the survivors through LDS and clips THOSE on dense wavefronts.
 constexpr int kClipChunk = 1024;
-template <typename T, bool ROTATED>
+// S: the matrix' element type -- T, or float under double arithmetic (D3D_F64_M32: the value is rounded where it is stored, what
+// box2d_iou(precise=True) does to fp32 boxes with a cast of the whole fp64 matrix, reference box/__init__.py:204-205, 224)
+template <typename T, bool ROTATED, typename S = T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_iou_clip(const BoxGeom<T> *__restrict__ ga, const BoxGeom<T> *__restrict__ gb,
-                                                  int64_t n, int64_t m, T *__restrict__ ious, const IouList *hdr,
+                                                  int64_t n, int64_t m, S *__restrict__ ious, const IouList *hdr,
                                                   const unsigned long long *__restrict__ list, unsigned long long cap)
 {
     if (hdr->overflow) {
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                 const BoxCore<T> *ca = reinterpret_cast<const BoxCore<T> *>(ga), *cb = reinterpret_cast<const BoxCore<T> *>(gb);
                 v = sat_separated(ca[i], cb[j]) ? (T)0 : iou_rbox_core<T, true>(ca[i], cb[j]);
             } else v = iou_aabb(ga[i], gb[j]);
-            if (v != 0) ious[t] = v;
+            if (v != 0) ious[t] = (S)v;
         }
         return;
     }
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                 const unsigned long long e = surv[q];
                 const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
                 const T v = iou_rbox_core<T, true>(ca[i], cb[j]);
-                if (v != 0) ious[i * m + j] = v;
+                if (v != 0) ious[i * m + j] = (S)v;
             }
             __syncthreads();
         }
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             const unsigned long long e = seg[t];
             const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
             const T v = iou_aabb(ga[i], gb[j]);
-            if (v != 0) ious[i * m + j] = v;
+            if (v != 0) ious[i * m + j] = (S)v;
         }
     }
     }
@@ -369,9 +371,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 // fallback = five launches of ~5 us each.  Same candidate test (conservative fp32 AABBs, empty for degenerate boxes) and the
 // same per-pair function as the two-phase path: identical values.
 constexpr unsigned long long kIouSmallPairs = 1ull << 16;
-template <typename T, bool ROTATED>
+template <typename T, bool ROTATED, typename S = T>
 __global__ __launch_bounds__(256) void k_iou_small(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
-                                                   T *__restrict__ ious)
+                                                   S *__restrict__ ious)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * m) return;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) void k_iou_small(const T *__restrict__ b1, int
     const BoxGeom<T> a = Box2D<T>::load(b1 + i * 5), b = Box2D<T>::load(b2 + j * 5);
     T v = 0;
     if (aabb_gap(cand_aabb(a, ROTATED), cand_aabb(b, ROTATED)) > 0.f) v = ROTATED ? iou_rbox(a, b) : iou_aabb(a, b);
-    ious[idx] = v;
+    ious[idx] = (S)v;
 }
 
 // ---------------------------------------------------------------- pairwise "3D IoU" (BEV x z), fp32
@@ -480,10 +482,10 @@ constexpr int kMarkStripes = 64;             // counters of the marks
 // conservative bounding boxes and (rotated) no separating axis, one 64-bit word per row and wavefront of columns.  Inside the
 // gradient kernel -- 246 VGPRs, two wavefronts per SIMD -- the same loop ran the 400 M pairs of 20 k x 20 k boxes at config 3's
 // density in 0.62 ms; the list form of rounds 2-4 took 0.22 ms for that call.  Lane = 2 columns (two words per wavefront and row).
-template <typename T, bool ROTATED>
+template <typename T, bool ROTATED, typename G = T /* element of grad[n,m]: T, or float under double arithmetic (D3D_F64_M32) */>
 __global__ __launch_bounds__(kGradCols) void k_iou_grad_mark(const BoxGeom<T> *__restrict__ ga, const float4 *__restrict__ ra, int64_t n,
                                                              const BoxGeom<T> *__restrict__ gb, const float4 *__restrict__ cb, int64_t m,
-                                                             const T *__restrict__ grad, unsigned long long *__restrict__ bitmap,
+                                                             const G *__restrict__ grad, unsigned long long *__restrict__ bitmap,
                                                              int64_t wpr, int tile_rows, unsigned long long *nmarks)
 {
     __shared__ BoxCore<T> rcore[kTileRows];
@@ -523,8 +525,8 @@ __global__ __launch_bounds__(kGradCols) void k_iou_grad_mark(const BoxGeom<T> *_
             T g0[4], g1[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {                          // the weights of the candidate pairs only, all loads in flight together
-                g0[u] = x0[u] ? grad[(i0 + r0 + u) * m + j0] : (T)0;
-                g1[u] = x1[u] ? grad[(i0 + r0 + u) * m + j1] : (T)0;
+                g0[u] = x0[u] ? (T)grad[(i0 + r0 + u) * m + j0] : (T)0;
+                g1[u] = x1[u] ? (T)grad[(i0 + r0 + u) * m + j1] : (T)0;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -568,13 +570,13 @@ __device__ __forceinline__ bool grad_marks_dense(const unsigned long long *nmark
 
 // a frame's worth of pairs (<= kIouSmallPairs): ONE launch, one pair per lane, geometry rebuilt per pair, atomics per pair --
 // the marks / decision / tiles / compaction above are five launches of ~5 us each, more than the arithmetic at this size
-template <typename T, bool ROTATED>
+template <typename T, bool ROTATED, typename G = T>
 __global__ __launch_bounds__(256) void k_iou_grad_small(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
-                                                        const T *__restrict__ grad, T *g1, T *g2)
+                                                        const G *__restrict__ grad, T *g1, T *g2)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * m) return;
-    const T g = grad[idx];
+    const T g = (T)grad[idx];
     if (g == 0) return;
     const int64_t i = idx / m, j = idx - i * m;
     const BoxGeom<T> a = Box2D<T>::load(b1 + i * 5), b = Box2D<T>::load(b2 + j * 5);
@@ -590,10 +592,10 @@ __global__ __launch_bounds__(256) void k_iou_grad_small(const T *__restrict__ b1
 }
 
 constexpr int kSparseWords = 2048;                 // bitmap words per workgroup (131 k pairs)
-template <typename T, bool ROTATED>
+template <typename T, bool ROTATED, typename G = T>
 __global__ __launch_bounds__(256) void k_iou_grad_sparse(const BoxGeom<T> *__restrict__ ga, const T *__restrict__ b1, int64_t n,
                                                          const BoxGeom<T> *__restrict__ gb, const T *__restrict__ b2, int64_t m,
-                                                         const T *__restrict__ grad, T *g1, T *g2,
+                                                         const G *__restrict__ grad, T *g1, T *g2,
                                                          const unsigned long long *__restrict__ bitmap, int64_t wpr,
                                                          const unsigned long long *nmarks)
 {
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(256) void k_iou_grad_sparse(const BoxGeom<T> *__res
         for (unsigned int skip = t - pre[lo]; skip; skip--) x &= x - 1;       // drop the marks before this one
         const int bit = __ffsll((long long)x) - 1;
         const int64_t w = base + lo, i = w / wpr, j = (w - i * wpr) * 64 + bit;
-        const T g = grad[i * m + j];
+        const T g = (T)grad[i * m + j];
         T da[5], db[5];
         if (ROTATED) iou_rbox_grad<T>(ga[i], gb[j], b1[i * 5 + 2], b1[i * 5 + 3], b2[j * 5 + 2], b2[j * 5 + 3], da, db);
         else iou_aabb_grad<T>(ga[i], gb[j], b1 + i * 5, b2 + j * 5, da, db);
@@ -643,11 +645,11 @@ __global__ __launch_bounds__(256) void k_iou_grad_sparse(const BoxGeom<T> *__res
 // (round 6: three wavefronts per SIMD for the fp64 rotated form -- 226 -> 168 VGPRs with 80 bytes of scratch, possible since its LDS
 // went from 57 to 44 KB: 603 -> 539 us on the reference's 5 k x 5 k benchmark boxes, profiles/r06_pre_rows_ab.txt; the other three
 // forms need fewer registers than that anyway)
-template <typename T, bool ROTATED>
+template <typename T, bool ROTATED, typename G = T>
 __global__ __launch_bounds__(kGradCols) __attribute__((amdgpu_waves_per_eu(3))) void k_iou_grad_tiles(const BoxGeom<T> *__restrict__ ga, const float4 *__restrict__ ra,
                                                               const T *__restrict__ b1, int64_t n, const BoxGeom<T> *__restrict__ gb,
                                                               const float4 *__restrict__ cb, const T *__restrict__ b2, int64_t m,
-                                                              const T *__restrict__ grad, T *g1, T *g2, int tile_rows,
+                                                              const G *__restrict__ grad, T *g1, T *g2, int tile_rows,
                                                               const unsigned long long *__restrict__ bitmap, int64_t wpr,
                                                               const unsigned long long *nmarks)
 {
@@ -715,12 +717,12 @@ __global__ __launch_bounds__(kGradCols) __attribute__((amdgpu_waves_per_eu(3))) 
     // the tile's words of the bitmap (k_iou_grad_mark), one row per lane; a marked pair's weight is fetched when it is queued
     const unsigned long long words = lane < nrows ? bitmap[(i0 + lane) * wpr + (j >> 6)] : 0ull;
     if (__any(words != 0)) {
-        const T *gp = grad + i0 * m + (active ? j : m - 1);
+        const G *gp = grad + i0 * m + (active ? j : m - 1);
         for (int r = 0; r < nrows; r++) {
             const unsigned long long word = __shfl(words, r, kWave);
             if (word == 0) continue;
             const bool mark = (word >> lane) & 1ull;
-            const T g = mark ? gp[(int64_t)r * m] : (T)0;
+            const T g = mark ? (T)gp[(int64_t)r * m] : (T)0;
             const unsigned int cnt = (unsigned int)__popcll(word);
             if (wn + cnt > 64u) process();
             if (mark) {
@@ -1806,7 +1808,8 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const BoxCore<T> *__restrict_
 constexpr int kSpinPasses = 4096;
 __global__ __launch_bounds__(256) void k_nms_resolve(int64_t n, uint8_t *state, const uint32_t *__restrict__ inc_cnt,
                                                      const uint32_t *__restrict__ inc_off, uint32_t *inc, NmsFlags *flags,
-                                                     const int64_t *__restrict__ order, uint8_t *__restrict__ suppressed)
+                                                     const int64_t *__restrict__ order, uint8_t *__restrict__ suppressed,
+                                                     uint8_t inv /* 1: the KEEP mask (D3D_NMS_KEEP_MASK) */)
 {
     if (__hip_atomic_load(&flags->need_sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the list overflowed
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1814,7 +1817,7 @@ __global__ __launch_bounds__(256) void k_nms_resolve(int64_t n, uint8_t *state, 
     // every box reports its own result as soon as it is final (if the dense path takes over after all, its sweep rewrites
     // every entry): no separate pass over the states
     const int64_t mine_out = q < n ? order[q] : 0;
-    if (q < n && done) suppressed[mine_out] = state[q] == kSuppressed;
+    if (q < n && done) suppressed[mine_out] = (uint8_t)(state[q] == kSuppressed) ^ inv;
     // hitters [pos, cnt) are still undecided as far as this lane knows: every pass looks at all of them (ONE kept hitter
     // decides, wherever it sits in the list) and moves the ones found suppressed in front of pos
     // Before the list, the box's lowest-ranked hitter alone (one load per pass): in a cluster of detections it is the cluster's
@@ -1857,7 +1860,7 @@ __global__ __launch_bounds__(256) void k_nms_resolve(int64_t n, uint8_t *state, 
             }
             if (hit || (!wait && cnt == 0)) {
                 __hip_atomic_store(&state[q], (uint8_t)(hit ? kSuppressed : kKept), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                suppressed[mine_out] = hit ? 1 : 0;
+                suppressed[mine_out] = (uint8_t)(hit ? 1 : 0) ^ inv;
                 done = true;
             }
         }
@@ -1874,7 +1877,7 @@ constexpr int kSweepLdsWords = 16384;   // 128 KiB of LDS -> up to 1,048,576 box
 __global__ __launch_bounds__(kSweepThreads) void k_nms_sweep(const unsigned long long *__restrict__ mask, int64_t n,
                                                              int64_t nb, unsigned long long *remv_g,
                                                              const int64_t *__restrict__ order, const uint8_t *state,
-                                                             const NmsFlags *flags, uint8_t *suppressed)
+                                                             const NmsFlags *flags, uint8_t *suppressed, uint8_t inv)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];
     if (!flags->need_sweep) return;      // the fixed point was reached: k_nms_resolve wrote the result
@@ -1919,7 +1922,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_nms_sweep(const unsigned long
         __syncthreads();
     }
     for (int64_t p = threadIdx.x; p < n; p += kSweepThreads)
-        suppressed[order[p]] = (uint8_t)((remv[p >> 6] >> (p & 63)) & 1ull);
+        suppressed[order[p]] = (uint8_t)((remv[p >> 6] >> (p & 63)) & 1ull) ^ inv;
 }
 
 // ---------------------------------------------------------------- small sets (n <= kNmsSmallMax): five launches
@@ -2086,7 +2089,7 @@ __global__ __launch_bounds__(1024) void k_nms_fill_small(const unsigned long lon
 __global__ __launch_bounds__(1024) void k_nms_resolve_small(uint32_t n, const uint8_t *__restrict__ state0,
                                                             const uint32_t *__restrict__ inc_cnt, const uint32_t *__restrict__ inc_off,
                                                             uint32_t *inc, const int64_t *__restrict__ order,
-                                                            uint8_t *__restrict__ suppressed)
+                                                            uint8_t *__restrict__ suppressed, uint8_t inv)
 {
     __shared__ uint8_t st_lds[kNmsSmallResolveMax];
     volatile uint8_t *st = st_lds;
@@ -2152,7 +2155,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_small(uint32_t n, const ui
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const uint32_t q = threadIdx.x + u * 1024;
-        if (q < n) suppressed[order[q]] = st[q] == kSuppressed;
+        if (q < n) suppressed[order[q]] = (uint8_t)(st[q] == kSuppressed) ^ inv;
     }
 }
 
@@ -2194,6 +2197,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
               int32_t *host_word)
 {
     const int64_t nb = d3d_divup(n, 64);
+    const uint8_t inv = (opts & D3D_NMS_KEEP_MASK) ? 1 : 0;        // the mask comes out inverted: what box2d_nms returns
     WsCarver w(ws, ws_bytes);
     NmsFlags *flags = w.take<NmsFlags>(1);                 // at offset 0: d3d_nms2d_status reads it there
     BoxCore<T> *geom = w.take<BoxCore<T>>(nb * 64);
@@ -2262,19 +2266,19 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
                    (const NmsCand *)cand_hdr, (const uint32_t *)inc_cnt, (uint32_t)n, inc_off, (const uint32_t *)arrival, inc);
         if (n <= kNmsSmallResolveMax) {
             D3D_LAUNCH("k_nms_resolve_small", k_nms_resolve_small, dim3(1), dim3(1024), 0, st, (uint32_t)n, (const uint8_t *)state,
-                       (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, ord, suppressed);
+                       (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, ord, suppressed, inv);
             return D3D_OK;
         }
         // 1 k - 4 k boxes: the general fixed point (+ its dense fallback for dependency chains beyond the poll limit)
         D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,
-                   (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, flags, ord, suppressed);
+                   (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, flags, ord, suppressed, inv);
         const unsigned pb = (unsigned)std::min<int64_t>(d3d_divup(nb, kColsPerBlock) * d3d_divup(nb, 4), 8192);
         if (rot)
             D3D_LAUNCH("k_nms_pairs", (k_nms_pairs<T, true>), dim3(pb), dim3(256), 0, st, geom, fbox, n, nb, (T)iou_thr, mask, flags);
         else
             D3D_LAUNCH("k_nms_pairs", (k_nms_pairs<T, false>), dim3(pb), dim3(256), 0, st, geom, fbox, n, nb, (T)iou_thr, mask, flags);
         D3D_LAUNCH("k_nms_sweep", k_nms_sweep, dim3(1), dim3(kSweepThreads), (size_t)nb * 8, st, mask, n, nb, remv, ord, state, flags,
-                   suppressed);
+                   suppressed, inv);
         return D3D_OK;
     }
     const bool use_grid = !(opts & D3D_NMS_BROAD_SWEEP);
@@ -2367,7 +2371,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     D3D_LAUNCH("k_nms_fill", k_nms_fill, dim3(hits_blocks), dim3(256), 0, st, (const unsigned long long *)cand, cap,
                (const NmsCand *)cand_hdr, (const uint32_t *)inc_off, (const uint32_t *)arrival, inc, (const NmsFlags *)flags);
     D3D_LAUNCH("k_nms_resolve", k_nms_resolve, dim3((unsigned)d3d_divup(n, 256)), dim3(256), 0, st, n, state,
-               (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, flags, order, suppressed);
+               (const uint32_t *)inc_cnt, (const uint32_t *)inc_off, inc, flags, order, suppressed, inv);
     // dense path, gated on need_sweep inside the kernels
     const unsigned pair_blocks = (unsigned)std::min<int64_t>(d3d_divup(nb, kColsPerBlock) * d3d_divup(nb, 4), 8192);
     if (rot)
@@ -2378,7 +2382,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
                    mask, flags);
     size_t lds = nb <= kSweepLdsWords ? (size_t)nb * 8 : 0;
     D3D_LAUNCH("k_nms_sweep", k_nms_sweep, dim3(1), dim3(kSweepThreads), lds, st, mask, n, nb, remv, order, state, flags,
-               suppressed);
+               suppressed, inv);
     return D3D_OK;
 }
 
@@ -2408,7 +2412,7 @@ __global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ 
                                                           const int64_t *__restrict__ order_in, int n, int sup,
                                                           float iou_thr, float score_thr, float param,
                                                           BoxGeom<T> *geom, float4 *aabb, int *g_ord, T *g_sc, uint8_t *g_sp,
-                                                          int in_lds, uint8_t *suppressed)
+                                                          int in_lds, uint8_t *suppressed, uint8_t inv)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char soft_lds[];
     __shared__ int s_S, s_mod, s_prevS, s_cnt;
@@ -2517,7 +2521,7 @@ __global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ 
         __syncthreads();
     }
     __syncthreads();
-    for (int p = tid; p < n; p += kSoftThreads) suppressed[order_in[ord[p]]] = sp[p];
+    for (int p = tid; p < n; p += kSoftThreads) suppressed[order_in[ord[p]]] = sp[p] ^ inv;
 }
 
 // ---------------------------------------------------------------- crop: points in rotated boxes
@@ -2581,14 +2585,14 @@ extern "C" size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype)
 {
     if (n < 1) n = 1;
     if (m < 1) m = 1;
-    const size_t g = dtype == D3D_F64 ? sizeof(BoxGeom<double>) : sizeof(BoxGeom<float>);
+    const size_t g = dtype != D3D_F32 ? sizeof(BoxGeom<double>) : sizeof(BoxGeom<float>);
     // 64 bytes per box instead of the 16 of the candidate boxes: GRBOX keeps its per-box hull terms there (boxloss.hip, HullPre)
     return d3d_align_up(g * n) + d3d_align_up(g * m) + d3d_align_up(64 * n) + d3d_align_up(64 * m) + d3d_align_up(sizeof(IouList)) + d3d_align_up(8 * iou_list_capacity(n, m)) +
            256;
 }
 
-template <typename T, bool ROTATED>
-static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *ious, void *ws, size_t ws_bytes, hipStream_t st,
+template <typename T, bool ROTATED, typename S = T>
+static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, S *ious, void *ws, size_t ws_bytes, hipStream_t st,
                            uint32_t opts)
 {
     WsCarver w(ws, ws_bytes);
@@ -2603,15 +2607,15 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, T *io
     if ((opts >> 8) != 0 && (unsigned long long)(opts >> 8) < cap) cap = opts >> 8;     // D3D_IOU_LIST_CAP: use less of it
     D3D_LAUNCH("k_geom", (k_geom2<T, ROTATED>), dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, ga, ra, b2, m, gb, cb,
                hdr, list_segments(cap), ROTATED);
-    T *fill = ious;
+    S *fill = ious;
     if (reinterpret_cast<uintptr_t>(ious) & 15) {             // unaligned output: plain memset, candidates only
-        D3D_HIP_CHECK(hipMemsetAsync(ious, 0, (size_t)n * (size_t)m * sizeof(T), st));
+        D3D_HIP_CHECK(hipMemsetAsync(ious, 0, (size_t)n * (size_t)m * sizeof(S), st));
         fill = nullptr;
     }
     const int prows = pre_tile_rows(n, m);
-    D3D_LAUNCH("k_iou_pre", k_iou_pre<T>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), (unsigned)d3d_divup(n, (int64_t)prows)),
+    D3D_LAUNCH("k_iou_pre", k_iou_pre<S>, dim3((unsigned)d3d_divup(m, (int64_t)kPreCols), (unsigned)d3d_divup(n, (int64_t)prows)),
                dim3(kTileCols), 0, st, (const float4 *)ra, n, (const float4 *)cb, m, fill, hdr, list, cap, 0.f, prows);
-    D3D_LAUNCH("k_iou_clip", (k_iou_clip<T, ROTATED>), dim3(256 * 16), dim3(256), 0, st, ga, gb, n, m, ious, hdr, list, cap);
+    D3D_LAUNCH("k_iou_clip", (k_iou_clip<T, ROTATED, S>), dim3(256 * 16), dim3(256), 0, st, ga, gb, n, m, ious, hdr, list, cap);
     return D3D_OK;
 }
 
@@ -2620,9 +2624,10 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || m < 0 || (flags & 0xffu)) return D3D_ERR_BAD_ARG;
-    if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
+    if (dtype != D3D_F32 && dtype != D3D_F64 && dtype != D3D_F64_M32) return D3D_ERR_BAD_ARG;
     const bool loss_kind = iou_type == D3D_IOU_GRBOX || iou_type == D3D_IOU_DRBOX;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX && !loss_kind) return D3D_ERR_UNSUPPORTED;
+    if (loss_kind && dtype == D3D_F64_M32) return D3D_ERR_UNSUPPORTED;
     if (n == 0 || m == 0) return D3D_OK;
     if (!boxes1 || !boxes2 || !ious) return D3D_ERR_BAD_ARG;
     if (loss_kind) {        // GIoU / DIoU: every pair has a value (boxloss.hip); GIoU lists the pairs that need the clip
@@ -2637,7 +2642,10 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     const bool rot = iou_type == D3D_IOU_RBOX;
     if ((unsigned long long)n * (unsigned long long)m <= kIouSmallPairs && (flags >> 8) == 0) {      // (a list-cap flag asks for the list path)
         const dim3 sgrid((unsigned)d3d_divup(n * m, 256));
-        if (dtype == D3D_F64) {
+        if (dtype == D3D_F64_M32) {
+            if (rot) D3D_LAUNCH("k_iou_small", (k_iou_small<double, true, float>), sgrid, dim3(256), 0, st, (const double *)boxes1, n, (const double *)boxes2, m, (float *)ious);
+            else D3D_LAUNCH("k_iou_small", (k_iou_small<double, false, float>), sgrid, dim3(256), 0, st, (const double *)boxes1, n, (const double *)boxes2, m, (float *)ious);
+        } else if (dtype == D3D_F64) {
             if (rot) D3D_LAUNCH("k_iou_small", (k_iou_small<double, true>), sgrid, dim3(256), 0, st, (const double *)boxes1, n, (const double *)boxes2, m, (double *)ious);
             else D3D_LAUNCH("k_iou_small", (k_iou_small<double, false>), sgrid, dim3(256), 0, st, (const double *)boxes1, n, (const double *)boxes2, m, (double *)ious);
         } else {
@@ -2649,10 +2657,15 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     if (workspace && workspace_bytes >= d3d_iou2d_workspace_bytes(n, m, dtype)) {
         // zero fill + candidate list + one candidate per lane (BOX too: its IoU is non-zero only where the AABBs overlap)
 #define D3D_TWO_PHASE(T, R) iou2d_two_phase<T, R>((const T *)boxes1, n, (const T *)boxes2, m, (T *)ious, workspace, workspace_bytes, st, flags)
+        if (dtype == D3D_F64_M32) {
+            if (rot) return iou2d_two_phase<double, true, float>((const double *)boxes1, n, (const double *)boxes2, m, (float *)ious, workspace, workspace_bytes, st, flags);
+            return iou2d_two_phase<double, false, float>((const double *)boxes1, n, (const double *)boxes2, m, (float *)ious, workspace, workspace_bytes, st, flags);
+        }
         if (dtype == D3D_F64) return rot ? D3D_TWO_PHASE(double, true) : D3D_TWO_PHASE(double, false);
         return rot ? D3D_TWO_PHASE(float, true) : D3D_TWO_PHASE(float, false);
 #undef D3D_TWO_PHASE
     }
+    if (dtype == D3D_F64_M32) return D3D_ERR_WORKSPACE;       // (the mixed form has no workspace-free kernel)
     // single-kernel path: no workspace
     const bool al16 = (reinterpret_cast<uintptr_t>(ious) & 15) == 0;
 #define D3D_IOU2D(T, R, K)                                                                                          \
@@ -2769,7 +2782,7 @@ static int softnms_typed(const T *boxes, const T *scores, const int64_t *order, 
         D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softnms<T, ROTATED>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSoftLdsBytes));
     D3D_LAUNCH("k_softnms", (k_softnms<T, ROTATED>), dim3(1), dim3(kSoftThreads), in_lds ? lds : 0, st, boxes, scores, order, (int)n,
-               sup, iou_thr, score_thr, param, geom, aabb, ord, sc, sp, in_lds ? 1 : 0, suppressed);
+               sup, iou_thr, score_thr, param, geom, aabb, ord, sc, sp, in_lds ? 1 : 0, suppressed, (uint8_t)((opts & D3D_NMS_KEEP_MASK) ? 1 : 0));
     return D3D_OK;
 }
 
@@ -2800,7 +2813,7 @@ static int nms2d_impl(const void *boxes, const void *scores, const int64_t *orde
                       void *stream, uint32_t flags, int32_t *host_word)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL | D3D_NMS_TEST_WITHHOLD | D3D_NMS_FORCE_LEVELS | D3D_NMS_ONE_LEVEL))) return D3D_ERR_BAD_ARG;
+    if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL | D3D_NMS_TEST_WITHHOLD | D3D_NMS_FORCE_LEVELS | D3D_NMS_ONE_LEVEL | D3D_NMS_KEEP_MASK))) return D3D_ERR_BAD_ARG;
     if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;   // common.h:25
     if (suppression_type != D3D_SUPPRESS_HARD && suppression_type != D3D_SUPPRESS_LINEAR &&
@@ -2902,8 +2915,8 @@ extern "C" int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, in
     return D3D_OK;
 }
 
-template <typename T>
-static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, const T *grad, bool rot, T *g1, T *g2, void *ws,
+template <typename T, typename G = T>
+static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, const G *grad, bool rot, T *g1, T *g2, void *ws,
                                 size_t ws_bytes, hipStream_t st)
 {
     WsCarver w(ws, ws_bytes);
@@ -2928,8 +2941,8 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     D3D_HIP_CHECK(hipMemsetAsync(g1, 0, sizeof(T) * 5 * (size_t)n, st));
     D3D_HIP_CHECK(hipMemsetAsync(g2, 0, sizeof(T) * 5 * (size_t)m, st));
     if ((unsigned long long)n * (unsigned long long)m <= kIouSmallPairs) {
-        if (rot) D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, true>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
-        else D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, false>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
+        if (rot) D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, true, G>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
+        else D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, false, G>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
         return D3D_OK;
     }
     D3D_LAUNCH("k_geom", (k_geom2<T, false>), dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, ga, ra, b2, m, gb, cb,
@@ -2943,15 +2956,15 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
             const int64_t nr = (n - r0) < rows_max ? (n - r0) : rows_max;
 #define D3D_GRAD_TILES(R)                                                                                                                   \
     D3D_HIP_CHECK(hipMemsetAsync(nmarks, 0, 8 * kMarkStripes, st));                                                                                         \
-    D3D_LAUNCH("k_iou_grad_mark", (k_iou_grad_mark<T, R>), dim3((unsigned)d3d_divup(m, 2 * kGradCols), (unsigned)d3d_divup(nr, tr)),            \
+    D3D_LAUNCH("k_iou_grad_mark", (k_iou_grad_mark<T, R, G>), dim3((unsigned)d3d_divup(m, 2 * kGradCols), (unsigned)d3d_divup(nr, tr)),            \
                dim3(kGradCols), 0, st, (const BoxGeom<T> *)ga + r0, (const float4 *)ra + r0, nr, (const BoxGeom<T> *)gb, (const float4 *)cb, \
                m, grad + r0 * m, bitmap, wpr, tr, nmarks);                                                                                  \
     D3D_LAUNCH("k_iou_grad_decide", k_iou_grad_decide, dim3(1), dim3(kMarkStripes), 0, st, nmarks, nr, m);                                    \
-    D3D_LAUNCH("k_iou_grad_tiles", (k_iou_grad_tiles<T, R>), dim3((unsigned)d3d_divup(m, kGradCols), (unsigned)d3d_divup(nr, tr)),               \
+    D3D_LAUNCH("k_iou_grad_tiles", (k_iou_grad_tiles<T, R, G>), dim3((unsigned)d3d_divup(m, kGradCols), (unsigned)d3d_divup(nr, tr)),               \
                dim3(kGradCols), 0, st, (const BoxGeom<T> *)ga + r0, (const float4 *)ra + r0, b1 + r0 * 5, nr, (const BoxGeom<T> *)gb,        \
                (const float4 *)cb, b2, m, grad + r0 * m, g1 + r0 * 5, g2, tr, (const unsigned long long *)bitmap, wpr,                      \
                (const unsigned long long *)nmarks);                                                                                         \
-    D3D_LAUNCH("k_iou_grad_sparse", (k_iou_grad_sparse<T, R>), dim3((unsigned)d3d_divup(nr * wpr, (int64_t)kSparseWords)), dim3(256), 0, st,   \
+    D3D_LAUNCH("k_iou_grad_sparse", (k_iou_grad_sparse<T, R, G>), dim3((unsigned)d3d_divup(nr * wpr, (int64_t)kSparseWords)), dim3(256), 0, st,   \
                (const BoxGeom<T> *)ga + r0, b1 + r0 * 5, nr, (const BoxGeom<T> *)gb, b2, m, grad + r0 * m, g1 + r0 * 5, g2,                  \
                (const unsigned long long *)bitmap, wpr, (const unsigned long long *)nmarks)
             if (rot) { D3D_GRAD_TILES(true); } else { D3D_GRAD_TILES(false); }
@@ -2967,12 +2980,13 @@ extern "C" int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *box
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || m < 0) return D3D_ERR_BAD_ARG;
-    if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
+    if (dtype != D3D_F32 && dtype != D3D_F64 && dtype != D3D_F64_M32) return D3D_ERR_BAD_ARG;
     const bool loss_kind = iou_type == D3D_IOU_GRBOX || iou_type == D3D_IOU_DRBOX;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX && !loss_kind) return D3D_ERR_UNSUPPORTED;
+    if (loss_kind && dtype == D3D_F64_M32) return D3D_ERR_UNSUPPORTED;
     if (n > 0 && (!boxes1 || !grad_boxes1)) return D3D_ERR_BAD_ARG;
     if (m > 0 && (!boxes2 || !grad_boxes2)) return D3D_ERR_BAD_ARG;
-    const size_t esz = dtype == D3D_F64 ? 8 : 4;
+    const size_t esz = dtype != D3D_F32 ? 8 : 4;
     if (n == 0 || m == 0) {
         if (n > 0) D3D_HIP_CHECK(hipMemsetAsync(grad_boxes1, 0, esz * 5 * (size_t)n, st));
         if (m > 0) D3D_HIP_CHECK(hipMemsetAsync(grad_boxes2, 0, esz * 5 * (size_t)m, st));
@@ -2984,6 +2998,9 @@ extern "C" int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *box
                                               grad_boxes2, workspace, workspace ? workspace_bytes : 0, st);
     if (workspace_bytes < d3d_iou2d_workspace_bytes(n, m, dtype)) return D3D_ERR_WORKSPACE;
     const bool rot = iou_type == D3D_IOU_RBOX;
+    if (dtype == D3D_F64_M32)
+        return iou2d_backward_typed<double, float>((const double *)boxes1, n, (const double *)boxes2, m, (const float *)grad, rot,
+                                                   (double *)grad_boxes1, (double *)grad_boxes2, workspace, workspace_bytes, st);
     if (dtype == D3D_F64)
         return iou2d_backward_typed<double>((const double *)boxes1, n, (const double *)boxes2, m, (const double *)grad, rot,
                                             (double *)grad_boxes1, (double *)grad_boxes2, workspace, workspace_bytes, st);

@@ -44,7 +44,12 @@ enum { D3D_MAXVOX_NONE = 0, D3D_MAXVOX_TRIM = 1, D3D_MAXVOX_DESCENDING = 2 };
 enum { D3D_IOU_NA = 0, D3D_IOU_BOX = 1, D3D_IOU_RBOX = 2, D3D_IOU_GBOX = 3, D3D_IOU_GRBOX = 4,
        D3D_IOU_DBOX = 5, D3D_IOU_DRBOX = 6 };
 enum { D3D_SUPPRESS_HARD = 0, D3D_SUPPRESS_LINEAR = 1, D3D_SUPPRESS_GAUSSIAN = 2 };
-enum { D3D_F32 = 0, D3D_F64 = 1 };
+enum { D3D_F32 = 0, D3D_F64 = 1,
+       /* d3d_iou2d_forward / d3d_iou2d_backward, BOX and RBOX only: boxes and box gradients f64, arithmetic f64, the [n,m] MATRIX
+        * (ious written, grad read) f32 -- every value rounded where it is stored / widened where it is read.  The results of
+        * box2d_iou(precise=True) on fp32 boxes (reference box/__init__.py:204-205, 224: boxes.double(), ious.to(dtype)) without
+        * the fp64 copy of the matrix: a third of the bytes. */
+       D3D_F64_M32 = 2 };
 
 /* status bits OR-ed into counts[D3D_COUNT_STATUS] by the voxel kernels */
 enum { D3D_VOXEL_STATUS_COORD_OVERFLOW = 1,   /* sparse: 2^20 <= |floor(p/size)| < 2^31 (NaN, inf and
@@ -462,7 +467,9 @@ int d3d_stream_probe(int mode, void *buf, size_t bytes, void *stream);
  * GIoU = IoU - (H - U) / H, H = area of the convex hull of the two rectangles, U = union area; DIoU = IoU - d^2 / D^2,
  * d = distance of the centres, D = diameter of that hull (dgal's source is not vendored: the published definitions);
  * a rectangle of non-positive area gives 0 for every type.  GBOX / DBOX are D3D_ERR_UNSUPPORTED (the reference's Python
- * layer raises "Unrecognized iou type!" for them, box/__init__.py:216-217). */
+ * layer raises "Unrecognized iou type!" for them, box/__init__.py:216-217).
+ * dtype D3D_F64_M32 (BOX / RBOX; GRBOX / DRBOX: D3D_ERR_UNSUPPORTED): boxes f64, ious f32; above 65536 pairs the workspace is
+ * required (D3D_ERR_WORKSPACE without it; size: the query with D3D_F64_M32). */
 size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype);
 int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t m,
                       int32_t iou_type, int32_t dtype, void *ious,
@@ -476,7 +483,8 @@ int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t
  * grad_boxes1[n,5], grad_boxes2[m,5] (overwritten), all in `dtype`.  The flags the reference saves in forward (nx,
  * xflags, ...) are not needed: the geometry is recomputed analytically.
  * Workspace: d3d_iou2d_workspace_bytes(n, m, dtype); required for BOX / RBOX, optional for GRBOX / DRBOX (with it, matrices
- * of more than 65536 pairs take a gradient kernel for the pairs that are apart and the complete routine for the rest). */
+ * of more than 65536 pairs take a gradient kernel for the pairs that are apart and the complete routine for the rest).
+ * dtype D3D_F64_M32 (BOX / RBOX): boxes and grad_boxes f64, grad[n,m] f32 (widened as it is read). */
 int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *boxes2, int64_t m, const void *grad,
                        int32_t iou_type, int32_t dtype, void *grad_boxes1, void *grad_boxes2,
                        void *workspace, size_t workspace_bytes, void *stream);
@@ -568,7 +576,9 @@ size_t d3d_nms2d_workspace_bytes(int64_t n);
  *   All give the same mask.
  *   soft-NMS has no size limit of its own (100 k boxes with most of them alive: seconds). */
 enum { D3D_NMS_BROAD_SWEEP = 1, D3D_NMS_FORCE_DENSE = 2, D3D_NMS_SOFT_NO_LDS = 4, D3D_NMS_GENERAL = 8, D3D_NMS_TEST_WITHHOLD = 16,
-       D3D_NMS_FORCE_LEVELS = 32, D3D_NMS_ONE_LEVEL = 64 };
+       D3D_NMS_FORCE_LEVELS = 32, D3D_NMS_ONE_LEVEL = 64,
+       D3D_NMS_KEEP_MASK = 128   /* `suppressed` receives the KEEP mask -- what box2d_nms returns, ~suppressed (reference
+                                    box/__init__.py:272) -- written by the kernels that decide it instead of a pass over the mask */ };
 #define D3D_NMS_CAND_CAP(k) ((uint32_t)(k) << 8)
 int d3d_nms2d(const void *boxes, const void *scores, const int64_t *order, int64_t n,
               int32_t iou_type, int32_t suppression_type, int32_t dtype,

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, n), "libd3d_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "d3d_amd/_lib.py does not bind %s" % n
     assert set(_lib.SIGNATURES) <= set(names)
-    assert _lib.load().d3d_abi_version() == 12
+    assert _lib.load().d3d_abi_version() == 13
     assert _lib.load().d3d_status_string(-2) == b"unsupported option"
 
 

@@ -641,14 +641,19 @@ def test_c_abi_error_codes():
     assert lib.d3d_iou2d_forward(p(b), -1, p(b), 4, 2, _lib.F64, p(out), z, 0, z, 0) == _lib.ERR_BAD_ARG       # negative size
     assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 3, _lib.F64, p(out), z, 0, z, 0) == _lib.ERR_UNSUPPORTED    # GBOX
     assert lib.d3d_iou2d_forward(p(b), 0, p(b), 4, 2, _lib.F64, z, z, 0, z, 0) == 0                             # empty: ok
+    assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 4, _lib.F64_M32, p(out), z, 0, z, 0) == _lib.ERR_UNSUPPORTED  # GRBOX with an fp32 matrix
+    assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 2, 3, p(out), z, 0, z, 0) == _lib.ERR_BAD_ARG                # unknown dtype code
+    big = torch.zeros((300, 5), dtype=torch.float64, device="cuda")
+    o32 = torch.zeros((300, 300), dtype=torch.float32, device="cuda")
+    assert lib.d3d_iou2d_forward(p(big), 300, p(big), 300, 2, _lib.F64_M32, p(o32), z, 0, z, 0) == _lib.ERR_WORKSPACE   # mixed form: list path only
+    assert lib.d3d_iou2d_workspace_bytes(300, 300, _lib.F64_M32) == lib.d3d_iou2d_workspace_bytes(300, 300, _lib.F64)
     assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 3, 0, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), ws.numel(),
                          z, 0) == _lib.ERR_UNSUPPORTED                                                          # GBOX in NMS
     assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 2, 7, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), ws.numel(),
                          z, 0) == _lib.ERR_UNSUPPORTED                                                          # suppression enum
     assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 2, 0, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), 16,
                          z, 0) == _lib.ERR_WORKSPACE                                                            # workspace too small
-    assert lib.d3d_nms2d(p(b), p(b[:, 0].contiguous()), p(order), 4, 2, 0, _lib.F64, 0.5, 0.0, 0.0, p(sup), p(ws), ws.numel(),
-                         z, 0x80) == _lib.ERR_BAD_ARG                                                           # unknown option bit
+    assert lib.d3d_iou3d_forward(z, 4, z, 4, 1, z, z, 0, z) == _lib.ERR_BAD_ARG                                     # null boxes
     assert lib.d3d_status_string(_lib.ERR_WORKSPACE) == b"workspace too small"
     torch.cuda.synchronize()
 
@@ -931,3 +936,79 @@ def test_crop_2dr_fp32_points_within_an_ulp_of_an_edge(npts):
     own = exp[which, np.arange(npts)]
     assert 0.2 < own.mean() < 0.8                     # the planted points really straddle their edges
     assert np.array_equal(crop_2dr(T(pts), T(box)).cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("method", ["rbox", "box"])
+@pytest.mark.parametrize("shape", [(7, 9), (1, 1), (300, 400), (257, 1023), (3, 70001), (2100, 33)])
+def test_precise_on_fp32_boxes_rounds_where_the_matrix_is_stored(method, shape):
+    """box2d_iou(precise=True) on fp32 boxes (the reference's default call, box/__init__.py:204-205, 224: boxes.double(), fp64
+    kernels, ious.to(float32)) runs as fp64 arithmetic with an fp32 matrix (D3D_F64_M32): the values are those of the explicit
+    chain bit for bit -- small matrices (one launch), the two-phase path, an overflowed candidate list -- and within an fp32
+    ulp of the oracle's fp64 values; the gradients are those of the chain (fp64 atomics: the order of the sums is not fixed)"""
+    from d3d_amd import _lib, synth
+    from d3d_amd.box import IouType, Iou2D, Iou2DR, box2d_iou
+    n, m = shape
+    gen = synth.boxes2d_dense if n * m < 200000 else synth.boxes2d_sparse
+    b1 = gen(n, 61)[0].astype(np.float32)
+    b2 = gen(m, 62)[0].astype(np.float32)
+    if n > 4 and m > 4:
+        b2[:4] = b1[:4]                                          # identical boxes
+        b1[4, 2] = 0.0                                           # a degenerate rectangle
+    fn = Iou2DR if method == "rbox" else Iou2D
+    for cap in (0, 8):
+        if cap and n * m <= 65536:
+            continue                                             # (one launch, no list)
+        set_opts(iou_flags=_lib.iou_list_cap(cap) if cap else 0)
+        t1, t2 = T(b1).requires_grad_(True), T(b2).requires_grad_(True)
+        got = box2d_iou(t1, t2, method=method)
+        assert got.dtype == torch.float32 and got.shape == (n, m)
+        c1, c2 = T(b1).requires_grad_(True), T(b2).requires_grad_(True)
+        chain = fn.apply(c1.double(), c2.double()).to(torch.float32)
+        assert torch.equal(got, chain)
+        exp = oracle.box2d_iou(b1.astype(np.float64), b2.astype(np.float64), method, nthreads=4)
+        assert np.max(np.abs(got.detach().cpu().numpy().astype(np.float64) - exp)) <= 6.1e-8
+        w = torch.from_numpy((np.random.default_rng(5).random((n, m)) - 0.3).astype(np.float32)).cuda()
+        (got * w).sum().backward()
+        (chain * w).sum().backward()
+        for a, b in ((t1.grad, c1.grad), (t2.grad, c2.grad)):
+            assert a.dtype == torch.float32 and torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+    set_opts(iou_flags=0)
+    # numpy in, numpy out, on the same path
+    gn = box2d_iou(b1, b2, method=method)
+    assert isinstance(gn, np.ndarray) and gn.dtype == np.float32 and np.array_equal(gn, got.detach().cpu().numpy())
+
+
+def test_precise_on_fp32_boxes_allocates_no_fp64_matrix():
+    """4096 x 4096: the fp32 matrix is 64 MB; the chain around fp64 kernels held 128 MB + 64 MB at its peak"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_iou
+    b = T(synth.boxes2d_sparse(4096, 3)[0].astype(np.float32))
+    box2d_iou(b, b, method="rbox")                               # (workspace arena allocated)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    before = torch.cuda.memory_allocated()
+    out = box2d_iou(b, b, method="rbox")
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float32
+    assert torch.cuda.max_memory_allocated() - before < 100 * (1 << 20)
+
+
+@pytest.mark.parametrize("n", [100, 1500, 3000, 20000])
+def test_nms_keep_mask_is_the_inverted_suppressed_mask(n, nms_broad):
+    """D3D_NMS_KEEP_MASK (what box2d_nms asks for: the reference returns ~suppressed, box/__init__.py:272): every kernel that
+    decides a box writes the inverted bit -- the small-set resolve, the fixed point, the dense sweep, soft-NMS"""
+    from d3d_amd import _lib, synth
+    from d3d_amd.box import IouType, box2d_nms, nms2d
+    b, s = synth.boxes2d_dense(n, 71) if n <= 3000 else synth.boxes2d_sparse(n, 71)
+    bt, st = T(b), T(s)
+    base = cur_opts().nms_flags
+    for extra in (0, _lib.NMS_FORCE_DENSE):
+        sup = nms2d(bt, st, IouType.RBOX, 0, 0.3, 0.1, 0.0, flags=base | extra)
+        keep = nms2d(bt, st, IouType.RBOX, 0, 0.3, 0.1, 0.0, flags=base | extra, keep_mask=True)
+        assert keep.dtype == torch.bool and torch.equal(keep, ~sup) and 0 < int(keep.sum()) < n
+    assert torch.equal(box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.3, score_threshold=0.1), keep)
+    assert np.array_equal(keep.cpu().numpy(), oracle.box2d_nms(b, s, iou_method="rbox", iou_threshold=0.3, score_threshold=0.1))
+    if n <= 3000 and nms_broad == "auto":
+        for sm in (1, 2):
+            sup = nms2d(bt, st, IouType.RBOX, sm, 0.3, 0.1, 0.5)
+            assert torch.equal(nms2d(bt, st, IouType.RBOX, sm, 0.3, 0.1, 0.5, keep_mask=True), ~sup)
