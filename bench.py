@@ -491,6 +491,15 @@ def extras(args):
     bdt = torch.from_numpy(bd).cuda()
     dt = timed(lambda: box2d_iou(bdt, bdt, method="rbox"), 10, 2)
     ex["iou2d_rbox_fp64_dense5k_mpairs_per_s"] = round(25e6 * 10 / dt / 1e6, 1)
+    # box2d_iou's default form on fp32 boxes (precise=True): fp64 arithmetic with an fp32 matrix (D3D_F64_M32) against the chain the
+    # reference's Python layer spells out -- boxes.double(), fp64 kernels, ious.to(float32) (box/__init__.py:204-205, 224)
+    from d3d_amd.box import Iou2DR
+    b32 = torch.from_numpy(b[:20000].astype(np.float32)).cuda()
+    dt = timed(lambda: box2d_iou(b32, b32, method="rbox"), 5, 1)
+    dtc = timed(lambda: Iou2DR.apply(b32.double(), b32.double()).to(torch.float32), 5, 1)
+    ex["box2d_iou_precise_fp32_boxes_20kx20k_ms"] = dict(fp32_matrix=round(1e3 * dt / 5, 3), fp64_matrix_then_cast=round(1e3 * dtc / 5, 3))
+    del b32
+    torch.cuda.empty_cache()
     # (no warm-up streak: since round 4 every call decides from ITS OWN grid whether the level kernels are launched)
     ex.update(nms_leg(n3, 20, 1))
     try:        # the same operator captured into a HIP graph by the caller and replayed (~28 launches without host work)
