@@ -13,8 +13,9 @@ are numpy.  Two associations:
   has two acceptable ground truths.
 """
 import numpy as np
+import torch
 
-from .tracking.matcher import DistanceTypes, prepare_boxes, score_match, score_match_reference_compat
+from .tracking.matcher import DistanceTypes, ReferenceAssociation, prepare_boxes, score_match
 from .utils import Dict
 
 
@@ -126,19 +127,40 @@ class DetectionEvaluator:
             for k in ("acc_iou", "acc_angular", "acc_dist", "acc_box", "acc_var"):
                 out[k][c] = [float("nan")] * T
         cache = prepare_boxes(dt, gt, DistanceTypes.RIoU) if len(gt) and len(dt) else None             # :188-189
+        # the 40 associations are queued on the stream one after the other -- what they share (the ground truths' columns of the
+        # cache, which pairs are acceptable) prepared once, nothing read back in between -- and fetched together
+        assoc = gt_idx_t = None
+        if cache is not None and len(gt_idx):
+            assoc = ReferenceAssociation(cache, dt_score, dt_tag, gt_tag, self._max_distance, gt_idx)
+            gt_idx_t = torch.from_numpy(gt_idx).to(cache.device)
+        dt_idxs, queued = [], []
         for t in range(T):
             dt_idx = np.nonzero(dt_in & ~(dt_score < thr[t]))[0]                                        # :219-228 (`score < thres`: skip)
+            dt_idxs.append(dt_idx)
+            if assoc is not None and len(dt_idx):
+                sm_t, dm_t = assoc.match(dt_idx)                                                       # :231-232
+                d_of_t = dm_t.index_select(0, gt_idx_t).long()
+                iou_t = 1 - cache[d_of_t.clamp_min(0), gt_idx_t]                                       # :243 (rows of the unmatched: unused)
+                queued.append((t, sm_t, dm_t, iou_t))
+        fetched = {}
+        if queued:
+            sm_all = torch.stack([q[1] for q in queued]).cpu().numpy().astype(np.int64)
+            dm_all = torch.stack([q[2] for q in queued]).cpu().numpy().astype(np.int64)
+            iou_all = torch.stack([q[3] for q in queued]).cpu().numpy().astype(np.float32)
+            fetched = {q[0]: (sm_all[i], dm_all[i], iou_all[i]) for i, q in enumerate(queued)}
+        for t in range(T):
+            dt_idx = dt_idxs[t]
             for c in classes:
                 out.ndt[c][t] = int((dt_tag[dt_idx] == c).sum())
-            if cache is not None and len(dt_idx) and len(gt_idx):
-                sm, dm = score_match_reference_compat(cache, dt_score, dt_tag, gt_tag, self._max_distance, dt_idx, gt_idx)   # :231-232
-                sm, dm = sm.cpu().numpy().astype(np.int64), dm.cpu().numpy().astype(np.int64)
+            if t in fetched:
+                sm, dm, iou_row = fetched[t]
             else:
-                sm, dm = np.full((len(dt),), -1, np.int64), np.full((len(gt),), -1, np.int64)
-            g_hit = gt_idx[dm[gt_idx] >= 0]
+                sm, dm, iou_row = np.full((len(dt),), -1, np.int64), np.full((len(gt),), -1, np.int64), None
+            hit = dm[gt_idx] >= 0
+            g_hit = gt_idx[hit]
             d_of = dm[g_hit]
             if len(g_hit):
-                iou = (1 - cache[d_of, g_hit]).cpu().numpy().astype(np.float32)                         # :243
+                iou = iou_row[hit]
                 dist = np.linalg.norm(gt[g_hit, 2:5] - dt[d_of, 2:5], axis=1)                           # :244
                 box = np.linalg.norm(gt[g_hit, 5:8] - dt[d_of, 5:8], axis=1)                            # :245
                 dyaw = gt[g_hit, 8] - dt[d_of, 8]

@@ -107,39 +107,77 @@ def score_match_reference_compat(distance, src_scores, src_tags, dst_tags, dista
     leaves that open in the reference); a destination tag missing from `distance_threshold` gets the threshold 0.0, as
     unordered_map::operator[] hands out (:112).
     Returns (src_match[n], dst_match[m]) int32 tensors, -1 = unmatched."""
-    dev = distance.device
-    n, m = distance.shape
-    src_match = torch.full((n,), -1, dtype=torch.int32, device=dev)
-    dst_match = torch.full((m,), -1, dtype=torch.int32, device=dev)
-    ssub = np.asarray(list(src_subset), dtype=np.int64).reshape(-1)
-    dsub = np.asarray(list(dst_subset), dtype=np.int64).reshape(-1)
-    if ssub.size == 0 or dsub.size == 0:
-        return src_match, dst_match
+    return ReferenceAssociation(distance, src_scores, src_tags, dst_tags, distance_threshold, dst_subset).match(src_subset)
 
-    def host(a):
-        return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    scores = host(src_scores).astype(np.float32).reshape(-1)
-    stags, dtags = host(src_tags).astype(np.int64).reshape(-1), host(dst_tags).astype(np.int64).reshape(-1)
-    src_order = np.flip(np.argsort([float(scores[i]) for i in ssub]))                  # matcher.pyx:145-146, literally
-    best = ssub[src_order]                                                                # slot k's source
-    thr = np.array([float(distance_threshold.get(int(t), 0.0)) for t in dtags[dsub]], np.float32)
-    with torch.cuda.device(dev):
-        ssub_t, dsub_t, best_t = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (ssub, dsub, best))
-        own = distance.index_select(0, best_t).index_select(1, dsub_t)                    # the source's own distances: the test of :112
-        ok = (own <= torch.from_numpy(thr).to(dev)[None, :]) & \
-             (torch.from_numpy(stags[best]).to(dev)[:, None] == torch.from_numpy(dtags[dsub]).to(dev)[None, :])
-        del own
-        pref = distance.index_select(0, ssub_t).index_select(1, dsub_t)                   # row k of the subset: the order walked (:148, :158)
-        pref = torch.where(ok, pref, torch.full((), float("inf"), dtype=pref.dtype, device=dev))
-        del ok
-        k = len(ssub)
-        sm, dm = score_match(pref, -np.arange(k, dtype=np.float32), np.zeros((k,), np.int32), np.zeros((len(dsub),), np.int32),
-                             {0: 3.0e38})
-        hit = sm >= 0
-        src_match[best_t[hit]] = dsub_t[sm[hit].long()].to(torch.int32)
-        taken = dm >= 0
-        dst_match[dsub_t[taken]] = best_t[dm[taken].long()].to(torch.int32)
-    return src_match, dst_match
+
+def _index_array(subset):
+    return np.asarray(subset if isinstance(subset, np.ndarray) else list(subset), dtype=np.int64).reshape(-1)
+
+
+class ReferenceAssociation:
+    """score_match_reference_compat for MANY source subsets against one destination subset (the evaluator: 40 score thresholds,
+    benchmarks.pyx:218-238): what does not depend on the sources' subset is prepared once -- the destinations' columns of the
+    distance matrix, and for every (source, destination) whether the pair is acceptable (tag, the source's OWN distance within the
+    destination tag's threshold) -- and `match` queues its work on the stream without reading anything back: the caller
+    synchronises once, when it fetches the results."""
+
+    def __init__(self, distance, src_scores, src_tags, dst_tags, distance_threshold, dst_subset):
+        def host(a):
+            return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        self.dev = dev = distance.device
+        self.n, self.m = distance.shape
+        self.scores = host(src_scores).astype(np.float32).reshape(-1)
+        stags, dtags = host(src_tags).astype(np.int64).reshape(-1), host(dst_tags).astype(np.int64).reshape(-1)
+        self.dsub = dsub = _index_array(dst_subset)
+        if dsub.size == 0 or self.n == 0:
+            return
+        # a destination tag missing from `distance_threshold` gets 0.0, as unordered_map::operator[] hands out (matcher.pyx:112)
+        thr = np.zeros((dsub.size,), np.float32)
+        dt_sub = dtags[dsub]
+        for tag in np.unique(dt_sub):
+            thr[dt_sub == tag] = np.float32(float(distance_threshold.get(int(tag), 0.0)))
+        with torch.cuda.device(dev):
+            self.dsub_t = torch.from_numpy(dsub).to(dev)
+            self.cols = distance.index_select(1, self.dsub_t)                                   # [n, md]
+            self.ok = (self.cols <= torch.from_numpy(thr).to(dev)[None, :]) & \
+                      (torch.from_numpy(stags).to(dev)[:, None] == torch.from_numpy(dt_sub).to(dev)[None, :])
+            md = dsub.size
+            self._dtag0 = torch.zeros((md,), dtype=torch.int32, device=dev)
+            self._dthr = torch.full((md,), 3.0e38, dtype=torch.float32, device=dev)
+            self._inf = torch.full((), float("inf"), dtype=self.cols.dtype, device=dev)
+
+    def match(self, src_subset):
+        """-> (src_match[n], dst_match[m]) int32 tensors on the device, -1 = unmatched (nothing is read back here)"""
+        dev, n, m = self.dev, self.n, self.m
+        src_match = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        dst_match = torch.full((m,), -1, dtype=torch.int32, device=dev)
+        ssub = _index_array(src_subset)
+        if ssub.size == 0 or self.dsub.size == 0:
+            return src_match, dst_match
+        # matcher.pyx:145-146: np.flip(np.argsort([scores of the subset])) -- the same call on the same float64 values (a Python
+        # list of floats becomes a float64 array), so equal scores come out as they do there
+        src_order = np.flip(np.argsort(self.scores[ssub].astype(np.float64)))
+        best = ssub[src_order]                                                                # slot k's source
+        lib = _lib.load()
+        k, md = int(ssub.size), int(self.dsub.size)
+        with torch.cuda.device(dev):
+            both = torch.from_numpy(np.concatenate([ssub, best])).to(dev)
+            ssub_t, best_t = both[:k], both[k:]
+            # P[k, j] = distance[subset row k, j] where (k-th best source, j) is acceptable, +inf elsewhere
+            pref = torch.where(self.ok.index_select(0, best_t), self.cols.index_select(0, ssub_t), self._inf)
+            sm = torch.empty((k,), dtype=torch.int32, device=dev)
+            dm = torch.empty((md,), dtype=torch.int32, device=dev)
+            status = torch.zeros((1,), dtype=torch.int32, device=dev)
+            order = torch.arange(k, dtype=torch.int64, device=dev)                            # the slots are in order already
+            stag0 = torch.zeros((k,), dtype=torch.int32, device=dev)
+            ws = _lib.workspace(lib.d3d_score_match_workspace_bytes(k, md), dev)
+            rc = lib.d3d_score_match(_lib.ptr(pref), k, md, _lib.ptr(stag0), _lib.ptr(self._dtag0), _lib.ptr(self._dthr), _lib.ptr(order),
+                                     _lib.ptr(sm), _lib.ptr(dm), _lib.ptr(status), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "score_match")
+            neg = torch.full((), -1, dtype=torch.int32, device=dev)
+            src_match[best_t] = torch.where(sm >= 0, self.dsub_t[sm.clamp_min(0).long()].to(torch.int32), neg)
+            dst_match[self.dsub_t] = torch.where(dm >= 0, best_t[dm.clamp_min(0).long()].to(torch.int32), neg)
+        return src_match, dst_match
 
 
 class ScoreMatcher:
