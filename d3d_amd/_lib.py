@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libd3d_hip.so")
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = 0, -1, -2, -3, -4
 COUNT_VOXELS, COUNT_POINTS, COUNT_STATUS, COUNT_AUX, NUM_COUNTS = 0, 1, 2, 3, 4
 STATUS_COORD_OVERFLOW, STATUS_TABLE_FULL, STATUS_PACK_OVERFLOW, STATUS_BIN_OVERFLOW = 1, 2, 4, 8
-F32, F64, F64_M32 = 0, 1, 2      # (F64_M32: d3d_iou2d_forward / _backward -- fp64 boxes and arithmetic, fp32 [n,m] matrix)
+F32, F64, F64_M32, F32_WIDE = 0, 1, 2, 3      # (F64_M32: d3d_iou2d_forward / _backward -- fp64 boxes and arithmetic, fp32 [n,m] matrix)
 # per-call option bits (include/d3d_hip.h)
 VOXEL_PATH_HASH, VOXEL_PARTITION_3PASS, VOXEL_PLAIN_SLOTS, VOXEL_SPLIT_FILL, VOXEL_EXACT_MEAN, VOXEL_WIDE_KEYS = 1, 2, 4, 8, 16, 64
 OWNER_MERGE_CHAINS, OWNER_MERGE_TEST_TINY = 1, 2

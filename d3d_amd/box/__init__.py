@@ -59,8 +59,9 @@ def _to_device(*ts):
 _MAX_ROWS = 65535 * 64      # rows of boxes1 per d3d_iou2d_forward launch (grid.y limit x 64-row tiles)
 
 
-def _iou_forward(boxes1, boxes2, iou_type, flags=None, matrix32=False):
-    """matrix32 (fp64 boxes, BOX / RBOX): the arithmetic in fp64, `ious` stored as fp32 (D3D_F64_M32)"""
+def _iou_forward(boxes1, boxes2, iou_type, flags=None, matrix32=False, wide32=False):
+    """matrix32 (fp64 boxes, BOX / RBOX): the arithmetic in fp64, `ious` stored as fp32 (D3D_F64_M32);
+    wide32 (fp32 boxes, BOX / RBOX): the same with the boxes widened where the kernels load them (D3D_F32_WIDE)"""
     lib = _lib.load()
     odev = boxes1.device
     if boxes1.dtype != boxes2.dtype:
@@ -73,10 +74,10 @@ def _iou_forward(boxes1, boxes2, iou_type, flags=None, matrix32=False):
         if options.current().poison:
             ious.fill_(float("nan"))
         code = _dtype_code(b1)
-        if matrix32:
-            if code != _lib.F64 or int(iou_type) not in (IouType.BOX, IouType.RBOX):
-                raise ValueError("matrix32 takes fp64 boxes and the box / rbox methods")
-            code = _lib.F64_M32
+        if matrix32 or wide32:
+            if code != (_lib.F32 if wide32 else _lib.F64) or int(iou_type) not in (IouType.BOX, IouType.RBOX):
+                raise ValueError("matrix32 takes fp64 boxes, wide32 fp32 boxes, both the box / rbox methods")
+            code = _lib.F32_WIDE if wide32 else _lib.F64_M32
         # one launch covers 65535 tiles of 64 rows; taller inputs go in row blocks into the same output
         for r0 in range(0, max(n, 1), _MAX_ROWS):
             r1 = min(n, r0 + _MAX_ROWS)
@@ -228,14 +229,14 @@ class DIou2DR(torch.autograd.Function):
 class _IouPrecise32(torch.autograd.Function):
     """box2d_iou(precise=True) on fp32 boxes, 'box' / 'rbox': the reference widens the boxes, computes in fp64 and casts the matrix
     back (box/__init__.py:204-205, 224).  Same numbers -- fp64 arithmetic on the widened boxes, every value rounded once -- with
-    the rounding where the matrix is stored, and in backward the widening where the incoming gradient is read: no fp64 copy of an
-    [N,M] matrix in either direction."""
+    the widening where the boxes are loaded, the rounding where the matrix is stored, and in backward the widening where the
+    incoming gradient is read: no fp64 copy of an [N,M] matrix in either direction, no cast launches in front of the forward."""
 
     @staticmethod
     def forward(ctx, boxes1, boxes2, iou_type):
         ctx.save_for_backward(boxes1, boxes2)
         ctx.iou_type = iou_type
-        return _iou_forward(boxes1.double(), boxes2.double(), iou_type, matrix32=True)
+        return _iou_forward(boxes1, boxes2, iou_type, wide32=True)
 
     @staticmethod
     def backward(ctx, grad):
@@ -309,12 +310,14 @@ NMS_STATUS_DENSE_PATH, NMS_STATUS_SCAN_GAVE_UP = 1, 2
 
 
 def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_threshold, supression_param, sort_keys=None,
-          flags=None, return_status=False, keep_mask=False):
+          flags=None, return_status=False, keep_mask=False, wide32=False):
     """nms2d / nms2d_cuda (nms.h:6-18; nms.cpp:98-119): returns the SUPPRESSED mask (bool[N]).
     Follows the CPU control flow of the reference (nms.cpp:23-59).  sort_keys: optional fp32 tensor that orders like
     `scores` (the scores before their promotion to fp64): half the radix passes of the argsort, same order.
     return_status: (mask, status) with d3d_nms2d_status's bits -- which route decided the mask (waits for the stream).
-    keep_mask: the kernels write the KEEP mask instead (D3D_NMS_KEEP_MASK): box2d_nms's `~suppressed` without the extra pass."""
+    keep_mask: the kernels write the KEEP mask instead (D3D_NMS_KEEP_MASK): box2d_nms's `~suppressed` without the extra pass.
+    wide32 (fp32 boxes and scores): the arithmetic in fp64, the values widened where the kernels load them (D3D_F32_WIDE): what
+    box2d_nms(precise=True) computes for fp32 tensors, without the .double() copies."""
     lib = _lib.load()
     iou_type, supression_type = int(iou_type), int(supression_type)
     if iou_type not in (IouType.BOX, IouType.RBOX):
@@ -327,6 +330,10 @@ def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_thresho
     (b, s), dev = _to_device(boxes, scores)
     n = b.shape[0]
     code = _dtype_code(b)
+    if wide32:
+        if code != _lib.F32:
+            raise ValueError("wide32 takes fp32 boxes and scores")
+        code = _lib.F32_WIDE
     with torch.cuda.device(dev):
         # order = None: the library sorts the scores itself (inside the first kernel for up to 4096 boxes)
         order = None
@@ -360,7 +367,9 @@ def box2d_nms(boxes, scores, iou_method="box", supression_method="hard",
     (boxes, scores), was_numpy = _ingress(boxes, scores)
     # (the order of fp32 scores survives the promotion -- fp32 -> fp64 is monotone and injective -- so the sort may use the narrow keys)
     keys = scores if scores.dtype == torch.float32 else None
-    if precise:
+    # fp32 boxes AND scores, precise: fp64 arithmetic on values widened inside the kernels (D3D_F32_WIDE) instead of .double() copies
+    wide32 = precise and boxes.dtype == torch.float32 and scores.dtype == torch.float32
+    if precise and not wide32:
         boxes, scores = boxes.double(), scores.double()
     if len(boxes) != len(scores):
         raise ValueError("Numbers of boxes and scores are inconsistent!")
@@ -371,7 +380,7 @@ def box2d_nms(boxes, scores, iou_method="box", supression_method="hard",
         return torch.tensor([], dtype=torch.bool)
     # (the reference returns ~suppressed, box/__init__.py:272: here the kernels that decide the mask write it inverted)
     keep = nms2d(boxes, scores, getattr(IouType, iou_method.upper()), getattr(SupressionType, supression_method.upper()),
-                 iou_threshold, score_threshold, supression_param, sort_keys=keys, keep_mask=True)
+                 iou_threshold, score_threshold, supression_param, sort_keys=None if wide32 else keys, keep_mask=True, wide32=wide32)
     return _egress(keep, was_numpy)
 
 

@@ -26,7 +26,8 @@ constexpr int kTileRows = 64;    // rows per tile (LDS-staged)
 // ---------------------------------------------------------------- box loaders
 template <typename T> struct Box2D {     // rows of [.,5] = (x, y, w, h, r)
     static constexpr int kStride = 5;
-    __device__ static BoxGeom<T> load(const T *b) { return make_geom<T>(b[0], b[1], b[2], b[3], b[4]); }
+    // (B: the element type in memory -- T, or float widened to double where it is loaded: D3D_F32_WIDE)
+    template <typename B> __device__ static BoxGeom<T> load(const B *b) { return make_geom<T>((T)b[0], (T)b[1], (T)b[2], (T)b[3], (T)b[4]); }
 };
 
 struct Box3DGeom {
@@ -140,9 +141,9 @@ __device__ __forceinline__ float aabb_gap(const float4 &a, const float4 &b)
 // CORE: the six numbers of a box (centre, half-extent vectors) in one 64-byte (fp64) / 32-byte (fp32) aligned record instead of
 // the 88 / 44-byte BoxGeom: what the rotated clip gathers per candidate -- one sector per box instead of two
 // both operands of a pairwise call in ONE launch (a launch per operand costs ~6 us each at a few thousand boxes)
-template <typename T, bool CORE>
-__global__ __launch_bounds__(256) void k_geom2(const T *__restrict__ b1, int64_t n, BoxGeom<T> *g1, float4 *a1,
-                                               const T *__restrict__ b2, int64_t m, BoxGeom<T> *g2, float4 *a2,
+template <typename T, bool CORE, typename B = T>
+__global__ __launch_bounds__(256) void k_geom2(const B *__restrict__ b1, int64_t n, BoxGeom<T> *g1, float4 *a1,
+                                               const B *__restrict__ b2, int64_t m, BoxGeom<T> *g2, float4 *a2,
                                                IouList *hdr, unsigned int nseg, bool rotated)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -371,8 +372,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 // fallback = five launches of ~5 us each.  Same candidate test (conservative fp32 AABBs, empty for degenerate boxes) and the
 // same per-pair function as the two-phase path: identical values.
 constexpr unsigned long long kIouSmallPairs = 1ull << 16;
-template <typename T, bool ROTATED, typename S = T>
-__global__ __launch_bounds__(256) void k_iou_small(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
+template <typename T, bool ROTATED, typename S = T, typename B = T>
+__global__ __launch_bounds__(256) void k_iou_small(const B *__restrict__ b1, int64_t n, const B *__restrict__ b2, int64_t m,
                                                    S *__restrict__ ious)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -963,8 +964,8 @@ __device__ __forceinline__ void block_reduce_extent(float (&v)[6], float (*sm)[6
 constexpr int kGridScanWgs = (kGridCells + 1 + 1023) / 1024;      // workgroups of k_nms_gridscan
 constexpr int kGridFoldMax = 512;      // most k_nms_prepare partials that k_nms_gridreg folds itself (else: k_nms_extent)
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_nms_prepare(const T *__restrict__ boxes, const T *__restrict__ scores,
+template <typename T, typename B = T /* element type of boxes / scores in memory: T, or float widened on load (D3D_F32_WIDE) */>
+__global__ __launch_bounds__(256) void k_nms_prepare(const B *__restrict__ boxes, const B *__restrict__ scores,
                               const int64_t *__restrict__ order, int64_t n, float score_threshold,
                               BoxCore<T> *geom, float4 *fbox, uint8_t *state, uint32_t *inc_cnt, float *farea,
                               unsigned long long *remv, int64_t nb, NmsFlags *flags, NmsCand *cand_hdr,
@@ -995,7 +996,7 @@ __global__ __launch_bounds__(256) void k_nms_prepare(const T *__restrict__ boxes
         const int32_t bits = __float_as_int(f.x);
         xkey[p] = ~(bits ^ ((bits >> 31) & 0x7fffffff));
         // nms.cpp:23-29: the tail with score <= threshold is suppressed up front, never position 0
-        pre = p > 0 && !(scores[i] > (T)score_threshold);
+        pre = p > 0 && !((T)scores[i] > (T)score_threshold);
         state[p] = pre ? kSuppressed : kUndecided;
         inc_cnt[p] = 0;
         blocked[p] = 0;                     // set by the broad phase for every box that has a better-ranked candidate partner
@@ -1942,8 +1943,8 @@ constexpr int kNmsSmallMax = 4096;
 constexpr int kNmsSmallResolveMax = 1024;     // one box per lane of k_nms_resolve_small; above: k_nms_resolve (state in global
                                               // memory, all CUs: 4 boxes per lane of one workgroup took 106 us at 4 k clustered boxes)
 
-template <typename T>
-__global__ __launch_bounds__(1024) void k_nms_small_front(const T *__restrict__ boxes, const T *__restrict__ scores,
+template <typename T, typename B = T>
+__global__ __launch_bounds__(1024) void k_nms_small_front(const B *__restrict__ boxes, const B *__restrict__ scores,
                                                           const int64_t *__restrict__ order_in, uint32_t n, float score_threshold,
                                                           int64_t *order_out, BoxCore<T> *geom, float4 *fbox, float *farea,
                                                           uint8_t *state, uint32_t *inc_cnt, NmsFlags *flags, NmsCand *cand_hdr,
@@ -1958,7 +1959,7 @@ __global__ __launch_bounds__(1024) void k_nms_small_front(const T *__restrict__ 
     uint32_t *ii = i0;
     if (!order_in) {
         for (uint32_t e = threadIdx.x; e < npad; e += blockDim.x) {
-            d0[e] = e < n ? KeyBits<T>::desc(scores[e]) : ~(U)0;         // padding sorts behind every real entry and is unique
+            d0[e] = e < n ? KeyBits<T>::desc((T)scores[e]) : ~(U)0;         // padding sorts behind every real entry and is unique
             i0[e] = e < n ? e : 0x80000000u + e;
         }
         __syncthreads();
@@ -1979,7 +1980,7 @@ __global__ __launch_bounds__(1024) void k_nms_small_front(const T *__restrict__ 
             fbox[p] = make_float4(round_down(g.xmin), round_down(g.ymin), round_up(g.xmax), round_up(g.ymax));
             farea[p] = round_down(g.area);
             // nms.cpp:23-29: the tail with score <= threshold is suppressed up front, never position 0
-            pre = p > 0 && !(scores[i] > (T)score_threshold);
+            pre = p > 0 && !((T)scores[i] > (T)score_threshold);
             state[p] = pre ? kSuppressed : kUndecided;
             inc_cnt[p] = 0;
         }
@@ -2191,8 +2192,8 @@ static inline bool nms_small_eligible(int64_t n, uint32_t opts)
     return n <= kNmsSmallMax && !(opts & (D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_GENERAL | D3D_NMS_FORCE_LEVELS)) && (opts >> 8) == 0;
 }
 
-template <typename T>
-int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, int iou_type, float iou_thr,
+template <typename T, typename B = T>
+int nms_typed(const B *boxes, const B *scores, const int64_t *order, int64_t n, int iou_type, float iou_thr,
               float score_thr, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st, uint32_t opts, int64_t *order_ws,
               int32_t *host_word)
 {
@@ -2248,10 +2249,10 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
         while ((int64_t)npad < n) npad <<= 1;
         const size_t lds = order ? 0 : (size_t)npad * (2 * sizeof(U) + 8);
         if (lds > 65536)
-            D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nms_small_front<T>),
+            D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nms_small_front<T, B>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t *ord = order ? order : order_ws;
-        D3D_LAUNCH("k_nms_small_front", k_nms_small_front<T>, dim3(1), dim3(1024), lds, st, boxes, scores, order, (uint32_t)n, score_thr,
+        D3D_LAUNCH("k_nms_small_front", (k_nms_small_front<T, B>), dim3(1), dim3(1024), lds, st, boxes, scores, order, (uint32_t)n, score_thr,
                    order_ws, geom, fbox, farea, state, inc_cnt, flags, cand_hdr, remv);
         D3D_LAUNCH("k_nms_cand_all", k_nms_cand_all, dim3((unsigned)d3d_divup(n, 256), (unsigned)nb), dim3(256), 0, st,
                    (const float4 *)fbox, (const float *)farea, (uint32_t)n, rot ? iou_thr : -1.f, cand, cap, cand_hdr, flags);
@@ -2283,7 +2284,7 @@ int nms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, 
     }
     const bool use_grid = !(opts & D3D_NMS_BROAD_SWEEP);
     const unsigned nbl = (unsigned)d3d_divup(n, 256);
-    D3D_LAUNCH("k_nms_prepare", k_nms_prepare<T>, dim3(nbl), dim3(256), 0, st, boxes, scores, order, n, score_thr,
+    D3D_LAUNCH("k_nms_prepare", (k_nms_prepare<T, B>), dim3(nbl), dim3(256), 0, st, boxes, scores, order, n, score_thr,
                geom, fbox, state, inc_cnt, farea, remv, nb, flags, cand_hdr, (opts & D3D_NMS_FORCE_DENSE) ? 1u : 0u, xkey, &grid->ticket, tile_tot, gpartial, cellcur, chunk_tot, blocked,
                (opts & D3D_NMS_FORCE_LEVELS) ? 1u : 0u);
     if (use_grid) {
@@ -2407,8 +2408,8 @@ template <> __device__ __forceinline__ double soft_decay<double>(double iou, flo
     return sup == D3D_SUPPRESS_LINEAR ? 1 - pow(iou, (double)param) : exp(-iou * iou / (double)param);
 }
 
-template <typename T, bool ROTATED>
-__global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ boxes, const T *__restrict__ scores,
+template <typename T, bool ROTATED, typename B = T>
+__global__ __launch_bounds__(kSoftThreads) void k_softnms(const B *__restrict__ boxes, const B *__restrict__ scores,
                                                           const int64_t *__restrict__ order_in, int n, int sup,
                                                           float iou_thr, float score_thr, float param,
                                                           BoxGeom<T> *geom, float4 *aabb, int *g_ord, T *g_sc, uint8_t *g_sp,
@@ -2425,7 +2426,7 @@ __global__ __launch_bounds__(kSoftThreads) void k_softnms(const T *__restrict__ 
     for (int p = tid; p < n; p += kSoftThreads) {
         const int i = (int)order_in[p];
         ord[p] = p;                                          // initial rank of the box now at position p
-        sc[p] = scores[i];                                   // nms.cpp:104: the scores are copied
+        sc[p] = (T)scores[i];                                // nms.cpp:104: the scores are copied
         const BoxGeom<T> g = Box2D<T>::load(boxes + (size_t)i * 5);
         geom[p] = g;                                         // geometry by initial rank
         aabb[p] = cand_aabb(g, ROTATED);                     // 16 bytes: what the inner loop gathers first
@@ -2591,8 +2592,8 @@ extern "C" size_t d3d_iou2d_workspace_bytes(int64_t n, int64_t m, int32_t dtype)
            256;
 }
 
-template <typename T, bool ROTATED, typename S = T>
-static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, S *ious, void *ws, size_t ws_bytes, hipStream_t st,
+template <typename T, bool ROTATED, typename S = T, typename B = T>
+static int iou2d_two_phase(const B *b1, int64_t n, const B *b2, int64_t m, S *ious, void *ws, size_t ws_bytes, hipStream_t st,
                            uint32_t opts)
 {
     WsCarver w(ws, ws_bytes);
@@ -2605,7 +2606,7 @@ static int iou2d_two_phase(const T *b1, int64_t n, const T *b2, int64_t m, S *io
     unsigned long long *list = w.take<unsigned long long>(cap);
     if (!w.ok()) return D3D_ERR_WORKSPACE;
     if ((opts >> 8) != 0 && (unsigned long long)(opts >> 8) < cap) cap = opts >> 8;     // D3D_IOU_LIST_CAP: use less of it
-    D3D_LAUNCH("k_geom", (k_geom2<T, ROTATED>), dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, ga, ra, b2, m, gb, cb,
+    D3D_LAUNCH("k_geom", (k_geom2<T, ROTATED, B>), dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, ga, ra, b2, m, gb, cb,
                hdr, list_segments(cap), ROTATED);
     S *fill = ious;
     if (reinterpret_cast<uintptr_t>(ious) & 15) {             // unaligned output: plain memset, candidates only
@@ -2624,10 +2625,10 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || m < 0 || (flags & 0xffu)) return D3D_ERR_BAD_ARG;
-    if (dtype != D3D_F32 && dtype != D3D_F64 && dtype != D3D_F64_M32) return D3D_ERR_BAD_ARG;
+    if (dtype != D3D_F32 && dtype != D3D_F64 && dtype != D3D_F64_M32 && dtype != D3D_F32_WIDE) return D3D_ERR_BAD_ARG;
     const bool loss_kind = iou_type == D3D_IOU_GRBOX || iou_type == D3D_IOU_DRBOX;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX && !loss_kind) return D3D_ERR_UNSUPPORTED;
-    if (loss_kind && dtype == D3D_F64_M32) return D3D_ERR_UNSUPPORTED;
+    if (loss_kind && (dtype == D3D_F64_M32 || dtype == D3D_F32_WIDE)) return D3D_ERR_UNSUPPORTED;
     if (n == 0 || m == 0) return D3D_OK;
     if (!boxes1 || !boxes2 || !ious) return D3D_ERR_BAD_ARG;
     if (loss_kind) {        // GIoU / DIoU: every pair has a value (boxloss.hip); GIoU lists the pairs that need the clip
@@ -2642,7 +2643,10 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     const bool rot = iou_type == D3D_IOU_RBOX;
     if ((unsigned long long)n * (unsigned long long)m <= kIouSmallPairs && (flags >> 8) == 0) {      // (a list-cap flag asks for the list path)
         const dim3 sgrid((unsigned)d3d_divup(n * m, 256));
-        if (dtype == D3D_F64_M32) {
+        if (dtype == D3D_F32_WIDE) {
+            if (rot) D3D_LAUNCH("k_iou_small", (k_iou_small<double, true, float, float>), sgrid, dim3(256), 0, st, (const float *)boxes1, n, (const float *)boxes2, m, (float *)ious);
+            else D3D_LAUNCH("k_iou_small", (k_iou_small<double, false, float, float>), sgrid, dim3(256), 0, st, (const float *)boxes1, n, (const float *)boxes2, m, (float *)ious);
+        } else if (dtype == D3D_F64_M32) {
             if (rot) D3D_LAUNCH("k_iou_small", (k_iou_small<double, true, float>), sgrid, dim3(256), 0, st, (const double *)boxes1, n, (const double *)boxes2, m, (float *)ious);
             else D3D_LAUNCH("k_iou_small", (k_iou_small<double, false, float>), sgrid, dim3(256), 0, st, (const double *)boxes1, n, (const double *)boxes2, m, (float *)ious);
         } else if (dtype == D3D_F64) {
@@ -2657,6 +2661,10 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
     if (workspace && workspace_bytes >= d3d_iou2d_workspace_bytes(n, m, dtype)) {
         // zero fill + candidate list + one candidate per lane (BOX too: its IoU is non-zero only where the AABBs overlap)
 #define D3D_TWO_PHASE(T, R) iou2d_two_phase<T, R>((const T *)boxes1, n, (const T *)boxes2, m, (T *)ious, workspace, workspace_bytes, st, flags)
+        if (dtype == D3D_F32_WIDE) {
+            if (rot) return iou2d_two_phase<double, true, float, float>((const float *)boxes1, n, (const float *)boxes2, m, (float *)ious, workspace, workspace_bytes, st, flags);
+            return iou2d_two_phase<double, false, float, float>((const float *)boxes1, n, (const float *)boxes2, m, (float *)ious, workspace, workspace_bytes, st, flags);
+        }
         if (dtype == D3D_F64_M32) {
             if (rot) return iou2d_two_phase<double, true, float>((const double *)boxes1, n, (const double *)boxes2, m, (float *)ious, workspace, workspace_bytes, st, flags);
             return iou2d_two_phase<double, false, float>((const double *)boxes1, n, (const double *)boxes2, m, (float *)ious, workspace, workspace_bytes, st, flags);
@@ -2665,7 +2673,7 @@ extern "C" int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxe
         return rot ? D3D_TWO_PHASE(float, true) : D3D_TWO_PHASE(float, false);
 #undef D3D_TWO_PHASE
     }
-    if (dtype == D3D_F64_M32) return D3D_ERR_WORKSPACE;       // (the mixed form has no workspace-free kernel)
+    if (dtype == D3D_F64_M32 || dtype == D3D_F32_WIDE) return D3D_ERR_WORKSPACE;       // (the mixed forms have no workspace-free kernel)
     // single-kernel path: no workspace
     const bool al16 = (reinterpret_cast<uintptr_t>(ious) & 15) == 0;
 #define D3D_IOU2D(T, R, K)                                                                                          \
@@ -2765,8 +2773,8 @@ extern "C" int d3d_match_distance(const float *src, int64_t n, const float *dst,
 }
 
 constexpr size_t kSoftLdsBytes = 128 * 1024;      // position-indexed state of the soft-NMS kernel stays in LDS below this
-template <typename T, bool ROTATED>
-static int softnms_typed(const T *boxes, const T *scores, const int64_t *order, int64_t n, int sup, float iou_thr,
+template <typename T, bool ROTATED, typename B = T>
+static int softnms_typed(const B *boxes, const B *scores, const int64_t *order, int64_t n, int sup, float iou_thr,
                          float score_thr, float param, uint8_t *suppressed, void *ws, size_t ws_bytes, hipStream_t st, uint32_t opts)
 {
     WsCarver w(ws, ws_bytes);
@@ -2779,9 +2787,9 @@ static int softnms_typed(const T *boxes, const T *scores, const int64_t *order, 
     const size_t lds = (size_t)n * (sizeof(T) + 4 + 1);
     const bool in_lds = lds <= kSoftLdsBytes && !(opts & D3D_NMS_SOFT_NO_LDS);    // (flag: the global-scratch variant)
     if (in_lds)
-        D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softnms<T, ROTATED>),
+        D3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softnms<T, ROTATED, B>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSoftLdsBytes));
-    D3D_LAUNCH("k_softnms", (k_softnms<T, ROTATED>), dim3(1), dim3(kSoftThreads), in_lds ? lds : 0, st, boxes, scores, order, (int)n,
+    D3D_LAUNCH("k_softnms", (k_softnms<T, ROTATED, B>), dim3(1), dim3(kSoftThreads), in_lds ? lds : 0, st, boxes, scores, order, (int)n,
                sup, iou_thr, score_thr, param, geom, aabb, ord, sc, sp, in_lds ? 1 : 0, suppressed, (uint8_t)((opts & D3D_NMS_KEEP_MASK) ? 1 : 0));
     return D3D_OK;
 }
@@ -2814,7 +2822,7 @@ static int nms2d_impl(const void *boxes, const void *scores, const int64_t *orde
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || (flags & 0xffu & ~(uint32_t)(D3D_NMS_BROAD_SWEEP | D3D_NMS_FORCE_DENSE | D3D_NMS_SOFT_NO_LDS | D3D_NMS_GENERAL | D3D_NMS_TEST_WITHHOLD | D3D_NMS_FORCE_LEVELS | D3D_NMS_ONE_LEVEL | D3D_NMS_KEEP_MASK))) return D3D_ERR_BAD_ARG;
-    if (dtype != D3D_F32 && dtype != D3D_F64) return D3D_ERR_BAD_ARG;
+    if (dtype != D3D_F32 && dtype != D3D_F64 && dtype != D3D_F32_WIDE) return D3D_ERR_BAD_ARG;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX) return D3D_ERR_UNSUPPORTED;   // common.h:25
     if (suppression_type != D3D_SUPPRESS_HARD && suppression_type != D3D_SUPPRESS_LINEAR &&
         suppression_type != D3D_SUPPRESS_GAUSSIAN)
@@ -2829,7 +2837,9 @@ static int nms2d_impl(const void *boxes, const void *scores, const int64_t *orde
     const bool small = suppression_type == D3D_SUPPRESS_HARD && nms_small_eligible(n, flags);
     if (!order && !small) {
         char *sort_ws = reinterpret_cast<char *>(order_ws) + d3d_align_up((size_t)n * 8);
-        const int rc = d3d_argsort_desc(scores, n, dtype, order_ws, sort_ws, d3d_argsort_desc_workspace_bytes(n, dtype), stream);
+        // (D3D_F32_WIDE: the order of the fp32 scores is the order of their widened values)
+        const int sdt = dtype == D3D_F32_WIDE ? D3D_F32 : dtype;
+        const int rc = d3d_argsort_desc(scores, n, sdt, order_ws, sort_ws, d3d_argsort_desc_workspace_bytes(n, sdt), stream);
         if (rc) return rc;
         order = order_ws;
     }
@@ -2840,6 +2850,13 @@ static int nms2d_impl(const void *boxes, const void *scores, const int64_t *orde
         // insertion pass that is itself quadratic per round).  No size limit of its own (nms.cpp has none)
         if (n >= (1ll << 31) - 64) return D3D_ERR_BAD_ARG;
         const bool rot = iou_type == D3D_IOU_RBOX;
+        if (dtype == D3D_F32_WIDE)
+            return rot ? softnms_typed<double, true, float>((const float *)boxes, (const float *)scores, order, n, suppression_type,
+                                                            iou_threshold, score_threshold, suppression_param, suppressed, workspace,
+                                                            workspace_bytes, st, flags)
+                       : softnms_typed<double, false, float>((const float *)boxes, (const float *)scores, order, n, suppression_type,
+                                                             iou_threshold, score_threshold, suppression_param, suppressed, workspace,
+                                                             workspace_bytes, st, flags);
         if (dtype == D3D_F64)
             return rot ? softnms_typed<double, true>((const double *)boxes, (const double *)scores, order, n, suppression_type,
                                                      iou_threshold, score_threshold, suppression_param, suppressed, workspace,
@@ -2855,6 +2872,9 @@ static int nms2d_impl(const void *boxes, const void *scores, const int64_t *orde
                                                  workspace_bytes, st, flags);
     }
     if (d3d_divup(n, 64) > 65535) return D3D_ERR_BAD_ARG;
+    if (dtype == D3D_F32_WIDE)
+        return nms_typed<double, float>((const float *)boxes, (const float *)scores, order, n, iou_type, iou_threshold,
+                                        score_threshold, suppressed, workspace, nms_bytes, st, flags, order_ws, host_word);
     if (dtype == D3D_F64)
         return nms_typed<double>((const double *)boxes, (const double *)scores, order, n, iou_type, iou_threshold,
                                  score_threshold, suppressed, workspace, nms_bytes, st, flags, order_ws, host_word);

@@ -49,7 +49,11 @@ enum { D3D_F32 = 0, D3D_F64 = 1,
         * (ious written, grad read) f32 -- every value rounded where it is stored / widened where it is read.  The results of
         * box2d_iou(precise=True) on fp32 boxes (reference box/__init__.py:204-205, 224: boxes.double(), ious.to(dtype)) without
         * the fp64 copy of the matrix: a third of the bytes. */
-       D3D_F64_M32 = 2 };
+       D3D_F64_M32 = 2,
+       /* d3d_iou2d_forward (BOX / RBOX), d3d_nms2d: everything in memory f32 (boxes, scores, the matrix), the arithmetic f64 --
+        * every value widened where it is loaded.  box2d_iou / box2d_nms (precise=True) on fp32 tensors without the .double()
+        * copies either (box/__init__.py:204-205, 254-255). */
+       D3D_F32_WIDE = 3 };
 
 /* status bits OR-ed into counts[D3D_COUNT_STATUS] by the voxel kernels */
 enum { D3D_VOXEL_STATUS_COORD_OVERFLOW = 1,   /* sparse: 2^20 <= |floor(p/size)| < 2^31 (NaN, inf and
@@ -574,7 +578,9 @@ size_t d3d_nms2d_workspace_bytes(int64_t n);
  *   before any pair is listed; automatic on dense grids: clusters of detections) on any input, implies the general path;
  *   D3D_NMS_ONE_LEVEL = one level of them instead of two (clusters of a few boxes).
  *   All give the same mask.
- *   soft-NMS has no size limit of its own (100 k boxes with most of them alive: seconds). */
+ *   soft-NMS has no size limit of its own (100 k boxes with most of them alive: seconds).
+ *   dtype: D3D_F32 / D3D_F64 (boxes and scores), or D3D_F32_WIDE = f32 in memory, f64 arithmetic (what box2d_nms(precise=True)
+ *   computes for fp32 tensors, box/__init__.py:254-255, without the copies). */
 enum { D3D_NMS_BROAD_SWEEP = 1, D3D_NMS_FORCE_DENSE = 2, D3D_NMS_SOFT_NO_LDS = 4, D3D_NMS_GENERAL = 8, D3D_NMS_TEST_WITHHOLD = 16,
        D3D_NMS_FORCE_LEVELS = 32, D3D_NMS_ONE_LEVEL = 64,
        D3D_NMS_KEEP_MASK = 128   /* `suppressed` receives the KEEP mask -- what box2d_nms returns, ~suppressed (reference

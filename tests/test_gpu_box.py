@@ -642,7 +642,7 @@ def test_c_abi_error_codes():
     assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 3, _lib.F64, p(out), z, 0, z, 0) == _lib.ERR_UNSUPPORTED    # GBOX
     assert lib.d3d_iou2d_forward(p(b), 0, p(b), 4, 2, _lib.F64, z, z, 0, z, 0) == 0                             # empty: ok
     assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 4, _lib.F64_M32, p(out), z, 0, z, 0) == _lib.ERR_UNSUPPORTED  # GRBOX with an fp32 matrix
-    assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 2, 3, p(out), z, 0, z, 0) == _lib.ERR_BAD_ARG                # unknown dtype code
+    assert lib.d3d_iou2d_forward(p(b), 4, p(b), 4, 2, 7, p(out), z, 0, z, 0) == _lib.ERR_BAD_ARG                # unknown dtype code
     big = torch.zeros((300, 5), dtype=torch.float64, device="cuda")
     o32 = torch.zeros((300, 300), dtype=torch.float32, device="cuda")
     assert lib.d3d_iou2d_forward(p(big), 300, p(big), 300, 2, _lib.F64_M32, p(o32), z, 0, z, 0) == _lib.ERR_WORKSPACE   # mixed form: list path only
@@ -965,6 +965,8 @@ def test_precise_on_fp32_boxes_rounds_where_the_matrix_is_stored(method, shape):
         c1, c2 = T(b1).requires_grad_(True), T(b2).requires_grad_(True)
         chain = fn.apply(c1.double(), c2.double()).to(torch.float32)
         assert torch.equal(got, chain)
+        from d3d_amd.box import _iou_forward
+        assert torch.equal(_iou_forward(T(b1).double(), T(b2).double(), IouType[method.upper()], matrix32=True), got.detach())   # D3D_F64_M32
         exp = oracle.box2d_iou(b1.astype(np.float64), b2.astype(np.float64), method, nthreads=4)
         assert np.max(np.abs(got.detach().cpu().numpy().astype(np.float64) - exp)) <= 6.1e-8
         w = torch.from_numpy((np.random.default_rng(5).random((n, m)) - 0.3).astype(np.float32)).cuda()
@@ -1012,3 +1014,31 @@ def test_nms_keep_mask_is_the_inverted_suppressed_mask(n, nms_broad):
         for sm in (1, 2):
             sup = nms2d(bt, st, IouType.RBOX, sm, 0.3, 0.1, 0.5)
             assert torch.equal(nms2d(bt, st, IouType.RBOX, sm, 0.3, 0.1, 0.5, keep_mask=True), ~sup)
+
+
+@pytest.mark.parametrize("n", [100, 1500, 3000, 20000])
+def test_nms_precise_on_fp32_tensors_widens_inside_the_kernels(n, nms_broad):
+    """box2d_nms(precise=True) on fp32 boxes and scores (reference box/__init__.py:254-255: boxes.double(), scores.double()) runs
+    as D3D_F32_WIDE -- fp64 arithmetic on values widened where they are loaded, the score order from the fp32 keys: the masks
+    of the explicit fp64 call, ties in the scores included; soft-NMS too"""
+    from d3d_amd import synth
+    from d3d_amd.box import box2d_nms
+    b, s = synth.boxes2d_dense(n, 81) if n <= 3000 else synth.boxes2d_sparse(n, 81)
+    b32 = b.astype(np.float32)
+    for ties in (False, True):
+        s32 = (np.round(s * 50) / 50 if ties else s).astype(np.float32)
+        bt, st = T(b32), T(s32)
+        keep = box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.3, score_threshold=0.1)
+        wide = box2d_nms(bt.double(), st.double(), iou_method="rbox", iou_threshold=0.3, score_threshold=0.1)
+        assert torch.equal(keep, wide) and 0 < int(keep.sum()) < n
+        if not ties:
+            assert np.array_equal(keep.cpu().numpy(), oracle.box2d_nms(b32.astype(np.float64), s32.astype(np.float64), iou_method="rbox",
+                                                                       iou_threshold=0.3, score_threshold=0.1))
+    assert torch.equal(box2d_nms(bt, st, iou_method="box", iou_threshold=0.5), box2d_nms(bt.double(), st.double(), iou_method="box", iou_threshold=0.5))
+    if n <= 1500 and nms_broad == "auto":
+        for sup, prm in (("linear", 1.0), ("gaussian", 0.5)):
+            kw = dict(iou_method="rbox", supression_method=sup, iou_threshold=0.3, score_threshold=0.2, supression_param=prm)
+            assert torch.equal(box2d_nms(bt, st, **kw), box2d_nms(bt.double(), st.double(), **kw))
+    # [N,K] class scores: the class maximum commutes with the widening
+    sk = torch.stack([st, st * 0.5], dim=1)
+    assert torch.equal(box2d_nms(bt, sk, iou_method="rbox", iou_threshold=0.3), box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.3))
