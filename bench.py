@@ -497,6 +497,17 @@ def extras(args):
     b32 = torch.from_numpy(b[:20000].astype(np.float32)).cuda()
     dt = timed(lambda: box2d_iou(b32, b32, method="rbox"), 5, 1)
     dtc = timed(lambda: Iou2DR.apply(b32.double(), b32.double()).to(torch.float32), 5, 1)
+    # call latency at a detector's sizes, fp32 tensors through the default (precise=True) forms: D3D_F32_WIDE, no cast launches
+    bsm = torch.from_numpy(synth.boxes2d_dense(2000, 7)[0].astype(np.float32)).cuda()
+    ssm = torch.from_numpy(synth.boxes2d_dense(2000, 7)[1].astype(np.float32)).cuda()
+    lat = {}
+    for key, fn in (("box2d_iou_100x50", lambda: box2d_iou(bsm[:100], bsm[100:150], method="rbox")),
+                    ("box2d_iou_1000x200", lambda: box2d_iou(bsm[:1000], bsm[1000:1200], method="rbox")),
+                    ("box2d_nms_500", lambda: box2d_nms(bsm[:500], ssm[:500], iou_method="rbox", iou_threshold=0.3)),
+                    ("box2d_nms_2000", lambda: box2d_nms(bsm, ssm, iou_method="rbox", iou_threshold=0.3))):
+        lat[key] = round(1e6 * timed(fn, 200, 5) / 200, 1)
+    ex["call_latency_fp32_tensors_us"] = lat
+    del bsm, ssm
     ex["box2d_iou_precise_fp32_boxes_20kx20k_ms"] = dict(fp32_matrix=round(1e3 * dt / 5, 3), fp64_matrix_then_cast=round(1e3 * dtc / 5, 3))
     del b32
     torch.cuda.empty_cache()
