@@ -200,6 +200,42 @@ def workspace(nbytes, device):
     return buf
 
 
+_PINNED_RESULT_MIN_BYTES = 1 << 20
+
+
+def to_caller(results, odev, dev):
+    """results (a tensor, or a dict / tuple of tensors on `dev`) on the CALLER's device `odev` -- the reference's operators take
+    and return CPU tensors (voxelize.cpp), so a drop-in caller may hand over host tensors and expects host tensors back.  To the
+    host, tensors of 1 MiB and more go through torch's pinned host allocator (cached blocks) with asynchronous copies and ONE
+    wait on the stream: config 2's 328 MB of dense outputs take 6.5 ms that way instead of 47 ms for pageable destinations
+    (tensor.to("cpu") allocates and faults in fresh pages, then copies through a staging buffer).  The tensors that come back
+    are ordinary CPU tensors whose memory happens to be page-locked."""
+    if odev == dev:
+        return results
+    if isinstance(results, dict):
+        keys = list(results)
+        vals = to_caller(tuple(results[k] for k in keys), odev, dev)
+        return {k: v for k, v in zip(keys, vals)}
+    single = torch.is_tensor(results)
+    seq = (results,) if single else tuple(results)
+    if odev.type != "cpu":
+        out = tuple(t.to(odev) for t in seq)
+    else:
+        out, pending = [], False
+        for t in seq:
+            if t.numel() * t.element_size() >= _PINNED_RESULT_MIN_BYTES:
+                h = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                out.append(h)
+                pending = True
+            else:
+                out.append(t.to(odev))
+        if pending:
+            torch.cuda.current_stream(dev).synchronize()
+        out = tuple(out)
+    return out[0] if single else out
+
+
 class HostWord:
     """host-mapped pinned int32 word, one per thread: d3d_nms2d_notify's density verdict lands here"""
     _local = threading.local()

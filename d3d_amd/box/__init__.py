@@ -85,7 +85,7 @@ def _iou_forward(boxes1, boxes2, iou_type, flags=None, matrix32=False, wide32=Fa
             rc = lib.d3d_iou2d_forward(_lib.ptr(b1[r0:r1]), r1 - r0, _lib.ptr(b2), m, int(iou_type), code, _lib.ptr(ious[r0:r1]),
                                        _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr(), fl)
             _lib.check(rc, "iou2d_forward")
-    return ious.to(odev) if odev != dev else ious
+    return _lib.to_caller(ious, odev, dev)
 
 
 def iou2d_forward(boxes1, boxes2):
@@ -353,7 +353,7 @@ def nms2d(boxes, scores, iou_type, supression_type, iou_threshold, score_thresho
         if return_status and n > 0:
             _lib.check(lib.d3d_nms2d_status(_lib.ptr(ws), supression_type, _lib.stream_ptr(), ctypes.byref(status)), "nms2d_status")
     sup = sup.view(torch.bool)
-    sup = sup.to(odev) if odev != dev else sup
+    sup = _lib.to_caller(sup, odev, dev)
     return (sup, int(status.value)) if return_status else sup
 
 
@@ -411,8 +411,7 @@ def iou3d(boxes1, boxes2, method="rbox"):
         rc = lib.d3d_iou3d_forward(_lib.ptr(b1), n, _lib.ptr(b2), m, 1 if key == "RBOX" else 0, _lib.ptr(out),
                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
     _lib.check(rc, "iou3d_forward")
-    if odev != dev:
-        out = out.to(odev)
+    out = _lib.to_caller(out, odev, dev)
     return out.numpy() if convert_numpy else out
 
 
@@ -432,7 +431,7 @@ def crop_2dr(points, boxes):
         rc = lib.d3d_crop_2dr(_lib.ptr(p), n, _lib.ptr(b), m, _dtype_code(p), _lib.ptr(out), _lib.stream_ptr())
     _lib.check(rc, "crop_2dr")
     out = out.view(torch.bool)
-    return out.to(odev) if odev != dev else out
+    return _lib.to_caller(out, odev, dev)
 
 
 def box2dr_crop(points, boxes):

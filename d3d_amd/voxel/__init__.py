@@ -238,8 +238,7 @@ def voxelize_3d_dense(points, voxel_shape, voxel_bound, max_points, max_voxels, 
                voxel_npoints=npts[:nv])
     if red != 0:
         ret["aggregates"] = agg[:nv]
-    if odev != dev:
-        ret = {k: v.to(odev) for k, v in ret.items()}
+    ret = _lib.to_caller(ret, odev, dev)
     return ret
 
 
@@ -269,8 +268,7 @@ def voxelize_3d_sparse(points, voxel_size, ndim=3, flags=None):
             return int(_counts_to_host(counts, "voxelize_3d_sparse")[_lib.COUNT_VOXELS])
         nv = _with_retry(run, flags)
     ret = dict(points_mapping=mapping, coords=coords[:nv], voxel_npoints=npts[:nv])
-    if odev != dev:
-        ret = {k: v.to(odev) for k, v in ret.items()}
+    ret = _lib.to_caller(ret, odev, dev)
     return ret
 
 
@@ -322,8 +320,7 @@ def voxelize_3d_filter(feats, points_mapping, coords, voxel_npoints, coords_boun
         k, v = int(host[_lib.COUNT_POINTS]), int(host[_lib.COUNT_VOXELS])
     ret = dict(points=o_feats[:k], points_mask=o_mask[:k], points_mapping=o_map[:k],
                voxel_npoints=o_cnt[:v], coords=o_crd[:v])
-    if odev != dev:
-        ret = {kk: vv.to(odev) for kk, vv in ret.items()}
+    ret = _lib.to_caller(ret, odev, dev)
     return ret
 
 
@@ -464,8 +461,7 @@ def _sparse_filter_planned(plan, points, flags=None):
                    points_mapping=buf[off[2]:off[2] + k * 8].view(torch.int64),
                    voxel_npoints=buf[off[3]:off[3] + v * 4].view(torch.int32),
                    coords=buf[off[4]:off[4] + v * 24].view(torch.int64).view(v, 3))
-    if odev != dev:
-        ret = {kk: vv.to(odev) for kk, vv in ret.items()}
+    ret = _lib.to_caller(ret, odev, dev)
     return ret
 
 
@@ -583,7 +579,7 @@ class VoxelGenerator:
                     off = self._offset_dev[ret.coords.device] = self._offset.to(ret.coords.device)
                 ret.coords = ret.coords - off                                                 # :103
         if odev != points.device:
-            ret = Dict({k: v.to(odev) for k, v in ret.items()})
+            ret = Dict(_lib.to_caller(dict(ret), odev, points.device))
         return ret
 
 
