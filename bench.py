@@ -415,6 +415,23 @@ def extras(args):
     del res
     dt = timed(lambda: gen(cloud), 20, 3)
     ex["voxelize_sparse_trim_mpoints_per_s"] = round(args.points * 20 / dt / 1e6, 2)
+    # the reference's calling convention -- CPU tensor in, CPU tensors out (its voxelizer is a CPU operator): the PCIe-inclusive rate
+    # (never `value`): staged in, computed on the device, results back through the pinned host allocator (_lib.to_caller)
+    cloud_h = cloud.cpu()
+    gen_d = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=32, max_voxels=args.points)
+    pcie = {}
+    for key, g in (("dense_mean", gen_d), ("sparse_trim", gen)):
+        for _ in range(4):           # (the pinned allocator's cache fills: two result sets are alive at a time in this loop)
+            r = g(cloud_h)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            r = g(cloud_h)
+        dth = (time.perf_counter() - t0) / 3
+        pcie[key] = dict(ms_per_call=round(1e3 * dth, 2), mpoints_per_s=round(args.points / dth / 1e6, 1),
+                         bytes_back=int(sum(v.numel() * v.element_size() for v in r.values() if torch.is_tensor(v))))
+        del r
+    ex["voxelize_cpu_tensors_in_and_out_pcie_inclusive"] = pcie
+    del cloud_h, gen_d
     # compulsory bytes of sparse + filter = N C 4 in + N' (C 4 + 8 + 8) + V' (24 + 4) out (62 B/point at config 2).
     # No single kernel of this path is HBM-bound (ten latency- / request-bound launches over 62 MB): the whole-operator rate
     # against the peak is the figure, the per-kernel durations say where the time goes.
