@@ -128,24 +128,30 @@ def iou2dr_flags(boxes1, boxes2, which=("nx", "xflags")):
     return {k: (v.to(odev) if odev != dev else v) for k, v in out.items()}
 
 
-def _iou_backward(boxes1, boxes2, grad, iou_type, matrix32=False):
-    """matrix32 (fp64 boxes, BOX / RBOX): `grad` is read as fp32 and widened in the kernels (D3D_F64_M32)"""
+def _iou_backward(boxes1, boxes2, grad, iou_type, matrix32=False, wide32=False):
+    """matrix32 (fp64 boxes, BOX / RBOX): `grad` is read as fp32 and widened in the kernels (D3D_F64_M32);
+    wide32 (fp32 boxes, BOX / RBOX): the boxes too (D3D_F32_WIDE) -- the sums are kept in fp64 and come back rounded to fp32"""
     lib = _lib.load()
     odev = boxes1.device
-    (b1, b2, g), dev = _to_device(boxes1.detach(), boxes2.detach(), grad.to(torch.float32 if matrix32 else boxes1.dtype))
+    mixed = matrix32 or wide32
+    (b1, b2, g), dev = _to_device(boxes1.detach(), boxes2.detach(), grad.to(torch.float32 if mixed else boxes1.dtype))
     n, m = b1.shape[0], b2.shape[0]
     code = _dtype_code(b1)
-    if matrix32:
-        if code != _lib.F64 or int(iou_type) not in (IouType.BOX, IouType.RBOX):
-            raise ValueError("matrix32 takes fp64 boxes and the box / rbox methods")
-        code = _lib.F64_M32
+    if mixed:
+        if code != (_lib.F32 if wide32 else _lib.F64) or int(iou_type) not in (IouType.BOX, IouType.RBOX):
+            raise ValueError("matrix32 takes fp64 boxes, wide32 fp32 boxes, both the box / rbox methods")
+        code = _lib.F32_WIDE if wide32 else _lib.F64_M32
     with torch.cuda.device(dev):
-        g1 = torch.empty((n, 5), dtype=b1.dtype, device=dev)
-        g2 = torch.empty((m, 5), dtype=b1.dtype, device=dev)
+        # both results in ONE buffer: the library then clears them with one launch, and the wide form rounds them with one
+        gg = torch.empty((n + m, 5), dtype=torch.float64 if wide32 else b1.dtype, device=dev)
+        g1, g2 = gg[:n], gg[n:]
         ws = _lib.workspace(lib.d3d_iou2d_workspace_bytes(n, m, code), dev)
         rc = lib.d3d_iou2d_backward(_lib.ptr(b1), n, _lib.ptr(b2), m, _lib.ptr(g), int(iou_type), code, _lib.ptr(g1),
                                     _lib.ptr(g2), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
-    _lib.check(rc, "iou2d_backward")
+        _lib.check(rc, "iou2d_backward")
+        if wide32:
+            gg = gg.to(torch.float32)
+            g1, g2 = gg[:n], gg[n:]
     return (g1.to(odev), g2.to(odev)) if odev != dev else (g1, g2)
 
 
@@ -241,8 +247,8 @@ class _IouPrecise32(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         boxes1, boxes2 = ctx.saved_tensors
-        g1, g2 = _iou_backward(boxes1.double(), boxes2.double(), grad.contiguous(), ctx.iou_type, matrix32=True)
-        return g1.to(boxes1.dtype), g2.to(boxes2.dtype), None
+        g1, g2 = _iou_backward(boxes1, boxes2, grad.contiguous(), ctx.iou_type, wide32=True)
+        return g1, g2, None
 
 
 _IOU_FUNCTIONS = {IouType.BOX: Iou2D, IouType.RBOX: Iou2DR, IouType.GRBOX: GIou2DR, IouType.DRBOX: DIou2DR}

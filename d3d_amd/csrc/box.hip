@@ -571,8 +571,8 @@ __device__ __forceinline__ bool grad_marks_dense(const unsigned long long *nmark
 
 // a frame's worth of pairs (<= kIouSmallPairs): ONE launch, one pair per lane, geometry rebuilt per pair, atomics per pair --
 // the marks / decision / tiles / compaction above are five launches of ~5 us each, more than the arithmetic at this size
-template <typename T, bool ROTATED, typename G = T>
-__global__ __launch_bounds__(256) void k_iou_grad_small(const T *__restrict__ b1, int64_t n, const T *__restrict__ b2, int64_t m,
+template <typename T, bool ROTATED, typename G = T, typename B = T /* element of the box rows in memory (D3D_F32_WIDE: float) */>
+__global__ __launch_bounds__(256) void k_iou_grad_small(const B *__restrict__ b1, int64_t n, const B *__restrict__ b2, int64_t m,
                                                         const G *__restrict__ grad, T *g1, T *g2)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -583,8 +583,8 @@ __global__ __launch_bounds__(256) void k_iou_grad_small(const T *__restrict__ b1
     const BoxGeom<T> a = Box2D<T>::load(b1 + i * 5), b = Box2D<T>::load(b2 + j * 5);
     if (!(aabb_gap(cand_aabb(a, ROTATED), cand_aabb(b, ROTATED)) > 0.f)) return;
     T da[5], db[5];
-    if (ROTATED) iou_rbox_grad<T>(a, b, b1[i * 5 + 2], b1[i * 5 + 3], b2[j * 5 + 2], b2[j * 5 + 3], da, db);
-    else iou_aabb_grad<T>(a, b, b1 + i * 5, b2 + j * 5, da, db);
+    if (ROTATED) iou_rbox_grad<T>(a, b, (T)b1[i * 5 + 2], (T)b1[i * 5 + 3], (T)b2[j * 5 + 2], (T)b2[j * 5 + 3], da, db);
+    else iou_aabb_grad<T, B>(a, b, b1 + i * 5, b2 + j * 5, da, db);
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         if (da[k] != 0) atomicAdd(&g1[i * 5 + k], g * da[k]);
@@ -593,9 +593,9 @@ __global__ __launch_bounds__(256) void k_iou_grad_small(const T *__restrict__ b1
 }
 
 constexpr int kSparseWords = 2048;                 // bitmap words per workgroup (131 k pairs)
-template <typename T, bool ROTATED, typename G = T>
-__global__ __launch_bounds__(256) void k_iou_grad_sparse(const BoxGeom<T> *__restrict__ ga, const T *__restrict__ b1, int64_t n,
-                                                         const BoxGeom<T> *__restrict__ gb, const T *__restrict__ b2, int64_t m,
+template <typename T, bool ROTATED, typename G = T, typename B = T>
+__global__ __launch_bounds__(256) void k_iou_grad_sparse(const BoxGeom<T> *__restrict__ ga, const B *__restrict__ b1, int64_t n,
+                                                         const BoxGeom<T> *__restrict__ gb, const B *__restrict__ b2, int64_t m,
                                                          const G *__restrict__ grad, T *g1, T *g2,
                                                          const unsigned long long *__restrict__ bitmap, int64_t wpr,
                                                          const unsigned long long *nmarks)
@@ -633,8 +633,8 @@ __global__ __launch_bounds__(256) void k_iou_grad_sparse(const BoxGeom<T> *__res
         const int64_t w = base + lo, i = w / wpr, j = (w - i * wpr) * 64 + bit;
         const T g = (T)grad[i * m + j];
         T da[5], db[5];
-        if (ROTATED) iou_rbox_grad<T>(ga[i], gb[j], b1[i * 5 + 2], b1[i * 5 + 3], b2[j * 5 + 2], b2[j * 5 + 3], da, db);
-        else iou_aabb_grad<T>(ga[i], gb[j], b1 + i * 5, b2 + j * 5, da, db);
+        if (ROTATED) iou_rbox_grad<T>(ga[i], gb[j], (T)b1[i * 5 + 2], (T)b1[i * 5 + 3], (T)b2[j * 5 + 2], (T)b2[j * 5 + 3], da, db);
+        else iou_aabb_grad<T, B>(ga[i], gb[j], b1 + i * 5, b2 + j * 5, da, db);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             if (da[k] != 0) atomicAdd(&g1[i * 5 + k], g * da[k]);
@@ -646,10 +646,10 @@ __global__ __launch_bounds__(256) void k_iou_grad_sparse(const BoxGeom<T> *__res
 // (round 6: three wavefronts per SIMD for the fp64 rotated form -- 226 -> 168 VGPRs with 80 bytes of scratch, possible since its LDS
 // went from 57 to 44 KB: 603 -> 539 us on the reference's 5 k x 5 k benchmark boxes, profiles/r06_pre_rows_ab.txt; the other three
 // forms need fewer registers than that anyway)
-template <typename T, bool ROTATED, typename G = T>
+template <typename T, bool ROTATED, typename G = T, typename B = T>
 __global__ __launch_bounds__(kGradCols) __attribute__((amdgpu_waves_per_eu(3))) void k_iou_grad_tiles(const BoxGeom<T> *__restrict__ ga, const float4 *__restrict__ ra,
-                                                              const T *__restrict__ b1, int64_t n, const BoxGeom<T> *__restrict__ gb,
-                                                              const float4 *__restrict__ cb, const T *__restrict__ b2, int64_t m,
+                                                              const B *__restrict__ b1, int64_t n, const BoxGeom<T> *__restrict__ gb,
+                                                              const float4 *__restrict__ cb, const B *__restrict__ b2, int64_t m,
                                                               const G *__restrict__ grad, T *g1, T *g2, int tile_rows,
                                                               const unsigned long long *__restrict__ bitmap, int64_t wpr,
                                                               const unsigned long long *nmarks)
@@ -677,14 +677,14 @@ __global__ __launch_bounds__(kGradCols) __attribute__((amdgpu_waves_per_eu(3))) 
         if constexpr (ROTATED) { const BoxGeom<T> g = ga[i]; rgeo[threadIdx.x] = Core6{g.cx, g.cy, g.ux, g.uy, g.vx, g.vy}; }
         else rgeo[threadIdx.x] = ga[i];
         rbox[threadIdx.x] = ra[i];
-        rwh[threadIdx.x][0] = b1[i * 5 + 2]; rwh[threadIdx.x][1] = b1[i * 5 + 3];
+        rwh[threadIdx.x][0] = (T)b1[i * 5 + 2]; rwh[threadIdx.x][1] = (T)b1[i * 5 + 3];
     }
     float4 cbox = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
     if (active) {
         if constexpr (ROTATED) { const BoxGeom<T> g = gb[j]; cgeo[threadIdx.x] = Core6{g.cx, g.cy, g.ux, g.uy, g.vx, g.vy}; }
         else cgeo[threadIdx.x] = gb[j];
         cbox = cb[j];
-        cwh[threadIdx.x][0] = b2[j * 5 + 2]; cwh[threadIdx.x][1] = b2[j * 5 + 3];
+        cwh[threadIdx.x][0] = (T)b2[j * 5 + 2]; cwh[threadIdx.x][1] = (T)b2[j * 5 + 3];
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) { racc[wave][lane][k] = 0; cacc[threadIdx.x][k] = 0; }
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(kGradCols) __attribute__((amdgpu_waves_per_eu(3))) 
                 a.cx = ca.cx; a.cy = ca.cy; a.ux = ca.ux; a.uy = ca.uy; a.vx = ca.vx; a.vy = ca.vy; a.area = 4 * (ca.ux * ca.vy - ca.uy * ca.vx);
                 b.cx = cc.cx; b.cy = cc.cy; b.ux = cc.ux; b.uy = cc.uy; b.vx = cc.vx; b.vy = cc.vy; b.area = 4 * (cc.ux * cc.vy - cc.uy * cc.vx);
                 iou_rbox_grad<T, false>(a, b, rwh[r][0], rwh[r][1], cwh[wave * 64 + c][0], cwh[wave * 64 + c][1], da, db);
-            } else iou_aabb_grad<T>(rgeo[r], cgeo[wave * 64 + c], b1 + (i0 + r) * 5, b2 + (jb + wave * 64 + c) * 5, da, db);
+            } else iou_aabb_grad<T, B>(rgeo[r], cgeo[wave * 64 + c], b1 + (i0 + r) * 5, b2 + (jb + wave * 64 + c) * 5, da, db);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 if (da[k] != 0) atomicAdd(&racc[wave][r][k], g * da[k]);
@@ -2935,8 +2935,8 @@ extern "C" int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, in
     return D3D_OK;
 }
 
-template <typename T, typename G = T>
-static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, const G *grad, bool rot, T *g1, T *g2, void *ws,
+template <typename T, typename G = T, typename B = T>
+static int iou2d_backward_typed(const B *b1, int64_t n, const B *b2, int64_t m, const G *grad, bool rot, T *g1, T *g2, void *ws,
                                 size_t ws_bytes, hipStream_t st)
 {
     WsCarver w(ws, ws_bytes);
@@ -2958,14 +2958,17 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
     unsigned long long *bitmap = w.take<unsigned long long>((size_t)rows_bm * (size_t)wpr);
     unsigned long long *nmarks = w.take<unsigned long long>(kMarkStripes + 1);        // 64 counters + the decision
     if (!ws || !w.ok()) return D3D_ERR_WORKSPACE;      // (geometry and candidate boxes of both sets + one bit per pair: inside the forward's workspace)
-    D3D_HIP_CHECK(hipMemsetAsync(g1, 0, sizeof(T) * 5 * (size_t)n, st));
-    D3D_HIP_CHECK(hipMemsetAsync(g2, 0, sizeof(T) * 5 * (size_t)m, st));
+    if (g2 == g1 + 5 * (size_t)n) D3D_HIP_CHECK(hipMemsetAsync(g1, 0, sizeof(T) * 5 * (size_t)(n + m), st));   // one buffer: one launch
+    else {
+        D3D_HIP_CHECK(hipMemsetAsync(g1, 0, sizeof(T) * 5 * (size_t)n, st));
+        D3D_HIP_CHECK(hipMemsetAsync(g2, 0, sizeof(T) * 5 * (size_t)m, st));
+    }
     if ((unsigned long long)n * (unsigned long long)m <= kIouSmallPairs) {
-        if (rot) D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, true, G>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
-        else D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, false, G>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
+        if (rot) D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, true, G, B>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
+        else D3D_LAUNCH("k_iou_grad_small", (k_iou_grad_small<T, false, G, B>), dim3((unsigned)d3d_divup(n * m, 256)), dim3(256), 0, st, b1, n, b2, m, grad, g1, g2);
         return D3D_OK;
     }
-    D3D_LAUNCH("k_geom", (k_geom2<T, false>), dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, ga, ra, b2, m, gb, cb,
+    D3D_LAUNCH("k_geom", (k_geom2<T, false, B>), dim3((unsigned)d3d_divup(n + m, 256)), dim3(256), 0, st, b1, n, ga, ra, b2, m, gb, cb,
                (IouList *)nullptr, 1u, rot);           // (both operands in one launch, as the forward does)
     {                                                  // marks, then tiles with LDS accumulators (k_iou_grad_mark, k_iou_grad_tiles)
         int tr = kTileRows;                            // fewer rows per workgroup while the launch is short of 2048 workgroups
@@ -2980,11 +2983,11 @@ static int iou2d_backward_typed(const T *b1, int64_t n, const T *b2, int64_t m, 
                dim3(kGradCols), 0, st, (const BoxGeom<T> *)ga + r0, (const float4 *)ra + r0, nr, (const BoxGeom<T> *)gb, (const float4 *)cb, \
                m, grad + r0 * m, bitmap, wpr, tr, nmarks);                                                                                  \
     D3D_LAUNCH("k_iou_grad_decide", k_iou_grad_decide, dim3(1), dim3(kMarkStripes), 0, st, nmarks, nr, m);                                    \
-    D3D_LAUNCH("k_iou_grad_tiles", (k_iou_grad_tiles<T, R, G>), dim3((unsigned)d3d_divup(m, kGradCols), (unsigned)d3d_divup(nr, tr)),               \
+    D3D_LAUNCH("k_iou_grad_tiles", (k_iou_grad_tiles<T, R, G, B>), dim3((unsigned)d3d_divup(m, kGradCols), (unsigned)d3d_divup(nr, tr)),               \
                dim3(kGradCols), 0, st, (const BoxGeom<T> *)ga + r0, (const float4 *)ra + r0, b1 + r0 * 5, nr, (const BoxGeom<T> *)gb,        \
                (const float4 *)cb, b2, m, grad + r0 * m, g1 + r0 * 5, g2, tr, (const unsigned long long *)bitmap, wpr,                      \
                (const unsigned long long *)nmarks);                                                                                         \
-    D3D_LAUNCH("k_iou_grad_sparse", (k_iou_grad_sparse<T, R, G>), dim3((unsigned)d3d_divup(nr * wpr, (int64_t)kSparseWords)), dim3(256), 0, st,   \
+    D3D_LAUNCH("k_iou_grad_sparse", (k_iou_grad_sparse<T, R, G, B>), dim3((unsigned)d3d_divup(nr * wpr, (int64_t)kSparseWords)), dim3(256), 0, st,   \
                (const BoxGeom<T> *)ga + r0, b1 + r0 * 5, nr, (const BoxGeom<T> *)gb, b2, m, grad + r0 * m, g1 + r0 * 5, g2,                  \
                (const unsigned long long *)bitmap, wpr, (const unsigned long long *)nmarks)
             if (rot) { D3D_GRAD_TILES(true); } else { D3D_GRAD_TILES(false); }
@@ -3000,10 +3003,10 @@ extern "C" int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *box
 {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || m < 0) return D3D_ERR_BAD_ARG;
-    if (dtype != D3D_F32 && dtype != D3D_F64 && dtype != D3D_F64_M32) return D3D_ERR_BAD_ARG;
+    if (dtype != D3D_F32 && dtype != D3D_F64 && dtype != D3D_F64_M32 && dtype != D3D_F32_WIDE) return D3D_ERR_BAD_ARG;
     const bool loss_kind = iou_type == D3D_IOU_GRBOX || iou_type == D3D_IOU_DRBOX;
     if (iou_type != D3D_IOU_BOX && iou_type != D3D_IOU_RBOX && !loss_kind) return D3D_ERR_UNSUPPORTED;
-    if (loss_kind && dtype == D3D_F64_M32) return D3D_ERR_UNSUPPORTED;
+    if (loss_kind && (dtype == D3D_F64_M32 || dtype == D3D_F32_WIDE)) return D3D_ERR_UNSUPPORTED;
     if (n > 0 && (!boxes1 || !grad_boxes1)) return D3D_ERR_BAD_ARG;
     if (m > 0 && (!boxes2 || !grad_boxes2)) return D3D_ERR_BAD_ARG;
     const size_t esz = dtype != D3D_F32 ? 8 : 4;
@@ -3018,6 +3021,9 @@ extern "C" int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *box
                                               grad_boxes2, workspace, workspace ? workspace_bytes : 0, st);
     if (workspace_bytes < d3d_iou2d_workspace_bytes(n, m, dtype)) return D3D_ERR_WORKSPACE;
     const bool rot = iou_type == D3D_IOU_RBOX;
+    if (dtype == D3D_F32_WIDE)
+        return iou2d_backward_typed<double, float, float>((const float *)boxes1, n, (const float *)boxes2, m, (const float *)grad, rot,
+                                                          (double *)grad_boxes1, (double *)grad_boxes2, workspace, workspace_bytes, st);
     if (dtype == D3D_F64_M32)
         return iou2d_backward_typed<double, float>((const double *)boxes1, n, (const double *)boxes2, m, (const float *)grad, rot,
                                                    (double *)grad_boxes1, (double *)grad_boxes2, workspace, workspace_bytes, st);

@@ -455,8 +455,8 @@ __device__ __forceinline__ void aabb_param_grad(T w, T h, T r, T dIdx0, T dIdx1,
     for (int k = 0; k < 5; k++) g[k] = (dI[k] * (U + I) - I * dA[k]) / U2;
 }
 
-template <typename T>
-__device__ __forceinline__ T iou_aabb_grad(const BoxGeom<T> &a, const BoxGeom<T> &b, const T *pa, const T *pb, T (&ga)[5],
+template <typename T, typename P = T /* element type of the raw box rows: T, or float widened as it is read */>
+__device__ __forceinline__ T iou_aabb_grad(const BoxGeom<T> &a, const BoxGeom<T> &b, const P *pa, const P *pb, T (&ga)[5],
                                            T (&gb)[5])
 {
 #pragma unroll
@@ -473,8 +473,8 @@ __device__ __forceinline__ T iou_aabb_grad(const BoxGeom<T> &a, const BoxGeom<T>
     const T a_y1 = a.ymax < b.ymax ? ix : 0, b_y1 = a.ymax < b.ymax ? 0 : ix;
     const T a_y0 = a.ymin > b.ymin ? -ix : 0, b_y0 = a.ymin > b.ymin ? 0 : -ix;
     // area = (2 hx)(2 hy): dA/dhx = 2 * (2 hy) = 2 * height
-    aabb_param_grad<T>(pa[2], pa[3], pa[4], a_x0, a_x1, a_y0, a_y1, 2 * ay, 2 * ax, I, U, ga);
-    aabb_param_grad<T>(pb[2], pb[3], pb[4], b_x0, b_x1, b_y0, b_y1, 2 * by, 2 * bx, I, U, gb);
+    aabb_param_grad<T>((T)pa[2], (T)pa[3], (T)pa[4], a_x0, a_x1, a_y0, a_y1, 2 * ay, 2 * ax, I, U, ga);
+    aabb_param_grad<T>((T)pb[2], (T)pb[3], (T)pb[4], b_x0, b_x1, b_y0, b_y1, 2 * by, 2 * bx, I, U, gb);
     return I / U;
 }
 

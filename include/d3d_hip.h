@@ -50,7 +50,7 @@ enum { D3D_F32 = 0, D3D_F64 = 1,
         * box2d_iou(precise=True) on fp32 boxes (reference box/__init__.py:204-205, 224: boxes.double(), ious.to(dtype)) without
         * the fp64 copy of the matrix: a third of the bytes. */
        D3D_F64_M32 = 2,
-       /* d3d_iou2d_forward (BOX / RBOX), d3d_nms2d: everything in memory f32 (boxes, scores, the matrix), the arithmetic f64 --
+       /* d3d_iou2d_forward / _backward (BOX / RBOX), d3d_nms2d: everything in memory f32 (boxes, scores, the matrix), the arithmetic f64 --
         * every value widened where it is loaded.  box2d_iou / box2d_nms (precise=True) on fp32 tensors without the .double()
         * copies either (box/__init__.py:204-205, 254-255). */
        D3D_F32_WIDE = 3 };
@@ -488,7 +488,9 @@ int d3d_iou2d_forward(const void *boxes1, int64_t n, const void *boxes2, int64_t
  * xflags, ...) are not needed: the geometry is recomputed analytically.
  * Workspace: d3d_iou2d_workspace_bytes(n, m, dtype); required for BOX / RBOX, optional for GRBOX / DRBOX (with it, matrices
  * of more than 65536 pairs take a gradient kernel for the pairs that are apart and the complete routine for the rest).
- * dtype D3D_F64_M32 (BOX / RBOX): boxes and grad_boxes f64, grad[n,m] f32 (widened as it is read). */
+ * dtype D3D_F64_M32 (BOX / RBOX): boxes and grad_boxes f64, grad[n,m] f32 (widened as it is read); D3D_F32_WIDE: boxes f32 too,
+ * grad_boxes still f64 (the sums are kept in f64: round them once).  grad_boxes2 == grad_boxes1 + 5 n (one buffer): cleared by
+ * one launch. */
 int d3d_iou2d_backward(const void *boxes1, int64_t n, const void *boxes2, int64_t m, const void *grad,
                        int32_t iou_type, int32_t dtype, void *grad_boxes1, void *grad_boxes2,
                        void *workspace, size_t workspace_bytes, void *stream);

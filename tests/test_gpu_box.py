@@ -974,6 +974,9 @@ def test_precise_on_fp32_boxes_rounds_where_the_matrix_is_stored(method, shape):
         (chain * w).sum().backward()
         for a, b in ((t1.grad, c1.grad), (t2.grad, c2.grad)):
             assert a.dtype == torch.float32 and torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+        from d3d_amd.box import _iou_backward
+        m1, m2 = _iou_backward(T(b1).double(), T(b2).double(), w, IouType[method.upper()], matrix32=True)      # D3D_F64_M32: fp32 grad, fp64 boxes
+        assert m1.dtype == torch.float64 and torch.allclose(m1.float(), c1.grad, rtol=2e-6, atol=1e-7) and torch.allclose(m2.float(), c2.grad, rtol=2e-6, atol=1e-7)
     set_opts(iou_flags=0)
     # numpy in, numpy out, on the same path
     gn = box2d_iou(b1, b2, method=method)
