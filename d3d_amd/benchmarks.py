@@ -127,54 +127,56 @@ class DetectionEvaluator:
             for k in ("acc_iou", "acc_angular", "acc_dist", "acc_box", "acc_var"):
                 out[k][c] = [float("nan")] * T
         cache = prepare_boxes(dt, gt, DistanceTypes.RIoU) if len(gt) and len(dt) else None             # :188-189
-        # the 40 associations are queued on the stream one after the other -- what they share (the ground truths' columns of the
-        # cache, which pairs are acceptable) prepared once, nothing read back in between -- and fetched together
+        # the 40 associations share what does not depend on the threshold (the ground truths' columns of the cache, which pairs are
+        # acceptable) and go to the device as batched calls (ReferenceAssociation.match_many: one for a frame, a few for config 4's
+        # 20 k x 5 k), nothing read back in between; the results are fetched together
         assoc = gt_idx_t = None
         if cache is not None and len(gt_idx):
             assoc = ReferenceAssociation(cache, dt_score, dt_tag, gt_tag, self._max_distance, gt_idx)
             gt_idx_t = torch.from_numpy(gt_idx).to(cache.device)
-        dt_idxs, queued = [], []
-        for t in range(T):
-            dt_idx = np.nonzero(dt_in & ~(dt_score < thr[t]))[0]                                        # :219-228 (`score < thres`: skip)
-            dt_idxs.append(dt_idx)
-            if assoc is not None and len(dt_idx):
-                sm_t, dm_t = assoc.match(dt_idx)                                                       # :231-232
-                d_of_t = dm_t.index_select(0, gt_idx_t).long()
-                iou_t = 1 - cache[d_of_t.clamp_min(0), gt_idx_t]                                       # :243 (rows of the unmatched: unused)
-                queued.append((t, sm_t, dm_t, iou_t))
-        fetched = {}
-        if queued:
-            sm_all = torch.stack([q[1] for q in queued]).cpu().numpy().astype(np.int64)
-            dm_all = torch.stack([q[2] for q in queued]).cpu().numpy().astype(np.int64)
-            iou_all = torch.stack([q[3] for q in queued]).cpu().numpy().astype(np.float32)
-            fetched = {q[0]: (sm_all[i], dm_all[i], iou_all[i]) for i, q in enumerate(queued)}
-        for t in range(T):
-            dt_idx = dt_idxs[t]
-            for c in classes:
-                out.ndt[c][t] = int((dt_tag[dt_idx] == c).sum())
-            if t in fetched:
-                sm, dm, iou_row = fetched[t]
-            else:
-                sm, dm, iou_row = np.full((len(dt),), -1, np.int64), np.full((len(gt),), -1, np.int64), None
-            hit = dm[gt_idx] >= 0
-            g_hit = gt_idx[hit]
-            d_of = dm[g_hit]
-            if len(g_hit):
-                iou = iou_row[hit]
-                dist = np.linalg.norm(gt[g_hit, 2:5] - dt[d_of, 2:5], axis=1)                           # :244
-                box = np.linalg.norm(gt[g_hit, 5:8] - dt[d_of, 5:8], axis=1)                            # :245
-                dyaw = gt[g_hit, 8] - dt[d_of, 8]
-                ang = np.abs((dyaw + np.pi) % (2 * np.pi) - np.pi) / np.pi                               # :247-248
-            for c in classes:
-                gc = gt_tag[g_hit] == c
-                tp = int(gc.sum())
-                out.tp[c][t] = tp
-                out.fn[c][t] = out.ngt[c] - tp                                                           # :236-240
-                out.fp[c][t] = int(((dt_tag[dt_idx] == c) & (sm[dt_idx] < 0)).sum())                     # :262-265
-                if tp:                                                                                   # :150-174 (sum / count, fp32)
-                    for name, v in (("acc_iou", iou), ("acc_angular", ang), ("acc_dist", dist), ("acc_box", box)):
-                        out[name][c][t] = float(np.float32(np.sum(v[gc].astype(np.float64)) / tp))
-                    out.acc_var[c][t] = float("-inf")       # no variances travel in the [n,9] arrays: orientation_var = 0 (:250-258)
+        sel = dt_in[None, :] & ~(dt_score[None, :] < thr[:, None])                                   # [T, n]: :219-228 (`score < thres`: skip)
+        dt_idxs = [np.nonzero(sel[t])[0] for t in range(T)]
+        md = len(gt_idx)
+        sm_all = np.full((T, len(dt)), -1, np.int32)
+        dm_g = np.full((T, md), -1, np.int32)                                                       # dst_match over the ground truths taking part
+        iou_all = np.zeros((T, md), np.float32)
+        if assoc is not None:
+            sm_t, dm_t = assoc.match_many(dt_idxs)                                                     # :231-232, all thresholds
+            dmg_t = dm_t.index_select(1, gt_idx_t)
+            iou_t = 1 - cache[dmg_t.long().clamp_min(0), gt_idx_t[None, :]]                            # :243 (entries of the unmatched: unused)
+            sm_all, dm_g, iou_all = sm_t.cpu().numpy(), dmg_t.cpu().numpy(), iou_t.cpu().numpy()
+        # the counts and means of :236-283 for all thresholds at once: the K matched (threshold, ground truth) pairs as flat arrays,
+        # per-threshold counts and float64 sums by bincount (the arithmetic of one pair is unchanged: float32 terms, their sum in
+        # float64, one division, rounded to float32)
+        tt, jj = np.nonzero(dm_g >= 0)
+        terms, gcls = {}, np.zeros((0,), np.int64)
+        if len(tt):
+            gi, d_of = gt_idx[jj], dm_g[tt, jj]
+            ga, da = gt[gi], dt[d_of]                                                                  # [K, 9]
+            dp, db = ga[:, 2:5] - da[:, 2:5], ga[:, 5:8] - da[:, 5:8]
+            dyaw = ga[:, 8] - da[:, 8]
+            terms = dict(acc_iou=iou_all[tt, jj],
+                         acc_angular=np.abs((dyaw + np.pi) % (2 * np.pi) - np.pi) / np.pi,              # :247-248
+                         # (np.linalg.norm(., axis=1) spelled out -- sqrt(add.reduce(x * x)) over three terms, the same bits)
+                         acc_dist=np.sqrt((dp[:, 0] * dp[:, 0] + dp[:, 1] * dp[:, 1]) + dp[:, 2] * dp[:, 2]),   # :244
+                         acc_box=np.sqrt((db[:, 0] * db[:, 0] + db[:, 1] * db[:, 1]) + db[:, 2] * db[:, 2]))    # :245
+            gcls = gt_tag[gi]
+        unmatched = sm_all < 0
+        for c in classes:
+            dc = sel & (dt_tag == c)[None, :]
+            of_c = gcls == c
+            tc = tt[of_c]
+            tp = np.bincount(tc, minlength=T)
+            out.ndt[c] = dc.sum(1).tolist()
+            out.tp[c] = tp.tolist()
+            out.fn[c] = (out.ngt[c] - tp).tolist()                                                     # :236-240
+            out.fp[c] = (dc & unmatched).sum(1).tolist()                                               # :262-265
+            for name, v in terms.items():                                                              # :150-174 (sum / count, fp32)
+                ssum = np.bincount(tc, weights=v[of_c].astype(np.float64), minlength=T)
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    out[name][c] = np.where(tp > 0, (ssum / tp).astype(np.float32), np.float32(np.nan)).tolist()
+            # no variances travel in the [n,9] arrays: orientation_var = 0 -> -inf per match (:250-258), NaN without one
+            out.acc_var[c] = np.where(tp > 0, -np.inf, np.nan).tolist()
         return out
 
 

@@ -141,13 +141,20 @@ __global__ __launch_bounds__(64) void k_match_greedy(const int64_t *__restrict__
                                                      int32_t *src_match, int32_t *dst_match, unsigned int *taken_g /* zeroed */,
                                                      const float *__restrict__ dist, const int32_t *__restrict__ src_tag,
                                                      const int32_t *__restrict__ dst_tag, const float *__restrict__ thr,
-                                                     const int32_t *only_if = nullptr)
+                                                     const int32_t *only_if = nullptr, const int64_t *__restrict__ row_off = nullptr)
 {
     extern __shared__ unsigned int taken_l[];
     __shared__ int stage[kWave][kMaxCand];
+    const int64_t nwords = (m + 31) / 32;
+    if (row_off) {                             // batched (d3d_score_match_batched): workgroup b = problem b, rows [row_off[b], row_off[b + 1])
+        const int64_t b = blockIdx.x, o = row_off[b];
+        n = row_off[b + 1] - o;
+        order += o; cand_dst += o * kMaxCand; cand_cnt += o; src_match += o; dst_match += b * m; taken_g += b * nwords;
+        dist += o * m; src_tag += o;
+        if (only_if) only_if += b;
+    }
     if (only_if && !*only_if) return;          // k_match_stable decided everything (the usual case)
     const int lane = threadIdx.x;
-    const int64_t nwords = (m + 31) / 32;
     if (LDS_MAP)
         for (int64_t t = lane; t < nwords; t += kWave) taken_l[t] = 0;
     for (int64_t j = lane; j < m; j += kWave) dst_match[j] = -1;
@@ -235,9 +242,16 @@ constexpr int kStableRounds = 512;      // a displacement chain longer than this
 __global__ __launch_bounds__(kStableThreads) void k_match_stable(const int64_t *__restrict__ order, int64_t n, int64_t m,
                                                                  const int32_t *__restrict__ cand_dst, const int32_t *__restrict__ cand_cnt,
                                                                  int32_t *src_match, int32_t *dst_match, int32_t *rank, int32_t *ptr,
-                                                                 int32_t *hold, int32_t *q0, int32_t *q1, int32_t *need_walk)
+                                                                 int32_t *hold, int32_t *q0, int32_t *q1, int32_t *need_walk,
+                                                                 const int64_t *__restrict__ row_off = nullptr)
 {
     __shared__ unsigned int qn[2];
+    if (row_off) {                             // batched: workgroup b = problem b (indices below are local to its rows)
+        const int64_t b = blockIdx.x, o = row_off[b];
+        n = row_off[b + 1] - o;
+        order += o; cand_dst += o * kMaxCand; cand_cnt += o; src_match += o; dst_match += b * m;
+        rank += o; ptr += o; q0 += o; q1 += o; hold += b * m; need_walk += b;
+    }
     const int tid = threadIdx.x;
     constexpr int kFree = 0x7fffffff;
     for (int64_t p = tid; p < n; p += kStableThreads) {
@@ -298,6 +312,62 @@ __global__ __launch_bounds__(kStableThreads) void k_match_stable(const int64_t *
 }
 
 }  // namespace
+
+// B problems at once (the evaluator's score thresholds on a frame: 40 small associations, each a chain of short launches when
+// issued one by one): the rows of all problems stacked in dist[N, m] (problem b = rows [row_off[b], row_off[b + 1])), the
+// destinations -- dst_tag, dst_threshold, m -- common to all; order / src_match in the same stacked layout with indices LOCAL
+// to the problem, dst_match[B, m] likewise local.  One candidate launch over all rows, one workgroup per problem after that.
+extern "C" size_t d3d_score_match_batched_workspace_bytes(int64_t n_total, int64_t m, int64_t batches)
+{
+    if (n_total < 1) n_total = 1;
+    if (m < 1) m = 1;
+    if (batches < 1) batches = 1;
+    return d3d_align_up((size_t)n_total * kMaxCand * 4) * 2 + d3d_align_up((size_t)n_total * 4) * 5 +
+           d3d_align_up((size_t)batches * (((size_t)m + 31) / 32) * 4) + d3d_align_up((size_t)batches * (size_t)m * 4) +
+           d3d_align_up((size_t)batches * 4) + 1024;
+}
+
+extern "C" int d3d_score_match_batched(const float *dist, const int64_t *row_off, int64_t batches, int64_t n_total, int64_t m,
+                                       const int32_t *src_tag, const int32_t *dst_tag, const float *dst_threshold,
+                                       const int64_t *order, int32_t *src_match, int32_t *dst_match, int32_t *status, void *workspace,
+                                       size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (batches < 0 || n_total < 0 || m < 0 || !status) return D3D_ERR_BAD_ARG;
+    D3D_HIP_CHECK(hipMemsetAsync(status, 0, 4, st));
+    if (batches == 0) return D3D_OK;
+    if (!row_off || (m > 0 && !dst_match)) return D3D_ERR_BAD_ARG;
+    if (m > 0) D3D_HIP_CHECK(hipMemsetAsync(dst_match, 0xff, (size_t)batches * (size_t)m * 4, st));
+    if (n_total == 0) return D3D_OK;
+    if (!src_match || !src_tag || !order) return D3D_ERR_BAD_ARG;
+    if (m == 0) { D3D_HIP_CHECK(hipMemsetAsync(src_match, 0xff, (size_t)n_total * 4, st)); return D3D_OK; }
+    if (!dist || !dst_tag || !dst_threshold || m >= (1ll << 31) || n_total >= (1ll << 31) || batches > 65535) return D3D_ERR_BAD_ARG;
+    const size_t words = ((size_t)m + 31) / 32;
+    WsCarver w(workspace, workspace_bytes);
+    int32_t *cand_dst = w.take<int32_t>((size_t)n_total * kMaxCand);
+    float *cand_dist = w.take<float>((size_t)n_total * kMaxCand);
+    int32_t *cand_cnt = w.take<int32_t>((size_t)n_total);
+    unsigned int *taken = w.take<unsigned int>((size_t)batches * words);
+    int32_t *rank = w.take<int32_t>((size_t)n_total), *ptr = w.take<int32_t>((size_t)n_total), *q0 = w.take<int32_t>((size_t)n_total),
+            *q1 = w.take<int32_t>((size_t)n_total);
+    int32_t *hold = w.take<int32_t>((size_t)batches * (size_t)m), *need_walk = w.take<int32_t>((size_t)batches);
+    if (!workspace || !w.ok()) return D3D_ERR_WORKSPACE;
+    D3D_HIP_CHECK(hipMemsetAsync(taken, 0, (size_t)batches * words * 4, st));
+    D3D_LAUNCH("k_match_candidates", k_match_candidates, dim3((unsigned)d3d_divup(n_total, 256 / kWave)), dim3(256), 0, st, dist, n_total, m,
+               src_tag, dst_tag, dst_threshold, cand_dst, cand_dist, cand_cnt, status);
+    D3D_LAUNCH("k_match_stable", k_match_stable, dim3((unsigned)batches), dim3(kStableThreads), 0, st, order, (int64_t)0, m,
+               (const int32_t *)cand_dst, (const int32_t *)cand_cnt, src_match, dst_match, rank, ptr, hold, q0, q1, need_walk, row_off);
+    const size_t map_bytes = words * 4;
+    if (map_bytes <= 32 * 1024)
+        D3D_LAUNCH("k_match_greedy", k_match_greedy<true>, dim3((unsigned)batches), dim3(64), map_bytes, st, order, (int64_t)0, m,
+                   (const int32_t *)cand_dst, (const int32_t *)cand_cnt, src_match, dst_match, taken, dist, src_tag, dst_tag, dst_threshold,
+                   (const int32_t *)need_walk, row_off);
+    else
+        D3D_LAUNCH("k_match_greedy", k_match_greedy<false>, dim3((unsigned)batches), dim3(64), 0, st, order, (int64_t)0, m,
+                   (const int32_t *)cand_dst, (const int32_t *)cand_cnt, src_match, dst_match, taken, dist, src_tag, dst_tag, dst_threshold,
+                   (const int32_t *)need_walk, row_off);
+    return D3D_OK;
+}
 
 extern "C" size_t d3d_score_match_workspace_bytes(int64_t n, int64_t m)
 {

@@ -110,6 +110,9 @@ def score_match_reference_compat(distance, src_scores, src_tags, dst_tags, dista
     return ReferenceAssociation(distance, src_scores, src_tags, dst_tags, distance_threshold, dst_subset).match(src_subset)
 
 
+_BATCH_MAX_ELEMENTS = 1 << 26          # stacked P matrices of one batched call: 256 MB of fp32
+
+
 def _index_array(subset):
     return np.asarray(subset if isinstance(subset, np.ndarray) else list(subset), dtype=np.int64).reshape(-1)
 
@@ -178,6 +181,59 @@ class ReferenceAssociation:
             src_match[best_t] = torch.where(sm >= 0, self.dsub_t[sm.clamp_min(0).long()].to(torch.int32), neg)
             dst_match[self.dsub_t] = torch.where(dm >= 0, best_t[dm.clamp_min(0).long()].to(torch.int32), neg)
         return src_match, dst_match
+
+
+    def match_many(self, src_subsets):
+        """`match` for a list of source subsets -> (src_match[T, n], dst_match[T, m]) int32 tensors on the device, row t = the
+        association of src_subsets[t].  Subsets whose stacked matrices fit _BATCH_MAX_ELEMENTS go through ONE
+        d3d_score_match_batched call (a frame's 40 thresholds: three launches instead of 120 and a dozen tensor operations instead
+        of 500); larger ones in several."""
+        dev, n, m = self.dev, self.n, self.m
+        T = len(src_subsets)
+        src_all = torch.full((T, n), -1, dtype=torch.int32, device=dev)
+        dst_all = torch.full((T, m), -1, dtype=torch.int32, device=dev)
+        md = int(self.dsub.size)
+        if md == 0 or n == 0:
+            return src_all, dst_all
+        subs = [_index_array(x) for x in src_subsets]
+        lib = _lib.load()
+        t0 = 0
+        while t0 < T:
+            t1, rows = t0, 0
+            while t1 < T and (t1 == t0 or (rows + subs[t1].size) * md <= _BATCH_MAX_ELEMENTS):
+                rows += subs[t1].size
+                t1 += 1
+            if rows == 0:
+                t0 = t1
+                continue
+            B = t1 - t0
+            bests = [ss[np.flip(np.argsort(self.scores[ss].astype(np.float64)))] for ss in subs[t0:t1]]      # matcher.pyx:145-146 per subset
+            off = np.zeros((B + 1,), np.int64)
+            off[1:] = np.cumsum([ss.size for ss in subs[t0:t1]])
+            local = np.concatenate([np.arange(ss.size, dtype=np.int64) for ss in subs[t0:t1]])
+            bid = np.repeat(np.arange(B, dtype=np.int64), [ss.size for ss in subs[t0:t1]])
+            with torch.cuda.device(dev):
+                host = torch.from_numpy(np.concatenate([np.concatenate(subs[t0:t1]), np.concatenate(bests), off, local, bid]))
+                d = host.to(dev)
+                ssub_t, best_t = d[:rows], d[rows:2 * rows]
+                off_t, order_t, bid_t = d[2 * rows:2 * rows + B + 1], d[2 * rows + B + 1:3 * rows + B + 1], d[3 * rows + B + 1:]
+                pref = torch.where(self.ok.index_select(0, best_t), self.cols.index_select(0, ssub_t), self._inf)
+                sm = torch.empty((rows,), dtype=torch.int32, device=dev)
+                dm = torch.empty((B, md), dtype=torch.int32, device=dev)
+                status = torch.zeros((1,), dtype=torch.int32, device=dev)
+                stag0 = torch.zeros((rows,), dtype=torch.int32, device=dev)
+                ws = _lib.workspace(lib.d3d_score_match_batched_workspace_bytes(rows, md, B), dev)
+                rc = lib.d3d_score_match_batched(_lib.ptr(pref), _lib.ptr(off_t), B, rows, md, _lib.ptr(stag0), _lib.ptr(self._dtag0),
+                                                 _lib.ptr(self._dthr), _lib.ptr(order_t), _lib.ptr(sm), _lib.ptr(dm), _lib.ptr(status),
+                                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                _lib.check(rc, "score_match_batched")
+                neg = torch.full((), -1, dtype=torch.int32, device=dev)
+                # slot k of problem b matched destination slot sm: source best[k] <-> destination dsub[sm]
+                src_all[t0:t1][bid_t, best_t] = torch.where(sm >= 0, self.dsub_t[sm.clamp_min(0).long()].to(torch.int32), neg)
+                who = best_t[(dm.clamp_min(0).long() + off_t[:B, None]).clamp_max(rows - 1)].to(torch.int32)
+                dst_all[t0:t1, self.dsub_t] = torch.where(dm >= 0, who, neg)
+            t0 = t1
+        return src_all, dst_all
 
 
 class ScoreMatcher:

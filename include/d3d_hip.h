@@ -546,6 +546,17 @@ int d3d_score_match(const float *dist, int64_t n, int64_t m, const int32_t *src_
                     const float *dst_threshold, const int64_t *order, int32_t *src_match, int32_t *dst_match,
                     int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 
+/* `batches` associations in one call (the evaluator's score thresholds on a frame, benchmarks.pyx:218-238: 40 short chains of
+ * launches when issued one by one).  The rows of all problems are stacked: dist[n_total, m], src_tag[n_total], order[n_total],
+ * src_match[n_total]; problem b owns rows row_off[b] .. row_off[b + 1] (row_off[batches + 1] i64, device) and its order /
+ * src_match / dst_match entries are indices LOCAL to those rows; the destinations (m, dst_tag, dst_threshold) are common,
+ * dst_match[batches, m].  Same result per problem as d3d_score_match. */
+size_t d3d_score_match_batched_workspace_bytes(int64_t n_total, int64_t m, int64_t batches);
+int d3d_score_match_batched(const float *dist, const int64_t *row_off, int64_t batches, int64_t n_total, int64_t m,
+                            const int32_t *src_tag, const int32_t *dst_tag, const float *dst_threshold, const int64_t *order,
+                            int32_t *src_match, int32_t *dst_match, int32_t *status, void *workspace, size_t workspace_bytes,
+                            void *stream);
+
 /* replaces crop_2dr (reference d3d/box/utils.cpp:9-47, bound at box/impl.cpp as crop_2dr; Python box2dr_crop /
  * box3dp_crop, box/__init__.py:278-315): points[n,2], boxes[m,5] in `dtype`; out[m,n] u8 (0/1),
  * out[i,j] = point j lies in rotated box i (boundary inclusive). */

@@ -491,6 +491,32 @@ def test_score_match_reference_compat_reproduces_the_row_mixup():
         assert {j: int(i) for j, i in enumerate(cd.cpu().numpy()) if i >= 0} == ld
 
 
+def test_reference_association_batched_equals_one_by_one(monkeypatch):
+    """ReferenceAssociation.match_many (d3d_score_match_batched: the evaluator's thresholds as ONE call -- problems stacked, one
+    workgroup each) row for row against `match` on the same subsets: nested subsets as the evaluator passes them, an empty one,
+    one with a single source; in one batched call and split into several (a small element budget)"""
+    from d3d_amd import synth
+    from d3d_amd.tracking import DistanceTypes, matcher, prepare_boxes
+    rng = np.random.default_rng(3)
+    for seed, ngt in ((0, 30), (1, 200)):
+        pred, gt = synth.boxes3d_eval(ngt, 4, 200 + seed)
+        d9, g9 = _labelled(pred, 2), _labelled(gt, 2, scores=False)
+        d9[:, 1] = np.round(d9[:, 1] * 16) / 16                                   # tied scores
+        thr = {1: 0.95, 2: 0.9}
+        cache = prepare_boxes(d9, g9, DistanceTypes.RIoU)
+        dst = np.nonzero(np.isin(g9[:, 0].astype(np.int64), [1, 2]))[0]
+        subsets = [np.nonzero(d9[:, 1] >= t)[0] for t in (0.0, 0.2, 0.5, 0.8, 2.0)] + [np.array([3]), rng.permutation(len(d9))[:17]]
+        for budget in (1 << 26, len(d9) * len(dst) + 1, 1):
+            monkeypatch.setattr(matcher, "_BATCH_MAX_ELEMENTS", budget)
+            assoc = matcher.ReferenceAssociation(cache, d9[:, 1], d9[:, 0], g9[:, 0], thr, dst)
+            sm, dm = assoc.match_many(subsets)
+            assert sm.shape == (len(subsets), len(d9)) and dm.shape == (len(subsets), len(g9))
+            for t, sub in enumerate(subsets):
+                s1, d1 = assoc.match(sub)
+                assert torch.equal(sm[t], s1) and torch.equal(dm[t], d1), (seed, budget, t)
+            assert int((sm[4] >= 0).sum()) == 0 and int((sm[0] >= 0).sum()) > 0   # the empty subset; the full one
+
+
 def test_evaluator_reference_compat_on_crowded_scenes():
     """VERDICT r05 missing #1: DetectionEvaluator's default reproduces benchmarks.pyx:188-238 with the literal per-threshold
     association of matcher.pyx:142-162 -- on scenes where that matters (loose thresholds: several acceptable ground truths per
