@@ -27,7 +27,7 @@ void d3d_prof_post(const char *name, hipStream_t st)
     (void)hipEventRecord(g_recs.back().b, st);
 }
 
-extern "C" int d3d_abi_version(void) { return 13; }   // 13: dtypes D3D_F64_M32 (d3d_iou2d_forward / _backward: fp64 arithmetic, fp32 [n,m] matrix) and D3D_F32_WIDE (d3d_iou2d_forward, d3d_nms2d: fp32 in memory, fp64 arithmetic), D3D_NMS_KEEP_MASK; 12: D3DSparseFilterCall, d3d_voxelize_dense_last_plan, D3D_VOXEL_INDEX_V1 retired; 11: point_off of d3d_owner_merge, D3D_VOXEL_INDEX_V1; 10: d3d_voxelize_3d_dense_resident, row_state of d3d_owner_dense; 9: d3d_nms2d_status, flags of d3d_owner_merge / _dense, points of d3d_owner_pack, status word behind d3d_owner_mark_first's bitmap; 8: coord_offset of d3d_voxelize_3d_sparse_filter, D3D_VOXEL_PARTITION_3PASS
+extern "C" int d3d_abi_version(void) { return 13; }   // 13: dtypes D3D_F64_M32 (d3d_iou2d_forward / _backward: fp64 arithmetic, fp32 [n,m] matrix) and D3D_F32_WIDE (d3d_iou2d_forward, d3d_nms2d: fp32 in memory, fp64 arithmetic), D3D_NMS_KEEP_MASK, d3d_score_match_batched; 12: D3DSparseFilterCall, d3d_voxelize_dense_last_plan, D3D_VOXEL_INDEX_V1 retired; 11: point_off of d3d_owner_merge, D3D_VOXEL_INDEX_V1; 10: d3d_voxelize_3d_dense_resident, row_state of d3d_owner_dense; 9: d3d_nms2d_status, flags of d3d_owner_merge / _dense, points of d3d_owner_pack, status word behind d3d_owner_mark_first's bitmap; 8: coord_offset of d3d_voxelize_3d_sparse_filter, D3D_VOXEL_PARTITION_3PASS
 extern "C" int d3d_last_hip_error(void) { return g_d3d_last_hip_error; }
 extern "C" const char *d3d_status_string(int status)
 {
