@@ -343,7 +343,48 @@ __global__ __launch_bounds__(kGridThreads) void k_crop2dr_grid(const float *__re
     }
 }
 
+// box3dp_crop along z in ONE launch (reference box/__init__.py:289-315 composes it from seven tensor operations around crop_2dr:
+// two column gathers, [M,N] differences, comparisons and ANDs -- 200 us for a frame's 120 k points x 50 boxes, 6 M-element passes
+// each): the rotated-rectangle test of k_crop2dr_grid on columns (x, y | w, h, r) = (0, 1 | 3, 4, 6) of the 7-float box rows, and
+// the interval test in the reference's own float expressions: (p - d / 2 < b) & (b < p + d / 2), :311-313.
+__global__ __launch_bounds__(kGridThreads) void k_crop3dp_grid(const float *__restrict__ points, int64_t n, int pstride,
+                                                               const float *__restrict__ boxes, int64_t m, int bstride,
+                                                               uint8_t *__restrict__ out)
+{
+    __shared__ BoxGrid G;
+    build_box_grid(G, boxes, m, bstride, 0);
+    const int64_t j0 = (int64_t)blockIdx.x * (kGridThreads * kGridPts) + threadIdx.x;
+    for (int k = 0; k < kGridPts; k++) {
+        const int64_t j = j0 + (int64_t)k * kGridThreads;
+        if (j >= n) break;
+        const float x = points[j * pstride], y = points[j * pstride + 1], z = points[j * pstride + 2];
+        for_candidates(G, m, x, y, [&](int i) {
+            const float *b = boxes + (size_t)i * bstride;
+            if (!quad_contains<float>(make_geom_cs<float>(b[0], b[1], b[3], b[4], G.cs[i].x, G.cs[i].y), x, y)) return;
+            const float hd = b[5] / 2;
+            if ((z - hd < b[2]) & (b[2] < z + hd)) out[(size_t)i * n + j] = 1;
+        });
+    }
+}
+
 }  // namespace
+
+// bool[M,N] of box3dp_crop (reference box/__init__.py:289-315) for project_axis = 2: points[n, point_stride >= 3] f32, boxes
+// [m, box_stride >= 7] f32 rows (x, y, z, lx, ly, lz, rz).  D3D_ERR_UNSUPPORTED (nothing touched) for another axis, more than 4096
+// boxes or fewer than 4096 points: the caller composes it from d3d_crop_2dr as the reference does.
+extern "C" int d3d_crop_3dp(const float *points, int64_t n, int32_t point_stride, const float *boxes, int64_t m, int32_t box_stride,
+                            int32_t project_axis, uint8_t *out, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || m < 0 || point_stride < 3 || box_stride < 7) return D3D_ERR_BAD_ARG;
+    if (project_axis != 2 || m > kGridMaxBoxes || n < 4096) return D3D_ERR_UNSUPPORTED;
+    if (m == 0) return D3D_OK;
+    if (!points || !boxes || !out) return D3D_ERR_BAD_ARG;
+    D3D_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)m * (size_t)n, st));
+    D3D_LAUNCH("k_crop3dp_grid", k_crop3dp_grid, dim3((unsigned)d3d_divup(n, kGridThreads * kGridPts)), dim3(kGridThreads), 0, st, points, n,
+               point_stride, boxes, m, box_stride, out);
+    return D3D_OK;
+}
 
 // d3d_crop_2dr's fp32 path for up to kGridMaxBoxes boxes (box.hip): zeros at the memset's rate, then the hits
 extern "C" int d3d_internal_crop2dr_grid_f32(const float *points, int64_t n, const float *boxes, int64_t m, uint8_t *out, hipStream_t st)

@@ -562,6 +562,13 @@ int d3d_score_match_batched(const float *dist, const int64_t *row_off, int64_t b
  * out[i,j] = point j lies in rotated box i (boundary inclusive). */
 int d3d_crop_2dr(const void *points, int64_t n, const void *boxes, int64_t m, int32_t dtype, uint8_t *out, void *stream);
 
+/* box3dp_crop for project_axis = 2 in one launch (reference d3d/box/__init__.py:289-315: crop_2dr on gathered columns, then
+ * the interval test (p - d / 2 < b) & (b < p + d / 2) as [M,N] tensor operations, :311-313): points[n, point_stride >= 3] f32,
+ * boxes[m, box_stride >= 7] f32 rows (x, y, z, lx, ly, lz, rz); out[m,n] u8 (0/1), the same bits as the composition.
+ * D3D_ERR_UNSUPPORTED, nothing touched: another axis, m > 4096 or n < 4096 -- compose it from d3d_crop_2dr. */
+int d3d_crop_3dp(const float *points, int64_t n, int32_t point_stride, const float *boxes, int64_t m, int32_t box_stride,
+                 int32_t project_axis, uint8_t *out, void *stream);
+
 /* stable descending argsort (the role torch::argsort plays inside the reference's nms2d,
  * nms.cpp:103): keys[n] in `dtype` -> order[n] i64; ties keep ascending index.  The order is torch's:
  * by value (-0 == +0), NaN before every number.  8 k .. 128 k keys: a 4-launch sample sort; other sizes: rocPRIM. */

@@ -1045,3 +1045,36 @@ def test_nms_precise_on_fp32_tensors_widens_inside_the_kernels(n, nms_broad):
     # [N,K] class scores: the class maximum commutes with the widening
     sk = torch.stack([st, st * 0.5], dim=1)
     assert torch.equal(box2d_nms(bt, sk, iou_method="rbox", iou_threshold=0.3), box2d_nms(bt, st, iou_method="rbox", iou_threshold=0.3))
+
+
+@pytest.mark.parametrize("n,m", [(120000, 50), (5000, 1), (70001, 700), (4096, 4096)])
+def test_box3dp_crop_one_launch_equals_the_composition(n, m):
+    """box3dp_crop along z as one launch (d3d_crop_3dp) against the reference's composition (box/__init__.py:289-315: crop_2dr on
+    gathered columns & the interval test as [M,N] tensor operations), bit for bit: points ON box faces and edges (copies of box
+    centres shifted by exactly half an extent), NaN points, a degenerate box, extra point columns; numpy / CPU ingress"""
+    from d3d_amd import synth
+    from d3d_amd.box import box3dp_crop, crop_2dr
+    rng = np.random.default_rng(n + m)
+    _, g = synth.boxes3d_eval(max(m, 2), 1, 5)
+    boxes = g[:m].astype(np.float32).copy()
+    pts = np.stack([rng.random(n) * 150, rng.random(n) * 150, rng.random(n) * 4 - 3, rng.random(n)], 1).astype(np.float32)
+    k = min(m, n // 8)
+    pts[:k, :3] = boxes[:k, :3]                                                   # centres
+    pts[k:2 * k, :3] = boxes[:k, :3]; pts[k:2 * k, 2] += boxes[:k, 5] / 2        # on the top face (z - d / 2 == b: outside, strict)
+    pts[2 * k:3 * k, :3] = boxes[:k, :3]; pts[2 * k:3 * k, 2] -= boxes[:k, 5] / 2
+    pts[3 * k, 0] = np.nan
+    if m > 3:
+        boxes[3, 3] = 0.0                                                        # a degenerate rectangle
+    for cols in (4, 3):
+        p, b = T(np.ascontiguousarray(pts[:, :cols])), T(boxes)
+        got = box3dp_crop(p, b)
+        pz, bz, hd = p[:, [2]].t(), b[:, [2]], b[:, [5]] / 2
+        exp = crop_2dr(p[:, [0, 1]], b[:, [0, 1, 3, 4, 6]]) & ((pz - hd < bz) & (bz < pz + hd))
+        assert got.dtype == torch.bool and got.shape == (m, n) and torch.equal(got, exp)
+        assert int(got.sum()) >= k                                                # the centres are inside
+    host = box3dp_crop(torch.from_numpy(pts[:, :3].copy()), torch.from_numpy(boxes))
+    assert not host.is_cuda and torch.equal(host, got.cpu())
+    for axis in (0, 1):                                                           # the other axes: the composition, as before
+        assert box3dp_crop(p, b, project_axis=axis).shape == (m, n)
+    with pytest.raises(ValueError):
+        box3dp_crop(p, b, project_axis=3)
