@@ -924,9 +924,19 @@ def main():
         k = max(args.steps // 4, 3)
         dt_rep = timed(lambda: gen_rep(cloud), k, 2, barrier) / k
         del gen_rep
-        t = torch.tensor([dt_local, solo_ms, dt_rep], dtype=torch.float64, device="cuda")
+        # the N = 1 line's own workload on every rank at once -- config 2, dense + MEAN, each rank ITS OWN frame, no collective: the
+        # data-parallel use of the operator (a training job voxelizes one batch per GPU) and the curve that is comparable with N = 1
+        gen2 = VoxelGenerator(synth.KITTI_BOUNDS, synth.KITTI_SHAPE, dense=True, reduction="mean", max_points=P, max_voxels=n)
+        cloud2 = torch.from_numpy(synth.lidar_like(n, rank)).cuda()
+        dt_frames = timed(lambda: gen2(cloud2), args.steps, args.warmup, barrier)
+        del gen2, cloud2
+        t = torch.tensor([dt_local, solo_ms, dt_rep, dt_frames], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
+        out["independent_frames_per_rank"] = dict(
+            ms_per_step=round(1e3 * float(t[3].item()) / args.steps, 4), mpoints_per_s=round(n * world * args.steps / float(t[3].item()) / 1e6, 2),
+            note="config 2 (dense + MEAN, the workload of the N = 1 line) on every rank's own %d-point frame at once, no collective, max "
+                 "over ranks: the data-parallel use of the operator; `value` above is the point-sharded single frame of config 5" % n)
         value = n * world * args.steps / dt / 1e6
         out["same_operator_one_rank"] = dict(ms_per_step=round(float(t[1].item()), 4),
                                              mpoints_per_s=round(n / float(t[1].item()) / 1e3, 2),
