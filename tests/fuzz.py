@@ -74,6 +74,18 @@ for seed in range(first, first + count):
     err = float(np.max(np.abs(got - ref))) if got.size else 0.0
     if err > 1e-9:
         bad += 1; print("IOU seed", seed, method, n, m, "FAILED", err)
+    # (round 6) the same calls on fp32 tensors, precise=True: D3D_F32_WIDE -- values widened in the kernels, the matrix rounded where
+    # it is stored; NMS: the mask of the widened fp64 call, exactly
+    b32, b232, s32 = b.astype(np.float32), b2.astype(np.float32), s.astype(np.float32)
+    got32 = box2d_iou(torch.from_numpy(b32).cuda(), torch.from_numpy(b232).cuda(), method=method).cpu().numpy()
+    ref32 = oracle.box2d_iou(b32.astype(np.float64), b232.astype(np.float64), method)
+    if got32.dtype != np.float32 or (got32.size and float(np.max(np.abs(got32.astype(np.float64) - ref32))) > 6.1e-8):
+        bad += 1; print("IOU-F32-WIDE seed", seed, method, n, m, "FAILED")
+    if len(np.unique(s32)) == len(s32):                     # (ties among the fp32 scores would be ordered by index on both sides anyway; keep the oracle's call plain)
+        keep32 = box2d_nms(torch.from_numpy(b32).cuda(), torch.from_numpy(s32).cuda(), **kw).cpu().numpy()
+        exp32 = oracle.box2d_nms(b32.astype(np.float64), s32.astype(np.float64), **kw)
+        if not np.array_equal(keep32, exp32):
+            bad += 1; print("NMS-F32-WIDE seed", seed, kw, n, "FAILED", int(np.sum(keep32 != exp32)))
     # ---- round-2 operators: GIoU / DIoU values, flag tensors, point-to-box distance, matcher association
     m2 = min(m, 120)
     bs, b2s = b[: min(n, 200)], b2[:m2]
