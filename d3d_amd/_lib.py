@@ -108,7 +108,7 @@ SIGNATURES = {
     "d3d_score_match_workspace_bytes": (_sz, [_i64, _i64]),
     "d3d_score_match": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_score_match_batched_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "d3d_score_match_batched": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3d_score_match_batched": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3d_crop_2dr": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "d3d_crop_3dp": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp]),
     "d3d_crop_3dr": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp]),

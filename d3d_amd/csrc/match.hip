@@ -62,7 +62,10 @@ __device__ __forceinline__ void wave_merge_lowest(float &bd, int &bj, float cd, 
 __global__ __launch_bounds__(256) void k_match_candidates(const float *__restrict__ dist, int64_t n, int64_t m,
                                                           const int32_t *__restrict__ src_tag, const int32_t *__restrict__ dst_tag,
                                                           const float *__restrict__ thr, int32_t *cand_dst, float *cand_dist,
-                                                          int32_t *cand_cnt, int32_t *overflow)
+                                                          int32_t *cand_cnt, int32_t *overflow,
+                                                          const int64_t *__restrict__ row_src = nullptr /* row r reads dist row row_src[r] */,
+                                                          const uint8_t *__restrict__ mask = nullptr /* [., m]: 0 = the pair takes no part */,
+                                                          const int64_t *__restrict__ row_mask = nullptr /* row r reads mask row row_mask[r] */)
 {
     __shared__ float sd[256 / kWave][kMaxCand];
     __shared__ int sj[256 / kWave][kMaxCand];
@@ -77,7 +80,8 @@ __global__ __launch_bounds__(256) void k_match_candidates(const float *__restric
     float bd = INFINITY;
     int bj = 0x7fffffff;
     if (tag >= 0) {
-        const float *drow = dist + row * m;
+        const float *drow = dist + (row_src ? row_src[row] : row) * m;
+        const uint8_t *mrow = mask ? mask + (row_mask ? row_mask[row] : row) * m : nullptr;
         // four stretches of 64 columns in flight per step (the sweep is a chain of round trips otherwise: 78 for 5 k columns)
         for (int64_t jq = 0; jq < m; jq += 4 * kWave) {
           float dq[4];
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void k_match_candidates(const float *__restric
           for (int u = 0; u < 4; u++) {
               const int64_t j = jq + u * kWave + lane, jc = j < m ? j : m - 1;      // (no branch: the four loads leave together)
               dq[u] = drow[jc];
-              okq[u] = (j < m) & (dst_tag[jc] == tag) & (dq[u] <= thr[jc]);
+              okq[u] = (j < m) & (dst_tag[jc] == tag) & (dq[u] <= thr[jc]) & (!mrow || mrow[jc] != 0);
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
@@ -141,7 +145,9 @@ __global__ __launch_bounds__(64) void k_match_greedy(const int64_t *__restrict__
                                                      int32_t *src_match, int32_t *dst_match, unsigned int *taken_g /* zeroed */,
                                                      const float *__restrict__ dist, const int32_t *__restrict__ src_tag,
                                                      const int32_t *__restrict__ dst_tag, const float *__restrict__ thr,
-                                                     const int32_t *only_if = nullptr, const int64_t *__restrict__ row_off = nullptr)
+                                                     const int32_t *only_if = nullptr, const int64_t *__restrict__ row_off = nullptr,
+                                                     const int64_t *__restrict__ row_src = nullptr, const uint8_t *__restrict__ okmask = nullptr,
+                                                     const int64_t *__restrict__ row_mask = nullptr)
 {
     extern __shared__ unsigned int taken_l[];
     __shared__ int stage[kWave][kMaxCand];
@@ -150,7 +156,9 @@ __global__ __launch_bounds__(64) void k_match_greedy(const int64_t *__restrict__
         const int64_t b = blockIdx.x, o = row_off[b];
         n = row_off[b + 1] - o;
         order += o; cand_dst += o * kMaxCand; cand_cnt += o; src_match += o; dst_match += b * m; taken_g += b * nwords;
-        dist += o * m; src_tag += o;
+        if (row_src) row_src += o; else dist += o * m;
+        if (row_mask) row_mask += o; else if (okmask) okmask += o * m;
+        src_tag += o;
         if (only_if) only_if += b;
     }
     if (only_if && !*only_if) return;          // k_match_stable decided everything (the usual case)
@@ -186,14 +194,15 @@ __global__ __launch_bounds__(64) void k_match_greedy(const int64_t *__restrict__
                 // all 64 nearest are taken and there are more: the nearest free candidate of the WHOLE row (the reference
                 // considers every pair within the threshold, matcher.pyx:100-117), 64 columns per step
                 const int32_t tag = src_tag[rowr];
-                const float *drow = dist + rowr * m;
+                const float *drow = dist + (row_src ? row_src[rowr] : rowr) * m;
+                const uint8_t *mrow = okmask ? okmask + (row_mask ? row_mask[rowr] : rowr) * m : nullptr;
                 float bd = INFINITY;
                 int bj = 0x7fffffff;
                 for (int64_t j0 = 0; j0 < m; j0 += kWave) {
                     const int64_t j = j0 + lane;
                     if (j >= m) continue;
                     const float d = drow[j];
-                    if (dst_tag[j] != tag || !(d <= thr[j])) continue;
+                    if (dst_tag[j] != tag || !(d <= thr[j]) || (mrow && mrow[j] == 0)) continue;
                     const unsigned int word = LDS_MAP ? taken_l[j >> 5]
                                                       : __hip_atomic_load(&taken_g[j >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((word >> (j & 31)) & 1u) continue;
@@ -317,6 +326,9 @@ __global__ __launch_bounds__(kStableThreads) void k_match_stable(const int64_t *
 // issued one by one): the rows of all problems stacked in dist[N, m] (problem b = rows [row_off[b], row_off[b + 1])), the
 // destinations -- dst_tag, dst_threshold, m -- common to all; order / src_match in the same stacked layout with indices LOCAL
 // to the problem, dst_match[B, m] likewise local.  One candidate launch over all rows, one workgroup per problem after that.
+// Optional indirection (the evaluator's literal association: row k of a problem takes its DISTANCES from one row of the cache and
+// its ACCEPTABLE pairs from another, matcher.pyx:155-158): stacked row r reads dist row row_src[r] (NULL: r) and, with `mask`
+// (u8 [., m], 0 = the pair takes no part), mask row row_mask[r] (NULL: r) -- no stacked matrix is materialised then.
 extern "C" size_t d3d_score_match_batched_workspace_bytes(int64_t n_total, int64_t m, int64_t batches)
 {
     if (n_total < 1) n_total = 1;
@@ -327,7 +339,8 @@ extern "C" size_t d3d_score_match_batched_workspace_bytes(int64_t n_total, int64
            d3d_align_up((size_t)batches * 4) + 1024;
 }
 
-extern "C" int d3d_score_match_batched(const float *dist, const int64_t *row_off, int64_t batches, int64_t n_total, int64_t m,
+extern "C" int d3d_score_match_batched(const float *dist, const int64_t *row_src, const uint8_t *mask, const int64_t *row_mask,
+                                       const int64_t *row_off, int64_t batches, int64_t n_total, int64_t m,
                                        const int32_t *src_tag, const int32_t *dst_tag, const float *dst_threshold,
                                        const int64_t *order, int32_t *src_match, int32_t *dst_match, int32_t *status, void *workspace,
                                        size_t workspace_bytes, void *stream)
@@ -354,18 +367,18 @@ extern "C" int d3d_score_match_batched(const float *dist, const int64_t *row_off
     if (!workspace || !w.ok()) return D3D_ERR_WORKSPACE;
     D3D_HIP_CHECK(hipMemsetAsync(taken, 0, (size_t)batches * words * 4, st));
     D3D_LAUNCH("k_match_candidates", k_match_candidates, dim3((unsigned)d3d_divup(n_total, 256 / kWave)), dim3(256), 0, st, dist, n_total, m,
-               src_tag, dst_tag, dst_threshold, cand_dst, cand_dist, cand_cnt, status);
+               src_tag, dst_tag, dst_threshold, cand_dst, cand_dist, cand_cnt, status, row_src, mask, row_mask);
     D3D_LAUNCH("k_match_stable", k_match_stable, dim3((unsigned)batches), dim3(kStableThreads), 0, st, order, (int64_t)0, m,
                (const int32_t *)cand_dst, (const int32_t *)cand_cnt, src_match, dst_match, rank, ptr, hold, q0, q1, need_walk, row_off);
     const size_t map_bytes = words * 4;
     if (map_bytes <= 32 * 1024)
         D3D_LAUNCH("k_match_greedy", k_match_greedy<true>, dim3((unsigned)batches), dim3(64), map_bytes, st, order, (int64_t)0, m,
                    (const int32_t *)cand_dst, (const int32_t *)cand_cnt, src_match, dst_match, taken, dist, src_tag, dst_tag, dst_threshold,
-                   (const int32_t *)need_walk, row_off);
+                   (const int32_t *)need_walk, row_off, row_src, mask, row_mask);
     else
         D3D_LAUNCH("k_match_greedy", k_match_greedy<false>, dim3((unsigned)batches), dim3(64), 0, st, order, (int64_t)0, m,
                    (const int32_t *)cand_dst, (const int32_t *)cand_cnt, src_match, dst_match, taken, dist, src_tag, dst_tag, dst_threshold,
-                   (const int32_t *)need_walk, row_off);
+                   (const int32_t *)need_walk, row_off, row_src, mask, row_mask);
     return D3D_OK;
 }
 

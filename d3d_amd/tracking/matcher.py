@@ -110,7 +110,7 @@ def score_match_reference_compat(distance, src_scores, src_tags, dst_tags, dista
     return ReferenceAssociation(distance, src_scores, src_tags, dst_tags, distance_threshold, dst_subset).match(src_subset)
 
 
-_BATCH_MAX_ELEMENTS = 1 << 26          # stacked P matrices of one batched call: 256 MB of fp32
+_BATCH_MAX_ROWS = 1 << 21              # stacked rows of one batched call (its candidate lists: 512 B of workspace per row)
 
 
 def _index_array(subset):
@@ -148,6 +148,7 @@ class ReferenceAssociation:
             self._dtag0 = torch.zeros((md,), dtype=torch.int32, device=dev)
             self._dthr = torch.full((md,), 3.0e38, dtype=torch.float32, device=dev)
             self._inf = torch.full((), float("inf"), dtype=self.cols.dtype, device=dev)
+            self._ok_u8 = self.ok.view(torch.uint8)
 
     def match(self, src_subset):
         """-> (src_match[n], dst_match[m]) int32 tensors on the device, -1 = unmatched (nothing is read back here)"""
@@ -185,9 +186,9 @@ class ReferenceAssociation:
 
     def match_many(self, src_subsets):
         """`match` for a list of source subsets -> (src_match[T, n], dst_match[T, m]) int32 tensors on the device, row t = the
-        association of src_subsets[t].  Subsets whose stacked matrices fit _BATCH_MAX_ELEMENTS go through ONE
-        d3d_score_match_batched call (a frame's 40 thresholds: three launches instead of 120 and a dozen tensor operations instead
-        of 500); larger ones in several."""
+        association of src_subsets[t].  ONE d3d_score_match_batched call (a few above _BATCH_MAX_ROWS stacked rows): the problems'
+        rows stacked, and no stacked matrix -- slot k of a problem reads its distances from the k-th subset row of the prepared
+        columns and its acceptable pairs from the k-th best source's row of the prepared mask, by index."""
         dev, n, m = self.dev, self.n, self.m
         T = len(src_subsets)
         src_all = torch.full((T, n), -1, dtype=torch.int32, device=dev)
@@ -200,7 +201,7 @@ class ReferenceAssociation:
         t0 = 0
         while t0 < T:
             t1, rows = t0, 0
-            while t1 < T and (t1 == t0 or (rows + subs[t1].size) * md <= _BATCH_MAX_ELEMENTS):
+            while t1 < T and (t1 == t0 or rows + subs[t1].size <= _BATCH_MAX_ROWS):
                 rows += subs[t1].size
                 t1 += 1
             if rows == 0:
@@ -208,22 +209,23 @@ class ReferenceAssociation:
                 continue
             B = t1 - t0
             bests = [ss[np.flip(np.argsort(self.scores[ss].astype(np.float64)))] for ss in subs[t0:t1]]      # matcher.pyx:145-146 per subset
+            sizes = [ss.size for ss in subs[t0:t1]]
             off = np.zeros((B + 1,), np.int64)
-            off[1:] = np.cumsum([ss.size for ss in subs[t0:t1]])
-            local = np.concatenate([np.arange(ss.size, dtype=np.int64) for ss in subs[t0:t1]])
-            bid = np.repeat(np.arange(B, dtype=np.int64), [ss.size for ss in subs[t0:t1]])
+            off[1:] = np.cumsum(sizes)
+            local = np.concatenate([np.arange(k, dtype=np.int64) for k in sizes])
+            bid = np.repeat(np.arange(B, dtype=np.int64), sizes)
             with torch.cuda.device(dev):
-                host = torch.from_numpy(np.concatenate([np.concatenate(subs[t0:t1]), np.concatenate(bests), off, local, bid]))
-                d = host.to(dev)
+                d = torch.from_numpy(np.concatenate([np.concatenate(subs[t0:t1]), np.concatenate(bests), off, local, bid])).to(dev)
                 ssub_t, best_t = d[:rows], d[rows:2 * rows]
                 off_t, order_t, bid_t = d[2 * rows:2 * rows + B + 1], d[2 * rows + B + 1:3 * rows + B + 1], d[3 * rows + B + 1:]
-                pref = torch.where(self.ok.index_select(0, best_t), self.cols.index_select(0, ssub_t), self._inf)
                 sm = torch.empty((rows,), dtype=torch.int32, device=dev)
                 dm = torch.empty((B, md), dtype=torch.int32, device=dev)
                 status = torch.zeros((1,), dtype=torch.int32, device=dev)
                 stag0 = torch.zeros((rows,), dtype=torch.int32, device=dev)
                 ws = _lib.workspace(lib.d3d_score_match_batched_workspace_bytes(rows, md, B), dev)
-                rc = lib.d3d_score_match_batched(_lib.ptr(pref), _lib.ptr(off_t), B, rows, md, _lib.ptr(stag0), _lib.ptr(self._dtag0),
+                # P[k, j] = cols[subset row k, j] where ok[k-th best source, j], +inf elsewhere -- read through the two index arrays
+                rc = lib.d3d_score_match_batched(_lib.ptr(self.cols), _lib.ptr(ssub_t), _lib.ptr(self._ok_u8), _lib.ptr(best_t),
+                                                 _lib.ptr(off_t), B, rows, md, _lib.ptr(stag0), _lib.ptr(self._dtag0),
                                                  _lib.ptr(self._dthr), _lib.ptr(order_t), _lib.ptr(sm), _lib.ptr(dm), _lib.ptr(status),
                                                  _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
                 _lib.check(rc, "score_match_batched")

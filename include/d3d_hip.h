@@ -550,9 +550,13 @@ int d3d_score_match(const float *dist, int64_t n, int64_t m, const int32_t *src_
  * launches when issued one by one).  The rows of all problems are stacked: dist[n_total, m], src_tag[n_total], order[n_total],
  * src_match[n_total]; problem b owns rows row_off[b] .. row_off[b + 1] (row_off[batches + 1] i64, device) and its order /
  * src_match / dst_match entries are indices LOCAL to those rows; the destinations (m, dst_tag, dst_threshold) are common,
- * dst_match[batches, m].  Same result per problem as d3d_score_match. */
+ * dst_match[batches, m].  Same result per problem as d3d_score_match.
+ * Optional indirection (NULL = none): stacked row r takes its distances from dist row row_src[r] and, with mask (u8 [., m], 0 = the
+ * pair takes no part), its acceptable pairs from mask row row_mask[r] -- the literal association of matcher.pyx:155-158 (the k-th
+ * best source walks the k-th subset row's distances) without materialising a stacked matrix. */
 size_t d3d_score_match_batched_workspace_bytes(int64_t n_total, int64_t m, int64_t batches);
-int d3d_score_match_batched(const float *dist, const int64_t *row_off, int64_t batches, int64_t n_total, int64_t m,
+int d3d_score_match_batched(const float *dist, const int64_t *row_src, const uint8_t *mask, const int64_t *row_mask,
+                            const int64_t *row_off, int64_t batches, int64_t n_total, int64_t m,
                             const int32_t *src_tag, const int32_t *dst_tag, const float *dst_threshold, const int64_t *order,
                             int32_t *src_match, int32_t *dst_match, int32_t *status, void *workspace, size_t workspace_bytes,
                             void *stream);

@@ -494,7 +494,7 @@ def test_score_match_reference_compat_reproduces_the_row_mixup():
 def test_reference_association_batched_equals_one_by_one(monkeypatch):
     """ReferenceAssociation.match_many (d3d_score_match_batched: the evaluator's thresholds as ONE call -- problems stacked, one
     workgroup each) row for row against `match` on the same subsets: nested subsets as the evaluator passes them, an empty one,
-    one with a single source; in one batched call and split into several (a small element budget)"""
+    one with a single source; in one batched call and split into several (a small row budget)"""
     from d3d_amd import synth
     from d3d_amd.tracking import DistanceTypes, matcher, prepare_boxes
     rng = np.random.default_rng(3)
@@ -506,8 +506,8 @@ def test_reference_association_batched_equals_one_by_one(monkeypatch):
         cache = prepare_boxes(d9, g9, DistanceTypes.RIoU)
         dst = np.nonzero(np.isin(g9[:, 0].astype(np.int64), [1, 2]))[0]
         subsets = [np.nonzero(d9[:, 1] >= t)[0] for t in (0.0, 0.2, 0.5, 0.8, 2.0)] + [np.array([3]), rng.permutation(len(d9))[:17]]
-        for budget in (1 << 26, len(d9) * len(dst) + 1, 1):
-            monkeypatch.setattr(matcher, "_BATCH_MAX_ELEMENTS", budget)
+        for budget in (1 << 21, len(d9) + 1, 1):
+            monkeypatch.setattr(matcher, "_BATCH_MAX_ROWS", budget)
             assoc = matcher.ReferenceAssociation(cache, d9[:, 1], d9[:, 0], g9[:, 0], thr, dst)
             sm, dm = assoc.match_many(subsets)
             assert sm.shape == (len(subsets), len(d9)) and dm.shape == (len(subsets), len(g9))
