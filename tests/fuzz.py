@@ -231,6 +231,16 @@ for seed in range(first, first + count):
     esm, edm = oracle.score_match_rows(cache.cpu().numpy(), dt9, gt9, thr_c)       # on the GPU's own distances: exact
     if not (np.array_equal(sm.cpu().numpy(), esm) and np.array_equal(dm.cpu().numpy(), edm)):
         bad += 1; print("MATCH seed", seed, "FAILED", int(np.sum(sm.cpu().numpy() != esm)))
+    if seed % 4 == 1:        # (round 6) the evaluator's default -- the reference's association per threshold, batched on the device
+        # (d3d_score_match_batched with row indices) + statistics over all thresholds -- against the literal restatement
+        from d3d_amd.benchmarks import DetectionEvaluator
+        ev = DetectionEvaluator([1, 2], [0.3, 0.2], pr_sample_count=10)
+        gs = ev.calc_stats(gt9, dt9)
+        es = oracle.calc_stats(gt9, dt9, [1, 2], {1: 0.7, 2: 0.8}, ev.score_thresholds, literal=True)
+        okc = all(gs[k][c] == es[k][c] for c in (1, 2) for k in ("ndt", "tp", "fp", "fn")) and all(gs.ngt[c] == es.ngt[c] for c in (1, 2))
+        oka = all(np.allclose(gs[k][c], es[k][c], rtol=1e-4, atol=1e-5, equal_nan=True) for c in (1, 2) for k in ("acc_iou", "acc_angular", "acc_dist", "acc_box"))
+        if not (okc and oka):
+            bad += 1; print("EVALUATOR seed", seed, nd, ng, "FAILED", okc, oka)
     # gradients of the loss path against central differences of the fp64 oracle (small sets: 2 x (8 + 6) x 5 oracle passes)
     g1n, g2n = bs[:8].copy(), b2s[:6].copy()
     if len(g1n) and len(g2n) and seed % 6 != 0:        # (identical / touching boxes sit ON a kink: no two-sided derivative there)
