@@ -2974,7 +2974,9 @@ static int iou2d_backward_typed(const B *b1, int64_t n, const B *b2, int64_t m, 
         int tr = kTileRows;                            // fewer rows per workgroup while the launch is short of 2048 workgroups
         while (tr > 8 && d3d_divup(m, kGradCols) * d3d_divup(n, tr) < 2048) tr >>= 1;
         while (tr > 8 && tr > rows_bm) tr >>= 1;
-        const int64_t rows_max = (int64_t)65535 * tr < rows_bm ? (int64_t)65535 * tr : (rows_bm >= tr ? rows_bm / tr * tr : rows_bm);
+        // rows per pass: what the bitmap holds and one launch's grid.y covers (a pass may end on a partial tile -- rounding this down
+        // to whole tiles gave 5000 rows a second pass of 8 rows with its four launches)
+        const int64_t rows_max = (int64_t)65535 * tr < rows_bm ? (int64_t)65535 * tr : rows_bm;
         for (int64_t r0 = 0; r0 < n; r0 += rows_max) {
             const int64_t nr = (n - r0) < rows_max ? (n - r0) : rows_max;
 #define D3D_GRAD_TILES(R)                                                                                                                   \

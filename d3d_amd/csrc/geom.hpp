@@ -177,47 +177,6 @@ __device__ __forceinline__ bool aabb_disjoint(const BoxGeom<T> &a, const BoxGeom
     return !(a.xmin < b.xmax && b.xmin < a.xmax && a.ymin < b.ymax && b.ymin < a.ymax);
 }
 
-// Clip segment P + t*D, t in [0,1], against the CCW convex quad with vertices (qx, qy): the surviving piece
-// [S, E] (false if none).
-// CLOSED: a segment lying exactly on a quad edge that runs in the same direction counts as
-// inside (used for A's edges so that a shared boundary is integrated exactly once; collinear
-// edges running in opposite directions -- boxes touching from outside -- are dropped from both).
-template <typename T, bool CLOSED>
-__device__ __forceinline__ bool clip_edge_piece(T px, T py, T dx, T dy, const T (&qx)[4], const T (&qy)[4], T &sx, T &sy,
-                                                T &ex_, T &ey_)
-{
-    T t0 = 0, t1 = 1;
-    bool alive = true;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const T ex = qx[(e + 1) & 3] - qx[e], ey = qy[(e + 1) & 3] - qy[e];
-        const T n0 = ex * (py - qy[e]) - ey * (px - qx[e]);   // cross(E, P - Q_e): >= 0 inside
-        const T nd = ex * dy - ey * dx;                        // d/dt of the above
-        if (nd > 0) {
-            t0 = fmax(t0, -n0 / nd);
-        } else if (nd < 0) {
-            t1 = fmin(t1, -n0 / nd);
-        } else {
-            bool in = n0 > 0;
-            if (CLOSED) in = in || (n0 == 0 && (ex * dx + ey * dy) > 0);
-            alive = alive && in;
-        }
-    }
-    if (!alive || !(t0 < t1)) return false;
-    sx = px + t0 * dx; sy = py + t0 * dy;
-    ex_ = px + t1 * dx; ey_ = py + t1 * dy;
-    return true;
-}
-
-// cross(start, end) of the surviving piece (0 if none): its contribution to the Green's-theorem area integral
-template <typename T, bool CLOSED>
-__device__ __forceinline__ T clip_edge_cross(T px, T py, T dx, T dy, const T (&qx)[4], const T (&qy)[4])
-{
-    T sx, sy, ex, ey;
-    if (!clip_edge_piece<T, CLOSED>(px, py, dx, dy, qx, qy, sx, sy, ex, ey)) return 0;
-    return sx * ey - sy * ex;
-}
-
 // area of A ∩ B for two rectangles (CCW quads given by centre and half-extent vectors).
 // Green's theorem over the boundary of the intersection: every edge P + t D of either quad contributes cross(S, E) / 2 for
 // the piece [S, E] = [P + t0 D, P + t1 D] that survives the four half-planes of the other quad (Cyrus-Beck) -- and
@@ -405,20 +364,61 @@ __device__ __forceinline__ T iou_rbox_grad(const BoxGeom<T> &a, const BoxGeom<T>
     const T aux = 2 * a.ux * iw1, auy = 2 * a.uy * iw1, avx = 2 * a.vx * ih1, avy = 2 * a.vy * ih1;
     const T bux = 2 * b.ux * iw2, buy = 2 * b.uy * iw2, bvx = 2 * b.vx * ih2, bvy = 2 * b.vy * ih2;
     T acc = 0, da[5] = {0, 0, 0, 0, 0}, db[5] = {0, 0, 0, 0, 0};
+    // the clip as intersection_area does it (round 6): the 32 (edge, half-plane) denominators are +-4 x FOUR cross products of the
+    // half-extent vectors -- four reciprocals instead of the 32 divisions the per-edge Cyrus-Beck form of rounds 2-5 made for a pair (~15 fp64 instructions
+    // each) -- and the surviving piece [S, E] = [P + t0 D, P + t1 D] of an edge feeds both the area (the forward's expression: the
+    // backward's intersection IS the forward's now) and piece_grad
+    const T eax[4] = {2 * a.ux, 2 * a.vx, -2 * a.ux, -2 * a.vx}, eay[4] = {2 * a.uy, 2 * a.vy, -2 * a.uy, -2 * a.vy};
+    const T ebx[4] = {2 * b.ux, 2 * b.vx, -2 * b.ux, -2 * b.vx}, eby[4] = {2 * b.uy, 2 * b.vy, -2 * b.uy, -2 * b.vy};
+    T rc[2][2];
+    bool pos[2][2], neg[2][2];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        T sx, sy, ex, ey;
-        if (clip_edge_piece<T, true>(ax[k], ay[k], ax[(k + 1) & 3] - ax[k], ay[(k + 1) & 3] - ay[k], bx, by, sx, sy, ex, ey)) {
-            acc += sx * ey - sy * ex;
-            piece_grad<T>(sx, sy, ex, ey, (T)0, (T)0, aux, auy, avx, avy, iw1, ih1, da);
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const T base = ebx[e] * eay[k] - eby[e] * eax[k];          // cross(Eb_e, Ea_k);  nd(k, e) = sgn(k) sgn(e) base,  sgn = + + - -
+            pos[k][e] = base > 0;
+            neg[k][e] = base < 0;
+            rc[k][e] = 1 / fabs(base);                                  // inf when parallel: never used then
+        }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                                       // A's edges inside B (closed, see intersection_area)
+        T t0 = 0, t1 = 1;
+        bool alive = true;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool flip = ((k >> 1) ^ (e >> 1)) != 0;
+            const bool dpos = flip ? neg[k & 1][e & 1] : pos[k & 1][e & 1], dneg = flip ? pos[k & 1][e & 1] : neg[k & 1][e & 1];
+            const T n0 = ebx[e] * (ay[k] - by[e]) - eby[e] * (ax[k] - bx[e]);
+            const T t = n0 * rc[k & 1][e & 1];
+            if (dpos) t0 = fmax(t0, -t);
+            else if (dneg) t1 = fmin(t1, t);
+            else alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
+        }
+        if (alive && t0 < t1) {
+            acc += (t1 - t0) * (ax[k] * eay[k] - ay[k] * eax[k]);
+            piece_grad<T>(ax[k] + t0 * eax[k], ay[k] + t0 * eay[k], ax[k] + t1 * eax[k], ay[k] + t1 * eay[k], (T)0, (T)0, aux, auy, avx, avy,
+                          iw1, ih1, da);
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        T sx, sy, ex, ey;
-        if (clip_edge_piece<T, false>(bx[k], by[k], bx[(k + 1) & 3] - bx[k], by[(k + 1) & 3] - by[k], ax, ay, sx, sy, ex, ey)) {
-            acc += sx * ey - sy * ex;
-            piece_grad<T>(sx, sy, ex, ey, ox, oy, bux, buy, bvx, bvy, iw2, ih2, db);
+    for (int e = 0; e < 4; e++) {                                       // B's edges inside A (open)
+        T t0 = 0, t1 = 1;
+        bool alive = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool flip = ((k >> 1) ^ (e >> 1)) == 0;
+            const bool dpos = flip ? neg[k & 1][e & 1] : pos[k & 1][e & 1], dneg = flip ? pos[k & 1][e & 1] : neg[k & 1][e & 1];
+            const T n0 = eax[k] * (by[e] - ay[k]) - eay[k] * (bx[e] - ax[k]);
+            const T t = n0 * rc[k & 1][e & 1];
+            if (dpos) t0 = fmax(t0, -t);
+            else if (dneg) t1 = fmin(t1, t);
+            else alive = alive && n0 > 0;
+        }
+        if (alive && t0 < t1) {
+            acc += (t1 - t0) * (bx[e] * eby[e] - by[e] * ebx[e]);
+            piece_grad<T>(bx[e] + t0 * ebx[e], by[e] + t0 * eby[e], bx[e] + t1 * ebx[e], by[e] + t1 * eby[e], ox, oy, bux, buy, bvx, bvy,
+                          iw2, ih2, db);
         }
     }
     const T I = acc / 2;
