@@ -371,6 +371,7 @@ __device__ __forceinline__ T iou_rbox_grad(const BoxGeom<T> &a, const BoxGeom<T>
     const T eax[4] = {2 * a.ux, 2 * a.vx, -2 * a.ux, -2 * a.vx}, eay[4] = {2 * a.uy, 2 * a.vy, -2 * a.uy, -2 * a.vy};
     const T ebx[4] = {2 * b.ux, 2 * b.vx, -2 * b.ux, -2 * b.vx}, eby[4] = {2 * b.uy, 2 * b.vy, -2 * b.uy, -2 * b.vy};
     T rc[2][2];
+    const T kBig = (T)3.0e38;                     // "no bound from this half-plane" (finite: no NaN from inf - inf anywhere)
     bool pos[2][2], neg[2][2];
 #pragma unroll
     for (int k = 0; k < 2; k++)
@@ -391,9 +392,9 @@ __device__ __forceinline__ T iou_rbox_grad(const BoxGeom<T> &a, const BoxGeom<T>
             const bool dpos = flip ? neg[k & 1][e & 1] : pos[k & 1][e & 1], dneg = flip ? pos[k & 1][e & 1] : neg[k & 1][e & 1];
             const T n0 = ebx[e] * (ay[k] - by[e]) - eby[e] * (ax[k] - bx[e]);
             const T t = n0 * rc[k & 1][e & 1];
-            if (dpos) t0 = fmax(t0, -t);
-            else if (dneg) t1 = fmin(t1, t);
-            else alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
+            t0 = fmax(t0, dpos ? -t : -kBig);       // (selects, as intersection_area<T, true>: tiles 322 -> 304 us at 5 k x 5 k)
+            t1 = fmin(t1, dneg ? t : kBig);
+            if (!dpos && !dneg) alive = alive && (n0 > 0 || (n0 == 0 && (ebx[e] * eax[k] + eby[e] * eay[k]) > 0));
         }
         if (alive && t0 < t1) {
             acc += (t1 - t0) * (ax[k] * eay[k] - ay[k] * eax[k]);
@@ -411,9 +412,9 @@ __device__ __forceinline__ T iou_rbox_grad(const BoxGeom<T> &a, const BoxGeom<T>
             const bool dpos = flip ? neg[k & 1][e & 1] : pos[k & 1][e & 1], dneg = flip ? pos[k & 1][e & 1] : neg[k & 1][e & 1];
             const T n0 = eax[k] * (by[e] - ay[k]) - eay[k] * (bx[e] - ax[k]);
             const T t = n0 * rc[k & 1][e & 1];
-            if (dpos) t0 = fmax(t0, -t);
-            else if (dneg) t1 = fmin(t1, t);
-            else alive = alive && n0 > 0;
+            t0 = fmax(t0, dpos ? -t : -kBig);
+            t1 = fmin(t1, dneg ? t : kBig);
+            alive = alive && (dpos || dneg || n0 > 0);
         }
         if (alive && t0 < t1) {
             acc += (t1 - t0) * (bx[e] * eby[e] - by[e] * ebx[e]);
